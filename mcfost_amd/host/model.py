@@ -1,0 +1,578 @@
+"""Host-side model tables for the continuum Monte Carlo packet loop.
+
+In MCFOST these tables are produced by the Fortran host (parameter reader,
+grid, density, Mie, stellar spectra, ``init_reemission``) *before* the packet
+loop runs; the HIP engine only consumes them through the C-ABI
+(``include/mcgpu.h``).  This module is the harness-side mirror that lets the
+tests and ``bench.py`` stand up the BASELINE configs without the Fortran host
+(which cannot be built in this image).  Everything here is setup code outside
+the hot path; each builder cites the reference routine it follows
+(file:line into ``/root/reference/src``).
+
+Precision notes: the reference mixes default ``real`` and ``real(dp)``; where a
+value ends up in a table the packet loop reads, the same rounding is applied
+here (``np.float32`` intermediates) so that grids agree bit-for-bit with the
+reference's own ``define_cylindrical_grid`` (checked in
+``tests/test_ref_geometry.py`` against ``oracle/_ref``).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Optional
+
+import numpy as np
+
+f32 = np.float32
+f64 = np.float64
+
+# ---- constants.f90:8-115 -------------------------------------------------
+PI = 3.141592653589793238462643383279502884197
+HP = 6.626070040e-34
+KB = 1.38064852e-23
+C_LIGHT = 299792458.0
+THERMAL_CONST = float(f32(C_LIGHT * HP / KB))  # real, parameter (constants.f90:24)
+AU_TO_M = 149597870700.0
+AU_TO_CM = AU_TO_M * 100.0
+RSUN = 6.957e8
+RSUN_TO_AU = RSUN / AU_TO_M
+MUM_TO_CM = 1.0e-4
+GXMSUN = 1.3271244e20
+GGRAV = float(f32(6.67428e-11))
+MSUN_TO_G = GXMSUN / GGRAV * 1.0e3
+TINY_REAL = float(np.finfo(np.float32).tiny)
+TINY_DP = float(np.finfo(np.float64).tiny)
+CUTOFF = float(f32(7.0))  # parameters.f90:111
+NANG_SCATT = 180  # parameters.f90:29
+
+
+@dataclass
+class DiskConfig:
+    """The subset of a MCFOST parameter file the thermal packet loop depends on
+    (single zone, single dust population; ``read_param.f90:16-555``)."""
+
+    name: str = "ref4.1"
+    # grid (ref4.1.para:16)
+    n_rad: int = 100
+    nz: int = 70
+    n_az: int = 1
+    n_rad_in: int = 20
+    l3D: bool = False
+    # wavelengths (ref4.1.para:9)
+    n_lambda: int = 50
+    lambda_min: float = 0.1
+    lambda_max: float = 3000.0
+    # disk zone (ref4.1.para:44-50)
+    dust_mass: float = 1.0e-3  # Msun
+    sclht: float = 10.0
+    rref: float = 100.0
+    rin: float = 1.0
+    edge: float = 0.0
+    rout: float = 300.0
+    exp_beta: float = 1.125
+    surf: float = -0.5
+    # star (ref4.1.para:78): blackbody (-star_bb)
+    T_star: float = 5000.0
+    R_star: float = 2.0  # Rsun
+    star_xyz: tuple = (0.0, 0.0, 0.0)
+    # temperature grid (read_param.f90:237)
+    n_T: int = 100
+    T_min: float = 1.0
+    T_max: float = 3000.0
+    # scattering
+    aniso_method: int = 1
+    lisotropic: bool = False
+    lsepar_pola: bool = True
+    # SED bins (read_param.f90:180)
+    N_thet: int = 10
+    N_phi: int = 1
+    l_sym_centrale: bool = True
+    l_sym_axiale: bool = True
+    # synthetic dust family: "silicate" (ref4.1-like mix) or "pascucci"
+    dust: str = "silicate"
+
+
+def ref41() -> DiskConfig:
+    """ref4.1.para (BASELINE config 2)."""
+    return DiskConfig()
+
+
+def ref41_3d(n_az: int = 72, nz: int = 50) -> DiskConfig:
+    """ref4.1_3D.para (BASELINE config 3): 100 x 50 x 72, 720 000 cells."""
+    return DiskConfig(name="ref4.1_3D", nz=nz, n_az=n_az, l3D=True)
+
+
+def pascucci() -> DiskConfig:
+    """Pascucci_3.0.para (BASELINE config 1; Pascucci et al. 2004 benchmark):
+    isotropic scattering forced by ``init_Pascucci_benchmark``
+    (benchmarks.f90:15-35)."""
+    return DiskConfig(
+        name="Pascucci",
+        n_lambda=61,
+        lambda_min=0.110662,
+        lambda_max=2168.76,
+        dust_mass=1.1e-6,
+        sclht=99.7356,
+        rref=500.0,
+        rin=1.0,
+        rout=1000.0,
+        exp_beta=1.125,
+        surf=0.125,
+        T_star=5800.0,
+        R_star=1.0,
+        lisotropic=True,
+        lsepar_pola=False,
+        dust="pascucci",
+    )
+
+
+def small(n_rad: int = 20, nz: int = 10, n_az: int = 1, l3D: bool = False,
+          n_lambda: int = 24, **kw) -> DiskConfig:
+    """A reduced grid for fast tests (same physics as ref4.1)."""
+    return DiskConfig(name="small", n_rad=n_rad, nz=nz, n_az=n_az, l3D=l3D,
+                      n_rad_in=5, n_lambda=n_lambda, **kw)
+
+
+# --------------------------------------------------------------------------
+# Cell mapping (cylindrical_grid.f90:45-179)
+# --------------------------------------------------------------------------
+def cell_mapping_sizes(n_rad, nz, n_az, l3D):
+    j_start = -nz if l3D else 1
+    n_cells = 2 * n_rad * nz * n_az if l3D else n_rad * nz
+    jstart2 = min(1, j_start) - 1
+    jend2 = nz + 1
+    if jstart2 < 0:
+        ntot2 = (n_rad + 2) * (jend2 - jstart2) * n_az
+    else:
+        ntot2 = (n_rad + 2) * (jend2 - jstart2 + 1) * n_az
+    return n_cells, ntot2, jstart2, jend2 - jstart2 + 1
+
+
+def build_cell_mapping(n_rad, nz, n_az, l3D):
+    """Returns cell_map (Fortran-ordered flat, dims (0:n_rad+1, jlo:nz+1, n_az)),
+    cell_map_i/j/k and lexit_cell."""
+    n_cells, ntot2, jlo, jn = cell_mapping_sizes(n_rad, nz, n_az, l3D)
+    j_start = -nz if l3D else 1
+    cm = np.zeros((n_az, jn, n_rad + 2), dtype=np.int32)  # C order == Fortran (i,j,k)
+    cmi = np.zeros(ntot2, np.int32)
+    cmj = np.zeros(ntot2, np.int32)
+    cmk = np.zeros(ntot2, np.int32)
+    lexit = np.zeros(ntot2, np.int32)
+    icell = 0
+    for k in range(1, n_az + 1):
+        for j in range(j_start, nz + 1):
+            if j == 0:
+                continue
+            for i in range(1, n_rad + 1):
+                icell += 1
+                cmi[icell - 1], cmj[icell - 1], cmk[icell - 1] = i, j, k
+                cm[k - 1, j - jlo, i] = icell
+    assert icell == n_cells
+    jend2 = nz + 1
+    for k in range(1, n_az + 1):
+        for j in (jlo, jend2):
+            for i in range(0, n_rad + 2):
+                icell += 1
+                if abs(j) == jend2:
+                    lexit[icell - 1] = 2
+                if i == n_rad + 1:
+                    lexit[icell - 1] = 1
+                cmi[icell - 1], cmj[icell - 1], cmk[icell - 1] = i, j, k
+                cm[k - 1, j - jlo, i] = icell
+    for k in range(1, n_az + 1):
+        for j in range(j_start, nz + 1):
+            if j == 0:
+                continue
+            for i in (0, n_rad + 1):
+                icell += 1
+                if i == n_rad + 1:
+                    lexit[icell - 1] = 1
+                cmi[icell - 1], cmj[icell - 1], cmk[icell - 1] = i, j, k
+                cm[k - 1, j - jlo, i] = icell
+    assert icell == ntot2
+    return cm.reshape(-1), cmi, cmj, cmk, lexit
+
+
+# --------------------------------------------------------------------------
+# Grid (cylindrical_grid.f90:183-676), single region, log radial grid
+# --------------------------------------------------------------------------
+def define_cylindrical_grid(cfg: DiskConfig):
+    n_rad, nz, n_az = cfg.n_rad, cfg.nz, cfg.n_az
+    rmin_zone = cfg.rin - 5 * cfg.edge  # read_param.f90:279
+    rmax_zone = cfg.rout
+    Rmin, Rmax = rmin_zone, rmax_zone
+    n_rad_in = max(cfg.n_rad_in, 1)
+
+    tab_r = np.zeros(n_rad + 2, f64)  # 1-based
+    R0 = Rmin
+    tab_r[1] = R0
+    ln_delta_r = (1.0 / float(n_rad - n_rad_in + 1)) * math.log(Rmax / R0)  # :309
+    delta_r = math.exp(ln_delta_r)
+    puiss = 0.0
+    p = 1 + cfg.surf - cfg.exp_beta  # :319
+    if p > puiss:
+        puiss = p
+    if puiss == 0.0:
+        for i in range(2, 2 + n_rad_in):
+            fr = float(f32(2.0) ** f32(i - 1) - f32(1.0)) / float(f32(2.0) ** f32(n_rad_in) - f32(1.0))
+            tab_r[i] = math.exp(math.log(R0) - (math.log(R0) - math.log(R0 * delta_r)) * fr)
+    else:
+        den = float(f32(2.0) ** f32(n_rad_in + 1) - f32(1.0))
+        for i in range(2, 2 + n_rad_in):
+            num = float(f32(2.0) ** f32(i) - f32(1.0))
+            a = R0 ** puiss
+            tab_r[i] = (a - (a - (R0 * delta_r) ** puiss) * num / den) ** (1.0 / puiss)  # :336
+    for i in range(2 + n_rad_in, n_rad + 2):
+        tab_r[i] = tab_r[i - 1] * delta_r  # :349
+
+    tab_r2 = tab_r * tab_r
+    r_lim = np.zeros(n_rad + 1, f64)
+    r_lim_2 = np.zeros(n_rad + 1, f64)
+    r_lim[0] = Rmin
+    r_lim_2[0] = Rmin ** 2
+    r_lim[1:] = tab_r[2:n_rad + 2]
+    r_lim_2[1:] = tab_r2[2:n_rad + 2]
+
+    zmax = np.zeros(n_rad, f64)
+    rc = np.zeros(n_rad, f64)
+    for i in range(1, n_rad + 1):
+        rcyl = 0.5 * (r_lim[i] + r_lim[i - 1])
+        rc[i - 1] = rcyl
+        H = 0.0
+        if rmin_zone < rcyl < rmax_zone:
+            H = cfg.sclht * (rcyl / cfg.rref) ** cfg.exp_beta
+        zmax[i - 1] = CUTOFF * H  # :430
+    assert np.all(zmax > TINY_REAL)
+    cell_height = zmax / float(f32(nz))  # :459
+    z_lim = np.zeros((nz + 2, n_rad), f64)  # [j-1, i-1]; flat Fortran order (i,j)
+    for j in range(1, nz + 1):
+        z_lim[j - 1, :] = (float(j) - 1.0) * cell_height
+    z_lim[nz, :] = zmax
+    z_lim[nz + 1, :] = float(f32(1.0e30))  # :493
+    zmaxmax = float(zmax.max())
+
+    pi_sp = float(f32(3.1415926535))  # local single-precision pi (:191)
+    V = np.zeros((nz, n_rad), f64)
+    for i in range(1, n_rad + 1):
+        if (tab_r2[i + 1] - tab_r2[i]) > float(f32(1.0e-6)) * tab_r2[i]:
+            dr2 = 2.0 * pi_sp * (tab_r2[i + 1] - tab_r2[i])
+        else:
+            dr2 = 4.0 * pi_sp * rc[i - 1] * (tab_r[i + 1] - tab_r[i])
+        V[:, i - 1] = dr2 * cell_height[i - 1]
+    z_c = z_lim[:nz, :] + 0.5 * cell_height[None, :]
+
+    tan_phi_lim = np.zeros(n_az, f64)
+    phi_c = np.zeros(n_az, f64)
+    if cfg.l3D:
+        delta_phi = f32(f32(2.0) * f32(pi_sp) / f32(n_az))  # :587 default real
+        for k in range(1, n_az + 1):
+            phi_c[k - 1] = float(f32(delta_phi * f32(f32(k) - f32(0.5))))
+            phi = f32(delta_phi * f32(k))
+            mod = float(np.mod(f32(phi - f32(0.5) * f32(pi_sp)), f32(pi_sp)))
+            if abs(mod) < 1.0e-6:
+                tan_phi_lim[k - 1] = 1.0e300
+            else:
+                tan_phi_lim[k - 1] = float(np.tan(phi))  # default-real tan
+        V = V * 0.5 / float(f32(n_az))
+
+    n_cells, ntot2, jlo, jn = cell_mapping_sizes(n_rad, nz, n_az, cfg.l3D)
+    cm, cmi, cmj, cmk, lexit = build_cell_mapping(n_rad, nz, n_az, cfg.l3D)
+    ii = cmi[:n_cells] - 1
+    jj = np.abs(cmj[:n_cells]) - 1
+    volume = V[jj, ii].copy()
+    r_grid = rc[ii].copy()
+    z_grid = z_c[jj, ii] * np.sign(cmj[:n_cells])
+    phi_grid = phi_c[cmk[:n_cells] - 1].copy()
+    return dict(
+        n_rad=n_rad, nz=nz, n_az=n_az, l3D=int(cfg.l3D), n_cells=n_cells, ntot2=ntot2,
+        jdim_lo=jlo, jdim_n=jn, r_lim=r_lim, r_lim_2=r_lim_2, zmax=zmax,
+        z_lim=np.ascontiguousarray(z_lim.reshape(-1)), tan_phi_lim=tan_phi_lim,
+        zmaxmax=zmaxmax, Rmax2=Rmax * Rmax, cell_map=cm, cell_map_i=cmi, cell_map_j=cmj,
+        cell_map_k=cmk, lexit_cell=lexit, volume=volume, r_grid=r_grid, z_grid=z_grid,
+        phi_grid=phi_grid, Rmin=Rmin, Rmax=Rmax,
+    )
+
+
+# --------------------------------------------------------------------------
+# Wavelength and temperature grids
+# --------------------------------------------------------------------------
+def init_lambda(n_lambda, lambda_min, lambda_max):
+    """wavelengths.f90:49-62.  lambda_min/max are default real."""
+    lmin, lmax = f32(lambda_min), f32(lambda_max)
+    delta = math.exp((1.0 / float(n_lambda)) * float(np.log(f32(lmax / lmin))))
+    lam = np.zeros(n_lambda, f64)
+    inf = np.zeros(n_lambda, f64)
+    sup = np.zeros(n_lambda, f64)
+    inf[0] = float(lmin)
+    lam[0] = float(lmin) * math.sqrt(delta)
+    sup[0] = float(lmin) * delta
+    for i in range(1, n_lambda):
+        lam[i] = lam[i - 1] * delta
+        sup[i] = sup[i - 1] * delta
+        inf[i] = sup[i - 1]
+    return lam, inf, sup, sup - inf
+
+
+def init_tab_temp(n_T, T_min, T_max):
+    """Temperature.f90:23-39 (tab_Temp is default real)."""
+    delta_T = math.exp((1.0 / float(n_T)) * float(np.log(f32(f32(T_max) / f32(T_min)))))
+    tab = np.zeros(n_T, f32)
+    tab[0] = f32(float(f32(T_min)) * math.sqrt(delta_T))
+    for t in range(1, n_T):
+        tab[t] = f32(delta_T * float(tab[t - 1]))
+    return tab
+
+
+# --------------------------------------------------------------------------
+# Density -> kappa_factor (density.f90:84-187,1906; dust_prop.f90:945-956)
+# --------------------------------------------------------------------------
+def dust_density(cfg: DiskConfig, grid):
+    """Dust mass density per cell in g/cm^3, normalised to ``cfg.dust_mass``."""
+    r, z = grid["r_grid"], grid["z_grid"]
+    fact_exp = (r / cfg.rref) ** (cfg.surf - cfg.exp_beta)
+    coeff_exp = 2 * (r / cfg.rref) ** (2 * cfg.exp_beta)
+    rho = fact_exp * np.exp(-((z / cfg.sclht) ** 2) / coeff_exp)
+    rmin_zone = cfg.rin - 5 * cfg.edge
+    rho = np.where((r > cfg.rout) | (r < rmin_zone), 0.0, rho)
+    if cfg.edge > 0:
+        inner = r < cfg.rin
+        rho = np.where(inner, rho * np.exp(-((r - cfg.rin) ** 2) / (2.0 * cfg.edge ** 2)), rho)
+    mass = float(np.sum(rho * grid["volume"])) * AU_TO_CM ** 3  # g if rho in g/cm3
+    rho *= cfg.dust_mass * MSUN_TO_G / mass
+    return rho
+
+
+# --------------------------------------------------------------------------
+# Synthetic dust optical properties.
+# The reference gets these from Mie theory on optical-constant files that are
+# not available offline (MCFOST_UTILS); the harness uses smooth analytic
+# stand-in *data* of similar magnitude.  They are inputs, not algorithm.
+# --------------------------------------------------------------------------
+def synthetic_dust(cfg: DiskConfig, lam):
+    """Returns kappa_ext [cm^2/g dust], albedo, g, and Mueller-matrix ratios on
+    the 0..180 deg grid, per wavelength."""
+    n_lambda = lam.size
+    th = np.arange(NANG_SCATT + 1) * (PI / NANG_SCATT)
+    mu = np.cos(th)
+    if cfg.dust == "pascucci":
+        # single 0.12 um grain (Pascucci et al. 2004): Rayleigh-like fall-off
+        x = 2 * PI * 0.12 / lam
+        qabs = np.minimum(1.0, 0.9 * x) * (1 + 1.5 * np.exp(-0.5 * ((np.log(lam / 9.7)) / 0.2) ** 2))
+        qsca = np.minimum(1.2, 1.1 * x ** 4)
+        kabs = 1.7e4 * qabs
+        ksca = 1.7e4 * qsca
+        g = np.zeros(n_lambda)
+    else:
+        # a^-3.5, 0.03 um - 1 mm silicate-like mix
+        kabs = 3.0e3 * (1 + lam / 0.3) ** -1.0 * (1 + (lam / 300.0) ** 2) ** -0.25
+        kabs *= 1 + 2.0 * np.exp(-0.5 * (np.log(lam / 9.7) / 0.15) ** 2) \
+                  + 1.0 * np.exp(-0.5 * (np.log(lam / 18.0) / 0.2) ** 2)
+        ksca = 4.0e3 * (1 + (lam / 1.0) ** 1.6) ** -1.0 + 2.0 * (1 + (lam / 1000.0) ** 2) ** -1
+        g = 0.75 / (1 + (lam / 8.0) ** 1.2) + 0.05
+    kext = kabs + ksca
+    albedo = ksca / kext
+    s11 = np.zeros((n_lambda, NANG_SCATT + 1))
+    for l in range(n_lambda):
+        gg = g[l]
+        s11[l] = (1 - gg * gg) / (1 + gg * gg - 2 * gg * mu) ** 1.5
+    pol = (1 - mu ** 2) / (1 + mu ** 2)  # Rayleigh-like polarisability shape
+    pmax = 0.6 / (1 + (0.5 / lam) ** 2) if cfg.dust != "pascucci" else np.ones(n_lambda)
+    s12 = -pmax[:, None] * pol[None, :]
+    s33 = np.tile(2 * mu / (1 + mu ** 2), (n_lambda, 1))
+    s22 = np.ones_like(s11)
+    s34 = 0.2 * pol[None, :] * np.sin(th)[None, :] * np.ones((n_lambda, 1))
+    s44 = s33.copy()
+    return dict(kext=kext, albedo=albedo, g=g, s11=s11, s12_o_s11=s12, s22_o_s11=s22,
+                s33_o_s11=s33, s34_o_s11=s34, s44_o_s11=s44)
+
+
+def scattering_cdf(s11_row, k_sca_tot):
+    """prob_s11_pos for one wavelength (dust_prop.f90:1139-1154).  ``s11_row``
+    is normalised like tab_s11_pos, i.e. sum_l s11(l) sin(theta_l) dtheta ~
+    k_sca_tot."""
+    dtheta = PI / NANG_SCATT
+    prob = np.zeros(NANG_SCATT + 1, f64)
+    for l in range(2, NANG_SCATT + 1):
+        theta = float(f32(l)) * dtheta
+        prob[l] = prob[l - 1] + s11_row[l] * math.sin(theta) * dtheta
+    prob[1:] = prob[1:] + k_sca_tot - prob[NANG_SCATT]
+    prob = prob / k_sca_tot
+    return prob.astype(f32)
+
+
+# --------------------------------------------------------------------------
+# Stellar spectrum, blackbody case (stars.f90:305-328, 505-617)
+# --------------------------------------------------------------------------
+def star_energy(cfg: DiskConfig, lam, lam_inf, lam_sup):
+    r_au = cfg.R_star * RSUN_TO_AU
+    surface = 4 * PI * r_au ** 2
+    n_hr = 1000
+    # spanl: log-spaced samples between lambda_min and lambda_max (utils.f90)
+    hr = np.exp(np.linspace(math.log(float(f32(cfg.lambda_min))), math.log(float(f32(cfg.lambda_max))), n_hr))
+    wl = hr * 1.0e-6
+    cst_wl = THERMAL_CONST / (cfg.T_star * wl)
+    spec = np.maximum(1.0 / (((np.exp(np.minimum(cst_wl, 700.0)) - 1.0) + 1.0e-30) * wl ** 5), 1e-200)
+    E = np.zeros(lam.size, f64)
+    loghr, logspec = np.log(hr), np.log(spec + 1e-30)
+    for l in range(lam.size):
+        sel = (hr > lam_inf[l]) & (hr < lam_sup[l])
+        N = int(sel.sum())
+        terme = float(spec[sel].sum())
+        dev = (hr[sel].mean() / lam[l]) if N > 1 else 0.0
+        if terme > TINY_DP and N > 3 and abs(dev - 1.0) < 0.1:
+            E[l] = terme / N * surface
+        else:
+            E[l] = surface * math.exp(float(np.interp(math.log(lam[l]), loghr, logspec)))
+    return E, r_au
+
+
+# --------------------------------------------------------------------------
+# init_reemission (thermal_emission.f90:404-550)
+# --------------------------------------------------------------------------
+def init_reemission(lam, delta_lam, tab_Temp, kappa_abs_LTE):
+    n_lambda, n_T = lam.size, tab_Temp.size
+    cst_E = 2.0 * HP * C_LIGHT ** 2 * (4.0 * PI)
+    B = np.zeros((n_T, n_lambda), f64)
+    dB = np.zeros((n_T, n_lambda), f64)
+    wl = lam * 1.0e-6
+    dwl = delta_lam * 1.0e-6
+    for t in range(n_T):
+        cst = THERMAL_CONST / float(tab_Temp[t])
+        cst_wl = cst / wl
+        ok = cst_wl < 500.0
+        ce = np.exp(np.where(ok, cst_wl, 1.0))
+        b = np.where(ok, 1.0 / ((wl ** 5) * (ce - 1.0)) * dwl, 0.0)
+        B[t] = b
+        dB[t] = np.where(ok, b * cst_wl * ce / (ce - 1.0), 0.0)
+    log_Qcool = np.zeros(n_T, f64)
+    Qcool0 = 0.0
+    for t in range(n_T):
+        integ = 0.0
+        for l in range(n_lambda):
+            integ = integ + kappa_abs_LTE[l] * B[t, l]
+        Qcool = integ * cst_E
+        if t == 0:
+            Qcool0 = Qcool
+        q = Qcool - Qcool0
+        log_Qcool[t] = math.log(q) if q > TINY_DP else -1000.0
+    cdf = np.zeros((n_T, n_lambda), f64)
+    for t in range(n_T):
+        integ3 = np.zeros(n_lambda + 1, f64)
+        for l in range(1, n_lambda + 1):
+            integ3[l] = integ3[l - 1] + kappa_abs_LTE[l - 1] * dB[t, l - 1]
+        if integ3[n_lambda] > TINY_DP:
+            cdf[t] = integ3[1:] / integ3[n_lambda]
+    return log_Qcool, cdf
+
+
+# --------------------------------------------------------------------------
+# The assembled model
+# --------------------------------------------------------------------------
+@dataclass
+class Model:
+    cfg: DiskConfig
+    grid: dict
+    lam: np.ndarray
+    delta_lam: np.ndarray
+    kappa: np.ndarray
+    kappa_abs_LTE: np.ndarray
+    albedo: np.ndarray
+    kappa_factor: np.ndarray
+    prob_s11_pos: np.ndarray
+    s12_o_s11: np.ndarray
+    s22_o_s11: np.ndarray
+    s33_o_s11: np.ndarray
+    s34_o_s11: np.ndarray
+    s44_o_s11: np.ndarray
+    tab_g_pos: np.ndarray
+    tab_Temp: np.ndarray
+    log_Qcool: np.ndarray
+    kdB_dT_CDF: np.ndarray
+    spectre_emission_cumul: np.ndarray
+    frac_E_stars: np.ndarray
+    frac_E_disk: np.ndarray
+    CDF_E_star: np.ndarray
+    E_stars: np.ndarray
+    L_tot: float
+    stars: np.ndarray  # rows: x, y, z, r, icell, out_model
+    rho_dust: np.ndarray
+    l_dark_zone: Optional[np.ndarray] = None
+    p_lambda_fixed: int = 1
+    extra: dict = field(default_factory=dict)
+
+    @property
+    def n_cells(self):
+        return self.grid["n_cells"]
+
+    @property
+    def n_lambda(self):
+        return self.lam.size
+
+    def L_packet_th(self, n_packets_total: float) -> float:
+        """thermal_emission.f90:355-356."""
+        return self.L_tot / float(n_packets_total)
+
+
+def star_cell(grid, x, y, z):
+    """index_cell_cyl for a point inside the inner hole or in the grid
+    (stars.f90:789-808); only the inner-hole case is needed by the configs."""
+    r2 = x * x + y * y
+    if r2 < grid["r_lim_2"][0]:
+        i, j, k = 0, 1, 1
+        idx = i + (grid["n_rad"] + 2) * ((j - grid["jdim_lo"]) + grid["jdim_n"] * (k - 1))
+        return int(grid["cell_map"][idx])
+    raise NotImplementedError("star inside the gridded region")
+
+
+def build_model(cfg: DiskConfig) -> Model:
+    grid = define_cylindrical_grid(cfg)
+    lam, lam_inf, lam_sup, dlam = init_lambda(cfg.n_lambda, cfg.lambda_min, cfg.lambda_max)
+    tab_Temp = init_tab_temp(cfg.n_T, cfg.T_min, cfg.T_max)
+    rho = dust_density(cfg, grid)
+    nz_idx = np.nonzero(rho * grid["volume"] > TINY_REAL)[0]
+    icell_ref = int(nz_idx[0])  # find_non_empty_cell (density.f90:2030)
+    rho0 = rho[icell_ref]
+    kappa_factor = rho / rho0  # dust_prop.f90:955
+
+    d = synthetic_dust(cfg, lam)
+    # kappa in AU^-1 at the reference cell: inverse of dust_prop.f90:1372
+    kappa = d["kext"] * rho0 * AU_TO_CM
+    albedo = d["albedo"].astype(f32)
+    kappa_abs = kappa * (1.0 - d["albedo"])
+    na1 = NANG_SCATT + 1
+    prob = np.zeros((cfg.n_lambda, na1), f32)
+    dtheta = PI / NANG_SCATT
+    th = np.arange(na1) * dtheta
+    for l in range(cfg.n_lambda):
+        k_sca = kappa[l] * float(albedo[l])
+        # normalise s11 like tab_s11_pos: integral over sin(theta) dtheta = k_sca
+        norm = float(np.sum(d["s11"][l][1:NANG_SCATT] * np.sin(th[1:NANG_SCATT]) * dtheta))
+        s11n = d["s11"][l] * (k_sca / norm) * 0.97  # 3 % unresolved forward peak -> bin 1
+        prob[l] = scattering_cdf(s11n, k_sca)
+
+    log_Qcool, cdf = init_reemission(lam, dlam, tab_Temp, kappa_abs)
+
+    E_stars, r_au = star_energy(cfg, lam, lam_inf, lam_sup)
+    cum = np.zeros(cfg.n_lambda + 1, f64)
+    for l in range(1, cfg.n_lambda + 1):  # thermal_emission.f90:329-341
+        cum[l] = cum[l - 1] + E_stars[l - 1] * (dlam[l - 1] * 1.0e-6)
+    cum = cum / cum[cfg.n_lambda]
+    E_star_tot = float(np.sum(E_stars * dlam * 1.0e-6))
+    L_tot = 2.0 * PI * HP * C_LIGHT ** 2 * E_star_tot  # :355
+
+    sx, sy, sz = cfg.star_xyz
+    stars = np.array([[sx, sy, sz, r_au, star_cell(grid, sx, sy, sz), 0]], f64)
+    CDF_E_star = np.zeros((2, cfg.n_lambda), f64)  # (lambda, 0:n_stars) Fortran order
+    CDF_E_star[1, :] = 1.0
+
+    return Model(
+        cfg=cfg, grid=grid, lam=lam, delta_lam=dlam, kappa=kappa, kappa_abs_LTE=kappa_abs,
+        albedo=albedo, kappa_factor=kappa_factor, prob_s11_pos=prob,
+        s12_o_s11=d["s12_o_s11"].astype(f32), s22_o_s11=d["s22_o_s11"].astype(f32),
+        s33_o_s11=d["s33_o_s11"].astype(f32), s34_o_s11=d["s34_o_s11"].astype(f32),
+        s44_o_s11=d["s44_o_s11"].astype(f32), tab_g_pos=d["g"].astype(f32), tab_Temp=tab_Temp,
+        log_Qcool=log_Qcool, kdB_dT_CDF=cdf, spectre_emission_cumul=cum,
+        frac_E_stars=np.ones(cfg.n_lambda, f64), frac_E_disk=np.ones(cfg.n_lambda, f64),
+        CDF_E_star=CDF_E_star.reshape(-1), E_stars=E_stars, L_tot=L_tot, stars=stars,
+        rho_dust=rho, extra=dict(icell_ref=icell_ref + 1, rho0=rho0),
+    )

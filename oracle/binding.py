@@ -1,0 +1,422 @@
+"""ctypes bindings for the CPU oracle (``libmc_oracle.so``) and for the
+compiled reference geometry (``oracle/_ref/libmcfost_ref_geom.so``).
+
+TEST INFRASTRUCTURE ONLY (see ``oracle/__init__.py``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+N_SED_TYPES = 9
+N_COUNTERS = 8
+COUNTER_NAMES = ("packets", "crossings", "flights", "scatterings", "absorptions",
+                 "escaped", "killed_star", "dark_mirrors")
+
+
+def oracle_lib_path():
+    return os.path.join(_HERE, "libmc_oracle.so")
+
+
+def ref_lib_path():
+    return os.path.join(_HERE, "_ref", "libmcfost_ref_geom.so")
+
+
+def build_oracle(force=False):
+    """Compile the C restatement with gcc (plain IEEE evaluation: no FMA
+    contraction, so it can be compared bit-for-bit with ``oracle/_ref``)."""
+    out = oracle_lib_path()
+    src = os.path.join(_HERE, "mc_oracle.c")
+    if force or not os.path.exists(out) or os.path.getmtime(out) < max(
+            os.path.getmtime(src), os.path.getmtime(os.path.join(_HERE, "mc_oracle.h"))):
+        subprocess.check_call(
+            ["gcc", "-O2", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off", "-Wall",
+             "-o", out, src, "-lm"])
+    return out
+
+
+def build_ref(force=False):
+    """Build ``oracle/_ref`` from the reference sources where they lie.  Only
+    possible where ``/root/reference`` exists (not on the GPU box, which uses
+    the prebuilt file).  Returns the path or ``None``."""
+    out = ref_lib_path()
+    if os.path.exists(out) and not force:
+        return out
+    if not os.path.isdir("/root/reference/src"):
+        return out if os.path.exists(out) else None
+    subprocess.check_call(["make", "-C", os.path.join(_HERE, "ref_build")],
+                          stdout=subprocess.DEVNULL)
+    return out if os.path.exists(out) else None
+
+
+class _Star(C.Structure):
+    _fields_ = [("x", C.c_double), ("y", C.c_double), ("z", C.c_double), ("r", C.c_double),
+                ("icell", C.c_int), ("out_model", C.c_int)]
+
+
+_dp = C.POINTER(C.c_double)
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int)
+_up = C.POINTER(C.c_ubyte)
+
+
+class _Model(C.Structure):
+    _fields_ = [
+        ("n_rad", C.c_int), ("nz", C.c_int), ("n_az", C.c_int), ("l3D", C.c_int),
+        ("n_cells", C.c_int), ("ntot2", C.c_int), ("jdim_lo", C.c_int), ("jdim_n", C.c_int),
+        ("r_lim_2", _dp), ("zmax", _dp), ("z_lim", _dp), ("tan_phi_lim", _dp),
+        ("zmaxmax", C.c_double), ("Rmax2", C.c_double),
+        ("cell_map", _ip), ("cell_map_i", _ip), ("cell_map_j", _ip), ("cell_map_k", _ip),
+        ("lexit_cell", _ip), ("volume", _dp),
+        ("n_stars", C.c_int), ("stars", C.POINTER(_Star)),
+        ("n_lambda", C.c_int), ("kappa", _dp), ("kappa_abs_LTE", _dp), ("albedo", _fp),
+        ("kappa_factor", _dp), ("l_dark_zone", _up),
+        ("nang_scatt", C.c_int), ("aniso_method", C.c_int), ("lisotropic", C.c_int),
+        ("lsepar_pola", C.c_int), ("p_lambda_fixed", C.c_int),
+        ("prob_s11_pos", _fp), ("s12_o_s11", _fp), ("s22_o_s11", _fp), ("s33_o_s11", _fp),
+        ("s34_o_s11", _fp), ("s44_o_s11", _fp), ("tab_g_pos", _fp),
+        ("n_T", C.c_int), ("tab_Temp", _fp), ("log_Qcool", _dp), ("kdB_dT_CDF", _dp),
+        ("spectre_emission_cumul", _dp), ("frac_E_stars", _dp), ("frac_E_disk", _dp),
+        ("CDF_E_star", _dp), ("prob_E_cell", _dp), ("L_packet_th", C.c_double),
+        ("T_min", C.c_float),
+        ("N_thet", C.c_int), ("N_phi", C.c_int), ("l_sym_centrale", C.c_int),
+        ("l_sym_axiale", C.c_int),
+    ]
+
+
+class _Opts(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("first_packet", C.c_uint64), ("n_packets", C.c_uint64),
+                ("n_threads", C.c_int), ("frozen", C.c_int), ("tau_fp32", C.c_int),
+                ("n_replicas", C.c_double)]
+
+
+def _a(x, dt):
+    return np.ascontiguousarray(x, dtype=dt)
+
+
+def _p(arr, ct):
+    return arr.ctypes.data_as(C.POINTER(ct))
+
+
+class Oracle:
+    """The CPU oracle bound to one model (``mcfost_amd.host.model.Model``-like
+    object: duck-typed, nothing from the product is imported here)."""
+
+    def __init__(self, model, n_packets_total):
+        self.lib = C.CDLL(build_oracle())
+        self.model = model
+        self._keep = []
+        self.cm = self._make_struct(model, float(n_packets_total))
+        L = self.lib
+        L.oracle_run_thermal.restype = C.c_int
+        L.oracle_packet_rand.restype = C.c_float
+        L.oracle_packet_rand.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32]
+
+    def _hold(self, arr, ct):
+        self._keep.append(arr)
+        return _p(arr, ct)
+
+    def _make_struct(self, m, n_tot):
+        g, cfg = m.grid, m.cfg
+        s = _Model()
+        for k in ("n_rad", "nz", "n_az", "l3D", "n_cells", "ntot2", "jdim_lo", "jdim_n"):
+            setattr(s, k, int(g[k]))
+        s.r_lim_2 = self._hold(_a(g["r_lim_2"], np.float64), C.c_double)
+        s.zmax = self._hold(_a(g["zmax"], np.float64), C.c_double)
+        s.z_lim = self._hold(_a(g["z_lim"], np.float64), C.c_double)
+        s.tan_phi_lim = self._hold(_a(g["tan_phi_lim"], np.float64), C.c_double)
+        s.zmaxmax = float(g["zmaxmax"])
+        s.Rmax2 = float(g["Rmax2"])
+        for k in ("cell_map", "cell_map_i", "cell_map_j", "cell_map_k", "lexit_cell"):
+            setattr(s, k, self._hold(_a(g[k], np.int32), C.c_int))
+        s.volume = self._hold(_a(g["volume"], np.float64), C.c_double)
+        ns = m.stars.shape[0]
+        stars = (_Star * ns)()
+        for i in range(ns):
+            x, y, z, r, ic, om = m.stars[i]
+            stars[i] = _Star(x, y, z, r, int(ic), int(om))
+        self._keep.append(stars)
+        s.n_stars = ns
+        s.stars = stars
+        s.n_lambda = m.n_lambda
+        s.kappa = self._hold(_a(m.kappa, np.float64), C.c_double)
+        s.kappa_abs_LTE = self._hold(_a(m.kappa_abs_LTE, np.float64), C.c_double)
+        s.albedo = self._hold(_a(m.albedo, np.float32), C.c_float)
+        s.kappa_factor = self._hold(_a(m.kappa_factor, np.float64), C.c_double)
+        if m.l_dark_zone is not None:
+            s.l_dark_zone = self._hold(_a(m.l_dark_zone, np.uint8), C.c_ubyte)
+        s.nang_scatt = 180
+        s.aniso_method = cfg.aniso_method
+        s.lisotropic = int(cfg.lisotropic)
+        s.lsepar_pola = int(cfg.lsepar_pola)
+        s.p_lambda_fixed = int(m.p_lambda_fixed)
+        for k in ("prob_s11_pos", "s12_o_s11", "s22_o_s11", "s33_o_s11", "s34_o_s11",
+                  "s44_o_s11", "tab_g_pos"):
+            setattr(s, k, self._hold(_a(getattr(m, k), np.float32), C.c_float))
+        s.n_T = m.tab_Temp.size
+        s.tab_Temp = self._hold(_a(m.tab_Temp, np.float32), C.c_float)
+        s.log_Qcool = self._hold(_a(m.log_Qcool, np.float64), C.c_double)
+        s.kdB_dT_CDF = self._hold(_a(m.kdB_dT_CDF, np.float64), C.c_double)
+        s.spectre_emission_cumul = self._hold(_a(m.spectre_emission_cumul, np.float64), C.c_double)
+        s.frac_E_stars = self._hold(_a(m.frac_E_stars, np.float64), C.c_double)
+        s.frac_E_disk = self._hold(_a(m.frac_E_disk, np.float64), C.c_double)
+        s.CDF_E_star = self._hold(_a(m.CDF_E_star, np.float64), C.c_double)
+        pe = getattr(m, "prob_E_cell", None)
+        if pe is not None:
+            s.prob_E_cell = self._hold(_a(pe, np.float64), C.c_double)
+        s.L_packet_th = m.L_packet_th(n_tot)
+        s.T_min = float(cfg.T_min)
+        s.N_thet, s.N_phi = cfg.N_thet, cfg.N_phi
+        s.l_sym_centrale, s.l_sym_axiale = int(cfg.l_sym_centrale), int(cfg.l_sym_axiale)
+        return s
+
+    # -- packet loop -------------------------------------------------------
+    def run_thermal(self, n_packets, seed=1, first_packet=0, n_threads=1, frozen=False,
+                    E_prior=None, tau_fp32=False, n_replicas=1.0):
+        m = self.model
+        nl, nt, nphi = m.n_lambda, m.cfg.N_thet, m.cfg.N_phi
+        E = np.zeros(m.n_cells, np.float64)
+        sed = np.zeros((N_SED_TYPES, nphi, nt, nl), np.float64)
+        n_sent = np.zeros(nl, np.float64)
+        cnt = np.zeros(N_COUNTERS, np.uint64)
+        o = _Opts(seed, first_packet, n_packets, n_threads, int(frozen), int(tau_fp32),
+                  float(n_replicas))
+        ep = None
+        if E_prior is not None:
+            ep = _a(E_prior, np.float64)
+        rc = self.lib.oracle_run_thermal(
+            C.byref(self.cm), C.byref(o), _p(ep, C.c_double) if ep is not None else None,
+            _p(E, C.c_double), _p(sed, C.c_double), _p(n_sent, C.c_double), _p(cnt, C.c_uint64))
+        if rc:
+            raise RuntimeError(f"oracle_run_thermal failed: {rc}")
+        return dict(E_abs=E, sed=sed, n_sent=n_sent,
+                    counters=dict(zip(COUNTER_NAMES, (int(c) for c in cnt))))
+
+    def temp_finale(self, E_abs):
+        T = np.zeros(self.model.n_cells, np.float32)
+        E = _a(E_abs, np.float64)
+        self.lib.oracle_temp_finale(C.byref(self.cm), _p(E, C.c_double), _p(T, C.c_float))
+        return T
+
+    # -- unit operators (batched in Python; small n only) -------------------
+    def cross_cell(self, x0, y0, z0, u, v, w, cell):
+        n = len(cell)
+        x1 = np.zeros(n); y1 = np.zeros(n); z1 = np.zeros(n); l = np.zeros(n)
+        nxt = np.zeros(n, np.int32)
+        f = self.lib.oracle_cross_cylindrical_cell
+        f.argtypes = [C.c_void_p] + [C.c_double] * 6 + [C.c_int, C.c_int] + [_dp] * 3 + [_ip] + [_dp] * 3
+        a, b, c_, d = C.c_double(), C.c_double(), C.c_double(), C.c_double()
+        lc, lv = C.c_double(), C.c_double()
+        nc = C.c_int()
+        mp = C.addressof(self.cm)
+        for i in range(n):
+            f(mp, x0[i], y0[i], z0[i], u[i], v[i], w[i], int(cell[i]), 0, C.byref(a), C.byref(b),
+              C.byref(c_), C.byref(nc), C.byref(d), C.byref(lc), C.byref(lv))
+            x1[i], y1[i], z1[i], l[i], nxt[i] = a.value, b.value, c_.value, d.value, nc.value
+        return x1, y1, z1, nxt, l
+
+    def index_cell(self, x, y, z):
+        n = len(x)
+        out = np.zeros(n, np.int32)
+        f = self.lib.oracle_index_cell_cyl
+        f.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, _ip]
+        ic = C.c_int()
+        mp = C.addressof(self.cm)
+        for i in range(n):
+            f(mp, x[i], y[i], z[i], C.byref(ic))
+            out[i] = ic.value
+        return out
+
+    def test_exit_grid(self, icell, x, y, z):
+        f = self.lib.oracle_test_exit_grid_cyl
+        f.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double]
+        f.restype = C.c_int
+        mp = C.addressof(self.cm)
+        return np.array([f(mp, int(icell[i]), x[i], y[i], z[i]) for i in range(len(x))], np.int32)
+
+    def move_to_grid(self, x, y, z, u, v, w):
+        n = len(x)
+        xo, yo, zo = np.array(x, float), np.array(y, float), np.array(z, float)
+        ic = np.zeros(n, np.int32); li = np.zeros(n, np.int32)
+        f = self.lib.oracle_move_to_grid_cyl
+        f.argtypes = [C.c_void_p, _dp, _dp, _dp, C.c_double, C.c_double, C.c_double, _ip, _ip]
+        mp = C.addressof(self.cm)
+        for i in range(n):
+            a, b, c_ = C.c_double(xo[i]), C.c_double(yo[i]), C.c_double(zo[i])
+            cc, ll = C.c_int(0), C.c_int(0)
+            f(mp, C.byref(a), C.byref(b), C.byref(c_), u[i], v[i], w[i], C.byref(cc), C.byref(ll))
+            xo[i], yo[i], zo[i], ic[i], li[i] = a.value, b.value, c_.value, cc.value, ll.value
+        return xo, yo, zo, ic, li
+
+    def pos_em_cell(self, icell, r1, r2, r3):
+        n = len(icell)
+        x = np.zeros(n); y = np.zeros(n); z = np.zeros(n)
+        f = self.lib.oracle_pos_em_cell_cyl
+        f.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, _dp, _dp, _dp]
+        mp = C.addressof(self.cm)
+        a, b, c_ = C.c_double(), C.c_double(), C.c_double()
+        for i in range(n):
+            f(mp, int(icell[i]), float(r1[i]), float(r2[i]), float(r3[i]), C.byref(a), C.byref(b),
+              C.byref(c_))
+            x[i], y[i], z[i] = a.value, b.value, c_.value
+        return x, y, z
+
+    def cdapres(self, cospsi, phi, u0, v0, w0):
+        f = self.lib.oracle_cdapres
+        f.argtypes = [C.c_double] * 5 + [_dp] * 3
+        a, b, c_ = C.c_double(), C.c_double(), C.c_double()
+        f(cospsi, phi, u0, v0, w0, C.byref(a), C.byref(b), C.byref(c_))
+        return a.value, b.value, c_.value
+
+    def hg(self, g, rand):
+        f = self.lib.oracle_hg
+        f.argtypes = [C.c_float, C.c_float, C.c_int, _ip, _dp]
+        it, cp = C.c_int(), C.c_double()
+        f(g, rand, 180, C.byref(it), C.byref(cp))
+        return it.value, cp.value
+
+    def angle_diff_theta_pos(self, p_lambda, rand, rand2):
+        f = self.lib.oracle_angle_diff_theta_pos
+        f.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, _ip, _dp]
+        it, cp = C.c_int(), C.c_double()
+        f(C.addressof(self.cm), p_lambda, rand, rand2, C.byref(it), C.byref(cp))
+        return it.value, cp.value
+
+    def select_wl_em(self, rand):
+        f = self.lib.oracle_select_wl_em
+        f.argtypes = [C.c_void_p, C.c_float, _ip]
+        lam = C.c_int()
+        f(C.addressof(self.cm), rand, C.byref(lam))
+        return lam.value
+
+    def update_stokes(self, S, d0, d1, M):
+        f = self.lib.oracle_update_stokes
+        f.argtypes = [_dp] + [C.c_double] * 6 + [_dp]
+        Sa = _a(S, np.float64).copy()
+        Ma = _a(np.asarray(M).T, np.float64).copy()  # column-major M(i,j)
+        f(_p(Sa, C.c_double), *d0, *d1, _p(Ma, C.c_double))
+        return Sa
+
+    def philox(self, ctr, key):
+        c = (C.c_uint32 * 4)(*ctr)
+        k = (C.c_uint32 * 2)(*key)
+        o = (C.c_uint32 * 4)()
+        self.lib.oracle_philox4x32_10(c, k, o)
+        return [int(v) for v in o]
+
+    def packet_rand(self, seed, packet, n):
+        return float(self.lib.oracle_packet_rand(seed, packet, n))
+
+
+class RefGeom:
+    """The reference's own geometry routines (``oracle/_ref``).  One grid per
+    process (the reference allocates its module arrays once)."""
+
+    def __init__(self):
+        path = build_ref()
+        if path is None or not os.path.exists(path):
+            raise FileNotFoundError("oracle/_ref/libmcfost_ref_geom.so not built")
+        self.lib = C.CDLL(path)
+        self.ready = False
+
+    def setup_grid(self, cfg):
+        ierr = C.c_int()
+        self.lib.ref_setup_grid.argtypes = [C.c_int] * 5 + [C.c_double] * 7 + [_ip]
+        self.lib.ref_setup_grid(cfg.n_rad, cfg.nz, cfg.n_az, int(cfg.l3D), cfg.n_rad_in, cfg.rin,
+                                cfg.edge, cfg.rout, cfg.rref, cfg.sclht, cfg.exp_beta, cfg.surf,
+                                C.byref(ierr))
+        if ierr.value:
+            raise RuntimeError("reference grid already set up in this process")
+        self.cfg = cfg
+        self.ready = True
+        a, b, c_, d = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        self.lib.ref_grid_sizes(C.byref(a), C.byref(b), C.byref(c_), C.byref(d))
+        self.n_cells, self.ntot2, self.jlo, self.jn = a.value, b.value, c_.value, d.value
+
+    def get_grid(self):
+        cfg = self.cfg
+        n_rad, nz, n_az = cfg.n_rad, cfg.nz, cfg.n_az
+        o = dict(
+            r_lim=np.zeros(n_rad + 1), r_lim_2=np.zeros(n_rad + 1), zmax=np.zeros(n_rad),
+            z_lim=np.zeros(n_rad * (nz + 2)), tan_phi_lim=np.zeros(n_az),
+            volume=np.zeros(self.n_cells), r_grid=np.zeros(self.n_cells),
+            z_grid=np.zeros(self.n_cells),
+            cell_map=np.zeros((n_rad + 2) * self.jn * n_az, np.int32),
+            cell_map_i=np.zeros(self.ntot2, np.int32), cell_map_j=np.zeros(self.ntot2, np.int32),
+            cell_map_k=np.zeros(self.ntot2, np.int32), lexit_cell=np.zeros(self.ntot2, np.int32))
+        rm = C.c_double()
+        self.lib.ref_get_grid(*[_p(o[k], C.c_double) for k in
+                                ("r_lim", "r_lim_2", "zmax", "z_lim", "tan_phi_lim", "volume",
+                                 "r_grid", "z_grid")],
+                              *[_p(o[k], C.c_int) for k in
+                                ("cell_map", "cell_map_i", "cell_map_j", "cell_map_k", "lexit_cell")],
+                              C.byref(rm))
+        o["Rmax2"] = rm.value
+        return o
+
+    def cross_cell(self, x0, y0, z0, u, v, w, cell):
+        n = len(cell)
+        arrs = [_a(q, np.float64) for q in (x0, y0, z0, u, v, w)]
+        cell = _a(cell, np.int32)
+        x1 = np.zeros(n); y1 = np.zeros(n); z1 = np.zeros(n); l = np.zeros(n)
+        nxt = np.zeros(n, np.int32)
+        self.lib.ref_cross_cell(C.c_int(n), *[_p(q, C.c_double) for q in arrs], _p(cell, C.c_int),
+                                _p(x1, C.c_double), _p(y1, C.c_double), _p(z1, C.c_double),
+                                _p(nxt, C.c_int), _p(l, C.c_double))
+        return x1, y1, z1, nxt, l
+
+    def index_cell(self, x, y, z):
+        n = len(x)
+        arrs = [_a(q, np.float64) for q in (x, y, z)]
+        ic = np.zeros(n, np.int32)
+        self.lib.ref_index_cell(C.c_int(n), *[_p(q, C.c_double) for q in arrs], _p(ic, C.c_int))
+        return ic
+
+    def test_exit_grid(self, icell, x, y, z):
+        n = len(x)
+        ic = _a(icell, np.int32)
+        arrs = [_a(q, np.float64) for q in (x, y, z)]
+        out = np.zeros(n, np.int32)
+        self.lib.ref_test_exit_grid(C.c_int(n), _p(ic, C.c_int), *[_p(q, C.c_double) for q in arrs],
+                                    _p(out, C.c_int))
+        return out
+
+    def move_to_grid(self, x, y, z, u, v, w):
+        n = len(x)
+        xo, yo, zo = (_a(q, np.float64).copy() for q in (x, y, z))
+        d = [_a(q, np.float64) for q in (u, v, w)]
+        ic = np.zeros(n, np.int32); li = np.zeros(n, np.int32)
+        self.lib.ref_move_to_grid(C.c_int(n), _p(xo, C.c_double), _p(yo, C.c_double),
+                                  _p(zo, C.c_double), *[_p(q, C.c_double) for q in d],
+                                  _p(ic, C.c_int), _p(li, C.c_int))
+        return xo, yo, zo, ic, li
+
+    def pos_em_cell(self, icell, r1, r2, r3):
+        n = len(icell)
+        ic = _a(icell, np.int32)
+        r = [_a(q, np.float32) for q in (r1, r2, r3)]
+        x = np.zeros(n); y = np.zeros(n); z = np.zeros(n)
+        self.lib.ref_pos_em_cell(C.c_int(n), _p(ic, C.c_int), *[_p(q, C.c_float) for q in r],
+                                 _p(x, C.c_double), _p(y, C.c_double), _p(z, C.c_double))
+        return x, y, z
+
+    def init_tab_temp(self, n_T, T_min, T_max):
+        out = np.zeros(n_T, np.float32)
+        self.lib.ref_init_tab_temp.argtypes = [C.c_int, C.c_float, C.c_float, _fp]
+        self.lib.ref_init_tab_temp(n_T, T_min, T_max, _p(out, C.c_float))
+        return out
+
+    def init_lambda(self, n, lmin, lmax):
+        o = [np.zeros(n) for _ in range(4)]
+        self.lib.ref_init_lambda.argtypes = [C.c_int, C.c_float, C.c_float] + [_dp] * 4
+        self.lib.ref_init_lambda(n, lmin, lmax, *[_p(q, C.c_double) for q in o])
+        return o
+
+    def constants(self):
+        o = np.zeros(16)
+        self.lib.ref_constants(_p(o, C.c_double))
+        return o

@@ -1,0 +1,1181 @@
+/*
+ * mc_oracle.c -- CPU ORACLE (test infrastructure, never shipped) for the
+ * MCFOST continuum Monte Carlo packet loop.  See mc_oracle.h for the status
+ * header.  Every routine cites the reference routine it restates
+ * (file:line into /root/reference/src/).
+ *
+ * Fortran default-real arithmetic is reproduced with C float where it
+ * matters for discrete decisions (literals such as 1.0e30, the zj index
+ * computed through real(), random numbers stored in default real).
+ */
+#include "mc_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* constants.f90:8-13,151-159 */
+static const double PI = 3.141592653589793238462643383279502884197;
+static const double GRID_PREC = 1.0e-14;  /* cylindrical_grid.f90:16 */
+#define TINY_REAL ((double)FLT_MIN)       /* tiny(0.0)   */
+#define HUGE_REAL ((double)FLT_MAX)       /* huge(1.0)   */
+#define HUGE_DP DBL_MAX                   /* huge(1.0_dp)*/
+#define TINY_DP DBL_MIN                   /* tiny(0.0_dp)*/
+
+static inline float max_int_real(void) {
+  /* constants.f90:159  max_int = real(huge_integer) * (1.0-1.0e-5) */
+  return (float)2147483647 * (1.0f - 1.0e-5f);
+}
+static inline double sign_d(double a, double b) {
+  /* Fortran sign(a,b): |a| with the sign of b (b = +0 counts as positive) */
+  return signbit(b) ? -fabs(a) : fabs(a);
+}
+static inline double modulo_d(double a, double p) {
+  /* Fortran modulo(a,p) = a - floor(a/p)*p */
+  return a - floor(a / p) * p;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Counter-based RNG: Philox4x32-10 (Salmon et al., SC'11).  The reference   */
+/* uses SPRNG streams (random_numbers.f90:28); no reference test pins its    */
+/* bit-stream, so any good generator is statistically equivalent.            */
+/* ------------------------------------------------------------------------ */
+void oracle_philox4x32_10(const uint32_t ctr_in[4], const uint32_t key_in[2],
+                          uint32_t out[4]) {
+  uint32_t c0 = ctr_in[0], c1 = ctr_in[1], c2 = ctr_in[2], c3 = ctr_in[3];
+  uint32_t k0 = key_in[0], k1 = key_in[1];
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+typedef struct {
+  uint32_t key[2];
+  uint32_t ctr[4];
+  uint32_t buf[4];
+  int have; /* unread values in buf */
+} rng_t;
+
+static void rng_init(rng_t *r, uint64_t seed, uint64_t packet) {
+  r->key[0] = (uint32_t)seed;
+  r->key[1] = (uint32_t)(seed >> 32);
+  r->ctr[0] = 0; /* block index within the packet's stream */
+  r->ctr[1] = 0;
+  r->ctr[2] = (uint32_t)packet;
+  r->ctr[3] = (uint32_t)(packet >> 32);
+  r->have = 0;
+}
+/* Uniform default-real in [0,1) with 24 random bits (the reference rounds
+ * SPRNG's double to default real at every call site, e.g.
+ * dust_transfer.f90:536,1073,1208). */
+static inline float rng_float(rng_t *r) {
+  if (r->have == 0) {
+    oracle_philox4x32_10(r->ctr, r->key, r->buf);
+    r->ctr[0] += 1;
+    r->have = 4;
+  }
+  uint32_t u = r->buf[4 - r->have];
+  r->have -= 1;
+  return (float)(u >> 8) * (1.0f / 16777216.0f);
+}
+float oracle_packet_rand(uint64_t seed, uint64_t packet, uint32_t n) {
+  rng_t r;
+  rng_init(&r, seed, packet);
+  float f = 0.0f;
+  for (uint32_t i = 0; i <= n; ++i) f = rng_float(&r);
+  return f;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Cell mapping (cylindrical_grid.f90:45-179)                                */
+/* ------------------------------------------------------------------------ */
+void oracle_cell_mapping_sizes(int n_rad, int nz, int n_az, int l3D,
+                               int *n_cells, int *ntot2, int *jdim_lo,
+                               int *jdim_n) {
+  int j_start = l3D ? -nz : 1;                 /* grid.f90:316-326 */
+  int nrz = n_rad * nz;
+  *n_cells = l3D ? 2 * nrz * n_az : nrz;       /* grid.f90:277-283 */
+  int jstart2 = (j_start < 1 ? j_start : 1) - 1; /* :76 */
+  int jend2 = nz + 1;
+  if (jstart2 < 0)
+    *ntot2 = (n_rad + 2) * (jend2 - jstart2) * n_az;      /* :83 */
+  else
+    *ntot2 = (n_rad + 2) * (jend2 - jstart2 + 1) * n_az;  /* :85 */
+  *jdim_lo = jstart2;
+  *jdim_n = jend2 - jstart2 + 1;
+}
+
+#define CM_IDX(n_rad, jlo, jn, i, j, k) \
+  ((i) + ((n_rad) + 2) * (((j) - (jlo)) + (jn) * ((k)-1)))
+
+int oracle_build_cell_mapping(int n_rad, int nz, int n_az, int l3D,
+                              int *cell_map, int *cell_map_i, int *cell_map_j,
+                              int *cell_map_k, int *lexit_cell) {
+  int n_cells, ntot2, jlo, jn;
+  oracle_cell_mapping_sizes(n_rad, nz, n_az, l3D, &n_cells, &ntot2, &jlo, &jn);
+  int j_start = l3D ? -nz : 1;
+  int istart2 = 0, iend2 = n_rad + 1, jstart2 = jlo, jend2 = nz + 1;
+  int icell = 0;
+  for (int q = 0; q < (n_rad + 2) * jn * n_az; ++q) cell_map[q] = 0;
+  /* real cells (:90-107) */
+  for (int k = 1; k <= n_az; ++k)
+    for (int j = j_start; j <= nz; ++j) {
+      if (j == 0) continue;
+      for (int i = 1; i <= n_rad; ++i) {
+        icell++;
+        if (icell > n_cells) return 1;
+        cell_map_i[icell - 1] = i;
+        cell_map_j[icell - 1] = j;
+        cell_map_k[icell - 1] = k;
+        cell_map[CM_IDX(n_rad, jlo, jn, i, j, k)] = icell;
+      }
+    }
+  if (icell != n_cells) return 2;
+  for (int q = 0; q < ntot2; ++q) lexit_cell[q] = 0; /* :121 */
+  /* virtual cells j = jstart2 and j = jend2 (:123-141) */
+  for (int k = 1; k <= n_az; ++k)
+    for (int j = jstart2; j <= jend2; j += jend2 - jstart2)
+      for (int i = istart2; i <= iend2; ++i) {
+        icell++;
+        if (icell > ntot2) return 3;
+        if (abs(j) == jend2) lexit_cell[icell - 1] = 2;
+        if (i == iend2) lexit_cell[icell - 1] = 1;
+        cell_map_i[icell - 1] = i;
+        cell_map_j[icell - 1] = j;
+        cell_map_k[icell - 1] = k;
+        cell_map[CM_IDX(n_rad, jlo, jn, i, j, k)] = icell;
+      }
+  /* virtual cells i = 0 and i = n_rad+1 (:143-167) */
+  for (int k = 1; k <= n_az; ++k)
+    for (int j = j_start; j <= nz; ++j) {
+      if (j == 0) continue;
+      for (int i = istart2; i <= iend2; i += iend2 - istart2) {
+        icell++;
+        if (icell > ntot2) return 4;
+        if (i == iend2) lexit_cell[icell - 1] = 1;
+        cell_map_i[icell - 1] = i;
+        cell_map_j[icell - 1] = j;
+        cell_map_k[icell - 1] = k;
+        cell_map[CM_IDX(n_rad, jlo, jn, i, j, k)] = icell;
+      }
+    }
+  if (icell != ntot2) return 5;
+  return 0;
+}
+
+static inline int cmap(const oracle_model *m, int i, int j, int k) {
+  return m->cell_map[CM_IDX(m->n_rad, m->jdim_lo, m->jdim_n, i, j, k)];
+}
+static inline double zlim(const oracle_model *m, int i, int j) {
+  return m->z_lim[(i - 1) + m->n_rad * (j - 1)];
+}
+
+/* ------------------------------------------------------------------------ */
+/* Geometry operators                                                        */
+/* ------------------------------------------------------------------------ */
+
+/* cylindrical_grid.f90:680-704 */
+int oracle_test_exit_grid_cyl(const oracle_model *m, int icell, double x,
+                              double y, double z) {
+  (void)x; (void)y;
+  if (icell <= m->n_cells) return 0;
+  int le = m->lexit_cell[icell - 1];
+  if (le == 0) return 0;
+  if (le == 1) return 1;
+  return fabs(z) > m->zmaxmax;
+}
+
+/* zj from |z| exactly as cylindrical_grid.f90:868,1116: through default real */
+static inline int zj_from_z_real(const oracle_model *m, double absz, int ri) {
+  float q = (float)(absz / m->zmax[ri - 1] * (double)m->nz);
+  float mi = max_int_real();
+  if (!(q < mi)) q = mi; /* min(real(...), max_int) */
+  return (int)floorf(q) + 1;
+}
+
+/* cylindrical_grid.f90:833-890 */
+void oracle_index_cell_cyl(const oracle_model *m, double xin, double yin,
+                           double zin, int *icell) {
+  double r2 = xin * xin + yin * yin;
+  int ri_out, zj_out, phik_out;
+  if (r2 < m->r_lim_2[0]) {
+    ri_out = 0; zj_out = 1; phik_out = 1;
+  } else if (r2 > m->Rmax2) {
+    ri_out = m->n_rad + 1; zj_out = 1; phik_out = 1;
+  } else {
+    int ri_min = 0, ri_max = m->n_rad;
+    int ri = (ri_min + ri_max) / 2;
+    while ((ri_max - ri_min) > 1) {
+      if (r2 > m->r_lim_2[ri]) ri_min = ri; else ri_max = ri;
+      ri = (ri_min + ri_max) / 2;
+    }
+    ri_out = ri + 1;
+    zj_out = zj_from_z_real(m, fabs(zin), ri_out);
+    if (m->l3D) {
+      if (zj_out > m->nz) zj_out = m->nz + 1;
+      if (zin < 0.0) zj_out = -zj_out;
+      if (zin != 0.0) {
+        double phi = modulo_d(atan2(yin, xin), 2 * PI);
+        phik_out = (int)floor(phi / (2 * PI) * (double)(float)m->n_az) + 1;
+        if (phik_out == m->n_az + 1) phik_out = m->n_az;
+      } else {
+        phik_out = 1;
+      }
+    } else {
+      if (zj_out > m->nz) zj_out = m->nz + 1;
+      phik_out = 1;
+    }
+  }
+  *icell = cmap(m, ri_out, zj_out, phik_out);
+}
+
+/* cylindrical_grid.f90:918-1175 */
+void oracle_cross_cylindrical_cell(const oracle_model *m, double x0, double y0,
+                                   double z0, double u, double v, double w,
+                                   int cell, int previous_cell, double *x1,
+                                   double *y1, double *z1, int *next_cell,
+                                   double *l_out, double *l_contrib,
+                                   double *l_void_before) {
+  (void)previous_cell;
+  const int nz = m->nz, n_rad = m->n_rad, n_az = m->n_az, l3D = m->l3D;
+  const double correct_moins = 1.0 - GRID_PREC; /* :938 */
+  const double correct_plus = 1.0 + GRID_PREC;  /* :939 */
+  double inv_a, inv_w, a, b, c, s, rac, t, t_phi, delta, r_2, den;
+  double tan_angle_lim, phi, delta_vol, zl, dotprod, l;
+  int ri0, zj0, k0, k0m1, delta_rad = 0, delta_zj = 0, delta_phi = 0;
+  int ri1, zj1, k1;
+
+  a = u * u + v * v;                                   /* :941-946 */
+  if (a > TINY_REAL) inv_a = 1.0 / a; else inv_a = HUGE_REAL;
+  if (fabs(w) > TINY_REAL) inv_w = 1.0 / w;            /* :948-952 */
+  else inv_w = sign_d(HUGE_DP, w);
+
+  ri0 = m->cell_map_i[cell - 1];                       /* :956 */
+  zj0 = m->cell_map_j[cell - 1];
+  k0 = m->cell_map_k[cell - 1];
+
+  r_2 = x0 * x0 + y0 * y0;                             /* :959-960 */
+  b = (x0 * u + y0 * v) * inv_a;
+
+  if (ri0 == 0) {                                      /* :962-971 */
+    c = (r_2 - m->r_lim_2[0]) * inv_a;
+    delta = b * b - c;
+    rac = sqrt(delta);
+    s = (-b + rac) * correct_plus;
+    t = HUGE_REAL;
+    t_phi = HUGE_REAL;
+    delta_rad = 1;
+  } else {
+    /* 1) radial interface (:973-1000) */
+    dotprod = u * x0 + v * y0;
+    if (dotprod < 0.0) {
+      c = (r_2 - m->r_lim_2[ri0 - 1] * correct_moins) * inv_a;
+      delta = b * b - c;
+      if (delta < 0.0) {
+        c = (r_2 - m->r_lim_2[ri0] * correct_plus) * inv_a;
+        delta = fmax(b * b - c, 0.0);
+        delta_rad = 1;
+      } else {
+        delta_rad = -1;
+      }
+    } else {
+      c = (r_2 - m->r_lim_2[ri0] * correct_plus) * inv_a;
+      delta = fmax(b * b - c, 0.0);
+      delta_rad = 1;
+    }
+    rac = sqrt(delta);
+    s = (-b - rac) * correct_plus;
+    if (s < 0.0) s = (-b + rac) * correct_plus;
+    else if (s == 0.0) s = GRID_PREC;
+
+    /* 2) vertical interface (:1003-1055) */
+    dotprod = w * z0;
+    if (dotprod == 0.0) {
+      t = (double)1.0e10f;
+    } else {
+      if (dotprod > 0.0) {
+        if (abs(zj0) == nz + 1) {
+          delta_zj = 0;
+          zl = sign_d(1.0e10, z0);
+        } else {
+          zl = sign_d(zlim(m, ri0, abs(zj0) + 1) * correct_plus, z0);
+          delta_zj = 1;
+          if (l3D && (z0 < 0.0)) delta_zj = -1;
+        }
+      } else {
+        if (l3D) {
+          if (z0 > 0.0) {
+            zl = zlim(m, ri0, abs(zj0)) * correct_moins;
+            delta_zj = -1;
+            if (zj0 == 1) delta_zj = -2;
+          } else {
+            zl = -zlim(m, ri0, abs(zj0)) * correct_moins;
+            delta_zj = 1;
+            if (zj0 == -1) delta_zj = 2;
+          }
+        } else {
+          if (zj0 == 1) { /* cross the midplane, z changes sign (:1032-1040) */
+            delta_zj = 1;
+            if (z0 > 0.0) zl = -zlim(m, ri0, 2) * correct_moins;
+            else zl = zlim(m, ri0, 2) * correct_moins;
+          } else {
+            if (z0 > 0.0) zl = zlim(m, ri0, zj0) * correct_moins;
+            else zl = -zlim(m, ri0, zj0) * correct_moins;
+            delta_zj = -1;
+          }
+        }
+      }
+      t = (zl - z0) * inv_w;
+      if (t < 0.0) t = GRID_PREC;
+    }
+
+    /* 3) azimuthal interface (:1058-1094) */
+    if (l3D) {
+      dotprod = x0 * v - y0 * u;
+      if (fabs(dotprod) < (double)1.0e-10f) {
+        t_phi = (double)1.0e30f;
+      } else {
+        if (dotprod > 0.0) {
+          tan_angle_lim = m->tan_phi_lim[k0 - 1];
+          delta_phi = 1;
+        } else {
+          k0m1 = k0 - 1;
+          if (k0m1 == 0) k0m1 = n_az;
+          tan_angle_lim = m->tan_phi_lim[k0m1 - 1];
+          delta_phi = -1;
+        }
+        if (tan_angle_lim > 1.0e299) {
+          if (fabs(u) > (double)1e-6f) t_phi = -x0 / u;
+          else t_phi = (double)1.0e30f;
+        } else {
+          den = v - u * tan_angle_lim;
+          if (fabs(den) > (double)1.0e-6f)
+            t_phi = -(y0 - x0 * tan_angle_lim) / den;
+          else
+            t_phi = (double)1.0e30f;
+        }
+        if (t_phi < 0.0) t_phi = (double)1.0e30f;
+      }
+    } else {
+      t_phi = HUGE_REAL;
+    }
+  }
+
+  /* 4) which interface (:1098-1156) */
+  if ((s < t) && (s < t_phi)) {
+    l = s;
+    delta_vol = s;
+    *x1 = x0 + delta_vol * u;
+    *y1 = y0 + delta_vol * v;
+    *z1 = z0 + delta_vol * w;
+    ri1 = ri0 + delta_rad;
+    if (ri1 == 0) {
+      zj1 = 1;
+      k1 = 1;
+    } else {
+      if (ri1 > n_rad) {
+        zj1 = zj0;
+      } else {
+        zj1 = zj_from_z_real(m, fabs(*z1), ri1);
+        if (zj1 > nz) zj1 = nz + 1;
+        if (l3D && (*z1 < 0.0)) zj1 = -zj1;
+      }
+      k1 = k0;
+      if ((ri0 == 0) && l3D) {
+        phi = modulo_d(atan2(*y1, *x1), 2 * PI);
+        k1 = (int)floor(phi * (1.0 / (2.0 * PI)) * (double)(float)n_az) + 1;
+        if (k1 == n_az + 1) k1 = n_az;
+      }
+    }
+  } else if (t < t_phi) {
+    l = t;
+    delta_vol = t;
+    *x1 = x0 + delta_vol * u;
+    *y1 = y0 + delta_vol * v;
+    *z1 = z0 + delta_vol * w;
+    ri1 = ri0;
+    zj1 = zj0 + delta_zj;
+    k1 = k0;
+  } else {
+    l = t_phi;
+    delta_vol = correct_plus * t_phi;
+    *x1 = x0 + delta_vol * u;
+    *y1 = y0 + delta_vol * v;
+    *z1 = z0 + delta_vol * w;
+    ri1 = ri0;
+    zj1 = (int)floor(fabs(*z1) / m->zmax[ri1 - 1] * (double)nz) + 1;
+    if (zj1 > nz) zj1 = nz + 1;
+    if (*z1 < 0.0) zj1 = -zj1;
+    k1 = k0 + delta_phi;
+    if (k1 == 0) k1 = n_az;
+    if (k1 == n_az + 1) k1 = 1;
+  }
+
+  if (*z1 == 0.0) {                                    /* :1158-1165 */
+    if (l3D) *z1 = sign_d(GRID_PREC, w);
+    else *z1 = GRID_PREC;
+  }
+
+  *next_cell = cmap(m, ri1, zj1, k1);                  /* :1168 */
+  *l_out = l;
+  *l_contrib = l;
+  *l_void_before = 0.0;
+}
+
+/* cylindrical_grid.f90:1284-1411 */
+void oracle_move_to_grid_cyl(const oracle_model *m, double *x, double *y,
+                             double *z, double u, double v, double w,
+                             int *icell, int *lintersect) {
+  const double correct_moins = 1.0 - 1.0e-10;
+  double x0 = *x, y0 = *y, z0 = *z, z1, a, inv_a, r_2, b, c, delta, rac;
+  double s1, s2, dotprod, t1, t2, zl, zl2, delta_vol, inv_w;
+
+  a = u * u + v * v;
+  if (a > TINY_REAL) inv_a = 1.0 / a; else inv_a = HUGE_REAL;
+  if (fabs(w) > TINY_REAL) inv_w = 1.0 / w; else inv_w = sign_d(HUGE_DP, w);
+
+  r_2 = x0 * x0 + y0 * y0;
+  b = (x0 * u + y0 * v) * inv_a;
+  c = (r_2 - m->r_lim_2[m->n_rad] * correct_moins) * inv_a;
+  delta = b * b - c;
+  if (delta < 0.0) {
+    s1 = HUGE_REAL; s2 = HUGE_REAL;
+  } else {
+    rac = sqrt(delta);
+    s1 = -b - rac;
+    s2 = -b + rac;
+  }
+  dotprod = w * z0;
+  if (fabs(dotprod) < TINY_REAL) {
+    t1 = HUGE_REAL; t2 = HUGE_REAL;
+  } else {
+    if (z0 > 0.0) {
+      zl = m->zmaxmax * correct_moins;
+      zl2 = -m->zmaxmax * correct_moins;
+    } else {
+      zl = -m->zmaxmax * correct_moins;
+      zl2 = m->zmaxmax * correct_moins;
+    }
+    t1 = (zl - z0) * inv_w;
+    t2 = (zl2 - z0) * inv_w;
+  }
+  if (t1 > (double)1e20f) {
+    if (s1 > (double)1e20f) { *lintersect = 0; return; }
+  }
+  if (t1 > s1) {
+    if (t1 > s2) {
+      delta_vol = s1;
+      z1 = z0 + delta_vol * w;
+      if (fabs(z1) > m->zmaxmax) { *lintersect = 0; return; }
+      *lintersect = 1;
+    } else {
+      *lintersect = 1;
+      delta_vol = t1;
+    }
+  } else {
+    if (t2 < s1) { *lintersect = 0; return; }
+    *lintersect = 1;
+    delta_vol = s1;
+  }
+  *x = x0 + delta_vol * u;
+  *y = y0 + delta_vol * v;
+  *z = z0 + delta_vol * w;
+  oracle_index_cell_cyl(m, *x, *y, *z, icell);
+}
+
+/* cylindrical_grid.f90:1415-1466 */
+void oracle_pos_em_cell_cyl(const oracle_model *m, int icell, float rand1,
+                            float rand2, float rand3, double *x, double *y,
+                            double *z) {
+  int ri = m->cell_map_i[icell - 1];
+  int zj = m->cell_map_j[icell - 1];
+  int phik = m->cell_map_k[icell - 1];
+  double r = sqrt(m->r_lim_2[ri - 1] +
+                  (double)rand1 * (m->r_lim_2[ri] - m->r_lim_2[ri - 1]));
+  if (m->l3D) {
+    if (zj > 0)
+      *z = zlim(m, ri, zj) + (double)rand2 * (zlim(m, ri, zj + 1) - zlim(m, ri, zj));
+    else
+      *z = -(zlim(m, ri, -zj) +
+             (double)rand2 * (zlim(m, ri, -zj + 1) - zlim(m, ri, -zj)));
+  } else {
+    if ((double)rand2 > 0.5)
+      *z = zlim(m, ri, zj) + (2.0 * ((double)rand2 - 0.5)) *
+                                 (zlim(m, ri, abs(zj) + 1) - zlim(m, ri, zj));
+    else
+      *z = -(zlim(m, ri, zj) +
+             (2.0 * (double)rand2) * (zlim(m, ri, zj + 1) - zlim(m, ri, zj)));
+  }
+  double phi = 2.0 * PI * ((double)phik - 1.0 + (double)rand3) / (double)m->n_az;
+  *x = r * cos(phi);
+  *y = r * sin(phi);
+}
+
+/* ------------------------------------------------------------------------ */
+/* Direction helpers                                                         */
+/* ------------------------------------------------------------------------ */
+
+/* utils.f90:1636-1690 */
+void oracle_cdapres(double cospsi, double phi, double u0, double v0, double w0,
+                    double *u1, double *v1, double *w1) {
+  double cpsi = cospsi;
+  double spsi = sqrt(1.0 - cpsi * cpsi);
+  double sphi = sin(phi);
+  double cphi = cos(phi);
+  double a = spsi * cphi;
+  double b = spsi * sphi;
+  if (fabs(w0) <= (double)0.999999f) {
+    double c = sqrt(1.0 - w0 * w0);
+    double cm1 = 1.0 / c;
+    double aw0 = a * w0;
+    *u1 = (aw0 * u0 - b * v0) * cm1 + cpsi * u0;
+    *v1 = (aw0 * v0 + b * u0) * cm1 + cpsi * v0;
+    *w1 = cpsi * w0 - a * c;
+  } else {
+    *u1 = a;
+    *v1 = b;
+    *w1 = cpsi;
+  }
+}
+
+/* utils.f90:553-601 */
+void oracle_rotation(double xinit, double yinit, double zinit, double u1,
+                     double v1, double w1, double *xfin, double *yfin,
+                     double *zfin) {
+  double cost, sint, sing, prod, theta;
+  if (w1 > 0.999999999) {
+    cost = 1.0; sint = 0.0; sing = 0.0;
+  } else {
+    if (fabs(u1) < TINY_REAL) {
+      cost = 0.0; sint = 1.0;
+      sing = sqrt(1.0 - w1 * w1);
+    } else {
+      theta = atan2(v1, u1);
+      cost = cos(theta);
+      sint = sin(theta);
+      sing = sqrt(1.0 - w1 * w1);
+    }
+  }
+  prod = cost * xinit + sint * yinit;
+  *xfin = sing * prod + w1 * zinit;
+  *yfin = cost * yinit - sint * xinit;
+  *zfin = sing * zinit - w1 * prod;
+}
+
+/* random_numbers.f90:32-51 */
+static void random_isotropic_direction(rng_t *r, double *u, double *v,
+                                       double *w) {
+  float rand = rng_float(r);
+  *w = 2.0 * (double)rand - 1.0;
+  double uv = sqrt(1.0 - (*w) * (*w));
+  rand = rng_float(r);
+  double phi = PI * (2.0 * (double)rand - 1.0);
+  *u = uv * cos(phi);
+  *v = uv * sin(phi);
+}
+
+/* scattering.f90:1354-1383 */
+void oracle_hg(float g, float rand, int nang_scatt, int *itheta,
+               double *cospsi) {
+  double rand_dp = fmin((double)rand, 1.0 - 1e-6);
+  if (fabsf(g) > FLT_MIN) {
+    double g1 = (double)g;
+    double g2 = g1 * g1;
+    double q = (1.0 - g2) / (1.0 - g1 + 2.0 * g1 * rand_dp);
+    *cospsi = (1.0 + g2 - q * q) / (2.0 * g1);
+  } else {
+    *cospsi = 2.0 * rand_dp - 1.0;
+  }
+  *itheta = (int)floor(acos(*cospsi) * 180.0 / PI) + 1;
+  if (*itheta > nang_scatt) *itheta = nang_scatt;
+}
+
+/* scattering.f90:1433-1475 */
+void oracle_angle_diff_theta_pos(const oracle_model *m, int p_lambda,
+                                 float rand, float rand2, int *itheta,
+                                 double *cospsi) {
+  const int na = m->nang_scatt;
+  const float *prob = m->prob_s11_pos + (size_t)(na + 1) * (p_lambda - 1);
+  int kmin = 0, kmax = na, k = (kmin + kmax) / 2;
+  while ((kmax - kmin) > 1) {
+    if (prob[k] < rand) kmin = k; else kmax = k;
+    k = (kmin + kmax) / 2;
+  }
+  k = kmax;
+  *itheta = k;
+  double c0 = cos(((double)k - 1.0) * PI / (double)na);
+  double c1 = cos(((double)k) * PI / (double)na);
+  *cospsi = c0 + (double)rand2 * (c1 - c0);
+}
+
+/* scattering.f90:1328-1350 */
+static void get_mueller_matrix_per_cell(const oracle_model *m, int lambda,
+                                        int itheta, float frac, double M[16]) {
+  const size_t o = (size_t)(m->nang_scatt + 1) * (lambda - 1);
+  float frac_m1 = 1.0f - frac;
+  memset(M, 0, 16 * sizeof(double));
+  /* M is column-major M(i,j) -> M[(i-1)+4*(j-1)] */
+#define MM(i, j) M[((i)-1) + 4 * ((j)-1)]
+#define INTERP(t) ((t)[o + itheta] * frac + (t)[o + itheta - 1] * frac_m1)
+  MM(1, 1) = 1.0;
+  MM(2, 2) = (double)INTERP(m->s22_o_s11);
+  MM(1, 2) = (double)INTERP(m->s12_o_s11);
+  MM(2, 1) = MM(1, 2);
+  MM(3, 3) = (double)INTERP(m->s33_o_s11);
+  MM(4, 4) = (double)INTERP(m->s44_o_s11);
+  MM(3, 4) = (double)(-m->s34_o_s11[o + itheta] * frac -
+                      m->s34_o_s11[o + itheta - 1] * frac_m1);
+  MM(4, 3) = -MM(3, 4);
+#undef INTERP
+}
+
+/* scattering.f90:1187-1298 */
+void oracle_update_stokes(double S[4], double u0, double v0, double w0,
+                          double u1, double v1, double w1, const double M[16]) {
+  float sinw, cosw, omega, theta, costhet, xnyp;
+  double v1pi, v1pj, v1pk, S1_0;
+  double C[4], D[4];
+  oracle_rotation(u0, v0, w0, u1, v1, w1, &v1pi, &v1pj, &v1pk);
+  xnyp = (float)sqrt(v1pk * v1pk + v1pj * v1pj);
+  if (xnyp < 1e-10f) {
+    xnyp = 0.0f;
+    costhet = 1.0f;
+  } else {
+    costhet = (float)(-1.0 * v1pj / (double)xnyp);
+  }
+  theta = acosf(costhet);
+  if ((double)theta >= PI) theta = 0.0f;
+  theta = (float)((double)theta + 0.5 * PI);
+  omega = 2.0f * theta;
+  if (v1pk < 0.0) omega = -1.0f * omega;
+  cosw = cosf(omega);
+  sinw = sinf(omega);
+  if (fabsf(cosw) < 1e-06f) cosw = 0.0f;
+  if (fabsf(sinw) < 1e-06f) sinw = 0.0f;
+  /* ROP: (2,2)=cosw (3,2)=sinw (2,3)=-sinw (3,3)=cosw ; C = ROP*S */
+  C[0] = S[0];
+  C[1] = (double)cosw * S[1] - (double)sinw * S[2];
+  C[2] = (double)sinw * S[1] + (double)cosw * S[2];
+  C[3] = S[3];
+  for (int i = 0; i < 4; ++i) {
+    D[i] = 0.0;
+    for (int j = 0; j < 4; ++j) D[i] += M[i + 4 * j] * C[j];
+  }
+  S1_0 = S[0];
+  /* RPO: (2,2)=cosw (2,3)=sinw (3,2)=-sinw (3,3)=cosw ; S = RPO*D */
+  S[0] = D[0];
+  S[1] = (double)cosw * D[1] + (double)sinw * D[2];
+  S[2] = -(double)sinw * D[1] + (double)cosw * D[2];
+  S[3] = D[3];
+  if (S[0] > TINY_REAL) {
+    double f = M[0] * S1_0 / S[0];
+    for (int i = 0; i < 4; ++i) S[i] *= f;
+  }
+}
+
+/* thermal_emission.f90:364-400 */
+void oracle_select_wl_em(const oracle_model *m, float rand, int *lambda) {
+  const double *cum = m->spectre_emission_cumul;
+  int kmin = 0, kmax = m->n_lambda, k = (kmin + kmax) / 2;
+  while (cum[k] != (double)rand) {
+    if (cum[k] < (double)rand) kmin = k; else kmax = k;
+    k = (kmin + kmax) / 2;
+    if ((kmax - kmin) <= 1) break;
+  }
+  *lambda = kmax;
+}
+
+/* stars.f90:75-104 */
+static int select_star(const oracle_model *m, int lambda, float rand) {
+  int kmin = 0, kmax = m->n_stars, k = (kmax - kmin) / 2;
+  while ((kmax - kmin) > 1) {
+    /* CDF_E_star(lambda,k), k = 0..n_stars */
+    if (m->CDF_E_star[(lambda - 1) + (size_t)m->n_lambda * k] < (double)rand)
+      kmin = k;
+    else
+      kmax = k;
+    k = (kmin + kmax) / 2;
+  }
+  return kmax;
+}
+
+/* thermal_emission.f90:2044-2073 */
+static int select_cellule(const oracle_model *m, int lambda, float rand) {
+  const double *p = m->prob_E_cell + (size_t)(m->n_cells + 1) * (lambda - 1);
+  int kmin = 0, kmax = m->n_cells, k = (kmin + kmax) / 2;
+  while ((kmax - kmin) > 1) {
+    if (p[k] < (double)rand) kmin = k; else kmax = k;
+    k = (kmin + kmax) / 2;
+  }
+  return kmax;
+}
+
+/* stars.f90:812-884 */
+void oracle_intersect_stars(const oracle_model *m, double x, double y,
+                            double z, double u, double v, double w,
+                            int *lintersect, int *i_star, int *icell_star) {
+  double d_to_star = DBL_MAX;
+  *i_star = 0;
+  for (int i = 1; i <= m->n_stars; ++i) {
+    const oracle_star *st = &m->stars[i - 1];
+    double dx = x - st->x, dy = y - st->y, dz = z - st->z;
+    double b = dx * u + dy * v + dz * w;
+    double c = dx * dx + dy * dy + dz * dz - st->r * st->r;
+    double delta = b * b - c;
+    if (delta >= 0.0) {
+      double rac = sqrt(delta);
+      double s1 = -b - rac;
+      if (s1 < 0) {
+        double s2 = -b + rac;
+        if (s2 > 0) {
+          d_to_star = 0.0;
+          *i_star = i;
+        }
+      } else {
+        if (s1 < d_to_star) {
+          d_to_star = s1;
+          *i_star = i;
+        }
+      }
+    }
+  }
+  *lintersect = (*i_star > 0);
+  *icell_star = *lintersect ? m->stars[*i_star - 1].icell : 0;
+}
+
+/* stars.f90:108-169 */
+static void emit_packet_uniform_sphere(const oracle_model *m, int i_star,
+                                       float rand1, float rand2, float rand3,
+                                       float rand4, int *icell, double *x,
+                                       double *y, double *z, double *u,
+                                       double *v, double *w, int *lintersect) {
+  const oracle_star *st = &m->stars[i_star - 1];
+  *z = 2.0 * (double)rand1 - 1.0;
+  double srw02 = sqrt(1.0 - (*z) * (*z));
+  double argmt = PI * (2.0 * (double)rand2 - 1.0);
+  *x = srw02 * cos(argmt);
+  *y = srw02 * sin(argmt);
+  double cospsi = sqrt((double)rand3);
+  double phi = 2.0 * PI * (double)rand4;
+  oracle_cdapres(cospsi, phi, *x, *y, *z, u, v, w);
+  double r_star = st->r * (1.0 + 1e-6);
+  *x = *x * r_star + st->x;
+  *y = *y * r_star + st->y;
+  *z = *z * r_star + st->z;
+  oracle_index_cell_cyl(m, *x, *y, *z, icell);
+  if (st->out_model)
+    oracle_move_to_grid_cyl(m, x, y, z, *u, *v, *w, icell, lintersect);
+  else
+    *lintersect = 1;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Temperature                                                               */
+/* ------------------------------------------------------------------------ */
+
+/* Temp_LTE (thermal_emission.f90:649-706) given the cell's heating integral
+ * sum_k kappa_abs*l (Qheat = E*L_packet_th/volume is formed here).  Ti_start
+ * is the cached xT_ech entry (>= 2).  When the cell is at T_min the reference
+ * leaves `frac` unassigned (:674,:679); the oracle returns frac = 0, i.e. the
+ * T_1 row of the CDF. */
+void oracle_temp_lte(const oracle_model *m, double E_scaled, double volume,
+                     int Ti_start, int *Ti_out, float *Temp, double *frac) {
+  const double *lq = m->log_Qcool; /* 1-based: lq[T-1] */
+  double Qheat = E_scaled * m->L_packet_th / volume;
+  int Ti;
+  *frac = 0.0;
+  if (Qheat < TINY_DP) {
+    *Temp = m->T_min; Ti = 2;
+  } else {
+    double log_Qheat = log(Qheat);
+    if (log_Qheat < lq[0]) {
+      *Temp = m->T_min; Ti = 2;
+    } else {
+      Ti = Ti_start;
+      while ((lq[Ti - 1] < log_Qheat) && (Ti < m->n_T)) Ti++;
+      *frac = (log_Qheat - lq[Ti - 2]) / (lq[Ti - 1] - lq[Ti - 2]);
+      /* log of a default real is a default-real log (:697) */
+      *Temp = (float)exp((double)logf(m->tab_Temp[Ti - 1]) * (*frac) +
+                         (double)logf(m->tab_Temp[Ti - 2]) * (1.0 - *frac));
+    }
+  }
+  *Ti_out = Ti;
+}
+
+/* Temp_finale (thermal_emission.f90:870-906): id = 0, E_abs already summed */
+void oracle_temp_finale(const oracle_model *m, const double *E_abs,
+                        float *Tdust) {
+  for (int icell = 1; icell <= m->n_cells; ++icell) {
+    int Ti; double frac;
+    oracle_temp_lte(m, E_abs[icell - 1], m->volume[icell - 1], 2, &Ti,
+                    &Tdust[icell - 1], &frac);
+  }
+}
+
+/* ------------------------------------------------------------------------ */
+/* Packet loop                                                               */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+  const oracle_model *m;
+  const oracle_opts *o;
+  const double *E_prior;
+  double *E_abs;   /* this thread's xKJ_abs(:,id) */
+  int *xT_ech;     /* this thread's xT_ech(:,id) */
+  double *sed;     /* this thread's sed arrays */
+  double *n_sent;
+  uint64_t cnt[ORACLE_N_COUNTERS];
+  double qscale;   /* nb_proc * n_replicas */
+  rng_t rng;
+} worker_t;
+
+/* physical_length (optical_depth.f90:21-182), letape_th branch only */
+static void physical_length(worker_t *W, int lambda, const double Stokes[4],
+                            int *icell, double *xio, double *yio, double *zio,
+                            double *u, double *v, double *w, double extrin,
+                            int *flag_sortie, int *lpacket_alive) {
+  const oracle_model *m = W->m;
+  double x0 = *xio, y0 = *yio, z0 = *zio, x1 = *xio, y1 = *yio, z1 = *zio;
+  double x_old, y_old, z_old, extr = extrin, l, tau, opacity, l_contrib,
+         l_void_before;
+  int icell_old, next_cell = *icell, previous_cell, icell0 = 0;
+  int lintersect_stars, i_star, icell_star, lstop = 0, lcell_not_empty;
+  *flag_sortie = 0;
+  W->cnt[ORC_CNT_FLIGHTS]++;
+
+  oracle_intersect_stars(m, x0, y0, z0, *u, *v, *w, &lintersect_stars, &i_star,
+                         &icell_star);                              /* :68 */
+  for (;;) {
+    icell_old = icell0;                                             /* :79 */
+    x_old = x0; y_old = y0; z_old = z0;
+    x0 = x1; y0 = y1; z0 = z1;
+    previous_cell = icell0;
+    icell0 = next_cell;
+
+    if (oracle_test_exit_grid_cyl(m, icell0, x0, y0, z0)) {         /* :87 */
+      *flag_sortie = 1;
+      return;
+    }
+    if (lintersect_stars && icell0 == icell_star) {                 /* :91 */
+      *lpacket_alive = 0;
+      *flag_sortie = 1;
+      W->cnt[ORC_CNT_KILLED_STAR]++;
+      return;
+    }
+    if (icell0 <= m->n_cells) {                                     /* :100 */
+      lcell_not_empty = 1;
+      opacity = m->kappa[lambda - 1] * m->kappa_factor[icell0 - 1];
+      if (m->l_dark_zone && m->l_dark_zone[icell0 - 1]) {           /* :104 */
+        *u = -*u; *v = -*v; *w = -*w;
+        *icell = icell_old;
+        *xio = x_old; *yio = y_old; *zio = z_old;
+        *flag_sortie = 0;
+        W->cnt[ORC_CNT_DARK]++;
+        return;
+      }
+    } else {
+      lcell_not_empty = 0;
+      opacity = 0.0;
+    }
+    oracle_cross_cylindrical_cell(m, x0, y0, z0, *u, *v, *w, icell0,
+                                  previous_cell, &x1, &y1, &z1, &next_cell, &l,
+                                  &l_contrib, &l_void_before);      /* :119 */
+    W->cnt[ORC_CNT_CROSSINGS]++;
+    tau = l_contrib * opacity;                                      /* :134 */
+    if (tau > extr) {                                               /* :138 */
+      lstop = 1;
+      l_contrib = l_contrib * (extr / tau);
+      l = l_void_before + l_contrib;
+    } else {
+      extr = extr - tau;
+    }
+    /* save_radiation_field, thermal step (radiation_field.f90:53) */
+    if (lcell_not_empty)
+      W->E_abs[icell0 - 1] += m->kappa_abs_LTE[lambda - 1] * l_contrib * Stokes[0];
+    if (lstop) {                                                    /* :153 */
+      *flag_sortie = 0;
+      *xio = x0 + l * (*u);
+      *yio = y0 + l * (*v);
+      *zio = z0 + l * (*w);
+      *icell = icell0;
+      if (m->l3D) oracle_index_cell_cyl(m, *xio, *yio, *zio, icell); /* :162 */
+      return;
+    }
+  }
+}
+
+/* im_reemission_LTE (thermal_emission.f90:710-771) */
+static void im_reemission_LTE(worker_t *W, int icell, float rand1, float rand2,
+                              int *lambda) {
+  const oracle_model *m = W->m;
+  (void)rand1;
+  int Ti; float Temp; double frac_T2;
+  if (W->o->frozen) {
+    oracle_temp_lte(m, W->E_prior[icell - 1], m->volume[icell - 1], 2, &Ti,
+                    &Temp, &frac_T2);
+  } else {
+    /* id > 0 branch (:670): partial sum * nb_proc, cached xT_ech (:685,:702) */
+    oracle_temp_lte(m, W->E_abs[icell - 1] * W->qscale, m->volume[icell - 1],
+                    W->xT_ech[icell - 1], &Ti, &Temp, &frac_T2);
+    W->xT_ech[icell - 1] = Ti;
+  }
+  int T2 = Ti, T1 = Ti - 1;
+  double frac_T1 = 1.0 - frac_T2;
+  int l1 = 0, l2 = m->n_lambda, l = (l1 + l2) / 2;
+  const double *cdf1 = m->kdB_dT_CDF + (size_t)m->n_lambda * (T1 - 1);
+  const double *cdf2 = m->kdB_dT_CDF + (size_t)m->n_lambda * (T2 - 1);
+  while ((l2 - l1) > 1) {
+    double proba = frac_T1 * cdf1[l - 1] + frac_T2 * cdf2[l - 1];
+    if ((double)rand2 > proba) l1 = l; else l2 = l;
+    l = (l1 + l2) / 2;
+  }
+  *lambda = l + 1;
+}
+
+/* emit_packet (dust_transfer.f90:1047-1151) */
+static int emit_packet(worker_t *W, int lambda, int *icell, double *x,
+                       double *y, double *z, double *u, double *v, double *w,
+                       double Stokes[4], int *flag_star, int *flag_ISM,
+                       int *lintersect) {
+  const oracle_model *m = W->m;
+  *lintersect = 1;
+  float rand = rng_float(&W->rng);
+  if ((double)rand <= m->frac_E_stars[lambda - 1]) {
+    *flag_star = 1; *flag_ISM = 0;
+    rand = rng_float(&W->rng);
+    int i_star = select_star(m, lambda, rand);
+    float r1 = rng_float(&W->rng), r2 = rng_float(&W->rng);
+    float r3 = rng_float(&W->rng), r4 = rng_float(&W->rng);
+    emit_packet_uniform_sphere(m, i_star, r1, r2, r3, r4, icell, x, y, z, u, v,
+                               w, lintersect);
+    Stokes[0] = 1.0; Stokes[1] = 0.0; Stokes[2] = 0.0; Stokes[3] = 0.0;
+  } else if ((double)rand <= m->frac_E_disk[lambda - 1]) {
+    *flag_star = 0; *flag_ISM = 0;
+    if (!m->prob_E_cell) return 11;
+    rand = rng_float(&W->rng);
+    *icell = select_cellule(m, lambda, rand);
+    float r1 = rng_float(&W->rng), r2 = rng_float(&W->rng),
+          r3 = rng_float(&W->rng);
+    oracle_pos_em_cell_cyl(m, *icell, r1, r2, r3, x, y, z);
+    random_isotropic_direction(&W->rng, u, v, w);
+    Stokes[0] = 1.0; Stokes[1] = 0.0; Stokes[2] = 0.0; Stokes[3] = 0.0;
+  } else {
+    return 12; /* ISM emission (stars.f90:728) not in scope */
+  }
+  return 0;
+}
+
+/* propagate_packet (dust_transfer.f90:1155-1409), .not.lmono, lonly_LTE,
+ * scattering method 2 */
+static void propagate_packet(worker_t *W, int *lambda, int p_lambda,
+                             int *icell, double *x, double *y, double *z,
+                             double *u, double *v, double *w, double Stokes[4],
+                             int *flag_star, int *flag_ISM, int *flag_scatt,
+                             int *lpacket_alive) {
+  const oracle_model *m = W->m;
+  int flag_sortie = 0;
+  *flag_scatt = 0;
+  for (;;) {
+    float rand = rng_float(&W->rng);                          /* :1208 */
+    double tau;
+    if (W->o->tau_fp32) {
+      float tf;
+      if (rand == 1.0f) tf = 1.0e30f;
+      else if (rand > 1.0e-6f) tf = -logf(1.0f - rand);
+      else tf = rand;
+      tau = (double)tf;
+    } else {
+      if (rand > 1.0e-6f) tau = -log(1.0 - (double)rand);
+      else tau = (double)rand;
+    }
+    physical_length(W, *lambda, Stokes, icell, x, y, z, u, v, w, tau,
+                    &flag_sortie, lpacket_alive);             /* :1243 */
+    if (flag_sortie) return;                                  /* :1251 */
+
+    rand = rng_float(&W->rng);                                /* :1280 */
+    if (rand < m->albedo[*lambda - 1]) {                      /* :1284 */
+      *flag_scatt = 1;
+      W->cnt[ORC_CNT_SCATT]++;
+      rand = rng_float(&W->rng);                              /* :1319 */
+      float rand2 = rng_float(&W->rng);
+      int itheta; double cospsi, u1, v1, w1;
+      if (m->aniso_method == 1) {
+        int pl = m->p_lambda_fixed ? p_lambda : *lambda;
+        oracle_angle_diff_theta_pos(m, pl, rand, rand2, &itheta, &cospsi);
+        if (m->lisotropic) { itheta = 1; cospsi = 2.0 * (double)rand - 1.0; }
+        rand = rng_float(&W->rng);
+        double phi = PI * (2.0 * (double)rand - 1.0);
+        oracle_cdapres(cospsi, phi, *u, *v, *w, &u1, &v1, &w1);
+        if (m->lsepar_pola) {
+          double M[16];
+          get_mueller_matrix_per_cell(m, *lambda, itheta, rand2, M);
+          oracle_update_stokes(Stokes, *u, *v, *w, u1, v1, w1, M);
+        }
+      } else {
+        oracle_hg(m->tab_g_pos[*lambda - 1], rand, m->nang_scatt, &itheta,
+                  &cospsi);
+        if (m->lisotropic) { itheta = 1; cospsi = 2.0 * (double)rand - 1.0; }
+        rand = rng_float(&W->rng);
+        double phi = PI * (2.0 * (double)rand - 1.0);
+        oracle_cdapres(cospsi, phi, *u, *v, *w, &u1, &v1, &w1);
+      }
+      *u = u1; *v = v1; *w = w1;                              /* :1351 */
+    } else {
+      W->cnt[ORC_CNT_ABS]++;
+      *flag_star = 0; *flag_scatt = 0; *flag_ISM = 0;         /* :1367 */
+      rand = rng_float(&W->rng);                              /* :1374 */
+      float rand2 = rng_float(&W->rng);
+      im_reemission_LTE(W, *icell, rand, rand2, lambda);
+      random_isotropic_direction(&W->rng, u, v, w);           /* :1398 */
+      Stokes[1] = 0.0; Stokes[2] = 0.0; Stokes[3] = 0.0;
+    }
+  }
+}
+
+/* capteur, SED branch (output.f90:294-397, 572-592) */
+static void capteur(worker_t *W, int lambda, double uin, double vin,
+                    double win, const double stokin[4], int flag_star,
+                    int flag_scatt) {
+  const oracle_model *m = W->m;
+  double u1 = uin, v1 = vin, w1 = win;
+  double stok[4] = {stokin[0], stokin[1], stokin[2], stokin[3]};
+  if (w1 < 0.0) {
+    if (m->l_sym_centrale) {
+      u1 = -u1; v1 = -v1; w1 = -w1;
+      stok[2] = -stok[2];
+    } else {
+      return;
+    }
+  }
+  int capt = (int)((-1.0 * w1 + 1.0) * (double)m->N_thet) + 1;
+  if (capt == m->N_thet + 1) capt = m->N_thet;
+  int c_phi;
+  if (m->l_sym_axiale) {
+    if (v1 < 0.0) { v1 = -v1; stok[2] = -stok[2]; }
+    if (w1 == 1.0) c_phi = 1;
+    else c_phi = (int)(atan2(v1, u1) / PI * (double)m->N_phi) + 1;
+  } else {
+    if (w1 == 1.0) c_phi = 1;
+    else
+      c_phi = (int)(modulo_d(atan2(u1, v1) + PI / 2, 2 * PI) / (2 * PI) *
+                    (double)m->N_phi) + 1;
+  }
+  if (c_phi == m->N_phi + 1) c_phi = m->N_phi;
+  else if (c_phi == 0) c_phi = 1;
+
+  size_t plane = (size_t)m->n_lambda * m->N_thet * m->N_phi;
+  size_t idx = (size_t)(lambda - 1) +
+               (size_t)m->n_lambda * ((capt - 1) + (size_t)m->N_thet * (c_phi - 1));
+  W->sed[0 * plane + idx] += stok[0];
+  W->sed[1 * plane + idx] += stok[1];
+  W->sed[2 * plane + idx] += stok[2];
+  W->sed[3 * plane + idx] += stok[3];
+  W->sed[4 * plane + idx] += 1.0;
+  if (flag_star) {
+    if (flag_scatt) W->sed[6 * plane + idx] += stok[0];
+    else W->sed[5 * plane + idx] += stok[0];
+  } else {
+    if (flag_scatt) W->sed[8 * plane + idx] += stok[0];
+    else W->sed[7 * plane + idx] += stok[0];
+  }
+  W->cnt[ORC_CNT_ESCAPED]++;
+}
+
+/* one packet of mc_photon_loop's body (dust_transfer.f90:529-552) */
+static int one_packet(worker_t *W, uint64_t packet) {
+  const oracle_model *m = W->m;
+  rng_init(&W->rng, W->o->seed, packet);
+  W->cnt[ORC_CNT_PACKETS]++;
+  int lambda, icell = 0, lintersect, flag_star, flag_ISM, flag_scatt = 0;
+  int alive = 1;
+  double x, y, z, u, v, w, Stokes[4];
+  float rand = rng_float(&W->rng);
+  oracle_select_wl_em(m, rand, &lambda);                      /* :536-537 */
+  W->n_sent[lambda - 1] += 1.0;                               /* :531 */
+  int rc = emit_packet(W, lambda, &icell, &x, &y, &z, &u, &v, &w, Stokes,
+                       &flag_star, &flag_ISM, &lintersect);
+  if (rc) return rc;
+  if (lintersect)
+    propagate_packet(W, &lambda, 1, &icell, &x, &y, &z, &u, &v, &w, Stokes,
+                     &flag_star, &flag_ISM, &flag_scatt, &alive);
+  if (alive && !flag_ISM)
+    capteur(W, lambda, u, v, w, Stokes, flag_star, flag_scatt);
+  return 0;
+}
+
+int oracle_run_thermal(const oracle_model *m, const oracle_opts *o,
+                       const double *E_prior, double *E_abs, double *sed,
+                       double *n_sent, uint64_t *counters) {
+  int nth = o->n_threads > 0 ? o->n_threads : 1;
+  if (o->frozen && !E_prior) return 21;
+  const size_t nc = (size_t)m->n_cells;
+  const size_t nsed =
+      (size_t)ORACLE_N_SED_TYPES * m->n_lambda * m->N_thet * m->N_phi;
+  double *E_t = (double *)calloc(nc * nth, sizeof(double));
+  int *xT_t = (int *)malloc(nc * nth * sizeof(int));
+  double *sed_t = (double *)calloc(nsed * nth, sizeof(double));
+  double *ns_t = (double *)calloc((size_t)m->n_lambda * nth, sizeof(double));
+  worker_t *Ws = (worker_t *)calloc(nth, sizeof(worker_t));
+  if (!E_t || !xT_t || !sed_t || !ns_t || !Ws) return 22;
+  for (size_t q = 0; q < nc * nth; ++q) xT_t[q] = 2; /* thermal_emission.f90:119 */
+  int err = 0;
+  const uint64_t chunk = 1024;
+  const uint64_t nchunks = (o->n_packets + chunk - 1) / chunk;
+#ifdef _OPENMP
+#pragma omp parallel num_threads(nth)
+#endif
+  {
+    int tid = 0;
+#ifdef _OPENMP
+    tid = omp_get_thread_num();
+#endif
+    worker_t *W = &Ws[tid];
+    W->m = m; W->o = o; W->E_prior = E_prior;
+    W->E_abs = E_t + nc * tid;
+    W->xT_ech = xT_t + nc * tid;
+    W->sed = sed_t + nsed * tid;
+    W->n_sent = ns_t + (size_t)m->n_lambda * tid;
+    W->qscale = (double)nth * (o->n_replicas >= 1.0 ? o->n_replicas : 1.0);
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 1)
+#endif
+    for (uint64_t ch = 0; ch < nchunks; ++ch) {
+      uint64_t p0 = ch * chunk;
+      uint64_t p1 = p0 + chunk < o->n_packets ? p0 + chunk : o->n_packets;
+      for (uint64_t p = p0; p < p1; ++p) {
+        int rc = one_packet(W, o->first_packet + p);
+        if (rc) {
+#ifdef _OPENMP
+#pragma omp atomic write
+#endif
+          err = rc;
+        }
+      }
+    }
+  }
+  memset(E_abs, 0, nc * sizeof(double));
+  memset(sed, 0, nsed * sizeof(double));
+  memset(n_sent, 0, (size_t)m->n_lambda * sizeof(double));
+  memset(counters, 0, ORACLE_N_COUNTERS * sizeof(uint64_t));
+  for (int t = 0; t < nth; ++t) {
+    for (size_t q = 0; q < nc; ++q) E_abs[q] += E_t[nc * t + q];
+    for (size_t q = 0; q < nsed; ++q) sed[q] += sed_t[nsed * t + q];
+    for (int q = 0; q < m->n_lambda; ++q)
+      n_sent[q] += ns_t[(size_t)m->n_lambda * t + q];
+    for (int q = 0; q < ORACLE_N_COUNTERS; ++q) counters[q] += Ws[t].cnt[q];
+  }
+  free(E_t); free(xT_t); free(sed_t); free(ns_t); free(Ws);
+  return err;
+}

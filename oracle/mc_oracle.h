@@ -1,0 +1,209 @@
+/*
+ * mc_oracle.h -- CPU ORACLE for the MCFOST continuum Monte Carlo packet loop.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is a plain-C restatement of the reference
+ * algorithm (cpinte/mcfost 4.1.13, Fortran) used as the checker for the HIP
+ * engine.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg may load it.  The product (libmcfost_hip.so) never links or calls it.
+ *
+ * Parity status ("pinning"):
+ *   - geometry (cell mapping, grid definition, cell crossing, point location,
+ *     move-to-grid, emission position), the temperature grid and the
+ *     wavelength grid are PINNED bit-for-bit against the reference's own
+ *     routines compiled from /root/reference/src (see oracle/ref_build/).
+ *   - the sampling / thermal routines that live in reference modules which
+ *     cannot be built in this image (they need SPRNG, generated sha.f90 /
+ *     operating_system.f90) are restated from source and pinned only by
+ *     analytic known-answer tests: PARITY UNPINNED for those.
+ *
+ * All "file:line" citations are into /root/reference/src/.
+ */
+#ifndef MC_ORACLE_H
+#define MC_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORACLE_N_SED_TYPES 9 /* sed, sed_q, sed_u, sed_v, n_phot_sed, sed_star,
+                                sed_star_scat, sed_disk, sed_disk_scat
+                                (output.f90:572-592) */
+#define ORACLE_N_COUNTERS 8
+enum {
+  ORC_CNT_PACKETS = 0,     /* packets launched                              */
+  ORC_CNT_CROSSINGS = 1,   /* cross_cell calls                              */
+  ORC_CNT_FLIGHTS = 2,     /* physical_length calls                         */
+  ORC_CNT_SCATT = 3,       /* scattering events                             */
+  ORC_CNT_ABS = 4,         /* absorb + re-emit events                       */
+  ORC_CNT_ESCAPED = 5,     /* packets binned by capteur                     */
+  ORC_CNT_KILLED_STAR = 6, /* packets that hit a star                       */
+  ORC_CNT_DARK = 7         /* dark-zone mirror events                       */
+};
+
+/* One star (parameters.f90:230-238). Lengths in AU. */
+typedef struct {
+  double x, y, z, r;
+  int icell;     /* cell holding the star centre (stars.f90:789-808) */
+  int out_model; /* star outside the grid -> move_to_grid on emission */
+} oracle_star;
+
+/*
+ * The model: every array the packet loop reads.  Column-major, 1-based cell
+ * ids exactly as the Fortran host holds them.
+ */
+typedef struct {
+  /* ---- cylindrical grid (cylindrical_grid.f90:20-35) ---- */
+  int n_rad, nz, n_az, l3D;
+  int n_cells; /* grid.f90:276-283 */
+  int ntot2;   /* real + virtual cells (cylindrical_grid.f90:73-88) */
+  int jdim_lo; /* jstart2: lowest j index of cell_map */
+  int jdim_n;  /* number of j slots in cell_map (jend2-jstart2+1) */
+  const double *r_lim_2;     /* [0..n_rad] */
+  const double *zmax;        /* [n_rad] */
+  const double *z_lim;       /* (n_rad, nz+2) */
+  const double *tan_phi_lim; /* [n_az] */
+  double zmaxmax, Rmax2;
+  const int *cell_map;   /* (0:n_rad+1, jdim_lo:nz+1, 1:n_az) */
+  const int *cell_map_i; /* [ntot2] */
+  const int *cell_map_j;
+  const int *cell_map_k;
+  const int *lexit_cell; /* [ntot2] */
+  const double *volume;  /* [n_cells] AU^3 */
+
+  /* ---- stars ---- */
+  int n_stars;
+  const oracle_star *stars;
+
+  /* ---- opacities: one cell class (p_n_cells = 1), dust_prop.f90:17-21 ---- */
+  int n_lambda;
+  const double *kappa;         /* [n_lambda] AU^-1 at the reference cell */
+  const double *kappa_abs_LTE; /* [n_lambda] */
+  const float *albedo;         /* tab_albedo_pos [n_lambda] (grains.f90:62) */
+  const double *kappa_factor;  /* [n_cells] */
+  const unsigned char *l_dark_zone; /* [n_cells] or NULL */
+
+  /* ---- scattering (grains.f90:62-64) ---- */
+  int nang_scatt;    /* 180 */
+  int aniso_method;  /* 1 = tabulated phase function, 2 = HG */
+  int lisotropic;    /* dust_transfer.f90:1323-1326 */
+  int lsepar_pola;   /* update Stokes on scattering */
+  int p_lambda_fixed; /* !=0: sample angle CDF at wavelength index 1
+                         (reference behaviour, dust_transfer.f90:491-502) */
+  const float *prob_s11_pos; /* (0:nang, n_lambda) */
+  const float *s12_o_s11;    /* (0:nang, n_lambda) each */
+  const float *s22_o_s11;
+  const float *s33_o_s11;
+  const float *s34_o_s11;
+  const float *s44_o_s11;
+  const float *tab_g_pos; /* [n_lambda] */
+
+  /* ---- thermal tables (thermal_emission.f90:34-60) ---- */
+  int n_T;
+  const float *tab_Temp;     /* [n_T] (Temperature.f90:23) */
+  const double *log_Qcool;   /* log_Qcool_minus_extra_heating [n_T] */
+  const double *kdB_dT_CDF;  /* (n_lambda, n_T) */
+  const double *spectre_emission_cumul; /* [0..n_lambda] */
+  const double *frac_E_stars; /* [n_lambda] */
+  const double *frac_E_disk;  /* [n_lambda] */
+  const double *CDF_E_star;   /* (n_lambda, 0:n_stars) */
+  const double *prob_E_cell;  /* (0:n_cells, n_lambda) or NULL */
+  double L_packet_th;
+  float T_min;
+
+  /* ---- SED binning (output.f90:294-597) ---- */
+  int N_thet, N_phi;
+  int l_sym_centrale, l_sym_axiale;
+} oracle_model;
+
+/* Run options. */
+typedef struct {
+  uint64_t seed;
+  uint64_t first_packet; /* global id of the first packet of this run */
+  uint64_t n_packets;
+  int n_threads;         /* OpenMP threads; per-thread accumulators like the
+                            reference (radiation_field.f90:20-27) */
+  int frozen;            /* 0: live Bjorkman&Wood feedback from the running
+                               accumulator (reference);
+                            1: Temp_LTE reads E_prior (deterministic mode) */
+  int tau_fp32;          /* 1: tau = -log(1-rand) in default real like
+                               dust_transfer.f90:1208-1215; 0: same formula in
+                               FP64 (used for bit-parity with the device) */
+  double n_replicas;     /* in-flight Qheat scale on top of n_threads (number
+                            of GPUs/ranks sharing the job); >=1 */
+} oracle_opts;
+
+/* Cell mapping sizes + builder (cylindrical_grid.f90:45-179). */
+void oracle_cell_mapping_sizes(int n_rad, int nz, int n_az, int l3D,
+                               int *n_cells, int *ntot2, int *jdim_lo,
+                               int *jdim_n);
+int oracle_build_cell_mapping(int n_rad, int nz, int n_az, int l3D,
+                              int *cell_map, int *cell_map_i, int *cell_map_j,
+                              int *cell_map_k, int *lexit_cell);
+
+/* Geometry operators (cylindrical_grid.f90). */
+int oracle_test_exit_grid_cyl(const oracle_model *m, int icell, double x,
+                              double y, double z);
+void oracle_index_cell_cyl(const oracle_model *m, double x, double y, double z,
+                           int *icell);
+void oracle_cross_cylindrical_cell(const oracle_model *m, double x0, double y0,
+                                   double z0, double u, double v, double w,
+                                   int cell, int previous_cell, double *x1,
+                                   double *y1, double *z1, int *next_cell,
+                                   double *l, double *l_contrib,
+                                   double *l_void_before);
+void oracle_move_to_grid_cyl(const oracle_model *m, double *x, double *y,
+                             double *z, double u, double v, double w,
+                             int *icell, int *lintersect);
+void oracle_pos_em_cell_cyl(const oracle_model *m, int icell, float rand1,
+                            float rand2, float rand3, double *x, double *y,
+                            double *z);
+
+/* Direction / sampling helpers. */
+void oracle_cdapres(double cospsi, double phi, double u0, double v0, double w0,
+                    double *u1, double *v1, double *w1);
+void oracle_rotation(double xinit, double yinit, double zinit, double u1,
+                     double v1, double w1, double *xfin, double *yfin,
+                     double *zfin);
+void oracle_hg(float g, float rand, int nang_scatt, int *itheta,
+               double *cospsi);
+void oracle_angle_diff_theta_pos(const oracle_model *m, int p_lambda,
+                                 float rand, float rand2, int *itheta,
+                                 double *cospsi);
+void oracle_update_stokes(double S[4], double u0, double v0, double w0,
+                          double u1, double v1, double w1, const double M[16]);
+void oracle_select_wl_em(const oracle_model *m, float rand, int *lambda);
+void oracle_intersect_stars(const oracle_model *m, double x, double y,
+                            double z, double u, double v, double w,
+                            int *lintersect, int *i_star, int *icell_star);
+
+/* Temperature from absorbed energy (Temp_LTE id=0, thermal_emission.f90:649). */
+void oracle_temp_lte(const oracle_model *m, double E_abs_cell, double volume,
+                     int Ti_start, int *Ti, float *Temp, double *frac);
+void oracle_temp_finale(const oracle_model *m, const double *E_abs,
+                        float *Tdust);
+
+/* Philox4x32-10 block: ctr[4], key[2] -> out[4]. */
+void oracle_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2],
+                          uint32_t out[4]);
+/* The n-th uniform float of a packet's stream. */
+float oracle_packet_rand(uint64_t seed, uint64_t packet, uint32_t n);
+
+/*
+ * The thermal Monte Carlo loop (mc_photon_loop with letape_th,
+ * dust_transfer.f90:439-572).  Outputs are summed over threads:
+ *   E_abs[n_cells]                     (xKJ_abs)
+ *   sed[9][N_phi][N_thet][n_lambda]    (flat: lambda fastest)
+ *   n_sent[n_lambda]                   (n_phot_envoyes)
+ *   counters[ORACLE_N_COUNTERS]
+ * Returns 0 on success.
+ */
+int oracle_run_thermal(const oracle_model *m, const oracle_opts *o,
+                       const double *E_prior, double *E_abs, double *sed,
+                       double *n_sent, uint64_t *counters);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
