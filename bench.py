@@ -1,0 +1,153 @@
+#!/usr/bin/env python3
+"""bench.py -- photon packets/s of the thermal Monte Carlo packet loop on the
+BASELINE workload (ref4.1.para 2D cylindrical disk, 1e8 packets per GPU).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of mc_photon_loop (dust_transfer.f90:439-572) for the
+temperature step: `--packets` packets per GPU through the persistent HIP
+kernel with all tables resident in HBM, followed (N > 1) by the single RCCL
+all-reduce of the fused accumulator [E_abs | sed | n_sent].  Weak scaling:
+per-GPU work is fixed.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+BYTES_PER_CROSSING = 28.0    # kappa_factor 8 B + next-cell id 4 B + E_abs RMW 16 B
+BYTES_PER_INTERACTION = 8.0  # E_abs read for Temp_LTE
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def cpu_baseline(model, n_total, target_s=15.0):
+    """The CPU restatement (oracle, kind "port") timed on this box's host cores
+    on a bounded sample of the same workload."""
+    from oracle import Oracle
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    orc = Oracle(model, n_total)
+    t = time.perf_counter()
+    orc.run_thermal(20000 * cores, seed=99, n_threads=cores)
+    rate = 20000 * cores / (time.perf_counter() - t)
+    n = int(max(20000 * cores, min(rate * target_s, 5e7)))
+    t = time.perf_counter()
+    res = orc.run_thermal(n, seed=100, n_threads=cores)
+    dt = time.perf_counter() - t
+    return dict(value=n / dt, unit="packets/s", cores=cores, kind="port",
+                sample="%d packets of the same ref4.1 2D thermal workload, %d OpenMP threads, %.1f s; "
+                       "%.1f crossings/packet" % (n, cores, dt, res["counters"]["crossings"] / n))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--packets", type=float, default=1e8, help="packets per GPU per step")
+    ap.add_argument("--config", default="ref41", choices=["ref41", "ref41_3d", "pascucci"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--grid-blocks", type=int, default=0)
+    ap.add_argument("--block-threads", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from mcfost_amd import distributed as D
+    from mcfost_amd.engine import Engine
+    from mcfost_amd.host import model as M
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    cfg = {"ref41": M.ref41, "ref41_3d": M.ref41_3d, "pascucci": M.pascucci}[args.config]()
+    model = M.build_model(cfg)
+    n_local = int(args.packets)
+    n_total = n_local * world
+    eng = Engine(model, n_total, device=local_rank)
+    first = rank * n_local
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step(i):
+        eng.launch_thermal(n_local, seed=1000 + i, first_packet=first, n_replicas=float(world),
+                           grid_blocks=args.grid_blocks, block_threads=args.block_threads)
+        ms = eng.sync()
+        if world > 1:
+            acc, cnt = eng.device_accumulators()
+            dist.all_reduce(acc)
+            dist.all_reduce(cnt)
+        return ms
+
+    for i in range(args.warmup):
+        step(-1 - i)
+    barrier()
+    t0 = time.perf_counter()
+    kernel_ms = []
+    for i in range(args.steps):
+        kernel_ms.append(step(i))
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    out = eng.fetch()      # after the all-reduce: global sums of the last step
+    cnt = out["counters"]
+    if rank == 0:
+        ms_step = dt / args.steps * 1e3
+        value = n_total * args.steps / dt
+        n_units = cnt["packets"] if world == 1 else cnt["packets"] / world
+        cross_pp = cnt["crossings"] / max(cnt["packets"], 1)
+        inter_pp = (cnt["scatterings"] + cnt["absorptions"]) / max(cnt["packets"], 1)
+        bytes_launch = n_local * (cross_pp * BYTES_PER_CROSSING + inter_pp * BYTES_PER_INTERACTION)
+        k_ms = sum(kernel_ms) / len(kernel_ms)
+        achieved = bytes_launch / (k_ms * 1e-3) / 1e9
+        line = {
+            "metric": "photon packets/sec (whole node), thermal MC packet loop", "value": value,
+            "unit": "packets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%s 2D cylindrical disk %dx%dx%d, %d wavelengths, %.3g packets/GPU/step, "
+                                   "temperature step (live Bjorkman&Wood re-emission), synthetic dust tables, "
+                                   "blackbody star" % (cfg.name, cfg.n_rad, cfg.nz, cfg.n_az, cfg.n_lambda, n_local)
+                       if not cfg.l3D else "%s 3D cylindrical disk %dx%dx%d, %.3g packets/GPU/step"
+                       % (cfg.name, cfg.n_rad, cfg.nz, cfg.n_az, n_local),
+                       "packets_per_gpu": n_local, "parallelism": "packets sharded x%d, tables replicated" % world,
+                       "crossings_per_packet": cross_pp, "interactions_per_packet": inter_pp},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_thermal", "kernel_ms": k_ms,
+                         "algorithmic_bytes_per_launch": bytes_launch},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(model, n_total, args.cpu_seconds)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,206 @@
+/*
+ * mcgpu.h -- C-ABI of the MI355X Monte Carlo packet engine (libmcfost_hip.so).
+ *
+ * Drop-in boundary for ONE path of MCFOST (cpinte/mcfost 4.1.13): the body of
+ *     subroutine mc_photon_loop            src/dust_transfer.f90:439-572
+ * as called by run_thermal_mc              src/dust_transfer.f90:576-650
+ * plus the reduction that follows it,
+ *     subroutine Temp_finale               src/thermal_emission.f90:870-906.
+ *
+ * In the reference every input/output of that loop is a module-level array
+ * owned by the Fortran host (shared list, dust_transfer.f90:486-488).  The
+ * setters below receive exactly those arrays -- column-major, 1-based cell
+ * ids, caller-owned, copied to HBM once -- and mcgpu_run_thermal() replaces
+ * the OpenMP region.  The Fortran side of the shim is
+ * mcfost_amd/fortran/mcgpu_f.f90 (ISO_C_BINDING); INTEGRATION.md shows the
+ * patch to dust_transfer.f90.
+ *
+ * Conventions (following the reference's own FFI precedents,
+ * Voronoi.f90:70-96 `voro_C` and mcfost2phantom.f90:159-162):
+ *   - scalars by value, arrays as plain pointers, `int` return = ierr
+ *     (0 = ok); the library never calls exit();
+ *   - no hidden state besides the context handle;
+ *   - packet counts are 64-bit (config 3 is 1e9 packets; the reference counts
+ *     in real(dp), dust_transfer.f90:462-464);
+ *   - thread-safe for a single caller per context.
+ *
+ * There is NO CPU fallback: every entry point fails with MCGPU_ERR_NO_DEVICE
+ * when no HIP device is usable.
+ */
+#ifndef MCGPU_H
+#define MCGPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mcgpu_ctx mcgpu_ctx;
+
+enum {
+  MCGPU_OK = 0,
+  MCGPU_ERR_NO_DEVICE = 1,   /* no usable HIP device                         */
+  MCGPU_ERR_HIP = 2,         /* a HIP runtime call failed (see last_error)   */
+  MCGPU_ERR_ARG = 3,         /* bad argument                                 */
+  MCGPU_ERR_UNSUPPORTED = 4, /* valid MCFOST input this engine does not take */
+  MCGPU_ERR_STATE = 5,       /* a required mcgpu_set_* call is missing       */
+  MCGPU_ERR_KERNEL = 6       /* the kernel flagged an internal error         */
+};
+
+#define MCGPU_N_SED_TYPES 9 /* sed, sed_q, sed_u, sed_v, n_phot_sed, sed_star,
+                               sed_star_scat, sed_disk, sed_disk_scat
+                               (output.f90:572-592, allocate_sed :103)       */
+#define MCGPU_N_COUNTERS 8
+enum {
+  MCGPU_CNT_PACKETS = 0,   /* packets launched (sum of n_phot_envoyes)       */
+  MCGPU_CNT_CROSSINGS = 1, /* cross_cell evaluations                         */
+  MCGPU_CNT_FLIGHTS = 2,   /* physical_length calls                          */
+  MCGPU_CNT_SCATT = 3,
+  MCGPU_CNT_ABS = 4,
+  MCGPU_CNT_ESCAPED = 5,
+  MCGPU_CNT_KILLED_STAR = 6,
+  MCGPU_CNT_DARK = 7
+};
+
+/* Device context on HIP device `device` (one per process/rank). */
+int mcgpu_create(int device, mcgpu_ctx **ctx);
+int mcgpu_destroy(mcgpu_ctx *ctx);
+const char *mcgpu_last_error(const mcgpu_ctx *ctx);
+
+/*
+ * Cylindrical grid: module cylindrical_grid (cylindrical_grid.f90:20-35).
+ *   r_lim_2[0:n_rad], zmax[n_rad], z_lim(n_rad,nz+2), tan_phi_lim[n_az],
+ *   volume[n_cells], cell_map(0:n_rad+1, jstart2:nz+1, n_az),
+ *   cell_map_i/j/k[ntot2], lexit_cell[ntot2]  -- as built by
+ *   build_cylindrical_cell_mapping (:45) and define_cylindrical_grid (:183).
+ * zmaxmax is private in the reference module (:20): pass maxval(zmax).
+ * The engine keeps (ri,zj,phik) in registers and evaluates the mapping in
+ * closed form; the arrays are used to VERIFY that closed form (returns
+ * MCGPU_ERR_UNSUPPORTED for a mapping or a non-uniform z grid it cannot
+ * reproduce, e.g. lidefix grids :467-477).
+ */
+int mcgpu_set_grid_cyl(mcgpu_ctx *ctx, int n_rad, int nz, int n_az, int l3D,
+                       const double *r_lim_2, const double *zmax,
+                       const double *z_lim, const double *tan_phi_lim,
+                       double zmaxmax, double Rmax2, const double *volume,
+                       const int *cell_map, const int *cell_map_i,
+                       const int *cell_map_j, const int *cell_map_k,
+                       const int *lexit_cell);
+
+/* Stars: type star_type (parameters.f90:230-242); icell/out_model from
+ * stars_cell_indices (stars.f90:789-808). Lengths in AU. */
+int mcgpu_set_stars(mcgpu_ctx *ctx, int n_stars, const double *x,
+                    const double *y, const double *z, const double *r,
+                    const int *icell, const int *out_model);
+
+/* Opacities for one cell class (lvariable_dust = .false., p_n_cells = 1):
+ * kappa(1,:), kappa_abs_LTE(1,:) (dust_prop.f90:17-19), tab_albedo_pos(1,:)
+ * (grains.f90:62), kappa_factor(n_cells) (dust_prop.f90:17),
+ * l_dark_zone(n_cells) as bytes or NULL (cylindrical_grid.f90:38). */
+int mcgpu_set_opacity(mcgpu_ctx *ctx, int n_lambda, const double *kappa,
+                      const double *kappa_abs_LTE, const float *tab_albedo_pos,
+                      const double *kappa_factor,
+                      const unsigned char *l_dark_zone);
+
+/* Scattering tables of scattering method 2 (per cell class), grains.f90:62-64:
+ * prob_s11_pos(0:nang,1,n_lambda), tab_sXX_o_s11_pos(0:nang,1,n_lambda),
+ * tab_g_pos(1,n_lambda).  aniso_method 1 = tabulated, 2 = HG.
+ * p_lambda_fixed != 0 reproduces the reference: during the thermal step the
+ * angle CDF is sampled at wavelength index 1 (dust_transfer.f90:491-502). */
+int mcgpu_set_scattering(mcgpu_ctx *ctx, int nang_scatt, int aniso_method,
+                         int lisotropic, int lsepar_pola, int p_lambda_fixed,
+                         const float *prob_s11_pos, const float *s12_o_s11,
+                         const float *s22_o_s11, const float *s33_o_s11,
+                         const float *s34_o_s11, const float *s44_o_s11,
+                         const float *tab_g_pos);
+
+/* Thermal tables (thermal_emission.f90:34-60; several are `private` there, so
+ * the Fortran shim lives next to that module):
+ *   tab_Temp[n_T] (Temperature.f90:11), log_Qcool_minus_extra_heating(n_T,1),
+ *   kdB_dT_CDF(n_lambda,n_T,1), spectre_emission_cumul(0:n_lambda),
+ *   frac_E_stars[n_lambda], frac_E_disk[n_lambda],
+ *   CDF_E_star(n_lambda,0:n_stars) (stars.f90:575-604),
+ *   prob_E_cell(0:n_cells,n_lambda) or NULL when frac_E_stars == 1,
+ *   L_packet_th (:355-356), T_min (parameters.f90:269). */
+int mcgpu_set_thermal(mcgpu_ctx *ctx, int n_T, const float *tab_Temp,
+                      const double *log_Qcool, const double *kdB_dT_CDF,
+                      const double *spectre_emission_cumul,
+                      const double *frac_E_stars, const double *frac_E_disk,
+                      const double *CDF_E_star, const double *prob_E_cell,
+                      double L_packet_th, float T_min);
+
+/* SED bins used by capteur (output.f90:294): N_thet, N_phi and the symmetry
+ * flags (parameters.f90:103-107). */
+int mcgpu_set_sed_bins(mcgpu_ctx *ctx, int N_thet, int N_phi,
+                       int l_sym_centrale, int l_sym_axiale);
+
+typedef struct {
+  uint64_t seed;         /* Philox key (reference: SPRNG seed 269753)        */
+  uint64_t first_packet; /* global id of this call's first packet: ranks use
+                            disjoint ranges                                  */
+  uint64_t n_packets;
+  double n_replicas;     /* ranks sharing the job: the in-flight temperature
+                            uses local E_abs * n_replicas, the analogue of
+                            `* nb_proc` in thermal_emission.f90:670          */
+  int frozen;            /* 0 = live Bjorkman & Wood feedback (reference);
+                            1 = Temp_LTE reads the prior set by
+                                mcgpu_set_E_prior (reproducible mode)        */
+  int accumulate;        /* 0 = zero the accumulators first (what
+                            reset_radiation_field does, dust_transfer.f90:594)
+                            1 = keep accumulating                            */
+  int grid_blocks;       /* 0 = auto                                         */
+  int block_threads;     /* 0 = auto                                         */
+} mcgpu_run_opts;
+
+/* Prior absorbed-energy grid for frozen mode (host array, n_cells). */
+int mcgpu_set_E_prior(mcgpu_ctx *ctx, const double *E_prior);
+
+/*
+ * mc_photon_loop, thermal step (letape_th = .true., lmono = .false.).
+ * Synchronous convenience form for the Fortran host.  Outputs (host, caller
+ * owned, overwritten with this context's totals):
+ *   E_abs[n_cells]                          -> xKJ_abs(:,1)
+ *   sed[9][N_phi][N_thet][n_lambda]         -> sed, sed_q, ... (:,:,:,1)
+ *   n_sent[n_lambda]                        -> n_phot_envoyes(:,1)
+ *   counters[MCGPU_N_COUNTERS], kernel_ms   (any may be NULL)
+ */
+int mcgpu_run_thermal(mcgpu_ctx *ctx, const mcgpu_run_opts *opts,
+                      double *E_abs, double *sed, double *n_sent,
+                      uint64_t *counters, double *kernel_ms);
+
+/* Asynchronous pieces of the same call, for hosts that keep the accumulators
+ * on the device between the launch and the RCCL all-reduce. */
+int mcgpu_launch_thermal(mcgpu_ctx *ctx, const mcgpu_run_opts *opts);
+int mcgpu_sync(mcgpu_ctx *ctx, double *kernel_ms);
+/* Device pointers of the fused accumulator [E_abs | sed | n_sent] (doubles)
+ * and of the counters (uint64[MCGPU_N_COUNTERS]). */
+int mcgpu_device_accumulators(mcgpu_ctx *ctx, void **accum_dev,
+                              uint64_t *n_doubles, void **counters_dev);
+int mcgpu_fetch(mcgpu_ctx *ctx, double *E_abs, double *sed, double *n_sent,
+                uint64_t *counters);
+/* Use an external stream (e.g. torch's current stream); NULL = own stream. */
+int mcgpu_set_stream(mcgpu_ctx *ctx, void *hip_stream);
+
+/* Temp_finale (thermal_emission.f90:870-906): Tdust(icell) from the summed
+ * absorbed-energy grid.  E_abs == NULL uses the device accumulator. */
+int mcgpu_temp_finale(mcgpu_ctx *ctx, const double *E_abs, float *Tdust);
+
+/* Unit probes used by the parity tests (device evaluation of the operators
+ * the kernel uses; n items each). */
+int mcgpu_probe_cross_cell(mcgpu_ctx *ctx, int n, const double *x0,
+                           const double *y0, const double *z0, const double *u,
+                           const double *v, const double *w, const int *cell,
+                           double *x1, double *y1, double *z1, int *next_cell,
+                           double *l);
+int mcgpu_probe_index_cell(mcgpu_ctx *ctx, int n, const double *x,
+                           const double *y, const double *z, int *icell);
+int mcgpu_probe_philox(mcgpu_ctx *ctx, const uint32_t ctr[4],
+                       const uint32_t key[2], uint32_t out[4]);
+int mcgpu_probe_packet_rand(mcgpu_ctx *ctx, uint64_t seed, uint64_t packet,
+                            int n, float *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,1125 @@
+// mc_device.hip.h -- device side of the MI355X Monte Carlo packet engine.
+//
+// One photon packet per lane, persistent wavefronts.  This is a from-scratch
+// CDNA4 design of the path the reference runs as an OpenMP loop
+// (dust_transfer.f90:439-572); it is NOT a translation of the Fortran:
+//   * the packet is a register-resident state machine (EMIT -> NEWFLIGHT ->
+//     FLIGHT -> INTERACT -> ...); a lane whose packet leaves the grid pulls the
+//     next packet id from a wave-aggregated global counter;
+//   * the cell is carried as (ri, zj, phik) integers; the reference's
+//     cell_map / cell_map_i/j/k gathers are replaced by closed forms;
+//   * z_lim is evaluated from one per-radius cell height held in LDS;
+//   * all wavelength tables (opacities, emission CDFs, Lucy/B&W tables) are
+//     staged in LDS once per workgroup; kappa_factor and the absorbed-energy
+//     grid stay in HBM/L2, deposits are native FP64 atomics;
+//   * random numbers are counter-based (Philox4x32-10) in registers, keyed by
+//     (seed, packet id): results do not depend on which lane runs a packet.
+// The arithmetic of every operator follows the reference expression by
+// expression (file:line cited at each routine) so that it can be checked
+// against the CPU oracle.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mcgpu {
+
+constexpr double PI = 3.141592653589793238462643383279502884197;
+constexpr double GRID_PREC = 1.0e-14;              // cylindrical_grid.f90:16
+constexpr double TINY_REAL = 1.17549435082228750797e-38;  // tiny(0.0)
+constexpr double HUGE_REAL = 3.40282346638528859812e+38;  // huge(1.0)
+constexpr double HUGE_DP = 1.79769313486231570815e+308;
+constexpr double TINY_DP = 2.22507385850720138309e-308;
+
+struct DevModel {
+  // grid
+  int n_rad, nz, n_az, l3D, n_cells;
+  const double* r_lim_2;   // [n_rad+1]
+  const double* zmax;      // [n_rad]
+  const double* ch;        // [n_rad] cell height = z_lim(i,2)
+  const double* tan_phi_lim;  // [n_az]
+  double zmaxmax, Rmax2;
+  const double* volume;    // [n_cells]
+  // stars: x,y,z,r and (ri,zj,k,out_model)
+  int n_stars;
+  const double* star_xyzr;  // [4*n_stars]
+  const int* star_cell;     // [4*n_stars]
+  // opacity
+  int n_lambda;
+  const double* kappa;
+  const double* kappa_abs;
+  const float* albedo;
+  const double* kappa_factor;  // [n_cells]
+  const unsigned char* dark;   // [n_cells] or null
+  // scattering
+  int nang, aniso_method, lisotropic, p_lambda_fixed;
+  const float* prob_s11;  // (0:nang, n_lambda)
+  const float* s12;
+  const float* s22;
+  const float* s33;
+  const float* s34;
+  const float* s44;
+  const float* tab_g;
+  // thermal
+  int n_T;
+  const double* log_Qcool;  // [n_T]
+  const double* cdf;        // (n_lambda, n_T)
+  const double* spec_cum;   // [n_lambda+1]
+  const double* frac_E_stars;
+  const double* frac_E_disk;
+  const double* CDF_E_star;   // (n_lambda, 0:n_stars)
+  const double* prob_E_cell;  // (0:n_cells, n_lambda) or null
+  double L_packet_th;
+  // sed
+  int N_thet, N_phi, sym_c, sym_a;
+};
+
+struct RunArgs {
+  uint64_t seed, first_packet, n_packets;
+  double qscale;            // n_replicas
+  int frozen;
+  const double* E_prior;    // [n_cells] (frozen mode)
+  double* E_abs;            // [n_cells]
+  double* sed;              // [9 * n_lambda*N_thet*N_phi]
+  double* n_sent;           // [n_lambda]
+  unsigned long long* counters;  // [8]
+  unsigned long long* next_packet;  // work counter
+  int* err;
+};
+
+// ---------------------------------------------------------------------------
+// Philox4x32-10
+// ---------------------------------------------------------------------------
+__host__ __device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+struct Rng {
+  uint32_t k0, k1;   // seed
+  uint32_t blk;      // block index in the packet's stream
+  uint32_t p_lo, p_hi;
+  uint32_t b0, b1, b2, b3;
+  int have;
+  __device__ inline void init(uint64_t seed, uint64_t packet) {
+    k0 = (uint32_t)seed; k1 = (uint32_t)(seed >> 32);
+    blk = 0; p_lo = (uint32_t)packet; p_hi = (uint32_t)(packet >> 32);
+    have = 0;
+  }
+  // uniform default-real in [0,1), 24 bits
+  __device__ inline float next() {
+    if (have == 0) {
+      uint32_t o[4];
+      philox4x32_10(blk, 0u, p_lo, p_hi, k0, k1, o);
+      b0 = o[0]; b1 = o[1]; b2 = o[2]; b3 = o[3];
+      blk += 1; have = 4;
+    }
+    uint32_t u = (have == 4) ? b0 : (have == 3) ? b1 : (have == 2) ? b2 : b3;
+    have -= 1;
+    return (float)(u >> 8) * (1.0f / 16777216.0f);
+  }
+};
+
+// ---------------------------------------------------------------------------
+// LDS-resident tables
+// ---------------------------------------------------------------------------
+struct Lds {
+  double* r_lim_2;  // n_rad+1
+  double* zmax;     // n_rad
+  double* ch;       // n_rad
+  double* tan_phi;  // n_az
+  double* kappa;    // n_lambda
+  double* kabs;     // n_lambda
+  double* lq;       // n_T
+  double* cum;      // n_lambda+1
+  double* fstar;    // n_lambda
+  double* cdf;      // n_lambda*n_T
+  float* albedo;    // n_lambda
+  float* prob;      // (nang+1) * (p_lambda_fixed ? 1 : n_lambda)
+  float* g;         // n_lambda
+};
+
+__host__ __device__ inline size_t lds_doubles(const DevModel& M) {
+  return (size_t)(M.n_rad + 1) + M.n_rad + M.n_rad + M.n_az + M.n_lambda + M.n_lambda + M.n_T +
+         (M.n_lambda + 1) + M.n_lambda + (size_t)M.n_lambda * M.n_T;
+}
+__host__ __device__ inline size_t lds_floats(const DevModel& M) {
+  return (size_t)M.n_lambda + (size_t)(M.nang + 1) * (M.p_lambda_fixed ? 1 : M.n_lambda) + M.n_lambda;
+}
+__host__ __device__ inline size_t lds_bytes(const DevModel& M) {
+  return lds_doubles(M) * sizeof(double) + lds_floats(M) * sizeof(float);
+}
+
+__device__ inline Lds lds_carve(double* base, const DevModel& M) {
+  Lds T;
+  double* p = base;
+  T.r_lim_2 = p; p += M.n_rad + 1;
+  T.zmax = p; p += M.n_rad;
+  T.ch = p; p += M.n_rad;
+  T.tan_phi = p; p += M.n_az;
+  T.kappa = p; p += M.n_lambda;
+  T.kabs = p; p += M.n_lambda;
+  T.lq = p; p += M.n_T;
+  T.cum = p; p += M.n_lambda + 1;
+  T.fstar = p; p += M.n_lambda;
+  T.cdf = p; p += (size_t)M.n_lambda * M.n_T;
+  float* f = reinterpret_cast<float*>(p);
+  T.albedo = f; f += M.n_lambda;
+  T.prob = f; f += (size_t)(M.nang + 1) * (M.p_lambda_fixed ? 1 : M.n_lambda);
+  T.g = f;
+  return T;
+}
+
+template <typename Tp>
+__device__ inline void stage(Tp* dst, const Tp* src, size_t n) {
+  for (size_t i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+}
+
+__device__ inline void lds_stage(const Lds& T, const DevModel& M) {
+  stage(T.r_lim_2, M.r_lim_2, (size_t)M.n_rad + 1);
+  stage(T.zmax, M.zmax, (size_t)M.n_rad);
+  stage(T.ch, M.ch, (size_t)M.n_rad);
+  stage(T.tan_phi, M.tan_phi_lim, (size_t)M.n_az);
+  stage(T.kappa, M.kappa, (size_t)M.n_lambda);
+  stage(T.kabs, M.kappa_abs, (size_t)M.n_lambda);
+  stage(T.lq, M.log_Qcool, (size_t)M.n_T);
+  stage(T.cum, M.spec_cum, (size_t)M.n_lambda + 1);
+  stage(T.fstar, M.frac_E_stars, (size_t)M.n_lambda);
+  stage(T.cdf, M.cdf, (size_t)M.n_lambda * M.n_T);
+  stage(T.albedo, M.albedo, (size_t)M.n_lambda);
+  stage(T.prob, M.prob_s11, (size_t)(M.nang + 1) * (M.p_lambda_fixed ? 1 : M.n_lambda));
+  stage(T.g, M.tab_g, (size_t)M.n_lambda);
+}
+
+// ---------------------------------------------------------------------------
+// Cell identity
+// ---------------------------------------------------------------------------
+// z_lim(ri,j) of the reference (cylindrical_grid.f90:459-465,493): uniform in z
+__device__ inline double z_lim_of(const Lds& T, int nz, int ri, int j) {
+  if (j <= nz) return ((double)j - 1.0) * T.ch[ri - 1];
+  if (j == nz + 1) return T.zmax[ri - 1];
+  return 1.00000001504746621988e+30;  // real 1.0e30
+}
+
+template <bool L3D>
+__device__ inline bool is_real_cell(int n_rad, int nz, int ri, int zj) {
+  int az = L3D ? (zj < 0 ? -zj : zj) : zj;
+  return (ri >= 1) & (ri <= n_rad) & (az >= 1) & (az <= nz);
+}
+
+// 0-based index of a real cell, the closed form of cell_map
+// (cylindrical_grid.f90:90-107: k outermost, then j skipping 0, then i)
+template <bool L3D>
+__device__ inline int cell_index(int n_rad, int nz, int ri, int zj, int k) {
+  if (L3D) {
+    int jj = zj < 0 ? zj + nz : zj + nz - 1;
+    return (ri - 1) + n_rad * (jj + 2 * nz * (k - 1));
+  }
+  return (ri - 1) + n_rad * (zj - 1);
+}
+
+// the icell the reference would return for (ri,zj,k), real or virtual:
+// closed form of build_cylindrical_cell_mapping (cylindrical_grid.f90:45-179)
+__host__ __device__ inline int icell_of(int n_rad, int nz, int n_az, int l3D, int i, int j, int k) {
+  const int n_cells = l3D ? 2 * n_rad * nz * n_az : n_rad * nz;
+  const int jlo = l3D ? -nz - 1 : 0, jhi = nz + 1;
+  const int aj = j < 0 ? -j : j;
+  if (i >= 1 && i <= n_rad && aj >= 1 && aj <= nz && (l3D || j > 0)) {
+    if (l3D) {
+      int jj = j < 0 ? j + nz : j + nz - 1;
+      return 1 + (i - 1) + n_rad * (jj + 2 * nz * (k - 1));
+    }
+    return 1 + (i - 1) + n_rad * (j - 1);
+  }
+  if (j == jlo || j == jhi) {  // first virtual group (:123-141)
+    int jrow = (j == jlo) ? 0 : 1;
+    return n_cells + 1 + i + (n_rad + 2) * (jrow + 2 * (k - 1));
+  }
+  // second virtual group (:143-167): i = 0 or n_rad+1, j real
+  const int base = n_cells + (n_rad + 2) * 2 * n_az;
+  const int nj = l3D ? 2 * nz : nz;
+  int jj = l3D ? (j < 0 ? j + nz : j + nz - 1) : j - 1;
+  int ii = (i == 0) ? 0 : 1;
+  return base + 1 + ii + 2 * (jj + nj * (k - 1));
+}
+
+// zj from |z| through default real (cylindrical_grid.f90:868,1116)
+__device__ inline int zj_from_z_real(const Lds& T, int nz, double absz, int ri) {
+  float q = (float)(absz / T.zmax[ri - 1] * (double)nz);
+  const float mi = 2147483648.0f * (1.0f - 1.0e-5f);  // max_int (constants.f90:159)
+  if (!(q < mi)) q = mi;
+  return (int)floorf(q) + 1;
+}
+
+__device__ inline double modulo_d(double a, double p) { return a - floor(a / p) * p; }
+
+// index_cell_cyl (cylindrical_grid.f90:833-890) -> (ri,zj,k)
+template <bool L3D>
+__device__ inline void index_cell(const Lds& T, const DevModel& M, double x, double y, double z,
+                                  int& ri_out, int& zj_out, int& k_out) {
+  double r2 = x * x + y * y;
+  if (r2 < T.r_lim_2[0]) {
+    ri_out = 0; zj_out = 1; k_out = 1;
+  } else if (r2 > M.Rmax2) {
+    ri_out = M.n_rad + 1; zj_out = 1; k_out = 1;
+  } else {
+    int ri_min = 0, ri_max = M.n_rad;
+    int ri = (ri_min + ri_max) / 2;
+    while ((ri_max - ri_min) > 1) {
+      if (r2 > T.r_lim_2[ri]) ri_min = ri; else ri_max = ri;
+      ri = (ri_min + ri_max) / 2;
+    }
+    ri_out = ri + 1;
+    int zj = zj_from_z_real(T, M.nz, fabs(z), ri_out);
+    if (zj > M.nz) zj = M.nz + 1;
+    k_out = 1;
+    if (L3D) {
+      if (z < 0.0) zj = -zj;
+      if (z != 0.0) {
+        double phi = modulo_d(atan2(y, x), 2 * PI);
+        int pk = (int)floor(phi / (2 * PI) * (double)(float)M.n_az) + 1;
+        if (pk == M.n_az + 1) pk = M.n_az;
+        k_out = pk;
+      }
+    }
+    zj_out = zj;
+  }
+}
+
+// cross_cylindrical_cell (cylindrical_grid.f90:918-1175) on (ri,zj,k).
+// inv_a / inv_w (:941-952) are per-flight constants computed by the caller.
+template <bool L3D>
+__device__ inline void cross_cell(const Lds& T, const DevModel& M, double x0, double y0, double z0,
+                                  double u, double v, double w, double inv_a, double inv_w, int ri0,
+                                  int zj0, int k0, double& x1, double& y1, double& z1, int& ri1,
+                                  int& zj1, int& k1, double& l) {
+  const int nz = M.nz, n_rad = M.n_rad, n_az = M.n_az;
+  const double correct_moins = 1.0 - GRID_PREC;
+  const double correct_plus = 1.0 + GRID_PREC;
+  double b, c, s, rac, t, t_phi, delta, r_2, zl, dotprod;
+  int delta_rad = 0, delta_zj = 0, delta_phi = 0;
+
+  r_2 = x0 * x0 + y0 * y0;
+  b = (x0 * u + y0 * v) * inv_a;
+  if (ri0 == 0) {
+    c = (r_2 - T.r_lim_2[0]) * inv_a;
+    delta = b * b - c;
+    rac = sqrt(delta);
+    s = (-b + rac) * correct_plus;
+    t = HUGE_REAL;
+    t_phi = HUGE_REAL;
+    delta_rad = 1;
+  } else {
+    dotprod = u * x0 + v * y0;
+    if (dotprod < 0.0) {
+      c = (r_2 - T.r_lim_2[ri0 - 1] * correct_moins) * inv_a;
+      delta = b * b - c;
+      if (delta < 0.0) {
+        c = (r_2 - T.r_lim_2[ri0] * correct_plus) * inv_a;
+        delta = fmax(b * b - c, 0.0);
+        delta_rad = 1;
+      } else {
+        delta_rad = -1;
+      }
+    } else {
+      c = (r_2 - T.r_lim_2[ri0] * correct_plus) * inv_a;
+      delta = fmax(b * b - c, 0.0);
+      delta_rad = 1;
+    }
+    rac = sqrt(delta);
+    s = (-b - rac) * correct_plus;
+    if (s < 0.0) s = (-b + rac) * correct_plus;
+    else if (s == 0.0) s = GRID_PREC;
+
+    dotprod = w * z0;
+    if (dotprod == 0.0) {
+      t = 1.0e10;
+    } else {
+      const int azj0 = zj0 < 0 ? -zj0 : zj0;
+      if (dotprod > 0.0) {
+        if (azj0 == nz + 1) {
+          delta_zj = 0;
+          zl = copysign(1.0e10, z0);
+        } else {
+          zl = copysign(z_lim_of(T, nz, ri0, azj0 + 1) * correct_plus, z0);
+          delta_zj = 1;
+          if (L3D && (z0 < 0.0)) delta_zj = -1;
+        }
+      } else {
+        if (L3D) {
+          if (z0 > 0.0) {
+            zl = z_lim_of(T, nz, ri0, azj0) * correct_moins;
+            delta_zj = -1;
+            if (zj0 == 1) delta_zj = -2;
+          } else {
+            zl = -z_lim_of(T, nz, ri0, azj0) * correct_moins;
+            delta_zj = 1;
+            if (zj0 == -1) delta_zj = 2;
+          }
+        } else {
+          if (zj0 == 1) {
+            delta_zj = 1;
+            double zz = z_lim_of(T, nz, ri0, 2) * correct_moins;
+            zl = (z0 > 0.0) ? -zz : zz;
+          } else {
+            double zz = z_lim_of(T, nz, ri0, zj0) * correct_moins;
+            zl = (z0 > 0.0) ? zz : -zz;
+            delta_zj = -1;
+          }
+        }
+      }
+      t = (zl - z0) * inv_w;
+      if (t < 0.0) t = GRID_PREC;
+    }
+
+    if (L3D) {
+      dotprod = x0 * v - y0 * u;
+      const double r1e30 = 1.00000001504746621988e+30;  // real 1.0e30
+      if (fabs(dotprod) < (double)1.0e-10f) {
+        t_phi = r1e30;
+      } else {
+        double tan_angle_lim;
+        if (dotprod > 0.0) {
+          tan_angle_lim = T.tan_phi[k0 - 1];
+          delta_phi = 1;
+        } else {
+          int k0m1 = k0 - 1;
+          if (k0m1 == 0) k0m1 = n_az;
+          tan_angle_lim = T.tan_phi[k0m1 - 1];
+          delta_phi = -1;
+        }
+        if (tan_angle_lim > 1.0e299) {
+          if (fabs(u) > (double)1e-6f) t_phi = -x0 / u;
+          else t_phi = r1e30;
+        } else {
+          double den = v - u * tan_angle_lim;
+          if (fabs(den) > (double)1.0e-6f) t_phi = -(y0 - x0 * tan_angle_lim) / den;
+          else t_phi = r1e30;
+        }
+        if (t_phi < 0.0) t_phi = r1e30;
+      }
+    } else {
+      t_phi = HUGE_REAL;
+    }
+  }
+
+  if ((s < t) && (s < t_phi)) {
+    l = s;
+    x1 = x0 + s * u;
+    y1 = y0 + s * v;
+    z1 = z0 + s * w;
+    ri1 = ri0 + delta_rad;
+    if (ri1 == 0) {
+      zj1 = 1;
+      k1 = 1;
+    } else {
+      if (ri1 > n_rad) {
+        zj1 = zj0;
+      } else {
+        int zj = zj_from_z_real(T, nz, fabs(z1), ri1);
+        if (zj > nz) zj = nz + 1;
+        if (L3D && (z1 < 0.0)) zj = -zj;
+        zj1 = zj;
+      }
+      k1 = k0;
+      if (L3D && (ri0 == 0)) {
+        double phi = modulo_d(atan2(y1, x1), 2 * PI);
+        int kk = (int)floor(phi * (1.0 / (2.0 * PI)) * (double)(float)n_az) + 1;
+        if (kk == n_az + 1) kk = n_az;
+        k1 = kk;
+      }
+    }
+  } else if (t < t_phi) {
+    l = t;
+    x1 = x0 + t * u;
+    y1 = y0 + t * v;
+    z1 = z0 + t * w;
+    ri1 = ri0;
+    zj1 = zj0 + delta_zj;
+    k1 = k0;
+  } else {
+    l = t_phi;
+    double dv = correct_plus * t_phi;
+    x1 = x0 + dv * u;
+    y1 = y0 + dv * v;
+    z1 = z0 + dv * w;
+    ri1 = ri0;
+    int zj = (int)floor(fabs(z1) / T.zmax[ri1 - 1] * (double)nz) + 1;
+    if (zj > nz) zj = nz + 1;
+    if (z1 < 0.0) zj = -zj;
+    zj1 = zj;
+    int kk = k0 + delta_phi;
+    if (kk == 0) kk = n_az;
+    if (kk == n_az + 1) kk = 1;
+    k1 = kk;
+  }
+  if (z1 == 0.0) {
+    if (L3D) z1 = copysign(GRID_PREC, w);
+    else z1 = GRID_PREC;
+  }
+}
+
+// move_to_grid_cyl (cylindrical_grid.f90:1284-1411)
+template <bool L3D>
+__device__ inline bool move_to_grid(const Lds& T, const DevModel& M, double& x, double& y, double& z,
+                                    double u, double v, double w, int& ri, int& zj, int& k) {
+  const double correct_moins = 1.0 - 1.0e-10;
+  double x0 = x, y0 = y, z0 = z, a, inv_a, inv_w, r_2, b, c, delta, s1, s2, t1, t2, delta_vol;
+  a = u * u + v * v;
+  inv_a = (a > TINY_REAL) ? 1.0 / a : HUGE_REAL;
+  inv_w = (fabs(w) > TINY_REAL) ? 1.0 / w : copysign(HUGE_DP, w);
+  r_2 = x0 * x0 + y0 * y0;
+  b = (x0 * u + y0 * v) * inv_a;
+  c = (r_2 - T.r_lim_2[M.n_rad] * correct_moins) * inv_a;
+  delta = b * b - c;
+  if (delta < 0.0) {
+    s1 = HUGE_REAL; s2 = HUGE_REAL;
+  } else {
+    double rac = sqrt(delta);
+    s1 = -b - rac;
+    s2 = -b + rac;
+  }
+  double dotprod = w * z0;
+  if (fabs(dotprod) < TINY_REAL) {
+    t1 = HUGE_REAL; t2 = HUGE_REAL;
+  } else {
+    double zl = M.zmaxmax * correct_moins;
+    double zlim1 = (z0 > 0.0) ? zl : -zl;
+    t1 = (zlim1 - z0) * inv_w;
+    t2 = (-zlim1 - z0) * inv_w;
+  }
+  if (t1 > (double)1e20f) {
+    if (s1 > (double)1e20f) return false;
+  }
+  if (t1 > s1) {
+    if (t1 > s2) {
+      delta_vol = s1;
+      double z1 = z0 + delta_vol * w;
+      if (fabs(z1) > M.zmaxmax) return false;
+    } else {
+      delta_vol = t1;
+    }
+  } else {
+    if (t2 < s1) return false;
+    delta_vol = s1;
+  }
+  x = x0 + delta_vol * u;
+  y = y0 + delta_vol * v;
+  z = z0 + delta_vol * w;
+  index_cell<L3D>(T, M, x, y, z, ri, zj, k);
+  return true;
+}
+
+// pos_em_cell_cyl (cylindrical_grid.f90:1415-1466)
+template <bool L3D>
+__device__ inline void pos_em_cell(const Lds& T, const DevModel& M, int ri, int zj, int k, float rand1,
+                                   float rand2, float rand3, double& x, double& y, double& z) {
+  double r = sqrt(T.r_lim_2[ri - 1] + (double)rand1 * (T.r_lim_2[ri] - T.r_lim_2[ri - 1]));
+  const int nz = M.nz;
+  if (L3D) {
+    int aj = zj > 0 ? zj : -zj;
+    double zz = z_lim_of(T, nz, ri, aj) + (double)rand2 * (z_lim_of(T, nz, ri, aj + 1) - z_lim_of(T, nz, ri, aj));
+    z = zj > 0 ? zz : -zz;
+  } else {
+    double z0 = z_lim_of(T, nz, ri, zj), z1 = z_lim_of(T, nz, ri, zj + 1);
+    if ((double)rand2 > 0.5) z = z0 + (2.0 * ((double)rand2 - 0.5)) * (z1 - z0);
+    else z = -(z0 + (2.0 * (double)rand2) * (z1 - z0));
+  }
+  double phi = 2.0 * PI * ((double)k - 1.0 + (double)rand3) / (double)M.n_az;
+  x = r * cos(phi);
+  y = r * sin(phi);
+}
+
+// cdapres (utils.f90:1636-1690)
+__device__ inline void cdapres(double cospsi, double phi, double u0, double v0, double w0, double& u1,
+                               double& v1, double& w1) {
+  double cpsi = cospsi;
+  double spsi = sqrt(1.0 - cpsi * cpsi);
+  double sphi, cphi;
+  sincos(phi, &sphi, &cphi);
+  double a = spsi * cphi;
+  double b = spsi * sphi;
+  if (fabs(w0) <= (double)0.999999f) {
+    double c = sqrt(1.0 - w0 * w0);
+    double cm1 = 1.0 / c;
+    double aw0 = a * w0;
+    u1 = (aw0 * u0 - b * v0) * cm1 + cpsi * u0;
+    v1 = (aw0 * v0 + b * u0) * cm1 + cpsi * v0;
+    w1 = cpsi * w0 - a * c;
+  } else {
+    u1 = a;
+    v1 = b;
+    w1 = cpsi;
+  }
+}
+
+// rotation (utils.f90:553-601)
+__device__ inline void rotation(double xinit, double yinit, double zinit, double u1, double v1,
+                                double w1, double& xfin, double& yfin, double& zfin) {
+  double cost, sint, sing;
+  if (w1 > 0.999999999) {
+    cost = 1.0; sint = 0.0; sing = 0.0;
+  } else if (fabs(u1) < TINY_REAL) {
+    cost = 0.0; sint = 1.0;
+    sing = sqrt(1.0 - w1 * w1);
+  } else {
+    double theta = atan2(v1, u1);
+    sincos(theta, &sint, &cost);
+    sing = sqrt(1.0 - w1 * w1);
+  }
+  double prod = cost * xinit + sint * yinit;
+  xfin = sing * prod + w1 * zinit;
+  yfin = cost * yinit - sint * xinit;
+  zfin = sing * zinit - w1 * prod;
+}
+
+// update_Stokes (scattering.f90:1187-1298) with get_Mueller_matrix_per_cell
+// (:1328-1350) folded in: M11 = 1, M12 = M21, M34 = -M43.
+__device__ inline void update_stokes(double S[4], double u0, double v0, double w0, double u1, double v1,
+                                     double w1, double M12, double M22, double M33, double M34,
+                                     double M44) {
+  double v1pi, v1pj, v1pk;
+  rotation(u0, v0, w0, u1, v1, w1, v1pi, v1pj, v1pk);
+  float xnyp = (float)sqrt(v1pk * v1pk + v1pj * v1pj);
+  float costhet;
+  if (xnyp < 1e-10f) costhet = 1.0f;
+  else costhet = (float)(-1.0 * v1pj / (double)xnyp);
+  float theta = acosf(costhet);
+  if ((double)theta >= PI) theta = 0.0f;
+  theta = (float)((double)theta + 0.5 * PI);
+  float omega = 2.0f * theta;
+  if (v1pk < 0.0) omega = -1.0f * omega;
+  float cosw = cosf(omega), sinw = sinf(omega);
+  if (fabsf(cosw) < 1e-06f) cosw = 0.0f;
+  if (fabsf(sinw) < 1e-06f) sinw = 0.0f;
+  const double cw = (double)cosw, sw = (double)sinw;
+  double C0 = S[0], C1 = cw * S[1] - sw * S[2], C2 = sw * S[1] + cw * S[2], C3 = S[3];
+  // D = M*C with M = [[1,M12,0,0],[M12,M22,0,0],[0,0,M33,M34],[0,0,-M34,M44]]
+  double D0 = C0 + M12 * C1;
+  double D1 = M12 * C0 + M22 * C1;
+  double D2 = M33 * C2 + M34 * C3;
+  double D3 = -M34 * C2 + M44 * C3;
+  double S1_0 = S[0];
+  S[0] = D0;
+  S[1] = cw * D1 + sw * D2;
+  S[2] = -sw * D1 + cw * D2;
+  S[3] = D3;
+  if (S[0] > TINY_REAL) {
+    double f = 1.0 * S1_0 / S[0];
+    S[0] *= f; S[1] *= f; S[2] *= f; S[3] *= f;
+  }
+}
+
+// intersect_stars (stars.f90:812-884): returns star index (1-based) or 0
+__device__ inline int intersect_stars(const DevModel& M, double x, double y, double z, double u,
+                                      double v, double w) {
+  double d_to_star = HUGE_DP;
+  int i_star = 0;
+  for (int i = 0; i < M.n_stars; ++i) {
+    double dx = x - M.star_xyzr[4 * i + 0], dy = y - M.star_xyzr[4 * i + 1], dz = z - M.star_xyzr[4 * i + 2];
+    double r = M.star_xyzr[4 * i + 3];
+    double b = dx * u + dy * v + dz * w;
+    double c = dx * dx + dy * dy + dz * dz - r * r;
+    double delta = b * b - c;
+    if (delta >= 0.0) {
+      double rac = sqrt(delta);
+      double s1 = -b - rac;
+      if (s1 < 0) {
+        double s2 = -b + rac;
+        if (s2 > 0) { d_to_star = 0.0; i_star = i + 1; }
+      } else if (s1 < d_to_star) {
+        d_to_star = s1; i_star = i + 1;
+      }
+    }
+  }
+  return i_star;
+}
+
+// Temp_LTE (thermal_emission.f90:649-706) -> (Ti, frac); E_scaled already
+// includes the replica factor.  First Ti >= 2 with lq(Ti) >= log Qheat,
+// equal to the reference's cached linear scan because Qheat only grows.
+__device__ inline void temp_lte(const double* lq, int n_T, double E_scaled, double L_packet_th,
+                                double volume, int& Ti, double& frac) {
+  double Qheat = E_scaled * L_packet_th / volume;
+  frac = 0.0;
+  Ti = 2;
+  if (Qheat < TINY_DP) return;
+  double log_Qheat = log(Qheat);
+  if (log_Qheat < lq[0]) return;
+  int lo = 2, hi = n_T;  // 1-based
+  while (lo < hi) {
+    int mid = (lo + hi) >> 1;
+    if (lq[mid - 1] < log_Qheat) lo = mid + 1; else hi = mid;
+  }
+  Ti = lo;
+  frac = (log_Qheat - lq[Ti - 2]) / (lq[Ti - 1] - lq[Ti - 2]);
+}
+
+// native FP64 atomic add (global_atomic_add_f64), no CAS loop
+__device__ inline void atomic_add_f64(double* p, double v) { unsafeAtomicAdd(p, v); }
+
+enum : int { S_EMIT = 0, S_INTERACT = 1, S_NEWFLIGHT = 2, S_FLIGHT = 3, S_DONE = 4 };
+
+// capteur, SED branch (output.f90:294-397,572-592)
+template <bool POLA>
+__device__ inline void capteur(const DevModel& M, double* sed, int lambda, double u1, double v1,
+                               double w1, const double S[4], bool flag_star, bool flag_scatt) {
+  double s2 = POLA ? S[2] : 0.0;
+  if (w1 < 0.0) {
+    if (!M.sym_c) return;
+    u1 = -u1; v1 = -v1; w1 = -w1;
+    s2 = -s2;
+  }
+  int capt = (int)((-1.0 * w1 + 1.0) * (double)M.N_thet) + 1;
+  if (capt == M.N_thet + 1) capt = M.N_thet;
+  int c_phi = 1;
+  if (M.sym_a) {
+    if (v1 < 0.0) { v1 = -v1; s2 = -s2; }
+    if (M.N_phi > 1 && w1 != 1.0) c_phi = (int)(atan2(v1, u1) / PI * (double)M.N_phi) + 1;
+  } else {
+    if (M.N_phi > 1 && w1 != 1.0)
+      c_phi = (int)(modulo_d(atan2(u1, v1) + PI / 2, 2 * PI) / (2 * PI) * (double)M.N_phi) + 1;
+  }
+  if (c_phi == M.N_phi + 1) c_phi = M.N_phi;
+  else if (c_phi == 0) c_phi = 1;
+  const size_t plane = (size_t)M.n_lambda * M.N_thet * M.N_phi;
+  const size_t idx = (size_t)(lambda - 1) + (size_t)M.n_lambda * ((capt - 1) + (size_t)M.N_thet * (c_phi - 1));
+  const double I = POLA ? S[0] : 1.0;
+  atomic_add_f64(&sed[0 * plane + idx], I);
+  if (POLA) {
+    atomic_add_f64(&sed[1 * plane + idx], S[1]);
+    atomic_add_f64(&sed[2 * plane + idx], s2);
+    atomic_add_f64(&sed[3 * plane + idx], S[3]);
+  }
+  atomic_add_f64(&sed[4 * plane + idx], 1.0);
+  const int tp = flag_star ? (flag_scatt ? 6 : 5) : (flag_scatt ? 8 : 7);
+  atomic_add_f64(&sed[tp * plane + idx], I);
+}
+
+// ---------------------------------------------------------------------------
+// The thermal packet kernel
+// ---------------------------------------------------------------------------
+template <bool L3D, bool POLA, bool DARK>
+__global__ void __launch_bounds__(256) k_thermal(const DevModel M, const RunArgs A) {
+  extern __shared__ double lds_raw[];
+  const Lds T = lds_carve(lds_raw, M);
+  lds_stage(T, M);
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const int n_rad = M.n_rad, nz = M.nz;
+
+  // packet state
+  int st = S_EMIT;
+  double x = 0, y = 0, z = 0, u = 0, v = 0, w = 1, extr = 0, inv_a = 0, inv_w = 0;
+  double xo = 0, yo = 0, zo = 0;  // entry point of the previous cell (dark-zone mirror)
+  int ri = 0, zj = 1, k = 1, ri_o = 0, zj_o = 1, k_o = 1;
+  int lambda = 1;
+  int star_key = -1;  // packed (ri,zj,k) of the star the flight would hit
+  bool flag_star = false, flag_scatt = false;
+  double S[4] = {1.0, 0.0, 0.0, 0.0};
+  Rng rng;
+  rng.init(0, 0);
+  unsigned int c_cross = 0, c_flight = 0, c_scatt = 0, c_abs = 0, c_esc = 0, c_kill = 0, c_dark = 0,
+               c_pack = 0;
+  unsigned int pk_cross = 0;  // crossings of the current packet (runaway guard)
+
+  for (;;) {
+    // ---- EMIT: pull the next packet id (wave-aggregated) -----------------
+    {
+      const bool need = (st == S_EMIT);
+      const unsigned long long mask = __ballot(need);
+      if (mask) {
+        const int leader = __ffsll((long long)mask) - 1;
+        unsigned long long base = 0;
+        if (lane == leader) base = atomicAdd(A.next_packet, (unsigned long long)__popcll(mask));
+        base = __shfl(base, leader);
+        if (need) {
+          const unsigned long long my = base + __popcll(mask & ((1ull << lane) - 1ull));
+          if (my >= A.n_packets) {
+            st = S_DONE;
+          } else {
+            // mc_photon_loop body (dust_transfer.f90:529-541)
+            rng.init(A.seed, A.first_packet + my);
+            c_pack++;
+            pk_cross = 0;
+            float rand = rng.next();
+            {  // select_wl_em (thermal_emission.f90:364-400)
+              int kmin = 0, kmax = M.n_lambda, kk = (kmin + kmax) / 2;
+              while (T.cum[kk] != (double)rand) {
+                if (T.cum[kk] < (double)rand) kmin = kk; else kmax = kk;
+                kk = (kmin + kmax) / 2;
+                if ((kmax - kmin) <= 1) break;
+              }
+              lambda = kmax;
+            }
+            atomic_add_f64(&A.n_sent[lambda - 1], 1.0);
+            // emit_packet (dust_transfer.f90:1047-1151)
+            bool lintersect = true;
+            rand = rng.next();
+            flag_scatt = false;
+            S[0] = 1.0; S[1] = 0.0; S[2] = 0.0; S[3] = 0.0;
+            if ((double)rand <= T.fstar[lambda - 1]) {
+              flag_star = true;
+              rand = rng.next();
+              int i_star;
+              {  // select_star (stars.f90:75-104)
+                int kmin = 0, kmax = M.n_stars, kk = (kmax - kmin) / 2;
+                while ((kmax - kmin) > 1) {
+                  if (M.CDF_E_star[(lambda - 1) + (size_t)M.n_lambda * kk] < (double)rand) kmin = kk;
+                  else kmax = kk;
+                  kk = (kmin + kmax) / 2;
+                }
+                i_star = kmax;
+              }
+              const float r1 = rng.next(), r2 = rng.next(), r3 = rng.next(), r4 = rng.next();
+              // emit_packet_uniform_sphere (stars.f90:108-169)
+              z = 2.0 * (double)r1 - 1.0;
+              const double srw02 = sqrt(1.0 - z * z);
+              const double argmt = PI * (2.0 * (double)r2 - 1.0);
+              double sa, ca;
+              sincos(argmt, &sa, &ca);
+              x = srw02 * ca;
+              y = srw02 * sa;
+              const double cospsi = sqrt((double)r3);
+              const double phi = 2.0 * PI * (double)r4;
+              cdapres(cospsi, phi, x, y, z, u, v, w);
+              const double* st4 = &M.star_xyzr[4 * (i_star - 1)];
+              const double r_star = st4[3] * (1.0 + 1e-6);
+              x = x * r_star + st4[0];
+              y = y * r_star + st4[1];
+              z = z * r_star + st4[2];
+              index_cell<L3D>(T, M, x, y, z, ri, zj, k);
+              if (M.star_cell[4 * (i_star - 1) + 3])
+                lintersect = move_to_grid<L3D>(T, M, x, y, z, u, v, w, ri, zj, k);
+            } else if ((double)rand <= M.frac_E_disk[lambda - 1] && M.prob_E_cell) {
+              flag_star = false;
+              rand = rng.next();
+              int icell;
+              {  // select_cellule (thermal_emission.f90:2044-2073)
+                const double* p = M.prob_E_cell + (size_t)(M.n_cells + 1) * (lambda - 1);
+                int kmin = 0, kmax = M.n_cells, kk = (kmin + kmax) / 2;
+                while ((kmax - kmin) > 1) {
+                  if (p[kk] < (double)rand) kmin = kk; else kmax = kk;
+                  kk = (kmin + kmax) / 2;
+                }
+                icell = kmax;
+              }
+              // inverse of the closed-form mapping
+              {
+                int q = icell - 1;
+                ri = q % n_rad + 1;
+                q /= n_rad;
+                if (L3D) {
+                  int jj = q % (2 * nz);
+                  k = q / (2 * nz) + 1;
+                  zj = jj < nz ? jj - nz : jj - nz + 1;
+                } else {
+                  zj = q + 1;
+                  k = 1;
+                }
+              }
+              const float r1 = rng.next(), r2 = rng.next(), r3 = rng.next();
+              pos_em_cell<L3D>(T, M, ri, zj, k, r1, r2, r3, x, y, z);
+              // random_isotropic_direction (random_numbers.f90:32-51)
+              rand = rng.next();
+              w = 2.0 * (double)rand - 1.0;
+              const double uv = sqrt(1.0 - w * w);
+              rand = rng.next();
+              const double ph = PI * (2.0 * (double)rand - 1.0);
+              double sp, cp;
+              sincos(ph, &sp, &cp);
+              u = uv * cp;
+              v = uv * sp;
+            } else {
+              *A.err = 12;  // ISM emission / missing prob_E_cell: not in scope
+              st = S_DONE;
+            }
+            if (st != S_DONE) {
+              if (lintersect) {
+                st = S_NEWFLIGHT;
+              } else {  // never entered the grid: binned directly (:549-550)
+                capteur<POLA>(M, A.sed, lambda, u, v, w, S, flag_star, flag_scatt);
+                c_esc++;
+                st = S_EMIT;
+              }
+            }
+          }
+        }
+      }
+    }
+
+    // ---- INTERACT: scatter or absorb + re-emit (dust_transfer.f90:1260-1402)
+    if (st == S_INTERACT) {
+      float rand = rng.next();
+      if (rand < T.albedo[lambda - 1]) {
+        flag_scatt = true;
+        c_scatt++;
+        rand = rng.next();
+        const float rand2 = rng.next();
+        int itheta;
+        double cospsi;
+        if (M.aniso_method == 1) {
+          // angle_diff_theta_pos (scattering.f90:1433-1475)
+          const float* prob = T.prob + (M.p_lambda_fixed ? 0 : (size_t)(M.nang + 1) * (lambda - 1));
+          int kmin = 0, kmax = M.nang, kk = (kmin + kmax) / 2;
+          while ((kmax - kmin) > 1) {
+            if (prob[kk] < rand) kmin = kk; else kmax = kk;
+            kk = (kmin + kmax) / 2;
+          }
+          itheta = kmax;
+          const double c0 = cos(((double)itheta - 1.0) * PI / (double)M.nang);
+          const double c1 = cos(((double)itheta) * PI / (double)M.nang);
+          cospsi = c0 + (double)rand2 * (c1 - c0);
+        } else {
+          // hg (scattering.f90:1354-1383)
+          const float g = T.g[lambda - 1];
+          const double rand_dp = fmin((double)rand, 1.0 - 1e-6);
+          if (fabsf(g) > 1.17549435e-38f) {
+            const double g1 = (double)g, g2 = g1 * g1;
+            const double q = (1.0 - g2) / (1.0 - g1 + 2.0 * g1 * rand_dp);
+            cospsi = (1.0 + g2 - q * q) / (2.0 * g1);
+          } else {
+            cospsi = 2.0 * rand_dp - 1.0;
+          }
+          itheta = (int)floor(acos(cospsi) * 180.0 / PI) + 1;
+          if (itheta > M.nang) itheta = M.nang;
+        }
+        if (M.lisotropic) { itheta = 1; cospsi = 2.0 * (double)rand - 1.0; }
+        rand = rng.next();
+        const double phi = PI * (2.0 * (double)rand - 1.0);
+        double u1, v1, w1;
+        cdapres(cospsi, phi, u, v, w, u1, v1, w1);
+        if (POLA && M.aniso_method == 1) {
+          const size_t o = (size_t)(M.nang + 1) * (lambda - 1) + itheta;
+          const float fr = rand2, fm = 1.0f - rand2;
+          const double M22 = (double)(M.s22[o] * fr + M.s22[o - 1] * fm);
+          const double M12 = (double)(M.s12[o] * fr + M.s12[o - 1] * fm);
+          const double M33 = (double)(M.s33[o] * fr + M.s33[o - 1] * fm);
+          const double M44 = (double)(M.s44[o] * fr + M.s44[o - 1] * fm);
+          const double M34 = (double)(-M.s34[o] * fr - M.s34[o - 1] * fm);
+          update_stokes(S, u, v, w, u1, v1, w1, M12, M22, M33, M34, M44);
+        }
+        u = u1; v = v1; w = w1;
+      } else {
+        c_abs++;
+        flag_star = false;
+        flag_scatt = false;
+        rand = rng.next();
+        const float rand2 = rng.next();
+        // im_reemission_LTE (thermal_emission.f90:710-771)
+        const int ic = cell_index<L3D>(n_rad, nz, ri, zj, k);
+        double E;
+        if (A.frozen) E = A.E_prior[ic];
+        else E = __hip_atomic_load(&A.E_abs[ic], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * A.qscale;
+        int Ti;
+        double frac_T2;
+        temp_lte(T.lq, M.n_T, E, M.L_packet_th, M.volume[ic], Ti, frac_T2);
+        const double frac_T1 = 1.0 - frac_T2;
+        const double* cdf1 = T.cdf + (size_t)M.n_lambda * (Ti - 2);
+        const double* cdf2 = T.cdf + (size_t)M.n_lambda * (Ti - 1);
+        int l1 = 0, l2 = M.n_lambda, l = (l1 + l2) / 2;
+        while ((l2 - l1) > 1) {
+          const double proba = frac_T1 * cdf1[l - 1] + frac_T2 * cdf2[l - 1];
+          if ((double)rand2 > proba) l1 = l; else l2 = l;
+          l = (l1 + l2) / 2;
+        }
+        lambda = l + 1;
+        // random_isotropic_direction
+        rand = rng.next();
+        w = 2.0 * (double)rand - 1.0;
+        const double uv = sqrt(1.0 - w * w);
+        rand = rng.next();
+        const double ph = PI * (2.0 * (double)rand - 1.0);
+        double sp, cp;
+        sincos(ph, &sp, &cp);
+        u = uv * cp;
+        v = uv * sp;
+        S[1] = 0.0; S[2] = 0.0; S[3] = 0.0;
+      }
+      st = S_NEWFLIGHT;
+    }
+
+    // ---- NEWFLIGHT: optical depth to the next event + per-flight constants
+    if (st == S_NEWFLIGHT) {
+      const float rand = rng.next();  // dust_transfer.f90:1208-1215 (tau in FP64)
+      extr = (rand > 1.0e-6f) ? -log(1.0 - (double)rand) : (double)rand;
+      const double a = u * u + v * v;  // cylindrical_grid.f90:941-952
+      inv_a = (a > TINY_REAL) ? 1.0 / a : HUGE_REAL;
+      inv_w = (fabs(w) > TINY_REAL) ? 1.0 / w : copysign(HUGE_DP, w);
+      const int i_star = intersect_stars(M, x, y, z, u, v, w);  // optical_depth.f90:68
+      star_key = -1;
+      if (i_star > 0) {
+        const int* sc = &M.star_cell[4 * (i_star - 1)];
+        star_key = sc[0] + (n_rad + 2) * ((sc[1] + nz + 1) + (2 * nz + 3) * (sc[2] - 1));
+      }
+      c_flight++;
+      ri_o = 0; zj_o = 0; k_o = 0;
+      xo = x; yo = y; zo = z;
+      st = S_FLIGHT;
+    }
+
+    if (__ballot(st != S_DONE) == 0ull) break;
+
+    // ---- FLIGHT: cell crossings (physical_length, optical_depth.f90:77-178)
+#pragma unroll 1
+    for (int it = 0; it < 8; ++it) {
+      if (st == S_FLIGHT) {
+        const int azj = zj < 0 ? -zj : zj;
+        // test_exit_grid_cyl (cylindrical_grid.f90:680-704) in closed form
+        const bool out = (ri == n_rad + 1) || ((azj == nz + 1) && (fabs(z) > M.zmaxmax));
+        bool killed = false;
+        if (star_key >= 0) {
+          const int key = ri + (n_rad + 2) * ((zj + nz + 1) + (2 * nz + 3) * (k - 1));
+          killed = (key == star_key);
+        }
+        if (out) {
+          capteur<POLA>(M, A.sed, lambda, u, v, w, S, flag_star, flag_scatt);
+          c_esc++;
+          st = S_EMIT;
+        } else if (killed) {
+          c_kill++;
+          st = S_EMIT;
+        } else {
+          const bool real_cell = is_real_cell<L3D>(n_rad, nz, ri, zj);
+          double opacity = 0.0;
+          int ic = 0;
+          bool mirrored = false;
+          if (real_cell) {
+            ic = cell_index<L3D>(n_rad, nz, ri, zj, k);
+            opacity = T.kappa[lambda - 1] * M.kappa_factor[ic];
+            if (DARK) {
+              if (M.dark[ic]) {  // optical_depth.f90:104-112
+                u = -u; v = -v; w = -w;
+                x = xo; y = yo; z = zo;
+                ri = ri_o; zj = zj_o; k = k_o;
+                c_dark++;
+                mirrored = true;
+                st = S_INTERACT;
+              }
+            }
+          }
+          if (!mirrored) {
+            double x1, y1, z1, l;
+            int ri1, zj1, k1;
+            cross_cell<L3D>(T, M, x, y, z, u, v, w, inv_a, inv_w, ri, zj, k, x1, y1, z1, ri1, zj1, k1, l);
+            c_cross++;
+            if (++pk_cross > 200000000u) {  // a packet that never leaves: flag it, drop it
+              *A.err = 13;
+              st = S_EMIT;
+            }
+            const double tau = l * opacity;
+            if (tau > extr) {
+              const double lc = l * (extr / tau);
+              if (real_cell) atomic_add_f64(&A.E_abs[ic], T.kabs[lambda - 1] * lc * S[0]);
+              x = x + lc * u;
+              y = y + lc * v;
+              z = z + lc * w;
+              if (L3D) index_cell<L3D>(T, M, x, y, z, ri, zj, k);  // optical_depth.f90:162-165
+              st = S_INTERACT;
+            } else {
+              extr = extr - tau;
+              if (real_cell) atomic_add_f64(&A.E_abs[ic], T.kabs[lambda - 1] * l * S[0]);
+              if (DARK) { xo = x; yo = y; zo = z; ri_o = ri; zj_o = zj; k_o = k; }
+              x = x1; y = y1; z = z1;
+              ri = ri1; zj = zj1; k = k1;
+            }
+          }
+        }
+      }
+    }
+  }
+
+  // ---- counters: wave reduce, one atomic per wave and counter -------------
+  unsigned int cs[8] = {c_pack, c_cross, c_flight, c_scatt, c_abs, c_esc, c_kill, c_dark};
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    unsigned long long vsum = cs[q];
+    for (int off = 32; off > 0; off >>= 1) vsum += __shfl_down(vsum, off);
+    if (lane == 0 && vsum) atomicAdd(&A.counters[q], vsum);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Temp_finale (thermal_emission.f90:870-906)
+// ---------------------------------------------------------------------------
+__global__ void k_temp_finale(const DevModel M, const double* E_abs, const float* tab_Temp, float T_min,
+                              float* Tdust) {
+  const int ic = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ic >= M.n_cells) return;
+  int Ti;
+  double frac;
+  const double E = E_abs[ic];
+  const double Qheat = E * M.L_packet_th / M.volume[ic];
+  float Temp = T_min;
+  if (!(Qheat < TINY_DP) && !(log(Qheat) < M.log_Qcool[0])) {
+    temp_lte(M.log_Qcool, M.n_T, E, M.L_packet_th, M.volume[ic], Ti, frac);
+    // log of a default real is a default-real log (thermal_emission.f90:697)
+    Temp = (float)exp((double)logf(tab_Temp[Ti - 1]) * frac + (double)logf(tab_Temp[Ti - 2]) * (1.0 - frac));
+  }
+  Tdust[ic] = Temp;
+}
+
+// ---------------------------------------------------------------------------
+// Probes for the parity tests
+// ---------------------------------------------------------------------------
+template <bool L3D>
+__global__ void k_probe_cross(const DevModel M, int n, const double* x0, const double* y0,
+                              const double* z0, const double* u, const double* v, const double* w,
+                              const int* cmi, const int* cmj, const int* cmk, const int* cell, double* x1,
+                              double* y1, double* z1, int* next_cell, double* l) {
+  extern __shared__ double lds_raw[];
+  const Lds T = lds_carve(lds_raw, M);
+  lds_stage(T, M);
+  __syncthreads();
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const double a = u[i] * u[i] + v[i] * v[i];
+    const double inv_a = (a > TINY_REAL) ? 1.0 / a : HUGE_REAL;
+    const double inv_w = (fabs(w[i]) > TINY_REAL) ? 1.0 / w[i] : copysign(HUGE_DP, w[i]);
+    const int c = cell[i] - 1;
+    int ri1, zj1, k1;
+    cross_cell<L3D>(T, M, x0[i], y0[i], z0[i], u[i], v[i], w[i], inv_a, inv_w, cmi[c], cmj[c], cmk[c],
+                    x1[i], y1[i], z1[i], ri1, zj1, k1, l[i]);
+    next_cell[i] = icell_of(M.n_rad, M.nz, M.n_az, M.l3D, ri1, zj1, k1);
+  }
+}
+
+template <bool L3D>
+__global__ void k_probe_index(const DevModel M, int n, const double* x, const double* y, const double* z,
+                              int* icell) {
+  extern __shared__ double lds_raw[];
+  const Lds T = lds_carve(lds_raw, M);
+  lds_stage(T, M);
+  __syncthreads();
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    int ri, zj, k;
+    index_cell<L3D>(T, M, x[i], y[i], z[i], ri, zj, k);
+    icell[i] = icell_of(M.n_rad, M.nz, M.n_az, M.l3D, ri, zj, k);
+  }
+}
+
+__global__ void k_probe_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                               uint32_t k1, uint32_t* out) {
+  uint32_t o[4];
+  philox4x32_10(c0, c1, c2, c3, k0, k1, o);
+  out[0] = o[0]; out[1] = o[1]; out[2] = o[2]; out[3] = o[3];
+}
+
+__global__ void k_probe_rand(uint64_t seed, uint64_t packet, int n, float* out) {
+  Rng r;
+  r.init(seed, packet);
+  for (int i = 0; i < n; ++i) out[i] = r.next();
+}
+
+}  // namespace mcgpu

@@ -1,0 +1,586 @@
+// mcgpu.hip -- host side of libmcfost_hip.so: the C-ABI declared in
+// include/mcgpu.h.  Owns the HBM copies of the model tables, launches the
+// persistent packet kernel and hands the accumulators back.  No CPU fallback:
+// without a HIP device every call fails.
+#include "../../include/mcgpu.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "mc_device.hip.h"
+
+using namespace mcgpu;
+
+struct mcgpu_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipDeviceProp_t prop;
+  std::string err;
+  DevModel M;
+  bool have_grid = false, have_stars = false, have_opacity = false, have_scatt = false,
+       have_thermal = false, have_sed = false;
+  int lsepar_pola = 0;
+  float T_min = 1.0f;
+  std::vector<void*> allocs;   // every table buffer (freed in destroy)
+  // per-setter buffers that may be replaced
+  int *d_cmi = nullptr, *d_cmj = nullptr, *d_cmk = nullptr;
+  float* d_tab_Temp = nullptr;
+  // accumulators: [E_abs | sed | n_sent]
+  double* d_accum = nullptr;
+  size_t n_accum = 0;
+  unsigned long long* d_counters = nullptr;  // 8 counters + work counter + pad
+  int* d_err = nullptr;
+  double* d_E_prior = nullptr;
+  bool launched = false;
+};
+
+#define HIPCHK(call)                                                              \
+  do {                                                                            \
+    hipError_t e_ = (call);                                                       \
+    if (e_ != hipSuccess) {                                                       \
+      ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);               \
+      return MCGPU_ERR_HIP;                                                       \
+    }                                                                             \
+  } while (0)
+
+template <typename Tp>
+static int upload(mcgpu_ctx* ctx, const Tp* host, size_t n, const Tp** dev_out) {
+  Tp* d = nullptr;
+  HIPCHK(hipMalloc((void**)&d, (n ? n : 1) * sizeof(Tp)));
+  ctx->allocs.push_back(d);
+  if (n) HIPCHK(hipMemcpy(d, host, n * sizeof(Tp), hipMemcpyHostToDevice));
+  *dev_out = d;
+  return MCGPU_OK;
+}
+
+static int fail(mcgpu_ctx* ctx, int code, const char* msg) {
+  if (ctx) ctx->err = msg;
+  return code;
+}
+
+extern "C" int mcgpu_create(int device, mcgpu_ctx** out) {
+  if (!out) return MCGPU_ERR_ARG;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return MCGPU_ERR_NO_DEVICE;
+  if (device < 0 || device >= n) return MCGPU_ERR_ARG;
+  mcgpu_ctx* ctx = new mcgpu_ctx();
+  ctx->device = device;
+  std::memset(&ctx->M, 0, sizeof(DevModel));
+  if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&ctx->prop, device) != hipSuccess ||
+      hipStreamCreate(&ctx->own_stream) != hipSuccess || hipEventCreate(&ctx->ev0) != hipSuccess ||
+      hipEventCreate(&ctx->ev1) != hipSuccess) {
+    delete ctx;
+    return MCGPU_ERR_HIP;
+  }
+  ctx->stream = ctx->own_stream;
+  if (hipMalloc((void**)&ctx->d_counters, 16 * sizeof(unsigned long long)) != hipSuccess ||
+      hipMalloc((void**)&ctx->d_err, sizeof(int)) != hipSuccess) {
+    delete ctx;
+    return MCGPU_ERR_HIP;
+  }
+  hipMemset(ctx->d_counters, 0, 16 * sizeof(unsigned long long));
+  hipMemset(ctx->d_err, 0, sizeof(int));
+  *out = ctx;
+  return MCGPU_OK;
+}
+
+extern "C" int mcgpu_destroy(mcgpu_ctx* ctx) {
+  if (!ctx) return MCGPU_OK;
+  hipSetDevice(ctx->device);
+  hipDeviceSynchronize();
+  for (void* p : ctx->allocs) hipFree(p);
+  if (ctx->d_accum) hipFree(ctx->d_accum);
+  if (ctx->d_counters) hipFree(ctx->d_counters);
+  if (ctx->d_err) hipFree(ctx->d_err);
+  if (ctx->d_E_prior) hipFree(ctx->d_E_prior);
+  if (ctx->ev0) hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) hipEventDestroy(ctx->ev1);
+  if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+  return MCGPU_OK;
+}
+
+extern "C" const char* mcgpu_last_error(const mcgpu_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+extern "C" int mcgpu_set_stream(mcgpu_ctx* ctx, void* s) {
+  if (!ctx) return MCGPU_ERR_ARG;
+  ctx->stream = s ? (hipStream_t)s : ctx->own_stream;
+  return MCGPU_OK;
+}
+
+extern "C" int mcgpu_set_grid_cyl(mcgpu_ctx* ctx, int n_rad, int nz, int n_az, int l3D,
+                                  const double* r_lim_2, const double* zmax, const double* z_lim,
+                                  const double* tan_phi_lim, double zmaxmax, double Rmax2,
+                                  const double* volume, const int* cell_map, const int* cell_map_i,
+                                  const int* cell_map_j, const int* cell_map_k, const int* lexit_cell) {
+  if (!ctx || n_rad < 1 || nz < 1 || n_az < 1 || !r_lim_2 || !zmax || !z_lim || !tan_phi_lim || !volume ||
+      !cell_map || !cell_map_i || !cell_map_j || !cell_map_k || !lexit_cell)
+    return fail(ctx, MCGPU_ERR_ARG, "mcgpu_set_grid_cyl: bad argument");
+  if (!l3D && n_az != 1) return fail(ctx, MCGPU_ERR_ARG, "2D grid needs n_az = 1");
+  HIPCHK(hipSetDevice(ctx->device));
+  const int n_cells = l3D ? 2 * n_rad * nz * n_az : n_rad * nz;
+  const int jlo = l3D ? -nz - 1 : 0;
+  const int jn = nz + 1 - jlo + 1;
+  const int ntot2 = l3D ? (n_rad + 2) * (2 * nz + 2) * n_az : (n_rad + 2) * (nz + 2) * n_az;
+  // verify the closed-form mapping against the host's arrays
+  for (int k = 1; k <= n_az; ++k)
+    for (int j = jlo; j <= nz + 1; ++j) {
+      if (l3D && j == 0) continue;
+      for (int i = 0; i <= n_rad + 1; ++i) {
+        const int ic = cell_map[i + (n_rad + 2) * ((j - jlo) + jn * (k - 1))];
+        if (ic != icell_of(n_rad, nz, n_az, l3D, i, j, k))
+          return fail(ctx, MCGPU_ERR_UNSUPPORTED, "cell_map differs from build_cylindrical_cell_mapping order");
+        if (ic < 1 || ic > ntot2 || cell_map_i[ic - 1] != i || cell_map_j[ic - 1] != j || cell_map_k[ic - 1] != k)
+          return fail(ctx, MCGPU_ERR_UNSUPPORTED, "cell_map_i/j/k inconsistent with cell_map");
+        const int aj = j < 0 ? -j : j;
+        int le = 0;
+        if (ic > n_cells) {
+          if (i == n_rad + 1) le = 1;
+          else if (aj == nz + 1) le = 2;
+        }
+        if (lexit_cell[ic - 1] != le) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "lexit_cell differs from the reference rule");
+      }
+    }
+  // verify the uniform vertical grid the kernel evaluates in closed form
+  std::vector<double> ch(n_rad);
+  for (int i = 1; i <= n_rad; ++i) {
+    ch[i - 1] = (nz >= 2) ? z_lim[(i - 1) + n_rad * 1] : zmax[i - 1];
+    for (int j = 1; j <= nz; ++j)
+      if (z_lim[(i - 1) + n_rad * (j - 1)] != ((double)j - 1.0) * ch[i - 1])
+        return fail(ctx, MCGPU_ERR_UNSUPPORTED, "z_lim is not the uniform grid (j-1)*cell_height");
+    if (z_lim[(i - 1) + n_rad * nz] != zmax[i - 1]) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "z_lim(i,nz+1) != zmax(i)");
+    if (z_lim[(i - 1) + n_rad * (nz + 1)] != (double)1.0e30f)
+      return fail(ctx, MCGPU_ERR_UNSUPPORTED, "z_lim(i,nz+2) != 1.0e30");
+  }
+  DevModel& M = ctx->M;
+  M.n_rad = n_rad; M.nz = nz; M.n_az = n_az; M.l3D = l3D ? 1 : 0; M.n_cells = n_cells;
+  M.zmaxmax = zmaxmax; M.Rmax2 = Rmax2;
+  int rc;
+  if ((rc = upload(ctx, r_lim_2, (size_t)n_rad + 1, &M.r_lim_2))) return rc;
+  if ((rc = upload(ctx, zmax, (size_t)n_rad, &M.zmax))) return rc;
+  if ((rc = upload(ctx, ch.data(), (size_t)n_rad, &M.ch))) return rc;
+  if ((rc = upload(ctx, tan_phi_lim, (size_t)n_az, &M.tan_phi_lim))) return rc;
+  if ((rc = upload(ctx, volume, (size_t)n_cells, &M.volume))) return rc;
+  const int *a, *b, *c;
+  if ((rc = upload(ctx, cell_map_i, (size_t)ntot2, &a))) return rc;
+  if ((rc = upload(ctx, cell_map_j, (size_t)ntot2, &b))) return rc;
+  if ((rc = upload(ctx, cell_map_k, (size_t)ntot2, &c))) return rc;
+  ctx->d_cmi = (int*)a; ctx->d_cmj = (int*)b; ctx->d_cmk = (int*)c;
+  ctx->have_grid = true;
+  return MCGPU_OK;
+}
+
+extern "C" int mcgpu_set_stars(mcgpu_ctx* ctx, int n_stars, const double* x, const double* y,
+                               const double* z, const double* r, const int* icell, const int* out_model) {
+  if (!ctx || n_stars < 1 || !x || !y || !z || !r || !icell || !out_model)
+    return fail(ctx, MCGPU_ERR_ARG, "mcgpu_set_stars: bad argument");
+  if (!ctx->have_grid) return fail(ctx, MCGPU_ERR_STATE, "set the grid before the stars");
+  HIPCHK(hipSetDevice(ctx->device));
+  const DevModel& G = ctx->M;
+  std::vector<double> xyzr(4 * n_stars);
+  std::vector<int> cell(4 * n_stars);
+  // invert the closed-form mapping on the host by search over (i,j,k)
+  const int jlo = G.l3D ? -G.nz - 1 : 0;
+  for (int s = 0; s < n_stars; ++s) {
+    xyzr[4 * s + 0] = x[s]; xyzr[4 * s + 1] = y[s]; xyzr[4 * s + 2] = z[s]; xyzr[4 * s + 3] = r[s];
+    bool found = false;
+    for (int k = 1; k <= G.n_az && !found; ++k)
+      for (int j = jlo; j <= G.nz + 1 && !found; ++j) {
+        if (G.l3D && j == 0) continue;
+        for (int i = 0; i <= G.n_rad + 1; ++i)
+          if (icell_of(G.n_rad, G.nz, G.n_az, G.l3D, i, j, k) == icell[s]) {
+            cell[4 * s + 0] = i; cell[4 * s + 1] = j; cell[4 * s + 2] = k;
+            found = true;
+            break;
+          }
+      }
+    if (!found) return fail(ctx, MCGPU_ERR_ARG, "star icell is not a cell of the grid");
+    cell[4 * s + 3] = out_model[s] ? 1 : 0;
+  }
+  ctx->M.n_stars = n_stars;
+  int rc;
+  if ((rc = upload(ctx, xyzr.data(), xyzr.size(), &ctx->M.star_xyzr))) return rc;
+  if ((rc = upload(ctx, cell.data(), cell.size(), &ctx->M.star_cell))) return rc;
+  ctx->have_stars = true;
+  return MCGPU_OK;
+}
+
+extern "C" int mcgpu_set_opacity(mcgpu_ctx* ctx, int n_lambda, const double* kappa, const double* kappa_abs_LTE,
+                                 const float* tab_albedo_pos, const double* kappa_factor,
+                                 const unsigned char* l_dark_zone) {
+  if (!ctx || n_lambda < 1 || !kappa || !kappa_abs_LTE || !tab_albedo_pos || !kappa_factor)
+    return fail(ctx, MCGPU_ERR_ARG, "mcgpu_set_opacity: bad argument");
+  if (!ctx->have_grid) return fail(ctx, MCGPU_ERR_STATE, "set the grid before the opacities");
+  if (ctx->M.n_lambda && ctx->M.n_lambda != n_lambda) return fail(ctx, MCGPU_ERR_ARG, "n_lambda mismatch");
+  HIPCHK(hipSetDevice(ctx->device));
+  DevModel& M = ctx->M;
+  M.n_lambda = n_lambda;
+  int rc;
+  if ((rc = upload(ctx, kappa, (size_t)n_lambda, &M.kappa))) return rc;
+  if ((rc = upload(ctx, kappa_abs_LTE, (size_t)n_lambda, &M.kappa_abs))) return rc;
+  if ((rc = upload(ctx, tab_albedo_pos, (size_t)n_lambda, &M.albedo))) return rc;
+  if ((rc = upload(ctx, kappa_factor, (size_t)M.n_cells, &M.kappa_factor))) return rc;
+  M.dark = nullptr;
+  if (l_dark_zone) {
+    bool any = false;
+    for (int i = 0; i < M.n_cells; ++i) any |= (l_dark_zone[i] != 0);
+    if (any && (rc = upload(ctx, l_dark_zone, (size_t)M.n_cells, &M.dark))) return rc;
+  }
+  ctx->have_opacity = true;
+  return MCGPU_OK;
+}
+
+extern "C" int mcgpu_set_scattering(mcgpu_ctx* ctx, int nang_scatt, int aniso_method, int lisotropic,
+                                    int lsepar_pola, int p_lambda_fixed, const float* prob_s11_pos,
+                                    const float* s12, const float* s22, const float* s33, const float* s34,
+                                    const float* s44, const float* tab_g_pos) {
+  if (!ctx || nang_scatt < 2 || (aniso_method != 1 && aniso_method != 2) || !prob_s11_pos || !tab_g_pos)
+    return fail(ctx, MCGPU_ERR_ARG, "mcgpu_set_scattering: bad argument");
+  if (!ctx->M.n_lambda) return fail(ctx, MCGPU_ERR_STATE, "set the opacities before the scattering tables");
+  if (lsepar_pola && aniso_method == 1 && (!s12 || !s22 || !s33 || !s34 || !s44))
+    return fail(ctx, MCGPU_ERR_ARG, "lsepar_pola needs the five Mueller ratio tables");
+  HIPCHK(hipSetDevice(ctx->device));
+  DevModel& M = ctx->M;
+  M.nang = nang_scatt; M.aniso_method = aniso_method; M.lisotropic = lisotropic ? 1 : 0;
+  M.p_lambda_fixed = p_lambda_fixed ? 1 : 0;
+  ctx->lsepar_pola = (lsepar_pola && aniso_method == 1) ? 1 : 0;
+  const size_t nt = (size_t)(nang_scatt + 1) * M.n_lambda;
+  int rc;
+  if ((rc = upload(ctx, prob_s11_pos, nt, &M.prob_s11))) return rc;
+  if ((rc = upload(ctx, tab_g_pos, (size_t)M.n_lambda, &M.tab_g))) return rc;
+  if (ctx->lsepar_pola) {
+    if ((rc = upload(ctx, s12, nt, &M.s12))) return rc;
+    if ((rc = upload(ctx, s22, nt, &M.s22))) return rc;
+    if ((rc = upload(ctx, s33, nt, &M.s33))) return rc;
+    if ((rc = upload(ctx, s34, nt, &M.s34))) return rc;
+    if ((rc = upload(ctx, s44, nt, &M.s44))) return rc;
+  }
+  ctx->have_scatt = true;
+  return MCGPU_OK;
+}
+
+extern "C" int mcgpu_set_thermal(mcgpu_ctx* ctx, int n_T, const float* tab_Temp, const double* log_Qcool,
+                                 const double* kdB_dT_CDF, const double* spectre_emission_cumul,
+                                 const double* frac_E_stars, const double* frac_E_disk,
+                                 const double* CDF_E_star, const double* prob_E_cell, double L_packet_th,
+                                 float T_min) {
+  if (!ctx || n_T < 2 || !tab_Temp || !log_Qcool || !kdB_dT_CDF || !spectre_emission_cumul || !frac_E_stars ||
+      !frac_E_disk || !CDF_E_star)
+    return fail(ctx, MCGPU_ERR_ARG, "mcgpu_set_thermal: bad argument");
+  if (!ctx->have_opacity || !ctx->have_stars) return fail(ctx, MCGPU_ERR_STATE, "set opacities and stars first");
+  for (int t = 2; t < n_T; ++t)
+    if (log_Qcool[t] < log_Qcool[t - 1]) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "log_Qcool must increase with T");
+  HIPCHK(hipSetDevice(ctx->device));
+  DevModel& M = ctx->M;
+  M.n_T = n_T; M.L_packet_th = L_packet_th;
+  ctx->T_min = T_min;
+  int rc;
+  const float* tt;
+  if ((rc = upload(ctx, tab_Temp, (size_t)n_T, &tt))) return rc;
+  ctx->d_tab_Temp = (float*)tt;
+  if ((rc = upload(ctx, log_Qcool, (size_t)n_T, &M.log_Qcool))) return rc;
+  if ((rc = upload(ctx, kdB_dT_CDF, (size_t)n_T * M.n_lambda, &M.cdf))) return rc;
+  if ((rc = upload(ctx, spectre_emission_cumul, (size_t)M.n_lambda + 1, &M.spec_cum))) return rc;
+  if ((rc = upload(ctx, frac_E_stars, (size_t)M.n_lambda, &M.frac_E_stars))) return rc;
+  if ((rc = upload(ctx, frac_E_disk, (size_t)M.n_lambda, &M.frac_E_disk))) return rc;
+  if ((rc = upload(ctx, CDF_E_star, (size_t)M.n_lambda * (M.n_stars + 1), &M.CDF_E_star))) return rc;
+  M.prob_E_cell = nullptr;
+  if (prob_E_cell && (rc = upload(ctx, prob_E_cell, (size_t)(M.n_cells + 1) * M.n_lambda, &M.prob_E_cell))) return rc;
+  if (!prob_E_cell)
+    for (int l = 0; l < M.n_lambda; ++l)
+      if (frac_E_stars[l] < 1.0) return fail(ctx, MCGPU_ERR_ARG, "frac_E_stars < 1 needs prob_E_cell");
+  ctx->have_thermal = true;
+  return MCGPU_OK;
+}
+
+extern "C" int mcgpu_set_sed_bins(mcgpu_ctx* ctx, int N_thet, int N_phi, int l_sym_centrale, int l_sym_axiale) {
+  if (!ctx || N_thet < 1 || N_phi < 1) return fail(ctx, MCGPU_ERR_ARG, "mcgpu_set_sed_bins: bad argument");
+  ctx->M.N_thet = N_thet; ctx->M.N_phi = N_phi;
+  ctx->M.sym_c = l_sym_centrale ? 1 : 0; ctx->M.sym_a = l_sym_axiale ? 1 : 0;
+  ctx->have_sed = true;
+  return MCGPU_OK;
+}
+
+static size_t n_sed(const DevModel& M) { return (size_t)MCGPU_N_SED_TYPES * M.n_lambda * M.N_thet * M.N_phi; }
+
+static int ensure_accum(mcgpu_ctx* ctx) {
+  const DevModel& M = ctx->M;
+  const size_t n = (size_t)M.n_cells + n_sed(M) + M.n_lambda;
+  if (ctx->d_accum && ctx->n_accum == n) return MCGPU_OK;
+  if (ctx->d_accum) hipFree(ctx->d_accum);
+  ctx->d_accum = nullptr;
+  HIPCHK(hipMalloc((void**)&ctx->d_accum, n * sizeof(double)));
+  HIPCHK(hipMemset(ctx->d_accum, 0, n * sizeof(double)));
+  ctx->n_accum = n;
+  return MCGPU_OK;
+}
+
+static int ready(mcgpu_ctx* ctx) {
+  if (!ctx) return MCGPU_ERR_ARG;
+  if (!(ctx->have_grid && ctx->have_stars && ctx->have_opacity && ctx->have_scatt && ctx->have_thermal &&
+        ctx->have_sed))
+    return fail(ctx, MCGPU_ERR_STATE, "model incomplete: call every mcgpu_set_* first");
+  return MCGPU_OK;
+}
+
+extern "C" int mcgpu_set_E_prior(mcgpu_ctx* ctx, const double* E_prior) {
+  if (!ctx || !E_prior || !ctx->have_grid) return fail(ctx, MCGPU_ERR_ARG, "mcgpu_set_E_prior: bad argument");
+  HIPCHK(hipSetDevice(ctx->device));
+  if (!ctx->d_E_prior) HIPCHK(hipMalloc((void**)&ctx->d_E_prior, (size_t)ctx->M.n_cells * sizeof(double)));
+  HIPCHK(hipMemcpy(ctx->d_E_prior, E_prior, (size_t)ctx->M.n_cells * sizeof(double), hipMemcpyHostToDevice));
+  return MCGPU_OK;
+}
+
+template <bool L3D, bool POLA, bool DARK>
+static hipError_t launch_k(const DevModel& M, const RunArgs& A, int blocks, int threads, size_t lds, hipStream_t s) {
+  auto kern = k_thermal<L3D, POLA, DARK>;
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, s, M, A);
+  return hipGetLastError();
+}
+
+extern "C" int mcgpu_launch_thermal(mcgpu_ctx* ctx, const mcgpu_run_opts* o) {
+  int rc = ready(ctx);
+  if (rc) return rc;
+  if (!o) return fail(ctx, MCGPU_ERR_ARG, "null options");
+  if (o->frozen && !ctx->d_E_prior) return fail(ctx, MCGPU_ERR_STATE, "frozen mode needs mcgpu_set_E_prior");
+  HIPCHK(hipSetDevice(ctx->device));
+  if ((rc = ensure_accum(ctx))) return rc;
+  const DevModel& M = ctx->M;
+  const size_t lds = lds_bytes(M);
+  if (lds > (size_t)ctx->prop.sharedMemPerBlock && lds > 160 * 1024)
+    return fail(ctx, MCGPU_ERR_UNSUPPORTED, "wavelength tables exceed the LDS of one CU");
+  if (!o->accumulate) {
+    HIPCHK(hipMemsetAsync(ctx->d_accum, 0, ctx->n_accum * sizeof(double), ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_counters, 0, 16 * sizeof(unsigned long long), ctx->stream));
+  } else {
+    HIPCHK(hipMemsetAsync(ctx->d_counters + 8, 0, sizeof(unsigned long long), ctx->stream));
+  }
+  HIPCHK(hipMemsetAsync(ctx->d_err, 0, sizeof(int), ctx->stream));
+  RunArgs A;
+  A.seed = o->seed; A.first_packet = o->first_packet; A.n_packets = o->n_packets;
+  A.qscale = o->n_replicas >= 1.0 ? o->n_replicas : 1.0;
+  A.frozen = o->frozen ? 1 : 0;
+  A.E_prior = ctx->d_E_prior;
+  A.E_abs = ctx->d_accum;
+  A.sed = ctx->d_accum + M.n_cells;
+  A.n_sent = ctx->d_accum + M.n_cells + n_sed(M);
+  A.counters = ctx->d_counters;
+  A.next_packet = ctx->d_counters + 8;
+  A.err = ctx->d_err;
+  const int threads = o->block_threads > 0 ? o->block_threads : 256;
+  if (threads % 64 || threads > 256) return fail(ctx, MCGPU_ERR_ARG, "block_threads must be 64..256, multiple of 64");
+  int blocks = o->grid_blocks;
+  if (blocks <= 0) {
+    // persistent grid: as many workgroups as the LDS footprint lets reside
+    int per_cu = (int)((160 * 1024) / (lds > 0 ? lds : 1));
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > 8) per_cu = 8;
+    blocks = ctx->prop.multiProcessorCount * per_cu;
+    const unsigned long long need = (o->n_packets + threads - 1) / threads;
+    if ((unsigned long long)blocks > need) blocks = (int)(need ? need : 1);
+  }
+  const bool pola = ctx->lsepar_pola != 0, dark = M.dark != nullptr, l3d = M.l3D != 0;
+  HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+  hipError_t e;
+#define LAUNCH(a, b, c) e = launch_k<a, b, c>(M, A, blocks, threads, lds, ctx->stream)
+  if (l3d) {
+    if (pola) { if (dark) LAUNCH(true, true, true); else LAUNCH(true, true, false); }
+    else { if (dark) LAUNCH(true, false, true); else LAUNCH(true, false, false); }
+  } else {
+    if (pola) { if (dark) LAUNCH(false, true, true); else LAUNCH(false, true, false); }
+    else { if (dark) LAUNCH(false, false, true); else LAUNCH(false, false, false); }
+  }
+#undef LAUNCH
+  if (e != hipSuccess) {
+    ctx->err = std::string("kernel launch: ") + hipGetErrorString(e);
+    return MCGPU_ERR_HIP;
+  }
+  HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+  ctx->launched = true;
+  return MCGPU_OK;
+}
+
+extern "C" int mcgpu_sync(mcgpu_ctx* ctx, double* kernel_ms) {
+  if (!ctx) return MCGPU_ERR_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (kernel_ms) {
+    *kernel_ms = 0.0;
+    if (ctx->launched) {
+      float ms = 0.f;
+      HIPCHK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+      *kernel_ms = ms;
+    }
+  }
+  int herr = 0;
+  HIPCHK(hipMemcpy(&herr, ctx->d_err, sizeof(int), hipMemcpyDeviceToHost));
+  if (herr) {
+    ctx->err = "kernel error code " + std::to_string(herr) + " (12 = emission source outside the engine's scope)";
+    return MCGPU_ERR_KERNEL;
+  }
+  return MCGPU_OK;
+}
+
+extern "C" int mcgpu_device_accumulators(mcgpu_ctx* ctx, void** accum_dev, uint64_t* n_doubles, void** counters_dev) {
+  int rc = ready(ctx);
+  if (rc) return rc;
+  HIPCHK(hipSetDevice(ctx->device));
+  if ((rc = ensure_accum(ctx))) return rc;
+  if (accum_dev) *accum_dev = ctx->d_accum;
+  if (n_doubles) *n_doubles = ctx->n_accum;
+  if (counters_dev) *counters_dev = ctx->d_counters;
+  return MCGPU_OK;
+}
+
+extern "C" int mcgpu_fetch(mcgpu_ctx* ctx, double* E_abs, double* sed, double* n_sent, uint64_t* counters) {
+  int rc = ready(ctx);
+  if (rc) return rc;
+  if (!ctx->d_accum) return fail(ctx, MCGPU_ERR_STATE, "nothing launched yet");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  const DevModel& M = ctx->M;
+  if (E_abs) HIPCHK(hipMemcpy(E_abs, ctx->d_accum, (size_t)M.n_cells * sizeof(double), hipMemcpyDeviceToHost));
+  if (sed) HIPCHK(hipMemcpy(sed, ctx->d_accum + M.n_cells, n_sed(M) * sizeof(double), hipMemcpyDeviceToHost));
+  if (n_sent)
+    HIPCHK(hipMemcpy(n_sent, ctx->d_accum + M.n_cells + n_sed(M), (size_t)M.n_lambda * sizeof(double),
+                     hipMemcpyDeviceToHost));
+  if (counters) HIPCHK(hipMemcpy(counters, ctx->d_counters, MCGPU_N_COUNTERS * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  return MCGPU_OK;
+}
+
+extern "C" int mcgpu_run_thermal(mcgpu_ctx* ctx, const mcgpu_run_opts* opts, double* E_abs, double* sed,
+                                 double* n_sent, uint64_t* counters, double* kernel_ms) {
+  int rc = mcgpu_launch_thermal(ctx, opts);
+  if (rc) return rc;
+  if ((rc = mcgpu_sync(ctx, kernel_ms))) return rc;
+  return mcgpu_fetch(ctx, E_abs, sed, n_sent, counters);
+}
+
+extern "C" int mcgpu_temp_finale(mcgpu_ctx* ctx, const double* E_abs, float* Tdust) {
+  int rc = ready(ctx);
+  if (rc) return rc;
+  if (!Tdust) return fail(ctx, MCGPU_ERR_ARG, "null Tdust");
+  HIPCHK(hipSetDevice(ctx->device));
+  const DevModel& M = ctx->M;
+  double* d_E = nullptr;
+  const double* src = ctx->d_accum;
+  if (E_abs) {
+    HIPCHK(hipMalloc((void**)&d_E, (size_t)M.n_cells * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(d_E, E_abs, (size_t)M.n_cells * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    src = d_E;
+  } else if (!src) {
+    return fail(ctx, MCGPU_ERR_STATE, "no accumulator to reduce");
+  }
+  float* d_T = nullptr;
+  HIPCHK(hipMalloc((void**)&d_T, (size_t)M.n_cells * sizeof(float)));
+  const int threads = 256, blocks = (M.n_cells + threads - 1) / threads;
+  hipLaunchKernelGGL(k_temp_finale, dim3(blocks), dim3(threads), 0, ctx->stream, M, src, ctx->d_tab_Temp,
+                     ctx->T_min, d_T);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(Tdust, d_T, (size_t)M.n_cells * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  hipFree(d_T);
+  if (d_E) hipFree(d_E);
+  return MCGPU_OK;
+}
+
+// ---- probes ---------------------------------------------------------------
+template <typename Tp>
+struct DevBuf {
+  Tp* p = nullptr;
+  ~DevBuf() { if (p) hipFree(p); }
+  hipError_t alloc(size_t n) { return hipMalloc((void**)&p, (n ? n : 1) * sizeof(Tp)); }
+  hipError_t put(const Tp* h, size_t n) { return hipMemcpy(p, h, n * sizeof(Tp), hipMemcpyHostToDevice); }
+  hipError_t get(Tp* h, size_t n) { return hipMemcpy(h, p, n * sizeof(Tp), hipMemcpyDeviceToHost); }
+};
+
+extern "C" int mcgpu_probe_cross_cell(mcgpu_ctx* ctx, int n, const double* x0, const double* y0, const double* z0,
+                                      const double* u, const double* v, const double* w, const int* cell,
+                                      double* x1, double* y1, double* z1, int* next_cell, double* l) {
+  int rc = ready(ctx);
+  if (rc) return rc;
+  HIPCHK(hipSetDevice(ctx->device));
+  const DevModel& M = ctx->M;
+  DevBuf<double> in[6], out[4];
+  DevBuf<int> dc, dn;
+  const double* hin[6] = {x0, y0, z0, u, v, w};
+  for (int q = 0; q < 6; ++q) { HIPCHK(in[q].alloc(n)); HIPCHK(in[q].put(hin[q], n)); }
+  for (int q = 0; q < 4; ++q) HIPCHK(out[q].alloc(n));
+  HIPCHK(dc.alloc(n)); HIPCHK(dc.put(cell, n)); HIPCHK(dn.alloc(n));
+  const size_t lds = lds_bytes(M);
+  if (M.l3D) {
+    hipFuncSetAttribute((const void*)k_probe_cross<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_probe_cross<true>, dim3(64), dim3(256), lds, ctx->stream, M, n, in[0].p, in[1].p, in[2].p,
+                       in[3].p, in[4].p, in[5].p, ctx->d_cmi, ctx->d_cmj, ctx->d_cmk, dc.p, out[0].p, out[1].p,
+                       out[2].p, dn.p, out[3].p);
+  } else {
+    hipFuncSetAttribute((const void*)k_probe_cross<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_probe_cross<false>, dim3(64), dim3(256), lds, ctx->stream, M, n, in[0].p, in[1].p, in[2].p,
+                       in[3].p, in[4].p, in[5].p, ctx->d_cmi, ctx->d_cmj, ctx->d_cmk, dc.p, out[0].p, out[1].p,
+                       out[2].p, dn.p, out[3].p);
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(out[0].get(x1, n)); HIPCHK(out[1].get(y1, n)); HIPCHK(out[2].get(z1, n)); HIPCHK(out[3].get(l, n));
+  HIPCHK(dn.get(next_cell, n));
+  return MCGPU_OK;
+}
+
+extern "C" int mcgpu_probe_index_cell(mcgpu_ctx* ctx, int n, const double* x, const double* y, const double* z,
+                                      int* icell) {
+  int rc = ready(ctx);
+  if (rc) return rc;
+  HIPCHK(hipSetDevice(ctx->device));
+  const DevModel& M = ctx->M;
+  DevBuf<double> in[3];
+  DevBuf<int> dn;
+  const double* hin[3] = {x, y, z};
+  for (int q = 0; q < 3; ++q) { HIPCHK(in[q].alloc(n)); HIPCHK(in[q].put(hin[q], n)); }
+  HIPCHK(dn.alloc(n));
+  const size_t lds = lds_bytes(M);
+  if (M.l3D) {
+    hipFuncSetAttribute((const void*)k_probe_index<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_probe_index<true>, dim3(64), dim3(256), lds, ctx->stream, M, n, in[0].p, in[1].p, in[2].p, dn.p);
+  } else {
+    hipFuncSetAttribute((const void*)k_probe_index<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_probe_index<false>, dim3(64), dim3(256), lds, ctx->stream, M, n, in[0].p, in[1].p, in[2].p, dn.p);
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(dn.get(icell, n));
+  return MCGPU_OK;
+}
+
+extern "C" int mcgpu_probe_philox(mcgpu_ctx* ctx, const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+  if (!ctx) return MCGPU_ERR_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  DevBuf<uint32_t> d;
+  HIPCHK(d.alloc(4));
+  hipLaunchKernelGGL(k_probe_philox, dim3(1), dim3(1), 0, ctx->stream, ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], d.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(d.get(out, 4));
+  return MCGPU_OK;
+}
+
+extern "C" int mcgpu_probe_packet_rand(mcgpu_ctx* ctx, uint64_t seed, uint64_t packet, int n, float* out) {
+  if (!ctx || n < 1) return MCGPU_ERR_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  DevBuf<float> d;
+  HIPCHK(d.alloc(n));
+  hipLaunchKernelGGL(k_probe_rand, dim3(1), dim3(1), 0, ctx->stream, seed, packet, n, d.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(d.get(out, n));
+  return MCGPU_OK;
+}

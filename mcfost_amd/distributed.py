@@ -1,0 +1,88 @@
+"""Multi-GPU sharding of the packet loop: one process per GPU.
+
+The reference runs packets on independent OpenMP threads with private
+accumulators that are summed after the loop (``dust_transfer.f90:480-489``,
+``thermal_emission.f90:668``).  The same structure over ranks: the packet id
+range is split into disjoint contiguous shards (the per-packet Philox streams
+make the result independent of the split), every rank holds a replica of the
+tables, and ONE all-reduce (RCCL over xGMI when the backend is ``nccl``) sums
+the fused accumulator ``[E_abs | sed | n_sent]`` plus the integer counters per
+temperature iteration.  The in-flight temperature uses the local partial sum
+times ``world_size`` -- the reference's ``* nb_proc``
+(``thermal_emission.f90:670``).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def shard_packets(n_packets: int, rank: int, world_size: int):
+    """Contiguous, disjoint, exhaustive split: returns (first_packet, count)."""
+    base, rem = divmod(int(n_packets), int(world_size))
+    count = base + (1 if rank < rem else 0)
+    first = rank * base + min(rank, rem)
+    return first, count
+
+
+def pack_results(res, n_cells):
+    """[E_abs | sed | n_sent] as one float64 vector + counters as int64."""
+    acc = np.concatenate([res["E_abs"].ravel(), res["sed"].ravel(), res["n_sent"].ravel()])
+    cnt = np.array(list(res["counters"].values()), dtype=np.int64)
+    return acc, cnt
+
+
+def unpack_results(acc, cnt, like):
+    n_c = like["E_abs"].size
+    n_s = like["sed"].size
+    out = dict(E_abs=acc[:n_c].copy(), sed=acc[n_c:n_c + n_s].reshape(like["sed"].shape).copy(),
+               n_sent=acc[n_c + n_s:].copy(),
+               counters=dict(zip(like["counters"].keys(), (int(c) for c in cnt))))
+    return out
+
+
+def allreduce_host(res, group=None):
+    """Sum host-side results over ranks (any torch.distributed backend)."""
+    import torch
+    import torch.distributed as dist
+
+    acc, cnt = pack_results(res, res["E_abs"].size)
+    t_acc, t_cnt = torch.from_numpy(acc), torch.from_numpy(cnt)
+    dist.all_reduce(t_acc, op=dist.ReduceOp.SUM, group=group)
+    dist.all_reduce(t_cnt, op=dist.ReduceOp.SUM, group=group)
+    return unpack_results(t_acc.numpy(), t_cnt.numpy(), res)
+
+
+def run_thermal_sharded(run_local, n_packets: int, seed: int, rank: int, world_size: int,
+                        reduce=allreduce_host, **kw):
+    """One temperature iteration on ``world_size`` ranks.
+
+    ``run_local(n_packets, seed=, first_packet=, n_replicas=, **kw)`` is this
+    rank's packet loop (``Engine.run_thermal`` on a GPU rank).  Returns the
+    globally summed result on every rank.
+    """
+    first, count = shard_packets(n_packets, rank, world_size)
+    res = run_local(count, seed=seed, first_packet=first, n_replicas=float(world_size), **kw)
+    if world_size == 1:
+        return res
+    out = reduce(res)
+    out["kernel_ms"] = res.get("kernel_ms")
+    return out
+
+
+def run_thermal_device(engine, n_packets: int, seed: int, rank: int, world_size: int, **kw):
+    """GPU path: the accumulators stay in HBM; the all-reduce runs on the fused
+    device buffer (RCCL).  Returns (result dict after reduction, kernel ms)."""
+    import torch
+    import torch.distributed as dist
+
+    first, count = shard_packets(n_packets, rank, world_size)
+    engine.launch_thermal(count, seed=seed, first_packet=first, n_replicas=float(world_size), **kw)
+    ms = engine.sync()
+    if world_size > 1:
+        acc, cnt = engine.device_accumulators()
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
+    out = engine.fetch()
+    out["kernel_ms"] = ms
+    return out

@@ -1,0 +1,261 @@
+"""Host-side binding of the MI355X packet engine (``libmcfost_hip.so``).
+
+This is the Python mirror of the Fortran shim (``mcfost_amd/fortran/mcgpu_f.f90``):
+it hands the model tables to the C-ABI of ``include/mcgpu.h`` and calls the
+replacement of ``mc_photon_loop`` (``dust_transfer.f90:439-572``) and
+``Temp_finale`` (``thermal_emission.f90:870-906``).  There is no CPU path
+here: if the HIP library is missing or no device is usable, construction
+fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmcfost_hip.so")
+
+N_SED_TYPES = 9
+N_COUNTERS = 8
+COUNTER_NAMES = ("packets", "crossings", "flights", "scatterings", "absorptions",
+                 "escaped", "killed_star", "dark_mirrors")
+SED_NAMES = ("sed", "sed_q", "sed_u", "sed_v", "n_phot_sed", "sed_star", "sed_star_scat",
+             "sed_disk", "sed_disk_scat")
+
+# every symbol include/mcgpu.h declares
+ABI_SYMBOLS = (
+    "mcgpu_create", "mcgpu_destroy", "mcgpu_last_error", "mcgpu_set_grid_cyl", "mcgpu_set_stars",
+    "mcgpu_set_opacity", "mcgpu_set_scattering", "mcgpu_set_thermal", "mcgpu_set_sed_bins",
+    "mcgpu_set_E_prior", "mcgpu_run_thermal", "mcgpu_launch_thermal", "mcgpu_sync",
+    "mcgpu_device_accumulators", "mcgpu_fetch", "mcgpu_set_stream", "mcgpu_temp_finale",
+    "mcgpu_probe_cross_cell", "mcgpu_probe_index_cell", "mcgpu_probe_philox",
+    "mcgpu_probe_packet_rand",
+)
+
+
+class McgpuError(RuntimeError):
+    pass
+
+
+class RunOpts(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("first_packet", C.c_uint64), ("n_packets", C.c_uint64),
+                ("n_replicas", C.c_double), ("frozen", C.c_int), ("accumulate", C.c_int),
+                ("grid_blocks", C.c_int), ("block_threads", C.c_int)]
+
+
+_lib = None
+
+
+def load_library(path: str = LIB_PATH):
+    """Load the C-ABI library; fail loudly if it was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise McgpuError(
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(path)
+    lib.mcgpu_last_error.restype = C.c_char_p
+    lib.mcgpu_last_error.argtypes = [C.c_void_p]
+    for s in ABI_SYMBOLS:
+        getattr(lib, s)  # AttributeError if the symbol is not exported
+    _lib = lib
+    return lib
+
+
+def _a(x, dt):
+    return np.ascontiguousarray(x, dtype=dt)
+
+
+def _p(arr, ct):
+    return arr.ctypes.data_as(C.POINTER(ct))
+
+
+class _DevArray:
+    """Exposes a raw device pointer through ``__cuda_array_interface__`` so
+    that torch can wrap the accumulator without a copy."""
+
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr,
+                                         "data": (int(ptr), False), "version": 2}
+
+
+class Engine:
+    """One device context holding one model (the tables ``init_dust_transfer``
+    prepares, ``dust_transfer.f90:41-340``)."""
+
+    def __init__(self, model, n_packets_total, device: int = 0):
+        self.lib = load_library()
+        self.model = model
+        self.ctx = C.c_void_p()
+        rc = self.lib.mcgpu_create(C.c_int(device), C.byref(self.ctx))
+        if rc:
+            self.ctx = C.c_void_p()
+            raise McgpuError(f"mcgpu_create(device={device}) failed with code {rc} "
+                             "(1 = no usable HIP device; the engine has no CPU path)")
+        self.device = device
+        self._upload(model, float(n_packets_total))
+
+    # -- plumbing ----------------------------------------------------------
+    def _chk(self, rc, what):
+        if rc:
+            msg = self.lib.mcgpu_last_error(self.ctx)
+            raise McgpuError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+    def close(self):
+        if getattr(self, "ctx", None) and self.ctx.value:
+            self.lib.mcgpu_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _upload(self, m, n_tot):
+        g, cfg, L = m.grid, m.cfg, self.lib
+        d, i32 = np.float64, np.int32
+        self._chk(L.mcgpu_set_grid_cyl(
+            self.ctx, C.c_int(g["n_rad"]), C.c_int(g["nz"]), C.c_int(g["n_az"]), C.c_int(g["l3D"]),
+            _p(_a(g["r_lim_2"], d), C.c_double), _p(_a(g["zmax"], d), C.c_double),
+            _p(_a(g["z_lim"], d), C.c_double), _p(_a(g["tan_phi_lim"], d), C.c_double),
+            C.c_double(g["zmaxmax"]), C.c_double(g["Rmax2"]), _p(_a(g["volume"], d), C.c_double),
+            _p(_a(g["cell_map"], i32), C.c_int), _p(_a(g["cell_map_i"], i32), C.c_int),
+            _p(_a(g["cell_map_j"], i32), C.c_int), _p(_a(g["cell_map_k"], i32), C.c_int),
+            _p(_a(g["lexit_cell"], i32), C.c_int)), "mcgpu_set_grid_cyl")
+        st = np.asarray(m.stars, d)
+        cols = [_a(st[:, q], d) for q in range(4)]
+        self._chk(L.mcgpu_set_stars(
+            self.ctx, C.c_int(st.shape[0]), *[_p(c, C.c_double) for c in cols],
+            _p(_a(st[:, 4], i32), C.c_int), _p(_a(st[:, 5], i32), C.c_int)), "mcgpu_set_stars")
+        dark = None if m.l_dark_zone is None else _p(_a(m.l_dark_zone, np.uint8), C.c_ubyte)
+        self._chk(L.mcgpu_set_opacity(
+            self.ctx, C.c_int(m.n_lambda), _p(_a(m.kappa, d), C.c_double),
+            _p(_a(m.kappa_abs_LTE, d), C.c_double), _p(_a(m.albedo, np.float32), C.c_float),
+            _p(_a(m.kappa_factor, d), C.c_double), dark), "mcgpu_set_opacity")
+        f = np.float32
+        self._chk(L.mcgpu_set_scattering(
+            self.ctx, C.c_int(180), C.c_int(cfg.aniso_method), C.c_int(int(cfg.lisotropic)),
+            C.c_int(int(cfg.lsepar_pola)), C.c_int(int(m.p_lambda_fixed)),
+            _p(_a(m.prob_s11_pos, f), C.c_float), _p(_a(m.s12_o_s11, f), C.c_float),
+            _p(_a(m.s22_o_s11, f), C.c_float), _p(_a(m.s33_o_s11, f), C.c_float),
+            _p(_a(m.s34_o_s11, f), C.c_float), _p(_a(m.s44_o_s11, f), C.c_float),
+            _p(_a(m.tab_g_pos, f), C.c_float)), "mcgpu_set_scattering")
+        pe = getattr(m, "prob_E_cell", None)
+        self._chk(L.mcgpu_set_thermal(
+            self.ctx, C.c_int(m.tab_Temp.size), _p(_a(m.tab_Temp, f), C.c_float),
+            _p(_a(m.log_Qcool, d), C.c_double), _p(_a(m.kdB_dT_CDF, d), C.c_double),
+            _p(_a(m.spectre_emission_cumul, d), C.c_double), _p(_a(m.frac_E_stars, d), C.c_double),
+            _p(_a(m.frac_E_disk, d), C.c_double), _p(_a(m.CDF_E_star, d), C.c_double),
+            None if pe is None else _p(_a(pe, d), C.c_double),
+            C.c_double(m.L_packet_th(n_tot)), C.c_float(cfg.T_min)), "mcgpu_set_thermal")
+        self._chk(L.mcgpu_set_sed_bins(
+            self.ctx, C.c_int(cfg.N_thet), C.c_int(cfg.N_phi), C.c_int(int(cfg.l_sym_centrale)),
+            C.c_int(int(cfg.l_sym_axiale))), "mcgpu_set_sed_bins")
+
+    # -- the packet loop ---------------------------------------------------
+    def _opts(self, n_packets, seed, first_packet, frozen, n_replicas, accumulate, grid_blocks,
+              block_threads):
+        return RunOpts(int(seed), int(first_packet), int(n_packets), float(n_replicas), int(frozen),
+                       int(accumulate), int(grid_blocks), int(block_threads))
+
+    def set_E_prior(self, E_prior):
+        self._chk(self.lib.mcgpu_set_E_prior(self.ctx, _p(_a(E_prior, np.float64), C.c_double)),
+                  "mcgpu_set_E_prior")
+
+    def launch_thermal(self, n_packets, seed=1, first_packet=0, frozen=False, n_replicas=1.0,
+                       accumulate=False, grid_blocks=0, block_threads=0):
+        o = self._opts(n_packets, seed, first_packet, frozen, n_replicas, accumulate, grid_blocks,
+                       block_threads)
+        self._chk(self.lib.mcgpu_launch_thermal(self.ctx, C.byref(o)), "mcgpu_launch_thermal")
+
+    def sync(self):
+        ms = C.c_double()
+        self._chk(self.lib.mcgpu_sync(self.ctx, C.byref(ms)), "mcgpu_sync")
+        return ms.value
+
+    def fetch(self):
+        m = self.model
+        nl, nt, nphi = m.n_lambda, m.cfg.N_thet, m.cfg.N_phi
+        E = np.zeros(m.n_cells, np.float64)
+        sed = np.zeros((N_SED_TYPES, nphi, nt, nl), np.float64)
+        n_sent = np.zeros(nl, np.float64)
+        cnt = np.zeros(N_COUNTERS, np.uint64)
+        self._chk(self.lib.mcgpu_fetch(self.ctx, _p(E, C.c_double), _p(sed, C.c_double),
+                                       _p(n_sent, C.c_double), _p(cnt, C.c_uint64)), "mcgpu_fetch")
+        return dict(E_abs=E, sed=sed, n_sent=n_sent,
+                    counters=dict(zip(COUNTER_NAMES, (int(c) for c in cnt))))
+
+    def run_thermal(self, n_packets, seed=1, first_packet=0, frozen=False, E_prior=None,
+                    n_replicas=1.0, accumulate=False, grid_blocks=0, block_threads=0):
+        """``mc_photon_loop`` for the thermal step; returns E_abs, sed, n_sent,
+        counters and the kernel time in ms."""
+        if E_prior is not None:
+            self.set_E_prior(E_prior)
+        self.launch_thermal(n_packets, seed, first_packet, frozen, n_replicas, accumulate,
+                            grid_blocks, block_threads)
+        ms = self.sync()
+        out = self.fetch()
+        out["kernel_ms"] = ms
+        return out
+
+    def temp_finale(self, E_abs=None):
+        T = np.zeros(self.model.n_cells, np.float32)
+        ep = None if E_abs is None else _p(_a(E_abs, np.float64), C.c_double)
+        self._chk(self.lib.mcgpu_temp_finale(self.ctx, ep, _p(T, C.c_float)), "mcgpu_temp_finale")
+        return T
+
+    def set_stream(self, stream_ptr):
+        self._chk(self.lib.mcgpu_set_stream(self.ctx, C.c_void_p(stream_ptr)), "mcgpu_set_stream")
+
+    def device_accumulators(self):
+        """(fused f64 accumulator, u64 counters) as zero-copy torch tensors on
+        this context's device: what the RCCL all-reduce operates on."""
+        import torch
+
+        acc, cnt, n = C.c_void_p(), C.c_void_p(), C.c_uint64()
+        self._chk(self.lib.mcgpu_device_accumulators(self.ctx, C.byref(acc), C.byref(n), C.byref(cnt)),
+                  "mcgpu_device_accumulators")
+        dev = torch.device("cuda", self.device)
+        t_acc = torch.as_tensor(_DevArray(acc.value, n.value, "<f8"), device=dev)
+        t_cnt = torch.as_tensor(_DevArray(cnt.value, N_COUNTERS, "<i8"), device=dev)
+        return t_acc, t_cnt
+
+    # -- probes (parity tests) ---------------------------------------------
+    def probe_cross_cell(self, x0, y0, z0, u, v, w, cell):
+        n = len(cell)
+        ins = [_a(q, np.float64) for q in (x0, y0, z0, u, v, w)]
+        cell = _a(cell, np.int32)
+        x1, y1, z1, l = (np.zeros(n) for _ in range(4))
+        nxt = np.zeros(n, np.int32)
+        self._chk(self.lib.mcgpu_probe_cross_cell(
+            self.ctx, C.c_int(n), *[_p(q, C.c_double) for q in ins], _p(cell, C.c_int),
+            _p(x1, C.c_double), _p(y1, C.c_double), _p(z1, C.c_double), _p(nxt, C.c_int),
+            _p(l, C.c_double)), "mcgpu_probe_cross_cell")
+        return x1, y1, z1, nxt, l
+
+    def probe_index_cell(self, x, y, z):
+        n = len(x)
+        ins = [_a(q, np.float64) for q in (x, y, z)]
+        ic = np.zeros(n, np.int32)
+        self._chk(self.lib.mcgpu_probe_index_cell(self.ctx, C.c_int(n), *[_p(q, C.c_double) for q in ins],
+                                                  _p(ic, C.c_int)), "mcgpu_probe_index_cell")
+        return ic
+
+    def probe_philox(self, ctr, key):
+        c = (C.c_uint32 * 4)(*ctr)
+        k = (C.c_uint32 * 2)(*key)
+        o = (C.c_uint32 * 4)()
+        self._chk(self.lib.mcgpu_probe_philox(self.ctx, c, k, o), "mcgpu_probe_philox")
+        return [int(v) for v in o]
+
+    def probe_packet_rand(self, seed, packet, n):
+        out = np.zeros(n, np.float32)
+        self._chk(self.lib.mcgpu_probe_packet_rand(self.ctx, C.c_uint64(seed), C.c_uint64(packet),
+                                                   C.c_int(n), _p(out, C.c_float)),
+                  "mcgpu_probe_packet_rand")
+        return out

@@ -1,0 +1,102 @@
+"""Generates tests/golden/geom_*.npz from the REFERENCE's own routines compiled
+in oracle/_ref (see oracle/ref_build/Makefile).  Run in the build container,
+where /root/reference exists:
+
+    python tests/golden/make_golden.py
+
+Each file holds inputs and the reference's outputs (data only) for:
+define_cylindrical_grid + build_cylindrical_cell_mapping (grid tables),
+cross_cylindrical_cell along random walks, index_cell_cyl, test_exit_grid_cyl,
+move_to_grid_cyl, pos_em_cell_cyl, init_tab_Temp, init_lambda and the
+constants.  One process per configuration (the reference allocates its module
+arrays once).
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    "ref41": "M.ref41()",
+    "pascucci": "M.pascucci()",
+    "small2d": "M.small()",
+    "small3d": "M.small(n_rad=12, nz=6, n_az=8, l3D=True)",
+}
+
+
+def make_one(name, expr, n_rays=400, n_steps=30, seed=7):
+    from mcfost_amd.host import model as M
+    from oracle import RefGeom
+
+    cfg = eval(expr)
+    ref = RefGeom()
+    ref.setup_grid(cfg)
+    g = ref.get_grid()
+    out = {("grid_" + k): v for k, v in g.items()}
+    rng = np.random.default_rng(seed)
+    n_cells = ref.n_cells
+    # emission positions inside random real cells
+    icell = rng.integers(1, n_cells + 1, n_rays).astype(np.int32)
+    r1, r2, r3 = (rng.random(n_rays).astype(np.float32) for _ in range(3))
+    x, y, z = ref.pos_em_cell(icell, r1, r2, r3)
+    out.update(pos_icell=icell, pos_r1=r1, pos_r2=r2, pos_r3=r3, pos_x=x, pos_y=y, pos_z=z)
+    out["index_icell"] = ref.index_cell(x, y, z)
+    # also points in the hole, above the disk and outside
+    rmax = np.sqrt(g["Rmax2"])
+    xs = rng.uniform(-1.3 * rmax, 1.3 * rmax, n_rays)
+    ys = rng.uniform(-1.3 * rmax, 1.3 * rmax, n_rays)
+    zs = rng.uniform(-1.5, 1.5, n_rays) * g["zmax"].max()
+    out.update(idx2_x=xs, idx2_y=ys, idx2_z=zs, idx2_icell=ref.index_cell(xs, ys, zs))
+    # random walks
+    w = rng.uniform(-1, 1, n_rays)
+    ph = rng.uniform(0, 2 * np.pi, n_rays)
+    s = np.sqrt(1 - w * w)
+    u, v = s * np.cos(ph), s * np.sin(ph)
+    cur = [x, y, z, out["index_icell"].copy()]
+    walk = []
+    for step in range(n_steps):
+        x1, y1, z1, nxt, l = ref.cross_cell(cur[0], cur[1], cur[2], u, v, w, cur[3])
+        ex = ref.test_exit_grid(nxt, x1, y1, z1)
+        walk.append(np.stack([cur[0], cur[1], cur[2], u, v, w, cur[3].astype(float), x1, y1, z1,
+                              nxt.astype(float), l, ex.astype(float)], axis=1))
+        keep = ex == 0
+        cur = [x1[keep], y1[keep], z1[keep], nxt[keep]]
+        u, v, w = u[keep], v[keep], w[keep]
+        if keep.sum() == 0:
+            break
+    out["walk"] = np.concatenate(walk, axis=0)
+    # move_to_grid from outside
+    n_m = 400
+    R = 3.0 * rmax
+    cz = rng.uniform(-1, 1, n_m)
+    ph = rng.uniform(0, 2 * np.pi, n_m)
+    px, py, pz = R * np.sqrt(1 - cz * cz) * np.cos(ph), R * np.sqrt(1 - cz * cz) * np.sin(ph), R * cz
+    tx, ty, tz = (rng.uniform(-1, 1, n_m) * rmax * 0.8 for _ in range(3))
+    tz = tz * (g["zmax"].max() / rmax)
+    d = np.stack([tx - px, ty - py, tz - pz], 1)
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    # half of the rays point in random directions (most of them miss the grid)
+    rd = rng.normal(size=(n_m // 2, 3))
+    d[: n_m // 2] = rd / np.linalg.norm(rd, axis=1)[:, None]
+    mx, my, mz, mic, mli = ref.move_to_grid(px, py, pz, d[:, 0], d[:, 1], d[:, 2])
+    out.update(mtg_in=np.stack([px, py, pz, d[:, 0], d[:, 1], d[:, 2]], 1),
+               mtg_out=np.stack([mx, my, mz, mic.astype(float), mli.astype(float)], 1))
+    out["tab_Temp"] = ref.init_tab_temp(cfg.n_T, cfg.T_min, cfg.T_max)
+    lam = ref.init_lambda(cfg.n_lambda, cfg.lambda_min, cfg.lambda_max)
+    out.update(lam=lam[0], lam_inf=lam[1], lam_sup=lam[2], lam_delta=lam[3])
+    out["constants"] = ref.constants()
+    np.savez_compressed(os.path.join(HERE, f"geom_{name}.npz"), **out)
+    print(name, "walk rows", out["walk"].shape[0])
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1:
+        make_one(sys.argv[1], CONFIGS[sys.argv[1]])
+    else:
+        for name in CONFIGS:
+            subprocess.check_call([sys.executable, __file__, name])

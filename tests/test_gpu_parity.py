@@ -1,0 +1,245 @@
+"""Parity tests proper: the HIP engine, called through the C-ABI
+(include/mcgpu.h), against the CPU oracle on the same seeded inputs, against
+the committed golden vectors of the reference's own geometry routines, and --
+at BASELINE sizes -- through size-independent properties.
+
+Tolerances (stated here, used below):
+  * integer / index outputs (cell ids, SED packet counts, n_sent, event
+    counters): bit-exact;
+  * FP64 positions and path lengths of ONE operator call: |diff| <= 1e-12 *
+    (|x|+|y|+|z|+l)  (the device contracts a*b+c into FMA, the reference
+    build does not);
+  * absorbed energy per cell, frozen-temperature mode (same packets, same
+    random numbers, different summation order and FMA): rtol 1e-9;
+  * live Bjorkman & Wood mode is not bit-reproducible by construction (the
+    reference's own threads race the same way): statistical gate = relative
+    RMS of Tdust over cells with T > 1.01 T_min  <= 3 * sigma_MC(N) and the
+    reference's own gate p75(|dT|/T) < 5 % (test_suite/test_mcfost.py:88).
+"""
+import numpy as np
+import pytest
+
+from helpers import CONFIGS, load_golden, mc_similar, rel_rms
+from mcfost_amd.host import model as M
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(model, n_tot):
+    from mcfost_amd.engine import Engine
+    return Engine(model, n_tot)
+
+
+def _oracle(model, n_tot):
+    from oracle import Oracle
+    return Oracle(model, n_tot)
+
+
+@pytest.fixture(scope="module")
+def small_pair(small_model):
+    return small_model, _engine(small_model, 2e4), _oracle(small_model, 2e4)
+
+
+def test_native_library_is_loaded(small_pair):
+    import mcfost_amd.engine as eng
+    assert eng._lib is not None and "libmcfost_hip.so" in eng.LIB_PATH
+    maps = open("/proc/self/maps").read()
+    assert "libmcfost_hip.so" in maps
+
+
+def test_philox_on_device(small_pair):
+    m, e, o = small_pair
+    assert e.probe_philox([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert e.probe_philox([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert e.probe_philox([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+    for seed, pk in ((1, 0), (269753, 12345678901), (2 ** 40 + 3, 2 ** 33 + 5)):
+        dev = e.probe_packet_rand(seed, pk, 23)
+        ref = np.array([o.packet_rand(seed, pk, n) for n in range(23)], np.float32)
+        assert np.array_equal(dev, ref)
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_device_geometry_against_reference_golden(name):
+    """cross_cylindrical_cell / index_cell_cyl evaluated by the device code on
+    the reference's golden walks."""
+    cfg = CONFIGS[name](M)
+    m = M.build_model(cfg)
+    e = _engine(m, 1e5)
+    g = load_golden(name)
+    wk = g["walk"]
+    x1, y1, z1, nxt, l = e.probe_cross_cell(wk[:, 0], wk[:, 1], wk[:, 2], wk[:, 3], wk[:, 4], wk[:, 5],
+                                            wk[:, 6].astype(np.int32))
+    assert np.array_equal(nxt, wk[:, 10].astype(np.int32))
+    scale = np.abs(wk[:, 0]) + np.abs(wk[:, 1]) + np.abs(wk[:, 2]) + wk[:, 11]
+    for a, col in ((x1, 7), (y1, 8), (z1, 9), (l, 11)):
+        assert np.all(np.abs(a - wk[:, col]) <= 1e-12 * scale), col
+    assert np.array_equal(e.probe_index_cell(g["pos_x"], g["pos_y"], g["pos_z"]), g["index_icell"])
+    assert np.array_equal(e.probe_index_cell(g["idx2_x"], g["idx2_y"], g["idx2_z"]), g["idx2_icell"])
+    e.close()
+
+
+def _frozen_parity(m, n, seed, n_prior=2000, **kw):
+    e, o = _engine(m, n), _oracle(m, n)
+    prior = o.run_thermal(n_prior, seed=1)["E_abs"]
+    a = e.run_thermal(n, seed=seed, frozen=True, E_prior=prior, **kw)
+    b = o.run_thermal(n, seed=seed, frozen=True, E_prior=prior, n_threads=8)
+    assert a["counters"] == b["counters"]
+    assert np.array_equal(a["n_sent"], b["n_sent"])
+    for t in (0, 4, 5, 6, 7, 8):                      # I and packet counts: exact
+        assert np.array_equal(a["sed"][t], b["sed"][t]), t
+    assert np.allclose(a["sed"][1:4], b["sed"][1:4], rtol=1e-5, atol=1e-5 * max(1.0, np.abs(b["sed"][0]).max()))
+    assert np.allclose(a["E_abs"], b["E_abs"], rtol=1e-9, atol=1e-12 * b["E_abs"].max())
+    Ta, Tb = e.temp_finale(a["E_abs"]), o.temp_finale(b["E_abs"])
+    assert np.allclose(Ta, Tb, rtol=2e-6)
+    e.close()
+    return a, b
+
+
+def test_frozen_parity_small_2d(small_model):
+    _frozen_parity(small_model, 20000, seed=7)
+
+
+def test_frozen_parity_small_3d():
+    m = M.build_model(M.small(n_rad=12, nz=6, n_az=8, l3D=True))
+    _frozen_parity(m, 20000, seed=8)
+
+
+def test_frozen_parity_unpolarised_isotropic_hg():
+    """Pascucci-style isotropic scattering, HG branch and no Stokes update."""
+    m = M.build_model(M.small(lisotropic=True, lsepar_pola=False))
+    _frozen_parity(m, 10000, seed=9)
+    m = M.build_model(M.small(aniso_method=2, lsepar_pola=False))
+    _frozen_parity(m, 10000, seed=10)
+
+
+def test_frozen_parity_per_wavelength_phase_function(small_model):
+    import copy
+    m = copy.copy(small_model)
+    m.p_lambda_fixed = 0
+    _frozen_parity(m, 10000, seed=11)
+
+
+def test_frozen_parity_dark_zone(small_model):
+    """Dark-zone mirror (optical_depth.f90:104-112) with synthetic flags on the
+    densest midplane cells."""
+    import copy
+    m = copy.copy(small_model)
+    dz = np.zeros(m.n_cells, np.uint8)
+    kf = m.kappa_factor.reshape(m.cfg.nz, m.cfg.n_rad)
+    flags = dz.reshape(m.cfg.nz, m.cfg.n_rad)
+    flags[0:2, 4:12] = 1
+    assert kf[0, 4] > 0
+    m.l_dark_zone = dz
+    a, b = _frozen_parity(m, 20000, seed=12)
+    assert a["counters"]["dark_mirrors"] > 0
+    assert np.all(a["E_abs"][dz == 1] == 0)
+
+
+def test_frozen_parity_disk_emission(small_model):
+    """emit_packet's disk branch: select_cellule + pos_em_cell + isotropic
+    direction (dust_transfer.f90:1121-1142)."""
+    import copy
+    m = copy.copy(small_model)
+    rng = np.random.default_rng(0)
+    E_cell = rng.random((m.n_lambda, m.n_cells)) * m.kappa_factor[None, :]
+    pe = np.zeros((m.n_lambda, m.n_cells + 1))
+    pe[:, 1:] = np.cumsum(E_cell, axis=1)
+    pe /= pe[:, -1:]
+    m.prob_E_cell = pe.reshape(-1)
+    m.frac_E_stars = np.full(m.n_lambda, 0.4)
+    _frozen_parity(m, 10000, seed=13)
+
+
+def test_frozen_parity_ref41_full_grid(ref41_model):
+    """BASELINE config 2 grid (100 x 70, 50 wavelengths) at an oracle-sized
+    packet count."""
+    _frozen_parity(ref41_model, 100000, seed=14, n_prior=20000)
+
+
+def test_independent_of_launch_geometry(small_model):
+    """Counter-based per-packet streams: the result must not depend on how
+    many workgroups/lanes share the work (frozen mode)."""
+    e, o = _engine(small_model, 1e4), _oracle(small_model, 1e4)
+    prior = o.run_thermal(2000, seed=1)["E_abs"]
+    a = e.run_thermal(10000, seed=3, frozen=True, E_prior=prior, grid_blocks=1, block_threads=64)
+    b = e.run_thermal(10000, seed=3, frozen=True, E_prior=prior, grid_blocks=64, block_threads=256)
+    assert a["counters"] == b["counters"] and np.array_equal(a["sed"][4], b["sed"][4])
+    assert np.allclose(a["E_abs"], b["E_abs"], rtol=1e-10, atol=0)
+    e.close()
+
+
+def test_accumulate_is_linear(small_model):
+    """Two launches over adjacent packet ranges, accumulated on the device,
+    equal one launch over the union (linearity of the estimator)."""
+    e, o = _engine(small_model, 1e4), _oracle(small_model, 1e4)
+    prior = o.run_thermal(2000, seed=1)["E_abs"]
+    whole = e.run_thermal(9000, seed=5, frozen=True, E_prior=prior)
+    e.run_thermal(4000, seed=5, frozen=True, first_packet=0)
+    parts = e.run_thermal(5000, seed=5, frozen=True, first_packet=4000, accumulate=True)
+    assert parts["counters"] == whole["counters"] and np.array_equal(parts["sed"][4], whole["sed"][4])
+    assert np.allclose(parts["E_abs"], whole["E_abs"], rtol=1e-10, atol=0)
+    e.close()
+
+
+def test_live_mode_statistical_parity_ref41(ref41_model):
+    """The reference algorithm proper (live immediate re-emission)."""
+    m = ref41_model
+    n = 1_000_000
+    e, o = _engine(m, n), _oracle(m, n)
+    a = e.run_thermal(n, seed=21)
+    b = o.run_thermal(n, seed=22, n_threads=8)         # independent noise realisation
+    ca, cb = a["counters"], b["counters"]
+    assert ca["packets"] == n and ca["escaped"] + ca["killed_star"] == n
+    for k in ("crossings", "flights", "scatterings", "absorptions"):
+        assert abs(ca[k] / cb[k] - 1) < 0.01, k
+    Ta, Tb = e.temp_finale(a["E_abs"]), o.temp_finale(b["E_abs"])
+    T_floor = 1.01 * m.cfg.T_min
+    # sigma_MC(N) ~ 1.7 % sqrt(1.28e5/N) for one run; two independent runs -> sqrt(2)
+    sigma = 0.017 * np.sqrt(1.28e5 / n) * np.sqrt(2.0)
+    rms = rel_rms(Ta, Tb, T_floor)
+    ok, p75 = mc_similar(Tb, Ta, 0.05, mask_threshold=T_floor)
+    assert ok, p75
+    assert rms <= 3 * sigma, (rms, sigma)
+    # thermal SED: the reference's SED gate is p75 < 10 % (test_mcfost.py:104-109)
+    sa, sb = a["sed"][0].sum(axis=(0, 1)), b["sed"][0].sum(axis=(0, 1))
+    okS, p75S = mc_similar(sb, sa, 0.10, mask_threshold=200.0)
+    assert okS, p75S
+    e.close()
+
+
+def test_full_size_properties_ref41(ref41_model):
+    """BASELINE config 2 at a GPU-sized packet count (1e7): properties that do
+    not need the oracle."""
+    m = ref41_model
+    n = 10_000_000
+    e = _engine(m, n)
+    a = e.run_thermal(n, seed=31)
+    c = a["counters"]
+    assert c["packets"] == n and c["escaped"] + c["killed_star"] == n          # energy conservation
+    assert a["n_sent"].sum() == n and a["sed"][4].sum() == c["escaped"]
+    assert c["flights"] == c["scatterings"] + c["absorptions"] + c["escaped"] + c["killed_star"]
+    assert np.allclose(a["sed"][0], a["sed"][5:9].sum(axis=0))
+    # emitted wavelengths follow the stellar CDF
+    cdf = np.cumsum(a["n_sent"]) / n
+    assert np.max(np.abs(cdf - m.spectre_emission_cumul[1:])) < 1e-3
+    # two different seeds agree within Monte Carlo noise
+    b = e.run_thermal(n, seed=32)
+    Ta, Tb = e.temp_finale(a["E_abs"]), e.temp_finale(b["E_abs"])
+    sigma = 0.017 * np.sqrt(1.28e5 / n) * np.sqrt(2.0)
+    assert rel_rms(Ta, Tb, 1.01 * m.cfg.T_min) <= 3 * sigma
+    # device Temp_finale on the device accumulator == on the fetched array
+    assert np.array_equal(e.temp_finale(), Tb)
+    e.close()
+
+
+def test_device_accumulator_is_visible_to_torch(small_model):
+    import torch
+    e = _engine(small_model, 1e4)
+    res = e.run_thermal(5000, seed=2)
+    acc, cnt = e.device_accumulators()
+    assert acc.is_cuda and acc.dtype == torch.float64
+    n_c = small_model.n_cells
+    assert np.array_equal(acc[:n_c].cpu().numpy(), res["E_abs"])
+    assert int(cnt[0].item()) == 5000
+    e.close()

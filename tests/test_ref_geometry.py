@@ -1,0 +1,144 @@
+"""Pins the oracle's geometry and the host grid builder to the REFERENCE:
+golden vectors produced by the reference's own routines (oracle/_ref, built
+from /root/reference/src by oracle/ref_build/Makefile; generator:
+tests/golden/make_golden.py).  Bit-exact comparisons: the C oracle is compiled
+without FMA contraction, like the reference build."""
+import numpy as np
+import pytest
+
+from helpers import CONFIGS, load_golden
+from mcfost_amd.host import model as M
+from oracle import Oracle
+
+NAMES = list(CONFIGS)
+
+
+@pytest.fixture(scope="module", params=NAMES)
+def case(request):
+    cfg = CONFIGS[request.param](M)
+    m = M.build_model(cfg)
+    return request.param, cfg, m, Oracle(m, 1e5), load_golden(request.param)
+
+
+def test_grid_tables_match_reference(case):
+    """define_cylindrical_grid + build_cylindrical_cell_mapping
+    (cylindrical_grid.f90:45-676) restated by mcfost_amd.host.model."""
+    name, cfg, m, orc, gold = case
+    g = m.grid
+    for k in ("r_lim", "r_lim_2", "zmax", "z_lim", "tan_phi_lim", "volume", "r_grid", "z_grid",
+              "cell_map_i", "cell_map_j", "cell_map_k", "lexit_cell"):
+        assert np.array_equal(np.asarray(g[k]), gold["grid_" + k]), k
+    # cell_map: slots the reference never assigns (j = 0 in 3D) are undefined there
+    a, b = np.asarray(g["cell_map"]), gold["grid_cell_map"]
+    assigned = a > 0
+    assert np.array_equal(a[assigned], b[assigned])
+    assert g["Rmax2"] == float(gold["grid_Rmax2"])
+
+
+def test_oracle_cell_mapping_matches_reference(case):
+    import ctypes as C
+    name, cfg, m, orc, gold = case
+    g = m.grid
+    n_tot = g["ntot2"]
+    cm = np.zeros(g["cell_map"].size, np.int32)
+    ci, cj, ck, le = (np.zeros(n_tot, np.int32) for _ in range(4))
+    p = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+    rc = orc.lib.oracle_build_cell_mapping(g["n_rad"], g["nz"], g["n_az"], g["l3D"], p(cm), p(ci), p(cj),
+                                           p(ck), p(le))
+    assert rc == 0
+    assert np.array_equal(ci, gold["grid_cell_map_i"])
+    assert np.array_equal(cj, gold["grid_cell_map_j"])
+    assert np.array_equal(ck, gold["grid_cell_map_k"])
+    assert np.array_equal(le, gold["grid_lexit_cell"])
+    assigned = cm > 0
+    assert np.array_equal(cm[assigned], gold["grid_cell_map"][assigned])
+
+
+def test_temperature_and_wavelength_grids(case):
+    """init_tab_Temp (Temperature.f90:23) and init_lambda (wavelengths.f90:25)."""
+    name, cfg, m, orc, gold = case
+    assert np.array_equal(m.tab_Temp, gold["tab_Temp"])
+    assert np.array_equal(m.lam, gold["lam"])
+    assert np.array_equal(m.delta_lam, gold["lam_delta"])
+
+
+def test_constants(case):
+    name, cfg, m, orc, gold = case
+    c = gold["constants"]
+    assert c[0] == M.PI and c[1] == M.HP and c[2] == M.KB and c[3] == M.C_LIGHT
+    assert c[4] == M.THERMAL_CONST and c[5] == M.AU_TO_CM and c[6] == M.RSUN_TO_AU
+    assert c[7] == M.TINY_REAL and c[13] == M.CUTOFF
+    assert abs(c[12] / M.MSUN_TO_G - 1) < 1e-15
+
+
+def test_pos_em_cell(case):
+    """pos_em_cell_cyl (cylindrical_grid.f90:1415)."""
+    name, cfg, m, orc, gold = case
+    x, y, z = orc.pos_em_cell(gold["pos_icell"], gold["pos_r1"], gold["pos_r2"], gold["pos_r3"])
+    assert np.array_equal(x, gold["pos_x"])
+    assert np.array_equal(y, gold["pos_y"])
+    assert np.array_equal(z, gold["pos_z"])
+
+
+def test_index_cell(case):
+    """index_cell_cyl (cylindrical_grid.f90:833)."""
+    name, cfg, m, orc, gold = case
+    assert np.array_equal(orc.index_cell(gold["pos_x"], gold["pos_y"], gold["pos_z"]), gold["index_icell"])
+    assert np.array_equal(gold["index_icell"], gold["pos_icell"])  # emission point lies in its cell
+    assert np.array_equal(orc.index_cell(gold["idx2_x"], gold["idx2_y"], gold["idx2_z"]), gold["idx2_icell"])
+
+
+def test_cross_cell_walks(case):
+    """cross_cylindrical_cell (cylindrical_grid.f90:918) and test_exit_grid_cyl
+    (:680) along random walks through real and virtual cells."""
+    name, cfg, m, orc, gold = case
+    wk = gold["walk"]
+    x1, y1, z1, nxt, l = orc.cross_cell(wk[:, 0], wk[:, 1], wk[:, 2], wk[:, 3], wk[:, 4], wk[:, 5],
+                                        wk[:, 6].astype(np.int32))
+    assert np.array_equal(x1, wk[:, 7])
+    assert np.array_equal(y1, wk[:, 8])
+    assert np.array_equal(z1, wk[:, 9])
+    assert np.array_equal(nxt, wk[:, 10].astype(np.int32))
+    assert np.array_equal(l, wk[:, 11])
+    ex = orc.test_exit_grid(nxt, x1, y1, z1)
+    assert np.array_equal(ex, wk[:, 12].astype(np.int32))
+    # the walks visit virtual cells and, in 3D, azimuthal walls
+    assert (wk[:, 6] > m.n_cells).any()
+
+
+def test_move_to_grid(case):
+    """move_to_grid_cyl (cylindrical_grid.f90:1284)."""
+    name, cfg, m, orc, gold = case
+    i, o = gold["mtg_in"], gold["mtg_out"]
+    x, y, z, ic, li = orc.move_to_grid(i[:, 0], i[:, 1], i[:, 2], i[:, 3], i[:, 4], i[:, 5])
+    assert np.array_equal(li, o[:, 4].astype(np.int32))
+    hit = li == 1
+    assert hit.any() and (~hit).any()
+    assert np.array_equal(x[hit], o[hit, 0]) and np.array_equal(y[hit], o[hit, 1])
+    assert np.array_equal(z[hit], o[hit, 2])
+    assert np.array_equal(ic[hit], o[hit, 3].astype(np.int32))
+
+
+def test_live_reference_library_if_built(case):
+    """Same check against the compiled reference itself when oracle/_ref is
+    present (it is built by __graft_entry__.build() where /root/reference
+    exists and travels to the GPU box as a built .so)."""
+    import os
+    import subprocess
+    import sys
+    from oracle import ref_lib_path
+    name, cfg, m, orc, gold = case
+    if not os.path.exists(ref_lib_path()):
+        pytest.skip("oracle/_ref not built")
+    code = (
+        "import sys, numpy as np; sys.path[:0]=[%r, %r]\n"
+        "from helpers import CONFIGS, load_golden\n"
+        "from mcfost_amd.host import model as M\n"
+        "from oracle import RefGeom\n"
+        "cfg = CONFIGS[%r](M); r = RefGeom(); r.setup_grid(cfg); g = load_golden(%r); wk = g['walk']\n"
+        "o = r.cross_cell(wk[:,0],wk[:,1],wk[:,2],wk[:,3],wk[:,4],wk[:,5],wk[:,6].astype(np.int32))\n"
+        "assert all(np.array_equal(a, b) for a, b in zip(o, (wk[:,7],wk[:,8],wk[:,9],wk[:,10].astype(np.int32),wk[:,11])))\n"
+        "print('ok')\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                           os.path.dirname(os.path.abspath(__file__)), name, name)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr
