@@ -88,6 +88,17 @@ int mcgpu_set_grid_cyl(mcgpu_ctx *ctx, int n_rad, int nz, int n_az, int l3D,
                        const int *cell_map_j, const int *cell_map_k,
                        const int *lexit_cell);
 
+/*
+ * 3D grids only.  on != 0 (default): a packet that crosses the midplane lands
+ * at z = sign(grid_prec, w), i.e. the reference's own z1 == 0 correction
+ * (cylindrical_grid.f90:1158-1165) applied to every rounding residue of
+ * z0 + t*w.  In the reference the SIGN of that residue -- the last ulp of the
+ * product, compiler (FMA) and libm dependent -- decides on which side of the
+ * midplane the packet is for the next cell.  on == 0 reproduces the literal
+ * arithmetic of a reference built without FMA contraction.
+ */
+int mcgpu_set_midplane_snap(mcgpu_ctx *ctx, int on);
+
 /* Stars: type star_type (parameters.f90:230-242); icell/out_model from
  * stars_cell_indices (stars.f90:789-808). Lengths in AU. */
 int mcgpu_set_stars(mcgpu_ctx *ctx, int n_stars, const double *x,

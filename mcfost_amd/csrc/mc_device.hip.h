@@ -18,7 +18,9 @@
 // expression (file:line cited at each routine) so that it can be checked
 // against the CPU oracle.
 #pragma once
+#ifndef MCGPU_LANE_EMULATION  // tests/emu compiles this header for one emulated lane on the CPU
 #include <hip/hip_runtime.h>
+#endif
 #include <stdint.h>
 
 namespace mcgpu {
@@ -71,6 +73,8 @@ struct DevModel {
   double L_packet_th;
   // sed
   int N_thet, N_phi, sym_c, sym_a;
+  // 3D midplane crossings land at sign(grid_prec, w) (see include/mcgpu.h)
+  int midplane_snap;
 };
 
 struct RunArgs {
@@ -84,6 +88,8 @@ struct RunArgs {
   unsigned long long* counters;  // [8]
   unsigned long long* next_packet;  // work counter
   int* err;
+  int inner_iters;  // crossings attempted between two interaction phases
+  int flags;        // diagnostics: bit 0 = skip the E_abs deposits (timing experiments only)
 };
 
 // ---------------------------------------------------------------------------
@@ -444,7 +450,12 @@ __device__ inline void cross_cell(const Lds& T, const DevModel& M, double x0, do
     l = t;
     x1 = x0 + t * u;
     y1 = y0 + t * v;
-    z1 = z0 + t * w;
+    // NOT fused: at the midplane zl = 0 has no grid_prec margin, so whether
+    // z1 comes out as exactly 0 (-> sign(grid_prec,w), :1158-1165) or as a
+    // rounding residue of either sign is decided by the rounding of t*w.
+    // The reference build (no FMA contraction) rounds the product first.
+    z1 = __dadd_rn(z0, __dmul_rn(t, w));
+    if (L3D && M.midplane_snap && (delta_zj == 2 || delta_zj == -2)) z1 = copysign(GRID_PREC, w);
     ri1 = ri0;
     zj1 = zj0 + delta_zj;
     k1 = k0;
@@ -974,7 +985,7 @@ __global__ void __launch_bounds__(256) k_thermal(const DevModel M, const RunArgs
 
     // ---- FLIGHT: cell crossings (physical_length, optical_depth.f90:77-178)
 #pragma unroll 1
-    for (int it = 0; it < 8; ++it) {
+    for (int it = 0; it < A.inner_iters; ++it) {
       if (st == S_FLIGHT) {
         const int azj = zj < 0 ? -zj : zj;
         // test_exit_grid_cyl (cylindrical_grid.f90:680-704) in closed form
@@ -1022,7 +1033,7 @@ __global__ void __launch_bounds__(256) k_thermal(const DevModel M, const RunArgs
             const double tau = l * opacity;
             if (tau > extr) {
               const double lc = l * (extr / tau);
-              if (real_cell) atomic_add_f64(&A.E_abs[ic], T.kabs[lambda - 1] * lc * S[0]);
+              if (real_cell && !(A.flags & 1)) atomic_add_f64(&A.E_abs[ic], T.kabs[lambda - 1] * lc * S[0]);
               x = x + lc * u;
               y = y + lc * v;
               z = z + lc * w;
@@ -1030,7 +1041,7 @@ __global__ void __launch_bounds__(256) k_thermal(const DevModel M, const RunArgs
               st = S_INTERACT;
             } else {
               extr = extr - tau;
-              if (real_cell) atomic_add_f64(&A.E_abs[ic], T.kabs[lambda - 1] * l * S[0]);
+              if (real_cell && !(A.flags & 1)) atomic_add_f64(&A.E_abs[ic], T.kabs[lambda - 1] * l * S[0]);
               if (DARK) { xo = x; yo = y; zo = z; ri_o = ri; zj_o = zj; k_o = k; }
               x = x1; y = y1; z = z1;
               ri = ri1; zj = zj1; k = k1;

@@ -8,6 +8,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -81,6 +82,7 @@ extern "C" int mcgpu_create(int device, mcgpu_ctx** out) {
     return MCGPU_ERR_HIP;
   }
   ctx->stream = ctx->own_stream;
+  ctx->M.midplane_snap = 1;
   if (hipMalloc((void**)&ctx->d_counters, 16 * sizeof(unsigned long long)) != hipSuccess ||
       hipMalloc((void**)&ctx->d_err, sizeof(int)) != hipSuccess) {
     delete ctx;
@@ -175,6 +177,12 @@ extern "C" int mcgpu_set_grid_cyl(mcgpu_ctx* ctx, int n_rad, int nz, int n_az, i
   if ((rc = upload(ctx, cell_map_k, (size_t)ntot2, &c))) return rc;
   ctx->d_cmi = (int*)a; ctx->d_cmj = (int*)b; ctx->d_cmk = (int*)c;
   ctx->have_grid = true;
+  return MCGPU_OK;
+}
+
+extern "C" int mcgpu_set_midplane_snap(mcgpu_ctx* ctx, int on) {
+  if (!ctx) return MCGPU_ERR_ARG;
+  ctx->M.midplane_snap = on ? 1 : 0;
   return MCGPU_OK;
 }
 
@@ -377,6 +385,11 @@ extern "C" int mcgpu_launch_thermal(mcgpu_ctx* ctx, const mcgpu_run_opts* o) {
   A.counters = ctx->d_counters;
   A.next_packet = ctx->d_counters + 8;
   A.err = ctx->d_err;
+  // tuning / diagnostic knobs (environment; defaults are the shipped configuration)
+  A.inner_iters = 8;
+  A.flags = 0;
+  if (const char* e = getenv("MCGPU_INNER_ITERS")) { int v = atoi(e); if (v >= 1 && v <= 4096) A.inner_iters = v; }
+  if (const char* e = getenv("MCGPU_DIAG_FLAGS")) A.flags = atoi(e);
   const int threads = o->block_threads > 0 ? o->block_threads : 256;
   if (threads % 64 || threads > 256) return fail(ctx, MCGPU_ERR_ARG, "block_threads must be 64..256, multiple of 64");
   int blocks = o->grid_blocks;

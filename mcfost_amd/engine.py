@@ -31,7 +31,7 @@ ABI_SYMBOLS = (
     "mcgpu_set_E_prior", "mcgpu_run_thermal", "mcgpu_launch_thermal", "mcgpu_sync",
     "mcgpu_device_accumulators", "mcgpu_fetch", "mcgpu_set_stream", "mcgpu_temp_finale",
     "mcgpu_probe_cross_cell", "mcgpu_probe_index_cell", "mcgpu_probe_philox",
-    "mcgpu_probe_packet_rand",
+    "mcgpu_probe_packet_rand", "mcgpu_set_midplane_snap",
 )
 
 
@@ -127,6 +127,8 @@ class Engine:
             _p(_a(g["cell_map"], i32), C.c_int), _p(_a(g["cell_map_i"], i32), C.c_int),
             _p(_a(g["cell_map_j"], i32), C.c_int), _p(_a(g["cell_map_k"], i32), C.c_int),
             _p(_a(g["lexit_cell"], i32), C.c_int)), "mcgpu_set_grid_cyl")
+        self._chk(L.mcgpu_set_midplane_snap(self.ctx, C.c_int(int(getattr(m, "midplane_snap", 1)))),
+                  "mcgpu_set_midplane_snap")
         st = np.asarray(m.stars, d)
         cols = [_a(st[:, q], d) for q in range(4)]
         self._chk(L.mcgpu_set_stars(

@@ -498,6 +498,7 @@ class Model:
     rho_dust: np.ndarray
     l_dark_zone: Optional[np.ndarray] = None
     p_lambda_fixed: int = 1
+    midplane_snap: int = 1  # engine default (include/mcgpu.h: mcgpu_set_midplane_snap)
     extra: dict = field(default_factory=dict)
 
     @property

@@ -84,7 +84,7 @@ class _Model(C.Structure):
         ("CDF_E_star", _dp), ("prob_E_cell", _dp), ("L_packet_th", C.c_double),
         ("T_min", C.c_float),
         ("N_thet", C.c_int), ("N_phi", C.c_int), ("l_sym_centrale", C.c_int),
-        ("l_sym_axiale", C.c_int),
+        ("l_sym_axiale", C.c_int), ("midplane_snap", C.c_int),
     ]
 
 
@@ -172,6 +172,7 @@ class Oracle:
         s.T_min = float(cfg.T_min)
         s.N_thet, s.N_phi = cfg.N_thet, cfg.N_phi
         s.l_sym_centrale, s.l_sym_axiale = int(cfg.l_sym_centrale), int(cfg.l_sym_axiale)
+        s.midplane_snap = int(getattr(m, "midplane_snap", 0))
         return s
 
     # -- packet loop -------------------------------------------------------

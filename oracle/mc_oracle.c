@@ -409,6 +409,8 @@ void oracle_cross_cylindrical_cell(const oracle_model *m, double x0, double y0,
     ri1 = ri0;
     zj1 = zj0 + delta_zj;
     k1 = k0;
+    if (l3D && m->midplane_snap && (delta_zj == 2 || delta_zj == -2))
+      *z1 = sign_d(GRID_PREC, w); /* see mc_oracle.h: midplane_snap */
   } else {
     l = t_phi;
     delta_vol = correct_plus * t_phi;
@@ -839,7 +841,7 @@ typedef struct {
   uint64_t cnt[ORACLE_N_COUNTERS];
   double qscale;   /* nb_proc * n_replicas */
   rng_t rng;
-} worker_t;
+} __attribute__((aligned(256))) worker_t; /* one cache-line group per thread: no false sharing */
 
 /* physical_length (optical_depth.f90:21-182), letape_th branch only */
 static void physical_length(worker_t *W, int lambda, const double Stokes[4],
@@ -1127,7 +1129,9 @@ int oracle_run_thermal(const oracle_model *m, const oracle_opts *o,
   int *xT_t = (int *)malloc(nc * nth * sizeof(int));
   double *sed_t = (double *)calloc(nsed * nth, sizeof(double));
   double *ns_t = (double *)calloc((size_t)m->n_lambda * nth, sizeof(double));
-  worker_t *Ws = (worker_t *)calloc(nth, sizeof(worker_t));
+  worker_t *Ws = NULL;
+  if (posix_memalign((void **)&Ws, 256, (size_t)nth * sizeof(worker_t))) Ws = NULL;
+  if (Ws) memset(Ws, 0, (size_t)nth * sizeof(worker_t));
   if (!E_t || !xT_t || !sed_t || !ns_t || !Ws) return 22;
   for (size_t q = 0; q < nc * nth; ++q) xT_t[q] = 2; /* thermal_emission.f90:119 */
   int err = 0;

@@ -115,6 +115,15 @@ typedef struct {
   /* ---- SED binning (output.f90:294-597) ---- */
   int N_thet, N_phi;
   int l_sym_centrale, l_sym_axiale;
+
+  /* 0 = reference-literal arithmetic (pinned bit-for-bit to oracle/_ref).
+   * 1 = after a 3D crossing of the midplane (zlim = 0, no grid_prec margin)
+   *     put z1 at sign(grid_prec, w): the reference's own correction for
+   *     z1 == 0 (cylindrical_grid.f90:1158-1165) applied to every rounding
+   *     residue of z0 + t*w, whose SIGN is otherwise decided by the last ulp
+   *     (FMA or not, libm) and can leave the packet on the wrong side of the
+   *     midplane for one cell.  The engine's default; see DESIGN.md. */
+  int midplane_snap;
 } oracle_model;
 
 /* Run options. */

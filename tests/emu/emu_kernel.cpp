@@ -1,0 +1,119 @@
+// emu_kernel.cpp -- TEST INFRASTRUCTURE: compiles the DEVICE source
+// (mcfost_amd/csrc/mc_device.hip.h) for the host with a one-lane emulation of
+// the few HIP builtins it uses, so that the kernel's control flow can be
+// debugged and regression-tested against the oracle without a GPU.  This is
+// not a CPU path of the product: nothing in mcfost_amd/ references it, it is
+// built only by tests/test_kernel_emulation.py, and it runs one lane.
+#define MCGPU_LANE_EMULATION 1
+#define _GNU_SOURCE 1
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <cmath>
+#include <vector>
+
+#define __device__
+#define __host__
+#define __global__
+#define __shared__
+#define __launch_bounds__(...)
+#define __ATOMIC_RELAXED_EMU 0
+#define __HIP_MEMORY_SCOPE_AGENT 0
+#define __hip_atomic_load(p, order, scope) (*(p))
+
+struct emu_dim3 { unsigned x, y, z; };
+static emu_dim3 threadIdx{0, 0, 0}, blockIdx{0, 0, 0}, blockDim{1, 1, 1}, gridDim{1, 1, 1};
+static inline unsigned long long __ballot(bool p) { return p ? 1ull : 0ull; }
+static inline int __ffsll(long long m) { return __builtin_ffsll(m); }
+static inline int __popcll(unsigned long long m) { return __builtin_popcountll(m); }
+template <class T> static inline T __shfl(T v, int) { return v; }
+template <class T> static inline T __shfl_down(T, int) { return T(0); }
+static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) {
+  unsigned long long o = *p; *p += v; return o;
+}
+#include <stdio.h>
+static double* g_trace_base = nullptr;
+static long g_trace_n = 0;
+static inline void unsafeAtomicAdd(double* p, double v) {
+  if (g_trace_base && p >= g_trace_base && p < g_trace_base + g_trace_n)
+    fprintf(stderr, "dep %ld %.17g\n", (long)(p - g_trace_base), v);
+  *p += v;
+}
+static inline void __syncthreads() {}
+static inline double __dmul_rn(double a, double b) { volatile double r = a * b; return r; }
+static inline double __dadd_rn(double a, double b) { volatile double r = a + b; return r; }
+using std::fabs; using std::floor; using std::sqrt; using std::log; using std::exp; using std::fmax;
+using std::fmin; using std::atan2; using std::acos; using std::cos; using std::copysign;
+
+namespace mcgpu { double lds_raw[1 << 18]; }
+
+#include "../../mcfost_amd/csrc/mc_device.hip.h"
+#include "../../oracle/mc_oracle.h"
+
+using namespace mcgpu;
+
+// oracle_model -> DevModel, as the setters of mcgpu.hip do
+extern "C" int emu_run_thermal(const oracle_model* m, const oracle_opts* o, const double* E_prior, double* E_abs,
+                               double* sed, double* n_sent, uint64_t* counters) {
+  DevModel M;
+  memset(&M, 0, sizeof(M));
+  M.n_rad = m->n_rad; M.nz = m->nz; M.n_az = m->n_az; M.l3D = m->l3D; M.n_cells = m->n_cells;
+  M.r_lim_2 = m->r_lim_2; M.zmax = m->zmax; M.tan_phi_lim = m->tan_phi_lim;
+  std::vector<double> ch(m->n_rad);
+  for (int i = 0; i < m->n_rad; ++i) ch[i] = m->nz >= 2 ? m->z_lim[i + m->n_rad] : m->zmax[i];
+  M.ch = ch.data();
+  M.zmaxmax = m->zmaxmax; M.Rmax2 = m->Rmax2; M.volume = m->volume;
+  M.n_stars = m->n_stars;
+  std::vector<double> sx(4 * m->n_stars);
+  std::vector<int> sc(4 * m->n_stars);
+  for (int s = 0; s < m->n_stars; ++s) {
+    sx[4 * s] = m->stars[s].x; sx[4 * s + 1] = m->stars[s].y; sx[4 * s + 2] = m->stars[s].z; sx[4 * s + 3] = m->stars[s].r;
+    int ic = m->stars[s].icell;
+    sc[4 * s] = m->cell_map_i[ic - 1]; sc[4 * s + 1] = m->cell_map_j[ic - 1]; sc[4 * s + 2] = m->cell_map_k[ic - 1];
+    sc[4 * s + 3] = m->stars[s].out_model;
+  }
+  M.star_xyzr = sx.data(); M.star_cell = sc.data();
+  M.n_lambda = m->n_lambda; M.kappa = m->kappa; M.kappa_abs = m->kappa_abs_LTE; M.albedo = m->albedo;
+  M.kappa_factor = m->kappa_factor;
+  bool any_dark = false;
+  if (m->l_dark_zone) for (int i = 0; i < m->n_cells; ++i) any_dark |= m->l_dark_zone[i] != 0;
+  M.dark = any_dark ? m->l_dark_zone : nullptr;
+  M.nang = m->nang_scatt; M.aniso_method = m->aniso_method; M.lisotropic = m->lisotropic;
+  M.p_lambda_fixed = m->p_lambda_fixed;
+  M.prob_s11 = m->prob_s11_pos; M.s12 = m->s12_o_s11; M.s22 = m->s22_o_s11; M.s33 = m->s33_o_s11;
+  M.s34 = m->s34_o_s11; M.s44 = m->s44_o_s11; M.tab_g = m->tab_g_pos;
+  M.n_T = m->n_T; M.log_Qcool = m->log_Qcool; M.cdf = m->kdB_dT_CDF; M.spec_cum = m->spectre_emission_cumul;
+  M.frac_E_stars = m->frac_E_stars; M.frac_E_disk = m->frac_E_disk; M.CDF_E_star = m->CDF_E_star;
+  M.prob_E_cell = m->prob_E_cell; M.L_packet_th = m->L_packet_th;
+  M.N_thet = m->N_thet; M.N_phi = m->N_phi; M.sym_c = m->l_sym_centrale; M.sym_a = m->l_sym_axiale;
+  M.midplane_snap = m->midplane_snap;
+  if (lds_bytes(M) > sizeof(lds_raw)) return 31;
+
+  const size_t nsed = (size_t)9 * m->n_lambda * m->N_thet * m->N_phi;
+  memset(E_abs, 0, sizeof(double) * m->n_cells);
+  memset(sed, 0, sizeof(double) * nsed);
+  memset(n_sent, 0, sizeof(double) * m->n_lambda);
+  unsigned long long cnt[16];
+  memset(cnt, 0, sizeof(cnt));
+  int err = 0;
+  if (getenv("MCGPU_EMU_TRACE")) { g_trace_base = E_abs; g_trace_n = m->n_cells; }
+  RunArgs A;
+  A.seed = o->seed; A.first_packet = o->first_packet; A.n_packets = o->n_packets;
+  A.qscale = o->n_replicas >= 1.0 ? o->n_replicas : 1.0;
+  A.frozen = o->frozen; A.E_prior = E_prior; A.E_abs = E_abs; A.sed = sed; A.n_sent = n_sent;
+  A.counters = cnt; A.next_packet = cnt + 8; A.err = &err;
+  A.inner_iters = 8; A.flags = 0;
+  const bool pola = m->lsepar_pola && m->aniso_method == 1, dark = M.dark != nullptr, l3d = m->l3D != 0;
+#define RUN(a, b, c) k_thermal<a, b, c>(M, A)
+  if (l3d) {
+    if (pola) { if (dark) RUN(true, true, true); else RUN(true, true, false); }
+    else { if (dark) RUN(true, false, true); else RUN(true, false, false); }
+  } else {
+    if (pola) { if (dark) RUN(false, true, true); else RUN(false, true, false); }
+    else { if (dark) RUN(false, false, true); else RUN(false, false, false); }
+  }
+  for (int q = 0; q < 8; ++q) counters[q] = cnt[q];
+  return err;
+}

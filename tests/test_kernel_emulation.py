@@ -1,0 +1,132 @@
+"""Kernel control flow on the CPU: tests/emu/emu_kernel.cpp compiles the DEVICE
+source (mcfost_amd/csrc/mc_device.hip.h) for the host with a one-lane
+emulation of the HIP builtins, WITH FMA contraction enabled like hipcc's
+default, and the result is compared with the oracle in frozen-temperature
+mode.  This is test infrastructure (a debugger for the state machine), not a
+CPU path of the product; the real parity tests are tests/test_gpu_parity.py.
+"""
+import copy
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from mcfost_amd.host import model as M
+from oracle import Oracle
+from oracle.binding import _Opts, _p
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "emu", "emu_kernel.cpp")
+LIB = os.path.join(HERE, "emu", "libemu_kernel.so")
+DEV = os.path.join(os.path.dirname(HERE), "mcfost_amd", "csrc", "mc_device.hip.h")
+
+
+@pytest.fixture(scope="module")
+def emu():
+    if (not os.path.exists(LIB)) or os.path.getmtime(LIB) < max(os.path.getmtime(SRC), os.path.getmtime(DEV)):
+        fma = ["-mfma"] if "fma" in open("/proc/cpuinfo").read() else []
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=fast"] + fma +
+                              ["-o", LIB, SRC])
+    return C.CDLL(LIB)
+
+
+def emu_run(emu, orc, n, seed, first=0, frozen=True, prior=None):
+    m = orc.model
+    E = np.zeros(m.n_cells)
+    sed = np.zeros((9, m.cfg.N_phi, m.cfg.N_thet, m.n_lambda))
+    ns = np.zeros(m.n_lambda)
+    cnt = np.zeros(8, np.uint64)
+    o = _Opts(seed, first, n, 1, int(frozen), 0, 1.0)
+    rc = emu.emu_run_thermal(C.byref(orc.cm), C.byref(o), _p(prior, C.c_double) if prior is not None else None,
+                             _p(E, C.c_double), _p(sed, C.c_double), _p(ns, C.c_double), _p(cnt, C.c_uint64))
+    assert rc == 0, rc
+    return dict(E_abs=E, sed=sed, n_sent=ns, counters=[int(c) for c in cnt])
+
+
+def check(emu, m, n, seed, rtol=1e-9):
+    orc = Oracle(m, n)
+    prior = orc.run_thermal(2000, seed=1)["E_abs"]
+    a = emu_run(emu, orc, n, seed, prior=prior)
+    b = orc.run_thermal(n, seed=seed, frozen=True, E_prior=prior, n_threads=4)
+    assert a["counters"] == list(b["counters"].values())
+    assert np.array_equal(a["n_sent"], b["n_sent"]) and np.array_equal(a["sed"][4], b["sed"][4])
+    assert np.allclose(a["E_abs"], b["E_abs"], rtol=rtol, atol=1e-12 * b["E_abs"].max())
+    return a, b
+
+
+def test_emulated_kernel_2d(emu, small_model):
+    check(emu, small_model, 5000, 7)
+
+
+def test_emulated_kernel_3d(emu):
+    check(emu, M.build_model(M.small(n_rad=12, nz=6, n_az=8, l3D=True)), 5000, 8)
+
+
+def test_emulated_kernel_hg_isotropic_unpolarised(emu):
+    check(emu, M.build_model(M.small(lisotropic=True, lsepar_pola=False)), 3000, 9)
+    check(emu, M.build_model(M.small(aniso_method=2, lsepar_pola=False)), 3000, 10)
+
+
+def test_emulated_kernel_dark_zone(emu, small_model):
+    m = copy.copy(small_model)
+    dz = np.zeros(m.n_cells, np.uint8)
+    dz.reshape(m.cfg.nz, m.cfg.n_rad)[0:2, 4:12] = 1
+    m.l_dark_zone = dz
+    a, b = check(emu, m, 5000, 12)
+    assert a["counters"][7] > 0
+
+
+def test_emulated_kernel_disk_emission(emu, small_model):
+    m = copy.copy(small_model)
+    rng = np.random.default_rng(0)
+    E_cell = rng.random((m.n_lambda, m.n_cells)) * m.kappa_factor[None, :]
+    pe = np.zeros((m.n_lambda, m.n_cells + 1))
+    pe[:, 1:] = np.cumsum(E_cell, axis=1)
+    pe /= pe[:, -1:]
+    m.prob_E_cell = pe.reshape(-1)
+    m.frac_E_stars = np.full(m.n_lambda, 0.4)
+    # packets born in the thick midplane random-walk for >1e4 flights: FMA-level rounding
+    # differences accumulate along such walks (continuous, no discrete divergence)
+    check(emu, m, 3000, 13, rtol=1e-6)
+
+
+def test_axisymmetric_3d_reproduces_2d_packet_for_packet():
+    """Why the engine defaults to mcgpu_set_midplane_snap(1): an axisymmetric 3D
+    grid must give the same physics as the 2D grid (which has no cell wall at
+    the midplane, cylindrical_grid.f90:1032-1040).  With the snap the 3D run
+    reproduces the 2D run packet for packet (same seeds, frozen temperature,
+    equivalent priors): identical flights / scatterings / absorptions and the
+    same vertical energy profile.  The reference-literal arithmetic loses ~6 %
+    of the interactions: after a midplane crossing the rounding residue of
+    z0 + t*w is on the wrong side about half of the time, and the packet then
+    runs through mislabelled cells until the next radial wall."""
+    n = 100000
+    m2 = M.build_model(M.small(n_rad=12, nz=6))
+    m3 = M.build_model(M.small(n_rad=12, nz=6, n_az=8, l3D=True))
+    m3l = copy.copy(m3)
+    m3l.midplane_snap = 0
+    prior2 = Oracle(m2, n).run_thermal(n, seed=1, n_threads=8)["E_abs"]
+    g3 = m3.grid
+    i = g3["cell_map_i"][:m3.n_cells] - 1
+    j = np.abs(g3["cell_map_j"][:m3.n_cells]) - 1
+    # E_abs is in units of the reference cell's opacity (dust_prop.f90:955): rescale
+    prior3 = prior2.reshape(6, 12)[j, i] / 16.0 * (m3.extra["rho0"] / m2.extra["rho0"])
+    out = {}
+    for name, m, pr in (("2d", m2, prior2), ("snap", m3, prior3), ("literal", m3l, prior3)):
+        r = Oracle(m, n).run_thermal(n, seed=3, n_threads=8, frozen=True, E_prior=pr)
+        E = r["E_abs"]
+        if m.cfg.l3D:
+            E2 = np.zeros((6, 12))
+            np.add.at(E2, (j, i), E)
+        else:
+            E2 = E.reshape(6, 12)
+        out[name] = (r["counters"], E2 / E2.sum())
+    c2, c3, cl = out["2d"][0], out["snap"][0], out["literal"][0]
+    for k in ("flights", "scatterings", "absorptions", "escaped", "killed_star"):
+        assert c3[k] == c2[k], k
+    assert np.allclose(out["snap"][1], out["2d"][1], rtol=1e-9, atol=1e-15)
+    assert np.array_equal(Oracle(m2, n).run_thermal(1000, seed=3, frozen=True, E_prior=prior2)["sed"][4],
+                          Oracle(m3, n).run_thermal(1000, seed=3, frozen=True, E_prior=prior3)["sed"][4])
+    assert cl["flights"] < 0.97 * c2["flights"]          # the literal arithmetic is measurably off

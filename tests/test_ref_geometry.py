@@ -17,6 +17,7 @@ NAMES = list(CONFIGS)
 def case(request):
     cfg = CONFIGS[request.param](M)
     m = M.build_model(cfg)
+    m.midplane_snap = 0  # reference-literal arithmetic: what the golden vectors hold
     return request.param, cfg, m, Oracle(m, 1e5), load_golden(request.param)
 
 
