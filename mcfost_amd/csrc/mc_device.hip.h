@@ -89,6 +89,7 @@ struct RunArgs {
   unsigned long long* next_packet;  // work counter
   int* err;
   int inner_iters;  // crossings attempted between two interaction phases
+  int flush_every;  // LDS-deposit kernels: outer iterations per fold of the private grid
   int flags;        // diagnostics: bit 0 = skip the E_abs deposits (timing experiments only)
 };
 
@@ -680,6 +681,13 @@ __device__ inline void temp_lte(const double* lq, int n_T, double E_scaled, doub
 // native FP64 atomic add (global_atomic_add_f64), no CAS loop
 __device__ inline void atomic_add_f64(double* p, double v) { unsafeAtomicAdd(p, v); }
 
+// one path-length deposit (save_radiation_field, radiation_field.f90:53)
+template <bool LDSE>
+__device__ inline void deposit(double* E_glob, double* E_lds, int ic, double v) {
+  if (LDSE) atomicAdd(&E_lds[ic], v);  // ds_add_f64
+  else atomic_add_f64(&E_glob[ic], v);
+}
+
 enum : int { S_EMIT = 0, S_INTERACT = 1, S_NEWFLIGHT = 2, S_FLIGHT = 3, S_DONE = 4 };
 
 // capteur, SED branch (output.f90:294-397,572-592)
@@ -721,11 +729,19 @@ __device__ inline void capteur(const DevModel& M, double* sed, int lambda, doubl
 // ---------------------------------------------------------------------------
 // The thermal packet kernel
 // ---------------------------------------------------------------------------
-template <bool L3D, bool POLA, bool DARK>
-__global__ void __launch_bounds__(256) k_thermal(const DevModel M, const RunArgs A) {
-  extern __shared__ double lds_raw[];
-  const Lds T = lds_carve(lds_raw, M);
+// LDSE: the absorbed-energy grid of this workgroup lives in LDS (2D grids:
+// n_cells * 8 B + tables fit the 160 KB of a CU); deposits are LDS atomics
+// (ds_add_f64); the waves fold rotating slices of the private grid into HBM
+// every A.flush_every outer iterations, without a workgroup barrier.  Otherwise deposits go straight to HBM
+// (global_atomic_add_f64), the only option for 3D grids (5.76 MB at 720 000
+// cells).
+template <bool L3D, bool POLA, bool DARK, bool LDSE>
+__device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A, double* lds_base) {
+  double* const E_lds = lds_base;  // [n_cells] when LDSE
+  const Lds T = lds_carve(lds_base + (LDSE ? M.n_cells : 0), M);
   lds_stage(T, M);
+  if (LDSE)
+    for (int i = threadIdx.x; i < M.n_cells; i += blockDim.x) E_lds[i] = 0.0;
   __syncthreads();
 
   const int lane = threadIdx.x & 63;
@@ -746,7 +762,7 @@ __global__ void __launch_bounds__(256) k_thermal(const DevModel M, const RunArgs
                c_pack = 0;
   unsigned int pk_cross = 0;  // crossings of the current packet (runaway guard)
 
-  for (;;) {
+  for (int ep = 0;; ++ep) {  // outer iterations
     // ---- EMIT: pull the next packet id (wave-aggregated) -----------------
     {
       const bool need = (st == S_EMIT);
@@ -933,7 +949,16 @@ __global__ void __launch_bounds__(256) k_thermal(const DevModel M, const RunArgs
         const int ic = cell_index<L3D>(n_rad, nz, ri, zj, k);
         double E;
         if (A.frozen) E = A.E_prior[ic];
-        else E = __hip_atomic_load(&A.E_abs[ic], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * A.qscale;
+        else {
+          // running absorbed energy of the cell: what every workgroup has folded into HBM so
+          // far, plus (LDSE) this workgroup's not yet folded part; * n_replicas like the
+          // reference's `* nb_proc` (thermal_emission.f90:670)
+          E = __hip_atomic_load(&A.E_abs[ic], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          // the other workgroups' unfolded parts are estimated by this one's, exactly the
+          // reference's partial * nb_proc with workgroups in the role of threads
+          if (LDSE) E += E_lds[ic] * (double)gridDim.x;
+          E *= A.qscale;
+        }
         int Ti;
         double frac_T2;
         temp_lte(T.lq, M.n_T, E, M.L_packet_th, M.volume[ic], Ti, frac_T2);
@@ -1033,7 +1058,7 @@ __global__ void __launch_bounds__(256) k_thermal(const DevModel M, const RunArgs
             const double tau = l * opacity;
             if (tau > extr) {
               const double lc = l * (extr / tau);
-              if (real_cell && !(A.flags & 1)) atomic_add_f64(&A.E_abs[ic], T.kabs[lambda - 1] * lc * S[0]);
+              if (real_cell && !(A.flags & 1)) deposit<LDSE>(A.E_abs, E_lds, ic, T.kabs[lambda - 1] * lc * S[0]);
               x = x + lc * u;
               y = y + lc * v;
               z = z + lc * w;
@@ -1041,7 +1066,7 @@ __global__ void __launch_bounds__(256) k_thermal(const DevModel M, const RunArgs
               st = S_INTERACT;
             } else {
               extr = extr - tau;
-              if (real_cell && !(A.flags & 1)) atomic_add_f64(&A.E_abs[ic], T.kabs[lambda - 1] * l * S[0]);
+              if (real_cell && !(A.flags & 1)) deposit<LDSE>(A.E_abs, E_lds, ic, T.kabs[lambda - 1] * l * S[0]);
               if (DARK) { xo = x; yo = y; zo = z; ri_o = ri; zj_o = zj; k_o = k; }
               x = x1; y = y1; z = z1;
               ri = ri1; zj = zj1; k = k1;
@@ -1049,6 +1074,28 @@ __global__ void __launch_bounds__(256) k_thermal(const DevModel M, const RunArgs
           }
         }
       }
+    }
+    // ---- barrier-free partial fold: every A.flush_every outer iterations this wave swaps
+    // one slice of the workgroup's private grid to zero (ds_wrxchg_rtn_b64) and adds what it
+    // took to HBM.  Slices rotate over the waves, so the whole grid keeps flowing into the
+    // global sum that the in-flight temperature reads, without any workgroup barrier.
+    if (LDSE && ((ep + 1) % A.flush_every) == 0) {
+      const int n_waves = (blockDim.x + 63) >> 6, wave = threadIdx.x >> 6;
+      const int slice = (wave + (ep + 1) / A.flush_every) % n_waves;
+      const int per = (M.n_cells + n_waves - 1) / n_waves;
+      const int i0 = slice * per, i1 = (i0 + per < M.n_cells) ? i0 + per : M.n_cells;
+      for (int i = i0 + lane; i < i1; i += 64) {
+        const unsigned long long bits = atomicExch(reinterpret_cast<unsigned long long*>(&E_lds[i]), 0ull);
+        const double e = __longlong_as_double((long long)bits);
+        if (e != 0.0) atomic_add_f64(&A.E_abs[i], e);
+      }
+    }
+  }  // outer iterations
+  if (LDSE) {  // final fold: every wave of the workgroup is done depositing
+    __syncthreads();
+    for (int i = threadIdx.x; i < M.n_cells; i += blockDim.x) {
+      const double e = E_lds[i];
+      if (e != 0.0) atomic_add_f64(&A.E_abs[i], e);
     }
   }
 
@@ -1060,6 +1107,20 @@ __global__ void __launch_bounds__(256) k_thermal(const DevModel M, const RunArgs
     for (int off = 32; off > 0; off >>= 1) vsum += __shfl_down(vsum, off);
     if (lane == 0 && vsum) atomicAdd(&A.counters[q], vsum);
   }
+}
+
+// HBM-deposit variant: 256-thread workgroups, several per CU.
+template <bool L3D, bool POLA, bool DARK>
+__global__ void __launch_bounds__(256) k_thermal(const DevModel M, const RunArgs A) {
+  extern __shared__ double lds_raw[];
+  thermal_body<L3D, POLA, DARK, false>(M, A, lds_raw);
+}
+
+// LDS-deposit variant: one 512-thread workgroup per CU shares one private grid.
+template <bool L3D, bool POLA, bool DARK>
+__global__ void __launch_bounds__(512) k_thermal_lds(const DevModel M, const RunArgs A) {
+  extern __shared__ double lds_raw[];
+  thermal_body<L3D, POLA, DARK, true>(M, A, lds_raw);
 }
 
 // ---------------------------------------------------------------------------

@@ -347,9 +347,9 @@ extern "C" int mcgpu_set_E_prior(mcgpu_ctx* ctx, const double* E_prior) {
   return MCGPU_OK;
 }
 
-template <bool L3D, bool POLA, bool DARK>
+template <bool L3D, bool POLA, bool DARK, bool LDSE>
 static hipError_t launch_k(const DevModel& M, const RunArgs& A, int blocks, int threads, size_t lds, hipStream_t s) {
-  auto kern = k_thermal<L3D, POLA, DARK>;
+  auto kern = LDSE ? k_thermal_lds<L3D, POLA, DARK> : k_thermal<L3D, POLA, DARK>;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, s, M, A);
@@ -386,18 +386,36 @@ extern "C" int mcgpu_launch_thermal(mcgpu_ctx* ctx, const mcgpu_run_opts* o) {
   A.next_packet = ctx->d_counters + 8;
   A.err = ctx->d_err;
   // tuning / diagnostic knobs (environment; defaults are the shipped configuration)
-  A.inner_iters = 8;
+  A.inner_iters = 32;
+  A.flush_every = 16;
   A.flags = 0;
   if (const char* e = getenv("MCGPU_INNER_ITERS")) { int v = atoi(e); if (v >= 1 && v <= 4096) A.inner_iters = v; }
+  if (const char* e = getenv("MCGPU_FLUSH_EVERY")) { int v = atoi(e); if (v >= 1 && v <= 1000000) A.flush_every = v; }
   if (const char* e = getenv("MCGPU_DIAG_FLAGS")) A.flags = atoi(e);
-  const int threads = o->block_threads > 0 ? o->block_threads : 256;
-  if (threads % 64 || threads > 256) return fail(ctx, MCGPU_ERR_ARG, "block_threads must be 64..256, multiple of 64");
+  // Deposit mode: a private absorbed-energy grid in LDS when it fits next to the tables
+  // (2D grids), HBM atomics otherwise.  MCGPU_DEPOSIT=hbm|lds overrides.
+  const size_t lds_e = lds + (size_t)M.n_cells * sizeof(double);
+  const size_t lds_cap = 160 * 1024;
+  bool use_lds = lds_e <= lds_cap;
+  if (const char* e = getenv("MCGPU_DEPOSIT")) {
+    if (!strcmp(e, "hbm")) use_lds = false;
+    else if (!strcmp(e, "lds")) {
+      if (lds_e > lds_cap) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "MCGPU_DEPOSIT=lds: grid does not fit in LDS");
+      use_lds = true;
+    }
+  }
+  const size_t lds_k = use_lds ? lds_e : lds;
+  const int max_threads = use_lds ? 512 : 256;
+  const int threads = o->block_threads > 0 ? o->block_threads : max_threads;
+  if (threads % 64 || threads > max_threads)
+    return fail(ctx, MCGPU_ERR_ARG, "block_threads must be a multiple of 64, at most 256 (HBM deposits) / 512 (LDS deposits)");
   int blocks = o->grid_blocks;
   if (blocks <= 0) {
     // persistent grid: as many workgroups as the LDS footprint lets reside
-    int per_cu = (int)((160 * 1024) / (lds > 0 ? lds : 1));
+    int per_cu = (int)(lds_cap / (lds_k > 0 ? lds_k : 1));
+    const int cap = 2048 / threads;  // waves
     if (per_cu < 1) per_cu = 1;
-    if (per_cu > 8) per_cu = 8;
+    if (per_cu > cap) per_cu = cap;
     blocks = ctx->prop.multiProcessorCount * per_cu;
     const unsigned long long need = (o->n_packets + threads - 1) / threads;
     if ((unsigned long long)blocks > need) blocks = (int)(need ? need : 1);
@@ -405,7 +423,9 @@ extern "C" int mcgpu_launch_thermal(mcgpu_ctx* ctx, const mcgpu_run_opts* o) {
   const bool pola = ctx->lsepar_pola != 0, dark = M.dark != nullptr, l3d = M.l3D != 0;
   HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
   hipError_t e;
-#define LAUNCH(a, b, c) e = launch_k<a, b, c>(M, A, blocks, threads, lds, ctx->stream)
+#define LAUNCH(a, b, c)                                                                \
+  e = use_lds ? launch_k<a, b, c, true>(M, A, blocks, threads, lds_k, ctx->stream)     \
+              : launch_k<a, b, c, false>(M, A, blocks, threads, lds_k, ctx->stream)
   if (l3d) {
     if (pola) { if (dark) LAUNCH(true, true, true); else LAUNCH(true, true, false); }
     else { if (dark) LAUNCH(true, false, true); else LAUNCH(true, false, false); }

@@ -19,6 +19,7 @@
 #define __global__
 #define __shared__
 #define __launch_bounds__(...)
+#define __forceinline__ inline
 #define __ATOMIC_RELAXED_EMU 0
 #define __HIP_MEMORY_SCOPE_AGENT 0
 #define __hip_atomic_load(p, order, scope) (*(p))
@@ -42,6 +43,10 @@ static inline void unsafeAtomicAdd(double* p, double v) {
   *p += v;
 }
 static inline void __syncthreads() {}
+static inline int __syncthreads_or(int p) { return p; }
+static inline unsigned long long atomicExch(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p = v; return o; }
+static inline double __longlong_as_double(long long b) { double d; memcpy(&d, &b, 8); return d; }
+static inline double atomicAdd(double* p, double v) { double o = *p; *p += v; return o; }
 static inline double __dmul_rn(double a, double b) { volatile double r = a * b; return r; }
 static inline double __dadd_rn(double a, double b) { volatile double r = a + b; return r; }
 using std::fabs; using std::floor; using std::sqrt; using std::log; using std::exp; using std::fmax;
@@ -89,7 +94,7 @@ extern "C" int emu_run_thermal(const oracle_model* m, const oracle_opts* o, cons
   M.prob_E_cell = m->prob_E_cell; M.L_packet_th = m->L_packet_th;
   M.N_thet = m->N_thet; M.N_phi = m->N_phi; M.sym_c = m->l_sym_centrale; M.sym_a = m->l_sym_axiale;
   M.midplane_snap = m->midplane_snap;
-  if (lds_bytes(M) > sizeof(lds_raw)) return 31;
+  if (lds_bytes(M) + sizeof(double) * m->n_cells > sizeof(lds_raw)) return 31;
 
   const size_t nsed = (size_t)9 * m->n_lambda * m->N_thet * m->N_phi;
   memset(E_abs, 0, sizeof(double) * m->n_cells);
@@ -104,9 +109,9 @@ extern "C" int emu_run_thermal(const oracle_model* m, const oracle_opts* o, cons
   A.qscale = o->n_replicas >= 1.0 ? o->n_replicas : 1.0;
   A.frozen = o->frozen; A.E_prior = E_prior; A.E_abs = E_abs; A.sed = sed; A.n_sent = n_sent;
   A.counters = cnt; A.next_packet = cnt + 8; A.err = &err;
-  A.inner_iters = 8; A.flags = 0;
+  A.inner_iters = 8; A.flags = 0; A.flush_every = 4;
   const bool pola = m->lsepar_pola && m->aniso_method == 1, dark = M.dark != nullptr, l3d = m->l3D != 0;
-#define RUN(a, b, c) k_thermal<a, b, c>(M, A)
+#define RUN(a, b, c) do { if (getenv("MCGPU_EMU_LDS")) k_thermal_lds<a, b, c>(M, A); else k_thermal<a, b, c>(M, A); } while (0)
   if (l3d) {
     if (pola) { if (dark) RUN(true, true, true); else RUN(true, true, false); }
     else { if (dark) RUN(true, false, true); else RUN(true, false, false); }

@@ -1,5 +1,5 @@
 """Throughput sweeps on the GPU (tuning aid, not part of the product)."""
-import os, sys, time, json, subprocess
+import os, sys, json, subprocess
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 def run(env, packets=2e7, extra=()):
     e = dict(os.environ); e.update(env)
@@ -7,15 +7,25 @@ def run(env, packets=2e7, extra=()):
                          capture_output=True, text=True, env=e)
     try:
         j = json.loads(out.stdout.strip().split("\n")[-1])
-        return j["value"], j["roofline"]["kernel_ms"]
+        return "%.3e pk/s  kernel %.1f ms" % (j["value"], j["roofline"]["kernel_ms"])
     except Exception:
-        return out.stdout[-300:] + out.stderr[-300:], None
+        return out.stdout[-300:] + out.stderr[-600:]
 if __name__ == "__main__":
-    for it in (2, 4, 8, 16, 32, 64):
-        print("inner_iters", it, run({"MCGPU_INNER_ITERS": str(it)}), flush=True)
-    print("no deposit", run({"MCGPU_DIAG_FLAGS": "1"}), flush=True)
-    for gb in (256, 512, 768, 1024, 2048):
-        print("grid_blocks", gb, run({}, extra=("--grid-blocks", str(gb))), flush=True)
-    for bt in (64, 128, 256):
-        print("block_threads", bt, run({}, extra=("--block-threads", str(bt))), flush=True)
-    print("1e8", run({}, packets=1e8), flush=True)
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if which in ("all", "mode"):
+        print("hbm default", run({"MCGPU_DEPOSIT": "hbm"}), flush=True)
+        print("lds default", run({"MCGPU_DEPOSIT": "lds"}), flush=True)
+        print("lds nodeposit", run({"MCGPU_DEPOSIT": "lds", "MCGPU_DIAG_FLAGS": "1"}), flush=True)
+    if which in ("all", "inner"):
+        for it in (8, 16, 32, 64, 128, 256):
+            print("lds inner_iters", it, run({"MCGPU_INNER_ITERS": str(it)}), flush=True)
+    if which in ("all", "flush"):
+        for f in (1, 4, 16, 64, 256):
+            print("lds flush_every", f, run({"MCGPU_FLUSH_EVERY": str(f)}), flush=True)
+    if which in ("all", "block"):
+        for bt in (256, 384, 512):
+            print("lds block_threads", bt, run({}, extra=("--block-threads", str(bt))), flush=True)
+    if which in ("all", "big"):
+        print("lds 1e8", run({}, packets=1e8), flush=True)
+        print("pascucci 2e7", run({}, extra=("--config", "pascucci")), flush=True)
+        print("3d 5e6", run({}, packets=5e6, extra=("--config", "ref41_3d")), flush=True)
