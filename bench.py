@@ -59,6 +59,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--grid-blocks", type=int, default=0)
     ap.add_argument("--block-threads", type=int, default=0)
+    ap.add_argument("--frozen", action="store_true",
+                    help="tuning aid: time the loop with the temperature feedback frozen to a prior "
+                         "(keeps the physics identical across diagnostic builds); not the benchmark")
     args = ap.parse_args()
 
     import torch
@@ -90,9 +93,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.frozen:
+        env_flags = os.environ.pop("MCGPU_DIAG_FLAGS", None)
+        eng.set_E_prior(eng.run_thermal(min(n_local, 2_000_000), seed=5)["E_abs"] * (n_local / min(n_local, 2_000_000)))
+        if env_flags is not None:
+            os.environ["MCGPU_DIAG_FLAGS"] = env_flags
+
     def step(i):
         eng.launch_thermal(n_local, seed=1000 + i, first_packet=first, n_replicas=float(world),
-                           grid_blocks=args.grid_blocks, block_threads=args.block_threads)
+                           frozen=args.frozen, grid_blocks=args.grid_blocks, block_threads=args.block_threads)
         ms = eng.sync()
         if world > 1:
             acc, cnt = eng.device_accumulators()

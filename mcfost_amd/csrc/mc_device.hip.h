@@ -23,6 +23,13 @@
 #endif
 #include <stdint.h>
 
+#ifndef MCGPU_CROSS
+#define MCGPU_CROSS cross_cell_lean  // or cross_cell: the branch-for-branch form (A/B and debugging)
+#endif
+#ifndef MCGPU_LDS_BLOCK
+#define MCGPU_LDS_BLOCK 512  // threads of an LDS-deposit workgroup (one per CU on the 2D BASELINE grid)
+#endif
+
 namespace mcgpu {
 
 constexpr double PI = 3.141592653589793238462643383279502884197;
@@ -145,6 +152,7 @@ struct Lds {
   double* r_lim_2;  // n_rad+1
   double* zmax;     // n_rad
   double* ch;       // n_rad
+  double* rzn;      // n_rad: nz / zmax, for the fast path of the zj recomputation
   double* tan_phi;  // n_az
   double* kappa;    // n_lambda
   double* kabs;     // n_lambda
@@ -158,7 +166,7 @@ struct Lds {
 };
 
 __host__ __device__ inline size_t lds_doubles(const DevModel& M) {
-  return (size_t)(M.n_rad + 1) + M.n_rad + M.n_rad + M.n_az + M.n_lambda + M.n_lambda + M.n_T +
+  return (size_t)(M.n_rad + 1) + M.n_rad + M.n_rad + M.n_rad + M.n_az + M.n_lambda + M.n_lambda + M.n_T +
          (M.n_lambda + 1) + M.n_lambda + (size_t)M.n_lambda * M.n_T;
 }
 __host__ __device__ inline size_t lds_floats(const DevModel& M) {
@@ -174,6 +182,7 @@ __device__ inline Lds lds_carve(double* base, const DevModel& M) {
   T.r_lim_2 = p; p += M.n_rad + 1;
   T.zmax = p; p += M.n_rad;
   T.ch = p; p += M.n_rad;
+  T.rzn = p; p += M.n_rad;
   T.tan_phi = p; p += M.n_az;
   T.kappa = p; p += M.n_lambda;
   T.kabs = p; p += M.n_lambda;
@@ -197,6 +206,7 @@ __device__ inline void lds_stage(const Lds& T, const DevModel& M) {
   stage(T.r_lim_2, M.r_lim_2, (size_t)M.n_rad + 1);
   stage(T.zmax, M.zmax, (size_t)M.n_rad);
   stage(T.ch, M.ch, (size_t)M.n_rad);
+  for (int i = threadIdx.x; i < M.n_rad; i += blockDim.x) T.rzn[i] = (double)M.nz / M.zmax[i];
   stage(T.tan_phi, M.tan_phi_lim, (size_t)M.n_az);
   stage(T.kappa, M.kappa, (size_t)M.n_lambda);
   stage(T.kabs, M.kappa_abs, (size_t)M.n_lambda);
@@ -482,6 +492,141 @@ __device__ inline void cross_cell(const Lds& T, const DevModel& M, double x0, do
   }
 }
 
+// zj of a point (|z| = absz) in radial column ri, capped at nz+1: the reference's
+//   floor(min(real(abs(z1)/zmax(ri1)*nz), max_int)) + 1        (cylindrical_grid.f90:1116)
+// The default-real rounding only matters within ~nz*6e-8 of an integer, so the common case
+// is one multiply by nz/zmax; the literal expression runs when the quotient is that close.
+__device__ inline int zj_capped(const Lds& T, int nz, double absz, int ri) {
+  const double qd = absz * T.rzn[ri - 1];
+  const double fl = floor(qd);
+  const double fr = qd - fl;
+  int zj;
+  if (!(qd < (double)nz + 0.5)) zj = nz + 1;         // far above the grid (or not finite)
+  else if (fr < 1.0e-4 || fr > 1.0 - 1.0e-4) zj = zj_from_z_real(T, nz, absz, ri);
+  else zj = (int)fl + 1;
+  return zj > nz ? nz + 1 : zj;
+}
+
+// cross_cylindrical_cell (cylindrical_grid.f90:918-1175), the same arithmetic as
+// cross_cell() above with the reference's branch tree flattened into selects: a wavefront
+// executes ONE instruction stream whatever mix of inward/outward, up/down, radial/vertical
+// moves its 64 packets make.  Every value that decides an index or a position is computed by
+// the same expression as in the reference.
+template <bool L3D>
+__device__ inline void cross_cell_lean(const Lds& T, const DevModel& M, double x0, double y0, double z0,
+                                       double u, double v, double w, double inv_a, double inv_w, int ri0,
+                                       int zj0, int k0, double& x1, double& y1, double& z1, int& ri1,
+                                       int& zj1, int& k1, double& l) {
+  const int nz = M.nz, n_rad = M.n_rad, n_az = M.n_az;
+  const double cm = 1.0 - GRID_PREC, cp = 1.0 + GRID_PREC;
+  const bool hole = (ri0 == 0);
+
+  // 1) radial wall (:959-1000)
+  const double r_2 = x0 * x0 + y0 * y0;
+  const double dot = x0 * u + y0 * v;
+  const double b = dot * inv_a;
+  const double rl_in = T.r_lim_2[hole ? 0 : ri0 - 1];
+  const double rl_out = T.r_lim_2[hole ? 0 : ri0];
+  const double c_in = (r_2 - (hole ? rl_in : rl_in * cm)) * inv_a;
+  const double c_out = (r_2 - rl_out * cp) * inv_a;
+  const double bb = b * b;
+  const double d_in = bb - c_in;
+  const double d_out = fmax(bb - c_out, 0.0);
+  const bool use_in = hole || ((dot < 0.0) && !(d_in < 0.0));
+  const double delta = use_in ? d_in : d_out;
+  const int delta_rad = (use_in && !hole) ? -1 : 1;
+  const double rac = sqrt(delta);
+  const double s1 = (-b - rac) * cp, s2 = (-b + rac) * cp;
+  double s = (s1 < 0.0) ? s2 : ((s1 == 0.0) ? GRID_PREC : s1);
+  if (hole) s = s2;
+
+  // 2) vertical wall (:1003-1055)
+  const int azj = zj0 < 0 ? -zj0 : zj0;
+  const double dz = w * z0;
+  const bool away = dz > 0.0;
+  const bool top = (azj == nz + 1);
+  const bool flip2d = !L3D && !away && (zj0 == 1);  // 2D: through the midplane to the mirror side
+  const int jsel = away ? azj + 1 : (L3D ? azj : (zj0 == 1 ? 2 : zj0));
+  double zmag = (jsel <= nz) ? ((double)jsel - 1.0) * T.ch[hole ? 0 : ri0 - 1]
+                             : ((jsel == nz + 1) ? T.zmax[hole ? 0 : ri0 - 1] : 1.00000001504746621988e+30);
+  zmag = zmag * (away ? cp : cm);
+  if (away && top) zmag = 1.0e10;
+  const bool neg = (z0 < 0.0) != flip2d;
+  const double zl = neg ? -zmag : zmag;
+  int delta_zj;
+  if (L3D) {
+    if (away) delta_zj = top ? 0 : ((z0 < 0.0) ? -1 : 1);
+    else delta_zj = (z0 > 0.0) ? ((zj0 == 1) ? -2 : -1) : ((zj0 == -1) ? 2 : 1);
+  } else {
+    delta_zj = away ? (top ? 0 : 1) : ((zj0 == 1) ? 1 : -1);
+  }
+  double t = (zl - z0) * inv_w;
+  if (t < 0.0) t = GRID_PREC;
+  if (dz == 0.0) t = 1.0e10;
+  if (hole) t = HUGE_REAL;
+
+  // 3) azimuthal wall (:1058-1094)
+  double t_phi = HUGE_REAL;
+  int delta_phi = 0;
+  if (L3D) {
+    const double r1e30 = 1.00000001504746621988e+30;
+    const double dp = x0 * v - y0 * u;
+    delta_phi = (dp > 0.0) ? 1 : -1;
+    int kk = (dp > 0.0) ? k0 : k0 - 1;
+    if (kk == 0) kk = n_az;
+    const double tan_lim = T.tan_phi[kk - 1];
+    const double den = v - u * tan_lim;
+    double tp = (fabs(den) > (double)1.0e-6f) ? -(y0 - x0 * tan_lim) / den : r1e30;
+    if (tan_lim > 1.0e299) tp = (fabs(u) > (double)1e-6f) ? -x0 / u : r1e30;
+    if (tp < 0.0) tp = r1e30;
+    if (fabs(dp) < (double)1.0e-10f) tp = r1e30;
+    t_phi = hole ? HUGE_REAL : tp;
+  }
+
+  // 4) nearest wall (:1098-1156)
+  const bool rad = (s < t) && (s < t_phi);
+  const bool vert = !rad && (t < t_phi);
+  l = rad ? s : (vert ? t : t_phi);
+  const double dv = (rad || vert) ? l : cp * t_phi;
+  x1 = x0 + dv * u;
+  y1 = y0 + dv * v;
+  // products rounded before the sum, like the reference build (see cross_cell above)
+  z1 = __dadd_rn(z0, __dmul_rn(dv, w));
+  ri1 = rad ? ri0 + delta_rad : ri0;
+  k1 = k0;
+  if (rad) {
+    if (ri1 == 0) {
+      zj1 = 1;
+      k1 = 1;
+    } else if (ri1 > n_rad) {
+      zj1 = zj0;
+    } else {
+      int zj = zj_capped(T, nz, fabs(z1), ri1);
+      if (L3D && (z1 < 0.0)) zj = -zj;
+      zj1 = zj;
+    }
+    if (L3D && hole) {
+      const double phi = modulo_d(atan2(y1, x1), 2 * PI);
+      int kk = (int)floor(phi * (1.0 / (2.0 * PI)) * (double)(float)n_az) + 1;
+      if (kk == n_az + 1) kk = n_az;
+      k1 = kk;
+    }
+  } else if (vert) {
+    zj1 = zj0 + delta_zj;
+    if (L3D && M.midplane_snap && (delta_zj == 2 || delta_zj == -2)) z1 = copysign(GRID_PREC, w);
+  } else {
+    int zj = (int)floor(fabs(z1) / T.zmax[ri1 - 1] * (double)nz) + 1;
+    if (zj > nz) zj = nz + 1;
+    if (z1 < 0.0) zj = -zj;
+    zj1 = zj;
+    int kk = k0 + delta_phi;
+    if (kk == 0) kk = n_az;
+    if (kk == n_az + 1) kk = 1;
+    k1 = kk;
+  }
+  if (z1 == 0.0) z1 = L3D ? copysign(GRID_PREC, w) : GRID_PREC;
+}
+
 // move_to_grid_cyl (cylindrical_grid.f90:1284-1411)
 template <bool L3D>
 __device__ inline bool move_to_grid(const Lds& T, const DevModel& M, double& x, double& y, double& z,
@@ -761,6 +906,7 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
   unsigned int c_cross = 0, c_flight = 0, c_scatt = 0, c_abs = 0, c_esc = 0, c_kill = 0, c_dark = 0,
                c_pack = 0;
   unsigned int pk_cross = 0;  // crossings of the current packet (runaway guard)
+  double kf = 0.0;  // kappa_factor of the current cell (0 in virtual cells), fetched one crossing ahead
 
   for (int ep = 0;; ++ep) {  // outer iterations
     // ---- EMIT: pull the next packet id (wave-aggregated) -----------------
@@ -1003,6 +1149,7 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
       c_flight++;
       ri_o = 0; zj_o = 0; k_o = 0;
       xo = x; yo = y; zo = z;
+      kf = is_real_cell<L3D>(n_rad, nz, ri, zj) ? M.kappa_factor[cell_index<L3D>(n_rad, nz, ri, zj, k)] : 0.0;
       st = S_FLIGHT;
     }
 
@@ -1034,7 +1181,7 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
           bool mirrored = false;
           if (real_cell) {
             ic = cell_index<L3D>(n_rad, nz, ri, zj, k);
-            opacity = T.kappa[lambda - 1] * M.kappa_factor[ic];
+            opacity = T.kappa[lambda - 1] * kf;
             if (DARK) {
               if (M.dark[ic]) {  // optical_depth.f90:104-112
                 u = -u; v = -v; w = -w;
@@ -1049,7 +1196,7 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
           if (!mirrored) {
             double x1, y1, z1, l;
             int ri1, zj1, k1;
-            cross_cell<L3D>(T, M, x, y, z, u, v, w, inv_a, inv_w, ri, zj, k, x1, y1, z1, ri1, zj1, k1, l);
+            MCGPU_CROSS<L3D>(T, M, x, y, z, u, v, w, inv_a, inv_w, ri, zj, k, x1, y1, z1, ri1, zj1, k1, l);
             c_cross++;
             if (++pk_cross > 200000000u) {  // a packet that never leaves: flag it, drop it
               *A.err = 13;
@@ -1070,6 +1217,8 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
               if (DARK) { xo = x; yo = y; zo = z; ri_o = ri; zj_o = zj; k_o = k; }
               x = x1; y = y1; z = z1;
               ri = ri1; zj = zj1; k = k1;
+              // the next cell's opacity factor travels through L2 while the next crossing computes
+              kf = is_real_cell<L3D>(n_rad, nz, ri, zj) ? M.kappa_factor[cell_index<L3D>(n_rad, nz, ri, zj, k)] : 0.0;
             }
           }
         }
@@ -1116,9 +1265,9 @@ __global__ void __launch_bounds__(256) k_thermal(const DevModel M, const RunArgs
   thermal_body<L3D, POLA, DARK, false>(M, A, lds_raw);
 }
 
-// LDS-deposit variant: one 512-thread workgroup per CU shares one private grid.
+// LDS-deposit variant: one MCGPU_LDS_BLOCK-thread workgroup per CU shares one private grid.
 template <bool L3D, bool POLA, bool DARK>
-__global__ void __launch_bounds__(512) k_thermal_lds(const DevModel M, const RunArgs A) {
+__global__ void __launch_bounds__(MCGPU_LDS_BLOCK) k_thermal_lds(const DevModel M, const RunArgs A) {
   extern __shared__ double lds_raw[];
   thermal_body<L3D, POLA, DARK, true>(M, A, lds_raw);
 }
@@ -1161,7 +1310,7 @@ __global__ void k_probe_cross(const DevModel M, int n, const double* x0, const d
     const double inv_w = (fabs(w[i]) > TINY_REAL) ? 1.0 / w[i] : copysign(HUGE_DP, w[i]);
     const int c = cell[i] - 1;
     int ri1, zj1, k1;
-    cross_cell<L3D>(T, M, x0[i], y0[i], z0[i], u[i], v[i], w[i], inv_a, inv_w, cmi[c], cmj[c], cmk[c],
+    MCGPU_CROSS<L3D>(T, M, x0[i], y0[i], z0[i], u[i], v[i], w[i], inv_a, inv_w, cmi[c], cmj[c], cmk[c],
                     x1[i], y1[i], z1[i], ri1, zj1, k1, l[i]);
     next_cell[i] = icell_of(M.n_rad, M.nz, M.n_az, M.l3D, ri1, zj1, k1);
   }

@@ -405,7 +405,7 @@ extern "C" int mcgpu_launch_thermal(mcgpu_ctx* ctx, const mcgpu_run_opts* o) {
     }
   }
   const size_t lds_k = use_lds ? lds_e : lds;
-  const int max_threads = use_lds ? 512 : 256;
+  const int max_threads = use_lds ? MCGPU_LDS_BLOCK : 256;
   const int threads = o->block_threads > 0 ? o->block_threads : max_threads;
   if (threads % 64 || threads > max_threads)
     return fail(ctx, MCGPU_ERR_ARG, "block_threads must be a multiple of 64, at most 256 (HBM deposits) / 512 (LDS deposits)");

@@ -15,7 +15,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmcfost_hip.so")
+LIB_PATH = os.environ.get("MCGPU_LIB") or os.path.join(_HERE, "csrc", "libmcfost_hip.so")
 
 N_SED_TYPES = 9
 N_COUNTERS = 8

@@ -7,7 +7,9 @@ def run(env, packets=2e7, extra=()):
                          capture_output=True, text=True, env=e)
     try:
         j = json.loads(out.stdout.strip().split("\n")[-1])
-        return "%.3e pk/s  kernel %.1f ms" % (j["value"], j["roofline"]["kernel_ms"])
+        return "%.3e pk/s  kernel %.1f ms  %.1f cross/pk  %.3e cross/s" % (
+            j["value"], j["roofline"]["kernel_ms"], j["config"]["crossings_per_packet"],
+            j["value"] * j["config"]["crossings_per_packet"])
     except Exception:
         return out.stdout[-300:] + out.stderr[-600:]
 if __name__ == "__main__":
