@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--grid-blocks", type=int, default=0)
     ap.add_argument("--block-threads", type=int, default=0)
+    ap.add_argument("--no-pola", action="store_true", help="tuning aid: do not track Stokes Q,U,V")
     ap.add_argument("--frozen", action="store_true",
                     help="tuning aid: time the loop with the temperature feedback frozen to a prior "
                          "(keeps the physics identical across diagnostic builds); not the benchmark")
@@ -82,6 +83,8 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     cfg = {"ref41": M.ref41, "ref41_3d": M.ref41_3d, "pascucci": M.pascucci}[args.config]()
+    if args.no_pola:
+        cfg.lsepar_pola = False
     model = M.build_model(cfg)
     n_local = int(args.packets)
     n_total = n_local * world

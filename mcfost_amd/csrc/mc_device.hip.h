@@ -833,7 +833,8 @@ __device__ inline void deposit(double* E_glob, double* E_lds, int ic, double v) 
   else atomic_add_f64(&E_glob[ic], v);
 }
 
-enum : int { S_EMIT = 0, S_INTERACT = 1, S_NEWFLIGHT = 2, S_FLIGHT = 3, S_DONE = 4 };
+enum : int { S_EMIT = 0, S_INTERACT = 1, S_NEWFLIGHT = 2, S_FLIGHT = 3, S_DONE = 4, S_EXITED = 5 };
+constexpr unsigned long long PK_BATCH = 128;  // packet ids reserved per wave and global atomic
 
 // capteur, SED branch (output.f90:294-397,572-592)
 template <bool POLA>
@@ -906,23 +907,42 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
   unsigned int c_cross = 0, c_flight = 0, c_scatt = 0, c_abs = 0, c_esc = 0, c_kill = 0, c_dark = 0,
                c_pack = 0;
   unsigned int pk_cross = 0;  // crossings of the current packet (runaway guard)
+  unsigned long long pk_next = 0, pk_end = 0;  // this wave's reserved packet ids (wave-uniform)
   double kf = 0.0;  // kappa_factor of the current cell (0 in virtual cells), fetched one crossing ahead
 
   for (int ep = 0;; ++ep) {  // outer iterations
-    // ---- EMIT: pull the next packet id (wave-aggregated) -----------------
+    // ---- EXITED: bin the packets that left the grid (capteur) --------------
+    if (st == S_EXITED) {
+      capteur<POLA>(M, A.sed, lambda, u, v, w, S, flag_star, flag_scatt);
+      c_esc++;
+      st = S_EMIT;
+    }
+
+    // ---- EMIT: hand out packet ids from this wave's reserved batch; one global atomic per
+    // PK_BATCH packets and wave (the ids, hence the random streams, are independent of who
+    // runs them) ---------------------------------------------------------------------------
     {
       const bool need = (st == S_EMIT);
       const unsigned long long mask = __ballot(need);
       if (mask) {
-        const int leader = __ffsll((long long)mask) - 1;
-        unsigned long long base = 0;
-        if (lane == leader) base = atomicAdd(A.next_packet, (unsigned long long)__popcll(mask));
-        base = __shfl(base, leader);
-        if (need) {
-          const unsigned long long my = base + __popcll(mask & ((1ull << lane) - 1ull));
-          if (my >= A.n_packets) {
-            st = S_DONE;
-          } else {
+        if (pk_next >= pk_end) {  // wave-uniform
+          const int leader = __ffsll((long long)mask) - 1;
+          unsigned long long base = 0;
+          if (lane == leader) base = atomicAdd(A.next_packet, (unsigned long long)PK_BATCH);
+          base = __shfl(base, leader);
+          pk_next = base < A.n_packets ? base : A.n_packets;
+          pk_end = (base + PK_BATCH < A.n_packets) ? base + PK_BATCH : A.n_packets;
+          if (pk_end < pk_next) pk_end = pk_next;
+        }
+        const unsigned long long avail = pk_end - pk_next;
+        const unsigned long long rank = (unsigned long long)__popcll(mask & ((1ull << lane) - 1ull));
+        const unsigned long long cnt = (unsigned long long)__popcll(mask);
+        const unsigned long long my = pk_next + rank;
+        const bool served = need && (rank < avail);
+        if (need && !served && pk_next >= A.n_packets) st = S_DONE;  // nothing left anywhere
+        pk_next += (cnt < avail) ? cnt : avail;
+        if (served) {
+          {
             // mc_photon_loop body (dust_transfer.f90:529-541)
             rng.init(A.seed, A.first_packet + my);
             c_pack++;
@@ -1019,15 +1039,8 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
               *A.err = 12;  // ISM emission / missing prob_E_cell: not in scope
               st = S_DONE;
             }
-            if (st != S_DONE) {
-              if (lintersect) {
-                st = S_NEWFLIGHT;
-              } else {  // never entered the grid: binned directly (:549-550)
-                capteur<POLA>(M, A.sed, lambda, u, v, w, S, flag_star, flag_scatt);
-                c_esc++;
-                st = S_EMIT;
-              }
-            }
+            if (st != S_DONE) st = lintersect ? S_NEWFLIGHT : S_EXITED;  // never entered the grid:
+                                                                         // binned directly (:549-550)
           }
         }
       }
@@ -1168,9 +1181,7 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
           killed = (key == star_key);
         }
         if (out) {
-          capteur<POLA>(M, A.sed, lambda, u, v, w, S, flag_star, flag_scatt);
-          c_esc++;
-          st = S_EMIT;
+          st = S_EXITED;  // binned by capteur in the next outer phase
         } else if (killed) {
           c_kill++;
           st = S_EMIT;
