@@ -68,6 +68,7 @@ struct DevModel {
   const float* s34;
   const float* s44;
   const float* tab_g;
+  const double* cos_tab;  // [nang+1] cos(k*pi/nang), tabulated by the host (scattering.f90:1470-1471)
   // thermal
   int n_T;
   const double* log_Qcool;  // [n_T]
@@ -120,28 +121,38 @@ __host__ __device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
+// Per-packet random stream, drawn per EVENT so that a wavefront computes the Philox blocks in
+// lock-step (no per-draw refill branches) and the only state is the event counter:
+//   event 0 (emission + first flight): blocks 0,1,2 -> f[0..11]
+//       f0 wavelength, f1 star/disk choice, star: f2 select_star, f3..f6 uniform sphere,
+//       disk: f2 select_cellule, f3..f5 pos_em_cell, f6,f7 isotropic direction, f8 first tau
+//   event e >= 1 (e-th interaction + next flight): blocks 3+2(e-1), 4+2(e-1) -> g[0..7]
+//       g0 scatter/absorb, g1 rand, g2 rand2, scatter: g3 azimuth, absorb: g3,g4 isotropic
+//       direction, g5 tau of the next flight
 struct Rng {
-  uint32_t k0, k1;   // seed
-  uint32_t blk;      // block index in the packet's stream
-  uint32_t p_lo, p_hi;
-  uint32_t b0, b1, b2, b3;
-  int have;
+  uint32_t k0, k1;      // seed (wave-uniform)
+  uint32_t p_lo, p_hi;  // packet id
+  uint32_t event;       // next event index
   __device__ inline void init(uint64_t seed, uint64_t packet) {
     k0 = (uint32_t)seed; k1 = (uint32_t)(seed >> 32);
-    blk = 0; p_lo = (uint32_t)packet; p_hi = (uint32_t)(packet >> 32);
-    have = 0;
+    p_lo = (uint32_t)packet; p_hi = (uint32_t)(packet >> 32);
+    event = 0;
   }
   // uniform default-real in [0,1), 24 bits
-  __device__ inline float next() {
-    if (have == 0) {
-      uint32_t o[4];
-      philox4x32_10(blk, 0u, p_lo, p_hi, k0, k1, o);
-      b0 = o[0]; b1 = o[1]; b2 = o[2]; b3 = o[3];
-      blk += 1; have = 4;
-    }
-    uint32_t u = (have == 4) ? b0 : (have == 3) ? b1 : (have == 2) ? b2 : b3;
-    have -= 1;
-    return (float)(u >> 8) * (1.0f / 16777216.0f);
+  static __device__ inline float real(uint32_t u) { return (float)(u >> 8) * (1.0f / 16777216.0f); }
+  __device__ inline void block(uint32_t b, float* f) const {
+    uint32_t o[4];
+    philox4x32_10(b, 0u, p_lo, p_hi, k0, k1, o);
+    f[0] = real(o[0]); f[1] = real(o[1]); f[2] = real(o[2]); f[3] = real(o[3]);
+  }
+  __device__ inline void emission_event(float f[12]) {
+    block(0u, f); block(1u, f + 4); block(2u, f + 8);
+    event = 1;
+  }
+  __device__ inline void interaction_event(float g[8]) {
+    const uint32_t first = 3u + 2u * (event - 1u);
+    block(first, g); block(first + 1u, g + 4);
+    event += 1;
   }
 };
 
@@ -160,6 +171,7 @@ struct Lds {
   double* cum;      // n_lambda+1
   double* fstar;    // n_lambda
   double* cdf;      // n_lambda*n_T
+  double* cost;     // nang+1
   float* albedo;    // n_lambda
   float* prob;      // (nang+1) * (p_lambda_fixed ? 1 : n_lambda)
   float* g;         // n_lambda
@@ -167,7 +179,7 @@ struct Lds {
 
 __host__ __device__ inline size_t lds_doubles(const DevModel& M) {
   return (size_t)(M.n_rad + 1) + M.n_rad + M.n_rad + M.n_rad + M.n_az + M.n_lambda + M.n_lambda + M.n_T +
-         (M.n_lambda + 1) + M.n_lambda + (size_t)M.n_lambda * M.n_T;
+         (M.n_lambda + 1) + M.n_lambda + (size_t)M.n_lambda * M.n_T + (M.nang + 1);
 }
 __host__ __device__ inline size_t lds_floats(const DevModel& M) {
   return (size_t)M.n_lambda + (size_t)(M.nang + 1) * (M.p_lambda_fixed ? 1 : M.n_lambda) + M.n_lambda;
@@ -190,6 +202,7 @@ __device__ inline Lds lds_carve(double* base, const DevModel& M) {
   T.cum = p; p += M.n_lambda + 1;
   T.fstar = p; p += M.n_lambda;
   T.cdf = p; p += (size_t)M.n_lambda * M.n_T;
+  T.cost = p; p += M.nang + 1;
   float* f = reinterpret_cast<float*>(p);
   T.albedo = f; f += M.n_lambda;
   T.prob = f; f += (size_t)(M.nang + 1) * (M.p_lambda_fixed ? 1 : M.n_lambda);
@@ -214,6 +227,7 @@ __device__ inline void lds_stage(const Lds& T, const DevModel& M) {
   stage(T.cum, M.spec_cum, (size_t)M.n_lambda + 1);
   stage(T.fstar, M.frac_E_stars, (size_t)M.n_lambda);
   stage(T.cdf, M.cdf, (size_t)M.n_lambda * M.n_T);
+  stage(T.cost, M.cos_tab, (size_t)M.nang + 1);
   stage(T.albedo, M.albedo, (size_t)M.n_lambda);
   stage(T.prob, M.prob_s11, (size_t)(M.nang + 1) * (M.p_lambda_fixed ? 1 : M.n_lambda));
   stage(T.g, M.tab_g, (size_t)M.n_lambda);
@@ -908,9 +922,19 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
                c_pack = 0;
   unsigned int pk_cross = 0;  // crossings of the current packet (runaway guard)
   unsigned long long pk_next = 0, pk_end = 0;  // this wave's reserved packet ids (wave-uniform)
+  float tau_rand = 0.0f;  // the current event's draw for the next flight's optical depth
   double kf = 0.0;  // kappa_factor of the current cell (0 in virtual cells), fetched one crossing ahead
 
+#ifdef MCGPU_PHASE_TIMING
+  unsigned long long tp_emit = 0, tp_int = 0, tp_new = 0, tp_fly = 0, tp0;
+#define TP_START() tp0 = clock64()
+#define TP_ADD(acc) do { unsigned long long t1_ = clock64(); acc += t1_ - tp0; tp0 = t1_; } while (0)
+#else
+#define TP_START()
+#define TP_ADD(acc)
+#endif
   for (int ep = 0;; ++ep) {  // outer iterations
+    TP_START();
     // ---- EXITED: bin the packets that left the grid (capteur) --------------
     if (st == S_EXITED) {
       capteur<POLA>(M, A.sed, lambda, u, v, w, S, flag_star, flag_scatt);
@@ -947,7 +971,10 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
             rng.init(A.seed, A.first_packet + my);
             c_pack++;
             pk_cross = 0;
-            float rand = rng.next();
+            float f[12];
+            rng.emission_event(f);
+            tau_rand = f[8];
+            float rand = f[0];
             {  // select_wl_em (thermal_emission.f90:364-400)
               int kmin = 0, kmax = M.n_lambda, kk = (kmin + kmax) / 2;
               while (T.cum[kk] != (double)rand) {
@@ -960,12 +987,12 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
             atomic_add_f64(&A.n_sent[lambda - 1], 1.0);
             // emit_packet (dust_transfer.f90:1047-1151)
             bool lintersect = true;
-            rand = rng.next();
+            rand = f[1];
             flag_scatt = false;
             S[0] = 1.0; S[1] = 0.0; S[2] = 0.0; S[3] = 0.0;
             if ((double)rand <= T.fstar[lambda - 1]) {
               flag_star = true;
-              rand = rng.next();
+              rand = f[2];
               int i_star;
               {  // select_star (stars.f90:75-104)
                 int kmin = 0, kmax = M.n_stars, kk = (kmax - kmin) / 2;
@@ -976,7 +1003,7 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
                 }
                 i_star = kmax;
               }
-              const float r1 = rng.next(), r2 = rng.next(), r3 = rng.next(), r4 = rng.next();
+              const float r1 = f[3], r2 = f[4], r3 = f[5], r4 = f[6];
               // emit_packet_uniform_sphere (stars.f90:108-169)
               z = 2.0 * (double)r1 - 1.0;
               const double srw02 = sqrt(1.0 - z * z);
@@ -998,7 +1025,7 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
                 lintersect = move_to_grid<L3D>(T, M, x, y, z, u, v, w, ri, zj, k);
             } else if ((double)rand <= M.frac_E_disk[lambda - 1] && M.prob_E_cell) {
               flag_star = false;
-              rand = rng.next();
+              rand = f[2];
               int icell;
               {  // select_cellule (thermal_emission.f90:2044-2073)
                 const double* p = M.prob_E_cell + (size_t)(M.n_cells + 1) * (lambda - 1);
@@ -1023,13 +1050,13 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
                   k = 1;
                 }
               }
-              const float r1 = rng.next(), r2 = rng.next(), r3 = rng.next();
+              const float r1 = f[3], r2 = f[4], r3 = f[5];
               pos_em_cell<L3D>(T, M, ri, zj, k, r1, r2, r3, x, y, z);
               // random_isotropic_direction (random_numbers.f90:32-51)
-              rand = rng.next();
+              rand = f[6];
               w = 2.0 * (double)rand - 1.0;
               const double uv = sqrt(1.0 - w * w);
-              rand = rng.next();
+              rand = f[7];
               const double ph = PI * (2.0 * (double)rand - 1.0);
               double sp, cp;
               sincos(ph, &sp, &cp);
@@ -1046,16 +1073,19 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
       }
     }
 
+    TP_ADD(tp_emit);
     // ---- INTERACT: scatter or absorb + re-emit (dust_transfer.f90:1260-1402)
     if (st == S_INTERACT) {
-      float rand = rng.next();
-      if (rand < T.albedo[lambda - 1]) {
+      float g[8];
+      rng.interaction_event(g);
+      tau_rand = g[5];
+      const bool scat = g[0] < T.albedo[lambda - 1];  // dust_transfer.f90:1284
+      const float rand = g[1], rand2 = g[2];
+      int itheta = 1;
+      double cospsi, phi;
+      if (scat) {
         flag_scatt = true;
         c_scatt++;
-        rand = rng.next();
-        const float rand2 = rng.next();
-        int itheta;
-        double cospsi;
         if (M.aniso_method == 1) {
           // angle_diff_theta_pos (scattering.f90:1433-1475)
           const float* prob = T.prob + (M.p_lambda_fixed ? 0 : (size_t)(M.nang + 1) * (lambda - 1));
@@ -1065,15 +1095,14 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
             kk = (kmin + kmax) / 2;
           }
           itheta = kmax;
-          const double c0 = cos(((double)itheta - 1.0) * PI / (double)M.nang);
-          const double c1 = cos(((double)itheta) * PI / (double)M.nang);
+          const double c0 = T.cost[itheta - 1], c1 = T.cost[itheta];
           cospsi = c0 + (double)rand2 * (c1 - c0);
         } else {
           // hg (scattering.f90:1354-1383)
-          const float g = T.g[lambda - 1];
+          const float gg = T.g[lambda - 1];
           const double rand_dp = fmin((double)rand, 1.0 - 1e-6);
-          if (fabsf(g) > 1.17549435e-38f) {
-            const double g1 = (double)g, g2 = g1 * g1;
+          if (fabsf(gg) > 1.17549435e-38f) {
+            const double g1 = (double)gg, g2 = g1 * g1;
             const double q = (1.0 - g2) / (1.0 - g1 + 2.0 * g1 * rand_dp);
             cospsi = (1.0 + g2 - q * q) / (2.0 * g1);
           } else {
@@ -1083,27 +1112,11 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
           if (itheta > M.nang) itheta = M.nang;
         }
         if (M.lisotropic) { itheta = 1; cospsi = 2.0 * (double)rand - 1.0; }
-        rand = rng.next();
-        const double phi = PI * (2.0 * (double)rand - 1.0);
-        double u1, v1, w1;
-        cdapres(cospsi, phi, u, v, w, u1, v1, w1);
-        if (POLA && M.aniso_method == 1) {
-          const size_t o = (size_t)(M.nang + 1) * (lambda - 1) + itheta;
-          const float fr = rand2, fm = 1.0f - rand2;
-          const double M22 = (double)(M.s22[o] * fr + M.s22[o - 1] * fm);
-          const double M12 = (double)(M.s12[o] * fr + M.s12[o - 1] * fm);
-          const double M33 = (double)(M.s33[o] * fr + M.s33[o - 1] * fm);
-          const double M44 = (double)(M.s44[o] * fr + M.s44[o - 1] * fm);
-          const double M34 = (double)(-M.s34[o] * fr - M.s34[o - 1] * fm);
-          update_stokes(S, u, v, w, u1, v1, w1, M12, M22, M33, M34, M44);
-        }
-        u = u1; v = v1; w = w1;
+        phi = PI * (2.0 * (double)g[3] - 1.0);
       } else {
         c_abs++;
         flag_star = false;
         flag_scatt = false;
-        rand = rng.next();
-        const float rand2 = rng.next();
         // im_reemission_LTE (thermal_emission.f90:710-771)
         const int ic = cell_index<L3D>(n_rad, nz, ri, zj, k);
         double E;
@@ -1131,24 +1144,35 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
           l = (l1 + l2) / 2;
         }
         lambda = l + 1;
-        // random_isotropic_direction
-        rand = rng.next();
-        w = 2.0 * (double)rand - 1.0;
-        const double uv = sqrt(1.0 - w * w);
-        rand = rng.next();
-        const double ph = PI * (2.0 * (double)rand - 1.0);
-        double sp, cp;
-        sincos(ph, &sp, &cp);
-        u = uv * cp;
-        v = uv * sp;
-        S[1] = 0.0; S[2] = 0.0; S[3] = 0.0;
+        // random_isotropic_direction (random_numbers.f90:32-51): w = 2r-1, (u,v) = sqrt(1-w^2)
+        // (cos,sin)(phi) is cdapres' own |w0| > 0.999999 branch applied to the z axis
+        cospsi = 2.0 * (double)g[3] - 1.0;
+        phi = PI * (2.0 * (double)g[4] - 1.0);
       }
+      // new direction: one instruction stream for both kinds of event
+      double u1, v1, w1;
+      cdapres(cospsi, phi, scat ? u : 0.0, scat ? v : 0.0, scat ? w : 1.0, u1, v1, w1);
+      if (POLA) {
+        if (scat && M.aniso_method == 1) {
+          const size_t o = (size_t)(M.nang + 1) * (lambda - 1) + itheta;
+          const float fr = rand2, fm = 1.0f - rand2;
+          const double M22 = (double)(M.s22[o] * fr + M.s22[o - 1] * fm);
+          const double M12 = (double)(M.s12[o] * fr + M.s12[o - 1] * fm);
+          const double M33 = (double)(M.s33[o] * fr + M.s33[o - 1] * fm);
+          const double M44 = (double)(M.s44[o] * fr + M.s44[o - 1] * fm);
+          const double M34 = (double)(-M.s34[o] * fr - M.s34[o - 1] * fm);
+          update_stokes(S, u, v, w, u1, v1, w1, M12, M22, M33, M34, M44);
+        }
+        if (!scat) { S[1] = 0.0; S[2] = 0.0; S[3] = 0.0; }
+      }
+      u = u1; v = v1; w = w1;
       st = S_NEWFLIGHT;
     }
 
+    TP_ADD(tp_int);
     // ---- NEWFLIGHT: optical depth to the next event + per-flight constants
     if (st == S_NEWFLIGHT) {
-      const float rand = rng.next();  // dust_transfer.f90:1208-1215 (tau in FP64)
+      const float rand = tau_rand;  // dust_transfer.f90:1208-1215 (tau in FP64)
       extr = (rand > 1.0e-6f) ? -log(1.0 - (double)rand) : (double)rand;
       const double a = u * u + v * v;  // cylindrical_grid.f90:941-952
       inv_a = (a > TINY_REAL) ? 1.0 / a : HUGE_REAL;
@@ -1166,6 +1190,7 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
       st = S_FLIGHT;
     }
 
+    TP_ADD(tp_new);
     if (__ballot(st != S_DONE) == 0ull) break;
 
     // ---- FLIGHT: cell crossings (physical_length, optical_depth.f90:77-178)
@@ -1235,6 +1260,7 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
         }
       }
     }
+    TP_ADD(tp_fly);
     // ---- barrier-free partial fold: every A.flush_every outer iterations this wave swaps
     // one slice of the workgroup's private grid to zero (ds_wrxchg_rtn_b64) and adds what it
     // took to HBM.  Slices rotate over the waves, so the whole grid keeps flowing into the
@@ -1261,6 +1287,12 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
 
   // ---- counters: wave reduce, one atomic per wave and counter -------------
   unsigned int cs[8] = {c_pack, c_cross, c_flight, c_scatt, c_abs, c_esc, c_kill, c_dark};
+#ifdef MCGPU_PHASE_TIMING  // diagnostic build: four counters carry per-wave phase cycles / 1024
+  cs[3] = lane == 0 ? (unsigned int)(tp_emit >> 10) : 0u;
+  cs[4] = lane == 0 ? (unsigned int)(tp_int >> 10) : 0u;
+  cs[6] = lane == 0 ? (unsigned int)(tp_new >> 10) : 0u;
+  cs[7] = lane == 0 ? (unsigned int)(tp_fly >> 10) : 0u;
+#endif
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
     unsigned long long vsum = cs[q];
@@ -1351,7 +1383,11 @@ __global__ void k_probe_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c
 __global__ void k_probe_rand(uint64_t seed, uint64_t packet, int n, float* out) {
   Rng r;
   r.init(seed, packet);
-  for (int i = 0; i < n; ++i) out[i] = r.next();
+  for (int i = 0; i < n; i += 4) {
+    float f[4];
+    r.block((uint32_t)(i / 4), f);
+    for (int q = 0; q < 4 && i + q < n; ++q) out[i + q] = f[q];
+  }
 }
 
 }  // namespace mcgpu

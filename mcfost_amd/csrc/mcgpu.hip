@@ -264,6 +264,11 @@ extern "C" int mcgpu_set_scattering(mcgpu_ctx* ctx, int nang_scatt, int aniso_me
   int rc;
   if ((rc = upload(ctx, prob_s11_pos, nt, &M.prob_s11))) return rc;
   if ((rc = upload(ctx, tab_g_pos, (size_t)M.n_lambda, &M.tab_g))) return rc;
+  {  // bin-edge cosines of angle_diff_theta_pos (scattering.f90:1470-1471), same expression
+    std::vector<double> ct(nang_scatt + 1);
+    for (int k = 0; k <= nang_scatt; ++k) ct[k] = std::cos(((double)k) * PI / (double)nang_scatt);
+    if ((rc = upload(ctx, ct.data(), ct.size(), &M.cos_tab))) return rc;
+  }
   if (ctx->lsepar_pola) {
     if ((rc = upload(ctx, s12, nt, &M.s12))) return rc;
     if ((rc = upload(ctx, s22, nt, &M.s22))) return rc;

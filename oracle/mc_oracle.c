@@ -62,41 +62,65 @@ void oracle_philox4x32_10(const uint32_t ctr_in[4], const uint32_t key_in[2],
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
+/*
+ * Random stream layout (ours; the reference draws sequentially from SPRNG).  A packet's
+ * stream is the sequence of Philox blocks ctr = (block, 0, packet_lo, packet_hi), four
+ * default-real uniforms per block.  Draws are grouped per EVENT so that a wavefront computes
+ * them in lock-step:
+ *   event 0 (emission + first flight): blocks 0,1,2 -> f[0..11]
+ *       f0 wavelength (select_wl_em)      f1 star / disk / ISM choice
+ *       star:  f2 select_star, f3..f6 emit_packet_uniform_sphere
+ *       disk:  f2 select_cellule, f3..f5 pos_em_cell, f6,f7 isotropic direction
+ *       f8 optical depth of the first flight
+ *   event e >= 1 (e-th interaction + next flight): blocks 3+2(e-1), 4+2(e-1) -> g[0..7]
+ *       g0 scatter / absorb choice, g1 rand, g2 rand2
+ *       scatter: g3 azimuth          absorb: g3,g4 isotropic direction
+ *       g5 optical depth of the next flight
+ */
 typedef struct {
   uint32_t key[2];
-  uint32_t ctr[4];
-  uint32_t buf[4];
-  int have; /* unread values in buf */
+  uint32_t p_lo, p_hi;
+  uint32_t event;   /* next event index */
+  float ev[12];     /* the current event's uniforms */
+  int pos;          /* next unread entry of ev */
+  int tau_idx;      /* where the current event keeps the flight's optical-depth draw */
 } rng_t;
+
+static inline float u32_to_real(uint32_t u) {
+  /* Uniform default-real in [0,1) with 24 random bits (the reference rounds SPRNG's double
+   * to default real at every call site, e.g. dust_transfer.f90:536,1073,1208). */
+  return (float)(u >> 8) * (1.0f / 16777216.0f);
+}
 
 static void rng_init(rng_t *r, uint64_t seed, uint64_t packet) {
   r->key[0] = (uint32_t)seed;
   r->key[1] = (uint32_t)(seed >> 32);
-  r->ctr[0] = 0; /* block index within the packet's stream */
-  r->ctr[1] = 0;
-  r->ctr[2] = (uint32_t)packet;
-  r->ctr[3] = (uint32_t)(packet >> 32);
-  r->have = 0;
+  r->p_lo = (uint32_t)packet;
+  r->p_hi = (uint32_t)(packet >> 32);
+  r->event = 0;
+  r->pos = 0;
+  r->tau_idx = 8;
 }
-/* Uniform default-real in [0,1) with 24 random bits (the reference rounds
- * SPRNG's double to default real at every call site, e.g.
- * dust_transfer.f90:536,1073,1208). */
-static inline float rng_float(rng_t *r) {
-  if (r->have == 0) {
-    oracle_philox4x32_10(r->ctr, r->key, r->buf);
-    r->ctr[0] += 1;
-    r->have = 4;
+static void rng_begin_event(rng_t *r) {
+  const uint32_t first = r->event == 0 ? 0u : 3u + 2u * (r->event - 1u);
+  const int nb = r->event == 0 ? 3 : 2;
+  for (int b = 0; b < nb; ++b) {
+    uint32_t ctr[4] = {first + (uint32_t)b, 0u, r->p_lo, r->p_hi}, out[4];
+    oracle_philox4x32_10(ctr, r->key, out);
+    for (int q = 0; q < 4; ++q) r->ev[4 * b + q] = u32_to_real(out[q]);
   }
-  uint32_t u = r->buf[4 - r->have];
-  r->have -= 1;
-  return (float)(u >> 8) * (1.0f / 16777216.0f);
+  r->tau_idx = r->event == 0 ? 8 : 5;
+  r->pos = 0;
+  r->event += 1;
 }
+static inline float rng_float(rng_t *r) { return r->ev[r->pos++]; }
+static inline float rng_tau(const rng_t *r) { return r->ev[r->tau_idx]; }
+
 float oracle_packet_rand(uint64_t seed, uint64_t packet, uint32_t n) {
-  rng_t r;
-  rng_init(&r, seed, packet);
-  float f = 0.0f;
-  for (uint32_t i = 0; i <= n; ++i) f = rng_float(&r);
-  return f;
+  uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+  uint32_t ctr[4] = {n / 4u, 0u, (uint32_t)packet, (uint32_t)(packet >> 32)}, out[4];
+  oracle_philox4x32_10(ctr, key, out);
+  return u32_to_real(out[n % 4u]);
 }
 
 /* ------------------------------------------------------------------------ */
@@ -990,7 +1014,7 @@ static void propagate_packet(worker_t *W, int *lambda, int p_lambda,
   int flag_sortie = 0;
   *flag_scatt = 0;
   for (;;) {
-    float rand = rng_float(&W->rng);                          /* :1208 */
+    float rand = rng_tau(&W->rng);                            /* :1208 */
     double tau;
     if (W->o->tau_fp32) {
       float tf;
@@ -1006,6 +1030,7 @@ static void propagate_packet(worker_t *W, int *lambda, int p_lambda,
                     &flag_sortie, lpacket_alive);             /* :1243 */
     if (flag_sortie) return;                                  /* :1251 */
 
+    rng_begin_event(&W->rng);
     rand = rng_float(&W->rng);                                /* :1280 */
     if (rand < m->albedo[*lambda - 1]) {                      /* :1284 */
       *flag_scatt = 1;
@@ -1099,6 +1124,7 @@ static void capteur(worker_t *W, int lambda, double uin, double vin,
 static int one_packet(worker_t *W, uint64_t packet) {
   const oracle_model *m = W->m;
   rng_init(&W->rng, W->o->seed, packet);
+  rng_begin_event(&W->rng);
   W->cnt[ORC_CNT_PACKETS]++;
   int lambda, icell = 0, lintersect, flag_star, flag_ISM, flag_scatt = 0;
   int alive = 1;

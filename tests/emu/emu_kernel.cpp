@@ -89,6 +89,9 @@ extern "C" int emu_run_thermal(const oracle_model* m, const oracle_opts* o, cons
   M.p_lambda_fixed = m->p_lambda_fixed;
   M.prob_s11 = m->prob_s11_pos; M.s12 = m->s12_o_s11; M.s22 = m->s22_o_s11; M.s33 = m->s33_o_s11;
   M.s34 = m->s34_o_s11; M.s44 = m->s44_o_s11; M.tab_g = m->tab_g_pos;
+  std::vector<double> ct(m->nang_scatt + 1);
+  for (int k = 0; k <= m->nang_scatt; ++k) ct[k] = std::cos(((double)k) * PI / (double)m->nang_scatt);
+  M.cos_tab = ct.data();
   M.n_T = m->n_T; M.log_Qcool = m->log_Qcool; M.cdf = m->kdB_dT_CDF; M.spec_cum = m->spectre_emission_cumul;
   M.frac_E_stars = m->frac_E_stars; M.frac_E_disk = m->frac_E_disk; M.CDF_E_star = m->CDF_E_star;
   M.prob_E_cell = m->prob_E_cell; M.L_packet_th = m->L_packet_th;
