@@ -35,6 +35,12 @@ def cpu_baseline(model, n_total, target_s=15.0):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    try:  # container CPU quota (cgroup v2): more threads than the quota only get throttled
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(round(int(quota) / int(period)))))
+    except Exception:
+        pass
     orc = Oracle(model, n_total)
     t = time.perf_counter()
     orc.run_thermal(20000 * cores, seed=99, n_threads=cores)

@@ -391,7 +391,7 @@ extern "C" int mcgpu_launch_thermal(mcgpu_ctx* ctx, const mcgpu_run_opts* o) {
   A.next_packet = ctx->d_counters + 8;
   A.err = ctx->d_err;
   // tuning / diagnostic knobs (environment; defaults are the shipped configuration)
-  A.inner_iters = 32;
+  A.inner_iters = 24;
   A.flush_every = 16;
   A.flags = 0;
   if (const char* e = getenv("MCGPU_INNER_ITERS")) { int v = atoi(e); if (v >= 1 && v <= 4096) A.inner_iters = v; }

@@ -1,0 +1,228 @@
+! mcgpu_f.f90 -- ISO_C_BINDING interface to the MI355X packet engine
+! (libmcfost_hip.so, include/mcgpu.h) and the drop-in replacement of the body of
+!
+!     subroutine mc_photon_loop            (src/dust_transfer.f90:439-572)
+!
+! for the temperature step (letape_th = .true.).  Style follows the reference's
+! own bind(C) interface to voro++ (src/Voronoi.f90:70-96): `value` scalars,
+! assumed-size arrays, integer error code.
+!
+! The routine mcgpu_thermal_loop below takes, as explicit arguments, exactly the
+! module arrays the reference's OpenMP region shares (dust_transfer.f90:486-488
+! plus the tables those routines read); INTEGRATION.md shows the 30-line patch
+! that passes them from dust_transfer.f90.  Nothing here depends on MCFOST
+! modules, so the file compiles stand-alone (amdflang / gfortran / ifort).
+
+module mcgpu_f
+
+  use, intrinsic :: iso_c_binding
+  implicit none
+  private
+
+  integer, parameter :: dp = selected_real_kind(p=13,r=200) ! mcfost_env.f90:23
+
+  integer(c_int), parameter, public :: MCGPU_N_SED_TYPES = 9, MCGPU_N_COUNTERS = 8
+
+  type, bind(C), public :: mcgpu_run_opts
+     integer(c_int64_t) :: seed
+     integer(c_int64_t) :: first_packet
+     integer(c_int64_t) :: n_packets
+     real(c_double)     :: n_replicas
+     integer(c_int)     :: frozen
+     integer(c_int)     :: accumulate
+     integer(c_int)     :: grid_blocks
+     integer(c_int)     :: block_threads
+  end type mcgpu_run_opts
+
+  public :: mcgpu_create, mcgpu_destroy, mcgpu_set_grid_cyl, mcgpu_set_midplane_snap, mcgpu_set_stars, &
+       mcgpu_set_opacity, mcgpu_set_scattering, mcgpu_set_thermal, mcgpu_set_sed_bins, mcgpu_run_thermal, &
+       mcgpu_temp_finale, mcgpu_thermal_loop, mcgpu_error_message
+
+  interface
+     integer(c_int) function mcgpu_create(device, ctx) bind(C, name="mcgpu_create")
+       import :: c_int, c_ptr
+       integer(c_int), value :: device
+       type(c_ptr), intent(out) :: ctx
+     end function mcgpu_create
+
+     integer(c_int) function mcgpu_destroy(ctx) bind(C, name="mcgpu_destroy")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+     end function mcgpu_destroy
+
+     type(c_ptr) function mcgpu_last_error(ctx) bind(C, name="mcgpu_last_error")
+       import :: c_ptr
+       type(c_ptr), value :: ctx
+     end function mcgpu_last_error
+
+     integer(c_int) function mcgpu_set_grid_cyl(ctx, n_rad, nz, n_az, l3D, r_lim_2, zmax, z_lim, tan_phi_lim, &
+          zmaxmax, Rmax2, volume, cell_map, cell_map_i, cell_map_j, cell_map_k, lexit_cell) &
+          bind(C, name="mcgpu_set_grid_cyl")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: n_rad, nz, n_az, l3D
+       real(c_double), intent(in) :: r_lim_2(*), zmax(*), z_lim(*), tan_phi_lim(*), volume(*)
+       real(c_double), value :: zmaxmax, Rmax2
+       integer(c_int), intent(in) :: cell_map(*), cell_map_i(*), cell_map_j(*), cell_map_k(*), lexit_cell(*)
+     end function mcgpu_set_grid_cyl
+
+     integer(c_int) function mcgpu_set_midplane_snap(ctx, on) bind(C, name="mcgpu_set_midplane_snap")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: on
+     end function mcgpu_set_midplane_snap
+
+     integer(c_int) function mcgpu_set_stars(ctx, n_stars, x, y, z, r, icell, out_model) bind(C, name="mcgpu_set_stars")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: n_stars
+       real(c_double), intent(in) :: x(*), y(*), z(*), r(*)
+       integer(c_int), intent(in) :: icell(*), out_model(*)
+     end function mcgpu_set_stars
+
+     integer(c_int) function mcgpu_set_opacity(ctx, n_lambda, kappa, kappa_abs_LTE, tab_albedo_pos, kappa_factor, &
+          l_dark_zone) bind(C, name="mcgpu_set_opacity")
+       import :: c_int, c_ptr, c_double, c_float
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: n_lambda
+       real(c_double), intent(in) :: kappa(*), kappa_abs_LTE(*), kappa_factor(*)
+       real(c_float), intent(in) :: tab_albedo_pos(*)
+       type(c_ptr), value :: l_dark_zone     ! c_loc of an integer(c_int8_t) array, or c_null_ptr
+     end function mcgpu_set_opacity
+
+     integer(c_int) function mcgpu_set_scattering(ctx, nang_scatt, aniso_method, lisotropic, lsepar_pola, &
+          p_lambda_fixed, prob_s11_pos, s12, s22, s33, s34, s44, tab_g_pos) bind(C, name="mcgpu_set_scattering")
+       import :: c_int, c_ptr, c_float
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: nang_scatt, aniso_method, lisotropic, lsepar_pola, p_lambda_fixed
+       real(c_float), intent(in) :: prob_s11_pos(*), s12(*), s22(*), s33(*), s34(*), s44(*), tab_g_pos(*)
+     end function mcgpu_set_scattering
+
+     integer(c_int) function mcgpu_set_thermal(ctx, n_T, tab_Temp, log_Qcool, kdB_dT_CDF, spectre_emission_cumul, &
+          frac_E_stars, frac_E_disk, CDF_E_star, prob_E_cell, L_packet_th, T_min) bind(C, name="mcgpu_set_thermal")
+       import :: c_int, c_ptr, c_double, c_float
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: n_T
+       real(c_float), intent(in) :: tab_Temp(*)
+       real(c_double), intent(in) :: log_Qcool(*), kdB_dT_CDF(*), spectre_emission_cumul(*), frac_E_stars(*), &
+            frac_E_disk(*), CDF_E_star(*)
+       type(c_ptr), value :: prob_E_cell     ! c_loc(prob_E_cell) or c_null_ptr when frac_E_stars == 1
+       real(c_double), value :: L_packet_th
+       real(c_float), value :: T_min
+     end function mcgpu_set_thermal
+
+     integer(c_int) function mcgpu_set_sed_bins(ctx, N_thet, N_phi, l_sym_centrale, l_sym_axiale) &
+          bind(C, name="mcgpu_set_sed_bins")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: N_thet, N_phi, l_sym_centrale, l_sym_axiale
+     end function mcgpu_set_sed_bins
+
+     integer(c_int) function mcgpu_run_thermal(ctx, opts, E_abs, sed, n_sent, counters, kernel_ms) &
+          bind(C, name="mcgpu_run_thermal")
+       import :: c_int, c_ptr, c_double, c_int64_t, mcgpu_run_opts
+       type(c_ptr), value :: ctx
+       type(mcgpu_run_opts), intent(in) :: opts
+       real(c_double), intent(out) :: E_abs(*), sed(*), n_sent(*)
+       integer(c_int64_t), intent(out) :: counters(*)
+       real(c_double), intent(out) :: kernel_ms
+     end function mcgpu_run_thermal
+
+     integer(c_int) function mcgpu_temp_finale(ctx, E_abs, Tdust) bind(C, name="mcgpu_temp_finale")
+       import :: c_int, c_ptr, c_double, c_float
+       type(c_ptr), value :: ctx
+       real(c_double), intent(in) :: E_abs(*)
+       real(c_float), intent(out) :: Tdust(*)
+     end function mcgpu_temp_finale
+  end interface
+
+contains
+
+  ! The body of mc_photon_loop for the thermal step, on the GPU.
+  !
+  ! Inputs are the reference's module arrays, by the names they have there:
+  !   cylindrical_grid : r_lim_2, zmax, z_lim, tan_phi_lim, volume, cell_map, cell_map_i/j/k, lexit_cell,
+  !                      l_dark_zone, (zmaxmax = maxval(zmax))
+  !   parameters       : n_rad, nz, n_az, l3D, Rmax2, n_stars, star(:)%x,y,z,r,icell,out_model, n_T, T_min,
+  !                      N_thet, N_phi, l_sym_centrale, l_sym_axiale, nang_scatt, aniso_method, lisotropic,
+  !                      lsepar_pola
+  !   dust_prop/grains : kappa(1,:), kappa_abs_LTE(1,:), tab_albedo_pos(1,:), kappa_factor, prob_s11_pos(:,1,:),
+  !                      tab_s12/22/33/34/44_o_s11_pos(:,1,:), tab_g_pos(1,:)
+  !   thermal_emission : tab_Temp, log_Qcool_minus_extra_heating(:,1), kdB_dT_CDF(:,:,1),
+  !                      spectre_emission_cumul(0:), frac_E_stars, frac_E_disk, prob_E_cell, L_packet_th
+  !   stars            : CDF_E_star(:,0:)
+  ! Outputs go where the reference's reductions expect them:
+  !   xKJ_abs(:,1) = E_abs ; xKJ_abs(:,2:) = 0   -> Temp_finale (thermal_emission.f90:668) unchanged
+  !   sed, sed_q, ... (:,:,:,1) from sed(:,:,:,1:9) ; n_phot_envoyes(:,1) = n_sent
+  subroutine mcgpu_thermal_loop(n_packets, seed, &
+       n_rad, nz, n_az, l3D, r_lim_2, zmax, z_lim, tan_phi_lim, Rmax2, volume, cell_map, cell_map_i, cell_map_j, &
+       cell_map_k, lexit_cell, &
+       n_stars, star_x, star_y, star_z, star_r, star_icell, star_out_model, &
+       n_lambda, kappa, kappa_abs_LTE, tab_albedo_pos, kappa_factor, &
+       nang_scatt, aniso_method, lisotropic, lsepar_pola, prob_s11_pos, s12, s22, s33, s34, s44, tab_g_pos, &
+       n_T, tab_Temp, log_Qcool, kdB_dT_CDF, spectre_emission_cumul, frac_E_stars, frac_E_disk, CDF_E_star, &
+       L_packet_th, T_min, N_thet, N_phi, l_sym_centrale, l_sym_axiale, &
+       E_abs, sed, n_sent, kernel_ms, ierr)
+
+    integer(c_int64_t), intent(in) :: n_packets, seed
+    integer, intent(in) :: n_rad, nz, n_az, n_stars, n_lambda, nang_scatt, aniso_method, n_T, N_thet, N_phi
+    logical, intent(in) :: l3D, lisotropic, lsepar_pola, l_sym_centrale, l_sym_axiale
+    real(dp), intent(in) :: r_lim_2(*), zmax(*), z_lim(*), tan_phi_lim(*), volume(*), Rmax2
+    integer, intent(in) :: cell_map(*), cell_map_i(*), cell_map_j(*), cell_map_k(*), lexit_cell(*)
+    real(dp), intent(in) :: star_x(*), star_y(*), star_z(*), star_r(*)
+    integer, intent(in) :: star_icell(*), star_out_model(*)
+    real(dp), intent(in) :: kappa(*), kappa_abs_LTE(*), kappa_factor(*)
+    real, intent(in) :: tab_albedo_pos(*), prob_s11_pos(*), s12(*), s22(*), s33(*), s34(*), s44(*), tab_g_pos(*)
+    real, intent(in) :: tab_Temp(*), T_min
+    real(dp), intent(in) :: log_Qcool(*), kdB_dT_CDF(*), spectre_emission_cumul(*), frac_E_stars(*), &
+         frac_E_disk(*), CDF_E_star(*), L_packet_th
+    real(dp), intent(out) :: E_abs(*), sed(*), n_sent(*), kernel_ms
+    integer, intent(out) :: ierr
+
+    type(c_ptr) :: ctx
+    type(mcgpu_run_opts) :: opts
+    integer(c_int64_t) :: counters(MCGPU_N_COUNTERS)
+    integer(c_int) :: rc
+
+    ierr = 0
+    rc = mcgpu_create(0_c_int, ctx)
+    if (rc /= 0) then
+       ierr = rc ; return
+    endif
+    rc = mcgpu_set_grid_cyl(ctx, n_rad, nz, n_az, merge(1,0,l3D), r_lim_2, zmax, z_lim, tan_phi_lim, &
+         maxval(zmax(1:n_rad)), Rmax2, volume, cell_map, cell_map_i, cell_map_j, cell_map_k, lexit_cell)
+    if (rc == 0) rc = mcgpu_set_stars(ctx, n_stars, star_x, star_y, star_z, star_r, star_icell, star_out_model)
+    if (rc == 0) rc = mcgpu_set_opacity(ctx, n_lambda, kappa, kappa_abs_LTE, tab_albedo_pos, kappa_factor, c_null_ptr)
+    if (rc == 0) rc = mcgpu_set_scattering(ctx, nang_scatt, aniso_method, merge(1,0,lisotropic), &
+         merge(1,0,lsepar_pola), 1_c_int, prob_s11_pos, s12, s22, s33, s34, s44, tab_g_pos)
+    if (rc == 0) rc = mcgpu_set_thermal(ctx, n_T, tab_Temp, log_Qcool, kdB_dT_CDF, spectre_emission_cumul, &
+         frac_E_stars, frac_E_disk, CDF_E_star, c_null_ptr, L_packet_th, T_min)
+    if (rc == 0) rc = mcgpu_set_sed_bins(ctx, N_thet, N_phi, merge(1,0,l_sym_centrale), merge(1,0,l_sym_axiale))
+    if (rc == 0) then
+       opts%seed = seed ; opts%first_packet = 0 ; opts%n_packets = n_packets ; opts%n_replicas = 1.0_c_double
+       opts%frozen = 0 ; opts%accumulate = 0 ; opts%grid_blocks = 0 ; opts%block_threads = 0
+       rc = mcgpu_run_thermal(ctx, opts, E_abs, sed, n_sent, counters, kernel_ms)
+    endif
+    if (rc /= 0) write(*,*) "mcgpu error ", rc, ": ", trim(mcgpu_error_message(ctx))
+    ierr = rc
+    rc = mcgpu_destroy(ctx)
+
+  end subroutine mcgpu_thermal_loop
+
+  function mcgpu_error_message(ctx) result(msg)
+    type(c_ptr), intent(in) :: ctx
+    character(len=256) :: msg
+    type(c_ptr) :: p
+    character(kind=c_char), pointer :: s(:)
+    integer :: i
+    msg = ""
+    p = mcgpu_last_error(ctx)
+    if (.not. c_associated(p)) return
+    call c_f_pointer(p, s, (/ 256 /))
+    do i = 1, 256
+       if (s(i) == c_null_char) exit
+       msg(i:i) = s(i)
+    enddo
+  end function mcgpu_error_message
+
+end module mcgpu_f

@@ -257,3 +257,30 @@ def test_device_accumulator_is_visible_to_torch(small_model):
     assert np.array_equal(acc[:n_c].cpu().numpy(), res["E_abs"])
     assert int(cnt[0].item()) == 5000
     e.close()
+
+
+def test_fortran_host_through_iso_c_binding(small_model, tmp_path):
+    """The drop-in boundary as the reference's host would use it: a Fortran program
+    (mcfost_amd/fortran/thermal_host_example.f90) hands the module arrays to the
+    ISO_C_BINDING shim (mcgpu_f.f90) which calls the C-ABI."""
+    import os
+    import subprocess
+    from mcfost_amd.host import dump
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "mcfost_amd", "fortran", "build", "thermal_host_example")
+    if not os.path.exists(exe):
+        pytest.skip("Fortran host example not built (amdflang missing at build time)")
+    n, seed = 200000, 4242
+    fin, fout = str(tmp_path / "model.bin"), str(tmp_path / "result.bin")
+    dump.write_model(small_model, n, fin)
+    out = subprocess.run([exe, fin, fout, str(n), str(seed)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "packets/s" in out.stdout
+    f = dump.read_result(small_model, fout)
+    e = _engine(small_model, n)
+    p = e.run_thermal(n, seed=seed)
+    assert np.array_equal(f["n_sent"], p["n_sent"])            # emission wavelengths: deterministic
+    assert abs(f["sed"][4].sum() - p["sed"][4].sum()) <= 10    # all but the few star hits escape
+    Tf, Tp = e.temp_finale(f["E_abs"]), e.temp_finale(p["E_abs"])
+    assert rel_rms(Tf, Tp, 1.01 * small_model.cfg.T_min) < 0.02
+    e.close()

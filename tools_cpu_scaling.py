@@ -5,7 +5,7 @@ from oracle import Oracle
 m = M.build_model(M.ref41())
 o = Oracle(m, 1e6)
 print("affinity", len(os.sched_getaffinity(0)), "cpu_count", os.cpu_count())
-for nt in (1, 8, 32, 64, 128, 256):
-    n = 20000*nt
+for nt in (1, 16, 64, 128, 256):
+    n = 40000*nt
     t=time.perf_counter(); o.run_thermal(n, seed=3, n_threads=nt); dt=time.perf_counter()-t
-    print(nt, "threads", n/dt, "packets/s", n/dt/nt, "per thread")
+    print(nt, "threads %.3e packets/s  %.3e per thread" % (n/dt, n/dt/nt), flush=True)
