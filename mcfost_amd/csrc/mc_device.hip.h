@@ -98,6 +98,7 @@ struct RunArgs {
   int* err;
   int inner_iters;  // crossings attempted between two interaction phases
   int flush_every;  // LDS-deposit kernels: outer iterations per fold of the private grid
+  int min_active;   // leave the crossing loop early once fewer lanes than this are in flight
   int flags;        // diagnostics: bit 0 = skip the E_abs deposits (timing experiments only)
 };
 
@@ -1196,6 +1197,11 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
     // ---- FLIGHT: cell crossings (physical_length, optical_depth.f90:77-178)
 #pragma unroll 1
     for (int it = 0; it < A.inner_iters; ++it) {
+      if (A.min_active > 0 && it > 0) {
+        // leave early once fewer than min_active/64 of the lanes that still own a packet fly
+        const int flying = __popcll(__ballot(st == S_FLIGHT)), alive = __popcll(__ballot(st != S_DONE));
+        if (flying * 64 < A.min_active * alive) break;
+      }
       if (st == S_FLIGHT) {
         const int azj = zj < 0 ? -zj : zj;
         // test_exit_grid_cyl (cylindrical_grid.f90:680-704) in closed form

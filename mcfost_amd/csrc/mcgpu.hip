@@ -391,9 +391,11 @@ extern "C" int mcgpu_launch_thermal(mcgpu_ctx* ctx, const mcgpu_run_opts* o) {
   A.next_packet = ctx->d_counters + 8;
   A.err = ctx->d_err;
   // tuning / diagnostic knobs (environment; defaults are the shipped configuration)
-  A.inner_iters = 24;
+  A.inner_iters = 64;
   A.flush_every = 16;
   A.flags = 0;
+  A.min_active = 32;
+  if (const char* e = getenv("MCGPU_MIN_ACTIVE")) { int v = atoi(e); if (v >= 0 && v <= 64) A.min_active = v; }
   if (const char* e = getenv("MCGPU_INNER_ITERS")) { int v = atoi(e); if (v >= 1 && v <= 4096) A.inner_iters = v; }
   if (const char* e = getenv("MCGPU_FLUSH_EVERY")) { int v = atoi(e); if (v >= 1 && v <= 1000000) A.flush_every = v; }
   if (const char* e = getenv("MCGPU_DIAG_FLAGS")) A.flags = atoi(e);

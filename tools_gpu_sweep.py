@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 def run(env, packets=2e7, extra=()):
     e = dict(os.environ); e.update(env)
     out = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--packets", str(packets), "--no-cpu-baseline", *extra],
-                         capture_output=True, text=True, env=e)
+                         capture_output=True, text=True, env=e, timeout=150)
     try:
         j = json.loads(out.stdout.strip().split("\n")[-1])
         return "%.3e pk/s  kernel %.1f ms  %.1f cross/pk  %.3e cross/s" % (
