@@ -1,7 +1,7 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 os.environ["MCGPU_LIB"] = os.path.abspath("mcfost_amd/csrc/variants/lib_timing.so")
-os.environ.setdefault("MCGPU_INNER_ITERS", "16")
+pass
 from mcfost_amd.host import model as M
 from mcfost_amd.engine import Engine
 cfgname = sys.argv[1] if len(sys.argv) > 1 else "ref41"
