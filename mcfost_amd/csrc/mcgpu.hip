@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "mc_device.hip.h"
+#include "mc_rounds.hip.h"
 
 using namespace mcgpu;
 
@@ -40,6 +41,13 @@ struct mcgpu_ctx {
   int* d_err = nullptr;
   double* d_E_prior = nullptr;
   bool launched = false;
+  // packet pool of the two-kernel ("rounds") engine
+  Pool pool;
+  size_t pool_slots = 0;
+  bool pool_pola = false;
+  std::vector<void*> pool_allocs;
+  int* d_list = nullptr;
+  unsigned int* d_round_counts = nullptr;  // [0] list_n, [1] flying_n
 };
 
 #define HIPCHK(call)                                                              \
@@ -103,6 +111,9 @@ extern "C" int mcgpu_destroy(mcgpu_ctx* ctx) {
   if (ctx->d_counters) hipFree(ctx->d_counters);
   if (ctx->d_err) hipFree(ctx->d_err);
   if (ctx->d_E_prior) hipFree(ctx->d_E_prior);
+  for (void* p : ctx->pool_allocs) hipFree(p);
+  if (ctx->d_list) hipFree(ctx->d_list);
+  if (ctx->d_round_counts) hipFree(ctx->d_round_counts);
   if (ctx->ev0) hipEventDestroy(ctx->ev0);
   if (ctx->ev1) hipEventDestroy(ctx->ev1);
   if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
@@ -361,6 +372,111 @@ static hipError_t launch_k(const DevModel& M, const RunArgs& A, int blocks, int 
   return hipGetLastError();
 }
 
+// ---- the two-kernel engine (mc_rounds.hip.h) -------------------------------------------------
+static int ensure_pool(mcgpu_ctx* ctx, size_t n_slots, bool pola) {
+  if (ctx->pool_slots == n_slots && ctx->pool_pola == pola) return MCGPU_OK;
+  for (void* p : ctx->pool_allocs) hipFree(p);
+  ctx->pool_allocs.clear();
+  if (ctx->d_list) { hipFree(ctx->d_list); ctx->d_list = nullptr; }
+  ctx->pool_slots = 0;
+  Pool& P = ctx->pool;
+  P.n_slots = (int)n_slots;
+  auto dal = [&](double** p, size_t n) -> hipError_t { hipError_t e = hipMalloc((void**)p, n * sizeof(double)); if (e == hipSuccess) ctx->pool_allocs.push_back(*p); return e; };
+  auto ial = [&](int** p) -> hipError_t { hipError_t e = hipMalloc((void**)p, n_slots * sizeof(int)); if (e == hipSuccess) ctx->pool_allocs.push_back(*p); return e; };
+  double** dd[7] = {&P.x, &P.y, &P.z, &P.u, &P.v, &P.w, &P.extr};
+  for (auto q : dd) HIPCHK(dal(q, n_slots));
+  P.S = nullptr;
+  if (pola) HIPCHK(dal(&P.S, 4 * n_slots));
+  int** ii[6] = {&P.ri, &P.zj, &P.k, &P.lambda, &P.star_key, &P.st};
+  for (auto q : ii) HIPCHK(ial(q));
+  int** uu[3] = {(int**)&P.p_lo, (int**)&P.p_hi, (int**)&P.event};
+  for (auto q : uu) HIPCHK(ial(q));
+  HIPCHK(hipMalloc((void**)&ctx->d_list, n_slots * sizeof(int)));
+  if (!ctx->d_round_counts) HIPCHK(hipMalloc((void**)&ctx->d_round_counts, 4 * sizeof(unsigned int)));
+  ctx->pool_slots = n_slots;
+  ctx->pool_pola = pola;
+  return MCGPU_OK;
+}
+
+template <bool L3D, bool POLA, bool DARK, bool LDSE>
+static hipError_t launch_fly(const DevModel& M, const RunArgs& A, const Pool& P, const RoundArgs& R, int blocks,
+                             int threads, size_t lds, hipStream_t s) {
+  if (LDSE) hipLaunchKernelGGL((k_fly_lds<L3D, POLA, DARK>), dim3(blocks), dim3(threads), lds, s, M, A, P, R);
+  else hipLaunchKernelGGL((k_fly_hbm<L3D, POLA, DARK>), dim3(blocks), dim3(threads), lds, s, M, A, P, R);
+  return hipGetLastError();
+}
+template <bool L3D, bool POLA, bool DARK, bool LDSE>
+static const void* fly_fn() {
+  return LDSE ? (const void*)k_fly_lds<L3D, POLA, DARK> : (const void*)k_fly_hbm<L3D, POLA, DARK>;
+}
+
+template <bool L3D, bool POLA, bool DARK, bool LDSE>
+static int run_rounds_t(mcgpu_ctx* ctx, RunArgs A, const mcgpu_run_opts* o) {
+  const DevModel& M = ctx->M;
+  const size_t lds_serve = lds_bytes(M);
+  const size_t lds_fly = ((LDSE ? (size_t)M.n_cells : 0) + lds_fly_doubles(M)) * sizeof(double);
+  const void* ffn = fly_fn<L3D, POLA, DARK, LDSE>();
+  HIPCHK(hipFuncSetAttribute(ffn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fly));
+  HIPCHK(hipFuncSetAttribute((const void*)k_serve<L3D, POLA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_serve));
+  int fly_threads = LDSE ? 1024 : 512;
+  if (o->block_threads > 0) fly_threads = o->block_threads;
+  if (fly_threads % 64 || fly_threads > (LDSE ? 1024 : 512)) return fail(ctx, MCGPU_ERR_ARG, "block_threads out of range for the rounds engine");
+  int occ = 1;
+  HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ffn, fly_threads, lds_fly));
+  if (occ < 1) occ = 1;
+  int fly_blocks = o->grid_blocks > 0 ? o->grid_blocks : ctx->prop.multiProcessorCount * occ;
+  const size_t n_lanes = (size_t)fly_blocks * fly_threads;
+  int n_passes = 16;
+  if (const char* e = getenv("MCGPU_PASSES")) { int v = atoi(e); if (v >= 1 && v <= 1024) n_passes = v; }
+  {  // no more slots than packets
+    const unsigned long long need = (o->n_packets + n_lanes - 1) / n_lanes;
+    if ((unsigned long long)n_passes > need) n_passes = (int)(need ? need : 1);
+  }
+  const size_t n_slots = n_lanes * n_passes;
+  int rc = ensure_pool(ctx, n_slots, POLA);
+  if (rc) return rc;
+  const Pool& P = ctx->pool;
+  RoundArgs R;
+  R.list = ctx->d_list; R.list_n = ctx->d_round_counts; R.flying_n = ctx->d_round_counts + 1; R.n_passes = n_passes;
+  hipStream_t s = ctx->stream;
+  hipLaunchKernelGGL(k_pool_init, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, s, P, ctx->d_list);
+  HIPCHK(hipGetLastError());
+  unsigned int h_counts[2] = {(unsigned int)n_slots, 0u};
+  HIPCHK(hipMemcpyAsync(ctx->d_round_counts, h_counts, sizeof(h_counts), hipMemcpyHostToDevice, s));
+  int serve_occ = 1;
+  HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&serve_occ, (const void*)k_serve<L3D, POLA>, 256, lds_serve));
+  if (serve_occ < 1) serve_occ = 1;
+  const int serve_blocks = ctx->prop.multiProcessorCount * serve_occ;
+  int check_every = 4;
+  const long max_rounds = 4000000;
+  for (long round = 0; round < max_rounds; ++round) {
+    hipLaunchKernelGGL((k_serve<L3D, POLA>), dim3(serve_blocks), dim3(256), lds_serve, s, M, A, P, R);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemsetAsync(ctx->d_round_counts, 0, 2 * sizeof(unsigned int), s));
+    hipError_t e = launch_fly<L3D, POLA, DARK, LDSE>(M, A, P, R, fly_blocks, fly_threads, lds_fly, s);
+    if (e != hipSuccess) { ctx->err = std::string("k_fly launch: ") + hipGetErrorString(e); return MCGPU_ERR_HIP; }
+    if ((round + 1) % check_every == 0) {
+      HIPCHK(hipMemcpyAsync(h_counts, ctx->d_round_counts, sizeof(h_counts), hipMemcpyDeviceToHost, s));
+      HIPCHK(hipStreamSynchronize(s));
+      if (h_counts[0] == 0 && h_counts[1] == 0) return MCGPU_OK;
+    }
+  }
+  return fail(ctx, MCGPU_ERR_KERNEL, "rounds engine: packets still in flight after the round limit");
+}
+
+static int run_rounds(mcgpu_ctx* ctx, const RunArgs& A, const mcgpu_run_opts* o, bool use_lds) {
+  const DevModel& M = ctx->M;
+  const bool pola = ctx->lsepar_pola != 0, dark = M.dark != nullptr, l3d = M.l3D != 0;
+#define RR(a, b, c) (use_lds ? run_rounds_t<a, b, c, true>(ctx, A, o) : run_rounds_t<a, b, c, false>(ctx, A, o))
+  if (l3d) {
+    if (pola) return dark ? RR(true, true, true) : RR(true, true, false);
+    return dark ? RR(true, false, true) : RR(true, false, false);
+  }
+  if (pola) return dark ? RR(false, true, true) : RR(false, true, false);
+  return dark ? RR(false, false, true) : RR(false, false, false);
+#undef RR
+}
+
 extern "C" int mcgpu_launch_thermal(mcgpu_ctx* ctx, const mcgpu_run_opts* o) {
   int rc = ready(ctx);
   if (rc) return rc;
@@ -410,6 +526,22 @@ extern "C" int mcgpu_launch_thermal(mcgpu_ctx* ctx, const mcgpu_run_opts* o) {
       if (lds_e > lds_cap) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "MCGPU_DEPOSIT=lds: grid does not fit in LDS");
       use_lds = true;
     }
+  }
+  bool rounds = true;  // engine: two alternating kernels (default) or the single persistent kernel
+  if (const char* e = getenv("MCGPU_ENGINE")) rounds = strcmp(e, "mega") != 0;
+  if (rounds) {
+    const size_t lds_fly = (size_t)M.n_cells * sizeof(double) + lds_fly_doubles(M) * sizeof(double);
+    bool fly_lds = lds_fly <= lds_cap;
+    if (const char* e = getenv("MCGPU_DEPOSIT")) {
+      if (!strcmp(e, "hbm")) fly_lds = false;
+      else if (!strcmp(e, "lds") && lds_fly > lds_cap) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "MCGPU_DEPOSIT=lds: grid does not fit in LDS");
+    }
+    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+    int rc2 = run_rounds(ctx, A, o, fly_lds);
+    if (rc2) return rc2;
+    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+    ctx->launched = true;
+    return MCGPU_OK;
   }
   const size_t lds_k = use_lds ? lds_e : lds;
   const int max_threads = use_lds ? MCGPU_LDS_BLOCK : 256;

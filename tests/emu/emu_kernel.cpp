@@ -31,6 +31,7 @@ static inline int __ffsll(long long m) { return __builtin_ffsll(m); }
 static inline int __popcll(unsigned long long m) { return __builtin_popcountll(m); }
 template <class T> static inline T __shfl(T v, int) { return v; }
 template <class T> static inline T __shfl_down(T, int) { return T(0); }
+static inline unsigned int atomicAdd(unsigned int* p, unsigned int v) { unsigned int o = *p; *p += v; return o; }
 static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) {
   unsigned long long o = *p; *p += v; return o;
 }
@@ -55,6 +56,7 @@ using std::fmin; using std::atan2; using std::acos; using std::cos; using std::c
 namespace mcgpu { double lds_raw[1 << 18]; }
 
 #include "../../mcfost_amd/csrc/mc_device.hip.h"
+#include "../../mcfost_amd/csrc/mc_rounds.hip.h"
 #include "../../oracle/mc_oracle.h"
 
 using namespace mcgpu;
@@ -114,6 +116,42 @@ extern "C" int emu_run_thermal(const oracle_model* m, const oracle_opts* o, cons
   A.counters = cnt; A.next_packet = cnt + 8; A.err = &err;
   A.inner_iters = 8; A.flags = 0; A.flush_every = 4; A.min_active = 0;
   const bool pola = m->lsepar_pola && m->aniso_method == 1, dark = M.dark != nullptr, l3d = m->l3D != 0;
+  if (getenv("MCGPU_EMU_ROUNDS")) {
+    // the two-kernel engine, one emulated lane: slots are passes of that lane
+    const int n_slots = (int)(o->n_packets < 48 ? (o->n_packets ? o->n_packets : 1) : 48);
+    Pool P;
+    P.n_slots = n_slots;
+    std::vector<double> pd(7 * (size_t)n_slots), pS(4 * (size_t)n_slots);
+    std::vector<int> pi(9 * (size_t)n_slots), list(n_slots);
+    P.x = pd.data(); P.y = P.x + n_slots; P.z = P.y + n_slots; P.u = P.z + n_slots; P.v = P.u + n_slots;
+    P.w = P.v + n_slots; P.extr = P.w + n_slots; P.S = pS.data();
+    P.ri = pi.data(); P.zj = P.ri + n_slots; P.k = P.zj + n_slots; P.lambda = P.k + n_slots;
+    P.star_key = P.lambda + n_slots; P.st = P.star_key + n_slots;
+    P.p_lo = (uint32_t*)(P.st + n_slots); P.p_hi = P.p_lo + n_slots; P.event = P.p_hi + n_slots;
+    unsigned int counts[2] = {(unsigned int)n_slots, 0u};
+    RoundArgs R;
+    R.list = list.data(); R.list_n = &counts[0]; R.flying_n = &counts[1]; R.n_passes = n_slots;
+    for (int i = 0; i < n_slots; ++i) { P.st[i] = S_EMIT; list[i] = i; }
+    A.min_active = 32; A.inner_iters = 16;
+    const bool use_lds = getenv("MCGPU_EMU_LDS") != nullptr;
+    for (long round = 0; round < 100000000; ++round) {
+#define SERVE(a, b) k_serve<a, b>(M, A, P, R)
+      if (l3d) { if (pola) SERVE(true, true); else SERVE(true, false); }
+      else { if (pola) SERVE(false, true); else SERVE(false, false); }
+      counts[0] = 0; counts[1] = 0;
+#define FLY(a, b, c) do { if (use_lds) k_fly_lds<a, b, c>(M, A, P, R); else k_fly_hbm<a, b, c>(M, A, P, R); } while (0)
+      if (l3d) {
+        if (pola) { if (dark) FLY(true, true, true); else FLY(true, true, false); }
+        else { if (dark) FLY(true, false, true); else FLY(true, false, false); }
+      } else {
+        if (pola) { if (dark) FLY(false, true, true); else FLY(false, true, false); }
+        else { if (dark) FLY(false, false, true); else FLY(false, false, false); }
+      }
+      if (counts[0] == 0 && counts[1] == 0) break;
+    }
+    for (int q = 0; q < 8; ++q) counters[q] = cnt[q];
+    return err;
+  }
 #define RUN(a, b, c) do { if (getenv("MCGPU_EMU_LDS")) k_thermal_lds<a, b, c>(M, A); else k_thermal<a, b, c>(M, A); } while (0)
   if (l3d) {
     if (pola) { if (dark) RUN(true, true, true); else RUN(true, true, false); }
