@@ -85,6 +85,17 @@ struct DevModel {
   int midplane_snap;
 };
 
+// Packet pool of the two-kernel engine (mc_rounds.hip.h): structure of arrays in HBM indexed
+// by slot.  Declared here because the single-kernel engine can resume packets from it.
+struct Pool {
+  int n_slots;
+  double *x, *y, *z, *u, *v, *w, *extr;
+  double* S;  // [4*n_slots] Stokes (I at S[slot], Q at S[n+slot], ...); only with Stokes tracking
+  int *ri, *zj, *k, *lambda, *star_key, *st;
+  uint32_t *p_lo, *p_hi, *event;
+};
+constexpr int ST_MASK = 15, ST_STAR = 16, ST_SCATT = 32;  // Pool::st = state | flags
+
 struct RunArgs {
   uint64_t seed, first_packet, n_packets;
   double qscale;            // n_replicas
@@ -99,6 +110,9 @@ struct RunArgs {
   int inner_iters;  // crossings attempted between two interaction phases
   int flush_every;  // LDS-deposit kernels: outer iterations per fold of the private grid
   int min_active;   // leave the crossing loop early once fewer lanes than this are in flight
+  // finisher mode: the work items are in-flight packets of the pool, not fresh packet ids
+  const int* resume_list;
+  const Pool* resume_pool;  // device copy of the Pool descriptor; null = normal operation
   int flags;        // diagnostics: bit 0 = skip the E_abs deposits (timing experiments only)
 };
 
@@ -848,7 +862,7 @@ __device__ inline void deposit(double* E_glob, double* E_lds, int ic, double v) 
   else atomic_add_f64(&E_glob[ic], v);
 }
 
-enum : int { S_EMIT = 0, S_INTERACT = 1, S_NEWFLIGHT = 2, S_FLIGHT = 3, S_DONE = 4, S_EXITED = 5 };
+enum : int { S_EMIT = 0, S_INTERACT = 1, S_NEWFLIGHT = 2, S_FLIGHT = 3, S_DONE = 4, S_EXITED = 5, S_KILLED = 6 };
 constexpr unsigned long long PK_BATCH = 128;  // packet ids reserved per wave and global atomic
 
 // capteur, SED branch (output.f90:294-397,572-592)
@@ -966,7 +980,33 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
         const bool served = need && (rank < avail);
         if (need && !served && pk_next >= A.n_packets) st = S_DONE;  // nothing left anywhere
         pk_next += (cnt < avail) ? cnt : avail;
-        if (served) {
+        if (served && A.resume_pool) {
+          // finisher: take over a packet in flight from the pool of the two-kernel engine
+          const Pool& Q = *A.resume_pool;
+          const int slot = A.resume_list[my];
+          x = Q.x[slot]; y = Q.y[slot]; z = Q.z[slot];
+          u = Q.u[slot]; v = Q.v[slot]; w = Q.w[slot];
+          extr = Q.extr[slot];
+          ri = Q.ri[slot]; zj = Q.zj[slot]; k = Q.k[slot];
+          lambda = Q.lambda[slot]; star_key = Q.star_key[slot];
+          rng.k0 = (uint32_t)A.seed; rng.k1 = (uint32_t)(A.seed >> 32);
+          rng.p_lo = Q.p_lo[slot]; rng.p_hi = Q.p_hi[slot]; rng.event = Q.event[slot];
+          const int stw = Q.st[slot];
+          flag_star = (stw & ST_STAR) != 0; flag_scatt = (stw & ST_SCATT) != 0;
+          S[0] = 1.0; S[1] = 0.0; S[2] = 0.0; S[3] = 0.0;
+          if (POLA) {
+            S[0] = Q.S[slot]; S[1] = Q.S[Q.n_slots + slot];
+            S[2] = Q.S[2 * (size_t)Q.n_slots + slot]; S[3] = Q.S[3 * (size_t)Q.n_slots + slot];
+          }
+          const double a = u * u + v * v;
+          inv_a = (a > TINY_REAL) ? 1.0 / a : HUGE_REAL;
+          inv_w = (fabs(w) > TINY_REAL) ? 1.0 / w : copysign(HUGE_DP, w);
+          kf = is_real_cell<L3D>(n_rad, nz, ri, zj) ? M.kappa_factor[cell_index<L3D>(n_rad, nz, ri, zj, k)] : 0.0;
+          ri_o = 0; zj_o = 0; k_o = 0;
+          xo = x; yo = y; zo = z;
+          pk_cross = 0;
+          st = S_FLIGHT;
+        } else if (served) {
           {
             // mc_photon_loop body (dust_transfer.f90:529-541)
             rng.init(A.seed, A.first_packet + my);

@@ -24,16 +24,6 @@
 
 namespace mcgpu {
 
-enum : int { S_KILLED = 6 };  // extends the state codes of mc_device.hip.h
-constexpr int ST_MASK = 15, ST_STAR = 16, ST_SCATT = 32;
-
-struct Pool {
-  int n_slots;
-  double *x, *y, *z, *u, *v, *w, *extr;
-  double* S;  // [4*n_slots] Stokes (I at S[slot], Q at S[n+slot], ...); only with Stokes tracking
-  int *ri, *zj, *k, *lambda, *star_key, *st;
-  uint32_t *p_lo, *p_hi, *event;
-};
 
 struct RoundArgs {
   int* list;               // slots that need service
@@ -492,6 +482,20 @@ __global__ void __launch_bounds__(256) k_serve(const DevModel M, const RunArgs A
     unsigned long long vsum = cs[q];
     for (int off = 32; off > 0; off >>= 1) vsum += __shfl_down(vsum, off);
     if (lane == 0 && vsum) atomicAdd(&A.counters[q], vsum);
+  }
+}
+
+// lists the slots that hold a packet in flight (hand-over to the single-kernel finisher)
+__global__ void k_collect_flying(const Pool P, int* list, unsigned int* n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool fly = (i < P.n_slots) && ((P.st[i] & ST_MASK) == S_FLIGHT);
+  const unsigned long long mask = __ballot(fly);
+  if (mask) {
+    const int lane = threadIdx.x & 63, leader = __ffsll((long long)mask) - 1;
+    unsigned int base = 0;
+    if (lane == leader) base = atomicAdd(n, (unsigned int)__popcll(mask));
+    base = __shfl(base, leader);
+    if (fly) list[base + __popcll(mask & ((1ull << lane) - 1ull))] = i;
   }
 }
 

@@ -48,6 +48,7 @@ struct mcgpu_ctx {
   std::vector<void*> pool_allocs;
   int* d_list = nullptr;
   unsigned int* d_round_counts = nullptr;  // [0] list_n, [1] flying_n
+  Pool* d_pool_desc = nullptr;             // device copy of `pool` for the finisher
 };
 
 #define HIPCHK(call)                                                              \
@@ -114,6 +115,7 @@ extern "C" int mcgpu_destroy(mcgpu_ctx* ctx) {
   for (void* p : ctx->pool_allocs) hipFree(p);
   if (ctx->d_list) hipFree(ctx->d_list);
   if (ctx->d_round_counts) hipFree(ctx->d_round_counts);
+  if (ctx->d_pool_desc) hipFree(ctx->d_pool_desc);
   if (ctx->ev0) hipEventDestroy(ctx->ev0);
   if (ctx->ev1) hipEventDestroy(ctx->ev1);
   if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
@@ -372,6 +374,58 @@ static hipError_t launch_k(const DevModel& M, const RunArgs& A, int blocks, int 
   return hipGetLastError();
 }
 
+// the single persistent kernel (mc_device.hip.h); also the finisher of the two-kernel engine
+static int launch_mega(mcgpu_ctx* ctx, const RunArgs& A, bool use_lds, int grid_blocks, int block_threads) {
+  const DevModel& M = ctx->M;
+  const size_t lds = lds_bytes(M);
+  const size_t lds_cap = 160 * 1024;
+  const size_t lds_k = use_lds ? lds + (size_t)M.n_cells * sizeof(double) : lds;
+  const int max_threads = use_lds ? MCGPU_LDS_BLOCK : 256;
+  const int threads = (block_threads > 0 && block_threads <= max_threads) ? block_threads : max_threads;
+  if (threads % 64) return fail(ctx, MCGPU_ERR_ARG, "block_threads must be a multiple of 64");
+  int blocks = grid_blocks;
+  if (blocks <= 0) {
+    // persistent grid: as many workgroups as the LDS footprint lets reside
+    int per_cu = (int)(lds_cap / (lds_k > 0 ? lds_k : 1));
+    const int cap = 2048 / threads;  // waves
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > cap) per_cu = cap;
+    blocks = ctx->prop.multiProcessorCount * per_cu;
+    const unsigned long long need = (A.n_packets + threads - 1) / threads;
+    if ((unsigned long long)blocks > need) blocks = (int)(need ? need : 1);
+  }
+  const bool pola = ctx->lsepar_pola != 0, dark = M.dark != nullptr, l3d = M.l3D != 0;
+  hipError_t e;
+#define LAUNCH(a, b, c)                                                                \
+  e = use_lds ? launch_k<a, b, c, true>(M, A, blocks, threads, lds_k, ctx->stream)     \
+              : launch_k<a, b, c, false>(M, A, blocks, threads, lds_k, ctx->stream)
+  if (l3d) {
+    if (pola) { if (dark) LAUNCH(true, true, true); else LAUNCH(true, true, false); }
+    else { if (dark) LAUNCH(true, false, true); else LAUNCH(true, false, false); }
+  } else {
+    if (pola) { if (dark) LAUNCH(false, true, true); else LAUNCH(false, true, false); }
+    else { if (dark) LAUNCH(false, false, true); else LAUNCH(false, false, false); }
+  }
+#undef LAUNCH
+  if (e != hipSuccess) {
+    ctx->err = std::string("kernel launch: ") + hipGetErrorString(e);
+    return MCGPU_ERR_HIP;
+  }
+  return MCGPU_OK;
+}
+
+static int run_finisher(mcgpu_ctx* ctx, RunArgs A, unsigned int n_resume) {
+  const DevModel& M = ctx->M;
+  A.n_packets = n_resume;  // work items = listed pool slots
+  A.resume_list = ctx->d_list;
+  A.resume_pool = ctx->d_pool_desc;
+  HIPCHK(hipMemsetAsync(A.next_packet, 0, sizeof(unsigned long long), ctx->stream));
+  const size_t lds_e = lds_bytes(M) + (size_t)M.n_cells * sizeof(double);
+  bool use_lds = lds_e <= 160 * 1024;
+  if (const char* e = getenv("MCGPU_DEPOSIT")) if (!strcmp(e, "hbm")) use_lds = false;
+  return launch_mega(ctx, A, use_lds, 0, 0);
+}
+
 // ---- the two-kernel engine (mc_rounds.hip.h) -------------------------------------------------
 static int ensure_pool(mcgpu_ctx* ctx, size_t n_slots, bool pola) {
   if (ctx->pool_slots == n_slots && ctx->pool_pola == pola) return MCGPU_OK;
@@ -393,6 +447,8 @@ static int ensure_pool(mcgpu_ctx* ctx, size_t n_slots, bool pola) {
   for (auto q : uu) HIPCHK(ial(q));
   HIPCHK(hipMalloc((void**)&ctx->d_list, n_slots * sizeof(int)));
   if (!ctx->d_round_counts) HIPCHK(hipMalloc((void**)&ctx->d_round_counts, 4 * sizeof(unsigned int)));
+  if (!ctx->d_pool_desc) HIPCHK(hipMalloc((void**)&ctx->d_pool_desc, sizeof(Pool)));
+  HIPCHK(hipMemcpy(ctx->d_pool_desc, &P, sizeof(Pool), hipMemcpyHostToDevice));
   ctx->pool_slots = n_slots;
   ctx->pool_pola = pola;
   return MCGPU_OK;
@@ -448,6 +504,8 @@ static int run_rounds_t(mcgpu_ctx* ctx, RunArgs A, const mcgpu_run_opts* o) {
   if (serve_occ < 1) serve_occ = 1;
   const int serve_blocks = ctx->prop.multiProcessorCount * serve_occ;
   int check_every = 4;
+  size_t switch_below = n_slots / 4;
+  if (const char* e = getenv("MCGPU_SWITCH_FRAC")) { double f = atof(e); if (f >= 0.0 && f <= 1.0) switch_below = (size_t)(f * n_slots); }
   const long max_rounds = 4000000;
   for (long round = 0; round < max_rounds; ++round) {
     hipLaunchKernelGGL((k_serve<L3D, POLA>), dim3(serve_blocks), dim3(256), lds_serve, s, M, A, P, R);
@@ -459,6 +517,24 @@ static int run_rounds_t(mcgpu_ctx* ctx, RunArgs A, const mcgpu_run_opts* o) {
       HIPCHK(hipMemcpyAsync(h_counts, ctx->d_round_counts, sizeof(h_counts), hipMemcpyDeviceToHost, s));
       HIPCHK(hipStreamSynchronize(s));
       if (h_counts[0] == 0 && h_counts[1] == 0) return MCGPU_OK;
+      unsigned long long next_id = 0;
+      HIPCHK(hipMemcpy(&next_id, A.next_packet, sizeof(next_id), hipMemcpyDeviceToHost));
+      if (next_id >= A.n_packets && (size_t)h_counts[0] + h_counts[1] < switch_below) {
+        // Few packets left and no fresh ones to refill the pool: the alternating kernels would
+        // now spend their time on launch overheads while stragglers random-walk for thousands
+        // of flights.  Serve the listed slots once more, then let the single persistent kernel
+        // run every packet still in flight to completion.
+        hipLaunchKernelGGL((k_serve<L3D, POLA>), dim3(serve_blocks), dim3(256), lds_serve, s, M, A, P, R);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemsetAsync(ctx->d_round_counts, 0, 2 * sizeof(unsigned int), s));
+        hipLaunchKernelGGL(k_collect_flying, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, s, P, ctx->d_list,
+                           ctx->d_round_counts);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(h_counts, ctx->d_round_counts, sizeof(h_counts), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (h_counts[0] == 0) return MCGPU_OK;
+        return run_finisher(ctx, A, h_counts[0]);
+      }
     }
   }
   return fail(ctx, MCGPU_ERR_KERNEL, "rounds engine: packets still in flight after the round limit");
@@ -506,6 +582,8 @@ extern "C" int mcgpu_launch_thermal(mcgpu_ctx* ctx, const mcgpu_run_opts* o) {
   A.counters = ctx->d_counters;
   A.next_packet = ctx->d_counters + 8;
   A.err = ctx->d_err;
+  A.resume_list = nullptr;
+  A.resume_pool = nullptr;
   // tuning / diagnostic knobs (environment; defaults are the shipped configuration)
   A.inner_iters = 64;
   A.flush_every = 16;
@@ -543,40 +621,9 @@ extern "C" int mcgpu_launch_thermal(mcgpu_ctx* ctx, const mcgpu_run_opts* o) {
     ctx->launched = true;
     return MCGPU_OK;
   }
-  const size_t lds_k = use_lds ? lds_e : lds;
-  const int max_threads = use_lds ? MCGPU_LDS_BLOCK : 256;
-  const int threads = o->block_threads > 0 ? o->block_threads : max_threads;
-  if (threads % 64 || threads > max_threads)
-    return fail(ctx, MCGPU_ERR_ARG, "block_threads must be a multiple of 64, at most 256 (HBM deposits) / 512 (LDS deposits)");
-  int blocks = o->grid_blocks;
-  if (blocks <= 0) {
-    // persistent grid: as many workgroups as the LDS footprint lets reside
-    int per_cu = (int)(lds_cap / (lds_k > 0 ? lds_k : 1));
-    const int cap = 2048 / threads;  // waves
-    if (per_cu < 1) per_cu = 1;
-    if (per_cu > cap) per_cu = cap;
-    blocks = ctx->prop.multiProcessorCount * per_cu;
-    const unsigned long long need = (o->n_packets + threads - 1) / threads;
-    if ((unsigned long long)blocks > need) blocks = (int)(need ? need : 1);
-  }
-  const bool pola = ctx->lsepar_pola != 0, dark = M.dark != nullptr, l3d = M.l3D != 0;
   HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
-  hipError_t e;
-#define LAUNCH(a, b, c)                                                                \
-  e = use_lds ? launch_k<a, b, c, true>(M, A, blocks, threads, lds_k, ctx->stream)     \
-              : launch_k<a, b, c, false>(M, A, blocks, threads, lds_k, ctx->stream)
-  if (l3d) {
-    if (pola) { if (dark) LAUNCH(true, true, true); else LAUNCH(true, true, false); }
-    else { if (dark) LAUNCH(true, false, true); else LAUNCH(true, false, false); }
-  } else {
-    if (pola) { if (dark) LAUNCH(false, true, true); else LAUNCH(false, true, false); }
-    else { if (dark) LAUNCH(false, false, true); else LAUNCH(false, false, false); }
-  }
-#undef LAUNCH
-  if (e != hipSuccess) {
-    ctx->err = std::string("kernel launch: ") + hipGetErrorString(e);
-    return MCGPU_ERR_HIP;
-  }
+  int rc3 = launch_mega(ctx, A, use_lds, o->grid_blocks, o->block_threads);
+  if (rc3) return rc3;
   HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
   ctx->launched = true;
   return MCGPU_OK;

@@ -114,7 +114,7 @@ extern "C" int emu_run_thermal(const oracle_model* m, const oracle_opts* o, cons
   A.qscale = o->n_replicas >= 1.0 ? o->n_replicas : 1.0;
   A.frozen = o->frozen; A.E_prior = E_prior; A.E_abs = E_abs; A.sed = sed; A.n_sent = n_sent;
   A.counters = cnt; A.next_packet = cnt + 8; A.err = &err;
-  A.inner_iters = 8; A.flags = 0; A.flush_every = 4; A.min_active = 0;
+  A.resume_list = nullptr; A.resume_pool = nullptr; A.inner_iters = 8; A.flags = 0; A.flush_every = 4; A.min_active = 0;
   const bool pola = m->lsepar_pola && m->aniso_method == 1, dark = M.dark != nullptr, l3d = m->l3D != 0;
   if (getenv("MCGPU_EMU_ROUNDS")) {
     // the two-kernel engine, one emulated lane: slots are passes of that lane
