@@ -605,8 +605,10 @@ extern "C" int mcgpu_launch_thermal(mcgpu_ctx* ctx, const mcgpu_run_opts* o) {
       use_lds = true;
     }
   }
-  bool rounds = true;  // engine: two alternating kernels (default) or the single persistent kernel
-  if (const char* e = getenv("MCGPU_ENGINE")) rounds = strcmp(e, "mega") != 0;
+  // Engine: the single persistent kernel (default) or, opt-in, two alternating kernels over a
+  // packet pool in HBM (MCGPU_ENGINE=rounds; same results, currently slower: DESIGN.md sec. 3)
+  bool rounds = false;
+  if (const char* e = getenv("MCGPU_ENGINE")) rounds = strcmp(e, "rounds") == 0;
   if (rounds) {
     const size_t lds_fly = (size_t)M.n_cells * sizeof(double) + lds_fly_doubles(M) * sizeof(double);
     bool fly_lds = lds_fly <= lds_cap;

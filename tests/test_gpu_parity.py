@@ -284,3 +284,14 @@ def test_fortran_host_through_iso_c_binding(small_model, tmp_path):
     Tf, Tp = e.temp_finale(f["E_abs"]), e.temp_finale(p["E_abs"])
     assert rel_rms(Tf, Tp, 1.01 * small_model.cfg.T_min) < 0.02
     e.close()
+
+
+def test_rounds_engine_matches_oracle(small_model, monkeypatch):
+    """The opt-in two-kernel engine (MCGPU_ENGINE=rounds: k_fly + k_serve over a packet pool in
+    HBM, stragglers handed to the persistent kernel) gives the same packets the same history."""
+    monkeypatch.setenv("MCGPU_ENGINE", "rounds")
+    _frozen_parity(small_model, 20000, seed=7)
+    m3 = M.build_model(M.small(n_rad=12, nz=6, n_az=8, l3D=True))
+    _frozen_parity(m3, 20000, seed=8)
+    monkeypatch.setenv("MCGPU_SWITCH_FRAC", "0.9")      # early hand-over to the finisher
+    _frozen_parity(small_model, 30000, seed=9)
