@@ -295,3 +295,69 @@ def test_rounds_engine_matches_oracle(small_model, monkeypatch):
     _frozen_parity(m3, 20000, seed=8)
     monkeypatch.setenv("MCGPU_SWITCH_FRAC", "0.9")      # early hand-over to the finisher
     _frozen_parity(small_model, 30000, seed=9)
+
+
+def test_edge_cases_empty_and_tiny_runs(small_model):
+    """n_packets = 0, 1 and a non-multiple of the wave / batch sizes."""
+    e, o = _engine(small_model, 1000), _oracle(small_model, 1000)
+    prior = o.run_thermal(500, seed=1)["E_abs"]
+    z = e.run_thermal(0, seed=1)
+    assert z["counters"]["packets"] == 0 and z["E_abs"].sum() == 0 and z["sed"].sum() == 0
+    for n in (1, 63, 65, 129, 1000):
+        a = e.run_thermal(n, seed=5, frozen=True, E_prior=prior, first_packet=17)
+        b = o.run_thermal(n, seed=5, frozen=True, E_prior=prior, first_packet=17)
+        assert a["counters"] == b["counters"], n
+        assert np.allclose(a["E_abs"], b["E_abs"], rtol=1e-9, atol=1e-12 * max(b["E_abs"].max(), 1e-300))
+    e.close()
+
+
+def test_packet_ids_beyond_32_bits(small_model):
+    """Config 3 runs 1e9 packets over 8 GPUs: ids are 64-bit end to end."""
+    e, o = _engine(small_model, 1000), _oracle(small_model, 1000)
+    prior = o.run_thermal(500, seed=1)["E_abs"]
+    first = (1 << 33) + 12345
+    a = e.run_thermal(500, seed=9, frozen=True, E_prior=prior, first_packet=first)
+    b = o.run_thermal(500, seed=9, frozen=True, E_prior=prior, first_packet=first)
+    c = o.run_thermal(500, seed=9, frozen=True, E_prior=prior, first_packet=12345)
+    assert a["counters"] == b["counters"] and np.array_equal(a["n_sent"], b["n_sent"])
+    assert not np.array_equal(b["n_sent"], c["n_sent"])      # the high word matters
+    e.close()
+
+
+def test_single_wavelength_and_coarse_grids():
+    """Ragged / minimal table shapes: 2 wavelengths, 3 x 2 cells, 3D with 2 azimuths."""
+    for cfg in (M.small(n_rad=3, nz=2, n_lambda=2), M.small(n_rad=4, nz=1, n_lambda=3),
+                M.small(n_rad=5, nz=3, n_az=2, l3D=True, n_lambda=4)):
+        cfg.n_rad_in = 1
+        m = M.build_model(cfg)
+        _frozen_parity(m, 3000, seed=3, n_prior=500)
+
+
+def test_abi_rejects_what_it_cannot_reproduce(small_model):
+    """Error behaviour of the C-ABI: explicit codes, never a silent wrong answer."""
+    import copy
+    from mcfost_amd.engine import Engine, McgpuError
+    m = copy.copy(small_model)
+    g = dict(m.grid)
+    zl = g["z_lim"].copy()
+    zl[m.cfg.n_rad * 3 + 2] *= 1.01                  # non-uniform vertical grid (e.g. lidefix)
+    g["z_lim"] = zl
+    m.grid = g
+    with pytest.raises(McgpuError, match="z_lim"):
+        Engine(m, 100)
+    m = copy.copy(small_model)
+    g = dict(m.grid)
+    cm = g["cell_map_i"].copy()
+    cm[5], cm[6] = cm[6], cm[5]                      # a permuted cell numbering
+    g["cell_map_i"] = cm
+    m.grid = g
+    with pytest.raises(McgpuError, match="cell_map"):
+        Engine(m, 100)
+    m = copy.copy(small_model)
+    m.frac_E_stars = np.full(m.n_lambda, 0.5)        # disk emission without prob_E_cell
+    with pytest.raises(McgpuError, match="prob_E_cell"):
+        Engine(m, 100)
+    e = _engine(small_model, 100)
+    with pytest.raises(McgpuError, match="frozen"):
+        e.run_thermal(10, frozen=True)               # frozen mode without a prior
+    e.close()
