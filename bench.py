@@ -50,7 +50,7 @@ def cpu_baseline(model, n_total, target_s=15.0):
     res = orc.run_thermal(n, seed=100, n_threads=cores)
     dt = time.perf_counter() - t
     return dict(value=n / dt, unit="packets/s", cores=cores, kind="port",
-                sample="%d packets of the same ref4.1 2D thermal workload, %d OpenMP threads, %.1f s; "
+                sample="%d packets of the same thermal workload, %d OpenMP threads, %.1f s; "
                        "%.1f crossings/packet" % (n, cores, dt, res["counters"]["crossings"] / n))
 
 
@@ -60,7 +60,9 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--packets", type=float, default=1e8, help="packets per GPU per step")
-    ap.add_argument("--config", default="ref41", choices=["ref41", "ref41_3d", "pascucci"])
+    ap.add_argument("--config", default="ref41", choices=["ref41", "ref41_3d", "pascucci", "voronoi"])
+    ap.add_argument("--sites", type=int, default=100000,
+                    help="--config voronoi: number of SPH-like sites of the tessellation (BASELINE config 5 stand-in)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--grid-blocks", type=int, default=0)
@@ -88,10 +90,14 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    cfg = {"ref41": M.ref41, "ref41_3d": M.ref41_3d, "pascucci": M.pascucci}[args.config]()
+    cfg = {"ref41": M.ref41, "ref41_3d": M.ref41_3d, "pascucci": M.pascucci, "voronoi": M.ref41}[args.config]()
     if args.no_pola:
         cfg.lsepar_pola = False
-    model = M.build_model(cfg)
+    if args.config == "voronoi":
+        cfg.name = "ref4.1 disk as %d Voronoi sites" % args.sites
+        model = M.build_voronoi_model(cfg, args.sites, seed=1)
+    else:
+        model = M.build_model(cfg)
     n_local = int(args.packets)
     n_total = n_local * world
     eng = Engine(model, n_total, device=local_rank)
@@ -141,7 +147,13 @@ def main():
         n_units = cnt["packets"] if world == 1 else cnt["packets"] / world
         cross_pp = cnt["crossings"] / max(cnt["packets"], 1)
         inter_pp = (cnt["scatterings"] + cnt["absorptions"]) / max(cnt["packets"], 1)
-        bytes_launch = n_local * (cross_pp * BYTES_PER_CROSSING + inter_pp * BYTES_PER_INTERACTION)
+        per_crossing = BYTES_PER_CROSSING
+        if args.config == "voronoi":
+            # a crossing reads the cell record (32 B) and its inlined
+            # neighbour list (16 B per neighbour), then the E_abs RMW (16 B)
+            g = model.grid
+            per_crossing = 32.0 + 16.0 * (g["v_neigh"].size / g["n_cells"]) + 16.0
+        bytes_launch = n_local * (cross_pp * per_crossing + inter_pp * BYTES_PER_INTERACTION)
         k_ms = sum(kernel_ms) / len(kernel_ms)
         achieved = bytes_launch / (k_ms * 1e-3) / 1e9
         line = {
@@ -152,13 +164,16 @@ def main():
             "config": {"workload": "%s 2D cylindrical disk %dx%dx%d, %d wavelengths, %.3g packets/GPU/step, "
                                    "temperature step (live Bjorkman&Wood re-emission), synthetic dust tables, "
                                    "blackbody star" % (cfg.name, cfg.n_rad, cfg.nz, cfg.n_az, cfg.n_lambda, n_local)
-                       if not cfg.l3D else "%s 3D cylindrical disk %dx%dx%d, %.3g packets/GPU/step"
-                       % (cfg.name, cfg.n_rad, cfg.nz, cfg.n_az, n_local),
+                       if not (cfg.l3D or args.config == "voronoi") else
+                       ("%s, %d cells, %.3g packets/GPU/step" % (cfg.name, model.n_cells, n_local)
+                        if args.config == "voronoi" else
+                        "%s 3D cylindrical disk %dx%dx%d, %.3g packets/GPU/step"
+                        % (cfg.name, cfg.n_rad, cfg.nz, cfg.n_az, n_local)),
                        "packets_per_gpu": n_local, "parallelism": "packets sharded x%d, tables replicated" % world,
                        "crossings_per_packet": cross_pp, "interactions_per_packet": inter_pp},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_thermal", "kernel_ms": k_ms,
+                         "kernel": "k_thermal_voro" if args.config == "voronoi" else "k_thermal", "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": bytes_launch},
         }
         if world == 1 and not args.no_cpu_baseline:

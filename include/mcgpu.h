@@ -89,6 +89,37 @@ int mcgpu_set_grid_cyl(mcgpu_ctx *ctx, int n_rad, int nz, int n_az, int l3D,
                        const int *lexit_cell);
 
 /*
+ * Voronoi grid: module Voronoi_grid (Voronoi.f90:23-67), the arrays
+ * Voronoi_tesselation (:183-640) leaves behind.  All ids are 1-based.
+ *   voronoi_xyz(3,n_cells)   Voronoi_xyz, default real (:62)
+ *   xyz_dp(3,n_cells)        Voronoi(:)%xyz (:24)
+ *   h[n_cells]               Voronoi(:)%h (:25)
+ *   first/last_neighbour     Voronoi(:)%first_neighbour, %last_neighbour (:26)
+ *   neighbours_list[n_neighbours]  cell id > 0, or -iwall (:65, :560-600)
+ *   was_cut, is_star_neighbour     Voronoi(:)%was_cut (:27), %is_star_neighbour (:28);
+ *                                  NULL = all false
+ *   walls[6*4]               wall(i)%x1..x4 in the order of init_Voronoi_walls
+ *                            (:1262-1283): -x,+x,-y,+y,-z,+z
+ *   cutting_distance_o_h     PS%cutting_distance_o_h (:50)
+ *   wall_first[7], wall_cells wall(i)%neighbour_list(1:n_neighbours) (:36-37)
+ *                            concatenated, wall_first[i] = 0-based start of wall i+1
+ *   volume[n_cells]          volume (cylindrical_grid.f90:26; filled at Voronoi.f90:529)
+ * Star sites are ordinary cells here (:361-376); pass their ids as `icell` to
+ * mcgpu_set_stars.  The grid operators replaced: cross_Voronoi_cell (:839),
+ * test_exit_grid_Voronoi (:1446), move_to_grid_Voronoi (:1379),
+ * index_cell_voronoi (:1548), pos_em_cell_voronoi (:1510).
+ */
+int mcgpu_set_grid_voronoi(mcgpu_ctx *ctx, int n_cells, const float *voronoi_xyz,
+                           const double *xyz_dp, const double *h,
+                           const int *first_neighbour, const int *last_neighbour,
+                           const int *neighbours_list, long long n_neighbours,
+                           const unsigned char *was_cut,
+                           const unsigned char *is_star_neighbour,
+                           const float *walls, double cutting_distance_o_h,
+                           const int *wall_first, const int *wall_cells,
+                           const double *volume);
+
+/*
  * 3D grids only.  on != 0 (default): a packet that crosses the midplane lands
  * at z = sign(grid_prec, w), i.e. the reference's own z1 == 0 correction
  * (cylindrical_grid.f90:1158-1165) applied to every rounding residue of
@@ -206,6 +237,13 @@ int mcgpu_probe_cross_cell(mcgpu_ctx *ctx, int n, const double *x0,
                            double *l);
 int mcgpu_probe_index_cell(mcgpu_ctx *ctx, int n, const double *x,
                            const double *y, const double *z, int *icell);
+/* cross_Voronoi_cell (Voronoi.f90:839-992), all of its outputs */
+int mcgpu_probe_cross_voronoi(mcgpu_ctx *ctx, int n, const double *x0,
+                              const double *y0, const double *z0,
+                              const double *u, const double *v, const double *w,
+                              const int *cell, const int *previous_cell,
+                              double *x1, double *y1, double *z1, int *next_cell,
+                              double *l, double *l_contrib, double *l_void_before);
 int mcgpu_probe_philox(mcgpu_ctx *ctx, const uint32_t ctr[4],
                        const uint32_t key[2], uint32_t out[4]);
 int mcgpu_probe_packet_rand(mcgpu_ctx *ctx, uint64_t seed, uint64_t packet,

@@ -902,6 +902,159 @@ __device__ inline void capteur(const DevModel& M, double* sed, int lambda, doubl
 }
 
 // ---------------------------------------------------------------------------
+// Emission and interaction pieces shared by every grid's packet kernel
+// ---------------------------------------------------------------------------
+// select_wl_em (thermal_emission.f90:364-400)
+__device__ inline int select_wl_em(const Lds& T, const DevModel& M, float rand) {
+  int kmin = 0, kmax = M.n_lambda, kk = (kmin + kmax) / 2;
+  while (T.cum[kk] != (double)rand) {
+    if (T.cum[kk] < (double)rand) kmin = kk; else kmax = kk;
+    kk = (kmin + kmax) / 2;
+    if ((kmax - kmin) <= 1) break;
+  }
+  return kmax;
+}
+
+// select_star (stars.f90:75-104)
+__device__ inline int select_star(const DevModel& M, int lambda, float rand) {
+  int kmin = 0, kmax = M.n_stars, kk = (kmax - kmin) / 2;
+  while ((kmax - kmin) > 1) {
+    if (M.CDF_E_star[(lambda - 1) + (size_t)M.n_lambda * kk] < (double)rand) kmin = kk;
+    else kmax = kk;
+    kk = (kmin + kmax) / 2;
+  }
+  return kmax;
+}
+
+// select_cellule (thermal_emission.f90:2044-2073)
+__device__ inline int select_cellule(const DevModel& M, int lambda, float rand) {
+  const double* p = M.prob_E_cell + (size_t)(M.n_cells + 1) * (lambda - 1);
+  int kmin = 0, kmax = M.n_cells, kk = (kmin + kmax) / 2;
+  while ((kmax - kmin) > 1) {
+    if (p[kk] < (double)rand) kmin = kk; else kmax = kk;
+    kk = (kmin + kmax) / 2;
+  }
+  return kmax;
+}
+
+// emit_packet_uniform_sphere (stars.f90:108-169), up to the cell lookup
+__device__ inline void emit_uniform_sphere(const DevModel& M, int i_star, float r1, float r2, float r3,
+                                           float r4, double& x, double& y, double& z, double& u, double& v,
+                                           double& w) {
+  z = 2.0 * (double)r1 - 1.0;
+  const double srw02 = sqrt(1.0 - z * z);
+  const double argmt = PI * (2.0 * (double)r2 - 1.0);
+  double sa, ca;
+  sincos(argmt, &sa, &ca);
+  x = srw02 * ca;
+  y = srw02 * sa;
+  const double cospsi = sqrt((double)r3);
+  const double phi = 2.0 * PI * (double)r4;
+  cdapres(cospsi, phi, x, y, z, u, v, w);
+  const double* st4 = &M.star_xyzr[4 * (i_star - 1)];
+  const double r_star = st4[3] * (1.0 + 1e-6);
+  x = x * r_star + st4[0];
+  y = y * r_star + st4[1];
+  z = z * r_star + st4[2];
+}
+
+// random_isotropic_direction (random_numbers.f90:32-51)
+__device__ inline void random_isotropic_direction(float r1, float r2, double& u, double& v, double& w) {
+  w = 2.0 * (double)r1 - 1.0;
+  const double uv = sqrt(1.0 - w * w);
+  const double ph = PI * (2.0 * (double)r2 - 1.0);
+  double sp, cp;
+  sincos(ph, &sp, &cp);
+  u = uv * cp;
+  v = uv * sp;
+}
+
+// One interaction (dust_transfer.f90:1260-1402): scatter (new direction, Stokes) or absorb +
+// immediate re-emission (new wavelength from the cell's temperature, isotropic direction).
+// g = the event's draws (see Rng); cell_energy() returns the cell's absorbed energy scaled like
+// the reference's partial sum * nb_proc, and is evaluated for absorptions only.
+template <bool POLA, typename EnergyFn>
+__device__ __forceinline__ void interact(const Lds& T, const DevModel& M, const float g[8], int& lambda,
+                                         double u, double v, double w, double& u1, double& v1, double& w1,
+                                         double S[4], bool& flag_star, bool& flag_scatt,
+                                         unsigned int& c_scatt, unsigned int& c_abs, EnergyFn cell_energy,
+                                         const double* volume_of_cell) {
+  const bool scat = g[0] < T.albedo[lambda - 1];  // dust_transfer.f90:1284
+  const float rand = g[1], rand2 = g[2];
+  int itheta = 1;
+  double cospsi, phi;
+  if (scat) {
+    flag_scatt = true;
+    c_scatt++;
+    if (M.aniso_method == 1) {
+      // angle_diff_theta_pos (scattering.f90:1433-1475)
+      const float* prob = T.prob + (M.p_lambda_fixed ? 0 : (size_t)(M.nang + 1) * (lambda - 1));
+      int kmin = 0, kmax = M.nang, kk = (kmin + kmax) / 2;
+      while ((kmax - kmin) > 1) {
+        if (prob[kk] < rand) kmin = kk; else kmax = kk;
+        kk = (kmin + kmax) / 2;
+      }
+      itheta = kmax;
+      const double c0 = T.cost[itheta - 1], c1 = T.cost[itheta];
+      cospsi = c0 + (double)rand2 * (c1 - c0);
+    } else {
+      // hg (scattering.f90:1354-1383)
+      const float gg = T.g[lambda - 1];
+      const double rand_dp = fmin((double)rand, 1.0 - 1e-6);
+      if (fabsf(gg) > 1.17549435e-38f) {
+        const double g1 = (double)gg, g2 = g1 * g1;
+        const double q = (1.0 - g2) / (1.0 - g1 + 2.0 * g1 * rand_dp);
+        cospsi = (1.0 + g2 - q * q) / (2.0 * g1);
+      } else {
+        cospsi = 2.0 * rand_dp - 1.0;
+      }
+      itheta = (int)floor(acos(cospsi) * 180.0 / PI) + 1;
+      if (itheta > M.nang) itheta = M.nang;
+    }
+    if (M.lisotropic) { itheta = 1; cospsi = 2.0 * (double)rand - 1.0; }
+    phi = PI * (2.0 * (double)g[3] - 1.0);
+  } else {
+    c_abs++;
+    flag_star = false;
+    flag_scatt = false;
+    // im_reemission_LTE (thermal_emission.f90:710-771)
+    const double E = cell_energy();
+    int Ti;
+    double frac_T2;
+    temp_lte(T.lq, M.n_T, E, M.L_packet_th, *volume_of_cell, Ti, frac_T2);
+    const double frac_T1 = 1.0 - frac_T2;
+    const double* cdf1 = T.cdf + (size_t)M.n_lambda * (Ti - 2);
+    const double* cdf2 = T.cdf + (size_t)M.n_lambda * (Ti - 1);
+    int l1 = 0, l2 = M.n_lambda, l = (l1 + l2) / 2;
+    while ((l2 - l1) > 1) {
+      const double proba = frac_T1 * cdf1[l - 1] + frac_T2 * cdf2[l - 1];
+      if ((double)rand2 > proba) l1 = l; else l2 = l;
+      l = (l1 + l2) / 2;
+    }
+    lambda = l + 1;
+    // random_isotropic_direction (random_numbers.f90:32-51): w = 2r-1, (u,v) = sqrt(1-w^2)
+    // (cos,sin)(phi) is cdapres' own |w0| > 0.999999 branch applied to the z axis
+    cospsi = 2.0 * (double)g[3] - 1.0;
+    phi = PI * (2.0 * (double)g[4] - 1.0);
+  }
+  // new direction: one instruction stream for both kinds of event
+  cdapres(cospsi, phi, scat ? u : 0.0, scat ? v : 0.0, scat ? w : 1.0, u1, v1, w1);
+  if (POLA) {
+    if (scat && M.aniso_method == 1) {
+      const size_t o = (size_t)(M.nang + 1) * (lambda - 1) + itheta;
+      const float fr = rand2, fm = 1.0f - rand2;
+      const double M22 = (double)(M.s22[o] * fr + M.s22[o - 1] * fm);
+      const double M12 = (double)(M.s12[o] * fr + M.s12[o - 1] * fm);
+      const double M33 = (double)(M.s33[o] * fr + M.s33[o - 1] * fm);
+      const double M44 = (double)(M.s44[o] * fr + M.s44[o - 1] * fm);
+      const double M34 = (double)(-M.s34[o] * fr - M.s34[o - 1] * fm);
+      update_stokes(S, u, v, w, u1, v1, w1, M12, M22, M33, M34, M44);
+    }
+    if (!scat) { S[1] = 0.0; S[2] = 0.0; S[3] = 0.0; }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // The thermal packet kernel
 // ---------------------------------------------------------------------------
 // LDSE: the absorbed-energy grid of this workgroup lives in LDS (2D grids:
@@ -1016,15 +1169,7 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
             rng.emission_event(f);
             tau_rand = f[8];
             float rand = f[0];
-            {  // select_wl_em (thermal_emission.f90:364-400)
-              int kmin = 0, kmax = M.n_lambda, kk = (kmin + kmax) / 2;
-              while (T.cum[kk] != (double)rand) {
-                if (T.cum[kk] < (double)rand) kmin = kk; else kmax = kk;
-                kk = (kmin + kmax) / 2;
-                if ((kmax - kmin) <= 1) break;
-              }
-              lambda = kmax;
-            }
+            lambda = select_wl_em(T, M, rand);
             atomic_add_f64(&A.n_sent[lambda - 1], 1.0);
             // emit_packet (dust_transfer.f90:1047-1151)
             bool lintersect = true;
@@ -1033,50 +1178,14 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
             S[0] = 1.0; S[1] = 0.0; S[2] = 0.0; S[3] = 0.0;
             if ((double)rand <= T.fstar[lambda - 1]) {
               flag_star = true;
-              rand = f[2];
-              int i_star;
-              {  // select_star (stars.f90:75-104)
-                int kmin = 0, kmax = M.n_stars, kk = (kmax - kmin) / 2;
-                while ((kmax - kmin) > 1) {
-                  if (M.CDF_E_star[(lambda - 1) + (size_t)M.n_lambda * kk] < (double)rand) kmin = kk;
-                  else kmax = kk;
-                  kk = (kmin + kmax) / 2;
-                }
-                i_star = kmax;
-              }
-              const float r1 = f[3], r2 = f[4], r3 = f[5], r4 = f[6];
-              // emit_packet_uniform_sphere (stars.f90:108-169)
-              z = 2.0 * (double)r1 - 1.0;
-              const double srw02 = sqrt(1.0 - z * z);
-              const double argmt = PI * (2.0 * (double)r2 - 1.0);
-              double sa, ca;
-              sincos(argmt, &sa, &ca);
-              x = srw02 * ca;
-              y = srw02 * sa;
-              const double cospsi = sqrt((double)r3);
-              const double phi = 2.0 * PI * (double)r4;
-              cdapres(cospsi, phi, x, y, z, u, v, w);
-              const double* st4 = &M.star_xyzr[4 * (i_star - 1)];
-              const double r_star = st4[3] * (1.0 + 1e-6);
-              x = x * r_star + st4[0];
-              y = y * r_star + st4[1];
-              z = z * r_star + st4[2];
+              const int i_star = select_star(M, lambda, f[2]);
+              emit_uniform_sphere(M, i_star, f[3], f[4], f[5], f[6], x, y, z, u, v, w);
               index_cell<L3D>(T, M, x, y, z, ri, zj, k);
               if (M.star_cell[4 * (i_star - 1) + 3])
                 lintersect = move_to_grid<L3D>(T, M, x, y, z, u, v, w, ri, zj, k);
             } else if ((double)rand <= M.frac_E_disk[lambda - 1] && M.prob_E_cell) {
               flag_star = false;
-              rand = f[2];
-              int icell;
-              {  // select_cellule (thermal_emission.f90:2044-2073)
-                const double* p = M.prob_E_cell + (size_t)(M.n_cells + 1) * (lambda - 1);
-                int kmin = 0, kmax = M.n_cells, kk = (kmin + kmax) / 2;
-                while ((kmax - kmin) > 1) {
-                  if (p[kk] < (double)rand) kmin = kk; else kmax = kk;
-                  kk = (kmin + kmax) / 2;
-                }
-                icell = kmax;
-              }
+              const int icell = select_cellule(M, lambda, f[2]);
               // inverse of the closed-form mapping
               {
                 int q = icell - 1;
@@ -1093,16 +1202,7 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
               }
               const float r1 = f[3], r2 = f[4], r3 = f[5];
               pos_em_cell<L3D>(T, M, ri, zj, k, r1, r2, r3, x, y, z);
-              // random_isotropic_direction (random_numbers.f90:32-51)
-              rand = f[6];
-              w = 2.0 * (double)rand - 1.0;
-              const double uv = sqrt(1.0 - w * w);
-              rand = f[7];
-              const double ph = PI * (2.0 * (double)rand - 1.0);
-              double sp, cp;
-              sincos(ph, &sp, &cp);
-              u = uv * cp;
-              v = uv * sp;
+              random_isotropic_direction(f[6], f[7], u, v, w);
             } else {
               *A.err = 12;  // ISM emission / missing prob_E_cell: not in scope
               st = S_DONE;
@@ -1120,46 +1220,10 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
       float g[8];
       rng.interaction_event(g);
       tau_rand = g[5];
-      const bool scat = g[0] < T.albedo[lambda - 1];  // dust_transfer.f90:1284
-      const float rand = g[1], rand2 = g[2];
-      int itheta = 1;
-      double cospsi, phi;
-      if (scat) {
-        flag_scatt = true;
-        c_scatt++;
-        if (M.aniso_method == 1) {
-          // angle_diff_theta_pos (scattering.f90:1433-1475)
-          const float* prob = T.prob + (M.p_lambda_fixed ? 0 : (size_t)(M.nang + 1) * (lambda - 1));
-          int kmin = 0, kmax = M.nang, kk = (kmin + kmax) / 2;
-          while ((kmax - kmin) > 1) {
-            if (prob[kk] < rand) kmin = kk; else kmax = kk;
-            kk = (kmin + kmax) / 2;
-          }
-          itheta = kmax;
-          const double c0 = T.cost[itheta - 1], c1 = T.cost[itheta];
-          cospsi = c0 + (double)rand2 * (c1 - c0);
-        } else {
-          // hg (scattering.f90:1354-1383)
-          const float gg = T.g[lambda - 1];
-          const double rand_dp = fmin((double)rand, 1.0 - 1e-6);
-          if (fabsf(gg) > 1.17549435e-38f) {
-            const double g1 = (double)gg, g2 = g1 * g1;
-            const double q = (1.0 - g2) / (1.0 - g1 + 2.0 * g1 * rand_dp);
-            cospsi = (1.0 + g2 - q * q) / (2.0 * g1);
-          } else {
-            cospsi = 2.0 * rand_dp - 1.0;
-          }
-          itheta = (int)floor(acos(cospsi) * 180.0 / PI) + 1;
-          if (itheta > M.nang) itheta = M.nang;
-        }
-        if (M.lisotropic) { itheta = 1; cospsi = 2.0 * (double)rand - 1.0; }
-        phi = PI * (2.0 * (double)g[3] - 1.0);
-      } else {
-        c_abs++;
-        flag_star = false;
-        flag_scatt = false;
-        // im_reemission_LTE (thermal_emission.f90:710-771)
-        const int ic = cell_index<L3D>(n_rad, nz, ri, zj, k);
+      double u1, v1, w1;
+      const int ic = cell_index<L3D>(n_rad, nz, ri, zj, k);
+      interact<POLA>(T, M, g, lambda, u, v, w, u1, v1, w1, S, flag_star, flag_scatt, c_scatt, c_abs, [&]() {
+        // the cell's absorbed energy for Temp_LTE (thermal_emission.f90:649-706)
         double E;
         if (A.frozen) E = A.E_prior[ic];
         else {
@@ -1172,40 +1236,8 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
           if (LDSE) E += E_lds[ic] * (double)gridDim.x;
           E *= A.qscale;
         }
-        int Ti;
-        double frac_T2;
-        temp_lte(T.lq, M.n_T, E, M.L_packet_th, M.volume[ic], Ti, frac_T2);
-        const double frac_T1 = 1.0 - frac_T2;
-        const double* cdf1 = T.cdf + (size_t)M.n_lambda * (Ti - 2);
-        const double* cdf2 = T.cdf + (size_t)M.n_lambda * (Ti - 1);
-        int l1 = 0, l2 = M.n_lambda, l = (l1 + l2) / 2;
-        while ((l2 - l1) > 1) {
-          const double proba = frac_T1 * cdf1[l - 1] + frac_T2 * cdf2[l - 1];
-          if ((double)rand2 > proba) l1 = l; else l2 = l;
-          l = (l1 + l2) / 2;
-        }
-        lambda = l + 1;
-        // random_isotropic_direction (random_numbers.f90:32-51): w = 2r-1, (u,v) = sqrt(1-w^2)
-        // (cos,sin)(phi) is cdapres' own |w0| > 0.999999 branch applied to the z axis
-        cospsi = 2.0 * (double)g[3] - 1.0;
-        phi = PI * (2.0 * (double)g[4] - 1.0);
-      }
-      // new direction: one instruction stream for both kinds of event
-      double u1, v1, w1;
-      cdapres(cospsi, phi, scat ? u : 0.0, scat ? v : 0.0, scat ? w : 1.0, u1, v1, w1);
-      if (POLA) {
-        if (scat && M.aniso_method == 1) {
-          const size_t o = (size_t)(M.nang + 1) * (lambda - 1) + itheta;
-          const float fr = rand2, fm = 1.0f - rand2;
-          const double M22 = (double)(M.s22[o] * fr + M.s22[o - 1] * fm);
-          const double M12 = (double)(M.s12[o] * fr + M.s12[o - 1] * fm);
-          const double M33 = (double)(M.s33[o] * fr + M.s33[o - 1] * fm);
-          const double M44 = (double)(M.s44[o] * fr + M.s44[o - 1] * fm);
-          const double M34 = (double)(-M.s34[o] * fr - M.s34[o - 1] * fm);
-          update_stokes(S, u, v, w, u1, v1, w1, M12, M22, M33, M34, M44);
-        }
-        if (!scat) { S[1] = 0.0; S[2] = 0.0; S[3] = 0.0; }
-      }
+        return E;
+      }, M.volume + ic);
       u = u1; v = v1; w = w1;
       st = S_NEWFLIGHT;
     }

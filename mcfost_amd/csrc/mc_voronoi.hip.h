@@ -1,0 +1,420 @@
+// Voronoi-grid backend of the thermal packet kernel (Voronoi.f90).
+//
+// Same state machine, random streams and shared emission/interaction code as the cylindrical
+// kernel (mc_device.hip.h); only the grid operators differ:
+//   cross_Voronoi_cell    Voronoi.f90:839-992   (distance_to_wall :1289, distance_to_star :1321)
+//   test_exit_grid        :1446  (icell < 0)
+//   move_to_grid_Voronoi  :1379  (+ find_Voronoi_cell over the wall's neighbour list, :1485)
+//   index_cell_voronoi    :1548  (brute force; only the rounding-error recovery path uses it)
+//   pos_em_cell_voronoi   :1510  (the cell centre)
+//
+// HBM layout (MI355X: memory is plentiful, scattered 12-byte gathers are not):
+//   * VoroCell[n_cells], 32 B, one aligned load per crossing: the site in default real, the CSR
+//     offset/count, the flags and the cell's opacity factor.
+//   * the neighbour list is stored INLINED: one float4 per (cell, neighbour) = the neighbour
+//     site's coordinates + its id in the 4th word, in the reference's list order.  A crossing
+//     streams ~15 consecutive float4 of its own cell instead of chasing 15 random sites (the
+//     idea of the reference's disabled `Voronoi_neighbour_xyz`, Voronoi.f90:18-20,886-887,
+//     paid for with 16 B x nnz of HBM: 250 MB per million cells).
+//   * the plane tests are done in default real exactly like the reference (:859), with the
+//     products and sums left unfused so that the CPU oracle reproduces them bit for bit.
+#pragma once
+#include "mc_device.hip.h"
+
+namespace mcgpu {
+
+struct VoroCell {
+  float x, y, z;  // Voronoi_xyz(:,icell)
+  int first;      // 0-based offset of the cell's entries in VoroGrid::nb
+  int count;      // last_neighbour - first_neighbour + 1
+  int flags;      // bit 0 was_cut, bit 1 is_star_neighbour
+  double kf;      // kappa_factor(icell)
+};
+static_assert(sizeof(VoroCell) == 32, "VoroCell is one 32-byte record");
+
+struct VoroNb {
+  float x, y, z;  // Voronoi_xyz(:,id) (unused for walls)
+  int id;         // neighbour cell (> 0) or -iwall
+};
+static_assert(sizeof(VoroNb) == 16, "VoroNb is one 16-byte record");
+
+struct VoroGrid {
+  int n_cells;
+  const VoroCell* cell;
+  const VoroNb* nb;
+  const double* h;        // Voronoi(:)%h, read for cut cells only
+  const double* xyz_dp;   // Voronoi(:)%xyz (3 per cell)
+  const int* wall_first;  // [7]
+  const int* wall_cells;  // wall(iwall)%neighbour_list, concatenated
+  float walls[24];        // 6 x (x1,x2,x3,x4) (Voronoi.f90:1275-1280)
+  double cut_o_h;         // PS%cutting_distance_o_h
+};
+
+constexpr float FLT_TINY = 1.17549435082228750797e-38f;
+constexpr float FLT_HUGE = 3.40282346638528859812e+38f;
+
+// default-real dot product, evaluated left to right without contraction
+__device__ inline float dot3f(float a0, float a1, float a2, float b0, float b1, float b2) {
+  return __fadd_rn(__fadd_rn(__fmul_rn(a0, b0), __fmul_rn(a1, b1)), __fmul_rn(a2, b2));
+}
+
+// distance_to_wall (Voronoi.f90:1289-1317)
+__device__ inline double voro_distance_to_wall(const VoroGrid& G, double x, double y, double z, double u,
+                                               double v, double w, int iwall) {
+  const float* W = G.walls + 4 * (iwall - 1);
+  const double n0 = W[0], n1 = W[1], n2 = W[2];
+  const double p0 = (double)W[3] * fabs(n0), p1 = (double)W[3] * fabs(n1), p2 = (double)W[3] * fabs(n2);
+  const float den = (float)__dadd_rn(__dadd_rn(__dmul_rn(n0, u), __dmul_rn(n1, v)), __dmul_rn(n2, w));
+  if (fabsf(den) > FLT_TINY) {
+    const double num = __dadd_rn(__dadd_rn(__dmul_rn(n0, p0 - x), __dmul_rn(n1, p1 - y)), __dmul_rn(n2, p2 - z));
+    return num / (double)den;
+  }
+  return (double)FLT_HUGE;
+}
+
+// distance_to_star (Voronoi.f90:1321-1375)
+__device__ inline double voro_distance_to_star(const DevModel& M, double x, double y, double z, double u,
+                                               double v, double w, int& i_star) {
+  double d = HUGE_DP;
+  i_star = 0;
+  for (int i = 1; i <= M.n_stars; ++i) {
+    const double* s4 = &M.star_xyzr[4 * (i - 1)];
+    const double dx = x - s4[0], dy = y - s4[1], dz = z - s4[2];
+    const double b = __dadd_rn(__dadd_rn(__dmul_rn(dx, u), __dmul_rn(dy, v)), __dmul_rn(dz, w));
+    const double c = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz)),
+                               -__dmul_rn(s4[3], s4[3]));
+    const double delta = __dadd_rn(__dmul_rn(b, b), -c);
+    if (delta >= 0.0) {
+      const double rac = sqrt(delta), s1 = -b - rac;
+      if (s1 < 0) {
+        const double s2 = -b + rac;
+        if (s2 > 0) { d = 0.0; i_star = i; }
+      } else if (s1 < d) {
+        d = s1; i_star = i;
+      }
+    }
+  }
+  return d;
+}
+
+// is_in_volume (Voronoi.f90:1462-1478)
+__device__ inline bool voro_is_in_volume(const VoroGrid& G, double x, double y, double z) {
+  return (x > (double)G.walls[3]) && (x < (double)G.walls[7]) && (y > (double)G.walls[11]) &&
+         (y < (double)G.walls[15]) && (z > (double)G.walls[19]) && (z < (double)G.walls[23]);
+}
+
+__device__ inline float voro_dist2f(const double* c, double x, double y, double z) {
+  const double dx = c[0] - x, dy = c[1] - y, dz = c[2] - z;
+  return (float)__dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
+}
+
+// index_cell_voronoi (Voronoi.f90:1548-1570): brute force with default-real distances
+__device__ inline int voro_index_cell(const VoroGrid& G, double x, double y, double z) {
+  float dmin = FLT_HUGE;
+  int ic = 0;
+  for (int i = 1; i <= G.n_cells; ++i) {
+    const float d2 = voro_dist2f(G.xyz_dp + 3 * (size_t)(i - 1), x, y, z);
+    if (d2 < dmin) { ic = i; dmin = d2; }
+  }
+  return ic;
+}
+
+// cross_Voronoi_cell (Voronoi.f90:839-992).  C = the cell's record (loaded by the caller, who also
+// needs its opacity factor).
+__device__ inline void voro_cross_cell(const VoroGrid& G, const DevModel& M, const VoroCell& C, double x,
+                                       double y, double z, double u, double v, double w, int icell,
+                                       int previous_cell, double& x1, double& y1, double& z1,
+                                       int& next_cell, double& s_out, double& s_contrib,
+                                       double& s_void_before) {
+  const float r0 = (float)x, r1 = (float)y, r2 = (float)z;
+  const float k0 = (float)u, k1 = (float)v, k2 = (float)w;
+  double s = 1.00000001504746621988e+30;  // real 1e30
+  next_cell = 0;
+  const VoroNb* nb = G.nb + C.first;
+  for (int i = 0; i < C.count; ++i) {
+    const VoroNb N = nb[i];
+    if (N.id == previous_cell) continue;
+    double s_tmp;
+    if (N.id > 0) {
+      const float n0 = __fsub_rn(N.x, C.x), n1 = __fsub_rn(N.y, C.y), n2 = __fsub_rn(N.z, C.z);
+      const double den = (double)dot3f(n0, n1, n2, k0, k1, k2);
+      if (den <= 0.0) continue;
+      const float p0 = __fmul_rn(0.5f, __fadd_rn(N.x, C.x)), p1 = __fmul_rn(0.5f, __fadd_rn(N.y, C.y)),
+                  p2 = __fmul_rn(0.5f, __fadd_rn(N.z, C.z));
+      s_tmp = (double)dot3f(n0, n1, n2, __fsub_rn(p0, r0), __fsub_rn(p1, r1), __fsub_rn(p2, r2)) / den;
+      if (s_tmp < 0.0) s_tmp = (double)FLT_HUGE;
+    } else {
+      s_tmp = voro_distance_to_wall(G, x, y, z, u, v, w, -N.id);
+      if (s_tmp < 0.0) s_tmp = (double)FLT_HUGE;
+    }
+    if (s_tmp < s) { s = s_tmp; next_cell = N.id; }
+  }
+  s = __dmul_rn(s, 1.0 + (double)1e-5f);
+  x1 = __dadd_rn(x, __dmul_rn(u, s));
+  y1 = __dadd_rn(y, __dmul_rn(v, s));
+  z1 = __dadd_rn(z, __dmul_rn(w, s));
+  if (next_cell == 0) {  // rounding error somewhere (:926-937)
+    x1 = x; y1 = y; z1 = z; s = 0.0;
+    if (voro_is_in_volume(G, x, y, z)) {
+      next_cell = voro_index_cell(G, x, y, z);
+      if (icell == next_cell) next_cell = -1;
+    } else {
+      next_cell = -1;
+    }
+  }
+  if (C.flags & 1) {  // cut cell: only the sphere of radius h*cutting_distance_o_h holds matter (:939-975)
+    const double d0 = (double)__fsub_rn(r0, C.x), d1 = (double)__fsub_rn(r1, C.y), d2 = (double)__fsub_rn(r2, C.z);
+    const double b = __dadd_rn(__dadd_rn(__dmul_rn(d0, (double)k0), __dmul_rn(d1, (double)k1)), __dmul_rn(d2, (double)k2));
+    const double hc = __dmul_rn(G.h[icell - 1], G.cut_o_h);
+    const double c = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(d0, d0), __dmul_rn(d1, d1)), __dmul_rn(d2, d2)),
+                               -__dmul_rn(hc, hc));
+    const double delta = __dadd_rn(__dmul_rn(b, b), -c);
+    if (delta < 0.0) {
+      s_void_before = s; s_contrib = 0.0;
+    } else {
+      const double rac = sqrt(delta), s1 = -b - rac, s2 = -b + rac;
+      if (s1 < 0) {
+        if (s2 < 0) { s_void_before = s; s_contrib = 0.0; }
+        else { s_void_before = 0.0; s_contrib = fmin(s2, s); }
+      } else if (s1 < s) {
+        s_void_before = s1; s_contrib = fmin(s2, s) - s1;
+      } else {
+        s_void_before = s; s_contrib = 0.0;
+      }
+    }
+  } else {
+    s_void_before = 0.0; s_contrib = s;
+  }
+  if (C.flags & 2) {  // star neighbour (:977-988)
+    int i_star;
+    const double d_to_star = voro_distance_to_star(M, x, y, z, u, v, w, i_star);
+    if (i_star > 0 && d_to_star < s) {
+      s_contrib = d_to_star;
+      next_cell = M.star_cell[4 * (i_star - 1)];
+    }
+  }
+  s_out = s;
+}
+
+// move_to_grid_Voronoi (Voronoi.f90:1379-1442) + find_Voronoi_cell_brute_force (:1485)
+__device__ inline bool voro_move_to_grid(const VoroGrid& G, double& x, double& y, double& z, double u,
+                                         double v, double w, int& icell) {
+  double s_walls[6];
+  int order[6];
+  for (int iw = 1; iw <= 6; ++iw) {
+    const double l = voro_distance_to_wall(G, x, y, z, u, v, w, iw);
+    s_walls[iw - 1] = (l >= 0) ? __dmul_rn(l, 1.0 + 1.e-6) : (double)FLT_HUGE;
+    order[iw - 1] = iw;
+  }
+  for (int a = 1; a < 6; ++a)
+    for (int b = a; b > 0 && s_walls[order[b] - 1] < s_walls[order[b - 1] - 1]; --b) {
+      const int t = order[b]; order[b] = order[b - 1]; order[b - 1] = t;
+    }
+  int iwall = 0;
+  double xt = 0, yt = 0, zt = 0;
+  bool found = false;
+  for (int i = 0; i < 6 && !found; ++i) {
+    iwall = order[i];
+    const double l = s_walls[iwall - 1];
+    xt = __dadd_rn(x, __dmul_rn(l, u)); yt = __dadd_rn(y, __dmul_rn(l, v)); zt = __dadd_rn(z, __dmul_rn(l, w));
+    found = voro_is_in_volume(G, xt, yt, zt);
+  }
+  if (!found) { icell = 0; return false; }
+  x = xt; y = yt; z = zt;
+  float dmin = FLT_HUGE;
+  int imin = 0;
+  for (int q = G.wall_first[iwall - 1]; q < G.wall_first[iwall]; ++q) {
+    const int ic = G.wall_cells[q];
+    const float d2 = voro_dist2f(G.xyz_dp + 3 * (size_t)(ic - 1), xt, yt, zt);
+    if (d2 < dmin) { imin = ic; dmin = d2; }
+  }
+  icell = imin;
+  return true;
+}
+
+// ---------------------------------------------------------------------------
+// The thermal packet kernel on a Voronoi grid: deposits go to HBM (global_atomic_add_f64), the
+// grid does not fit a CU's LDS.
+// ---------------------------------------------------------------------------
+template <bool POLA>
+__device__ __forceinline__ void thermal_body_voro(const DevModel& M, const RunArgs& A, const VoroGrid& G,
+                                                  double* lds_base) {
+  const Lds T = lds_carve(lds_base, M);
+  lds_stage(T, M);
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+
+  int st = S_EMIT;
+  double x = 0, y = 0, z = 0, u = 0, v = 0, w = 1, extr = 0;
+  int icell = 0, prev_cell = 0, lambda = 1;
+  int star_icell = 0;  // cell of the star this flight would hit (0: none)
+  bool flag_star = false, flag_scatt = false;
+  double S[4] = {1.0, 0.0, 0.0, 0.0};
+  Rng rng;
+  rng.init(0, 0);
+  unsigned int c_cross = 0, c_flight = 0, c_scatt = 0, c_abs = 0, c_esc = 0, c_kill = 0, c_pack = 0;
+  unsigned int pk_cross = 0;
+  unsigned long long pk_next = 0, pk_end = 0;
+  float tau_rand = 0.0f;
+
+  for (;;) {
+    if (st == S_EXITED) {
+      capteur<POLA>(M, A.sed, lambda, u, v, w, S, flag_star, flag_scatt);
+      c_esc++;
+      st = S_EMIT;
+    }
+    {  // EMIT: packet ids from this wave's reserved batch (see thermal_body)
+      const bool need = (st == S_EMIT);
+      const unsigned long long mask = __ballot(need);
+      if (mask) {
+        if (pk_next >= pk_end) {
+          const int leader = __ffsll((long long)mask) - 1;
+          unsigned long long base = 0;
+          if (lane == leader) base = atomicAdd(A.next_packet, (unsigned long long)PK_BATCH);
+          base = __shfl(base, leader);
+          pk_next = base < A.n_packets ? base : A.n_packets;
+          pk_end = (base + PK_BATCH < A.n_packets) ? base + PK_BATCH : A.n_packets;
+          if (pk_end < pk_next) pk_end = pk_next;
+        }
+        const unsigned long long avail = pk_end - pk_next;
+        const unsigned long long rank = (unsigned long long)__popcll(mask & ((1ull << lane) - 1ull));
+        const unsigned long long cnt = (unsigned long long)__popcll(mask);
+        const unsigned long long my = pk_next + rank;
+        const bool served = need && (rank < avail);
+        if (need && !served && pk_next >= A.n_packets) st = S_DONE;
+        pk_next += (cnt < avail) ? cnt : avail;
+        if (served) {
+          // mc_photon_loop body (dust_transfer.f90:529-541)
+          rng.init(A.seed, A.first_packet + my);
+          c_pack++;
+          pk_cross = 0;
+          float f[12];
+          rng.emission_event(f);
+          tau_rand = f[8];
+          lambda = select_wl_em(T, M, f[0]);
+          atomic_add_f64(&A.n_sent[lambda - 1], 1.0);
+          bool lintersect = true;
+          flag_scatt = false;
+          S[0] = 1.0; S[1] = 0.0; S[2] = 0.0; S[3] = 0.0;
+          if ((double)f[1] <= T.fstar[lambda - 1]) {  // emit_packet (dust_transfer.f90:1047-1151)
+            flag_star = true;
+            const int i_star = select_star(M, lambda, f[2]);
+            emit_uniform_sphere(M, i_star, f[3], f[4], f[5], f[6], x, y, z, u, v, w);
+            icell = M.star_cell[4 * (i_star - 1)];  // stars.f90:155-156
+            if (M.star_cell[4 * (i_star - 1) + 3]) lintersect = voro_move_to_grid(G, x, y, z, u, v, w, icell);
+          } else if ((double)f[1] <= M.frac_E_disk[lambda - 1] && M.prob_E_cell) {
+            flag_star = false;
+            icell = select_cellule(M, lambda, f[2]);
+            const double* c = G.xyz_dp + 3 * (size_t)(icell - 1);  // pos_em_cell_voronoi (:1510-1542)
+            x = c[0]; y = c[1]; z = c[2];
+            random_isotropic_direction(f[6], f[7], u, v, w);
+          } else {
+            *A.err = 12;
+            st = S_DONE;
+          }
+          if (st != S_DONE) st = lintersect ? S_NEWFLIGHT : S_EXITED;
+        }
+      }
+    }
+
+    if (st == S_INTERACT) {  // dust_transfer.f90:1260-1402
+      float g[8];
+      rng.interaction_event(g);
+      tau_rand = g[5];
+      double u1, v1, w1;
+      const int ic = icell - 1;
+      interact<POLA>(T, M, g, lambda, u, v, w, u1, v1, w1, S, flag_star, flag_scatt, c_scatt, c_abs, [&]() {
+        if (A.frozen) return A.E_prior[ic];
+        return __hip_atomic_load(&A.E_abs[ic], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * A.qscale;
+      }, M.volume + ic);
+      u = u1; v = v1; w = w1;
+      st = S_NEWFLIGHT;
+    }
+
+    if (st == S_NEWFLIGHT) {
+      const float rand = tau_rand;  // dust_transfer.f90:1208-1215
+      extr = (rand > 1.0e-6f) ? -log(1.0 - (double)rand) : (double)rand;
+      const int i_star = intersect_stars(M, x, y, z, u, v, w);  // optical_depth.f90:68
+      star_icell = (i_star > 0) ? M.star_cell[4 * (i_star - 1)] : 0;
+      c_flight++;
+      prev_cell = 0;
+      st = S_FLIGHT;
+    }
+
+    if (__ballot(st != S_DONE) == 0ull) break;
+
+    // FLIGHT: cell crossings (physical_length, optical_depth.f90:77-178)
+#pragma unroll 1
+    for (int it = 0; it < A.inner_iters; ++it) {
+      if (A.min_active > 0 && it > 0) {
+        const int flying = __popcll(__ballot(st == S_FLIGHT)), alive = __popcll(__ballot(st != S_DONE));
+        if (flying * 64 < A.min_active * alive) break;
+      }
+      if (st == S_FLIGHT) {
+        if (icell < 0) {  // test_exit_grid_Voronoi (:1446)
+          st = S_EXITED;
+        } else if (star_icell > 0 && icell == star_icell) {  // optical_depth.f90:91-97
+          c_kill++;
+          st = S_EMIT;
+        } else {
+          const VoroCell C = G.cell[icell - 1];
+          const double opacity = T.kappa[lambda - 1] * C.kf;
+          double x1, y1, z1, l, l_contrib, l_void;
+          int next;
+          voro_cross_cell(G, M, C, x, y, z, u, v, w, icell, prev_cell, x1, y1, z1, next, l, l_contrib, l_void);
+          c_cross++;
+          if (++pk_cross > 200000000u) {
+            *A.err = 13;
+            st = S_EMIT;
+          }
+          const double tau = l_contrib * opacity;
+          if (tau > extr) {
+            const double lc = l_contrib * (extr / tau);
+            const double ls = l_void + lc;
+            const double dE = T.kabs[lambda - 1] * lc * S[0];
+            if (dE != 0.0 && !(A.flags & 1)) atomic_add_f64(&A.E_abs[icell - 1], dE);
+            x = __dadd_rn(x, __dmul_rn(ls, u));
+            y = __dadd_rn(y, __dmul_rn(ls, v));
+            z = __dadd_rn(z, __dmul_rn(ls, w));
+            st = S_INTERACT;
+          } else {
+            extr = extr - tau;
+            const double dE = T.kabs[lambda - 1] * l_contrib * S[0];
+            if (dE != 0.0 && !(A.flags & 1)) atomic_add_f64(&A.E_abs[icell - 1], dE);
+            x = x1; y = y1; z = z1;
+            prev_cell = icell;
+            icell = next;
+          }
+        }
+      }
+    }
+  }
+
+  unsigned int cs[8] = {c_pack, c_cross, c_flight, c_scatt, c_abs, c_esc, c_kill, 0u};
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    unsigned long long vsum = cs[q];
+    for (int off = 32; off > 0; off >>= 1) vsum += __shfl_down(vsum, off);
+    if (lane == 0 && vsum) atomicAdd(&A.counters[q], vsum);
+  }
+}
+
+template <bool POLA>
+__global__ void __launch_bounds__(256) k_thermal_voro(const DevModel M, const RunArgs A, const VoroGrid G) {
+  extern __shared__ double lds_raw[];
+  thermal_body_voro<POLA>(M, A, G, lds_raw);
+}
+
+// probe: one cross_Voronoi_cell per thread (tests)
+__global__ void k_probe_cross_voro(const DevModel M, const VoroGrid G, int n, const double* x0, const double* y0,
+                                   const double* z0, const double* u, const double* v, const double* w,
+                                   const int* cell, const int* prev, double* x1, double* y1, double* z1,
+                                   int* next, double* l, double* l_contrib, double* l_void) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const VoroCell C = G.cell[cell[i] - 1];
+  voro_cross_cell(G, M, C, x0[i], y0[i], z0[i], u[i], v[i], w[i], cell[i], prev[i], x1[i], y1[i], z1[i], next[i],
+                  l[i], l_contrib[i], l_void[i]);
+}
+
+}  // namespace mcgpu

@@ -15,6 +15,7 @@
 
 #include "mc_device.hip.h"
 #include "mc_rounds.hip.h"
+#include "mc_voronoi.hip.h"
 
 using namespace mcgpu;
 
@@ -49,6 +50,11 @@ struct mcgpu_ctx {
   int* d_list = nullptr;
   unsigned int* d_round_counts = nullptr;  // [0] list_n, [1] flying_n
   Pool* d_pool_desc = nullptr;             // device copy of `pool` for the finisher
+  // Voronoi grid (mc_voronoi.hip.h)
+  bool voro = false;
+  VoroGrid V;
+  std::vector<VoroCell> h_cells;  // host copy: kappa_factor is patched in by mcgpu_set_opacity
+  VoroCell* d_cells = nullptr;
 };
 
 #define HIPCHK(call)                                                              \
@@ -140,6 +146,7 @@ extern "C" int mcgpu_set_grid_cyl(mcgpu_ctx* ctx, int n_rad, int nz, int n_az, i
       !cell_map || !cell_map_i || !cell_map_j || !cell_map_k || !lexit_cell)
     return fail(ctx, MCGPU_ERR_ARG, "mcgpu_set_grid_cyl: bad argument");
   if (!l3D && n_az != 1) return fail(ctx, MCGPU_ERR_ARG, "2D grid needs n_az = 1");
+  if (ctx->voro) return fail(ctx, MCGPU_ERR_STATE, "the context already holds a Voronoi grid");
   HIPCHK(hipSetDevice(ctx->device));
   const int n_cells = l3D ? 2 * n_rad * nz * n_az : n_rad * nz;
   const int jlo = l3D ? -nz - 1 : 0;
@@ -193,6 +200,80 @@ extern "C" int mcgpu_set_grid_cyl(mcgpu_ctx* ctx, int n_rad, int nz, int n_az, i
   return MCGPU_OK;
 }
 
+// The arrays Voronoi_tesselation hands to the packet loop (Voronoi.f90:23-67, 385-640).
+extern "C" int mcgpu_set_grid_voronoi(mcgpu_ctx* ctx, int n_cells, const float* voronoi_xyz,
+                                      const double* xyz_dp, const double* h, const int* first_neighbour,
+                                      const int* last_neighbour, const int* neighbours_list,
+                                      long long n_neighbours, const unsigned char* was_cut,
+                                      const unsigned char* is_star_neighbour, const float* walls,
+                                      double cutting_distance_o_h, const int* wall_first,
+                                      const int* wall_cells, const double* volume) {
+  if (!ctx || n_cells < 1 || !voronoi_xyz || !xyz_dp || !h || !first_neighbour || !last_neighbour ||
+      !neighbours_list || n_neighbours < 1 || !walls || !wall_first || !wall_cells || !volume)
+    return fail(ctx, MCGPU_ERR_ARG, "mcgpu_set_grid_voronoi: bad argument");
+  if (ctx->have_grid) return fail(ctx, MCGPU_ERR_STATE, "the grid of a context is set once");
+  for (int iw = 0; iw < 6; ++iw) {  // plane walls in the order of Voronoi.f90:1275-1280
+    const float* W = walls + 4 * iw;
+    const float want = (iw & 1) ? 1.0f : -1.0f;
+    for (int a = 0; a < 3; ++a)
+      if (W[a] != ((a == iw / 2) ? want : 0.0f))
+        return fail(ctx, MCGPU_ERR_UNSUPPORTED, "walls must be the 6 axis-aligned planes (-x,+x,-y,+y,-z,+z)");
+  }
+  HIPCHK(hipSetDevice(ctx->device));
+  std::vector<VoroNb> nb((size_t)n_neighbours);
+  ctx->h_cells.assign((size_t)n_cells, VoroCell{});
+  for (int i = 0; i < n_cells; ++i) {
+    const long long f = first_neighbour[i], l = last_neighbour[i];
+    if (f < 1 || l < f - 1 || l > n_neighbours)
+      return fail(ctx, MCGPU_ERR_ARG, "first_neighbour/last_neighbour out of range");
+    VoroCell& C = ctx->h_cells[i];
+    C.x = voronoi_xyz[3 * (size_t)i]; C.y = voronoi_xyz[3 * (size_t)i + 1]; C.z = voronoi_xyz[3 * (size_t)i + 2];
+    C.first = (int)(f - 1);
+    C.count = (int)(l - f + 1);
+    C.flags = ((was_cut && was_cut[i]) ? 1 : 0) | ((is_star_neighbour && is_star_neighbour[i]) ? 2 : 0);
+    C.kf = 0.0;
+    for (long long q = f - 1; q < l; ++q) {
+      const int id = neighbours_list[q];
+      if (id == 0 || id > n_cells || id < -6) return fail(ctx, MCGPU_ERR_ARG, "neighbours_list entry out of range");
+      VoroNb& N = nb[(size_t)q];
+      N.id = id;
+      if (id > 0) {
+        N.x = voronoi_xyz[3 * (size_t)(id - 1)]; N.y = voronoi_xyz[3 * (size_t)(id - 1) + 1];
+        N.z = voronoi_xyz[3 * (size_t)(id - 1) + 2];
+      } else {
+        N.x = N.y = N.z = 0.0f;
+      }
+    }
+  }
+  if (wall_first[0] != 0) return fail(ctx, MCGPU_ERR_ARG, "wall_first[0] must be 0");
+  for (int iw = 0; iw < 6; ++iw)
+    if (wall_first[iw + 1] < wall_first[iw]) return fail(ctx, MCGPU_ERR_ARG, "wall_first must not decrease");
+  for (int q = 0; q < wall_first[6]; ++q)
+    if (wall_cells[q] < 1 || wall_cells[q] > n_cells) return fail(ctx, MCGPU_ERR_ARG, "wall_cells entry out of range");
+  DevModel& M = ctx->M;
+  M.n_rad = 0; M.nz = 0; M.n_az = 0; M.l3D = 1; M.n_cells = n_cells;
+  VoroGrid& V = ctx->V;
+  V.n_cells = n_cells;
+  V.cut_o_h = cutting_distance_o_h;
+  std::memcpy(V.walls, walls, 24 * sizeof(float));
+  int rc;
+  const double dummy = 0.0;
+  if ((rc = upload(ctx, &dummy, 1, &M.r_lim_2))) return rc;  // the shared LDS carve stages r_lim_2(0:n_rad)
+  if ((rc = upload(ctx, nb.data(), nb.size(), &V.nb))) return rc;
+  if ((rc = upload(ctx, h, (size_t)n_cells, &V.h))) return rc;
+  if ((rc = upload(ctx, xyz_dp, 3 * (size_t)n_cells, &V.xyz_dp))) return rc;
+  if ((rc = upload(ctx, wall_first, 7, &V.wall_first))) return rc;
+  if ((rc = upload(ctx, wall_cells, (size_t)wall_first[6], &V.wall_cells))) return rc;
+  if ((rc = upload(ctx, volume, (size_t)n_cells, &M.volume))) return rc;
+  const VoroCell* dc;
+  if ((rc = upload(ctx, ctx->h_cells.data(), ctx->h_cells.size(), &dc))) return rc;
+  ctx->d_cells = (VoroCell*)dc;
+  V.cell = dc;
+  ctx->voro = true;
+  ctx->have_grid = true;
+  return MCGPU_OK;
+}
+
 extern "C" int mcgpu_set_midplane_snap(mcgpu_ctx* ctx, int on) {
   if (!ctx) return MCGPU_ERR_ARG;
   ctx->M.midplane_snap = on ? 1 : 0;
@@ -212,6 +293,13 @@ extern "C" int mcgpu_set_stars(mcgpu_ctx* ctx, int n_stars, const double* x, con
   const int jlo = G.l3D ? -G.nz - 1 : 0;
   for (int s = 0; s < n_stars; ++s) {
     xyzr[4 * s + 0] = x[s]; xyzr[4 * s + 1] = y[s]; xyzr[4 * s + 2] = z[s]; xyzr[4 * s + 3] = r[s];
+    if (ctx->voro) {  // a star inside the box is a site of its own (Voronoi.f90:357-376)
+      if (icell[s] < 0 || icell[s] > G.n_cells || (icell[s] == 0 && !out_model[s]))
+        return fail(ctx, MCGPU_ERR_ARG, "star icell is not a cell of the Voronoi grid");
+      cell[4 * s + 0] = icell[s]; cell[4 * s + 1] = 0; cell[4 * s + 2] = 0;
+      cell[4 * s + 3] = out_model[s] ? 1 : 0;
+      continue;
+    }
     bool found = false;
     for (int k = 1; k <= G.n_az && !found; ++k)
       for (int j = jlo; j <= G.nz + 1 && !found; ++j) {
@@ -253,7 +341,13 @@ extern "C" int mcgpu_set_opacity(mcgpu_ctx* ctx, int n_lambda, const double* kap
   if (l_dark_zone) {
     bool any = false;
     for (int i = 0; i < M.n_cells; ++i) any |= (l_dark_zone[i] != 0);
+    if (any && ctx->voro)  // the reference never builds a dark zone there (dust_transfer.f90:290-293)
+      return fail(ctx, MCGPU_ERR_UNSUPPORTED, "no dark zone on a Voronoi grid");
     if (any && (rc = upload(ctx, l_dark_zone, (size_t)M.n_cells, &M.dark))) return rc;
+  }
+  if (ctx->voro) {  // the cell records carry the opacity factor
+    for (int i = 0; i < M.n_cells; ++i) ctx->h_cells[i].kf = kappa_factor[i];
+    HIPCHK(hipMemcpy(ctx->d_cells, ctx->h_cells.data(), ctx->h_cells.size() * sizeof(VoroCell), hipMemcpyHostToDevice));
   }
   ctx->have_opacity = true;
   return MCGPU_OK;
@@ -407,6 +501,34 @@ static int launch_mega(mcgpu_ctx* ctx, const RunArgs& A, bool use_lds, int grid_
     else { if (dark) LAUNCH(false, false, true); else LAUNCH(false, false, false); }
   }
 #undef LAUNCH
+  if (e != hipSuccess) {
+    ctx->err = std::string("kernel launch: ") + hipGetErrorString(e);
+    return MCGPU_ERR_HIP;
+  }
+  return MCGPU_OK;
+}
+
+// the Voronoi-grid kernel (mc_voronoi.hip.h): HBM deposits, 256-thread workgroups
+static int launch_voro(mcgpu_ctx* ctx, const RunArgs& A, int grid_blocks, int block_threads) {
+  const DevModel& M = ctx->M;
+  const size_t lds = lds_bytes(M);
+  const int threads = (block_threads > 0 && block_threads <= 256) ? block_threads : 256;
+  if (threads % 64) return fail(ctx, MCGPU_ERR_ARG, "block_threads must be a multiple of 64");
+  const bool pola = ctx->lsepar_pola != 0;
+  const void* fn = pola ? (const void*)k_thermal_voro<true> : (const void*)k_thermal_voro<false>;
+  HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  int blocks = grid_blocks;
+  if (blocks <= 0) {
+    int occ = 1;
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, threads, lds));
+    if (occ < 1) occ = 1;
+    blocks = ctx->prop.multiProcessorCount * occ;
+    const unsigned long long need = (A.n_packets + threads - 1) / threads;
+    if ((unsigned long long)blocks > need) blocks = (int)(need ? need : 1);
+  }
+  if (pola) hipLaunchKernelGGL(k_thermal_voro<true>, dim3(blocks), dim3(threads), lds, ctx->stream, M, A, ctx->V);
+  else hipLaunchKernelGGL(k_thermal_voro<false>, dim3(blocks), dim3(threads), lds, ctx->stream, M, A, ctx->V);
+  hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     ctx->err = std::string("kernel launch: ") + hipGetErrorString(e);
     return MCGPU_ERR_HIP;
@@ -593,6 +715,14 @@ extern "C" int mcgpu_launch_thermal(mcgpu_ctx* ctx, const mcgpu_run_opts* o) {
   if (const char* e = getenv("MCGPU_INNER_ITERS")) { int v = atoi(e); if (v >= 1 && v <= 4096) A.inner_iters = v; }
   if (const char* e = getenv("MCGPU_FLUSH_EVERY")) { int v = atoi(e); if (v >= 1 && v <= 1000000) A.flush_every = v; }
   if (const char* e = getenv("MCGPU_DIAG_FLAGS")) A.flags = atoi(e);
+  if (ctx->voro) {
+    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+    int rcv = launch_voro(ctx, A, o->grid_blocks, o->block_threads);
+    if (rcv) return rcv;
+    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+    ctx->launched = true;
+    return MCGPU_OK;
+  }
   // Deposit mode: a private absorbed-energy grid in LDS when it fits next to the tables
   // (2D grids), HBM atomics otherwise.  MCGPU_DEPOSIT=hbm|lds overrides.
   const size_t lds_e = lds + (size_t)M.n_cells * sizeof(double);
@@ -730,6 +860,7 @@ extern "C" int mcgpu_probe_cross_cell(mcgpu_ctx* ctx, int n, const double* x0, c
                                       double* x1, double* y1, double* z1, int* next_cell, double* l) {
   int rc = ready(ctx);
   if (rc) return rc;
+  if (ctx->voro) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "cylindrical probe on a Voronoi grid");
   HIPCHK(hipSetDevice(ctx->device));
   const DevModel& M = ctx->M;
   DevBuf<double> in[6], out[4];
@@ -757,10 +888,39 @@ extern "C" int mcgpu_probe_cross_cell(mcgpu_ctx* ctx, int n, const double* x0, c
   return MCGPU_OK;
 }
 
+extern "C" int mcgpu_probe_cross_voronoi(mcgpu_ctx* ctx, int n, const double* x0, const double* y0,
+                                         const double* z0, const double* u, const double* v, const double* w,
+                                         const int* cell, const int* previous_cell, double* x1, double* y1,
+                                         double* z1, int* next_cell, double* l, double* l_contrib,
+                                         double* l_void_before) {
+  int rc = ready(ctx);
+  if (rc) return rc;
+  if (!ctx->voro) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "Voronoi probe on a cylindrical grid");
+  HIPCHK(hipSetDevice(ctx->device));
+  DevBuf<double> in[6], out[6];
+  DevBuf<int> dc, dp, dn;
+  const double* hin[6] = {x0, y0, z0, u, v, w};
+  for (int q = 0; q < 6; ++q) { HIPCHK(in[q].alloc(n)); HIPCHK(in[q].put(hin[q], n)); }
+  for (int q = 0; q < 6; ++q) HIPCHK(out[q].alloc(n));
+  HIPCHK(dc.alloc(n)); HIPCHK(dc.put(cell, n));
+  HIPCHK(dp.alloc(n)); HIPCHK(dp.put(previous_cell, n));
+  HIPCHK(dn.alloc(n));
+  hipLaunchKernelGGL(k_probe_cross_voro, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->M, ctx->V, n,
+                     in[0].p, in[1].p, in[2].p, in[3].p, in[4].p, in[5].p, dc.p, dp.p, out[0].p, out[1].p, out[2].p,
+                     dn.p, out[3].p, out[4].p, out[5].p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(out[0].get(x1, n)); HIPCHK(out[1].get(y1, n)); HIPCHK(out[2].get(z1, n)); HIPCHK(out[3].get(l, n));
+  HIPCHK(out[4].get(l_contrib, n)); HIPCHK(out[5].get(l_void_before, n));
+  HIPCHK(dn.get(next_cell, n));
+  return MCGPU_OK;
+}
+
 extern "C" int mcgpu_probe_index_cell(mcgpu_ctx* ctx, int n, const double* x, const double* y, const double* z,
                                       int* icell) {
   int rc = ready(ctx);
   if (rc) return rc;
+  if (ctx->voro) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "cylindrical probe on a Voronoi grid");
   HIPCHK(hipSetDevice(ctx->device));
   const DevModel& M = ctx->M;
   DevBuf<double> in[3];

@@ -31,7 +31,8 @@ ABI_SYMBOLS = (
     "mcgpu_set_E_prior", "mcgpu_run_thermal", "mcgpu_launch_thermal", "mcgpu_sync",
     "mcgpu_device_accumulators", "mcgpu_fetch", "mcgpu_set_stream", "mcgpu_temp_finale",
     "mcgpu_probe_cross_cell", "mcgpu_probe_index_cell", "mcgpu_probe_philox",
-    "mcgpu_probe_packet_rand", "mcgpu_set_midplane_snap",
+    "mcgpu_probe_packet_rand", "mcgpu_set_midplane_snap", "mcgpu_set_grid_voronoi",
+    "mcgpu_probe_cross_voronoi",
 )
 
 
@@ -119,6 +120,24 @@ class Engine:
     def _upload(self, m, n_tot):
         g, cfg, L = m.grid, m.cfg, self.lib
         d, i32 = np.float64, np.int32
+        if g.get("grid_type", 1) == 3:
+            u8 = np.uint8
+            self._chk(L.mcgpu_set_grid_voronoi(
+                self.ctx, C.c_int(g["n_cells"]), _p(_a(g["v_xyz"], np.float32), C.c_float),
+                _p(_a(g["v_xyz_dp"], d), C.c_double), _p(_a(g["v_h"], d), C.c_double),
+                _p(_a(g["v_first"], i32), C.c_int), _p(_a(g["v_last"], i32), C.c_int),
+                _p(_a(g["v_neigh"], i32), C.c_int), C.c_longlong(int(np.asarray(g["v_neigh"]).size)),
+                _p(_a(g["v_was_cut"], u8), C.c_ubyte), _p(_a(g["v_is_star_neighbour"], u8), C.c_ubyte),
+                _p(_a(g["v_walls"], np.float32), C.c_float), C.c_double(g["v_cut_o_h"]),
+                _p(_a(g["v_wall_first"], i32), C.c_int), _p(_a(g["v_wall_cells"], i32), C.c_int),
+                _p(_a(g["volume"], d), C.c_double)), "mcgpu_set_grid_voronoi")
+        else:
+            self._upload_grid_cyl(m)
+        self._upload_tables(m, n_tot)
+
+    def _upload_grid_cyl(self, m):
+        g, L = m.grid, self.lib
+        d, i32 = np.float64, np.int32
         self._chk(L.mcgpu_set_grid_cyl(
             self.ctx, C.c_int(g["n_rad"]), C.c_int(g["nz"]), C.c_int(g["n_az"]), C.c_int(g["l3D"]),
             _p(_a(g["r_lim_2"], d), C.c_double), _p(_a(g["zmax"], d), C.c_double),
@@ -129,6 +148,10 @@ class Engine:
             _p(_a(g["lexit_cell"], i32), C.c_int)), "mcgpu_set_grid_cyl")
         self._chk(L.mcgpu_set_midplane_snap(self.ctx, C.c_int(int(getattr(m, "midplane_snap", 1)))),
                   "mcgpu_set_midplane_snap")
+
+    def _upload_tables(self, m, n_tot):
+        cfg, L = m.cfg, self.lib
+        d, i32 = np.float64, np.int32
         st = np.asarray(m.stars, d)
         cols = [_a(st[:, q], d) for q in range(4)]
         self._chk(L.mcgpu_set_stars(
@@ -239,6 +262,19 @@ class Engine:
             _p(x1, C.c_double), _p(y1, C.c_double), _p(z1, C.c_double), _p(nxt, C.c_int),
             _p(l, C.c_double)), "mcgpu_probe_cross_cell")
         return x1, y1, z1, nxt, l
+
+    def probe_cross_voronoi(self, x0, y0, z0, u, v, w, cell, previous_cell):
+        n = len(cell)
+        d = np.float64
+        ins = [_a(q, d) for q in (x0, y0, z0, u, v, w)]
+        outs = [np.zeros(n, d) for _ in range(6)]
+        nxt = np.zeros(n, np.int32)
+        self._chk(self.lib.mcgpu_probe_cross_voronoi(
+            self.ctx, C.c_int(n), *[_p(q, C.c_double) for q in ins], _p(_a(cell, np.int32), C.c_int),
+            _p(_a(previous_cell, np.int32), C.c_int), *[_p(q, C.c_double) for q in outs[:3]],
+            _p(nxt, C.c_int), *[_p(q, C.c_double) for q in outs[3:]]), "mcgpu_probe_cross_voronoi")
+        return dict(x1=outs[0], y1=outs[1], z1=outs[2], next_cell=nxt, l=outs[3], l_contrib=outs[4],
+                    l_void_before=outs[5])
 
     def probe_index_cell(self, x, y, z):
         n = len(x)

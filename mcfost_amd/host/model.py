@@ -525,11 +525,15 @@ def star_cell(grid, x, y, z):
     raise NotImplementedError("star inside the gridded region")
 
 
-def build_model(cfg: DiskConfig) -> Model:
-    grid = define_cylindrical_grid(cfg)
+def build_model(cfg: DiskConfig, grid=None, rho=None) -> Model:
+    """``grid``/``rho`` given: a Voronoi grid from ``host/voronoi.py`` with its own
+    density (``build_voronoi_model``); otherwise the cylindrical grid of ``cfg``."""
+    if grid is None:
+        grid = define_cylindrical_grid(cfg)
     lam, lam_inf, lam_sup, dlam = init_lambda(cfg.n_lambda, cfg.lambda_min, cfg.lambda_max)
     tab_Temp = init_tab_temp(cfg.n_T, cfg.T_min, cfg.T_max)
-    rho = dust_density(cfg, grid)
+    if rho is None:
+        rho = dust_density(cfg, grid)
     nz_idx = np.nonzero(rho * grid["volume"] > TINY_REAL)[0]
     icell_ref = int(nz_idx[0])  # find_non_empty_cell (density.f90:2030)
     rho0 = rho[icell_ref]
@@ -562,7 +566,11 @@ def build_model(cfg: DiskConfig) -> Model:
     L_tot = 2.0 * PI * HP * C_LIGHT ** 2 * E_star_tot  # :355
 
     sx, sy, sz = cfg.star_xyz
-    stars = np.array([[sx, sy, sz, r_au, star_cell(grid, sx, sy, sz), 0]], f64)
+    if grid.get("grid_type", 1) == 3:  # Voronoi.f90:357-376: the star is a site of its own
+        ic = int(grid["star_icell"][0])
+        stars = np.array([[sx, sy, sz, r_au, ic, 0 if ic > 0 else 1]], f64)
+    else:
+        stars = np.array([[sx, sy, sz, r_au, star_cell(grid, sx, sy, sz), 0]], f64)
     CDF_E_star = np.zeros((2, cfg.n_lambda), f64)  # (lambda, 0:n_stars) Fortran order
     CDF_E_star[1, :] = 1.0
 
@@ -577,3 +585,34 @@ def build_model(cfg: DiskConfig) -> Model:
         CDF_E_star=CDF_E_star.reshape(-1), E_stars=E_stars, L_tot=L_tot, stars=stars,
         rho_dust=rho, extra=dict(icell_ref=icell_ref + 1, rho0=rho0),
     )
+
+
+def build_voronoi_model(cfg: DiskConfig, n_sites: int, seed: int = 1, box_z_over_h: float = 6.0,
+                        cut: bool = True) -> Model:
+    """BASELINE config 5 stand-in: ``n_sites`` SPH-like sites drawn from the cfg's disk,
+    tessellated in a box (``Voronoi.f90:183-640`` hands the same arrays to the loop), the
+    star added as its own site, densities from the analytic disk evaluated at the sites."""
+    from . import voronoi as V
+
+    sites = V.sample_disk_sites(cfg, n_sites, seed)
+    zlim = box_z_over_h * cfg.sclht * (cfg.rout / cfg.rref) ** cfg.exp_beta
+    zlim = max(zlim, 1.001 * float(np.abs(sites[:, 2]).max()))
+    L = 1.001 * cfg.rout
+    limits = (-L, L, -L, L, -zlim, zlim)
+    lam = init_lambda(cfg.n_lambda, cfg.lambda_min, cfg.lambda_max)[0]
+    _, r_au = star_energy(cfg, lam, *init_lambda(cfg.n_lambda, cfg.lambda_min, cfg.lambda_max)[1:3])
+    sx, sy, sz = cfg.star_xyz
+    # SPH smoothing length h = 1.2 (m/rho)^(1/3) from the analytic number density of the sites
+    rs = np.hypot(sites[:, 0], sites[:, 1])
+    Hs = cfg.sclht * (rs / cfg.rref) ** cfg.exp_beta
+    p = cfg.surf + 2.0
+    pdf_r = p * rs ** (p - 1.0) / (cfg.rout ** p - cfg.rin ** p)  # per unit r
+    dens = n_sites * pdf_r / (2 * PI * rs) * np.exp(-0.5 * (sites[:, 2] / Hs) ** 2) / (math.sqrt(2 * PI) * Hs)
+    h = 1.2 * np.cbrt(1.0 / dens)
+    grid = V.build_voronoi_grid(sites, limits, stars_xyz_r=[(sx, sy, sz, r_au)], h=h, cut=cut)
+    # equal-mass SPH particles: rho_i = (M_dust / N) / V_i; star sites carry no dust
+    nb = grid["n_cells_before_stars"]
+    rho = np.zeros(grid["n_cells"], f64)
+    rho[:nb] = (cfg.dust_mass * MSUN_TO_G / nb) / (grid["volume"][:nb] * AU_TO_CM ** 3)
+    m = build_model(cfg, grid=grid, rho=rho)
+    return m

@@ -85,6 +85,10 @@ class _Model(C.Structure):
         ("T_min", C.c_float),
         ("N_thet", C.c_int), ("N_phi", C.c_int), ("l_sym_centrale", C.c_int),
         ("l_sym_axiale", C.c_int), ("midplane_snap", C.c_int),
+        ("grid_type", C.c_int), ("v_xyz", _fp), ("v_xyz_dp", _dp), ("v_h", _dp),
+        ("v_first", _ip), ("v_last", _ip), ("v_neigh", _ip), ("v_was_cut", _up),
+        ("v_is_star_neighbour", _up), ("v_walls", _fp), ("v_cut_o_h", C.c_double),
+        ("v_wall_first", _ip), ("v_wall_cells", _ip),
     ]
 
 
@@ -123,16 +127,29 @@ class Oracle:
     def _make_struct(self, m, n_tot):
         g, cfg = m.grid, m.cfg
         s = _Model()
-        for k in ("n_rad", "nz", "n_az", "l3D", "n_cells", "ntot2", "jdim_lo", "jdim_n"):
-            setattr(s, k, int(g[k]))
-        s.r_lim_2 = self._hold(_a(g["r_lim_2"], np.float64), C.c_double)
-        s.zmax = self._hold(_a(g["zmax"], np.float64), C.c_double)
-        s.z_lim = self._hold(_a(g["z_lim"], np.float64), C.c_double)
-        s.tan_phi_lim = self._hold(_a(g["tan_phi_lim"], np.float64), C.c_double)
-        s.zmaxmax = float(g["zmaxmax"])
-        s.Rmax2 = float(g["Rmax2"])
-        for k in ("cell_map", "cell_map_i", "cell_map_j", "cell_map_k", "lexit_cell"):
-            setattr(s, k, self._hold(_a(g[k], np.int32), C.c_int))
+        s.grid_type = int(g.get("grid_type", 1))
+        if s.grid_type == 3:
+            s.n_cells, s.l3D, s.n_az = int(g["n_cells"]), 1, 1
+            s.v_xyz = self._hold(_a(g["v_xyz"], np.float32), C.c_float)
+            s.v_xyz_dp = self._hold(_a(g["v_xyz_dp"], np.float64), C.c_double)
+            s.v_h = self._hold(_a(g["v_h"], np.float64), C.c_double)
+            for k in ("v_first", "v_last", "v_neigh", "v_wall_first", "v_wall_cells"):
+                setattr(s, k, self._hold(_a(g[k], np.int32), C.c_int))
+            s.v_was_cut = self._hold(_a(g["v_was_cut"], np.uint8), C.c_ubyte)
+            s.v_is_star_neighbour = self._hold(_a(g["v_is_star_neighbour"], np.uint8), C.c_ubyte)
+            s.v_walls = self._hold(_a(g["v_walls"], np.float32), C.c_float)
+            s.v_cut_o_h = float(g["v_cut_o_h"])
+        else:
+            for k in ("n_rad", "nz", "n_az", "l3D", "n_cells", "ntot2", "jdim_lo", "jdim_n"):
+                setattr(s, k, int(g[k]))
+            s.r_lim_2 = self._hold(_a(g["r_lim_2"], np.float64), C.c_double)
+            s.zmax = self._hold(_a(g["zmax"], np.float64), C.c_double)
+            s.z_lim = self._hold(_a(g["z_lim"], np.float64), C.c_double)
+            s.tan_phi_lim = self._hold(_a(g["tan_phi_lim"], np.float64), C.c_double)
+            s.zmaxmax = float(g["zmaxmax"])
+            s.Rmax2 = float(g["Rmax2"])
+            for k in ("cell_map", "cell_map_i", "cell_map_j", "cell_map_k", "lexit_cell"):
+                setattr(s, k, self._hold(_a(g[k], np.int32), C.c_int))
         s.volume = self._hold(_a(g["volume"], np.float64), C.c_double)
         ns = m.stars.shape[0]
         stars = (_Star * ns)()
@@ -202,6 +219,53 @@ class Oracle:
         E = _a(E_abs, np.float64)
         self.lib.oracle_temp_finale(C.byref(self.cm), _p(E, C.c_double), _p(T, C.c_float))
         return T
+
+    # -- Voronoi operators ---------------------------------------------------
+    def cross_voronoi(self, x0, y0, z0, u, v, w, cell, prev):
+        n = len(cell)
+        out = {k: np.zeros(n) for k in ("x1", "y1", "z1", "l", "l_contrib", "l_void_before")}
+        nxt = np.zeros(n, np.int32)
+        f = self.lib.oracle_cross_voronoi_cell
+        f.restype = None
+        f.argtypes = [C.c_void_p] + [C.c_double] * 6 + [C.c_int, C.c_int] + [_dp] * 3 + [_ip] + [_dp] * 3
+        d = [C.c_double() for _ in range(6)]
+        nc = C.c_int()
+        mp = C.addressof(self.cm)
+        for i in range(n):
+            f(mp, x0[i], y0[i], z0[i], u[i], v[i], w[i], int(cell[i]), int(prev[i]), C.byref(d[0]),
+              C.byref(d[1]), C.byref(d[2]), C.byref(nc), C.byref(d[3]), C.byref(d[4]), C.byref(d[5]))
+            for k, q in zip(("x1", "y1", "z1", "l", "l_contrib", "l_void_before"), d):
+                out[k][i] = q.value
+            nxt[i] = nc.value
+        out["next_cell"] = nxt
+        return out
+
+    def index_cell_voronoi(self, x, y, z):
+        f = self.lib.oracle_index_cell_voronoi
+        f.restype = None
+        f.argtypes = [C.c_void_p] + [C.c_double] * 3 + [_ip]
+        out = np.zeros(len(x), np.int32)
+        ic = C.c_int()
+        mp = C.addressof(self.cm)
+        for i in range(len(x)):
+            f(mp, x[i], y[i], z[i], C.byref(ic))
+            out[i] = ic.value
+        return out
+
+    def move_to_grid_voronoi(self, x, y, z, u, v, w):
+        f = self.lib.oracle_move_to_grid_voronoi
+        f.restype = None
+        f.argtypes = [C.c_void_p] + [_dp] * 3 + [C.c_double] * 3 + [_ip, _ip]
+        n = len(x)
+        xo, yo, zo = np.array(x, float), np.array(y, float), np.array(z, float)
+        ic = np.zeros(n, np.int32); ok = np.zeros(n, np.int32)
+        mp = C.addressof(self.cm)
+        for i in range(n):
+            a, b, c_ = C.c_double(xo[i]), C.c_double(yo[i]), C.c_double(zo[i])
+            i1, i2 = C.c_int(), C.c_int()
+            f(mp, C.byref(a), C.byref(b), C.byref(c_), u[i], v[i], w[i], C.byref(i1), C.byref(i2))
+            xo[i], yo[i], zo[i], ic[i], ok[i] = a.value, b.value, c_.value, i1.value, i2.value
+        return xo, yo, zo, ic, ok
 
     # -- unit operators (batched in Python; small n only) -------------------
     def cross_cell(self, x0, y0, z0, u, v, w, cell):

@@ -551,6 +551,195 @@ void oracle_pos_em_cell_cyl(const oracle_model *m, int icell, float rand1,
 }
 
 /* ------------------------------------------------------------------------ */
+/* Voronoi grid operators (Voronoi.f90).  The plane tests are in default real  */
+/* exactly like the reference (n, p, r, k are `real` arrays, :859).             */
+/* ------------------------------------------------------------------------ */
+
+/* distance_to_wall (Voronoi.f90:1289-1317) */
+static double voro_distance_to_wall(const oracle_model *m, double x, double y,
+                                    double z, double u, double v, double w,
+                                    int iwall) {
+  const float *W = m->v_walls + 4 * (iwall - 1);
+  double n[3] = {W[0], W[1], W[2]};
+  double p[3] = {W[3] * fabs(n[0]), W[3] * fabs(n[1]), W[3] * fabs(n[2])};
+  float den = (float)(n[0] * u + n[1] * v + n[2] * w);
+  if (fabsf(den) > FLT_MIN)
+    return (n[0] * (p[0] - x) + n[1] * (p[1] - y) + n[2] * (p[2] - z)) / (double)den;
+  return (double)FLT_MAX;
+}
+
+/* distance_to_star (Voronoi.f90:1321-1375) */
+static double voro_distance_to_star(const oracle_model *m, double x, double y,
+                                    double z, double u, double v, double w,
+                                    int *i_star) {
+  double d = DBL_MAX;
+  *i_star = 0;
+  for (int i = 1; i <= m->n_stars; ++i) {
+    const oracle_star *st = &m->stars[i - 1];
+    double dx = x - st->x, dy = y - st->y, dz = z - st->z;
+    double b = dx * u + dy * v + dz * w;
+    double c = dx * dx + dy * dy + dz * dz - st->r * st->r;
+    double delta = b * b - c;
+    if (delta >= 0.) {
+      double rac = sqrt(delta), s1 = -b - rac;
+      if (s1 < 0) {
+        double s2 = -b + rac;
+        if (s2 > 0) { d = 0.0; *i_star = i; }
+      } else if (s1 < d) {
+        d = s1; *i_star = i;
+      }
+    }
+  }
+  return d;
+}
+
+/* is_in_volume (Voronoi.f90:1462-1478) */
+static int voro_is_in_volume(const oracle_model *m, double x, double y, double z) {
+  const float *W = m->v_walls;
+  return (x > W[3]) && (x < W[7]) && (y > W[11]) && (y < W[15]) && (z > W[19]) && (z < W[23]);
+}
+
+/* index_cell_voronoi (Voronoi.f90:1548-1570): brute force, default-real distances */
+void oracle_index_cell_voronoi(const oracle_model *m, double xin, double yin,
+                               double zin, int *icell) {
+  float dist2_min = FLT_MAX;
+  for (int i = 1; i <= m->n_cells; ++i) {
+    const double *c = m->v_xyz_dp + 3 * (size_t)(i - 1);
+    float dist2 = (float)((c[0] - xin) * (c[0] - xin) + (c[1] - yin) * (c[1] - yin) +
+                          (c[2] - zin) * (c[2] - zin));
+    if (dist2 < dist2_min) { *icell = i; dist2_min = dist2; }
+  }
+}
+
+/* cross_Voronoi_cell (Voronoi.f90:839-992) */
+void oracle_cross_voronoi_cell(const oracle_model *m, double x, double y,
+                               double z, double u, double v, double w,
+                               int icell, int previous_cell, double *x1,
+                               double *y1, double *z1, int *next_cell,
+                               double *s_out, double *s_contrib,
+                               double *s_void_before) {
+  const double prec = (double)1e-5f;
+  const float r[3] = {(float)x, (float)y, (float)z};
+  const float k[3] = {(float)u, (float)v, (float)w};
+  double s = (double)1e30f;
+  *next_cell = 0;
+  const double *rc_dp = m->v_xyz_dp + 3 * (size_t)(icell - 1);
+  const float r_cell[3] = {(float)rc_dp[0], (float)rc_dp[1], (float)rc_dp[2]};
+  const int ifirst = m->v_first[icell - 1], ilast = m->v_last[icell - 1];
+  const int was_cut = m->v_was_cut ? m->v_was_cut[icell - 1] : 0;
+  const double h = m->v_h[icell - 1];
+  const int star_nb = m->v_is_star_neighbour ? m->v_is_star_neighbour[icell - 1] : 0;
+
+  for (int i = ifirst; i <= ilast; ++i) {
+    const int id_n = m->v_neigh[i - 1];
+    double s_tmp;
+    if (id_n == previous_cell) continue;
+    if (id_n > 0) {
+      const float *rn = m->v_xyz + 3 * (size_t)(id_n - 1);
+      const float n[3] = {rn[0] - r_cell[0], rn[1] - r_cell[1], rn[2] - r_cell[2]};
+      /* den is real(dp) in the reference: the default-real dot product, widened */
+      const double den = (double)(n[0] * k[0] + n[1] * k[1] + n[2] * k[2]);
+      if (den <= 0.) continue;
+      const float p[3] = {0.5f * (rn[0] + r_cell[0]), 0.5f * (rn[1] + r_cell[1]), 0.5f * (rn[2] + r_cell[2])};
+      s_tmp = (double)(n[0] * (p[0] - r[0]) + n[1] * (p[1] - r[1]) + n[2] * (p[2] - r[2])) / den;
+      if (s_tmp < 0.) s_tmp = (double)FLT_MAX;
+    } else {
+      s_tmp = voro_distance_to_wall(m, x, y, z, u, v, w, -id_n);
+      if (s_tmp < 0.) s_tmp = (double)FLT_MAX;
+    }
+    if (s_tmp < s) { s = s_tmp; *next_cell = id_n; }
+  }
+  s = s * (1.0 + prec);
+  *x1 = x + u * s;
+  *y1 = y + v * s;
+  *z1 = z + w * s;
+  if (*next_cell == 0) { /* rounding error somewhere (:926-937) */
+    *x1 = x; *y1 = y; *z1 = z; s = 0.0;
+    if (voro_is_in_volume(m, x, y, z)) {
+      oracle_index_cell_voronoi(m, x, y, z, next_cell);
+      if (icell == *next_cell) *next_cell = -1;
+    } else {
+      *next_cell = -1;
+    }
+  }
+  if (was_cut) { /* :939-975 */
+    const double dr[3] = {(double)(r[0] - r_cell[0]), (double)(r[1] - r_cell[1]), (double)(r[2] - r_cell[2])};
+    const double b = dr[0] * (double)k[0] + dr[1] * (double)k[1] + dr[2] * (double)k[2];
+    const double hc = h * m->v_cut_o_h;
+    const double c = dr[0] * dr[0] + dr[1] * dr[1] + dr[2] * dr[2] - hc * hc;
+    const double delta = b * b - c;
+    if (delta < 0.) {
+      *s_void_before = s; *s_contrib = 0.0;
+    } else {
+      const double rac = sqrt(delta), s1 = -b - rac, s2 = -b + rac;
+      if (s1 < 0) {
+        if (s2 < 0) { *s_void_before = s; *s_contrib = 0.0; }
+        else { *s_void_before = 0.0; *s_contrib = fmin(s2, s); }
+      } else if (s1 < s) {
+        *s_void_before = s1; *s_contrib = fmin(s2, s) - s1;
+      } else {
+        *s_void_before = s; *s_contrib = 0.0;
+      }
+    }
+  } else {
+    *s_void_before = 0.0; *s_contrib = s;
+  }
+  if (star_nb) { /* :977-988 */
+    int i_star;
+    const double d_to_star = voro_distance_to_star(m, x, y, z, u, v, w, &i_star);
+    if (i_star > 0 && d_to_star < s) {
+      *s_contrib = d_to_star;
+      *next_cell = m->stars[i_star - 1].icell;
+    }
+  }
+  *s_out = s;
+}
+
+/* move_to_grid_Voronoi (Voronoi.f90:1379-1442) with find_Voronoi_cell_brute_force (:1485) */
+void oracle_move_to_grid_voronoi(const oracle_model *m, double *x, double *y,
+                                 double *z, double u, double v, double w,
+                                 int *icell, int *lintersect) {
+  const double prec = 1.e-6; /* module parameter (:21) */
+  double s_walls[6];
+  int order[6];
+  for (int iw = 1; iw <= 6; ++iw) {
+    double l = voro_distance_to_wall(m, *x, *y, *z, u, v, w, iw);
+    s_walls[iw - 1] = (l >= 0) ? l * (1.0 + prec) : (double)FLT_MAX;
+    order[iw - 1] = iw;
+  }
+  for (int a = 1; a < 6; ++a) /* index_quicksort: ascending */
+    for (int b = a; b > 0 && s_walls[order[b] - 1] < s_walls[order[b - 1] - 1]; --b) {
+      int t = order[b]; order[b] = order[b - 1]; order[b - 1] = t;
+    }
+  int iwall = 0;
+  double xt = 0, yt = 0, zt = 0;
+  for (int i = 0; i < 6; ++i) {
+    iwall = order[i];
+    const double l = s_walls[iwall - 1];
+    xt = *x + l * u; yt = *y + l * v; zt = *z + l * w;
+    if (voro_is_in_volume(m, xt, yt, zt)) break;
+    if (i == 5) { *icell = 0; *lintersect = 0; return; }
+  }
+  *lintersect = 1;
+  *x = xt; *y = yt; *z = zt;
+  float dist2_min = FLT_MAX;
+  int icell_min = 0;
+  for (int q = m->v_wall_first[iwall - 1]; q < m->v_wall_first[iwall]; ++q) {
+    const int ic = m->v_wall_cells[q];
+    const double *c = m->v_xyz_dp + 3 * (size_t)(ic - 1);
+    float dist2 = (float)((c[0] - xt) * (c[0] - xt) + (c[1] - yt) * (c[1] - yt) + (c[2] - zt) * (c[2] - zt));
+    if (dist2 < dist2_min) { icell_min = ic; dist2_min = dist2; }
+  }
+  *icell = icell_min;
+}
+
+/* grid operator table (grid.f90:16-22, 298-357) */
+static inline int grid_test_exit(const oracle_model *m, int icell, double x, double y, double z) {
+  if (m->grid_type == 3) return icell < 0; /* test_exit_grid_Voronoi (:1446) */
+  return oracle_test_exit_grid_cyl(m, icell, x, y, z);
+}
+
+/* ------------------------------------------------------------------------ */
 /* Direction helpers                                                         */
 /* ------------------------------------------------------------------------ */
 
@@ -801,11 +990,14 @@ static void emit_packet_uniform_sphere(const oracle_model *m, int i_star,
   *x = *x * r_star + st->x;
   *y = *y * r_star + st->y;
   *z = *z * r_star + st->z;
-  oracle_index_cell_cyl(m, *x, *y, *z, icell);
-  if (st->out_model)
-    oracle_move_to_grid_cyl(m, x, y, z, *u, *v, *w, icell, lintersect);
-  else
+  if (m->grid_type == 3) *icell = st->icell; /* stars.f90:155-156 */
+  else oracle_index_cell_cyl(m, *x, *y, *z, icell);
+  if (st->out_model) {
+    if (m->grid_type == 3) oracle_move_to_grid_voronoi(m, x, y, z, *u, *v, *w, icell, lintersect);
+    else oracle_move_to_grid_cyl(m, x, y, z, *u, *v, *w, icell, lintersect);
+  } else {
     *lintersect = 1;
+  }
 }
 
 /* ------------------------------------------------------------------------ */
@@ -890,7 +1082,7 @@ static void physical_length(worker_t *W, int lambda, const double Stokes[4],
     previous_cell = icell0;
     icell0 = next_cell;
 
-    if (oracle_test_exit_grid_cyl(m, icell0, x0, y0, z0)) {         /* :87 */
+    if (grid_test_exit(m, icell0, x0, y0, z0)) {                    /* :87 */
       *flag_sortie = 1;
       return;
     }
@@ -900,7 +1092,7 @@ static void physical_length(worker_t *W, int lambda, const double Stokes[4],
       W->cnt[ORC_CNT_KILLED_STAR]++;
       return;
     }
-    if (icell0 <= m->n_cells) {                                     /* :100 */
+    if (icell0 <= m->n_cells && icell0 >= 1) {                      /* :100 */
       lcell_not_empty = 1;
       opacity = m->kappa[lambda - 1] * m->kappa_factor[icell0 - 1];
       if (m->l_dark_zone && m->l_dark_zone[icell0 - 1]) {           /* :104 */
@@ -915,9 +1107,13 @@ static void physical_length(worker_t *W, int lambda, const double Stokes[4],
       lcell_not_empty = 0;
       opacity = 0.0;
     }
-    oracle_cross_cylindrical_cell(m, x0, y0, z0, *u, *v, *w, icell0,
-                                  previous_cell, &x1, &y1, &z1, &next_cell, &l,
-                                  &l_contrib, &l_void_before);      /* :119 */
+    if (m->grid_type == 3)
+      oracle_cross_voronoi_cell(m, x0, y0, z0, *u, *v, *w, icell0, previous_cell, &x1, &y1, &z1,
+                                &next_cell, &l, &l_contrib, &l_void_before);
+    else
+      oracle_cross_cylindrical_cell(m, x0, y0, z0, *u, *v, *w, icell0,
+                                    previous_cell, &x1, &y1, &z1, &next_cell, &l,
+                                    &l_contrib, &l_void_before);    /* :119 */
     W->cnt[ORC_CNT_CROSSINGS]++;
     tau = l_contrib * opacity;                                      /* :134 */
     if (tau > extr) {                                               /* :138 */
@@ -936,7 +1132,7 @@ static void physical_length(worker_t *W, int lambda, const double Stokes[4],
       *yio = y0 + l * (*v);
       *zio = z0 + l * (*w);
       *icell = icell0;
-      if (m->l3D) oracle_index_cell_cyl(m, *xio, *yio, *zio, icell); /* :162 */
+      if (m->l3D && m->grid_type != 3) oracle_index_cell_cyl(m, *xio, *yio, *zio, icell); /* :162 */
       return;
     }
   }
@@ -994,7 +1190,12 @@ static int emit_packet(worker_t *W, int lambda, int *icell, double *x,
     *icell = select_cellule(m, lambda, rand);
     float r1 = rng_float(&W->rng), r2 = rng_float(&W->rng),
           r3 = rng_float(&W->rng);
-    oracle_pos_em_cell_cyl(m, *icell, r1, r2, r3, x, y, z);
+    if (m->grid_type == 3) { /* pos_em_cell_voronoi (Voronoi.f90:1510-1542): the cell centre */
+      const double *c = m->v_xyz_dp + 3 * (size_t)(*icell - 1);
+      *x = c[0]; *y = c[1]; *z = c[2];
+    } else {
+      oracle_pos_em_cell_cyl(m, *icell, r1, r2, r3, x, y, z);
+    }
     random_isotropic_direction(&W->rng, u, v, w);
     Stokes[0] = 1.0; Stokes[1] = 0.0; Stokes[2] = 0.0; Stokes[3] = 0.0;
   } else {

@@ -124,6 +124,21 @@ typedef struct {
    *     (FMA or not, libm) and can leave the packet on the wrong side of the
    *     midplane for one cell.  The engine's default; see DESIGN.md. */
   int midplane_snap;
+
+  /* ---- Voronoi grid (Voronoi.f90:23-67); grid_type 3, otherwise cylindrical ---- */
+  int grid_type;
+  const float *v_xyz;      /* Voronoi_xyz(3,n_cells), default real */
+  const double *v_xyz_dp;  /* Voronoi(:)%xyz */
+  const double *v_h;       /* Voronoi(:)%h */
+  const int *v_first;      /* first_neighbour (1-based into v_neigh) */
+  const int *v_last;       /* last_neighbour */
+  const int *v_neigh;      /* neighbours_list: cell id > 0, or -iwall */
+  const unsigned char *v_was_cut;
+  const unsigned char *v_is_star_neighbour;
+  const float *v_walls;    /* 6 x (x1,x2,x3,x4) (Voronoi.f90:1275-1280) */
+  double v_cut_o_h;        /* PS%cutting_distance_o_h */
+  const int *v_wall_first; /* [7] offsets (0-based) into v_wall_cells */
+  const int *v_wall_cells; /* wall(iwall)%neighbour_list, concatenated */
 } oracle_model;
 
 /* Run options. */
@@ -168,6 +183,19 @@ void oracle_move_to_grid_cyl(const oracle_model *m, double *x, double *y,
 void oracle_pos_em_cell_cyl(const oracle_model *m, int icell, float rand1,
                             float rand2, float rand3, double *x, double *y,
                             double *z);
+
+/* Voronoi grid operators (Voronoi.f90). */
+void oracle_cross_voronoi_cell(const oracle_model *m, double x, double y,
+                               double z, double u, double v, double w,
+                               int icell, int previous_cell, double *x1,
+                               double *y1, double *z1, int *next_cell,
+                               double *s, double *s_contrib,
+                               double *s_void_before);
+void oracle_index_cell_voronoi(const oracle_model *m, double x, double y,
+                               double z, int *icell);
+void oracle_move_to_grid_voronoi(const oracle_model *m, double *x, double *y,
+                                 double *z, double u, double v, double w,
+                                 int *icell, int *lintersect);
 
 /* Direction / sampling helpers. */
 void oracle_cdapres(double cospsi, double phi, double u0, double v0, double w0,

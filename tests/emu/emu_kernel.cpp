@@ -50,6 +50,9 @@ static inline double __longlong_as_double(long long b) { double d; memcpy(&d, &b
 static inline double atomicAdd(double* p, double v) { double o = *p; *p += v; return o; }
 static inline double __dmul_rn(double a, double b) { volatile double r = a * b; return r; }
 static inline double __dadd_rn(double a, double b) { volatile double r = a + b; return r; }
+static inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }
+static inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }
+static inline float __fsub_rn(float a, float b) { volatile float r = a - b; return r; }
 using std::fabs; using std::floor; using std::sqrt; using std::log; using std::exp; using std::fmax;
 using std::fmin; using std::atan2; using std::acos; using std::cos; using std::copysign;
 
@@ -57,6 +60,7 @@ namespace mcgpu { double lds_raw[1 << 18]; }
 
 #include "../../mcfost_amd/csrc/mc_device.hip.h"
 #include "../../mcfost_amd/csrc/mc_rounds.hip.h"
+#include "../../mcfost_amd/csrc/mc_voronoi.hip.h"
 #include "../../oracle/mc_oracle.h"
 
 using namespace mcgpu;
@@ -66,19 +70,48 @@ extern "C" int emu_run_thermal(const oracle_model* m, const oracle_opts* o, cons
                                double* sed, double* n_sent, uint64_t* counters) {
   DevModel M;
   memset(&M, 0, sizeof(M));
+  const bool voro = m->grid_type == 3;
   M.n_rad = m->n_rad; M.nz = m->nz; M.n_az = m->n_az; M.l3D = m->l3D; M.n_cells = m->n_cells;
   M.r_lim_2 = m->r_lim_2; M.zmax = m->zmax; M.tan_phi_lim = m->tan_phi_lim;
   std::vector<double> ch(m->n_rad);
-  for (int i = 0; i < m->n_rad; ++i) ch[i] = m->nz >= 2 ? m->z_lim[i + m->n_rad] : m->zmax[i];
+  const double dummy = 0.0;
+  if (voro) { M.n_rad = 0; M.nz = 0; M.n_az = 0; M.l3D = 1; M.r_lim_2 = &dummy; }
+  else for (int i = 0; i < m->n_rad; ++i) ch[i] = m->nz >= 2 ? m->z_lim[i + m->n_rad] : m->zmax[i];
   M.ch = ch.data();
   M.zmaxmax = m->zmaxmax; M.Rmax2 = m->Rmax2; M.volume = m->volume;
+  // Voronoi records, as mcgpu_set_grid_voronoi + mcgpu_set_opacity build them
+  VoroGrid G;
+  memset(&G, 0, sizeof(G));
+  std::vector<VoroCell> vcell;
+  std::vector<VoroNb> vnb;
+  if (voro) {
+    vcell.resize(m->n_cells);
+    vnb.resize(m->v_last[m->n_cells - 1]);
+    for (int i = 0; i < m->n_cells; ++i) {
+      VoroCell& Cc = vcell[i];
+      Cc.x = m->v_xyz[3 * i]; Cc.y = m->v_xyz[3 * i + 1]; Cc.z = m->v_xyz[3 * i + 2];
+      Cc.first = m->v_first[i] - 1; Cc.count = m->v_last[i] - m->v_first[i] + 1;
+      Cc.flags = (m->v_was_cut && m->v_was_cut[i] ? 1 : 0) | (m->v_is_star_neighbour && m->v_is_star_neighbour[i] ? 2 : 0);
+      Cc.kf = m->kappa_factor[i];
+      for (int q = m->v_first[i] - 1; q < m->v_last[i]; ++q) {
+        const int id = m->v_neigh[q];
+        vnb[q].id = id;
+        if (id > 0) { vnb[q].x = m->v_xyz[3 * (id - 1)]; vnb[q].y = m->v_xyz[3 * (id - 1) + 1]; vnb[q].z = m->v_xyz[3 * (id - 1) + 2]; }
+        else { vnb[q].x = vnb[q].y = vnb[q].z = 0.0f; }
+      }
+    }
+    G.n_cells = m->n_cells; G.cell = vcell.data(); G.nb = vnb.data(); G.h = m->v_h; G.xyz_dp = m->v_xyz_dp;
+    G.wall_first = m->v_wall_first; G.wall_cells = m->v_wall_cells; G.cut_o_h = m->v_cut_o_h;
+    memcpy(G.walls, m->v_walls, 24 * sizeof(float));
+  }
   M.n_stars = m->n_stars;
   std::vector<double> sx(4 * m->n_stars);
   std::vector<int> sc(4 * m->n_stars);
   for (int s = 0; s < m->n_stars; ++s) {
     sx[4 * s] = m->stars[s].x; sx[4 * s + 1] = m->stars[s].y; sx[4 * s + 2] = m->stars[s].z; sx[4 * s + 3] = m->stars[s].r;
     int ic = m->stars[s].icell;
-    sc[4 * s] = m->cell_map_i[ic - 1]; sc[4 * s + 1] = m->cell_map_j[ic - 1]; sc[4 * s + 2] = m->cell_map_k[ic - 1];
+    if (voro) { sc[4 * s] = ic; sc[4 * s + 1] = 0; sc[4 * s + 2] = 0; }
+    else { sc[4 * s] = m->cell_map_i[ic - 1]; sc[4 * s + 1] = m->cell_map_j[ic - 1]; sc[4 * s + 2] = m->cell_map_k[ic - 1]; }
     sc[4 * s + 3] = m->stars[s].out_model;
   }
   M.star_xyzr = sx.data(); M.star_cell = sc.data();
@@ -116,6 +149,11 @@ extern "C" int emu_run_thermal(const oracle_model* m, const oracle_opts* o, cons
   A.counters = cnt; A.next_packet = cnt + 8; A.err = &err;
   A.resume_list = nullptr; A.resume_pool = nullptr; A.inner_iters = 8; A.flags = 0; A.flush_every = 4; A.min_active = 0;
   const bool pola = m->lsepar_pola && m->aniso_method == 1, dark = M.dark != nullptr, l3d = m->l3D != 0;
+  if (voro) {
+    if (pola) k_thermal_voro<true>(M, A, G); else k_thermal_voro<false>(M, A, G);
+    for (int q = 0; q < 8; ++q) counters[q] = cnt[q];
+    return err;
+  }
   if (getenv("MCGPU_EMU_ROUNDS")) {
     // the two-kernel engine, one emulated lane: slots are passes of that lane
     const int n_slots = (int)(o->n_packets < 48 ? (o->n_packets ? o->n_packets : 1) : 48);

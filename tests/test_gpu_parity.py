@@ -361,3 +361,101 @@ def test_abi_rejects_what_it_cannot_reproduce(small_model):
     with pytest.raises(McgpuError, match="frozen"):
         e.run_thermal(10, frozen=True)               # frozen mode without a prior
     e.close()
+
+
+# ---------------------------------------------------------------------------
+# Voronoi grid backend (mc_voronoi.hip.h)
+# ---------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def voro_model():
+    return M.build_voronoi_model(M.small(), 3000, seed=3)
+
+
+def test_voronoi_cross_cell_probe_bit_exact(voro_model):
+    """cross_Voronoi_cell on the device vs the oracle: same next cell, and -- because the
+    plane tests are kept in unfused default real and the position update unfused FP64 --
+    the same lengths and end points to the last bit."""
+    m = voro_model
+    g = m.grid
+    e, o = _engine(m, 1e4), _oracle(m, 1e4)
+    rng = np.random.default_rng(5)
+    n = 4000
+    cells = rng.integers(1, g["n_cells"] + 1, n).astype(np.int32)
+    x = g["v_xyz_dp"][cells - 1] * (1 + 1e-3 * rng.standard_normal((n, 3)))
+    d = rng.standard_normal((n, 3))
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    prev = np.zeros(n, np.int32)
+    # half of the probes come with a previous cell: one of the cell's own neighbours
+    for i in range(0, n, 2):
+        nb = g["v_neigh"][g["v_first"][cells[i] - 1] - 1:g["v_last"][cells[i] - 1]]
+        prev[i] = nb[rng.integers(0, nb.size)]
+    a = e.probe_cross_voronoi(x[:, 0], x[:, 1], x[:, 2], d[:, 0], d[:, 1], d[:, 2], cells, prev)
+    b = o.cross_voronoi(x[:, 0], x[:, 1], x[:, 2], d[:, 0], d[:, 1], d[:, 2], cells, prev)
+    assert np.array_equal(a["next_cell"], b["next_cell"])
+    for k in ("l", "l_contrib", "l_void_before", "x1", "y1", "z1"):
+        assert np.array_equal(a[k], b[k]), k
+    e.close()
+
+
+def test_frozen_parity_voronoi(voro_model):
+    a, b = _frozen_parity(voro_model, 20000, seed=31, rtol=1e-7)
+    assert a["counters"]["killed_star"] == b["counters"]["killed_star"]
+    assert voro_model.grid["v_was_cut"].sum() > 0
+
+
+def test_frozen_parity_voronoi_unpolarised_star_outside_box():
+    cfg = M.small(lsepar_pola=False)
+    cfg.star_xyz = (0.0, 0.0, 400.0)
+    m = M.build_voronoi_model(cfg, 1500, seed=5)
+    assert m.stars[0, 5] == 1
+    a, b = _frozen_parity(m, 20000, seed=32, rtol=1e-7)
+    assert a["counters"]["escaped"] == 20000  # packets that miss the box are binned directly
+
+
+def test_voronoi_launch_geometry_independence(voro_model):
+    m = voro_model
+    e, o = _engine(m, 1e4), _oracle(m, 1e4)
+    prior = o.run_thermal(2000, seed=1)["E_abs"]
+    ref = e.run_thermal(10000, seed=9, frozen=True, E_prior=prior)
+    for gb, bt in ((1, 64), (7, 128), (300, 256)):
+        r = e.run_thermal(10000, seed=9, frozen=True, E_prior=prior, grid_blocks=gb, block_threads=bt)
+        assert r["counters"] == ref["counters"]
+        assert np.array_equal(r["sed"][4], ref["sed"][4])
+        assert np.allclose(r["E_abs"], ref["E_abs"], rtol=1e-10, atol=1e-12 * ref["E_abs"].max())
+    e.close()
+
+
+def test_voronoi_live_statistical_parity(voro_model):
+    """Live immediate re-emission on the Voronoi grid: device vs oracle, independent noise."""
+    m = voro_model
+    n = 1_000_000
+    e, o = _engine(m, n), _oracle(m, n)
+    a = e.run_thermal(n, seed=41)
+    b = o.run_thermal(n, seed=42, n_threads=8)
+    ca, cb = a["counters"], b["counters"]
+    assert ca["packets"] == n and ca["escaped"] + ca["killed_star"] == n
+    for k in ("crossings", "flights", "scatterings", "absorptions"):
+        assert abs(ca[k] / cb[k] - 1) < 0.05, k
+    Ta, Tb = e.temp_finale(a["E_abs"]), o.temp_finale(b["E_abs"])
+    # cells that absorbed enough packets to have a defined temperature: the top half by energy
+    well = (Tb > 1.01 * m.cfg.T_min) & (b["E_abs"] > np.median(b["E_abs"]))
+    assert well.sum() > 1000
+    ok, p75 = mc_similar(Tb[well], Ta[well], 0.05)
+    assert ok, p75
+    sa, sb = a["sed"][0].sum(axis=(0, 1)), b["sed"][0].sum(axis=(0, 1))
+    okS, p75S = mc_similar(sb, sa, 0.10, mask_threshold=200.0)
+    assert okS, p75S
+    e.close()
+
+
+def test_voronoi_abi_errors(voro_model):
+    import ctypes as C
+    from mcfost_amd.engine import McgpuError
+    e = _engine(voro_model, 1e4)
+    with pytest.raises(McgpuError):  # cylindrical probes refuse a Voronoi context
+        e.probe_index_cell(np.zeros(1), np.zeros(1), np.zeros(1))
+    e.close()
+    m = M.build_voronoi_model(M.small(lsepar_pola=False), 300, seed=8)
+    m.l_dark_zone = np.ones(m.n_cells, np.uint8)
+    with pytest.raises(McgpuError):  # no dark zone on Voronoi grids (dust_transfer.f90:290-293)
+        _engine(m, 1e4)

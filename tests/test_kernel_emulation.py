@@ -22,11 +22,12 @@ SRC = os.path.join(HERE, "emu", "emu_kernel.cpp")
 LIB = os.path.join(HERE, "emu", "libemu_kernel.so")
 DEV = os.path.join(os.path.dirname(HERE), "mcfost_amd", "csrc", "mc_device.hip.h")
 DEV2 = os.path.join(os.path.dirname(HERE), "mcfost_amd", "csrc", "mc_rounds.hip.h")
+DEV3 = os.path.join(os.path.dirname(HERE), "mcfost_amd", "csrc", "mc_voronoi.hip.h")
 
 
 @pytest.fixture(scope="module")
 def emu():
-    if (not os.path.exists(LIB)) or os.path.getmtime(LIB) < max(os.path.getmtime(SRC), os.path.getmtime(DEV), os.path.getmtime(DEV2)):
+    if (not os.path.exists(LIB)) or os.path.getmtime(LIB) < max(os.path.getmtime(SRC), os.path.getmtime(DEV), os.path.getmtime(DEV2), os.path.getmtime(DEV3)):
         fma = ["-mfma"] if "fma" in open("/proc/cpuinfo").read() else []
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=fast"] + fma +
                               ["-o", LIB, SRC])
@@ -131,3 +132,29 @@ def test_axisymmetric_3d_reproduces_2d_packet_for_packet():
     assert np.array_equal(Oracle(m2, n).run_thermal(1000, seed=3, frozen=True, E_prior=prior2)["sed"][4],
                           Oracle(m3, n).run_thermal(1000, seed=3, frozen=True, E_prior=prior3)["sed"][4])
     assert cl["flights"] < 0.97 * c2["flights"]          # the literal arithmetic is measurably off
+
+
+def test_emulated_kernel_voronoi(emu):
+    """Voronoi backend (mc_voronoi.hip.h) against the oracle's restatement of Voronoi.f90:
+    identical event counts, packet-for-packet, with cut cells and the star site."""
+    m = M.build_voronoi_model(M.small(), 1500, seed=3)
+    assert m.grid["v_was_cut"].sum() > 0 and m.grid["v_is_star_neighbour"].sum() > 0
+    check(emu, m, 4000, 21, rtol=1e-7)
+
+
+def test_emulated_kernel_voronoi_star_outside_and_disk_emission(emu):
+    """move_to_grid_Voronoi (star outside the box) and pos_em_cell_voronoi (cell-centre emission)."""
+    cfg = M.small(lsepar_pola=False)
+    cfg.star_xyz = (0.0, 0.0, 400.0)
+    m = M.build_voronoi_model(cfg, 800, seed=5)
+    assert m.stars[0, 5] == 1 and m.stars[0, 4] == 0
+    check(emu, m, 3000, 22, rtol=1e-7)
+    m = M.build_voronoi_model(M.small(lsepar_pola=False), 800, seed=6)
+    rng = np.random.default_rng(0)
+    E_cell = rng.random((m.n_lambda, m.n_cells)) * m.kappa_factor[None, :]
+    pe = np.zeros((m.n_lambda, m.n_cells + 1))
+    pe[:, 1:] = np.cumsum(E_cell, axis=1)
+    pe /= pe[:, -1:]
+    m.prob_E_cell = pe.reshape(-1)
+    m.frac_E_stars = np.full(m.n_lambda, 0.4)
+    check(emu, m, 3000, 23, rtol=1e-6)

@@ -1,0 +1,167 @@
+"""The oracle's restatement of the Voronoi grid operators (Voronoi.f90) checked against
+geometry that does not depend on it: a crossing must end in the cell whose site is nearest,
+stay inside the current cell until then, and the tessellation the harness builds must tile
+the box.  Voronoi.f90 itself cannot be compiled here (it needs the generated `os`/`sha`
+modules, sprng and voro++), so these properties -- not reference outputs -- pin the
+restatement: parity for this row is UNPINNED against the reference."""
+import numpy as np
+import pytest
+
+from mcfost_amd.host import model as M
+from oracle import Oracle
+
+
+@pytest.fixture(scope="module")
+def vmodel():
+    return M.build_voronoi_model(M.small(), 1200, seed=11)
+
+
+@pytest.fixture(scope="module")
+def vorc(vmodel):
+    return Oracle(vmodel, 1000)
+
+
+def nearest(g, p):
+    d = ((g["v_xyz_dp"] - p[None, :]) ** 2).sum(axis=1)
+    return int(np.argmin(d)) + 1
+
+
+def test_tessellation_tiles_the_box(vmodel):
+    g = vmodel.grid
+    lim = g["limits"]
+    box = (lim[1] - lim[0]) * (lim[3] - lim[2]) * (lim[5] - lim[4])
+    assert abs(g["volume"].sum() / box - 1) < 1e-9
+    # neighbour relation is symmetric, star site is the last cell, every wall has cells
+    nb = [set(g["v_neigh"][g["v_first"][i] - 1:g["v_last"][i]]) for i in range(g["n_cells"])]
+    for i in range(g["n_cells"]):
+        for j in nb[i]:
+            if j > 0:
+                assert (i + 1) in nb[j - 1]
+    assert int(vmodel.stars[0, 4]) == g["n_cells"]
+    assert vmodel.kappa_factor[-1] == 0.0
+    assert np.all(np.diff(g["v_wall_first"]) > 0)
+    # a cell lists wall w exactly when it is in wall w's list
+    for iw in range(1, 7):
+        cells = set(g["v_wall_cells"][g["v_wall_first"][iw - 1]:g["v_wall_first"][iw]])
+        assert cells == {i + 1 for i in range(g["n_cells"]) if -iw in nb[i]}
+    # equal-mass particles: rho * V constant
+    mass = vmodel.rho_dust[:-1] * g["volume"][:-1]
+    assert np.allclose(mass, mass[0], rtol=1e-12)
+
+
+def test_cross_voronoi_cell_lands_in_the_nearest_site_cell(vmodel, vorc):
+    g = vmodel.grid
+    rng = np.random.default_rng(1)
+    n = 400
+    cells = rng.integers(1, g["n_cells"], n)  # not the star site
+    nocut = g["v_was_cut"][cells - 1] == 0
+    x = g["v_xyz_dp"][cells - 1] * (1 + 1e-3 * rng.standard_normal((n, 3)))
+    ok = np.array([nearest(g, x[i]) == cells[i] for i in range(n)])
+    d = rng.standard_normal((n, 3))
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    r = vorc.cross_voronoi(x[:, 0], x[:, 1], x[:, 2], d[:, 0], d[:, 1], d[:, 2], cells, np.zeros(n, int))
+    checked = 0
+    for i in np.nonzero(ok)[0]:
+        if g["v_is_star_neighbour"][cells[i] - 1]:
+            continue
+        s = r["l"][i]
+        p1 = np.array([r["x1"][i], r["y1"][i], r["z1"][i]])
+        assert np.allclose(p1, x[i] + s * d[i], rtol=0, atol=1e-12 * (1 + abs(s)))
+        mid = x[i] + 0.5 * s * d[i]
+        assert nearest(g, mid) == cells[i]
+        nxt = r["next_cell"][i]
+        if nxt > 0:
+            assert nearest(g, p1) == nxt
+        else:  # a wall: the end point is (just) outside the box on that side
+            iw = -nxt
+            ax, sg = (iw - 1) // 2, (1 if iw % 2 == 0 else -1)
+            assert sg * (p1[ax] - g["limits"][iw - 1]) > 0
+        if nocut[i]:
+            assert r["l_contrib"][i] == s and r["l_void_before"][i] == 0
+        else:
+            assert 0 <= r["l_contrib"][i] <= s and 0 <= r["l_void_before"][i] <= s
+            assert r["l_void_before"][i] + r["l_contrib"][i] <= s * (1 + 1e-12)
+        checked += 1
+    assert checked > 300
+
+
+def test_cut_cell_sphere(vmodel, vorc):
+    """was_cut: only the chord inside the sphere of radius h*cutting_distance_o_h counts."""
+    g = vmodel.grid
+    cut = np.nonzero(g["v_was_cut"])[0]
+    assert cut.size > 0
+    rng = np.random.default_rng(2)
+    for ic in cut[:50]:
+        c = g["v_xyz_dp"][ic]
+        d = rng.standard_normal(3)
+        d /= np.linalg.norm(d)
+        r = vorc.cross_voronoi([c[0]], [c[1]], [c[2]], [d[0]], [d[1]], [d[2]], [ic + 1], [0])
+        R = g["v_h"][ic] * g["v_cut_o_h"]
+        # from the site: inside the sphere at once, leaves it after R (or the cell ends first)
+        assert r["l_void_before"][0] == 0
+        assert np.isclose(r["l_contrib"][0], min(R, r["l"][0]), rtol=1e-6)
+
+
+def test_star_neighbour_override(vmodel, vorc):
+    """A ray from a star-neighbour cell towards the star stops at the stellar surface and
+    continues in the star's own cell (Voronoi.f90:977-988)."""
+    g = vmodel.grid
+    sx, sy, sz, sr, sic, _ = vmodel.stars[0]
+    nbs = np.nonzero(g["v_is_star_neighbour"])[0]
+    assert nbs.size > 0
+    for ic in nbs:
+        c = g["v_xyz_dp"][ic]
+        d = np.array([sx, sy, sz]) - c
+        dist = np.linalg.norm(d)
+        d /= dist
+        r = vorc.cross_voronoi([c[0]], [c[1]], [c[2]], [d[0]], [d[1]], [d[2]], [ic + 1], [0])
+        if r["next_cell"][0] == int(sic):
+            assert np.isclose(r["l_contrib"][0], dist - sr, rtol=1e-9) or g["v_was_cut"][ic]
+
+
+def test_move_to_grid_voronoi(vmodel, vorc):
+    g = vmodel.grid
+    lim = g["limits"]
+    rng = np.random.default_rng(3)
+    n = 60
+    target = np.stack([rng.uniform(0.5 * lim[0], 0.5 * lim[1], n), rng.uniform(0.5 * lim[2], 0.5 * lim[3], n),
+                       rng.uniform(0.5 * lim[4], 0.5 * lim[5], n)], axis=1)
+    start = target + rng.standard_normal((n, 3)) * 4 * max(lim[1], lim[5])
+    outside = (np.abs(start[:, 0]) > lim[1]) | (np.abs(start[:, 1]) > lim[3]) | (np.abs(start[:, 2]) > lim[5])
+    d = target - start
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    x, y, z, ic, ok = vorc.move_to_grid_voronoi(start[:, 0], start[:, 1], start[:, 2], d[:, 0], d[:, 1], d[:, 2])
+    assert outside.sum() > 30
+    for i in np.nonzero(outside)[0]:
+        assert ok[i] == 1
+        p = np.array([x[i], y[i], z[i]])
+        assert lim[0] < p[0] < lim[1] and lim[2] < p[1] < lim[3] and lim[4] < p[2] < lim[5]
+        # on (just inside) a wall, in the nearest wall-adjacent cell
+        rel = min(abs(p[0] - lim[0]), abs(p[0] - lim[1]), abs(p[1] - lim[2]), abs(p[1] - lim[3]),
+                  abs(p[2] - lim[4]), abs(p[2] - lim[5]))
+        assert rel < 1e-3 * lim[1]
+        assert ic[i] == nearest(g, p)
+    # a ray that misses the box
+    x, y, z, ic, ok = vorc.move_to_grid_voronoi([10 * lim[1]], [0.0], [0.0], [0.0], [1.0], [0.0])
+    assert ok[0] == 0 and ic[0] == 0
+
+
+def test_index_cell_voronoi(vmodel, vorc):
+    g = vmodel.grid
+    rng = np.random.default_rng(4)
+    lim = g["limits"]
+    p = np.stack([rng.uniform(lim[0], lim[1], 100), rng.uniform(lim[2], lim[3], 100),
+                  rng.uniform(lim[4], lim[5], 100)], axis=1)
+    ic = vorc.index_cell_voronoi(p[:, 0], p[:, 1], p[:, 2])
+    assert all(ic[i] == nearest(g, p[i]) for i in range(100))
+
+
+def test_voronoi_thermal_run_conserves_packets(vmodel):
+    orc = Oracle(vmodel, 5000)
+    r = orc.run_thermal(5000, seed=3, n_threads=4)
+    c = r["counters"]
+    assert c["packets"] == 5000 and c["escaped"] + c["killed_star"] == 5000
+    assert r["sed"][4].sum() == c["escaped"]
+    assert c["crossings"] > c["flights"] > c["absorptions"] > 0
+    T = orc.temp_finale(r["E_abs"])
+    assert T[:-1].max() < 1500 and T[:-1].min() >= 1.0
