@@ -39,6 +39,33 @@ constexpr double HUGE_REAL = 3.40282346638528859812e+38;  // huge(1.0)
 constexpr double HUGE_DP = 1.79769313486231570815e+308;
 constexpr double TINY_DP = 2.22507385850720138309e-308;
 
+// Products and sums that must NOT be contracted into FMA (hipcc's default -ffp-contract=
+// fast-honor-pragmas fuses a*b+c everywhere else, and HIP's __fmul_rn/nd_add are plain
+// operators that get fused too): used where the reference's unfused default-real / FP64
+// arithmetic decides a discrete outcome, so that the CPU oracle reproduces it bit for bit.
+#ifndef MCGPU_LANE_EMULATION
+__device__ __forceinline__ float nf_mul(float a, float b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+__device__ __forceinline__ float nf_add(float a, float b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
+__device__ __forceinline__ float nf_sub(float a, float b) {
+#pragma clang fp contract(off)
+  return a - b;
+}
+__device__ __forceinline__ double nd_mul(double a, double b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+__device__ __forceinline__ double nd_add(double a, double b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
+#endif
+
 struct DevModel {
   // grid
   int n_rad, nz, n_az, l3D, n_cells;
@@ -494,7 +521,7 @@ __device__ inline void cross_cell(const Lds& T, const DevModel& M, double x0, do
     // z1 comes out as exactly 0 (-> sign(grid_prec,w), :1158-1165) or as a
     // rounding residue of either sign is decided by the rounding of t*w.
     // The reference build (no FMA contraction) rounds the product first.
-    z1 = __dadd_rn(z0, __dmul_rn(t, w));
+    z1 = nd_add(z0, nd_mul(t, w));
     if (L3D && M.midplane_snap && (delta_zj == 2 || delta_zj == -2)) z1 = copysign(GRID_PREC, w);
     ri1 = ri0;
     zj1 = zj0 + delta_zj;
@@ -620,7 +647,7 @@ __device__ inline void cross_cell_lean(const Lds& T, const DevModel& M, double x
   x1 = x0 + dv * u;
   y1 = y0 + dv * v;
   // products rounded before the sum, like the reference build (see cross_cell above)
-  z1 = __dadd_rn(z0, __dmul_rn(dv, w));
+  z1 = nd_add(z0, nd_mul(dv, w));
   ri1 = rad ? ri0 + delta_rad : ri0;
   k1 = k0;
   if (rad) {

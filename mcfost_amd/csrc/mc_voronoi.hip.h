@@ -18,6 +18,13 @@
 //     paid for with 16 B x nnz of HBM: 250 MB per million cells).
 //   * the plane tests are done in default real exactly like the reference (:859), with the
 //     products and sums left unfused so that the CPU oracle reproduces them bit for bit.
+//   * absorbed energy: the grid (8 B x n_cells) does not fit a CU's LDS, but the deposits are
+//     extremely concentrated (every packet starts in the handful of cells around the star), and
+//     same-address global_atomic_add_f64 serialise in L2: measured 8x slower than no deposits at
+//     all.  Each workgroup therefore keeps a hashed DEPOSIT CACHE in LDS (tag + FP64 sum per
+//     slot, slots claimed first-come and then fixed for the launch): hits are ds_add_f64, misses
+//     go straight to HBM, and the waves fold rotating slices of the cache into HBM without a
+//     workgroup barrier, exactly like the 2D kernel's private grid.
 #pragma once
 #include "mc_device.hip.h"
 
@@ -55,7 +62,7 @@ constexpr float FLT_HUGE = 3.40282346638528859812e+38f;
 
 // default-real dot product, evaluated left to right without contraction
 __device__ inline float dot3f(float a0, float a1, float a2, float b0, float b1, float b2) {
-  return __fadd_rn(__fadd_rn(__fmul_rn(a0, b0), __fmul_rn(a1, b1)), __fmul_rn(a2, b2));
+  return nf_add(nf_add(nf_mul(a0, b0), nf_mul(a1, b1)), nf_mul(a2, b2));
 }
 
 // distance_to_wall (Voronoi.f90:1289-1317)
@@ -64,9 +71,9 @@ __device__ inline double voro_distance_to_wall(const VoroGrid& G, double x, doub
   const float* W = G.walls + 4 * (iwall - 1);
   const double n0 = W[0], n1 = W[1], n2 = W[2];
   const double p0 = (double)W[3] * fabs(n0), p1 = (double)W[3] * fabs(n1), p2 = (double)W[3] * fabs(n2);
-  const float den = (float)__dadd_rn(__dadd_rn(__dmul_rn(n0, u), __dmul_rn(n1, v)), __dmul_rn(n2, w));
+  const float den = (float)nd_add(nd_add(nd_mul(n0, u), nd_mul(n1, v)), nd_mul(n2, w));
   if (fabsf(den) > FLT_TINY) {
-    const double num = __dadd_rn(__dadd_rn(__dmul_rn(n0, p0 - x), __dmul_rn(n1, p1 - y)), __dmul_rn(n2, p2 - z));
+    const double num = nd_add(nd_add(nd_mul(n0, p0 - x), nd_mul(n1, p1 - y)), nd_mul(n2, p2 - z));
     return num / (double)den;
   }
   return (double)FLT_HUGE;
@@ -80,10 +87,10 @@ __device__ inline double voro_distance_to_star(const DevModel& M, double x, doub
   for (int i = 1; i <= M.n_stars; ++i) {
     const double* s4 = &M.star_xyzr[4 * (i - 1)];
     const double dx = x - s4[0], dy = y - s4[1], dz = z - s4[2];
-    const double b = __dadd_rn(__dadd_rn(__dmul_rn(dx, u), __dmul_rn(dy, v)), __dmul_rn(dz, w));
-    const double c = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz)),
-                               -__dmul_rn(s4[3], s4[3]));
-    const double delta = __dadd_rn(__dmul_rn(b, b), -c);
+    const double b = nd_add(nd_add(nd_mul(dx, u), nd_mul(dy, v)), nd_mul(dz, w));
+    const double c = nd_add(nd_add(nd_add(nd_mul(dx, dx), nd_mul(dy, dy)), nd_mul(dz, dz)),
+                               -nd_mul(s4[3], s4[3]));
+    const double delta = nd_add(nd_mul(b, b), -c);
     if (delta >= 0.0) {
       const double rac = sqrt(delta), s1 = -b - rac;
       if (s1 < 0) {
@@ -105,7 +112,7 @@ __device__ inline bool voro_is_in_volume(const VoroGrid& G, double x, double y, 
 
 __device__ inline float voro_dist2f(const double* c, double x, double y, double z) {
   const double dx = c[0] - x, dy = c[1] - y, dz = c[2] - z;
-  return (float)__dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
+  return (float)nd_add(nd_add(nd_mul(dx, dx), nd_mul(dy, dy)), nd_mul(dz, dz));
 }
 
 // index_cell_voronoi (Voronoi.f90:1548-1570): brute force with default-real distances
@@ -136,12 +143,12 @@ __device__ inline void voro_cross_cell(const VoroGrid& G, const DevModel& M, con
     if (N.id == previous_cell) continue;
     double s_tmp;
     if (N.id > 0) {
-      const float n0 = __fsub_rn(N.x, C.x), n1 = __fsub_rn(N.y, C.y), n2 = __fsub_rn(N.z, C.z);
+      const float n0 = nf_sub(N.x, C.x), n1 = nf_sub(N.y, C.y), n2 = nf_sub(N.z, C.z);
       const double den = (double)dot3f(n0, n1, n2, k0, k1, k2);
       if (den <= 0.0) continue;
-      const float p0 = __fmul_rn(0.5f, __fadd_rn(N.x, C.x)), p1 = __fmul_rn(0.5f, __fadd_rn(N.y, C.y)),
-                  p2 = __fmul_rn(0.5f, __fadd_rn(N.z, C.z));
-      s_tmp = (double)dot3f(n0, n1, n2, __fsub_rn(p0, r0), __fsub_rn(p1, r1), __fsub_rn(p2, r2)) / den;
+      const float p0 = nf_mul(0.5f, nf_add(N.x, C.x)), p1 = nf_mul(0.5f, nf_add(N.y, C.y)),
+                  p2 = nf_mul(0.5f, nf_add(N.z, C.z));
+      s_tmp = (double)dot3f(n0, n1, n2, nf_sub(p0, r0), nf_sub(p1, r1), nf_sub(p2, r2)) / den;
       if (s_tmp < 0.0) s_tmp = (double)FLT_HUGE;
     } else {
       s_tmp = voro_distance_to_wall(G, x, y, z, u, v, w, -N.id);
@@ -149,10 +156,10 @@ __device__ inline void voro_cross_cell(const VoroGrid& G, const DevModel& M, con
     }
     if (s_tmp < s) { s = s_tmp; next_cell = N.id; }
   }
-  s = __dmul_rn(s, 1.0 + (double)1e-5f);
-  x1 = __dadd_rn(x, __dmul_rn(u, s));
-  y1 = __dadd_rn(y, __dmul_rn(v, s));
-  z1 = __dadd_rn(z, __dmul_rn(w, s));
+  s = nd_mul(s, 1.0 + (double)1e-5f);
+  x1 = nd_add(x, nd_mul(u, s));
+  y1 = nd_add(y, nd_mul(v, s));
+  z1 = nd_add(z, nd_mul(w, s));
   if (next_cell == 0) {  // rounding error somewhere (:926-937)
     x1 = x; y1 = y; z1 = z; s = 0.0;
     if (voro_is_in_volume(G, x, y, z)) {
@@ -163,12 +170,12 @@ __device__ inline void voro_cross_cell(const VoroGrid& G, const DevModel& M, con
     }
   }
   if (C.flags & 1) {  // cut cell: only the sphere of radius h*cutting_distance_o_h holds matter (:939-975)
-    const double d0 = (double)__fsub_rn(r0, C.x), d1 = (double)__fsub_rn(r1, C.y), d2 = (double)__fsub_rn(r2, C.z);
-    const double b = __dadd_rn(__dadd_rn(__dmul_rn(d0, (double)k0), __dmul_rn(d1, (double)k1)), __dmul_rn(d2, (double)k2));
-    const double hc = __dmul_rn(G.h[icell - 1], G.cut_o_h);
-    const double c = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(d0, d0), __dmul_rn(d1, d1)), __dmul_rn(d2, d2)),
-                               -__dmul_rn(hc, hc));
-    const double delta = __dadd_rn(__dmul_rn(b, b), -c);
+    const double d0 = (double)nf_sub(r0, C.x), d1 = (double)nf_sub(r1, C.y), d2 = (double)nf_sub(r2, C.z);
+    const double b = nd_add(nd_add(nd_mul(d0, (double)k0), nd_mul(d1, (double)k1)), nd_mul(d2, (double)k2));
+    const double hc = nd_mul(G.h[icell - 1], G.cut_o_h);
+    const double c = nd_add(nd_add(nd_add(nd_mul(d0, d0), nd_mul(d1, d1)), nd_mul(d2, d2)),
+                               -nd_mul(hc, hc));
+    const double delta = nd_add(nd_mul(b, b), -c);
     if (delta < 0.0) {
       s_void_before = s; s_contrib = 0.0;
     } else {
@@ -203,7 +210,7 @@ __device__ inline bool voro_move_to_grid(const VoroGrid& G, double& x, double& y
   int order[6];
   for (int iw = 1; iw <= 6; ++iw) {
     const double l = voro_distance_to_wall(G, x, y, z, u, v, w, iw);
-    s_walls[iw - 1] = (l >= 0) ? __dmul_rn(l, 1.0 + 1.e-6) : (double)FLT_HUGE;
+    s_walls[iw - 1] = (l >= 0) ? nd_mul(l, 1.0 + 1.e-6) : (double)FLT_HUGE;
     order[iw - 1] = iw;
   }
   for (int a = 1; a < 6; ++a)
@@ -216,7 +223,7 @@ __device__ inline bool voro_move_to_grid(const VoroGrid& G, double& x, double& y
   for (int i = 0; i < 6 && !found; ++i) {
     iwall = order[i];
     const double l = s_walls[iwall - 1];
-    xt = __dadd_rn(x, __dmul_rn(l, u)); yt = __dadd_rn(y, __dmul_rn(l, v)); zt = __dadd_rn(z, __dmul_rn(l, w));
+    xt = nd_add(x, nd_mul(l, u)); yt = nd_add(y, nd_mul(l, v)); zt = nd_add(z, nd_mul(l, w));
     found = voro_is_in_volume(G, xt, yt, zt);
   }
   if (!found) { icell = 0; return false; }
@@ -233,14 +240,49 @@ __device__ inline bool voro_move_to_grid(const VoroGrid& G, double& x, double& y
 }
 
 // ---------------------------------------------------------------------------
-// The thermal packet kernel on a Voronoi grid: deposits go to HBM (global_atomic_add_f64), the
-// grid does not fit a CU's LDS.
+// Deposit cache: 2^log_ns slots of (cell id, partial sum) in LDS
 // ---------------------------------------------------------------------------
-template <bool POLA>
+struct DepCache {
+  double* val;
+  int* tag;  // 0 = free, else the 1-based cell id that owns the slot for the whole launch
+  int log_ns;
+  __device__ inline int slot_of(int icell) const { return (int)(((unsigned)icell * 2654435761u) >> (32 - log_ns)); }
+  // returns true when the deposit went to the cache
+  __device__ inline bool add(int icell, double v) const {
+    const int sl = slot_of(icell);
+    int t = tag[sl];
+    if (t == 0) {
+      t = atomicCAS(&tag[sl], 0, icell);
+      if (t == 0) t = icell;
+    }
+    if (t != icell) return false;
+    atomic_add_f64(&val[sl], v);
+    return true;
+  }
+  // this workgroup's not yet folded part of a cell's energy
+  __device__ inline double pending(int icell) const {
+    const int sl = slot_of(icell);
+    return tag[sl] == icell ? val[sl] : 0.0;
+  }
+};
+
+constexpr int VORO_CACHE_BLOCK = 1024;  // most threads of a cached-deposit workgroup (one per CU)
+
+// ---------------------------------------------------------------------------
+// The thermal packet kernel on a Voronoi grid.  CACHE: deposits go through the workgroup's LDS
+// deposit cache; otherwise straight to HBM (global_atomic_add_f64).
+// ---------------------------------------------------------------------------
+template <bool POLA, bool CACHE>
 __device__ __forceinline__ void thermal_body_voro(const DevModel& M, const RunArgs& A, const VoroGrid& G,
-                                                  double* lds_base) {
+                                                  double* lds_base, int cache_log_ns) {
   const Lds T = lds_carve(lds_base, M);
   lds_stage(T, M);
+  DepCache DC;
+  DC.log_ns = cache_log_ns;
+  DC.val = lds_base + (lds_bytes(M) + sizeof(double) - 1) / sizeof(double);
+  DC.tag = reinterpret_cast<int*>(DC.val + ((size_t)1 << cache_log_ns));
+  if (CACHE)
+    for (int i = threadIdx.x; i < (1 << cache_log_ns); i += blockDim.x) { DC.val[i] = 0.0; DC.tag[i] = 0; }
   __syncthreads();
   const int lane = threadIdx.x & 63;
 
@@ -257,7 +299,7 @@ __device__ __forceinline__ void thermal_body_voro(const DevModel& M, const RunAr
   unsigned long long pk_next = 0, pk_end = 0;
   float tau_rand = 0.0f;
 
-  for (;;) {
+  for (int ep = 0;; ++ep) {
     if (st == S_EXITED) {
       capteur<POLA>(M, A.sed, lambda, u, v, w, S, flag_star, flag_scatt);
       c_esc++;
@@ -325,7 +367,11 @@ __device__ __forceinline__ void thermal_body_voro(const DevModel& M, const RunAr
       const int ic = icell - 1;
       interact<POLA>(T, M, g, lambda, u, v, w, u1, v1, w1, S, flag_star, flag_scatt, c_scatt, c_abs, [&]() {
         if (A.frozen) return A.E_prior[ic];
-        return __hip_atomic_load(&A.E_abs[ic], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * A.qscale;
+        // what every workgroup has put into HBM so far + this workgroup's pending part standing
+        // in for the others' (the reference's partial * nb_proc, thermal_emission.f90:670)
+        double E = __hip_atomic_load(&A.E_abs[ic], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (CACHE) E += DC.pending(ic + 1) * (double)gridDim.x;
+        return E * A.qscale;
       }, M.volume + ic);
       u = u1; v = v1; w = w1;
       st = S_NEWFLIGHT;
@@ -372,21 +418,48 @@ __device__ __forceinline__ void thermal_body_voro(const DevModel& M, const RunAr
             const double lc = l_contrib * (extr / tau);
             const double ls = l_void + lc;
             const double dE = T.kabs[lambda - 1] * lc * S[0];
-            if (dE != 0.0 && !(A.flags & 1)) atomic_add_f64(&A.E_abs[icell - 1], dE);
-            x = __dadd_rn(x, __dmul_rn(ls, u));
-            y = __dadd_rn(y, __dmul_rn(ls, v));
-            z = __dadd_rn(z, __dmul_rn(ls, w));
+            if (dE != 0.0 && !(A.flags & 1)) {
+              if (!(CACHE && DC.add(icell, dE))) atomic_add_f64(&A.E_abs[icell - 1], dE);
+            }
+            x = nd_add(x, nd_mul(ls, u));
+            y = nd_add(y, nd_mul(ls, v));
+            z = nd_add(z, nd_mul(ls, w));
             st = S_INTERACT;
           } else {
             extr = extr - tau;
             const double dE = T.kabs[lambda - 1] * l_contrib * S[0];
-            if (dE != 0.0 && !(A.flags & 1)) atomic_add_f64(&A.E_abs[icell - 1], dE);
+            if (dE != 0.0 && !(A.flags & 1)) {
+              if (!(CACHE && DC.add(icell, dE))) atomic_add_f64(&A.E_abs[icell - 1], dE);
+            }
             x = x1; y = y1; z = z1;
             prev_cell = icell;
             icell = next;
           }
         }
       }
+    }
+    // barrier-free partial fold of the deposit cache (see thermal_body): a slot's owner never
+    // changes, so swapping its sum to zero and adding it to the owner's HBM cell is race-free
+    if (CACHE && ((ep + 1) % A.flush_every) == 0) {
+      const int n_waves = (blockDim.x + 63) >> 6, wave = threadIdx.x >> 6;
+      const int slice = (wave + (ep + 1) / A.flush_every) % n_waves;
+      const int ns = 1 << cache_log_ns, per = (ns + n_waves - 1) / n_waves;
+      const int i0 = slice * per, i1 = (i0 + per < ns) ? i0 + per : ns;
+      for (int i = i0 + lane; i < i1; i += 64) {
+        const int t = DC.tag[i];
+        if (t == 0) continue;
+        const unsigned long long bits = atomicExch(reinterpret_cast<unsigned long long*>(&DC.val[i]), 0ull);
+        const double e = __longlong_as_double((long long)bits);
+        if (e != 0.0) atomic_add_f64(&A.E_abs[t - 1], e);
+      }
+    }
+  }
+
+  if (CACHE) {  // final fold
+    __syncthreads();
+    for (int i = threadIdx.x; i < (1 << cache_log_ns); i += blockDim.x) {
+      const double e = DC.val[i];
+      if (e != 0.0) atomic_add_f64(&A.E_abs[DC.tag[i] - 1], e);
     }
   }
 
@@ -402,7 +475,15 @@ __device__ __forceinline__ void thermal_body_voro(const DevModel& M, const RunAr
 template <bool POLA>
 __global__ void __launch_bounds__(256) k_thermal_voro(const DevModel M, const RunArgs A, const VoroGrid G) {
   extern __shared__ double lds_raw[];
-  thermal_body_voro<POLA>(M, A, G, lds_raw);
+  thermal_body_voro<POLA, false>(M, A, G, lds_raw, 0);
+}
+
+// BLOCK = 1024: 4 waves/SIMD at <= 128 VGPRs; BLOCK = 512: 2 waves/SIMD at <= 256 VGPRs
+template <bool POLA, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) k_thermal_voro_cache(const DevModel M, const RunArgs A,
+                                                              const VoroGrid G, int cache_log_ns) {
+  extern __shared__ double lds_raw[];
+  thermal_body_voro<POLA, true>(M, A, G, lds_raw, cache_log_ns);
 }
 
 // probe: one cross_Voronoi_cell per thread (tests)

@@ -508,14 +508,31 @@ static int launch_mega(mcgpu_ctx* ctx, const RunArgs& A, bool use_lds, int grid_
   return MCGPU_OK;
 }
 
-// the Voronoi-grid kernel (mc_voronoi.hip.h): HBM deposits, 256-thread workgroups
+// the Voronoi-grid kernel (mc_voronoi.hip.h).  Default: one 1024-thread workgroup per CU with a
+// hashed deposit cache in the LDS left over by the tables; MCGPU_DEPOSIT=hbm: 256-thread
+// workgroups depositing straight to HBM.
 static int launch_voro(mcgpu_ctx* ctx, const RunArgs& A, int grid_blocks, int block_threads) {
   const DevModel& M = ctx->M;
-  const size_t lds = lds_bytes(M);
-  const int threads = (block_threads > 0 && block_threads <= 256) ? block_threads : 256;
+  const size_t lds_t = (lds_bytes(M) + 7) / 8 * 8;
+  const size_t lds_cap = 160 * 1024;
+  bool cache = true;
+  if (const char* e = getenv("MCGPU_DEPOSIT")) if (!strcmp(e, "hbm")) cache = false;
+  int log_ns = 0;
+  if (cache) {
+    log_ns = 13;  // 8192 slots = 96 KB
+    if (const char* e = getenv("MCGPU_CACHE_LOG_SLOTS")) { int v = atoi(e); if (v >= 6 && v <= 13) log_ns = v; }
+    while (log_ns > 6 && lds_t + ((size_t)12 << log_ns) > lds_cap) --log_ns;
+    if (lds_t + ((size_t)12 << log_ns) > lds_cap) cache = false;
+  }
+  const size_t lds = cache ? lds_t + ((size_t)12 << log_ns) : lds_t;
+  const int max_threads = cache ? VORO_CACHE_BLOCK : 256;
+  const int threads = (block_threads > 0 && block_threads <= max_threads) ? block_threads : max_threads;
   if (threads % 64) return fail(ctx, MCGPU_ERR_ARG, "block_threads must be a multiple of 64");
   const bool pola = ctx->lsepar_pola != 0;
-  const void* fn = pola ? (const void*)k_thermal_voro<true> : (const void*)k_thermal_voro<false>;
+  const bool big = threads > 512;  // which register budget the workgroup was compiled for
+  const void* fn = cache ? (big ? (pola ? (const void*)k_thermal_voro_cache<true, 1024> : (const void*)k_thermal_voro_cache<false, 1024>)
+                                : (pola ? (const void*)k_thermal_voro_cache<true, 512> : (const void*)k_thermal_voro_cache<false, 512>))
+                         : (pola ? (const void*)k_thermal_voro<true> : (const void*)k_thermal_voro<false>);
   HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int blocks = grid_blocks;
   if (blocks <= 0) {
@@ -526,8 +543,16 @@ static int launch_voro(mcgpu_ctx* ctx, const RunArgs& A, int grid_blocks, int bl
     const unsigned long long need = (A.n_packets + threads - 1) / threads;
     if ((unsigned long long)blocks > need) blocks = (int)(need ? need : 1);
   }
-  if (pola) hipLaunchKernelGGL(k_thermal_voro<true>, dim3(blocks), dim3(threads), lds, ctx->stream, M, A, ctx->V);
-  else hipLaunchKernelGGL(k_thermal_voro<false>, dim3(blocks), dim3(threads), lds, ctx->stream, M, A, ctx->V);
+  if (cache && big) {
+    if (pola) hipLaunchKernelGGL((k_thermal_voro_cache<true, 1024>), dim3(blocks), dim3(threads), lds, ctx->stream, M, A, ctx->V, log_ns);
+    else hipLaunchKernelGGL((k_thermal_voro_cache<false, 1024>), dim3(blocks), dim3(threads), lds, ctx->stream, M, A, ctx->V, log_ns);
+  } else if (cache) {
+    if (pola) hipLaunchKernelGGL((k_thermal_voro_cache<true, 512>), dim3(blocks), dim3(threads), lds, ctx->stream, M, A, ctx->V, log_ns);
+    else hipLaunchKernelGGL((k_thermal_voro_cache<false, 512>), dim3(blocks), dim3(threads), lds, ctx->stream, M, A, ctx->V, log_ns);
+  } else {
+    if (pola) hipLaunchKernelGGL(k_thermal_voro<true>, dim3(blocks), dim3(threads), lds, ctx->stream, M, A, ctx->V);
+    else hipLaunchKernelGGL(k_thermal_voro<false>, dim3(blocks), dim3(threads), lds, ctx->stream, M, A, ctx->V);
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     ctx->err = std::string("kernel launch: ") + hipGetErrorString(e);

@@ -46,13 +46,16 @@ static inline void unsafeAtomicAdd(double* p, double v) {
 static inline void __syncthreads() {}
 static inline int __syncthreads_or(int p) { return p; }
 static inline unsigned long long atomicExch(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p = v; return o; }
+static inline int atomicCAS(int* p, int cmp, int v) { int o = *p; if (o == cmp) *p = v; return o; }
 static inline double __longlong_as_double(long long b) { double d; memcpy(&d, &b, 8); return d; }
 static inline double atomicAdd(double* p, double v) { double o = *p; *p += v; return o; }
-static inline double __dmul_rn(double a, double b) { volatile double r = a * b; return r; }
-static inline double __dadd_rn(double a, double b) { volatile double r = a + b; return r; }
-static inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }
-static inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }
-static inline float __fsub_rn(float a, float b) { volatile float r = a - b; return r; }
+namespace mcgpu {  // the device source's unfused helpers (mc_device.hip.h), for the host compiler
+static inline double nd_mul(double a, double b) { volatile double r = a * b; return r; }
+static inline double nd_add(double a, double b) { volatile double r = a + b; return r; }
+static inline float nf_mul(float a, float b) { volatile float r = a * b; return r; }
+static inline float nf_add(float a, float b) { volatile float r = a + b; return r; }
+static inline float nf_sub(float a, float b) { volatile float r = a - b; return r; }
+}  // namespace mcgpu
 using std::fabs; using std::floor; using std::sqrt; using std::log; using std::exp; using std::fmax;
 using std::fmin; using std::atan2; using std::acos; using std::cos; using std::copysign;
 
@@ -150,7 +153,11 @@ extern "C" int emu_run_thermal(const oracle_model* m, const oracle_opts* o, cons
   A.resume_list = nullptr; A.resume_pool = nullptr; A.inner_iters = 8; A.flags = 0; A.flush_every = 4; A.min_active = 0;
   const bool pola = m->lsepar_pola && m->aniso_method == 1, dark = M.dark != nullptr, l3d = m->l3D != 0;
   if (voro) {
-    if (pola) k_thermal_voro<true>(M, A, G); else k_thermal_voro<false>(M, A, G);
+    if (getenv("MCGPU_EMU_LDS")) {  // deposit cache, few slots so that hits, misses and folds all occur
+      if (pola) k_thermal_voro_cache<true, 512>(M, A, G, 6); else k_thermal_voro_cache<false, 512>(M, A, G, 6);
+    } else {
+      if (pola) k_thermal_voro<true>(M, A, G); else k_thermal_voro<false>(M, A, G);
+    }
     for (int q = 0; q < 8; ++q) counters[q] = cnt[q];
     return err;
   }

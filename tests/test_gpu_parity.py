@@ -459,3 +459,24 @@ def test_voronoi_abi_errors(voro_model):
     m.l_dark_zone = np.ones(m.n_cells, np.uint8)
     with pytest.raises(McgpuError):  # no dark zone on Voronoi grids (dust_transfer.f90:290-293)
         _engine(m, 1e4)
+
+
+def test_voronoi_deposit_paths_agree(voro_model, monkeypatch):
+    """LDS deposit cache (default; 1024- and 512-thread workgroups, tiny cache that must miss)
+    vs plain HBM atomics: same packets, same sums."""
+    m = voro_model
+    e, o = _engine(m, 1e4), _oracle(m, 1e4)
+    prior = o.run_thermal(2000, seed=1)["E_abs"]
+    ref = o.run_thermal(30000, seed=13, frozen=True, E_prior=prior, n_threads=8)
+    runs = []
+    runs.append(e.run_thermal(30000, seed=13, frozen=True, E_prior=prior))
+    runs.append(e.run_thermal(30000, seed=13, frozen=True, E_prior=prior, block_threads=512))
+    monkeypatch.setenv("MCGPU_CACHE_LOG_SLOTS", "6")
+    runs.append(e.run_thermal(30000, seed=13, frozen=True, E_prior=prior))
+    monkeypatch.delenv("MCGPU_CACHE_LOG_SLOTS")
+    monkeypatch.setenv("MCGPU_DEPOSIT", "hbm")
+    runs.append(e.run_thermal(30000, seed=13, frozen=True, E_prior=prior))
+    for r in runs:
+        assert r["counters"] == ref["counters"]
+        assert np.allclose(r["E_abs"], ref["E_abs"], rtol=1e-7, atol=1e-12 * ref["E_abs"].max())
+    e.close()

@@ -140,6 +140,11 @@ def test_emulated_kernel_voronoi(emu):
     m = M.build_voronoi_model(M.small(), 1500, seed=3)
     assert m.grid["v_was_cut"].sum() > 0 and m.grid["v_is_star_neighbour"].sum() > 0
     check(emu, m, 4000, 21, rtol=1e-7)
+    os.environ["MCGPU_EMU_LDS"] = "1"  # the same through the LDS deposit cache (64 slots here)
+    try:
+        check(emu, m, 4000, 21, rtol=1e-7)
+    finally:
+        del os.environ["MCGPU_EMU_LDS"]
 
 
 def test_emulated_kernel_voronoi_star_outside_and_disk_emission(emu):
