@@ -66,6 +66,24 @@ module mcgpu_f
        integer(c_int), intent(in) :: cell_map(*), cell_map_i(*), cell_map_j(*), cell_map_k(*), lexit_cell(*)
      end function mcgpu_set_grid_cyl
 
+     ! Voronoi grid (Voronoi.f90:23-67): pass Voronoi_xyz, Voronoi(:)%xyz packed (3,n), Voronoi(:)%h,
+     ! %first_neighbour, %last_neighbour, neighbours_list, the two logical flags as int8 copies,
+     ! wall(:)%x1..x4 packed (4,6), PS%cutting_distance_o_h, the wall neighbour lists and volume
+     integer(c_int) function mcgpu_set_grid_voronoi(ctx, n_cells, voronoi_xyz, xyz_dp, h, first_neighbour, &
+          last_neighbour, neighbours_list, n_neighbours, was_cut, is_star_neighbour, walls, &
+          cutting_distance_o_h, wall_first, wall_cells, volume) bind(C, name="mcgpu_set_grid_voronoi")
+       import :: c_int, c_ptr, c_double, c_float, c_long_long, c_int8_t
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: n_cells
+       real(c_float), intent(in) :: voronoi_xyz(*), walls(*)
+       real(c_double), intent(in) :: xyz_dp(*), h(*), volume(*)
+       integer(c_int), intent(in) :: first_neighbour(*), last_neighbour(*), neighbours_list(*)
+       integer(c_long_long), value :: n_neighbours
+       integer(c_int8_t), intent(in) :: was_cut(*), is_star_neighbour(*)
+       real(c_double), value :: cutting_distance_o_h
+       integer(c_int), intent(in) :: wall_first(*), wall_cells(*)
+     end function mcgpu_set_grid_voronoi
+
      integer(c_int) function mcgpu_set_midplane_snap(ctx, on) bind(C, name="mcgpu_set_midplane_snap")
        import :: c_int, c_ptr
        type(c_ptr), value :: ctx
