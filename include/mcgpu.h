@@ -224,6 +224,64 @@ int mcgpu_fetch(mcgpu_ctx *ctx, double *E_abs, double *sed, double *n_sent,
 /* Use an external stream (e.g. torch's current stream); NULL = own stream. */
 int mcgpu_set_stream(mcgpu_ctx *ctx, void *hip_stream);
 
+/* ------------------------------------------------------------------------
+ * SED mode: one wavelength of run_sed_mc (dust_transfer.f90:828-1042), i.e.
+ * mc_photon_loop (:439-572) with lmono = .true., lmono0 = .false.:
+ * monochromatic packets, forced scattering (:1263-1278), ray-tracing method 1
+ * deposits xI_scatt (radiation_field.f90:63-89, dust_ray_tracing.f90:409-632)
+ * and capteur into the SED arrays.  Cylindrical grids.
+ * ------------------------------------------------------------------------ */
+
+/*
+ * Ray-tracing method 1 tables (module dust_ray_tracing):
+ *   tab_u_rt, tab_v_rt (RT_n_incl, RT_n_az), tab_w_rt[RT_n_incl]   (:18-19, :234-300)
+ *   n_az_rt, n_theta_rt   layout of xI_scatt: 45, 2 in 2D; 1, 1 in 3D (:91-98)
+ *   N_type_flux           8 / 4 / 5 / 1 (init_mcfost.f90:1603-1616)
+ *   tab_s11_pos(0:nang_scatt, 1, n_lambda_pos)                      (grains.f90:63)
+ * Call after mcgpu_set_scattering.
+ */
+int mcgpu_set_rt1(mcgpu_ctx *ctx, int RT_n_incl, int RT_n_az,
+                  const double *tab_u_rt, const double *tab_v_rt,
+                  const double *tab_w_rt, int n_az_rt, int n_theta_rt,
+                  int N_type_flux, int lsepar_contrib, const float *tab_s11_pos,
+                  int n_lambda_pos);
+
+typedef struct {
+  uint64_t seed;
+  int lambda;           /* 1-based wavelength index                                */
+  int p_lambda;         /* index into the phase-function tables (run_sed_mc :899-909) */
+  int n_chunks;         /* n_photons_loop: independent sequential streams (:525)   */
+  uint64_t n_photons2;  /* n_photons_lambda: packets each stream must see binned in
+                           inclination bin capt_sup before it stops (:526, :551)   */
+  double n_phot_lim;    /* n_photons_lim: cap on the packets a stream sends (:526) */
+  int capt_sup;         /* read_param.f90:184                                      */
+  int rt1;              /* lscatt_ray_tracing1: accumulate xI_scatt                */
+  int accumulate;       /* 0: zero sed / n_sent / counters / xI_scatt first        */
+  int grid_blocks, block_threads; /* 0 = automatic                                  */
+} mcgpu_mono_opts;
+
+/*
+ * Replaces `call mc_photon_loop(lambda, p_lambda, n_photons2, n_phot_lim, 1, .false.)`
+ * at dust_transfer.f90:939.  frac_E_stars / frac_E_disk / prob_E_cell(0:n_cells) are the
+ * wavelength's entries as left by repartition_energie(lambda) (:924,
+ * thermal_emission.f90:1771-1949); prob_E_cell may be NULL when frac_E_stars = 1.
+ * A stream's packets are id (stream << 40 | sequence) of the random generator; each stream
+ * stops EXACTLY where the reference's sequential loop would: a first pass without deposits
+ * finds the stopping index, a second pass replays the packets before it with deposits.
+ * n_sent_chunk[n_chunks] (may be NULL) returns the packets each stream sent; their sum is
+ * what the call added to n_sent(lambda) = n_phot_envoyes(lambda,:).  sed, n_sent and the
+ * counters are read back with mcgpu_fetch, xI_scatt with mcgpu_fetch_xI.
+ */
+int mcgpu_run_mono(mcgpu_ctx *ctx, const mcgpu_mono_opts *opts,
+                   double frac_E_stars, double frac_E_disk,
+                   const double *prob_E_cell, uint64_t *n_sent_chunk,
+                   double *kernel_ms);
+
+/* xI_scatt(n_az_rt, n_theta_rt, N_type_flux, RT_n_incl*RT_n_az, n_cells) summed over what the
+ * reference keeps per thread (dust_ray_tracing.f90:33,152): default real like the reference's
+ * array and/or the FP64 sums the engine accumulates.  Either pointer may be NULL. */
+int mcgpu_fetch_xI(mcgpu_ctx *ctx, float *xI_scatt_f32, double *xI_scatt_f64);
+
 /* Temp_finale (thermal_emission.f90:870-906): Tdust(icell) from the summed
  * absorbed-energy grid.  E_abs == NULL uses the device accumulator. */
 int mcgpu_temp_finale(mcgpu_ctx *ctx, const double *E_abs, float *Tdust);

@@ -38,6 +38,9 @@ constexpr double TINY_REAL = 1.17549435082228750797e-38;  // tiny(0.0)
 constexpr double HUGE_REAL = 3.40282346638528859812e+38;  // huge(1.0)
 constexpr double HUGE_DP = 1.79769313486231570815e+308;
 constexpr double TINY_DP = 2.22507385850720138309e-308;
+constexpr float FLT_TINY = 1.17549435082228750797e-38f;
+constexpr float FLT_HUGE = 3.40282346638528859812e+38f;
+constexpr float FLT_TINY_X1E6 = 1.17549435082228750797e-38f * 1.0e6f;  // tiny_real_x1e6 (constants.f90:156)
 
 // Products and sums that must NOT be contracted into FMA (hipcc's default -ffp-contract=
 // fast-honor-pragmas fuses a*b+c everywhere else, and HIP's __fmul_rn/nd_add are plain
@@ -893,17 +896,20 @@ enum : int { S_EMIT = 0, S_INTERACT = 1, S_NEWFLIGHT = 2, S_FLIGHT = 3, S_DONE =
 constexpr unsigned long long PK_BATCH = 128;  // packet ids reserved per wave and global atomic
 
 // capteur, SED branch (output.f90:294-397,572-592)
-template <bool POLA>
-__device__ inline void capteur(const DevModel& M, double* sed, int lambda, double u1, double v1,
-                               double w1, const double S[4], bool flag_star, bool flag_scatt) {
+// WEIGHTED: the packet carries a weight in S[0] even when Q,U,V are not tracked (SED mode).
+// sed == nullptr: only determine the inclination bin.  Returns capt (0: packet not binned).
+template <bool POLA, bool WEIGHTED = false>
+__device__ inline int capteur(const DevModel& M, double* sed, int lambda, double u1, double v1,
+                              double w1, const double S[4], bool flag_star, bool flag_scatt) {
   double s2 = POLA ? S[2] : 0.0;
   if (w1 < 0.0) {
-    if (!M.sym_c) return;
+    if (!M.sym_c) return 0;
     u1 = -u1; v1 = -v1; w1 = -w1;
     s2 = -s2;
   }
   int capt = (int)((-1.0 * w1 + 1.0) * (double)M.N_thet) + 1;
   if (capt == M.N_thet + 1) capt = M.N_thet;
+  if (!sed) return capt;
   int c_phi = 1;
   if (M.sym_a) {
     if (v1 < 0.0) { v1 = -v1; s2 = -s2; }
@@ -916,7 +922,7 @@ __device__ inline void capteur(const DevModel& M, double* sed, int lambda, doubl
   else if (c_phi == 0) c_phi = 1;
   const size_t plane = (size_t)M.n_lambda * M.N_thet * M.N_phi;
   const size_t idx = (size_t)(lambda - 1) + (size_t)M.n_lambda * ((capt - 1) + (size_t)M.N_thet * (c_phi - 1));
-  const double I = POLA ? S[0] : 1.0;
+  const double I = (POLA || WEIGHTED) ? S[0] : 1.0;
   atomic_add_f64(&sed[0 * plane + idx], I);
   if (POLA) {
     atomic_add_f64(&sed[1 * plane + idx], S[1]);
@@ -926,6 +932,7 @@ __device__ inline void capteur(const DevModel& M, double* sed, int lambda, doubl
   atomic_add_f64(&sed[4 * plane + idx], 1.0);
   const int tp = flag_star ? (flag_scatt ? 6 : 5) : (flag_scatt ? 8 : 7);
   atomic_add_f64(&sed[tp * plane + idx], I);
+  return capt;
 }
 
 // ---------------------------------------------------------------------------
@@ -953,15 +960,17 @@ __device__ inline int select_star(const DevModel& M, int lambda, float rand) {
   return kmax;
 }
 
-// select_cellule (thermal_emission.f90:2044-2073)
-__device__ inline int select_cellule(const DevModel& M, int lambda, float rand) {
-  const double* p = M.prob_E_cell + (size_t)(M.n_cells + 1) * (lambda - 1);
-  int kmin = 0, kmax = M.n_cells, kk = (kmin + kmax) / 2;
+// select_cellule (thermal_emission.f90:2044-2073); p = prob_E_cell(0:n_cells, lambda)
+__device__ inline int select_cellule(const double* p, int n_cells, float rand) {
+  int kmin = 0, kmax = n_cells, kk = (kmin + kmax) / 2;
   while ((kmax - kmin) > 1) {
     if (p[kk] < (double)rand) kmin = kk; else kmax = kk;
     kk = (kmin + kmax) / 2;
   }
   return kmax;
+}
+__device__ inline int select_cellule(const DevModel& M, int lambda, float rand) {
+  return select_cellule(M.prob_E_cell + (size_t)(M.n_cells + 1) * (lambda - 1), M.n_cells, rand);
 }
 
 // emit_packet_uniform_sphere (stars.f90:108-169), up to the cell lookup
@@ -1000,13 +1009,16 @@ __device__ inline void random_isotropic_direction(float r1, float r2, double& u,
 // immediate re-emission (new wavelength from the cell's temperature, isotropic direction).
 // g = the event's draws (see Rng); cell_energy() returns the cell's absorbed energy scaled like
 // the reference's partial sum * nb_proc, and is evaluated for absorptions only.
+// forced (SED mode, :1263-1278): always a scattering; p_lambda_scatt > 0 overrides the wavelength
+// index of the phase-function CDF (the caller's p_lambda).
 template <bool POLA, typename EnergyFn>
 __device__ __forceinline__ void interact(const Lds& T, const DevModel& M, const float g[8], int& lambda,
                                          double u, double v, double w, double& u1, double& v1, double& w1,
                                          double S[4], bool& flag_star, bool& flag_scatt,
                                          unsigned int& c_scatt, unsigned int& c_abs, EnergyFn cell_energy,
-                                         const double* volume_of_cell) {
-  const bool scat = g[0] < T.albedo[lambda - 1];  // dust_transfer.f90:1284
+                                         const double* volume_of_cell, bool forced = false,
+                                         const float* prob_forced = nullptr) {
+  const bool scat = forced || (g[0] < T.albedo[lambda - 1]);  // dust_transfer.f90:1284
   const float rand = g[1], rand2 = g[2];
   int itheta = 1;
   double cospsi, phi;
@@ -1015,7 +1027,8 @@ __device__ __forceinline__ void interact(const Lds& T, const DevModel& M, const 
     c_scatt++;
     if (M.aniso_method == 1) {
       // angle_diff_theta_pos (scattering.f90:1433-1475)
-      const float* prob = T.prob + (M.p_lambda_fixed ? 0 : (size_t)(M.nang + 1) * (lambda - 1));
+      const float* prob = prob_forced ? prob_forced
+                                      : T.prob + (M.p_lambda_fixed ? 0 : (size_t)(M.nang + 1) * (lambda - 1));
       int kmin = 0, kmax = M.nang, kk = (kmin + kmax) / 2;
       while ((kmax - kmin) > 1) {
         if (prob[kk] < rand) kmin = kk; else kmax = kk;

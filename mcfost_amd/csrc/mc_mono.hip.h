@@ -1,0 +1,472 @@
+// SED-mode packet loop: one wavelength of run_sed_mc
+// (dust_transfer.f90:828-1042), i.e. mc_photon_loop with lmono and not lmono0 (:439-572):
+//   * fixed wavelength, emission split star / disk by frac_E_stars(lambda), prob_E_cell(:,lambda)
+//     (repartition_energie, thermal_emission.f90:1771-1949, stays on the host);
+//   * forced scattering: Stokes *= albedo at every interaction, packet dropped below
+//     tiny_real*1e6 or in a dark-zone cell (dust_transfer.f90:1263-1278);
+//   * ray-tracing method 1 deposits: per flight the scattering angle towards every observer
+//     (angles_scatt_rt1, dust_ray_tracing.f90:409-476), per cell crossing
+//     xI_scatt(phik,psup,:,iRT,icell) += l * (RPO.M.ROP.Stokes) (calc_xI_scatt[_pola] :480-632
+//     from save_radiation_field, radiation_field.f90:63-89);
+//   * capteur into the SED arrays (output.f90:294-397, 572-592).
+//
+// The reference runs n_photons_loop sequential streams, each until n_photons2 packets landed in
+// inclination bin capt_sup (or n_phot_lim were sent).  Here a SCOUT pass transports batches of
+// every stream's packets without deposits and records which of them land in capt_sup; a scan
+// gives each stream's exact stopping index K; the COMMIT pass then runs exactly the packets
+// s < K of every stream with deposits.  Counter-based random numbers (stream c, sequence s ->
+// id (c << 40) | s) make the second pass replay the first exactly.
+//
+// xI_scatt is accumulated in FP64 (global_atomic_add_f64) in the reference's index order and
+// converted to default real when fetched.
+#pragma once
+#include "mc_device.hip.h"
+
+namespace mcgpu {
+
+struct MonoArgs {
+  uint64_t seed;
+  int lambda, p_lambda, capt_sup, rt1;
+  double frac_E_stars, frac_E_disk;
+  const double* prob_E_cell;  // (0:n_cells) at this wavelength, or null
+  // work items
+  unsigned long long n_items;
+  const unsigned long long* item_base;  // COMMIT: [n_chunks+1] prefix sums of K
+  int n_chunks;
+  const int* active;                    // SCOUT: streams still running
+  const unsigned long long* seq0;       // SCOUT: [n_chunks] first sequence number of this batch
+  unsigned long long batch;             // SCOUT: packets per stream in this batch
+  unsigned char* hits;                  // SCOUT: [n_active * batch] 1 = binned in capt_sup
+  // ray tracing method 1
+  int RT_n_incl, nRT;                   // nRT = RT_n_incl * RT_n_az
+  const double* rt_u;                   // [nRT] tab_u_rt(ibin,iaz), q = ibin-1 + RT_n_incl*(iaz-1)
+  const double* rt_v;
+  const double* rt_w;                   // [RT_n_incl]
+  int n_az_rt, n_theta_rt, N_type_flux, contrib;
+  const float* s11;                     // tab_s11_pos(0:nang, p_lambda)
+  double* xI;                           // (n_az_rt, n_theta_rt, N_type_flux, nRT, n_cells)
+  // accumulators
+  double* sed;
+  double* n_sent;
+  unsigned long long* counters;
+  unsigned long long* next_item;
+  int* err;
+  int inner_iters, min_active;
+};
+
+// per-lane results of angles_scatt_rt1, kept in LDS as [q][thread]
+struct RtScratch {
+  int* itheta;
+  double* cosw;
+  double* sinw;
+};
+
+__host__ __device__ inline size_t mono_lds_bytes(const DevModel& M, int nRT, int threads, bool pola) {
+  size_t b = (lds_bytes(M) + 7) / 8 * 8;
+  b += (size_t)6 * (M.nang + 1) * sizeof(float);                     // the Mueller columns of p_lambda
+  b = (b + 7) / 8 * 8;
+  b += (size_t)nRT * threads * (pola ? 2 * sizeof(double) : 0);      // cosw, sinw
+  b += (size_t)nRT * threads * sizeof(int);                          // itheta
+  return b;
+}
+
+// angles_scatt_rt1 (dust_ray_tracing.f90:409-476) for this lane's direction
+template <bool POLA>
+__device__ inline void angles_scatt_rt1(const DevModel& M, const MonoArgs& A, const RtScratch& R, double u,
+                                        double v, double w) {
+  for (int q = 0; q < A.nRT; ++q) {
+    const double ur = A.rt_u[q], vr = A.rt_v[q], wr = A.rt_w[q % A.RT_n_incl];
+    const float cos_scatt = (float)nd_add(nd_add(nd_mul(ur, u), nd_mul(vr, v)), nd_mul(wr, w));
+    const float ac = (float)acos((double)cos_scatt);  // the correctly rounded default-real acos
+    int k;
+    if (ac != ac) k = 1;
+    else k = (int)llrint(floor(nf_mul(ac, (float)M.nang) / PI + 0.5));  // nint()
+    if (k > M.nang) k = M.nang;
+    if (k < 1) k = 1;
+    R.itheta[q * blockDim.x + threadIdx.x] = k;
+    if (POLA) {
+      double v1pi, v1pj, v1pk;
+      rotation(u, v, w, -ur, -vr, -wr, v1pi, v1pj, v1pk);
+      double xnyp = sqrt(v1pk * v1pk + v1pj * v1pj), costhet;
+      if (xnyp < 1e-10) { xnyp = 0.0; costhet = 1.0; }
+      else costhet = -1.0 * v1pj / xnyp;
+      double theta = acos(costhet);
+      if (theta >= PI) theta = 0.0;
+      theta = theta + PI / 2;
+      double omega = 2.0 * theta;
+      if (v1pk < 0.0) omega = -1.0 * omega;
+      double sinw, cosw;
+      sincos(omega, &sinw, &cosw);
+      if (fabs(cosw) < 1e-06) cosw = 0.0;
+      if (fabs(sinw) < 1e-06) sinw = 0.0;
+      R.cosw[q * blockDim.x + threadIdx.x] = cosw;
+      R.sinw[q * blockDim.x + threadIdx.x] = sinw;
+    }
+  }
+}
+
+// save_radiation_field, lscatt_ray_tracing1 branch (radiation_field.f90:63-89) with calc_xI_scatt
+// (dust_ray_tracing.f90:480-529) / calc_xI_scatt_pola (:533-632).  mu = the six Mueller columns
+// [s11 | s12/s11 | s22/s11 | s33/s11 | s34/s11 | s44/s11] of p_lambda in LDS.
+template <bool L3D, bool POLA>
+__device__ inline void deposit_rt1(const DevModel& M, const MonoArgs& A, const RtScratch& R, const float* mu,
+                                   int icell, const double S[4], double l, double x0, double y0, double z0,
+                                   double x1, double y1, double z1, bool flag_star) {
+  int phik = 1, psup = 1;
+  if (!L3D) {
+    const double xm = 0.5 * (x0 + x1), ym = 0.5 * (y0 + y1), zm = 0.5 * (z0 + z1);
+    const double phi_pos = atan2(xm, ym);
+    phik = (int)floor(modulo_d(phi_pos, 2 * PI) / (2 * PI) * (double)A.n_az_rt) + 1;
+    if (phik > A.n_az_rt) phik = A.n_az_rt;
+    psup = (zm > 0.0) ? 1 : 2;
+  }
+  const size_t st_type = (size_t)A.n_az_rt * A.n_theta_rt;
+  const size_t st_rt = st_type * A.N_type_flux;
+  double* base = A.xI + (size_t)(phik - 1) + (size_t)A.n_az_rt * (psup - 1) + st_rt * A.nRT * (size_t)(icell - 1);
+  const int na1 = M.nang + 1;
+  for (int q = 0; q < A.nRT; ++q) {
+    const int it = R.itheta[q * blockDim.x + threadIdx.x];
+    const float s11 = mu[it];
+    double* p = base + st_rt * q;
+    if (!POLA) {
+      const double flux = l * S[0] * (double)s11;
+      atomic_add_f64(p, flux);
+      if (A.contrib) atomic_add_f64(p + st_type * (flag_star ? 2 : 4), flux);  // n_Stokes + 2 / + 4, n_Stokes = 1
+      continue;
+    }
+    const float s12 = -s11 * mu[na1 + it], s22 = s11 * mu[2 * na1 + it], s33 = -s11 * mu[3 * na1 + it];
+    const float s34 = -s11 * mu[4 * na1 + it], s44 = -s11 * mu[5 * na1 + it];
+    const double cosw = R.cosw[q * blockDim.x + threadIdx.x], sinw = R.sinw[q * blockDim.x + threadIdx.x];
+    const double C1 = S[0], C4 = S[3];
+    const double C2 = cosw * S[1] + (-sinw) * S[2];
+    const double C3 = sinw * S[1] + cosw * S[2];
+    const double D1 = (double)s11 * C1 + (double)s12 * C2;
+    const double D2 = (double)s12 * C1 + (double)s22 * C2;
+    const double D3 = (double)s33 * C3 + (double)(-s34) * C4;
+    const double D4 = (double)s34 * C3 + (double)s44 * C4;
+    const double S2 = (-cosw) * D2 + (-sinw) * D3;
+    const double S3 = (-sinw) * D2 + cosw * D3;
+    atomic_add_f64(p, l * D1);
+    atomic_add_f64(p + st_type, l * S2);
+    atomic_add_f64(p + 2 * st_type, l * S3);
+    atomic_add_f64(p + 3 * st_type, l * D4);
+    if (A.contrib) atomic_add_f64(p + st_type * (flag_star ? 5 : 7), l * D1);
+  }
+}
+
+// SCOUT: no deposits, no SED; records hits.  Otherwise the COMMIT pass.
+template <bool L3D, bool POLA, bool DARK, bool SCOUT>
+__device__ __forceinline__ void mono_body(const DevModel& M, const MonoArgs& A, double* lds_base) {
+  const Lds T = lds_carve(lds_base, M);
+  lds_stage(T, M);
+  const int na1 = M.nang + 1;
+  float* mu = reinterpret_cast<float*>(lds_base + (lds_bytes(M) + 7) / 8);
+  RtScratch R;
+  {
+    double* p = lds_base + (lds_bytes(M) + 7) / 8 + ((size_t)6 * na1 * sizeof(float) + 7) / 8;
+    R.cosw = p;
+    R.sinw = p + (POLA ? (size_t)A.nRT * blockDim.x : 0);
+    R.itheta = reinterpret_cast<int*>(p + (POLA ? (size_t)2 * A.nRT * blockDim.x : 0));
+  }
+  {  // the Mueller columns of p_lambda, and the phase-function CDF of p_lambda for the forced scattering
+    const size_t col = (size_t)na1 * (A.p_lambda - 1);
+    for (int i = threadIdx.x; i < na1; i += blockDim.x) {
+      mu[i] = A.s11 ? A.s11[i] : 0.0f;
+      if (POLA) {
+        mu[na1 + i] = M.s12[col + i]; mu[2 * na1 + i] = M.s22[col + i]; mu[3 * na1 + i] = M.s33[col + i];
+        mu[4 * na1 + i] = M.s34[col + i]; mu[5 * na1 + i] = M.s44[col + i];
+      }
+    }
+  }
+  __syncthreads();
+  const float* prob_p = M.prob_s11 + (size_t)na1 * (A.p_lambda - 1);
+
+  const int lane = threadIdx.x & 63;
+  const int n_rad = M.n_rad, nz = M.nz;
+  const int lambda = A.lambda;
+  int st = S_EMIT;
+  double x = 0, y = 0, z = 0, u = 0, v = 0, w = 1, extr = 0, inv_a = 0, inv_w = 0;
+  double xo = 0, yo = 0, zo = 0;
+  int ri = 0, zj = 1, k = 1, ri_o = 0, zj_o = 1, k_o = 1;
+  int star_key = -1;
+  bool flag_star = false, flag_scatt = false;
+  double S[4] = {1.0, 0.0, 0.0, 0.0};
+  Rng rng;
+  rng.init(0, 0);
+  unsigned int c_cross = 0, c_flight = 0, c_scatt = 0, c_abs = 0, c_esc = 0, c_kill = 0, c_dark = 0, c_pack = 0;
+  unsigned int pk_cross = 0;
+  unsigned long long pk_next = 0, pk_end = 0, my_item = 0;
+  float tau_rand = 0.0f;
+  double kf = 0.0;
+
+  for (;;) {
+    if (st == S_EXITED) {  // capteur (dust_transfer.f90:549-552)
+      const int capt = capteur<POLA, true>(M, SCOUT ? nullptr : A.sed, lambda, u, v, w, S, flag_star, flag_scatt);
+      if (SCOUT) { if (capt == A.capt_sup) A.hits[my_item] = 1; }
+      if (capt > 0) c_esc++;
+      st = S_EMIT;
+    }
+    {
+      const bool need = (st == S_EMIT);
+      const unsigned long long mask = __ballot(need);
+      if (mask) {
+        if (pk_next >= pk_end) {
+          const int leader = __ffsll((long long)mask) - 1;
+          unsigned long long base = 0;
+          if (lane == leader) base = atomicAdd(A.next_item, (unsigned long long)PK_BATCH);
+          base = __shfl(base, leader);
+          pk_next = base < A.n_items ? base : A.n_items;
+          pk_end = (base + PK_BATCH < A.n_items) ? base + PK_BATCH : A.n_items;
+          if (pk_end < pk_next) pk_end = pk_next;
+        }
+        const unsigned long long avail = pk_end - pk_next;
+        const unsigned long long rank = (unsigned long long)__popcll(mask & ((1ull << lane) - 1ull));
+        const unsigned long long cnt = (unsigned long long)__popcll(mask);
+        const unsigned long long my = pk_next + rank;
+        const bool served = need && (rank < avail);
+        if (need && !served && pk_next >= A.n_items) st = S_DONE;
+        pk_next += (cnt < avail) ? cnt : avail;
+        if (served) {
+          // work item -> (stream, sequence number)
+          my_item = my;
+          unsigned long long chunk, seq;
+          if (SCOUT) {
+            const unsigned long long a = my / A.batch;
+            chunk = (unsigned long long)A.active[a];
+            seq = A.seq0[chunk] + (my - a * A.batch);
+          } else {
+            int lo = 0, hi = A.n_chunks;  // item_base[lo] <= my < item_base[hi]
+            while (hi - lo > 1) {
+              const int mid = (lo + hi) >> 1;
+              if (A.item_base[mid] <= my) lo = mid; else hi = mid;
+            }
+            chunk = (unsigned long long)lo;
+            seq = my - A.item_base[lo];
+          }
+          rng.init(A.seed, (chunk << 40) | seq);
+          c_pack++;
+          pk_cross = 0;
+          float f[12];
+          rng.emission_event(f);  // f[0]: the wavelength draw of the thermal step, unused (lmono, :535)
+          tau_rand = f[8];
+          if (!SCOUT) atomic_add_f64(&A.n_sent[lambda - 1], 1.0);
+          bool lintersect = true;
+          flag_scatt = false;
+          S[0] = 1.0; S[1] = 0.0; S[2] = 0.0; S[3] = 0.0;
+          if ((double)f[1] <= A.frac_E_stars) {  // emit_packet (dust_transfer.f90:1047-1151)
+            flag_star = true;
+            const int i_star = select_star(M, lambda, f[2]);
+            emit_uniform_sphere(M, i_star, f[3], f[4], f[5], f[6], x, y, z, u, v, w);
+            index_cell<L3D>(T, M, x, y, z, ri, zj, k);
+            if (M.star_cell[4 * (i_star - 1) + 3]) lintersect = move_to_grid<L3D>(T, M, x, y, z, u, v, w, ri, zj, k);
+          } else if ((double)f[1] <= A.frac_E_disk && A.prob_E_cell) {
+            flag_star = false;
+            const int icell = select_cellule(A.prob_E_cell, M.n_cells, f[2]);
+            int q = icell - 1;
+            ri = q % n_rad + 1;
+            q /= n_rad;
+            if (L3D) {
+              const int jj = q % (2 * nz);
+              k = q / (2 * nz) + 1;
+              zj = jj < nz ? jj - nz : jj - nz + 1;
+            } else {
+              zj = q + 1;
+              k = 1;
+            }
+            pos_em_cell<L3D>(T, M, ri, zj, k, f[3], f[4], f[5], x, y, z);
+            random_isotropic_direction(f[6], f[7], u, v, w);
+          } else {
+            *A.err = 12;  // ISM emission / missing prob_E_cell
+            st = S_DONE;
+          }
+          if (st != S_DONE) st = lintersect ? S_NEWFLIGHT : S_EXITED;
+        }
+      }
+    }
+
+    if (st == S_INTERACT) {  // forced scattering (dust_transfer.f90:1263-1278)
+      float g[8];
+      rng.interaction_event(g);
+      tau_rand = g[5];
+      bool dead = false;
+      if (DARK) dead = M.dark[cell_index<L3D>(n_rad, nz, ri, zj, k)] != 0;
+      if (!dead) {
+        const double alb = (double)T.albedo[lambda - 1];
+        S[0] *= alb;
+        if (POLA) { S[1] *= alb; S[2] *= alb; S[3] *= alb; }
+        dead = S[0] < (double)(FLT_TINY_X1E6);
+      }
+      if (dead) {
+        c_abs++;
+        st = S_EMIT;  // lpacket_alive = .false.: not binned
+      } else {
+        double u1, v1, w1;
+        int lam = lambda;
+        interact<POLA>(T, M, g, lam, u, v, w, u1, v1, w1, S, flag_star, flag_scatt, c_scatt, c_abs,
+                       []() { return 0.0; }, M.volume, true, prob_p);
+        u = u1; v = v1; w = w1;
+        st = S_NEWFLIGHT;
+      }
+    }
+
+    if (st == S_NEWFLIGHT) {
+      const float rand = tau_rand;
+      extr = (rand > 1.0e-6f) ? -log(1.0 - (double)rand) : (double)rand;
+      const double a = u * u + v * v;
+      inv_a = (a > TINY_REAL) ? 1.0 / a : HUGE_REAL;
+      inv_w = (fabs(w) > TINY_REAL) ? 1.0 / w : copysign(HUGE_DP, w);
+      if (!SCOUT && A.rt1) angles_scatt_rt1<POLA>(M, A, R, u, v, w);  // optical_depth.f90:65
+      const int i_star = intersect_stars(M, x, y, z, u, v, w);
+      star_key = -1;
+      if (i_star > 0) {
+        const int* sc = &M.star_cell[4 * (i_star - 1)];
+        star_key = sc[0] + (n_rad + 2) * ((sc[1] + nz + 1) + (2 * nz + 3) * (sc[2] - 1));
+      }
+      c_flight++;
+      ri_o = 0; zj_o = 0; k_o = 0;
+      xo = x; yo = y; zo = z;
+      kf = is_real_cell<L3D>(n_rad, nz, ri, zj) ? M.kappa_factor[cell_index<L3D>(n_rad, nz, ri, zj, k)] : 0.0;
+      st = S_FLIGHT;
+    }
+
+    if (__ballot(st != S_DONE) == 0ull) break;
+
+#pragma unroll 1
+    for (int it = 0; it < A.inner_iters; ++it) {
+      if (A.min_active > 0 && it > 0) {
+        const int flying = __popcll(__ballot(st == S_FLIGHT)), alive = __popcll(__ballot(st != S_DONE));
+        if (flying * 64 < A.min_active * alive) break;
+      }
+      if (st == S_FLIGHT) {
+        const int azj = zj < 0 ? -zj : zj;
+        const bool out = (ri == n_rad + 1) || ((azj == nz + 1) && (fabs(z) > M.zmaxmax));
+        bool killed = false;
+        if (star_key >= 0) {
+          const int key = ri + (n_rad + 2) * ((zj + nz + 1) + (2 * nz + 3) * (k - 1));
+          killed = (key == star_key);
+        }
+        if (out) {
+          st = S_EXITED;
+        } else if (killed) {
+          c_kill++;
+          st = S_EMIT;
+        } else {
+          const bool real_cell = is_real_cell<L3D>(n_rad, nz, ri, zj);
+          double opacity = 0.0;
+          int ic = 0;
+          bool mirrored = false;
+          if (real_cell) {
+            ic = cell_index<L3D>(n_rad, nz, ri, zj, k);
+            opacity = T.kappa[lambda - 1] * kf;
+            if (DARK) {
+              if (M.dark[ic]) {  // optical_depth.f90:104-112
+                u = -u; v = -v; w = -w;
+                x = xo; y = yo; z = zo;
+                ri = ri_o; zj = zj_o; k = k_o;
+                c_dark++;
+                mirrored = true;
+                st = S_INTERACT;
+              }
+            }
+          }
+          if (!mirrored) {
+            double x1, y1, z1, l;
+            int ri1, zj1, k1;
+            MCGPU_CROSS<L3D>(T, M, x, y, z, u, v, w, inv_a, inv_w, ri, zj, k, x1, y1, z1, ri1, zj1, k1, l);
+            c_cross++;
+            if (++pk_cross > 200000000u) {
+              *A.err = 13;
+              st = S_EMIT;
+            }
+            const double tau = l * opacity;
+            if (tau > extr) {
+              const double lc = l * (extr / tau);
+              if (!SCOUT && A.rt1 && real_cell)
+                deposit_rt1<L3D, POLA>(M, A, R, mu, ic + 1, S, lc, x, y, z, x1, y1, z1, flag_star);
+              x = x + lc * u;
+              y = y + lc * v;
+              z = z + lc * w;
+              if (L3D) index_cell<L3D>(T, M, x, y, z, ri, zj, k);
+              st = S_INTERACT;
+            } else {
+              extr = extr - tau;
+              if (!SCOUT && A.rt1 && real_cell)
+                deposit_rt1<L3D, POLA>(M, A, R, mu, ic + 1, S, l, x, y, z, x1, y1, z1, flag_star);
+              if (DARK) { xo = x; yo = y; zo = z; ri_o = ri; zj_o = zj; k_o = k; }
+              x = x1; y = y1; z = z1;
+              ri = ri1; zj = zj1; k = k1;
+              kf = is_real_cell<L3D>(n_rad, nz, ri, zj) ? M.kappa_factor[cell_index<L3D>(n_rad, nz, ri, zj, k)] : 0.0;
+            }
+          }
+        }
+      }
+    }
+  }
+
+  if (!SCOUT) {
+    unsigned int cs[8] = {c_pack, c_cross, c_flight, c_scatt, c_abs, c_esc, c_kill, c_dark};
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      unsigned long long vsum = cs[q];
+      for (int off = 32; off > 0; off >>= 1) vsum += __shfl_down(vsum, off);
+      if (lane == 0 && vsum) atomicAdd(&A.counters[q], vsum);
+    }
+  }
+}
+
+template <bool L3D, bool POLA, bool DARK, bool SCOUT>
+__global__ void __launch_bounds__(256) k_mono(const DevModel M, const MonoArgs A) {
+  extern __shared__ double lds_raw[];
+  mono_body<L3D, POLA, DARK, SCOUT>(M, A, lds_raw);
+}
+
+// Stopping index of every active stream from this batch's hit flags: one wave per stream.
+//   need[c]  packets still to be binned in capt_sup (updated)
+//   sent[c]  packets sent so far = seq0 (updated: += batch, or the exact stop)
+//   lim      n_phot_lim as an integer cap
+// done[c] = 1 when the stream stopped inside this batch (or hit the cap).
+__global__ void k_mono_scan(const int* active, int n_active, unsigned long long batch, const unsigned char* hits,
+                            unsigned long long* need, unsigned long long* sent, unsigned long long lim,
+                            int* done) {
+  const int a = blockIdx.x;
+  if (a >= n_active) return;
+  const int c = active[a];
+  const int lane = threadIdx.x;
+  const unsigned char* h = hits + (size_t)a * batch;
+  unsigned long long want = need[c], base = sent[c];
+  unsigned long long stop = batch;  // packets of this batch that count
+  bool fin = false;
+  // the cap: the stream may send at most lim packets in total
+  unsigned long long usable = batch;
+  if (base + batch >= lim) { usable = lim > base ? lim - base : 0; }
+  for (unsigned long long s0 = 0; s0 < usable && !fin; s0 += 64) {
+    const unsigned long long s = s0 + lane;
+    const bool hit = (s < usable) && h[s];
+    const unsigned long long m = __ballot(hit);
+    const unsigned long long n = (unsigned long long)__popcll(m);
+    if (n >= want) {  // the want-th hit of this group ends the stream
+      unsigned long long mm = m;
+      for (unsigned long long q = 1; q < want; ++q) mm &= mm - 1;  // drop the first want-1 hits
+      const int pos = __ffsll((long long)mm) - 1;
+      stop = s0 + (unsigned long long)pos + 1;
+      want = 0;
+      fin = true;
+    } else {
+      want -= n;
+    }
+  }
+  if (!fin && usable < batch) { stop = usable; fin = true; }  // n_phot_lim reached
+  if (lane == 0) {
+    need[c] = want;
+    sent[c] = base + (fin ? stop : batch);
+    done[c] = fin ? 1 : 0;
+  }
+}
+
+// xI_scatt in default real (what the reference's array holds)
+__global__ void k_xI_to_float(const double* xI, float* out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (float)xI[i];
+}
+
+}  // namespace mcgpu

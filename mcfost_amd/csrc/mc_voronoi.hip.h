@@ -57,9 +57,6 @@ struct VoroGrid {
   double cut_o_h;         // PS%cutting_distance_o_h
 };
 
-constexpr float FLT_TINY = 1.17549435082228750797e-38f;
-constexpr float FLT_HUGE = 3.40282346638528859812e+38f;
-
 // default-real dot product, evaluated left to right without contraction
 __device__ inline float dot3f(float a0, float a1, float a2, float b0, float b1, float b2) {
   return nf_add(nf_add(nf_mul(a0, b0), nf_mul(a1, b1)), nf_mul(a2, b2));

@@ -16,6 +16,7 @@
 #include "mc_device.hip.h"
 #include "mc_rounds.hip.h"
 #include "mc_voronoi.hip.h"
+#include "mc_mono.hip.h"
 
 using namespace mcgpu;
 
@@ -50,6 +51,19 @@ struct mcgpu_ctx {
   int* d_list = nullptr;
   unsigned int* d_round_counts = nullptr;  // [0] list_n, [1] flying_n
   Pool* d_pool_desc = nullptr;             // device copy of `pool` for the finisher
+  // SED mode (mc_mono.hip.h)
+  bool have_rt1 = false;
+  int RT_n_incl = 0, RT_n_az = 0, n_az_rt = 0, n_theta_rt = 0, N_type_flux = 0, lsepar_contrib = 0, n_lambda_pos = 0;
+  const double *d_rt_u = nullptr, *d_rt_v = nullptr, *d_rt_w = nullptr;
+  const float* d_tab_s11 = nullptr;
+  double* d_xI = nullptr;
+  size_t n_xI = 0;
+  double* d_prob_E = nullptr;               // prob_E_cell(0:n_cells) of the current wavelength
+  unsigned long long* d_mono_u64 = nullptr; // [4 * n_chunks + 1]: need | sent | item_base(+1)
+  int* d_mono_i32 = nullptr;                // [2 * n_chunks]: active | done
+  int mono_chunks = 0;
+  unsigned char* d_hits = nullptr;
+  size_t hits_cap = 0;
   // Voronoi grid (mc_voronoi.hip.h)
   bool voro = false;
   VoroGrid V;
@@ -122,6 +136,11 @@ extern "C" int mcgpu_destroy(mcgpu_ctx* ctx) {
   if (ctx->d_list) hipFree(ctx->d_list);
   if (ctx->d_round_counts) hipFree(ctx->d_round_counts);
   if (ctx->d_pool_desc) hipFree(ctx->d_pool_desc);
+  if (ctx->d_xI) hipFree(ctx->d_xI);
+  if (ctx->d_prob_E) hipFree(ctx->d_prob_E);
+  if (ctx->d_mono_u64) hipFree(ctx->d_mono_u64);
+  if (ctx->d_mono_i32) hipFree(ctx->d_mono_i32);
+  if (ctx->d_hits) hipFree(ctx->d_hits);
   if (ctx->ev0) hipEventDestroy(ctx->ev0);
   if (ctx->ev1) hipEventDestroy(ctx->ev1);
   if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
@@ -840,6 +859,220 @@ extern "C" int mcgpu_run_thermal(mcgpu_ctx* ctx, const mcgpu_run_opts* opts, dou
   if (rc) return rc;
   if ((rc = mcgpu_sync(ctx, kernel_ms))) return rc;
   return mcgpu_fetch(ctx, E_abs, sed, n_sent, counters);
+}
+
+// ---------------------------------------------------------------------------------------------
+// SED mode (mc_mono.hip.h)
+// ---------------------------------------------------------------------------------------------
+extern "C" int mcgpu_set_rt1(mcgpu_ctx* ctx, int RT_n_incl, int RT_n_az, const double* tab_u_rt,
+                             const double* tab_v_rt, const double* tab_w_rt, int n_az_rt, int n_theta_rt,
+                             int N_type_flux, int lsepar_contrib, const float* tab_s11_pos, int n_lambda_pos) {
+  if (!ctx || RT_n_incl < 1 || RT_n_az < 1 || !tab_u_rt || !tab_v_rt || !tab_w_rt || n_az_rt < 1 ||
+      n_theta_rt < 1 || N_type_flux < 1 || !tab_s11_pos || n_lambda_pos < 1)
+    return fail(ctx, MCGPU_ERR_ARG, "mcgpu_set_rt1: bad argument");
+  if (!ctx->have_scatt) return fail(ctx, MCGPU_ERR_STATE, "set the scattering tables before mcgpu_set_rt1");
+  const bool pola = ctx->lsepar_pola != 0;
+  const int want = pola ? (lsepar_contrib ? 8 : 4) : (lsepar_contrib ? 5 : 1);  // init_mcfost.f90:1603-1616
+  if (N_type_flux != want) return fail(ctx, MCGPU_ERR_ARG, "N_type_flux inconsistent with lsepar_pola / lsepar_contrib");
+  if (ctx->M.l3D ? (n_az_rt != 1 || n_theta_rt != 1) : (n_theta_rt != 2))
+    return fail(ctx, MCGPU_ERR_UNSUPPORTED, "n_az_rt / n_theta_rt must follow dust_ray_tracing.f90:91-98");
+  HIPCHK(hipSetDevice(ctx->device));
+  int rc;
+  if ((rc = upload(ctx, tab_u_rt, (size_t)RT_n_incl * RT_n_az, &ctx->d_rt_u))) return rc;
+  if ((rc = upload(ctx, tab_v_rt, (size_t)RT_n_incl * RT_n_az, &ctx->d_rt_v))) return rc;
+  if ((rc = upload(ctx, tab_w_rt, (size_t)RT_n_incl, &ctx->d_rt_w))) return rc;
+  if ((rc = upload(ctx, tab_s11_pos, (size_t)(ctx->M.nang + 1) * n_lambda_pos, &ctx->d_tab_s11))) return rc;
+  ctx->RT_n_incl = RT_n_incl; ctx->RT_n_az = RT_n_az; ctx->n_az_rt = n_az_rt; ctx->n_theta_rt = n_theta_rt;
+  ctx->N_type_flux = N_type_flux; ctx->lsepar_contrib = lsepar_contrib ? 1 : 0; ctx->n_lambda_pos = n_lambda_pos;
+  ctx->have_rt1 = true;
+  return MCGPU_OK;
+}
+
+template <bool SCOUT>
+static int launch_mono(mcgpu_ctx* ctx, const MonoArgs& A, int grid_blocks, int block_threads) {
+  const DevModel& M = ctx->M;
+  const bool pola = ctx->lsepar_pola != 0, dark = M.dark != nullptr, l3d = M.l3D != 0;
+  const int threads = (block_threads > 0 && block_threads <= 256 && block_threads % 64 == 0) ? block_threads : 256;
+  const size_t lds = mono_lds_bytes(M, A.nRT, threads, pola);
+  if (lds > 160 * 1024) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "too many ray-tracing directions for the LDS of one CU");
+  const void* fn;
+#define PICK(a, b, c) fn = (const void*)k_mono<a, b, c, SCOUT>
+  if (l3d) {
+    if (pola) { if (dark) PICK(true, true, true); else PICK(true, true, false); }
+    else { if (dark) PICK(true, false, true); else PICK(true, false, false); }
+  } else {
+    if (pola) { if (dark) PICK(false, true, true); else PICK(false, true, false); }
+    else { if (dark) PICK(false, false, true); else PICK(false, false, false); }
+  }
+#undef PICK
+  HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  int blocks = grid_blocks;
+  if (blocks <= 0) {
+    int occ = 1;
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, threads, lds));
+    if (occ < 1) occ = 1;
+    blocks = ctx->prop.multiProcessorCount * occ;
+    const unsigned long long need = (A.n_items + threads - 1) / threads;
+    if ((unsigned long long)blocks > need) blocks = (int)(need ? need : 1);
+  }
+  void* args[] = {(void*)&M, (void*)&A};
+  HIPCHK(hipLaunchKernel(fn, dim3(blocks), dim3(threads), args, lds, ctx->stream));
+  return MCGPU_OK;
+}
+
+extern "C" int mcgpu_run_mono(mcgpu_ctx* ctx, const mcgpu_mono_opts* o, double frac_E_stars, double frac_E_disk,
+                              const double* prob_E_cell, uint64_t* n_sent_chunk, double* kernel_ms) {
+  int rc = ready(ctx);
+  if (rc) return rc;
+  if (!o) return fail(ctx, MCGPU_ERR_ARG, "null options");
+  if (ctx->voro) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "SED mode on Voronoi grids is not built yet");
+  DevModel& M = ctx->M;
+  if (o->lambda < 1 || o->lambda > M.n_lambda || o->n_chunks < 1 || o->n_chunks > (1 << 22) || o->capt_sup < 1)
+    return fail(ctx, MCGPU_ERR_ARG, "mcgpu_run_mono: bad option");
+  if (o->rt1 && !ctx->have_rt1) return fail(ctx, MCGPU_ERR_STATE, "rt1 deposits need mcgpu_set_rt1");
+  const int n_pos = ctx->have_rt1 ? ctx->n_lambda_pos : M.n_lambda;
+  if (o->p_lambda < 1 || o->p_lambda > n_pos || o->p_lambda > M.n_lambda) return fail(ctx, MCGPU_ERR_ARG, "p_lambda out of range");
+  if (frac_E_stars < 1.0 && frac_E_disk > frac_E_stars && !prob_E_cell)
+    return fail(ctx, MCGPU_ERR_ARG, "disk emission needs prob_E_cell");
+  if (frac_E_disk < 1.0) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "ISM emission is not built");
+  HIPCHK(hipSetDevice(ctx->device));
+  if ((rc = ensure_accum(ctx))) return rc;
+  const int nc = o->n_chunks;
+  if (ctx->mono_chunks < nc) {
+    if (ctx->d_mono_u64) hipFree(ctx->d_mono_u64);
+    if (ctx->d_mono_i32) hipFree(ctx->d_mono_i32);
+    ctx->d_mono_u64 = nullptr; ctx->d_mono_i32 = nullptr; ctx->mono_chunks = 0;
+    HIPCHK(hipMalloc((void**)&ctx->d_mono_u64, ((size_t)3 * nc + 1) * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc((void**)&ctx->d_mono_i32, (size_t)2 * nc * sizeof(int)));
+    ctx->mono_chunks = nc;
+  }
+  unsigned long long *d_need = ctx->d_mono_u64, *d_sent = d_need + nc, *d_base = d_sent + nc;
+  int *d_active = ctx->d_mono_i32, *d_done = d_active + nc;
+  if (prob_E_cell) {
+    if (!ctx->d_prob_E) HIPCHK(hipMalloc((void**)&ctx->d_prob_E, ((size_t)M.n_cells + 1) * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(ctx->d_prob_E, prob_E_cell, ((size_t)M.n_cells + 1) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  }
+  const int nRT = ctx->have_rt1 ? ctx->RT_n_incl * ctx->RT_n_az : 0;
+  const size_t n_xI = o->rt1 ? (size_t)ctx->n_az_rt * ctx->n_theta_rt * ctx->N_type_flux * nRT * (size_t)M.n_cells : 0;
+  if (o->rt1 && ctx->n_xI != n_xI) {
+    if (ctx->d_xI) hipFree(ctx->d_xI);
+    ctx->d_xI = nullptr; ctx->n_xI = 0;
+    HIPCHK(hipMalloc((void**)&ctx->d_xI, n_xI * sizeof(double)));
+    ctx->n_xI = n_xI;
+    HIPCHK(hipMemsetAsync(ctx->d_xI, 0, n_xI * sizeof(double), ctx->stream));
+  } else if (o->rt1 && !o->accumulate) {
+    HIPCHK(hipMemsetAsync(ctx->d_xI, 0, n_xI * sizeof(double), ctx->stream));
+  }
+  if (!o->accumulate) {
+    HIPCHK(hipMemsetAsync(ctx->d_accum, 0, ctx->n_accum * sizeof(double), ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_counters, 0, 16 * sizeof(unsigned long long), ctx->stream));
+  }
+  HIPCHK(hipMemsetAsync(ctx->d_err, 0, sizeof(int), ctx->stream));
+
+  MonoArgs A;
+  std::memset(&A, 0, sizeof(A));
+  A.seed = o->seed; A.lambda = o->lambda; A.p_lambda = o->p_lambda; A.capt_sup = o->capt_sup; A.rt1 = o->rt1 ? 1 : 0;
+  A.frac_E_stars = frac_E_stars; A.frac_E_disk = frac_E_disk;
+  A.prob_E_cell = prob_E_cell ? ctx->d_prob_E : nullptr;
+  A.n_chunks = nc;
+  A.RT_n_incl = ctx->have_rt1 ? ctx->RT_n_incl : 1; A.nRT = o->rt1 ? nRT : 0;
+  A.rt_u = ctx->d_rt_u; A.rt_v = ctx->d_rt_v; A.rt_w = ctx->d_rt_w;
+  A.n_az_rt = ctx->n_az_rt; A.n_theta_rt = ctx->n_theta_rt; A.N_type_flux = ctx->N_type_flux; A.contrib = ctx->lsepar_contrib;
+  A.s11 = ctx->have_rt1 ? ctx->d_tab_s11 + (size_t)(M.nang + 1) * (o->p_lambda - 1) : nullptr;
+  A.xI = ctx->d_xI;
+  A.sed = ctx->d_accum + M.n_cells;
+  A.n_sent = ctx->d_accum + M.n_cells + n_sed(M);
+  A.counters = ctx->d_counters; A.next_item = ctx->d_counters + 8; A.err = ctx->d_err;
+  A.inner_iters = 64; A.min_active = 32;
+  if (const char* e = getenv("MCGPU_MIN_ACTIVE")) { int v = atoi(e); if (v >= 0 && v <= 64) A.min_active = v; }
+  if (const char* e = getenv("MCGPU_INNER_ITERS")) { int v = atoi(e); if (v >= 1 && v <= 4096) A.inner_iters = v; }
+
+  // ---- SCOUT: find every stream's stopping index (dust_transfer.f90:526-553) ----------------
+  double lim_d = std::ceil((double)o->n_phot_lim);
+  if (!(lim_d >= 0.0)) lim_d = 0.0;
+  const unsigned long long lim = lim_d > 9.0e18 ? ~0ull : (unsigned long long)lim_d;
+  std::vector<unsigned long long> need(nc, o->n_photons2), sent(nc, 0ull);
+  std::vector<int> active, done(nc, 0);
+  if (o->n_photons2 > 0 && lim > 0) for (int c = 0; c < nc; ++c) active.push_back(c);
+  HIPCHK(hipMemcpyAsync(d_need, need.data(), nc * sizeof(unsigned long long), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(d_sent, sent.data(), nc * sizeof(unsigned long long), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+  double rate = 1.0 / (double)M.N_thet;  // first guess: an isotropic source fills the bins evenly
+  unsigned long long scout_packets = 0, hits_found = 0;
+  while (!active.empty()) {
+    const int na = (int)active.size();
+    unsigned long long max_need = 0;
+    for (int c : active) if (need[c] > max_need) max_need = need[c];
+    double b = 1.25 * (double)max_need / rate + 64.0;
+    const double bmax = 2.0e9 / (double)na;
+    if (b > bmax) b = bmax;
+    if (b < 64.0) b = 64.0;
+    const unsigned long long batch = ((unsigned long long)b + 63ull) / 64ull * 64ull;
+    const size_t nh = (size_t)na * batch;
+    if (ctx->hits_cap < nh) {
+      if (ctx->d_hits) hipFree(ctx->d_hits);
+      ctx->d_hits = nullptr; ctx->hits_cap = 0;
+      HIPCHK(hipMalloc((void**)&ctx->d_hits, nh));
+      ctx->hits_cap = nh;
+    }
+    HIPCHK(hipMemsetAsync(ctx->d_hits, 0, nh, ctx->stream));
+    HIPCHK(hipMemcpyAsync(d_active, active.data(), na * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_counters + 8, 0, sizeof(unsigned long long), ctx->stream));
+    A.active = d_active; A.seq0 = d_sent; A.batch = batch; A.hits = ctx->d_hits; A.n_items = nh;
+    if ((rc = launch_mono<true>(ctx, A, o->grid_blocks, o->block_threads))) return rc;
+    hipLaunchKernelGGL(k_mono_scan, dim3(na), dim3(64), 0, ctx->stream, d_active, na, batch, ctx->d_hits, d_need, d_sent,
+                       lim, d_done);
+    HIPCHK(hipGetLastError());
+    std::vector<unsigned long long> need2(nc), sent2(nc);
+    HIPCHK(hipMemcpyAsync(need2.data(), d_need, nc * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(sent2.data(), d_sent, nc * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(done.data(), d_done, nc * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    int dev_err = 0;
+    HIPCHK(hipMemcpy(&dev_err, ctx->d_err, sizeof(int), hipMemcpyDeviceToHost));
+    if (dev_err) { ctx->err = "device error " + std::to_string(dev_err) + " in the scout pass"; return MCGPU_ERR_KERNEL; }
+    std::vector<int> still;
+    for (int c : active) {
+      scout_packets += sent2[c] - sent[c];
+      hits_found += need[c] - need2[c];
+      if (!done[c]) still.push_back(c);
+    }
+    need = need2; sent = sent2;
+    active.swap(still);
+    if (scout_packets > 0 && hits_found > 0) rate = (double)hits_found / (double)scout_packets;
+    else rate *= 0.25;  // nothing landed in capt_sup yet: widen the next batch
+  }
+
+  // ---- COMMIT: exactly the packets s < K of every stream, with deposits -----------------------
+  std::vector<unsigned long long> base(nc + 1, 0ull);
+  for (int c = 0; c < nc; ++c) base[c + 1] = base[c] + sent[c];
+  if (n_sent_chunk) for (int c = 0; c < nc; ++c) n_sent_chunk[c] = sent[c];
+  HIPCHK(hipMemcpyAsync(d_base, base.data(), ((size_t)nc + 1) * sizeof(unsigned long long), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->d_counters + 8, 0, sizeof(unsigned long long), ctx->stream));
+  A.item_base = d_base; A.n_items = base[nc]; A.active = nullptr; A.seq0 = nullptr; A.hits = nullptr; A.batch = 0;
+  if (A.n_items > 0 && (rc = launch_mono<false>(ctx, A, o->grid_blocks, o->block_threads))) return rc;
+  HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+  ctx->launched = true;
+  if ((rc = mcgpu_sync(ctx, kernel_ms))) return rc;
+  return MCGPU_OK;
+}
+
+extern "C" int mcgpu_fetch_xI(mcgpu_ctx* ctx, float* xI_scatt_f32, double* xI_scatt_f64) {
+  if (!ctx || !ctx->d_xI) return fail(ctx, MCGPU_ERR_STATE, "no xI_scatt accumulated yet");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (xI_scatt_f64) HIPCHK(hipMemcpy(xI_scatt_f64, ctx->d_xI, ctx->n_xI * sizeof(double), hipMemcpyDeviceToHost));
+  if (xI_scatt_f32) {
+    float* d = nullptr;
+    HIPCHK(hipMalloc((void**)&d, ctx->n_xI * sizeof(float)));
+    hipLaunchKernelGGL(k_xI_to_float, dim3((unsigned)((ctx->n_xI + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_xI, d, ctx->n_xI);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(xI_scatt_f32, d, ctx->n_xI * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    hipFree(d);
+    HIPCHK(e);
+  }
+  return MCGPU_OK;
 }
 
 extern "C" int mcgpu_temp_finale(mcgpu_ctx* ctx, const double* E_abs, float* Tdust) {

@@ -32,7 +32,7 @@ ABI_SYMBOLS = (
     "mcgpu_device_accumulators", "mcgpu_fetch", "mcgpu_set_stream", "mcgpu_temp_finale",
     "mcgpu_probe_cross_cell", "mcgpu_probe_index_cell", "mcgpu_probe_philox",
     "mcgpu_probe_packet_rand", "mcgpu_set_midplane_snap", "mcgpu_set_grid_voronoi",
-    "mcgpu_probe_cross_voronoi",
+    "mcgpu_probe_cross_voronoi", "mcgpu_set_rt1", "mcgpu_run_mono", "mcgpu_fetch_xI",
 )
 
 
@@ -44,6 +44,12 @@ class RunOpts(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("first_packet", C.c_uint64), ("n_packets", C.c_uint64),
                 ("n_replicas", C.c_double), ("frozen", C.c_int), ("accumulate", C.c_int),
                 ("grid_blocks", C.c_int), ("block_threads", C.c_int)]
+
+
+class MonoOpts(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("lambda_", C.c_int), ("p_lambda", C.c_int), ("n_chunks", C.c_int),
+                ("n_photons2", C.c_uint64), ("n_phot_lim", C.c_double), ("capt_sup", C.c_int), ("rt1", C.c_int),
+                ("accumulate", C.c_int), ("grid_blocks", C.c_int), ("block_threads", C.c_int)]
 
 
 _lib = None
@@ -262,6 +268,55 @@ class Engine:
             _p(x1, C.c_double), _p(y1, C.c_double), _p(z1, C.c_double), _p(nxt, C.c_int),
             _p(l, C.c_double)), "mcgpu_probe_cross_cell")
         return x1, y1, z1, nxt, l
+
+    # -- SED mode ------------------------------------------------------------
+    def set_rt1(self):
+        m, rt = self.model, self.model.rt
+        d = np.float64
+        self._chk(self.lib.mcgpu_set_rt1(
+            self.ctx, C.c_int(rt["RT_n_incl"]), C.c_int(rt["RT_n_az"]), _p(_a(rt["tab_u_rt"], d), C.c_double),
+            _p(_a(rt["tab_v_rt"], d), C.c_double), _p(_a(rt["tab_w_rt"], d), C.c_double), C.c_int(rt["n_az_rt"]),
+            C.c_int(rt["n_theta_rt"]), C.c_int(rt["N_type_flux"]), C.c_int(rt["lsepar_contrib"]),
+            _p(_a(m.tab_s11_pos, np.float32), C.c_float), C.c_int(m.n_lambda)), "mcgpu_set_rt1")
+        self._rt1 = True
+
+    def xI_shape(self):
+        rt = self.model.rt
+        return (self.model.n_cells, rt["RT_n_incl"] * rt["RT_n_az"], rt["N_type_flux"], rt["n_theta_rt"],
+                rt["n_az_rt"])
+
+    def run_mono(self, lam, n_photons2, n_phot_lim=None, p_lambda=None, seed=1, n_chunks=None, rt1=True,
+                 accumulate=False, grid_blocks=0, block_threads=0, fetch_xI=True):
+        """One wavelength (1-based ``lam``) of the SED Monte Carlo: ``mcgpu_run_mono`` with the
+        model's frac_E_stars / prob_E_cell of that wavelength."""
+        m = self.model
+        if rt1 and not getattr(self, "_rt1", False):
+            self.set_rt1()
+        nt, nphi = m.cfg.N_thet, m.cfg.N_phi
+        n_chunks = int(n_chunks or m.cfg.n_photons_loop)
+        if n_phot_lim is None:  # read_param.f90:551
+            n_phot_lim = float(np.float32(1.0e4) * np.float32(nt) * np.float32(nphi) * np.float32(n_photons2))
+        o = MonoOpts(seed, int(lam), int(p_lambda or lam), n_chunks, int(n_photons2), float(n_phot_lim),
+                     int(m.capt_sup), int(rt1), int(accumulate), grid_blocks, block_threads)
+        pe = getattr(m, "prob_E_cell", None)
+        pe_l = None
+        if pe is not None:
+            pe_l = _a(np.asarray(pe).reshape(m.n_lambda, m.n_cells + 1)[lam - 1], np.float64)
+        per_chunk = np.zeros(n_chunks, np.uint64)
+        ms = C.c_double()
+        self._chk(self.lib.mcgpu_run_mono(
+            self.ctx, C.byref(o), C.c_double(float(m.frac_E_stars[lam - 1])), C.c_double(float(m.frac_E_disk[lam - 1])),
+            _p(pe_l, C.c_double) if pe_l is not None else None, _p(per_chunk, C.c_uint64), C.byref(ms)),
+            "mcgpu_run_mono")
+        out = self.fetch()
+        out["n_sent_chunk"] = per_chunk
+        out["kernel_ms"] = ms.value
+        if rt1 and fetch_xI:
+            x64 = np.zeros(self.xI_shape(), np.float64)
+            x32 = np.zeros(self.xI_shape(), np.float32)
+            self._chk(self.lib.mcgpu_fetch_xI(self.ctx, _p(x32, C.c_float), _p(x64, C.c_double)), "mcgpu_fetch_xI")
+            out["xI_scatt"], out["xI_scatt_f32"] = x64, x32
+        return out
 
     def probe_cross_voronoi(self, x0, y0, z0, u, v, w, cell, previous_cell):
         n = len(cell)

@@ -90,6 +90,19 @@ class DiskConfig:
     l_sym_axiale: bool = True
     # synthetic dust family: "silicate" (ref4.1-like mix) or "pascucci"
     dust: str = "silicate"
+    # SED Monte Carlo + ray-tracing directions (ref4.1.para:5,19-20; read_param.f90:145-149,180-184)
+    n_photons_loop: int = 128
+    RT_imin: float = 0.0
+    RT_imax: float = 45.0
+    RT_n_incl: int = 3
+    lRT_i_centered: bool = False
+    RT_az_min: float = 0.0
+    RT_az_max: float = 0.0
+    RT_n_az: int = 1
+    lsepar_contrib: bool = True
+    capt_interet: int = 1
+    delta_capt: int = 1
+    distance: float = 140.0
 
 
 def ref41() -> DiskConfig:
@@ -500,6 +513,15 @@ class Model:
     p_lambda_fixed: int = 1
     midplane_snap: int = 1  # engine default (include/mcgpu.h: mcgpu_set_midplane_snap)
     extra: dict = field(default_factory=dict)
+    # SED mode (ray-tracing method 1): tab_s11_pos(0:nang, n_lambda) and the observer directions
+    tab_s11_pos: Optional[np.ndarray] = None
+    rt: Optional[dict] = None
+    prob_E_cell: Optional[np.ndarray] = None
+
+    @property
+    def capt_sup(self):
+        """read_param.f90:184"""
+        return min(self.cfg.N_thet, self.cfg.capt_interet + self.cfg.delta_capt)
 
     @property
     def n_cells(self):
@@ -512,6 +534,85 @@ class Model:
     def L_packet_th(self, n_packets_total: float) -> float:
         """thermal_emission.f90:355-356."""
         return self.L_tot / float(n_packets_total)
+
+
+def init_directions_ray_tracing(cfg: DiskConfig, l3D: bool):
+    """Observer directions of the ray-tracing (dust_ray_tracing.f90:234-300), the layout of
+    xI_scatt (:91-98, :152) and N_type_flux (init_mcfost.f90:1603-1616)."""
+    deg = PI / 180.0
+    ni, na = cfg.RT_n_incl, cfg.RT_n_az
+    incl = np.zeros(ni, f32)
+    if ni == 1:
+        incl[0] = cfg.RT_imin
+    else:
+        cmin, cmax = math.cos(float(f32(cfg.RT_imin)) * deg), math.cos(float(f32(cfg.RT_imax)) * deg)
+        for i in range(1, ni + 1):
+            if cfg.lRT_i_centered:
+                fr = float(f32(f32(i) - f32(0.5)) / f32(ni))
+            else:
+                fr = float(f32(f32(i) - f32(1)) / f32(f32(ni) - f32(1)))
+            incl[i - 1] = math.acos(cmin + fr * (cmax - cmin)) / deg
+    az = np.zeros(na, f32)
+    if na == 1:
+        az[0] = cfg.RT_az_min
+    else:
+        for i in range(1, na + 1):
+            az[i - 1] = f32(cfg.RT_az_min) + f32(f32(i) - f32(1)) / f32(f32(na) - f32(1)) * f32(cfg.RT_az_max - cfg.RT_az_min)
+    uv = np.zeros(ni, f64)
+    w = np.zeros(ni, f64)
+    for i in range(ni):
+        if abs(float(incl[i])) > 1e-20:
+            uv[i] = math.sin(float(incl[i]) * deg)
+            w[i] = math.cos(float(incl[i]) * deg)
+        else:
+            uv[i] = math.copysign(float(f32(1e-20)), float(incl[i]))
+            w[i] = 1.0
+    u = np.zeros((na, ni), f64)  # Fortran (RT_n_incl, RT_n_az): ibin fastest
+    v = np.zeros((na, ni), f64)
+    for i in range(ni):
+        for a in range(na):
+            u[a, i] = uv[i] * math.sin(float(az[a]) * deg)
+            v[a, i] = -uv[i] * math.cos(float(az[a]) * deg)
+    if cfg.lsepar_pola and cfg.aniso_method == 1:
+        ntf = 8 if cfg.lsepar_contrib else 4
+    else:
+        ntf = 5 if cfg.lsepar_contrib else 1
+    return dict(RT_n_incl=ni, RT_n_az=na, tab_RT_incl=incl, tab_RT_az=az, tab_u_rt=u.reshape(-1),
+                tab_v_rt=v.reshape(-1), tab_w_rt=w, n_az_rt=1 if l3D else 45, n_theta_rt=1 if l3D else 2,
+                N_type_flux=ntf, lsepar_contrib=int(cfg.lsepar_contrib))
+
+
+def repartition_energie(m: "Model", Tdust):
+    """thermal_emission.f90:1771-1949 for every wavelength (LTE grains, no ISM field, no
+    emission weights): fills ``frac_E_stars``, ``frac_E_disk`` and ``prob_E_cell`` of the model
+    for the SED step from the dust temperature of the thermal step."""
+    cst_wl_max = math.log(float(np.finfo(f32).max)) - 1.0e-4
+    nl, nc = m.n_lambda, m.n_cells
+    Td = np.asarray(Tdust, f64)
+    dark = np.zeros(nc, bool) if m.l_dark_zone is None else (np.asarray(m.l_dark_zone) != 0)
+    pe = np.zeros((nl, nc + 1), f64)
+    fs = np.zeros(nl, f64)
+    fd = np.zeros(nl, f64)
+    vol = np.asarray(m.grid["volume"], f64)
+    for l in range(nl):
+        wl = m.lam[l] * 1.0e-6
+        E_cell = np.zeros(nc, f64)
+        ok = (~dark) & (Td >= TINY_REAL)
+        cst = np.full(nc, np.inf)
+        cst[ok] = THERMAL_CONST / (Td[ok] * wl)
+        ok &= cst < cst_wl_max
+        E_cell[ok] = 4.0 * m.kappa_abs_LTE[l] * m.kappa_factor[ok] * vol[ok] / ((wl ** 5) * (np.exp(cst[ok]) - 1.0))
+        E_disk = float(np.sum(E_cell))
+        E_star = float(m.E_stars[l])
+        fs[l] = E_star / (E_star + E_disk)
+        fd[l] = 1.0  # (E_star + E_disk) / (E_star + E_disk + E_ISM), E_ISM = 0
+        pe[l, 1:] = np.cumsum(E_cell)
+        if pe[l, nc] > TINY_DP:
+            pe[l] /= pe[l, nc]
+        else:
+            pe[l] = 0.0
+    m.frac_E_stars, m.frac_E_disk, m.prob_E_cell = fs, fd, pe.reshape(-1)
+    return m
 
 
 def star_cell(grid, x, y, z):
@@ -546,6 +647,7 @@ def build_model(cfg: DiskConfig, grid=None, rho=None) -> Model:
     kappa_abs = kappa * (1.0 - d["albedo"])
     na1 = NANG_SCATT + 1
     prob = np.zeros((cfg.n_lambda, na1), f32)
+    tab_s11 = np.zeros((cfg.n_lambda, na1), f32)
     dtheta = PI / NANG_SCATT
     th = np.arange(na1) * dtheta
     for l in range(cfg.n_lambda):
@@ -554,6 +656,7 @@ def build_model(cfg: DiskConfig, grid=None, rho=None) -> Model:
         norm = float(np.sum(d["s11"][l][1:NANG_SCATT] * np.sin(th[1:NANG_SCATT]) * dtheta))
         s11n = d["s11"][l] * (k_sca / norm) * 0.97  # 3 % unresolved forward peak -> bin 1
         prob[l] = scattering_cdf(s11n, k_sca)
+        tab_s11[l] = (s11n * dtheta / (k_sca * 2.0 * PI)).astype(f32)  # dust_prop.f90:1172
 
     log_Qcool, cdf = init_reemission(lam, dlam, tab_Temp, kappa_abs)
 
@@ -584,6 +687,7 @@ def build_model(cfg: DiskConfig, grid=None, rho=None) -> Model:
         frac_E_stars=np.ones(cfg.n_lambda, f64), frac_E_disk=np.ones(cfg.n_lambda, f64),
         CDF_E_star=CDF_E_star.reshape(-1), E_stars=E_stars, L_tot=L_tot, stars=stars,
         rho_dust=rho, extra=dict(icell_ref=icell_ref + 1, rho0=rho0),
+        tab_s11_pos=tab_s11, rt=init_directions_ray_tracing(cfg, bool(grid["l3D"])),
     )
 
 

@@ -89,7 +89,16 @@ class _Model(C.Structure):
         ("v_first", _ip), ("v_last", _ip), ("v_neigh", _ip), ("v_was_cut", _up),
         ("v_is_star_neighbour", _up), ("v_walls", _fp), ("v_cut_o_h", C.c_double),
         ("v_wall_first", _ip), ("v_wall_cells", _ip),
+        ("RT_n_incl", C.c_int), ("RT_n_az", C.c_int), ("tab_u_rt", _dp), ("tab_v_rt", _dp),
+        ("tab_w_rt", _dp), ("n_az_rt", C.c_int), ("n_theta_rt", C.c_int), ("N_type_flux", C.c_int),
+        ("lsepar_contrib", C.c_int), ("tab_s11_pos", _fp),
     ]
+
+
+class _MonoOpts(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("lambda_", C.c_int), ("p_lambda", C.c_int), ("n_chunks", C.c_int),
+                ("n_photons2", C.c_double), ("n_phot_lim", C.c_double), ("capt_sup", C.c_int),
+                ("rt1", C.c_int), ("n_threads", C.c_int)]
 
 
 class _Opts(C.Structure):
@@ -190,7 +199,44 @@ class Oracle:
         s.N_thet, s.N_phi = cfg.N_thet, cfg.N_phi
         s.l_sym_centrale, s.l_sym_axiale = int(cfg.l_sym_centrale), int(cfg.l_sym_axiale)
         s.midplane_snap = int(getattr(m, "midplane_snap", 0))
+        rt = getattr(m, "rt", None)
+        if rt is not None:
+            s.RT_n_incl, s.RT_n_az = int(rt["RT_n_incl"]), int(rt["RT_n_az"])
+            for k in ("tab_u_rt", "tab_v_rt", "tab_w_rt"):
+                setattr(s, k, self._hold(_a(rt[k], np.float64), C.c_double))
+            s.n_az_rt, s.n_theta_rt = int(rt["n_az_rt"]), int(rt["n_theta_rt"])
+            s.N_type_flux, s.lsepar_contrib = int(rt["N_type_flux"]), int(rt["lsepar_contrib"])
+            s.tab_s11_pos = self._hold(_a(m.tab_s11_pos, np.float32), C.c_float)
         return s
+
+    def xI_shape(self):
+        """xI_scatt(n_az_rt, n_theta_rt, N_type_flux, RT_n_incl*RT_n_az, n_cells), C order reversed"""
+        rt = self.model.rt
+        return (self.model.n_cells, rt["RT_n_incl"] * rt["RT_n_az"], rt["N_type_flux"], rt["n_theta_rt"],
+                rt["n_az_rt"])
+
+    def run_mono(self, lam, n_photons2, n_phot_lim=None, p_lambda=None, seed=1, n_chunks=None,
+                 rt1=True, n_threads=1):
+        """One wavelength (1-based ``lam``) of the SED Monte Carlo."""
+        m = self.model
+        nl, nt, nphi = m.n_lambda, m.cfg.N_thet, m.cfg.N_phi
+        n_chunks = int(n_chunks or m.cfg.n_photons_loop)
+        if n_phot_lim is None:  # read_param.f90:551
+            n_phot_lim = float(np.float32(1.0e4) * np.float32(nt) * np.float32(nphi) * np.float32(n_photons2))
+        o = _MonoOpts(seed, int(lam), int(p_lambda or lam), n_chunks, float(n_photons2), float(n_phot_lim),
+                      int(m.capt_sup), int(rt1), n_threads)
+        xI = np.zeros(self.xI_shape() if rt1 else (1,), np.float64)
+        sed = np.zeros((N_SED_TYPES, nphi, nt, nl), np.float64)
+        n_sent = np.zeros(nl, np.float64)
+        per_chunk = np.zeros(n_chunks, np.uint64)
+        cnt = np.zeros(N_COUNTERS, np.uint64)
+        self.lib.oracle_run_mono.restype = C.c_int
+        rc = self.lib.oracle_run_mono(C.byref(self.cm), C.byref(o), _p(xI, C.c_double), _p(sed, C.c_double),
+                                      _p(n_sent, C.c_double), _p(per_chunk, C.c_uint64), _p(cnt, C.c_uint64))
+        if rc:
+            raise RuntimeError(f"oracle_run_mono failed: {rc}")
+        return dict(xI_scatt=xI, sed=sed, n_sent=n_sent, n_sent_chunk=per_chunk,
+                    counters=dict(zip(COUNTER_NAMES, (int(c) for c in cnt))))
 
     # -- packet loop -------------------------------------------------------
     def run_thermal(self, n_packets, seed=1, first_packet=0, n_threads=1, frozen=False,

@@ -1046,6 +1046,7 @@ void oracle_temp_finale(const oracle_model *m, const double *E_abs,
 /* ------------------------------------------------------------------------ */
 /* Packet loop                                                               */
 /* ------------------------------------------------------------------------ */
+#define ORACLE_MAX_RT 64
 typedef struct {
   const oracle_model *m;
   const oracle_opts *o;
@@ -1057,12 +1058,119 @@ typedef struct {
   uint64_t cnt[ORACLE_N_COUNTERS];
   double qscale;   /* nb_proc * n_replicas */
   rng_t rng;
+  /* SED mode (lmono): NULL in the thermal step */
+  const oracle_mono_opts *mono;
+  double *xI;          /* shared xI_scatt (atomic adds) */
+  int itheta_rt1[ORACLE_MAX_RT];      /* dust_ray_tracing.f90:39 */
+  double cos_omega_rt1[ORACLE_MAX_RT], sin_omega_rt1[ORACLE_MAX_RT]; /* :40 */
 } __attribute__((aligned(256))) worker_t; /* one cache-line group per thread: no false sharing */
+
+/* angles_scatt_rt1 (dust_ray_tracing.f90:409-476) */
+static void angles_scatt_rt1(worker_t *W, double u, double v, double w) {
+  const oracle_model *m = W->m;
+  for (int ibin = 1; ibin <= m->RT_n_incl; ++ibin)
+    for (int iaz = 1; iaz <= m->RT_n_az; ++iaz) {
+      const int q = (ibin - 1) + m->RT_n_incl * (iaz - 1);
+      const double ur = m->tab_u_rt[q], vr = m->tab_v_rt[q], wr = m->tab_w_rt[ibin - 1];
+      const float cos_scatt = (float)(ur * u + vr * v + wr * w);
+      /* nint(acos(cos_scatt) * real(nang_scatt)/pi): default-real acos and product, then / pi in
+       * dp.  The default-real acos is taken as the correctly rounded one ((float)acos(double)) so
+       * that every libm gives the same index; |cos_scatt| > 1 by rounding gives NaN, which the
+       * reference's nint turns into a value < 1, i.e. k = 1. */
+      const float ac = (float)acos((double)cos_scatt);
+      int k;
+      if (ac != ac) k = 1;
+      else k = (int)lround((double)(ac * (float)m->nang_scatt) / PI);
+      if (k > m->nang_scatt) k = m->nang_scatt;
+      if (k < 1) k = 1;
+      W->itheta_rt1[q] = k;
+      if (m->lsepar_pola) {
+        double v1pi, v1pj, v1pk;
+        oracle_rotation(u, v, w, -ur, -vr, -wr, &v1pi, &v1pj, &v1pk);
+        double xnyp = sqrt(v1pk * v1pk + v1pj * v1pj), costhet;
+        if (xnyp < 1e-10) { xnyp = 0.0; costhet = 1.0; }
+        else costhet = -1.0 * v1pj / xnyp;
+        double theta = acos(costhet);
+        if (theta >= PI) theta = 0.0;
+        theta = theta + PI / 2;
+        double omega = 2.0 * theta;
+        if (v1pk < 0.0) omega = -1.0 * omega;
+        double cosw = cos(omega), sinw = sin(omega);
+        if (fabs(cosw) < 1e-06) cosw = 0.0;
+        if (fabs(sinw) < 1e-06) sinw = 0.0;
+        W->cos_omega_rt1[q] = cosw;
+        W->sin_omega_rt1[q] = sinw;
+      }
+    }
+}
+
+static inline void xI_add(worker_t *W, int phik, int psup, int type, int iRT, int icell, double v) {
+  const oracle_model *m = W->m;
+  const size_t idx = (size_t)(phik - 1) + (size_t)m->n_az_rt * ((psup - 1) + (size_t)m->n_theta_rt * ((type - 1) +
+                     (size_t)m->N_type_flux * ((iRT - 1) + (size_t)(m->RT_n_incl * m->RT_n_az) * (size_t)(icell - 1))));
+#ifdef _OPENMP
+#pragma omp atomic
+#endif
+  W->xI[idx] += v;
+}
+
+/* save_radiation_field, lscatt_ray_tracing1 branch (radiation_field.f90:63-89) with
+ * calc_xI_scatt (dust_ray_tracing.f90:480-529) / calc_xI_scatt_pola (:533-632) */
+static void save_radiation_field_rt1(worker_t *W, int icell, const double Stokes[4], double l,
+                                     double x0, double y0, double z0, double x1, double y1, double z1,
+                                     int flag_star) {
+  const oracle_model *m = W->m;
+  const int p_lambda = W->mono->p_lambda;
+  const double xm = 0.5 * (x0 + x1), ym = 0.5 * (y0 + y1), zm = 0.5 * (z0 + z1);
+  int phik, psup;
+  if (m->l3D) { phik = 1; psup = 1; }
+  else {
+    const double phi_pos = atan2(xm, ym);
+    phik = (int)floor(modulo_d(phi_pos, 2 * PI) / (2 * PI) * (double)m->n_az_rt) + 1;
+    if (phik > m->n_az_rt) phik = m->n_az_rt;
+    psup = (zm > 0.0) ? 1 : 2;
+  }
+  const size_t na1 = (size_t)m->nang_scatt + 1, col = na1 * (size_t)(p_lambda - 1);
+  for (int ibin = 1; ibin <= m->RT_n_incl; ++ibin)
+    for (int iaz = 1; iaz <= m->RT_n_az; ++iaz) {
+      const int q = (ibin - 1) + m->RT_n_incl * (iaz - 1), iRT = q + 1; /* RT2d_to_RT1d (:66-76) */
+      const int it = W->itheta_rt1[q];
+      const float s11 = m->tab_s11_pos[col + it];
+      if (!m->lsepar_pola) {
+        const double flux = l * Stokes[0] * (double)s11;
+        xI_add(W, phik, psup, 1, iRT, icell, flux);
+        if (m->lsepar_contrib) xI_add(W, phik, psup, flag_star ? 3 : 5, iRT, icell, flux); /* n_Stokes = 1 */
+        continue;
+      }
+      const float s12 = -s11 * m->s12_o_s11[col + it], s22 = s11 * m->s22_o_s11[col + it];
+      const float s33 = -s11 * m->s33_o_s11[col + it], s34 = -s11 * m->s34_o_s11[col + it];
+      const float s44 = -s11 * m->s44_o_s11[col + it];
+      const double cosw = W->cos_omega_rt1[q], sinw = W->sin_omega_rt1[q];
+      /* C = ROP * Stokes, ROP(2:3,2:3) = [[cosw, -sinw], [sinw, cosw]] */
+      const double C1 = Stokes[0], C4 = Stokes[3];
+      const double C2 = cosw * Stokes[1] + (-sinw) * Stokes[2];
+      const double C3 = sinw * Stokes[1] + cosw * Stokes[2];
+      /* D = M * C */
+      const double D1 = (double)s11 * C1 + (double)s12 * C2;
+      const double D2 = (double)s12 * C1 + (double)s22 * C2;
+      const double D3 = (double)s33 * C3 + (double)(-s34) * C4;
+      const double D4 = (double)s34 * C3 + (double)s44 * C4;
+      /* S = RPO * D, RPO(2:3,2:3) = [[-cosw, -sinw], [-sinw, cosw]] */
+      const double S1 = D1, S4 = D4;
+      const double S2 = (-cosw) * D2 + (-sinw) * D3;
+      const double S3 = (-sinw) * D2 + cosw * D3;
+      xI_add(W, phik, psup, 1, iRT, icell, l * S1);
+      xI_add(W, phik, psup, 2, iRT, icell, l * S2);
+      xI_add(W, phik, psup, 3, iRT, icell, l * S3);
+      xI_add(W, phik, psup, 4, iRT, icell, l * S4);
+      if (m->lsepar_contrib) xI_add(W, phik, psup, flag_star ? 6 : 8, iRT, icell, l * S1);
+    }
+}
 
 /* physical_length (optical_depth.f90:21-182), letape_th branch only */
 static void physical_length(worker_t *W, int lambda, const double Stokes[4],
                             int *icell, double *xio, double *yio, double *zio,
-                            double *u, double *v, double *w, double extrin,
+                            double *u, double *v, double *w, int flag_star, double extrin,
                             int *flag_sortie, int *lpacket_alive) {
   const oracle_model *m = W->m;
   double x0 = *xio, y0 = *yio, z0 = *zio, x1 = *xio, y1 = *yio, z1 = *zio;
@@ -1072,6 +1180,7 @@ static void physical_length(worker_t *W, int lambda, const double Stokes[4],
   int lintersect_stars, i_star, icell_star, lstop = 0, lcell_not_empty;
   *flag_sortie = 0;
   W->cnt[ORC_CNT_FLIGHTS]++;
+  if (W->mono && W->mono->rt1) angles_scatt_rt1(W, *u, *v, *w);   /* :65 */
 
   oracle_intersect_stars(m, x0, y0, z0, *u, *v, *w, &lintersect_stars, &i_star,
                          &icell_star);                              /* :68 */
@@ -1123,9 +1232,13 @@ static void physical_length(worker_t *W, int lambda, const double Stokes[4],
     } else {
       extr = extr - tau;
     }
-    /* save_radiation_field, thermal step (radiation_field.f90:53) */
-    if (lcell_not_empty)
-      W->E_abs[icell0 - 1] += m->kappa_abs_LTE[lambda - 1] * l_contrib * Stokes[0];
+    /* save_radiation_field (radiation_field.f90:31-135): thermal step :53, SED mode :63-89 */
+    if (lcell_not_empty) {
+      if (!W->mono)
+        W->E_abs[icell0 - 1] += m->kappa_abs_LTE[lambda - 1] * l_contrib * Stokes[0];
+      else if (W->mono->rt1)
+        save_radiation_field_rt1(W, icell0, Stokes, l_contrib, x0, y0, z0, x1, y1, z1, flag_star);
+    }
     if (lstop) {                                                    /* :153 */
       *flag_sortie = 0;
       *xio = x0 + l * (*u);
@@ -1227,12 +1340,23 @@ static void propagate_packet(worker_t *W, int *lambda, int p_lambda,
       if (rand > 1.0e-6f) tau = -log(1.0 - (double)rand);
       else tau = (double)rand;
     }
-    physical_length(W, *lambda, Stokes, icell, x, y, z, u, v, w, tau,
+    physical_length(W, *lambda, Stokes, icell, x, y, z, u, v, w, *flag_star, tau,
                     &flag_sortie, lpacket_alive);             /* :1243 */
     if (flag_sortie) return;                                  /* :1251 */
 
     rng_begin_event(&W->rng);
     rand = rng_float(&W->rng);                                /* :1280 */
+    if (W->mono) { /* forced scattering (:1263-1278); the draw above is not used */
+      if (m->l_dark_zone && m->l_dark_zone[*icell - 1]) { W->cnt[ORC_CNT_ABS]++; *lpacket_alive = 0; return; }
+      const double alb = (double)m->albedo[*lambda - 1];
+      Stokes[0] *= alb; Stokes[1] *= alb; Stokes[2] *= alb; Stokes[3] *= alb;
+      if (Stokes[0] < (double)(FLT_MIN * 1.0e6f)) { /* tiny_real_x1e6 */
+        W->cnt[ORC_CNT_ABS]++; /* SED mode: "absorptions" counts the packets dropped here */
+        *lpacket_alive = 0;
+        return;
+      }
+      rand = -1.0f;
+    }
     if (rand < m->albedo[*lambda - 1]) {                      /* :1284 */
       *flag_scatt = 1;
       W->cnt[ORC_CNT_SCATT]++;
@@ -1240,7 +1364,7 @@ static void propagate_packet(worker_t *W, int *lambda, int p_lambda,
       float rand2 = rng_float(&W->rng);
       int itheta; double cospsi, u1, v1, w1;
       if (m->aniso_method == 1) {
-        int pl = m->p_lambda_fixed ? p_lambda : *lambda;
+        int pl = (W->mono || m->p_lambda_fixed) ? p_lambda : *lambda;
         oracle_angle_diff_theta_pos(m, pl, rand, rand2, &itheta, &cospsi);
         if (m->lisotropic) { itheta = 1; cospsi = 2.0 * (double)rand - 1.0; }
         rand = rng_float(&W->rng);
@@ -1273,9 +1397,9 @@ static void propagate_packet(worker_t *W, int *lambda, int p_lambda,
 }
 
 /* capteur, SED branch (output.f90:294-397, 572-592) */
-static void capteur(worker_t *W, int lambda, double uin, double vin,
-                    double win, const double stokin[4], int flag_star,
-                    int flag_scatt) {
+static int capteur(worker_t *W, int lambda, double uin, double vin,
+                   double win, const double stokin[4], int flag_star,
+                   int flag_scatt) {
   const oracle_model *m = W->m;
   double u1 = uin, v1 = vin, w1 = win;
   double stok[4] = {stokin[0], stokin[1], stokin[2], stokin[3]};
@@ -1284,7 +1408,7 @@ static void capteur(worker_t *W, int lambda, double uin, double vin,
       u1 = -u1; v1 = -v1; w1 = -w1;
       stok[2] = -stok[2];
     } else {
-      return;
+      return 0; /* capt is left undefined by the reference here (output.f90:339) */
     }
   }
   int capt = (int)((-1.0 * w1 + 1.0) * (double)m->N_thet) + 1;
@@ -1319,6 +1443,7 @@ static void capteur(worker_t *W, int lambda, double uin, double vin,
     else W->sed[7 * plane + idx] += stok[0];
   }
   W->cnt[ORC_CNT_ESCAPED]++;
+  return capt;
 }
 
 /* one packet of mc_photon_loop's body (dust_transfer.f90:529-552) */
@@ -1408,5 +1533,97 @@ int oracle_run_thermal(const oracle_model *m, const oracle_opts *o,
     for (int q = 0; q < ORACLE_N_COUNTERS; ++q) counters[q] += Ws[t].cnt[q];
   }
   free(E_t); free(xT_t); free(sed_t); free(ns_t); free(Ws);
+  return err;
+}
+
+/* ------------------------------------------------------------------------ */
+/* SED mode: one wavelength of run_sed_mc (dust_transfer.f90:828-1042)        */
+/* ------------------------------------------------------------------------ */
+/* one packet of mc_photon_loop's body with lmono (dust_transfer.f90:529-552);
+ * returns 1 when the packet was binned in capt_sup (:551) */
+static int one_packet_mono(worker_t *W, uint64_t packet, int *err) {
+  const oracle_model *m = W->m;
+  rng_init(&W->rng, W->o->seed, packet);
+  rng_begin_event(&W->rng);
+  W->cnt[ORC_CNT_PACKETS]++;
+  int lambda = W->mono->lambda, icell = 0, lintersect, flag_star, flag_ISM, flag_scatt = 0;
+  int alive = 1;
+  double x, y, z, u, v, w, Stokes[4];
+  (void)rng_float(&W->rng); /* the wavelength draw of the thermal step keeps its slot (lmono: :535) */
+  W->n_sent[lambda - 1] += 1.0;
+  int rc = emit_packet(W, lambda, &icell, &x, &y, &z, &u, &v, &w, Stokes, &flag_star, &flag_ISM, &lintersect);
+  if (rc) { *err = rc; return 0; }
+  if (lintersect)
+    propagate_packet(W, &lambda, W->mono->p_lambda, &icell, &x, &y, &z, &u, &v, &w, Stokes, &flag_star,
+                     &flag_ISM, &flag_scatt, &alive);
+  if (alive && !flag_ISM) {
+    const int capt = capteur(W, lambda, u, v, w, Stokes, flag_star, flag_scatt);
+    return capt == W->mono->capt_sup;
+  }
+  return 0;
+}
+
+int oracle_run_mono(const oracle_model *m, const oracle_mono_opts *o, double *xI_scatt,
+                    double *sed, double *n_sent, uint64_t *n_sent_chunk,
+                    uint64_t *counters) {
+  int nth = o->n_threads > 0 ? o->n_threads : 1;
+  if (o->lambda < 1 || o->lambda > m->n_lambda || o->p_lambda < 1 || o->n_chunks < 1) return 23;
+  if (o->rt1 && (m->RT_n_incl * m->RT_n_az > ORACLE_MAX_RT || m->RT_n_incl < 1 || !m->tab_s11_pos)) return 24;
+  const size_t nsed = (size_t)ORACLE_N_SED_TYPES * m->n_lambda * m->N_thet * m->N_phi;
+  const size_t nxI = o->rt1 ? (size_t)m->n_az_rt * m->n_theta_rt * m->N_type_flux * m->RT_n_incl * m->RT_n_az * (size_t)m->n_cells : 0;
+  double *sed_t = (double *)calloc(nsed * nth, sizeof(double));
+  double *ns_t = (double *)calloc((size_t)m->n_lambda * nth, sizeof(double));
+  worker_t *Ws = NULL;
+  if (posix_memalign((void **)&Ws, 256, (size_t)nth * sizeof(worker_t))) Ws = NULL;
+  if (!sed_t || !ns_t || !Ws) return 22;
+  memset(Ws, 0, (size_t)nth * sizeof(worker_t));
+  if (nxI) memset(xI_scatt, 0, nxI * sizeof(double));
+  oracle_opts base;
+  memset(&base, 0, sizeof(base));
+  base.seed = o->seed; base.n_threads = nth;
+  int err = 0;
+#ifdef _OPENMP
+#pragma omp parallel num_threads(nth)
+#endif
+  {
+    int tid = 0;
+#ifdef _OPENMP
+    tid = omp_get_thread_num();
+#endif
+    worker_t *W = &Ws[tid];
+    W->m = m; W->o = &base; W->mono = o; W->xI = xI_scatt;
+    W->sed = sed_t + nsed * tid;
+    W->n_sent = ns_t + (size_t)m->n_lambda * tid;
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 1)
+#endif
+    for (int ch = 0; ch < o->n_chunks; ++ch) { /* nnfot1 (:525) */
+      double n_phot_sed2 = 0.0, n_in_loop = 0.0;
+      uint64_t seq = 0;
+      while (n_phot_sed2 < o->n_photons2 && n_in_loop < o->n_phot_lim) { /* :530 */
+        n_in_loop += 1.0;
+        int e = 0;
+        if (one_packet_mono(W, ((uint64_t)ch << 40) | seq, &e)) n_phot_sed2 += 1.0;
+        if (e) {
+#ifdef _OPENMP
+#pragma omp atomic write
+#endif
+          err = e;
+          break;
+        }
+        ++seq;
+      }
+      n_sent_chunk[ch] = seq;
+    }
+  }
+  memset(sed, 0, nsed * sizeof(double));
+  memset(n_sent, 0, (size_t)m->n_lambda * sizeof(double));
+  memset(counters, 0, ORACLE_N_COUNTERS * sizeof(uint64_t));
+  for (int t = 0; t < nth; ++t) {
+    for (size_t q = 0; q < nsed; ++q) sed[q] += sed_t[nsed * t + q];
+    for (int q = 0; q < m->n_lambda; ++q) n_sent[q] += ns_t[(size_t)m->n_lambda * t + q];
+    for (int q = 0; q < ORACLE_N_COUNTERS; ++q) counters[q] += Ws[t].cnt[q];
+  }
+  free(sed_t); free(ns_t); free(Ws);
   return err;
 }

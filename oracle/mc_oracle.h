@@ -139,6 +139,16 @@ typedef struct {
   double v_cut_o_h;        /* PS%cutting_distance_o_h */
   const int *v_wall_first; /* [7] offsets (0-based) into v_wall_cells */
   const int *v_wall_cells; /* wall(iwall)%neighbour_list, concatenated */
+
+  /* ---- ray-tracing method 1 (dust_ray_tracing.f90:17-40, 80-160) ---- */
+  int RT_n_incl, RT_n_az;   /* observer directions */
+  const double *tab_u_rt;   /* (RT_n_incl, RT_n_az) */
+  const double *tab_v_rt;   /* (RT_n_incl, RT_n_az) */
+  const double *tab_w_rt;   /* [RT_n_incl] */
+  int n_az_rt, n_theta_rt;  /* 45, 2 in 2D; 1, 1 in 3D (:91-98) */
+  int N_type_flux;          /* init_mcfost.f90:1603-1616 */
+  int lsepar_contrib;
+  const float *tab_s11_pos; /* (0:nang_scatt, n_lambda): tab_s11_pos(:,1,p_lambda) */
 } oracle_model;
 
 /* Run options. */
@@ -183,6 +193,32 @@ void oracle_move_to_grid_cyl(const oracle_model *m, double *x, double *y,
 void oracle_pos_em_cell_cyl(const oracle_model *m, int icell, float rand1,
                             float rand2, float rand3, double *x, double *y,
                             double *z);
+
+/*
+ * One wavelength of the SED Monte Carlo (run_sed_mc, dust_transfer.f90:828-1042 ->
+ * mc_photon_loop with lmono and not lmono0): n_chunks = n_photons_loop sequential
+ * streams; a stream sends packets until n_photons2 of them were binned in
+ * inclination bin capt_sup or n_phot_lim were sent (:526).
+ */
+typedef struct {
+  uint64_t seed;
+  int lambda, p_lambda;
+  int n_chunks;        /* n_photons_loop */
+  double n_photons2;   /* n_photons_lambda */
+  double n_phot_lim;   /* n_photons_lim */
+  int capt_sup;
+  int rt1;             /* lscatt_ray_tracing1: deposit xI_scatt */
+  int n_threads;
+} oracle_mono_opts;
+
+/* xI_scatt(n_az_rt, n_theta_rt, N_type_flux, RT_n_incl*RT_n_az, n_cells) summed over
+ * threads (FP64 here; the reference keeps default real per thread); sed/n_sent as in
+ * oracle_run_thermal (only the lambda slice is touched); n_sent_chunk[n_chunks] =
+ * packets each stream sent.  Packet (chunk c, sequence s) uses the random stream
+ * of id (c << 40) | s. */
+int oracle_run_mono(const oracle_model *m, const oracle_mono_opts *o, double *xI_scatt,
+                    double *sed, double *n_sent, uint64_t *n_sent_chunk,
+                    uint64_t *counters);
 
 /* Voronoi grid operators (Voronoi.f90). */
 void oracle_cross_voronoi_cell(const oracle_model *m, double x, double y,

@@ -64,6 +64,7 @@ namespace mcgpu { double lds_raw[1 << 18]; }
 #include "../../mcfost_amd/csrc/mc_device.hip.h"
 #include "../../mcfost_amd/csrc/mc_rounds.hip.h"
 #include "../../mcfost_amd/csrc/mc_voronoi.hip.h"
+#include "../../mcfost_amd/csrc/mc_mono.hip.h"
 #include "../../oracle/mc_oracle.h"
 
 using namespace mcgpu;
@@ -205,6 +206,113 @@ extern "C" int emu_run_thermal(const oracle_model* m, const oracle_opts* o, cons
     if (pola) { if (dark) RUN(false, true, true); else RUN(false, true, false); }
     else { if (dark) RUN(false, false, true); else RUN(false, false, false); }
   }
+  for (int q = 0; q < 8; ++q) counters[q] = cnt[q];
+  return err;
+}
+
+
+// ---- SED mode: the host orchestration of mcgpu_run_mono with one emulated lane --------------
+extern "C" int emu_run_mono(const oracle_model* m, const oracle_mono_opts* o, double* xI, double* sed, double* n_sent,
+                            uint64_t* n_sent_chunk, uint64_t* counters) {
+  if (m->grid_type == 3) return 41;
+  DevModel M;
+  memset(&M, 0, sizeof(M));
+  M.n_rad = m->n_rad; M.nz = m->nz; M.n_az = m->n_az; M.l3D = m->l3D; M.n_cells = m->n_cells;
+  M.r_lim_2 = m->r_lim_2; M.zmax = m->zmax; M.tan_phi_lim = m->tan_phi_lim;
+  std::vector<double> ch(m->n_rad);
+  for (int i = 0; i < m->n_rad; ++i) ch[i] = m->nz >= 2 ? m->z_lim[i + m->n_rad] : m->zmax[i];
+  M.ch = ch.data();
+  M.zmaxmax = m->zmaxmax; M.Rmax2 = m->Rmax2; M.volume = m->volume;
+  M.n_stars = m->n_stars;
+  std::vector<double> sx(4 * m->n_stars);
+  std::vector<int> sc(4 * m->n_stars);
+  for (int s = 0; s < m->n_stars; ++s) {
+    sx[4 * s] = m->stars[s].x; sx[4 * s + 1] = m->stars[s].y; sx[4 * s + 2] = m->stars[s].z; sx[4 * s + 3] = m->stars[s].r;
+    int ic = m->stars[s].icell;
+    sc[4 * s] = m->cell_map_i[ic - 1]; sc[4 * s + 1] = m->cell_map_j[ic - 1]; sc[4 * s + 2] = m->cell_map_k[ic - 1];
+    sc[4 * s + 3] = m->stars[s].out_model;
+  }
+  M.star_xyzr = sx.data(); M.star_cell = sc.data();
+  M.n_lambda = m->n_lambda; M.kappa = m->kappa; M.kappa_abs = m->kappa_abs_LTE; M.albedo = m->albedo;
+  M.kappa_factor = m->kappa_factor;
+  bool any_dark = false;
+  if (m->l_dark_zone) for (int i = 0; i < m->n_cells; ++i) any_dark |= m->l_dark_zone[i] != 0;
+  M.dark = any_dark ? m->l_dark_zone : nullptr;
+  M.nang = m->nang_scatt; M.aniso_method = m->aniso_method; M.lisotropic = m->lisotropic;
+  M.p_lambda_fixed = m->p_lambda_fixed;
+  M.prob_s11 = m->prob_s11_pos; M.s12 = m->s12_o_s11; M.s22 = m->s22_o_s11; M.s33 = m->s33_o_s11;
+  M.s34 = m->s34_o_s11; M.s44 = m->s44_o_s11; M.tab_g = m->tab_g_pos;
+  std::vector<double> ct(m->nang_scatt + 1);
+  for (int k = 0; k <= m->nang_scatt; ++k) ct[k] = std::cos(((double)k) * PI / (double)m->nang_scatt);
+  M.cos_tab = ct.data();
+  M.n_T = m->n_T; M.log_Qcool = m->log_Qcool; M.cdf = m->kdB_dT_CDF; M.spec_cum = m->spectre_emission_cumul;
+  M.frac_E_stars = m->frac_E_stars; M.frac_E_disk = m->frac_E_disk; M.CDF_E_star = m->CDF_E_star;
+  M.prob_E_cell = m->prob_E_cell; M.L_packet_th = m->L_packet_th;
+  M.N_thet = m->N_thet; M.N_phi = m->N_phi; M.sym_c = m->l_sym_centrale; M.sym_a = m->l_sym_axiale;
+  M.midplane_snap = m->midplane_snap;
+
+  const size_t nsed = (size_t)9 * m->n_lambda * m->N_thet * m->N_phi;
+  const int nRT = m->RT_n_incl * m->RT_n_az;
+  const size_t nxI = o->rt1 ? (size_t)m->n_az_rt * m->n_theta_rt * m->N_type_flux * nRT * (size_t)m->n_cells : 0;
+  memset(sed, 0, sizeof(double) * nsed);
+  memset(n_sent, 0, sizeof(double) * m->n_lambda);
+  if (nxI) memset(xI, 0, sizeof(double) * nxI);
+  unsigned long long cnt[16];
+  memset(cnt, 0, sizeof(cnt));
+  int err = 0;
+  const bool pola = m->lsepar_pola && m->aniso_method == 1, dark = M.dark != nullptr, l3d = m->l3D != 0;
+  MonoArgs A;
+  memset(&A, 0, sizeof(A));
+  A.seed = o->seed; A.lambda = o->lambda; A.p_lambda = o->p_lambda; A.capt_sup = o->capt_sup; A.rt1 = o->rt1;
+  A.frac_E_stars = m->frac_E_stars[o->lambda - 1]; A.frac_E_disk = m->frac_E_disk[o->lambda - 1];
+  A.prob_E_cell = m->prob_E_cell ? m->prob_E_cell + (size_t)(m->n_cells + 1) * (o->lambda - 1) : nullptr;
+  A.n_chunks = o->n_chunks;
+  A.RT_n_incl = m->RT_n_incl > 0 ? m->RT_n_incl : 1; A.nRT = o->rt1 ? nRT : 0;
+  A.rt_u = m->tab_u_rt; A.rt_v = m->tab_v_rt; A.rt_w = m->tab_w_rt;
+  A.n_az_rt = m->n_az_rt; A.n_theta_rt = m->n_theta_rt; A.N_type_flux = m->N_type_flux; A.contrib = m->lsepar_contrib;
+  A.s11 = m->tab_s11_pos ? m->tab_s11_pos + (size_t)(m->nang_scatt + 1) * (o->p_lambda - 1) : nullptr;
+  A.xI = xI; A.sed = sed; A.n_sent = n_sent; A.counters = cnt; A.next_item = cnt + 8; A.err = &err;
+  A.inner_iters = 8; A.min_active = 0;
+#define MONO(sc_) do {                                                                     \
+    if (l3d) {                                                                            \
+      if (pola) { if (dark) k_mono<true, true, true, sc_>(M, A); else k_mono<true, true, false, sc_>(M, A); }      \
+      else { if (dark) k_mono<true, false, true, sc_>(M, A); else k_mono<true, false, false, sc_>(M, A); }         \
+    } else {                                                                              \
+      if (pola) { if (dark) k_mono<false, true, true, sc_>(M, A); else k_mono<false, true, false, sc_>(M, A); }    \
+      else { if (dark) k_mono<false, false, true, sc_>(M, A); else k_mono<false, false, false, sc_>(M, A); }       \
+    } } while (0)
+  const int nc = o->n_chunks;
+  const unsigned long long lim = (unsigned long long)std::ceil(o->n_phot_lim);
+  std::vector<unsigned long long> need(nc, (unsigned long long)o->n_photons2), sent(nc, 0ull), base(nc + 1, 0ull);
+  std::vector<int> active;
+  if (o->n_photons2 > 0 && lim > 0) for (int c = 0; c < nc; ++c) active.push_back(c);
+  while (!active.empty()) {
+    const int na = (int)active.size();
+    const unsigned long long batch = 64;  // small batches: several scout rounds per stream
+    std::vector<unsigned char> hits((size_t)na * batch, 0);
+    A.active = active.data(); A.seq0 = sent.data(); A.batch = batch; A.hits = hits.data(); A.n_items = (size_t)na * batch;
+    cnt[8] = 0;
+    MONO(true);
+    if (err) return err;
+    std::vector<int> still;
+    for (int a = 0; a < na; ++a) {  // what k_mono_scan does with one wave per stream
+      const int c = active[a];
+      unsigned long long usable = batch;
+      if (sent[c] + batch >= lim) usable = lim > sent[c] ? lim - sent[c] : 0;
+      unsigned long long s = 0;
+      bool fin = false;
+      for (; s < usable; ++s)
+        if (hits[(size_t)a * batch + s] && --need[c] == 0) { ++s; fin = true; break; }
+      if (!fin && usable < batch) { s = usable; fin = true; }
+      sent[c] += fin ? s : batch;
+      if (!fin) still.push_back(c);
+    }
+    active.swap(still);
+  }
+  for (int c = 0; c < nc; ++c) { base[c + 1] = base[c] + sent[c]; n_sent_chunk[c] = sent[c]; }
+  A.item_base = base.data(); A.n_items = base[nc]; A.active = nullptr; A.seq0 = nullptr; A.hits = nullptr; A.batch = 0;
+  cnt[8] = 0;
+  if (A.n_items) MONO(false);
   for (int q = 0; q < 8; ++q) counters[q] = cnt[q];
   return err;
 }

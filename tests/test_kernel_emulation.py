@@ -23,11 +23,12 @@ LIB = os.path.join(HERE, "emu", "libemu_kernel.so")
 DEV = os.path.join(os.path.dirname(HERE), "mcfost_amd", "csrc", "mc_device.hip.h")
 DEV2 = os.path.join(os.path.dirname(HERE), "mcfost_amd", "csrc", "mc_rounds.hip.h")
 DEV3 = os.path.join(os.path.dirname(HERE), "mcfost_amd", "csrc", "mc_voronoi.hip.h")
+DEV4 = os.path.join(os.path.dirname(HERE), "mcfost_amd", "csrc", "mc_mono.hip.h")
 
 
 @pytest.fixture(scope="module")
 def emu():
-    if (not os.path.exists(LIB)) or os.path.getmtime(LIB) < max(os.path.getmtime(SRC), os.path.getmtime(DEV), os.path.getmtime(DEV2), os.path.getmtime(DEV3)):
+    if (not os.path.exists(LIB)) or os.path.getmtime(LIB) < max(os.path.getmtime(SRC), os.path.getmtime(DEV), os.path.getmtime(DEV2), os.path.getmtime(DEV3), os.path.getmtime(DEV4)):
         fma = ["-mfma"] if "fma" in open("/proc/cpuinfo").read() else []
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=fast"] + fma +
                               ["-o", LIB, SRC])
@@ -163,3 +164,83 @@ def test_emulated_kernel_voronoi_star_outside_and_disk_emission(emu):
     m.prob_E_cell = pe.reshape(-1)
     m.frac_E_stars = np.full(m.n_lambda, 0.4)
     check(emu, m, 3000, 23, rtol=1e-6)
+
+
+def _sed_model(cfg):
+    """A model whose SED-step emission tables come from a thermal step, like run_sed_mc's."""
+    m = M.build_model(cfg)
+    orc = Oracle(m, 1e5)
+    T = orc.temp_finale(orc.run_thermal(100000, seed=3, n_threads=4)["E_abs"])
+    M.repartition_energie(m, T)
+    return m
+
+
+def emu_mono(emu, orc, lam, n2, seed, rt1=True, n_chunks=8, n_phot_lim=1e9):
+    from oracle.binding import _MonoOpts
+    m = orc.model
+    o = _MonoOpts(seed, lam, lam, n_chunks, float(n2), float(n_phot_lim), int(m.capt_sup), int(rt1), 1)
+    xI = np.zeros(orc.xI_shape() if rt1 else (1,))
+    sed = np.zeros((9, m.cfg.N_phi, m.cfg.N_thet, m.n_lambda))
+    ns = np.zeros(m.n_lambda)
+    per = np.zeros(n_chunks, np.uint64)
+    cnt = np.zeros(8, np.uint64)
+    rc = emu.emu_run_mono(C.byref(orc.cm), C.byref(o), _p(xI, C.c_double), _p(sed, C.c_double), _p(ns, C.c_double),
+                          _p(per, C.c_uint64), _p(cnt, C.c_uint64))
+    assert rc == 0, rc
+    return dict(xI_scatt=xI, sed=sed, n_sent=ns, n_sent_chunk=per, counters=[int(c) for c in cnt])
+
+
+def xI_close(xa, xb, rtol=1e-6, n_midplane_cells=0):
+    """xI_scatt of two runs of the same packets.  A path that crosses a midplane cell of a 2D grid from
+    its upper wall to the mirrored lower wall has its midpoint at z = +-rounding, so whether its deposit
+    counts as "above" or "below" (psup, radiation_field.f90:78-82) is rounding noise in any build of the
+    algorithm: the comparison is made on the sum of the two.  Likewise a deposit may (rarely) fall into the
+    neighbouring azimuth sub-bin when FMA-level drift moves a midpoint across a sub-bin edge."""
+    scale = np.abs(xb).max()
+    assert np.allclose(xa.sum(axis=(3, 4)), xb.sum(axis=(3, 4)), rtol=rtol, atol=1e-8 * scale)
+    sa, sb = xa.sum(axis=3), xb.sum(axis=3)
+    bad = np.abs(sa - sb) > rtol * np.abs(sb) + 1e-8 * scale
+    assert bad.sum() <= max(4, 2e-4 * np.count_nonzero(sb)), (bad.sum(), np.count_nonzero(sb))
+    if n_midplane_cells:  # away from the midplane layer (cells 1..n_rad of a 2D grid) psup itself must agree
+        ua, ub = xa[n_midplane_cells:], xb[n_midplane_cells:]
+        bad2 = np.abs(ua - ub) > rtol * np.abs(ub) + 1e-8 * scale
+        assert bad2.sum() <= max(4, 2e-4 * np.count_nonzero(ub)), (bad2.sum(), np.count_nonzero(ub))
+    return bad.sum()
+
+
+def check_mono(emu, m, lam, n2, seed, **kw):
+    orc = Oracle(m, 1e5)
+    a = emu_mono(emu, orc, lam, n2, seed, **kw)
+    b = orc.run_mono(lam, n2, seed=seed, n_chunks=kw.get("n_chunks", 8), n_phot_lim=kw.get("n_phot_lim", 1e9),
+                     rt1=kw.get("rt1", True), n_threads=4)
+    assert np.array_equal(a["n_sent_chunk"], b["n_sent_chunk"])       # every stream stops at the same packet
+    assert a["counters"] == list(b["counters"].values())
+    assert np.array_equal(a["n_sent"], b["n_sent"]) and np.array_equal(a["sed"][4], b["sed"][4])
+    for t in (0, 5, 6, 7, 8):   # weights: albedo**n_scatt (times the ulp-level renormalisation of update_Stokes)
+        assert np.allclose(a["sed"][t], b["sed"][t], rtol=1e-12, atol=1e-12)
+    # Q, U, V go through update_Stokes' default-real trigonometry (scattering.f90:1218): FMA-level noise
+    assert np.allclose(a["sed"][1:4], b["sed"][1:4], rtol=1e-5, atol=1e-6 * max(1.0, np.abs(b["sed"][0]).max()))
+    if kw.get("rt1", True):
+        xI_close(a["xI_scatt"], b["xI_scatt"], n_midplane_cells=0 if m.cfg.l3D else m.cfg.n_rad)
+    return a, b
+
+
+def test_emulated_sed_mode_2d(emu):
+    """SED mode (mc_mono.hip.h): scout + scan + commit against the oracle's sequential streams --
+    same stopping packet in every stream, same SED bins, same xI_scatt."""
+    m = _sed_model(M.small())
+    for lam in (3, 9, 14):  # star-dominated, mixed, disk-dominated emission
+        a, b = check_mono(emu, m, lam, 6, 40 + lam)
+        assert a["sed"][4][0, m.capt_sup - 1, lam - 1] == 8 * 6
+    a, b = check_mono(emu, m, 3, 1000, 5, n_phot_lim=150.0)   # n_phot_lim stops the streams
+    assert np.all(a["n_sent_chunk"] == 150)
+
+
+def test_emulated_sed_mode_variants(emu):
+    check_mono(emu, _sed_model(M.small(lsepar_pola=False)), 4, 5, 7)                    # N_type_flux = 5
+    check_mono(emu, _sed_model(M.small(lsepar_pola=False, lsepar_contrib=False)), 4, 5, 8)  # = 1
+    check_mono(emu, _sed_model(M.small(n_rad=10, nz=5, n_az=6, l3D=True)), 4, 5, 9)     # 3D: phik = psup = 1
+    check_mono(emu, _sed_model(M.small(aniso_method=2, lsepar_pola=False)), 4, 5, 10)   # HG
+    m = _sed_model(M.small(RT_n_incl=2, RT_n_az=3, RT_az_max=90.0, RT_imin=20.0, RT_imax=70.0))
+    check_mono(emu, m, 5, 5, 11)                                                        # several azimuths
+    check_mono(emu, _sed_model(M.small()), 4, 5, 12, rt1=False)                         # no ray-tracing deposits
