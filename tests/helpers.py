@@ -31,3 +31,35 @@ def mc_similar(x, y, threshold, mask_threshold=0.0):
 def rel_rms(T, Tref, T_floor):
     sel = Tref > T_floor
     return float(np.sqrt(np.mean(((T[sel] - Tref[sel]) / Tref[sel]) ** 2)))
+
+
+def sed_model(cfg, n_thermal=100000):
+    """A model whose SED-step emission tables (frac_E_stars, prob_E_cell) come from a thermal step of
+    the CPU oracle, like run_sed_mc's come from the temperature step."""
+    from mcfost_amd.host import model as M
+    from oracle import Oracle
+    m = M.build_model(cfg)
+    orc = Oracle(m, n_thermal)
+    T = orc.temp_finale(orc.run_thermal(n_thermal, seed=3, n_threads=4)["E_abs"])
+    M.repartition_energie(m, T)
+    return m
+
+
+def xI_close(xa, xb, rtol=1e-6, n_midplane_cells=0, atol_rel=1e-8):
+    """xI_scatt of two runs of the same packets.  A path that crosses a midplane cell of a 2D grid from
+    its upper wall to the mirrored lower wall has its midpoint at z = +-rounding, so whether its deposit
+    counts as "above" or "below" (psup, radiation_field.f90:78-82) is rounding noise in any build of the
+    algorithm: the comparison is made on the sum of the two.  Likewise a deposit may (rarely) fall into the
+    neighbouring azimuth sub-bin when FMA-level drift moves a midpoint across a sub-bin edge."""
+    scale = np.abs(xb).max()
+    assert np.allclose(xa.sum(axis=(3, 4)), xb.sum(axis=(3, 4)), rtol=rtol, atol=atol_rel * scale)
+    sa, sb = xa.sum(axis=3), xb.sum(axis=3)
+    bad = np.abs(sa - sb) > rtol * np.abs(sb) + atol_rel * scale
+    assert bad.sum() <= max(4, 2e-4 * np.count_nonzero(sb)), (bad.sum(), np.count_nonzero(sb))
+    if n_midplane_cells:  # away from the midplane layer (cells 1..n_rad of a 2D grid) psup itself must agree
+        ua, ub = xa[n_midplane_cells:], xb[n_midplane_cells:]
+        bad2 = np.abs(ua - ub) > rtol * np.abs(ub) + atol_rel * scale
+        assert bad2.sum() <= max(4, 2e-4 * np.count_nonzero(ub)), (bad2.sum(), np.count_nonzero(ub))
+    return bad.sum()
+
+

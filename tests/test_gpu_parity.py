@@ -480,3 +480,118 @@ def test_voronoi_deposit_paths_agree(voro_model, monkeypatch):
         assert r["counters"] == ref["counters"]
         assert np.allclose(r["E_abs"], ref["E_abs"], rtol=1e-7, atol=1e-12 * ref["E_abs"].max())
     e.close()
+
+
+# ---------------------------------------------------------------------------
+# SED mode (mc_mono.hip.h)
+# ---------------------------------------------------------------------------
+def _mono_parity(m, lam, n2, seed, n_chunks=64, **kw):
+    from helpers import xI_close
+    e, o = _engine(m, 1e5), _oracle(m, 1e5)
+    rt1 = kw.get("rt1", True)
+    a = e.run_mono(lam, n2, seed=seed, n_chunks=n_chunks, **kw)
+    b = o.run_mono(lam, n2, seed=seed, n_chunks=n_chunks, n_threads=8,
+                   **{k: v for k, v in kw.items() if k in ("n_phot_lim", "p_lambda", "rt1")})
+    assert np.array_equal(a["n_sent_chunk"], b["n_sent_chunk"])   # every stream stops at the same packet
+    assert a["counters"] == b["counters"]
+    assert np.array_equal(a["n_sent"], b["n_sent"]) and np.array_equal(a["sed"][4], b["sed"][4])
+    for t in (0, 5, 6, 7, 8):
+        assert np.allclose(a["sed"][t], b["sed"][t], rtol=1e-11, atol=1e-11), t
+    assert np.allclose(a["sed"][1:4], b["sed"][1:4], rtol=1e-5, atol=1e-6 * max(1.0, np.abs(b["sed"][0]).max()))
+    if rt1:
+        # with Stokes tracking every deposit inherits the default-real trigonometry of update_Stokes
+        # (scattering.f90:1218; device sincosf vs glibc sinf/cosf: 1 ulp of default real per scattering)
+        pola = m.cfg.lsepar_pola and m.cfg.aniso_method == 1
+        xI_close(a["xI_scatt"], b["xI_scatt"], n_midplane_cells=0 if m.cfg.l3D else m.cfg.n_rad,
+                 rtol=3e-5 if pola else 1e-6, atol_rel=1e-6 if pola else 1e-8)
+        assert np.array_equal(a["xI_scatt_f32"], a["xI_scatt"].astype(np.float32))
+    e.close()
+    return a, b
+
+
+@pytest.fixture(scope="module")
+def sed_small():
+    from helpers import sed_model
+    return sed_model(M.small())
+
+
+def test_sed_mode_parity_2d(sed_small):
+    """mcgpu_run_mono vs the oracle's sequential streams: star-dominated, mixed and disk-dominated
+    wavelengths; exact stopping packet per stream, SED bins, xI_scatt."""
+    m = sed_small
+    for lam in (3, 9, 14):
+        a, b = _mono_parity(m, lam, 12, 60 + lam)
+        assert a["sed"][4][0, m.capt_sup - 1, lam - 1] == 64 * 12
+        assert a["n_sent"][lam - 1] == a["n_sent_chunk"].sum() == a["counters"]["packets"]
+
+
+def test_sed_mode_variants():
+    from helpers import sed_model
+    _mono_parity(sed_model(M.small(lsepar_pola=False)), 4, 8, 7)                         # N_type_flux = 5
+    _mono_parity(sed_model(M.small(lsepar_pola=False, lsepar_contrib=False)), 4, 8, 8)   # N_type_flux = 1
+    _mono_parity(sed_model(M.small(n_rad=10, nz=5, n_az=6, l3D=True)), 4, 8, 9)          # 3D
+    _mono_parity(sed_model(M.small(aniso_method=2, lsepar_pola=False)), 4, 8, 10)        # HG
+    _mono_parity(sed_model(M.small(RT_n_incl=2, RT_n_az=3, RT_az_max=90.0, RT_imin=20.0, RT_imax=70.0)), 5, 8, 11)
+    _mono_parity(sed_model(M.small()), 4, 8, 12, rt1=False)                              # no RT deposits
+
+
+def test_sed_mode_packet_cap_and_launch_geometry(sed_small):
+    m = sed_small
+    a, b = _mono_parity(m, 3, 100000, 5, n_chunks=16, n_phot_lim=700.0)   # n_phot_lim ends every stream
+    assert np.all(a["n_sent_chunk"] == 700)
+    e = _engine(m, 1e5)
+    ref = e.run_mono(9, 10, seed=3, n_chunks=32)
+    for gb, bt in ((1, 64), (5, 128), (40, 256)):
+        r = e.run_mono(9, 10, seed=3, n_chunks=32, grid_blocks=gb, block_threads=bt)
+        assert np.array_equal(r["n_sent_chunk"], ref["n_sent_chunk"]) and r["counters"] == ref["counters"]
+        assert np.allclose(r["sed"], ref["sed"], rtol=1e-10, atol=1e-10)
+        assert np.allclose(r["xI_scatt"].sum(axis=(3, 4)), ref["xI_scatt"].sum(axis=(3, 4)), rtol=1e-9,
+                           atol=1e-12 * np.abs(ref["xI_scatt"]).max())
+    # accumulate: two wavelengths into the same SED arrays, like the lambda loop of run_sed_mc
+    r1 = e.run_mono(3, 10, seed=3, n_chunks=32)
+    r2 = e.run_mono(9, 10, seed=3, n_chunks=32, accumulate=True)
+    assert np.array_equal(r2["sed"][4][..., 2], r1["sed"][4][..., 2]) and r2["n_sent"][2] == r1["n_sent"][2]
+    assert np.array_equal(r2["sed"][4][..., 8], ref["sed"][4][..., 8])
+    e.close()
+
+
+def test_sed_mode_full_size_properties(ref41_model):
+    """BASELINE config 2's SED half at a GPU-sized packet count: 128 streams x 2000 packets in capt_sup."""
+    from mcfost_amd.host import model as MM
+    import copy
+    m = copy.copy(ref41_model)
+    e = _engine(m, 2e6)
+    T = e.temp_finale(e.run_thermal(2_000_000, seed=3)["E_abs"])
+    MM.repartition_energie(m, T)
+    e.close()
+    e = _engine(m, 2e6)
+    lam = 20
+    a = e.run_mono(lam, 2000, seed=11)
+    assert a["sed"][4][0, m.capt_sup - 1, lam - 1] == 128 * 2000
+    assert a["n_sent"][lam - 1] == a["n_sent_chunk"].sum() == a["counters"]["packets"]
+    c = a["counters"]
+    assert c["escaped"] + c["killed_star"] + c["absorptions"] == c["packets"]
+    # forced scattering only removes energy: what escapes is below what was sent
+    assert 0 < a["sed"][0][..., lam - 1].sum() <= c["escaped"]
+    # the streams are statistically identical: packets sent per stream scatter like a negative binomial
+    k = a["n_sent_chunk"].astype(float)
+    assert abs(k.std() / k.mean() - np.sqrt((1 - 2000 / k.mean()) / 2000)) < 0.02
+    x = a["xI_scatt"]
+    assert np.all(x[:, :, 0] >= 0) and np.all(x[:, :, 4] == 0) and np.all(x[:, :, 6] == 0)
+    assert np.allclose(x[:, :, 0], x[:, :, 5] + x[:, :, 7], rtol=1e-9, atol=1e-12 * x.max())   # star + disk = total
+    e.close()
+
+
+def test_sed_mode_abi_errors(sed_small):
+    from mcfost_amd.engine import McgpuError
+    e = _engine(sed_small, 1e4)
+    with pytest.raises(McgpuError):
+        e.run_mono(0, 5)                      # wavelength out of range
+    with pytest.raises(McgpuError):
+        e.run_mono(3, 5, n_chunks=2 ** 23)    # more streams than the engine takes
+    e.close()
+    vm = M.build_voronoi_model(M.small(lsepar_pola=False), 300, seed=8)
+    e = _engine(vm, 1e4)
+    with pytest.raises(McgpuError):           # SED mode on Voronoi grids: not built
+        e.run_mono(3, 5, rt1=False)
+    e.close()

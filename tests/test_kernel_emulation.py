@@ -15,6 +15,7 @@ import pytest
 
 from mcfost_amd.host import model as M
 from oracle import Oracle
+from helpers import sed_model, xI_close
 from oracle.binding import _Opts, _p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -166,15 +167,6 @@ def test_emulated_kernel_voronoi_star_outside_and_disk_emission(emu):
     check(emu, m, 3000, 23, rtol=1e-6)
 
 
-def _sed_model(cfg):
-    """A model whose SED-step emission tables come from a thermal step, like run_sed_mc's."""
-    m = M.build_model(cfg)
-    orc = Oracle(m, 1e5)
-    T = orc.temp_finale(orc.run_thermal(100000, seed=3, n_threads=4)["E_abs"])
-    M.repartition_energie(m, T)
-    return m
-
-
 def emu_mono(emu, orc, lam, n2, seed, rt1=True, n_chunks=8, n_phot_lim=1e9):
     from oracle.binding import _MonoOpts
     m = orc.model
@@ -188,24 +180,6 @@ def emu_mono(emu, orc, lam, n2, seed, rt1=True, n_chunks=8, n_phot_lim=1e9):
                           _p(per, C.c_uint64), _p(cnt, C.c_uint64))
     assert rc == 0, rc
     return dict(xI_scatt=xI, sed=sed, n_sent=ns, n_sent_chunk=per, counters=[int(c) for c in cnt])
-
-
-def xI_close(xa, xb, rtol=1e-6, n_midplane_cells=0):
-    """xI_scatt of two runs of the same packets.  A path that crosses a midplane cell of a 2D grid from
-    its upper wall to the mirrored lower wall has its midpoint at z = +-rounding, so whether its deposit
-    counts as "above" or "below" (psup, radiation_field.f90:78-82) is rounding noise in any build of the
-    algorithm: the comparison is made on the sum of the two.  Likewise a deposit may (rarely) fall into the
-    neighbouring azimuth sub-bin when FMA-level drift moves a midpoint across a sub-bin edge."""
-    scale = np.abs(xb).max()
-    assert np.allclose(xa.sum(axis=(3, 4)), xb.sum(axis=(3, 4)), rtol=rtol, atol=1e-8 * scale)
-    sa, sb = xa.sum(axis=3), xb.sum(axis=3)
-    bad = np.abs(sa - sb) > rtol * np.abs(sb) + 1e-8 * scale
-    assert bad.sum() <= max(4, 2e-4 * np.count_nonzero(sb)), (bad.sum(), np.count_nonzero(sb))
-    if n_midplane_cells:  # away from the midplane layer (cells 1..n_rad of a 2D grid) psup itself must agree
-        ua, ub = xa[n_midplane_cells:], xb[n_midplane_cells:]
-        bad2 = np.abs(ua - ub) > rtol * np.abs(ub) + 1e-8 * scale
-        assert bad2.sum() <= max(4, 2e-4 * np.count_nonzero(ub)), (bad2.sum(), np.count_nonzero(ub))
-    return bad.sum()
 
 
 def check_mono(emu, m, lam, n2, seed, **kw):
@@ -228,7 +202,7 @@ def check_mono(emu, m, lam, n2, seed, **kw):
 def test_emulated_sed_mode_2d(emu):
     """SED mode (mc_mono.hip.h): scout + scan + commit against the oracle's sequential streams --
     same stopping packet in every stream, same SED bins, same xI_scatt."""
-    m = _sed_model(M.small())
+    m = sed_model(M.small())
     for lam in (3, 9, 14):  # star-dominated, mixed, disk-dominated emission
         a, b = check_mono(emu, m, lam, 6, 40 + lam)
         assert a["sed"][4][0, m.capt_sup - 1, lam - 1] == 8 * 6
@@ -237,10 +211,10 @@ def test_emulated_sed_mode_2d(emu):
 
 
 def test_emulated_sed_mode_variants(emu):
-    check_mono(emu, _sed_model(M.small(lsepar_pola=False)), 4, 5, 7)                    # N_type_flux = 5
-    check_mono(emu, _sed_model(M.small(lsepar_pola=False, lsepar_contrib=False)), 4, 5, 8)  # = 1
-    check_mono(emu, _sed_model(M.small(n_rad=10, nz=5, n_az=6, l3D=True)), 4, 5, 9)     # 3D: phik = psup = 1
-    check_mono(emu, _sed_model(M.small(aniso_method=2, lsepar_pola=False)), 4, 5, 10)   # HG
-    m = _sed_model(M.small(RT_n_incl=2, RT_n_az=3, RT_az_max=90.0, RT_imin=20.0, RT_imax=70.0))
+    check_mono(emu, sed_model(M.small(lsepar_pola=False)), 4, 5, 7)                    # N_type_flux = 5
+    check_mono(emu, sed_model(M.small(lsepar_pola=False, lsepar_contrib=False)), 4, 5, 8)  # = 1
+    check_mono(emu, sed_model(M.small(n_rad=10, nz=5, n_az=6, l3D=True)), 4, 5, 9)     # 3D: phik = psup = 1
+    check_mono(emu, sed_model(M.small(aniso_method=2, lsepar_pola=False)), 4, 5, 10)   # HG
+    m = sed_model(M.small(RT_n_incl=2, RT_n_az=3, RT_az_max=90.0, RT_imin=20.0, RT_imax=70.0))
     check_mono(emu, m, 5, 5, 11)                                                        # several azimuths
-    check_mono(emu, _sed_model(M.small()), 4, 5, 12, rt1=False)                         # no ray-tracing deposits
+    check_mono(emu, sed_model(M.small()), 4, 5, 12, rt1=False)                         # no ray-tracing deposits

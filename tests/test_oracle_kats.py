@@ -178,3 +178,63 @@ def test_optically_thin_inner_rim_temperature(small_model):
     f = (lq - m.log_Qcool[Ti - 1]) / (m.log_Qcool[Ti] - m.log_Qcool[Ti - 1])
     T_exp = math.exp(math.log(m.tab_Temp[Ti]) * f + math.log(m.tab_Temp[Ti - 1]) * (1 - f))
     assert abs(T[0, i] / T_exp - 1) < 0.03, (T[0, i], T_exp)
+
+
+# ---------------------------------------------------------------------------
+# SED mode (oracle_run_mono): known answers
+# ---------------------------------------------------------------------------
+def test_mono_streams_stop_exactly_and_conserve_packets():
+    from helpers import sed_model
+    m = sed_model(M.small(), n_thermal=50000)
+    orc = Oracle(m, 1e5)
+    for lam in (3, 14):
+        r = orc.run_mono(lam, 7, seed=5, n_chunks=32, n_threads=4)
+        c = r["counters"]
+        assert r["sed"][4][0, m.capt_sup - 1, lam - 1] == 32 * 7          # each stream: exactly 7 in capt_sup
+        assert r["n_sent"][lam - 1] == r["n_sent_chunk"].sum() == c["packets"]
+        assert c["escaped"] + c["killed_star"] + c["absorptions"] == c["packets"]
+        assert c["absorptions"] < c["packets"] and c["scatterings"] > 0
+        # weights only shrink (forced scattering multiplies by the albedo)
+        assert r["sed"][0][..., lam - 1].sum() <= c["escaped"] + 1e-9
+        # independent of the thread count (streams are keyed by their own ids)
+        r1 = orc.run_mono(lam, 7, seed=5, n_chunks=32, n_threads=1)
+        assert np.array_equal(r1["n_sent_chunk"], r["n_sent_chunk"]) and np.array_equal(r1["sed"][4], r["sed"][4])
+
+
+def test_mono_flat_phase_function_gives_direction_independent_xI():
+    """With a flat S11 (Pascucci benchmark dust, g = 0) calc_xI_scatt adds l * I * s11 with the same s11
+    for every observer: the ray-tracing source is the same in all directions, and equals s11 times the
+    path-length estimator of the mean intensity."""
+    from helpers import sed_model
+    cfg = M.small(dust="pascucci", lisotropic=True, lsepar_pola=False)
+    m = sed_model(cfg, n_thermal=50000)
+    orc = Oracle(m, 1e5)
+    lam = 6
+    r = orc.run_mono(lam, 20, seed=2, n_chunks=16, n_threads=4)
+    x = r["xI_scatt"]                       # (cell, iRT, type, psup, phik)
+    tot = x[:, :, 0].sum(axis=(2, 3))       # (cell, iRT)
+    assert np.allclose(tot[:, 0], tot[:, 1], rtol=1e-12) and np.allclose(tot[:, 0], tot[:, 2], rtol=1e-12)
+    s11 = m.tab_s11_pos[lam - 1]
+    assert np.allclose(s11[1:], s11[1], rtol=1e-6)
+    # contributions: star-origin + disk-origin = total
+    assert np.allclose(x[:, :, 0], x[:, :, 2] + x[:, :, 4], rtol=1e-12, atol=1e-300)
+
+
+def test_mono_optically_thin_mean_intensity():
+    """Optically thin limit: the path-length estimator sum(l * I) / V of a cell equals the geometric
+    dilution of the stellar packets, N / (4 pi r^2) per packet sent (no scattering source needed)."""
+    from helpers import sed_model
+    cfg = M.small(dust="pascucci", lisotropic=True, lsepar_pola=False, dust_mass=1e-14)
+    m = sed_model(cfg, n_thermal=20000)
+    orc = Oracle(m, 1e5)
+    lam = 6
+    r = orc.run_mono(lam, 400, seed=9, n_chunks=16, n_threads=4)
+    x = r["xI_scatt"][:, 0, 0].sum(axis=(1, 2)) / m.tab_s11_pos[lam - 1][1]   # sum(l * I) per cell
+    g = m.grid
+    J = x / g["volume"] / r["n_sent"][lam - 1]
+    r_c, z_c = g["r_grid"], g["z_grid"]
+    d2 = r_c ** 2 + z_c ** 2
+    sel = (np.abs(z_c) < 0.5 * r_c) & (r_c > 3.0) & (r_c < 200.0)
+    expect = 1.0 / (4 * np.pi * d2)
+    ratio = J[sel] / expect[sel]
+    assert abs(np.median(ratio) - 1.0) < 0.05, np.median(ratio)
