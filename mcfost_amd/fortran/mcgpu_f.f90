@@ -34,9 +34,25 @@ module mcgpu_f
      integer(c_int)     :: block_threads
   end type mcgpu_run_opts
 
-  public :: mcgpu_create, mcgpu_destroy, mcgpu_set_grid_cyl, mcgpu_set_midplane_snap, mcgpu_set_stars, &
-       mcgpu_set_opacity, mcgpu_set_scattering, mcgpu_set_thermal, mcgpu_set_sed_bins, mcgpu_run_thermal, &
-       mcgpu_temp_finale, mcgpu_thermal_loop, mcgpu_error_message
+  ! SED mode: one wavelength of run_sed_mc (include/mcgpu.h: mcgpu_mono_opts)
+  type, bind(C), public :: mcgpu_mono_opts
+     integer(c_int64_t) :: seed
+     integer(c_int)     :: lambda
+     integer(c_int)     :: p_lambda
+     integer(c_int)     :: n_chunks       ! n_photons_loop
+     integer(c_int64_t) :: n_photons2     ! n_photons_lambda
+     real(c_double)     :: n_phot_lim     ! n_photons_lim
+     integer(c_int)     :: capt_sup
+     integer(c_int)     :: rt1            ! lscatt_ray_tracing1
+     integer(c_int)     :: accumulate
+     integer(c_int)     :: grid_blocks
+     integer(c_int)     :: block_threads
+  end type mcgpu_mono_opts
+
+  public :: mcgpu_create, mcgpu_destroy, mcgpu_set_grid_cyl, mcgpu_set_grid_voronoi, mcgpu_set_midplane_snap, &
+       mcgpu_set_stars, mcgpu_set_opacity, mcgpu_set_scattering, mcgpu_set_thermal, mcgpu_set_sed_bins, &
+       mcgpu_run_thermal, mcgpu_temp_finale, mcgpu_thermal_loop, mcgpu_error_message, mcgpu_set_rt1, &
+       mcgpu_run_mono, mcgpu_fetch, mcgpu_fetch_xI
 
   interface
      integer(c_int) function mcgpu_create(device, ctx) bind(C, name="mcgpu_create")
@@ -145,6 +161,38 @@ module mcgpu_f
        integer(c_int64_t), intent(out) :: counters(*)
        real(c_double), intent(out) :: kernel_ms
      end function mcgpu_run_thermal
+
+     ! tab_u_rt, tab_v_rt, tab_w_rt, n_az_rt, N_type_flux: module dust_ray_tracing; tab_s11_pos(:,1,:): grains
+     integer(c_int) function mcgpu_set_rt1(ctx, RT_n_incl, RT_n_az, tab_u_rt, tab_v_rt, tab_w_rt, n_az_rt, &
+          n_theta_rt, N_type_flux, lsepar_contrib, tab_s11_pos, n_lambda_pos) bind(C, name="mcgpu_set_rt1")
+       import :: c_int, c_ptr, c_double, c_float
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: RT_n_incl, RT_n_az, n_az_rt, n_theta_rt, N_type_flux, lsepar_contrib, n_lambda_pos
+       real(c_double), intent(in) :: tab_u_rt(*), tab_v_rt(*), tab_w_rt(*)
+       real(c_float), intent(in) :: tab_s11_pos(*)
+     end function mcgpu_set_rt1
+
+     ! replaces `call mc_photon_loop(lambda, p_lambda, n_photons2, n_phot_lim, 1, .false.)` (dust_transfer.f90:939)
+     integer(c_int) function mcgpu_run_mono(ctx, opts, frac_E_stars, frac_E_disk, prob_E_cell, n_sent_chunk, &
+          kernel_ms) bind(C, name="mcgpu_run_mono")
+       import :: c_int, c_ptr, c_double, c_int64_t, mcgpu_mono_opts
+       type(c_ptr), value :: ctx
+       type(mcgpu_mono_opts), intent(in) :: opts
+       real(c_double), value :: frac_E_stars, frac_E_disk
+       type(c_ptr), value :: prob_E_cell    ! c_loc(prob_E_cell(0,lambda)) or c_null_ptr
+       integer(c_int64_t), intent(out) :: n_sent_chunk(*)
+       real(c_double), intent(out) :: kernel_ms
+     end function mcgpu_run_mono
+
+     integer(c_int) function mcgpu_fetch(ctx, E_abs, sed, n_sent, counters) bind(C, name="mcgpu_fetch")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx, E_abs, sed, n_sent, counters   ! c_loc(...) or c_null_ptr
+     end function mcgpu_fetch
+
+     integer(c_int) function mcgpu_fetch_xI(ctx, xI_scatt_f32, xI_scatt_f64) bind(C, name="mcgpu_fetch_xI")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx, xI_scatt_f32, xI_scatt_f64       ! c_loc(xI_scatt(1,1,1,1,1,1)) or c_null_ptr
+     end function mcgpu_fetch_xI
 
      integer(c_int) function mcgpu_temp_finale(ctx, E_abs, Tdust) bind(C, name="mcgpu_temp_finale")
        import :: c_int, c_ptr, c_double, c_float
