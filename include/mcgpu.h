@@ -251,6 +251,8 @@ typedef struct {
   int lambda;           /* 1-based wavelength index                                */
   int p_lambda;         /* index into the phase-function tables (run_sed_mc :899-909) */
   int n_chunks;         /* n_photons_loop: independent sequential streams (:525)   */
+  int first_chunk;      /* global id of this call's first stream (0 on one GPU; rank r
+                           of a multi-GPU run takes its own contiguous range)       */
   uint64_t n_photons2;  /* n_photons_lambda: packets each stream must see binned in
                            inclination bin capt_sup before it stops (:526, :551)   */
   double n_phot_lim;    /* n_photons_lim: cap on the packets a stream sends (:526) */
@@ -265,7 +267,7 @@ typedef struct {
  * at dust_transfer.f90:939.  frac_E_stars / frac_E_disk / prob_E_cell(0:n_cells) are the
  * wavelength's entries as left by repartition_energie(lambda) (:924,
  * thermal_emission.f90:1771-1949); prob_E_cell may be NULL when frac_E_stars = 1.
- * A stream's packets are id (stream << 40 | sequence) of the random generator; each stream
+ * A stream's packets are id ((first_chunk + stream) << 40 | sequence) of the random generator; each stream
  * stops EXACTLY where the reference's sequential loop would: a first pass without deposits
  * finds the stopping index, a second pass replays the packets before it with deposits.
  * n_sent_chunk[n_chunks] (may be NULL) returns the packets each stream sent; their sum is

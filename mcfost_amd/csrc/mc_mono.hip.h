@@ -32,7 +32,7 @@ struct MonoArgs {
   // work items
   unsigned long long n_items;
   const unsigned long long* item_base;  // COMMIT: [n_chunks+1] prefix sums of K
-  int n_chunks;
+  int n_chunks, first_chunk;
   const int* active;                    // SCOUT: streams still running
   const unsigned long long* seq0;       // SCOUT: [n_chunks] first sequence number of this batch
   unsigned long long batch;             // SCOUT: packets per stream in this batch
@@ -243,7 +243,7 @@ __device__ __forceinline__ void mono_body(const DevModel& M, const MonoArgs& A, 
             chunk = (unsigned long long)lo;
             seq = my - A.item_base[lo];
           }
-          rng.init(A.seed, (chunk << 40) | seq);
+          rng.init(A.seed, ((chunk + (unsigned long long)A.first_chunk) << 40) | seq);
           c_pack++;
           pk_cross = 0;
           float f[12];

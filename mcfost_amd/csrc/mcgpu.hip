@@ -927,7 +927,8 @@ extern "C" int mcgpu_run_mono(mcgpu_ctx* ctx, const mcgpu_mono_opts* o, double f
   if (!o) return fail(ctx, MCGPU_ERR_ARG, "null options");
   if (ctx->voro) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "SED mode on Voronoi grids is not built yet");
   DevModel& M = ctx->M;
-  if (o->lambda < 1 || o->lambda > M.n_lambda || o->n_chunks < 1 || o->n_chunks > (1 << 22) || o->capt_sup < 1)
+  if (o->lambda < 1 || o->lambda > M.n_lambda || o->n_chunks < 1 || o->n_chunks > (1 << 22) || o->capt_sup < 1 ||
+      o->first_chunk < 0 || (long long)o->first_chunk + o->n_chunks > (1 << 23))
     return fail(ctx, MCGPU_ERR_ARG, "mcgpu_run_mono: bad option");
   if (o->rt1 && !ctx->have_rt1) return fail(ctx, MCGPU_ERR_STATE, "rt1 deposits need mcgpu_set_rt1");
   const int n_pos = ctx->have_rt1 ? ctx->n_lambda_pos : M.n_lambda;
@@ -974,7 +975,7 @@ extern "C" int mcgpu_run_mono(mcgpu_ctx* ctx, const mcgpu_mono_opts* o, double f
   A.seed = o->seed; A.lambda = o->lambda; A.p_lambda = o->p_lambda; A.capt_sup = o->capt_sup; A.rt1 = o->rt1 ? 1 : 0;
   A.frac_E_stars = frac_E_stars; A.frac_E_disk = frac_E_disk;
   A.prob_E_cell = prob_E_cell ? ctx->d_prob_E : nullptr;
-  A.n_chunks = nc;
+  A.n_chunks = nc; A.first_chunk = o->first_chunk;
   A.RT_n_incl = ctx->have_rt1 ? ctx->RT_n_incl : 1; A.nRT = o->rt1 ? nRT : 0;
   A.rt_u = ctx->d_rt_u; A.rt_v = ctx->d_rt_v; A.rt_w = ctx->d_rt_w;
   A.n_az_rt = ctx->n_az_rt; A.n_theta_rt = ctx->n_theta_rt; A.N_type_flux = ctx->N_type_flux; A.contrib = ctx->lsepar_contrib;

@@ -86,3 +86,50 @@ def run_thermal_device(engine, n_packets: int, seed: int, rank: int, world_size:
     out = engine.fetch()
     out["kernel_ms"] = ms
     return out
+
+
+# ---------------------------------------------------------------------------
+# SED mode: the n_photons_loop streams of a wavelength are independent and carry
+# their own stopping rule (dust_transfer.f90:525-553), so they shard as they are.
+# ---------------------------------------------------------------------------
+def shard_streams(n_chunks: int, rank: int, world_size: int):
+    """Contiguous range of stream ids of this rank: (first_chunk, count)."""
+    return shard_packets(n_chunks, rank, world_size)
+
+
+def run_mono_sharded(run_local, lam: int, n_photons2: int, n_chunks: int, seed: int, rank: int, world_size: int,
+                     group=None, **kw):
+    """One wavelength of the SED Monte Carlo on ``world_size`` ranks.
+
+    ``run_local(lam, n_photons2, seed=, n_chunks=, first_chunk=, **kw)`` is this rank's loop
+    (``Engine.run_mono``).  Every rank runs its own streams to their own stopping packets; ONE
+    all-reduce sums ``[sed | n_sent | xI_scatt]`` and the counters, one all-gather returns the
+    packets every stream sent.  The result equals the single-rank run stream for stream."""
+    import torch
+    import torch.distributed as dist
+
+    first, count = shard_streams(n_chunks, rank, world_size)
+    res = run_local(lam, n_photons2, seed=seed, n_chunks=max(count, 1), first_chunk=first, **kw) if count > 0 else None
+    if world_size == 1:
+        return res
+    if res is None:
+        raise ValueError("more ranks than streams")
+    parts = [res["sed"].ravel(), res["n_sent"].ravel()]
+    has_xI = "xI_scatt" in res
+    if has_xI:
+        parts.append(res["xI_scatt"].ravel())
+    acc = torch.from_numpy(np.concatenate(parts))
+    cnt = torch.from_numpy(np.array(list(res["counters"].values()), dtype=np.int64))
+    dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
+    dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=group)
+    per = torch.zeros(n_chunks, dtype=torch.int64)
+    per[first:first + count] = torch.from_numpy(res["n_sent_chunk"].astype(np.int64))
+    dist.all_reduce(per, op=dist.ReduceOp.SUM, group=group)   # disjoint ranges: a gather by summation
+    a = acc.numpy()
+    n_s, n_n = res["sed"].size, res["n_sent"].size
+    out = dict(sed=a[:n_s].reshape(res["sed"].shape).copy(), n_sent=a[n_s:n_s + n_n].copy(),
+               n_sent_chunk=per.numpy().astype(np.uint64),
+               counters=dict(zip(res["counters"].keys(), (int(c) for c in cnt.numpy()))))
+    if has_xI:
+        out["xI_scatt"] = a[n_s + n_n:].reshape(res["xI_scatt"].shape).copy()
+    return out

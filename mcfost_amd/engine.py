@@ -48,8 +48,8 @@ class RunOpts(C.Structure):
 
 class MonoOpts(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("lambda_", C.c_int), ("p_lambda", C.c_int), ("n_chunks", C.c_int),
-                ("n_photons2", C.c_uint64), ("n_phot_lim", C.c_double), ("capt_sup", C.c_int), ("rt1", C.c_int),
-                ("accumulate", C.c_int), ("grid_blocks", C.c_int), ("block_threads", C.c_int)]
+                ("first_chunk", C.c_int), ("n_photons2", C.c_uint64), ("n_phot_lim", C.c_double),
+                ("capt_sup", C.c_int), ("rt1", C.c_int), ("accumulate", C.c_int), ("grid_blocks", C.c_int), ("block_threads", C.c_int)]
 
 
 _lib = None
@@ -286,7 +286,7 @@ class Engine:
                 rt["n_az_rt"])
 
     def run_mono(self, lam, n_photons2, n_phot_lim=None, p_lambda=None, seed=1, n_chunks=None, rt1=True,
-                 accumulate=False, grid_blocks=0, block_threads=0, fetch_xI=True):
+                 accumulate=False, grid_blocks=0, block_threads=0, fetch_xI=True, first_chunk=0):
         """One wavelength (1-based ``lam``) of the SED Monte Carlo: ``mcgpu_run_mono`` with the
         model's frac_E_stars / prob_E_cell of that wavelength."""
         m = self.model
@@ -296,7 +296,7 @@ class Engine:
         n_chunks = int(n_chunks or m.cfg.n_photons_loop)
         if n_phot_lim is None:  # read_param.f90:551
             n_phot_lim = float(np.float32(1.0e4) * np.float32(nt) * np.float32(nphi) * np.float32(n_photons2))
-        o = MonoOpts(seed, int(lam), int(p_lambda or lam), n_chunks, int(n_photons2), float(n_phot_lim),
+        o = MonoOpts(seed, int(lam), int(p_lambda or lam), n_chunks, int(first_chunk), int(n_photons2), float(n_phot_lim),
                      int(m.capt_sup), int(rt1), int(accumulate), grid_blocks, block_threads)
         pe = getattr(m, "prob_E_cell", None)
         pe_l = None

@@ -40,6 +40,7 @@ module mcgpu_f
      integer(c_int)     :: lambda
      integer(c_int)     :: p_lambda
      integer(c_int)     :: n_chunks       ! n_photons_loop
+     integer(c_int)     :: first_chunk    ! 0 on one GPU
      integer(c_int64_t) :: n_photons2     ! n_photons_lambda
      real(c_double)     :: n_phot_lim     ! n_photons_lim
      integer(c_int)     :: capt_sup

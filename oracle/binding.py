@@ -97,7 +97,7 @@ class _Model(C.Structure):
 
 class _MonoOpts(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("lambda_", C.c_int), ("p_lambda", C.c_int), ("n_chunks", C.c_int),
-                ("n_photons2", C.c_double), ("n_phot_lim", C.c_double), ("capt_sup", C.c_int),
+                ("first_chunk", C.c_int), ("n_photons2", C.c_double), ("n_phot_lim", C.c_double), ("capt_sup", C.c_int),
                 ("rt1", C.c_int), ("n_threads", C.c_int)]
 
 
@@ -216,14 +216,14 @@ class Oracle:
                 rt["n_az_rt"])
 
     def run_mono(self, lam, n_photons2, n_phot_lim=None, p_lambda=None, seed=1, n_chunks=None,
-                 rt1=True, n_threads=1):
+                 rt1=True, n_threads=1, first_chunk=0):
         """One wavelength (1-based ``lam``) of the SED Monte Carlo."""
         m = self.model
         nl, nt, nphi = m.n_lambda, m.cfg.N_thet, m.cfg.N_phi
         n_chunks = int(n_chunks or m.cfg.n_photons_loop)
         if n_phot_lim is None:  # read_param.f90:551
             n_phot_lim = float(np.float32(1.0e4) * np.float32(nt) * np.float32(nphi) * np.float32(n_photons2))
-        o = _MonoOpts(seed, int(lam), int(p_lambda or lam), n_chunks, float(n_photons2), float(n_phot_lim),
+        o = _MonoOpts(seed, int(lam), int(p_lambda or lam), n_chunks, int(first_chunk), float(n_photons2), float(n_phot_lim),
                       int(m.capt_sup), int(rt1), n_threads)
         xI = np.zeros(self.xI_shape() if rt1 else (1,), np.float64)
         sed = np.zeros((N_SED_TYPES, nphi, nt, nl), np.float64)

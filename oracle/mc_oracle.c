@@ -1542,7 +1542,6 @@ int oracle_run_thermal(const oracle_model *m, const oracle_opts *o,
 /* one packet of mc_photon_loop's body with lmono (dust_transfer.f90:529-552);
  * returns 1 when the packet was binned in capt_sup (:551) */
 static int one_packet_mono(worker_t *W, uint64_t packet, int *err) {
-  const oracle_model *m = W->m;
   rng_init(&W->rng, W->o->seed, packet);
   rng_begin_event(&W->rng);
   W->cnt[ORC_CNT_PACKETS]++;
@@ -1603,7 +1602,7 @@ int oracle_run_mono(const oracle_model *m, const oracle_mono_opts *o, double *xI
       while (n_phot_sed2 < o->n_photons2 && n_in_loop < o->n_phot_lim) { /* :530 */
         n_in_loop += 1.0;
         int e = 0;
-        if (one_packet_mono(W, ((uint64_t)ch << 40) | seq, &e)) n_phot_sed2 += 1.0;
+        if (one_packet_mono(W, ((uint64_t)(ch + o->first_chunk) << 40) | seq, &e)) n_phot_sed2 += 1.0;
         if (e) {
 #ifdef _OPENMP
 #pragma omp atomic write

@@ -204,6 +204,7 @@ typedef struct {
   uint64_t seed;
   int lambda, p_lambda;
   int n_chunks;        /* n_photons_loop */
+  int first_chunk;     /* global id of the first stream */
   double n_photons2;   /* n_photons_lambda */
   double n_phot_lim;   /* n_photons_lim */
   int capt_sup;
@@ -215,7 +216,7 @@ typedef struct {
  * threads (FP64 here; the reference keeps default real per thread); sed/n_sent as in
  * oracle_run_thermal (only the lambda slice is touched); n_sent_chunk[n_chunks] =
  * packets each stream sent.  Packet (chunk c, sequence s) uses the random stream
- * of id (c << 40) | s. */
+ * of id ((first_chunk + c) << 40) | s. */
 int oracle_run_mono(const oracle_model *m, const oracle_mono_opts *o, double *xI_scatt,
                     double *sed, double *n_sent, uint64_t *n_sent_chunk,
                     uint64_t *counters);

@@ -266,7 +266,7 @@ extern "C" int emu_run_mono(const oracle_model* m, const oracle_mono_opts* o, do
   A.seed = o->seed; A.lambda = o->lambda; A.p_lambda = o->p_lambda; A.capt_sup = o->capt_sup; A.rt1 = o->rt1;
   A.frac_E_stars = m->frac_E_stars[o->lambda - 1]; A.frac_E_disk = m->frac_E_disk[o->lambda - 1];
   A.prob_E_cell = m->prob_E_cell ? m->prob_E_cell + (size_t)(m->n_cells + 1) * (o->lambda - 1) : nullptr;
-  A.n_chunks = o->n_chunks;
+  A.n_chunks = o->n_chunks; A.first_chunk = o->first_chunk;
   A.RT_n_incl = m->RT_n_incl > 0 ? m->RT_n_incl : 1; A.nRT = o->rt1 ? nRT : 0;
   A.rt_u = m->tab_u_rt; A.rt_v = m->tab_v_rt; A.rt_w = m->tab_w_rt;
   A.n_az_rt = m->n_az_rt; A.n_theta_rt = m->n_theta_rt; A.N_type_flux = m->N_type_flux; A.contrib = m->lsepar_contrib;

@@ -40,7 +40,7 @@ def sed_model(cfg, n_thermal=100000):
     from oracle import Oracle
     m = M.build_model(cfg)
     orc = Oracle(m, n_thermal)
-    T = orc.temp_finale(orc.run_thermal(n_thermal, seed=3, n_threads=4)["E_abs"])
+    T = orc.temp_finale(orc.run_thermal(n_thermal, seed=3, n_threads=1)["E_abs"])  # 1 thread: reproducible
     M.repartition_energie(m, T)
     return m
 

@@ -52,3 +52,42 @@ def test_two_ranks_equal_one(tmp_path):
     assert np.array_equal(r0["sed"][4], one["sed"][4]) and np.array_equal(r0["ns"], one["n_sent"])
     assert np.array_equal(r0["cnt"], np.array(list(one["counters"].values())))
     assert np.allclose(r0["E"], one["E_abs"], rtol=1e-12, atol=0)
+
+
+def _worker_mono(rank, world, port, out_dir):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+    import torch.distributed as dist
+    from helpers import sed_model
+    from mcfost_amd import distributed as D
+    from mcfost_amd.host import model as M
+    from oracle import Oracle
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m = sed_model(M.small(), n_thermal=20000)
+    orc = Oracle(m, 1e5)
+    res = D.run_mono_sharded(orc.run_mono, 9, 5, 13, 77, rank, world)   # 13 streams: uneven split
+    np.savez(os.path.join(out_dir, f"m{rank}.npz"), sed=res["sed"], ns=res["n_sent"], per=res["n_sent_chunk"],
+             xI=res["xI_scatt"], cnt=np.array(list(res["counters"].values())))
+    dist.destroy_process_group()
+
+
+def test_sed_mode_streams_shard_over_ranks(tmp_path):
+    """SED mode on 2 ranks: the streams are split, every stream still stops at its own packet, and the
+    all-reduced result equals the single-rank run stream for stream."""
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+    from helpers import sed_model
+    from mcfost_amd.host import model as M
+    from oracle import Oracle
+    port = 29500 + ((os.getpid() + 7) % 1000)
+    mp.spawn(_worker_mono, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    m = sed_model(M.small(), n_thermal=20000)
+    one = Oracle(m, 1e5).run_mono(9, 5, seed=77, n_chunks=13)
+    r0, r1 = np.load(tmp_path / "m0.npz"), np.load(tmp_path / "m1.npz")
+    for k in ("sed", "ns", "per", "xI", "cnt"):
+        assert np.array_equal(r0[k], r1[k])
+    assert np.array_equal(r0["per"], one["n_sent_chunk"])
+    assert np.array_equal(r0["sed"][4], one["sed"][4]) and np.array_equal(r0["ns"], one["n_sent"])
+    assert np.array_equal(r0["cnt"], np.array(list(one["counters"].values())))
+    assert np.allclose(r0["sed"], one["sed"], rtol=1e-12, atol=1e-14)
+    assert np.allclose(r0["xI"], one["xI_scatt"], rtol=1e-10, atol=1e-14 * np.abs(one["xI_scatt"]).max())

@@ -170,7 +170,7 @@ def test_emulated_kernel_voronoi_star_outside_and_disk_emission(emu):
 def emu_mono(emu, orc, lam, n2, seed, rt1=True, n_chunks=8, n_phot_lim=1e9):
     from oracle.binding import _MonoOpts
     m = orc.model
-    o = _MonoOpts(seed, lam, lam, n_chunks, float(n2), float(n_phot_lim), int(m.capt_sup), int(rt1), 1)
+    o = _MonoOpts(seed, lam, lam, n_chunks, 0, float(n2), float(n_phot_lim), int(m.capt_sup), int(rt1), 1)
     xI = np.zeros(orc.xI_shape() if rt1 else (1,))
     sed = np.zeros((9, m.cfg.N_phi, m.cfg.N_thet, m.n_lambda))
     ns = np.zeros(m.n_lambda)
