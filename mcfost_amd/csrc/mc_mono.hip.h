@@ -17,8 +17,11 @@
 // s < K of every stream with deposits.  Counter-based random numbers (stream c, sequence s ->
 // id (c << 40) | s) make the second pass replay the first exactly.
 //
-// xI_scatt is accumulated in FP64 (global_atomic_add_f64) in the reference's index order and
-// converted to default real when fetched.
+// xI_scatt is accumulated in FP64 (global_atomic_add_f64) in a device layout with the flux type
+// fastest and padded to one 64-byte line, [icell][psup][phik][iRT][8]: the <= 5 deposits per observer of
+// one crossing are ONE L2 line operation when issued by 8 neighbouring lanes of one instruction
+// (deposit_rt1_wave).  mcgpu_fetch_xI transposes to the reference's xI_scatt(phik,psup,type,iRT,icell)
+// and rounds to default real.
 #pragma once
 #include "mc_device.hip.h"
 
@@ -44,7 +47,7 @@ struct MonoArgs {
   const double* rt_w;                   // [RT_n_incl]
   int n_az_rt, n_theta_rt, N_type_flux, contrib;
   const float* s11;                     // tab_s11_pos(0:nang, p_lambda)
-  double* xI;                           // (n_az_rt, n_theta_rt, N_type_flux, nRT, n_cells)
+  double* xI;                           // device layout [n_cells][n_theta_rt][n_az_rt][nRT][XI_LINE]
   // accumulators
   double* sed;
   double* n_sent;
@@ -52,6 +55,7 @@ struct MonoArgs {
   unsigned long long* next_item;
   int* err;
   int inner_iters, min_active;
+  int flags;  // diagnostics: bit 0 = compute the deposits but skip the atomics, bit 1 = only the I deposit
 };
 
 // per-lane results of angles_scatt_rt1, kept in LDS as [q][thread]
@@ -66,7 +70,9 @@ __host__ __device__ inline size_t mono_lds_bytes(const DevModel& M, int nRT, int
   b += (size_t)6 * (M.nang + 1) * sizeof(float);                     // the Mueller columns of p_lambda
   b = (b + 7) / 8 * 8;
   b += (size_t)nRT * threads * (pola ? 2 * sizeof(double) : 0);      // cosw, sinw
+  b += (size_t)threads * (8 * sizeof(double) + sizeof(unsigned long long));  // deposit tiles: record + address
   b += (size_t)nRT * threads * sizeof(int);                          // itheta
+  b += (size_t)threads * sizeof(unsigned int);                       // deposit tiles: slot mask
   return b;
 }
 
@@ -105,14 +111,18 @@ __device__ inline void angles_scatt_rt1(const DevModel& M, const MonoArgs& A, co
   }
 }
 
-// save_radiation_field, lscatt_ray_tracing1 branch (radiation_field.f90:63-89) with calc_xI_scatt
-// (dust_ray_tracing.f90:480-529) / calc_xI_scatt_pola (:533-632).  mu = the six Mueller columns
-// [s11 | s12/s11 | s22/s11 | s33/s11 | s34/s11 | s44/s11] of p_lambda in LDS.
-template <bool L3D, bool POLA>
-__device__ inline void deposit_rt1(const DevModel& M, const MonoArgs& A, const RtScratch& R, const float* mu,
-                                   int icell, const double S[4], double l, double x0, double y0, double z0,
-                                   double x1, double y1, double z1, bool flag_star) {
-  int phik = 1, psup = 1;
+// One pending deposit of a lane: where (cell, azimuth / elevation sub-bin) and how long the path was.
+struct RtDeposit {
+  bool on;
+  int icell, phik, psup;
+  double l;
+};
+
+// sub-bin of a path (radiation_field.f90:64-83)
+template <bool L3D>
+__device__ inline void rt1_subbin(const MonoArgs& A, double x0, double y0, double z0, double x1, double y1,
+                                  double z1, int& phik, int& psup) {
+  phik = 1; psup = 1;
   if (!L3D) {
     const double xm = 0.5 * (x0 + x1), ym = 0.5 * (y0 + y1), zm = 0.5 * (z0 + z1);
     const double phi_pos = atan2(xm, ym);
@@ -120,37 +130,92 @@ __device__ inline void deposit_rt1(const DevModel& M, const MonoArgs& A, const R
     if (phik > A.n_az_rt) phik = A.n_az_rt;
     psup = (zm > 0.0) ? 1 : 2;
   }
-  const size_t st_type = (size_t)A.n_az_rt * A.n_theta_rt;
-  const size_t st_rt = st_type * A.N_type_flux;
-  double* base = A.xI + (size_t)(phik - 1) + (size_t)A.n_az_rt * (psup - 1) + st_rt * A.nRT * (size_t)(icell - 1);
+}
+
+constexpr int XI_LINE = 8;  // doubles per (cell, sub-bin, observer) record of the device layout: one 64-byte line
+
+// save_radiation_field, lscatt_ray_tracing1 branch (radiation_field.f90:63-89) with calc_xI_scatt
+// (dust_ray_tracing.f90:480-529) / calc_xI_scatt_pola (:533-632), for the whole wavefront.
+// mu = the six Mueller columns [s11 | s12/s11 | s22/s11 | s33/s11 | s34/s11 | s44/s11] of p_lambda in LDS.
+//
+// FP64 atomics to scattered addresses are bound by L2 line operations (2.4e10 /s on MI355X, measured:
+// tools/atomic_line_bench.hip), and a line operation costs the same whether one or eight lanes of the
+// instruction hit that line.  A lane's <= 5 values for one observer share one 64-byte record, so the wave
+// transposes them through a per-wave LDS tile: lane j stores its record, then in round r the 8 lanes of
+// group g = lane/8 add the 8 slots of lane 8r+g's record -- one instruction, 8 records, 8 line
+// operations instead of 40.
+template <bool POLA>
+__device__ inline void deposit_rt1_wave(const DevModel& M, const MonoArgs& A, const RtScratch& R, const float* mu,
+                                        const RtDeposit& D, const double S[4], bool flag_star, double* tile,
+                                        unsigned long long* tile_addr, unsigned int* tile_mask) {
   const int na1 = M.nang + 1;
+  const int lane = threadIdx.x & 63;
+#ifdef MCGPU_LANE_EMULATION
+  (void)tile; (void)tile_addr; (void)tile_mask;
+#else
+  const int t = lane & 7, g = lane >> 3;
+#endif
   for (int q = 0; q < A.nRT; ++q) {
-    const int it = R.itheta[q * blockDim.x + threadIdx.x];
-    const float s11 = mu[it];
-    double* p = base + st_rt * q;
-    if (!POLA) {
-      const double flux = l * S[0] * (double)s11;
-      atomic_add_f64(p, flux);
-      if (A.contrib) atomic_add_f64(p + st_type * (flag_star ? 2 : 4), flux);  // n_Stokes + 2 / + 4, n_Stokes = 1
-      continue;
+    double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+    unsigned int mask = 0;
+    int cslot = 0;
+    double* rec = nullptr;
+    if (D.on) {
+      rec = A.xI + ((((size_t)(D.icell - 1) * A.n_theta_rt + (D.psup - 1)) * A.n_az_rt + (D.phik - 1)) * A.nRT + q) * XI_LINE;
+      const int it = R.itheta[q * blockDim.x + threadIdx.x];
+      const float s11 = mu[it];
+      if (!POLA) {
+        v0 = D.l * S[0] * (double)s11;
+        mask = 1u;
+        if (A.contrib) { cslot = flag_star ? 2 : 4; mask |= 1u << cslot; }  // n_Stokes + 2 / + 4, n_Stokes = 1
+      } else {
+        const float s12 = -s11 * mu[na1 + it], s22 = s11 * mu[2 * na1 + it], s33 = -s11 * mu[3 * na1 + it];
+        const float s34 = -s11 * mu[4 * na1 + it], s44 = -s11 * mu[5 * na1 + it];
+        const double cosw = R.cosw[q * blockDim.x + threadIdx.x], sinw = R.sinw[q * blockDim.x + threadIdx.x];
+        const double C1 = S[0], C4 = S[3];
+        const double C2 = cosw * S[1] + (-sinw) * S[2];
+        const double C3 = sinw * S[1] + cosw * S[2];
+        const double D1 = (double)s11 * C1 + (double)s12 * C2;
+        const double D2 = (double)s12 * C1 + (double)s22 * C2;
+        const double D3 = (double)s33 * C3 + (double)(-s34) * C4;
+        const double D4 = (double)s34 * C3 + (double)s44 * C4;
+        v0 = D.l * D1;
+        v1 = D.l * ((-cosw) * D2 + (-sinw) * D3);
+        v2 = D.l * ((-sinw) * D2 + cosw * D3);
+        v3 = D.l * D4;
+        mask = 0xFu;
+        if (A.contrib) { cslot = flag_star ? 5 : 7; mask |= 1u << cslot; }
+      }
+      if (A.flags & 1) mask = 0;            // diagnostics: compute, do not deposit
+      else if (A.flags & 2) mask &= 1u;     // diagnostics: only the I deposit
     }
-    const float s12 = -s11 * mu[na1 + it], s22 = s11 * mu[2 * na1 + it], s33 = -s11 * mu[3 * na1 + it];
-    const float s34 = -s11 * mu[4 * na1 + it], s44 = -s11 * mu[5 * na1 + it];
-    const double cosw = R.cosw[q * blockDim.x + threadIdx.x], sinw = R.sinw[q * blockDim.x + threadIdx.x];
-    const double C1 = S[0], C4 = S[3];
-    const double C2 = cosw * S[1] + (-sinw) * S[2];
-    const double C3 = sinw * S[1] + cosw * S[2];
-    const double D1 = (double)s11 * C1 + (double)s12 * C2;
-    const double D2 = (double)s12 * C1 + (double)s22 * C2;
-    const double D3 = (double)s33 * C3 + (double)(-s34) * C4;
-    const double D4 = (double)s34 * C3 + (double)s44 * C4;
-    const double S2 = (-cosw) * D2 + (-sinw) * D3;
-    const double S3 = (-sinw) * D2 + cosw * D3;
-    atomic_add_f64(p, l * D1);
-    atomic_add_f64(p + st_type, l * S2);
-    atomic_add_f64(p + 2 * st_type, l * S3);
-    atomic_add_f64(p + 3 * st_type, l * D4);
-    if (A.contrib) atomic_add_f64(p + st_type * (flag_star ? 5 : 7), l * D1);
+#ifdef MCGPU_LANE_EMULATION
+    if (mask & 1u) atomic_add_f64(rec, v0);
+    if (POLA && (mask & 2u)) atomic_add_f64(rec + 1, v1);
+    if (POLA && (mask & 4u)) atomic_add_f64(rec + 2, v2);
+    if (POLA && (mask & 8u)) atomic_add_f64(rec + 3, v3);
+    if (cslot && ((mask >> cslot) & 1u)) atomic_add_f64(rec + cslot, v0);
+#else
+    // stage this lane's record (slots the mask does not name are never read)
+    volatile double* my = tile + lane * XI_LINE;
+    my[0] = v0; my[1] = v1; my[2] = v2; my[3] = v3;
+    if (cslot) my[cslot] = v0;
+    tile_addr[lane] = (unsigned long long)rec;
+    tile_mask[lane] = mask;
+    __builtin_amdgcn_wave_barrier();
+    const unsigned long long any = __ballot(mask != 0);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      if (((any >> (8 * r)) & 0xFFull) == 0ull) continue;  // wave-uniform: nobody of this round deposits
+      const int src = 8 * r + g;
+      const unsigned int m = ((volatile unsigned int*)tile_mask)[src];
+      if ((m >> t) & 1u) {
+        double* dst = reinterpret_cast<double*>(((volatile unsigned long long*)tile_addr)[src]) + t;
+        atomic_add_f64(dst, ((volatile double*)tile)[src * XI_LINE + t]);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+#endif
   }
 }
 
@@ -162,11 +227,20 @@ __device__ __forceinline__ void mono_body(const DevModel& M, const MonoArgs& A, 
   const int na1 = M.nang + 1;
   float* mu = reinterpret_cast<float*>(lds_base + (lds_bytes(M) + 7) / 8);
   RtScratch R;
+  double* tile;
+  unsigned long long* tile_addr;
+  unsigned int* tile_mask;
   {
     double* p = lds_base + (lds_bytes(M) + 7) / 8 + ((size_t)6 * na1 * sizeof(float) + 7) / 8;
     R.cosw = p;
     R.sinw = p + (POLA ? (size_t)A.nRT * blockDim.x : 0);
-    R.itheta = reinterpret_cast<int*>(p + (POLA ? (size_t)2 * A.nRT * blockDim.x : 0));
+    p += (POLA ? (size_t)2 * A.nRT * blockDim.x : 0);
+    tile = p + (size_t)(threadIdx.x >> 6) * 64 * XI_LINE;           // this wave's 64 x 8 doubles
+    p += (size_t)blockDim.x * XI_LINE;
+    tile_addr = reinterpret_cast<unsigned long long*>(p) + (size_t)(threadIdx.x >> 6) * 64;
+    p += blockDim.x;
+    R.itheta = reinterpret_cast<int*>(p);
+    tile_mask = reinterpret_cast<unsigned int*>(R.itheta + (size_t)A.nRT * blockDim.x) + (size_t)(threadIdx.x >> 6) * 64;
   }
   {  // the Mueller columns of p_lambda, and the phase-function CDF of p_lambda for the forced scattering
     const size_t col = (size_t)na1 * (A.p_lambda - 1);
@@ -337,6 +411,8 @@ __device__ __forceinline__ void mono_body(const DevModel& M, const MonoArgs& A, 
         const int flying = __popcll(__ballot(st == S_FLIGHT)), alive = __popcll(__ballot(st != S_DONE));
         if (flying * 64 < A.min_active * alive) break;
       }
+      RtDeposit dep;
+      dep.on = false; dep.icell = 1; dep.phik = 1; dep.psup = 1; dep.l = 0.0;
       if (st == S_FLIGHT) {
         const int azj = zj < 0 ? -zj : zj;
         const bool out = (ri == n_rad + 1) || ((azj == nz + 1) && (fabs(z) > M.zmaxmax));
@@ -381,8 +457,10 @@ __device__ __forceinline__ void mono_body(const DevModel& M, const MonoArgs& A, 
             const double tau = l * opacity;
             if (tau > extr) {
               const double lc = l * (extr / tau);
-              if (!SCOUT && A.rt1 && real_cell)
-                deposit_rt1<L3D, POLA>(M, A, R, mu, ic + 1, S, lc, x, y, z, x1, y1, z1, flag_star);
+              if (!SCOUT && A.rt1 && real_cell) {
+                dep.on = true; dep.icell = ic + 1; dep.l = lc;
+                rt1_subbin<L3D>(A, x, y, z, x1, y1, z1, dep.phik, dep.psup);
+              }
               x = x + lc * u;
               y = y + lc * v;
               z = z + lc * w;
@@ -390,8 +468,10 @@ __device__ __forceinline__ void mono_body(const DevModel& M, const MonoArgs& A, 
               st = S_INTERACT;
             } else {
               extr = extr - tau;
-              if (!SCOUT && A.rt1 && real_cell)
-                deposit_rt1<L3D, POLA>(M, A, R, mu, ic + 1, S, l, x, y, z, x1, y1, z1, flag_star);
+              if (!SCOUT && A.rt1 && real_cell) {
+                dep.on = true; dep.icell = ic + 1; dep.l = l;
+                rt1_subbin<L3D>(A, x, y, z, x1, y1, z1, dep.phik, dep.psup);
+              }
               if (DARK) { xo = x; yo = y; zo = z; ri_o = ri; zj_o = zj; k_o = k; }
               x = x1; y = y1; z = z1;
               ri = ri1; zj = zj1; k = k1;
@@ -400,6 +480,10 @@ __device__ __forceinline__ void mono_body(const DevModel& M, const MonoArgs& A, 
           }
         }
       }
+      // the deposits of this crossing, by the whole wavefront (S and flag_star are still the flight's:
+      // an interaction changes them only in the next outer phase)
+      if (!SCOUT && A.rt1 && __ballot(dep.on) != 0ull)
+        deposit_rt1_wave<POLA>(M, A, R, mu, dep, S, flag_star, tile, tile_addr, tile_mask);
     }
   }
 
@@ -463,10 +547,20 @@ __global__ void k_mono_scan(const int* active, int n_active, unsigned long long 
   }
 }
 
-// xI_scatt in default real (what the reference's array holds)
-__global__ void k_xI_to_float(const double* xI, float* out, size_t n) {
+// device layout [icell][psup][phik][iRT][8] -> the reference's xI_scatt(phik,psup,type,iRT,icell),
+// in FP64 and/or default real (what the reference's array holds).  One thread per output element.
+__global__ void k_xI_fetch(const double* xI, float* out32, double* out64, int n_az, int n_theta, int n_type, int nRT,
+                           size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = (float)xI[i];
+  if (i >= n) return;
+  size_t r = i;
+  const int phik = (int)(r % n_az); r /= n_az;
+  const int psup = (int)(r % n_theta); r /= n_theta;
+  const int type = (int)(r % n_type); r /= n_type;
+  const int q = (int)(r % nRT); r /= nRT;  // r = icell - 1
+  const double v = xI[(((r * n_theta + psup) * n_az + phik) * nRT + q) * XI_LINE + type];
+  if (out64) out64[i] = v;
+  if (out32) out32[i] = (float)v;
 }
 
 }  // namespace mcgpu

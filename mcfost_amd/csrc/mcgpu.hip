@@ -954,15 +954,18 @@ extern "C" int mcgpu_run_mono(mcgpu_ctx* ctx, const mcgpu_mono_opts* o, double f
     HIPCHK(hipMemcpyAsync(ctx->d_prob_E, prob_E_cell, ((size_t)M.n_cells + 1) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   }
   const int nRT = ctx->have_rt1 ? ctx->RT_n_incl * ctx->RT_n_az : 0;
+  // n_xI: elements of the reference's array; the device keeps XI_LINE doubles per (cell, sub-bin, observer)
   const size_t n_xI = o->rt1 ? (size_t)ctx->n_az_rt * ctx->n_theta_rt * ctx->N_type_flux * nRT * (size_t)M.n_cells : 0;
+  const size_t n_dev = o->rt1 ? (size_t)ctx->n_az_rt * ctx->n_theta_rt * XI_LINE * nRT * (size_t)M.n_cells : 0;
+  if (o->rt1 && ctx->N_type_flux > XI_LINE) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "N_type_flux > 8");
   if (o->rt1 && ctx->n_xI != n_xI) {
     if (ctx->d_xI) hipFree(ctx->d_xI);
     ctx->d_xI = nullptr; ctx->n_xI = 0;
-    HIPCHK(hipMalloc((void**)&ctx->d_xI, n_xI * sizeof(double)));
+    HIPCHK(hipMalloc((void**)&ctx->d_xI, n_dev * sizeof(double)));
     ctx->n_xI = n_xI;
-    HIPCHK(hipMemsetAsync(ctx->d_xI, 0, n_xI * sizeof(double), ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_xI, 0, n_dev * sizeof(double), ctx->stream));
   } else if (o->rt1 && !o->accumulate) {
-    HIPCHK(hipMemsetAsync(ctx->d_xI, 0, n_xI * sizeof(double), ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_xI, 0, n_dev * sizeof(double), ctx->stream));
   }
   if (!o->accumulate) {
     HIPCHK(hipMemsetAsync(ctx->d_accum, 0, ctx->n_accum * sizeof(double), ctx->stream));
@@ -987,6 +990,7 @@ extern "C" int mcgpu_run_mono(mcgpu_ctx* ctx, const mcgpu_mono_opts* o, double f
   A.inner_iters = 64; A.min_active = 32;
   if (const char* e = getenv("MCGPU_MIN_ACTIVE")) { int v = atoi(e); if (v >= 0 && v <= 64) A.min_active = v; }
   if (const char* e = getenv("MCGPU_INNER_ITERS")) { int v = atoi(e); if (v >= 1 && v <= 4096) A.inner_iters = v; }
+  if (const char* e = getenv("MCGPU_DIAG_FLAGS")) A.flags = atoi(e);
 
   // ---- SCOUT: find every stream's stopping index (dust_transfer.f90:526-553) ----------------
   double lim_d = std::ceil((double)o->n_phot_lim);
@@ -1061,18 +1065,23 @@ extern "C" int mcgpu_run_mono(mcgpu_ctx* ctx, const mcgpu_mono_opts* o, double f
 extern "C" int mcgpu_fetch_xI(mcgpu_ctx* ctx, float* xI_scatt_f32, double* xI_scatt_f64) {
   if (!ctx || !ctx->d_xI) return fail(ctx, MCGPU_ERR_STATE, "no xI_scatt accumulated yet");
   HIPCHK(hipSetDevice(ctx->device));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  if (xI_scatt_f64) HIPCHK(hipMemcpy(xI_scatt_f64, ctx->d_xI, ctx->n_xI * sizeof(double), hipMemcpyDeviceToHost));
-  if (xI_scatt_f32) {
-    float* d = nullptr;
-    HIPCHK(hipMalloc((void**)&d, ctx->n_xI * sizeof(float)));
-    hipLaunchKernelGGL(k_xI_to_float, dim3((unsigned)((ctx->n_xI + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_xI, d, ctx->n_xI);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(xI_scatt_f32, d, ctx->n_xI * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    hipFree(d);
-    HIPCHK(e);
+  const size_t n = ctx->n_xI;
+  float* d32 = nullptr;
+  double* d64 = nullptr;
+  hipError_t e = hipSuccess;
+  if (xI_scatt_f32) e = hipMalloc((void**)&d32, n * sizeof(float));
+  if (e == hipSuccess && xI_scatt_f64) e = hipMalloc((void**)&d64, n * sizeof(double));
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_xI_fetch, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_xI, d32, d64,
+                       ctx->n_az_rt, ctx->n_theta_rt, ctx->N_type_flux, ctx->RT_n_incl * ctx->RT_n_az, n);
+    e = hipGetLastError();
   }
+  if (e == hipSuccess && d32) e = hipMemcpyAsync(xI_scatt_f32, d32, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess && d64) e = hipMemcpyAsync(xI_scatt_f64, d64, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (d32) hipFree(d32);
+  if (d64) hipFree(d64);
+  HIPCHK(e);
   return MCGPU_OK;
 }
 

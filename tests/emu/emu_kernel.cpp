@@ -256,7 +256,7 @@ extern "C" int emu_run_mono(const oracle_model* m, const oracle_mono_opts* o, do
   const size_t nxI = o->rt1 ? (size_t)m->n_az_rt * m->n_theta_rt * m->N_type_flux * nRT * (size_t)m->n_cells : 0;
   memset(sed, 0, sizeof(double) * nsed);
   memset(n_sent, 0, sizeof(double) * m->n_lambda);
-  if (nxI) memset(xI, 0, sizeof(double) * nxI);
+  std::vector<double> xI_dev(nxI ? nxI / m->N_type_flux * XI_LINE : 1, 0.0);  // the kernel's own layout, transposed at the end
   unsigned long long cnt[16];
   memset(cnt, 0, sizeof(cnt));
   int err = 0;
@@ -271,7 +271,7 @@ extern "C" int emu_run_mono(const oracle_model* m, const oracle_mono_opts* o, do
   A.rt_u = m->tab_u_rt; A.rt_v = m->tab_v_rt; A.rt_w = m->tab_w_rt;
   A.n_az_rt = m->n_az_rt; A.n_theta_rt = m->n_theta_rt; A.N_type_flux = m->N_type_flux; A.contrib = m->lsepar_contrib;
   A.s11 = m->tab_s11_pos ? m->tab_s11_pos + (size_t)(m->nang_scatt + 1) * (o->p_lambda - 1) : nullptr;
-  A.xI = xI; A.sed = sed; A.n_sent = n_sent; A.counters = cnt; A.next_item = cnt + 8; A.err = &err;
+  A.xI = xI_dev.data(); A.sed = sed; A.n_sent = n_sent; A.counters = cnt; A.next_item = cnt + 8; A.err = &err;
   A.inner_iters = 8; A.min_active = 0;
 #define MONO(sc_) do {                                                                     \
     if (l3d) {                                                                            \
@@ -313,6 +313,14 @@ extern "C" int emu_run_mono(const oracle_model* m, const oracle_mono_opts* o, do
   A.item_base = base.data(); A.n_items = base[nc]; A.active = nullptr; A.seq0 = nullptr; A.hits = nullptr; A.batch = 0;
   cnt[8] = 0;
   if (A.n_items) MONO(false);
+  if (nxI) {  // mcgpu_fetch_xI
+    gridDim.x = 1; blockDim.x = 1; threadIdx.x = 0;
+    for (size_t i = 0; i < nxI; ++i) {
+      blockIdx.x = (unsigned)i;
+      k_xI_fetch(xI_dev.data(), nullptr, xI, m->n_az_rt, m->n_theta_rt, m->N_type_flux, nRT, nxI);
+    }
+    blockIdx.x = 0;
+  }
   for (int q = 0; q < 8; ++q) counters[q] = cnt[q];
   return err;
 }
