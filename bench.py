@@ -26,10 +26,7 @@ BYTES_PER_INTERACTION = 8.0  # E_abs read for Temp_LTE
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
-def cpu_baseline(model, n_total, target_s=15.0):
-    """The CPU restatement (oracle, kind "port") timed on this box's host cores
-    on a bounded sample of the same workload."""
-    from oracle import Oracle
+def _quota_cores():
     cores = os.cpu_count() or 1
     try:
         cores = len(os.sched_getaffinity(0))
@@ -41,6 +38,14 @@ def cpu_baseline(model, n_total, target_s=15.0):
             cores = max(1, min(cores, int(round(int(quota) / int(period)))))
     except Exception:
         pass
+    return cores
+
+
+def cpu_baseline(model, n_total, target_s=15.0):
+    """The CPU restatement (oracle, kind "port") timed on this box's host cores
+    on a bounded sample of the same workload."""
+    from oracle import Oracle
+    cores = _quota_cores()
     orc = Oracle(model, n_total)
     t = time.perf_counter()
     orc.run_thermal(20000 * cores, seed=99, n_threads=cores)
@@ -54,13 +59,104 @@ def cpu_baseline(model, n_total, target_s=15.0):
                        "%.1f crossings/packet" % (n, cores, dt, res["counters"]["crossings"] / n))
 
 
+def bench_sed(args, world, rank, local_rank):
+    """SED mode on the ref4.1 grid (not the headline metric): one step = the SED Monte Carlo
+    (mcgpu_run_mono: scout + commit passes, ray-tracing deposits) of the listed wavelengths, every stream
+    asked for packets/128/len(wavelengths) packets in the stop bin; streams sharded over the ranks."""
+    import torch
+    import torch.distributed as dist
+    from mcfost_amd import distributed as D
+    from mcfost_amd.engine import Engine
+    from mcfost_amd.host import model as M
+
+    m = M.build_model(M.ref41())
+    e = Engine(m, 5e6, device=local_rank)
+    T = e.temp_finale(e.run_thermal(5_000_000, seed=3)["E_abs"])
+    M.repartition_energie(m, T)
+    e.close()
+    eng = Engine(m, 5e6, device=local_rank)
+    lams = [int(x) for x in args.sed_lambdas.split(",")]
+    n_streams = m.cfg.n_photons_loop * world                 # weak scaling: 128 streams per GPU
+    first, count = D.shard_streams(n_streams, rank, world)
+    # packets in the stop bin per stream so that a step sends about --packets packets per GPU (1 in ~11 lands there)
+    n2 = max(10, int(args.packets / 11.0 / m.cfg.n_photons_loop / len(lams)))
+
+    def step(i):
+        sent = 0
+        for lam in lams:
+            r = eng.run_mono(lam, n2, seed=100 + i, n_chunks=count, first_chunk=first, fetch_xI=False)
+            sent += int(r["n_sent_chunk"].sum())
+            if world > 1:   # one all-reduce of [sed | n_sent] + xI_scatt per wavelength
+                acc, cnt = eng.device_accumulators()
+                dist.all_reduce(acc)
+                dist.all_reduce(eng.device_xI())
+                torch.cuda.current_stream().synchronize()
+        return sent
+
+    for i in range(args.warmup):
+        step(-1 - i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sent = 0
+    for i in range(args.steps):
+        sent += step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tot = torch.tensor([float(sent), dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        s2 = tot.clone()
+        dist.all_reduce(s2, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tot, op=dist.ReduceOp.MAX)
+        sent_all, dt = float(s2[0].item()), float(tot[1].item())
+    else:
+        sent_all = float(sent)
+    if rank == 0:
+        cnt = eng.fetch()["counters"]
+        cross_pp = cnt["crossings"] / max(cnt["packets"], 1)
+        nRT = m.rt["RT_n_incl"] * m.rt["RT_n_az"]
+        # per crossing: kappa_factor 8 B + one 64-byte xI_scatt record RMW per observer
+        bytes_step = sent_all / world / args.steps * cross_pp * (8.0 + 2 * 64.0 * nRT)
+        line = {
+            "metric": "photon packets/sec (whole node), SED-mode MC packet loop with ray-tracing deposits",
+            "value": sent_all / dt, "unit": "packets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "ref4.1 2D disk 100x70, SED Monte Carlo of wavelengths %s, 128 streams/GPU x %d packets "
+                                   "in the stop bin each, RT1 deposits for %d observers (both passes timed)"
+                                   % (args.sed_lambdas, n2, nRT),
+                       "packets_per_gpu_per_step": sent_all / world / args.steps, "crossings_per_packet": cross_pp},
+            "roofline": {"bound": "hbm", "achieved": bytes_step / (dt / args.steps) / 1e9, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": bytes_step / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_mono (scout + commit)", "algorithmic_bytes_per_launch": bytes_step},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import Oracle
+            cores = _quota_cores()
+            orc = Oracle(m, 5e6)
+            t = time.perf_counter()
+            r = orc.run_mono(lams[0], max(2, int(2e5 / 11 / m.cfg.n_photons_loop)), seed=5, n_threads=cores)
+            dtc = time.perf_counter() - t
+            line["cpu_baseline"] = dict(value=r["counters"]["packets"] / dtc, unit="packets/s", cores=cores, kind="port",
+                                        sample="%d packets of wavelength %d of the same SED workload, %d OpenMP threads, "
+                                               "%.1f s" % (r["counters"]["packets"], lams[0], cores, dtc))
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--packets", type=float, default=1e8, help="packets per GPU per step")
-    ap.add_argument("--config", default="ref41", choices=["ref41", "ref41_3d", "pascucci", "voronoi"])
+    ap.add_argument("--config", default="ref41", choices=["ref41", "ref41_3d", "pascucci", "voronoi", "sed"])
+    ap.add_argument("--sed-lambdas", default="5,15,25,35",
+                    help="--config sed: wavelengths (1-based) whose SED Monte Carlo one step runs")
     ap.add_argument("--sites", type=int, default=100000,
                     help="--config voronoi: number of SPH-like sites of the tessellation (BASELINE config 5 stand-in)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -90,6 +186,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    if args.config == "sed":
+        return bench_sed(args, world, rank, local_rank)
     cfg = {"ref41": M.ref41, "ref41_3d": M.ref41_3d, "pascucci": M.pascucci, "voronoi": M.ref41}[args.config]()
     if args.no_pola:
         cfg.lsepar_pola = False

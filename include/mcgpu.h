@@ -284,6 +284,10 @@ int mcgpu_run_mono(mcgpu_ctx *ctx, const mcgpu_mono_opts *opts,
  * array and/or the FP64 sums the engine accumulates.  Either pointer may be NULL. */
 int mcgpu_fetch_xI(mcgpu_ctx *ctx, float *xI_scatt_f32, double *xI_scatt_f64);
 
+/* The device-resident FP64 xI_scatt accumulator (engine layout) for an in-place RCCL
+ * all-reduce across the ranks of a multi-GPU SED step; fetch afterwards with mcgpu_fetch_xI. */
+int mcgpu_device_xI(mcgpu_ctx *ctx, void **xI_dev, uint64_t *n_doubles);
+
 /* Temp_finale (thermal_emission.f90:870-906): Tdust(icell) from the summed
  * absorbed-energy grid.  E_abs == NULL uses the device accumulator. */
 int mcgpu_temp_finale(mcgpu_ctx *ctx, const double *E_abs, float *Tdust);

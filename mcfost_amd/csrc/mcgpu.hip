@@ -1062,6 +1062,13 @@ extern "C" int mcgpu_run_mono(mcgpu_ctx* ctx, const mcgpu_mono_opts* o, double f
   return MCGPU_OK;
 }
 
+extern "C" int mcgpu_device_xI(mcgpu_ctx* ctx, void** xI_dev, uint64_t* n_doubles) {
+  if (!ctx || !ctx->d_xI) return fail(ctx, MCGPU_ERR_STATE, "no xI_scatt accumulated yet");
+  if (xI_dev) *xI_dev = ctx->d_xI;
+  if (n_doubles) *n_doubles = ctx->n_xI / ctx->N_type_flux * XI_LINE;
+  return MCGPU_OK;
+}
+
 extern "C" int mcgpu_fetch_xI(mcgpu_ctx* ctx, float* xI_scatt_f32, double* xI_scatt_f64) {
   if (!ctx || !ctx->d_xI) return fail(ctx, MCGPU_ERR_STATE, "no xI_scatt accumulated yet");
   HIPCHK(hipSetDevice(ctx->device));

@@ -33,6 +33,7 @@ ABI_SYMBOLS = (
     "mcgpu_probe_cross_cell", "mcgpu_probe_index_cell", "mcgpu_probe_philox",
     "mcgpu_probe_packet_rand", "mcgpu_set_midplane_snap", "mcgpu_set_grid_voronoi",
     "mcgpu_probe_cross_voronoi", "mcgpu_set_rt1", "mcgpu_run_mono", "mcgpu_fetch_xI",
+    "mcgpu_device_xI",
 )
 
 
@@ -255,6 +256,14 @@ class Engine:
         t_acc = torch.as_tensor(_DevArray(acc.value, n.value, "<f8"), device=dev)
         t_cnt = torch.as_tensor(_DevArray(cnt.value, N_COUNTERS, "<i8"), device=dev)
         return t_acc, t_cnt
+
+    def device_xI(self):
+        """The FP64 xI_scatt accumulator (engine layout) as a zero-copy torch tensor."""
+        import torch
+
+        p, n = C.c_void_p(), C.c_uint64()
+        self._chk(self.lib.mcgpu_device_xI(self.ctx, C.byref(p), C.byref(n)), "mcgpu_device_xI")
+        return torch.as_tensor(_DevArray(p.value, n.value, "<f8"), device=torch.device("cuda", self.device))
 
     # -- probes (parity tests) ---------------------------------------------
     def probe_cross_cell(self, x0, y0, z0, u, v, w, cell):

@@ -1,6 +1,6 @@
 """Throughput sweeps on the GPU (tuning aid, not part of the product)."""
 import os, sys, json, subprocess
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def run(env, packets=2e7, extra=()):
     e = dict(os.environ); e.update(env)
     out = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--packets", str(packets), "--no-cpu-baseline", *extra],

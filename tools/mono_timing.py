@@ -2,7 +2,7 @@
 """Timing of the SED-mode packet loop (mcgpu_run_mono) on the ref4.1 grid: packets/s per wavelength,
 split of the scout and commit passes.  Not the benchmark (bench.py is)."""
 import argparse, json, sys, time, os
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from mcfost_amd.engine import Engine
 from mcfost_amd.host import model as M

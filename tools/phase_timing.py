@@ -1,5 +1,5 @@
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["MCGPU_LIB"] = os.path.abspath("mcfost_amd/csrc/variants/lib_timing.so")
 pass
 from mcfost_amd.host import model as M
