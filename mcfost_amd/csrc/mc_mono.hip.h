@@ -219,40 +219,84 @@ __device__ inline void deposit_rt1_wave(const DevModel& M, const MonoArgs& A, co
   }
 }
 
+// LDS of a SED-mode workgroup after the shared tables: the Mueller columns of p_lambda, the per-lane
+// results of angles_scatt_rt1 and the per-wave deposit tiles (mono_lds_bytes is the matching size).
+struct MonoLds {
+  float* mu;
+  RtScratch R;
+  double* tile;
+  unsigned long long* tile_addr;
+  unsigned int* tile_mask;
+};
+
+template <bool POLA>
+__device__ inline MonoLds mono_lds_setup(const DevModel& M, const MonoArgs& A, double* lds_base) {
+  MonoLds L;
+  const int na1 = M.nang + 1;
+  L.mu = reinterpret_cast<float*>(lds_base + (lds_bytes(M) + 7) / 8);
+  double* p = lds_base + (lds_bytes(M) + 7) / 8 + ((size_t)6 * na1 * sizeof(float) + 7) / 8;
+  L.R.cosw = p;
+  L.R.sinw = p + (POLA ? (size_t)A.nRT * blockDim.x : 0);
+  p += (POLA ? (size_t)2 * A.nRT * blockDim.x : 0);
+  L.tile = p + (size_t)(threadIdx.x >> 6) * 64 * XI_LINE;  // this wave's 64 x 8 doubles
+  p += (size_t)blockDim.x * XI_LINE;
+  L.tile_addr = reinterpret_cast<unsigned long long*>(p) + (size_t)(threadIdx.x >> 6) * 64;
+  p += blockDim.x;
+  L.R.itheta = reinterpret_cast<int*>(p);
+  L.tile_mask = reinterpret_cast<unsigned int*>(L.R.itheta + (size_t)A.nRT * blockDim.x) + (size_t)(threadIdx.x >> 6) * 64;
+  // the Mueller columns of p_lambda
+  const size_t col = (size_t)na1 * (A.p_lambda - 1);
+  for (int i = threadIdx.x; i < na1; i += blockDim.x) {
+    L.mu[i] = A.s11 ? A.s11[i] : 0.0f;
+    if (POLA) {
+      L.mu[na1 + i] = M.s12[col + i]; L.mu[2 * na1 + i] = M.s22[col + i]; L.mu[3 * na1 + i] = M.s33[col + i];
+      L.mu[4 * na1 + i] = M.s34[col + i]; L.mu[5 * na1 + i] = M.s44[col + i];
+    }
+  }
+  __syncthreads();
+  return L;
+}
+
+// work item -> (stream, sequence number) (see the header comment)
+template <bool SCOUT>
+__device__ inline void mono_item(const MonoArgs& A, unsigned long long my, unsigned long long& chunk,
+                                 unsigned long long& seq) {
+  if (SCOUT) {
+    const unsigned long long a = my / A.batch;
+    chunk = (unsigned long long)A.active[a];
+    seq = A.seq0[chunk] + (my - a * A.batch);
+  } else {
+    int lo = 0, hi = A.n_chunks;  // item_base[lo] <= my < item_base[hi]
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (A.item_base[mid] <= my) lo = mid; else hi = mid;
+    }
+    chunk = (unsigned long long)lo;
+    seq = my - A.item_base[lo];
+  }
+}
+
+// forced scattering (dust_transfer.f90:1263-1278): the packet's weight after the albedo, or dead
+template <bool POLA>
+__device__ inline bool mono_attenuate(const Lds& T, int lambda, double S[4]) {
+  const double alb = (double)T.albedo[lambda - 1];
+  S[0] *= alb;
+  if (POLA) { S[1] *= alb; S[2] *= alb; S[3] *= alb; }
+  return S[0] < (double)(FLT_TINY_X1E6);
+}
+
 // SCOUT: no deposits, no SED; records hits.  Otherwise the COMMIT pass.
 template <bool L3D, bool POLA, bool DARK, bool SCOUT>
 __device__ __forceinline__ void mono_body(const DevModel& M, const MonoArgs& A, double* lds_base) {
   const Lds T = lds_carve(lds_base, M);
   lds_stage(T, M);
   const int na1 = M.nang + 1;
-  float* mu = reinterpret_cast<float*>(lds_base + (lds_bytes(M) + 7) / 8);
-  RtScratch R;
-  double* tile;
-  unsigned long long* tile_addr;
-  unsigned int* tile_mask;
-  {
-    double* p = lds_base + (lds_bytes(M) + 7) / 8 + ((size_t)6 * na1 * sizeof(float) + 7) / 8;
-    R.cosw = p;
-    R.sinw = p + (POLA ? (size_t)A.nRT * blockDim.x : 0);
-    p += (POLA ? (size_t)2 * A.nRT * blockDim.x : 0);
-    tile = p + (size_t)(threadIdx.x >> 6) * 64 * XI_LINE;           // this wave's 64 x 8 doubles
-    p += (size_t)blockDim.x * XI_LINE;
-    tile_addr = reinterpret_cast<unsigned long long*>(p) + (size_t)(threadIdx.x >> 6) * 64;
-    p += blockDim.x;
-    R.itheta = reinterpret_cast<int*>(p);
-    tile_mask = reinterpret_cast<unsigned int*>(R.itheta + (size_t)A.nRT * blockDim.x) + (size_t)(threadIdx.x >> 6) * 64;
-  }
-  {  // the Mueller columns of p_lambda, and the phase-function CDF of p_lambda for the forced scattering
-    const size_t col = (size_t)na1 * (A.p_lambda - 1);
-    for (int i = threadIdx.x; i < na1; i += blockDim.x) {
-      mu[i] = A.s11 ? A.s11[i] : 0.0f;
-      if (POLA) {
-        mu[na1 + i] = M.s12[col + i]; mu[2 * na1 + i] = M.s22[col + i]; mu[3 * na1 + i] = M.s33[col + i];
-        mu[4 * na1 + i] = M.s34[col + i]; mu[5 * na1 + i] = M.s44[col + i];
-      }
-    }
-  }
-  __syncthreads();
+  const MonoLds ML = mono_lds_setup<POLA>(M, A, lds_base);
+  const float* mu = ML.mu;
+  const RtScratch& R = ML.R;
+  double* const tile = ML.tile;
+  unsigned long long* const tile_addr = ML.tile_addr;
+  unsigned int* const tile_mask = ML.tile_mask;
   const float* prob_p = M.prob_s11 + (size_t)na1 * (A.p_lambda - 1);
 
   const int lane = threadIdx.x & 63;
@@ -304,19 +348,7 @@ __device__ __forceinline__ void mono_body(const DevModel& M, const MonoArgs& A, 
           // work item -> (stream, sequence number)
           my_item = my;
           unsigned long long chunk, seq;
-          if (SCOUT) {
-            const unsigned long long a = my / A.batch;
-            chunk = (unsigned long long)A.active[a];
-            seq = A.seq0[chunk] + (my - a * A.batch);
-          } else {
-            int lo = 0, hi = A.n_chunks;  // item_base[lo] <= my < item_base[hi]
-            while (hi - lo > 1) {
-              const int mid = (lo + hi) >> 1;
-              if (A.item_base[mid] <= my) lo = mid; else hi = mid;
-            }
-            chunk = (unsigned long long)lo;
-            seq = my - A.item_base[lo];
-          }
+          mono_item<SCOUT>(A, my, chunk, seq);
           rng.init(A.seed, ((chunk + (unsigned long long)A.first_chunk) << 40) | seq);
           c_pack++;
           pk_cross = 0;
@@ -364,12 +396,7 @@ __device__ __forceinline__ void mono_body(const DevModel& M, const MonoArgs& A, 
       tau_rand = g[5];
       bool dead = false;
       if (DARK) dead = M.dark[cell_index<L3D>(n_rad, nz, ri, zj, k)] != 0;
-      if (!dead) {
-        const double alb = (double)T.albedo[lambda - 1];
-        S[0] *= alb;
-        if (POLA) { S[1] *= alb; S[2] *= alb; S[3] *= alb; }
-        dead = S[0] < (double)(FLT_TINY_X1E6);
-      }
+      if (!dead) dead = mono_attenuate<POLA>(T, lambda, S);
       if (dead) {
         c_abs++;
         st = S_EMIT;  // lpacket_alive = .false.: not binned

@@ -17,6 +17,7 @@
 #include "mc_rounds.hip.h"
 #include "mc_voronoi.hip.h"
 #include "mc_mono.hip.h"
+#include "mc_mono_voronoi.hip.h"
 
 using namespace mcgpu;
 
@@ -874,7 +875,7 @@ extern "C" int mcgpu_set_rt1(mcgpu_ctx* ctx, int RT_n_incl, int RT_n_az, const d
   const bool pola = ctx->lsepar_pola != 0;
   const int want = pola ? (lsepar_contrib ? 8 : 4) : (lsepar_contrib ? 5 : 1);  // init_mcfost.f90:1603-1616
   if (N_type_flux != want) return fail(ctx, MCGPU_ERR_ARG, "N_type_flux inconsistent with lsepar_pola / lsepar_contrib");
-  if (ctx->M.l3D ? (n_az_rt != 1 || n_theta_rt != 1) : (n_theta_rt != 2))
+  if ((ctx->M.l3D || ctx->voro) ? (n_az_rt != 1 || n_theta_rt != 1) : (n_theta_rt != 2))
     return fail(ctx, MCGPU_ERR_UNSUPPORTED, "n_az_rt / n_theta_rt must follow dust_ray_tracing.f90:91-98");
   HIPCHK(hipSetDevice(ctx->device));
   int rc;
@@ -897,7 +898,9 @@ static int launch_mono(mcgpu_ctx* ctx, const MonoArgs& A, int grid_blocks, int b
   if (lds > 160 * 1024) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "too many ray-tracing directions for the LDS of one CU");
   const void* fn;
 #define PICK(a, b, c) fn = (const void*)k_mono<a, b, c, SCOUT>
-  if (l3d) {
+  if (ctx->voro) {
+    fn = pola ? (const void*)k_mono_voro<true, SCOUT> : (const void*)k_mono_voro<false, SCOUT>;
+  } else if (l3d) {
     if (pola) { if (dark) PICK(true, true, true); else PICK(true, true, false); }
     else { if (dark) PICK(true, false, true); else PICK(true, false, false); }
   } else {
@@ -915,7 +918,7 @@ static int launch_mono(mcgpu_ctx* ctx, const MonoArgs& A, int grid_blocks, int b
     const unsigned long long need = (A.n_items + threads - 1) / threads;
     if ((unsigned long long)blocks > need) blocks = (int)(need ? need : 1);
   }
-  void* args[] = {(void*)&M, (void*)&A};
+  void* args[] = {(void*)&M, (void*)&A, (void*)&ctx->V};  // the Voronoi kernels take the grid as 3rd argument
   HIPCHK(hipLaunchKernel(fn, dim3(blocks), dim3(threads), args, lds, ctx->stream));
   return MCGPU_OK;
 }
@@ -925,7 +928,6 @@ extern "C" int mcgpu_run_mono(mcgpu_ctx* ctx, const mcgpu_mono_opts* o, double f
   int rc = ready(ctx);
   if (rc) return rc;
   if (!o) return fail(ctx, MCGPU_ERR_ARG, "null options");
-  if (ctx->voro) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "SED mode on Voronoi grids is not built yet");
   DevModel& M = ctx->M;
   if (o->lambda < 1 || o->lambda > M.n_lambda || o->n_chunks < 1 || o->n_chunks > (1 << 22) || o->capt_sup < 1 ||
       o->first_chunk < 0 || (long long)o->first_chunk + o->n_chunks > (1 << 23))

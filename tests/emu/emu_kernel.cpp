@@ -65,77 +65,89 @@ namespace mcgpu { double lds_raw[1 << 18]; }
 #include "../../mcfost_amd/csrc/mc_rounds.hip.h"
 #include "../../mcfost_amd/csrc/mc_voronoi.hip.h"
 #include "../../mcfost_amd/csrc/mc_mono.hip.h"
+#include "../../mcfost_amd/csrc/mc_mono_voronoi.hip.h"
 #include "../../oracle/mc_oracle.h"
 
 using namespace mcgpu;
 
-// oracle_model -> DevModel, as the setters of mcgpu.hip do
-extern "C" int emu_run_thermal(const oracle_model* m, const oracle_opts* o, const double* E_prior, double* E_abs,
-                               double* sed, double* n_sent, uint64_t* counters) {
+// oracle_model -> DevModel (+ VoroGrid), as the setters of mcgpu.hip do
+struct Conv {
   DevModel M;
-  memset(&M, 0, sizeof(M));
-  const bool voro = m->grid_type == 3;
-  M.n_rad = m->n_rad; M.nz = m->nz; M.n_az = m->n_az; M.l3D = m->l3D; M.n_cells = m->n_cells;
-  M.r_lim_2 = m->r_lim_2; M.zmax = m->zmax; M.tan_phi_lim = m->tan_phi_lim;
-  std::vector<double> ch(m->n_rad);
-  const double dummy = 0.0;
-  if (voro) { M.n_rad = 0; M.nz = 0; M.n_az = 0; M.l3D = 1; M.r_lim_2 = &dummy; }
-  else for (int i = 0; i < m->n_rad; ++i) ch[i] = m->nz >= 2 ? m->z_lim[i + m->n_rad] : m->zmax[i];
-  M.ch = ch.data();
-  M.zmaxmax = m->zmaxmax; M.Rmax2 = m->Rmax2; M.volume = m->volume;
-  // Voronoi records, as mcgpu_set_grid_voronoi + mcgpu_set_opacity build them
   VoroGrid G;
-  memset(&G, 0, sizeof(G));
+  bool voro;
+  std::vector<double> ch, sx, ct;
+  std::vector<int> sc;
   std::vector<VoroCell> vcell;
   std::vector<VoroNb> vnb;
-  if (voro) {
-    vcell.resize(m->n_cells);
-    vnb.resize(m->v_last[m->n_cells - 1]);
-    for (int i = 0; i < m->n_cells; ++i) {
-      VoroCell& Cc = vcell[i];
-      Cc.x = m->v_xyz[3 * i]; Cc.y = m->v_xyz[3 * i + 1]; Cc.z = m->v_xyz[3 * i + 2];
-      Cc.first = m->v_first[i] - 1; Cc.count = m->v_last[i] - m->v_first[i] + 1;
-      Cc.flags = (m->v_was_cut && m->v_was_cut[i] ? 1 : 0) | (m->v_is_star_neighbour && m->v_is_star_neighbour[i] ? 2 : 0);
-      Cc.kf = m->kappa_factor[i];
-      for (int q = m->v_first[i] - 1; q < m->v_last[i]; ++q) {
-        const int id = m->v_neigh[q];
-        vnb[q].id = id;
-        if (id > 0) { vnb[q].x = m->v_xyz[3 * (id - 1)]; vnb[q].y = m->v_xyz[3 * (id - 1) + 1]; vnb[q].z = m->v_xyz[3 * (id - 1) + 2]; }
-        else { vnb[q].x = vnb[q].y = vnb[q].z = 0.0f; }
+  double dummy = 0.0;
+  explicit Conv(const oracle_model* m) {
+    memset(&M, 0, sizeof(M));
+    memset(&G, 0, sizeof(G));
+    voro = m->grid_type == 3;
+    M.n_rad = m->n_rad; M.nz = m->nz; M.n_az = m->n_az; M.l3D = m->l3D; M.n_cells = m->n_cells;
+    M.r_lim_2 = m->r_lim_2; M.zmax = m->zmax; M.tan_phi_lim = m->tan_phi_lim;
+    ch.assign(m->n_rad > 0 ? m->n_rad : 1, 0.0);
+    if (voro) { M.n_rad = 0; M.nz = 0; M.n_az = 0; M.l3D = 1; M.r_lim_2 = &dummy; }
+    else for (int i = 0; i < m->n_rad; ++i) ch[i] = m->nz >= 2 ? m->z_lim[i + m->n_rad] : m->zmax[i];
+    M.ch = ch.data();
+    M.zmaxmax = m->zmaxmax; M.Rmax2 = m->Rmax2; M.volume = m->volume;
+    if (voro) {  // the records mcgpu_set_grid_voronoi + mcgpu_set_opacity build
+      vcell.resize(m->n_cells);
+      vnb.resize(m->v_last[m->n_cells - 1]);
+      for (int i = 0; i < m->n_cells; ++i) {
+        VoroCell& Cc = vcell[i];
+        Cc.x = m->v_xyz[3 * i]; Cc.y = m->v_xyz[3 * i + 1]; Cc.z = m->v_xyz[3 * i + 2];
+        Cc.first = m->v_first[i] - 1; Cc.count = m->v_last[i] - m->v_first[i] + 1;
+        Cc.flags = (m->v_was_cut && m->v_was_cut[i] ? 1 : 0) | (m->v_is_star_neighbour && m->v_is_star_neighbour[i] ? 2 : 0);
+        Cc.kf = m->kappa_factor[i];
+        for (int q = m->v_first[i] - 1; q < m->v_last[i]; ++q) {
+          const int id = m->v_neigh[q];
+          vnb[q].id = id;
+          if (id > 0) { vnb[q].x = m->v_xyz[3 * (id - 1)]; vnb[q].y = m->v_xyz[3 * (id - 1) + 1]; vnb[q].z = m->v_xyz[3 * (id - 1) + 2]; }
+          else { vnb[q].x = vnb[q].y = vnb[q].z = 0.0f; }
+        }
       }
+      G.n_cells = m->n_cells; G.cell = vcell.data(); G.nb = vnb.data(); G.h = m->v_h; G.xyz_dp = m->v_xyz_dp;
+      G.wall_first = m->v_wall_first; G.wall_cells = m->v_wall_cells; G.cut_o_h = m->v_cut_o_h;
+      memcpy(G.walls, m->v_walls, 24 * sizeof(float));
     }
-    G.n_cells = m->n_cells; G.cell = vcell.data(); G.nb = vnb.data(); G.h = m->v_h; G.xyz_dp = m->v_xyz_dp;
-    G.wall_first = m->v_wall_first; G.wall_cells = m->v_wall_cells; G.cut_o_h = m->v_cut_o_h;
-    memcpy(G.walls, m->v_walls, 24 * sizeof(float));
+    M.n_stars = m->n_stars;
+    sx.resize(4 * m->n_stars);
+    sc.resize(4 * m->n_stars);
+    for (int s = 0; s < m->n_stars; ++s) {
+      sx[4 * s] = m->stars[s].x; sx[4 * s + 1] = m->stars[s].y; sx[4 * s + 2] = m->stars[s].z; sx[4 * s + 3] = m->stars[s].r;
+      int ic = m->stars[s].icell;
+      if (voro) { sc[4 * s] = ic; sc[4 * s + 1] = 0; sc[4 * s + 2] = 0; }
+      else { sc[4 * s] = m->cell_map_i[ic - 1]; sc[4 * s + 1] = m->cell_map_j[ic - 1]; sc[4 * s + 2] = m->cell_map_k[ic - 1]; }
+      sc[4 * s + 3] = m->stars[s].out_model;
+    }
+    M.star_xyzr = sx.data(); M.star_cell = sc.data();
+    M.n_lambda = m->n_lambda; M.kappa = m->kappa; M.kappa_abs = m->kappa_abs_LTE; M.albedo = m->albedo;
+    M.kappa_factor = m->kappa_factor;
+    bool any_dark = false;
+    if (m->l_dark_zone) for (int i = 0; i < m->n_cells; ++i) any_dark |= m->l_dark_zone[i] != 0;
+    M.dark = any_dark ? m->l_dark_zone : nullptr;
+    M.nang = m->nang_scatt; M.aniso_method = m->aniso_method; M.lisotropic = m->lisotropic;
+    M.p_lambda_fixed = m->p_lambda_fixed;
+    M.prob_s11 = m->prob_s11_pos; M.s12 = m->s12_o_s11; M.s22 = m->s22_o_s11; M.s33 = m->s33_o_s11;
+    M.s34 = m->s34_o_s11; M.s44 = m->s44_o_s11; M.tab_g = m->tab_g_pos;
+    ct.resize(m->nang_scatt + 1);
+    for (int k = 0; k <= m->nang_scatt; ++k) ct[k] = std::cos(((double)k) * PI / (double)m->nang_scatt);
+    M.cos_tab = ct.data();
+    M.n_T = m->n_T; M.log_Qcool = m->log_Qcool; M.cdf = m->kdB_dT_CDF; M.spec_cum = m->spectre_emission_cumul;
+    M.frac_E_stars = m->frac_E_stars; M.frac_E_disk = m->frac_E_disk; M.CDF_E_star = m->CDF_E_star;
+    M.prob_E_cell = m->prob_E_cell; M.L_packet_th = m->L_packet_th;
+    M.N_thet = m->N_thet; M.N_phi = m->N_phi; M.sym_c = m->l_sym_centrale; M.sym_a = m->l_sym_axiale;
+    M.midplane_snap = m->midplane_snap;
   }
-  M.n_stars = m->n_stars;
-  std::vector<double> sx(4 * m->n_stars);
-  std::vector<int> sc(4 * m->n_stars);
-  for (int s = 0; s < m->n_stars; ++s) {
-    sx[4 * s] = m->stars[s].x; sx[4 * s + 1] = m->stars[s].y; sx[4 * s + 2] = m->stars[s].z; sx[4 * s + 3] = m->stars[s].r;
-    int ic = m->stars[s].icell;
-    if (voro) { sc[4 * s] = ic; sc[4 * s + 1] = 0; sc[4 * s + 2] = 0; }
-    else { sc[4 * s] = m->cell_map_i[ic - 1]; sc[4 * s + 1] = m->cell_map_j[ic - 1]; sc[4 * s + 2] = m->cell_map_k[ic - 1]; }
-    sc[4 * s + 3] = m->stars[s].out_model;
-  }
-  M.star_xyzr = sx.data(); M.star_cell = sc.data();
-  M.n_lambda = m->n_lambda; M.kappa = m->kappa; M.kappa_abs = m->kappa_abs_LTE; M.albedo = m->albedo;
-  M.kappa_factor = m->kappa_factor;
-  bool any_dark = false;
-  if (m->l_dark_zone) for (int i = 0; i < m->n_cells; ++i) any_dark |= m->l_dark_zone[i] != 0;
-  M.dark = any_dark ? m->l_dark_zone : nullptr;
-  M.nang = m->nang_scatt; M.aniso_method = m->aniso_method; M.lisotropic = m->lisotropic;
-  M.p_lambda_fixed = m->p_lambda_fixed;
-  M.prob_s11 = m->prob_s11_pos; M.s12 = m->s12_o_s11; M.s22 = m->s22_o_s11; M.s33 = m->s33_o_s11;
-  M.s34 = m->s34_o_s11; M.s44 = m->s44_o_s11; M.tab_g = m->tab_g_pos;
-  std::vector<double> ct(m->nang_scatt + 1);
-  for (int k = 0; k <= m->nang_scatt; ++k) ct[k] = std::cos(((double)k) * PI / (double)m->nang_scatt);
-  M.cos_tab = ct.data();
-  M.n_T = m->n_T; M.log_Qcool = m->log_Qcool; M.cdf = m->kdB_dT_CDF; M.spec_cum = m->spectre_emission_cumul;
-  M.frac_E_stars = m->frac_E_stars; M.frac_E_disk = m->frac_E_disk; M.CDF_E_star = m->CDF_E_star;
-  M.prob_E_cell = m->prob_E_cell; M.L_packet_th = m->L_packet_th;
-  M.N_thet = m->N_thet; M.N_phi = m->N_phi; M.sym_c = m->l_sym_centrale; M.sym_a = m->l_sym_axiale;
-  M.midplane_snap = m->midplane_snap;
+};
+
+extern "C" int emu_run_thermal(const oracle_model* m, const oracle_opts* o, const double* E_prior, double* E_abs,
+                               double* sed, double* n_sent, uint64_t* counters) {
+  Conv cv(m);
+  const DevModel& M = cv.M;
+  const VoroGrid& G = cv.G;
+  const bool voro = cv.voro;
   if (lds_bytes(M) + sizeof(double) * m->n_cells > sizeof(lds_raw)) return 31;
 
   const size_t nsed = (size_t)9 * m->n_lambda * m->N_thet * m->N_phi;
@@ -214,42 +226,10 @@ extern "C" int emu_run_thermal(const oracle_model* m, const oracle_opts* o, cons
 // ---- SED mode: the host orchestration of mcgpu_run_mono with one emulated lane --------------
 extern "C" int emu_run_mono(const oracle_model* m, const oracle_mono_opts* o, double* xI, double* sed, double* n_sent,
                             uint64_t* n_sent_chunk, uint64_t* counters) {
-  if (m->grid_type == 3) return 41;
-  DevModel M;
-  memset(&M, 0, sizeof(M));
-  M.n_rad = m->n_rad; M.nz = m->nz; M.n_az = m->n_az; M.l3D = m->l3D; M.n_cells = m->n_cells;
-  M.r_lim_2 = m->r_lim_2; M.zmax = m->zmax; M.tan_phi_lim = m->tan_phi_lim;
-  std::vector<double> ch(m->n_rad);
-  for (int i = 0; i < m->n_rad; ++i) ch[i] = m->nz >= 2 ? m->z_lim[i + m->n_rad] : m->zmax[i];
-  M.ch = ch.data();
-  M.zmaxmax = m->zmaxmax; M.Rmax2 = m->Rmax2; M.volume = m->volume;
-  M.n_stars = m->n_stars;
-  std::vector<double> sx(4 * m->n_stars);
-  std::vector<int> sc(4 * m->n_stars);
-  for (int s = 0; s < m->n_stars; ++s) {
-    sx[4 * s] = m->stars[s].x; sx[4 * s + 1] = m->stars[s].y; sx[4 * s + 2] = m->stars[s].z; sx[4 * s + 3] = m->stars[s].r;
-    int ic = m->stars[s].icell;
-    sc[4 * s] = m->cell_map_i[ic - 1]; sc[4 * s + 1] = m->cell_map_j[ic - 1]; sc[4 * s + 2] = m->cell_map_k[ic - 1];
-    sc[4 * s + 3] = m->stars[s].out_model;
-  }
-  M.star_xyzr = sx.data(); M.star_cell = sc.data();
-  M.n_lambda = m->n_lambda; M.kappa = m->kappa; M.kappa_abs = m->kappa_abs_LTE; M.albedo = m->albedo;
-  M.kappa_factor = m->kappa_factor;
-  bool any_dark = false;
-  if (m->l_dark_zone) for (int i = 0; i < m->n_cells; ++i) any_dark |= m->l_dark_zone[i] != 0;
-  M.dark = any_dark ? m->l_dark_zone : nullptr;
-  M.nang = m->nang_scatt; M.aniso_method = m->aniso_method; M.lisotropic = m->lisotropic;
-  M.p_lambda_fixed = m->p_lambda_fixed;
-  M.prob_s11 = m->prob_s11_pos; M.s12 = m->s12_o_s11; M.s22 = m->s22_o_s11; M.s33 = m->s33_o_s11;
-  M.s34 = m->s34_o_s11; M.s44 = m->s44_o_s11; M.tab_g = m->tab_g_pos;
-  std::vector<double> ct(m->nang_scatt + 1);
-  for (int k = 0; k <= m->nang_scatt; ++k) ct[k] = std::cos(((double)k) * PI / (double)m->nang_scatt);
-  M.cos_tab = ct.data();
-  M.n_T = m->n_T; M.log_Qcool = m->log_Qcool; M.cdf = m->kdB_dT_CDF; M.spec_cum = m->spectre_emission_cumul;
-  M.frac_E_stars = m->frac_E_stars; M.frac_E_disk = m->frac_E_disk; M.CDF_E_star = m->CDF_E_star;
-  M.prob_E_cell = m->prob_E_cell; M.L_packet_th = m->L_packet_th;
-  M.N_thet = m->N_thet; M.N_phi = m->N_phi; M.sym_c = m->l_sym_centrale; M.sym_a = m->l_sym_axiale;
-  M.midplane_snap = m->midplane_snap;
+  Conv cv(m);
+  const DevModel& M = cv.M;
+  const VoroGrid& G = cv.G;
+  const bool voro = cv.voro;
 
   const size_t nsed = (size_t)9 * m->n_lambda * m->N_thet * m->N_phi;
   const int nRT = m->RT_n_incl * m->RT_n_az;
@@ -274,7 +254,8 @@ extern "C" int emu_run_mono(const oracle_model* m, const oracle_mono_opts* o, do
   A.xI = xI_dev.data(); A.sed = sed; A.n_sent = n_sent; A.counters = cnt; A.next_item = cnt + 8; A.err = &err;
   A.inner_iters = 8; A.min_active = 0;
 #define MONO(sc_) do {                                                                     \
-    if (l3d) {                                                                            \
+    if (voro) { if (pola) k_mono_voro<true, sc_>(M, A, G); else k_mono_voro<false, sc_>(M, A, G); }               \
+    else if (l3d) {                                                                            \
       if (pola) { if (dark) k_mono<true, true, true, sc_>(M, A); else k_mono<true, true, false, sc_>(M, A); }      \
       else { if (dark) k_mono<true, false, true, sc_>(M, A); else k_mono<true, false, false, sc_>(M, A); }         \
     } else {                                                                              \

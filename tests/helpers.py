@@ -33,12 +33,12 @@ def rel_rms(T, Tref, T_floor):
     return float(np.sqrt(np.mean(((T[sel] - Tref[sel]) / Tref[sel]) ** 2)))
 
 
-def sed_model(cfg, n_thermal=100000):
+def sed_model(cfg, n_thermal=100000, voronoi_sites=0, seed=3):
     """A model whose SED-step emission tables (frac_E_stars, prob_E_cell) come from a thermal step of
     the CPU oracle, like run_sed_mc's come from the temperature step."""
     from mcfost_amd.host import model as M
     from oracle import Oracle
-    m = M.build_model(cfg)
+    m = M.build_voronoi_model(cfg, voronoi_sites, seed=seed) if voronoi_sites else M.build_model(cfg)
     orc = Oracle(m, n_thermal)
     T = orc.temp_finale(orc.run_thermal(n_thermal, seed=3, n_threads=1)["E_abs"])  # 1 thread: reproducible
     M.repartition_energie(m, T)

@@ -590,8 +590,13 @@ def test_sed_mode_abi_errors(sed_small):
     with pytest.raises(McgpuError):
         e.run_mono(3, 5, n_chunks=2 ** 23)    # more streams than the engine takes
     e.close()
-    vm = M.build_voronoi_model(M.small(lsepar_pola=False), 300, seed=8)
-    e = _engine(vm, 1e4)
-    with pytest.raises(McgpuError):           # SED mode on Voronoi grids: not built
-        e.run_mono(3, 5, rt1=False)
-    e.close()
+
+
+def test_sed_mode_voronoi():
+    """SED mode on a Voronoi grid: same checks as on the cylindrical grids."""
+    from helpers import sed_model
+    m = sed_model(M.small(), voronoi_sites=3000, n_thermal=100000)
+    for lam in (3, 9, 14):
+        a, b = _mono_parity(m, lam, 10, 80 + lam)
+        assert a["sed"][4][0, m.capt_sup - 1, lam - 1] == 64 * 10
+    _mono_parity(sed_model(M.small(lsepar_pola=False), voronoi_sites=1500, n_thermal=50000), 9, 10, 4)

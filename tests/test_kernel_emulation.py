@@ -218,3 +218,12 @@ def test_emulated_sed_mode_variants(emu):
     m = sed_model(M.small(RT_n_incl=2, RT_n_az=3, RT_az_max=90.0, RT_imin=20.0, RT_imax=70.0))
     check_mono(emu, m, 5, 5, 11)                                                        # several azimuths
     check_mono(emu, sed_model(M.small()), 4, 5, 12, rt1=False)                         # no ray-tracing deposits
+
+
+def test_emulated_sed_mode_voronoi(emu):
+    """SED mode on a Voronoi grid (mc_mono_voronoi.hip.h): cut cells, star site, cell-centre disk emission."""
+    m = sed_model(M.small(), voronoi_sites=1200, n_thermal=50000)
+    assert m.rt["n_az_rt"] == 1 and m.rt["n_theta_rt"] == 1
+    for lam in (3, 14):
+        check_mono(emu, m, lam, 6, 70 + lam)
+    check_mono(emu, sed_model(M.small(lsepar_pola=False), voronoi_sites=600, n_thermal=30000), 9, 5, 3)
