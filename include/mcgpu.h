@@ -89,6 +89,16 @@ int mcgpu_set_grid_cyl(mcgpu_ctx *ctx, int n_rad, int nz, int n_az, int l3D,
                        const int *lexit_cell);
 
 /*
+ * Interstellar radiation field: packets whose emission draw exceeds frac_E_disk(lambda) start
+ * on the sphere (centre_ISM, R_ISM) with a cosine law towards the interior (emit_packet_ISM,
+ * stars.f90:27-28, 655-666, 728-785) and are binned only once the dust has absorbed and
+ * re-emitted them (flag_ISM, dust_transfer.f90:549).  R_ISM = 0 (default): no such source, a
+ * draw beyond frac_E_disk is an error.  The weight of the field enters through the host's
+ * spectre_emission_cumul / frac_E_disk (E_ISM, thermal_emission.f90:329-341, 1916-1917).
+ */
+int mcgpu_set_ism(mcgpu_ctx *ctx, double R_ISM, const double *centre_ISM);
+
+/*
  * Voronoi grid: module Voronoi_grid (Voronoi.f90:23-67), the arrays
  * Voronoi_tesselation (:183-640) leaves behind.  All ids are 1-based.
  *   voronoi_xyz(3,n_cells)   Voronoi_xyz, default real (:62)

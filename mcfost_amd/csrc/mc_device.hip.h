@@ -113,6 +113,8 @@ struct DevModel {
   int N_thet, N_phi, sym_c, sym_a;
   // 3D midplane crossings land at sign(grid_prec, w) (see include/mcgpu.h)
   int midplane_snap;
+  // interstellar radiation field: emitting sphere (stars.f90:27-28); R_ISM = 0: no ISM emission
+  double R_ISM, centre_ISM[3];
 };
 
 // Packet pool of the two-kernel engine (mc_rounds.hip.h): structure of arrays in HBM indexed
@@ -1095,6 +1097,82 @@ __device__ __forceinline__ void interact(const Lds& T, const DevModel& M, const 
 }
 
 // ---------------------------------------------------------------------------
+// emit_packet (dust_transfer.f90:1047-1151) for any grid.  f = the emission event's draws (see
+// Rng): f1 chooses star / disk / ISM against frac_E_stars, frac_E_disk; star: f2 select_star,
+// f3..f6 emit_packet_uniform_sphere; disk: f2 select_cellule, f3..f5 pos_em_cell, f6,f7 direction;
+// ISM: f2..f5 emit_packet_ISM (stars.f90:728-785).  Ops supplies the grid operators and keeps the
+// packet's cell: star_cell(i_star, x,y,z), bool enter_grid(x,y,z,u,v,w), disk_cell(icell, r1,r2,r3,
+// x,y,z).  Returns 0, or the error code of a source the tables do not provide.
+// ---------------------------------------------------------------------------
+template <class Ops>
+__device__ inline int emit_packet(const DevModel& M, const float f[12], int lambda, double frac_E_stars,
+                                  double frac_E_disk, const double* prob_E_cell, Ops& ops, double& x, double& y,
+                                  double& z, double& u, double& v, double& w, bool& flag_star, bool& flag_ism,
+                                  bool& lintersect) {
+  lintersect = true;
+  flag_ism = false;
+  if ((double)f[1] <= frac_E_stars) {
+    flag_star = true;
+    const int i_star = select_star(M, lambda, f[2]);
+    emit_uniform_sphere(M, i_star, f[3], f[4], f[5], f[6], x, y, z, u, v, w);
+    ops.star_cell(i_star, x, y, z);
+    if (M.star_cell[4 * (i_star - 1) + 3]) lintersect = ops.enter_grid(x, y, z, u, v, w);
+    return 0;
+  }
+  flag_star = false;
+  if ((double)f[1] <= frac_E_disk) {
+    if (!prob_E_cell) return 12;
+    const int icell = select_cellule(prob_E_cell, M.n_cells, f[2]);
+    ops.disk_cell(icell, f[3], f[4], f[5], x, y, z);
+    random_isotropic_direction(f[6], f[7], u, v, w);
+    return 0;
+  }
+  if (!(M.R_ISM > 0.0)) return 12;
+  flag_ism = true;  // emit_packet_ISM: a point of the sphere, cosine law towards the interior
+  z = 2.0 * (double)f[2] - 1.0;
+  const double srw02 = sqrt(1.0 - z * z);
+  const double argmt = PI * (2.0 * (double)f[3] - 1.0);
+  double sa, ca;
+  sincos(argmt, &sa, &ca);
+  x = srw02 * ca;
+  y = srw02 * sa;
+  const double cospsi = -sqrt((double)f[4]);
+  const double phi = 2.0 * PI * (double)f[5];
+  cdapres(cospsi, phi, x, y, z, u, v, w);
+  x = M.centre_ISM[0] + x * M.R_ISM;
+  y = M.centre_ISM[1] + y * M.R_ISM;
+  z = M.centre_ISM[2] + z * M.R_ISM;
+  lintersect = ops.enter_grid(x, y, z, u, v, w);
+  return 0;
+}
+
+// the cylindrical grid's operators for emit_packet; the packet's cell lives in (ri, zj, k)
+template <bool L3D>
+struct CylEmitOps {
+  const Lds& T;
+  const DevModel& M;
+  int &ri, &zj, &k;
+  __device__ inline void star_cell(int, double x, double y, double z) { index_cell<L3D>(T, M, x, y, z, ri, zj, k); }
+  __device__ inline bool enter_grid(double& x, double& y, double& z, double u, double v, double w) {
+    return move_to_grid<L3D>(T, M, x, y, z, u, v, w, ri, zj, k);
+  }
+  __device__ inline void disk_cell(int icell, float r1, float r2, float r3, double& x, double& y, double& z) {
+    int q = icell - 1;  // inverse of the closed-form mapping
+    ri = q % M.n_rad + 1;
+    q /= M.n_rad;
+    if (L3D) {
+      const int jj = q % (2 * M.nz);
+      k = q / (2 * M.nz) + 1;
+      zj = jj < M.nz ? jj - M.nz : jj - M.nz + 1;
+    } else {
+      zj = q + 1;
+      k = 1;
+    }
+    pos_em_cell<L3D>(T, M, ri, zj, k, r1, r2, r3, x, y, z);
+  }
+};
+
+// ---------------------------------------------------------------------------
 // The thermal packet kernel
 // ---------------------------------------------------------------------------
 // LDSE: the absorbed-energy grid of this workgroup lives in LDS (2D grids:
@@ -1122,7 +1200,7 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
   int ri = 0, zj = 1, k = 1, ri_o = 0, zj_o = 1, k_o = 1;
   int lambda = 1;
   int star_key = -1;  // packed (ri,zj,k) of the star the flight would hit
-  bool flag_star = false, flag_scatt = false;
+  bool flag_star = false, flag_scatt = false, flag_ism = false;
   double S[4] = {1.0, 0.0, 0.0, 0.0};
   Rng rng;
   rng.init(0, 0);
@@ -1145,8 +1223,10 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
     TP_START();
     // ---- EXITED: bin the packets that left the grid (capteur) --------------
     if (st == S_EXITED) {
-      capteur<POLA>(M, A.sed, lambda, u, v, w, S, flag_star, flag_scatt);
-      c_esc++;
+      if (!flag_ism) {  // ISM packets that were never absorbed are not binned (dust_transfer.f90:549)
+        capteur<POLA>(M, A.sed, lambda, u, v, w, S, flag_star, flag_scatt);
+        c_esc++;
+      }
       st = S_EMIT;
     }
 
@@ -1211,40 +1291,15 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
             float rand = f[0];
             lambda = select_wl_em(T, M, rand);
             atomic_add_f64(&A.n_sent[lambda - 1], 1.0);
-            // emit_packet (dust_transfer.f90:1047-1151)
-            bool lintersect = true;
-            rand = f[1];
+            bool lintersect;
             flag_scatt = false;
             S[0] = 1.0; S[1] = 0.0; S[2] = 0.0; S[3] = 0.0;
-            if ((double)rand <= T.fstar[lambda - 1]) {
-              flag_star = true;
-              const int i_star = select_star(M, lambda, f[2]);
-              emit_uniform_sphere(M, i_star, f[3], f[4], f[5], f[6], x, y, z, u, v, w);
-              index_cell<L3D>(T, M, x, y, z, ri, zj, k);
-              if (M.star_cell[4 * (i_star - 1) + 3])
-                lintersect = move_to_grid<L3D>(T, M, x, y, z, u, v, w, ri, zj, k);
-            } else if ((double)rand <= M.frac_E_disk[lambda - 1] && M.prob_E_cell) {
-              flag_star = false;
-              const int icell = select_cellule(M, lambda, f[2]);
-              // inverse of the closed-form mapping
-              {
-                int q = icell - 1;
-                ri = q % n_rad + 1;
-                q /= n_rad;
-                if (L3D) {
-                  int jj = q % (2 * nz);
-                  k = q / (2 * nz) + 1;
-                  zj = jj < nz ? jj - nz : jj - nz + 1;
-                } else {
-                  zj = q + 1;
-                  k = 1;
-                }
-              }
-              const float r1 = f[3], r2 = f[4], r3 = f[5];
-              pos_em_cell<L3D>(T, M, ri, zj, k, r1, r2, r3, x, y, z);
-              random_isotropic_direction(f[6], f[7], u, v, w);
-            } else {
-              *A.err = 12;  // ISM emission / missing prob_E_cell: not in scope
+            CylEmitOps<L3D> ops{T, M, ri, zj, k};
+            const int rc = emit_packet(M, f, lambda, T.fstar[lambda - 1], M.frac_E_disk[lambda - 1],
+                                       M.prob_E_cell ? M.prob_E_cell + (size_t)(M.n_cells + 1) * (lambda - 1) : nullptr,
+                                       ops, x, y, z, u, v, w, flag_star, flag_ism, lintersect);
+            if (rc) {  // a source the tables do not provide
+              *A.err = rc;
               st = S_DONE;
             }
             if (st != S_DONE) st = lintersect ? S_NEWFLIGHT : S_EXITED;  // never entered the grid:
@@ -1278,6 +1333,7 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
         }
         return E;
       }, M.volume + ic);
+      if (!flag_scatt) flag_ism = false;  // absorbed and re-emitted by the dust (:1367)
       u = u1; v = v1; w = w1;
       st = S_NEWFLIGHT;
     }

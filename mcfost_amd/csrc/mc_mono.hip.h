@@ -307,7 +307,7 @@ __device__ __forceinline__ void mono_body(const DevModel& M, const MonoArgs& A, 
   double xo = 0, yo = 0, zo = 0;
   int ri = 0, zj = 1, k = 1, ri_o = 0, zj_o = 1, k_o = 1;
   int star_key = -1;
-  bool flag_star = false, flag_scatt = false;
+  bool flag_star = false, flag_scatt = false, flag_ism = false;
   double S[4] = {1.0, 0.0, 0.0, 0.0};
   Rng rng;
   rng.init(0, 0);
@@ -318,10 +318,12 @@ __device__ __forceinline__ void mono_body(const DevModel& M, const MonoArgs& A, 
   double kf = 0.0;
 
   for (;;) {
-    if (st == S_EXITED) {  // capteur (dust_transfer.f90:549-552)
-      const int capt = capteur<POLA, true>(M, SCOUT ? nullptr : A.sed, lambda, u, v, w, S, flag_star, flag_scatt);
-      if (SCOUT) { if (capt == A.capt_sup) A.hits[my_item] = 1; }
-      if (capt > 0) c_esc++;
+    if (st == S_EXITED) {  // capteur (dust_transfer.f90:549-552); forced scattering never clears flag_ISM
+      if (!flag_ism) {
+        const int capt = capteur<POLA, true>(M, SCOUT ? nullptr : A.sed, lambda, u, v, w, S, flag_star, flag_scatt);
+        if (SCOUT) { if (capt == A.capt_sup) A.hits[my_item] = 1; }
+        if (capt > 0) c_esc++;
+      }
       st = S_EMIT;
     }
     {
@@ -356,33 +358,14 @@ __device__ __forceinline__ void mono_body(const DevModel& M, const MonoArgs& A, 
           rng.emission_event(f);  // f[0]: the wavelength draw of the thermal step, unused (lmono, :535)
           tau_rand = f[8];
           if (!SCOUT) atomic_add_f64(&A.n_sent[lambda - 1], 1.0);
-          bool lintersect = true;
+          bool lintersect;
           flag_scatt = false;
           S[0] = 1.0; S[1] = 0.0; S[2] = 0.0; S[3] = 0.0;
-          if ((double)f[1] <= A.frac_E_stars) {  // emit_packet (dust_transfer.f90:1047-1151)
-            flag_star = true;
-            const int i_star = select_star(M, lambda, f[2]);
-            emit_uniform_sphere(M, i_star, f[3], f[4], f[5], f[6], x, y, z, u, v, w);
-            index_cell<L3D>(T, M, x, y, z, ri, zj, k);
-            if (M.star_cell[4 * (i_star - 1) + 3]) lintersect = move_to_grid<L3D>(T, M, x, y, z, u, v, w, ri, zj, k);
-          } else if ((double)f[1] <= A.frac_E_disk && A.prob_E_cell) {
-            flag_star = false;
-            const int icell = select_cellule(A.prob_E_cell, M.n_cells, f[2]);
-            int q = icell - 1;
-            ri = q % n_rad + 1;
-            q /= n_rad;
-            if (L3D) {
-              const int jj = q % (2 * nz);
-              k = q / (2 * nz) + 1;
-              zj = jj < nz ? jj - nz : jj - nz + 1;
-            } else {
-              zj = q + 1;
-              k = 1;
-            }
-            pos_em_cell<L3D>(T, M, ri, zj, k, f[3], f[4], f[5], x, y, z);
-            random_isotropic_direction(f[6], f[7], u, v, w);
-          } else {
-            *A.err = 12;  // ISM emission / missing prob_E_cell
+          CylEmitOps<L3D> ops{T, M, ri, zj, k};
+          const int rc = emit_packet(M, f, lambda, A.frac_E_stars, A.frac_E_disk, A.prob_E_cell, ops, x, y, z, u, v, w,
+                                     flag_star, flag_ism, lintersect);
+          if (rc) {
+            *A.err = rc;
             st = S_DONE;
           }
           if (st != S_DONE) st = lintersect ? S_NEWFLIGHT : S_EXITED;

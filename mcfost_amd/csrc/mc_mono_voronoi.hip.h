@@ -22,7 +22,7 @@ __device__ __forceinline__ void mono_body_voro(const DevModel& M, const MonoArgs
   int st = S_EMIT;
   double x = 0, y = 0, z = 0, u = 0, v = 0, w = 1, extr = 0;
   int icell = 0, prev_cell = 0, star_icell = 0;
-  bool flag_star = false, flag_scatt = false;
+  bool flag_star = false, flag_scatt = false, flag_ism = false;
   double S[4] = {1.0, 0.0, 0.0, 0.0};
   Rng rng;
   rng.init(0, 0);
@@ -33,9 +33,11 @@ __device__ __forceinline__ void mono_body_voro(const DevModel& M, const MonoArgs
 
   for (;;) {
     if (st == S_EXITED) {
-      const int capt = capteur<POLA, true>(M, SCOUT ? nullptr : A.sed, lambda, u, v, w, S, flag_star, flag_scatt);
-      if (SCOUT) { if (capt == A.capt_sup) A.hits[my_item] = 1; }
-      if (capt > 0) c_esc++;
+      if (!flag_ism) {
+        const int capt = capteur<POLA, true>(M, SCOUT ? nullptr : A.sed, lambda, u, v, w, S, flag_star, flag_scatt);
+        if (SCOUT) { if (capt == A.capt_sup) A.hits[my_item] = 1; }
+        if (capt > 0) c_esc++;
+      }
       st = S_EMIT;
     }
     {
@@ -69,23 +71,14 @@ __device__ __forceinline__ void mono_body_voro(const DevModel& M, const MonoArgs
           rng.emission_event(f);
           tau_rand = f[8];
           if (!SCOUT) atomic_add_f64(&A.n_sent[lambda - 1], 1.0);
-          bool lintersect = true;
+          bool lintersect;
           flag_scatt = false;
           S[0] = 1.0; S[1] = 0.0; S[2] = 0.0; S[3] = 0.0;
-          if ((double)f[1] <= A.frac_E_stars) {  // emit_packet (dust_transfer.f90:1047-1151)
-            flag_star = true;
-            const int i_star = select_star(M, lambda, f[2]);
-            emit_uniform_sphere(M, i_star, f[3], f[4], f[5], f[6], x, y, z, u, v, w);
-            icell = M.star_cell[4 * (i_star - 1)];
-            if (M.star_cell[4 * (i_star - 1) + 3]) lintersect = voro_move_to_grid(G, x, y, z, u, v, w, icell);
-          } else if ((double)f[1] <= A.frac_E_disk && A.prob_E_cell) {
-            flag_star = false;
-            icell = select_cellule(A.prob_E_cell, M.n_cells, f[2]);
-            const double* c = G.xyz_dp + 3 * (size_t)(icell - 1);  // pos_em_cell_voronoi (Voronoi.f90:1510-1542)
-            x = c[0]; y = c[1]; z = c[2];
-            random_isotropic_direction(f[6], f[7], u, v, w);
-          } else {
-            *A.err = 12;
+          VoroEmitOps ops{G, M, icell};
+          const int rc = emit_packet(M, f, lambda, A.frac_E_stars, A.frac_E_disk, A.prob_E_cell, ops, x, y, z, u, v, w,
+                                     flag_star, flag_ism, lintersect);
+          if (rc) {
+            *A.err = rc;
             st = S_DONE;
           }
           if (st != S_DONE) st = lintersect ? S_NEWFLIGHT : S_EXITED;

@@ -236,6 +236,22 @@ __device__ inline bool voro_move_to_grid(const VoroGrid& G, double& x, double& y
   return true;
 }
 
+// the Voronoi grid's operators for emit_packet (mc_device.hip.h); the packet's cell is `icell`
+struct VoroEmitOps {
+  const VoroGrid& G;
+  const DevModel& M;
+  int& icell;
+  __device__ inline void star_cell(int i_star, double, double, double) { icell = M.star_cell[4 * (i_star - 1)]; }  // stars.f90:155-156
+  __device__ inline bool enter_grid(double& x, double& y, double& z, double u, double v, double w) {
+    return voro_move_to_grid(G, x, y, z, u, v, w, icell);
+  }
+  __device__ inline void disk_cell(int ic, float, float, float, double& x, double& y, double& z) {
+    icell = ic;
+    const double* c = G.xyz_dp + 3 * (size_t)(ic - 1);  // pos_em_cell_voronoi (Voronoi.f90:1510-1542): the cell centre
+    x = c[0]; y = c[1]; z = c[2];
+  }
+};
+
 // ---------------------------------------------------------------------------
 // Deposit cache: 2^log_ns slots of (cell id, partial sum) in LDS
 // ---------------------------------------------------------------------------
@@ -287,7 +303,7 @@ __device__ __forceinline__ void thermal_body_voro(const DevModel& M, const RunAr
   double x = 0, y = 0, z = 0, u = 0, v = 0, w = 1, extr = 0;
   int icell = 0, prev_cell = 0, lambda = 1;
   int star_icell = 0;  // cell of the star this flight would hit (0: none)
-  bool flag_star = false, flag_scatt = false;
+  bool flag_star = false, flag_scatt = false, flag_ism = false;
   double S[4] = {1.0, 0.0, 0.0, 0.0};
   Rng rng;
   rng.init(0, 0);
@@ -298,8 +314,10 @@ __device__ __forceinline__ void thermal_body_voro(const DevModel& M, const RunAr
 
   for (int ep = 0;; ++ep) {
     if (st == S_EXITED) {
-      capteur<POLA>(M, A.sed, lambda, u, v, w, S, flag_star, flag_scatt);
-      c_esc++;
+      if (!flag_ism) {
+        capteur<POLA>(M, A.sed, lambda, u, v, w, S, flag_star, flag_scatt);
+        c_esc++;
+      }
       st = S_EMIT;
     }
     {  // EMIT: packet ids from this wave's reserved batch (see thermal_body)
@@ -332,23 +350,15 @@ __device__ __forceinline__ void thermal_body_voro(const DevModel& M, const RunAr
           tau_rand = f[8];
           lambda = select_wl_em(T, M, f[0]);
           atomic_add_f64(&A.n_sent[lambda - 1], 1.0);
-          bool lintersect = true;
+          bool lintersect;
           flag_scatt = false;
           S[0] = 1.0; S[1] = 0.0; S[2] = 0.0; S[3] = 0.0;
-          if ((double)f[1] <= T.fstar[lambda - 1]) {  // emit_packet (dust_transfer.f90:1047-1151)
-            flag_star = true;
-            const int i_star = select_star(M, lambda, f[2]);
-            emit_uniform_sphere(M, i_star, f[3], f[4], f[5], f[6], x, y, z, u, v, w);
-            icell = M.star_cell[4 * (i_star - 1)];  // stars.f90:155-156
-            if (M.star_cell[4 * (i_star - 1) + 3]) lintersect = voro_move_to_grid(G, x, y, z, u, v, w, icell);
-          } else if ((double)f[1] <= M.frac_E_disk[lambda - 1] && M.prob_E_cell) {
-            flag_star = false;
-            icell = select_cellule(M, lambda, f[2]);
-            const double* c = G.xyz_dp + 3 * (size_t)(icell - 1);  // pos_em_cell_voronoi (:1510-1542)
-            x = c[0]; y = c[1]; z = c[2];
-            random_isotropic_direction(f[6], f[7], u, v, w);
-          } else {
-            *A.err = 12;
+          VoroEmitOps ops{G, M, icell};
+          const int rc = emit_packet(M, f, lambda, T.fstar[lambda - 1], M.frac_E_disk[lambda - 1],
+                                     M.prob_E_cell ? M.prob_E_cell + (size_t)(M.n_cells + 1) * (lambda - 1) : nullptr,
+                                     ops, x, y, z, u, v, w, flag_star, flag_ism, lintersect);
+          if (rc) {
+            *A.err = rc;
             st = S_DONE;
           }
           if (st != S_DONE) st = lintersect ? S_NEWFLIGHT : S_EXITED;
@@ -370,6 +380,7 @@ __device__ __forceinline__ void thermal_body_voro(const DevModel& M, const RunAr
         if (CACHE) E += DC.pending(ic + 1) * (double)gridDim.x;
         return E * A.qscale;
       }, M.volume + ic);
+      if (!flag_scatt) flag_ism = false;
       u = u1; v = v1; w = w1;
       st = S_NEWFLIGHT;
     }

@@ -441,6 +441,13 @@ extern "C" int mcgpu_set_thermal(mcgpu_ctx* ctx, int n_T, const float* tab_Temp,
   return MCGPU_OK;
 }
 
+extern "C" int mcgpu_set_ism(mcgpu_ctx* ctx, double R_ISM, const double* centre_ISM) {
+  if (!ctx || !(R_ISM >= 0.0) || (R_ISM > 0.0 && !centre_ISM)) return fail(ctx, MCGPU_ERR_ARG, "mcgpu_set_ism: bad argument");
+  ctx->M.R_ISM = R_ISM;
+  for (int q = 0; q < 3; ++q) ctx->M.centre_ISM[q] = centre_ISM ? centre_ISM[q] : 0.0;
+  return MCGPU_OK;
+}
+
 extern "C" int mcgpu_set_sed_bins(mcgpu_ctx* ctx, int N_thet, int N_phi, int l_sym_centrale, int l_sym_axiale) {
   if (!ctx || N_thet < 1 || N_phi < 1) return fail(ctx, MCGPU_ERR_ARG, "mcgpu_set_sed_bins: bad argument");
   ctx->M.N_thet = N_thet; ctx->M.N_phi = N_phi;
@@ -937,7 +944,7 @@ extern "C" int mcgpu_run_mono(mcgpu_ctx* ctx, const mcgpu_mono_opts* o, double f
   if (o->p_lambda < 1 || o->p_lambda > n_pos || o->p_lambda > M.n_lambda) return fail(ctx, MCGPU_ERR_ARG, "p_lambda out of range");
   if (frac_E_stars < 1.0 && frac_E_disk > frac_E_stars && !prob_E_cell)
     return fail(ctx, MCGPU_ERR_ARG, "disk emission needs prob_E_cell");
-  if (frac_E_disk < 1.0) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "ISM emission is not built");
+  if (frac_E_disk < 1.0 && !(M.R_ISM > 0.0)) return fail(ctx, MCGPU_ERR_ARG, "frac_E_disk < 1 needs mcgpu_set_ism");
   HIPCHK(hipSetDevice(ctx->device));
   if ((rc = ensure_accum(ctx))) return rc;
   const int nc = o->n_chunks;

@@ -33,7 +33,7 @@ ABI_SYMBOLS = (
     "mcgpu_probe_cross_cell", "mcgpu_probe_index_cell", "mcgpu_probe_philox",
     "mcgpu_probe_packet_rand", "mcgpu_set_midplane_snap", "mcgpu_set_grid_voronoi",
     "mcgpu_probe_cross_voronoi", "mcgpu_set_rt1", "mcgpu_run_mono", "mcgpu_fetch_xI",
-    "mcgpu_device_xI",
+    "mcgpu_device_xI", "mcgpu_set_ism",
 )
 
 
@@ -159,6 +159,10 @@ class Engine:
     def _upload_tables(self, m, n_tot):
         cfg, L = m.cfg, self.lib
         d, i32 = np.float64, np.int32
+        ism = getattr(m, "ism", None)
+        if ism is not None:
+            self._chk(L.mcgpu_set_ism(self.ctx, C.c_double(float(ism["R_ISM"])),
+                                      _p(_a(ism["centre_ISM"], d), C.c_double)), "mcgpu_set_ism")
         st = np.asarray(m.stars, d)
         cols = [_a(st[:, q], d) for q in range(4)]
         self._chk(L.mcgpu_set_stars(

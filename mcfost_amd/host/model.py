@@ -517,6 +517,7 @@ class Model:
     tab_s11_pos: Optional[np.ndarray] = None
     rt: Optional[dict] = None
     prob_E_cell: Optional[np.ndarray] = None
+    ism: Optional[dict] = None   # {"R_ISM": float, "centre_ISM": (3,)} (stars.f90:27-28); None: no ISM field
 
     @property
     def capt_sup(self):

@@ -89,6 +89,7 @@ class _Model(C.Structure):
         ("v_first", _ip), ("v_last", _ip), ("v_neigh", _ip), ("v_was_cut", _up),
         ("v_is_star_neighbour", _up), ("v_walls", _fp), ("v_cut_o_h", C.c_double),
         ("v_wall_first", _ip), ("v_wall_cells", _ip),
+        ("R_ISM", C.c_double), ("centre_ISM", C.c_double * 3),
         ("RT_n_incl", C.c_int), ("RT_n_az", C.c_int), ("tab_u_rt", _dp), ("tab_v_rt", _dp),
         ("tab_w_rt", _dp), ("n_az_rt", C.c_int), ("n_theta_rt", C.c_int), ("N_type_flux", C.c_int),
         ("lsepar_contrib", C.c_int), ("tab_s11_pos", _fp),
@@ -199,6 +200,11 @@ class Oracle:
         s.N_thet, s.N_phi = cfg.N_thet, cfg.N_phi
         s.l_sym_centrale, s.l_sym_axiale = int(cfg.l_sym_centrale), int(cfg.l_sym_axiale)
         s.midplane_snap = int(getattr(m, "midplane_snap", 0))
+        ism = getattr(m, "ism", None)
+        if ism is not None:
+            s.R_ISM = float(ism["R_ISM"])
+            for q in range(3):
+                s.centre_ISM[q] = float(ism["centre_ISM"][q])
         rt = getattr(m, "rt", None)
         if rt is not None:
             s.RT_n_incl, s.RT_n_az = int(rt["RT_n_incl"]), int(rt["RT_n_az"])

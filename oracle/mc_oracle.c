@@ -1311,8 +1311,25 @@ static int emit_packet(worker_t *W, int lambda, int *icell, double *x,
     }
     random_isotropic_direction(&W->rng, u, v, w);
     Stokes[0] = 1.0; Stokes[1] = 0.0; Stokes[2] = 0.0; Stokes[3] = 0.0;
-  } else {
-    return 12; /* ISM emission (stars.f90:728) not in scope */
+  } else { /* emit_packet_ISM (stars.f90:728-785) */
+    *flag_star = 0; *flag_ISM = 1;
+    if (!(m->R_ISM > 0.0)) return 12;
+    float r1 = rng_float(&W->rng), r2 = rng_float(&W->rng);
+    *z = 2.0 * (double)r1 - 1.0;
+    const double srw02 = sqrt(1.0 - (*z) * (*z));
+    const double argmt = PI * (2.0 * (double)r2 - 1.0);
+    *x = srw02 * cos(argmt);
+    *y = srw02 * sin(argmt);
+    float r3 = rng_float(&W->rng), r4 = rng_float(&W->rng);
+    const double cospsi = -sqrt((double)r3); /* towards the interior */
+    const double phi = 2.0 * PI * (double)r4;
+    oracle_cdapres(cospsi, phi, *x, *y, *z, u, v, w);
+    *x = m->centre_ISM[0] + *x * m->R_ISM;
+    *y = m->centre_ISM[1] + *y * m->R_ISM;
+    *z = m->centre_ISM[2] + *z * m->R_ISM;
+    Stokes[0] = 1.0; Stokes[1] = 0.0; Stokes[2] = 0.0; Stokes[3] = 0.0;
+    if (m->grid_type == 3) oracle_move_to_grid_voronoi(m, x, y, z, *u, *v, *w, icell, lintersect);
+    else oracle_move_to_grid_cyl(m, x, y, z, *u, *v, *w, icell, lintersect);
   }
   return 0;
 }

@@ -140,6 +140,10 @@ typedef struct {
   const int *v_wall_first; /* [7] offsets (0-based) into v_wall_cells */
   const int *v_wall_cells; /* wall(iwall)%neighbour_list, concatenated */
 
+  /* ---- interstellar radiation field: emitting sphere (stars.f90:27-28, 655-666) ---- */
+  double R_ISM;
+  double centre_ISM[3];
+
   /* ---- ray-tracing method 1 (dust_ray_tracing.f90:17-40, 80-160) ---- */
   int RT_n_incl, RT_n_az;   /* observer directions */
   const double *tab_u_rt;   /* (RT_n_incl, RT_n_az) */

@@ -139,6 +139,8 @@ struct Conv {
     M.prob_E_cell = m->prob_E_cell; M.L_packet_th = m->L_packet_th;
     M.N_thet = m->N_thet; M.N_phi = m->N_phi; M.sym_c = m->l_sym_centrale; M.sym_a = m->l_sym_axiale;
     M.midplane_snap = m->midplane_snap;
+    M.R_ISM = m->R_ISM;
+    for (int q = 0; q < 3; ++q) M.centre_ISM[q] = m->centre_ISM[q];
   }
 };
 

@@ -600,3 +600,41 @@ def test_sed_mode_voronoi():
         a, b = _mono_parity(m, lam, 10, 80 + lam)
         assert a["sed"][4][0, m.capt_sup - 1, lam - 1] == 64 * 10
     _mono_parity(sed_model(M.small(lsepar_pola=False), voronoi_sites=1500, n_thermal=50000), 9, 10, 4)
+
+
+def test_ism_emission_on_the_gpu(small_model):
+    """emit_packet's third branch (emit_packet_ISM, stars.f90:728-785) through mcgpu_set_ism: thermal step on
+    2D / 3D / Voronoi grids and the SED step; a draw beyond frac_E_disk without the sphere is an error."""
+    import copy
+    from mcfost_amd.engine import McgpuError
+
+    def with_ism(m, f_star=0.4, f_disk=0.7):
+        m = copy.copy(m)
+        g = m.grid
+        if g.get("grid_type", 1) == 3:
+            lim = g["limits"]
+            R = 1.000001 * float(np.sqrt(lim[1] ** 2 + lim[3] ** 2 + lim[5] ** 2))
+        else:
+            R = 1.000001 * float(np.sqrt(g["Rmax2"] + g["zmax"][-1] ** 2))
+        m.ism = dict(R_ISM=R, centre_ISM=(0.0, 0.0, 0.0))
+        rng = np.random.default_rng(0)
+        E_cell = rng.random((m.n_lambda, m.n_cells)) * m.kappa_factor[None, :]
+        pe = np.zeros((m.n_lambda, m.n_cells + 1))
+        pe[:, 1:] = np.cumsum(E_cell, axis=1)
+        pe /= pe[:, -1:]
+        m.prob_E_cell = pe.reshape(-1)
+        m.frac_E_stars = np.full(m.n_lambda, f_star)
+        m.frac_E_disk = np.full(m.n_lambda, f_disk)
+        return m
+
+    a, b = _frozen_parity(with_ism(small_model), 20000, seed=51, rtol=1e-5)
+    assert a["counters"]["escaped"] < 20000        # ISM packets that were never absorbed are not binned
+    _frozen_parity(with_ism(M.build_model(M.small(n_rad=10, nz=5, n_az=6, l3D=True))), 10000, seed=52, rtol=1e-5)
+    _frozen_parity(with_ism(M.build_voronoi_model(M.small(lsepar_pola=False), 1000, seed=4)), 10000, seed=53, rtol=1e-5)
+    _mono_parity(with_ism(small_model), 5, 6, 54)
+    m = with_ism(small_model)
+    m.ism = None
+    e = _engine(m, 1e4)
+    with pytest.raises(McgpuError):
+        e.run_thermal(2000, seed=1)
+    e.close()

@@ -227,3 +227,35 @@ def test_emulated_sed_mode_voronoi(emu):
     for lam in (3, 14):
         check_mono(emu, m, lam, 6, 70 + lam)
     check_mono(emu, sed_model(M.small(lsepar_pola=False), voronoi_sites=600, n_thermal=30000), 9, 5, 3)
+
+
+def _with_ism(m, f_star=0.4, f_disk=0.7):
+    """Star + disk + interstellar field: 30 % of the packets start on the ISM sphere."""
+    m = copy.copy(m)
+    g = m.grid
+    if g.get("grid_type", 1) == 3:
+        lim = g["limits"]
+        R = 1.000001 * float(np.sqrt(lim[1] ** 2 + lim[3] ** 2 + lim[5] ** 2))
+    else:
+        R = 1.000001 * float(np.sqrt(g["Rmax2"] + g["zmax"][-1] ** 2))   # stars.f90:657
+    m.ism = dict(R_ISM=R, centre_ISM=(0.0, 0.0, 0.0))
+    rng = np.random.default_rng(0)
+    E_cell = rng.random((m.n_lambda, m.n_cells)) * m.kappa_factor[None, :]
+    pe = np.zeros((m.n_lambda, m.n_cells + 1))
+    pe[:, 1:] = np.cumsum(E_cell, axis=1)
+    pe /= pe[:, -1:]
+    m.prob_E_cell = pe.reshape(-1)
+    m.frac_E_stars = np.full(m.n_lambda, f_star)
+    m.frac_E_disk = np.full(m.n_lambda, f_disk)
+    return m
+
+
+def test_emulated_ism_emission(emu, small_model):
+    """The third branch of emit_packet (emit_packet_ISM): thermal step on 2D, 3D and Voronoi grids, and
+    the SED step, where forced scattering never clears flag_ISM so these packets are never binned."""
+    a, b = check(emu, _with_ism(small_model), 3000, 31, rtol=1e-6)
+    assert a["counters"][5] < 3000                                   # some ISM packets leave unabsorbed
+    check(emu, _with_ism(M.build_model(M.small(n_rad=10, nz=5, n_az=6, l3D=True))), 2000, 32, rtol=1e-6)
+    check(emu, _with_ism(M.build_voronoi_model(M.small(lsepar_pola=False), 600, seed=4)), 2000, 33, rtol=1e-6)
+    a, b = check_mono(emu, _with_ism(small_model), 5, 4, 34)
+    assert a["counters"][5] < a["counters"][0] * 0.8

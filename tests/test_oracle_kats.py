@@ -238,3 +238,28 @@ def test_mono_optically_thin_mean_intensity():
     expect = 1.0 / (4 * np.pi * d2)
     ratio = J[sel] / expect[sel]
     assert abs(np.median(ratio) - 1.0) < 0.05, np.median(ratio)
+
+
+def test_ism_field_is_uniform_and_isotropic_inside_the_sphere():
+    """emit_packet_ISM (stars.f90:728-785): N packets leaving a sphere of radius R inwards with a cosine
+    law fill it with a uniform isotropic field; the path-length estimator per unit volume is N / (pi R^2)
+    (N mean chords 4R/3 in the volume 4/3 pi R^3)."""
+    from helpers import sed_model
+    cfg = M.small(dust="pascucci", lisotropic=True, lsepar_pola=False, dust_mass=1e-14)
+    m = sed_model(cfg, n_thermal=5000)
+    g = m.grid
+    R = 1.000001 * np.sqrt(g["Rmax2"] + g["zmax"][-1] ** 2)     # stars.f90:657
+    m.ism = dict(R_ISM=R, centre_ISM=(0.0, 0.0, 0.0))
+    m.frac_E_stars = np.zeros(m.n_lambda)
+    m.frac_E_disk = np.zeros(m.n_lambda)
+    orc = Oracle(m, 1e5)
+    lam = 6
+    r = orc.run_mono(lam, 10 ** 9, n_phot_lim=5000.0, seed=4, n_chunks=16, n_threads=4)   # 80000 ISM packets
+    c = r["counters"]
+    assert c["packets"] == 80000 and c["escaped"] == 0          # never absorbed: never binned (:549)
+    assert r["sed"].sum() == 0
+    x = r["xI_scatt"][:, 0, 0].sum(axis=(1, 2)) / m.tab_s11_pos[lam - 1][1]
+    J = x / g["volume"] / c["packets"] * (np.pi * R ** 2)
+    big = g["volume"] > np.percentile(g["volume"], 60)           # cells crossed by many packets
+    assert abs(np.median(J[big]) - 1.0) < 0.03, np.median(J[big])
+    assert np.std(J[big]) < 0.15
