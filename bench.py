@@ -41,6 +41,23 @@ def _quota_cores():
     return cores
 
 
+def pmc_traffic(config, n_local, world):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes of THIS command
+    (`tools/collect_profiles.sh`: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate runs of
+    `python bench.py --steps 1 --warmup 0`, summarised in profiles/r01_pmc_{fetch,write}.json).  Counters are in
+    KB; FETCH_SIZE is doubled for gfx950 (MI355X guide, HBM section).  None when the command differs."""
+    if config != "ref41" or world != 1 or int(n_local) != 100000000:
+        return None
+    try:
+        f = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_fetch.json")))
+        w = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_write.json")))
+        fk = f["pmc_k_thermal_sum_over_launches"]["FETCH_SIZE"] / f["pmc_k_thermal_launches"]["FETCH_SIZE"]
+        wk = w["pmc_k_thermal_sum_over_launches"]["WRITE_SIZE"] / w["pmc_k_thermal_launches"]["WRITE_SIZE"]
+        return (2.0 * fk + wk) * 1024.0
+    except Exception:
+        return None
+
+
 def cpu_baseline(model, n_total, target_s=15.0):
     """The CPU restatement (oracle, kind "port") timed on this box's host cores
     on a bounded sample of the same workload."""
@@ -270,7 +287,7 @@ def main():
                        "packets_per_gpu": n_local, "parallelism": "packets sharded x%d, tables replicated" % world,
                        "crossings_per_packet": cross_pp, "interactions_per_packet": inter_pp},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.config, n_local, world),
                          "kernel": "k_thermal_voro" if args.config == "voronoi" else "k_thermal", "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": bytes_launch},
         }

@@ -10,7 +10,7 @@ for f in glob.glob(os.path.join(src, "**", "*kernel_stats.csv"), recursive=True)
 for f in glob.glob(os.path.join(src, "**", "*counter_collection.csv"), recursive=True):
     acc = collections.defaultdict(float); n = collections.defaultdict(int)
     for r in csv.DictReader(open(f)):
-        if "k_thermal" in r["Kernel_Name"]:
+        if "k_thermal" in r["Kernel_Name"] or "k_mono" in r["Kernel_Name"]:
             acc[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
     for k in acc:
         out.setdefault("pmc_k_thermal_sum_over_launches", {})[k] = acc[k]
