@@ -126,7 +126,7 @@ struct Pool {
   int *ri, *zj, *k, *lambda, *star_key, *st;
   uint32_t *p_lo, *p_hi, *event;
 };
-constexpr int ST_MASK = 15, ST_STAR = 16, ST_SCATT = 32;  // Pool::st = state | flags
+constexpr int ST_MASK = 15, ST_STAR = 16, ST_SCATT = 32, ST_ISM = 64;  // Pool::st = state | flags
 
 struct RunArgs {
   uint64_t seed, first_packet, n_packets;
@@ -1265,7 +1265,7 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
           rng.k0 = (uint32_t)A.seed; rng.k1 = (uint32_t)(A.seed >> 32);
           rng.p_lo = Q.p_lo[slot]; rng.p_hi = Q.p_hi[slot]; rng.event = Q.event[slot];
           const int stw = Q.st[slot];
-          flag_star = (stw & ST_STAR) != 0; flag_scatt = (stw & ST_SCATT) != 0;
+          flag_star = (stw & ST_STAR) != 0; flag_scatt = (stw & ST_SCATT) != 0; flag_ism = (stw & ST_ISM) != 0;
           S[0] = 1.0; S[1] = 0.0; S[2] = 0.0; S[3] = 0.0;
           if (POLA) {
             S[0] = Q.S[slot]; S[1] = Q.S[Q.n_slots + slot];

@@ -221,7 +221,7 @@ __global__ void __launch_bounds__(256) k_serve(const DevModel M, const RunArgs A
     const int slot = valid ? R.list[i] : 0;
     int stw = valid ? P.st[slot] : S_DONE;
     int st = stw & ST_MASK;
-    bool flag_star = (stw & ST_STAR) != 0, flag_scatt = (stw & ST_SCATT) != 0;
+    bool flag_star = (stw & ST_STAR) != 0, flag_scatt = (stw & ST_SCATT) != 0, flag_ism = (stw & ST_ISM) != 0;
     double x = 0, y = 0, z = 0, u = 0, v = 0, w = 1, extr = 0;
     double S[4] = {1.0, 0.0, 0.0, 0.0};
     int ri = 0, zj = 1, k = 1, lambda = 1, star_key = -1;
@@ -244,8 +244,10 @@ __global__ void __launch_bounds__(256) k_serve(const DevModel M, const RunArgs A
     for (int rep = 0; rep < 4; ++rep) {  // > 1 turn only when a fresh packet misses the grid
       // ---- packets that left the grid or hit a star ---------------------------------------
       if (st == S_EXITED) {
-        capteur<POLA>(M, A.sed, lambda, u, v, w, S, flag_star, flag_scatt);
-        c_esc++;
+        if (!flag_ism) {
+          capteur<POLA>(M, A.sed, lambda, u, v, w, S, flag_star, flag_scatt);
+          c_esc++;
+        }
         st = S_EMIT;
       }
       if (st == S_KILLED) {
@@ -269,91 +271,18 @@ __global__ void __launch_bounds__(256) k_serve(const DevModel M, const RunArgs A
             float f[12];
             rng.emission_event(f);
             tau_rand = f[8];
-            float rand = f[0];
-            {  // select_wl_em (thermal_emission.f90:364-400)
-              int kmin = 0, kmax = M.n_lambda, kk = (kmin + kmax) / 2;
-              while (T.cum[kk] != (double)rand) {
-                if (T.cum[kk] < (double)rand) kmin = kk; else kmax = kk;
-                kk = (kmin + kmax) / 2;
-                if ((kmax - kmin) <= 1) break;
-              }
-              lambda = kmax;
-            }
+            lambda = select_wl_em(T, M, f[0]);
             atomic_add_f64(&A.n_sent[lambda - 1], 1.0);
-            bool lintersect = true;
-            rand = f[1];
+            bool lintersect;
             flag_scatt = false;
             S[0] = 1.0; S[1] = 0.0; S[2] = 0.0; S[3] = 0.0;
             st = S_NEWFLIGHT;
-            if ((double)rand <= T.fstar[lambda - 1]) {
-              flag_star = true;
-              rand = f[2];
-              int i_star;
-              {  // select_star (stars.f90:75-104)
-                int kmin = 0, kmax = M.n_stars, kk = (kmax - kmin) / 2;
-                while ((kmax - kmin) > 1) {
-                  if (M.CDF_E_star[(lambda - 1) + (size_t)M.n_lambda * kk] < (double)rand) kmin = kk;
-                  else kmax = kk;
-                  kk = (kmin + kmax) / 2;
-                }
-                i_star = kmax;
-              }
-              const float r1 = f[3], r2 = f[4], r3 = f[5], r4 = f[6];
-              // emit_packet_uniform_sphere (stars.f90:108-169)
-              z = 2.0 * (double)r1 - 1.0;
-              const double srw02 = sqrt(1.0 - z * z);
-              const double argmt = PI * (2.0 * (double)r2 - 1.0);
-              double sa, ca;
-              sincos(argmt, &sa, &ca);
-              x = srw02 * ca;
-              y = srw02 * sa;
-              const double cospsi = sqrt((double)r3);
-              const double phi = 2.0 * PI * (double)r4;
-              cdapres(cospsi, phi, x, y, z, u, v, w);
-              const double* st4 = &M.star_xyzr[4 * (i_star - 1)];
-              const double r_star = st4[3] * (1.0 + 1e-6);
-              x = x * r_star + st4[0];
-              y = y * r_star + st4[1];
-              z = z * r_star + st4[2];
-              index_cell<L3D>(T, M, x, y, z, ri, zj, k);
-              if (M.star_cell[4 * (i_star - 1) + 3]) lintersect = move_to_grid<L3D>(T, M, x, y, z, u, v, w, ri, zj, k);
-            } else if ((double)rand <= M.frac_E_disk[lambda - 1] && M.prob_E_cell) {
-              flag_star = false;
-              rand = f[2];
-              int icell;
-              {  // select_cellule (thermal_emission.f90:2044-2073)
-                const double* p = M.prob_E_cell + (size_t)(M.n_cells + 1) * (lambda - 1);
-                int kmin = 0, kmax = M.n_cells, kk = (kmin + kmax) / 2;
-                while ((kmax - kmin) > 1) {
-                  if (p[kk] < (double)rand) kmin = kk; else kmax = kk;
-                  kk = (kmin + kmax) / 2;
-                }
-                icell = kmax;
-              }
-              {
-                int q = icell - 1;
-                ri = q % n_rad + 1;
-                q /= n_rad;
-                if (L3D) {
-                  const int jj = q % (2 * nz);
-                  k = q / (2 * nz) + 1;
-                  zj = jj < nz ? jj - nz : jj - nz + 1;
-                } else {
-                  zj = q + 1;
-                  k = 1;
-                }
-              }
-              pos_em_cell<L3D>(T, M, ri, zj, k, f[3], f[4], f[5], x, y, z);
-              // random_isotropic_direction (random_numbers.f90:32-51)
-              w = 2.0 * (double)f[6] - 1.0;
-              const double uv = sqrt(1.0 - w * w);
-              const double ph = PI * (2.0 * (double)f[7] - 1.0);
-              double sp, cp;
-              sincos(ph, &sp, &cp);
-              u = uv * cp;
-              v = uv * sp;
-            } else {
-              *A.err = 12;  // ISM emission / missing prob_E_cell: not in scope
+            CylEmitOps<L3D> ops{T, M, ri, zj, k};
+            const int rc = emit_packet(M, f, lambda, T.fstar[lambda - 1], M.frac_E_disk[lambda - 1],
+                                       M.prob_E_cell ? M.prob_E_cell + (size_t)(M.n_cells + 1) * (lambda - 1) : nullptr,
+                                       ops, x, y, z, u, v, w, flag_star, flag_ism, lintersect);
+            if (rc) {
+              *A.err = rc;
               st = S_DONE;
             }
             if (st != S_DONE && !lintersect) st = S_EXITED;  // never entered the grid (:549-550)
@@ -368,79 +297,15 @@ __global__ void __launch_bounds__(256) k_serve(const DevModel M, const RunArgs A
       float g[8];
       rng.interaction_event(g);
       tau_rand = g[5];
-      const bool scat = g[0] < T.albedo[lambda - 1];
-      const float rand = g[1], rand2 = g[2];
-      int itheta = 1;
-      double cospsi, phi;
-      if (scat) {
-        flag_scatt = true;
-        c_scatt++;
-        if (M.aniso_method == 1) {  // angle_diff_theta_pos (scattering.f90:1433-1475)
-          const float* prob = T.prob + (M.p_lambda_fixed ? 0 : (size_t)(M.nang + 1) * (lambda - 1));
-          int kmin = 0, kmax = M.nang, kk = (kmin + kmax) / 2;
-          while ((kmax - kmin) > 1) {
-            if (prob[kk] < rand) kmin = kk; else kmax = kk;
-            kk = (kmin + kmax) / 2;
-          }
-          itheta = kmax;
-          const double c0 = T.cost[itheta - 1], c1 = T.cost[itheta];
-          cospsi = c0 + (double)rand2 * (c1 - c0);
-        } else {  // hg (scattering.f90:1354-1383)
-          const float gg = T.g[lambda - 1];
-          const double rand_dp = fmin((double)rand, 1.0 - 1e-6);
-          if (fabsf(gg) > 1.17549435e-38f) {
-            const double g1 = (double)gg, g2 = g1 * g1;
-            const double q = (1.0 - g2) / (1.0 - g1 + 2.0 * g1 * rand_dp);
-            cospsi = (1.0 + g2 - q * q) / (2.0 * g1);
-          } else {
-            cospsi = 2.0 * rand_dp - 1.0;
-          }
-          itheta = (int)floor(acos(cospsi) * 180.0 / PI) + 1;
-          if (itheta > M.nang) itheta = M.nang;
-        }
-        if (M.lisotropic) { itheta = 1; cospsi = 2.0 * (double)rand - 1.0; }
-        phi = PI * (2.0 * (double)g[3] - 1.0);
-      } else {
-        c_abs++;
-        flag_star = false;
-        flag_scatt = false;
-        // im_reemission_LTE (thermal_emission.f90:710-771); every k_fly launch folds its
-        // deposits into HBM, so the running sum below is the energy absorbed so far by all
-        // packets of this GPU (x n_replicas: thermal_emission.f90:670)
-        const int ic = cell_index<L3D>(n_rad, nz, ri, zj, k);
-        const double E = A.frozen ? A.E_prior[ic]
-                                  : __hip_atomic_load(&A.E_abs[ic], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * A.qscale;
-        int Ti;
-        double frac_T2;
-        temp_lte(T.lq, M.n_T, E, M.L_packet_th, M.volume[ic], Ti, frac_T2);
-        const double frac_T1 = 1.0 - frac_T2;
-        const double* cdf1 = T.cdf + (size_t)M.n_lambda * (Ti - 2);
-        const double* cdf2 = T.cdf + (size_t)M.n_lambda * (Ti - 1);
-        int l1 = 0, l2 = M.n_lambda, l = (l1 + l2) / 2;
-        while ((l2 - l1) > 1) {
-          const double proba = frac_T1 * cdf1[l - 1] + frac_T2 * cdf2[l - 1];
-          if ((double)rand2 > proba) l1 = l; else l2 = l;
-          l = (l1 + l2) / 2;
-        }
-        lambda = l + 1;
-        cospsi = 2.0 * (double)g[3] - 1.0;  // random_isotropic_direction == cdapres about z
-        phi = PI * (2.0 * (double)g[4] - 1.0);
-      }
       double u1, v1, w1;
-      cdapres(cospsi, phi, scat ? u : 0.0, scat ? v : 0.0, scat ? w : 1.0, u1, v1, w1);
-      if (POLA) {
-        if (scat && M.aniso_method == 1) {
-          const size_t o = (size_t)(M.nang + 1) * (lambda - 1) + itheta;
-          const float fr = rand2, fm = 1.0f - rand2;
-          const double M22 = (double)(M.s22[o] * fr + M.s22[o - 1] * fm);
-          const double M12 = (double)(M.s12[o] * fr + M.s12[o - 1] * fm);
-          const double M33 = (double)(M.s33[o] * fr + M.s33[o - 1] * fm);
-          const double M44 = (double)(M.s44[o] * fr + M.s44[o - 1] * fm);
-          const double M34 = (double)(-M.s34[o] * fr - M.s34[o - 1] * fm);
-          update_stokes(S, u, v, w, u1, v1, w1, M12, M22, M33, M34, M44);
-        }
-        if (!scat) { S[1] = 0.0; S[2] = 0.0; S[3] = 0.0; }
-      }
+      const int ic = cell_index<L3D>(n_rad, nz, ri, zj, k);
+      // every k_fly launch folds its deposits into HBM, so the running sum is the energy absorbed so
+      // far by all packets of this GPU (x n_replicas: thermal_emission.f90:670)
+      interact<POLA>(T, M, g, lambda, u, v, w, u1, v1, w1, S, flag_star, flag_scatt, c_scatt, c_abs, [&]() {
+        return A.frozen ? A.E_prior[ic]
+                        : __hip_atomic_load(&A.E_abs[ic], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * A.qscale;
+      }, M.volume + ic);
+      if (!flag_scatt) flag_ism = false;
       u = u1; v = v1; w = w1;
       st = S_NEWFLIGHT;
     }
@@ -472,7 +337,7 @@ __global__ void __launch_bounds__(256) k_serve(const DevModel M, const RunArgs A
           P.S[2 * (size_t)P.n_slots + slot] = S[2]; P.S[3 * (size_t)P.n_slots + slot] = S[3];
         }
       }
-      P.st[slot] = st | (flag_star ? ST_STAR : 0) | (flag_scatt ? ST_SCATT : 0);
+      P.st[slot] = st | (flag_star ? ST_STAR : 0) | (flag_scatt ? ST_SCATT : 0) | (flag_ism ? ST_ISM : 0);
     }
   }
 
