@@ -1370,6 +1370,9 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
         const int flying = __popcll(__ballot(st == S_FLIGHT)), alive = __popcll(__ballot(st != S_DONE));
         if (flying * 64 < A.min_active * alive) break;
       }
+#ifdef MCGPU_COUNT_ITERS  // diagnostic build (tools/loop_utilisation.py): wave iterations of this loop
+      if (lane == 0) c_dark++;
+#endif
       if (st == S_FLIGHT) {
         const int azj = zj < 0 ? -zj : zj;
         // test_exit_grid_cyl (cylindrical_grid.f90:680-704) in closed form
