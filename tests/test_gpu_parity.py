@@ -638,3 +638,43 @@ def test_ism_emission_on_the_gpu(small_model):
     with pytest.raises(McgpuError):
         e.run_thermal(2000, seed=1)
     e.close()
+
+
+def test_frozen_parity_pascucci_and_3d_baseline_grids():
+    """BASELINE configs 1 and 3 on their own grids (Pascucci 100x70, 61 wavelengths, isotropic; ref4.1_3D at
+    100 x 50 x 12 azimuths -- the full 72 azimuths in the property test below)."""
+    _frozen_parity(M.build_model(M.pascucci()), 60000, seed=61, n_prior=20000)
+    # thick-midplane random walks of 1e4+ flights: FMA-level drift accumulates in the path lengths (counts stay exact)
+    _frozen_parity(M.build_model(M.ref41_3d(n_az=12)), 60000, seed=62, n_prior=20000, rtol=1e-6)
+
+
+def test_full_size_properties_ref41_3d():
+    """BASELINE config 3's grid (100 x 50 x 72 = 720 000 cells) at a GPU-sized packet count: conservation,
+    azimuthal symmetry of the result, agreement of its azimuthal mean with the 2D run of the same disk."""
+    m3 = M.build_model(M.ref41_3d())
+    n = 20_000_000
+    e = _engine(m3, n)
+    a = e.run_thermal(n, seed=71)
+    c = a["counters"]
+    assert c["packets"] == n and c["escaped"] + c["killed_star"] == n and a["n_sent"].sum() == n
+    T3 = e.temp_finale(a["E_abs"]).reshape(72, 100, 100)        # (k, j: -50..-1,1..50, i)
+    e.close()
+    Tm = T3.mean(axis=0)
+    hot = Tm > 1.2 * m3.cfg.T_min
+    # every azimuth is a noisy copy of the mean: no systematic azimuthal structure
+    dev = (T3[:, hot] / Tm[hot] - 1.0)
+    assert abs(dev.mean(axis=1)).max() < 0.01
+    # north / south symmetry of the azimuthal mean
+    north, south = Tm[50:, :], Tm[49::-1, :]
+    sel = (north > 1.2 * m3.cfg.T_min) & (south > 1.2 * m3.cfg.T_min)
+    assert np.median(np.abs(north[sel] / south[sel] - 1.0)) < 0.01
+    # and the 2D grid of the same disk (nz = 50) gives the same temperature
+    cfg2 = M.ref41()
+    cfg2.nz = 50
+    m2 = M.build_model(cfg2)
+    e2 = _engine(m2, n)
+    T2 = e2.temp_finale(e2.run_thermal(n, seed=72)["E_abs"]).reshape(50, 100)
+    e2.close()
+    sel = (T2 > 1.2 * cfg2.T_min) & (north > 1.2 * cfg2.T_min)
+    ok, p75 = mc_similar(T2[sel], north[sel], 0.05)
+    assert ok, p75
