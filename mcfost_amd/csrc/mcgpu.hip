@@ -18,6 +18,7 @@
 #include "mc_voronoi.hip.h"
 #include "mc_mono.hip.h"
 #include "mc_mono_voronoi.hip.h"
+#include "mc_roles.hip.h"
 
 using namespace mcgpu;
 
@@ -517,6 +518,38 @@ static int launch_mega(mcgpu_ctx* ctx, const RunArgs& A, bool use_lds, int grid_
   }
   const bool pola = ctx->lsepar_pola != 0, dark = M.dark != nullptr, l3d = M.l3D != 0;
   hipError_t e;
+  // Waves with roles and LDS packet queues (mc_roles.hip.h): the default wherever the queues fit next to the
+  // tables and the grid has no dark zone.  MCGPU_ROLES: -1 = the single-role kernel (thermal_body), 0..7 = that
+  // many fixed flyer waves, 100+f = every wave picks its role per round (flyer when f lanes can fly; default 164).
+  int n_flyers = 164, k_short = 3, fly_iters = 16, fly_idle = 32;
+  if (const char* ev = getenv("MCGPU_ROLES")) n_flyers = atoi(ev);
+  {
+    const size_t lds_try = (lds_k + 7) / 8 * 8 + (pola ? sizeof(RoleQ<true>) : sizeof(RoleQ<false>));
+    if (lds_try > lds_cap && !getenv("MCGPU_ROLES")) n_flyers = -1;  // no room for the queues: single-role kernel
+  }
+  if (const char* ev = getenv("MCGPU_K_SHORT")) { int v = atoi(ev); if (v >= 1 && v <= 64) k_short = v; }
+  if (const char* ev = getenv("MCGPU_FLY_ITERS")) { int v = atoi(ev); if (v >= 1 && v <= 256) fly_iters = v; }
+  if (const char* ev = getenv("MCGPU_FLY_IDLE")) { int v = atoi(ev); if (v >= 1 && v <= 65) fly_idle = v; }
+  if (n_flyers >= 0 && !dark && !A.resume_pool) {
+    const size_t lds_r = (lds_k + 7) / 8 * 8 + (pola ? sizeof(RoleQ<true>) : sizeof(RoleQ<false>));
+    if (lds_r > lds_cap) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "MCGPU_ROLES: the packet queues do not fit in LDS next to the tables");
+    const int rthreads = (block_threads > 0 && block_threads <= MCGPU_LDS_BLOCK) ? block_threads : MCGPU_LDS_BLOCK;
+    if (n_flyers < 100 && n_flyers >= rthreads / 64) n_flyers = rthreads / 64 - 1;  // (>= 100: dynamic roles)
+    int rblocks = grid_blocks > 0 ? grid_blocks : ctx->prop.multiProcessorCount;
+    {
+      const unsigned long long need = (A.n_packets + rthreads - 1) / rthreads;
+      if (grid_blocks <= 0 && (unsigned long long)rblocks > need) rblocks = (int)(need ? need : 1);
+    }
+    const void* fn;
+#define PICKR(a, b) fn = use_lds ? (const void*)k_thermal_roles<a, b, true> : (const void*)k_thermal_roles<a, b, false>
+    if (l3d) { if (pola) PICKR(true, true); else PICKR(true, false); }
+    else { if (pola) PICKR(false, true); else PICKR(false, false); }
+#undef PICKR
+    HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));
+    void* args[] = {(void*)&M, (void*)&A, (void*)&n_flyers, (void*)&k_short, (void*)&fly_iters, (void*)&fly_idle};
+    HIPCHK(hipLaunchKernel(fn, dim3(rblocks), dim3(rthreads), args, lds_r, ctx->stream));
+    return MCGPU_OK;
+  }
 #define LAUNCH(a, b, c)                                                                \
   e = use_lds ? launch_k<a, b, c, true>(M, A, blocks, threads, lds_k, ctx->stream)     \
               : launch_k<a, b, c, false>(M, A, blocks, threads, lds_k, ctx->stream)

@@ -1,0 +1,64 @@
+"""Correctness and timing of the opt-in role schedule (MCGPU_ROLES=<flyer waves>, mc_roles.hip.h) against the
+default kernel: same packets, same counters, same sums."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+if len(sys.argv) > 1 and sys.argv[1] == "diag":  # the -DMCGPU_COUNT_ITERS build, chosen before the engine loads
+    os.environ["MCGPU_LIB"] = os.path.join(ROOT, "mcfost_amd/csrc/variants/lib_iters.so")
+import numpy as np
+from mcfost_amd.engine import Engine
+from mcfost_amd.host import model as M
+
+def run(m, n, roles, k_short=2, fly_iters=16, fly_idle=65, **kw):
+    os.environ.pop("MCGPU_ROLES", None)
+    if roles is not None:
+        os.environ["MCGPU_ROLES"] = str(roles)
+        os.environ["MCGPU_K_SHORT"] = str(k_short)
+        os.environ["MCGPU_FLY_ITERS"] = str(fly_iters)
+        os.environ["MCGPU_FLY_IDLE"] = str(fly_idle)
+    e = Engine(m, n)
+    prior = kw.pop("prior", None)
+    t = time.perf_counter()
+    r = e.run_thermal(n, seed=7, frozen=prior is not None, E_prior=prior)
+    r["wall"] = time.perf_counter() - t
+    e.close()
+    os.environ.pop("MCGPU_ROLES", None)
+    return r
+
+stage = sys.argv[1] if len(sys.argv) > 1 else "small"
+if stage == "diag":  # needs mcfost_amd/csrc/variants/lib_iters.so (-DMCGPU_COUNT_ITERS)
+    m = M.build_model(M.ref41())
+    n = 20_000_000
+    for roles, ks, fi in ((5, 2, 64), (164, 2, 16), (148, 3, 16), (164, 3, 8)):
+        r = run(m, n, roles, ks, fi)
+        c = r["counters"]
+        fly_cross, srv_it, fly_it, idle = c["scatterings"], c["absorptions"], c["dark_mirrors"], c["killed_star"]
+        print("roles", roles, ks, fi, "ms %.1f" % r["kernel_ms"], "flyer share of crossings %.3f" % (fly_cross / c["crossings"]),
+              "flyer lane utilisation %.3f" % (fly_cross / (64.0 * max(fly_it, 1))),
+              "server lane utilisation %.3f" % ((c["crossings"] - fly_cross) / (64.0 * max(srv_it, 1))),
+              "flyer iterations %.3g server iterations %.3g idle rounds %.3g" % (fly_it, srv_it, idle))
+    sys.exit(0)
+if stage == "small":
+    for cfg in (M.small(), M.small(lsepar_pola=False), M.small(n_rad=12, nz=6, n_az=8, l3D=True)):
+        m = M.build_model(cfg)
+        prior = run(m, 20000, None)["E_abs"]
+        ref = run(m, 50000, None, prior=prior)
+        for roles in (0, 1, 4, 7, 132, 148):
+            r = run(m, 50000, roles, prior=prior)
+            ok = r["counters"] == ref["counters"] and np.array_equal(r["sed"][4], ref["sed"][4]) and \
+                np.allclose(r["E_abs"], ref["E_abs"], rtol=1e-9, atol=1e-12 * ref["E_abs"].max())
+            print(cfg.l3D, cfg.lsepar_pola, "roles", roles, "OK" if ok else "MISMATCH", r["counters"]["packets"], r["kernel_ms"])
+            assert ok
+else:
+    cfg = M.ref41()
+    if "--no-pola" in sys.argv:
+        cfg.lsepar_pola = False
+    m = M.build_model(cfg)
+    n = int(float(sys.argv[2])) if len(sys.argv) > 2 else 20_000_000
+    base = run(m, n, None)
+    print("default", base["kernel_ms"])
+    for roles, ks, fi, idle in ((164, 2, 16, 65), (164, 3, 16, 65), (164, 4, 16, 65), (164, 3, 8, 65), (164, 3, 24, 65), (156, 3, 16, 65),
+                                (164, 3, 12, 65), (164, 6, 16, 65), (160, 3, 16, 65), (164, 3, 16, 32)):
+        r = run(m, n, roles, ks, fi, idle)
+        print("roles", roles, "k_short", ks, "fly_iters", fi, "fly_idle", idle, "ms", r["kernel_ms"], "crossings/pk", r["counters"]["crossings"] / n,
+              "escaped+killed", r["counters"]["escaped"] + r["counters"]["killed_star"])
