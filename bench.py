@@ -288,7 +288,7 @@ def main():
                        "crossings_per_packet": cross_pp, "interactions_per_packet": inter_pp},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.config, n_local, world),
-                         "kernel": "k_thermal_voro" if args.config == "voronoi" else "k_thermal", "kernel_ms": k_ms,
+                         "kernel": "k_thermal_voro" if args.config == "voronoi" else "k_thermal_roles", "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": bytes_launch},
         }
         if world == 1 and not args.no_cpu_baseline:

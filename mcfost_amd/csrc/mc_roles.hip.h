@@ -262,7 +262,7 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
   const int n_rad = M.n_rad, nz = M.nz;
   bool flyer = wave < n_flyers;  // n_flyers >= 100: every wave picks its role anew in each round
   const bool auto_roles = n_flyers >= 100;
-  const int fly_fill = auto_roles ? n_flyers - 100 : 0;  // become a flyer when so many lanes can fly
+  const int fly_fill = auto_roles ? n_flyers - 100 : 0;  // policy A: become a flyer when so many lanes can fly
   PkState p;
   p.x = p.y = p.z = p.u = p.v = 0.0; p.w = 1.0; p.extr = 0.0;
   p.S[0] = 1.0; p.S[1] = p.S[2] = p.S[3] = 0.0;
@@ -276,7 +276,7 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
   unsigned long long pk_next = 0, pk_end = 0;
   bool no_more_ids = false;  // wave-uniform: the global id counter is exhausted
   int idle_spins = 0;        // consecutive rounds without work: bounded, a lost packet must not hang the GPU
-  unsigned int d_iters = 0, d_idle = 0;  // diagnostics
+  unsigned int d_iters = 0, d_idle = 0, d_srv_iters = 0, d_fly_cross = 0, d_srv_rounds = 0, d_fly_rounds = 0;  // diagnostics
 
   for (int ep = 0;; ++ep) {
     if (rq_ld(&Q->abort_flag)) break;
@@ -286,8 +286,19 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
       // and the packets that wait here for their interaction can be handed over; serve otherwise
       const int nF = __popcll(__ballot(p.st == S_FLIGHT)), nI = __popcll(__ballot(p.st == S_INTERACT));
       const int ft = rq_ld(&Q->fly_top), sfree = rq_ld(&Q->srv_free_top);
-      const int room = 64 - nF;
-      flyer = (nF + (ft < room ? ft : room) >= fly_fill) && (sfree >= nI);
+      if (n_flyers < 200) {  // policy A: fly when at least fly_fill lanes can fly
+        const int room = 64 - nF;
+        flyer = (nF + (ft < room ? ft : room) >= fly_fill) && (sfree >= nI);
+      } else {  // policy B / C: take the role in which more of the 64 lanes have work in this round
+        const int stq = rq_ld(&Q->srv_top), ffree = rq_ld(&Q->fly_free_top);
+        const int keepI = nI - (nI < sfree ? nI : sfree);          // waiting packets a flyer could not hand over
+        const int roomF = 64 - nF - keepI;
+        const int fly_pot = nF + (ft < roomF ? ft : roomF);
+        const int keepF = nF - (nF < ffree ? nF : ffree);          // flights a server could not hand over
+        const int roomS = 64 - nI - keepF;
+        const int srv_pot = nI + (no_more_ids ? (stq < roomS ? stq : roomS) : roomS);  // (new packets fill the rest)
+        flyer = (n_flyers < 300) ? (fly_pot >= srv_pot) : (fly_pot * 2 >= srv_pot * (n_flyers - 300) / 50);
+      }
       // the tail: flights left in the queue when there is nothing to serve or emit any more must still be flown
       if (!flyer && ft > 0 && nI == 0 && no_more_ids && rq_ld(&Q->srv_top) == 0) flyer = true;
     }
@@ -317,11 +328,13 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
         d_idle++;
       } else {
       idle_spins = 0;
+      d_fly_rounds++;
 #pragma unroll 1
       for (int it = 0; it < fly_iters; ++it) {
         // back to the queues as soon as enough lanes have nothing to fly (or after fly_iters crossings)
         if (it > 0 && __popcll(__ballot(p.st != S_FLIGHT)) >= fly_idle) break;
         d_iters++;
+        if (p.st == S_FLIGHT) d_fly_cross++;
         if (p.st == S_FLIGHT) finished += roles_cross<L3D, POLA, LDSE>(T, M, A, E_lds, p, inv_a, inv_w, kf, c_cross, c_kill);
         if (p.st == S_EXITED) {  // binned on the spot (capteur)
           if (!p.flag_ism) { capteur<POLA>(M, A.sed, p.lambda, p.u, p.v, p.w, p.S, p.flag_star, p.flag_scatt); c_esc++; }
@@ -332,6 +345,7 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
       }  // something to fly
     } else {
       // ---- SERVER ------------------------------------------------------------------------------
+      d_srv_rounds++;
       // long flights go to the flyers, empty lanes take packets that wait for their interaction
       bool pushed, popped;
       rq_exchange<POLA, true>(Q, lane, p.st == S_FLIGHT && n_flyers > 0, p.st == S_EMIT, p, pushed, popped, A.err);
@@ -449,7 +463,7 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
 #pragma unroll 1
       for (int it = 0; it < k_short; ++it) {
         if (__ballot(p.st == S_FLIGHT) == 0ull) break;
-        d_iters++;
+        d_srv_iters++;
         if (p.st == S_FLIGHT) finished += roles_cross<L3D, POLA, LDSE>(T, M, A, E_lds, p, inv_a, inv_w, kf, c_cross, c_kill);
       }
     }
@@ -481,10 +495,12 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
   }
   unsigned int cs[8] = {c_pack, c_cross, c_flight, c_scatt, c_abs, c_esc, c_kill, 0u};
 #ifdef MCGPU_COUNT_ITERS  // diagnostic build (tools/roles_check.py diag): where the crossings happen
-  cs[3] = flyer ? c_cross : 0u;             // lane-crossings done by flyer waves
-  cs[4] = (!flyer && lane == 0) ? d_iters : 0u;  // crossing iterations of server waves
-  cs[7] = (flyer && lane == 0) ? d_iters : 0u;   // crossing iterations of flyer waves
+  cs[3] = d_fly_cross;                           // lane-crossings done in flyer rounds
+  cs[4] = (lane == 0) ? d_srv_iters : 0u;        // crossing iterations of server rounds
+  cs[7] = (lane == 0) ? d_iters : 0u;            // crossing iterations of flyer rounds
   cs[6] = (lane == 0) ? d_idle : 0u;             // rounds a wave found nothing to do
+  cs[2] = (lane == 0) ? d_srv_rounds : 0u;       // server rounds
+  cs[5] = (lane == 0) ? d_fly_rounds : 0u;       // flyer rounds
 #endif
 #pragma unroll
   for (int q = 0; q < 8; ++q) {

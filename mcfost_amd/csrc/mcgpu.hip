@@ -520,8 +520,9 @@ static int launch_mega(mcgpu_ctx* ctx, const RunArgs& A, bool use_lds, int grid_
   hipError_t e;
   // Waves with roles and LDS packet queues (mc_roles.hip.h): the default wherever the queues fit next to the
   // tables and the grid has no dark zone.  MCGPU_ROLES: -1 = the single-role kernel (thermal_body), 0..7 = that
-  // many fixed flyer waves, 100+f = every wave picks its role per round (flyer when f lanes can fly; default 164).
-  int n_flyers = 164, k_short = 3, fly_iters = 16, fly_idle = 32;
+  // many fixed flyer waves, 100+f = every wave picks its role per round (flyer when f lanes can fly), 200 = per
+  // round, the role in which more of its lanes have work (default).
+  int n_flyers = 200, k_short = 2, fly_iters = 16, fly_idle = 16;
   if (const char* ev = getenv("MCGPU_ROLES")) n_flyers = atoi(ev);
   {
     const size_t lds_try = (lds_k + 7) / 8 * 8 + (pola ? sizeof(RoleQ<true>) : sizeof(RoleQ<false>));

@@ -23,6 +23,10 @@
 #define __ATOMIC_RELAXED_EMU 0
 #define __HIP_MEMORY_SCOPE_AGENT 0
 #define __hip_atomic_load(p, order, scope) (*(p))
+#define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
+#define __HIP_MEMORY_SCOPE_WORKGROUP 0
+static inline void __builtin_amdgcn_s_sleep(int) {}
+static inline void __threadfence_block() {}
 
 struct emu_dim3 { unsigned x, y, z; };
 static emu_dim3 threadIdx{0, 0, 0}, blockIdx{0, 0, 0}, blockDim{1, 1, 1}, gridDim{1, 1, 1};
@@ -46,6 +50,7 @@ static inline void unsafeAtomicAdd(double* p, double v) {
 static inline void __syncthreads() {}
 static inline int __syncthreads_or(int p) { return p; }
 static inline unsigned long long atomicExch(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p = v; return o; }
+static inline int atomicAdd(int* p, int v) { int o = *p; *p += v; return o; }
 static inline int atomicCAS(int* p, int cmp, int v) { int o = *p; if (o == cmp) *p = v; return o; }
 static inline double __longlong_as_double(long long b) { double d; memcpy(&d, &b, 8); return d; }
 static inline double atomicAdd(double* p, double v) { double o = *p; *p += v; return o; }
@@ -66,6 +71,7 @@ namespace mcgpu { double lds_raw[1 << 18]; }
 #include "../../mcfost_amd/csrc/mc_voronoi.hip.h"
 #include "../../mcfost_amd/csrc/mc_mono.hip.h"
 #include "../../mcfost_amd/csrc/mc_mono_voronoi.hip.h"
+#include "../../mcfost_amd/csrc/mc_roles.hip.h"
 #include "../../oracle/mc_oracle.h"
 
 using namespace mcgpu;
@@ -209,6 +215,16 @@ extern "C" int emu_run_thermal(const oracle_model* m, const oracle_opts* o, cons
       }
       if (counts[0] == 0 && counts[1] == 0) break;
     }
+    for (int q = 0; q < 8; ++q) counters[q] = cnt[q];
+    return err;
+  }
+  if (getenv("MCGPU_EMU_ROLES") && !dark) {  // the role schedule on one lane: the wave alternates between both roles
+    const int nf = atoi(getenv("MCGPU_EMU_ROLES"));
+    const bool ld = getenv("MCGPU_EMU_LDS") != nullptr;
+    A.flush_every = 4;
+#define RUNR(a, b) do { if (ld) k_thermal_roles<a, b, true>(M, A, nf, 2, 3, 65); else k_thermal_roles<a, b, false>(M, A, nf, 2, 3, 65); } while (0)
+    if (l3d) { if (pola) RUNR(true, true); else RUNR(true, false); }
+    else { if (pola) RUNR(false, true); else RUNR(false, false); }
     for (int q = 0; q < 8; ++q) counters[q] = cnt[q];
     return err;
   }

@@ -25,11 +25,12 @@ DEV = os.path.join(os.path.dirname(HERE), "mcfost_amd", "csrc", "mc_device.hip.h
 DEV2 = os.path.join(os.path.dirname(HERE), "mcfost_amd", "csrc", "mc_rounds.hip.h")
 DEV3 = os.path.join(os.path.dirname(HERE), "mcfost_amd", "csrc", "mc_voronoi.hip.h")
 DEV4 = os.path.join(os.path.dirname(HERE), "mcfost_amd", "csrc", "mc_mono.hip.h")
+DEV5 = os.path.join(os.path.dirname(HERE), "mcfost_amd", "csrc", "mc_roles.hip.h")
 
 
 @pytest.fixture(scope="module")
 def emu():
-    if (not os.path.exists(LIB)) or os.path.getmtime(LIB) < max(os.path.getmtime(SRC), os.path.getmtime(DEV), os.path.getmtime(DEV2), os.path.getmtime(DEV3), os.path.getmtime(DEV4)):
+    if (not os.path.exists(LIB)) or os.path.getmtime(LIB) < max(os.path.getmtime(SRC), os.path.getmtime(DEV), os.path.getmtime(DEV2), os.path.getmtime(DEV3), os.path.getmtime(DEV4), os.path.getmtime(DEV5)):
         fma = ["-mfma"] if "fma" in open("/proc/cpuinfo").read() else []
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=fast"] + fma +
                               ["-o", LIB, SRC])
@@ -259,3 +260,21 @@ def test_emulated_ism_emission(emu, small_model):
     check(emu, _with_ism(M.build_voronoi_model(M.small(lsepar_pola=False), 600, seed=4)), 2000, 33, rtol=1e-6)
     a, b = check_mono(emu, _with_ism(small_model), 5, 4, 34)
     assert a["counters"][5] < a["counters"][0] * 0.8
+
+
+def test_emulated_role_schedule(emu, small_model):
+    """mc_roles.hip.h on one lane: with MCGPU_EMU_ROLES=101 the wave becomes a flyer whenever a single packet can
+    fly, so packets keep going through both queues (pushed as long flights, popped, pushed back for their
+    interaction); 0 = server role only.  Same packets, same sums as the oracle."""
+    for roles in ("101", "0"):
+        os.environ["MCGPU_EMU_ROLES"] = roles
+        try:
+            check(emu, small_model, 4000, 7)
+            os.environ["MCGPU_EMU_LDS"] = "1"
+            check(emu, small_model, 4000, 7)
+            del os.environ["MCGPU_EMU_LDS"]
+            check(emu, M.build_model(M.small(n_rad=12, nz=6, n_az=8, l3D=True)), 2000, 8)
+            check(emu, M.build_model(M.small(aniso_method=2, lsepar_pola=False)), 2000, 10)
+        finally:
+            os.environ.pop("MCGPU_EMU_ROLES", None)
+            os.environ.pop("MCGPU_EMU_LDS", None)

@@ -29,14 +29,15 @@ stage = sys.argv[1] if len(sys.argv) > 1 else "small"
 if stage == "diag":  # needs mcfost_amd/csrc/variants/lib_iters.so (-DMCGPU_COUNT_ITERS)
     m = M.build_model(M.ref41())
     n = 20_000_000
-    for roles, ks, fi in ((5, 2, 64), (164, 2, 16), (148, 3, 16), (164, 3, 8)):
-        r = run(m, n, roles, ks, fi)
+    for roles, ks, fi, idle in ((164, 3, 16, 32), (200, 3, 16, 32), (350, 3, 16, 32), (400, 3, 16, 32)):
+        r = run(m, n, roles, ks, fi, idle)
         c = r["counters"]
-        fly_cross, srv_it, fly_it, idle = c["scatterings"], c["absorptions"], c["dark_mirrors"], c["killed_star"]
-        print("roles", roles, ks, fi, "ms %.1f" % r["kernel_ms"], "flyer share of crossings %.3f" % (fly_cross / c["crossings"]),
-              "flyer lane utilisation %.3f" % (fly_cross / (64.0 * max(fly_it, 1))),
-              "server lane utilisation %.3f" % ((c["crossings"] - fly_cross) / (64.0 * max(srv_it, 1))),
-              "flyer iterations %.3g server iterations %.3g idle rounds %.3g" % (fly_it, srv_it, idle))
+        fly_cross, srv_it, fly_it, idle_r = c["scatterings"], c["absorptions"], c["dark_mirrors"], c["killed_star"]
+        srv_rounds, fly_rounds = c["flights"], c["escaped"]
+        print("roles", roles, ks, fi, idle, "ms %.1f" % r["kernel_ms"], "| flyer rounds: share of crossings %.3f, lane utilisation %.3f, %.3g rounds x %.1f iterations"
+              % (fly_cross / c["crossings"], fly_cross / (64.0 * max(fly_it, 1)), fly_rounds, fly_it / max(fly_rounds, 1)),
+              "| server rounds: lane utilisation of their crossings %.3f, %.3g rounds x %.2f iterations | idle rounds %.3g"
+              % ((c["crossings"] - fly_cross) / (64.0 * max(srv_it, 1)), srv_rounds, srv_it / max(srv_rounds, 1), idle_r))
     sys.exit(0)
 if stage == "small":
     for cfg in (M.small(), M.small(lsepar_pola=False), M.small(n_rad=12, nz=6, n_az=8, l3D=True)):
@@ -57,8 +58,8 @@ else:
     n = int(float(sys.argv[2])) if len(sys.argv) > 2 else 20_000_000
     base = run(m, n, None)
     print("default", base["kernel_ms"])
-    for roles, ks, fi, idle in ((164, 2, 16, 65), (164, 3, 16, 65), (164, 4, 16, 65), (164, 3, 8, 65), (164, 3, 24, 65), (156, 3, 16, 65),
-                                (164, 3, 12, 65), (164, 6, 16, 65), (160, 3, 16, 65), (164, 3, 16, 32)):
+    for roles, ks, fi, idle in ((164, 3, 16, 32), (200, 3, 16, 32), (200, 2, 16, 32), (200, 4, 16, 32), (200, 3, 8, 32), (200, 3, 32, 32),
+                                (200, 3, 16, 16), (200, 3, 16, 65), (400, 3, 16, 32), (375, 3, 16, 32)):
         r = run(m, n, roles, ks, fi, idle)
         print("roles", roles, "k_short", ks, "fly_iters", fi, "fly_idle", idle, "ms", r["kernel_ms"], "crossings/pk", r["counters"]["crossings"] / n,
               "escaped+killed", r["counters"]["escaped"] + r["counters"]["killed_star"])
