@@ -243,7 +243,7 @@ __device__ inline int roles_cross(const Lds& T, const DevModel& M, const RunArgs
 
 template <bool L3D, bool POLA, bool LDSE>
 __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, double* lds_base, int n_flyers,
-                                           int k_short, int fly_iters, int fly_idle) {
+                                           int k_short, int fly_iters, int fly_idle, int emit_qmax) {
   double* const E_lds = lds_base;
   const Lds T = lds_carve(lds_base + (LDSE ? M.n_cells : 0), M);
   lds_stage(T, M);
@@ -277,10 +277,15 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
   bool no_more_ids = false;  // wave-uniform: the global id counter is exhausted
   int idle_spins = 0;        // consecutive rounds without work: bounded, a lost packet must not hang the GPU
   unsigned int d_iters = 0, d_idle = 0, d_srv_iters = 0, d_fly_cross = 0, d_srv_rounds = 0, d_fly_rounds = 0;  // diagnostics
+  unsigned long long d_t_fly = 0, d_t_srv = 0, d_t_idle = 0;
 
   for (int ep = 0;; ++ep) {
     if (rq_ld(&Q->abort_flag)) break;
     int finished = 0;  // packets this lane finished in this round
+#ifdef MCGPU_COUNT_ITERS
+    const unsigned long long t_round0 = clock64();
+    int round_kind = 0;  // 1 flyer, 2 server, 3 idle
+#endif
     if (auto_roles) {
       // fly when the lanes can be (nearly) filled with packets in flight -- the wave's own plus the queue's --
       // and the packets that wait here for their interaction can be handed over; serve otherwise
@@ -296,7 +301,8 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
         const int fly_pot = nF + (ft < roomF ? ft : roomF);
         const int keepF = nF - (nF < ffree ? nF : ffree);          // flights a server could not hand over
         const int roomS = 64 - nI - keepF;
-        const int srv_pot = nI + (no_more_ids ? (stq < roomS ? stq : roomS) : roomS);  // (new packets fill the rest)
+        const bool can_emit = !no_more_ids && (ft + stq) <= emit_qmax;  // (new packets fill the rest)
+        const int srv_pot = nI + (can_emit ? roomS : (stq < roomS ? stq : roomS));
         flyer = (n_flyers < 300) ? (fly_pot >= srv_pot) : (fly_pot * 2 >= srv_pot * (n_flyers - 300) / 50);
       }
       // the tail: flights left in the queue when there is nothing to serve or emit any more must still be flown
@@ -326,9 +332,15 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
         __builtin_amdgcn_s_sleep(8);  // nothing to fly: wait for the servers
         if (++idle_spins > (1 << 24)) { *A.err = 15; rq_st(&Q->abort_flag, 1); }
         d_idle++;
+#ifdef MCGPU_COUNT_ITERS
+        round_kind = 3;
+#endif
       } else {
       idle_spins = 0;
       d_fly_rounds++;
+#ifdef MCGPU_COUNT_ITERS
+      round_kind = 1;
+#endif
 #pragma unroll 1
       for (int it = 0; it < fly_iters; ++it) {
         // back to the queues as soon as enough lanes have nothing to fly (or after fly_iters crossings)
@@ -346,6 +358,9 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
     } else {
       // ---- SERVER ------------------------------------------------------------------------------
       d_srv_rounds++;
+#ifdef MCGPU_COUNT_ITERS
+      round_kind = 2;
+#endif
       // long flights go to the flyers, empty lanes take packets that wait for their interaction
       bool pushed, popped;
       rq_exchange<POLA, true>(Q, lane, p.st == S_FLIGHT && n_flyers > 0, p.st == S_EMIT, p, pushed, popped, A.err);
@@ -354,7 +369,9 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
       {
         const bool need = (p.st == S_EMIT);
         const unsigned long long mask = __ballot(need);
-        if (mask && !no_more_ids) {
+        // new packets only while the queues are not loaded: a workgroup that keeps every lane AND both queues
+        // full cannot move packets between its waves any more
+        if (mask && !no_more_ids && (rq_ld(&Q->fly_top) + rq_ld(&Q->srv_top)) <= emit_qmax) {
           if (pk_next >= pk_end) {
             const int leader = __ffsll((long long)mask) - 1;
             unsigned long long base = 0;
@@ -455,6 +472,9 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
           __builtin_amdgcn_s_sleep(8);
           if (++idle_spins > (1 << 24)) { *A.err = 15; rq_st(&Q->abort_flag, 1); }
           d_idle++;
+#ifdef MCGPU_COUNT_ITERS
+          round_kind = 3;
+#endif
         }
       } else {
         idle_spins = 0;
@@ -468,6 +488,12 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
       }
     }
 
+#ifdef MCGPU_COUNT_ITERS
+    {
+      const unsigned long long dt = clock64() - t_round0;
+      if (round_kind == 1) d_t_fly += dt; else if (round_kind == 2) d_t_srv += dt; else d_t_idle += dt;
+    }
+#endif
     // ---- bookkeeping common to both roles ---------------------------------------------------------
     {
       const int fin = __popcll(__ballot(finished > 0)) + __popcll(__ballot(finished > 1));
@@ -501,6 +527,9 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
   cs[6] = (lane == 0) ? d_idle : 0u;             // rounds a wave found nothing to do
   cs[2] = (lane == 0) ? d_srv_rounds : 0u;       // server rounds
   cs[5] = (lane == 0) ? d_fly_rounds : 0u;       // flyer rounds
+  cs[0] = (lane == 0) ? (unsigned int)(d_t_fly >> 12) : 0u;   // cycles / 4096 in flyer rounds
+  cs[1] = (lane == 0) ? (unsigned int)(d_t_srv >> 12) : 0u;   // ... in server rounds
+  cs[6] = (lane == 0) ? (unsigned int)(d_t_idle >> 12) : 0u;  // ... idle
 #endif
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
@@ -512,9 +541,10 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
 
 template <bool L3D, bool POLA, bool LDSE>
 __global__ void __launch_bounds__(MCGPU_LDS_BLOCK) k_thermal_roles(const DevModel M, const RunArgs A, int n_flyers,
-                                                                   int k_short, int fly_iters, int fly_idle) {
+                                                                   int k_short, int fly_iters, int fly_idle,
+                                                                   int emit_qmax) {
   extern __shared__ double lds_raw[];
-  roles_body<L3D, POLA, LDSE>(M, A, lds_raw, n_flyers, k_short, fly_iters, fly_idle);
+  roles_body<L3D, POLA, LDSE>(M, A, lds_raw, n_flyers, k_short, fly_iters, fly_idle, emit_qmax);
 }
 
 }  // namespace mcgpu
