@@ -23,6 +23,12 @@
 #pragma once
 #include "mc_device.hip.h"
 
+#ifdef MCGPU_COUNT_ITERS  // diagnostic build (tools/roles_check.py diag): statements that only count
+#define RQ_DIAG(...) __VA_ARGS__
+#else
+#define RQ_DIAG(...)
+#endif
+
 namespace mcgpu {
 
 constexpr int RQ_NF = 192;  // records of packets ready for a long flight
@@ -243,7 +249,7 @@ __device__ inline int roles_cross(const Lds& T, const DevModel& M, const RunArgs
 
 template <bool L3D, bool POLA, bool LDSE>
 __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, double* lds_base, int n_flyers,
-                                           int k_short, int fly_iters, int fly_idle, int emit_qmax) {
+                                           int k_short, int fly_iters, int fly_idle, int emit_qmax, int emit_min) {
   double* const E_lds = lds_base;
   const Lds T = lds_carve(lds_base + (LDSE ? M.n_cells : 0), M);
   lds_stage(T, M);
@@ -276,16 +282,12 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
   unsigned long long pk_next = 0, pk_end = 0;
   bool no_more_ids = false;  // wave-uniform: the global id counter is exhausted
   int idle_spins = 0;        // consecutive rounds without work: bounded, a lost packet must not hang the GPU
-  unsigned int d_iters = 0, d_idle = 0, d_srv_iters = 0, d_fly_cross = 0, d_srv_rounds = 0, d_fly_rounds = 0;  // diagnostics
-  unsigned long long d_t_fly = 0, d_t_srv = 0, d_t_idle = 0;
+  RQ_DIAG(unsigned int d_fly_iters = 0, d_srv_iters = 0, d_fly_cross = 0, d_srv_rounds = 0, d_fly_rounds = 0;)
+  RQ_DIAG(unsigned int d_in_flight = 0, d_handed = 0, d_popped = 0, d_empty = 0;)
 
   for (int ep = 0;; ++ep) {
     if (rq_ld(&Q->abort_flag)) break;
     int finished = 0;  // packets this lane finished in this round
-#ifdef MCGPU_COUNT_ITERS
-    const unsigned long long t_round0 = clock64();
-    int round_kind = 0;  // 1 flyer, 2 server, 3 idle
-#endif
     if (auto_roles) {
       // fly when the lanes can be (nearly) filled with packets in flight -- the wave's own plus the queue's --
       // and the packets that wait here for their interaction can be handed over; serve otherwise
@@ -294,7 +296,7 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
       if (n_flyers < 200) {  // policy A: fly when at least fly_fill lanes can fly
         const int room = 64 - nF;
         flyer = (nF + (ft < room ? ft : room) >= fly_fill) && (sfree >= nI);
-      } else {  // policy B / C: take the role in which more of the 64 lanes have work in this round
+      } else {  // policy B (default): take the role in which more of the 64 lanes have work in this round
         const int stq = rq_ld(&Q->srv_top), ffree = rq_ld(&Q->fly_free_top);
         const int keepI = nI - (nI < sfree ? nI : sfree);          // waiting packets a flyer could not hand over
         const int roomF = 64 - nF - keepI;
@@ -303,7 +305,7 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
         const int roomS = 64 - nI - keepF;
         const bool can_emit = !no_more_ids && (ft + stq) <= emit_qmax;  // (new packets fill the rest)
         const int srv_pot = nI + (can_emit ? roomS : (stq < roomS ? stq : roomS));
-        flyer = (n_flyers < 300) ? (fly_pot >= srv_pot) : (fly_pot * 2 >= srv_pot * (n_flyers - 300) / 50);
+        flyer = fly_pot >= srv_pot;
       }
       // the tail: flights left in the queue when there is nothing to serve or emit any more must still be flown
       if (!flyer && ft > 0 && nI == 0 && no_more_ids && rq_ld(&Q->srv_top) == 0) flyer = true;
@@ -331,22 +333,14 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
           break;  // (every operand is wave-uniform)
         __builtin_amdgcn_s_sleep(8);  // nothing to fly: wait for the servers
         if (++idle_spins > (1 << 24)) { *A.err = 15; rq_st(&Q->abort_flag, 1); }
-        d_idle++;
-#ifdef MCGPU_COUNT_ITERS
-        round_kind = 3;
-#endif
       } else {
       idle_spins = 0;
-      d_fly_rounds++;
-#ifdef MCGPU_COUNT_ITERS
-      round_kind = 1;
-#endif
+      RQ_DIAG(if (lane == 0) d_fly_rounds++;)
 #pragma unroll 1
       for (int it = 0; it < fly_iters; ++it) {
         // back to the queues as soon as enough lanes have nothing to fly (or after fly_iters crossings)
         if (it > 0 && __popcll(__ballot(p.st != S_FLIGHT)) >= fly_idle) break;
-        d_iters++;
-        if (p.st == S_FLIGHT) d_fly_cross++;
+        RQ_DIAG(if (lane == 0) d_fly_iters++; if (p.st == S_FLIGHT) d_fly_cross++;)
         if (p.st == S_FLIGHT) finished += roles_cross<L3D, POLA, LDSE>(T, M, A, E_lds, p, inv_a, inv_w, kf, c_cross, c_kill);
         if (p.st == S_EXITED) {  // binned on the spot (capteur)
           if (!p.flag_ism) { capteur<POLA>(M, A.sed, p.lambda, p.u, p.v, p.w, p.S, p.flag_star, p.flag_scatt); c_esc++; }
@@ -357,13 +351,12 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
       }  // something to fly
     } else {
       // ---- SERVER ------------------------------------------------------------------------------
-      d_srv_rounds++;
-#ifdef MCGPU_COUNT_ITERS
-      round_kind = 2;
-#endif
+      RQ_DIAG(if (lane == 0) d_srv_rounds++;)
       // long flights go to the flyers, empty lanes take packets that wait for their interaction
       bool pushed, popped;
+      RQ_DIAG(if (p.st == S_FLIGHT) d_in_flight++;)  // lanes that come into the server round with a flight
       rq_exchange<POLA, true>(Q, lane, p.st == S_FLIGHT && n_flyers > 0, p.st == S_EMIT, p, pushed, popped, A.err);
+      RQ_DIAG(if (pushed) d_handed++; if (popped) d_popped++; if (p.st == S_EMIT) d_empty++;)
 
       // EMIT: lanes that are still empty start new packets (mc_photon_loop body, dust_transfer.f90:529-541)
       {
@@ -371,7 +364,11 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
         const unsigned long long mask = __ballot(need);
         // new packets only while the queues are not loaded: a workgroup that keeps every lane AND both queues
         // full cannot move packets between its waves any more
-        if (mask && !no_more_ids && (rq_ld(&Q->fly_top) + rq_ld(&Q->srv_top)) <= emit_qmax) {
+        // ... and only for several lanes at a time (the emission code costs the wave the same for 1 lane or 64),
+        // unless the wave has nothing else to do
+        const int n_need = __popcll(mask);
+        const bool emit_now = n_need >= emit_min || __ballot(p.st != S_EMIT) == 0ull;
+        if (mask && emit_now && !no_more_ids && (rq_ld(&Q->fly_top) + rq_ld(&Q->srv_top)) <= emit_qmax) {
           if (pk_next >= pk_end) {
             const int leader = __ffsll((long long)mask) - 1;
             unsigned long long base = 0;
@@ -471,10 +468,6 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
         if (no_more_ids) {  // packets are with the flyers: wait for them to come back
           __builtin_amdgcn_s_sleep(8);
           if (++idle_spins > (1 << 24)) { *A.err = 15; rq_st(&Q->abort_flag, 1); }
-          d_idle++;
-#ifdef MCGPU_COUNT_ITERS
-          round_kind = 3;
-#endif
         }
       } else {
         idle_spins = 0;
@@ -483,17 +476,11 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
 #pragma unroll 1
       for (int it = 0; it < k_short; ++it) {
         if (__ballot(p.st == S_FLIGHT) == 0ull) break;
-        d_srv_iters++;
+        RQ_DIAG(if (lane == 0) d_srv_iters++;)
         if (p.st == S_FLIGHT) finished += roles_cross<L3D, POLA, LDSE>(T, M, A, E_lds, p, inv_a, inv_w, kf, c_cross, c_kill);
       }
     }
 
-#ifdef MCGPU_COUNT_ITERS
-    {
-      const unsigned long long dt = clock64() - t_round0;
-      if (round_kind == 1) d_t_fly += dt; else if (round_kind == 2) d_t_srv += dt; else d_t_idle += dt;
-    }
-#endif
     // ---- bookkeeping common to both roles ---------------------------------------------------------
     {
       const int fin = __popcll(__ballot(finished > 0)) + __popcll(__ballot(finished > 1));
@@ -520,16 +507,10 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
     }
   }
   unsigned int cs[8] = {c_pack, c_cross, c_flight, c_scatt, c_abs, c_esc, c_kill, 0u};
-#ifdef MCGPU_COUNT_ITERS  // diagnostic build (tools/roles_check.py diag): where the crossings happen
-  cs[3] = d_fly_cross;                           // lane-crossings done in flyer rounds
-  cs[4] = (lane == 0) ? d_srv_iters : 0u;        // crossing iterations of server rounds
-  cs[7] = (lane == 0) ? d_iters : 0u;            // crossing iterations of flyer rounds
-  cs[6] = (lane == 0) ? d_idle : 0u;             // rounds a wave found nothing to do
-  cs[2] = (lane == 0) ? d_srv_rounds : 0u;       // server rounds
-  cs[5] = (lane == 0) ? d_fly_rounds : 0u;       // flyer rounds
-  cs[0] = (lane == 0) ? (unsigned int)(d_t_fly >> 12) : 0u;   // cycles / 4096 in flyer rounds
-  cs[1] = (lane == 0) ? (unsigned int)(d_t_srv >> 12) : 0u;   // ... in server rounds
-  cs[6] = (lane == 0) ? (unsigned int)(d_t_idle >> 12) : 0u;  // ... idle
+#ifdef MCGPU_COUNT_ITERS  // the eight counters carry the schedule's statistics instead
+  cs[0] = d_in_flight; cs[1] = d_handed; cs[6] = d_popped; cs[3] = d_empty;  // lanes, summed over server rounds
+  cs[2] = d_srv_rounds; cs[5] = d_fly_rounds;                                 // rounds
+  cs[4] = d_srv_iters; cs[7] = d_fly_iters;                                   // crossing iterations
 #endif
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
@@ -542,9 +523,9 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
 template <bool L3D, bool POLA, bool LDSE>
 __global__ void __launch_bounds__(MCGPU_LDS_BLOCK) k_thermal_roles(const DevModel M, const RunArgs A, int n_flyers,
                                                                    int k_short, int fly_iters, int fly_idle,
-                                                                   int emit_qmax) {
+                                                                   int emit_qmax, int emit_min) {
   extern __shared__ double lds_raw[];
-  roles_body<L3D, POLA, LDSE>(M, A, lds_raw, n_flyers, k_short, fly_iters, fly_idle, emit_qmax);
+  roles_body<L3D, POLA, LDSE>(M, A, lds_raw, n_flyers, k_short, fly_iters, fly_idle, emit_qmax, emit_min);
 }
 
 }  // namespace mcgpu

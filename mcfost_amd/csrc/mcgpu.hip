@@ -522,7 +522,7 @@ static int launch_mega(mcgpu_ctx* ctx, const RunArgs& A, bool use_lds, int grid_
   // tables and the grid has no dark zone.  MCGPU_ROLES: -1 = the single-role kernel (thermal_body), 0..7 = that
   // many fixed flyer waves, 100+f = every wave picks its role per round (flyer when f lanes can fly), 200 = per
   // round, the role in which more of its lanes have work (default).
-  int n_flyers = 200, k_short = 2, fly_iters = 16, fly_idle = 16, emit_qmax = 1 << 20;
+  int n_flyers = 200, k_short = 2, fly_iters = 16, fly_idle = 16, emit_qmax = 1 << 20, emit_min = 1;
   if (const char* ev = getenv("MCGPU_ROLES")) n_flyers = atoi(ev);
   {
     const size_t lds_try = (lds_k + 7) / 8 * 8 + (pola ? sizeof(RoleQ<true>) : sizeof(RoleQ<false>));
@@ -532,6 +532,7 @@ static int launch_mega(mcgpu_ctx* ctx, const RunArgs& A, bool use_lds, int grid_
   if (const char* ev = getenv("MCGPU_FLY_ITERS")) { int v = atoi(ev); if (v >= 1 && v <= 256) fly_iters = v; }
   if (const char* ev = getenv("MCGPU_FLY_IDLE")) { int v = atoi(ev); if (v >= 1 && v <= 65) fly_idle = v; }
   if (const char* ev = getenv("MCGPU_EMIT_QMAX")) { int v = atoi(ev); if (v >= 0) emit_qmax = v; }
+  if (const char* ev = getenv("MCGPU_EMIT_MIN")) { int v = atoi(ev); if (v >= 1 && v <= 64) emit_min = v; }
   if (n_flyers >= 0 && !dark && !A.resume_pool) {
     const size_t lds_r = (lds_k + 7) / 8 * 8 + (pola ? sizeof(RoleQ<true>) : sizeof(RoleQ<false>));
     if (lds_r > lds_cap) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "MCGPU_ROLES: the packet queues do not fit in LDS next to the tables");
@@ -548,7 +549,7 @@ static int launch_mega(mcgpu_ctx* ctx, const RunArgs& A, bool use_lds, int grid_
     else { if (pola) PICKR(false, true); else PICKR(false, false); }
 #undef PICKR
     HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));
-    void* args[] = {(void*)&M, (void*)&A, (void*)&n_flyers, (void*)&k_short, (void*)&fly_iters, (void*)&fly_idle, (void*)&emit_qmax};
+    void* args[] = {(void*)&M, (void*)&A, (void*)&n_flyers, (void*)&k_short, (void*)&fly_iters, (void*)&fly_idle, (void*)&emit_qmax, (void*)&emit_min};
     HIPCHK(hipLaunchKernel(fn, dim3(rblocks), dim3(rthreads), args, lds_r, ctx->stream));
     return MCGPU_OK;
   }

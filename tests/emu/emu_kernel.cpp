@@ -222,7 +222,7 @@ extern "C" int emu_run_thermal(const oracle_model* m, const oracle_opts* o, cons
     const int nf = atoi(getenv("MCGPU_EMU_ROLES"));
     const bool ld = getenv("MCGPU_EMU_LDS") != nullptr;
     A.flush_every = 4;
-#define RUNR(a, b) do { if (ld) k_thermal_roles<a, b, true>(M, A, nf, 2, 3, 65, 1 << 20); else k_thermal_roles<a, b, false>(M, A, nf, 2, 3, 65, 1 << 20); } while (0)
+#define RUNR(a, b) do { if (ld) k_thermal_roles<a, b, true>(M, A, nf, 2, 3, 65, 1 << 20, 1); else k_thermal_roles<a, b, false>(M, A, nf, 2, 3, 65, 1 << 20, 1); } while (0)
     if (l3d) { if (pola) RUNR(true, true); else RUNR(true, false); }
     else { if (pola) RUNR(false, true); else RUNR(false, false); }
     for (int q = 0; q < 8; ++q) counters[q] = cnt[q];

@@ -9,7 +9,7 @@ import numpy as np
 from mcfost_amd.engine import Engine
 from mcfost_amd.host import model as M
 
-def run(m, n, roles, k_short=2, fly_iters=16, fly_idle=16, emit_qmax=1 << 20, **kw):
+def run(m, n, roles, k_short=2, fly_iters=16, fly_idle=16, emit_qmax=1 << 20, emit_min=1, **kw):
     os.environ.pop("MCGPU_ROLES", None)
     if roles is not None:
         os.environ["MCGPU_ROLES"] = str(roles)
@@ -17,6 +17,7 @@ def run(m, n, roles, k_short=2, fly_iters=16, fly_idle=16, emit_qmax=1 << 20, **
         os.environ["MCGPU_FLY_ITERS"] = str(fly_iters)
         os.environ["MCGPU_FLY_IDLE"] = str(fly_idle)
         os.environ["MCGPU_EMIT_QMAX"] = str(emit_qmax)
+        os.environ["MCGPU_EMIT_MIN"] = str(emit_min)
     e = Engine(m, n)
     prior = kw.pop("prior", None)
     t = time.perf_counter()
@@ -30,16 +31,15 @@ stage = sys.argv[1] if len(sys.argv) > 1 else "small"
 if stage == "diag":  # needs mcfost_amd/csrc/variants/lib_iters.so (-DMCGPU_COUNT_ITERS)
     m = M.build_model(M.ref41())
     n = 20_000_000
-    for roles, ks, fi, idle in ((200, 2, 16, 16), (164, 3, 16, 32)):
+    for roles, ks, fi, idle in ((200, 2, 16, 16), (5, 2, 64, 65)):
         r = run(m, n, roles, ks, fi, idle)
-        c = r["counters"]
-        t_fly, t_srv, t_idle = c["packets"], c["crossings"], c["killed_star"]
-        tot = float(t_fly + t_srv + t_idle)
-        print("roles", roles, ks, fi, idle, "ms %.1f" % r["kernel_ms"], "wave time: flyer rounds %.1f %%, server rounds %.1f %%, idle %.1f %%"
-              % (100 * t_fly / tot, 100 * t_srv / tot, 100 * t_idle / tot),
-              "| %.3g flyer rounds x %.1f iterations, %.3g server rounds x %.2f iterations" %
-              (c["escaped"], c["dark_mirrors"] / max(c["escaped"], 1), c["flights"], c["absorptions"] / max(c["flights"], 1)),
-              "| cycles per server round %.0f, per flyer round %.0f" % (4096.0 * t_srv / max(c["flights"], 1), 4096.0 * t_fly / max(c["escaped"], 1)))
+        c = r["counters"]  # carry the schedule's statistics in this build (mc_roles.hip.h)
+        srv_rounds, fly_rounds = float(c["flights"]), float(c["escaped"])
+        print("roles", roles, "ms %.1f" % r["kernel_ms"],
+              "| per server round: %.1f lanes arrive with a flight, %.1f hand it over, %.1f pop a waiting packet, %.1f stay "
+              "empty after the exchange, %.2f crossing iterations" % (c["packets"] / srv_rounds, c["crossings"] / srv_rounds,
+              c["killed_star"] / srv_rounds, c["scatterings"] / srv_rounds, c["absorptions"] / srv_rounds),
+              "| %.3g server rounds, %.3g flyer rounds x %.1f crossing iterations" % (srv_rounds, fly_rounds, c["dark_mirrors"] / max(fly_rounds, 1)))
     sys.exit(0)
 if stage == "small":
     for cfg in (M.small(), M.small(lsepar_pola=False), M.small(n_rad=12, nz=6, n_az=8, l3D=True)):
@@ -60,9 +60,9 @@ else:
     n = int(float(sys.argv[2])) if len(sys.argv) > 2 else 20_000_000
     base = run(m, n, None)
     print("default", base["kernel_ms"])
-    for roles, ks, fi, idle, qm in ((200, 2, 16, 16, 1 << 20), (200, 2, 16, 16, 256), (200, 2, 16, 16, 192), (200, 2, 16, 16, 128), (200, 2, 16, 16, 96),
-                                    (200, 2, 16, 16, 64), (200, 2, 16, 16, 32), (200, 3, 16, 16, 128), (164, 3, 16, 32, 128)):
-        r = run(m, n, roles, ks, fi, idle, qm)
-        print("emit_qmax", qm, end=" ")
+    for em in (1, 4, 8, 16, 24, 32, 48):
+        roles, ks, fi, idle = 200, 2, 16, 16
+        r = run(m, n, roles, ks, fi, idle, 1 << 20, em)
+        print("emit_min", em, end=" ")
         print("roles", roles, "k_short", ks, "fly_iters", fi, "fly_idle", idle, "ms", r["kernel_ms"], "crossings/pk", r["counters"]["crossings"] / n,
               "escaped+killed", r["counters"]["escaped"] + r["counters"]["killed_star"])
