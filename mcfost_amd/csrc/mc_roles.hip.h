@@ -17,8 +17,8 @@
 //
 // The queues are two record pools in LDS (structure of arrays) with index stacks, guarded by one
 // workgroup spin lock taken by lane 0 of a wave for a few LDS operations; a wave exchanges all
-// its pushes and pops in one step.  Every spin is bounded: on overflow the workgroup aborts with
-// error 14 instead of hanging.  Results do not depend on who runs a packet (counter-based random
+// its pushes and pops in one step.  Every spin is bounded (the lock: 2^22 tries; a wave without work:
+// 2^26 polls, i.e. minutes): on overflow the workgroup aborts with error 14 / 15 instead of hanging.  Results do not depend on who runs a packet (counter-based random
 // numbers keyed by the packet id), so this schedule reproduces thermal_body packet for packet.
 #pragma once
 #include "mc_device.hip.h"
@@ -331,8 +331,8 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
         if (__ballot(finished > 0) == 0ull && __ballot(p.st == S_INTERACT) == 0ull && rq_ld(&Q->ids_done) &&
             rq_ld(&Q->n_pending) == 0)
           break;  // (every operand is wave-uniform)
-        __builtin_amdgcn_s_sleep(8);  // nothing to fly: wait for the servers
-        if (++idle_spins > (1 << 24)) { *A.err = 15; rq_st(&Q->abort_flag, 1); }
+        __builtin_amdgcn_s_sleep(32);  // nothing to fly: wait for the servers
+        if (++idle_spins > (1 << 26)) { *A.err = 15; rq_st(&Q->abort_flag, 1); }  // (minutes: a lost packet, not a long tail)
       } else {
       idle_spins = 0;
       RQ_DIAG(if (lane == 0) d_fly_rounds++;)
@@ -466,8 +466,8 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
       if (__ballot(p.st != S_EMIT) == 0ull) {  // the wave holds no packet at all
         if (no_more_ids && rq_ld(&Q->n_pending) == 0) break;
         if (no_more_ids) {  // packets are with the flyers: wait for them to come back
-          __builtin_amdgcn_s_sleep(8);
-          if (++idle_spins > (1 << 24)) { *A.err = 15; rq_st(&Q->abort_flag, 1); }
+          __builtin_amdgcn_s_sleep(32);
+          if (++idle_spins > (1 << 26)) { *A.err = 15; rq_st(&Q->abort_flag, 1); }
         }
       } else {
         idle_spins = 0;
