@@ -272,6 +272,21 @@ class Oracle:
         self.lib.oracle_temp_finale(C.byref(self.cm), _p(E, C.c_double), _p(T, C.c_float))
         return T
 
+    def define_dark_zone(self, lam, tau_max):
+        """optical_depth.f90:1425-1651 (2D): the flags the reference's thermal step computes with
+        tau_max = tau_dark_zone_eq_th = 1500 at the first wavelength beyond wl_seuil = 0.81 um."""
+        m = self.model
+        g = m.grid
+        out = np.zeros(m.n_cells, np.uint8)
+        rl, rg, zg = _a(g["r_lim"], np.float64), _a(g["r_grid"], np.float64), _a(g["z_grid"], np.float64)
+        self.lib.oracle_define_dark_zone.restype = C.c_int
+        rc = self.lib.oracle_define_dark_zone(C.byref(self.cm), C.c_int(int(lam)), C.c_double(float(tau_max)),
+                                              _p(rl, C.c_double), _p(rg, C.c_double), _p(zg, C.c_double),
+                                              _p(out, C.c_ubyte))
+        if rc:
+            raise RuntimeError(f"oracle_define_dark_zone failed: {rc}")
+        return out
+
     # -- Voronoi operators ---------------------------------------------------
     def cross_voronoi(self, x0, y0, z0, u, v, w, cell, prev):
         n = len(cell)

@@ -1643,3 +1643,73 @@ int oracle_run_mono(const oracle_model *m, const oracle_mono_opts *o, double *xI
   free(sed_t); free(ns_t); free(Ws);
   return err;
 }
+
+/* ------------------------------------------------------------------------ */
+/* define_dark_zone (optical_depth.f90:1425-1651), 2D cylindrical grids       */
+/* ------------------------------------------------------------------------ */
+int oracle_define_dark_zone(const oracle_model *m, int lambda, double tau_max_in, const double *r_lim,
+                            const double *r_grid, const double *z_grid, unsigned char *dz) {
+  if (m->l3D || m->grid_type == 3) return 31;
+  const int n_rad = m->n_rad, nz = m->nz;
+  const float tau_max = (float)tau_max_in; /* real, intent(in) */
+  const double kap = m->kappa[lambda - 1];
+  int ri_in = n_rad, ri_out = 1;
+  int *zj_sup = (int *)calloc((size_t)n_rad + 1, sizeof(int));
+  if (!zj_sup) return 22;
+  memset(dz, 0, (size_t)m->n_cells);
+  float total; /* real :: total_sum */
+  /* step 1: radially from the centre (:1460-1470); cell_map(i,1,1) = i in 2D */
+  total = 0.0f;
+  for (int i = 1; i <= n_rad; ++i) {
+    total = (float)((double)total + kap * m->kappa_factor[i - 1] * (r_lim[i] - r_lim[i - 1]));
+    if (total > tau_max) { ri_in = i; break; }
+  }
+  /* step 2: radially from the outer edge (:1473-1482) */
+  total = 0.0f;
+  for (int i = n_rad; i >= 1; --i) {
+    total = (float)((double)total + kap * m->kappa_factor[i - 1] * (r_lim[i] - r_lim[i - 1]));
+    if (total > tau_max) { ri_out = i; break; }
+  }
+  if (ri_out == n_rad) ri_out = n_rad - 1;
+  /* step 3: vertically from the top (:1485-1497) */
+  for (int i = ri_in; i <= ri_out; ++i) {
+    total = 0.0f;
+    for (int j = nz; j >= 1; --j) {
+      const int icell = i + n_rad * (j - 1);
+      const double dzl = m->z_lim[(i - 1) + (size_t)n_rad * j] - m->z_lim[(i - 1) + (size_t)n_rad * (j - 1)];
+      total = (float)((double)total + kap * m->kappa_factor[icell - 1] * dzl);
+      if (total > tau_max) { zj_sup[i] = j; break; }
+    }
+  }
+  /* step 4: test rays in 11 directions from the cell centres (:1522-1551) */
+  worker_t W;
+  memset(&W, 0, sizeof(W));
+  oracle_opts o;
+  memset(&o, 0, sizeof(o));
+  double *E_dummy = (double *)calloc((size_t)m->n_cells, sizeof(double));
+  if (!E_dummy) { free(zj_sup); return 22; }
+  oracle_model mm = *m;
+  mm.l_dark_zone = NULL; /* the flags are being built: no mirror while probing */
+  W.m = &mm; W.o = &o; W.E_abs = E_dummy;
+  const double Stokes[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int i = (ri_in > 2 ? ri_in : 2); i <= ri_out; ++i) {
+    int done = 0;
+    for (int j = zj_sup[i]; j >= 1 && !done; --j) {
+      int icell = i + n_rad * (j - 1);
+      for (int n = 1; n <= 11; ++n) {
+        const float angle = (float)(PI * (double)((float)n / (float)12)); /* pi * real(n)/real(nbre_angle+1) */
+        double x0 = r_grid[icell - 1], y0 = 0.0, z0 = z_grid[icell - 1];
+        double u0 = (double)cosf(angle), v0 = 0.0, w0 = (double)sinf(angle);
+        int ic = icell, flag_sortie = 0, alive = 1;
+        physical_length(&W, lambda, Stokes, &ic, &x0, &y0, &z0, &u0, &v0, &w0, 0, (double)tau_max, &flag_sortie, &alive);
+        if (!flag_sortie) { /* the ray does not leave: this cell and those below are dark */
+          for (int jj = 1; jj <= j; ++jj) dz[i + n_rad * (jj - 1) - 1] = 1;
+          done = 1;
+          break;
+        }
+      }
+    }
+  }
+  free(E_dummy); free(zj_sup);
+  return 0;
+}

@@ -225,6 +225,16 @@ int oracle_run_mono(const oracle_model *m, const oracle_mono_opts *o, double *xI
                     double *sed, double *n_sent, uint64_t *n_sent_chunk,
                     uint64_t *counters);
 
+/*
+ * define_dark_zone (optical_depth.f90:1425-1651) for a 2D cylindrical grid: cells from which a
+ * ray of optical depth tau_max does not leave the grid in any of 11 directions, plus the cells
+ * below them.  r_lim[0..n_rad], r_grid / z_grid [n_cells] are cylindrical_grid's arrays.  A host
+ * table builder of the reference, restated here so that the harness can feed
+ * the packet loop the same kind of dark zone the reference's own ref4.1 run has.
+ */
+int oracle_define_dark_zone(const oracle_model *m, int lambda, double tau_max, const double *r_lim,
+                            const double *r_grid, const double *z_grid, unsigned char *l_dark_zone);
+
 /* Voronoi grid operators (Voronoi.f90). */
 void oracle_cross_voronoi_cell(const oracle_model *m, double x, double y,
                                double z, double u, double v, double w,

