@@ -1,4 +1,4 @@
-// Opt-in schedule for the thermal packet loop on cylindrical grids (MCGPU_ROLES=<flyer waves>):
+// The default schedule of the thermal packet loop on cylindrical grids (MCGPU_ROLES, see mcgpu.hip):
 // the waves of a workgroup take ROLES and pass packets to each other through queues in LDS.
 //
 // Why: the flight lengths are heavy-tailed (most flights of a packet random-walking in the thick
@@ -201,11 +201,17 @@ __device__ inline void rq_exchange(RoleQ<POLA>* Q, int lane, bool want_push, boo
   }
 }
 
-// One cell crossing of a packet in flight (physical_length's loop body, optical_depth.f90:77-178;
-// grids without a dark zone).  Returns the number of packets this lane finished (0 or 1).
-template <bool L3D, bool POLA, bool LDSE>
+// One cell crossing of a packet in flight (physical_length's loop body, optical_depth.f90:77-178).  Returns the
+// number of packets this lane finished (0 or 1).
+// DARK: the reference tests l_dark_zone(icell0) at the top of the NEXT loop turn and then puts the packet back at
+// the point where it entered the cell it has just crossed, direction reversed (:104-112).  The same thing is done
+// here at the end of the crossing that leads into the dark cell -- the entry point is still at hand, so the packet
+// needs no memory of it (a flight never starts inside a dark cell: packets are mirrored at its edge and the dark
+// cells emit nothing, thermal_emission.f90:1817).
+template <bool L3D, bool POLA, bool DARK, bool LDSE>
 __device__ inline int roles_cross(const Lds& T, const DevModel& M, const RunArgs& A, double* E_lds, PkState& p,
-                                  double inv_a, double inv_w, double& kf, unsigned int& c_cross, unsigned int& c_kill) {
+                                  double inv_a, double inv_w, double& kf, unsigned int& c_cross, unsigned int& c_kill,
+                                  unsigned int& c_dark) {
   const int n_rad = M.n_rad, nz = M.nz;
   const int azj = p.zj < 0 ? -p.zj : p.zj;
   const bool out = (p.ri == n_rad + 1) || ((azj == nz + 1) && (fabs(p.z) > M.zmaxmax));
@@ -240,14 +246,22 @@ __device__ inline int roles_cross(const Lds& T, const DevModel& M, const RunArgs
   } else {
     p.extr = p.extr - tau;
     if (real_cell && !(A.flags & 1)) deposit<LDSE>(A.E_abs, E_lds, ic, T.kabs[p.lambda - 1] * l * p.S[0]);
-    p.x = x1; p.y = y1; p.z = z1;
-    p.ri = ri1; p.zj = zj1; p.k = k1;
-    kf = is_real_cell<L3D>(n_rad, nz, p.ri, p.zj) ? M.kappa_factor[cell_index<L3D>(n_rad, nz, p.ri, p.zj, p.k)] : 0.0;
+    const bool next_real = is_real_cell<L3D>(n_rad, nz, ri1, zj1);
+    const int ic1 = next_real ? cell_index<L3D>(n_rad, nz, ri1, zj1, k1) : 0;
+    if (DARK && next_real && M.dark[ic1]) {
+      p.u = -p.u; p.v = -p.v; p.w = -p.w;  // back at the entry point of this cell, an interaction follows there
+      c_dark++;
+      p.st = S_INTERACT;
+    } else {
+      p.x = x1; p.y = y1; p.z = z1;
+      p.ri = ri1; p.zj = zj1; p.k = k1;
+      kf = next_real ? M.kappa_factor[ic1] : 0.0;
+    }
   }
   return 0;
 }
 
-template <bool L3D, bool POLA, bool LDSE>
+template <bool L3D, bool POLA, bool DARK, bool LDSE>
 __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, double* lds_base, int n_flyers,
                                            int k_short, int fly_iters, int fly_idle, int emit_qmax, int emit_min) {
   double* const E_lds = lds_base;
@@ -278,7 +292,7 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
   p.st = S_EMIT;  // S_EMIT = the lane holds no packet
   p.tau_rand = 0.0f; p.pk_cross = 0;
   double inv_a = 0.0, inv_w = 0.0, kf = 0.0;
-  unsigned int c_cross = 0, c_flight = 0, c_scatt = 0, c_abs = 0, c_esc = 0, c_kill = 0, c_pack = 0;
+  unsigned int c_cross = 0, c_flight = 0, c_scatt = 0, c_abs = 0, c_esc = 0, c_kill = 0, c_pack = 0, c_dark = 0;
   unsigned long long pk_next = 0, pk_end = 0;
   bool no_more_ids = false;  // wave-uniform: the global id counter is exhausted
   int idle_spins = 0;        // consecutive rounds without work: bounded, a lost packet must not hang the GPU
@@ -341,7 +355,7 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
         // back to the queues as soon as enough lanes have nothing to fly (or after fly_iters crossings)
         if (it > 0 && __popcll(__ballot(p.st != S_FLIGHT)) >= fly_idle) break;
         RQ_DIAG(if (lane == 0) d_fly_iters++; if (p.st == S_FLIGHT) d_fly_cross++;)
-        if (p.st == S_FLIGHT) finished += roles_cross<L3D, POLA, LDSE>(T, M, A, E_lds, p, inv_a, inv_w, kf, c_cross, c_kill);
+        if (p.st == S_FLIGHT) finished += roles_cross<L3D, POLA, DARK, LDSE>(T, M, A, E_lds, p, inv_a, inv_w, kf, c_cross, c_kill, c_dark);
         if (p.st == S_EXITED) {  // binned on the spot (capteur)
           if (!p.flag_ism) { capteur<POLA>(M, A.sed, p.lambda, p.u, p.v, p.w, p.S, p.flag_star, p.flag_scatt); c_esc++; }
           p.st = S_EMIT;
@@ -477,7 +491,7 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
       for (int it = 0; it < k_short; ++it) {
         if (__ballot(p.st == S_FLIGHT) == 0ull) break;
         RQ_DIAG(if (lane == 0) d_srv_iters++;)
-        if (p.st == S_FLIGHT) finished += roles_cross<L3D, POLA, LDSE>(T, M, A, E_lds, p, inv_a, inv_w, kf, c_cross, c_kill);
+        if (p.st == S_FLIGHT) finished += roles_cross<L3D, POLA, DARK, LDSE>(T, M, A, E_lds, p, inv_a, inv_w, kf, c_cross, c_kill, c_dark);
       }
     }
 
@@ -506,7 +520,7 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
       if (e != 0.0) atomic_add_f64(&A.E_abs[i], e);
     }
   }
-  unsigned int cs[8] = {c_pack, c_cross, c_flight, c_scatt, c_abs, c_esc, c_kill, 0u};
+  unsigned int cs[8] = {c_pack, c_cross, c_flight, c_scatt, c_abs, c_esc, c_kill, c_dark};
 #ifdef MCGPU_COUNT_ITERS  // the eight counters carry the schedule's statistics instead
   cs[0] = d_in_flight; cs[1] = d_handed; cs[6] = d_popped; cs[3] = d_empty;  // lanes, summed over server rounds
   cs[2] = d_srv_rounds; cs[5] = d_fly_rounds;                                 // rounds
@@ -520,12 +534,12 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
   }
 }
 
-template <bool L3D, bool POLA, bool LDSE>
+template <bool L3D, bool POLA, bool DARK, bool LDSE>
 __global__ void __launch_bounds__(MCGPU_LDS_BLOCK) k_thermal_roles(const DevModel M, const RunArgs A, int n_flyers,
                                                                    int k_short, int fly_iters, int fly_idle,
                                                                    int emit_qmax, int emit_min) {
   extern __shared__ double lds_raw[];
-  roles_body<L3D, POLA, LDSE>(M, A, lds_raw, n_flyers, k_short, fly_iters, fly_idle, emit_qmax, emit_min);
+  roles_body<L3D, POLA, DARK, LDSE>(M, A, lds_raw, n_flyers, k_short, fly_iters, fly_idle, emit_qmax, emit_min);
 }
 
 }  // namespace mcgpu

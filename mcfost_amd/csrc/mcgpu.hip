@@ -519,7 +519,7 @@ static int launch_mega(mcgpu_ctx* ctx, const RunArgs& A, bool use_lds, int grid_
   const bool pola = ctx->lsepar_pola != 0, dark = M.dark != nullptr, l3d = M.l3D != 0;
   hipError_t e;
   // Waves with roles and LDS packet queues (mc_roles.hip.h): the default wherever the queues fit next to the
-  // tables and the grid has no dark zone.  MCGPU_ROLES: -1 = the single-role kernel (thermal_body), 0..7 = that
+  // tables.  MCGPU_ROLES: -1 = the single-role kernel (thermal_body), 0..7 = that
   // many fixed flyer waves, 100+f = every wave picks its role per round (flyer when f lanes can fly), 200 = per
   // round, the role in which more of its lanes have work (default).
   int n_flyers = 200, k_short = 2, fly_iters = 16, fly_idle = 16, emit_qmax = 1 << 20, emit_min = 1;
@@ -533,7 +533,7 @@ static int launch_mega(mcgpu_ctx* ctx, const RunArgs& A, bool use_lds, int grid_
   if (const char* ev = getenv("MCGPU_FLY_IDLE")) { int v = atoi(ev); if (v >= 1 && v <= 65) fly_idle = v; }
   if (const char* ev = getenv("MCGPU_EMIT_QMAX")) { int v = atoi(ev); if (v >= 0) emit_qmax = v; }
   if (const char* ev = getenv("MCGPU_EMIT_MIN")) { int v = atoi(ev); if (v >= 1 && v <= 64) emit_min = v; }
-  if (n_flyers >= 0 && !dark && !A.resume_pool) {
+  if (n_flyers >= 0 && !A.resume_pool) {
     const size_t lds_r = (lds_k + 7) / 8 * 8 + (pola ? sizeof(RoleQ<true>) : sizeof(RoleQ<false>));
     if (lds_r > lds_cap) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "MCGPU_ROLES: the packet queues do not fit in LDS next to the tables");
     const int rthreads = (block_threads > 0 && block_threads <= MCGPU_LDS_BLOCK) ? block_threads : MCGPU_LDS_BLOCK;
@@ -544,9 +544,14 @@ static int launch_mega(mcgpu_ctx* ctx, const RunArgs& A, bool use_lds, int grid_
       if (grid_blocks <= 0 && (unsigned long long)rblocks > need) rblocks = (int)(need ? need : 1);
     }
     const void* fn;
-#define PICKR(a, b) fn = use_lds ? (const void*)k_thermal_roles<a, b, true> : (const void*)k_thermal_roles<a, b, false>
-    if (l3d) { if (pola) PICKR(true, true); else PICKR(true, false); }
-    else { if (pola) PICKR(false, true); else PICKR(false, false); }
+#define PICKR(a, b, c) fn = use_lds ? (const void*)k_thermal_roles<a, b, c, true> : (const void*)k_thermal_roles<a, b, c, false>
+    if (l3d) {
+      if (pola) { if (dark) PICKR(true, true, true); else PICKR(true, true, false); }
+      else { if (dark) PICKR(true, false, true); else PICKR(true, false, false); }
+    } else {
+      if (pola) { if (dark) PICKR(false, true, true); else PICKR(false, true, false); }
+      else { if (dark) PICKR(false, false, true); else PICKR(false, false, false); }
+    }
 #undef PICKR
     HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));
     void* args[] = {(void*)&M, (void*)&A, (void*)&n_flyers, (void*)&k_short, (void*)&fly_iters, (void*)&fly_idle, (void*)&emit_qmax, (void*)&emit_min};

@@ -218,13 +218,18 @@ extern "C" int emu_run_thermal(const oracle_model* m, const oracle_opts* o, cons
     for (int q = 0; q < 8; ++q) counters[q] = cnt[q];
     return err;
   }
-  if (getenv("MCGPU_EMU_ROLES") && !dark) {  // the role schedule on one lane: the wave alternates between both roles
+  if (getenv("MCGPU_EMU_ROLES")) {  // the role schedule on one lane: the wave alternates between both roles
     const int nf = atoi(getenv("MCGPU_EMU_ROLES"));
     const bool ld = getenv("MCGPU_EMU_LDS") != nullptr;
     A.flush_every = 4;
-#define RUNR(a, b) do { if (ld) k_thermal_roles<a, b, true>(M, A, nf, 2, 3, 65, 1 << 20, 1); else k_thermal_roles<a, b, false>(M, A, nf, 2, 3, 65, 1 << 20, 1); } while (0)
-    if (l3d) { if (pola) RUNR(true, true); else RUNR(true, false); }
-    else { if (pola) RUNR(false, true); else RUNR(false, false); }
+#define RUNR(a, b, c) do { if (ld) k_thermal_roles<a, b, c, true>(M, A, nf, 2, 3, 65, 1 << 20, 1); else k_thermal_roles<a, b, c, false>(M, A, nf, 2, 3, 65, 1 << 20, 1); } while (0)
+    if (l3d) {
+      if (pola) { if (dark) RUNR(true, true, true); else RUNR(true, true, false); }
+      else { if (dark) RUNR(true, false, true); else RUNR(true, false, false); }
+    } else {
+      if (pola) { if (dark) RUNR(false, true, true); else RUNR(false, true, false); }
+      else { if (dark) RUNR(false, false, true); else RUNR(false, false, false); }
+    }
     for (int q = 0; q < 8; ++q) counters[q] = cnt[q];
     return err;
   }

@@ -275,6 +275,14 @@ def test_emulated_role_schedule(emu, small_model):
             del os.environ["MCGPU_EMU_LDS"]
             check(emu, M.build_model(M.small(n_rad=12, nz=6, n_az=8, l3D=True)), 2000, 8)
             check(emu, M.build_model(M.small(aniso_method=2, lsepar_pola=False)), 2000, 10)
+            md = copy.copy(small_model)   # dark zone: mirror at the end of the crossing that leads into it
+            dz = np.zeros(md.n_cells, np.uint8)
+            kf = md.kappa_factor.copy()
+            kf[::md.cfg.n_rad] = 0.0          # never the first radial cell (optical_depth.f90:1524: i >= 2)
+            dz[np.argsort(kf)[-40:]] = 1
+            md.l_dark_zone = dz
+            a, b = check(emu, md, 4000, 12)
+            assert a["counters"][7] > 0
         finally:
             os.environ.pop("MCGPU_EMU_ROLES", None)
             os.environ.pop("MCGPU_EMU_LDS", None)
