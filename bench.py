@@ -68,12 +68,26 @@ def cpu_baseline(model, n_total, target_s=15.0):
     orc.run_thermal(20000 * cores, seed=99, n_threads=cores)
     rate = 20000 * cores / (time.perf_counter() - t)
     n = int(max(20000 * cores, min(rate * target_s, 5e7)))
+    orc = Oracle(model, n)   # a self-consistent run of n packets: its own packet luminosity, its own temperature
     t = time.perf_counter()
     res = orc.run_thermal(n, seed=100, n_threads=cores)
     dt = time.perf_counter() - t
-    return dict(value=n / dt, unit="packets/s", cores=cores, kind="port",
+    base = dict(value=n / dt, unit="packets/s", cores=cores, kind="port",
                 sample="%d packets of the same thermal workload, %d OpenMP threads, %.1f s; "
                        "%.1f crossings/packet" % (n, cores, dt, res["counters"]["crossings"] / n))
+    return base, orc.temp_finale(res["E_abs"]), n
+
+
+def tdust_parity(T_gpu, n_gpu, T_cpu, n_cpu, T_min):
+    """Temperature of the GPU step against the CPU port's (independent noise): relative RMS over the cells with
+    T > 1.01 T_min, the reference's own gate p75(|dT|/T) (test_suite/test_mcfost.py:46-57,88: < 5 %), and the
+    tolerance 3 sigma_MC with sigma_MC(N) = 1.7 % sqrt(1.28e5 / N) per run."""
+    import numpy as np
+    sel = (T_cpu > 1.01 * T_min) & (T_gpu > 1.01 * T_min)
+    rel = (T_gpu[sel] - T_cpu[sel]) / T_cpu[sel]
+    sigma = 0.017 * float(np.sqrt(1.28e5 / n_gpu + 1.28e5 / n_cpu))
+    return dict(rel_rms=float(np.sqrt(np.mean(rel ** 2))), p75=float(np.percentile(np.abs(rel), 75)),
+                tolerance_rel_rms=3.0 * sigma, cells=int(sel.sum()), ok=bool(np.sqrt(np.mean(rel ** 2)) <= 3.0 * sigma))
 
 
 def bench_sed(args, world, rank, local_rank):
@@ -292,7 +306,10 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_launch},
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(model, n_total, args.cpu_seconds)
+            base, T_cpu, n_cpu = cpu_baseline(model, n_total, args.cpu_seconds)
+            line["cpu_baseline"] = base
+            if not args.frozen:  # Tdust of the last timed step against the CPU port's
+                line["tdust_vs_cpu"] = tdust_parity(eng.temp_finale(out["E_abs"]), n_total, T_cpu, n_cpu, cfg.T_min)
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
