@@ -85,9 +85,11 @@ def tdust_parity(T_gpu, n_gpu, T_cpu, n_cpu, T_min):
     import numpy as np
     sel = (T_cpu > 1.01 * T_min) & (T_gpu > 1.01 * T_min)
     rel = (T_gpu[sel] - T_cpu[sel]) / T_cpu[sel]
-    sigma = 0.017 * float(np.sqrt(1.28e5 / n_gpu + 1.28e5 / n_cpu))
-    return dict(rel_rms=float(np.sqrt(np.mean(rel ** 2))), p75=float(np.percentile(np.abs(rel), 75)),
-                tolerance_rel_rms=3.0 * sigma, cells=int(sel.sum()), ok=bool(np.sqrt(np.mean(rel ** 2)) <= 3.0 * sigma))
+    # sigma_MC was measured on the 7000-cell ref4.1 grid; the noise per cell scales with sqrt(cells / packets)
+    sigma = 0.017 * float(np.sqrt(1.28e5 / n_gpu + 1.28e5 / n_cpu)) * float(np.sqrt(max(T_cpu.size, 7000) / 7000.0))
+    rms, p75 = float(np.sqrt(np.mean(rel ** 2))), float(np.percentile(np.abs(rel), 75))
+    return dict(rel_rms=rms, p75=p75, tolerance_rel_rms=3.0 * sigma, cells=int(sel.sum()), ok=bool(rms <= 3.0 * sigma),
+                reference_gate_p75_below_5pct=bool(p75 < 0.05))
 
 
 def bench_sed(args, world, rank, local_rank):
