@@ -298,6 +298,40 @@ int mcgpu_fetch_xI(mcgpu_ctx *ctx, float *xI_scatt_f32, double *xI_scatt_f64);
  * all-reduce across the ranks of a multi-GPU SED step; fetch afterwards with mcgpu_fetch_xI. */
 int mcgpu_device_xI(mcgpu_ctx *ctx, void **xI_dev, uint64_t *n_doubles);
 
+/* ------------------------------------------------------------------------
+ * Ray-traced SED of the dust, ray-tracing method 1: what
+ * dust_map(lambda, ibin, iaz) (dust_transfer.f90:1413-1600) adds to
+ * Stokes_ray_tracing(lambda,1,1,ibin,iaz,:) when RT_sed_method == 1 --
+ * init_dust_source_fct1 (dust_ray_tracing.f90:636-716) + calc_Jth (:810-846)
+ * + the 128 x 30 log-r / phi sampling of the image plane (:1481-1535) +
+ * intensite_pixel_dust with one sub-pixel (:1899-2004) + integ_ray_dust
+ * (optical_depth.f90:1327-1421) -- for every observer direction of
+ * mcgpu_set_rt1, from the xI_scatt the last mcgpu_run_mono(rt1=1) of this
+ * wavelength left on the device (after the all-reduce on several GPUs).
+ * The stellar term (compute_stars_map, :1603-1895) stays with the host.
+ * Cylindrical grids.
+ * ------------------------------------------------------------------------ */
+typedef struct {
+  int lambda;               /* 1-based wavelength index                                   */
+  double wl_um;             /* tab_lambda(lambda)                                         */
+  double E_src;             /* E_totale(lambda) = E_stars + E_disk + E_ISM (:666)          */
+  double n_sent_photons;    /* sum(n_phot_envoyes(lambda,:)) (:662)                       */
+  double distance;          /* pc                                                         */
+  double ang_disque;        /* degrees                                                    */
+  int l_sym_ima;            /* half-plane sampling doubled by symmetry (:1517-1521)       */
+  double tau_dark_zone_obs; /* integ_ray_dust stops beyond it (optical_depth.f90:1414)    */
+  double Rmin, Rmax;        /* grid extent, AU (:1492-1493)                               */
+} mcgpu_rt_opts;
+
+/* tab_RT_az[RT_n_az] in degrees; Tdust[n_cells] (host).  stokes[RT_n_incl*RT_n_az][N_type_flux]
+ * receives the dust contribution to Stokes_ray_tracing in the same units (W.m-2 once the caller
+ * applies the SED normalisation of ecriture_sed_ray_tracing).  With l_sym_ima the 30 azimuths
+ * sample half of the image plane with pixels of the full annulus / 30 (:1506-1511), so nothing
+ * is doubled afterwards. */
+int mcgpu_rt1_dust_map(mcgpu_ctx *ctx, const mcgpu_rt_opts *opts,
+                       const float *tab_RT_az, const float *Tdust,
+                       double *stokes, double *kernel_ms);
+
 /* Temp_finale (thermal_emission.f90:870-906): Tdust(icell) from the summed
  * absorbed-energy grid.  E_abs == NULL uses the device accumulator. */
 int mcgpu_temp_finale(mcgpu_ctx *ctx, const double *E_abs, float *Tdust);

@@ -132,6 +132,19 @@ __device__ inline void rt1_subbin(const MonoArgs& A, double x0, double y0, doubl
   }
 }
 
+// the same from plain arguments (the ray tracer has no MonoArgs)
+__device__ inline void rt1_subbin_of(int n_az_rt, bool l3D, double x0, double y0, double z0, double x1, double y1,
+                                     double z1, int& phik, int& psup) {
+  phik = 1; psup = 1;
+  if (!l3D) {
+    const double xm = 0.5 * (x0 + x1), ym = 0.5 * (y0 + y1), zm = 0.5 * (z0 + z1);
+    const double phi_pos = atan2(xm, ym);
+    phik = (int)floor(modulo_d(phi_pos, 2 * PI) / (2 * PI) * (double)n_az_rt) + 1;
+    if (phik > n_az_rt) phik = n_az_rt;
+    psup = (zm > 0.0) ? 1 : 2;
+  }
+}
+
 constexpr int XI_LINE = 8;  // doubles per (cell, sub-bin, observer) record of the device layout: one 64-byte line
 
 // save_radiation_field, lscatt_ray_tracing1 branch (radiation_field.f90:63-89) with calc_xI_scatt

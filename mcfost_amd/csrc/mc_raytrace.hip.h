@@ -1,0 +1,155 @@
+// Ray-traced SED of the dust, ray-tracing method 1: what dust_map(lambda,ibin,iaz)
+// (dust_transfer.f90:1413-1600) adds to Stokes_ray_tracing(lambda,1,1,ibin,iaz,:) with RT_sed_method = 1.
+//   k_calc_Jth      calc_Jth (dust_ray_tracing.f90:810-846, LTE grains): thermal emissivity per cell
+//   k_rt1_dust_map  one ray per lane: the 128 x 30 log-r / uniform-phi sampling of the image plane of every
+//                   observer direction (:1481-1535); intensite_pixel_dust with one sub-pixel (:1899-2004):
+//                   move_to_grid from far away, then integ_ray_dust (optical_depth.f90:1327-1421), the formal
+//                   solution sum exp(-tau) (1 - exp(-dtau)) S with the RT1 source function
+//                   eps_dust1(k,psup,:,icell) (dust_ray_tracing.f90:1455-1475), built on the fly from the
+//                   xI_scatt records the SED Monte Carlo left in HBM and J_th (init_dust_source_fct1 :636-716).
+// The stellar term (compute_stars_map: 1024 random rays per star on the host) is not part of this kernel.
+#pragma once
+#include "mc_mono.hip.h"
+
+namespace mcgpu {
+
+struct RtArgs {
+  int lambda, RT_n_incl, nRT, n_az_rt, n_theta_rt, N_type_flux, contrib, l_sym_ima;
+  double wl, photon_energy, pix_scale;  // metres; (:661-663); 1 / (distance * pc_to_AU)
+  double ang_disque, tau_dark_zone_obs, rmin_RT, fact_r, fact_A, cst_phi, l_far;
+  const double* rt_u; const double* rt_v; const double* rt_w;  // observer directions (see MonoArgs)
+  const float* rt_az;                                           // tab_RT_az [RT_n_az], degrees
+  const double* xI;                                             // device layout [cell][psup][phik][iRT][XI_LINE]
+  const double* J_th;                                           // [n_cells]
+  double* out;                                                  // [nRT * N_type_flux]
+};
+
+constexpr int RT_N_RAD = 128, RT_N_PHI = 30;  // dust_map (:1434)
+
+__global__ void k_calc_Jth(const DevModel M, int lambda, double wl, const float* Tdust, double* J_th) {
+  const int ic = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ic >= M.n_cells) return;
+  const double cst_E = 2.0 * 6.626070040e-34 * 299792458.0 * 299792458.0;
+  const float thermal_const = (float)(299792458.0 * 6.626070040e-34 / 1.38064852e-23);  // real (constants.f90:24)
+  const double Temp = (double)Tdust[ic];
+  double j = 0.0;
+  if (Temp * wl > 3.e-4) {
+    const double cst_wl = (double)thermal_const / (Temp * wl);
+    const double coeff_exp = exp(cst_wl);
+    j = cst_E / (pow(wl, 5) * (coeff_exp - 1.0)) * wl * M.kappa_abs[lambda - 1] * M.kappa_factor[ic];
+  }
+  J_th[ic] = j;
+}
+
+// rotation_3d (utils.f90:1545-1589)
+__device__ inline void rotation_3d(const double axis[3], double angle_deg, const double v[3], double out[3]) {
+  const double d = v[0] * axis[0] + v[1] * axis[1] + v[2] * axis[2];
+  const double vp[3] = {d * axis[0], d * axis[1], d * axis[2]};
+  double vn[3] = {v[0] - vp[0], v[1] - vp[1], v[2] - vp[2]};
+  const double norm = sqrt(vn[0] * vn[0] + vn[1] * vn[1] + vn[2] * vn[2]);
+  if (norm < TINY_DP) { out[0] = vp[0]; out[1] = vp[1]; out[2] = vp[2]; return; }
+  vn[0] /= norm; vn[1] /= norm; vn[2] /= norm;
+  const double vn2[3] = {axis[1] * vn[2] - axis[2] * vn[1], axis[2] * vn[0] - axis[0] * vn[2],
+                         axis[0] * vn[1] - axis[1] * vn[0]};
+  double sa, ca;
+  sincos(angle_deg * (PI / 180.0), &sa, &ca);
+  for (int q = 0; q < 3; ++q) out[q] = vp[q] + norm * (ca * vn[q] + sa * vn2[q]);
+}
+
+template <bool L3D, bool POLA>
+__global__ void __launch_bounds__(256) k_rt1_dust_map(const DevModel M, const RtArgs A) {
+  extern __shared__ double lds_raw[];
+  const Lds T = lds_carve(lds_raw, M);
+  lds_stage(T, M);
+  __syncthreads();
+  const int n_rad = M.n_rad, nz = M.nz;
+  const int rays_per_dir = RT_N_RAD * RT_N_PHI;  // 3840 = 60 wavefronts: a wavefront never straddles two directions
+  const int n_rays = A.nRT * rays_per_dir;
+  const int n_Stokes = POLA ? 4 : 1;
+  const int lane = threadIdx.x & 63;
+
+  for (int base = (blockIdx.x * blockDim.x + (threadIdx.x & ~63)); base < n_rays; base += gridDim.x * blockDim.x) {
+    const int ray = base + lane;  // (n_rays is a multiple of 64)
+    const int q = ray / rays_per_dir, rem = ray - q * rays_per_dir;
+    const int ri_RT = rem / RT_N_PHI, phi_RT = rem - ri_RT * RT_N_PHI + 1;
+    const double u = A.rt_u[q], v = A.rt_v[q], w = A.rt_w[q % A.RT_n_incl];
+    // image-plane basis (:1440-1455)
+    const double uvw[3] = {u, v, w};
+    double sa, ca;
+    sincos((double)A.rt_az[q / A.RT_n_incl] * (PI / 180.0), &sa, &ca);
+    const double xv[3] = {ca, sa, 0.0};
+    double xpi[3];
+    if (fabs(A.ang_disque) > TINY_REAL) rotation_3d(uvw, A.ang_disque, xv, xpi);
+    else { xpi[0] = xv[0]; xpi[1] = xv[1]; xpi[2] = xv[2]; }
+    const double ypi[3] = {-(xpi[1] * uvw[2] - xpi[2] * uvw[1]), -(xpi[2] * uvw[0] - xpi[0] * uvw[2]),
+                           -(xpi[0] * uvw[1] - xpi[1] * uvw[0])};
+    // tab_r(ri) = rmin_RT * fact_r**(ri-1), built by repeated products like the reference (:1499-1503)
+    double r = A.rmin_RT;
+    for (int i = 0; i < ri_RT; ++i) r = r * A.fact_r;
+    const double taille_pix = A.fact_A * r;
+    const double phi = A.cst_phi * ((double)phi_RT - 0.5);
+    double sp, cp;
+    sincos(phi, &sp, &cp);
+    double x = u * A.l_far + r * sp * xpi[0] + r * cp * ypi[0];
+    double y = v * A.l_far + r * sp * xpi[1] + r * cp * ypi[1];
+    double z = w * A.l_far + r * sp * xpi[2] + r * cp * ypi[2];
+    const double u0 = -u, v0 = -v, w0 = -w;  // reverse propagation
+    int ri, zj, k;
+    double S[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (move_to_grid<L3D>(T, M, x, y, z, u0, v0, w0, ri, zj, k)) {
+      // integ_ray_dust (optical_depth.f90:1327-1421)
+      const double a = u0 * u0 + v0 * v0;
+      const double inv_a = (a > TINY_REAL) ? 1.0 / a : HUGE_REAL;
+      const double inv_w = (fabs(w0) > TINY_REAL) ? 1.0 / w0 : copysign(HUGE_DP, w0);
+      const int i_star = intersect_stars(M, x, y, z, u0, v0, w0);
+      int star_key = -1;
+      if (i_star > 0) {
+        const int* sc = &M.star_cell[4 * (i_star - 1)];
+        star_key = sc[0] + (n_rad + 2) * ((sc[1] + nz + 1) + (2 * nz + 3) * (sc[2] - 1));
+      }
+      double tau = 0.0;
+      for (long guard = 0; guard < 100000000L; ++guard) {
+        const int azj = zj < 0 ? -zj : zj;
+        if ((ri == n_rad + 1) || ((azj == nz + 1) && (fabs(z) > M.zmaxmax))) break;  // test_exit_grid
+        if (star_key >= 0 && (ri + (n_rad + 2) * ((zj + nz + 1) + (2 * nz + 3) * (k - 1))) == star_key) break;
+        double x1, y1, z1, l;
+        int ri1, zj1, k1;
+        MCGPU_CROSS<L3D>(T, M, x, y, z, u0, v0, w0, inv_a, inv_w, ri, zj, k, x1, y1, z1, ri1, zj1, k1, l);
+        if (is_real_cell<L3D>(n_rad, nz, ri, zj)) {
+          const int ic = cell_index<L3D>(n_rad, nz, ri, zj, k);
+          const double kappa_ext = T.kappa[A.lambda - 1] * M.kappa_factor[ic];
+          const double dtau = l * kappa_ext;
+          int phik = 1, psup = 1;
+          rt1_subbin_of(A.n_az_rt, L3D, x, y, z, x1, y1, z1, phik, psup);
+          if (kappa_ext > TINY_DP) {
+            const double factor = A.photon_energy / M.volume[ic] * A.n_az_rt * A.n_theta_rt;
+            const double kappa_sca = kappa_ext * (double)T.albedo[A.lambda - 1];
+            const double* rec = A.xI + ((((size_t)ic * A.n_theta_rt + (psup - 1)) * A.n_az_rt + (phik - 1)) * A.nRT + q) * XI_LINE;
+            const double wgt = exp(-tau) * (1.0 - exp(-dtau));
+            const double jth = A.J_th[ic];
+            const double fs = factor * kappa_sca / kappa_ext;
+            S[0] += wgt * (rec[0] * fs + jth / kappa_ext);
+            if (POLA) { S[1] += wgt * rec[1] * fs; S[2] += wgt * rec[2] * fs; S[3] += wgt * rec[3] * fs; }
+            if (A.contrib) {
+              S[n_Stokes + 1] += wgt * rec[n_Stokes + 1] * fs;
+              S[n_Stokes + 2] += wgt * (jth / kappa_ext);
+              S[n_Stokes + 3] += wgt * rec[n_Stokes + 3] * fs;
+            }
+          }
+          tau += dtau;
+          if (tau > A.tau_dark_zone_obs) break;
+        }
+        x = x1; y = y1; z = z1;
+        ri = ri1; zj = zj1; k = k1;
+      }
+    }
+    const double pix = taille_pix * A.pix_scale;
+    for (int t = 0; t < A.N_type_flux; ++t) {
+      double vsum = S[t] * pix * pix;
+      for (int off = 32; off > 0; off >>= 1) vsum += __shfl_down(vsum, off);
+      if (lane == 0 && vsum != 0.0) atomic_add_f64(&A.out[(size_t)q * A.N_type_flux + t], vsum);
+    }
+  }
+}
+
+}  // namespace mcgpu

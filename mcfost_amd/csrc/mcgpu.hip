@@ -18,6 +18,7 @@
 #include "mc_voronoi.hip.h"
 #include "mc_mono.hip.h"
 #include "mc_mono_voronoi.hip.h"
+#include "mc_raytrace.hip.h"
 #include "mc_roles.hip.h"
 
 using namespace mcgpu;
@@ -1179,6 +1180,74 @@ struct DevBuf {
   hipError_t put(const Tp* h, size_t n) { return hipMemcpy(p, h, n * sizeof(Tp), hipMemcpyHostToDevice); }
   hipError_t get(Tp* h, size_t n) { return hipMemcpy(h, p, n * sizeof(Tp), hipMemcpyDeviceToHost); }
 };
+
+// ---------------------------------------------------------------------------------------------
+// RT1 ray-traced dust SED (mc_raytrace.hip.h)
+// ---------------------------------------------------------------------------------------------
+template <bool L3D, bool POLA>
+static int launch_rt1(mcgpu_ctx* ctx, const RtArgs& A, int blocks) {
+  const size_t lds = lds_bytes(ctx->M);
+  const void* fn = (const void*)k_rt1_dust_map<L3D, POLA>;
+  HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL((k_rt1_dust_map<L3D, POLA>), dim3(blocks), dim3(256), lds, ctx->stream, ctx->M, A);
+  HIPCHK(hipGetLastError());
+  return MCGPU_OK;
+}
+
+extern "C" int mcgpu_rt1_dust_map(mcgpu_ctx* ctx, const mcgpu_rt_opts* o, const float* tab_RT_az, const float* Tdust,
+                                  double* stokes, double* kernel_ms) {
+  int rc = ready(ctx);
+  if (rc) return rc;
+  if (ctx->voro) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "mcgpu_rt1_dust_map: cylindrical grids only");
+  if (!o || !tab_RT_az || !Tdust || !stokes) return fail(ctx, MCGPU_ERR_ARG, "mcgpu_rt1_dust_map: null argument");
+  if (!ctx->have_rt1 || !ctx->d_xI) return fail(ctx, MCGPU_ERR_STATE, "mcgpu_rt1_dust_map needs the xI_scatt of mcgpu_run_mono(rt1=1)");
+  const DevModel& M = ctx->M;
+  if (o->lambda < 1 || o->lambda > M.n_lambda || !(o->wl_um > 0.0) || !(o->n_sent_photons > 0.0) ||
+      !(o->distance > 0.0) || !(o->Rmin > 0.0) || !(o->Rmax > o->Rmin))
+    return fail(ctx, MCGPU_ERR_ARG, "mcgpu_rt1_dust_map: bad option");
+  HIPCHK(hipSetDevice(ctx->device));
+  const int nRT = ctx->RT_n_incl * ctx->RT_n_az;
+  DevBuf<float> d_T, d_az;
+  DevBuf<double> d_J, d_out;
+  HIPCHK(d_T.alloc(M.n_cells)); HIPCHK(d_T.put(Tdust, M.n_cells));
+  HIPCHK(d_az.alloc(ctx->RT_n_az)); HIPCHK(d_az.put(tab_RT_az, ctx->RT_n_az));
+  HIPCHK(d_J.alloc(M.n_cells));
+  HIPCHK(d_out.alloc((size_t)nRT * ctx->N_type_flux));
+  HIPCHK(hipMemsetAsync(d_out.p, 0, (size_t)nRT * ctx->N_type_flux * sizeof(double), ctx->stream));
+
+  RtArgs A;
+  std::memset(&A, 0, sizeof(A));
+  A.lambda = o->lambda; A.RT_n_incl = ctx->RT_n_incl; A.nRT = nRT; A.n_az_rt = ctx->n_az_rt; A.n_theta_rt = ctx->n_theta_rt;
+  A.N_type_flux = ctx->N_type_flux; A.contrib = ctx->lsepar_contrib; A.l_sym_ima = o->l_sym_ima ? 1 : 0;
+  A.wl = o->wl_um * 1.e-6;
+  const double AU_to_cm = 149597870700.0 * 100.0, pc_to_AU = 648000.0 / M_PI;
+  A.photon_energy = o->E_src * o->wl_um * 1.0e-6 / (o->n_sent_photons * AU_to_cm * M_PI);
+  A.pix_scale = 1.0 / (o->distance * pc_to_AU);
+  A.ang_disque = o->ang_disque; A.tau_dark_zone_obs = o->tau_dark_zone_obs;
+  A.rmin_RT = 0.01 * o->Rmin;
+  const double rmax_RT = 2.0 * o->Rmax;
+  A.fact_r = std::exp((1.0 / ((double)RT_N_RAD - 1)) * std::log(rmax_RT / A.rmin_RT));
+  A.fact_A = std::sqrt(M_PI * (A.fact_r - 1.0 / A.fact_r) / RT_N_PHI);
+  A.cst_phi = (o->l_sym_ima ? M_PI : 2 * M_PI) / (double)RT_N_PHI;
+  A.l_far = 10. * o->Rmax;
+  A.rt_u = ctx->d_rt_u; A.rt_v = ctx->d_rt_v; A.rt_w = ctx->d_rt_w; A.rt_az = d_az.p;
+  A.xI = ctx->d_xI; A.J_th = d_J.p; A.out = d_out.p;
+
+  HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+  hipLaunchKernelGGL(k_calc_Jth, dim3((M.n_cells + 255) / 256), dim3(256), 0, ctx->stream, M, o->lambda, A.wl, d_T.p, d_J.p);
+  HIPCHK(hipGetLastError());
+  const int n_rays = nRT * RT_N_RAD * RT_N_PHI;
+  const int blocks = (n_rays + 255) / 256;  // one ray per lane
+  const bool pola = ctx->N_type_flux == 4 || ctx->N_type_flux == 8;
+  if (M.l3D) rc = pola ? launch_rt1<true, true>(ctx, A, blocks) : launch_rt1<true, false>(ctx, A, blocks);
+  else rc = pola ? launch_rt1<false, true>(ctx, A, blocks) : launch_rt1<false, false>(ctx, A, blocks);
+  if (rc) return rc;
+  HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (kernel_ms) { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1)); *kernel_ms = ms; }
+  HIPCHK(d_out.get(stokes, (size_t)nRT * ctx->N_type_flux));
+  return MCGPU_OK;
+}
 
 extern "C" int mcgpu_probe_cross_cell(mcgpu_ctx* ctx, int n, const double* x0, const double* y0, const double* z0,
                                       const double* u, const double* v, const double* w, const int* cell,

@@ -33,7 +33,7 @@ ABI_SYMBOLS = (
     "mcgpu_probe_cross_cell", "mcgpu_probe_index_cell", "mcgpu_probe_philox",
     "mcgpu_probe_packet_rand", "mcgpu_set_midplane_snap", "mcgpu_set_grid_voronoi",
     "mcgpu_probe_cross_voronoi", "mcgpu_set_rt1", "mcgpu_run_mono", "mcgpu_fetch_xI",
-    "mcgpu_device_xI", "mcgpu_set_ism",
+    "mcgpu_device_xI", "mcgpu_set_ism", "mcgpu_rt1_dust_map",
 )
 
 
@@ -51,6 +51,12 @@ class MonoOpts(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("lambda_", C.c_int), ("p_lambda", C.c_int), ("n_chunks", C.c_int),
                 ("first_chunk", C.c_int), ("n_photons2", C.c_uint64), ("n_phot_lim", C.c_double),
                 ("capt_sup", C.c_int), ("rt1", C.c_int), ("accumulate", C.c_int), ("grid_blocks", C.c_int), ("block_threads", C.c_int)]
+
+
+class RtOpts(C.Structure):
+    _fields_ = [("lambda_", C.c_int), ("wl_um", C.c_double), ("E_src", C.c_double), ("n_sent_photons", C.c_double),
+                ("distance", C.c_double), ("ang_disque", C.c_double), ("l_sym_ima", C.c_int),
+                ("tau_dark_zone_obs", C.c_double), ("Rmin", C.c_double), ("Rmax", C.c_double)]
 
 
 _lib = None
@@ -298,6 +304,12 @@ class Engine:
         return (self.model.n_cells, rt["RT_n_incl"] * rt["RT_n_az"], rt["N_type_flux"], rt["n_theta_rt"],
                 rt["n_az_rt"])
 
+    def fetch_xI(self):
+        """xI_scatt in the reference's layout (see ``xI_shape``), FP64 sums: ``mcgpu_fetch_xI``."""
+        x64 = np.zeros(self.xI_shape(), np.float64)
+        self._chk(self.lib.mcgpu_fetch_xI(self.ctx, None, _p(x64, C.c_double)), "mcgpu_fetch_xI")
+        return x64
+
     def run_mono(self, lam, n_photons2, n_phot_lim=None, p_lambda=None, seed=1, n_chunks=None, rt1=True,
                  accumulate=False, grid_blocks=0, block_threads=0, fetch_xI=True, first_chunk=0):
         """One wavelength (1-based ``lam``) of the SED Monte Carlo: ``mcgpu_run_mono`` with the
@@ -330,6 +342,22 @@ class Engine:
             self._chk(self.lib.mcgpu_fetch_xI(self.ctx, _p(x32, C.c_float), _p(x64, C.c_double)), "mcgpu_fetch_xI")
             out["xI_scatt"], out["xI_scatt_f32"] = x64, x32
         return out
+
+    def dust_map_sed(self, lam, Tdust, n_sent_photons, E_disk, ang_disque=0.0, l_sym_ima=True,
+                     tau_dark_zone_obs=100.0):
+        """Ray-traced SED of the dust at wavelength ``lam`` (``mcgpu_rt1_dust_map``) from the xI_scatt the
+        last ``run_mono(lam, rt1=True)`` left on the device: (nRT, N_type_flux) and the kernel time."""
+        m = self.model
+        rt = m.rt
+        o = RtOpts(int(lam), float(m.lam[lam - 1]), float(m.E_stars[lam - 1] + E_disk), float(n_sent_photons),
+                   float(m.cfg.distance), float(ang_disque), int(l_sym_ima), float(tau_dark_zone_obs),
+                   float(m.cfg.rin), float(m.cfg.rout))
+        out = np.zeros((rt["RT_n_incl"] * rt["RT_n_az"], rt["N_type_flux"]), np.float64)
+        ms = C.c_double()
+        self._chk(self.lib.mcgpu_rt1_dust_map(
+            self.ctx, C.byref(o), _p(_a(rt["tab_RT_az"], np.float32), C.c_float), _p(_a(Tdust, np.float32), C.c_float),
+            _p(out, C.c_double), C.byref(ms)), "mcgpu_rt1_dust_map")
+        return out, ms.value
 
     def probe_cross_voronoi(self, x0, y0, z0, u, v, w, cell, previous_cell):
         n = len(cell)

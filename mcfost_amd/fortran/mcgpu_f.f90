@@ -50,10 +50,23 @@ module mcgpu_f
      integer(c_int)     :: block_threads
   end type mcgpu_mono_opts
 
+  ! RT1 ray-traced dust SED (include/mcgpu.h: mcgpu_rt_opts)
+  type, bind(C), public :: mcgpu_rt_opts
+     integer(c_int) :: lambda
+     real(c_double) :: wl_um              ! tab_lambda(lambda)
+     real(c_double) :: E_src              ! E_totale(lambda)
+     real(c_double) :: n_sent_photons     ! sum(n_phot_envoyes(lambda,:))
+     real(c_double) :: distance
+     real(c_double) :: ang_disque
+     integer(c_int) :: l_sym_ima
+     real(c_double) :: tau_dark_zone_obs
+     real(c_double) :: Rmin, Rmax
+  end type mcgpu_rt_opts
+
   public :: mcgpu_create, mcgpu_destroy, mcgpu_set_grid_cyl, mcgpu_set_grid_voronoi, mcgpu_set_midplane_snap, &
        mcgpu_set_stars, mcgpu_set_opacity, mcgpu_set_scattering, mcgpu_set_thermal, mcgpu_set_sed_bins, &
        mcgpu_run_thermal, mcgpu_temp_finale, mcgpu_thermal_loop, mcgpu_error_message, mcgpu_set_rt1, &
-       mcgpu_run_mono, mcgpu_fetch, mcgpu_fetch_xI
+       mcgpu_run_mono, mcgpu_fetch, mcgpu_fetch_xI, mcgpu_rt1_dust_map
 
   interface
      integer(c_int) function mcgpu_create(device, ctx) bind(C, name="mcgpu_create")
@@ -194,6 +207,18 @@ module mcgpu_f
        import :: c_int, c_ptr
        type(c_ptr), value :: ctx, xI_scatt_f32, xI_scatt_f64       ! c_loc(xI_scatt(1,1,1,1,1,1)) or c_null_ptr
      end function mcgpu_fetch_xI
+
+     ! replaces the `call dust_map(lambda,ibin,iaz)` loop of the SED branch (dust_transfer.f90:990-1005) minus
+     ! compute_stars_map: stokes(N_type_flux, RT_n_incl, RT_n_az) is added to Stokes_ray_tracing(lambda,1,1,:,:,:,1)
+     integer(c_int) function mcgpu_rt1_dust_map(ctx, opts, tab_RT_az, Tdust, stokes, kernel_ms) &
+          bind(C, name="mcgpu_rt1_dust_map")
+       import :: c_int, c_ptr, c_double, c_float, mcgpu_rt_opts
+       type(c_ptr), value :: ctx
+       type(mcgpu_rt_opts), intent(in) :: opts
+       real(c_float), intent(in) :: tab_RT_az(*), Tdust(*)
+       real(c_double), intent(out) :: stokes(*)
+       real(c_double), intent(out) :: kernel_ms
+     end function mcgpu_rt1_dust_map
 
      integer(c_int) function mcgpu_temp_finale(ctx, E_abs, Tdust) bind(C, name="mcgpu_temp_finale")
        import :: c_int, c_ptr, c_double, c_float

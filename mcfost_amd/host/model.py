@@ -594,6 +594,7 @@ def repartition_energie(m: "Model", Tdust):
     pe = np.zeros((nl, nc + 1), f64)
     fs = np.zeros(nl, f64)
     fd = np.zeros(nl, f64)
+    E_disk_all = []
     vol = np.asarray(m.grid["volume"], f64)
     for l in range(nl):
         wl = m.lam[l] * 1.0e-6
@@ -604,6 +605,7 @@ def repartition_energie(m: "Model", Tdust):
         ok &= cst < cst_wl_max
         E_cell[ok] = 4.0 * m.kappa_abs_LTE[l] * m.kappa_factor[ok] * vol[ok] / ((wl ** 5) * (np.exp(cst[ok]) - 1.0))
         E_disk = float(np.sum(E_cell))
+        E_disk_all.append(E_disk)
         E_star = float(m.E_stars[l])
         fs[l] = E_star / (E_star + E_disk)
         fd[l] = 1.0  # (E_star + E_disk) / (E_star + E_disk + E_ISM), E_ISM = 0
@@ -613,6 +615,7 @@ def repartition_energie(m: "Model", Tdust):
         else:
             pe[l] = 0.0
     m.frac_E_stars, m.frac_E_disk, m.prob_E_cell = fs, fd, pe.reshape(-1)
+    m.extra["E_disk"] = np.array(E_disk_all)   # E_disk(lambda) (thermal_emission.f90:1902)
     return m
 
 

@@ -102,6 +102,13 @@ class _MonoOpts(C.Structure):
                 ("rt1", C.c_int), ("n_threads", C.c_int)]
 
 
+class _RtOpts(C.Structure):
+    _fields_ = [("lambda_", C.c_int), ("wl_um", C.c_double), ("E_src", C.c_double), ("n_sent_photons", C.c_double),
+                ("distance", C.c_double), ("ang_disque", C.c_double), ("l_sym_ima", C.c_int),
+                ("tau_dark_zone_obs", C.c_double), ("Rmin", C.c_double), ("Rmax", C.c_double), ("tab_RT_az", _fp),
+                ("n_threads", C.c_int)]
+
+
 class _Opts(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("first_packet", C.c_uint64), ("n_packets", C.c_uint64),
                 ("n_threads", C.c_int), ("frozen", C.c_int), ("tau_fp32", C.c_int),
@@ -271,6 +278,26 @@ class Oracle:
         E = _a(E_abs, np.float64)
         self.lib.oracle_temp_finale(C.byref(self.cm), _p(E, C.c_double), _p(T, C.c_float))
         return T
+
+    def dust_map_sed(self, lam, xI_scatt, Tdust, n_sent_photons, E_disk, ang_disque=0.0, l_sym_ima=True,
+                     tau_dark_zone_obs=100.0, n_threads=1):
+        """Ray-traced SED of the dust at wavelength ``lam`` (1-based), RT method 1: (nRT, N_type_flux)."""
+        m = self.model
+        rt = m.rt
+        az = _a(rt["tab_RT_az"], np.float32)
+        o = _RtOpts(int(lam), float(m.lam[lam - 1]), float(m.E_stars[lam - 1] + E_disk), float(n_sent_photons),
+                    float(m.cfg.distance), float(ang_disque), int(l_sym_ima), float(tau_dark_zone_obs),
+                    float(m.cfg.rin), float(m.cfg.rout), _p(az, C.c_float), int(n_threads))
+        nRT = rt["RT_n_incl"] * rt["RT_n_az"]
+        out = np.zeros((nRT, rt["N_type_flux"]), np.float64)
+        x = _a(xI_scatt, np.float64)
+        T = _a(Tdust, np.float32)
+        self.lib.oracle_dust_map_sed.restype = C.c_int
+        rc = self.lib.oracle_dust_map_sed(C.byref(self.cm), C.byref(o), _p(x, C.c_double), _p(T, C.c_float),
+                                          _p(out, C.c_double))
+        if rc:
+            raise RuntimeError(f"oracle_dust_map_sed failed: {rc}")
+        return out
 
     def define_dark_zone(self, lam, tau_max):
         """optical_depth.f90:1425-1651 (2D): the flags the reference's thermal step computes with

@@ -1713,3 +1713,156 @@ int oracle_define_dark_zone(const oracle_model *m, int lambda, double tau_max_in
   free(E_dummy); free(zj_sup);
   return 0;
 }
+
+/* ------------------------------------------------------------------------ */
+/* Ray-traced SED of the dust, RT method 1 (dust_transfer.f90:1413-1600)      */
+/* ------------------------------------------------------------------------ */
+#define ORC_PC_TO_AU (648000.0 / PI)           /* constants.f90:91 */
+#define ORC_AU_TO_CM (149597870700.0 * 100.0)  /* constants.f90:62-65 */
+#define ORC_HP 6.626070040e-34
+#define ORC_C_LIGHT 299792458.0
+#define ORC_KB 1.38064852e-23
+
+/* rotation_3d (utils.f90:1545-1589) */
+static void rotation_3d(const double axis[3], double angle_deg, const double v[3], double out[3]) {
+  const double d = v[0] * axis[0] + v[1] * axis[1] + v[2] * axis[2];
+  double vp[3] = {d * axis[0], d * axis[1], d * axis[2]};
+  double vn[3] = {v[0] - vp[0], v[1] - vp[1], v[2] - vp[2]};
+  const double norm = sqrt(vn[0] * vn[0] + vn[1] * vn[1] + vn[2] * vn[2]);
+  if (norm < DBL_MIN) { out[0] = vp[0]; out[1] = vp[1]; out[2] = vp[2]; return; }
+  vn[0] /= norm; vn[1] /= norm; vn[2] /= norm;
+  const double vn2[3] = {axis[1] * vn[2] - axis[2] * vn[1], axis[2] * vn[0] - axis[0] * vn[2],
+                         axis[0] * vn[1] - axis[1] * vn[0]};
+  const double ca = cos(angle_deg * (PI / 180.0)), sa = sin(angle_deg * (PI / 180.0));
+  for (int q = 0; q < 3; ++q) out[q] = vp[q] + norm * (ca * vn[q] + sa * vn2[q]);
+}
+
+int oracle_dust_map_sed(const oracle_model *m, const oracle_rt_opts *o, const double *xI, const float *Tdust,
+                        double *out) {
+  if (m->grid_type == 3) return 31;
+  const int ntf = m->N_type_flux, nRT = m->RT_n_incl * m->RT_n_az, nc = m->n_cells;
+  const int n_Stokes = m->lsepar_pola ? 4 : 1; /* init_mcfost.f90:1603-1616 */
+  const int lam = o->lambda;
+  const double wl = o->wl_um * 1.e-6;
+  memset(out, 0, sizeof(double) * (size_t)ntf * nRT);
+
+  /* calc_Jth (dust_ray_tracing.f90:810-846) */
+  double *J_th = (double *)calloc((size_t)nc, sizeof(double));
+  if (!J_th) return 22;
+  {
+    const double cst_E = 2.0 * ORC_HP * ORC_C_LIGHT * ORC_C_LIGHT;
+    const float thermal_const = (float)(ORC_C_LIGHT * ORC_HP / ORC_KB);
+    for (int ic = 0; ic < nc; ++ic) {
+      const double Temp = (double)Tdust[ic];
+      if (Temp * wl > 3.e-4) {
+        const double cst_wl = (double)thermal_const / (Temp * wl);
+        const double coeff_exp = exp(cst_wl);
+        J_th[ic] = cst_E / (pow(wl, 5) * (coeff_exp - 1.0)) * wl * m->kappa_abs_LTE[lam - 1] * m->kappa_factor[ic];
+      }
+    }
+  }
+  /* photon_energy (:661-663), SED branch */
+  const double photon_energy = o->E_src * o->wl_um * 1.0e-6 / (o->n_sent_photons * ORC_AU_TO_CM * PI);
+
+  /* image-plane sampling of dust_map, method 1 (:1481-1535) */
+  enum { n_rad_RT = 128, n_phi_RT = 30 };
+  double tab_r[n_rad_RT];
+  const double rmin_RT = 0.01 * o->Rmin, rmax_RT = 2.0 * o->Rmax;
+  tab_r[0] = rmin_RT;
+  const double fact_r = exp((1.0 / ((double)n_rad_RT - 1)) * log(rmax_RT / rmin_RT));
+  for (int i = 1; i < n_rad_RT; ++i) tab_r[i] = tab_r[i - 1] * fact_r;
+  const double fact_A = sqrt(PI * (fact_r - 1.0 / fact_r) / n_phi_RT);
+  const double cst_phi = (o->l_sym_ima ? PI : 2 * PI) / (double)n_phi_RT;
+  const size_t st_type = (size_t)m->n_az_rt * m->n_theta_rt, st_rt = st_type * ntf;
+
+  int err = 0;
+  for (int ibin = 1; ibin <= m->RT_n_incl; ++ibin)
+    for (int iaz = 1; iaz <= m->RT_n_az; ++iaz) {
+      const int q = (ibin - 1) + m->RT_n_incl * (iaz - 1);
+      const double u = m->tab_u_rt[q], v = m->tab_v_rt[q], w = m->tab_w_rt[ibin - 1];
+      const double uvw[3] = {u, v, w};
+      const double az = (double)o->tab_RT_az[iaz - 1] * (PI / 180.0);
+      const double x[3] = {cos(az), sin(az), 0.0};
+      double xpi[3];
+      if (fabs(o->ang_disque) > (double)FLT_MIN) rotation_3d(uvw, o->ang_disque, x, xpi);
+      else { xpi[0] = x[0]; xpi[1] = x[1]; xpi[2] = x[2]; }
+      /* y_plan_image = -cross_product(x_plan_image, uvw) */
+      const double ypi[3] = {-(xpi[1] * uvw[2] - xpi[2] * uvw[1]), -(xpi[2] * uvw[0] - xpi[0] * uvw[2]),
+                             -(xpi[0] * uvw[1] - xpi[1] * uvw[0])};
+      const double lfar = 10. * o->Rmax;
+      const double center[3] = {u * lfar, v * lfar, w * lfar};
+      double *acc = out + (size_t)q * ntf;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(o->n_threads > 0 ? o->n_threads : 1)
+#endif
+      for (int ri = 0; ri < n_rad_RT; ++ri) {
+        double loc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const double r = tab_r[ri], taille_pix = fact_A * r;
+        for (int ph = 1; ph <= n_phi_RT; ++ph) {
+          const double phi = cst_phi * ((double)ph - 0.5);
+          /* intensite_pixel_dust (:1899-2004) with one sub-pixel: the pixel centre, reverse propagation */
+          double x0 = center[0] + r * sin(phi) * xpi[0] + r * cos(phi) * ypi[0];
+          double y0 = center[1] + r * sin(phi) * xpi[1] + r * cos(phi) * ypi[1];
+          double z0 = center[2] + r * sin(phi) * xpi[2] + r * cos(phi) * ypi[2];
+          const double u0 = -u, v0 = -v, w0 = -w;
+          int icell, lintersect;
+          oracle_move_to_grid_cyl(m, &x0, &y0, &z0, u0, v0, w0, &icell, &lintersect);
+          if (!lintersect) continue;
+          /* integ_ray_dust (optical_depth.f90:1327-1421) */
+          double S[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+          double x1 = x0, y1 = y0, z1 = z0, tau = 0.0;
+          int next_cell = icell, lis, i_star, icell_star;
+          oracle_intersect_stars(m, x0, y0, z0, u0, v0, w0, &lis, &i_star, &icell_star);
+          for (long guard = 0; guard < 100000000L; ++guard) {
+            const int ic = next_cell;
+            const double xa = x1, ya = y1, za = z1;
+            if (oracle_test_exit_grid_cyl(m, ic, xa, ya, za)) break;
+            if (lis && ic == icell_star) break;
+            double l, lc, lv;
+            oracle_cross_cylindrical_cell(m, xa, ya, za, u0, v0, w0, ic, 0, &x1, &y1, &z1, &next_cell, &l, &lc, &lv);
+            if (ic <= nc) {
+              const double kappa_ext = m->kappa[lam - 1] * m->kappa_factor[ic - 1];
+              const double dtau = lc * kappa_ext;
+              const double xm = 0.5 * (xa + x1), ym = 0.5 * (ya + y1), zm = 0.5 * (za + z1);
+              /* dust_source_fct, RT1 (dust_ray_tracing.f90:1455-1475) = eps_dust1(k,psup,:,icell), built here
+               * from xI_scatt like init_dust_source_fct1 (:676-703) */
+              int k = 1, psup = 1;
+              if (!m->l3D) {
+                psup = (zm > 0.0) ? 1 : 2;
+                const double phi_pos = atan2(xm, ym);
+                k = (int)floor(modulo_d(phi_pos, 2 * PI) / (2 * PI) * (double)m->n_az_rt) + 1;
+                if (k > m->n_az_rt) k = m->n_az_rt;
+              }
+              if (kappa_ext > DBL_MIN) {
+                const double factor = photon_energy / m->volume[ic - 1] * m->n_az_rt * m->n_theta_rt;
+                const double kappa_sca = kappa_ext * (double)m->albedo[lam - 1];
+                const double *px = xI + (size_t)(k - 1) + (size_t)m->n_az_rt * (psup - 1) + st_rt * ((size_t)q + (size_t)nRT * (ic - 1));
+                const double wgt = exp(-tau) * (1.0 - exp(-dtau));
+                double eps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (int t = 0; t < ntf; ++t) eps[t] = px[st_type * t] * factor * kappa_sca; /* I_scatt(:,:,itype) */
+                double src[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                src[0] = (eps[0] + J_th[ic - 1]) / kappa_ext;
+                if (m->lsepar_pola) { src[1] = eps[1] / kappa_ext; src[2] = eps[2] / kappa_ext; src[3] = eps[3] / kappa_ext; }
+                if (m->lsepar_contrib) {
+                  src[n_Stokes + 1] = eps[n_Stokes + 1] / kappa_ext; /* n_Stokes+2 */
+                  src[n_Stokes + 2] = J_th[ic - 1] / kappa_ext;      /* n_Stokes+3 */
+                  src[n_Stokes + 3] = eps[n_Stokes + 3] / kappa_ext; /* n_Stokes+4 */
+                }
+                for (int t = 0; t < ntf; ++t) S[t] += wgt * src[t];
+              }
+              tau += dtau;
+              if (tau > o->tau_dark_zone_obs) break;
+            }
+          }
+          const double pix = (taille_pix / (o->distance * ORC_PC_TO_AU));
+          for (int t = 0; t < ntf; ++t) loc[t] += S[t] * pix * pix; /* (:1989, :1993) */
+        }
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+        for (int t = 0; t < ntf; ++t) acc[t] += loc[t];
+      }
+    }
+  free(J_th);
+  return err;
+}

@@ -226,6 +226,33 @@ int oracle_run_mono(const oracle_model *m, const oracle_mono_opts *o, double *xI
                     uint64_t *counters);
 
 /*
+ * Ray-traced SED of the dust, ray-tracing method 1: what dust_map(lambda,ibin,iaz)
+ * (dust_transfer.f90:1413-1600) adds to Stokes_ray_tracing(lambda,1,1,ibin,iaz,:) with RT_sed_method = 1,
+ * for every observer direction: calc_Jth (dust_ray_tracing.f90:810-905, LTE grains),
+ * init_dust_source_fct1 (:636-716), the 128 x 30 image-plane sampling of dust_map, intensite_pixel_dust
+ * (:1899-2004, one ray per pixel), integ_ray_dust (optical_depth.f90:1327-1421) with dust_source_fct
+ * (dust_ray_tracing.f90:1442-1475, RT1 branch).  The stellar term (compute_stars_map) is not included.
+ */
+typedef struct {
+  int lambda;
+  double wl_um;              /* tab_lambda(lambda) */
+  double E_src;              /* E_stars(lambda) + E_disk(lambda) */
+  double n_sent_photons;     /* sum(n_phot_envoyes(lambda,:)) */
+  double distance;           /* pc */
+  double ang_disque;         /* degrees, after init_mcfost.f90:1781 */
+  int l_sym_ima;
+  double tau_dark_zone_obs;  /* parameters.f90:25 */
+  double Rmin, Rmax;         /* grid.f90:234-235 */
+  const float *tab_RT_az;    /* [RT_n_az] degrees */
+  int n_threads;
+} oracle_rt_opts;
+
+/* xI_scatt: reference layout, FP64 (oracle_run_mono's output); Tdust [n_cells];
+ * out[(ibin-1 + RT_n_incl*(iaz-1)) * N_type_flux + type-1] */
+int oracle_dust_map_sed(const oracle_model *m, const oracle_rt_opts *o, const double *xI_scatt,
+                        const float *Tdust, double *out);
+
+/*
  * define_dark_zone (optical_depth.f90:1425-1651) for a 2D cylindrical grid: cells from which a
  * ray of optical depth tau_max does not leave the grid in any of 11 directions, plus the cells
  * below them.  r_lim[0..n_rad], r_grid / z_grid [n_cells] are cylindrical_grid's arrays.  A host

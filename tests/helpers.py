@@ -42,6 +42,7 @@ def sed_model(cfg, n_thermal=100000, voronoi_sites=0, seed=3):
     orc = Oracle(m, n_thermal)
     T = orc.temp_finale(orc.run_thermal(n_thermal, seed=3, n_threads=1)["E_abs"])  # 1 thread: reproducible
     M.repartition_energie(m, T)
+    m.extra["Tdust"] = T
     return m
 
 

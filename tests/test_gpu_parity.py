@@ -602,6 +602,62 @@ def test_sed_mode_voronoi():
     _mono_parity(sed_model(M.small(lsepar_pola=False), voronoi_sites=1500, n_thermal=50000), 9, 10, 4)
 
 
+# ---------------------------------------------------------------------------
+# RT1 ray-traced dust SED (mc_raytrace.hip.h)
+# ---------------------------------------------------------------------------
+def _dust_map_parity(cfg, lam, n2, seed, ang=0.0, sym=True, tau_obs=100.0):
+    from helpers import sed_model
+    m = sed_model(cfg, n_thermal=50000)
+    e, o = _engine(m, 1e5), _oracle(m, 1e5)
+    a = e.run_mono(lam, n2, seed=seed, n_chunks=32, fetch_xI=False)
+    if not cfg.l3D:
+        # a ray that crosses a midplane cell from its upper to its lower wall has its midpoint at z = +-rounding
+        # (see helpers.xI_close): make psup irrelevant in that layer, in place in HBM
+        rt = m.rt
+        x = e.device_xI().view(m.n_cells, rt["n_theta_rt"], rt["n_az_rt"], -1)
+        x[:cfg.n_rad] = x[:cfg.n_rad].mean(dim=1, keepdim=True)
+    ns, Ed = a["n_sent"][lam - 1], m.extra["E_disk"][lam - 1]
+    got, ms = e.dust_map_sed(lam, m.extra["Tdust"], ns, Ed, ang_disque=ang, l_sym_ima=sym, tau_dark_zone_obs=tau_obs)
+    ref = o.dust_map_sed(lam, e.fetch_xI(), m.extra["Tdust"], ns, Ed, ang_disque=ang, l_sym_ima=sym,
+                         tau_dark_zone_obs=tau_obs, n_threads=8)
+    e.close()
+    assert (ref[:, 0] > 0).all() and ms > 0
+    # same rays through the same cells; exp() and the summation order differ
+    assert np.allclose(got, ref, rtol=1e-9, atol=1e-13 * np.abs(ref).max()), np.abs(got / ref - 1).max()
+    return got, ref
+
+
+def test_rt1_dust_map_parity_2d():
+    """mcgpu_rt1_dust_map on the xI_scatt the SED Monte Carlo left in HBM vs the oracle's dust_map restatement
+    on the same (fetched) xI_scatt: scattered starlight, mixed and thermal wavelengths."""
+    cfg = M.small(RT_n_incl=3)
+    for lam in (3, 9, 14):
+        got, ref = _dust_map_parity(cfg, lam, 50, 20 + lam)
+        assert np.allclose(got[:, 0], got[:, 5] + got[:, 6] + got[:, 7], rtol=1e-9, atol=0)
+
+
+def test_rt1_dust_map_variants():
+    _dust_map_parity(M.small(lsepar_pola=False), 5, 30, 3)                                      # N_type_flux = 5
+    _dust_map_parity(M.small(lsepar_pola=False, lsepar_contrib=False), 5, 30, 4)                # N_type_flux = 1
+    _dust_map_parity(M.small(n_rad=10, nz=5, n_az=6, l3D=True), 5, 30, 5)                       # 3D
+    _dust_map_parity(M.small(RT_n_incl=2, RT_n_az=3, RT_az_max=90.0, RT_imin=20.0, RT_imax=70.0), 12, 30, 6,
+                     ang=17.0, sym=False)                                                       # rotated, full plane
+    _dust_map_parity(M.small(), 12, 30, 7, tau_obs=0.5)                                         # early cut-off
+
+
+def test_rt1_dust_map_abi_errors(sed_small):
+    from mcfost_amd.engine import McgpuError
+    e = _engine(sed_small, 1e5)
+    with pytest.raises(McgpuError):   # no xI_scatt yet
+        e.dust_map_sed(3, sed_small.extra["Tdust"], 100.0, 0.0)
+    e.run_mono(3, 5, seed=1, n_chunks=8, fetch_xI=False)
+    with pytest.raises(McgpuError):
+        e.dust_map_sed(3, sed_small.extra["Tdust"], 0.0, 0.0)        # n_sent_photons must be positive
+    with pytest.raises(McgpuError):
+        e.dust_map_sed(0, sed_small.extra["Tdust"], 100.0, 0.0)      # lambda out of range
+    e.close()
+
+
 def test_ism_emission_on_the_gpu(small_model):
     """emit_packet's third branch (emit_packet_ISM, stars.f90:728-785) through mcgpu_set_ism: thermal step on
     2D / 3D / Voronoi grids and the SED step; a draw beyond frac_E_disk without the sphere is an error."""

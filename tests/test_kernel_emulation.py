@@ -26,11 +26,12 @@ DEV2 = os.path.join(os.path.dirname(HERE), "mcfost_amd", "csrc", "mc_rounds.hip.
 DEV3 = os.path.join(os.path.dirname(HERE), "mcfost_amd", "csrc", "mc_voronoi.hip.h")
 DEV4 = os.path.join(os.path.dirname(HERE), "mcfost_amd", "csrc", "mc_mono.hip.h")
 DEV5 = os.path.join(os.path.dirname(HERE), "mcfost_amd", "csrc", "mc_roles.hip.h")
+DEV6 = os.path.join(os.path.dirname(HERE), "mcfost_amd", "csrc", "mc_raytrace.hip.h")
 
 
 @pytest.fixture(scope="module")
 def emu():
-    if (not os.path.exists(LIB)) or os.path.getmtime(LIB) < max(os.path.getmtime(SRC), os.path.getmtime(DEV), os.path.getmtime(DEV2), os.path.getmtime(DEV3), os.path.getmtime(DEV4), os.path.getmtime(DEV5)):
+    if (not os.path.exists(LIB)) or os.path.getmtime(LIB) < max(os.path.getmtime(SRC), os.path.getmtime(DEV), os.path.getmtime(DEV2), os.path.getmtime(DEV3), os.path.getmtime(DEV4), os.path.getmtime(DEV5), os.path.getmtime(DEV6)):
         fma = ["-mfma"] if "fma" in open("/proc/cpuinfo").read() else []
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=fast"] + fma +
                               ["-o", LIB, SRC])
@@ -286,3 +287,38 @@ def test_emulated_role_schedule(emu, small_model):
         finally:
             os.environ.pop("MCGPU_EMU_ROLES", None)
             os.environ.pop("MCGPU_EMU_LDS", None)
+
+
+def emu_dust_map(emu, orc, lam, xI, Tdust, n_sent, E_disk, ang_disque=0.0, l_sym_ima=True, tau_obs=100.0):
+    from oracle.binding import _RtOpts
+    m = orc.model
+    az = np.ascontiguousarray(m.rt["tab_RT_az"], np.float32)
+    o = _RtOpts(int(lam), float(m.lam[lam - 1]), float(m.E_stars[lam - 1] + E_disk), float(n_sent),
+                float(m.cfg.distance), float(ang_disque), int(l_sym_ima), float(tau_obs), float(m.cfg.rin),
+                float(m.cfg.rout), _p(az, C.c_float), 1)
+    out = np.zeros((m.rt["RT_n_incl"] * m.rt["RT_n_az"], m.rt["N_type_flux"]))
+    x = np.ascontiguousarray(xI, np.float64)
+    T = np.ascontiguousarray(Tdust, np.float32)
+    rc = emu.emu_rt1_dust_map(C.byref(orc.cm), C.byref(o), _p(x, C.c_double), _p(T, C.c_float), _p(out, C.c_double))
+    assert rc == 0, rc
+    return out
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(l3D=True, n_az=4), dict(lsepar_pola=False, lsepar_contrib=False),
+                                dict(RT_n_az=2, RT_az_max=90.0)])
+def test_emulated_rt1_dust_map(emu, kw):
+    """mc_raytrace.hip.h against the oracle's dust_map restatement on the same xI_scatt and Tdust: the same
+    rays through the same cells, so the fluxes agree to summation order."""
+    cfg = M.small(**{**dict(n_rad=10, nz=6, RT_n_incl=2), **kw})
+    m = sed_model(cfg, n_thermal=20000)
+    orc = Oracle(m, 1e5)
+    for lam, ang, sym in ((3, 0.0, True), (m.n_lambda - 6, 17.0, False)):  # 17 deg: no ray on a sub-bin edge
+        b = orc.run_mono(lam, 40, seed=5, n_chunks=4, rt1=True, n_threads=1)
+        xI = b["xI_scatt"].copy()
+        if not cfg.l3D:  # a ray through a midplane cell has its midpoint at z = +-rounding (see helpers.xI_close):
+            xI[:cfg.n_rad] = xI[:cfg.n_rad].mean(axis=3, keepdims=True)  # make psup irrelevant there
+        args = (lam, xI, m.extra["Tdust"], b["n_sent"][lam - 1], m.extra["E_disk"][lam - 1])
+        ref = orc.dust_map_sed(*args, ang_disque=ang, l_sym_ima=sym)
+        got = emu_dust_map(emu, orc, *args, ang_disque=ang, l_sym_ima=sym)
+        assert np.abs(ref[:, 0]).max() > 0
+        assert np.allclose(got, ref, rtol=1e-10, atol=1e-14 * np.abs(ref).max())

@@ -310,3 +310,55 @@ def test_define_dark_zone_restatement():
             assert max(taus) > 1500.0
         else:
             assert min(taus) < 1500.0
+
+
+# ---- RT1 ray-traced dust SED (oracle_dust_map_sed) -----------------------------------------------
+def _thin_rt_model(**kw):
+    from helpers import sed_model
+    cfg = M.small(**{**dict(n_rad=12, nz=8, dust_mass=1e-12, RT_n_incl=3, rout=100.0), **kw})
+    return cfg, sed_model(cfg, n_thermal=20000)
+
+
+def test_dust_map_optically_thin_thermal_flux_is_the_volume_integral():
+    """Without scattered light (xI = 0) and tau << 1 every ray integrates sum(l * J_th), so the flux of any
+    observer is sum(J_th * V) / d^2 up to the image-plane quadrature (128 log radii x 30 azimuths)."""
+    cfg, m = _thin_rt_model()
+    orc = Oracle(m, 1e5)
+    T = np.full(m.n_cells, 80.0, np.float32)
+    lam = m.n_lambda - 8
+    wl = m.lam[lam - 1] * 1e-6
+    hp, c, kb = 6.626070040e-34, 299792458.0, 1.38064852e-23
+    J = 2 * hp * c * c / (wl ** 5 * (np.exp(hp * c / (kb * 80.0 * wl)) - 1.0)) * wl * m.kappa_abs_LTE[lam - 1] * m.kappa_factor
+    d_au = cfg.distance * 648000.0 / math.pi
+    vol = np.asarray(m.grid["volume"])  # (a 2D cell's volume counts both sides of the midplane)
+    expect = (J * vol).sum() / d_au ** 2
+    out = orc.dust_map_sed(lam, np.zeros(orc.xI_shape()), T, 1000.0, 0.0)
+    nS = 4
+    assert out.shape == (3, 8)
+    # pole-on, the sharp outer edge falls inside one 8 % radial step of the sampling: 5 % there, 0.5 % inclined
+    assert np.allclose(out[:, 0], expect, rtol=0.06, atol=0) and np.allclose(out[1:, 0], expect, rtol=0.01, atol=0), (out[:, 0], expect)
+    assert np.array_equal(out[:, 0], out[:, nS + 2])          # all of it is thermal emission
+    assert not out[:, 1:nS + 1].any() and not out[:, nS + 1].any() and not out[:, nS + 3].any()
+    # the half-plane sampling with doubled pixels sees the same axisymmetric disk
+    full = orc.dust_map_sed(lam, np.zeros(orc.xI_shape()), T, 1000.0, 0.0, l_sym_ima=False)
+    assert np.allclose(full, out, rtol=2e-3, atol=0)
+
+
+def test_dust_map_is_linear_in_xI_and_separates_contributions():
+    cfg, m = _thin_rt_model(dust_mass=1e-6)
+    orc = Oracle(m, 1e5)
+    lam = 6
+    b = orc.run_mono(lam, 200, seed=2, n_chunks=4, rt1=True, n_threads=1)
+    T, Ed, ns = m.extra["Tdust"], m.extra["E_disk"][lam - 1], b["n_sent"][lam - 1]
+    th = orc.dust_map_sed(lam, np.zeros_like(b["xI_scatt"]), T, ns, Ed)
+    one = orc.dust_map_sed(lam, b["xI_scatt"], T, ns, Ed)
+    two = orc.dust_map_sed(lam, 2 * b["xI_scatt"], T, ns, Ed)
+    assert np.allclose(two - th, 2 * (one - th), rtol=1e-9, atol=1e-12 * np.abs(one).max())
+    assert np.allclose(orc.dust_map_sed(lam, b["xI_scatt"], T, 2 * ns, Ed) - th, 0.5 * (one - th), rtol=1e-9,
+                       atol=1e-12 * np.abs(one).max())
+    # I = star-origin scattered + thermal + disk-origin scattered (no direct starlight in dust_map)
+    assert np.allclose(one[:, 0], one[:, 5] + one[:, 6] + one[:, 7], rtol=1e-9, atol=0)
+    assert (one[:, 5] > 0).all() and not one[:, 4].any()
+    # a ray never looks behind tau_dark_zone_obs: a tiny cut-off removes everything but the skin
+    cut = orc.dust_map_sed(lam, b["xI_scatt"], T, ns, Ed, tau_dark_zone_obs=1e-30)
+    assert (cut[:, 0] < 0.5 * one[:, 0]).all()
