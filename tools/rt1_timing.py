@@ -8,7 +8,8 @@ from mcfost_amd.engine import Engine
 from oracle import Oracle
 
 n_incl = int(sys.argv[1]) if len(sys.argv) > 1 else 10
-cfg = M.ref41(RT_n_incl=n_incl)
+import dataclasses
+cfg = dataclasses.replace(M.ref41(), RT_n_incl=n_incl)
 m = M.build_model(cfg)
 e = Engine(m, 2e6)
 T = e.temp_finale(e.run_thermal(2_000_000, seed=3)["E_abs"])
