@@ -294,6 +294,11 @@ int mcgpu_run_mono(mcgpu_ctx *ctx, const mcgpu_mono_opts *opts,
  * array and/or the FP64 sums the engine accumulates.  Either pointer may be NULL. */
 int mcgpu_fetch_xI(mcgpu_ctx *ctx, float *xI_scatt_f32, double *xI_scatt_f64);
 
+/* Replace the device accumulator by the host's xI_scatt (same layout as mcgpu_fetch_xI's FP64 output):
+ * what a host that reduced xI_scatt itself (the reference's thread sum :152, an MPI reduction) hands
+ * back before mcgpu_rt1_dust_map.  Needs mcgpu_set_rt1. */
+int mcgpu_set_xI(mcgpu_ctx *ctx, const double *xI_scatt_f64);
+
 /* The device-resident FP64 xI_scatt accumulator (engine layout) for an in-place RCCL
  * all-reduce across the ranks of a multi-GPU SED step; fetch afterwards with mcgpu_fetch_xI. */
 int mcgpu_device_xI(mcgpu_ctx *ctx, void **xI_dev, uint64_t *n_doubles);

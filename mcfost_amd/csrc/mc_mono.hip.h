@@ -586,4 +586,16 @@ __global__ void k_xI_fetch(const double* xI, float* out32, double* out64, int n_
   if (out32) out32[i] = (float)v;
 }
 
+// the reference's xI_scatt(phik,psup,type,iRT,icell) -> device layout (mcgpu_set_xI).  One thread per element.
+__global__ void k_xI_put(double* xI, const double* in64, int n_az, int n_theta, int n_type, int nRT, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  size_t r = i;
+  const int phik = (int)(r % n_az); r /= n_az;
+  const int psup = (int)(r % n_theta); r /= n_theta;
+  const int type = (int)(r % n_type); r /= n_type;
+  const int q = (int)(r % nRT); r /= nRT;
+  xI[(((r * n_theta + psup) * n_az + phik) * nRT + q) * XI_LINE + type] = in64[i];
+}
+
 }  // namespace mcgpu

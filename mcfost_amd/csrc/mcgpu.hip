@@ -1120,6 +1120,35 @@ extern "C" int mcgpu_device_xI(mcgpu_ctx* ctx, void** xI_dev, uint64_t* n_double
   return MCGPU_OK;
 }
 
+extern "C" int mcgpu_set_xI(mcgpu_ctx* ctx, const double* xI_scatt) {
+  if (!ctx || !xI_scatt) return fail(ctx, MCGPU_ERR_ARG, "mcgpu_set_xI: null argument");
+  if (!ctx->have_rt1) return fail(ctx, MCGPU_ERR_STATE, "mcgpu_set_xI needs mcgpu_set_rt1");
+  if (ctx->N_type_flux > XI_LINE) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "N_type_flux > 8");
+  HIPCHK(hipSetDevice(ctx->device));
+  const int nRT = ctx->RT_n_incl * ctx->RT_n_az;
+  const size_t n = (size_t)ctx->n_az_rt * ctx->n_theta_rt * ctx->N_type_flux * nRT * (size_t)ctx->M.n_cells;
+  const size_t n_dev = n / ctx->N_type_flux * XI_LINE;
+  if (ctx->n_xI != n) {
+    if (ctx->d_xI) hipFree(ctx->d_xI);
+    ctx->d_xI = nullptr; ctx->n_xI = 0;
+    HIPCHK(hipMalloc((void**)&ctx->d_xI, n_dev * sizeof(double)));
+    ctx->n_xI = n;
+  }
+  HIPCHK(hipMemsetAsync(ctx->d_xI, 0, n_dev * sizeof(double), ctx->stream));
+  double* d_in = nullptr;
+  HIPCHK(hipMalloc((void**)&d_in, n * sizeof(double)));
+  hipError_t e = hipMemcpyAsync(d_in, xI_scatt, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_xI_put, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_xI, d_in,
+                       ctx->n_az_rt, ctx->n_theta_rt, ctx->N_type_flux, nRT, n);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  hipFree(d_in);
+  HIPCHK(e);
+  return MCGPU_OK;
+}
+
 extern "C" int mcgpu_fetch_xI(mcgpu_ctx* ctx, float* xI_scatt_f32, double* xI_scatt_f64) {
   if (!ctx || !ctx->d_xI) return fail(ctx, MCGPU_ERR_STATE, "no xI_scatt accumulated yet");
   HIPCHK(hipSetDevice(ctx->device));

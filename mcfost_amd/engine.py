@@ -33,7 +33,7 @@ ABI_SYMBOLS = (
     "mcgpu_probe_cross_cell", "mcgpu_probe_index_cell", "mcgpu_probe_philox",
     "mcgpu_probe_packet_rand", "mcgpu_set_midplane_snap", "mcgpu_set_grid_voronoi",
     "mcgpu_probe_cross_voronoi", "mcgpu_set_rt1", "mcgpu_run_mono", "mcgpu_fetch_xI",
-    "mcgpu_device_xI", "mcgpu_set_ism", "mcgpu_rt1_dust_map",
+    "mcgpu_device_xI", "mcgpu_set_ism", "mcgpu_rt1_dust_map", "mcgpu_set_xI",
 )
 
 
@@ -309,6 +309,15 @@ class Engine:
         x64 = np.zeros(self.xI_shape(), np.float64)
         self._chk(self.lib.mcgpu_fetch_xI(self.ctx, None, _p(x64, C.c_double)), "mcgpu_fetch_xI")
         return x64
+
+    def set_xI(self, xI_scatt):
+        """Replace the device xI_scatt by a host array of ``xI_shape()`` (``mcgpu_set_xI``)."""
+        if not getattr(self, "_rt1", False):
+            self.set_rt1()
+        x = _a(xI_scatt, np.float64)
+        if x.shape != self.xI_shape():
+            raise McgpuError(f"xI_scatt has shape {x.shape}, expected {self.xI_shape()}")
+        self._chk(self.lib.mcgpu_set_xI(self.ctx, _p(x, C.c_double)), "mcgpu_set_xI")
 
     def run_mono(self, lam, n_photons2, n_phot_lim=None, p_lambda=None, seed=1, n_chunks=None, rt1=True,
                  accumulate=False, grid_blocks=0, block_threads=0, fetch_xI=True, first_chunk=0):

@@ -66,7 +66,7 @@ module mcgpu_f
   public :: mcgpu_create, mcgpu_destroy, mcgpu_set_grid_cyl, mcgpu_set_grid_voronoi, mcgpu_set_midplane_snap, &
        mcgpu_set_stars, mcgpu_set_opacity, mcgpu_set_scattering, mcgpu_set_thermal, mcgpu_set_sed_bins, &
        mcgpu_run_thermal, mcgpu_temp_finale, mcgpu_thermal_loop, mcgpu_error_message, mcgpu_set_rt1, &
-       mcgpu_run_mono, mcgpu_fetch, mcgpu_fetch_xI, mcgpu_rt1_dust_map
+       mcgpu_run_mono, mcgpu_fetch, mcgpu_fetch_xI, mcgpu_rt1_dust_map, mcgpu_set_xI
 
   interface
      integer(c_int) function mcgpu_create(device, ctx) bind(C, name="mcgpu_create")
@@ -207,6 +207,12 @@ module mcgpu_f
        import :: c_int, c_ptr
        type(c_ptr), value :: ctx, xI_scatt_f32, xI_scatt_f64       ! c_loc(xI_scatt(1,1,1,1,1,1)) or c_null_ptr
      end function mcgpu_fetch_xI
+
+     integer(c_int) function mcgpu_set_xI(ctx, xI_scatt_f64) bind(C, name="mcgpu_set_xI")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(in) :: xI_scatt_f64(*)                  ! sum(xI_scatt, dim=6)
+     end function mcgpu_set_xI
 
      ! replaces the `call dust_map(lambda,ibin,iaz)` loop of the SED branch (dust_transfer.f90:990-1005) minus
      ! compute_stars_map: stokes(N_type_flux, RT_n_incl, RT_n_az) is added to Stokes_ray_tracing(lambda,1,1,:,:,:,1)

@@ -609,13 +609,14 @@ def _dust_map_parity(cfg, lam, n2, seed, ang=0.0, sym=True, tau_obs=100.0):
     from helpers import sed_model
     m = sed_model(cfg, n_thermal=50000)
     e, o = _engine(m, 1e5), _oracle(m, 1e5)
-    a = e.run_mono(lam, n2, seed=seed, n_chunks=32, fetch_xI=False)
+    a = e.run_mono(lam, n2, seed=seed, n_chunks=32)
     if not cfg.l3D:
         # a ray that crosses a midplane cell from its upper to its lower wall has its midpoint at z = +-rounding
-        # (see helpers.xI_close): make psup irrelevant in that layer, in place in HBM
-        rt = m.rt
-        x = e.device_xI().view(m.n_cells, rt["n_theta_rt"], rt["n_az_rt"], -1)
-        x[:cfg.n_rad] = x[:cfg.n_rad].mean(dim=1, keepdim=True)
+        # (see helpers.xI_close): make psup irrelevant in that layer and hand the array back (mcgpu_set_xI)
+        x = a["xI_scatt"].copy()
+        x[:cfg.n_rad] = x[:cfg.n_rad].mean(axis=3, keepdims=True)
+        e.set_xI(x)
+        assert np.array_equal(e.fetch_xI(), x)
     ns, Ed = a["n_sent"][lam - 1], m.extra["E_disk"][lam - 1]
     got, ms = e.dust_map_sed(lam, m.extra["Tdust"], ns, Ed, ang_disque=ang, l_sym_ima=sym, tau_dark_zone_obs=tau_obs)
     ref = o.dust_map_sed(lam, e.fetch_xI(), m.extra["Tdust"], ns, Ed, ang_disque=ang, l_sym_ima=sym,
