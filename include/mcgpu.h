@@ -337,6 +337,20 @@ int mcgpu_rt1_dust_map(mcgpu_ctx *ctx, const mcgpu_rt_opts *opts,
                        const float *tab_RT_az, const float *Tdust,
                        double *stokes, double *kernel_ms);
 
+/* The same for images: dust_map method 2 (dust_transfer.f90:1537-1577) -- npix_x x npix_y square pixels of
+ * (map_size/zoom)/max(npix_x,npix_y) AU, each refined by intensite_pixel_dust (:1899-2004): 1, 2x2, ... 32x32
+ * sub-pixel rays, at least 2 and at most 6 iterations, until Stokes I changes by less than 1 %.
+ * image(npix_x, npix_y, RT_n_incl, RT_n_az, N_type_flux) column-major = Stokes_ray_tracing(lambda,:,:,:,:,:) of the
+ * dust; with l_sym_ima only the columns i <= npix_x/2 + mod(npix_x,2) are computed (the rest stays 0: the
+ * reference mirrors them when it writes the image, output.f90:1007-1025).  n_rays (may be NULL) returns the
+ * number of rays traced.  The xI_scatt comes from an image-mode Monte Carlo: mcgpu_run_mono with
+ * n_photons2 = huge and n_phot_lim = n_photons_image (run_image_mc, dust_transfer.f90:711-713: every stream
+ * sends exactly n_photons_image packets). */
+int mcgpu_rt1_image(mcgpu_ctx *ctx, const mcgpu_rt_opts *opts,
+                    const float *tab_RT_az, const float *Tdust, int npix_x,
+                    int npix_y, double map_size, double zoom, double *image,
+                    uint64_t *n_rays, double *kernel_ms);
+
 /* Temp_finale (thermal_emission.f90:870-906): Tdust(icell) from the summed
  * absorbed-energy grid.  E_abs == NULL uses the device accumulator. */
 int mcgpu_temp_finale(mcgpu_ctx *ctx, const double *E_abs, float *Tdust);

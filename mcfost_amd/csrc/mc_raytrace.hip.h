@@ -7,7 +7,10 @@
 //                   solution sum exp(-tau) (1 - exp(-dtau)) S with the RT1 source function
 //                   eps_dust1(k,psup,:,icell) (dust_ray_tracing.f90:1455-1475), built on the fly from the
 //                   xI_scatt records the SED Monte Carlo left in HBM and J_th (init_dust_source_fct1 :636-716).
-// The stellar term (compute_stars_map: 1024 random rays per star on the host) is not part of this kernel.
+//   k_rt1_image     dust_map method 2 (:1537-1577): square pixels, one WAVEFRONT per pixel; intensite_pixel_dust's
+//                   refinement 1, 2x2, 4x4 ... 32x32 sub-pixels (at least 2 iterations, at most 6, until Stokes I
+//                   changes by < 1 %) with the sub-pixels of an iteration spread over the 64 lanes.
+// The stellar term (compute_stars_map: 1024 random rays per star on the host) is not part of these kernels.
 #pragma once
 #include "mc_mono.hip.h"
 
@@ -22,6 +25,11 @@ struct RtArgs {
   const double* xI;                                             // device layout [cell][psup][phik][iRT][XI_LINE]
   const double* J_th;                                           // [n_cells]
   double* out;                                                  // [nRT * N_type_flux]
+  // images (k_rt1_image)
+  int npix_x, npix_y, npix_x_max;
+  double taille_pix;                                            // AU
+  double* image;                                                // [N_type_flux][RT_n_az][RT_n_incl][npix_y][npix_x]
+  unsigned long long* n_rays;
 };
 
 constexpr int RT_N_RAD = 128, RT_N_PHI = 30;  // dust_map (:1434)
@@ -56,33 +64,92 @@ __device__ inline void rotation_3d(const double axis[3], double angle_deg, const
   for (int q = 0; q < 3; ++q) out[q] = vp[q] + norm * (ca * vn[q] + sa * vn2[q]);
 }
 
+// image-plane basis of an observer direction (dust_transfer.f90:1440-1455)
+__device__ inline void rt_image_plane(const RtArgs& A, int q, double uvw[3], double xpi[3], double ypi[3]) {
+  uvw[0] = A.rt_u[q]; uvw[1] = A.rt_v[q]; uvw[2] = A.rt_w[q % A.RT_n_incl];
+  double sa, ca;
+  sincos((double)A.rt_az[q / A.RT_n_incl] * (PI / 180.0), &sa, &ca);
+  const double xv[3] = {ca, sa, 0.0};
+  if (fabs(A.ang_disque) > TINY_REAL) rotation_3d(uvw, A.ang_disque, xv, xpi);
+  else { xpi[0] = xv[0]; xpi[1] = xv[1]; xpi[2] = xv[2]; }
+  ypi[0] = -(xpi[1] * uvw[2] - xpi[2] * uvw[1]);
+  ypi[1] = -(xpi[2] * uvw[0] - xpi[0] * uvw[2]);
+  ypi[2] = -(xpi[0] * uvw[1] - xpi[1] * uvw[0]);
+}
+
+// move_to_grid + integ_ray_dust (optical_depth.f90:1327-1421) for observer q from the point (x,y,z) of the image
+// plane, propagating along (u0,v0,w0) = -(direction to the observer).  S[0..N_type_flux) is overwritten.
+template <bool L3D, bool POLA>
+__device__ inline void rt1_integ_ray(const Lds& T, const DevModel& M, const RtArgs& A, int q, double x, double y,
+                                     double z, double u0, double v0, double w0, double S[8]) {
+  const int n_rad = M.n_rad, nz = M.nz;
+  const int n_Stokes = POLA ? 4 : 1;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) S[t] = 0.0;
+  int ri, zj, k;
+  if (!move_to_grid<L3D>(T, M, x, y, z, u0, v0, w0, ri, zj, k)) return;
+  const double a = u0 * u0 + v0 * v0;
+  const double inv_a = (a > TINY_REAL) ? 1.0 / a : HUGE_REAL;
+  const double inv_w = (fabs(w0) > TINY_REAL) ? 1.0 / w0 : copysign(HUGE_DP, w0);
+  const int i_star = intersect_stars(M, x, y, z, u0, v0, w0);
+  int star_key = -1;
+  if (i_star > 0) {
+    const int* sc = &M.star_cell[4 * (i_star - 1)];
+    star_key = sc[0] + (n_rad + 2) * ((sc[1] + nz + 1) + (2 * nz + 3) * (sc[2] - 1));
+  }
+  double tau = 0.0;
+  for (long guard = 0; guard < 100000000L; ++guard) {
+    const int azj = zj < 0 ? -zj : zj;
+    if ((ri == n_rad + 1) || ((azj == nz + 1) && (fabs(z) > M.zmaxmax))) break;  // test_exit_grid
+    if (star_key >= 0 && (ri + (n_rad + 2) * ((zj + nz + 1) + (2 * nz + 3) * (k - 1))) == star_key) break;
+    double x1, y1, z1, l;
+    int ri1, zj1, k1;
+    MCGPU_CROSS<L3D>(T, M, x, y, z, u0, v0, w0, inv_a, inv_w, ri, zj, k, x1, y1, z1, ri1, zj1, k1, l);
+    if (is_real_cell<L3D>(n_rad, nz, ri, zj)) {
+      const int ic = cell_index<L3D>(n_rad, nz, ri, zj, k);
+      const double kappa_ext = T.kappa[A.lambda - 1] * M.kappa_factor[ic];
+      const double dtau = l * kappa_ext;
+      int phik = 1, psup = 1;
+      rt1_subbin_of(A.n_az_rt, L3D, x, y, z, x1, y1, z1, phik, psup);
+      if (kappa_ext > TINY_DP) {
+        const double factor = A.photon_energy / M.volume[ic] * A.n_az_rt * A.n_theta_rt;
+        const double kappa_sca = kappa_ext * (double)T.albedo[A.lambda - 1];
+        const double* rec = A.xI + ((((size_t)ic * A.n_theta_rt + (psup - 1)) * A.n_az_rt + (phik - 1)) * A.nRT + q) * XI_LINE;
+        const double wgt = exp(-tau) * (1.0 - exp(-dtau));
+        const double jth = A.J_th[ic];
+        const double fs = factor * kappa_sca / kappa_ext;
+        S[0] += wgt * (rec[0] * fs + jth / kappa_ext);
+        if (POLA) { S[1] += wgt * rec[1] * fs; S[2] += wgt * rec[2] * fs; S[3] += wgt * rec[3] * fs; }
+        if (A.contrib) {
+          S[n_Stokes + 1] += wgt * rec[n_Stokes + 1] * fs;
+          S[n_Stokes + 2] += wgt * (jth / kappa_ext);
+          S[n_Stokes + 3] += wgt * rec[n_Stokes + 3] * fs;
+        }
+      }
+      tau += dtau;
+      if (tau > A.tau_dark_zone_obs) break;
+    }
+    x = x1; y = y1; z = z1;
+    ri = ri1; zj = zj1; k = k1;
+  }
+}
+
 template <bool L3D, bool POLA>
 __global__ void __launch_bounds__(256) k_rt1_dust_map(const DevModel M, const RtArgs A) {
   extern __shared__ double lds_raw[];
   const Lds T = lds_carve(lds_raw, M);
   lds_stage(T, M);
   __syncthreads();
-  const int n_rad = M.n_rad, nz = M.nz;
   const int rays_per_dir = RT_N_RAD * RT_N_PHI;  // 3840 = 60 wavefronts: a wavefront never straddles two directions
   const int n_rays = A.nRT * rays_per_dir;
-  const int n_Stokes = POLA ? 4 : 1;
   const int lane = threadIdx.x & 63;
 
   for (int base = (blockIdx.x * blockDim.x + (threadIdx.x & ~63)); base < n_rays; base += gridDim.x * blockDim.x) {
     const int ray = base + lane;  // (n_rays is a multiple of 64)
     const int q = ray / rays_per_dir, rem = ray - q * rays_per_dir;
     const int ri_RT = rem / RT_N_PHI, phi_RT = rem - ri_RT * RT_N_PHI + 1;
-    const double u = A.rt_u[q], v = A.rt_v[q], w = A.rt_w[q % A.RT_n_incl];
-    // image-plane basis (:1440-1455)
-    const double uvw[3] = {u, v, w};
-    double sa, ca;
-    sincos((double)A.rt_az[q / A.RT_n_incl] * (PI / 180.0), &sa, &ca);
-    const double xv[3] = {ca, sa, 0.0};
-    double xpi[3];
-    if (fabs(A.ang_disque) > TINY_REAL) rotation_3d(uvw, A.ang_disque, xv, xpi);
-    else { xpi[0] = xv[0]; xpi[1] = xv[1]; xpi[2] = xv[2]; }
-    const double ypi[3] = {-(xpi[1] * uvw[2] - xpi[2] * uvw[1]), -(xpi[2] * uvw[0] - xpi[0] * uvw[2]),
-                           -(xpi[0] * uvw[1] - xpi[1] * uvw[0])};
+    double uvw[3], xpi[3], ypi[3];
+    rt_image_plane(A, q, uvw, xpi, ypi);
     // tab_r(ri) = rmin_RT * fact_r**(ri-1), built by repeated products like the reference (:1499-1503)
     double r = A.rmin_RT;
     for (int i = 0; i < ri_RT; ++i) r = r * A.fact_r;
@@ -90,65 +157,89 @@ __global__ void __launch_bounds__(256) k_rt1_dust_map(const DevModel M, const Rt
     const double phi = A.cst_phi * ((double)phi_RT - 0.5);
     double sp, cp;
     sincos(phi, &sp, &cp);
-    double x = u * A.l_far + r * sp * xpi[0] + r * cp * ypi[0];
-    double y = v * A.l_far + r * sp * xpi[1] + r * cp * ypi[1];
-    double z = w * A.l_far + r * sp * xpi[2] + r * cp * ypi[2];
-    const double u0 = -u, v0 = -v, w0 = -w;  // reverse propagation
-    int ri, zj, k;
-    double S[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (move_to_grid<L3D>(T, M, x, y, z, u0, v0, w0, ri, zj, k)) {
-      // integ_ray_dust (optical_depth.f90:1327-1421)
-      const double a = u0 * u0 + v0 * v0;
-      const double inv_a = (a > TINY_REAL) ? 1.0 / a : HUGE_REAL;
-      const double inv_w = (fabs(w0) > TINY_REAL) ? 1.0 / w0 : copysign(HUGE_DP, w0);
-      const int i_star = intersect_stars(M, x, y, z, u0, v0, w0);
-      int star_key = -1;
-      if (i_star > 0) {
-        const int* sc = &M.star_cell[4 * (i_star - 1)];
-        star_key = sc[0] + (n_rad + 2) * ((sc[1] + nz + 1) + (2 * nz + 3) * (sc[2] - 1));
-      }
-      double tau = 0.0;
-      for (long guard = 0; guard < 100000000L; ++guard) {
-        const int azj = zj < 0 ? -zj : zj;
-        if ((ri == n_rad + 1) || ((azj == nz + 1) && (fabs(z) > M.zmaxmax))) break;  // test_exit_grid
-        if (star_key >= 0 && (ri + (n_rad + 2) * ((zj + nz + 1) + (2 * nz + 3) * (k - 1))) == star_key) break;
-        double x1, y1, z1, l;
-        int ri1, zj1, k1;
-        MCGPU_CROSS<L3D>(T, M, x, y, z, u0, v0, w0, inv_a, inv_w, ri, zj, k, x1, y1, z1, ri1, zj1, k1, l);
-        if (is_real_cell<L3D>(n_rad, nz, ri, zj)) {
-          const int ic = cell_index<L3D>(n_rad, nz, ri, zj, k);
-          const double kappa_ext = T.kappa[A.lambda - 1] * M.kappa_factor[ic];
-          const double dtau = l * kappa_ext;
-          int phik = 1, psup = 1;
-          rt1_subbin_of(A.n_az_rt, L3D, x, y, z, x1, y1, z1, phik, psup);
-          if (kappa_ext > TINY_DP) {
-            const double factor = A.photon_energy / M.volume[ic] * A.n_az_rt * A.n_theta_rt;
-            const double kappa_sca = kappa_ext * (double)T.albedo[A.lambda - 1];
-            const double* rec = A.xI + ((((size_t)ic * A.n_theta_rt + (psup - 1)) * A.n_az_rt + (phik - 1)) * A.nRT + q) * XI_LINE;
-            const double wgt = exp(-tau) * (1.0 - exp(-dtau));
-            const double jth = A.J_th[ic];
-            const double fs = factor * kappa_sca / kappa_ext;
-            S[0] += wgt * (rec[0] * fs + jth / kappa_ext);
-            if (POLA) { S[1] += wgt * rec[1] * fs; S[2] += wgt * rec[2] * fs; S[3] += wgt * rec[3] * fs; }
-            if (A.contrib) {
-              S[n_Stokes + 1] += wgt * rec[n_Stokes + 1] * fs;
-              S[n_Stokes + 2] += wgt * (jth / kappa_ext);
-              S[n_Stokes + 3] += wgt * rec[n_Stokes + 3] * fs;
-            }
-          }
-          tau += dtau;
-          if (tau > A.tau_dark_zone_obs) break;
-        }
-        x = x1; y = y1; z = z1;
-        ri = ri1; zj = zj1; k = k1;
-      }
-    }
+    const double x = uvw[0] * A.l_far + r * sp * xpi[0] + r * cp * ypi[0];
+    const double y = uvw[1] * A.l_far + r * sp * xpi[1] + r * cp * ypi[1];
+    const double z = uvw[2] * A.l_far + r * sp * xpi[2] + r * cp * ypi[2];
+    double S[8];
+    rt1_integ_ray<L3D, POLA>(T, M, A, q, x, y, z, -uvw[0], -uvw[1], -uvw[2], S);  // reverse propagation
     const double pix = taille_pix * A.pix_scale;
     for (int t = 0; t < A.N_type_flux; ++t) {
       double vsum = S[t] * pix * pix;
       for (int off = 32; off > 0; off >>= 1) vsum += __shfl_down(vsum, off);
       if (lane == 0 && vsum != 0.0) atomic_add_f64(&A.out[(size_t)q * A.N_type_flux + t], vsum);
     }
+  }
+}
+
+template <bool L3D, bool POLA>
+__global__ void __launch_bounds__(256) k_rt1_image(const DevModel M, const RtArgs A) {
+  extern __shared__ double lds_raw[];
+  const Lds T = lds_carve(lds_raw, M);
+  lds_stage(T, M);
+  __syncthreads();
+  const int lanes = blockDim.x < 64 ? (int)blockDim.x : 64;  // (the CPU emulation of the tests runs one lane)
+  const int lane = threadIdx.x % lanes;
+  const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) / lanes;
+  const long n_waves = (long)gridDim.x * blockDim.x / lanes;
+  const long pix_per_dir = (long)A.npix_x_max * A.npix_y, n_pix = pix_per_dir * A.nRT;
+  const int n_iter_min = 2, n_iter_max = 6;  // dust_map (:1566-1567)
+  const double precision = 1.e-2;            // intensite_pixel_dust (:1921)
+  unsigned long long rays = 0;
+
+  for (long pix = wave; pix < n_pix; pix += n_waves) {
+    const int q = (int)(pix / pix_per_dir);
+    const long rem = pix - (long)q * pix_per_dir;
+    const int i = (int)(rem / A.npix_y) + 1, j = (int)(rem - (long)(i - 1) * A.npix_y) + 1;
+    double uvw[3], xpi[3], ypi[3], corner[3], dx[3], dy[3];
+    rt_image_plane(A, q, uvw, xpi, ypi);
+    for (int c = 0; c < 3; ++c) {
+      dx[c] = xpi[c] * A.taille_pix;
+      dy[c] = ypi[c] * A.taille_pix;
+      const double Icorner = uvw[c] * A.l_far - (0.5 * A.npix_x * dx[c] + 0.5 * A.npix_y * dy[c]);
+      corner[c] = Icorner + (i - 1) * dx[c] + (j - 1) * dy[c];
+    }
+    double S[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int subpixels = 1;
+    for (int iter = 1;; ++iter) {
+      const double S_old = S[0];
+      double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      double sdx[3], sdy[3];
+      for (int c = 0; c < 3; ++c) { sdx[c] = dx[c] / (double)subpixels; sdy[c] = dy[c] / (double)subpixels; }
+      const int n_sub = subpixels * subpixels;
+      for (int s = lane; s < n_sub; s += lanes) {
+        const int si = s / subpixels + 1, sj = s - (si - 1) * subpixels + 1;
+        const double x = corner[0] + (si - 0.5) * sdx[0] + (sj - 0.5) * sdy[0];
+        const double y = corner[1] + (si - 0.5) * sdx[1] + (sj - 0.5) * sdy[1];
+        const double z = corner[2] + (si - 0.5) * sdx[2] + (sj - 0.5) * sdy[2];
+        double R[8];
+        rt1_integ_ray<L3D, POLA>(T, M, A, q, x, y, z, -uvw[0], -uvw[1], -uvw[2], R);
+        rays++;
+        for (int t = 0; t < 8; ++t) acc[t] += R[t];
+      }
+      // all-reduce over the wavefront (xor butterfly: every lane ends with the same bits, so the refinement
+      // decision below is wave-uniform)
+      const double npix2 = (double)n_sub;
+      for (int t = 0; t < A.N_type_flux; ++t) {
+        double vsum = acc[t];
+        for (int off = 32; off > 0; off >>= 1) vsum += __shfl_xor(vsum, off);
+        S[t] = vsum / npix2;
+      }
+      if (iter < n_iter_min) subpixels *= 2;
+      else if (iter >= n_iter_max) break;
+      else if (fabs(S[0] - S_old) > precision * S_old) subpixels *= 2;
+      else break;
+    }
+    if (lane == 0) {
+      const double pixs = A.taille_pix * A.pix_scale;
+      const int iaz = q / A.RT_n_incl, ibin = q - iaz * A.RT_n_incl, n_az = A.nRT / A.RT_n_incl;
+      for (int t = 0; t < A.N_type_flux; ++t)
+        A.image[((((size_t)t * n_az + iaz) * A.RT_n_incl + ibin) * A.npix_y + (j - 1)) * A.npix_x + (i - 1)] =
+            S[t] * (pixs * pixs);
+    }
+  }
+  if (A.n_rays) {
+    for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off);
+    if (lane == 0) atomicAdd(A.n_rays, rays);
   }
 }
 

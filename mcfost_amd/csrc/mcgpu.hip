@@ -1213,38 +1213,31 @@ struct DevBuf {
 // ---------------------------------------------------------------------------------------------
 // RT1 ray-traced dust SED (mc_raytrace.hip.h)
 // ---------------------------------------------------------------------------------------------
-template <bool L3D, bool POLA>
-static int launch_rt1(mcgpu_ctx* ctx, const RtArgs& A, int blocks) {
-  const size_t lds = lds_bytes(ctx->M);
-  const void* fn = (const void*)k_rt1_dust_map<L3D, POLA>;
-  HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL((k_rt1_dust_map<L3D, POLA>), dim3(blocks), dim3(256), lds, ctx->stream, ctx->M, A);
-  HIPCHK(hipGetLastError());
-  return MCGPU_OK;
-}
+// common part of the two entry points: checks, J_th, the RtArgs both kernels share
+struct Rt1Job {
+  DevBuf<float> d_T, d_az;
+  DevBuf<double> d_J;
+  RtArgs A;
+};
 
-extern "C" int mcgpu_rt1_dust_map(mcgpu_ctx* ctx, const mcgpu_rt_opts* o, const float* tab_RT_az, const float* Tdust,
-                                  double* stokes, double* kernel_ms) {
+static int rt1_prepare(mcgpu_ctx* ctx, const mcgpu_rt_opts* o, const float* tab_RT_az, const float* Tdust, Rt1Job& J,
+                       const char* who) {
   int rc = ready(ctx);
   if (rc) return rc;
-  if (ctx->voro) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "mcgpu_rt1_dust_map: cylindrical grids only");
-  if (!o || !tab_RT_az || !Tdust || !stokes) return fail(ctx, MCGPU_ERR_ARG, "mcgpu_rt1_dust_map: null argument");
-  if (!ctx->have_rt1 || !ctx->d_xI) return fail(ctx, MCGPU_ERR_STATE, "mcgpu_rt1_dust_map needs the xI_scatt of mcgpu_run_mono(rt1=1)");
+  if (ctx->voro) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "RT1 ray tracing: cylindrical grids only");
+  if (!o || !tab_RT_az || !Tdust) return fail(ctx, MCGPU_ERR_ARG, "RT1 ray tracing: null argument");
+  if (!ctx->have_rt1 || !ctx->d_xI)
+    return fail(ctx, MCGPU_ERR_STATE, "RT1 ray tracing needs the xI_scatt of mcgpu_run_mono(rt1=1) or mcgpu_set_xI");
   const DevModel& M = ctx->M;
   if (o->lambda < 1 || o->lambda > M.n_lambda || !(o->wl_um > 0.0) || !(o->n_sent_photons > 0.0) ||
       !(o->distance > 0.0) || !(o->Rmin > 0.0) || !(o->Rmax > o->Rmin))
-    return fail(ctx, MCGPU_ERR_ARG, "mcgpu_rt1_dust_map: bad option");
+    return fail(ctx, MCGPU_ERR_ARG, who);
   HIPCHK(hipSetDevice(ctx->device));
   const int nRT = ctx->RT_n_incl * ctx->RT_n_az;
-  DevBuf<float> d_T, d_az;
-  DevBuf<double> d_J, d_out;
-  HIPCHK(d_T.alloc(M.n_cells)); HIPCHK(d_T.put(Tdust, M.n_cells));
-  HIPCHK(d_az.alloc(ctx->RT_n_az)); HIPCHK(d_az.put(tab_RT_az, ctx->RT_n_az));
-  HIPCHK(d_J.alloc(M.n_cells));
-  HIPCHK(d_out.alloc((size_t)nRT * ctx->N_type_flux));
-  HIPCHK(hipMemsetAsync(d_out.p, 0, (size_t)nRT * ctx->N_type_flux * sizeof(double), ctx->stream));
-
-  RtArgs A;
+  HIPCHK(J.d_T.alloc(M.n_cells)); HIPCHK(J.d_T.put(Tdust, M.n_cells));
+  HIPCHK(J.d_az.alloc(ctx->RT_n_az)); HIPCHK(J.d_az.put(tab_RT_az, ctx->RT_n_az));
+  HIPCHK(J.d_J.alloc(M.n_cells));
+  RtArgs& A = J.A;
   std::memset(&A, 0, sizeof(A));
   A.lambda = o->lambda; A.RT_n_incl = ctx->RT_n_incl; A.nRT = nRT; A.n_az_rt = ctx->n_az_rt; A.n_theta_rt = ctx->n_theta_rt;
   A.N_type_flux = ctx->N_type_flux; A.contrib = ctx->lsepar_contrib; A.l_sym_ima = o->l_sym_ima ? 1 : 0;
@@ -1259,22 +1252,77 @@ extern "C" int mcgpu_rt1_dust_map(mcgpu_ctx* ctx, const mcgpu_rt_opts* o, const 
   A.fact_A = std::sqrt(M_PI * (A.fact_r - 1.0 / A.fact_r) / RT_N_PHI);
   A.cst_phi = (o->l_sym_ima ? M_PI : 2 * M_PI) / (double)RT_N_PHI;
   A.l_far = 10. * o->Rmax;
-  A.rt_u = ctx->d_rt_u; A.rt_v = ctx->d_rt_v; A.rt_w = ctx->d_rt_w; A.rt_az = d_az.p;
-  A.xI = ctx->d_xI; A.J_th = d_J.p; A.out = d_out.p;
-
+  A.rt_u = ctx->d_rt_u; A.rt_v = ctx->d_rt_v; A.rt_w = ctx->d_rt_w; A.rt_az = J.d_az.p;
+  A.xI = ctx->d_xI; A.J_th = J.d_J.p;
   HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
-  hipLaunchKernelGGL(k_calc_Jth, dim3((M.n_cells + 255) / 256), dim3(256), 0, ctx->stream, M, o->lambda, A.wl, d_T.p, d_J.p);
+  hipLaunchKernelGGL(k_calc_Jth, dim3((M.n_cells + 255) / 256), dim3(256), 0, ctx->stream, M, o->lambda, A.wl, J.d_T.p, J.d_J.p);
   HIPCHK(hipGetLastError());
-  const int n_rays = nRT * RT_N_RAD * RT_N_PHI;
-  const int blocks = (n_rays + 255) / 256;  // one ray per lane
-  const bool pola = ctx->N_type_flux == 4 || ctx->N_type_flux == 8;
-  if (M.l3D) rc = pola ? launch_rt1<true, true>(ctx, A, blocks) : launch_rt1<true, false>(ctx, A, blocks);
-  else rc = pola ? launch_rt1<false, true>(ctx, A, blocks) : launch_rt1<false, false>(ctx, A, blocks);
-  if (rc) return rc;
+  return MCGPU_OK;
+}
+
+template <bool IMAGE>
+static int rt1_launch(mcgpu_ctx* ctx, const RtArgs& A, int blocks) {
+  const size_t lds = lds_bytes(ctx->M);
+  const bool pola = ctx->N_type_flux == 4 || ctx->N_type_flux == 8, l3d = ctx->M.l3D != 0;
+#define RT1_GO(a, b) do {                                                                                          \
+    const void* fn = IMAGE ? (const void*)k_rt1_image<a, b> : (const void*)k_rt1_dust_map<a, b>;                    \
+    HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                           \
+    if (IMAGE) hipLaunchKernelGGL((k_rt1_image<a, b>), dim3(blocks), dim3(256), lds, ctx->stream, ctx->M, A);       \
+    else hipLaunchKernelGGL((k_rt1_dust_map<a, b>), dim3(blocks), dim3(256), lds, ctx->stream, ctx->M, A);          \
+  } while (0)
+  if (l3d) { if (pola) RT1_GO(true, true); else RT1_GO(true, false); }
+  else { if (pola) RT1_GO(false, true); else RT1_GO(false, false); }
+#undef RT1_GO
+  HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  return MCGPU_OK;
+}
+
+extern "C" int mcgpu_rt1_dust_map(mcgpu_ctx* ctx, const mcgpu_rt_opts* o, const float* tab_RT_az, const float* Tdust,
+                                  double* stokes, double* kernel_ms) {
+  if (ctx && !stokes) return fail(ctx, MCGPU_ERR_ARG, "mcgpu_rt1_dust_map: null argument");
+  Rt1Job J;
+  int rc = rt1_prepare(ctx, o, tab_RT_az, Tdust, J, "mcgpu_rt1_dust_map: bad option");
+  if (rc) return rc;
+  const size_t n_out = (size_t)J.A.nRT * ctx->N_type_flux;
+  DevBuf<double> d_out;
+  HIPCHK(d_out.alloc(n_out));
+  HIPCHK(hipMemsetAsync(d_out.p, 0, n_out * sizeof(double), ctx->stream));
+  J.A.out = d_out.p;
+  const int n_rays = J.A.nRT * RT_N_RAD * RT_N_PHI;
+  if ((rc = rt1_launch<false>(ctx, J.A, (n_rays + 255) / 256))) return rc;  // one ray per lane
   if (kernel_ms) { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1)); *kernel_ms = ms; }
-  HIPCHK(d_out.get(stokes, (size_t)nRT * ctx->N_type_flux));
+  HIPCHK(d_out.get(stokes, n_out));
+  return MCGPU_OK;
+}
+
+extern "C" int mcgpu_rt1_image(mcgpu_ctx* ctx, const mcgpu_rt_opts* o, const float* tab_RT_az, const float* Tdust,
+                               int npix_x, int npix_y, double map_size, double zoom, double* image, uint64_t* n_rays,
+                               double* kernel_ms) {
+  if (ctx && (!image || npix_x < 1 || npix_y < 1 || npix_x > 32768 || npix_y > 32768 || !(map_size > 0.0) || !(zoom > 0.0)))
+    return fail(ctx, MCGPU_ERR_ARG, "mcgpu_rt1_image: bad argument");
+  Rt1Job J;
+  int rc = rt1_prepare(ctx, o, tab_RT_az, Tdust, J, "mcgpu_rt1_image: bad option");
+  if (rc) return rc;
+  RtArgs& A = J.A;
+  A.npix_x = npix_x; A.npix_y = npix_y;
+  A.npix_x_max = o->l_sym_ima ? npix_x / 2 + npix_x % 2 : npix_x;               // dust_transfer.f90:1553-1557
+  A.taille_pix = (map_size / zoom) / (double)(npix_x > npix_y ? npix_x : npix_y);  // (:1545)
+  const size_t n_out = (size_t)A.nRT * ctx->N_type_flux * npix_x * npix_y;
+  DevBuf<double> d_img;
+  DevBuf<unsigned long long> d_rays;
+  HIPCHK(d_img.alloc(n_out)); HIPCHK(d_rays.alloc(1));
+  HIPCHK(hipMemsetAsync(d_img.p, 0, n_out * sizeof(double), ctx->stream));
+  HIPCHK(hipMemsetAsync(d_rays.p, 0, sizeof(unsigned long long), ctx->stream));
+  A.image = d_img.p; A.n_rays = d_rays.p;
+  const long n_pix = (long)A.nRT * A.npix_x_max * npix_y;                        // one wavefront per pixel
+  long blocks = (n_pix + 3) / 4;
+  if (blocks > 65536) blocks = 65536;
+  if ((rc = rt1_launch<true>(ctx, A, (int)blocks))) return rc;
+  if (kernel_ms) { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1)); *kernel_ms = ms; }
+  HIPCHK(d_img.get(image, n_out));
+  if (n_rays) { unsigned long long r = 0; HIPCHK(d_rays.get(&r, 1)); *n_rays = r; }
   return MCGPU_OK;
 }
 

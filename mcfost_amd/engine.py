@@ -33,7 +33,7 @@ ABI_SYMBOLS = (
     "mcgpu_probe_cross_cell", "mcgpu_probe_index_cell", "mcgpu_probe_philox",
     "mcgpu_probe_packet_rand", "mcgpu_set_midplane_snap", "mcgpu_set_grid_voronoi",
     "mcgpu_probe_cross_voronoi", "mcgpu_set_rt1", "mcgpu_run_mono", "mcgpu_fetch_xI",
-    "mcgpu_device_xI", "mcgpu_set_ism", "mcgpu_rt1_dust_map", "mcgpu_set_xI",
+    "mcgpu_device_xI", "mcgpu_set_ism", "mcgpu_rt1_dust_map", "mcgpu_set_xI", "mcgpu_rt1_image",
 )
 
 
@@ -367,6 +367,23 @@ class Engine:
             self.ctx, C.byref(o), _p(_a(rt["tab_RT_az"], np.float32), C.c_float), _p(_a(Tdust, np.float32), C.c_float),
             _p(out, C.c_double), C.byref(ms)), "mcgpu_rt1_dust_map")
         return out, ms.value
+
+    def dust_map_image(self, lam, Tdust, n_sent_photons, E_disk, npix_x, npix_y, map_size, zoom=1.0, ang_disque=0.0,
+                       l_sym_ima=False, tau_dark_zone_obs=100.0):
+        """Ray-traced image of the dust at wavelength ``lam`` (``mcgpu_rt1_image``):
+        (N_type_flux, RT_n_az, RT_n_incl, npix_y, npix_x), the number of rays traced and the kernel time."""
+        m = self.model
+        rt = m.rt
+        o = RtOpts(int(lam), float(m.lam[lam - 1]), float(m.E_stars[lam - 1] + E_disk), float(n_sent_photons),
+                   float(m.cfg.distance), float(ang_disque), int(l_sym_ima), float(tau_dark_zone_obs),
+                   float(m.cfg.rin), float(m.cfg.rout))
+        out = np.zeros((rt["N_type_flux"], rt["RT_n_az"], rt["RT_n_incl"], int(npix_y), int(npix_x)), np.float64)
+        ms, nr = C.c_double(), C.c_uint64()
+        self._chk(self.lib.mcgpu_rt1_image(
+            self.ctx, C.byref(o), _p(_a(rt["tab_RT_az"], np.float32), C.c_float), _p(_a(Tdust, np.float32), C.c_float),
+            C.c_int(int(npix_x)), C.c_int(int(npix_y)), C.c_double(float(map_size)), C.c_double(float(zoom)),
+            _p(out, C.c_double), C.byref(nr), C.byref(ms)), "mcgpu_rt1_image")
+        return out, int(nr.value), ms.value
 
     def probe_cross_voronoi(self, x0, y0, z0, u, v, w, cell, previous_cell):
         n = len(cell)

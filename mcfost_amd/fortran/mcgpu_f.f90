@@ -66,7 +66,7 @@ module mcgpu_f
   public :: mcgpu_create, mcgpu_destroy, mcgpu_set_grid_cyl, mcgpu_set_grid_voronoi, mcgpu_set_midplane_snap, &
        mcgpu_set_stars, mcgpu_set_opacity, mcgpu_set_scattering, mcgpu_set_thermal, mcgpu_set_sed_bins, &
        mcgpu_run_thermal, mcgpu_temp_finale, mcgpu_thermal_loop, mcgpu_error_message, mcgpu_set_rt1, &
-       mcgpu_run_mono, mcgpu_fetch, mcgpu_fetch_xI, mcgpu_rt1_dust_map, mcgpu_set_xI
+       mcgpu_run_mono, mcgpu_fetch, mcgpu_fetch_xI, mcgpu_rt1_dust_map, mcgpu_set_xI, mcgpu_rt1_image
 
   interface
      integer(c_int) function mcgpu_create(device, ctx) bind(C, name="mcgpu_create")
@@ -225,6 +225,21 @@ module mcgpu_f
        real(c_double), intent(out) :: stokes(*)
        real(c_double), intent(out) :: kernel_ms
      end function mcgpu_rt1_dust_map
+
+     ! the image branch of dust_map (dust_transfer.f90:1537-1577) for all observers:
+     ! image(npix_x, npix_y, RT_n_incl, RT_n_az, N_type_flux) -> Stokes_ray_tracing(lambda,:,:,:,:,:,1)
+     integer(c_int) function mcgpu_rt1_image(ctx, opts, tab_RT_az, Tdust, npix_x, npix_y, map_size, zoom, image, &
+          n_rays, kernel_ms) bind(C, name="mcgpu_rt1_image")
+       import :: c_int, c_ptr, c_double, c_float, c_int64_t, mcgpu_rt_opts
+       type(c_ptr), value :: ctx
+       type(mcgpu_rt_opts), intent(in) :: opts
+       real(c_float), intent(in) :: tab_RT_az(*), Tdust(*)
+       integer(c_int), value :: npix_x, npix_y
+       real(c_double), value :: map_size, zoom
+       real(c_double), intent(out) :: image(*)
+       integer(c_int64_t), intent(out) :: n_rays
+       real(c_double), intent(out) :: kernel_ms
+     end function mcgpu_rt1_image
 
      integer(c_int) function mcgpu_temp_finale(ctx, E_abs, Tdust) bind(C, name="mcgpu_temp_finale")
        import :: c_int, c_ptr, c_double, c_float

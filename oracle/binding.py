@@ -299,6 +299,28 @@ class Oracle:
             raise RuntimeError(f"oracle_dust_map_sed failed: {rc}")
         return out
 
+    def dust_map_image(self, lam, xI_scatt, Tdust, n_sent_photons, E_disk, npix_x, npix_y, map_size, zoom=1.0,
+                       ang_disque=0.0, l_sym_ima=False, tau_dark_zone_obs=100.0, n_threads=1):
+        """Ray-traced image of the dust at wavelength ``lam`` (dust_map method 2):
+        (N_type_flux, RT_n_az, RT_n_incl, npix_y, npix_x) and the number of rays traced."""
+        m = self.model
+        rt = m.rt
+        az = _a(rt["tab_RT_az"], np.float32)
+        o = _RtOpts(int(lam), float(m.lam[lam - 1]), float(m.E_stars[lam - 1] + E_disk), float(n_sent_photons),
+                    float(m.cfg.distance), float(ang_disque), int(l_sym_ima), float(tau_dark_zone_obs),
+                    float(m.cfg.rin), float(m.cfg.rout), _p(az, C.c_float), int(n_threads))
+        out = np.zeros((rt["N_type_flux"], rt["RT_n_az"], rt["RT_n_incl"], npix_y, npix_x), np.float64)
+        x = _a(xI_scatt, np.float64)
+        T = _a(Tdust, np.float32)
+        n_rays = C.c_int(0)
+        self.lib.oracle_dust_map_image.restype = C.c_int
+        rc = self.lib.oracle_dust_map_image(C.byref(self.cm), C.byref(o), C.c_int(npix_x), C.c_int(npix_y),
+                                            C.c_double(map_size), C.c_double(zoom), _p(x, C.c_double), _p(T, C.c_float),
+                                            _p(out, C.c_double), C.byref(n_rays))
+        if rc:
+            raise RuntimeError(f"oracle_dust_map_image failed: {rc}")
+        return out, n_rays.value
+
     def define_dark_zone(self, lam, tau_max):
         """optical_depth.f90:1425-1651 (2D): the flags the reference's thermal step computes with
         tau_max = tau_dark_zone_eq_th = 1500 at the first wavelength beyond wl_seuil = 0.81 um."""

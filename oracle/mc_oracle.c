@@ -1737,32 +1737,107 @@ static void rotation_3d(const double axis[3], double angle_deg, const double v[3
   for (int q = 0; q < 3; ++q) out[q] = vp[q] + norm * (ca * vn[q] + sa * vn2[q]);
 }
 
+/* calc_Jth (dust_ray_tracing.f90:810-846), LTE grains */
+static double *rt_calc_Jth(const oracle_model *m, int lam, double wl, const float *Tdust) {
+  double *J_th = (double *)calloc((size_t)m->n_cells, sizeof(double));
+  if (!J_th) return NULL;
+  const double cst_E = 2.0 * ORC_HP * ORC_C_LIGHT * ORC_C_LIGHT;
+  const float thermal_const = (float)(ORC_C_LIGHT * ORC_HP / ORC_KB);
+  for (int ic = 0; ic < m->n_cells; ++ic) {
+    const double Temp = (double)Tdust[ic];
+    if (Temp * wl > 3.e-4) {
+      const double cst_wl = (double)thermal_const / (Temp * wl);
+      const double coeff_exp = exp(cst_wl);
+      J_th[ic] = cst_E / (pow(wl, 5) * (coeff_exp - 1.0)) * wl * m->kappa_abs_LTE[lam - 1] * m->kappa_factor[ic];
+    }
+  }
+  return J_th;
+}
+
+/* integ_ray_dust (optical_depth.f90:1327-1421) from (x0,y0,z0) on the grid edge in cell icell, direction
+ * (u0,v0,w0), with dust_source_fct of RT method 1 (dust_ray_tracing.f90:1455-1475) = eps_dust1(k,psup,:,icell)
+ * / kappa_ext, eps_dust1 built here from xI_scatt like init_dust_source_fct1 (:676-703) for observer q. */
+static void rt1_integ_ray_dust(const oracle_model *m, int lam, double tau_dark_zone_obs, const double *xI,
+                               const double *J_th, double photon_energy, int q, double x0, double y0, double z0,
+                               double u0, double v0, double w0, int icell, double S[8]) {
+  const int ntf = m->N_type_flux, nRT = m->RT_n_incl * m->RT_n_az, nc = m->n_cells;
+  const int n_Stokes = m->lsepar_pola ? 4 : 1; /* init_mcfost.f90:1603-1616 */
+  const size_t st_type = (size_t)m->n_az_rt * m->n_theta_rt, st_rt = st_type * ntf;
+  for (int t = 0; t < 8; ++t) S[t] = 0.0;
+  double x1 = x0, y1 = y0, z1 = z0, tau = 0.0;
+  int next_cell = icell, lis, i_star, icell_star;
+  oracle_intersect_stars(m, x0, y0, z0, u0, v0, w0, &lis, &i_star, &icell_star);
+  for (long guard = 0; guard < 100000000L; ++guard) {
+    const int ic = next_cell;
+    const double xa = x1, ya = y1, za = z1;
+    if (oracle_test_exit_grid_cyl(m, ic, xa, ya, za)) break;
+    if (lis && ic == icell_star) break;
+    double l, lc, lv;
+    oracle_cross_cylindrical_cell(m, xa, ya, za, u0, v0, w0, ic, 0, &x1, &y1, &z1, &next_cell, &l, &lc, &lv);
+    if (ic <= nc) {
+      const double kappa_ext = m->kappa[lam - 1] * m->kappa_factor[ic - 1];
+      const double dtau = lc * kappa_ext;
+      const double xm = 0.5 * (xa + x1), ym = 0.5 * (ya + y1), zm = 0.5 * (za + z1);
+      int k = 1, psup = 1;
+      if (!m->l3D) {
+        psup = (zm > 0.0) ? 1 : 2;
+        const double phi_pos = atan2(xm, ym);
+        k = (int)floor(modulo_d(phi_pos, 2 * PI) / (2 * PI) * (double)m->n_az_rt) + 1;
+        if (k > m->n_az_rt) k = m->n_az_rt;
+      }
+      if (kappa_ext > DBL_MIN) {
+        const double factor = photon_energy / m->volume[ic - 1] * m->n_az_rt * m->n_theta_rt;
+        const double kappa_sca = kappa_ext * (double)m->albedo[lam - 1];
+        const double *px = xI + (size_t)(k - 1) + (size_t)m->n_az_rt * (psup - 1) + st_rt * ((size_t)q + (size_t)nRT * (ic - 1));
+        const double wgt = exp(-tau) * (1.0 - exp(-dtau));
+        double eps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int t = 0; t < ntf; ++t) eps[t] = px[st_type * t] * factor * kappa_sca; /* I_scatt(:,:,itype) */
+        double src[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        src[0] = (eps[0] + J_th[ic - 1]) / kappa_ext;
+        if (m->lsepar_pola) { src[1] = eps[1] / kappa_ext; src[2] = eps[2] / kappa_ext; src[3] = eps[3] / kappa_ext; }
+        if (m->lsepar_contrib) {
+          src[n_Stokes + 1] = eps[n_Stokes + 1] / kappa_ext; /* n_Stokes+2 */
+          src[n_Stokes + 2] = J_th[ic - 1] / kappa_ext;      /* n_Stokes+3 */
+          src[n_Stokes + 3] = eps[n_Stokes + 3] / kappa_ext; /* n_Stokes+4 */
+        }
+        for (int t = 0; t < ntf; ++t) S[t] += wgt * src[t];
+      }
+      tau += dtau;
+      if (tau > tau_dark_zone_obs) break;
+    }
+  }
+}
+
+/* image-plane basis of dust_map (dust_transfer.f90:1440-1455) */
+static void rt_image_plane(const oracle_model *m, const oracle_rt_opts *o, int ibin, int iaz, double uvw[3],
+                           double xpi[3], double ypi[3], double center[3]) {
+  const int q = (ibin - 1) + m->RT_n_incl * (iaz - 1);
+  uvw[0] = m->tab_u_rt[q]; uvw[1] = m->tab_v_rt[q]; uvw[2] = m->tab_w_rt[ibin - 1];
+  const double az = (double)o->tab_RT_az[iaz - 1] * (PI / 180.0);
+  const double x[3] = {cos(az), sin(az), 0.0};
+  if (fabs(o->ang_disque) > (double)FLT_MIN) rotation_3d(uvw, o->ang_disque, x, xpi);
+  else { xpi[0] = x[0]; xpi[1] = x[1]; xpi[2] = x[2]; }
+  /* y_plan_image = -cross_product(x_plan_image, uvw) */
+  ypi[0] = -(xpi[1] * uvw[2] - xpi[2] * uvw[1]);
+  ypi[1] = -(xpi[2] * uvw[0] - xpi[0] * uvw[2]);
+  ypi[2] = -(xpi[0] * uvw[1] - xpi[1] * uvw[0]);
+  const double lfar = 10. * o->Rmax;
+  for (int c = 0; c < 3; ++c) center[c] = uvw[c] * lfar;
+}
+
+static double rt_photon_energy(const oracle_rt_opts *o) { /* (:661-663), SED / image branch alike */
+  return o->E_src * o->wl_um * 1.0e-6 / (o->n_sent_photons * ORC_AU_TO_CM * PI);
+}
+
 int oracle_dust_map_sed(const oracle_model *m, const oracle_rt_opts *o, const double *xI, const float *Tdust,
                         double *out) {
   if (m->grid_type == 3) return 31;
-  const int ntf = m->N_type_flux, nRT = m->RT_n_incl * m->RT_n_az, nc = m->n_cells;
-  const int n_Stokes = m->lsepar_pola ? 4 : 1; /* init_mcfost.f90:1603-1616 */
+  const int ntf = m->N_type_flux, nRT = m->RT_n_incl * m->RT_n_az;
   const int lam = o->lambda;
-  const double wl = o->wl_um * 1.e-6;
   memset(out, 0, sizeof(double) * (size_t)ntf * nRT);
-
-  /* calc_Jth (dust_ray_tracing.f90:810-846) */
-  double *J_th = (double *)calloc((size_t)nc, sizeof(double));
+  double *J_th = rt_calc_Jth(m, lam, o->wl_um * 1.e-6, Tdust);
   if (!J_th) return 22;
-  {
-    const double cst_E = 2.0 * ORC_HP * ORC_C_LIGHT * ORC_C_LIGHT;
-    const float thermal_const = (float)(ORC_C_LIGHT * ORC_HP / ORC_KB);
-    for (int ic = 0; ic < nc; ++ic) {
-      const double Temp = (double)Tdust[ic];
-      if (Temp * wl > 3.e-4) {
-        const double cst_wl = (double)thermal_const / (Temp * wl);
-        const double coeff_exp = exp(cst_wl);
-        J_th[ic] = cst_E / (pow(wl, 5) * (coeff_exp - 1.0)) * wl * m->kappa_abs_LTE[lam - 1] * m->kappa_factor[ic];
-      }
-    }
-  }
-  /* photon_energy (:661-663), SED branch */
-  const double photon_energy = o->E_src * o->wl_um * 1.0e-6 / (o->n_sent_photons * ORC_AU_TO_CM * PI);
+  const double photon_energy = rt_photon_energy(o);
 
   /* image-plane sampling of dust_map, method 1 (:1481-1535) */
   enum { n_rad_RT = 128, n_phi_RT = 30 };
@@ -1773,24 +1848,13 @@ int oracle_dust_map_sed(const oracle_model *m, const oracle_rt_opts *o, const do
   for (int i = 1; i < n_rad_RT; ++i) tab_r[i] = tab_r[i - 1] * fact_r;
   const double fact_A = sqrt(PI * (fact_r - 1.0 / fact_r) / n_phi_RT);
   const double cst_phi = (o->l_sym_ima ? PI : 2 * PI) / (double)n_phi_RT;
-  const size_t st_type = (size_t)m->n_az_rt * m->n_theta_rt, st_rt = st_type * ntf;
 
-  int err = 0;
   for (int ibin = 1; ibin <= m->RT_n_incl; ++ibin)
     for (int iaz = 1; iaz <= m->RT_n_az; ++iaz) {
       const int q = (ibin - 1) + m->RT_n_incl * (iaz - 1);
-      const double u = m->tab_u_rt[q], v = m->tab_v_rt[q], w = m->tab_w_rt[ibin - 1];
-      const double uvw[3] = {u, v, w};
-      const double az = (double)o->tab_RT_az[iaz - 1] * (PI / 180.0);
-      const double x[3] = {cos(az), sin(az), 0.0};
-      double xpi[3];
-      if (fabs(o->ang_disque) > (double)FLT_MIN) rotation_3d(uvw, o->ang_disque, x, xpi);
-      else { xpi[0] = x[0]; xpi[1] = x[1]; xpi[2] = x[2]; }
-      /* y_plan_image = -cross_product(x_plan_image, uvw) */
-      const double ypi[3] = {-(xpi[1] * uvw[2] - xpi[2] * uvw[1]), -(xpi[2] * uvw[0] - xpi[0] * uvw[2]),
-                             -(xpi[0] * uvw[1] - xpi[1] * uvw[0])};
-      const double lfar = 10. * o->Rmax;
-      const double center[3] = {u * lfar, v * lfar, w * lfar};
+      double uvw[3], xpi[3], ypi[3], center[3];
+      rt_image_plane(m, o, ibin, iaz, uvw, xpi, ypi, center);
+      const double u0 = -uvw[0], v0 = -uvw[1], w0 = -uvw[2]; /* reverse propagation */
       double *acc = out + (size_t)q * ntf;
 #ifdef _OPENMP
 #pragma omp parallel for schedule(dynamic, 1) num_threads(o->n_threads > 0 ? o->n_threads : 1)
@@ -1800,60 +1864,15 @@ int oracle_dust_map_sed(const oracle_model *m, const oracle_rt_opts *o, const do
         const double r = tab_r[ri], taille_pix = fact_A * r;
         for (int ph = 1; ph <= n_phi_RT; ++ph) {
           const double phi = cst_phi * ((double)ph - 0.5);
-          /* intensite_pixel_dust (:1899-2004) with one sub-pixel: the pixel centre, reverse propagation */
+          /* intensite_pixel_dust (:1899-2004) with one sub-pixel: the pixel centre */
           double x0 = center[0] + r * sin(phi) * xpi[0] + r * cos(phi) * ypi[0];
           double y0 = center[1] + r * sin(phi) * xpi[1] + r * cos(phi) * ypi[1];
           double z0 = center[2] + r * sin(phi) * xpi[2] + r * cos(phi) * ypi[2];
-          const double u0 = -u, v0 = -v, w0 = -w;
           int icell, lintersect;
           oracle_move_to_grid_cyl(m, &x0, &y0, &z0, u0, v0, w0, &icell, &lintersect);
           if (!lintersect) continue;
-          /* integ_ray_dust (optical_depth.f90:1327-1421) */
-          double S[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-          double x1 = x0, y1 = y0, z1 = z0, tau = 0.0;
-          int next_cell = icell, lis, i_star, icell_star;
-          oracle_intersect_stars(m, x0, y0, z0, u0, v0, w0, &lis, &i_star, &icell_star);
-          for (long guard = 0; guard < 100000000L; ++guard) {
-            const int ic = next_cell;
-            const double xa = x1, ya = y1, za = z1;
-            if (oracle_test_exit_grid_cyl(m, ic, xa, ya, za)) break;
-            if (lis && ic == icell_star) break;
-            double l, lc, lv;
-            oracle_cross_cylindrical_cell(m, xa, ya, za, u0, v0, w0, ic, 0, &x1, &y1, &z1, &next_cell, &l, &lc, &lv);
-            if (ic <= nc) {
-              const double kappa_ext = m->kappa[lam - 1] * m->kappa_factor[ic - 1];
-              const double dtau = lc * kappa_ext;
-              const double xm = 0.5 * (xa + x1), ym = 0.5 * (ya + y1), zm = 0.5 * (za + z1);
-              /* dust_source_fct, RT1 (dust_ray_tracing.f90:1455-1475) = eps_dust1(k,psup,:,icell), built here
-               * from xI_scatt like init_dust_source_fct1 (:676-703) */
-              int k = 1, psup = 1;
-              if (!m->l3D) {
-                psup = (zm > 0.0) ? 1 : 2;
-                const double phi_pos = atan2(xm, ym);
-                k = (int)floor(modulo_d(phi_pos, 2 * PI) / (2 * PI) * (double)m->n_az_rt) + 1;
-                if (k > m->n_az_rt) k = m->n_az_rt;
-              }
-              if (kappa_ext > DBL_MIN) {
-                const double factor = photon_energy / m->volume[ic - 1] * m->n_az_rt * m->n_theta_rt;
-                const double kappa_sca = kappa_ext * (double)m->albedo[lam - 1];
-                const double *px = xI + (size_t)(k - 1) + (size_t)m->n_az_rt * (psup - 1) + st_rt * ((size_t)q + (size_t)nRT * (ic - 1));
-                const double wgt = exp(-tau) * (1.0 - exp(-dtau));
-                double eps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                for (int t = 0; t < ntf; ++t) eps[t] = px[st_type * t] * factor * kappa_sca; /* I_scatt(:,:,itype) */
-                double src[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                src[0] = (eps[0] + J_th[ic - 1]) / kappa_ext;
-                if (m->lsepar_pola) { src[1] = eps[1] / kappa_ext; src[2] = eps[2] / kappa_ext; src[3] = eps[3] / kappa_ext; }
-                if (m->lsepar_contrib) {
-                  src[n_Stokes + 1] = eps[n_Stokes + 1] / kappa_ext; /* n_Stokes+2 */
-                  src[n_Stokes + 2] = J_th[ic - 1] / kappa_ext;      /* n_Stokes+3 */
-                  src[n_Stokes + 3] = eps[n_Stokes + 3] / kappa_ext; /* n_Stokes+4 */
-                }
-                for (int t = 0; t < ntf; ++t) S[t] += wgt * src[t];
-              }
-              tau += dtau;
-              if (tau > o->tau_dark_zone_obs) break;
-            }
-          }
+          double S[8];
+          rt1_integ_ray_dust(m, lam, o->tau_dark_zone_obs, xI, J_th, photon_energy, q, x0, y0, z0, u0, v0, w0, icell, S);
           const double pix = (taille_pix / (o->distance * ORC_PC_TO_AU));
           for (int t = 0; t < ntf; ++t) loc[t] += S[t] * pix * pix; /* (:1989, :1993) */
         }
@@ -1864,5 +1883,79 @@ int oracle_dust_map_sed(const oracle_model *m, const oracle_rt_opts *o, const do
       }
     }
   free(J_th);
-  return err;
+  return 0;
+}
+
+/* dust_map, method 2 (images, dust_transfer.f90:1537-1577): square pixels of map_size/zoom / max(npix_x,npix_y) AU,
+ * each refined by intensite_pixel_dust (:1899-2004) -- 1, 2x2, 4x4 ... sub-pixels, at least n_iter_min = 2
+ * iterations, at most n_iter_max = 6, until Stokes I changes by less than 1 %.
+ * image[(((type * RT_n_az + iaz) * RT_n_incl + ibin) * npix_y + j) * npix_x + i] = Stokes_ray_tracing(lambda,i,j,ibin,
+ * iaz,type); with l_sym_ima only i <= npix_x/2 + mod(npix_x,2) is computed (the writer mirrors, output.f90:1007). */
+int oracle_dust_map_image(const oracle_model *m, const oracle_rt_opts *o, int npix_x, int npix_y, double map_size,
+                          double zoom, const double *xI, const float *Tdust, double *image, int *n_rays) {
+  if (m->grid_type == 3) return 31;
+  if (npix_x < 1 || npix_y < 1 || !(map_size > 0.0) || !(zoom > 0.0)) return 11;
+  const int ntf = m->N_type_flux, nRT = m->RT_n_incl * m->RT_n_az;
+  const int lam = o->lambda;
+  memset(image, 0, sizeof(double) * (size_t)ntf * nRT * npix_x * npix_y);
+  double *J_th = rt_calc_Jth(m, lam, o->wl_um * 1.e-6, Tdust);
+  if (!J_th) return 22;
+  const double photon_energy = rt_photon_energy(o);
+  const int n_iter_min = 2, n_iter_max = 6;
+  const double precision = 1.e-2;
+  const double taille_pix = (map_size / zoom) / (double)(npix_x > npix_y ? npix_x : npix_y);
+  const int npix_x_max = o->l_sym_ima ? npix_x / 2 + npix_x % 2 : npix_x;
+  long rays = 0;
+
+  for (int ibin = 1; ibin <= m->RT_n_incl; ++ibin)
+    for (int iaz = 1; iaz <= m->RT_n_az; ++iaz) {
+      const int q = (ibin - 1) + m->RT_n_incl * (iaz - 1);
+      double uvw[3], xpi[3], ypi[3], center[3], dx[3], dy[3], Icorner[3];
+      rt_image_plane(m, o, ibin, iaz, uvw, xpi, ypi, center);
+      const double u0 = -uvw[0], v0 = -uvw[1], w0 = -uvw[2];
+      for (int c = 0; c < 3; ++c) { dx[c] = xpi[c] * taille_pix; dy[c] = ypi[c] * taille_pix; }
+      for (int c = 0; c < 3; ++c) Icorner[c] = center[c] - (0.5 * npix_x * dx[c] + 0.5 * npix_y * dy[c]);
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(o->n_threads > 0 ? o->n_threads : 1) reduction(+ : rays)
+#endif
+      for (int i = 1; i <= npix_x_max; ++i)
+        for (int j = 1; j <= npix_y; ++j) {
+          double corner[3];
+          for (int c = 0; c < 3; ++c) corner[c] = Icorner[c] + (i - 1) * dx[c] + (j - 1) * dy[c];
+          double S[8] = {0, 0, 0, 0, 0, 0, 0, 0}, S_old[8];
+          int subpixels = 1, iter = 1;
+          for (;;) {
+            const double npix2 = (double)subpixels * (double)subpixels;
+            for (int t = 0; t < 8; ++t) { S_old[t] = S[t]; S[t] = 0.0; }
+            double sdx[3], sdy[3];
+            for (int c = 0; c < 3; ++c) { sdx[c] = dx[c] / (double)subpixels; sdy[c] = dy[c] / (double)subpixels; }
+            for (int si = 1; si <= subpixels; ++si)
+              for (int sj = 1; sj <= subpixels; ++sj) {
+                double x0 = corner[0] + (si - 0.5) * sdx[0] + (sj - 0.5) * sdy[0];
+                double y0 = corner[1] + (si - 0.5) * sdx[1] + (sj - 0.5) * sdy[1];
+                double z0 = corner[2] + (si - 0.5) * sdx[2] + (sj - 0.5) * sdy[2];
+                int icell, lintersect;
+                oracle_move_to_grid_cyl(m, &x0, &y0, &z0, u0, v0, w0, &icell, &lintersect);
+                ++rays;
+                if (!lintersect) continue;
+                double R[8];
+                rt1_integ_ray_dust(m, lam, o->tau_dark_zone_obs, xI, J_th, photon_energy, q, x0, y0, z0, u0, v0, w0, icell, R);
+                for (int t = 0; t < ntf; ++t) S[t] += R[t];
+              }
+            for (int t = 0; t < ntf; ++t) S[t] = S[t] / npix2;
+            if (iter < n_iter_min) subpixels *= 2;
+            else if (iter >= n_iter_max) break;
+            else if (fabs(S[0] - S_old[0]) > precision * S_old[0]) subpixels *= 2;
+            else break;
+            ++iter;
+          }
+          const double pix = taille_pix / (o->distance * ORC_PC_TO_AU);
+          for (int t = 0; t < ntf; ++t)
+            image[((((size_t)t * m->RT_n_az + (iaz - 1)) * m->RT_n_incl + (ibin - 1)) * npix_y + (j - 1)) * npix_x + (i - 1)] =
+                S[t] * (pix * pix);
+        }
+    }
+  if (n_rays) *n_rays = (int)(rays > 2147483647L ? 2147483647L : rays);
+  free(J_th);
+  return 0;
 }

@@ -251,6 +251,10 @@ typedef struct {
  * out[(ibin-1 + RT_n_incl*(iaz-1)) * N_type_flux + type-1] */
 int oracle_dust_map_sed(const oracle_model *m, const oracle_rt_opts *o, const double *xI_scatt,
                         const float *Tdust, double *out);
+/* dust_map method 2 (images): see mc_oracle.c; n_rays (may be NULL) returns the rays traced */
+int oracle_dust_map_image(const oracle_model *m, const oracle_rt_opts *o, int npix_x, int npix_y, double map_size,
+                          double zoom, const double *xI, const float *Tdust, double *image, int *n_rays);
+
 
 /*
  * define_dark_zone (optical_depth.f90:1425-1651) for a 2D cylindrical grid: cells from which a

@@ -35,6 +35,7 @@ static inline int __ffsll(long long m) { return __builtin_ffsll(m); }
 static inline int __popcll(unsigned long long m) { return __builtin_popcountll(m); }
 template <class T> static inline T __shfl(T v, int) { return v; }
 template <class T> static inline T __shfl_down(T, int) { return T(0); }
+template <class T> static inline T __shfl_xor(T, int) { return T(0); }
 static inline unsigned int atomicAdd(unsigned int* p, unsigned int v) { unsigned int o = *p; *p += v; return o; }
 static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) {
   unsigned long long o = *p; *p += v; return o;
@@ -331,46 +332,73 @@ extern "C" int emu_run_mono(const oracle_model* m, const oracle_mono_opts* o, do
 }
 
 
-// ---- RT1 ray-traced dust SED: mcgpu_rt1_dust_map with one emulated lane --------------------------
+// ---- RT1 ray tracing: mcgpu_rt1_dust_map / mcgpu_rt1_image with one emulated lane -----------------------------
+struct EmuRt {
+  Conv cv;
+  std::vector<double> xI_dev, J;
+  RtArgs A;
+  EmuRt(const oracle_model* m, const oracle_rt_opts* o, const double* xI, const float* Tdust) : cv(m) {
+    const DevModel& M = cv.M;
+    const int nRT = m->RT_n_incl * m->RT_n_az, ntf = m->N_type_flux;
+    const size_t st_type = (size_t)m->n_az_rt * m->n_theta_rt, st_rt = st_type * ntf;
+    // reference layout (n_az_rt, n_theta_rt, N_type_flux, nRT, n_cells) -> engine layout [cell][psup][phik][iRT][XI_LINE]
+    xI_dev.assign((size_t)m->n_cells * st_type * nRT * XI_LINE, 0.0);
+    for (int ic = 0; ic < m->n_cells; ++ic)
+      for (int q = 0; q < nRT; ++q)
+        for (int t = 0; t < ntf; ++t)
+          for (int ps = 0; ps < m->n_theta_rt; ++ps)
+            for (int k = 0; k < m->n_az_rt; ++k)
+              xI_dev[((((size_t)ic * m->n_theta_rt + ps) * m->n_az_rt + k) * nRT + q) * XI_LINE + t] =
+                  xI[(size_t)k + (size_t)m->n_az_rt * ps + st_type * t + st_rt * ((size_t)q + (size_t)nRT * ic)];
+    J.assign(m->n_cells, 0.0);
+    memset(&A, 0, sizeof(A));
+    A.lambda = o->lambda; A.RT_n_incl = m->RT_n_incl; A.nRT = nRT; A.n_az_rt = m->n_az_rt; A.n_theta_rt = m->n_theta_rt;
+    A.N_type_flux = ntf; A.contrib = m->lsepar_contrib; A.l_sym_ima = o->l_sym_ima;
+    A.wl = o->wl_um * 1.e-6;
+    const double AU_to_cm = 149597870700.0 * 100.0, pc_to_AU = 648000.0 / M_PI;
+    A.photon_energy = o->E_src * o->wl_um * 1.0e-6 / (o->n_sent_photons * AU_to_cm * M_PI);
+    A.pix_scale = 1.0 / (o->distance * pc_to_AU);
+    A.ang_disque = o->ang_disque; A.tau_dark_zone_obs = o->tau_dark_zone_obs;
+    A.rmin_RT = 0.01 * o->Rmin;
+    A.fact_r = std::exp((1.0 / ((double)RT_N_RAD - 1)) * std::log(2.0 * o->Rmax / A.rmin_RT));
+    A.fact_A = std::sqrt(M_PI * (A.fact_r - 1.0 / A.fact_r) / RT_N_PHI);
+    A.cst_phi = (o->l_sym_ima ? M_PI : 2 * M_PI) / (double)RT_N_PHI;
+    A.l_far = 10. * o->Rmax;
+    A.rt_u = m->tab_u_rt; A.rt_v = m->tab_v_rt; A.rt_w = m->tab_w_rt; A.rt_az = o->tab_RT_az;
+    A.xI = xI_dev.data(); A.J_th = J.data();
+    gridDim.x = 1; blockDim.x = 1; threadIdx.x = 0;
+    for (int ic = 0; ic < m->n_cells; ++ic) { blockIdx.x = (unsigned)ic; k_calc_Jth(M, o->lambda, A.wl, Tdust, J.data()); }
+    blockIdx.x = 0;
+  }
+};
+
 extern "C" int emu_rt1_dust_map(const oracle_model* m, const oracle_rt_opts* o, const double* xI, const float* Tdust,
                                 double* out) {
-  Conv cv(m);
-  const DevModel& M = cv.M;
-  if (cv.voro) return 31;
-  const int nRT = m->RT_n_incl * m->RT_n_az, ntf = m->N_type_flux;
-  const size_t st_type = (size_t)m->n_az_rt * m->n_theta_rt, st_rt = st_type * ntf;
-  // reference layout (n_az_rt, n_theta_rt, N_type_flux, nRT, n_cells) -> engine layout [cell][psup][phik][iRT][XI_LINE]
-  std::vector<double> xI_dev((size_t)m->n_cells * st_type * nRT * XI_LINE, 0.0);
-  for (int ic = 0; ic < m->n_cells; ++ic)
-    for (int q = 0; q < nRT; ++q)
-      for (int t = 0; t < ntf; ++t)
-        for (int ps = 0; ps < m->n_theta_rt; ++ps)
-          for (int k = 0; k < m->n_az_rt; ++k)
-            xI_dev[((((size_t)ic * m->n_theta_rt + ps) * m->n_az_rt + k) * nRT + q) * XI_LINE + t] =
-                xI[(size_t)k + (size_t)m->n_az_rt * ps + st_type * t + st_rt * ((size_t)q + (size_t)nRT * ic)];
-  std::vector<double> J(m->n_cells, 0.0);
-  memset(out, 0, sizeof(double) * (size_t)nRT * ntf);
-  RtArgs A;
-  memset(&A, 0, sizeof(A));
-  A.lambda = o->lambda; A.RT_n_incl = m->RT_n_incl; A.nRT = nRT; A.n_az_rt = m->n_az_rt; A.n_theta_rt = m->n_theta_rt;
-  A.N_type_flux = ntf; A.contrib = m->lsepar_contrib; A.l_sym_ima = o->l_sym_ima;
-  A.wl = o->wl_um * 1.e-6;
-  const double AU_to_cm = 149597870700.0 * 100.0, pc_to_AU = 648000.0 / M_PI;
-  A.photon_energy = o->E_src * o->wl_um * 1.0e-6 / (o->n_sent_photons * AU_to_cm * M_PI);
-  A.pix_scale = 1.0 / (o->distance * pc_to_AU);
-  A.ang_disque = o->ang_disque; A.tau_dark_zone_obs = o->tau_dark_zone_obs;
-  A.rmin_RT = 0.01 * o->Rmin;
-  A.fact_r = std::exp((1.0 / ((double)RT_N_RAD - 1)) * std::log(2.0 * o->Rmax / A.rmin_RT));
-  A.fact_A = std::sqrt(M_PI * (A.fact_r - 1.0 / A.fact_r) / RT_N_PHI);
-  A.cst_phi = (o->l_sym_ima ? M_PI : 2 * M_PI) / (double)RT_N_PHI;
-  A.l_far = 10. * o->Rmax;
-  A.rt_u = m->tab_u_rt; A.rt_v = m->tab_v_rt; A.rt_w = m->tab_w_rt; A.rt_az = o->tab_RT_az;
-  A.xI = xI_dev.data(); A.J_th = J.data(); A.out = out;
-  gridDim.x = 1; blockDim.x = 1; threadIdx.x = 0;
-  for (int ic = 0; ic < m->n_cells; ++ic) { blockIdx.x = (unsigned)ic; k_calc_Jth(M, o->lambda, A.wl, Tdust, J.data()); }
-  blockIdx.x = 0;
+  if (m->grid_type == 3) return 31;
+  EmuRt E(m, o, xI, Tdust);
+  const int ntf = m->N_type_flux;
+  memset(out, 0, sizeof(double) * (size_t)E.A.nRT * ntf);
+  E.A.out = out;
   const bool pola = ntf == 4 || ntf == 8;
-  if (m->l3D) { if (pola) k_rt1_dust_map<true, true>(M, A); else k_rt1_dust_map<true, false>(M, A); }
-  else { if (pola) k_rt1_dust_map<false, true>(M, A); else k_rt1_dust_map<false, false>(M, A); }
+  if (m->l3D) { if (pola) k_rt1_dust_map<true, true>(E.cv.M, E.A); else k_rt1_dust_map<true, false>(E.cv.M, E.A); }
+  else { if (pola) k_rt1_dust_map<false, true>(E.cv.M, E.A); else k_rt1_dust_map<false, false>(E.cv.M, E.A); }
+  return 0;
+}
+
+extern "C" int emu_rt1_image(const oracle_model* m, const oracle_rt_opts* o, int npix_x, int npix_y, double map_size,
+                             double zoom, const double* xI, const float* Tdust, double* image, int* n_rays) {
+  if (m->grid_type == 3) return 31;
+  EmuRt E(m, o, xI, Tdust);
+  const int ntf = m->N_type_flux;
+  memset(image, 0, sizeof(double) * (size_t)E.A.nRT * ntf * npix_x * npix_y);
+  unsigned long long rays = 0;
+  E.A.npix_x = npix_x; E.A.npix_y = npix_y;
+  E.A.npix_x_max = o->l_sym_ima ? npix_x / 2 + npix_x % 2 : npix_x;
+  E.A.taille_pix = (map_size / zoom) / (double)(npix_x > npix_y ? npix_x : npix_y);
+  E.A.image = image; E.A.n_rays = &rays;
+  const bool pola = ntf == 4 || ntf == 8;
+  if (m->l3D) { if (pola) k_rt1_image<true, true>(E.cv.M, E.A); else k_rt1_image<true, false>(E.cv.M, E.A); }
+  else { if (pola) k_rt1_image<false, true>(E.cv.M, E.A); else k_rt1_image<false, false>(E.cv.M, E.A); }
+  if (n_rays) *n_rays = (int)rays;
   return 0;
 }

@@ -646,6 +646,36 @@ def test_rt1_dust_map_variants():
     _dust_map_parity(M.small(), 12, 30, 7, tau_obs=0.5)                                         # early cut-off
 
 
+def test_rt1_image_parity():
+    """mcgpu_rt1_image (one wavefront per pixel, sub-pixel refinement) after an image-mode Monte Carlo (every
+    stream sends exactly n_photons_image packets) vs the oracle's dust_map method 2: same number of rays (same
+    refinement decisions), same pixels."""
+    from helpers import sed_model
+    for cfg, ang, sym, npx, npy in ((M.small(RT_n_incl=3), 0.0, True, 33, 33),
+                                    (M.small(RT_n_incl=2, RT_n_az=2, RT_az_max=60.0), 17.3, False, 24, 15),
+                                    (M.small(n_rad=10, nz=5, n_az=6, l3D=True, lsepar_pola=False), 0.0, False, 16, 16)):
+        m = sed_model(cfg, n_thermal=50000)
+        e, o = _engine(m, 1e5), _oracle(m, 1e5)
+        lam = 9
+        a = e.run_mono(lam, 10 ** 12, seed=4, n_chunks=16, n_phot_lim=500.0)
+        assert np.all(a["n_sent_chunk"] == 500)
+        x = a["xI_scatt"].copy()
+        if not cfg.l3D:
+            x[:cfg.n_rad] = x[:cfg.n_rad].mean(axis=3, keepdims=True)   # see _dust_map_parity
+            e.set_xI(x)
+        ns, Ed = a["n_sent"][lam - 1], m.extra["E_disk"][lam - 1]
+        got, n_rays, ms = e.dust_map_image(lam, m.extra["Tdust"], ns, Ed, npx, npy, 2.2 * cfg.rout, zoom=1.2,
+                                           ang_disque=ang, l_sym_ima=sym)
+        ref, nr = o.dust_map_image(lam, x, m.extra["Tdust"], ns, Ed, npx, npy, 2.2 * cfg.rout, zoom=1.2, ang_disque=ang,
+                                   l_sym_ima=sym, n_threads=8)
+        e.close()
+        assert n_rays == nr and ms > 0
+        assert ref[0].max() > 0
+        assert np.allclose(got, ref, rtol=1e-9, atol=1e-13 * np.abs(ref).max()), np.abs(got - ref).max() / np.abs(ref).max()
+        if sym:   # only the left half is computed (the reference mirrors it when it writes the image)
+            assert not got[..., npx // 2 + npx % 2:].any()
+
+
 def test_rt1_dust_map_abi_errors(sed_small):
     from mcfost_amd.engine import McgpuError
     e = _engine(sed_small, 1e5)
@@ -656,6 +686,10 @@ def test_rt1_dust_map_abi_errors(sed_small):
         e.dust_map_sed(3, sed_small.extra["Tdust"], 0.0, 0.0)        # n_sent_photons must be positive
     with pytest.raises(McgpuError):
         e.dust_map_sed(0, sed_small.extra["Tdust"], 100.0, 0.0)      # lambda out of range
+    with pytest.raises(McgpuError):
+        e.dust_map_image(3, sed_small.extra["Tdust"], 100.0, 0.0, 0, 8, 100.0)     # no pixels
+    with pytest.raises(McgpuError):
+        e.dust_map_image(3, sed_small.extra["Tdust"], 100.0, 0.0, 8, 8, -1.0)      # map size
     e.close()
 
 

@@ -322,3 +322,34 @@ def test_emulated_rt1_dust_map(emu, kw):
         got = emu_dust_map(emu, orc, *args, ang_disque=ang, l_sym_ima=sym)
         assert np.abs(ref[:, 0]).max() > 0
         assert np.allclose(got, ref, rtol=1e-10, atol=1e-14 * np.abs(ref).max())
+
+
+def test_emulated_rt1_image(emu):
+    """k_rt1_image (one pixel per wavefront, sub-pixel refinement) against the oracle's dust_map method 2: the same
+    refinement decisions (same number of rays) and the same pixels."""
+    from oracle.binding import _RtOpts
+    cfg = M.small(n_rad=10, nz=6, RT_n_incl=2, RT_n_az=2, RT_az_max=60.0)
+    m = sed_model(cfg, n_thermal=20000)
+    orc = Oracle(m, 1e5)
+    lam = 9
+    b = orc.run_mono(lam, 10 ** 9, seed=5, n_chunks=4, n_phot_lim=300.0, rt1=True, n_threads=1)  # image-mode MC: fixed count
+    assert np.all(b["n_sent_chunk"] == 300)
+    xI = b["xI_scatt"].copy()
+    xI[:cfg.n_rad] = xI[:cfg.n_rad].mean(axis=3, keepdims=True)
+    az = np.ascontiguousarray(m.rt["tab_RT_az"], np.float32)
+    T = np.ascontiguousarray(m.extra["Tdust"], np.float32)
+    for npx, npy, sym, ang in ((9, 9, False, 17.3), (12, 7, True, 0.0)):  # (17 deg + the 45 deg diagonal = a sub-bin edge)
+        ns, Ed = b["n_sent"][lam - 1], m.extra["E_disk"][lam - 1]
+        ref, nr = orc.dust_map_image(lam, xI, T, ns, Ed, npx, npy, 2.2 * cfg.rout, zoom=1.5, ang_disque=ang, l_sym_ima=sym)
+        o = _RtOpts(int(lam), float(m.lam[lam - 1]), float(m.E_stars[lam - 1] + Ed), float(ns), float(cfg.distance),
+                    float(ang), int(sym), 100.0, float(cfg.rin), float(cfg.rout), _p(az, C.c_float), 1)
+        got = np.zeros_like(ref)
+        n_rays = C.c_int(0)
+        rc = emu.emu_rt1_image(C.byref(orc.cm), C.byref(o), C.c_int(npx), C.c_int(npy), C.c_double(2.2 * cfg.rout),
+                               C.c_double(1.5), _p(xI, C.c_double), _p(T, C.c_float), _p(got, C.c_double), C.byref(n_rays))
+        assert rc == 0
+        assert n_rays.value == nr and nr >= 5 * ref[0].size * (0.5 if sym else 1.0)
+        assert ref[0].max() > 0
+        assert np.allclose(got, ref, rtol=1e-10, atol=1e-14 * np.abs(ref).max())
+        if sym:
+            assert not ref[..., npx // 2 + npx % 2:].any() and not got[..., npx // 2 + npx % 2:].any()

@@ -362,3 +362,32 @@ def test_dust_map_is_linear_in_xI_and_separates_contributions():
     # a ray never looks behind tau_dark_zone_obs: a tiny cut-off removes everything but the skin
     cut = orc.dust_map_sed(lam, b["xI_scatt"], T, ns, Ed, tau_dark_zone_obs=1e-30)
     assert (cut[:, 0] < 0.5 * one[:, 0]).all()
+
+
+def test_dust_map_image_integrates_to_the_volume_integral_and_mirrors():
+    """dust_map method 2 on the optically-thin isothermal disk: the pixels sum to sum(J_th V) / d^2 (0.5 %), the
+    half image of l_sym_ima is the left half of the full one, and every pixel is refined at least once (>= 5 rays)."""
+    cfg, m = _thin_rt_model()
+    orc = Oracle(m, 1e5)
+    T = np.full(m.n_cells, 80.0, np.float32)
+    lam = m.n_lambda - 8
+    wl = m.lam[lam - 1] * 1e-6
+    hp, c, kb = 6.626070040e-34, 299792458.0, 1.38064852e-23
+    J = 2 * hp * c * c / (wl ** 5 * (np.exp(hp * c / (kb * 80.0 * wl)) - 1.0)) * wl * m.kappa_abs_LTE[lam - 1] * m.kappa_factor
+    expect = (J * np.asarray(m.grid["volume"])).sum() / (cfg.distance * 648000.0 / math.pi) ** 2
+    z = np.zeros(orc.xI_shape())
+    for npx in (32, 33):
+        img, nr = orc.dust_map_image(lam, z, T, 1000.0, 0.0, npx, npx, 2.2 * cfg.rout, n_threads=4)
+        assert img.shape == (8, 1, 3, npx, npx) and nr >= 5 * 3 * npx * npx
+        assert np.allclose(img[0, 0].sum(axis=(1, 2)), expect, rtol=5e-3, atol=0)
+        assert np.array_equal(img[0], img[6]) and not img[1:6].any() and not img[7].any()
+        half, nr2 = orc.dust_map_image(lam, z, T, 1000.0, 0.0, npx, npx, 2.2 * cfg.rout, l_sym_ima=True, n_threads=4)
+        h = npx // 2 + npx % 2
+        assert np.allclose(half[..., :h], img[..., :h], rtol=1e-12, atol=0) and not half[..., h:].any()
+        assert np.allclose(img[0, 0, :, :, :npx - h], img[0, 0, :, :, h:][:, :, ::-1], rtol=1e-6, atol=1e-9 * img.max())
+        # a pixel four times larger holds the flux of its four children (to the 1 % refinement criterion)
+        if npx == 32:
+            coarse, _ = orc.dust_map_image(lam, z, T, 1000.0, 0.0, 16, 16, 2.2 * cfg.rout, n_threads=4)
+            fine4 = img[0, 0].reshape(3, 16, 2, 16, 2).sum(axis=(2, 4))
+            sel = coarse[0, 0] > 1e-3 * coarse[0, 0].max()
+            assert np.allclose(coarse[0, 0][sel], fine4[sel], rtol=0.05, atol=0)
