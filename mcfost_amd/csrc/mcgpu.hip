@@ -1049,7 +1049,13 @@ extern "C" int mcgpu_run_mono(mcgpu_ctx* ctx, const mcgpu_mono_opts* o, double f
   const unsigned long long lim = lim_d > 9.0e18 ? ~0ull : (unsigned long long)lim_d;
   std::vector<unsigned long long> need(nc, o->n_photons2), sent(nc, 0ull);
   std::vector<int> active, done(nc, 0);
-  if (o->n_photons2 > 0 && lim > 0) for (int c = 0; c < nc; ++c) active.push_back(c);
+  if (o->n_photons2 >= lim) {
+    // a stream cannot collect n_photons2 packets in capt_sup out of fewer than n_photons2 sent: every stream runs
+    // to n_phot_lim and nothing has to be scouted (image mode, run_image_mc: p_nnfot2 => nnfot2, :507-508, 711-713)
+    for (int c = 0; c < nc; ++c) sent[c] = lim;
+  } else if (o->n_photons2 > 0 && lim > 0) {
+    for (int c = 0; c < nc; ++c) active.push_back(c);
+  }
   HIPCHK(hipMemcpyAsync(d_need, need.data(), nc * sizeof(unsigned long long), hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemcpyAsync(d_sent, sent.data(), nc * sizeof(unsigned long long), hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
@@ -1062,6 +1068,9 @@ extern "C" int mcgpu_run_mono(mcgpu_ctx* ctx, const mcgpu_mono_opts* o, double f
     double b = 1.25 * (double)max_need / rate + 64.0;
     const double bmax = 2.0e9 / (double)na;
     if (b > bmax) b = bmax;
+    unsigned long long max_left = 0;  // no stream can use more than what n_phot_lim leaves it
+    for (int c : active) if (lim - sent[c] > max_left) max_left = lim - sent[c];
+    if (b > (double)max_left) b = (double)max_left;
     if (b < 64.0) b = 64.0;
     const unsigned long long batch = ((unsigned long long)b + 63ull) / 64ull * 64ull;
     const size_t nh = (size_t)na * batch;
