@@ -299,8 +299,13 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
   RQ_DIAG(unsigned int d_fly_iters = 0, d_srv_iters = 0, d_fly_cross = 0, d_srv_rounds = 0, d_fly_rounds = 0;)
   RQ_DIAG(unsigned int d_in_flight = 0, d_handed = 0, d_popped = 0, d_empty = 0;)
 
+  // diagnostics (A.flags bit 1): wall-clock (100 MHz) of this wave's start, of the moment the packet ids ran out
+  // and of its end, summed over the waves into counters[10..14] (tools/wave_timeline.py)
+  const unsigned long long t_start = (A.flags & 2) ? wall_clock64() : 0ull;
+  unsigned long long t_ids_out = 0;
   for (int ep = 0;; ++ep) {
     if (rq_ld(&Q->abort_flag)) break;
+    if ((A.flags & 2) && no_more_ids && !t_ids_out) t_ids_out = wall_clock64();
     int finished = 0;  // packets this lane finished in this round
     if (auto_roles) {
       // fly when the lanes can be (nearly) filled with packets in flight -- the wave's own plus the queue's --
@@ -513,6 +518,14 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
     }
   }
 
+  if ((A.flags & 2) && lane == 0) {
+    const unsigned long long t_end = wall_clock64();
+    atomicAdd(&A.counters[10], t_end - t_start);
+    atomicAdd(&A.counters[11], (t_ids_out ? t_ids_out : t_end) - t_start);
+    atomicMax(&A.counters[12], ~t_start);
+    atomicMax(&A.counters[13], t_end);
+    atomicAdd(&A.counters[14], 1ull);
+  }
   if (LDSE) {
     __syncthreads();
     for (int i = threadIdx.x; i < M.n_cells; i += blockDim.x) {

@@ -788,6 +788,7 @@ extern "C" int mcgpu_launch_thermal(mcgpu_ctx* ctx, const mcgpu_run_opts* o) {
   }
   HIPCHK(hipMemsetAsync(ctx->d_err, 0, sizeof(int), ctx->stream));
   RunArgs A;
+  std::memset(&A, 0, sizeof(A));
   A.seed = o->seed; A.first_packet = o->first_packet; A.n_packets = o->n_packets;
   A.qscale = o->n_replicas >= 1.0 ? o->n_replicas : 1.0;
   A.frozen = o->frozen ? 1 : 0;

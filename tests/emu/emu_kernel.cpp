@@ -36,6 +36,8 @@ static inline int __popcll(unsigned long long m) { return __builtin_popcountll(m
 template <class T> static inline T __shfl(T v, int) { return v; }
 template <class T> static inline T __shfl_down(T, int) { return T(0); }
 template <class T> static inline T __shfl_xor(T, int) { return T(0); }
+static inline unsigned long long wall_clock64() { return 0ull; }
+static inline unsigned long long atomicMax(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; if (v > o) *p = v; return o; }
 static inline unsigned int atomicAdd(unsigned int* p, unsigned int v) { unsigned int o = *p; *p += v; return o; }
 static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) {
   unsigned long long o = *p; *p += v; return o;
@@ -169,6 +171,7 @@ extern "C" int emu_run_thermal(const oracle_model* m, const oracle_opts* o, cons
   int err = 0;
   if (getenv("MCGPU_EMU_TRACE")) { g_trace_base = E_abs; g_trace_n = m->n_cells; }
   RunArgs A;
+  memset(&A, 0, sizeof(A));
   A.seed = o->seed; A.first_packet = o->first_packet; A.n_packets = o->n_packets;
   A.qscale = o->n_replicas >= 1.0 ? o->n_replicas : 1.0;
   A.frozen = o->frozen; A.E_prior = E_prior; A.E_abs = E_abs; A.sed = sed; A.n_sent = n_sent;
