@@ -193,6 +193,7 @@ def main():
     ap.add_argument("--sites", type=int, default=100000,
                     help="--config voronoi: number of SPH-like sites of the tessellation (BASELINE config 5 stand-in)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pascucci", action="store_true", help="skip the extra Pascucci-disk timing of the default run")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--grid-blocks", type=int, default=0)
     ap.add_argument("--block-threads", type=int, default=0)
@@ -272,6 +273,42 @@ def main():
 
     out = eng.fetch()      # after the all-reduce: global sums of the last step
     cnt = out["counters"]
+
+    # BASELINE.json quotes its metric on the Pascucci 2D disk and lists ref4.1 as the single-GPU configuration
+    # (configs[1], the headline line above): the same loop on the Pascucci disk is timed next to it, same packet
+    # count, same barriers and all-reduce, and reported under "pascucci_2d".
+    extra = None
+    if args.config == "ref41" and not args.no_pascucci and not args.frozen:
+        pm = M.build_model(M.pascucci())
+        pe = Engine(pm, n_total, device=local_rank)
+
+        def pstep(i):
+            pe.launch_thermal(n_local, seed=2000 + i, first_packet=first, n_replicas=float(world))
+            ms = pe.sync()
+            if world > 1:
+                acc, cnt2 = pe.device_accumulators()
+                dist.all_reduce(acc)
+                dist.all_reduce(cnt2)
+                torch.cuda.current_stream().synchronize()
+            return ms
+
+        pstep(-1)
+        barrier()
+        tp0 = time.perf_counter()
+        pk = [pstep(i) for i in range(2)]
+        barrier()
+        dtp = time.perf_counter() - tp0
+        if world > 1:
+            tt = torch.tensor([dtp], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dtp = float(tt.item())
+        pc = pe.fetch()["counters"]
+        extra = {"value": n_total * 2 / dtp, "unit": "packets/s", "steps": 2, "warmup": 1, "ms_per_step": dtp / 2 * 1e3,
+                 "kernel_ms": sum(pk) / 2, "workload": "Pascucci 2D disk 100x70, 61 wavelengths, isotropic scattering, "
+                 "%.3g packets/GPU/step" % n_local,
+                 "crossings_per_packet": pc["crossings"] / max(pc["packets"], 1),
+                 "interactions_per_packet": (pc["scatterings"] + pc["absorptions"]) / max(pc["packets"], 1)}
+        pe.close()
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         value = n_total * args.steps / dt
@@ -288,7 +325,7 @@ def main():
         k_ms = sum(kernel_ms) / len(kernel_ms)
         achieved = bytes_launch / (k_ms * 1e-3) / 1e9
         line = {
-            "metric": "photon packets/sec (whole node), thermal MC packet loop", "value": value,
+            "metric": "photon packets/sec (whole node), thermal MC packet loop, %s" % cfg.name, "value": value,
             "unit": "packets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
@@ -307,6 +344,8 @@ def main():
                          "kernel": "k_thermal_voro" if args.config == "voronoi" else "k_thermal_roles", "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": bytes_launch},
         }
+        if extra is not None:
+            line["pascucci_2d"] = extra
         if world == 1 and not args.no_cpu_baseline:
             base, T_cpu, n_cpu = cpu_baseline(model, n_total, args.cpu_seconds)
             line["cpu_baseline"] = base

@@ -12,9 +12,9 @@ run() { # name, then the rocprofv3 options, then -- program
   timeout 900 rocprofv3 "$@" > $R/gpurun_out/p_$name.log 2>&1 </dev/null
   (cd $R && python3 tools/summarize_prof.py gpurun_out/p_$name gpurun_out ${TAG}_$name > /dev/null 2>&1)
 }
-run kt       --kernel-trace --stats --output-format csv -d $R/gpurun_out/p_kt -o kt -- python3 $R/bench.py --no-cpu-baseline
-run pmc_fetch --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/p_pmc_fetch -o f -- python3 $R/bench.py --no-cpu-baseline --steps 1 --warmup 0
-run pmc_write --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/p_pmc_write -o w -- python3 $R/bench.py --no-cpu-baseline --steps 1 --warmup 0
+run kt       --kernel-trace --stats --output-format csv -d $R/gpurun_out/p_kt -o kt -- python3 $R/bench.py --no-cpu-baseline --no-pascucci
+run pmc_fetch --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/p_pmc_fetch -o f -- python3 $R/bench.py --no-cpu-baseline --no-pascucci --steps 1 --warmup 0
+run pmc_write --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/p_pmc_write -o w -- python3 $R/bench.py --no-cpu-baseline --no-pascucci --steps 1 --warmup 0
 run kt_voro  --kernel-trace --stats --output-format csv -d $R/gpurun_out/p_kt_voro -o kt -- python3 $R/bench.py --config voronoi --sites 50000 --packets 2e7 --no-cpu-baseline
 run kt_sed   --kernel-trace --stats --output-format csv -d $R/gpurun_out/p_kt_sed -o kt -- python3 $R/bench.py --config sed --packets 2e7 --no-cpu-baseline
 ls -la $R/gpurun_out/${TAG}_*.json
