@@ -210,8 +210,8 @@ __device__ inline void rq_exchange(RoleQ<POLA>* Q, int lane, bool want_push, boo
 // cells emit nothing, thermal_emission.f90:1817).
 template <bool L3D, bool POLA, bool DARK, bool LDSE>
 __device__ inline int roles_cross(const Lds& T, const DevModel& M, const RunArgs& A, double* E_lds, PkState& p,
-                                  double inv_a, double inv_w, double& kf, unsigned int& c_cross, unsigned int& c_kill,
-                                  unsigned int& c_dark) {
+                                  double inv_a, double inv_w, double kap, double kab, double& kf,
+                                  unsigned int& c_cross, unsigned int& c_kill, unsigned int& c_dark) {
   const int n_rad = M.n_rad, nz = M.nz;
   const int azj = p.zj < 0 ? -p.zj : p.zj;
   const bool out = (p.ri == n_rad + 1) || ((azj == nz + 1) && (fabs(p.z) > M.zmaxmax));
@@ -223,21 +223,19 @@ __device__ inline int roles_cross(const Lds& T, const DevModel& M, const RunArgs
   if (out) { p.st = S_EXITED; return 0; }
   if (killed) { c_kill++; p.st = S_EMIT; return 1; }
   const bool real_cell = is_real_cell<L3D>(n_rad, nz, p.ri, p.zj);
-  double opacity = 0.0;
-  int ic = 0;
-  if (real_cell) {
-    ic = cell_index<L3D>(n_rad, nz, p.ri, p.zj, p.k);
-    opacity = T.kappa[p.lambda - 1] * kf;
-  }
+  const int ic = real_cell ? cell_index<L3D>(n_rad, nz, p.ri, p.zj, p.k) : 0;
   double x1, y1, z1, l;
   int ri1, zj1, k1;
   MCGPU_CROSS<L3D>(T, M, p.x, p.y, p.z, p.u, p.v, p.w, inv_a, inv_w, p.ri, p.zj, p.k, x1, y1, z1, ri1, zj1, k1, l);
   c_cross++;
   if (++p.pk_cross > 200000000u) { *A.err = 13; p.st = S_EMIT; return 1; }
+  // (kf was loaded at the end of the previous crossing: first used here, behind the geometry, so that the
+  // latency of that load is covered by it)
+  const double opacity = real_cell ? kap * kf : 0.0;
   const double tau = l * opacity;
   if (tau > p.extr) {
     const double lc = l * (p.extr / tau);
-    if (real_cell && !(A.flags & 1)) deposit<LDSE>(A.E_abs, E_lds, ic, T.kabs[p.lambda - 1] * lc * p.S[0]);
+    if (real_cell && !(A.flags & 1)) deposit<LDSE>(A.E_abs, E_lds, ic, kab * lc * p.S[0]);
     p.x = p.x + lc * p.u;
     p.y = p.y + lc * p.v;
     p.z = p.z + lc * p.w;
@@ -245,7 +243,7 @@ __device__ inline int roles_cross(const Lds& T, const DevModel& M, const RunArgs
     p.st = S_INTERACT;
   } else {
     p.extr = p.extr - tau;
-    if (real_cell && !(A.flags & 1)) deposit<LDSE>(A.E_abs, E_lds, ic, T.kabs[p.lambda - 1] * l * p.S[0]);
+    if (real_cell && !(A.flags & 1)) deposit<LDSE>(A.E_abs, E_lds, ic, kab * l * p.S[0]);
     const bool next_real = is_real_cell<L3D>(n_rad, nz, ri1, zj1);
     const int ic1 = next_real ? cell_index<L3D>(n_rad, nz, ri1, zj1, k1) : 0;
     if (DARK && next_real && M.dark[ic1]) {
@@ -292,6 +290,7 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
   p.st = S_EMIT;  // S_EMIT = the lane holds no packet
   p.tau_rand = 0.0f; p.pk_cross = 0;
   double inv_a = 0.0, inv_w = 0.0, kf = 0.0;
+  double kap = 0.0, kab = 0.0;  // kappa(lambda), kappa_abs(lambda) of the packet in this lane: constants of a flight
   unsigned int c_cross = 0, c_flight = 0, c_scatt = 0, c_abs = 0, c_esc = 0, c_kill = 0, c_pack = 0, c_dark = 0;
   unsigned long long pk_next = 0, pk_end = 0;
   bool no_more_ids = false;  // wave-uniform: the global id counter is exhausted
@@ -339,6 +338,7 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
         inv_a = (a > TINY_REAL) ? 1.0 / a : HUGE_REAL;
         inv_w = (fabs(p.w) > TINY_REAL) ? 1.0 / p.w : copysign(HUGE_DP, p.w);
         kf = is_real_cell<L3D>(n_rad, nz, p.ri, p.zj) ? M.kappa_factor[cell_index<L3D>(n_rad, nz, p.ri, p.zj, p.k)] : 0.0;
+        kap = T.kappa[p.lambda - 1]; kab = T.kabs[p.lambda - 1];
       }
       if (p.st == S_EXITED) {  // (left over from a round as a server)
         if (!p.flag_ism) { capteur<POLA>(M, A.sed, p.lambda, p.u, p.v, p.w, p.S, p.flag_star, p.flag_scatt); c_esc++; }
@@ -360,7 +360,7 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
         // back to the queues as soon as enough lanes have nothing to fly (or after fly_iters crossings)
         if (it > 0 && __popcll(__ballot(p.st != S_FLIGHT)) >= fly_idle) break;
         RQ_DIAG(if (lane == 0) d_fly_iters++; if (p.st == S_FLIGHT) d_fly_cross++;)
-        if (p.st == S_FLIGHT) finished += roles_cross<L3D, POLA, DARK, LDSE>(T, M, A, E_lds, p, inv_a, inv_w, kf, c_cross, c_kill, c_dark);
+        if (p.st == S_FLIGHT) finished += roles_cross<L3D, POLA, DARK, LDSE>(T, M, A, E_lds, p, inv_a, inv_w, kap, kab, kf, c_cross, c_kill, c_dark);
         if (p.st == S_EXITED) {  // binned on the spot (capteur)
           if (!p.flag_ism) { capteur<POLA>(M, A.sed, p.lambda, p.u, p.v, p.w, p.S, p.flag_star, p.flag_scatt); c_esc++; }
           p.st = S_EMIT;
@@ -479,6 +479,7 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
         const double a = p.u * p.u + p.v * p.v;
         inv_a = (a > TINY_REAL) ? 1.0 / a : HUGE_REAL;
         inv_w = (fabs(p.w) > TINY_REAL) ? 1.0 / p.w : copysign(HUGE_DP, p.w);
+        kap = T.kappa[p.lambda - 1]; kab = T.kabs[p.lambda - 1];
         if (p.st == S_FLIGHT)
           kf = is_real_cell<L3D>(n_rad, nz, p.ri, p.zj) ? M.kappa_factor[cell_index<L3D>(n_rad, nz, p.ri, p.zj, p.k)] : 0.0;
       }
@@ -496,7 +497,7 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
       for (int it = 0; it < k_short; ++it) {
         if (__ballot(p.st == S_FLIGHT) == 0ull) break;
         RQ_DIAG(if (lane == 0) d_srv_iters++;)
-        if (p.st == S_FLIGHT) finished += roles_cross<L3D, POLA, DARK, LDSE>(T, M, A, E_lds, p, inv_a, inv_w, kf, c_cross, c_kill, c_dark);
+        if (p.st == S_FLIGHT) finished += roles_cross<L3D, POLA, DARK, LDSE>(T, M, A, E_lds, p, inv_a, inv_w, kap, kab, kf, c_cross, c_kill, c_dark);
       }
     }
 
