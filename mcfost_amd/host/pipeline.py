@@ -1,0 +1,79 @@
+"""Host-side sequence of a "temperature + SED" run (BASELINE config 2) over the engine: what
+``transfert_poussiere`` does around the packet loops (dust_transfer.f90:188-433) --
+
+    run_thermal_mc      (:575-688)   one temperature iteration + Temp_finale
+    repartition_energie (thermal_emission.f90:1771)   emission tables of the SED step from Tdust
+    run_sed_mc          (:828-1042)  per wavelength: the monochromatic packet loop (SED bins + xI_scatt),
+                                     then the ray-traced SED of the dust (dust_map, RT method 1)
+
+The Fortran host keeps doing this itself; this mirror drives the same C-ABI calls from Python
+for the tests, ``tools/run_config2.py`` and as an executable description of the call order.  ``backend`` is
+anything with the Engine's methods (``EngineBackend`` below; the tests pass the CPU oracle through an adapter)."""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+
+from . import model as M
+
+
+class EngineBackend:
+    """The MI355X engine (mcfost_amd.engine.Engine) behind the pipeline's four calls."""
+
+    def __init__(self, engine):
+        self.e = engine
+
+    def run_thermal(self, n, seed):
+        return self.e.run_thermal(n, seed=seed)
+
+    def temp_finale(self, E_abs):
+        return self.e.temp_finale(E_abs)
+
+    def run_mono(self, lam, n2, seed, n_chunks):
+        return self.e.run_mono(lam, n2, seed=seed, n_chunks=n_chunks, fetch_xI=False)
+
+    def dust_map(self, lam, Tdust, res, E_disk):
+        return self.e.dust_map_sed(lam, Tdust, res["n_sent"][lam - 1], E_disk)[0]
+
+
+def temperature_and_sed(backend, m, n_thermal, n_photons_lambda, lambdas=None, seed=1, n_chunks=None,
+                        ray_tracing=True):
+    """Returns Tdust, the nine Monte Carlo SED arrays ``sed_mc`` (9, N_phi, N_thet, n_lambda), ``n_sent``
+    (packets sent per wavelength in the SED step), ``sed_rt`` (n_lambda, nRT, N_type_flux; dust only) and the
+    wall time of each stage."""
+    t = {}
+    t0 = time.perf_counter()
+    th = backend.run_thermal(int(n_thermal), seed)
+    Tdust = backend.temp_finale(th["E_abs"])
+    t["thermal"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    M.repartition_energie(m, Tdust)
+    t["repartition_energie"] = time.perf_counter() - t0
+    nl = m.n_lambda
+    lambdas = list(lambdas) if lambdas is not None else list(range(1, nl + 1))
+    sed = np.zeros((9, m.cfg.N_phi, m.cfg.N_thet, nl))
+    n_sent = np.zeros(nl)
+    rt = m.rt
+    sed_rt = np.zeros((nl, rt["RT_n_incl"] * rt["RT_n_az"], rt["N_type_flux"]))
+    t["sed_mc"] = t["ray_tracing"] = 0.0
+    for lam in lambdas:
+        t0 = time.perf_counter()
+        r = backend.run_mono(lam, int(n_photons_lambda), seed + lam, n_chunks)
+        t["sed_mc"] += time.perf_counter() - t0
+        sed[..., lam - 1] = r["sed"][..., lam - 1]
+        n_sent[lam - 1] = r["n_sent"][lam - 1]
+        if ray_tracing:
+            t0 = time.perf_counter()
+            sed_rt[lam - 1] = backend.dust_map(lam, Tdust, r, m.extra["E_disk"][lam - 1])
+            t["ray_tracing"] += time.perf_counter() - t0
+    return dict(Tdust=Tdust, sed_mc=sed, n_sent=n_sent, sed_rt=sed_rt, seconds=t, thermal_counters=th["counters"])
+
+
+def sed_flux(m, sed_mc, n_sent):
+    """Monte Carlo SED per packet energy: sed(lambda) * E_totale(lambda) / n_phot_envoyes(lambda), the factor the
+    reference applies when it writes sed2 (output.f90: ecriture_sed), without the unit constants."""
+    E_tot = np.asarray(m.E_stars) + np.asarray(m.extra["E_disk"])
+    with np.errstate(divide="ignore", invalid="ignore"):
+        f = np.where(n_sent > 0, E_tot / n_sent, 0.0)
+    return sed_mc * f

@@ -64,3 +64,26 @@ def xI_close(xa, xb, rtol=1e-6, n_midplane_cells=0, atol_rel=1e-8):
     return bad.sum()
 
 
+
+
+class OracleBackend:
+    """The CPU oracle behind mcfost_amd.host.pipeline.temperature_and_sed (checker side of the end-to-end test)."""
+
+    def __init__(self, orc, n_threads=8):
+        self.o, self.nt, self.sed_tables = orc, n_threads, False
+
+    def run_thermal(self, n, seed):
+        return self.o.run_thermal(n, seed=seed, n_threads=self.nt)
+
+    def temp_finale(self, E_abs):
+        return self.o.temp_finale(E_abs)
+
+    def run_mono(self, lam, n2, seed, n_chunks):
+        if not self.sed_tables:   # the oracle copies the emission tables when it is built: take the SED step's
+            from oracle import Oracle
+            self.o = Oracle(self.o.model, 1e5)   # (the packet count only scales L_packet_th: not used by the SED step)
+            self.sed_tables = True
+        return self.o.run_mono(lam, n2, seed=seed, n_chunks=n_chunks, rt1=True, n_threads=self.nt)
+
+    def dust_map(self, lam, Tdust, res, E_disk):
+        return self.o.dust_map_sed(lam, res["xI_scatt"], Tdust, res["n_sent"][lam - 1], E_disk, n_threads=self.nt)

@@ -693,6 +693,36 @@ def test_rt1_dust_map_abi_errors(sed_small):
     e.close()
 
 
+def test_temperature_and_sed_end_to_end():
+    """BASELINE config 2 in small: temperature step (live), emission tables of the SED step from the GPU's own
+    Tdust, SED Monte Carlo of every wavelength, ray-traced dust SED -- engine vs CPU oracle through the same host
+    sequence (mcfost_amd/host/pipeline.py), each with its own noise, against the reference's gates
+    (test_suite/test_mcfost.py:88,104-109: p75 of the relative difference < 5 % on T, < 10 % on the SEDs)."""
+    import copy
+    from helpers import OracleBackend
+    from mcfost_amd.host import pipeline as P
+    cfg = M.small(RT_n_incl=3)
+    n_th, n2, nch = 400000, 800, 32
+    mg, mc = M.build_model(cfg), M.build_model(cfg)
+    e = _engine(mg, n_th)
+    g = P.temperature_and_sed(P.EngineBackend(e), mg, n_th, n2, seed=11, n_chunks=nch)
+    e.close()
+    c = P.temperature_and_sed(OracleBackend(_oracle(mc, n_th)), mc, n_th, n2, seed=23, n_chunks=nch)
+    sel = c["Tdust"] > 1.01 * cfg.T_min
+    assert np.percentile(np.abs(g["Tdust"][sel] / c["Tdust"][sel] - 1), 75) < 0.05
+    # Monte Carlo SED: flux per inclination bin and wavelength (azimuth summed), where the oracle has signal
+    fg, fc = P.sed_flux(mg, g["sed_mc"], g["n_sent"])[0].sum(axis=0), P.sed_flux(mc, c["sed_mc"], c["n_sent"])[0].sum(axis=0)
+    ok = c["sed_mc"][4].sum(axis=0) >= 200          # bins with at least 200 packets
+    assert ok.sum() > 0.5 * ok.size
+    assert np.percentile(np.abs(fg[ok] / fc[ok] - 1), 75) < 0.10
+    # ray-traced SED of the dust, Stokes I of every observer and wavelength
+    ig, ic_ = g["sed_rt"][:, :, 0], c["sed_rt"][:, :, 0]
+    assert (ic_ > 0).all()
+    assert np.percentile(np.abs(ig / ic_ - 1), 75) < 0.10
+    # and the stages ran on the device: every wavelength sent packets, every stream stopped by its count
+    assert (g["n_sent"] >= nch * n2).all()
+
+
 def test_ism_emission_on_the_gpu(small_model):
     """emit_packet's third branch (emit_packet_ISM, stars.f90:728-785) through mcgpu_set_ism: thermal step on
     2D / 3D / Voronoi grids and the SED step; a draw beyond frac_E_disk without the sphere is an error."""
