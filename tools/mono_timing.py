@@ -12,8 +12,10 @@ ap.add_argument("--n2", type=int, default=20000)
 ap.add_argument("--lams", default="5,15,25,35")
 ap.add_argument("--config", default="ref41")
 ap.add_argument("--no-rt1", action="store_true")
+ap.add_argument("--incl", type=int, default=3, help="RT_n_incl (observers of the xI_scatt deposits)")
 a = ap.parse_args()
-cfg = {"ref41": M.ref41, "ref41_3d": M.ref41_3d, "small": M.small}[a.config]()
+import dataclasses
+cfg = dataclasses.replace({"ref41": M.ref41, "ref41_3d": M.ref41_3d, "small": M.small}[a.config](), RT_n_incl=a.incl)
 m = M.build_model(cfg)
 e = Engine(m, 5e6)
 T = e.temp_finale(e.run_thermal(5_000_000, seed=3)["E_abs"])
