@@ -105,6 +105,17 @@ class Engine:
         self.lib = load_library()
         self.model = model
         self.ctx = C.c_void_p()
+        # If this process also uses torch (device_accumulators / device_xI hand the engine's buffers to it), torch
+        # must initialise its HIP context first: torch wheels carry their own HIP runtime, and brought up second it
+        # has been seen to report "No HIP GPUs are available".
+        import sys
+        t = sys.modules.get("torch")
+        if t is not None:
+            try:
+                if t.cuda.is_available():
+                    t.cuda.init()
+            except Exception:
+                pass
         rc = self.lib.mcgpu_create(C.c_int(device), C.byref(self.ctx))
         if rc:
             self.ctx = C.c_void_p()
