@@ -166,7 +166,15 @@ __device__ inline void deposit_rt1_wave(const DevModel& M, const MonoArgs& A, co
 #ifdef MCGPU_LANE_EMULATION
   (void)tile; (void)tile_addr; (void)tile_mask;
 #else
-  const int t = lane & 7, g = lane >> 3;
+  // the values a record receives: I (and Q, U, V with Stokes tracking) plus, with lsepar_contrib, the copy of I in the
+  // slot of its origin.  An atomic instruction costs the wave about the same whatever its lanes do (measured: half the
+  // records per instruction = 1.7x the time), so the 64 lanes of one instruction serve floor(64 / K) records with K
+  // lanes each: 12 records instead of 8 with Stokes tracking and contributions, 32 without Stokes tracking.
+  const int K = (POLA ? 4 : 1) + (A.contrib ? 1 : 0);
+  const int NR = 64 / K;                      // records per instruction
+  const int rl = lane / K, j = lane - rl * K; // this lane's record within a round, and which of its values
+  const bool lane_used = rl < NR;
+  const bool is_contrib = A.contrib && j == K - 1;
 #endif
   for (int q = 0; q < A.nRT; ++q) {
     double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
@@ -209,22 +217,25 @@ __device__ inline void deposit_rt1_wave(const DevModel& M, const MonoArgs& A, co
     if (POLA && (mask & 8u)) atomic_add_f64(rec + 3, v3);
     if (cslot && ((mask >> cslot) & 1u)) atomic_add_f64(rec + cslot, v0);
 #else
-    // stage this lane's record (slots the mask does not name are never read)
+    // stage this lane's record: values 0..3 = I, Q, U, V; the tile's mask word keeps the mask and the slot of the
+    // contribution copy (slots the mask does not name are never read)
     volatile double* my = tile + lane * XI_LINE;
     my[0] = v0; my[1] = v1; my[2] = v2; my[3] = v3;
-    if (cslot) my[cslot] = v0;
     tile_addr[lane] = (unsigned long long)rec;
-    tile_mask[lane] = mask;
+    tile_mask[lane] = mask | ((unsigned int)cslot << 8);
     __builtin_amdgcn_wave_barrier();
     const unsigned long long any = __ballot(mask != 0);
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      if (((any >> (8 * r)) & 0xFFull) == 0ull) continue;  // wave-uniform: nobody of this round deposits
-      const int src = 8 * r + g;
-      const unsigned int m = ((volatile unsigned int*)tile_mask)[src];
-      if ((m >> t) & 1u) {
-        double* dst = reinterpret_cast<double*>(((volatile unsigned long long*)tile_addr)[src]) + t;
-        atomic_add_f64(dst, ((volatile double*)tile)[src * XI_LINE + t]);
+    for (int r0 = 0; r0 < 64; r0 += NR) {
+      const unsigned long long span = (NR >= 64) ? ~0ull : (((1ull << NR) - 1ull) << r0);
+      if ((any & span) == 0ull) continue;  // wave-uniform: nobody of this round deposits
+      const int src = r0 + rl;
+      if (lane_used && src < 64) {
+        const unsigned int mw = ((volatile unsigned int*)tile_mask)[src];
+        const int slot = is_contrib ? (int)(mw >> 8) : j;
+        if ((mw >> slot) & 1u) {
+          double* dst = reinterpret_cast<double*>(((volatile unsigned long long*)tile_addr)[src]) + slot;
+          atomic_add_f64(dst, ((volatile double*)tile)[src * XI_LINE + (is_contrib ? 0 : j)]);
+        }
       }
     }
     __builtin_amdgcn_wave_barrier();
