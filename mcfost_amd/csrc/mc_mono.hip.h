@@ -219,17 +219,20 @@ __device__ inline void deposit_rt1_wave(const DevModel& M, const MonoArgs& A, co
 #else
     // stage this lane's record: values 0..3 = I, Q, U, V; the tile's mask word keeps the mask and the slot of the
     // contribution copy (slots the mask does not name are never read)
-    volatile double* my = tile + lane * XI_LINE;
-    my[0] = v0; my[1] = v1; my[2] = v2; my[3] = v3;
-    tile_addr[lane] = (unsigned long long)rec;
-    tile_mask[lane] = mask | ((unsigned int)cslot << 8);
-    __builtin_amdgcn_wave_barrier();
+    // ... densely: the lanes that deposit take consecutive places of the tile, so that the instructions are full
     const unsigned long long any = __ballot(mask != 0);
-    for (int r0 = 0; r0 < 64; r0 += NR) {
-      const unsigned long long span = (NR >= 64) ? ~0ull : (((1ull << NR) - 1ull) << r0);
-      if ((any & span) == 0ull) continue;  // wave-uniform: nobody of this round deposits
+    const int n_act = __popcll(any);
+    if (mask) {
+      const int place = __popcll(any & ((1ull << lane) - 1ull));
+      volatile double* my = tile + place * XI_LINE;
+      my[0] = v0; my[1] = v1; my[2] = v2; my[3] = v3;
+      tile_addr[place] = (unsigned long long)rec;
+      tile_mask[place] = mask | ((unsigned int)cslot << 8);
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int r0 = 0; r0 < n_act; r0 += NR) {
       const int src = r0 + rl;
-      if (lane_used && src < 64) {
+      if (lane_used && src < n_act) {
         const unsigned int mw = ((volatile unsigned int*)tile_mask)[src];
         const int slot = is_contrib ? (int)(mw >> 8) : j;
         if ((mw >> slot) & 1u) {
