@@ -224,18 +224,21 @@ struct Lds {
   float* g;         // n_lambda
 };
 
-__host__ __device__ inline size_t lds_doubles(const DevModel& M) {
-  return (size_t)(M.n_rad + 1) + M.n_rad + M.n_rad + M.n_rad + M.n_az + M.n_lambda + M.n_lambda + M.n_T +
-         (M.n_lambda + 1) + M.n_lambda + (size_t)M.n_lambda * M.n_T + (M.nang + 1);
+// mono = the SED-mode kernels (mc_mono*.hip.h): no re-emission, one phase-function column -- they leave out the
+// thermal tables (log_Qcool, the emission spectrum, frac_E_stars, the re-emission CDF: 41 KB on ref4.1) and stage
+// only column p_lambda of prob_s11, which leaves the LDS to the per-lane ray-tracing scratch and to more waves.
+__host__ __device__ inline size_t lds_doubles(const DevModel& M, bool mono = false) {
+  const size_t geo = (size_t)(M.n_rad + 1) + M.n_rad + M.n_rad + M.n_rad + M.n_az + M.n_lambda + M.n_lambda + (M.nang + 1);
+  return mono ? geo : geo + M.n_T + (M.n_lambda + 1) + M.n_lambda + (size_t)M.n_lambda * M.n_T;
 }
-__host__ __device__ inline size_t lds_floats(const DevModel& M) {
-  return (size_t)M.n_lambda + (size_t)(M.nang + 1) * (M.p_lambda_fixed ? 1 : M.n_lambda) + M.n_lambda;
+__host__ __device__ inline size_t lds_floats(const DevModel& M, bool mono = false) {
+  return (size_t)M.n_lambda + (size_t)(M.nang + 1) * ((mono || M.p_lambda_fixed) ? 1 : M.n_lambda) + M.n_lambda;
 }
-__host__ __device__ inline size_t lds_bytes(const DevModel& M) {
-  return lds_doubles(M) * sizeof(double) + lds_floats(M) * sizeof(float);
+__host__ __device__ inline size_t lds_bytes(const DevModel& M, bool mono = false) {
+  return lds_doubles(M, mono) * sizeof(double) + lds_floats(M, mono) * sizeof(float);
 }
 
-__device__ inline Lds lds_carve(double* base, const DevModel& M) {
+__device__ inline Lds lds_carve(double* base, const DevModel& M, bool mono = false) {
   Lds T;
   double* p = base;
   T.r_lim_2 = p; p += M.n_rad + 1;
@@ -245,14 +248,18 @@ __device__ inline Lds lds_carve(double* base, const DevModel& M) {
   T.tan_phi = p; p += M.n_az;
   T.kappa = p; p += M.n_lambda;
   T.kabs = p; p += M.n_lambda;
-  T.lq = p; p += M.n_T;
-  T.cum = p; p += M.n_lambda + 1;
-  T.fstar = p; p += M.n_lambda;
-  T.cdf = p; p += (size_t)M.n_lambda * M.n_T;
+  if (mono) {
+    T.lq = p; T.cum = p; T.fstar = p; T.cdf = p;  // (not staged, never read by those kernels)
+  } else {
+    T.lq = p; p += M.n_T;
+    T.cum = p; p += M.n_lambda + 1;
+    T.fstar = p; p += M.n_lambda;
+    T.cdf = p; p += (size_t)M.n_lambda * M.n_T;
+  }
   T.cost = p; p += M.nang + 1;
   float* f = reinterpret_cast<float*>(p);
   T.albedo = f; f += M.n_lambda;
-  T.prob = f; f += (size_t)(M.nang + 1) * (M.p_lambda_fixed ? 1 : M.n_lambda);
+  T.prob = f; f += (size_t)(M.nang + 1) * ((mono || M.p_lambda_fixed) ? 1 : M.n_lambda);
   T.g = f;
   return T;
 }
@@ -277,6 +284,21 @@ __device__ inline void lds_stage(const Lds& T, const DevModel& M) {
   stage(T.cost, M.cos_tab, (size_t)M.nang + 1);
   stage(T.albedo, M.albedo, (size_t)M.n_lambda);
   stage(T.prob, M.prob_s11, (size_t)(M.nang + 1) * (M.p_lambda_fixed ? 1 : M.n_lambda));
+  stage(T.g, M.tab_g, (size_t)M.n_lambda);
+}
+
+// the tables of the SED-mode kernels (lds_carve(..., mono = true)): T.prob is column p_lambda of prob_s11
+__device__ inline void lds_stage_mono(const Lds& T, const DevModel& M, int p_lambda) {
+  stage(T.r_lim_2, M.r_lim_2, (size_t)M.n_rad + 1);
+  stage(T.zmax, M.zmax, (size_t)M.n_rad);
+  stage(T.ch, M.ch, (size_t)M.n_rad);
+  for (int i = threadIdx.x; i < M.n_rad; i += blockDim.x) T.rzn[i] = (double)M.nz / M.zmax[i];
+  stage(T.tan_phi, M.tan_phi_lim, (size_t)M.n_az);
+  stage(T.kappa, M.kappa, (size_t)M.n_lambda);
+  stage(T.kabs, M.kappa_abs, (size_t)M.n_lambda);
+  stage(T.cost, M.cos_tab, (size_t)M.nang + 1);
+  stage(T.albedo, M.albedo, (size_t)M.n_lambda);
+  stage(T.prob, M.prob_s11 + (size_t)(M.nang + 1) * (p_lambda - 1), (size_t)M.nang + 1);
   stage(T.g, M.tab_g, (size_t)M.n_lambda);
 }
 
@@ -1019,7 +1041,7 @@ __device__ __forceinline__ void interact(const Lds& T, const DevModel& M, const 
                                          double S[4], bool& flag_star, bool& flag_scatt,
                                          unsigned int& c_scatt, unsigned int& c_abs, EnergyFn cell_energy,
                                          const double* volume_of_cell, bool forced = false,
-                                         const float* prob_forced = nullptr) {
+                                         const float* prob_forced = nullptr, int lds_col = -1) {
   const bool scat = forced || (g[0] < T.albedo[lambda - 1]);  // dust_transfer.f90:1284
   const float rand = g[1], rand2 = g[2];
   int itheta = 1;
@@ -1029,8 +1051,9 @@ __device__ __forceinline__ void interact(const Lds& T, const DevModel& M, const 
     c_scatt++;
     if (M.aniso_method == 1) {
       // angle_diff_theta_pos (scattering.f90:1433-1475)
-      const float* prob = prob_forced ? prob_forced
-                                      : T.prob + (M.p_lambda_fixed ? 0 : (size_t)(M.nang + 1) * (lambda - 1));
+      // (lds_col >= 0: that column of T.prob -- the SED-mode tables hold only column p_lambda, as column 0)
+      const size_t col = lds_col >= 0 ? (size_t)lds_col : (M.p_lambda_fixed ? (size_t)0 : (size_t)(lambda - 1));
+      const float* prob = prob_forced ? prob_forced : T.prob + (size_t)(M.nang + 1) * col;
       int kmin = 0, kmax = M.nang, kk = (kmin + kmax) / 2;
       while ((kmax - kmin) > 1) {
         if (prob[kk] < rand) kmin = kk; else kmax = kk;

@@ -65,8 +65,10 @@ struct RtScratch {
   double* sinw;
 };
 
-__host__ __device__ inline size_t mono_lds_bytes(const DevModel& M, int nRT, int threads, bool pola) {
-  size_t b = (lds_bytes(M) + 7) / 8 * 8;
+// slim = the workgroup stages only the tables the SED mode reads (lds_carve(..., mono = true)); the Voronoi body keeps
+// the full set (hipcc 7.2 crashes in simplifycfg on that body with the slim one)
+__host__ __device__ inline size_t mono_lds_bytes(const DevModel& M, int nRT, int threads, bool pola, bool slim) {
+  size_t b = (lds_bytes(M, slim) + 7) / 8 * 8;
   b += (size_t)6 * (M.nang + 1) * sizeof(float);                     // the Mueller columns of p_lambda
   b = (b + 7) / 8 * 8;
   b += (size_t)nRT * threads * (pola ? 2 * sizeof(double) : 0);      // cosw, sinw
@@ -257,11 +259,11 @@ struct MonoLds {
 };
 
 template <bool POLA>
-__device__ inline MonoLds mono_lds_setup(const DevModel& M, const MonoArgs& A, double* lds_base) {
+__device__ inline MonoLds mono_lds_setup(const DevModel& M, const MonoArgs& A, double* lds_base, bool slim) {
   MonoLds L;
   const int na1 = M.nang + 1;
-  L.mu = reinterpret_cast<float*>(lds_base + (lds_bytes(M) + 7) / 8);
-  double* p = lds_base + (lds_bytes(M) + 7) / 8 + ((size_t)6 * na1 * sizeof(float) + 7) / 8;
+  L.mu = reinterpret_cast<float*>(lds_base + (lds_bytes(M, slim) + 7) / 8);
+  double* p = lds_base + (lds_bytes(M, slim) + 7) / 8 + ((size_t)6 * na1 * sizeof(float) + 7) / 8;
   L.R.cosw = p;
   L.R.sinw = p + (POLA ? (size_t)A.nRT * blockDim.x : 0);
   p += (POLA ? (size_t)2 * A.nRT * blockDim.x : 0);
@@ -315,16 +317,16 @@ __device__ inline bool mono_attenuate(const Lds& T, int lambda, double S[4]) {
 // SCOUT: no deposits, no SED; records hits.  Otherwise the COMMIT pass.
 template <bool L3D, bool POLA, bool DARK, bool SCOUT>
 __device__ __forceinline__ void mono_body(const DevModel& M, const MonoArgs& A, double* lds_base) {
-  const Lds T = lds_carve(lds_base, M);
-  lds_stage(T, M);
+  const Lds T = lds_carve(lds_base, M, true);
+  lds_stage_mono(T, M, A.p_lambda);
   const int na1 = M.nang + 1;
-  const MonoLds ML = mono_lds_setup<POLA>(M, A, lds_base);
+  const MonoLds ML = mono_lds_setup<POLA>(M, A, lds_base, true);
   const float* mu = ML.mu;
   const RtScratch& R = ML.R;
   double* const tile = ML.tile;
   unsigned long long* const tile_addr = ML.tile_addr;
   unsigned int* const tile_mask = ML.tile_mask;
-  const float* prob_p = M.prob_s11 + (size_t)na1 * (A.p_lambda - 1);
+
 
   const int lane = threadIdx.x & 63;
   const int n_rad = M.n_rad, nz = M.nz;
@@ -414,7 +416,7 @@ __device__ __forceinline__ void mono_body(const DevModel& M, const MonoArgs& A, 
         double u1, v1, w1;
         int lam = lambda;
         interact<POLA>(T, M, g, lam, u, v, w, u1, v1, w1, S, flag_star, flag_scatt, c_scatt, c_abs,
-                       []() { return 0.0; }, M.volume, true, prob_p);
+                       []() { return 0.0; }, M.volume, true, nullptr, 0);  // T.prob = column p_lambda
         u = u1; v = v1; w = w1;
         st = S_NEWFLIGHT;
       }
@@ -536,7 +538,7 @@ __device__ __forceinline__ void mono_body(const DevModel& M, const MonoArgs& A, 
 }
 
 template <bool L3D, bool POLA, bool DARK, bool SCOUT>
-__global__ void __launch_bounds__(256) k_mono(const DevModel M, const MonoArgs A) {
+__global__ void __launch_bounds__(512) k_mono(const DevModel M, const MonoArgs A) {
   extern __shared__ double lds_raw[];
   mono_body<L3D, POLA, DARK, SCOUT>(M, A, lds_raw);
 }

@@ -14,7 +14,7 @@ __device__ __forceinline__ void mono_body_voro(const DevModel& M, const MonoArgs
   const Lds T = lds_carve(lds_base, M);
   lds_stage(T, M);
   const int na1 = M.nang + 1;
-  const MonoLds ML = mono_lds_setup<POLA>(M, A, lds_base);
+  const MonoLds ML = mono_lds_setup<POLA>(M, A, lds_base, false);
   const float* prob_p = M.prob_s11 + (size_t)na1 * (A.p_lambda - 1);
   const int lane = threadIdx.x & 63;
   const int lambda = A.lambda;

@@ -943,8 +943,26 @@ template <bool SCOUT>
 static int launch_mono(mcgpu_ctx* ctx, const MonoArgs& A, int grid_blocks, int block_threads) {
   const DevModel& M = ctx->M;
   const bool pola = ctx->lsepar_pola != 0, dark = M.dark != nullptr, l3d = M.l3D != 0;
-  const int threads = (block_threads > 0 && block_threads <= 256 && block_threads % 64 == 0) ? block_threads : 256;
-  const size_t lds = mono_lds_bytes(M, A.nRT, threads, pola);
+  // workgroup size: the one that keeps the most wavefronts on a CU -- 8 at most with the kernel's 256 VGPRs; the LDS
+  // of a workgroup is the shared tables plus the per-lane ray-tracing scratch, which grows with the observer count
+  int threads = 0;
+  const bool slim = !ctx->voro;             // (mono_lds_bytes)
+  const int max_threads = ctx->voro ? 256 : 512;
+  if (block_threads > 0 && block_threads <= max_threads && block_threads % 64 == 0) {
+    threads = block_threads;
+  } else {
+    int best_waves = 0;
+    for (int th = max_threads; th >= 64; th -= 64) {
+      const size_t l = mono_lds_bytes(M, A.nRT, th, pola, slim);
+      if (l > 160 * 1024) continue;
+      int per_cu = (int)((160 * 1024) / l);
+      if (per_cu > max_threads / th) per_cu = max_threads / th;
+      const int waves = per_cu * th / 64;
+      if (waves > best_waves) { best_waves = waves; threads = th; }
+    }
+    if (!threads) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "too many ray-tracing directions for the LDS of one CU");
+  }
+  const size_t lds = mono_lds_bytes(M, A.nRT, threads, pola, slim);
   if (lds > 160 * 1024) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "too many ray-tracing directions for the LDS of one CU");
   const void* fn;
 #define PICK(a, b, c) fn = (const void*)k_mono<a, b, c, SCOUT>
