@@ -11,6 +11,14 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port():
+    """A TCP port nobody listens on right now (a fixed one can still be in TIME_WAIT from the previous test)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def _worker(rank, world, port, n_packets, out_dir):
     sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
     import torch.distributed as dist
@@ -39,7 +47,7 @@ def test_two_ranks_equal_one(tmp_path):
     from mcfost_amd.host import model as M
     from oracle import Oracle
     n = 3001  # odd: uneven shards
-    port = 29500 + (os.getpid() % 1000)
+    port = _free_port()
     mp.spawn(_worker, args=(2, port, n, str(tmp_path)), nprocs=2, join=True)
     m = M.build_model(M.small())
     orc = Oracle(m, n)
