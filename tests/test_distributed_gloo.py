@@ -87,7 +87,7 @@ def test_sed_mode_streams_shard_over_ranks(tmp_path):
     from helpers import sed_model
     from mcfost_amd.host import model as M
     from oracle import Oracle
-    port = 29500 + ((os.getpid() + 7) % 1000)
+    port = _free_port()
     mp.spawn(_worker_mono, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     m = sed_model(M.small(), n_thermal=20000)
     one = Oracle(m, 1e5).run_mono(9, 5, seed=77, n_chunks=13)
