@@ -65,8 +65,8 @@ struct RtScratch {
   double* sinw;
 };
 
-// slim = the workgroup stages only the tables the SED mode reads (lds_carve(..., mono = true)); the Voronoi body keeps
-// the full set (hipcc 7.2 crashes in simplifycfg on that body with the slim one)
+// slim = the workgroup stages only the tables the SED mode reads (lds_carve(..., mono = true)).  (The phase-function
+// column is selected by index, interact(..., lds_col): choosing between two LDS pointers there crashed hipcc 7.2.)
 __host__ __device__ inline size_t mono_lds_bytes(const DevModel& M, int nRT, int threads, bool pola, bool slim) {
   size_t b = (lds_bytes(M, slim) + 7) / 8 * 8;
   b += (size_t)6 * (M.nang + 1) * sizeof(float);                     // the Mueller columns of p_lambda

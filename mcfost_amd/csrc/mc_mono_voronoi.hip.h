@@ -11,11 +11,9 @@ namespace mcgpu {
 template <bool POLA, bool SCOUT>
 __device__ __forceinline__ void mono_body_voro(const DevModel& M, const MonoArgs& A, const VoroGrid& G,
                                                double* lds_base) {
-  const Lds T = lds_carve(lds_base, M);
-  lds_stage(T, M);
-  const int na1 = M.nang + 1;
-  const MonoLds ML = mono_lds_setup<POLA>(M, A, lds_base, false);
-  const float* prob_p = M.prob_s11 + (size_t)na1 * (A.p_lambda - 1);
+  const Lds T = lds_carve(lds_base, M, true);
+  lds_stage_mono(T, M, A.p_lambda);
+  const MonoLds ML = mono_lds_setup<POLA>(M, A, lds_base, true);
   const int lane = threadIdx.x & 63;
   const int lambda = A.lambda;
 
@@ -97,7 +95,7 @@ __device__ __forceinline__ void mono_body_voro(const DevModel& M, const MonoArgs
         double u1, v1, w1;
         int lam = lambda;
         interact<POLA>(T, M, g, lam, u, v, w, u1, v1, w1, S, flag_star, flag_scatt, c_scatt, c_abs,
-                       []() { return 0.0; }, M.volume, true, prob_p);
+                       []() { return 0.0; }, M.volume, true, nullptr, 0);  // T.prob = column p_lambda
         u = u1; v = v1; w = w1;
         st = S_NEWFLIGHT;
       }
@@ -176,7 +174,7 @@ __device__ __forceinline__ void mono_body_voro(const DevModel& M, const MonoArgs
 }
 
 template <bool POLA, bool SCOUT>
-__global__ void __launch_bounds__(256) k_mono_voro(const DevModel M, const MonoArgs A, const VoroGrid G) {
+__global__ void __launch_bounds__(512) k_mono_voro(const DevModel M, const MonoArgs A, const VoroGrid G) {
   extern __shared__ double lds_raw[];
   mono_body_voro<POLA, SCOUT>(M, A, G, lds_raw);
 }

@@ -946,8 +946,8 @@ static int launch_mono(mcgpu_ctx* ctx, const MonoArgs& A, int grid_blocks, int b
   // workgroup size: the one that keeps the most wavefronts on a CU -- 8 at most with the kernel's 256 VGPRs; the LDS
   // of a workgroup is the shared tables plus the per-lane ray-tracing scratch, which grows with the observer count
   int threads = 0;
-  const bool slim = !ctx->voro;             // (mono_lds_bytes)
-  const int max_threads = ctx->voro ? 256 : 512;
+  const bool slim = true;                   // (mono_lds_bytes)
+  const int max_threads = 512;
   if (block_threads > 0 && block_threads <= max_threads && block_threads % 64 == 0) {
     threads = block_threads;
   } else {
