@@ -137,8 +137,8 @@ __device__ inline void rt1_integ_ray(const Lds& T, const DevModel& M, const RtAr
 template <bool L3D, bool POLA>
 __global__ void __launch_bounds__(256) k_rt1_dust_map(const DevModel M, const RtArgs A) {
   extern __shared__ double lds_raw[];
-  const Lds T = lds_carve(lds_raw, M);
-  lds_stage(T, M);
+  const Lds T = lds_carve(lds_raw, M, true);  // geometry, kappa, albedo: the SED-mode table set
+  lds_stage_mono(T, M, 1);
   __syncthreads();
   const int rays_per_dir = RT_N_RAD * RT_N_PHI;  // 3840 = 60 wavefronts: a wavefront never straddles two directions
   const int n_rays = A.nRT * rays_per_dir;
@@ -174,8 +174,8 @@ __global__ void __launch_bounds__(256) k_rt1_dust_map(const DevModel M, const Rt
 template <bool L3D, bool POLA>
 __global__ void __launch_bounds__(256) k_rt1_image(const DevModel M, const RtArgs A) {
   extern __shared__ double lds_raw[];
-  const Lds T = lds_carve(lds_raw, M);
-  lds_stage(T, M);
+  const Lds T = lds_carve(lds_raw, M, true);  // geometry, kappa, albedo: the SED-mode table set
+  lds_stage_mono(T, M, 1);
   __syncthreads();
   const int lanes = blockDim.x < 64 ? (int)blockDim.x : 64;  // (the CPU emulation of the tests runs one lane)
   const int lane = threadIdx.x % lanes;

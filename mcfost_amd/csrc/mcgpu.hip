@@ -1290,7 +1290,7 @@ static int rt1_prepare(mcgpu_ctx* ctx, const mcgpu_rt_opts* o, const float* tab_
 
 template <bool IMAGE>
 static int rt1_launch(mcgpu_ctx* ctx, const RtArgs& A, int blocks) {
-  const size_t lds = lds_bytes(ctx->M);
+  const size_t lds = lds_bytes(ctx->M, true);
   const bool pola = ctx->N_type_flux == 4 || ctx->N_type_flux == 8, l3d = ctx->M.l3D != 0;
 #define RT1_GO(a, b) do {                                                                                          \
     const void* fn = IMAGE ? (const void*)k_rt1_image<a, b> : (const void*)k_rt1_dust_map<a, b>;                    \
