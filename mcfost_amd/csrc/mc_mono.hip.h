@@ -40,6 +40,7 @@ struct MonoArgs {
   const unsigned long long* seq0;       // SCOUT: [n_chunks] first sequence number of this batch
   unsigned long long batch;             // SCOUT: packets per stream in this batch
   unsigned char* hits;                  // SCOUT: [n_active * batch] 1 = binned in capt_sup
+  unsigned long long* hit_count;        // COMMIT (may be null): [n_chunks] packets of the launch binned in capt_sup
   // ray tracing method 1
   int RT_n_incl, nRT;                   // nRT = RT_n_incl * RT_n_az
   const double* rt_u;                   // [nRT] tab_u_rt(ibin,iaz), q = ibin-1 + RT_n_incl*(iaz-1)
@@ -301,7 +302,7 @@ __device__ inline void mono_item(const MonoArgs& A, unsigned long long my, unsig
       if (A.item_base[mid] <= my) lo = mid; else hi = mid;
     }
     chunk = (unsigned long long)lo;
-    seq = my - A.item_base[lo];
+    seq = my - A.item_base[lo] + (A.seq0 ? A.seq0[lo] : 0ull);  // (seq0: where this launch's range of the stream starts)
   }
 }
 
@@ -351,6 +352,11 @@ __device__ __forceinline__ void mono_body(const DevModel& M, const MonoArgs& A, 
       if (!flag_ism) {
         const int capt = capteur<POLA, true>(M, SCOUT ? nullptr : A.sed, lambda, u, v, w, S, flag_star, flag_scatt);
         if (SCOUT) { if (capt == A.capt_sup) A.hits[my_item] = 1; }
+        else if (A.hit_count && capt == A.capt_sup) {
+          unsigned long long ch, sq;
+          mono_item<false>(A, my_item, ch, sq);
+          atomicAdd(&A.hit_count[ch], 1ull);
+        }
         if (capt > 0) c_esc++;
       }
       st = S_EMIT;

@@ -34,6 +34,11 @@ __device__ __forceinline__ void mono_body_voro(const DevModel& M, const MonoArgs
       if (!flag_ism) {
         const int capt = capteur<POLA, true>(M, SCOUT ? nullptr : A.sed, lambda, u, v, w, S, flag_star, flag_scatt);
         if (SCOUT) { if (capt == A.capt_sup) A.hits[my_item] = 1; }
+        else if (A.hit_count && capt == A.capt_sup) {
+          unsigned long long ch, sq;
+          mono_item<false>(A, my_item, ch, sq);
+          atomicAdd(&A.hit_count[ch], 1ull);
+        }
         if (capt > 0) c_esc++;
       }
       st = S_EMIT;

@@ -62,7 +62,7 @@ struct mcgpu_ctx {
   double* d_xI = nullptr;
   size_t n_xI = 0;
   double* d_prob_E = nullptr;               // prob_E_cell(0:n_cells) of the current wavelength
-  unsigned long long* d_mono_u64 = nullptr; // [4 * n_chunks + 1]: need | sent | item_base(+1)
+  unsigned long long* d_mono_u64 = nullptr; // [5 * n_chunks + 1]: need | sent | item_base(+1) | start | hit_count
   int* d_mono_i32 = nullptr;                // [2 * n_chunks]: active | done
   int mono_chunks = 0;
   unsigned char* d_hits = nullptr;
@@ -1013,11 +1013,12 @@ extern "C" int mcgpu_run_mono(mcgpu_ctx* ctx, const mcgpu_mono_opts* o, double f
     if (ctx->d_mono_u64) hipFree(ctx->d_mono_u64);
     if (ctx->d_mono_i32) hipFree(ctx->d_mono_i32);
     ctx->d_mono_u64 = nullptr; ctx->d_mono_i32 = nullptr; ctx->mono_chunks = 0;
-    HIPCHK(hipMalloc((void**)&ctx->d_mono_u64, ((size_t)3 * nc + 1) * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc((void**)&ctx->d_mono_u64, ((size_t)5 * nc + 1) * sizeof(unsigned long long)));
     HIPCHK(hipMalloc((void**)&ctx->d_mono_i32, (size_t)2 * nc * sizeof(int)));
     ctx->mono_chunks = nc;
   }
   unsigned long long *d_need = ctx->d_mono_u64, *d_sent = d_need + nc, *d_base = d_sent + nc;
+  unsigned long long *d_start = d_base + nc + 1, *d_hitcnt = d_start + nc;
   int *d_active = ctx->d_mono_i32, *d_done = d_active + nc;
   if (prob_E_cell) {
     if (!ctx->d_prob_E) HIPCHK(hipMalloc((void**)&ctx->d_prob_E, ((size_t)M.n_cells + 1) * sizeof(double)));
@@ -1066,8 +1067,16 @@ extern "C" int mcgpu_run_mono(mcgpu_ctx* ctx, const mcgpu_mono_opts* o, double f
   double lim_d = std::ceil((double)o->n_phot_lim);
   if (!(lim_d >= 0.0)) lim_d = 0.0;
   const unsigned long long lim = lim_d > 9.0e18 ? ~0ull : (unsigned long long)lim_d;
-  std::vector<unsigned long long> need(nc, o->n_photons2), sent(nc, 0ull);
+  // Speculative commit: after a short first scout batch has measured the rate at which packets land in capt_sup,
+  // most of every stream -- as many packets as can be sent with (statistical) certainty before the stopping packet,
+  // 7 sigma short of it -- is committed directly, with its hits counted, and only the remainder is scouted.  Without
+  // it every packet is transported twice.  Should a stream reach its count inside the speculative range after all,
+  // the accumulators are cleared and the call starts over without speculation (so: only when the call owns them).
+  bool speculate = !o->accumulate && !getenv("MCGPU_NO_SPECULATION");
+restart:
+  std::vector<unsigned long long> need(nc, o->n_photons2), sent(nc, 0ull), start(nc, 0ull);
   std::vector<int> active, done(nc, 0);
+  bool probed = false;
   if (o->n_photons2 >= lim) {
     // a stream cannot collect n_photons2 packets in capt_sup out of fewer than n_photons2 sent: every stream runs
     // to n_phot_lim and nothing has to be scouted (image mode, run_image_mc: p_nnfot2 => nnfot2, :507-508, 711-713)
@@ -1085,6 +1094,7 @@ extern "C" int mcgpu_run_mono(mcgpu_ctx* ctx, const mcgpu_mono_opts* o, double f
     unsigned long long max_need = 0;
     for (int c : active) if (need[c] > max_need) max_need = need[c];
     double b = 1.25 * (double)max_need / rate + 64.0;
+    if (speculate && !probed) b = 0.05 * (double)max_need / rate + 64.0;  // the probe that measures the rate
     const double bmax = 2.0e9 / (double)na;
     if (b > bmax) b = bmax;
     unsigned long long max_left = 0;  // no stream can use more than what n_phot_lim leaves it
@@ -1125,15 +1135,63 @@ extern "C" int mcgpu_run_mono(mcgpu_ctx* ctx, const mcgpu_mono_opts* o, double f
     active.swap(still);
     if (scout_packets > 0 && hits_found > 0) rate = (double)hits_found / (double)scout_packets;
     else rate *= 0.25;  // nothing landed in capt_sup yet: widen the next batch
+
+    if (speculate && !probed) {
+      probed = true;
+      std::vector<unsigned long long> extra(nc, 0ull), cnt(nc, 0ull);
+      unsigned long long total_extra = 0;
+      if (hits_found >= 100)
+        for (int c : active) {
+          const double nr = (double)need[c];
+          if (nr < 400.0) continue;
+          const double margin = 7.0 / std::sqrt(nr) + 0.02 + 3.0 / std::sqrt((double)hits_found);
+          double n1 = std::floor(nr * (1.0 - margin) / rate);
+          if (n1 < 0.0) n1 = 0.0;
+          if (n1 > (double)(lim - sent[c])) n1 = (double)(lim - sent[c]);
+          extra[c] = (unsigned long long)n1;
+          total_extra += extra[c];
+        }
+      if (total_extra > 0) {
+        std::vector<unsigned long long> base(nc + 1, 0ull);
+        for (int c = 0; c < nc; ++c) { cnt[c] = sent[c] + extra[c]; base[c + 1] = base[c] + cnt[c]; }
+        HIPCHK(hipMemcpyAsync(d_base, base.data(), ((size_t)nc + 1) * sizeof(unsigned long long), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemsetAsync(d_hitcnt, 0, nc * sizeof(unsigned long long), ctx->stream));
+        HIPCHK(hipMemsetAsync(ctx->d_counters + 8, 0, sizeof(unsigned long long), ctx->stream));
+        A.item_base = d_base; A.n_items = base[nc]; A.active = nullptr; A.seq0 = nullptr; A.hits = nullptr; A.batch = 0;
+        A.hit_count = d_hitcnt;
+        if ((rc = launch_mono<false>(ctx, A, o->grid_blocks, o->block_threads))) return rc;
+        A.hit_count = nullptr;
+        std::vector<unsigned long long> hc(nc);
+        HIPCHK(hipMemcpyAsync(hc.data(), d_hitcnt, nc * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(hipMemcpy(&dev_err, ctx->d_err, sizeof(int), hipMemcpyDeviceToHost));
+        if (dev_err) { ctx->err = "device error " + std::to_string(dev_err) + " in the commit pass"; return MCGPU_ERR_KERNEL; }
+        bool overshoot = false;
+        for (int c : active) if (extra[c] > 0 && hc[c] >= o->n_photons2) overshoot = true;
+        if (overshoot) {  // (a 7-sigma event) clear what this call accumulated and run it the plain way
+          speculate = false;
+          HIPCHK(hipMemsetAsync(ctx->d_accum, 0, ctx->n_accum * sizeof(double), ctx->stream));
+          HIPCHK(hipMemsetAsync(ctx->d_counters, 0, 16 * sizeof(unsigned long long), ctx->stream));
+          if (o->rt1) HIPCHK(hipMemsetAsync(ctx->d_xI, 0, n_dev * sizeof(double), ctx->stream));
+          goto restart;
+        }
+        for (int c = 0; c < nc; ++c) start[c] = cnt[c];   // committed so far: [0, start)
+        for (int c : active)
+          if (extra[c] > 0) { need[c] = o->n_photons2 - hc[c]; sent[c] += extra[c]; }
+        HIPCHK(hipMemcpyAsync(d_need, need.data(), nc * sizeof(unsigned long long), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(d_sent, sent.data(), nc * sizeof(unsigned long long), hipMemcpyHostToDevice, ctx->stream));
+      }
+    }
   }
 
   // ---- COMMIT: exactly the packets s < K of every stream, with deposits -----------------------
   std::vector<unsigned long long> base(nc + 1, 0ull);
-  for (int c = 0; c < nc; ++c) base[c + 1] = base[c] + sent[c];
+  for (int c = 0; c < nc; ++c) base[c + 1] = base[c] + (sent[c] - start[c]);
   if (n_sent_chunk) for (int c = 0; c < nc; ++c) n_sent_chunk[c] = sent[c];
   HIPCHK(hipMemcpyAsync(d_base, base.data(), ((size_t)nc + 1) * sizeof(unsigned long long), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(d_start, start.data(), nc * sizeof(unsigned long long), hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->d_counters + 8, 0, sizeof(unsigned long long), ctx->stream));
-  A.item_base = d_base; A.n_items = base[nc]; A.active = nullptr; A.seq0 = nullptr; A.hits = nullptr; A.batch = 0;
+  A.item_base = d_base; A.n_items = base[nc]; A.active = nullptr; A.seq0 = d_start; A.hits = nullptr; A.batch = 0;
   if (A.n_items > 0 && (rc = launch_mono<false>(ctx, A, o->grid_blocks, o->block_threads))) return rc;
   HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
   ctx->launched = true;

@@ -535,6 +535,26 @@ def test_sed_mode_variants():
     _mono_parity(sed_model(M.small()), 4, 8, 12, rt1=False)                              # no RT deposits
 
 
+def test_sed_mode_speculative_commit(sed_small, monkeypatch):
+    """Counts large enough for the speculative commit (most of every stream is deposited right after a short probe,
+    only the rest is scouted): every stream still stops at the oracle's packet, same SED bins and xI_scatt; and the
+    plain two-pass path (MCGPU_NO_SPECULATION) gives the same."""
+    m = sed_small
+    for lam in (3, 9):
+        a, b = _mono_parity(m, lam, 700, 40 + lam, n_chunks=16)
+        assert a["sed"][4][0, m.capt_sup - 1, lam - 1] == 16 * 700
+    monkeypatch.setenv("MCGPU_NO_SPECULATION", "1")
+    _mono_parity(m, 9, 700, 49, n_chunks=16)
+    monkeypatch.delenv("MCGPU_NO_SPECULATION")
+    # accumulate = 1 (the call does not own the accumulators): no speculation, still exact
+    e, o = _engine(m, 1e5), _oracle(m, 1e5)
+    e.run_mono(3, 5, seed=1, n_chunks=16)
+    a = e.run_mono(9, 700, seed=49, n_chunks=16, accumulate=True)
+    b = o.run_mono(9, 700, seed=49, n_chunks=16, n_threads=8)
+    assert np.array_equal(a["n_sent_chunk"], b["n_sent_chunk"])
+    e.close()
+
+
 def test_sed_mode_packet_cap_and_launch_geometry(sed_small):
     m = sed_small
     a, b = _mono_parity(m, 3, 100000, 5, n_chunks=16, n_phot_lim=700.0)   # n_phot_lim ends every stream
