@@ -75,8 +75,11 @@ def _worker_mono(rank, world, port, out_dir):
     m = sed_model(M.small(), n_thermal=20000)
     orc = Oracle(m, 1e5)
     res = D.run_mono_sharded(orc.run_mono, 9, 5, 13, 77, rank, world)   # 13 streams: uneven split
+    # the ray-traced SED of the dust from the all-reduced xI_scatt: every rank holds the same input, so any rank
+    # (or each rank for its share of the observers) can compute it
+    rt = orc.dust_map_sed(9, res["xI_scatt"], m.extra["Tdust"], res["n_sent"][8], m.extra["E_disk"][8])
     np.savez(os.path.join(out_dir, f"m{rank}.npz"), sed=res["sed"], ns=res["n_sent"], per=res["n_sent_chunk"],
-             xI=res["xI_scatt"], cnt=np.array(list(res["counters"].values())))
+             xI=res["xI_scatt"], cnt=np.array(list(res["counters"].values())), rt=rt)
     dist.destroy_process_group()
 
 
@@ -92,8 +95,10 @@ def test_sed_mode_streams_shard_over_ranks(tmp_path):
     m = sed_model(M.small(), n_thermal=20000)
     one = Oracle(m, 1e5).run_mono(9, 5, seed=77, n_chunks=13)
     r0, r1 = np.load(tmp_path / "m0.npz"), np.load(tmp_path / "m1.npz")
-    for k in ("sed", "ns", "per", "xI", "cnt"):
+    for k in ("sed", "ns", "per", "xI", "cnt", "rt"):
         assert np.array_equal(r0[k], r1[k])
+    rt_one = Oracle(m, 1e5).dust_map_sed(9, one["xI_scatt"], m.extra["Tdust"], one["n_sent"][8], m.extra["E_disk"][8])
+    assert (rt_one[:, 0] > 0).all() and np.allclose(r0["rt"], rt_one, rtol=1e-9, atol=0)
     assert np.array_equal(r0["per"], one["n_sent_chunk"])
     assert np.array_equal(r0["sed"][4], one["sed"][4]) and np.array_equal(r0["ns"], one["n_sent"])
     assert np.array_equal(r0["cnt"], np.array(list(one["counters"].values())))
