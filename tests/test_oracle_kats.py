@@ -391,3 +391,22 @@ def test_dust_map_image_integrates_to_the_volume_integral_and_mirrors():
             fine4 = img[0, 0].reshape(3, 16, 2, 16, 2).sum(axis=(2, 4))
             sel = coarse[0, 0] > 1e-3 * coarse[0, 0].max()
             assert np.allclose(coarse[0, 0][sel], fine4[sel], rtol=0.05, atol=0)
+
+
+def test_oracle_regression_anchors():
+    """The oracle against its own committed outputs (tests/golden/oracle_anchors.npz, made by
+    make_oracle_anchors.py): a change of the checker that moves the thermal loop, the SED mode or the ray tracer has
+    to be deliberate.  (Anchors of the oracle, not reference data: those parts are unpinned)"""
+    import importlib.util
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_oracle_anchors", os.path.join(here, "make_oracle_anchors.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    now, ref = mod.compute(), np.load(os.path.join(here, "oracle_anchors.npz"))
+    assert sorted(now) == sorted(ref.files)
+    for k in ref.files:
+        if ref[k].dtype.kind == "i":
+            assert np.array_equal(now[k], ref[k]), k
+        else:   # (libm differences between hosts stay far below this)
+            assert np.allclose(now[k], ref[k], rtol=1e-9, atol=1e-12 * np.abs(ref[k]).max()), k
