@@ -294,14 +294,24 @@ int mcgpu_run_mono(mcgpu_ctx *ctx, const mcgpu_mono_opts *opts,
  * array and/or the FP64 sums the engine accumulates.  Either pointer may be NULL. */
 int mcgpu_fetch_xI(mcgpu_ctx *ctx, float *xI_scatt_f32, double *xI_scatt_f64);
 
+/* Accumulator type of xI_scatt on the device: 8 = FP64 sums (default: device = oracle to 1e-6), 4 = default real,
+ * the type of the reference's own array (dust_ray_tracing.f90:33).  With 4 the records of two observers share a
+ * 64-byte line, which halves the L2 read-modify-writes a run with many observers is bound by (-24 % at 10
+ * observers, slower below ~5); a sum of N deposits then carries a rounding error ~ sqrt(N) * 6e-8, far below its
+ * Monte Carlo noise 1/sqrt(N).  Call before the first mcgpu_run_mono / mcgpu_set_xI; changing it drops what was
+ * accumulated.  mcgpu_fetch_xI, mcgpu_set_xI and the ray tracer work with either; mcgpu_device_xI exposes
+ * accumulators of this type. */
+int mcgpu_set_xI_precision(mcgpu_ctx *ctx, int bytes_per_value);
+int mcgpu_get_xI_precision(mcgpu_ctx *ctx);
+
 /* Replace the device accumulator by the host's xI_scatt (same layout as mcgpu_fetch_xI's FP64 output):
  * what a host that reduced xI_scatt itself (the reference's thread sum :152, an MPI reduction) hands
  * back before mcgpu_rt1_dust_map.  Needs mcgpu_set_rt1. */
 int mcgpu_set_xI(mcgpu_ctx *ctx, const double *xI_scatt_f64);
 
-/* The device-resident FP64 xI_scatt accumulator (engine layout) for an in-place RCCL
+/* The device-resident xI_scatt accumulator (engine layout, n_values of the type set above) for an in-place RCCL
  * all-reduce across the ranks of a multi-GPU SED step; fetch afterwards with mcgpu_fetch_xI. */
-int mcgpu_device_xI(mcgpu_ctx *ctx, void **xI_dev, uint64_t *n_doubles);
+int mcgpu_device_xI(mcgpu_ctx *ctx, void **xI_dev, uint64_t *n_values);
 
 /* ------------------------------------------------------------------------
  * Ray-traced SED of the dust, ray-tracing method 1: what

@@ -48,7 +48,8 @@ struct MonoArgs {
   const double* rt_w;                   // [RT_n_incl]
   int n_az_rt, n_theta_rt, N_type_flux, contrib;
   const float* s11;                     // tab_s11_pos(0:nang, p_lambda)
-  double* xI;                           // device layout [n_cells][n_theta_rt][n_az_rt][nRT][XI_LINE]
+  double* xI;                           // device layout [n_cells][n_theta_rt][n_az_rt][nRT][XI_LINE] of doubles, or with
+  int xI_f32, nRT_pad;                  // xI_f32 (mcgpu_set_xI_precision(4)): ... [nRT_pad][XI_LINE] of floats, nRT_pad even
   // accumulators
   double* sed;
   double* n_sent;
@@ -214,11 +215,21 @@ __device__ inline void deposit_rt1_wave(const DevModel& M, const MonoArgs& A, co
       else if (A.flags & 2) mask &= 1u;     // diagnostics: only the I deposit
     }
 #ifdef MCGPU_LANE_EMULATION
-    if (mask & 1u) atomic_add_f64(rec, v0);
-    if (POLA && (mask & 2u)) atomic_add_f64(rec + 1, v1);
-    if (POLA && (mask & 4u)) atomic_add_f64(rec + 2, v2);
-    if (POLA && (mask & 8u)) atomic_add_f64(rec + 3, v3);
-    if (cslot && ((mask >> cslot) & 1u)) atomic_add_f64(rec + cslot, v0);
+    if (A.xI_f32 && D.on) {  // (the CPU emulation has one lane and no tile: the default-real layout, value by value)
+      float* rec32 = reinterpret_cast<float*>(A.xI) +
+          ((((size_t)(D.icell - 1) * A.n_theta_rt + (D.psup - 1)) * A.n_az_rt + (D.phik - 1)) * A.nRT_pad + q) * XI_LINE;
+      if (mask & 1u) atomicAdd(rec32, (float)v0);
+      if (POLA && (mask & 2u)) atomicAdd(rec32 + 1, (float)v1);
+      if (POLA && (mask & 4u)) atomicAdd(rec32 + 2, (float)v2);
+      if (POLA && (mask & 8u)) atomicAdd(rec32 + 3, (float)v3);
+      if (cslot && ((mask >> cslot) & 1u)) atomicAdd(rec32 + cslot, (float)v0);
+    } else {
+      if (mask & 1u) atomic_add_f64(rec, v0);
+      if (POLA && (mask & 2u)) atomic_add_f64(rec + 1, v1);
+      if (POLA && (mask & 4u)) atomic_add_f64(rec + 2, v2);
+      if (POLA && (mask & 8u)) atomic_add_f64(rec + 3, v3);
+      if (cslot && ((mask >> cslot) & 1u)) atomic_add_f64(rec + cslot, v0);
+    }
 #else
     // stage this lane's record: values 0..3 = I, Q, U, V; the tile's mask word keeps the mask and the slot of the
     // contribution copy (slots the mask does not name are never read)
@@ -248,6 +259,89 @@ __device__ inline void deposit_rt1_wave(const DevModel& M, const MonoArgs& A, co
 #endif
   }
 }
+
+#ifndef MCGPU_LANE_EMULATION
+// The same with default-real records (mcgpu_set_xI_precision(4), the type of the reference's own array): the records
+// of two observers share a 64-byte line, so a lane stages the pair (q, q+1) side by side -- 16 floats -- and 2K lanes
+// serve it: half the lines per crossing, which is what bounds a run with many observers.
+template <bool POLA>
+__device__ inline void deposit_rt1_wave_f32(const DevModel& M, const MonoArgs& A, const RtScratch& R, const float* mu,
+                                            const RtDeposit& D, const double S[4], bool flag_star, double* tile,
+                                            unsigned long long* tile_addr, unsigned int* tile_mask) {
+  const int na1 = M.nang + 1;
+  const int lane = threadIdx.x & 63;
+  const int K = (POLA ? 4 : 1) + (A.contrib ? 1 : 0);
+  const int NR = 64 / (2 * K);                 // pairs per instruction
+  const int rl = lane / (2 * K), jj = lane - rl * 2 * K;
+  const int hh = jj / K, j = jj - hh * K;      // which record of the pair, and which of its values
+  const bool lane_used = rl < NR;
+  const bool is_contrib = A.contrib && j == K - 1;
+  const unsigned long long any = __ballot(D.on && !(A.flags & 1));
+  const int n_act = __popcll(any);
+  if (n_act == 0) return;
+  const int place = __popcll(any & ((1ull << lane) - 1ull));
+  volatile float* const tile32 = reinterpret_cast<volatile float*>(tile);
+  for (int q0 = 0; q0 < A.nRT; q0 += 2) {
+    unsigned int pair_mask = 0;
+    for (int h = 0; h < 2; ++h) {
+      const int q = q0 + h;
+      double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+      unsigned int mask = 0;
+      int cslot = 0;
+      if (D.on && q < A.nRT) {
+        const int it = R.itheta[q * blockDim.x + threadIdx.x];
+        const float s11 = mu[it];
+        if (!POLA) {
+          v0 = D.l * S[0] * (double)s11;
+          mask = 1u;
+          if (A.contrib) { cslot = flag_star ? 2 : 4; mask |= 1u << cslot; }
+        } else {
+          const float s12 = -s11 * mu[na1 + it], s22 = s11 * mu[2 * na1 + it], s33 = -s11 * mu[3 * na1 + it];
+          const float s34 = -s11 * mu[4 * na1 + it], s44 = -s11 * mu[5 * na1 + it];
+          const double cosw = R.cosw[q * blockDim.x + threadIdx.x], sinw = R.sinw[q * blockDim.x + threadIdx.x];
+          const double C1 = S[0], C4 = S[3];
+          const double C2 = cosw * S[1] + (-sinw) * S[2];
+          const double C3 = sinw * S[1] + cosw * S[2];
+          const double D1 = (double)s11 * C1 + (double)s12 * C2;
+          const double D2 = (double)s12 * C1 + (double)s22 * C2;
+          const double D3 = (double)s33 * C3 + (double)(-s34) * C4;
+          const double D4 = (double)s34 * C3 + (double)s44 * C4;
+          v0 = D.l * D1;
+          v1 = D.l * ((-cosw) * D2 + (-sinw) * D3);
+          v2 = D.l * ((-sinw) * D2 + cosw * D3);
+          v3 = D.l * D4;
+          mask = 0xFu;
+          if (A.contrib) { cslot = flag_star ? 5 : 7; mask |= 1u << cslot; }
+        }
+        if (A.flags & 1) mask = 0;
+        else if (A.flags & 2) mask &= 1u;
+        if (mask) {
+          volatile float* my = tile32 + place * 2 * XI_LINE + h * XI_LINE;
+          my[0] = (float)v0; my[1] = (float)v1; my[2] = (float)v2; my[3] = (float)v3;
+        }
+      }
+      pair_mask |= (mask | ((unsigned int)cslot << 8)) << (16 * h);
+    }
+    if (pair_mask & 0x00FF00FFu) {
+      const size_t bin = ((size_t)(D.icell - 1) * A.n_theta_rt + (D.psup - 1)) * A.n_az_rt + (D.phik - 1);
+      tile_addr[place] = (unsigned long long)(reinterpret_cast<float*>(A.xI) + (bin * A.nRT_pad + q0) * XI_LINE);
+      tile_mask[place] = pair_mask;
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int r0 = 0; r0 < n_act; r0 += NR) {
+      const int src = r0 + rl;
+      if (lane_used && src < n_act) {
+        const unsigned int mw = (((volatile unsigned int*)tile_mask)[src] >> (16 * hh)) & 0xFFFFu;
+        const int slot = is_contrib ? (int)(mw >> 8) : j;
+        if ((mw >> slot) & 1u)
+          atomicAdd(reinterpret_cast<float*>(((volatile unsigned long long*)tile_addr)[src]) + hh * XI_LINE + slot,
+                    tile32[src * 2 * XI_LINE + hh * XI_LINE + (is_contrib ? 0 : j)]);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+#endif
 
 // LDS of a SED-mode workgroup after the shared tables: the Mueller columns of p_lambda, the per-lane
 // results of angles_scatt_rt1 and the per-wave deposit tiles (mono_lds_bytes is the matching size).
@@ -316,7 +410,7 @@ __device__ inline bool mono_attenuate(const Lds& T, int lambda, double S[4]) {
 }
 
 // SCOUT: no deposits, no SED; records hits.  Otherwise the COMMIT pass.
-template <bool L3D, bool POLA, bool DARK, bool SCOUT>
+template <bool L3D, bool POLA, bool DARK, bool SCOUT, bool F32 = false>
 __device__ __forceinline__ void mono_body(const DevModel& M, const MonoArgs& A, double* lds_base) {
   const Lds T = lds_carve(lds_base, M, true);
   lds_stage_mono(T, M, A.p_lambda);
@@ -528,7 +622,13 @@ __device__ __forceinline__ void mono_body(const DevModel& M, const MonoArgs& A, 
       // the deposits of this crossing, by the whole wavefront (S and flag_star are still the flight's:
       // an interaction changes them only in the next outer phase)
       if (!SCOUT && A.rt1 && __ballot(dep.on) != 0ull)
+      {
+#ifndef MCGPU_LANE_EMULATION
+        if constexpr (F32) deposit_rt1_wave_f32<POLA>(M, A, R, mu, dep, S, flag_star, tile, tile_addr, tile_mask);
+        else
+#endif
         deposit_rt1_wave<POLA>(M, A, R, mu, dep, S, flag_star, tile, tile_addr, tile_mask);
+      }
     }
   }
 
@@ -543,10 +643,10 @@ __device__ __forceinline__ void mono_body(const DevModel& M, const MonoArgs& A, 
   }
 }
 
-template <bool L3D, bool POLA, bool DARK, bool SCOUT>
+template <bool L3D, bool POLA, bool DARK, bool SCOUT, bool F32 = false>
 __global__ void __launch_bounds__(512) k_mono(const DevModel M, const MonoArgs A) {
   extern __shared__ double lds_raw[];
-  mono_body<L3D, POLA, DARK, SCOUT>(M, A, lds_raw);
+  mono_body<L3D, POLA, DARK, SCOUT, F32>(M, A, lds_raw);
 }
 
 // Stopping index of every active stream from this batch's hit flags: one wave per stream.
@@ -595,7 +695,7 @@ __global__ void k_mono_scan(const int* active, int n_active, unsigned long long 
 // device layout [icell][psup][phik][iRT][8] -> the reference's xI_scatt(phik,psup,type,iRT,icell),
 // in FP64 and/or default real (what the reference's array holds).  One thread per output element.
 __global__ void k_xI_fetch(const double* xI, float* out32, double* out64, int n_az, int n_theta, int n_type, int nRT,
-                           size_t n) {
+                           size_t n, int f32, int nRT_pad) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   size_t r = i;
@@ -603,13 +703,16 @@ __global__ void k_xI_fetch(const double* xI, float* out32, double* out64, int n_
   const int psup = (int)(r % n_theta); r /= n_theta;
   const int type = (int)(r % n_type); r /= n_type;
   const int q = (int)(r % nRT); r /= nRT;  // r = icell - 1
-  const double v = xI[(((r * n_theta + psup) * n_az + phik) * nRT + q) * XI_LINE + type];
+  const size_t bin = (r * n_theta + psup) * n_az + phik;
+  const double v = f32 ? (double)reinterpret_cast<const float*>(xI)[(bin * nRT_pad + q) * XI_LINE + type]
+                       : xI[(bin * nRT + q) * XI_LINE + type];
   if (out64) out64[i] = v;
   if (out32) out32[i] = (float)v;
 }
 
 // the reference's xI_scatt(phik,psup,type,iRT,icell) -> device layout (mcgpu_set_xI).  One thread per element.
-__global__ void k_xI_put(double* xI, const double* in64, int n_az, int n_theta, int n_type, int nRT, size_t n) {
+__global__ void k_xI_put(double* xI, const double* in64, int n_az, int n_theta, int n_type, int nRT, size_t n, int f32,
+                         int nRT_pad) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   size_t r = i;
@@ -617,7 +720,9 @@ __global__ void k_xI_put(double* xI, const double* in64, int n_az, int n_theta, 
   const int psup = (int)(r % n_theta); r /= n_theta;
   const int type = (int)(r % n_type); r /= n_type;
   const int q = (int)(r % nRT); r /= nRT;
-  xI[(((r * n_theta + psup) * n_az + phik) * nRT + q) * XI_LINE + type] = in64[i];
+  const size_t bin = (r * n_theta + psup) * n_az + phik;
+  if (f32) reinterpret_cast<float*>(xI)[(bin * nRT_pad + q) * XI_LINE + type] = (float)in64[i];
+  else xI[(bin * nRT + q) * XI_LINE + type] = in64[i];
 }
 
 }  // namespace mcgpu

@@ -8,7 +8,7 @@
 
 namespace mcgpu {
 
-template <bool POLA, bool SCOUT>
+template <bool POLA, bool SCOUT, bool F32 = false>
 __device__ __forceinline__ void mono_body_voro(const DevModel& M, const MonoArgs& A, const VoroGrid& G,
                                                double* lds_base) {
   const Lds T = lds_carve(lds_base, M, true);
@@ -163,7 +163,13 @@ __device__ __forceinline__ void mono_body_voro(const DevModel& M, const MonoArgs
         }
       }
       if (!SCOUT && A.rt1 && __ballot(dep.on) != 0ull)
+      {
+#ifndef MCGPU_LANE_EMULATION
+        if constexpr (F32) deposit_rt1_wave_f32<POLA>(M, A, ML.R, ML.mu, dep, S, flag_star, ML.tile, ML.tile_addr, ML.tile_mask);
+        else
+#endif
         deposit_rt1_wave<POLA>(M, A, ML.R, ML.mu, dep, S, flag_star, ML.tile, ML.tile_addr, ML.tile_mask);
+      }
     }
   }
 
@@ -178,10 +184,10 @@ __device__ __forceinline__ void mono_body_voro(const DevModel& M, const MonoArgs
   }
 }
 
-template <bool POLA, bool SCOUT>
+template <bool POLA, bool SCOUT, bool F32 = false>
 __global__ void __launch_bounds__(512) k_mono_voro(const DevModel M, const MonoArgs A, const VoroGrid G) {
   extern __shared__ double lds_raw[];
-  mono_body_voro<POLA, SCOUT>(M, A, G, lds_raw);
+  mono_body_voro<POLA, SCOUT, F32>(M, A, G, lds_raw);
 }
 
 }  // namespace mcgpu

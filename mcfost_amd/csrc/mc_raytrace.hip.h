@@ -23,6 +23,7 @@ struct RtArgs {
   const double* rt_u; const double* rt_v; const double* rt_w;  // observer directions (see MonoArgs)
   const float* rt_az;                                           // tab_RT_az [RT_n_az], degrees
   const double* xI;                                             // device layout [cell][psup][phik][iRT][XI_LINE]
+  int xI_f32, nRT_pad;                                          // ... or [iRT_pad][XI_LINE] floats (MonoArgs::xI_f32)
   const double* J_th;                                           // [n_cells]
   double* out;                                                  // [nRT * N_type_flux]
   // images (k_rt1_image)
@@ -114,7 +115,17 @@ __device__ inline void rt1_integ_ray(const Lds& T, const DevModel& M, const RtAr
       if (kappa_ext > TINY_DP) {
         const double factor = A.photon_energy / M.volume[ic] * A.n_az_rt * A.n_theta_rt;
         const double kappa_sca = kappa_ext * (double)T.albedo[A.lambda - 1];
-        const double* rec = A.xI + ((((size_t)ic * A.n_theta_rt + (psup - 1)) * A.n_az_rt + (phik - 1)) * A.nRT + q) * XI_LINE;
+        const size_t bin = ((size_t)ic * A.n_theta_rt + (psup - 1)) * A.n_az_rt + (phik - 1);
+        double rec[XI_LINE];
+        if (A.xI_f32) {
+          const float* r32 = reinterpret_cast<const float*>(A.xI) + (bin * A.nRT_pad + q) * XI_LINE;
+#pragma unroll
+          for (int t = 0; t < XI_LINE; ++t) rec[t] = (double)r32[t];
+        } else {
+          const double* r64 = A.xI + (bin * A.nRT + q) * XI_LINE;
+#pragma unroll
+          for (int t = 0; t < XI_LINE; ++t) rec[t] = r64[t];
+        }
         const double wgt = exp(-tau) * (1.0 - exp(-dtau));
         const double jth = A.J_th[ic];
         const double fs = factor * kappa_sca / kappa_ext;

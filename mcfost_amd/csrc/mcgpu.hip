@@ -61,6 +61,7 @@ struct mcgpu_ctx {
   const float* d_tab_s11 = nullptr;
   double* d_xI = nullptr;
   size_t n_xI = 0;
+  int xI_bytes = 8;  // accumulator type of xI_scatt on the device: 8 = FP64 (default), 4 = default real (mcgpu_set_xI_precision)
   double* d_prob_E = nullptr;               // prob_E_cell(0:n_cells) of the current wavelength
   unsigned long long* d_mono_u64 = nullptr; // [5 * n_chunks + 1]: need | sent | item_base(+1) | start | hit_count
   int* d_mono_i32 = nullptr;                // [2 * n_chunks]: active | done
@@ -92,6 +93,16 @@ static int upload(mcgpu_ctx* ctx, const Tp* host, size_t n, const Tp** dev_out) 
   *dev_out = d;
   return MCGPU_OK;
 }
+
+// xI_scatt on the device: values (of xI_bytes each) and bytes; default-real records are padded to an even observer count
+static inline int xi_nrt_pad(const mcgpu_ctx* ctx) {
+  const int nRT = ctx->RT_n_incl * ctx->RT_n_az;
+  return ctx->xI_bytes == 4 ? nRT + (nRT & 1) : nRT;
+}
+static inline size_t xi_dev_values(const mcgpu_ctx* ctx) {
+  return (size_t)ctx->n_az_rt * ctx->n_theta_rt * XI_LINE * xi_nrt_pad(ctx) * (size_t)ctx->M.n_cells;
+}
+static inline size_t xi_dev_bytes(const mcgpu_ctx* ctx) { return xi_dev_values(ctx) * (size_t)ctx->xI_bytes; }
 
 static int fail(mcgpu_ctx* ctx, int code, const char* msg) {
   if (ctx) ctx->err = msg;
@@ -965,9 +976,13 @@ static int launch_mono(mcgpu_ctx* ctx, const MonoArgs& A, int grid_blocks, int b
   const size_t lds = mono_lds_bytes(M, A.nRT, threads, pola, slim);
   if (lds > 160 * 1024) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "too many ray-tracing directions for the LDS of one CU");
   const void* fn;
-#define PICK(a, b, c) fn = (const void*)k_mono<a, b, c, SCOUT>
+  // (the commit pass of a context with default-real xI_scatt runs the F32 variant of the deposit code)
+  constexpr bool kCommit = !SCOUT;
+  const bool f32 = kCommit && A.rt1 && ctx->xI_bytes == 4;
+#define PICK(a, b, c) fn = f32 ? (const void*)k_mono<a, b, c, SCOUT, kCommit> : (const void*)k_mono<a, b, c, SCOUT, false>
   if (ctx->voro) {
-    fn = pola ? (const void*)k_mono_voro<true, SCOUT> : (const void*)k_mono_voro<false, SCOUT>;
+    if (f32) fn = pola ? (const void*)k_mono_voro<true, SCOUT, kCommit> : (const void*)k_mono_voro<false, SCOUT, kCommit>;
+    else fn = pola ? (const void*)k_mono_voro<true, SCOUT, false> : (const void*)k_mono_voro<false, SCOUT, false>;
   } else if (l3d) {
     if (pola) { if (dark) PICK(true, true, true); else PICK(true, true, false); }
     else { if (dark) PICK(true, false, true); else PICK(true, false, false); }
@@ -1027,16 +1042,16 @@ extern "C" int mcgpu_run_mono(mcgpu_ctx* ctx, const mcgpu_mono_opts* o, double f
   const int nRT = ctx->have_rt1 ? ctx->RT_n_incl * ctx->RT_n_az : 0;
   // n_xI: elements of the reference's array; the device keeps XI_LINE doubles per (cell, sub-bin, observer)
   const size_t n_xI = o->rt1 ? (size_t)ctx->n_az_rt * ctx->n_theta_rt * ctx->N_type_flux * nRT * (size_t)M.n_cells : 0;
-  const size_t n_dev = o->rt1 ? (size_t)ctx->n_az_rt * ctx->n_theta_rt * XI_LINE * nRT * (size_t)M.n_cells : 0;
+  const size_t xi_bytes = o->rt1 ? xi_dev_bytes(ctx) : 0;
   if (o->rt1 && ctx->N_type_flux > XI_LINE) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "N_type_flux > 8");
   if (o->rt1 && ctx->n_xI != n_xI) {
     if (ctx->d_xI) hipFree(ctx->d_xI);
     ctx->d_xI = nullptr; ctx->n_xI = 0;
-    HIPCHK(hipMalloc((void**)&ctx->d_xI, n_dev * sizeof(double)));
+    HIPCHK(hipMalloc((void**)&ctx->d_xI, xi_bytes));
     ctx->n_xI = n_xI;
-    HIPCHK(hipMemsetAsync(ctx->d_xI, 0, n_dev * sizeof(double), ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_xI, 0, xi_bytes, ctx->stream));
   } else if (o->rt1 && !o->accumulate) {
-    HIPCHK(hipMemsetAsync(ctx->d_xI, 0, n_dev * sizeof(double), ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_xI, 0, xi_bytes, ctx->stream));
   }
   if (!o->accumulate) {
     HIPCHK(hipMemsetAsync(ctx->d_accum, 0, ctx->n_accum * sizeof(double), ctx->stream));
@@ -1054,7 +1069,7 @@ extern "C" int mcgpu_run_mono(mcgpu_ctx* ctx, const mcgpu_mono_opts* o, double f
   A.rt_u = ctx->d_rt_u; A.rt_v = ctx->d_rt_v; A.rt_w = ctx->d_rt_w;
   A.n_az_rt = ctx->n_az_rt; A.n_theta_rt = ctx->n_theta_rt; A.N_type_flux = ctx->N_type_flux; A.contrib = ctx->lsepar_contrib;
   A.s11 = ctx->have_rt1 ? ctx->d_tab_s11 + (size_t)(M.nang + 1) * (o->p_lambda - 1) : nullptr;
-  A.xI = ctx->d_xI;
+  A.xI = ctx->d_xI; A.xI_f32 = ctx->xI_bytes == 4 ? 1 : 0; A.nRT_pad = xi_nrt_pad(ctx);
   A.sed = ctx->d_accum + M.n_cells;
   A.n_sent = ctx->d_accum + M.n_cells + n_sed(M);
   A.counters = ctx->d_counters; A.next_item = ctx->d_counters + 8; A.err = ctx->d_err;
@@ -1172,7 +1187,7 @@ restart:
           speculate = false;
           HIPCHK(hipMemsetAsync(ctx->d_accum, 0, ctx->n_accum * sizeof(double), ctx->stream));
           HIPCHK(hipMemsetAsync(ctx->d_counters, 0, 16 * sizeof(unsigned long long), ctx->stream));
-          if (o->rt1) HIPCHK(hipMemsetAsync(ctx->d_xI, 0, n_dev * sizeof(double), ctx->stream));
+          if (o->rt1) HIPCHK(hipMemsetAsync(ctx->d_xI, 0, xi_bytes, ctx->stream));
           goto restart;
         }
         for (int c = 0; c < nc; ++c) start[c] = cnt[c];   // committed so far: [0, start)
@@ -1202,9 +1217,23 @@ restart:
 extern "C" int mcgpu_device_xI(mcgpu_ctx* ctx, void** xI_dev, uint64_t* n_doubles) {
   if (!ctx || !ctx->d_xI) return fail(ctx, MCGPU_ERR_STATE, "no xI_scatt accumulated yet");
   if (xI_dev) *xI_dev = ctx->d_xI;
-  if (n_doubles) *n_doubles = ctx->n_xI / ctx->N_type_flux * XI_LINE;
+  if (n_doubles) *n_doubles = xi_dev_values(ctx);
   return MCGPU_OK;
 }
+
+extern "C" int mcgpu_set_xI_precision(mcgpu_ctx* ctx, int bytes_per_value) {
+  if (!ctx) return MCGPU_ERR_ARG;
+  if (bytes_per_value != 4 && bytes_per_value != 8) return fail(ctx, MCGPU_ERR_ARG, "mcgpu_set_xI_precision: 4 or 8");
+  if (bytes_per_value != ctx->xI_bytes) {
+    hipSetDevice(ctx->device);
+    if (ctx->d_xI) hipFree(ctx->d_xI);  // the layout changes with the type: what was accumulated is dropped
+    ctx->d_xI = nullptr; ctx->n_xI = 0;
+    ctx->xI_bytes = bytes_per_value;
+  }
+  return MCGPU_OK;
+}
+
+extern "C" int mcgpu_get_xI_precision(mcgpu_ctx* ctx) { return ctx ? ctx->xI_bytes : 0; }
 
 extern "C" int mcgpu_set_xI(mcgpu_ctx* ctx, const double* xI_scatt) {
   if (!ctx || !xI_scatt) return fail(ctx, MCGPU_ERR_ARG, "mcgpu_set_xI: null argument");
@@ -1213,20 +1242,20 @@ extern "C" int mcgpu_set_xI(mcgpu_ctx* ctx, const double* xI_scatt) {
   HIPCHK(hipSetDevice(ctx->device));
   const int nRT = ctx->RT_n_incl * ctx->RT_n_az;
   const size_t n = (size_t)ctx->n_az_rt * ctx->n_theta_rt * ctx->N_type_flux * nRT * (size_t)ctx->M.n_cells;
-  const size_t n_dev = n / ctx->N_type_flux * XI_LINE;
+  const size_t xi_bytes = xi_dev_bytes(ctx);
   if (ctx->n_xI != n) {
     if (ctx->d_xI) hipFree(ctx->d_xI);
     ctx->d_xI = nullptr; ctx->n_xI = 0;
-    HIPCHK(hipMalloc((void**)&ctx->d_xI, n_dev * sizeof(double)));
+    HIPCHK(hipMalloc((void**)&ctx->d_xI, xi_bytes));
     ctx->n_xI = n;
   }
-  HIPCHK(hipMemsetAsync(ctx->d_xI, 0, n_dev * sizeof(double), ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->d_xI, 0, xi_bytes, ctx->stream));
   double* d_in = nullptr;
   HIPCHK(hipMalloc((void**)&d_in, n * sizeof(double)));
   hipError_t e = hipMemcpyAsync(d_in, xI_scatt, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) {
     hipLaunchKernelGGL(k_xI_put, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_xI, d_in,
-                       ctx->n_az_rt, ctx->n_theta_rt, ctx->N_type_flux, nRT, n);
+                       ctx->n_az_rt, ctx->n_theta_rt, ctx->N_type_flux, nRT, n, ctx->xI_bytes == 4 ? 1 : 0, xi_nrt_pad(ctx));
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -1246,7 +1275,8 @@ extern "C" int mcgpu_fetch_xI(mcgpu_ctx* ctx, float* xI_scatt_f32, double* xI_sc
   if (e == hipSuccess && xI_scatt_f64) e = hipMalloc((void**)&d64, n * sizeof(double));
   if (e == hipSuccess) {
     hipLaunchKernelGGL(k_xI_fetch, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_xI, d32, d64,
-                       ctx->n_az_rt, ctx->n_theta_rt, ctx->N_type_flux, ctx->RT_n_incl * ctx->RT_n_az, n);
+                       ctx->n_az_rt, ctx->n_theta_rt, ctx->N_type_flux, ctx->RT_n_incl * ctx->RT_n_az, n,
+                       ctx->xI_bytes == 4 ? 1 : 0, xi_nrt_pad(ctx));
     e = hipGetLastError();
   }
   if (e == hipSuccess && d32) e = hipMemcpyAsync(xI_scatt_f32, d32, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
@@ -1340,6 +1370,7 @@ static int rt1_prepare(mcgpu_ctx* ctx, const mcgpu_rt_opts* o, const float* tab_
   A.l_far = 10. * o->Rmax;
   A.rt_u = ctx->d_rt_u; A.rt_v = ctx->d_rt_v; A.rt_w = ctx->d_rt_w; A.rt_az = J.d_az.p;
   A.xI = ctx->d_xI; A.J_th = J.d_J.p;
+  A.xI_f32 = ctx->xI_bytes == 4 ? 1 : 0; A.nRT_pad = xi_nrt_pad(ctx);
   HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
   hipLaunchKernelGGL(k_calc_Jth, dim3((M.n_cells + 255) / 256), dim3(256), 0, ctx->stream, M, o->lambda, A.wl, J.d_T.p, J.d_J.p);
   HIPCHK(hipGetLastError());

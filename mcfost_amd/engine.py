@@ -33,7 +33,8 @@ ABI_SYMBOLS = (
     "mcgpu_probe_cross_cell", "mcgpu_probe_index_cell", "mcgpu_probe_philox",
     "mcgpu_probe_packet_rand", "mcgpu_set_midplane_snap", "mcgpu_set_grid_voronoi",
     "mcgpu_probe_cross_voronoi", "mcgpu_set_rt1", "mcgpu_run_mono", "mcgpu_fetch_xI",
-    "mcgpu_device_xI", "mcgpu_set_ism", "mcgpu_rt1_dust_map", "mcgpu_set_xI", "mcgpu_rt1_image",
+    "mcgpu_device_xI", "mcgpu_set_ism", "mcgpu_rt1_dust_map", "mcgpu_set_xI", "mcgpu_rt1_image", "mcgpu_set_xI_precision",
+    "mcgpu_get_xI_precision",
 )
 
 
@@ -278,13 +279,20 @@ class Engine:
         t_cnt = torch.as_tensor(_DevArray(cnt.value, N_COUNTERS, "<i8"), device=dev)
         return t_acc, t_cnt
 
+    def set_xI_precision(self, bytes_per_value):
+        """8 (default): FP64 xI_scatt sums; 4: default real like the reference's array, half the atomic lines -- for
+        runs with many observers (``mcgpu_set_xI_precision``)."""
+        self._chk(self.lib.mcgpu_set_xI_precision(self.ctx, C.c_int(int(bytes_per_value))), "mcgpu_set_xI_precision")
+
     def device_xI(self):
-        """The FP64 xI_scatt accumulator (engine layout) as a zero-copy torch tensor."""
+        """The xI_scatt accumulator (engine layout, FP64 or FP32 as set) as a zero-copy torch tensor."""
         import torch
 
         p, n = C.c_void_p(), C.c_uint64()
         self._chk(self.lib.mcgpu_device_xI(self.ctx, C.byref(p), C.byref(n)), "mcgpu_device_xI")
-        return torch.as_tensor(_DevArray(p.value, n.value, "<f8"), device=torch.device("cuda", self.device))
+        self.lib.mcgpu_get_xI_precision.argtypes = [C.c_void_p]
+        dt = "<f4" if self.lib.mcgpu_get_xI_precision(self.ctx) == 4 else "<f8"
+        return torch.as_tensor(_DevArray(p.value, n.value, dt), device=torch.device("cuda", self.device))
 
     # -- probes (parity tests) ---------------------------------------------
     def probe_cross_cell(self, x0, y0, z0, u, v, w, cell):

@@ -66,7 +66,7 @@ module mcgpu_f
   public :: mcgpu_create, mcgpu_destroy, mcgpu_set_grid_cyl, mcgpu_set_grid_voronoi, mcgpu_set_midplane_snap, &
        mcgpu_set_stars, mcgpu_set_opacity, mcgpu_set_scattering, mcgpu_set_thermal, mcgpu_set_sed_bins, &
        mcgpu_run_thermal, mcgpu_temp_finale, mcgpu_thermal_loop, mcgpu_error_message, mcgpu_set_rt1, &
-       mcgpu_run_mono, mcgpu_fetch, mcgpu_fetch_xI, mcgpu_rt1_dust_map, mcgpu_set_xI, mcgpu_rt1_image
+       mcgpu_run_mono, mcgpu_fetch, mcgpu_fetch_xI, mcgpu_rt1_dust_map, mcgpu_set_xI, mcgpu_rt1_image, mcgpu_set_xI_precision
 
   interface
      integer(c_int) function mcgpu_create(device, ctx) bind(C, name="mcgpu_create")
@@ -207,6 +207,13 @@ module mcgpu_f
        import :: c_int, c_ptr
        type(c_ptr), value :: ctx, xI_scatt_f32, xI_scatt_f64       ! c_loc(xI_scatt(1,1,1,1,1,1)) or c_null_ptr
      end function mcgpu_fetch_xI
+
+     ! 8 (default) = FP64 sums of xI_scatt on the device, 4 = default real like the reference's array
+     integer(c_int) function mcgpu_set_xI_precision(ctx, bytes_per_value) bind(C, name="mcgpu_set_xI_precision")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: bytes_per_value
+     end function mcgpu_set_xI_precision
 
      integer(c_int) function mcgpu_set_xI(ctx, xI_scatt_f64) bind(C, name="mcgpu_set_xI")
        import :: c_int, c_ptr, c_double

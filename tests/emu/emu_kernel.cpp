@@ -57,6 +57,7 @@ static inline int atomicAdd(int* p, int v) { int o = *p; *p += v; return o; }
 static inline int atomicCAS(int* p, int cmp, int v) { int o = *p; if (o == cmp) *p = v; return o; }
 static inline double __longlong_as_double(long long b) { double d; memcpy(&d, &b, 8); return d; }
 static inline double atomicAdd(double* p, double v) { double o = *p; *p += v; return o; }
+static inline float atomicAdd(float* p, float v) { float o = *p; *p += v; return o; }
 namespace mcgpu {  // the device source's unfused helpers (mc_device.hip.h), for the host compiler
 static inline double nd_mul(double a, double b) { volatile double r = a * b; return r; }
 static inline double nd_add(double a, double b) { volatile double r = a + b; return r; }
@@ -264,7 +265,9 @@ extern "C" int emu_run_mono(const oracle_model* m, const oracle_mono_opts* o, do
   const size_t nxI = o->rt1 ? (size_t)m->n_az_rt * m->n_theta_rt * m->N_type_flux * nRT * (size_t)m->n_cells : 0;
   memset(sed, 0, sizeof(double) * nsed);
   memset(n_sent, 0, sizeof(double) * m->n_lambda);
-  std::vector<double> xI_dev(nxI ? nxI / m->N_type_flux * XI_LINE : 1, 0.0);  // the kernel's own layout, transposed at the end
+  const bool xi32 = getenv("MCGPU_EMU_XI_F32") != nullptr;  // default-real records (mcgpu_set_xI_precision(4))
+  const int nRT_pad = xi32 ? nRT + (nRT & 1) : nRT;
+  std::vector<double> xI_dev(nxI ? nxI / m->N_type_flux / (nRT ? nRT : 1) * nRT_pad * XI_LINE : 1, 0.0);  // the kernel's own layout (FP32: half of it used)
   unsigned long long cnt[16];
   memset(cnt, 0, sizeof(cnt));
   int err = 0;
@@ -279,7 +282,8 @@ extern "C" int emu_run_mono(const oracle_model* m, const oracle_mono_opts* o, do
   A.rt_u = m->tab_u_rt; A.rt_v = m->tab_v_rt; A.rt_w = m->tab_w_rt;
   A.n_az_rt = m->n_az_rt; A.n_theta_rt = m->n_theta_rt; A.N_type_flux = m->N_type_flux; A.contrib = m->lsepar_contrib;
   A.s11 = m->tab_s11_pos ? m->tab_s11_pos + (size_t)(m->nang_scatt + 1) * (o->p_lambda - 1) : nullptr;
-  A.xI = xI_dev.data(); A.sed = sed; A.n_sent = n_sent; A.counters = cnt; A.next_item = cnt + 8; A.err = &err;
+  A.xI = xI_dev.data(); A.xI_f32 = xi32 ? 1 : 0; A.nRT_pad = nRT_pad;
+  A.sed = sed; A.n_sent = n_sent; A.counters = cnt; A.next_item = cnt + 8; A.err = &err;
   A.inner_iters = 8; A.min_active = 0;
 #define MONO(sc_) do {                                                                     \
     if (voro) { if (pola) k_mono_voro<true, sc_>(M, A, G); else k_mono_voro<false, sc_>(M, A, G); }               \
@@ -326,7 +330,7 @@ extern "C" int emu_run_mono(const oracle_model* m, const oracle_mono_opts* o, do
     gridDim.x = 1; blockDim.x = 1; threadIdx.x = 0;
     for (size_t i = 0; i < nxI; ++i) {
       blockIdx.x = (unsigned)i;
-      k_xI_fetch(xI_dev.data(), nullptr, xI, m->n_az_rt, m->n_theta_rt, m->N_type_flux, nRT, nxI);
+      k_xI_fetch(xI_dev.data(), nullptr, xI, m->n_az_rt, m->n_theta_rt, m->N_type_flux, nRT, nxI, xi32 ? 1 : 0, nRT_pad);
     }
     blockIdx.x = 0;
   }

@@ -555,6 +555,46 @@ def test_sed_mode_speculative_commit(sed_small, monkeypatch):
     e.close()
 
 
+def test_sed_mode_default_real_records():
+    """mcgpu_set_xI_precision(4): xI_scatt accumulated in default real (the reference's own type), two observers per
+    64-byte line.  Same packets and SED bins; xI_scatt to FP32 rounding; fetch / set / ray tracing / the zero-copy
+    tensor all follow the type; back to FP64 the 1e-6 parity returns."""
+    import torch
+    from helpers import sed_model, xI_close
+    for cfg, lam, n2 in ((M.small(RT_n_incl=3), 9, 40), (M.small(RT_n_incl=2, RT_n_az=2, RT_az_max=60.0, lsepar_pola=False), 5, 40),
+                         (M.small(n_rad=10, nz=5, n_az=6, l3D=True, RT_n_incl=4), 4, 700)):
+        m = sed_model(cfg, n_thermal=50000)
+        e, o = _engine(m, 1e5), _oracle(m, 1e5)
+        e.set_rt1()
+        e.set_xI_precision(4)
+        a = e.run_mono(lam, n2, seed=3, n_chunks=16)
+        b = o.run_mono(lam, n2, seed=3, n_chunks=16, n_threads=8)
+        assert np.array_equal(a["n_sent_chunk"], b["n_sent_chunk"]) and a["counters"] == b["counters"]
+        assert np.array_equal(a["sed"][4], b["sed"][4])
+        xI_close(a["xI_scatt"], b["xI_scatt"], rtol=1e-4, n_midplane_cells=0 if cfg.l3D else cfg.n_rad, atol_rel=1e-5)
+        t = e.device_xI()
+        nRT = m.rt["RT_n_incl"] * m.rt["RT_n_az"]
+        assert t.dtype == torch.float32 and t.numel() == m.n_cells * m.rt["n_theta_rt"] * m.rt["n_az_rt"] * (nRT + nRT % 2) * 8
+        assert abs(float(t.double().sum()) / a["xI_scatt"].sum() - 1) < 1e-6
+        # ray tracing from the default-real records == the oracle's on the same values (psup-symmetrised, see above)
+        x = a["xI_scatt"].copy()
+        if not cfg.l3D:
+            x[:cfg.n_rad] = x[:cfg.n_rad].mean(axis=3, keepdims=True)
+        x = x.astype(np.float32).astype(np.float64)
+        e.set_xI(x)
+        assert np.array_equal(e.fetch_xI(), x)
+        ns, Ed = a["n_sent"][lam - 1], m.extra["E_disk"][lam - 1]
+        got, _ = e.dust_map_sed(lam, m.extra["Tdust"], ns, Ed)
+        ref = o.dust_map_sed(lam, x, m.extra["Tdust"], ns, Ed, n_threads=8)
+        assert np.allclose(got, ref, rtol=1e-9, atol=1e-13 * np.abs(ref).max())
+        e.set_xI_precision(8)          # back to FP64 sums: the accumulator is dropped and rebuilt
+        a8 = e.run_mono(lam, n2, seed=3, n_chunks=16)
+        pola = cfg.lsepar_pola and cfg.aniso_method == 1          # (tolerances of _mono_parity)
+        xI_close(a8["xI_scatt"], b["xI_scatt"], n_midplane_cells=0 if cfg.l3D else cfg.n_rad,
+                 rtol=3e-5 if pola else 1e-6, atol_rel=1e-6 if pola else 1e-8)
+        e.close()
+
+
 def test_sed_mode_packet_cap_and_launch_geometry(sed_small):
     m = sed_small
     a, b = _mono_parity(m, 3, 100000, 5, n_chunks=16, n_phot_lim=700.0)   # n_phot_lim ends every stream

@@ -201,6 +201,26 @@ def check_mono(emu, m, lam, n2, seed, **kw):
     return a, b
 
 
+def test_emulated_sed_mode_default_real_records(emu):
+    """xI_scatt accumulated in default real, two observers per 64-byte line (mcgpu_set_xI_precision(4)): same packets,
+    same SED bins, xI_scatt to FP32 rounding -- odd and even observer counts, polarised or not, 2D and 3D.  (The
+    emulation covers the layout, the fetch and the values; the pair staging of the wavefront is a GPU test.)"""
+    os.environ["MCGPU_EMU_XI_F32"] = "1"
+    try:
+        for cfg, lam in ((M.small(RT_n_incl=3), 9), (M.small(RT_n_incl=2, RT_n_az=2, RT_az_max=60.0, lsepar_pola=False), 5),
+                         (M.small(n_rad=10, nz=5, n_az=6, l3D=True, RT_n_incl=1), 4)):
+            m = sed_model(cfg, n_thermal=20000)
+            orc = Oracle(m, 1e5)
+            a = emu_mono(emu, orc, lam, 10, 7)
+            b = orc.run_mono(lam, 10, seed=7, n_chunks=8, rt1=True, n_threads=4)
+            assert np.array_equal(a["n_sent_chunk"], b["n_sent_chunk"]) and a["counters"] == list(b["counters"].values())
+            assert np.array_equal(a["sed"][4], b["sed"][4])
+            xI_close(a["xI_scatt"], b["xI_scatt"], rtol=1e-4, n_midplane_cells=0 if cfg.l3D else cfg.n_rad, atol_rel=1e-5)
+            assert np.abs(b["xI_scatt"]).max() > 0
+    finally:
+        os.environ.pop("MCGPU_EMU_XI_F32", None)
+
+
 def test_emulated_sed_mode_2d(emu):
     """SED mode (mc_mono.hip.h): scout + scan + commit against the oracle's sequential streams --
     same stopping packet in every stream, same SED bins, same xI_scatt."""

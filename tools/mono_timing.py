@@ -12,6 +12,7 @@ ap.add_argument("--n2", type=int, default=20000)
 ap.add_argument("--lams", default="5,15,25,35")
 ap.add_argument("--config", default="ref41")
 ap.add_argument("--no-rt1", action="store_true")
+ap.add_argument("--xi-bytes", type=int, default=8, help="accumulator type of xI_scatt: 8 or 4")
 ap.add_argument("--incl", type=int, default=3, help="RT_n_incl (observers of the xI_scatt deposits)")
 a = ap.parse_args()
 import dataclasses
@@ -22,6 +23,9 @@ T = e.temp_finale(e.run_thermal(5_000_000, seed=3)["E_abs"])
 M.repartition_energie(m, T)
 e.close()
 e = Engine(m, 5e6)
+if not a.no_rt1:
+    e.set_rt1()
+    e.set_xI_precision(a.xi_bytes)
 for lam in [int(x) for x in a.lams.split(",")]:
     e.run_mono(lam, 100, seed=1, rt1=not a.no_rt1, fetch_xI=False)
     t = time.perf_counter()
