@@ -1,6 +1,6 @@
 """BASELINE config 2 end to end on one MI355X: ref4.1 2D disk, temperature step + SED (Monte Carlo SED bins,
 xI_scatt, ray-traced SED of the dust for 10 inclinations) through mcfost_amd/host/pipeline.py.
-Usage: python tools/run_config2.py [n_thermal=1e8] [n_photons_lambda=10000]   (x 128 streams per wavelength)"""
+Usage: python tools/run_config2.py [n_thermal=1e8] [n_photons_lambda=10000] [xI bytes = 8 | 4]   (x 128 streams per wavelength)"""
 import os, sys, time, dataclasses
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -12,6 +12,9 @@ n2 = int(float(sys.argv[2])) if len(sys.argv) > 2 else 10000
 cfg = dataclasses.replace(M.ref41(), RT_n_incl=10)
 m = M.build_model(cfg)
 e = Engine(m, n_th)
+xi_bytes = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+e.set_rt1()
+e.set_xI_precision(xi_bytes)   # 4: xI_scatt in default real, two observers per line (mcgpu_set_xI_precision)
 e.run_thermal(1000, seed=1)   # (first launch: module load)
 t0 = time.perf_counter()
 r = P.temperature_and_sed(P.EngineBackend(e), m, n_th, n2, seed=5)
@@ -20,7 +23,7 @@ s = r["seconds"]
 n_sed = r["n_sent"].sum()
 print(f"thermal step: {n_th:.3g} packets in {s['thermal']:.3f} s ({n_th / s['thermal']:.3g} packets/s incl. Temp_finale)")
 print(f"repartition_energie (host, numpy): {s['repartition_energie']:.3f} s")
-print(f"SED Monte Carlo: {m.n_lambda} wavelengths, {n_sed:.3g} packets in {s['sed_mc']:.3f} s ({n_sed / s['sed_mc']:.3g} packets/s, "
+print(f"SED Monte Carlo (xI_scatt in {xi_bytes}-byte sums): {m.n_lambda} wavelengths, {n_sed:.3g} packets in {s['sed_mc']:.3f} s ({n_sed / s['sed_mc']:.3g} packets/s, "
       f"scout + commit passes and the fetch of the SED arrays included)")
 print(f"ray-traced dust SED: {m.n_lambda} x {cfg.RT_n_incl} inclinations in {s['ray_tracing']:.3f} s")
 print(f"total {wall:.2f} s;  Tdust {r['Tdust'].min():.1f} .. {r['Tdust'].max():.1f} K")
