@@ -250,11 +250,8 @@ def main():
         eng.launch_thermal(n_local, seed=1000 + i, first_packet=first, n_replicas=float(world),
                            frozen=args.frozen, grid_blocks=args.grid_blocks, block_threads=args.block_threads)
         ms = eng.sync()
-        if world > 1:
-            acc, cnt = eng.device_accumulators()
-            dist.all_reduce(acc)
-            dist.all_reduce(cnt)
-            torch.cuda.current_stream().synchronize()   # the next launch zeroes this buffer on the engine's stream
+        if world > 1:   # ONE all-reduce of the fused [E_abs | sed | n_sent | counters] buffer
+            eng.allreduce_device(dist.all_reduce)
         return ms
 
     for i in range(args.warmup):
@@ -286,10 +283,7 @@ def main():
             pe.launch_thermal(n_local, seed=2000 + i, first_packet=first, n_replicas=float(world))
             ms = pe.sync()
             if world > 1:
-                acc, cnt2 = pe.device_accumulators()
-                dist.all_reduce(acc)
-                dist.all_reduce(cnt2)
-                torch.cuda.current_stream().synchronize()
+                pe.allreduce_device(dist.all_reduce)
             return ms
 
         pstep(-1)

@@ -140,6 +140,22 @@ int mcgpu_set_grid_voronoi(mcgpu_ctx *ctx, int n_cells, const float *voronoi_xyz
  */
 int mcgpu_set_midplane_snap(mcgpu_ctx *ctx, int on);
 
+/*
+ * Per-context run options (the library reads no environment variable; the switches of the
+ * reference that select code paths are its command-line flags, init_mcfost.f90):
+ *   "deposit"      0 = automatic (default): the absorbed-energy grid of a 2D model is kept
+ *                      per workgroup in LDS, larger grids deposit with HBM atomics (Voronoi:
+ *                      through a hashed LDS cache); 1 = HBM atomics only; 2 = LDS (refused
+ *                      when the grid does not fit)
+ *   "schedule"     0 = automatic (default): waves with roles and LDS packet queues where
+ *                      the queues fit; 1 = the single-role kernel
+ *   "speculation"  SED mode: 1 (default) = most of every stream is committed before the
+ *                      scout pass (exact; see mcgpu_run_mono), 0 = scout every packet first
+ *   "voronoi_cache_log_slots"  6..13 (default 13): log2 of the slots of the Voronoi deposit cache
+ * Results do not depend on any of them (same packets, same random numbers).
+ */
+int mcgpu_set_option(mcgpu_ctx *ctx, const char *name, int value);
+
 /* Stars: type star_type (parameters.f90:230-242); icell/out_model from
  * stars_cell_indices (stars.f90:789-808). Lengths in AU. */
 int mcgpu_set_stars(mcgpu_ctx *ctx, int n_stars, const double *x,
@@ -225,12 +241,20 @@ int mcgpu_run_thermal(mcgpu_ctx *ctx, const mcgpu_run_opts *opts,
  * on the device between the launch and the RCCL all-reduce. */
 int mcgpu_launch_thermal(mcgpu_ctx *ctx, const mcgpu_run_opts *opts);
 int mcgpu_sync(mcgpu_ctx *ctx, double *kernel_ms);
-/* Device pointers of the fused accumulator [E_abs | sed | n_sent] (doubles)
- * and of the counters (uint64[MCGPU_N_COUNTERS]). */
+/* Device pointers of the fused accumulator [E_abs | sed | n_sent | counters] (doubles; the last
+ * MCGPU_N_COUNTERS entries are the tail filled by mcgpu_counters_to_accum) and of the counters
+ * themselves (uint64[MCGPU_N_COUNTERS]). */
 int mcgpu_device_accumulators(mcgpu_ctx *ctx, void **accum_dev,
                               uint64_t *n_doubles, void **counters_dev);
 int mcgpu_fetch(mcgpu_ctx *ctx, double *E_abs, double *sed, double *n_sent,
                 uint64_t *counters);
+
+/* Multi-GPU hosts reduce ONE buffer per temperature iteration: mcgpu_counters_to_accum copies the
+ * event counters into the tail of the fused accumulator as doubles (exact below 2^53) before the
+ * all-reduce, mcgpu_counters_from_accum takes the summed values back afterwards.  Both are
+ * asynchronous on the context's stream. */
+int mcgpu_counters_to_accum(mcgpu_ctx *ctx);
+int mcgpu_counters_from_accum(mcgpu_ctx *ctx);
 /* Use an external stream (e.g. torch's current stream); NULL = own stream. */
 int mcgpu_set_stream(mcgpu_ctx *ctx, void *hip_stream);
 
@@ -385,6 +409,30 @@ int mcgpu_probe_philox(mcgpu_ctx *ctx, const uint32_t ctr[4],
                        const uint32_t key[2], uint32_t out[4]);
 int mcgpu_probe_packet_rand(mcgpu_ctx *ctx, uint64_t seed, uint64_t packet,
                             int n, float *out);
+
+/*
+ * Several GPUs of one node behind ONE host thread -- the reference's host is a single OpenMP
+ * process (mcfost.f90; the Phantom caller mcfost2phantom.f90:159), so this is the entry it binds.
+ * mcgpu_multi_create opens one context per device and one RCCL communicator over them
+ * (devices = NULL: 0..n_dev-1).  The host uploads the model to every context
+ * (mcgpu_multi_ctx(m, i) with the mcgpu_set_* calls above: tables are replicated).
+ * mcgpu_multi_run_thermal replaces the OpenMP region of run_thermal_mc (dust_transfer.f90:617):
+ * opts->n_packets is the GLOBAL packet count; device i runs the contiguous id shard
+ * mcgpu_shard_packets(n, i, n_dev) with n_replicas = n_dev (the `* nb_proc` of
+ * thermal_emission.f90:670), then ONE ncclAllReduce sums the fused accumulator
+ * [E_abs | sed | n_sent | counters] over xGMI and the outputs are read from device 0.
+ * kernel_ms = the slowest device's packet loop.  With n_dev = 1 the result equals
+ * mcgpu_run_thermal's.
+ */
+typedef struct mcgpu_multi mcgpu_multi;
+int mcgpu_multi_create(int n_dev, const int *devices, mcgpu_multi **out);
+int mcgpu_multi_destroy(mcgpu_multi *m);
+int mcgpu_multi_size(const mcgpu_multi *m);
+mcgpu_ctx *mcgpu_multi_ctx(mcgpu_multi *m, int i);
+const char *mcgpu_multi_last_error(const mcgpu_multi *m);
+void mcgpu_shard_packets(uint64_t n_packets, int rank, int world, uint64_t *first, uint64_t *count);
+int mcgpu_multi_run_thermal(mcgpu_multi *m, const mcgpu_run_opts *opts, double *E_abs, double *sed,
+                            double *n_sent, uint64_t *counters, double *kernel_ms);
 
 #ifdef __cplusplus
 }

@@ -24,10 +24,18 @@
 #include <stdint.h>
 
 #ifndef MCGPU_CROSS
-#define MCGPU_CROSS cross_cell_lean  // or cross_cell: the branch-for-branch form (A/B and debugging)
+#define MCGPU_CROSS cross_cell_lean  // (tests/emu can substitute the branch-for-branch form of tests/emu/cross_cell_literal.h)
 #endif
 #ifndef MCGPU_LDS_BLOCK
 #define MCGPU_LDS_BLOCK 512  // threads of an LDS-deposit workgroup (one per CU on the 2D BASELINE grid)
+#endif
+
+// Diagnostic switches of the kernels (skip deposits, record wave timelines: tools/*.py) exist in
+// -DMCGPU_TUNING builds only; the shipped library compiles them out.
+#ifdef MCGPU_TUNING
+#define MCGPU_DIAG(flags, bit) (((flags) & (bit)) != 0)
+#else
+#define MCGPU_DIAG(flags, bit) false
 #endif
 
 namespace mcgpu {
@@ -117,16 +125,8 @@ struct DevModel {
   double R_ISM, centre_ISM[3];
 };
 
-// Packet pool of the two-kernel engine (mc_rounds.hip.h): structure of arrays in HBM indexed
-// by slot.  Declared here because the single-kernel engine can resume packets from it.
-struct Pool {
-  int n_slots;
-  double *x, *y, *z, *u, *v, *w, *extr;
-  double* S;  // [4*n_slots] Stokes (I at S[slot], Q at S[n+slot], ...); only with Stokes tracking
-  int *ri, *zj, *k, *lambda, *star_key, *st;
-  uint32_t *p_lo, *p_hi, *event;
-};
-constexpr int ST_MASK = 15, ST_STAR = 16, ST_SCATT = 32, ST_ISM = 64;  // Pool::st = state | flags
+// packet state word of the queue records: state | flags
+constexpr int ST_MASK = 15, ST_STAR = 16, ST_SCATT = 32, ST_ISM = 64;
 
 struct RunArgs {
   uint64_t seed, first_packet, n_packets;
@@ -142,10 +142,7 @@ struct RunArgs {
   int inner_iters;  // crossings attempted between two interaction phases
   int flush_every;  // LDS-deposit kernels: outer iterations per fold of the private grid
   int min_active;   // leave the crossing loop early once fewer lanes than this are in flight
-  // finisher mode: the work items are in-flight packets of the pool, not fresh packet ids
-  const int* resume_list;
-  const Pool* resume_pool;  // device copy of the Pool descriptor; null = normal operation
-  int flags;        // diagnostics: bit 0 = skip the E_abs deposits (timing experiments only)
+  int flags;        // diagnostics, -DMCGPU_TUNING builds only (MCGPU_DIAG)
 };
 
 // ---------------------------------------------------------------------------
@@ -222,6 +219,7 @@ struct Lds {
   float* albedo;    // n_lambda
   float* prob;      // (nang+1) * (p_lambda_fixed ? 1 : n_lambda)
   float* g;         // n_lambda
+  unsigned int* nsent;  // n_lambda: packets this workgroup emitted per wavelength (thermal kernels; see lds_count_sent)
 };
 
 // mono = the SED-mode kernels (mc_mono*.hip.h): no re-emission, one phase-function column -- they leave out the
@@ -232,7 +230,8 @@ __host__ __device__ inline size_t lds_doubles(const DevModel& M, bool mono = fal
   return mono ? geo : geo + M.n_T + (M.n_lambda + 1) + M.n_lambda + (size_t)M.n_lambda * M.n_T;
 }
 __host__ __device__ inline size_t lds_floats(const DevModel& M, bool mono = false) {
-  return (size_t)M.n_lambda + (size_t)(M.nang + 1) * ((mono || M.p_lambda_fixed) ? 1 : M.n_lambda) + M.n_lambda;
+  return (size_t)M.n_lambda + (size_t)(M.nang + 1) * ((mono || M.p_lambda_fixed) ? 1 : M.n_lambda) + M.n_lambda +
+         (mono ? 0 : (size_t)M.n_lambda);  // (the last term: the n_sent histogram, 32-bit words)
 }
 __host__ __device__ inline size_t lds_bytes(const DevModel& M, bool mono = false) {
   return lds_doubles(M, mono) * sizeof(double) + lds_floats(M, mono) * sizeof(float);
@@ -260,7 +259,8 @@ __device__ inline Lds lds_carve(double* base, const DevModel& M, bool mono = fal
   float* f = reinterpret_cast<float*>(p);
   T.albedo = f; f += M.n_lambda;
   T.prob = f; f += (size_t)(M.nang + 1) * ((mono || M.p_lambda_fixed) ? 1 : M.n_lambda);
-  T.g = f;
+  T.g = f; f += M.n_lambda;
+  T.nsent = reinterpret_cast<unsigned int*>(f);
   return T;
 }
 
@@ -285,6 +285,20 @@ __device__ inline void lds_stage(const Lds& T, const DevModel& M) {
   stage(T.albedo, M.albedo, (size_t)M.n_lambda);
   stage(T.prob, M.prob_s11, (size_t)(M.nang + 1) * (M.p_lambda_fixed ? 1 : M.n_lambda));
   stage(T.g, M.tab_g, (size_t)M.n_lambda);
+  for (int i = threadIdx.x; i < M.n_lambda; i += blockDim.x) T.nsent[i] = 0u;
+}
+
+// n_phot_envoyes(lambda) += 1 (dust_transfer.f90:536).  One global FP64 atomic per packet onto these few addresses
+// was THE bound of the whole thermal loop (same-address atomics serialise at the memory side at ~3.4 ns each:
+// 2.9e8 packets/s whatever the kernel did otherwise; measured r02: 346 -> 186 ms per 1e8 packets without it), so the
+// workgroup counts in LDS and adds its histogram to the global array once, at the end of the launch.
+__device__ inline void lds_count_sent(const Lds& T, int lambda) { atomicAdd(&T.nsent[lambda - 1], 1u); }
+// (call after a __syncthreads() that follows the last emission of the workgroup)
+__device__ inline void lds_flush_sent(const Lds& T, const DevModel& M, double* n_sent) {
+  for (int i = threadIdx.x; i < M.n_lambda; i += blockDim.x) {
+    const unsigned int c = T.nsent[i];
+    if (c) unsafeAtomicAdd(&n_sent[i], (double)c);
+  }
 }
 
 // the tables of the SED-mode kernels (lds_carve(..., mono = true)): T.prob is column p_lambda of prob_s11
@@ -397,184 +411,6 @@ __device__ inline void index_cell(const Lds& T, const DevModel& M, double x, dou
   }
 }
 
-// cross_cylindrical_cell (cylindrical_grid.f90:918-1175) on (ri,zj,k).
-// inv_a / inv_w (:941-952) are per-flight constants computed by the caller.
-template <bool L3D>
-__device__ inline void cross_cell(const Lds& T, const DevModel& M, double x0, double y0, double z0,
-                                  double u, double v, double w, double inv_a, double inv_w, int ri0,
-                                  int zj0, int k0, double& x1, double& y1, double& z1, int& ri1,
-                                  int& zj1, int& k1, double& l) {
-  const int nz = M.nz, n_rad = M.n_rad, n_az = M.n_az;
-  const double correct_moins = 1.0 - GRID_PREC;
-  const double correct_plus = 1.0 + GRID_PREC;
-  double b, c, s, rac, t, t_phi, delta, r_2, zl, dotprod;
-  int delta_rad = 0, delta_zj = 0, delta_phi = 0;
-
-  r_2 = x0 * x0 + y0 * y0;
-  b = (x0 * u + y0 * v) * inv_a;
-  if (ri0 == 0) {
-    c = (r_2 - T.r_lim_2[0]) * inv_a;
-    delta = b * b - c;
-    rac = sqrt(delta);
-    s = (-b + rac) * correct_plus;
-    t = HUGE_REAL;
-    t_phi = HUGE_REAL;
-    delta_rad = 1;
-  } else {
-    dotprod = u * x0 + v * y0;
-    if (dotprod < 0.0) {
-      c = (r_2 - T.r_lim_2[ri0 - 1] * correct_moins) * inv_a;
-      delta = b * b - c;
-      if (delta < 0.0) {
-        c = (r_2 - T.r_lim_2[ri0] * correct_plus) * inv_a;
-        delta = fmax(b * b - c, 0.0);
-        delta_rad = 1;
-      } else {
-        delta_rad = -1;
-      }
-    } else {
-      c = (r_2 - T.r_lim_2[ri0] * correct_plus) * inv_a;
-      delta = fmax(b * b - c, 0.0);
-      delta_rad = 1;
-    }
-    rac = sqrt(delta);
-    s = (-b - rac) * correct_plus;
-    if (s < 0.0) s = (-b + rac) * correct_plus;
-    else if (s == 0.0) s = GRID_PREC;
-
-    dotprod = w * z0;
-    if (dotprod == 0.0) {
-      t = 1.0e10;
-    } else {
-      const int azj0 = zj0 < 0 ? -zj0 : zj0;
-      if (dotprod > 0.0) {
-        if (azj0 == nz + 1) {
-          delta_zj = 0;
-          zl = copysign(1.0e10, z0);
-        } else {
-          zl = copysign(z_lim_of(T, nz, ri0, azj0 + 1) * correct_plus, z0);
-          delta_zj = 1;
-          if (L3D && (z0 < 0.0)) delta_zj = -1;
-        }
-      } else {
-        if (L3D) {
-          if (z0 > 0.0) {
-            zl = z_lim_of(T, nz, ri0, azj0) * correct_moins;
-            delta_zj = -1;
-            if (zj0 == 1) delta_zj = -2;
-          } else {
-            zl = -z_lim_of(T, nz, ri0, azj0) * correct_moins;
-            delta_zj = 1;
-            if (zj0 == -1) delta_zj = 2;
-          }
-        } else {
-          if (zj0 == 1) {
-            delta_zj = 1;
-            double zz = z_lim_of(T, nz, ri0, 2) * correct_moins;
-            zl = (z0 > 0.0) ? -zz : zz;
-          } else {
-            double zz = z_lim_of(T, nz, ri0, zj0) * correct_moins;
-            zl = (z0 > 0.0) ? zz : -zz;
-            delta_zj = -1;
-          }
-        }
-      }
-      t = (zl - z0) * inv_w;
-      if (t < 0.0) t = GRID_PREC;
-    }
-
-    if (L3D) {
-      dotprod = x0 * v - y0 * u;
-      const double r1e30 = 1.00000001504746621988e+30;  // real 1.0e30
-      if (fabs(dotprod) < (double)1.0e-10f) {
-        t_phi = r1e30;
-      } else {
-        double tan_angle_lim;
-        if (dotprod > 0.0) {
-          tan_angle_lim = T.tan_phi[k0 - 1];
-          delta_phi = 1;
-        } else {
-          int k0m1 = k0 - 1;
-          if (k0m1 == 0) k0m1 = n_az;
-          tan_angle_lim = T.tan_phi[k0m1 - 1];
-          delta_phi = -1;
-        }
-        if (tan_angle_lim > 1.0e299) {
-          if (fabs(u) > (double)1e-6f) t_phi = -x0 / u;
-          else t_phi = r1e30;
-        } else {
-          double den = v - u * tan_angle_lim;
-          if (fabs(den) > (double)1.0e-6f) t_phi = -(y0 - x0 * tan_angle_lim) / den;
-          else t_phi = r1e30;
-        }
-        if (t_phi < 0.0) t_phi = r1e30;
-      }
-    } else {
-      t_phi = HUGE_REAL;
-    }
-  }
-
-  if ((s < t) && (s < t_phi)) {
-    l = s;
-    x1 = x0 + s * u;
-    y1 = y0 + s * v;
-    z1 = z0 + s * w;
-    ri1 = ri0 + delta_rad;
-    if (ri1 == 0) {
-      zj1 = 1;
-      k1 = 1;
-    } else {
-      if (ri1 > n_rad) {
-        zj1 = zj0;
-      } else {
-        int zj = zj_from_z_real(T, nz, fabs(z1), ri1);
-        if (zj > nz) zj = nz + 1;
-        if (L3D && (z1 < 0.0)) zj = -zj;
-        zj1 = zj;
-      }
-      k1 = k0;
-      if (L3D && (ri0 == 0)) {
-        double phi = modulo_d(atan2(y1, x1), 2 * PI);
-        int kk = (int)floor(phi * (1.0 / (2.0 * PI)) * (double)(float)n_az) + 1;
-        if (kk == n_az + 1) kk = n_az;
-        k1 = kk;
-      }
-    }
-  } else if (t < t_phi) {
-    l = t;
-    x1 = x0 + t * u;
-    y1 = y0 + t * v;
-    // NOT fused: at the midplane zl = 0 has no grid_prec margin, so whether
-    // z1 comes out as exactly 0 (-> sign(grid_prec,w), :1158-1165) or as a
-    // rounding residue of either sign is decided by the rounding of t*w.
-    // The reference build (no FMA contraction) rounds the product first.
-    z1 = nd_add(z0, nd_mul(t, w));
-    if (L3D && M.midplane_snap && (delta_zj == 2 || delta_zj == -2)) z1 = copysign(GRID_PREC, w);
-    ri1 = ri0;
-    zj1 = zj0 + delta_zj;
-    k1 = k0;
-  } else {
-    l = t_phi;
-    double dv = correct_plus * t_phi;
-    x1 = x0 + dv * u;
-    y1 = y0 + dv * v;
-    z1 = z0 + dv * w;
-    ri1 = ri0;
-    int zj = (int)floor(fabs(z1) / T.zmax[ri1 - 1] * (double)nz) + 1;
-    if (zj > nz) zj = nz + 1;
-    if (z1 < 0.0) zj = -zj;
-    zj1 = zj;
-    int kk = k0 + delta_phi;
-    if (kk == 0) kk = n_az;
-    if (kk == n_az + 1) kk = 1;
-    k1 = kk;
-  }
-  if (z1 == 0.0) {
-    if (L3D) z1 = copysign(GRID_PREC, w);
-    else z1 = GRID_PREC;
-  }
-}
-
 // zj of a point (|z| = absz) in radial column ri, capped at nz+1: the reference's
 //   floor(min(real(abs(z1)/zmax(ri1)*nz), max_int)) + 1        (cylindrical_grid.f90:1116)
 // The default-real rounding only matters within ~nz*6e-8 of an integer, so the common case
@@ -591,7 +427,7 @@ __device__ inline int zj_capped(const Lds& T, int nz, double absz, int ri) {
 }
 
 // cross_cylindrical_cell (cylindrical_grid.f90:918-1175), the same arithmetic as
-// cross_cell() above with the reference's branch tree flattened into selects: a wavefront
+// the reference's branch tree flattened into selects: a wavefront
 // executes ONE instruction stream whatever mix of inward/outward, up/down, radial/vertical
 // moves its 64 packets make.  Every value that decides an index or a position is computed by
 // the same expression as in the reference.
@@ -673,7 +509,9 @@ __device__ inline void cross_cell_lean(const Lds& T, const DevModel& M, double x
   const double dv = (rad || vert) ? l : cp * t_phi;
   x1 = x0 + dv * u;
   y1 = y0 + dv * v;
-  // products rounded before the sum, like the reference build (see cross_cell above)
+  // products rounded before the sum, like the reference build (no FMA contraction): at the midplane zl = 0 has
+  // no grid_prec margin, so whether z1 comes out as exactly 0 (-> sign(grid_prec,w), :1158-1165) or as a rounding
+  // residue of either sign is decided by the rounding of t*w
   z1 = nd_add(z0, nd_mul(dv, w));
   ri1 = rad ? ri0 + delta_rad : ri0;
   k1 = k0;
@@ -1035,16 +873,23 @@ __device__ inline void random_isotropic_direction(float r1, float r2, double& u,
 // the reference's partial sum * nb_proc, and is evaluated for absorptions only.
 // forced (SED mode, :1263-1278): always a scattering; p_lambda_scatt > 0 overrides the wavelength
 // index of the phase-function CDF (the caller's p_lambda).
-template <bool POLA, typename EnergyFn>
-__device__ __forceinline__ void interact(const Lds& T, const DevModel& M, const float g[8], int& lambda,
-                                         double u, double v, double w, double& u1, double& v1, double& w1,
-                                         double S[4], bool& flag_star, bool& flag_scatt,
-                                         unsigned int& c_scatt, unsigned int& c_abs, EnergyFn cell_energy,
-                                         const double* volume_of_cell, bool forced = false,
-                                         const float* prob_forced = nullptr, int lds_col = -1) {
+// The two halves of interact(), so that a kernel can run them as separate phases (mc_roles.hip.h):
+// interact_direction: the kind of event, the new wavelength or scattering angle and the new direction
+// (returns true for a scattering, with the angle bin `itheta` and the draw `rand2` the Stokes update needs);
+// interact_stokes: update_Stokes for a scattering with the interpolated Mueller ratios, Q = U = V = 0 after a
+// re-emission.
+template <typename EnergyFn>
+__device__ __forceinline__ bool interact_direction(const Lds& T, const DevModel& M, const float g[8], int& lambda,
+                                                   double u, double v, double w, double& u1, double& v1, double& w1,
+                                                   bool& flag_star, bool& flag_scatt, unsigned int& c_scatt,
+                                                   unsigned int& c_abs, EnergyFn cell_energy,
+                                                   const double* volume_of_cell, int& itheta, float& rand2_out,
+                                                   bool forced = false, const float* prob_forced = nullptr,
+                                                   int lds_col = -1) {
   const bool scat = forced || (g[0] < T.albedo[lambda - 1]);  // dust_transfer.f90:1284
   const float rand = g[1], rand2 = g[2];
-  int itheta = 1;
+  itheta = 1;
+  rand2_out = rand2;
   double cospsi, phi;
   if (scat) {
     flag_scatt = true;
@@ -1104,19 +949,39 @@ __device__ __forceinline__ void interact(const Lds& T, const DevModel& M, const 
   }
   // new direction: one instruction stream for both kinds of event
   cdapres(cospsi, phi, scat ? u : 0.0, scat ? v : 0.0, scat ? w : 1.0, u1, v1, w1);
-  if (POLA) {
-    if (scat && M.aniso_method == 1) {
-      const size_t o = (size_t)(M.nang + 1) * (lambda - 1) + itheta;
-      const float fr = rand2, fm = 1.0f - rand2;
-      const double M22 = (double)(M.s22[o] * fr + M.s22[o - 1] * fm);
-      const double M12 = (double)(M.s12[o] * fr + M.s12[o - 1] * fm);
-      const double M33 = (double)(M.s33[o] * fr + M.s33[o - 1] * fm);
-      const double M44 = (double)(M.s44[o] * fr + M.s44[o - 1] * fm);
-      const double M34 = (double)(-M.s34[o] * fr - M.s34[o - 1] * fm);
-      update_stokes(S, u, v, w, u1, v1, w1, M12, M22, M33, M34, M44);
-    }
-    if (!scat) { S[1] = 0.0; S[2] = 0.0; S[3] = 0.0; }
+  return scat;
+}
+
+// lambda: the packet's wavelength at the time of the scattering (a scattering does not change it)
+__device__ __forceinline__ void interact_stokes(const DevModel& M, bool scat, int lambda, int itheta, float rand2,
+                                                double u, double v, double w, double u1, double v1, double w1,
+                                                double S[4]) {
+  if (scat && M.aniso_method == 1) {
+    const size_t o = (size_t)(M.nang + 1) * (lambda - 1) + itheta;
+    const float fr = rand2, fm = 1.0f - rand2;
+    const double M22 = (double)(M.s22[o] * fr + M.s22[o - 1] * fm);
+    const double M12 = (double)(M.s12[o] * fr + M.s12[o - 1] * fm);
+    const double M33 = (double)(M.s33[o] * fr + M.s33[o - 1] * fm);
+    const double M44 = (double)(M.s44[o] * fr + M.s44[o - 1] * fm);
+    const double M34 = (double)(-M.s34[o] * fr - M.s34[o - 1] * fm);
+    update_stokes(S, u, v, w, u1, v1, w1, M12, M22, M33, M34, M44);
   }
+  if (!scat) { S[1] = 0.0; S[2] = 0.0; S[3] = 0.0; }
+}
+
+template <bool POLA, typename EnergyFn>
+__device__ __forceinline__ void interact(const Lds& T, const DevModel& M, const float g[8], int& lambda,
+                                         double u, double v, double w, double& u1, double& v1, double& w1,
+                                         double S[4], bool& flag_star, bool& flag_scatt,
+                                         unsigned int& c_scatt, unsigned int& c_abs, EnergyFn cell_energy,
+                                         const double* volume_of_cell, bool forced = false,
+                                         const float* prob_forced = nullptr, int lds_col = -1) {
+  int itheta;
+  float rand2;
+  const int lambda_in = lambda;
+  const bool scat = interact_direction(T, M, g, lambda, u, v, w, u1, v1, w1, flag_star, flag_scatt, c_scatt, c_abs,
+                                       cell_energy, volume_of_cell, itheta, rand2, forced, prob_forced, lds_col);
+  if (POLA) interact_stokes(M, scat, lambda_in, itheta, rand2, u, v, w, u1, v1, w1, S);
 }
 
 // ---------------------------------------------------------------------------
@@ -1276,33 +1141,7 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
         const bool served = need && (rank < avail);
         if (need && !served && pk_next >= A.n_packets) st = S_DONE;  // nothing left anywhere
         pk_next += (cnt < avail) ? cnt : avail;
-        if (served && A.resume_pool) {
-          // finisher: take over a packet in flight from the pool of the two-kernel engine
-          const Pool& Q = *A.resume_pool;
-          const int slot = A.resume_list[my];
-          x = Q.x[slot]; y = Q.y[slot]; z = Q.z[slot];
-          u = Q.u[slot]; v = Q.v[slot]; w = Q.w[slot];
-          extr = Q.extr[slot];
-          ri = Q.ri[slot]; zj = Q.zj[slot]; k = Q.k[slot];
-          lambda = Q.lambda[slot]; star_key = Q.star_key[slot];
-          rng.k0 = (uint32_t)A.seed; rng.k1 = (uint32_t)(A.seed >> 32);
-          rng.p_lo = Q.p_lo[slot]; rng.p_hi = Q.p_hi[slot]; rng.event = Q.event[slot];
-          const int stw = Q.st[slot];
-          flag_star = (stw & ST_STAR) != 0; flag_scatt = (stw & ST_SCATT) != 0; flag_ism = (stw & ST_ISM) != 0;
-          S[0] = 1.0; S[1] = 0.0; S[2] = 0.0; S[3] = 0.0;
-          if (POLA) {
-            S[0] = Q.S[slot]; S[1] = Q.S[Q.n_slots + slot];
-            S[2] = Q.S[2 * (size_t)Q.n_slots + slot]; S[3] = Q.S[3 * (size_t)Q.n_slots + slot];
-          }
-          const double a = u * u + v * v;
-          inv_a = (a > TINY_REAL) ? 1.0 / a : HUGE_REAL;
-          inv_w = (fabs(w) > TINY_REAL) ? 1.0 / w : copysign(HUGE_DP, w);
-          kf = is_real_cell<L3D>(n_rad, nz, ri, zj) ? M.kappa_factor[cell_index<L3D>(n_rad, nz, ri, zj, k)] : 0.0;
-          ri_o = 0; zj_o = 0; k_o = 0;
-          xo = x; yo = y; zo = z;
-          pk_cross = 0;
-          st = S_FLIGHT;
-        } else if (served) {
+        if (served) {
           {
             // mc_photon_loop body (dust_transfer.f90:529-541)
             rng.init(A.seed, A.first_packet + my);
@@ -1313,7 +1152,7 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
             tau_rand = f[8];
             float rand = f[0];
             lambda = select_wl_em(T, M, rand);
-            atomic_add_f64(&A.n_sent[lambda - 1], 1.0);
+            lds_count_sent(T, lambda);
             bool lintersect;
             flag_scatt = false;
             S[0] = 1.0; S[1] = 0.0; S[2] = 0.0; S[3] = 0.0;
@@ -1434,14 +1273,10 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
             int ri1, zj1, k1;
             MCGPU_CROSS<L3D>(T, M, x, y, z, u, v, w, inv_a, inv_w, ri, zj, k, x1, y1, z1, ri1, zj1, k1, l);
             c_cross++;
-            if (++pk_cross > 200000000u) {  // a packet that never leaves: flag it, drop it
-              *A.err = 13;
-              st = S_EMIT;
-            }
             const double tau = l * opacity;
             if (tau > extr) {
               const double lc = l * (extr / tau);
-              if (real_cell && !(A.flags & 1)) deposit<LDSE>(A.E_abs, E_lds, ic, T.kabs[lambda - 1] * lc * S[0]);
+              if (real_cell && !MCGPU_DIAG(A.flags, 1)) deposit<LDSE>(A.E_abs, E_lds, ic, T.kabs[lambda - 1] * lc * S[0]);
               x = x + lc * u;
               y = y + lc * v;
               z = z + lc * w;
@@ -1449,12 +1284,16 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
               st = S_INTERACT;
             } else {
               extr = extr - tau;
-              if (real_cell && !(A.flags & 1)) deposit<LDSE>(A.E_abs, E_lds, ic, T.kabs[lambda - 1] * l * S[0]);
+              if (real_cell && !MCGPU_DIAG(A.flags, 1)) deposit<LDSE>(A.E_abs, E_lds, ic, T.kabs[lambda - 1] * l * S[0]);
               if (DARK) { xo = x; yo = y; zo = z; ri_o = ri; zj_o = zj; k_o = k; }
               x = x1; y = y1; z = z1;
               ri = ri1; zj = zj1; k = k1;
               // the next cell's opacity factor travels through L2 while the next crossing computes
               kf = is_real_cell<L3D>(n_rad, nz, ri, zj) ? M.kappa_factor[cell_index<L3D>(n_rad, nz, ri, zj, k)] : 0.0;
+            }
+            if (++pk_cross > 200000000u) {  // a packet that never leaves: flag it, drop it
+              *A.err = 13;
+              st = S_EMIT;
             }
           }
         }
@@ -1477,8 +1316,9 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
       }
     }
   }  // outer iterations
-  if (LDSE) {  // final fold: every wave of the workgroup is done depositing
-    __syncthreads();
+  __syncthreads();  // every wave of the workgroup is done emitting and depositing
+  lds_flush_sent(T, M, A.n_sent);
+  if (LDSE) {  // final fold
     for (int i = threadIdx.x; i < M.n_cells; i += blockDim.x) {
       const double e = E_lds[i];
       if (e != 0.0) atomic_add_f64(&A.E_abs[i], e);

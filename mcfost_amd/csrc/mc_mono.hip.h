@@ -211,8 +211,8 @@ __device__ inline void deposit_rt1_wave(const DevModel& M, const MonoArgs& A, co
         mask = 0xFu;
         if (A.contrib) { cslot = flag_star ? 5 : 7; mask |= 1u << cslot; }
       }
-      if (A.flags & 1) mask = 0;            // diagnostics: compute, do not deposit
-      else if (A.flags & 2) mask &= 1u;     // diagnostics: only the I deposit
+      if (MCGPU_DIAG(A.flags, 1)) mask = 0;            // diagnostics: compute, do not deposit
+      else if (MCGPU_DIAG(A.flags, 2)) mask &= 1u;     // diagnostics: only the I deposit
     }
 #ifdef MCGPU_LANE_EMULATION
     if (A.xI_f32 && D.on) {  // (the CPU emulation has one lane and no tile: the default-real layout, value by value)
@@ -276,7 +276,7 @@ __device__ inline void deposit_rt1_wave_f32(const DevModel& M, const MonoArgs& A
   const int hh = jj / K, j = jj - hh * K;      // which record of the pair, and which of its values
   const bool lane_used = rl < NR;
   const bool is_contrib = A.contrib && j == K - 1;
-  const unsigned long long any = __ballot(D.on && !(A.flags & 1));
+  const unsigned long long any = __ballot(D.on && !MCGPU_DIAG(A.flags, 1));
   const int n_act = __popcll(any);
   if (n_act == 0) return;
   const int place = __popcll(any & ((1ull << lane) - 1ull));
@@ -313,8 +313,8 @@ __device__ inline void deposit_rt1_wave_f32(const DevModel& M, const MonoArgs& A
           mask = 0xFu;
           if (A.contrib) { cslot = flag_star ? 5 : 7; mask |= 1u << cslot; }
         }
-        if (A.flags & 1) mask = 0;
-        else if (A.flags & 2) mask &= 1u;
+        if (MCGPU_DIAG(A.flags, 1)) mask = 0;
+        else if (MCGPU_DIAG(A.flags, 2)) mask &= 1u;
         if (mask) {
           volatile float* my = tile32 + place * 2 * XI_LINE + h * XI_LINE;
           my[0] = (float)v0; my[1] = (float)v1; my[2] = (float)v2; my[3] = (float)v3;
@@ -486,7 +486,6 @@ __device__ __forceinline__ void mono_body(const DevModel& M, const MonoArgs& A, 
           float f[12];
           rng.emission_event(f);  // f[0]: the wavelength draw of the thermal step, unused (lmono, :535)
           tau_rand = f[8];
-          if (!SCOUT) atomic_add_f64(&A.n_sent[lambda - 1], 1.0);
           bool lintersect;
           flag_scatt = false;
           S[0] = 1.0; S[1] = 0.0; S[2] = 0.0; S[3] = 0.0;
@@ -589,10 +588,6 @@ __device__ __forceinline__ void mono_body(const DevModel& M, const MonoArgs& A, 
             int ri1, zj1, k1;
             MCGPU_CROSS<L3D>(T, M, x, y, z, u, v, w, inv_a, inv_w, ri, zj, k, x1, y1, z1, ri1, zj1, k1, l);
             c_cross++;
-            if (++pk_cross > 200000000u) {
-              *A.err = 13;
-              st = S_EMIT;
-            }
             const double tau = l * opacity;
             if (tau > extr) {
               const double lc = l * (extr / tau);
@@ -615,6 +610,10 @@ __device__ __forceinline__ void mono_body(const DevModel& M, const MonoArgs& A, 
               x = x1; y = y1; z = z1;
               ri = ri1; zj = zj1; k = k1;
               kf = is_real_cell<L3D>(n_rad, nz, ri, zj) ? M.kappa_factor[cell_index<L3D>(n_rad, nz, ri, zj, k)] : 0.0;
+            }
+            if (++pk_cross > 200000000u) {  // a packet that never leaves: flag it, drop it
+              *A.err = 13;
+              st = S_EMIT;
             }
           }
         }
@@ -639,6 +638,9 @@ __device__ __forceinline__ void mono_body(const DevModel& M, const MonoArgs& A, 
       unsigned long long vsum = cs[q];
       for (int off = 32; off > 0; off >>= 1) vsum += __shfl_down(vsum, off);
       if (lane == 0 && vsum) atomicAdd(&A.counters[q], vsum);
+      // n_phot_envoyes(lambda) (dust_transfer.f90:536): every packet of this launch has the same wavelength, so the
+      // wave adds its packet count once (one FP64 atomic per packet on ONE address would serialise the whole chip)
+      if (q == 0 && lane == 0 && vsum) unsafeAtomicAdd(&A.n_sent[A.lambda - 1], (double)vsum);
     }
   }
 }

@@ -73,7 +73,6 @@ __device__ __forceinline__ void mono_body_voro(const DevModel& M, const MonoArgs
           float f[12];
           rng.emission_event(f);
           tau_rand = f[8];
-          if (!SCOUT) atomic_add_f64(&A.n_sent[lambda - 1], 1.0);
           bool lintersect;
           flag_scatt = false;
           S[0] = 1.0; S[1] = 0.0; S[2] = 0.0; S[3] = 0.0;
@@ -140,10 +139,6 @@ __device__ __forceinline__ void mono_body_voro(const DevModel& M, const MonoArgs
           int next;
           voro_cross_cell(G, M, C, x, y, z, u, v, w, icell, prev_cell, x1, y1, z1, next, l, l_contrib, l_void);
           c_cross++;
-          if (++pk_cross > 200000000u) {
-            *A.err = 13;
-            st = S_EMIT;
-          }
           const double tau = l_contrib * opacity;
           const bool stop = tau > extr;
           const double lc = stop ? l_contrib * (extr / tau) : l_contrib;
@@ -159,6 +154,10 @@ __device__ __forceinline__ void mono_body_voro(const DevModel& M, const MonoArgs
             x = x1; y = y1; z = z1;
             prev_cell = icell;
             icell = next;
+          }
+          if (++pk_cross > 200000000u) {  // a packet that never leaves: flag it, drop it
+            *A.err = 13;
+            st = S_EMIT;
           }
         }
       }
@@ -180,6 +179,9 @@ __device__ __forceinline__ void mono_body_voro(const DevModel& M, const MonoArgs
       unsigned long long vsum = cs[q];
       for (int off = 32; off > 0; off >>= 1) vsum += __shfl_down(vsum, off);
       if (lane == 0 && vsum) atomicAdd(&A.counters[q], vsum);
+      // n_phot_envoyes(lambda) (dust_transfer.f90:536): every packet of this launch has the same wavelength, so the
+      // wave adds its packet count once (one FP64 atomic per packet on ONE address would serialise the whole chip)
+      if (q == 0 && lane == 0 && vsum) unsafeAtomicAdd(&A.n_sent[A.lambda - 1], (double)vsum);
     }
   }
 }

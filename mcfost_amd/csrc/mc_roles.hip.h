@@ -1,25 +1,36 @@
-// The default schedule of the thermal packet loop on cylindrical grids (MCGPU_ROLES, see mcgpu.hip):
-// the waves of a workgroup take ROLES and pass packets to each other through queues in LDS.
+// The default schedule of the thermal packet loop on cylindrical grids: the waves of a workgroup take
+// ROLES and pass packets to each other through lock-free queues in LDS.
 //
-// Why: the flight lengths are heavy-tailed (most flights of a packet random-walking in the thick
-// inner disk are 1-2 cell crossings, a few are 100+, and those few hold 94 % of all crossings).
-// With one packet per lane and every lane doing everything (thermal_body), a wavefront leaves the
-// crossing loop to serve the short flights again and again while its long flights idle: measured
-// lane utilisation of the crossing loop 54 %.
+// Why roles: the flight lengths are heavy-tailed (most flights of a packet random-walking in the thick
+// inner disk are 1-2 cell crossings, a few are 100+, and those few hold 94 % of all crossings).  With one
+// packet per lane and every lane doing everything (thermal_body), a wavefront leaves the crossing loop to
+// serve the short flights again and again while its long flights idle: lane utilisation of the crossing
+// loop 54 %.
+// Why records: the crossing loop needs ~90 VGPRs, the interaction code ~230 when it holds a whole packet
+// in registers next to its own temporaries -- fused, the kernel ran at 2 waves per SIMD (256 VGPRs).  Here
+// the SERVING role never holds a packet in registers: a packet that is not in flight lives in a RECORD in
+// LDS, and the serving code runs as short phases (emission / interaction / new flight / first crossings)
+// that each load the few fields they need from the record and store what they changed.  The kernel is
+// compiled for 128 VGPRs: 1024-thread workgroups, 4 waves per SIMD.
 //
-//   SERVER waves  emit packets, run the interactions and the first k_short crossings of every
-//                 flight; a packet still in flight after those is a long flight: it is pushed
-//                 to the FLY queue and the lane takes over a packet that waits for its
-//                 interaction (SRV queue) or emits a new one.
-//   FLYER waves   only cross cells: every R crossings the lanes whose packet stopped for an
-//                 interaction push it to the SRV queue and the empty lanes pop the FLY queue;
-//                 packets that leave the grid are binned on the spot.
+//   SERVING   a lane owns a record; per round: interaction (dust_transfer.f90:1260-1402), optical depth
+//             and star test of the next flight, the first k_short crossings.  A packet still in flight
+//             after those is a long flight: the record's index goes to the FLY ring (no copy) and the
+//             lane takes a record from the SRV ring (a packet that waits for its interaction) or a free
+//             record for a new packet (emission, dust_transfer.f90:529-541).
+//   FLYING    a lane holds a packet in registers and only crosses cells (physical_length,
+//             optical_depth.f90:77-178).  Every fly_iters crossings (or when fly_idle lanes have
+//             nothing to fly) the lanes whose packet stopped SWAP it with a record from the FLY ring
+//             (field by field, so the record now holds the stopped packet) and put that index on the
+//             SRV ring; empty lanes load a FLY record and return its index to the FREE ring.
 //
-// The queues are two record pools in LDS (structure of arrays) with index stacks, guarded by one
-// workgroup spin lock taken by lane 0 of a wave for a few LDS operations; a wave exchanges all
-// its pushes and pops in one step.  Every spin is bounded (the lock: 2^22 tries; a wave without work:
-// 2^26 polls, i.e. minutes): on overflow the workgroup aborts with error 14 / 15 instead of hanging.  Results do not depend on who runs a packet (counter-based random
-// numbers keyed by the packet id), so this schedule reproduces thermal_body packet for packet.
+// Rings: three index rings in LDS (FREE, FLY, SRV) of RQ_CAP >= n_rec entries.  An entry is one 32-bit word
+// (16-bit position tag | record index) written with one store, so publishing is atomic; a ring can never be
+// full (there are only n_rec indices), so pushing is one ds_add_rtn on the tail plus the entry stores;
+// popping is a compare-and-swap on the head after the entries' tags have been checked.  No lock anywhere.
+// Results do not depend on who runs a packet (counter-based random numbers keyed by the packet id), so
+// this schedule reproduces thermal_body packet for packet.  Every wait is bounded (error 15) so that a
+// logic error cannot hang the GPU.
 #pragma once
 #include "mc_device.hip.h"
 
@@ -31,174 +42,118 @@
 
 namespace mcgpu {
 
-constexpr int RQ_NF = 192;  // records of packets ready for a long flight
-constexpr int RQ_NS = 192;  // records of packets waiting for their interaction
-constexpr int RQ_N = RQ_NF + RQ_NS;
+constexpr int RQ_CAP = 512;          // entries per ring (power of two, >= records per workgroup)
+constexpr int RQ_MIN_REC = 96;       // fewer records than this: the single-role kernel runs instead
+enum : int { RQ_FREE = 0, RQ_FLY = 1, RQ_SRV = 2 };
 
+// a packet that is not in a flyer's registers (array of structures: every field is an immediate offset
+// from one per-lane address; strides 136 / 120 B keep consecutive records on different banks)
 template <bool POLA>
-struct RoleQ {
-  int lock, n_pending, ids_done, abort_flag;
-  int fly_top, fly_free_top, srv_top, srv_free_top;
-  short fly_stack[RQ_NF], fly_free[RQ_NF], srv_stack[RQ_NS], srv_free[RQ_NS];
-  double x[RQ_N], y[RQ_N], z[RQ_N], u[RQ_N], v[RQ_N], w[RQ_N], extr[RQ_N];
-  double S[POLA ? 4 : 1][RQ_N];
-  int ri[RQ_N], zj[RQ_N], k[RQ_N], lambda[RQ_N], star_key[RQ_N], p_lo[RQ_N], p_hi[RQ_N], event[RQ_N], flags[RQ_N];
-  unsigned int pk_cross[RQ_N];
-  float tau_rand[RQ_N];
-};
-
-struct PkState {
+struct alignas(8) Rec {
   double x, y, z, u, v, w, extr;
-  double S[4];
+  double S[POLA ? 4 : 1];
   int ri, zj, k, lambda, star_key;
-  Rng rng;
-  bool flag_star, flag_scatt, flag_ism;
-  int st;
+  uint32_t p_lo, p_hi, event;
+  int flags;  // state | ST_STAR | ST_SCATT | ST_ISM
+  uint32_t pk_cross;
   float tau_rand;
-  unsigned int pk_cross;
+  int pad[POLA ? 1 : 3];
 };
+static_assert(sizeof(Rec<true>) == 136 && sizeof(Rec<false>) == 120, "record stride");
 
-template <bool POLA>
-__device__ inline void rq_store(RoleQ<POLA>* Q, int id, const PkState& p) {
-  Q->x[id] = p.x; Q->y[id] = p.y; Q->z[id] = p.z; Q->u[id] = p.u; Q->v[id] = p.v; Q->w[id] = p.w;
-  Q->extr[id] = p.extr;
-  Q->S[0][id] = p.S[0];
-  if (POLA) { Q->S[POLA ? 1 : 0][id] = p.S[1]; Q->S[POLA ? 2 : 0][id] = p.S[2]; Q->S[POLA ? 3 : 0][id] = p.S[3]; }
-  Q->ri[id] = p.ri; Q->zj[id] = p.zj; Q->k[id] = p.k; Q->lambda[id] = p.lambda; Q->star_key[id] = p.star_key;
-  Q->p_lo[id] = (int)p.rng.p_lo; Q->p_hi[id] = (int)p.rng.p_hi; Q->event[id] = (int)p.rng.event;
-  Q->flags[id] = p.st | (p.flag_star ? ST_STAR : 0) | (p.flag_scatt ? ST_SCATT : 0) | (p.flag_ism ? ST_ISM : 0);
-  Q->pk_cross[id] = p.pk_cross;
-  Q->tau_rand[id] = p.tau_rand;
+struct RqCtl {
+  int n_pending, ids_done, abort_flag, pad0;
+  unsigned int head[3], tail[3];
+  int pad1[6];
+};
+static_assert(sizeof(RqCtl) == 64, "control block");
+
+__host__ __device__ inline size_t rq_lds_bytes(bool pola, int n_rec) {
+  return sizeof(RqCtl) + (size_t)3 * RQ_CAP * sizeof(unsigned int) + (size_t)n_rec * (pola ? sizeof(Rec<true>) : sizeof(Rec<false>));
 }
-
-template <bool POLA>
-__device__ inline void rq_load(const RoleQ<POLA>* Q, int id, PkState& p) {
-  p.x = Q->x[id]; p.y = Q->y[id]; p.z = Q->z[id]; p.u = Q->u[id]; p.v = Q->v[id]; p.w = Q->w[id];
-  p.extr = Q->extr[id];
-  p.S[0] = Q->S[0][id];
-  if (POLA) { p.S[1] = Q->S[POLA ? 1 : 0][id]; p.S[2] = Q->S[POLA ? 2 : 0][id]; p.S[3] = Q->S[POLA ? 3 : 0][id]; }
-  p.ri = Q->ri[id]; p.zj = Q->zj[id]; p.k = Q->k[id]; p.lambda = Q->lambda[id]; p.star_key = Q->star_key[id];
-  p.rng.p_lo = (uint32_t)Q->p_lo[id]; p.rng.p_hi = (uint32_t)Q->p_hi[id]; p.rng.event = (uint32_t)Q->event[id];
-  const int f = Q->flags[id];
-  p.st = f & ST_MASK; p.flag_star = (f & ST_STAR) != 0; p.flag_scatt = (f & ST_SCATT) != 0; p.flag_ism = (f & ST_ISM) != 0;
-  p.pk_cross = Q->pk_cross[id];
-  p.tau_rand = Q->tau_rand[id];
+// records that fit into `free_bytes` of LDS (0: not enough for this schedule)
+__host__ __device__ inline int rq_records_that_fit(bool pola, size_t free_bytes) {
+  const size_t fixed = sizeof(RqCtl) + (size_t)3 * RQ_CAP * sizeof(unsigned int);
+  if (free_bytes <= fixed) return 0;
+  size_t n = (free_bytes - fixed) / (pola ? sizeof(Rec<true>) : sizeof(Rec<false>));
+  if (n > (size_t)RQ_CAP) n = RQ_CAP;
+  return n >= (size_t)RQ_MIN_REC ? (int)n : 0;
 }
 
 __device__ inline int rq_ld(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ inline unsigned int rq_ldu(const unsigned int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ inline void rq_st(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ inline void rq_stu(unsigned int* p, unsigned int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ inline int rq_count(const RqCtl* Q, int q) { return (int)(rq_ldu(&Q->tail[q]) - rq_ldu(&Q->head[q])); }
 
-// lane 0 of the calling wave takes / releases the workgroup lock; false: gave up (abort)
-template <bool POLA>
-__device__ inline bool rq_lock(RoleQ<POLA>* Q, int* err) {
-  int spins = 0;
-  while (atomicCAS(&Q->lock, 0, 1) != 0) {
-    __builtin_amdgcn_s_sleep(1);
-    if (++spins > (1 << 22) || rq_ld(&Q->abort_flag)) {
-      rq_st(&Q->abort_flag, 1);
-      *err = 14;
-      return false;
-    }
+// Push the indices of the lanes with `want` onto ring q (never full).  The records they name must have been
+// written before the call (the fence orders those stores in front of the entries).
+__device__ inline void rq_push(RqCtl* Q, unsigned int* rings, int q, int lane, bool want, int rid) {
+  const unsigned long long m = __ballot(want);
+  if (m == 0ull) return;
+  __threadfence_block();
+  const int n = __popcll(m), rank = __popcll(m & ((1ull << lane) - 1ull));
+  const int leader = __ffsll((long long)m) - 1;
+  unsigned int pos = 0;
+  if (lane == leader) pos = atomicAdd(&Q->tail[q], (unsigned int)n);
+  pos = __shfl(pos, leader);
+  if (want) {
+    const unsigned int at = pos + (unsigned int)rank;
+    rq_stu(&rings[q * RQ_CAP + (at & (RQ_CAP - 1))], ((at + 1u) << 16) | (unsigned int)rid);
   }
-  __threadfence_block();
-  return true;
-}
-template <bool POLA>
-__device__ inline void rq_unlock(RoleQ<POLA>* Q) {
-  __threadfence_block();
-  rq_st(&Q->lock, 0);
 }
 
-// One wave-wide exchange with the queues.  SERVER: pushes go to the FLY queue, pops come from the
-// SRV queue; flyers the other way round.  Lanes with want_push own a packet to hand over, lanes
-// with want_pop are empty; a lane that manages to push is empty afterwards and pops in the same
-// step.  On return `pushed` / `popped` say what happened to this lane (popped: p holds the new
-// packet).
-template <bool POLA, bool SERVER>
-__device__ inline void rq_exchange(RoleQ<POLA>* Q, int lane, bool want_push, bool want_pop, PkState& p,
-                                   bool& pushed, bool& popped, int* err) {
-  pushed = false; popped = false;
-  const unsigned long long m_push = __ballot(want_push);
-  if ((m_push | __ballot(want_pop)) == 0ull) return;
-  short* push_stack = SERVER ? Q->fly_stack : Q->srv_stack;
-  short* push_free = SERVER ? Q->fly_free : Q->srv_free;
-  int* push_top = SERVER ? &Q->fly_top : &Q->srv_top;
-  int* push_free_top = SERVER ? &Q->fly_free_top : &Q->srv_free_top;
-  short* pop_stack = SERVER ? Q->srv_stack : Q->fly_stack;
-  short* pop_free = SERVER ? Q->srv_free : Q->fly_free;
-  int* pop_top = SERVER ? &Q->srv_top : &Q->fly_top;
-  int* pop_free_top = SERVER ? &Q->srv_free_top : &Q->fly_free_top;
-  const unsigned long long lt = (1ull << lane) - 1ull;
-  const int rank_push = __popcll(m_push & lt);
-  // look before locking: an idle wave must not fight for the lock when there is nothing to move
-  {
-    const bool can_push = (m_push != 0ull) && rq_ld(push_free_top) > 0;
-    const bool can_pop = rq_ld(pop_top) > 0;  // (a lane that pushes also wants to pop)
-    if (!can_push && !can_pop) return;
-  }
-
-  // ---- reserve: free records for the pushes, queued records for the pops -------------------
-  int ok = 1, n_push = 0, base_free = 0;
-  if (lane == 0) {
-    ok = rq_lock(Q, err) ? 1 : 0;
-    if (ok) {
-      const int ft = rq_ld(push_free_top);
-      n_push = __popcll(m_push) < ft ? __popcll(m_push) : ft;
-      base_free = ft - n_push;
-      rq_st(push_free_top, base_free);
-    }
-  }
-  ok = __shfl(ok, 0);
-  if (!ok) return;
-  n_push = __shfl(n_push, 0);
-  base_free = __shfl(base_free, 0);
-  const bool do_push = want_push && rank_push < n_push;
-  const bool wants = want_pop || do_push;
-  const unsigned long long m_pop = __ballot(wants);
-  const int rank_pop = __popcll(m_pop & lt);
-  int n_pop = 0, base_pop = 0;
-  if (lane == 0) {
-    const int pt = rq_ld(pop_top);
-    n_pop = __popcll(m_pop) < pt ? __popcll(m_pop) : pt;
-    base_pop = pt - n_pop;
-    rq_st(pop_top, base_pop);
-  }
-  n_pop = __shfl(n_pop, 0);
-  base_pop = __shfl(base_pop, 0);
-  const bool do_pop = wants && rank_pop < n_pop;
-  int id_push = -1, id_pop = -1;
-  if (do_push) id_push = ((volatile short*)push_free)[base_free + rank_push];
-  if (do_pop) id_pop = ((volatile short*)pop_stack)[base_pop + rank_pop];
-  if (lane == 0) rq_unlock(Q);  // (the fence inside orders the index reads above before the release)
-
-  // ---- move the packets ------------------------------------------------------------------
-  if (do_push) { rq_store(Q, id_push, p); pushed = true; p.st = S_EMIT; }
-  if (do_pop) { rq_load(Q, id_pop, p); popped = true; }
-  __threadfence_block();
-
-  // ---- publish the pushed records, return the popped ones to their free list ----------------
-  if (n_push > 0 || n_pop > 0) {
-    int tp = 0, fp = 0;
-    if (lane == 0) {
-      ok = rq_lock(Q, err) ? 1 : 0;
-      if (ok) {
-        tp = rq_ld(push_top);
-        fp = rq_ld(pop_free_top);
-      }
-    }
-    ok = __shfl(ok, 0);
-    if (!ok) return;
-    tp = __shfl(tp, 0);
-    fp = __shfl(fp, 0);
-    if (do_push) ((volatile short*)push_stack)[tp + rank_push] = (short)id_push;
-    if (do_pop) ((volatile short*)pop_free)[fp + rank_pop] = (short)id_pop;
-    if (lane == 0) {
+// Pop up to one index per lane with `want` from ring q; returns the index or -1.  Lanes are served in lane
+// order; entries whose producer has reserved but not yet written them end the batch early.
+__device__ inline int rq_pop(RqCtl* Q, unsigned int* rings, int q, int lane, bool want) {
+  const unsigned long long m = __ballot(want);
+  if (m == 0ull) return -1;
+  const int n = __popcll(m), rank = __popcll(m & ((1ull << lane) - 1ull));
+  const int leader = __ffsll((long long)m) - 1;
+  for (int attempt = 0; attempt < 8; ++attempt) {
+    const unsigned int h = rq_ldu(&Q->head[q]), t = rq_ldu(&Q->tail[q]);  // (same address in every lane)
+    const int avail = (int)(t - h);
+    if (avail <= 0) return -1;
+    int c = n < avail ? n : avail;
+    const bool mine = want && rank < c;
+    const unsigned int at = h + (unsigned int)rank;
+    unsigned int word = 0;
+    if (mine) word = rq_ldu(&rings[q * RQ_CAP + (at & (RQ_CAP - 1))]);
+    const bool ok = mine && (word >> 16) == ((at + 1u) & 0xFFFFu);
+    const unsigned long long bad = __ballot(mine && !ok);
+    if (bad) c = __popcll(m & ((1ull << (__ffsll((long long)bad) - 1)) - 1ull));  // entries in front of the first unpublished one
+    if (c == 0) return -1;
+    unsigned int old = 0;
+    if (lane == leader) old = atomicCAS(&Q->head[q], h, h + (unsigned int)c);
+    old = __shfl(old, leader);
+    if (old == h) {
       __threadfence_block();
-      rq_st(push_top, tp + n_push);
-      rq_st(pop_free_top, fp + n_pop);
-      rq_unlock(Q);
+      return (want && rank < c) ? (int)(word & 0xFFFFu) : -1;
     }
   }
+  return -1;
+}
+
+// what a lane needs to cross cells (registers)
+struct Flight {
+  double x, y, z, u, v, w, extr, S0, inv_a, inv_w, kf, kap, kab;
+  int ri, zj, k, star_key, st;
+  unsigned int pk_cross;
+};
+
+__device__ inline void flight_clear(Flight& F) {
+  F.x = F.y = F.z = F.u = F.v = 0.0; F.w = 1.0; F.extr = 0.0; F.S0 = 1.0; F.inv_a = F.inv_w = F.kf = F.kap = F.kab = 0.0;
+  F.ri = 0; F.zj = 1; F.k = 1; F.star_key = -1; F.st = S_EMIT; F.pk_cross = 0u;
+}
+
+template <bool L3D>
+__device__ inline void flight_constants(const Lds& T, const DevModel& M, Flight& F, int lambda) {
+  const double a = F.u * F.u + F.v * F.v;  // cylindrical_grid.f90:941-952
+  F.inv_a = (a > TINY_REAL) ? 1.0 / a : HUGE_REAL;
+  F.inv_w = (fabs(F.w) > TINY_REAL) ? 1.0 / F.w : copysign(HUGE_DP, F.w);
+  F.kap = T.kappa[lambda - 1];
+  F.kab = T.kabs[lambda - 1];
+  F.kf = is_real_cell<L3D>(M.n_rad, M.nz, F.ri, F.zj) ? M.kappa_factor[cell_index<L3D>(M.n_rad, M.nz, F.ri, F.zj, F.k)] : 0.0;
 }
 
 // One cell crossing of a packet in flight (physical_length's loop body, optical_depth.f90:77-178).  Returns the
@@ -208,9 +163,8 @@ __device__ inline void rq_exchange(RoleQ<POLA>* Q, int lane, bool want_push, boo
 // here at the end of the crossing that leads into the dark cell -- the entry point is still at hand, so the packet
 // needs no memory of it (a flight never starts inside a dark cell: packets are mirrored at its edge and the dark
 // cells emit nothing, thermal_emission.f90:1817).
-template <bool L3D, bool POLA, bool DARK, bool LDSE>
-__device__ inline int roles_cross(const Lds& T, const DevModel& M, const RunArgs& A, double* E_lds, PkState& p,
-                                  double inv_a, double inv_w, double kap, double kab, double& kf,
+template <bool L3D, bool DARK, bool LDSE>
+__device__ inline int roles_cross(const Lds& T, const DevModel& M, const RunArgs& A, double* E_lds, Flight& p,
                                   unsigned int& c_cross, unsigned int& c_kill, unsigned int& c_dark) {
   const int n_rad = M.n_rad, nz = M.nz;
   const int azj = p.zj < 0 ? -p.zj : p.zj;
@@ -226,16 +180,15 @@ __device__ inline int roles_cross(const Lds& T, const DevModel& M, const RunArgs
   const int ic = real_cell ? cell_index<L3D>(n_rad, nz, p.ri, p.zj, p.k) : 0;
   double x1, y1, z1, l;
   int ri1, zj1, k1;
-  MCGPU_CROSS<L3D>(T, M, p.x, p.y, p.z, p.u, p.v, p.w, inv_a, inv_w, p.ri, p.zj, p.k, x1, y1, z1, ri1, zj1, k1, l);
+  MCGPU_CROSS<L3D>(T, M, p.x, p.y, p.z, p.u, p.v, p.w, p.inv_a, p.inv_w, p.ri, p.zj, p.k, x1, y1, z1, ri1, zj1, k1, l);
   c_cross++;
-  if (++p.pk_cross > 200000000u) { *A.err = 13; p.st = S_EMIT; return 1; }
   // (kf was loaded at the end of the previous crossing: first used here, behind the geometry, so that the
   // latency of that load is covered by it)
-  const double opacity = real_cell ? kap * kf : 0.0;
+  const double opacity = real_cell ? p.kap * p.kf : 0.0;
   const double tau = l * opacity;
   if (tau > p.extr) {
     const double lc = l * (p.extr / tau);
-    if (real_cell && !(A.flags & 1)) deposit<LDSE>(A.E_abs, E_lds, ic, kab * lc * p.S[0]);
+    if (real_cell && !MCGPU_DIAG(A.flags, 1)) deposit<LDSE>(A.E_abs, E_lds, ic, p.kab * lc * p.S0);
     p.x = p.x + lc * p.u;
     p.y = p.y + lc * p.v;
     p.z = p.z + lc * p.w;
@@ -243,7 +196,7 @@ __device__ inline int roles_cross(const Lds& T, const DevModel& M, const RunArgs
     p.st = S_INTERACT;
   } else {
     p.extr = p.extr - tau;
-    if (real_cell && !(A.flags & 1)) deposit<LDSE>(A.E_abs, E_lds, ic, kab * l * p.S[0]);
+    if (real_cell && !MCGPU_DIAG(A.flags, 1)) deposit<LDSE>(A.E_abs, E_lds, ic, p.kab * l * p.S0);
     const bool next_real = is_real_cell<L3D>(n_rad, nz, ri1, zj1);
     const int ic1 = next_real ? cell_index<L3D>(n_rad, nz, ri1, zj1, k1) : 0;
     if (DARK && next_real && M.dark[ic1]) {
@@ -253,141 +206,311 @@ __device__ inline int roles_cross(const Lds& T, const DevModel& M, const RunArgs
     } else {
       p.x = x1; p.y = y1; p.z = z1;
       p.ri = ri1; p.zj = zj1; p.k = k1;
-      kf = next_real ? M.kappa_factor[ic1] : 0.0;
+      p.kf = next_real ? M.kappa_factor[ic1] : 0.0;
     }
   }
+  if (++p.pk_cross > 200000000u) { *A.err = 13; p.st = S_EMIT; return 1; }  // a packet that never leaves: flag it, drop it
   return 0;
 }
 
+// The same crossing for 2D grids, written for the instruction ISSUE rate that bounds this kernel (measured: the
+// loop runs at ~4 cycles per wave instruction of ANY kind at 2, 3 and 4 waves per SIMD alike, so its time is its
+// instruction count): one straight-line stream for all 64 lanes -- every lane computes, results are committed by
+// selects on `go` -- instead of nested divergent branches (each costs s_and_saveexec / s_or / s_cbranch plus the
+// moves that merge the two sides).  The only branches left are the ones whose bodies are expensive or have side
+// effects: the stop (an FP64 division), the deposit (an LDS atomic) and the rare default-real zj recomputation.
+// Every value that decides an index or a position is computed by the reference's expression, exactly as in
+// cross_cell_lean / roles_cross above (cylindrical_grid.f90:918-1175, optical_depth.f90:77-178).
+template <bool DARK, bool LDSE>
+__device__ __forceinline__ int fly_step_2d(const Lds& T, const DevModel& M, const RunArgs& A, double* E_lds, Flight& p,
+                                           unsigned int& c_cross, unsigned int& c_kill, unsigned int& c_dark) {
+  const int n_rad = M.n_rad, nz = M.nz;
+  const double cm = 1.0 - GRID_PREC, cp = 1.0 + GRID_PREC;
+  const bool active = (p.st == S_FLIGHT);
+  const int ri0 = p.ri, zj0 = p.zj;
+  const double x0 = p.x, y0 = p.y, z0 = p.z, u = p.u, v = p.v, w = p.w;
+  const bool top = (zj0 == nz + 1);
+  // test_exit_grid_cyl (cylindrical_grid.f90:680-704) in closed form; the star's cell (optical_depth.f90:91-97)
+  const bool out = (ri0 == n_rad + 1) || (top && (fabs(z0) > M.zmaxmax));
+  const bool killed = (p.star_key >= 0) && (ri0 + (n_rad + 2) * (zj0 + nz + 1) == p.star_key);
+  const bool go = active && !out && !killed;
+  const bool hole = (ri0 == 0);
+  const bool real_cell = (ri0 >= 1) && (ri0 <= n_rad) && (zj0 >= 1) && (zj0 <= nz);
+  const int ic = real_cell ? (ri0 - 1) + n_rad * (zj0 - 1) : 0;
+  // rows of the tables (lanes outside the grid read a valid row; their results are discarded)
+  const int row_in = hole ? 0 : (ri0 - 1 < n_rad ? ri0 - 1 : n_rad - 1);
+  const int row_out = hole ? 0 : (ri0 < n_rad ? ri0 : n_rad);
+
+  // 1) radial wall (:959-1000)
+  const double r_2 = x0 * x0 + y0 * y0;
+  const double dot = x0 * u + y0 * v;
+  const double b = dot * p.inv_a;
+  const double rl_in = T.r_lim_2[row_in];
+  const double rl_out = T.r_lim_2[row_out];
+  const double c_in = (r_2 - (hole ? rl_in : rl_in * cm)) * p.inv_a;
+  const double c_out = (r_2 - rl_out * cp) * p.inv_a;
+  const double bb = b * b;
+  const double d_in = bb - c_in;
+  const double d_out = fmax(bb - c_out, 0.0);
+  const bool use_in = hole || ((dot < 0.0) && !(d_in < 0.0));
+  const double delta = use_in ? d_in : d_out;
+  const int delta_rad = (use_in && !hole) ? -1 : 1;
+  const double rac = sqrt(delta);
+  const double s1 = (-b - rac) * cp, s2 = (-b + rac) * cp;
+  double s = (s1 < 0.0) ? s2 : ((s1 == 0.0) ? GRID_PREC : s1);
+  s = hole ? s2 : s;
+
+  // 2) vertical wall (:1003-1055), 2D: zj >= 1, the midplane mirrors
+  const double dz = w * z0;
+  const bool away = dz > 0.0;
+  const bool flip = !away && (zj0 == 1);  // through the midplane to the mirror side
+  const int jsel = away ? zj0 + 1 : (zj0 == 1 ? 2 : zj0);
+  const double chr = T.ch[row_in], zmr = T.zmax[row_in];
+  double zmag = (jsel <= nz) ? ((double)jsel - 1.0) * chr : ((jsel == nz + 1) ? zmr : 1.00000001504746621988e+30);
+  zmag = zmag * (away ? cp : cm);
+  zmag = (away && top) ? 1.0e10 : zmag;
+  const bool neg = (z0 < 0.0) != flip;
+  const double zl = neg ? -zmag : zmag;
+  const int delta_zj = away ? (top ? 0 : 1) : ((zj0 == 1) ? 1 : -1);
+  double t = (zl - z0) * p.inv_w;
+  t = (t < 0.0) ? GRID_PREC : t;
+  t = (dz == 0.0) ? 1.0e10 : t;
+  t = hole ? HUGE_REAL : t;
+
+  // 3) nearest wall (:1098-1156)
+  const bool rad = (s < t);
+  const double l = rad ? s : t;
+  const double x1 = x0 + l * u;
+  const double y1 = y0 + l * v;
+  // products rounded before the sum, like the reference build (see cross_cell_lean)
+  double z1 = nd_add(z0, nd_mul(l, w));
+  const int ri1 = rad ? ri0 + delta_rad : ri0;
+  // zj of the end point for a radial move (:1116): the fast form of zj_capped, its rare default-real fallback below
+  const int row1 = ri1 < 1 ? 0 : (ri1 > n_rad ? n_rad - 1 : ri1 - 1);
+  const double qd = fabs(z1) * T.rzn[row1];
+  const double fl = floor(qd);
+  const double fr = qd - fl;
+  const bool far_above = !(qd < (double)nz + 0.5);
+  int zjr = far_above ? nz + 1 : (int)fl + 1;
+  zjr = zjr > nz ? nz + 1 : zjr;
+  const bool rad_in = rad && (ri1 >= 1) && (ri1 <= n_rad);
+  if (go && rad_in && !far_above && (fr < 1.0e-4 || fr > 1.0 - 1.0e-4)) {  // (rare) within 1e-4 of an integer
+    int zq = zj_from_z_real(T, nz, fabs(z1), ri1);
+    zjr = zq > nz ? nz + 1 : zq;
+  }
+  zjr = (ri1 == 0) ? 1 : ((ri1 > n_rad) ? zj0 : zjr);
+  const int zj1 = rad ? zjr : zj0 + delta_zj;
+  z1 = (z1 == 0.0) ? GRID_PREC : z1;
+
+  // 4) optical depth of the crossing, stop or go on (optical_depth.f90:102, 134-146)
+  // (kf was loaded at the end of the previous crossing: first used here, behind the geometry)
+  const double opacity = real_cell ? p.kap * p.kf : 0.0;
+  const double tau = l * opacity;
+  const bool stop = go && (tau > p.extr);
+  double lc = l;
+  if (stop) lc = l * (p.extr / tau);
+  // save_radiation_field (radiation_field.f90:53)
+  if (go && real_cell && !MCGPU_DIAG(A.flags, 1)) deposit<LDSE>(A.E_abs, E_lds, ic, p.kab * lc * p.S0);
+
+  // the next cell; DARK: mirrored back at the wall of a dark cell (see roles_cross)
+  const bool next_real = (ri1 >= 1) && (ri1 <= n_rad) && (zj1 >= 1) && (zj1 <= nz);
+  const int ic1 = next_real ? (ri1 - 1) + n_rad * (zj1 - 1) : 0;
+  bool mirror = false;
+  if (DARK) mirror = go && !stop && next_real && M.dark[ic1];
+  const bool move = go && !stop && !mirror;
+  const double kf1 = M.kappa_factor[ic1];   // (lanes without a next cell read cell 0 and drop it)
+
+  // 5) commit
+  const double xs = x0 + lc * u, ys = y0 + lc * v, zs = z0 + lc * w;
+  p.x = stop ? xs : (move ? x1 : x0);
+  p.y = stop ? ys : (move ? y1 : y0);
+  p.z = stop ? zs : (move ? z1 : z0);
+  p.extr = (go && !stop) ? p.extr - tau : p.extr;
+  p.ri = move ? ri1 : ri0;
+  p.zj = move ? zj1 : zj0;
+  p.kf = move ? (next_real ? kf1 : 0.0) : p.kf;
+  if (DARK) {
+    p.u = mirror ? -u : u; p.v = mirror ? -v : v; p.w = mirror ? -w : w;
+    c_dark += mirror ? 1u : 0u;
+  }
+  int st = p.st;
+  st = (active && out) ? S_EXITED : st;
+  st = (active && !out && killed) ? S_EMIT : st;
+  st = (stop || mirror) ? S_INTERACT : st;
+  c_cross += go ? 1u : 0u;
+  c_kill += (active && !out && killed) ? 1u : 0u;
+  p.pk_cross += go ? 1u : 0u;
+  const bool runaway = go && (p.pk_cross > 200000000u);  // a packet that never leaves: flag it, drop it
+  if (runaway) { *A.err = 13; st = S_EMIT; }
+  p.st = st;
+  return ((active && !out && killed) || runaway) ? 1 : 0;
+}
+
+// the compiler must not carry values from one serving phase to the next in registers: they go through the record
+#ifndef MCGPU_LANE_EMULATION
+#define RQ_PHASE_END() asm volatile("" ::: "memory")
+#else
+#define RQ_PHASE_END()
+#endif
+
 template <bool L3D, bool POLA, bool DARK, bool LDSE>
-__device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, double* lds_base, int n_flyers,
-                                           int k_short, int fly_iters, int fly_idle, int emit_qmax, int emit_min) {
+__device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, double* lds_base, int n_rec, int n_srv_pref,
+                                           int k_short, int fly_iters, int fly_idle, int emit_qmax) {
   double* const E_lds = lds_base;
   const Lds T = lds_carve(lds_base + (LDSE ? M.n_cells : 0), M);
   lds_stage(T, M);
-  RoleQ<POLA>* Q = reinterpret_cast<RoleQ<POLA>*>(lds_base + (LDSE ? M.n_cells : 0) + (lds_bytes(M) + 7) / 8);
+  char* const qbase = reinterpret_cast<char*>(lds_base + (LDSE ? M.n_cells : 0) + (lds_bytes(M) + 7) / 8);
+  RqCtl* const Q = reinterpret_cast<RqCtl*>(qbase);
+  unsigned int* const rings = reinterpret_cast<unsigned int*>(qbase + sizeof(RqCtl));
+  Rec<POLA>* const recs = reinterpret_cast<Rec<POLA>*>(qbase + sizeof(RqCtl) + 3 * RQ_CAP * sizeof(unsigned int));
   if (LDSE)
     for (int i = threadIdx.x; i < M.n_cells; i += blockDim.x) E_lds[i] = 0.0;
-  for (int i = threadIdx.x; i < RQ_NF; i += blockDim.x) Q->fly_free[i] = (short)i;
-  for (int i = threadIdx.x; i < RQ_NS; i += blockDim.x) Q->srv_free[i] = (short)(RQ_NF + i);
+  for (int i = threadIdx.x; i < 3 * RQ_CAP; i += blockDim.x)  // every record starts on the FREE ring
+    rings[i] = (i < n_rec) ? ((((unsigned int)i + 1u) << 16) | (unsigned int)i) : 0u;
   if (threadIdx.x == 0) {
-    Q->lock = 0; Q->n_pending = 0; Q->ids_done = 0; Q->abort_flag = 0;
-    Q->fly_top = 0; Q->fly_free_top = RQ_NF; Q->srv_top = 0; Q->srv_free_top = RQ_NS;
+    Q->n_pending = 0; Q->ids_done = 0; Q->abort_flag = 0;
+    Q->head[0] = Q->head[1] = Q->head[2] = 0u;
+    Q->tail[RQ_FREE] = (unsigned int)n_rec; Q->tail[RQ_FLY] = 0u; Q->tail[RQ_SRV] = 0u;
   }
   __syncthreads();
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n_rad = M.n_rad, nz = M.nz;
-  bool flyer = wave < n_flyers;  // n_flyers >= 100: every wave picks its role anew in each round
-  const bool auto_roles = n_flyers >= 100;
-  const int fly_fill = auto_roles ? n_flyers - 100 : 0;  // policy A: become a flyer when so many lanes can fly
-  PkState p;
-  p.x = p.y = p.z = p.u = p.v = 0.0; p.w = 1.0; p.extr = 0.0;
-  p.S[0] = 1.0; p.S[1] = p.S[2] = p.S[3] = 0.0;
-  p.ri = 0; p.zj = 1; p.k = 1; p.lambda = 1; p.star_key = -1;
-  p.rng.init(A.seed, 0);
-  p.flag_star = p.flag_scatt = p.flag_ism = false;
-  p.st = S_EMIT;  // S_EMIT = the lane holds no packet
-  p.tau_rand = 0.0f; p.pk_cross = 0;
-  double inv_a = 0.0, inv_w = 0.0, kf = 0.0;
-  double kap = 0.0, kab = 0.0;  // kappa(lambda), kappa_abs(lambda) of the packet in this lane: constants of a flight
+  const bool prefer_server = wave < n_srv_pref;
+  const int free_reserve = n_rec / 8 < 32 ? n_rec / 8 : 32;
+  const uint32_t key0 = (uint32_t)A.seed, key1 = (uint32_t)(A.seed >> 32);
+
+  // ---- per-lane state ------------------------------------------------------------------------------------
+  // serving: rid >= 0 names the record this lane owns, st its packet's state (S_INTERACT between rounds)
+  // flying:  rid < 0 and F, bag_* hold a packet (st = S_FLIGHT, or S_INTERACT / S_EXITED once it stopped); st = S_EMIT: empty
+  int rid = -1, st = S_EMIT;
+  Flight F;
+  flight_clear(F);
+  double bag_S1 = 0.0, bag_S2 = 0.0, bag_S3 = 0.0;     // what a packet carries but a flight does not use
+  uint32_t bag_plo = 0, bag_phi = 0, bag_event = 0;
+  int bag_lambda = 1, bag_fl = 0;
+  float bag_tau = 0.0f;
+
   unsigned int c_cross = 0, c_flight = 0, c_scatt = 0, c_abs = 0, c_esc = 0, c_kill = 0, c_pack = 0, c_dark = 0;
   unsigned long long pk_next = 0, pk_end = 0;
   bool no_more_ids = false;  // wave-uniform: the global id counter is exhausted
   int idle_spins = 0;        // consecutive rounds without work: bounded, a lost packet must not hang the GPU
   RQ_DIAG(unsigned int d_fly_iters = 0, d_srv_iters = 0, d_fly_cross = 0, d_srv_rounds = 0, d_fly_rounds = 0;)
-  RQ_DIAG(unsigned int d_in_flight = 0, d_handed = 0, d_popped = 0, d_empty = 0;)
+  RQ_DIAG(unsigned int d_srv_lanes = 0, d_srv_int = 0, d_emit = 0;)
 
-  // diagnostics (A.flags bit 1): wall-clock (100 MHz) of this wave's start, of the moment the packet ids ran out
-  // and of its end, summed over the waves into counters[10..14] (tools/wave_timeline.py)
-  const unsigned long long t_start = (A.flags & 2) ? wall_clock64() : 0ull;
-  unsigned long long t_ids_out = 0;
   for (int ep = 0;; ++ep) {
     if (rq_ld(&Q->abort_flag)) break;
-    if ((A.flags & 2) && no_more_ids && !t_ids_out) t_ids_out = wall_clock64();
     int finished = 0;  // packets this lane finished in this round
-    if (auto_roles) {
-      // fly when the lanes can be (nearly) filled with packets in flight -- the wave's own plus the queue's --
-      // and the packets that wait here for their interaction can be handed over; serve otherwise
-      const int nF = __popcll(__ballot(p.st == S_FLIGHT)), nI = __popcll(__ballot(p.st == S_INTERACT));
-      const int ft = rq_ld(&Q->fly_top), sfree = rq_ld(&Q->srv_free_top);
-      if (n_flyers < 200) {  // policy A: fly when at least fly_fill lanes can fly
-        const int room = 64 - nF;
-        flyer = (nF + (ft < room ? ft : room) >= fly_fill) && (sfree >= nI);
-      } else {  // policy B (default): take the role in which more of the 64 lanes have work in this round
-        const int stq = rq_ld(&Q->srv_top), ffree = rq_ld(&Q->fly_free_top);
-        const int keepI = nI - (nI < sfree ? nI : sfree);          // waiting packets a flyer could not hand over
-        const int roomF = 64 - nF - keepI;
-        const int fly_pot = nF + (ft < roomF ? ft : roomF);
-        const int keepF = nF - (nF < ffree ? nF : ffree);          // flights a server could not hand over
-        const int roomS = 64 - nI - keepF;
-        const bool can_emit = !no_more_ids && (ft + stq) <= emit_qmax;  // (new packets fill the rest)
-        const int srv_pot = nI + (can_emit ? roomS : (stq < roomS ? stq : roomS));
-        flyer = fly_pot >= srv_pot;
+
+    // ---- which role this round -----------------------------------------------------------------------
+    const bool any_owned = __ballot(rid >= 0) != 0ull;
+    const bool any_held = __ballot(rid < 0 && st != S_EMIT) != 0ull;
+    const int fly_n = rq_count(Q, RQ_FLY), srv_n = rq_count(Q, RQ_SRV);
+    // (new packets leave free records for the flyers' stopped packets)
+    const bool can_emit = !no_more_ids && fly_n <= emit_qmax && rq_count(Q, RQ_FREE) > free_reserve;
+    // Liveness: a wave that holds stopped packets in registers cannot serve, and it can only put them down into a
+    // free record or a FLY record.  So the waves that prefer to serve NEVER take packets into registers (they fly
+    // long flights in place, below): whatever the others hold, somebody always empties the SRV ring, which turns
+    // waiting packets into FLY records or free records.
+    bool serve;
+    if (prefer_server) {
+      serve = true;
+    } else if (any_owned) {
+      serve = true;
+      // a wave that prefers to fly gives its waiting packets back when long flights pile up
+      if (fly_n >= 64) {
+        rq_push(Q, rings, RQ_SRV, lane, rid >= 0, rid);
+        rid = -1; st = S_EMIT;
+        serve = false;
       }
-      // the tail: flights left in the queue when there is nothing to serve or emit any more must still be flown
-      if (!flyer && ft > 0 && nI == 0 && no_more_ids && rq_ld(&Q->srv_top) == 0) flyer = true;
+    } else if (any_held) {
+      serve = false;
+    } else {
+      serve = (fly_n == 0) && ((srv_n > 0) || can_emit);
     }
 
-    if (flyer) {
-      // ---- FLYER: hand over the packets that stopped, take long flights from the queue ------
-      bool pushed, popped;
-      rq_exchange<POLA, false>(Q, lane, p.st == S_INTERACT, p.st == S_EMIT, p, pushed, popped, A.err);
-      if (popped) {  // per-flight constants (cylindrical_grid.f90:941-952) and the cell's opacity factor
-        const double a = p.u * p.u + p.v * p.v;
-        inv_a = (a > TINY_REAL) ? 1.0 / a : HUGE_REAL;
-        inv_w = (fabs(p.w) > TINY_REAL) ? 1.0 / p.w : copysign(HUGE_DP, p.w);
-        kf = is_real_cell<L3D>(n_rad, nz, p.ri, p.zj) ? M.kappa_factor[cell_index<L3D>(n_rad, nz, p.ri, p.zj, p.k)] : 0.0;
-        kap = T.kappa[p.lambda - 1]; kab = T.kabs[p.lambda - 1];
+    if (!serve) {
+      // ======================= FLYING ==================================================================
+      // lanes whose packet stopped swap it for a long flight, empty lanes load one
+      const bool stopped = (st == S_INTERACT || st == S_EXITED);  // (packets that left the grid are binned by the servers)
+      const int rin = rq_pop(Q, rings, RQ_FLY, lane, st != S_FLIGHT);
+      int rout = -1;  // record that leaves with this lane's stopped packet
+      if (rin >= 0) {
+        Rec<POLA>& R = recs[rin];
+        if (stopped) {
+          // swap registers <-> record, field by field: the record then holds the stopped packet
+#define RQ_SWAP(reg, fld) do { const auto t_ = (fld); (fld) = (reg); (reg) = t_; } while (0)
+          RQ_SWAP(F.x, R.x); RQ_SWAP(F.y, R.y); RQ_SWAP(F.z, R.z); RQ_SWAP(F.u, R.u); RQ_SWAP(F.v, R.v); RQ_SWAP(F.w, R.w);
+          RQ_SWAP(F.extr, R.extr); RQ_SWAP(F.S0, R.S[0]);
+          if (POLA) { RQ_SWAP(bag_S1, R.S[POLA ? 1 : 0]); RQ_SWAP(bag_S2, R.S[POLA ? 2 : 0]); RQ_SWAP(bag_S3, R.S[POLA ? 3 : 0]); }
+          RQ_SWAP(F.ri, R.ri); RQ_SWAP(F.zj, R.zj); RQ_SWAP(F.k, R.k); RQ_SWAP(bag_lambda, R.lambda); RQ_SWAP(F.star_key, R.star_key);
+          RQ_SWAP(bag_plo, R.p_lo); RQ_SWAP(bag_phi, R.p_hi); RQ_SWAP(bag_event, R.event);
+          RQ_SWAP(F.pk_cross, R.pk_cross); RQ_SWAP(bag_tau, R.tau_rand);
+#undef RQ_SWAP
+          const int fl_in = R.flags;
+          R.flags = st | bag_fl;
+          bag_fl = fl_in & ~ST_MASK;
+          rout = rin;
+        } else {
+          F.x = R.x; F.y = R.y; F.z = R.z; F.u = R.u; F.v = R.v; F.w = R.w; F.extr = R.extr; F.S0 = R.S[0];
+          if (POLA) { bag_S1 = R.S[POLA ? 1 : 0]; bag_S2 = R.S[POLA ? 2 : 0]; bag_S3 = R.S[POLA ? 3 : 0]; }
+          F.ri = R.ri; F.zj = R.zj; F.k = R.k; bag_lambda = R.lambda; F.star_key = R.star_key;
+          bag_plo = R.p_lo; bag_phi = R.p_hi; bag_event = R.event; F.pk_cross = R.pk_cross; bag_tau = R.tau_rand;
+          bag_fl = R.flags & ~ST_MASK;
+        }
+        st = S_FLIGHT;
+        flight_constants<L3D>(T, M, F, bag_lambda);
       }
-      if (p.st == S_EXITED) {  // (left over from a round as a server)
-        if (!p.flag_ism) { capteur<POLA>(M, A.sed, p.lambda, p.u, p.v, p.w, p.S, p.flag_star, p.flag_scatt); c_esc++; }
-        p.st = S_EMIT;
-        finished++;
-      }
-      const bool nothing_to_fly = __ballot(p.st == S_FLIGHT) == 0ull;
-      if (nothing_to_fly) {
-        if (__ballot(finished > 0) == 0ull && __ballot(p.st == S_INTERACT) == 0ull && rq_ld(&Q->ids_done) &&
-            rq_ld(&Q->n_pending) == 0)
-          break;  // (every operand is wave-uniform)
-        __builtin_amdgcn_s_sleep(32);  // nothing to fly: wait for the servers
-        if (++idle_spins > (1 << 26)) { *A.err = 15; rq_st(&Q->abort_flag, 1); }  // (minutes: a lost packet, not a long tail)
-      } else {
-      idle_spins = 0;
-      RQ_DIAG(if (lane == 0) d_fly_rounds++;)
-#pragma unroll 1
-      for (int it = 0; it < fly_iters; ++it) {
-        // back to the queues as soon as enough lanes have nothing to fly (or after fly_iters crossings)
-        if (it > 0 && __popcll(__ballot(p.st != S_FLIGHT)) >= fly_idle) break;
-        RQ_DIAG(if (lane == 0) d_fly_iters++; if (p.st == S_FLIGHT) d_fly_cross++;)
-        if (p.st == S_FLIGHT) finished += roles_cross<L3D, POLA, DARK, LDSE>(T, M, A, E_lds, p, inv_a, inv_w, kap, kab, kf, c_cross, c_kill, c_dark);
-        if (p.st == S_EXITED) {  // binned on the spot (capteur)
-          if (!p.flag_ism) { capteur<POLA>(M, A.sed, p.lambda, p.u, p.v, p.w, p.S, p.flag_star, p.flag_scatt); c_esc++; }
-          p.st = S_EMIT;
-          finished++;
+      // stopped packets that found no flight to swap with go to a free record
+      {
+        const int rf = rq_pop(Q, rings, RQ_FREE, lane, st == S_INTERACT || st == S_EXITED);
+        if (rf >= 0) {
+          Rec<POLA>& R = recs[rf];
+          R.x = F.x; R.y = F.y; R.z = F.z; R.u = F.u; R.v = F.v; R.w = F.w; R.extr = F.extr; R.S[0] = F.S0;
+          if (POLA) { R.S[POLA ? 1 : 0] = bag_S1; R.S[POLA ? 2 : 0] = bag_S2; R.S[POLA ? 3 : 0] = bag_S3; }
+          R.ri = F.ri; R.zj = F.zj; R.k = F.k; R.lambda = bag_lambda; R.star_key = F.star_key;
+          R.p_lo = bag_plo; R.p_hi = bag_phi; R.event = bag_event; R.pk_cross = F.pk_cross; R.tau_rand = bag_tau;
+          R.flags = st | bag_fl;
+          rout = rf;
+          st = S_EMIT;
         }
       }
-      }  // something to fly
-    } else {
-      // ---- SERVER ------------------------------------------------------------------------------
-      RQ_DIAG(if (lane == 0) d_srv_rounds++;)
-      // long flights go to the flyers, empty lanes take packets that wait for their interaction
-      bool pushed, popped;
-      RQ_DIAG(if (p.st == S_FLIGHT) d_in_flight++;)  // lanes that come into the server round with a flight
-      rq_exchange<POLA, true>(Q, lane, p.st == S_FLIGHT && n_flyers > 0, p.st == S_EMIT, p, pushed, popped, A.err);
-      RQ_DIAG(if (pushed) d_handed++; if (popped) d_popped++; if (p.st == S_EMIT) d_empty++;)
+      rq_push(Q, rings, RQ_SRV, lane, rout >= 0, rout);
+      rq_push(Q, rings, RQ_FREE, lane, rin >= 0 && rout != rin, rin);  // loaded, not swapped: the record is free again
 
-      // EMIT: lanes that are still empty start new packets (mc_photon_loop body, dust_transfer.f90:529-541)
+      if (__ballot(st == S_FLIGHT) == 0ull) {
+        if (__ballot(st != S_EMIT) == 0ull && rq_ld(&Q->ids_done) && rq_ld(&Q->n_pending) == 0) break;
+        __builtin_amdgcn_s_sleep(16);  // nothing to fly (or no record for a stopped packet): wait for the others
+        if (++idle_spins > (1 << 21)) { *A.err = 15; rq_st(&Q->abort_flag, 1); }  // (seconds without any work: a lost packet, not a long tail)
+      } else {
+        idle_spins = 0;
+        RQ_DIAG(if (lane == 0) d_fly_rounds++;)
+        F.st = st;
+#pragma unroll 1
+        for (int it = 0; it < fly_iters; ++it) {
+          // back to the rings as soon as enough lanes have nothing to fly (or after fly_iters crossings)
+          if (it > 0 && __popcll(__ballot(F.st != S_FLIGHT)) >= fly_idle) break;
+          RQ_DIAG(if (lane == 0) d_fly_iters++; if (F.st == S_FLIGHT) d_fly_cross++;)
+          if (L3D) {
+            if (F.st == S_FLIGHT) finished += roles_cross<L3D, DARK, LDSE>(T, M, A, E_lds, F, c_cross, c_kill, c_dark);
+          } else {
+            finished += fly_step_2d<DARK, LDSE>(T, M, A, E_lds, F, c_cross, c_kill, c_dark);
+          }
+        }
+        st = F.st;
+      }
+    } else {
+      // ======================= SERVING =================================================================
+      RQ_DIAG(if (lane == 0) d_srv_rounds++;)
+      // ---- lanes without a record take a packet that waits for its interaction ... ----------------------
+      if (__ballot(rid < 0) != 0ull) {
+        const int r = rq_pop(Q, rings, RQ_SRV, lane, rid < 0);
+        if (r >= 0) { rid = r; st = recs[r].flags & ST_MASK; }  // (S_INTERACT, or S_EXITED: to be binned)
+      }
+      // ---- ... or a free record for a new packet (mc_photon_loop body, dust_transfer.f90:529-541) -------
       {
-        const bool need = (p.st == S_EMIT);
-        const unsigned long long mask = __ballot(need);
-        // new packets only while the queues are not loaded: a workgroup that keeps every lane AND both queues
-        // full cannot move packets between its waves any more
-        // ... and only for several lanes at a time (the emission code costs the wave the same for 1 lane or 64),
-        // unless the wave has nothing else to do
-        const int n_need = __popcll(mask);
-        const bool emit_now = n_need >= emit_min || __ballot(p.st != S_EMIT) == 0ull;
-        if (mask && emit_now && !no_more_ids && (rq_ld(&Q->fly_top) + rq_ld(&Q->srv_top)) <= emit_qmax) {
+        const unsigned long long mask = __ballot(rid < 0);
+        if (mask && can_emit) {
           if (pk_next >= pk_end) {
             const int leader = __ffsll((long long)mask) - 1;
             unsigned long long base = 0;
@@ -411,94 +534,183 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
           }
           const unsigned long long avail = pk_end - pk_next;
           const unsigned long long rank = (unsigned long long)__popcll(mask & ((1ull << lane) - 1ull));
-          const unsigned long long cnt = (unsigned long long)__popcll(mask);
-          const unsigned long long my = pk_next + rank;
-          const bool served = need && (rank < avail);
-          pk_next += (cnt < avail) ? cnt : avail;
-          if (served) {
-            p.rng.init(A.seed, A.first_packet + my);
+          const int r = rq_pop(Q, rings, RQ_FREE, lane, rid < 0 && rank < avail);
+          // ids go to the lanes that got a record, in lane order
+          const unsigned long long got = __ballot(r >= 0);
+          const unsigned long long my = pk_next + (unsigned long long)__popcll(got & ((1ull << lane) - 1ull));
+          pk_next += (unsigned long long)__popcll(got);
+          if (r >= 0) {
+            rid = r;
+            Rec<POLA>& R = recs[rid];
+            Rng rng;
+            rng.init(A.seed, A.first_packet + my);
             c_pack++;
-            p.pk_cross = 0;
+            RQ_DIAG(d_emit++;)
             float f[12];
-            p.rng.emission_event(f);
-            p.tau_rand = f[8];
-            p.lambda = select_wl_em(T, M, f[0]);
-            atomic_add_f64(&A.n_sent[p.lambda - 1], 1.0);
-            bool lintersect;
-            p.flag_scatt = false;
-            p.S[0] = 1.0; p.S[1] = 0.0; p.S[2] = 0.0; p.S[3] = 0.0;
-            CylEmitOps<L3D> ops{T, M, p.ri, p.zj, p.k};
-            const int rc = emit_packet(M, f, p.lambda, T.fstar[p.lambda - 1], M.frac_E_disk[p.lambda - 1],
-                                       M.prob_E_cell ? M.prob_E_cell + (size_t)(M.n_cells + 1) * (p.lambda - 1) : nullptr,
-                                       ops, p.x, p.y, p.z, p.u, p.v, p.w, p.flag_star, p.flag_ism, lintersect);
+            rng.emission_event(f);
+            const int lambda = select_wl_em(T, M, f[0]);
+            lds_count_sent(T, lambda);
+            bool lintersect, flag_star, flag_ism;
+            double x, y, z, u, v, w;
+            int ri = 0, zj = 1, k = 1;
+            CylEmitOps<L3D> ops{T, M, ri, zj, k};
+            const int rc = emit_packet(M, f, lambda, T.fstar[lambda - 1], M.frac_E_disk[lambda - 1],
+                                       M.prob_E_cell ? M.prob_E_cell + (size_t)(M.n_cells + 1) * (lambda - 1) : nullptr,
+                                       ops, x, y, z, u, v, w, flag_star, flag_ism, lintersect);
             if (rc) { *A.err = rc; rq_st(&Q->abort_flag, 1); }
-            p.st = lintersect ? S_NEWFLIGHT : S_EXITED;
+            st = lintersect ? S_NEWFLIGHT : S_EXITED;
+            R.x = x; R.y = y; R.z = z; R.u = u; R.v = v; R.w = w; R.extr = 0.0;
+            R.S[0] = 1.0;
+            if (POLA) { R.S[POLA ? 1 : 0] = 0.0; R.S[POLA ? 2 : 0] = 0.0; R.S[POLA ? 3 : 0] = 0.0; }
+            R.ri = ri; R.zj = zj; R.k = k; R.lambda = lambda; R.star_key = -1;
+            R.p_lo = rng.p_lo; R.p_hi = rng.p_hi; R.event = rng.event;
+            R.flags = st | (flag_star ? ST_STAR : 0) | (flag_ism ? ST_ISM : 0);
+            R.pk_cross = 0u;
+            R.tau_rand = f[8];
           }
         }
       }
-      if (p.st == S_EXITED) {  // capteur
-        if (!p.flag_ism) { capteur<POLA>(M, A.sed, p.lambda, p.u, p.v, p.w, p.S, p.flag_star, p.flag_scatt); c_esc++; }
-        p.st = S_EMIT;
-        finished++;
+      // ---- ... or, when the wave has little to serve, a long flight that it flies in place (the record stays the
+      // packet's home: loaded, crossed fly_iters times, stored back) ------------------------------------------
+      bool flying_in_place = false;
+      if (prefer_server && __popcll(__ballot(rid >= 0)) < 32) {
+        const int r = rq_pop(Q, rings, RQ_FLY, lane, rid < 0);
+        if (r >= 0) { rid = r; st = S_FLIGHT; }
+        flying_in_place = __ballot(r >= 0) != 0ull;
       }
-      if (p.st == S_INTERACT) {  // dust_transfer.f90:1260-1402
-        float g[8];
-        p.rng.interaction_event(g);
-        p.tau_rand = g[5];
-        double u1, v1, w1;
-        const int ic = cell_index<L3D>(n_rad, nz, p.ri, p.zj, p.k);
-        interact<POLA>(T, M, g, p.lambda, p.u, p.v, p.w, u1, v1, w1, p.S, p.flag_star, p.flag_scatt, c_scatt, c_abs, [&]() {
-          double E;
-          if (A.frozen) E = A.E_prior[ic];
-          else {
-            E = __hip_atomic_load(&A.E_abs[ic], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (LDSE) E += E_lds[ic] * (double)gridDim.x;
-            E *= A.qscale;
-          }
-          return E;
-        }, M.volume + ic);
-        if (!p.flag_scatt) p.flag_ism = false;
-        p.u = u1; p.v = v1; p.w = w1;
-        p.st = S_NEWFLIGHT;
-      }
-      if (p.st == S_NEWFLIGHT) {
-        const float rand = p.tau_rand;
-        p.extr = (rand > 1.0e-6f) ? -log(1.0 - (double)rand) : (double)rand;
-        const int i_star = intersect_stars(M, p.x, p.y, p.z, p.u, p.v, p.w);
-        p.star_key = -1;
-        if (i_star > 0) {
-          const int* sc = &M.star_cell[4 * (i_star - 1)];
-          p.star_key = sc[0] + (n_rad + 2) * ((sc[1] + nz + 1) + (2 * nz + 3) * (sc[2] - 1));
-        }
-        c_flight++;
-        p.st = S_FLIGHT;
-      }
-      // per-flight constants of whatever flies in this lane now (new flight, or one kept because the
-      // FLY queue was full)
-      {
-        const double a = p.u * p.u + p.v * p.v;
-        inv_a = (a > TINY_REAL) ? 1.0 / a : HUGE_REAL;
-        inv_w = (fabs(p.w) > TINY_REAL) ? 1.0 / p.w : copysign(HUGE_DP, p.w);
-        kap = T.kappa[p.lambda - 1]; kab = T.kabs[p.lambda - 1];
-        if (p.st == S_FLIGHT)
-          kf = is_real_cell<L3D>(n_rad, nz, p.ri, p.zj) ? M.kappa_factor[cell_index<L3D>(n_rad, nz, p.ri, p.zj, p.k)] : 0.0;
-      }
-      if (__ballot(p.st != S_EMIT) == 0ull) {  // the wave holds no packet at all
-        if (no_more_ids && rq_ld(&Q->n_pending) == 0) break;
-        if (no_more_ids) {  // packets are with the flyers: wait for them to come back
-          __builtin_amdgcn_s_sleep(32);
-          if (++idle_spins > (1 << 26)) { *A.err = 15; rq_st(&Q->abort_flag, 1); }
-        }
+      RQ_PHASE_END();
+      RQ_DIAG(if (rid >= 0) d_srv_lanes++; if (st == S_INTERACT && rid >= 0) d_srv_int++;)
+
+      if (__ballot(rid >= 0) == 0ull) {  // the wave owns no packet at all
+        if (rq_ld(&Q->ids_done) && rq_ld(&Q->n_pending) == 0) break;
+        __builtin_amdgcn_s_sleep(16);
+        if (++idle_spins > (1 << 21)) { *A.err = 15; rq_st(&Q->abort_flag, 1); }
       } else {
         idle_spins = 0;
-      }
-      // the first crossings of every flight
+        // ---- INTERACT: scatter or absorb + re-emit (dust_transfer.f90:1260-1402), in two phases: the event and
+        // the new direction, then (Stokes tracking) the Stokes vector.  Only the new direction, the scattering
+        // angle bin and one draw cross the phase boundary in registers.
+        double u1 = 0.0, v1 = 0.0, w1 = 1.0;
+        int itheta = 1, lambda_sc = 1;
+        float rand2 = 0.0f;
+        bool scat = false;
+        const bool inter = rid >= 0 && st == S_INTERACT;
+        if (inter) {
+          Rec<POLA>& R = recs[rid];
+          Rng rng;
+          rng.k0 = key0; rng.k1 = key1; rng.p_lo = R.p_lo; rng.p_hi = R.p_hi; rng.event = R.event;
+          float g[8];
+          rng.interaction_event(g);
+          int lambda = R.lambda;
+          lambda_sc = lambda;
+          const int fl = R.flags;
+          bool flag_star = (fl & ST_STAR) != 0, flag_scatt = (fl & ST_SCATT) != 0, flag_ism = (fl & ST_ISM) != 0;
+          const int ic = cell_index<L3D>(n_rad, nz, R.ri, R.zj, R.k);
+          scat = interact_direction(T, M, g, lambda, R.u, R.v, R.w, u1, v1, w1, flag_star, flag_scatt, c_scatt, c_abs, [&]() {
+            // the cell's absorbed energy for Temp_LTE (thermal_emission.f90:649-706): what every workgroup has
+            // folded into HBM so far plus (LDSE) this workgroup's not yet folded part -- the other workgroups'
+            // unfolded parts are estimated by this one's, exactly the reference's partial * nb_proc
+            // (thermal_emission.f90:670) with workgroups in the role of threads; * n_replicas across GPUs
+            double E;
+            if (A.frozen) E = A.E_prior[ic];
+            else {
+              E = __hip_atomic_load(&A.E_abs[ic], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (LDSE) E += E_lds[ic] * (double)gridDim.x;
+              E *= A.qscale;
+            }
+            return E;
+          }, M.volume + ic, itheta, rand2);
+          if (!flag_scatt) flag_ism = false;  // absorbed and re-emitted by the dust (:1367)
+          R.lambda = lambda;
+          R.event = rng.event;
+          R.tau_rand = g[5];
+          R.flags = S_NEWFLIGHT | (flag_star ? ST_STAR : 0) | (flag_scatt ? ST_SCATT : 0) | (flag_ism ? ST_ISM : 0);
+          if (!POLA) { R.u = u1; R.v = v1; R.w = w1; }
+        }
+        if (POLA) {
+          RQ_PHASE_END();
+          if (inter) {
+            Rec<POLA>& R = recs[rid];
+            double S[4] = {R.S[0], R.S[POLA ? 1 : 0], R.S[POLA ? 2 : 0], R.S[POLA ? 3 : 0]};
+            interact_stokes(M, scat, lambda_sc, itheta, rand2, R.u, R.v, R.w, u1, v1, w1, S);
+            R.S[0] = S[0]; R.S[POLA ? 1 : 0] = S[1]; R.S[POLA ? 2 : 0] = S[2]; R.S[POLA ? 3 : 0] = S[3];
+            R.u = u1; R.v = v1; R.w = w1;
+          }
+        }
+        if (inter) st = S_NEWFLIGHT;
+        RQ_PHASE_END();
+        // ---- NEWFLIGHT: optical depth to the next event (dust_transfer.f90:1208-1215, tau in FP64) and the
+        // star on the way (optical_depth.f90:68) ---------------------------------------------------------
+        if (rid >= 0 && st == S_NEWFLIGHT) {
+          Rec<POLA>& R = recs[rid];
+          const float rand = R.tau_rand;
+          R.extr = (rand > 1.0e-6f) ? -log(1.0 - (double)rand) : (double)rand;
+          const int i_star = intersect_stars(M, R.x, R.y, R.z, R.u, R.v, R.w);
+          int key = -1;
+          if (i_star > 0) {
+            const int* sc = &M.star_cell[4 * (i_star - 1)];
+            key = sc[0] + (n_rad + 2) * ((sc[1] + nz + 1) + (2 * nz + 3) * (sc[2] - 1));
+          }
+          R.star_key = key;
+          c_flight++;
+          st = S_FLIGHT;
+        }
+        RQ_PHASE_END();
+        // ---- the first crossings of every flight ----------------------------------------------------------
+        if (__ballot(rid >= 0 && st == S_FLIGHT) != 0ull) {
+          const bool fly = rid >= 0 && st == S_FLIGHT;
+          Rec<POLA>& R = recs[fly ? rid : 0];
+          flight_clear(F);
+          F.st = fly ? S_FLIGHT : S_EMIT;
+          if (fly) {
+            F.x = R.x; F.y = R.y; F.z = R.z; F.u = R.u; F.v = R.v; F.w = R.w; F.extr = R.extr; F.S0 = R.S[0];
+            F.ri = R.ri; F.zj = R.zj; F.k = R.k; F.star_key = R.star_key; F.pk_cross = R.pk_cross;
+            flight_constants<L3D>(T, M, F, R.lambda);
+          }
+          const int n_it = flying_in_place ? fly_iters : k_short;
 #pragma unroll 1
-      for (int it = 0; it < k_short; ++it) {
-        if (__ballot(p.st == S_FLIGHT) == 0ull) break;
-        RQ_DIAG(if (lane == 0) d_srv_iters++;)
-        if (p.st == S_FLIGHT) finished += roles_cross<L3D, POLA, DARK, LDSE>(T, M, A, E_lds, p, inv_a, inv_w, kap, kab, kf, c_cross, c_kill, c_dark);
+          for (int it = 0; it < n_it; ++it) {
+            if (__ballot(F.st == S_FLIGHT) == 0ull) break;
+            RQ_DIAG(if (lane == 0) d_srv_iters++;)
+            if (L3D) {
+              if (F.st == S_FLIGHT) finished += roles_cross<L3D, DARK, LDSE>(T, M, A, E_lds, F, c_cross, c_kill, c_dark);
+            } else {
+              finished += fly_step_2d<DARK, LDSE>(T, M, A, E_lds, F, c_cross, c_kill, c_dark);
+            }
+          }
+          if (fly) {
+            R.x = F.x; R.y = F.y; R.z = F.z; R.extr = F.extr;
+            if (DARK) { R.u = F.u; R.v = F.v; R.w = F.w; }
+            R.ri = F.ri; R.zj = F.zj; R.k = F.k; R.pk_cross = F.pk_cross;
+            st = F.st;
+            R.flags = (R.flags & ~ST_MASK) | st;
+          }
+        }
+        RQ_PHASE_END();
+        // ---- packets that left the grid: capteur (output.f90:294-597) --------------------------------------
+        if (rid >= 0 && st == S_EXITED) {
+          const Rec<POLA>& R = recs[rid];
+          const int fl = R.flags;
+          if (!(fl & ST_ISM) ) {  // ISM packets that were never absorbed are not binned (dust_transfer.f90:549)
+            const double S[4] = {R.S[0], POLA ? R.S[POLA ? 1 : 0] : 0.0, POLA ? R.S[POLA ? 2 : 0] : 0.0, POLA ? R.S[POLA ? 3 : 0] : 0.0};
+            capteur<POLA>(M, A.sed, R.lambda, R.u, R.v, R.w, S, (fl & ST_STAR) != 0, (fl & ST_SCATT) != 0);
+            c_esc++;
+          }
+          st = S_EMIT;
+          finished++;
+        }
+        // ---- long flights to the FLY ring, finished packets' records to the FREE ring ------------------------
+        {
+          const bool to_fly = rid >= 0 && st == S_FLIGHT, to_free = rid >= 0 && st == S_EMIT;
+          rq_push(Q, rings, RQ_FLY, lane, to_fly, rid);
+          rq_push(Q, rings, RQ_FREE, lane, to_free, rid);
+          if (to_fly || to_free) { rid = -1; st = S_EMIT; }
+        }
       }
+      // a serving wave holds no packet in registers: say so, so that the flight registers are not kept alive
+      // through the serving phases
+      flight_clear(F);
+      bag_S1 = bag_S2 = bag_S3 = 0.0; bag_plo = bag_phi = bag_event = 0u; bag_lambda = 1; bag_fl = 0; bag_tau = 0.0f;
     }
 
     // ---- bookkeeping common to both roles ---------------------------------------------------------
@@ -519,16 +731,9 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
     }
   }
 
-  if ((A.flags & 2) && lane == 0) {
-    const unsigned long long t_end = wall_clock64();
-    atomicAdd(&A.counters[10], t_end - t_start);
-    atomicAdd(&A.counters[11], (t_ids_out ? t_ids_out : t_end) - t_start);
-    atomicMax(&A.counters[12], ~t_start);
-    atomicMax(&A.counters[13], t_end);
-    atomicAdd(&A.counters[14], 1ull);
-  }
+  __syncthreads();
+  lds_flush_sent(T, M, A.n_sent);
   if (LDSE) {
-    __syncthreads();
     for (int i = threadIdx.x; i < M.n_cells; i += blockDim.x) {
       const double e = E_lds[i];
       if (e != 0.0) atomic_add_f64(&A.E_abs[i], e);
@@ -536,9 +741,9 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
   }
   unsigned int cs[8] = {c_pack, c_cross, c_flight, c_scatt, c_abs, c_esc, c_kill, c_dark};
 #ifdef MCGPU_COUNT_ITERS  // the eight counters carry the schedule's statistics instead
-  cs[0] = d_in_flight; cs[1] = d_handed; cs[6] = d_popped; cs[3] = d_empty;  // lanes, summed over server rounds
-  cs[2] = d_srv_rounds; cs[5] = d_fly_rounds;                                 // rounds
-  cs[4] = d_srv_iters; cs[7] = d_fly_iters;                                   // crossing iterations
+  cs[0] = d_srv_lanes; cs[1] = d_srv_int; cs[6] = d_emit; cs[3] = d_fly_cross;  // lanes, summed over rounds
+  cs[2] = d_srv_rounds; cs[5] = d_fly_rounds;                                   // rounds
+  cs[4] = d_srv_iters; cs[7] = d_fly_iters;                                     // crossing iterations
 #endif
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
@@ -548,12 +753,15 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
   }
 }
 
+#ifndef MCGPU_ROLES_BLOCK
+#define MCGPU_ROLES_BLOCK 768  // threads of a workgroup of this schedule: 168 VGPRs, 3 waves per SIMD
+#endif
+
 template <bool L3D, bool POLA, bool DARK, bool LDSE>
-__global__ void __launch_bounds__(MCGPU_LDS_BLOCK) k_thermal_roles(const DevModel M, const RunArgs A, int n_flyers,
-                                                                   int k_short, int fly_iters, int fly_idle,
-                                                                   int emit_qmax, int emit_min) {
+__global__ void __launch_bounds__(MCGPU_ROLES_BLOCK) k_thermal_roles(const DevModel M, const RunArgs A, int n_rec, int n_srv_pref,
+                                                                     int k_short, int fly_iters, int fly_idle, int emit_qmax) {
   extern __shared__ double lds_raw[];
-  roles_body<L3D, POLA, DARK, LDSE>(M, A, lds_raw, n_flyers, k_short, fly_iters, fly_idle, emit_qmax, emit_min);
+  roles_body<L3D, POLA, DARK, LDSE>(M, A, lds_raw, n_rec, n_srv_pref, k_short, fly_iters, fly_idle, emit_qmax);
 }
 
 }  // namespace mcgpu

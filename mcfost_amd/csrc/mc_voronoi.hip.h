@@ -349,7 +349,7 @@ __device__ __forceinline__ void thermal_body_voro(const DevModel& M, const RunAr
           rng.emission_event(f);
           tau_rand = f[8];
           lambda = select_wl_em(T, M, f[0]);
-          atomic_add_f64(&A.n_sent[lambda - 1], 1.0);
+          lds_count_sent(T, lambda);
           bool lintersect;
           flag_scatt = false;
           S[0] = 1.0; S[1] = 0.0; S[2] = 0.0; S[3] = 0.0;
@@ -417,16 +417,12 @@ __device__ __forceinline__ void thermal_body_voro(const DevModel& M, const RunAr
           int next;
           voro_cross_cell(G, M, C, x, y, z, u, v, w, icell, prev_cell, x1, y1, z1, next, l, l_contrib, l_void);
           c_cross++;
-          if (++pk_cross > 200000000u) {
-            *A.err = 13;
-            st = S_EMIT;
-          }
           const double tau = l_contrib * opacity;
           if (tau > extr) {
             const double lc = l_contrib * (extr / tau);
             const double ls = l_void + lc;
             const double dE = T.kabs[lambda - 1] * lc * S[0];
-            if (dE != 0.0 && !(A.flags & 1)) {
+            if (dE != 0.0 && !MCGPU_DIAG(A.flags, 1)) {
               if (!(CACHE && DC.add(icell, dE))) atomic_add_f64(&A.E_abs[icell - 1], dE);
             }
             x = nd_add(x, nd_mul(ls, u));
@@ -436,12 +432,16 @@ __device__ __forceinline__ void thermal_body_voro(const DevModel& M, const RunAr
           } else {
             extr = extr - tau;
             const double dE = T.kabs[lambda - 1] * l_contrib * S[0];
-            if (dE != 0.0 && !(A.flags & 1)) {
+            if (dE != 0.0 && !MCGPU_DIAG(A.flags, 1)) {
               if (!(CACHE && DC.add(icell, dE))) atomic_add_f64(&A.E_abs[icell - 1], dE);
             }
             x = x1; y = y1; z = z1;
             prev_cell = icell;
             icell = next;
+          }
+          if (++pk_cross > 200000000u) {  // a packet that never leaves: flag it, drop it
+            *A.err = 13;
+            st = S_EMIT;
           }
         }
       }
@@ -463,8 +463,9 @@ __device__ __forceinline__ void thermal_body_voro(const DevModel& M, const RunAr
     }
   }
 
+  __syncthreads();  // every wave of the workgroup is done emitting and depositing
+  lds_flush_sent(T, M, A.n_sent);
   if (CACHE) {  // final fold
-    __syncthreads();
     for (int i = threadIdx.x; i < (1 << cache_log_ns); i += blockDim.x) {
       const double e = DC.val[i];
       if (e != 0.0) atomic_add_f64(&A.E_abs[DC.tag[i] - 1], e);

@@ -5,6 +5,7 @@
 #include "../../include/mcgpu.h"
 
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 
 #include <cmath>
 #include <cstdio>
@@ -14,7 +15,6 @@
 #include <vector>
 
 #include "mc_device.hip.h"
-#include "mc_rounds.hip.h"
 #include "mc_voronoi.hip.h"
 #include "mc_mono.hip.h"
 #include "mc_mono_voronoi.hip.h"
@@ -22,6 +22,17 @@
 #include "mc_roles.hip.h"
 
 using namespace mcgpu;
+
+// Tuning knobs.  The shipped library takes its configuration from the context alone (mcgpu_set_option);
+// a -DMCGPU_TUNING build additionally reads MCGPU_<NAME> from the environment (tools/*.py sweeps).
+static int tune(const char* name, int dflt, int lo, int hi) {
+#ifdef MCGPU_TUNING
+  if (const char* e = getenv(name)) { const int v = atoi(e); if (v >= lo && v <= hi) return v; }
+#else
+  (void)name; (void)lo; (void)hi;
+#endif
+  return dflt;
+}
 
 struct mcgpu_ctx {
   int device = 0;
@@ -35,25 +46,22 @@ struct mcgpu_ctx {
        have_thermal = false, have_sed = false;
   int lsepar_pola = 0;
   float T_min = 1.0f;
+  // mcgpu_set_option
+  int opt_deposit = 0;      // 0 = automatic, 1 = HBM atomics, 2 = LDS-private grid / deposit cache
+  int opt_schedule = 0;     // 0 = automatic (waves with roles where the queues fit), 1 = single-role kernel
+  int opt_speculation = 1;  // SED mode: commit most of every stream before the scout pass
+  int opt_cache_log_slots = 13;  // Voronoi deposit cache: 2^13 slots = 96 KB of LDS
   std::vector<void*> allocs;   // every table buffer (freed in destroy)
   // per-setter buffers that may be replaced
   int *d_cmi = nullptr, *d_cmj = nullptr, *d_cmk = nullptr;
   float* d_tab_Temp = nullptr;
-  // accumulators: [E_abs | sed | n_sent]
+  // accumulators: [E_abs | sed | n_sent | counters as doubles (mcgpu_counters_to_accum)]
   double* d_accum = nullptr;
   size_t n_accum = 0;
   unsigned long long* d_counters = nullptr;  // 8 counters + work counter + pad
   int* d_err = nullptr;
   double* d_E_prior = nullptr;
   bool launched = false;
-  // packet pool of the two-kernel ("rounds") engine
-  Pool pool;
-  size_t pool_slots = 0;
-  bool pool_pola = false;
-  std::vector<void*> pool_allocs;
-  int* d_list = nullptr;
-  unsigned int* d_round_counts = nullptr;  // [0] list_n, [1] flying_n
-  Pool* d_pool_desc = nullptr;             // device copy of `pool` for the finisher
   // SED mode (mc_mono.hip.h)
   bool have_rt1 = false;
   int RT_n_incl = 0, RT_n_az = 0, n_az_rt = 0, n_theta_rt = 0, N_type_flux = 0, lsepar_contrib = 0, n_lambda_pos = 0;
@@ -146,10 +154,6 @@ extern "C" int mcgpu_destroy(mcgpu_ctx* ctx) {
   if (ctx->d_counters) hipFree(ctx->d_counters);
   if (ctx->d_err) hipFree(ctx->d_err);
   if (ctx->d_E_prior) hipFree(ctx->d_E_prior);
-  for (void* p : ctx->pool_allocs) hipFree(p);
-  if (ctx->d_list) hipFree(ctx->d_list);
-  if (ctx->d_round_counts) hipFree(ctx->d_round_counts);
-  if (ctx->d_pool_desc) hipFree(ctx->d_pool_desc);
   if (ctx->d_xI) hipFree(ctx->d_xI);
   if (ctx->d_prob_E) hipFree(ctx->d_prob_E);
   if (ctx->d_mono_u64) hipFree(ctx->d_mono_u64);
@@ -304,6 +308,16 @@ extern "C" int mcgpu_set_grid_voronoi(mcgpu_ctx* ctx, int n_cells, const float* 
   V.cell = dc;
   ctx->voro = true;
   ctx->have_grid = true;
+  return MCGPU_OK;
+}
+
+extern "C" int mcgpu_set_option(mcgpu_ctx* ctx, const char* name, int value) {
+  if (!ctx || !name) return MCGPU_ERR_ARG;
+  if (!strcmp(name, "deposit")) { if (value < 0 || value > 2) return fail(ctx, MCGPU_ERR_ARG, "deposit: 0, 1 or 2"); ctx->opt_deposit = value; }
+  else if (!strcmp(name, "schedule")) { if (value < 0 || value > 1) return fail(ctx, MCGPU_ERR_ARG, "schedule: 0 or 1"); ctx->opt_schedule = value; }
+  else if (!strcmp(name, "speculation")) ctx->opt_speculation = value ? 1 : 0;
+  else if (!strcmp(name, "voronoi_cache_log_slots")) { if (value < 6 || value > 13) return fail(ctx, MCGPU_ERR_ARG, "voronoi_cache_log_slots: 6..13"); ctx->opt_cache_log_slots = value; }
+  else return fail(ctx, MCGPU_ERR_ARG, "mcgpu_set_option: unknown option");
   return MCGPU_OK;
 }
 
@@ -473,7 +487,7 @@ static size_t n_sed(const DevModel& M) { return (size_t)MCGPU_N_SED_TYPES * M.n_
 
 static int ensure_accum(mcgpu_ctx* ctx) {
   const DevModel& M = ctx->M;
-  const size_t n = (size_t)M.n_cells + n_sed(M) + M.n_lambda;
+  const size_t n = (size_t)M.n_cells + n_sed(M) + M.n_lambda + MCGPU_N_COUNTERS;
   if (ctx->d_accum && ctx->n_accum == n) return MCGPU_OK;
   if (ctx->d_accum) hipFree(ctx->d_accum);
   ctx->d_accum = nullptr;
@@ -508,7 +522,7 @@ static hipError_t launch_k(const DevModel& M, const RunArgs& A, int blocks, int 
   return hipGetLastError();
 }
 
-// the single persistent kernel (mc_device.hip.h); also the finisher of the two-kernel engine
+// the persistent packet kernel of the cylindrical grids (mc_roles.hip.h, mc_device.hip.h)
 static int launch_mega(mcgpu_ctx* ctx, const RunArgs& A, bool use_lds, int grid_blocks, int block_threads) {
   const DevModel& M = ctx->M;
   const size_t lds = lds_bytes(M);
@@ -534,41 +548,40 @@ static int launch_mega(mcgpu_ctx* ctx, const RunArgs& A, bool use_lds, int grid_
   // tables.  MCGPU_ROLES: -1 = the single-role kernel (thermal_body), 0..7 = that
   // many fixed flyer waves, 100+f = every wave picks its role per round (flyer when f lanes can fly), 200 = per
   // round, the role in which more of its lanes have work (default).
-  int n_flyers = 200, k_short = 2, fly_iters = 16, fly_idle = 16, emit_qmax = 1 << 20, emit_min = 1;
-  if (const char* ev = getenv("MCGPU_ROLES")) n_flyers = atoi(ev);
+  // Waves with roles and LDS packet records (mc_roles.hip.h): the default wherever enough records fit next to the
+  // tables; otherwise (or with option "schedule" = 1) the single-role kernel below.
   {
-    const size_t lds_try = (lds_k + 7) / 8 * 8 + (pola ? sizeof(RoleQ<true>) : sizeof(RoleQ<false>));
-    if (lds_try > lds_cap && !getenv("MCGPU_ROLES")) n_flyers = -1;  // no room for the queues: single-role kernel
-  }
-  if (const char* ev = getenv("MCGPU_K_SHORT")) { int v = atoi(ev); if (v >= 1 && v <= 64) k_short = v; }
-  if (const char* ev = getenv("MCGPU_FLY_ITERS")) { int v = atoi(ev); if (v >= 1 && v <= 256) fly_iters = v; }
-  if (const char* ev = getenv("MCGPU_FLY_IDLE")) { int v = atoi(ev); if (v >= 1 && v <= 65) fly_idle = v; }
-  if (const char* ev = getenv("MCGPU_EMIT_QMAX")) { int v = atoi(ev); if (v >= 0) emit_qmax = v; }
-  if (const char* ev = getenv("MCGPU_EMIT_MIN")) { int v = atoi(ev); if (v >= 1 && v <= 64) emit_min = v; }
-  if (n_flyers >= 0 && !A.resume_pool) {
-    const size_t lds_r = (lds_k + 7) / 8 * 8 + (pola ? sizeof(RoleQ<true>) : sizeof(RoleQ<false>));
-    if (lds_r > lds_cap) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "MCGPU_ROLES: the packet queues do not fit in LDS next to the tables");
-    const int rthreads = (block_threads > 0 && block_threads <= MCGPU_LDS_BLOCK) ? block_threads : MCGPU_LDS_BLOCK;
-    if (n_flyers < 100 && n_flyers >= rthreads / 64) n_flyers = rthreads / 64 - 1;  // (>= 100: dynamic roles)
-    int rblocks = grid_blocks > 0 ? grid_blocks : ctx->prop.multiProcessorCount;
-    {
-      const unsigned long long need = (A.n_packets + rthreads - 1) / rthreads;
-      if (grid_blocks <= 0 && (unsigned long long)rblocks > need) rblocks = (int)(need ? need : 1);
-    }
-    const void* fn;
+    const int rthreads = (block_threads > 0 && block_threads <= MCGPU_ROLES_BLOCK) ? block_threads : MCGPU_ROLES_BLOCK;
+    if (rthreads % 64) return fail(ctx, MCGPU_ERR_ARG, "block_threads must be a multiple of 64");
+    const size_t lds_t = (lds_k + 7) / 8 * 8;
+    int n_rec = lds_t < lds_cap ? rq_records_that_fit(pola, lds_cap - lds_t) : 0;
+    // (more records than twice the lanes buy nothing; small models keep their LDS footprint small)
+    if (n_rec > 2 * rthreads) n_rec = 2 * rthreads > RQ_MIN_REC ? 2 * rthreads : RQ_MIN_REC;
+    if (tune("MCGPU_ROLES", ctx->opt_schedule == 1 ? 0 : 1, 0, 1) && n_rec > 0) {
+      const size_t lds_r = lds_t + rq_lds_bytes(pola, n_rec);
+      int rblocks = grid_blocks > 0 ? grid_blocks : ctx->prop.multiProcessorCount;
+      {
+        const unsigned long long need = (A.n_packets + rthreads - 1) / rthreads;
+        if (grid_blocks <= 0 && (unsigned long long)rblocks > need) rblocks = (int)(need ? need : 1);
+      }
+      int n_srv_pref = tune("MCGPU_N_SRV", (rthreads / 64 + 3) / 4, 1, 16);   // one wave in four only serves (at least one: liveness)
+      int k_short = tune("MCGPU_K_SHORT", 2, 0, 64), fly_iters = tune("MCGPU_FLY_ITERS", 16, 1, 256);
+      int fly_idle = tune("MCGPU_FLY_IDLE", 16, 1, 65), emit_qmax = tune("MCGPU_EMIT_QMAX", 128, 0, 1 << 20);
+      const void* fn;
 #define PICKR(a, b, c) fn = use_lds ? (const void*)k_thermal_roles<a, b, c, true> : (const void*)k_thermal_roles<a, b, c, false>
-    if (l3d) {
-      if (pola) { if (dark) PICKR(true, true, true); else PICKR(true, true, false); }
-      else { if (dark) PICKR(true, false, true); else PICKR(true, false, false); }
-    } else {
-      if (pola) { if (dark) PICKR(false, true, true); else PICKR(false, true, false); }
-      else { if (dark) PICKR(false, false, true); else PICKR(false, false, false); }
-    }
+      if (l3d) {
+        if (pola) { if (dark) PICKR(true, true, true); else PICKR(true, true, false); }
+        else { if (dark) PICKR(true, false, true); else PICKR(true, false, false); }
+      } else {
+        if (pola) { if (dark) PICKR(false, true, true); else PICKR(false, true, false); }
+        else { if (dark) PICKR(false, false, true); else PICKR(false, false, false); }
+      }
 #undef PICKR
-    HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));
-    void* args[] = {(void*)&M, (void*)&A, (void*)&n_flyers, (void*)&k_short, (void*)&fly_iters, (void*)&fly_idle, (void*)&emit_qmax, (void*)&emit_min};
-    HIPCHK(hipLaunchKernel(fn, dim3(rblocks), dim3(rthreads), args, lds_r, ctx->stream));
-    return MCGPU_OK;
+      HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));
+      void* args[] = {(void*)&M, (void*)&A, (void*)&n_rec, (void*)&n_srv_pref, (void*)&k_short, (void*)&fly_iters, (void*)&fly_idle, (void*)&emit_qmax};
+      HIPCHK(hipLaunchKernel(fn, dim3(rblocks), dim3(rthreads), args, lds_r, ctx->stream));
+      return MCGPU_OK;
+    }
   }
 #define LAUNCH(a, b, c)                                                                \
   e = use_lds ? launch_k<a, b, c, true>(M, A, blocks, threads, lds_k, ctx->stream)     \
@@ -595,12 +608,10 @@ static int launch_voro(mcgpu_ctx* ctx, const RunArgs& A, int grid_blocks, int bl
   const DevModel& M = ctx->M;
   const size_t lds_t = (lds_bytes(M) + 7) / 8 * 8;
   const size_t lds_cap = 160 * 1024;
-  bool cache = true;
-  if (const char* e = getenv("MCGPU_DEPOSIT")) if (!strcmp(e, "hbm")) cache = false;
+  bool cache = ctx->opt_deposit != 1;
   int log_ns = 0;
   if (cache) {
-    log_ns = 13;  // 8192 slots = 96 KB
-    if (const char* e = getenv("MCGPU_CACHE_LOG_SLOTS")) { int v = atoi(e); if (v >= 6 && v <= 13) log_ns = v; }
+    log_ns = ctx->opt_cache_log_slots;
     while (log_ns > 6 && lds_t + ((size_t)12 << log_ns) > lds_cap) --log_ns;
     if (lds_t + ((size_t)12 << log_ns) > lds_cap) cache = false;
   }
@@ -641,145 +652,6 @@ static int launch_voro(mcgpu_ctx* ctx, const RunArgs& A, int grid_blocks, int bl
   return MCGPU_OK;
 }
 
-static int run_finisher(mcgpu_ctx* ctx, RunArgs A, unsigned int n_resume) {
-  const DevModel& M = ctx->M;
-  A.n_packets = n_resume;  // work items = listed pool slots
-  A.resume_list = ctx->d_list;
-  A.resume_pool = ctx->d_pool_desc;
-  HIPCHK(hipMemsetAsync(A.next_packet, 0, sizeof(unsigned long long), ctx->stream));
-  const size_t lds_e = lds_bytes(M) + (size_t)M.n_cells * sizeof(double);
-  bool use_lds = lds_e <= 160 * 1024;
-  if (const char* e = getenv("MCGPU_DEPOSIT")) if (!strcmp(e, "hbm")) use_lds = false;
-  return launch_mega(ctx, A, use_lds, 0, 0);
-}
-
-// ---- the two-kernel engine (mc_rounds.hip.h) -------------------------------------------------
-static int ensure_pool(mcgpu_ctx* ctx, size_t n_slots, bool pola) {
-  if (ctx->pool_slots == n_slots && ctx->pool_pola == pola) return MCGPU_OK;
-  for (void* p : ctx->pool_allocs) hipFree(p);
-  ctx->pool_allocs.clear();
-  if (ctx->d_list) { hipFree(ctx->d_list); ctx->d_list = nullptr; }
-  ctx->pool_slots = 0;
-  Pool& P = ctx->pool;
-  P.n_slots = (int)n_slots;
-  auto dal = [&](double** p, size_t n) -> hipError_t { hipError_t e = hipMalloc((void**)p, n * sizeof(double)); if (e == hipSuccess) ctx->pool_allocs.push_back(*p); return e; };
-  auto ial = [&](int** p) -> hipError_t { hipError_t e = hipMalloc((void**)p, n_slots * sizeof(int)); if (e == hipSuccess) ctx->pool_allocs.push_back(*p); return e; };
-  double** dd[7] = {&P.x, &P.y, &P.z, &P.u, &P.v, &P.w, &P.extr};
-  for (auto q : dd) HIPCHK(dal(q, n_slots));
-  P.S = nullptr;
-  if (pola) HIPCHK(dal(&P.S, 4 * n_slots));
-  int** ii[6] = {&P.ri, &P.zj, &P.k, &P.lambda, &P.star_key, &P.st};
-  for (auto q : ii) HIPCHK(ial(q));
-  int** uu[3] = {(int**)&P.p_lo, (int**)&P.p_hi, (int**)&P.event};
-  for (auto q : uu) HIPCHK(ial(q));
-  HIPCHK(hipMalloc((void**)&ctx->d_list, n_slots * sizeof(int)));
-  if (!ctx->d_round_counts) HIPCHK(hipMalloc((void**)&ctx->d_round_counts, 4 * sizeof(unsigned int)));
-  if (!ctx->d_pool_desc) HIPCHK(hipMalloc((void**)&ctx->d_pool_desc, sizeof(Pool)));
-  HIPCHK(hipMemcpy(ctx->d_pool_desc, &P, sizeof(Pool), hipMemcpyHostToDevice));
-  ctx->pool_slots = n_slots;
-  ctx->pool_pola = pola;
-  return MCGPU_OK;
-}
-
-template <bool L3D, bool POLA, bool DARK, bool LDSE>
-static hipError_t launch_fly(const DevModel& M, const RunArgs& A, const Pool& P, const RoundArgs& R, int blocks,
-                             int threads, size_t lds, hipStream_t s) {
-  if (LDSE) hipLaunchKernelGGL((k_fly_lds<L3D, POLA, DARK>), dim3(blocks), dim3(threads), lds, s, M, A, P, R);
-  else hipLaunchKernelGGL((k_fly_hbm<L3D, POLA, DARK>), dim3(blocks), dim3(threads), lds, s, M, A, P, R);
-  return hipGetLastError();
-}
-template <bool L3D, bool POLA, bool DARK, bool LDSE>
-static const void* fly_fn() {
-  return LDSE ? (const void*)k_fly_lds<L3D, POLA, DARK> : (const void*)k_fly_hbm<L3D, POLA, DARK>;
-}
-
-template <bool L3D, bool POLA, bool DARK, bool LDSE>
-static int run_rounds_t(mcgpu_ctx* ctx, RunArgs A, const mcgpu_run_opts* o) {
-  const DevModel& M = ctx->M;
-  const size_t lds_serve = lds_bytes(M);
-  const size_t lds_fly = ((LDSE ? (size_t)M.n_cells : 0) + lds_fly_doubles(M)) * sizeof(double);
-  const void* ffn = fly_fn<L3D, POLA, DARK, LDSE>();
-  HIPCHK(hipFuncSetAttribute(ffn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fly));
-  HIPCHK(hipFuncSetAttribute((const void*)k_serve<L3D, POLA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_serve));
-  int fly_threads = LDSE ? 1024 : 512;
-  if (o->block_threads > 0) fly_threads = o->block_threads;
-  if (fly_threads % 64 || fly_threads > (LDSE ? 1024 : 512)) return fail(ctx, MCGPU_ERR_ARG, "block_threads out of range for the rounds engine");
-  int occ = 1;
-  HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ffn, fly_threads, lds_fly));
-  if (occ < 1) occ = 1;
-  int fly_blocks = o->grid_blocks > 0 ? o->grid_blocks : ctx->prop.multiProcessorCount * occ;
-  const size_t n_lanes = (size_t)fly_blocks * fly_threads;
-  int n_passes = 16;
-  if (const char* e = getenv("MCGPU_PASSES")) { int v = atoi(e); if (v >= 1 && v <= 1024) n_passes = v; }
-  {  // no more slots than packets
-    const unsigned long long need = (o->n_packets + n_lanes - 1) / n_lanes;
-    if ((unsigned long long)n_passes > need) n_passes = (int)(need ? need : 1);
-  }
-  const size_t n_slots = n_lanes * n_passes;
-  int rc = ensure_pool(ctx, n_slots, POLA);
-  if (rc) return rc;
-  const Pool& P = ctx->pool;
-  RoundArgs R;
-  R.list = ctx->d_list; R.list_n = ctx->d_round_counts; R.flying_n = ctx->d_round_counts + 1; R.n_passes = n_passes;
-  hipStream_t s = ctx->stream;
-  hipLaunchKernelGGL(k_pool_init, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, s, P, ctx->d_list);
-  HIPCHK(hipGetLastError());
-  unsigned int h_counts[2] = {(unsigned int)n_slots, 0u};
-  HIPCHK(hipMemcpyAsync(ctx->d_round_counts, h_counts, sizeof(h_counts), hipMemcpyHostToDevice, s));
-  int serve_occ = 1;
-  HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&serve_occ, (const void*)k_serve<L3D, POLA>, 256, lds_serve));
-  if (serve_occ < 1) serve_occ = 1;
-  const int serve_blocks = ctx->prop.multiProcessorCount * serve_occ;
-  int check_every = 4;
-  size_t switch_below = n_slots / 4;
-  if (const char* e = getenv("MCGPU_SWITCH_FRAC")) { double f = atof(e); if (f >= 0.0 && f <= 1.0) switch_below = (size_t)(f * n_slots); }
-  const long max_rounds = 4000000;
-  for (long round = 0; round < max_rounds; ++round) {
-    hipLaunchKernelGGL((k_serve<L3D, POLA>), dim3(serve_blocks), dim3(256), lds_serve, s, M, A, P, R);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemsetAsync(ctx->d_round_counts, 0, 2 * sizeof(unsigned int), s));
-    hipError_t e = launch_fly<L3D, POLA, DARK, LDSE>(M, A, P, R, fly_blocks, fly_threads, lds_fly, s);
-    if (e != hipSuccess) { ctx->err = std::string("k_fly launch: ") + hipGetErrorString(e); return MCGPU_ERR_HIP; }
-    if ((round + 1) % check_every == 0) {
-      HIPCHK(hipMemcpyAsync(h_counts, ctx->d_round_counts, sizeof(h_counts), hipMemcpyDeviceToHost, s));
-      HIPCHK(hipStreamSynchronize(s));
-      if (h_counts[0] == 0 && h_counts[1] == 0) return MCGPU_OK;
-      unsigned long long next_id = 0;
-      HIPCHK(hipMemcpy(&next_id, A.next_packet, sizeof(next_id), hipMemcpyDeviceToHost));
-      if (next_id >= A.n_packets && (size_t)h_counts[0] + h_counts[1] < switch_below) {
-        // Few packets left and no fresh ones to refill the pool: the alternating kernels would
-        // now spend their time on launch overheads while stragglers random-walk for thousands
-        // of flights.  Serve the listed slots once more, then let the single persistent kernel
-        // run every packet still in flight to completion.
-        hipLaunchKernelGGL((k_serve<L3D, POLA>), dim3(serve_blocks), dim3(256), lds_serve, s, M, A, P, R);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipMemsetAsync(ctx->d_round_counts, 0, 2 * sizeof(unsigned int), s));
-        hipLaunchKernelGGL(k_collect_flying, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, s, P, ctx->d_list,
-                           ctx->d_round_counts);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(h_counts, ctx->d_round_counts, sizeof(h_counts), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
-        if (h_counts[0] == 0) return MCGPU_OK;
-        return run_finisher(ctx, A, h_counts[0]);
-      }
-    }
-  }
-  return fail(ctx, MCGPU_ERR_KERNEL, "rounds engine: packets still in flight after the round limit");
-}
-
-static int run_rounds(mcgpu_ctx* ctx, const RunArgs& A, const mcgpu_run_opts* o, bool use_lds) {
-  const DevModel& M = ctx->M;
-  const bool pola = ctx->lsepar_pola != 0, dark = M.dark != nullptr, l3d = M.l3D != 0;
-#define RR(a, b, c) (use_lds ? run_rounds_t<a, b, c, true>(ctx, A, o) : run_rounds_t<a, b, c, false>(ctx, A, o))
-  if (l3d) {
-    if (pola) return dark ? RR(true, true, true) : RR(true, true, false);
-    return dark ? RR(true, false, true) : RR(true, false, false);
-  }
-  if (pola) return dark ? RR(false, true, true) : RR(false, true, false);
-  return dark ? RR(false, false, true) : RR(false, false, false);
-#undef RR
-}
-
 extern "C" int mcgpu_launch_thermal(mcgpu_ctx* ctx, const mcgpu_run_opts* o) {
   int rc = ready(ctx);
   if (rc) return rc;
@@ -810,17 +682,10 @@ extern "C" int mcgpu_launch_thermal(mcgpu_ctx* ctx, const mcgpu_run_opts* o) {
   A.counters = ctx->d_counters;
   A.next_packet = ctx->d_counters + 8;
   A.err = ctx->d_err;
-  A.resume_list = nullptr;
-  A.resume_pool = nullptr;
-  // tuning / diagnostic knobs (environment; defaults are the shipped configuration)
-  A.inner_iters = 64;
-  A.flush_every = 16;
-  A.flags = 0;
-  A.min_active = 32;
-  if (const char* e = getenv("MCGPU_MIN_ACTIVE")) { int v = atoi(e); if (v >= 0 && v <= 64) A.min_active = v; }
-  if (const char* e = getenv("MCGPU_INNER_ITERS")) { int v = atoi(e); if (v >= 1 && v <= 4096) A.inner_iters = v; }
-  if (const char* e = getenv("MCGPU_FLUSH_EVERY")) { int v = atoi(e); if (v >= 1 && v <= 1000000) A.flush_every = v; }
-  if (const char* e = getenv("MCGPU_DIAG_FLAGS")) A.flags = atoi(e);
+  A.inner_iters = tune("MCGPU_INNER_ITERS", 64, 1, 4096);
+  A.flush_every = tune("MCGPU_FLUSH_EVERY", 16, 1, 1000000);
+  A.min_active = tune("MCGPU_MIN_ACTIVE", 32, 0, 64);
+  A.flags = tune("MCGPU_DIAG_FLAGS", 0, 0, 255);  // (diagnostic builds only)
   if (ctx->voro) {
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     int rcv = launch_voro(ctx, A, o->grid_blocks, o->block_threads);
@@ -830,34 +695,14 @@ extern "C" int mcgpu_launch_thermal(mcgpu_ctx* ctx, const mcgpu_run_opts* o) {
     return MCGPU_OK;
   }
   // Deposit mode: a private absorbed-energy grid in LDS when it fits next to the tables
-  // (2D grids), HBM atomics otherwise.  MCGPU_DEPOSIT=hbm|lds overrides.
+  // (2D grids), HBM atomics otherwise; mcgpu_set_option("deposit") overrides.
   const size_t lds_e = lds + (size_t)M.n_cells * sizeof(double);
   const size_t lds_cap = 160 * 1024;
   bool use_lds = lds_e <= lds_cap;
-  if (const char* e = getenv("MCGPU_DEPOSIT")) {
-    if (!strcmp(e, "hbm")) use_lds = false;
-    else if (!strcmp(e, "lds")) {
-      if (lds_e > lds_cap) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "MCGPU_DEPOSIT=lds: grid does not fit in LDS");
-      use_lds = true;
-    }
-  }
-  // Engine: the single persistent kernel (default) or, opt-in, two alternating kernels over a
-  // packet pool in HBM (MCGPU_ENGINE=rounds; same results, currently slower: DESIGN.md sec. 3)
-  bool rounds = false;
-  if (const char* e = getenv("MCGPU_ENGINE")) rounds = strcmp(e, "rounds") == 0;
-  if (rounds) {
-    const size_t lds_fly = (size_t)M.n_cells * sizeof(double) + lds_fly_doubles(M) * sizeof(double);
-    bool fly_lds = lds_fly <= lds_cap;
-    if (const char* e = getenv("MCGPU_DEPOSIT")) {
-      if (!strcmp(e, "hbm")) fly_lds = false;
-      else if (!strcmp(e, "lds") && lds_fly > lds_cap) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "MCGPU_DEPOSIT=lds: grid does not fit in LDS");
-    }
-    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
-    int rc2 = run_rounds(ctx, A, o, fly_lds);
-    if (rc2) return rc2;
-    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
-    ctx->launched = true;
-    return MCGPU_OK;
+  if (ctx->opt_deposit == 1) use_lds = false;
+  else if (ctx->opt_deposit == 2) {
+    if (lds_e > lds_cap) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "deposit = lds: the grid does not fit in LDS");
+    use_lds = true;
   }
   HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
   int rc3 = launch_mega(ctx, A, use_lds, o->grid_blocks, o->block_threads);
@@ -912,6 +757,37 @@ extern "C" int mcgpu_fetch(mcgpu_ctx* ctx, double* E_abs, double* sed, double* n
     HIPCHK(hipMemcpy(n_sent, ctx->d_accum + M.n_cells + n_sed(M), (size_t)M.n_lambda * sizeof(double),
                      hipMemcpyDeviceToHost));
   if (counters) HIPCHK(hipMemcpy(counters, ctx->d_counters, MCGPU_N_COUNTERS * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  return MCGPU_OK;
+}
+
+// The eight event counters ride in the tail of the fused accumulator as doubles (exact below 2^53), so that a
+// multi-GPU host reduces ONE buffer per temperature iteration.
+__global__ void k_counters_to_accum(const unsigned long long* cnt, double* tail) {
+  if (threadIdx.x < MCGPU_N_COUNTERS) tail[threadIdx.x] = (double)cnt[threadIdx.x];
+}
+__global__ void k_counters_from_accum(unsigned long long* cnt, const double* tail) {
+  if (threadIdx.x < MCGPU_N_COUNTERS) cnt[threadIdx.x] = (unsigned long long)(tail[threadIdx.x] + 0.5);
+}
+
+extern "C" int mcgpu_counters_to_accum(mcgpu_ctx* ctx) {
+  int rc = ready(ctx);
+  if (rc) return rc;
+  if (!ctx->d_accum) return fail(ctx, MCGPU_ERR_STATE, "nothing launched yet");
+  HIPCHK(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(k_counters_to_accum, dim3(1), dim3(64), 0, ctx->stream, ctx->d_counters,
+                     ctx->d_accum + (ctx->n_accum - MCGPU_N_COUNTERS));
+  HIPCHK(hipGetLastError());
+  return MCGPU_OK;
+}
+
+extern "C" int mcgpu_counters_from_accum(mcgpu_ctx* ctx) {
+  int rc = ready(ctx);
+  if (rc) return rc;
+  if (!ctx->d_accum) return fail(ctx, MCGPU_ERR_STATE, "nothing launched yet");
+  HIPCHK(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(k_counters_from_accum, dim3(1), dim3(64), 0, ctx->stream, ctx->d_counters,
+                     ctx->d_accum + (ctx->n_accum - MCGPU_N_COUNTERS));
+  HIPCHK(hipGetLastError());
   return MCGPU_OK;
 }
 
@@ -1053,8 +929,10 @@ extern "C" int mcgpu_run_mono(mcgpu_ctx* ctx, const mcgpu_mono_opts* o, double f
   } else if (o->rt1 && !o->accumulate) {
     HIPCHK(hipMemsetAsync(ctx->d_xI, 0, xi_bytes, ctx->stream));
   }
+  // (the E_abs part of the fused accumulator belongs to the thermal step: a host may run the SED Monte Carlo and
+  // then call mcgpu_temp_finale(ctx, NULL, ...) on the device's own absorbed-energy grid)
   if (!o->accumulate) {
-    HIPCHK(hipMemsetAsync(ctx->d_accum, 0, ctx->n_accum * sizeof(double), ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_accum + M.n_cells, 0, (ctx->n_accum - M.n_cells) * sizeof(double), ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->d_counters, 0, 16 * sizeof(unsigned long long), ctx->stream));
   }
   HIPCHK(hipMemsetAsync(ctx->d_err, 0, sizeof(int), ctx->stream));
@@ -1073,10 +951,9 @@ extern "C" int mcgpu_run_mono(mcgpu_ctx* ctx, const mcgpu_mono_opts* o, double f
   A.sed = ctx->d_accum + M.n_cells;
   A.n_sent = ctx->d_accum + M.n_cells + n_sed(M);
   A.counters = ctx->d_counters; A.next_item = ctx->d_counters + 8; A.err = ctx->d_err;
-  A.inner_iters = 64; A.min_active = 32;
-  if (const char* e = getenv("MCGPU_MIN_ACTIVE")) { int v = atoi(e); if (v >= 0 && v <= 64) A.min_active = v; }
-  if (const char* e = getenv("MCGPU_INNER_ITERS")) { int v = atoi(e); if (v >= 1 && v <= 4096) A.inner_iters = v; }
-  if (const char* e = getenv("MCGPU_DIAG_FLAGS")) A.flags = atoi(e);
+  A.inner_iters = tune("MCGPU_INNER_ITERS", 64, 1, 4096);
+  A.min_active = tune("MCGPU_MIN_ACTIVE", 32, 0, 64);
+  A.flags = tune("MCGPU_DIAG_FLAGS", 0, 0, 255);  // (diagnostic builds only)
 
   // ---- SCOUT: find every stream's stopping index (dust_transfer.f90:526-553) ----------------
   double lim_d = std::ceil((double)o->n_phot_lim);
@@ -1087,7 +964,7 @@ extern "C" int mcgpu_run_mono(mcgpu_ctx* ctx, const mcgpu_mono_opts* o, double f
   // 7 sigma short of it -- is committed directly, with its hits counted, and only the remainder is scouted.  Without
   // it every packet is transported twice.  Should a stream reach its count inside the speculative range after all,
   // the accumulators are cleared and the call starts over without speculation (so: only when the call owns them).
-  bool speculate = !o->accumulate && !getenv("MCGPU_NO_SPECULATION");
+  bool speculate = !o->accumulate && ctx->opt_speculation != 0;
 restart:
   std::vector<unsigned long long> need(nc, o->n_photons2), sent(nc, 0ull), start(nc, 0ull);
   std::vector<int> active, done(nc, 0);
@@ -1185,7 +1062,7 @@ restart:
         for (int c : active) if (extra[c] > 0 && hc[c] >= o->n_photons2) overshoot = true;
         if (overshoot) {  // (a 7-sigma event) clear what this call accumulated and run it the plain way
           speculate = false;
-          HIPCHK(hipMemsetAsync(ctx->d_accum, 0, ctx->n_accum * sizeof(double), ctx->stream));
+          HIPCHK(hipMemsetAsync(ctx->d_accum + M.n_cells, 0, (ctx->n_accum - M.n_cells) * sizeof(double), ctx->stream));
           HIPCHK(hipMemsetAsync(ctx->d_counters, 0, 16 * sizeof(unsigned long long), ctx->stream));
           if (o->rt1) HIPCHK(hipMemsetAsync(ctx->d_xI, 0, xi_bytes, ctx->stream));
           goto restart;
@@ -1551,5 +1428,119 @@ extern "C" int mcgpu_probe_packet_rand(mcgpu_ctx* ctx, uint64_t seed, uint64_t p
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(ctx->stream));
   HIPCHK(d.get(out, n));
+  return MCGPU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Several GPUs behind ONE host thread (the reference's host is one OpenMP process: mcfost.f90,
+// mcfost2phantom.f90:159).  Packets shard by id range, tables are replicated (the host calls the
+// setters on every context), and ONE ncclAllReduce per temperature iteration sums the fused
+// accumulator [E_abs | sed | n_sent | counters] over xGMI.  No other exchange.
+// ---------------------------------------------------------------------------------------------
+struct mcgpu_multi {
+  int n_dev = 0;
+  std::vector<mcgpu_ctx*> ctx;
+  std::vector<ncclComm_t> comm;
+  std::string err;
+};
+
+extern "C" int mcgpu_multi_create(int n_dev, const int* devices, mcgpu_multi** out) {
+  if (!out || n_dev < 1) return MCGPU_ERR_ARG;
+  *out = nullptr;
+  int n_have = 0;
+  if (hipGetDeviceCount(&n_have) != hipSuccess || n_have <= 0) return MCGPU_ERR_NO_DEVICE;
+  std::vector<int> devs(n_dev);
+  for (int i = 0; i < n_dev; ++i) {
+    devs[i] = devices ? devices[i] : i;
+    if (devs[i] < 0 || devs[i] >= n_have) return MCGPU_ERR_ARG;
+    for (int j = 0; j < i; ++j) if (devs[j] == devs[i]) return MCGPU_ERR_ARG;
+  }
+  mcgpu_multi* mm = new mcgpu_multi();
+  mm->n_dev = n_dev;
+  mm->ctx.assign(n_dev, nullptr);
+  mm->comm.assign(n_dev, nullptr);
+  for (int i = 0; i < n_dev; ++i) {
+    const int rc = mcgpu_create(devs[i], &mm->ctx[i]);
+    if (rc) { for (int j = 0; j < i; ++j) mcgpu_destroy(mm->ctx[j]); delete mm; return rc; }
+  }
+  if (ncclCommInitAll(mm->comm.data(), n_dev, devs.data()) != ncclSuccess) {
+    for (int j = 0; j < n_dev; ++j) mcgpu_destroy(mm->ctx[j]);
+    delete mm;
+    return MCGPU_ERR_HIP;
+  }
+  *out = mm;
+  return MCGPU_OK;
+}
+
+extern "C" int mcgpu_multi_destroy(mcgpu_multi* mm) {
+  if (!mm) return MCGPU_OK;
+  for (int i = 0; i < mm->n_dev; ++i) {
+    if (mm->ctx[i]) { hipSetDevice(mm->ctx[i]->device); hipDeviceSynchronize(); }
+    if (mm->comm[i]) ncclCommDestroy(mm->comm[i]);
+  }
+  for (int i = 0; i < mm->n_dev; ++i) mcgpu_destroy(mm->ctx[i]);
+  delete mm;
+  return MCGPU_OK;
+}
+
+extern "C" int mcgpu_multi_size(const mcgpu_multi* mm) { return mm ? mm->n_dev : 0; }
+extern "C" mcgpu_ctx* mcgpu_multi_ctx(mcgpu_multi* mm, int i) { return (mm && i >= 0 && i < mm->n_dev) ? mm->ctx[i] : nullptr; }
+extern "C" const char* mcgpu_multi_last_error(const mcgpu_multi* mm) { return mm ? mm->err.c_str() : "null handle"; }
+
+// the shard of device i: contiguous, disjoint, exhaustive (same rule as mcfost_amd/distributed.py::shard_packets)
+extern "C" void mcgpu_shard_packets(uint64_t n_packets, int rank, int world, uint64_t* first, uint64_t* count) {
+  const uint64_t base = n_packets / (uint64_t)world, rem = n_packets % (uint64_t)world;
+  if (count) *count = base + ((uint64_t)rank < rem ? 1u : 0u);
+  if (first) *first = (uint64_t)rank * base + ((uint64_t)rank < rem ? (uint64_t)rank : rem);
+}
+
+extern "C" int mcgpu_multi_run_thermal(mcgpu_multi* mm, const mcgpu_run_opts* opts, double* E_abs, double* sed,
+                                       double* n_sent, uint64_t* counters, double* kernel_ms) {
+  if (!mm || !opts) return MCGPU_ERR_ARG;
+  const int n = mm->n_dev;
+  auto failed = [&](int i, int rc) { mm->err = "device " + std::to_string(i) + ": " + mcgpu_last_error(mm->ctx[i]); return rc; };
+  // 1) every device runs its shard of the packet ids; the in-flight temperature scales the local partial sum by
+  //    the number of replicas (thermal_emission.f90:670)
+  for (int i = 0; i < n; ++i) {
+    mcgpu_run_opts o = *opts;
+    uint64_t first = 0, count = 0;
+    mcgpu_shard_packets(opts->n_packets, i, n, &first, &count);
+    o.first_packet = opts->first_packet + first;
+    o.n_packets = count;
+    o.n_replicas = (opts->n_replicas >= 1.0 ? opts->n_replicas : 1.0) * (double)n;
+    const int rc = mcgpu_launch_thermal(mm->ctx[i], &o);
+    if (rc) return failed(i, rc);
+  }
+  // 2) ONE all-reduce of the fused accumulator (counters in its tail), in place, on every device's own stream
+  for (int i = 0; i < n; ++i) {
+    const int rc = mcgpu_counters_to_accum(mm->ctx[i]);
+    if (rc) return failed(i, rc);
+  }
+  if (ncclGroupStart() != ncclSuccess) { mm->err = "ncclGroupStart failed"; return MCGPU_ERR_HIP; }
+  for (int i = 0; i < n; ++i) {
+    mcgpu_ctx* c = mm->ctx[i];
+    hipSetDevice(c->device);
+    if (ncclAllReduce(c->d_accum, c->d_accum, c->n_accum, ncclDouble, ncclSum, mm->comm[i], c->stream) != ncclSuccess) {
+      ncclGroupEnd();
+      mm->err = "ncclAllReduce failed on device " + std::to_string(i);
+      return MCGPU_ERR_HIP;
+    }
+  }
+  if (ncclGroupEnd() != ncclSuccess) { mm->err = "ncclGroupEnd failed"; return MCGPU_ERR_HIP; }
+  for (int i = 0; i < n; ++i) {
+    const int rc = mcgpu_counters_from_accum(mm->ctx[i]);
+    if (rc) return failed(i, rc);
+  }
+  // 3) wait; the packet loop's time is the slowest device's
+  double ms_max = 0.0;
+  for (int i = 0; i < n; ++i) {
+    double ms = 0.0;
+    const int rc = mcgpu_sync(mm->ctx[i], &ms);
+    if (rc) return failed(i, rc);
+    if (ms > ms_max) ms_max = ms;
+  }
+  if (kernel_ms) *kernel_ms = ms_max;
+  const int rc = mcgpu_fetch(mm->ctx[0], E_abs, sed, n_sent, counters);  // every device now holds the global sums
+  if (rc) return failed(0, rc);
   return MCGPU_OK;
 }

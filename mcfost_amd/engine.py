@@ -34,7 +34,9 @@ ABI_SYMBOLS = (
     "mcgpu_probe_packet_rand", "mcgpu_set_midplane_snap", "mcgpu_set_grid_voronoi",
     "mcgpu_probe_cross_voronoi", "mcgpu_set_rt1", "mcgpu_run_mono", "mcgpu_fetch_xI",
     "mcgpu_device_xI", "mcgpu_set_ism", "mcgpu_rt1_dust_map", "mcgpu_set_xI", "mcgpu_rt1_image", "mcgpu_set_xI_precision",
-    "mcgpu_get_xI_precision",
+    "mcgpu_get_xI_precision", "mcgpu_set_option", "mcgpu_counters_to_accum", "mcgpu_counters_from_accum",
+    "mcgpu_multi_create", "mcgpu_multi_destroy", "mcgpu_multi_size", "mcgpu_multi_ctx", "mcgpu_multi_last_error",
+    "mcgpu_shard_packets", "mcgpu_multi_run_thermal",
 )
 
 
@@ -278,6 +280,24 @@ class Engine:
         t_acc = torch.as_tensor(_DevArray(acc.value, n.value, "<f8"), device=dev)
         t_cnt = torch.as_tensor(_DevArray(cnt.value, N_COUNTERS, "<i8"), device=dev)
         return t_acc, t_cnt
+
+    def allreduce_device(self, all_reduce):
+        """ONE collective per temperature iteration: the counters join the fused accumulator as doubles
+        (``mcgpu_counters_to_accum``), ``all_reduce(tensor)`` sums it over the ranks (RCCL with the ``nccl``
+        backend), the summed counters go back (``mcgpu_counters_from_accum``)."""
+        import torch
+
+        self._chk(self.lib.mcgpu_counters_to_accum(self.ctx), "mcgpu_counters_to_accum")
+        torch.cuda.synchronize(self.device)        # the engine's stream -> the collective's stream
+        acc, _ = self.device_accumulators()
+        all_reduce(acc)
+        torch.cuda.synchronize(self.device)
+        self._chk(self.lib.mcgpu_counters_from_accum(self.ctx), "mcgpu_counters_from_accum")
+
+    def set_option(self, name, value):
+        """Per-context run option (``mcgpu_set_option``): "deposit" 0/1/2 = auto / HBM atomics / LDS,
+        "schedule" 0/1 = auto / single-role kernel, "speculation" 1/0 (SED mode)."""
+        self._chk(self.lib.mcgpu_set_option(self.ctx, name.encode(), C.c_int(int(value))), "mcgpu_set_option")
 
     def set_xI_precision(self, bytes_per_value):
         """8 (default): FP64 xI_scatt sums; 4: default real like the reference's array, half the atomic lines -- for

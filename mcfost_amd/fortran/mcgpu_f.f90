@@ -63,7 +63,7 @@ module mcgpu_f
      real(c_double) :: Rmin, Rmax
   end type mcgpu_rt_opts
 
-  public :: mcgpu_create, mcgpu_destroy, mcgpu_set_grid_cyl, mcgpu_set_grid_voronoi, mcgpu_set_midplane_snap, &
+  public :: mcgpu_create, mcgpu_destroy, mcgpu_set_grid_cyl, mcgpu_set_grid_voronoi, mcgpu_set_midplane_snap, mcgpu_set_option, &
        mcgpu_set_stars, mcgpu_set_opacity, mcgpu_set_scattering, mcgpu_set_thermal, mcgpu_set_sed_bins, &
        mcgpu_run_thermal, mcgpu_temp_finale, mcgpu_thermal_loop, mcgpu_error_message, mcgpu_set_rt1, &
        mcgpu_run_mono, mcgpu_fetch, mcgpu_fetch_xI, mcgpu_rt1_dust_map, mcgpu_set_xI, mcgpu_rt1_image, mcgpu_set_xI_precision
@@ -119,6 +119,14 @@ module mcgpu_f
        type(c_ptr), value :: ctx
        integer(c_int), value :: on
      end function mcgpu_set_midplane_snap
+
+     ! name: a C string (trim(name)//c_null_char): "deposit", "schedule", "speculation"
+     integer(c_int) function mcgpu_set_option(ctx, name, value) bind(C, name="mcgpu_set_option")
+       import :: c_int, c_ptr, c_char
+       type(c_ptr), value :: ctx
+       character(kind=c_char), intent(in) :: name(*)
+       integer(c_int), value :: value
+     end function mcgpu_set_option
 
      integer(c_int) function mcgpu_set_stars(ctx, n_stars, x, y, z, r, icell, out_model) bind(C, name="mcgpu_set_stars")
        import :: c_int, c_ptr, c_double

@@ -55,6 +55,7 @@ static inline int __syncthreads_or(int p) { return p; }
 static inline unsigned long long atomicExch(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p = v; return o; }
 static inline int atomicAdd(int* p, int v) { int o = *p; *p += v; return o; }
 static inline int atomicCAS(int* p, int cmp, int v) { int o = *p; if (o == cmp) *p = v; return o; }
+static inline unsigned int atomicCAS(unsigned int* p, unsigned int cmp, unsigned int v) { unsigned int o = *p; if (o == cmp) *p = v; return o; }
 static inline double __longlong_as_double(long long b) { double d; memcpy(&d, &b, 8); return d; }
 static inline double atomicAdd(double* p, double v) { double o = *p; *p += v; return o; }
 static inline float atomicAdd(float* p, float v) { float o = *p; *p += v; return o; }
@@ -71,7 +72,7 @@ using std::fmin; using std::atan2; using std::acos; using std::cos; using std::c
 namespace mcgpu { double lds_raw[1 << 18]; }
 
 #include "../../mcfost_amd/csrc/mc_device.hip.h"
-#include "../../mcfost_amd/csrc/mc_rounds.hip.h"
+#include "cross_cell_literal.h"
 #include "../../mcfost_amd/csrc/mc_voronoi.hip.h"
 #include "../../mcfost_amd/csrc/mc_mono.hip.h"
 #include "../../mcfost_amd/csrc/mc_mono_voronoi.hip.h"
@@ -177,7 +178,7 @@ extern "C" int emu_run_thermal(const oracle_model* m, const oracle_opts* o, cons
   A.qscale = o->n_replicas >= 1.0 ? o->n_replicas : 1.0;
   A.frozen = o->frozen; A.E_prior = E_prior; A.E_abs = E_abs; A.sed = sed; A.n_sent = n_sent;
   A.counters = cnt; A.next_packet = cnt + 8; A.err = &err;
-  A.resume_list = nullptr; A.resume_pool = nullptr; A.inner_iters = 8; A.flags = 0; A.flush_every = 4; A.min_active = 0;
+  A.inner_iters = 8; A.flags = 0; A.flush_every = 4; A.min_active = 0;
   const bool pola = m->lsepar_pola && m->aniso_method == 1, dark = M.dark != nullptr, l3d = m->l3D != 0;
   if (voro) {
     if (getenv("MCGPU_EMU_LDS")) {  // deposit cache, few slots so that hits, misses and folds all occur
@@ -188,47 +189,16 @@ extern "C" int emu_run_thermal(const oracle_model* m, const oracle_opts* o, cons
     for (int q = 0; q < 8; ++q) counters[q] = cnt[q];
     return err;
   }
-  if (getenv("MCGPU_EMU_ROUNDS")) {
-    // the two-kernel engine, one emulated lane: slots are passes of that lane
-    const int n_slots = (int)(o->n_packets < 48 ? (o->n_packets ? o->n_packets : 1) : 48);
-    Pool P;
-    P.n_slots = n_slots;
-    std::vector<double> pd(7 * (size_t)n_slots), pS(4 * (size_t)n_slots);
-    std::vector<int> pi(9 * (size_t)n_slots), list(n_slots);
-    P.x = pd.data(); P.y = P.x + n_slots; P.z = P.y + n_slots; P.u = P.z + n_slots; P.v = P.u + n_slots;
-    P.w = P.v + n_slots; P.extr = P.w + n_slots; P.S = pS.data();
-    P.ri = pi.data(); P.zj = P.ri + n_slots; P.k = P.zj + n_slots; P.lambda = P.k + n_slots;
-    P.star_key = P.lambda + n_slots; P.st = P.star_key + n_slots;
-    P.p_lo = (uint32_t*)(P.st + n_slots); P.p_hi = P.p_lo + n_slots; P.event = P.p_hi + n_slots;
-    unsigned int counts[2] = {(unsigned int)n_slots, 0u};
-    RoundArgs R;
-    R.list = list.data(); R.list_n = &counts[0]; R.flying_n = &counts[1]; R.n_passes = n_slots;
-    for (int i = 0; i < n_slots; ++i) { P.st[i] = S_EMIT; list[i] = i; }
-    A.min_active = 32; A.inner_iters = 16;
-    const bool use_lds = getenv("MCGPU_EMU_LDS") != nullptr;
-    for (long round = 0; round < 100000000; ++round) {
-#define SERVE(a, b) k_serve<a, b>(M, A, P, R)
-      if (l3d) { if (pola) SERVE(true, true); else SERVE(true, false); }
-      else { if (pola) SERVE(false, true); else SERVE(false, false); }
-      counts[0] = 0; counts[1] = 0;
-#define FLY(a, b, c) do { if (use_lds) k_fly_lds<a, b, c>(M, A, P, R); else k_fly_hbm<a, b, c>(M, A, P, R); } while (0)
-      if (l3d) {
-        if (pola) { if (dark) FLY(true, true, true); else FLY(true, true, false); }
-        else { if (dark) FLY(true, false, true); else FLY(true, false, false); }
-      } else {
-        if (pola) { if (dark) FLY(false, true, true); else FLY(false, true, false); }
-        else { if (dark) FLY(false, false, true); else FLY(false, false, false); }
-      }
-      if (counts[0] == 0 && counts[1] == 0) break;
-    }
-    for (int q = 0; q < 8; ++q) counters[q] = cnt[q];
-    return err;
-  }
-  if (getenv("MCGPU_EMU_ROLES")) {  // the role schedule on one lane: the wave alternates between both roles
-    const int nf = atoi(getenv("MCGPU_EMU_ROLES"));
+  if (getenv("MCGPU_EMU_ROLES")) {  // the role schedule on one lane: the one wave alternates between both roles
+    // MCGPU_EMU_ROLES = "<n_srv_pref>,<k_short>,<fly_iters>,<emit_qmax>": 1,... the wave prefers to serve (it flies when
+    // there is nothing to serve or emit), 0,... it prefers to fly (it serves only while the FLY ring is empty)
+    int nsp = 1, ks = 2, fi = 3, eq = 128;
+    sscanf(getenv("MCGPU_EMU_ROLES"), "%d,%d,%d,%d", &nsp, &ks, &fi, &eq);
     const bool ld = getenv("MCGPU_EMU_LDS") != nullptr;
+    const int n_rec = RQ_MIN_REC;
+    if (lds_bytes(M) + sizeof(double) * m->n_cells + rq_lds_bytes(true, n_rec) + 64 > sizeof(lds_raw)) return 31;
     A.flush_every = 4;
-#define RUNR(a, b, c) do { if (ld) k_thermal_roles<a, b, c, true>(M, A, nf, 2, 3, 65, 1 << 20, 1); else k_thermal_roles<a, b, c, false>(M, A, nf, 2, 3, 65, 1 << 20, 1); } while (0)
+#define RUNR(a, b, c) do { if (ld) k_thermal_roles<a, b, c, true>(M, A, n_rec, nsp, ks, fi, 65, eq); else k_thermal_roles<a, b, c, false>(M, A, n_rec, nsp, ks, fi, 65, eq); } while (0)
     if (l3d) {
       if (pola) { if (dark) RUNR(true, true, true); else RUNR(true, true, false); }
       else { if (dark) RUNR(true, false, true); else RUNR(true, false, false); }
@@ -251,6 +221,35 @@ extern "C" int emu_run_thermal(const oracle_model* m, const oracle_opts* o, cons
   return err;
 }
 
+
+// ---- one cell crossing by the product's branch-free cross_cell_lean (literal = 0) or by the branch-for-branch
+// restatement of cross_cylindrical_cell kept in tests/emu/cross_cell_literal.h (literal = 1) ----------------
+extern "C" int emu_cross_cell(const oracle_model* m, int literal, int n, const double* x0, const double* y0, const double* z0,
+                              const double* u, const double* v, const double* w, const int* cell, double* x1, double* y1,
+                              double* z1, int* next_cell, double* l) {
+  Conv cv(m);
+  const DevModel& M = cv.M;
+  if (cv.voro || lds_bytes(M) > sizeof(lds_raw)) return 31;
+  const Lds T = lds_carve(lds_raw, M);
+  lds_stage(T, M);
+  for (int i = 0; i < n; ++i) {
+    const double a = u[i] * u[i] + v[i] * v[i];
+    const double inv_a = (a > TINY_REAL) ? 1.0 / a : HUGE_REAL;
+    const double inv_w = (fabs(w[i]) > TINY_REAL) ? 1.0 / w[i] : copysign(HUGE_DP, w[i]);
+    const int c = cell[i] - 1;
+    const int ri = m->cell_map_i[c], zj = m->cell_map_j[c], k = m->cell_map_k[c];
+    int ri1, zj1, k1;
+    if (m->l3D) {
+      if (literal) cross_cell<true>(T, M, x0[i], y0[i], z0[i], u[i], v[i], w[i], inv_a, inv_w, ri, zj, k, x1[i], y1[i], z1[i], ri1, zj1, k1, l[i]);
+      else cross_cell_lean<true>(T, M, x0[i], y0[i], z0[i], u[i], v[i], w[i], inv_a, inv_w, ri, zj, k, x1[i], y1[i], z1[i], ri1, zj1, k1, l[i]);
+    } else {
+      if (literal) cross_cell<false>(T, M, x0[i], y0[i], z0[i], u[i], v[i], w[i], inv_a, inv_w, ri, zj, k, x1[i], y1[i], z1[i], ri1, zj1, k1, l[i]);
+      else cross_cell_lean<false>(T, M, x0[i], y0[i], z0[i], u[i], v[i], w[i], inv_a, inv_w, ri, zj, k, x1[i], y1[i], z1[i], ri1, zj1, k1, l[i]);
+    }
+    next_cell[i] = icell_of(M.n_rad, M.nz, M.n_az, M.l3D, ri1, zj1, k1);
+  }
+  return 0;
+}
 
 // ---- SED mode: the host orchestration of mcgpu_run_mono with one emulated lane --------------
 extern "C" int emu_run_mono(const oracle_model* m, const oracle_mono_opts* o, double* xI, double* sed, double* n_sent,

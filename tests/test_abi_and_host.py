@@ -63,8 +63,9 @@ def test_shard_packets_partitions_the_range():
 def test_pack_unpack_roundtrip():
     res = dict(E_abs=np.arange(5.0), sed=np.arange(24.0).reshape(2, 1, 3, 4), n_sent=np.arange(4.0),
                counters=dict(a=1, b=2))
-    acc, cnt = D.pack_results(res, 5)
-    out = D.unpack_results(acc, cnt, res)
+    acc = D.pack_results(res)
+    assert acc.size == 5 + 24 + 4 + 2     # ONE buffer: [E_abs | sed | n_sent | counters]
+    out = D.unpack_results(acc, res)
     assert np.array_equal(out["E_abs"], res["E_abs"]) and np.array_equal(out["sed"], res["sed"])
     assert np.array_equal(out["n_sent"], res["n_sent"]) and out["counters"] == res["counters"]
 

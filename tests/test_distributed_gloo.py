@@ -74,6 +74,11 @@ def _worker_mono(rank, world, port, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     m = sed_model(M.small(), n_thermal=20000)
     orc = Oracle(m, 1e5)
+    try:   # more ranks than streams: refused on EVERY rank before any collective (nobody is left waiting in one)
+        D.run_mono_sharded(orc.run_mono, 9, 5, 1, 77, rank, world)
+        raise AssertionError("expected ValueError")
+    except ValueError:
+        pass
     res = D.run_mono_sharded(orc.run_mono, 9, 5, 13, 77, rank, world)   # 13 streams: uneven split
     # the ray-traced SED of the dust from the all-reduced xI_scatt: every rank holds the same input, so any rank
     # (or each rank for its share of the observers) can compute it

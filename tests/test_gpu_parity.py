@@ -286,17 +286,6 @@ def test_fortran_host_through_iso_c_binding(small_model, tmp_path):
     e.close()
 
 
-def test_rounds_engine_matches_oracle(small_model, monkeypatch):
-    """The opt-in two-kernel engine (MCGPU_ENGINE=rounds: k_fly + k_serve over a packet pool in
-    HBM, stragglers handed to the persistent kernel) gives the same packets the same history."""
-    monkeypatch.setenv("MCGPU_ENGINE", "rounds")
-    _frozen_parity(small_model, 20000, seed=7)
-    m3 = M.build_model(M.small(n_rad=12, nz=6, n_az=8, l3D=True))
-    _frozen_parity(m3, 20000, seed=8)
-    monkeypatch.setenv("MCGPU_SWITCH_FRAC", "0.9")      # early hand-over to the finisher
-    _frozen_parity(small_model, 30000, seed=9)
-
-
 def test_edge_cases_empty_and_tiny_runs(small_model):
     """n_packets = 0, 1 and a non-multiple of the wave / batch sizes."""
     e, o = _engine(small_model, 1000), _oracle(small_model, 1000)
@@ -461,7 +450,7 @@ def test_voronoi_abi_errors(voro_model):
         _engine(m, 1e4)
 
 
-def test_voronoi_deposit_paths_agree(voro_model, monkeypatch):
+def test_voronoi_deposit_paths_agree(voro_model):
     """LDS deposit cache (default; 1024- and 512-thread workgroups, tiny cache that must miss)
     vs plain HBM atomics: same packets, same sums."""
     m = voro_model
@@ -471,10 +460,10 @@ def test_voronoi_deposit_paths_agree(voro_model, monkeypatch):
     runs = []
     runs.append(e.run_thermal(30000, seed=13, frozen=True, E_prior=prior))
     runs.append(e.run_thermal(30000, seed=13, frozen=True, E_prior=prior, block_threads=512))
-    monkeypatch.setenv("MCGPU_CACHE_LOG_SLOTS", "6")
+    e.set_option("voronoi_cache_log_slots", 6)
     runs.append(e.run_thermal(30000, seed=13, frozen=True, E_prior=prior))
-    monkeypatch.delenv("MCGPU_CACHE_LOG_SLOTS")
-    monkeypatch.setenv("MCGPU_DEPOSIT", "hbm")
+    e.set_option("voronoi_cache_log_slots", 13)
+    e.set_option("deposit", 1)
     runs.append(e.run_thermal(30000, seed=13, frozen=True, E_prior=prior))
     for r in runs:
         assert r["counters"] == ref["counters"]
@@ -488,6 +477,8 @@ def test_voronoi_deposit_paths_agree(voro_model, monkeypatch):
 def _mono_parity(m, lam, n2, seed, n_chunks=64, **kw):
     from helpers import xI_close
     e, o = _engine(m, 1e5), _oracle(m, 1e5)
+    for name, value in kw.pop("options", {}).items():
+        e.set_option(name, value)
     rt1 = kw.get("rt1", True)
     a = e.run_mono(lam, n2, seed=seed, n_chunks=n_chunks, **kw)
     b = o.run_mono(lam, n2, seed=seed, n_chunks=n_chunks, n_threads=8,
@@ -535,17 +526,15 @@ def test_sed_mode_variants():
     _mono_parity(sed_model(M.small()), 4, 8, 12, rt1=False)                              # no RT deposits
 
 
-def test_sed_mode_speculative_commit(sed_small, monkeypatch):
+def test_sed_mode_speculative_commit(sed_small):
     """Counts large enough for the speculative commit (most of every stream is deposited right after a short probe,
     only the rest is scouted): every stream still stops at the oracle's packet, same SED bins and xI_scatt; and the
-    plain two-pass path (MCGPU_NO_SPECULATION) gives the same."""
+    plain two-pass path (option "speculation" = 0) gives the same."""
     m = sed_small
     for lam in (3, 9):
         a, b = _mono_parity(m, lam, 700, 40 + lam, n_chunks=16)
         assert a["sed"][4][0, m.capt_sup - 1, lam - 1] == 16 * 700
-    monkeypatch.setenv("MCGPU_NO_SPECULATION", "1")
-    _mono_parity(m, 9, 700, 49, n_chunks=16)
-    monkeypatch.delenv("MCGPU_NO_SPECULATION")
+    _mono_parity(m, 9, 700, 49, n_chunks=16, options={"speculation": 0})
     # accumulate = 1 (the call does not own the accumulators): no speculation, still exact
     e, o = _engine(m, 1e5), _oracle(m, 1e5)
     e.run_mono(3, 5, seed=1, n_chunks=16)

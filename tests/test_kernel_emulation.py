@@ -22,7 +22,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "emu", "emu_kernel.cpp")
 LIB = os.path.join(HERE, "emu", "libemu_kernel.so")
 DEV = os.path.join(os.path.dirname(HERE), "mcfost_amd", "csrc", "mc_device.hip.h")
-DEV2 = os.path.join(os.path.dirname(HERE), "mcfost_amd", "csrc", "mc_rounds.hip.h")
+DEV2 = os.path.join(HERE, "emu", "cross_cell_literal.h")
 DEV3 = os.path.join(os.path.dirname(HERE), "mcfost_amd", "csrc", "mc_voronoi.hip.h")
 DEV4 = os.path.join(os.path.dirname(HERE), "mcfost_amd", "csrc", "mc_mono.hip.h")
 DEV5 = os.path.join(os.path.dirname(HERE), "mcfost_amd", "csrc", "mc_roles.hip.h")
@@ -60,6 +60,37 @@ def check(emu, m, n, seed, rtol=1e-9):
     assert np.array_equal(a["n_sent"], b["n_sent"]) and np.array_equal(a["sed"][4], b["sed"][4])
     assert np.allclose(a["E_abs"], b["E_abs"], rtol=rtol, atol=1e-12 * b["E_abs"].max())
     return a, b
+
+
+@pytest.mark.parametrize("name", ["small2d", "small3d", "ref41", "pascucci"])
+def test_emulated_cross_cell_against_reference_golden(emu, name):
+    """The device source of the crossing operator on the reference's golden walks, on the CPU: the branch-free
+    cross_cell_lean the product runs and the branch-for-branch restatement (tests/emu/cross_cell_literal.h) give the
+    reference's next cell exactly and its end points / lengths to 1e-12 (the emulator contracts multiply-adds like
+    hipcc), and they agree with each other."""
+    from helpers import CONFIGS, load_golden
+    m = M.build_model(CONFIGS[name](M))
+    m.midplane_snap = 0  # reference-literal arithmetic: what the golden vectors hold
+    orc = Oracle(m, 1000)
+    wk = load_golden(name)["walk"]
+    n = wk.shape[0]
+    cols = [np.ascontiguousarray(wk[:, q]) for q in range(6)]
+    cell = np.ascontiguousarray(wk[:, 6].astype(np.int32))
+    outs = []
+    for literal in (0, 1):
+        x1, y1, z1, l = (np.zeros(n) for _ in range(4))
+        nxt = np.zeros(n, np.int32)
+        rc = emu.emu_cross_cell(C.byref(orc.cm), literal, n, *[_p(c, C.c_double) for c in cols], _p(cell, C.c_int),
+                                _p(x1, C.c_double), _p(y1, C.c_double), _p(z1, C.c_double), _p(nxt, C.c_int),
+                                _p(l, C.c_double))
+        assert rc == 0
+        assert np.array_equal(nxt, wk[:, 10].astype(np.int32)), literal
+        scale = np.abs(wk[:, 0]) + np.abs(wk[:, 1]) + np.abs(wk[:, 2]) + wk[:, 11]
+        for a, col in ((x1, 7), (y1, 8), (z1, 9), (l, 11)):
+            assert np.all(np.abs(a - wk[:, col]) <= 1e-12 * scale), (literal, col)
+        outs.append((x1, y1, z1, l))
+    for a, b in zip(*outs):
+        assert np.all(np.abs(a - b) <= 1e-13 * scale)
 
 
 def test_emulated_kernel_2d(emu, small_model):
@@ -284,10 +315,12 @@ def test_emulated_ism_emission(emu, small_model):
 
 
 def test_emulated_role_schedule(emu, small_model):
-    """mc_roles.hip.h on one lane: with MCGPU_EMU_ROLES=101 the wave becomes a flyer whenever a single packet can
-    fly, so packets keep going through both queues (pushed as long flights, popped, pushed back for their
-    interaction); 0 = server role only.  Same packets, same sums as the oracle."""
-    for roles in ("101", "0"):
+    """mc_roles.hip.h on one lane (n_srv_pref, k_short, fly_iters, emit_qmax): a wave that prefers to serve emits and
+    serves and flies the long flights when it has nothing else to do; a wave that prefers to fly serves only while the
+    FLY ring is empty; with emit_qmax = 0 every long flight is flown before the next packet starts; k_short = 0 sends
+    every flight through the FLY ring.  Packets go through all three rings (records popped, swapped, pushed back for
+    their interaction or for binning).  Same packets, same sums as the oracle."""
+    for roles in ("1,2,3,128", "0,2,3,128", "1,0,2,0", "0,1,64,4"):
         os.environ["MCGPU_EMU_ROLES"] = roles
         try:
             check(emu, small_model, 4000, 7)
@@ -304,6 +337,7 @@ def test_emulated_role_schedule(emu, small_model):
             md.l_dark_zone = dz
             a, b = check(emu, md, 4000, 12)
             assert a["counters"][7] > 0
+            check(emu, _with_ism(small_model), 2000, 31, rtol=1e-6)
         finally:
             os.environ.pop("MCGPU_EMU_ROLES", None)
             os.environ.pop("MCGPU_EMU_LDS", None)

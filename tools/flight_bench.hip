@@ -92,6 +92,6 @@ int main() {
   M.zmaxmax = zmax[n_rad - 1]; M.Rmax2 = r2[n_rad]; M.kappa_factor = up(kf); M.n_lambda = nl; M.kappa = up(dl); M.kappa_abs = up(dl); M.albedo = up(fl);
   M.nang = nang; M.p_lambda_fixed = 1; M.prob_s11 = up(prob); M.tab_g = up(fl); M.cos_tab = up(ct); M.n_T = nT; M.log_Qcool = up(dT); M.cdf = up(cdf); M.spec_cum = up(cum); M.frac_E_stars = up(dl);
   const int iters = 20000;
-  run<512>(M, iters); run<768>(M, iters); run<1024>(M, iters);
+  run<256>(M, iters); run<512>(M, iters); run<768>(M, iters); run<1024>(M, iters);
   return 0;
 }
