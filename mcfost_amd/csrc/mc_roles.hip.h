@@ -64,7 +64,9 @@ static_assert(sizeof(Rec<true>) == 136 && sizeof(Rec<false>) == 120, "record str
 struct RqCtl {
   int n_pending, ids_done, abort_flag, pad0;
   unsigned int head[3], tail[3];
-  int pad1[6];
+  int n_srv, cooldown;  // waves [0, n_srv) serve; adapted by wave 0 (see roles_body)
+  int idle_f, idle_s;   // lanes the flying / serving waves could not fill since the last adaptation
+  int pad1[2];
 };
 static_assert(sizeof(RqCtl) == 64, "control block");
 
@@ -369,6 +371,7 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
     rings[i] = (i < n_rec) ? ((((unsigned int)i + 1u) << 16) | (unsigned int)i) : 0u;
   if (threadIdx.x == 0) {
     Q->n_pending = 0; Q->ids_done = 0; Q->abort_flag = 0;
+    Q->n_srv = n_srv_pref > 0 ? (n_srv_pref < 1000 ? n_srv_pref : n_srv_pref - 1000) : 0; Q->cooldown = 0; Q->idle_f = 0; Q->idle_s = 0;
     Q->head[0] = Q->head[1] = Q->head[2] = 0u;
     Q->tail[RQ_FREE] = (unsigned int)n_rec; Q->tail[RQ_FLY] = 0u; Q->tail[RQ_SRV] = 0u;
   }
@@ -376,7 +379,16 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n_rad = M.n_rad, nz = M.nz;
-  const bool prefer_server = wave < n_srv_pref;
+  // n_srv_pref >= 1000: that many (minus 1000) serving waves, fixed; otherwise the starting value of the adaptive count
+  const bool adapt = n_srv_pref > 0 && n_srv_pref < 1000;
+  const int n_waves_wg = (int)(blockDim.x >> 6);
+#ifdef MCGPU_TUNING  // parameters of the adaptation from A.flags (bits 8..): window, ratio, margin / 16 (sweeps)
+  const int ad_cd = ((A.flags >> 8) & 0xFF) ? ((A.flags >> 8) & 0xFF) : 2;
+  const int ad_ratio = ((A.flags >> 16) & 0xFF) ? ((A.flags >> 16) & 0xFF) : 2;
+  const int ad_margin = ((A.flags >> 24) & 0x7F) ? 16 * ((A.flags >> 24) & 0x7F) : 256;
+#else
+  const int ad_cd = 2, ad_ratio = 2, ad_margin = 256;
+#endif
   const int free_reserve = n_rec / 8 < 32 ? n_rec / 8 : 32;
   const uint32_t key0 = (uint32_t)A.seed, key1 = (uint32_t)(A.seed >> 32);
 
@@ -408,13 +420,30 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
     const int fly_n = rq_count(Q, RQ_FLY), srv_n = rq_count(Q, RQ_SRV);
     // (new packets leave free records for the flyers' stopped packets)
     const bool can_emit = !no_more_ids && fly_n <= emit_qmax && rq_count(Q, RQ_FREE) > free_reserve;
+    // Which waves serve: waves [0, n_srv).  The share of serving work depends on the model (Pascucci: 0.15
+    // interactions per packet, ref4.1: 11), so wave 0 adapts n_srv every few of its rounds to what the two kinds of
+    // waves could not fill since the last time: lanes of flying waves left without a flight (the servers do not
+    // produce flights fast enough: one more server) against lanes of serving waves left without a packet (one fewer).
+    const int n_srv_now = rq_ld(&Q->n_srv);
+    const bool prefer_server = wave < n_srv_now;
+    if (adapt && wave == 0 && lane == 0) {
+      const int cd = rq_ld(&Q->cooldown);
+      if (cd > 0) rq_st(&Q->cooldown, cd - 1);
+      else {
+        const int f = atomicExch(&Q->idle_f, 0), sv = atomicExch(&Q->idle_s, 0);
+        if (f > ad_ratio * sv + ad_margin && n_srv_now < n_waves_wg - 1) rq_st(&Q->n_srv, n_srv_now + 1);
+        else if (sv > ad_ratio * f + ad_margin && n_srv_now > 1) rq_st(&Q->n_srv, n_srv_now - 1);
+        rq_st(&Q->cooldown, ad_cd);
+      }
+    }
     // Liveness: a wave that holds stopped packets in registers cannot serve, and it can only put them down into a
-    // free record or a FLY record.  So the waves that prefer to serve NEVER take packets into registers (they fly
-    // long flights in place, below): whatever the others hold, somebody always empties the SRV ring, which turns
-    // waiting packets into FLY records or free records.
+    // free record or a FLY record.  Wave 0 NEVER takes packets into registers (it flies long flights in place,
+    // below): whatever the others hold, somebody always empties the SRV ring, which turns waiting packets into FLY
+    // records or free records.  A flying wave that becomes a server drains first (no new flights; its flights go
+    // to free records as they become available).
     bool serve;
     if (prefer_server) {
-      serve = true;
+      serve = !any_held;
     } else if (any_owned) {
       serve = true;
       // a wave that prefers to fly gives its waiting packets back when long flights pile up
@@ -433,7 +462,8 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
       // ======================= FLYING ==================================================================
       // lanes whose packet stopped swap it for a long flight, empty lanes load one
       const bool stopped = (st == S_INTERACT || st == S_EXITED);  // (packets that left the grid are binned by the servers)
-      const int rin = rq_pop(Q, rings, RQ_FLY, lane, st != S_FLIGHT);
+      const bool draining = prefer_server;  // on its way to the serving role: takes no new flights
+      const int rin = rq_pop(Q, rings, RQ_FLY, lane, !draining && st != S_FLIGHT);
       int rout = -1;  // record that leaves with this lane's stopped packet
       if (rin >= 0) {
         Rec<POLA>& R = recs[rin];
@@ -463,7 +493,8 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
       }
       // stopped packets that found no flight to swap with go to a free record
       {
-        const int rf = rq_pop(Q, rings, RQ_FREE, lane, st == S_INTERACT || st == S_EXITED);
+        // (a draining wave also puts its flights down: they go back to the FLY ring)
+        const int rf = rq_pop(Q, rings, RQ_FREE, lane, st == S_INTERACT || st == S_EXITED || (draining && st == S_FLIGHT));
         if (rf >= 0) {
           Rec<POLA>& R = recs[rf];
           R.x = F.x; R.y = F.y; R.z = F.z; R.u = F.u; R.v = F.v; R.w = F.w; R.extr = F.extr; R.S[0] = F.S0;
@@ -475,9 +506,17 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
           st = S_EMIT;
         }
       }
-      rq_push(Q, rings, RQ_SRV, lane, rout >= 0, rout);
+      {
+        const bool was_flight = rout >= 0 && (recs[rout].flags & ST_MASK) == S_FLIGHT;
+        rq_push(Q, rings, RQ_SRV, lane, rout >= 0 && !was_flight, rout);
+        rq_push(Q, rings, RQ_FLY, lane, rout >= 0 && was_flight, rout);
+      }
       rq_push(Q, rings, RQ_FREE, lane, rin >= 0 && rout != rin, rin);  // loaded, not swapped: the record is free again
 
+      if (adapt && !draining) {
+        const int n_idle = __popcll(__ballot(st != S_FLIGHT));
+        if (n_idle > 0 && lane == 0) atomicAdd(&Q->idle_f, n_idle);
+      }
       if (__ballot(st == S_FLIGHT) == 0ull) {
         if (__ballot(st != S_EMIT) == 0ull && rq_ld(&Q->ids_done) && rq_ld(&Q->n_pending) == 0) break;
         __builtin_amdgcn_s_sleep(16);  // nothing to fly (or no record for a stopped packet): wait for the others
@@ -572,6 +611,10 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
       }
       // ---- ... or, when the wave has little to serve, a long flight that it flies in place (the record stays the
       // packet's home: loaded, crossed fly_iters times, stored back) ------------------------------------------
+      if (adapt && prefer_server) {
+        const int n_idle = __popcll(__ballot(rid < 0));
+        if (n_idle > 0 && lane == 0) atomicAdd(&Q->idle_s, n_idle);
+      }
       bool flying_in_place = false;
       if (prefer_server && __popcll(__ballot(rid >= 0)) < 32) {
         const int r = rq_pop(Q, rings, RQ_FLY, lane, rid < 0);
@@ -754,7 +797,7 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
 }
 
 #ifndef MCGPU_ROLES_BLOCK
-#define MCGPU_ROLES_BLOCK 768  // threads of a workgroup of this schedule: 168 VGPRs, 3 waves per SIMD
+#define MCGPU_ROLES_BLOCK 1024  // threads of a workgroup of this schedule: 128 VGPRs, 4 waves per SIMD
 #endif
 
 template <bool L3D, bool POLA, bool DARK, bool LDSE>

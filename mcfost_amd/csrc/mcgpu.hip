@@ -564,9 +564,9 @@ static int launch_mega(mcgpu_ctx* ctx, const RunArgs& A, bool use_lds, int grid_
         const unsigned long long need = (A.n_packets + rthreads - 1) / rthreads;
         if (grid_blocks <= 0 && (unsigned long long)rblocks > need) rblocks = (int)(need ? need : 1);
       }
-      int n_srv_pref = tune("MCGPU_N_SRV", (rthreads / 64 + 3) / 4, 1, 16);   // one wave in four only serves (at least one: liveness)
+      int n_srv_pref = tune("MCGPU_N_SRV", (rthreads / 64 + 3) / 4, 1, 1016);  // serving waves to start with (adaptive; 1000 + n: fixed)
       int k_short = tune("MCGPU_K_SHORT", 2, 0, 64), fly_iters = tune("MCGPU_FLY_ITERS", 16, 1, 256);
-      int fly_idle = tune("MCGPU_FLY_IDLE", 16, 1, 65), emit_qmax = tune("MCGPU_EMIT_QMAX", 128, 0, 1 << 20);
+      int fly_idle = tune("MCGPU_FLY_IDLE", 32, 1, 65), emit_qmax = tune("MCGPU_EMIT_QMAX", 128, 0, 1 << 20);
       const void* fn;
 #define PICKR(a, b, c) fn = use_lds ? (const void*)k_thermal_roles<a, b, c, true> : (const void*)k_thermal_roles<a, b, c, false>
       if (l3d) {
@@ -685,7 +685,7 @@ extern "C" int mcgpu_launch_thermal(mcgpu_ctx* ctx, const mcgpu_run_opts* o) {
   A.inner_iters = tune("MCGPU_INNER_ITERS", 64, 1, 4096);
   A.flush_every = tune("MCGPU_FLUSH_EVERY", 16, 1, 1000000);
   A.min_active = tune("MCGPU_MIN_ACTIVE", 32, 0, 64);
-  A.flags = tune("MCGPU_DIAG_FLAGS", 0, 0, 255);  // (diagnostic builds only)
+  A.flags = tune("MCGPU_DIAG_FLAGS", 0, 0, 0x7FFFFFFF);  // (diagnostic builds only)
   if (ctx->voro) {
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     int rcv = launch_voro(ctx, A, o->grid_blocks, o->block_threads);

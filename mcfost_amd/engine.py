@@ -104,10 +104,16 @@ class Engine:
     """One device context holding one model (the tables ``init_dust_transfer``
     prepares, ``dust_transfer.f90:41-340``)."""
 
-    def __init__(self, model, n_packets_total, device: int = 0):
+    def __init__(self, model, n_packets_total, device: int = 0, _borrowed_ctx=None):
         self.lib = load_library()
         self.model = model
         self.ctx = C.c_void_p()
+        self._owns_ctx = _borrowed_ctx is None
+        if _borrowed_ctx is not None:   # a context of a MultiEngine: it creates and destroys it
+            self.ctx = C.c_void_p(_borrowed_ctx)
+            self.device = device
+            self._upload(model, float(n_packets_total))
+            return
         # If this process also uses torch (device_accumulators / device_xI hand the engine's buffers to it), torch
         # must initialise its HIP context first: torch wheels carry their own HIP runtime, and brought up second it
         # has been seen to report "No HIP GPUs are available".
@@ -135,7 +141,8 @@ class Engine:
 
     def close(self):
         if getattr(self, "ctx", None) and self.ctx.value:
-            self.lib.mcgpu_destroy(self.ctx)
+            if getattr(self, "_owns_ctx", True):
+                self.lib.mcgpu_destroy(self.ctx)
             self.ctx = C.c_void_p()
 
     def __del__(self):
@@ -458,3 +465,62 @@ class Engine:
                                                    C.c_int(n), _p(out, C.c_float)),
                   "mcgpu_probe_packet_rand")
         return out
+
+
+class MultiEngine:
+    """Several GPUs of one node behind one host thread (``mcgpu_multi_*``): one context per device holding a
+    replica of the model, packets sharded by id range, ONE RCCL all-reduce of the fused accumulator per
+    temperature iteration inside the library."""
+
+    def __init__(self, model, n_packets_total, devices=(0,)):
+        self.lib = load_library()
+        self.model = model
+        self.h = C.c_void_p()
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        self.lib.mcgpu_multi_ctx.restype = C.c_void_p
+        self.lib.mcgpu_multi_last_error.restype = C.c_char_p
+        rc = self.lib.mcgpu_multi_create(C.c_int(len(devices)), devs, C.byref(self.h))
+        if rc:
+            self.h = C.c_void_p()
+            raise McgpuError(f"mcgpu_multi_create({list(devices)}) failed with code {rc}")
+        self.engines = [Engine(model, n_packets_total, device=int(d),
+                               _borrowed_ctx=self.lib.mcgpu_multi_ctx(self.h, C.c_int(i)))
+                        for i, d in enumerate(devices)]
+
+    def set_E_prior(self, E_prior):
+        for e in self.engines:
+            e.set_E_prior(E_prior)
+
+    def run_thermal(self, n_packets, seed=1, first_packet=0, frozen=False, E_prior=None, n_replicas=1.0,
+                    accumulate=False, grid_blocks=0, block_threads=0):
+        if E_prior is not None:
+            self.set_E_prior(E_prior)
+        e0 = self.engines[0]
+        o = e0._opts(n_packets, seed, first_packet, frozen, n_replicas, accumulate, grid_blocks, block_threads)
+        m = self.model
+        E = np.zeros(m.n_cells, np.float64)
+        sed = np.zeros((N_SED_TYPES, m.cfg.N_phi, m.cfg.N_thet, m.n_lambda), np.float64)
+        n_sent = np.zeros(m.n_lambda, np.float64)
+        cnt = np.zeros(N_COUNTERS, np.uint64)
+        ms = C.c_double()
+        rc = self.lib.mcgpu_multi_run_thermal(self.h, C.byref(o), _p(E, C.c_double), _p(sed, C.c_double),
+                                              _p(n_sent, C.c_double), _p(cnt, C.c_uint64), C.byref(ms))
+        if rc:
+            msg = self.lib.mcgpu_multi_last_error(self.h)
+            raise McgpuError(f"mcgpu_multi_run_thermal failed ({rc}): {msg.decode() if msg else ''}")
+        return dict(E_abs=E, sed=sed, n_sent=n_sent, kernel_ms=ms.value,
+                    counters=dict(zip(COUNTER_NAMES, (int(c) for c in cnt))))
+
+    def close(self):
+        for e in getattr(self, "engines", []):
+            e.close()
+        self.engines = []
+        if getattr(self, "h", None) and self.h.value:
+            self.lib.mcgpu_multi_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

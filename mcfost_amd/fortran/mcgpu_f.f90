@@ -66,7 +66,9 @@ module mcgpu_f
   public :: mcgpu_create, mcgpu_destroy, mcgpu_set_grid_cyl, mcgpu_set_grid_voronoi, mcgpu_set_midplane_snap, mcgpu_set_option, &
        mcgpu_set_stars, mcgpu_set_opacity, mcgpu_set_scattering, mcgpu_set_thermal, mcgpu_set_sed_bins, &
        mcgpu_run_thermal, mcgpu_temp_finale, mcgpu_thermal_loop, mcgpu_error_message, mcgpu_set_rt1, &
-       mcgpu_run_mono, mcgpu_fetch, mcgpu_fetch_xI, mcgpu_rt1_dust_map, mcgpu_set_xI, mcgpu_rt1_image, mcgpu_set_xI_precision
+       mcgpu_run_mono, mcgpu_fetch, mcgpu_fetch_xI, mcgpu_rt1_dust_map, mcgpu_set_xI, mcgpu_rt1_image, mcgpu_set_xI_precision, &
+       mcgpu_set_E_prior, mcgpu_multi_create, mcgpu_multi_destroy, mcgpu_multi_size, mcgpu_multi_ctx, mcgpu_multi_run_thermal, &
+       mcgpu_counters_to_accum, mcgpu_counters_from_accum
 
   interface
      integer(c_int) function mcgpu_create(device, ctx) bind(C, name="mcgpu_create")
@@ -184,6 +186,60 @@ module mcgpu_f
        real(c_double), intent(out) :: kernel_ms
      end function mcgpu_run_thermal
 
+     ! prior absorbed-energy grid of the reproducible (frozen-temperature) mode
+     integer(c_int) function mcgpu_set_E_prior(ctx, E_prior) bind(C, name="mcgpu_set_E_prior")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(in) :: E_prior(*)
+     end function mcgpu_set_E_prior
+
+     ! ---- several GPUs behind this one host thread (include/mcgpu.h: mcgpu_multi_*) ---------------------------
+     ! devices: c_null_ptr = devices 0..n_dev-1, or c_loc of an integer(c_int) array
+     integer(c_int) function mcgpu_multi_create(n_dev, devices, multi) bind(C, name="mcgpu_multi_create")
+       import :: c_int, c_ptr
+       integer(c_int), value :: n_dev
+       type(c_ptr), value :: devices
+       type(c_ptr), intent(out) :: multi
+     end function mcgpu_multi_create
+
+     integer(c_int) function mcgpu_multi_destroy(multi) bind(C, name="mcgpu_multi_destroy")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: multi
+     end function mcgpu_multi_destroy
+
+     integer(c_int) function mcgpu_multi_size(multi) bind(C, name="mcgpu_multi_size")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: multi
+     end function mcgpu_multi_size
+
+     ! the context of device i (0-based): upload the model to every one of them with the mcgpu_set_* calls
+     type(c_ptr) function mcgpu_multi_ctx(multi, i) bind(C, name="mcgpu_multi_ctx")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: multi
+       integer(c_int), value :: i
+     end function mcgpu_multi_ctx
+
+     ! opts%n_packets = the GLOBAL packet count; one RCCL all-reduce inside; outputs = the global sums
+     integer(c_int) function mcgpu_multi_run_thermal(multi, opts, E_abs, sed, n_sent, counters, kernel_ms) &
+          bind(C, name="mcgpu_multi_run_thermal")
+       import :: c_int, c_ptr, c_double, c_int64_t, mcgpu_run_opts
+       type(c_ptr), value :: multi
+       type(mcgpu_run_opts), intent(in) :: opts
+       real(c_double), intent(out) :: E_abs(*), sed(*), n_sent(*)
+       integer(c_int64_t), intent(out) :: counters(*)
+       real(c_double), intent(out) :: kernel_ms
+     end function mcgpu_multi_run_thermal
+
+     integer(c_int) function mcgpu_counters_to_accum(ctx) bind(C, name="mcgpu_counters_to_accum")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+     end function mcgpu_counters_to_accum
+
+     integer(c_int) function mcgpu_counters_from_accum(ctx) bind(C, name="mcgpu_counters_from_accum")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+     end function mcgpu_counters_from_accum
+
      ! tab_u_rt, tab_v_rt, tab_w_rt, n_az_rt, N_type_flux: module dust_ray_tracing; tab_s11_pos(:,1,:): grains
      integer(c_int) function mcgpu_set_rt1(ctx, RT_n_incl, RT_n_az, tab_u_rt, tab_v_rt, tab_w_rt, n_az_rt, &
           n_theta_rt, N_type_flux, lsepar_contrib, tab_s11_pos, n_lambda_pos) bind(C, name="mcgpu_set_rt1")
@@ -290,7 +346,7 @@ contains
        nang_scatt, aniso_method, lisotropic, lsepar_pola, prob_s11_pos, s12, s22, s33, s34, s44, tab_g_pos, &
        n_T, tab_Temp, log_Qcool, kdB_dT_CDF, spectre_emission_cumul, frac_E_stars, frac_E_disk, CDF_E_star, &
        L_packet_th, T_min, N_thet, N_phi, l_sym_centrale, l_sym_axiale, &
-       E_abs, sed, n_sent, kernel_ms, ierr)
+       E_abs, sed, n_sent, kernel_ms, ierr, n_dev, E_prior)
 
     integer(c_int64_t), intent(in) :: n_packets, seed
     integer, intent(in) :: n_rad, nz, n_az, n_stars, n_lambda, nang_scatt, aniso_method, n_T, N_thet, N_phi
@@ -306,34 +362,47 @@ contains
          frac_E_disk(*), CDF_E_star(*), L_packet_th
     real(dp), intent(out) :: E_abs(*), sed(*), n_sent(*), kernel_ms
     integer, intent(out) :: ierr
+    integer, intent(in), optional :: n_dev          ! GPUs of this node to use (default 1)
+    real(dp), intent(in), optional :: E_prior(*)    ! present: reproducible mode, Temp_LTE reads this prior
 
-    type(c_ptr) :: ctx
+    type(c_ptr) :: multi, ctx
     type(mcgpu_run_opts) :: opts
     integer(c_int64_t) :: counters(MCGPU_N_COUNTERS)
-    integer(c_int) :: rc
+    integer(c_int) :: rc, nd, i
 
     ierr = 0
-    rc = mcgpu_create(0_c_int, ctx)
+    nd = 1
+    if (present(n_dev)) nd = n_dev
+    rc = mcgpu_multi_create(nd, c_null_ptr, multi)
     if (rc /= 0) then
        ierr = rc ; return
     endif
-    rc = mcgpu_set_grid_cyl(ctx, n_rad, nz, n_az, merge(1,0,l3D), r_lim_2, zmax, z_lim, tan_phi_lim, &
-         maxval(zmax(1:n_rad)), Rmax2, volume, cell_map, cell_map_i, cell_map_j, cell_map_k, lexit_cell)
-    if (rc == 0) rc = mcgpu_set_stars(ctx, n_stars, star_x, star_y, star_z, star_r, star_icell, star_out_model)
-    if (rc == 0) rc = mcgpu_set_opacity(ctx, n_lambda, kappa, kappa_abs_LTE, tab_albedo_pos, kappa_factor, c_null_ptr)
-    if (rc == 0) rc = mcgpu_set_scattering(ctx, nang_scatt, aniso_method, merge(1,0,lisotropic), &
-         merge(1,0,lsepar_pola), 1_c_int, prob_s11_pos, s12, s22, s33, s34, s44, tab_g_pos)
-    if (rc == 0) rc = mcgpu_set_thermal(ctx, n_T, tab_Temp, log_Qcool, kdB_dT_CDF, spectre_emission_cumul, &
-         frac_E_stars, frac_E_disk, CDF_E_star, c_null_ptr, L_packet_th, T_min)
-    if (rc == 0) rc = mcgpu_set_sed_bins(ctx, N_thet, N_phi, merge(1,0,l_sym_centrale), merge(1,0,l_sym_axiale))
+    ! the tables are replicated: the same upload on every device
+    do i = 0, nd-1
+       ctx = mcgpu_multi_ctx(multi, i)
+       if (rc == 0) rc = mcgpu_set_grid_cyl(ctx, n_rad, nz, n_az, merge(1,0,l3D), r_lim_2, zmax, z_lim, tan_phi_lim, &
+            maxval(zmax(1:n_rad)), Rmax2, volume, cell_map, cell_map_i, cell_map_j, cell_map_k, lexit_cell)
+       if (rc == 0) rc = mcgpu_set_stars(ctx, n_stars, star_x, star_y, star_z, star_r, star_icell, star_out_model)
+       if (rc == 0) rc = mcgpu_set_opacity(ctx, n_lambda, kappa, kappa_abs_LTE, tab_albedo_pos, kappa_factor, c_null_ptr)
+       if (rc == 0) rc = mcgpu_set_scattering(ctx, nang_scatt, aniso_method, merge(1,0,lisotropic), &
+            merge(1,0,lsepar_pola), 1_c_int, prob_s11_pos, s12, s22, s33, s34, s44, tab_g_pos)
+       if (rc == 0) rc = mcgpu_set_thermal(ctx, n_T, tab_Temp, log_Qcool, kdB_dT_CDF, spectre_emission_cumul, &
+            frac_E_stars, frac_E_disk, CDF_E_star, c_null_ptr, L_packet_th, T_min)
+       if (rc == 0) rc = mcgpu_set_sed_bins(ctx, N_thet, N_phi, merge(1,0,l_sym_centrale), merge(1,0,l_sym_axiale))
+       if (rc == 0 .and. present(E_prior)) rc = mcgpu_set_E_prior(ctx, E_prior)
+       if (rc /= 0) then
+          write(*,*) "mcgpu error ", rc, " on device ", i, ": ", trim(mcgpu_error_message(ctx))
+          exit
+       endif
+    enddo
     if (rc == 0) then
        opts%seed = seed ; opts%first_packet = 0 ; opts%n_packets = n_packets ; opts%n_replicas = 1.0_c_double
-       opts%frozen = 0 ; opts%accumulate = 0 ; opts%grid_blocks = 0 ; opts%block_threads = 0
-       rc = mcgpu_run_thermal(ctx, opts, E_abs, sed, n_sent, counters, kernel_ms)
+       opts%frozen = merge(1, 0, present(E_prior)) ; opts%accumulate = 0 ; opts%grid_blocks = 0 ; opts%block_threads = 0
+       rc = mcgpu_multi_run_thermal(multi, opts, E_abs, sed, n_sent, counters, kernel_ms)
+       if (rc /= 0) write(*,*) "mcgpu_multi_run_thermal failed: ", rc
     endif
-    if (rc /= 0) write(*,*) "mcgpu error ", rc, ": ", trim(mcgpu_error_message(ctx))
     ierr = rc
-    rc = mcgpu_destroy(ctx)
+    rc = mcgpu_multi_destroy(multi)
 
   end subroutine mcgpu_thermal_loop
 

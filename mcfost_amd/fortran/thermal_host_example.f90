@@ -6,7 +6,9 @@
 ! calls the drop-in replacement of mc_photon_loop through the ISO_C_BINDING shim
 ! (mcgpu_f.f90) and writes E_abs (xKJ_abs), the SED arrays and n_phot_envoyes back.
 !
-!   thermal_host_example model.bin result.bin n_packets seed
+!   thermal_host_example model.bin result.bin n_packets seed [n_dev [prior.bin]]
+! n_dev: GPUs of this node (one host thread, RCCL all-reduce inside the library); prior.bin: n_cells doubles,
+! the absorbed-energy prior of the reproducible (frozen-temperature) mode.
 
 program thermal_host_example
   use, intrinsic :: iso_c_binding
@@ -22,11 +24,18 @@ program thermal_host_example
        kappa(:), kabs(:), kfac(:), lq(:), cdf(:), cum(:), fst(:), fdi(:), cdfs(:), E_abs(:), sed(:), n_sent(:)
   real, allocatable :: albedo(:), prob(:), s12(:), s22(:), s33(:), s34(:), s44(:), g(:), tab_Temp(:)
   integer, allocatable :: cell_map(:), cmi(:), cmj(:), cmk(:), lexit(:), sic(:), som(:)
-  integer :: u, ierr
+  integer :: u, ierr, n_dev
+  real(dp), allocatable :: E_prior(:)
+  character(len=512) :: fprior
 
   call get_command_argument(1, fin) ; call get_command_argument(2, fout)
   call get_command_argument(3, arg) ; read(arg,*) n_packets
   call get_command_argument(4, arg) ; read(arg,*) seed
+  n_dev = 1 ; fprior = ""
+  if (command_argument_count() >= 5) then
+     call get_command_argument(5, arg) ; read(arg,*) n_dev
+  endif
+  if (command_argument_count() >= 6) call get_command_argument(6, fprior)
 
   open(newunit=u, file=trim(fin), access='stream', form='unformatted', status='old')
   read(u) n_rad, nz, n_az, il3D, n_cells, ntot2, ncm, n_stars, n_lambda, nang, aniso, iiso, ipola, n_T, N_thet, N_phi, isc, isa
@@ -49,10 +58,23 @@ program thermal_host_example
   close(u)
 
   allocate(E_abs(n_cells), sed(9*n_lambda*N_thet*N_phi), n_sent(n_lambda))
-  call mcgpu_thermal_loop(n_packets, seed, n_rad, nz, n_az, il3D /= 0, r_lim_2, zmax, z_lim, tan_phi_lim, Rmax2, &
-       volume, cell_map, cmi, cmj, cmk, lexit, n_stars, sx, sy, sz, sr, sic, som, n_lambda, kappa, kabs, albedo, &
-       kfac, nang, aniso, iiso /= 0, ipola /= 0, prob, s12, s22, s33, s34, s44, g, n_T, tab_Temp, lq, cdf, cum, &
-       fst, fdi, cdfs, L_packet_th, T_min, N_thet, N_phi, isc /= 0, isa /= 0, E_abs, sed, n_sent, kernel_ms, ierr)
+  if (len_trim(fprior) > 0) then
+     allocate(E_prior(n_cells))
+     open(newunit=u, file=trim(fprior), access='stream', form='unformatted', status='old')
+     read(u) E_prior
+     close(u)
+     call mcgpu_thermal_loop(n_packets, seed, n_rad, nz, n_az, il3D /= 0, r_lim_2, zmax, z_lim, tan_phi_lim, Rmax2, &
+          volume, cell_map, cmi, cmj, cmk, lexit, n_stars, sx, sy, sz, sr, sic, som, n_lambda, kappa, kabs, albedo, &
+          kfac, nang, aniso, iiso /= 0, ipola /= 0, prob, s12, s22, s33, s34, s44, g, n_T, tab_Temp, lq, cdf, cum, &
+          fst, fdi, cdfs, L_packet_th, T_min, N_thet, N_phi, isc /= 0, isa /= 0, E_abs, sed, n_sent, kernel_ms, ierr, &
+          n_dev=n_dev, E_prior=E_prior)
+  else
+     call mcgpu_thermal_loop(n_packets, seed, n_rad, nz, n_az, il3D /= 0, r_lim_2, zmax, z_lim, tan_phi_lim, Rmax2, &
+          volume, cell_map, cmi, cmj, cmk, lexit, n_stars, sx, sy, sz, sr, sic, som, n_lambda, kappa, kabs, albedo, &
+          kfac, nang, aniso, iiso /= 0, ipola /= 0, prob, s12, s22, s33, s34, s44, g, n_T, tab_Temp, lq, cdf, cum, &
+          fst, fdi, cdfs, L_packet_th, T_min, N_thet, N_phi, isc /= 0, isa /= 0, E_abs, sed, n_sent, kernel_ms, ierr, &
+          n_dev=n_dev)
+  endif
   if (ierr /= 0) then
      write(*,*) "mc_photon_loop on the GPU failed, ierr =", ierr
      call exit(1)

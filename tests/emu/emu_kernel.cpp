@@ -54,6 +54,7 @@ static inline void __syncthreads() {}
 static inline int __syncthreads_or(int p) { return p; }
 static inline unsigned long long atomicExch(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p = v; return o; }
 static inline int atomicAdd(int* p, int v) { int o = *p; *p += v; return o; }
+static inline int atomicExch(int* p, int v) { int o = *p; *p = v; return o; }
 static inline int atomicCAS(int* p, int cmp, int v) { int o = *p; if (o == cmp) *p = v; return o; }
 static inline unsigned int atomicCAS(unsigned int* p, unsigned int cmp, unsigned int v) { unsigned int o = *p; if (o == cmp) *p = v; return o; }
 static inline double __longlong_as_double(long long b) { double d; memcpy(&d, &b, 8); return d; }

@@ -271,19 +271,60 @@ def test_fortran_host_through_iso_c_binding(small_model, tmp_path):
     if not os.path.exists(exe):
         pytest.skip("Fortran host example not built (amdflang missing at build time)")
     n, seed = 200000, 4242
-    fin, fout = str(tmp_path / "model.bin"), str(tmp_path / "result.bin")
+    fin, fout, fpr = str(tmp_path / "model.bin"), str(tmp_path / "result.bin"), str(tmp_path / "prior.bin")
     dump.write_model(small_model, n, fin)
-    out = subprocess.run([exe, fin, fout, str(n), str(seed)], capture_output=True, text=True, timeout=600)
+    o = _oracle(small_model, n)
+    prior = o.run_thermal(2000, seed=1)["E_abs"]
+    np.ascontiguousarray(prior, np.float64).tofile(fpr)
+    # reproducible (frozen-temperature) mode through the multi-device entry with one device: the Fortran-driven run
+    # equals the oracle packet for packet
+    out = subprocess.run([exe, fin, fout, str(n), str(seed), "1", fpr], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "packets/s" in out.stdout
     f = dump.read_result(small_model, fout)
+    b = o.run_thermal(n, seed=seed, frozen=True, E_prior=prior, n_threads=8)
+    assert np.array_equal(f["n_sent"], b["n_sent"]) and np.array_equal(f["sed"][4], b["sed"][4])
+    assert np.allclose(f["E_abs"], b["E_abs"], rtol=1e-9, atol=1e-12 * b["E_abs"].max())
+    # live mode (the reference algorithm) still runs through the same binding
+    out = subprocess.run([exe, fin, fout, str(n), str(seed)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    f = dump.read_result(small_model, fout)
+    assert f["n_sent"].sum() == n and f["E_abs"].sum() > 0
+
+
+def test_multi_device_entry_with_one_device_equals_the_single_context_call(small_model):
+    """mcgpu_multi_run_thermal (one host thread, RCCL all-reduce of the fused [E_abs | sed | n_sent | counters] buffer)
+    with n_dev = 1 returns what mcgpu_run_thermal returns."""
+    from mcfost_amd.engine import MultiEngine
+    n = 30000
+    o = _oracle(small_model, n)
+    prior = o.run_thermal(2000, seed=1)["E_abs"]
     e = _engine(small_model, n)
-    p = e.run_thermal(n, seed=seed)
-    assert np.array_equal(f["n_sent"], p["n_sent"])            # emission wavelengths: deterministic
-    assert abs(f["sed"][4].sum() - p["sed"][4].sum()) <= 10    # all but the few star hits escape
-    Tf, Tp = e.temp_finale(f["E_abs"]), e.temp_finale(p["E_abs"])
-    assert rel_rms(Tf, Tp, 1.01 * small_model.cfg.T_min) < 0.02
+    a = e.run_thermal(n, seed=11, frozen=True, E_prior=prior)
     e.close()
+    me = MultiEngine(small_model, n, devices=(0,))
+    b = me.run_thermal(n, seed=11, frozen=True, E_prior=prior)
+    me.close()
+    assert a["counters"] == b["counters"] and b["counters"]["packets"] == n
+    assert np.array_equal(a["n_sent"], b["n_sent"]) and np.array_equal(a["sed"][4], b["sed"][4])
+    assert np.allclose(a["E_abs"], b["E_abs"], rtol=1e-12, atol=0)
+
+
+def test_single_role_schedule_option(small_model):
+    """option "schedule" = 1 (the single-role kernel) and "deposit" = 1 (HBM atomics): same packets, same sums."""
+    m = small_model
+    o = _oracle(m, 20000)
+    prior = o.run_thermal(2000, seed=1)["E_abs"]
+    ref = o.run_thermal(20000, seed=21, frozen=True, E_prior=prior, n_threads=8)
+    for opts in ({"schedule": 1}, {"deposit": 1}, {"schedule": 1, "deposit": 1}):
+        e = _engine(m, 20000)
+        for k, v in opts.items():
+            e.set_option(k, v)
+        a = e.run_thermal(20000, seed=21, frozen=True, E_prior=prior)
+        assert a["counters"] == ref["counters"], opts
+        assert np.array_equal(a["n_sent"], ref["n_sent"])
+        assert np.allclose(a["E_abs"], ref["E_abs"], rtol=1e-9, atol=1e-12 * ref["E_abs"].max())
+        e.close()
 
 
 def test_edge_cases_empty_and_tiny_runs(small_model):
