@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """bench.py -- photon packets/s of the thermal Monte Carlo packet loop on the
-BASELINE workload (ref4.1.para 2D cylindrical disk, 1e8 packets per GPU).
+BASELINE workloads: the Pascucci 2D disk BASELINE.json's metric is quoted on (the
+headline line) and ref4.1.para 2D (configs[1], carried as a second full block),
+1e8 packets per GPU and step each.
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -41,21 +43,32 @@ def _quota_cores():
     return cores
 
 
-def pmc_traffic(config, n_local, world):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes of THIS command
-    (`tools/collect_profiles.sh`: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate runs of
-    `python bench.py --steps 1 --warmup 0`, summarised in profiles/r01_pmc_{fetch,write}.json).  Counters are in
-    KB; FETCH_SIZE is doubled for gfx950 (MI355X guide, HBM section).  None when the command differs."""
-    if config != "ref41" or world != 1 or int(n_local) != 100000000:
-        return None
+def source_hash():
+    """Hash of the kernel sources: a committed PMC summary only counts for the code it was measured on."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "mcfost_amd", "csrc", "*.h")) +
+                    glob.glob(os.path.join(ROOT, "mcfost_amd", "csrc", "*.hip"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_summary(config, n_local, world):
+    """Counter evidence for the dominant kernel from the committed PMC passes of THIS command and THIS source
+    (`tools/collect_profiles.sh`: rocprofv3 --pmc in separate passes of `python bench.py --config <config> --steps 1
+    --warmup 0`, summarised in profiles/r02_pmc_<config>.json with the hash of the kernel sources).  HBM traffic per
+    launch = 2 x FETCH_SIZE (gfx950 correction, MI355X guide, HBM section) + WRITE_SIZE, counters in KB.  Returns {} when
+    there is no summary for this command or the sources changed since (so nothing stale is ever reported)."""
+    if world != 1:
+        return {}
     try:
-        f = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_fetch.json")))
-        w = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_write.json")))
-        fk = f["pmc_k_thermal_sum_over_launches"]["FETCH_SIZE"] / f["pmc_k_thermal_launches"]["FETCH_SIZE"]
-        wk = w["pmc_k_thermal_sum_over_launches"]["WRITE_SIZE"] / w["pmc_k_thermal_launches"]["WRITE_SIZE"]
-        return (2.0 * fk + wk) * 1024.0
+        d = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_%s.json" % config)))
+        if d.get("source_hash") != source_hash() or int(d.get("packets", 0)) != int(n_local):
+            return {}
+        return d.get("per_launch", {})
     except Exception:
-        return None
+        return {}
 
 
 def cpu_baseline(model, n_total, target_s=15.0):
@@ -181,20 +194,117 @@ def bench_sed(args, world, rank, local_rank):
         dist.destroy_process_group()
 
 
+def thermal_block(M, D, Engine, dist, torch, args, config, world, rank, local_rank, steps, warmup, with_cpu):
+    """Times `steps` passes of the thermal packet loop on one configuration; returns (block dict or None on ranks > 0)."""
+    cfg = {"ref41": M.ref41, "ref41_3d": M.ref41_3d, "pascucci": M.pascucci, "voronoi": M.ref41}[config]()
+    if args.no_pola:
+        cfg.lsepar_pola = False
+    if config == "voronoi":
+        cfg.name = "ref4.1 disk as %d Voronoi sites" % args.sites
+        model = M.build_voronoi_model(cfg, args.sites, seed=1)
+    else:
+        model = M.build_model(cfg)
+    n_local = int(args.packets)
+    n_total = n_local * world
+    eng = Engine(model, n_total, device=local_rank)
+    first = rank * n_local
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.frozen:
+        eng.set_E_prior(eng.run_thermal(min(n_local, 2_000_000), seed=5)["E_abs"] * (n_local / min(n_local, 2_000_000)))
+
+    def step(i):
+        eng.launch_thermal(n_local, seed=1000 + i, first_packet=first, n_replicas=float(world),
+                           frozen=args.frozen, grid_blocks=args.grid_blocks, block_threads=args.block_threads)
+        ms = eng.sync()   # HIP events on the engine's own stream around the launch
+        if world > 1:     # ONE all-reduce of the fused [E_abs | sed | n_sent | counters] buffer
+            eng.allreduce_device(dist.all_reduce)
+        return ms
+
+    for i in range(warmup):
+        step(-1 - i)
+    barrier()
+    t0 = time.perf_counter()
+    kernel_ms = []
+    for i in range(steps):
+        kernel_ms.append(step(i))
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    out = eng.fetch()      # after the all-reduce: global sums of the last step
+    cnt = out["counters"]
+    block = None
+    if rank == 0:
+        cross_pp = cnt["crossings"] / max(cnt["packets"], 1)
+        inter_pp = (cnt["scatterings"] + cnt["absorptions"]) / max(cnt["packets"], 1)
+        per_crossing = BYTES_PER_CROSSING
+        if config == "voronoi":
+            # SURVEY.md 8(a) row a8: a crossing reads the cell record (32 B) and its inlined
+            # neighbour list (16 B per neighbour), then the E_abs RMW (16 B)
+            g = model.grid
+            per_crossing = 32.0 + 16.0 * (g["v_neigh"].size / g["n_cells"]) + 16.0
+        bytes_launch = n_local * (cross_pp * per_crossing + inter_pp * BYTES_PER_INTERACTION)
+        k_ms = sum(kernel_ms) / len(kernel_ms)
+        achieved = bytes_launch / (k_ms * 1e-3) / 1e9
+        pmc = pmc_summary(config, n_local, world)
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": pmc.get("hbm_bytes"),
+                "kernel": "k_thermal_voro_cache" if config == "voronoi" else "k_thermal_roles", "kernel_ms": k_ms,
+                "algorithmic_bytes_per_launch": bytes_launch,
+                # what `achieved` is: SURVEY 8(d)'s per-crossing byte model x the kernel's own event counts / kernel time.
+                # The 2D working set (absorbed-energy grid, tables, packet records) lives in LDS and L2, so the model
+                # bytes are NOT HBM traffic: `traffic` (PMC) is, and the binding resource is instruction issue
+                # (valu_busy, waves_per_simd; DESIGN.md section 3)
+                "note": "achieved = algorithmic bytes (SURVEY 8d model) / kernel time; HBM utilisation = traffic / kernel_ms",
+                "hbm_frac_measured": (pmc["hbm_bytes"] / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if pmc.get("hbm_bytes") else None,
+                "valu_busy": pmc.get("valu_busy"), "wait_frac": pmc.get("wait_frac"),
+                "waves_per_simd": pmc.get("waves_per_simd"), "fp64_tflops": pmc.get("fp64_tflops"),
+                "lane_utilisation": pmc.get("lane_utilisation")}
+        block = {"value": n_total * steps / dt, "unit": "packets/s", "steps": steps, "warmup": warmup,
+                 "ms_per_step": dt / steps * 1e3,
+                 "config": {"workload": ("%s 2D cylindrical disk %dx%dx%d, %d wavelengths, %.3g packets/GPU/step, temperature "
+                                         "step (live Bjorkman&Wood re-emission), synthetic dust tables, blackbody star"
+                                         % (cfg.name, cfg.n_rad, cfg.nz, cfg.n_az, cfg.n_lambda, n_local))
+                            if not (cfg.l3D or config == "voronoi") else
+                            ("%s, %d cells, %.3g packets/GPU/step" % (cfg.name, model.n_cells, n_local) if config == "voronoi"
+                             else "%s 3D cylindrical disk %dx%dx%d, %.3g packets/GPU/step"
+                             % (cfg.name, cfg.n_rad, cfg.nz, cfg.n_az, n_local)),
+                            "packets_per_gpu": n_local, "parallelism": "packets sharded x%d, tables replicated" % world,
+                            "crossings_per_packet": cross_pp, "interactions_per_packet": inter_pp},
+                 "roofline": roof}
+        if with_cpu:
+            base, T_cpu, n_cpu = cpu_baseline(model, n_total, args.cpu_seconds)
+            block["cpu_baseline"] = base
+            if not args.frozen:  # Tdust of the last timed step against the CPU port's
+                block["tdust_vs_cpu"] = tdust_parity(eng.temp_finale(out["E_abs"]), n_total, T_cpu, n_cpu, cfg.T_min)
+    eng.close()
+    return block, cfg
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--packets", type=float, default=1e8, help="packets per GPU per step")
-    ap.add_argument("--config", default="ref41", choices=["ref41", "ref41_3d", "pascucci", "voronoi", "sed"])
+    ap.add_argument("--config", default="pascucci", choices=["pascucci", "ref41", "ref41_3d", "voronoi", "sed"],
+                    help="pascucci (default): the disk BASELINE.json's metric is quoted on, with ref4.1 (configs[1]) as a "
+                         "second full block of the same line")
     ap.add_argument("--sed-lambdas", default="5,15,25,35",
                     help="--config sed: wavelengths (1-based) whose SED Monte Carlo one step runs")
     ap.add_argument("--sites", type=int, default=100000,
                     help="--config voronoi: number of SPH-like sites of the tessellation (BASELINE config 5 stand-in)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-pascucci", action="store_true", help="skip the extra Pascucci-disk timing of the default run")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-ref41", action="store_true", help="--config pascucci: skip the ref4.1 block")
+    ap.add_argument("--no-pascucci", action="store_true", help="(kept for older command lines: same as --no-ref41)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--grid-blocks", type=int, default=0)
     ap.add_argument("--block-threads", type=int, default=0)
     ap.add_argument("--no-pola", action="store_true", help="tuning aid: do not track Stokes Q,U,V")
@@ -222,129 +332,25 @@ def main():
 
     if args.config == "sed":
         return bench_sed(args, world, rank, local_rank)
-    cfg = {"ref41": M.ref41, "ref41_3d": M.ref41_3d, "pascucci": M.pascucci, "voronoi": M.ref41}[args.config]()
-    if args.no_pola:
-        cfg.lsepar_pola = False
-    if args.config == "voronoi":
-        cfg.name = "ref4.1 disk as %d Voronoi sites" % args.sites
-        model = M.build_voronoi_model(cfg, args.sites, seed=1)
-    else:
-        model = M.build_model(cfg)
-    n_local = int(args.packets)
-    n_total = n_local * world
-    eng = Engine(model, n_total, device=local_rank)
-    first = rank * n_local
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    if args.frozen:
-        env_flags = os.environ.pop("MCGPU_DIAG_FLAGS", None)
-        eng.set_E_prior(eng.run_thermal(min(n_local, 2_000_000), seed=5)["E_abs"] * (n_local / min(n_local, 2_000_000)))
-        if env_flags is not None:
-            os.environ["MCGPU_DIAG_FLAGS"] = env_flags
-
-    def step(i):
-        eng.launch_thermal(n_local, seed=1000 + i, first_packet=first, n_replicas=float(world),
-                           frozen=args.frozen, grid_blocks=args.grid_blocks, block_threads=args.block_threads)
-        ms = eng.sync()
-        if world > 1:   # ONE all-reduce of the fused [E_abs | sed | n_sent | counters] buffer
-            eng.allreduce_device(dist.all_reduce)
-        return ms
-
-    for i in range(args.warmup):
-        step(-1 - i)
-    barrier()
-    t0 = time.perf_counter()
-    kernel_ms = []
-    for i in range(args.steps):
-        kernel_ms.append(step(i))
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-
-    out = eng.fetch()      # after the all-reduce: global sums of the last step
-    cnt = out["counters"]
-
-    # BASELINE.json quotes its metric on the Pascucci 2D disk and lists ref4.1 as the single-GPU configuration
-    # (configs[1], the headline line above): the same loop on the Pascucci disk is timed next to it, same packet
-    # count, same barriers and all-reduce, and reported under "pascucci_2d".
+    with_cpu = world == 1 and not args.no_cpu_baseline
+    block, cfg = thermal_block(M, D, Engine, dist, torch, args, args.config, world, rank, local_rank, args.steps,
+                               args.warmup, with_cpu)
     extra = None
-    if args.config == "ref41" and not args.no_pascucci and not args.frozen:
-        pm = M.build_model(M.pascucci())
-        pe = Engine(pm, n_total, device=local_rank)
-
-        def pstep(i):
-            pe.launch_thermal(n_local, seed=2000 + i, first_packet=first, n_replicas=float(world))
-            ms = pe.sync()
-            if world > 1:
-                pe.allreduce_device(dist.all_reduce)
-            return ms
-
-        pstep(-1)
-        barrier()
-        tp0 = time.perf_counter()
-        pk = [pstep(i) for i in range(2)]
-        barrier()
-        dtp = time.perf_counter() - tp0
-        if world > 1:
-            tt = torch.tensor([dtp], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dtp = float(tt.item())
-        pc = pe.fetch()["counters"]
-        extra = {"value": n_total * 2 / dtp, "unit": "packets/s", "steps": 2, "warmup": 1, "ms_per_step": dtp / 2 * 1e3,
-                 "kernel_ms": sum(pk) / 2, "workload": "Pascucci 2D disk 100x70, 61 wavelengths, isotropic scattering, "
-                 "%.3g packets/GPU/step" % n_local,
-                 "crossings_per_packet": pc["crossings"] / max(pc["packets"], 1),
-                 "interactions_per_packet": (pc["scatterings"] + pc["absorptions"]) / max(pc["packets"], 1)}
-        pe.close()
+    if args.config == "pascucci" and not (args.no_ref41 or args.no_pascucci) and not args.frozen:
+        # BASELINE.json lists ref4.1 as the single-GPU configuration (configs[1]): the same loop, same packet count,
+        # same steps, barriers and all-reduce, with its own roofline, CPU baseline and temperature parity
+        extra, _ = thermal_block(M, D, Engine, dist, torch, args, "ref41", world, rank, local_rank, args.steps,
+                                 args.warmup, with_cpu)
     if rank == 0:
-        ms_step = dt / args.steps * 1e3
-        value = n_total * args.steps / dt
-        n_units = cnt["packets"] if world == 1 else cnt["packets"] / world
-        cross_pp = cnt["crossings"] / max(cnt["packets"], 1)
-        inter_pp = (cnt["scatterings"] + cnt["absorptions"]) / max(cnt["packets"], 1)
-        per_crossing = BYTES_PER_CROSSING
-        if args.config == "voronoi":
-            # a crossing reads the cell record (32 B) and its inlined
-            # neighbour list (16 B per neighbour), then the E_abs RMW (16 B)
-            g = model.grid
-            per_crossing = 32.0 + 16.0 * (g["v_neigh"].size / g["n_cells"]) + 16.0
-        bytes_launch = n_local * (cross_pp * per_crossing + inter_pp * BYTES_PER_INTERACTION)
-        k_ms = sum(kernel_ms) / len(kernel_ms)
-        achieved = bytes_launch / (k_ms * 1e-3) / 1e9
-        line = {
-            "metric": "photon packets/sec (whole node), thermal MC packet loop, %s" % cfg.name, "value": value,
-            "unit": "packets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%s 2D cylindrical disk %dx%dx%d, %d wavelengths, %.3g packets/GPU/step, "
-                                   "temperature step (live Bjorkman&Wood re-emission), synthetic dust tables, "
-                                   "blackbody star" % (cfg.name, cfg.n_rad, cfg.nz, cfg.n_az, cfg.n_lambda, n_local)
-                       if not (cfg.l3D or args.config == "voronoi") else
-                       ("%s, %d cells, %.3g packets/GPU/step" % (cfg.name, model.n_cells, n_local)
-                        if args.config == "voronoi" else
-                        "%s 3D cylindrical disk %dx%dx%d, %.3g packets/GPU/step"
-                        % (cfg.name, cfg.n_rad, cfg.nz, cfg.n_az, n_local)),
-                       "packets_per_gpu": n_local, "parallelism": "packets sharded x%d, tables replicated" % world,
-                       "crossings_per_packet": cross_pp, "interactions_per_packet": inter_pp},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.config, n_local, world),
-                         "kernel": "k_thermal_voro" if args.config == "voronoi" else "k_thermal_roles", "kernel_ms": k_ms,
-                         "algorithmic_bytes_per_launch": bytes_launch},
-        }
+        line = {"metric": "photon packets/sec (whole node), thermal MC packet loop, %s" % cfg.name,
+                "value": block["value"], "unit": "packets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": block["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "f64", "data": "synthetic", "config": block["config"], "roofline": block["roofline"]}
+        for k in ("cpu_baseline", "tdust_vs_cpu"):
+            if k in block:
+                line[k] = block[k]
         if extra is not None:
-            line["pascucci_2d"] = extra
-        if world == 1 and not args.no_cpu_baseline:
-            base, T_cpu, n_cpu = cpu_baseline(model, n_total, args.cpu_seconds)
-            line["cpu_baseline"] = base
-            if not args.frozen:  # Tdust of the last timed step against the CPU port's
-                line["tdust_vs_cpu"] = tdust_parity(eng.temp_finale(out["E_abs"]), n_total, T_cpu, n_cpu, cfg.T_min)
+            line["ref41_2d"] = extra
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -252,33 +252,6 @@ struct VoroEmitOps {
   }
 };
 
-// ---------------------------------------------------------------------------
-// Deposit cache: 2^log_ns slots of (cell id, partial sum) in LDS
-// ---------------------------------------------------------------------------
-struct DepCache {
-  double* val;
-  int* tag;  // 0 = free, else the 1-based cell id that owns the slot for the whole launch
-  int log_ns;
-  __device__ inline int slot_of(int icell) const { return (int)(((unsigned)icell * 2654435761u) >> (32 - log_ns)); }
-  // returns true when the deposit went to the cache
-  __device__ inline bool add(int icell, double v) const {
-    const int sl = slot_of(icell);
-    int t = tag[sl];
-    if (t == 0) {
-      t = atomicCAS(&tag[sl], 0, icell);
-      if (t == 0) t = icell;
-    }
-    if (t != icell) return false;
-    atomic_add_f64(&val[sl], v);
-    return true;
-  }
-  // this workgroup's not yet folded part of a cell's energy
-  __device__ inline double pending(int icell) const {
-    const int sl = slot_of(icell);
-    return tag[sl] == icell ? val[sl] : 0.0;
-  }
-};
-
 constexpr int VORO_CACHE_BLOCK = 1024;  // most threads of a cached-deposit workgroup (one per CU)
 
 // ---------------------------------------------------------------------------

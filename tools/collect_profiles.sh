@@ -1,20 +1,23 @@
 #!/bin/bash
-# Run on the GPU box (gpurun): rocprofv3 kernel traces of the three bench workloads and the two HBM PMC
-# passes of the default bench command; summaries land in gpurun_out/ (copy them to profiles/).
-# Counters are collected in their own runs, with --kernel-trace only (MI355X guide, HBM section).
+# Round-2 profile collection on the GPU box (run from the repo root through gpurun):
+#   tools/collect_profiles.sh [config ...]        (default: pascucci ref41)
+# Per configuration: one rocprofv3 kernel trace with --stats of `python3 bench.py --config C` and four PMC passes
+# (separate runs, counters only with --kernel-trace, as the MI355X guide prescribes) of the same command with
+# --steps 1 --warmup 0.  tools/summarize_prof.py turns them into gpurun_out/r02_kt_C.json / r02_pmc_C.json, which
+# are then copied to profiles/ and committed.
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r01}
-mkdir -p $R/gpurun_out
+mkdir -p $R/gpurun_out/prof
 cd /tmp; export TMPDIR=/tmp
-run() { # name, then the rocprofv3 options, then -- program
-  local name=$1; shift
-  rm -rf $R/gpurun_out/p_$name; mkdir -p $R/gpurun_out/p_$name
-  timeout 900 rocprofv3 "$@" > $R/gpurun_out/p_$name.log 2>&1 </dev/null
-  (cd $R && python3 tools/summarize_prof.py gpurun_out/p_$name gpurun_out ${TAG}_$name > /dev/null 2>&1)
-}
-run kt       --kernel-trace --stats --output-format csv -d $R/gpurun_out/p_kt -o kt -- python3 $R/bench.py --no-cpu-baseline --no-pascucci
-run pmc_fetch --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/p_pmc_fetch -o f -- python3 $R/bench.py --no-cpu-baseline --no-pascucci --steps 1 --warmup 0
-run pmc_write --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/p_pmc_write -o w -- python3 $R/bench.py --no-cpu-baseline --no-pascucci --steps 1 --warmup 0
-run kt_voro  --kernel-trace --stats --output-format csv -d $R/gpurun_out/p_kt_voro -o kt -- python3 $R/bench.py --config voronoi --sites 50000 --packets 2e7 --no-cpu-baseline
-run kt_sed   --kernel-trace --stats --output-format csv -d $R/gpurun_out/p_kt_sed -o kt -- python3 $R/bench.py --config sed --packets 2e7 --no-cpu-baseline
-ls -la $R/gpurun_out/${TAG}_*.json
+CFGS="$@"; [ -z "$CFGS" ] && CFGS="pascucci ref41"
+for C in $CFGS; do
+  B="python3 $R/bench.py --config $C --no-cpu-baseline --no-ref41"
+  P=$R/gpurun_out/prof/$C
+  rm -rf $P; mkdir -p $P
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $P/kt -o kt -- $B > $P/kt.log 2>&1 </dev/null
+  timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $P/f -o f -- $B --steps 1 --warmup 0 > $P/f.log 2>&1 </dev/null
+  timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $P/w -o w -- $B --steps 1 --warmup 0 > $P/w.log 2>&1 </dev/null
+  timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $P/a -o a -- $B --steps 1 --warmup 0 > $P/a.log 2>&1 </dev/null
+  timeout 600 rocprofv3 --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $P/b -o b -- $B --steps 1 --warmup 0 > $P/b.log 2>&1 </dev/null
+  (cd $R && python3 tools/summarize_prof.py gpurun_out/prof/$C $C gpurun_out)
+done
+ls -la $R/gpurun_out/r02_*.json
