@@ -130,6 +130,22 @@ int mcgpu_set_grid_voronoi(mcgpu_ctx *ctx, int n_cells, const float *voronoi_xyz
                            const double *volume);
 
 /*
+ * Spherical grid (grid_type = 2: the operators of spherical_grid.f90 bound at grid.f90:345-357).  Arrays of module
+ * cylindrical_grid (cylindrical_grid.f90:28-31, filled by the spherical branch of define_cylindrical_grid,
+ * :496-580): r_lim_2(0:n_rad), r_lim_3(0:n_rad), tan_theta_lim(0:nz), theta_lim(0:nz), tan_phi_lim(n_az); the cell
+ * mapping arrays are the ones build_cylindrical_cell_mapping fills for both structured grids (verified like
+ * mcgpu_set_grid_cyl's).  Replaces cross_spherical_cell (:182), index_cell_sph (:48), move_to_grid_sph (:562),
+ * pos_em_cell_sph (:619), test_exit_grid_sph (:24).  Thermal step only for now: a dark zone, the SED mode and the
+ * ray tracer on this grid return MCGPU_ERR_UNSUPPORTED.
+ */
+int mcgpu_set_grid_sph(mcgpu_ctx *ctx, int n_rad, int nz, int n_az, int l3D,
+                       const double *r_lim_2, const double *r_lim_3,
+                       const double *tan_theta_lim, const double *theta_lim,
+                       const double *tan_phi_lim, double Rmax2, const double *volume,
+                       const int *cell_map, const int *cell_map_i, const int *cell_map_j,
+                       const int *cell_map_k, const int *lexit_cell);
+
+/*
  * 3D grids only.  on != 0 (default): a packet that crosses the midplane lands
  * at z = sign(grid_prec, w), i.e. the reference's own z1 == 0 correction
  * (cylindrical_grid.f90:1158-1165) applied to every rounding residue of

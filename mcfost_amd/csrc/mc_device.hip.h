@@ -85,6 +85,11 @@ struct DevModel {
   const double* ch;        // [n_rad] cell height = z_lim(i,2)
   const double* tan_phi_lim;  // [n_az]
   double zmaxmax, Rmax2;
+  // spherical grid (spherical_grid.f90; grid_sph != 0): the polar walls and r^3 (cylindrical_grid.f90:28-31)
+  int grid_sph;
+  const double* tan_theta_lim;  // [nz+1]
+  const double* theta_lim;      // [nz+1]
+  const double* r_lim_3;        // [n_rad+1]
   const double* volume;    // [n_cells]
   // stars: x,y,z,r and (ri,zj,k,out_model)
   int n_stars;
@@ -619,6 +624,213 @@ __device__ inline void pos_em_cell(const Lds& T, const DevModel& M, int ri, int 
   y = r * sin(phi);
 }
 
+// ---------------------------------------------------------------------------
+// Spherical grid operators (spherical_grid.f90) on (ri, thetaj, phik): the same cell identity and mapping as the
+// cylindrical grid (build_cylindrical_cell_mapping serves both, grid.f90:356); thetaj counts the polar bins from the
+// midplane, negative below it in 3D.  Only the outer radius is an exit (test_exit_grid_sph, :24-44).
+// ---------------------------------------------------------------------------
+constexpr double PREC_GRILLE_SPH = 1.0e-7;  // spherical_grid.f90:19
+
+// indice_cellule_sph_theta (:129-178) = the polar / azimuthal part of index_cell_sph (:83-120)
+template <bool L3D>
+__device__ inline void sph_theta_phi(const DevModel& M, double x, double y, double z, int& tj_out, int& k_out) {
+  const double r02 = x * x + y * y;
+  const double tan_theta = (r02 > TINY_DP) ? fabs(z) / sqrt(r02) : (double)1.0e30f;
+  int tmin = 0, tmax = M.nz, tj = (tmin + tmax) / 2;
+  while ((tmax - tmin) > 1) {
+    if (tan_theta > M.tan_theta_lim[tj]) tmin = tj; else tmax = tj;
+    tj = (tmin + tmax) / 2;
+  }
+  tj_out = tj + 1;
+  k_out = 1;
+  if (L3D) {
+    if (z < 0.0) tj_out = -tj_out;
+    if (z != 0.0) {
+      const double phi = modulo_d(atan2(y, x), 2 * PI);
+      int pk = (int)floor(phi / (2 * PI) * (double)(float)M.n_az) + 1;
+      if (pk == M.n_az + 1) pk = M.n_az;
+      k_out = pk;
+    }
+  }
+}
+
+// index_cell_sph (:48-125)
+template <bool L3D>
+__device__ inline void index_cell_sph(const Lds& T, const DevModel& M, double x, double y, double z, int& ri_out,
+                                      int& tj_out, int& k_out) {
+  const double r2 = x * x + y * y + z * z;
+  if (r2 < T.r_lim_2[0]) {
+    ri_out = 0; tj_out = 1; k_out = 1;
+  } else if (r2 > M.Rmax2) {
+    ri_out = M.n_rad + 1; tj_out = 1; k_out = 1;
+  } else {
+    int ri_min = 0, ri_max = M.n_rad, ri = (ri_min + ri_max) / 2;
+    while ((ri_max - ri_min) > 1) {
+      if (r2 > T.r_lim_2[ri]) ri_min = ri; else ri_max = ri;
+      ri = (ri_min + ri_max) / 2;
+    }
+    ri_out = ri + 1;
+    sph_theta_phi<L3D>(M, x, y, z, tj_out, k_out);
+  }
+}
+
+// one polar cone (:247-307): the smallest positive root of the crossing with tan(theta) = tan_lim.  The
+// discriminant is a difference of products of nearly equal size: kept unfused, like the reference build.
+__device__ inline double sph_theta_root(double x0, double y0, double z0, double u, double v, double w, double tan_lim) {
+  const double precision = 1.0e-15;
+  const double tan2 = nd_mul(tan_lim, tan_lim);
+  const double a_theta = nd_add(nd_mul(w, w), -nd_mul(tan2, nd_add(nd_mul(u, u), nd_mul(v, v))));
+  const double a_theta_m1 = 1.0 / a_theta;
+  const double b_theta = nd_add(nd_mul(w, z0), -nd_mul(tan2, nd_add(nd_mul(x0, u), nd_mul(y0, v))));
+  const double c_theta = nd_add(nd_mul(z0, z0), -nd_mul(tan2, nd_add(nd_mul(x0, x0), nd_mul(y0, y0))));
+  const double delta = nd_add(nd_mul(b_theta, b_theta), -nd_mul(a_theta, c_theta));
+  if (delta < 0.0) return 1.0e30;
+  const double rac = sqrt(delta);
+  const double t_1 = nd_mul(-b_theta - rac, a_theta_m1);
+  const double t_2 = nd_mul(-b_theta + rac, a_theta_m1);
+  if (t_1 <= precision) return (t_2 <= precision) ? 1.0e30 : t_2;
+  if (t_2 <= precision) return t_1;
+  return t_1 < t_2 ? t_1 : t_2;
+}
+
+// cross_spherical_cell (:182-446)
+template <bool L3D>
+__device__ inline void cross_cell_sph(const Lds& T, const DevModel& M, double x0, double y0, double z0, double u,
+                                      double v, double w, int ri0, int tj0, int k0, double& x1, double& y1,
+                                      double& z1, int& ri1, int& tj1, int& k1, double& l) {
+  const double cm = 1.0 - PREC_GRILLE_SPH, cp = 1.0 + PREC_GRILLE_SPH;
+  const double r0_2 = nd_add(nd_add(nd_mul(x0, x0), nd_mul(y0, y0)), nd_mul(z0, z0));
+  const double b = nd_add(nd_add(nd_mul(x0, u), nd_mul(y0, v)), nd_mul(z0, w));
+  double s, t, t_phi;
+  int delta_rad, delta_theta = 0, delta_phi = 0;
+  if (ri0 == 0) {  // inside the inner boundary: the one positive root with rmin
+    const double c = nd_add(r0_2, -nd_mul(T.r_lim_2[0], cp));
+    const double rac = sqrt(nd_add(nd_mul(b, b), -c));
+    s = nd_mul(-b + rac, cp);
+    t = HUGE_REAL;
+    t_phi = HUGE_REAL;
+    delta_rad = 1;
+  } else {
+    double delta;
+    if (b < 0.0) {
+      const double c = nd_add(r0_2, -nd_mul(T.r_lim_2[ri0 - 1], cm));
+      delta = nd_add(nd_mul(b, b), -c);
+      if (delta < 0.0) {
+        const double c2 = nd_add(r0_2, -nd_mul(T.r_lim_2[ri0], cp));
+        delta = fmax(nd_add(nd_mul(b, b), -c2), 0.0);
+        delta_rad = 1;
+      } else {
+        delta_rad = -1;
+      }
+    } else {
+      const double c = nd_add(r0_2, -nd_mul(T.r_lim_2[ri0], cp));
+      delta = fmax(nd_add(nd_mul(b, b), -c), 0.0);
+      delta_rad = 1;
+    }
+    const double rac = sqrt(delta);
+    s = -b - rac;
+    if (s < 0.0) s = -b + rac;
+    else if (s == 0.0) s = GRID_PREC;
+    const int aj = tj0 < 0 ? -tj0 : tj0;
+    const double sg = (z0 >= 0.0) ? 1.0 : -1.0;
+    const double t1 = sph_theta_root(x0, y0, z0, u, v, w, sg * nd_mul(M.tan_theta_lim[aj], cp));
+    const double t2 = sph_theta_root(x0, y0, z0, u, v, w, sg * nd_mul(M.tan_theta_lim[aj - 1], cm));
+    if (t1 < t2) {
+      t = t1;
+      delta_theta = (aj == M.nz) ? 0 : 1;
+    } else {
+      t = t2;
+      delta_theta = (aj == 1) ? 0 : -1;
+    }
+    t_phi = HUGE_REAL;
+    if (L3D) {
+      const double r1e30 = (double)1.0e30f;
+      const double dp = nd_add(nd_mul(x0, v), -nd_mul(y0, u));
+      if (fabs(dp) < (double)1.0e-10f) {
+        t_phi = r1e30;
+      } else {
+        int kk = (dp > 0.0) ? k0 : k0 - 1;
+        if (kk == 0) kk = M.n_az;
+        delta_phi = (dp > 0.0) ? 1 : -1;
+        const double tan_lim = T.tan_phi[kk - 1];
+        if (tan_lim > 1.0e299) {
+          t_phi = -x0 / u;
+        } else {
+          const double den = nd_add(v, -nd_mul(u, tan_lim));
+          if (fabs(den) > (double)1.0e-6f) t_phi = -nd_add(y0, -nd_mul(x0, tan_lim)) / den;
+          else { t_phi = r1e30; delta_phi = 0; }
+        }
+        if (t_phi < 0.0) { t_phi = r1e30; delta_phi = 0; }
+      }
+    }
+  }
+  if ((s < t) && (s < t_phi)) {
+    l = s;
+    x1 = nd_add(x0, nd_mul(s, u)); y1 = nd_add(y0, nd_mul(s, v)); z1 = nd_add(z0, nd_mul(s, w));
+    ri1 = ri0 + delta_rad;
+    tj1 = tj0; k1 = k0;
+    if (ri0 == 0) sph_theta_phi<L3D>(M, x1, y1, z1, tj1, k1);
+    if (ri1 == 0) { tj1 = 1; k1 = 1; }
+  } else if (t < t_phi) {
+    l = t;
+    x1 = nd_add(x0, nd_mul(t, u)); y1 = nd_add(y0, nd_mul(t, v)); z1 = nd_add(z0, nd_mul(t, w));
+    ri1 = ri0;
+    tj1 = (tj0 < 0 ? -tj0 : tj0) + delta_theta;
+    if (L3D && z1 < 0.0) tj1 = -tj1;
+    k1 = k0;
+  } else {
+    l = t_phi;
+    const double dv = nd_mul(cp, t_phi);
+    x1 = nd_add(x0, nd_mul(dv, u)); y1 = nd_add(y0, nd_mul(dv, v)); z1 = nd_add(z0, nd_mul(dv, w));
+    ri1 = ri0; tj1 = tj0;
+    int kk = k0 + delta_phi;
+    if (kk == 0) kk = M.n_az;
+    if (kk == M.n_az + 1) kk = 1;
+    k1 = kk;
+  }
+  if (z1 == 0.0) z1 = GRID_PREC;
+}
+
+// move_to_grid_sph (:562-615)
+template <bool L3D>
+__device__ inline bool move_to_grid_sph(const Lds& T, const DevModel& M, double& x, double& y, double& z, double u,
+                                        double v, double w, int& ri, int& tj, int& k) {
+  const double correct_moins = 1.0 - 1.0e-10;
+  const double x0 = x, y0 = y, z0 = z;
+  const double r0_2 = nd_add(nd_add(nd_mul(x0, x0), nd_mul(y0, y0)), nd_mul(z0, z0));
+  const double b = nd_add(nd_add(nd_mul(x0, u), nd_mul(y0, v)), nd_mul(z0, w));
+  const double c = nd_add(r0_2, -nd_mul(T.r_lim_2[M.n_rad], correct_moins));
+  const double delta = nd_add(nd_mul(b, b), -c);
+  if (delta < 0.0) return false;
+  const double s1 = -b - sqrt(delta);
+  x = nd_add(x0, nd_mul(s1, u)); y = nd_add(y0, nd_mul(s1, v)); z = nd_add(z0, nd_mul(s1, w));
+  index_cell_sph<L3D>(T, M, x, y, z, ri, tj, k);
+  return true;
+}
+
+// pos_em_cell_sph (:619-699); in 3D every packet starts in the upper hemisphere, as in the reference (:647)
+template <bool L3D>
+__device__ inline void pos_em_cell_sph(const DevModel& M, int ri, int tj, int k, float rand1, float rand2, float rand3,
+                                       double& x, double& y, double& z) {
+  const double r = pow(M.r_lim_3[ri - 1] + (double)rand1 * (M.r_lim_3[ri] - M.r_lim_3[ri - 1]), 1.0 / 3.0);
+  double theta;
+  if (L3D) {
+    const int aj = tj < 0 ? -tj : tj;
+    theta = M.theta_lim[aj - 1] + (double)rand2 * (M.theta_lim[aj] - M.theta_lim[aj - 1]);
+  } else {
+    if ((double)rand2 > 0.5) theta = M.theta_lim[tj - 1] + (2.0 * ((double)rand2 - 0.5)) * (M.theta_lim[tj] - M.theta_lim[tj - 1]);
+    else theta = -(M.theta_lim[tj - 1] + (2.0 * (double)rand2) * (M.theta_lim[tj] - M.theta_lim[tj - 1]));
+  }
+  const double phi = 2.0 * PI * ((double)(float)k - 1.0 + (double)rand3) / (double)(float)M.n_az;
+  double st, ct, sp, cph;
+  sincos(theta, &st, &ct);
+  sincos(phi, &sp, &cph);
+  z = r * st;
+  const double rc = r * ct;
+  x = rc * cph;
+  y = rc * sp;
+}
+
 // cdapres (utils.f90:1636-1690)
 __device__ inline void cdapres(double cospsi, double phi, double u0, double v0, double w0, double& u1,
                                double& v1, double& w1) {
@@ -1092,6 +1304,32 @@ struct CylEmitOps {
   }
 };
 
+// the spherical grid's operators for emit_packet
+template <bool L3D>
+struct SphEmitOps {
+  const Lds& T;
+  const DevModel& M;
+  int &ri, &zj, &k;
+  __device__ inline void star_cell(int, double x, double y, double z) { index_cell_sph<L3D>(T, M, x, y, z, ri, zj, k); }
+  __device__ inline bool enter_grid(double& x, double& y, double& z, double u, double v, double w) {
+    return move_to_grid_sph<L3D>(T, M, x, y, z, u, v, w, ri, zj, k);
+  }
+  __device__ inline void disk_cell(int icell, float r1, float r2, float r3, double& x, double& y, double& z) {
+    int q = icell - 1;  // inverse of the closed-form mapping
+    ri = q % M.n_rad + 1;
+    q /= M.n_rad;
+    if (L3D) {
+      const int jj = q % (2 * M.nz);
+      k = q / (2 * M.nz) + 1;
+      zj = jj < M.nz ? jj - M.nz : jj - M.nz + 1;
+    } else {
+      zj = q + 1;
+      k = 1;
+    }
+    pos_em_cell_sph<L3D>(M, ri, zj, k, r1, r2, r3, x, y, z);
+  }
+};
+
 // ---------------------------------------------------------------------------
 // The thermal packet kernel
 // ---------------------------------------------------------------------------
@@ -1101,7 +1339,8 @@ struct CylEmitOps {
 // every A.flush_every outer iterations, without a workgroup barrier.  Otherwise deposits go straight to HBM
 // (global_atomic_add_f64), the only option for 3D grids (5.76 MB at 720 000
 // cells).
-template <bool L3D, bool POLA, bool DARK, bool LDSE>
+// SPH: the grid operators of spherical_grid.f90 instead of cylindrical_grid.f90 (same cell identity and mapping).
+template <bool L3D, bool POLA, bool DARK, bool LDSE, bool SPH = false>
 __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A, double* lds_base) {
   double* const E_lds = lds_base;  // [n_cells] when LDSE
   const Lds T = lds_carve(lds_base + (LDSE ? M.n_cells : 0), M);
@@ -1188,10 +1427,18 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
             bool lintersect;
             flag_scatt = false;
             S[0] = 1.0; S[1] = 0.0; S[2] = 0.0; S[3] = 0.0;
-            CylEmitOps<L3D> ops{T, M, ri, zj, k};
-            const int rc = emit_packet(M, f, lambda, T.fstar[lambda - 1], M.frac_E_disk[lambda - 1],
-                                       M.prob_E_cell ? M.prob_E_cell + (size_t)(M.n_cells + 1) * (lambda - 1) : nullptr,
-                                       ops, x, y, z, u, v, w, flag_star, flag_ism, lintersect);
+            int rc;
+            if (SPH) {
+              SphEmitOps<L3D> ops{T, M, ri, zj, k};
+              rc = emit_packet(M, f, lambda, T.fstar[lambda - 1], M.frac_E_disk[lambda - 1],
+                               M.prob_E_cell ? M.prob_E_cell + (size_t)(M.n_cells + 1) * (lambda - 1) : nullptr,
+                               ops, x, y, z, u, v, w, flag_star, flag_ism, lintersect);
+            } else {
+              CylEmitOps<L3D> ops{T, M, ri, zj, k};
+              rc = emit_packet(M, f, lambda, T.fstar[lambda - 1], M.frac_E_disk[lambda - 1],
+                               M.prob_E_cell ? M.prob_E_cell + (size_t)(M.n_cells + 1) * (lambda - 1) : nullptr,
+                               ops, x, y, z, u, v, w, flag_star, flag_ism, lintersect);
+            }
             if (rc) {  // a source the tables do not provide
               *A.err = rc;
               st = S_DONE;
@@ -1269,8 +1516,8 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
 #endif
       if (st == S_FLIGHT) {
         const int azj = zj < 0 ? -zj : zj;
-        // test_exit_grid_cyl (cylindrical_grid.f90:680-704) in closed form
-        const bool out = (ri == n_rad + 1) || ((azj == nz + 1) && (fabs(z) > M.zmaxmax));
+        // test_exit_grid_cyl (cylindrical_grid.f90:680-704) / test_exit_grid_sph (spherical_grid.f90:24-44) in closed form
+        const bool out = (ri == n_rad + 1) || (!SPH && (azj == nz + 1) && (fabs(z) > M.zmaxmax));
         bool killed = false;
         if (star_key >= 0) {
           const int key = ri + (n_rad + 2) * ((zj + nz + 1) + (2 * nz + 3) * (k - 1));
@@ -1303,7 +1550,8 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
           if (!mirrored) {
             double x1, y1, z1, l;
             int ri1, zj1, k1;
-            MCGPU_CROSS<L3D>(T, M, x, y, z, u, v, w, inv_a, inv_w, ri, zj, k, x1, y1, z1, ri1, zj1, k1, l);
+            if (SPH) cross_cell_sph<L3D>(T, M, x, y, z, u, v, w, ri, zj, k, x1, y1, z1, ri1, zj1, k1, l);
+            else MCGPU_CROSS<L3D>(T, M, x, y, z, u, v, w, inv_a, inv_w, ri, zj, k, x1, y1, z1, ri1, zj1, k1, l);
             c_cross++;
             const double tau = l * opacity;
             if (tau > extr) {
@@ -1312,7 +1560,7 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
               x = x + lc * u;
               y = y + lc * v;
               z = z + lc * w;
-              if (L3D) index_cell<L3D>(T, M, x, y, z, ri, zj, k);  // optical_depth.f90:162-165
+              if (L3D && !SPH) index_cell<L3D>(T, M, x, y, z, ri, zj, k);  // optical_depth.f90:162-165 (lcylindrical only)
               st = S_INTERACT;
             } else {
               extr = extr - tau;
@@ -1380,6 +1628,13 @@ __global__ void __launch_bounds__(256) k_thermal(const DevModel M, const RunArgs
   thermal_body<L3D, POLA, DARK, false>(M, A, lds_raw);
 }
 
+// the spherical grid (spherical_grid.f90): the same packet loop with that grid's operators; no dark zone
+template <bool L3D, bool POLA, bool LDSE>
+__global__ void __launch_bounds__(LDSE ? MCGPU_LDS_BLOCK : 256) k_thermal_sph(const DevModel M, const RunArgs A) {
+  extern __shared__ double lds_raw[];
+  thermal_body<L3D, POLA, false, LDSE, true>(M, A, lds_raw);
+}
+
 // LDS-deposit variant: one MCGPU_LDS_BLOCK-thread workgroup per CU shares one private grid.
 template <bool L3D, bool POLA, bool DARK>
 __global__ void __launch_bounds__(MCGPU_LDS_BLOCK) k_thermal_lds(const DevModel M, const RunArgs A) {
@@ -1410,7 +1665,7 @@ __global__ void k_temp_finale(const DevModel M, const double* E_abs, const float
 // ---------------------------------------------------------------------------
 // Probes for the parity tests
 // ---------------------------------------------------------------------------
-template <bool L3D>
+template <bool L3D, bool SPH = false>
 __global__ void k_probe_cross(const DevModel M, int n, const double* x0, const double* y0,
                               const double* z0, const double* u, const double* v, const double* w,
                               const int* cmi, const int* cmj, const int* cmk, const int* cell, double* x1,
@@ -1425,13 +1680,15 @@ __global__ void k_probe_cross(const DevModel M, int n, const double* x0, const d
     const double inv_w = (fabs(w[i]) > TINY_REAL) ? 1.0 / w[i] : copysign(HUGE_DP, w[i]);
     const int c = cell[i] - 1;
     int ri1, zj1, k1;
-    MCGPU_CROSS<L3D>(T, M, x0[i], y0[i], z0[i], u[i], v[i], w[i], inv_a, inv_w, cmi[c], cmj[c], cmk[c],
-                    x1[i], y1[i], z1[i], ri1, zj1, k1, l[i]);
+    if (SPH) cross_cell_sph<L3D>(T, M, x0[i], y0[i], z0[i], u[i], v[i], w[i], cmi[c], cmj[c], cmk[c], x1[i], y1[i], z1[i],
+                                 ri1, zj1, k1, l[i]);
+    else MCGPU_CROSS<L3D>(T, M, x0[i], y0[i], z0[i], u[i], v[i], w[i], inv_a, inv_w, cmi[c], cmj[c], cmk[c],
+                          x1[i], y1[i], z1[i], ri1, zj1, k1, l[i]);
     next_cell[i] = icell_of(M.n_rad, M.nz, M.n_az, M.l3D, ri1, zj1, k1);
   }
 }
 
-template <bool L3D>
+template <bool L3D, bool SPH = false>
 __global__ void k_probe_index(const DevModel M, int n, const double* x, const double* y, const double* z,
                               int* icell) {
   extern __shared__ double lds_raw[];
@@ -1440,7 +1697,8 @@ __global__ void k_probe_index(const DevModel M, int n, const double* x, const do
   __syncthreads();
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     int ri, zj, k;
-    index_cell<L3D>(T, M, x[i], y[i], z[i], ri, zj, k);
+    if (SPH) index_cell_sph<L3D>(T, M, x[i], y[i], z[i], ri, zj, k);
+    else index_cell<L3D>(T, M, x[i], y[i], z[i], ri, zj, k);
     icell[i] = icell_of(M.n_rad, M.nz, M.n_az, M.l3D, ri, zj, k);
   }
 }

@@ -237,6 +237,62 @@ extern "C" int mcgpu_set_grid_cyl(mcgpu_ctx* ctx, int n_rad, int nz, int n_az, i
   return MCGPU_OK;
 }
 
+// The spherical grid (grid_type = 2): the arrays define_cylindrical_grid fills in its spherical branch
+// (cylindrical_grid.f90:496-580) and the cell mapping both structured grids share.
+extern "C" int mcgpu_set_grid_sph(mcgpu_ctx* ctx, int n_rad, int nz, int n_az, int l3D, const double* r_lim_2,
+                                  const double* r_lim_3, const double* tan_theta_lim, const double* theta_lim,
+                                  const double* tan_phi_lim, double Rmax2, const double* volume, const int* cell_map,
+                                  const int* cell_map_i, const int* cell_map_j, const int* cell_map_k,
+                                  const int* lexit_cell) {
+  if (!ctx || n_rad < 1 || nz < 1 || n_az < 1 || !r_lim_2 || !r_lim_3 || !tan_theta_lim || !theta_lim || !tan_phi_lim ||
+      !volume || !cell_map || !cell_map_i || !cell_map_j || !cell_map_k || !lexit_cell)
+    return fail(ctx, MCGPU_ERR_ARG, "mcgpu_set_grid_sph: bad argument");
+  if (!l3D && n_az != 1) return fail(ctx, MCGPU_ERR_ARG, "2D grid needs n_az = 1");
+  if (ctx->have_grid) return fail(ctx, MCGPU_ERR_STATE, "the grid of a context is set once");
+  HIPCHK(hipSetDevice(ctx->device));
+  const int n_cells = l3D ? 2 * n_rad * nz * n_az : n_rad * nz;
+  const int jlo = l3D ? -nz - 1 : 0;
+  const int jn = nz + 1 - jlo + 1;
+  const int ntot2 = l3D ? (n_rad + 2) * (2 * nz + 2) * n_az : (n_rad + 2) * (nz + 2) * n_az;
+  for (int k = 1; k <= n_az; ++k)   // the closed-form mapping of build_cylindrical_cell_mapping, as for the cylindrical grid
+    for (int j = jlo; j <= nz + 1; ++j) {
+      if (l3D && j == 0) continue;
+      for (int i = 0; i <= n_rad + 1; ++i) {
+        const int ic = cell_map[i + (n_rad + 2) * ((j - jlo) + jn * (k - 1))];
+        if (ic != icell_of(n_rad, nz, n_az, l3D, i, j, k))
+          return fail(ctx, MCGPU_ERR_UNSUPPORTED, "cell_map differs from build_cylindrical_cell_mapping order");
+        if (ic < 1 || ic > ntot2 || cell_map_i[ic - 1] != i || cell_map_j[ic - 1] != j || cell_map_k[ic - 1] != k)
+          return fail(ctx, MCGPU_ERR_UNSUPPORTED, "cell_map_i/j/k inconsistent with cell_map");
+        int le = 0;
+        const int aj = j < 0 ? -j : j;
+        if (ic > n_cells) { if (i == n_rad + 1) le = 1; else if (aj == nz + 1) le = 2; }
+        if (lexit_cell[ic - 1] != le) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "lexit_cell differs from the reference rule");
+      }
+    }
+  for (int j = 1; j <= nz; ++j)
+    if (!(tan_theta_lim[j] > tan_theta_lim[j - 1])) return fail(ctx, MCGPU_ERR_ARG, "tan_theta_lim must increase");
+  DevModel& M = ctx->M;
+  M.n_rad = n_rad; M.nz = nz; M.n_az = n_az; M.l3D = l3D ? 1 : 0; M.n_cells = n_cells;
+  M.zmaxmax = 0.0; M.Rmax2 = Rmax2; M.grid_sph = 1;
+  std::vector<double> ones(n_rad, 1.0);   // (the cylindrical vectors the shared LDS carve stages; unused by this grid)
+  int rc;
+  if ((rc = upload(ctx, r_lim_2, (size_t)n_rad + 1, &M.r_lim_2))) return rc;
+  if ((rc = upload(ctx, ones.data(), (size_t)n_rad, &M.zmax))) return rc;
+  if ((rc = upload(ctx, ones.data(), (size_t)n_rad, &M.ch))) return rc;
+  if ((rc = upload(ctx, tan_phi_lim, (size_t)n_az, &M.tan_phi_lim))) return rc;
+  if ((rc = upload(ctx, volume, (size_t)n_cells, &M.volume))) return rc;
+  if ((rc = upload(ctx, r_lim_3, (size_t)n_rad + 1, &M.r_lim_3))) return rc;
+  if ((rc = upload(ctx, tan_theta_lim, (size_t)nz + 1, &M.tan_theta_lim))) return rc;
+  if ((rc = upload(ctx, theta_lim, (size_t)nz + 1, &M.theta_lim))) return rc;
+  const int *a, *b, *c;
+  if ((rc = upload(ctx, cell_map_i, (size_t)ntot2, &a))) return rc;
+  if ((rc = upload(ctx, cell_map_j, (size_t)ntot2, &b))) return rc;
+  if ((rc = upload(ctx, cell_map_k, (size_t)ntot2, &c))) return rc;
+  ctx->d_cmi = (int*)a; ctx->d_cmj = (int*)b; ctx->d_cmk = (int*)c;
+  ctx->have_grid = true;
+  return MCGPU_OK;
+}
+
 // The arrays Voronoi_tesselation hands to the packet loop (Voronoi.f90:23-67, 385-640).
 extern "C" int mcgpu_set_grid_voronoi(mcgpu_ctx* ctx, int n_cells, const float* voronoi_xyz,
                                       const double* xyz_dp, const double* h, const int* first_neighbour,
@@ -390,6 +446,7 @@ extern "C" int mcgpu_set_opacity(mcgpu_ctx* ctx, int n_lambda, const double* kap
     for (int i = 0; i < M.n_cells; ++i) any |= (l_dark_zone[i] != 0);
     if (any && ctx->voro)  // the reference never builds a dark zone there (dust_transfer.f90:290-293)
       return fail(ctx, MCGPU_ERR_UNSUPPORTED, "no dark zone on a Voronoi grid");
+    if (any && M.grid_sph) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "dark zones on a spherical grid are not supported yet");
     if (any && (rc = upload(ctx, l_dark_zone, (size_t)M.n_cells, &M.dark))) return rc;
   }
   if (ctx->voro) {  // the cell records carry the opacity factor
@@ -548,6 +605,18 @@ static int launch_mega(mcgpu_ctx* ctx, const RunArgs& A, bool use_lds, int grid_
   // tables.  MCGPU_ROLES: -1 = the single-role kernel (thermal_body), 0..7 = that
   // many fixed flyer waves, 100+f = every wave picks its role per round (flyer when f lanes can fly), 200 = per
   // round, the role in which more of its lanes have work (default).
+  if (M.grid_sph) {  // the spherical grid runs the single-role kernel with its own grid operators
+    const size_t lds_k2 = lds_k;
+    const void* fn;
+    if (l3d) fn = pola ? (use_lds ? (const void*)k_thermal_sph<true, true, true> : (const void*)k_thermal_sph<true, true, false>)
+                       : (use_lds ? (const void*)k_thermal_sph<true, false, true> : (const void*)k_thermal_sph<true, false, false>);
+    else fn = pola ? (use_lds ? (const void*)k_thermal_sph<false, true, true> : (const void*)k_thermal_sph<false, true, false>)
+                   : (use_lds ? (const void*)k_thermal_sph<false, false, true> : (const void*)k_thermal_sph<false, false, false>);
+    HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k2));
+    void* args[] = {(void*)&M, (void*)&A};
+    HIPCHK(hipLaunchKernel(fn, dim3(blocks), dim3(threads), args, lds_k2, ctx->stream));
+    return MCGPU_OK;
+  }
   // Waves with roles and LDS packet records (mc_roles.hip.h): the default wherever enough records fit next to the
   // tables; otherwise (or with option "schedule" = 1) the single-role kernel below.
   {
@@ -892,6 +961,7 @@ extern "C" int mcgpu_run_mono(mcgpu_ctx* ctx, const mcgpu_mono_opts* o, double f
       o->first_chunk < 0 || (long long)o->first_chunk + o->n_chunks > (1 << 23))
     return fail(ctx, MCGPU_ERR_ARG, "mcgpu_run_mono: bad option");
   if (o->rt1 && !ctx->have_rt1) return fail(ctx, MCGPU_ERR_STATE, "rt1 deposits need mcgpu_set_rt1");
+  if (M.grid_sph) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "SED mode on a spherical grid is not supported yet");
   const int n_pos = ctx->have_rt1 ? ctx->n_lambda_pos : M.n_lambda;
   if (o->p_lambda < 1 || o->p_lambda > n_pos || o->p_lambda > M.n_lambda) return fail(ctx, MCGPU_ERR_ARG, "p_lambda out of range");
   if (frac_E_stars < 1.0 && frac_E_disk > frac_E_stars && !prob_E_cell)
@@ -1217,7 +1287,7 @@ static int rt1_prepare(mcgpu_ctx* ctx, const mcgpu_rt_opts* o, const float* tab_
                        const char* who) {
   int rc = ready(ctx);
   if (rc) return rc;
-  if (ctx->voro) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "RT1 ray tracing: cylindrical grids only");
+  if (ctx->voro || ctx->M.grid_sph) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "RT1 ray tracing: cylindrical grids only");
   if (!o || !tab_RT_az || !Tdust) return fail(ctx, MCGPU_ERR_ARG, "RT1 ray tracing: null argument");
   if (!ctx->have_rt1 || !ctx->d_xI)
     return fail(ctx, MCGPU_ERR_STATE, "RT1 ray tracing needs the xI_scatt of mcgpu_run_mono(rt1=1) or mcgpu_set_xI");
@@ -1335,17 +1405,15 @@ extern "C" int mcgpu_probe_cross_cell(mcgpu_ctx* ctx, int n, const double* x0, c
   for (int q = 0; q < 4; ++q) HIPCHK(out[q].alloc(n));
   HIPCHK(dc.alloc(n)); HIPCHK(dc.put(cell, n)); HIPCHK(dn.alloc(n));
   const size_t lds = lds_bytes(M);
-  if (M.l3D) {
-    hipFuncSetAttribute((const void*)k_probe_cross<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_probe_cross<true>, dim3(64), dim3(256), lds, ctx->stream, M, n, in[0].p, in[1].p, in[2].p,
-                       in[3].p, in[4].p, in[5].p, ctx->d_cmi, ctx->d_cmj, ctx->d_cmk, dc.p, out[0].p, out[1].p,
-                       out[2].p, dn.p, out[3].p);
-  } else {
-    hipFuncSetAttribute((const void*)k_probe_cross<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_probe_cross<false>, dim3(64), dim3(256), lds, ctx->stream, M, n, in[0].p, in[1].p, in[2].p,
-                       in[3].p, in[4].p, in[5].p, ctx->d_cmi, ctx->d_cmj, ctx->d_cmk, dc.p, out[0].p, out[1].p,
-                       out[2].p, dn.p, out[3].p);
-  }
+#define PROBE_CROSS(a, b) do {                                                                                       \
+    hipFuncSetAttribute((const void*)k_probe_cross<a, b>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
+    hipLaunchKernelGGL((k_probe_cross<a, b>), dim3(64), dim3(256), lds, ctx->stream, M, n, in[0].p, in[1].p, in[2].p,  \
+                       in[3].p, in[4].p, in[5].p, ctx->d_cmi, ctx->d_cmj, ctx->d_cmk, dc.p, out[0].p, out[1].p,       \
+                       out[2].p, dn.p, out[3].p);                                                                     \
+  } while (0)
+  if (M.grid_sph) { if (M.l3D) PROBE_CROSS(true, true); else PROBE_CROSS(false, true); }
+  else { if (M.l3D) PROBE_CROSS(true, false); else PROBE_CROSS(false, false); }
+#undef PROBE_CROSS
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(ctx->stream));
   HIPCHK(out[0].get(x1, n)); HIPCHK(out[1].get(y1, n)); HIPCHK(out[2].get(z1, n)); HIPCHK(out[3].get(l, n));
@@ -1394,13 +1462,13 @@ extern "C" int mcgpu_probe_index_cell(mcgpu_ctx* ctx, int n, const double* x, co
   for (int q = 0; q < 3; ++q) { HIPCHK(in[q].alloc(n)); HIPCHK(in[q].put(hin[q], n)); }
   HIPCHK(dn.alloc(n));
   const size_t lds = lds_bytes(M);
-  if (M.l3D) {
-    hipFuncSetAttribute((const void*)k_probe_index<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_probe_index<true>, dim3(64), dim3(256), lds, ctx->stream, M, n, in[0].p, in[1].p, in[2].p, dn.p);
-  } else {
-    hipFuncSetAttribute((const void*)k_probe_index<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_probe_index<false>, dim3(64), dim3(256), lds, ctx->stream, M, n, in[0].p, in[1].p, in[2].p, dn.p);
-  }
+#define PROBE_INDEX(a, b) do {                                                                                       \
+    hipFuncSetAttribute((const void*)k_probe_index<a, b>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
+    hipLaunchKernelGGL((k_probe_index<a, b>), dim3(64), dim3(256), lds, ctx->stream, M, n, in[0].p, in[1].p, in[2].p, dn.p); \
+  } while (0)
+  if (M.grid_sph) { if (M.l3D) PROBE_INDEX(true, true); else PROBE_INDEX(false, true); }
+  else { if (M.l3D) PROBE_INDEX(true, false); else PROBE_INDEX(false, false); }
+#undef PROBE_INDEX
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(ctx->stream));
   HIPCHK(dn.get(icell, n));

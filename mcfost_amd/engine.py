@@ -35,7 +35,7 @@ ABI_SYMBOLS = (
     "mcgpu_probe_cross_voronoi", "mcgpu_set_rt1", "mcgpu_run_mono", "mcgpu_fetch_xI",
     "mcgpu_device_xI", "mcgpu_set_ism", "mcgpu_rt1_dust_map", "mcgpu_set_xI", "mcgpu_rt1_image", "mcgpu_set_xI_precision",
     "mcgpu_get_xI_precision", "mcgpu_set_option", "mcgpu_counters_to_accum", "mcgpu_counters_from_accum",
-    "mcgpu_multi_create", "mcgpu_multi_destroy", "mcgpu_multi_size", "mcgpu_multi_ctx", "mcgpu_multi_last_error",
+    "mcgpu_set_grid_sph", "mcgpu_multi_create", "mcgpu_multi_destroy", "mcgpu_multi_size", "mcgpu_multi_ctx", "mcgpu_multi_last_error",
     "mcgpu_shard_packets", "mcgpu_multi_run_thermal",
 )
 
@@ -172,6 +172,16 @@ class Engine:
     def _upload_grid_cyl(self, m):
         g, L = m.grid, self.lib
         d, i32 = np.float64, np.int32
+        if g.get("grid_type", 1) == 2:
+            self._chk(L.mcgpu_set_grid_sph(
+                self.ctx, C.c_int(g["n_rad"]), C.c_int(g["nz"]), C.c_int(g["n_az"]), C.c_int(g["l3D"]),
+                _p(_a(g["r_lim_2"], d), C.c_double), _p(_a(g["r_lim_3"], d), C.c_double),
+                _p(_a(g["tan_theta_lim"], d), C.c_double), _p(_a(g["theta_lim"], d), C.c_double),
+                _p(_a(g["tan_phi_lim"], d), C.c_double), C.c_double(g["Rmax2"]), _p(_a(g["volume"], d), C.c_double),
+                _p(_a(g["cell_map"], i32), C.c_int), _p(_a(g["cell_map_i"], i32), C.c_int),
+                _p(_a(g["cell_map_j"], i32), C.c_int), _p(_a(g["cell_map_k"], i32), C.c_int),
+                _p(_a(g["lexit_cell"], i32), C.c_int)), "mcgpu_set_grid_sph")
+            return
         self._chk(L.mcgpu_set_grid_cyl(
             self.ctx, C.c_int(g["n_rad"]), C.c_int(g["nz"]), C.c_int(g["n_az"]), C.c_int(g["l3D"]),
             _p(_a(g["r_lim_2"], d), C.c_double), _p(_a(g["zmax"], d), C.c_double),

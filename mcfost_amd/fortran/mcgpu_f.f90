@@ -63,7 +63,7 @@ module mcgpu_f
      real(c_double) :: Rmin, Rmax
   end type mcgpu_rt_opts
 
-  public :: mcgpu_create, mcgpu_destroy, mcgpu_set_grid_cyl, mcgpu_set_grid_voronoi, mcgpu_set_midplane_snap, mcgpu_set_option, &
+  public :: mcgpu_create, mcgpu_destroy, mcgpu_set_grid_cyl, mcgpu_set_grid_sph, mcgpu_set_grid_voronoi, mcgpu_set_midplane_snap, mcgpu_set_option, &
        mcgpu_set_stars, mcgpu_set_opacity, mcgpu_set_scattering, mcgpu_set_thermal, mcgpu_set_sed_bins, &
        mcgpu_run_thermal, mcgpu_temp_finale, mcgpu_thermal_loop, mcgpu_error_message, mcgpu_set_rt1, &
        mcgpu_run_mono, mcgpu_fetch, mcgpu_fetch_xI, mcgpu_rt1_dust_map, mcgpu_set_xI, mcgpu_rt1_image, mcgpu_set_xI_precision, &
@@ -115,6 +115,19 @@ module mcgpu_f
        real(c_double), value :: cutting_distance_o_h
        integer(c_int), intent(in) :: wall_first(*), wall_cells(*)
      end function mcgpu_set_grid_voronoi
+
+     ! spherical grid (grid_type = 2): arrays of module cylindrical_grid filled by the spherical branch of
+     ! define_cylindrical_grid; replaces the operators of spherical_grid.f90 (grid.f90:345-357)
+     integer(c_int) function mcgpu_set_grid_sph(ctx, n_rad, nz, n_az, l3D, r_lim_2, r_lim_3, tan_theta_lim, theta_lim, &
+          tan_phi_lim, Rmax2, volume, cell_map, cell_map_i, cell_map_j, cell_map_k, lexit_cell) &
+          bind(C, name="mcgpu_set_grid_sph")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: n_rad, nz, n_az, l3D
+       real(c_double), intent(in) :: r_lim_2(*), r_lim_3(*), tan_theta_lim(*), theta_lim(*), tan_phi_lim(*), volume(*)
+       real(c_double), value :: Rmax2
+       integer(c_int), intent(in) :: cell_map(*), cell_map_i(*), cell_map_j(*), cell_map_k(*), lexit_cell(*)
+     end function mcgpu_set_grid_sph
 
      integer(c_int) function mcgpu_set_midplane_snap(ctx, on) bind(C, name="mcgpu_set_midplane_snap")
        import :: c_int, c_ptr

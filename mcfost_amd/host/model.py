@@ -58,6 +58,7 @@ class DiskConfig:
     n_az: int = 1
     n_rad_in: int = 20
     l3D: bool = False
+    grid_type: int = 1   # 1 = cylindrical, 2 = spherical (parameter file line "grid geometry", read_param.f90)
     # wavelengths (ref4.1.para:9)
     n_lambda: int = 50
     lambda_min: float = 0.1
@@ -209,8 +210,9 @@ def build_cell_mapping(n_rad, nz, n_az, l3D):
 # --------------------------------------------------------------------------
 # Grid (cylindrical_grid.f90:183-676), single region, log radial grid
 # --------------------------------------------------------------------------
-def define_cylindrical_grid(cfg: DiskConfig):
-    n_rad, nz, n_az = cfg.n_rad, cfg.nz, cfg.n_az
+def _radial_grid(cfg: DiskConfig):
+    """tab_r(1:n_rad+1), r_lim, r_lim_2 (cylindrical_grid.f90:256-388): the radial grid both geometries share."""
+    n_rad = cfg.n_rad
     rmin_zone = cfg.rin - 5 * cfg.edge  # read_param.f90:279
     rmax_zone = cfg.rout
     Rmin, Rmax = rmin_zone, rmax_zone
@@ -245,6 +247,109 @@ def define_cylindrical_grid(cfg: DiskConfig):
     r_lim_2[0] = Rmin ** 2
     r_lim[1:] = tab_r[2:n_rad + 2]
     r_lim_2[1:] = tab_r2[2:n_rad + 2]
+    return tab_r, tab_r2, r_lim, r_lim_2, Rmin, Rmax
+
+
+_libm = None
+
+
+def _tanf(x):
+    """Default-real tan as the Fortran runtime evaluates it (libm's tanf; numpy's vectorised float32 tan differs in the
+    last place for some arguments)."""
+    global _libm
+    if _libm is None:
+        import ctypes
+        import ctypes.util
+        _libm = ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6")
+        _libm.tanf.restype = ctypes.c_float
+        _libm.tanf.argtypes = [ctypes.c_float]
+    return float(_libm.tanf(float(x)))
+
+
+def _phi_grid(cfg: DiskConfig, pi_sp):
+    """tan_phi_lim, phi_grid (cylindrical_grid.f90:583-600), default-real arithmetic."""
+    n_az = cfg.n_az
+    tan_phi_lim = np.zeros(n_az, f64)
+    phi_c = np.zeros(n_az, f64)
+    if cfg.l3D:
+        delta_phi = f32(f32(2.0) * f32(pi_sp) / f32(n_az))  # :587 default real
+        for k in range(1, n_az + 1):
+            phi_c[k - 1] = float(f32(delta_phi * f32(f32(k) - f32(0.5))))
+            phi = f32(delta_phi * f32(k))
+            mod = float(np.mod(f32(phi - f32(0.5) * f32(pi_sp)), f32(pi_sp)))
+            if abs(mod) < 1.0e-6:
+                tan_phi_lim[k - 1] = 1.0e300
+            else:
+                tan_phi_lim[k - 1] = _tanf(phi)  # default-real tan
+    return tan_phi_lim, phi_c
+
+
+def define_spherical_grid(cfg: DiskConfig):
+    """The spherical branch of define_cylindrical_grid (cylindrical_grid.f90:496-580): the cylindrical grid's radial
+    bins taken as spherical radii, nz polar bins uniform in cos(theta) per hemisphere (theta measured from the
+    midplane), the cell mapping of build_cylindrical_cell_mapping.  Pinned bit for bit to the reference compiled in
+    oracle/_ref (tests/test_ref_geometry.py)."""
+    n_rad, nz, n_az = cfg.n_rad, cfg.nz, cfg.n_az
+    tab_r, tab_r2, r_lim, r_lim_2, Rmin, Rmax = _radial_grid(cfg)
+    tab_r3 = tab_r2 * tab_r
+    r_lim_3 = np.zeros(n_rad + 1, f64)
+    r_lim_3[0] = Rmin ** 3
+    r_lim_3[1:] = tab_r3[2:n_rad + 2]
+    w_lim = np.zeros(nz + 1, f64)
+    theta_lim = np.zeros(nz + 1, f64)
+    tan_theta_lim = np.zeros(nz + 1, f64)
+    tan_theta_lim[0] = 1.0e-10
+    w_lim[nz] = 1.0
+    theta_lim[nz] = float(f32(3.1415926535)) / 2.0   # `pi/2.` with the routine's local default-real pi (:191)
+    tan_theta_lim[nz] = 1.0e30
+    for j in range(1, nz):   # uniform in cosine (:531-539)
+        w = float(j) / float(nz)
+        c = math.sqrt(1.0 - w * w)
+        w_lim[j] = w
+        tan_theta_lim[j] = w / c
+        theta_lim[j] = math.atan(tan_theta_lim[j])
+    dcos = 1.0 / float(f32(nz))   # 1.0_dp/real(nz)
+    pi_sp = f32(3.1415926535)
+    V = np.zeros((nz, n_rad), f64)
+    rg = np.zeros((nz, n_rad), f64)
+    zg = np.zeros((nz, n_rad), f64)
+    for i in range(1, n_rad + 1):
+        rsph = math.sqrt(r_lim[i] * r_lim[i - 1])
+        for j in range(1, nz + 1):
+            w = 0.5 * (w_lim[j] + w_lim[j - 1])
+            uv = math.sqrt(1.0 - w * w)
+            rg[j - 1, i - 1] = rsph * uv
+            zg[j - 1, i - 1] = rsph * w
+        if (tab_r3[i + 1] - tab_r3[i]) > float(f32(1.0e-6)) * tab_r3[i]:
+            Vi = float(f32(f32(4.0) / f32(3.0)) * pi_sp) * (tab_r3[i + 1] - tab_r3[i])   # 4.0/3.0*pi in default real
+        else:
+            Vi = float(f32(4.0) * pi_sp) * rsph ** 2 * (tab_r[i + 1] - tab_r[i])
+        V[:, i - 1] = Vi * dcos
+    tan_phi_lim, phi_c = _phi_grid(cfg, float(pi_sp))
+    if cfg.l3D:
+        V = V * 0.5 / float(f32(n_az))
+    n_cells, ntot2, jlo, jn = cell_mapping_sizes(n_rad, nz, n_az, cfg.l3D)
+    cm, cmi, cmj, cmk, lexit = build_cell_mapping(n_rad, nz, n_az, cfg.l3D)
+    ii = cmi[:n_cells] - 1
+    jj = np.abs(cmj[:n_cells]) - 1
+    return dict(
+        grid_type=2, n_rad=n_rad, nz=nz, n_az=n_az, l3D=int(cfg.l3D), n_cells=n_cells, ntot2=ntot2,
+        jdim_lo=jlo, jdim_n=jn, r_lim=r_lim, r_lim_2=r_lim_2, r_lim_3=r_lim_3, w_lim=w_lim, theta_lim=theta_lim,
+        tan_theta_lim=tan_theta_lim, tan_phi_lim=tan_phi_lim,
+        # (the cylindrical arrays the structures carry along; unused by the spherical operators)
+        zmax=np.ones(n_rad, f64), z_lim=np.zeros(n_rad * (nz + 2), f64), zmaxmax=0.0,
+        Rmax2=Rmax * Rmax, cell_map=cm, cell_map_i=cmi, cell_map_j=cmj, cell_map_k=cmk, lexit_cell=lexit,
+        volume=V[jj, ii].copy(), r_grid=rg[jj, ii].copy(), z_grid=zg[jj, ii] * np.sign(cmj[:n_cells]),
+        phi_grid=phi_c[cmk[:n_cells] - 1].copy(), Rmin=Rmin, Rmax=Rmax,
+    )
+
+
+def define_cylindrical_grid(cfg: DiskConfig):
+    if int(getattr(cfg, "grid_type", 1)) == 2:
+        return define_spherical_grid(cfg)
+    n_rad, nz, n_az = cfg.n_rad, cfg.nz, cfg.n_az
+    tab_r, tab_r2, r_lim, r_lim_2, Rmin, Rmax = _radial_grid(cfg)
+    rmin_zone, rmax_zone = Rmin, Rmax
 
     zmax = np.zeros(n_rad, f64)
     rc = np.zeros(n_rad, f64)
@@ -274,18 +379,8 @@ def define_cylindrical_grid(cfg: DiskConfig):
         V[:, i - 1] = dr2 * cell_height[i - 1]
     z_c = z_lim[:nz, :] + 0.5 * cell_height[None, :]
 
-    tan_phi_lim = np.zeros(n_az, f64)
-    phi_c = np.zeros(n_az, f64)
+    tan_phi_lim, phi_c = _phi_grid(cfg, pi_sp)
     if cfg.l3D:
-        delta_phi = f32(f32(2.0) * f32(pi_sp) / f32(n_az))  # :587 default real
-        for k in range(1, n_az + 1):
-            phi_c[k - 1] = float(f32(delta_phi * f32(f32(k) - f32(0.5))))
-            phi = f32(delta_phi * f32(k))
-            mod = float(np.mod(f32(phi - f32(0.5) * f32(pi_sp)), f32(pi_sp)))
-            if abs(mod) < 1.0e-6:
-                tan_phi_lim[k - 1] = 1.0e300
-            else:
-                tan_phi_lim[k - 1] = float(np.tan(phi))  # default-real tan
         V = V * 0.5 / float(f32(n_az))
 
     n_cells, ntot2, jlo, jn = cell_mapping_sizes(n_rad, nz, n_az, cfg.l3D)
@@ -622,7 +717,7 @@ def repartition_energie(m: "Model", Tdust):
 def star_cell(grid, x, y, z):
     """index_cell_cyl for a point inside the inner hole or in the grid
     (stars.f90:789-808); only the inner-hole case is needed by the configs."""
-    r2 = x * x + y * y
+    r2 = x * x + y * y + (z * z if grid.get("grid_type", 1) == 2 else 0.0)
     if r2 < grid["r_lim_2"][0]:
         i, j, k = 0, 1, 1
         idx = i + (grid["n_rad"] + 2) * ((j - grid["jdim_lo"]) + grid["jdim_n"] * (k - 1))

@@ -89,6 +89,7 @@ class _Model(C.Structure):
         ("v_first", _ip), ("v_last", _ip), ("v_neigh", _ip), ("v_was_cut", _up),
         ("v_is_star_neighbour", _up), ("v_walls", _fp), ("v_cut_o_h", C.c_double),
         ("v_wall_first", _ip), ("v_wall_cells", _ip),
+        ("tan_theta_lim", _dp), ("theta_lim", _dp), ("r_lim_3", _dp),
         ("R_ISM", C.c_double), ("centre_ISM", C.c_double * 3),
         ("RT_n_incl", C.c_int), ("RT_n_az", C.c_int), ("tab_u_rt", _dp), ("tab_v_rt", _dp),
         ("tab_w_rt", _dp), ("n_az_rt", C.c_int), ("n_theta_rt", C.c_int), ("N_type_flux", C.c_int),
@@ -167,6 +168,9 @@ class Oracle:
             s.Rmax2 = float(g["Rmax2"])
             for k in ("cell_map", "cell_map_i", "cell_map_j", "cell_map_k", "lexit_cell"):
                 setattr(s, k, self._hold(_a(g[k], np.int32), C.c_int))
+            if s.grid_type == 2:  # spherical grid: cylindrical_grid.f90:28-31
+                for k in ("tan_theta_lim", "theta_lim", "r_lim_3"):
+                    setattr(s, k, self._hold(_a(g[k], np.float64), C.c_double))
         s.volume = self._hold(_a(g["volume"], np.float64), C.c_double)
         ns = m.stars.shape[0]
         stars = (_Star * ns)()
@@ -388,7 +392,7 @@ class Oracle:
         n = len(cell)
         x1 = np.zeros(n); y1 = np.zeros(n); z1 = np.zeros(n); l = np.zeros(n)
         nxt = np.zeros(n, np.int32)
-        f = self.lib.oracle_cross_cylindrical_cell
+        f = self.lib.oracle_cross_spherical_cell if self.cm.grid_type == 2 else self.lib.oracle_cross_cylindrical_cell
         f.argtypes = [C.c_void_p] + [C.c_double] * 6 + [C.c_int, C.c_int] + [_dp] * 3 + [_ip] + [_dp] * 3
         a, b, c_, d = C.c_double(), C.c_double(), C.c_double(), C.c_double()
         lc, lv = C.c_double(), C.c_double()
@@ -403,7 +407,7 @@ class Oracle:
     def index_cell(self, x, y, z):
         n = len(x)
         out = np.zeros(n, np.int32)
-        f = self.lib.oracle_index_cell_cyl
+        f = self.lib.oracle_index_cell_sph if self.cm.grid_type == 2 else self.lib.oracle_index_cell_cyl
         f.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, _ip]
         ic = C.c_int()
         mp = C.addressof(self.cm)
@@ -413,17 +417,22 @@ class Oracle:
         return out
 
     def test_exit_grid(self, icell, x, y, z):
+        mp = C.addressof(self.cm)
+        if self.cm.grid_type == 2:
+            g = self.lib.oracle_test_exit_grid_sph
+            g.argtypes = [C.c_void_p, C.c_int]
+            g.restype = C.c_int
+            return np.array([g(mp, int(icell[i])) for i in range(len(x))], np.int32)
         f = self.lib.oracle_test_exit_grid_cyl
         f.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double]
         f.restype = C.c_int
-        mp = C.addressof(self.cm)
         return np.array([f(mp, int(icell[i]), x[i], y[i], z[i]) for i in range(len(x))], np.int32)
 
     def move_to_grid(self, x, y, z, u, v, w):
         n = len(x)
         xo, yo, zo = np.array(x, float), np.array(y, float), np.array(z, float)
         ic = np.zeros(n, np.int32); li = np.zeros(n, np.int32)
-        f = self.lib.oracle_move_to_grid_cyl
+        f = self.lib.oracle_move_to_grid_sph if self.cm.grid_type == 2 else self.lib.oracle_move_to_grid_cyl
         f.argtypes = [C.c_void_p, _dp, _dp, _dp, C.c_double, C.c_double, C.c_double, _ip, _ip]
         mp = C.addressof(self.cm)
         for i in range(n):
@@ -436,7 +445,7 @@ class Oracle:
     def pos_em_cell(self, icell, r1, r2, r3):
         n = len(icell)
         x = np.zeros(n); y = np.zeros(n); z = np.zeros(n)
-        f = self.lib.oracle_pos_em_cell_cyl
+        f = self.lib.oracle_pos_em_cell_sph if self.cm.grid_type == 2 else self.lib.oracle_pos_em_cell_cyl
         f.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, _dp, _dp, _dp]
         mp = C.addressof(self.cm)
         a, b, c_ = C.c_double(), C.c_double(), C.c_double()
@@ -506,8 +515,11 @@ class RefGeom:
 
     def setup_grid(self, cfg):
         ierr = C.c_int()
-        self.lib.ref_setup_grid.argtypes = [C.c_int] * 5 + [C.c_double] * 7 + [_ip]
-        self.lib.ref_setup_grid(cfg.n_rad, cfg.nz, cfg.n_az, int(cfg.l3D), cfg.n_rad_in, cfg.rin,
+        self.sph = int(getattr(cfg, "grid_type", 1)) == 2
+        setup = self.lib.ref_setup_grid_sph if self.sph else self.lib.ref_setup_grid
+        self._sfx = "_sph" if self.sph else ""
+        setup.argtypes = [C.c_int] * 5 + [C.c_double] * 7 + [_ip]
+        setup(cfg.n_rad, cfg.nz, cfg.n_az, int(cfg.l3D), cfg.n_rad_in, cfg.rin,
                                 cfg.edge, cfg.rout, cfg.rref, cfg.sclht, cfg.exp_beta, cfg.surf,
                                 C.byref(ierr))
         if ierr.value:
@@ -537,6 +549,10 @@ class RefGeom:
                                 ("cell_map", "cell_map_i", "cell_map_j", "cell_map_k", "lexit_cell")],
                               C.byref(rm))
         o["Rmax2"] = rm.value
+        if self.sph:
+            for k, n in (("tan_theta_lim", nz + 1), ("theta_lim", nz + 1), ("w_lim", nz + 1), ("r_lim_3", n_rad + 1)):
+                o[k] = np.zeros(n)
+            self.lib.ref_get_grid_sph(*[_p(o[k], C.c_double) for k in ("tan_theta_lim", "theta_lim", "w_lim", "r_lim_3")])
         return o
 
     def cross_cell(self, x0, y0, z0, u, v, w, cell):
@@ -545,7 +561,7 @@ class RefGeom:
         cell = _a(cell, np.int32)
         x1 = np.zeros(n); y1 = np.zeros(n); z1 = np.zeros(n); l = np.zeros(n)
         nxt = np.zeros(n, np.int32)
-        self.lib.ref_cross_cell(C.c_int(n), *[_p(q, C.c_double) for q in arrs], _p(cell, C.c_int),
+        getattr(self.lib, "ref_cross_cell" + self._sfx)(C.c_int(n), *[_p(q, C.c_double) for q in arrs], _p(cell, C.c_int),
                                 _p(x1, C.c_double), _p(y1, C.c_double), _p(z1, C.c_double),
                                 _p(nxt, C.c_int), _p(l, C.c_double))
         return x1, y1, z1, nxt, l
@@ -554,7 +570,7 @@ class RefGeom:
         n = len(x)
         arrs = [_a(q, np.float64) for q in (x, y, z)]
         ic = np.zeros(n, np.int32)
-        self.lib.ref_index_cell(C.c_int(n), *[_p(q, C.c_double) for q in arrs], _p(ic, C.c_int))
+        getattr(self.lib, "ref_index_cell" + self._sfx)(C.c_int(n), *[_p(q, C.c_double) for q in arrs], _p(ic, C.c_int))
         return ic
 
     def test_exit_grid(self, icell, x, y, z):
@@ -562,7 +578,7 @@ class RefGeom:
         ic = _a(icell, np.int32)
         arrs = [_a(q, np.float64) for q in (x, y, z)]
         out = np.zeros(n, np.int32)
-        self.lib.ref_test_exit_grid(C.c_int(n), _p(ic, C.c_int), *[_p(q, C.c_double) for q in arrs],
+        getattr(self.lib, "ref_test_exit_grid" + self._sfx)(C.c_int(n), _p(ic, C.c_int), *[_p(q, C.c_double) for q in arrs],
                                     _p(out, C.c_int))
         return out
 
@@ -571,7 +587,7 @@ class RefGeom:
         xo, yo, zo = (_a(q, np.float64).copy() for q in (x, y, z))
         d = [_a(q, np.float64) for q in (u, v, w)]
         ic = np.zeros(n, np.int32); li = np.zeros(n, np.int32)
-        self.lib.ref_move_to_grid(C.c_int(n), _p(xo, C.c_double), _p(yo, C.c_double),
+        getattr(self.lib, "ref_move_to_grid" + self._sfx)(C.c_int(n), _p(xo, C.c_double), _p(yo, C.c_double),
                                   _p(zo, C.c_double), *[_p(q, C.c_double) for q in d],
                                   _p(ic, C.c_int), _p(li, C.c_int))
         return xo, yo, zo, ic, li
@@ -581,7 +597,7 @@ class RefGeom:
         ic = _a(icell, np.int32)
         r = [_a(q, np.float32) for q in (r1, r2, r3)]
         x = np.zeros(n); y = np.zeros(n); z = np.zeros(n)
-        self.lib.ref_pos_em_cell(C.c_int(n), _p(ic, C.c_int), *[_p(q, C.c_float) for q in r],
+        getattr(self.lib, "ref_pos_em_cell" + self._sfx)(C.c_int(n), _p(ic, C.c_int), *[_p(q, C.c_float) for q in r],
                                  _p(x, C.c_double), _p(y, C.c_double), _p(z, C.c_double))
         return x, y, z
 

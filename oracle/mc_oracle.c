@@ -12,6 +12,8 @@
 
 #include <float.h>
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
@@ -733,9 +735,270 @@ void oracle_move_to_grid_voronoi(const oracle_model *m, double *x, double *y,
   *icell = icell_min;
 }
 
+/* ------------------------------------------------------------------------ */
+/* Spherical grid (spherical_grid.f90)                                        */
+/* ------------------------------------------------------------------------ */
+static const double PREC_GRILLE_SPH = 1.0e-7; /* spherical_grid.f90:19 */
+
+/* spherical_grid.f90:24-44: only the outer radius is an exit */
+int oracle_test_exit_grid_sph(const oracle_model *m, int icell) {
+  if (icell <= m->n_cells) return 0;
+  return m->lexit_cell[icell - 1] == 1;
+}
+
+/* indice_cellule_sph_theta (:129-178) and the theta / phi part of index_cell_sph (:83-120) */
+static void sph_theta_phi(const oracle_model *m, double xin, double yin, double zin, int *thetaj_out,
+                          int *phik_out) {
+  const double r02 = xin * xin + yin * yin;
+  double tan_theta;
+  if (r02 > TINY_DP) tan_theta = fabs(zin) / sqrt(r02);
+  else tan_theta = (double)1.0e30f; /* default-real literal 1.0e30 */
+  int tmin = 0, tmax = m->nz, tj = (tmin + tmax) / 2;
+  while ((tmax - tmin) > 1) {
+    if (tan_theta > m->tan_theta_lim[tj]) tmin = tj; else tmax = tj;
+    tj = (tmin + tmax) / 2;
+  }
+  *thetaj_out = tj + 1;
+  if (m->l3D) {
+    if (zin < 0.0) *thetaj_out = -*thetaj_out;
+    if (zin != 0.0) {
+      double phi = modulo_d(atan2(yin, xin), 2 * PI);
+      int pk = (int)floor(phi / (2 * PI) * (double)(float)m->n_az) + 1;
+      if (pk == m->n_az + 1) pk = m->n_az;
+      *phik_out = pk;
+    } else {
+      *phik_out = 1;
+    }
+  } else {
+    *phik_out = 1;
+  }
+}
+
+/* spherical_grid.f90:48-125 */
+void oracle_index_cell_sph(const oracle_model *m, double xin, double yin, double zin, int *icell) {
+  const double r02 = xin * xin + yin * yin;
+  const double r2 = r02 + zin * zin;
+  int ri_out, thetaj_out, phik_out;
+  if (r2 < m->r_lim_2[0]) {
+    ri_out = 0; thetaj_out = 1; phik_out = 1;
+  } else if (r2 > m->Rmax2) {
+    ri_out = m->n_rad + 1; thetaj_out = 1; phik_out = 1;
+  } else {
+    int ri_min = 0, ri_max = m->n_rad, ri = (ri_min + ri_max) / 2;
+    while ((ri_max - ri_min) > 1) {
+      if (r2 > m->r_lim_2[ri]) ri_min = ri; else ri_max = ri;
+      ri = (ri_min + ri_max) / 2;
+    }
+    ri_out = ri + 1;
+    sph_theta_phi(m, xin, yin, zin, &thetaj_out, &phik_out);
+  }
+  *icell = cmap(m, ri_out, thetaj_out, phik_out);
+}
+
+/* one theta cone (:247-276, 279-307): smallest positive root of the crossing with tan(theta) = tan_lim */
+static double sph_theta_root(double x0, double y0, double z0, double u, double v, double w, double tan_lim) {
+  const double precision = 1.0e-15;
+  const double tan2 = tan_lim * tan_lim;
+  const double a_theta = w * w - tan2 * (u * u + v * v);
+  const double a_theta_m1 = 1.0 / a_theta;
+  const double b_theta = w * z0 - tan2 * (x0 * u + y0 * v);
+  const double c_theta = z0 * z0 - tan2 * (x0 * x0 + y0 * y0);
+  const double delta = b_theta * b_theta - a_theta * c_theta;
+  if (delta < 0.0) return 1.0e30;
+  const double rac = sqrt(delta);
+  const double t_1 = (-b_theta - rac) * a_theta_m1;
+  const double t_2 = (-b_theta + rac) * a_theta_m1;
+  if (t_1 <= precision) {
+    if (t_2 <= precision) return 1.0e30;
+    return t_2;
+  }
+  if (t_2 <= precision) return t_1;
+  return t_1 < t_2 ? t_1 : t_2;
+}
+
+/* spherical_grid.f90:182-446 */
+void oracle_cross_spherical_cell(const oracle_model *m, double x0, double y0, double z0, double u, double v,
+                                 double w, int cell, int previous_cell, double *x1, double *y1, double *z1,
+                                 int *next_cell, double *l, double *l_contrib, double *l_void_before) {
+  (void)previous_cell;
+  const double correct_moins = 1.0 - PREC_GRILLE_SPH, correct_plus = 1.0 + PREC_GRILLE_SPH;
+  const int ri0 = m->cell_map_i[cell - 1], thetaj0 = m->cell_map_j[cell - 1], phik0 = m->cell_map_k[cell - 1];
+  const double r0_2_cyl = x0 * x0 + y0 * y0;
+  const double r0_2 = r0_2_cyl + z0 * z0;
+  const double b = (x0 * u + y0 * v + z0 * w);
+  double c, delta, rac, s, t, t_phi;
+  int delta_rad, delta_theta = 0, delta_phi = 0;
+  if (ri0 == 0) {
+    c = (r0_2 - m->r_lim_2[0] * correct_plus);
+    delta = b * b - c;
+    rac = sqrt(delta);
+    s = (-b + rac) * correct_plus;
+    t = HUGE_REAL;
+    delta_rad = 1;
+    t_phi = HUGE_REAL;
+  } else {
+    /* 1) radial interface */
+    if (b < 0.0) {
+      c = (r0_2 - m->r_lim_2[ri0 - 1] * correct_moins);
+      delta = b * b - c;
+      if (delta < 0.0) {
+        c = (r0_2 - m->r_lim_2[ri0] * correct_plus);
+        delta = fmax(b * b - c, 0.0);
+        delta_rad = 1;
+      } else {
+        delta_rad = -1;
+      }
+    } else {
+      c = (r0_2 - m->r_lim_2[ri0] * correct_plus);
+      delta = fmax(b * b - c, 0.0);
+      delta_rad = 1;
+    }
+    rac = sqrt(delta);
+    s = -b - rac;
+    if (s < 0.0) s = -b + rac;
+    else if (s == 0.0) s = GRID_PREC;
+    /* 2) the two theta cones of the cell */
+    const int aj = thetaj0 < 0 ? -thetaj0 : thetaj0;
+    double tan_angle_lim1, tan_angle_lim2;
+    if (z0 >= 0.0) {
+      tan_angle_lim1 = m->tan_theta_lim[aj] * correct_plus;
+      tan_angle_lim2 = m->tan_theta_lim[aj - 1] * correct_moins;
+    } else {
+      tan_angle_lim1 = -m->tan_theta_lim[aj] * correct_plus;
+      tan_angle_lim2 = -m->tan_theta_lim[aj - 1] * correct_moins;
+    }
+    const double t1 = sph_theta_root(x0, y0, z0, u, v, w, tan_angle_lim1);
+    const double t2 = sph_theta_root(x0, y0, z0, u, v, w, tan_angle_lim2);
+    if (t1 < t2) {
+      t = t1;
+      delta_theta = 1;
+      if (aj == m->nz) delta_theta = 0;
+    } else {
+      t = t2;
+      delta_theta = -1;
+      if (aj == 1) delta_theta = 0;
+    }
+    /* 3) azimuthal interface */
+    if (m->l3D) {
+      const double dotprod = x0 * v - y0 * u;
+      if (fabs(dotprod) < (double)1.0e-10f) {
+        t_phi = (double)1.0e30f;
+        delta_phi = 0;
+      } else {
+        double tan_angle_lim;
+        if (dotprod > 0.0) {
+          tan_angle_lim = m->tan_phi_lim[phik0 - 1];
+          delta_phi = 1;
+        } else {
+          int phik0m1 = phik0 - 1;
+          if (phik0m1 == 0) phik0m1 = m->n_az;
+          tan_angle_lim = m->tan_phi_lim[phik0m1 - 1];
+          delta_phi = -1;
+        }
+        if (tan_angle_lim > 1.0e299) {
+          t_phi = -x0 / u;
+        } else {
+          const double den = v - u * tan_angle_lim;
+          if (fabs(den) > (double)1.0e-6f) {
+            t_phi = -(y0 - x0 * tan_angle_lim) / den;
+          } else {
+            t_phi = (double)1.0e30f;
+            delta_phi = 0;
+          }
+        }
+        if (t_phi < 0.0) {
+          t_phi = (double)1.0e30f;
+          delta_phi = 0;
+        }
+      }
+    } else {
+      t_phi = HUGE_REAL;
+    }
+  }
+  /* 4) which interface */
+  int ri1, thetaj1, phik1;
+  if ((s < t) && (s < t_phi)) {
+    *l = s;
+    *x1 = x0 + s * u; *y1 = y0 + s * v; *z1 = z0 + s * w;
+    ri1 = ri0 + delta_rad;
+    thetaj1 = thetaj0;
+    phik1 = phik0;
+    if (ri0 == 0) sph_theta_phi(m, *x1, *y1, *z1, &thetaj1, &phik1);
+    if (ri1 == 0) { thetaj1 = 1; phik1 = 1; }
+  } else if (t < t_phi) {
+    *l = t;
+    *x1 = x0 + t * u; *y1 = y0 + t * v; *z1 = z0 + t * w;
+    ri1 = ri0;
+    thetaj1 = (thetaj0 < 0 ? -thetaj0 : thetaj0) + delta_theta;
+    if (m->l3D) {
+      if (*z1 < 0) thetaj1 = -thetaj1;
+    }
+    phik1 = phik0;
+  } else {
+    *l = t_phi;
+    const double delta_vol = correct_plus * t_phi;
+    *x1 = x0 + delta_vol * u; *y1 = y0 + delta_vol * v; *z1 = z0 + delta_vol * w;
+    ri1 = ri0;
+    thetaj1 = thetaj0;
+    phik1 = phik0 + delta_phi;
+    if (phik1 == 0) phik1 = m->n_az;
+    if (phik1 == m->n_az + 1) phik1 = 1;
+  }
+  if (*z1 == 0.0) *z1 = GRID_PREC;
+  *next_cell = cmap(m, ri1, thetaj1, phik1);
+  *l_contrib = *l;
+  *l_void_before = 0.0;
+}
+
+/* spherical_grid.f90:562-615 */
+void oracle_move_to_grid_sph(const oracle_model *m, double *x, double *y, double *z, double u, double v, double w,
+                             int *icell, int *lintersect) {
+  const double correct_moins = 1.0 - 1.0e-10;
+  const double x0 = *x, y0 = *y, z0 = *z;
+  const double r0_2 = x0 * x0 + y0 * y0 + z0 * z0;
+  const double b = (x0 * u + y0 * v + z0 * w);
+  const double c = (r0_2 - m->r_lim_2[m->n_rad] * correct_moins);
+  const double delta = b * b - c;
+  if (delta < 0.0) {
+    *lintersect = 0;
+    *icell = 0;
+    return;
+  }
+  *lintersect = 1;
+  const double rac = sqrt(delta);
+  const double s1 = -b - rac;
+  const double x1 = x0 + s1 * u, y1 = y0 + s1 * v, z1 = z0 + s1 * w;
+  oracle_index_cell_sph(m, x1, y1, z1, icell);
+  *x = x1; *y = y1; *z = z1;
+}
+
+/* spherical_grid.f90:619-699 */
+void oracle_pos_em_cell_sph(const oracle_model *m, int icell, float rand1, float rand2, float rand3, double *x,
+                            double *y, double *z) {
+  const int ri = m->cell_map_i[icell - 1], thetaj = m->cell_map_j[icell - 1], phik = m->cell_map_k[icell - 1];
+  const double one_third = 1.0 / 3.0;
+  const double r = pow(m->r_lim_3[ri - 1] + (double)rand1 * (m->r_lim_3[ri] - m->r_lim_3[ri - 1]), one_third);
+  double theta;
+  if (m->l3D) {
+    const int aj = thetaj < 0 ? -thetaj : thetaj;
+    theta = m->theta_lim[aj - 1] + (double)rand2 * (m->theta_lim[aj] - m->theta_lim[aj - 1]);
+  } else {
+    if ((double)rand2 > 0.5)
+      theta = m->theta_lim[thetaj - 1] + (2.0 * ((double)rand2 - 0.5)) * (m->theta_lim[thetaj] - m->theta_lim[thetaj - 1]);
+    else
+      theta = -(m->theta_lim[thetaj - 1] + (2.0 * (double)rand2) * (m->theta_lim[thetaj] - m->theta_lim[thetaj - 1]));
+  }
+  const double phi = 2.0 * PI * ((double)(float)phik - 1.0 + (double)rand3) / (double)(float)m->n_az;
+  *z = r * sin(theta);
+  const double r_cos_theta = r * cos(theta);
+  *x = r_cos_theta * cos(phi);
+  *y = r_cos_theta * sin(phi);
+}
+
 /* grid operator table (grid.f90:16-22, 298-357) */
 static inline int grid_test_exit(const oracle_model *m, int icell, double x, double y, double z) {
   if (m->grid_type == 3) return icell < 0; /* test_exit_grid_Voronoi (:1446) */
+  if (m->grid_type == 2) return oracle_test_exit_grid_sph(m, icell);
   return oracle_test_exit_grid_cyl(m, icell, x, y, z);
 }
 
@@ -991,9 +1254,11 @@ static void emit_packet_uniform_sphere(const oracle_model *m, int i_star,
   *y = *y * r_star + st->y;
   *z = *z * r_star + st->z;
   if (m->grid_type == 3) *icell = st->icell; /* stars.f90:155-156 */
+  else if (m->grid_type == 2) oracle_index_cell_sph(m, *x, *y, *z, icell);
   else oracle_index_cell_cyl(m, *x, *y, *z, icell);
   if (st->out_model) {
     if (m->grid_type == 3) oracle_move_to_grid_voronoi(m, x, y, z, *u, *v, *w, icell, lintersect);
+    else if (m->grid_type == 2) oracle_move_to_grid_sph(m, x, y, z, *u, *v, *w, icell, lintersect);
     else oracle_move_to_grid_cyl(m, x, y, z, *u, *v, *w, icell, lintersect);
   } else {
     *lintersect = 1;
@@ -1219,6 +1484,9 @@ static void physical_length(worker_t *W, int lambda, const double Stokes[4],
     if (m->grid_type == 3)
       oracle_cross_voronoi_cell(m, x0, y0, z0, *u, *v, *w, icell0, previous_cell, &x1, &y1, &z1,
                                 &next_cell, &l, &l_contrib, &l_void_before);
+    else if (m->grid_type == 2)
+      oracle_cross_spherical_cell(m, x0, y0, z0, *u, *v, *w, icell0, previous_cell, &x1, &y1, &z1,
+                                  &next_cell, &l, &l_contrib, &l_void_before);
     else
       oracle_cross_cylindrical_cell(m, x0, y0, z0, *u, *v, *w, icell0,
                                     previous_cell, &x1, &y1, &z1, &next_cell, &l,
@@ -1245,7 +1513,7 @@ static void physical_length(worker_t *W, int lambda, const double Stokes[4],
       *yio = y0 + l * (*v);
       *zio = z0 + l * (*w);
       *icell = icell0;
-      if (m->l3D && m->grid_type != 3) oracle_index_cell_cyl(m, *xio, *yio, *zio, icell); /* :162 */
+      if (m->l3D && m->grid_type != 3 && m->grid_type != 2) oracle_index_cell_cyl(m, *xio, *yio, *zio, icell); /* :162: lcylindrical only */
       return;
     }
   }
@@ -1306,6 +1574,8 @@ static int emit_packet(worker_t *W, int lambda, int *icell, double *x,
     if (m->grid_type == 3) { /* pos_em_cell_voronoi (Voronoi.f90:1510-1542): the cell centre */
       const double *c = m->v_xyz_dp + 3 * (size_t)(*icell - 1);
       *x = c[0]; *y = c[1]; *z = c[2];
+    } else if (m->grid_type == 2) {
+      oracle_pos_em_cell_sph(m, *icell, r1, r2, r3, x, y, z);
     } else {
       oracle_pos_em_cell_cyl(m, *icell, r1, r2, r3, x, y, z);
     }
@@ -1329,6 +1599,7 @@ static int emit_packet(worker_t *W, int lambda, int *icell, double *x,
     *z = m->centre_ISM[2] + *z * m->R_ISM;
     Stokes[0] = 1.0; Stokes[1] = 0.0; Stokes[2] = 0.0; Stokes[3] = 0.0;
     if (m->grid_type == 3) oracle_move_to_grid_voronoi(m, x, y, z, *u, *v, *w, icell, lintersect);
+    else if (m->grid_type == 2) oracle_move_to_grid_sph(m, x, y, z, *u, *v, *w, icell, lintersect);
     else oracle_move_to_grid_cyl(m, x, y, z, *u, *v, *w, icell, lintersect);
   }
   return 0;

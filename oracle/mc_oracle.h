@@ -140,6 +140,12 @@ typedef struct {
   const int *v_wall_first; /* [7] offsets (0-based) into v_wall_cells */
   const int *v_wall_cells; /* wall(iwall)%neighbour_list, concatenated */
 
+  /* ---- spherical grid (grid_type 2: spherical_grid.f90; arrays of cylindrical_grid.f90:28-31).  The cell mapping,
+   * r_lim_2, tan_phi_lim, volume are the fields above (build_cylindrical_cell_mapping serves both grids). ---- */
+  const double *tan_theta_lim; /* [0..nz] */
+  const double *theta_lim;     /* [0..nz] */
+  const double *r_lim_3;       /* [0..n_rad] */
+
   /* ---- interstellar radiation field: emitting sphere (stars.f90:27-28, 655-666) ---- */
   double R_ISM;
   double centre_ISM[3];
@@ -197,6 +203,18 @@ void oracle_move_to_grid_cyl(const oracle_model *m, double *x, double *y,
 void oracle_pos_em_cell_cyl(const oracle_model *m, int icell, float rand1,
                             float rand2, float rand3, double *x, double *y,
                             double *z);
+
+/* Geometry operators of the spherical grid (spherical_grid.f90): PINNED bit-for-bit to the reference's
+ * module compiled in oracle/_ref (tests/test_ref_geometry.py, tests/golden/geom_sph*.npz). */
+int oracle_test_exit_grid_sph(const oracle_model *m, int icell);
+void oracle_index_cell_sph(const oracle_model *m, double x, double y, double z, int *icell);
+void oracle_cross_spherical_cell(const oracle_model *m, double x0, double y0, double z0, double u, double v,
+                                 double w, int cell, int previous_cell, double *x1, double *y1, double *z1,
+                                 int *next_cell, double *l, double *l_contrib, double *l_void_before);
+void oracle_move_to_grid_sph(const oracle_model *m, double *x, double *y, double *z, double u, double v, double w,
+                             int *icell, int *lintersect);
+void oracle_pos_em_cell_sph(const oracle_model *m, int icell, float rand1, float rand2, float rand3, double *x,
+                            double *y, double *z);
 
 /*
  * One wavelength of the SED Monte Carlo (run_sed_mc, dust_transfer.f90:828-1042 ->

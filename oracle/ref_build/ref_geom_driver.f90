@@ -4,7 +4,7 @@
 ! TEST INFRASTRUCTURE.  This file is ours; it contains no reference code.  It
 ! is compiled together with the reference's unmodified sources where they lie
 ! under /root/reference/src (mcfost_env, parameters, constants, messages,
-! cylindrical_grid, Temperature, wavelengths) by oracle/ref_build/Makefile
+! cylindrical_grid, spherical_grid, Temperature, wavelengths) by oracle/ref_build/Makefile
 ! into oracle/_ref/libmcfost_ref_geom.so.  Those modules need no library,
 ! generated file or header the image lacks, so no stand-in is written.  The
 ! rest of the reference (anything that pulls utils.f90 -> sha/os generated
@@ -19,6 +19,7 @@ module ref_geom_driver
   use parameters
   use constants
   use cylindrical_grid
+  use spherical_grid
   use temperature, only : tab_Temp, init_tab_Temp
   use wavelengths, only : lmono0, lambda_min, lambda_max, n_lambda, tab_lambda, tab_lambda_inf, &
        tab_lambda_sup, tab_delta_lambda, init_lambda
@@ -32,6 +33,24 @@ contains
     integer(c_int), value :: c_n_rad, c_nz, c_n_az, c_l3D, c_n_rad_in
     real(c_double), value :: rin, edge, rout, rref, sclht, exp_beta, surf
     integer(c_int), intent(out) :: ierr
+    call setup_grid_any(1, c_n_rad, c_nz, c_n_az, c_l3D, c_n_rad_in, rin, edge, rout, rref, sclht, exp_beta, surf, ierr)
+  end subroutine ref_setup_grid
+
+  ! The same zone on a spherical grid (grid_type = 2, grid.f90:345-357): uniform in cos(theta)
+  subroutine ref_setup_grid_sph(c_n_rad, c_nz, c_n_az, c_l3D, c_n_rad_in, rin, edge, rout, rref, sclht, &
+       exp_beta, surf, ierr) bind(C, name="ref_setup_grid_sph")
+    integer(c_int), value :: c_n_rad, c_nz, c_n_az, c_l3D, c_n_rad_in
+    real(c_double), value :: rin, edge, rout, rref, sclht, exp_beta, surf
+    integer(c_int), intent(out) :: ierr
+    call setup_grid_any(2, c_n_rad, c_nz, c_n_az, c_l3D, c_n_rad_in, rin, edge, rout, rref, sclht, exp_beta, surf, ierr)
+  end subroutine ref_setup_grid_sph
+
+  subroutine setup_grid_any(gtype, c_n_rad, c_nz, c_n_az, c_l3D, c_n_rad_in, rin, edge, rout, rref, sclht, &
+       exp_beta, surf, ierr)
+    integer, intent(in) :: gtype
+    integer(c_int), intent(in) :: c_n_rad, c_nz, c_n_az, c_l3D, c_n_rad_in
+    real(c_double), intent(in) :: rin, edge, rout, rref, sclht, exp_beta, surf
+    integer(c_int), intent(out) :: ierr
 
     ierr = 0
     if (allocated(disk_zone)) then
@@ -41,7 +60,7 @@ contains
 
     n_rad = c_n_rad ; nz = c_nz ; n_az = c_n_az ; n_rad_in = c_n_rad_in
     l3D = (c_l3D /= 0)
-    lVoronoi = .false. ; lcylindrical = .true. ; lspherical = .false.
+    lVoronoi = .false. ; lcylindrical = (gtype == 1) ; lspherical = (gtype == 2) ; grid_type = gtype
     llinear_rgrid = .false. ; lidefix = .false. ; lsphere_model = .false. ; lmodel_1d = .false.
     lfargo3d = .false. ; lSeb_Charnoz = .false. ; lregular_theta = .false.
 
@@ -73,7 +92,81 @@ contains
 
     call build_cylindrical_cell_mapping()
     call define_cylindrical_grid()
-  end subroutine ref_setup_grid
+  end subroutine setup_grid_any
+
+  ! the arrays only the spherical grid uses (cylindrical_grid.f90:28-31)
+  subroutine ref_get_grid_sph(o_tan_theta_lim, o_theta_lim, o_w_lim, o_r_lim_3) bind(C, name="ref_get_grid_sph")
+    real(c_double), intent(out) :: o_tan_theta_lim(*), o_theta_lim(*), o_w_lim(*), o_r_lim_3(*)
+    o_tan_theta_lim(1:nz+1) = tan_theta_lim(0:nz)
+    o_theta_lim(1:nz+1) = theta_lim(0:nz)
+    o_w_lim(1:nz+1) = w_lim(0:nz)
+    o_r_lim_3(1:n_rad+1) = r_lim_3(0:n_rad)
+  end subroutine ref_get_grid_sph
+
+  ! cross_spherical_cell, spherical_grid.f90:182
+  subroutine ref_cross_cell_sph(n, x0, y0, z0, u, v, w, cell, x1, y1, z1, next_cell, l) bind(C, name="ref_cross_cell_sph")
+    integer(c_int), value :: n
+    real(c_double), intent(in) :: x0(n), y0(n), z0(n), u(n), v(n), w(n)
+    integer(c_int), intent(in) :: cell(n)
+    real(c_double), intent(out) :: x1(n), y1(n), z1(n), l(n)
+    integer(c_int), intent(out) :: next_cell(n)
+    integer :: i
+    real(kind=dp) :: l_contrib, l_void_before
+    do i = 1, n
+       call cross_spherical_cell(x0(i), y0(i), z0(i), u(i), v(i), w(i), cell(i), 0, x1(i), y1(i), z1(i), &
+            next_cell(i), l(i), l_contrib, l_void_before)
+    enddo
+  end subroutine ref_cross_cell_sph
+
+  ! index_cell_sph, spherical_grid.f90:48
+  subroutine ref_index_cell_sph(n, x, y, z, icell) bind(C, name="ref_index_cell_sph")
+    integer(c_int), value :: n
+    real(c_double), intent(in) :: x(n), y(n), z(n)
+    integer(c_int), intent(out) :: icell(n)
+    integer :: i
+    do i = 1, n
+       call index_cell_sph(x(i), y(i), z(i), icell(i))
+    enddo
+  end subroutine ref_index_cell_sph
+
+  ! test_exit_grid_sph, spherical_grid.f90:24
+  subroutine ref_test_exit_grid_sph(n, icell, x, y, z, lexit) bind(C, name="ref_test_exit_grid_sph")
+    integer(c_int), value :: n
+    integer(c_int), intent(in) :: icell(n)
+    real(c_double), intent(in) :: x(n), y(n), z(n)
+    integer(c_int), intent(out) :: lexit(n)
+    integer :: i
+    do i = 1, n
+       lexit(i) = merge(1, 0, test_exit_grid_sph(icell(i), x(i), y(i), z(i)))
+    enddo
+  end subroutine ref_test_exit_grid_sph
+
+  ! move_to_grid_sph, spherical_grid.f90:562
+  subroutine ref_move_to_grid_sph(n, x, y, z, u, v, w, icell, lintersect) bind(C, name="ref_move_to_grid_sph")
+    integer(c_int), value :: n
+    real(c_double), intent(inout) :: x(n), y(n), z(n)
+    real(c_double), intent(in) :: u(n), v(n), w(n)
+    integer(c_int), intent(out) :: icell(n), lintersect(n)
+    integer :: i
+    logical :: lint
+    do i = 1, n
+       icell(i) = 0
+       call move_to_grid_sph(1, x(i), y(i), z(i), u(i), v(i), w(i), icell(i), lint)
+       lintersect(i) = merge(1, 0, lint)
+    enddo
+  end subroutine ref_move_to_grid_sph
+
+  ! pos_em_cell_sph, spherical_grid.f90:619
+  subroutine ref_pos_em_cell_sph(n, icell, r1, r2, r3, x, y, z) bind(C, name="ref_pos_em_cell_sph")
+    integer(c_int), value :: n
+    integer(c_int), intent(in) :: icell(n)
+    real(c_float), intent(in) :: r1(n), r2(n), r3(n)
+    real(c_double), intent(out) :: x(n), y(n), z(n)
+    integer :: i
+    do i = 1, n
+       call pos_em_cell_sph(icell(i), r1(i), r2(i), r3(i), x(i), y(i), z(i))
+    enddo
+  end subroutine ref_pos_em_cell_sph
 
   subroutine ref_grid_sizes(o_n_cells, o_ntot2, o_jlo, o_jn) bind(C, name="ref_grid_sizes")
     integer(c_int), intent(out) :: o_n_cells, o_ntot2, o_jlo, o_jn

@@ -68,7 +68,7 @@ static inline float nf_add(float a, float b) { volatile float r = a + b; return 
 static inline float nf_sub(float a, float b) { volatile float r = a - b; return r; }
 }  // namespace mcgpu
 using std::fabs; using std::floor; using std::sqrt; using std::log; using std::exp; using std::fmax;
-using std::fmin; using std::atan2; using std::acos; using std::cos; using std::copysign;
+using std::fmin; using std::atan2; using std::acos; using std::cos; using std::copysign; using std::pow;
 
 namespace mcgpu { double lds_raw[1 << 18]; }
 
@@ -101,6 +101,7 @@ struct Conv {
     M.r_lim_2 = m->r_lim_2; M.zmax = m->zmax; M.tan_phi_lim = m->tan_phi_lim;
     ch.assign(m->n_rad > 0 ? m->n_rad : 1, 0.0);
     if (voro) { M.n_rad = 0; M.nz = 0; M.n_az = 0; M.l3D = 1; M.r_lim_2 = &dummy; }
+    else if (m->grid_type == 2) for (int i = 0; i < m->n_rad; ++i) ch[i] = 1.0;
     else for (int i = 0; i < m->n_rad; ++i) ch[i] = m->nz >= 2 ? m->z_lim[i + m->n_rad] : m->zmax[i];
     M.ch = ch.data();
     M.zmaxmax = m->zmaxmax; M.Rmax2 = m->Rmax2; M.volume = m->volume;
@@ -152,6 +153,8 @@ struct Conv {
     M.prob_E_cell = m->prob_E_cell; M.L_packet_th = m->L_packet_th;
     M.N_thet = m->N_thet; M.N_phi = m->N_phi; M.sym_c = m->l_sym_centrale; M.sym_a = m->l_sym_axiale;
     M.midplane_snap = m->midplane_snap;
+    M.grid_sph = m->grid_type == 2;
+    M.tan_theta_lim = m->tan_theta_lim; M.theta_lim = m->theta_lim; M.r_lim_3 = m->r_lim_3;
     M.R_ISM = m->R_ISM;
     for (int q = 0; q < 3; ++q) M.centre_ISM[q] = m->centre_ISM[q];
   }
@@ -187,6 +190,16 @@ extern "C" int emu_run_thermal(const oracle_model* m, const oracle_opts* o, cons
     } else {
       if (pola) k_thermal_voro<true>(M, A, G); else k_thermal_voro<false>(M, A, G);
     }
+    for (int q = 0; q < 8; ++q) counters[q] = cnt[q];
+    return err;
+  }
+  if (M.grid_sph) {  // spherical grid: the single-role kernel with that grid's operators
+    const bool ld = getenv("MCGPU_EMU_LDS") != nullptr;
+    if (dark) return 31;
+    if (l3d) { if (pola) { if (ld) k_thermal_sph<true, true, true>(M, A); else k_thermal_sph<true, true, false>(M, A); }
+               else { if (ld) k_thermal_sph<true, false, true>(M, A); else k_thermal_sph<true, false, false>(M, A); } }
+    else { if (pola) { if (ld) k_thermal_sph<false, true, true>(M, A); else k_thermal_sph<false, true, false>(M, A); }
+           else { if (ld) k_thermal_sph<false, false, true>(M, A); else k_thermal_sph<false, false, false>(M, A); } }
     for (int q = 0; q < 8; ++q) counters[q] = cnt[q];
     return err;
   }
@@ -240,7 +253,10 @@ extern "C" int emu_cross_cell(const oracle_model* m, int literal, int n, const d
     const int c = cell[i] - 1;
     const int ri = m->cell_map_i[c], zj = m->cell_map_j[c], k = m->cell_map_k[c];
     int ri1, zj1, k1;
-    if (m->l3D) {
+    if (M.grid_sph) {
+      if (m->l3D) cross_cell_sph<true>(T, M, x0[i], y0[i], z0[i], u[i], v[i], w[i], ri, zj, k, x1[i], y1[i], z1[i], ri1, zj1, k1, l[i]);
+      else cross_cell_sph<false>(T, M, x0[i], y0[i], z0[i], u[i], v[i], w[i], ri, zj, k, x1[i], y1[i], z1[i], ri1, zj1, k1, l[i]);
+    } else if (m->l3D) {
       if (literal) cross_cell<true>(T, M, x0[i], y0[i], z0[i], u[i], v[i], w[i], inv_a, inv_w, ri, zj, k, x1[i], y1[i], z1[i], ri1, zj1, k1, l[i]);
       else cross_cell_lean<true>(T, M, x0[i], y0[i], z0[i], u[i], v[i], w[i], inv_a, inv_w, ri, zj, k, x1[i], y1[i], z1[i], ri1, zj1, k1, l[i]);
     } else {

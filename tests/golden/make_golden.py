@@ -7,8 +7,10 @@ where /root/reference exists:
 Each file holds inputs and the reference's outputs (data only) for:
 define_cylindrical_grid + build_cylindrical_cell_mapping (grid tables),
 cross_cylindrical_cell along random walks, index_cell_cyl, test_exit_grid_cyl,
-move_to_grid_cyl, pos_em_cell_cyl, init_tab_Temp, init_lambda and the
-constants.  One process per configuration (the reference allocates its module
+move_to_grid_cyl, pos_em_cell_cyl -- or, for the spherical configurations, the
+operators of spherical_grid.f90 (cross_spherical_cell, index_cell_sph,
+test_exit_grid_sph, move_to_grid_sph, pos_em_cell_sph) -- init_tab_Temp,
+init_lambda and the constants.  One process per configuration (the reference allocates its module
 arrays once).
 """
 import os
@@ -26,6 +28,9 @@ CONFIGS = {
     "pascucci": "M.pascucci()",
     "small2d": "M.small()",
     "small3d": "M.small(n_rad=12, nz=6, n_az=8, l3D=True)",
+    "ref41_3d": "M.ref41_3d()",                                          # the true BASELINE config-3 grid, 100 x 50 x 72
+    "sph2d": "M.small(grid_type=2)",                                     # spherical_grid.f90
+    "sph3d": "M.small(n_rad=12, nz=6, n_az=8, l3D=True, grid_type=2)",
 }
 
 
@@ -50,7 +55,9 @@ def make_one(name, expr, n_rays=400, n_steps=30, seed=7):
     rmax = np.sqrt(g["Rmax2"])
     xs = rng.uniform(-1.3 * rmax, 1.3 * rmax, n_rays)
     ys = rng.uniform(-1.3 * rmax, 1.3 * rmax, n_rays)
-    zs = rng.uniform(-1.5, 1.5, n_rays) * g["zmax"].max()
+    sph = int(getattr(cfg, "grid_type", 1)) == 2
+    zext = rmax if sph else g["zmax"].max()
+    zs = rng.uniform(-1.5, 1.5, n_rays) * zext
     out.update(idx2_x=xs, idx2_y=ys, idx2_z=zs, idx2_icell=ref.index_cell(xs, ys, zs))
     # random walks
     w = rng.uniform(-1, 1, n_rays)
@@ -77,7 +84,7 @@ def make_one(name, expr, n_rays=400, n_steps=30, seed=7):
     ph = rng.uniform(0, 2 * np.pi, n_m)
     px, py, pz = R * np.sqrt(1 - cz * cz) * np.cos(ph), R * np.sqrt(1 - cz * cz) * np.sin(ph), R * cz
     tx, ty, tz = (rng.uniform(-1, 1, n_m) * rmax * 0.8 for _ in range(3))
-    tz = tz * (g["zmax"].max() / rmax)
+    tz = tz * (zext / rmax)
     d = np.stack([tx - px, ty - py, tz - pz], 1)
     d /= np.linalg.norm(d, axis=1)[:, None]
     # half of the rays point in random directions (most of them miss the grid)
@@ -90,6 +97,9 @@ def make_one(name, expr, n_rays=400, n_steps=30, seed=7):
     lam = ref.init_lambda(cfg.n_lambda, cfg.lambda_min, cfg.lambda_max)
     out.update(lam=lam[0], lam_inf=lam[1], lam_sup=lam[2], lam_delta=lam[3])
     out["constants"] = ref.constants()
+    if name == "ref41_3d":   # 720 000 cells: keep the fixture small -- drop the per-cell tables (the small 3D grid pins
+        # their construction), keep the walks, the point location and the vectors the operators read
+        out = {k: v for k, v in out.items() if k == "walk" or np.asarray(v).size <= 100000}
     np.savez_compressed(os.path.join(HERE, f"geom_{name}.npz"), **out)
     print(name, "walk rows", out["walk"].shape[0])
 

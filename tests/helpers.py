@@ -10,6 +10,9 @@ CONFIGS = {
     "pascucci": lambda M: M.pascucci(),
     "small2d": lambda M: M.small(),
     "small3d": lambda M: M.small(n_rad=12, nz=6, n_az=8, l3D=True),
+    "ref41_3d": lambda M: M.ref41_3d(),
+    "sph2d": lambda M: M.small(grid_type=2),
+    "sph3d": lambda M: M.small(n_rad=12, nz=6, n_az=8, l3D=True, grid_type=2),
 }
 
 

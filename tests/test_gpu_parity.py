@@ -80,6 +80,35 @@ def test_device_geometry_against_reference_golden(name):
     e.close()
 
 
+def test_spherical_grid_on_the_gpu():
+    """spherical_grid.f90 on the device: the probes against the reference's golden walks (next cell exact, end points
+    and lengths to 1e-12), then the packet loop against the oracle (2D: same packets; 3D: hemispheres summed, see
+    tests/test_kernel_emulation.py::_check_spherical), HBM and LDS deposits."""
+    from test_kernel_emulation import _check_spherical
+    for name in ("sph2d", "sph3d"):
+        m = M.build_model(CONFIGS[name](M))
+        e = _engine(m, 20000)
+        g = load_golden(name)
+        wk = g["walk"]
+        x1, y1, z1, nxt, l = e.probe_cross_cell(wk[:, 0], wk[:, 1], wk[:, 2], wk[:, 3], wk[:, 4], wk[:, 5],
+                                                wk[:, 6].astype(np.int32))
+        assert np.array_equal(nxt, wk[:, 10].astype(np.int32))
+        scale = np.abs(wk[:, 0]) + np.abs(wk[:, 1]) + np.abs(wk[:, 2]) + wk[:, 11]
+        for a, col in ((x1, 7), (y1, 8), (z1, 9), (l, 11)):
+            assert np.all(np.abs(a - wk[:, col]) <= 1e-12 * scale), col
+        assert np.array_equal(e.probe_index_cell(g["pos_x"], g["pos_y"], g["pos_z"]), g["index_icell"])
+        assert np.array_equal(e.probe_index_cell(g["idx2_x"], g["idx2_y"], g["idx2_z"]), g["idx2_icell"])
+        o = _oracle(m, 20000)
+        prior = o.run_thermal(2000, seed=1)["E_abs"]
+        _check_spherical(e.run_thermal(20000, seed=31, frozen=True, E_prior=prior), o, m, 20000, 31, prior)
+        e.set_option("deposit", 1)
+        _check_spherical(e.run_thermal(20000, seed=32, frozen=True, E_prior=prior), o, m, 20000, 32, prior)
+        live = e.run_thermal(50000, seed=5)
+        assert live["counters"]["escaped"] + live["counters"]["killed_star"] == 50000
+        assert e.temp_finale(live["E_abs"]).max() > 50.0
+        e.close()
+
+
 def _frozen_parity(m, n, seed, n_prior=2000, rtol=1e-9, **kw):
     e, o = _engine(m, n), _oracle(m, n)
     prior = o.run_thermal(n_prior, seed=1)["E_abs"]

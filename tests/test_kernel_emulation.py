@@ -62,7 +62,7 @@ def check(emu, m, n, seed, rtol=1e-9):
     return a, b
 
 
-@pytest.mark.parametrize("name", ["small2d", "small3d", "ref41", "pascucci"])
+@pytest.mark.parametrize("name", ["small2d", "small3d", "ref41", "pascucci", "ref41_3d", "sph2d", "sph3d"])
 def test_emulated_cross_cell_against_reference_golden(emu, name):
     """The device source of the crossing operator on the reference's golden walks, on the CPU: the branch-free
     cross_cell_lean the product runs and the branch-for-branch restatement (tests/emu/cross_cell_literal.h) give the
@@ -77,7 +77,7 @@ def test_emulated_cross_cell_against_reference_golden(emu, name):
     cols = [np.ascontiguousarray(wk[:, q]) for q in range(6)]
     cell = np.ascontiguousarray(wk[:, 6].astype(np.int32))
     outs = []
-    for literal in (0, 1):
+    for literal in ((0,) if name.startswith("sph") else (0, 1)):   # (spherical_grid.f90 has the one form)
         x1, y1, z1, l = (np.zeros(n) for _ in range(4))
         nxt = np.zeros(n, np.int32)
         rc = emu.emu_cross_cell(C.byref(orc.cm), literal, n, *[_p(c, C.c_double) for c in cols], _p(cell, C.c_int),
@@ -89,8 +89,9 @@ def test_emulated_cross_cell_against_reference_golden(emu, name):
         for a, col in ((x1, 7), (y1, 8), (z1, 9), (l, 11)):
             assert np.all(np.abs(a - wk[:, col]) <= 1e-12 * scale), (literal, col)
         outs.append((x1, y1, z1, l))
-    for a, b in zip(*outs):
-        assert np.all(np.abs(a - b) <= 1e-13 * scale)
+    if len(outs) == 2:
+        for a, b in zip(*outs):
+            assert np.all(np.abs(a - b) <= 1e-13 * scale)
 
 
 def test_emulated_kernel_2d(emu, small_model):
@@ -99,6 +100,51 @@ def test_emulated_kernel_2d(emu, small_model):
 
 def test_emulated_kernel_3d(emu):
     check(emu, M.build_model(M.small(n_rad=12, nz=6, n_az=8, l3D=True)), 5000, 8)
+
+
+def _check_spherical(run, orc, m, n, seed, prior):
+    """Device result `run` against the oracle on a spherical grid.  The grid's midplane is the cone tan(theta) = 1e-10
+    (cylindrical_grid.f90:500) and a packet that crosses it passes two roots ~1e-10 apart, kept or dropped by
+    `t <= 1e-15` (spherical_grid.f90:262-275): a last-ulp matter (the device contracts multiply-adds elsewhere), so
+    (2D) a zero-length crossing more or less per ~1e5 crossings, same packets and sums otherwise; (3D) the reference
+    keeps the label +j until the next polar wall, so which hemisphere's cell collects a path is rounding noise there
+    -- the hemispheres are compared summed."""
+    a = run
+    b = orc.run_thermal(n, seed=seed, frozen=True, E_prior=prior, n_threads=4)
+    ca, cb = a["counters"], list(b["counters"].values())
+    if not isinstance(ca, list):
+        ca = list(ca.values())
+    assert ca[0] == cb[0] == n and ca[5] + ca[6] == n
+    g = m.grid
+    if g["l3D"]:
+        assert abs(ca[1] - cb[1]) <= 0.03 * cb[1] and abs(ca[2] - cb[2]) <= 0.05 * cb[2]
+        i, j, k = g["cell_map_i"][:m.n_cells], g["cell_map_j"][:m.n_cells], g["cell_map_k"][:m.n_cells]
+        key = (i - 1) + g["n_rad"] * (np.abs(j) - 1)
+
+        def prof(E):  # radial-polar profile, hemispheres and azimuths summed
+            return np.bincount(key, weights=E, minlength=g["n_rad"] * g["nz"])
+        pa, pb = prof(a["E_abs"]), prof(b["E_abs"])
+        big = pb > 0.01 * pb.max()
+        assert np.all(np.abs(pa[big] - pb[big]) <= 0.35 * pb[big]) and abs(pa.sum() - pb.sum()) <= 0.05 * pb.sum()
+    else:
+        assert ca[2:] == cb[2:] and abs(ca[1] - cb[1]) <= 3 + 3e-4 * cb[1]
+        assert np.array_equal(a["n_sent"], b["n_sent"]) and np.array_equal(a["sed"][4], b["sed"][4])
+        assert np.allclose(a["E_abs"], b["E_abs"], rtol=1e-9, atol=1e-12 * b["E_abs"].max())
+
+
+def test_emulated_kernel_spherical_grid(emu):
+    """The packet loop on the spherical grid (spherical_grid.f90 operators in the device source), 2D and 3D, HBM and
+    LDS deposits, against the oracle, whose operators are pinned bit for bit to the reference."""
+    for kw in (dict(), dict(n_rad=12, nz=6, n_az=8, l3D=True), dict(lsepar_pola=False)):
+        m = M.build_model(M.small(grid_type=2, **kw))
+        orc = Oracle(m, 4000)
+        prior = orc.run_thermal(2000, seed=1)["E_abs"]
+        _check_spherical(emu_run(emu, orc, 4000, 17, prior=prior), orc, m, 4000, 17, prior)
+        os.environ["MCGPU_EMU_LDS"] = "1"
+        try:
+            _check_spherical(emu_run(emu, orc, 2000, 18, prior=prior), orc, m, 2000, 18, prior)
+        finally:
+            del os.environ["MCGPU_EMU_LDS"]
 
 
 def test_emulated_kernel_hg_isotropic_unpolarised(emu):
