@@ -899,27 +899,6 @@ template <bool SCOUT>
 static int launch_mono(mcgpu_ctx* ctx, const MonoArgs& A, int grid_blocks, int block_threads) {
   const DevModel& M = ctx->M;
   const bool pola = ctx->lsepar_pola != 0, dark = M.dark != nullptr, l3d = M.l3D != 0;
-  // workgroup size: the one that keeps the most wavefronts on a CU -- 8 at most with the kernel's 256 VGPRs; the LDS
-  // of a workgroup is the shared tables plus the per-lane ray-tracing scratch, which grows with the observer count
-  int threads = 0;
-  const bool slim = true;                   // (mono_lds_bytes)
-  const int max_threads = 512;
-  if (block_threads > 0 && block_threads <= max_threads && block_threads % 64 == 0) {
-    threads = block_threads;
-  } else {
-    int best_waves = 0;
-    for (int th = max_threads; th >= 64; th -= 64) {
-      const size_t l = mono_lds_bytes(M, A.nRT, th, pola, slim);
-      if (l > 160 * 1024) continue;
-      int per_cu = (int)((160 * 1024) / l);
-      if (per_cu > max_threads / th) per_cu = max_threads / th;
-      const int waves = per_cu * th / 64;
-      if (waves > best_waves) { best_waves = waves; threads = th; }
-    }
-    if (!threads) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "too many ray-tracing directions for the LDS of one CU");
-  }
-  const size_t lds = mono_lds_bytes(M, A.nRT, threads, pola, slim);
-  if (lds > 160 * 1024) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "too many ray-tracing directions for the LDS of one CU");
   const void* fn;
   // (the commit pass of a context with default-real xI_scatt runs the F32 variant of the deposit code)
   constexpr bool kCommit = !SCOUT;
@@ -936,6 +915,30 @@ static int launch_mono(mcgpu_ctx* ctx, const MonoArgs& A, int grid_blocks, int b
     else { if (dark) PICK(false, false, true); else PICK(false, false, false); }
   }
 #undef PICK
+  // workgroup size: the one that keeps the most wavefronts on a CU, up to 8 (2 per SIMD).  The r02 build needs only
+  // 101-169 VGPRs here, so the registers would admit 3-4 waves per SIMD -- measured slower (bench sed 4.03e7 against
+  // 4.87e7 packets/s): this mode is bound by the xI_scatt atomics, and more waves in flight only deepen their queues.
+  // The LDS of a workgroup is the shared tables plus the per-lane ray-tracing scratch, which grows with the observers.
+  const int cu_threads = 512;
+  int threads = 0;
+  const bool slim = true;                   // (mono_lds_bytes)
+  const int max_threads = 512;              // (__launch_bounds__ of the kernels)
+  if (block_threads > 0 && block_threads <= max_threads && block_threads % 64 == 0) {
+    threads = block_threads;
+  } else {
+    int best_waves = 0;
+    for (int th = max_threads; th >= 64; th -= 64) {
+      const size_t l = mono_lds_bytes(M, A.nRT, th, pola, slim);
+      if (l > 160 * 1024) continue;
+      int per_cu = (int)((160 * 1024) / l);
+      if (per_cu > cu_threads / th) per_cu = cu_threads / th;
+      const int waves = per_cu * th / 64;
+      if (waves > best_waves) { best_waves = waves; threads = th; }
+    }
+    if (!threads) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "too many ray-tracing directions for the LDS of one CU");
+  }
+  const size_t lds = mono_lds_bytes(M, A.nRT, threads, pola, slim);
+  if (lds > 160 * 1024) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "too many ray-tracing directions for the LDS of one CU");
   HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int blocks = grid_blocks;
   if (blocks <= 0) {
