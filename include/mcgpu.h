@@ -427,6 +427,20 @@ int mcgpu_probe_packet_rand(mcgpu_ctx *ctx, uint64_t seed, uint64_t packet,
                             int n, float *out);
 
 /*
+ * Temp_approx_diffusion_vertical (diffusion.f90:292-374; called after Temp_finale at dust_transfer.f90:316 / :659 when
+ * define_dark_zone found a dark zone): the 1+1D diffusion approximation that refills the temperature of the dark
+ * zone, column by column (clean_temperature, temperature_to_DensE, setDiffusion_coeff0/_coeff,
+ * iter_Temp_approx_diffusion_vertical, DensE_to_temperature).  2D cylindrical grids.  tab_lambda / tab_delta_lambda
+ * [n_lambda] in micron (module wavelengths); ri_in_dark_zone(1), ri_out_dark_zone(1), zj_sup_dark_zone(1:n_rad,1) as
+ * define_dark_zone leaves them (optical_depth.f90:1459-1500, 1579-1586; module cylindrical_grid); Tdust[n_cells] in
+ * and out (host).  n_iterations (may be NULL): pseudo-time steps summed over the columns.
+ */
+int mcgpu_temp_approx_diffusion_vertical(mcgpu_ctx *ctx, const double *tab_lambda,
+                                         const double *tab_delta_lambda, int ri_in_dark_zone,
+                                         int ri_out_dark_zone, const int *zj_sup_dark_zone,
+                                         float *Tdust, int *n_iterations);
+
+/*
  * Several GPUs of one node behind ONE host thread -- the reference's host is a single OpenMP
  * process (mcfost.f90; the Phantom caller mcfost2phantom.f90:159), so this is the entry it binds.
  * mcgpu_multi_create opens one context per device and one RCCL communicator over them

@@ -1663,6 +1663,120 @@ __global__ void k_temp_finale(const DevModel M, const double* E_abs, const float
 }
 
 // ---------------------------------------------------------------------------
+// Temp_approx_diffusion_vertical (diffusion.f90:292-374): the 1+1D diffusion fill of the dark zone (2D cylindrical
+// grids).  One workgroup per radius; the column's energy density, its previous value and the diffusion coefficients
+// live in LDS; a pseudo-time step of the explicit scheme is three block-wide phases (time step = minimum over the
+// column, stencil + largest relative change, refresh of the coefficients that moved by more than 10 %).
+//   clean_temperature (:183) is done by the caller's first kernel (k_clean_dark_temperature);
+//   temperature_to_DensE (:131), setDiffusion_coeff0 (:78), iter_Temp_approx_diffusion_vertical (:504),
+//   setDiffusion_coeff (:17), DensE_to_temperature (:162) are the phases below.
+// ---------------------------------------------------------------------------
+constexpr int DELTA_CELL_DARK_ZONE = 3;  // cylindrical_grid.f90:39
+
+__global__ void k_clean_dark_temperature(int n_rad, int ri_in, int ri_out, const int* zj_sup, float T_min, float* Tdust) {
+  const int i = ri_in + blockIdx.x;
+  if (i > ri_out) return;
+  for (int j = 1 + threadIdx.x; j <= zj_sup[i - 1]; j += blockDim.x) Tdust[(i - 1) + n_rad * (j - 1)] = T_min;
+}
+
+// the Rosseland-type sum of setDiffusion_coeff[0] for one cell at temperature Temp
+__device__ inline double diffusion_coeff(const DevModel& M, const double* tab_lambda, const double* tab_delta_lambda,
+                                         int ic, double Temp) {
+  const float thermal_const = (float)(299792458.0 * 6.626070040e-34 / 1.38064852e-23);  // constants.f90:24
+  const double cst_Dcoeff = PI / (double)(12.0f * 5.670367e-8f);                          // pi/(12.*sigma)
+  const double cst = (double)thermal_const / Temp;
+  double total_sum = 0.0;
+  for (int l = 0; l < M.n_lambda; ++l) {
+    const double wl = tab_lambda[l] * (double)1.e-6f;
+    const double delta_wl = tab_delta_lambda[l] * (double)1.e-6f;
+    const double cst_wl = cst / wl;
+    double dB_dT = 0.0;
+    if (cst_wl < 200.0) {
+      const double coeff_exp = exp(cst_wl);
+      const double wl2 = wl * wl, wl5 = (wl2 * wl2) * wl;
+      dB_dT = cst_wl * coeff_exp / (wl5 * ((coeff_exp - 1.0) * (coeff_exp - 1.0)));
+    }
+    total_sum = total_sum + dB_dT / (M.kappa[l] * M.kappa_factor[ic]) * delta_wl;
+  }
+  return cst_Dcoeff * total_sum / (Temp * Temp * Temp);
+}
+
+__global__ void __launch_bounds__(128) k_diffusion_vertical(const DevModel M, const double* tab_lambda,
+                                                            const double* tab_delta_lambda, int i_lo, int i_hi,
+                                                            const int* zj_sup, float* Tdust, int* n_iter_out,
+                                                            int* err) {
+  extern __shared__ double lds_raw[];
+  const int nz = M.nz, n_rad = M.n_rad;
+  double* DensE = lds_raw;            // [0..nz]
+  double* DensE_m1 = DensE + nz + 2;  // [0..nz]
+  double* Dcoeff = DensE_m1 + nz + 2; // [0..nz]
+  __shared__ double red[128];
+  const int i = i_lo + blockIdx.x;
+  if (i > i_hi) return;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  int jtop = zj_sup[i - 1] + DELTA_CELL_DARK_ZONE;
+  if (jtop > nz - 1) jtop = nz - 1;  // the stencil reads j+1
+  const double dz = M.ch[i - 1];     // cell_height(i,j): the uniform vertical grid
+  const double dz2 = dz * dz;
+  for (int j = 1 + tid; j <= nz; j += nt) {
+    const float T = Tdust[(i - 1) + n_rad * (j - 1)];
+    DensE[j] = (double)((T * T) * (T * T));  // Tdust**4 in default real (:151)
+    Dcoeff[j] = diffusion_coeff(M, tab_lambda, tab_delta_lambda, (i - 1) + n_rad * (j - 1), (double)T);
+  }
+  __syncthreads();
+  if (tid == 0) { DensE[0] = DensE[1]; Dcoeff[0] = Dcoeff[1]; }
+  __syncthreads();
+  const float precision = 1.0e-6f, stabilite = 2.0f;
+  int n_iter = 0;
+  for (;;) {
+    n_iter++;
+    // time step: stabilite * 0.5 * min(dz^2 / D) over the zone (:527-534)
+    double tmin = HUGE_DP;
+    for (int j = 1 + tid; j <= jtop; j += nt) tmin = fmin(tmin, dz2 / Dcoeff[j]);
+    red[tid] = tmin;
+    for (int j = tid; j <= nz; j += nt) DensE_m1[j] = DensE[j];
+    __syncthreads();
+    for (int sft = nt >> 1; sft > 0; sft >>= 1) {
+      if (tid < sft) red[tid] = fmin(red[tid], red[tid + sft]);
+      __syncthreads();
+    }
+    const double dt = (double)(stabilite * 0.5f) * red[0];
+    __syncthreads();
+    // one explicit step (:545-583)
+    float dmax = 0.0f;
+    for (int j = 1 + tid; j <= jtop; j += nt) {
+      const double dE_dz_p1 = DensE_m1[j + 1] - DensE_m1[j];
+      const double dE_dz_m1 = DensE_m1[j] - DensE_m1[j - 1];
+      const double delta_E = Dcoeff[j] * (dE_dz_p1 - dE_dz_m1) / (2.0 * dz2) * dt;
+      const double e = DensE_m1[j] + delta_E;
+      DensE[j] = e;
+      const double r = delta_E / e;
+      if (r > (double)dmax) dmax = (float)r;
+    }
+    red[tid] = (double)dmax;
+    __syncthreads();
+    for (int sft = nt >> 1; sft > 0; sft >>= 1) {
+      if (tid < sft) red[tid] = fmax(red[tid], red[tid + sft]);
+      __syncthreads();
+    }
+    const float max_delta_E_r = (float)red[0];
+    if (tid == 0) DensE[0] = DensE[1];  // no flux through the midplane (:586)
+    __syncthreads();
+    if (max_delta_E_r < precision) break;
+    if (n_iter > 50000000) { if (tid == 0) *err = 23; break; }
+    // setDiffusion_coeff (:17-74)
+    for (int j = 1 + tid; j <= nz; j += nt)
+      if (fabs(DensE[j] - DensE_m1[j]) > 1.0e-1 * DensE_m1[j])
+        Dcoeff[j] = diffusion_coeff(M, tab_lambda, tab_delta_lambda, (i - 1) + n_rad * (j - 1), pow(DensE[j], 0.25));
+    __syncthreads();
+    if (tid == 0) Dcoeff[0] = Dcoeff[1];
+    __syncthreads();
+  }
+  for (int j = 1 + tid; j <= jtop; j += nt) Tdust[(i - 1) + n_rad * (j - 1)] = (float)pow(DensE[j], 0.25);
+  if (tid == 0) atomicAdd(n_iter_out, n_iter);
+}
+
+// ---------------------------------------------------------------------------
 // Probes for the parity tests
 // ---------------------------------------------------------------------------
 template <bool L3D, bool SPH = false>

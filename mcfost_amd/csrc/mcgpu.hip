@@ -1276,6 +1276,52 @@ struct DevBuf {
   hipError_t get(Tp* h, size_t n) { return hipMemcpy(h, p, n * sizeof(Tp), hipMemcpyDeviceToHost); }
 };
 
+// Temp_approx_diffusion_vertical (diffusion.f90:292-374, called at dust_transfer.f90:316,659 after Temp_finale when
+// the model has a dark zone): refills the temperature of the dark zone and of delta_cell_dark_zone cells around it.
+extern "C" int mcgpu_temp_approx_diffusion_vertical(mcgpu_ctx* ctx, const double* tab_lambda, const double* tab_delta_lambda,
+                                                    int ri_in_dark_zone, int ri_out_dark_zone, const int* zj_sup_dark_zone,
+                                                    float* Tdust, int* n_iterations) {
+  int rc = ready(ctx);
+  if (rc) return rc;
+  if (!tab_lambda || !tab_delta_lambda || !zj_sup_dark_zone || !Tdust) return fail(ctx, MCGPU_ERR_ARG, "mcgpu_temp_approx_diffusion_vertical: null argument");
+  const DevModel& M = ctx->M;
+  if (ctx->voro || M.l3D || M.grid_sph) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "diffusion approximation: 2D cylindrical grids only");
+  if (ri_in_dark_zone < 1 || ri_out_dark_zone > M.n_rad) return fail(ctx, MCGPU_ERR_ARG, "dark-zone radii out of range");
+  for (int i = 0; i < M.n_rad; ++i)
+    if (zj_sup_dark_zone[i] < 0 || zj_sup_dark_zone[i] > M.nz) return fail(ctx, MCGPU_ERR_ARG, "zj_sup_dark_zone out of range");
+  HIPCHK(hipSetDevice(ctx->device));
+  DevBuf<double> d_lam, d_dl;
+  DevBuf<int> d_zj, d_it;
+  DevBuf<float> d_T;
+  HIPCHK(d_lam.alloc(M.n_lambda)); HIPCHK(d_lam.put(tab_lambda, M.n_lambda));
+  HIPCHK(d_dl.alloc(M.n_lambda)); HIPCHK(d_dl.put(tab_delta_lambda, M.n_lambda));
+  HIPCHK(d_zj.alloc(M.n_rad)); HIPCHK(d_zj.put(zj_sup_dark_zone, M.n_rad));
+  HIPCHK(d_it.alloc(1)); HIPCHK(hipMemset(d_it.p, 0, sizeof(int)));
+  HIPCHK(d_T.alloc(M.n_cells)); HIPCHK(d_T.put(Tdust, M.n_cells));
+  HIPCHK(hipMemsetAsync(ctx->d_err, 0, sizeof(int), ctx->stream));
+  if (ri_out_dark_zone >= ri_in_dark_zone) {
+    hipLaunchKernelGGL(k_clean_dark_temperature, dim3(ri_out_dark_zone - ri_in_dark_zone + 1), dim3(64), 0, ctx->stream,
+                       M.n_rad, ri_in_dark_zone, ri_out_dark_zone, d_zj.p, ctx->T_min, d_T.p);
+    HIPCHK(hipGetLastError());
+  }
+  const int i_lo = ri_in_dark_zone - DELTA_CELL_DARK_ZONE > 3 ? ri_in_dark_zone - DELTA_CELL_DARK_ZONE : 3;
+  const int i_hi = ri_out_dark_zone + DELTA_CELL_DARK_ZONE < M.n_rad - 2 ? ri_out_dark_zone + DELTA_CELL_DARK_ZONE : M.n_rad - 2;
+  if (i_hi >= i_lo) {
+    const size_t lds = (size_t)3 * (M.nz + 2) * sizeof(double);
+    hipLaunchKernelGGL(k_diffusion_vertical, dim3(i_hi - i_lo + 1), dim3(128), lds, ctx->stream, M, d_lam.p, d_dl.p, i_lo, i_hi,
+                       d_zj.p, d_T.p, d_it.p, ctx->d_err);
+    HIPCHK(hipGetLastError());
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  int herr = 0;
+  HIPCHK(hipMemcpy(&herr, ctx->d_err, sizeof(int), hipMemcpyDeviceToHost));
+  if (herr) return fail(ctx, MCGPU_ERR_KERNEL, "diffusion approximation did not converge");
+  HIPCHK(d_T.get(Tdust, M.n_cells));
+  if (n_iterations) HIPCHK(d_it.get(n_iterations, 1));
+  return MCGPU_OK;
+}
+
+
 // ---------------------------------------------------------------------------------------------
 // RT1 ray-traced dust SED (mc_raytrace.hip.h)
 // ---------------------------------------------------------------------------------------------

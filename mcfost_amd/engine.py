@@ -35,7 +35,7 @@ ABI_SYMBOLS = (
     "mcgpu_probe_cross_voronoi", "mcgpu_set_rt1", "mcgpu_run_mono", "mcgpu_fetch_xI",
     "mcgpu_device_xI", "mcgpu_set_ism", "mcgpu_rt1_dust_map", "mcgpu_set_xI", "mcgpu_rt1_image", "mcgpu_set_xI_precision",
     "mcgpu_get_xI_precision", "mcgpu_set_option", "mcgpu_counters_to_accum", "mcgpu_counters_from_accum",
-    "mcgpu_set_grid_sph", "mcgpu_multi_create", "mcgpu_multi_destroy", "mcgpu_multi_size", "mcgpu_multi_ctx", "mcgpu_multi_last_error",
+    "mcgpu_set_grid_sph", "mcgpu_temp_approx_diffusion_vertical", "mcgpu_multi_create", "mcgpu_multi_destroy", "mcgpu_multi_size", "mcgpu_multi_ctx", "mcgpu_multi_last_error",
     "mcgpu_shard_packets", "mcgpu_multi_run_thermal",
 )
 
@@ -297,6 +297,17 @@ class Engine:
         t_acc = torch.as_tensor(_DevArray(acc.value, n.value, "<f8"), device=dev)
         t_cnt = torch.as_tensor(_DevArray(cnt.value, N_COUNTERS, "<i8"), device=dev)
         return t_acc, t_cnt
+
+    def temp_approx_diffusion_vertical(self, Tdust, ri_in, ri_out, zj_sup):
+        """``Temp_approx_diffusion_vertical`` (diffusion.f90:292-374) on the device: returns (Tdust, iterations)."""
+        m = self.model
+        T = np.array(Tdust, np.float32)
+        n_it = C.c_int()
+        self._chk(self.lib.mcgpu_temp_approx_diffusion_vertical(
+            self.ctx, _p(_a(m.lam, np.float64), C.c_double), _p(_a(m.delta_lam, np.float64), C.c_double),
+            C.c_int(int(ri_in)), C.c_int(int(ri_out)), _p(_a(zj_sup, np.int32), C.c_int), _p(T, C.c_float),
+            C.byref(n_it)), "mcgpu_temp_approx_diffusion_vertical")
+        return T, n_it.value
 
     def allreduce_device(self, all_reduce):
         """ONE collective per temperature iteration: the counters join the fused accumulator as doubles

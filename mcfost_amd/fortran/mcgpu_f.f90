@@ -68,7 +68,7 @@ module mcgpu_f
        mcgpu_run_thermal, mcgpu_temp_finale, mcgpu_thermal_loop, mcgpu_error_message, mcgpu_set_rt1, &
        mcgpu_run_mono, mcgpu_fetch, mcgpu_fetch_xI, mcgpu_rt1_dust_map, mcgpu_set_xI, mcgpu_rt1_image, mcgpu_set_xI_precision, &
        mcgpu_set_E_prior, mcgpu_multi_create, mcgpu_multi_destroy, mcgpu_multi_size, mcgpu_multi_ctx, mcgpu_multi_run_thermal, &
-       mcgpu_counters_to_accum, mcgpu_counters_from_accum
+       mcgpu_counters_to_accum, mcgpu_counters_from_accum, mcgpu_temp_approx_diffusion_vertical
 
   interface
      integer(c_int) function mcgpu_create(device, ctx) bind(C, name="mcgpu_create")
@@ -205,6 +205,19 @@ module mcgpu_f
        type(c_ptr), value :: ctx
        real(c_double), intent(in) :: E_prior(*)
      end function mcgpu_set_E_prior
+
+     ! Temp_approx_diffusion_vertical (diffusion.f90:292): tab_lambda / tab_delta_lambda of module wavelengths,
+     ! ri_in_dark_zone(1), ri_out_dark_zone(1), zj_sup_dark_zone(:,1) of module cylindrical_grid, Tdust in/out
+     integer(c_int) function mcgpu_temp_approx_diffusion_vertical(ctx, tab_lambda, tab_delta_lambda, ri_in_dark_zone, &
+          ri_out_dark_zone, zj_sup_dark_zone, Tdust, n_iterations) bind(C, name="mcgpu_temp_approx_diffusion_vertical")
+       import :: c_int, c_ptr, c_double, c_float
+       type(c_ptr), value :: ctx
+       real(c_double), intent(in) :: tab_lambda(*), tab_delta_lambda(*)
+       integer(c_int), value :: ri_in_dark_zone, ri_out_dark_zone
+       integer(c_int), intent(in) :: zj_sup_dark_zone(*)
+       real(c_float), intent(inout) :: Tdust(*)
+       integer(c_int), intent(out) :: n_iterations
+     end function mcgpu_temp_approx_diffusion_vertical
 
      ! ---- several GPUs behind this one host thread (include/mcgpu.h: mcgpu_multi_*) ---------------------------
      ! devices: c_null_ptr = devices 0..n_dev-1, or c_loc of an integer(c_int) array

@@ -678,6 +678,42 @@ def init_directions_ray_tracing(cfg: DiskConfig, l3D: bool):
                 N_type_flux=ntf, lsepar_contrib=int(cfg.lsepar_contrib))
 
 
+def dark_zone_extent(m: "Model", lam: int, tau_max: float = 1500.0):
+    """Steps 1-3 of ``define_dark_zone`` (optical_depth.f90:1459-1500, 1621-1628) on a 2D cylindrical grid: the radii
+    ``ri_in_dark_zone`` / ``ri_out_dark_zone`` where the midplane optical depth at wavelength ``lam`` (1-based) exceeds
+    ``tau_max`` from either side, and per radius the topmost layer ``zj_sup_dark_zone`` below which the vertical
+    optical depth from the surface does.  The sums run in default real like the reference's ``total_sum``."""
+    g = m.grid
+    n_rad, nz = g["n_rad"], g["nz"]
+    kap = float(m.kappa[lam - 1]) * np.asarray(m.kappa_factor, np.float64).reshape(-1)[:n_rad * nz].reshape(nz, n_rad)
+    r_lim = np.asarray(g["r_lim"], np.float64)
+    z_lim = np.asarray(g["z_lim"], np.float64).reshape(nz + 2, n_rad)[:nz + 1]
+    tmax = np.float32(tau_max)
+
+    def first_over(terms):
+        tot = np.float32(0.0)
+        for k, t in enumerate(terms):
+            tot = np.float32(np.float64(tot) + t)
+            if tot > tmax:
+                return k
+        return None
+
+    k = first_over(kap[0] * np.diff(r_lim))
+    ri_in = n_rad if k is None else k + 1
+    k = first_over((kap[0] * np.diff(r_lim))[::-1])
+    ri_out = 1 if k is None else n_rad - k
+    if ri_out == n_rad:
+        ri_out = n_rad - 1
+    zj = np.zeros(n_rad, np.int32)
+    for i in range(ri_in, ri_out + 1):
+        k = first_over((kap[:, i - 1] * np.diff(z_lim[:, i - 1]))[::-1])
+        zj[i - 1] = 0 if k is None else nz - k
+    if ri_in <= ri_out:
+        zj[:ri_in - 1] = zj[ri_in - 1]
+        zj[ri_out:] = zj[ri_out - 1]
+    return ri_in, ri_out, zj
+
+
 def repartition_energie(m: "Model", Tdust):
     """thermal_emission.f90:1771-1949 for every wavelength (LTE grains, no ISM field, no
     emission weights): fills ``frac_E_stars``, ``frac_E_disk`` and ``prob_E_cell`` of the model

@@ -30,6 +30,9 @@ class EngineBackend:
     def temp_finale(self, E_abs):
         return self.e.temp_finale(E_abs)
 
+    def temp_approx_diffusion_vertical(self, Tdust, ri_in, ri_out, zj_sup):
+        return self.e.temp_approx_diffusion_vertical(Tdust, ri_in, ri_out, zj_sup)[0]
+
     def run_mono(self, lam, n2, seed, n_chunks):
         return self.e.run_mono(lam, n2, seed=seed, n_chunks=n_chunks, fetch_xI=False)
 
@@ -38,7 +41,7 @@ class EngineBackend:
 
 
 def temperature_and_sed(backend, m, n_thermal, n_photons_lambda, lambdas=None, seed=1, n_chunks=None,
-                        ray_tracing=True):
+                        ray_tracing=True, diff_approx=None):
     """Returns Tdust, the nine Monte Carlo SED arrays ``sed_mc`` (9, N_phi, N_thet, n_lambda), ``n_sent``
     (packets sent per wavelength in the SED step), ``sed_rt`` (n_lambda, nRT, N_type_flux; dust only) and the
     wall time of each stage."""
@@ -47,6 +50,10 @@ def temperature_and_sed(backend, m, n_thermal, n_photons_lambda, lambdas=None, s
     th = backend.run_thermal(int(n_thermal), seed)
     Tdust = backend.temp_finale(th["E_abs"])
     t["thermal"] = time.perf_counter() - t0
+    if diff_approx is not None:  # ldiff_approx with a dark zone: dust_transfer.f90:316 / :659
+        t0 = time.perf_counter()
+        Tdust = backend.temp_approx_diffusion_vertical(Tdust, *diff_approx)
+        t["diffusion"] = time.perf_counter() - t0
     t0 = time.perf_counter()
     M.repartition_energie(m, Tdust)
     t["repartition_energie"] = time.perf_counter() - t0

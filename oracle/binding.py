@@ -340,6 +340,34 @@ class Oracle:
             raise RuntimeError(f"oracle_define_dark_zone failed: {rc}")
         return out
 
+    def dark_zone_extent(self, lam, tau_max):
+        """(ri_in, ri_out, zj_sup[n_rad]) of define_dark_zone's steps 1-3 (optical_depth.f90:1459-1500, 1579-1586)."""
+        m = self.model
+        rl = _a(m.grid["r_lim"], np.float64)
+        a, b = C.c_int(), C.c_int()
+        zs = np.zeros(m.grid["n_rad"], np.int32)
+        self.lib.oracle_dark_zone_extent.restype = C.c_int
+        rc = self.lib.oracle_dark_zone_extent(C.byref(self.cm), C.c_int(int(lam)), C.c_double(float(tau_max)),
+                                              _p(rl, C.c_double), C.byref(a), C.byref(b), _p(zs, C.c_int))
+        if rc:
+            raise RuntimeError(f"oracle_dark_zone_extent failed: {rc}")
+        return a.value, b.value, zs
+
+    def temp_approx_diffusion_vertical(self, Tdust, ri_in, ri_out, zj_sup):
+        """Temp_approx_diffusion_vertical (diffusion.f90:292-374): returns (Tdust after the fill, iterations)."""
+        m = self.model
+        T = np.array(Tdust, np.float32)
+        lam, dl = _a(m.lam, np.float64), _a(m.delta_lam, np.float64)
+        zs = _a(zj_sup, np.int32)
+        n_it = C.c_int()
+        self.lib.oracle_temp_approx_diffusion_vertical.restype = C.c_int
+        rc = self.lib.oracle_temp_approx_diffusion_vertical(C.byref(self.cm), _p(lam, C.c_double), _p(dl, C.c_double),
+                                                            C.c_int(int(ri_in)), C.c_int(int(ri_out)), _p(zs, C.c_int),
+                                                            _p(T, C.c_float), C.byref(n_it))
+        if rc:
+            raise RuntimeError(f"oracle_temp_approx_diffusion_vertical failed: {rc}")
+        return T, n_it.value
+
     # -- Voronoi operators ---------------------------------------------------
     def cross_voronoi(self, x0, y0, z0, u, v, w, cell, prev):
         n = len(cell)

@@ -1985,14 +1985,157 @@ int oracle_define_dark_zone(const oracle_model *m, int lambda, double tau_max_in
   return 0;
 }
 
-/* ------------------------------------------------------------------------ */
-/* Ray-traced SED of the dust, RT method 1 (dust_transfer.f90:1413-1600)      */
-/* ------------------------------------------------------------------------ */
 #define ORC_PC_TO_AU (648000.0 / PI)           /* constants.f90:91 */
 #define ORC_AU_TO_CM (149597870700.0 * 100.0)  /* constants.f90:62-65 */
 #define ORC_HP 6.626070040e-34
 #define ORC_C_LIGHT 299792458.0
 #define ORC_KB 1.38064852e-23
+
+/* Steps 1-3 of define_dark_zone (optical_depth.f90:1459-1500) and the extension of zj_sup to the radii outside
+ * [ri_in, ri_out] (:1579-1586): the extent of the zone the diffusion approximation refills (2D cylindrical).
+ * zj_sup[i-1], i = 1..n_rad (0 where the reference leaves it: mem.f90:169). */
+int oracle_dark_zone_extent(const oracle_model *m, int lambda, double tau_max_in, const double *r_lim, int *ri_in_out,
+                            int *ri_out_out, int *zj_sup) {
+  if (m->l3D || m->grid_type != 1) return 31;
+  const int n_rad = m->n_rad, nz = m->nz;
+  const float tau_max = (float)tau_max_in;
+  const double kap = m->kappa[lambda - 1];
+  int ri_in = n_rad, ri_out = 1;
+  float total = 0.0f;
+  for (int i = 0; i < n_rad; ++i) zj_sup[i] = 0;
+  for (int i = 1; i <= n_rad; ++i) {
+    total = (float)((double)total + kap * m->kappa_factor[i - 1] * (r_lim[i] - r_lim[i - 1]));
+    if (total > tau_max) { ri_in = i; break; }
+  }
+  total = 0.0f;
+  for (int i = n_rad; i >= 1; --i) {
+    total = (float)((double)total + kap * m->kappa_factor[i - 1] * (r_lim[i] - r_lim[i - 1]));
+    if (total > tau_max) { ri_out = i; break; }
+  }
+  if (ri_out == n_rad) ri_out = n_rad - 1;
+  for (int i = ri_in; i <= ri_out; ++i) {
+    total = 0.0f;
+    for (int j = nz; j >= 1; --j) {
+      const int icell = i + n_rad * (j - 1);
+      const double dzl = m->z_lim[(i - 1) + (size_t)n_rad * j] - m->z_lim[(i - 1) + (size_t)n_rad * (j - 1)];
+      total = (float)((double)total + kap * m->kappa_factor[icell - 1] * dzl);
+      if (total > tau_max) { zj_sup[i - 1] = j; break; }
+    }
+  }
+  if (ri_in <= ri_out) {
+    for (int i = 1; i < ri_in; ++i) zj_sup[i - 1] = zj_sup[ri_in - 1];
+    for (int i = ri_out + 1; i <= n_rad; ++i) zj_sup[i - 1] = zj_sup[ri_out - 1];
+  }
+  *ri_in_out = ri_in; *ri_out_out = ri_out;
+  return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Temp_approx_diffusion_vertical (diffusion.f90:292-374) with clean_temperature (:183), temperature_to_DensE        */
+/* (:131), setDiffusion_coeff0 (:78), iter_Temp_approx_diffusion_vertical (:504), setDiffusion_coeff (:17) and        */
+/* DensE_to_temperature (:162): the 1+1D diffusion fill of the dark zone, 2D cylindrical grids.  PARITY UNPINNED      */
+/* (module diffusion uses dust_prop / thermal_emission, unbuildable here); known-answer tests in tests/.               */
+/* ------------------------------------------------------------------------ */
+#define ORC_DELTA_CELL_DARK_ZONE 3 /* cylindrical_grid.f90:39 */
+
+/* the Rosseland-type sum of setDiffusion_coeff[0] for one cell at temperature Temp */
+static double diffusion_coeff(const oracle_model *m, const double *tab_lambda, const double *tab_delta_lambda,
+                              int icell, double Temp) {
+  const float thermal_const = (float)(ORC_C_LIGHT * ORC_HP / ORC_KB);            /* constants.f90:24, default real */
+  const double cst_Dcoeff = PI / (double)(12.0f * 5.670367e-8f);                  /* pi/(12.*sigma), sigma default real */
+  const double cst = (double)thermal_const / Temp;
+  double total_sum = 0.0;
+  for (int l = 0; l < m->n_lambda; ++l) {
+    const double wl = tab_lambda[l] * (double)1.e-6f;
+    const double delta_wl = tab_delta_lambda[l] * (double)1.e-6f;
+    const double cst_wl = cst / wl;
+    double dB_dT;
+    if (cst_wl < 200.0) {
+      const double coeff_exp = exp(cst_wl);
+      const double wl2 = wl * wl, wl5 = (wl2 * wl2) * wl; /* wl**5 */
+      dB_dT = cst_wl * coeff_exp / (wl5 * ((coeff_exp - 1.0) * (coeff_exp - 1.0)));
+    } else {
+      dB_dT = 0.0;
+    }
+    total_sum = total_sum + dB_dT / (m->kappa[l] * m->kappa_factor[icell - 1]) * delta_wl;
+  }
+  return cst_Dcoeff * total_sum / (Temp * Temp * Temp);
+}
+
+int oracle_temp_approx_diffusion_vertical(const oracle_model *m, const double *tab_lambda,
+                                          const double *tab_delta_lambda, int ri_in, int ri_out, const int *zj_sup,
+                                          float *Tdust, int *n_iter_out) {
+  if (m->l3D || m->grid_type != 1) return 31;
+  const int n_rad = m->n_rad, nz = m->nz, dcz = ORC_DELTA_CELL_DARK_ZONE;
+  /* clean_temperature (:183-199) */
+  for (int i = ri_in; i <= ri_out; ++i)
+    for (int j = 1; j <= zj_sup[i - 1]; ++j) Tdust[i + n_rad * (j - 1) - 1] = m->T_min;
+  double *DensE = (double *)calloc((size_t)nz + 2, sizeof(double));
+  double *DensE_m1 = (double *)calloc((size_t)nz + 2, sizeof(double));
+  double *Dcoeff = (double *)calloc((size_t)nz + 2, sizeof(double));
+  if (!DensE || !DensE_m1 || !Dcoeff) { free(DensE); free(DensE_m1); free(Dcoeff); return 22; }
+  const int i_lo = (ri_in - dcz > 3) ? ri_in - dcz : 3, i_hi = (ri_out + dcz < n_rad - 2) ? ri_out + dcz : n_rad - 2;
+  int n_iter_total = 0;
+  for (int i = i_lo; i <= i_hi; ++i) {
+    const float precision = 1.0e-6f;
+    const float stabilite = 2.0f;
+    int jtop = zj_sup[i - 1] + dcz;
+    if (jtop > nz - 1) jtop = nz - 1; /* the stencil reads j+1 */
+    /* temperature_to_DensE (:131-158): Tdust**4 in default real */
+    for (int j = 1; j <= nz; ++j) {
+      const float T = Tdust[i + n_rad * (j - 1) - 1];
+      DensE[j] = (double)((T * T) * (T * T));
+    }
+    DensE[0] = DensE[1];
+    memcpy(DensE_m1, DensE, ((size_t)nz + 1) * sizeof(double));
+    /* setDiffusion_coeff0 (:78-127) */
+    for (int j = 1; j <= nz; ++j)
+      Dcoeff[j] = diffusion_coeff(m, tab_lambda, tab_delta_lambda, i + n_rad * (j - 1), (double)Tdust[i + n_rad * (j - 1) - 1]);
+    int n_iter = 0;
+    for (;;) {
+      n_iter++;
+      /* iter_Temp_approx_diffusion_vertical (:504-594) */
+      double dt_min = 1.79769313486231570815e+308;
+      for (int j = 1; j <= jtop; ++j) {
+        const double dz = m->z_lim[(i - 1) + (size_t)n_rad]; /* cell_height(i,j) = zmax(i)/nz = z_lim(i,2), cylindrical_grid.f90:459-463 */
+        const double t = dz * dz / Dcoeff[j];
+        if (t < dt_min) dt_min = t;
+      }
+      const double dt = (double)(stabilite * 0.5f) * dt_min;
+      memcpy(DensE_m1, DensE, ((size_t)nz + 1) * sizeof(double));
+      float max_delta_E_r = 0.0f;
+      for (int j = 1; j <= jtop; ++j) {
+        const double dz = m->z_lim[(i - 1) + (size_t)n_rad]; /* cell_height(i,j) = zmax(i)/nz = z_lim(i,2), cylindrical_grid.f90:459-463 */
+        const double dE_dz_p1 = DensE_m1[j + 1] - DensE_m1[j];
+        const double dE_dz_m1 = DensE_m1[j] - DensE_m1[j - 1];
+        const double d2E_dz2 = Dcoeff[j] * (dE_dz_p1 - dE_dz_m1) / (2.0 * (dz * dz));
+        const double delta_E = d2E_dz2 * dt;
+        DensE[j] = DensE_m1[j] + delta_E;
+        const double delta_E_r = delta_E / DensE[j];
+        if (delta_E_r > (double)max_delta_E_r) max_delta_E_r = (float)delta_E_r;
+      }
+      DensE[0] = DensE[1];
+      if (max_delta_E_r < precision) break;
+      if (n_iter > 50000000) { free(DensE); free(DensE_m1); free(Dcoeff); return 23; }
+      /* setDiffusion_coeff (:17-74): refreshed where the energy density moved by more than 10 % in this step */
+      for (int j = 1; j <= nz; ++j) {
+        if (fabs(DensE[j] - DensE_m1[j]) > 1.0e-1 * DensE_m1[j])
+          Dcoeff[j] = diffusion_coeff(m, tab_lambda, tab_delta_lambda, i + n_rad * (j - 1), pow(DensE[j], (double)0.25f));
+      }
+      Dcoeff[0] = Dcoeff[1];
+    }
+    n_iter_total += n_iter;
+    /* DensE_to_temperature (:162-179) */
+    for (int j = 1; j <= jtop; ++j) Tdust[i + n_rad * (j - 1) - 1] = (float)pow(DensE[j], (double)0.25f);
+  }
+  if (n_iter_out) *n_iter_out = n_iter_total;
+  free(DensE); free(DensE_m1); free(Dcoeff);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Ray-traced SED of the dust, RT method 1 (dust_transfer.f90:1413-1600)      */
+/* ------------------------------------------------------------------------ */
 
 /* rotation_3d (utils.f90:1545-1589) */
 static void rotation_3d(const double axis[3], double angle_deg, const double v[3], double out[3]) {

@@ -284,6 +284,16 @@ int oracle_dust_map_image(const oracle_model *m, const oracle_rt_opts *o, int np
 int oracle_define_dark_zone(const oracle_model *m, int lambda, double tau_max, const double *r_lim,
                             const double *r_grid, const double *z_grid, unsigned char *l_dark_zone);
 
+/* Steps 1-3 of define_dark_zone + the extension of zj_sup (optical_depth.f90:1459-1500, 1579-1586): the extent of
+ * the zone the diffusion approximation refills; zj_sup[n_rad]. */
+int oracle_dark_zone_extent(const oracle_model *m, int lambda, double tau_max, const double *r_lim, int *ri_in,
+                            int *ri_out, int *zj_sup);
+/* Temp_approx_diffusion_vertical (diffusion.f90:292-374): the 1+1D diffusion fill of the dark zone; tab_lambda /
+ * tab_delta_lambda in micron; Tdust[n_cells] in and out.  PARITY UNPINNED (known-answer tests). */
+int oracle_temp_approx_diffusion_vertical(const oracle_model *m, const double *tab_lambda,
+                                          const double *tab_delta_lambda, int ri_in, int ri_out, const int *zj_sup,
+                                          float *Tdust, int *n_iter);
+
 /* Voronoi grid operators (Voronoi.f90). */
 void oracle_cross_voronoi_cell(const oracle_model *m, double x, double y,
                                double z, double u, double v, double w,

@@ -1,0 +1,114 @@
+"""The 1+1D diffusion fill of the dark zone (``Temp_approx_diffusion_vertical``, diffusion.f90:292-374) and the
+extent of the zone it works on (``define_dark_zone`` steps 1-3, optical_depth.f90:1459-1500, 1621-1628).
+
+PARITY UNPINNED: module ``diffusion`` pulls dust_prop / thermal_emission / the parameter file reader and cannot be
+built here (oracle/ref_build/README), and the reference holds no fixture for it.  The oracle restates the routine
+line by line; these tests pin it with known answers (the steady state of the scheme, the maximum principle, the cells
+it may touch) and the device against the oracle."""
+import numpy as np
+import pytest
+
+from mcfost_amd.host import model as M
+from oracle import Oracle
+
+
+def thick_disk():
+    cfg = M.small(n_rad=30, nz=20, dust_mass=1e-2)
+    m = M.build_model(cfg)
+    lam = int(np.argmin(np.abs(m.lam - 0.81))) + 1
+    return m, lam
+
+
+def test_dark_zone_extent_known_answer():
+    m, lam = thick_disk()
+    o = Oracle(m, 1000)
+    ri_in, ri_out, zj = o.dark_zone_extent(lam, 1500.0)
+    g, n_rad, nz = m.grid, m.grid["n_rad"], m.grid["nz"]
+    kap = m.kappa[lam - 1] * np.asarray(m.kappa_factor).reshape(nz, n_rad)  # [j, i]
+    dr = np.diff(g["r_lim"])
+    tau_r = np.cumsum(kap[0] * dr)
+    assert ri_in == 1 + int(np.argmax(tau_r > 1500.0)) and ri_in >= 2          # étape 1
+    tau_r_out = np.cumsum((kap[0] * dr)[::-1])
+    assert ri_out == min(n_rad - int(np.argmax(tau_r_out > 1500.0)), n_rad - 1)  # étape 2
+    z_lim = np.asarray(g["z_lim"]).reshape(nz + 2, n_rad)[:nz + 1]
+    for i in range(ri_in, ri_out + 1):                                          # étape 3: from the top down
+        tau_z = np.cumsum((kap[:, i - 1] * np.diff(z_lim[:, i - 1]))[::-1])
+        want = nz - int(np.argmax(tau_z > 1500.0)) if tau_z[-1] > 1500.0 else 0
+        assert zj[i - 1] == want, (i, zj[i - 1], want)
+    assert np.all(zj[:ri_in - 1] == zj[ri_in - 1]) and np.all(zj[ri_out:] == zj[ri_out - 1])  # :1621-1628
+    assert M.dark_zone_extent(m, lam, 1500.0)[:2] == (ri_in, ri_out)
+    assert np.array_equal(M.dark_zone_extent(m, lam, 1500.0)[2], zj)
+
+
+def surface_temperature(m):
+    """A smooth stand-in for the Monte Carlo temperature: falls with radius and rises with height."""
+    n_rad, nz = m.grid["n_rad"], m.grid["nz"]
+    i = np.arange(n_rad)[None, :]
+    j = np.arange(nz)[:, None]
+    return (120.0 * (1.0 + i) ** -0.4 * (1.0 + 0.08 * j)).astype(np.float32).ravel()
+
+
+def test_fill_known_answers():
+    m, lam = thick_disk()
+    o = Oracle(m, 1000)
+    ri_in, ri_out, zj = o.dark_zone_extent(lam, 1500.0)
+    n_rad, nz = m.grid["n_rad"], m.grid["nz"]
+    T0 = surface_temperature(m)
+    T1, n_it = o.temp_approx_diffusion_vertical(T0, ri_in, ri_out, zj)
+    A, B = T0.reshape(nz, n_rad), T1.reshape(nz, n_rad)
+    i_lo, i_hi = max(ri_in - 3, 3), min(ri_out + 3, n_rad - 2)
+    assert n_it > 0
+    for i in range(1, n_rad + 1):
+        top = zj[i - 1] + 3
+        col0, col1 = A[:, i - 1], B[:, i - 1]
+        if i_lo <= i <= i_hi:
+            # above the zone (+ delta_cell_dark_zone) nothing moves; inside, the steady state of a column with a
+            # no-flux midplane and the Monte Carlo temperature on top is isothermal at that temperature
+            assert np.array_equal(col1[top:], col0[top:])
+            assert np.allclose(col1[:top], col0[top], rtol=2e-3), (i, col1[:top + 1])
+            assert np.all(np.diff(col1[:top + 1]) >= -1e-6 * col0[top])        # monotone towards the boundary
+        else:
+            # columns outside [ri_in-3, ri_out+3] (and the first two / last two radii) are only cleaned
+            clean = np.zeros(nz, bool)
+            if ri_in <= i <= ri_out:
+                clean[:zj[i - 1]] = True
+            assert np.array_equal(col1[~clean], col0[~clean]) and np.all(col1[clean] == np.float32(m.cfg.T_min))
+
+
+def test_fill_is_a_fixed_point_of_an_isothermal_column():
+    """DensE uniform -> every difference in the stencil is exactly 0 -> one iteration, temperature unchanged to the
+    rounding of T -> T^4 -> T."""
+    m, lam = thick_disk()
+    o = Oracle(m, 1000)
+    ri_in, ri_out, zj = o.dark_zone_extent(lam, 1500.0)
+    T0 = np.full(m.n_cells, 40.0, np.float32)
+    T1, n_it = o.temp_approx_diffusion_vertical(T0, ri_in, ri_out, np.zeros_like(zj))  # nothing cleaned
+    assert np.allclose(T1, 40.0, rtol=1e-6)
+    assert n_it == min(ri_out + 3, m.grid["n_rad"] - 2) - max(ri_in - 3, 3) + 1        # one step per column
+
+
+@pytest.mark.gpu
+def test_device_fill_against_the_oracle():
+    from mcfost_amd.engine import Engine
+    m, lam = thick_disk()
+    o = Oracle(m, 1000)
+    ri_in, ri_out, zj = o.dark_zone_extent(lam, 1500.0)
+    T0 = surface_temperature(m)
+    want, it_o = o.temp_approx_diffusion_vertical(T0, ri_in, ri_out, zj)
+    e = Engine(m, 1000)
+    got, it_d = e.temp_approx_diffusion_vertical(T0, ri_in, ri_out, zj)
+    assert abs(it_d - it_o) <= 0.01 * it_o + 2, (it_d, it_o)   # exp / pow differ by an ulp: the stopping step may move
+    assert np.allclose(got, want, rtol=2e-5), np.abs(got / want - 1).max()
+    changed = got != T0
+    assert changed.any() and np.array_equal(changed, want != T0)
+    e.close()
+
+
+@pytest.mark.gpu
+def test_device_fill_rejects_what_the_reference_does_not_do():
+    from mcfost_amd.engine import Engine, McgpuError
+    m3 = M.build_model(M.small(n_rad=12, nz=6, n_az=8, l3D=True))
+    e = Engine(m3, 1000)
+    with pytest.raises(McgpuError):
+        e.temp_approx_diffusion_vertical(np.ones(m3.n_cells, np.float32), 3, 5, np.zeros(12, np.int32))
+    e.close()
