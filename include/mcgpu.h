@@ -51,7 +51,7 @@ enum {
 #define MCGPU_N_SED_TYPES 9 /* sed, sed_q, sed_u, sed_v, n_phot_sed, sed_star,
                                sed_star_scat, sed_disk, sed_disk_scat
                                (output.f90:572-592, allocate_sed :103)       */
-#define MCGPU_N_COUNTERS 8
+#define MCGPU_N_COUNTERS 10
 enum {
   MCGPU_CNT_PACKETS = 0,   /* packets launched (sum of n_phot_envoyes)       */
   MCGPU_CNT_CROSSINGS = 1, /* cross_cell evaluations                         */
@@ -60,7 +60,9 @@ enum {
   MCGPU_CNT_ABS = 4,
   MCGPU_CNT_ESCAPED = 5,
   MCGPU_CNT_KILLED_STAR = 6,
-  MCGPU_CNT_DARK = 7
+  MCGPU_CNT_DARK = 7,
+  MCGPU_CNT_MRW_WALKS = 8, /* modified random walks (mcgpu_set_mrw)            */
+  MCGPU_CNT_MRW_STEPS = 9  /* sphere steps of those walks                      */
 };
 
 /* Device context on HIP device `device` (one per process/rank). */
@@ -425,6 +427,27 @@ int mcgpu_probe_philox(mcgpu_ctx *ctx, const uint32_t ctr[4],
                        const uint32_t key[2], uint32_t out[4]);
 int mcgpu_probe_packet_rand(mcgpu_ctx *ctx, uint64_t seed, uint64_t packet,
                             int n, float *out);
+
+/*
+ * Modified random walk (module MRW, MRW.f90; the call site dust_transfer.f90:1222-1239 is commented out in the
+ * reference and make_MRW_step, MRW.f90:74-115, is an unfinished stub: this is the working form of what they
+ * describe -- Min et al. 2009, Robitaille 2010 -- see DESIGN.md; PARITY UNPINNED, validated against the brute-force
+ * loop).  2D cylindrical grids, thermal step.  After more than n_interactions (reference: 5) interactions in a row
+ * whose flights never left the cell, a packet that its cell has just re-emitted walks: while the distance d to the
+ * closest wall (distance_to_closest_wall_cyl, cylindrical_grid.f90:1179) times the cell's mean extinction exceeds
+ * gamma (gamma_MRW = 2, MRW.f90:11) it jumps to a random point of the sphere of radius d and deposits the energy of
+ * the path  -log(y) (3/pi^2) chi (d + ext)^2,  zeta(y) uniform (MRW.f90:12,93-99); then it leaves as a thermal packet.
+ *   zeta[n_zeta]     initialize_cumulative_zeta's table (MRW.f90:16-53), y_i = i/(n_zeta-1)
+ *   chi[n_T]         mean transport extinction at tab_Temp, reference cell (the engine scales by kappa_factor):
+ *                    what compute_Planck_opacities (diffusion.f90:631) calls rec_Planck_opacity
+ *   kappa_dep[n_T]   mean of kappa_abs_LTE with which the walk's path deposits ("Planck_opacity")
+ *   ext[n_T]         length added to d in the path (zeros: the formula of MRW.f90:99 as written)
+ *   r_lim[n_rad+1]   cylindrical_grid's r_lim(0:n_rad)
+ * n_zeta = 0 switches the walk off.  Counters 8 and 9 count walks and sphere steps.
+ */
+int mcgpu_set_mrw(mcgpu_ctx *ctx, int n_zeta, const double *zeta, const double *chi,
+                  const double *kappa_dep, const double *ext, double gamma, int n_interactions,
+                  const double *r_lim);
 
 /*
  * Temp_approx_diffusion_vertical (diffusion.f90:292-374; called after Temp_finale at dust_transfer.f90:316 / :659 when

@@ -128,10 +128,19 @@ struct DevModel {
   int midplane_snap;
   // interstellar radiation field: emitting sphere (stars.f90:27-28); R_ISM = 0: no ISM emission
   double R_ISM, centre_ISM[3];
+  // modified random walk (mcgpu_set_mrw; MRW.f90, dust_transfer.f90:1222-1239): mrw = 0: off
+  int mrw, mrw_n_zeta, mrw_n_inter;
+  float mrw_gamma;
+  const double* mrw_zeta;  // [mrw_n_zeta] zeta(y_i), y_i = i/(n-1)
+  const double* mrw_chi;   // [n_T] mean transport extinction at tab_Temp, reference cell
+  const double* mrw_kdep;  // [n_T] mean absorption opacity of the walk's deposits
+  const double* mrw_ext;   // [n_T] extrapolation length of the sphere radius, reference cell
+  const double* r_lim;     // [n_rad+1] (distance_to_closest_wall_cyl)
 };
 
 // packet state word of the queue records: state | flags
 constexpr int ST_MASK = 15, ST_STAR = 16, ST_SCATT = 32, ST_ISM = 64;
+constexpr int ST_NINT_SHIFT = 8;  // bits 8..10: MRW's count of interactions in a row inside one cell (0..7)
 
 struct RunArgs {
   uint64_t seed, first_packet, n_packets;
@@ -141,7 +150,7 @@ struct RunArgs {
   double* E_abs;            // [n_cells]
   double* sed;              // [9 * n_lambda*N_thet*N_phi]
   double* n_sent;           // [n_lambda]
-  unsigned long long* counters;  // [8]
+  unsigned long long* counters;  // [MCGPU_N_COUNTERS]
   unsigned long long* next_packet;  // work counter
   int* err;
   int inner_iters;  // crossings attempted between two interaction phases
@@ -1111,6 +1120,20 @@ __device__ inline void random_isotropic_direction(float r1, float r2, double& u,
   v = uv * sp;
 }
 
+// the wavelength of im_reemission_LTE (thermal_emission.f90:740-771) for the temperature (Ti, frac_T2) of Temp_LTE
+__device__ inline int reemission_wavelength(const Lds& T, const DevModel& M, int Ti, double frac_T2, float rand2) {
+  const double frac_T1 = 1.0 - frac_T2;
+  const double* cdf1 = T.cdf + (size_t)M.n_lambda * (Ti - 2);
+  const double* cdf2 = T.cdf + (size_t)M.n_lambda * (Ti - 1);
+  int l1 = 0, l2 = M.n_lambda, l = (l1 + l2) / 2;
+  while ((l2 - l1) > 1) {
+    const double proba = frac_T1 * cdf1[l - 1] + frac_T2 * cdf2[l - 1];
+    if ((double)rand2 > proba) l1 = l; else l2 = l;
+    l = (l1 + l2) / 2;
+  }
+  return l + 1;
+}
+
 // One interaction (dust_transfer.f90:1260-1402): scatter (new direction, Stokes) or absorb +
 // immediate re-emission (new wavelength from the cell's temperature, isotropic direction).
 // g = the event's draws (see Rng); cell_energy() returns the cell's absorbed energy scaled like
@@ -1176,16 +1199,7 @@ __device__ __forceinline__ bool interact_direction(const Lds& T, const DevModel&
     int Ti;
     double frac_T2;
     temp_lte(T.lq, M.n_T, E, M.L_packet_th, *volume_of_cell, Ti, frac_T2);
-    const double frac_T1 = 1.0 - frac_T2;
-    const double* cdf1 = T.cdf + (size_t)M.n_lambda * (Ti - 2);
-    const double* cdf2 = T.cdf + (size_t)M.n_lambda * (Ti - 1);
-    int l1 = 0, l2 = M.n_lambda, l = (l1 + l2) / 2;
-    while ((l2 - l1) > 1) {
-      const double proba = frac_T1 * cdf1[l - 1] + frac_T2 * cdf2[l - 1];
-      if ((double)rand2 > proba) l1 = l; else l2 = l;
-      l = (l1 + l2) / 2;
-    }
-    lambda = l + 1;
+    lambda = reemission_wavelength(T, M, Ti, frac_T2, rand2);
     // random_isotropic_direction (random_numbers.f90:32-51): w = 2r-1, (u,v) = sqrt(1-w^2)
     // (cos,sin)(phi) is cdapres' own |w0| > 0.999999 branch applied to the z axis
     cospsi = 2.0 * (double)g[3] - 1.0;
@@ -1226,6 +1240,80 @@ __device__ __forceinline__ void interact(const Lds& T, const DevModel& M, const 
   const bool scat = interact_direction(T, M, g, lambda, u, v, w, u1, v1, w1, flag_star, flag_scatt, c_scatt, c_abs,
                                        cell_energy, volume_of_cell, itheta, rand2, forced, prob_forced, lds_col);
   if (POLA) interact_stokes(M, scat, lambda_in, itheta, rand2, u, v, w, u1, v1, w1, S);
+}
+
+// ---------------------------------------------------------------------------
+// Modified random walk (Min et al. 2009; Robitaille 2010) for the 2D cylindrical grid.  The reference carries the
+// pieces (MRW.f90: zeta table :16-53, gamma_MRW :11, cst_ct :12, the step :74-115; distance_to_closest_wall_cyl,
+// cylindrical_grid.f90:1179; the trigger and the loop, dust_transfer.f90:1222-1239) but its step is an unfinished
+// stub behind a commented-out call; this is the working algorithm, stated in oracle/mc_oracle.c (mrw_walk) and
+// validated against the brute-force loop.  The walk's draws come from the packet's own counter
+// sub-space (block k of event e: Philox counter (k, e, packet id)), so the result does not depend on the schedule.
+// ---------------------------------------------------------------------------
+// distance_to_closest_wall_cyl (cylindrical_grid.f90:1179-1226), 2D
+__device__ inline double distance_to_closest_wall_cyl(const Lds& T, const DevModel& M, int ri, int zj, double x,
+                                                      double y, double z) {
+  const double r = sqrt(x * x + y * y);
+  const double s1 = M.r_lim[ri] - r, s2 = r - M.r_lim[ri - 1];
+  const double z0 = fabs(z);
+  const int azj = zj < 0 ? -zj : zj;
+  const double s3 = z_lim_of(T, M.nz, ri, azj + 1) - z0, s4 = z0 - z_lim_of(T, M.nz, ri, azj);
+  return fmin(fmin(s1, s2), fmin(s3, s4));
+}
+
+// y with zeta(y) = xi (MRW.f90:58-70 read as the inverse it means)
+__device__ inline double mrw_sample_y(const DevModel& M, float xi) {
+  const double* zt = M.mrw_zeta;
+  const double x = xi > 0.0f ? (double)xi : 2.9802322387695312e-08;
+  int lo = 0, hi = M.mrw_n_zeta - 1;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) / 2;
+    if (zt[mid] <= x) lo = mid; else hi = mid;
+  }
+  const double f = (x - zt[lo]) / (zt[hi] - zt[lo]);
+  return ((double)lo + f) / (double)(M.mrw_n_zeta - 1);
+}
+
+// One walk of a packet the cell (ri, zj; index ic) has just re-emitted.  cell_energy() as in interact();
+// add_energy(v) deposits v into the cell.  Returns false (nothing drawn, nothing changed) when the sphere is
+// not optically thick enough.
+template <typename EnergyFn, typename DepositFn>
+__device__ inline bool mrw_walk(const Lds& T, const DevModel& M, uint32_t k0, uint32_t k1, uint32_t p_lo, uint32_t p_hi,
+                                uint32_t event, int ri, int zj, int ic, double S0, double& x, double& y, double& z,
+                                double& u, double& v, double& w, int& lambda, EnergyFn cell_energy,
+                                DepositFn add_energy, unsigned int& c_walks, unsigned int& c_steps) {
+  double d = distance_to_closest_wall_cyl(T, M, ri, zj, x, y, z);
+  int Ti;
+  double frac;
+  temp_lte(T.lq, M.n_T, cell_energy(), M.L_packet_th, M.volume[ic], Ti, frac);
+  const double kf = M.kappa_factor[ic];
+  const double chi = (M.mrw_chi[Ti - 2] * (1.0 - frac) + M.mrw_chi[Ti - 1] * frac) * kf;
+  if (!(d * chi > (double)M.mrw_gamma)) return false;
+  const double kdep = M.mrw_kdep[Ti - 2] * (1.0 - frac) + M.mrw_kdep[Ti - 1] * frac;
+  const double ext = (M.mrw_ext[Ti - 2] * (1.0 - frac) + M.mrw_ext[Ti - 1] * frac) / kf;
+  const double cst_ct = 3.0 / (PI * PI);
+  double su, sv, sw;
+  uint32_t blk = 0, o[4];
+  do {
+    philox4x32_10(blk++, event, p_lo, p_hi, k0, k1, o);
+    random_isotropic_direction(Rng::real(o[0]), Rng::real(o[1]), su, sv, sw);
+    x += su * d;
+    y += sv * d;
+    z += sw * d;
+    const double yv = mrw_sample_y(M, Rng::real(o[2]));
+    const double de = d + ext;
+    const double ct = -log(yv) * cst_ct * chi * (de * de);
+    add_energy(kdep * ct * S0);
+    c_steps++;
+    d = distance_to_closest_wall_cyl(T, M, ri, zj, x, y, z);
+  } while (d * chi > (double)M.mrw_gamma);
+  philox4x32_10(blk, event, p_lo, p_hi, k0, k1, o);
+  // the cell's temperature now, the walk's deposits included (im_reemission_LTE)
+  temp_lte(T.lq, M.n_T, cell_energy(), M.L_packet_th, M.volume[ic], Ti, frac);
+  lambda = reemission_wavelength(T, M, Ti, frac, Rng::real(o[0]));
+  cdapres(sqrt((double)Rng::real(o[1])), PI * (2.0 * (double)Rng::real(o[2]) - 1.0), su, sv, sw, u, v, w);
+  c_walks++;
+  return true;
 }
 
 // ---------------------------------------------------------------------------
@@ -1340,7 +1428,7 @@ struct SphEmitOps {
 // (global_atomic_add_f64), the only option for 3D grids (5.76 MB at 720 000
 // cells).
 // SPH: the grid operators of spherical_grid.f90 instead of cylindrical_grid.f90 (same cell identity and mapping).
-template <bool L3D, bool POLA, bool DARK, bool LDSE, bool SPH = false>
+template <bool L3D, bool POLA, bool DARK, bool LDSE, bool SPH = false, bool MRW = false>
 __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A, double* lds_base) {
   double* const E_lds = lds_base;  // [n_cells] when LDSE
   const Lds T = lds_carve(lds_base + (LDSE ? M.n_cells : 0), M);
@@ -1366,6 +1454,9 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
   unsigned int c_cross = 0, c_flight = 0, c_scatt = 0, c_abs = 0, c_esc = 0, c_kill = 0, c_dark = 0,
                c_pack = 0;
   unsigned int pk_cross = 0;  // crossings of the current packet (runaway guard)
+  int n_inter = 0;            // MRW: interactions in a row whose flights never left the cell (0..7)
+  bool first_cross = true;    // MRW: the flight is still in the cell it started in
+  unsigned int c_walks = 0, c_steps = 0;
   unsigned long long pk_next = 0, pk_end = 0;  // this wave's reserved packet ids (wave-uniform)
   float tau_rand = 0.0f;  // the current event's draw for the next flight's optical depth
   double kf = 0.0;  // kappa_factor of the current cell (0 in virtual cells), fetched one crossing ahead
@@ -1418,6 +1509,7 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
             rng.init(A.seed, A.first_packet + my);
             c_pack++;
             pk_cross = 0;
+            n_inter = 0;
             float f[12];
             rng.emission_event(f);
             tau_rand = f[8];
@@ -1476,6 +1568,24 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
       }, M.volume + ic);
       if (!flag_scatt) flag_ism = false;  // absorbed and re-emitted by the dust (:1367)
       u = u1; v = v1; w = w1;
+      if (MRW) {
+        // modified random walk of a packet the cell has just re-emitted for the (n_inter+1)-th time in a row
+        // (dust_transfer.f90:1222-1239; mrw_walk above)
+        if (!flag_scatt && !flag_star && n_inter > M.mrw_n_inter) {
+          mrw_walk(T, M, rng.k0, rng.k1, rng.p_lo, rng.p_hi, rng.event, ri, zj, ic, S[0], x, y, z, u, v, w, lambda,
+                   [&]() {
+                     double E;
+                     if (A.frozen) E = A.E_prior[ic];
+                     else {
+                       E = __hip_atomic_load(&A.E_abs[ic], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                       if (LDSE) E += E_lds[ic] * (double)gridDim.x;
+                       E *= A.qscale;
+                     }
+                     return E;
+                   },
+                   [&](double e) { deposit<LDSE>(A.E_abs, E_lds, ic, e); }, c_walks, c_steps);
+        }
+      }
       st = S_NEWFLIGHT;
     }
 
@@ -1496,6 +1606,7 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
       c_flight++;
       ri_o = 0; zj_o = 0; k_o = 0;
       xo = x; yo = y; zo = z;
+      first_cross = true;
       kf = is_real_cell<L3D>(n_rad, nz, ri, zj) ? M.kappa_factor[cell_index<L3D>(n_rad, nz, ri, zj, k)] : 0.0;
       st = S_FLIGHT;
     }
@@ -1544,6 +1655,7 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
                 c_dark++;
                 mirrored = true;
                 st = S_INTERACT;
+                n_inter = 0;
               }
             }
           }
@@ -1562,7 +1674,9 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
               z = z + lc * w;
               if (L3D && !SPH) index_cell<L3D>(T, M, x, y, z, ri, zj, k);  // optical_depth.f90:162-165 (lcylindrical only)
               st = S_INTERACT;
+              if (MRW) n_inter = first_cross ? (n_inter < 7 ? n_inter + 1 : 7) : 0;  // dust_transfer.f90:1244-1249
             } else {
+              first_cross = false;
               extr = extr - tau;
               if (real_cell && !MCGPU_DIAG(A.flags, 1)) deposit<LDSE>(A.E_abs, E_lds, ic, T.kabs[lambda - 1] * l * S[0]);
               if (DARK) { xo = x; yo = y; zo = z; ri_o = ri; zj_o = zj; k_o = k; }
@@ -1619,13 +1733,19 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
     for (int off = 32; off > 0; off >>= 1) vsum += __shfl_down(vsum, off);
     if (lane == 0 && vsum) atomicAdd(&A.counters[q], vsum);
   }
+  if (MRW) {
+    unsigned long long v8 = c_walks, v9 = c_steps;
+    for (int off = 32; off > 0; off >>= 1) { v8 += __shfl_down(v8, off); v9 += __shfl_down(v9, off); }
+    if (lane == 0 && v8) atomicAdd(&A.counters[8], v8);
+    if (lane == 0 && v9) atomicAdd(&A.counters[9], v9);
+  }
 }
 
 // HBM-deposit variant: 256-thread workgroups, several per CU.
-template <bool L3D, bool POLA, bool DARK>
+template <bool L3D, bool POLA, bool DARK, bool MRW = false>
 __global__ void __launch_bounds__(256) k_thermal(const DevModel M, const RunArgs A) {
   extern __shared__ double lds_raw[];
-  thermal_body<L3D, POLA, DARK, false>(M, A, lds_raw);
+  thermal_body<L3D, POLA, DARK, false, false, MRW>(M, A, lds_raw);
 }
 
 // the spherical grid (spherical_grid.f90): the same packet loop with that grid's operators; no dark zone
@@ -1636,10 +1756,10 @@ __global__ void __launch_bounds__(LDSE ? MCGPU_LDS_BLOCK : 256) k_thermal_sph(co
 }
 
 // LDS-deposit variant: one MCGPU_LDS_BLOCK-thread workgroup per CU shares one private grid.
-template <bool L3D, bool POLA, bool DARK>
+template <bool L3D, bool POLA, bool DARK, bool MRW = false>
 __global__ void __launch_bounds__(MCGPU_LDS_BLOCK) k_thermal_lds(const DevModel M, const RunArgs A) {
   extern __shared__ double lds_raw[];
-  thermal_body<L3D, POLA, DARK, true>(M, A, lds_raw);
+  thermal_body<L3D, POLA, DARK, true, false, MRW>(M, A, lds_raw);
 }
 
 // ---------------------------------------------------------------------------

@@ -66,7 +66,8 @@ struct RqCtl {
   unsigned int head[3], tail[3];
   int n_srv, cooldown;  // waves [0, n_srv) serve; adapted by wave 0 (see roles_body)
   int idle_f, idle_s;   // lanes the flying / serving waves could not fill since the last adaptation
-  int pad1[2];
+  int beat;             // bumped by every wave in every round in which it had work: the idle waves' sign of life
+  int pad1;
 };
 static_assert(sizeof(RqCtl) == 64, "control block");
 
@@ -223,7 +224,7 @@ __device__ inline int roles_cross(const Lds& T, const DevModel& M, const RunArgs
 // effects: the stop (an FP64 division), the deposit (an LDS atomic) and the rare default-real zj recomputation.
 // Every value that decides an index or a position is computed by the reference's expression, exactly as in
 // cross_cell_lean / roles_cross above (cylindrical_grid.f90:918-1175, optical_depth.f90:77-178).
-template <bool DARK, bool LDSE>
+template <bool DARK, bool LDSE, bool MRW = false>
 __device__ __forceinline__ int fly_step_2d(const Lds& T, const DevModel& M, const RunArgs& A, double* E_lds, Flight& p,
                                            unsigned int& c_cross, unsigned int& c_kill, unsigned int& c_dark) {
   const int n_rad = M.n_rad, nz = M.nz;
@@ -342,7 +343,9 @@ __device__ __forceinline__ int fly_step_2d(const Lds& T, const DevModel& M, cons
   c_cross += go ? 1u : 0u;
   c_kill += (active && !out && killed) ? 1u : 0u;
   p.pk_cross += go ? 1u : 0u;
-  const bool runaway = go && (p.pk_cross > 200000000u);  // a packet that never leaves: flag it, drop it
+  // MRW: bit 31 of the crossing counter remembers that this flight has left the cell it started in
+  if (MRW) p.pk_cross |= (move || mirror) ? 0x80000000u : 0u;
+  const bool runaway = go && ((MRW ? (p.pk_cross & 0x7FFFFFFFu) : p.pk_cross) > 200000000u);  // a packet that never leaves: flag it, drop it
   if (runaway) { *A.err = 13; st = S_EMIT; }
   p.st = st;
   return ((active && !out && killed) || runaway) ? 1 : 0;
@@ -355,7 +358,7 @@ __device__ __forceinline__ int fly_step_2d(const Lds& T, const DevModel& M, cons
 #define RQ_PHASE_END()
 #endif
 
-template <bool L3D, bool POLA, bool DARK, bool LDSE>
+template <bool L3D, bool POLA, bool DARK, bool LDSE, bool MRW = false>
 __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, double* lds_base, int n_rec, int n_srv_pref,
                                            int k_short, int fly_iters, int fly_idle, int emit_qmax) {
   double* const E_lds = lds_base;
@@ -371,7 +374,7 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
     rings[i] = (i < n_rec) ? ((((unsigned int)i + 1u) << 16) | (unsigned int)i) : 0u;
   if (threadIdx.x == 0) {
     Q->n_pending = 0; Q->ids_done = 0; Q->abort_flag = 0;
-    Q->n_srv = n_srv_pref > 0 ? (n_srv_pref < 1000 ? n_srv_pref : n_srv_pref - 1000) : 0; Q->cooldown = 0; Q->idle_f = 0; Q->idle_s = 0;
+    Q->n_srv = n_srv_pref > 0 ? (n_srv_pref < 1000 ? n_srv_pref : n_srv_pref - 1000) : 0; Q->cooldown = 0; Q->idle_f = 0; Q->idle_s = 0; Q->beat = 0;
     Q->head[0] = Q->head[1] = Q->head[2] = 0u;
     Q->tail[RQ_FREE] = (unsigned int)n_rec; Q->tail[RQ_FLY] = 0u; Q->tail[RQ_SRV] = 0u;
   }
@@ -404,9 +407,13 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
   float bag_tau = 0.0f;
 
   unsigned int c_cross = 0, c_flight = 0, c_scatt = 0, c_abs = 0, c_esc = 0, c_kill = 0, c_pack = 0, c_dark = 0;
+  unsigned int c_walks = 0, c_steps = 0;  // MRW
   unsigned long long pk_next = 0, pk_end = 0;
   bool no_more_ids = false;  // wave-uniform: the global id counter is exhausted
-  int idle_spins = 0;        // consecutive rounds without work: bounded, a lost packet must not hang the GPU
+  // consecutive rounds in which neither this wave nor any other wave of the workgroup had work (Q->beat stands
+  // still): bounded, a lost packet must not hang the GPU -- while the long tail of a thick model, in which a few
+  // lanes work for seconds and everybody else waits, must not trip it
+  int idle_spins = 0, last_beat = 0;
   RQ_DIAG(unsigned int d_fly_iters = 0, d_srv_iters = 0, d_fly_cross = 0, d_srv_rounds = 0, d_fly_rounds = 0;)
   RQ_DIAG(unsigned int d_srv_lanes = 0, d_srv_int = 0, d_emit = 0;)
 
@@ -520,9 +527,11 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
       if (__ballot(st == S_FLIGHT) == 0ull) {
         if (__ballot(st != S_EMIT) == 0ull && rq_ld(&Q->ids_done) && rq_ld(&Q->n_pending) == 0) break;
         __builtin_amdgcn_s_sleep(16);  // nothing to fly (or no record for a stopped packet): wait for the others
-        if (++idle_spins > (1 << 21)) { *A.err = 15; rq_st(&Q->abort_flag, 1); }  // (seconds without any work: a lost packet, not a long tail)
+        { const int b = rq_ld(&Q->beat); if (b != last_beat) { last_beat = b; idle_spins = 0; } }
+        if (++idle_spins > (1 << 21)) { *A.err = 15; rq_st(&Q->abort_flag, 1); }  // (seconds without work anywhere in the workgroup: a lost packet)
       } else {
         idle_spins = 0;
+        if (lane == 0) atomicAdd(&Q->beat, 1);
         RQ_DIAG(if (lane == 0) d_fly_rounds++;)
         F.st = st;
 #pragma unroll 1
@@ -533,7 +542,7 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
           if (L3D) {
             if (F.st == S_FLIGHT) finished += roles_cross<L3D, DARK, LDSE>(T, M, A, E_lds, F, c_cross, c_kill, c_dark);
           } else {
-            finished += fly_step_2d<DARK, LDSE>(T, M, A, E_lds, F, c_cross, c_kill, c_dark);
+            finished += fly_step_2d<DARK, LDSE, MRW>(T, M, A, E_lds, F, c_cross, c_kill, c_dark);
           }
         }
         st = F.st;
@@ -627,9 +636,11 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
       if (__ballot(rid >= 0) == 0ull) {  // the wave owns no packet at all
         if (rq_ld(&Q->ids_done) && rq_ld(&Q->n_pending) == 0) break;
         __builtin_amdgcn_s_sleep(16);
+        { const int b = rq_ld(&Q->beat); if (b != last_beat) { last_beat = b; idle_spins = 0; } }
         if (++idle_spins > (1 << 21)) { *A.err = 15; rq_st(&Q->abort_flag, 1); }
       } else {
         idle_spins = 0;
+        if (lane == 0) atomicAdd(&Q->beat, 1);
         // ---- INTERACT: scatter or absorb + re-emit (dust_transfer.f90:1260-1402), in two phases: the event and
         // the new direction, then (Stokes tracking) the Stokes vector.  Only the new direction, the scattering
         // angle bin and one draw cross the phase boundary in registers.
@@ -667,7 +678,13 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
           R.lambda = lambda;
           R.event = rng.event;
           R.tau_rand = g[5];
-          R.flags = S_NEWFLIGHT | (flag_star ? ST_STAR : 0) | (flag_scatt ? ST_SCATT : 0) | (flag_ism ? ST_ISM : 0);
+          int n_int = 0;
+          if (MRW) {  // interactions in a row whose flights never left the cell (dust_transfer.f90:1244-1249), 0..7
+            n_int = (fl >> ST_NINT_SHIFT) & 7;
+            n_int = (R.pk_cross & 0x80000000u) ? 0 : (n_int < 7 ? n_int + 1 : 7);
+            R.pk_cross &= 0x7FFFFFFFu;  // the next flight starts here
+          }
+          R.flags = S_NEWFLIGHT | (flag_star ? ST_STAR : 0) | (flag_scatt ? ST_SCATT : 0) | (flag_ism ? ST_ISM : 0) | (n_int << ST_NINT_SHIFT);
           if (!POLA) { R.u = u1; R.v = v1; R.w = w1; }
         }
         if (POLA) {
@@ -682,6 +699,35 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
         }
         if (inter) st = S_NEWFLIGHT;
         RQ_PHASE_END();
+        if (MRW) {
+          // ---- modified random walk of the packets their cell has just re-emitted for the (n_inter+1)-th time in
+          // a row (dust_transfer.f90:1222-1239; mrw_walk in mc_device.hip.h) --------------------------------------
+          bool walk = false;
+          if (inter) {
+            const int fl = recs[rid].flags;
+            walk = !(fl & (ST_SCATT | ST_STAR)) && ((fl >> ST_NINT_SHIFT) & 7) > M.mrw_n_inter;
+          }
+          if (walk) {
+            Rec<POLA>& R = recs[rid];
+            const int ic = cell_index<L3D>(n_rad, nz, R.ri, R.zj, R.k);
+            double x = R.x, y = R.y, z = R.z, u = R.u, v = R.v, w = R.w;
+            int lambda = R.lambda;
+            const bool done = mrw_walk(T, M, key0, key1, R.p_lo, R.p_hi, R.event, R.ri, R.zj, ic, R.S[0], x, y, z, u, v, w, lambda,
+              [&]() {
+                double E;
+                if (A.frozen) E = A.E_prior[ic];
+                else {
+                  E = __hip_atomic_load(&A.E_abs[ic], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  if (LDSE) E += E_lds[ic] * (double)gridDim.x;
+                  E *= A.qscale;
+                }
+                return E;
+              },
+              [&](double e) { deposit<LDSE>(A.E_abs, E_lds, ic, e); }, c_walks, c_steps);
+            if (done) { R.x = x; R.y = y; R.z = z; R.u = u; R.v = v; R.w = w; R.lambda = lambda; }
+          }
+          RQ_PHASE_END();
+        }
         // ---- NEWFLIGHT: optical depth to the next event (dust_transfer.f90:1208-1215, tau in FP64) and the
         // star on the way (optical_depth.f90:68) ---------------------------------------------------------
         if (rid >= 0 && st == S_NEWFLIGHT) {
@@ -718,7 +764,7 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
             if (L3D) {
               if (F.st == S_FLIGHT) finished += roles_cross<L3D, DARK, LDSE>(T, M, A, E_lds, F, c_cross, c_kill, c_dark);
             } else {
-              finished += fly_step_2d<DARK, LDSE>(T, M, A, E_lds, F, c_cross, c_kill, c_dark);
+              finished += fly_step_2d<DARK, LDSE, MRW>(T, M, A, E_lds, F, c_cross, c_kill, c_dark);
             }
           }
           if (fly) {
@@ -794,17 +840,23 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
     for (int off = 32; off > 0; off >>= 1) vsum += __shfl_down(vsum, off);
     if (lane == 0 && vsum) atomicAdd(&A.counters[q], vsum);
   }
+  if (MRW) {
+    unsigned long long v8 = c_walks, v9 = c_steps;
+    for (int off = 32; off > 0; off >>= 1) { v8 += __shfl_down(v8, off); v9 += __shfl_down(v9, off); }
+    if (lane == 0 && v8) atomicAdd(&A.counters[8], v8);
+    if (lane == 0 && v9) atomicAdd(&A.counters[9], v9);
+  }
 }
 
 #ifndef MCGPU_ROLES_BLOCK
 #define MCGPU_ROLES_BLOCK 1024  // threads of a workgroup of this schedule: 128 VGPRs, 4 waves per SIMD
 #endif
 
-template <bool L3D, bool POLA, bool DARK, bool LDSE>
+template <bool L3D, bool POLA, bool DARK, bool LDSE, bool MRW = false>
 __global__ void __launch_bounds__(MCGPU_ROLES_BLOCK) k_thermal_roles(const DevModel M, const RunArgs A, int n_rec, int n_srv_pref,
                                                                      int k_short, int fly_iters, int fly_idle, int emit_qmax) {
   extern __shared__ double lds_raw[];
-  roles_body<L3D, POLA, DARK, LDSE>(M, A, lds_raw, n_rec, n_srv_pref, k_short, fly_iters, fly_idle, emit_qmax);
+  roles_body<L3D, POLA, DARK, LDSE, MRW>(M, A, lds_raw, n_rec, n_srv_pref, k_short, fly_iters, fly_idle, emit_qmax);
 }
 
 }  // namespace mcgpu

@@ -34,6 +34,9 @@ static int tune(const char* name, int dflt, int lo, int hi) {
   return dflt;
 }
 
+constexpr int WORK_SLOT = 12;  // where the kernels' work counter lives in d_counters
+static_assert(MCGPU_N_COUNTERS <= WORK_SLOT, "counter buffer layout");
+
 struct mcgpu_ctx {
   int device = 0;
   hipStream_t own_stream = nullptr;
@@ -58,7 +61,7 @@ struct mcgpu_ctx {
   // accumulators: [E_abs | sed | n_sent | counters as doubles (mcgpu_counters_to_accum)]
   double* d_accum = nullptr;
   size_t n_accum = 0;
-  unsigned long long* d_counters = nullptr;  // 8 counters + work counter + pad
+  unsigned long long* d_counters = nullptr;  // [16]: MCGPU_N_COUNTERS counters, pad, the work counter at WORK_SLOT
   int* d_err = nullptr;
   double* d_E_prior = nullptr;
   bool launched = false;
@@ -525,6 +528,29 @@ extern "C" int mcgpu_set_thermal(mcgpu_ctx* ctx, int n_T, const float* tab_Temp,
   return MCGPU_OK;
 }
 
+// Modified random walk (MRW.f90; dust_transfer.f90:1222-1239): see include/mcgpu.h
+extern "C" int mcgpu_set_mrw(mcgpu_ctx* ctx, int n_zeta, const double* zeta, const double* chi, const double* kappa_dep,
+                             const double* ext, double gamma, int n_interactions, const double* r_lim) {
+  if (!ctx) return MCGPU_ERR_ARG;
+  DevModel& M = ctx->M;
+  if (n_zeta == 0) { M.mrw = 0; return MCGPU_OK; }  // off
+  if (n_zeta < 2 || !zeta || !chi || !kappa_dep || !ext || !r_lim || !(gamma > 0.0) || n_interactions < 0 || n_interactions > 6)
+    return fail(ctx, MCGPU_ERR_ARG, "mcgpu_set_mrw: bad argument (n_interactions is 0..6)");
+  if (!ctx->have_grid || !ctx->have_thermal) return fail(ctx, MCGPU_ERR_STATE, "set the grid and the thermal tables first");
+  if (ctx->voro || M.l3D || M.grid_sph) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "modified random walk: 2D cylindrical grids only");
+  for (int i = 1; i < n_zeta; ++i)
+    if (!(zeta[i] >= zeta[i - 1])) return fail(ctx, MCGPU_ERR_ARG, "mcgpu_set_mrw: zeta must not decrease");
+  HIPCHK(hipSetDevice(ctx->device));
+  int rc;
+  if ((rc = upload(ctx, zeta, (size_t)n_zeta, &M.mrw_zeta))) return rc;
+  if ((rc = upload(ctx, chi, (size_t)M.n_T, &M.mrw_chi))) return rc;
+  if ((rc = upload(ctx, kappa_dep, (size_t)M.n_T, &M.mrw_kdep))) return rc;
+  if ((rc = upload(ctx, ext, (size_t)M.n_T, &M.mrw_ext))) return rc;
+  if ((rc = upload(ctx, r_lim, (size_t)M.n_rad + 1, &M.r_lim))) return rc;
+  M.mrw_n_zeta = n_zeta; M.mrw_gamma = (float)gamma; M.mrw_n_inter = n_interactions; M.mrw = 1;
+  return MCGPU_OK;
+}
+
 extern "C" int mcgpu_set_ism(mcgpu_ctx* ctx, double R_ISM, const double* centre_ISM) {
   if (!ctx || !(R_ISM >= 0.0) || (R_ISM > 0.0 && !centre_ISM)) return fail(ctx, MCGPU_ERR_ARG, "mcgpu_set_ism: bad argument");
   ctx->M.R_ISM = R_ISM;
@@ -638,7 +664,11 @@ static int launch_mega(mcgpu_ctx* ctx, const RunArgs& A, bool use_lds, int grid_
       int fly_idle = tune("MCGPU_FLY_IDLE", 32, 1, 65), emit_qmax = tune("MCGPU_EMIT_QMAX", 128, 0, 1 << 20);
       const void* fn;
 #define PICKR(a, b, c) fn = use_lds ? (const void*)k_thermal_roles<a, b, c, true> : (const void*)k_thermal_roles<a, b, c, false>
-      if (l3d) {
+#define PICKM(b, c) fn = use_lds ? (const void*)k_thermal_roles<false, b, c, true, true> : (const void*)k_thermal_roles<false, b, c, false, true>
+      if (M.mrw) {  // (2D; mcgpu_set_mrw refuses the other grids)
+        if (pola) { if (dark) PICKM(true, true); else PICKM(true, false); }
+        else { if (dark) PICKM(false, true); else PICKM(false, false); }
+      } else if (l3d) {
         if (pola) { if (dark) PICKR(true, true, true); else PICKR(true, true, false); }
         else { if (dark) PICKR(true, false, true); else PICKR(true, false, false); }
       } else {
@@ -646,6 +676,7 @@ static int launch_mega(mcgpu_ctx* ctx, const RunArgs& A, bool use_lds, int grid_
         else { if (dark) PICKR(false, false, true); else PICKR(false, false, false); }
       }
 #undef PICKR
+#undef PICKM
       HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));
       void* args[] = {(void*)&M, (void*)&A, (void*)&n_rec, (void*)&n_srv_pref, (void*)&k_short, (void*)&fly_iters, (void*)&fly_idle, (void*)&emit_qmax};
       HIPCHK(hipLaunchKernel(fn, dim3(rblocks), dim3(rthreads), args, lds_r, ctx->stream));
@@ -655,7 +686,17 @@ static int launch_mega(mcgpu_ctx* ctx, const RunArgs& A, bool use_lds, int grid_
 #define LAUNCH(a, b, c)                                                                \
   e = use_lds ? launch_k<a, b, c, true>(M, A, blocks, threads, lds_k, ctx->stream)     \
               : launch_k<a, b, c, false>(M, A, blocks, threads, lds_k, ctx->stream)
-  if (l3d) {
+#define LAUNCHM(b, c)                                                                                                   \
+  {                                                                                                                     \
+    const void* kern = use_lds ? (const void*)k_thermal_lds<false, b, c, true> : (const void*)k_thermal<false, b, c, true>; \
+    e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k);                               \
+    void* args[] = {(void*)&M, (void*)&A};                                                                               \
+    if (e == hipSuccess) e = hipLaunchKernel(kern, dim3(blocks), dim3(threads), args, lds_k, ctx->stream);               \
+  }
+  if (M.mrw) {
+    if (pola) { if (dark) LAUNCHM(true, true) else LAUNCHM(true, false) }
+    else { if (dark) LAUNCHM(false, true) else LAUNCHM(false, false) }
+  } else if (l3d) {
     if (pola) { if (dark) LAUNCH(true, true, true); else LAUNCH(true, true, false); }
     else { if (dark) LAUNCH(true, false, true); else LAUNCH(true, false, false); }
   } else {
@@ -663,6 +704,7 @@ static int launch_mega(mcgpu_ctx* ctx, const RunArgs& A, bool use_lds, int grid_
     else { if (dark) LAUNCH(false, false, true); else LAUNCH(false, false, false); }
   }
 #undef LAUNCH
+#undef LAUNCHM
   if (e != hipSuccess) {
     ctx->err = std::string("kernel launch: ") + hipGetErrorString(e);
     return MCGPU_ERR_HIP;
@@ -736,7 +778,7 @@ extern "C" int mcgpu_launch_thermal(mcgpu_ctx* ctx, const mcgpu_run_opts* o) {
     HIPCHK(hipMemsetAsync(ctx->d_accum, 0, ctx->n_accum * sizeof(double), ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->d_counters, 0, 16 * sizeof(unsigned long long), ctx->stream));
   } else {
-    HIPCHK(hipMemsetAsync(ctx->d_counters + 8, 0, sizeof(unsigned long long), ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_counters + WORK_SLOT, 0, sizeof(unsigned long long), ctx->stream));
   }
   HIPCHK(hipMemsetAsync(ctx->d_err, 0, sizeof(int), ctx->stream));
   RunArgs A;
@@ -749,7 +791,7 @@ extern "C" int mcgpu_launch_thermal(mcgpu_ctx* ctx, const mcgpu_run_opts* o) {
   A.sed = ctx->d_accum + M.n_cells;
   A.n_sent = ctx->d_accum + M.n_cells + n_sed(M);
   A.counters = ctx->d_counters;
-  A.next_packet = ctx->d_counters + 8;
+  A.next_packet = ctx->d_counters + WORK_SLOT;
   A.err = ctx->d_err;
   A.inner_iters = tune("MCGPU_INNER_ITERS", 64, 1, 4096);
   A.flush_every = tune("MCGPU_FLUSH_EVERY", 16, 1, 1000000);
@@ -1023,7 +1065,7 @@ extern "C" int mcgpu_run_mono(mcgpu_ctx* ctx, const mcgpu_mono_opts* o, double f
   A.xI = ctx->d_xI; A.xI_f32 = ctx->xI_bytes == 4 ? 1 : 0; A.nRT_pad = xi_nrt_pad(ctx);
   A.sed = ctx->d_accum + M.n_cells;
   A.n_sent = ctx->d_accum + M.n_cells + n_sed(M);
-  A.counters = ctx->d_counters; A.next_item = ctx->d_counters + 8; A.err = ctx->d_err;
+  A.counters = ctx->d_counters; A.next_item = ctx->d_counters + WORK_SLOT; A.err = ctx->d_err;
   A.inner_iters = tune("MCGPU_INNER_ITERS", 64, 1, 4096);
   A.min_active = tune("MCGPU_MIN_ACTIVE", 32, 0, 64);
   A.flags = tune("MCGPU_DIAG_FLAGS", 0, 0, 255);  // (diagnostic builds only)
@@ -1076,7 +1118,7 @@ restart:
     }
     HIPCHK(hipMemsetAsync(ctx->d_hits, 0, nh, ctx->stream));
     HIPCHK(hipMemcpyAsync(d_active, active.data(), na * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemsetAsync(ctx->d_counters + 8, 0, sizeof(unsigned long long), ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_counters + WORK_SLOT, 0, sizeof(unsigned long long), ctx->stream));
     A.active = d_active; A.seq0 = d_sent; A.batch = batch; A.hits = ctx->d_hits; A.n_items = nh;
     if ((rc = launch_mono<true>(ctx, A, o->grid_blocks, o->block_threads))) return rc;
     hipLaunchKernelGGL(k_mono_scan, dim3(na), dim3(64), 0, ctx->stream, d_active, na, batch, ctx->d_hits, d_need, d_sent,
@@ -1121,7 +1163,7 @@ restart:
         for (int c = 0; c < nc; ++c) { cnt[c] = sent[c] + extra[c]; base[c + 1] = base[c] + cnt[c]; }
         HIPCHK(hipMemcpyAsync(d_base, base.data(), ((size_t)nc + 1) * sizeof(unsigned long long), hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(hipMemsetAsync(d_hitcnt, 0, nc * sizeof(unsigned long long), ctx->stream));
-        HIPCHK(hipMemsetAsync(ctx->d_counters + 8, 0, sizeof(unsigned long long), ctx->stream));
+        HIPCHK(hipMemsetAsync(ctx->d_counters + WORK_SLOT, 0, sizeof(unsigned long long), ctx->stream));
         A.item_base = d_base; A.n_items = base[nc]; A.active = nullptr; A.seq0 = nullptr; A.hits = nullptr; A.batch = 0;
         A.hit_count = d_hitcnt;
         if ((rc = launch_mono<false>(ctx, A, o->grid_blocks, o->block_threads))) return rc;
@@ -1155,7 +1197,7 @@ restart:
   if (n_sent_chunk) for (int c = 0; c < nc; ++c) n_sent_chunk[c] = sent[c];
   HIPCHK(hipMemcpyAsync(d_base, base.data(), ((size_t)nc + 1) * sizeof(unsigned long long), hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemcpyAsync(d_start, start.data(), nc * sizeof(unsigned long long), hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipMemsetAsync(ctx->d_counters + 8, 0, sizeof(unsigned long long), ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->d_counters + WORK_SLOT, 0, sizeof(unsigned long long), ctx->stream));
   A.item_base = d_base; A.n_items = base[nc]; A.active = nullptr; A.seq0 = d_start; A.hits = nullptr; A.batch = 0;
   if (A.n_items > 0 && (rc = launch_mono<false>(ctx, A, o->grid_blocks, o->block_threads))) return rc;
   HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));

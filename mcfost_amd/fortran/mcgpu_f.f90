@@ -21,7 +21,7 @@ module mcgpu_f
 
   integer, parameter :: dp = selected_real_kind(p=13,r=200) ! mcfost_env.f90:23
 
-  integer(c_int), parameter, public :: MCGPU_N_SED_TYPES = 9, MCGPU_N_COUNTERS = 8
+  integer(c_int), parameter, public :: MCGPU_N_SED_TYPES = 9, MCGPU_N_COUNTERS = 10
 
   type, bind(C), public :: mcgpu_run_opts
      integer(c_int64_t) :: seed
@@ -68,7 +68,7 @@ module mcgpu_f
        mcgpu_run_thermal, mcgpu_temp_finale, mcgpu_thermal_loop, mcgpu_error_message, mcgpu_set_rt1, &
        mcgpu_run_mono, mcgpu_fetch, mcgpu_fetch_xI, mcgpu_rt1_dust_map, mcgpu_set_xI, mcgpu_rt1_image, mcgpu_set_xI_precision, &
        mcgpu_set_E_prior, mcgpu_multi_create, mcgpu_multi_destroy, mcgpu_multi_size, mcgpu_multi_ctx, mcgpu_multi_run_thermal, &
-       mcgpu_counters_to_accum, mcgpu_counters_from_accum, mcgpu_temp_approx_diffusion_vertical
+       mcgpu_counters_to_accum, mcgpu_counters_from_accum, mcgpu_temp_approx_diffusion_vertical, mcgpu_set_mrw
 
   interface
      integer(c_int) function mcgpu_create(device, ctx) bind(C, name="mcgpu_create")
@@ -205,6 +205,17 @@ module mcgpu_f
        type(c_ptr), value :: ctx
        real(c_double), intent(in) :: E_prior(*)
      end function mcgpu_set_E_prior
+
+     ! modified random walk (module MRW): zeta(:) of initialize_cumulative_zeta, the mean opacities per tab_Temp,
+     ! gamma_MRW, the interaction count of dust_transfer.f90:1223, r_lim(0:n_rad); n_zeta = 0 switches it off
+     integer(c_int) function mcgpu_set_mrw(ctx, n_zeta, zeta, chi, kappa_dep, ext, gamma, n_interactions, r_lim) &
+          bind(C, name="mcgpu_set_mrw")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: n_zeta, n_interactions
+       real(c_double), intent(in) :: zeta(*), chi(*), kappa_dep(*), ext(*), r_lim(*)
+       real(c_double), value :: gamma
+     end function mcgpu_set_mrw
 
      ! Temp_approx_diffusion_vertical (diffusion.f90:292): tab_lambda / tab_delta_lambda of module wavelengths,
      ! ri_in_dark_zone(1), ri_out_dark_zone(1), zj_sup_dark_zone(:,1) of module cylindrical_grid, Tdust in/out

@@ -613,6 +613,7 @@ class Model:
     rt: Optional[dict] = None
     prob_E_cell: Optional[np.ndarray] = None
     ism: Optional[dict] = None   # {"R_ISM": float, "centre_ISM": (3,)} (stars.f90:27-28); None: no ISM field
+    mrw: Optional[dict] = None   # tables of the modified random walk (init_mrw); None: off
 
     @property
     def capt_sup(self):
@@ -676,6 +677,69 @@ def init_directions_ray_tracing(cfg: DiskConfig, l3D: bool):
     return dict(RT_n_incl=ni, RT_n_az=na, tab_RT_incl=incl, tab_RT_az=az, tab_u_rt=u.reshape(-1),
                 tab_v_rt=v.reshape(-1), tab_w_rt=w, n_az_rt=1 if l3D else 45, n_theta_rt=1 if l3D else 2,
                 N_type_flux=ntf, lsepar_contrib=int(cfg.lsepar_contrib))
+
+
+def cumulative_zeta(n: int = 10000):
+    """``initialize_cumulative_zeta`` (MRW.f90:16-53): zeta(y) = 2 sum_{j>=1} (-1)^(j+1) y^(j^2) (Min et al. 2009,
+    eq. 7) on y_i = (i-1)/(n-1); the last point is the limit 1."""
+    y = np.arange(n, dtype=f64) / f64(n - 1)
+    zeta = np.zeros(n, f64)
+    j = 0
+    while True:
+        j += 1
+        term = y[:-1] ** float(j * j)
+        if not term.any():
+            break
+        zeta[:-1] += term if j % 2 else -term
+    zeta[-1] = 0.5
+    return zeta * 2.0
+
+
+def init_mrw(m: "Model", gamma: float = 2.0, n_inter: int = 5, n_zeta: int = 10000, weights: str = "dB_dT",
+             ext_factor: float = 0.4):
+    """Tables of the modified random walk (``mcgpu_set_mrw``), one value per temperature of ``tab_Temp``, for the
+    reference cell (the engine scales by ``kappa_factor``) -- the working form of ``compute_Planck_opacities``
+    (diffusion.f90:631-696), which the reference evaluates at a fixed T = 20 K only:
+
+      chi        mean of the transport extinction kappa (1 - albedo g), harmonic (the diffusion coefficient is
+                 D = 1/(3 chi)): the reference's ``rec_Planck_opacity``
+      kappa_dep  mean of kappa_abs_LTE, arithmetic: the opacity the walk's path deposits energy with
+
+    ``weights``: "dB_dT" (default) weighs wavelengths with dB/dT -- the spectrum a packet carries between two
+    immediate re-emissions (``kdB_dT_CDF``), i.e. the Rosseland mean of Min et al. (2009); "B" weighs with the Planck
+    function (Robitaille 2010; the reference's comments)."""
+    wl = np.asarray(m.lam, f64) * 1.0e-6
+    dwl = np.asarray(m.delta_lam, f64) * 1.0e-6
+    # the asymmetry parameter the loop's scattering events actually have: with the tabulated phase function the
+    # thermal step samples every wavelength's angle from the table of p_lambda = 1 (dust_transfer.f90:491-502)
+    g = np.asarray(m.tab_g_pos, f64)
+    if getattr(m.cfg, "lisotropic", False):
+        g = np.zeros_like(g)
+    elif int(getattr(m.cfg, "aniso_method", 1)) == 1 and m.p_lambda_fixed:
+        g = np.full_like(g, g[0])
+    k_tr = np.asarray(m.kappa, f64) * (1.0 - np.asarray(m.albedo, f64) * g)
+    k_abs = np.asarray(m.kappa_abs_LTE, f64)
+    n_T = m.tab_Temp.size
+    chi, kdep, ext = np.zeros(n_T, f64), np.zeros(n_T, f64), np.zeros(n_T, f64)
+    for t in range(n_T):
+        cst_wl = THERMAL_CONST / float(m.tab_Temp[t]) / wl
+        ok = cst_wl < 500.0
+        ce = np.exp(np.where(ok, cst_wl, 1.0))
+        wgt = np.where(ok, 1.0 / ((wl ** 5) * (ce - 1.0)) * dwl, 0.0)
+        if weights == "dB_dT":
+            wgt = np.where(ok, wgt * cst_wl * ce / (ce - 1.0), 0.0)
+        elif weights != "B":
+            raise ValueError("init_mrw: weights is 'dB_dT' or 'B'")
+        norm = wgt.sum()
+        if norm > 0.0:
+            chi[t] = norm / (wgt / k_tr).sum()
+            kdep[t] = (wgt * k_abs).sum() / norm
+            ext[t] = ext_factor * 0.7104 * (wgt / k_tr ** 2).sum() / (wgt / k_tr).sum()
+    # (the series saturates at 1 to within rounding for y > 0.9: the sampler wants a non-decreasing table)
+    zeta = np.minimum(np.maximum.accumulate(cumulative_zeta(n_zeta)), 1.0)
+    m.mrw = dict(zeta=zeta, chi=chi, kappa_dep=kdep, ext=ext, gamma=float(gamma),
+                 n_inter=int(n_inter), weights=weights)
+    return m.mrw
 
 
 def dark_zone_extent(m: "Model", lam: int, tau_max: float = 1500.0):

@@ -13,9 +13,9 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 N_SED_TYPES = 9
-N_COUNTERS = 8
+N_COUNTERS = 10
 COUNTER_NAMES = ("packets", "crossings", "flights", "scatterings", "absorptions",
-                 "escaped", "killed_star", "dark_mirrors")
+                 "escaped", "killed_star", "dark_mirrors", "mrw_walks", "mrw_steps")
 
 
 def oracle_lib_path():
@@ -94,6 +94,8 @@ class _Model(C.Structure):
         ("RT_n_incl", C.c_int), ("RT_n_az", C.c_int), ("tab_u_rt", _dp), ("tab_v_rt", _dp),
         ("tab_w_rt", _dp), ("n_az_rt", C.c_int), ("n_theta_rt", C.c_int), ("N_type_flux", C.c_int),
         ("lsepar_contrib", C.c_int), ("tab_s11_pos", _fp),
+        ("mrw", C.c_int), ("mrw_n_zeta", C.c_int), ("mrw_zeta", _dp), ("mrw_chi", _dp), ("mrw_kappa_dep", _dp),
+        ("mrw_ext", _dp), ("mrw_gamma", C.c_float), ("mrw_n_inter", C.c_int), ("r_lim", _dp),
     ]
 
 
@@ -224,7 +226,30 @@ class Oracle:
             s.n_az_rt, s.n_theta_rt = int(rt["n_az_rt"]), int(rt["n_theta_rt"])
             s.N_type_flux, s.lsepar_contrib = int(rt["N_type_flux"]), int(rt["lsepar_contrib"])
             s.tab_s11_pos = self._hold(_a(m.tab_s11_pos, np.float32), C.c_float)
+        if "r_lim" in g:
+            s.r_lim = self._hold(_a(g["r_lim"], np.float64), C.c_double)
+        mrw = getattr(m, "mrw", None)
+        if mrw is not None:
+            s.mrw, s.mrw_n_zeta = 1, int(mrw["zeta"].size)
+            for k in ("zeta", "chi", "kappa_dep", "ext"):
+                setattr(s, "mrw_" + k, self._hold(_a(mrw[k], np.float64), C.c_double))
+            s.mrw_gamma, s.mrw_n_inter = float(mrw["gamma"]), int(mrw["n_inter"])
         return s
+
+    def distance_to_closest_wall(self, icell, x, y, z):
+        self.lib.oracle_distance_to_closest_wall_cyl.restype = C.c_double
+        return np.array([self.lib.oracle_distance_to_closest_wall_cyl(C.byref(self.cm), C.c_int(int(c)), C.c_double(a),
+                                                                        C.c_double(b), C.c_double(d))
+                         for c, a, b, d in zip(icell, x, y, z)])
+
+    def mrw_zeta_table(self, n=10000):
+        out = np.zeros(n)
+        self.lib.oracle_mrw_zeta_table(C.c_int(n), _p(out, C.c_double))
+        return out
+
+    def mrw_sample_y(self, xi):
+        self.lib.oracle_mrw_sample_y.restype = C.c_double
+        return np.array([self.lib.oracle_mrw_sample_y(C.byref(self.cm), C.c_float(float(v))) for v in xi])
 
     def xI_shape(self):
         """xI_scatt(n_az_rt, n_theta_rt, N_type_flux, RT_n_incl*RT_n_az, n_cells), C order reversed"""
@@ -628,6 +653,15 @@ class RefGeom:
         getattr(self.lib, "ref_pos_em_cell" + self._sfx)(C.c_int(n), _p(ic, C.c_int), *[_p(q, C.c_float) for q in r],
                                  _p(x, C.c_double), _p(y, C.c_double), _p(z, C.c_double))
         return x, y, z
+
+    def distance_to_closest_wall(self, icell, x, y, z):
+        n = len(icell)
+        ic = _a(icell, np.int32)
+        d = np.zeros(n)
+        self.lib.ref_distance_to_closest_wall(C.c_int(n), _p(ic, C.c_int), _p(_a(x, np.float64), C.c_double),
+                                              _p(_a(y, np.float64), C.c_double), _p(_a(z, np.float64), C.c_double),
+                                              _p(d, C.c_double))
+        return d
 
     def init_tab_temp(self, n_T, T_min, T_max):
         out = np.zeros(n_T, np.float32)

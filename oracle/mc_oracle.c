@@ -116,6 +116,13 @@ static void rng_begin_event(rng_t *r) {
   r->event += 1;
 }
 static inline float rng_float(rng_t *r) { return r->ev[r->pos++]; }
+/* the modified random walk draws from its own counter sub-space: block k of the walk that follows event number
+ * r->event (>= 1; the events themselves use ctr[1] = 0) */
+static void rng_mrw_block(const rng_t *r, uint32_t k, float out4[4]) {
+  uint32_t ctr[4] = {k, r->event, r->p_lo, r->p_hi}, out[4];
+  oracle_philox4x32_10(ctr, r->key, out);
+  for (int q = 0; q < 4; ++q) out4[q] = u32_to_real(out[q]);
+}
 static inline float rng_tau(const rng_t *r) { return r->ev[r->tau_idx]; }
 
 float oracle_packet_rand(uint64_t seed, uint64_t packet, uint32_t n) {
@@ -1520,20 +1527,26 @@ static void physical_length(worker_t *W, int lambda, const double Stokes[4],
 }
 
 /* im_reemission_LTE (thermal_emission.f90:710-771) */
+/* the cell's temperature as im_reemission_LTE sees it (thermal_emission.f90:660-708) */
+static void cell_temperature(worker_t *W, int icell, int *Ti, float *Temp, double *frac_T2) {
+  const oracle_model *m = W->m;
+  if (W->o->frozen) {
+    oracle_temp_lte(m, W->E_prior[icell - 1], m->volume[icell - 1], 2, Ti,
+                    Temp, frac_T2);
+  } else {
+    /* id > 0 branch (:670): partial sum * nb_proc, cached xT_ech (:685,:702) */
+    oracle_temp_lte(m, W->E_abs[icell - 1] * W->qscale, m->volume[icell - 1],
+                    W->xT_ech[icell - 1], Ti, Temp, frac_T2);
+    W->xT_ech[icell - 1] = *Ti;
+  }
+}
+
 static void im_reemission_LTE(worker_t *W, int icell, float rand1, float rand2,
                               int *lambda) {
   const oracle_model *m = W->m;
   (void)rand1;
   int Ti; float Temp; double frac_T2;
-  if (W->o->frozen) {
-    oracle_temp_lte(m, W->E_prior[icell - 1], m->volume[icell - 1], 2, &Ti,
-                    &Temp, &frac_T2);
-  } else {
-    /* id > 0 branch (:670): partial sum * nb_proc, cached xT_ech (:685,:702) */
-    oracle_temp_lte(m, W->E_abs[icell - 1] * W->qscale, m->volume[icell - 1],
-                    W->xT_ech[icell - 1], &Ti, &Temp, &frac_T2);
-    W->xT_ech[icell - 1] = Ti;
-  }
+  cell_temperature(W, icell, &Ti, &Temp, &frac_T2);
   int T2 = Ti, T1 = Ti - 1;
   double frac_T1 = 1.0 - frac_T2;
   int l1 = 0, l2 = m->n_lambda, l = (l1 + l2) / 2;
@@ -1607,6 +1620,107 @@ static int emit_packet(worker_t *W, int lambda, int *icell, double *x,
 
 /* propagate_packet (dust_transfer.f90:1155-1409), .not.lmono, lonly_LTE,
  * scattering method 2 */
+/* ------------------------------------------------------------------------ */
+/* Modified random walk (Min et al. 2009; Robitaille 2010).  The reference carries the pieces -- the zeta table     */
+/* (MRW.f90:16-53), gamma_MRW = 2 (:11), cst_ct = 3/pi^2 (:12), the step (:74-115), distance_to_closest_wall_cyl     */
+/* (cylindrical_grid.f90:1179), the trigger n_interactions_in_cell > 5 and the loop (dust_transfer.f90:1222-1239) --  */
+/* but its step is an unfinished stub behind a commented-out call.  What follows is the algorithm those pieces and    */
+/* their TODO comments describe, made to work: PARITY UNPINNED, checked against the brute-force loop.                 */
+/* ------------------------------------------------------------------------ */
+double oracle_distance_to_closest_wall_cyl(const oracle_model *m, int icell, double x, double y, double z) {
+  const int ri0 = m->cell_map_i[icell - 1];
+  int zj0 = m->cell_map_j[icell - 1];
+  const double r = sqrt(x * x + y * y);
+  const double s1 = m->r_lim[ri0] - r;
+  const double s2 = r - m->r_lim[ri0 - 1];
+  const double z0 = fabs(z);
+  if (zj0 < 0) zj0 = -zj0;
+  const double s3 = zlim(m, ri0, zj0 + 1) - z0;
+  const double s4 = z0 - zlim(m, ri0, zj0);
+  double s = s1 < s2 ? s1 : s2;
+  if (s3 < s) s = s3;
+  if (s4 < s) s = s4;
+  return s;
+}
+
+void oracle_mrw_zeta_table(int n, double *zeta) {
+  for (int i = 1; i <= n; ++i) {
+    const double yv = (double)(i - 1) / (double)(n - 1);
+    double zt = 0.0;
+    if (i == n) {
+      zt = 0.5;
+    } else {
+      for (int j = 1;; ++j) {
+        const double term = pow(yv, (double)(j * j));
+        if (term == 0.0) break;
+        if (j % 2 == 0) zt -= term; else zt += term;
+      }
+    }
+    zeta[i - 1] = zt * 2.0;
+  }
+}
+
+double oracle_mrw_sample_y(const oracle_model *m, float xi) {
+  const double *zt = m->mrw_zeta;
+  const int n = m->mrw_n_zeta;
+  const double x = xi > 0.0f ? (double)xi : 2.9802322387695312e-08; /* a zero draw: half the smallest one */
+  int lo = 0, hi = n - 1; /* zt[lo] <= x < zt[hi] */
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) / 2;
+    if (zt[mid] <= x) lo = mid; else hi = mid;
+  }
+  const double f = (x - zt[lo]) / (zt[hi] - zt[lo]);
+  return ((double)lo + f) / (double)(n - 1);
+}
+
+/* One walk: returns 0 when the criterion d * chi > gamma does not hold at the start (nothing is drawn). */
+static int mrw_walk(worker_t *W, int *lambda, int icell, double *x, double *y, double *z, double *u, double *v,
+                    double *w, double Stokes[4]) {
+  const oracle_model *m = W->m;
+  double d = oracle_distance_to_closest_wall_cyl(m, icell, *x, *y, *z);
+  int Ti; float Temp; double frac;
+  cell_temperature(W, icell, &Ti, &Temp, &frac);
+  const double kf = m->kappa_factor[icell - 1];
+  const double chi = (m->mrw_chi[Ti - 2] * (1.0 - frac) + m->mrw_chi[Ti - 1] * frac) * kf;
+  if (!(d * chi > (double)m->mrw_gamma)) return 0;
+  const double kdep = m->mrw_kappa_dep[Ti - 2] * (1.0 - frac) + m->mrw_kappa_dep[Ti - 1] * frac;
+  /* the radius the diffusion solution is extrapolated to (the packets' mean free paths are not small against a
+   * sphere of a few of them): d + ext, ext at the reference cell's density */
+  const double ext = (m->mrw_ext[Ti - 2] * (1.0 - frac) + m->mrw_ext[Ti - 1] * frac) / kf;
+  const double cst_ct = 3.0 / (PI * PI);
+  float r4[4];
+  double su, sv, sw;
+  uint32_t blk = 0;
+  do {
+    rng_mrw_block(&W->rng, blk++, r4);
+    /* the packet leaves the sphere of radius d through a uniformly distributed point (MRW.f90:85-89) */
+    sw = 2.0 * (double)r4[0] - 1.0;
+    const double uv = sqrt(1.0 - sw * sw), phi = PI * (2.0 * (double)r4[1] - 1.0);
+    su = uv * cos(phi);
+    sv = uv * sin(phi);
+    *x += su * d;
+    *y += sv * d;
+    *z += sw * d;
+    /* the path it travelled inside: Min et al. eq. 8 (MRW.f90:93-99) */
+    const double yv = oracle_mrw_sample_y(m, r4[2]);
+    const double de = d + ext;
+    const double ct = -log(yv) * cst_ct * chi * (de * de);
+    /* "Deposit energy using Planck mean opacity" (MRW.f90:102-103): the Lucy estimator over that path */
+    W->E_abs[icell - 1] += kdep * ct * Stokes[0];
+    W->cnt[ORC_CNT_MRW_STEPS]++;
+    d = oracle_distance_to_closest_wall_cyl(m, icell, *x, *y, *z);
+  } while (d * chi > (double)m->mrw_gamma);
+  /* "Only at end of MRW, to switch to MC: select new wavelength, select new photon direction" (MRW.f90:108-112):
+   * the packet was absorbed and re-emitted inside, so it leaves as a thermal packet of this cell -- through the
+   * sphere's surface, i.e. outwards: cosine law about the last step's direction */
+  rng_mrw_block(&W->rng, blk, r4);
+  im_reemission_LTE(W, icell, r4[3], r4[0], lambda);
+  oracle_cdapres(sqrt((double)r4[1]), PI * (2.0 * (double)r4[2] - 1.0), su, sv, sw, u, v, w);
+  Stokes[1] = 0.0; Stokes[2] = 0.0; Stokes[3] = 0.0;
+  W->cnt[ORC_CNT_MRW_WALKS]++;
+  return 1;
+}
+
 static void propagate_packet(worker_t *W, int *lambda, int p_lambda,
                              int *icell, double *x, double *y, double *z,
                              double *u, double *v, double *w, double Stokes[4],
@@ -1614,6 +1728,7 @@ static void propagate_packet(worker_t *W, int *lambda, int p_lambda,
                              int *lpacket_alive) {
   const oracle_model *m = W->m;
   int flag_sortie = 0;
+  int n_interactions_in_cell = 0;                             /* :1204 */
   *flag_scatt = 0;
   for (;;) {
     float rand = rng_tau(&W->rng);                            /* :1208 */
@@ -1628,8 +1743,21 @@ static void propagate_packet(worker_t *W, int *lambda, int p_lambda,
       if (rand > 1.0e-6f) tau = -log(1.0 - (double)rand);
       else tau = (double)rand;
     }
+    /* :1222-1239.  A walk starts from a packet the cell has just re-emitted (it is what the walk's diffusion
+     * describes: a packet that still carries starlight it has only scattered has its first absorption ahead) */
+    if (m->mrw && !W->mono && n_interactions_in_cell > m->mrw_n_inter && !*flag_scatt && !*flag_star) {
+      if (mrw_walk(W, lambda, *icell, x, y, z, u, v, w, Stokes)) {
+        *flag_star = 0; *flag_scatt = 0; *flag_ISM = 0;
+      }
+    }
+    const uint64_t cross_before = W->cnt[ORC_CNT_CROSSINGS], dark_before = W->cnt[ORC_CNT_DARK];
     physical_length(W, *lambda, Stokes, icell, x, y, z, u, v, w, *flag_star, tau,
                     &flag_sortie, lpacket_alive);             /* :1243 */
+    /* :1244-1249 counts the flights that end in the cell they started in; here: that never left it (in a 2D grid
+     * a flight can come back to its ring on the other side of the star) */
+    if (W->cnt[ORC_CNT_CROSSINGS] - cross_before == 1 && W->cnt[ORC_CNT_DARK] == dark_before) {
+      if (n_interactions_in_cell < 7) n_interactions_in_cell++;
+    } else n_interactions_in_cell = 0;
     if (flag_sortie) return;                                  /* :1251 */
 
     rng_begin_event(&W->rng);

@@ -30,7 +30,7 @@ extern "C" {
 #define ORACLE_N_SED_TYPES 9 /* sed, sed_q, sed_u, sed_v, n_phot_sed, sed_star,
                                 sed_star_scat, sed_disk, sed_disk_scat
                                 (output.f90:572-592) */
-#define ORACLE_N_COUNTERS 8
+#define ORACLE_N_COUNTERS 10
 enum {
   ORC_CNT_PACKETS = 0,     /* packets launched                              */
   ORC_CNT_CROSSINGS = 1,   /* cross_cell calls                              */
@@ -39,7 +39,9 @@ enum {
   ORC_CNT_ABS = 4,         /* absorb + re-emit events                       */
   ORC_CNT_ESCAPED = 5,     /* packets binned by capteur                     */
   ORC_CNT_KILLED_STAR = 6, /* packets that hit a star                       */
-  ORC_CNT_DARK = 7         /* dark-zone mirror events                       */
+  ORC_CNT_DARK = 7,        /* dark-zone mirror events                       */
+  ORC_CNT_MRW_WALKS = 8,   /* modified random walks (each ends in one re-emission) */
+  ORC_CNT_MRW_STEPS = 9    /* sphere steps of those walks                   */
 };
 
 /* One star (parameters.f90:230-238). Lengths in AU. */
@@ -159,6 +161,20 @@ typedef struct {
   int N_type_flux;          /* init_mcfost.f90:1603-1616 */
   int lsepar_contrib;
   const float *tab_s11_pos; /* (0:nang_scatt, n_lambda): tab_s11_pos(:,1,p_lambda) */
+
+  /* ---- modified random walk (MRW.f90, dust_transfer.f90:1222-1239; Min et al. 2009, Robitaille 2010).  The
+   * reference's routine is an unfinished stub that is never called (SURVEY finding 2): this is the working
+   * algorithm its comments describe -- PARITY UNPINNED, validated against the brute-force loop.  mrw = 0: off. ---- */
+  int mrw;
+  int mrw_n_zeta;              /* n = 10000 (MRW.f90:8) */
+  const double *mrw_zeta;      /* zeta(y_i), y_i = (i-1)/(n-1): initialize_cumulative_zeta (MRW.f90:16-53) */
+  const double *mrw_chi;       /* [n_T] mean transport extinction at tab_Temp, reference cell (AU^-1): the "rec_Planck_opacity"
+                                  of make_MRW_step, D = 1/(3 chi kappa_factor) */
+  const double *mrw_kappa_dep; /* [n_T] mean absorption opacity the walk deposits with (units of kappa_abs_LTE) */
+  const double *mrw_ext;       /* [n_T] extrapolation length of the sphere radius, reference cell (AU); zeros: none */
+  float mrw_gamma;             /* gamma_MRW = 2 (MRW.f90:11) */
+  int mrw_n_inter;             /* a walk may start after more than this many interactions in one cell: 5 (:1223) */
+  const double *r_lim;         /* [0..n_rad] (cylindrical_grid.f90:22), read by distance_to_closest_wall_cyl */
 } oracle_model;
 
 /* Run options. */
@@ -283,6 +299,15 @@ int oracle_dust_map_image(const oracle_model *m, const oracle_rt_opts *o, int np
  */
 int oracle_define_dark_zone(const oracle_model *m, int lambda, double tau_max, const double *r_lim,
                             const double *r_grid, const double *z_grid, unsigned char *l_dark_zone);
+
+/* distance_to_closest_wall_cyl (cylindrical_grid.f90:1179-1226), 2D: PINNED to the reference's module
+ * (tests/golden/mrw_dist_*.npz); reads m->r_lim. */
+double oracle_distance_to_closest_wall_cyl(const oracle_model *m, int icell, double x, double y, double z);
+/* initialize_cumulative_zeta (MRW.f90:16-53): zeta[n] on y_i = (i-1)/(n-1) */
+void oracle_mrw_zeta_table(int n, double *zeta);
+/* y with zeta(y) = xi: the inverse the stub's sample_zeta (MRW.f90:58-70) means (it interpolates the table the
+ * wrong way round) */
+double oracle_mrw_sample_y(const oracle_model *m, float xi);
 
 /* Steps 1-3 of define_dark_zone + the extension of zj_sup (optical_depth.f90:1459-1500, 1579-1586): the extent of
  * the zone the diffusion approximation refills; zj_sup[n_rad]. */

@@ -264,6 +264,18 @@ contains
     enddo
   end subroutine ref_pos_em_cell
 
+  ! distance_to_closest_wall_cyl, cylindrical_grid.f90:1179
+  subroutine ref_distance_to_closest_wall(n, icell, x, y, z, d) bind(C, name="ref_distance_to_closest_wall")
+    integer(c_int), value :: n
+    integer(c_int), intent(in) :: icell(n)
+    real(c_double), intent(in) :: x(n), y(n), z(n)
+    real(c_double), intent(out) :: d(n)
+    integer :: i
+    do i = 1, n
+       d(i) = distance_to_closest_wall_cyl(icell(i), x(i), y(i), z(i))
+    enddo
+  end subroutine ref_distance_to_closest_wall
+
   ! init_tab_Temp, Temperature.f90:23
   subroutine ref_init_tab_temp(c_n_T, c_T_min, c_T_max, o_tab_Temp) bind(C, name="ref_init_tab_temp")
     integer(c_int), value :: c_n_T

@@ -157,6 +157,9 @@ struct Conv {
     M.tan_theta_lim = m->tan_theta_lim; M.theta_lim = m->theta_lim; M.r_lim_3 = m->r_lim_3;
     M.R_ISM = m->R_ISM;
     for (int q = 0; q < 3; ++q) M.centre_ISM[q] = m->centre_ISM[q];
+    M.mrw = m->mrw; M.mrw_n_zeta = m->mrw_n_zeta; M.mrw_n_inter = m->mrw_n_inter; M.mrw_gamma = m->mrw_gamma;
+    M.mrw_zeta = m->mrw_zeta; M.mrw_chi = m->mrw_chi; M.mrw_kdep = m->mrw_kappa_dep; M.mrw_ext = m->mrw_ext;
+    M.r_lim = m->r_lim;
   }
 };
 
@@ -181,7 +184,7 @@ extern "C" int emu_run_thermal(const oracle_model* m, const oracle_opts* o, cons
   A.seed = o->seed; A.first_packet = o->first_packet; A.n_packets = o->n_packets;
   A.qscale = o->n_replicas >= 1.0 ? o->n_replicas : 1.0;
   A.frozen = o->frozen; A.E_prior = E_prior; A.E_abs = E_abs; A.sed = sed; A.n_sent = n_sent;
-  A.counters = cnt; A.next_packet = cnt + 8; A.err = &err;
+  A.counters = cnt; A.next_packet = cnt + 12; A.err = &err;
   A.inner_iters = 8; A.flags = 0; A.flush_every = 4; A.min_active = 0;
   const bool pola = m->lsepar_pola && m->aniso_method == 1, dark = M.dark != nullptr, l3d = m->l3D != 0;
   if (voro) {
@@ -190,7 +193,7 @@ extern "C" int emu_run_thermal(const oracle_model* m, const oracle_opts* o, cons
     } else {
       if (pola) k_thermal_voro<true>(M, A, G); else k_thermal_voro<false>(M, A, G);
     }
-    for (int q = 0; q < 8; ++q) counters[q] = cnt[q];
+    for (int q = 0; q < ORACLE_N_COUNTERS; ++q) counters[q] = cnt[q];
     return err;
   }
   if (M.grid_sph) {  // spherical grid: the single-role kernel with that grid's operators
@@ -200,7 +203,7 @@ extern "C" int emu_run_thermal(const oracle_model* m, const oracle_opts* o, cons
                else { if (ld) k_thermal_sph<true, false, true>(M, A); else k_thermal_sph<true, false, false>(M, A); } }
     else { if (pola) { if (ld) k_thermal_sph<false, true, true>(M, A); else k_thermal_sph<false, true, false>(M, A); }
            else { if (ld) k_thermal_sph<false, false, true>(M, A); else k_thermal_sph<false, false, false>(M, A); } }
-    for (int q = 0; q < 8; ++q) counters[q] = cnt[q];
+    for (int q = 0; q < ORACLE_N_COUNTERS; ++q) counters[q] = cnt[q];
     return err;
   }
   if (getenv("MCGPU_EMU_ROLES")) {  // the role schedule on one lane: the one wave alternates between both roles
@@ -213,25 +216,35 @@ extern "C" int emu_run_thermal(const oracle_model* m, const oracle_opts* o, cons
     if (lds_bytes(M) + sizeof(double) * m->n_cells + rq_lds_bytes(true, n_rec) + 64 > sizeof(lds_raw)) return 31;
     A.flush_every = 4;
 #define RUNR(a, b, c) do { if (ld) k_thermal_roles<a, b, c, true>(M, A, n_rec, nsp, ks, fi, 65, eq); else k_thermal_roles<a, b, c, false>(M, A, n_rec, nsp, ks, fi, 65, eq); } while (0)
-    if (l3d) {
+#define RUNRM(b, c) do { if (ld) k_thermal_roles<false, b, c, true, true>(M, A, n_rec, nsp, ks, fi, 65, eq); else k_thermal_roles<false, b, c, false, true>(M, A, n_rec, nsp, ks, fi, 65, eq); } while (0)
+    if (M.mrw) {
+      if (l3d) return 31;
+      if (pola) { if (dark) RUNRM(true, true); else RUNRM(true, false); }
+      else { if (dark) RUNRM(false, true); else RUNRM(false, false); }
+    } else if (l3d) {
       if (pola) { if (dark) RUNR(true, true, true); else RUNR(true, true, false); }
       else { if (dark) RUNR(true, false, true); else RUNR(true, false, false); }
     } else {
       if (pola) { if (dark) RUNR(false, true, true); else RUNR(false, true, false); }
       else { if (dark) RUNR(false, false, true); else RUNR(false, false, false); }
     }
-    for (int q = 0; q < 8; ++q) counters[q] = cnt[q];
+    for (int q = 0; q < ORACLE_N_COUNTERS; ++q) counters[q] = cnt[q];
     return err;
   }
 #define RUN(a, b, c) do { if (getenv("MCGPU_EMU_LDS")) k_thermal_lds<a, b, c>(M, A); else k_thermal<a, b, c>(M, A); } while (0)
-  if (l3d) {
+#define RUNM(b, c) do { if (getenv("MCGPU_EMU_LDS")) k_thermal_lds<false, b, c, true>(M, A); else k_thermal<false, b, c, true>(M, A); } while (0)
+  if (M.mrw) {
+    if (l3d) return 31;
+    if (pola) { if (dark) RUNM(true, true); else RUNM(true, false); }
+    else { if (dark) RUNM(false, true); else RUNM(false, false); }
+  } else if (l3d) {
     if (pola) { if (dark) RUN(true, true, true); else RUN(true, true, false); }
     else { if (dark) RUN(true, false, true); else RUN(true, false, false); }
   } else {
     if (pola) { if (dark) RUN(false, true, true); else RUN(false, true, false); }
     else { if (dark) RUN(false, false, true); else RUN(false, false, false); }
   }
-  for (int q = 0; q < 8; ++q) counters[q] = cnt[q];
+  for (int q = 0; q < ORACLE_N_COUNTERS; ++q) counters[q] = cnt[q];
   return err;
 }
 

@@ -10,7 +10,7 @@ cross_cylindrical_cell along random walks, index_cell_cyl, test_exit_grid_cyl,
 move_to_grid_cyl, pos_em_cell_cyl -- or, for the spherical configurations, the
 operators of spherical_grid.f90 (cross_spherical_cell, index_cell_sph,
 test_exit_grid_sph, move_to_grid_sph, pos_em_cell_sph) -- init_tab_Temp,
-init_lambda and the constants.  One process per configuration (the reference allocates its module
+init_lambda and the constants; dist_*.npz hold distance_to_closest_wall_cyl.  One process per configuration (the reference allocates its module
 arrays once).
 """
 import os
@@ -104,9 +104,34 @@ def make_one(name, expr, n_rays=400, n_steps=30, seed=7):
     print(name, "walk rows", out["walk"].shape[0])
 
 
+DIST_CONFIGS = ("small2d", "ref41", "pascucci")   # distance_to_closest_wall_cyl, 2D (the 3D branch reads sin_phi_lim(0))
+
+
+def make_dist(name, expr, n=600, seed=11):
+    """dist_<name>.npz: distance_to_closest_wall_cyl (cylindrical_grid.f90:1179) at random points of random cells."""
+    from mcfost_amd.host import model as M
+    from oracle import RefGeom
+
+    cfg = eval(expr)
+    ref = RefGeom()
+    ref.setup_grid(cfg)
+    rng = np.random.default_rng(seed)
+    icell = rng.integers(1, ref.n_cells + 1, n).astype(np.int32)
+    r1, r2, r3 = (rng.random(n).astype(np.float32) for _ in range(3))
+    x, y, z = ref.pos_em_cell(icell, r1, r2, r3)
+    z = z * rng.choice([-1.0, 1.0], n)     # both sides of the midplane: the routine works on |z|
+    d = ref.distance_to_closest_wall(icell, x, y, z)
+    np.savez_compressed(os.path.join(HERE, f"dist_{name}.npz"), icell=icell, x=x, y=y, z=z, d=d)
+    print(name, "distances", d.min(), d.max())
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1:
+    if len(sys.argv) > 2 and sys.argv[1] == "dist":
+        make_dist(sys.argv[2], CONFIGS[sys.argv[2]])
+    elif len(sys.argv) > 1:
         make_one(sys.argv[1], CONFIGS[sys.argv[1]])
     else:
         for name in CONFIGS:
             subprocess.check_call([sys.executable, __file__, name])
+        for name in DIST_CONFIGS:
+            subprocess.check_call([sys.executable, __file__, "dist", name])

@@ -14,6 +14,7 @@ import numpy as np
 import pytest
 
 from mcfost_amd.host import model as M
+from oracle.binding import N_COUNTERS
 from oracle import Oracle
 from helpers import sed_model, xI_close
 from oracle.binding import _Opts, _p
@@ -43,7 +44,7 @@ def emu_run(emu, orc, n, seed, first=0, frozen=True, prior=None):
     E = np.zeros(m.n_cells)
     sed = np.zeros((9, m.cfg.N_phi, m.cfg.N_thet, m.n_lambda))
     ns = np.zeros(m.n_lambda)
-    cnt = np.zeros(8, np.uint64)
+    cnt = np.zeros(N_COUNTERS, np.uint64)
     o = _Opts(seed, first, n, 1, int(frozen), 0, 1.0)
     rc = emu.emu_run_thermal(C.byref(orc.cm), C.byref(o), _p(prior, C.c_double) if prior is not None else None,
                              _p(E, C.c_double), _p(sed, C.c_double), _p(ns, C.c_double), _p(cnt, C.c_uint64))
@@ -254,7 +255,7 @@ def emu_mono(emu, orc, lam, n2, seed, rt1=True, n_chunks=8, n_phot_lim=1e9):
     sed = np.zeros((9, m.cfg.N_phi, m.cfg.N_thet, m.n_lambda))
     ns = np.zeros(m.n_lambda)
     per = np.zeros(n_chunks, np.uint64)
-    cnt = np.zeros(8, np.uint64)
+    cnt = np.zeros(N_COUNTERS, np.uint64)
     rc = emu.emu_run_mono(C.byref(orc.cm), C.byref(o), _p(xI, C.c_double), _p(sed, C.c_double), _p(ns, C.c_double),
                           _p(per, C.c_uint64), _p(cnt, C.c_uint64))
     assert rc == 0, rc
