@@ -1246,7 +1246,7 @@ __device__ __forceinline__ void interact(const Lds& T, const DevModel& M, const 
 // Modified random walk (Min et al. 2009; Robitaille 2010) for the 2D cylindrical grid.  The reference carries the
 // pieces (MRW.f90: zeta table :16-53, gamma_MRW :11, cst_ct :12, the step :74-115; distance_to_closest_wall_cyl,
 // cylindrical_grid.f90:1179; the trigger and the loop, dust_transfer.f90:1222-1239) but its step is an unfinished
-// stub behind a commented-out call; this is the working algorithm, stated in oracle/mc_oracle.c (mrw_walk) and
+// stub behind a commented-out call; this is the working algorithm, described in DESIGN.md (section "Modified random walk") and
 // validated against the brute-force loop.  The walk's draws come from the packet's own counter
 // sub-space (block k of event e: Philox counter (k, e, packet id)), so the result does not depend on the schedule.
 // ---------------------------------------------------------------------------

@@ -118,7 +118,8 @@ def test_emulated_kernels_walk_like_the_oracle(emu):
     m = thick_disk()
     n = 3000
     orc = Oracle(m, n)
-    prior = Oracle(thick_disk(mrw=False), n).run_thermal(20000, seed=1, n_threads=4)["E_abs"] * (n / 20000)
+    # (one thread: the live prior, hence the whole test, is the same in every run)
+    prior = Oracle(thick_disk(mrw=False), n).run_thermal(20000, seed=1, n_threads=1)["E_abs"] * (n / 20000)
     want = orc.run_thermal(n, seed=9, frozen=True, E_prior=prior, n_threads=4)
     assert want["counters"]["mrw_walks"] > 100
     for env in ({}, {"MCGPU_EMU_LDS": "1"}, {"MCGPU_EMU_ROLES": "1,2,3,128"}, {"MCGPU_EMU_ROLES": "0,2,3,128", "MCGPU_EMU_LDS": "1"}):
@@ -131,7 +132,8 @@ def test_emulated_kernels_walk_like_the_oracle(emu):
             for k in env:
                 os.environ.pop(k, None)
         assert got["counters"] == list(want["counters"].values()), (env, got["counters"], want["counters"])
-        assert np.allclose(got["E_abs"], want["E_abs"], rtol=1e-8, atol=1e-10 * want["E_abs"].max()), env
+        err = np.abs(got["E_abs"] - want["E_abs"]) / (1e-8 * np.abs(want["E_abs"]) + 1e-10 * want["E_abs"].max())
+        assert err.max() < 1.0, (env, err.max(), int(err.argmax()))
 
 
 # ---------------------------------------------------------------------------------------------------------------

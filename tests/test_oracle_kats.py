@@ -407,6 +407,10 @@ def test_oracle_regression_anchors():
     assert sorted(now) == sorted(ref.files)
     for k in ref.files:
         if ref[k].dtype.kind == "i":
-            assert np.array_equal(now[k], ref[k]), k
+            got = now[k]
+            if k.endswith("counters"):   # the anchors hold the eight event counters; the two MRW counters follow them
+                assert not got[ref[k].size:].any()
+                got = got[:ref[k].size]
+            assert np.array_equal(got, ref[k]), k
         else:   # (libm differences between hosts stay far below this)
             assert np.allclose(now[k], ref[k], rtol=1e-9, atol=1e-12 * np.abs(ref[k]).max()), k
