@@ -196,14 +196,20 @@ def bench_sed(args, world, rank, local_rank):
 
 def thermal_block(M, D, Engine, dist, torch, args, config, world, rank, local_rank, steps, warmup, with_cpu):
     """Times `steps` passes of the thermal packet loop on one configuration; returns (block dict or None on ranks > 0)."""
-    cfg = {"ref41": M.ref41, "ref41_3d": M.ref41_3d, "pascucci": M.pascucci, "voronoi": M.ref41}[config]()
+    cfg = {"ref41": M.ref41, "ref41_mrw": M.ref41, "ref41_3d": M.ref41_3d, "pascucci": M.pascucci, "voronoi": M.ref41}[config]()
     if args.no_pola:
         cfg.lsepar_pola = False
+    if args.dust_mass:   # a heavier (optically thicker) disk than the configuration's: where the random walk matters
+        cfg.dust_mass = args.dust_mass
+        cfg.name += " with M_dust = %g Msun" % args.dust_mass
     if config == "voronoi":
         cfg.name = "ref4.1 disk as %d Voronoi sites" % args.sites
         model = M.build_voronoi_model(cfg, args.sites, seed=1)
     else:
         model = M.build_model(cfg)
+    if config == "ref41_mrw":   # BASELINE config 4: ref4.1 with the modified random walk (gamma_MRW = 2, MRW.f90:11)
+        cfg.name += " + MRW (gamma %g)" % args.mrw_gamma
+        M.init_mrw(model, gamma=args.mrw_gamma)
     n_local = int(args.packets)
     n_total = n_local * world
     eng = Engine(model, n_total, device=local_rank)
@@ -277,7 +283,10 @@ def thermal_block(M, D, Engine, dist, torch, args, config, world, rank, local_ra
                              else "%s 3D cylindrical disk %dx%dx%d, %.3g packets/GPU/step"
                              % (cfg.name, cfg.n_rad, cfg.nz, cfg.n_az, n_local)),
                             "packets_per_gpu": n_local, "parallelism": "packets sharded x%d, tables replicated" % world,
-                            "crossings_per_packet": cross_pp, "interactions_per_packet": inter_pp},
+                            "crossings_per_packet": cross_pp, "interactions_per_packet": inter_pp,
+                            **({"mrw_walks_per_packet": cnt["mrw_walks"] / max(cnt["packets"], 1),
+                                "mrw_steps_per_packet": cnt["mrw_steps"] / max(cnt["packets"], 1)}
+                               if config == "ref41_mrw" else {})},
                  "roofline": roof}
         if with_cpu:
             base, T_cpu, n_cpu = cpu_baseline(model, n_total, args.cpu_seconds)
@@ -294,7 +303,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--packets", type=float, default=1e8, help="packets per GPU per step")
-    ap.add_argument("--config", default="pascucci", choices=["pascucci", "ref41", "ref41_3d", "voronoi", "sed"],
+    ap.add_argument("--config", default="pascucci", choices=["pascucci", "ref41", "ref41_mrw", "ref41_3d", "voronoi", "sed"],
                     help="pascucci (default): the disk BASELINE.json's metric is quoted on, with ref4.1 (configs[1]) as a "
                          "second full block of the same line")
     ap.add_argument("--sed-lambdas", default="5,15,25,35",
@@ -302,6 +311,8 @@ def main():
     ap.add_argument("--sites", type=int, default=100000,
                     help="--config voronoi: number of SPH-like sites of the tessellation (BASELINE config 5 stand-in)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mrw-gamma", type=float, default=2.0, help="--config ref41_mrw: gamma_MRW")
+    ap.add_argument("--dust-mass", type=float, default=0.0, help="override the disk's dust mass [Msun] (thermal configs)")
     ap.add_argument("--no-ref41", action="store_true", help="--config pascucci: skip the ref4.1 block")
     ap.add_argument("--no-pascucci", action="store_true", help="(kept for older command lines: same as --no-ref41)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
