@@ -204,7 +204,7 @@ def thermal_block(M, D, Engine, dist, torch, args, config, world, rank, local_ra
         cfg.name += " with M_dust = %g Msun" % args.dust_mass
     if config == "voronoi":
         cfg.name = "ref4.1 disk as %d Voronoi sites" % args.sites
-        model = M.build_voronoi_model(cfg, args.sites, seed=1)
+        model = M.build_voronoi_model(cfg, args.sites, seed=1, cache_dir=os.path.join(ROOT, "tools", "cache"))
     else:
         model = M.build_model(cfg)
     if config == "ref41_mrw":   # BASELINE config 4: ref4.1 with the modified random walk (gamma_MRW = 2, MRW.f90:11)

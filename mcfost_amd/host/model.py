@@ -891,7 +891,7 @@ def build_model(cfg: DiskConfig, grid=None, rho=None) -> Model:
 
 
 def build_voronoi_model(cfg: DiskConfig, n_sites: int, seed: int = 1, box_z_over_h: float = 6.0,
-                        cut: bool = True) -> Model:
+                        cut: bool = True, cache_dir: Optional[str] = None) -> Model:
     """BASELINE config 5 stand-in: ``n_sites`` SPH-like sites drawn from the cfg's disk,
     tessellated in a box (``Voronoi.f90:183-640`` hands the same arrays to the loop), the
     star added as its own site, densities from the analytic disk evaluated at the sites."""
@@ -912,7 +912,20 @@ def build_voronoi_model(cfg: DiskConfig, n_sites: int, seed: int = 1, box_z_over
     pdf_r = p * rs ** (p - 1.0) / (cfg.rout ** p - cfg.rin ** p)  # per unit r
     dens = n_sites * pdf_r / (2 * PI * rs) * np.exp(-0.5 * (sites[:, 2] / Hs) ** 2) / (math.sqrt(2 * PI) * Hs)
     h = 1.2 * np.cbrt(1.0 / dens)
-    grid = V.build_voronoi_grid(sites, limits, stars_xyz_r=[(sx, sy, sz, r_au)], h=h, cut=cut)
+    # (the tessellation of 1e6 sites takes minutes on the host: ``cache_dir`` keeps it between runs of one model)
+    grid, cache = None, None
+    if cache_dir:
+        import os
+        cache = os.path.join(cache_dir, "voronoi_%s_%d_%d_%g_%d.npz" % (cfg.name.split()[0], n_sites, seed, box_z_over_h,
+                                                                        int(cut)))
+        if os.path.exists(cache):
+            z = np.load(cache)
+            grid = {k: (z[k] if z[k].ndim else z[k].item()) for k in z.files}
+    if grid is None:
+        grid = V.build_voronoi_grid(sites, limits, stars_xyz_r=[(sx, sy, sz, r_au)], h=h, cut=cut)
+        if cache:
+            os.makedirs(cache_dir, exist_ok=True)
+            np.savez(cache, **grid)
     # equal-mass SPH particles: rho_i = (M_dust / N) / V_i; star sites carry no dust
     nb = grid["n_cells_before_stars"]
     rho = np.zeros(grid["n_cells"], f64)

@@ -920,6 +920,61 @@ def test_full_size_properties_ref41_3d():
     assert ok, p75
 
 
+@pytest.mark.parametrize("snap", [0, 1])
+def test_3d_midplane_conventions_frozen_parity(snap):
+    """3D grids, both treatments of a crossing that lands on z = 0 (include/mcgpu.h: mcgpu_set_midplane_snap).
+    snap = 1 (engine default): the landing point is put at sign(grid_prec, w), the reference's own correction for
+    z1 == 0 (cylindrical_grid.f90:1158-1165) applied to every rounding residue -- device and oracle then agree packet
+    for packet.  snap = 0 is the reference's literal arithmetic (what the golden walks pin): the SIGN of the residue
+    of z0 + t*w decides the hemisphere of the next cell, and it is decided by the last ulp (FMA or not), so a device
+    build and a host build of the same formula part ways on a few crossings in a million; the packets concerned cross
+    one cell in the mirror hemisphere (same density: the disk is symmetric) and nothing else changes."""
+    for cfg, n, seed in ((M.small(n_rad=12, nz=6, n_az=8, l3D=True), 20000, 8), (M.ref41_3d(n_az=12), 40000, 62)):
+        m = M.build_model(cfg)
+        m.midplane_snap = snap
+        if snap == 1:
+            _frozen_parity(m, n, seed=seed, n_prior=20000, rtol=1e-6)
+            continue
+        e, o = _engine(m, n), _oracle(m, n)
+        prior = o.run_thermal(20000, seed=1)["E_abs"]
+        a = e.run_thermal(n, seed=seed, frozen=True, E_prior=prior)
+        b = o.run_thermal(n, seed=seed, frozen=True, E_prior=prior, n_threads=8)
+        e.close()
+        ca, cb = a["counters"], b["counters"]
+        for k in ("packets", "escaped", "killed_star"):
+            assert ca[k] == cb[k]
+        assert np.array_equal(a["n_sent"], b["n_sent"])
+        for k in ("crossings", "flights", "scatterings", "absorptions"):
+            assert abs(ca[k] - cb[k]) <= 3 + 1e-3 * cb[k], (k, ca, cb)
+        # hemispheres summed: the deposits are the same to the packets that parted
+        n_az, nz2, n_rad = cfg.n_az, 2 * cfg.nz, cfg.n_rad
+        Ea, Eb = a["E_abs"].reshape(n_az, nz2, n_rad), b["E_abs"].reshape(n_az, nz2, n_rad)
+        Ea, Eb = Ea[:, :cfg.nz][:, ::-1] + Ea[:, cfg.nz:], Eb[:, :cfg.nz][:, ::-1] + Eb[:, cfg.nz:]
+        assert np.isclose(Ea.sum(), Eb.sum(), rtol=2e-3)
+
+
+def test_3d_midplane_conventions_give_the_same_temperature():
+    """Full-size 3D grid (720 000 cells), live mode, 2e7 packets with either convention: same conservation laws and
+    statistically the same temperature -- the choice is a matter of reproducibility, not of physics."""
+    n = 20_000_000
+    T = {}
+    for snap in (0, 1):
+        m3 = M.build_model(M.ref41_3d())
+        m3.midplane_snap = snap
+        e = _engine(m3, n)
+        a = e.run_thermal(n, seed=71)
+        c = a["counters"]
+        assert c["packets"] == n and c["escaped"] + c["killed_star"] == n and a["n_sent"].sum() == n
+        T[snap] = e.temp_finale(a["E_abs"]).reshape(72, 100, 100).mean(axis=0)
+        e.close()
+    sel = (T[0] > 1.2 * m3.cfg.T_min) & (T[1] > 1.2 * m3.cfg.T_min)
+    ok, p75 = mc_similar(T[0][sel], T[1][sel], 0.01)
+    assert ok, p75
+    north, south = T[0][50:, :], T[0][49::-1, :]
+    s2 = (north > 1.2 * m3.cfg.T_min) & (south > 1.2 * m3.cfg.T_min)
+    assert np.median(np.abs(north[s2] / south[s2] - 1.0)) < 0.01
+
+
 def test_frozen_parity_with_the_reference_style_dark_zone():
     """A disk massive enough to have a dark zone by define_dark_zone's rule (optical_depth.f90:1425-1651, restated
     in the oracle): mirror at the zone's edge in the thermal step, packets dropped inside it in the SED step."""

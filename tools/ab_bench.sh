@@ -6,8 +6,10 @@ for spec in "$@"; do
   lib=$(echo $spec | cut -d: -f1); cfg=$(echo $spec | cut -d: -f2); envs=$(echo $spec | cut -d: -f3 | tr ',' ' ')
   libpath=mcfost_amd/csrc/libmcfost_hip.so
   [ "$lib" != "default" ] && libpath=mcfost_amd/csrc/variants/$lib.so
+  extra=""
+  case $cfg in *@*) extra="--sites ${cfg#*@}"; cfg=${cfg%@*};; esac   # voronoi@1000000: that many sites
   echo "== $spec" >> $out
-  env MCGPU_LIB=$PWD/$libpath $envs python bench.py --config $cfg --packets $n --steps 2 --warmup 1 --no-cpu-baseline --no-pascucci 2>>$out.err | python -c "
+  env MCGPU_LIB=$PWD/$libpath $envs python bench.py --config $cfg $extra --packets $n --steps 2 --warmup 1 --no-cpu-baseline --no-pascucci 2>>$out.err | python -c "
 import sys,json
 for l in sys.stdin:
     try: d=json.loads(l)
