@@ -170,6 +170,8 @@ int mcgpu_set_midplane_snap(mcgpu_ctx *ctx, int on);
  *   "speculation"  SED mode: 1 (default) = most of every stream is committed before the
  *                      scout pass (exact; see mcgpu_run_mono), 0 = scout every packet first
  *   "voronoi_cache_log_slots"  6..13 (default 13): log2 of the slots of the Voronoi deposit cache
+ *   "radiation_field"  bit 0: keep xN_abs, bit 1: keep xJ_abs in the thermal step (mcgpu_fetch_radiation_field);
+ *                      cylindrical grids then run the single-role kernel
  * Results do not depend on any of them (same packets, same random numbers).
  */
 int mcgpu_set_option(mcgpu_ctx *ctx, const char *name, int value);
@@ -427,6 +429,16 @@ int mcgpu_probe_philox(mcgpu_ctx *ctx, const uint32_t ctr[4],
                        const uint32_t key[2], uint32_t out[4]);
 int mcgpu_probe_packet_rand(mcgpu_ctx *ctx, uint64_t seed, uint64_t packet,
                             int n, float *out);
+
+/*
+ * The optional accumulators of save_radiation_field's thermal branch (radiation_field.f90:54-55):
+ *   xN_abs[n_cells]             path segments per cell (xN_abs(icell,1,id) with lmcfost_lib: what run_mcfost_phantom
+ *                               returns, mcfost2phantom.f90:361), summed over "threads"
+ *   xJ_abs[n_cells * n_lambda]  sum of l * Stokes(1) per cell and wavelength (lxJ_abs_step1), column-major (icell, lambda)
+ * Switched on before a thermal launch with mcgpu_set_option(ctx, "radiation_field", bits) -- bit 0: xN_abs, bit 1:
+ * xJ_abs; zeroed by a launch unless accumulate is set.  Either pointer may be NULL.
+ */
+int mcgpu_fetch_radiation_field(mcgpu_ctx *ctx, double *xN_abs, double *xJ_abs);
 
 /*
  * Modified random walk (module MRW, MRW.f90; the call site dust_transfer.f90:1222-1239 is commented out in the

@@ -157,6 +157,9 @@ struct RunArgs {
   int flush_every;  // LDS-deposit kernels: outer iterations per fold of the private grid
   int min_active;   // leave the crossing loop early once fewer lanes than this are in flight
   int flags;        // diagnostics, -DMCGPU_TUNING builds only (MCGPU_DIAG)
+  // optional radiation-field accumulators of save_radiation_field (radiation_field.f90:54-55): null = off
+  unsigned int* xN_abs;  // [n_cells] path segments per cell (xN_abs(icell,1,id), lmcfost_lib)
+  double* xJ_abs;        // (n_cells, n_lambda) sum of l * Stokes(1) (lxJ_abs_step1)
 };
 
 // ---------------------------------------------------------------------------
@@ -975,6 +978,12 @@ __device__ inline void deposit(double* E_glob, double* E_lds, int ic, double v) 
   else atomic_add_f64(&E_glob[ic], v);
 }
 
+// the optional accumulators of save_radiation_field's thermal branch (radiation_field.f90:54-55)
+__device__ inline void radiation_field_extras(const DevModel& M, const RunArgs& A, int ic, int lambda, double l_S0) {
+  if (A.xN_abs) atomicAdd(&A.xN_abs[ic], 1u);
+  if (A.xJ_abs) atomic_add_f64(&A.xJ_abs[(size_t)ic + (size_t)M.n_cells * (size_t)(lambda - 1)], l_S0);
+}
+
 // ---------------------------------------------------------------------------
 // Deposit cache: 2^log_ns slots of (cell id, partial sum) in LDS, for grids whose absorbed-energy array does not
 // fit in LDS (3D cylindrical: 5.76 MB; Voronoi).  The deposits are extremely concentrated (every packet starts in
@@ -1669,6 +1678,7 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
             if (tau > extr) {
               const double lc = l * (extr / tau);
               if (real_cell && !MCGPU_DIAG(A.flags, 1)) deposit<LDSE>(A.E_abs, E_lds, ic, T.kabs[lambda - 1] * lc * S[0]);
+              if (real_cell) radiation_field_extras(M, A, ic, lambda, lc * S[0]);
               x = x + lc * u;
               y = y + lc * v;
               z = z + lc * w;
@@ -1679,6 +1689,7 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
               first_cross = false;
               extr = extr - tau;
               if (real_cell && !MCGPU_DIAG(A.flags, 1)) deposit<LDSE>(A.E_abs, E_lds, ic, T.kabs[lambda - 1] * l * S[0]);
+              if (real_cell) radiation_field_extras(M, A, ic, lambda, l * S[0]);
               if (DARK) { xo = x; yo = y; zo = z; ri_o = ri; zj_o = zj; k_o = k; }
               x = x1; y = y1; z = z1;
               ri = ri1; zj = zj1; k = k1;

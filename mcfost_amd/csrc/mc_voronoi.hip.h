@@ -407,6 +407,7 @@ __device__ __forceinline__ void thermal_body_voro(const DevModel& M, const RunAr
             if (dE != 0.0 && !MCGPU_DIAG(A.flags, 1)) {
               if (!(CACHE && DC.add(icell, dE))) atomic_add_f64(&A.E_abs[icell - 1], dE);
             }
+            radiation_field_extras(M, A, icell - 1, lambda, lc * S[0]);
             x = nd_add(x, nd_mul(ls, u));
             y = nd_add(y, nd_mul(ls, v));
             z = nd_add(z, nd_mul(ls, w));
@@ -417,6 +418,7 @@ __device__ __forceinline__ void thermal_body_voro(const DevModel& M, const RunAr
             if (dE != 0.0 && !MCGPU_DIAG(A.flags, 1)) {
               if (!(CACHE && DC.add(icell, dE))) atomic_add_f64(&A.E_abs[icell - 1], dE);
             }
+            radiation_field_extras(M, A, icell - 1, lambda, l_contrib * S[0]);
             x = x1; y = y1; z = z1;
             prev_cell = icell;
             icell = next;

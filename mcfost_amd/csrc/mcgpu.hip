@@ -54,6 +54,9 @@ struct mcgpu_ctx {
   int opt_schedule = 0;     // 0 = automatic (waves with roles where the queues fit), 1 = single-role kernel
   int opt_speculation = 1;  // SED mode: commit most of every stream before the scout pass
   int opt_cache_log_slots = 13;  // Voronoi deposit cache: 2^13 slots = 96 KB of LDS
+  int opt_radiation_field = 0;   // bit 0: xN_abs, bit 1: xJ_abs (thermal step; radiation_field.f90:54-55)
+  unsigned int* d_xN = nullptr;  // [n_cells]
+  double* d_xJ = nullptr;        // (n_cells, n_lambda)
   std::vector<void*> allocs;   // every table buffer (freed in destroy)
   // per-setter buffers that may be replaced
   int *d_cmi = nullptr, *d_cmj = nullptr, *d_cmk = nullptr;
@@ -155,6 +158,8 @@ extern "C" int mcgpu_destroy(mcgpu_ctx* ctx) {
   for (void* p : ctx->allocs) hipFree(p);
   if (ctx->d_accum) hipFree(ctx->d_accum);
   if (ctx->d_counters) hipFree(ctx->d_counters);
+  if (ctx->d_xN) hipFree(ctx->d_xN);
+  if (ctx->d_xJ) hipFree(ctx->d_xJ);
   if (ctx->d_err) hipFree(ctx->d_err);
   if (ctx->d_E_prior) hipFree(ctx->d_E_prior);
   if (ctx->d_xI) hipFree(ctx->d_xI);
@@ -376,6 +381,7 @@ extern "C" int mcgpu_set_option(mcgpu_ctx* ctx, const char* name, int value) {
   else if (!strcmp(name, "schedule")) { if (value < 0 || value > 1) return fail(ctx, MCGPU_ERR_ARG, "schedule: 0 or 1"); ctx->opt_schedule = value; }
   else if (!strcmp(name, "speculation")) ctx->opt_speculation = value ? 1 : 0;
   else if (!strcmp(name, "voronoi_cache_log_slots")) { if (value < 6 || value > 13) return fail(ctx, MCGPU_ERR_ARG, "voronoi_cache_log_slots: 6..13"); ctx->opt_cache_log_slots = value; }
+  else if (!strcmp(name, "radiation_field")) { if (value < 0 || value > 3) return fail(ctx, MCGPU_ERR_ARG, "radiation_field: bit 0 xN_abs, bit 1 xJ_abs"); ctx->opt_radiation_field = value; }
   else return fail(ctx, MCGPU_ERR_ARG, "mcgpu_set_option: unknown option");
   return MCGPU_OK;
 }
@@ -652,7 +658,8 @@ static int launch_mega(mcgpu_ctx* ctx, const RunArgs& A, bool use_lds, int grid_
     int n_rec = lds_t < lds_cap ? rq_records_that_fit(pola, lds_cap - lds_t) : 0;
     // (more records than twice the lanes buy nothing; small models keep their LDS footprint small)
     if (n_rec > 2 * rthreads) n_rec = 2 * rthreads > RQ_MIN_REC ? 2 * rthreads : RQ_MIN_REC;
-    if (tune("MCGPU_ROLES", ctx->opt_schedule == 1 ? 0 : 1, 0, 1) && n_rec > 0) {
+    // (the optional radiation-field accumulators are kept by the single-role kernel)
+    if (tune("MCGPU_ROLES", (ctx->opt_schedule == 1 || A.xN_abs || A.xJ_abs) ? 0 : 1, 0, 1) && n_rec > 0) {
       const size_t lds_r = lds_t + rq_lds_bytes(pola, n_rec);
       int rblocks = grid_blocks > 0 ? grid_blocks : ctx->prop.multiProcessorCount;
       {
@@ -797,6 +804,17 @@ extern "C" int mcgpu_launch_thermal(mcgpu_ctx* ctx, const mcgpu_run_opts* o) {
   A.flush_every = tune("MCGPU_FLUSH_EVERY", 16, 1, 1000000);
   A.min_active = tune("MCGPU_MIN_ACTIVE", 32, 0, 64);
   A.flags = tune("MCGPU_DIAG_FLAGS", 0, 0, 0x7FFFFFFF);  // (diagnostic builds only)
+  if (ctx->opt_radiation_field & 1) {
+    if (!ctx->d_xN) { HIPCHK(hipMalloc((void**)&ctx->d_xN, (size_t)M.n_cells * sizeof(unsigned int))); HIPCHK(hipMemset(ctx->d_xN, 0, (size_t)M.n_cells * sizeof(unsigned int))); }
+    if (!o->accumulate) HIPCHK(hipMemsetAsync(ctx->d_xN, 0, (size_t)M.n_cells * sizeof(unsigned int), ctx->stream));
+    A.xN_abs = ctx->d_xN;
+  }
+  if (ctx->opt_radiation_field & 2) {
+    const size_t nj = (size_t)M.n_cells * M.n_lambda;
+    if (!ctx->d_xJ) { HIPCHK(hipMalloc((void**)&ctx->d_xJ, nj * sizeof(double))); HIPCHK(hipMemset(ctx->d_xJ, 0, nj * sizeof(double))); }
+    if (!o->accumulate) HIPCHK(hipMemsetAsync(ctx->d_xJ, 0, nj * sizeof(double), ctx->stream));
+    A.xJ_abs = ctx->d_xJ;
+  }
   if (ctx->voro) {
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     int rcv = launch_voro(ctx, A, o->grid_blocks, o->block_threads);
@@ -878,6 +896,27 @@ __global__ void k_counters_to_accum(const unsigned long long* cnt, double* tail)
 }
 __global__ void k_counters_from_accum(unsigned long long* cnt, const double* tail) {
   if (threadIdx.x < MCGPU_N_COUNTERS) cnt[threadIdx.x] = (unsigned long long)(tail[threadIdx.x] + 0.5);
+}
+
+// xN_abs(1:n_cells,1) and xJ_abs(1:n_cells,1:n_lambda) of the last thermal launch(es), summed over "threads"
+// (radiation_field.f90:20-24, 54-55); needs mcgpu_set_option("radiation_field", bits) before the launch
+extern "C" int mcgpu_fetch_radiation_field(mcgpu_ctx* ctx, double* xN_abs, double* xJ_abs) {
+  int rc = ready(ctx);
+  if (rc) return rc;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  const DevModel& M = ctx->M;
+  if (xN_abs) {
+    if (!ctx->d_xN) return fail(ctx, MCGPU_ERR_STATE, "xN_abs was not accumulated (option radiation_field bit 0)");
+    std::vector<unsigned int> h(M.n_cells);
+    HIPCHK(hipMemcpy(h.data(), ctx->d_xN, (size_t)M.n_cells * sizeof(unsigned int), hipMemcpyDeviceToHost));
+    for (int i = 0; i < M.n_cells; ++i) xN_abs[i] = (double)h[i];
+  }
+  if (xJ_abs) {
+    if (!ctx->d_xJ) return fail(ctx, MCGPU_ERR_STATE, "xJ_abs was not accumulated (option radiation_field bit 1)");
+    HIPCHK(hipMemcpy(xJ_abs, ctx->d_xJ, (size_t)M.n_cells * M.n_lambda * sizeof(double), hipMemcpyDeviceToHost));
+  }
+  return MCGPU_OK;
 }
 
 extern "C" int mcgpu_counters_to_accum(mcgpu_ctx* ctx) {

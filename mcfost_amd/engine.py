@@ -35,7 +35,7 @@ ABI_SYMBOLS = (
     "mcgpu_probe_cross_voronoi", "mcgpu_set_rt1", "mcgpu_run_mono", "mcgpu_fetch_xI",
     "mcgpu_device_xI", "mcgpu_set_ism", "mcgpu_rt1_dust_map", "mcgpu_set_xI", "mcgpu_rt1_image", "mcgpu_set_xI_precision",
     "mcgpu_get_xI_precision", "mcgpu_set_option", "mcgpu_counters_to_accum", "mcgpu_counters_from_accum",
-    "mcgpu_set_grid_sph", "mcgpu_temp_approx_diffusion_vertical", "mcgpu_set_mrw", "mcgpu_multi_create", "mcgpu_multi_destroy", "mcgpu_multi_size", "mcgpu_multi_ctx", "mcgpu_multi_last_error",
+    "mcgpu_set_grid_sph", "mcgpu_temp_approx_diffusion_vertical", "mcgpu_set_mrw", "mcgpu_fetch_radiation_field", "mcgpu_multi_create", "mcgpu_multi_destroy", "mcgpu_multi_size", "mcgpu_multi_ctx", "mcgpu_multi_last_error",
     "mcgpu_shard_packets", "mcgpu_multi_run_thermal",
 )
 
@@ -322,6 +322,16 @@ class Engine:
             C.c_int(int(ri_in)), C.c_int(int(ri_out)), _p(_a(zj_sup, np.int32), C.c_int), _p(T, C.c_float),
             C.byref(n_it)), "mcgpu_temp_approx_diffusion_vertical")
         return T, n_it.value
+
+    def fetch_radiation_field(self, xN=True, xJ=True):
+        """xN_abs [n_cells] and xJ_abs [n_lambda, n_cells] of the last thermal launch (needs
+        ``set_option("radiation_field", bits)`` before it; radiation_field.f90:54-55)."""
+        m = self.model
+        a = np.zeros(m.n_cells) if xN else None
+        b = np.zeros((m.n_lambda, m.n_cells)) if xJ else None
+        self._chk(self.lib.mcgpu_fetch_radiation_field(self.ctx, _p(a, C.c_double) if xN else None,
+                                                       _p(b, C.c_double) if xJ else None), "mcgpu_fetch_radiation_field")
+        return a, b
 
     def allreduce_device(self, all_reduce):
         """ONE collective per temperature iteration: the counters join the fused accumulator as doubles

@@ -68,7 +68,7 @@ module mcgpu_f
        mcgpu_run_thermal, mcgpu_temp_finale, mcgpu_thermal_loop, mcgpu_error_message, mcgpu_set_rt1, &
        mcgpu_run_mono, mcgpu_fetch, mcgpu_fetch_xI, mcgpu_rt1_dust_map, mcgpu_set_xI, mcgpu_rt1_image, mcgpu_set_xI_precision, &
        mcgpu_set_E_prior, mcgpu_multi_create, mcgpu_multi_destroy, mcgpu_multi_size, mcgpu_multi_ctx, mcgpu_multi_run_thermal, &
-       mcgpu_counters_to_accum, mcgpu_counters_from_accum, mcgpu_temp_approx_diffusion_vertical, mcgpu_set_mrw
+       mcgpu_counters_to_accum, mcgpu_counters_from_accum, mcgpu_temp_approx_diffusion_vertical, mcgpu_set_mrw, mcgpu_fetch_radiation_field
 
   interface
      integer(c_int) function mcgpu_create(device, ctx) bind(C, name="mcgpu_create")
@@ -205,6 +205,12 @@ module mcgpu_f
        type(c_ptr), value :: ctx
        real(c_double), intent(in) :: E_prior(*)
      end function mcgpu_set_E_prior
+
+     ! xN_abs(:,1) and xJ_abs(:,:) summed over threads (radiation_field.f90:54-55); pass c_null_ptr for either
+     integer(c_int) function mcgpu_fetch_radiation_field(ctx, xN_abs, xJ_abs) bind(C, name="mcgpu_fetch_radiation_field")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx, xN_abs, xJ_abs
+     end function mcgpu_fetch_radiation_field
 
      ! modified random walk (module MRW): zeta(:) of initialize_cumulative_zeta, the mean opacities per tab_Temp,
      ! gamma_MRW, the interaction count of dust_transfer.f90:1223, r_lim(0:n_rad); n_zeta = 0 switches it off

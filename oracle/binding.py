@@ -302,6 +302,18 @@ class Oracle:
         return dict(E_abs=E, sed=sed, n_sent=n_sent,
                     counters=dict(zip(COUNTER_NAMES, (int(c) for c in cnt))))
 
+    def run_thermal_with_radiation_field(self, n_packets, **kw):
+        """run_thermal + xN_abs[n_cells], xJ_abs[n_lambda, n_cells] (radiation_field.f90:54-55)."""
+        m = self.model
+        xN, xJ = np.zeros(m.n_cells), np.zeros((m.n_lambda, m.n_cells))
+        self.lib.oracle_set_radiation_field_outputs(_p(xN, C.c_double), _p(xJ, C.c_double))
+        try:
+            res = self.run_thermal(n_packets, **kw)
+        finally:
+            self.lib.oracle_set_radiation_field_outputs(None, None)
+        res["xN_abs"], res["xJ_abs"] = xN, xJ
+        return res
+
     def temp_finale(self, E_abs):
         T = np.zeros(self.model.n_cells, np.float32)
         E = _a(E_abs, np.float64)

@@ -1440,6 +1440,10 @@ static void save_radiation_field_rt1(worker_t *W, int icell, const double Stokes
 }
 
 /* physical_length (optical_depth.f90:21-182), letape_th branch only */
+/* optional accumulators of save_radiation_field's thermal branch (radiation_field.f90:54-55), shared by the threads */
+static double *g_xN_abs = NULL, *g_xJ_abs = NULL;
+void oracle_set_radiation_field_outputs(double *xN_abs, double *xJ_abs) { g_xN_abs = xN_abs; g_xJ_abs = xJ_abs; }
+
 static void physical_length(worker_t *W, int lambda, const double Stokes[4],
                             int *icell, double *xio, double *yio, double *zio,
                             double *u, double *v, double *w, int flag_star, double extrin,
@@ -1509,8 +1513,17 @@ static void physical_length(worker_t *W, int lambda, const double Stokes[4],
     }
     /* save_radiation_field (radiation_field.f90:31-135): thermal step :53, SED mode :63-89 */
     if (lcell_not_empty) {
-      if (!W->mono)
+      if (!W->mono) {
         W->E_abs[icell0 - 1] += m->kappa_abs_LTE[lambda - 1] * l_contrib * Stokes[0];
+        if (g_xN_abs) { /* :55 (lmcfost_lib) */
+#pragma omp atomic
+          g_xN_abs[icell0 - 1] += 1.0;
+        }
+        if (g_xJ_abs) { /* :54 (lxJ_abs_step1) */
+#pragma omp atomic
+          g_xJ_abs[(size_t)(icell0 - 1) + (size_t)m->n_cells * (size_t)(lambda - 1)] += l_contrib * Stokes[0];
+        }
+      }
       else if (W->mono->rt1)
         save_radiation_field_rt1(W, icell0, Stokes, l_contrib, x0, y0, z0, x1, y1, z1, flag_star);
     }

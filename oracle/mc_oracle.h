@@ -194,6 +194,10 @@ typedef struct {
                             of GPUs/ranks sharing the job); >=1 */
 } oracle_opts;
 
+/* xN_abs[n_cells] / xJ_abs[n_cells*n_lambda] (radiation_field.f90:54-55) filled by the next oracle_run_thermal calls;
+ * NULL switches them off again.  The caller zeroes them. */
+void oracle_set_radiation_field_outputs(double *xN_abs, double *xJ_abs);
+
 /* Cell mapping sizes + builder (cylindrical_grid.f90:45-179). */
 void oracle_cell_mapping_sizes(int n_rad, int nz, int n_az, int l3D,
                                int *n_cells, int *ntot2, int *jdim_lo,
