@@ -115,12 +115,17 @@ def bench_sed(args, world, rank, local_rank):
     from mcfost_amd.engine import Engine
     from mcfost_amd.host import model as M
 
-    m = M.build_model(M.ref41())
+    cfg = M.ref41()
+    if args.sed_observers:   # ref4.1.para asks for RT n_incl = 3; BASELINE config 2 quotes 10 inclinations
+        cfg.RT_n_incl = args.sed_observers
+    m = M.build_model(cfg)
     e = Engine(m, 5e6, device=local_rank)
     T = e.temp_finale(e.run_thermal(5_000_000, seed=3)["E_abs"])
     M.repartition_energie(m, T)
     e.close()
     eng = Engine(m, 5e6, device=local_rank)
+    if args.xI_precision == 4:
+        eng.set_xI_precision(4)
     lams = [int(x) for x in args.sed_lambdas.split(",")]
     n_streams = m.cfg.n_photons_loop * world                 # weak scaling: 128 streams per GPU
     first, count = D.shard_streams(n_streams, rank, world)
@@ -174,7 +179,9 @@ def bench_sed(args, world, rank, local_rank):
             "config": {"workload": "ref4.1 2D disk 100x70, SED Monte Carlo of wavelengths %s, 128 streams/GPU x %d packets "
                                    "in the stop bin each, RT1 deposits for %d observers (both passes timed)"
                                    % (args.sed_lambdas, n2, nRT),
-                       "packets_per_gpu_per_step": sent_all / world / args.steps, "crossings_per_packet": cross_pp},
+                       "packets_per_gpu_per_step": sent_all / world / args.steps, "crossings_per_packet": cross_pp,
+                       "observers": nRT, "xI_record": "f32 pairs" if args.xI_precision == 4 else "f64",
+                       "records_per_s": sent_all / dt * cross_pp * nRT},
             "roofline": {"bound": "hbm", "achieved": bytes_step / (dt / args.steps) / 1e9, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": bytes_step / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "k_mono (scout + commit)", "algorithmic_bytes_per_launch": bytes_step},
@@ -311,6 +318,8 @@ def main():
     ap.add_argument("--sites", type=int, default=100000,
                     help="--config voronoi: number of SPH-like sites of the tessellation (BASELINE config 5 stand-in)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sed-observers", type=int, default=0, help="--config sed: RT_n_incl (default: the configuration's)")
+    ap.add_argument("--xI-precision", type=int, default=8, choices=[4, 8], help="--config sed: mcgpu_set_xI_precision")
     ap.add_argument("--mrw-gamma", type=float, default=2.0, help="--config ref41_mrw: gamma_MRW")
     ap.add_argument("--dust-mass", type=float, default=0.0, help="override the disk's dust mass [Msun] (thermal configs)")
     ap.add_argument("--no-ref41", action="store_true", help="--config pascucci: skip the ref4.1 block")
