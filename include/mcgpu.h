@@ -431,6 +431,25 @@ int mcgpu_probe_packet_rand(mcgpu_ctx *ctx, uint64_t seed, uint64_t packet,
                             int n, float *out);
 
 /*
+ * lvariable_dust (dust settling etc.; mem.f90:213-244): the opacity and re-emission tables gain the cell axis
+ * p_n_cells and the loop reads them with p_icell (optical_depth.f90:100-102, radiation_field.f90:47-53,
+ * dust_transfer.f90:1284, thermal_emission.f90:659-771).  Call after mcgpu_set_opacity and mcgpu_set_thermal, with
+ * the reference's own arrays and layouts:
+ *   p_icell[n_cells]                        the class of every cell, 1..p_n_cells (the reference: p_icell = icell)
+ *   kappa, kappa_abs_LTE (p_n_cells, n_lambda)    dust_prop.f90:17-21, class fastest
+ *   tab_albedo_pos (p_n_cells, n_lambda)          grains.f90:62
+ *   log_Qcool (n_T, p_n_cells)                    log_Qcool_minus_extra_heating, thermal_emission.f90:34
+ *   kdB_dT_CDF (n_lambda, n_T, p_n_cells)         thermal_emission.f90:45
+ * p_n_cells may be smaller than n_cells (classes of cells with the same dust).  The thermal step then runs the
+ * HBM-gather variant of the single-role kernel and mcgpu_temp_finale reads log_Qcool per class.  The scattering
+ * matrices keep their single-class tables (prob_s11_pos etc. per class: not built), and so do the SED mode, the ray
+ * tracing, the random walk and the diffusion fill, which refuse a context with variable dust.  p_n_cells = 0: off.
+ */
+int mcgpu_set_variable_dust(mcgpu_ctx *ctx, int p_n_cells, const int *p_icell, const double *kappa,
+                            const double *kappa_abs_LTE, const float *tab_albedo_pos,
+                            const double *log_Qcool, const double *kdB_dT_CDF);
+
+/*
  * The optional accumulators of save_radiation_field's thermal branch (radiation_field.f90:54-55):
  *   xN_abs[n_cells]             path segments per cell (xN_abs(icell,1,id) with lmcfost_lib: what run_mcfost_phantom
  *                               returns, mcfost2phantom.f90:361), summed over "threads"

@@ -136,6 +136,14 @@ struct DevModel {
   const double* mrw_kdep;  // [n_T] mean absorption opacity of the walk's deposits
   const double* mrw_ext;   // [n_T] extrapolation length of the sphere radius, reference cell
   const double* r_lim;     // [n_rad+1] (distance_to_closest_wall_cyl)
+  // lvariable_dust (mcgpu_set_variable_dust; mem.f90:213-244, p_n_cells > 1): per-class tables in HBM, class-major
+  int n_classes;             // 0: one class, the tables above (and their LDS copies)
+  const int* cell_class;     // [n_cells] p_icell - 1
+  const double* v_kappa;     // [n_classes][n_lambda]
+  const double* v_kabs;      // [n_classes][n_lambda]
+  const float* v_albedo;     // [n_classes][n_lambda]
+  const double* v_lq;        // [n_classes][n_T]
+  const double* v_cdf;       // [n_classes][n_T][n_lambda]
 };
 
 // packet state word of the queue records: state | flags
@@ -331,6 +339,18 @@ __device__ inline void lds_stage_mono(const Lds& T, const DevModel& M, int p_lam
   stage(T.albedo, M.albedo, (size_t)M.n_lambda);
   stage(T.prob, M.prob_s11 + (size_t)(M.nang + 1) * (p_lambda - 1), (size_t)M.nang + 1);
   stage(T.g, M.tab_g, (size_t)M.n_lambda);
+}
+
+// lvariable_dust: the table pointers of one cell class -- the LDS copies hold one class only, so the per-class rows
+// are read from HBM (a gather per crossing / interaction: the memory regime of SURVEY 8f rank 4)
+__device__ inline Lds class_tables(const Lds& T, const DevModel& M, int cls) {
+  Lds V = T;
+  V.kappa = const_cast<double*>(M.v_kappa) + (size_t)cls * M.n_lambda;
+  V.kabs = const_cast<double*>(M.v_kabs) + (size_t)cls * M.n_lambda;
+  V.albedo = const_cast<float*>(M.v_albedo) + (size_t)cls * M.n_lambda;
+  V.lq = const_cast<double*>(M.v_lq) + (size_t)cls * M.n_T;
+  V.cdf = const_cast<double*>(M.v_cdf) + (size_t)cls * M.n_T * M.n_lambda;
+  return V;
 }
 
 // ---------------------------------------------------------------------------
@@ -1437,7 +1457,7 @@ struct SphEmitOps {
 // (global_atomic_add_f64), the only option for 3D grids (5.76 MB at 720 000
 // cells).
 // SPH: the grid operators of spherical_grid.f90 instead of cylindrical_grid.f90 (same cell identity and mapping).
-template <bool L3D, bool POLA, bool DARK, bool LDSE, bool SPH = false, bool MRW = false>
+template <bool L3D, bool POLA, bool DARK, bool LDSE, bool SPH = false, bool MRW = false, bool VAR = false>
 __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A, double* lds_base) {
   double* const E_lds = lds_base;  // [n_cells] when LDSE
   const Lds T = lds_carve(lds_base + (LDSE ? M.n_cells : 0), M);
@@ -1559,7 +1579,8 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
       tau_rand = g[5];
       double u1, v1, w1;
       const int ic = cell_index<L3D>(n_rad, nz, ri, zj, k);
-      interact<POLA>(T, M, g, lambda, u, v, w, u1, v1, w1, S, flag_star, flag_scatt, c_scatt, c_abs, [&]() {
+      const Lds Tc = VAR ? class_tables(T, M, M.cell_class[ic]) : T;   // (lvariable_dust: this cell's tables)
+      interact<POLA>(Tc, M, g, lambda, u, v, w, u1, v1, w1, S, flag_star, flag_scatt, c_scatt, c_abs, [&]() {
         // the cell's absorbed energy for Temp_LTE (thermal_emission.f90:649-706)
         double E;
         if (A.frozen) E = A.E_prior[ic];
@@ -1650,12 +1671,13 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
           st = S_EMIT;
         } else {
           const bool real_cell = is_real_cell<L3D>(n_rad, nz, ri, zj);
-          double opacity = 0.0;
+          double opacity = 0.0, kabs_c = 0.0;
           int ic = 0;
           bool mirrored = false;
           if (real_cell) {
             ic = cell_index<L3D>(n_rad, nz, ri, zj, k);
-            opacity = T.kappa[lambda - 1] * kf;
+            if (VAR) { const size_t row = (size_t)M.cell_class[ic] * M.n_lambda + (lambda - 1); opacity = M.v_kappa[row] * kf; kabs_c = M.v_kabs[row]; }
+            else { opacity = T.kappa[lambda - 1] * kf; kabs_c = T.kabs[lambda - 1]; }
             if (DARK) {
               if (M.dark[ic]) {  // optical_depth.f90:104-112
                 u = -u; v = -v; w = -w;
@@ -1677,7 +1699,7 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
             const double tau = l * opacity;
             if (tau > extr) {
               const double lc = l * (extr / tau);
-              if (real_cell && !MCGPU_DIAG(A.flags, 1)) deposit<LDSE>(A.E_abs, E_lds, ic, T.kabs[lambda - 1] * lc * S[0]);
+              if (real_cell && !MCGPU_DIAG(A.flags, 1)) deposit<LDSE>(A.E_abs, E_lds, ic, kabs_c * lc * S[0]);
               if (real_cell) radiation_field_extras(M, A, ic, lambda, lc * S[0]);
               x = x + lc * u;
               y = y + lc * v;
@@ -1688,7 +1710,7 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
             } else {
               first_cross = false;
               extr = extr - tau;
-              if (real_cell && !MCGPU_DIAG(A.flags, 1)) deposit<LDSE>(A.E_abs, E_lds, ic, T.kabs[lambda - 1] * l * S[0]);
+              if (real_cell && !MCGPU_DIAG(A.flags, 1)) deposit<LDSE>(A.E_abs, E_lds, ic, kabs_c * l * S[0]);
               if (real_cell) radiation_field_extras(M, A, ic, lambda, l * S[0]);
               if (DARK) { xo = x; yo = y; zo = z; ri_o = ri; zj_o = zj; k_o = k; }
               x = x1; y = y1; z = z1;
@@ -1759,6 +1781,13 @@ __global__ void __launch_bounds__(256) k_thermal(const DevModel M, const RunArgs
   thermal_body<L3D, POLA, DARK, false, false, MRW>(M, A, lds_raw);
 }
 
+// lvariable_dust: per-class opacity / re-emission tables gathered from HBM (HBM deposits; any cylindrical grid)
+template <bool L3D, bool POLA, bool DARK>
+__global__ void __launch_bounds__(256) k_thermal_var(const DevModel M, const RunArgs A) {
+  extern __shared__ double lds_raw[];
+  thermal_body<L3D, POLA, DARK, false, false, false, true>(M, A, lds_raw);
+}
+
 // the spherical grid (spherical_grid.f90): the same packet loop with that grid's operators; no dark zone
 template <bool L3D, bool POLA, bool LDSE>
 __global__ void __launch_bounds__(LDSE ? MCGPU_LDS_BLOCK : 256) k_thermal_sph(const DevModel M, const RunArgs A) {
@@ -1785,8 +1814,9 @@ __global__ void k_temp_finale(const DevModel M, const double* E_abs, const float
   const double E = E_abs[ic];
   const double Qheat = E * M.L_packet_th / M.volume[ic];
   float Temp = T_min;
-  if (!(Qheat < TINY_DP) && !(log(Qheat) < M.log_Qcool[0])) {
-    temp_lte(M.log_Qcool, M.n_T, E, M.L_packet_th, M.volume[ic], Ti, frac);
+  const double* lq = M.n_classes ? M.v_lq + (size_t)M.cell_class[ic] * M.n_T : M.log_Qcool;  // (lvariable_dust)
+  if (!(Qheat < TINY_DP) && !(log(Qheat) < lq[0])) {
+    temp_lte(lq, M.n_T, E, M.L_packet_th, M.volume[ic], Ti, frac);
     // log of a default real is a default-real log (thermal_emission.f90:697)
     Temp = (float)exp((double)logf(tab_Temp[Ti - 1]) * frac + (double)logf(tab_Temp[Ti - 2]) * (1.0 - frac));
   }

@@ -534,6 +534,50 @@ extern "C" int mcgpu_set_thermal(mcgpu_ctx* ctx, int n_T, const float* tab_Temp,
   return MCGPU_OK;
 }
 
+// lvariable_dust (mem.f90:213-244: the tables gain the cell axis p_n_cells): see include/mcgpu.h.  The arrays come in
+// the reference's own layouts and are re-laid class-major for the device.
+extern "C" int mcgpu_set_variable_dust(mcgpu_ctx* ctx, int p_n_cells, const int* p_icell, const double* kappa,
+                                       const double* kappa_abs_LTE, const float* tab_albedo_pos,
+                                       const double* log_Qcool, const double* kdB_dT_CDF) {
+  if (!ctx) return MCGPU_ERR_ARG;
+  DevModel& M = ctx->M;
+  if (p_n_cells == 0) { M.n_classes = 0; return MCGPU_OK; }  // back to one class
+  if (p_n_cells < 1 || !p_icell || !kappa || !kappa_abs_LTE || !tab_albedo_pos || !log_Qcool || !kdB_dT_CDF)
+    return fail(ctx, MCGPU_ERR_ARG, "mcgpu_set_variable_dust: bad argument");
+  if (!ctx->have_grid || !ctx->have_opacity || !ctx->have_thermal)
+    return fail(ctx, MCGPU_ERR_STATE, "set the grid, the opacities and the thermal tables first");
+  if (ctx->voro || M.grid_sph) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "variable dust: cylindrical grids only");
+  for (int i = 0; i < M.n_cells; ++i)
+    if (p_icell[i] < 1 || p_icell[i] > p_n_cells) return fail(ctx, MCGPU_ERR_ARG, "mcgpu_set_variable_dust: p_icell out of range");
+  const int nc = p_n_cells, nl = M.n_lambda, nT = M.n_T;
+  for (int c = 0; c < nc; ++c)
+    for (int t = 2; t < nT; ++t)
+      if (log_Qcool[(size_t)c * nT + t] < log_Qcool[(size_t)c * nT + t - 1])
+        return fail(ctx, MCGPU_ERR_UNSUPPORTED, "log_Qcool must increase with T");
+  HIPCHK(hipSetDevice(ctx->device));
+  std::vector<int> cls(M.n_cells);
+  for (int i = 0; i < M.n_cells; ++i) cls[i] = p_icell[i] - 1;
+  // kappa(p_n_cells, n_lambda), kappa_abs_LTE, tab_albedo_pos: class fastest in the reference -> [class][lambda]
+  std::vector<double> k((size_t)nc * nl), ka((size_t)nc * nl);
+  std::vector<float> al((size_t)nc * nl);
+  for (int c = 0; c < nc; ++c)
+    for (int l = 0; l < nl; ++l) {
+      k[(size_t)c * nl + l] = kappa[(size_t)c + (size_t)nc * l];
+      ka[(size_t)c * nl + l] = kappa_abs_LTE[(size_t)c + (size_t)nc * l];
+      al[(size_t)c * nl + l] = tab_albedo_pos[(size_t)c + (size_t)nc * l];
+    }
+  int rc;
+  if ((rc = upload(ctx, cls.data(), (size_t)M.n_cells, &M.cell_class))) return rc;
+  if ((rc = upload(ctx, k.data(), k.size(), &M.v_kappa))) return rc;
+  if ((rc = upload(ctx, ka.data(), ka.size(), &M.v_kabs))) return rc;
+  if ((rc = upload(ctx, al.data(), al.size(), &M.v_albedo))) return rc;
+  // log_Qcool_minus_extra_heating(n_T, p_n_cells) and kdB_dT_CDF(n_lambda, n_T, p_n_cells): class slowest already
+  if ((rc = upload(ctx, log_Qcool, (size_t)nc * nT, &M.v_lq))) return rc;
+  if ((rc = upload(ctx, kdB_dT_CDF, (size_t)nc * nT * nl, &M.v_cdf))) return rc;
+  M.n_classes = nc;
+  return MCGPU_OK;
+}
+
 // Modified random walk (MRW.f90; dust_transfer.f90:1222-1239): see include/mcgpu.h
 extern "C" int mcgpu_set_mrw(mcgpu_ctx* ctx, int n_zeta, const double* zeta, const double* chi, const double* kappa_dep,
                              const double* ext, double gamma, int n_interactions, const double* r_lim) {
@@ -544,6 +588,7 @@ extern "C" int mcgpu_set_mrw(mcgpu_ctx* ctx, int n_zeta, const double* zeta, con
     return fail(ctx, MCGPU_ERR_ARG, "mcgpu_set_mrw: bad argument (n_interactions is 0..6)");
   if (!ctx->have_grid || !ctx->have_thermal) return fail(ctx, MCGPU_ERR_STATE, "set the grid and the thermal tables first");
   if (ctx->voro || M.l3D || M.grid_sph) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "modified random walk: 2D cylindrical grids only");
+  if (M.n_classes) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "variable dust and the modified random walk do not combine");
   for (int i = 1; i < n_zeta; ++i)
     if (!(zeta[i] >= zeta[i - 1])) return fail(ctx, MCGPU_ERR_ARG, "mcgpu_set_mrw: zeta must not decrease");
   HIPCHK(hipSetDevice(ctx->device));
@@ -637,6 +682,28 @@ static int launch_mega(mcgpu_ctx* ctx, const RunArgs& A, bool use_lds, int grid_
   // tables.  MCGPU_ROLES: -1 = the single-role kernel (thermal_body), 0..7 = that
   // many fixed flyer waves, 100+f = every wave picks its role per round (flyer when f lanes can fly), 200 = per
   // round, the role in which more of its lanes have work (default).
+  if (M.n_classes) {  // lvariable_dust: the HBM-gather variant of the single-role kernel
+    if (M.mrw) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "variable dust and the modified random walk do not combine");
+    const void* fn;
+#define PICKV(a) fn = pola ? (dark ? (const void*)k_thermal_var<a, true, true> : (const void*)k_thermal_var<a, true, false>) \
+                           : (dark ? (const void*)k_thermal_var<a, false, true> : (const void*)k_thermal_var<a, false, false>)
+    if (l3d) PICKV(true); else PICKV(false);
+#undef PICKV
+    const int vthreads = (block_threads > 0 && block_threads <= 256) ? block_threads : 256;
+    int vblocks = grid_blocks;
+    if (vblocks <= 0) {
+      int occ = 1;
+      HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, vthreads, lds));
+      vblocks = ctx->prop.multiProcessorCount * (occ < 1 ? 1 : occ);
+      const unsigned long long need = (A.n_packets + vthreads - 1) / vthreads;
+      if ((unsigned long long)vblocks > need) vblocks = (int)(need ? need : 1);
+    }
+    HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    void* args[] = {(void*)&M, (void*)&A};
+    HIPCHK(hipLaunchKernel(fn, dim3(vblocks), dim3(vthreads), args, lds, ctx->stream));
+    return MCGPU_OK;
+  }
   if (M.grid_sph) {  // the spherical grid runs the single-role kernel with its own grid operators
     const size_t lds_k2 = lds_k;
     const void* fn;
@@ -1041,6 +1108,7 @@ extern "C" int mcgpu_run_mono(mcgpu_ctx* ctx, const mcgpu_mono_opts* o, double f
   if (rc) return rc;
   if (!o) return fail(ctx, MCGPU_ERR_ARG, "null options");
   DevModel& M = ctx->M;
+  if (M.n_classes) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "SED mode with variable dust (mcgpu_set_variable_dust) is not built");
   if (o->lambda < 1 || o->lambda > M.n_lambda || o->n_chunks < 1 || o->n_chunks > (1 << 22) || o->capt_sup < 1 ||
       o->first_chunk < 0 || (long long)o->first_chunk + o->n_chunks > (1 << 23))
     return fail(ctx, MCGPU_ERR_ARG, "mcgpu_run_mono: bad option");
@@ -1367,6 +1435,7 @@ extern "C" int mcgpu_temp_approx_diffusion_vertical(mcgpu_ctx* ctx, const double
   if (!tab_lambda || !tab_delta_lambda || !zj_sup_dark_zone || !Tdust) return fail(ctx, MCGPU_ERR_ARG, "mcgpu_temp_approx_diffusion_vertical: null argument");
   const DevModel& M = ctx->M;
   if (ctx->voro || M.l3D || M.grid_sph) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "diffusion approximation: 2D cylindrical grids only");
+  if (M.n_classes) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "diffusion approximation with variable dust is not built");
   if (ri_in_dark_zone < 1 || ri_out_dark_zone > M.n_rad) return fail(ctx, MCGPU_ERR_ARG, "dark-zone radii out of range");
   for (int i = 0; i < M.n_rad; ++i)
     if (zj_sup_dark_zone[i] < 0 || zj_sup_dark_zone[i] > M.nz) return fail(ctx, MCGPU_ERR_ARG, "zj_sup_dark_zone out of range");
@@ -1415,6 +1484,7 @@ struct Rt1Job {
 
 static int rt1_prepare(mcgpu_ctx* ctx, const mcgpu_rt_opts* o, const float* tab_RT_az, const float* Tdust, Rt1Job& J,
                        const char* who) {
+  if (ctx && ctx->M.n_classes) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "ray tracing with variable dust (mcgpu_set_variable_dust) is not built");
   int rc = ready(ctx);
   if (rc) return rc;
   if (ctx->voro || ctx->M.grid_sph) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "RT1 ray tracing: cylindrical grids only");

@@ -35,7 +35,7 @@ ABI_SYMBOLS = (
     "mcgpu_probe_cross_voronoi", "mcgpu_set_rt1", "mcgpu_run_mono", "mcgpu_fetch_xI",
     "mcgpu_device_xI", "mcgpu_set_ism", "mcgpu_rt1_dust_map", "mcgpu_set_xI", "mcgpu_rt1_image", "mcgpu_set_xI_precision",
     "mcgpu_get_xI_precision", "mcgpu_set_option", "mcgpu_counters_to_accum", "mcgpu_counters_from_accum",
-    "mcgpu_set_grid_sph", "mcgpu_temp_approx_diffusion_vertical", "mcgpu_set_mrw", "mcgpu_fetch_radiation_field", "mcgpu_multi_create", "mcgpu_multi_destroy", "mcgpu_multi_size", "mcgpu_multi_ctx", "mcgpu_multi_last_error",
+    "mcgpu_set_grid_sph", "mcgpu_temp_approx_diffusion_vertical", "mcgpu_set_mrw", "mcgpu_fetch_radiation_field", "mcgpu_set_variable_dust", "mcgpu_multi_create", "mcgpu_multi_destroy", "mcgpu_multi_size", "mcgpu_multi_ctx", "mcgpu_multi_last_error",
     "mcgpu_shard_packets", "mcgpu_multi_run_thermal",
 )
 
@@ -231,6 +231,21 @@ class Engine:
             C.c_int(int(cfg.l_sym_axiale))), "mcgpu_set_sed_bins")
         if getattr(m, "mrw", None) is not None:
             self.set_mrw(m.mrw)
+        if getattr(m, "variable_dust", None) is not None:
+            self.set_variable_dust(m.variable_dust)
+
+    def set_variable_dust(self, vd):
+        """Per-class tables of ``lvariable_dust`` (``mcfost_amd.host.model.init_variable_dust``); ``None``: one class."""
+        if vd is None:
+            self._chk(self.lib.mcgpu_set_variable_dust(self.ctx, C.c_int(0), None, None, None, None, None, None),
+                      "mcgpu_set_variable_dust")
+            return
+        d = np.float64
+        self._chk(self.lib.mcgpu_set_variable_dust(
+            self.ctx, C.c_int(int(vd["p_n_cells"])), _p(_a(vd["p_icell"], np.int32), C.c_int),
+            _p(_a(vd["kappa"], d), C.c_double), _p(_a(vd["kappa_abs_LTE"], d), C.c_double),
+            _p(_a(vd["albedo"], np.float32), C.c_float), _p(_a(vd["log_Qcool"], d), C.c_double),
+            _p(_a(vd["kdB_dT_CDF"], d), C.c_double)), "mcgpu_set_variable_dust")
 
     def set_mrw(self, mrw):
         """Tables of the modified random walk (``mcfost_amd.host.model.init_mrw``); ``None`` switches it off."""

@@ -68,7 +68,8 @@ module mcgpu_f
        mcgpu_run_thermal, mcgpu_temp_finale, mcgpu_thermal_loop, mcgpu_error_message, mcgpu_set_rt1, &
        mcgpu_run_mono, mcgpu_fetch, mcgpu_fetch_xI, mcgpu_rt1_dust_map, mcgpu_set_xI, mcgpu_rt1_image, mcgpu_set_xI_precision, &
        mcgpu_set_E_prior, mcgpu_multi_create, mcgpu_multi_destroy, mcgpu_multi_size, mcgpu_multi_ctx, mcgpu_multi_run_thermal, &
-       mcgpu_counters_to_accum, mcgpu_counters_from_accum, mcgpu_temp_approx_diffusion_vertical, mcgpu_set_mrw, mcgpu_fetch_radiation_field
+       mcgpu_counters_to_accum, mcgpu_counters_from_accum, mcgpu_temp_approx_diffusion_vertical, mcgpu_set_mrw, mcgpu_fetch_radiation_field, &
+       mcgpu_set_variable_dust
 
   interface
      integer(c_int) function mcgpu_create(device, ctx) bind(C, name="mcgpu_create")
@@ -205,6 +206,17 @@ module mcgpu_f
        type(c_ptr), value :: ctx
        real(c_double), intent(in) :: E_prior(*)
      end function mcgpu_set_E_prior
+
+     ! lvariable_dust: p_icell(:) and the tables with the p_n_cells axis, as the modules hold them (mem.f90:213-244)
+     integer(c_int) function mcgpu_set_variable_dust(ctx, p_n_cells, p_icell, kappa, kappa_abs_LTE, tab_albedo_pos, &
+          log_Qcool, kdB_dT_CDF) bind(C, name="mcgpu_set_variable_dust")
+       import :: c_int, c_ptr, c_double, c_float
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: p_n_cells
+       integer(c_int), intent(in) :: p_icell(*)
+       real(c_double), intent(in) :: kappa(*), kappa_abs_LTE(*), log_Qcool(*), kdB_dT_CDF(*)
+       real(c_float), intent(in) :: tab_albedo_pos(*)
+     end function mcgpu_set_variable_dust
 
      ! xN_abs(:,1) and xJ_abs(:,:) summed over threads (radiation_field.f90:54-55); pass c_null_ptr for either
      integer(c_int) function mcgpu_fetch_radiation_field(ctx, xN_abs, xJ_abs) bind(C, name="mcgpu_fetch_radiation_field")

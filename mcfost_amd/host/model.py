@@ -614,6 +614,7 @@ class Model:
     prob_E_cell: Optional[np.ndarray] = None
     ism: Optional[dict] = None   # {"R_ISM": float, "centre_ISM": (3,)} (stars.f90:27-28); None: no ISM field
     mrw: Optional[dict] = None   # tables of the modified random walk (init_mrw); None: off
+    variable_dust: Optional[dict] = None   # per-class tables of lvariable_dust (init_variable_dust); None: one class
 
     @property
     def capt_sup(self):
@@ -677,6 +678,44 @@ def init_directions_ray_tracing(cfg: DiskConfig, l3D: bool):
     return dict(RT_n_incl=ni, RT_n_az=na, tab_RT_incl=incl, tab_RT_az=az, tab_u_rt=u.reshape(-1),
                 tab_v_rt=v.reshape(-1), tab_w_rt=w, n_az_rt=1 if l3D else 45, n_theta_rt=1 if l3D else 2,
                 N_type_flux=ntf, lsepar_contrib=int(cfg.lsepar_contrib))
+
+
+def init_variable_dust(m: "Model", n_classes: int = 0, slope: float = 0.6, identical: bool = False):
+    """``lvariable_dust`` tables (mem.f90:213-244) for the thermal step, in the reference's layouts: every cell gets
+    a class ``p_icell`` and the opacity / re-emission tables gain that axis.  The reference builds them from the
+    local grain-size distribution of a settled disk (dust_prop.f90:791-1243, a host table builder); here the classes
+    are the vertical layers (``n_classes`` <= nz of them, folded over |j|) and the per-class dust is a smooth
+    stand-in for settling: towards the midplane the extinction flattens in wavelength (bigger grains) and the albedo
+    rises -- inputs, not algorithm.  ``identical``: every class gets the model's own tables (the known-answer case:
+    the run must equal the single-class run)."""
+    g = m.grid
+    n_rad, nz, n_cells = g["n_rad"], g["nz"], m.n_cells
+    nc = int(n_classes) if n_classes else nz
+    nl, nT = m.n_lambda, m.tab_Temp.size
+    j = np.abs(np.asarray(g["cell_map_j"], np.int64)[:n_cells])              # 1..nz
+    p_icell = (np.minimum((j - 1) * nc // nz, nc - 1) + 1).astype(np.int32)
+    lam = np.asarray(m.lam, f64)
+    kappa = np.zeros((nl, nc), f64)          # Fortran (p_n_cells, n_lambda): class fastest
+    kabs = np.zeros((nl, nc), f64)
+    alb = np.zeros((nl, nc), f32)
+    lq = np.zeros((nc, nT), f64)             # Fortran (n_T, p_n_cells)
+    cdf = np.zeros((nc, nT, nl), f64)        # Fortran (n_lambda, n_T, p_n_cells)
+    for c in range(nc):
+        if identical:
+            k_c, a_c = np.asarray(m.kappa, f64), np.asarray(m.albedo, f32)
+        else:
+            depth = 1.0 - (c + 0.5) / nc       # 1 at the midplane class, 0 at the surface class
+            k_c = np.asarray(m.kappa, f64) * (lam / 1.0) ** (slope * depth)
+            a_c = np.clip(np.asarray(m.albedo, f64) * (1.0 + 0.3 * depth), 0.0, 0.95).astype(f32)
+        ka_c = np.asarray(m.kappa_abs_LTE, f64) if identical else k_c * (1.0 - a_c.astype(f64))
+        kappa[:, c], kabs[:, c], alb[:, c] = k_c, ka_c, a_c
+        if identical:
+            lq[c], cdf[c] = m.log_Qcool, np.asarray(m.kdB_dT_CDF, f64).reshape(nT, nl)
+        else:
+            lq[c], cdf[c] = init_reemission(lam, np.asarray(m.delta_lam, f64), m.tab_Temp, ka_c)
+    m.variable_dust = dict(p_n_cells=nc, p_icell=p_icell, kappa=kappa.reshape(-1), kappa_abs_LTE=kabs.reshape(-1),
+                           albedo=alb.reshape(-1), log_Qcool=lq.reshape(-1), kdB_dT_CDF=cdf.reshape(-1))
+    return m.variable_dust
 
 
 def cumulative_zeta(n: int = 10000):

@@ -95,7 +95,9 @@ class _Model(C.Structure):
         ("tab_w_rt", _dp), ("n_az_rt", C.c_int), ("n_theta_rt", C.c_int), ("N_type_flux", C.c_int),
         ("lsepar_contrib", C.c_int), ("tab_s11_pos", _fp),
         ("mrw", C.c_int), ("mrw_n_zeta", C.c_int), ("mrw_zeta", _dp), ("mrw_chi", _dp), ("mrw_kappa_dep", _dp),
-        ("mrw_ext", _dp), ("mrw_gamma", C.c_float), ("mrw_n_inter", C.c_int), ("r_lim", _dp),
+        ("mrw_ext", _dp), ("mrw_gamma", C.c_float), ("mrw_n_inter", C.c_int),
+        ("p_n_cells", C.c_int), ("p_icell", _ip), ("v_kappa", _dp), ("v_kappa_abs_LTE", _dp), ("v_albedo", _fp),
+        ("v_log_Qcool", _dp), ("v_kdB_dT_CDF", _dp), ("r_lim", _dp),
     ]
 
 
@@ -228,6 +230,15 @@ class Oracle:
             s.tab_s11_pos = self._hold(_a(m.tab_s11_pos, np.float32), C.c_float)
         if "r_lim" in g:
             s.r_lim = self._hold(_a(g["r_lim"], np.float64), C.c_double)
+        vd = getattr(m, "variable_dust", None)
+        if vd is not None:   # reference layouts (mcfost_amd.host.model.init_variable_dust)
+            s.p_n_cells = int(vd["p_n_cells"])
+            s.p_icell = self._hold(_a(vd["p_icell"], np.int32), C.c_int)
+            s.v_kappa = self._hold(_a(vd["kappa"], np.float64), C.c_double)
+            s.v_kappa_abs_LTE = self._hold(_a(vd["kappa_abs_LTE"], np.float64), C.c_double)
+            s.v_albedo = self._hold(_a(vd["albedo"], np.float32), C.c_float)
+            s.v_log_Qcool = self._hold(_a(vd["log_Qcool"], np.float64), C.c_double)
+            s.v_kdB_dT_CDF = self._hold(_a(vd["kdB_dT_CDF"], np.float64), C.c_double)
         mrw = getattr(m, "mrw", None)
         if mrw is not None:
             s.mrw, s.mrw_n_zeta = 1, int(mrw["zeta"].size)

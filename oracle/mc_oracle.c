@@ -212,6 +212,24 @@ int oracle_build_cell_mapping(int n_rad, int nz, int n_az, int l3D,
 static inline int cmap(const oracle_model *m, int i, int j, int k) {
   return m->cell_map[CM_IDX(m->n_rad, m->jdim_lo, m->jdim_n, i, j, k)];
 }
+/* lvariable_dust: the tables of the cell's class p_icell (optical_depth.f90:100-102 etc.) */
+static inline double tab_kappa(const oracle_model *m, int icell, int lambda) {
+  return m->p_n_cells ? m->v_kappa[(m->p_icell[icell - 1] - 1) + (size_t)m->p_n_cells * (lambda - 1)] : m->kappa[lambda - 1];
+}
+static inline double tab_kappa_abs(const oracle_model *m, int icell, int lambda) {
+  return m->p_n_cells ? m->v_kappa_abs_LTE[(m->p_icell[icell - 1] - 1) + (size_t)m->p_n_cells * (lambda - 1)]
+                      : m->kappa_abs_LTE[lambda - 1];
+}
+static inline float tab_albedo(const oracle_model *m, int icell, int lambda) {
+  return m->p_n_cells ? m->v_albedo[(m->p_icell[icell - 1] - 1) + (size_t)m->p_n_cells * (lambda - 1)] : m->albedo[lambda - 1];
+}
+static inline const double *tab_log_Qcool(const oracle_model *m, int icell) {
+  return m->p_n_cells ? m->v_log_Qcool + (size_t)(m->p_icell[icell - 1] - 1) * m->n_T : m->log_Qcool;
+}
+static inline const double *tab_cdf(const oracle_model *m, int icell) {
+  return m->p_n_cells ? m->v_kdB_dT_CDF + (size_t)(m->p_icell[icell - 1] - 1) * m->n_T * m->n_lambda : m->kdB_dT_CDF;
+}
+
 static inline double zlim(const oracle_model *m, int i, int j) {
   return m->z_lim[(i - 1) + m->n_rad * (j - 1)];
 }
@@ -1281,9 +1299,15 @@ static void emit_packet_uniform_sphere(const oracle_model *m, int i_star,
  * is the cached xT_ech entry (>= 2).  When the cell is at T_min the reference
  * leaves `frac` unassigned (:674,:679); the oracle returns frac = 0, i.e. the
  * T_1 row of the CDF. */
+static void temp_lte_tab(const oracle_model *m, const double *lq, double E_scaled, double volume,
+                         int Ti_start, int *Ti_out, float *Temp, double *frac);
 void oracle_temp_lte(const oracle_model *m, double E_scaled, double volume,
                      int Ti_start, int *Ti_out, float *Temp, double *frac) {
-  const double *lq = m->log_Qcool; /* 1-based: lq[T-1] */
+  temp_lte_tab(m, m->log_Qcool, E_scaled, volume, Ti_start, Ti_out, Temp, frac);
+}
+/* lq = log_Qcool_minus_extra_heating(:, p_icell), 1-based: lq[T-1] */
+static void temp_lte_tab(const oracle_model *m, const double *lq, double E_scaled, double volume,
+                         int Ti_start, int *Ti_out, float *Temp, double *frac) {
   double Qheat = E_scaled * m->L_packet_th / volume;
   int Ti;
   *frac = 0.0;
@@ -1310,8 +1334,8 @@ void oracle_temp_finale(const oracle_model *m, const double *E_abs,
                         float *Tdust) {
   for (int icell = 1; icell <= m->n_cells; ++icell) {
     int Ti; double frac;
-    oracle_temp_lte(m, E_abs[icell - 1], m->volume[icell - 1], 2, &Ti,
-                    &Tdust[icell - 1], &frac);
+    temp_lte_tab(m, tab_log_Qcool(m, icell), E_abs[icell - 1], m->volume[icell - 1], 2, &Ti,
+                 &Tdust[icell - 1], &frac);
   }
 }
 
@@ -1479,7 +1503,7 @@ static void physical_length(worker_t *W, int lambda, const double Stokes[4],
     }
     if (icell0 <= m->n_cells && icell0 >= 1) {                      /* :100 */
       lcell_not_empty = 1;
-      opacity = m->kappa[lambda - 1] * m->kappa_factor[icell0 - 1];
+      opacity = tab_kappa(m, icell0, lambda) * m->kappa_factor[icell0 - 1];
       if (m->l_dark_zone && m->l_dark_zone[icell0 - 1]) {           /* :104 */
         *u = -*u; *v = -*v; *w = -*w;
         *icell = icell_old;
@@ -1514,7 +1538,7 @@ static void physical_length(worker_t *W, int lambda, const double Stokes[4],
     /* save_radiation_field (radiation_field.f90:31-135): thermal step :53, SED mode :63-89 */
     if (lcell_not_empty) {
       if (!W->mono) {
-        W->E_abs[icell0 - 1] += m->kappa_abs_LTE[lambda - 1] * l_contrib * Stokes[0];
+        W->E_abs[icell0 - 1] += tab_kappa_abs(m, icell0, lambda) * l_contrib * Stokes[0];
         if (g_xN_abs) { /* :55 (lmcfost_lib) */
 #pragma omp atomic
           g_xN_abs[icell0 - 1] += 1.0;
@@ -1543,13 +1567,14 @@ static void physical_length(worker_t *W, int lambda, const double Stokes[4],
 /* the cell's temperature as im_reemission_LTE sees it (thermal_emission.f90:660-708) */
 static void cell_temperature(worker_t *W, int icell, int *Ti, float *Temp, double *frac_T2) {
   const oracle_model *m = W->m;
+  const double *lq = tab_log_Qcool(m, icell);
   if (W->o->frozen) {
-    oracle_temp_lte(m, W->E_prior[icell - 1], m->volume[icell - 1], 2, Ti,
-                    Temp, frac_T2);
+    temp_lte_tab(m, lq, W->E_prior[icell - 1], m->volume[icell - 1], 2, Ti,
+                 Temp, frac_T2);
   } else {
     /* id > 0 branch (:670): partial sum * nb_proc, cached xT_ech (:685,:702) */
-    oracle_temp_lte(m, W->E_abs[icell - 1] * W->qscale, m->volume[icell - 1],
-                    W->xT_ech[icell - 1], Ti, Temp, frac_T2);
+    temp_lte_tab(m, lq, W->E_abs[icell - 1] * W->qscale, m->volume[icell - 1],
+                 W->xT_ech[icell - 1], Ti, Temp, frac_T2);
     W->xT_ech[icell - 1] = *Ti;
   }
 }
@@ -1563,8 +1588,8 @@ static void im_reemission_LTE(worker_t *W, int icell, float rand1, float rand2,
   int T2 = Ti, T1 = Ti - 1;
   double frac_T1 = 1.0 - frac_T2;
   int l1 = 0, l2 = m->n_lambda, l = (l1 + l2) / 2;
-  const double *cdf1 = m->kdB_dT_CDF + (size_t)m->n_lambda * (T1 - 1);
-  const double *cdf2 = m->kdB_dT_CDF + (size_t)m->n_lambda * (T2 - 1);
+  const double *cdf1 = tab_cdf(m, icell) + (size_t)m->n_lambda * (T1 - 1);
+  const double *cdf2 = tab_cdf(m, icell) + (size_t)m->n_lambda * (T2 - 1);
   while ((l2 - l1) > 1) {
     double proba = frac_T1 * cdf1[l - 1] + frac_T2 * cdf2[l - 1];
     if ((double)rand2 > proba) l1 = l; else l2 = l;
@@ -1786,7 +1811,7 @@ static void propagate_packet(worker_t *W, int *lambda, int p_lambda,
       }
       rand = -1.0f;
     }
-    if (rand < m->albedo[*lambda - 1]) {                      /* :1284 */
+    if (rand < tab_albedo(m, *icell, *lambda)) {              /* :1284 */
       *flag_scatt = 1;
       W->cnt[ORC_CNT_SCATT]++;
       rand = rng_float(&W->rng);                              /* :1319 */
@@ -1995,6 +2020,7 @@ int oracle_run_mono(const oracle_model *m, const oracle_mono_opts *o, double *xI
                     double *sed, double *n_sent, uint64_t *n_sent_chunk,
                     uint64_t *counters) {
   int nth = o->n_threads > 0 ? o->n_threads : 1;
+  if (m->p_n_cells) return 32; /* variable dust: thermal step only */
   if (o->lambda < 1 || o->lambda > m->n_lambda || o->p_lambda < 1 || o->n_chunks < 1) return 23;
   if (o->rt1 && (m->RT_n_incl * m->RT_n_az > ORACLE_MAX_RT || m->RT_n_incl < 1 || !m->tab_s11_pos)) return 24;
   const size_t nsed = (size_t)ORACLE_N_SED_TYPES * m->n_lambda * m->N_thet * m->N_phi;

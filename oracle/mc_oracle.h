@@ -174,6 +174,15 @@ typedef struct {
   const double *mrw_ext;       /* [n_T] extrapolation length of the sphere radius, reference cell (AU); zeros: none */
   float mrw_gamma;             /* gamma_MRW = 2 (MRW.f90:11) */
   int mrw_n_inter;             /* a walk may start after more than this many interactions in one cell: 5 (:1223) */
+  /* ---- lvariable_dust (mem.f90:213-244): tables with the cell axis p_n_cells, in the reference's layouts.  p_n_cells = 0:
+   * one class (the tables above).  Thermal step only. ---- */
+  int p_n_cells;
+  const int *p_icell;             /* [n_cells] 1..p_n_cells */
+  const double *v_kappa;          /* kappa(p_n_cells, n_lambda) */
+  const double *v_kappa_abs_LTE;  /* (p_n_cells, n_lambda) */
+  const float *v_albedo;          /* tab_albedo_pos(p_n_cells, n_lambda) */
+  const double *v_log_Qcool;      /* (n_T, p_n_cells) */
+  const double *v_kdB_dT_CDF;     /* (n_lambda, n_T, p_n_cells) */
   const double *r_lim;         /* [0..n_rad] (cylindrical_grid.f90:22), read by distance_to_closest_wall_cyl */
 } oracle_model;
 

@@ -88,8 +88,9 @@ struct Conv {
   DevModel M;
   VoroGrid G;
   bool voro;
-  std::vector<double> ch, sx, ct;
-  std::vector<int> sc;
+  std::vector<double> ch, sx, ct, vk, vka;
+  std::vector<float> val;
+  std::vector<int> sc, vcls;
   std::vector<VoroCell> vcell;
   std::vector<VoroNb> vnb;
   double dummy = 0.0;
@@ -160,6 +161,20 @@ struct Conv {
     M.mrw = m->mrw; M.mrw_n_zeta = m->mrw_n_zeta; M.mrw_n_inter = m->mrw_n_inter; M.mrw_gamma = m->mrw_gamma;
     M.mrw_zeta = m->mrw_zeta; M.mrw_chi = m->mrw_chi; M.mrw_kdep = m->mrw_kappa_dep; M.mrw_ext = m->mrw_ext;
     M.r_lim = m->r_lim;
+    M.n_classes = m->p_n_cells;
+    if (m->p_n_cells) {  // class-major copies, as mcgpu_set_variable_dust lays them out
+      const int nc = m->p_n_cells, nl = m->n_lambda;
+      vcls.resize(m->n_cells); vk.resize((size_t)nc * nl); vka.resize((size_t)nc * nl); val.resize((size_t)nc * nl);
+      for (int i = 0; i < m->n_cells; ++i) vcls[i] = m->p_icell[i] - 1;
+      for (int c = 0; c < nc; ++c)
+        for (int l = 0; l < nl; ++l) {
+          vk[(size_t)c * nl + l] = m->v_kappa[c + (size_t)nc * l];
+          vka[(size_t)c * nl + l] = m->v_kappa_abs_LTE[c + (size_t)nc * l];
+          val[(size_t)c * nl + l] = m->v_albedo[c + (size_t)nc * l];
+        }
+      M.cell_class = vcls.data(); M.v_kappa = vk.data(); M.v_kabs = vka.data(); M.v_albedo = val.data();
+      M.v_lq = m->v_log_Qcool; M.v_cdf = m->v_kdB_dT_CDF;
+    }
   }
 };
 
@@ -203,6 +218,14 @@ extern "C" int emu_run_thermal(const oracle_model* m, const oracle_opts* o, cons
                else { if (ld) k_thermal_sph<true, false, true>(M, A); else k_thermal_sph<true, false, false>(M, A); } }
     else { if (pola) { if (ld) k_thermal_sph<false, true, true>(M, A); else k_thermal_sph<false, true, false>(M, A); }
            else { if (ld) k_thermal_sph<false, false, true>(M, A); else k_thermal_sph<false, false, false>(M, A); } }
+    for (int q = 0; q < ORACLE_N_COUNTERS; ++q) counters[q] = cnt[q];
+    return err;
+  }
+  if (M.n_classes) {  // lvariable_dust: the HBM-gather variant
+    if (l3d) { if (pola) { if (dark) k_thermal_var<true, true, true>(M, A); else k_thermal_var<true, true, false>(M, A); }
+               else { if (dark) k_thermal_var<true, false, true>(M, A); else k_thermal_var<true, false, false>(M, A); } }
+    else { if (pola) { if (dark) k_thermal_var<false, true, true>(M, A); else k_thermal_var<false, true, false>(M, A); }
+           else { if (dark) k_thermal_var<false, false, true>(M, A); else k_thermal_var<false, false, false>(M, A); } }
     for (int q = 0; q < ORACLE_N_COUNTERS; ++q) counters[q] = cnt[q];
     return err;
   }

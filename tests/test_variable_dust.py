@@ -1,0 +1,103 @@
+"""lvariable_dust (mem.f90:213-244): opacity and re-emission tables with the cell axis p_n_cells.
+The reference reads them with p_icell in physical_length (optical_depth.f90:100-102), save_radiation_field
+(radiation_field.f90:47-53), the albedo test (dust_transfer.f90:1284), Temp_LTE / im_reemission_LTE
+(thermal_emission.f90:659-771) and Temp_finale.  PARITY: the restatement in the oracle is pinned by the known answer
+"every class = the model's own tables gives the single-class run bit for bit"; the device is held to the oracle."""
+import numpy as np
+import pytest
+
+from mcfost_amd.host import model as M
+from oracle import Oracle
+from test_kernel_emulation import emu, emu_run  # noqa: F401  (the lane emulator's fixture)
+
+
+def settled(n_classes=0, identical=False, **kw):
+    m = M.build_model(M.small(**kw))
+    M.init_variable_dust(m, n_classes=n_classes, identical=identical)
+    return m
+
+
+def test_identical_classes_equal_the_single_class_run():
+    base = M.build_model(M.small())
+    o0, o1 = Oracle(base, 5000), Oracle(settled(identical=True), 5000)
+    a = o0.run_thermal(5000, seed=3, n_threads=1)
+    b = o1.run_thermal(5000, seed=3, n_threads=1)
+    assert a["counters"] == b["counters"]
+    assert np.array_equal(a["E_abs"], b["E_abs"]) and np.array_equal(a["sed"], b["sed"])
+    assert np.array_equal(o0.temp_finale(a["E_abs"]), o1.temp_finale(b["E_abs"]))
+
+
+def test_classes_change_the_physics_where_they_should():
+    m = settled()
+    vd = m.variable_dust
+    nz, n_rad = m.grid["nz"], m.grid["n_rad"]
+    assert vd["p_n_cells"] == nz and vd["p_icell"].min() == 1 and vd["p_icell"].max() == nz
+    assert np.array_equal(vd["p_icell"].reshape(nz, n_rad)[:, 0], np.arange(1, nz + 1))   # one class per layer
+    k = vd["kappa"].reshape(m.n_lambda, nz)
+    assert not np.allclose(k[:, 0], k[:, -1])                       # midplane dust differs from surface dust
+    a = Oracle(M.build_model(M.small()), 20000).run_thermal(20000, seed=3, n_threads=4)
+    b = Oracle(m, 20000).run_thermal(20000, seed=3, n_threads=4)
+    assert b["counters"]["escaped"] + b["counters"]["killed_star"] == 20000
+    assert abs(b["counters"]["absorptions"] / a["counters"]["absorptions"] - 1.0) > 0.02
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(n_rad=12, nz=6, n_az=8, l3D=True)])
+def test_emulated_kernel_against_the_oracle(emu, kw):   # noqa: F811
+    m = settled(**kw)
+    n = 3000
+    orc = Oracle(m, n)
+    prior = orc.run_thermal(2000, seed=1, n_threads=1)["E_abs"]
+    want = orc.run_thermal(n, seed=7, frozen=True, E_prior=prior, n_threads=4)
+    got = emu_run(emu, orc, n, 7, prior=prior)
+    assert got["counters"] == list(want["counters"].values())
+    assert np.array_equal(got["n_sent"], want["n_sent"]) and np.array_equal(got["sed"][4], want["sed"][4])
+    assert np.allclose(got["E_abs"], want["E_abs"], rtol=1e-7, atol=1e-12 * want["E_abs"].max())   # (FMA-level: grazing segments)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(), dict(n_rad=12, nz=6, n_az=8, l3D=True)])
+def test_device_against_the_oracle_frozen(kw):
+    from mcfost_amd.engine import Engine
+    m = settled(**kw)
+    n = 20000
+    orc = Oracle(m, n)
+    prior = orc.run_thermal(2000, seed=1)["E_abs"]
+    want = orc.run_thermal(n, seed=7, frozen=True, E_prior=prior, n_threads=8)
+    e = Engine(m, n)
+    got = e.run_thermal(n, seed=7, frozen=True, E_prior=prior)
+    assert got["counters"] == want["counters"]
+    assert np.array_equal(got["n_sent"], want["n_sent"]) and np.array_equal(got["sed"][4], want["sed"][4])
+    assert np.allclose(got["E_abs"], want["E_abs"], rtol=1e-7, atol=1e-12 * want["E_abs"].max())   # (FMA-level: grazing segments)
+    assert np.allclose(e.temp_finale(got["E_abs"]), orc.temp_finale(want["E_abs"]), rtol=2e-6)
+    e.close()
+
+
+@pytest.mark.gpu
+def test_device_identical_classes_and_live_statistics():
+    from mcfost_amd.engine import Engine
+    from helpers import mc_similar
+    n = 2_000_000
+    base = M.build_model(M.small())
+    e0 = Engine(base, n)
+    prior = e0.run_thermal(100000, seed=1)["E_abs"] * (n / 100000)
+    a = e0.run_thermal(n, seed=5, frozen=True, E_prior=prior)
+    e0.close()
+    e1 = Engine(settled(identical=True), n)
+    b = e1.run_thermal(n, seed=5, frozen=True, E_prior=prior)
+    e1.close()
+    assert a["counters"] == b["counters"]                       # the gather variant runs the same packets
+    assert np.allclose(a["E_abs"], b["E_abs"], rtol=1e-9, atol=1e-12 * a["E_abs"].max())
+    # live mode with real classes: temperature against the oracle's own live run
+    m = settled()
+    e2 = Engine(m, n)
+    T_gpu = e2.temp_finale(e2.run_thermal(n, seed=9)["E_abs"])
+    o = Oracle(m, n)
+    T_cpu = o.temp_finale(o.run_thermal(n, seed=10, n_threads=8)["E_abs"])
+    sel = (T_cpu > 1.2 * m.cfg.T_min) & (T_gpu > 1.2 * m.cfg.T_min)
+    ok, p75 = mc_similar(T_cpu[sel], T_gpu[sel], 0.02)
+    assert ok, p75
+    # what is not built refuses
+    from mcfost_amd.engine import McgpuError
+    with pytest.raises(McgpuError):
+        e2.set_mrw(M.init_mrw(m))
+    e2.close()
