@@ -166,7 +166,9 @@ int mcgpu_set_midplane_snap(mcgpu_ctx *ctx, int on);
  *                      through a hashed LDS cache); 1 = HBM atomics only; 2 = LDS (refused
  *                      when the grid does not fit)
  *   "schedule"     0 = automatic (default): waves with roles and LDS packet queues where
- *                      the queues fit; 1 = the single-role kernel
+ *                      the queues fit (cylindrical grids; Voronoi grids run the single-role
+ *                      kernel, which is faster on them); 1 = the single-role kernel;
+ *                      2 = the role schedule wherever it is built (also Voronoi grids)
  *   "speculation"  SED mode: 1 (default) = most of every stream is committed before the
  *                      scout pass (exact; see mcgpu_run_mono), 0 = scout every packet first
  *   "voronoi_cache_log_slots"  6..13 (default 13): log2 of the slots of the Voronoi deposit cache

@@ -33,6 +33,7 @@
 // logic error cannot hang the GPU.
 #pragma once
 #include "mc_device.hip.h"
+#include "mc_voronoi.hip.h"
 
 #ifdef MCGPU_COUNT_ITERS  // diagnostic build (tools/roles_check.py diag): statements that only count
 #define RQ_DIAG(...) __VA_ARGS__
@@ -351,6 +352,43 @@ __device__ __forceinline__ int fly_step_2d(const Lds& T, const DevModel& M, cons
   return ((active && !out && killed) || runaway) ? 1 : 0;
 }
 
+// One cell crossing of a packet in flight on a Voronoi grid (the crossing of thermal_body_voro, mc_voronoi.hip.h, on a
+// Flight): p.ri = the cell, p.zj = the cell it came from, p.star_key = the cell of the star on the way (0: none).
+template <bool CACHE>
+__device__ inline int voro_roles_cross(const Lds& T, const DevModel& M, const RunArgs& A, const VoroGrid& G,
+                                       const DepCache& DC, Flight& p, unsigned int& c_cross, unsigned int& c_kill) {
+  const int icell = p.ri;
+  if (icell < 0) { p.st = S_EXITED; return 0; }                                  // test_exit_grid_Voronoi (:1446)
+  if (p.star_key > 0 && icell == p.star_key) { c_kill++; p.st = S_EMIT; return 1; }  // optical_depth.f90:91-97
+  const VoroCell C = G.cell[icell - 1];
+  const double opacity = p.kap * C.kf;
+  double x1, y1, z1, l, l_contrib, l_void;
+  int next;
+  voro_cross_cell(G, M, C, p.x, p.y, p.z, p.u, p.v, p.w, icell, p.zj, x1, y1, z1, next, l, l_contrib, l_void);
+  c_cross++;
+  const double tau = l_contrib * opacity;
+  const bool stop = tau > p.extr;
+  const double lc = stop ? l_contrib * (p.extr / tau) : l_contrib;
+  const double dE = p.kab * lc * p.S0;
+  if (dE != 0.0 && !MCGPU_DIAG(A.flags, 1)) {
+    if (!(CACHE && DC.add(icell, dE))) atomic_add_f64(&A.E_abs[icell - 1], dE);
+  }
+  if (stop) {
+    const double ls = l_void + lc;
+    p.x = nd_add(p.x, nd_mul(ls, p.u));
+    p.y = nd_add(p.y, nd_mul(ls, p.v));
+    p.z = nd_add(p.z, nd_mul(ls, p.w));
+    p.st = S_INTERACT;
+  } else {
+    p.extr = p.extr - tau;
+    p.x = x1; p.y = y1; p.z = z1;
+    p.zj = icell;
+    p.ri = next;
+  }
+  if (++p.pk_cross > 200000000u) { *A.err = 13; p.st = S_EMIT; return 1; }  // a packet that never leaves: flag it, drop it
+  return 0;
+}
+
 // the compiler must not carry values from one serving phase to the next in registers: they go through the record
 #ifndef MCGPU_LANE_EMULATION
 #define RQ_PHASE_END() asm volatile("" ::: "memory")
@@ -358,13 +396,25 @@ __device__ __forceinline__ int fly_step_2d(const Lds& T, const DevModel& M, cons
 #define RQ_PHASE_END()
 #endif
 
-template <bool L3D, bool POLA, bool DARK, bool LDSE, bool MRW = false>
+// VORO: the same schedule on a Voronoi grid (G; L3D = true, DARK = LDSE = MRW = false): a record's ri is the packet's
+// cell, zj the cell it came from, star_key the cell of the star on its way; deposits go through the workgroup's
+// deposit cache (DepCache, 2^cache_log_ns slots behind the tables) instead of a private grid.
+template <bool L3D, bool POLA, bool DARK, bool LDSE, bool MRW = false, bool VORO = false>
 __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, double* lds_base, int n_rec, int n_srv_pref,
-                                           int k_short, int fly_iters, int fly_idle, int emit_qmax) {
+                                           int k_short, int fly_iters, int fly_idle, int emit_qmax,
+                                           const VoroGrid* Gp = nullptr, int cache_log_ns = 0) {
+  static_assert(!VORO || (L3D && !DARK && !LDSE && !MRW), "Voronoi variant");
   double* const E_lds = lds_base;
   const Lds T = lds_carve(lds_base + (LDSE ? M.n_cells : 0), M);
   lds_stage(T, M);
-  char* const qbase = reinterpret_cast<char*>(lds_base + (LDSE ? M.n_cells : 0) + (lds_bytes(M) + 7) / 8);
+  DepCache DC;
+  DC.log_ns = cache_log_ns;
+  DC.val = lds_base + (lds_bytes(M) + 7) / 8;
+  DC.tag = reinterpret_cast<int*>(DC.val + ((size_t)1 << cache_log_ns));
+  const size_t cache_doubles = VORO ? (((size_t)12 << cache_log_ns) + 7) / 8 : 0;
+  if (VORO)
+    for (int i = threadIdx.x; i < (1 << cache_log_ns); i += blockDim.x) { DC.val[i] = 0.0; DC.tag[i] = 0; }
+  char* const qbase = reinterpret_cast<char*>(lds_base + (LDSE ? M.n_cells : 0) + (lds_bytes(M) + 7) / 8 + cache_doubles);
   RqCtl* const Q = reinterpret_cast<RqCtl*>(qbase);
   unsigned int* const rings = reinterpret_cast<unsigned int*>(qbase + sizeof(RqCtl));
   Rec<POLA>* const recs = reinterpret_cast<Rec<POLA>*>(qbase + sizeof(RqCtl) + 3 * RQ_CAP * sizeof(unsigned int));
@@ -496,7 +546,8 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
           bag_fl = R.flags & ~ST_MASK;
         }
         st = S_FLIGHT;
-        flight_constants<L3D>(T, M, F, bag_lambda);
+        if (VORO) { F.kap = T.kappa[bag_lambda - 1]; F.kab = T.kabs[bag_lambda - 1]; }
+        else flight_constants<L3D>(T, M, F, bag_lambda);
       }
       // stopped packets that found no flight to swap with go to a free record
       {
@@ -539,7 +590,9 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
           // back to the rings as soon as enough lanes have nothing to fly (or after fly_iters crossings)
           if (it > 0 && __popcll(__ballot(F.st != S_FLIGHT)) >= fly_idle) break;
           RQ_DIAG(if (lane == 0) d_fly_iters++; if (F.st == S_FLIGHT) d_fly_cross++;)
-          if (L3D) {
+          if (VORO) {
+            if (F.st == S_FLIGHT) finished += voro_roles_cross<true>(T, M, A, *Gp, DC, F, c_cross, c_kill);
+          } else if (L3D) {
             if (F.st == S_FLIGHT) finished += roles_cross<L3D, DARK, LDSE>(T, M, A, E_lds, F, c_cross, c_kill, c_dark);
           } else {
             finished += fly_step_2d<DARK, LDSE, MRW>(T, M, A, E_lds, F, c_cross, c_kill, c_dark);
@@ -601,10 +654,19 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
             bool lintersect, flag_star, flag_ism;
             double x, y, z, u, v, w;
             int ri = 0, zj = 1, k = 1;
-            CylEmitOps<L3D> ops{T, M, ri, zj, k};
-            const int rc = emit_packet(M, f, lambda, T.fstar[lambda - 1], M.frac_E_disk[lambda - 1],
-                                       M.prob_E_cell ? M.prob_E_cell + (size_t)(M.n_cells + 1) * (lambda - 1) : nullptr,
-                                       ops, x, y, z, u, v, w, flag_star, flag_ism, lintersect);
+            int rc;
+            if (VORO) {
+              zj = 0;
+              VoroEmitOps ops{*Gp, M, ri};
+              rc = emit_packet(M, f, lambda, T.fstar[lambda - 1], M.frac_E_disk[lambda - 1],
+                               M.prob_E_cell ? M.prob_E_cell + (size_t)(M.n_cells + 1) * (lambda - 1) : nullptr,
+                               ops, x, y, z, u, v, w, flag_star, flag_ism, lintersect);
+            } else {
+              CylEmitOps<L3D> ops{T, M, ri, zj, k};
+              rc = emit_packet(M, f, lambda, T.fstar[lambda - 1], M.frac_E_disk[lambda - 1],
+                               M.prob_E_cell ? M.prob_E_cell + (size_t)(M.n_cells + 1) * (lambda - 1) : nullptr,
+                               ops, x, y, z, u, v, w, flag_star, flag_ism, lintersect);
+            }
             if (rc) { *A.err = rc; rq_st(&Q->abort_flag, 1); }
             st = lintersect ? S_NEWFLIGHT : S_EXITED;
             R.x = x; R.y = y; R.z = z; R.u = u; R.v = v; R.w = w; R.extr = 0.0;
@@ -659,7 +721,7 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
           lambda_sc = lambda;
           const int fl = R.flags;
           bool flag_star = (fl & ST_STAR) != 0, flag_scatt = (fl & ST_SCATT) != 0, flag_ism = (fl & ST_ISM) != 0;
-          const int ic = cell_index<L3D>(n_rad, nz, R.ri, R.zj, R.k);
+          const int ic = VORO ? R.ri - 1 : cell_index<L3D>(n_rad, nz, R.ri, R.zj, R.k);
           scat = interact_direction(T, M, g, lambda, R.u, R.v, R.w, u1, v1, w1, flag_star, flag_scatt, c_scatt, c_abs, [&]() {
             // the cell's absorbed energy for Temp_LTE (thermal_emission.f90:649-706): what every workgroup has
             // folded into HBM so far plus (LDSE) this workgroup's not yet folded part -- the other workgroups'
@@ -670,6 +732,7 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
             else {
               E = __hip_atomic_load(&A.E_abs[ic], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               if (LDSE) E += E_lds[ic] * (double)gridDim.x;
+              if (VORO) E += DC.pending(ic + 1) * (double)gridDim.x;
               E *= A.qscale;
             }
             return E;
@@ -738,8 +801,9 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
           int key = -1;
           if (i_star > 0) {
             const int* sc = &M.star_cell[4 * (i_star - 1)];
-            key = sc[0] + (n_rad + 2) * ((sc[1] + nz + 1) + (2 * nz + 3) * (sc[2] - 1));
+            key = VORO ? sc[0] : sc[0] + (n_rad + 2) * ((sc[1] + nz + 1) + (2 * nz + 3) * (sc[2] - 1));
           }
+          if (VORO) R.zj = 0;  // a new flight has no previous cell (prev_cell = 0)
           R.star_key = key;
           c_flight++;
           st = S_FLIGHT;
@@ -754,14 +818,17 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
           if (fly) {
             F.x = R.x; F.y = R.y; F.z = R.z; F.u = R.u; F.v = R.v; F.w = R.w; F.extr = R.extr; F.S0 = R.S[0];
             F.ri = R.ri; F.zj = R.zj; F.k = R.k; F.star_key = R.star_key; F.pk_cross = R.pk_cross;
-            flight_constants<L3D>(T, M, F, R.lambda);
+            if (VORO) { F.kap = T.kappa[R.lambda - 1]; F.kab = T.kabs[R.lambda - 1]; }
+            else flight_constants<L3D>(T, M, F, R.lambda);
           }
           const int n_it = flying_in_place ? fly_iters : k_short;
 #pragma unroll 1
           for (int it = 0; it < n_it; ++it) {
             if (__ballot(F.st == S_FLIGHT) == 0ull) break;
             RQ_DIAG(if (lane == 0) d_srv_iters++;)
-            if (L3D) {
+            if (VORO) {
+              if (F.st == S_FLIGHT) finished += voro_roles_cross<true>(T, M, A, *Gp, DC, F, c_cross, c_kill);
+            } else if (L3D) {
               if (F.st == S_FLIGHT) finished += roles_cross<L3D, DARK, LDSE>(T, M, A, E_lds, F, c_cross, c_kill, c_dark);
             } else {
               finished += fly_step_2d<DARK, LDSE, MRW>(T, M, A, E_lds, F, c_cross, c_kill, c_dark);
@@ -807,6 +874,19 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
       const int fin = __popcll(__ballot(finished > 0)) + __popcll(__ballot(finished > 1));
       if (fin > 0 && lane == 0) atomicAdd(&Q->n_pending, -fin);
     }
+    if (VORO && ((ep + 1) % A.flush_every) == 0) {  // barrier-free partial fold of the deposit cache (see thermal_body_voro)
+      const int n_waves = (blockDim.x + 63) >> 6;
+      const int slice = (wave + (ep + 1) / A.flush_every) % n_waves;
+      const int ns = 1 << cache_log_ns, per = (ns + n_waves - 1) / n_waves;
+      const int i0 = slice * per, i1 = (i0 + per < ns) ? i0 + per : ns;
+      for (int i = i0 + lane; i < i1; i += 64) {
+        const int t = DC.tag[i];
+        if (t == 0) continue;
+        const unsigned long long bits = atomicExch(reinterpret_cast<unsigned long long*>(&DC.val[i]), 0ull);
+        const double e = __longlong_as_double((long long)bits);
+        if (e != 0.0) atomic_add_f64(&A.E_abs[t - 1], e);
+      }
+    }
     if (LDSE && ((ep + 1) % A.flush_every) == 0) {  // barrier-free partial fold (see thermal_body)
       const int n_waves = (blockDim.x + 63) >> 6;
       const int slice = (wave + (ep + 1) / A.flush_every) % n_waves;
@@ -826,6 +906,12 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
     for (int i = threadIdx.x; i < M.n_cells; i += blockDim.x) {
       const double e = E_lds[i];
       if (e != 0.0) atomic_add_f64(&A.E_abs[i], e);
+    }
+  }
+  if (VORO) {  // final fold of the deposit cache
+    for (int i = threadIdx.x; i < (1 << cache_log_ns); i += blockDim.x) {
+      const double e = DC.val[i];
+      if (e != 0.0) atomic_add_f64(&A.E_abs[DC.tag[i] - 1], e);
     }
   }
   unsigned int cs[8] = {c_pack, c_cross, c_flight, c_scatt, c_abs, c_esc, c_kill, c_dark};
@@ -857,6 +943,16 @@ __global__ void __launch_bounds__(MCGPU_ROLES_BLOCK) k_thermal_roles(const DevMo
                                                                      int k_short, int fly_iters, int fly_idle, int emit_qmax) {
   extern __shared__ double lds_raw[];
   roles_body<L3D, POLA, DARK, LDSE, MRW>(M, A, lds_raw, n_rec, n_srv_pref, k_short, fly_iters, fly_idle, emit_qmax);
+}
+
+// the role schedule on a Voronoi grid
+template <bool POLA>
+__global__ void __launch_bounds__(MCGPU_ROLES_BLOCK) k_thermal_voro_roles(const DevModel M, const RunArgs A, const VoroGrid G,
+                                                                          int cache_log_ns, int n_rec, int n_srv_pref, int k_short,
+                                                                          int fly_iters, int fly_idle, int emit_qmax) {
+  extern __shared__ double lds_raw[];
+  roles_body<true, POLA, false, false, false, true>(M, A, lds_raw, n_rec, n_srv_pref, k_short, fly_iters, fly_idle, emit_qmax,
+                                                    &G, cache_log_ns);
 }
 
 }  // namespace mcgpu

@@ -378,7 +378,7 @@ extern "C" int mcgpu_set_grid_voronoi(mcgpu_ctx* ctx, int n_cells, const float* 
 extern "C" int mcgpu_set_option(mcgpu_ctx* ctx, const char* name, int value) {
   if (!ctx || !name) return MCGPU_ERR_ARG;
   if (!strcmp(name, "deposit")) { if (value < 0 || value > 2) return fail(ctx, MCGPU_ERR_ARG, "deposit: 0, 1 or 2"); ctx->opt_deposit = value; }
-  else if (!strcmp(name, "schedule")) { if (value < 0 || value > 1) return fail(ctx, MCGPU_ERR_ARG, "schedule: 0 or 1"); ctx->opt_schedule = value; }
+  else if (!strcmp(name, "schedule")) { if (value < 0 || value > 2) return fail(ctx, MCGPU_ERR_ARG, "schedule: 0, 1 or 2"); ctx->opt_schedule = value; }
   else if (!strcmp(name, "speculation")) ctx->opt_speculation = value ? 1 : 0;
   else if (!strcmp(name, "voronoi_cache_log_slots")) { if (value < 6 || value > 13) return fail(ctx, MCGPU_ERR_ARG, "voronoi_cache_log_slots: 6..13"); ctx->opt_cache_log_slots = value; }
   else if (!strcmp(name, "radiation_field")) { if (value < 0 || value > 3) return fail(ctx, MCGPU_ERR_ARG, "radiation_field: bit 0 xN_abs, bit 1 xJ_abs"); ctx->opt_radiation_field = value; }
@@ -793,6 +793,38 @@ static int launch_voro(mcgpu_ctx* ctx, const RunArgs& A, int grid_blocks, int bl
   const DevModel& M = ctx->M;
   const size_t lds_t = (lds_bytes(M) + 7) / 8 * 8;
   const size_t lds_cap = 160 * 1024;
+  // Option "schedule" = 2: the role schedule of mc_roles.hip.h (serving and flying waves over packet records in LDS)
+  // with the deposit cache in what the tables and at least 256 records leave.  Not the default on this grid:
+  // measured at 100 000 sites 2.5e7 packets/s against 4.7e7 for the single-role kernel below -- the stand-in disk's
+  // packets interact 119 times for 162 crossings, so almost all work is serving work, and the serving lanes are
+  // limited by the records that fit into LDS (512 for 1024 lanes).
+  if (ctx->opt_schedule == 2 && ctx->opt_deposit != 1 && !A.xN_abs && !A.xJ_abs) {
+    const bool pola = ctx->lsepar_pola != 0;
+    int log_ns = ctx->opt_cache_log_slots, n_rec = 0;
+    for (; log_ns >= 6; --log_ns) {
+      const size_t used = lds_t + (((size_t)12 << log_ns) + 7) / 8 * 8;
+      n_rec = used < lds_cap ? rq_records_that_fit(pola, lds_cap - used) : 0;
+      if (n_rec >= 256) break;
+    }
+    if (log_ns >= 6 && n_rec >= 256) {
+      const int rthreads = (block_threads > 0 && block_threads <= MCGPU_ROLES_BLOCK) ? block_threads : MCGPU_ROLES_BLOCK;
+      if (rthreads % 64) return fail(ctx, MCGPU_ERR_ARG, "block_threads must be a multiple of 64");
+      if (n_rec > RQ_CAP) n_rec = RQ_CAP;
+      const size_t lds_r = lds_t + (((size_t)12 << log_ns) + 7) / 8 * 8 + rq_lds_bytes(pola, n_rec);
+      int rblocks = grid_blocks > 0 ? grid_blocks : ctx->prop.multiProcessorCount;
+      const unsigned long long need = (A.n_packets + rthreads - 1) / rthreads;
+      if (grid_blocks <= 0 && (unsigned long long)rblocks > need) rblocks = (int)(need ? need : 1);
+      int n_srv_pref = tune("MCGPU_N_SRV", (rthreads / 64 + 1) / 2, 1, 1016);  // (this grid's packets interact as often as they cross)
+      int k_short = tune("MCGPU_K_SHORT", 2, 0, 64), fly_iters = tune("MCGPU_FLY_ITERS", 16, 1, 256);
+      int fly_idle = tune("MCGPU_FLY_IDLE", 32, 1, 65), emit_qmax = tune("MCGPU_EMIT_QMAX", 128, 0, 1 << 20);
+      const void* fn = pola ? (const void*)k_thermal_voro_roles<true> : (const void*)k_thermal_voro_roles<false>;
+      HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));
+      void* args[] = {(void*)&M, (void*)&A, (void*)&ctx->V, (void*)&log_ns, (void*)&n_rec, (void*)&n_srv_pref, (void*)&k_short,
+                      (void*)&fly_iters, (void*)&fly_idle, (void*)&emit_qmax};
+      HIPCHK(hipLaunchKernel(fn, dim3(rblocks), dim3(rthreads), args, lds_r, ctx->stream));
+      return MCGPU_OK;
+    }
+  }
   bool cache = ctx->opt_deposit != 1;
   int log_ns = 0;
   if (cache) {

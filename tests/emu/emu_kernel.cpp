@@ -202,6 +202,17 @@ extern "C" int emu_run_thermal(const oracle_model* m, const oracle_opts* o, cons
   A.counters = cnt; A.next_packet = cnt + 12; A.err = &err;
   A.inner_iters = 8; A.flags = 0; A.flush_every = 4; A.min_active = 0;
   const bool pola = m->lsepar_pola && m->aniso_method == 1, dark = M.dark != nullptr, l3d = m->l3D != 0;
+  if (voro && getenv("MCGPU_EMU_ROLES")) {  // the role schedule on a Voronoi grid, one lane
+    int nsp = 1, ks = 2, fi = 3, eq = 128;
+    sscanf(getenv("MCGPU_EMU_ROLES"), "%d,%d,%d,%d", &nsp, &ks, &fi, &eq);
+    const int n_rec = RQ_MIN_REC, log_ns = 6;
+    if (lds_bytes(M) + ((size_t)12 << log_ns) + rq_lds_bytes(true, n_rec) + 64 > sizeof(lds_raw)) return 31;
+    A.flush_every = 4;
+    if (pola) k_thermal_voro_roles<true>(M, A, G, log_ns, n_rec, nsp, ks, fi, 65, eq);
+    else k_thermal_voro_roles<false>(M, A, G, log_ns, n_rec, nsp, ks, fi, 65, eq);
+    for (int q = 0; q < ORACLE_N_COUNTERS; ++q) counters[q] = cnt[q];
+    return err;
+  }
   if (voro) {
     if (getenv("MCGPU_EMU_LDS")) {  // deposit cache, few slots so that hits, misses and folds all occur
       if (pola) k_thermal_voro_cache<true, 512>(M, A, G, 6); else k_thermal_voro_cache<false, 512>(M, A, G, 6);

@@ -481,6 +481,12 @@ def test_voronoi_launch_geometry_independence(voro_model):
         assert r["counters"] == ref["counters"]
         assert np.array_equal(r["sed"][4], ref["sed"][4])
         assert np.allclose(r["E_abs"], ref["E_abs"], rtol=1e-10, atol=1e-12 * ref["E_abs"].max())
+    e.set_option("schedule", 2)   # the role schedule on this grid (opt-in: slower here, same packets)
+    for gb, bt in ((0, 0), (3, 256)):
+        r = e.run_thermal(10000, seed=9, frozen=True, E_prior=prior, grid_blocks=gb, block_threads=bt)
+        assert r["counters"] == ref["counters"]
+        assert np.array_equal(r["sed"][4], ref["sed"][4])
+        assert np.allclose(r["E_abs"], ref["E_abs"], rtol=1e-10, atol=1e-12 * ref["E_abs"].max())
     e.close()
 
 

@@ -227,6 +227,12 @@ def test_emulated_kernel_voronoi(emu):
         check(emu, m, 4000, 21, rtol=1e-7)
     finally:
         del os.environ["MCGPU_EMU_LDS"]
+    for roles in ("1,2,3,128", "0,2,3,128", "1,0,2,0"):   # and under the role schedule (mc_roles.hip.h, VORO)
+        os.environ["MCGPU_EMU_ROLES"] = roles
+        try:
+            check(emu, m, 4000, 21, rtol=1e-7)
+        finally:
+            del os.environ["MCGPU_EMU_ROLES"]
 
 
 def test_emulated_kernel_voronoi_star_outside_and_disk_emission(emu):
@@ -245,6 +251,11 @@ def test_emulated_kernel_voronoi_star_outside_and_disk_emission(emu):
     m.prob_E_cell = pe.reshape(-1)
     m.frac_E_stars = np.full(m.n_lambda, 0.4)
     check(emu, m, 3000, 23, rtol=1e-6)
+    os.environ["MCGPU_EMU_ROLES"] = "1,2,3,128"
+    try:
+        check(emu, m, 3000, 23, rtol=1e-6)
+    finally:
+        del os.environ["MCGPU_EMU_ROLES"]
 
 
 def emu_mono(emu, orc, lam, n2, seed, rt1=True, n_chunks=8, n_phot_lim=1e9):
