@@ -442,14 +442,20 @@ int mcgpu_probe_packet_rand(mcgpu_ctx *ctx, uint64_t seed, uint64_t packet,
  *   tab_albedo_pos (p_n_cells, n_lambda)          grains.f90:62
  *   log_Qcool (n_T, p_n_cells)                    log_Qcool_minus_extra_heating, thermal_emission.f90:34
  *   kdB_dT_CDF (n_lambda, n_T, p_n_cells)         thermal_emission.f90:45
+ *   prob_s11_pos, tab_s12_o_s11_pos ... tab_s44_o_s11_pos (0:nang_scatt, p_n_cells, n_lambda), tab_g_pos
+ *   (p_n_cells, n_lambda)                         mem.f90:205-243; all seven or all NULL (NULL: every class scatters
+ *                                                 with the tables of mcgpu_set_scattering)
  * p_n_cells may be smaller than n_cells (classes of cells with the same dust).  The thermal step then runs the
- * HBM-gather variant of the single-role kernel and mcgpu_temp_finale reads log_Qcool per class.  The scattering
- * matrices keep their single-class tables (prob_s11_pos etc. per class: not built), and so do the SED mode, the ray
- * tracing, the random walk and the diffusion fill, which refuse a context with variable dust.  p_n_cells = 0: off.
+ * HBM-gather variant of the single-role kernel and mcgpu_temp_finale reads log_Qcool per class.  The SED mode, the
+ * ray tracing, the random walk and the diffusion fill are not built for it and refuse such a context.
+ * p_n_cells = 0: off.
  */
 int mcgpu_set_variable_dust(mcgpu_ctx *ctx, int p_n_cells, const int *p_icell, const double *kappa,
                             const double *kappa_abs_LTE, const float *tab_albedo_pos,
-                            const double *log_Qcool, const double *kdB_dT_CDF);
+                            const double *log_Qcool, const double *kdB_dT_CDF, const float *prob_s11_pos,
+                            const float *tab_s12_o_s11_pos, const float *tab_s22_o_s11_pos,
+                            const float *tab_s33_o_s11_pos, const float *tab_s34_o_s11_pos,
+                            const float *tab_s44_o_s11_pos, const float *tab_g_pos);
 
 /*
  * The optional accumulators of save_radiation_field's thermal branch (radiation_field.f90:54-55):

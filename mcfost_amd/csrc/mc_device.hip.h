@@ -144,6 +144,15 @@ struct DevModel {
   const float* v_albedo;     // [n_classes][n_lambda]
   const double* v_lq;        // [n_classes][n_T]
   const double* v_cdf;       // [n_classes][n_T][n_lambda]
+  // ... and, when the host passed them (v_scatt != 0), the scattering tables per class
+  int v_scatt;
+  const float* v_prob;       // [n_classes][p_lambda_fixed ? 1 : n_lambda][nang+1]
+  const float* v_g;          // [n_classes][n_lambda]
+  const float* v_s12;        // [n_classes][n_lambda][nang+1], likewise v_s22 ... v_s44
+  const float* v_s22;
+  const float* v_s33;
+  const float* v_s34;
+  const float* v_s44;
 };
 
 // packet state word of the queue records: state | flags
@@ -350,6 +359,10 @@ __device__ inline Lds class_tables(const Lds& T, const DevModel& M, int cls) {
   V.albedo = const_cast<float*>(M.v_albedo) + (size_t)cls * M.n_lambda;
   V.lq = const_cast<double*>(M.v_lq) + (size_t)cls * M.n_T;
   V.cdf = const_cast<double*>(M.v_cdf) + (size_t)cls * M.n_T * M.n_lambda;
+  if (M.v_scatt) {
+    V.prob = const_cast<float*>(M.v_prob) + (size_t)cls * (M.p_lambda_fixed ? 1 : M.n_lambda) * (M.nang + 1);
+    V.g = const_cast<float*>(M.v_g) + (size_t)cls * M.n_lambda;
+  }
   return V;
 }
 
@@ -1240,17 +1253,24 @@ __device__ __forceinline__ bool interact_direction(const Lds& T, const DevModel&
 }
 
 // lambda: the packet's wavelength at the time of the scattering (a scattering does not change it)
+// cls >= 0: the Mueller ratios of that cell class (lvariable_dust with per-class scattering tables)
 __device__ __forceinline__ void interact_stokes(const DevModel& M, bool scat, int lambda, int itheta, float rand2,
                                                 double u, double v, double w, double u1, double v1, double w1,
-                                                double S[4]) {
+                                                double S[4], int cls = -1) {
   if (scat && M.aniso_method == 1) {
     const size_t o = (size_t)(M.nang + 1) * (lambda - 1) + itheta;
     const float fr = rand2, fm = 1.0f - rand2;
-    const double M22 = (double)(M.s22[o] * fr + M.s22[o - 1] * fm);
-    const double M12 = (double)(M.s12[o] * fr + M.s12[o - 1] * fm);
-    const double M33 = (double)(M.s33[o] * fr + M.s33[o - 1] * fm);
-    const double M44 = (double)(M.s44[o] * fr + M.s44[o - 1] * fm);
-    const double M34 = (double)(-M.s34[o] * fr - M.s34[o - 1] * fm);
+    const size_t co = cls >= 0 ? (size_t)cls * M.n_lambda * (M.nang + 1) : 0;
+    const float* s22 = (cls >= 0 ? M.v_s22 : M.s22) + co;
+    const float* s12 = (cls >= 0 ? M.v_s12 : M.s12) + co;
+    const float* s33 = (cls >= 0 ? M.v_s33 : M.s33) + co;
+    const float* s44 = (cls >= 0 ? M.v_s44 : M.s44) + co;
+    const float* s34 = (cls >= 0 ? M.v_s34 : M.s34) + co;
+    const double M22 = (double)(s22[o] * fr + s22[o - 1] * fm);
+    const double M12 = (double)(s12[o] * fr + s12[o - 1] * fm);
+    const double M33 = (double)(s33[o] * fr + s33[o - 1] * fm);
+    const double M44 = (double)(s44[o] * fr + s44[o - 1] * fm);
+    const double M34 = (double)(-s34[o] * fr - s34[o - 1] * fm);
     update_stokes(S, u, v, w, u1, v1, w1, M12, M22, M33, M34, M44);
   }
   if (!scat) { S[1] = 0.0; S[2] = 0.0; S[3] = 0.0; }
@@ -1262,13 +1282,13 @@ __device__ __forceinline__ void interact(const Lds& T, const DevModel& M, const 
                                          double S[4], bool& flag_star, bool& flag_scatt,
                                          unsigned int& c_scatt, unsigned int& c_abs, EnergyFn cell_energy,
                                          const double* volume_of_cell, bool forced = false,
-                                         const float* prob_forced = nullptr, int lds_col = -1) {
+                                         const float* prob_forced = nullptr, int lds_col = -1, int mueller_class = -1) {
   int itheta;
   float rand2;
   const int lambda_in = lambda;
   const bool scat = interact_direction(T, M, g, lambda, u, v, w, u1, v1, w1, flag_star, flag_scatt, c_scatt, c_abs,
                                        cell_energy, volume_of_cell, itheta, rand2, forced, prob_forced, lds_col);
-  if (POLA) interact_stokes(M, scat, lambda_in, itheta, rand2, u, v, w, u1, v1, w1, S);
+  if (POLA) interact_stokes(M, scat, lambda_in, itheta, rand2, u, v, w, u1, v1, w1, S, mueller_class);
 }
 
 // ---------------------------------------------------------------------------
@@ -1595,7 +1615,7 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
           E *= A.qscale;
         }
         return E;
-      }, M.volume + ic);
+      }, M.volume + ic, false, nullptr, -1, (VAR && M.v_scatt) ? M.cell_class[ic] : -1);
       if (!flag_scatt) flag_ism = false;  // absorbed and re-emitted by the dust (:1367)
       u = u1; v = v1; w = w1;
       if (MRW) {

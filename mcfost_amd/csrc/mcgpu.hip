@@ -538,7 +538,10 @@ extern "C" int mcgpu_set_thermal(mcgpu_ctx* ctx, int n_T, const float* tab_Temp,
 // the reference's own layouts and are re-laid class-major for the device.
 extern "C" int mcgpu_set_variable_dust(mcgpu_ctx* ctx, int p_n_cells, const int* p_icell, const double* kappa,
                                        const double* kappa_abs_LTE, const float* tab_albedo_pos,
-                                       const double* log_Qcool, const double* kdB_dT_CDF) {
+                                       const double* log_Qcool, const double* kdB_dT_CDF, const float* prob_s11_pos,
+                                       const float* tab_s12_o_s11_pos, const float* tab_s22_o_s11_pos,
+                                       const float* tab_s33_o_s11_pos, const float* tab_s34_o_s11_pos,
+                                       const float* tab_s44_o_s11_pos, const float* tab_g_pos) {
   if (!ctx) return MCGPU_ERR_ARG;
   DevModel& M = ctx->M;
   if (p_n_cells == 0) { M.n_classes = 0; return MCGPU_OK; }  // back to one class
@@ -574,6 +577,35 @@ extern "C" int mcgpu_set_variable_dust(mcgpu_ctx* ctx, int p_n_cells, const int*
   // log_Qcool_minus_extra_heating(n_T, p_n_cells) and kdB_dT_CDF(n_lambda, n_T, p_n_cells): class slowest already
   if ((rc = upload(ctx, log_Qcool, (size_t)nc * nT, &M.v_lq))) return rc;
   if ((rc = upload(ctx, kdB_dT_CDF, (size_t)nc * nT * nl, &M.v_cdf))) return rc;
+  // scattering tables per class (all or none): (0:nang, p_n_cells, n_lambda) in the reference -> [class][lambda][angle]
+  M.v_scatt = 0;
+  const bool any_sc = prob_s11_pos || tab_s12_o_s11_pos || tab_s22_o_s11_pos || tab_s33_o_s11_pos || tab_s34_o_s11_pos ||
+                      tab_s44_o_s11_pos || tab_g_pos;
+  if (any_sc) {
+    if (!ctx->have_scatt) return fail(ctx, MCGPU_ERR_STATE, "set the scattering tables first");
+    if (!(prob_s11_pos && tab_s12_o_s11_pos && tab_s22_o_s11_pos && tab_s33_o_s11_pos && tab_s34_o_s11_pos &&
+          tab_s44_o_s11_pos && tab_g_pos))
+      return fail(ctx, MCGPU_ERR_ARG, "mcgpu_set_variable_dust: pass all seven scattering tables or none");
+    const int na1 = M.nang + 1, ncol = M.p_lambda_fixed ? 1 : nl;
+    auto relay = [&](const float* src, int cols, const float** dst) {
+      std::vector<float> t((size_t)nc * cols * na1);
+      for (int c = 0; c < nc; ++c)
+        for (int l = 0; l < cols; ++l)
+          std::memcpy(&t[((size_t)c * cols + l) * na1], &src[((size_t)l * nc + c) * na1], na1 * sizeof(float));
+      return upload(ctx, t.data(), t.size(), dst);
+    };
+    if ((rc = relay(prob_s11_pos, ncol, &M.v_prob))) return rc;   // (p_lambda_fixed: only the column of p_lambda = 1 is read)
+    if ((rc = relay(tab_s12_o_s11_pos, nl, &M.v_s12))) return rc;
+    if ((rc = relay(tab_s22_o_s11_pos, nl, &M.v_s22))) return rc;
+    if ((rc = relay(tab_s33_o_s11_pos, nl, &M.v_s33))) return rc;
+    if ((rc = relay(tab_s34_o_s11_pos, nl, &M.v_s34))) return rc;
+    if ((rc = relay(tab_s44_o_s11_pos, nl, &M.v_s44))) return rc;
+    std::vector<float> gg((size_t)nc * nl);
+    for (int c = 0; c < nc; ++c)
+      for (int l = 0; l < nl; ++l) gg[(size_t)c * nl + l] = tab_g_pos[(size_t)c + (size_t)nc * l];
+    if ((rc = upload(ctx, gg.data(), gg.size(), &M.v_g))) return rc;
+    M.v_scatt = 1;
+  }
   M.n_classes = nc;
   return MCGPU_OK;
 }

@@ -237,7 +237,7 @@ class Engine:
     def set_variable_dust(self, vd):
         """Per-class tables of ``lvariable_dust`` (``mcfost_amd.host.model.init_variable_dust``); ``None``: one class."""
         if vd is None:
-            self._chk(self.lib.mcgpu_set_variable_dust(self.ctx, C.c_int(0), None, None, None, None, None, None),
+            self._chk(self.lib.mcgpu_set_variable_dust(self.ctx, C.c_int(0), *([None] * 13)),
                       "mcgpu_set_variable_dust")
             return
         d = np.float64
@@ -245,7 +245,10 @@ class Engine:
             self.ctx, C.c_int(int(vd["p_n_cells"])), _p(_a(vd["p_icell"], np.int32), C.c_int),
             _p(_a(vd["kappa"], d), C.c_double), _p(_a(vd["kappa_abs_LTE"], d), C.c_double),
             _p(_a(vd["albedo"], np.float32), C.c_float), _p(_a(vd["log_Qcool"], d), C.c_double),
-            _p(_a(vd["kdB_dT_CDF"], d), C.c_double)), "mcgpu_set_variable_dust")
+            _p(_a(vd["kdB_dT_CDF"], d), C.c_double),
+            *[(_p(_a(vd[k], np.float32), C.c_float) if vd.get("prob_s11_pos") is not None else None)
+              for k in ("prob_s11_pos", "s12_o_s11", "s22_o_s11", "s33_o_s11", "s34_o_s11", "s44_o_s11", "tab_g_pos")]),
+            "mcgpu_set_variable_dust")
 
     def set_mrw(self, mrw):
         """Tables of the modified random walk (``mcfost_amd.host.model.init_mrw``); ``None`` switches it off."""

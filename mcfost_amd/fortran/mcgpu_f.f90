@@ -208,14 +208,18 @@ module mcgpu_f
      end function mcgpu_set_E_prior
 
      ! lvariable_dust: p_icell(:) and the tables with the p_n_cells axis, as the modules hold them (mem.f90:213-244)
+     ! (the seven scattering tables: c_loc of the arrays, or c_null_ptr for all of them)
      integer(c_int) function mcgpu_set_variable_dust(ctx, p_n_cells, p_icell, kappa, kappa_abs_LTE, tab_albedo_pos, &
-          log_Qcool, kdB_dT_CDF) bind(C, name="mcgpu_set_variable_dust")
+          log_Qcool, kdB_dT_CDF, prob_s11_pos, tab_s12_o_s11_pos, tab_s22_o_s11_pos, tab_s33_o_s11_pos, &
+          tab_s34_o_s11_pos, tab_s44_o_s11_pos, tab_g_pos) bind(C, name="mcgpu_set_variable_dust")
        import :: c_int, c_ptr, c_double, c_float
        type(c_ptr), value :: ctx
        integer(c_int), value :: p_n_cells
        integer(c_int), intent(in) :: p_icell(*)
        real(c_double), intent(in) :: kappa(*), kappa_abs_LTE(*), log_Qcool(*), kdB_dT_CDF(*)
        real(c_float), intent(in) :: tab_albedo_pos(*)
+       type(c_ptr), value :: prob_s11_pos, tab_s12_o_s11_pos, tab_s22_o_s11_pos, tab_s33_o_s11_pos, &
+            tab_s34_o_s11_pos, tab_s44_o_s11_pos, tab_g_pos
      end function mcgpu_set_variable_dust
 
      ! xN_abs(:,1) and xJ_abs(:,:) summed over threads (radiation_field.f90:54-55); pass c_null_ptr for either

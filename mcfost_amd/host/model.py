@@ -680,7 +680,8 @@ def init_directions_ray_tracing(cfg: DiskConfig, l3D: bool):
                 N_type_flux=ntf, lsepar_contrib=int(cfg.lsepar_contrib))
 
 
-def init_variable_dust(m: "Model", n_classes: int = 0, slope: float = 0.6, identical: bool = False):
+def init_variable_dust(m: "Model", n_classes: int = 0, slope: float = 0.6, identical: bool = False,
+                       scattering: bool = True):
     """``lvariable_dust`` tables (mem.f90:213-244) for the thermal step, in the reference's layouts: every cell gets
     a class ``p_icell`` and the opacity / re-emission tables gain that axis.  The reference builds them from the
     local grain-size distribution of a settled disk (dust_prop.f90:791-1243, a host table builder); here the classes
@@ -715,6 +716,33 @@ def init_variable_dust(m: "Model", n_classes: int = 0, slope: float = 0.6, ident
             lq[c], cdf[c] = init_reemission(lam, np.asarray(m.delta_lam, f64), m.tab_Temp, ka_c)
     m.variable_dust = dict(p_n_cells=nc, p_icell=p_icell, kappa=kappa.reshape(-1), kappa_abs_LTE=kabs.reshape(-1),
                            albedo=alb.reshape(-1), log_Qcool=lq.reshape(-1), kdB_dT_CDF=cdf.reshape(-1))
+    if scattering:
+        # scattering tables per class, Fortran (0:nang, p_n_cells, n_lambda): bigger grains towards the midplane
+        # scatter more forward (the HG shape with the class's g) and polarise less
+        na1 = NANG_SCATT + 1
+        th = np.arange(na1) * (PI / NANG_SCATT)
+        mu = np.cos(th)
+        dtheta = PI / NANG_SCATT
+        base = {k: np.asarray(getattr(m, k), f32).reshape(nl, na1) for k in
+                ("prob_s11_pos", "s12_o_s11", "s22_o_s11", "s33_o_s11", "s34_o_s11", "s44_o_s11")}
+        out = {k: np.zeros((nl, nc, na1), f32) for k in base}
+        gtab = np.zeros((nl, nc), f32)
+        for c in range(nc):
+            depth = 0.0 if identical else 1.0 - (c + 0.5) / nc
+            g_c = np.clip(np.asarray(m.tab_g_pos, f64) + 0.15 * depth, -0.9, 0.9)
+            gtab[:, c] = np.asarray(m.tab_g_pos, f32) if identical else g_c.astype(f32)
+            for l in range(nl):
+                if identical:
+                    out["prob_s11_pos"][l, c] = base["prob_s11_pos"][l]
+                else:
+                    s11 = (1 - g_c[l] ** 2) / (1 + g_c[l] ** 2 - 2 * g_c[l] * mu) ** 1.5
+                    k_sca = kappa[l, c] * float(alb[l, c])
+                    norm = float(np.sum(s11[1:NANG_SCATT] * np.sin(th[1:NANG_SCATT]) * dtheta))
+                    out["prob_s11_pos"][l, c] = scattering_cdf(s11 * (k_sca / norm) * 0.97, k_sca)
+            for k in ("s12_o_s11", "s22_o_s11", "s33_o_s11", "s34_o_s11", "s44_o_s11"):
+                out[k][:, c, :] = base[k] * (f32(1.0 - 0.3 * depth) if k in ("s12_o_s11", "s34_o_s11") else f32(1.0))
+        m.variable_dust.update({k: v.reshape(-1) for k, v in out.items()})
+        m.variable_dust["tab_g_pos"] = gtab.reshape(-1)
     return m.variable_dust
 
 

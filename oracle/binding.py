@@ -97,7 +97,8 @@ class _Model(C.Structure):
         ("mrw", C.c_int), ("mrw_n_zeta", C.c_int), ("mrw_zeta", _dp), ("mrw_chi", _dp), ("mrw_kappa_dep", _dp),
         ("mrw_ext", _dp), ("mrw_gamma", C.c_float), ("mrw_n_inter", C.c_int),
         ("p_n_cells", C.c_int), ("p_icell", _ip), ("v_kappa", _dp), ("v_kappa_abs_LTE", _dp), ("v_albedo", _fp),
-        ("v_log_Qcool", _dp), ("v_kdB_dT_CDF", _dp), ("r_lim", _dp),
+        ("v_log_Qcool", _dp), ("v_kdB_dT_CDF", _dp), ("v_prob_s11_pos", _fp), ("v_s12_o_s11", _fp), ("v_s22_o_s11", _fp),
+        ("v_s33_o_s11", _fp), ("v_s34_o_s11", _fp), ("v_s44_o_s11", _fp), ("v_tab_g_pos", _fp), ("r_lim", _dp),
     ]
 
 
@@ -239,6 +240,11 @@ class Oracle:
             s.v_albedo = self._hold(_a(vd["albedo"], np.float32), C.c_float)
             s.v_log_Qcool = self._hold(_a(vd["log_Qcool"], np.float64), C.c_double)
             s.v_kdB_dT_CDF = self._hold(_a(vd["kdB_dT_CDF"], np.float64), C.c_double)
+            if vd.get("prob_s11_pos") is not None:
+                for k, f in (("prob_s11_pos", "v_prob_s11_pos"), ("s12_o_s11", "v_s12_o_s11"), ("s22_o_s11", "v_s22_o_s11"),
+                             ("s33_o_s11", "v_s33_o_s11"), ("s34_o_s11", "v_s34_o_s11"), ("s44_o_s11", "v_s44_o_s11"),
+                             ("tab_g_pos", "v_tab_g_pos")):
+                    setattr(s, f, self._hold(_a(vd[k], np.float32), C.c_float))
         mrw = getattr(m, "mrw", None)
         if mrw is not None:
             s.mrw, s.mrw_n_zeta = 1, int(mrw["zeta"].size)

@@ -1817,8 +1817,16 @@ static void propagate_packet(worker_t *W, int *lambda, int p_lambda,
       rand = rng_float(&W->rng);                              /* :1319 */
       float rand2 = rng_float(&W->rng);
       int itheta; double cospsi, u1, v1, w1;
+      /* lvariable_dust with per-class scattering tables: (0:nang, p_n_cells, n_lambda) slices of the cell's class */
+      const int vsc = m->p_n_cells && m->v_prob_s11_pos;
+      const size_t vrow = vsc ? (size_t)(m->p_icell[*icell - 1] - 1) : 0;
       if (m->aniso_method == 1) {
         int pl = (W->mono || m->p_lambda_fixed) ? p_lambda : *lambda;
+        if (vsc) {
+          oracle_model mv = *m; /* the class's column (p_icell, pl) as a one-column table */
+          mv.prob_s11_pos = m->v_prob_s11_pos + ((size_t)(pl - 1) * m->p_n_cells + vrow) * (m->nang_scatt + 1);
+          oracle_angle_diff_theta_pos(&mv, 1, rand, rand2, &itheta, &cospsi);
+        } else
         oracle_angle_diff_theta_pos(m, pl, rand, rand2, &itheta, &cospsi);
         if (m->lisotropic) { itheta = 1; cospsi = 2.0 * (double)rand - 1.0; }
         rand = rng_float(&W->rng);
@@ -1826,11 +1834,18 @@ static void propagate_packet(worker_t *W, int *lambda, int p_lambda,
         oracle_cdapres(cospsi, phi, *u, *v, *w, &u1, &v1, &w1);
         if (m->lsepar_pola) {
           double M[16];
+          if (vsc) {
+            oracle_model mv = *m;
+            const size_t o = ((size_t)(*lambda - 1) * m->p_n_cells + vrow) * (m->nang_scatt + 1);
+            mv.s12_o_s11 = m->v_s12_o_s11 + o; mv.s22_o_s11 = m->v_s22_o_s11 + o; mv.s33_o_s11 = m->v_s33_o_s11 + o;
+            mv.s34_o_s11 = m->v_s34_o_s11 + o; mv.s44_o_s11 = m->v_s44_o_s11 + o;
+            get_mueller_matrix_per_cell(&mv, 1, itheta, rand2, M);
+          } else
           get_mueller_matrix_per_cell(m, *lambda, itheta, rand2, M);
           oracle_update_stokes(Stokes, *u, *v, *w, u1, v1, w1, M);
         }
       } else {
-        oracle_hg(m->tab_g_pos[*lambda - 1], rand, m->nang_scatt, &itheta,
+        oracle_hg(vsc ? m->v_tab_g_pos[vrow + (size_t)m->p_n_cells * (*lambda - 1)] : m->tab_g_pos[*lambda - 1], rand, m->nang_scatt, &itheta,
                   &cospsi);
         if (m->lisotropic) { itheta = 1; cospsi = 2.0 * (double)rand - 1.0; }
         rand = rng_float(&W->rng);

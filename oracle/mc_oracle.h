@@ -183,6 +183,10 @@ typedef struct {
   const float *v_albedo;          /* tab_albedo_pos(p_n_cells, n_lambda) */
   const double *v_log_Qcool;      /* (n_T, p_n_cells) */
   const double *v_kdB_dT_CDF;     /* (n_lambda, n_T, p_n_cells) */
+  /* optional (all or none; v_prob_s11_pos == NULL: the single-class scattering tables above) */
+  const float *v_prob_s11_pos;    /* (0:nang, p_n_cells, n_lambda) */
+  const float *v_s12_o_s11, *v_s22_o_s11, *v_s33_o_s11, *v_s34_o_s11, *v_s44_o_s11; /* likewise */
+  const float *v_tab_g_pos;       /* (p_n_cells, n_lambda) */
   const double *r_lim;         /* [0..n_rad] (cylindrical_grid.f90:22), read by distance_to_closest_wall_cyl */
 } oracle_model;
 

@@ -89,7 +89,7 @@ struct Conv {
   VoroGrid G;
   bool voro;
   std::vector<double> ch, sx, ct, vk, vka;
-  std::vector<float> val;
+  std::vector<float> val, vsc[7];
   std::vector<int> sc, vcls;
   std::vector<VoroCell> vcell;
   std::vector<VoroNb> vnb;
@@ -174,6 +174,24 @@ struct Conv {
         }
       M.cell_class = vcls.data(); M.v_kappa = vk.data(); M.v_kabs = vka.data(); M.v_albedo = val.data();
       M.v_lq = m->v_log_Qcool; M.v_cdf = m->v_kdB_dT_CDF;
+      if (m->v_prob_s11_pos) {
+        const int na1 = m->nang_scatt + 1, ncol = m->p_lambda_fixed ? 1 : nl;
+        auto relay = [&](const float* src, int cols, std::vector<float>& t) {
+          t.resize((size_t)nc * cols * na1);
+          for (int c = 0; c < nc; ++c)
+            for (int l = 0; l < cols; ++l)
+              memcpy(&t[((size_t)c * cols + l) * na1], &src[((size_t)l * nc + c) * na1], na1 * sizeof(float));
+          return t.data();
+        };
+        M.v_prob = relay(m->v_prob_s11_pos, ncol, vsc[0]); M.v_s12 = relay(m->v_s12_o_s11, nl, vsc[1]);
+        M.v_s22 = relay(m->v_s22_o_s11, nl, vsc[2]); M.v_s33 = relay(m->v_s33_o_s11, nl, vsc[3]);
+        M.v_s34 = relay(m->v_s34_o_s11, nl, vsc[4]); M.v_s44 = relay(m->v_s44_o_s11, nl, vsc[5]);
+        vsc[6].resize((size_t)nc * nl);
+        for (int c = 0; c < nc; ++c)
+          for (int l = 0; l < nl; ++l) vsc[6][(size_t)c * nl + l] = m->v_tab_g_pos[c + (size_t)nc * l];
+        M.v_g = vsc[6].data();
+        M.v_scatt = 1;
+      }
     }
   }
 };

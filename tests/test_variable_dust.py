@@ -1,4 +1,4 @@
-"""lvariable_dust (mem.f90:213-244): opacity and re-emission tables with the cell axis p_n_cells.
+"""lvariable_dust (mem.f90:213-244): opacity, re-emission and scattering tables with the cell axis p_n_cells.
 The reference reads them with p_icell in physical_length (optical_depth.f90:100-102), save_radiation_field
 (radiation_field.f90:47-53), the albedo test (dust_transfer.f90:1284), Temp_LTE / im_reemission_LTE
 (thermal_emission.f90:659-771) and Temp_finale.  PARITY: the restatement in the oracle is pinned by the known answer
@@ -41,9 +41,15 @@ def test_classes_change_the_physics_where_they_should():
     assert abs(b["counters"]["absorptions"] / a["counters"]["absorptions"] - 1.0) > 0.02
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(n_rad=12, nz=6, n_az=8, l3D=True)])
+@pytest.mark.parametrize("kw", [dict(), dict(n_rad=12, nz=6, n_az=8, l3D=True), dict(aniso_method=2, lsepar_pola=False),
+                                dict(per_wavelength_angles=True)])
 def test_emulated_kernel_against_the_oracle(emu, kw):   # noqa: F811
-    m = settled(**kw)
+    kw = dict(kw)
+    per_wl = kw.pop("per_wavelength_angles", False)
+    m = M.build_model(M.small(**kw))
+    if per_wl:
+        m.p_lambda_fixed = 0          # the angle CDF of the packet's own wavelength (and class)
+    M.init_variable_dust(m)
     n = 3000
     orc = Oracle(m, n)
     prior = orc.run_thermal(2000, seed=1, n_threads=1)["E_abs"]
