@@ -203,7 +203,7 @@ def bench_sed(args, world, rank, local_rank):
 
 def thermal_block(M, D, Engine, dist, torch, args, config, world, rank, local_rank, steps, warmup, with_cpu):
     """Times `steps` passes of the thermal packet loop on one configuration; returns (block dict or None on ranks > 0)."""
-    cfg = {"ref41": M.ref41, "ref41_mrw": M.ref41, "ref41_3d": M.ref41_3d, "pascucci": M.pascucci, "voronoi": M.ref41}[config]()
+    cfg = {"ref41": M.ref41, "ref41_mrw": M.ref41, "ref41_var": M.ref41, "ref41_3d": M.ref41_3d, "pascucci": M.pascucci, "voronoi": M.ref41}[config]()
     if args.no_pola:
         cfg.lsepar_pola = False
     if args.dust_mass:   # a heavier (optically thicker) disk than the configuration's: where the random walk matters
@@ -214,6 +214,9 @@ def thermal_block(M, D, Engine, dist, torch, args, config, world, rank, local_ra
         model = M.build_voronoi_model(cfg, args.sites, seed=1, cache_dir=os.path.join(ROOT, "tools", "cache"))
     else:
         model = M.build_model(cfg)
+    if config == "ref41_var":   # every layer of the disk its own dust (lvariable_dust), HBM-gather kernel
+        cfg.name += " with variable dust (%d classes%s)" % (cfg.nz, ", all equal to the model's dust" if args.var_identical else "")
+        M.init_variable_dust(model, identical=args.var_identical)
     if config == "ref41_mrw":   # BASELINE config 4: ref4.1 with the modified random walk (gamma_MRW = 2, MRW.f90:11)
         cfg.name += " + MRW (gamma %g)" % args.mrw_gamma
         M.init_mrw(model, gamma=args.mrw_gamma)
@@ -269,7 +272,7 @@ def thermal_block(M, D, Engine, dist, torch, args, config, world, rank, local_ra
         pmc = pmc_summary(config, n_local, world)
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": pmc.get("hbm_bytes"),
-                "kernel": "k_thermal_voro_cache" if config == "voronoi" else "k_thermal_roles", "kernel_ms": k_ms,
+                "kernel": {"voronoi": "k_thermal_voro_cache", "ref41_var": "k_thermal_var"}.get(config, "k_thermal_roles"), "kernel_ms": k_ms,
                 "algorithmic_bytes_per_launch": bytes_launch,
                 # what `achieved` is: SURVEY 8(d)'s per-crossing byte model x the kernel's own event counts / kernel time.
                 # The 2D working set (absorbed-energy grid, tables, packet records) lives in LDS and L2, so the model
@@ -310,7 +313,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--packets", type=float, default=1e8, help="packets per GPU per step")
-    ap.add_argument("--config", default="pascucci", choices=["pascucci", "ref41", "ref41_mrw", "ref41_3d", "voronoi", "sed"],
+    ap.add_argument("--config", default="pascucci", choices=["pascucci", "ref41", "ref41_mrw", "ref41_var", "ref41_3d", "voronoi", "sed"],
                     help="pascucci (default): the disk BASELINE.json's metric is quoted on, with ref4.1 (configs[1]) as a "
                          "second full block of the same line")
     ap.add_argument("--sed-lambdas", default="5,15,25,35",
@@ -320,6 +323,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sed-observers", type=int, default=0, help="--config sed: RT_n_incl (default: the configuration's)")
     ap.add_argument("--xI-precision", type=int, default=8, choices=[4, 8], help="--config sed: mcgpu_set_xI_precision")
+    ap.add_argument("--var-identical", action="store_true", help="--config ref41_var: every class gets the model's own tables "
+                    "(the physics of --config ref41 through the HBM-gather kernel)")
     ap.add_argument("--mrw-gamma", type=float, default=2.0, help="--config ref41_mrw: gamma_MRW")
     ap.add_argument("--dust-mass", type=float, default=0.0, help="override the disk's dust mass [Msun] (thermal configs)")
     ap.add_argument("--no-ref41", action="store_true", help="--config pascucci: skip the ref4.1 block")

@@ -1801,11 +1801,12 @@ __global__ void __launch_bounds__(256) k_thermal(const DevModel M, const RunArgs
   thermal_body<L3D, POLA, DARK, false, false, MRW>(M, A, lds_raw);
 }
 
-// lvariable_dust: per-class opacity / re-emission tables gathered from HBM (HBM deposits; any cylindrical grid)
-template <bool L3D, bool POLA, bool DARK>
-__global__ void __launch_bounds__(256) k_thermal_var(const DevModel M, const RunArgs A) {
+// lvariable_dust: per-class opacity / re-emission / scattering tables gathered from HBM (any cylindrical grid; LDSE: the
+// workgroup's private absorbed-energy grid in LDS like k_thermal_lds, otherwise HBM deposits like k_thermal)
+template <bool L3D, bool POLA, bool DARK, bool LDSE>
+__global__ void __launch_bounds__(LDSE ? MCGPU_LDS_BLOCK : 256) k_thermal_var(const DevModel M, const RunArgs A) {
   extern __shared__ double lds_raw[];
-  thermal_body<L3D, POLA, DARK, false, false, false, true>(M, A, lds_raw);
+  thermal_body<L3D, POLA, DARK, LDSE, false, false, true>(M, A, lds_raw);
 }
 
 // the spherical grid (spherical_grid.f90): the same packet loop with that grid's operators; no dark zone

@@ -717,23 +717,14 @@ static int launch_mega(mcgpu_ctx* ctx, const RunArgs& A, bool use_lds, int grid_
   if (M.n_classes) {  // lvariable_dust: the HBM-gather variant of the single-role kernel
     if (M.mrw) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "variable dust and the modified random walk do not combine");
     const void* fn;
-#define PICKV(a) fn = pola ? (dark ? (const void*)k_thermal_var<a, true, true> : (const void*)k_thermal_var<a, true, false>) \
-                           : (dark ? (const void*)k_thermal_var<a, false, true> : (const void*)k_thermal_var<a, false, false>)
-    if (l3d) PICKV(true); else PICKV(false);
+#define PICKV(a, l) fn = pola ? (dark ? (const void*)k_thermal_var<a, true, true, l> : (const void*)k_thermal_var<a, true, false, l>) \
+                              : (dark ? (const void*)k_thermal_var<a, false, true, l> : (const void*)k_thermal_var<a, false, false, l>)
+    if (l3d) { if (use_lds) PICKV(true, true); else PICKV(true, false); }
+    else { if (use_lds) PICKV(false, true); else PICKV(false, false); }
 #undef PICKV
-    const int vthreads = (block_threads > 0 && block_threads <= 256) ? block_threads : 256;
-    int vblocks = grid_blocks;
-    if (vblocks <= 0) {
-      int occ = 1;
-      HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, vthreads, lds));
-      vblocks = ctx->prop.multiProcessorCount * (occ < 1 ? 1 : occ);
-      const unsigned long long need = (A.n_packets + vthreads - 1) / vthreads;
-      if ((unsigned long long)vblocks > need) vblocks = (int)(need ? need : 1);
-    }
-    HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k));
     void* args[] = {(void*)&M, (void*)&A};
-    HIPCHK(hipLaunchKernel(fn, dim3(vblocks), dim3(vthreads), args, lds, ctx->stream));
+    HIPCHK(hipLaunchKernel(fn, dim3(blocks), dim3(threads), args, lds_k, ctx->stream));
     return MCGPU_OK;
   }
   if (M.grid_sph) {  // the spherical grid runs the single-role kernel with its own grid operators

@@ -680,7 +680,7 @@ def init_directions_ray_tracing(cfg: DiskConfig, l3D: bool):
                 N_type_flux=ntf, lsepar_contrib=int(cfg.lsepar_contrib))
 
 
-def init_variable_dust(m: "Model", n_classes: int = 0, slope: float = 0.6, identical: bool = False,
+def init_variable_dust(m: "Model", n_classes: int = 0, slope: float = 0.15, identical: bool = False,
                        scattering: bool = True):
     """``lvariable_dust`` tables (mem.f90:213-244) for the thermal step, in the reference's layouts: every cell gets
     a class ``p_icell`` and the opacity / re-emission tables gain that axis.  The reference builds them from the
@@ -706,7 +706,7 @@ def init_variable_dust(m: "Model", n_classes: int = 0, slope: float = 0.6, ident
             k_c, a_c = np.asarray(m.kappa, f64), np.asarray(m.albedo, f32)
         else:
             depth = 1.0 - (c + 0.5) / nc       # 1 at the midplane class, 0 at the surface class
-            k_c = np.asarray(m.kappa, f64) * (lam / 1.0) ** (slope * depth)
+            k_c = np.asarray(m.kappa, f64) * (lam / 10.0) ** (slope * depth)
             a_c = np.clip(np.asarray(m.albedo, f64) * (1.0 + 0.3 * depth), 0.0, 0.95).astype(f32)
         ka_c = np.asarray(m.kappa_abs_LTE, f64) if identical else k_c * (1.0 - a_c.astype(f64))
         kappa[:, c], kabs[:, c], alb[:, c] = k_c, ka_c, a_c

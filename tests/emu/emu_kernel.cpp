@@ -250,11 +250,13 @@ extern "C" int emu_run_thermal(const oracle_model* m, const oracle_opts* o, cons
     for (int q = 0; q < ORACLE_N_COUNTERS; ++q) counters[q] = cnt[q];
     return err;
   }
-  if (M.n_classes) {  // lvariable_dust: the HBM-gather variant
-    if (l3d) { if (pola) { if (dark) k_thermal_var<true, true, true>(M, A); else k_thermal_var<true, true, false>(M, A); }
-               else { if (dark) k_thermal_var<true, false, true>(M, A); else k_thermal_var<true, false, false>(M, A); } }
-    else { if (pola) { if (dark) k_thermal_var<false, true, true>(M, A); else k_thermal_var<false, true, false>(M, A); }
-           else { if (dark) k_thermal_var<false, false, true>(M, A); else k_thermal_var<false, false, false>(M, A); } }
+  if (M.n_classes) {  // lvariable_dust: the HBM-gather variant (MCGPU_EMU_LDS: with the private grid in LDS)
+#define RUNV(a, b, c) do { if (getenv("MCGPU_EMU_LDS")) k_thermal_var<a, b, c, true>(M, A); else k_thermal_var<a, b, c, false>(M, A); } while (0)
+    if (l3d) { if (pola) { if (dark) RUNV(true, true, true); else RUNV(true, true, false); }
+               else { if (dark) RUNV(true, false, true); else RUNV(true, false, false); } }
+    else { if (pola) { if (dark) RUNV(false, true, true); else RUNV(false, true, false); }
+           else { if (dark) RUNV(false, false, true); else RUNV(false, false, false); } }
+#undef RUNV
     for (int q = 0; q < ORACLE_N_COUNTERS; ++q) counters[q] = cnt[q];
     return err;
   }

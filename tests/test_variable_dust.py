@@ -54,10 +54,17 @@ def test_emulated_kernel_against_the_oracle(emu, kw):   # noqa: F811
     orc = Oracle(m, n)
     prior = orc.run_thermal(2000, seed=1, n_threads=1)["E_abs"]
     want = orc.run_thermal(n, seed=7, frozen=True, E_prior=prior, n_threads=4)
-    got = emu_run(emu, orc, n, 7, prior=prior)
-    assert got["counters"] == list(want["counters"].values())
-    assert np.array_equal(got["n_sent"], want["n_sent"]) and np.array_equal(got["sed"][4], want["sed"][4])
-    assert np.allclose(got["E_abs"], want["E_abs"], rtol=1e-7, atol=1e-12 * want["E_abs"].max())   # (FMA-level: grazing segments)
+    import os
+    for lds in (False, True):     # HBM deposits / the private grid in LDS
+        if lds:
+            os.environ["MCGPU_EMU_LDS"] = "1"
+        try:
+            got = emu_run(emu, orc, n, 7, prior=prior)
+        finally:
+            os.environ.pop("MCGPU_EMU_LDS", None)
+        assert got["counters"] == list(want["counters"].values())
+        assert np.array_equal(got["n_sent"], want["n_sent"]) and np.array_equal(got["sed"][4], want["sed"][4])
+        assert np.allclose(got["E_abs"], want["E_abs"], rtol=1e-7, atol=1e-12 * want["E_abs"].max())   # (FMA-level: grazing segments)
 
 
 @pytest.mark.gpu
