@@ -209,7 +209,7 @@ __device__ inline void voro_cross_cell(const VoroGrid& G, const DevModel& M, con
   s_out = s;
 }
 
-// move_to_grid_Voronoi (Voronoi.f90:1379-1442) + find_Voronoi_cell_brute_force (:1485)
+// move_to_grid_Voronoi (Voronoi.f90:1379-1442) + find_Voronoi_cell (:1625; the kd-tree's answer by direct search)
 __device__ inline bool voro_move_to_grid(const VoroGrid& G, double& x, double& y, double& z, double u,
                                          double v, double w, int& icell) {
   double s_walls[6];
@@ -234,11 +234,14 @@ __device__ inline bool voro_move_to_grid(const VoroGrid& G, double& x, double& y
   }
   if (!found) { icell = 0; return false; }
   x = xt; y = yt; z = zt;
-  float dmin = FLT_HUGE;
+  // find_Voronoi_cell (:1625-1645): kdtree2_n_nearest, i.e. the nearest site of the wall's list in kdkind = dp
+  double dmin = HUGE_DP;
   int imin = 0;
   for (int q = G.wall_first[iwall - 1]; q < G.wall_first[iwall]; ++q) {
     const int ic = G.wall_cells[q];
-    const float d2 = voro_dist2f(G.xyz_dp + 3 * (size_t)(ic - 1), xt, yt, zt);
+    const double* c = G.xyz_dp + 3 * (size_t)(ic - 1);
+    const double dx = c[0] - xt, dy = c[1] - yt, dz = c[2] - zt;
+    const double d2 = nd_add(nd_add(nd_mul(dx, dx), nd_mul(dy, dy)), nd_mul(dz, dz));
     if (d2 < dmin) { imin = ic; dmin = d2; }
   }
   icell = imin;

@@ -253,6 +253,10 @@ class Oracle:
             s.mrw_gamma, s.mrw_n_inter = float(mrw["gamma"]), int(mrw["n_inter"])
         return s
 
+    def find_voronoi_cell(self, iwall, x, y, z):
+        return np.array([self.lib.oracle_find_voronoi_cell(C.byref(self.cm), C.c_int(int(iwall)), C.c_double(a), C.c_double(b),
+                                                           C.c_double(c)) for a, b, c in zip(x, y, z)], np.int32)
+
     def distance_to_closest_wall(self, icell, x, y, z):
         self.lib.oracle_distance_to_closest_wall_cyl.restype = C.c_double
         return np.array([self.lib.oracle_distance_to_closest_wall_cyl(C.byref(self.cm), C.c_int(int(c)), C.c_double(a),
@@ -682,6 +686,14 @@ class RefGeom:
         getattr(self.lib, "ref_pos_em_cell" + self._sfx)(C.c_int(n), _p(ic, C.c_int), *[_p(q, C.c_float) for q in r],
                                  _p(x, C.c_double), _p(y, C.c_double), _p(z, C.c_double))
         return x, y, z
+
+    def kdtree_nearest(self, sites, queries):
+        """1-based index of the site nearest to every query, by the reference's kdtree2 (find_Voronoi_cell)."""
+        s, q = _a(sites, np.float64), _a(queries, np.float64)
+        idx = np.zeros(q.shape[0], np.int32)
+        self.lib.ref_kdtree_nearest(C.c_int(s.shape[0]), _p(s, C.c_double), C.c_int(q.shape[0]), _p(q, C.c_double),
+                                    _p(idx, C.c_int))
+        return idx
 
     def distance_to_closest_wall(self, icell, x, y, z):
         n = len(icell)

@@ -723,6 +723,22 @@ void oracle_cross_voronoi_cell(const oracle_model *m, double x, double y,
 }
 
 /* move_to_grid_Voronoi (Voronoi.f90:1379-1442) with find_Voronoi_cell_brute_force (:1485) */
+/* find_Voronoi_cell (Voronoi.f90:1625-1645): the site of wall iwall's neighbour list closest to the point, by
+ * kdtree2_n_nearest with NN = 1 -- a nearest-neighbour search in kdkind = dp (kdtree2.f90:23), whose answer is the
+ * minimum of the dp squared distances summed over the coordinates in order (kdtree2.f90 process_terminal_node).
+ * PINNED to the reference's kdtree2 module compiled in oracle/_ref (tests/golden/kdtree_nearest.npz). */
+int oracle_find_voronoi_cell(const oracle_model *m, int iwall, double x, double y, double z) {
+  double dist2_min = 1.79769313486231570815e+308;
+  int icell_min = 0;
+  for (int q = m->v_wall_first[iwall - 1]; q < m->v_wall_first[iwall]; ++q) {
+    const int ic = m->v_wall_cells[q];
+    const double *c = m->v_xyz_dp + 3 * (size_t)(ic - 1);
+    const double dist2 = (c[0] - x) * (c[0] - x) + (c[1] - y) * (c[1] - y) + (c[2] - z) * (c[2] - z);
+    if (dist2 < dist2_min) { icell_min = ic; dist2_min = dist2; }
+  }
+  return icell_min;
+}
+
 void oracle_move_to_grid_voronoi(const oracle_model *m, double *x, double *y,
                                  double *z, double u, double v, double w,
                                  int *icell, int *lintersect) {
@@ -749,15 +765,7 @@ void oracle_move_to_grid_voronoi(const oracle_model *m, double *x, double *y,
   }
   *lintersect = 1;
   *x = xt; *y = yt; *z = zt;
-  float dist2_min = FLT_MAX;
-  int icell_min = 0;
-  for (int q = m->v_wall_first[iwall - 1]; q < m->v_wall_first[iwall]; ++q) {
-    const int ic = m->v_wall_cells[q];
-    const double *c = m->v_xyz_dp + 3 * (size_t)(ic - 1);
-    float dist2 = (float)((c[0] - xt) * (c[0] - xt) + (c[1] - yt) * (c[1] - yt) + (c[2] - zt) * (c[2] - zt));
-    if (dist2 < dist2_min) { icell_min = ic; dist2_min = dist2; }
-  }
-  *icell = icell_min;
+  *icell = oracle_find_voronoi_cell(m, iwall, xt, yt, zt);
 }
 
 /* ------------------------------------------------------------------------ */

@@ -337,6 +337,7 @@ int oracle_temp_approx_diffusion_vertical(const oracle_model *m, const double *t
                                           float *Tdust, int *n_iter);
 
 /* Voronoi grid operators (Voronoi.f90). */
+int oracle_find_voronoi_cell(const oracle_model *m, int iwall, double x, double y, double z);
 void oracle_cross_voronoi_cell(const oracle_model *m, double x, double y,
                                double z, double u, double v, double w,
                                int icell, int previous_cell, double *x1,

@@ -21,6 +21,8 @@ module ref_geom_driver
   use cylindrical_grid
   use spherical_grid
   use temperature, only : tab_Temp, init_tab_Temp
+  use kdtree2_module, only : kdtree2, kdtree2_result, wall_kdtree2_create, kdtree2_n_nearest, allocate_kdtree2_search, &
+       deallocate_kdtree2_search, kdkind
   use wavelengths, only : lmono0, lambda_min, lambda_max, n_lambda, tab_lambda, tab_lambda_inf, &
        tab_lambda_sup, tab_delta_lambda, init_lambda
   implicit none
@@ -275,6 +277,29 @@ contains
        d(i) = distance_to_closest_wall_cyl(icell(i), x(i), y(i), z(i))
     enddo
   end subroutine ref_distance_to_closest_wall
+
+  ! find_Voronoi_cell (Voronoi.f90:1625-1645) on one wall's sites: the tree of build_wall_kdtrees (:1593-1621,
+  ! wall_kdtree2_create with rearrange = sort = .false.) and kdtree2_n_nearest with NN = 1.  idx is 1-based into sites.
+  subroutine ref_kdtree_nearest(n, sites, nq, q, idx) bind(C, name="ref_kdtree_nearest")
+    integer(c_int), value :: n, nq
+    real(c_double), intent(in) :: sites(3, n), q(3, nq)
+    integer(c_int), intent(out) :: idx(nq)
+    real(kdkind), allocatable, target :: wall_cells(:,:,:)
+    real(kdkind), target :: qv(3)
+    type(kdtree2), pointer :: tree
+    type(kdtree2_result) :: results(1)
+    integer :: i
+    allocate(wall_cells(3, n, 1))
+    wall_cells(:,:,1) = sites
+    call deallocate_kdtree2_search()
+    call allocate_kdtree2_search(1)
+    tree => wall_kdtree2_create(wall_cells, 1, n_points=n, rearrange=.false., sort=.false.)
+    do i = 1, nq
+       qv = q(:, i)
+       call kdtree2_n_nearest(1, tree, qv, 1, results)
+       idx(i) = results(1)%idx
+    enddo
+  end subroutine ref_kdtree_nearest
 
   ! init_tab_Temp, Temperature.f90:23
   subroutine ref_init_tab_temp(c_n_T, c_T_min, c_T_max, o_tab_Temp) bind(C, name="ref_init_tab_temp")

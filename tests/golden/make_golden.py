@@ -125,8 +125,34 @@ def make_dist(name, expr, n=600, seed=11):
     print(name, "distances", d.min(), d.max())
 
 
+def make_kdtree(seed=13):
+    """kdtree_nearest.npz: find_Voronoi_cell (Voronoi.f90:1625) = kdtree2_n_nearest(NN = 1) over the sites next to
+    each wall of a Voronoi model, for points on that wall (where move_to_grid_Voronoi asks) and random points."""
+    from mcfost_amd.host import model as M
+    from oracle import RefGeom
+
+    m = M.build_voronoi_model(M.small(), 1500, seed=3)
+    g = m.grid
+    ref = RefGeom()
+    rng = np.random.default_rng(seed)
+    lim = np.asarray(g["limits"], float)
+    out = dict(model="M.build_voronoi_model(M.small(), 1500, seed=3)", v_wall_first=g["v_wall_first"], v_wall_cells=g["v_wall_cells"])
+    for iwall in range(1, 7):
+        cells = np.asarray(g["v_wall_cells"][g["v_wall_first"][iwall - 1]:g["v_wall_first"][iwall]])
+        sites = np.asarray(g["v_xyz_dp"]).reshape(-1, 3)[cells - 1]
+        nq = 1500
+        q = np.stack([rng.uniform(lim[0], lim[1], nq), rng.uniform(lim[2], lim[3], nq), rng.uniform(lim[4], lim[5], nq)], 1)
+        q[:1000, (iwall - 1) // 2] = lim[iwall - 1]          # on the wall's plane
+        idx = ref.kdtree_nearest(sites, q)
+        out[f"q{iwall}"], out[f"cell{iwall}"] = q, cells[idx - 1].astype(np.int32)
+    np.savez_compressed(os.path.join(HERE, "kdtree_nearest.npz"), **out)
+    print("kdtree: walls", [int(out[f"cell{i}"].size) for i in range(1, 7)])
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 2 and sys.argv[1] == "dist":
+    if len(sys.argv) > 1 and sys.argv[1] == "kdtree":
+        make_kdtree()
+    elif len(sys.argv) > 2 and sys.argv[1] == "dist":
         make_dist(sys.argv[2], CONFIGS[sys.argv[2]])
     elif len(sys.argv) > 1:
         make_one(sys.argv[1], CONFIGS[sys.argv[1]])
@@ -135,3 +161,4 @@ if __name__ == "__main__":
             subprocess.check_call([sys.executable, __file__, name])
         for name in DIST_CONFIGS:
             subprocess.check_call([sys.executable, __file__, "dist", name])
+        subprocess.check_call([sys.executable, __file__, "kdtree"])

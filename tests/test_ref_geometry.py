@@ -161,3 +161,21 @@ def test_live_reference_library_if_built(case):
                            os.path.dirname(os.path.abspath(__file__)), name, name)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr
+
+
+def test_find_voronoi_cell_against_the_reference_kdtree():
+    """find_Voronoi_cell (Voronoi.f90:1625-1645) is kdtree2_n_nearest with NN = 1 over the sites next to a wall; the
+    golden file holds the answers of the reference's own kdtree2 module (oracle/_ref) for points on every wall of a
+    Voronoi model and for random points: the oracle's direct dp search gives the same cell every time."""
+    import os
+    from helpers import GOLDEN
+    from mcfost_amd.host import model as M
+    from oracle import Oracle
+    g = np.load(os.path.join(GOLDEN, "kdtree_nearest.npz"))
+    m = M.build_voronoi_model(M.small(), 1500, seed=3)
+    assert np.array_equal(m.grid["v_wall_first"], g["v_wall_first"]) and np.array_equal(m.grid["v_wall_cells"], g["v_wall_cells"])
+    o = Oracle(m, 1000)
+    for iwall in range(1, 7):
+        q = g[f"q{iwall}"]
+        got = o.find_voronoi_cell(iwall, q[:, 0], q[:, 1], q[:, 2])
+        assert np.array_equal(got, g[f"cell{iwall}"]), iwall
