@@ -369,7 +369,7 @@ int mcgpu_device_xI(mcgpu_ctx *ctx, void **xI_dev, uint64_t *n_values);
  * (optical_depth.f90:1327-1421) -- for every observer direction of
  * mcgpu_set_rt1, from the xI_scatt the last mcgpu_run_mono(rt1=1) of this
  * wavelength left on the device (after the all-reduce on several GPUs).
- * The stellar term (compute_stars_map, :1603-1895) stays with the host.
+ * The stellar term (compute_stars_map, :1603-1895): mcgpu_rt1_stars_map_sed below.
  * Cylindrical grids.
  * ------------------------------------------------------------------------ */
 typedef struct {
@@ -406,6 +406,17 @@ int mcgpu_rt1_image(mcgpu_ctx *ctx, const mcgpu_rt_opts *opts,
                     const float *tab_RT_az, const float *Tdust, int npix_x,
                     int npix_y, double map_size, double zoom, double *image,
                     uint64_t *n_rays, double *kernel_ms);
+
+/* The stars' term of the ray-traced SED: compute_stars_map (dust_transfer.f90:1604-1854) with lresolved = .false.
+ * and no limb darkening, i.e. stars_map(1,1,1) for every observer -- per star a 21 x 21 screen of optical depths
+ * towards the observer (optical_length_tot, optical_depth.f90:248) and n_ray_star_SED / n_stars = 1024 / n_stars
+ * random points of the stellar sphere with the screen's interpolated optical depth.
+ *   star_flux[n_stars]   factor * prob_E_star(lambda, istar) of :1657-1659 and :1819 (the host's numbers)
+ *   stars_flux[RT_n_incl * RT_n_az]   = sum over stars of star_flux * sum(exp(-tau) cos_thet) / sum(cos_thet)
+ * Of opts only lambda and ang_disque are read.  The reference draws the points from SPRNG; here ray k of (observer q,
+ * star s) is Philox block (k, 2, q * n_stars + s) of `seed`.  Cylindrical grids. */
+int mcgpu_rt1_stars_map_sed(mcgpu_ctx *ctx, const mcgpu_rt_opts *opts, const float *tab_RT_az,
+                            uint64_t seed, const double *star_flux, double *stars_flux);
 
 /* Temp_finale (thermal_emission.f90:870-906): Tdust(icell) from the summed
  * absorbed-energy grid.  E_abs == NULL uses the device accumulator. */

@@ -254,4 +254,100 @@ __global__ void __launch_bounds__(256) k_rt1_image(const DevModel M, const RtArg
   }
 }
 
+// ---------------------------------------------------------------------------
+// compute_stars_map for the SED (dust_transfer.f90:1604-1854 with lresolved = .false., no limb darkening): the
+// stars' flux towards every observer.  Per (observer, star): a 21 x 21 screen of optical depths in front of the star
+// (optical_length_tot from points of the star's disc towards the observer), then n_ray_star_SED / n_stars random
+// points of the stellar sphere, each with the screen's bilinearly interpolated optical depth; the flux is
+// star_flux * sum(exp(-tau) cos_thet) / sum(cos_thet).  One workgroup per (observer, star).  The reference draws
+// the points from SPRNG; here ray k of (observer q, star s) uses Philox block (k, 2, q * n_stars + s) of the seed.
+// ---------------------------------------------------------------------------
+// optical_length_tot (optical_depth.f90:248-324): optical depth from (x,y,z) to the edge of the grid along (u,v,w)
+template <bool L3D>
+__device__ inline float optical_length_tot(const Lds& T, const DevModel& M, int lambda, double x, double y, double z,
+                                           double u, double v, double w) {
+  const int n_rad = M.n_rad, nz = M.nz;
+  int ri, zj, k;
+  index_cell<L3D>(T, M, x, y, z, ri, zj, k);
+  const double a = u * u + v * v;
+  const double inv_a = (a > TINY_REAL) ? 1.0 / a : HUGE_REAL;
+  const double inv_w = (fabs(w) > TINY_REAL) ? 1.0 / w : copysign(HUGE_DP, w);
+  double tau = 0.0;
+  for (long guard = 0; guard < 100000000L; ++guard) {
+    const int azj = zj < 0 ? -zj : zj;
+    if ((ri == n_rad + 1) || ((azj == nz + 1) && (fabs(z) > M.zmaxmax))) break;  // test_exit_grid
+    double x1, y1, z1, l;
+    int ri1, zj1, k1;
+    MCGPU_CROSS<L3D>(T, M, x, y, z, u, v, w, inv_a, inv_w, ri, zj, k, x1, y1, z1, ri1, zj1, k1, l);
+    if (is_real_cell<L3D>(n_rad, nz, ri, zj))
+      tau += l * (T.kappa[lambda - 1] * M.kappa_factor[cell_index<L3D>(n_rad, nz, ri, zj, k)]);
+    x = x1; y = y1; z = z1;
+    ri = ri1; zj = zj1; k = k1;
+  }
+  return (float)tau;  // tau_tot_out is a default real
+}
+
+constexpr int STARS_NX_SCREEN = 10, STARS_N_RAY_SED = 1024;  // dust_transfer.f90:1615,1627
+
+template <bool L3D>
+__global__ void __launch_bounds__(512) k_stars_map_sed(const DevModel M, const RtArgs A, unsigned int key0, unsigned int key1,
+                                                       const double* star_flux, double* out) {
+  extern __shared__ double lds_raw[];
+  const Lds T = lds_carve(lds_raw, M, true);  // geometry, kappa, albedo: the SED-mode table set
+  lds_stage_mono(T, M, 1);
+  __shared__ float tau_screen[(2 * STARS_NX_SCREEN + 1) * (2 * STARS_NX_SCREEN + 1)];
+  __shared__ double red_a[512], red_b[512];
+  __syncthreads();
+  const int q = blockIdx.x / M.n_stars, istar = blockIdx.x % M.n_stars;
+  const int tid = threadIdx.x, nt = blockDim.x, ns = 2 * STARS_NX_SCREEN + 1;
+  double uvw[3], xpi[3], ypi[3];
+  rt_image_plane(A, q, uvw, xpi, ypi);
+  const double* s4 = &M.star_xyzr[4 * istar];
+  const double delta = s4[3] / (double)STARS_NX_SCREEN;
+  const double nx = sqrt(xpi[0] * xpi[0] + xpi[1] * xpi[1] + xpi[2] * xpi[2]);
+  const double ny = sqrt(ypi[0] * ypi[0] + ypi[1] * ypi[1] + ypi[2] * ypi[2]);
+  const double dxs[3] = {delta * xpi[0] / nx, delta * xpi[1] / nx, delta * xpi[2] / nx};
+  const double dys[3] = {delta * ypi[0] / ny, delta * ypi[1] / ny, delta * ypi[2] / ny};
+  for (int p = tid; p < ns * ns; p += nt) {
+    const int i = p % ns - STARS_NX_SCREEN, j = p / ns - STARS_NX_SCREEN;
+    const double x = s4[0] + dxs[0] * i + dys[0] * j, y = s4[1] + dxs[1] * i + dys[1] * j, z = s4[2] + dxs[2] * i + dys[2] * j;
+    tau_screen[p] = optical_length_tot<L3D>(T, M, A.lambda, x, y, z, uvw[0], uvw[1], uvw[2]);
+  }
+  __syncthreads();
+  const int n_ray = STARS_N_RAY_SED / M.n_stars > 1 ? STARS_N_RAY_SED / M.n_stars : 1;
+  const double norm_screen2 = 1.0 / (delta * delta);
+  double sum_f = 0.0, sum_n = 0.0;
+  for (int iray = tid; iray < n_ray; iray += nt) {
+    uint32_t o[4];
+    philox4x32_10((uint32_t)iray, 2u, (uint32_t)blockIdx.x, 0u, key0, key1, o);
+    const float rand = Rng::real(o[0]), rand2 = Rng::real(o[1]);
+    const double z = 2.0 * (double)rand - 1.0;
+    const double srw02 = sqrt(1.0 - z * z), argmt = PI * (2.0 * (double)rand2 - 1.0);
+    double sa, ca;
+    sincos(argmt, &sa, &ca);
+    const double x = srw02 * ca, y = srw02 * sa;
+    const float cos_thet = (float)fabs(x * uvw[0] + y * uvw[1] + z * uvw[2]);
+    const double vec[3] = {x * s4[3], y * s4[3], z * s4[3]};
+    const double offset_x = (vec[0] * dxs[0] + vec[1] * dxs[1] + vec[2] * dxs[2]) * norm_screen2;
+    const double offset_y = (vec[0] * dys[0] + vec[1] * dys[1] + vec[2] * dys[2]) * norm_screen2;
+    const int i = (int)floor(offset_x), j = (int)floor(offset_y);
+    const double fx = offset_x - i, fy = offset_y - j;
+    float tau = 0.0f;
+    if (i >= -STARS_NX_SCREEN && i < STARS_NX_SCREEN && j >= -STARS_NX_SCREEN && j < STARS_NX_SCREEN) {
+      const int p = (i + STARS_NX_SCREEN) + ns * (j + STARS_NX_SCREEN);
+      tau = (float)((double)tau_screen[p] * (1 - fx) * (1 - fy) + (double)tau_screen[p + 1] * fx * (1 - fy) +
+                    (double)tau_screen[p + ns] * (1 - fx) * fy + (double)tau_screen[p + ns + 1] * fx * fy);
+    }
+    sum_f += (double)(expf(-tau) * cos_thet);  // exp(-tau) * cos_thet * LimbDarkening in default real
+    sum_n += (double)cos_thet;
+  }
+  red_a[tid] = sum_f; red_b[tid] = sum_n;
+  __syncthreads();
+  for (int sft = nt >> 1; sft > 0; sft >>= 1) {
+    if (tid < sft) { red_a[tid] += red_a[tid + sft]; red_b[tid] += red_b[tid + sft]; }
+    __syncthreads();
+  }
+  if (tid == 0) atomic_add_f64(&out[q], star_flux[istar] * red_a[0] / red_b[0]);
+}
+
 }  // namespace mcgpu

@@ -1616,6 +1616,42 @@ extern "C" int mcgpu_rt1_dust_map(mcgpu_ctx* ctx, const mcgpu_rt_opts* o, const 
   return MCGPU_OK;
 }
 
+// compute_stars_map for the SED (dust_transfer.f90:1604-1854): see include/mcgpu.h
+extern "C" int mcgpu_rt1_stars_map_sed(mcgpu_ctx* ctx, const mcgpu_rt_opts* o, const float* tab_RT_az, uint64_t seed,
+                                       const double* star_flux, double* stars_flux) {
+  int rc = ready(ctx);
+  if (rc) return rc;
+  if (!o || !tab_RT_az || !star_flux || !stars_flux) return fail(ctx, MCGPU_ERR_ARG, "mcgpu_rt1_stars_map_sed: null argument");
+  const DevModel& M = ctx->M;
+  if (ctx->voro || M.grid_sph || M.n_classes) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "stars map: cylindrical grids, one dust class");
+  if (!ctx->have_rt1) return fail(ctx, MCGPU_ERR_STATE, "stars map: set the observers first (mcgpu_set_rt1)");
+  if (o->lambda < 1 || o->lambda > M.n_lambda) return fail(ctx, MCGPU_ERR_ARG, "mcgpu_rt1_stars_map_sed: bad option");
+  HIPCHK(hipSetDevice(ctx->device));
+  const int nRT = ctx->RT_n_incl * ctx->RT_n_az;
+  DevBuf<float> d_az;
+  DevBuf<double> d_flux, d_out;
+  HIPCHK(d_az.alloc(ctx->RT_n_az)); HIPCHK(d_az.put(tab_RT_az, ctx->RT_n_az));
+  HIPCHK(d_flux.alloc(M.n_stars)); HIPCHK(d_flux.put(star_flux, M.n_stars));
+  HIPCHK(d_out.alloc(nRT)); HIPCHK(hipMemsetAsync(d_out.p, 0, nRT * sizeof(double), ctx->stream));
+  RtArgs A;
+  std::memset(&A, 0, sizeof(A));
+  A.lambda = o->lambda; A.RT_n_incl = ctx->RT_n_incl; A.nRT = nRT; A.ang_disque = o->ang_disque;
+  A.rt_u = ctx->d_rt_u; A.rt_v = ctx->d_rt_v; A.rt_w = ctx->d_rt_w; A.rt_az = d_az.p;
+  const size_t lds = lds_bytes(M, true);
+  const unsigned int k0 = (unsigned int)seed, k1 = (unsigned int)(seed >> 32);
+  if (M.l3D) {
+    HIPCHK(hipFuncSetAttribute((const void*)k_stars_map_sed<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_stars_map_sed<true>, dim3(nRT * M.n_stars), dim3(512), lds, ctx->stream, M, A, k0, k1, d_flux.p, d_out.p);
+  } else {
+    HIPCHK(hipFuncSetAttribute((const void*)k_stars_map_sed<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_stars_map_sed<false>, dim3(nRT * M.n_stars), dim3(512), lds, ctx->stream, M, A, k0, k1, d_flux.p, d_out.p);
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(d_out.get(stars_flux, nRT));
+  return MCGPU_OK;
+}
+
 extern "C" int mcgpu_rt1_image(mcgpu_ctx* ctx, const mcgpu_rt_opts* o, const float* tab_RT_az, const float* Tdust,
                                int npix_x, int npix_y, double map_size, double zoom, double* image, uint64_t* n_rays,
                                double* kernel_ms) {

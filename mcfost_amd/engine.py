@@ -35,7 +35,7 @@ ABI_SYMBOLS = (
     "mcgpu_probe_cross_voronoi", "mcgpu_set_rt1", "mcgpu_run_mono", "mcgpu_fetch_xI",
     "mcgpu_device_xI", "mcgpu_set_ism", "mcgpu_rt1_dust_map", "mcgpu_set_xI", "mcgpu_rt1_image", "mcgpu_set_xI_precision",
     "mcgpu_get_xI_precision", "mcgpu_set_option", "mcgpu_counters_to_accum", "mcgpu_counters_from_accum",
-    "mcgpu_set_grid_sph", "mcgpu_temp_approx_diffusion_vertical", "mcgpu_set_mrw", "mcgpu_fetch_radiation_field", "mcgpu_set_variable_dust", "mcgpu_multi_create", "mcgpu_multi_destroy", "mcgpu_multi_size", "mcgpu_multi_ctx", "mcgpu_multi_last_error",
+    "mcgpu_set_grid_sph", "mcgpu_temp_approx_diffusion_vertical", "mcgpu_set_mrw", "mcgpu_fetch_radiation_field", "mcgpu_set_variable_dust", "mcgpu_rt1_stars_map_sed", "mcgpu_multi_create", "mcgpu_multi_destroy", "mcgpu_multi_size", "mcgpu_multi_ctx", "mcgpu_multi_last_error",
     "mcgpu_shard_packets", "mcgpu_multi_run_thermal",
 )
 
@@ -476,6 +476,21 @@ class Engine:
             self.ctx, C.byref(o), _p(_a(rt["tab_RT_az"], np.float32), C.c_float), _p(_a(Tdust, np.float32), C.c_float),
             _p(out, C.c_double), C.byref(ms)), "mcgpu_rt1_dust_map")
         return out, ms.value
+
+    def stars_map_sed(self, lam, star_flux, seed=1, ang_disque=0.0):
+        """The stars' term of the ray-traced SED (``mcgpu_rt1_stars_map_sed`` = ``compute_stars_map`` with an
+        unresolved star): (nRT,) fluxes for ``star_flux[n_stars]`` = factor * prob_E_star(lambda, :)."""
+        m = self.model
+        rt = m.rt
+        if not getattr(self, "_rt1", False):
+            self.set_rt1()
+        o = RtOpts(int(lam), float(m.lam[lam - 1]), 1.0, 1.0, float(m.cfg.distance), float(ang_disque), 0, 100.0,
+                   float(m.cfg.rin), float(m.cfg.rout))
+        out = np.zeros(rt["RT_n_incl"] * rt["RT_n_az"], np.float64)
+        self._chk(self.lib.mcgpu_rt1_stars_map_sed(
+            self.ctx, C.byref(o), _p(_a(rt["tab_RT_az"], np.float32), C.c_float), C.c_uint64(int(seed)),
+            _p(_a(star_flux, np.float64), C.c_double), _p(out, C.c_double)), "mcgpu_rt1_stars_map_sed")
+        return out
 
     def dust_map_image(self, lam, Tdust, n_sent_photons, E_disk, npix_x, npix_y, map_size, zoom=1.0, ang_disque=0.0,
                        l_sym_ima=False, tau_dark_zone_obs=100.0):

@@ -69,7 +69,7 @@ module mcgpu_f
        mcgpu_run_mono, mcgpu_fetch, mcgpu_fetch_xI, mcgpu_rt1_dust_map, mcgpu_set_xI, mcgpu_rt1_image, mcgpu_set_xI_precision, &
        mcgpu_set_E_prior, mcgpu_multi_create, mcgpu_multi_destroy, mcgpu_multi_size, mcgpu_multi_ctx, mcgpu_multi_run_thermal, &
        mcgpu_counters_to_accum, mcgpu_counters_from_accum, mcgpu_temp_approx_diffusion_vertical, mcgpu_set_mrw, mcgpu_fetch_radiation_field, &
-       mcgpu_set_variable_dust
+       mcgpu_set_variable_dust, mcgpu_rt1_stars_map_sed
 
   interface
      integer(c_int) function mcgpu_create(device, ctx) bind(C, name="mcgpu_create")
@@ -206,6 +206,19 @@ module mcgpu_f
        type(c_ptr), value :: ctx
        real(c_double), intent(in) :: E_prior(*)
      end function mcgpu_set_E_prior
+
+     ! compute_stars_map for the SED (dust_transfer.f90:1604): star_flux(istar) = factor * prob_E_star(lambda,istar),
+     ! stars_flux(RT_n_incl*RT_n_az) = stars_map(1,1,1) per observer
+     integer(c_int) function mcgpu_rt1_stars_map_sed(ctx, opts, tab_RT_az, seed, star_flux, stars_flux) &
+          bind(C, name="mcgpu_rt1_stars_map_sed")
+       import :: c_int, c_ptr, c_float, c_double, c_int64_t, mcgpu_rt_opts
+       type(c_ptr), value :: ctx
+       type(mcgpu_rt_opts), intent(in) :: opts
+       real(c_float), intent(in) :: tab_RT_az(*)
+       integer(c_int64_t), value :: seed
+       real(c_double), intent(in) :: star_flux(*)
+       real(c_double), intent(out) :: stars_flux(*)
+     end function mcgpu_rt1_stars_map_sed
 
      ! lvariable_dust: p_icell(:) and the tables with the p_n_cells axis, as the modules hold them (mem.f90:213-244)
      ! (the seven scattering tables: c_loc of the arrays, or c_null_ptr for all of them)

@@ -39,6 +39,9 @@ class EngineBackend:
     def dust_map(self, lam, Tdust, res, E_disk):
         return self.e.dust_map_sed(lam, Tdust, res["n_sent"][lam - 1], E_disk)[0]
 
+    def stars_map(self, lam, star_flux, seed):
+        return self.e.stars_map_sed(lam, star_flux, seed=seed)
+
 
 def temperature_and_sed(backend, m, n_thermal, n_photons_lambda, lambdas=None, seed=1, n_chunks=None,
                         ray_tracing=True, diff_approx=None):
@@ -63,6 +66,7 @@ def temperature_and_sed(backend, m, n_thermal, n_photons_lambda, lambdas=None, s
     n_sent = np.zeros(nl)
     rt = m.rt
     sed_rt = np.zeros((nl, rt["RT_n_incl"] * rt["RT_n_az"], rt["N_type_flux"]))
+    sed_rt_stars = np.zeros((nl, rt["RT_n_incl"] * rt["RT_n_az"]))
     t["sed_mc"] = t["ray_tracing"] = 0.0
     for lam in lambdas:
         t0 = time.perf_counter()
@@ -73,8 +77,20 @@ def temperature_and_sed(backend, m, n_thermal, n_photons_lambda, lambdas=None, s
         if ray_tracing:
             t0 = time.perf_counter()
             sed_rt[lam - 1] = backend.dust_map(lam, Tdust, r, m.extra["E_disk"][lam - 1])
+            if hasattr(backend, "stars_map"):   # compute_stars_map (dust_transfer.f90:1583-1586): added to type 1 by the caller
+                sed_rt_stars[lam - 1] = backend.stars_map(lam, stars_flux_factor(m, lam), seed + 7919 * lam)
             t["ray_tracing"] += time.perf_counter() - t0
-    return dict(Tdust=Tdust, sed_mc=sed, n_sent=n_sent, sed_rt=sed_rt, seconds=t, thermal_counters=th["counters"])
+    return dict(Tdust=Tdust, sed_mc=sed, n_sent=n_sent, sed_rt=sed_rt, sed_rt_stars=sed_rt_stars, seconds=t,
+                thermal_counters=th["counters"])
+
+
+def stars_flux_factor(m, lam):
+    """``factor * prob_E_star(lambda, :)`` of compute_stars_map (dust_transfer.f90:1657-1659, :1819): the flux an
+    unobscured star sends to the observer, in the units of Stokes_ray_tracing."""
+    pc_to_AU, AU_to_Rsun = 648000.0 / np.pi, 149597870700.0 / 6.957e8
+    factor = float(m.E_stars[lam - 1]) * float(m.lam[lam - 1]) * 1.0e-6 / (m.cfg.distance * pc_to_AU * AU_to_Rsun) ** 2 * 1.35e-12
+    cdf = np.asarray(m.CDF_E_star, float).reshape(-1, m.n_lambda)[:, lam - 1]     # (0:n_stars) of this wavelength
+    return factor * np.diff(cdf)
 
 
 def sed_flux(m, sed_mc, n_sent):

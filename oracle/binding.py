@@ -361,6 +361,20 @@ class Oracle:
             raise RuntimeError(f"oracle_dust_map_sed failed: {rc}")
         return out
 
+    def stars_map_sed(self, lam, star_flux, seed=1, ang_disque=0.0):
+        """compute_stars_map for the SED: the stars' flux towards every observer, (nRT,)."""
+        m = self.model
+        rt = m.rt
+        az = _a(rt["tab_RT_az"], np.float32)
+        o = _RtOpts(int(lam), float(m.lam[lam - 1]), 1.0, 1.0, float(m.cfg.distance), float(ang_disque), 0, 100.0,
+                    float(m.cfg.rin), float(m.cfg.rout), _p(az, C.c_float), 1)
+        out = np.zeros(rt["RT_n_incl"] * rt["RT_n_az"])
+        rc = self.lib.oracle_stars_map_sed(C.byref(self.cm), C.byref(o), C.c_uint64(int(seed)),
+                                           _p(_a(star_flux, np.float64), C.c_double), _p(out, C.c_double))
+        if rc:
+            raise RuntimeError(f"oracle_stars_map_sed failed: {rc}")
+        return out
+
     def dust_map_image(self, lam, xI_scatt, Tdust, n_sent_photons, E_disk, npix_x, npix_y, map_size, zoom=1.0,
                        ang_disque=0.0, l_sym_ima=False, tau_dark_zone_obs=100.0, n_threads=1):
         """Ray-traced image of the dust at wavelength ``lam`` (dust_map method 2):

@@ -2433,6 +2433,83 @@ static double rt_photon_energy(const oracle_rt_opts *o) { /* (:661-663), SED / i
   return o->E_src * o->wl_um * 1.0e-6 / (o->n_sent_photons * ORC_AU_TO_CM * PI);
 }
 
+/* ------------------------------------------------------------------------ */
+/* compute_stars_map for the SED (dust_transfer.f90:1604-1854, lresolved = .false., no limb darkening)               */
+/* ------------------------------------------------------------------------ */
+/* optical_length_tot (optical_depth.f90:248-324), cylindrical grids */
+static float optical_length_tot(const oracle_model *m, int lambda, double x, double y, double z, double u, double v,
+                                double w) {
+  int icell, next_cell, previous_cell = 0;
+  oracle_index_cell_cyl(m, x, y, z, &icell);
+  next_cell = icell;
+  double x1 = x, y1 = y, z1 = z, tau_tot = 0.0;
+  int icell0 = 0;
+  for (;;) {
+    previous_cell = icell0;
+    icell0 = next_cell;
+    const double x0 = x1, y0 = y1, z0 = z1;
+    if (oracle_test_exit_grid_cyl(m, icell0, x0, y0, z0)) return (float)tau_tot;
+    const double opacity = (icell0 <= m->n_cells && icell0 >= 1) ? m->kappa[lambda - 1] * m->kappa_factor[icell0 - 1] : 0.0;
+    double l, l_contrib, l_void;
+    oracle_cross_cylindrical_cell(m, x0, y0, z0, u, v, w, icell0, previous_cell, &x1, &y1, &z1, &next_cell, &l, &l_contrib,
+                                  &l_void);
+    tau_tot += l_contrib * opacity;
+  }
+}
+
+int oracle_stars_map_sed(const oracle_model *m, const oracle_rt_opts *o, uint64_t seed, const double *star_flux,
+                         double *out) {
+  if (m->grid_type != 1 || m->p_n_cells) return 31;
+  enum { NXS = 10, NS = 21, N_RAY_SED = 1024 };
+  const int nRT = m->RT_n_incl * m->RT_n_az;
+  const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+  for (int q = 0; q < nRT; ++q) out[q] = 0.0;
+  for (int q = 0; q < nRT; ++q)
+    for (int istar = 0; istar < m->n_stars; ++istar) {
+      double uvw[3], xpi[3], ypi[3], center[3];
+      rt_image_plane(m, o, q % m->RT_n_incl + 1, q / m->RT_n_incl + 1, uvw, xpi, ypi, center);
+      const oracle_star *st = &m->stars[istar];
+      const double delta = st->r / (double)NXS;
+      const double nx = sqrt(xpi[0] * xpi[0] + xpi[1] * xpi[1] + xpi[2] * xpi[2]);
+      const double ny = sqrt(ypi[0] * ypi[0] + ypi[1] * ypi[1] + ypi[2] * ypi[2]);
+      const double dxs[3] = {delta * xpi[0] / nx, delta * xpi[1] / nx, delta * xpi[2] / nx};
+      const double dys[3] = {delta * ypi[0] / ny, delta * ypi[1] / ny, delta * ypi[2] / ny};
+      float tau_screen[NS * NS];
+      for (int j = -NXS; j <= NXS; ++j)
+        for (int i = -NXS; i <= NXS; ++i)
+          tau_screen[(i + NXS) + NS * (j + NXS)] =
+              optical_length_tot(m, o->lambda, st->x + dxs[0] * i + dys[0] * j, st->y + dxs[1] * i + dys[1] * j,
+                                 st->z + dxs[2] * i + dys[2] * j, uvw[0], uvw[1], uvw[2]);
+      const int n_ray = N_RAY_SED / m->n_stars > 1 ? N_RAY_SED / m->n_stars : 1;
+      const double norm_screen2 = 1.0 / (delta * delta);
+      double sum_f = 0.0, sum_n = 0.0;
+      for (int iray = 0; iray < n_ray; ++iray) {
+        uint32_t ctr[4] = {(uint32_t)iray, 2u, (uint32_t)(q * m->n_stars + istar), 0u}, r4[4];
+        oracle_philox4x32_10(ctr, key, r4);
+        const float rand = u32_to_real(r4[0]), rand2 = u32_to_real(r4[1]);
+        const double z = 2.0 * (double)rand - 1.0;
+        const double srw02 = sqrt(1.0 - z * z), argmt = PI * (2.0 * (double)rand2 - 1.0);
+        const double x = srw02 * cos(argmt), y = srw02 * sin(argmt);
+        const float cos_thet = (float)fabs(x * uvw[0] + y * uvw[1] + z * uvw[2]);
+        const double vec[3] = {x * st->r, y * st->r, z * st->r};
+        const double offset_x = (vec[0] * dxs[0] + vec[1] * dxs[1] + vec[2] * dxs[2]) * norm_screen2;
+        const double offset_y = (vec[0] * dys[0] + vec[1] * dys[1] + vec[2] * dys[2]) * norm_screen2;
+        const int i = (int)floor(offset_x), j = (int)floor(offset_y);
+        const double fx = offset_x - i, fy = offset_y - j;
+        float tau = 0.0f;
+        if (i >= -NXS && i < NXS && j >= -NXS && j < NXS) {
+          const int p = (i + NXS) + NS * (j + NXS);
+          tau = (float)((double)tau_screen[p] * (1 - fx) * (1 - fy) + (double)tau_screen[p + 1] * fx * (1 - fy) +
+                        (double)tau_screen[p + NS] * (1 - fx) * fy + (double)tau_screen[p + NS + 1] * fx * fy);
+        }
+        sum_f += (double)(expf(-tau) * cos_thet);
+        sum_n += (double)cos_thet;
+      }
+      out[q] += star_flux[istar] * sum_f / sum_n;
+    }
+  return 0;
+}
+
 int oracle_dust_map_sed(const oracle_model *m, const oracle_rt_opts *o, const double *xI, const float *Tdust,
                         double *out) {
   if (m->grid_type == 3) return 31;

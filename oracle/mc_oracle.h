@@ -298,6 +298,12 @@ typedef struct {
   int n_threads;
 } oracle_rt_opts;
 
+/* compute_stars_map for the SED (dust_transfer.f90:1604-1854; lresolved = .false., no limb darkening): out[nRT] =
+ * sum over stars of star_flux[istar] * sum(exp(-tau) cos_thet) / sum(cos_thet); 2D / 3D cylindrical grids.  PARITY
+ * UNPINNED (dust_transfer.f90 is unbuildable here; the reference's points come from SPRNG). */
+int oracle_stars_map_sed(const oracle_model *m, const oracle_rt_opts *o, uint64_t seed, const double *star_flux,
+                         double *out);
+
 /* xI_scatt: reference layout, FP64 (oracle_run_mono's output); Tdust [n_cells];
  * out[(ibin-1 + RT_n_incl*(iaz-1)) * N_type_flux + type-1] */
 int oracle_dust_map_sed(const oracle_model *m, const oracle_rt_opts *o, const double *xI_scatt,

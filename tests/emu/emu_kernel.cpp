@@ -475,6 +475,25 @@ extern "C" int emu_rt1_dust_map(const oracle_model* m, const oracle_rt_opts* o, 
   return 0;
 }
 
+extern "C" int emu_stars_map_sed(const oracle_model* m, const oracle_rt_opts* o, uint64_t seed, const double* star_flux,
+                                 double* out) {
+  if (m->grid_type != 1) return 31;
+  Conv cv(m);
+  RtArgs A;
+  memset(&A, 0, sizeof(A));
+  A.lambda = o->lambda; A.RT_n_incl = m->RT_n_incl; A.nRT = m->RT_n_incl * m->RT_n_az; A.ang_disque = o->ang_disque;
+  A.rt_u = m->tab_u_rt; A.rt_v = m->tab_v_rt; A.rt_w = m->tab_w_rt; A.rt_az = o->tab_RT_az;
+  for (int q = 0; q < A.nRT; ++q) out[q] = 0.0;
+  gridDim.x = (unsigned)(A.nRT * m->n_stars); blockDim.x = 1; threadIdx.x = 0;
+  for (unsigned b = 0; b < gridDim.x; ++b) {
+    blockIdx.x = b;
+    if (m->l3D) k_stars_map_sed<true>(cv.M, A, (unsigned)seed, (unsigned)(seed >> 32), star_flux, out);
+    else k_stars_map_sed<false>(cv.M, A, (unsigned)seed, (unsigned)(seed >> 32), star_flux, out);
+  }
+  blockIdx.x = 0;
+  return 0;
+}
+
 extern "C" int emu_rt1_image(const oracle_model* m, const oracle_rt_opts* o, int npix_x, int npix_y, double map_size,
                              double zoom, const double* xI, const float* Tdust, double* image, int* n_rays) {
   if (m->grid_type == 3) return 31;

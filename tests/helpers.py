@@ -90,3 +90,6 @@ class OracleBackend:
 
     def dust_map(self, lam, Tdust, res, E_disk):
         return self.o.dust_map_sed(lam, res["xI_scatt"], Tdust, res["n_sent"][lam - 1], E_disk, n_threads=self.nt)
+
+    def stars_map(self, lam, star_flux, seed):
+        return self.o.stars_map_sed(lam, star_flux, seed=seed)

@@ -844,6 +844,9 @@ def test_temperature_and_sed_end_to_end():
     ig, ic_ = g["sed_rt"][:, :, 0], c["sed_rt"][:, :, 0]
     assert (ic_ > 0).all()
     assert np.percentile(np.abs(ig / ic_ - 1), 75) < 0.10
+    # the stars' term (compute_stars_map): same screens and rays apart from the two runs' seeds
+    sg, sc = g["sed_rt_stars"], c["sed_rt_stars"]
+    assert (sc > 0).all() and np.allclose(sg, sc, rtol=0.05)
     # and the stages ran on the device: every wavelength sent packets, every stream stopped by its count
     assert (g["n_sent"] >= nch * n2).all()
 
