@@ -132,7 +132,13 @@ __device__ inline void voro_cross_cell(const VoroGrid& G, const DevModel& M, con
                                        double& s_void_before) {
   const float r0 = (float)x, r1 = (float)y, r2 = (float)z;
   const float k0 = (float)u, k1 = (float)v, k2 = (float)w;
-  double s = 1.00000001504746621988e+30;  // real 1e30
+  // The reference keeps the smallest quotient s_tmp = num / den over the neighbours (:859-905), one FP64 division per
+  // neighbour.  num and den are default reals, so the cross products num * den_best and num_best * den are exact in
+  // FP64 (24 + 24 bits) and "num / den < num_best / den_best" can be decided without dividing: two different such
+  // fractions differ by more than 2^-48 relatively, which the rounded quotients resolve as well, and equal fractions
+  // are "not smaller" either way.  The running minimum is (s_num, s_den); ONE division at the end (or when a wall of
+  // the box, whose distance is a genuine double, has to be compared).
+  double s_num = 1.00000001504746621988e+30, s_den = 1.0;  // real 1e30
   next_cell = 0;
   const VoroNb* nb = G.nb + C.first;
   const int cnt = C.count;
@@ -146,22 +152,22 @@ __device__ inline void voro_cross_cell(const VoroGrid& G, const DevModel& M, con
     for (int q = 0; q < 4; ++q) {
       const VoroNb N = N4[q];
       if (i0 + q >= cnt || N.id == previous_cell) continue;
-      double s_tmp;
       if (N.id > 0) {
         const float n0 = nf_sub(N.x, C.x), n1 = nf_sub(N.y, C.y), n2 = nf_sub(N.z, C.z);
         const double den = (double)dot3f(n0, n1, n2, k0, k1, k2);
-        if (den <= 0.0) continue;
         const float p0 = nf_mul(0.5f, nf_add(N.x, C.x)), p1 = nf_mul(0.5f, nf_add(N.y, C.y)),
                     p2 = nf_mul(0.5f, nf_add(N.z, C.z));
-        s_tmp = (double)dot3f(n0, n1, n2, nf_sub(p0, r0), nf_sub(p1, r1), nf_sub(p2, r2)) / den;
-        if (s_tmp < 0.0) s_tmp = (double)FLT_HUGE;
+        const double num = (double)dot3f(n0, n1, n2, nf_sub(p0, r0), nf_sub(p1, r1), nf_sub(p2, r2));
+        // den <= 0: skipped; num < 0: the reference sets s_tmp = huge(1.0) > 1e30, never the minimum
+        if (den > 0.0 && !(num < 0.0) && nd_mul(num, s_den) < nd_mul(s_num, den)) { s_num = num; s_den = den; next_cell = N.id; }
       } else {
-        s_tmp = voro_distance_to_wall(G, x, y, z, u, v, w, -N.id);
+        double s_tmp = voro_distance_to_wall(G, x, y, z, u, v, w, -N.id);
         if (s_tmp < 0.0) s_tmp = (double)FLT_HUGE;
+        if (s_tmp < s_num / s_den) { s_num = s_tmp; s_den = 1.0; next_cell = N.id; }
       }
-      if (s_tmp < s) { s = s_tmp; next_cell = N.id; }
     }
   }
+  double s = s_num / s_den;
   s = nd_mul(s, 1.0 + (double)1e-5f);
   x1 = nd_add(x, nd_mul(u, s));
   y1 = nd_add(y, nd_mul(v, s));
