@@ -202,3 +202,36 @@ def test_device_walk_against_brute_force():
     assert res[8.0][0] < 3.0 and res[8.0][1] < 0.02, res
     assert res[2.0][1] < 0.04, res
     assert res[2.0][2] > 1.5, res
+
+
+@pytest.mark.gpu
+def test_config4_thick_ref41_live_against_brute_force_with_the_reference_gate():
+    """BASELINE config 4 at scale: the ref4.1 grid with 10x the dust mass (the stock ref4.1 never walks: its cells
+    are thin at the re-emission wavelengths), 1e7 packets, live Bjorkman & Wood temperature on both sides, gamma_MRW
+    = 2 -- temperature against the brute-force run through the reference's own gate (test_suite/test_mcfost.py:46-57,
+    88: 75th percentile of |dT|/T below 5 %), and far inside it."""
+    from mcfost_amd.engine import Engine
+    from helpers import mc_similar
+    n = 10_000_000
+    cfg = M.ref41()
+    cfg.dust_mass = 1e-2
+    m0 = M.build_model(cfg)
+    e0 = Engine(m0, n)
+    r0 = e0.run_thermal(n, seed=3)
+    T0 = e0.temp_finale(r0["E_abs"])
+    e0.close()
+    m1 = M.build_model(cfg)
+    M.init_mrw(m1)
+    e1 = Engine(m1, n)
+    r1 = e1.run_thermal(n, seed=4)
+    T1 = e1.temp_finale(r1["E_abs"])
+    e1.close()
+    c0, c1 = r0["counters"], r1["counters"]
+    assert c1["mrw_walks"] > 1e6 and c1["escaped"] + c1["killed_star"] == n
+    assert c1["absorptions"] < 0.7 * c0["absorptions"]
+    sel = (T0 > 1.2 * cfg.T_min) & (T1 > 1.2 * cfg.T_min)
+    ok, p75 = mc_similar(T0[sel], T1[sel], 0.05)
+    assert ok and p75 < 0.01, p75
+    assert np.abs(T1[sel] / T0[sel] - 1.0).max() < 0.10            # no cell is far off (noise included)
+    print("config 4 (thick ref4.1): p75 |dT/T| = %.4f, max = %.3f, kernel %.0f -> %.0f ms" %
+          (p75, np.abs(T1[sel] / T0[sel] - 1.0).max(), r0["kernel_ms"], r1["kernel_ms"]))
