@@ -112,3 +112,40 @@ def test_device_fill_rejects_what_the_reference_does_not_do():
     with pytest.raises(McgpuError):
         e.temp_approx_diffusion_vertical(np.ones(m3.n_cells, np.float32), 3, 5, np.zeros(12, np.int32))
     e.close()
+
+
+@pytest.mark.gpu
+def test_dark_zone_and_diffusion_fill_against_brute_force_at_scale():
+    """What the reference does with an optically thick midplane, end to end on the device: define_dark_zone's cells
+    (tau = 1500 at the first wavelength beyond 0.81 um) mirror the packets, Temp_finale leaves T_min there, the
+    diffusion fill restores the temperature -- against the brute-force run of the same disk (the ref4.1 grid with 10x
+    the dust mass: 301 dark cells) through the reference's gate: p75 of |dT|/T below 5 % inside the zone and outside."""
+    from mcfost_amd.engine import Engine
+    cfg = M.ref41()
+    cfg.dust_mass = 1e-2
+    m = M.build_model(cfg)
+    lam = int(np.searchsorted(m.lam, 0.81)) + 1
+    dz = Oracle(m, 1000).define_dark_zone(lam, 1500.0)
+    ri_in, ri_out, zj = M.dark_zone_extent(m, lam, 1500.0)
+    assert dz.sum() > 100 and ri_in >= 2
+    n = 20_000_000
+    e0 = Engine(m, n)
+    r0 = e0.run_thermal(n, seed=3)
+    T0 = e0.temp_finale(r0["E_abs"])
+    e0.close()
+    m1 = M.build_model(cfg)
+    m1.l_dark_zone = dz
+    e1 = Engine(m1, n)
+    r1 = e1.run_thermal(n, seed=4)
+    T1 = e1.temp_finale(r1["E_abs"])
+    T2, n_it = e1.temp_approx_diffusion_vertical(T1, ri_in, ri_out, zj)
+    e1.close()
+    d = dz != 0
+    assert np.all(T1[d] == np.float32(cfg.T_min)) and r1["counters"]["dark_mirrors"] > 0
+    rel = T2[d] / T0[d] - 1.0
+    out = (~d) & (T0 > 1.2 * cfg.T_min)
+    p75_in, p75_out = np.percentile(np.abs(rel), 75), np.percentile(np.abs(T2[out] / T0[out] - 1.0), 75)
+    print("dark zone %d cells: fill vs brute force p50 %.4f, p75 %.4f, max %.3f; outside p75 %.4f; kernel %.0f -> %.0f ms, "
+          "%d fill iterations" % (d.sum(), np.median(rel), p75_in, np.abs(rel).max(), p75_out, r0["kernel_ms"], r1["kernel_ms"], n_it))
+    assert p75_in < 0.05 and abs(np.median(rel)) < 0.02 and p75_out < 0.01
+    assert r1["kernel_ms"] < 0.5 * r0["kernel_ms"]
