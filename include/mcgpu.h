@@ -500,6 +500,19 @@ int mcgpu_set_mrw(mcgpu_ctx *ctx, int n_zeta, const double *zeta, const double *
                   const double *r_lim);
 
 /*
+ * define_dark_zone (optical_depth.f90:1425-1651) for a 2D cylindrical grid: steps 1-3 (the radii and heights where the
+ * optical depth at `lambda` exceeds tau_max from outside) and step 4 (11 test rays from the centre of every candidate
+ * cell; one ray per device thread).  r_lim[n_rad+1], r_grid / z_grid[n_cells], z_lim(n_rad, nz+1...) are module
+ * cylindrical_grid's arrays.  Outputs: l_dark_zone[n_cells] (to be passed to mcgpu_set_opacity), ri_in_dark_zone,
+ * ri_out_dark_zone, zj_sup_dark_zone[n_rad] (to mcgpu_temp_approx_diffusion_vertical).  The context's own dark-zone
+ * flags, if any, are ignored by the rays.  3D grids (:1553-1618) are not built.
+ */
+int mcgpu_define_dark_zone(mcgpu_ctx *ctx, int lambda, double tau_max, const double *r_lim,
+                           const double *r_grid, const double *z_grid, const double *z_lim,
+                           unsigned char *l_dark_zone, int *ri_in_dark_zone, int *ri_out_dark_zone,
+                           int *zj_sup_dark_zone);
+
+/*
  * Temp_approx_diffusion_vertical (diffusion.f90:292-374; called after Temp_finale at dust_transfer.f90:316 / :659 when
  * define_dark_zone found a dark zone): the 1+1D diffusion approximation that refills the temperature of the dark
  * zone, column by column (clean_temperature, temperature_to_DensE, setDiffusion_coeff0/_coeff,

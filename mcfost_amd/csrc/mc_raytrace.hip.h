@@ -350,4 +350,55 @@ __global__ void __launch_bounds__(512) k_stars_map_sed(const DevModel M, const R
   if (tid == 0) atomic_add_f64(&out[q], star_flux[istar] * red_a[0] / red_b[0]);
 }
 
+// ---------------------------------------------------------------------------
+// define_dark_zone, step 4 (optical_depth.f90:1522-1551; 2D): from the centre of every candidate cell, 11 rays in the
+// (x, z) plane at angles pi n / 12; a ray that uses up the optical depth tau_max before it leaves the grid marks its
+// cell.  One ray per thread: physical_length (optical_depth.f90:21-178) without deposits (Stokes = 0).
+// flag[icell] = 1 when some ray of the cell does not leave.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_dark_zone_rays(const DevModel M, int lambda, float tau_max, int i_lo, int i_hi,
+                                                        const int* zj_sup, const double* r_grid, const double* z_grid,
+                                                        unsigned char* flag) {
+  extern __shared__ double lds_raw[];
+  const Lds T = lds_carve(lds_raw, M, true);
+  lds_stage_mono(T, M, 1);
+  __syncthreads();
+  const int n_rad = M.n_rad, nz = M.nz;
+  const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = (int)(tid % 11) + 1;
+  const long long c = tid / 11;
+  const int i = i_lo + (int)(c % (i_hi - i_lo + 1)), j = 1 + (int)(c / (i_hi - i_lo + 1));
+  if (i > i_hi || j > nz || j > zj_sup[i - 1]) return;
+  const int icell = (i - 1) + n_rad * (j - 1);
+  const float angle = (float)(PI * (double)((float)n / 12.0f));  // pi * real(n)/real(nbre_angle+1)
+  double x = r_grid[icell], y = 0.0, z = z_grid[icell];
+  const double u = (double)cosf(angle), v = 0.0, w = (double)sinf(angle);
+  int ri = i, zj = j, k = 1;
+  const double a = u * u + v * v;
+  const double inv_a = (a > TINY_REAL) ? 1.0 / a : HUGE_REAL;
+  const double inv_w = (fabs(w) > TINY_REAL) ? 1.0 / w : copysign(HUGE_DP, w);
+  const int i_star = intersect_stars(M, x, y, z, u, v, w);
+  int star_key = -1;
+  if (i_star > 0) {
+    const int* sc = &M.star_cell[4 * (i_star - 1)];
+    star_key = sc[0] + (n_rad + 2) * ((sc[1] + nz + 1) + (2 * nz + 3) * (sc[2] - 1));
+  }
+  double extr = (double)tau_max;
+  for (long guard = 0; guard < 100000000L; ++guard) {
+    const int azj = zj < 0 ? -zj : zj;
+    if ((ri == n_rad + 1) || ((azj == nz + 1) && (fabs(z) > M.zmaxmax))) return;  // leaves the grid
+    if (star_key >= 0 && (ri + (n_rad + 2) * ((zj + nz + 1) + (2 * nz + 3) * (k - 1))) == star_key) return;  // (:91-97: flag_sortie)
+    double x1, y1, z1, l;
+    int ri1, zj1, k1;
+    MCGPU_CROSS<false>(T, M, x, y, z, u, v, w, inv_a, inv_w, ri, zj, k, x1, y1, z1, ri1, zj1, k1, l);
+    const double opacity = is_real_cell<false>(n_rad, nz, ri, zj)
+                               ? T.kappa[lambda - 1] * M.kappa_factor[cell_index<false>(n_rad, nz, ri, zj, k)] : 0.0;
+    const double tau = l * opacity;
+    if (tau > extr) { flag[icell] = 1; return; }  // the ray stops inside: the cell is dark
+    extr = extr - tau;
+    x = x1; y = y1; z = z1;
+    ri = ri1; zj = zj1; k = k1;
+  }
+}
+
 }  // namespace mcgpu

@@ -1616,6 +1616,84 @@ extern "C" int mcgpu_rt1_dust_map(mcgpu_ctx* ctx, const mcgpu_rt_opts* o, const 
   return MCGPU_OK;
 }
 
+// define_dark_zone (optical_depth.f90:1425-1651), 2D cylindrical grids: see include/mcgpu.h
+extern "C" int mcgpu_define_dark_zone(mcgpu_ctx* ctx, int lambda, double tau_max_in, const double* r_lim, const double* r_grid,
+                                      const double* z_grid, const double* z_lim, unsigned char* l_dark_zone, int* ri_in_dark_zone,
+                                      int* ri_out_dark_zone, int* zj_sup_dark_zone) {
+  int rc = ready(ctx);
+  if (rc) return rc;
+  if (!r_lim || !r_grid || !z_grid || !z_lim || !l_dark_zone || !ri_in_dark_zone || !ri_out_dark_zone || !zj_sup_dark_zone)
+    return fail(ctx, MCGPU_ERR_ARG, "mcgpu_define_dark_zone: null argument");
+  const DevModel& M = ctx->M;
+  if (ctx->voro || M.l3D || M.grid_sph || M.n_classes) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "define_dark_zone: 2D cylindrical grids, one dust class");
+  if (lambda < 1 || lambda > M.n_lambda) return fail(ctx, MCGPU_ERR_ARG, "mcgpu_define_dark_zone: bad wavelength");
+  HIPCHK(hipSetDevice(ctx->device));
+  const int n_rad = M.n_rad, nz = M.nz;
+  std::vector<double> kf(M.n_cells);
+  double kap = 0.0;
+  HIPCHK(hipMemcpy(kf.data(), M.kappa_factor, (size_t)M.n_cells * sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(&kap, M.kappa + (lambda - 1), sizeof(double), hipMemcpyDeviceToHost));
+  const float tau_max = (float)tau_max_in;  // real, intent(in)
+  // steps 1-3 (:1459-1500): the running sums are default reals
+  int ri_in = n_rad, ri_out = 1;
+  float total = 0.0f;
+  for (int i = 1; i <= n_rad; ++i) {
+    total = (float)((double)total + kap * kf[i - 1] * (r_lim[i] - r_lim[i - 1]));
+    if (total > tau_max) { ri_in = i; break; }
+  }
+  total = 0.0f;
+  for (int i = n_rad; i >= 1; --i) {
+    total = (float)((double)total + kap * kf[i - 1] * (r_lim[i] - r_lim[i - 1]));
+    if (total > tau_max) { ri_out = i; break; }
+  }
+  if (ri_out == n_rad) ri_out = n_rad - 1;
+  std::vector<int> zj(n_rad, 0);
+  for (int i = ri_in; i <= ri_out; ++i) {
+    total = 0.0f;
+    for (int j = nz; j >= 1; --j) {
+      const double dzl = z_lim[(i - 1) + (size_t)n_rad * j] - z_lim[(i - 1) + (size_t)n_rad * (j - 1)];
+      total = (float)((double)total + kap * kf[(i - 1) + (size_t)n_rad * (j - 1)] * dzl);
+      if (total > tau_max) { zj[i - 1] = j; break; }
+    }
+  }
+  // step 4 (:1522-1551) on the device: one ray per thread
+  std::memset(l_dark_zone, 0, (size_t)M.n_cells);
+  const int i_lo = ri_in > 2 ? ri_in : 2, i_hi = ri_out;
+  if (i_hi >= i_lo) {
+    DevBuf<int> d_zj;
+    DevBuf<double> d_rg, d_zg;
+    DevBuf<unsigned char> d_flag;
+    HIPCHK(d_zj.alloc(n_rad)); HIPCHK(d_zj.put(zj.data(), n_rad));
+    HIPCHK(d_rg.alloc(M.n_cells)); HIPCHK(d_rg.put(r_grid, M.n_cells));
+    HIPCHK(d_zg.alloc(M.n_cells)); HIPCHK(d_zg.put(z_grid, M.n_cells));
+    HIPCHK(d_flag.alloc(M.n_cells)); HIPCHK(hipMemsetAsync(d_flag.p, 0, M.n_cells, ctx->stream));
+    const long long n_rays = 11LL * (i_hi - i_lo + 1) * nz;
+    const size_t lds = lds_bytes(M, true);
+    HIPCHK(hipFuncSetAttribute((const void*)k_dark_zone_rays, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_dark_zone_rays, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), lds, ctx->stream, M, lambda, tau_max, i_lo,
+                       i_hi, d_zj.p, d_rg.p, d_zg.p, d_flag.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    std::vector<unsigned char> flag(M.n_cells);
+    HIPCHK(d_flag.get(flag.data(), M.n_cells));
+    // the first flagged cell from the top of the candidate range, and everything below it (:1541-1547)
+    for (int i = i_lo; i <= i_hi; ++i)
+      for (int j = zj[i - 1]; j >= 1; --j)
+        if (flag[(i - 1) + (size_t)n_rad * (j - 1)]) {
+          for (int jj = 1; jj <= j; ++jj) l_dark_zone[(i - 1) + (size_t)n_rad * (jj - 1)] = 1;
+          break;
+        }
+  }
+  // (:1621-1628) the extent handed to the diffusion fill
+  if (ri_in <= ri_out) {
+    for (int i = 1; i < ri_in; ++i) zj[i - 1] = zj[ri_in - 1];
+    for (int i = ri_out + 1; i <= n_rad; ++i) zj[i - 1] = zj[ri_out - 1];
+  }
+  *ri_in_dark_zone = ri_in; *ri_out_dark_zone = ri_out;
+  for (int i = 0; i < n_rad; ++i) zj_sup_dark_zone[i] = zj[i];
+  return MCGPU_OK;
+}
+
 // compute_stars_map for the SED (dust_transfer.f90:1604-1854): see include/mcgpu.h
 extern "C" int mcgpu_rt1_stars_map_sed(mcgpu_ctx* ctx, const mcgpu_rt_opts* o, const float* tab_RT_az, uint64_t seed,
                                        const double* star_flux, double* stars_flux) {

@@ -35,7 +35,7 @@ ABI_SYMBOLS = (
     "mcgpu_probe_cross_voronoi", "mcgpu_set_rt1", "mcgpu_run_mono", "mcgpu_fetch_xI",
     "mcgpu_device_xI", "mcgpu_set_ism", "mcgpu_rt1_dust_map", "mcgpu_set_xI", "mcgpu_rt1_image", "mcgpu_set_xI_precision",
     "mcgpu_get_xI_precision", "mcgpu_set_option", "mcgpu_counters_to_accum", "mcgpu_counters_from_accum",
-    "mcgpu_set_grid_sph", "mcgpu_temp_approx_diffusion_vertical", "mcgpu_set_mrw", "mcgpu_fetch_radiation_field", "mcgpu_set_variable_dust", "mcgpu_rt1_stars_map_sed", "mcgpu_multi_create", "mcgpu_multi_destroy", "mcgpu_multi_size", "mcgpu_multi_ctx", "mcgpu_multi_last_error",
+    "mcgpu_set_grid_sph", "mcgpu_temp_approx_diffusion_vertical", "mcgpu_set_mrw", "mcgpu_fetch_radiation_field", "mcgpu_set_variable_dust", "mcgpu_rt1_stars_map_sed", "mcgpu_define_dark_zone", "mcgpu_multi_create", "mcgpu_multi_destroy", "mcgpu_multi_size", "mcgpu_multi_ctx", "mcgpu_multi_last_error",
     "mcgpu_shard_packets", "mcgpu_multi_run_thermal",
 )
 
@@ -329,6 +329,19 @@ class Engine:
         t_acc = torch.as_tensor(_DevArray(acc.value, n.value, "<f8"), device=dev)
         t_cnt = torch.as_tensor(_DevArray(cnt.value, N_COUNTERS, "<i8"), device=dev)
         return t_acc, t_cnt
+
+    def define_dark_zone(self, lam, tau_max=1500.0):
+        """``define_dark_zone`` (optical_depth.f90:1425-1651, 2D): returns (l_dark_zone[n_cells] u8, ri_in, ri_out, zj_sup)."""
+        m, g = self.model, self.model.grid
+        dz = np.zeros(m.n_cells, np.uint8)
+        zj = np.zeros(g["n_rad"], np.int32)
+        a, b = C.c_int(), C.c_int()
+        d = np.float64
+        self._chk(self.lib.mcgpu_define_dark_zone(
+            self.ctx, C.c_int(int(lam)), C.c_double(float(tau_max)), _p(_a(g["r_lim"], d), C.c_double),
+            _p(_a(g["r_grid"], d), C.c_double), _p(_a(g["z_grid"], d), C.c_double), _p(_a(g["z_lim"], d), C.c_double),
+            _p(dz, C.c_ubyte), C.byref(a), C.byref(b), _p(zj, C.c_int)), "mcgpu_define_dark_zone")
+        return dz, a.value, b.value, zj
 
     def temp_approx_diffusion_vertical(self, Tdust, ri_in, ri_out, zj_sup):
         """``Temp_approx_diffusion_vertical`` (diffusion.f90:292-374) on the device: returns (Tdust, iterations)."""

@@ -69,7 +69,7 @@ module mcgpu_f
        mcgpu_run_mono, mcgpu_fetch, mcgpu_fetch_xI, mcgpu_rt1_dust_map, mcgpu_set_xI, mcgpu_rt1_image, mcgpu_set_xI_precision, &
        mcgpu_set_E_prior, mcgpu_multi_create, mcgpu_multi_destroy, mcgpu_multi_size, mcgpu_multi_ctx, mcgpu_multi_run_thermal, &
        mcgpu_counters_to_accum, mcgpu_counters_from_accum, mcgpu_temp_approx_diffusion_vertical, mcgpu_set_mrw, mcgpu_fetch_radiation_field, &
-       mcgpu_set_variable_dust, mcgpu_rt1_stars_map_sed
+       mcgpu_set_variable_dust, mcgpu_rt1_stars_map_sed, mcgpu_define_dark_zone
 
   interface
      integer(c_int) function mcgpu_create(device, ctx) bind(C, name="mcgpu_create")
@@ -251,6 +251,19 @@ module mcgpu_f
        real(c_double), intent(in) :: zeta(*), chi(*), kappa_dep(*), ext(*), r_lim(*)
        real(c_double), value :: gamma
      end function mcgpu_set_mrw
+
+     ! define_dark_zone (optical_depth.f90:1425), 2D: module cylindrical_grid's r_lim, r_grid, z_grid, z_lim in;
+     ! l_dark_zone (as integer(c_int8_t)), ri_in/out_dark_zone(1), zj_sup_dark_zone(:,1) out
+     integer(c_int) function mcgpu_define_dark_zone(ctx, lambda, tau_max, r_lim, r_grid, z_grid, z_lim, l_dark_zone, &
+          ri_in_dark_zone, ri_out_dark_zone, zj_sup_dark_zone) bind(C, name="mcgpu_define_dark_zone")
+       import :: c_int, c_ptr, c_double, c_int8_t
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: lambda
+       real(c_double), value :: tau_max
+       real(c_double), intent(in) :: r_lim(*), r_grid(*), z_grid(*), z_lim(*)
+       integer(c_int8_t), intent(out) :: l_dark_zone(*)
+       integer(c_int), intent(out) :: ri_in_dark_zone, ri_out_dark_zone, zj_sup_dark_zone(*)
+     end function mcgpu_define_dark_zone
 
      ! Temp_approx_diffusion_vertical (diffusion.f90:292): tab_lambda / tab_delta_lambda of module wavelengths,
      ! ri_in_dark_zone(1), ri_out_dark_zone(1), zj_sup_dark_zone(:,1) of module cylindrical_grid, Tdust in/out

@@ -475,6 +475,23 @@ extern "C" int emu_rt1_dust_map(const oracle_model* m, const oracle_rt_opts* o, 
   return 0;
 }
 
+// step 4 of define_dark_zone: the device's ray kernel, one thread at a time; flag[n_cells] receives the cells with a ray
+// that does not leave
+extern "C" int emu_dark_zone_rays(const oracle_model* m, int lambda, double tau_max, int i_lo, int i_hi, const int* zj_sup,
+                                  const double* r_grid, const double* z_grid, unsigned char* flag) {
+  if (m->l3D || m->grid_type != 1) return 31;
+  Conv cv(m);
+  memset(flag, 0, m->n_cells);
+  const long long n_rays = 11LL * (i_hi - i_lo + 1) * m->nz;
+  gridDim.x = (unsigned)n_rays; blockDim.x = 1; threadIdx.x = 0;
+  for (long long t = 0; t < n_rays; ++t) {
+    blockIdx.x = (unsigned)t;
+    k_dark_zone_rays(cv.M, lambda, (float)tau_max, i_lo, i_hi, zj_sup, r_grid, z_grid, flag);
+  }
+  blockIdx.x = 0;
+  return 0;
+}
+
 extern "C" int emu_stars_map_sed(const oracle_model* m, const oracle_rt_opts* o, uint64_t seed, const double* star_flux,
                                  double* out) {
   if (m->grid_type != 1) return 31;

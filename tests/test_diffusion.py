@@ -10,6 +10,7 @@ import pytest
 
 from mcfost_amd.host import model as M
 from oracle import Oracle
+from test_kernel_emulation import emu  # noqa: F401  (the lane emulator's fixture)
 
 
 def thick_disk():
@@ -125,11 +126,11 @@ def test_dark_zone_and_diffusion_fill_against_brute_force_at_scale():
     cfg.dust_mass = 1e-2
     m = M.build_model(cfg)
     lam = int(np.searchsorted(m.lam, 0.81)) + 1
-    dz = Oracle(m, 1000).define_dark_zone(lam, 1500.0)
-    ri_in, ri_out, zj = M.dark_zone_extent(m, lam, 1500.0)
-    assert dz.sum() > 100 and ri_in >= 2
     n = 20_000_000
     e0 = Engine(m, n)
+    dz, ri_in, ri_out, zj = e0.define_dark_zone(lam, 1500.0)       # the device's own define_dark_zone
+    assert dz.sum() > 100 and ri_in >= 2
+    assert (ri_in, ri_out) == M.dark_zone_extent(m, lam, 1500.0)[:2]
     r0 = e0.run_thermal(n, seed=3)
     T0 = e0.temp_finale(r0["E_abs"])
     e0.close()
@@ -149,3 +150,62 @@ def test_dark_zone_and_diffusion_fill_against_brute_force_at_scale():
           "%d fill iterations" % (d.sum(), np.median(rel), p75_in, np.abs(rel).max(), p75_out, r0["kernel_ms"], r1["kernel_ms"], n_it))
     assert p75_in < 0.05 and abs(np.median(rel)) < 0.02 and p75_out < 0.01
     assert r1["kernel_ms"] < 0.5 * r0["kernel_ms"]
+
+
+def _thick_ref_grid():
+    cfg = M.small(n_rad=30, nz=20, dust_mass=3e-2)
+    m = M.build_model(cfg)
+    lam = int(np.searchsorted(m.lam, 0.81)) + 1
+    return m, lam
+
+
+def test_emulated_dark_zone_rays_against_the_oracle(emu):   # noqa: F811
+    """Step 4 of define_dark_zone on the device source (one ray per thread) against the oracle's sequential version:
+    the same dark cells."""
+    import ctypes as C
+    from oracle.binding import _a, _p
+    m, lam = _thick_ref_grid()
+    o = Oracle(m, 1000)
+    want = o.define_dark_zone(lam, 1500.0)
+    ri_in, ri_out, zj_ext = o.dark_zone_extent(lam, 1500.0)
+    assert want.sum() > 20
+    # the candidate heights before the extension of :1621-1628
+    zj = zj_ext.copy()
+    zj[:ri_in - 1] = 0
+    zj[ri_out:] = 0
+    g = m.grid
+    flag = np.zeros(m.n_cells, np.uint8)
+    rc = emu.emu_dark_zone_rays(C.byref(o.cm), C.c_int(lam), C.c_double(1500.0), C.c_int(max(ri_in, 2)), C.c_int(ri_out),
+                                _p(_a(zj, np.int32), C.c_int), _p(_a(g["r_grid"], np.float64), C.c_double),
+                                _p(_a(g["z_grid"], np.float64), C.c_double), _p(flag, C.c_ubyte))
+    assert rc == 0
+    n_rad, nz = g["n_rad"], g["nz"]
+    got = np.zeros(m.n_cells, np.uint8)
+    F = flag.reshape(nz, n_rad)
+    for i in range(max(ri_in, 2), ri_out + 1):
+        for j in range(zj[i - 1], 0, -1):
+            if F[j - 1, i - 1]:
+                got.reshape(nz, n_rad)[:j, i - 1] = 1
+                break
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.gpu
+def test_device_define_dark_zone_equals_the_oracle():
+    from mcfost_amd.engine import Engine
+    for m, lam in (_thick_ref_grid(), thick_disk()):
+        o = Oracle(m, 1000)
+        want = o.define_dark_zone(lam, 1500.0)
+        ext = o.dark_zone_extent(lam, 1500.0)
+        e = Engine(m, 1000)
+        dz, ri_in, ri_out, zj = e.define_dark_zone(lam, 1500.0)
+        e.close()
+        assert np.array_equal(dz, want) and (ri_in, ri_out) == ext[:2] and np.array_equal(zj, ext[2])
+    cfg = M.ref41()
+    cfg.dust_mass = 1e-2
+    m = M.build_model(cfg)
+    lam = int(np.searchsorted(m.lam, 0.81)) + 1
+    e = Engine(m, 1000)
+    dz, *_ = e.define_dark_zone(lam, 1500.0)
+    e.close()
+    assert np.array_equal(dz, Oracle(m, 1000).define_dark_zone(lam, 1500.0)) and dz.sum() == 301
