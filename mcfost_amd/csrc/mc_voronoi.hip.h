@@ -142,29 +142,22 @@ __device__ inline void voro_cross_cell(const VoroGrid& G, const DevModel& M, con
   next_cell = 0;
   const VoroNb* nb = G.nb + C.first;
   const int cnt = C.count;
-  // four neighbours per trip: their 64 consecutive bytes are requested together (one trip to L2 instead of four),
-  // then tested in the list's order like the reference's loop
-  for (int i0 = 0; i0 < cnt; i0 += 4) {
-    VoroNb N4[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) N4[q] = nb[i0 + q < cnt ? i0 + q : cnt - 1];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const VoroNb N = N4[q];
-      if (i0 + q >= cnt || N.id == previous_cell) continue;
-      if (N.id > 0) {
-        const float n0 = nf_sub(N.x, C.x), n1 = nf_sub(N.y, C.y), n2 = nf_sub(N.z, C.z);
-        const double den = (double)dot3f(n0, n1, n2, k0, k1, k2);
-        const float p0 = nf_mul(0.5f, nf_add(N.x, C.x)), p1 = nf_mul(0.5f, nf_add(N.y, C.y)),
-                    p2 = nf_mul(0.5f, nf_add(N.z, C.z));
-        const double num = (double)dot3f(n0, n1, n2, nf_sub(p0, r0), nf_sub(p1, r1), nf_sub(p2, r2));
-        // den <= 0: skipped; num < 0: the reference sets s_tmp = huge(1.0) > 1e30, never the minimum
-        if (den > 0.0 && !(num < 0.0) && nd_mul(num, s_den) < nd_mul(s_num, den)) { s_num = num; s_den = den; next_cell = N.id; }
-      } else {
-        double s_tmp = voro_distance_to_wall(G, x, y, z, u, v, w, -N.id);
-        if (s_tmp < 0.0) s_tmp = (double)FLT_HUGE;
-        if (s_tmp < s_num / s_den) { s_num = s_tmp; s_den = 1.0; next_cell = N.id; }
-      }
+  for (int i = 0; i < cnt; ++i) {
+    const VoroNb N = nb[i];
+    if (N.id == previous_cell) continue;
+    if (N.id > 0) {
+      const float n0 = nf_sub(N.x, C.x), n1 = nf_sub(N.y, C.y), n2 = nf_sub(N.z, C.z);
+      const double den = (double)dot3f(n0, n1, n2, k0, k1, k2);
+      if (den <= 0.0) continue;
+      const float p0 = nf_mul(0.5f, nf_add(N.x, C.x)), p1 = nf_mul(0.5f, nf_add(N.y, C.y)),
+                  p2 = nf_mul(0.5f, nf_add(N.z, C.z));
+      const double num = (double)dot3f(n0, n1, n2, nf_sub(p0, r0), nf_sub(p1, r1), nf_sub(p2, r2));
+      // num < 0: the reference sets s_tmp = huge(1.0) > 1e30, never the minimum
+      if (!(num < 0.0) && nd_mul(num, s_den) < nd_mul(s_num, den)) { s_num = num; s_den = den; next_cell = N.id; }
+    } else {
+      double s_tmp = voro_distance_to_wall(G, x, y, z, u, v, w, -N.id);
+      if (s_tmp < 0.0) s_tmp = (double)FLT_HUGE;
+      if (s_tmp < s_num / s_den) { s_num = s_tmp; s_den = 1.0; next_cell = N.id; }
     }
   }
   double s = s_num / s_den;
@@ -480,7 +473,7 @@ __global__ void __launch_bounds__(256) k_thermal_voro(const DevModel M, const Ru
   thermal_body_voro<POLA, false>(M, A, G, lds_raw, 0);
 }
 
-// BLOCK = 1024: 4 waves/SIMD at <= 128 VGPRs; BLOCK = 512: 2 waves/SIMD at <= 256 VGPRs
+// BLOCK = 1024: 4 waves/SIMD at <= 128 VGPRs (spills); 768 (default): 3 waves/SIMD at <= 168, no scratch; 512: 2 waves/SIMD
 template <bool POLA, int BLOCK>
 __global__ void __launch_bounds__(BLOCK) k_thermal_voro_cache(const DevModel M, const RunArgs A,
                                                               const VoroGrid G, int cache_log_ns) {

@@ -857,12 +857,15 @@ static int launch_voro(mcgpu_ctx* ctx, const RunArgs& A, int grid_blocks, int bl
   }
   const size_t lds = cache ? lds_t + ((size_t)12 << log_ns) : lds_t;
   const int max_threads = cache ? VORO_CACHE_BLOCK : 256;
-  const int threads = (block_threads > 0 && block_threads <= max_threads) ? block_threads : max_threads;
+  // default 768 threads = 3 waves/SIMD at 168 VGPRs and no scratch; the 1024-thread build (4 waves/SIMD at 128 VGPRs,
+  // 51-66 spilled) measured 3 % faster at most, within the run-to-run noise
+  const int threads = (block_threads > 0 && block_threads <= max_threads) ? block_threads : (cache ? 768 : max_threads);
   if (threads % 64) return fail(ctx, MCGPU_ERR_ARG, "block_threads must be a multiple of 64");
   const bool pola = ctx->lsepar_pola != 0;
-  const bool big = threads > 512;  // which register budget the workgroup was compiled for
+  const bool big = threads > 768, mid = threads > 512 && !big;  // which register budget the workgroup was compiled for
   const void* fn = cache ? (big ? (pola ? (const void*)k_thermal_voro_cache<true, 1024> : (const void*)k_thermal_voro_cache<false, 1024>)
-                                : (pola ? (const void*)k_thermal_voro_cache<true, 512> : (const void*)k_thermal_voro_cache<false, 512>))
+                            : mid ? (pola ? (const void*)k_thermal_voro_cache<true, 768> : (const void*)k_thermal_voro_cache<false, 768>)
+                                  : (pola ? (const void*)k_thermal_voro_cache<true, 512> : (const void*)k_thermal_voro_cache<false, 512>))
                          : (pola ? (const void*)k_thermal_voro<true> : (const void*)k_thermal_voro<false>);
   HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int blocks = grid_blocks;
@@ -877,6 +880,9 @@ static int launch_voro(mcgpu_ctx* ctx, const RunArgs& A, int grid_blocks, int bl
   if (cache && big) {
     if (pola) hipLaunchKernelGGL((k_thermal_voro_cache<true, 1024>), dim3(blocks), dim3(threads), lds, ctx->stream, M, A, ctx->V, log_ns);
     else hipLaunchKernelGGL((k_thermal_voro_cache<false, 1024>), dim3(blocks), dim3(threads), lds, ctx->stream, M, A, ctx->V, log_ns);
+  } else if (cache && mid) {
+    if (pola) hipLaunchKernelGGL((k_thermal_voro_cache<true, 768>), dim3(blocks), dim3(threads), lds, ctx->stream, M, A, ctx->V, log_ns);
+    else hipLaunchKernelGGL((k_thermal_voro_cache<false, 768>), dim3(blocks), dim3(threads), lds, ctx->stream, M, A, ctx->V, log_ns);
   } else if (cache) {
     if (pola) hipLaunchKernelGGL((k_thermal_voro_cache<true, 512>), dim3(blocks), dim3(threads), lds, ctx->stream, M, A, ctx->V, log_ns);
     else hipLaunchKernelGGL((k_thermal_voro_cache<false, 512>), dim3(blocks), dim3(threads), lds, ctx->stream, M, A, ctx->V, log_ns);
