@@ -476,7 +476,7 @@ def test_voronoi_launch_geometry_independence(voro_model):
     e, o = _engine(m, 1e4), _oracle(m, 1e4)
     prior = o.run_thermal(2000, seed=1)["E_abs"]
     ref = e.run_thermal(10000, seed=9, frozen=True, E_prior=prior)
-    for gb, bt in ((1, 64), (7, 128), (300, 256)):
+    for gb, bt in ((1, 64), (7, 128), (300, 256), (3, 768), (2, 1024)):   # (the 512-, 768- and 1024-thread builds)
         r = e.run_thermal(10000, seed=9, frozen=True, E_prior=prior, grid_blocks=gb, block_threads=bt)
         assert r["counters"] == ref["counters"]
         assert np.array_equal(r["sed"][4], ref["sed"][4])
