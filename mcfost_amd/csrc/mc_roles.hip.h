@@ -261,8 +261,8 @@ __device__ __forceinline__ int fly_step_2d(const Lds& T, const DevModel& M, cons
   const int delta_rad = (use_in && !hole) ? -1 : 1;
   const double rac = sqrt(delta);
   const double s1 = (-b - rac) * cp, s2 = (-b + rac) * cp;
-  double s = (s1 < 0.0) ? s2 : ((s1 == 0.0) ? GRID_PREC : s1);
-  s = hole ? s2 : s;
+  const double s_pos = (s1 == 0.0) ? GRID_PREC : s1;
+  const double s = (hole || (s1 < 0.0)) ? s2 : s_pos;
 
   // 2) vertical wall (:1003-1055), 2D: zj >= 1, the midplane mirrors
   const double dz = w * z0;
@@ -274,18 +274,19 @@ __device__ __forceinline__ int fly_step_2d(const Lds& T, const DevModel& M, cons
   zmag = zmag * (away ? cp : cm);
   zmag = (away && top) ? 1.0e10 : zmag;
   const bool neg = (z0 < 0.0) != flip;
-  const double zl = neg ? -zmag : zmag;
+  // zl = neg ? -zmag : zmag (zmag >= 0): the sign bit is set directly
+  const double zl = __longlong_as_double(__double_as_longlong(zmag) | (neg ? (long long)0x8000000000000000ull : 0ll));
   const int delta_zj = away ? (top ? 0 : 1) : ((zj0 == 1) ? 1 : -1);
   double t = (zl - z0) * p.inv_w;
   t = (t < 0.0) ? GRID_PREC : t;
-  t = (dz == 0.0) ? 1.0e10 : t;
-  t = hole ? HUGE_REAL : t;
+  // dz == 0: no vertical wall ahead (1e10, :1052); in the hole the reference does not look for one (:1003): the
+  // same 1e10 serves, being longer than any chord of the hole
+  t = ((dz == 0.0) || hole) ? 1.0e10 : t;
 
   // 3) nearest wall (:1098-1156)
   const bool rad = (s < t);
   const double l = rad ? s : t;
-  const double x1 = x0 + l * u;
-  const double y1 = y0 + l * v;
+  // (x1, y1 = x0 + l u, y0 + l v are formed in the commit below, together with the stopping point)
   // products rounded before the sum, like the reference build (see cross_cell_lean)
   double z1 = nd_add(z0, nd_mul(l, w));
   const int ri1 = rad ? ri0 + delta_rad : ri0;
@@ -325,14 +326,17 @@ __device__ __forceinline__ int fly_step_2d(const Lds& T, const DevModel& M, cons
   const double kf1 = M.kappa_factor[ic1];   // (lanes without a next cell read cell 0 and drop it)
 
   // 5) commit
-  const double xs = x0 + lc * u, ys = y0 + lc * v, zs = z0 + lc * w;
-  p.x = stop ? xs : (move ? x1 : x0);
-  p.y = stop ? ys : (move ? y1 : y0);
+  // x and y: one multiply-add with the length that applies (l to the wall, lc to the stopping point, 0: the packet
+  // stays) instead of selecting among three finished points -- the same x0 + l u / x0 + lc u as before
+  const double lf = stop ? lc : (move ? l : 0.0);
+  const double zs = z0 + lc * w;
+  p.x = x0 + lf * u;
+  p.y = y0 + lf * v;
   p.z = stop ? zs : (move ? z1 : z0);
   p.extr = (go && !stop) ? p.extr - tau : p.extr;
   p.ri = move ? ri1 : ri0;
   p.zj = move ? zj1 : zj0;
-  p.kf = move ? (next_real ? kf1 : 0.0) : p.kf;
+  p.kf = move ? kf1 : p.kf;  // (outside the real cells kf is not read: the opacity there is 0 by the test on real_cell)
   if (DARK) {
     p.u = mirror ? -u : u; p.v = mirror ? -v : v; p.w = mirror ? -w : w;
     c_dark += mirror ? 1u : 0u;

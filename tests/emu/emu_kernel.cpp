@@ -58,6 +58,7 @@ static inline int atomicExch(int* p, int v) { int o = *p; *p = v; return o; }
 static inline int atomicCAS(int* p, int cmp, int v) { int o = *p; if (o == cmp) *p = v; return o; }
 static inline unsigned int atomicCAS(unsigned int* p, unsigned int cmp, unsigned int v) { unsigned int o = *p; if (o == cmp) *p = v; return o; }
 static inline double __longlong_as_double(long long b) { double d; memcpy(&d, &b, 8); return d; }
+static inline long long __double_as_longlong(double d) { long long b; memcpy(&b, &d, 8); return b; }
 static inline double atomicAdd(double* p, double v) { double o = *p; *p += v; return o; }
 static inline float atomicAdd(float* p, float v) { float o = *p; *p += v; return o; }
 namespace mcgpu {  // the device source's unfused helpers (mc_device.hip.h), for the host compiler
