@@ -270,7 +270,8 @@ __device__ __forceinline__ int fly_step_2d(const Lds& T, const DevModel& M, cons
   const bool flip = !away && (zj0 == 1);  // through the midplane to the mirror side
   const int jsel = away ? zj0 + 1 : (zj0 == 1 ? 2 : zj0);
   const double chr = T.ch[row_in], zmr = T.zmax[row_in];
-  double zmag = (jsel <= nz) ? ((double)jsel - 1.0) * chr : ((jsel == nz + 1) ? zmr : 1.00000001504746621988e+30);
+  // (jsel = nz + 2, where z_lim is 1e30, only occurs for away && top, which the 1e10 below replaces)
+  double zmag = (jsel <= nz) ? ((double)jsel - 1.0) * chr : zmr;
   zmag = zmag * (away ? cp : cm);
   zmag = (away && top) ? 1.0e10 : zmag;
   const bool neg = (z0 < 0.0) != flip;
@@ -285,7 +286,7 @@ __device__ __forceinline__ int fly_step_2d(const Lds& T, const DevModel& M, cons
 
   // 3) nearest wall (:1098-1156)
   const bool rad = (s < t);
-  const double l = rad ? s : t;
+  const double l = fmin(s, t);  // (= rad ? s : t; both are finite)
   // (x1, y1 = x0 + l u, y0 + l v are formed in the commit below, together with the stopping point)
   // products rounded before the sum, like the reference build (see cross_cell_lean)
   double z1 = nd_add(z0, nd_mul(l, w));
