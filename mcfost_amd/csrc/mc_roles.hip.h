@@ -310,7 +310,9 @@ __device__ __forceinline__ int fly_step_2d(const Lds& T, const DevModel& M, cons
 
   // 4) optical depth of the crossing, stop or go on (optical_depth.f90:102, 134-146)
   // (kf was loaded at the end of the previous crossing: first used here, behind the geometry)
-  const double opacity = real_cell ? p.kap * p.kf : 0.0;
+  // (outside the real cells p.kf = 0: flight_constants sets it so, and the commit below reads the zero entry that
+  // ends the device's kappa_factor array)
+  const double opacity = p.kap * p.kf;
   const double tau = l * opacity;
   const bool stop = go && (tau > p.extr);
   double lc = l;
@@ -320,16 +322,16 @@ __device__ __forceinline__ int fly_step_2d(const Lds& T, const DevModel& M, cons
 
   // the next cell; DARK: mirrored back at the wall of a dark cell (see roles_cross)
   const bool next_real = (ri1 >= 1) && (ri1 <= n_rad) && (zj1 >= 1) && (zj1 <= nz);
-  const int ic1 = next_real ? (ri1 - 1) + n_rad * (zj1 - 1) : 0;
+  const int ic1 = next_real ? (ri1 - 1) + n_rad * (zj1 - 1) : M.n_cells;  // (n_cells: the entry of "no cell", 0)
   bool mirror = false;
-  if (DARK) mirror = go && !stop && next_real && M.dark[ic1];
+  if (DARK) mirror = go && !stop && next_real && M.dark[next_real ? ic1 : 0];
   const bool move = go && !stop && !mirror;
-  const double kf1 = M.kappa_factor[ic1];   // (lanes without a next cell read cell 0 and drop it)
+  const double kf1 = M.kappa_factor[ic1];
 
   // 5) commit
   // x and y: one multiply-add with the length that applies (l to the wall, lc to the stopping point, 0: the packet
   // stays) instead of selecting among three finished points -- the same x0 + l u / x0 + lc u as before
-  const double lf = stop ? lc : (move ? l : 0.0);
+  const double lf = (stop || move) ? lc : 0.0;  // (lc = l unless the packet stops)
   const double zs = z0 + lc * w;
   p.x = x0 + lf * u;
   p.y = y0 + lf * v;
@@ -337,7 +339,7 @@ __device__ __forceinline__ int fly_step_2d(const Lds& T, const DevModel& M, cons
   p.extr = (go && !stop) ? p.extr - tau : p.extr;
   p.ri = move ? ri1 : ri0;
   p.zj = move ? zj1 : zj0;
-  p.kf = move ? kf1 : p.kf;  // (outside the real cells kf is not read: the opacity there is 0 by the test on real_cell)
+  p.kf = move ? kf1 : p.kf;
   if (DARK) {
     p.u = mirror ? -u : u; p.v = mirror ? -v : v; p.w = mirror ? -w : w;
     c_dark += mirror ? 1u : 0u;

@@ -448,7 +448,11 @@ extern "C" int mcgpu_set_opacity(mcgpu_ctx* ctx, int n_lambda, const double* kap
   if ((rc = upload(ctx, kappa, (size_t)n_lambda, &M.kappa))) return rc;
   if ((rc = upload(ctx, kappa_abs_LTE, (size_t)n_lambda, &M.kappa_abs))) return rc;
   if ((rc = upload(ctx, tab_albedo_pos, (size_t)n_lambda, &M.albedo))) return rc;
-  if ((rc = upload(ctx, kappa_factor, (size_t)M.n_cells, &M.kappa_factor))) return rc;
+  {  // one extra entry, 0: the factor of "no cell" (the 2D crossing reads it for the virtual cells, mc_roles.hip.h)
+    std::vector<double> kfp((size_t)M.n_cells + 1, 0.0);
+    std::memcpy(kfp.data(), kappa_factor, (size_t)M.n_cells * sizeof(double));
+    if ((rc = upload(ctx, kfp.data(), kfp.size(), &M.kappa_factor))) return rc;
+  }
   M.dark = nullptr;
   if (l_dark_zone) {
     bool any = false;

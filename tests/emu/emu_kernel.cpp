@@ -89,7 +89,7 @@ struct Conv {
   DevModel M;
   VoroGrid G;
   bool voro;
-  std::vector<double> ch, sx, ct, vk, vka;
+  std::vector<double> ch, sx, ct, vk, vka, kfpad;
   std::vector<float> val, vsc[7];
   std::vector<int> sc, vcls;
   std::vector<VoroCell> vcell;
@@ -139,7 +139,8 @@ struct Conv {
     }
     M.star_xyzr = sx.data(); M.star_cell = sc.data();
     M.n_lambda = m->n_lambda; M.kappa = m->kappa; M.kappa_abs = m->kappa_abs_LTE; M.albedo = m->albedo;
-    M.kappa_factor = m->kappa_factor;
+    kfpad.assign(m->kappa_factor, m->kappa_factor + m->n_cells); kfpad.push_back(0.0);  // (+ the entry of "no cell")
+    M.kappa_factor = kfpad.data();
     bool any_dark = false;
     if (m->l_dark_zone) for (int i = 0; i < m->n_cells; ++i) any_dark |= m->l_dark_zone[i] != 0;
     M.dark = any_dark ? m->l_dark_zone : nullptr;
