@@ -332,11 +332,11 @@ __device__ __forceinline__ int fly_step_2d(const Lds& T, const DevModel& M, cons
   // x and y: one multiply-add with the length that applies (l to the wall, lc to the stopping point, 0: the packet
   // stays) instead of selecting among three finished points -- the same x0 + l u / x0 + lc u as before
   const double lf = (stop || move) ? lc : 0.0;  // (lc = l unless the packet stops)
-  const double zs = z0 + lc * w;
   p.x = x0 + lf * u;
   p.y = y0 + lf * v;
-  p.z = stop ? zs : (move ? z1 : z0);
-  p.extr = (go && !stop) ? p.extr - tau : p.extr;
+  p.z = move ? z1 : z0 + lf * w;  // (the wall point z1 keeps its own rounding and zero fix; stopping point / stay as x, y)
+  // (a packet that stopped, left or was not in flight does not read extr again before its next flight sets it)
+  p.extr = p.extr - tau;
   p.ri = move ? ri1 : ri0;
   p.zj = move ? zj1 : zj0;
   p.kf = move ? kf1 : p.kf;
