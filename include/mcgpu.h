@@ -212,7 +212,9 @@ int mcgpu_set_scattering(mcgpu_ctx *ctx, int nang_scatt, int aniso_method,
  *   frac_E_stars[n_lambda], frac_E_disk[n_lambda],
  *   CDF_E_star(n_lambda,0:n_stars) (stars.f90:575-604),
  *   prob_E_cell(0:n_cells,n_lambda) or NULL when frac_E_stars == 1,
- *   L_packet_th (:355-356), T_min (parameters.f90:269). */
+ *   L_packet_th (:355-356), T_min (parameters.f90:269).
+ * log_Qcool and kdB_dT_CDF may both be NULL: mcgpu_init_reemission then builds them on the device (a launch before
+ * that call fails with MCGPU_ERR_STATE). */
 int mcgpu_set_thermal(mcgpu_ctx *ctx, int n_T, const float *tab_Temp,
                       const double *log_Qcool, const double *kdB_dT_CDF,
                       const double *spectre_emission_cumul,
@@ -459,7 +461,7 @@ int mcgpu_probe_packet_rand(mcgpu_ctx *ctx, uint64_t seed, uint64_t packet,
  * p_n_cells may be smaller than n_cells (classes of cells with the same dust).  The thermal step then runs the
  * HBM-gather variant of the single-role kernel and mcgpu_temp_finale reads log_Qcool per class.  The SED mode, the
  * ray tracing, the random walk and the diffusion fill are not built for it and refuse such a context.
- * p_n_cells = 0: off.
+ * p_n_cells = 0: off.  log_Qcool and kdB_dT_CDF may both be NULL (see mcgpu_init_reemission).
  */
 int mcgpu_set_variable_dust(mcgpu_ctx *ctx, int p_n_cells, const int *p_icell, const double *kappa,
                             const double *kappa_abs_LTE, const float *tab_albedo_pos,
@@ -467,6 +469,23 @@ int mcgpu_set_variable_dust(mcgpu_ctx *ctx, int p_n_cells, const int *p_icell, c
                             const float *tab_s12_o_s11_pos, const float *tab_s22_o_s11_pos,
                             const float *tab_s33_o_s11_pos, const float *tab_s34_o_s11_pos,
                             const float *tab_s44_o_s11_pos, const float *tab_g_pos);
+
+/*
+ * init_reemission on the device (thermal_emission.f90:404-550, the LTE part: lines 431-452 the Planck function and its
+ * temperature derivative per wavelength bin, 464-513 the cooling rate, 533-549 the re-emission CDF).  Rebuilds every
+ * re-emission table of the context from the kappa_abs_LTE it already holds -- the single class of mcgpu_set_opacity
+ * and, with mcgpu_set_variable_dust, every class -- on the temperature grid of mcgpu_set_thermal:
+ *   log_Qcool_minus_extra_heating(T, p_icell) = log( cst_E sum_lambda kappa_abs_LTE B_lambda(T) dlambda - the same at
+ *                                               tab_Temp(1) ),  -1000 where that is not positive
+ *   kdB_dT_CDF(lambda, T, p_icell)            = running sum of kappa_abs_LTE dB_lambda/dT dlambda, normalised
+ * so the host need not build or upload them (with lvariable_dust: n_lambda * n_T * p_n_cells doubles, 280 MB at 7000
+ * cells, mem.f90:213-244).  tab_lambda / tab_delta_lambda [n_lambda] in micron (module wavelengths).  Outputs, either
+ * may be NULL: the tables in the reference's layouts (of the classes when variable dust is set, else of the single
+ * class).  Not built: lextra_heating / dudt (the Phantom coupling's non-radiative heating term, :486-494) and the
+ * per-grain tables of the non-LTE / non-equilibrium grains (:517-532, 552-619).
+ */
+int mcgpu_init_reemission(mcgpu_ctx *ctx, const double *tab_lambda, const double *tab_delta_lambda,
+                          double *log_Qcool, double *kdB_dT_CDF);
 
 /*
  * The optional accumulators of save_radiation_field's thermal branch (radiation_field.f90:54-55):

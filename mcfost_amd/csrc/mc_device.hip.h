@@ -1845,6 +1845,56 @@ __global__ void k_temp_finale(const DevModel M, const double* E_abs, const float
 }
 
 // ---------------------------------------------------------------------------
+// init_reemission (thermal_emission.f90:404-550), the LTE tables: log_Qcool_minus_extra_heating(T, p_icell) and
+// kdB_dT_CDF(lambda, T, p_icell), built where they are used (with lvariable_dust they are 280 MB at 7000 cells,
+// mem.f90:213-244).  One thread per (class, T): the wavelength sums run in the reference's order.  No extra heating
+// (lextra_heating off): the floor is the cooling rate at tab_Temp(1) (:483-485).
+// ---------------------------------------------------------------------------
+// sum over lambda of kappa_abs_LTE * B(lambda, T) (:431-452, :468-473); row (may be null) receives the running sum of
+// kappa_abs_LTE * dB_dT (:536-541)
+__device__ inline double reemission_sums(double Temp, int n_lambda, const double* tab_lambda, const double* tab_delta_lambda,
+                                         const double* ka, double* row) {
+  const float thermal_const = (float)(299792458.0 * 6.626070040e-34 / 1.38064852e-23);  // constants.f90:24
+  const double cst = (double)thermal_const / Temp;
+  double integ = 0.0, integ3 = 0.0;
+  for (int l = 0; l < n_lambda; ++l) {
+    const double wl = tab_lambda[l] * (double)1.e-6f;  // default-real literals (:439-440)
+    const double delta_wl = tab_delta_lambda[l] * (double)1.e-6f;
+    const double cst_wl = cst / wl;
+    double B = 0.0, dB_dT = 0.0;
+    if (cst_wl < 500.0) {
+      const double coeff_exp = exp(cst_wl);
+      const double wl2 = wl * wl, wl5 = (wl2 * wl2) * wl;
+      B = 1.0 / (wl5 * (coeff_exp - 1.0)) * delta_wl;
+      dB_dT = B * cst_wl * coeff_exp / (coeff_exp - 1.0);
+    }
+    integ = integ + ka[l] * B;
+    integ3 = integ3 + ka[l] * dB_dT;
+    if (row) row[l] = integ3;
+  }
+  return integ;
+}
+
+__global__ void k_init_reemission(int n_classes, int n_T, int n_lambda, const float* tab_Temp, const double* tab_lambda,
+                                  const double* tab_delta_lambda, const double* kabs, double* lq, double* cdf) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_classes * n_T) return;
+  const int c = idx / n_T, t = idx - c * n_T;
+  const double* ka = kabs + (size_t)c * n_lambda;
+  double* row = cdf + ((size_t)c * n_T + t) * n_lambda;
+  const double cst_E = 2.0 * 6.626070040e-34 * (299792458.0 * 299792458.0) * (4.0 * PI);  // :427
+  const double Qcool = reemission_sums((double)tab_Temp[t], n_lambda, tab_lambda, tab_delta_lambda, ka, row) * cst_E;
+  // (T = 1 is its own floor, exactly: the two inlined sums need not contract alike)
+  const double Qcool0 =
+      (t == 0) ? Qcool : reemission_sums((double)tab_Temp[0], n_lambda, tab_lambda, tab_delta_lambda, ka, nullptr) * cst_E;
+  const double q = Qcool - Qcool0;
+  lq[(size_t)c * n_T + t] = (q > TINY_DP) ? log(q) : -1000.0;  // :496-504
+  const double tot = row[n_lambda - 1];
+  const bool ok = tot > TINY_DP;                               // :544-548 (the table stays 0 otherwise)
+  for (int l = 0; l < n_lambda; ++l) row[l] = ok ? row[l] / tot : 0.0;
+}
+
+// ---------------------------------------------------------------------------
 // Temp_approx_diffusion_vertical (diffusion.f90:292-374): the 1+1D diffusion fill of the dark zone (2D cylindrical
 // grids).  One workgroup per radius; the column's energy density, its previous value and the diffusion coefficients
 // live in LDS; a pseudo-time step of the explicit scheme is three block-wide phases (time step = minimum over the

@@ -47,6 +47,7 @@ struct mcgpu_ctx {
   DevModel M;
   bool have_grid = false, have_stars = false, have_opacity = false, have_scatt = false,
        have_thermal = false, have_sed = false;
+  bool reemission_pending = false;  // set_thermal / set_variable_dust left the LTE tables to mcgpu_init_reemission
   int lsepar_pola = 0;
   float T_min = 1.0f;
   // mcgpu_set_option
@@ -98,11 +99,14 @@ struct mcgpu_ctx {
     }                                                                             \
   } while (0)
 
+// n values from the host into a new device array of max(n, n_alloc) values (the rest zeroed)
 template <typename Tp>
-static int upload(mcgpu_ctx* ctx, const Tp* host, size_t n, const Tp** dev_out) {
+static int upload(mcgpu_ctx* ctx, const Tp* host, size_t n, const Tp** dev_out, size_t n_alloc = 0) {
   Tp* d = nullptr;
-  HIPCHK(hipMalloc((void**)&d, (n ? n : 1) * sizeof(Tp)));
+  const size_t na = n_alloc > n ? n_alloc : n;
+  HIPCHK(hipMalloc((void**)&d, (na ? na : 1) * sizeof(Tp)));
   ctx->allocs.push_back(d);
+  if (na > n) HIPCHK(hipMemset(d, 0, na * sizeof(Tp)));
   if (n) HIPCHK(hipMemcpy(d, host, n * sizeof(Tp), hipMemcpyHostToDevice));
   *dev_out = d;
   return MCGPU_OK;
@@ -509,11 +513,11 @@ extern "C" int mcgpu_set_thermal(mcgpu_ctx* ctx, int n_T, const float* tab_Temp,
                                  const double* frac_E_stars, const double* frac_E_disk,
                                  const double* CDF_E_star, const double* prob_E_cell, double L_packet_th,
                                  float T_min) {
-  if (!ctx || n_T < 2 || !tab_Temp || !log_Qcool || !kdB_dT_CDF || !spectre_emission_cumul || !frac_E_stars ||
-      !frac_E_disk || !CDF_E_star)
+  if (!ctx || n_T < 2 || !tab_Temp || !spectre_emission_cumul || !frac_E_stars || !frac_E_disk || !CDF_E_star ||
+      ((log_Qcool == nullptr) != (kdB_dT_CDF == nullptr)))
     return fail(ctx, MCGPU_ERR_ARG, "mcgpu_set_thermal: bad argument");
   if (!ctx->have_opacity || !ctx->have_stars) return fail(ctx, MCGPU_ERR_STATE, "set opacities and stars first");
-  for (int t = 2; t < n_T; ++t)
+  for (int t = 2; log_Qcool && t < n_T; ++t)
     if (log_Qcool[t] < log_Qcool[t - 1]) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "log_Qcool must increase with T");
   HIPCHK(hipSetDevice(ctx->device));
   DevModel& M = ctx->M;
@@ -523,8 +527,10 @@ extern "C" int mcgpu_set_thermal(mcgpu_ctx* ctx, int n_T, const float* tab_Temp,
   const float* tt;
   if ((rc = upload(ctx, tab_Temp, (size_t)n_T, &tt))) return rc;
   ctx->d_tab_Temp = (float*)tt;
-  if ((rc = upload(ctx, log_Qcool, (size_t)n_T, &M.log_Qcool))) return rc;
-  if ((rc = upload(ctx, kdB_dT_CDF, (size_t)n_T * M.n_lambda, &M.cdf))) return rc;
+  // both NULL: the two re-emission tables are left to mcgpu_init_reemission (a launch before it is refused)
+  ctx->reemission_pending = (log_Qcool == nullptr);
+  if ((rc = upload(ctx, log_Qcool, log_Qcool ? (size_t)n_T : 0, &M.log_Qcool, (size_t)n_T))) return rc;
+  if ((rc = upload(ctx, kdB_dT_CDF, kdB_dT_CDF ? (size_t)n_T * M.n_lambda : 0, &M.cdf, (size_t)n_T * M.n_lambda))) return rc;
   if ((rc = upload(ctx, spectre_emission_cumul, (size_t)M.n_lambda + 1, &M.spec_cum))) return rc;
   if ((rc = upload(ctx, frac_E_stars, (size_t)M.n_lambda, &M.frac_E_stars))) return rc;
   if ((rc = upload(ctx, frac_E_disk, (size_t)M.n_lambda, &M.frac_E_disk))) return rc;
@@ -549,7 +555,8 @@ extern "C" int mcgpu_set_variable_dust(mcgpu_ctx* ctx, int p_n_cells, const int*
   if (!ctx) return MCGPU_ERR_ARG;
   DevModel& M = ctx->M;
   if (p_n_cells == 0) { M.n_classes = 0; return MCGPU_OK; }  // back to one class
-  if (p_n_cells < 1 || !p_icell || !kappa || !kappa_abs_LTE || !tab_albedo_pos || !log_Qcool || !kdB_dT_CDF)
+  if (p_n_cells < 1 || !p_icell || !kappa || !kappa_abs_LTE || !tab_albedo_pos ||
+      ((log_Qcool == nullptr) != (kdB_dT_CDF == nullptr)))
     return fail(ctx, MCGPU_ERR_ARG, "mcgpu_set_variable_dust: bad argument");
   if (!ctx->have_grid || !ctx->have_opacity || !ctx->have_thermal)
     return fail(ctx, MCGPU_ERR_STATE, "set the grid, the opacities and the thermal tables first");
@@ -557,7 +564,7 @@ extern "C" int mcgpu_set_variable_dust(mcgpu_ctx* ctx, int p_n_cells, const int*
   for (int i = 0; i < M.n_cells; ++i)
     if (p_icell[i] < 1 || p_icell[i] > p_n_cells) return fail(ctx, MCGPU_ERR_ARG, "mcgpu_set_variable_dust: p_icell out of range");
   const int nc = p_n_cells, nl = M.n_lambda, nT = M.n_T;
-  for (int c = 0; c < nc; ++c)
+  for (int c = 0; log_Qcool && c < nc; ++c)
     for (int t = 2; t < nT; ++t)
       if (log_Qcool[(size_t)c * nT + t] < log_Qcool[(size_t)c * nT + t - 1])
         return fail(ctx, MCGPU_ERR_UNSUPPORTED, "log_Qcool must increase with T");
@@ -579,8 +586,10 @@ extern "C" int mcgpu_set_variable_dust(mcgpu_ctx* ctx, int p_n_cells, const int*
   if ((rc = upload(ctx, ka.data(), ka.size(), &M.v_kabs))) return rc;
   if ((rc = upload(ctx, al.data(), al.size(), &M.v_albedo))) return rc;
   // log_Qcool_minus_extra_heating(n_T, p_n_cells) and kdB_dT_CDF(n_lambda, n_T, p_n_cells): class slowest already
-  if ((rc = upload(ctx, log_Qcool, (size_t)nc * nT, &M.v_lq))) return rc;
-  if ((rc = upload(ctx, kdB_dT_CDF, (size_t)nc * nT * nl, &M.v_cdf))) return rc;
+  // (both NULL: left to mcgpu_init_reemission -- 280 MB at 7000 classes that never cross the bus)
+  if (!log_Qcool) ctx->reemission_pending = true;
+  if ((rc = upload(ctx, log_Qcool, log_Qcool ? (size_t)nc * nT : 0, &M.v_lq, (size_t)nc * nT))) return rc;
+  if ((rc = upload(ctx, kdB_dT_CDF, kdB_dT_CDF ? (size_t)nc * nT * nl : 0, &M.v_cdf, (size_t)nc * nT * nl))) return rc;
   // scattering tables per class (all or none): (0:nang, p_n_cells, n_lambda) in the reference -> [class][lambda][angle]
   M.v_scatt = 0;
   const bool any_sc = prob_s11_pos || tab_s12_o_s11_pos || tab_s22_o_s11_pos || tab_s33_o_s11_pos || tab_s34_o_s11_pos ||
@@ -611,6 +620,52 @@ extern "C" int mcgpu_set_variable_dust(mcgpu_ctx* ctx, int p_n_cells, const int*
     M.v_scatt = 1;
   }
   M.n_classes = nc;
+  return MCGPU_OK;
+}
+
+// init_reemission on the device (thermal_emission.f90:404-550): see include/mcgpu.h
+extern "C" int mcgpu_init_reemission(mcgpu_ctx* ctx, const double* tab_lambda, const double* tab_delta_lambda,
+                                     double* log_Qcool, double* kdB_dT_CDF) {
+  if (!ctx || !tab_lambda || !tab_delta_lambda) return fail(ctx, MCGPU_ERR_ARG, "mcgpu_init_reemission: bad argument");
+  if (!ctx->have_opacity || !ctx->have_thermal) return fail(ctx, MCGPU_ERR_STATE, "set the opacities and the thermal tables first");
+  HIPCHK(hipSetDevice(ctx->device));
+  DevModel& M = ctx->M;
+  const int nl = M.n_lambda, nT = M.n_T;
+  for (int l = 0; l < nl; ++l)
+    if (!(tab_lambda[l] > 0.0) || !(tab_delta_lambda[l] > 0.0))
+      return fail(ctx, MCGPU_ERR_ARG, "mcgpu_init_reemission: wavelengths and bin widths must be positive");
+  double *d_lam = nullptr, *d_dlam = nullptr;
+  HIPCHK(hipMalloc((void**)&d_lam, 2 * (size_t)nl * sizeof(double)));
+  d_dlam = d_lam + nl;
+  hipError_t e = hipMemcpy(d_lam, tab_lambda, (size_t)nl * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_dlam, tab_delta_lambda, (size_t)nl * sizeof(double), hipMemcpyHostToDevice);
+  auto build = [&](int nc, const double* kabs, const double* lq, const double* cdf) {
+    const int n = nc * nT, threads = 64;  // one (class, T) row per thread: short rows, many of them
+    hipLaunchKernelGGL(k_init_reemission, dim3((n + threads - 1) / threads), dim3(threads), 0, ctx->stream, nc, nT, nl,
+                       ctx->d_tab_Temp, d_lam, d_dlam, kabs, const_cast<double*>(lq), const_cast<double*>(cdf));
+  };
+  if (e == hipSuccess) {
+    build(1, M.kappa_abs, M.log_Qcool, M.cdf);
+    if (M.n_classes) build(M.n_classes, M.v_kabs, M.v_lq, M.v_cdf);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  // the same gate as the setters: Temp_LTE's search needs log_Qcool to increase with T
+  const int nc = M.n_classes ? M.n_classes : 1;
+  const double* d_lq = M.n_classes ? M.v_lq : M.log_Qcool;
+  const double* d_cdf = M.n_classes ? M.v_cdf : M.cdf;
+  std::vector<double> lq((size_t)nc * nT);
+  if (e == hipSuccess) e = hipMemcpy(lq.data(), d_lq, lq.size() * sizeof(double), hipMemcpyDeviceToHost);
+  if (e == hipSuccess && kdB_dT_CDF)
+    e = hipMemcpy(kdB_dT_CDF, d_cdf, (size_t)nc * nT * nl * sizeof(double), hipMemcpyDeviceToHost);
+  hipFree(d_lam);
+  if (e != hipSuccess) return fail(ctx, MCGPU_ERR_HIP, hipGetErrorString(e));
+  if (log_Qcool) std::memcpy(log_Qcool, lq.data(), lq.size() * sizeof(double));
+  for (int c = 0; c < nc; ++c)
+    for (int t = 2; t < nT; ++t)
+      if (lq[(size_t)c * nT + t] < lq[(size_t)c * nT + t - 1])
+        return fail(ctx, MCGPU_ERR_UNSUPPORTED, "log_Qcool must increase with T");
+  ctx->reemission_pending = false;
   return MCGPU_OK;
 }
 
@@ -672,6 +727,8 @@ static int ready(mcgpu_ctx* ctx) {
   if (!(ctx->have_grid && ctx->have_stars && ctx->have_opacity && ctx->have_scatt && ctx->have_thermal &&
         ctx->have_sed))
     return fail(ctx, MCGPU_ERR_STATE, "model incomplete: call every mcgpu_set_* first");
+  if (ctx->reemission_pending)
+    return fail(ctx, MCGPU_ERR_STATE, "the re-emission tables were left to mcgpu_init_reemission: call it first");
   return MCGPU_OK;
 }
 

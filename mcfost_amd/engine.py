@@ -35,7 +35,7 @@ ABI_SYMBOLS = (
     "mcgpu_probe_cross_voronoi", "mcgpu_set_rt1", "mcgpu_run_mono", "mcgpu_fetch_xI",
     "mcgpu_device_xI", "mcgpu_set_ism", "mcgpu_rt1_dust_map", "mcgpu_set_xI", "mcgpu_rt1_image", "mcgpu_set_xI_precision",
     "mcgpu_get_xI_precision", "mcgpu_set_option", "mcgpu_counters_to_accum", "mcgpu_counters_from_accum",
-    "mcgpu_set_grid_sph", "mcgpu_temp_approx_diffusion_vertical", "mcgpu_set_mrw", "mcgpu_fetch_radiation_field", "mcgpu_set_variable_dust", "mcgpu_rt1_stars_map_sed", "mcgpu_define_dark_zone", "mcgpu_multi_create", "mcgpu_multi_destroy", "mcgpu_multi_size", "mcgpu_multi_ctx", "mcgpu_multi_last_error",
+    "mcgpu_set_grid_sph", "mcgpu_temp_approx_diffusion_vertical", "mcgpu_set_mrw", "mcgpu_fetch_radiation_field", "mcgpu_set_variable_dust", "mcgpu_rt1_stars_map_sed", "mcgpu_define_dark_zone", "mcgpu_init_reemission", "mcgpu_multi_create", "mcgpu_multi_destroy", "mcgpu_multi_size", "mcgpu_multi_ctx", "mcgpu_multi_last_error",
     "mcgpu_shard_packets", "mcgpu_multi_run_thermal",
 )
 
@@ -221,7 +221,9 @@ class Engine:
         pe = getattr(m, "prob_E_cell", None)
         self._chk(L.mcgpu_set_thermal(
             self.ctx, C.c_int(m.tab_Temp.size), _p(_a(m.tab_Temp, f), C.c_float),
-            _p(_a(m.log_Qcool, d), C.c_double), _p(_a(m.kdB_dT_CDF, d), C.c_double),
+            # (both None: the tables are left to init_reemission(), i.e. built on the device)
+            None if m.log_Qcool is None else _p(_a(m.log_Qcool, d), C.c_double),
+            None if m.kdB_dT_CDF is None else _p(_a(m.kdB_dT_CDF, d), C.c_double),
             _p(_a(m.spectre_emission_cumul, d), C.c_double), _p(_a(m.frac_E_stars, d), C.c_double),
             _p(_a(m.frac_E_disk, d), C.c_double), _p(_a(m.CDF_E_star, d), C.c_double),
             None if pe is None else _p(_a(pe, d), C.c_double),
@@ -244,11 +246,27 @@ class Engine:
         self._chk(self.lib.mcgpu_set_variable_dust(
             self.ctx, C.c_int(int(vd["p_n_cells"])), _p(_a(vd["p_icell"], np.int32), C.c_int),
             _p(_a(vd["kappa"], d), C.c_double), _p(_a(vd["kappa_abs_LTE"], d), C.c_double),
-            _p(_a(vd["albedo"], np.float32), C.c_float), _p(_a(vd["log_Qcool"], d), C.c_double),
-            _p(_a(vd["kdB_dT_CDF"], d), C.c_double),
+            _p(_a(vd["albedo"], np.float32), C.c_float),
+            None if vd.get("log_Qcool") is None else _p(_a(vd["log_Qcool"], d), C.c_double),
+            None if vd.get("kdB_dT_CDF") is None else _p(_a(vd["kdB_dT_CDF"], d), C.c_double),
             *[(_p(_a(vd[k], np.float32), C.c_float) if vd.get("prob_s11_pos") is not None else None)
               for k in ("prob_s11_pos", "s12_o_s11", "s22_o_s11", "s33_o_s11", "s34_o_s11", "s44_o_s11", "tab_g_pos")]),
             "mcgpu_set_variable_dust")
+
+    def init_reemission(self, fetch=True):
+        """``init_reemission`` (thermal_emission.f90:404-550) on the device: rebuilds ``log_Qcool_minus_extra_heating``
+        and ``kdB_dT_CDF`` of the context (of every class with variable dust) from its ``kappa_abs_LTE``.  Returns
+        ``(log_Qcool [classes, n_T], kdB_dT_CDF [classes, n_T, n_lambda])`` when ``fetch``."""
+        m = self.model
+        vd = getattr(m, "variable_dust", None)
+        nc = int(vd["p_n_cells"]) if vd is not None else 1
+        nT, nl = m.tab_Temp.size, m.n_lambda
+        lq = np.zeros((nc, nT), np.float64) if fetch else None
+        cdf = np.zeros((nc, nT, nl), np.float64) if fetch else None
+        self._chk(self.lib.mcgpu_init_reemission(
+            self.ctx, _p(_a(m.lam, np.float64), C.c_double), _p(_a(m.delta_lam, np.float64), C.c_double),
+            _p(lq, C.c_double) if fetch else None, _p(cdf, C.c_double) if fetch else None), "mcgpu_init_reemission")
+        return lq, cdf
 
     def set_mrw(self, mrw):
         """Tables of the modified random walk (``mcfost_amd.host.model.init_mrw``); ``None`` switches it off."""

@@ -69,7 +69,7 @@ module mcgpu_f
        mcgpu_run_mono, mcgpu_fetch, mcgpu_fetch_xI, mcgpu_rt1_dust_map, mcgpu_set_xI, mcgpu_rt1_image, mcgpu_set_xI_precision, &
        mcgpu_set_E_prior, mcgpu_multi_create, mcgpu_multi_destroy, mcgpu_multi_size, mcgpu_multi_ctx, mcgpu_multi_run_thermal, &
        mcgpu_counters_to_accum, mcgpu_counters_from_accum, mcgpu_temp_approx_diffusion_vertical, mcgpu_set_mrw, mcgpu_fetch_radiation_field, &
-       mcgpu_set_variable_dust, mcgpu_rt1_stars_map_sed, mcgpu_define_dark_zone
+       mcgpu_set_variable_dust, mcgpu_rt1_stars_map_sed, mcgpu_define_dark_zone, mcgpu_init_reemission
 
   interface
      integer(c_int) function mcgpu_create(device, ctx) bind(C, name="mcgpu_create")
@@ -234,6 +234,17 @@ module mcgpu_f
        type(c_ptr), value :: prob_s11_pos, tab_s12_o_s11_pos, tab_s22_o_s11_pos, tab_s33_o_s11_pos, &
             tab_s34_o_s11_pos, tab_s44_o_s11_pos, tab_g_pos
      end function mcgpu_set_variable_dust
+
+     ! init_reemission on the device (thermal_emission.f90:404): rebuilds log_Qcool_minus_extra_heating and kdB_dT_CDF
+     ! of the context from its kappa_abs_LTE (the module arrays passed to mcgpu_set_thermal / mcgpu_set_variable_dust
+     ! may then be unfilled); outputs c_loc(log_Qcool_minus_extra_heating), c_loc(kdB_dT_CDF) or c_null_ptr
+     integer(c_int) function mcgpu_init_reemission(ctx, tab_lambda, tab_delta_lambda, log_Qcool, kdB_dT_CDF) &
+          bind(C, name="mcgpu_init_reemission")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(in) :: tab_lambda(*), tab_delta_lambda(*)
+       type(c_ptr), value :: log_Qcool, kdB_dT_CDF
+     end function mcgpu_init_reemission
 
      ! xN_abs(:,1) and xJ_abs(:,:) summed over threads (radiation_field.f90:54-55); pass c_null_ptr for either
      integer(c_int) function mcgpu_fetch_radiation_field(ctx, xN_abs, xJ_abs) bind(C, name="mcgpu_fetch_radiation_field")

@@ -440,6 +440,28 @@ class Oracle:
             raise RuntimeError(f"oracle_temp_approx_diffusion_vertical failed: {rc}")
         return T, n_it.value
 
+    def init_reemission(self, kappa_abs_LTE=None, lam=None, delta_lam=None):
+        """init_reemission (thermal_emission.f90:404-550): ``kappa_abs_LTE [classes, n_lambda]`` (default: the
+        model's single class) -> ``(log_Qcool [classes, n_T], kdB_dT_CDF [classes, n_T, n_lambda])``; ``lam`` /
+        ``delta_lam`` [micron] default to the model's wavelength grid."""
+        m = self.model
+        lam = m.lam if lam is None else lam
+        delta_lam = m.delta_lam if delta_lam is None else delta_lam
+        ka = np.atleast_2d(np.asarray(m.kappa_abs_LTE if kappa_abs_LTE is None else kappa_abs_LTE, np.float64))
+        nc, nl = ka.shape
+        nT = m.tab_Temp.size
+        ka_ref = _a(ka.T, np.float64)  # (p_n_cells, n_lambda) column-major = [lambda][class] in memory
+        lq = np.zeros((nc, nT), np.float64)
+        cdf = np.zeros((nc, nT, nl), np.float64)
+        self.lib.oracle_init_reemission.restype = C.c_int
+        rc = self.lib.oracle_init_reemission(
+            C.c_int(nc), C.c_int(nT), C.c_int(nl), _p(_a(m.tab_Temp, np.float32), C.c_float),
+            _p(_a(lam, np.float64), C.c_double), _p(_a(delta_lam, np.float64), C.c_double),
+            _p(ka_ref, C.c_double), _p(lq, C.c_double), _p(cdf, C.c_double))
+        if rc:
+            raise RuntimeError(f"oracle_init_reemission failed: {rc}")
+        return lq, cdf
+
     # -- Voronoi operators ---------------------------------------------------
     def cross_voronoi(self, x0, y0, z0, u, v, w, cell, prev):
         n = len(cell)

@@ -2640,3 +2640,71 @@ int oracle_dust_map_image(const oracle_model *m, const oracle_rt_opts *o, int np
   free(J_th);
   return 0;
 }
+
+/* ---------------------------------------------------------------------------
+ * init_reemission (thermal_emission.f90:404-550): the LTE tables, lextra_heating off.
+ * Arrays in the reference's layouts: kappa_abs_LTE(p_n_cells, n_lambda),
+ * log_Qcool_minus_extra_heating(n_T, p_n_cells), kdB_dT_CDF(n_lambda, n_T, p_n_cells).
+ * ------------------------------------------------------------------------- */
+int oracle_init_reemission(int p_n_cells, int n_T, int n_lambda, const float *tab_Temp, const double *tab_lambda,
+                           const double *tab_delta_lambda, const double *kappa_abs_LTE, double *log_Qcool,
+                           double *kdB_dT_CDF) {
+  const double hp = 6.626070040e-34, c_light = 299792458.0, kb = 1.38064852e-23; /* constants.f90:21-23 */
+  const float thermal_const = (float)(c_light * hp / kb);                         /* real, constants.f90:24 */
+  const double cst_E = 2.0 * hp * (c_light * c_light) * (4.0 * M_PI);             /* :427 */
+  const double tiny_dp = 2.2250738585072014e-308;
+  double *B = (double *)calloc((size_t)n_lambda * n_T, sizeof(double));
+  double *dB_dT = (double *)calloc((size_t)n_lambda * n_T, sizeof(double));
+  double *integ3 = (double *)calloc((size_t)n_lambda + 1, sizeof(double));
+  if (!B || !dB_dT || !integ3) { free(B); free(dB_dT); free(integ3); return 1; }
+  /* the black body and its temperature derivative, bin width included (:431-452) */
+  for (int t = 1; t <= n_T; ++t) {
+    const double Temp = (double)tab_Temp[t - 1];
+    const double cst = (double)thermal_const / Temp;
+    for (int lambda = 1; lambda <= n_lambda; ++lambda) {
+      const double wl = tab_lambda[lambda - 1] * (double)1.e-6f; /* default-real literal */
+      const double delta_wl = tab_delta_lambda[lambda - 1] * (double)1.e-6f;
+      const double cst_wl = cst / wl;
+      const size_t k = (size_t)(lambda - 1) + (size_t)n_lambda * (t - 1);
+      if (cst_wl < 500.0) {
+        const double coeff_exp = exp(cst_wl);
+        const double wl2 = wl * wl, wl5 = (wl2 * wl2) * wl; /* wl**5 */
+        B[k] = 1.0 / (wl5 * (coeff_exp - 1.0)) * delta_wl;
+        dB_dT[k] = B[k] * cst_wl * coeff_exp / (coeff_exp - 1.0);
+      } else {
+        B[k] = 0.0;
+        dB_dT[k] = 0.0;
+      }
+    }
+  }
+  /* the cooling rate above the one at tab_Temp(1) (:464-513) */
+  for (int icell = 1; icell <= p_n_cells; ++icell) {
+    double Qcool0 = 0.0;
+    for (int t = 1; t <= n_T; ++t) {
+      double integ = 0.0;
+      for (int lambda = 1; lambda <= n_lambda; ++lambda)
+        integ = integ + kappa_abs_LTE[(size_t)(icell - 1) + (size_t)p_n_cells * (lambda - 1)] *
+                            B[(size_t)(lambda - 1) + (size_t)n_lambda * (t - 1)];
+      const double Qcool = integ * cst_E;
+      if (t == 1) Qcool0 = Qcool;
+      const double extra_heating = Qcool0; /* .not.lextra_heating (:483-485) */
+      const double q = Qcool - extra_heating;
+      log_Qcool[(size_t)(t - 1) + (size_t)n_T * (icell - 1)] = (q > tiny_dp) ? log(q) : -1000.0;
+    }
+  }
+  /* the re-emission CDF (:533-549) */
+  for (int icell = 1; icell <= p_n_cells; ++icell)
+    for (int t = 1; t <= n_T; ++t) {
+      double *cdf = kdB_dT_CDF + (size_t)n_lambda * ((size_t)(t - 1) + (size_t)n_T * (icell - 1));
+      integ3[0] = 0.0;
+      for (int lambda = 1; lambda <= n_lambda; ++lambda)
+        integ3[lambda] = integ3[lambda - 1] + kappa_abs_LTE[(size_t)(icell - 1) + (size_t)p_n_cells * (lambda - 1)] *
+                                                  dB_dT[(size_t)(lambda - 1) + (size_t)n_lambda * (t - 1)];
+      if (integ3[n_lambda] > tiny_dp)
+        for (int lambda = 1; lambda <= n_lambda; ++lambda) cdf[lambda - 1] = integ3[lambda] / integ3[n_lambda];
+      else
+        for (int lambda = 1; lambda <= n_lambda; ++lambda) cdf[lambda - 1] = 0.0; /* the allocation value */
+    }
+  free(B); free(dB_dT); free(integ3);
+  return 0;
+}

@@ -342,6 +342,15 @@ int oracle_temp_approx_diffusion_vertical(const oracle_model *m, const double *t
                                           const double *tab_delta_lambda, int ri_in, int ri_out, const int *zj_sup,
                                           float *Tdust, int *n_iter);
 
+/* init_reemission (thermal_emission.f90:404-550), LTE tables without extra heating:
+ *   kappa_abs_LTE(p_n_cells, n_lambda) in  ->  log_Qcool_minus_extra_heating(n_T, p_n_cells),
+ *   kdB_dT_CDF(n_lambda, n_T, p_n_cells) out (reference layouts, column-major).  PARITY UNPINNED (module
+ * thermal_emission is unbuildable here): pinned by known answers (Stefan-Boltzmann, grey dust) in
+ * tests/test_init_reemission.py. */
+int oracle_init_reemission(int p_n_cells, int n_T, int n_lambda, const float *tab_Temp, const double *tab_lambda,
+                           const double *tab_delta_lambda, const double *kappa_abs_LTE, double *log_Qcool,
+                           double *kdB_dT_CDF);
+
 /* Voronoi grid operators (Voronoi.f90). */
 int oracle_find_voronoi_cell(const oracle_model *m, int iwall, double x, double y, double z);
 void oracle_cross_voronoi_cell(const oracle_model *m, double x, double y,

@@ -494,6 +494,18 @@ extern "C" int emu_dark_zone_rays(const oracle_model* m, int lambda, double tau_
   return 0;
 }
 
+// k_init_reemission, one (class, T) row per call; kabs[class][lambda], outputs [class][T] and [class][T][lambda]
+extern "C" int emu_init_reemission(int n_classes, int n_T, int n_lambda, const float* tab_Temp, const double* tab_lambda,
+                                   const double* tab_delta_lambda, const double* kabs, double* lq, double* cdf) {
+  gridDim.x = (unsigned)(n_classes * n_T); blockDim.x = 1; threadIdx.x = 0;
+  for (unsigned b = 0; b < gridDim.x; ++b) {
+    blockIdx.x = b;
+    k_init_reemission(n_classes, n_T, n_lambda, tab_Temp, tab_lambda, tab_delta_lambda, kabs, lq, cdf);
+  }
+  blockIdx.x = 0;
+  return 0;
+}
+
 extern "C" int emu_stars_map_sed(const oracle_model* m, const oracle_rt_opts* o, uint64_t seed, const double* star_flux,
                                  double* out) {
   if (m->grid_type != 1) return 31;
