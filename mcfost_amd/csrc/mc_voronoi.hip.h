@@ -142,8 +142,19 @@ __device__ inline void voro_cross_cell(const VoroGrid& G, const DevModel& M, con
   next_cell = 0;
   const VoroNb* nb = G.nb + C.first;
   const int cnt = C.count;
+  // The walls of the box among the neighbours (ids -1 .. -6; their distance is a genuine double with two more
+  // divisions) are only noted in the scan -- (position, wall) in 10 bits each, at most six -- and compared after it:
+  // a wave runs this loop as long as its longest list, and the wall branch would be taken on almost every trip by
+  // some lane.  The reference's sequential scan keeps the FIRST of equal minima, so the late comparison carries the
+  // list positions: the result is the one of the scan in list order.
+  unsigned long long walls = 0ull;
+  int best_pos = 128;
+  // the records are fetched one trip ahead: the scan is a chain of dependent 16-byte gathers, and a wave that waits
+  // for each of them in turn spends more time waiting than computing (wait_frac 0.59 before)
+  VoroNb N_ahead = nb[0];
   for (int i = 0; i < cnt; ++i) {
-    const VoroNb N = nb[i];
+    const VoroNb N = N_ahead;
+    N_ahead = nb[(i + 1 < cnt) ? i + 1 : i];
     if (N.id == previous_cell) continue;
     if (N.id > 0) {
       const float n0 = nf_sub(N.x, C.x), n1 = nf_sub(N.y, C.y), n2 = nf_sub(N.z, C.z);
@@ -153,14 +164,19 @@ __device__ inline void voro_cross_cell(const VoroGrid& G, const DevModel& M, con
                   p2 = nf_mul(0.5f, nf_add(N.z, C.z));
       const double num = (double)dot3f(n0, n1, n2, nf_sub(p0, r0), nf_sub(p1, r1), nf_sub(p2, r2));
       // num < 0: the reference sets s_tmp = huge(1.0) > 1e30, never the minimum
-      if (!(num < 0.0) && nd_mul(num, s_den) < nd_mul(s_num, den)) { s_num = num; s_den = den; next_cell = N.id; }
+      if (!(num < 0.0) && nd_mul(num, s_den) < nd_mul(s_num, den)) { s_num = num; s_den = den; next_cell = N.id; best_pos = i; }
     } else {
-      double s_tmp = voro_distance_to_wall(G, x, y, z, u, v, w, -N.id);
-      if (s_tmp < 0.0) s_tmp = (double)FLT_HUGE;
-      if (s_tmp < s_num / s_den) { s_num = s_tmp; s_den = 1.0; next_cell = N.id; }
+      walls = (walls << 10) | (unsigned long long)(((i < 127 ? i : 127) << 3) | (-N.id));
     }
   }
   double s = s_num / s_den;
+  while (__builtin_expect(walls != 0ull, 0)) {
+    const int wid = (int)(walls & 7ull), pos = (int)((walls >> 3) & 127ull);
+    walls >>= 10;
+    double s_tmp = voro_distance_to_wall(G, x, y, z, u, v, w, wid);
+    if (s_tmp < 0.0) s_tmp = (double)FLT_HUGE;
+    if (s_tmp < s || (s_tmp == s && pos < best_pos)) { s = s_tmp; next_cell = -wid; best_pos = pos; }
+  }
   s = nd_mul(s, 1.0 + (double)1e-5f);
   x1 = nd_add(x, nd_mul(u, s));
   y1 = nd_add(y, nd_mul(v, s));
