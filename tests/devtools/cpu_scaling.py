@@ -1,5 +1,5 @@
 import sys, time, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from mcfost_amd.host import model as M
 from oracle import Oracle
 m = M.build_model(M.ref41())

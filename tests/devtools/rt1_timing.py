@@ -1,7 +1,7 @@
 """Kernel time of the RT1 ray-traced dust SED (mcgpu_rt1_dust_map) on the ref4.1-sized grid, next to the
-oracle on the host cores.  Usage: python tools/rt1_timing.py [n_incl]"""
+oracle on the host cores.  Usage: python tests/devtools/rt1_timing.py [n_incl]"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from mcfost_amd.host import model as M
 from mcfost_amd.engine import Engine

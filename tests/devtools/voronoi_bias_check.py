@@ -2,7 +2,7 @@
 workgroups) unbiased against the CPU port?  Compare GPU-vs-GPU (two seeds: the noise floor) with GPU-vs-CPU at
 equal packet counts."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 from mcfost_amd.engine import Engine
