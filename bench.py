@@ -298,6 +298,9 @@ def thermal_block(M, D, Engine, dist, torch, args, config, world, rank, local_ra
                                 "mrw_steps_per_packet": cnt["mrw_steps"] / max(cnt["packets"], 1)}
                                if config == "ref41_mrw" else {})},
                  "roofline": roof}
+        if cfg.l3D and config != "voronoi":   # binned deposits (mc_binned.hip.h): how the step was chunked, what overflowed
+            block["binned_deposits"] = {k: eng.get_info("bin_" + k) for k in
+                                        ("buckets", "log_blocks", "chunks", "deposits_per_packet", "overflow_blocks", "drained_records")}
         if with_cpu:
             base, T_cpu, n_cpu = cpu_baseline(model, n_total, args.cpu_seconds)
             block["cpu_baseline"] = base

@@ -162,9 +162,15 @@ int mcgpu_set_midplane_snap(mcgpu_ctx *ctx, int on);
  * Per-context run options (the library reads no environment variable; the switches of the
  * reference that select code paths are its command-line flags, init_mcfost.f90):
  *   "deposit"      0 = automatic (default): the absorbed-energy grid of a 2D model is kept
- *                      per workgroup in LDS, larger grids deposit with HBM atomics (Voronoi:
- *                      through a hashed LDS cache); 1 = HBM atomics only; 2 = LDS (refused
- *                      when the grid does not fit)
+ *                      per workgroup in LDS; 3D cylindrical grids write binned deposit records
+ *                      to a log in HBM that is folded into the grid between chunks of the run
+ *                      (mc_binned.hip.h; the launch stays asynchronous); Voronoi grids deposit
+ *                      through a hashed LDS cache in front of HBM atomics; 1 = HBM atomics only;
+ *                      2 = LDS (refused when the grid does not fit); 3 = binned (refused where
+ *                      it is not built)
+ *   "deposit_log_mb"  size of the binned-deposit log in MiB; 0 (default) = 24 GiB or a third of
+ *                      the free device memory.  A smaller log means more, shorter chunks; a
+ *                      block that finds its part of the log full is added with atomics.
  *   "schedule"     0 = automatic (default): waves with roles and LDS packet queues where
  *                      the queues fit (cylindrical grids; Voronoi grids run the single-role
  *                      kernel, which is faster on them); 1 = the single-role kernel;
@@ -177,6 +183,9 @@ int mcgpu_set_midplane_snap(mcgpu_ctx *ctx, int on);
  * Results do not depend on any of them (same packets, same random numbers).
  */
 int mcgpu_set_option(mcgpu_ctx *ctx, const char *name, int value);
+/* Diagnostics of the last launches: "bin_buckets", "bin_log_blocks", "bin_chunks",
+ * "bin_deposits_per_packet", "bin_overflow_blocks", "bin_drained_records". */
+int mcgpu_get_info(mcgpu_ctx *ctx, const char *name, double *value);
 
 /* Stars: type star_type (parameters.f90:230-242); icell/out_model from
  * stars_cell_indices (stars.f90:789-808). Lengths in AU. */

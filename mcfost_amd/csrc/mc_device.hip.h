@@ -159,6 +159,18 @@ struct DevModel {
 constexpr int ST_MASK = 15, ST_STAR = 16, ST_SCATT = 32, ST_ISM = 64;
 constexpr int ST_NINT_SHIFT = 8;  // bits 8..10: MRW's count of interactions in a row inside one cell (0..7)
 
+// HBM side of the binned-deposit log (mc_binned.hip.h); n_buckets = 0: not in use
+struct BinLog {
+  unsigned int* keys;          // [blocks][64] cell indices (0-based)
+  double* vals;                // [blocks][64]
+  unsigned int* count;         // [n_buckets][n_parts] blocks written by workgroup `part` since the last fold
+  const unsigned int* off;     // [n_buckets] first block of the bucket's region
+  const unsigned int* cap;     // [n_buckets] blocks of ONE workgroup's part of the region (n_parts of them in a row)
+  unsigned long long* stats;   // [0] blocks that overflowed their part, [1] records added at the end of a launch
+  int n_buckets, shift;        // bucket = cell >> shift
+  int n_parts;                 // workgroups of the packet kernel
+};
+
 struct RunArgs {
   uint64_t seed, first_packet, n_packets;
   double qscale;            // n_replicas
@@ -177,6 +189,17 @@ struct RunArgs {
   // optional radiation-field accumulators of save_radiation_field (radiation_field.f90:54-55): null = off
   unsigned int* xN_abs;  // [n_cells] path segments per cell (xN_abs(icell,1,id), lmcfost_lib)
   double* xJ_abs;        // (n_cells, n_lambda) sum of l * Stokes(1) (lxJ_abs_step1)
+  // binned deposits (mc_binned.hip.h): the launch is one CHUNK of a run whose deposits reach E_abs when the chunk's
+  // log is folded; n_folded = packets whose deposits E_abs holds when this chunk starts (see bin_energy_scale)
+  BinLog bin;
+  double n_folded;
+  // chunked runs of the role kernel (mc_roles.hip.h, "Chunks without tails"): packets a chunk leaves unfinished are
+  // written to carry_out as records and are the first work items of the next chunk (carry_in); null = run to the end
+  const void* carry_in;             // [*carry_in_n] records (Rec<POLA>)
+  const unsigned int* carry_in_n;
+  void* carry_out;                  // [carry_cap] records; null: this chunk finishes every packet
+  unsigned int* carry_out_n;
+  unsigned int carry_cap;
 };
 
 // ---------------------------------------------------------------------------

@@ -31,9 +31,20 @@
 // Results do not depend on who runs a packet (counter-based random numbers keyed by the packet id), so
 // this schedule reproduces thermal_body packet for packet.  Every wait is bounded (error 15) so that a
 // logic error cannot hang the GPU.
+//
+// Chunks without tails (BIN kernels; RunArgs::carry_*).  A run with binned deposits is a sequence of launches (the log
+// is folded between them), and a persistent kernel's launch ends with a TAIL: a packet is sequential, a lone packet
+// costs ~2.6 us per event, and the slowest of a few million packets has 10^4 events -- measured: 65 of the 95 ms of a
+// 3.75e6-packet chunk of ref4.1_3D.  So a chunk does not finish its packets: when a workgroup finds the global work
+// counter exhausted, every wave writes the packets it holds (registers or owned records, and the work items it had
+// reserved but not started) to carry_out as records, the workgroup sweeps the FLY and SRV rings into it, and the
+// launch ends.  The next chunk's work items are [carried records | new packet ids]: a serving lane that takes an item
+// below *carry_in_n loads that record instead of emitting a packet.  Only the last chunk runs to the end.  A packet's
+// random numbers and its whole state travel in the record, so the results are the single launch's, packet for packet.
 #pragma once
 #include "mc_device.hip.h"
 #include "mc_voronoi.hip.h"
+#include "mc_binned.hip.h"
 
 #ifdef MCGPU_COUNT_ITERS  // diagnostic build (tools/roles_check.py diag): statements that only count
 #define RQ_DIAG(...) __VA_ARGS__
@@ -167,9 +178,11 @@ __device__ inline void flight_constants(const Lds& T, const DevModel& M, Flight&
 // here at the end of the crossing that leads into the dark cell -- the entry point is still at hand, so the packet
 // needs no memory of it (a flight never starts inside a dark cell: packets are mirrored at its edge and the dark
 // cells emit nothing, thermal_emission.f90:1817).
-template <bool L3D, bool DARK, bool LDSE>
+// BIN: the deposit is handed back (dep_ic >= 0: cell, dep_v: value) for the caller's bin_deposit, which needs the whole
+// wave in converged control flow (mc_binned.hip.h).
+template <bool L3D, bool DARK, bool LDSE, bool BIN = false>
 __device__ inline int roles_cross(const Lds& T, const DevModel& M, const RunArgs& A, double* E_lds, Flight& p,
-                                  unsigned int& c_cross, unsigned int& c_kill, unsigned int& c_dark) {
+                                  unsigned int& c_cross, unsigned int& c_kill, unsigned int& c_dark, int& dep_ic, double& dep_v) {
   const int n_rad = M.n_rad, nz = M.nz;
   const int azj = p.zj < 0 ? -p.zj : p.zj;
   const bool out = (p.ri == n_rad + 1) || ((azj == nz + 1) && (fabs(p.z) > M.zmaxmax));
@@ -192,7 +205,10 @@ __device__ inline int roles_cross(const Lds& T, const DevModel& M, const RunArgs
   const double tau = l * opacity;
   if (tau > p.extr) {
     const double lc = l * (p.extr / tau);
-    if (real_cell && !MCGPU_DIAG(A.flags, 1)) deposit<LDSE>(A.E_abs, E_lds, ic, p.kab * lc * p.S0);
+    if (real_cell && !MCGPU_DIAG(A.flags, 1)) {
+      if (BIN) { dep_ic = ic; dep_v = p.kab * lc * p.S0; }
+      else deposit<LDSE>(A.E_abs, E_lds, ic, p.kab * lc * p.S0);
+    }
     p.x = p.x + lc * p.u;
     p.y = p.y + lc * p.v;
     p.z = p.z + lc * p.w;
@@ -200,7 +216,10 @@ __device__ inline int roles_cross(const Lds& T, const DevModel& M, const RunArgs
     p.st = S_INTERACT;
   } else {
     p.extr = p.extr - tau;
-    if (real_cell && !MCGPU_DIAG(A.flags, 1)) deposit<LDSE>(A.E_abs, E_lds, ic, p.kab * l * p.S0);
+    if (real_cell && !MCGPU_DIAG(A.flags, 1)) {
+      if (BIN) { dep_ic = ic; dep_v = p.kab * l * p.S0; }
+      else deposit<LDSE>(A.E_abs, E_lds, ic, p.kab * l * p.S0);
+    }
     const bool next_real = is_real_cell<L3D>(n_rad, nz, ri1, zj1);
     const int ic1 = next_real ? cell_index<L3D>(n_rad, nz, ri1, zj1, k1) : 0;
     if (DARK && next_real && M.dark[ic1]) {
@@ -406,11 +425,14 @@ __device__ inline int voro_roles_cross(const Lds& T, const DevModel& M, const Ru
 // VORO: the same schedule on a Voronoi grid (G; L3D = true, DARK = LDSE = MRW = false): a record's ri is the packet's
 // cell, zj the cell it came from, star_key the cell of the star on its way; deposits go through the workgroup's
 // deposit cache (DepCache, 2^cache_log_ns slots behind the tables) instead of a private grid.
-template <bool L3D, bool POLA, bool DARK, bool LDSE, bool MRW = false, bool VORO = false>
+// BIN: deposits go through the workgroup's staging buckets to the log in HBM (mc_binned.hip.h; grids whose
+// absorbed-energy array does not fit in LDS), the staging area sits between the tables and the queues.
+template <bool L3D, bool POLA, bool DARK, bool LDSE, bool MRW = false, bool VORO = false, bool BIN = false>
 __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, double* lds_base, int n_rec, int n_srv_pref,
                                            int k_short, int fly_iters, int fly_idle, int emit_qmax,
                                            const VoroGrid* Gp = nullptr, int cache_log_ns = 0) {
   static_assert(!VORO || (L3D && !DARK && !LDSE && !MRW), "Voronoi variant");
+  static_assert(!BIN || (!LDSE && !MRW && !VORO), "binned deposits: grids that do not fit in LDS");
   double* const E_lds = lds_base;
   const Lds T = lds_carve(lds_base + (LDSE ? M.n_cells : 0), M);
   lds_stage(T, M);
@@ -421,7 +443,11 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
   const size_t cache_doubles = VORO ? (((size_t)12 << cache_log_ns) + 7) / 8 : 0;
   if (VORO)
     for (int i = threadIdx.x; i < (1 << cache_log_ns); i += blockDim.x) { DC.val[i] = 0.0; DC.tag[i] = 0; }
-  char* const qbase = reinterpret_cast<char*>(lds_base + (LDSE ? M.n_cells : 0) + (lds_bytes(M) + 7) / 8 + cache_doubles);
+  double* const bin_base = lds_base + (LDSE ? M.n_cells : 0) + (lds_bytes(M) + 7) / 8 + cache_doubles;
+  const size_t bin_doubles = BIN ? (bin_lds_bytes(A.bin.n_buckets) + 7) / 8 : 0;
+  const BinStage BS = bin_carve(bin_base, BIN ? A.bin.n_buckets : 0);
+  if (BIN) bin_init(BS, A.bin.n_buckets);
+  char* const qbase = reinterpret_cast<char*>(bin_base + bin_doubles);
   RqCtl* const Q = reinterpret_cast<RqCtl*>(qbase);
   unsigned int* const rings = reinterpret_cast<unsigned int*>(qbase + sizeof(RqCtl));
   Rec<POLA>* const recs = reinterpret_cast<Rec<POLA>*>(qbase + sizeof(RqCtl) + 3 * RQ_CAP * sizeof(unsigned int));
@@ -451,6 +477,12 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
 #endif
   const int free_reserve = n_rec / 8 < 32 ? n_rec / 8 : 32;
   const uint32_t key0 = (uint32_t)A.seed, key1 = (uint32_t)(A.seed >> 32);
+  // work items of this launch: [0, n_carry) the records the last chunk left unfinished, then the new packets
+  const unsigned long long n_carry = (BIN && A.carry_in_n) ? (unsigned long long)*A.carry_in_n : 0ull;
+  const unsigned long long n_items = n_carry + A.n_packets;
+  const Rec<POLA>* const carry_in = reinterpret_cast<const Rec<POLA>*>(A.carry_in);
+  Rec<POLA>* const carry_out = reinterpret_cast<Rec<POLA>*>(A.carry_out);
+  bool suspended = false;
 
   // ---- per-lane state ------------------------------------------------------------------------------------
   // serving: rid >= 0 names the record this lane owns, st its packet's state (S_INTERACT between rounds)
@@ -458,6 +490,8 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
   int rid = -1, st = S_EMIT;
   Flight F;
   flight_clear(F);
+  BinLane BP;  // (BIN) this lane's last deposit, see bin_deposit
+  bin_lane_init(BP);
   double bag_S1 = 0.0, bag_S2 = 0.0, bag_S3 = 0.0;     // what a packet carries but a flight does not use
   uint32_t bag_plo = 0, bag_phi = 0, bag_event = 0;
   int bag_lambda = 1, bag_fl = 0;
@@ -476,6 +510,54 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
 
   for (int ep = 0;; ++ep) {
     if (rq_ld(&Q->abort_flag)) break;
+    if (BIN && carry_out && wave == 0 && (ep & 15) == 15 && !rq_ld(&Q->ids_done)) {
+      // (a workgroup that emits nothing for a while -- its records full of long flights -- would not notice that the
+      // work counter has run out)
+      if (__hip_atomic_load(A.next_packet, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n_items) rq_st(&Q->ids_done, 1);
+    }
+    if (BIN && carry_out && rq_ld(&Q->ids_done)) {
+      // ---- end of a chunk: what this wave holds goes to carry_out (see "Chunks without tails") -----------------
+      const bool held = rid < 0 && st != S_EMIT;   // a packet in registers
+      const bool owned = rid >= 0;                 // a record of this lane's
+      const unsigned long long left = pk_end - pk_next;  // reserved, not started (lane i takes the items pk_next + i + 64 q)
+      const int n_left = (int)((left > (unsigned long long)lane) ? (left - lane + (BIN_WAVE - 1)) / BIN_WAVE : 0ull);
+      const int mine = (held || owned ? 1 : 0) + n_left;
+      int pre = mine;  // inclusive prefix sum over the lanes
+      for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(pre, off); if (lane >= off) pre += t; }
+      const int total = __shfl(pre, 63);
+      unsigned int base = 0u;
+      if (lane == 0 && total > 0) base = atomicAdd(A.carry_out_n, (unsigned int)total);
+      base = __shfl(base, 0);
+      unsigned int at = base + (unsigned int)(pre - mine);
+      if (at + (unsigned int)mine > A.carry_cap) { *A.err = 16; rq_st(&Q->abort_flag, 1); }  // (never: the host sizes it for the worst case)
+      else {
+        if (held) {
+          Rec<POLA>& R = carry_out[at++];
+          R.x = F.x; R.y = F.y; R.z = F.z; R.u = F.u; R.v = F.v; R.w = F.w; R.extr = F.extr; R.S[0] = F.S0;
+          if (POLA) { R.S[POLA ? 1 : 0] = bag_S1; R.S[POLA ? 2 : 0] = bag_S2; R.S[POLA ? 3 : 0] = bag_S3; }
+          R.ri = F.ri; R.zj = F.zj; R.k = F.k; R.lambda = bag_lambda; R.star_key = F.star_key;
+          R.p_lo = bag_plo; R.p_hi = bag_phi; R.event = bag_event; R.pk_cross = F.pk_cross; R.tau_rand = bag_tau;
+          R.flags = st | bag_fl;
+        } else if (owned) {
+          Rec<POLA> Rc = recs[rid];
+          Rc.flags = (Rc.flags & ~ST_MASK) | st;
+          carry_out[at++] = Rc;
+        }
+        for (int q = 0; q < n_left; ++q) {
+          const unsigned long long item = pk_next + (unsigned long long)lane + (unsigned long long)BIN_WAVE * q;
+          if (item < n_carry) carry_out[at++] = carry_in[item];
+          else {  // a packet that was never emitted: state S_EMIT, its id in p_lo / p_hi
+            Rec<POLA> Rc;
+            memset(&Rc, 0, sizeof(Rc));
+            const unsigned long long pid = A.first_packet + (item - n_carry);
+            Rc.p_lo = (uint32_t)pid; Rc.p_hi = (uint32_t)(pid >> 32); Rc.flags = S_EMIT;
+            carry_out[at++] = Rc;
+          }
+        }
+      }
+      suspended = true;
+      break;
+    }
     int finished = 0;  // packets this lane finished in this round
 
     // ---- which role this round -----------------------------------------------------------------------
@@ -600,11 +682,15 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
           if (VORO) {
             if (F.st == S_FLIGHT) finished += voro_roles_cross<true>(T, M, A, *Gp, DC, F, c_cross, c_kill);
           } else if (L3D) {
-            if (F.st == S_FLIGHT) finished += roles_cross<L3D, DARK, LDSE>(T, M, A, E_lds, F, c_cross, c_kill, c_dark);
+            int dep_ic = -1;
+            double dep_v = 0.0;
+            if (F.st == S_FLIGHT) finished += roles_cross<L3D, DARK, LDSE, BIN>(T, M, A, E_lds, F, c_cross, c_kill, c_dark, dep_ic, dep_v);
+            if (BIN) bin_deposit(BS, A.bin, A.E_abs, lane, BP, dep_ic >= 0, dep_ic, dep_v);
           } else {
             finished += fly_step_2d<DARK, LDSE, MRW>(T, M, A, E_lds, F, c_cross, c_kill, c_dark);
           }
         }
+        if (BIN) bin_settle(BS, A.bin, A.E_abs, lane, BP);
         st = F.st;
       }
     } else {
@@ -630,8 +716,8 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
               base = atomicAdd(A.next_packet, (unsigned long long)PK_BATCH);
             }
             base = __shfl(base, leader);
-            pk_next = base < A.n_packets ? base : A.n_packets;
-            pk_end = (base + PK_BATCH < A.n_packets) ? base + PK_BATCH : A.n_packets;
+            pk_next = base < n_items ? base : n_items;
+            pk_end = (base + PK_BATCH < n_items) ? base + PK_BATCH : n_items;
             if (pk_end < pk_next) pk_end = pk_next;
             if (lane == leader) {
               const int got = (int)(pk_end - pk_next);
@@ -647,11 +733,20 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
           const unsigned long long got = __ballot(r >= 0);
           const unsigned long long my = pk_next + (unsigned long long)__popcll(got & ((1ull << lane) - 1ull));
           pk_next += (unsigned long long)__popcll(got);
-          if (r >= 0) {
+          // a carried record (see "Chunks without tails"): it goes on where the last chunk left it; one that was
+          // never emitted (state S_EMIT) is emitted now, with the id it carries
+          unsigned long long pid = A.first_packet + (my - n_carry);
+          bool fresh = r >= 0;
+          if (BIN && r >= 0 && my < n_carry) {
+            const Rec<POLA> Rc = carry_in[my];
+            if ((Rc.flags & ST_MASK) == S_EMIT) pid = ((unsigned long long)Rc.p_hi << 32) | Rc.p_lo;
+            else { recs[r] = Rc; rid = r; st = Rc.flags & ST_MASK; fresh = false; }
+          }
+          if (fresh) {
             rid = r;
             Rec<POLA>& R = recs[rid];
             Rng rng;
-            rng.init(A.seed, A.first_packet + my);
+            rng.init(A.seed, pid);
             c_pack++;
             RQ_DIAG(d_emit++;)
             float f[12];
@@ -740,6 +835,7 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
               E = __hip_atomic_load(&A.E_abs[ic], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               if (LDSE) E += E_lds[ic] * (double)gridDim.x;
               if (VORO) E += DC.pending(ic + 1) * (double)gridDim.x;
+              if (BIN) E *= bin_energy_scale(A);
               E *= A.qscale;
             }
             return E;
@@ -836,11 +932,15 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
             if (VORO) {
               if (F.st == S_FLIGHT) finished += voro_roles_cross<true>(T, M, A, *Gp, DC, F, c_cross, c_kill);
             } else if (L3D) {
-              if (F.st == S_FLIGHT) finished += roles_cross<L3D, DARK, LDSE>(T, M, A, E_lds, F, c_cross, c_kill, c_dark);
+              int dep_ic = -1;
+              double dep_v = 0.0;
+              if (F.st == S_FLIGHT) finished += roles_cross<L3D, DARK, LDSE, BIN>(T, M, A, E_lds, F, c_cross, c_kill, c_dark, dep_ic, dep_v);
+              if (BIN) bin_deposit(BS, A.bin, A.E_abs, lane, BP, dep_ic >= 0, dep_ic, dep_v);
             } else {
               finished += fly_step_2d<DARK, LDSE, MRW>(T, M, A, E_lds, F, c_cross, c_kill, c_dark);
             }
           }
+          if (BIN) bin_settle(BS, A.bin, A.E_abs, lane, BP);
           if (fly) {
             R.x = F.x; R.y = F.y; R.z = F.z; R.extr = F.extr;
             if (DARK) { R.u = F.u; R.v = F.v; R.w = F.w; }
@@ -908,7 +1008,23 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
   }
 
   __syncthreads();
+  if (BIN && carry_out && __syncthreads_or(suspended ? 1 : 0)) {
+    // the packets that wait in the FLY and SRV rings (nobody pops or pushes any more)
+    for (int q = RQ_FLY; q <= RQ_SRV; ++q) {
+      const unsigned int h = Q->head[q], t = Q->tail[q];
+      const unsigned int n = t - h;
+      if (threadIdx.x == 0) Q->pad1 = n ? (int)atomicAdd(A.carry_out_n, n) : 0;
+      __syncthreads();
+      const unsigned int base = (unsigned int)Q->pad1;
+      if (base + n > A.carry_cap) { if (threadIdx.x == 0) *A.err = 16; }
+      else
+        for (unsigned int i = threadIdx.x; i < n; i += blockDim.x)
+          carry_out[base + i] = recs[rings[q * RQ_CAP + ((h + i) & (RQ_CAP - 1))] & 0xFFFFu];
+      __syncthreads();
+    }
+  }
   lds_flush_sent(T, M, A.n_sent);
+  if (BIN) bin_drain(BS, A.bin, A.E_abs);
   if (LDSE) {
     for (int i = threadIdx.x; i < M.n_cells; i += blockDim.x) {
       const double e = E_lds[i];
@@ -950,6 +1066,17 @@ __global__ void __launch_bounds__(MCGPU_ROLES_BLOCK) k_thermal_roles(const DevMo
                                                                      int k_short, int fly_iters, int fly_idle, int emit_qmax) {
   extern __shared__ double lds_raw[];
   roles_body<L3D, POLA, DARK, LDSE, MRW>(M, A, lds_raw, n_rec, n_srv_pref, k_short, fly_iters, fly_idle, emit_qmax);
+}
+
+// the same with binned deposits (3D grids: the absorbed-energy array does not fit in LDS)
+#ifndef MCGPU_ROLES_BIN_BLOCK
+#define MCGPU_ROLES_BIN_BLOCK 768  // 168 VGPRs, 3 waves per SIMD: the 3D crossing + the staging do not fit into 128 registers
+#endif
+template <bool POLA, bool DARK>
+__global__ void __launch_bounds__(MCGPU_ROLES_BIN_BLOCK) k_thermal_roles_bin(const DevModel M, const RunArgs A, int n_rec, int n_srv_pref,
+                                                                         int k_short, int fly_iters, int fly_idle, int emit_qmax) {
+  extern __shared__ double lds_raw[];
+  roles_body<true, POLA, DARK, false, false, false, true>(M, A, lds_raw, n_rec, n_srv_pref, k_short, fly_iters, fly_idle, emit_qmax);
 }
 
 // the role schedule on a Voronoi grid

@@ -20,6 +20,7 @@
 #include "mc_mono_voronoi.hip.h"
 #include "mc_raytrace.hip.h"
 #include "mc_roles.hip.h"
+#include "mc_binned.hip.h"
 
 using namespace mcgpu;
 
@@ -51,7 +52,21 @@ struct mcgpu_ctx {
   int lsepar_pola = 0;
   float T_min = 1.0f;
   // mcgpu_set_option
-  int opt_deposit = 0;      // 0 = automatic, 1 = HBM atomics, 2 = LDS-private grid / deposit cache
+  int opt_deposit = 0;      // 0 = automatic, 1 = HBM atomics, 2 = LDS-private grid / deposit cache, 3 = binned deposits
+  int opt_log_mb = 0;       // binned deposits: size of the log in MiB (0 = automatic)
+  // binned deposits (mc_binned.hip.h): the log and its plan
+  BinLog bin{};
+  unsigned int *d_bin_off = nullptr, *d_bin_cap = nullptr;
+  double* d_bin_want = nullptr;  // [n_buckets] scratch of k_plan_bins
+  unsigned long long bin_total_blocks = 0;
+  int bin_max_parts = 0;
+  double bin_dep_per_packet = 0.0;  // deposits per packet of the last run (0: not yet known)
+  int bin_chunks = 0;               // chunks of the last launch
+  double accum_packets = 0.0;       // packets whose deposits the accumulators hold (across accumulate-launches)
+  // packets a chunk leaves unfinished (mc_roles.hip.h, "Chunks without tails"): two record buffers used in turns
+  void* d_carry[2] = {nullptr, nullptr};
+  unsigned int* d_carry_n = nullptr;  // [2]
+  size_t carry_cap = 0;               // records per buffer
   int opt_schedule = 0;     // 0 = automatic (waves with roles where the queues fit), 1 = single-role kernel
   int opt_speculation = 1;  // SED mode: commit most of every stream before the scout pass
   int opt_cache_log_slots = 13;  // Voronoi deposit cache: 2^13 slots = 96 KB of LDS
@@ -89,6 +104,8 @@ struct mcgpu_ctx {
   std::vector<VoroCell> h_cells;  // host copy: kappa_factor is patched in by mcgpu_set_opacity
   VoroCell* d_cells = nullptr;
 };
+
+static void bin_release(mcgpu_ctx* ctx);
 
 #define HIPCHK(call)                                                              \
   do {                                                                            \
@@ -171,6 +188,7 @@ extern "C" int mcgpu_destroy(mcgpu_ctx* ctx) {
   if (ctx->d_mono_u64) hipFree(ctx->d_mono_u64);
   if (ctx->d_mono_i32) hipFree(ctx->d_mono_i32);
   if (ctx->d_hits) hipFree(ctx->d_hits);
+  bin_release(ctx);
   if (ctx->ev0) hipEventDestroy(ctx->ev0);
   if (ctx->ev1) hipEventDestroy(ctx->ev1);
   if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
@@ -245,6 +263,7 @@ extern "C" int mcgpu_set_grid_cyl(mcgpu_ctx* ctx, int n_rad, int nz, int n_az, i
   if ((rc = upload(ctx, cell_map_j, (size_t)ntot2, &b))) return rc;
   if ((rc = upload(ctx, cell_map_k, (size_t)ntot2, &c))) return rc;
   ctx->d_cmi = (int*)a; ctx->d_cmj = (int*)b; ctx->d_cmk = (int*)c;
+  bin_release(ctx);
   ctx->have_grid = true;
   return MCGPU_OK;
 }
@@ -301,6 +320,7 @@ extern "C" int mcgpu_set_grid_sph(mcgpu_ctx* ctx, int n_rad, int nz, int n_az, i
   if ((rc = upload(ctx, cell_map_j, (size_t)ntot2, &b))) return rc;
   if ((rc = upload(ctx, cell_map_k, (size_t)ntot2, &c))) return rc;
   ctx->d_cmi = (int*)a; ctx->d_cmj = (int*)b; ctx->d_cmk = (int*)c;
+  bin_release(ctx);
   ctx->have_grid = true;
   return MCGPU_OK;
 }
@@ -375,18 +395,63 @@ extern "C" int mcgpu_set_grid_voronoi(mcgpu_ctx* ctx, int n_cells, const float* 
   ctx->d_cells = (VoroCell*)dc;
   V.cell = dc;
   ctx->voro = true;
+  bin_release(ctx);
   ctx->have_grid = true;
   return MCGPU_OK;
 }
 
+// the binned-deposit log is allocated by the first launch that uses it and kept until the context goes (or the grid /
+// the option that sizes it changes)
+static void bin_release(mcgpu_ctx* ctx) {
+  if (ctx->bin.keys) hipFree(ctx->bin.keys);
+  if (ctx->bin.vals) hipFree(ctx->bin.vals);
+  if (ctx->bin.count) hipFree(ctx->bin.count);
+  if (ctx->bin.stats) hipFree(ctx->bin.stats);
+  if (ctx->d_bin_off) hipFree(ctx->d_bin_off);
+  if (ctx->d_bin_cap) hipFree(ctx->d_bin_cap);
+  if (ctx->d_bin_want) hipFree(ctx->d_bin_want);
+  ctx->d_bin_want = nullptr;
+  for (int i = 0; i < 2; ++i) { if (ctx->d_carry[i]) hipFree(ctx->d_carry[i]); ctx->d_carry[i] = nullptr; }
+  if (ctx->d_carry_n) hipFree(ctx->d_carry_n);
+  ctx->d_carry_n = nullptr;
+  ctx->carry_cap = 0;
+  ctx->bin = BinLog{};
+  ctx->d_bin_off = ctx->d_bin_cap = nullptr;
+  ctx->bin_total_blocks = 0;
+  ctx->bin_max_parts = 0;
+}
+
 extern "C" int mcgpu_set_option(mcgpu_ctx* ctx, const char* name, int value) {
   if (!ctx || !name) return MCGPU_ERR_ARG;
-  if (!strcmp(name, "deposit")) { if (value < 0 || value > 2) return fail(ctx, MCGPU_ERR_ARG, "deposit: 0, 1 or 2"); ctx->opt_deposit = value; }
+  if (!strcmp(name, "deposit")) { if (value < 0 || value > 3) return fail(ctx, MCGPU_ERR_ARG, "deposit: 0, 1, 2 or 3"); ctx->opt_deposit = value; }
+  else if (!strcmp(name, "deposit_log_mb")) {
+    if (value < 0) return fail(ctx, MCGPU_ERR_ARG, "deposit_log_mb: >= 0");
+    if (value != ctx->opt_log_mb) bin_release(ctx);
+    ctx->opt_log_mb = value;
+  }
   else if (!strcmp(name, "schedule")) { if (value < 0 || value > 2) return fail(ctx, MCGPU_ERR_ARG, "schedule: 0, 1 or 2"); ctx->opt_schedule = value; }
   else if (!strcmp(name, "speculation")) ctx->opt_speculation = value ? 1 : 0;
   else if (!strcmp(name, "voronoi_cache_log_slots")) { if (value < 6 || value > 13) return fail(ctx, MCGPU_ERR_ARG, "voronoi_cache_log_slots: 6..13"); ctx->opt_cache_log_slots = value; }
   else if (!strcmp(name, "radiation_field")) { if (value < 0 || value > 3) return fail(ctx, MCGPU_ERR_ARG, "radiation_field: bit 0 xN_abs, bit 1 xJ_abs"); ctx->opt_radiation_field = value; }
   else return fail(ctx, MCGPU_ERR_ARG, "mcgpu_set_option: unknown option");
+  return MCGPU_OK;
+}
+
+extern "C" int mcgpu_get_info(mcgpu_ctx* ctx, const char* name, double* value) {
+  if (!ctx || !name || !value) return MCGPU_ERR_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  if (!strcmp(name, "bin_buckets")) *value = ctx->bin.n_buckets;
+  else if (!strcmp(name, "bin_log_blocks")) *value = (double)ctx->bin_total_blocks;
+  else if (!strcmp(name, "bin_chunks")) *value = ctx->bin_chunks;
+  else if (!strcmp(name, "bin_deposits_per_packet")) *value = ctx->bin_dep_per_packet;
+  else if (!strcmp(name, "bin_overflow_blocks") || !strcmp(name, "bin_drained_records")) {
+    unsigned long long st[2] = {0ull, 0ull};
+    if (ctx->bin.stats) {
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      HIPCHK(hipMemcpy(st, ctx->bin.stats, sizeof(st), hipMemcpyDeviceToHost));
+    }
+    *value = (double)st[!strcmp(name, "bin_overflow_blocks") ? 0 : 1];
+  } else return fail(ctx, MCGPU_ERR_ARG, "mcgpu_get_info: unknown name");
   return MCGPU_OK;
 }
 
@@ -959,6 +1024,164 @@ static int launch_voro(mcgpu_ctx* ctx, const RunArgs& A, int grid_blocks, int bl
   return MCGPU_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Binned deposits (mc_binned.hip.h): 3D cylindrical grids -- the absorbed-energy array does not fit in LDS
+// ---------------------------------------------------------------------------------------------
+// can this context's thermal step run with binned deposits?  (cylindrical 3D grids, one dust class, no MRW; the
+// optional radiation-field arrays are kept by the single-role kernel)
+static bool bin_applicable(const mcgpu_ctx* ctx, const RunArgs& A) {
+  const DevModel& M = ctx->M;
+  if (ctx->voro || M.grid_sph || M.n_classes || M.mrw || !M.l3D || A.xN_abs || A.xJ_abs) return false;
+  if (ctx->opt_schedule == 1) return false;
+  return true;
+}
+
+// bucket width: about 48 buckets, slices of at most 2^14 cells (128 KB of LDS in the fold)
+static int bin_shift_for(int n_cells) {
+  int s = 6;
+  while (s < 14 && ((n_cells + (1 << s) - 1) >> s) > 48) ++s;
+  return s;
+}
+
+static int bin_prepare(mcgpu_ctx* ctx, int n_parts) {
+  const DevModel& M = ctx->M;
+  const int shift = bin_shift_for(M.n_cells);
+  const int nb = (M.n_cells + (1 << shift) - 1) >> shift;
+  if (nb > BIN_MAX_BUCKETS) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "binned deposits: too many cells");
+  if (ctx->bin.keys && ctx->bin.n_buckets == nb && ctx->bin.shift == shift && ctx->bin_max_parts >= n_parts) return MCGPU_OK;
+  bin_release(ctx);
+  size_t free_b = 0, total_b = 0;
+  HIPCHK(hipMemGetInfo(&free_b, &total_b));
+  // automatic size: 24 GiB (32 M blocks = 2e9 deposits per chunk) or a third of what is free
+  size_t bytes = ctx->opt_log_mb > 0 ? (size_t)ctx->opt_log_mb << 20 : (size_t)24 << 30;
+  if (ctx->opt_log_mb <= 0 && bytes > free_b / 3) bytes = free_b / 3;
+  const size_t block_bytes = (size_t)BIN_H * (sizeof(double) + sizeof(unsigned int));
+  unsigned long long blocks = bytes / block_bytes;
+  const unsigned long long least = (unsigned long long)nb * n_parts * 2;
+  if (blocks < least) blocks = least;
+  if (blocks > 0xFFFFFFFFull) blocks = 0xFFFFFFFFull;  // (block indices are 32-bit)
+  HIPCHK(hipMalloc((void**)&ctx->bin.keys, blocks * BIN_H * sizeof(unsigned int)));
+  HIPCHK(hipMalloc((void**)&ctx->bin.vals, blocks * BIN_H * sizeof(double)));
+  HIPCHK(hipMalloc((void**)&ctx->bin.count, (size_t)nb * n_parts * sizeof(unsigned int)));
+  HIPCHK(hipMalloc((void**)&ctx->bin.stats, 2 * sizeof(unsigned long long)));
+  HIPCHK(hipMalloc((void**)&ctx->d_bin_off, nb * sizeof(unsigned int)));
+  HIPCHK(hipMalloc((void**)&ctx->d_bin_cap, nb * sizeof(unsigned int)));
+  HIPCHK(hipMalloc((void**)&ctx->d_bin_want, nb * sizeof(double)));
+  HIPCHK(hipMemset(ctx->bin.count, 0, (size_t)nb * n_parts * sizeof(unsigned int)));
+  HIPCHK(hipMemset(ctx->bin.stats, 0, 2 * sizeof(unsigned long long)));
+  ctx->bin.off = ctx->d_bin_off; ctx->bin.cap = ctx->d_bin_cap;
+  ctx->bin.n_buckets = nb; ctx->bin.shift = shift; ctx->bin.n_parts = n_parts;
+  ctx->bin_total_blocks = blocks;
+  ctx->bin_max_parts = n_parts;
+  return MCGPU_OK;
+}
+
+// The thermal step in chunks: [plan the log's regions] -> packet kernel (deposits to the log) -> fold, all asynchronous
+// on the context's stream.  The chunks grow by factors of four from a short first one (whose packets see E = 0 like
+// the reference's first packets) up to what the log holds; see bin_energy_scale for the in-flight temperature.
+static int launch_binned(mcgpu_ctx* ctx, RunArgs A, const mcgpu_run_opts* o) {
+  const DevModel& M = ctx->M;
+  const bool pola = ctx->lsepar_pola != 0, dark = M.dark != nullptr;
+  const size_t lds_cap = 160 * 1024 - 512;  // (a request of exactly 160 KB minus a few bytes is refused)
+  const size_t lds_t = (lds_bytes(M) + 7) / 8 * 8;
+  const int rthreads = (o->block_threads > 0 && o->block_threads <= MCGPU_ROLES_BIN_BLOCK) ? o->block_threads : MCGPU_ROLES_BIN_BLOCK;
+  if (rthreads % 64) return fail(ctx, MCGPU_ERR_ARG, "block_threads must be a multiple of 64");
+  const int n_cu = ctx->prop.multiProcessorCount;
+  const int max_parts = o->grid_blocks > n_cu ? o->grid_blocks : n_cu;
+  int rc = bin_prepare(ctx, max_parts);
+  if (rc) return rc;
+  const size_t lds_b = (bin_lds_bytes(ctx->bin.n_buckets) + 7) / 8 * 8;
+  int n_rec = lds_t + lds_b < lds_cap ? rq_records_that_fit(pola, lds_cap - lds_t - lds_b) : 0;
+  if (n_rec > 2 * rthreads) n_rec = 2 * rthreads > RQ_MIN_REC ? 2 * rthreads : RQ_MIN_REC;
+  if (n_rec <= 0) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "binned deposits: the staging buckets and the packet records do not fit in LDS");
+  const size_t lds_r = lds_t + lds_b + rq_lds_bytes(pola, n_rec);
+  const void* fn = pola ? (dark ? (const void*)k_thermal_roles_bin<true, true> : (const void*)k_thermal_roles_bin<true, false>)
+                        : (dark ? (const void*)k_thermal_roles_bin<false, true> : (const void*)k_thermal_roles_bin<false, false>);
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r) != hipSuccess) {
+    ctx->err = "binned deposits: LDS request of " + std::to_string(lds_r) + " bytes refused (tables " + std::to_string(lds_t) +
+               ", staging " + std::to_string(lds_b) + ", records " + std::to_string(n_rec) + ")";
+    return MCGPU_ERR_HIP;
+  }
+  const size_t fold_lds = sizeof(double) << ctx->bin.shift;
+  HIPCHK(hipFuncSetAttribute((const void*)k_fold_bins, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fold_lds));
+  int n_srv_pref = tune("MCGPU_N_SRV", (rthreads / 64 + 3) / 4, 1, 1016);
+  int k_short = tune("MCGPU_K_SHORT", 2, 0, 64), fly_iters = tune("MCGPU_FLY_ITERS", 16, 1, 256);
+  int fly_idle = tune("MCGPU_FLY_IDLE", 32, 1, 65), emit_qmax = tune("MCGPU_EMIT_QMAX", 128, 0, 1 << 20);
+  // what a chunk can leave unfinished: per workgroup its records, a packet per lane and a batch of work items per wave
+  {
+    const size_t cap = (size_t)max_parts * ((size_t)n_rec + rthreads + (size_t)(rthreads / 64) * PK_BATCH);
+    const size_t rec_bytes = pola ? sizeof(Rec<true>) : sizeof(Rec<false>);
+    if (ctx->carry_cap < cap || !ctx->d_carry[0]) {
+      for (int i = 0; i < 2; ++i) { if (ctx->d_carry[i]) hipFree(ctx->d_carry[i]); ctx->d_carry[i] = nullptr; }
+      for (int i = 0; i < 2; ++i) HIPCHK(hipMalloc(&ctx->d_carry[i], cap * sizeof(Rec<true>)));
+      if (!ctx->d_carry_n) HIPCHK(hipMalloc((void**)&ctx->d_carry_n, 2 * sizeof(unsigned int)));
+      ctx->carry_cap = cap;
+    }
+    (void)rec_bytes;
+  }
+  HIPCHK(hipMemsetAsync(ctx->d_carry_n, 0, 2 * sizeof(unsigned int), ctx->stream));
+
+  // chunk sizes: the log holds total_blocks * 64 deposits; a chunk uses at most 60 % of it (the regions carry half as
+  // much again as slack: the deposits per packet grow while the disk warms up)
+  const double dep_pp = ctx->bin_dep_per_packet > 0.0 ? ctx->bin_dep_per_packet : 400.0;
+  double c_max = 0.6 * (double)ctx->bin_total_blocks * BIN_H / dep_pp;
+  if (c_max < 1024.0) c_max = 1024.0;
+  const uint64_t n_total = A.n_packets, first0 = A.first_packet;
+  const double folded0 = o->accumulate ? ctx->accum_packets : 0.0;
+  uint64_t done = 0, chunk = 65536, last_chunk = 0;
+  if ((double)chunk > c_max) chunk = (uint64_t)c_max;
+  int last_parts = 0;
+  ctx->bin_chunks = 0;
+  const int split = 8;
+  while (done < n_total) {
+    uint64_t c = chunk < n_total - done ? chunk : n_total - done;
+    // (a remainder smaller than a quarter of a chunk rides with this one when the log has room for it)
+    if (n_total - done - c < c / 4 && (double)(n_total - done) <= c_max) c = n_total - done;
+    int rblocks = o->grid_blocks > 0 ? o->grid_blocks : n_cu;
+    const unsigned long long need = (c + rthreads - 1) / rthreads;
+    if (o->grid_blocks <= 0 && (unsigned long long)rblocks > need) rblocks = (int)(need ? need : 1);
+    if (last_chunk == 0) {
+      hipLaunchKernelGGL(k_plan_uniform, dim3(1), dim3(128), 0, ctx->stream, ctx->d_bin_off, ctx->d_bin_cap, ctx->bin.n_buckets,
+                         ctx->bin_total_blocks, rblocks);
+    } else {
+      BinLog Lp = ctx->bin;
+      Lp.n_parts = last_parts;
+      hipLaunchKernelGGL(k_plan_bins, dim3(1), dim3(128), 0, ctx->stream, Lp, ctx->d_bin_off, ctx->d_bin_cap,
+                         (unsigned long long)ctx->bin_total_blocks, (double)c / (double)last_chunk, rblocks, ctx->d_bin_want);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemsetAsync(ctx->d_counters + WORK_SLOT, 0, sizeof(unsigned long long), ctx->stream));
+    A.first_packet = first0 + done;
+    A.n_packets = c;
+    A.n_folded = A.frozen ? 0.0 : folded0 + (double)done;
+    A.bin = ctx->bin;
+    A.bin.n_parts = rblocks;
+    {
+      // the packets chunk i leaves unfinished are the first work items of chunk i + 1; the last chunk finishes all
+      const int in = ctx->bin_chunks & 1, out = in ^ 1;
+      const bool last = done + c >= n_total;
+      A.carry_in = ctx->d_carry[in]; A.carry_in_n = ctx->d_carry_n + in;
+      A.carry_out = last ? nullptr : ctx->d_carry[out]; A.carry_out_n = ctx->d_carry_n + out;
+      A.carry_cap = (unsigned int)ctx->carry_cap;
+      if (!last) HIPCHK(hipMemsetAsync(ctx->d_carry_n + out, 0, sizeof(unsigned int), ctx->stream));
+    }
+    void* args[] = {(void*)&M, (void*)&A, (void*)&n_rec, (void*)&n_srv_pref, (void*)&k_short, (void*)&fly_iters, (void*)&fly_idle, (void*)&emit_qmax};
+    HIPCHK(hipLaunchKernel(fn, dim3(rblocks), dim3(rthreads), args, lds_r, ctx->stream));
+    hipLaunchKernelGGL(k_fold_bins, dim3(ctx->bin.n_buckets * split), dim3(1024), fold_lds, ctx->stream, A.bin, A.E_abs, M.n_cells, split);
+    HIPCHK(hipGetLastError());
+    done += c;
+    last_chunk = c;
+    last_parts = rblocks;
+    ctx->bin_chunks++;
+    if ((double)chunk * 4.0 <= c_max) chunk *= 4; else chunk = (uint64_t)c_max;
+  }
+  // the counts of the last chunk are cleared for the next launch
+  if (last_parts > 0) {
+    HIPCHK(hipMemsetAsync(ctx->bin.count, 0, (size_t)ctx->bin.n_buckets * ctx->bin_max_parts * sizeof(unsigned int), ctx->stream));
+  }
+  return MCGPU_OK;
+}
+
 extern "C" int mcgpu_launch_thermal(mcgpu_ctx* ctx, const mcgpu_run_opts* o) {
   int rc = ready(ctx);
   if (rc) return rc;
@@ -1024,11 +1247,18 @@ extern "C" int mcgpu_launch_thermal(mcgpu_ctx* ctx, const mcgpu_run_opts* o) {
     if (lds_e > lds_cap) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "deposit = lds: the grid does not fit in LDS");
     use_lds = true;
   }
+  // Grids that do not fit in LDS: binned deposits (mc_binned.hip.h) where they are built, HBM atomics otherwise
+  bool use_bin = false;
+  if (ctx->opt_deposit == 3) {
+    if (!bin_applicable(ctx, A)) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "deposit = binned: 3D cylindrical grids, one dust class, role schedule");
+    use_bin = true; use_lds = false;
+  } else if (ctx->opt_deposit == 0 && !use_lds && bin_applicable(ctx, A)) use_bin = true;
   HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
-  int rc3 = launch_mega(ctx, A, use_lds, o->grid_blocks, o->block_threads);
+  int rc3 = use_bin ? launch_binned(ctx, A, o) : launch_mega(ctx, A, use_lds, o->grid_blocks, o->block_threads);
   if (rc3) return rc3;
   HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
   ctx->launched = true;
+  ctx->accum_packets = (o->accumulate ? ctx->accum_packets : 0.0) + (double)o->n_packets;
   return MCGPU_OK;
 }
 
@@ -1043,6 +1273,11 @@ extern "C" int mcgpu_sync(mcgpu_ctx* ctx, double* kernel_ms) {
       HIPCHK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
       *kernel_ms = ms;
     }
+  }
+  if (ctx->launched && ctx->bin.keys && ctx->d_counters) {  // what the next binned launch sizes its chunks with
+    unsigned long long c[2] = {0ull, 0ull};
+    HIPCHK(hipMemcpy(c, ctx->d_counters, sizeof(c), hipMemcpyDeviceToHost));
+    if (c[0] > 1000ull) ctx->bin_dep_per_packet = (double)c[1] / (double)c[0];
   }
   int herr = 0;
   HIPCHK(hipMemcpy(&herr, ctx->d_err, sizeof(int), hipMemcpyDeviceToHost));

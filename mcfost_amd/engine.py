@@ -34,7 +34,7 @@ ABI_SYMBOLS = (
     "mcgpu_probe_packet_rand", "mcgpu_set_midplane_snap", "mcgpu_set_grid_voronoi",
     "mcgpu_probe_cross_voronoi", "mcgpu_set_rt1", "mcgpu_run_mono", "mcgpu_fetch_xI",
     "mcgpu_device_xI", "mcgpu_set_ism", "mcgpu_rt1_dust_map", "mcgpu_set_xI", "mcgpu_rt1_image", "mcgpu_set_xI_precision",
-    "mcgpu_get_xI_precision", "mcgpu_set_option", "mcgpu_counters_to_accum", "mcgpu_counters_from_accum",
+    "mcgpu_get_xI_precision", "mcgpu_set_option", "mcgpu_get_info", "mcgpu_counters_to_accum", "mcgpu_counters_from_accum",
     "mcgpu_set_grid_sph", "mcgpu_temp_approx_diffusion_vertical", "mcgpu_set_mrw", "mcgpu_fetch_radiation_field", "mcgpu_set_variable_dust", "mcgpu_rt1_stars_map_sed", "mcgpu_define_dark_zone", "mcgpu_init_reemission", "mcgpu_multi_create", "mcgpu_multi_destroy", "mcgpu_multi_size", "mcgpu_multi_ctx", "mcgpu_multi_last_error",
     "mcgpu_shard_packets", "mcgpu_multi_run_thermal",
 )
@@ -399,6 +399,12 @@ class Engine:
         """Per-context run option (``mcgpu_set_option``): "deposit" 0/1/2 = auto / HBM atomics / LDS,
         "schedule" 0/1 = auto / single-role kernel, "speculation" 1/0 (SED mode)."""
         self._chk(self.lib.mcgpu_set_option(self.ctx, name.encode(), C.c_int(int(value))), "mcgpu_set_option")
+
+    def get_info(self, name):
+        """Diagnostics of the last launches (``mcgpu_get_info``), e.g. "bin_chunks", "bin_overflow_blocks"."""
+        v = C.c_double(0.0)
+        self._chk(self.lib.mcgpu_get_info(self.ctx, name.encode(), C.byref(v)), "mcgpu_get_info")
+        return v.value
 
     def set_xI_precision(self, bytes_per_value):
         """8 (default): FP64 xI_scatt sums; 4: default real like the reference's array, half the atomic lines -- for

@@ -35,6 +35,7 @@ static inline int __ffsll(long long m) { return __builtin_ffsll(m); }
 static inline int __popcll(unsigned long long m) { return __builtin_popcountll(m); }
 template <class T> static inline T __shfl(T v, int) { return v; }
 template <class T> static inline T __shfl_down(T, int) { return T(0); }
+template <class T> static inline T __shfl_up(T, int) { return T(0); }
 template <class T> static inline T __shfl_xor(T, int) { return T(0); }
 static inline unsigned long long wall_clock64() { return 0ull; }
 static inline unsigned long long atomicMax(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; if (v > o) *p = v; return o; }
@@ -260,6 +261,56 @@ extern "C" int emu_run_thermal(const oracle_model* m, const oracle_opts* o, cons
            else { if (dark) RUNV(false, false, true); else RUNV(false, false, false); } }
 #undef RUNV
     for (int q = 0; q < ORACLE_N_COUNTERS; ++q) counters[q] = cnt[q];
+    return err;
+  }
+  if (getenv("MCGPU_EMU_BIN")) {
+    // Binned deposits with chunks (mcgpu.hip::launch_binned on one lane): MCGPU_EMU_BIN = "<packets per chunk>,<log blocks>,
+    // <n_srv_pref>,<k_short>,<fly_iters>".  Every chunk but the last hands its unfinished packets on (carry_*).
+    if (!l3d || M.mrw || M.n_classes) return 31;
+    long chunk = 1000, log_blocks = 64;
+    int nsp = 1, ks = 2, fi = 3;
+    sscanf(getenv("MCGPU_EMU_BIN"), "%ld,%ld,%d,%d,%d", &chunk, &log_blocks, &nsp, &ks, &fi);
+    int shift = 6;
+    while (shift < 14 && ((m->n_cells + (1 << shift) - 1) >> shift) > 24) ++shift;
+    const int nb = (m->n_cells + (1 << shift) - 1) >> shift;
+    const int n_rec = RQ_MIN_REC;
+    if (lds_bytes(M) + bin_lds_bytes(nb) + rq_lds_bytes(true, n_rec) + 64 > sizeof(lds_raw)) return 31;
+    std::vector<unsigned int> keys((size_t)log_blocks * BIN_H), count(nb, 0u), off(nb), cap(nb);
+    std::vector<double> vals((size_t)log_blocks * BIN_H), want(nb);
+    unsigned long long stats[2] = {0ull, 0ull};
+    BinLog L;
+    L.keys = keys.data(); L.vals = vals.data(); L.count = count.data(); L.off = off.data(); L.cap = cap.data();
+    L.stats = stats; L.n_buckets = nb; L.shift = shift; L.n_parts = 1;
+    const size_t carry_cap = (size_t)n_rec + 1 + PK_BATCH;
+    std::vector<Rec<true>> carry[2] = {std::vector<Rec<true>>(carry_cap), std::vector<Rec<true>>(carry_cap)};
+    unsigned int carry_n[2] = {0u, 0u};
+    const uint64_t n_total = o->n_packets;
+    uint64_t done = 0, last = 0;
+    int ichunk = 0;
+    while (done < n_total) {
+      const uint64_t c = (uint64_t)chunk < n_total - done ? (uint64_t)chunk : n_total - done;
+      gridDim.x = 1; blockDim.x = 1; threadIdx.x = 0; blockIdx.x = 0;
+      if (last == 0) k_plan_uniform(off.data(), cap.data(), nb, (unsigned long long)log_blocks, 1);
+      else k_plan_bins(L, off.data(), cap.data(), (unsigned long long)log_blocks, (double)c / (double)last, 1, want.data());
+      cnt[12] = 0;
+      A.first_packet = o->first_packet + done; A.n_packets = c;
+      A.n_folded = A.frozen ? 0.0 : (double)done;
+      A.bin = L;
+      const int in = ichunk & 1, out = in ^ 1;
+      const bool fin = done + c >= n_total;
+      A.carry_in = carry[in].data(); A.carry_in_n = &carry_n[in];
+      A.carry_out = fin ? nullptr : carry[out].data(); A.carry_out_n = &carry_n[out];
+      A.carry_cap = (unsigned int)carry_cap;
+      carry_n[out] = 0u;
+      if (pola) { if (dark) k_thermal_roles_bin<true, true>(M, A, n_rec, nsp, ks, fi, 65, 128); else k_thermal_roles_bin<true, false>(M, A, n_rec, nsp, ks, fi, 65, 128); }
+      else { if (dark) k_thermal_roles_bin<false, true>(M, A, n_rec, nsp, ks, fi, 65, 128); else k_thermal_roles_bin<false, false>(M, A, n_rec, nsp, ks, fi, 65, 128); }
+      if (err) return err;
+      for (int b = 0; b < nb; ++b) { blockIdx.x = (unsigned)b; k_fold_bins(L, E_abs, m->n_cells, 1); }
+      blockIdx.x = 0;
+      done += c; last = c; ++ichunk;
+    }
+    for (int q = 0; q < ORACLE_N_COUNTERS; ++q) counters[q] = cnt[q];
+    if (getenv("MCGPU_EMU_BIN_STATS")) fprintf(stderr, "binned: %d chunks, %d buckets, overflow blocks %llu, drained %llu\n", ichunk, nb, stats[0], stats[1]);
     return err;
   }
   if (getenv("MCGPU_EMU_ROLES")) {  // the role schedule on one lane: the one wave alternates between both roles

@@ -1,0 +1,100 @@
+"""Binned deposits (mcfost_amd/csrc/mc_binned.hip.h) and chunks without tails (mc_roles.hip.h): the thermal step of 3D
+cylindrical grids writes (cell, value) records to a log in HBM that is folded into E_abs between the chunks of a run,
+and a chunk hands its unfinished packets to the next one.  save_radiation_field (radiation_field.f90:53) only changes
+its summation order, and which launch runs a packet cannot matter (counter-based random numbers), so:
+  * frozen mode: counters, n_sent, SED packet counts bit-exact against the oracle, E_abs rtol 1e-9 -- also with a log so
+    small that the run takes many chunks and overflows its regions (the graceful path: plain atomics);
+  * binned == HBM atomics on the same packets;
+  * live mode (in-flight temperature from the folded grid, scaled by the packets started since): statistically the
+    temperature of the atomic path.
+"""
+import numpy as np
+import pytest
+
+from helpers import mc_similar
+from mcfost_amd.host import model as M
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(model, n_tot):
+    from mcfost_amd.engine import Engine
+    return Engine(model, n_tot)
+
+
+def _oracle(model, n_tot):
+    from oracle import Oracle
+    return Oracle(model, n_tot)
+
+
+def _same_packets(a, b, rtol=1e-9):
+    assert a["counters"] == b["counters"]
+    assert np.array_equal(a["n_sent"], b["n_sent"])
+    assert np.array_equal(a["sed"][4], b["sed"][4])
+    assert np.allclose(a["E_abs"], b["E_abs"], rtol=rtol, atol=1e-12 * b["E_abs"].max())
+
+
+@pytest.mark.parametrize("log_mb", [0, 1])
+def test_binned_frozen_parity_against_the_oracle(log_mb):
+    """log_mb = 1: 1365 blocks for ~40 buckets x 256 workgroups -> chunks of 1024 packets, most blocks overflow."""
+    m = M.build_model(M.small(n_rad=12, nz=6, n_az=8, l3D=True))
+    n = 30000
+    e, o = _engine(m, n), _oracle(m, n)
+    prior = o.run_thermal(2000, seed=1)["E_abs"]
+    e.set_option("deposit", 3)
+    e.set_option("deposit_log_mb", log_mb)
+    a = e.run_thermal(n, seed=8, frozen=True, E_prior=prior)
+    b = o.run_thermal(n, seed=8, frozen=True, E_prior=prior, n_threads=8)
+    _same_packets(a, b)
+    assert e.get_info("bin_buckets") >= 16
+    if log_mb:
+        assert e.get_info("bin_chunks") >= 10
+    # a second launch on the same context (the log, its plan and the carry buffers are reused), accumulating
+    a2 = e.run_thermal(n, seed=9, first_packet=n, frozen=True, E_prior=prior, accumulate=True)
+    b2 = o.run_thermal(n, seed=9, first_packet=n, frozen=True, E_prior=prior, n_threads=8)
+    assert np.allclose(a2["E_abs"], a["E_abs"] + b2["E_abs"], rtol=1e-9, atol=1e-12 * a2["E_abs"].max())
+    assert a2["counters"]["packets"] == 2 * n
+    e.close()
+
+
+def test_binned_equals_atomics_on_the_baseline_grid():
+    """ref4.1_3D with 12 azimuths (the true radial / vertical grid), polarised, frozen: the two deposit paths run the
+    same packets; a mid-sized log gives several chunks with carried packets."""
+    m = M.build_model(M.ref41_3d(n_az=12))
+    n = 300000
+    o = _oracle(m, n)
+    prior = o.run_thermal(20000, seed=1)["E_abs"]
+    res = {}
+    for dep, mb in ((1, 0), (3, 0), (3, 64)):
+        e = _engine(m, n)
+        e.set_option("deposit", dep)
+        e.set_option("deposit_log_mb", mb)
+        res[(dep, mb)] = e.run_thermal(n, seed=63, frozen=True, E_prior=prior)
+        if mb:
+            assert e.get_info("bin_chunks") >= 4
+        e.close()
+    _same_packets(res[(3, 0)], res[(1, 0)], rtol=1e-10)
+    _same_packets(res[(3, 64)], res[(1, 0)], rtol=1e-10)
+
+
+def test_binned_live_mode_gives_the_temperature_of_the_atomic_path():
+    m = M.build_model(M.ref41_3d(n_az=12))
+    n = 4_000_000
+    T = {}
+    for dep in (1, 3):
+        e = _engine(m, n)
+        e.set_option("deposit", dep)
+        if dep == 3:
+            e.set_option("deposit_log_mb", 512)   # several chunks: the in-flight temperature lags by one of them
+        a = e.run_thermal(n, seed=11 + dep)
+        c = a["counters"]
+        assert c["packets"] == n and c["escaped"] + c["killed_star"] == n and a["n_sent"].sum() == n
+        T[dep] = e.temp_finale(a["E_abs"])
+        if dep == 3:
+            assert e.get_info("bin_chunks") >= 3
+        e.close()
+    sel = (T[1] > 1.5 * m.cfg.T_min) & (T[3] > 1.5 * m.cfg.T_min)
+    ok, p75 = mc_similar(T[1][sel], T[3][sel], 0.05)
+    assert ok, p75
+    # no systematic offset beyond the noise of the mean
+    assert abs(np.mean(T[3][sel] / T[1][sel]) - 1.0) < 0.01

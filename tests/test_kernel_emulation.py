@@ -28,11 +28,12 @@ DEV3 = os.path.join(os.path.dirname(HERE), "mcfost_amd", "csrc", "mc_voronoi.hip
 DEV4 = os.path.join(os.path.dirname(HERE), "mcfost_amd", "csrc", "mc_mono.hip.h")
 DEV5 = os.path.join(os.path.dirname(HERE), "mcfost_amd", "csrc", "mc_roles.hip.h")
 DEV6 = os.path.join(os.path.dirname(HERE), "mcfost_amd", "csrc", "mc_raytrace.hip.h")
+DEV7 = os.path.join(os.path.dirname(HERE), "mcfost_amd", "csrc", "mc_binned.hip.h")
 
 
 @pytest.fixture(scope="module")
 def emu():
-    if (not os.path.exists(LIB)) or os.path.getmtime(LIB) < max(os.path.getmtime(SRC), os.path.getmtime(DEV), os.path.getmtime(DEV2), os.path.getmtime(DEV3), os.path.getmtime(DEV4), os.path.getmtime(DEV5), os.path.getmtime(DEV6)):
+    if (not os.path.exists(LIB)) or os.path.getmtime(LIB) < max(os.path.getmtime(SRC), os.path.getmtime(DEV), os.path.getmtime(DEV2), os.path.getmtime(DEV3), os.path.getmtime(DEV4), os.path.getmtime(DEV5), os.path.getmtime(DEV6), os.path.getmtime(DEV7)):
         fma = ["-mfma"] if "fma" in open("/proc/cpuinfo").read() else []
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=fast"] + fma +
                               ["-o", LIB, SRC])
@@ -399,6 +400,23 @@ def test_emulated_role_schedule(emu, small_model):
         finally:
             os.environ.pop("MCGPU_EMU_ROLES", None)
             os.environ.pop("MCGPU_EMU_LDS", None)
+
+
+def test_emulated_binned_deposits_and_chunks_without_tails(emu):
+    """mc_binned.hip.h + the chunked launch of mcgpu.hip::launch_binned on one lane ("<packets per chunk>,<log blocks>,
+    <n_srv_pref>,<k_short>,<fly_iters>"): deposits go through the staging buckets, full blocks to the log (or, when the
+    bucket's region is full, straight to the grid), every chunk's log is folded, the regions are re-planned from the
+    last chunk's demand, and a chunk hands its unfinished packets -- records in the rings, packets in registers, work
+    items reserved but not started -- to the next one.  Same packets, same sums as the oracle, whatever the chunking."""
+    m3 = M.build_model(M.small(n_rad=12, nz=6, n_az=8, l3D=True))
+    mh = M.build_model(M.small(n_rad=10, nz=5, n_az=6, l3D=True, aniso_method=2, lsepar_pola=False))
+    for cfg in ("100000,4096,1,2,3", "300,4096,1,2,3", "97,64,0,2,3", "1000,8,1,0,2", "50,4096,0,1,64"):
+        os.environ["MCGPU_EMU_BIN"] = cfg
+        try:
+            check(emu, m3, 3000, 8)
+            check(emu, mh, 2000, 10)
+        finally:
+            os.environ.pop("MCGPU_EMU_BIN", None)
 
 
 def emu_dust_map(emu, orc, lam, xI, Tdust, n_sent, E_disk, ang_disque=0.0, l_sym_ima=True, tau_obs=100.0):
