@@ -1,17 +1,21 @@
 #!/usr/bin/env python3
-"""bench.py -- photon packets/s of the thermal Monte Carlo packet loop on the
-BASELINE workloads: the Pascucci 2D disk BASELINE.json's metric is quoted on (the
-headline line) and ref4.1.para 2D (configs[1], carried as a second full block),
-1e8 packets per GPU and step each.
+"""bench.py -- photon packets/s of the Monte Carlo packet loop on the BASELINE workloads.
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one pass of mc_photon_loop (dust_transfer.f90:439-572) for the
-temperature step: `--packets` packets per GPU through the persistent HIP
-kernel with all tables resident in HBM, followed (N > 1) by the single RCCL
-all-reduce of the fused accumulator [E_abs | sed | n_sent].  Weak scaling:
-per-GPU work is fixed.  Rank 0 prints ONE JSON line.
+The headline line is the Pascucci 2D disk BASELINE.json's metric is quoted on, 1e8 packets per GPU and step.
+One "step" = one pass of mc_photon_loop (dust_transfer.f90:439-572) for the temperature step with all tables resident
+in HBM, followed (N > 1) by the single RCCL all-reduce of the fused accumulator [E_abs | sed | n_sent | counters].
+Weak scaling: per-GPU work is fixed.  Rank 0 prints ONE JSON line.
+
+N > 1 runs either as one process per GPU under torch.distributed.run (backend nccl = RCCL), or -- started plainly --
+as ONE process that drives all N devices through the library's own multi-device entry (mcgpu_multi_run_thermal:
+RCCL inside the library, the entry a single-process Fortran host binds); the line says which ("launcher").
+
+On one GPU the same line carries a block per BASELINE configuration that fits one GPU -- ref4.1 2D (configs[1]),
+ref4.1_3D, the Voronoi stand-in, ref4.1 with 10x the dust + MRW, the SED-mode Monte Carlo with 10 observers -- each
+with its own roofline, CPU baseline and temperature parity (`--no-extra` leaves them out, `--config X` runs one alone).
 """
 import argparse
 import json
@@ -26,6 +30,9 @@ if ROOT not in sys.path:
 BYTES_PER_CROSSING = 28.0    # kappa_factor 8 B + next-cell id 4 B + E_abs RMW 16 B
 BYTES_PER_INTERACTION = 8.0  # E_abs read for Temp_LTE
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
+VALU_ISSUE_PEAK = 1024 * 2.4e9 / 4.0   # wave-instructions/s: 256 CUs x 4 SIMDs, one VALU instruction per 4 cycles at 2.4 GHz
+ATOMIC_LINE_PEAK = 2.37e10   # memory-side atomic operations/s, any type or footprint (profiles/r02_atomic_scope_bench.log)
+PROFILE_ROUND = "r03"
 
 
 def _quota_cores():
@@ -57,13 +64,13 @@ def source_hash():
 def pmc_summary(config, n_local, world):
     """Counter evidence for the dominant kernel from the committed PMC passes of THIS command and THIS source
     (`tools/collect_profiles.sh`: rocprofv3 --pmc in separate passes of `python bench.py --config <config> --steps 1
-    --warmup 0`, summarised in profiles/r02_pmc_<config>.json with the hash of the kernel sources).  HBM traffic per
+    --warmup 0`, summarised in profiles/<round>_pmc_<config>.json with the hash of the kernel sources).  HBM traffic per
     launch = 2 x FETCH_SIZE (gfx950 correction, MI355X guide, HBM section) + WRITE_SIZE, counters in KB.  Returns {} when
     there is no summary for this command or the sources changed since (so nothing stale is ever reported)."""
     if world != 1:
         return {}
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_%s.json" % config)))
+        d = json.load(open(os.path.join(ROOT, "profiles", "%s_pmc_%s.json" % (PROFILE_ROUND, config))))
         if d.get("source_hash") != source_hash() or int(d.get("packets", 0)) != int(n_local):
             return {}
         return d.get("per_launch", {})
@@ -78,9 +85,9 @@ def cpu_baseline(model, n_total, target_s=15.0):
     cores = _quota_cores()
     orc = Oracle(model, n_total)
     t = time.perf_counter()
-    orc.run_thermal(20000 * cores, seed=99, n_threads=cores)
-    rate = 20000 * cores / (time.perf_counter() - t)
-    n = int(max(20000 * cores, min(rate * target_s, 5e7)))
+    orc.run_thermal(5000 * cores, seed=99, n_threads=cores)
+    rate = 5000 * cores / (time.perf_counter() - t)
+    n = int(max(5000 * cores, min(rate * target_s, 5e7)))
     orc = Oracle(model, n)   # a self-consistent run of n packets: its own packet luminosity, its own temperature
     t = time.perf_counter()
     res = orc.run_thermal(n, seed=100, n_threads=cores)
@@ -91,124 +98,90 @@ def cpu_baseline(model, n_total, target_s=15.0):
     return base, orc.temp_finale(res["E_abs"]), n
 
 
-def tdust_parity(T_gpu, n_gpu, T_cpu, n_cpu, T_min):
+def tdust_parity(T_gpu, n_gpu, T_cpu, n_cpu, T_min, noise_pair=None):
     """Temperature of the GPU step against the CPU port's (independent noise): relative RMS over the cells with
     T > 1.01 T_min, the reference's own gate p75(|dT|/T) (test_suite/test_mcfost.py:46-57,88: < 5 %), and the
-    tolerance 3 sigma_MC with sigma_MC(N) = 1.7 % sqrt(1.28e5 / N) per run."""
+    tolerance 3 sigma_MC.  2D grids: sigma_MC(N) = 1.7 % sqrt(1.28e5 / N) per run (measured on
+    the 7000-cell ref4.1 grid).  Other grids (noise_pair = the temperatures of two runs of n_cpu packets with
+    different seeds): the seed-to-seed scatter measured on this very grid, sigma(n) = rms(T_a / T_b - 1) / sqrt(2)."""
     import numpy as np
     sel = (T_cpu > 1.01 * T_min) & (T_gpu > 1.01 * T_min)
     rel = (T_gpu[sel] - T_cpu[sel]) / T_cpu[sel]
-    # sigma_MC was measured on the 7000-cell ref4.1 grid; the noise per cell scales with sqrt(cells / packets)
-    sigma = 0.017 * float(np.sqrt(1.28e5 / n_gpu + 1.28e5 / n_cpu)) * float(np.sqrt(max(T_cpu.size, 7000) / 7000.0))
-    rms, p75 = float(np.sqrt(np.mean(rel ** 2))), float(np.percentile(np.abs(rel), 75))
-    return dict(rel_rms=rms, p75=p75, tolerance_rel_rms=3.0 * sigma, cells=int(sel.sum()), ok=bool(rms <= 3.0 * sigma),
-                reference_gate_p75_below_5pct=bool(p75 < 0.05))
-
-
-def bench_sed(args, world, rank, local_rank):
-    """SED mode on the ref4.1 grid (not the headline metric): one step = the SED Monte Carlo
-    (mcgpu_run_mono: scout + commit passes, ray-tracing deposits) of the listed wavelengths, every stream
-    asked for packets/128/len(wavelengths) packets in the stop bin; streams sharded over the ranks."""
-    import torch
-    import torch.distributed as dist
-    from mcfost_amd import distributed as D
-    from mcfost_amd.engine import Engine
-    from mcfost_amd.host import model as M
-
-    cfg = M.ref41()
-    if args.sed_observers:   # ref4.1.para asks for RT n_incl = 3; BASELINE config 2 quotes 10 inclinations
-        cfg.RT_n_incl = args.sed_observers
-    m = M.build_model(cfg)
-    e = Engine(m, 5e6, device=local_rank)
-    T = e.temp_finale(e.run_thermal(5_000_000, seed=3)["E_abs"])
-    M.repartition_energie(m, T)
-    e.close()
-    eng = Engine(m, 5e6, device=local_rank)
-    if args.xI_precision == 4:
-        eng.set_xI_precision(4)
-    lams = [int(x) for x in args.sed_lambdas.split(",")]
-    n_streams = m.cfg.n_photons_loop * world                 # weak scaling: 128 streams per GPU
-    first, count = D.shard_streams(n_streams, rank, world)
-    # packets in the stop bin per stream so that a step sends about --packets packets per GPU (1 in ~11 lands there)
-    n2 = max(10, int(args.packets / 11.0 / m.cfg.n_photons_loop / len(lams)))
-
-    def step(i):
-        sent = 0
-        for lam in lams:
-            r = eng.run_mono(lam, n2, seed=100 + i, n_chunks=count, first_chunk=first, fetch_xI=False)
-            sent += int(r["n_sent_chunk"].sum())
-            if world > 1:   # one all-reduce of [sed | n_sent] + xI_scatt per wavelength
-                acc, cnt = eng.device_accumulators()
-                dist.all_reduce(acc)
-                dist.all_reduce(eng.device_xI())
-                torch.cuda.current_stream().synchronize()
-        return sent
-
-    for i in range(args.warmup):
-        step(-1 - i)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    sent = 0
-    for i in range(args.steps):
-        sent += step(i)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    tot = torch.tensor([float(sent), dt], dtype=torch.float64, device="cuda")
-    if world > 1:
-        s2 = tot.clone()
-        dist.all_reduce(s2, op=dist.ReduceOp.SUM)
-        dist.all_reduce(tot, op=dist.ReduceOp.MAX)
-        sent_all, dt = float(s2[0].item()), float(tot[1].item())
+    if noise_pair is not None:
+        Ta, Tb = noise_pair
+        s2 = sel & (Ta > 1.01 * T_min) & (Tb > 1.01 * T_min)
+        sig_n = float(np.sqrt(np.mean((Ta[s2] / Tb[s2] - 1.0) ** 2))) / np.sqrt(2.0)   # one run of n_cpu packets
+        sigma = sig_n * float(np.sqrt(1.0 + n_cpu / n_gpu))
+        model = "seed-to-seed scatter of two runs of %d packets on this grid" % n_cpu
     else:
-        sent_all = float(sent)
-    if rank == 0:
-        cnt = eng.fetch()["counters"]
-        cross_pp = cnt["crossings"] / max(cnt["packets"], 1)
-        nRT = m.rt["RT_n_incl"] * m.rt["RT_n_az"]
-        # per crossing: kappa_factor 8 B + one 64-byte xI_scatt record RMW per observer
-        bytes_step = sent_all / world / args.steps * cross_pp * (8.0 + 2 * 64.0 * nRT)
-        line = {
-            "metric": "photon packets/sec (whole node), SED-mode MC packet loop with ray-tracing deposits",
-            "value": sent_all / dt, "unit": "packets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "ref4.1 2D disk 100x70, SED Monte Carlo of wavelengths %s, 128 streams/GPU x %d packets "
-                                   "in the stop bin each, RT1 deposits for %d observers (both passes timed)"
-                                   % (args.sed_lambdas, n2, nRT),
-                       "packets_per_gpu_per_step": sent_all / world / args.steps, "crossings_per_packet": cross_pp,
-                       "observers": nRT, "xI_record": "f32 pairs" if args.xI_precision == 4 else "f64",
-                       "records_per_s": sent_all / dt * cross_pp * nRT},
-            "roofline": {"bound": "hbm", "achieved": bytes_step / (dt / args.steps) / 1e9, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": bytes_step / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_mono (scout + commit)", "algorithmic_bytes_per_launch": bytes_step},
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            from oracle import Oracle
-            cores = _quota_cores()
-            orc = Oracle(m, 5e6)
-            t = time.perf_counter()
-            r = orc.run_mono(lams[0], max(2, int(2e5 / 11 / m.cfg.n_photons_loop)), seed=5, n_threads=cores)
-            dtc = time.perf_counter() - t
-            line["cpu_baseline"] = dict(value=r["counters"]["packets"] / dtc, unit="packets/s", cores=cores, kind="port",
-                                        sample="%d packets of wavelength %d of the same SED workload, %d OpenMP threads, "
-                                               "%.1f s" % (r["counters"]["packets"], lams[0], cores, dtc))
-        print(json.dumps(line))
-    if world > 1:
-        dist.destroy_process_group()
+        sigma = 0.017 * float(np.sqrt(1.28e5 / n_gpu + 1.28e5 / n_cpu)) * float(np.sqrt(max(T_cpu.size, 7000) / 7000.0))
+        model = "1.7 % sqrt(1.28e5 / N) per run (BASELINE.md section 2)"
+    rms, p75 = float(np.sqrt(np.mean(rel ** 2))), float(np.percentile(np.abs(rel), 75))
+    return dict(rel_rms=rms, p75=p75, tolerance_rel_rms=3.0 * sigma, noise_model=model, cells=int(sel.sum()),
+                ok=bool(rms <= 3.0 * sigma), reference_gate_p75_below_5pct=bool(p75 < 0.05))
 
 
-def thermal_block(M, D, Engine, dist, torch, args, config, world, rank, local_rank, steps, warmup, with_cpu):
-    """Times `steps` passes of the thermal packet loop on one configuration; returns (block dict or None on ranks > 0)."""
-    cfg = {"ref41": M.ref41, "ref41_mrw": M.ref41, "ref41_var": M.ref41, "ref41_3d": M.ref41_3d, "pascucci": M.pascucci, "voronoi": M.ref41}[config]()
+class Par:
+    """How the N GPUs are driven: "single" (N = 1), "torchrun" (one process per GPU, torch.distributed nccl = RCCL) or
+    "library" (ONE process, mcgpu_multi_*: RCCL inside the library)."""
+
+    def __init__(self, gpus):
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.dist = self.torch = None
+        self.rccl_ranks = None
+        if self.world > 1:
+            self.mode = "torchrun"
+            import torch
+            import torch.distributed as dist
+            self.torch, self.dist = torch, dist
+            torch.cuda.set_device(self.local_rank)
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+            self.n_gpus = self.world
+        elif gpus > 1:
+            self.mode = "library"
+            self.n_gpus = gpus
+        else:
+            self.mode = "single"
+            self.n_gpus = 1
+
+    def barrier(self):
+        if self.mode == "torchrun":
+            self.dist.barrier()
+            self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, x):
+        if self.mode != "torchrun":
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64, device="cuda")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum_over_ranks(self, x):
+        if self.mode != "torchrun":
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64, device="cuda")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return float(t.item())
+
+    def finish(self):
+        if self.mode == "torchrun":
+            self.dist.destroy_process_group()
+
+
+def build_workload(M, args, config):
+    cfg = {"ref41": M.ref41, "ref41_mrw": M.ref41, "ref41_var": M.ref41, "ref41_3d": M.ref41_3d, "pascucci": M.pascucci,
+           "voronoi": M.ref41}[config]()
     if args.no_pola:
         cfg.lsepar_pola = False
-    if args.dust_mass:   # a heavier (optically thicker) disk than the configuration's: where the random walk matters
-        cfg.dust_mass = args.dust_mass
-        cfg.name += " with M_dust = %g Msun" % args.dust_mass
+    dust_mass = args.dust_mass
+    if config == "ref41_mrw" and not dust_mass:
+        dust_mass = 10.0 * cfg.dust_mass   # the stock disk never walks (its cells are thin where packets are re-emitted)
+    if dust_mass:   # a heavier (optically thicker) disk than the configuration's: where the random walk matters
+        cfg.dust_mass = dust_mass
+        cfg.name += " with M_dust = %g Msun" % dust_mass
     if config == "voronoi":
         cfg.name = "ref4.1 disk as %d Voronoi sites" % args.sites
         model = M.build_voronoi_model(cfg, args.sites, seed=1, cache_dir=os.path.join(ROOT, "tools", "cache"))
@@ -220,44 +193,55 @@ def thermal_block(M, D, Engine, dist, torch, args, config, world, rank, local_ra
     if config == "ref41_mrw":   # BASELINE config 4: ref4.1 with the modified random walk (gamma_MRW = 2, MRW.f90:11)
         cfg.name += " + MRW (gamma %g)" % args.mrw_gamma
         M.init_mrw(model, gamma=args.mrw_gamma)
-    n_local = int(args.packets)
+    return cfg, model
+
+
+def thermal_block(par, args, config, steps, warmup, with_cpu, n_local):
+    """Times `steps` passes of the thermal packet loop on one configuration; returns (block or None on ranks > 0, cfg)."""
+    from mcfost_amd.engine import Engine, MultiEngine
+    from mcfost_amd.host import model as M
+    cfg, model = build_workload(M, args, config)
+    world = par.n_gpus
+    n_local = int(n_local)
     n_total = n_local * world
-    eng = Engine(model, n_total, device=local_rank)
-    first = rank * n_local
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
+    if par.mode == "library":
+        me = MultiEngine(model, n_total, devices=tuple(range(world)))
+        eng = me.engines[0]
+    else:
+        me = None
+        eng = Engine(model, n_total, device=par.local_rank)
+    first = par.rank * n_local
     if args.frozen:
         eng.set_E_prior(eng.run_thermal(min(n_local, 2_000_000), seed=5)["E_abs"] * (n_local / min(n_local, 2_000_000)))
+    last = {}
 
     def step(i):
+        if me is not None:   # ONE call: shards, launches on every device, the all-reduce, the fetch from device 0
+            last["out"] = me.run_thermal(n_total, seed=1000 + i, frozen=args.frozen, grid_blocks=args.grid_blocks,
+                                         block_threads=args.block_threads)
+            return last["out"]["kernel_ms"]
         eng.launch_thermal(n_local, seed=1000 + i, first_packet=first, n_replicas=float(world),
                            frozen=args.frozen, grid_blocks=args.grid_blocks, block_threads=args.block_threads)
         ms = eng.sync()   # HIP events on the engine's own stream around the launch
-        if world > 1:     # ONE all-reduce of the fused [E_abs | sed | n_sent | counters] buffer
-            eng.allreduce_device(dist.all_reduce)
+        if par.mode == "torchrun":     # ONE all-reduce of the fused [E_abs | sed | n_sent | counters] buffer
+            eng.allreduce_device(par.dist.all_reduce)
         return ms
 
     for i in range(warmup):
         step(-1 - i)
-    barrier()
+    par.barrier()
     t0 = time.perf_counter()
     kernel_ms = []
     for i in range(steps):
         kernel_ms.append(step(i))
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    out = eng.fetch()      # after the all-reduce: global sums of the last step
+    par.barrier()
+    dt = par.max_over_ranks(time.perf_counter() - t0)
+    out = last["out"] if me is not None else eng.fetch()      # after the all-reduce: global sums of the last step
+    if me is not None:
+        par.rccl_ranks = me.rccl_ranks()
     cnt = out["counters"]
     block = None
-    if rank == 0:
+    if par.rank == 0:
         cross_pp = cnt["crossings"] / max(cnt["packets"], 1)
         inter_pp = (cnt["scatterings"] + cnt["absorptions"]) / max(cnt["packets"], 1)
         per_crossing = BYTES_PER_CROSSING
@@ -270,17 +254,21 @@ def thermal_block(M, D, Engine, dist, torch, args, config, world, rank, local_ra
         k_ms = sum(kernel_ms) / len(kernel_ms)
         achieved = bytes_launch / (k_ms * 1e-3) / 1e9
         pmc = pmc_summary(config, n_local, world)
-        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        rate_gpu = n_local / (k_ms * 1e-3)
+        valu_pp = (pmc.get("insts_per_packet") or {}).get("valu")
+        binned = cfg.l3D and config != "voronoi" and eng.get_info("bin_buckets") > 0
+        # What binds the kernel: the 2D working set lives in LDS and L2, so the kernels issue
+        # vector-ALU instructions, not HBM requests; `frac` stays SURVEY 8(d)'s algorithmic-bytes figure.
+        roof = {"bound": "valu-issue", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": pmc.get("hbm_bytes"),
-                "kernel": {"voronoi": "k_thermal_voro_cache", "ref41_var": "k_thermal_var"}.get(config, "k_thermal_roles"), "kernel_ms": k_ms,
-                "algorithmic_bytes_per_launch": bytes_launch,
-                # what `achieved` is: SURVEY 8(d)'s per-crossing byte model x the kernel's own event counts / kernel time.
-                # The 2D working set (absorbed-energy grid, tables, packet records) lives in LDS and L2, so the model
-                # bytes are NOT HBM traffic: `traffic` (PMC) is, and the binding resource is instruction issue
-                # (valu_busy, waves_per_simd)
-                "note": "achieved = algorithmic bytes (SURVEY 8d model) / kernel time; HBM utilisation = traffic / kernel_ms",
+                "kernel": {"voronoi": "k_thermal_voro_cache", "ref41_var": "k_thermal_var"}.get(
+                    config, "k_thermal_roles_bin (+ k_fold_bins)" if binned else "k_thermal_roles"),
+                "kernel_ms": k_ms, "algorithmic_bytes_per_launch": bytes_launch,
+                "note": "achieved / frac = algorithmic bytes (SURVEY 8d model) / kernel time against the HBM peak; the bound "
+                        "names what the counters show binding the kernel; hbm_frac_measured = PMC traffic / kernel time",
+                "valu_issue_frac": (valu_pp * rate_gpu / VALU_ISSUE_PEAK) if valu_pp else None,
                 "hbm_frac_measured": (pmc["hbm_bytes"] / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if pmc.get("hbm_bytes") else None,
-                "valu_busy": pmc.get("valu_busy"), "wait_frac": pmc.get("wait_frac"),
+                "valu_busy": min(1.0, pmc["valu_busy"]) if pmc.get("valu_busy") else None, "wait_frac": pmc.get("wait_frac"),
                 "waves_per_simd": pmc.get("waves_per_simd"), "fp64_tflops": pmc.get("fp64_tflops"),
                 "lane_utilisation": pmc.get("lane_utilisation")}
         block = {"value": n_total * steps / dt, "unit": "packets/s", "steps": steps, "warmup": warmup,
@@ -298,16 +286,120 @@ def thermal_block(M, D, Engine, dist, torch, args, config, world, rank, local_ra
                                 "mrw_steps_per_packet": cnt["mrw_steps"] / max(cnt["packets"], 1)}
                                if config == "ref41_mrw" else {})},
                  "roofline": roof}
-        if cfg.l3D and config != "voronoi":   # binned deposits (mc_binned.hip.h): how the step was chunked, what overflowed
+        if binned:   # binned deposits (mc_binned.hip.h): how the step was chunked, what overflowed
             block["binned_deposits"] = {k: eng.get_info("bin_" + k) for k in
                                         ("buckets", "log_blocks", "chunks", "deposits_per_packet", "overflow_blocks", "drained_records")}
         if with_cpu:
             base, T_cpu, n_cpu = cpu_baseline(model, n_total, args.cpu_seconds)
             block["cpu_baseline"] = base
             if not args.frozen:  # Tdust of the last timed step against the CPU port's
-                block["tdust_vs_cpu"] = tdust_parity(eng.temp_finale(out["E_abs"]), n_total, T_cpu, n_cpu, cfg.T_min)
-    eng.close()
+                pair = None
+                if (cfg.l3D or config == "voronoi") and me is None:   # this grid's own noise at the CPU sample's packet count
+                    pair = [eng.temp_finale(eng.run_thermal(n_cpu, seed=s)["E_abs"]) for s in (7001, 7002)]
+                block["tdust_vs_cpu"] = tdust_parity(eng.temp_finale(out["E_abs"]), n_total, T_cpu, n_cpu, cfg.T_min, pair)
+    (me or eng).close()
     return block, cfg
+
+
+def sed_block(par, args, steps, warmup, with_cpu, packets, observers):
+    """SED mode on the ref4.1 grid (the second half of BASELINE config 2): one step = the SED Monte Carlo
+    (mcgpu_run_mono: scout + commit passes, ray-tracing deposits) of the listed wavelengths, every stream asked for
+    packets/128/len(wavelengths) packets in the stop bin; streams sharded over the GPUs."""
+    from mcfost_amd import distributed as D
+    from mcfost_amd.engine import Engine, MultiEngine
+    from mcfost_amd.host import model as M
+
+    world = par.n_gpus
+    cfg = M.ref41()
+    if observers:   # ref4.1.para asks for RT n_incl = 3; BASELINE config 2 quotes 10 inclinations
+        cfg.RT_n_incl = observers
+    m = M.build_model(cfg)
+    e = Engine(m, 5e6, device=par.local_rank)
+    T = e.temp_finale(e.run_thermal(5_000_000, seed=3)["E_abs"])
+    M.repartition_energie(m, T)
+    e.close()
+    if par.mode == "library":
+        me = MultiEngine(m, 5e6, devices=tuple(range(world)))
+        engs = me.engines
+    else:
+        me = None
+        engs = [Engine(m, 5e6, device=par.local_rank)]
+    eng = engs[0]
+    if args.xI_precision == 4:
+        for x in engs:
+            x.set_xI_precision(4)
+    lams = [int(x) for x in args.sed_lambdas.split(",")]
+    n_streams = m.cfg.n_photons_loop * world                 # weak scaling: 128 streams per GPU
+    first, count = D.shard_streams(n_streams, par.rank, par.world)
+    # packets in the stop bin per stream so that a step sends about `packets` packets per GPU (1 in ~11 lands there)
+    n2 = max(10, int(packets / 11.0 / m.cfg.n_photons_loop / len(lams)))
+
+    def step(i):
+        sent = 0
+        for lam in lams:
+            if me is not None:   # ONE call per wavelength: streams split, both all-reduces inside the library
+                r = me.run_mono(lam, n2, seed=100 + i, n_chunks=n_streams, fetch_xI=False)
+            else:
+                r = eng.run_mono(lam, n2, seed=100 + i, n_chunks=count, first_chunk=first, fetch_xI=False)
+            sent += int(r["n_sent_chunk"].sum())
+            if par.mode == "torchrun":   # one all-reduce of [sed | n_sent] + xI_scatt per wavelength
+                acc, cnt = eng.device_accumulators()
+                par.dist.all_reduce(acc)
+                par.dist.all_reduce(eng.device_xI())
+                par.torch.cuda.current_stream().synchronize()
+        return sent
+
+    for i in range(warmup):
+        step(-1 - i)
+    par.barrier()
+    t0 = time.perf_counter()
+    sent = 0
+    for i in range(steps):
+        sent += step(i)
+    par.barrier()
+    dt = par.max_over_ranks(time.perf_counter() - t0)
+    sent_all = par.sum_over_ranks(float(sent))
+    block = None
+    if par.rank == 0:
+        if me is not None:
+            par.rccl_ranks = me.rccl_ranks()
+        cnt = eng.fetch()["counters"]
+        cross_pp = cnt["crossings"] / max(cnt["packets"], 1)
+        nRT = m.rt["RT_n_incl"] * m.rt["RT_n_az"]
+        # per crossing: kappa_factor 8 B + one 64-byte xI_scatt record RMW per observer
+        bytes_step = sent_all / world / steps * cross_pp * (8.0 + 2 * 64.0 * nRT)
+        lines_per_rec = 0.5 if args.xI_precision == 4 else 1.0   # default-real records: two observers share a 64-byte line
+        line_ops_s = sent_all / world / dt * cross_pp * nRT * lines_per_rec
+        block = {
+            "metric": "photon packets/sec (whole node), SED-mode MC packet loop with ray-tracing deposits",
+            "value": sent_all / dt, "unit": "packets/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "ref4.1 2D disk 100x70, SED Monte Carlo of wavelengths %s, 128 streams/GPU x %d packets "
+                                   "in the stop bin each, RT1 deposits for %d observers (both passes timed)"
+                                   % (args.sed_lambdas, n2, nRT),
+                       "packets_per_gpu_per_step": sent_all / world / steps, "crossings_per_packet": cross_pp,
+                       "observers": nRT, "xI_record": "f32 pairs" if args.xI_precision == 4 else "f64",
+                       "records_per_s": sent_all / dt * cross_pp * nRT},
+            # one 64-byte record per crossing and observer is one memory-side atomic line operation: that rate, not
+            # bytes, binds this mode (DESIGN.md section 3)
+            "roofline": {"bound": "atomic-rate", "achieved": bytes_step / (dt / steps) / 1e9, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": bytes_step / (dt / steps) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "atomic_rate_frac": line_ops_s / ATOMIC_LINE_PEAK, "atomic_line_ops_per_s": line_ops_s,
+                         "kernel": "k_mono (scout + commit)", "algorithmic_bytes_per_launch": bytes_step},
+        }
+        if with_cpu:
+            from oracle import Oracle
+            cores = _quota_cores()
+            orc = Oracle(m, 5e6)
+            t = time.perf_counter()
+            r = orc.run_mono(lams[0], max(2, int(2e5 / 11 / m.cfg.n_photons_loop)), seed=5, n_threads=cores)
+            dtc = time.perf_counter() - t
+            block["cpu_baseline"] = dict(value=r["counters"]["packets"] / dtc, unit="packets/s", cores=cores, kind="port",
+                                         sample="%d packets of wavelength %d of the same SED workload, %d OpenMP threads, "
+                                                "%.1f s" % (r["counters"]["packets"], lams[0], cores, dtc))
+    (me or eng).close()
+    return block
 
 
 def main():
@@ -317,8 +409,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--packets", type=float, default=1e8, help="packets per GPU per step")
     ap.add_argument("--config", default="pascucci", choices=["pascucci", "ref41", "ref41_mrw", "ref41_var", "ref41_3d", "voronoi", "sed"],
-                    help="pascucci (default): the disk BASELINE.json's metric is quoted on, with ref4.1 (configs[1]) as a "
-                         "second full block of the same line")
+                    help="pascucci (default): the disk BASELINE.json's metric is quoted on, with the other configurations as "
+                         "blocks of the same line")
     ap.add_argument("--sed-lambdas", default="5,15,25,35",
                     help="--config sed: wavelengths (1-based) whose SED Monte Carlo one step runs")
     ap.add_argument("--sites", type=int, default=100000,
@@ -329,10 +421,12 @@ def main():
     ap.add_argument("--var-identical", action="store_true", help="--config ref41_var: every class gets the model's own tables "
                     "(the physics of --config ref41 through the HBM-gather kernel)")
     ap.add_argument("--mrw-gamma", type=float, default=2.0, help="--config ref41_mrw: gamma_MRW")
-    ap.add_argument("--dust-mass", type=float, default=0.0, help="override the disk's dust mass [Msun] (thermal configs)")
-    ap.add_argument("--no-ref41", action="store_true", help="--config pascucci: skip the ref4.1 block")
-    ap.add_argument("--no-pascucci", action="store_true", help="(kept for older command lines: same as --no-ref41)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--dust-mass", type=float, default=0.0, help="override the disk's dust mass [Msun] (thermal configs; "
+                    "ref41_mrw defaults to 10x the stock mass)")
+    ap.add_argument("--no-ref41", action="store_true", help="--config pascucci: the headline block alone (same as --no-extra)")
+    ap.add_argument("--no-extra", action="store_true", help="--config pascucci: the headline block alone")
+    ap.add_argument("--no-pascucci", action="store_true", help="(kept for older command lines: same as --no-extra)")
+    ap.add_argument("--cpu-seconds", type=float, default=8.0)
     ap.add_argument("--grid-blocks", type=int, default=0)
     ap.add_argument("--block-threads", type=int, default=0)
     ap.add_argument("--no-pola", action="store_true", help="tuning aid: do not track Stokes Q,U,V")
@@ -341,47 +435,55 @@ def main():
                          "(keeps the physics identical across diagnostic builds); not the benchmark")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
-    from mcfost_amd import distributed as D
-    from mcfost_amd.engine import Engine
-    from mcfost_amd.host import model as M
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    par = Par(args.gpus)
+    if par.mode == "torchrun" and par.world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE = %d" % (args.gpus, par.world))
+    world = par.n_gpus
+    with_cpu = world == 1 and not args.no_cpu_baseline
+    launcher = {"single": "one process, one GPU", "torchrun": "one process per GPU, torch.distributed nccl (RCCL)",
+                "library": "one process, mcgpu_multi_* (RCCL inside the library)"}[par.mode]
 
     if args.config == "sed":
-        return bench_sed(args, world, rank, local_rank)
-    with_cpu = world == 1 and not args.no_cpu_baseline
-    block, cfg = thermal_block(M, D, Engine, dist, torch, args, args.config, world, rank, local_rank, args.steps,
-                               args.warmup, with_cpu)
-    extra = None
-    if args.config == "pascucci" and not (args.no_ref41 or args.no_pascucci) and not args.frozen:
+        line = sed_block(par, args, args.steps, args.warmup, with_cpu, args.packets, args.sed_observers)
+        if par.rank == 0:
+            line["launcher"] = launcher
+            if par.rccl_ranks is not None:
+                line["rccl_ranks"] = par.rccl_ranks
+            print(json.dumps(line))
+        par.finish()
+        return
+
+    block, cfg = thermal_block(par, args, args.config, args.steps, args.warmup, with_cpu, args.packets)
+    extras = {}
+    if args.config == "pascucci" and not (args.no_ref41 or args.no_pascucci or args.no_extra) and not args.frozen:
         # BASELINE.json lists ref4.1 as the single-GPU configuration (configs[1]): the same loop, same packet count,
         # same steps, barriers and all-reduce, with its own roofline, CPU baseline and temperature parity
-        extra, _ = thermal_block(M, D, Engine, dist, torch, args, "ref41", world, rank, local_rank, args.steps,
-                                 args.warmup, with_cpu)
-    if rank == 0:
+        extras["ref41_2d"], _ = thermal_block(par, args, "ref41", args.steps, args.warmup, with_cpu, args.packets)
+        if world == 1:   # ... and, on one GPU, every other BASELINE configuration under the same clock
+            extras["ref41_3d"], _ = thermal_block(par, args, "ref41_3d", args.steps, args.warmup, with_cpu, args.packets)
+            try:
+                extras["voronoi"], _ = thermal_block(par, args, "voronoi", max(1, args.steps - 1), 1, with_cpu, args.packets)
+            except Exception as ex:   # (the tessellation of the stand-in needs scipy's Qhull and a minute of host time)
+                extras["voronoi"] = {"skipped": repr(ex)}
+            # BASELINE config 4: an optically thick midplane (10x the dust) with the modified random walk; tail-bound
+            # (DESIGN.md section 7), so a step is 1e7 packets
+            extras["ref41_mrw"], _ = thermal_block(par, args, "ref41_mrw", 1, 1, with_cpu, min(args.packets, 1e7))
+            # the SED half of BASELINE config 2: 10 observers
+            extras["sed"] = sed_block(par, args, 1, 0, with_cpu, min(args.packets, 2e7), args.sed_observers or 10)
+    if par.rank == 0:
         line = {"metric": "photon packets/sec (whole node), thermal MC packet loop, %s" % cfg.name,
                 "value": block["value"], "unit": "packets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": block["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": "f64", "data": "synthetic", "config": block["config"], "roofline": block["roofline"]}
-        for k in ("cpu_baseline", "tdust_vs_cpu"):
+                "dtype": "f64", "data": "synthetic", "config": block["config"], "roofline": block["roofline"],
+                "launcher": launcher}
+        if par.rccl_ranks is not None:
+            line["rccl_ranks"] = par.rccl_ranks
+        for k in ("cpu_baseline", "tdust_vs_cpu", "binned_deposits"):
             if k in block:
                 line[k] = block[k]
-        if extra is not None:
-            line["ref41_2d"] = extra
+        line.update(extras)
         print(json.dumps(line))
-    if world > 1:
-        dist.destroy_process_group()
+    par.finish()
 
 
 if __name__ == "__main__":

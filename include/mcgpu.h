@@ -566,7 +566,21 @@ int mcgpu_temp_approx_diffusion_vertical(mcgpu_ctx *ctx, const double *tab_lambd
  * thermal_emission.f90:670), then ONE ncclAllReduce sums the fused accumulator
  * [E_abs | sed | n_sent | counters] over xGMI and the outputs are read from device 0.
  * kernel_ms = the slowest device's packet loop.  With n_dev = 1 the result equals
- * mcgpu_run_thermal's.
+ * mcgpu_run_thermal's (and no communicator is created: the RCCL communicators are opened by the
+ * first call that has something to reduce; mcgpu_multi_rccl_ranks reads ncclCommCount back).
+ * opts->accumulate = 1: after the last call's in-place all-reduce every device holds the global
+ * sums, so each device first scales what it holds by 1 / n_dev (exact for 2, 4, 8 devices) and
+ * devices > 0 clear their event counters -- the next all-reduce then returns old totals + new
+ * parts, and the in-flight temperature's `local * n_replicas` stays the right estimate.
+ * An error on one device leaves nothing of the call running on the others.
+ *
+ * mcgpu_multi_run_mono replaces `call mc_photon_loop(lambda, ...)` of the SED loop
+ * (dust_transfer.f90:939) the same way: the opts->n_chunks independent streams are split into
+ * contiguous ranges (n_dev <= n_chunks), every device runs mcgpu_run_mono on its range (one host
+ * thread per device inside the call), then one all-reduce sums [sed | n_sent | counters] and one
+ * xI_scatt.  Afterwards every context holds the sums: read them with mcgpu_fetch / mcgpu_fetch_xI
+ * on mcgpu_multi_ctx(m, 0) and run mcgpu_rt1_dust_map on any device.  n_sent_chunk[n_chunks] as
+ * in mcgpu_run_mono.
  */
 typedef struct mcgpu_multi mcgpu_multi;
 int mcgpu_multi_create(int n_dev, const int *devices, mcgpu_multi **out);
@@ -577,6 +591,10 @@ const char *mcgpu_multi_last_error(const mcgpu_multi *m);
 void mcgpu_shard_packets(uint64_t n_packets, int rank, int world, uint64_t *first, uint64_t *count);
 int mcgpu_multi_run_thermal(mcgpu_multi *m, const mcgpu_run_opts *opts, double *E_abs, double *sed,
                             double *n_sent, uint64_t *counters, double *kernel_ms);
+int mcgpu_multi_run_mono(mcgpu_multi *m, const mcgpu_mono_opts *opts, double frac_E_stars,
+                         double frac_E_disk, const double *prob_E_cell, uint64_t *n_sent_chunk,
+                         double *kernel_ms);
+int mcgpu_multi_rccl_ranks(mcgpu_multi *m);
 
 #ifdef __cplusplus
 }

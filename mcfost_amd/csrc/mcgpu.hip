@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "mc_device.hip.h"
@@ -2180,10 +2181,22 @@ extern "C" int mcgpu_probe_packet_rand(mcgpu_ctx* ctx, uint64_t seed, uint64_t p
 // ---------------------------------------------------------------------------------------------
 struct mcgpu_multi {
   int n_dev = 0;
+  std::vector<int> devs;
   std::vector<mcgpu_ctx*> ctx;
-  std::vector<ncclComm_t> comm;
+  std::vector<ncclComm_t> comm;   // empty until the first collective (one device never needs them)
+  bool reduced = false;           // the accumulators of every device hold the all-reduced totals of the last call
+  bool reduced_xI = false;
   std::string err;
 };
+
+__global__ void k_scale_f64(double* a, size_t n, double f) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a[i] *= f;
+}
+__global__ void k_scale_f32(float* a, size_t n, float f) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a[i] *= f;
+}
 
 extern "C" int mcgpu_multi_create(int n_dev, const int* devices, mcgpu_multi** out) {
   if (!out || n_dev < 1) return MCGPU_ERR_ARG;
@@ -2198,18 +2211,25 @@ extern "C" int mcgpu_multi_create(int n_dev, const int* devices, mcgpu_multi** o
   }
   mcgpu_multi* mm = new mcgpu_multi();
   mm->n_dev = n_dev;
+  mm->devs = devs;
   mm->ctx.assign(n_dev, nullptr);
-  mm->comm.assign(n_dev, nullptr);
   for (int i = 0; i < n_dev; ++i) {
     const int rc = mcgpu_create(devs[i], &mm->ctx[i]);
     if (rc) { for (int j = 0; j < i; ++j) mcgpu_destroy(mm->ctx[j]); delete mm; return rc; }
   }
-  if (ncclCommInitAll(mm->comm.data(), n_dev, devs.data()) != ncclSuccess) {
-    for (int j = 0; j < n_dev; ++j) mcgpu_destroy(mm->ctx[j]);
-    delete mm;
+  *out = mm;
+  return MCGPU_OK;
+}
+
+// the RCCL communicators, created by the first call that has something to reduce (n_dev > 1)
+static int multi_comms(mcgpu_multi* mm) {
+  if (mm->n_dev < 2 || !mm->comm.empty()) return MCGPU_OK;
+  mm->comm.assign(mm->n_dev, nullptr);
+  if (ncclCommInitAll(mm->comm.data(), mm->n_dev, mm->devs.data()) != ncclSuccess) {
+    mm->comm.clear();
+    mm->err = "ncclCommInitAll failed";
     return MCGPU_ERR_HIP;
   }
-  *out = mm;
   return MCGPU_OK;
 }
 
@@ -2217,7 +2237,7 @@ extern "C" int mcgpu_multi_destroy(mcgpu_multi* mm) {
   if (!mm) return MCGPU_OK;
   for (int i = 0; i < mm->n_dev; ++i) {
     if (mm->ctx[i]) { hipSetDevice(mm->ctx[i]->device); hipDeviceSynchronize(); }
-    if (mm->comm[i]) ncclCommDestroy(mm->comm[i]);
+    if (i < (int)mm->comm.size() && mm->comm[i]) ncclCommDestroy(mm->comm[i]);
   }
   for (int i = 0; i < mm->n_dev; ++i) mcgpu_destroy(mm->ctx[i]);
   delete mm;
@@ -2227,6 +2247,12 @@ extern "C" int mcgpu_multi_destroy(mcgpu_multi* mm) {
 extern "C" int mcgpu_multi_size(const mcgpu_multi* mm) { return mm ? mm->n_dev : 0; }
 extern "C" mcgpu_ctx* mcgpu_multi_ctx(mcgpu_multi* mm, int i) { return (mm && i >= 0 && i < mm->n_dev) ? mm->ctx[i] : nullptr; }
 extern "C" const char* mcgpu_multi_last_error(const mcgpu_multi* mm) { return mm ? mm->err.c_str() : "null handle"; }
+// ranks of the handle's RCCL communicator as RCCL reports them (0: no communicator yet -- one device, or nothing reduced so far)
+extern "C" int mcgpu_multi_rccl_ranks(mcgpu_multi* mm) {
+  if (!mm || mm->comm.empty() || !mm->comm[0]) return 0;
+  int n = 0;
+  return ncclCommCount(mm->comm[0], &n) == ncclSuccess ? n : -1;
+}
 
 // the shard of device i: contiguous, disjoint, exhaustive (same rule as mcfost_amd/distributed.py::shard_packets)
 extern "C" void mcgpu_shard_packets(uint64_t n_packets, int rank, int world, uint64_t* first, uint64_t* count) {
@@ -2235,11 +2261,68 @@ extern "C" void mcgpu_shard_packets(uint64_t n_packets, int rank, int world, uin
   if (first) *first = (uint64_t)rank * base + ((uint64_t)rank < rem ? (uint64_t)rank : rem);
 }
 
+static void multi_drain(mcgpu_multi* mm) {  // after an error: nothing of this call is left running on any device
+  for (int i = 0; i < mm->n_dev; ++i) { hipSetDevice(mm->ctx[i]->device); hipStreamSynchronize(mm->ctx[i]->stream); }
+}
+
+// An accumulating call on several devices: after the last call's in-place all-reduce EVERY device holds the global
+// sums G, and adding this call's local parts L_i to n copies of G would reduce to n G + sum L_i.  So each device first
+// scales what it holds by 1/n -- n (G / n + L_i) = G + n L_i is also exactly what the in-flight temperature's
+// `local * n_replicas` should see -- and devices > 0 clear their event counters (integers; device 0 keeps the totals).
+// Exact for 2, 4, 8 devices (a power of two); otherwise G / n carries one rounding.
+static int multi_prepare_accumulate(mcgpu_multi* mm, bool with_xI) {
+  const int n = mm->n_dev;
+  if (n < 2) return MCGPU_OK;
+  for (int i = 0; i < n; ++i) {
+    mcgpu_ctx* c = mm->ctx[i];
+    if (hipSetDevice(c->device) != hipSuccess) return MCGPU_ERR_HIP;
+    if (mm->reduced && c->d_accum) {
+      hipLaunchKernelGGL(k_scale_f64, dim3((unsigned)((c->n_accum + 255) / 256)), dim3(256), 0, c->stream, c->d_accum, c->n_accum, 1.0 / n);
+      if (i > 0 && hipMemsetAsync(c->d_counters, 0, MCGPU_N_COUNTERS * sizeof(unsigned long long), c->stream) != hipSuccess) return MCGPU_ERR_HIP;
+    }
+    if (with_xI && mm->reduced_xI && c->d_xI) {
+      const size_t nv = xi_dev_values(c);
+      if (c->xI_bytes == 4) hipLaunchKernelGGL(k_scale_f32, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, c->stream, reinterpret_cast<float*>(c->d_xI), nv, 1.0f / n);
+      else hipLaunchKernelGGL(k_scale_f64, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, c->stream, c->d_xI, nv, 1.0 / n);
+    }
+    if (hipGetLastError() != hipSuccess) return MCGPU_ERR_HIP;
+  }
+  return MCGPU_OK;
+}
+
+// ONE all-reduce of the fused accumulator (counters in its tail), in place, on every device's own stream; with_xI:
+// and one of xI_scatt
+static int multi_allreduce(mcgpu_multi* mm, bool with_xI) {
+  const int n = mm->n_dev;
+  auto failed = [&](int i, int rc) { mm->err = "device " + std::to_string(i) + ": " + mcgpu_last_error(mm->ctx[i]); return rc; };
+  if (n < 2) return MCGPU_OK;
+  int rc = multi_comms(mm);
+  if (rc) return rc;
+  for (int i = 0; i < n; ++i) if ((rc = mcgpu_counters_to_accum(mm->ctx[i]))) return failed(i, rc);
+  if (ncclGroupStart() != ncclSuccess) { mm->err = "ncclGroupStart failed"; return MCGPU_ERR_HIP; }
+  bool bad = false;
+  for (int i = 0; i < n && !bad; ++i) {
+    mcgpu_ctx* c = mm->ctx[i];
+    hipSetDevice(c->device);
+    bad = ncclAllReduce(c->d_accum, c->d_accum, c->n_accum, ncclDouble, ncclSum, mm->comm[i], c->stream) != ncclSuccess;
+    if (!bad && with_xI && c->d_xI)
+      bad = ncclAllReduce(c->d_xI, c->d_xI, xi_dev_values(c), c->xI_bytes == 4 ? ncclFloat : ncclDouble, ncclSum, mm->comm[i], c->stream) != ncclSuccess;
+  }
+  if (ncclGroupEnd() != ncclSuccess || bad) { mm->err = "ncclAllReduce failed"; return MCGPU_ERR_HIP; }
+  for (int i = 0; i < n; ++i) if ((rc = mcgpu_counters_from_accum(mm->ctx[i]))) return failed(i, rc);
+  mm->reduced = true;
+  if (with_xI) mm->reduced_xI = true;
+  return MCGPU_OK;
+}
+
 extern "C" int mcgpu_multi_run_thermal(mcgpu_multi* mm, const mcgpu_run_opts* opts, double* E_abs, double* sed,
                                        double* n_sent, uint64_t* counters, double* kernel_ms) {
   if (!mm || !opts) return MCGPU_ERR_ARG;
   const int n = mm->n_dev;
-  auto failed = [&](int i, int rc) { mm->err = "device " + std::to_string(i) + ": " + mcgpu_last_error(mm->ctx[i]); return rc; };
+  auto failed = [&](int i, int rc) { mm->err = "device " + std::to_string(i) + ": " + mcgpu_last_error(mm->ctx[i]); multi_drain(mm); return rc; };
+  int rc;
+  if (opts->accumulate) { if ((rc = multi_prepare_accumulate(mm, false))) { multi_drain(mm); return rc; } }
+  else mm->reduced = false;
   // 1) every device runs its shard of the packet ids; the in-flight temperature scales the local partial sum by
   //    the number of replicas (thermal_emission.f90:670)
   for (int i = 0; i < n; ++i) {
@@ -2249,39 +2332,59 @@ extern "C" int mcgpu_multi_run_thermal(mcgpu_multi* mm, const mcgpu_run_opts* op
     o.first_packet = opts->first_packet + first;
     o.n_packets = count;
     o.n_replicas = (opts->n_replicas >= 1.0 ? opts->n_replicas : 1.0) * (double)n;
-    const int rc = mcgpu_launch_thermal(mm->ctx[i], &o);
-    if (rc) return failed(i, rc);
+    if ((rc = mcgpu_launch_thermal(mm->ctx[i], &o))) return failed(i, rc);
   }
-  // 2) ONE all-reduce of the fused accumulator (counters in its tail), in place, on every device's own stream
-  for (int i = 0; i < n; ++i) {
-    const int rc = mcgpu_counters_to_accum(mm->ctx[i]);
-    if (rc) return failed(i, rc);
-  }
-  if (ncclGroupStart() != ncclSuccess) { mm->err = "ncclGroupStart failed"; return MCGPU_ERR_HIP; }
-  for (int i = 0; i < n; ++i) {
-    mcgpu_ctx* c = mm->ctx[i];
-    hipSetDevice(c->device);
-    if (ncclAllReduce(c->d_accum, c->d_accum, c->n_accum, ncclDouble, ncclSum, mm->comm[i], c->stream) != ncclSuccess) {
-      ncclGroupEnd();
-      mm->err = "ncclAllReduce failed on device " + std::to_string(i);
-      return MCGPU_ERR_HIP;
-    }
-  }
-  if (ncclGroupEnd() != ncclSuccess) { mm->err = "ncclGroupEnd failed"; return MCGPU_ERR_HIP; }
-  for (int i = 0; i < n; ++i) {
-    const int rc = mcgpu_counters_from_accum(mm->ctx[i]);
-    if (rc) return failed(i, rc);
-  }
+  // 2) the all-reduce (nothing to do on one device: no communicator is ever created there)
+  if ((rc = multi_allreduce(mm, false))) { multi_drain(mm); return rc; }
   // 3) wait; the packet loop's time is the slowest device's
   double ms_max = 0.0;
   for (int i = 0; i < n; ++i) {
     double ms = 0.0;
-    const int rc = mcgpu_sync(mm->ctx[i], &ms);
-    if (rc) return failed(i, rc);
+    if ((rc = mcgpu_sync(mm->ctx[i], &ms))) return failed(i, rc);
     if (ms > ms_max) ms_max = ms;
   }
   if (kernel_ms) *kernel_ms = ms_max;
-  const int rc = mcgpu_fetch(mm->ctx[0], E_abs, sed, n_sent, counters);  // every device now holds the global sums
-  if (rc) return failed(0, rc);
+  if ((rc = mcgpu_fetch(mm->ctx[0], E_abs, sed, n_sent, counters))) return failed(0, rc);  // every device now holds the global sums
+  return MCGPU_OK;
+}
+
+// One wavelength of the SED Monte Carlo on every device of the handle: replaces the call at dust_transfer.f90:939 for a
+// host with several GPUs.  The opts->n_chunks streams are split into contiguous ranges (they are independent and carry
+// their own stopping rule, dust_transfer.f90:525-553), each device runs mcgpu_run_mono on its range -- from a host
+// thread of its own, the call's scout / commit passes are synchronous --, then ONE all-reduce sums
+// [sed | n_sent | counters] and one xI_scatt.  Needs n_dev <= n_chunks.  Afterwards every device holds the sums
+// (mcgpu_rt1_dust_map may run on any of them); sed, n_sent, counters and xI_scatt are read from device 0's context.
+extern "C" int mcgpu_multi_run_mono(mcgpu_multi* mm, const mcgpu_mono_opts* opts, double frac_E_stars, double frac_E_disk,
+                                    const double* prob_E_cell, uint64_t* n_sent_chunk, double* kernel_ms) {
+  if (!mm || !opts) return MCGPU_ERR_ARG;
+  const int n = mm->n_dev;
+  if (opts->n_chunks < n) { mm->err = "mcgpu_multi_run_mono: more devices than streams"; return MCGPU_ERR_ARG; }
+  int rc;
+  if (opts->accumulate) { if ((rc = multi_prepare_accumulate(mm, opts->rt1 != 0))) { multi_drain(mm); return rc; } }
+  else { mm->reduced = false; mm->reduced_xI = false; }
+  std::vector<int> rcs(n, 0);
+  std::vector<double> ms(n, 0.0);
+  std::vector<std::thread> th;
+  for (int i = 0; i < n; ++i) {
+    th.emplace_back([&, i]() {
+      mcgpu_mono_opts o = *opts;
+      uint64_t first = 0, count = 0;
+      mcgpu_shard_packets((uint64_t)opts->n_chunks, i, n, &first, &count);
+      o.first_chunk = opts->first_chunk + (int)first;
+      o.n_chunks = (int)count;
+      rcs[i] = mcgpu_run_mono(mm->ctx[i], &o, frac_E_stars, frac_E_disk, prob_E_cell, n_sent_chunk ? n_sent_chunk + first : nullptr, &ms[i]);
+    });
+  }
+  for (auto& t : th) t.join();
+  for (int i = 0; i < n; ++i)
+    if (rcs[i]) { mm->err = "device " + std::to_string(i) + ": " + mcgpu_last_error(mm->ctx[i]); multi_drain(mm); return rcs[i]; }
+  if ((rc = multi_allreduce(mm, opts->rt1 != 0))) { multi_drain(mm); return rc; }
+  double ms_max = 0.0;
+  for (int i = 0; i < n; ++i) {
+    hipSetDevice(mm->ctx[i]->device);
+    if (hipStreamSynchronize(mm->ctx[i]->stream) != hipSuccess) { mm->err = "stream synchronisation failed"; return MCGPU_ERR_HIP; }
+    if (ms[i] > ms_max) ms_max = ms[i];
+  }
+  if (kernel_ms) *kernel_ms = ms_max;
   return MCGPU_OK;
 }

@@ -36,7 +36,7 @@ ABI_SYMBOLS = (
     "mcgpu_device_xI", "mcgpu_set_ism", "mcgpu_rt1_dust_map", "mcgpu_set_xI", "mcgpu_rt1_image", "mcgpu_set_xI_precision",
     "mcgpu_get_xI_precision", "mcgpu_set_option", "mcgpu_get_info", "mcgpu_counters_to_accum", "mcgpu_counters_from_accum",
     "mcgpu_set_grid_sph", "mcgpu_temp_approx_diffusion_vertical", "mcgpu_set_mrw", "mcgpu_fetch_radiation_field", "mcgpu_set_variable_dust", "mcgpu_rt1_stars_map_sed", "mcgpu_define_dark_zone", "mcgpu_init_reemission", "mcgpu_multi_create", "mcgpu_multi_destroy", "mcgpu_multi_size", "mcgpu_multi_ctx", "mcgpu_multi_last_error",
-    "mcgpu_shard_packets", "mcgpu_multi_run_thermal",
+    "mcgpu_shard_packets", "mcgpu_multi_run_thermal", "mcgpu_multi_run_mono", "mcgpu_multi_rccl_ranks",
 )
 
 
@@ -625,6 +625,49 @@ class MultiEngine:
             raise McgpuError(f"mcgpu_multi_run_thermal failed ({rc}): {msg.decode() if msg else ''}")
         return dict(E_abs=E, sed=sed, n_sent=n_sent, kernel_ms=ms.value,
                     counters=dict(zip(COUNTER_NAMES, (int(c) for c in cnt))))
+
+    def run_mono(self, lam, n_photons2, n_phot_lim=None, p_lambda=None, seed=1, n_chunks=None, rt1=True,
+                 accumulate=False, fetch_xI=True, first_chunk=0):
+        """One wavelength of the SED Monte Carlo on every device (``mcgpu_multi_run_mono``): the streams are split
+        among the devices, ONE all-reduce of [sed | n_sent | counters] and one of xI_scatt; same outputs as
+        ``Engine.run_mono``, read from device 0."""
+        m = self.model
+        e0 = self.engines[0]
+        for e in self.engines:
+            if rt1 and not getattr(e, "_rt1", False):
+                e.set_rt1()
+        nt, nphi = m.cfg.N_thet, m.cfg.N_phi
+        n_chunks = int(n_chunks or m.cfg.n_photons_loop)
+        if n_phot_lim is None:  # read_param.f90:551
+            n_phot_lim = float(np.float32(1.0e4) * np.float32(nt) * np.float32(nphi) * np.float32(n_photons2))
+        o = MonoOpts(seed, int(lam), int(p_lambda or lam), n_chunks, int(first_chunk), int(n_photons2), float(n_phot_lim),
+                     int(m.capt_sup), int(rt1), int(accumulate), 0, 0)
+        pe = getattr(m, "prob_E_cell", None)
+        pe_l = None
+        if pe is not None:
+            pe_l = _a(np.asarray(pe).reshape(m.n_lambda, m.n_cells + 1)[lam - 1], np.float64)
+        per_chunk = np.zeros(n_chunks, np.uint64)
+        ms = C.c_double()
+        rc = self.lib.mcgpu_multi_run_mono(
+            self.h, C.byref(o), C.c_double(float(m.frac_E_stars[lam - 1])), C.c_double(float(m.frac_E_disk[lam - 1])),
+            _p(pe_l, C.c_double) if pe_l is not None else None, _p(per_chunk, C.c_uint64), C.byref(ms))
+        if rc:
+            msg = self.lib.mcgpu_multi_last_error(self.h)
+            raise McgpuError(f"mcgpu_multi_run_mono failed ({rc}): {msg.decode() if msg else ''}")
+        out = e0.fetch()
+        out["n_sent_chunk"] = per_chunk
+        out["kernel_ms"] = ms.value
+        if rt1 and fetch_xI:
+            x64 = np.zeros(e0.xI_shape(), np.float64)
+            x32 = np.zeros(e0.xI_shape(), np.float32)
+            e0._chk(self.lib.mcgpu_fetch_xI(e0.ctx, _p(x32, C.c_float), _p(x64, C.c_double)), "mcgpu_fetch_xI")
+            out["xI_scatt"], out["xI_scatt_f32"] = x64, x32
+        return out
+
+    def rccl_ranks(self):
+        """Ranks of the handle's RCCL communicator as ``ncclCommCount`` reports them (0 before the first collective
+        and on one device, which never opens one)."""
+        return int(self.lib.mcgpu_multi_rccl_ranks(self.h))
 
     def close(self):
         for e in getattr(self, "engines", []):

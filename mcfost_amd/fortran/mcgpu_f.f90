@@ -67,7 +67,7 @@ module mcgpu_f
        mcgpu_set_stars, mcgpu_set_opacity, mcgpu_set_scattering, mcgpu_set_thermal, mcgpu_set_sed_bins, &
        mcgpu_run_thermal, mcgpu_temp_finale, mcgpu_thermal_loop, mcgpu_error_message, mcgpu_set_rt1, &
        mcgpu_run_mono, mcgpu_fetch, mcgpu_fetch_xI, mcgpu_rt1_dust_map, mcgpu_set_xI, mcgpu_rt1_image, mcgpu_set_xI_precision, &
-       mcgpu_set_E_prior, mcgpu_multi_create, mcgpu_multi_destroy, mcgpu_multi_size, mcgpu_multi_ctx, mcgpu_multi_run_thermal, &
+       mcgpu_set_E_prior, mcgpu_multi_create, mcgpu_multi_destroy, mcgpu_multi_size, mcgpu_multi_ctx, mcgpu_multi_run_thermal, mcgpu_multi_run_mono, mcgpu_multi_rccl_ranks, &
        mcgpu_counters_to_accum, mcgpu_counters_from_accum, mcgpu_temp_approx_diffusion_vertical, mcgpu_set_mrw, mcgpu_fetch_radiation_field, &
        mcgpu_set_variable_dust, mcgpu_rt1_stars_map_sed, mcgpu_define_dark_zone, mcgpu_init_reemission
 
@@ -325,6 +325,26 @@ module mcgpu_f
        integer(c_int64_t), intent(out) :: counters(*)
        real(c_double), intent(out) :: kernel_ms
      end function mcgpu_multi_run_thermal
+
+     ! the SED loop's `call mc_photon_loop(lambda, ...)` (dust_transfer.f90:939) on every device of the handle: streams
+     ! split among the devices, one all-reduce of [sed | n_sent | counters] and one of xI_scatt inside the library;
+     ! results are read with mcgpu_fetch / mcgpu_fetch_xI on mcgpu_multi_ctx(multi, 0)
+     integer(c_int) function mcgpu_multi_run_mono(multi, opts, frac_E_stars, frac_E_disk, prob_E_cell, n_sent_chunk, &
+          kernel_ms) bind(C, name="mcgpu_multi_run_mono")
+       import :: c_int, c_ptr, c_double, c_int64_t, mcgpu_mono_opts
+       type(c_ptr), value :: multi
+       type(mcgpu_mono_opts), intent(in) :: opts
+       real(c_double), value :: frac_E_stars, frac_E_disk
+       type(c_ptr), value :: prob_E_cell    ! c_loc(prob_E_cell(0,lambda)) or c_null_ptr
+       integer(c_int64_t), intent(out) :: n_sent_chunk(*)
+       real(c_double), intent(out) :: kernel_ms
+     end function mcgpu_multi_run_mono
+
+     ! ranks of the handle's RCCL communicator (ncclCommCount); 0 while none has been opened
+     integer(c_int) function mcgpu_multi_rccl_ranks(multi) bind(C, name="mcgpu_multi_rccl_ranks")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: multi
+     end function mcgpu_multi_rccl_ranks
 
      integer(c_int) function mcgpu_counters_to_accum(ctx) bind(C, name="mcgpu_counters_to_accum")
        import :: c_int, c_ptr

@@ -957,6 +957,9 @@ def build_model(cfg: DiskConfig, grid=None, rho=None) -> Model:
     )
 
 
+VORONOI_CACHE_VERSION = 1
+
+
 def build_voronoi_model(cfg: DiskConfig, n_sites: int, seed: int = 1, box_z_over_h: float = 6.0,
                         cut: bool = True, cache_dir: Optional[str] = None) -> Model:
     """BASELINE config 5 stand-in: ``n_sites`` SPH-like sites drawn from the cfg's disk,
@@ -982,17 +985,24 @@ def build_voronoi_model(cfg: DiskConfig, n_sites: int, seed: int = 1, box_z_over
     # (the tessellation of 1e6 sites takes minutes on the host: ``cache_dir`` keeps it between runs of one model)
     grid, cache = None, None
     if cache_dir:
+        import hashlib
         import os
-        cache = os.path.join(cache_dir, "voronoi_%s_%d_%d_%g_%d.npz" % (cfg.name.split()[0], n_sites, seed, box_z_over_h,
-                                                                        int(cut)))
+        # the key names everything the tessellation depends on: the disk that the sites sample, the box, the star's
+        # site, and the version of the builder (bump VORONOI_CACHE_VERSION when host/voronoi.py changes its output)
+        geo = repr((VORONOI_CACHE_VERSION, n_sites, seed, box_z_over_h, int(cut), cfg.rin, cfg.rout, cfg.sclht, cfg.rref,
+                    cfg.exp_beta, cfg.surf, tuple(cfg.star_xyz), float(r_au), limits))
+        cache = os.path.join(cache_dir, "voronoi_%d_%s.npz" % (n_sites, hashlib.sha1(geo.encode()).hexdigest()[:12]))
         if os.path.exists(cache):
             z = np.load(cache)
             grid = {k: (z[k] if z[k].ndim else z[k].item()) for k in z.files}
     if grid is None:
         grid = V.build_voronoi_grid(sites, limits, stars_xyz_r=[(sx, sy, sz, r_au)], h=h, cut=cut)
         if cache:
+            # written under a private name and moved into place: concurrent builders (one per rank) never leave a torn file
             os.makedirs(cache_dir, exist_ok=True)
-            np.savez(cache, **grid)
+            tmp = "%s.%d.tmp.npz" % (cache, os.getpid())
+            np.savez(tmp, **grid)
+            os.replace(tmp, cache)
     # equal-mass SPH particles: rho_i = (M_dust / N) / V_i; star sites carry no dust
     nb = grid["n_cells_before_stars"]
     rho = np.zeros(grid["n_cells"], f64)
