@@ -187,6 +187,7 @@ def build_workload(M, args, config):
         model = M.build_voronoi_model(cfg, args.sites, seed=1, cache_dir=os.path.join(ROOT, "tools", "cache"))
     else:
         model = M.build_model(cfg)
+    model.midplane_snap = 0   # 3D grids: the library's default, the reference's literal arithmetic (include/mcgpu.h)
     if config == "ref41_var":   # every layer of the disk its own dust (lvariable_dust), HBM-gather kernel
         cfg.name += " with variable dust (%d classes%s)" % (cfg.nz, ", all equal to the model's dust" if args.var_identical else "")
         M.init_variable_dust(model, identical=args.var_identical)

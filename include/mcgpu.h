@@ -148,13 +148,13 @@ int mcgpu_set_grid_sph(mcgpu_ctx *ctx, int n_rad, int nz, int n_az, int l3D,
                        const int *cell_map_k, const int *lexit_cell);
 
 /*
- * 3D grids only.  on != 0 (default): a packet that crosses the midplane lands
- * at z = sign(grid_prec, w), i.e. the reference's own z1 == 0 correction
- * (cylindrical_grid.f90:1158-1165) applied to every rounding residue of
- * z0 + t*w.  In the reference the SIGN of that residue -- the last ulp of the
- * product, compiler (FMA) and libm dependent -- decides on which side of the
- * midplane the packet is for the next cell.  on == 0 reproduces the literal
- * arithmetic of a reference built without FMA contraction.
+ * 3D grids only.  on == 0 (default): the reference's literal arithmetic (a build without FMA
+ * contraction) -- a packet that crosses the midplane lands at z0 + t*w, whose SIGN (the last ulp of
+ * the product, compiler and libm dependent) decides on which side of the midplane the packet is for
+ * the next cell.  on != 0: the packet lands at z = sign(grid_prec, w), i.e. the reference's own
+ * z1 == 0 correction (cylindrical_grid.f90:1158-1165) applied to every rounding residue; an
+ * axisymmetric 3D run then reproduces the 2D run packet for packet, and two builds of the algorithm
+ * (this engine and its CPU oracle) can be compared packet for packet -- the parity tests switch it on.
  */
 int mcgpu_set_midplane_snap(mcgpu_ctx *ctx, int on);
 

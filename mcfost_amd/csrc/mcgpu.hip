@@ -161,7 +161,7 @@ extern "C" int mcgpu_create(int device, mcgpu_ctx** out) {
     return MCGPU_ERR_HIP;
   }
   ctx->stream = ctx->own_stream;
-  ctx->M.midplane_snap = 1;
+  ctx->M.midplane_snap = 0;  // the reference's literal arithmetic; mcgpu_set_midplane_snap(ctx, 1) is the option
   if (hipMalloc((void**)&ctx->d_counters, 16 * sizeof(unsigned long long)) != hipSuccess ||
       hipMalloc((void**)&ctx->d_err, sizeof(int)) != hipSuccess) {
     delete ctx;

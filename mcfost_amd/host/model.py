@@ -606,7 +606,8 @@ class Model:
     rho_dust: np.ndarray
     l_dark_zone: Optional[np.ndarray] = None
     p_lambda_fixed: int = 1
-    midplane_snap: int = 1  # engine default (include/mcgpu.h: mcgpu_set_midplane_snap)
+    midplane_snap: int = 1  # the HARNESS's choice (the parity tests compare two builds packet for packet); the library's
+                            # default is 0, the reference's literal arithmetic (include/mcgpu.h: mcgpu_set_midplane_snap)
     extra: dict = field(default_factory=dict)
     # SED mode (ray-tracing method 1): tab_s11_pos(0:nang, n_lambda) and the observer directions
     tab_s11_pos: Optional[np.ndarray] = None

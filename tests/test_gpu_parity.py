@@ -19,7 +19,7 @@ Tolerances (stated here, used below):
 import numpy as np
 import pytest
 
-from helpers import CONFIGS, load_golden, mc_similar, rel_rms
+from helpers import CONFIGS, load_golden, mc_similar, rel_rms, sed_model
 from mcfost_amd.host import model as M
 
 pytestmark = pytest.mark.gpu
@@ -337,6 +337,39 @@ def test_multi_device_entry_with_one_device_equals_the_single_context_call(small
     assert a["counters"] == b["counters"] and b["counters"]["packets"] == n
     assert np.array_equal(a["n_sent"], b["n_sent"]) and np.array_equal(a["sed"][4], b["sed"][4])
     assert np.allclose(a["E_abs"], b["E_abs"], rtol=1e-12, atol=0)
+
+
+def test_multi_device_entry_accumulates_and_runs_the_sed_step(small_model):
+    """mcgpu_multi_*: (a) two accumulating calls equal one call on the union of their packets (on several devices each
+    call first scales the all-reduced totals every device holds by 1 / n_dev, see include/mcgpu.h; on one device
+    nothing is scaled and no communicator is opened); (b) mcgpu_multi_run_mono with one device returns what
+    mcgpu_run_mono returns."""
+    from mcfost_amd.engine import MultiEngine
+    n = 20000
+    o = _oracle(small_model, 2 * n)
+    prior = o.run_thermal(2000, seed=1)["E_abs"]
+    me = MultiEngine(small_model, 2 * n, devices=(0,))
+    me.run_thermal(n, seed=11, first_packet=0, frozen=True, E_prior=prior)
+    ab = me.run_thermal(n, seed=11, first_packet=n, frozen=True, accumulate=True)
+    assert me.rccl_ranks() == 0          # one device: no RCCL communicator was ever needed
+    me.close()
+    e = _engine(small_model, 2 * n)
+    u = e.run_thermal(2 * n, seed=11, frozen=True, E_prior=prior)
+    e.close()
+    assert ab["counters"] == u["counters"] and u["counters"]["packets"] == 2 * n
+    assert np.array_equal(ab["n_sent"], u["n_sent"]) and np.array_equal(ab["sed"][4], u["sed"][4])
+    assert np.allclose(ab["E_abs"], u["E_abs"], rtol=1e-12, atol=0)
+
+    m = sed_model(M.small(RT_n_incl=3))
+    e = _engine(m, 1e5)
+    a = e.run_mono(5, 40, seed=3, n_chunks=8)
+    e.close()
+    me = MultiEngine(m, 1e5, devices=(0,))
+    b = me.run_mono(5, 40, seed=3, n_chunks=8)
+    me.close()
+    assert np.array_equal(a["n_sent_chunk"], b["n_sent_chunk"]) and a["counters"] == b["counters"]
+    assert np.array_equal(a["sed"][4], b["sed"][4])
+    assert np.allclose(a["xI_scatt"], b["xI_scatt"], rtol=1e-12, atol=0)
 
 
 def test_single_role_schedule_option(small_model):

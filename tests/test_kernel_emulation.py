@@ -178,7 +178,7 @@ def test_emulated_kernel_disk_emission(emu, small_model):
 
 
 def test_axisymmetric_3d_reproduces_2d_packet_for_packet():
-    """Why the engine defaults to mcgpu_set_midplane_snap(1): an axisymmetric 3D
+    """What the option mcgpu_set_midplane_snap(1) is for (the library defaults to the literal arithmetic): an axisymmetric 3D
     grid must give the same physics as the 2D grid (which has no cell wall at
     the midplane, cylindrical_grid.f90:1032-1040).  With the snap the 3D run
     reproduces the 2D run packet for packet (same seeds, frozen temperature,
