@@ -46,6 +46,10 @@
 #include "mc_voronoi.hip.h"
 #include "mc_binned.hip.h"
 
+#ifndef MCGPU_3D_BRANCHY  // 1: the 3D crossing through roles_cross / cross_cell_lean (A/B builds), 0: fly_step_3d
+#define MCGPU_3D_BRANCHY 0
+#endif
+
 #ifdef MCGPU_COUNT_ITERS  // diagnostic build (tools/roles_check.py diag): statements that only count
 #define RQ_DIAG(...) __VA_ARGS__
 #else
@@ -378,6 +382,178 @@ __device__ __forceinline__ int fly_step_2d(const Lds& T, const DevModel& M, cons
   return ((active && !out && killed) || runaway) ? 1 : 0;
 }
 
+// The crossing of a 3D cylindrical grid in the same straight-line, select-committed form (cross_cell_lean<true> +
+// roles_cross above, statement for statement: cylindrical_grid.f90:918-1175 with the azimuthal walls :1058-1094,
+// optical_depth.f90:77-178).  What stays a branch: the stop (a division, and the 3D re-indexing of the stopping point,
+// optical_depth.f90:140 -> index_cell: a bisection and an atan2), the deposit, the azimuth of a packet that leaves the
+// central hole (atan2), and the rare fallbacks of the zj recomputation.  The wall at tan(phi) = +-1e300 and the
+// ordinary azimuthal wall share ONE division (numerator and denominator are selected first).
+// BIN: the deposit is handed back (dep_ic >= 0, dep_v) for the caller's bin_deposit.
+template <bool DARK, bool LDSE, bool BIN>
+__device__ __forceinline__ int fly_step_3d(const Lds& T, const DevModel& M, const RunArgs& A, double* E_lds, Flight& p,
+                                           unsigned int& c_cross, unsigned int& c_kill, unsigned int& c_dark, int& dep_ic,
+                                           double& dep_v) {
+  const int n_rad = M.n_rad, nz = M.nz, n_az = M.n_az;
+  const double cm = 1.0 - GRID_PREC, cp = 1.0 + GRID_PREC;
+  const double r1e30 = 1.00000001504746621988e+30;
+  const bool active = (p.st == S_FLIGHT);
+  const int ri0 = p.ri, zj0 = p.zj, k0 = p.k;
+  const double x0 = p.x, y0 = p.y, z0 = p.z, u = p.u, v = p.v, w = p.w;
+  const int azj = zj0 < 0 ? -zj0 : zj0;
+  const bool top = (azj == nz + 1);
+  const bool out = (ri0 == n_rad + 1) || (top && (fabs(z0) > M.zmaxmax));
+  const bool killed = (p.star_key >= 0) && (ri0 + (n_rad + 2) * ((zj0 + nz + 1) + (2 * nz + 3) * (k0 - 1)) == p.star_key);
+  const bool go = active && !out && !killed;
+  const bool hole = (ri0 == 0);
+  const bool real_cell = (ri0 >= 1) && (ri0 <= n_rad) && (azj >= 1) && (azj <= nz);
+  const int jj0 = zj0 < 0 ? zj0 + nz : zj0 + nz - 1;
+  const int ic = real_cell ? (ri0 - 1) + n_rad * (jj0 + 2 * nz * (k0 - 1)) : 0;
+  const int row_in = hole ? 0 : (ri0 - 1 < n_rad ? ri0 - 1 : n_rad - 1);
+  const int row_out = hole ? 0 : (ri0 < n_rad ? ri0 : n_rad);
+
+  // 1) radial wall (:959-1000)
+  const double r_2 = x0 * x0 + y0 * y0;
+  const double dot = x0 * u + y0 * v;
+  const double b = dot * p.inv_a;
+  const double rl_in = T.r_lim_2[row_in];
+  const double rl_out = T.r_lim_2[row_out];
+  const double c_in = (r_2 - (hole ? rl_in : rl_in * cm)) * p.inv_a;
+  const double c_out = (r_2 - rl_out * cp) * p.inv_a;
+  const double bb = b * b;
+  const double d_in = bb - c_in;
+  const double d_out = fmax(bb - c_out, 0.0);
+  const bool use_in = hole || ((dot < 0.0) && !(d_in < 0.0));
+  const double delta = use_in ? d_in : d_out;
+  const int delta_rad = (use_in && !hole) ? -1 : 1;
+  const double rac = sqrt(delta);
+  const double s1 = (-b - rac) * cp, s2 = (-b + rac) * cp;
+  const double s_pos = (s1 == 0.0) ? GRID_PREC : s1;
+  const double s = (hole || (s1 < 0.0)) ? s2 : s_pos;
+
+  // 2) vertical wall (:1003-1055), 3D: zj = -(nz+1) .. -1, 1 .. nz+1, the midplane is a wall
+  const double dz = w * z0;
+  const bool away = dz > 0.0;
+  const bool neg = z0 < 0.0;
+  const int jsel = away ? azj + 1 : azj;
+  const double chr = T.ch[row_in], zmr = T.zmax[row_in];
+  // (jsel = nz + 2, where z_lim is 1e30, only occurs for away && top, which the 1e10 below replaces)
+  double zmag = (jsel <= nz) ? ((double)jsel - 1.0) * chr : zmr;
+  zmag = zmag * (away ? cp : cm);
+  zmag = (away && top) ? 1.0e10 : zmag;
+  const double zl = __longlong_as_double(__double_as_longlong(zmag) | (neg ? (long long)0x8000000000000000ull : 0ll));
+  const int dzj_away = top ? 0 : (neg ? -1 : 1);
+  const int dzj_back = (z0 > 0.0) ? ((zj0 == 1) ? -2 : -1) : ((zj0 == -1) ? 2 : 1);
+  const int delta_zj = away ? dzj_away : dzj_back;
+  double t = (zl - z0) * p.inv_w;
+  t = (t < 0.0) ? GRID_PREC : t;
+  t = (dz == 0.0) ? 1.0e10 : t;
+  t = hole ? HUGE_REAL : t;
+
+  // 3) azimuthal wall (:1058-1094)
+  const double dp = x0 * v - y0 * u;
+  const bool ccw = dp > 0.0;
+  int kk = ccw ? k0 : k0 - 1;
+  kk = (kk == 0) ? n_az : kk;
+  const double tan_lim = T.tan_phi[kk - 1];
+  const double den = v - u * tan_lim;
+  const bool inf_wall = tan_lim > 1.0e299;
+  const double num_w = inf_wall ? -x0 : -(y0 - x0 * tan_lim);
+  const double den_w = inf_wall ? u : den;
+  const bool den_ok = fabs(den_w) > (double)1.0e-6f;
+  double tp = den_ok ? num_w / den_w : r1e30;
+  tp = (tp < 0.0) ? r1e30 : tp;
+  tp = (fabs(dp) < (double)1.0e-10f) ? r1e30 : tp;
+  const double t_phi = hole ? HUGE_REAL : tp;
+
+  // 4) nearest wall (:1098-1156)
+  const bool rad = (s < t) && (s < t_phi);
+  const bool vert = !rad && (t < t_phi);
+  const double l = rad ? s : (vert ? t : t_phi);
+  const double dv = (rad || vert) ? l : cp * t_phi;
+  // products rounded before the sum, like the reference build (see cross_cell_lean)
+  double z1 = nd_add(z0, nd_mul(dv, w));
+  const int ri1 = rad ? ri0 + delta_rad : ri0;
+  // zj of the end point of a radial (:1116, through default real) or azimuthal (:1139, FP64) move: one multiply by
+  // nz / zmax decides it unless the quotient is within 1e-4 of an integer, where the reference's own expression runs
+  const int row1 = ri1 < 1 ? 0 : (ri1 > n_rad ? n_rad - 1 : ri1 - 1);
+  const double qd = fabs(z1) * T.rzn[row1];
+  const double fl = floor(qd);
+  const double fr = qd - fl;
+  const bool far_above = !(qd < (double)nz + 0.5);
+  int zjr = far_above ? nz + 1 : (int)fl + 1;
+  zjr = zjr > nz ? nz + 1 : zjr;
+  const bool ri1_in = (ri1 >= 1) && (ri1 <= n_rad);
+  if (__builtin_expect(go && !vert && ri1_in && !far_above && (fr < 1.0e-4 || fr > 1.0 - 1.0e-4), 0)) {  // (rare)
+    int zq = rad ? zj_from_z_real(T, nz, fabs(z1), ri1) : (int)floor(fabs(z1) / T.zmax[ri1 - 1] * (double)nz) + 1;
+    zjr = zq > nz ? nz + 1 : zq;
+  }
+  zjr = (z1 < 0.0) ? -zjr : zjr;
+  const int zj_rad = (ri1 == 0) ? 1 : ((ri1 > n_rad) ? zj0 : zjr);
+  int zj1 = rad ? zj_rad : (vert ? zj0 + delta_zj : zjr);
+  int k_phi = k0 + (ccw ? 1 : -1);
+  k_phi = (k_phi == 0) ? n_az : k_phi;
+  k_phi = (k_phi == n_az + 1) ? 1 : k_phi;
+  int k1 = (rad || vert) ? k0 : k_phi;
+  k1 = (rad && ri1 == 0) ? 1 : k1;
+  if (__builtin_expect(go && rad && hole, 0)) {  // out of the central hole: the azimuth of the landing point (:1121-1126)
+    const double x1h = x0 + dv * u, y1h = y0 + dv * v;
+    const double phi = modulo_d(atan2(y1h, x1h), 2 * PI);
+    int kh = (int)floor(phi * (1.0 / (2.0 * PI)) * (double)(float)n_az) + 1;
+    k1 = (kh == n_az + 1) ? n_az : kh;
+  }
+  const bool snap = vert && (M.midplane_snap != 0) && (delta_zj == 2 || delta_zj == -2);
+  z1 = (snap || z1 == 0.0) ? copysign(GRID_PREC, w) : z1;
+
+  // 5) optical depth of the crossing, stop or go on (optical_depth.f90:102, 134-146)
+  const double opacity = p.kap * p.kf;  // (p.kf = 0 outside the real cells, see fly_step_2d)
+  const double tau = l * opacity;
+  const bool stop = go && (tau > p.extr);
+  double lc = l;
+  if (__builtin_expect(stop, 0)) lc = l * (p.extr / tau);  // (once per flight)
+  // save_radiation_field (radiation_field.f90:53)
+  if (go && real_cell && !MCGPU_DIAG(A.flags, 1)) {
+    if (BIN) { dep_ic = ic; dep_v = p.kab * lc * p.S0; }
+    else deposit<LDSE>(A.E_abs, E_lds, ic, p.kab * lc * p.S0);
+  }
+
+  // the next cell; DARK: mirrored back at the wall of a dark cell (see roles_cross)
+  const int azj1 = zj1 < 0 ? -zj1 : zj1;
+  const bool next_real = (ri1 >= 1) && (ri1 <= n_rad) && (azj1 >= 1) && (azj1 <= nz);
+  const int jj1 = zj1 < 0 ? zj1 + nz : zj1 + nz - 1;
+  const int ic1 = next_real ? (ri1 - 1) + n_rad * (jj1 + 2 * nz * (k1 - 1)) : M.n_cells;  // (n_cells: the entry of "no cell", 0)
+  bool mirror = false;
+  if (DARK) mirror = go && !stop && next_real && M.dark[next_real ? ic1 : 0];
+  const bool move = go && !stop && !mirror;
+  const double kf1 = M.kappa_factor[ic1];
+
+  // 6) commit (x, y: one multiply-add with the length that applies, as in fly_step_2d)
+  const double lf = stop ? lc : (move ? dv : 0.0);
+  p.x = x0 + lf * u;
+  p.y = y0 + lf * v;
+  p.z = move ? z1 : z0 + lf * w;
+  p.extr = p.extr - tau;
+  p.ri = move ? ri1 : ri0;
+  p.zj = move ? zj1 : zj0;
+  p.k = move ? k1 : k0;
+  p.kf = move ? kf1 : p.kf;
+  if (__builtin_expect(stop, 0)) index_cell<true>(T, M, p.x, p.y, p.z, p.ri, p.zj, p.k);  // (:140: 3D re-indexes the stopping point)
+  if (DARK) {
+    p.u = mirror ? -u : u; p.v = mirror ? -v : v; p.w = mirror ? -w : w;
+    c_dark += mirror ? 1u : 0u;
+  }
+  int st = p.st;
+  st = (active && out) ? S_EXITED : st;
+  st = (active && !out && killed) ? S_EMIT : st;
+  st = (stop || mirror) ? S_INTERACT : st;
+  c_cross += go ? 1u : 0u;
+  c_kill += (active && !out && killed) ? 1u : 0u;
+  p.pk_cross += go ? 1u : 0u;
+  const bool runaway = go && (p.pk_cross > 200000000u);  // a packet that never leaves: flag it, drop it
+  if (runaway) { *A.err = 13; st = S_EMIT; }
+  p.st = st;
+  return ((active && !out && killed) || runaway) ? 1 : 0;
+}
+
 // One cell crossing of a packet in flight on a Voronoi grid (the crossing of thermal_body_voro, mc_voronoi.hip.h, on a
 // Flight): p.ri = the cell, p.zj = the cell it came from, p.star_key = the cell of the star on the way (0: none).
 template <bool CACHE>
@@ -684,7 +860,8 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
           } else if (L3D) {
             int dep_ic = -1;
             double dep_v = 0.0;
-            if (F.st == S_FLIGHT) finished += roles_cross<L3D, DARK, LDSE, BIN>(T, M, A, E_lds, F, c_cross, c_kill, c_dark, dep_ic, dep_v);
+            if (MCGPU_3D_BRANCHY) { if (F.st == S_FLIGHT) finished += roles_cross<L3D, DARK, LDSE, BIN>(T, M, A, E_lds, F, c_cross, c_kill, c_dark, dep_ic, dep_v); }
+            else finished += fly_step_3d<DARK, LDSE, BIN>(T, M, A, E_lds, F, c_cross, c_kill, c_dark, dep_ic, dep_v);
             if (BIN) bin_deposit(BS, A.bin, A.E_abs, lane, BP, dep_ic >= 0, dep_ic, dep_v);
           } else {
             finished += fly_step_2d<DARK, LDSE, MRW>(T, M, A, E_lds, F, c_cross, c_kill, c_dark);
@@ -934,7 +1111,8 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
             } else if (L3D) {
               int dep_ic = -1;
               double dep_v = 0.0;
-              if (F.st == S_FLIGHT) finished += roles_cross<L3D, DARK, LDSE, BIN>(T, M, A, E_lds, F, c_cross, c_kill, c_dark, dep_ic, dep_v);
+              if (MCGPU_3D_BRANCHY) { if (F.st == S_FLIGHT) finished += roles_cross<L3D, DARK, LDSE, BIN>(T, M, A, E_lds, F, c_cross, c_kill, c_dark, dep_ic, dep_v); }
+              else finished += fly_step_3d<DARK, LDSE, BIN>(T, M, A, E_lds, F, c_cross, c_kill, c_dark, dep_ic, dep_v);
               if (BIN) bin_deposit(BS, A.bin, A.E_abs, lane, BP, dep_ic >= 0, dep_ic, dep_v);
             } else {
               finished += fly_step_2d<DARK, LDSE, MRW>(T, M, A, E_lds, F, c_cross, c_kill, c_dark);

@@ -1,5 +1,5 @@
 """Summarise the rocprofv3 CSV output of tools/collect_profiles.sh for one configuration into
-<dst>/r02_kt_<config>.json (kernel trace statistics) and <dst>/r02_pmc_<config>.json (counters of the dominant
+<dst>/r03_kt_<config>.json (kernel trace statistics) and <dst>/r03_pmc_<config>.json (counters of the dominant
 kernel per launch, derived figures, and the hash of the kernel sources they were measured on: bench.py only
 reports them while that hash matches).
 
@@ -15,7 +15,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 src, config, dst = sys.argv[1], sys.argv[2], sys.argv[3]
-KERNELS = ("k_thermal", "k_mono")
+KERNELS = ("k_thermal", "k_mono", "k_fold_bins")
+ROUND = "r03"
 
 
 def dominant(name):
@@ -23,7 +24,7 @@ def dominant(name):
 
 
 # ---- kernel trace -----------------------------------------------------------------------------------------
-kt = {"config": config, "command": "python3 bench.py --config %s --no-cpu-baseline --no-ref41" % config}
+kt = {"config": config, "command": "python3 bench.py --config %s --no-cpu-baseline --no-extra" % config}
 for f in glob.glob(os.path.join(src, "kt", "**", "*kernel_stats.csv"), recursive=True):
     kt["kernel_stats"] = list(csv.DictReader(open(f)))
 dur = collections.defaultdict(list)
@@ -34,10 +35,12 @@ for f in glob.glob(os.path.join(src, "kt", "**", "*kernel_trace.csv"), recursive
             kt["launch"] = {k: r.get(k) for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size",
                                                    "Scratch_Size", "Workgroup_Size", "Grid_Size") if k in r}
 kt["kernel_durations_ns"] = {k: {"calls": len(v), "avg": sum(v) / len(v), "min": min(v), "max": max(v)} for k, v in dur.items()}
-json.dump(kt, open(os.path.join(dst, "r02_kt_%s.json" % config), "w"), indent=1)
+json.dump(kt, open(os.path.join(dst, "%s_kt_%s.json" % (ROUND, config)), "w"), indent=1)
 
 # ---- counters ---------------------------------------------------------------------------------------------
-cnt, launches, dur_pmc = collections.defaultdict(float), collections.defaultdict(int), []
+# Every pass runs ONE step (--steps 1 --warmup 0); a step may be several launches (the chunks of a run with binned
+# deposits and the folds between them): the counters and the kernel time are summed over the launches of the step.
+cnt, launches, dur_pass = collections.defaultdict(float), collections.defaultdict(int), []
 for sub in ("f", "w", "a", "b"):
     for f in glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
@@ -45,12 +48,17 @@ for sub in ("f", "w", "a", "b"):
                 cnt[r["Counter_Name"]] += float(r["Counter_Value"])
                 launches[r["Counter_Name"]] += 1
     for f in glob.glob(os.path.join(src, sub, "**", "*kernel_trace.csv"), recursive=True):
+        tot = 0
         for r in csv.DictReader(open(f)):
             if dominant(r["Kernel_Name"]):
-                dur_pmc.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-per = {k: cnt[k] / max(launches[k], 1) for k in cnt}
-out = {"config": config, "command": kt["command"] + " --steps 1 --warmup 0", "packets": 100000000,
-       "counters_per_launch": per, "launches_seen": dict(launches)}
+                tot += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        if tot:
+            dur_pass.append(tot)
+per = dict(cnt)
+dur_pmc = dur_pass
+n_packets = int(float(sys.argv[4])) if len(sys.argv) > 4 else 100000000
+out = {"config": config, "command": kt["command"] + " --steps 1 --warmup 0", "packets": n_packets,
+       "counters_per_step": per, "launches_per_step": dict(launches)}
 try:
     from bench import source_hash
     out["source_hash"] = source_hash()
@@ -85,8 +93,8 @@ f64 = 2.0 * per.get("SQ_INSTS_VALU_FMA_F64", 0.0) + per.get("SQ_INSTS_VALU_MUL_F
 if f64 and t_ns:
     d["fp64_tflops"] = f64 * 64.0 * d.get("lane_utilisation", 1.0) / t_ns * 1e-3
 if per.get("SQ_INSTS_VALU"):
-    d["insts_per_packet"] = {"valu": per["SQ_INSTS_VALU"] / 1e8, "salu": per.get("SQ_INSTS_SALU", 0.0) / 1e8,
-                             "lds": per.get("SQ_INSTS_LDS", 0.0) / 1e8}
+    d["insts_per_packet"] = {"valu": per["SQ_INSTS_VALU"] / n_packets, "salu": per.get("SQ_INSTS_SALU", 0.0) / n_packets,
+                             "lds": per.get("SQ_INSTS_LDS", 0.0) / n_packets}
 out["per_launch"] = d
-json.dump(out, open(os.path.join(dst, "r02_pmc_%s.json" % config), "w"), indent=1)
+json.dump(out, open(os.path.join(dst, "%s_pmc_%s.json" % (ROUND, config)), "w"), indent=1)
 print(json.dumps(out, indent=1)[:2500])
