@@ -1004,9 +1004,23 @@ def build_voronoi_model(cfg: DiskConfig, n_sites: int, seed: int = 1, box_z_over
             tmp = "%s.%d.tmp.npz" % (cache, os.getpid())
             np.savez(tmp, **grid)
             os.replace(tmp, cache)
-    # equal-mass SPH particles: rho_i = (M_dust / N) / V_i; star sites carry no dust
+    # Density: what an SPH dump hands over is the kernel-SMOOTHED density of equal-mass particles.  The raw m / V_i of
+    # randomly drawn sites is not that: Poisson-Voronoi volumes scatter by ~40 %, the small cells become clumps many
+    # times denser than the disk, and the packets trapped in them -- 119 interactions per packet against 11 in the same
+    # disk on the cylindrical grid -- make it another problem.  So rho_i is the geometric mean of m / V over the cell
+    # and its Voronoi neighbours (~16: the kernel of a tessellation; the mean of the logarithms, so that a large
+    # neighbour does not drain a small cell and an exponential profile stays what it is), normalised to the dust mass.
+    # Star sites carry no dust.
     nb = grid["n_cells_before_stars"]
+    vol = np.asarray(grid["volume"], f64)
+    first, last, neigh = np.asarray(grid["v_first"]), np.asarray(grid["v_last"]), np.asarray(grid["v_neigh"])
+    owner = np.repeat(np.arange(grid["n_cells"]), last - first + 1)       # CSR rows (1-based first / last)
+    gas = (neigh >= 1) & (neigh <= nb) & (owner < nb)                     # dusty neighbours of dusty cells
+    lv = np.log(vol[:nb])
+    l_sum = lv + np.bincount(owner[gas], weights=lv[neigh[gas] - 1], minlength=nb)[:nb]
+    n_sum = 1.0 + np.bincount(owner[gas], minlength=nb)[:nb]
     rho = np.zeros(grid["n_cells"], f64)
-    rho[:nb] = (cfg.dust_mass * MSUN_TO_G / nb) / (grid["volume"][:nb] * AU_TO_CM ** 3)
+    rho[:nb] = np.exp(-l_sum / n_sum)
+    rho[:nb] *= cfg.dust_mass * MSUN_TO_G / (float(np.sum(rho[:nb] * vol[:nb])) * AU_TO_CM ** 3)
     m = build_model(cfg, grid=grid, rho=rho)
     return m
