@@ -316,8 +316,7 @@ def sed_block(par, args, steps, warmup, with_cpu, packets, observers):
         cfg.RT_n_incl = observers
     m = M.build_model(cfg)
     e = Engine(m, 5e6, device=par.local_rank)
-    T = e.temp_finale(e.run_thermal(5_000_000, seed=3)["E_abs"])
-    M.repartition_energie(m, T)
+    T = e.temp_finale(e.run_thermal(5_000_000, seed=3)["E_abs"])   # the dust temperature the SED step emits with
     e.close()
     if par.mode == "library":
         me = MultiEngine(m, 5e6, devices=tuple(range(world)))
@@ -338,10 +337,12 @@ def sed_block(par, args, steps, warmup, with_cpu, packets, observers):
     def step(i):
         sent = 0
         for lam in lams:
+            # repartition_energie(lambda) on the device (dust_transfer.f90:924), then the wavelength's packet loop (:939)
             if me is not None:   # ONE call per wavelength: streams split, both all-reduces inside the library
-                r = me.run_mono(lam, n2, seed=100 + i, n_chunks=n_streams, fetch_xI=False)
+                r = me.run_mono(lam, n2, seed=100 + i, n_chunks=n_streams, fetch_xI=False, Tdust=T)
             else:
-                r = eng.run_mono(lam, n2, seed=100 + i, n_chunks=count, first_chunk=first, fetch_xI=False)
+                td = eng.repartition_energie(lam, T, fetch=False)
+                r = eng.run_mono(lam, n2, seed=100 + i, n_chunks=count, first_chunk=first, fetch_xI=False, device_tables=td)
             sent += int(r["n_sent_chunk"].sum())
             if par.mode == "torchrun":   # one all-reduce of [sed | n_sent] + xI_scatt per wavelength
                 acc, cnt = eng.device_accumulators()

@@ -330,10 +330,30 @@ typedef struct {
 } mcgpu_mono_opts;
 
 /*
+ * repartition_energie(lambda) (thermal_emission.f90:1771-1949; the call at dust_transfer.f90:924), LTE grains
+ * (lRE_LTE, :1814-1831, with kappa_abs_LTE per class under mcgpu_set_variable_dust and l_dark_zone as set with the
+ * opacity): how the energy emitted at one wavelength splits between the stars, the cells of the disk and the
+ * interstellar field, from the dust temperature of the thermal step -- on the device (one thread per cell; the
+ * cumulative distribution is summed in the reference's own cell order, so it is monotone and ends in exactly 1).
+ *   lambda, wl_um           the wavelength index (1-based) and tab_lambda(lambda) in micron
+ *   E_star, E_ISM           E_stars(lambda), E_ISM(lambda)
+ *   Tdust[n_cells]          default real (host); weight_proba_emission[n_cells] or NULL (lweight_emission)
+ * Out (any may be NULL): frac_E_stars(lambda), frac_E_disk(lambda), E_disk(lambda), prob_E_cell(0:n_cells, lambda).
+ * The cumulative distribution also STAYS on the device: a following mcgpu_run_mono of the same wavelength may pass
+ * prob_E_cell = NULL.  Fails (MCGPU_ERR_ARG) where the reference stops: no energy at all at this wavelength (:1899).
+ * The per-grain branches (lRE_nLTE, lnRE: :1833-1884) are not built -- the engine holds no per-grain temperatures.
+ */
+int mcgpu_repartition_energie(mcgpu_ctx *ctx, int lambda, double wl_um, double E_star, double E_ISM,
+                              const float *Tdust, const float *weight_proba_emission,
+                              double *frac_E_stars, double *frac_E_disk, double *E_disk,
+                              double *prob_E_cell);
+
+/*
  * Replaces `call mc_photon_loop(lambda, p_lambda, n_photons2, n_phot_lim, 1, .false.)`
  * at dust_transfer.f90:939.  frac_E_stars / frac_E_disk / prob_E_cell(0:n_cells) are the
  * wavelength's entries as left by repartition_energie(lambda) (:924,
- * thermal_emission.f90:1771-1949); prob_E_cell may be NULL when frac_E_stars = 1.
+ * thermal_emission.f90:1771-1949; mcgpu_repartition_energie above builds them on the device); prob_E_cell may be
+ * NULL when frac_E_stars = 1 or when mcgpu_repartition_energie of this wavelength was the last to fill the table.
  * A stream's packets are id ((first_chunk + stream) << 40 | sequence) of the random generator; each stream
  * stops EXACTLY where the reference's sequential loop would: a first pass without deposits
  * finds the stopping index, a second pass replays the packets before it with deposits.

@@ -2038,6 +2038,67 @@ __global__ void __launch_bounds__(128) k_diffusion_vertical(const DevModel M, co
 // ---------------------------------------------------------------------------
 // Probes for the parity tests
 // ---------------------------------------------------------------------------
+// ---------------------------------------------------------------------------
+// repartition_energie (thermal_emission.f90:1771-1949), LTE grains: E_cell of one wavelength (one thread per cell),
+// then the cumulative distribution prob_E_cell(0:n_cells) summed in the reference's own order (k_cumsum_in_order).
+// ---------------------------------------------------------------------------
+__global__ void k_repart_E_cell(const DevModel M, int lambda, double wl, const float* Tdust, const float* weight,
+                                double* E_cell, double* E_corr) {
+  const int ic = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ic >= M.n_cells) return;
+  const float thermal_const = (float)(299792458.0 * 6.626070040e-34 / 1.38064852e-23);  // real (constants.f90:24)
+  const double cst_wl_max = 88.72283905206835 - (double)1.0e-4f;                          // log(huge_real) - 1.0e-4 (:1802)
+  double E = 0.0;
+  if (!(M.dark && M.dark[ic])) {
+    const double Temp = (double)Tdust[ic];
+    if (!(Temp < TINY_REAL)) {
+      const double cst_wl = (double)thermal_const / (Temp * wl);
+      if (cst_wl < cst_wl_max) {
+        const double kabs = M.n_classes ? M.v_kabs[(size_t)M.cell_class[ic] * M.n_lambda + (lambda - 1)] : M.kappa_abs[lambda - 1];
+        const double wl2 = wl * wl, wl5 = (wl2 * wl2) * wl;
+        E = 4.0 * kabs * M.kappa_factor[ic] * M.volume[ic] / (wl5 * (exp(cst_wl) - 1.0));
+      }
+    }
+  }
+  E_cell[ic] = E;
+  E_corr[ic] = weight ? E * (double)weight[ic] : E;
+}
+
+constexpr int SCAN_TILE = 1024;
+// prob(0:n) = the running sum of in[0..n) in the REFERENCE's order (:1923-1926: cell by cell, which also makes the
+// distribution monotone and its last entry, divided by itself, exactly 1), tot[0] = its last entry, tot[1] = the
+// running sum of in2 (E_disk = sum(E_cell), :1897).  One workgroup: the tiles are staged in LDS by all threads, the
+// additions are one thread's -- 3 ms per million cells, next to seconds of Monte Carlo per wavelength.
+__global__ void __launch_bounds__(SCAN_TILE) k_cumsum_in_order(const double* in, const double* in2, int n, double* prob, double* tot) {
+  __shared__ double buf[SCAN_TILE], buf2[SCAN_TILE];
+  __shared__ double carry, carry2;
+  if (threadIdx.x == 0) { carry = 0.0; carry2 = 0.0; prob[0] = 0.0; }
+  __syncthreads();
+  for (int base = 0; base < n; base += SCAN_TILE) {
+    const int i = base + threadIdx.x;
+    buf[threadIdx.x] = i < n ? in[i] : 0.0;
+    buf2[threadIdx.x] = i < n ? in2[i] : 0.0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int m = n - base < SCAN_TILE ? n - base : SCAN_TILE;
+      double c = carry, c2 = carry2;
+      for (int q = 0; q < m; ++q) { c = c + buf[q]; buf[q] = c; c2 = c2 + buf2[q]; }
+      carry = c; carry2 = c2;
+    }
+    __syncthreads();
+    if (i < n) prob[1 + i] = buf[threadIdx.x];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { tot[0] = carry; tot[1] = carry2; }
+}
+// prob(:) = prob(:) / prob(n_cells), or 0 when that is not positive (:1933-1937)
+__global__ void k_cumsum_normalise(double* prob, const double* tot, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > n) return;
+  const double last = tot[0];
+  prob[i] = last > 2.2250738585072014e-308 ? prob[i] / last : 0.0;
+}
+
 template <bool L3D, bool SPH = false>
 __global__ void k_probe_cross(const DevModel M, int n, const double* x0, const double* y0,
                               const double* z0, const double* u, const double* v, const double* w,

@@ -94,6 +94,8 @@ struct mcgpu_ctx {
   size_t n_xI = 0;
   int xI_bytes = 8;  // accumulator type of xI_scatt on the device: 8 = FP64 (default), 4 = default real (mcgpu_set_xI_precision)
   double* d_prob_E = nullptr;               // prob_E_cell(0:n_cells) of the current wavelength
+  int prob_E_lambda = 0;                    // the wavelength mcgpu_repartition_energie left in d_prob_E (0: none)
+  double prob_E_fstar = 0.0, prob_E_fdisk = 0.0;
   unsigned long long* d_mono_u64 = nullptr; // [5 * n_chunks + 1]: need | sent | item_base(+1) | start | hit_count
   int* d_mono_i32 = nullptr;                // [2 * n_chunks]: active | done
   int mono_chunks = 0;
@@ -139,6 +141,16 @@ static inline size_t xi_dev_values(const mcgpu_ctx* ctx) {
   return (size_t)ctx->n_az_rt * ctx->n_theta_rt * XI_LINE * xi_nrt_pad(ctx) * (size_t)ctx->M.n_cells;
 }
 static inline size_t xi_dev_bytes(const mcgpu_ctx* ctx) { return xi_dev_values(ctx) * (size_t)ctx->xI_bytes; }
+
+// a device array that lives as long as the scope
+template <typename Tp>
+struct DevBuf {
+  Tp* p = nullptr;
+  ~DevBuf() { if (p) hipFree(p); }
+  hipError_t alloc(size_t n) { return hipMalloc((void**)&p, (n ? n : 1) * sizeof(Tp)); }
+  hipError_t put(const Tp* h, size_t n) { return hipMemcpy(p, h, n * sizeof(Tp), hipMemcpyHostToDevice); }
+  hipError_t get(Tp* h, size_t n) { return hipMemcpy(h, p, n * sizeof(Tp), hipMemcpyDeviceToHost); }
+};
 
 static int fail(mcgpu_ctx* ctx, int code, const char* msg) {
   if (ctx) ctx->err = msg;
@@ -1377,6 +1389,50 @@ extern "C" int mcgpu_run_thermal(mcgpu_ctx* ctx, const mcgpu_run_opts* opts, dou
 }
 
 // ---------------------------------------------------------------------------------------------
+// repartition_energie(lambda) (thermal_emission.f90:1771-1949), LTE grains: the SED step's emission tables of one
+// wavelength, built on the device from the dust temperature
+// ---------------------------------------------------------------------------------------------
+extern "C" int mcgpu_repartition_energie(mcgpu_ctx* ctx, int lambda, double wl_um, double E_star, double E_ISM, const float* Tdust,
+                                         const float* weight_proba_emission, double* frac_E_stars, double* frac_E_disk,
+                                         double* E_disk, double* prob_E_cell) {
+  if (!ctx || !ctx->have_grid || !ctx->have_opacity || !Tdust) return fail(ctx, MCGPU_ERR_ARG, "mcgpu_repartition_energie: grid, opacity and Tdust are needed");
+  const DevModel& M = ctx->M;
+  if (lambda < 1 || lambda > M.n_lambda || !(wl_um > 0.0)) return fail(ctx, MCGPU_ERR_ARG, "mcgpu_repartition_energie: bad wavelength");
+  HIPCHK(hipSetDevice(ctx->device));
+  const int n = M.n_cells;
+  DevBuf<float> d_T, d_w;
+  DevBuf<double> d_E, d_Ec, d_tot;
+  HIPCHK(hipMalloc((void**)&d_T.p, (size_t)n * sizeof(float)));
+  HIPCHK(hipMalloc((void**)&d_E.p, (size_t)n * sizeof(double)));
+  HIPCHK(hipMalloc((void**)&d_Ec.p, (size_t)n * sizeof(double)));
+  HIPCHK(hipMalloc((void**)&d_tot.p, 2 * sizeof(double)));
+  HIPCHK(hipMemcpyAsync(d_T.p, Tdust, (size_t)n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  if (weight_proba_emission) {
+    HIPCHK(hipMalloc((void**)&d_w.p, (size_t)n * sizeof(float)));
+    HIPCHK(hipMemcpyAsync(d_w.p, weight_proba_emission, (size_t)n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  }
+  if (!ctx->d_prob_E) HIPCHK(hipMalloc((void**)&ctx->d_prob_E, ((size_t)n + 1) * sizeof(double)));
+  const double wl = wl_um * (double)1.e-6f;  // (:1804: the default-real literal 1.e-6)
+  hipLaunchKernelGGL(k_repart_E_cell, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, M, lambda, wl, d_T.p, d_w.p, d_E.p, d_Ec.p);
+  hipLaunchKernelGGL(k_cumsum_in_order, dim3(1), dim3(SCAN_TILE), 0, ctx->stream, d_Ec.p, d_E.p, n, ctx->d_prob_E, d_tot.p);
+  hipLaunchKernelGGL(k_cumsum_normalise, dim3((n + 256) / 256), dim3(256), 0, ctx->stream, ctx->d_prob_E, d_tot.p, n);
+  HIPCHK(hipGetLastError());
+  double tot[2] = {0.0, 0.0};
+  HIPCHK(hipMemcpyAsync(tot, d_tot.p, sizeof(tot), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  const double Ed = tot[1];
+  ctx->prob_E_lambda = 0;
+  if (E_star + Ed + E_ISM < 2.2250738585072014e-308) return fail(ctx, MCGPU_ERR_ARG, "mcgpu_repartition_energie: no energy at this wavelength");  // (:1899-1903)
+  const double fs = E_star / (E_star + Ed + E_ISM), fd = (E_star + Ed) / (E_star + Ed + E_ISM);
+  if (frac_E_stars) *frac_E_stars = fs;
+  if (frac_E_disk) *frac_E_disk = fd;
+  if (E_disk) *E_disk = Ed;
+  if (prob_E_cell) HIPCHK(hipMemcpy(prob_E_cell, ctx->d_prob_E, ((size_t)n + 1) * sizeof(double), hipMemcpyDeviceToHost));
+  ctx->prob_E_lambda = lambda; ctx->prob_E_fstar = fs; ctx->prob_E_fdisk = fd;
+  return MCGPU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // SED mode (mc_mono.hip.h)
 // ---------------------------------------------------------------------------------------------
 extern "C" int mcgpu_set_rt1(mcgpu_ctx* ctx, int RT_n_incl, int RT_n_az, const double* tab_u_rt,
@@ -1476,8 +1532,9 @@ extern "C" int mcgpu_run_mono(mcgpu_ctx* ctx, const mcgpu_mono_opts* o, double f
   if (M.grid_sph) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "SED mode on a spherical grid is not supported yet");
   const int n_pos = ctx->have_rt1 ? ctx->n_lambda_pos : M.n_lambda;
   if (o->p_lambda < 1 || o->p_lambda > n_pos || o->p_lambda > M.n_lambda) return fail(ctx, MCGPU_ERR_ARG, "p_lambda out of range");
-  if (frac_E_stars < 1.0 && frac_E_disk > frac_E_stars && !prob_E_cell)
-    return fail(ctx, MCGPU_ERR_ARG, "disk emission needs prob_E_cell");
+  // prob_E_cell = NULL: the table mcgpu_repartition_energie left on the device for this wavelength
+  if (frac_E_stars < 1.0 && frac_E_disk > frac_E_stars && !prob_E_cell && ctx->prob_E_lambda != o->lambda)
+    return fail(ctx, MCGPU_ERR_ARG, "disk emission needs prob_E_cell (or mcgpu_repartition_energie of this wavelength first)");
   if (frac_E_disk < 1.0 && !(M.R_ISM > 0.0)) return fail(ctx, MCGPU_ERR_ARG, "frac_E_disk < 1 needs mcgpu_set_ism");
   HIPCHK(hipSetDevice(ctx->device));
   if ((rc = ensure_accum(ctx))) return rc;
@@ -1496,6 +1553,7 @@ extern "C" int mcgpu_run_mono(mcgpu_ctx* ctx, const mcgpu_mono_opts* o, double f
   if (prob_E_cell) {
     if (!ctx->d_prob_E) HIPCHK(hipMalloc((void**)&ctx->d_prob_E, ((size_t)M.n_cells + 1) * sizeof(double)));
     HIPCHK(hipMemcpyAsync(ctx->d_prob_E, prob_E_cell, ((size_t)M.n_cells + 1) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    ctx->prob_E_lambda = 0;
   }
   const int nRT = ctx->have_rt1 ? ctx->RT_n_incl * ctx->RT_n_az : 0;
   // n_xI: elements of the reference's array; the device keeps XI_LINE doubles per (cell, sub-bin, observer)
@@ -1523,7 +1581,7 @@ extern "C" int mcgpu_run_mono(mcgpu_ctx* ctx, const mcgpu_mono_opts* o, double f
   std::memset(&A, 0, sizeof(A));
   A.seed = o->seed; A.lambda = o->lambda; A.p_lambda = o->p_lambda; A.capt_sup = o->capt_sup; A.rt1 = o->rt1 ? 1 : 0;
   A.frac_E_stars = frac_E_stars; A.frac_E_disk = frac_E_disk;
-  A.prob_E_cell = prob_E_cell ? ctx->d_prob_E : nullptr;
+  A.prob_E_cell = (prob_E_cell || ctx->prob_E_lambda == o->lambda) ? ctx->d_prob_E : nullptr;
   A.n_chunks = nc; A.first_chunk = o->first_chunk;
   A.RT_n_incl = ctx->have_rt1 ? ctx->RT_n_incl : 1; A.nRT = o->rt1 ? nRT : 0;
   A.rt_u = ctx->d_rt_u; A.rt_v = ctx->d_rt_v; A.rt_w = ctx->d_rt_w;
@@ -1776,14 +1834,6 @@ extern "C" int mcgpu_temp_finale(mcgpu_ctx* ctx, const double* E_abs, float* Tdu
 }
 
 // ---- probes ---------------------------------------------------------------
-template <typename Tp>
-struct DevBuf {
-  Tp* p = nullptr;
-  ~DevBuf() { if (p) hipFree(p); }
-  hipError_t alloc(size_t n) { return hipMalloc((void**)&p, (n ? n : 1) * sizeof(Tp)); }
-  hipError_t put(const Tp* h, size_t n) { return hipMemcpy(p, h, n * sizeof(Tp), hipMemcpyHostToDevice); }
-  hipError_t get(Tp* h, size_t n) { return hipMemcpy(h, p, n * sizeof(Tp), hipMemcpyDeviceToHost); }
-};
 
 // Temp_approx_diffusion_vertical (diffusion.f90:292-374, called at dust_transfer.f90:316,659 after Temp_finale when
 // the model has a dark zone): refills the temperature of the dark zone and of delta_cell_dark_zone cells around it.

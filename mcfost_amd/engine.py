@@ -36,7 +36,7 @@ ABI_SYMBOLS = (
     "mcgpu_device_xI", "mcgpu_set_ism", "mcgpu_rt1_dust_map", "mcgpu_set_xI", "mcgpu_rt1_image", "mcgpu_set_xI_precision",
     "mcgpu_get_xI_precision", "mcgpu_set_option", "mcgpu_get_info", "mcgpu_counters_to_accum", "mcgpu_counters_from_accum",
     "mcgpu_set_grid_sph", "mcgpu_temp_approx_diffusion_vertical", "mcgpu_set_mrw", "mcgpu_fetch_radiation_field", "mcgpu_set_variable_dust", "mcgpu_rt1_stars_map_sed", "mcgpu_define_dark_zone", "mcgpu_init_reemission", "mcgpu_multi_create", "mcgpu_multi_destroy", "mcgpu_multi_size", "mcgpu_multi_ctx", "mcgpu_multi_last_error",
-    "mcgpu_shard_packets", "mcgpu_multi_run_thermal", "mcgpu_multi_run_mono", "mcgpu_multi_rccl_ranks",
+    "mcgpu_repartition_energie", "mcgpu_shard_packets", "mcgpu_multi_run_thermal", "mcgpu_multi_run_mono", "mcgpu_multi_rccl_ranks",
 )
 
 
@@ -400,6 +400,22 @@ class Engine:
         "schedule" 0/1 = auto / single-role kernel, "speculation" 1/0 (SED mode)."""
         self._chk(self.lib.mcgpu_set_option(self.ctx, name.encode(), C.c_int(int(value))), "mcgpu_set_option")
 
+    def repartition_energie(self, lam, Tdust, E_ISM=0.0, weight=None, fetch=True):
+        """``repartition_energie(lam)`` on the device (``mcgpu_repartition_energie``): returns frac_E_stars, frac_E_disk,
+        E_disk and (``fetch``) prob_E_cell(0:n_cells) of the 1-based wavelength ``lam``; the cumulative distribution stays
+        on the device for a following ``run_mono(lam, ..., device_tables=True)``."""
+        m = self.model
+        T = _a(Tdust, np.float32)
+        wgt = _a(weight, np.float32) if weight is not None else None
+        pe = np.zeros(m.n_cells + 1, np.float64) if fetch else None
+        fs, fd, ed = C.c_double(), C.c_double(), C.c_double()
+        self._chk(self.lib.mcgpu_repartition_energie(
+            self.ctx, C.c_int(int(lam)), C.c_double(float(m.lam[lam - 1])), C.c_double(float(m.E_stars[lam - 1])),
+            C.c_double(float(E_ISM)), _p(T, C.c_float), _p(wgt, C.c_float) if wgt is not None else None,
+            C.byref(fs), C.byref(fd), C.byref(ed), _p(pe, C.c_double) if pe is not None else None),
+            "mcgpu_repartition_energie")
+        return dict(frac_E_stars=fs.value, frac_E_disk=fd.value, E_disk=ed.value, prob_E_cell=pe)
+
     def get_info(self, name):
         """Diagnostics of the last launches (``mcgpu_get_info``), e.g. "bin_chunks", "bin_overflow_blocks"."""
         v = C.c_double(0.0)
@@ -466,9 +482,11 @@ class Engine:
         self._chk(self.lib.mcgpu_set_xI(self.ctx, _p(x, C.c_double)), "mcgpu_set_xI")
 
     def run_mono(self, lam, n_photons2, n_phot_lim=None, p_lambda=None, seed=1, n_chunks=None, rt1=True,
-                 accumulate=False, grid_blocks=0, block_threads=0, fetch_xI=True, first_chunk=0):
+                 accumulate=False, grid_blocks=0, block_threads=0, fetch_xI=True, first_chunk=0, device_tables=None):
         """One wavelength (1-based ``lam``) of the SED Monte Carlo: ``mcgpu_run_mono`` with the
-        model's frac_E_stars / prob_E_cell of that wavelength."""
+        model's frac_E_stars / prob_E_cell of that wavelength -- or, with ``device_tables`` = the dict
+        ``repartition_energie(lam, ...)`` returned, with the fractions of that call and the cumulative distribution it
+        left on the device."""
         m = self.model
         if rt1 and not getattr(self, "_rt1", False):
             self.set_rt1()
@@ -480,12 +498,15 @@ class Engine:
                      int(m.capt_sup), int(rt1), int(accumulate), grid_blocks, block_threads)
         pe = getattr(m, "prob_E_cell", None)
         pe_l = None
-        if pe is not None:
+        fs, fd = float(m.frac_E_stars[lam - 1]), float(m.frac_E_disk[lam - 1])
+        if device_tables is not None:
+            fs, fd = float(device_tables["frac_E_stars"]), float(device_tables["frac_E_disk"])
+        elif pe is not None:
             pe_l = _a(np.asarray(pe).reshape(m.n_lambda, m.n_cells + 1)[lam - 1], np.float64)
         per_chunk = np.zeros(n_chunks, np.uint64)
         ms = C.c_double()
         self._chk(self.lib.mcgpu_run_mono(
-            self.ctx, C.byref(o), C.c_double(float(m.frac_E_stars[lam - 1])), C.c_double(float(m.frac_E_disk[lam - 1])),
+            self.ctx, C.byref(o), C.c_double(fs), C.c_double(fd),
             _p(pe_l, C.c_double) if pe_l is not None else None, _p(per_chunk, C.c_uint64), C.byref(ms)),
             "mcgpu_run_mono")
         out = self.fetch()
@@ -627,12 +648,16 @@ class MultiEngine:
                     counters=dict(zip(COUNTER_NAMES, (int(c) for c in cnt))))
 
     def run_mono(self, lam, n_photons2, n_phot_lim=None, p_lambda=None, seed=1, n_chunks=None, rt1=True,
-                 accumulate=False, fetch_xI=True, first_chunk=0):
+                 accumulate=False, fetch_xI=True, first_chunk=0, Tdust=None):
         """One wavelength of the SED Monte Carlo on every device (``mcgpu_multi_run_mono``): the streams are split
         among the devices, ONE all-reduce of [sed | n_sent | counters] and one of xI_scatt; same outputs as
-        ``Engine.run_mono``, read from device 0."""
+        ``Engine.run_mono``, read from device 0.  ``Tdust`` given: every device first builds the wavelength's emission
+        tables itself (``mcgpu_repartition_energie``) instead of taking the model's."""
         m = self.model
         e0 = self.engines[0]
+        tables = None
+        if Tdust is not None:
+            tables = [e.repartition_energie(lam, Tdust, fetch=False) for e in self.engines][0]
         for e in self.engines:
             if rt1 and not getattr(e, "_rt1", False):
                 e.set_rt1()
@@ -644,12 +669,15 @@ class MultiEngine:
                      int(m.capt_sup), int(rt1), int(accumulate), 0, 0)
         pe = getattr(m, "prob_E_cell", None)
         pe_l = None
-        if pe is not None:
+        fs, fd = float(m.frac_E_stars[lam - 1]), float(m.frac_E_disk[lam - 1])
+        if tables is not None:
+            fs, fd = tables["frac_E_stars"], tables["frac_E_disk"]
+        elif pe is not None:
             pe_l = _a(np.asarray(pe).reshape(m.n_lambda, m.n_cells + 1)[lam - 1], np.float64)
         per_chunk = np.zeros(n_chunks, np.uint64)
         ms = C.c_double()
         rc = self.lib.mcgpu_multi_run_mono(
-            self.h, C.byref(o), C.c_double(float(m.frac_E_stars[lam - 1])), C.c_double(float(m.frac_E_disk[lam - 1])),
+            self.h, C.byref(o), C.c_double(fs), C.c_double(fd),
             _p(pe_l, C.c_double) if pe_l is not None else None, _p(per_chunk, C.c_uint64), C.byref(ms))
         if rc:
             msg = self.lib.mcgpu_multi_last_error(self.h)

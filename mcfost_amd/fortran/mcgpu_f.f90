@@ -69,7 +69,7 @@ module mcgpu_f
        mcgpu_run_mono, mcgpu_fetch, mcgpu_fetch_xI, mcgpu_rt1_dust_map, mcgpu_set_xI, mcgpu_rt1_image, mcgpu_set_xI_precision, &
        mcgpu_set_E_prior, mcgpu_multi_create, mcgpu_multi_destroy, mcgpu_multi_size, mcgpu_multi_ctx, mcgpu_multi_run_thermal, mcgpu_multi_run_mono, mcgpu_multi_rccl_ranks, &
        mcgpu_counters_to_accum, mcgpu_counters_from_accum, mcgpu_temp_approx_diffusion_vertical, mcgpu_set_mrw, mcgpu_fetch_radiation_field, &
-       mcgpu_set_variable_dust, mcgpu_rt1_stars_map_sed, mcgpu_define_dark_zone, mcgpu_init_reemission
+       mcgpu_set_variable_dust, mcgpu_rt1_stars_map_sed, mcgpu_define_dark_zone, mcgpu_init_reemission, mcgpu_repartition_energie
 
   interface
      integer(c_int) function mcgpu_create(device, ctx) bind(C, name="mcgpu_create")
@@ -365,6 +365,20 @@ module mcgpu_f
        real(c_double), intent(in) :: tab_u_rt(*), tab_v_rt(*), tab_w_rt(*)
        real(c_float), intent(in) :: tab_s11_pos(*)
      end function mcgpu_set_rt1
+
+     ! replaces `call repartition_energie(lambda)` (dust_transfer.f90:924; thermal_emission.f90:1771-1949, LTE grains);
+     ! the cumulative distribution also stays on the device for the mcgpu_run_mono of the same wavelength
+     integer(c_int) function mcgpu_repartition_energie(ctx, lambda, wl_um, E_star, E_ISM, Tdust, weight_proba_emission, &
+          frac_E_stars, frac_E_disk, E_disk, prob_E_cell) bind(C, name="mcgpu_repartition_energie")
+       import :: c_int, c_ptr, c_double, c_float
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: lambda
+       real(c_double), value :: wl_um, E_star, E_ISM
+       real(c_float), intent(in) :: Tdust(*)
+       type(c_ptr), value :: weight_proba_emission   ! c_loc(weight_proba_emission(1)) or c_null_ptr
+       real(c_double), intent(out) :: frac_E_stars, frac_E_disk, E_disk
+       type(c_ptr), value :: prob_E_cell             ! c_loc(prob_E_cell(0,lambda)) or c_null_ptr
+     end function mcgpu_repartition_energie
 
      ! replaces `call mc_photon_loop(lambda, p_lambda, n_photons2, n_phot_lim, 1, .false.)` (dust_transfer.f90:939)
      integer(c_int) function mcgpu_run_mono(ctx, opts, frac_E_stars, frac_E_disk, prob_E_cell, n_sent_chunk, &

@@ -33,8 +33,16 @@ class EngineBackend:
     def temp_approx_diffusion_vertical(self, Tdust, ri_in, ri_out, zj_sup):
         return self.e.temp_approx_diffusion_vertical(Tdust, ri_in, ri_out, zj_sup)[0]
 
+    def repartition_energie(self, lam, Tdust):
+        """repartition_energie(lam) on the device (mcgpu_repartition_energie): the wavelength's emission tables stay in
+        HBM for the run_mono that follows; returns E_disk(lam)."""
+        self._tables = (lam, self.e.repartition_energie(lam, Tdust, fetch=False))
+        return self._tables[1]["E_disk"]
+
     def run_mono(self, lam, n2, seed, n_chunks):
-        return self.e.run_mono(lam, n2, seed=seed, n_chunks=n_chunks, fetch_xI=False)
+        t = getattr(self, "_tables", None)
+        return self.e.run_mono(lam, n2, seed=seed, n_chunks=n_chunks, fetch_xI=False,
+                               device_tables=t[1] if t is not None and t[0] == lam else None)
 
     def dust_map(self, lam, Tdust, res, E_disk):
         return self.e.dust_map_sed(lam, Tdust, res["n_sent"][lam - 1], E_disk)[0]
@@ -58,7 +66,10 @@ def temperature_and_sed(backend, m, n_thermal, n_photons_lambda, lambdas=None, s
         Tdust = backend.temp_approx_diffusion_vertical(Tdust, *diff_approx)
         t["diffusion"] = time.perf_counter() - t0
     t0 = time.perf_counter()
-    M.repartition_energie(m, Tdust)
+    on_device = hasattr(backend, "repartition_energie")   # the engine builds each wavelength's tables itself (:924)
+    if not on_device:
+        M.repartition_energie(m, Tdust)
+    E_disk = {} if on_device else dict(enumerate(m.extra["E_disk"], start=1))
     t["repartition_energie"] = time.perf_counter() - t0
     nl = m.n_lambda
     lambdas = list(lambdas) if lambdas is not None else list(range(1, nl + 1))
@@ -69,6 +80,10 @@ def temperature_and_sed(backend, m, n_thermal, n_photons_lambda, lambdas=None, s
     sed_rt_stars = np.zeros((nl, rt["RT_n_incl"] * rt["RT_n_az"]))
     t["sed_mc"] = t["ray_tracing"] = 0.0
     for lam in lambdas:
+        if on_device:
+            t0 = time.perf_counter()
+            E_disk[lam] = backend.repartition_energie(lam, Tdust)
+            t["repartition_energie"] += time.perf_counter() - t0
         t0 = time.perf_counter()
         r = backend.run_mono(lam, int(n_photons_lambda), seed + lam, n_chunks)
         t["sed_mc"] += time.perf_counter() - t0
@@ -76,12 +91,17 @@ def temperature_and_sed(backend, m, n_thermal, n_photons_lambda, lambdas=None, s
         n_sent[lam - 1] = r["n_sent"][lam - 1]
         if ray_tracing:
             t0 = time.perf_counter()
-            sed_rt[lam - 1] = backend.dust_map(lam, Tdust, r, m.extra["E_disk"][lam - 1])
+            sed_rt[lam - 1] = backend.dust_map(lam, Tdust, r, E_disk[lam])
             if hasattr(backend, "stars_map"):   # compute_stars_map (dust_transfer.f90:1583-1586): added to type 1 by the caller
                 sed_rt_stars[lam - 1] = backend.stars_map(lam, stars_flux_factor(m, lam), seed + 7919 * lam)
             t["ray_tracing"] += time.perf_counter() - t0
+    if on_device:   # what sed_flux() and the callers' ray-tracing calls read
+        Ed = np.zeros(nl)
+        for lam, v in E_disk.items():
+            Ed[lam - 1] = v
+        m.extra["E_disk"] = Ed
     return dict(Tdust=Tdust, sed_mc=sed, n_sent=n_sent, sed_rt=sed_rt, sed_rt_stars=sed_rt_stars, seconds=t,
-                thermal_counters=th["counters"])
+                thermal_counters=th["counters"], E_disk=E_disk)
 
 
 def stars_flux_factor(m, lam):

@@ -462,6 +462,23 @@ class Oracle:
             raise RuntimeError(f"oracle_init_reemission failed: {rc}")
         return lq, cdf
 
+    def repartition_energie(self, lam, Tdust, E_ISM=0.0, weight=None):
+        """repartition_energie(lam) (thermal_emission.f90:1771-1949, LTE): frac_E_stars, frac_E_disk, E_disk and
+        prob_E_cell(0:n_cells) of the 1-based wavelength ``lam`` for the dust temperature ``Tdust``."""
+        m = self.model
+        f = self.lib.oracle_repartition_energie
+        f.restype = C.c_int
+        T = np.ascontiguousarray(Tdust, np.float32)
+        wgt = np.ascontiguousarray(weight, np.float32) if weight is not None else None
+        pe = np.zeros(m.n_cells + 1)
+        fs, fd, ed = C.c_double(), C.c_double(), C.c_double()
+        rc = f(C.byref(self.cm), C.c_int(int(lam)), C.c_double(float(m.lam[lam - 1])), C.c_double(float(m.E_stars[lam - 1])),
+               C.c_double(float(E_ISM)), _p(T, C.c_float), _p(wgt, C.c_float) if wgt is not None else None,
+               C.byref(fs), C.byref(fd), C.byref(ed), _p(pe, C.c_double))
+        if rc:
+            raise RuntimeError(f"oracle_repartition_energie: no energy at wavelength {lam}")
+        return dict(frac_E_stars=fs.value, frac_E_disk=fd.value, E_disk=ed.value, prob_E_cell=pe)
+
     # -- Voronoi operators ---------------------------------------------------
     def cross_voronoi(self, x0, y0, z0, u, v, w, cell, prev):
         n = len(cell)

@@ -2646,6 +2646,50 @@ int oracle_dust_map_image(const oracle_model *m, const oracle_rt_opts *o, int np
  * Arrays in the reference's layouts: kappa_abs_LTE(p_n_cells, n_lambda),
  * log_Qcool_minus_extra_heating(n_T, p_n_cells), kdB_dT_CDF(n_lambda, n_T, p_n_cells).
  * ------------------------------------------------------------------------- */
+/* -------------------------------------------------------------------------
+ * repartition_energie (thermal_emission.f90:1771-1949), the LTE branch (:1814-1831) with the normalisation that
+ * follows it (:1893-1942).
+ * ------------------------------------------------------------------------- */
+int oracle_repartition_energie(const oracle_model *m, int lambda, double wl_um, double E_star, double E_ISM,
+                               const float *Tdust, const float *weight_proba_emission, double *frac_E_stars,
+                               double *frac_E_disk, double *E_disk, double *prob_E_cell) {
+  const double hp = 6.626070040e-34, c_light = 299792458.0, kb = 1.38064852e-23; /* constants.f90:21-23 */
+  const float thermal_const = (float)(c_light * hp / kb);                         /* real, constants.f90:24 */
+  const double tiny_dp = 2.2250738585072014e-308;
+  const double cst_wl_max = log(HUGE_REAL) - (double)1.0e-4f;                     /* :1802 */
+  const double wl = wl_um * (double)1.e-6f;                                       /* :1804, default-real literal */
+  const int n_cells = m->n_cells;
+  double sum_E = 0.0;
+  prob_E_cell[0] = 0.0;                                                           /* :1923 */
+  for (int icell = 1; icell <= n_cells; ++icell) {
+    double E_cell = 0.0;
+    if (!(m->l_dark_zone && m->l_dark_zone[icell - 1])) {                         /* :1816 */
+      const double Temp = (double)Tdust[icell - 1];
+      if (!(Temp < TINY_REAL)) {                                                  /* :1818 */
+        const double cst_wl = (double)thermal_const / (Temp * wl);
+        if (cst_wl < cst_wl_max) {
+          const double kabs = m->p_n_cells > 0
+                                  ? m->v_kappa_abs_LTE[(size_t)(m->p_icell[icell - 1] - 1) + (size_t)m->p_n_cells * (lambda - 1)]
+                                  : m->kappa_abs_LTE[lambda - 1];
+          const double wl2 = wl * wl, wl5 = (wl2 * wl2) * wl;                     /* wl**5 */
+          E_cell = 4.0 * kabs * m->kappa_factor[icell - 1] * m->volume[icell - 1] / (wl5 * (exp(cst_wl) - 1.0)); /* :1823 */
+        }
+      }
+    }
+    sum_E = sum_E + E_cell;                                                       /* E_disk(lambda) = sum(E_cell), :1897 */
+    const double corr = weight_proba_emission ? E_cell * (double)weight_proba_emission[icell - 1] : E_cell; /* :1888-1894 */
+    prob_E_cell[icell] = prob_E_cell[icell - 1] + corr;                           /* :1924-1926 */
+  }
+  *E_disk = sum_E;
+  if (E_star + sum_E + E_ISM < tiny_dp) return 1;                                 /* :1899-1903 */
+  *frac_E_stars = E_star / (E_star + sum_E + E_ISM);                              /* :1905 */
+  *frac_E_disk = (E_star + sum_E) / (E_star + sum_E + E_ISM);                     /* :1906 */
+  const double last = prob_E_cell[n_cells];
+  if (last > tiny_dp) for (int i = 0; i <= n_cells; ++i) prob_E_cell[i] = prob_E_cell[i] / last; /* :1933-1937 */
+  else for (int i = 0; i <= n_cells; ++i) prob_E_cell[i] = 0.0;
+  return 0;
+}
+
 int oracle_init_reemission(int p_n_cells, int n_T, int n_lambda, const float *tab_Temp, const double *tab_lambda,
                            const double *tab_delta_lambda, const double *kappa_abs_LTE, double *log_Qcool,
                            double *kdB_dT_CDF) {

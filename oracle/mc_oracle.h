@@ -351,6 +351,17 @@ int oracle_init_reemission(int p_n_cells, int n_T, int n_lambda, const float *ta
                            const double *tab_delta_lambda, const double *kappa_abs_LTE, double *log_Qcool,
                            double *kdB_dT_CDF);
 
+/* repartition_energie(lambda) (thermal_emission.f90:1771-1949), LTE grains (lRE_LTE; :1814-1831): how the energy emitted at
+ * one wavelength splits between the stars, the disk's cells and the interstellar field.  In: tab_lambda(lambda) in
+ * micron, E_stars(lambda), E_ISM(lambda), Tdust(n_cells) (default real), weight_proba_emission(n_cells) or NULL
+ * (lweight_emission); the model's kappa_abs_LTE (per class with lvariable_dust), kappa_factor, volume, l_dark_zone.
+ * Out: frac_E_stars(lambda), frac_E_disk(lambda), E_disk(lambda), prob_E_cell(0:n_cells, lambda).  Returns 1 when the
+ * wavelength has no energy at all (the reference stops there, :1899-1903).  PARITY UNPINNED (module thermal_emission
+ * is unbuildable here): pinned by known answers in tests/test_repartition_energie.py. */
+int oracle_repartition_energie(const oracle_model *m, int lambda, double wl_um, double E_star, double E_ISM,
+                               const float *Tdust, const float *weight_proba_emission, double *frac_E_stars,
+                               double *frac_E_disk, double *E_disk, double *prob_E_cell);
+
 /* Voronoi grid operators (Voronoi.f90). */
 int oracle_find_voronoi_cell(const oracle_model *m, int iwall, double x, double y, double z);
 void oracle_cross_voronoi_cell(const oracle_model *m, double x, double y,

@@ -22,7 +22,7 @@ wall = time.perf_counter() - t0
 s = r["seconds"]
 n_sed = r["n_sent"].sum()
 print(f"thermal step: {n_th:.3g} packets in {s['thermal']:.3f} s ({n_th / s['thermal']:.3g} packets/s incl. Temp_finale)")
-print(f"repartition_energie (host, numpy): {s['repartition_energie']:.3f} s")
+print(f"repartition_energie (device, per wavelength): {s['repartition_energie']:.3f} s")
 print(f"SED Monte Carlo (xI_scatt in {xi_bytes}-byte sums): {m.n_lambda} wavelengths, {n_sed:.3g} packets in {s['sed_mc']:.3f} s ({n_sed / s['sed_mc']:.3g} packets/s, "
       f"scout + commit passes and the fetch of the SED arrays included)")
 print(f"ray-traced dust SED: {m.n_lambda} x {cfg.RT_n_incl} inclinations in {s['ray_tracing']:.3f} s")
