@@ -139,17 +139,39 @@ def test_emulated_kernels_walk_like_the_oracle(emu):
 # ---------------------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
 def test_device_walk_equals_the_oracle_frozen():
-    """The compiled kernels against the oracle on the same packets, frozen temperature.  The lane emulation above
-    holds the device source to the oracle packet for packet; on the GPU a packet of this disk goes through hundreds of
-    events and the device's libm (log, sincos) differs from the host's in the last place, so a few per cent of the
-    packets take another branch somewhere and their histories part: the totals agree to the noise of those packets,
-    the bookkeeping exactly."""
+    """The compiled kernels against the oracle on the same packets, frozen temperature.
+
+    Why this is NOT packet for packet although every other frozen test is.  Without the walk this very disk IS exact on
+    the GPU (5.0e6 crossings, 3.8e6 flights, every counter equal: asserted below).  The walk makes the packet's history
+    CHAOTIC in the rounding: a step jumps by d(x), the distance from x to the closest wall, so a perturbation delta of
+    the position changes the next jump by up to |delta| -- it can double per step, and a packet of this disk takes
+    hundreds to thousands of steps.  The last-place differences that are harmless everywhere else (FMA contraction,
+    the device's sincos / log against the host's) therefore decide, after ~50 steps, where the walk leaves its cell:
+    the histories of most walking packets part, between GPU and CPU and equally between the two GPU schedules (two
+    instantiations of the same source: 21 397 against 20 341 walks on the same 20 000 packets, measured).  The lane
+    emulation (same source, host arithmetic; test_emulated_kernels_walk_like_the_oracle) holds the device code to the
+    oracle packet for packet; here the two are independent samples of the same walk as far as the walking packets go,
+    so the gate is statistical and NOISE-AWARE: every counter within 4 sigma of the difference of two independent runs,
+    sigma measured from the oracle's own seed-to-seed scatter -- and exact for everything the walk does not touch."""
     from mcfost_amd.engine import Engine
-    m = thick_disk()
     n = 20000
-    orc = Oracle(m, n)
     prior = Oracle(thick_disk(mrw=False), n).run_thermal(n, seed=1, n_threads=1)["E_abs"]   # (one thread: reproducible)
+    # (a) the same disk without the walk: packet for packet
+    m0 = thick_disk(mrw=False)
+    want0 = Oracle(m0, n).run_thermal(n, seed=9, frozen=True, E_prior=prior, n_threads=8)
+    e = Engine(m0, n)
+    got0 = e.run_thermal(n, seed=9, frozen=True, E_prior=prior)
+    e.close()
+    assert got0["counters"] == want0["counters"]
+    assert np.allclose(got0["E_abs"], want0["E_abs"], rtol=1e-7, atol=1e-8 * want0["E_abs"].max())   # (millions of terms in the hot cells)
+    # (b) with the walk
+    m = thick_disk()
+    orc = Oracle(m, n)
     want = orc.run_thermal(n, seed=9, frozen=True, E_prior=prior, n_threads=8)
+    keys = ("mrw_walks", "mrw_steps", "absorptions", "scatterings", "crossings", "flights")
+    others = [orc.run_thermal(n, seed=s, frozen=True, E_prior=prior, n_threads=8) for s in (21, 22, 23, 24, 25, 26)]
+    sigma = {k: np.std([r["counters"][k] for r in others], ddof=1) for k in keys}
+    sigma_E = np.std([r["E_abs"].sum() for r in others], ddof=1)
     for sched in (0, 1):
         e = Engine(m, n)
         e.set_option("schedule", sched)
@@ -160,11 +182,10 @@ def test_device_walk_equals_the_oracle_frozen():
         for k in ("packets", "escaped", "killed_star", "dark_mirrors"):
             assert g[k] == w[k]
         assert g["escaped"] + g["killed_star"] == n
-        # (20 000 packets of a heavy-tailed walk count: the packets that parted contribute a few per cent of noise)
-        for k in ("mrw_walks", "mrw_steps", "absorptions", "scatterings", "crossings", "flights"):
-            assert abs(g[k] - w[k]) <= 0.10 * w[k], (k, g, w)
+        for k in keys:   # two samples of the same distribution (at most: the packets that never walk are identical)
+            assert abs(g[k] - w[k]) <= 4.0 * np.sqrt(2.0) * sigma[k], (k, g[k], w[k], sigma[k])
         assert np.array_equal(got["n_sent"], want["n_sent"])             # the emission draws are the same packets'
-        assert np.isclose(got["E_abs"].sum(), want["E_abs"].sum(), rtol=5e-2)
+        assert abs(got["E_abs"].sum() - want["E_abs"].sum()) <= 4.0 * np.sqrt(2.0) * sigma_E
         nz, nr = 20, 30                                                   # thin outer disk: no walks, few events
         a, b = got["E_abs"].reshape(nz, nr)[:, 20:], want["E_abs"].reshape(nz, nr)[:, 20:]
         assert np.isclose(a.sum(), b.sum(), rtol=5e-3)
@@ -172,9 +193,12 @@ def test_device_walk_equals_the_oracle_frozen():
 
 @pytest.mark.gpu
 def test_device_walk_against_brute_force():
-    """MRW on vs brute force on the GPU, same frozen prior, 4 independent runs each: per-cell z-scores of the absorbed
-    energy (gamma = 8: the walk's systematic error is below the noise; gamma = 2, the reference's value: within a few
-    per cent in temperature) and the time the walk saves."""
+    """MRW on vs brute force on the GPU, same frozen prior, 4 independent runs each, and the time the walk saves.
+    Noise-aware gates: with se the standard error of the difference of the two means per cell and T ~ E^(1/5),
+      * every cell:  |dE| <= 5 b E + 4.5 se   -- a temperature bias of at most b (2 % at gamma = 8, 4 % at gamma = 2, the
+        reference's value) plus what the noise of ~600 cells explains (4.5 sigma);
+      * the cells above a signal-to-noise floor (se < 1 % of E, i.e. 0.2 % in T): |dT / T| <= b outright;
+      * gamma = 8: the rms z-score of all cells < 3 (the walk's systematic error is below the noise there)."""
     from mcfost_amd.engine import Engine
     n = 4_000_000
     m0 = thick_disk(mrw=False)
@@ -197,14 +221,17 @@ def test_device_walk_against_brute_force():
         sel = ma > 0
         z = (mb[sel] - ma[sel]) / np.maximum(se[sel], 1e-300)
         bias_T = ((mb[sel] / ma[sel]) ** 0.2 - 1.0)       # T ~ E^(1/(4+beta)), beta ~ 1
-        res[gamma] = (np.sqrt(np.mean(z ** 2)), np.abs(bias_T).max(), t0 / t1, runs1[0]["counters"]["mrw_walks"],
-                      np.percentile(np.abs(bias_T), 99.0))
+        b = 0.02 if gamma == 8.0 else 0.04
+        excess = np.abs(mb[sel] - ma[sel]) - (5.0 * b * ma[sel] + 4.5 * se[sel])
+        clear = se[sel] < 0.01 * ma[sel]                   # signal-to-noise floor
+        res[gamma] = (np.sqrt(np.mean(z ** 2)), np.abs(bias_T[clear]).max(), t0 / t1, runs1[0]["counters"]["mrw_walks"],
+                      int(clear.sum()), float(excess.max() / ma[sel][np.argmax(excess)]))
         assert runs1[0]["counters"]["mrw_walks"] > 1000
-    print("MRW vs brute force (rms z, max |dT/T|, speed-up, walks, 99th percentile of |dT/T|):", res)
-    # the bulk by its 99th percentile; the largest of the ~600 cell deviations carries the noise of the faintest cells
-    # (0.013 and 0.023 at gamma = 8 on two boxes with different live priors), hence a looser bound on it
-    assert res[8.0][0] < 3.0 and res[8.0][4] < 0.02 and res[8.0][1] < 0.04, res
-    assert res[2.0][4] < 0.04 and res[2.0][1] < 0.06, res
+        assert clear.sum() > 100
+        assert (excess <= 0.0).all(), (gamma, res[gamma])
+        assert np.abs(bias_T[clear]).max() <= b, (gamma, res[gamma])
+    print("MRW vs brute force (rms z, max |dT/T| over the clear cells, speed-up, walks, clear cells, largest excess / E):", res)
+    assert res[8.0][0] < 3.0, res
     assert res[2.0][2] > 1.5, res
 
 
@@ -221,24 +248,41 @@ def test_config4_thick_ref41_live_against_brute_force_with_the_reference_gate():
     cfg.dust_mass = 1e-2
     m0 = M.build_model(cfg)
     e0 = Engine(m0, n)
-    r0 = e0.run_thermal(n, seed=3)
-    T0 = e0.temp_finale(r0["E_abs"])
+    r0 = [e0.run_thermal(n, seed=s) for s in (3, 13, 23)]
+    T0 = np.array([e0.temp_finale(r["E_abs"]) for r in r0])
     e0.close()
     m1 = M.build_model(cfg)
     M.init_mrw(m1)
     e1 = Engine(m1, n)
-    r1 = e1.run_thermal(n, seed=4)
-    T1 = e1.temp_finale(r1["E_abs"])
+    r1 = [e1.run_thermal(n, seed=s) for s in (4, 14, 24)]
+    T1 = np.array([e1.temp_finale(r["E_abs"]) for r in r1])
     e1.close()
-    c0, c1 = r0["counters"], r1["counters"]
+    c0, c1 = r0[0]["counters"], r1[0]["counters"]
     assert c1["mrw_walks"] > 1e6 and c1["escaped"] + c1["killed_star"] == n
     assert c1["absorptions"] < 0.7 * c0["absorptions"]
-    sel = (T0 > 1.2 * cfg.T_min) & (T1 > 1.2 * cfg.T_min)
-    ok, p75 = mc_similar(T0[sel], T1[sel], 0.05)
+    # the reference's gate on single runs, as its test suite applies it
+    sel = (T0[0] > 1.2 * cfg.T_min) & (T1[0] > 1.2 * cfg.T_min)
+    ok, p75 = mc_similar(T0[0][sel], T1[0][sel], 0.05)
     assert ok and p75 < 0.01, p75
-    # no cell is far off, the Monte Carlo noise of the faintest cells included (two independent runs: the largest of
-    # ~7000 deviations was 0.059 and 0.100 on two boxes, hence a percentile for the bulk and a loose bound for the tail)
-    dev = np.abs(T1[sel] / T0[sel] - 1.0)
-    assert np.percentile(dev, 99.5) < 0.05 and dev.max() < 0.25, (np.percentile(dev, 99.5), dev.max())
-    print("config 4 (thick ref4.1): p75 |dT/T| = %.4f, max = %.3f, kernel %.0f -> %.0f ms" %
-          (p75, np.abs(T1[sel] / T0[sel] - 1.0).max(), r0["kernel_ms"], r1["kernel_ms"]))
+    # ... and every cell, noise-aware -- no ad-hoc maximum.  Three independent runs each way give the standard error of
+    # the difference of the means; with two degrees of freedom per cell that estimate has heavy tails, so it is pooled:
+    # the cells are ranked by absorbed energy and the relative error of a cell is the median over its 140 neighbours in
+    # that ranking.  A cell may be off by the reference's own gate value (5 % in T, which its suite only asks of the
+    # 75th percentile) plus 5 sigma of that noise; the cells above a signal-to-noise floor by 4 % outright (the walk's
+    # bias bound at gamma = 2, as in test_device_walk_against_brute_force).
+    a, b = T0.mean(0), T1.mean(0)
+    se = np.sqrt(T0.var(0, ddof=1) / 3 + T1.var(0, ddof=1) / 3)
+    E0 = np.mean([r["E_abs"] for r in r0], axis=0)
+    order = np.argsort(E0)
+    rel = np.empty_like(se)
+    for i0 in range(0, order.size, 140):
+        idx = order[i0:i0 + 140]
+        rel[idx] = np.median(se[idx] / np.maximum(a[idx], 1e-30))
+    se_s = rel * a
+    sel = (a > 1.2 * cfg.T_min) & (b > 1.2 * cfg.T_min)
+    excess = np.abs(b[sel] - a[sel]) - (0.05 * a[sel] + 5.0 * se_s[sel])
+    assert (excess <= 0.0).all(), (float(excess.max()), int(np.argmax(excess)))
+    clear = se_s[sel] < 0.002 * a[sel]
+    assert clear.sum() > 1000 and np.abs(b[sel][clear] / a[sel][clear] - 1.0).max() < 0.04
+    print("config 4 (thick ref4.1): p75 |dT/T| = %.4f, largest |dT/T| over the %d clear cells %.4f, kernel %.0f -> %.0f ms" %
+          (p75, int(clear.sum()), np.abs(b[sel][clear] / a[sel][clear] - 1.0).max(), r0[0]["kernel_ms"], r1[0]["kernel_ms"]))
