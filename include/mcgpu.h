@@ -523,6 +523,9 @@ int mcgpu_init_reemission(mcgpu_ctx *ctx, const double *tab_lambda, const double
  *   xJ_abs[n_cells * n_lambda]  sum of l * Stokes(1) per cell and wavelength (lxJ_abs_step1), column-major (icell, lambda)
  * Switched on before a thermal launch with mcgpu_set_option(ctx, "radiation_field", bits) -- bit 0: xN_abs, bit 1:
  * xJ_abs; zeroed by a launch unless accumulate is set.  Either pointer may be NULL.
+ * xN_abs is counted in 32-bit words on the device: a cell crossed more than 2^32 times between two resets wraps
+ * (the reference's default-real counter stops growing at 2^24 instead); with `accumulate` over many 1e8-packet
+ * launches fetch and reset it in between.
  */
 int mcgpu_fetch_radiation_field(mcgpu_ctx *ctx, double *xN_abs, double *xJ_abs);
 

@@ -50,6 +50,7 @@ struct mcgpu_ctx {
   bool have_grid = false, have_stars = false, have_opacity = false, have_scatt = false,
        have_thermal = false, have_sed = false;
   bool reemission_pending = false;  // set_thermal / set_variable_dust left the LTE tables to mcgpu_init_reemission
+  bool pending_single = false, pending_classes = false;  // ... which of the two sets
   int lsepar_pola = 0;
   float T_min = 1.0f;
   // mcgpu_set_option
@@ -606,7 +607,8 @@ extern "C" int mcgpu_set_thermal(mcgpu_ctx* ctx, int n_T, const float* tab_Temp,
   if ((rc = upload(ctx, tab_Temp, (size_t)n_T, &tt))) return rc;
   ctx->d_tab_Temp = (float*)tt;
   // both NULL: the two re-emission tables are left to mcgpu_init_reemission (a launch before it is refused)
-  ctx->reemission_pending = (log_Qcool == nullptr);
+  ctx->pending_single = (log_Qcool == nullptr);
+  ctx->reemission_pending = ctx->pending_single || ctx->pending_classes;
   if ((rc = upload(ctx, log_Qcool, log_Qcool ? (size_t)n_T : 0, &M.log_Qcool, (size_t)n_T))) return rc;
   if ((rc = upload(ctx, kdB_dT_CDF, kdB_dT_CDF ? (size_t)n_T * M.n_lambda : 0, &M.cdf, (size_t)n_T * M.n_lambda))) return rc;
   if ((rc = upload(ctx, spectre_emission_cumul, (size_t)M.n_lambda + 1, &M.spec_cum))) return rc;
@@ -632,7 +634,12 @@ extern "C" int mcgpu_set_variable_dust(mcgpu_ctx* ctx, int p_n_cells, const int*
                                        const float* tab_s44_o_s11_pos, const float* tab_g_pos) {
   if (!ctx) return MCGPU_ERR_ARG;
   DevModel& M = ctx->M;
-  if (p_n_cells == 0) { M.n_classes = 0; return MCGPU_OK; }  // back to one class
+  if (p_n_cells == 0) {  // back to one class (what the class tables were waiting for no longer matters)
+    M.n_classes = 0;
+    ctx->pending_classes = false;
+    ctx->reemission_pending = ctx->pending_single;
+    return MCGPU_OK;
+  }
   if (p_n_cells < 1 || !p_icell || !kappa || !kappa_abs_LTE || !tab_albedo_pos ||
       ((log_Qcool == nullptr) != (kdB_dT_CDF == nullptr)))
     return fail(ctx, MCGPU_ERR_ARG, "mcgpu_set_variable_dust: bad argument");
@@ -665,7 +672,8 @@ extern "C" int mcgpu_set_variable_dust(mcgpu_ctx* ctx, int p_n_cells, const int*
   if ((rc = upload(ctx, al.data(), al.size(), &M.v_albedo))) return rc;
   // log_Qcool_minus_extra_heating(n_T, p_n_cells) and kdB_dT_CDF(n_lambda, n_T, p_n_cells): class slowest already
   // (both NULL: left to mcgpu_init_reemission -- 280 MB at 7000 classes that never cross the bus)
-  if (!log_Qcool) ctx->reemission_pending = true;
+  ctx->pending_classes = (log_Qcool == nullptr);
+  ctx->reemission_pending = ctx->pending_single || ctx->pending_classes;
   if ((rc = upload(ctx, log_Qcool, log_Qcool ? (size_t)nc * nT : 0, &M.v_lq, (size_t)nc * nT))) return rc;
   if ((rc = upload(ctx, kdB_dT_CDF, kdB_dT_CDF ? (size_t)nc * nT * nl : 0, &M.v_cdf, (size_t)nc * nT * nl))) return rc;
   // scattering tables per class (all or none): (0:nang, p_n_cells, n_lambda) in the reference -> [class][lambda][angle]
@@ -722,9 +730,13 @@ extern "C" int mcgpu_init_reemission(mcgpu_ctx* ctx, const double* tab_lambda, c
     hipLaunchKernelGGL(k_init_reemission, dim3((n + threads - 1) / threads), dim3(threads), 0, ctx->stream, nc, nT, nl,
                        ctx->d_tab_Temp, d_lam, d_dlam, kabs, const_cast<double*>(lq), const_cast<double*>(cdf));
   };
+  // the tables the setters left to this call; called with none pending, it rebuilds all of them (an explicit request),
+  // otherwise tables the host supplied are left alone
+  const bool all = !ctx->pending_single && !ctx->pending_classes;
+  const bool do_single = all || ctx->pending_single, do_classes = M.n_classes && (all || ctx->pending_classes);
   if (e == hipSuccess) {
-    build(1, M.kappa_abs, M.log_Qcool, M.cdf);
-    if (M.n_classes) build(M.n_classes, M.v_kabs, M.v_lq, M.v_cdf);
+    if (do_single) build(1, M.kappa_abs, M.log_Qcool, M.cdf);
+    if (do_classes) build(M.n_classes, M.v_kabs, M.v_lq, M.v_cdf);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -743,6 +755,13 @@ extern "C" int mcgpu_init_reemission(mcgpu_ctx* ctx, const double* tab_lambda, c
     for (int t = 2; t < nT; ++t)
       if (lq[(size_t)c * nT + t] < lq[(size_t)c * nT + t - 1])
         return fail(ctx, MCGPU_ERR_UNSUPPORTED, "log_Qcool must increase with T");
+  if (M.n_classes && do_single) {  // (the single-class table too: spherical / MRW / SED paths read it)
+    std::vector<double> lq1((size_t)nT);
+    HIPCHK(hipMemcpy(lq1.data(), M.log_Qcool, lq1.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int t = 2; t < nT; ++t)
+      if (lq1[t] < lq1[t - 1]) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "log_Qcool must increase with T");
+  }
+  ctx->pending_single = ctx->pending_classes = false;
   ctx->reemission_pending = false;
   return MCGPU_OK;
 }
@@ -1328,7 +1347,7 @@ extern "C" int mcgpu_fetch(mcgpu_ctx* ctx, double* E_abs, double* sed, double* n
   return MCGPU_OK;
 }
 
-// The eight event counters ride in the tail of the fused accumulator as doubles (exact below 2^53), so that a
+// The MCGPU_N_COUNTERS event counters ride in the tail of the fused accumulator as doubles (exact below 2^53), so that a
 // multi-GPU host reduces ONE buffer per temperature iteration.
 __global__ void k_counters_to_accum(const unsigned long long* cnt, double* tail) {
   if (threadIdx.x < MCGPU_N_COUNTERS) tail[threadIdx.x] = (double)cnt[threadIdx.x];

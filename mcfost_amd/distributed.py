@@ -6,7 +6,7 @@ accumulators that are summed after the loop (``dust_transfer.f90:480-489``,
 range is split into disjoint contiguous shards (the per-packet Philox streams
 make the result independent of the split), every rank holds a replica of the
 tables, and ONE all-reduce (RCCL over xGMI when the backend is ``nccl``) sums
-the fused accumulator ``[E_abs | sed | n_sent | counters]`` (the eight event
+the fused accumulator ``[E_abs | sed | n_sent | counters]`` (the ten event
 counters ride along as doubles, exact below 2^53) per temperature iteration.  The in-flight temperature uses the local partial sum
 times ``world_size`` -- the reference's ``* nb_proc``
 (``thermal_emission.f90:670``).

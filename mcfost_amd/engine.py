@@ -292,6 +292,11 @@ class Engine:
 
     def launch_thermal(self, n_packets, seed=1, first_packet=0, frozen=False, n_replicas=1.0,
                        accumulate=False, grid_blocks=0, block_threads=0):
+        if accumulate and getattr(self, "_holds_global_sums", False):
+            raise McgpuError("accumulate after allreduce_device: the accumulators hold the all-reduced totals, "
+                             "accumulating onto them and reducing again would count them world_size times")
+        if not accumulate:
+            self._holds_global_sums = False
         o = self._opts(n_packets, seed, first_packet, frozen, n_replicas, accumulate, grid_blocks,
                        block_threads)
         self._chk(self.lib.mcgpu_launch_thermal(self.ctx, C.byref(o)), "mcgpu_launch_thermal")
@@ -385,8 +390,11 @@ class Engine:
     def allreduce_device(self, all_reduce):
         """ONE collective per temperature iteration: the counters join the fused accumulator as doubles
         (``mcgpu_counters_to_accum``), ``all_reduce(tensor)`` sums it over the ranks (RCCL with the ``nccl``
-        backend), the summed counters go back (``mcgpu_counters_from_accum``)."""
+        backend), the summed counters go back (``mcgpu_counters_from_accum``).  Afterwards this rank holds the GLOBAL
+        sums: an accumulating launch on top of them is refused (every rank would add its new part to a copy of the
+        old total: world_size-fold overcount) -- use ``mcgpu_multi_run_thermal``, which rescales, or reduce once."""
         import torch
+        self._holds_global_sums = True
 
         self._chk(self.lib.mcgpu_counters_to_accum(self.ctx), "mcgpu_counters_to_accum")
         torch.cuda.synchronize(self.device)        # the engine's stream -> the collective's stream
