@@ -168,6 +168,10 @@ int mcgpu_set_midplane_snap(mcgpu_ctx *ctx, int on);
  *                      through a hashed LDS cache in front of HBM atomics; 1 = HBM atomics only;
  *                      2 = LDS (refused when the grid does not fit); 3 = binned (refused where
  *                      it is not built)
+ *   "tail"         the role kernels hand their last packets to the tail kernel (one packet per wave with the other
+ *                      lanes working ahead for it, mc_tail.hip.h) once a workgroup has this many left; 0 = never;
+ *                      -1 (default) = automatic: 48 where packets get trapped (the context's last launch had at
+ *                      least one interaction per packet, or -- first launch -- the midplane is optically thick)
  *   "deposit_log_mb"  size of the binned-deposit log in MiB; 0 (default) = 24 GiB or a third of
  *                      the free device memory.  A smaller log means more, shorter chunks; a
  *                      block that finds its part of the log full is added with atomics.
@@ -184,7 +188,7 @@ int mcgpu_set_midplane_snap(mcgpu_ctx *ctx, int on);
  */
 int mcgpu_set_option(mcgpu_ctx *ctx, const char *name, int value);
 /* Diagnostics of the last launches: "bin_buckets", "bin_log_blocks", "bin_chunks",
- * "bin_deposits_per_packet", "bin_overflow_blocks", "bin_drained_records". */
+ * "bin_deposits_per_packet", "bin_overflow_blocks", "bin_drained_records", "tail_threshold", "tau_midplane". */
 int mcgpu_get_info(mcgpu_ctx *ctx, const char *name, double *value);
 
 /* Stars: type star_type (parameters.f90:230-242); icell/out_model from

@@ -200,6 +200,8 @@ struct RunArgs {
   void* carry_out;                  // [carry_cap] records; null: this chunk finishes every packet
   unsigned int* carry_out_n;
   unsigned int carry_cap;
+  int tail_threshold;               // <= 0: hand over as soon as the work counter has run out (a chunk of a binned run);
+                                    // > 0: once the workgroup has no more than that many packets left (-> k_tail)
 };
 
 // ---------------------------------------------------------------------------
@@ -900,12 +902,19 @@ __device__ inline void pos_em_cell_sph(const DevModel& M, int ri, int tj, int k,
 }
 
 // cdapres (utils.f90:1636-1690)
+// (cdapres with sin and cos of phi given: the tail kernel computes them ahead, mc_tail.hip.h)
+__device__ inline void cdapres_sc(double cospsi, double sphi, double cphi, double u0, double v0, double w0, double& u1,
+                                  double& v1, double& w1);
 __device__ inline void cdapres(double cospsi, double phi, double u0, double v0, double w0, double& u1,
                                double& v1, double& w1) {
-  double cpsi = cospsi;
-  double spsi = sqrt(1.0 - cpsi * cpsi);
   double sphi, cphi;
   sincos(phi, &sphi, &cphi);
+  cdapres_sc(cospsi, sphi, cphi, u0, v0, w0, u1, v1, w1);
+}
+__device__ inline void cdapres_sc(double cospsi, double sphi, double cphi, double u0, double v0, double w0, double& u1,
+                                  double& v1, double& w1) {
+  double cpsi = cospsi;
+  double spsi = sqrt(1.0 - cpsi * cpsi);
   double a = spsi * cphi;
   double b = spsi * sphi;
   if (fabs(w0) <= (double)0.999999f) {

@@ -77,8 +77,18 @@ struct alignas(8) Rec {
 };
 static_assert(sizeof(Rec<true>) == 136 && sizeof(Rec<false>) == 120, "record stride");
 
+// a record copied (src = nullptr: cleared) word by word through two registers -- a struct assignment would stage all 34
+// dwords in registers, and the role kernels have none to spare
+template <bool POLA>
+__device__ inline void rec_copy(Rec<POLA>* dst, const Rec<POLA>* src) {
+  unsigned long long* d = reinterpret_cast<unsigned long long*>(dst);
+  const unsigned long long* s = reinterpret_cast<const unsigned long long*>(src);
+#pragma unroll 1
+  for (int i = 0; i < (int)(sizeof(Rec<POLA>) / 8); ++i) d[i] = s ? s[i] : 0ull;
+}
+
 struct RqCtl {
-  int n_pending, ids_done, abort_flag, pad0;
+  int n_pending, ids_done, abort_flag, suspend;  // suspend: the workgroup is handing its packets over (CARRY)
   unsigned int head[3], tail[3];
   int n_srv, cooldown;  // waves [0, n_srv) serve; adapted by wave 0 (see roles_body)
   int idle_f, idle_s;   // lanes the flying / serving waves could not fill since the last adaptation
@@ -248,9 +258,11 @@ __device__ inline int roles_cross(const Lds& T, const DevModel& M, const RunArgs
 // effects: the stop (an FP64 division), the deposit (an LDS atomic) and the rare default-real zj recomputation.
 // Every value that decides an index or a position is computed by the reference's expression, exactly as in
 // cross_cell_lean / roles_cross above (cylindrical_grid.f90:918-1175, optical_depth.f90:77-178).
-template <bool DARK, bool LDSE, bool MRW = false>
+// OUT: the deposit is handed back (dep_ic >= 0, dep_v) instead of being made (the tail kernel, mc_tail.hip.h)
+template <bool DARK, bool LDSE, bool MRW = false, bool OUT = false>
 __device__ __forceinline__ int fly_step_2d(const Lds& T, const DevModel& M, const RunArgs& A, double* E_lds, Flight& p,
-                                           unsigned int& c_cross, unsigned int& c_kill, unsigned int& c_dark) {
+                                           unsigned int& c_cross, unsigned int& c_kill, unsigned int& c_dark,
+                                           int* dep_ic = nullptr, double* dep_v = nullptr) {
   const int n_rad = M.n_rad, nz = M.nz;
   const double cm = 1.0 - GRID_PREC, cp = 1.0 + GRID_PREC;
   const bool active = (p.st == S_FLIGHT);
@@ -341,7 +353,10 @@ __device__ __forceinline__ int fly_step_2d(const Lds& T, const DevModel& M, cons
   double lc = l;
   if (__builtin_expect(stop, 0)) lc = l * (p.extr / tau);  // (once per flight)
   // save_radiation_field (radiation_field.f90:53)
-  if (go && real_cell && !MCGPU_DIAG(A.flags, 1)) deposit<LDSE>(A.E_abs, E_lds, ic, p.kab * lc * p.S0);
+  if (go && real_cell && !MCGPU_DIAG(A.flags, 1)) {
+    if (OUT) { *dep_ic = ic; *dep_v = p.kab * lc * p.S0; }
+    else deposit<LDSE>(A.E_abs, E_lds, ic, p.kab * lc * p.S0);
+  }
 
   // the next cell; DARK: mirrored back at the wall of a dark cell (see roles_cross)
   const bool next_real = (ri1 >= 1) && (ri1 <= n_rad) && (zj1 >= 1) && (zj1 <= nz);
@@ -603,12 +618,16 @@ __device__ inline int voro_roles_cross(const Lds& T, const DevModel& M, const Ru
 // deposit cache (DepCache, 2^cache_log_ns slots behind the tables) instead of a private grid.
 // BIN: deposits go through the workgroup's staging buckets to the log in HBM (mc_binned.hip.h; grids whose
 // absorbed-energy array does not fit in LDS), the staging area sits between the tables and the queues.
-template <bool L3D, bool POLA, bool DARK, bool LDSE, bool MRW = false, bool VORO = false, bool BIN = false>
+// CARRY: the kernel can end early and hand its unfinished packets over (RunArgs::carry_out; "Chunks without tails"
+// above, and the tail kernel, mc_tail.hip.h); BIN implies it.
+template <bool L3D, bool POLA, bool DARK, bool LDSE, bool MRW = false, bool VORO = false, bool BIN = false, bool CARRY = BIN>
 __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, double* lds_base, int n_rec, int n_srv_pref,
                                            int k_short, int fly_iters, int fly_idle, int emit_qmax,
                                            const VoroGrid* Gp = nullptr, int cache_log_ns = 0) {
   static_assert(!VORO || (L3D && !DARK && !LDSE && !MRW), "Voronoi variant");
   static_assert(!BIN || (!LDSE && !MRW && !VORO), "binned deposits: grids that do not fit in LDS");
+  static_assert(!BIN || CARRY, "the chunks of a binned run hand their packets on");
+  static_assert(!CARRY || !VORO, "no carry-over on Voronoi grids");
   double* const E_lds = lds_base;
   const Lds T = lds_carve(lds_base + (LDSE ? M.n_cells : 0), M);
   lds_stage(T, M);
@@ -632,7 +651,7 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
   for (int i = threadIdx.x; i < 3 * RQ_CAP; i += blockDim.x)  // every record starts on the FREE ring
     rings[i] = (i < n_rec) ? ((((unsigned int)i + 1u) << 16) | (unsigned int)i) : 0u;
   if (threadIdx.x == 0) {
-    Q->n_pending = 0; Q->ids_done = 0; Q->abort_flag = 0;
+    Q->n_pending = 0; Q->ids_done = 0; Q->abort_flag = 0; Q->suspend = 0;
     Q->n_srv = n_srv_pref > 0 ? (n_srv_pref < 1000 ? n_srv_pref : n_srv_pref - 1000) : 0; Q->cooldown = 0; Q->idle_f = 0; Q->idle_s = 0; Q->beat = 0;
     Q->head[0] = Q->head[1] = Q->head[2] = 0u;
     Q->tail[RQ_FREE] = (unsigned int)n_rec; Q->tail[RQ_FLY] = 0u; Q->tail[RQ_SRV] = 0u;
@@ -654,7 +673,7 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
   const int free_reserve = n_rec / 8 < 32 ? n_rec / 8 : 32;
   const uint32_t key0 = (uint32_t)A.seed, key1 = (uint32_t)(A.seed >> 32);
   // work items of this launch: [0, n_carry) the records the last chunk left unfinished, then the new packets
-  const unsigned long long n_carry = (BIN && A.carry_in_n) ? (unsigned long long)*A.carry_in_n : 0ull;
+  const unsigned long long n_carry = (BIN && A.carry_in_n) ? (unsigned long long)*A.carry_in_n : 0ull;  // (chunks only)
   const unsigned long long n_items = n_carry + A.n_packets;
   const Rec<POLA>* const carry_in = reinterpret_cast<const Rec<POLA>*>(A.carry_in);
   Rec<POLA>* const carry_out = reinterpret_cast<Rec<POLA>*>(A.carry_out);
@@ -685,55 +704,18 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
   RQ_DIAG(unsigned int d_srv_lanes = 0, d_srv_int = 0, d_emit = 0;)
 
   for (int ep = 0;; ++ep) {
-    if (rq_ld(&Q->abort_flag)) break;
-    if (BIN && carry_out && wave == 0 && (ep & 15) == 15 && !rq_ld(&Q->ids_done)) {
-      // (a workgroup that emits nothing for a while -- its records full of long flights -- would not notice that the
-      // work counter has run out)
-      if (__hip_atomic_load(A.next_packet, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n_items) rq_st(&Q->ids_done, 1);
+    const int stop_flag = rq_ld(&Q->abort_flag);   // 1: error, 2 (CARRY): hand the packets over
+    if (stop_flag == 1) break;
+    if (CARRY && carry_out && wave == 0 && lane == 0 && stop_flag == 0) {
+      // Wave 0 -- the one wave that always serves -- decides when the workgroup hands its packets over: the global work
+      // counter has run out (seen by an emission, or looked up every 16 rounds: a workgroup whose records are full of
+      // long flights emits nothing for a while) and (tail_threshold > 0: the launch's last packets go to the tail
+      // kernel) no more than that many packets are left here; tail_threshold <= 0: at once (a chunk of a binned run).
+      if ((ep & 15) == 15 && !rq_ld(&Q->ids_done) &&
+          __hip_atomic_load(A.next_packet, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n_items) rq_st(&Q->ids_done, 1);
+      if (rq_ld(&Q->ids_done) && (A.tail_threshold <= 0 || rq_ld(&Q->n_pending) <= A.tail_threshold)) atomicCAS(&Q->abort_flag, 0, 2);
     }
-    if (BIN && carry_out && rq_ld(&Q->ids_done)) {
-      // ---- end of a chunk: what this wave holds goes to carry_out (see "Chunks without tails") -----------------
-      const bool held = rid < 0 && st != S_EMIT;   // a packet in registers
-      const bool owned = rid >= 0;                 // a record of this lane's
-      const unsigned long long left = pk_end - pk_next;  // reserved, not started (lane i takes the items pk_next + i + 64 q)
-      const int n_left = (int)((left > (unsigned long long)lane) ? (left - lane + (BIN_WAVE - 1)) / BIN_WAVE : 0ull);
-      const int mine = (held || owned ? 1 : 0) + n_left;
-      int pre = mine;  // inclusive prefix sum over the lanes
-      for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(pre, off); if (lane >= off) pre += t; }
-      const int total = __shfl(pre, 63);
-      unsigned int base = 0u;
-      if (lane == 0 && total > 0) base = atomicAdd(A.carry_out_n, (unsigned int)total);
-      base = __shfl(base, 0);
-      unsigned int at = base + (unsigned int)(pre - mine);
-      if (at + (unsigned int)mine > A.carry_cap) { *A.err = 16; rq_st(&Q->abort_flag, 1); }  // (never: the host sizes it for the worst case)
-      else {
-        if (held) {
-          Rec<POLA>& R = carry_out[at++];
-          R.x = F.x; R.y = F.y; R.z = F.z; R.u = F.u; R.v = F.v; R.w = F.w; R.extr = F.extr; R.S[0] = F.S0;
-          if (POLA) { R.S[POLA ? 1 : 0] = bag_S1; R.S[POLA ? 2 : 0] = bag_S2; R.S[POLA ? 3 : 0] = bag_S3; }
-          R.ri = F.ri; R.zj = F.zj; R.k = F.k; R.lambda = bag_lambda; R.star_key = F.star_key;
-          R.p_lo = bag_plo; R.p_hi = bag_phi; R.event = bag_event; R.pk_cross = F.pk_cross; R.tau_rand = bag_tau;
-          R.flags = st | bag_fl;
-        } else if (owned) {
-          Rec<POLA> Rc = recs[rid];
-          Rc.flags = (Rc.flags & ~ST_MASK) | st;
-          carry_out[at++] = Rc;
-        }
-        for (int q = 0; q < n_left; ++q) {
-          const unsigned long long item = pk_next + (unsigned long long)lane + (unsigned long long)BIN_WAVE * q;
-          if (item < n_carry) carry_out[at++] = carry_in[item];
-          else {  // a packet that was never emitted: state S_EMIT, its id in p_lo / p_hi
-            Rec<POLA> Rc;
-            memset(&Rc, 0, sizeof(Rc));
-            const unsigned long long pid = A.first_packet + (item - n_carry);
-            Rc.p_lo = (uint32_t)pid; Rc.p_hi = (uint32_t)(pid >> 32); Rc.flags = S_EMIT;
-            carry_out[at++] = Rc;
-          }
-        }
-      }
-      suspended = true;
-      break;
-    }
+    if (CARRY && stop_flag == 2) { suspended = true; break; }  // (the hand-over itself: behind the loop)
     int finished = 0;  // packets this lane finished in this round
 
     // ---- which role this round -----------------------------------------------------------------------
@@ -915,9 +897,10 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
           unsigned long long pid = A.first_packet + (my - n_carry);
           bool fresh = r >= 0;
           if (BIN && r >= 0 && my < n_carry) {
-            const Rec<POLA> Rc = carry_in[my];
-            if ((Rc.flags & ST_MASK) == S_EMIT) pid = ((unsigned long long)Rc.p_hi << 32) | Rc.p_lo;
-            else { recs[r] = Rc; rid = r; st = Rc.flags & ST_MASK; fresh = false; }
+            const Rec<POLA>& Rc = carry_in[my];
+            const int fl_c = Rc.flags;
+            if ((fl_c & ST_MASK) == S_EMIT) pid = ((unsigned long long)Rc.p_hi << 32) | Rc.p_lo;
+            else { rec_copy(&recs[r], &Rc); rid = r; st = fl_c & ST_MASK; fresh = false; }
           }
           if (fresh) {
             rid = r;
@@ -1185,8 +1168,47 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
     }
   }
 
+  if (CARRY && suspended) {
+    // ---- end of a chunk: what this wave holds goes to carry_out (see "Chunks without tails") -----------------
+    const bool held = rid < 0 && st != S_EMIT;   // a packet in registers
+    const bool owned = rid >= 0;                 // a record of this lane's
+    const unsigned long long left = pk_end - pk_next;  // reserved, not started (lane i takes the items pk_next + i + 64 q)
+    const int n_left = (int)((left > (unsigned long long)lane) ? (left - lane + (BIN_WAVE - 1)) / BIN_WAVE : 0ull);
+    const int mine = (held || owned ? 1 : 0) + n_left;
+    int pre = mine;  // inclusive prefix sum over the lanes
+    for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(pre, off); if (lane >= off) pre += t; }
+    const int total = __shfl(pre, 63);
+    unsigned int base = 0u;
+    if (lane == 0 && total > 0) base = atomicAdd(A.carry_out_n, (unsigned int)total);
+    base = __shfl(base, 0);
+    unsigned int at = base + (unsigned int)(pre - mine);
+    if (at + (unsigned int)mine > A.carry_cap) { *A.err = 16; rq_st(&Q->abort_flag, 1); }  // (never: the host sizes it for the worst case)
+    else {
+      if (held) {
+        Rec<POLA>& R = carry_out[at++];
+        R.x = F.x; R.y = F.y; R.z = F.z; R.u = F.u; R.v = F.v; R.w = F.w; R.extr = F.extr; R.S[0] = F.S0;
+        if (POLA) { R.S[POLA ? 1 : 0] = bag_S1; R.S[POLA ? 2 : 0] = bag_S2; R.S[POLA ? 3 : 0] = bag_S3; }
+        R.ri = F.ri; R.zj = F.zj; R.k = F.k; R.lambda = bag_lambda; R.star_key = F.star_key;
+        R.p_lo = bag_plo; R.p_hi = bag_phi; R.event = bag_event; R.pk_cross = F.pk_cross; R.tau_rand = bag_tau;
+        R.flags = st | bag_fl;
+      } else if (owned) {
+        recs[rid].flags = (recs[rid].flags & ~ST_MASK) | st;
+        rec_copy(&carry_out[at++], &recs[rid]);
+      }
+      for (int q = 0; q < n_left; ++q) {
+        const unsigned long long item = pk_next + (unsigned long long)lane + (unsigned long long)BIN_WAVE * q;
+        if (BIN && item < n_carry) rec_copy(&carry_out[at++], &carry_in[item]);
+        else {  // a packet that was never emitted: state S_EMIT, its id in p_lo / p_hi
+          Rec<POLA>& Rc = carry_out[at++];
+          rec_copy(&Rc, static_cast<const Rec<POLA>*>(nullptr));
+          const unsigned long long pid = A.first_packet + (item - n_carry);
+          Rc.p_lo = (uint32_t)pid; Rc.p_hi = (uint32_t)(pid >> 32); Rc.flags = S_EMIT;
+        }
+      }
+    }
+  }
   __syncthreads();
-  if (BIN && carry_out && __syncthreads_or(suspended ? 1 : 0)) {
+  if (CARRY && carry_out && __syncthreads_or(suspended ? 1 : 0)) {
     // the packets that wait in the FLY and SRV rings (nobody pops or pushes any more)
     for (int q = RQ_FLY; q <= RQ_SRV; ++q) {
       const unsigned int h = Q->head[q], t = Q->tail[q];
@@ -1197,7 +1219,7 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
       if (base + n > A.carry_cap) { if (threadIdx.x == 0) *A.err = 16; }
       else
         for (unsigned int i = threadIdx.x; i < n; i += blockDim.x)
-          carry_out[base + i] = recs[rings[q * RQ_CAP + ((h + i) & (RQ_CAP - 1))] & 0xFFFFu];
+          rec_copy(&carry_out[base + i], &recs[rings[q * RQ_CAP + ((h + i) & (RQ_CAP - 1))] & 0xFFFFu]);
       __syncthreads();
     }
   }
@@ -1244,6 +1266,14 @@ __global__ void __launch_bounds__(MCGPU_ROLES_BLOCK) k_thermal_roles(const DevMo
                                                                      int k_short, int fly_iters, int fly_idle, int emit_qmax) {
   extern __shared__ double lds_raw[];
   roles_body<L3D, POLA, DARK, LDSE, MRW>(M, A, lds_raw, n_rec, n_srv_pref, k_short, fly_iters, fly_idle, emit_qmax);
+}
+
+// the same, handing its last packets to the tail kernel (mc_tail.hip.h); 2D grids (the 3D kernel below has it built in)
+template <bool POLA, bool DARK, bool LDSE, bool MRW>
+__global__ void __launch_bounds__(MCGPU_ROLES_BLOCK) k_thermal_roles_tail(const DevModel M, const RunArgs A, int n_rec, int n_srv_pref,
+                                                                          int k_short, int fly_iters, int fly_idle, int emit_qmax) {
+  extern __shared__ double lds_raw[];
+  roles_body<false, POLA, DARK, LDSE, MRW, false, false, true>(M, A, lds_raw, n_rec, n_srv_pref, k_short, fly_iters, fly_idle, emit_qmax);
 }
 
 // the same with binned deposits (3D grids: the absorbed-energy array does not fit in LDS)

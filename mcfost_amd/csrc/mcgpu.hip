@@ -22,6 +22,7 @@
 #include "mc_raytrace.hip.h"
 #include "mc_roles.hip.h"
 #include "mc_binned.hip.h"
+#include "mc_tail.hip.h"
 
 using namespace mcgpu;
 
@@ -38,6 +39,7 @@ static int tune(const char* name, int dflt, int lo, int hi) {
 
 constexpr int WORK_SLOT = 12;  // where the kernels' work counter lives in d_counters
 static_assert(MCGPU_N_COUNTERS <= WORK_SLOT, "counter buffer layout");
+static_assert(MCGPU_N_COUNTERS == TAIL_N_COUNTERS, "mc_tail.hip.h counts the same events");
 
 struct mcgpu_ctx {
   int device = 0;
@@ -56,6 +58,12 @@ struct mcgpu_ctx {
   // mcgpu_set_option
   int opt_deposit = 0;      // 0 = automatic, 1 = HBM atomics, 2 = LDS-private grid / deposit cache, 3 = binned deposits
   int opt_log_mb = 0;       // binned deposits: size of the log in MiB (0 = automatic)
+  int opt_tail = -1;        // role kernels hand their last packets to the tail kernel (mc_tail.hip.h) once a workgroup has this
+                            // many left; 0: never; -1 (default): automatic -- 48 where packets get trapped (see tail_threshold())
+  std::vector<double> h_r_lim;     // host copy of r_lim (cylindrical grids): the optical-thickness estimate below
+  double tau_midplane = -1.0;      // radial optical depth of the midplane at the most opaque wavelength (-1: unknown)
+  double last_inter_pp = -1.0;     // interactions per packet of the context's last completed thermal launch (-1: none yet)
+  unsigned int* d_tail_next = nullptr;  // the tail kernel's work counter
   // binned deposits (mc_binned.hip.h): the log and its plan
   BinLog bin{};
   unsigned int *d_bin_off = nullptr, *d_bin_cap = nullptr;
@@ -110,6 +118,7 @@ struct mcgpu_ctx {
 };
 
 static void bin_release(mcgpu_ctx* ctx);
+static int tail_threshold(const mcgpu_ctx* ctx);
 
 #define HIPCHK(call)                                                              \
   do {                                                                            \
@@ -231,6 +240,9 @@ extern "C" int mcgpu_set_grid_cyl(mcgpu_ctx* ctx, int n_rad, int nz, int n_az, i
   HIPCHK(hipSetDevice(ctx->device));
   const int n_cells = l3D ? 2 * n_rad * nz * n_az : n_rad * nz;
   const int jlo = l3D ? -nz - 1 : 0;
+  ctx->h_r_lim.resize((size_t)n_rad + 1);
+  for (int i = 0; i <= n_rad; ++i) ctx->h_r_lim[i] = std::sqrt(r_lim_2[i]);
+  ctx->tau_midplane = -1.0; ctx->last_inter_pp = -1.0;
   const int jn = nz + 1 - jlo + 1;
   const int ntot2 = l3D ? (n_rad + 2) * (2 * nz + 2) * n_az : (n_rad + 2) * (nz + 2) * n_az;
   // verify the closed-form mapping against the host's arrays
@@ -427,7 +439,9 @@ static void bin_release(mcgpu_ctx* ctx) {
   ctx->d_bin_want = nullptr;
   for (int i = 0; i < 2; ++i) { if (ctx->d_carry[i]) hipFree(ctx->d_carry[i]); ctx->d_carry[i] = nullptr; }
   if (ctx->d_carry_n) hipFree(ctx->d_carry_n);
+  if (ctx->d_tail_next) hipFree(ctx->d_tail_next);
   ctx->d_carry_n = nullptr;
+  ctx->d_tail_next = nullptr;
   ctx->carry_cap = 0;
   ctx->bin = BinLog{};
   ctx->d_bin_off = ctx->d_bin_cap = nullptr;
@@ -438,6 +452,7 @@ static void bin_release(mcgpu_ctx* ctx) {
 extern "C" int mcgpu_set_option(mcgpu_ctx* ctx, const char* name, int value) {
   if (!ctx || !name) return MCGPU_ERR_ARG;
   if (!strcmp(name, "deposit")) { if (value < 0 || value > 3) return fail(ctx, MCGPU_ERR_ARG, "deposit: 0, 1, 2 or 3"); ctx->opt_deposit = value; }
+  else if (!strcmp(name, "tail")) { if (value < -1 || value > (1 << 20)) return fail(ctx, MCGPU_ERR_ARG, "tail: -1 (automatic), 0 (off), or the packets left per workgroup at the hand-over"); ctx->opt_tail = value; }
   else if (!strcmp(name, "deposit_log_mb")) {
     if (value < 0) return fail(ctx, MCGPU_ERR_ARG, "deposit_log_mb: >= 0");
     if (value != ctx->opt_log_mb) bin_release(ctx);
@@ -458,6 +473,8 @@ extern "C" int mcgpu_get_info(mcgpu_ctx* ctx, const char* name, double* value) {
   else if (!strcmp(name, "bin_log_blocks")) *value = (double)ctx->bin_total_blocks;
   else if (!strcmp(name, "bin_chunks")) *value = ctx->bin_chunks;
   else if (!strcmp(name, "bin_deposits_per_packet")) *value = ctx->bin_dep_per_packet;
+  else if (!strcmp(name, "tail_threshold")) *value = tail_threshold(ctx);
+  else if (!strcmp(name, "tau_midplane")) *value = ctx->tau_midplane;
   else if (!strcmp(name, "bin_overflow_blocks") || !strcmp(name, "bin_drained_records")) {
     unsigned long long st[2] = {0ull, 0ull};
     if (ctx->bin.stats) {
@@ -531,6 +548,17 @@ extern "C" int mcgpu_set_opacity(mcgpu_ctx* ctx, int n_lambda, const double* kap
   if ((rc = upload(ctx, kappa, (size_t)n_lambda, &M.kappa))) return rc;
   if ((rc = upload(ctx, kappa_abs_LTE, (size_t)n_lambda, &M.kappa_abs))) return rc;
   if ((rc = upload(ctx, tab_albedo_pos, (size_t)n_lambda, &M.albedo))) return rc;
+  ctx->tau_midplane = -1.0; ctx->last_inter_pp = -1.0;
+  if (!ctx->voro && !M.grid_sph && (int)ctx->h_r_lim.size() == M.n_rad + 1) {
+    // radial optical depth through the first layer above the midplane (cells (i, j = 1, k = 1)) at the most opaque wavelength
+    double kmax = 0.0, tau = 0.0;
+    for (int l = 0; l < n_lambda; ++l) kmax = kappa[l] > kmax ? kappa[l] : kmax;
+    for (int i = 0; i < M.n_rad; ++i) {
+      const size_t ic = M.l3D ? (size_t)i + (size_t)M.n_rad * (size_t)M.nz : (size_t)i;   // (3D: j = +1 is row nz of k = 1)
+      tau += kmax * kappa_factor[ic] * (ctx->h_r_lim[i + 1] - ctx->h_r_lim[i]);
+    }
+    ctx->tau_midplane = tau;
+  }
   {  // one extra entry, 0: the factor of "no cell" (the 2D crossing reads it for the virtual cells, mc_roles.hip.h)
     std::vector<double> kfp((size_t)M.n_cells + 1, 0.0);
     std::memcpy(kfp.data(), kappa_factor, (size_t)M.n_cells * sizeof(double));
@@ -846,6 +874,53 @@ static hipError_t launch_k(const DevModel& M, const RunArgs& A, int blocks, int 
   return hipGetLastError();
 }
 
+// The hand-over threshold of this launch.  The kernels that can hand packets over run their bulk ~8 % slower (more
+// spilled registers: 160 against 116 bytes of scratch on the Pascucci instance), and the tail kernel only pays where
+// packets get trapped: Pascucci's launch has no tail at all (T(N) linear through 5 ms), ref4.1's has 73 ms, a thick
+// disk's seconds.  Automatic: what the context's last launch showed (at least one interaction per packet), else --
+// first launch -- the radial optical depth of the midplane at the most opaque wavelength (> 1000).
+static int tail_threshold(const mcgpu_ctx* ctx) {
+  if (ctx->opt_tail >= 0) return ctx->opt_tail;
+  if (ctx->last_inter_pp >= 0.0) return ctx->last_inter_pp >= 1.0 ? 48 : 0;
+  return ctx->tau_midplane > 1000.0 ? 48 : 0;
+}
+
+// the record buffers a role kernel hands unfinished packets over in (chunks of a binned run: two, used in turns; the
+// tail kernel: one): per workgroup its records, a packet per lane and a batch of work items per wave
+static int carry_prepare(mcgpu_ctx* ctx, int n_wg, int n_rec, int threads) {
+  const size_t cap = (size_t)n_wg * ((size_t)n_rec + threads + (size_t)(threads / 64) * PK_BATCH);
+  if (ctx->carry_cap < cap || !ctx->d_carry[0]) {
+    for (int i = 0; i < 2; ++i) { if (ctx->d_carry[i]) hipFree(ctx->d_carry[i]); ctx->d_carry[i] = nullptr; }
+    for (int i = 0; i < 2; ++i) HIPCHK(hipMalloc(&ctx->d_carry[i], cap * sizeof(Rec<true>)));
+    ctx->carry_cap = cap;
+  }
+  if (!ctx->d_carry_n) HIPCHK(hipMalloc((void**)&ctx->d_carry_n, 2 * sizeof(unsigned int)));
+  if (!ctx->d_tail_next) HIPCHK(hipMalloc((void**)&ctx->d_tail_next, sizeof(unsigned int)));
+  return MCGPU_OK;
+}
+
+// k_tail (mc_tail.hip.h) on the packets in `carry`: one packet per wave, as many 256-thread workgroups as the tables'
+// LDS footprint lets reside
+static int launch_tail(mcgpu_ctx* ctx, const RunArgs& A, const void* carry, const unsigned int* carry_n, bool l3d, bool mrw) {
+  const DevModel& M = ctx->M;
+  const bool pola = ctx->lsepar_pola != 0, dark = M.dark != nullptr;
+  const size_t lds = (lds_bytes(M) + 7) / 8 * 8;
+  int per_cu = (int)((160 * 1024 - 512) / (lds ? lds : 1));
+  if (per_cu < 1) per_cu = 1;
+  if (per_cu > 8) per_cu = 8;
+  const int blocks = ctx->prop.multiProcessorCount * per_cu;
+  const void* fn;
+#define PICKT(a, m) fn = pola ? (dark ? (const void*)k_tail<a, true, true, m> : (const void*)k_tail<a, true, false, m>) \
+                              : (dark ? (const void*)k_tail<a, false, true, m> : (const void*)k_tail<a, false, false, m>)
+  if (l3d) PICKT(true, false); else if (mrw) PICKT(false, true); else PICKT(false, false);
+#undef PICKT
+  HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  HIPCHK(hipMemsetAsync(ctx->d_tail_next, 0, sizeof(unsigned int), ctx->stream));
+  void* args[] = {(void*)&M, (void*)&A, (void*)&carry, (void*)&carry_n, (void*)&ctx->d_tail_next};
+  HIPCHK(hipLaunchKernel(fn, dim3(blocks), dim3(MCGPU_TAIL_BLOCK), args, lds, ctx->stream));
+  return MCGPU_OK;
+}
+
 // the persistent packet kernel of the cylindrical grids (mc_roles.hip.h, mc_device.hip.h)
 static int launch_mega(mcgpu_ctx* ctx, const RunArgs& A, bool use_lds, int grid_blocks, int block_threads) {
   const DevModel& M = ctx->M;
@@ -903,7 +978,10 @@ static int launch_mega(mcgpu_ctx* ctx, const RunArgs& A, bool use_lds, int grid_
     const int rthreads = (block_threads > 0 && block_threads <= MCGPU_ROLES_BLOCK) ? block_threads : MCGPU_ROLES_BLOCK;
     if (rthreads % 64) return fail(ctx, MCGPU_ERR_ARG, "block_threads must be a multiple of 64");
     const size_t lds_t = (lds_k + 7) / 8 * 8;
-    int n_rec = lds_t < lds_cap ? rq_records_that_fit(pola, lds_cap - lds_t) : 0;
+    // (the kernels that hand packets over hold 256 bytes of static LDS: a request of the full 160 KB is refused there)
+    const int tail_thr = tail_threshold(ctx);
+    const size_t lds_cap_r = lds_cap - ((!l3d && tail_thr > 0) ? 512 : 0);
+    int n_rec = lds_t < lds_cap_r ? rq_records_that_fit(pola, lds_cap_r - lds_t) : 0;
     // (more records than twice the lanes buy nothing; small models keep their LDS footprint small)
     if (n_rec > 2 * rthreads) n_rec = 2 * rthreads > RQ_MIN_REC ? 2 * rthreads : RQ_MIN_REC;
     // (the optional radiation-field accumulators are kept by the single-role kernel)
@@ -932,9 +1010,27 @@ static int launch_mega(mcgpu_ctx* ctx, const RunArgs& A, bool use_lds, int grid_
       }
 #undef PICKR
 #undef PICKM
+      // 2D grids: the launch's last packets go to the tail kernel (one packet per wave, mc_tail.hip.h) once a
+      // workgroup has no more than opt_tail of them left
+      RunArgs At = A;
+      const bool tail = !l3d && tail_thr > 0;
+      if (tail) {
+        int rc = carry_prepare(ctx, rblocks, n_rec, rthreads);
+        if (rc) return rc;
+        HIPCHK(hipMemsetAsync(ctx->d_carry_n, 0, 2 * sizeof(unsigned int), ctx->stream));
+        At.carry_out = ctx->d_carry[0]; At.carry_out_n = ctx->d_carry_n; At.carry_cap = (unsigned int)ctx->carry_cap;
+        At.tail_threshold = tail_thr;
+#define PICKRT(b, c, m) fn = use_lds ? (const void*)k_thermal_roles_tail<b, c, true, m> : (const void*)k_thermal_roles_tail<b, c, false, m>
+        if (M.mrw) { if (pola) { if (dark) PICKRT(true, true, true); else PICKRT(true, false, true); }
+                     else { if (dark) PICKRT(false, true, true); else PICKRT(false, false, true); } }
+        else { if (pola) { if (dark) PICKRT(true, true, false); else PICKRT(true, false, false); }
+               else { if (dark) PICKRT(false, true, false); else PICKRT(false, false, false); } }
+#undef PICKRT
+      }
       HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));
-      void* args[] = {(void*)&M, (void*)&A, (void*)&n_rec, (void*)&n_srv_pref, (void*)&k_short, (void*)&fly_iters, (void*)&fly_idle, (void*)&emit_qmax};
+      void* args[] = {(void*)&M, (void*)&At, (void*)&n_rec, (void*)&n_srv_pref, (void*)&k_short, (void*)&fly_iters, (void*)&fly_idle, (void*)&emit_qmax};
       HIPCHK(hipLaunchKernel(fn, dim3(rblocks), dim3(rthreads), args, lds_r, ctx->stream));
+      if (tail) return launch_tail(ctx, A, ctx->d_carry[0], ctx->d_carry_n, false, M.mrw != 0);
       return MCGPU_OK;
     }
   }
@@ -1139,18 +1235,9 @@ static int launch_binned(mcgpu_ctx* ctx, RunArgs A, const mcgpu_run_opts* o) {
   int n_srv_pref = tune("MCGPU_N_SRV", (rthreads / 64 + 3) / 4, 1, 1016);
   int k_short = tune("MCGPU_K_SHORT", 2, 0, 64), fly_iters = tune("MCGPU_FLY_ITERS", 16, 1, 256);
   int fly_idle = tune("MCGPU_FLY_IDLE", 32, 1, 65), emit_qmax = tune("MCGPU_EMIT_QMAX", 128, 0, 1 << 20);
-  // what a chunk can leave unfinished: per workgroup its records, a packet per lane and a batch of work items per wave
-  {
-    const size_t cap = (size_t)max_parts * ((size_t)n_rec + rthreads + (size_t)(rthreads / 64) * PK_BATCH);
-    const size_t rec_bytes = pola ? sizeof(Rec<true>) : sizeof(Rec<false>);
-    if (ctx->carry_cap < cap || !ctx->d_carry[0]) {
-      for (int i = 0; i < 2; ++i) { if (ctx->d_carry[i]) hipFree(ctx->d_carry[i]); ctx->d_carry[i] = nullptr; }
-      for (int i = 0; i < 2; ++i) HIPCHK(hipMalloc(&ctx->d_carry[i], cap * sizeof(Rec<true>)));
-      if (!ctx->d_carry_n) HIPCHK(hipMalloc((void**)&ctx->d_carry_n, 2 * sizeof(unsigned int)));
-      ctx->carry_cap = cap;
-    }
-    (void)rec_bytes;
-  }
+  if ((rc = carry_prepare(ctx, max_parts, n_rec, rthreads))) return rc;
+  // (the 3D kernel hands packets over anyway -- between chunks --: its last chunk always may; automatic = 48)
+  const int tail_thr = ctx->opt_tail >= 0 ? ctx->opt_tail : 48;
   HIPCHK(hipMemsetAsync(ctx->d_carry_n, 0, 2 * sizeof(unsigned int), ctx->stream));
 
   // chunk sizes: the log holds total_blocks * 64 deposits; a chunk uses at most 60 % of it (the regions carry half as
@@ -1192,15 +1279,23 @@ static int launch_binned(mcgpu_ctx* ctx, RunArgs A, const mcgpu_run_opts* o) {
       // the packets chunk i leaves unfinished are the first work items of chunk i + 1; the last chunk finishes all
       const int in = ctx->bin_chunks & 1, out = in ^ 1;
       const bool last = done + c >= n_total;
+      // (the last chunk hands ITS last packets to the tail kernel instead, once a workgroup has few of them left)
+      const bool to_tail = last && tail_thr > 0;
       A.carry_in = ctx->d_carry[in]; A.carry_in_n = ctx->d_carry_n + in;
-      A.carry_out = last ? nullptr : ctx->d_carry[out]; A.carry_out_n = ctx->d_carry_n + out;
+      A.carry_out = (last && !to_tail) ? nullptr : ctx->d_carry[out]; A.carry_out_n = ctx->d_carry_n + out;
       A.carry_cap = (unsigned int)ctx->carry_cap;
-      if (!last) HIPCHK(hipMemsetAsync(ctx->d_carry_n + out, 0, sizeof(unsigned int), ctx->stream));
+      A.tail_threshold = to_tail ? tail_thr : 0;
+      if (!last || to_tail) HIPCHK(hipMemsetAsync(ctx->d_carry_n + out, 0, sizeof(unsigned int), ctx->stream));
     }
     void* args[] = {(void*)&M, (void*)&A, (void*)&n_rec, (void*)&n_srv_pref, (void*)&k_short, (void*)&fly_iters, (void*)&fly_idle, (void*)&emit_qmax};
     HIPCHK(hipLaunchKernel(fn, dim3(rblocks), dim3(rthreads), args, lds_r, ctx->stream));
     hipLaunchKernelGGL(k_fold_bins, dim3(ctx->bin.n_buckets * split), dim3(1024), fold_lds, ctx->stream, A.bin, A.E_abs, M.n_cells, split);
     HIPCHK(hipGetLastError());
+    if (done + c >= n_total && tail_thr > 0) {  // behind the fold: E_abs is complete but for these packets' own deposits
+      RunArgs At = A;
+      At.n_folded = 0.0;
+      if ((rc = launch_tail(ctx, At, A.carry_out, A.carry_out_n, true, false))) return rc;
+    }
     done += c;
     last_chunk = c;
     last_parts = rblocks;
@@ -1306,10 +1401,13 @@ extern "C" int mcgpu_sync(mcgpu_ctx* ctx, double* kernel_ms) {
       *kernel_ms = ms;
     }
   }
-  if (ctx->launched && ctx->bin.keys && ctx->d_counters) {  // what the next binned launch sizes its chunks with
-    unsigned long long c[2] = {0ull, 0ull};
+  if (ctx->launched && ctx->d_counters) {  // what the next launch plans with: chunk sizes (binned), the tail hand-over
+    unsigned long long c[5] = {0ull, 0ull, 0ull, 0ull, 0ull};
     HIPCHK(hipMemcpy(c, ctx->d_counters, sizeof(c), hipMemcpyDeviceToHost));
-    if (c[0] > 1000ull) ctx->bin_dep_per_packet = (double)c[1] / (double)c[0];
+    if (c[0] > 1000ull) {
+      if (ctx->bin.keys) ctx->bin_dep_per_packet = (double)c[1] / (double)c[0];
+      ctx->last_inter_pp = (double)(c[3] + c[4]) / (double)c[0];
+    }
   }
   int herr = 0;
   HIPCHK(hipMemcpy(&herr, ctx->d_err, sizeof(int), hipMemcpyDeviceToHost));

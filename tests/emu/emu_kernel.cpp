@@ -81,6 +81,7 @@ namespace mcgpu { double lds_raw[1 << 18]; }
 #include "../../mcfost_amd/csrc/mc_mono_voronoi.hip.h"
 #include "../../mcfost_amd/csrc/mc_raytrace.hip.h"
 #include "../../mcfost_amd/csrc/mc_roles.hip.h"
+#include "../../mcfost_amd/csrc/mc_tail.hip.h"
 #include "../../oracle/mc_oracle.h"
 
 using namespace mcgpu;
@@ -268,8 +269,8 @@ extern "C" int emu_run_thermal(const oracle_model* m, const oracle_opts* o, cons
     // <n_srv_pref>,<k_short>,<fly_iters>".  Every chunk but the last hands its unfinished packets on (carry_*).
     if (!l3d || M.mrw || M.n_classes) return 31;
     long chunk = 1000, log_blocks = 64;
-    int nsp = 1, ks = 2, fi = 3;
-    sscanf(getenv("MCGPU_EMU_BIN"), "%ld,%ld,%d,%d,%d", &chunk, &log_blocks, &nsp, &ks, &fi);
+    int nsp = 1, ks = 2, fi = 3, tail_thr = 0;   // tail_thr > 0: the last chunk hands its last packets to k_tail
+    sscanf(getenv("MCGPU_EMU_BIN"), "%ld,%ld,%d,%d,%d,%d", &chunk, &log_blocks, &nsp, &ks, &fi, &tail_thr);
     int shift = 6;
     while (shift < 14 && ((m->n_cells + (1 << shift) - 1) >> shift) > 24) ++shift;
     const int nb = (m->n_cells + (1 << shift) - 1) >> shift;
@@ -299,14 +300,25 @@ extern "C" int emu_run_thermal(const oracle_model* m, const oracle_opts* o, cons
       const int in = ichunk & 1, out = in ^ 1;
       const bool fin = done + c >= n_total;
       A.carry_in = carry[in].data(); A.carry_in_n = &carry_n[in];
-      A.carry_out = fin ? nullptr : carry[out].data(); A.carry_out_n = &carry_n[out];
+      const bool to_tail = fin && tail_thr > 0;
+      A.carry_out = (fin && !to_tail) ? nullptr : carry[out].data(); A.carry_out_n = &carry_n[out];
       A.carry_cap = (unsigned int)carry_cap;
+      A.tail_threshold = to_tail ? tail_thr : 0;
       carry_n[out] = 0u;
       if (pola) { if (dark) k_thermal_roles_bin<true, true>(M, A, n_rec, nsp, ks, fi, 65, 128); else k_thermal_roles_bin<true, false>(M, A, n_rec, nsp, ks, fi, 65, 128); }
       else { if (dark) k_thermal_roles_bin<false, true>(M, A, n_rec, nsp, ks, fi, 65, 128); else k_thermal_roles_bin<false, false>(M, A, n_rec, nsp, ks, fi, 65, 128); }
       if (err) return err;
       for (int b = 0; b < nb; ++b) { blockIdx.x = (unsigned)b; k_fold_bins(L, E_abs, m->n_cells, 1); }
       blockIdx.x = 0;
+      if (to_tail) {
+        unsigned int next = 0u;
+        RunArgs At = A;
+        At.n_folded = 0.0;
+        if (pola) { if (dark) k_tail<true, true, true, false>(M, At, carry[out].data(), &carry_n[out], &next); else k_tail<true, true, false, false>(M, At, carry[out].data(), &carry_n[out], &next); }
+        else { if (dark) k_tail<true, false, true, false>(M, At, carry[out].data(), &carry_n[out], &next); else k_tail<true, false, false, false>(M, At, carry[out].data(), &carry_n[out], &next); }
+        if (err) return err;
+        if (getenv("MCGPU_EMU_BIN_STATS")) fprintf(stderr, "tail: %u packets\n", carry_n[out]);
+      }
       done += c; last = c; ++ichunk;
     }
     for (int q = 0; q < ORACLE_N_COUNTERS; ++q) counters[q] = cnt[q];
@@ -322,6 +334,22 @@ extern "C" int emu_run_thermal(const oracle_model* m, const oracle_opts* o, cons
     const int n_rec = RQ_MIN_REC;
     if (lds_bytes(M) + sizeof(double) * m->n_cells + rq_lds_bytes(true, n_rec) + 64 > sizeof(lds_raw)) return 31;
     A.flush_every = 4;
+    if (getenv("MCGPU_EMU_TAIL") && !l3d) {   // the role kernel hands its last packets to k_tail (mc_tail.hip.h)
+      const size_t carry_cap = (size_t)n_rec + 1 + PK_BATCH;
+      std::vector<Rec<true>> carry(carry_cap);
+      unsigned int carry_n = 0u, next = 0u;
+      RunArgs Ar = A;
+      Ar.carry_out = carry.data(); Ar.carry_out_n = &carry_n; Ar.carry_cap = (unsigned int)carry_cap;
+      Ar.tail_threshold = atoi(getenv("MCGPU_EMU_TAIL"));
+#define RUNT(b, c, mm) do { if (ld) k_thermal_roles_tail<b, c, true, mm>(M, Ar, n_rec, nsp, ks, fi, 65, eq); else k_thermal_roles_tail<b, c, false, mm>(M, Ar, n_rec, nsp, ks, fi, 65, eq); \
+                            if (!err) k_tail<false, b, c, mm>(M, A, carry.data(), &carry_n, &next); } while (0)
+      if (M.mrw) { if (pola) { if (dark) RUNT(true, true, true); else RUNT(true, false, true); } else { if (dark) RUNT(false, true, true); else RUNT(false, false, true); } }
+      else { if (pola) { if (dark) RUNT(true, true, false); else RUNT(true, false, false); } else { if (dark) RUNT(false, true, false); else RUNT(false, false, false); } }
+#undef RUNT
+      if (getenv("MCGPU_EMU_BIN_STATS")) fprintf(stderr, "tail: %u packets\n", carry_n);
+      for (int q = 0; q < ORACLE_N_COUNTERS; ++q) counters[q] = cnt[q];
+      return err;
+    }
 #define RUNR(a, b, c) do { if (ld) k_thermal_roles<a, b, c, true>(M, A, n_rec, nsp, ks, fi, 65, eq); else k_thermal_roles<a, b, c, false>(M, A, n_rec, nsp, ks, fi, 65, eq); } while (0)
 #define RUNRM(b, c) do { if (ld) k_thermal_roles<false, b, c, true, true>(M, A, n_rec, nsp, ks, fi, 65, eq); else k_thermal_roles<false, b, c, false, true>(M, A, n_rec, nsp, ks, fi, 65, eq); } while (0)
     if (M.mrw) {

@@ -98,3 +98,40 @@ def test_binned_live_mode_gives_the_temperature_of_the_atomic_path():
     assert ok, p75
     # no systematic offset beyond the noise of the mean
     assert abs(np.mean(T[3][sel] / T[1][sel]) - 1.0) < 0.01
+
+
+def test_tail_kernel_frozen_parity_and_the_automatic_threshold():
+    """mc_tail.hip.h through the C-ABI: a role kernel that hands its last packets -- or, with a huge threshold, every
+    packet the moment the work counter runs out -- to the tail kernel returns the oracle's counters and sums, on 2D
+    (LDS grid; dark zone; HG), 3D (binned deposits) and with the random walk; option "tail" = -1 picks the threshold
+    from the model's optical thickness (first launch) and from the last launch's interactions per packet."""
+    import copy
+    small = M.build_model(M.small())
+    md = copy.copy(small)
+    dz = np.zeros(md.n_cells, np.uint8)
+    kf = md.kappa_factor.copy()
+    kf[::md.cfg.n_rad] = 0.0
+    dz[np.argsort(kf)[-40:]] = 1
+    md.l_dark_zone = dz
+    models = [small, md, M.build_model(M.small(aniso_method=2, lsepar_pola=False)),
+              M.build_model(M.small(n_rad=12, nz=6, n_az=8, l3D=True))]
+    n = 30000
+    for m in models:
+        o = _oracle(m, n)
+        prior = o.run_thermal(2000, seed=1)["E_abs"]
+        b = o.run_thermal(n, seed=17, frozen=True, E_prior=prior, n_threads=8)
+        for thr in (0, 40, 100000):
+            e = _engine(m, n)
+            e.set_option("tail", thr)
+            a = e.run_thermal(n, seed=17, frozen=True, E_prior=prior)
+            e.close()
+            _same_packets(a, b)
+    # the automatic choice
+    e = _engine(M.build_model(M.pascucci()), 1e6)
+    assert e.get_info("tail_threshold") == 0            # thin: no hand-over (its launch has no tail; DESIGN.md section 7)
+    e.close()
+    e = _engine(M.build_model(M.ref41()), 1e6)
+    assert e.get_info("tau_midplane") > 1000 and e.get_info("tail_threshold") == 48
+    e.run_thermal(200000, seed=1)
+    assert e.get_info("tail_threshold") == 48           # ... confirmed by the launch: ~11 interactions per packet
+    e.close()

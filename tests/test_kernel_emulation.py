@@ -29,11 +29,12 @@ DEV4 = os.path.join(os.path.dirname(HERE), "mcfost_amd", "csrc", "mc_mono.hip.h"
 DEV5 = os.path.join(os.path.dirname(HERE), "mcfost_amd", "csrc", "mc_roles.hip.h")
 DEV6 = os.path.join(os.path.dirname(HERE), "mcfost_amd", "csrc", "mc_raytrace.hip.h")
 DEV7 = os.path.join(os.path.dirname(HERE), "mcfost_amd", "csrc", "mc_binned.hip.h")
+DEV8 = os.path.join(os.path.dirname(HERE), "mcfost_amd", "csrc", "mc_tail.hip.h")
 
 
 @pytest.fixture(scope="module")
 def emu():
-    if (not os.path.exists(LIB)) or os.path.getmtime(LIB) < max(os.path.getmtime(SRC), os.path.getmtime(DEV), os.path.getmtime(DEV2), os.path.getmtime(DEV3), os.path.getmtime(DEV4), os.path.getmtime(DEV5), os.path.getmtime(DEV6), os.path.getmtime(DEV7)):
+    if (not os.path.exists(LIB)) or os.path.getmtime(LIB) < max(os.path.getmtime(SRC), os.path.getmtime(DEV), os.path.getmtime(DEV2), os.path.getmtime(DEV3), os.path.getmtime(DEV4), os.path.getmtime(DEV5), os.path.getmtime(DEV6), os.path.getmtime(DEV7), os.path.getmtime(DEV8)):
         fma = ["-mfma"] if "fma" in open("/proc/cpuinfo").read() else []
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=fast"] + fma +
                               ["-o", LIB, SRC])
@@ -417,6 +418,40 @@ def test_emulated_binned_deposits_and_chunks_without_tails(emu):
             check(emu, mh, 2000, 10)
         finally:
             os.environ.pop("MCGPU_EMU_BIN", None)
+
+
+def test_emulated_tail_kernel(emu, small_model):
+    """mc_tail.hip.h on one lane: the role kernel hands its last packets over (MCGPU_EMU_TAIL = packets left per
+    workgroup at which it does; 3D: sixth field of MCGPU_EMU_BIN, on the last chunk) and k_tail finishes them -- the
+    draws of an interaction taken from the batch drawn ahead, the table searches as wave-parallel probes, emission of
+    work items that were reserved but never started.  With a threshold larger than the packet count EVERY packet runs
+    through the tail kernel from its emission on.  Same packets, same sums as the oracle."""
+    md = copy.copy(small_model)   # dark zone
+    dz = np.zeros(md.n_cells, np.uint8)
+    kf = md.kappa_factor.copy()
+    kf[::md.cfg.n_rad] = 0.0
+    dz[np.argsort(kf)[-40:]] = 1
+    md.l_dark_zone = dz
+    try:
+        for thr, roles in (("40", "1,2,3,128"), ("100000", "1,2,3,128"), ("25", "0,1,64,4")):
+            os.environ["MCGPU_EMU_TAIL"], os.environ["MCGPU_EMU_ROLES"] = thr, roles
+            check(emu, small_model, 3000, 7)
+            os.environ["MCGPU_EMU_LDS"] = "1"
+            check(emu, small_model, 3000, 7)
+            del os.environ["MCGPU_EMU_LDS"]
+            check(emu, M.build_model(M.small(aniso_method=2, lsepar_pola=False)), 2000, 10)
+            check(emu, M.build_model(M.small(lisotropic=True, lsepar_pola=False)), 2000, 11)
+            a, b = check(emu, md, 3000, 12)
+            assert a["counters"][7] > 0
+            check(emu, _with_ism(small_model), 2000, 31, rtol=1e-6)
+        os.environ.pop("MCGPU_EMU_TAIL"); os.environ.pop("MCGPU_EMU_ROLES")
+        m3 = M.build_model(M.small(n_rad=12, nz=6, n_az=8, l3D=True))
+        for cfg in ("100000,4096,1,2,3,50", "300,4096,1,2,3,100000", "97,64,0,2,3,30"):
+            os.environ["MCGPU_EMU_BIN"] = cfg
+            check(emu, m3, 3000, 8)
+    finally:
+        for k in ("MCGPU_EMU_TAIL", "MCGPU_EMU_ROLES", "MCGPU_EMU_LDS", "MCGPU_EMU_BIN"):
+            os.environ.pop(k, None)
 
 
 def emu_dust_map(emu, orc, lam, xI, Tdust, n_sent, E_disk, ang_disque=0.0, l_sym_ima=True, tau_obs=100.0):
