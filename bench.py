@@ -419,7 +419,10 @@ def main():
                     help="--config voronoi: number of SPH-like sites of the tessellation (BASELINE config 5 stand-in)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sed-observers", type=int, default=0, help="--config sed: RT_n_incl (default: the configuration's)")
-    ap.add_argument("--xI-precision", type=int, default=8, choices=[4, 8], help="--config sed: mcgpu_set_xI_precision")
+    ap.add_argument("--xI-precision", type=int, default=4, choices=[4, 8],
+                    help="--config sed: mcgpu_set_xI_precision -- 4 (default here): xI_scatt accumulated in default real, the type of "
+                         "the reference's own array (dust_ray_tracing.f90:33), two observers per 64-byte line; 8: FP64 sums "
+                         "(the library's default)")
     ap.add_argument("--var-identical", action="store_true", help="--config ref41_var: every class gets the model's own tables "
                     "(the physics of --config ref41 through the HBM-gather kernel)")
     ap.add_argument("--mrw-gamma", type=float, default=2.0, help="--config ref41_mrw: gamma_MRW")
