@@ -521,6 +521,47 @@ int mcgpu_init_reemission(mcgpu_ctx *ctx, const double *tab_lambda, const double
                           double *log_Qcool, double *kdB_dT_CDF);
 
 /*
+ * opacity + calc_local_scattering_matrices on the device (dust_prop.f90:791-1033 and 1037-1243):
+ * the opacities and scattering tables of every cell class from the grains' cross sections and Mueller matrices and
+ * the local grain densities, for every wavelength (p_lambda = lambda) -- with lvariable_dust the sums over the grain
+ * sizes run once per cell, and the tables (253 MB per Mueller element at 7000 classes, mem.f90:213-244) never cross
+ * the bus: they are built where the kernels read them and become the context's per-class tables exactly as if
+ * mcgpu_set_variable_dust had been called (the re-emission tables of the classes are left to mcgpu_init_reemission).
+ *   kappa(p, lambda)          = sum_k C_ext(k, lambda) n(k, p) * AU_to_cm mum_to_cm^2,  n(k, p) = dust_density_o_n_grains(k, p) n_grains(k)
+ *   tab_albedo_pos            = sum_k C_sca n / sum_k C_ext n;   kappa_abs_LTE over the grains grain_RE_LTE_start..end
+ *   tab_g_pos                 (aniso_method 2) the C_sca-weighted mean of tab_g
+ *   tab_s11_pos(0:nang, p, l) (aniso_method 1) sum_k tab_s11(:, k, l) S_grain(k) n(k, p); likewise S12 .. S44 (lsepar_pola),
+ *                             then prob_s11_pos = the running sum of s11 sin(theta) dtheta with the unresolved forward peak in
+ *                             bin 1, normalised (:1141-1154); S1x / S11; s11 dtheta / (2 pi k_sca) for the ray tracer (:1172);
+ *                             aniso_method 2: the Henyey-Greenstein phase function (:1190-1194)
+ * in the reference's types: default-real tables are rounded after every term.  aniso_method, lsepar_pola, nang,
+ * p_lambda_fixed are the context's (mcgpu_set_scattering).  Not built: scattering_method 1 (ksca_CDF), the non-LTE /
+ * non-equilibrium grain tables, lphase_function_file, loverwrite_s12, lno_scattering, lqsca_equal_qabs.
+ * The grains' tables, all default real, in the reference's layouts (grains.f90:38-54, mem.f90:71-84):
+ */
+typedef struct mcgpu_grain_tables {
+  int n_grains;                            /* n_grains_tot */
+  int grain_RE_LTE_start, grain_RE_LTE_end;/* 1-based range of the grains in radiative equilibrium and LTE */
+  const float *C_ext, *C_sca, *C_abs;      /* (n_grains, n_lambda) */
+  const float *tab_g;                      /* (n_grains, n_lambda); aniso_method 2 only */
+  const float *tab_s11, *tab_s12, *tab_s22, *tab_s33, *tab_s34, *tab_s44; /* (0:nang, n_grains, n_lambda); aniso_method 1 (s12..: lsepar_pola) */
+  const float *S_grain;                    /* (n_grains) geometric cross sections */
+  const double *n_grains_k;                /* (n_grains) n_grains(k), relative number of grains per size bin */
+} mcgpu_grain_tables;
+/* Copies of the result in the reference's layouts, any pointer may be NULL: (p_n_cells, n_lambda) and
+ * (0:nang, p_n_cells, n_lambda) (prob_s11_pos: one wavelength column when p_lambda_fixed). */
+typedef struct mcgpu_opacity_tables {
+  double *kappa, *kappa_abs_LTE;
+  float *tab_albedo_pos, *tab_g_pos;
+  float *tab_s11_pos, *prob_s11_pos;
+  float *tab_s12_o_s11_pos, *tab_s22_o_s11_pos, *tab_s33_o_s11_pos, *tab_s34_o_s11_pos, *tab_s44_o_s11_pos;
+} mcgpu_opacity_tables;
+/* p_icell[n_cells]: 1-based class of every cell (the identity when every cell has its own dust);
+ * dust_density_o_n_grains (n_grains, p_n_cells), double (density.f90:32).  `out` may be NULL. */
+int mcgpu_opacity(mcgpu_ctx *ctx, const mcgpu_grain_tables *grains, int p_n_cells, const int *p_icell,
+                  const double *dust_density_o_n_grains, const mcgpu_opacity_tables *out);
+
+/*
  * The optional accumulators of save_radiation_field's thermal branch (radiation_field.f90:54-55):
  *   xN_abs[n_cells]             path segments per cell (xN_abs(icell,1,id) with lmcfost_lib: what run_mcfost_phantom
  *                               returns, mcfost2phantom.f90:361), summed over "threads"

@@ -148,6 +148,7 @@ struct DevModel {
   int v_scatt;
   const float* v_prob;       // [n_classes][p_lambda_fixed ? 1 : n_lambda][nang+1]
   const float* v_g;          // [n_classes][n_lambda]
+  const float* v_s11;        // [n_classes][n_lambda][nang+1]: tab_s11_pos (the ray tracer's phase function; mcgpu_opacity builds it)
   const float* v_s12;        // [n_classes][n_lambda][nang+1], likewise v_s22 ... v_s44
   const float* v_s22;
   const float* v_s33;

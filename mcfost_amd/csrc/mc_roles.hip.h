@@ -702,6 +702,7 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
   int idle_spins = 0, last_beat = 0;
   RQ_DIAG(unsigned int d_fly_iters = 0, d_srv_iters = 0, d_fly_cross = 0, d_srv_rounds = 0, d_fly_rounds = 0;)
   RQ_DIAG(unsigned int d_srv_lanes = 0, d_srv_int = 0, d_emit = 0;)
+  RQ_DIAG(unsigned int d_emit_rounds = 0, d_exit_rounds = 0, d_exit = 0, d_int_rounds = 0, d_first_rounds = 0, d_first = 0;)
 
   for (int ep = 0;; ++ep) {
     const int stop_flag = rq_ld(&Q->abort_flag);   // 1: error, 2 (CARRY): hand the packets over
@@ -902,6 +903,7 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
             if ((fl_c & ST_MASK) == S_EMIT) pid = ((unsigned long long)Rc.p_hi << 32) | Rc.p_lo;
             else { rec_copy(&recs[r], &Rc); rid = r; st = fl_c & ST_MASK; fresh = false; }
           }
+          RQ_DIAG(if (lane == 0 && __ballot(fresh) != 0ull) d_emit_rounds++;)
           if (fresh) {
             rid = r;
             Rec<POLA>& R = recs[rid];
@@ -973,6 +975,7 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
         float rand2 = 0.0f;
         bool scat = false;
         const bool inter = rid >= 0 && st == S_INTERACT;
+        RQ_DIAG(if (lane == 0 && __ballot(inter) != 0ull) d_int_rounds++;)
         if (inter) {
           Rec<POLA>& R = recs[rid];
           Rng rng;
@@ -1075,6 +1078,7 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
         // ---- the first crossings of every flight ----------------------------------------------------------
         if (__ballot(rid >= 0 && st == S_FLIGHT) != 0ull) {
           const bool fly = rid >= 0 && st == S_FLIGHT;
+          RQ_DIAG(if (lane == 0) d_first_rounds++; if (fly) d_first++;)
           Rec<POLA>& R = recs[fly ? rid : 0];
           flight_clear(F);
           F.st = fly ? S_FLIGHT : S_EMIT;
@@ -1112,7 +1116,9 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
         }
         RQ_PHASE_END();
         // ---- packets that left the grid: capteur (output.f90:294-597) --------------------------------------
+        RQ_DIAG(if (lane == 0 && __ballot(rid >= 0 && st == S_EXITED) != 0ull) d_exit_rounds++;)
         if (rid >= 0 && st == S_EXITED) {
+          RQ_DIAG(d_exit++;)
           const Rec<POLA>& R = recs[rid];
           const int fl = R.flags;
           if (!(fl & ST_ISM) ) {  // ISM packets that were never absorbed are not binned (dust_transfer.f90:549)
@@ -1242,6 +1248,10 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
   cs[0] = d_srv_lanes; cs[1] = d_srv_int; cs[6] = d_emit; cs[3] = d_fly_cross;  // lanes, summed over rounds
   cs[2] = d_srv_rounds; cs[5] = d_fly_rounds;                                   // rounds
   cs[4] = d_srv_iters; cs[7] = d_fly_iters;                                     // crossing iterations
+#if MCGPU_COUNT_ITERS == 2  // ... or the serving phases': rounds in which a phase ran, lanes it ran for
+  cs[0] = d_emit_rounds; cs[1] = d_emit; cs[2] = d_exit_rounds; cs[3] = d_exit; cs[4] = d_int_rounds; cs[5] = d_srv_int;
+  cs[6] = d_first_rounds; cs[7] = d_first;
+#endif
 #endif
 #pragma unroll
   for (int q = 0; q < 8; ++q) {

@@ -23,6 +23,7 @@
 #include "mc_roles.hip.h"
 #include "mc_binned.hip.h"
 #include "mc_tail.hip.h"
+#include "mc_opacity.hip.h"
 
 using namespace mcgpu;
 
@@ -54,6 +55,7 @@ struct mcgpu_ctx {
   bool reemission_pending = false;  // set_thermal / set_variable_dust left the LTE tables to mcgpu_init_reemission
   bool pending_single = false, pending_classes = false;  // ... which of the two sets
   int lsepar_pola = 0;
+  std::vector<void*> opacity_allocs;  // the per-class tables mcgpu_opacity built (freed by the next call)
   float T_min = 1.0f;
   // mcgpu_set_option
   int opt_deposit = 0;      // 0 = automatic, 1 = HBM atomics, 2 = LDS-private grid / deposit cache, 3 = binned deposits
@@ -734,6 +736,117 @@ extern "C" int mcgpu_set_variable_dust(mcgpu_ctx* ctx, int p_n_cells, const int*
     M.v_scatt = 1;
   }
   M.n_classes = nc;
+  return MCGPU_OK;
+}
+
+// opacity + calc_local_scattering_matrices on the device (dust_prop.f90:791-1243): see include/mcgpu.h
+extern "C" int mcgpu_opacity(mcgpu_ctx* ctx, const mcgpu_grain_tables* G, int p_n_cells, const int* p_icell,
+                             const double* dust_density_o_n_grains, const mcgpu_opacity_tables* out) {
+  if (!ctx || !G || !p_icell || !dust_density_o_n_grains || p_n_cells < 1) return fail(ctx, MCGPU_ERR_ARG, "mcgpu_opacity: bad argument");
+  if (!ctx->have_grid || !ctx->have_opacity || !ctx->have_thermal || !ctx->have_scatt)
+    return fail(ctx, MCGPU_ERR_STATE, "set the grid, the opacities, the scattering and the thermal tables first");
+  DevModel& M = ctx->M;
+  if (ctx->voro || M.grid_sph) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "variable dust: cylindrical grids only");
+  const int ng = G->n_grains, nl = M.n_lambda, nc = p_n_cells, nT = M.n_T, na1 = M.nang + 1;
+  const bool pola = ctx->lsepar_pola != 0, mueller = M.aniso_method == 1;
+  if (ng < 1 || G->grain_RE_LTE_start < 1 || G->grain_RE_LTE_end > ng || !G->C_ext || !G->C_sca || !G->C_abs || !G->S_grain ||
+      !G->n_grains_k || (M.aniso_method == 2 && !G->tab_g) || (mueller && !G->tab_s11) ||
+      (mueller && pola && (!G->tab_s12 || !G->tab_s22 || !G->tab_s33 || !G->tab_s34 || !G->tab_s44)))
+    return fail(ctx, MCGPU_ERR_ARG, "mcgpu_opacity: a grain table is missing");
+  for (int i = 0; i < M.n_cells; ++i)
+    if (p_icell[i] < 1 || p_icell[i] > nc) return fail(ctx, MCGPU_ERR_ARG, "mcgpu_opacity: p_icell out of range");
+  HIPCHK(hipSetDevice(ctx->device));
+  int rc;
+  // the grains' tables: here for the time of the call
+  DevBuf<float> dCe, dCs, dCa, dg, d11, d12, d22, d33, d34, d44, dS;
+  DevBuf<double> dn, dd;
+  auto put = [&](auto& buf, const auto* host, size_t n) -> int {
+    if (!host) return MCGPU_OK;
+    using Tp = std::remove_cv_t<std::remove_pointer_t<decltype(host)>>;
+    HIPCHK(hipMalloc((void**)&buf.p, n * sizeof(Tp)));
+    HIPCHK(hipMemcpyAsync(buf.p, host, n * sizeof(Tp), hipMemcpyHostToDevice, ctx->stream));
+    return MCGPU_OK;
+  };
+  const size_t n_gl = (size_t)ng * nl, n_agl = (size_t)na1 * ng * nl;
+  if ((rc = put(dCe, G->C_ext, n_gl)) || (rc = put(dCs, G->C_sca, n_gl)) || (rc = put(dCa, G->C_abs, n_gl)) ||
+      (rc = put(dg, M.aniso_method == 2 ? G->tab_g : nullptr, n_gl)) || (rc = put(dS, G->S_grain, (size_t)ng)) ||
+      (rc = put(dn, G->n_grains_k, (size_t)ng)) || (rc = put(dd, dust_density_o_n_grains, (size_t)ng * nc)))
+    return rc;
+  if (mueller) {
+    if ((rc = put(d11, G->tab_s11, n_agl))) return rc;
+    if (pola && ((rc = put(d12, G->tab_s12, n_agl)) || (rc = put(d22, G->tab_s22, n_agl)) || (rc = put(d33, G->tab_s33, n_agl)) ||
+                 (rc = put(d34, G->tab_s34, n_agl)) || (rc = put(d44, G->tab_s44, n_agl))))
+      return rc;
+  }
+  // the context's per-class tables (mcgpu_set_variable_dust's): built in place; those of the last call go
+  for (void* q : ctx->opacity_allocs) {
+    for (auto it = ctx->allocs.begin(); it != ctx->allocs.end(); ++it)
+      if (*it == q) { ctx->allocs.erase(it); break; }
+    hipFree(q);
+  }
+  ctx->opacity_allocs.clear();
+  M.n_classes = 0;
+  const size_t allocs_before = ctx->allocs.size();
+  std::vector<int> cls(M.n_cells);
+  for (int i = 0; i < M.n_cells; ++i) cls[i] = p_icell[i] - 1;
+  const int pcols = M.p_lambda_fixed ? 1 : nl;
+  const size_t n_cl = (size_t)nc * nl, n_cla = n_cl * na1;
+  if ((rc = upload(ctx, cls.data(), (size_t)M.n_cells, &M.cell_class))) return rc;
+  if ((rc = upload<double>(ctx, nullptr, 0, &M.v_kappa, n_cl)) || (rc = upload<double>(ctx, nullptr, 0, &M.v_kabs, n_cl)) ||
+      (rc = upload<float>(ctx, nullptr, 0, &M.v_albedo, n_cl)) || (rc = upload<float>(ctx, nullptr, 0, &M.v_g, n_cl)) ||
+      (rc = upload<double>(ctx, nullptr, 0, &M.v_lq, (size_t)nc * nT)) || (rc = upload<double>(ctx, nullptr, 0, &M.v_cdf, (size_t)nc * nT * nl)) ||
+      (rc = upload<float>(ctx, nullptr, 0, &M.v_s11, n_cla)) || (rc = upload<float>(ctx, nullptr, 0, &M.v_prob, (size_t)nc * pcols * na1)) ||
+      (rc = upload<float>(ctx, nullptr, 0, &M.v_s12, n_cla)) || (rc = upload<float>(ctx, nullptr, 0, &M.v_s22, n_cla)) ||
+      (rc = upload<float>(ctx, nullptr, 0, &M.v_s33, n_cla)) || (rc = upload<float>(ctx, nullptr, 0, &M.v_s34, n_cla)) ||
+      (rc = upload<float>(ctx, nullptr, 0, &M.v_s44, n_cla)))
+    return rc;
+  ctx->opacity_allocs.assign(ctx->allocs.begin() + allocs_before, ctx->allocs.end());
+  OpacityIn I{ng, nl, nc, M.nang, M.aniso_method, pola ? 1 : 0, G->grain_RE_LTE_start, G->grain_RE_LTE_end, pcols,
+              dCe.p, dCs.p, dCa.p, dg.p, d11.p, d12.p, d22.p, d33.p, d34.p, d44.p, dS.p, dn.p, dd.p};
+  OpacityOut O{const_cast<double*>(M.v_kappa), const_cast<double*>(M.v_kabs), const_cast<float*>(M.v_albedo), const_cast<float*>(M.v_g),
+               const_cast<float*>(M.v_s11), const_cast<float*>(M.v_prob), const_cast<float*>(M.v_s12), const_cast<float*>(M.v_s22),
+               const_cast<float*>(M.v_s33), const_cast<float*>(M.v_s34), const_cast<float*>(M.v_s44)};
+  const int threads = 64, n_rows = nc * nl;
+  hipLaunchKernelGGL(k_opacity_sum, dim3((n_rows + threads - 1) / threads), dim3(threads), 0, ctx->stream, I, O);
+  if (mueller) {
+    const dim3 grid((na1 + 63) / 64, nc, nl);
+    if (pola) hipLaunchKernelGGL(k_scatt_sum<true>, grid, dim3(64), 0, ctx->stream, I, O);
+    else hipLaunchKernelGGL(k_scatt_sum<false>, grid, dim3(64), 0, ctx->stream, I, O);
+  }
+  hipLaunchKernelGGL(k_scatt_norm, dim3((n_rows + threads - 1) / threads), dim3(threads), 0, ctx->stream, I, O);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  M.v_scatt = 1;
+  M.n_classes = nc;
+  ctx->pending_classes = true;  // log_Qcool and kdB_dT_CDF of the classes: mcgpu_init_reemission, from the new kappa_abs_LTE
+  ctx->reemission_pending = true;
+  if (out) {  // copies in the reference's layouts: (p_n_cells, n_lambda) and (0:nang, p_n_cells, n_lambda)
+    auto fetch2 = [&](const auto* dev, auto* host) -> int {
+      if (!host) return MCGPU_OK;
+      using Tp = std::remove_cv_t<std::remove_pointer_t<decltype(dev)>>;
+      std::vector<Tp> t(n_cl);
+      HIPCHK(hipMemcpy(t.data(), dev, n_cl * sizeof(Tp), hipMemcpyDeviceToHost));
+      for (int c = 0; c < nc; ++c)
+        for (int l = 0; l < nl; ++l) host[(size_t)c + (size_t)nc * l] = t[(size_t)c * nl + l];
+      return MCGPU_OK;
+    };
+    auto fetch3 = [&](const float* dev, float* host, int cols) -> int {
+      if (!host) return MCGPU_OK;
+      std::vector<float> t((size_t)nc * cols * na1);
+      HIPCHK(hipMemcpy(t.data(), dev, t.size() * sizeof(float), hipMemcpyDeviceToHost));
+      for (int c = 0; c < nc; ++c)
+        for (int l = 0; l < cols; ++l)
+          std::memcpy(&host[((size_t)l * nc + c) * na1], &t[((size_t)c * cols + l) * na1], na1 * sizeof(float));
+      return MCGPU_OK;
+    };
+    if ((rc = fetch2(M.v_kappa, out->kappa)) || (rc = fetch2(M.v_kabs, out->kappa_abs_LTE)) || (rc = fetch2(M.v_albedo, out->tab_albedo_pos)) ||
+        (rc = fetch2(M.v_g, out->tab_g_pos)) || (rc = fetch3(M.v_s11, out->tab_s11_pos, nl)) || (rc = fetch3(M.v_prob, out->prob_s11_pos, pcols)))
+      return rc;
+    if (pola && ((rc = fetch3(M.v_s12, out->tab_s12_o_s11_pos, nl)) || (rc = fetch3(M.v_s22, out->tab_s22_o_s11_pos, nl)) ||
+                 (rc = fetch3(M.v_s33, out->tab_s33_o_s11_pos, nl)) || (rc = fetch3(M.v_s34, out->tab_s34_o_s11_pos, nl)) ||
+                 (rc = fetch3(M.v_s44, out->tab_s44_o_s11_pos, nl))))
+      return rc;
+  }
   return MCGPU_OK;
 }
 

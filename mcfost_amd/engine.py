@@ -36,7 +36,7 @@ ABI_SYMBOLS = (
     "mcgpu_device_xI", "mcgpu_set_ism", "mcgpu_rt1_dust_map", "mcgpu_set_xI", "mcgpu_rt1_image", "mcgpu_set_xI_precision",
     "mcgpu_get_xI_precision", "mcgpu_set_option", "mcgpu_get_info", "mcgpu_counters_to_accum", "mcgpu_counters_from_accum",
     "mcgpu_set_grid_sph", "mcgpu_temp_approx_diffusion_vertical", "mcgpu_set_mrw", "mcgpu_fetch_radiation_field", "mcgpu_set_variable_dust", "mcgpu_rt1_stars_map_sed", "mcgpu_define_dark_zone", "mcgpu_init_reemission", "mcgpu_multi_create", "mcgpu_multi_destroy", "mcgpu_multi_size", "mcgpu_multi_ctx", "mcgpu_multi_last_error",
-    "mcgpu_repartition_energie", "mcgpu_shard_packets", "mcgpu_multi_run_thermal", "mcgpu_multi_run_mono", "mcgpu_multi_rccl_ranks",
+    "mcgpu_repartition_energie", "mcgpu_opacity", "mcgpu_shard_packets", "mcgpu_multi_run_thermal", "mcgpu_multi_run_mono", "mcgpu_multi_rccl_ranks",
 )
 
 
@@ -54,6 +54,20 @@ class MonoOpts(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("lambda_", C.c_int), ("p_lambda", C.c_int), ("n_chunks", C.c_int),
                 ("first_chunk", C.c_int), ("n_photons2", C.c_uint64), ("n_phot_lim", C.c_double),
                 ("capt_sup", C.c_int), ("rt1", C.c_int), ("accumulate", C.c_int), ("grid_blocks", C.c_int), ("block_threads", C.c_int)]
+
+
+class GrainTables(C.Structure):       # mcgpu_grain_tables
+    _fields_ = [("n_grains", C.c_int), ("grain_RE_LTE_start", C.c_int), ("grain_RE_LTE_end", C.c_int)] + \
+               [(k, C.POINTER(C.c_float)) for k in ("C_ext", "C_sca", "C_abs", "tab_g", "tab_s11", "tab_s12", "tab_s22",
+                                                    "tab_s33", "tab_s34", "tab_s44", "S_grain")] + \
+               [("n_grains_k", C.POINTER(C.c_double))]
+
+
+class OpacityTables(C.Structure):     # mcgpu_opacity_tables
+    _fields_ = [("kappa", C.POINTER(C.c_double)), ("kappa_abs_LTE", C.POINTER(C.c_double))] + \
+               [(k, C.POINTER(C.c_float)) for k in ("tab_albedo_pos", "tab_g_pos", "tab_s11_pos", "prob_s11_pos",
+                                                    "tab_s12_o_s11_pos", "tab_s22_o_s11_pos", "tab_s33_o_s11_pos",
+                                                    "tab_s34_o_s11_pos", "tab_s44_o_s11_pos")]
 
 
 class RtOpts(C.Structure):
@@ -252,6 +266,37 @@ class Engine:
             *[(_p(_a(vd[k], np.float32), C.c_float) if vd.get("prob_s11_pos") is not None else None)
               for k in ("prob_s11_pos", "s12_o_s11", "s22_o_s11", "s33_o_s11", "s34_o_s11", "s44_o_s11", "tab_g_pos")]),
             "mcgpu_set_variable_dust")
+
+    def opacity(self, grains, p_icell, dens, fetch=True):
+        """``opacity`` + ``calc_local_scattering_matrices`` (dust_prop.f90:791-1243) on the device: builds the per-class
+        opacity and scattering tables of the context from the grains' tables (``mcfost_amd.host.model.synthetic_grains``)
+        and ``dens [p_n_cells, n_grains]``; they replace what ``mcgpu_set_variable_dust`` would have set (call
+        ``init_reemission`` next).  ``fetch``: returns them in the reference's layouts (C-ordered, wavelength first)."""
+        m = self.model
+        f32, f64 = np.float32, np.float64
+        dens = _a(dens, f64)
+        nc, nl, na1 = dens.shape[0], m.n_lambda, int(np.asarray(grains["tab_s11"]).shape[-1])
+        pola = bool(m.cfg.lsepar_pola) and int(m.cfg.aniso_method) == 1
+        keep = [_a(grains[k], f32) for k in ("C_ext", "C_sca", "C_abs", "tab_g", "tab_s11", "tab_s12", "tab_s22", "tab_s33",
+                                            "tab_s34", "tab_s44", "S_grain")]
+        nk = _a(grains["n_grains_k"], f64)
+        G = GrainTables(int(grains["n_grains"]), int(grains["grain_RE_LTE_start"]), int(grains["grain_RE_LTE_end"]),
+                        *[_p(v, C.c_float) for v in keep[:10]], _p(keep[10], C.c_float), _p(nk, C.c_double))
+        out, O = None, None
+        if fetch:
+            pcols = 1 if int(m.p_lambda_fixed) else nl
+            out = dict(kappa=np.zeros((nl, nc), f64), kappa_abs_LTE=np.zeros((nl, nc), f64), tab_albedo_pos=np.zeros((nl, nc), f32),
+                       tab_g_pos=np.zeros((nl, nc), f32), tab_s11_pos=np.zeros((nl, nc, na1), f32),
+                       prob_s11_pos=np.zeros((pcols, nc, na1), f32))
+            for k in ("tab_s12_o_s11_pos", "tab_s22_o_s11_pos", "tab_s33_o_s11_pos", "tab_s34_o_s11_pos", "tab_s44_o_s11_pos"):
+                out[k] = np.zeros((nl, nc, na1), f32) if pola else None
+            pf = lambda k: _p(out[k], C.c_float) if out[k] is not None else None
+            O = OpacityTables(_p(out["kappa"], C.c_double), _p(out["kappa_abs_LTE"], C.c_double), pf("tab_albedo_pos"), pf("tab_g_pos"),
+                              pf("tab_s11_pos"), pf("prob_s11_pos"), pf("tab_s12_o_s11_pos"), pf("tab_s22_o_s11_pos"),
+                              pf("tab_s33_o_s11_pos"), pf("tab_s34_o_s11_pos"), pf("tab_s44_o_s11_pos"))
+        self._chk(self.lib.mcgpu_opacity(self.ctx, C.byref(G), C.c_int(nc), _p(_a(p_icell, np.int32), C.c_int),
+                                         _p(dens, C.c_double), C.byref(O) if O is not None else None), "mcgpu_opacity")
+        return out
 
     def init_reemission(self, fetch=True):
         """``init_reemission`` (thermal_emission.f90:404-550) on the device: rebuilds ``log_Qcool_minus_extra_heating``

@@ -63,13 +63,32 @@ module mcgpu_f
      real(c_double) :: Rmin, Rmax
   end type mcgpu_rt_opts
 
+  ! the grains' tables for mcgpu_opacity (include/mcgpu.h: mcgpu_grain_tables): c_loc of module grains' arrays
+  type, bind(C), public :: mcgpu_grain_tables
+     integer(c_int) :: n_grains                                  ! n_grains_tot
+     integer(c_int) :: grain_RE_LTE_start, grain_RE_LTE_end
+     type(c_ptr)    :: C_ext, C_sca, C_abs                       ! real (n_grains_tot, n_lambda)
+     type(c_ptr)    :: tab_g
+     type(c_ptr)    :: tab_s11, tab_s12, tab_s22, tab_s33, tab_s34, tab_s44   ! real (0:nang_scatt, n_grains_tot, n_lambda)
+     type(c_ptr)    :: S_grain                                   ! real (n_grains_tot)
+     type(c_ptr)    :: n_grains_k                                ! real(dp) n_grains(n_grains_tot)
+  end type mcgpu_grain_tables
+
+  ! copies of what mcgpu_opacity built (include/mcgpu.h: mcgpu_opacity_tables): c_loc(...) or c_null_ptr
+  type, bind(C), public :: mcgpu_opacity_tables
+     type(c_ptr) :: kappa, kappa_abs_LTE                         ! real(dp) (p_n_cells, n_lambda)
+     type(c_ptr) :: tab_albedo_pos, tab_g_pos                    ! real (p_n_cells, n_lambda)
+     type(c_ptr) :: tab_s11_pos, prob_s11_pos                    ! real (0:nang_scatt, p_n_cells, p_n_lambda_pos)
+     type(c_ptr) :: tab_s12_o_s11_pos, tab_s22_o_s11_pos, tab_s33_o_s11_pos, tab_s34_o_s11_pos, tab_s44_o_s11_pos
+  end type mcgpu_opacity_tables
+
   public :: mcgpu_create, mcgpu_destroy, mcgpu_set_grid_cyl, mcgpu_set_grid_sph, mcgpu_set_grid_voronoi, mcgpu_set_midplane_snap, mcgpu_set_option, &
        mcgpu_set_stars, mcgpu_set_opacity, mcgpu_set_scattering, mcgpu_set_thermal, mcgpu_set_sed_bins, &
        mcgpu_run_thermal, mcgpu_temp_finale, mcgpu_thermal_loop, mcgpu_error_message, mcgpu_set_rt1, &
        mcgpu_run_mono, mcgpu_fetch, mcgpu_fetch_xI, mcgpu_rt1_dust_map, mcgpu_set_xI, mcgpu_rt1_image, mcgpu_set_xI_precision, &
        mcgpu_set_E_prior, mcgpu_multi_create, mcgpu_multi_destroy, mcgpu_multi_size, mcgpu_multi_ctx, mcgpu_multi_run_thermal, mcgpu_multi_run_mono, mcgpu_multi_rccl_ranks, &
        mcgpu_counters_to_accum, mcgpu_counters_from_accum, mcgpu_temp_approx_diffusion_vertical, mcgpu_set_mrw, mcgpu_fetch_radiation_field, &
-       mcgpu_set_variable_dust, mcgpu_rt1_stars_map_sed, mcgpu_define_dark_zone, mcgpu_init_reemission, mcgpu_repartition_energie
+       mcgpu_set_variable_dust, mcgpu_rt1_stars_map_sed, mcgpu_define_dark_zone, mcgpu_init_reemission, mcgpu_repartition_energie, mcgpu_opacity
 
   interface
      integer(c_int) function mcgpu_create(device, ctx) bind(C, name="mcgpu_create")
@@ -379,6 +398,20 @@ module mcgpu_f
        real(c_double), intent(out) :: frac_E_stars, frac_E_disk, E_disk
        type(c_ptr), value :: prob_E_cell             ! c_loc(prob_E_cell(0,lambda)) or c_null_ptr
      end function mcgpu_repartition_energie
+
+     ! replaces the loop `do lambda=1,n_lambda; call prop_grains(lambda); call opacity(lambda, p_lambda)` 's second call
+     ! (dust_prop.f90:791-1243; init in dust_transfer.f90:160-200) once prop_grains has filled module grains for every
+     ! wavelength; the per-class tables stay on the device
+     integer(c_int) function mcgpu_opacity(ctx, grains, p_n_cells, p_icell, dust_density_o_n_grains, out) &
+          bind(C, name="mcgpu_opacity")
+       import :: c_int, c_ptr, c_double, mcgpu_grain_tables
+       type(c_ptr), value :: ctx
+       type(mcgpu_grain_tables), intent(in) :: grains
+       integer(c_int), value :: p_n_cells
+       integer(c_int), intent(in) :: p_icell(*)
+       real(c_double), intent(in) :: dust_density_o_n_grains(*)
+       type(c_ptr), value :: out             ! c_loc(a mcgpu_opacity_tables) or c_null_ptr
+     end function mcgpu_opacity
 
      ! replaces `call mc_photon_loop(lambda, p_lambda, n_photons2, n_phot_lim, 1, .false.)` (dust_transfer.f90:939)
      integer(c_int) function mcgpu_run_mono(ctx, opts, frac_E_stars, frac_E_disk, prob_E_cell, n_sent_chunk, &

@@ -747,6 +747,95 @@ def init_variable_dust(m: "Model", n_classes: int = 0, slope: float = 0.15, iden
     return m.variable_dust
 
 
+def synthetic_grains(m: "Model", n_grains: int = 16, a_min: float = 0.03, a_max: float = 1000.0, aexp: float = 3.5):
+    """Per-grain tables for ``opacity`` / ``calc_local_scattering_matrices`` (dust_prop.f90:791-1243) in the
+    reference's layouts and types (grains.f90:38-54): a power-law size distribution of ``n_grains`` log-spaced sizes
+    with smooth stand-ins for the Mie results (size parameter x = 2 pi a / lambda: Q_abs ~ min(1, x), Q_sca ~ min(1.2, x^4),
+    g rising with x, Henyey-Greenstein S11 normalised to Q_sca with 3 % of it left to the unresolved forward peak,
+    Rayleigh-like polarisation that fades with x) -- inputs, not algorithm.  Arrays are C-ordered with the Fortran
+    first index last: ``C_ext[n_lambda, n_grains]``, ``tab_s11[n_lambda, n_grains, nang+1]``."""
+    lam = np.asarray(m.lam, f64)
+    nl, na1 = lam.size, NANG_SCATT + 1
+    a = np.exp(np.linspace(math.log(a_min), math.log(a_max), n_grains))
+    nk = a ** (1.0 - aexp)                      # n(a) da with da ~ a on a log grid
+    nk = nk / nk.sum()
+    S = (PI * a * a).astype(f32)                # micron^2
+    x = 2 * PI * a[None, :] / lam[:, None]      # [nl, ng]
+    feat = 1 + 1.5 * np.exp(-0.5 * (np.log(lam / 9.7) / 0.2) ** 2)[:, None] / (1 + (a[None, :] / 2.0) ** 2)
+    qabs = np.minimum(1.0, 0.9 * x) * feat
+    qsca = np.minimum(1.2, 1.1 * x ** 4)
+    g = 0.85 * x ** 2 / (1.0 + x ** 2)
+    th = np.arange(na1) * (PI / NANG_SCATT)
+    mu, dtheta = np.cos(th), PI / NANG_SCATT
+    s11 = (1 - g[..., None] ** 2) / (1 + g[..., None] ** 2 - 2 * g[..., None] * mu) ** 1.5      # [nl, ng, na1]
+    norm = np.sum(s11[..., 1:NANG_SCATT] * np.sin(th[1:NANG_SCATT]) * dtheta, axis=-1)
+    s11 = s11 * (0.97 * qsca / norm)[..., None]                                              # "normalised to Q_sca"
+    pol = (1 - mu ** 2) / (1 + mu ** 2)
+    pmax = 1.0 / (1.0 + x ** 2)
+    s12 = -pmax[..., None] * pol * s11
+    s22 = s11.copy()
+    s33 = (2 * mu / (1 + mu ** 2)) * s11
+    s34 = 0.2 * pol * np.sin(th) * s11 * (x / (1 + x))[..., None]
+    s44 = s33.copy()
+    c32 = lambda v: np.ascontiguousarray(v, f32)
+    return dict(n_grains=n_grains, a=a, grain_RE_LTE_start=1, grain_RE_LTE_end=n_grains,
+                C_ext=c32((qabs + qsca) * S[None, :]), C_sca=c32(qsca * S[None, :]), C_abs=c32(qabs * S[None, :]),
+                tab_g=c32(g), tab_s11=c32(s11), tab_s12=c32(s12), tab_s22=c32(s22), tab_s33=c32(s33), tab_s34=c32(s34),
+                tab_s44=c32(s44), S_grain=S, n_grains_k=np.ascontiguousarray(nk, f64))
+
+
+def settled_grain_density(m: "Model", grains: dict, xi: float = 0.25, per_cell: bool = True, n_classes: int = 0):
+    """``dust_density_o_n_grains(n_grains, p_n_cells)`` (density.f90:32, here ``[p_n_cells, n_grains]`` C-ordered) of a
+    settled disk: grain k has the scale height H (a_k / a_min)^-xi, its column density that of the model.
+    ``per_cell``: every cell its own class (the reference's lvariable_dust: p_icell = identity, kappa_factor = 1, the
+    density carries the cell's dust); otherwise ``n_classes`` vertical layers with relative abundances (kappa_factor stays
+    the model's).  Scaled so that the extinction at the reference wavelength matches the model's where the dust is
+    unsettled.  Returns ``(p_icell, dens)``."""
+    g, cfg = m.grid, m.cfg
+    n_cells, nz = m.n_cells, g["nz"]
+    a = np.asarray(grains["a"], f64)
+    r, z = np.asarray(g["r_grid"], f64), np.abs(np.asarray(g["z_grid"], f64))
+    H = cfg.sclht * (r / cfg.rref) ** cfg.exp_beta
+    shrink = (a / a[0]) ** (-xi)                                       # H_k / H
+    if per_cell:
+        p_icell = np.arange(1, n_cells + 1, dtype=np.int32)
+        zz = (z / H)[:, None]
+        w = np.exp(-0.5 * zz ** 2 * (1.0 / shrink[None, :] ** 2 - 1.0)) / shrink[None, :]
+        dens = np.asarray(m.kappa_factor, f64)[:, None] * w
+    else:
+        nc = int(n_classes) if n_classes else nz
+        j = np.abs(np.asarray(g["cell_map_j"], np.int64)[:n_cells])
+        p_icell = (np.minimum((j - 1) * nc // nz, nc - 1) + 1).astype(np.int32)
+        zz = ((np.arange(nc) + 0.5) / nc * 7.0)[:, None]   # layer centres in scale heights (the grid is cut at 7 H)
+        dens = np.exp(-0.5 * zz ** 2 * (1.0 / shrink[None, :] ** 2 - 1.0)) / shrink[None, :]
+    # calibration: sum_k C_ext(k, l0) n_k dens0 * fact = the model's kappa(l0) for unsettled dust of unit kappa_factor
+    l0 = int(np.argmin(np.abs(np.asarray(m.lam) - 1.0)))
+    fact = AU_TO_CM * 1.0e-8
+    k0 = float(np.sum(np.asarray(grains["C_ext"], f64)[l0] * np.asarray(grains["n_grains_k"], f64))) * fact
+    dens = dens * (float(np.asarray(m.kappa, f64)[l0]) / k0)
+    return p_icell, np.ascontiguousarray(dens, f64)
+
+
+def variable_dust_from_opacity(m: "Model", p_icell, tabs: dict, lq=None, cdf=None):
+    """The ``variable_dust`` description of a model (see ``init_variable_dust``) from the tables ``opacity`` built
+    (``Oracle.opacity`` / ``Engine.opacity``, the reference's layouts); ``lq`` / ``cdf``: the classes' re-emission
+    tables (None: left to ``mcgpu_init_reemission`` on the device)."""
+    nc = int(np.max(p_icell))
+    vd = dict(p_n_cells=nc, p_icell=np.asarray(p_icell, np.int32), kappa=np.asarray(tabs["kappa"], f64).reshape(-1),
+              kappa_abs_LTE=np.asarray(tabs["kappa_abs_LTE"], f64).reshape(-1), albedo=np.asarray(tabs["tab_albedo_pos"], f32).reshape(-1),
+              log_Qcool=None if lq is None else np.asarray(lq, f64).reshape(-1),
+              kdB_dT_CDF=None if cdf is None else np.asarray(cdf, f64).reshape(-1))
+    vd["prob_s11_pos"] = np.asarray(tabs["prob_s11_pos"], f32).reshape(-1)
+    na1 = NANG_SCATT + 1
+    zeros = np.zeros((m.n_lambda, nc, na1), f32)
+    for k_out, k_in in (("s12_o_s11", "tab_s12_o_s11_pos"), ("s22_o_s11", "tab_s22_o_s11_pos"), ("s33_o_s11", "tab_s33_o_s11_pos"),
+                        ("s34_o_s11", "tab_s34_o_s11_pos"), ("s44_o_s11", "tab_s44_o_s11_pos")):
+        vd[k_out] = np.asarray(tabs[k_in] if tabs.get(k_in) is not None else zeros, f32).reshape(-1)
+    vd["tab_g_pos"] = np.asarray(tabs["tab_g_pos"], f32).reshape(-1)
+    m.variable_dust = vd
+    return vd
+
+
 def cumulative_zeta(n: int = 10000):
     """``initialize_cumulative_zeta`` (MRW.f90:16-53): zeta(y) = 2 sum_{j>=1} (-1)^(j+1) y^(j^2) (Min et al. 2009,
     eq. 7) on y_i = (i-1)/(n-1); the last point is the limit 1."""

@@ -2752,3 +2752,123 @@ int oracle_init_reemission(int p_n_cells, int n_T, int n_lambda, const float *ta
   free(B); free(dB_dT); free(integ3);
   return 0;
 }
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * opacity (dust_prop.f90:791-1033) and calc_local_scattering_matrices (dust_prop.f90:1037-1243): the opacities and
+ * the scattering tables of every cell class from the grains' cross sections and Mueller matrices and the local grain
+ * densities -- the LTE / scattering-method-2 case, every wavelength with p_lambda = lambda.  The reference's types are
+ * kept: default-real tables accumulate in default real (each sum is rounded to it, as the assignment does), the
+ * opacities in double.  See mc_oracle.h. */
+int oracle_opacity(int n_grains, int n_lambda, int p_n_cells, int nang, int aniso_method, int lsepar_pola,
+                   int grain_RE_LTE_start, int grain_RE_LTE_end, const float *C_ext, const float *C_sca,
+                   const float *C_abs, const float *tab_g, const float *tab_s11, const float *tab_s12,
+                   const float *tab_s22, const float *tab_s33, const float *tab_s34, const float *tab_s44,
+                   const float *S_grain, const double *nbre_grains, const double *dens, double *kappa,
+                   double *kappa_abs_LTE, float *tab_albedo_pos, float *tab_g_pos, float *tab_s11_pos,
+                   float *prob_s11_pos, float *s12_o_s11, float *s22_o_s11, float *s33_o_s11, float *s34_o_s11,
+                   float *s44_o_s11) {
+  const double AU_to_cm = 149597870700.0 * 100.0, mum_to_cm = 1.0e-4; /* constants.f90:61-73 */
+  const double fact = AU_to_cm * (mum_to_cm * mum_to_cm);              /* :958 */
+  const double dtheta = M_PI / (double)(float)nang;                    /* pi/real(nang_scatt), :1041 */
+  const double two_pi = 2.0 * M_PI, four_pi = 4.0 * M_PI;
+  const int na1 = nang + 1;
+  if (n_grains < 1 || n_lambda < 1 || p_n_cells < 1 || nang < 2 || grain_RE_LTE_start < 1 || grain_RE_LTE_end > n_grains)
+    return 1;
+  if (aniso_method == 1 && (!tab_s11 || (lsepar_pola && (!tab_s12 || !tab_s22 || !tab_s33 || !tab_s34 || !tab_s44)))) return 1;
+  for (int lambda = 1; lambda <= n_lambda; ++lambda) {
+    const float *Ce = C_ext + (size_t)n_grains * (lambda - 1), *Cs = C_sca + (size_t)n_grains * (lambda - 1);
+    const float *Ca = C_abs + (size_t)n_grains * (lambda - 1);
+    const float *tg = tab_g ? tab_g + (size_t)n_grains * (lambda - 1) : NULL;
+    for (int icell = 1; icell <= p_n_cells; ++icell) {
+      const double *d = dens + (size_t)n_grains * (icell - 1);
+      const size_t cl = (size_t)(icell - 1) + (size_t)p_n_cells * (lambda - 1); /* (p_n_cells, n_lambda) */
+      /* ---- opacity(): the sums over the grains (:850-876) ---- */
+      double kap = 0.0, k_sca_tot = 0.0;
+      for (int k = 0; k < n_grains; ++k) {
+        const double density = d[k] * nbre_grains[k];
+        kap = kap + (double)Ce[k] * density;
+        k_sca_tot = k_sca_tot + (double)Cs[k] * density;
+      }
+      float albedo = 0.0f; /* (the array is zero before the first call) */
+      if (kap > (double)FLT_MIN) albedo = (float)(k_sca_tot / kap);
+      float g_pos = 0.0f;
+      if (aniso_method == 2) {
+        for (int k = 0; k < n_grains; ++k) {
+          const double density = d[k] * nbre_grains[k];
+          g_pos = (float)((double)g_pos + ((double)Cs[k] * density) * (double)tg[k]);
+        }
+        if (k_sca_tot > (double)FLT_MIN) g_pos = (float)((double)g_pos / k_sca_tot);
+        tab_g_pos[cl] = g_pos;
+      } else if (tab_g_pos) tab_g_pos[cl] = 0.0f;
+      double kabs = 0.0;
+      for (int k = grain_RE_LTE_start - 1; k < grain_RE_LTE_end; ++k) kabs = kabs + ((double)Ca[k] * d[k]) * nbre_grains[k];
+      kap = kap * fact;   /* :960-961 */
+      kabs = kabs * fact;
+      kappa[cl] = kap;
+      kappa_abs_LTE[cl] = kabs;
+      /* ---- calc_local_scattering_matrices() (scattering_method 2) ---- */
+      const size_t row = (size_t)na1 * cl; /* (0:nang, p_n_cells, p_n_lambda) */
+      float *s11 = tab_s11_pos + row, *prob = prob_s11_pos ? prob_s11_pos + row : NULL;
+      float *m12 = lsepar_pola ? s12_o_s11 + row : NULL, *m22 = lsepar_pola ? s22_o_s11 + row : NULL;
+      float *m33 = lsepar_pola ? s33_o_s11 + row : NULL, *m34 = lsepar_pola ? s34_o_s11 + row : NULL;
+      float *m44 = lsepar_pola ? s44_o_s11 + row : NULL;
+      if (aniso_method == 1) {
+        for (int l = 0; l < na1; ++l) {
+          s11[l] = 0.0f;
+          if (lsepar_pola) { m12[l] = 0.0f; m22[l] = 0.0f; m33[l] = 0.0f; m34[l] = 0.0f; m44[l] = 0.0f; }
+        }
+        for (int k = 0; k < n_grains; ++k) { /* Mueller matrix averaging (:1098-1120) */
+          const double density = d[k] * nbre_grains[k];
+          const size_t g0 = (size_t)na1 * ((size_t)k + (size_t)n_grains * (lambda - 1));
+          for (int l = 0; l < na1; ++l) {
+            s11[l] = (float)((double)s11[l] + (double)(tab_s11[g0 + l] * S_grain[k]) * density);
+            if (lsepar_pola) {
+              m12[l] = (float)((double)m12[l] + (double)(tab_s12[g0 + l] * S_grain[k]) * density);
+              m22[l] = (float)((double)m22[l] + (double)(tab_s22[g0 + l] * S_grain[k]) * density);
+              m33[l] = (float)((double)m33[l] + (double)(tab_s33[g0 + l] * S_grain[k]) * density);
+              m34[l] = (float)((double)m34[l] + (double)(tab_s34[g0 + l] * S_grain[k]) * density);
+              m44[l] = (float)((double)m44[l] + (double)(tab_s44[g0 + l] * S_grain[k]) * density);
+            }
+          }
+        }
+      }
+      k_sca_tot = kap * (double)albedo / fact; /* :1122 */
+      if (k_sca_tot > (double)FLT_MIN) {
+        if (aniso_method == 1) {
+          prob[0] = 0.0f;
+          prob[1] = 0.0f; /* (never assigned by the loop below: the allocation value) */
+          for (int l = 2; l <= nang; ++l) {
+            const double theta = (double)(float)l * dtheta;
+            prob[l] = (float)((double)prob[l - 1] + ((double)s11[l] * sin(theta)) * dtheta);
+          }
+          const double last = (double)prob[nang];
+          for (int l = 1; l <= nang; ++l) prob[l] = (float)(((double)prob[l] + k_sca_tot) - last); /* :1150 */
+          for (int l = 0; l <= nang; ++l) prob[l] = (float)((double)prob[l] / k_sca_tot);
+          for (int l = 0; l <= nang; ++l)
+            if (s11[l] > FLT_MIN) {
+              const float norm = 1.0f / s11[l];
+              if (lsepar_pola) { m12[l] *= norm; m22[l] *= norm; m33[l] *= norm; m34[l] *= norm; m44[l] *= norm; }
+            }
+          for (int l = 0; l <= nang; ++l) s11[l] = (float)(((double)s11[l] * dtheta) / (k_sca_tot * two_pi)); /* :1172 */
+        } else {
+          for (int l = 0; l <= nang; ++l) { /* Henyey-Greenstein, for the ray tracer (:1190-1194) */
+            const float g = g_pos, g2 = g * g;
+            const float mu = (float)cos((double)((float)l / (float)nang) * M_PI);
+            s11[l] = (float)((((1.0 / four_pi) * (double)(1.0f - g2)) * (double)powf((1.0f + g2) - (2.0f * g) * mu, -1.5f)) * dtheta);
+          }
+          if (prob) for (int l = 0; l <= nang; ++l) prob[l] = 0.0f; /* (not built for this method) */
+          if (lsepar_pola)
+            for (int l = 0; l <= nang; ++l) { m12[l] = 0.0f; m22[l] = 0.0f; m33[l] = 0.0f; m34[l] = 0.0f; m44[l] = 0.0f; }
+        }
+      } else { /* no scattering here (:1222-1236) */
+        albedo = 0.0f;
+        if (prob) { for (int l = 0; l <= nang; ++l) prob[l] = 1.0f; prob[0] = 0.0f; }
+        for (int l = 0; l <= nang; ++l) s11[l] = 1.0f;
+        if (lsepar_pola)
+          for (int l = 0; l <= nang; ++l) { m12[l] = 0.0f; m22[l] = 0.0f; m33[l] = 0.0f; m34[l] = 0.0f; m44[l] = 0.0f; }
+      }
+      tab_albedo_pos[cl] = albedo;
+    }
+  }
+  return 0;
+}

@@ -351,6 +351,24 @@ int oracle_init_reemission(int p_n_cells, int n_T, int n_lambda, const float *ta
                            const double *tab_delta_lambda, const double *kappa_abs_LTE, double *log_Qcool,
                            double *kdB_dT_CDF);
 
+/* opacity(lambda, p_lambda = lambda) (dust_prop.f90:791-1033; LTE grains, no scattering suppression) followed by
+ * calc_local_scattering_matrices (dust_prop.f90:1037-1243; scattering_method 2), for every wavelength: from the grains'
+ * C_ext / C_sca / C_abs / tab_g (n_grains, n_lambda), Mueller matrices tab_s11 .. tab_s44 (0:nang, n_grains, n_lambda),
+ * S_grain(n_grains) -- all default real --, n_grains(k) (double) and dust_density_o_n_grains(n_grains, p_n_cells)
+ * (double) to kappa, kappa_abs_LTE (double), tab_albedo_pos, tab_g_pos (p_n_cells, n_lambda), tab_s11_pos,
+ * prob_s11_pos, tab_s12_o_s11_pos .. tab_s44_o_s11_pos (0:nang, p_n_cells, n_lambda), in the reference's layouts and
+ * types.  aniso_method 2 (Henyey-Greenstein): tab_g_pos and the ray tracer's tab_s11_pos, no Mueller sums.
+ * PARITY UNPINNED (module dust_prop needs utils -> SPRNG / generated sources: unbuildable here): pinned by known
+ * answers (one grain, identical classes, normalisations) and an independent numpy mirror in tests/test_opacity.py. */
+int oracle_opacity(int n_grains, int n_lambda, int p_n_cells, int nang, int aniso_method, int lsepar_pola,
+                   int grain_RE_LTE_start, int grain_RE_LTE_end, const float *C_ext, const float *C_sca,
+                   const float *C_abs, const float *tab_g, const float *tab_s11, const float *tab_s12,
+                   const float *tab_s22, const float *tab_s33, const float *tab_s34, const float *tab_s44,
+                   const float *S_grain, const double *nbre_grains, const double *dens, double *kappa,
+                   double *kappa_abs_LTE, float *tab_albedo_pos, float *tab_g_pos, float *tab_s11_pos,
+                   float *prob_s11_pos, float *s12_o_s11, float *s22_o_s11, float *s33_o_s11, float *s34_o_s11,
+                   float *s44_o_s11);
+
 /* repartition_energie(lambda) (thermal_emission.f90:1771-1949), LTE grains (lRE_LTE; :1814-1831): how the energy emitted at
  * one wavelength splits between the stars, the disk's cells and the interstellar field.  In: tab_lambda(lambda) in
  * micron, E_stars(lambda), E_ISM(lambda), Tdust(n_cells) (default real), weight_proba_emission(n_cells) or NULL
