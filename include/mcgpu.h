@@ -492,8 +492,12 @@ int mcgpu_probe_packet_rand(mcgpu_ctx *ctx, uint64_t seed, uint64_t packet,
  *   (p_n_cells, n_lambda)                         mem.f90:205-243; all seven or all NULL (NULL: every class scatters
  *                                                 with the tables of mcgpu_set_scattering)
  * p_n_cells may be smaller than n_cells (classes of cells with the same dust).  The thermal step then runs the
- * HBM-gather variant of the single-role kernel and mcgpu_temp_finale reads log_Qcool per class.  The SED mode, the
- * ray tracing, the random walk and the diffusion fill are not built for it and refuse such a context.
+ * HBM-gather variant of the single-role kernel and mcgpu_temp_finale reads log_Qcool per class.  The SED mode
+ * (mcgpu_run_mono: albedo, opacity and scattering tables of the crossed cell's class; with the tabulated phase function it
+ * needs the cumulative tables per wavelength, i.e. mcgpu_set_scattering with p_lambda_fixed = 0, and for rt1 deposits
+ * tab_s11_pos per class, mcgpu_set_variable_dust_s11), mcgpu_repartition_energie and the ray tracer (mcgpu_rt1_dust_map,
+ * mcgpu_rt1_image, mcgpu_rt1_stars_map_sed) read per class too.  The random walk, the diffusion fill and
+ * mcgpu_define_dark_zone are not built for it and refuse such a context.
  * p_n_cells = 0: off.  log_Qcool and kdB_dT_CDF may both be NULL (see mcgpu_init_reemission).
  */
 int mcgpu_set_variable_dust(mcgpu_ctx *ctx, int p_n_cells, const int *p_icell, const double *kappa,
@@ -502,6 +506,12 @@ int mcgpu_set_variable_dust(mcgpu_ctx *ctx, int p_n_cells, const int *p_icell, c
                             const float *tab_s12_o_s11_pos, const float *tab_s22_o_s11_pos,
                             const float *tab_s33_o_s11_pos, const float *tab_s34_o_s11_pos,
                             const float *tab_s44_o_s11_pos, const float *tab_g_pos);
+
+/* tab_s11_pos(0:nang, p_n_cells, n_lambda) of the classes (default real; mem.f90:227): the phase function, normalised
+ * for the ray tracer (dust_prop.f90:1172), that the rt1 deposits read per crossed cell (tab_s11_pos(it, p_icell, p_lambda),
+ * dust_ray_tracing.f90:503-512).  Needed for mcgpu_run_mono with rt1 on a variable-dust context that was set with
+ * mcgpu_set_variable_dust (mcgpu_opacity builds it itself); call after mcgpu_set_variable_dust. */
+int mcgpu_set_variable_dust_s11(mcgpu_ctx *ctx, const float *tab_s11_pos);
 
 /*
  * init_reemission on the device (thermal_emission.f90:404-550, the LTE part: lines 431-452 the Planck function and its

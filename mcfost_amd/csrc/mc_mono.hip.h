@@ -161,12 +161,21 @@ constexpr int XI_LINE = 8;  // doubles per (cell, sub-bin, observer) record of t
 // transposes them through a per-wave LDS tile: lane j stores its record, then in round r the 8 lanes of
 // group g = lane/8 add the 8 slots of lane 8r+g's record -- one instruction, 8 records, 8 line
 // operations instead of 40.
+// lvariable_dust (M.n_classes): the columns are those of the cell's class, tab_s11_pos(it, p_icell, p_lambda) etc.
+// (dust_ray_tracing.f90:503-512), gathered from the per-class tables in HBM instead of the LDS copy.
+__device__ inline size_t mono_class_col(const DevModel& M, const MonoArgs& A, int icell) {
+  return M.n_classes ? ((size_t)M.cell_class[icell - 1] * M.n_lambda + (A.p_lambda - 1)) * (size_t)(M.nang + 1) : 0;
+}
+#define MONO_MU(tbl, vtab) (var ? (vtab)[vcol + it] : mu[(tbl) * na1 + it])
+
 template <bool POLA>
 __device__ inline void deposit_rt1_wave(const DevModel& M, const MonoArgs& A, const RtScratch& R, const float* mu,
                                         const RtDeposit& D, const double S[4], bool flag_star, double* tile,
                                         unsigned long long* tile_addr, unsigned int* tile_mask) {
   const int na1 = M.nang + 1;
   const int lane = threadIdx.x & 63;
+  const bool var = M.n_classes != 0;
+  const size_t vcol = D.on ? mono_class_col(M, A, D.icell) : 0;
 #ifdef MCGPU_LANE_EMULATION
   (void)tile; (void)tile_addr; (void)tile_mask;
 #else
@@ -188,14 +197,14 @@ __device__ inline void deposit_rt1_wave(const DevModel& M, const MonoArgs& A, co
     if (D.on) {
       rec = A.xI + ((((size_t)(D.icell - 1) * A.n_theta_rt + (D.psup - 1)) * A.n_az_rt + (D.phik - 1)) * A.nRT + q) * XI_LINE;
       const int it = R.itheta[q * blockDim.x + threadIdx.x];
-      const float s11 = mu[it];
+      const float s11 = MONO_MU(0, M.v_s11);
       if (!POLA) {
         v0 = D.l * S[0] * (double)s11;
         mask = 1u;
         if (A.contrib) { cslot = flag_star ? 2 : 4; mask |= 1u << cslot; }  // n_Stokes + 2 / + 4, n_Stokes = 1
       } else {
-        const float s12 = -s11 * mu[na1 + it], s22 = s11 * mu[2 * na1 + it], s33 = -s11 * mu[3 * na1 + it];
-        const float s34 = -s11 * mu[4 * na1 + it], s44 = -s11 * mu[5 * na1 + it];
+        const float s12 = -s11 * MONO_MU(1, M.v_s12), s22 = s11 * MONO_MU(2, M.v_s22), s33 = -s11 * MONO_MU(3, M.v_s33);
+        const float s34 = -s11 * MONO_MU(4, M.v_s34), s44 = -s11 * MONO_MU(5, M.v_s44);
         const double cosw = R.cosw[q * blockDim.x + threadIdx.x], sinw = R.sinw[q * blockDim.x + threadIdx.x];
         const double C1 = S[0], C4 = S[3];
         const double C2 = cosw * S[1] + (-sinw) * S[2];
@@ -270,6 +279,8 @@ __device__ inline void deposit_rt1_wave_f32(const DevModel& M, const MonoArgs& A
                                             unsigned long long* tile_addr, unsigned int* tile_mask) {
   const int na1 = M.nang + 1;
   const int lane = threadIdx.x & 63;
+  const bool var = M.n_classes != 0;
+  const size_t vcol = D.on ? mono_class_col(M, A, D.icell) : 0;
   const int K = (POLA ? 4 : 1) + (A.contrib ? 1 : 0);
   const int NR = 64 / (2 * K);                 // pairs per instruction
   const int rl = lane / (2 * K), jj = lane - rl * 2 * K;
@@ -290,14 +301,14 @@ __device__ inline void deposit_rt1_wave_f32(const DevModel& M, const MonoArgs& A
       int cslot = 0;
       if (D.on && q < A.nRT) {
         const int it = R.itheta[q * blockDim.x + threadIdx.x];
-        const float s11 = mu[it];
+        const float s11 = MONO_MU(0, M.v_s11);
         if (!POLA) {
           v0 = D.l * S[0] * (double)s11;
           mask = 1u;
           if (A.contrib) { cslot = flag_star ? 2 : 4; mask |= 1u << cslot; }
         } else {
-          const float s12 = -s11 * mu[na1 + it], s22 = s11 * mu[2 * na1 + it], s33 = -s11 * mu[3 * na1 + it];
-          const float s34 = -s11 * mu[4 * na1 + it], s44 = -s11 * mu[5 * na1 + it];
+          const float s12 = -s11 * MONO_MU(1, M.v_s12), s22 = s11 * MONO_MU(2, M.v_s22), s33 = -s11 * MONO_MU(3, M.v_s33);
+          const float s34 = -s11 * MONO_MU(4, M.v_s34), s44 = -s11 * MONO_MU(5, M.v_s44);
           const double cosw = R.cosw[q * blockDim.x + threadIdx.x], sinw = R.sinw[q * blockDim.x + threadIdx.x];
           const double C1 = S[0], C4 = S[3];
           const double C2 = cosw * S[1] + (-sinw) * S[2];
@@ -402,11 +413,20 @@ __device__ inline void mono_item(const MonoArgs& A, unsigned long long my, unsig
 
 // forced scattering (dust_transfer.f90:1263-1278): the packet's weight after the albedo, or dead
 template <bool POLA>
-__device__ inline bool mono_attenuate(const Lds& T, int lambda, double S[4]) {
+__device__ inline bool mono_attenuate(const Lds& T, int lambda, double S[4]) {  // (T: the tables of the cell's class)
   const double alb = (double)T.albedo[lambda - 1];
   S[0] *= alb;
   if (POLA) { S[1] *= alb; S[2] *= alb; S[3] *= alb; }
   return S[0] < (double)(FLT_TINY_X1E6);
+}
+
+// kappa(p_icell, lambda) * kappa_factor(icell) (optical_depth.f90:100-102) of a real cell
+template <bool L3D>
+__device__ inline double mono_opacity(const Lds& T, const DevModel& M, int lambda, int ri, int zj, int k) {
+  if (!is_real_cell<L3D>(M.n_rad, M.nz, ri, zj)) return 0.0;
+  const int ic = cell_index<L3D>(M.n_rad, M.nz, ri, zj, k);
+  const double kap = M.n_classes ? M.v_kappa[(size_t)M.cell_class[ic] * M.n_lambda + (lambda - 1)] : T.kappa[lambda - 1];
+  return kap * M.kappa_factor[ic];
 }
 
 // SCOUT: no deposits, no SED; records hits.  Otherwise the COMMIT pass.
@@ -439,7 +459,8 @@ __device__ __forceinline__ void mono_body(const DevModel& M, const MonoArgs& A, 
   unsigned int pk_cross = 0;
   unsigned long long pk_next = 0, pk_end = 0, my_item = 0;
   float tau_rand = 0.0f;
-  double kf = 0.0;
+  double kf = 0.0;  // opacity of the packet's cell (mono_opacity)
+  const bool var = M.n_classes != 0;
 
   for (;;) {
     if (st == S_EXITED) {  // capteur (dust_transfer.f90:549-552); forced scattering never clears flag_ISM
@@ -507,15 +528,19 @@ __device__ __forceinline__ void mono_body(const DevModel& M, const MonoArgs& A, 
       tau_rand = g[5];
       bool dead = false;
       if (DARK) dead = M.dark[cell_index<L3D>(n_rad, nz, ri, zj, k)] != 0;
-      if (!dead) dead = mono_attenuate<POLA>(T, lambda, S);
+      // lvariable_dust: the albedo and the scattering tables of the cell's class (column p_lambda of its cumulative table)
+      const int cls = var ? M.cell_class[cell_index<L3D>(n_rad, nz, ri, zj, k)] : -1;
+      const Lds Tc = var ? class_tables(T, M, cls) : T;
+      if (!dead) dead = mono_attenuate<POLA>(Tc, lambda, S);
       if (dead) {
         c_abs++;
         st = S_EMIT;  // lpacket_alive = .false.: not binned
       } else {
         double u1, v1, w1;
         int lam = lambda;
-        interact<POLA>(T, M, g, lam, u, v, w, u1, v1, w1, S, flag_star, flag_scatt, c_scatt, c_abs,
-                       []() { return 0.0; }, M.volume, true, nullptr, 0);  // T.prob = column p_lambda
+        const float* prob_c = (var && M.v_scatt) ? M.v_prob + ((size_t)cls * M.n_lambda + (A.p_lambda - 1)) * na1 : nullptr;
+        interact<POLA>(Tc, M, g, lam, u, v, w, u1, v1, w1, S, flag_star, flag_scatt, c_scatt, c_abs,
+                       []() { return 0.0; }, M.volume, true, prob_c, 0, (var && M.v_scatt) ? cls : -1);  // T.prob = column p_lambda
         u = u1; v = v1; w = w1;
         st = S_NEWFLIGHT;
       }
@@ -537,7 +562,7 @@ __device__ __forceinline__ void mono_body(const DevModel& M, const MonoArgs& A, 
       c_flight++;
       ri_o = 0; zj_o = 0; k_o = 0;
       xo = x; yo = y; zo = z;
-      kf = is_real_cell<L3D>(n_rad, nz, ri, zj) ? M.kappa_factor[cell_index<L3D>(n_rad, nz, ri, zj, k)] : 0.0;
+      kf = mono_opacity<L3D>(T, M, lambda, ri, zj, k);
       st = S_FLIGHT;
     }
 
@@ -571,7 +596,7 @@ __device__ __forceinline__ void mono_body(const DevModel& M, const MonoArgs& A, 
           bool mirrored = false;
           if (real_cell) {
             ic = cell_index<L3D>(n_rad, nz, ri, zj, k);
-            opacity = T.kappa[lambda - 1] * kf;
+            opacity = kf;
             if (DARK) {
               if (M.dark[ic]) {  // optical_depth.f90:104-112
                 u = -u; v = -v; w = -w;
@@ -609,7 +634,7 @@ __device__ __forceinline__ void mono_body(const DevModel& M, const MonoArgs& A, 
               if (DARK) { xo = x; yo = y; zo = z; ri_o = ri; zj_o = zj; k_o = k; }
               x = x1; y = y1; z = z1;
               ri = ri1; zj = zj1; k = k1;
-              kf = is_real_cell<L3D>(n_rad, nz, ri, zj) ? M.kappa_factor[cell_index<L3D>(n_rad, nz, ri, zj, k)] : 0.0;
+              kf = mono_opacity<L3D>(T, M, lambda, ri, zj, k);
             }
             if (++pk_cross > 200000000u) {  // a packet that never leaves: flag it, drop it
               *A.err = 13;

@@ -45,7 +45,9 @@ __global__ void k_calc_Jth(const DevModel M, int lambda, double wl, const float*
   if (Temp * wl > 3.e-4) {
     const double cst_wl = (double)thermal_const / (Temp * wl);
     const double coeff_exp = exp(cst_wl);
-    j = cst_E / (pow(wl, 5) * (coeff_exp - 1.0)) * wl * M.kappa_abs[lambda - 1] * M.kappa_factor[ic];
+    // (lvariable_dust: kappa_abs_LTE of the cell's class)
+    const double kabs = M.n_classes ? M.v_kabs[(size_t)M.cell_class[ic] * M.n_lambda + (lambda - 1)] : M.kappa_abs[lambda - 1];
+    j = cst_E / (pow(wl, 5) * (coeff_exp - 1.0)) * wl * kabs * M.kappa_factor[ic];
   }
   J_th[ic] = j;
 }
@@ -108,13 +110,14 @@ __device__ inline void rt1_integ_ray(const Lds& T, const DevModel& M, const RtAr
     MCGPU_CROSS<L3D>(T, M, x, y, z, u0, v0, w0, inv_a, inv_w, ri, zj, k, x1, y1, z1, ri1, zj1, k1, l);
     if (is_real_cell<L3D>(n_rad, nz, ri, zj)) {
       const int ic = cell_index<L3D>(n_rad, nz, ri, zj, k);
-      const double kappa_ext = T.kappa[A.lambda - 1] * M.kappa_factor[ic];
+      const size_t vrow = M.n_classes ? (size_t)M.cell_class[ic] * M.n_lambda + (A.lambda - 1) : 0;  // (lvariable_dust)
+      const double kappa_ext = (M.n_classes ? M.v_kappa[vrow] : T.kappa[A.lambda - 1]) * M.kappa_factor[ic];
       const double dtau = l * kappa_ext;
       int phik = 1, psup = 1;
       rt1_subbin_of(A.n_az_rt, L3D, x, y, z, x1, y1, z1, phik, psup);
       if (kappa_ext > TINY_DP) {
         const double factor = A.photon_energy / M.volume[ic] * A.n_az_rt * A.n_theta_rt;
-        const double kappa_sca = kappa_ext * (double)T.albedo[A.lambda - 1];
+        const double kappa_sca = kappa_ext * (double)(M.n_classes ? M.v_albedo[vrow] : T.albedo[A.lambda - 1]);
         const size_t bin = ((size_t)ic * A.n_theta_rt + (psup - 1)) * A.n_az_rt + (phik - 1);
         double rec[XI_LINE];
         if (A.xI_f32) {
@@ -279,8 +282,11 @@ __device__ inline float optical_length_tot(const Lds& T, const DevModel& M, int 
     double x1, y1, z1, l;
     int ri1, zj1, k1;
     MCGPU_CROSS<L3D>(T, M, x, y, z, u, v, w, inv_a, inv_w, ri, zj, k, x1, y1, z1, ri1, zj1, k1, l);
-    if (is_real_cell<L3D>(n_rad, nz, ri, zj))
-      tau += l * (T.kappa[lambda - 1] * M.kappa_factor[cell_index<L3D>(n_rad, nz, ri, zj, k)]);
+    if (is_real_cell<L3D>(n_rad, nz, ri, zj)) {
+      const int ic = cell_index<L3D>(n_rad, nz, ri, zj, k);
+      const double kap = M.n_classes ? M.v_kappa[(size_t)M.cell_class[ic] * M.n_lambda + (lambda - 1)] : T.kappa[lambda - 1];
+      tau += l * (kap * M.kappa_factor[ic]);
+    }
     x = x1; y = y1; z = z1;
     ri = ri1; zj = zj1; k = k1;
   }

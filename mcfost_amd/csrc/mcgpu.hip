@@ -708,6 +708,7 @@ extern "C" int mcgpu_set_variable_dust(mcgpu_ctx* ctx, int p_n_cells, const int*
   if ((rc = upload(ctx, kdB_dT_CDF, kdB_dT_CDF ? (size_t)nc * nT * nl : 0, &M.v_cdf, (size_t)nc * nT * nl))) return rc;
   // scattering tables per class (all or none): (0:nang, p_n_cells, n_lambda) in the reference -> [class][lambda][angle]
   M.v_scatt = 0;
+  M.v_s11 = nullptr;
   const bool any_sc = prob_s11_pos || tab_s12_o_s11_pos || tab_s22_o_s11_pos || tab_s33_o_s11_pos || tab_s34_o_s11_pos ||
                       tab_s44_o_s11_pos || tab_g_pos;
   if (any_sc) {
@@ -737,6 +738,20 @@ extern "C" int mcgpu_set_variable_dust(mcgpu_ctx* ctx, int p_n_cells, const int*
   }
   M.n_classes = nc;
   return MCGPU_OK;
+}
+
+// tab_s11_pos(0:nang, p_n_cells, n_lambda) of the classes: the phase function the rt1 deposits and the ray tracer read
+extern "C" int mcgpu_set_variable_dust_s11(mcgpu_ctx* ctx, const float* tab_s11_pos) {
+  if (!ctx || !tab_s11_pos) return fail(ctx, MCGPU_ERR_ARG, "mcgpu_set_variable_dust_s11: bad argument");
+  DevModel& M = ctx->M;
+  if (!M.n_classes) return fail(ctx, MCGPU_ERR_STATE, "mcgpu_set_variable_dust first");
+  HIPCHK(hipSetDevice(ctx->device));
+  const int nc = M.n_classes, nl = M.n_lambda, na1 = M.nang + 1;
+  std::vector<float> t((size_t)nc * nl * na1);
+  for (int c = 0; c < nc; ++c)
+    for (int l = 0; l < nl; ++l)
+      std::memcpy(&t[((size_t)c * nl + l) * na1], &tab_s11_pos[((size_t)l * nc + c) * na1], na1 * sizeof(float));
+  return upload(ctx, t.data(), t.size(), &M.v_s11);
 }
 
 // opacity + calc_local_scattering_matrices on the device (dust_prop.f90:791-1243): see include/mcgpu.h
@@ -1754,7 +1769,13 @@ extern "C" int mcgpu_run_mono(mcgpu_ctx* ctx, const mcgpu_mono_opts* o, double f
   if (rc) return rc;
   if (!o) return fail(ctx, MCGPU_ERR_ARG, "null options");
   DevModel& M = ctx->M;
-  if (M.n_classes) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "SED mode with variable dust (mcgpu_set_variable_dust) is not built");
+  if (M.n_classes) {  // lvariable_dust: the tables of every class, with a column per wavelength (p_lambda = lambda in SED mode)
+    if (M.v_scatt && M.aniso_method == 1 && M.p_lambda_fixed)
+      return fail(ctx, MCGPU_ERR_STATE, "SED mode with variable dust needs prob_s11_pos per wavelength: set the scattering tables with p_lambda_fixed = 0");
+    if (!M.v_scatt) return fail(ctx, MCGPU_ERR_STATE, "SED mode with variable dust needs the per-class scattering tables");
+    if (o->rt1 && !M.v_s11) return fail(ctx, MCGPU_ERR_STATE, "rt1 deposits with variable dust need tab_s11_pos per class (mcgpu_opacity or mcgpu_set_variable_dust_s11)");
+    if (ctx->voro) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "variable dust: cylindrical grids only");
+  }
   if (o->lambda < 1 || o->lambda > M.n_lambda || o->n_chunks < 1 || o->n_chunks > (1 << 22) || o->capt_sup < 1 ||
       o->first_chunk < 0 || (long long)o->first_chunk + o->n_chunks > (1 << 23))
     return fail(ctx, MCGPU_ERR_ARG, "mcgpu_run_mono: bad option");
@@ -2124,7 +2145,6 @@ struct Rt1Job {
 
 static int rt1_prepare(mcgpu_ctx* ctx, const mcgpu_rt_opts* o, const float* tab_RT_az, const float* Tdust, Rt1Job& J,
                        const char* who) {
-  if (ctx && ctx->M.n_classes) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "ray tracing with variable dust (mcgpu_set_variable_dust) is not built");
   int rc = ready(ctx);
   if (rc) return rc;
   if (ctx->voro || ctx->M.grid_sph) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "RT1 ray tracing: cylindrical grids only");
@@ -2286,7 +2306,7 @@ extern "C" int mcgpu_rt1_stars_map_sed(mcgpu_ctx* ctx, const mcgpu_rt_opts* o, c
   if (rc) return rc;
   if (!o || !tab_RT_az || !star_flux || !stars_flux) return fail(ctx, MCGPU_ERR_ARG, "mcgpu_rt1_stars_map_sed: null argument");
   const DevModel& M = ctx->M;
-  if (ctx->voro || M.grid_sph || M.n_classes) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "stars map: cylindrical grids, one dust class");
+  if (ctx->voro || M.grid_sph) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "stars map: cylindrical grids");
   if (!ctx->have_rt1) return fail(ctx, MCGPU_ERR_STATE, "stars map: set the observers first (mcgpu_set_rt1)");
   if (o->lambda < 1 || o->lambda > M.n_lambda) return fail(ctx, MCGPU_ERR_ARG, "mcgpu_rt1_stars_map_sed: bad option");
   HIPCHK(hipSetDevice(ctx->device));

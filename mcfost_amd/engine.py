@@ -36,7 +36,7 @@ ABI_SYMBOLS = (
     "mcgpu_device_xI", "mcgpu_set_ism", "mcgpu_rt1_dust_map", "mcgpu_set_xI", "mcgpu_rt1_image", "mcgpu_set_xI_precision",
     "mcgpu_get_xI_precision", "mcgpu_set_option", "mcgpu_get_info", "mcgpu_counters_to_accum", "mcgpu_counters_from_accum",
     "mcgpu_set_grid_sph", "mcgpu_temp_approx_diffusion_vertical", "mcgpu_set_mrw", "mcgpu_fetch_radiation_field", "mcgpu_set_variable_dust", "mcgpu_rt1_stars_map_sed", "mcgpu_define_dark_zone", "mcgpu_init_reemission", "mcgpu_multi_create", "mcgpu_multi_destroy", "mcgpu_multi_size", "mcgpu_multi_ctx", "mcgpu_multi_last_error",
-    "mcgpu_repartition_energie", "mcgpu_opacity", "mcgpu_shard_packets", "mcgpu_multi_run_thermal", "mcgpu_multi_run_mono", "mcgpu_multi_rccl_ranks",
+    "mcgpu_repartition_energie", "mcgpu_opacity", "mcgpu_set_variable_dust_s11", "mcgpu_shard_packets", "mcgpu_multi_run_thermal", "mcgpu_multi_run_mono", "mcgpu_multi_rccl_ranks",
 )
 
 
@@ -266,6 +266,9 @@ class Engine:
             *[(_p(_a(vd[k], np.float32), C.c_float) if vd.get("prob_s11_pos") is not None else None)
               for k in ("prob_s11_pos", "s12_o_s11", "s22_o_s11", "s33_o_s11", "s34_o_s11", "s44_o_s11", "tab_g_pos")]),
             "mcgpu_set_variable_dust")
+        if vd.get("tab_s11_pos") is not None:   # the phase function of the rt1 deposits, per class
+            self._chk(self.lib.mcgpu_set_variable_dust_s11(self.ctx, _p(_a(vd["tab_s11_pos"], np.float32), C.c_float)),
+                      "mcgpu_set_variable_dust_s11")
 
     def opacity(self, grains, p_icell, dens, fetch=True):
         """``opacity`` + ``calc_local_scattering_matrices`` (dust_prop.f90:791-1243) on the device: builds the per-class

@@ -88,7 +88,7 @@ module mcgpu_f
        mcgpu_run_mono, mcgpu_fetch, mcgpu_fetch_xI, mcgpu_rt1_dust_map, mcgpu_set_xI, mcgpu_rt1_image, mcgpu_set_xI_precision, &
        mcgpu_set_E_prior, mcgpu_multi_create, mcgpu_multi_destroy, mcgpu_multi_size, mcgpu_multi_ctx, mcgpu_multi_run_thermal, mcgpu_multi_run_mono, mcgpu_multi_rccl_ranks, &
        mcgpu_counters_to_accum, mcgpu_counters_from_accum, mcgpu_temp_approx_diffusion_vertical, mcgpu_set_mrw, mcgpu_fetch_radiation_field, &
-       mcgpu_set_variable_dust, mcgpu_rt1_stars_map_sed, mcgpu_define_dark_zone, mcgpu_init_reemission, mcgpu_repartition_energie, mcgpu_opacity
+       mcgpu_set_variable_dust, mcgpu_rt1_stars_map_sed, mcgpu_define_dark_zone, mcgpu_init_reemission, mcgpu_repartition_energie, mcgpu_opacity, mcgpu_set_variable_dust_s11
 
   interface
      integer(c_int) function mcgpu_create(device, ctx) bind(C, name="mcgpu_create")
@@ -398,6 +398,12 @@ module mcgpu_f
        real(c_double), intent(out) :: frac_E_stars, frac_E_disk, E_disk
        type(c_ptr), value :: prob_E_cell             ! c_loc(prob_E_cell(0,lambda)) or c_null_ptr
      end function mcgpu_repartition_energie
+
+     integer(c_int) function mcgpu_set_variable_dust_s11(ctx, tab_s11_pos) bind(C, name="mcgpu_set_variable_dust_s11")
+       import :: c_int, c_ptr, c_float
+       type(c_ptr), value :: ctx
+       real(c_float), intent(in) :: tab_s11_pos(*)   ! (0:nang_scatt, p_n_cells, n_lambda)
+     end function mcgpu_set_variable_dust_s11
 
      ! replaces the loop `do lambda=1,n_lambda; call prop_grains(lambda); call opacity(lambda, p_lambda)` 's second call
      ! (dust_prop.f90:791-1243; init in dust_transfer.f90:160-200) once prop_grains has filled module grains for every

@@ -832,6 +832,7 @@ def variable_dust_from_opacity(m: "Model", p_icell, tabs: dict, lq=None, cdf=Non
                         ("s34_o_s11", "tab_s34_o_s11_pos"), ("s44_o_s11", "tab_s44_o_s11_pos")):
         vd[k_out] = np.asarray(tabs[k_in] if tabs.get(k_in) is not None else zeros, f32).reshape(-1)
     vd["tab_g_pos"] = np.asarray(tabs["tab_g_pos"], f32).reshape(-1)
+    vd["tab_s11_pos"] = np.asarray(tabs["tab_s11_pos"], f32).reshape(-1)
     m.variable_dust = vd
     return vd
 
@@ -948,6 +949,7 @@ def repartition_energie(m: "Model", Tdust):
     fd = np.zeros(nl, f64)
     E_disk_all = []
     vol = np.asarray(m.grid["volume"], f64)
+    vd = getattr(m, "variable_dust", None)
     for l in range(nl):
         wl = m.lam[l] * 1.0e-6
         E_cell = np.zeros(nc, f64)
@@ -955,7 +957,11 @@ def repartition_energie(m: "Model", Tdust):
         cst = np.full(nc, np.inf)
         cst[ok] = THERMAL_CONST / (Td[ok] * wl)
         ok &= cst < cst_wl_max
-        E_cell[ok] = 4.0 * m.kappa_abs_LTE[l] * m.kappa_factor[ok] * vol[ok] / ((wl ** 5) * (np.exp(cst[ok]) - 1.0))
+        if vd is not None:   # lvariable_dust: kappa_abs_LTE(p_icell, lambda) (thermal_emission.f90:1822)
+            kabs = np.asarray(vd["kappa_abs_LTE"], f64).reshape(nl, -1)[l][np.asarray(vd["p_icell"]) - 1][ok]
+        else:
+            kabs = m.kappa_abs_LTE[l]
+        E_cell[ok] = 4.0 * kabs * m.kappa_factor[ok] * vol[ok] / ((wl ** 5) * (np.exp(cst[ok]) - 1.0))
         E_disk = float(np.sum(E_cell))
         E_disk_all.append(E_disk)
         E_star = float(m.E_stars[l])

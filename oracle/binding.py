@@ -99,6 +99,7 @@ class _Model(C.Structure):
         ("p_n_cells", C.c_int), ("p_icell", _ip), ("v_kappa", _dp), ("v_kappa_abs_LTE", _dp), ("v_albedo", _fp),
         ("v_log_Qcool", _dp), ("v_kdB_dT_CDF", _dp), ("v_prob_s11_pos", _fp), ("v_s12_o_s11", _fp), ("v_s22_o_s11", _fp),
         ("v_s33_o_s11", _fp), ("v_s34_o_s11", _fp), ("v_s44_o_s11", _fp), ("v_tab_g_pos", _fp), ("r_lim", _dp),
+        ("v_tab_s11_pos", _fp),
     ]
 
 
@@ -245,6 +246,8 @@ class Oracle:
                              ("s33_o_s11", "v_s33_o_s11"), ("s34_o_s11", "v_s34_o_s11"), ("s44_o_s11", "v_s44_o_s11"),
                              ("tab_g_pos", "v_tab_g_pos")):
                     setattr(s, f, self._hold(_a(vd[k], np.float32), C.c_float))
+            if vd.get("tab_s11_pos") is not None:
+                s.v_tab_s11_pos = self._hold(_a(vd["tab_s11_pos"], np.float32), C.c_float)
         mrw = getattr(m, "mrw", None)
         if mrw is not None:
             s.mrw, s.mrw_n_zeta = 1, int(mrw["zeta"].size)

@@ -1434,21 +1434,28 @@ static void save_radiation_field_rt1(worker_t *W, int icell, const double Stokes
     if (phik > m->n_az_rt) phik = m->n_az_rt;
     psup = (zm > 0.0) ? 1 : 2;
   }
-  const size_t na1 = (size_t)m->nang_scatt + 1, col = na1 * (size_t)(p_lambda - 1);
+  const size_t na1 = (size_t)m->nang_scatt + 1;
+  /* tab_s11_pos(it, p_icell, p_lambda) (dust_ray_tracing.f90:503-512): lvariable_dust reads the crossed cell's own tables */
+  const int vd = m->p_n_cells != 0;
+  const size_t col = vd ? na1 * ((size_t)(p_lambda - 1) * m->p_n_cells + (size_t)(m->p_icell[icell - 1] - 1)) : na1 * (size_t)(p_lambda - 1);
+  const float *t_s11 = vd ? m->v_tab_s11_pos : m->tab_s11_pos;
+  const float *t_s12 = vd ? m->v_s12_o_s11 : m->s12_o_s11, *t_s22 = vd ? m->v_s22_o_s11 : m->s22_o_s11;
+  const float *t_s33 = vd ? m->v_s33_o_s11 : m->s33_o_s11, *t_s34 = vd ? m->v_s34_o_s11 : m->s34_o_s11;
+  const float *t_s44 = vd ? m->v_s44_o_s11 : m->s44_o_s11;
   for (int ibin = 1; ibin <= m->RT_n_incl; ++ibin)
     for (int iaz = 1; iaz <= m->RT_n_az; ++iaz) {
       const int q = (ibin - 1) + m->RT_n_incl * (iaz - 1), iRT = q + 1; /* RT2d_to_RT1d (:66-76) */
       const int it = W->itheta_rt1[q];
-      const float s11 = m->tab_s11_pos[col + it];
+      const float s11 = t_s11[col + it];
       if (!m->lsepar_pola) {
         const double flux = l * Stokes[0] * (double)s11;
         xI_add(W, phik, psup, 1, iRT, icell, flux);
         if (m->lsepar_contrib) xI_add(W, phik, psup, flag_star ? 3 : 5, iRT, icell, flux); /* n_Stokes = 1 */
         continue;
       }
-      const float s12 = -s11 * m->s12_o_s11[col + it], s22 = s11 * m->s22_o_s11[col + it];
-      const float s33 = -s11 * m->s33_o_s11[col + it], s34 = -s11 * m->s34_o_s11[col + it];
-      const float s44 = -s11 * m->s44_o_s11[col + it];
+      const float s12 = -s11 * t_s12[col + it], s22 = s11 * t_s22[col + it];
+      const float s33 = -s11 * t_s33[col + it], s34 = -s11 * t_s34[col + it];
+      const float s44 = -s11 * t_s44[col + it];
       const double cosw = W->cos_omega_rt1[q], sinw = W->sin_omega_rt1[q];
       /* C = ROP * Stokes, ROP(2:3,2:3) = [[cosw, -sinw], [sinw, cosw]] */
       const double C1 = Stokes[0], C4 = Stokes[3];
@@ -1810,7 +1817,7 @@ static void propagate_packet(worker_t *W, int *lambda, int p_lambda,
     rand = rng_float(&W->rng);                                /* :1280 */
     if (W->mono) { /* forced scattering (:1263-1278); the draw above is not used */
       if (m->l_dark_zone && m->l_dark_zone[*icell - 1]) { W->cnt[ORC_CNT_ABS]++; *lpacket_alive = 0; return; }
-      const double alb = (double)m->albedo[*lambda - 1];
+      const double alb = (double)tab_albedo(m, *icell, *lambda);
       Stokes[0] *= alb; Stokes[1] *= alb; Stokes[2] *= alb; Stokes[3] *= alb;
       if (Stokes[0] < (double)(FLT_MIN * 1.0e6f)) { /* tiny_real_x1e6 */
         W->cnt[ORC_CNT_ABS]++; /* SED mode: "absorptions" counts the packets dropped here */
@@ -2043,9 +2050,9 @@ int oracle_run_mono(const oracle_model *m, const oracle_mono_opts *o, double *xI
                     double *sed, double *n_sent, uint64_t *n_sent_chunk,
                     uint64_t *counters) {
   int nth = o->n_threads > 0 ? o->n_threads : 1;
-  if (m->p_n_cells) return 32; /* variable dust: thermal step only */
+  if (m->p_n_cells && (!m->v_prob_s11_pos || (o->rt1 && !m->v_tab_s11_pos))) return 32; /* variable dust: the classes' scattering tables */
   if (o->lambda < 1 || o->lambda > m->n_lambda || o->p_lambda < 1 || o->n_chunks < 1) return 23;
-  if (o->rt1 && (m->RT_n_incl * m->RT_n_az > ORACLE_MAX_RT || m->RT_n_incl < 1 || !m->tab_s11_pos)) return 24;
+  if (o->rt1 && (m->RT_n_incl * m->RT_n_az > ORACLE_MAX_RT || m->RT_n_incl < 1 || (!m->p_n_cells && !m->tab_s11_pos))) return 24;
   const size_t nsed = (size_t)ORACLE_N_SED_TYPES * m->n_lambda * m->N_thet * m->N_phi;
   const size_t nxI = o->rt1 ? (size_t)m->n_az_rt * m->n_theta_rt * m->N_type_flux * m->RT_n_incl * m->RT_n_az * (size_t)m->n_cells : 0;
   double *sed_t = (double *)calloc(nsed * nth, sizeof(double));
@@ -2352,7 +2359,7 @@ static double *rt_calc_Jth(const oracle_model *m, int lam, double wl, const floa
     if (Temp * wl > 3.e-4) {
       const double cst_wl = (double)thermal_const / (Temp * wl);
       const double coeff_exp = exp(cst_wl);
-      J_th[ic] = cst_E / (pow(wl, 5) * (coeff_exp - 1.0)) * wl * m->kappa_abs_LTE[lam - 1] * m->kappa_factor[ic];
+      J_th[ic] = cst_E / (pow(wl, 5) * (coeff_exp - 1.0)) * wl * tab_kappa_abs(m, ic + 1, lam) * m->kappa_factor[ic];
     }
   }
   return J_th;
@@ -2379,7 +2386,7 @@ static void rt1_integ_ray_dust(const oracle_model *m, int lam, double tau_dark_z
     double l, lc, lv;
     oracle_cross_cylindrical_cell(m, xa, ya, za, u0, v0, w0, ic, 0, &x1, &y1, &z1, &next_cell, &l, &lc, &lv);
     if (ic <= nc) {
-      const double kappa_ext = m->kappa[lam - 1] * m->kappa_factor[ic - 1];
+      const double kappa_ext = tab_kappa(m, ic, lam) * m->kappa_factor[ic - 1];
       const double dtau = lc * kappa_ext;
       const double xm = 0.5 * (xa + x1), ym = 0.5 * (ya + y1), zm = 0.5 * (za + z1);
       int k = 1, psup = 1;
@@ -2391,7 +2398,7 @@ static void rt1_integ_ray_dust(const oracle_model *m, int lam, double tau_dark_z
       }
       if (kappa_ext > DBL_MIN) {
         const double factor = photon_energy / m->volume[ic - 1] * m->n_az_rt * m->n_theta_rt;
-        const double kappa_sca = kappa_ext * (double)m->albedo[lam - 1];
+        const double kappa_sca = kappa_ext * (double)tab_albedo(m, ic, lam);
         const double *px = xI + (size_t)(k - 1) + (size_t)m->n_az_rt * (psup - 1) + st_rt * ((size_t)q + (size_t)nRT * (ic - 1));
         const double wgt = exp(-tau) * (1.0 - exp(-dtau));
         double eps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -2449,7 +2456,7 @@ static float optical_length_tot(const oracle_model *m, int lambda, double x, dou
     icell0 = next_cell;
     const double x0 = x1, y0 = y1, z0 = z1;
     if (oracle_test_exit_grid_cyl(m, icell0, x0, y0, z0)) return (float)tau_tot;
-    const double opacity = (icell0 <= m->n_cells && icell0 >= 1) ? m->kappa[lambda - 1] * m->kappa_factor[icell0 - 1] : 0.0;
+    const double opacity = (icell0 <= m->n_cells && icell0 >= 1) ? tab_kappa(m, icell0, lambda) * m->kappa_factor[icell0 - 1] : 0.0;
     double l, l_contrib, l_void;
     oracle_cross_cylindrical_cell(m, x0, y0, z0, u, v, w, icell0, previous_cell, &x1, &y1, &z1, &next_cell, &l, &l_contrib,
                                   &l_void);
@@ -2459,7 +2466,7 @@ static float optical_length_tot(const oracle_model *m, int lambda, double x, dou
 
 int oracle_stars_map_sed(const oracle_model *m, const oracle_rt_opts *o, uint64_t seed, const double *star_flux,
                          double *out) {
-  if (m->grid_type != 1 || m->p_n_cells) return 31;
+  if (m->grid_type != 1) return 31;
   enum { NXS = 10, NS = 21, N_RAY_SED = 1024 };
   const int nRT = m->RT_n_incl * m->RT_n_az;
   const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};

@@ -188,6 +188,7 @@ typedef struct {
   const float *v_s12_o_s11, *v_s22_o_s11, *v_s33_o_s11, *v_s34_o_s11, *v_s44_o_s11; /* likewise */
   const float *v_tab_g_pos;       /* (p_n_cells, n_lambda) */
   const double *r_lim;         /* [0..n_rad] (cylindrical_grid.f90:22), read by distance_to_closest_wall_cyl */
+  const float *v_tab_s11_pos;     /* (0:nang, p_n_cells, n_lambda): the classes' phase function for rt1 (SED mode; may be NULL) */
 } oracle_model;
 
 /* Run options. */

@@ -1,0 +1,100 @@
+"""lvariable_dust beyond the temperature step (VERDICT r02 missing #3): the SED-mode packet loop (forced scattering with
+the albedo of the crossed cell's class, its cumulative scattering table of p_lambda, rt1 deposits with
+tab_s11_pos(it, p_icell, p_lambda), dust_ray_tracing.f90:503-512), repartition_energie and the ray tracer (kappa,
+albedo, kappa_abs_LTE per class) against the CPU oracle, on tables built from grains by opacity()'s restatement:
+every cell its own dust (p_icell = identity, kappa_factor = 1), polarised / unpolarised / Henyey-Greenstein / 3D."""
+import numpy as np
+import pytest
+
+from helpers import xI_close
+from mcfost_amd.host import model as M
+
+pytestmark = pytest.mark.gpu
+
+
+def _vd_model(n_thermal=50000, **kw):
+    from oracle import Oracle
+    m = M.build_model(M.small(n_rad=10, nz=5, **kw))
+    g = M.synthetic_grains(m, n_grains=10)
+    p_icell, dens = M.settled_grain_density(m, g)
+    m.kappa_factor = np.ones_like(m.kappa_factor)
+    m.p_lambda_fixed = 0            # SED mode: p_lambda = lambda, every wavelength its own cumulative table
+    o0 = Oracle(m, 1000)
+    t = o0.opacity(g, dens)
+    lq, cdf = o0.init_reemission(kappa_abs_LTE=t["kappa_abs_LTE"].T)
+    M.variable_dust_from_opacity(m, p_icell, t, lq, cdf)
+    orc = Oracle(m, n_thermal)
+    T = orc.temp_finale(orc.run_thermal(n_thermal, seed=3, n_threads=1)["E_abs"])
+    M.repartition_energie(m, T)
+    m.extra["Tdust"] = T
+    return m, g, p_icell, dens
+
+
+def _check_mono(m, lam, n2, seed, n_chunks=32):
+    from oracle import Oracle
+    from mcfost_amd.engine import Engine
+    e, o = Engine(m, 1e5), Oracle(m, 1e5)
+    a = e.run_mono(lam, n2, seed=seed, n_chunks=n_chunks)
+    b = o.run_mono(lam, n2, seed=seed, n_chunks=n_chunks, n_threads=8)
+    assert np.array_equal(a["n_sent_chunk"], b["n_sent_chunk"])
+    assert a["counters"] == b["counters"]
+    assert np.array_equal(a["sed"][4], b["sed"][4])
+    for t in (0, 5, 6, 7, 8):
+        assert np.allclose(a["sed"][t], b["sed"][t], rtol=1e-11, atol=1e-11), t
+    pola = m.cfg.lsepar_pola and m.cfg.aniso_method == 1
+    xI_close(a["xI_scatt"], b["xI_scatt"], n_midplane_cells=0 if m.cfg.l3D else m.cfg.n_rad,
+             rtol=3e-5 if pola else 1e-6, atol_rel=1e-6 if pola else 1e-8)
+    return e, o, a, b
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(lsepar_pola=False), dict(aniso_method=2, lsepar_pola=False),
+                                dict(n_az=4, l3D=True)])
+def test_sed_mode_on_variable_dust(kw):
+    m, g, p_icell, dens = _vd_model(**kw)
+    # the classes differ: the albedo at 1 micron varies over the cells
+    alb = np.asarray(m.variable_dust["albedo"]).reshape(m.n_lambda, -1)
+    assert alb[9].max() - alb[9].min() > 0.02
+    for lam in (3, 9, 14):
+        e, o, a, b = _check_mono(m, lam, 40, 70 + lam)
+        # repartition_energie on the device reads kappa_abs_LTE per class: the oracle's table to rounding
+        d = e.repartition_energie(lam, m.extra["Tdust"])
+        r = o.repartition_energie(lam, m.extra["Tdust"])
+        assert np.isclose(d["frac_E_stars"], r["frac_E_stars"], rtol=1e-12)
+        assert np.allclose(d["prob_E_cell"], r["prob_E_cell"], rtol=1e-12, atol=1e-15)
+        e.close()
+
+
+def test_ray_tracer_on_variable_dust():
+    """mcgpu_rt1_dust_map (kappa, albedo, J_th per class) and the stars' term (optical depths through the classes)."""
+    m, g, p_icell, dens = _vd_model(RT_n_incl=3)
+    for lam in (3, 12):
+        e, o, a, b = _check_mono(m, lam, 40, 5 + lam)
+        x = a["xI_scatt"].copy()
+        x[:m.cfg.n_rad] = x[:m.cfg.n_rad].mean(axis=3, keepdims=True)   # (psup in the midplane layer: helpers.xI_close)
+        e.set_xI(x)
+        ns, Ed = a["n_sent"][lam - 1], m.extra["E_disk"][lam - 1]
+        got, ms = e.dust_map_sed(lam, m.extra["Tdust"], ns, Ed)
+        ref = o.dust_map_sed(lam, e.fetch_xI(), m.extra["Tdust"], ns, Ed, n_threads=8)
+        assert (ref[:, 0] > 0).all()
+        assert np.allclose(got, ref, rtol=1e-9, atol=1e-13 * np.abs(ref).max()), np.abs(got / ref - 1).max()
+        flux = np.array([3.0])
+        s_dev = e.stars_map_sed(lam, flux, seed=4)
+        s_ref = o.stars_map_sed(lam, flux, seed=4)
+        assert np.allclose(s_dev, s_ref, rtol=1e-6), (s_dev, s_ref)
+        e.close()
+
+
+def test_device_built_tables_give_the_same_sed_step():
+    """grains -> mcgpu_opacity (tables built in HBM, tab_s11_pos included) -> SED step == the step on uploaded tables."""
+    from mcfost_amd.engine import Engine
+    m, g, p_icell, dens = _vd_model()
+    e1 = Engine(m, 1e5)
+    a1 = e1.run_mono(9, 40, seed=2, n_chunks=16)
+    e1.close()
+    e2 = Engine(m, 1e5)
+    e2.opacity(g, p_icell, dens, fetch=False)
+    e2.init_reemission(fetch=False)
+    a2 = e2.run_mono(9, 40, seed=2, n_chunks=16)
+    e2.close()
+    assert np.array_equal(a1["n_sent_chunk"], a2["n_sent_chunk"]) and a1["counters"] == a2["counters"]
+    assert np.allclose(a1["xI_scatt"], a2["xI_scatt"], rtol=1e-6, atol=1e-9 * np.abs(a1["xI_scatt"]).max())
