@@ -572,6 +572,23 @@ int mcgpu_opacity(mcgpu_ctx *ctx, const mcgpu_grain_tables *grains, int p_n_cell
                   const double *dust_density_o_n_grains, const mcgpu_opacity_tables *out);
 
 /*
+ * Scattering method 1 (lscattering_method1; dust_transfer.f90:1288-1316): at every scattering of the temperature step
+ * the grain that scatters is drawn from the local population -- select_scattering_grain (dust_prop.f90:1292-1336,
+ * low_mem_scattering: the CDF of C_sca(k, lambda) n(k, p_icell) is walked on the fly from the small or from the big
+ * grains) -- and the packet scatters off that grain: angle_diff_theta in prob_s11(lambda, igrain, :) (scattering.f90:
+ * 1387-1429) and get_Mueller_matrix_per_grain (:1302-1324), or hg(tab_g(igrain, lambda)).  The reference selects it by
+ * itself when the per-cell tables of method 2 would exceed max_mem (scattering.f90:39-66): lvariable_dust with many
+ * cells; the SED / image step always uses method 2 (lmono, :52-59), so mcgpu_run_mono ignores this setting.
+ * Needs a variable-dust context (the opacities and albedo per class: mcgpu_set_variable_dust without scattering
+ * tables, or mcgpu_opacity).  grains: C_sca, n_grains_k, and tab_g (aniso_method 2) or -- aniso_method 1 -- prob_s11
+ * (n_lambda, n_grains, 0:nang) (grains.f90:53) and, with lsepar_pola, tab_s11 .. tab_s44 in the normalisation of method 1
+ * (divided by s11, tab_s11 = 1: normalise_Mueller_matrix, scattering.f90:540-555); dust_density_o_n_grains
+ * (n_grains, p_n_cells) with p_n_cells the context's classes.  grains = NULL: back to method 2.
+ */
+int mcgpu_set_scattering_method1(mcgpu_ctx *ctx, const mcgpu_grain_tables *grains, const float *prob_s11,
+                                 int p_n_cells, const double *dust_density_o_n_grains);
+
+/*
  * The optional accumulators of save_radiation_field's thermal branch (radiation_field.f90:54-55):
  *   xN_abs[n_cells]             path segments per cell (xN_abs(icell,1,id) with lmcfost_lib: what run_mcfost_phantom
  *                               returns, mcfost2phantom.f90:361), summed over "threads"

@@ -154,6 +154,15 @@ struct DevModel {
   const float* v_s33;
   const float* v_s34;
   const float* v_s44;
+  // scattering method 1 (lscattering_method1, dust_transfer.f90:1288-1316; mcgpu_set_scattering_method1): the grain that
+  // scatters is drawn from the cell's population, then its own phase function and Mueller matrix are used
+  int m1, m1_ng;
+  const float* m1_Csca;      // C_sca(n_grains, n_lambda)
+  const double* m1_nk;       // n_grains(k)
+  const double* m1_dens;     // dust_density_o_n_grains(n_grains, class)
+  const float* m1_prob;      // [n_lambda][n_grains][nang+1] cumulative phase function of the grain
+  const float* m1_g;         // tab_g(n_grains, n_lambda)
+  const float *m1_s11, *m1_s12, *m1_s22, *m1_s33, *m1_s34, *m1_s44;  // tab_s1x(0:nang, n_grains, n_lambda)
 };
 
 // packet state word of the queue records: state | flags
@@ -960,7 +969,7 @@ __device__ inline void rotation(double xinit, double yinit, double zinit, double
 // (:1328-1350) folded in: M11 = 1, M12 = M21, M34 = -M43.
 __device__ inline void update_stokes(double S[4], double u0, double v0, double w0, double u1, double v1,
                                      double w1, double M12, double M22, double M33, double M34,
-                                     double M44) {
+                                     double M44, double M11 = 1.0) {
   double v1pi, v1pj, v1pk;
   rotation(u0, v0, w0, u1, v1, w1, v1pi, v1pj, v1pk);
   float xnyp = (float)sqrt(v1pk * v1pk + v1pj * v1pj);
@@ -977,8 +986,8 @@ __device__ inline void update_stokes(double S[4], double u0, double v0, double w
   if (fabsf(sinw) < 1e-06f) sinw = 0.0f;
   const double cw = (double)cosw, sw = (double)sinw;
   double C0 = S[0], C1 = cw * S[1] - sw * S[2], C2 = sw * S[1] + cw * S[2], C3 = S[3];
-  // D = M*C with M = [[1,M12,0,0],[M12,M22,0,0],[0,0,M33,M34],[0,0,-M34,M44]]
-  double D0 = C0 + M12 * C1;
+  // D = M*C with M = [[M11,M12,0,0],[M12,M22,0,0],[0,0,M33,M34],[0,0,-M34,M44]] (M11 = 1 but for scattering method 1)
+  double D0 = M11 * C0 + M12 * C1;
   double D1 = M12 * C0 + M22 * C1;
   double D2 = M33 * C2 + M34 * C3;
   double D3 = -M34 * C2 + M44 * C3;
@@ -988,7 +997,7 @@ __device__ inline void update_stokes(double S[4], double u0, double v0, double w
   S[2] = -sw * D1 + cw * D2;
   S[3] = D3;
   if (S[0] > TINY_REAL) {
-    double f = 1.0 * S1_0 / S[0];
+    double f = M11 * S1_0 / S[0];
     S[0] *= f; S[1] *= f; S[2] *= f; S[3] *= f;
   }
 }
@@ -1224,6 +1233,32 @@ __device__ inline int reemission_wavelength(const Lds& T, const DevModel& M, int
 // (returns true for a scattering, with the angle bin `itheta` and the draw `rand2` the Stokes update needs);
 // interact_stokes: update_Stokes for a scattering with the interpolated Mueller ratios, Q = U = V = 0 after a
 // re-emission.
+// select_scattering_grain (dust_prop.f90:1292-1336, low_mem_scattering): walk the CDF of C_sca n over the grain sizes of
+// the cell's class from the small grains (rand < 0.5) or from the big ones; k_sca = kappa albedo / (AU_to_cm mum_to_cm^2)
+__device__ inline int select_scattering_grain(const DevModel& M, int cls, int lambda, float rand, double norm) {
+  const int ng = M.m1_ng;
+  const double* d = M.m1_dens + (size_t)ng * cls;
+  const float* Cs = M.m1_Csca + (size_t)ng * (lambda - 1);
+  double CDF = 0.0;
+  int k;
+  if (rand < 0.5f) {
+    const double prob = (double)rand * norm;
+    for (k = 1; k <= ng; ++k) {
+      CDF = CDF + (double)Cs[k - 1] * (d[k - 1] * M.m1_nk[k - 1]);
+      if (CDF > prob) break;
+    }
+    if (k > ng) k = ng;
+  } else {
+    const double prob = (double)(1.0f - rand) * norm;
+    for (k = ng; k >= 1; --k) {
+      CDF = CDF + (double)Cs[k - 1] * (d[k - 1] * M.m1_nk[k - 1]);
+      if (CDF > prob) break;
+    }
+    if (k < 1) k = 1;
+  }
+  return k;
+}
+
 template <typename EnergyFn>
 __device__ __forceinline__ bool interact_direction(const Lds& T, const DevModel& M, const float g[8], int& lambda,
                                                    double u, double v, double w, double& u1, double& v1, double& w1,
@@ -1231,16 +1266,34 @@ __device__ __forceinline__ bool interact_direction(const Lds& T, const DevModel&
                                                    unsigned int& c_abs, EnergyFn cell_energy,
                                                    const double* volume_of_cell, int& itheta, float& rand2_out,
                                                    bool forced = false, const float* prob_forced = nullptr,
-                                                   int lds_col = -1) {
+                                                   int lds_col = -1, int m1_cls = -1, int* igrain_out = nullptr) {
   const bool scat = forced || (g[0] < T.albedo[lambda - 1]);  // dust_transfer.f90:1284
-  const float rand = g[1], rand2 = g[2];
+  // scattering method 1 (m1_cls >= 0: the cell's class): the draws are grain, angle, angle, azimuth (dust_transfer.f90:1289-1297)
+  const bool m1 = M.m1 != 0 && m1_cls >= 0;
+  const float rand = m1 ? g[2] : g[1], rand2 = m1 ? g[3] : g[2], rand_phi = m1 ? g[4] : g[3];
   itheta = 1;
   rand2_out = rand2;
   double cospsi, phi;
   if (scat) {
     flag_scatt = true;
     c_scatt++;
-    if (M.aniso_method == 1) {
+    int igrain = 0;
+    if (m1) {
+      igrain = select_scattering_grain(M, m1_cls, lambda, g[1], T.kappa[lambda - 1] * (double)T.albedo[lambda - 1] / (149597870700.0 * 100.0 * (1.0e-4 * 1.0e-4)));
+      if (igrain_out) *igrain_out = igrain;
+    }
+    if (m1 && M.aniso_method == 1) {
+      // angle_diff_theta (scattering.f90:1387-1429) in the grain's own cumulative phase function
+      const float* prob = M.m1_prob + ((size_t)(lambda - 1) * M.m1_ng + (igrain - 1)) * (size_t)(M.nang + 1);
+      int kmin = 0, kmax = M.nang, kk = (kmin + kmax) / 2;
+      while ((kmax - kmin) > 1) {
+        if (prob[kk] < rand) kmin = kk; else kmax = kk;
+        kk = (kmin + kmax) / 2;
+      }
+      itheta = kmax;
+      const double c0 = T.cost[itheta - 1], c1 = T.cost[itheta];
+      cospsi = c0 + (double)rand2 * (c1 - c0);
+    } else if (M.aniso_method == 1) {
       // angle_diff_theta_pos (scattering.f90:1433-1475)
       // (lds_col >= 0: that column of T.prob -- the SED-mode tables hold only column p_lambda, as column 0)
       const size_t col = lds_col >= 0 ? (size_t)lds_col : (M.p_lambda_fixed ? (size_t)0 : (size_t)(lambda - 1));
@@ -1254,8 +1307,8 @@ __device__ __forceinline__ bool interact_direction(const Lds& T, const DevModel&
       const double c0 = T.cost[itheta - 1], c1 = T.cost[itheta];
       cospsi = c0 + (double)rand2 * (c1 - c0);
     } else {
-      // hg (scattering.f90:1354-1383)
-      const float gg = T.g[lambda - 1];
+      // hg (scattering.f90:1354-1383); method 1: with the grain's asymmetry parameter (dust_transfer.f90:1307)
+      const float gg = m1 ? M.m1_g[(size_t)(igrain - 1) + (size_t)M.m1_ng * (lambda - 1)] : T.g[lambda - 1];
       const double rand_dp = fmin((double)rand, 1.0 - 1e-6);
       if (fabsf(gg) > 1.17549435e-38f) {
         const double g1 = (double)gg, g2 = g1 * g1;
@@ -1267,8 +1320,8 @@ __device__ __forceinline__ bool interact_direction(const Lds& T, const DevModel&
       itheta = (int)floor(acos(cospsi) * 180.0 / PI) + 1;
       if (itheta > M.nang) itheta = M.nang;
     }
-    if (M.lisotropic) { itheta = 1; cospsi = 2.0 * (double)rand - 1.0; }
-    phi = PI * (2.0 * (double)g[3] - 1.0);
+    if (M.lisotropic && !(m1 && M.aniso_method == 1)) { itheta = 1; cospsi = 2.0 * (double)rand - 1.0; }
+    phi = PI * (2.0 * (double)rand_phi - 1.0);
   } else {
     c_abs++;
     flag_star = false;
@@ -1278,7 +1331,7 @@ __device__ __forceinline__ bool interact_direction(const Lds& T, const DevModel&
     int Ti;
     double frac_T2;
     temp_lte(T.lq, M.n_T, E, M.L_packet_th, *volume_of_cell, Ti, frac_T2);
-    lambda = reemission_wavelength(T, M, Ti, frac_T2, rand2);
+    lambda = reemission_wavelength(T, M, Ti, frac_T2, g[2]);
     // random_isotropic_direction (random_numbers.f90:32-51): w = 2r-1, (u,v) = sqrt(1-w^2)
     // (cos,sin)(phi) is cdapres' own |w0| > 0.999999 branch applied to the z axis
     cospsi = 2.0 * (double)g[3] - 1.0;
@@ -1293,8 +1346,19 @@ __device__ __forceinline__ bool interact_direction(const Lds& T, const DevModel&
 // cls >= 0: the Mueller ratios of that cell class (lvariable_dust with per-class scattering tables)
 __device__ __forceinline__ void interact_stokes(const DevModel& M, bool scat, int lambda, int itheta, float rand2,
                                                 double u, double v, double w, double u1, double v1, double w1,
-                                                double S[4], int cls = -1) {
-  if (scat && M.aniso_method == 1) {
+                                                double S[4], int cls = -1, int igrain = 0) {
+  if (scat && M.aniso_method == 1 && igrain > 0) {
+    // get_Mueller_matrix_per_grain (scattering.f90:1302-1324): the grain's own matrix, s11 included
+    const size_t o = (size_t)(M.nang + 1) * ((size_t)(igrain - 1) + (size_t)M.m1_ng * (lambda - 1)) + itheta;
+    const float fr = rand2, fm = 1.0f - rand2;
+    const double M11 = (double)(M.m1_s11[o] * fr + M.m1_s11[o - 1] * fm);
+    const double M22 = (double)(M.m1_s22[o] * fr + M.m1_s22[o - 1] * fm);
+    const double M12 = (double)(M.m1_s12[o] * fr + M.m1_s12[o - 1] * fm);
+    const double M33 = (double)(M.m1_s33[o] * fr + M.m1_s33[o - 1] * fm);
+    const double M44 = (double)(M.m1_s44[o] * fr + M.m1_s44[o - 1] * fm);
+    const double M34 = (double)(-M.m1_s34[o] * fr - M.m1_s34[o - 1] * fm);
+    update_stokes(S, u, v, w, u1, v1, w1, M12, M22, M33, M34, M44, M11);
+  } else if (scat && M.aniso_method == 1) {
     const size_t o = (size_t)(M.nang + 1) * (lambda - 1) + itheta;
     const float fr = rand2, fm = 1.0f - rand2;
     const size_t co = cls >= 0 ? (size_t)cls * M.n_lambda * (M.nang + 1) : 0;
@@ -1319,13 +1383,14 @@ __device__ __forceinline__ void interact(const Lds& T, const DevModel& M, const 
                                          double S[4], bool& flag_star, bool& flag_scatt,
                                          unsigned int& c_scatt, unsigned int& c_abs, EnergyFn cell_energy,
                                          const double* volume_of_cell, bool forced = false,
-                                         const float* prob_forced = nullptr, int lds_col = -1, int mueller_class = -1) {
-  int itheta;
+                                         const float* prob_forced = nullptr, int lds_col = -1, int mueller_class = -1,
+                                         int m1_cls = -1) {
+  int itheta, igrain = 0;
   float rand2;
   const int lambda_in = lambda;
   const bool scat = interact_direction(T, M, g, lambda, u, v, w, u1, v1, w1, flag_star, flag_scatt, c_scatt, c_abs,
-                                       cell_energy, volume_of_cell, itheta, rand2, forced, prob_forced, lds_col);
-  if (POLA) interact_stokes(M, scat, lambda_in, itheta, rand2, u, v, w, u1, v1, w1, S, mueller_class);
+                                       cell_energy, volume_of_cell, itheta, rand2, forced, prob_forced, lds_col, m1_cls, &igrain);
+  if (POLA) interact_stokes(M, scat, lambda_in, itheta, rand2, u, v, w, u1, v1, w1, S, mueller_class, igrain);
 }
 
 // ---------------------------------------------------------------------------
@@ -1652,7 +1717,7 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
           E *= A.qscale;
         }
         return E;
-      }, M.volume + ic, false, nullptr, -1, (VAR && M.v_scatt) ? M.cell_class[ic] : -1);
+      }, M.volume + ic, false, nullptr, -1, (VAR && M.v_scatt) ? M.cell_class[ic] : -1, (VAR && M.m1) ? M.cell_class[ic] : -1);
       if (!flag_scatt) flag_ism = false;  // absorbed and re-emitted by the dust (:1367)
       u = u1; v = v1; w = w1;
       if (MRW) {

@@ -666,6 +666,7 @@ extern "C" int mcgpu_set_variable_dust(mcgpu_ctx* ctx, int p_n_cells, const int*
   DevModel& M = ctx->M;
   if (p_n_cells == 0) {  // back to one class (what the class tables were waiting for no longer matters)
     M.n_classes = 0;
+    M.m1 = 0;
     ctx->pending_classes = false;
     ctx->reemission_pending = ctx->pending_single;
     return MCGPU_OK;
@@ -709,6 +710,7 @@ extern "C" int mcgpu_set_variable_dust(mcgpu_ctx* ctx, int p_n_cells, const int*
   // scattering tables per class (all or none): (0:nang, p_n_cells, n_lambda) in the reference -> [class][lambda][angle]
   M.v_scatt = 0;
   M.v_s11 = nullptr;
+  M.m1 = 0;  // (scattering method 1 belongs to a set of classes: mcgpu_set_scattering_method1 again)
   const bool any_sc = prob_s11_pos || tab_s12_o_s11_pos || tab_s22_o_s11_pos || tab_s33_o_s11_pos || tab_s34_o_s11_pos ||
                       tab_s44_o_s11_pos || tab_g_pos;
   if (any_sc) {
@@ -752,6 +754,42 @@ extern "C" int mcgpu_set_variable_dust_s11(mcgpu_ctx* ctx, const float* tab_s11_
     for (int l = 0; l < nl; ++l)
       std::memcpy(&t[((size_t)c * nl + l) * na1], &tab_s11_pos[((size_t)l * nc + c) * na1], na1 * sizeof(float));
   return upload(ctx, t.data(), t.size(), &M.v_s11);
+}
+
+// scattering method 1 (dust_transfer.f90:1288-1316): see include/mcgpu.h
+extern "C" int mcgpu_set_scattering_method1(mcgpu_ctx* ctx, const mcgpu_grain_tables* G, const float* prob_s11,
+                                            int p_n_cells, const double* dust_density_o_n_grains) {
+  if (!ctx) return MCGPU_ERR_ARG;
+  DevModel& M = ctx->M;
+  if (!G) { M.m1 = 0; return MCGPU_OK; }  // off: back to method 2
+  if (!M.n_classes) return fail(ctx, MCGPU_ERR_STATE, "scattering method 1 runs on a variable-dust context: mcgpu_set_variable_dust or mcgpu_opacity first");
+  if (p_n_cells != M.n_classes || !dust_density_o_n_grains) return fail(ctx, MCGPU_ERR_ARG, "mcgpu_set_scattering_method1: the densities of the context's classes");
+  const int ng = G->n_grains, nl = M.n_lambda, na1 = M.nang + 1;
+  const bool mueller = M.aniso_method == 1, pola = ctx->lsepar_pola != 0;
+  if (ng < 1 || !G->C_sca || !G->n_grains_k || (mueller && !prob_s11) || (!mueller && !G->tab_g) ||
+      (mueller && pola && (!G->tab_s11 || !G->tab_s12 || !G->tab_s22 || !G->tab_s33 || !G->tab_s34 || !G->tab_s44)))
+    return fail(ctx, MCGPU_ERR_ARG, "mcgpu_set_scattering_method1: a grain table is missing");
+  HIPCHK(hipSetDevice(ctx->device));
+  int rc;
+  const size_t n_gl = (size_t)ng * nl, n_agl = n_gl * na1;
+  if ((rc = upload(ctx, G->C_sca, n_gl, &M.m1_Csca)) || (rc = upload(ctx, G->n_grains_k, (size_t)ng, &M.m1_nk)) ||
+      (rc = upload(ctx, dust_density_o_n_grains, (size_t)ng * p_n_cells, &M.m1_dens)))
+    return rc;
+  if (mueller) {
+    // prob_s11(n_lambda, n_grains, 0:nang) -> [lambda][grain][angle]: the bisection of one (wavelength, grain) walks one row
+    std::vector<float> t(n_agl);
+    for (int l = 0; l < nl; ++l)
+      for (int k = 0; k < ng; ++k)
+        for (int a = 0; a < na1; ++a) t[((size_t)l * ng + k) * na1 + a] = prob_s11[(size_t)l + (size_t)nl * ((size_t)k + (size_t)ng * a)];
+    if ((rc = upload(ctx, t.data(), t.size(), &M.m1_prob))) return rc;
+    if (pola && ((rc = upload(ctx, G->tab_s11, n_agl, &M.m1_s11)) || (rc = upload(ctx, G->tab_s12, n_agl, &M.m1_s12)) ||
+                 (rc = upload(ctx, G->tab_s22, n_agl, &M.m1_s22)) || (rc = upload(ctx, G->tab_s33, n_agl, &M.m1_s33)) ||
+                 (rc = upload(ctx, G->tab_s34, n_agl, &M.m1_s34)) || (rc = upload(ctx, G->tab_s44, n_agl, &M.m1_s44))))
+      return rc;
+  } else if ((rc = upload(ctx, G->tab_g, n_gl, &M.m1_g))) return rc;
+  M.m1_ng = ng;
+  M.m1 = 1;
+  return MCGPU_OK;
 }
 
 // opacity + calc_local_scattering_matrices on the device (dust_prop.f90:791-1243): see include/mcgpu.h
@@ -801,6 +839,7 @@ extern "C" int mcgpu_opacity(mcgpu_ctx* ctx, const mcgpu_grain_tables* G, int p_
   }
   ctx->opacity_allocs.clear();
   M.n_classes = 0;
+  M.m1 = 0;
   const size_t allocs_before = ctx->allocs.size();
   std::vector<int> cls(M.n_cells);
   for (int i = 0; i < M.n_cells; ++i) cls[i] = p_icell[i] - 1;

@@ -36,7 +36,7 @@ ABI_SYMBOLS = (
     "mcgpu_device_xI", "mcgpu_set_ism", "mcgpu_rt1_dust_map", "mcgpu_set_xI", "mcgpu_rt1_image", "mcgpu_set_xI_precision",
     "mcgpu_get_xI_precision", "mcgpu_set_option", "mcgpu_get_info", "mcgpu_counters_to_accum", "mcgpu_counters_from_accum",
     "mcgpu_set_grid_sph", "mcgpu_temp_approx_diffusion_vertical", "mcgpu_set_mrw", "mcgpu_fetch_radiation_field", "mcgpu_set_variable_dust", "mcgpu_rt1_stars_map_sed", "mcgpu_define_dark_zone", "mcgpu_init_reemission", "mcgpu_multi_create", "mcgpu_multi_destroy", "mcgpu_multi_size", "mcgpu_multi_ctx", "mcgpu_multi_last_error",
-    "mcgpu_repartition_energie", "mcgpu_opacity", "mcgpu_set_variable_dust_s11", "mcgpu_shard_packets", "mcgpu_multi_run_thermal", "mcgpu_multi_run_mono", "mcgpu_multi_rccl_ranks",
+    "mcgpu_repartition_energie", "mcgpu_opacity", "mcgpu_set_variable_dust_s11", "mcgpu_set_scattering_method1", "mcgpu_shard_packets", "mcgpu_multi_run_thermal", "mcgpu_multi_run_mono", "mcgpu_multi_rccl_ranks",
 )
 
 
@@ -266,6 +266,8 @@ class Engine:
             *[(_p(_a(vd[k], np.float32), C.c_float) if vd.get("prob_s11_pos") is not None else None)
               for k in ("prob_s11_pos", "s12_o_s11", "s22_o_s11", "s33_o_s11", "s34_o_s11", "s44_o_s11", "tab_g_pos")]),
             "mcgpu_set_variable_dust")
+        if getattr(self.model, "method1", None) is not None:
+            self.set_scattering_method1(self.model.method1)
         if vd.get("tab_s11_pos") is not None:   # the phase function of the rt1 deposits, per class
             self._chk(self.lib.mcgpu_set_variable_dust_s11(self.ctx, _p(_a(vd["tab_s11_pos"], np.float32), C.c_float)),
                       "mcgpu_set_variable_dust_s11")
@@ -300,6 +302,21 @@ class Engine:
         self._chk(self.lib.mcgpu_opacity(self.ctx, C.byref(G), C.c_int(nc), _p(_a(p_icell, np.int32), C.c_int),
                                          _p(dens, C.c_double), C.byref(O) if O is not None else None), "mcgpu_opacity")
         return out
+
+    def set_scattering_method1(self, m1):
+        """Scattering method 1 (``mcfost_amd.host.model.init_scattering_method1``): the scattering grain is drawn from
+        the cell's population (dust_transfer.f90:1288-1316); ``None``: back to method 2."""
+        if m1 is None:
+            self._chk(self.lib.mcgpu_set_scattering_method1(self.ctx, None, None, C.c_int(0), None), "mcgpu_set_scattering_method1")
+            return
+        f32 = np.float32
+        keep = [_a(m1[k], f32) for k in ("C_sca", "C_sca", "C_sca", "tab_g", "tab_s11", "tab_s12", "tab_s22", "tab_s33", "tab_s34",
+                                        "tab_s44", "C_sca")]
+        nk, dens, prob = _a(m1["n_grains_k"], np.float64), _a(m1["dens"], np.float64), _a(m1["prob_s11"], f32)
+        G = GrainTables(int(m1["n_grains"]), 1, int(m1["n_grains"]), *[_p(v, C.c_float) for v in keep[:10]], _p(keep[10], C.c_float),
+                        _p(nk, C.c_double))
+        self._chk(self.lib.mcgpu_set_scattering_method1(self.ctx, C.byref(G), _p(prob, C.c_float), C.c_int(dens.shape[0]),
+                                                        _p(dens, C.c_double)), "mcgpu_set_scattering_method1")
 
     def init_reemission(self, fetch=True):
         """``init_reemission`` (thermal_emission.f90:404-550) on the device: rebuilds ``log_Qcool_minus_extra_heating``

@@ -88,7 +88,7 @@ module mcgpu_f
        mcgpu_run_mono, mcgpu_fetch, mcgpu_fetch_xI, mcgpu_rt1_dust_map, mcgpu_set_xI, mcgpu_rt1_image, mcgpu_set_xI_precision, &
        mcgpu_set_E_prior, mcgpu_multi_create, mcgpu_multi_destroy, mcgpu_multi_size, mcgpu_multi_ctx, mcgpu_multi_run_thermal, mcgpu_multi_run_mono, mcgpu_multi_rccl_ranks, &
        mcgpu_counters_to_accum, mcgpu_counters_from_accum, mcgpu_temp_approx_diffusion_vertical, mcgpu_set_mrw, mcgpu_fetch_radiation_field, &
-       mcgpu_set_variable_dust, mcgpu_rt1_stars_map_sed, mcgpu_define_dark_zone, mcgpu_init_reemission, mcgpu_repartition_energie, mcgpu_opacity, mcgpu_set_variable_dust_s11
+       mcgpu_set_variable_dust, mcgpu_rt1_stars_map_sed, mcgpu_define_dark_zone, mcgpu_init_reemission, mcgpu_repartition_energie, mcgpu_opacity, mcgpu_set_variable_dust_s11, mcgpu_set_scattering_method1
 
   interface
      integer(c_int) function mcgpu_create(device, ctx) bind(C, name="mcgpu_create")
@@ -398,6 +398,17 @@ module mcgpu_f
        real(c_double), intent(out) :: frac_E_stars, frac_E_disk, E_disk
        type(c_ptr), value :: prob_E_cell             ! c_loc(prob_E_cell(0,lambda)) or c_null_ptr
      end function mcgpu_repartition_energie
+
+     ! lscattering_method1 (scattering.f90:39-66 chose it): the grains' tables of method 1 and the local densities
+     integer(c_int) function mcgpu_set_scattering_method1(ctx, grains, prob_s11, p_n_cells, dust_density_o_n_grains) &
+          bind(C, name="mcgpu_set_scattering_method1")
+       import :: c_int, c_ptr, c_float, c_double, mcgpu_grain_tables
+       type(c_ptr), value :: ctx
+       type(mcgpu_grain_tables), intent(in) :: grains
+       real(c_float), intent(in) :: prob_s11(*)                 ! (n_lambda, n_grains_tot, 0:nang_scatt)
+       integer(c_int), value :: p_n_cells
+       real(c_double), intent(in) :: dust_density_o_n_grains(*)
+     end function mcgpu_set_scattering_method1
 
      integer(c_int) function mcgpu_set_variable_dust_s11(ctx, tab_s11_pos) bind(C, name="mcgpu_set_variable_dust_s11")
        import :: c_int, c_ptr, c_float

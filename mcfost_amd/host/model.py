@@ -616,6 +616,7 @@ class Model:
     ism: Optional[dict] = None   # {"R_ISM": float, "centre_ISM": (3,)} (stars.f90:27-28); None: no ISM field
     mrw: Optional[dict] = None   # tables of the modified random walk (init_mrw); None: off
     variable_dust: Optional[dict] = None   # per-class tables of lvariable_dust (init_variable_dust); None: one class
+    method1: Optional[dict] = None         # scattering method 1 (init_scattering_method1); None: method 2
 
     @property
     def capt_sup(self):
@@ -835,6 +836,34 @@ def variable_dust_from_opacity(m: "Model", p_icell, tabs: dict, lq=None, cdf=Non
     vd["tab_s11_pos"] = np.asarray(tabs["tab_s11_pos"], f32).reshape(-1)
     m.variable_dust = vd
     return vd
+
+
+def init_scattering_method1(m: "Model", grains: dict, dens):
+    """Scattering method 1 (dust_transfer.f90:1288-1316): the per-grain tables in the normalisation
+    ``normalise_Mueller_matrix`` gives them for this method (scattering.f90:515-555) -- ``prob_s11(n_lambda, n_grains,
+    0:nang)``, the cumulative of s11 sin(theta) dtheta with the unresolved forward peak (here: what the quadrature misses of
+    Q_sca) added from bin 1 on, normalised to 1; ``tab_s1x = s1x / s11`` with ``tab_s11 = 1`` -- from ``synthetic_grains``'s
+    tables (which are normalised to Q_sca, method 2's convention).  Host-side Mie set-up: inputs, not algorithm."""
+    na1 = NANG_SCATT + 1
+    th = np.arange(na1) * (PI / NANG_SCATT)
+    dtheta = PI / NANG_SCATT
+    s11 = np.asarray(grains["tab_s11"], f64)                           # [nl, ng, na1]
+    inc = s11 * np.sin(th) * dtheta
+    prob = np.zeros_like(s11)
+    prob[..., 2:] = np.cumsum(inc[..., 2:], axis=-1)
+    qsca = (np.asarray(grains["C_sca"], f64) / np.asarray(grains["S_grain"], f64)[None, :])
+    norm = np.maximum(qsca, prob[..., NANG_SCATT])                      # "normalization" >= the numerical integral
+    prob[..., 1:] += (norm - prob[..., NANG_SCATT])[..., None]
+    prob /= prob[..., NANG_SCATT][..., None]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ratio = lambda k: np.where(s11 > 0, np.asarray(grains[k], f64) / s11, 0.0)
+        tabs = {k: np.ascontiguousarray(ratio(k), f32) for k in ("tab_s12", "tab_s22", "tab_s33", "tab_s34", "tab_s44")}
+    m.method1 = dict(n_grains=int(grains["n_grains"]), n_grains_k=np.asarray(grains["n_grains_k"], f64),
+                     dens=np.ascontiguousarray(dens, f64), C_sca=np.asarray(grains["C_sca"], f32),
+                     tab_g=np.asarray(grains["tab_g"], f32),
+                     prob_s11=np.ascontiguousarray(np.transpose(prob, (2, 1, 0)), f32),   # Fortran (n_lambda, n_grains, 0:nang)
+                     tab_s11=np.ones_like(s11, dtype=f32), **tabs)
+    return m.method1
 
 
 def cumulative_zeta(n: int = 10000):

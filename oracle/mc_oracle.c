@@ -1153,6 +1153,75 @@ static void get_mueller_matrix_per_cell(const oracle_model *m, int lambda,
 #undef INTERP
 }
 
+/* ---- scattering method 1: the scattering grain is drawn, then its own phase function (dust_transfer.f90:1288-1316) ---- */
+/* select_scattering_grain (dust_prop.f90:1292-1336), low_mem_scattering: the CDF of C_sca n over the grain sizes of the
+ * cell is walked on the fly, from the small grains when rand < 0.5, else from the big ones.  (A walk that rounding lets
+ * run off the end would index out of bounds in the reference: the last grain visited is returned here.) */
+int oracle_select_scattering_grain(const oracle_model *m, int lambda, int icell, float rand) {
+  const int ng = m->m1_n_grains;
+  const double AU_to_cm = 149597870700.0 * 100.0, mum_to_cm = 1.0e-4;
+  const double norm = tab_kappa(m, icell, lambda) * (double)tab_albedo(m, icell, lambda) / (AU_to_cm * (mum_to_cm * mum_to_cm));
+  const int cls = m->p_n_cells ? m->p_icell[icell - 1] - 1 : 0;
+  const double *d = m->m1_dens + (size_t)ng * cls;
+  const float *Cs = m->m1_C_sca + (size_t)ng * (lambda - 1);
+  double CDF = 0.0;
+  int k;
+  if (rand < 0.5f) {
+    const double prob = (double)rand * norm;
+    for (k = 1; k <= ng; ++k) {
+      const double density = d[k - 1] * m->m1_nk[k - 1];
+      CDF = CDF + (double)Cs[k - 1] * density;
+      if (CDF > prob) break;
+    }
+    if (k > ng) k = ng;
+  } else {
+    const double prob = (double)(1.0f - rand) * norm;
+    for (k = ng; k >= 1; --k) {
+      const double density = d[k - 1] * m->m1_nk[k - 1];
+      CDF = CDF + (double)Cs[k - 1] * density;
+      if (CDF > prob) break;
+    }
+    if (k < 1) k = 1;
+  }
+  return k;
+}
+
+/* angle_diff_theta (scattering.f90:1387-1429): prob_s11(lambda, igrain, 0:nang) */
+static void angle_diff_theta_grain(const oracle_model *m, int lambda, int igrain, float rand, float rand2, int *itheta,
+                                   double *cospsi) {
+  const int na = m->nang_scatt;
+  const size_t st = (size_t)m->n_lambda * m->m1_n_grains;   /* stride of the angle */
+  const float *prob = m->m1_prob_s11 + (size_t)(lambda - 1) + (size_t)m->n_lambda * (igrain - 1);
+  int kmin = 0, kmax = na, k = (kmin + kmax) / 2;
+  while ((kmax - kmin) > 1) {
+    if (prob[st * k] < rand) kmin = k; else kmax = k;
+    k = (kmin + kmax) / 2;
+  }
+  k = kmax;
+  *itheta = k;
+  const double c0 = cos(((double)k - 1.0) * PI / (double)na), c1 = cos(((double)k) * PI / (double)na);
+  *cospsi = c0 + (double)rand2 * (c1 - c0);
+}
+
+/* get_Mueller_matrix_per_grain (scattering.f90:1302-1324): tab_s1x(0:nang, n_grains, n_lambda), s11 included */
+static void get_mueller_matrix_per_grain(const oracle_model *m, int lambda, int itheta, float frac, int igrain, double M[16]) {
+  const size_t o = (size_t)(m->nang_scatt + 1) * ((size_t)(igrain - 1) + (size_t)m->m1_n_grains * (lambda - 1));
+  float frac_m1 = 1.0f - frac;
+  memset(M, 0, 16 * sizeof(double));
+#define MM(i, j) M[((i)-1) + 4 * ((j)-1)]
+#define INTERP(t) ((t)[o + itheta] * frac + (t)[o + itheta - 1] * frac_m1)
+  MM(1, 1) = (double)INTERP(m->m1_s11);
+  MM(2, 2) = (double)INTERP(m->m1_s22);
+  MM(1, 2) = (double)INTERP(m->m1_s12);
+  MM(2, 1) = MM(1, 2);
+  MM(3, 3) = (double)INTERP(m->m1_s33);
+  MM(4, 4) = (double)INTERP(m->m1_s44);
+  MM(3, 4) = (double)(-m->m1_s34[o + itheta] * frac - m->m1_s34[o + itheta - 1] * frac_m1);
+  MM(4, 3) = -MM(3, 4);
+#undef INTERP
+#undef MM
+}
+
 /* scattering.f90:1187-1298 */
 void oracle_update_stokes(double S[4], double u0, double v0, double w0,
                           double u1, double v1, double w1, const double M[16]) {
@@ -1829,13 +1898,28 @@ static void propagate_packet(worker_t *W, int *lambda, int p_lambda,
     if (rand < tab_albedo(m, *icell, *lambda)) {              /* :1284 */
       *flag_scatt = 1;
       W->cnt[ORC_CNT_SCATT]++;
+      int igrain = 0;
+      if (m->scattering_method1) {                            /* :1288-1290: the grain that scatters */
+        rand = rng_float(&W->rng);
+        igrain = oracle_select_scattering_grain(m, *lambda, *icell, rand);
+      }
       rand = rng_float(&W->rng);                              /* :1319 */
       float rand2 = rng_float(&W->rng);
       int itheta; double cospsi, u1, v1, w1;
       /* lvariable_dust with per-class scattering tables: (0:nang, p_n_cells, n_lambda) slices of the cell's class */
       const int vsc = m->p_n_cells && m->v_prob_s11_pos;
       const size_t vrow = vsc ? (size_t)(m->p_icell[*icell - 1] - 1) : 0;
-      if (m->aniso_method == 1) {
+      if (m->scattering_method1 && m->aniso_method == 1) {    /* :1294-1305: the grain's own Mie phase function */
+        angle_diff_theta_grain(m, *lambda, igrain, rand, rand2, &itheta, &cospsi);
+        rand = rng_float(&W->rng);
+        double phi = PI * (2.0 * (double)rand - 1.0);
+        oracle_cdapres(cospsi, phi, *u, *v, *w, &u1, &v1, &w1);
+        if (m->lsepar_pola) {
+          double M[16];
+          get_mueller_matrix_per_grain(m, *lambda, itheta, rand2, igrain, M);
+          oracle_update_stokes(Stokes, *u, *v, *w, u1, v1, w1, M);
+        }
+      } else if (m->aniso_method == 1) {
         int pl = (W->mono || m->p_lambda_fixed) ? p_lambda : *lambda;
         if (vsc) {
           oracle_model mv = *m; /* the class's column (p_icell, pl) as a one-column table */
@@ -1860,7 +1944,8 @@ static void propagate_packet(worker_t *W, int *lambda, int p_lambda,
           oracle_update_stokes(Stokes, *u, *v, *w, u1, v1, w1, M);
         }
       } else {
-        oracle_hg(vsc ? m->v_tab_g_pos[vrow + (size_t)m->p_n_cells * (*lambda - 1)] : m->tab_g_pos[*lambda - 1], rand, m->nang_scatt, &itheta,
+        oracle_hg(m->scattering_method1 ? m->m1_tab_g[(size_t)(igrain - 1) + (size_t)m->m1_n_grains * (*lambda - 1)] /* :1307 */
+                  : vsc ? m->v_tab_g_pos[vrow + (size_t)m->p_n_cells * (*lambda - 1)] : m->tab_g_pos[*lambda - 1], rand, m->nang_scatt, &itheta,
                   &cospsi);
         if (m->lisotropic) { itheta = 1; cospsi = 2.0 * (double)rand - 1.0; }
         rand = rng_float(&W->rng);

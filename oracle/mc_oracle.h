@@ -189,6 +189,15 @@ typedef struct {
   const float *v_tab_g_pos;       /* (p_n_cells, n_lambda) */
   const double *r_lim;         /* [0..n_rad] (cylindrical_grid.f90:22), read by distance_to_closest_wall_cyl */
   const float *v_tab_s11_pos;     /* (0:nang, p_n_cells, n_lambda): the classes' phase function for rt1 (SED mode; may be NULL) */
+  /* scattering method 1 (lscattering_method1, dust_transfer.f90:1288-1316): the scattering grain is drawn from the cell's
+   * population (select_scattering_grain, dust_prop.f90:1292-1336, low_mem_scattering), then its own tables are used */
+  int scattering_method1, m1_n_grains;
+  const float *m1_C_sca;          /* C_sca(n_grains, n_lambda) */
+  const double *m1_nk;            /* n_grains(k) */
+  const double *m1_dens;          /* dust_density_o_n_grains(n_grains, p_n_cells) (one column without lvariable_dust) */
+  const float *m1_prob_s11;       /* prob_s11(n_lambda, n_grains, 0:nang) (grains.f90:53) */
+  const float *m1_tab_g;          /* tab_g(n_grains, n_lambda) */
+  const float *m1_s11, *m1_s12, *m1_s22, *m1_s33, *m1_s34, *m1_s44; /* tab_s1x(0:nang, n_grains, n_lambda), per-grain normalisation (s11 = 1) */
 } oracle_model;
 
 /* Run options. */
@@ -351,6 +360,9 @@ int oracle_temp_approx_diffusion_vertical(const oracle_model *m, const double *t
 int oracle_init_reemission(int p_n_cells, int n_T, int n_lambda, const float *tab_Temp, const double *tab_lambda,
                            const double *tab_delta_lambda, const double *kappa_abs_LTE, double *log_Qcool,
                            double *kdB_dT_CDF);
+
+/* select_scattering_grain (dust_prop.f90:1292-1336) of the model's method-1 tables: 1-based grain for the draw `rand` */
+int oracle_select_scattering_grain(const oracle_model *m, int lambda, int icell, float rand);
 
 /* opacity(lambda, p_lambda = lambda) (dust_prop.f90:791-1033; LTE grains, no scattering suppression) followed by
  * calc_local_scattering_matrices (dust_prop.f90:1037-1243; scattering_method 2), for every wavelength: from the grains'

@@ -1,0 +1,104 @@
+"""Scattering method 1 (dust_transfer.f90:1288-1316 -- the scattering grain is drawn from the cell's
+population, select_scattering_grain dust_prop.f90:1292-1336, then its own phase function, angle_diff_theta
+scattering.f90:1387-1429, and Mueller matrix, get_Mueller_matrix_per_grain :1302-1324; the reference's choice when the
+per-cell tables of method 2 would not fit, scattering.f90:39-66).
+
+CPU: the oracle's grain selection against a numpy search of the same CDF from both ends; identical grains make method
+1 the physics of method 2 (same temperature within the noise).  GPU: the device's temperature step with method 1 equals
+the oracle's packet for packet (frozen), polarised / unpolarised / Henyey-Greenstein."""
+import ctypes as C
+import numpy as np
+import pytest
+
+from helpers import mc_similar
+from mcfost_amd.host import model as M
+
+
+def _model(n_grains=10, identical=False, **kw):
+    from oracle import Oracle
+    m = M.build_model(M.small(n_rad=10, nz=5, **kw))
+    g = M.synthetic_grains(m, n_grains=n_grains)
+    if identical:     # every size bin gets the optical properties of the middle one
+        k0 = n_grains // 2
+        for k in ("C_ext", "C_sca", "C_abs", "tab_g"):
+            g[k] = np.ascontiguousarray(np.repeat(g[k][:, k0:k0 + 1], n_grains, axis=1))
+        for k in ("tab_s11", "tab_s12", "tab_s22", "tab_s33", "tab_s34", "tab_s44"):
+            g[k] = np.ascontiguousarray(np.repeat(g[k][:, k0:k0 + 1, :], n_grains, axis=1))
+        g["S_grain"] = np.full(n_grains, g["S_grain"][k0], np.float32)
+    p_icell, dens = M.settled_grain_density(m, g)
+    m.kappa_factor = np.ones_like(m.kappa_factor)
+    o0 = Oracle(m, 1000)
+    t = o0.opacity(g, dens)
+    lq, cdf = o0.init_reemission(kappa_abs_LTE=t["kappa_abs_LTE"].T)
+    M.variable_dust_from_opacity(m, p_icell, t, lq, cdf)
+    return m, g, p_icell, dens
+
+
+def test_select_scattering_grain_against_a_numpy_search():
+    from oracle import Oracle
+    m, g, p_icell, dens = _model()
+    M.init_scattering_method1(m, g, dens)
+    o = Oracle(m, 1000)
+    f = o.lib.oracle_select_scattering_grain
+    f.restype = C.c_int
+    rng = np.random.default_rng(5)
+    nk = np.asarray(g["n_grains_k"])
+    for lam in (1, 9, 16):
+        for icell in (1, 17, m.n_cells):
+            w = np.asarray(g["C_sca"], np.float64)[lam - 1] * dens[icell - 1] * nk
+            up, down = np.cumsum(w), np.cumsum(w[::-1])
+            # the walk is normalised by kappa * albedo / fact, the default-real albedo makes that the CDF's end to 1e-7
+            for r in rng.random(200, dtype=np.float32):
+                k = f(C.byref(o.cm), C.c_int(lam), C.c_int(icell), C.c_float(r))
+                if r < 0.5:
+                    want = int(np.searchsorted(up, float(r) * up[-1], side="right")) + 1
+                else:
+                    want = len(w) - int(np.searchsorted(down, float(np.float32(1.0) - r) * down[-1], side="right"))
+                assert abs(k - want) <= 1 and 1 <= k <= len(w), (lam, icell, r, k, want)
+                if k != want:   # only where the draw sits on a step of the CDF (the two normalisations differ by 1e-7)
+                    c = up if r < 0.5 else down
+                    x = (float(r) if r < 0.5 else float(np.float32(1.0) - r)) * c[-1]
+                    assert np.min(np.abs(c - x)) < 1e-5 * c[-1]
+
+
+def test_identical_grains_give_the_temperature_of_method_2():
+    from oracle import Oracle
+    m, g, p_icell, dens = _model(identical=True, lsepar_pola=False)
+    n = 200000
+    T2 = Oracle(m, n)
+    a2 = T2.run_thermal(n, seed=3, n_threads=8)
+    M.init_scattering_method1(m, g, dens)
+    T1 = Oracle(m, n)
+    a1 = T1.run_thermal(n, seed=4, n_threads=8)
+    assert a1["counters"]["scatterings"] > 10000
+    assert abs(a1["counters"]["scatterings"] / a2["counters"]["scatterings"] - 1) < 0.03
+    t1, t2 = T1.temp_finale(a1["E_abs"]), T2.temp_finale(a2["E_abs"])
+    sel = (t1 > 1.5 * m.cfg.T_min) & (t2 > 1.5 * m.cfg.T_min)
+    ok, p75 = mc_similar(t1[sel], t2[sel], 0.05)
+    assert ok, p75
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(), dict(lsepar_pola=False), dict(aniso_method=2, lsepar_pola=False), dict(n_az=4, l3D=True)])
+def test_device_method1_equals_the_oracle_frozen(kw):
+    from oracle import Oracle
+    from mcfost_amd.engine import Engine
+    m, g, p_icell, dens = _model(**kw)
+    M.init_scattering_method1(m, g, dens)
+    n = 20000
+    e, o = Engine(m, n), Oracle(m, n)
+    prior = o.run_thermal(2000, seed=1)["E_abs"]
+    a = e.run_thermal(n, seed=6, frozen=True, E_prior=prior)
+    b = o.run_thermal(n, seed=6, frozen=True, E_prior=prior, n_threads=8)
+    assert a["counters"] == b["counters"]
+    assert np.array_equal(a["n_sent"], b["n_sent"]) and np.array_equal(a["sed"][4], b["sed"][4])
+    assert np.allclose(a["E_abs"], b["E_abs"], rtol=1e-9, atol=1e-12 * b["E_abs"].max())
+    assert np.allclose(a["sed"][0], b["sed"][0], rtol=1e-9, atol=1e-12)
+    if m.cfg.lsepar_pola and m.cfg.aniso_method == 1:
+        assert np.allclose(a["sed"][1:4], b["sed"][1:4], rtol=1e-5, atol=1e-6 * max(1.0, np.abs(b["sed"][0]).max()))
+    assert a["counters"]["scatterings"] > 5000
+    # method 2 on the same context runs other packets: the switch is live
+    e.set_scattering_method1(None)
+    a2 = e.run_thermal(n, seed=6, frozen=True, E_prior=prior)
+    assert a2["counters"] != a["counters"]
+    e.close()
