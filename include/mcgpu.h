@@ -328,10 +328,30 @@ typedef struct {
                            inclination bin capt_sup before it stops (:526, :551)   */
   double n_phot_lim;    /* n_photons_lim: cap on the packets a stream sends (:526) */
   int capt_sup;         /* read_param.f90:184                                      */
-  int rt1;              /* lscatt_ray_tracing1: accumulate xI_scatt                */
-  int accumulate;       /* 0: zero sed / n_sent / counters / xI_scatt first        */
+  int rt1;              /* 1: lscatt_ray_tracing1, accumulate xI_scatt; 2: lscatt_ray_tracing2,
+                           accumulate I_spec / I_spec_star (mcgpu_set_rt2); 0: neither */
+  int accumulate;       /* 0: zero sed / n_sent / counters / xI_scatt / I_spec first */
   int grid_blocks, block_threads; /* 0 = automatic                                  */
 } mcgpu_mono_opts;
+
+/*
+ * Ray tracing method 2 (lscatt_ray_tracing2; the reference's default for 2D images, init_mcfost.f90:1854-1863): the
+ * packet loop stores the specific intensity per cell and direction bin instead of the field scattered towards each
+ * observer (save_radiation_field, radiation_field.f90:91-129; 2D grids only):
+ *   I_spec(1:N_type_flux, theta_I, phi_I, icell) += l * Stokes   phi_I: azimuth of the flight direction relative to the
+ *                                                                azimuth of the path's midpoint, theta_I: cos(theta),
+ *                                                                mirrored below the midplane (n_phi_I x n_theta_I bins,
+ *                                                                15 x 15 in dust_ray_tracing.f90:102-105)
+ *   I_spec_star(icell)                           += l * Stokes(1) for starlight that has not interacted yet
+ * One 64-byte record per crossing, whatever the number of observers.  mcgpu_set_rt2 allocates (and zeroes) the two
+ * arrays in HBM; mcgpu_run_mono with opts->rt1 = 2 deposits; mcgpu_fetch_I_spec returns them in the reference's layout
+ * (N_type_flux, n_theta_I, n_phi_I, n_cells) as default real (the type of the reference's arrays) and / or as the FP64
+ * sums the device holds; any pointer may be NULL.  N_type_flux = n_Stokes (+ 4 with lsepar_contrib).
+ * The consumers -- calc_Isca_rt2, calc_Isca_rt2_star, init_dust_source_fct2 (dust_ray_tracing.f90:717-1440) -- are
+ * host-side steps of the ray tracer and are not part of this library yet.
+ */
+int mcgpu_set_rt2(mcgpu_ctx *ctx, int n_theta_I, int n_phi_I, int N_type_flux, int lsepar_contrib);
+int mcgpu_fetch_I_spec(mcgpu_ctx *ctx, float *I_spec, double *I_spec_f64, float *I_spec_star, double *I_spec_star_f64);
 
 /*
  * repartition_energie(lambda) (thermal_emission.f90:1771-1949; the call at dust_transfer.f90:924), LTE grains

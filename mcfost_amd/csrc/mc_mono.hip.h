@@ -50,6 +50,10 @@ struct MonoArgs {
   const float* s11;                     // tab_s11_pos(0:nang, p_lambda)
   double* xI;                           // device layout [n_cells][n_theta_rt][n_az_rt][nRT][XI_LINE] of doubles, or with
   int xI_f32, nRT_pad;                  // xI_f32 (mcgpu_set_xI_precision(4)): ... [nRT_pad][XI_LINE] of floats, nRT_pad even
+  // ray tracing method 2 (2D): the specific intensity per cell and direction bin
+  int rt2, n_theta_I, n_phi_I;
+  double* I_spec;                       // device layout [n_cells][n_phi_I][n_theta_I][XI_LINE]
+  double* I_spec_star;                  // [n_cells]: unscattered starlight
   // accumulators
   double* sed;
   double* n_sent;
@@ -151,6 +155,30 @@ __device__ inline void rt1_subbin_of(int n_az_rt, bool l3D, double x0, double y0
 
 constexpr int XI_LINE = 8;  // doubles per (cell, sub-bin, observer) record of the device layout: one 64-byte line
 
+// save_radiation_field, lscatt_ray_tracing2 branch (radiation_field.f90:91-129; 2D only): the direction bin of a path --
+// the azimuth of the packet's direction relative to the azimuth of the path's midpoint, and cos(theta) mirrored below
+// the midplane
+__device__ inline void rt2_bins(const MonoArgs& A, double x0, double y0, double z0, double x1, double y1, double z1,
+                                double u, double v, double w, int& theta_I, int& phi_I) {
+  const double xm = 0.5 * (x0 + x1), ym = 0.5 * (y0 + y1), zm = 0.5 * (z0 + z1);
+  const double phi_pos = atan2(xm, ym);
+  const double phi_vol = atan2(-u, -v) + 2 * PI;  // two_pi ensures phi_vol > phi_pos
+  phi_I = (int)floor(modulo_d(phi_vol - phi_pos, 2 * PI) / (2 * PI) * (double)A.n_phi_I) + 1;
+  if (phi_I > A.n_phi_I) phi_I = 1;
+  if (zm > 0.0) theta_I = (int)floor(0.5 * (w + 1.0) * (double)A.n_theta_I) + 1;
+  else theta_I = (int)floor(0.5 * (-w + 1.0) * (double)A.n_theta_I) + 1;
+  if (theta_I > A.n_theta_I) theta_I = A.n_theta_I;
+}
+
+// I_spec(1:n_Stokes, theta_I, phi_I, icell) += l * Stokes (and the copy of I in the slot of its origin with
+// lsepar_contrib), or I_spec_star(icell) += l * Stokes(1) for starlight that has not interacted yet: one record of one
+// 64-byte line per crossing -- against one per observer with method 1
+// (called by the whole wavefront: `on` = this lane deposits; the records go out through the wave's tile like method 1's)
+template <bool POLA>
+__device__ inline void deposit_rt2_wave(const MonoArgs& A, bool on, int icell, int theta_I, int phi_I, double l,
+                                        const double S[4], bool flag_star, bool direct, double* tile,
+                                        unsigned long long* tile_addr, unsigned int* tile_mask);
+
 // save_radiation_field, lscatt_ray_tracing1 branch (radiation_field.f90:63-89) with calc_xI_scatt
 // (dust_ray_tracing.f90:480-529) / calc_xI_scatt_pola (:533-632), for the whole wavefront.
 // mu = the six Mueller columns [s11 | s12/s11 | s22/s11 | s33/s11 | s34/s11 | s44/s11] of p_lambda in LDS.
@@ -161,6 +189,65 @@ constexpr int XI_LINE = 8;  // doubles per (cell, sub-bin, observer) record of t
 // transposes them through a per-wave LDS tile: lane j stores its record, then in round r the 8 lanes of
 // group g = lane/8 add the 8 slots of lane 8r+g's record -- one instruction, 8 records, 8 line
 // operations instead of 40.
+#ifndef MCGPU_LANE_EMULATION
+// The records of one instruction's lanes (<= 4 Stokes values + the copy of I in the slot of its origin, all in one
+// 64-byte line per lane) go out through the wave's LDS tile: the lanes that deposit stage their record in consecutive
+// places, then K lanes serve each record -- floor(64 / K) records per atomic instruction instead of one value of 64.
+__device__ inline void wave_deposit_records(int lane, int K, unsigned int mask, int cslot, double* rec, double v0, double v1,
+                                            double v2, double v3, double* tile, unsigned long long* tile_addr,
+                                            unsigned int* tile_mask, bool contrib) {
+  const int NR = 64 / K;
+  const int rl = lane / K, j = lane - rl * K;
+  const bool lane_used = rl < NR;
+  const bool is_contrib = contrib && j == K - 1;
+  const unsigned long long any = __ballot(mask != 0);
+  const int n_act = __popcll(any);
+  if (mask) {
+    const int place = __popcll(any & ((1ull << lane) - 1ull));
+    volatile double* my = tile + place * XI_LINE;
+    my[0] = v0; my[1] = v1; my[2] = v2; my[3] = v3;
+    tile_addr[place] = (unsigned long long)rec;
+    tile_mask[place] = mask | ((unsigned int)cslot << 8);
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (int r0 = 0; r0 < n_act; r0 += NR) {
+    const int src = r0 + rl;
+    if (lane_used && src < n_act) {
+      const unsigned int mw = ((volatile unsigned int*)tile_mask)[src];
+      const int slot = is_contrib ? (int)(mw >> 8) : j;
+      if ((mw >> slot) & 1u) {
+        double* dst = reinterpret_cast<double*>(((volatile unsigned long long*)tile_addr)[src]) + slot;
+        atomic_add_f64(dst, ((volatile double*)tile)[src * XI_LINE + (is_contrib ? 0 : j)]);
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+#endif
+
+template <bool POLA>
+__device__ inline void deposit_rt2_wave(const MonoArgs& A, bool on, int icell, int theta_I, int phi_I, double l,
+                                        const double S[4], bool flag_star, bool direct, double* tile,
+                                        unsigned long long* tile_addr, unsigned int* tile_mask) {
+  if (on && direct) atomic_add_f64(&A.I_spec_star[icell - 1], l * S[0]);
+  const bool rec_on = on && !direct;
+  double* rec = A.I_spec + ((((size_t)(rec_on ? icell - 1 : 0) * A.n_phi_I + (phi_I - 1)) * A.n_theta_I) + (theta_I - 1)) * XI_LINE;
+  const int cslot = A.contrib ? (POLA ? 4 : 1) + (flag_star ? 1 : 3) : 0;  // n_Stokes + 2 / + 4, 1-based
+  const unsigned int mask = rec_on ? ((POLA ? 0xFu : 1u) | (A.contrib ? 1u << cslot : 0u)) : 0u;
+#ifdef MCGPU_LANE_EMULATION
+  (void)tile; (void)tile_addr; (void)tile_mask;
+  if (rec_on) {
+    atomic_add_f64(rec, l * S[0]);
+    if (POLA) { atomic_add_f64(rec + 1, l * S[1]); atomic_add_f64(rec + 2, l * S[2]); atomic_add_f64(rec + 3, l * S[3]); }
+    if (A.contrib) atomic_add_f64(rec + cslot, l * S[0]);
+  }
+#else
+  if (__ballot(mask != 0) == 0ull) return;
+  wave_deposit_records(threadIdx.x & 63, (POLA ? 4 : 1) + (A.contrib ? 1 : 0), mask, cslot, rec, l * S[0], POLA ? l * S[1] : 0.0,
+                       POLA ? l * S[2] : 0.0, POLA ? l * S[3] : 0.0, tile, tile_addr, tile_mask, A.contrib != 0);
+#endif
+}
+
 // lvariable_dust (M.n_classes): the columns are those of the cell's class, tab_s11_pos(it, p_icell, p_lambda) etc.
 // (dust_ray_tracing.f90:503-512), gathered from the per-class tables in HBM instead of the LDS copy.
 __device__ inline size_t mono_class_col(const DevModel& M, const MonoArgs& A, int icell) {
@@ -184,10 +271,6 @@ __device__ inline void deposit_rt1_wave(const DevModel& M, const MonoArgs& A, co
   // records per instruction = 1.7x the time), so the 64 lanes of one instruction serve floor(64 / K) records with K
   // lanes each: 12 records instead of 8 with Stokes tracking and contributions, 32 without Stokes tracking.
   const int K = (POLA ? 4 : 1) + (A.contrib ? 1 : 0);
-  const int NR = 64 / K;                      // records per instruction
-  const int rl = lane / K, j = lane - rl * K; // this lane's record within a round, and which of its values
-  const bool lane_used = rl < NR;
-  const bool is_contrib = A.contrib && j == K - 1;
 #endif
   for (int q = 0; q < A.nRT; ++q) {
     double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
@@ -240,31 +323,7 @@ __device__ inline void deposit_rt1_wave(const DevModel& M, const MonoArgs& A, co
       if (cslot && ((mask >> cslot) & 1u)) atomic_add_f64(rec + cslot, v0);
     }
 #else
-    // stage this lane's record: values 0..3 = I, Q, U, V; the tile's mask word keeps the mask and the slot of the
-    // contribution copy (slots the mask does not name are never read)
-    // ... densely: the lanes that deposit take consecutive places of the tile, so that the instructions are full
-    const unsigned long long any = __ballot(mask != 0);
-    const int n_act = __popcll(any);
-    if (mask) {
-      const int place = __popcll(any & ((1ull << lane) - 1ull));
-      volatile double* my = tile + place * XI_LINE;
-      my[0] = v0; my[1] = v1; my[2] = v2; my[3] = v3;
-      tile_addr[place] = (unsigned long long)rec;
-      tile_mask[place] = mask | ((unsigned int)cslot << 8);
-    }
-    __builtin_amdgcn_wave_barrier();
-    for (int r0 = 0; r0 < n_act; r0 += NR) {
-      const int src = r0 + rl;
-      if (lane_used && src < n_act) {
-        const unsigned int mw = ((volatile unsigned int*)tile_mask)[src];
-        const int slot = is_contrib ? (int)(mw >> 8) : j;
-        if ((mw >> slot) & 1u) {
-          double* dst = reinterpret_cast<double*>(((volatile unsigned long long*)tile_addr)[src]) + slot;
-          atomic_add_f64(dst, ((volatile double*)tile)[src * XI_LINE + (is_contrib ? 0 : j)]);
-        }
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
+    wave_deposit_records(lane, K, mask, cslot, rec, v0, v1, v2, v3, tile, tile_addr, tile_mask, A.contrib != 0);
 #endif
   }
 }
@@ -620,6 +679,10 @@ __device__ __forceinline__ void mono_body(const DevModel& M, const MonoArgs& A, 
                 dep.on = true; dep.icell = ic + 1; dep.l = lc;
                 rt1_subbin<L3D>(A, x, y, z, x1, y1, z1, dep.phik, dep.psup);
               }
+              if (!L3D && !SCOUT && A.rt2 && real_cell) {  // (the midpoint is the crossing's, optical_depth.f90:149-150)
+                dep.on = true; dep.icell = ic + 1; dep.l = lc;
+                rt2_bins(A, x, y, z, x1, y1, z1, u, v, w, dep.psup, dep.phik);  // (psup, phik: theta_I, phi_I)
+              }
               x = x + lc * u;
               y = y + lc * v;
               z = z + lc * w;
@@ -630,6 +693,10 @@ __device__ __forceinline__ void mono_body(const DevModel& M, const MonoArgs& A, 
               if (!SCOUT && A.rt1 && real_cell) {
                 dep.on = true; dep.icell = ic + 1; dep.l = l;
                 rt1_subbin<L3D>(A, x, y, z, x1, y1, z1, dep.phik, dep.psup);
+              }
+              if (!L3D && !SCOUT && A.rt2 && real_cell) {
+                dep.on = true; dep.icell = ic + 1; dep.l = l;
+                rt2_bins(A, x, y, z, x1, y1, z1, u, v, w, dep.psup, dep.phik);
               }
               if (DARK) { xo = x; yo = y; zo = z; ri_o = ri; zj_o = zj; k_o = k; }
               x = x1; y = y1; z = z1;
@@ -645,6 +712,9 @@ __device__ __forceinline__ void mono_body(const DevModel& M, const MonoArgs& A, 
       }
       // the deposits of this crossing, by the whole wavefront (S and flag_star are still the flight's:
       // an interaction changes them only in the next outer phase)
+      if (!L3D && !SCOUT && A.rt2 && __ballot(dep.on) != 0ull)
+        deposit_rt2_wave<POLA>(A, dep.on, dep.icell, dep.psup, dep.phik, dep.l, S, flag_star, flag_star && !flag_scatt, tile,
+                               tile_addr, tile_mask);
       if (!SCOUT && A.rt1 && __ballot(dep.on) != 0ull)
       {
 #ifndef MCGPU_LANE_EMULATION

@@ -102,6 +102,9 @@ struct mcgpu_ctx {
   const double *d_rt_u = nullptr, *d_rt_v = nullptr, *d_rt_w = nullptr;
   const float* d_tab_s11 = nullptr;
   double* d_xI = nullptr;
+  bool have_rt2 = false;            // ray tracing method 2 (mcgpu_set_rt2): I_spec, I_spec_star
+  int n_theta_I = 0, n_phi_I = 0, rt2_N_type_flux = 0, rt2_contrib = 0;
+  double *d_I_spec = nullptr, *d_I_spec_star = nullptr;
   size_t n_xI = 0;
   int xI_bytes = 8;  // accumulator type of xI_scatt on the device: 8 = FP64 (default), 4 = default real (mcgpu_set_xI_precision)
   double* d_prob_E = nullptr;               // prob_E_cell(0:n_cells) of the current wavelength
@@ -209,6 +212,8 @@ extern "C" int mcgpu_destroy(mcgpu_ctx* ctx) {
   if (ctx->d_err) hipFree(ctx->d_err);
   if (ctx->d_E_prior) hipFree(ctx->d_E_prior);
   if (ctx->d_xI) hipFree(ctx->d_xI);
+  if (ctx->d_I_spec) hipFree(ctx->d_I_spec);
+  if (ctx->d_I_spec_star) hipFree(ctx->d_I_spec_star);
   if (ctx->d_prob_E) hipFree(ctx->d_prob_E);
   if (ctx->d_mono_u64) hipFree(ctx->d_mono_u64);
   if (ctx->d_mono_i32) hipFree(ctx->d_mono_i32);
@@ -1802,6 +1807,54 @@ static int launch_mono(mcgpu_ctx* ctx, const MonoArgs& A, int grid_blocks, int b
   return MCGPU_OK;
 }
 
+// Ray tracing method 2 (lscatt_ray_tracing2): the accumulators of save_radiation_field's branch radiation_field.f90:91-129
+extern "C" int mcgpu_set_rt2(mcgpu_ctx* ctx, int n_theta_I, int n_phi_I, int N_type_flux, int lsepar_contrib) {
+  if (!ctx) return MCGPU_ERR_ARG;
+  if (!ctx->have_grid) return fail(ctx, MCGPU_ERR_STATE, "set the grid first");
+  const int n_Stokes = ctx->lsepar_pola ? 4 : 1;
+  if (n_theta_I < 1 || n_phi_I < 1 || n_theta_I > 1024 || n_phi_I > 1024 || N_type_flux != n_Stokes + (lsepar_contrib ? 4 : 0))
+    return fail(ctx, MCGPU_ERR_ARG, "mcgpu_set_rt2: N_type_flux = n_Stokes (+ 4 with lsepar_contrib)");
+  if (ctx->M.l3D || ctx->voro || ctx->M.grid_sph) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "ray tracing method 2 is for 2D cylindrical grids");
+  HIPCHK(hipSetDevice(ctx->device));
+  if (ctx->d_I_spec) hipFree(ctx->d_I_spec);
+  if (ctx->d_I_spec_star) hipFree(ctx->d_I_spec_star);
+  ctx->d_I_spec = ctx->d_I_spec_star = nullptr; ctx->have_rt2 = false;
+  const size_t n = (size_t)ctx->M.n_cells * n_phi_I * n_theta_I * XI_LINE;
+  HIPCHK(hipMalloc((void**)&ctx->d_I_spec, n * sizeof(double)));
+  HIPCHK(hipMalloc((void**)&ctx->d_I_spec_star, (size_t)ctx->M.n_cells * sizeof(double)));
+  HIPCHK(hipMemset(ctx->d_I_spec, 0, n * sizeof(double)));
+  HIPCHK(hipMemset(ctx->d_I_spec_star, 0, (size_t)ctx->M.n_cells * sizeof(double)));
+  ctx->n_theta_I = n_theta_I; ctx->n_phi_I = n_phi_I; ctx->rt2_N_type_flux = N_type_flux; ctx->rt2_contrib = lsepar_contrib ? 1 : 0;
+  ctx->have_rt2 = true;
+  return MCGPU_OK;
+}
+
+// I_spec(N_type_flux, n_theta_I, n_phi_I, n_cells) and I_spec_star(n_cells) in the reference's layout: default real
+// and / or the FP64 sums the device holds
+extern "C" int mcgpu_fetch_I_spec(mcgpu_ctx* ctx, float* I_spec, double* I_spec_f64, float* I_spec_star, double* I_spec_star_f64) {
+  if (!ctx || !ctx->have_rt2) return fail(ctx, MCGPU_ERR_STATE, "mcgpu_set_rt2 first");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  const int nt = ctx->n_theta_I, np = ctx->n_phi_I, ntf = ctx->rt2_N_type_flux, nc = ctx->M.n_cells;
+  std::vector<double> t((size_t)nc * np * nt * XI_LINE), st((size_t)nc);
+  HIPCHK(hipMemcpy(t.data(), ctx->d_I_spec, t.size() * sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(st.data(), ctx->d_I_spec_star, st.size() * sizeof(double), hipMemcpyDeviceToHost));
+  for (int c = 0; c < nc; ++c)
+    for (int p = 0; p < np; ++p)
+      for (int th = 0; th < nt; ++th)
+        for (int f = 0; f < ntf; ++f) {
+          const double v = t[((((size_t)c * np + p) * nt) + th) * XI_LINE + f];
+          const size_t o = (size_t)f + (size_t)ntf * ((size_t)th + (size_t)nt * ((size_t)p + (size_t)np * c));
+          if (I_spec) I_spec[o] = (float)v;
+          if (I_spec_f64) I_spec_f64[o] = v;
+        }
+  for (int c = 0; c < nc; ++c) {
+    if (I_spec_star) I_spec_star[c] = (float)st[c];
+    if (I_spec_star_f64) I_spec_star_f64[c] = st[c];
+  }
+  return MCGPU_OK;
+}
+
 extern "C" int mcgpu_run_mono(mcgpu_ctx* ctx, const mcgpu_mono_opts* o, double frac_E_stars, double frac_E_disk,
                               const double* prob_E_cell, uint64_t* n_sent_chunk, double* kernel_ms) {
   int rc = ready(ctx);
@@ -1812,13 +1865,16 @@ extern "C" int mcgpu_run_mono(mcgpu_ctx* ctx, const mcgpu_mono_opts* o, double f
     if (M.v_scatt && M.aniso_method == 1 && M.p_lambda_fixed)
       return fail(ctx, MCGPU_ERR_STATE, "SED mode with variable dust needs prob_s11_pos per wavelength: set the scattering tables with p_lambda_fixed = 0");
     if (!M.v_scatt) return fail(ctx, MCGPU_ERR_STATE, "SED mode with variable dust needs the per-class scattering tables");
-    if (o->rt1 && !M.v_s11) return fail(ctx, MCGPU_ERR_STATE, "rt1 deposits with variable dust need tab_s11_pos per class (mcgpu_opacity or mcgpu_set_variable_dust_s11)");
+    if (o->rt1 == 1 && !M.v_s11) return fail(ctx, MCGPU_ERR_STATE, "rt1 deposits with variable dust need tab_s11_pos per class (mcgpu_opacity or mcgpu_set_variable_dust_s11)");
     if (ctx->voro) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "variable dust: cylindrical grids only");
   }
   if (o->lambda < 1 || o->lambda > M.n_lambda || o->n_chunks < 1 || o->n_chunks > (1 << 22) || o->capt_sup < 1 ||
       o->first_chunk < 0 || (long long)o->first_chunk + o->n_chunks > (1 << 23))
     return fail(ctx, MCGPU_ERR_ARG, "mcgpu_run_mono: bad option");
-  if (o->rt1 && !ctx->have_rt1) return fail(ctx, MCGPU_ERR_STATE, "rt1 deposits need mcgpu_set_rt1");
+  const bool rt2 = o->rt1 == 2, rt1 = o->rt1 != 0 && !rt2;   // opts->rt1: 0 none, 1 lscatt_ray_tracing1, 2 lscatt_ray_tracing2
+  if (rt1 && !ctx->have_rt1) return fail(ctx, MCGPU_ERR_STATE, "rt1 deposits need mcgpu_set_rt1");
+  if (rt2 && !ctx->have_rt2) return fail(ctx, MCGPU_ERR_STATE, "rt2 deposits need mcgpu_set_rt2");
+  if (rt2 && (M.l3D || ctx->voro)) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "ray tracing method 2 is 2D only (radiation_field.f90:91)");
   if (M.grid_sph) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "SED mode on a spherical grid is not supported yet");
   const int n_pos = ctx->have_rt1 ? ctx->n_lambda_pos : M.n_lambda;
   if (o->p_lambda < 1 || o->p_lambda > n_pos || o->p_lambda > M.n_lambda) return fail(ctx, MCGPU_ERR_ARG, "p_lambda out of range");
@@ -1847,17 +1903,21 @@ extern "C" int mcgpu_run_mono(mcgpu_ctx* ctx, const mcgpu_mono_opts* o, double f
   }
   const int nRT = ctx->have_rt1 ? ctx->RT_n_incl * ctx->RT_n_az : 0;
   // n_xI: elements of the reference's array; the device keeps XI_LINE doubles per (cell, sub-bin, observer)
-  const size_t n_xI = o->rt1 ? (size_t)ctx->n_az_rt * ctx->n_theta_rt * ctx->N_type_flux * nRT * (size_t)M.n_cells : 0;
-  const size_t xi_bytes = o->rt1 ? xi_dev_bytes(ctx) : 0;
-  if (o->rt1 && ctx->N_type_flux > XI_LINE) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "N_type_flux > 8");
-  if (o->rt1 && ctx->n_xI != n_xI) {
+  const size_t n_xI = rt1 ? (size_t)ctx->n_az_rt * ctx->n_theta_rt * ctx->N_type_flux * nRT * (size_t)M.n_cells : 0;
+  const size_t xi_bytes = rt1 ? xi_dev_bytes(ctx) : 0;
+  if (rt1 && ctx->N_type_flux > XI_LINE) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "N_type_flux > 8");
+  if (rt1 && ctx->n_xI != n_xI) {
     if (ctx->d_xI) hipFree(ctx->d_xI);
     ctx->d_xI = nullptr; ctx->n_xI = 0;
     HIPCHK(hipMalloc((void**)&ctx->d_xI, xi_bytes));
     ctx->n_xI = n_xI;
     HIPCHK(hipMemsetAsync(ctx->d_xI, 0, xi_bytes, ctx->stream));
-  } else if (o->rt1 && !o->accumulate) {
+  } else if (rt1 && !o->accumulate) {
     HIPCHK(hipMemsetAsync(ctx->d_xI, 0, xi_bytes, ctx->stream));
+  }
+  if (rt2 && !o->accumulate) {
+    HIPCHK(hipMemsetAsync(ctx->d_I_spec, 0, (size_t)M.n_cells * ctx->n_phi_I * ctx->n_theta_I * XI_LINE * sizeof(double), ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_I_spec_star, 0, (size_t)M.n_cells * sizeof(double), ctx->stream));
   }
   // (the E_abs part of the fused accumulator belongs to the thermal step: a host may run the SED Monte Carlo and
   // then call mcgpu_temp_finale(ctx, NULL, ...) on the device's own absorbed-energy grid)
@@ -1869,15 +1929,19 @@ extern "C" int mcgpu_run_mono(mcgpu_ctx* ctx, const mcgpu_mono_opts* o, double f
 
   MonoArgs A;
   std::memset(&A, 0, sizeof(A));
-  A.seed = o->seed; A.lambda = o->lambda; A.p_lambda = o->p_lambda; A.capt_sup = o->capt_sup; A.rt1 = o->rt1 ? 1 : 0;
+  A.seed = o->seed; A.lambda = o->lambda; A.p_lambda = o->p_lambda; A.capt_sup = o->capt_sup; A.rt1 = rt1 ? 1 : 0;
   A.frac_E_stars = frac_E_stars; A.frac_E_disk = frac_E_disk;
   A.prob_E_cell = (prob_E_cell || ctx->prob_E_lambda == o->lambda) ? ctx->d_prob_E : nullptr;
   A.n_chunks = nc; A.first_chunk = o->first_chunk;
-  A.RT_n_incl = ctx->have_rt1 ? ctx->RT_n_incl : 1; A.nRT = o->rt1 ? nRT : 0;
+  A.RT_n_incl = ctx->have_rt1 ? ctx->RT_n_incl : 1; A.nRT = rt1 ? nRT : 0;
   A.rt_u = ctx->d_rt_u; A.rt_v = ctx->d_rt_v; A.rt_w = ctx->d_rt_w;
   A.n_az_rt = ctx->n_az_rt; A.n_theta_rt = ctx->n_theta_rt; A.N_type_flux = ctx->N_type_flux; A.contrib = ctx->lsepar_contrib;
   A.s11 = ctx->have_rt1 ? ctx->d_tab_s11 + (size_t)(M.nang + 1) * (o->p_lambda - 1) : nullptr;
   A.xI = ctx->d_xI; A.xI_f32 = ctx->xI_bytes == 4 ? 1 : 0; A.nRT_pad = xi_nrt_pad(ctx);
+  if (rt2) {
+    A.rt2 = 1; A.n_theta_I = ctx->n_theta_I; A.n_phi_I = ctx->n_phi_I; A.I_spec = ctx->d_I_spec; A.I_spec_star = ctx->d_I_spec_star;
+    A.N_type_flux = ctx->rt2_N_type_flux; A.contrib = ctx->rt2_contrib;
+  }
   A.sed = ctx->d_accum + M.n_cells;
   A.n_sent = ctx->d_accum + M.n_cells + n_sed(M);
   A.counters = ctx->d_counters; A.next_item = ctx->d_counters + WORK_SLOT; A.err = ctx->d_err;
@@ -1994,7 +2058,11 @@ restart:
           speculate = false;
           HIPCHK(hipMemsetAsync(ctx->d_accum + M.n_cells, 0, (ctx->n_accum - M.n_cells) * sizeof(double), ctx->stream));
           HIPCHK(hipMemsetAsync(ctx->d_counters, 0, 16 * sizeof(unsigned long long), ctx->stream));
-          if (o->rt1) HIPCHK(hipMemsetAsync(ctx->d_xI, 0, xi_bytes, ctx->stream));
+          if (rt1) HIPCHK(hipMemsetAsync(ctx->d_xI, 0, xi_bytes, ctx->stream));
+          if (rt2) {
+            HIPCHK(hipMemsetAsync(ctx->d_I_spec, 0, (size_t)M.n_cells * ctx->n_phi_I * ctx->n_theta_I * XI_LINE * sizeof(double), ctx->stream));
+            HIPCHK(hipMemsetAsync(ctx->d_I_spec_star, 0, (size_t)M.n_cells * sizeof(double), ctx->stream));
+          }
           goto restart;
         }
         for (int c = 0; c < nc; ++c) start[c] = cnt[c];   // committed so far: [0, start)

@@ -36,7 +36,7 @@ ABI_SYMBOLS = (
     "mcgpu_device_xI", "mcgpu_set_ism", "mcgpu_rt1_dust_map", "mcgpu_set_xI", "mcgpu_rt1_image", "mcgpu_set_xI_precision",
     "mcgpu_get_xI_precision", "mcgpu_set_option", "mcgpu_get_info", "mcgpu_counters_to_accum", "mcgpu_counters_from_accum",
     "mcgpu_set_grid_sph", "mcgpu_temp_approx_diffusion_vertical", "mcgpu_set_mrw", "mcgpu_fetch_radiation_field", "mcgpu_set_variable_dust", "mcgpu_rt1_stars_map_sed", "mcgpu_define_dark_zone", "mcgpu_init_reemission", "mcgpu_multi_create", "mcgpu_multi_destroy", "mcgpu_multi_size", "mcgpu_multi_ctx", "mcgpu_multi_last_error",
-    "mcgpu_repartition_energie", "mcgpu_opacity", "mcgpu_set_variable_dust_s11", "mcgpu_set_scattering_method1", "mcgpu_shard_packets", "mcgpu_multi_run_thermal", "mcgpu_multi_run_mono", "mcgpu_multi_rccl_ranks",
+    "mcgpu_repartition_energie", "mcgpu_opacity", "mcgpu_set_variable_dust_s11", "mcgpu_set_scattering_method1", "mcgpu_set_rt2", "mcgpu_fetch_I_spec", "mcgpu_shard_packets", "mcgpu_multi_run_thermal", "mcgpu_multi_run_mono", "mcgpu_multi_rccl_ranks",
 )
 
 
@@ -554,14 +554,36 @@ class Engine:
             raise McgpuError(f"xI_scatt has shape {x.shape}, expected {self.xI_shape()}")
         self._chk(self.lib.mcgpu_set_xI(self.ctx, _p(x, C.c_double)), "mcgpu_set_xI")
 
+    def set_rt2(self, n_theta_I=15, n_phi_I=15):
+        """Ray tracing method 2 (``lscatt_ray_tracing2``, 2D): allocates ``I_spec`` / ``I_spec_star`` on the device
+        (dust_ray_tracing.f90:102-105: 15 x 15 direction bins by default)."""
+        cfg = self.model.cfg
+        ntf = (4 if (cfg.lsepar_pola and cfg.aniso_method == 1) else 1) + (4 if cfg.lsepar_contrib else 0)
+        self._chk(self.lib.mcgpu_set_rt2(self.ctx, C.c_int(int(n_theta_I)), C.c_int(int(n_phi_I)), C.c_int(ntf),
+                                         C.c_int(int(cfg.lsepar_contrib))), "mcgpu_set_rt2")
+        self._rt2 = (int(n_theta_I), int(n_phi_I), ntf)
+
+    def fetch_I_spec(self):
+        """``(I_spec [n_cells, n_phi_I, n_theta_I, N_type_flux], I_spec_star [n_cells])`` in FP64 (the device's sums)."""
+        nt, nphi, ntf = self._rt2
+        a = np.zeros((self.model.n_cells, nphi, nt, ntf), np.float64)
+        b = np.zeros(self.model.n_cells, np.float64)
+        self._chk(self.lib.mcgpu_fetch_I_spec(self.ctx, None, _p(a, C.c_double), None, _p(b, C.c_double)), "mcgpu_fetch_I_spec")
+        return a, b
+
     def run_mono(self, lam, n_photons2, n_phot_lim=None, p_lambda=None, seed=1, n_chunks=None, rt1=True,
-                 accumulate=False, grid_blocks=0, block_threads=0, fetch_xI=True, first_chunk=0, device_tables=None):
+                 accumulate=False, grid_blocks=0, block_threads=0, fetch_xI=True, first_chunk=0, device_tables=None,
+                 rt2=None):
         """One wavelength (1-based ``lam``) of the SED Monte Carlo: ``mcgpu_run_mono`` with the
         model's frac_E_stars / prob_E_cell of that wavelength -- or, with ``device_tables`` = the dict
         ``repartition_energie(lam, ...)`` returned, with the fractions of that call and the cumulative distribution it
-        left on the device."""
+        left on the device.  ``rt2 = (n_theta_I, n_phi_I)``: method 2's deposits (``I_spec``, ``I_spec_star``) instead."""
         m = self.model
-        if rt1 and not getattr(self, "_rt1", False):
+        if rt2 is not None:
+            if getattr(self, "_rt2", (0, 0, 0))[:2] != (int(rt2[0]), int(rt2[1])):
+                self.set_rt2(*rt2)
+            rt1 = 2
+        if rt1 == 1 and not getattr(self, "_rt1", False):
             self.set_rt1()
         nt, nphi = m.cfg.N_thet, m.cfg.N_phi
         n_chunks = int(n_chunks or m.cfg.n_photons_loop)
@@ -585,11 +607,13 @@ class Engine:
         out = self.fetch()
         out["n_sent_chunk"] = per_chunk
         out["kernel_ms"] = ms.value
-        if rt1 and fetch_xI:
+        if rt1 == 1 and fetch_xI:
             x64 = np.zeros(self.xI_shape(), np.float64)
             x32 = np.zeros(self.xI_shape(), np.float32)
             self._chk(self.lib.mcgpu_fetch_xI(self.ctx, _p(x32, C.c_float), _p(x64, C.c_double)), "mcgpu_fetch_xI")
             out["xI_scatt"], out["xI_scatt_f32"] = x64, x32
+        if rt1 == 2:
+            out["I_spec"], out["I_spec_star"] = self.fetch_I_spec()
         return out
 
     def dust_map_sed(self, lam, Tdust, n_sent_photons, E_disk, ang_disque=0.0, l_sym_ima=True,

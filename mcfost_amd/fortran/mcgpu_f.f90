@@ -88,7 +88,7 @@ module mcgpu_f
        mcgpu_run_mono, mcgpu_fetch, mcgpu_fetch_xI, mcgpu_rt1_dust_map, mcgpu_set_xI, mcgpu_rt1_image, mcgpu_set_xI_precision, &
        mcgpu_set_E_prior, mcgpu_multi_create, mcgpu_multi_destroy, mcgpu_multi_size, mcgpu_multi_ctx, mcgpu_multi_run_thermal, mcgpu_multi_run_mono, mcgpu_multi_rccl_ranks, &
        mcgpu_counters_to_accum, mcgpu_counters_from_accum, mcgpu_temp_approx_diffusion_vertical, mcgpu_set_mrw, mcgpu_fetch_radiation_field, &
-       mcgpu_set_variable_dust, mcgpu_rt1_stars_map_sed, mcgpu_define_dark_zone, mcgpu_init_reemission, mcgpu_repartition_energie, mcgpu_opacity, mcgpu_set_variable_dust_s11, mcgpu_set_scattering_method1
+       mcgpu_set_variable_dust, mcgpu_rt1_stars_map_sed, mcgpu_define_dark_zone, mcgpu_init_reemission, mcgpu_repartition_energie, mcgpu_opacity, mcgpu_set_variable_dust_s11, mcgpu_set_scattering_method1, mcgpu_set_rt2, mcgpu_fetch_I_spec
 
   interface
      integer(c_int) function mcgpu_create(device, ctx) bind(C, name="mcgpu_create")
@@ -398,6 +398,21 @@ module mcgpu_f
        real(c_double), intent(out) :: frac_E_stars, frac_E_disk, E_disk
        type(c_ptr), value :: prob_E_cell             ! c_loc(prob_E_cell(0,lambda)) or c_null_ptr
      end function mcgpu_repartition_energie
+
+     ! lscatt_ray_tracing2: I_spec(N_type_flux,n_theta_I,n_phi_I,n_cells) and I_spec_star(n_cells) live on the device;
+     ! mcgpu_run_mono with opts%rt1 = 2 deposits (radiation_field.f90:91-129), the fetch fills the module arrays of
+     ! dust_ray_tracing (slice (...,1) of the thread axis, the others zero) before calc_Isca_rt2
+     integer(c_int) function mcgpu_set_rt2(ctx, n_theta_I, n_phi_I, N_type_flux, lsepar_contrib) bind(C, name="mcgpu_set_rt2")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: n_theta_I, n_phi_I, N_type_flux, lsepar_contrib
+     end function mcgpu_set_rt2
+
+     integer(c_int) function mcgpu_fetch_I_spec(ctx, I_spec, I_spec_f64, I_spec_star, I_spec_star_f64) &
+          bind(C, name="mcgpu_fetch_I_spec")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx, I_spec, I_spec_f64, I_spec_star, I_spec_star_f64   ! c_loc(...) or c_null_ptr
+     end function mcgpu_fetch_I_spec
 
      ! lscattering_method1 (scattering.f90:39-66 chose it): the grains' tables of method 1 and the local densities
      integer(c_int) function mcgpu_set_scattering_method1(ctx, grains, prob_s11, p_n_cells, dust_density_o_n_grains) &

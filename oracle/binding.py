@@ -109,7 +109,8 @@ class _Model(C.Structure):
 class _MonoOpts(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("lambda_", C.c_int), ("p_lambda", C.c_int), ("n_chunks", C.c_int),
                 ("first_chunk", C.c_int), ("n_photons2", C.c_double), ("n_phot_lim", C.c_double), ("capt_sup", C.c_int),
-                ("rt1", C.c_int), ("n_threads", C.c_int)]
+                ("rt1", C.c_int), ("n_threads", C.c_int), ("n_theta_I", C.c_int), ("n_phi_I", C.c_int),
+                ("I_spec", C.POINTER(C.c_double)), ("I_spec_star", C.POINTER(C.c_double))]
 
 
 class _RtOpts(C.Structure):
@@ -294,15 +295,24 @@ class Oracle:
                 rt["n_az_rt"])
 
     def run_mono(self, lam, n_photons2, n_phot_lim=None, p_lambda=None, seed=1, n_chunks=None,
-                 rt1=True, n_threads=1, first_chunk=0):
-        """One wavelength (1-based ``lam``) of the SED Monte Carlo."""
+                 rt1=True, n_threads=1, first_chunk=0, rt2=None):
+        """One wavelength (1-based ``lam``) of the SED Monte Carlo.  ``rt2 = (n_theta_I, n_phi_I)``: ray tracing method
+        2's deposits instead of method 1's (``I_spec [n_cells, n_phi_I, n_theta_I, N_type_flux]``, ``I_spec_star``)."""
         m = self.model
         nl, nt, nphi = m.n_lambda, m.cfg.N_thet, m.cfg.N_phi
         n_chunks = int(n_chunks or m.cfg.n_photons_loop)
         if n_phot_lim is None:  # read_param.f90:551
             n_phot_lim = float(np.float32(1.0e4) * np.float32(nt) * np.float32(nphi) * np.float32(n_photons2))
+        I_spec = I_star = None
+        if rt2 is not None:
+            rt1 = False
+            ntf = (4 if (m.cfg.lsepar_pola and m.cfg.aniso_method == 1) else 1) + (4 if m.cfg.lsepar_contrib else 0)
+            I_spec = np.zeros((m.n_cells, int(rt2[1]), int(rt2[0]), ntf), np.float64)
+            I_star = np.zeros(m.n_cells, np.float64)
         o = _MonoOpts(seed, int(lam), int(p_lambda or lam), n_chunks, int(first_chunk), float(n_photons2), float(n_phot_lim),
-                      int(m.capt_sup), int(rt1), n_threads)
+                      int(m.capt_sup), 2 if rt2 is not None else int(rt1), n_threads,
+                      int(rt2[0]) if rt2 is not None else 0, int(rt2[1]) if rt2 is not None else 0,
+                      _p(I_spec, C.c_double) if rt2 is not None else None, _p(I_star, C.c_double) if rt2 is not None else None)
         xI = np.zeros(self.xI_shape() if rt1 else (1,), np.float64)
         sed = np.zeros((N_SED_TYPES, nphi, nt, nl), np.float64)
         n_sent = np.zeros(nl, np.float64)
@@ -313,7 +323,7 @@ class Oracle:
                                       _p(n_sent, C.c_double), _p(per_chunk, C.c_uint64), _p(cnt, C.c_uint64))
         if rc:
             raise RuntimeError(f"oracle_run_mono failed: {rc}")
-        return dict(xI_scatt=xI, sed=sed, n_sent=n_sent, n_sent_chunk=per_chunk,
+        return dict(xI_scatt=xI, sed=sed, n_sent=n_sent, n_sent_chunk=per_chunk, I_spec=I_spec, I_spec_star=I_star,
                     counters=dict(zip(COUNTER_NAMES, (int(c) for c in cnt))))
 
     # -- packet loop -------------------------------------------------------

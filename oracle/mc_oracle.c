@@ -1434,6 +1434,7 @@ typedef struct {
   /* SED mode (lmono): NULL in the thermal step */
   const oracle_mono_opts *mono;
   double *xI;          /* shared xI_scatt (atomic adds) */
+  int flag_direct_star; /* starlight that has not interacted yet (dust_transfer.f90:1189-1193, 1262) */
   int itheta_rt1[ORACLE_MAX_RT];      /* dust_ray_tracing.f90:39 */
   double cos_omega_rt1[ORACLE_MAX_RT], sin_omega_rt1[ORACLE_MAX_RT]; /* :40 */
 } __attribute__((aligned(256))) worker_t; /* one cache-line group per thread: no false sharing */
@@ -1547,6 +1548,46 @@ static void save_radiation_field_rt1(worker_t *W, int icell, const double Stokes
     }
 }
 
+/* save_radiation_field, lscatt_ray_tracing2 branch (radiation_field.f90:91-129; 2D): I_spec(N_type_flux, n_theta_I,
+ * n_phi_I, n_cells) and I_spec_star(n_cells), summed over the threads (atomic adds into the shared arrays) */
+static void save_radiation_field_rt2(worker_t *W, int icell, const double Stokes[4], double l, double x0, double y0,
+                                     double z0, double x1, double y1, double z1, double u, double v, double w,
+                                     int flag_star) {
+  const oracle_model *m = W->m;
+  const oracle_mono_opts *o = W->mono;
+  const int n_Stokes = m->lsepar_pola ? 4 : 1, ntf = n_Stokes + (m->lsepar_contrib ? 4 : 0);
+  if (W->flag_direct_star) {
+#ifdef _OPENMP
+#pragma omp atomic
+#endif
+    o->I_spec_star[icell - 1] += l * Stokes[0];
+    return;
+  }
+  const double xm = 0.5 * (x0 + x1), ym = 0.5 * (y0 + y1), zm = 0.5 * (z0 + z1);
+  const double phi_pos = atan2(xm, ym);
+  const double phi_vol = atan2(-u, -v) + 2 * PI;
+  int phi_I = (int)floor(modulo_d(phi_vol - phi_pos, 2 * PI) / (2 * PI) * (double)o->n_phi_I) + 1;
+  if (phi_I > o->n_phi_I) phi_I = 1;
+  int theta_I;
+  if (zm > 0.0) theta_I = (int)floor(0.5 * (w + 1.0) * (double)o->n_theta_I) + 1;
+  else theta_I = (int)floor(0.5 * (-w + 1.0) * (double)o->n_theta_I) + 1;
+  if (theta_I > o->n_theta_I) theta_I = o->n_theta_I;
+  double *rec = o->I_spec + (size_t)ntf * ((size_t)(theta_I - 1) + (size_t)o->n_theta_I * ((size_t)(phi_I - 1) + (size_t)o->n_phi_I * (icell - 1)));
+  for (int t = 0; t < n_Stokes; ++t) {
+#ifdef _OPENMP
+#pragma omp atomic
+#endif
+    rec[t] += l * Stokes[t];
+  }
+  if (m->lsepar_contrib) {
+    double *c = rec + (flag_star ? n_Stokes + 1 : n_Stokes + 3); /* n_Stokes + 2 / + 4, 1-based */
+#ifdef _OPENMP
+#pragma omp atomic
+#endif
+    *c += l * Stokes[0];
+  }
+}
+
 /* physical_length (optical_depth.f90:21-182), letape_th branch only */
 /* optional accumulators of save_radiation_field's thermal branch (radiation_field.f90:54-55), shared by the threads */
 static double *g_xN_abs = NULL, *g_xJ_abs = NULL;
@@ -1564,7 +1605,7 @@ static void physical_length(worker_t *W, int lambda, const double Stokes[4],
   int lintersect_stars, i_star, icell_star, lstop = 0, lcell_not_empty;
   *flag_sortie = 0;
   W->cnt[ORC_CNT_FLIGHTS]++;
-  if (W->mono && W->mono->rt1) angles_scatt_rt1(W, *u, *v, *w);   /* :65 */
+  if (W->mono && W->mono->rt1 == 1) angles_scatt_rt1(W, *u, *v, *w);   /* :65 */
 
   oracle_intersect_stars(m, x0, y0, z0, *u, *v, *w, &lintersect_stars, &i_star,
                          &icell_star);                              /* :68 */
@@ -1632,8 +1673,10 @@ static void physical_length(worker_t *W, int lambda, const double Stokes[4],
           g_xJ_abs[(size_t)(icell0 - 1) + (size_t)m->n_cells * (size_t)(lambda - 1)] += l_contrib * Stokes[0];
         }
       }
-      else if (W->mono->rt1)
+      else if (W->mono->rt1 == 1)
         save_radiation_field_rt1(W, icell0, Stokes, l_contrib, x0, y0, z0, x1, y1, z1, flag_star);
+      else if (W->mono->rt1 == 2)
+        save_radiation_field_rt2(W, icell0, Stokes, l_contrib, x0, y0, z0, x1, y1, z1, *u, *v, *w, flag_star);
     }
     if (lstop) {                                                    /* :153 */
       *flag_sortie = 0;
@@ -1873,6 +1916,7 @@ static void propagate_packet(worker_t *W, int *lambda, int p_lambda,
       }
     }
     const uint64_t cross_before = W->cnt[ORC_CNT_CROSSINGS], dark_before = W->cnt[ORC_CNT_DARK];
+    W->flag_direct_star = *flag_star && !*flag_scatt;
     physical_length(W, *lambda, Stokes, icell, x, y, z, u, v, w, *flag_star, tau,
                     &flag_sortie, lpacket_alive);             /* :1243 */
     /* :1244-1249 counts the flights that end in the cell they started in; here: that never left it (in a 2D grid
@@ -2135,11 +2179,12 @@ int oracle_run_mono(const oracle_model *m, const oracle_mono_opts *o, double *xI
                     double *sed, double *n_sent, uint64_t *n_sent_chunk,
                     uint64_t *counters) {
   int nth = o->n_threads > 0 ? o->n_threads : 1;
-  if (m->p_n_cells && (!m->v_prob_s11_pos || (o->rt1 && !m->v_tab_s11_pos))) return 32; /* variable dust: the classes' scattering tables */
+  if (m->p_n_cells && (!m->v_prob_s11_pos || (o->rt1 == 1 && !m->v_tab_s11_pos))) return 32; /* variable dust: the classes' scattering tables */
   if (o->lambda < 1 || o->lambda > m->n_lambda || o->p_lambda < 1 || o->n_chunks < 1) return 23;
-  if (o->rt1 && (m->RT_n_incl * m->RT_n_az > ORACLE_MAX_RT || m->RT_n_incl < 1 || (!m->p_n_cells && !m->tab_s11_pos))) return 24;
+  if (o->rt1 == 1 && (m->RT_n_incl * m->RT_n_az > ORACLE_MAX_RT || m->RT_n_incl < 1 || (!m->p_n_cells && !m->tab_s11_pos))) return 24;
   const size_t nsed = (size_t)ORACLE_N_SED_TYPES * m->n_lambda * m->N_thet * m->N_phi;
-  const size_t nxI = o->rt1 ? (size_t)m->n_az_rt * m->n_theta_rt * m->N_type_flux * m->RT_n_incl * m->RT_n_az * (size_t)m->n_cells : 0;
+  if (o->rt1 == 2 && (m->l3D || m->grid_type != 1 || !o->I_spec || !o->I_spec_star || o->n_theta_I < 1 || o->n_phi_I < 1)) return 25; /* rt2: 2D only */
+  const size_t nxI = o->rt1 == 1 ? (size_t)m->n_az_rt * m->n_theta_rt * m->N_type_flux * m->RT_n_incl * m->RT_n_az * (size_t)m->n_cells : 0;
   double *sed_t = (double *)calloc(nsed * nth, sizeof(double));
   double *ns_t = (double *)calloc((size_t)m->n_lambda * nth, sizeof(double));
   worker_t *Ws = NULL;

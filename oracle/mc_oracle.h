@@ -273,8 +273,12 @@ typedef struct {
   double n_photons2;   /* n_photons_lambda */
   double n_phot_lim;   /* n_photons_lim */
   int capt_sup;
-  int rt1;             /* lscatt_ray_tracing1: deposit xI_scatt */
+  int rt1;             /* 1: lscatt_ray_tracing1, deposit xI_scatt; 2: lscatt_ray_tracing2 (2D), deposit I_spec / I_spec_star */
   int n_threads;
+  /* ray tracing method 2 (radiation_field.f90:91-129): the caller's arrays, zeroed by it, in the reference's layout
+   * I_spec(N_type_flux, n_theta_I, n_phi_I, n_cells), I_spec_star(n_cells) -- in double (the reference's are default real) */
+  int n_theta_I, n_phi_I;
+  double *I_spec, *I_spec_star;
 } oracle_mono_opts;
 
 /* xI_scatt(n_az_rt, n_theta_rt, N_type_flux, RT_n_incl*RT_n_az, n_cells) summed over

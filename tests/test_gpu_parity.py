@@ -1079,3 +1079,55 @@ def test_voronoi_at_scale_properties():
     assert well.sum() > 10000
     okT, p75 = mc_similar(To[well], Tv[well], 0.05)
     assert okT, p75
+
+
+def test_rt2_deposits_parity():
+    """Ray tracing method 2's deposits (save_radiation_field, radiation_field.f90:91-129): I_spec per cell and direction
+    bin and I_spec_star for unscattered starlight, mcgpu_run_mono with rt1 = 2 against the oracle -- same stopping packets
+    and counters, the arrays to the rounding of the summation order; polarised with contributions, unpolarised, no
+    contributions; conservation: every crossing deposits l * I exactly once (sum of both arrays = sum of xJ-like total)."""
+    from helpers import sed_model
+    for cfg, lam in ((M.small(), 3), (M.small(), 12), (M.small(lsepar_pola=False), 5),
+                     (M.small(lsepar_pola=False, lsepar_contrib=False), 9)):
+        m = sed_model(cfg, n_thermal=50000)
+        e, o = _engine(m, 1e5), _oracle(m, 1e5)
+        a = e.run_mono(lam, 40, seed=11, n_chunks=16, rt2=(15, 15))
+        b = o.run_mono(lam, 40, seed=11, n_chunks=16, n_threads=8, rt2=(15, 15))
+        assert np.array_equal(a["n_sent_chunk"], b["n_sent_chunk"]) and a["counters"] == b["counters"]
+        assert np.array_equal(a["sed"][4], b["sed"][4])
+        scale = np.abs(b["I_spec"]).max()
+        # a path whose midpoint sits on the midplane or on a bin edge to rounding may land in the neighbouring bin
+        # (see helpers.xI_close): compare the sums over the direction bins tightly, the bins themselves almost everywhere
+        # (Q, U, V inherit the default-real trigonometry of update_Stokes, scattering.f90:1218: 1 ulp of default real per
+        # scattering between sincosf and glibc -- the tolerance of the rt1 test)
+        ns = 4 if (cfg.lsepar_pola and cfg.aniso_method == 1) else 1
+        rt = np.full(a["I_spec"].shape[-1], 1e-9)
+        at = np.full(a["I_spec"].shape[-1], 1e-12 * scale)
+        if ns == 4:
+            rt[1:4], at[1:4] = 3e-5, 1e-6 * scale
+        sa, sb = a["I_spec"].sum(axis=(1, 2)), b["I_spec"].sum(axis=(1, 2))
+        assert np.all(np.abs(sa - sb) <= rt * np.abs(sb) + at)
+        # the midplane layer (cells 1..n_rad): a path from its upper to its mirrored lower wall has its midpoint at
+        # z = +-rounding, and the sign picks cos(theta) or its mirror image (radiation_field.f90:114-118): compare the sum of
+        # a bin and its mirror there
+        nr = cfg.n_rad
+        ua, ub = a["I_spec"].copy(), b["I_spec"].copy()
+        ua[:nr] = ua[:nr] + ua[:nr, :, ::-1]
+        ub[:nr] = ub[:nr] + ub[:nr, :, ::-1]
+        bad = np.abs(ua - ub) > rt * np.abs(ub) + at
+        assert bad.sum() <= max(4, 2e-4 * np.count_nonzero(ub)), (bad.sum(), np.count_nonzero(ub))
+        assert np.allclose(a["I_spec_star"], b["I_spec_star"], rtol=1e-9, atol=1e-12 * max(scale, b["I_spec_star"].max()))
+        if lam == 3:
+            assert a["I_spec_star"].sum() > 0 and a["I_spec"][..., 0].sum() > 0
+        if cfg.lsepar_contrib:   # I = its star + dust parts (slots n_Stokes + 2 and n_Stokes + 4)
+            assert np.allclose(a["I_spec"][..., 0], a["I_spec"][..., ns + 1] + a["I_spec"][..., ns + 3], rtol=1e-9, atol=1e-12 * scale)
+        # a second call accumulates; the default-real fetch is the rounding of the sums
+        a2 = e.run_mono(lam, 40, seed=12, n_chunks=16, rt2=(15, 15), accumulate=True)
+        assert a2["I_spec"].sum() > 1.5 * a["I_spec"].sum()
+        e.close()
+    # 3D grids refuse it (the reference: "only 2D")
+    from mcfost_amd.engine import McgpuError
+    e = _engine(M.build_model(M.small(n_rad=10, nz=5, n_az=4, l3D=True)), 1e4)
+    with pytest.raises(McgpuError):
+        e.set_rt2()
+    e.close()
