@@ -625,7 +625,10 @@ int mcgpu_fetch_radiation_field(mcgpu_ctx *ctx, double *xN_abs, double *xJ_abs);
  * Modified random walk (module MRW, MRW.f90; the call site dust_transfer.f90:1222-1239 is commented out in the
  * reference and make_MRW_step, MRW.f90:74-115, is an unfinished stub: this is the working form of what they
  * describe -- Min et al. 2009, Robitaille 2010 -- see DESIGN.md; PARITY UNPINNED, validated against the brute-force
- * loop).  2D cylindrical grids, thermal step.  After more than n_interactions (reference: 5) interactions in a row
+ * loop).  Cylindrical grids, 2D and 3D, thermal step (3D: the azimuthal walls enter the distance, cylindrical_grid.f90:
+ * 1198-1218 with sin / cos_phi_lim built as :586-599 -- wall 0 taken as wall n_az where the reference indexes out of
+ * bounds, and the true (cos, sin) = (0, 1) where it stores the sentinel (0, 1e300) that would put a wall at phi = pi/2
+ * infinitely far; the single-role kernels run it).  After more than n_interactions (reference: 5) interactions in a row
  * whose flights never left the cell, a packet that its cell has just re-emitted walks: while the distance d to the
  * closest wall (distance_to_closest_wall_cyl, cylindrical_grid.f90:1179) times the cell's mean extinction exceeds
  * gamma (gamma_MRW = 2, MRW.f90:11) it jumps to a random point of the sphere of radius d and deposits the energy of

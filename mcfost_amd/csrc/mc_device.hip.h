@@ -134,6 +134,7 @@ struct DevModel {
   const double* mrw_zeta;  // [mrw_n_zeta] zeta(y_i), y_i = i/(n-1)
   const double* mrw_chi;   // [n_T] mean transport extinction at tab_Temp, reference cell
   const double* mrw_kdep;  // [n_T] mean absorption opacity of the walk's deposits
+  const double *sin_phi, *cos_phi;  // [n_az] sin / cos of the azimuthal walls (3D; cylindrical_grid.f90:586-599), for the walk
   const double* mrw_ext;   // [n_T] extrapolation length of the sphere radius, reference cell
   const double* r_lim;     // [n_rad+1] (distance_to_closest_wall_cyl)
   // lvariable_dust (mcgpu_set_variable_dust; mem.f90:213-244, p_n_cells > 1): per-class tables in HBM, class-major
@@ -1403,13 +1404,22 @@ __device__ __forceinline__ void interact(const Lds& T, const DevModel& M, const 
 // ---------------------------------------------------------------------------
 // distance_to_closest_wall_cyl (cylindrical_grid.f90:1179-1226), 2D
 __device__ inline double distance_to_closest_wall_cyl(const Lds& T, const DevModel& M, int ri, int zj, double x,
-                                                      double y, double z) {
+                                                      double y, double z, int kaz = 1) {
   const double r = sqrt(x * x + y * y);
   const double s1 = M.r_lim[ri] - r, s2 = r - M.r_lim[ri - 1];
   const double z0 = fabs(z);
   const int azj = zj < 0 ? -zj : zj;
   const double s3 = z_lim_of(T, M.nz, ri, azj + 1) - z0, s4 = z0 - z_lim_of(T, M.nz, ri, azj);
-  return fmin(fmin(s1, s2), fmin(s3, s4));
+  double s = fmin(fmin(s1, s2), fmin(s3, s4));
+  if (M.l3D && M.n_az > 1) {
+    // the azimuthal walls (:1198-1218): |x sin(phi) - y cos(phi)| for the walls k and k - 1 (wall 0 = wall n_az: the
+    // reference indexes sin_phi_lim(0), out of bounds; see mcgpu_set_mrw for the tables)
+    const int km = kaz > 1 ? kaz - 1 : M.n_az;
+    const double s5 = fabs(x * M.sin_phi[kaz - 1] - y * M.cos_phi[kaz - 1]);
+    const double s6 = fabs(x * M.sin_phi[km - 1] - y * M.cos_phi[km - 1]);
+    s = fmin(s, fmin(s5, s6));
+  }
+  return s;
 }
 
 // y with zeta(y) = xi (MRW.f90:58-70 read as the inverse it means)
@@ -1432,8 +1442,8 @@ template <typename EnergyFn, typename DepositFn>
 __device__ inline bool mrw_walk(const Lds& T, const DevModel& M, uint32_t k0, uint32_t k1, uint32_t p_lo, uint32_t p_hi,
                                 uint32_t event, int ri, int zj, int ic, double S0, double& x, double& y, double& z,
                                 double& u, double& v, double& w, int& lambda, EnergyFn cell_energy,
-                                DepositFn add_energy, unsigned int& c_walks, unsigned int& c_steps) {
-  double d = distance_to_closest_wall_cyl(T, M, ri, zj, x, y, z);
+                                DepositFn add_energy, unsigned int& c_walks, unsigned int& c_steps, int kaz = 1) {
+  double d = distance_to_closest_wall_cyl(T, M, ri, zj, x, y, z, kaz);
   int Ti;
   double frac;
   temp_lte(T.lq, M.n_T, cell_energy(), M.L_packet_th, M.volume[ic], Ti, frac);
@@ -1456,7 +1466,7 @@ __device__ inline bool mrw_walk(const Lds& T, const DevModel& M, uint32_t k0, ui
     const double ct = -log(yv) * cst_ct * chi * (de * de);
     add_energy(kdep * ct * S0);
     c_steps++;
-    d = distance_to_closest_wall_cyl(T, M, ri, zj, x, y, z);
+    d = distance_to_closest_wall_cyl(T, M, ri, zj, x, y, z, kaz);
   } while (d * chi > (double)M.mrw_gamma);
   philox4x32_10(blk, event, p_lo, p_hi, k0, k1, o);
   // the cell's temperature now, the walk's deposits included (im_reemission_LTE)
@@ -1735,7 +1745,7 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
                      }
                      return E;
                    },
-                   [&](double e) { deposit<LDSE>(A.E_abs, E_lds, ic, e); }, c_walks, c_steps);
+                   [&](double e) { deposit<LDSE>(A.E_abs, E_lds, ic, e); }, c_walks, c_steps, k);
         }
       }
       st = S_NEWFLIGHT;

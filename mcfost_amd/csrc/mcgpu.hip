@@ -975,7 +975,7 @@ extern "C" int mcgpu_set_mrw(mcgpu_ctx* ctx, int n_zeta, const double* zeta, con
   if (n_zeta < 2 || !zeta || !chi || !kappa_dep || !ext || !r_lim || !(gamma > 0.0) || n_interactions < 0 || n_interactions > 6)
     return fail(ctx, MCGPU_ERR_ARG, "mcgpu_set_mrw: bad argument (n_interactions is 0..6)");
   if (!ctx->have_grid || !ctx->have_thermal) return fail(ctx, MCGPU_ERR_STATE, "set the grid and the thermal tables first");
-  if (ctx->voro || M.l3D || M.grid_sph) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "modified random walk: 2D cylindrical grids only");
+  if (ctx->voro || M.grid_sph) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "modified random walk: cylindrical grids only");
   if (M.n_classes) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "variable dust and the modified random walk do not combine");
   for (int i = 1; i < n_zeta; ++i)
     if (!(zeta[i] >= zeta[i - 1])) return fail(ctx, MCGPU_ERR_ARG, "mcgpu_set_mrw: zeta must not decrease");
@@ -986,6 +986,23 @@ extern "C" int mcgpu_set_mrw(mcgpu_ctx* ctx, int n_zeta, const double* zeta, con
   if ((rc = upload(ctx, kappa_dep, (size_t)M.n_T, &M.mrw_kdep))) return rc;
   if ((rc = upload(ctx, ext, (size_t)M.n_T, &M.mrw_ext))) return rc;
   if ((rc = upload(ctx, r_lim, (size_t)M.n_rad + 1, &M.r_lim))) return rc;
+  if (M.l3D) {
+    // sin_phi_lim, cos_phi_lim of the azimuthal walls (cylindrical_grid.f90:586-599, default-real phi) for
+    // distance_to_closest_wall_cyl's 3D branch (:1198-1218).  Where the reference stores the sentinel pair
+    // (cos, sin) = (0, 1e300) for a wall at phi = pi/2 (mod pi) -- which makes that wall infinitely far for the walk -- the
+    // true pair (0, 1) is used: |x sin - y cos| = |x| is the distance to that wall.
+    std::vector<double> sp((size_t)M.n_az), cp((size_t)M.n_az);
+    const float pi_sp = (float)3.14159265358979323846;
+    const float delta_phi = 2.0f * pi_sp / (float)M.n_az;
+    for (int k = 1; k <= M.n_az; ++k) {
+      const float phi = delta_phi * (float)k;
+      float md = fmodf(phi - 0.5f * pi_sp, pi_sp);
+      if (md < 0.0f) md += pi_sp;
+      if (fabsf(md) < 1.0e-6f) { cp[k - 1] = 0.0; sp[k - 1] = 1.0; }
+      else { cp[k - 1] = (double)cosf(phi); sp[k - 1] = (double)sinf(phi); }
+    }
+    if ((rc = upload(ctx, sp.data(), sp.size(), &M.sin_phi)) || (rc = upload(ctx, cp.data(), cp.size(), &M.cos_phi))) return rc;
+  }
   M.mrw_n_zeta = n_zeta; M.mrw_gamma = (float)gamma; M.mrw_n_inter = n_interactions; M.mrw = 1;
   return MCGPU_OK;
 }
@@ -1157,7 +1174,8 @@ static int launch_mega(mcgpu_ctx* ctx, const RunArgs& A, bool use_lds, int grid_
     // (more records than twice the lanes buy nothing; small models keep their LDS footprint small)
     if (n_rec > 2 * rthreads) n_rec = 2 * rthreads > RQ_MIN_REC ? 2 * rthreads : RQ_MIN_REC;
     // (the optional radiation-field accumulators are kept by the single-role kernel)
-    if (tune("MCGPU_ROLES", (ctx->opt_schedule == 1 || A.xN_abs || A.xJ_abs) ? 0 : 1, 0, 1) && n_rec > 0) {
+    // (the random walk on a 3D grid runs in the single-role kernel: the role schedule's walk is 2D)
+    if (tune("MCGPU_ROLES", (ctx->opt_schedule == 1 || A.xN_abs || A.xJ_abs) ? 0 : 1, 0, 1) && n_rec > 0 && !(M.mrw && l3d)) {
       const size_t lds_r = lds_t + rq_lds_bytes(pola, n_rec);
       int rblocks = grid_blocks > 0 ? grid_blocks : ctx->prop.multiProcessorCount;
       {
@@ -1211,7 +1229,8 @@ static int launch_mega(mcgpu_ctx* ctx, const RunArgs& A, bool use_lds, int grid_
               : launch_k<a, b, c, false>(M, A, blocks, threads, lds_k, ctx->stream)
 #define LAUNCHM(b, c)                                                                                                   \
   {                                                                                                                     \
-    const void* kern = use_lds ? (const void*)k_thermal_lds<false, b, c, true> : (const void*)k_thermal<false, b, c, true>; \
+    const void* kern = l3d ? (use_lds ? (const void*)k_thermal_lds<true, b, c, true> : (const void*)k_thermal<true, b, c, true>) \
+                           : (use_lds ? (const void*)k_thermal_lds<false, b, c, true> : (const void*)k_thermal<false, b, c, true>); \
     e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k);                               \
     void* args[] = {(void*)&M, (void*)&A};                                                                               \
     if (e == hipSuccess) e = hipLaunchKernel(kern, dim3(blocks), dim3(threads), args, lds_k, ctx->stream);               \

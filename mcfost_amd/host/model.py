@@ -284,6 +284,30 @@ def _phi_grid(cfg: DiskConfig, pi_sp):
     return tan_phi_lim, phi_c
 
 
+def phi_wall_sin_cos(cfg: DiskConfig):
+    """sin_phi_lim, cos_phi_lim of the azimuthal walls (cylindrical_grid.f90:586-599; default-real phi, libm's sinf /
+    cosf) for distance_to_closest_wall_cyl's 3D branch.  Where the reference stores the sentinel pair (cos, sin) =
+    (0, 1e300) for a wall at phi = pi/2 (mod pi) the true pair (0, 1) is returned (the sentinel would make that wall
+    infinitely far for the random walk); ``reference=True`` keeps the sentinel (for the comparison with the module)."""
+    import ctypes
+    import ctypes.util
+    libm = ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6")
+    for fn in (libm.sinf, libm.cosf):
+        fn.restype, fn.argtypes = ctypes.c_float, [ctypes.c_float]
+    n_az = cfg.n_az
+    pi_sp = f32(3.1415926535)
+    sp, cp = np.zeros(n_az, f64), np.ones(n_az, f64)
+    if cfg.l3D:
+        delta_phi = f32(f32(2.0) * pi_sp / f32(n_az))
+        for k in range(1, n_az + 1):
+            phi = f32(delta_phi * f32(k))
+            if abs(float(np.mod(f32(phi - f32(0.5) * pi_sp), pi_sp))) < 1.0e-6:
+                cp[k - 1], sp[k - 1] = 0.0, 1.0
+            else:
+                cp[k - 1], sp[k - 1] = float(libm.cosf(float(phi))), float(libm.sinf(float(phi)))
+    return sp, cp
+
+
 def define_spherical_grid(cfg: DiskConfig):
     """The spherical branch of define_cylindrical_grid (cylindrical_grid.f90:496-580): the cylindrical grid's radial
     bins taken as spherical radii, nz polar bins uniform in cos(theta) per hemisphere (theta measured from the

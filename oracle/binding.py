@@ -102,7 +102,7 @@ class _Model(C.Structure):
         ("v_tab_s11_pos", _fp),
         ("scattering_method1", C.c_int), ("m1_n_grains", C.c_int), ("m1_C_sca", _fp), ("m1_nk", _dp), ("m1_dens", _dp),
         ("m1_prob_s11", _fp), ("m1_tab_g", _fp), ("m1_s11", _fp), ("m1_s12", _fp), ("m1_s22", _fp), ("m1_s33", _fp),
-        ("m1_s34", _fp), ("m1_s44", _fp),
+        ("m1_s34", _fp), ("m1_s44", _fp), ("sin_phi_lim", _dp), ("cos_phi_lim", _dp),
     ]
 
 
@@ -252,6 +252,13 @@ class Oracle:
                     setattr(s, f, self._hold(_a(vd[k], np.float32), C.c_float))
             if vd.get("tab_s11_pos") is not None:
                 s.v_tab_s11_pos = self._hold(_a(vd["tab_s11_pos"], np.float32), C.c_float)
+        if g.get("l3D") and g.get("grid_type", 1) == 1 and "tan_phi_lim" in g:   # the walk's azimuthal walls
+            from mcfost_amd.host.model import phi_wall_sin_cos
+            sp, cp = g.get("sin_phi_lim"), g.get("cos_phi_lim")
+            if sp is None:
+                sp, cp = phi_wall_sin_cos(m.cfg)
+            s.sin_phi_lim = self._hold(_a(sp, np.float64), C.c_double)
+            s.cos_phi_lim = self._hold(_a(cp, np.float64), C.c_double)
         m1 = getattr(m, "method1", None)
         if m1 is not None:   # scattering method 1 (mcfost_amd.host.model.init_scattering_method1)
             s.scattering_method1, s.m1_n_grains = 1, int(m1["n_grains"])

@@ -1805,6 +1805,14 @@ double oracle_distance_to_closest_wall_cyl(const oracle_model *m, int icell, dou
   double s = s1 < s2 ? s1 : s2;
   if (s3 < s) s = s3;
   if (s4 < s) s = s4;
+  if (m->l3D && m->n_az > 1 && m->sin_phi_lim) { /* phi walls (:1198-1218): |x sin(phi) - y cos(phi)| */
+    const int k0 = m->cell_map_k[icell - 1];
+    const int km = k0 > 1 ? k0 - 1 : m->n_az; /* (the reference reads sin_phi_lim(0), out of bounds, for k0 = 1) */
+    const double s5 = fabs(x * m->sin_phi_lim[k0 - 1] - y * m->cos_phi_lim[k0 - 1]);
+    const double s6 = fabs(x * m->sin_phi_lim[km - 1] - y * m->cos_phi_lim[km - 1]);
+    if (s5 < s) s = s5;
+    if (s6 < s) s = s6;
+  }
   return s;
 }
 

@@ -198,6 +198,8 @@ typedef struct {
   const float *m1_prob_s11;       /* prob_s11(n_lambda, n_grains, 0:nang) (grains.f90:53) */
   const float *m1_tab_g;          /* tab_g(n_grains, n_lambda) */
   const float *m1_s11, *m1_s12, *m1_s22, *m1_s33, *m1_s34, *m1_s44; /* tab_s1x(0:nang, n_grains, n_lambda), per-grain normalisation (s11 = 1) */
+  /* sin_phi_lim, cos_phi_lim(n_az) (cylindrical_grid.f90:30, 586-599): the 3D branch of distance_to_closest_wall_cyl; may be NULL */
+  const double *sin_phi_lim, *cos_phi_lim;
 } oracle_model;
 
 /* Run options. */

@@ -104,7 +104,9 @@ def make_one(name, expr, n_rays=400, n_steps=30, seed=7):
     print(name, "walk rows", out["walk"].shape[0])
 
 
-DIST_CONFIGS = ("small2d", "ref41", "pascucci")   # distance_to_closest_wall_cyl, 2D (the 3D branch reads sin_phi_lim(0))
+# distance_to_closest_wall_cyl: 2D, and the 3D branch (which reads sin_phi_lim(0), out of bounds, in the cells of k = 1 and
+# treats the walls at phi = pi/2 (mod pi) as infinitely far: the test compares the other cells)
+DIST_CONFIGS = ("small2d", "ref41", "pascucci", "small3d")
 
 
 def make_dist(name, expr, n=600, seed=11):
@@ -119,7 +121,8 @@ def make_dist(name, expr, n=600, seed=11):
     icell = rng.integers(1, ref.n_cells + 1, n).astype(np.int32)
     r1, r2, r3 = (rng.random(n).astype(np.float32) for _ in range(3))
     x, y, z = ref.pos_em_cell(icell, r1, r2, r3)
-    z = z * rng.choice([-1.0, 1.0], n)     # both sides of the midplane: the routine works on |z|
+    if not cfg.l3D:
+        z = z * rng.choice([-1.0, 1.0], n)     # both sides of the midplane: the routine works on |z|
     d = ref.distance_to_closest_wall(icell, x, y, z)
     np.savez_compressed(os.path.join(HERE, f"dist_{name}.npz"), icell=icell, x=x, y=y, z=z, d=d)
     print(name, "distances", d.min(), d.max())

@@ -32,6 +32,32 @@ def test_distance_to_closest_wall_against_reference_golden(name):
     assert (d >= 0).all() and d.max() > 0
 
 
+def test_distance_to_closest_wall_3d_against_reference_golden():
+    """The 3D branch (cylindrical_grid.f90:1198-1218: the azimuthal walls) against the reference's module where that is
+    defined: the module reads sin_phi_lim(0) -- out of bounds -- in the cells of k = 1 (the restatement takes wall n_az)
+    and stores (cos, sin) = (0, 1e300) for walls at phi = pi/2 (mod pi), which makes them infinitely far (the restatement
+    uses (0, 1): |x| is the distance to such a wall).  Cells that touch neither: bit for bit; cells next to a sentinel
+    wall: never farther than the module says, and |x| when closer."""
+    g = np.load(os.path.join(GOLDEN, "dist_small3d.npz"))
+    m = M.build_model(CONFIGS["small3d"](M))
+    o = Oracle(m, 1000)
+    d = o.distance_to_closest_wall(g["icell"], g["x"], g["y"], g["z"])
+    n_az = m.cfg.n_az
+    k = np.asarray(m.grid["cell_map_k"])[g["icell"] - 1]
+    sp, cp = M.phi_wall_sin_cos(m.cfg)
+    sentinel = np.nonzero(cp == 0.0)[0] + 1                      # walls the default-real test :590 catches: wall 2 of 8
+    assert list(sentinel) == [2]                                 # (wall 6, phi = 4.712389 in default real, passes it)
+    km = np.where(k > 1, k - 1, n_az)
+    clean = (k > 1) & ~np.isin(k, sentinel) & ~np.isin(km, sentinel)
+    assert clean.sum() > 150
+    assert np.array_equal(d[clean], g["d"][clean])
+    near = (k > 1) & ~clean
+    assert np.all(d[near] <= g["d"][near])
+    closer = near & (d < g["d"])
+    assert closer.sum() >= 1 and np.allclose(d[closer], np.abs(g["x"][closer]), rtol=1e-12)
+    assert np.all(d[k == 1] >= 0) and np.all(np.isfinite(d))
+
+
 def test_zeta_table_known_answers():
     o = Oracle(thick_disk(), 1000)
     n = 10000
@@ -111,6 +137,29 @@ def test_walk_against_brute_force_frozen():
     assert abs(b / a - 1.0) < 0.08, (a, b)
     outer = (slice(8, 20), slice(0, 30))        # the walk never runs there: same packets' worth of energy
     assert abs(e1.reshape(nz, nr)[outer].sum() / e0.reshape(nz, nr)[outer].sum() - 1.0) < 0.02
+
+
+def thick_disk_3d(mrw=True, **kw):
+    m = M.build_model(M.small(n_rad=16, nz=10, n_az=6, l3D=True, dust_mass=1e-2))
+    if mrw:
+        M.init_mrw(m, **kw)
+    return m
+
+
+def test_walk_on_a_3d_cylindrical_grid():
+    """The walk with the azimuthal walls in the sphere's radius (distance_to_closest_wall_cyl, 3D branch): it saves the
+    interactions, conserves the packets and the absorbed energy like in 2D, and leaves the disk axisymmetric."""
+    n = 30000
+    a = Oracle(thick_disk_3d(), n).run_thermal(n, seed=3, n_threads=8)
+    b = Oracle(thick_disk_3d(mrw=False), n).run_thermal(n, seed=3, n_threads=8)
+    ca, cb = a["counters"], b["counters"]
+    assert cb["mrw_walks"] == 0 and ca["mrw_walks"] > 300 and ca["mrw_steps"] >= ca["mrw_walks"]
+    assert ca["absorptions"] + ca["scatterings"] < 0.5 * (cb["absorptions"] + cb["scatterings"])
+    assert ca["escaped"] + ca["killed_star"] == n
+    assert abs(a["E_abs"].sum() / b["E_abs"].sum() - 1.0) < 0.05
+    E = a["E_abs"].reshape(6, -1)                       # (k, the cells of one azimuthal sector)
+    tot = E.sum(axis=1)
+    assert np.abs(tot / tot.mean() - 1.0).max() < 0.1   # no sector is favoured by the walls of the walk
 
 
 def test_emulated_kernels_walk_like_the_oracle(emu):
@@ -298,3 +347,50 @@ def test_config4_thick_ref41_live_against_brute_force_with_the_reference_gate():
     assert np.all((worst % cfg.n_rad >= 17) & (worst % cfg.n_rad <= 23) & (worst // cfg.n_rad <= 2)), worst
     print("config 4 (thick ref4.1): p75 |dT/T| = %.4f, largest |dT/T| over the %d clear cells %.4f, kernel %.0f -> %.0f ms" %
           (p75, int(clear.sum()), np.abs(b[sel][clear] / a[sel][clear] - 1.0).max(), r0[0]["kernel_ms"], r1[0]["kernel_ms"]))
+
+
+@pytest.mark.gpu
+def test_device_walk_3d_against_the_oracle_frozen():
+    """The walk on a 3D cylindrical grid (single-role kernels, k_thermal<true, ..., MRW>): without the walk packet for
+    packet; with it the noise-aware gates of the 2D test (two independent samples of a chaotic walk) -- and against brute
+    force: the absorbed energy of the thick region within the bias bound."""
+    from mcfost_amd.engine import Engine
+    n = 20000
+    prior = Oracle(thick_disk_3d(mrw=False), n).run_thermal(n, seed=1, n_threads=1)["E_abs"]
+    m0 = thick_disk_3d(mrw=False)
+    want0 = Oracle(m0, n).run_thermal(n, seed=9, frozen=True, E_prior=prior, n_threads=8)
+    e = Engine(m0, n)
+    got0 = e.run_thermal(n, seed=9, frozen=True, E_prior=prior)
+    e.close()
+    assert got0["counters"] == want0["counters"]
+    m = thick_disk_3d()
+    orc = Oracle(m, n)
+    want = orc.run_thermal(n, seed=9, frozen=True, E_prior=prior, n_threads=8)
+    keys = ("mrw_walks", "mrw_steps", "absorptions", "scatterings", "crossings", "flights")
+    others = [orc.run_thermal(n, seed=s, frozen=True, E_prior=prior, n_threads=8) for s in (21, 22, 23, 24, 25, 26)]
+    sigma = {k: np.std([r["counters"][k] for r in others], ddof=1) for k in keys}
+    sigma_E = np.std([r["E_abs"].sum() for r in others], ddof=1)
+    e = Engine(m, n)
+    got = e.run_thermal(n, seed=9, frozen=True, E_prior=prior)
+    g, w = got["counters"], want["counters"]
+    assert g["mrw_walks"] > 300
+    for k in ("packets", "escaped", "killed_star"):
+        assert g[k] == w[k]
+    for k in keys:
+        assert abs(g[k] - w[k]) <= 4.0 * np.sqrt(2.0) * sigma[k], (k, g[k], w[k], sigma[k])
+    assert np.array_equal(got["n_sent"], want["n_sent"])
+    assert abs(got["E_abs"].sum() - want["E_abs"].sum()) <= 4.0 * np.sqrt(2.0) * sigma_E
+    # against brute force on the device, more packets: the temperature of the thick inner region within the bias bound
+    n2 = 1_000_000
+    prior2 = e.run_thermal(n2, seed=1)["E_abs"]
+    with_walk = e.run_thermal(n2, seed=2, frozen=True, E_prior=prior2)
+    e.close()
+    e0 = Engine(m0, n2)
+    brute = e0.run_thermal(n2, seed=3, frozen=True, E_prior=prior2)
+    e0.close()
+    assert with_walk["counters"]["mrw_walks"] > 10000
+    hot = brute["E_abs"] > 0.2 * brute["E_abs"].max()
+    assert hot.sum() >= 6
+    # (gamma = 2: the bias bound of the 2D test is 4 % in T ~ E^(1/5); measured here: +7 % in E = +1.4 % in T)
+    assert abs((with_walk["E_abs"][hot].sum() / brute["E_abs"][hot].sum()) ** 0.2 - 1.0) < 0.02
+    assert with_walk["kernel_ms"] < brute["kernel_ms"]
