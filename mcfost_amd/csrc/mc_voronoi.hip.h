@@ -142,6 +142,7 @@ __device__ inline void voro_cross_cell(const VoroGrid& G, const DevModel& M, con
   next_cell = 0;
   const VoroNb* nb = G.nb + C.first;
   const int cnt = C.count;
+  const int last = cnt > 0 ? cnt - 1 : 0;  // (where the fetches past the end of the list are pointed)
   // The walls of the box among the neighbours (ids -1 .. -6; their distance is a genuine double with two more
   // divisions) are only noted in the scan -- (position, wall) in 10 bits each, at most six -- and compared after it:
   // a wave runs this loop as long as its longest list, and the wall branch would be taken on almost every trip by
@@ -162,7 +163,7 @@ __device__ inline void voro_cross_cell(const VoroGrid& G, const DevModel& M, con
   VoroNb Nn[VG];
   if (MCGPU_VORO_AHEAD) {
 #pragma unroll
-    for (int j = 0; j < VG; ++j) Nn[j] = nb[j < cnt ? j : cnt - 1];
+    for (int j = 0; j < VG; ++j) Nn[j] = nb[j < cnt ? j : last];
   }
   for (int i0 = 0; i0 < cnt; i0 += VG) {
     VoroNb Nc[VG];
@@ -171,11 +172,11 @@ __device__ inline void voro_cross_cell(const VoroGrid& G, const DevModel& M, con
       for (int j = 0; j < VG; ++j) Nc[j] = Nn[j];
       if (i0 + VG < cnt) {
 #pragma unroll
-        for (int j = 0; j < VG; ++j) Nn[j] = nb[(i0 + VG + j < cnt) ? i0 + VG + j : cnt - 1];
+        for (int j = 0; j < VG; ++j) Nn[j] = nb[(i0 + VG + j < cnt) ? i0 + VG + j : last];
       }
     } else {
 #pragma unroll
-      for (int j = 0; j < VG; ++j) Nc[j] = nb[(i0 + j < cnt) ? i0 + j : cnt - 1];
+      for (int j = 0; j < VG; ++j) Nc[j] = nb[(i0 + j < cnt) ? i0 + j : last];
     }
 #pragma unroll
     for (int j = 0; j < VG; ++j) {
