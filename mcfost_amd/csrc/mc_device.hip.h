@@ -145,6 +145,7 @@ struct DevModel {
   const float* v_albedo;     // [n_classes][n_lambda]
   const double* v_lq;        // [n_classes][n_T]
   const double* v_cdf;       // [n_classes][n_T][n_lambda]
+  const double2* v_kk;       // [n_cells + 1][n_lambda] (kappa(p_icell, l) kappa_factor(icell), kappa_abs_LTE(p_icell, l)); the last row 0
   // ... and, when the host passed them (v_scatt != 0), the scattering tables per class
   int v_scatt;
   const float* v_prob;       // [n_classes][p_lambda_fixed ? 1 : n_lambda][nang+1]
@@ -400,6 +401,21 @@ __device__ inline Lds class_tables(const Lds& T, const DevModel& M, int cls) {
     V.g = const_cast<float*>(M.v_g) + (size_t)cls * M.n_lambda;
   }
   return V;
+}
+
+// the per-cell opacity pairs of the variable-dust role kernel (DevModel::v_kk): one thread per (cell, wavelength)
+__global__ void k_build_vkk(const DevModel M, double2* out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t n = ((size_t)M.n_cells + 1) * M.n_lambda;
+  if (i >= n) return;
+  const int ic = (int)(i / M.n_lambda), l = (int)(i - (size_t)ic * M.n_lambda);
+  double2 v = make_double2(0.0, 0.0);
+  if (ic < M.n_cells) {
+    const size_t row = (size_t)M.cell_class[ic] * M.n_lambda + l;
+    v.x = M.v_kappa[row] * M.kappa_factor[ic];
+    v.y = M.v_kabs[row];
+  }
+  out[i] = v;
 }
 
 // ---------------------------------------------------------------------------

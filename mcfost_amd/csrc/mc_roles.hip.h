@@ -168,18 +168,34 @@ struct Flight {
   double x, y, z, u, v, w, extr, S0, inv_a, inv_w, kf, kap, kab;
   int ri, zj, k, star_key, st;
   unsigned int pk_cross;
+  int lam;  // (VAR: the packet's wavelength, for the per-cell opacities)
 };
 
 __device__ inline void flight_clear(Flight& F) {
   F.x = F.y = F.z = F.u = F.v = 0.0; F.w = 1.0; F.extr = 0.0; F.S0 = 1.0; F.inv_a = F.inv_w = F.kf = F.kap = F.kab = 0.0;
-  F.ri = 0; F.zj = 1; F.k = 1; F.star_key = -1; F.st = S_EMIT; F.pk_cross = 0u;
+  F.ri = 0; F.zj = 1; F.k = 1; F.star_key = -1; F.st = S_EMIT; F.pk_cross = 0u; F.lam = 1;
 }
 
-template <bool L3D>
+// VAR (lvariable_dust): the opacities change from cell to cell.  DevModel::v_kk holds, per (cell, wavelength), the pair
+// (kappa(p_icell, lambda) * kappa_factor(icell), kappa_abs_LTE(p_icell, lambda)) -- one 16-byte gather per cell entered
+// instead of the 8 bytes of kappa_factor; the flight then carries kap = 1, kf = the product, kab = the cell's value.
+__device__ inline void var_cell_opacities(const DevModel& M, Flight& F, int ic) {
+  const double2 kk = M.v_kk[(size_t)ic * M.n_lambda + (F.lam - 1)];
+  F.kf = kk.x;
+  F.kab = kk.y;
+}
+
+template <bool L3D, bool VAR = false>
 __device__ inline void flight_constants(const Lds& T, const DevModel& M, Flight& F, int lambda) {
   const double a = F.u * F.u + F.v * F.v;  // cylindrical_grid.f90:941-952
   F.inv_a = (a > TINY_REAL) ? 1.0 / a : HUGE_REAL;
   F.inv_w = (fabs(F.w) > TINY_REAL) ? 1.0 / F.w : copysign(HUGE_DP, F.w);
+  if (VAR) {
+    F.lam = lambda;
+    F.kap = 1.0;
+    var_cell_opacities(M, F, is_real_cell<L3D>(M.n_rad, M.nz, F.ri, F.zj) ? cell_index<L3D>(M.n_rad, M.nz, F.ri, F.zj, F.k) : M.n_cells);
+    return;
+  }
   F.kap = T.kappa[lambda - 1];
   F.kab = T.kabs[lambda - 1];
   F.kf = is_real_cell<L3D>(M.n_rad, M.nz, F.ri, F.zj) ? M.kappa_factor[cell_index<L3D>(M.n_rad, M.nz, F.ri, F.zj, F.k)] : 0.0;
@@ -259,7 +275,7 @@ __device__ inline int roles_cross(const Lds& T, const DevModel& M, const RunArgs
 // Every value that decides an index or a position is computed by the reference's expression, exactly as in
 // cross_cell_lean / roles_cross above (cylindrical_grid.f90:918-1175, optical_depth.f90:77-178).
 // OUT: the deposit is handed back (dep_ic >= 0, dep_v) instead of being made (the tail kernel, mc_tail.hip.h)
-template <bool DARK, bool LDSE, bool MRW = false, bool OUT = false>
+template <bool DARK, bool LDSE, bool MRW = false, bool OUT = false, bool VAR = false>
 __device__ __forceinline__ int fly_step_2d(const Lds& T, const DevModel& M, const RunArgs& A, double* E_lds, Flight& p,
                                            unsigned int& c_cross, unsigned int& c_kill, unsigned int& c_dark,
                                            int* dep_ic = nullptr, double* dep_v = nullptr) {
@@ -364,7 +380,9 @@ __device__ __forceinline__ int fly_step_2d(const Lds& T, const DevModel& M, cons
   bool mirror = false;
   if (DARK) mirror = go && !stop && next_real && M.dark[next_real ? ic1 : 0];
   const bool move = go && !stop && !mirror;
-  const double kf1 = M.kappa_factor[ic1];
+  // (VAR: the pair (kappa kappa_factor, kappa_abs_LTE) of the next cell and this wavelength, see var_cell_opacities)
+  const double2 kk1 = VAR ? M.v_kk[(size_t)ic1 * M.n_lambda + (p.lam - 1)] : make_double2(M.kappa_factor[ic1], 0.0);
+  const double kf1 = kk1.x;
 
   // 5) commit
   // x and y: one multiply-add with the length that applies (l to the wall, lc to the stopping point, 0: the packet
@@ -378,6 +396,7 @@ __device__ __forceinline__ int fly_step_2d(const Lds& T, const DevModel& M, cons
   p.ri = move ? ri1 : ri0;
   p.zj = move ? zj1 : zj0;
   p.kf = move ? kf1 : p.kf;
+  if (VAR) p.kab = move ? kk1.y : p.kab;
   if (DARK) {
     p.u = mirror ? -u : u; p.v = mirror ? -v : v; p.w = mirror ? -w : w;
     c_dark += mirror ? 1u : 0u;
@@ -404,7 +423,7 @@ __device__ __forceinline__ int fly_step_2d(const Lds& T, const DevModel& M, cons
 // central hole (atan2), and the rare fallbacks of the zj recomputation.  The wall at tan(phi) = +-1e300 and the
 // ordinary azimuthal wall share ONE division (numerator and denominator are selected first).
 // BIN: the deposit is handed back (dep_ic >= 0, dep_v) for the caller's bin_deposit.
-template <bool DARK, bool LDSE, bool BIN>
+template <bool DARK, bool LDSE, bool BIN, bool VAR = false>
 __device__ __forceinline__ int fly_step_3d(const Lds& T, const DevModel& M, const RunArgs& A, double* E_lds, Flight& p,
                                            unsigned int& c_cross, unsigned int& c_kill, unsigned int& c_dark, int& dep_ic,
                                            double& dep_v) {
@@ -539,7 +558,9 @@ __device__ __forceinline__ int fly_step_3d(const Lds& T, const DevModel& M, cons
   bool mirror = false;
   if (DARK) mirror = go && !stop && next_real && M.dark[next_real ? ic1 : 0];
   const bool move = go && !stop && !mirror;
-  const double kf1 = M.kappa_factor[ic1];
+  // (VAR: the pair (kappa kappa_factor, kappa_abs_LTE) of the next cell and this wavelength, see var_cell_opacities)
+  const double2 kk1 = VAR ? M.v_kk[(size_t)ic1 * M.n_lambda + (p.lam - 1)] : make_double2(M.kappa_factor[ic1], 0.0);
+  const double kf1 = kk1.x;
 
   // 6) commit (x, y: one multiply-add with the length that applies, as in fly_step_2d)
   const double lf = stop ? lc : (move ? dv : 0.0);
@@ -551,6 +572,7 @@ __device__ __forceinline__ int fly_step_3d(const Lds& T, const DevModel& M, cons
   p.zj = move ? zj1 : zj0;
   p.k = move ? k1 : k0;
   p.kf = move ? kf1 : p.kf;
+  if (VAR) p.kab = move ? kk1.y : p.kab;
   if (__builtin_expect(stop, 0)) index_cell<true>(T, M, p.x, p.y, p.z, p.ri, p.zj, p.k);  // (:140: 3D re-indexes the stopping point)
   if (DARK) {
     p.u = mirror ? -u : u; p.v = mirror ? -v : v; p.w = mirror ? -w : w;
@@ -620,7 +642,9 @@ __device__ inline int voro_roles_cross(const Lds& T, const DevModel& M, const Ru
 // absorbed-energy array does not fit in LDS), the staging area sits between the tables and the queues.
 // CARRY: the kernel can end early and hand its unfinished packets over (RunArgs::carry_out; "Chunks without tails"
 // above, and the tail kernel, mc_tail.hip.h); BIN implies it.
-template <bool L3D, bool POLA, bool DARK, bool LDSE, bool MRW = false, bool VORO = false, bool BIN = false, bool CARRY = BIN>
+// VAR: lvariable_dust -- the flights read the per-cell opacities (var_cell_opacities), the interactions the tables of the
+// cell's class (class_tables); cylindrical grids, no MRW.
+template <bool L3D, bool POLA, bool DARK, bool LDSE, bool MRW = false, bool VORO = false, bool BIN = false, bool CARRY = BIN, bool VAR = false>
 __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, double* lds_base, int n_rec, int n_srv_pref,
                                            int k_short, int fly_iters, int fly_idle, int emit_qmax,
                                            const VoroGrid* Gp = nullptr, int cache_log_ns = 0) {
@@ -628,6 +652,7 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
   static_assert(!BIN || (!LDSE && !MRW && !VORO), "binned deposits: grids that do not fit in LDS");
   static_assert(!BIN || CARRY, "the chunks of a binned run hand their packets on");
   static_assert(!CARRY || !VORO, "no carry-over on Voronoi grids");
+  static_assert(!VAR || (!MRW && !VORO && !BIN && !CARRY), "variable dust: the plain role kernel on cylindrical grids");
   double* const E_lds = lds_base;
   const Lds T = lds_carve(lds_base + (LDSE ? M.n_cells : 0), M);
   lds_stage(T, M);
@@ -795,7 +820,7 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
         }
         st = S_FLIGHT;
         if (VORO) { F.kap = T.kappa[bag_lambda - 1]; F.kab = T.kabs[bag_lambda - 1]; }
-        else flight_constants<L3D>(T, M, F, bag_lambda);
+        else flight_constants<L3D, VAR>(T, M, F, bag_lambda);
       }
       // stopped packets that found no flight to swap with go to a free record
       {
@@ -844,10 +869,10 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
             int dep_ic = -1;
             double dep_v = 0.0;
             if (MCGPU_3D_BRANCHY) { if (F.st == S_FLIGHT) finished += roles_cross<L3D, DARK, LDSE, BIN>(T, M, A, E_lds, F, c_cross, c_kill, c_dark, dep_ic, dep_v); }
-            else finished += fly_step_3d<DARK, LDSE, BIN>(T, M, A, E_lds, F, c_cross, c_kill, c_dark, dep_ic, dep_v);
+            else finished += fly_step_3d<DARK, LDSE, BIN, VAR>(T, M, A, E_lds, F, c_cross, c_kill, c_dark, dep_ic, dep_v);
             if (BIN) bin_deposit(BS, A.bin, A.E_abs, lane, BP, dep_ic >= 0, dep_ic, dep_v);
           } else {
-            finished += fly_step_2d<DARK, LDSE, MRW>(T, M, A, E_lds, F, c_cross, c_kill, c_dark);
+            finished += fly_step_2d<DARK, LDSE, MRW, false, VAR>(T, M, A, E_lds, F, c_cross, c_kill, c_dark);
           }
         }
         if (BIN) bin_settle(BS, A.bin, A.E_abs, lane, BP);
@@ -971,7 +996,7 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
         // the new direction, then (Stokes tracking) the Stokes vector.  Only the new direction, the scattering
         // angle bin and one draw cross the phase boundary in registers.
         double u1 = 0.0, v1 = 0.0, w1 = 1.0;
-        int itheta = 1, lambda_sc = 1;
+        int itheta = 1, lambda_sc = 1, vcls = -1, igrain = 0;  // (VAR: the cell's class, the grain of scattering method 1)
         float rand2 = 0.0f;
         bool scat = false;
         const bool inter = rid >= 0 && st == S_INTERACT;
@@ -987,7 +1012,10 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
           const int fl = R.flags;
           bool flag_star = (fl & ST_STAR) != 0, flag_scatt = (fl & ST_SCATT) != 0, flag_ism = (fl & ST_ISM) != 0;
           const int ic = VORO ? R.ri - 1 : cell_index<L3D>(n_rad, nz, R.ri, R.zj, R.k);
-          scat = interact_direction(T, M, g, lambda, R.u, R.v, R.w, u1, v1, w1, flag_star, flag_scatt, c_scatt, c_abs, [&]() {
+          const int cls = VAR ? M.cell_class[ic] : -1;
+          const Lds Tc = VAR ? class_tables(T, M, cls) : T;   // (lvariable_dust: this cell's tables)
+          vcls = cls;
+          scat = interact_direction(Tc, M, g, lambda, R.u, R.v, R.w, u1, v1, w1, flag_star, flag_scatt, c_scatt, c_abs, [&]() {
             // the cell's absorbed energy for Temp_LTE (thermal_emission.f90:649-706): what every workgroup has
             // folded into HBM so far plus (LDSE) this workgroup's not yet folded part -- the other workgroups'
             // unfolded parts are estimated by this one's, exactly the reference's partial * nb_proc
@@ -1002,7 +1030,7 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
               E *= A.qscale;
             }
             return E;
-          }, M.volume + ic, itheta, rand2);
+          }, M.volume + ic, itheta, rand2, false, nullptr, -1, (VAR && M.m1) ? cls : -1, &igrain);
           if (!flag_scatt) flag_ism = false;  // absorbed and re-emitted by the dust (:1367)
           R.lambda = lambda;
           R.event = rng.event;
@@ -1021,7 +1049,7 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
           if (inter) {
             Rec<POLA>& R = recs[rid];
             double S[4] = {R.S[0], R.S[POLA ? 1 : 0], R.S[POLA ? 2 : 0], R.S[POLA ? 3 : 0]};
-            interact_stokes(M, scat, lambda_sc, itheta, rand2, R.u, R.v, R.w, u1, v1, w1, S);
+            interact_stokes(M, scat, lambda_sc, itheta, rand2, R.u, R.v, R.w, u1, v1, w1, S, (VAR && M.v_scatt) ? vcls : -1, igrain);
             R.S[0] = S[0]; R.S[POLA ? 1 : 0] = S[1]; R.S[POLA ? 2 : 0] = S[2]; R.S[POLA ? 3 : 0] = S[3];
             R.u = u1; R.v = v1; R.w = w1;
           }
@@ -1086,7 +1114,7 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
             F.x = R.x; F.y = R.y; F.z = R.z; F.u = R.u; F.v = R.v; F.w = R.w; F.extr = R.extr; F.S0 = R.S[0];
             F.ri = R.ri; F.zj = R.zj; F.k = R.k; F.star_key = R.star_key; F.pk_cross = R.pk_cross;
             if (VORO) { F.kap = T.kappa[R.lambda - 1]; F.kab = T.kabs[R.lambda - 1]; }
-            else flight_constants<L3D>(T, M, F, R.lambda);
+            else flight_constants<L3D, VAR>(T, M, F, R.lambda);
           }
           const int n_it = flying_in_place ? fly_iters : k_short;
 #pragma unroll 1
@@ -1099,10 +1127,10 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
               int dep_ic = -1;
               double dep_v = 0.0;
               if (MCGPU_3D_BRANCHY) { if (F.st == S_FLIGHT) finished += roles_cross<L3D, DARK, LDSE, BIN>(T, M, A, E_lds, F, c_cross, c_kill, c_dark, dep_ic, dep_v); }
-              else finished += fly_step_3d<DARK, LDSE, BIN>(T, M, A, E_lds, F, c_cross, c_kill, c_dark, dep_ic, dep_v);
+              else finished += fly_step_3d<DARK, LDSE, BIN, VAR>(T, M, A, E_lds, F, c_cross, c_kill, c_dark, dep_ic, dep_v);
               if (BIN) bin_deposit(BS, A.bin, A.E_abs, lane, BP, dep_ic >= 0, dep_ic, dep_v);
             } else {
-              finished += fly_step_2d<DARK, LDSE, MRW>(T, M, A, E_lds, F, c_cross, c_kill, c_dark);
+              finished += fly_step_2d<DARK, LDSE, MRW, false, VAR>(T, M, A, E_lds, F, c_cross, c_kill, c_dark);
             }
           }
           if (BIN) bin_settle(BS, A.bin, A.E_abs, lane, BP);
@@ -1279,6 +1307,15 @@ __global__ void __launch_bounds__(MCGPU_ROLES_BLOCK) k_thermal_roles(const DevMo
 }
 
 // the same, handing its last packets to the tail kernel (mc_tail.hip.h); 2D grids (the 3D kernel below has it built in)
+// lvariable_dust in the role schedule (the tables gain the cell axis -- the flights gather 16 bytes per
+// cell entered, the interactions read the class's rows from HBM)
+template <bool L3D, bool POLA, bool DARK, bool LDSE>
+__global__ void __launch_bounds__(MCGPU_ROLES_BLOCK) k_thermal_roles_var(const DevModel M, const RunArgs A, int n_rec, int n_srv_pref,
+                                                                         int k_short, int fly_iters, int fly_idle, int emit_qmax) {
+  extern __shared__ double lds_raw[];
+  roles_body<L3D, POLA, DARK, LDSE, false, false, false, false, true>(M, A, lds_raw, n_rec, n_srv_pref, k_short, fly_iters, fly_idle, emit_qmax);
+}
+
 template <bool POLA, bool DARK, bool LDSE, bool MRW>
 __global__ void __launch_bounds__(MCGPU_ROLES_BLOCK) k_thermal_roles_tail(const DevModel M, const RunArgs A, int n_rec, int n_srv_pref,
                                                                           int k_short, int fly_iters, int fly_idle, int emit_qmax) {

@@ -55,6 +55,8 @@ struct mcgpu_ctx {
   bool reemission_pending = false;  // set_thermal / set_variable_dust left the LTE tables to mcgpu_init_reemission
   bool pending_single = false, pending_classes = false;  // ... which of the two sets
   int lsepar_pola = 0;
+  double2* d_vkk = nullptr;         // the variable-dust role kernel's per-cell opacity pairs (built at the first launch)
+  bool vkk_valid = false;
   std::vector<void*> opacity_allocs;  // the per-class tables mcgpu_opacity built (freed by the next call)
   float T_min = 1.0f;
   // mcgpu_set_option
@@ -213,6 +215,7 @@ extern "C" int mcgpu_destroy(mcgpu_ctx* ctx) {
   if (ctx->d_E_prior) hipFree(ctx->d_E_prior);
   if (ctx->d_xI) hipFree(ctx->d_xI);
   if (ctx->d_I_spec) hipFree(ctx->d_I_spec);
+  if (ctx->d_vkk) hipFree(ctx->d_vkk);
   if (ctx->d_I_spec_star) hipFree(ctx->d_I_spec_star);
   if (ctx->d_prob_E) hipFree(ctx->d_prob_E);
   if (ctx->d_mono_u64) hipFree(ctx->d_mono_u64);
@@ -549,6 +552,7 @@ extern "C" int mcgpu_set_opacity(mcgpu_ctx* ctx, int n_lambda, const double* kap
   if (!ctx->have_grid) return fail(ctx, MCGPU_ERR_STATE, "set the grid before the opacities");
   if (ctx->M.n_lambda && ctx->M.n_lambda != n_lambda) return fail(ctx, MCGPU_ERR_ARG, "n_lambda mismatch");
   HIPCHK(hipSetDevice(ctx->device));
+  ctx->vkk_valid = false;  // (kappa_factor enters the variable-dust role kernel's per-cell pairs)
   DevModel& M = ctx->M;
   M.n_lambda = n_lambda;
   int rc;
@@ -744,6 +748,7 @@ extern "C" int mcgpu_set_variable_dust(mcgpu_ctx* ctx, int p_n_cells, const int*
     M.v_scatt = 1;
   }
   M.n_classes = nc;
+  ctx->vkk_valid = false;
   return MCGPU_OK;
 }
 
@@ -877,6 +882,7 @@ extern "C" int mcgpu_opacity(mcgpu_ctx* ctx, const mcgpu_grain_tables* G, int p_
   HIPCHK(hipStreamSynchronize(ctx->stream));
   M.v_scatt = 1;
   M.n_classes = nc;
+  ctx->vkk_valid = false;
   ctx->pending_classes = true;  // log_Qcool and kdB_dT_CDF of the classes: mcgpu_init_reemission, from the new kappa_abs_LTE
   ctx->reemission_pending = true;
   if (out) {  // copies in the reference's layouts: (p_n_cells, n_lambda) and (0:nang, p_n_cells, n_lambda)
@@ -1136,9 +1142,45 @@ static int launch_mega(mcgpu_ctx* ctx, const RunArgs& A, bool use_lds, int grid_
   // tables.  MCGPU_ROLES: -1 = the single-role kernel (thermal_body), 0..7 = that
   // many fixed flyer waves, 100+f = every wave picks its role per round (flyer when f lanes can fly), 200 = per
   // round, the role in which more of its lanes have work (default).
-  if (M.n_classes) {  // lvariable_dust: the HBM-gather variant of the single-role kernel
+  if (M.n_classes) {  // lvariable_dust
     if (M.mrw) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "variable dust and the modified random walk do not combine");
     const void* fn;
+    // the role schedule (k_thermal_roles_var) wherever its records fit; option "schedule" = 1 or the radiation-field
+    // extras: the HBM-gather variant of the single-role kernel below
+    {
+      const int rthreads = (block_threads > 0 && block_threads <= MCGPU_ROLES_BLOCK) ? block_threads : MCGPU_ROLES_BLOCK;
+      if (rthreads % 64) return fail(ctx, MCGPU_ERR_ARG, "block_threads must be a multiple of 64");
+      const size_t lds_t = (lds_k + 7) / 8 * 8;
+      int n_rec = lds_t < lds_cap ? rq_records_that_fit(pola, lds_cap - lds_t) : 0;
+      if (n_rec > 2 * rthreads) n_rec = 2 * rthreads > RQ_MIN_REC ? 2 * rthreads : RQ_MIN_REC;
+      if (ctx->opt_schedule != 1 && !A.xN_abs && !A.xJ_abs && n_rec > 0) {
+        if (!ctx->vkk_valid) {  // (kappa kappa_factor, kappa_abs_LTE) per (cell, wavelength): what a flight reads per cell
+          const size_t n = ((size_t)M.n_cells + 1) * M.n_lambda;
+          if (ctx->d_vkk) hipFree(ctx->d_vkk);
+          ctx->d_vkk = nullptr;
+          HIPCHK(hipMalloc((void**)&ctx->d_vkk, n * sizeof(double2)));
+          hipLaunchKernelGGL(k_build_vkk, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, M, ctx->d_vkk);
+          HIPCHK(hipGetLastError());
+          ctx->M.v_kk = ctx->d_vkk;
+          ctx->vkk_valid = true;
+        }
+        DevModel Mv = ctx->M;
+        const size_t lds_r = lds_t + rq_lds_bytes(pola, n_rec);
+        int rblocks = grid_blocks > 0 ? grid_blocks : ctx->prop.multiProcessorCount;
+        const unsigned long long need = (A.n_packets + rthreads - 1) / rthreads;
+        if (grid_blocks <= 0 && (unsigned long long)rblocks > need) rblocks = (int)(need ? need : 1);
+        int n_srv_pref = (rthreads / 64 + 3) / 4, k_short = 2, fly_iters = 16, fly_idle = 32, emit_qmax = 128;
+#define PICKRV(a, l) fn = pola ? (dark ? (const void*)k_thermal_roles_var<a, true, true, l> : (const void*)k_thermal_roles_var<a, true, false, l>) \
+                               : (dark ? (const void*)k_thermal_roles_var<a, false, true, l> : (const void*)k_thermal_roles_var<a, false, false, l>)
+        if (l3d) { if (use_lds) PICKRV(true, true); else PICKRV(true, false); }
+        else { if (use_lds) PICKRV(false, true); else PICKRV(false, false); }
+#undef PICKRV
+        HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));
+        void* rargs[] = {(void*)&Mv, (void*)&A, (void*)&n_rec, (void*)&n_srv_pref, (void*)&k_short, (void*)&fly_iters, (void*)&fly_idle, (void*)&emit_qmax};
+        HIPCHK(hipLaunchKernel(fn, dim3(rblocks), dim3(rthreads), rargs, lds_r, ctx->stream));
+        return MCGPU_OK;
+      }
+    }
 #define PICKV(a, l) fn = pola ? (dark ? (const void*)k_thermal_var<a, true, true, l> : (const void*)k_thermal_var<a, true, false, l>) \
                               : (dark ? (const void*)k_thermal_var<a, false, true, l> : (const void*)k_thermal_var<a, false, false, l>)
     if (l3d) { if (use_lds) PICKV(true, true); else PICKV(true, false); }

@@ -88,8 +88,12 @@ def test_device_method1_equals_the_oracle_frozen(kw):
     n = 20000
     e, o = Engine(m, n), Oracle(m, n)
     prior = o.run_thermal(2000, seed=1)["E_abs"]
-    a = e.run_thermal(n, seed=6, frozen=True, E_prior=prior)
     b = o.run_thermal(n, seed=6, frozen=True, E_prior=prior, n_threads=8)
+    e.set_option("schedule", 1)               # the single-role kernel ...
+    a1 = e.run_thermal(n, seed=6, frozen=True, E_prior=prior)
+    assert a1["counters"] == b["counters"]
+    e.set_option("schedule", 0)               # ... and the role schedule (the default)
+    a = e.run_thermal(n, seed=6, frozen=True, E_prior=prior)
     assert a["counters"] == b["counters"]
     assert np.array_equal(a["n_sent"], b["n_sent"]) and np.array_equal(a["sed"][4], b["sed"][4])
     assert np.allclose(a["E_abs"], b["E_abs"], rtol=1e-9, atol=1e-12 * b["E_abs"].max())

@@ -76,13 +76,15 @@ def test_device_against_the_oracle_frozen(kw):
     orc = Oracle(m, n)
     prior = orc.run_thermal(2000, seed=1)["E_abs"]
     want = orc.run_thermal(n, seed=7, frozen=True, E_prior=prior, n_threads=8)
-    e = Engine(m, n)
-    got = e.run_thermal(n, seed=7, frozen=True, E_prior=prior)
-    assert got["counters"] == want["counters"]
-    assert np.array_equal(got["n_sent"], want["n_sent"]) and np.array_equal(got["sed"][4], want["sed"][4])
-    assert np.allclose(got["E_abs"], want["E_abs"], rtol=1e-7, atol=1e-12 * want["E_abs"].max())   # (FMA-level: grazing segments)
-    assert np.allclose(e.temp_finale(got["E_abs"]), orc.temp_finale(want["E_abs"]), rtol=2e-6)
-    e.close()
+    for schedule in (0, 1):   # the role schedule (k_thermal_roles_var: per-cell opacity pairs) and the single-role kernel
+        e = Engine(m, n)
+        e.set_option("schedule", schedule)
+        got = e.run_thermal(n, seed=7, frozen=True, E_prior=prior)
+        assert got["counters"] == want["counters"], schedule
+        assert np.array_equal(got["n_sent"], want["n_sent"]) and np.array_equal(got["sed"][4], want["sed"][4])
+        assert np.allclose(got["E_abs"], want["E_abs"], rtol=1e-7, atol=1e-12 * want["E_abs"].max())   # (FMA-level: grazing segments)
+        assert np.allclose(e.temp_finale(got["E_abs"]), orc.temp_finale(want["E_abs"]), rtol=2e-6)
+        e.close()
 
 
 @pytest.mark.gpu
