@@ -15,7 +15,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 src, config, dst = sys.argv[1], sys.argv[2], sys.argv[3]
-KERNELS = ("k_thermal", "k_mono", "k_fold_bins")
+KERNELS = ("k_thermal", "k_mono", "k_fold_bins", "k_tail")
 ROUND = "r03"
 
 
