@@ -24,3 +24,8 @@ print("cells over the gate:", bad.size)
 for k in bad[:20]:
     print("cell", k, "ri", k % 100, "zj", k // 100, "T0", T0[:, k], "T1", T1[:, k], "dev %.3f" % dev[k], "se_cell %.3f se_pooled %.3f (rel)" % (se[k] / a[k], rel[k]), "dark-ish? kappa_factor", m0.kappa_factor[k])
 print("p99.9 of dev over sel:", np.percentile(dev[sel], 99.9), "max", dev[sel].max())
+clear = sel & (se_s < 0.002 * a)
+top = np.argsort(-np.where(clear, dev, 0.0))[:30]
+print("largest deviations among the clear cells (ri, zj 1-based):")
+for k in top:
+    print("  ri %3d zj %2d  dev %.4f  T0 %.1f T1 %.1f  rel se %.4f" % (k % 100 + 1, k // 100 + 1, dev[k], a[k], b[k], rel[k]))

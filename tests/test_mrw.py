@@ -335,16 +335,22 @@ def test_config4_thick_ref41_live_against_brute_force_with_the_reference_gate():
     sel = (a > 1.2 * cfg.T_min) & (b > 1.2 * cfg.T_min)
     excess = np.abs(b[sel] - a[sel]) - (0.05 * a[sel] + 5.0 * se_s[sel])
     assert (excess <= 0.0).all(), (float(excess.max()), int(np.argmax(excess)))
-    # the cells above a signal-to-noise floor, where a deviation IS the walk's bias: 4 % at most but for the midplane
-    # cells of the illuminated inner rim (radial cells 19-21, the first behind the n_rad_in subdivision), which the
-    # walk heats by 5 % -- measured on three independent seeds each way (brute force 305.3 / 306.0 / 306.7 K, walk
-    # 321.5 / 322.2 / 321.9 K): packets that still carry scattered starlight do not walk, and the
-    # cell behind the rim sees their neighbours' walks end at its wall.  Stated, located, bounded at 6 %.
+    # the cells above a signal-to-noise floor, where a deviation IS the walk's bias: 4 % at most (the bound at gamma = 2)
+    # but for the columns of the illuminated inner rim (radial cells 18-22, the first behind the n_rad_in subdivision,
+    # up to 12 cells above the midplane), which the walk heats by 3.5-5.1 % -- measured on three independent seeds each
+    # way (ri 20: brute force 366 K, walk 384 K; ri 21: 307 / 321 K): packets that still carry scattered starlight do
+    # not walk, and the cells behind the rim see their neighbours' walks end at their wall.
+    # Stated, located (tests/devtools/mrw_cfg4_debug.py lists them), bounded at 6 %.
     clear = se_s[sel] < 0.002 * a[sel]
     dev_clear = np.abs(b[sel][clear] / a[sel][clear] - 1.0)
-    assert clear.sum() > 1000 and np.percentile(dev_clear, 99.9) < 0.045 and dev_clear.max() < 0.06
-    worst = np.flatnonzero(sel)[clear][dev_clear > 0.04]
-    assert np.all((worst % cfg.n_rad >= 17) & (worst % cfg.n_rad <= 23) & (worst // cfg.n_rad <= 2)), worst
+    ri = np.asarray(m0.grid["cell_map_i"])[:m0.n_cells][sel][clear]
+    zj = np.abs(np.asarray(m0.grid["cell_map_j"])[:m0.n_cells][sel][clear])
+    rim = (ri >= 17) & (ri <= 23) & (zj <= 12)          # the located cells: the columns of the illuminated inner rim
+    assert clear.sum() > 1000 and rim.sum() >= 40
+    assert dev_clear[~rim].max() < 0.04, (float(dev_clear[~rim].max()), int(np.argmax(np.where(rim, 0.0, dev_clear))))
+    assert dev_clear[rim].max() < 0.06
+    worst = np.flatnonzero(sel)[clear][dev_clear > 0.04]    # (0-based cell = (ri - 1) + n_rad (zj - 1): all of them in the rim)
+    assert np.all((worst % cfg.n_rad >= 16) & (worst % cfg.n_rad <= 22) & (worst // cfg.n_rad <= 11)), worst
     print("config 4 (thick ref4.1): p75 |dT/T| = %.4f, largest |dT/T| over the %d clear cells %.4f, kernel %.0f -> %.0f ms" %
           (p75, int(clear.sum()), np.abs(b[sel][clear] / a[sel][clear] - 1.0).max(), r0[0]["kernel_ms"], r1[0]["kernel_ms"]))
 
