@@ -516,8 +516,8 @@ int mcgpu_probe_packet_rand(mcgpu_ctx *ctx, uint64_t seed, uint64_t packet,
  * (mcgpu_run_mono: albedo, opacity and scattering tables of the crossed cell's class; with the tabulated phase function it
  * needs the cumulative tables per wavelength, i.e. mcgpu_set_scattering with p_lambda_fixed = 0, and for rt1 deposits
  * tab_s11_pos per class, mcgpu_set_variable_dust_s11), mcgpu_repartition_energie and the ray tracer (mcgpu_rt1_dust_map,
- * mcgpu_rt1_image, mcgpu_rt1_stars_map_sed) read per class too.  The random walk, the diffusion fill and
- * mcgpu_define_dark_zone are not built for it and refuse such a context.
+ * mcgpu_rt1_image, mcgpu_rt1_stars_map_sed), mcgpu_define_dark_zone and the diffusion fill read per class too.  Only the
+ * random walk is not built for it and refuses such a context.
  * p_n_cells = 0: off.  log_Qcool and kdB_dT_CDF may both be NULL (see mcgpu_init_reemission).
  */
 int mcgpu_set_variable_dust(mcgpu_ctx *ctx, int p_n_cells, const int *p_icell, const double *kappa,

@@ -2056,7 +2056,9 @@ __device__ inline double diffusion_coeff(const DevModel& M, const double* tab_la
       const double wl2 = wl * wl, wl5 = (wl2 * wl2) * wl;
       dB_dT = cst_wl * coeff_exp / (wl5 * ((coeff_exp - 1.0) * (coeff_exp - 1.0)));
     }
-    total_sum = total_sum + dB_dT / (M.kappa[l] * M.kappa_factor[ic]) * delta_wl;
+    // (kappa(p_icell, lambda): the cell's class with lvariable_dust, diffusion.f90:34-60)
+    const double kap = M.n_classes ? M.v_kappa[(size_t)M.cell_class[ic] * M.n_lambda + l] : M.kappa[l];
+    total_sum = total_sum + dB_dT / (kap * M.kappa_factor[ic]) * delta_wl;
   }
   return cst_Dcoeff * total_sum / (Temp * Temp * Temp);
 }

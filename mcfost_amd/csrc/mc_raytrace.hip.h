@@ -397,8 +397,12 @@ __global__ void __launch_bounds__(256) k_dark_zone_rays(const DevModel M, int la
     double x1, y1, z1, l;
     int ri1, zj1, k1;
     MCGPU_CROSS<false>(T, M, x, y, z, u, v, w, inv_a, inv_w, ri, zj, k, x1, y1, z1, ri1, zj1, k1, l);
-    const double opacity = is_real_cell<false>(n_rad, nz, ri, zj)
-                               ? T.kappa[lambda - 1] * M.kappa_factor[cell_index<false>(n_rad, nz, ri, zj, k)] : 0.0;
+    double opacity = 0.0;
+    if (is_real_cell<false>(n_rad, nz, ri, zj)) {
+      const int ic = cell_index<false>(n_rad, nz, ri, zj, k);
+      const double kap = M.n_classes ? M.v_kappa[(size_t)M.cell_class[ic] * M.n_lambda + (lambda - 1)] : T.kappa[lambda - 1];
+      opacity = kap * M.kappa_factor[ic];
+    }
     const double tau = l * opacity;
     if (tau > extr) { flag[icell] = 1; return; }  // the ray stops inside: the cell is dark
     extr = extr - tau;

@@ -2264,7 +2264,6 @@ extern "C" int mcgpu_temp_approx_diffusion_vertical(mcgpu_ctx* ctx, const double
   if (!tab_lambda || !tab_delta_lambda || !zj_sup_dark_zone || !Tdust) return fail(ctx, MCGPU_ERR_ARG, "mcgpu_temp_approx_diffusion_vertical: null argument");
   const DevModel& M = ctx->M;
   if (ctx->voro || M.l3D || M.grid_sph) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "diffusion approximation: 2D cylindrical grids only");
-  if (M.n_classes) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "diffusion approximation with variable dust is not built");
   if (ri_in_dark_zone < 1 || ri_out_dark_zone > M.n_rad) return fail(ctx, MCGPU_ERR_ARG, "dark-zone radii out of range");
   for (int i = 0; i < M.n_rad; ++i)
     if (zj_sup_dark_zone[i] < 0 || zj_sup_dark_zone[i] > M.nz) return fail(ctx, MCGPU_ERR_ARG, "zj_sup_dark_zone out of range");
@@ -2398,25 +2397,34 @@ extern "C" int mcgpu_define_dark_zone(mcgpu_ctx* ctx, int lambda, double tau_max
   if (!r_lim || !r_grid || !z_grid || !z_lim || !l_dark_zone || !ri_in_dark_zone || !ri_out_dark_zone || !zj_sup_dark_zone)
     return fail(ctx, MCGPU_ERR_ARG, "mcgpu_define_dark_zone: null argument");
   const DevModel& M = ctx->M;
-  if (ctx->voro || M.l3D || M.grid_sph || M.n_classes) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "define_dark_zone: 2D cylindrical grids, one dust class");
+  if (ctx->voro || M.l3D || M.grid_sph) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "define_dark_zone: 2D cylindrical grids");
   if (lambda < 1 || lambda > M.n_lambda) return fail(ctx, MCGPU_ERR_ARG, "mcgpu_define_dark_zone: bad wavelength");
   HIPCHK(hipSetDevice(ctx->device));
   const int n_rad = M.n_rad, nz = M.nz;
+  // kf: kappa(p_icell, lambda) * kappa_factor(icell) per cell (:1467: the cell's own class with lvariable_dust)
   std::vector<double> kf(M.n_cells);
   double kap = 0.0;
   HIPCHK(hipMemcpy(kf.data(), M.kappa_factor, (size_t)M.n_cells * sizeof(double), hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(&kap, M.kappa + (lambda - 1), sizeof(double), hipMemcpyDeviceToHost));
+  std::vector<double> kapc(M.n_cells, kap);
+  if (M.n_classes) {
+    std::vector<int> cls(M.n_cells);
+    std::vector<double> vk((size_t)M.n_classes * M.n_lambda);
+    HIPCHK(hipMemcpy(cls.data(), M.cell_class, cls.size() * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(vk.data(), M.v_kappa, vk.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int c = 0; c < M.n_cells; ++c) kapc[c] = vk[(size_t)cls[c] * M.n_lambda + (lambda - 1)];
+  }
   const float tau_max = (float)tau_max_in;  // real, intent(in)
   // steps 1-3 (:1459-1500): the running sums are default reals
   int ri_in = n_rad, ri_out = 1;
   float total = 0.0f;
   for (int i = 1; i <= n_rad; ++i) {
-    total = (float)((double)total + kap * kf[i - 1] * (r_lim[i] - r_lim[i - 1]));
+    total = (float)((double)total + kapc[i - 1] * kf[i - 1] * (r_lim[i] - r_lim[i - 1]));
     if (total > tau_max) { ri_in = i; break; }
   }
   total = 0.0f;
   for (int i = n_rad; i >= 1; --i) {
-    total = (float)((double)total + kap * kf[i - 1] * (r_lim[i] - r_lim[i - 1]));
+    total = (float)((double)total + kapc[i - 1] * kf[i - 1] * (r_lim[i] - r_lim[i - 1]));
     if (total > tau_max) { ri_out = i; break; }
   }
   if (ri_out == n_rad) ri_out = n_rad - 1;
@@ -2425,7 +2433,7 @@ extern "C" int mcgpu_define_dark_zone(mcgpu_ctx* ctx, int lambda, double tau_max
     total = 0.0f;
     for (int j = nz; j >= 1; --j) {
       const double dzl = z_lim[(i - 1) + (size_t)n_rad * j] - z_lim[(i - 1) + (size_t)n_rad * (j - 1)];
-      total = (float)((double)total + kap * kf[(i - 1) + (size_t)n_rad * (j - 1)] * dzl);
+      total = (float)((double)total + kapc[(i - 1) + (size_t)n_rad * (j - 1)] * kf[(i - 1) + (size_t)n_rad * (j - 1)] * dzl);
       if (total > tau_max) { zj[i - 1] = j; break; }
     }
   }

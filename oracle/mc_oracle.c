@@ -2258,8 +2258,7 @@ int oracle_define_dark_zone(const oracle_model *m, int lambda, double tau_max_in
   if (m->l3D || m->grid_type == 3) return 31;
   const int n_rad = m->n_rad, nz = m->nz;
   const float tau_max = (float)tau_max_in; /* real, intent(in) */
-  const double kap = m->kappa[lambda - 1];
-  int ri_in = n_rad, ri_out = 1;
+  int ri_in = n_rad, ri_out = 1;  /* (kappa(p_icell, lambda): the cell's class with lvariable_dust, optical_depth.f90:1454-1458) */
   int *zj_sup = (int *)calloc((size_t)n_rad + 1, sizeof(int));
   if (!zj_sup) return 22;
   memset(dz, 0, (size_t)m->n_cells);
@@ -2267,13 +2266,13 @@ int oracle_define_dark_zone(const oracle_model *m, int lambda, double tau_max_in
   /* step 1: radially from the centre (:1460-1470); cell_map(i,1,1) = i in 2D */
   total = 0.0f;
   for (int i = 1; i <= n_rad; ++i) {
-    total = (float)((double)total + kap * m->kappa_factor[i - 1] * (r_lim[i] - r_lim[i - 1]));
+    total = (float)((double)total + tab_kappa(m, i, lambda) * m->kappa_factor[i - 1] * (r_lim[i] - r_lim[i - 1]));
     if (total > tau_max) { ri_in = i; break; }
   }
   /* step 2: radially from the outer edge (:1473-1482) */
   total = 0.0f;
   for (int i = n_rad; i >= 1; --i) {
-    total = (float)((double)total + kap * m->kappa_factor[i - 1] * (r_lim[i] - r_lim[i - 1]));
+    total = (float)((double)total + tab_kappa(m, i, lambda) * m->kappa_factor[i - 1] * (r_lim[i] - r_lim[i - 1]));
     if (total > tau_max) { ri_out = i; break; }
   }
   if (ri_out == n_rad) ri_out = n_rad - 1;
@@ -2283,7 +2282,7 @@ int oracle_define_dark_zone(const oracle_model *m, int lambda, double tau_max_in
     for (int j = nz; j >= 1; --j) {
       const int icell = i + n_rad * (j - 1);
       const double dzl = m->z_lim[(i - 1) + (size_t)n_rad * j] - m->z_lim[(i - 1) + (size_t)n_rad * (j - 1)];
-      total = (float)((double)total + kap * m->kappa_factor[icell - 1] * dzl);
+      total = (float)((double)total + tab_kappa(m, icell, lambda) * m->kappa_factor[icell - 1] * dzl);
       if (total > tau_max) { zj_sup[i] = j; break; }
     }
   }
@@ -2334,17 +2333,16 @@ int oracle_dark_zone_extent(const oracle_model *m, int lambda, double tau_max_in
   if (m->l3D || m->grid_type != 1) return 31;
   const int n_rad = m->n_rad, nz = m->nz;
   const float tau_max = (float)tau_max_in;
-  const double kap = m->kappa[lambda - 1];
-  int ri_in = n_rad, ri_out = 1;
+  int ri_in = n_rad, ri_out = 1;  /* (kappa(p_icell, lambda): the cell's class with lvariable_dust, optical_depth.f90:1454-1458) */
   float total = 0.0f;
   for (int i = 0; i < n_rad; ++i) zj_sup[i] = 0;
   for (int i = 1; i <= n_rad; ++i) {
-    total = (float)((double)total + kap * m->kappa_factor[i - 1] * (r_lim[i] - r_lim[i - 1]));
+    total = (float)((double)total + tab_kappa(m, i, lambda) * m->kappa_factor[i - 1] * (r_lim[i] - r_lim[i - 1]));
     if (total > tau_max) { ri_in = i; break; }
   }
   total = 0.0f;
   for (int i = n_rad; i >= 1; --i) {
-    total = (float)((double)total + kap * m->kappa_factor[i - 1] * (r_lim[i] - r_lim[i - 1]));
+    total = (float)((double)total + tab_kappa(m, i, lambda) * m->kappa_factor[i - 1] * (r_lim[i] - r_lim[i - 1]));
     if (total > tau_max) { ri_out = i; break; }
   }
   if (ri_out == n_rad) ri_out = n_rad - 1;
@@ -2353,7 +2351,7 @@ int oracle_dark_zone_extent(const oracle_model *m, int lambda, double tau_max_in
     for (int j = nz; j >= 1; --j) {
       const int icell = i + n_rad * (j - 1);
       const double dzl = m->z_lim[(i - 1) + (size_t)n_rad * j] - m->z_lim[(i - 1) + (size_t)n_rad * (j - 1)];
-      total = (float)((double)total + kap * m->kappa_factor[icell - 1] * dzl);
+      total = (float)((double)total + tab_kappa(m, icell, lambda) * m->kappa_factor[icell - 1] * dzl);
       if (total > tau_max) { zj_sup[i - 1] = j; break; }
     }
   }
@@ -2392,7 +2390,7 @@ static double diffusion_coeff(const oracle_model *m, const double *tab_lambda, c
     } else {
       dB_dT = 0.0;
     }
-    total_sum = total_sum + dB_dT / (m->kappa[l] * m->kappa_factor[icell - 1]) * delta_wl;
+    total_sum = total_sum + dB_dT / (tab_kappa(m, icell, l + 1) * m->kappa_factor[icell - 1]) * delta_wl; /* kappa(p_icell, lambda), diffusion.f90:60 */
   }
   return cst_Dcoeff * total_sum / (Temp * Temp * Temp);
 }

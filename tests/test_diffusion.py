@@ -209,3 +209,29 @@ def test_device_define_dark_zone_equals_the_oracle():
     dz, *_ = e.define_dark_zone(lam, 1500.0)
     e.close()
     assert np.array_equal(dz, Oracle(m, 1000).define_dark_zone(lam, 1500.0)) and dz.sum() == 301
+
+
+@pytest.mark.gpu
+def test_dark_zone_and_diffusion_fill_on_variable_dust():
+    """lvariable_dust: define_dark_zone (kappa(p_icell, lambda) in the optical depths of steps 1-3 and in the test rays,
+    optical_depth.f90:1454-1551) and the diffusion fill (setDiffusion_coeff's Rosseland sum with the cell's own kappa,
+    diffusion.f90:34-60) on a settled thick disk: the device against the oracle, and the classes matter."""
+    from mcfost_amd.engine import Engine
+    m, lam = thick_disk()
+    o1 = Oracle(m, 1000)
+    dz1 = o1.define_dark_zone(lam, 1500.0)
+    M.init_variable_dust(m, n_classes=5, slope=0.3)
+    o = Oracle(m, 1000)
+    want = o.define_dark_zone(lam, 1500.0)
+    ext = o.dark_zone_extent(lam, 1500.0)
+    assert want.sum() > 0 and not np.array_equal(want, dz1)            # the classes change the zone
+    e = Engine(m, 1000)
+    dz, ri_in, ri_out, zj = e.define_dark_zone(lam, 1500.0)
+    assert np.array_equal(dz, want) and (ri_in, ri_out) == ext[:2] and np.array_equal(zj, ext[2])
+    T0 = surface_temperature(m)
+    want_T, it_o = o.temp_approx_diffusion_vertical(T0, ri_in, ri_out, zj)
+    got_T, it_d = e.temp_approx_diffusion_vertical(T0, ri_in, ri_out, zj)
+    e.close()
+    assert abs(it_d - it_o) <= 0.01 * it_o + 2, (it_d, it_o)
+    assert np.allclose(got_T, want_T, rtol=2e-5), np.abs(got_T / want_T - 1).max()
+    assert (got_T != T0).any()
