@@ -516,8 +516,8 @@ int mcgpu_probe_packet_rand(mcgpu_ctx *ctx, uint64_t seed, uint64_t packet,
  * (mcgpu_run_mono: albedo, opacity and scattering tables of the crossed cell's class; with the tabulated phase function it
  * needs the cumulative tables per wavelength, i.e. mcgpu_set_scattering with p_lambda_fixed = 0, and for rt1 deposits
  * tab_s11_pos per class, mcgpu_set_variable_dust_s11), mcgpu_repartition_energie and the ray tracer (mcgpu_rt1_dust_map,
- * mcgpu_rt1_image, mcgpu_rt1_stars_map_sed), mcgpu_define_dark_zone and the diffusion fill read per class too.  Only the
- * random walk is not built for it and refuses such a context.
+ * mcgpu_rt1_image, mcgpu_rt1_stars_map_sed), mcgpu_define_dark_zone, the diffusion fill and the random walk (mcgpu_set_mrw
+ * with one row of tables per class) read per class too.
  * p_n_cells = 0: off.  log_Qcool and kdB_dT_CDF may both be NULL (see mcgpu_init_reemission).
  */
 int mcgpu_set_variable_dust(mcgpu_ctx *ctx, int p_n_cells, const int *p_icell, const double *kappa,
@@ -639,6 +639,8 @@ int mcgpu_fetch_radiation_field(mcgpu_ctx *ctx, double *xN_abs, double *xJ_abs);
  *   kappa_dep[n_T]   mean of kappa_abs_LTE with which the walk's path deposits ("Planck_opacity")
  *   ext[n_T]         length added to d in the path (zeros: the formula of MRW.f90:99 as written)
  *   r_lim[n_rad+1]   cylindrical_grid's r_lim(0:n_rad)
+ * With lvariable_dust (set before this call) chi, kappa_dep and ext hold one row of n_T values per class, class after
+ * class; the walk of a cell reads its class's row (single-role kernels).
  * n_zeta = 0 switches the walk off.  Counters 8 and 9 count walks and sphere steps.
  */
 int mcgpu_set_mrw(mcgpu_ctx *ctx, int n_zeta, const double *zeta, const double *chi,

@@ -1464,10 +1464,13 @@ __device__ inline bool mrw_walk(const Lds& T, const DevModel& M, uint32_t k0, ui
   double frac;
   temp_lte(T.lq, M.n_T, cell_energy(), M.L_packet_th, M.volume[ic], Ti, frac);
   const double kf = M.kappa_factor[ic];
-  const double chi = (M.mrw_chi[Ti - 2] * (1.0 - frac) + M.mrw_chi[Ti - 1] * frac) * kf;
+  // (lvariable_dust: the mean opacities of the cell's class, [n_classes][n_T]; T then holds the class's lq / cdf)
+  const size_t co = M.n_classes ? (size_t)M.cell_class[ic] * M.n_T : 0;
+  const double *t_chi = M.mrw_chi + co, *t_kdep = M.mrw_kdep + co, *t_ext = M.mrw_ext + co;
+  const double chi = (t_chi[Ti - 2] * (1.0 - frac) + t_chi[Ti - 1] * frac) * kf;
   if (!(d * chi > (double)M.mrw_gamma)) return false;
-  const double kdep = M.mrw_kdep[Ti - 2] * (1.0 - frac) + M.mrw_kdep[Ti - 1] * frac;
-  const double ext = (M.mrw_ext[Ti - 2] * (1.0 - frac) + M.mrw_ext[Ti - 1] * frac) / kf;
+  const double kdep = t_kdep[Ti - 2] * (1.0 - frac) + t_kdep[Ti - 1] * frac;
+  const double ext = (t_ext[Ti - 2] * (1.0 - frac) + t_ext[Ti - 1] * frac) / kf;
   const double cst_ct = 3.0 / (PI * PI);
   double su, sv, sw;
   uint32_t blk = 0, o[4];
@@ -1750,7 +1753,7 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
         // modified random walk of a packet the cell has just re-emitted for the (n_inter+1)-th time in a row
         // (dust_transfer.f90:1222-1239; mrw_walk above)
         if (__builtin_expect(!flag_scatt && !flag_star && n_inter > M.mrw_n_inter, 0)) {
-          mrw_walk(T, M, rng.k0, rng.k1, rng.p_lo, rng.p_hi, rng.event, ri, zj, ic, S[0], x, y, z, u, v, w, lambda,
+          mrw_walk(Tc, M, rng.k0, rng.k1, rng.p_lo, rng.p_hi, rng.event, ri, zj, ic, S[0], x, y, z, u, v, w, lambda,
                    [&]() {
                      double E;
                      if (A.frozen) E = A.E_prior[ic];
@@ -1931,10 +1934,10 @@ __global__ void __launch_bounds__(256) k_thermal(const DevModel M, const RunArgs
 
 // lvariable_dust: per-class opacity / re-emission / scattering tables gathered from HBM (any cylindrical grid; LDSE: the
 // workgroup's private absorbed-energy grid in LDS like k_thermal_lds, otherwise HBM deposits like k_thermal)
-template <bool L3D, bool POLA, bool DARK, bool LDSE>
+template <bool L3D, bool POLA, bool DARK, bool LDSE, bool MRW = false>
 __global__ void __launch_bounds__(LDSE ? MCGPU_LDS_BLOCK : 256) k_thermal_var(const DevModel M, const RunArgs A) {
   extern __shared__ double lds_raw[];
-  thermal_body<L3D, POLA, DARK, LDSE, false, false, true>(M, A, lds_raw);
+  thermal_body<L3D, POLA, DARK, LDSE, false, MRW, true>(M, A, lds_raw);
 }
 
 // the spherical grid (spherical_grid.f90): the same packet loop with that grid's operators; no dark zone

@@ -55,6 +55,7 @@ struct mcgpu_ctx {
   bool reemission_pending = false;  // set_thermal / set_variable_dust left the LTE tables to mcgpu_init_reemission
   bool pending_single = false, pending_classes = false;  // ... which of the two sets
   int lsepar_pola = 0;
+  int mrw_classes = 0;              // the number of classes the random walk's tables were set for
   double2* d_vkk = nullptr;         // the variable-dust role kernel's per-cell opacity pairs (built at the first launch)
   bool vkk_valid = false;
   std::vector<void*> opacity_allocs;  // the per-class tables mcgpu_opacity built (freed by the next call)
@@ -982,15 +983,17 @@ extern "C" int mcgpu_set_mrw(mcgpu_ctx* ctx, int n_zeta, const double* zeta, con
     return fail(ctx, MCGPU_ERR_ARG, "mcgpu_set_mrw: bad argument (n_interactions is 0..6)");
   if (!ctx->have_grid || !ctx->have_thermal) return fail(ctx, MCGPU_ERR_STATE, "set the grid and the thermal tables first");
   if (ctx->voro || M.grid_sph) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "modified random walk: cylindrical grids only");
-  if (M.n_classes) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "variable dust and the modified random walk do not combine");
   for (int i = 1; i < n_zeta; ++i)
     if (!(zeta[i] >= zeta[i - 1])) return fail(ctx, MCGPU_ERR_ARG, "mcgpu_set_mrw: zeta must not decrease");
   HIPCHK(hipSetDevice(ctx->device));
   int rc;
   if ((rc = upload(ctx, zeta, (size_t)n_zeta, &M.mrw_zeta))) return rc;
-  if ((rc = upload(ctx, chi, (size_t)M.n_T, &M.mrw_chi))) return rc;
-  if ((rc = upload(ctx, kappa_dep, (size_t)M.n_T, &M.mrw_kdep))) return rc;
-  if ((rc = upload(ctx, ext, (size_t)M.n_T, &M.mrw_ext))) return rc;
+  // (lvariable_dust, set before this call: one row of n_T values per class)
+  const size_t n_tab = (size_t)M.n_T * (M.n_classes ? M.n_classes : 1);
+  ctx->mrw_classes = M.n_classes;
+  if ((rc = upload(ctx, chi, n_tab, &M.mrw_chi))) return rc;
+  if ((rc = upload(ctx, kappa_dep, n_tab, &M.mrw_kdep))) return rc;
+  if ((rc = upload(ctx, ext, n_tab, &M.mrw_ext))) return rc;
   if ((rc = upload(ctx, r_lim, (size_t)M.n_rad + 1, &M.r_lim))) return rc;
   if (M.l3D) {
     // sin_phi_lim, cos_phi_lim of the azimuthal walls (cylindrical_grid.f90:586-599, default-real phi) for
@@ -1142,8 +1145,9 @@ static int launch_mega(mcgpu_ctx* ctx, const RunArgs& A, bool use_lds, int grid_
   // tables.  MCGPU_ROLES: -1 = the single-role kernel (thermal_body), 0..7 = that
   // many fixed flyer waves, 100+f = every wave picks its role per round (flyer when f lanes can fly), 200 = per
   // round, the role in which more of its lanes have work (default).
+  if (M.mrw && ctx->mrw_classes != M.n_classes)
+    return fail(ctx, MCGPU_ERR_STATE, "the random walk's tables belong to another set of dust classes: mcgpu_set_mrw after mcgpu_set_variable_dust");
   if (M.n_classes) {  // lvariable_dust
-    if (M.mrw) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "variable dust and the modified random walk do not combine");
     const void* fn;
     // the role schedule (k_thermal_roles_var) wherever its records fit; option "schedule" = 1 or the radiation-field
     // extras: the HBM-gather variant of the single-role kernel below
@@ -1153,7 +1157,7 @@ static int launch_mega(mcgpu_ctx* ctx, const RunArgs& A, bool use_lds, int grid_
       const size_t lds_t = (lds_k + 7) / 8 * 8;
       int n_rec = lds_t < lds_cap ? rq_records_that_fit(pola, lds_cap - lds_t) : 0;
       if (n_rec > 2 * rthreads) n_rec = 2 * rthreads > RQ_MIN_REC ? 2 * rthreads : RQ_MIN_REC;
-      if (ctx->opt_schedule != 1 && !A.xN_abs && !A.xJ_abs && n_rec > 0) {
+      if (ctx->opt_schedule != 1 && !A.xN_abs && !A.xJ_abs && n_rec > 0 && !M.mrw) {  // (the walk: single-role kernel)
         if (!ctx->vkk_valid) {  // (kappa kappa_factor, kappa_abs_LTE) per (cell, wavelength): what a flight reads per cell
           const size_t n = ((size_t)M.n_cells + 1) * M.n_lambda;
           if (ctx->d_vkk) hipFree(ctx->d_vkk);
@@ -1181,10 +1185,15 @@ static int launch_mega(mcgpu_ctx* ctx, const RunArgs& A, bool use_lds, int grid_
         return MCGPU_OK;
       }
     }
-#define PICKV(a, l) fn = pola ? (dark ? (const void*)k_thermal_var<a, true, true, l> : (const void*)k_thermal_var<a, true, false, l>) \
-                              : (dark ? (const void*)k_thermal_var<a, false, true, l> : (const void*)k_thermal_var<a, false, false, l>)
-    if (l3d) { if (use_lds) PICKV(true, true); else PICKV(true, false); }
-    else { if (use_lds) PICKV(false, true); else PICKV(false, false); }
+#define PICKV(a, l, w) fn = pola ? (dark ? (const void*)k_thermal_var<a, true, true, l, w> : (const void*)k_thermal_var<a, true, false, l, w>) \
+                                 : (dark ? (const void*)k_thermal_var<a, false, true, l, w> : (const void*)k_thermal_var<a, false, false, l, w>)
+    if (M.mrw) {
+      if (l3d) { if (use_lds) PICKV(true, true, true); else PICKV(true, false, true); }
+      else { if (use_lds) PICKV(false, true, true); else PICKV(false, false, true); }
+    } else {
+      if (l3d) { if (use_lds) PICKV(true, true, false); else PICKV(true, false, false); }
+      else { if (use_lds) PICKV(false, true, false); else PICKV(false, false, false); }
+    }
 #undef PICKV
     HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k));
     void* args[] = {(void*)&M, (void*)&A};

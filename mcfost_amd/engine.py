@@ -245,10 +245,10 @@ class Engine:
         self._chk(L.mcgpu_set_sed_bins(
             self.ctx, C.c_int(cfg.N_thet), C.c_int(cfg.N_phi), C.c_int(int(cfg.l_sym_centrale)),
             C.c_int(int(cfg.l_sym_axiale))), "mcgpu_set_sed_bins")
-        if getattr(m, "mrw", None) is not None:
-            self.set_mrw(m.mrw)
         if getattr(m, "variable_dust", None) is not None:
             self.set_variable_dust(m.variable_dust)
+        if getattr(m, "mrw", None) is not None:      # (after the classes: its tables have one row per class)
+            self.set_mrw(m.mrw)
 
     def set_variable_dust(self, vd):
         """Per-class tables of ``lvariable_dust`` (``mcfost_amd.host.model.init_variable_dust``); ``None``: one class."""

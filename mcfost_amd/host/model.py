@@ -928,24 +928,48 @@ def init_mrw(m: "Model", gamma: float = 2.0, n_inter: int = 5, n_zeta: int = 100
         g = np.zeros_like(g)
     elif int(getattr(m.cfg, "aniso_method", 1)) == 1 and m.p_lambda_fixed:
         g = np.full_like(g, g[0])
-    k_tr = np.asarray(m.kappa, f64) * (1.0 - np.asarray(m.albedo, f64) * g)
-    k_abs = np.asarray(m.kappa_abs_LTE, f64)
     n_T = m.tab_Temp.size
-    chi, kdep, ext = np.zeros(n_T, f64), np.zeros(n_T, f64), np.zeros(n_T, f64)
-    for t in range(n_T):
-        cst_wl = THERMAL_CONST / float(m.tab_Temp[t]) / wl
-        ok = cst_wl < 500.0
-        ce = np.exp(np.where(ok, cst_wl, 1.0))
-        wgt = np.where(ok, 1.0 / ((wl ** 5) * (ce - 1.0)) * dwl, 0.0)
-        if weights == "dB_dT":
-            wgt = np.where(ok, wgt * cst_wl * ce / (ce - 1.0), 0.0)
-        elif weights != "B":
-            raise ValueError("init_mrw: weights is 'dB_dT' or 'B'")
-        norm = wgt.sum()
-        if norm > 0.0:
-            chi[t] = norm / (wgt / k_tr).sum()
-            kdep[t] = (wgt * k_abs).sum() / norm
-            ext[t] = ext_factor * 0.7104 * (wgt / k_tr ** 2).sum() / (wgt / k_tr).sum()
+    nl = wl.size
+    # lvariable_dust: one set of tables per class ([n_classes, n_T]; the walk of a cell reads its class's)
+    vd = getattr(m, "variable_dust", None)
+    if vd is not None:
+        nc = int(vd["p_n_cells"])
+        kap_c = np.asarray(vd["kappa"], f64).reshape(nl, nc).T
+        alb_c = np.asarray(vd["albedo"], f64).reshape(nl, nc).T
+        kab_c = np.asarray(vd["kappa_abs_LTE"], f64).reshape(nl, nc).T
+        if vd.get("tab_g_pos") is not None:
+            g_c = np.asarray(vd["tab_g_pos"], f64).reshape(nl, nc).T
+            if getattr(m.cfg, "lisotropic", False):
+                g_c = np.zeros_like(g_c)
+            elif int(getattr(m.cfg, "aniso_method", 1)) == 1 and m.p_lambda_fixed:
+                g_c = np.repeat(g_c[:, :1], nl, axis=1)
+        else:
+            g_c = np.tile(g, (nc, 1))
+    else:
+        nc = 1
+        kap_c, alb_c, kab_c, g_c = (np.asarray(v, f64)[None, :] for v in (m.kappa, m.albedo, m.kappa_abs_LTE, g))
+    chi, kdep, ext = np.zeros((nc, n_T), f64), np.zeros((nc, n_T), f64), np.zeros((nc, n_T), f64)
+    for c in range(nc):
+        k_tr = kap_c[c] * (1.0 - alb_c[c] * g_c[c])
+        k_abs = kab_c[c]
+        for t in range(n_T):
+            cst_wl = THERMAL_CONST / float(m.tab_Temp[t]) / wl
+            ok = cst_wl < 500.0
+            ce = np.exp(np.where(ok, cst_wl, 1.0))
+            wgt = np.where(ok, 1.0 / ((wl ** 5) * (ce - 1.0)) * dwl, 0.0)
+            if weights == "dB_dT":
+                wgt = np.where(ok, wgt * cst_wl * ce / (ce - 1.0), 0.0)
+            elif weights != "B":
+                raise ValueError("init_mrw: weights is 'dB_dT' or 'B'")
+            norm = wgt.sum()
+            if norm > 0.0:
+                chi[c, t] = norm / (wgt / k_tr).sum()
+                kdep[c, t] = (wgt * k_abs).sum() / norm
+                ext[c, t] = ext_factor * 0.7104 * (wgt / k_tr ** 2).sum() / (wgt / k_tr).sum()
+    if vd is None:
+        chi, kdep, ext = chi[0], kdep[0], ext[0]
+    else:
+        chi, kdep, ext = chi.reshape(-1), kdep.reshape(-1), ext.reshape(-1)
     # (the series saturates at 1 to within rounding for y > 0.9: the sampler wants a non-decreasing table)
     zeta = np.minimum(np.maximum.accumulate(cumulative_zeta(n_zeta)), 1.0)
     m.mrw = dict(zeta=zeta, chi=chi, kappa_dep=kdep, ext=ext, gamma=float(gamma),

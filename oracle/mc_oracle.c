@@ -1854,12 +1854,15 @@ static int mrw_walk(worker_t *W, int *lambda, int icell, double *x, double *y, d
   int Ti; float Temp; double frac;
   cell_temperature(W, icell, &Ti, &Temp, &frac);
   const double kf = m->kappa_factor[icell - 1];
-  const double chi = (m->mrw_chi[Ti - 2] * (1.0 - frac) + m->mrw_chi[Ti - 1] * frac) * kf;
+  /* lvariable_dust: the mean opacities of the cell's class ([p_n_cells][n_T]) */
+  const size_t co = m->p_n_cells ? (size_t)(m->p_icell[icell - 1] - 1) * m->n_T : 0;
+  const double *t_chi = m->mrw_chi + co, *t_kdep = m->mrw_kappa_dep + co, *t_ext = m->mrw_ext + co;
+  const double chi = (t_chi[Ti - 2] * (1.0 - frac) + t_chi[Ti - 1] * frac) * kf;
   if (!(d * chi > (double)m->mrw_gamma)) return 0;
-  const double kdep = m->mrw_kappa_dep[Ti - 2] * (1.0 - frac) + m->mrw_kappa_dep[Ti - 1] * frac;
+  const double kdep = t_kdep[Ti - 2] * (1.0 - frac) + t_kdep[Ti - 1] * frac;
   /* the radius the diffusion solution is extrapolated to (the packets' mean free paths are not small against a
    * sphere of a few of them): d + ext, ext at the reference cell's density */
-  const double ext = (m->mrw_ext[Ti - 2] * (1.0 - frac) + m->mrw_ext[Ti - 1] * frac) / kf;
+  const double ext = (t_ext[Ti - 2] * (1.0 - frac) + t_ext[Ti - 1] * frac) / kf;
   const double cst_ct = 3.0 / (PI * PI);
   float r4[4];
   double su, sv, sw;

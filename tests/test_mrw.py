@@ -404,3 +404,50 @@ def test_device_walk_3d_against_the_oracle_frozen():
     # (gamma = 2: the bias bound of the 2D test is 4 % in T ~ E^(1/5); measured here: +7 % in E = +1.4 % in T)
     assert abs((with_walk["E_abs"][hot].sum() / brute["E_abs"][hot].sum()) ** 0.2 - 1.0) < 0.02
     assert with_walk["kernel_ms"] < brute["kernel_ms"]
+
+
+def test_walk_on_variable_dust_oracle():
+    """lvariable_dust + the walk: the mean opacities are the cell's class's (one row of chi / kappa_dep / ext per class);
+    identical classes reproduce the single-class walk packet for packet."""
+    n = 20000
+    m1 = thick_disk()
+    want = Oracle(m1, n).run_thermal(n, seed=3, n_threads=1)
+    m2 = M.build_model(M.small(n_rad=30, nz=20, dust_mass=1e-2))
+    M.init_variable_dust(m2, n_classes=4, identical=True)
+    M.init_mrw(m2)
+    assert m2.mrw["chi"].size == 4 * m2.tab_Temp.size
+    got = Oracle(m2, n).run_thermal(n, seed=3, n_threads=1)
+    assert got["counters"] == want["counters"] and np.allclose(got["E_abs"], want["E_abs"], rtol=1e-12)
+    m3 = M.build_model(M.small(n_rad=30, nz=20, dust_mass=1e-2))
+    M.init_variable_dust(m3, n_classes=4, slope=0.3)
+    M.init_mrw(m3)
+    other = Oracle(m3, n).run_thermal(n, seed=3, n_threads=1)
+    assert other["counters"]["mrw_walks"] > 300 and other["counters"] != want["counters"]
+
+
+@pytest.mark.gpu
+def test_device_walk_on_variable_dust():
+    """The same on the device (k_thermal_var<..., MRW>): identical classes = the single-class run of the same kernel family
+    to the walk's noise (a different instantiation: the walk is chaotic in the rounding), settled classes against the
+    oracle with the noise-aware gates."""
+    from mcfost_amd.engine import Engine
+    n = 20000
+    m = M.build_model(M.small(n_rad=30, nz=20, dust_mass=1e-2))
+    M.init_variable_dust(m, n_classes=4, slope=0.3)
+    M.init_mrw(m)
+    orc = Oracle(m, n)
+    prior = orc.run_thermal(n, seed=1, n_threads=1)["E_abs"]
+    want = orc.run_thermal(n, seed=9, frozen=True, E_prior=prior, n_threads=8)
+    keys = ("mrw_walks", "mrw_steps", "absorptions", "scatterings", "crossings", "flights")
+    others = [orc.run_thermal(n, seed=s, frozen=True, E_prior=prior, n_threads=8) for s in (21, 22, 23, 24, 25, 26)]
+    sigma = {k: np.std([r["counters"][k] for r in others], ddof=1) for k in keys}
+    e = Engine(m, n)
+    got = e.run_thermal(n, seed=9, frozen=True, E_prior=prior)
+    e.close()
+    g, w = got["counters"], want["counters"]
+    assert g["mrw_walks"] > 300
+    for k in ("packets", "escaped", "killed_star"):
+        assert g[k] == w[k]
+    for k in keys:
+        assert abs(g[k] - w[k]) <= 4.0 * np.sqrt(2.0) * sigma[k], (k, g[k], w[k], sigma[k])
+    assert np.array_equal(got["n_sent"], want["n_sent"])

@@ -111,8 +111,8 @@ def test_device_identical_classes_and_live_statistics():
     sel = (T_cpu > 1.2 * m.cfg.T_min) & (T_gpu > 1.2 * m.cfg.T_min)
     ok, p75 = mc_similar(T_cpu[sel], T_gpu[sel], 0.02)
     assert ok, p75
-    # what is not built refuses
+    # SED mode asks for what it needs: the per-wavelength cumulative tables (p_lambda_fixed = 0) -- a clear error, not a run
     from mcfost_amd.engine import McgpuError
     with pytest.raises(McgpuError):
-        e2.set_mrw(M.init_mrw(m))
+        e2.run_mono(3, 5, seed=1, n_chunks=4, rt1=False)
     e2.close()
