@@ -30,6 +30,8 @@ static inline void __threadfence_block() {}
 
 struct emu_dim3 { unsigned x, y, z; };
 static emu_dim3 threadIdx{0, 0, 0}, blockIdx{0, 0, 0}, blockDim{1, 1, 1}, gridDim{1, 1, 1};
+struct double2 { double x, y; };
+static inline double2 make_double2(double a, double b) { return double2{a, b}; }
 static inline unsigned long long __ballot(bool p) { return p ? 1ull : 0ull; }
 static inline int __ffsll(long long m) { return __builtin_ffsll(m); }
 static inline int __popcll(unsigned long long m) { return __builtin_popcountll(m); }

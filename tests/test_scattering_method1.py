@@ -62,20 +62,25 @@ def test_select_scattering_grain_against_a_numpy_search():
 
 
 def test_identical_grains_give_the_temperature_of_method_2():
+    """Every size bin with the same optical properties: drawing the grain changes nothing physical.  Frozen temperature,
+    one thread (reproducible): the two methods are two samples of the same transport."""
     from oracle import Oracle
     m, g, p_icell, dens = _model(identical=True, lsepar_pola=False)
-    n = 200000
-    T2 = Oracle(m, n)
-    a2 = T2.run_thermal(n, seed=3, n_threads=8)
+    n = 120000
+    o2 = Oracle(m, n)
+    prior = o2.run_thermal(30000, seed=1, n_threads=1)["E_abs"] * 4.0
+    a2 = o2.run_thermal(n, seed=3, n_threads=1, frozen=True, E_prior=prior)
     M.init_scattering_method1(m, g, dens)
-    T1 = Oracle(m, n)
-    a1 = T1.run_thermal(n, seed=4, n_threads=8)
+    a1 = Oracle(m, n).run_thermal(n, seed=4, n_threads=1, frozen=True, E_prior=prior)
     assert a1["counters"]["scatterings"] > 10000
-    assert abs(a1["counters"]["scatterings"] / a2["counters"]["scatterings"] - 1) < 0.03
-    t1, t2 = T1.temp_finale(a1["E_abs"]), T2.temp_finale(a2["E_abs"])
-    sel = (t1 > 1.5 * m.cfg.T_min) & (t2 > 1.5 * m.cfg.T_min)
-    ok, p75 = mc_similar(t1[sel], t2[sel], 0.05)
-    assert ok, p75
+    # (event totals of 1.2e5 packets scatter by ~1 % from seed to seed: a few deep packets carry much of them)
+    assert abs(a1["counters"]["scatterings"] / a2["counters"]["scatterings"] - 1) < 0.05
+    assert abs(a1["counters"]["crossings"] / a2["counters"]["crossings"] - 1) < 0.05
+    e1, e2 = a1["E_abs"], a2["E_abs"]
+    hot = e2 > 0.05 * e2.max()
+    assert hot.sum() > 10
+    assert abs(e1[hot].sum() / e2[hot].sum() - 1.0) < 0.03
+    assert np.median(np.abs(e1[hot] / e2[hot] - 1.0)) < 0.1
 
 
 @pytest.mark.gpu
