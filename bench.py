@@ -262,7 +262,7 @@ def thermal_block(par, args, config, steps, warmup, with_cpu, n_local):
         # vector-ALU instructions, not HBM requests; `frac` stays SURVEY 8(d)'s algorithmic-bytes figure.
         roof = {"bound": "valu-issue", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": pmc.get("hbm_bytes"),
-                "kernel": {"voronoi": "k_thermal_voro_roles", "ref41_var": "k_thermal_roles_var"}.get(
+                "kernel": {"voronoi": "k_thermal_voro_cache", "ref41_var": "k_thermal_roles_var"}.get(
                     config, "k_thermal_roles_bin (+ k_fold_bins)" if binned else "k_thermal_roles"),
                 "kernel_ms": k_ms, "algorithmic_bytes_per_launch": bytes_launch,
                 "note": "achieved / frac = algorithmic bytes (SURVEY 8d model) / kernel time against the HBM peak; the bound "

@@ -98,3 +98,34 @@ def test_device_built_tables_give_the_same_sed_step():
     e2.close()
     assert np.array_equal(a1["n_sent_chunk"], a2["n_sent_chunk"]) and a1["counters"] == a2["counters"]
     assert np.allclose(a1["xI_scatt"], a2["xI_scatt"], rtol=1e-6, atol=1e-9 * np.abs(a1["xI_scatt"]).max())
+
+
+def test_temperature_and_sed_end_to_end_on_variable_dust():
+    """The whole host sequence of BASELINE config 2 (mcfost_amd/host/pipeline.py: temperature step, Temp_finale,
+    repartition_energie per wavelength, SED Monte Carlo with rt1 deposits, ray-traced dust SED, the stars' term) on a
+    settled disk whose tables mcgpu_opacity built from grains: engine against the CPU oracle, each with its own noise,
+    through the reference's gates (test_suite/test_mcfost.py:88, 104-109)."""
+    from helpers import OracleBackend
+    from oracle import Oracle
+    from mcfost_amd.engine import Engine
+    from mcfost_amd.host import pipeline as P
+    n_th, n2, nch = 300000, 600, 32
+    mg, g, p_icell, dens = _vd_model(RT_n_incl=3)
+    mc, _, _, _ = _vd_model(RT_n_incl=3)
+    e = Engine(mg, n_th)
+    e.opacity(g, p_icell, dens, fetch=False)        # the device's own tables replace the uploaded ones
+    e.init_reemission(fetch=False)
+    a = P.temperature_and_sed(P.EngineBackend(e), mg, n_th, n2, seed=11, n_chunks=nch)
+    e.close()
+    c = P.temperature_and_sed(OracleBackend(Oracle(mc, n_th)), mc, n_th, n2, seed=23, n_chunks=nch)
+    sel = c["Tdust"] > 1.01 * mg.cfg.T_min
+    assert np.percentile(np.abs(a["Tdust"][sel] / c["Tdust"][sel] - 1), 75) < 0.05
+    fa, fc = P.sed_flux(mg, a["sed_mc"], a["n_sent"])[0].sum(axis=0), P.sed_flux(mc, c["sed_mc"], c["n_sent"])[0].sum(axis=0)
+    ok = c["sed_mc"][4].sum(axis=0) >= 200
+    assert ok.sum() > 0.4 * ok.size
+    assert np.percentile(np.abs(fa[ok] / fc[ok] - 1), 75) < 0.10
+    ia, ic_ = a["sed_rt"][:, :, 0], c["sed_rt"][:, :, 0]
+    assert (ic_ > 0).all()
+    assert np.percentile(np.abs(ia / ic_ - 1), 75) < 0.10
+    assert (c["sed_rt_stars"] > 0).all() and np.allclose(a["sed_rt_stars"], c["sed_rt_stars"], rtol=0.05)
+    assert (a["n_sent"] >= nch * n2).all()
