@@ -448,6 +448,22 @@ int mcgpu_rt1_dust_map(mcgpu_ctx *ctx, const mcgpu_rt_opts *opts,
                        const float *tab_RT_az, const float *Tdust,
                        double *stokes, double *kernel_ms);
 
+/* The stars in an image: compute_stars_map (dust_transfer.f90:1604-1854) with lresolved = .true. -- per observer and
+ * star the 21 x 21 screen of optical depths in front of the star, then random points of the stellar sphere (1024 /
+ * n_stars, or 100 per pixel of the disc when the star is wider than a pixel, :1655-1667), each placed in its pixel
+ * (find_pixel, :1858-1893) with weight exp(-tau) cos_thet LimbDarkening(cos_thet) and normalised so that a star's map
+ * sums to star_flux[istar] (= factor * prob_E_star(lambda, istar), :1651-1652, 1829) when its disc lies inside the map.
+ * Limb darkening (llimb_darkening; n_mu > 0): the tables of read_limb_darkening_file (input.f90:628), interpolated like
+ * utils.f90's interp; with pola_limb_darkening also the polarised maps Q = P cos 2 phi, U = P sin 2 phi (:1817-1823,
+ * "only works for a star centered").  stars_map (npix_x, npix_y, n_maps, RT_n_incl, RT_n_az) column-major, n_maps = 3 with
+ * pola_limb_darkening else 1, in double (the reference sums default reals per thread); star_position (n_stars,
+ * RT_n_incl * RT_n_az, 2) in arcsec (:1847-1848), may be NULL.  The rays' positions come from the Philox stream of
+ * `seed` (the reference draws them from SPRNG).  Cylindrical grids. */
+int mcgpu_rt1_stars_map_image(mcgpu_ctx *ctx, const mcgpu_rt_opts *opts, const float *tab_RT_az, uint64_t seed,
+                              const double *star_flux, int npix_x, int npix_y, double map_size, double zoom, int n_mu,
+                              const float *mu_limb_darkening, const float *limb_darkening,
+                              const float *pola_limb_darkening, double *stars_map, double *star_position);
+
 /* The same for images: dust_map method 2 (dust_transfer.f90:1537-1577) -- npix_x x npix_y square pixels of
  * (map_size/zoom)/max(npix_x,npix_y) AU, each refined by intensite_pixel_dust (:1899-2004): 1, 2x2, ... 32x32
  * sub-pixel rays, at least 2 and at most 6 iterations, until Stokes I changes by less than 1 %.

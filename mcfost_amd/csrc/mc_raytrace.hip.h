@@ -356,6 +356,139 @@ __global__ void __launch_bounds__(512) k_stars_map_sed(const DevModel M, const R
   if (tid == 0) atomic_add_f64(&out[q], star_flux[istar] * red_a[0] / red_b[0]);
 }
 
+// interp (utils.f90:130-175, default real): linear interpolation in a table, the end values outside it
+__device__ inline float interp_sp(const float* y, const float* x, int n, float xp) {
+  float xmin = x[0], xmax = x[0];
+  for (int i = 1; i < n; ++i) { xmin = fminf(xmin, x[i]); xmax = fmaxf(xmax, x[i]); }
+  const bool inc = x[n - 1] > x[0];
+  if (xp < xmin) return inc ? y[0] : y[n - 1];
+  if (xp > xmax) return inc ? y[n - 1] : y[0];
+  int j;
+  if (inc) { for (j = 2; j <= n - 1; ++j) if (x[j - 1] > xp) break; }
+  else { for (j = 2; j <= n - 1; ++j) if (x[j - 1] < xp) break; }
+  const float frac = (xp - x[j - 2]) / (x[j - 1] - x[j - 2]);
+  return y[j - 2] * (1.f - frac) + y[j - 1] * frac;
+}
+
+// compute_stars_map for images (dust_transfer.f90:1604-1854 with lresolved = .true.): the stars' discs in the pixel map
+// of every observer, limb-darkened and polarised if asked.  One workgroup per (observer, star) like the SED version: the
+// 21 x 21 screen of optical depths, then n_ray random points of the stellar sphere (1024 / n_stars, or 100 per pixel of
+// the disc when the star is wider than a pixel, :1655-1667), each placed in its pixel (find_pixel, :1858-1893) with
+// weight exp(-tau) cos_thet LimbDarkening; the workgroup's map is normalised by sum(cos_thet LimbDarkening) in a second
+// pass (the rays are replayed: counter-based draws), so that the atomics add finished values.
+struct StarsImageArgs {
+  int npix_x, npix_y, n_maps, n_mu;
+  double taille_pix, distance;
+  float pix_size;
+  const float *mu_ld, *ld, *pola_ld;
+  double* map;            // (npix_x, npix_y, n_maps, nRT)
+  double* star_position;  // (n_stars, nRT, 2) or null
+};
+
+template <bool L3D>
+__global__ void __launch_bounds__(512) k_stars_map_image(const DevModel M, const RtArgs A, const StarsImageArgs I, unsigned int key0,
+                                                         unsigned int key1, const double* star_flux) {
+  extern __shared__ double lds_raw[];
+  const Lds T = lds_carve(lds_raw, M, true);
+  lds_stage_mono(T, M, 1);
+  __shared__ float tau_screen[(2 * STARS_NX_SCREEN + 1) * (2 * STARS_NX_SCREEN + 1)];
+  __shared__ double red_b[512];
+  __syncthreads();
+  const int q = blockIdx.x / M.n_stars, istar = blockIdx.x % M.n_stars;
+  const int tid = threadIdx.x, nt = blockDim.x, ns = 2 * STARS_NX_SCREEN + 1;
+  double uvw[3], xpi[3], ypi[3];
+  rt_image_plane(A, q, uvw, xpi, ypi);
+  const double* s4 = &M.star_xyzr[4 * istar];
+  const double dx_map[3] = {xpi[0] * I.taille_pix, xpi[1] * I.taille_pix, xpi[2] * I.taille_pix};
+  const double dy_map[3] = {ypi[0] * I.taille_pix, ypi[1] * I.taille_pix, ypi[2] * I.taille_pix};
+  const double delta = s4[3] / (double)STARS_NX_SCREEN;
+  const double nx = sqrt(xpi[0] * xpi[0] + xpi[1] * xpi[1] + xpi[2] * xpi[2]);
+  const double ny = sqrt(ypi[0] * ypi[0] + ypi[1] * ypi[1] + ypi[2] * ypi[2]);
+  const double dxs[3] = {delta * xpi[0] / nx, delta * xpi[1] / nx, delta * xpi[2] / nx};
+  const double dys[3] = {delta * ypi[0] / ny, delta * ypi[1] / ny, delta * ypi[2] / ny};
+  for (int p = tid; p < ns * ns; p += nt) {
+    const int i = p % ns - STARS_NX_SCREEN, j = p / ns - STARS_NX_SCREEN;
+    const double x = s4[0] + dxs[0] * i + dys[0] * j, y = s4[1] + dxs[1] * i + dys[1] * j, z = s4[2] + dxs[2] * i + dys[2] * j;
+    tau_screen[p] = optical_length_tot<L3D>(T, M, A.lambda, x, y, z, uvw[0], uvw[1], uvw[2]);
+  }
+  __syncthreads();
+  int n_ray = STARS_N_RAY_SED / M.n_stars > 1 ? STARS_N_RAY_SED / M.n_stars : 1;
+  if (2.0 * s4[3] > (double)I.pix_size) {
+    const float ratio = (float)(s4[3] / (double)I.pix_size);
+    const int n_res = 100 * (int)(4.0 * PI * (double)(ratio * ratio));
+    n_ray = n_res > STARS_N_RAY_SED ? n_res : STARS_N_RAY_SED;
+  }
+  const double norm_screen2 = 1.0 / (delta * delta);
+  const size_t n_pix = (size_t)I.npix_x * I.npix_y;
+  double* mp = I.map + n_pix * I.n_maps * (size_t)q;
+  const int x_center = I.npix_x / 2 + 1, y_center = I.npix_y / 2 + 1;
+  double factor2 = 0.0;
+  for (int pass = 0; pass < 2; ++pass) {
+    double sum_n = 0.0;
+    for (int iray = tid; iray < n_ray; iray += nt) {
+      uint32_t o[4];
+      philox4x32_10((uint32_t)iray, 2u, (uint32_t)blockIdx.x, 0u, key0, key1, o);
+      const float rand = Rng::real(o[0]), rand2 = Rng::real(o[1]);
+      const double z = 2.0 * (double)rand - 1.0;
+      const double srw02 = sqrt(1.0 - z * z), argmt = PI * (2.0 * (double)rand2 - 1.0);
+      double sa, ca;
+      sincos(argmt, &sa, &ca);
+      const double x = srw02 * ca, y = srw02 * sa;
+      const float cos_thet = (float)fabs(x * uvw[0] + y * uvw[1] + z * uvw[2]);
+      float LimbDarkening = 1.0f, Pola_LD = 0.0f;
+      if (I.n_mu > 0) {
+        LimbDarkening = interp_sp(I.ld, I.mu_ld, I.n_mu, cos_thet);
+        if (I.pola_ld) Pola_LD = interp_sp(I.pola_ld, I.mu_ld, I.n_mu, cos_thet);
+      }
+      if (pass == 0) { sum_n += (double)(cos_thet * LimbDarkening); continue; }
+      const double vec[3] = {x * s4[3], y * s4[3], z * s4[3]};
+      const double px = s4[0] + vec[0], py = s4[1] + vec[1], pz = s4[2] + vec[2];
+      const double offset_x = (vec[0] * dxs[0] + vec[1] * dxs[1] + vec[2] * dxs[2]) * norm_screen2;
+      const double offset_y = (vec[0] * dys[0] + vec[1] * dys[1] + vec[2] * dys[2]) * norm_screen2;
+      const int i = (int)floor(offset_x), j = (int)floor(offset_y);
+      const double fx = offset_x - i, fy = offset_y - j;
+      float tau = 0.0f;
+      if (i >= -STARS_NX_SCREEN && i < STARS_NX_SCREEN && j >= -STARS_NX_SCREEN && j < STARS_NX_SCREEN) {
+        const int p = (i + STARS_NX_SCREEN) + ns * (j + STARS_NX_SCREEN);
+        tau = (float)((double)tau_screen[p] * (1 - fx) * (1 - fy) + (double)tau_screen[p + 1] * fx * (1 - fy) +
+                      (double)tau_screen[p + ns] * (1 - fx) * fy + (double)tau_screen[p + ns + 1] * fx * fy);
+      }
+      const double factor = 1.0 / (I.taille_pix * I.taille_pix);  // find_pixel
+      const double x_map = (px * dx_map[0] + py * dx_map[1] + pz * dx_map[2]) * factor;
+      const double y_map = (px * dy_map[0] + py * dy_map[1] + pz * dy_map[2]) * factor;
+      const int ip = (I.npix_x % 2 == 1) ? (int)llround(x_map) + I.npix_x / 2 + 1 : (int)llround(x_map + 0.5) + I.npix_x / 2;
+      const int jp = (I.npix_y % 2 == 1) ? (int)llround(y_map) + I.npix_y / 2 + 1 : (int)llround(y_map + 0.5) + I.npix_y / 2;
+      if (ip >= 1 && ip <= I.npix_x && jp >= 1 && jp <= I.npix_y) {
+        const float wgt = expf(-tau) * cos_thet * LimbDarkening;
+        const size_t pp = (size_t)(ip - 1) + (size_t)I.npix_x * (jp - 1);
+        atomic_add_f64(&mp[pp], (double)wgt * factor2);
+        if (I.n_maps == 3) {
+          const float P = wgt * Pola_LD;
+          const float phi = atan2f((float)(jp - y_center) * 1.0f, (float)(ip - x_center) * 1.0f);
+          atomic_add_f64(&mp[pp + n_pix], (double)(P * cosf(2.0f * phi)) * factor2);
+          atomic_add_f64(&mp[pp + 2 * n_pix], (double)(P * sinf(2.0f * phi)) * factor2);
+        }
+      }
+    }
+    if (pass == 0) {
+      red_b[tid] = sum_n;
+      __syncthreads();
+      for (int sft = nt >> 1; sft > 0; sft >>= 1) {
+        if (tid < sft) red_b[tid] += red_b[tid + sft];
+        __syncthreads();
+      }
+      factor2 = star_flux[istar] / red_b[0];
+      __syncthreads();
+    }
+  }
+  if (tid == 0 && I.star_position) {
+    const double factor_pix = 1.0 / (I.taille_pix * I.distance);
+    I.star_position[(size_t)istar + (size_t)M.n_stars * q] = -(s4[0] * dx_map[0] + s4[1] * dx_map[1] + s4[2] * dx_map[2]) * factor_pix;
+    I.star_position[(size_t)istar + (size_t)M.n_stars * (q + (size_t)A.nRT)] =
+        (s4[0] * dy_map[0] + s4[1] * dy_map[1] + s4[2] * dy_map[2]) * factor_pix;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // define_dark_zone, step 4 (optical_depth.f90:1522-1551; 2D): from the centre of every candidate cell, 11 rays in the
 // (x, z) plane at angles pi n / 12; a ray that uses up the optical depth tau_max before it leaves the grid marks its

@@ -2520,6 +2520,62 @@ extern "C" int mcgpu_rt1_stars_map_sed(mcgpu_ctx* ctx, const mcgpu_rt_opts* o, c
   return MCGPU_OK;
 }
 
+// compute_stars_map for images (resolved discs, limb darkening): see include/mcgpu.h
+extern "C" int mcgpu_rt1_stars_map_image(mcgpu_ctx* ctx, const mcgpu_rt_opts* o, const float* tab_RT_az, uint64_t seed,
+                                         const double* star_flux, int npix_x, int npix_y, double map_size, double zoom, int n_mu,
+                                         const float* mu_limb_darkening, const float* limb_darkening,
+                                         const float* pola_limb_darkening, double* stars_map, double* star_position) {
+  int rc = ready(ctx);
+  if (rc) return rc;
+  if (!o || !tab_RT_az || !star_flux || !stars_map || npix_x < 1 || npix_y < 1 || npix_x > 32768 || npix_y > 32768 ||
+      !(map_size > 0.0) || !(zoom > 0.0) || n_mu < 0 || (n_mu > 0 && (n_mu < 2 || !mu_limb_darkening || !limb_darkening)))
+    return fail(ctx, MCGPU_ERR_ARG, "mcgpu_rt1_stars_map_image: bad argument");
+  const DevModel& M = ctx->M;
+  if (ctx->voro || M.grid_sph) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "stars map: cylindrical grids");
+  if (!ctx->have_rt1) return fail(ctx, MCGPU_ERR_STATE, "stars map: set the observers first (mcgpu_set_rt1)");
+  if (o->lambda < 1 || o->lambda > M.n_lambda || !(o->distance > 0.0)) return fail(ctx, MCGPU_ERR_ARG, "mcgpu_rt1_stars_map_image: bad option");
+  HIPCHK(hipSetDevice(ctx->device));
+  const int nRT = ctx->RT_n_incl * ctx->RT_n_az;
+  const int n_maps = (n_mu > 0 && pola_limb_darkening) ? 3 : 1;
+  const size_t n_out = (size_t)npix_x * npix_y * n_maps * nRT;
+  DevBuf<float> d_az, d_mu, d_ld, d_pld;
+  DevBuf<double> d_flux, d_map, d_pos;
+  HIPCHK(d_az.alloc(ctx->RT_n_az)); HIPCHK(d_az.put(tab_RT_az, ctx->RT_n_az));
+  HIPCHK(d_flux.alloc(M.n_stars)); HIPCHK(d_flux.put(star_flux, M.n_stars));
+  HIPCHK(d_map.alloc(n_out)); HIPCHK(hipMemsetAsync(d_map.p, 0, n_out * sizeof(double), ctx->stream));
+  HIPCHK(d_pos.alloc((size_t)M.n_stars * nRT * 2));
+  if (n_mu > 0) {
+    HIPCHK(d_mu.alloc(n_mu)); HIPCHK(d_mu.put(mu_limb_darkening, n_mu));
+    HIPCHK(d_ld.alloc(n_mu)); HIPCHK(d_ld.put(limb_darkening, n_mu));
+    if (pola_limb_darkening) { HIPCHK(d_pld.alloc(n_mu)); HIPCHK(d_pld.put(pola_limb_darkening, n_mu)); }
+  }
+  RtArgs A;
+  std::memset(&A, 0, sizeof(A));
+  A.lambda = o->lambda; A.RT_n_incl = ctx->RT_n_incl; A.nRT = nRT; A.ang_disque = o->ang_disque;
+  A.rt_u = ctx->d_rt_u; A.rt_v = ctx->d_rt_v; A.rt_w = ctx->d_rt_w; A.rt_az = d_az.p;
+  StarsImageArgs I;
+  I.npix_x = npix_x; I.npix_y = npix_y; I.n_maps = n_maps; I.n_mu = n_mu;
+  I.taille_pix = (map_size / zoom) / (double)(npix_x > npix_y ? npix_x : npix_y);
+  I.pix_size = (float)(map_size / zoom / (double)(npix_x > npix_y ? npix_x : npix_y));
+  I.distance = o->distance;
+  I.mu_ld = d_mu.p; I.ld = d_ld.p; I.pola_ld = (n_mu > 0 && pola_limb_darkening) ? d_pld.p : nullptr;
+  I.map = d_map.p; I.star_position = d_pos.p;
+  const size_t lds = lds_bytes(M, true);
+  const unsigned int k0 = (unsigned int)seed, k1 = (unsigned int)(seed >> 32);
+  if (M.l3D) {
+    HIPCHK(hipFuncSetAttribute((const void*)k_stars_map_image<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_stars_map_image<true>, dim3(nRT * M.n_stars), dim3(512), lds, ctx->stream, M, A, I, k0, k1, d_flux.p);
+  } else {
+    HIPCHK(hipFuncSetAttribute((const void*)k_stars_map_image<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_stars_map_image<false>, dim3(nRT * M.n_stars), dim3(512), lds, ctx->stream, M, A, I, k0, k1, d_flux.p);
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(d_map.get(stars_map, n_out));
+  if (star_position) HIPCHK(d_pos.get(star_position, (size_t)M.n_stars * nRT * 2));
+  return MCGPU_OK;
+}
+
 extern "C" int mcgpu_rt1_image(mcgpu_ctx* ctx, const mcgpu_rt_opts* o, const float* tab_RT_az, const float* Tdust,
                                int npix_x, int npix_y, double map_size, double zoom, double* image, uint64_t* n_rays,
                                double* kernel_ms) {

@@ -36,7 +36,7 @@ ABI_SYMBOLS = (
     "mcgpu_device_xI", "mcgpu_set_ism", "mcgpu_rt1_dust_map", "mcgpu_set_xI", "mcgpu_rt1_image", "mcgpu_set_xI_precision",
     "mcgpu_get_xI_precision", "mcgpu_set_option", "mcgpu_get_info", "mcgpu_counters_to_accum", "mcgpu_counters_from_accum",
     "mcgpu_set_grid_sph", "mcgpu_temp_approx_diffusion_vertical", "mcgpu_set_mrw", "mcgpu_fetch_radiation_field", "mcgpu_set_variable_dust", "mcgpu_rt1_stars_map_sed", "mcgpu_define_dark_zone", "mcgpu_init_reemission", "mcgpu_multi_create", "mcgpu_multi_destroy", "mcgpu_multi_size", "mcgpu_multi_ctx", "mcgpu_multi_last_error",
-    "mcgpu_repartition_energie", "mcgpu_opacity", "mcgpu_set_variable_dust_s11", "mcgpu_set_scattering_method1", "mcgpu_set_rt2", "mcgpu_fetch_I_spec", "mcgpu_shard_packets", "mcgpu_multi_run_thermal", "mcgpu_multi_run_mono", "mcgpu_multi_rccl_ranks",
+    "mcgpu_repartition_energie", "mcgpu_opacity", "mcgpu_set_variable_dust_s11", "mcgpu_set_scattering_method1", "mcgpu_set_rt2", "mcgpu_fetch_I_spec", "mcgpu_rt1_stars_map_image", "mcgpu_shard_packets", "mcgpu_multi_run_thermal", "mcgpu_multi_run_mono", "mcgpu_multi_rccl_ranks",
 )
 
 
@@ -646,6 +646,35 @@ class Engine:
             self.ctx, C.byref(o), _p(_a(rt["tab_RT_az"], np.float32), C.c_float), C.c_uint64(int(seed)),
             _p(_a(star_flux, np.float64), C.c_double), _p(out, C.c_double)), "mcgpu_rt1_stars_map_sed")
         return out
+
+    def stars_map_image(self, lam, star_flux, npix_x, npix_y, map_size, zoom=1.0, seed=1, ang_disque=0.0,
+                        limb_darkening=None):
+        """The stars in an image (``mcgpu_rt1_stars_map_image`` = ``compute_stars_map`` with resolved discs):
+        ``(maps [nRT, n_maps, npix_y, npix_x], star_position [2, nRT, n_stars] arcsec)``; ``limb_darkening = (mu, I(mu)
+        [, P(mu)])`` switches limb darkening (and, with P, the polarised maps) on."""
+        m = self.model
+        rt = m.rt
+        if not getattr(self, "_rt1", False):
+            self.set_rt1()
+        o = RtOpts(int(lam), float(m.lam[lam - 1]), 1.0, 1.0, float(m.cfg.distance), float(ang_disque), 0, 100.0,
+                   float(m.cfg.rin), float(m.cfg.rout))
+        nRT, ns = rt["RT_n_incl"] * rt["RT_n_az"], int(np.asarray(star_flux).size)
+        mu = ld = pld = None
+        n_mu = 0
+        if limb_darkening is not None:
+            mu, ld = _a(limb_darkening[0], np.float32), _a(limb_darkening[1], np.float32)
+            pld = _a(limb_darkening[2], np.float32) if len(limb_darkening) > 2 else None
+            n_mu = mu.size
+        n_maps = 3 if pld is not None else 1
+        maps = np.zeros((nRT, n_maps, npix_y, npix_x), np.float64)
+        pos = np.zeros((2, nRT, ns), np.float64)
+        self._chk(self.lib.mcgpu_rt1_stars_map_image(
+            self.ctx, C.byref(o), _p(_a(rt["tab_RT_az"], np.float32), C.c_float), C.c_uint64(int(seed)),
+            _p(_a(star_flux, np.float64), C.c_double), C.c_int(npix_x), C.c_int(npix_y), C.c_double(map_size), C.c_double(zoom),
+            C.c_int(n_mu), _p(mu, C.c_float) if n_mu else None, _p(ld, C.c_float) if n_mu else None,
+            _p(pld, C.c_float) if pld is not None else None, _p(maps, C.c_double), _p(pos, C.c_double)),
+            "mcgpu_rt1_stars_map_image")
+        return maps, pos
 
     def dust_map_image(self, lam, Tdust, n_sent_photons, E_disk, npix_x, npix_y, map_size, zoom=1.0, ang_disque=0.0,
                        l_sym_ima=False, tau_dark_zone_obs=100.0):

@@ -88,7 +88,7 @@ module mcgpu_f
        mcgpu_run_mono, mcgpu_fetch, mcgpu_fetch_xI, mcgpu_rt1_dust_map, mcgpu_set_xI, mcgpu_rt1_image, mcgpu_set_xI_precision, &
        mcgpu_set_E_prior, mcgpu_multi_create, mcgpu_multi_destroy, mcgpu_multi_size, mcgpu_multi_ctx, mcgpu_multi_run_thermal, mcgpu_multi_run_mono, mcgpu_multi_rccl_ranks, &
        mcgpu_counters_to_accum, mcgpu_counters_from_accum, mcgpu_temp_approx_diffusion_vertical, mcgpu_set_mrw, mcgpu_fetch_radiation_field, &
-       mcgpu_set_variable_dust, mcgpu_rt1_stars_map_sed, mcgpu_define_dark_zone, mcgpu_init_reemission, mcgpu_repartition_energie, mcgpu_opacity, mcgpu_set_variable_dust_s11, mcgpu_set_scattering_method1, mcgpu_set_rt2, mcgpu_fetch_I_spec
+       mcgpu_set_variable_dust, mcgpu_rt1_stars_map_sed, mcgpu_define_dark_zone, mcgpu_init_reemission, mcgpu_repartition_energie, mcgpu_opacity, mcgpu_set_variable_dust_s11, mcgpu_set_scattering_method1, mcgpu_set_rt2, mcgpu_fetch_I_spec, mcgpu_rt1_stars_map_image
 
   interface
      integer(c_int) function mcgpu_create(device, ctx) bind(C, name="mcgpu_create")
@@ -398,6 +398,24 @@ module mcgpu_f
        real(c_double), intent(out) :: frac_E_stars, frac_E_disk, E_disk
        type(c_ptr), value :: prob_E_cell             ! c_loc(prob_E_cell(0,lambda)) or c_null_ptr
      end function mcgpu_repartition_energie
+
+     ! replaces `call compute_stars_map(lambda, ibin, iaz, u,v,w, taille_pix, dx, dy, .true.)` of the image branch of
+     ! dust_map (dust_transfer.f90:1561) for every (ibin, iaz) at once
+     integer(c_int) function mcgpu_rt1_stars_map_image(ctx, opts, tab_RT_az, seed, star_flux, npix_x, npix_y, map_size, zoom, &
+          n_mu, mu_limb_darkening, limb_darkening, pola_limb_darkening, stars_map, star_position) &
+          bind(C, name="mcgpu_rt1_stars_map_image")
+       import :: c_int, c_ptr, c_double, c_float, c_int64_t, mcgpu_rt_opts
+       type(c_ptr), value :: ctx
+       type(mcgpu_rt_opts), intent(in) :: opts
+       real(c_float), intent(in) :: tab_RT_az(*)
+       integer(c_int64_t), value :: seed
+       real(c_double), intent(in) :: star_flux(*)
+       integer(c_int), value :: npix_x, npix_y, n_mu
+       real(c_double), value :: map_size, zoom
+       type(c_ptr), value :: mu_limb_darkening, limb_darkening, pola_limb_darkening   ! c_loc(...) or c_null_ptr
+       real(c_double), intent(out) :: stars_map(*)
+       type(c_ptr), value :: star_position
+     end function mcgpu_rt1_stars_map_image
 
      ! lscatt_ray_tracing2: I_spec(N_type_flux,n_theta_I,n_phi_I,n_cells) and I_spec_star(n_cells) live on the device;
      ! mcgpu_run_mono with opts%rt1 = 2 deposits (radiation_field.f90:91-129), the fetch fills the module arrays of

@@ -407,6 +407,34 @@ class Oracle:
             raise RuntimeError(f"oracle_stars_map_sed failed: {rc}")
         return out
 
+    def stars_map_image(self, lam, star_flux, npix_x, npix_y, map_size, zoom=1.0, seed=1, ang_disque=0.0,
+                        limb_darkening=None):
+        """compute_stars_map for images (resolved discs, limb darkening): ``(maps [nRT, n_maps, npix_y, npix_x],
+        star_position [2, nRT, n_stars])``."""
+        m = self.model
+        rt = m.rt
+        az = _a(rt["tab_RT_az"], np.float32)
+        o = _RtOpts(int(lam), float(m.lam[lam - 1]), 1.0, 1.0, float(m.cfg.distance), float(ang_disque), 0, 100.0,
+                    float(m.cfg.rin), float(m.cfg.rout), _p(az, C.c_float), 1)
+        nRT, ns = rt["RT_n_incl"] * rt["RT_n_az"], int(np.asarray(star_flux).size)
+        mu = ld = pld = None
+        n_mu = 0
+        if limb_darkening is not None:
+            mu, ld = _a(limb_darkening[0], np.float32), _a(limb_darkening[1], np.float32)
+            pld = _a(limb_darkening[2], np.float32) if len(limb_darkening) > 2 else None
+            n_mu = mu.size
+        n_maps = 3 if pld is not None else 1
+        maps = np.zeros((nRT, n_maps, npix_y, npix_x), np.float64)
+        pos = np.zeros((2, nRT, ns), np.float64)
+        rc = self.lib.oracle_stars_map_image(
+            C.byref(self.cm), C.byref(o), C.c_uint64(int(seed)), _p(_a(star_flux, np.float64), C.c_double), C.c_int(npix_x),
+            C.c_int(npix_y), C.c_double(map_size), C.c_double(zoom), C.c_int(n_mu), _p(mu, C.c_float) if n_mu else None,
+            _p(ld, C.c_float) if n_mu else None, _p(pld, C.c_float) if pld is not None else None, _p(maps, C.c_double),
+            _p(pos, C.c_double))
+        if rc:
+            raise RuntimeError(f"oracle_stars_map_image failed: {rc}")
+        return maps, pos
+
     def dust_map_image(self, lam, xI_scatt, Tdust, n_sent_photons, E_disk, npix_x, npix_y, map_size, zoom=1.0,
                        ang_disque=0.0, l_sym_ima=False, tau_dark_zone_obs=100.0, n_threads=1):
         """Ray-traced image of the dust at wavelength ``lam`` (dust_map method 2):

@@ -2656,6 +2656,130 @@ int oracle_stars_map_sed(const oracle_model *m, const oracle_rt_opts *o, uint64_
   return 0;
 }
 
+/* interp (utils.f90:130-175, default real): linear interpolation in a table, the end values outside it */
+static float interp_sp(const float *y, const float *x, int n, float xp) {
+  float xmin = x[0], xmax = x[0];
+  for (int i = 1; i < n; ++i) { if (x[i] < xmin) xmin = x[i]; if (x[i] > xmax) xmax = x[i]; }
+  const int inc = x[n - 1] > x[0];
+  if (xp < xmin) return inc ? y[0] : y[n - 1];
+  if (xp > xmax) return inc ? y[n - 1] : y[0];
+  int j; /* 1-based index of the upper point */
+  if (inc) { for (j = 2; j <= n - 1; ++j) if (x[j - 1] > xp) break; }
+  else { for (j = 2; j <= n - 1; ++j) if (x[j - 1] < xp) break; }
+  const float frac = (xp - x[j - 2]) / (x[j - 1] - x[j - 2]);
+  return y[j - 2] * (1.f - frac) + y[j - 1] * frac;
+}
+
+/* compute_stars_map for images (dust_transfer.f90:1604-1854 with lresolved = .true.): the stars' discs in the pixel map
+ * of every observer.  Per (observer, star): the 21 x 21 screen of optical depths as for the SED; n_ray_star random points
+ * of the stellar sphere -- 1024 / n_stars, or 100 per pixel of the disc when the star is wider than a pixel (:1655-1667) --
+ * each placed in its pixel (find_pixel :1858-1893) with weight exp(-tau) cos_thet LimbDarkening(cos_thet), normalised so
+ * that the star's map sums to star_flux (when every ray falls inside the map).  Limb darkening (n_mu > 0): interp of
+ * limb_darkening(mu); with pola_ld the polarised maps Q = P cos 2 phi, U = P sin 2 phi, phi the pixel's position angle
+ * about the map centre (:1817-1823: "only works for a star centered").
+ * map (npix_x, npix_y, n_maps, nRT) column-major in double (the reference sums default reals per thread), n_maps = 3 with
+ * pola_ld else 1; star_position (n_stars, nRT, 2) in arcsec (:1847-1848).  Ray k of (observer q, star s): Philox block
+ * (k, 2, q n_stars + s) of the seed, as in oracle_stars_map_sed. */
+int oracle_stars_map_image(const oracle_model *m, const oracle_rt_opts *o, uint64_t seed, const double *star_flux,
+                           int npix_x, int npix_y, double map_size, double zoom, int n_mu, const float *mu_ld,
+                           const float *ld, const float *pola_ld, double *map, double *star_position) {
+  if (m->grid_type != 1) return 31;
+  enum { NXS = 10, NS = 21, N_RAY_SED = 1024 };
+  const int nRT = m->RT_n_incl * m->RT_n_az, n_maps = (n_mu > 0 && pola_ld) ? 3 : 1;
+  const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+  const size_t n_pix = (size_t)npix_x * npix_y;
+  memset(map, 0, sizeof(double) * n_pix * n_maps * nRT);
+  const double taille_pix = (map_size / zoom) / (double)(npix_x > npix_y ? npix_x : npix_y);
+  const float pix_size = (float)(map_size / zoom / (double)(npix_x > npix_y ? npix_x : npix_y));
+  const int x_center = npix_x / 2 + 1, y_center = npix_y / 2 + 1;
+  const double factor_pix = 1.0 / (taille_pix * o->distance);
+  for (int q = 0; q < nRT; ++q)
+    for (int istar = 0; istar < m->n_stars; ++istar) {
+      double uvw[3], xpi[3], ypi[3], center[3];
+      rt_image_plane(m, o, q % m->RT_n_incl + 1, q / m->RT_n_incl + 1, uvw, xpi, ypi, center);
+      const oracle_star *st = &m->stars[istar];
+      const double dx_map[3] = {xpi[0] * taille_pix, xpi[1] * taille_pix, xpi[2] * taille_pix};
+      const double dy_map[3] = {ypi[0] * taille_pix, ypi[1] * taille_pix, ypi[2] * taille_pix};
+      const double delta = st->r / (double)NXS;
+      const double nx = sqrt(xpi[0] * xpi[0] + xpi[1] * xpi[1] + xpi[2] * xpi[2]);
+      const double ny = sqrt(ypi[0] * ypi[0] + ypi[1] * ypi[1] + ypi[2] * ypi[2]);
+      const double dxs[3] = {delta * xpi[0] / nx, delta * xpi[1] / nx, delta * xpi[2] / nx};
+      const double dys[3] = {delta * ypi[0] / ny, delta * ypi[1] / ny, delta * ypi[2] / ny};
+      float tau_screen[NS * NS];
+      for (int j = -NXS; j <= NXS; ++j)
+        for (int i = -NXS; i <= NXS; ++i)
+          tau_screen[(i + NXS) + NS * (j + NXS)] =
+              optical_length_tot(m, o->lambda, st->x + dxs[0] * i + dys[0] * j, st->y + dxs[1] * i + dys[1] * j,
+                                 st->z + dxs[2] * i + dys[2] * j, uvw[0], uvw[1], uvw[2]);
+      int n_ray = N_RAY_SED / m->n_stars > 1 ? N_RAY_SED / m->n_stars : 1;
+      if (2.0 * st->r > (double)pix_size) { /* resolved: on average 100 rays per pixel (:1659-1662) */
+        const float ratio = (float)(st->r / (double)pix_size);
+        const int n_res = 100 * (int)(4.0 * PI * (double)(ratio * ratio));
+        n_ray = n_res > N_RAY_SED ? n_res : N_RAY_SED;
+      }
+      const double norm_screen2 = 1.0 / (delta * delta);
+      double norm = 0.0;
+      double *mp = map + n_pix * n_maps * (size_t)q;
+      double *tmp = (double *)calloc(n_pix * n_maps, sizeof(double));
+      if (!tmp) return 22;
+      for (int iray = 0; iray < n_ray; ++iray) {
+        uint32_t ctr[4] = {(uint32_t)iray, 2u, (uint32_t)(q * m->n_stars + istar), 0u}, r4[4];
+        oracle_philox4x32_10(ctr, key, r4);
+        const float rand = u32_to_real(r4[0]), rand2 = u32_to_real(r4[1]);
+        const double z = 2.0 * (double)rand - 1.0;
+        const double srw02 = sqrt(1.0 - z * z), argmt = PI * (2.0 * (double)rand2 - 1.0);
+        const double x = srw02 * cos(argmt), y = srw02 * sin(argmt);
+        const float cos_thet = (float)fabs(x * uvw[0] + y * uvw[1] + z * uvw[2]);
+        float LimbDarkening = 1.0f, Pola_LD = 0.0f;
+        if (n_mu > 0) {
+          LimbDarkening = interp_sp(ld, mu_ld, n_mu, cos_thet);
+          if (pola_ld) Pola_LD = interp_sp(pola_ld, mu_ld, n_mu, cos_thet);
+        }
+        const double vec[3] = {x * st->r, y * st->r, z * st->r};
+        const double px = st->x + vec[0], py = st->y + vec[1], pz = st->z + vec[2];
+        const double offset_x = (vec[0] * dxs[0] + vec[1] * dxs[1] + vec[2] * dxs[2]) * norm_screen2;
+        const double offset_y = (vec[0] * dys[0] + vec[1] * dys[1] + vec[2] * dys[2]) * norm_screen2;
+        const int i = (int)floor(offset_x), j = (int)floor(offset_y);
+        const double fx = offset_x - i, fy = offset_y - j;
+        float tau = 0.0f;
+        if (i >= -NXS && i < NXS && j >= -NXS && j < NXS) {
+          const int p = (i + NXS) + NS * (j + NXS);
+          tau = (float)((double)tau_screen[p] * (1 - fx) * (1 - fy) + (double)tau_screen[p + 1] * fx * (1 - fy) +
+                        (double)tau_screen[p + NS] * (1 - fx) * fy + (double)tau_screen[p + NS + 1] * fx * fy);
+        }
+        /* find_pixel (:1858-1893) */
+        const double factor = 1.0 / (taille_pix * taille_pix);
+        const double x_map = (px * dx_map[0] + py * dx_map[1] + pz * dx_map[2]) * factor;
+        const double y_map = (px * dy_map[0] + py * dy_map[1] + pz * dy_map[2]) * factor;
+        const int ip = (npix_x % 2 == 1) ? (int)llround(x_map) + npix_x / 2 + 1 : (int)llround(x_map + 0.5) + npix_x / 2;
+        const int jp = (npix_y % 2 == 1) ? (int)llround(y_map) + npix_y / 2 + 1 : (int)llround(y_map + 0.5) + npix_y / 2;
+        if (ip >= 1 && ip <= npix_x && jp >= 1 && jp <= npix_y) {
+          const float wgt = expf(-tau) * cos_thet * LimbDarkening;
+          const size_t pp = (size_t)(ip - 1) + (size_t)npix_x * (jp - 1);
+          tmp[pp] += (double)wgt;
+          if (n_maps == 3) {
+            const float P = wgt * Pola_LD;
+            const float phi = atan2f((float)(jp - y_center) * 1.0f, (float)(ip - x_center) * 1.0f);
+            tmp[pp + n_pix] += (double)(P * cosf(2.0f * phi));
+            tmp[pp + 2 * n_pix] += (double)(P * sinf(2.0f * phi));
+          }
+        }
+        norm += (double)(cos_thet * LimbDarkening);
+      }
+      const double factor2 = star_flux[istar] / norm;
+      for (size_t t = 0; t < n_pix * n_maps; ++t) mp[t] += tmp[t] * factor2;
+      free(tmp);
+      if (star_position) {
+        const double xyz[3] = {st->x, st->y, st->z};
+        star_position[(size_t)istar + (size_t)m->n_stars * q] =
+            -(xyz[0] * dx_map[0] + xyz[1] * dx_map[1] + xyz[2] * dx_map[2]) * factor_pix;
+        star_position[(size_t)istar + (size_t)m->n_stars * (q + (size_t)nRT)] =
+            (xyz[0] * dy_map[0] + xyz[1] * dy_map[1] + xyz[2] * dy_map[2]) * factor_pix;
+      }
+    }
+  return 0;
+}
+
 int oracle_dust_map_sed(const oracle_model *m, const oracle_rt_opts *o, const double *xI, const float *Tdust,
                         double *out) {
   if (m->grid_type == 3) return 31;

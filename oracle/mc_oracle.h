@@ -314,6 +314,13 @@ typedef struct {
   int n_threads;
 } oracle_rt_opts;
 
+/* compute_stars_map for images (dust_transfer.f90:1604-1854, lresolved = .true.; find_pixel :1858-1893; interp
+ * utils.f90:130-175): the stars' discs, limb-darkened (n_mu > 0) and polarised (pola_ld) if asked, in the pixel maps of
+ * the observers; see the definition.  PARITY UNPINNED like oracle_stars_map_sed. */
+int oracle_stars_map_image(const oracle_model *m, const oracle_rt_opts *o, uint64_t seed, const double *star_flux,
+                           int npix_x, int npix_y, double map_size, double zoom, int n_mu, const float *mu_ld,
+                           const float *ld, const float *pola_ld, double *map, double *star_position);
+
 /* compute_stars_map for the SED (dust_transfer.f90:1604-1854; lresolved = .false., no limb darkening): out[nRT] =
  * sum over stars of star_flux[istar] * sum(exp(-tau) cos_thet) / sum(cos_thet); 2D / 3D cylindrical grids.  PARITY
  * UNPINNED (dust_transfer.f90 is unbuildable here; the reference's points come from SPRNG). */

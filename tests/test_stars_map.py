@@ -66,3 +66,65 @@ def test_device_against_the_oracle(kw):
         got = e.stars_map_sed(lam, flux, seed=7, ang_disque=20.0)
         assert np.allclose(got, want, rtol=1e-5, atol=1e-12 * flux[0]), (lam, got, want)
     e.close()
+
+
+def _ld_table(u=0.6, pmax=0.1, n=21):
+    mu = np.linspace(0.0, 1.0, n).astype(np.float32)
+    return mu, (1.0 - u * (1.0 - mu)).astype(np.float32), (pmax * (1.0 - mu) ** 2).astype(np.float32)
+
+
+def test_stars_image_known_answers():
+    """compute_stars_map with resolved discs (oracle): the map of a star sums to its flux where the path is thin, the disc
+    has the projected radius, limb darkening lowers the limb and keeps the sum, the polarised maps are tangential and
+    cancel in the sum, an unresolved star sits in one pixel at the projected position."""
+    m = M.build_model(M.small(RT_n_incl=3))
+    o = Oracle(m, 1000)
+    lam = m.n_lambda                      # longest wavelength: optically thin
+    flux = np.array([2.5])
+    # unresolved: 5 AU map, 65 pixels (odd: the star in the centre pixel)
+    maps, pos = o.stars_map_image(lam, flux, 65, 65, 5.0, seed=3)
+    assert maps.shape == (3, 1, 65, 65)
+    face_on = int(np.argmin(m.rt["tab_RT_incl"])) if "tab_RT_incl" in m.rt else 0
+    for q in range(3):
+        assert maps[q, 0, 32, 32] == maps[q].sum() and 0.0 < maps[q].sum() <= flux[0] * (1 + 1e-6)
+    assert maps[face_on].sum() > 0.9 * flux[0]          # thin towards the pole at 3 mm: the whole flux arrives
+    assert np.allclose(pos, 0.0)
+    # resolved: a map so small that the disc spans ~20 pixels
+    rs = m.cfg.R_star * 0.00465047                      # Rsun -> AU
+    size = 65 * rs / 10.0
+    maps, _ = o.stars_map_image(lam, flux, 65, 65, size, seed=3)
+    disc = maps[0, 0] > 0
+    yy, xx = np.nonzero(disc)
+    rad = np.hypot(xx - 32, yy - 32)
+    assert 9.0 < rad.max() < 11.0 and disc.sum() > 250            # the projected disc: radius 10 pixels
+    assert 0.5 * flux[0] < maps[face_on].sum() <= flux[0] * (1 + 1e-6)
+    mu, ld, pld = _ld_table()
+    dark, _ = o.stars_map_image(lam, flux, 65, 65, size, seed=3, limb_darkening=(mu, ld))
+    assert np.isclose(dark[0].sum(), maps[0].sum(), rtol=1e-3)   # the normalisation carries the limb darkening (:1826)
+    centre = lambda a: a[0, 0, 30:35, 30:35].mean()
+    ring = lambda a: a[0, 0][(rad.max() - 2 < np.hypot(*np.meshgrid(np.arange(65) - 32, np.arange(65) - 32)))
+                             & (np.hypot(*np.meshgrid(np.arange(65) - 32, np.arange(65) - 32)) < rad.max() - 0.5)].mean()
+    assert centre(dark) / ring(dark) > 1.15 * centre(maps) / ring(maps)
+    pol, _ = o.stars_map_image(lam, flux, 65, 65, size, seed=3, limb_darkening=(mu, ld, pld))
+    assert pol.shape[1] == 3 and np.allclose(pol[:, 0], dark[:, 0])
+    assert np.abs(pol[0, 1]).max() > 0 and abs(pol[0, 1].sum()) < 0.05 * np.abs(pol[0, 1]).sum()   # Q cancels over the disc
+
+
+@pytest.mark.gpu
+def test_device_stars_image_equals_the_oracle():
+    from mcfost_amd.engine import Engine
+    mu, ld, pld = _ld_table()
+    for cfg in (M.small(RT_n_incl=3), M.small(n_rad=10, nz=5, n_az=6, l3D=True, RT_n_incl=2)):
+        m = M.build_model(cfg)
+        o = Oracle(m, 1000)
+        e = Engine(m, 1000)
+        rs = m.cfg.R_star * 0.00465047
+        for lam in (3, m.n_lambda):
+            for npix, size, limb in ((65, 65 * rs / 10.0, None), (64, 64 * rs / 6.0, (mu, ld, pld)), (33, 5.0, (mu, ld))):
+                want, wpos = o.stars_map_image(lam, np.array([1.7]), npix, npix, size, seed=5, limb_darkening=limb)
+                got, gpos = e.stars_map_image(lam, np.array([1.7]), npix, npix, size, seed=5, limb_darkening=limb)
+                assert got.shape == want.shape and np.allclose(gpos, wpos, atol=1e-12)
+                assert np.array_equal(got != 0, want != 0)                     # the same rays in the same pixels
+                # (expf / sincos / atan2f, summation order; cos 2 phi of a pixel on the diagonal is 4e-8 or 0: absolute floor)
+                assert np.allclose(got, want, rtol=2e-5, atol=1e-6 * np.abs(want).max())
+        e.close()
