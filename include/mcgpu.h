@@ -347,11 +347,23 @@ typedef struct {
  * arrays in HBM; mcgpu_run_mono with opts->rt1 = 2 deposits; mcgpu_fetch_I_spec returns them in the reference's layout
  * (N_type_flux, n_theta_I, n_phi_I, n_cells) as default real (the type of the reference's arrays) and / or as the FP64
  * sums the device holds; any pointer may be NULL.  N_type_flux = n_Stokes (+ 4 with lsepar_contrib).
- * The consumers -- calc_Isca_rt2, calc_Isca_rt2_star, init_dust_source_fct2 (dust_ray_tracing.f90:717-1440) -- are
- * host-side steps of the ray tracer and are not part of this library yet.
+ * mcgpu_set_I_spec hands the arrays back (e.g. after a sum over processes; reference layout, double).
+ *
+ * mcgpu_rt2_source is init_dust_source_fct2(lambda, p_lambda, ibin) (dust_ray_tracing.f90:717-806) on the device -- with
+ * calc_Isca_rt2_star (:1245-1440; angles_scatt_rt2 :304-405), calc_Isca_rt2 (:907-1240) and calc_Jth, the slow steps of
+ * the reference's method-2 ray tracer -- from the I_spec / I_spec_star the device holds: the source function of the
+ * inclination ibin (1-based) in the reference's arrays and type,
+ *   eps_dust2(N_type_flux, nang_ray_tracing, 0:1, n_cells)        ( (I_sca2 + J_th) / kappa_ext; (Q, U) as (P, angle) )
+ *   eps_dust2_star(n_Stokes, nang_ray_tracing_star, 0:1, n_cells) ( once-scattered starlight )
+ * (default real; nang_ray_tracing = 15, nang_ray_tracing_star = 1000 in dust_ray_tracing.f90:109-110).  opts: lambda,
+ * wl_um, E_src, n_sent_photons; Tdust[n_cells]; r_grid / z_grid[n_cells] (cylindrical_grid.f90:26).  Needs
+ * mcgpu_set_rt1 (the observers' inclinations, tab_s11_pos) and mcgpu_set_rt2.  What stays with the host: the ray
+ * integration with the interpolating dust_source_fct of method 2 (:1478-1660).
  */
 int mcgpu_set_rt2(mcgpu_ctx *ctx, int n_theta_I, int n_phi_I, int N_type_flux, int lsepar_contrib);
 int mcgpu_fetch_I_spec(mcgpu_ctx *ctx, float *I_spec, double *I_spec_f64, float *I_spec_star, double *I_spec_star_f64);
+int mcgpu_set_I_spec(mcgpu_ctx *ctx, const double *I_spec, const double *I_spec_star);
+/* (mcgpu_rt2_source is declared below, behind mcgpu_rt_opts) */
 
 /*
  * repartition_energie(lambda) (thermal_emission.f90:1771-1949; the call at dust_transfer.f90:924), LTE grains
@@ -463,6 +475,11 @@ int mcgpu_rt1_stars_map_image(mcgpu_ctx *ctx, const mcgpu_rt_opts *opts, const f
                               const double *star_flux, int npix_x, int npix_y, double map_size, double zoom, int n_mu,
                               const float *mu_limb_darkening, const float *limb_darkening,
                               const float *pola_limb_darkening, double *stars_map, double *star_position);
+
+/* init_dust_source_fct2 of one inclination on the device: described with mcgpu_set_rt2 above */
+int mcgpu_rt2_source(mcgpu_ctx *ctx, const mcgpu_rt_opts *opts, int p_lambda, int ibin, const float *Tdust,
+                     const double *r_grid, const double *z_grid, int nang_ray_tracing, int nang_ray_tracing_star,
+                     float *eps_dust2, float *eps_dust2_star, double *kernel_ms);
 
 /* The same for images: dust_map method 2 (dust_transfer.f90:1537-1577) -- npix_x x npix_y square pixels of
  * (map_size/zoom)/max(npix_x,npix_y) AU, each refined by intensite_pixel_dust (:1899-2004): 1, 2x2, ... 32x32

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <cfloat>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -24,6 +25,7 @@
 #include "mc_binned.hip.h"
 #include "mc_tail.hip.h"
 #include "mc_opacity.hip.h"
+#include "mc_rt2.hip.h"
 
 using namespace mcgpu;
 
@@ -36,6 +38,27 @@ static int tune(const char* name, int dflt, int lo, int hi) {
   (void)name; (void)lo; (void)hi;
 #endif
   return dflt;
+}
+
+// rotation (scattering.f90:553-590): host copy for the direction tables of mcgpu_rt2_source
+static void host_rotation(double xinit, double yinit, double zinit, double u1, double v1, double w1, double& xfin, double& yfin,
+                          double& zfin) {
+  double cost, sint, sing;
+  if (w1 > 0.999999999) {
+    cost = 1.0; sint = 0.0; sing = 0.0;
+  } else if (std::fabs(u1) < (double)FLT_MIN) {
+    cost = 0.0; sint = 1.0;
+    sing = std::sqrt(1.0 - w1 * w1);
+  } else {
+    const double theta = std::atan2(v1, u1);
+    cost = std::cos(theta);
+    sint = std::sin(theta);
+    sing = std::sqrt(1.0 - w1 * w1);
+  }
+  const double prod = cost * xinit + sint * yinit;
+  xfin = sing * prod + w1 * zinit;
+  yfin = cost * yinit - sint * xinit;
+  zfin = sing * zinit - w1 * prod;
 }
 
 constexpr int WORK_SLOT = 12;  // where the kernels' work counter lives in d_counters
@@ -1922,6 +1945,145 @@ extern "C" int mcgpu_fetch_I_spec(mcgpu_ctx* ctx, float* I_spec, double* I_spec_
     if (I_spec_star) I_spec_star[c] = (float)st[c];
     if (I_spec_star_f64) I_spec_star_f64[c] = st[c];
   }
+  return MCGPU_OK;
+}
+
+// the reference's I_spec / I_spec_star handed to the device (e.g. sums over several processes): see include/mcgpu.h
+extern "C" int mcgpu_set_I_spec(mcgpu_ctx* ctx, const double* I_spec, const double* I_spec_star) {
+  if (!ctx || !ctx->have_rt2) return fail(ctx, MCGPU_ERR_STATE, "mcgpu_set_rt2 first");
+  if (!I_spec || !I_spec_star) return fail(ctx, MCGPU_ERR_ARG, "mcgpu_set_I_spec: null argument");
+  HIPCHK(hipSetDevice(ctx->device));
+  const int nt = ctx->n_theta_I, np = ctx->n_phi_I, ntf = ctx->rt2_N_type_flux, nc = ctx->M.n_cells;
+  const size_t n = (size_t)ntf * nt * np * nc;
+  DevBuf<double> d_in;
+  HIPCHK(d_in.alloc(n)); HIPCHK(d_in.put(I_spec, n));
+  HIPCHK(hipMemsetAsync(ctx->d_I_spec, 0, (size_t)nc * np * nt * XI_LINE * sizeof(double), ctx->stream));
+  hipLaunchKernelGGL(k_I_spec_put, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_I_spec, d_in.p, ntf, nt, np, n);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(ctx->d_I_spec_star, I_spec_star, (size_t)nc * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return MCGPU_OK;
+}
+
+// init_dust_source_fct2 (dust_ray_tracing.f90:717-806) of one inclination on the device: see include/mcgpu.h
+extern "C" int mcgpu_rt2_source(mcgpu_ctx* ctx, const mcgpu_rt_opts* o, int p_lambda, int ibin, const float* Tdust,
+                                const double* r_grid, const double* z_grid, int nang_ray_tracing,
+                                int nang_ray_tracing_star, float* eps_dust2, float* eps_dust2_star, double* kernel_ms) {
+  int rc = ready(ctx);
+  if (rc) return rc;
+  if (!o || !Tdust || !r_grid || !z_grid || !eps_dust2 || !eps_dust2_star || nang_ray_tracing < 1 || nang_ray_tracing_star < 1 ||
+      nang_ray_tracing > 4096 || nang_ray_tracing_star > 65536)
+    return fail(ctx, MCGPU_ERR_ARG, "mcgpu_rt2_source: bad argument");
+  DevModel& M = ctx->M;
+  if (!ctx->have_rt2 || !ctx->have_rt1) return fail(ctx, MCGPU_ERR_STATE, "mcgpu_rt2_source needs mcgpu_set_rt1 (the observers, tab_s11_pos) and mcgpu_set_rt2");
+  if (M.l3D || ctx->voro || M.grid_sph) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "ray tracing method 2 is 2D only");
+  if (M.n_classes && !M.v_s11) return fail(ctx, MCGPU_ERR_STATE, "variable dust: tab_s11_pos per class is missing (mcgpu_opacity or mcgpu_set_variable_dust_s11)");
+  if (o->lambda < 1 || o->lambda > M.n_lambda || p_lambda < 1 || p_lambda > M.n_lambda || ibin < 1 || ibin > ctx->RT_n_incl ||
+      !(o->wl_um > 0.0) || !(o->n_sent_photons > 0.0))
+    return fail(ctx, MCGPU_ERR_ARG, "mcgpu_rt2_source: bad option");
+  if (!M.n_classes && p_lambda > ctx->n_lambda_pos) return fail(ctx, MCGPU_ERR_ARG, "p_lambda out of range");
+  HIPCHK(hipSetDevice(ctx->device));
+  const int nt = ctx->n_theta_I, np = ctx->n_phi_I, na = nang_ray_tracing, ns = nang_ray_tracing_star, nang = M.nang;
+  const bool pola = ctx->lsepar_pola != 0;
+  const int n_Stokes = pola ? 4 : 1, ntf = ctx->rt2_N_type_flux;
+  // the observer's direction (tab_w_rt(ibin), tab_uv_rt(ibin) = sin(incl)): dust_ray_tracing.f90:280-289
+  std::vector<double> h_w(ctx->RT_n_incl);
+  HIPCHK(hipMemcpy(h_w.data(), ctx->d_rt_w, h_w.size() * sizeof(double), hipMemcpyDeviceToHost));
+  const double w0 = h_w[ibin - 1], uv0 = std::sqrt(1.0 - w0 * w0);
+  // ---- the directions where Inu * s11 is evaluated (:973-1072)
+  const size_t ntab = (size_t)2 * na * np * nt;
+  std::vector<int> tab_k(ntab * RT2_NSUP2);
+  std::vector<float> tab_sin(ntab * RT2_NSUP2);
+  std::vector<double> tab_cosw(ntab, 0.0), tab_sinw(ntab, 0.0);
+  const double PI_ = 3.14159265358979323846;
+  auto angle_index = [&](float cos_scatt) {
+    const float ac = (float)std::acos((double)cos_scatt);
+    if (ac != ac) return nang;
+    return (int)std::llrint(std::floor((double)(ac * (float)nang) / PI_ + 0.5));
+  };
+  for (int dir = 0; dir <= 1; ++dir)
+    for (int iscatt = 1; iscatt <= na; ++iscatt) {
+      const float phi_scatt = (float)(2 * PI_ * (double)((float)iscatt / (float)na));
+      const double ur = uv0 * std::sin((double)phi_scatt), vr = -uv0 * std::cos((double)phi_scatt), wr = w0;
+      for (int phi_I = 1; phi_I <= np; ++phi_I)
+        for (int theta_I = 1; theta_I <= nt; ++theta_I) {
+          const size_t b = (((size_t)dir * na + (iscatt - 1)) * np + (phi_I - 1)) * nt + (theta_I - 1);
+          float sum_sin = 0.f;
+          for (int i2 = 1; i2 <= RT2_N_SUPER; ++i2)
+            for (int i1 = 1; i1 <= RT2_N_SUPER; ++i1) {
+              const float f1 = (float)i1 / (float)(RT2_N_SUPER + 1), f2 = (float)i2 / (float)(RT2_N_SUPER + 1);
+              const double w = (2.0 * (((double)theta_I - (double)f1) / (double)nt) - 1.0) * (double)(2 * dir - 1);
+              const double phi = 2 * PI_ * ((double)phi_I - (double)f2) / (double)np;
+              const double w02 = std::sqrt(1.0 - w * w), u = w02 * std::sin(phi), v = -w02 * std::cos(phi);
+              const float cos_scatt = (float)(ur * u + vr * v + wr * w);
+              int k = angle_index(cos_scatt);
+              if (k > nang) k = nang;
+              if (k < 0) k = 0;
+              const float sin_scatt = (float)std::sqrt(1.0 - (double)cos_scatt * (double)cos_scatt);
+              tab_k[b * RT2_NSUP2 + (i1 - 1) + RT2_N_SUPER * (i2 - 1)] = k;
+              tab_sin[b * RT2_NSUP2 + (i1 - 1) + RT2_N_SUPER * (i2 - 1)] = sin_scatt;
+              sum_sin = sum_sin + sin_scatt;
+            }
+          for (int t = 0; t < RT2_NSUP2; ++t) tab_sin[b * RT2_NSUP2 + t] = tab_sin[b * RT2_NSUP2 + t] / sum_sin;
+          if (pola) {
+            const double w = (2.0 * (((double)theta_I - (double)0.5f) / (double)nt) - 1.0) * (double)(2 * dir - 1);
+            const double phi = 2 * PI_ * ((double)phi_I - (double)0.5f) / (double)np;
+            const double w02 = std::sqrt(1.0 - w * w), u = w02 * std::sin(phi), v = -w02 * std::cos(phi);
+            double v1pi, v1pj, v1pk;
+            host_rotation(u, v, w, -ur, -vr, -wr, v1pi, v1pj, v1pk);
+            const double xnyp = std::sqrt(v1pk * v1pk + v1pj * v1pj);
+            const double costhet = (xnyp < 1e-10) ? 1.0 : v1pj / xnyp;
+            double theta = std::acos(costhet);
+            if (theta >= PI_) theta = 0.0;
+            double omega = 2.0 * theta;
+            if (v1pk < 0.0) omega = -1.0 * omega;
+            double cosw = std::cos(omega), sinw = std::sin(omega);
+            if (std::fabs(cosw) < 1e-06) cosw = 0.0;
+            if (std::fabs(sinw) < 1e-06) sinw = 0.0;
+            tab_cosw[b] = cosw; tab_sinw[b] = sinw;
+          }
+        }
+    }
+  DevBuf<int> d_k;
+  DevBuf<float> d_sin, d_T, d_eps, d_eps_star;
+  DevBuf<double> d_cw, d_sw, d_J, d_rg, d_zg;
+  HIPCHK(d_k.alloc(tab_k.size())); HIPCHK(d_k.put(tab_k.data(), tab_k.size()));
+  HIPCHK(d_sin.alloc(tab_sin.size())); HIPCHK(d_sin.put(tab_sin.data(), tab_sin.size()));
+  HIPCHK(d_cw.alloc(ntab)); HIPCHK(d_cw.put(tab_cosw.data(), ntab));
+  HIPCHK(d_sw.alloc(ntab)); HIPCHK(d_sw.put(tab_sinw.data(), ntab));
+  HIPCHK(d_T.alloc(M.n_cells)); HIPCHK(d_T.put(Tdust, M.n_cells));
+  HIPCHK(d_J.alloc(M.n_cells));
+  HIPCHK(d_rg.alloc(M.n_cells)); HIPCHK(d_rg.put(r_grid, M.n_cells));
+  HIPCHK(d_zg.alloc(M.n_cells)); HIPCHK(d_zg.put(z_grid, M.n_cells));
+  const size_t n_eps = (size_t)ntf * na * 2 * M.n_cells, n_eps_s = (size_t)n_Stokes * ns * 2 * M.n_cells;
+  HIPCHK(d_eps.alloc(n_eps)); HIPCHK(d_eps_star.alloc(n_eps_s));
+  Rt2Args A;
+  std::memset(&A, 0, sizeof(A));
+  A.lambda = o->lambda; A.p_lambda = p_lambda; A.n_theta_I = nt; A.n_phi_I = np; A.nang_rt = na; A.nang_star = ns;
+  A.n_Stokes = n_Stokes; A.N_type_flux = ntf; A.contrib = ctx->rt2_contrib; A.pola = pola ? 1 : 0;
+  const double AU_to_cm = 149597870700.0 * 100.0;
+  A.photon_energy = o->E_src * o->wl_um * 1.0e-6 / (o->n_sent_photons * AU_to_cm * M_PI);
+  A.uv0 = uv0; A.w0 = w0;
+  A.I_spec = ctx->d_I_spec; A.I_spec_star = ctx->d_I_spec_star; A.J_th = d_J.p; A.r_grid = d_rg.p; A.z_grid = d_zg.p;
+  A.tab_k = d_k.p; A.tab_sin = d_sin.p; A.tab_cosw = d_cw.p; A.tab_sinw = d_sw.p;
+  A.s11_single = M.n_classes ? nullptr : ctx->d_tab_s11 + (size_t)(M.nang + 1) * (p_lambda - 1);
+  A.eps_dust2 = d_eps.p; A.eps_dust2_star = d_eps_star.p;
+  HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+  hipLaunchKernelGGL(k_calc_Jth, dim3((M.n_cells + 255) / 256), dim3(256), 0, ctx->stream, M, o->lambda, o->wl_um * 1.e-6, d_T.p, d_J.p);
+  const size_t n1 = (size_t)M.n_cells * 2 * na, n2 = (size_t)M.n_cells * 2 * ns;
+  if (pola) {
+    hipLaunchKernelGGL(k_rt2_source<true>, dim3((unsigned)((n1 + 127) / 128)), dim3(128), 0, ctx->stream, M, A);
+    hipLaunchKernelGGL(k_rt2_source_star<true>, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, ctx->stream, M, A);
+  } else {
+    hipLaunchKernelGGL(k_rt2_source<false>, dim3((unsigned)((n1 + 127) / 128)), dim3(128), 0, ctx->stream, M, A);
+    hipLaunchKernelGGL(k_rt2_source_star<false>, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, ctx->stream, M, A);
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (kernel_ms) { float ms = 0.f; hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1); *kernel_ms = ms; }
+  HIPCHK(d_eps.get(eps_dust2, n_eps));
+  HIPCHK(d_eps_star.get(eps_dust2_star, n_eps_s));
   return MCGPU_OK;
 }
 

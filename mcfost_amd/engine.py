@@ -36,7 +36,7 @@ ABI_SYMBOLS = (
     "mcgpu_device_xI", "mcgpu_set_ism", "mcgpu_rt1_dust_map", "mcgpu_set_xI", "mcgpu_rt1_image", "mcgpu_set_xI_precision",
     "mcgpu_get_xI_precision", "mcgpu_set_option", "mcgpu_get_info", "mcgpu_counters_to_accum", "mcgpu_counters_from_accum",
     "mcgpu_set_grid_sph", "mcgpu_temp_approx_diffusion_vertical", "mcgpu_set_mrw", "mcgpu_fetch_radiation_field", "mcgpu_set_variable_dust", "mcgpu_rt1_stars_map_sed", "mcgpu_define_dark_zone", "mcgpu_init_reemission", "mcgpu_multi_create", "mcgpu_multi_destroy", "mcgpu_multi_size", "mcgpu_multi_ctx", "mcgpu_multi_last_error",
-    "mcgpu_repartition_energie", "mcgpu_opacity", "mcgpu_set_variable_dust_s11", "mcgpu_set_scattering_method1", "mcgpu_set_rt2", "mcgpu_fetch_I_spec", "mcgpu_rt1_stars_map_image", "mcgpu_shard_packets", "mcgpu_multi_run_thermal", "mcgpu_multi_run_mono", "mcgpu_multi_rccl_ranks",
+    "mcgpu_repartition_energie", "mcgpu_opacity", "mcgpu_set_variable_dust_s11", "mcgpu_set_scattering_method1", "mcgpu_set_rt2", "mcgpu_fetch_I_spec", "mcgpu_rt1_stars_map_image", "mcgpu_set_I_spec", "mcgpu_rt2_source", "mcgpu_shard_packets", "mcgpu_multi_run_thermal", "mcgpu_multi_run_mono", "mcgpu_multi_rccl_ranks",
 )
 
 
@@ -570,6 +570,38 @@ class Engine:
         b = np.zeros(self.model.n_cells, np.float64)
         self._chk(self.lib.mcgpu_fetch_I_spec(self.ctx, None, _p(a, C.c_double), None, _p(b, C.c_double)), "mcgpu_fetch_I_spec")
         return a, b
+
+    def set_I_spec(self, I_spec, I_spec_star):
+        """Hands ``I_spec [n_cells, n_phi_I, n_theta_I, N_type_flux]`` / ``I_spec_star [n_cells]`` to the device."""
+        self._chk(self.lib.mcgpu_set_I_spec(self.ctx, _p(_a(I_spec, np.float64), C.c_double),
+                                            _p(_a(I_spec_star, np.float64), C.c_double)), "mcgpu_set_I_spec")
+
+    def init_dust_source_fct2(self, lam, ibin, I_spec, I_spec_star, Tdust, n_sent_photons, E_disk, nang_rt=15, nang_star=1000,
+                              p_lambda=None):
+        """``init_dust_source_fct2`` of inclination ``ibin`` on the device (``mcgpu_rt2_source``); ``I_spec`` = None: the
+        field the last ``run_mono(rt2=...)`` left in HBM.  Returns ``(eps_dust2 [n_cells, 2, nang_rt, N_type_flux],
+        eps_dust2_star [n_cells, 2, nang_star, n_Stokes])``."""
+        m = self.model
+        if not getattr(self, "_rt1", False):
+            self.set_rt1()
+        if I_spec is not None:
+            shp = np.asarray(I_spec).shape
+            if getattr(self, "_rt2", (0, 0, 0))[:2] != (shp[2], shp[1]):
+                self.set_rt2(shp[2], shp[1])
+            self.set_I_spec(I_spec, I_spec_star)
+        nt, nphi, ntf = self._rt2
+        ns = 4 if (m.cfg.lsepar_pola and m.cfg.aniso_method == 1) else 1
+        o = RtOpts(int(lam), float(m.lam[lam - 1]), float(m.E_stars[lam - 1] + E_disk), float(n_sent_photons),
+                   float(m.cfg.distance), 0.0, 0, 100.0, float(m.cfg.rin), float(m.cfg.rout))
+        eps = np.zeros((m.n_cells, 2, nang_rt, ntf), np.float32)
+        eps_star = np.zeros((m.n_cells, 2, nang_star, ns), np.float32)
+        ms = C.c_double()
+        self._chk(self.lib.mcgpu_rt2_source(
+            self.ctx, C.byref(o), C.c_int(int(p_lambda or lam)), C.c_int(int(ibin)), _p(_a(Tdust, np.float32), C.c_float),
+            _p(_a(m.grid["r_grid"], np.float64), C.c_double), _p(_a(np.abs(m.grid["z_grid"]), np.float64), C.c_double),
+            C.c_int(nang_rt), C.c_int(nang_star), _p(eps, C.c_float), _p(eps_star, C.c_float), C.byref(ms)), "mcgpu_rt2_source")
+        self.last_rt2_ms = ms.value
+        return eps, eps_star
 
     def run_mono(self, lam, n_photons2, n_phot_lim=None, p_lambda=None, seed=1, n_chunks=None, rt1=True,
                  accumulate=False, grid_blocks=0, block_threads=0, fetch_xI=True, first_chunk=0, device_tables=None,

@@ -88,7 +88,7 @@ module mcgpu_f
        mcgpu_run_mono, mcgpu_fetch, mcgpu_fetch_xI, mcgpu_rt1_dust_map, mcgpu_set_xI, mcgpu_rt1_image, mcgpu_set_xI_precision, &
        mcgpu_set_E_prior, mcgpu_multi_create, mcgpu_multi_destroy, mcgpu_multi_size, mcgpu_multi_ctx, mcgpu_multi_run_thermal, mcgpu_multi_run_mono, mcgpu_multi_rccl_ranks, &
        mcgpu_counters_to_accum, mcgpu_counters_from_accum, mcgpu_temp_approx_diffusion_vertical, mcgpu_set_mrw, mcgpu_fetch_radiation_field, &
-       mcgpu_set_variable_dust, mcgpu_rt1_stars_map_sed, mcgpu_define_dark_zone, mcgpu_init_reemission, mcgpu_repartition_energie, mcgpu_opacity, mcgpu_set_variable_dust_s11, mcgpu_set_scattering_method1, mcgpu_set_rt2, mcgpu_fetch_I_spec, mcgpu_rt1_stars_map_image
+       mcgpu_set_variable_dust, mcgpu_rt1_stars_map_sed, mcgpu_define_dark_zone, mcgpu_init_reemission, mcgpu_repartition_energie, mcgpu_opacity, mcgpu_set_variable_dust_s11, mcgpu_set_scattering_method1, mcgpu_set_rt2, mcgpu_fetch_I_spec, mcgpu_rt1_stars_map_image, mcgpu_set_I_spec, mcgpu_rt2_source
 
   interface
      integer(c_int) function mcgpu_create(device, ctx) bind(C, name="mcgpu_create")
@@ -425,6 +425,26 @@ module mcgpu_f
        type(c_ptr), value :: ctx
        integer(c_int), value :: n_theta_I, n_phi_I, N_type_flux, lsepar_contrib
      end function mcgpu_set_rt2
+
+     integer(c_int) function mcgpu_set_I_spec(ctx, I_spec, I_spec_star) bind(C, name="mcgpu_set_I_spec")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(in) :: I_spec(*), I_spec_star(*)
+     end function mcgpu_set_I_spec
+
+     ! replaces `call init_dust_source_fct2(lambda, p_lambda, ibin)` (dust_transfer.f90:1467; dust_ray_tracing.f90:717-806):
+     ! eps_dust2 / eps_dust2_star of module dust_ray_tracing, then the host's own dust_map ray-traces with them
+     integer(c_int) function mcgpu_rt2_source(ctx, opts, p_lambda, ibin, Tdust, r_grid, z_grid, nang_ray_tracing, &
+          nang_ray_tracing_star, eps_dust2, eps_dust2_star, kernel_ms) bind(C, name="mcgpu_rt2_source")
+       import :: c_int, c_ptr, c_double, c_float, mcgpu_rt_opts
+       type(c_ptr), value :: ctx
+       type(mcgpu_rt_opts), intent(in) :: opts
+       integer(c_int), value :: p_lambda, ibin, nang_ray_tracing, nang_ray_tracing_star
+       real(c_float), intent(in) :: Tdust(*)
+       real(c_double), intent(in) :: r_grid(*), z_grid(*)
+       real(c_float), intent(out) :: eps_dust2(*), eps_dust2_star(*)
+       real(c_double), intent(out) :: kernel_ms
+     end function mcgpu_rt2_source
 
      integer(c_int) function mcgpu_fetch_I_spec(ctx, I_spec, I_spec_f64, I_spec_star, I_spec_star_f64) &
           bind(C, name="mcgpu_fetch_I_spec")

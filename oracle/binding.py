@@ -407,6 +407,30 @@ class Oracle:
             raise RuntimeError(f"oracle_stars_map_sed failed: {rc}")
         return out
 
+    def init_dust_source_fct2(self, lam, ibin, I_spec, I_spec_star, Tdust, n_sent_photons, E_disk, nang_rt=15, nang_star=1000,
+                              p_lambda=None):
+        """Ray tracing method 2's source function of inclination ``ibin`` (1-based) from ``I_spec [n_cells, n_phi_I,
+        n_theta_I, N_type_flux]`` / ``I_spec_star [n_cells]``: ``(eps_dust2 [n_cells, 2, nang_rt, N_type_flux],
+        eps_dust2_star [n_cells, 2, nang_star, n_Stokes])`` (default real)."""
+        m = self.model
+        rt = m.rt
+        az = _a(rt["tab_RT_az"], np.float32)
+        o = _RtOpts(int(lam), float(m.lam[lam - 1]), float(m.E_stars[lam - 1] + E_disk), float(n_sent_photons),
+                    float(m.cfg.distance), 0.0, 0, 100.0, float(m.cfg.rin), float(m.cfg.rout), _p(az, C.c_float), 1)
+        I_spec = _a(I_spec, np.float64)
+        nc, nphi, nth, ntf = I_spec.shape
+        ns = 4 if (m.cfg.lsepar_pola and m.cfg.aniso_method == 1) else 1
+        eps = np.zeros((nc, 2, nang_rt, ntf), np.float32)
+        eps_star = np.zeros((nc, 2, nang_star, ns), np.float32)
+        rc = self.lib.oracle_init_dust_source_fct2(
+            C.byref(self.cm), C.byref(o), C.c_int(int(p_lambda or lam)), C.c_int(int(ibin)), C.c_int(nth), C.c_int(nphi),
+            C.c_int(nang_rt), C.c_int(nang_star), _p(I_spec, C.c_double), _p(_a(I_spec_star, np.float64), C.c_double),
+            _p(_a(Tdust, np.float32), C.c_float), _p(_a(m.grid["r_grid"], np.float64), C.c_double),
+            _p(_a(np.abs(m.grid["z_grid"]), np.float64), C.c_double), _p(eps, C.c_float), _p(eps_star, C.c_float))
+        if rc:
+            raise RuntimeError(f"oracle_init_dust_source_fct2 failed: {rc}")
+        return eps, eps_star
+
     def stars_map_image(self, lam, star_flux, npix_x, npix_y, map_size, zoom=1.0, seed=1, ang_disque=0.0,
                         limb_darkening=None):
         """compute_stars_map for images (resolved discs, limb darkening): ``(maps [nRT, n_maps, npix_y, npix_x],

@@ -2656,6 +2656,226 @@ int oracle_stars_map_sed(const oracle_model *m, const oracle_rt_opts *o, uint64_
   return 0;
 }
 
+/* ------------------------------------------------------------------------------------------------------------------ */
+/* Ray tracing method 2: init_dust_source_fct2 (dust_ray_tracing.f90:717-806) with calc_Isca_rt2 (:907-1240),           */
+/* calc_Isca_rt2_star (:1245-1440), angles_scatt_rt2 (:304-405) and calc_Jth -- the source function of one inclination  */
+/* from the specific intensity the packet loop stored (I_spec, I_spec_star): 2D grids.                                  */
+/* ------------------------------------------------------------------------------------------------------------------ */
+#define RT2_N_SUPER 5
+
+/* nint(acos(cos_scatt) * real(nang_scatt) / pi) with cos_scatt a default real (the correctly rounded default-real acos) */
+static int rt2_angle_index(float cos_scatt, int nang) {
+  const float ac = (float)acos((double)cos_scatt);
+  if (ac != ac) return nang;
+  return (int)llrint(floor((double)(ac * (float)nang) / PI + 0.5));
+}
+
+/* the rotation angle's cosine and sine between the scattering plane and the meridian of the ray-tracing direction
+ * (:1030-1065, :369-398): omega = 2 acos(v1pj / |(v1pj, v1pk)|), negative with v1pk */
+static double rt2_omega(double u, double v, double w, double ur, double vr, double wr) {
+  double v1pi, v1pj, v1pk;
+  oracle_rotation(u, v, w, -ur, -vr, -wr, &v1pi, &v1pj, &v1pk);
+  double xnyp = sqrt(v1pk * v1pk + v1pj * v1pj), costhet;
+  if (xnyp < 1e-10) costhet = 1.0; else costhet = v1pj / xnyp;
+  double theta = acos(costhet);
+  if (theta >= PI) theta = 0.0;
+  double omega = 2.0 * theta;
+  if (v1pk < 0.0) omega = -1.0 * omega;
+  return omega;
+}
+
+int oracle_init_dust_source_fct2(const oracle_model *m, const oracle_rt_opts *o, int p_lambda, int ibin, int n_theta_I,
+                                 int n_phi_I, int nang_rt, int nang_star, const double *I_spec, const double *I_spec_star,
+                                 const float *Tdust, const double *r_grid, const double *z_grid, float *eps_dust2,
+                                 float *eps_dust2_star) {
+  if (m->l3D || m->grid_type != 1) return 31;
+  const int lam = o->lambda, nang = m->nang_scatt, na1 = nang + 1, nc = m->n_cells;
+  const int n_Stokes = m->lsepar_pola ? 4 : 1, ntf = n_Stokes + (m->lsepar_contrib ? 4 : 0);
+  const int vd = m->p_n_cells != 0;
+  if (vd ? !m->v_tab_s11_pos : !m->tab_s11_pos) return 24;
+  const double w0 = m->tab_w_rt[ibin - 1], uv0 = sqrt(1.0 - w0 * w0); /* tab_uv_rt(ibin) = sin(incl), :280-289 */
+  const double photon_energy = rt_photon_energy(o);
+  double *J_th = rt_calc_Jth(m, lam, o->wl_um * 1.e-6, Tdust);
+  const size_t nbin = (size_t)n_theta_I * n_phi_I, nsup = RT2_N_SUPER * RT2_N_SUPER;
+  const size_t ntab = nbin * nang_rt * 2;
+  int *tab_k = (int *)malloc(sizeof(int) * ntab * nsup);
+  float *tab_sin = (float *)malloc(sizeof(float) * ntab * nsup);
+  double *tab_cosw = (double *)calloc(ntab, sizeof(double)), *tab_sinw = (double *)calloc(ntab, sizeof(double));
+  int *tab_kc = (int *)malloc(sizeof(int) * ntab);
+  if (!J_th || !tab_k || !tab_sin || !tab_cosw || !tab_sinw || !tab_kc) return 22;
+  /* ---- the directions where Inu * s11 is evaluated (:973-1072); index ((dir * nang_rt + iscatt) * n_phi_I + phi_I) * n_theta_I + theta_I */
+  for (int dir = 0; dir <= 1; ++dir)
+    for (int iscatt = 1; iscatt <= nang_rt; ++iscatt) {
+      const float phi_scatt = (float)(2 * PI * (double)((float)iscatt / (float)nang_rt)); /* two_pi * real / real -> default real */
+      const double ur = uv0 * sin((double)phi_scatt), vr = -uv0 * cos((double)phi_scatt), wr = w0;
+      for (int phi_I = 1; phi_I <= n_phi_I; ++phi_I)
+        for (int theta_I = 1; theta_I <= n_theta_I; ++theta_I) {
+          const size_t b = (((size_t)dir * nang_rt + (iscatt - 1)) * n_phi_I + (phi_I - 1)) * n_theta_I + (theta_I - 1);
+          float sum_sin = 0.f;
+          for (int i2 = 1; i2 <= RT2_N_SUPER; ++i2)
+            for (int i1 = 1; i1 <= RT2_N_SUPER; ++i1) {
+              const float f1 = (float)i1 / (float)(RT2_N_SUPER + 1), f2 = (float)i2 / (float)(RT2_N_SUPER + 1);
+              const double w = (2.0 * (((double)theta_I - (double)f1) / (double)n_theta_I) - 1.0) * (double)(2 * dir - 1);
+              const double phi = 2 * PI * ((double)phi_I - (double)f2) / (double)n_phi_I;
+              const double w02 = sqrt(1.0 - w * w), u = w02 * sin(phi), v = -w02 * cos(phi);
+              const float cos_scatt = (float)(ur * u + vr * v + wr * w);
+              int k = rt2_angle_index(cos_scatt, nang);
+              if (k > nang) k = nang;
+              if (k < 0) k = 0;
+              const float sin_scatt = (float)sqrt(1.0 - (double)cos_scatt * (double)cos_scatt);
+              tab_k[b * nsup + (i1 - 1) + RT2_N_SUPER * (i2 - 1)] = k;
+              tab_sin[b * nsup + (i1 - 1) + RT2_N_SUPER * (i2 - 1)] = sin_scatt;
+              sum_sin = sum_sin + sin_scatt;
+            }
+          for (size_t t = 0; t < nsup; ++t) tab_sin[b * nsup + t] = tab_sin[b * nsup + t] / sum_sin;
+          if (m->lsepar_pola) { /* the bin's centre for the polarisation (:1021-1070) */
+            const double w = (2.0 * (((double)theta_I - (double)0.5f) / (double)n_theta_I) - 1.0) * (double)(2 * dir - 1);
+            const double phi = 2 * PI * ((double)phi_I - (double)0.5f) / (double)n_phi_I;
+            const double w02 = sqrt(1.0 - w * w), u = w02 * sin(phi), v = -w02 * cos(phi);
+            const double omega = rt2_omega(u, v, w, ur, vr, wr);
+            double cosw = cos(omega), sinw = sin(omega);
+            if (fabs(cosw) < 1e-06) cosw = 0.0;
+            if (fabs(sinw) < 1e-06) sinw = 0.0;
+            tab_cosw[b] = cosw; tab_sinw[b] = sinw;
+          }
+          tab_kc[b] = tab_k[b * nsup + (RT2_N_SUPER / 2) + RT2_N_SUPER * (RT2_N_SUPER / 2)]; /* i1 = i2 = N_super/2 + 1 */
+        }
+    }
+  /* ---- per cell: the scattered field towards the nang_rt directions and both hemispheres (:1130-1232) */
+  memset(eps_dust2, 0, sizeof(float) * (size_t)ntf * nang_rt * 2 * nc);
+  memset(eps_dust2_star, 0, sizeof(float) * (size_t)n_Stokes * nang_star * 2 * nc);
+  for (int icell = 1; icell <= nc; ++icell) {
+    const size_t cls = vd ? (size_t)(m->p_icell[icell - 1] - 1) : 0;
+    const size_t col = vd ? (size_t)na1 * ((size_t)(p_lambda - 1) * m->p_n_cells + cls) : (size_t)na1 * (p_lambda - 1);
+    const float *t11 = (vd ? m->v_tab_s11_pos : m->tab_s11_pos) + col;
+    const float *t12 = (vd ? m->v_s12_o_s11 : m->s12_o_s11), *t22 = (vd ? m->v_s22_o_s11 : m->s22_o_s11);
+    const float *t33 = (vd ? m->v_s33_o_s11 : m->s33_o_s11), *t34 = (vd ? m->v_s34_o_s11 : m->s34_o_s11);
+    const float *t44 = (vd ? m->v_s44_o_s11 : m->s44_o_s11);
+    const double kappa_ext = tab_kappa(m, icell, lam) * m->kappa_factor[icell - 1];
+    const double factor = photon_energy / m->volume[icell - 1];
+    const double kappa_sca = tab_kappa(m, icell, lam) * m->kappa_factor[icell - 1] * (double)tab_albedo(m, icell, lam);
+    const double *Inu = I_spec + (size_t)ntf * nbin * (icell - 1); /* (N_type_flux, n_theta_I, n_phi_I, icell) */
+    float *eps = eps_dust2 + (size_t)ntf * nang_rt * 2 * (icell - 1); /* (N_type_flux, nang_rt, 0:1, icell) */
+    for (int dir = 0; dir <= 1; ++dir)
+      for (int iscatt = 1; iscatt <= nang_rt; ++iscatt) {
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int phi_I = 1; phi_I <= n_phi_I; ++phi_I)
+          for (int theta_I = 1; theta_I <= n_theta_I; ++theta_I) {
+            const size_t b = (((size_t)dir * nang_rt + (iscatt - 1)) * n_phi_I + (phi_I - 1)) * n_theta_I + (theta_I - 1);
+            float s11 = 0.f;
+            for (size_t t = 0; t < nsup; ++t) s11 = s11 + t11[tab_k[b * nsup + t]] * tab_sin[b * nsup + t];
+            const double *st = Inu + (size_t)ntf * ((size_t)(theta_I - 1) + (size_t)n_theta_I * (phi_I - 1));
+            if (m->lsepar_pola) {
+              const int k = tab_kc[b];
+              const double cosw = tab_cosw[b], sinw = tab_sinw[b];
+              const float s12 = -s11 * t12[col + k], s22 = s11 * t22[col + k], s33 = -s11 * t33[col + k];
+              const float s34 = -s11 * t34[col + k], s44 = -s11 * t44[col + k];
+              /* C = ROP S, ROP(2:3,2:3) = [[cosw, -sinw], [sinw, cosw]] */
+              const double C1 = st[0], C4 = st[3];
+              const double C2 = cosw * st[1] + (-1.0 * sinw) * st[2];
+              const double C3 = sinw * st[1] + cosw * st[2];
+              /* D = M C */
+              const double D1 = (double)s11 * C1 + (double)s12 * C2;
+              const double D2 = (double)s12 * C1 + (double)s22 * C2;
+              const double D3 = (double)s33 * C3 + (double)(-s34) * C4;
+              const double D4 = (double)s34 * C3 + (double)s44 * C4;
+              /* S = RPO D, RPO(2:3,2:3) = [[cosw, sinw], [-sinw, cosw]]; S(3) = -S(3) */
+              const double S2 = cosw * D2 + sinw * D3;
+              const double S3 = -((-1.0 * sinw) * D2 + cosw * D3);
+              acc[0] = (float)((double)acc[0] + D1);
+              acc[1] = (float)((double)acc[1] + S2);
+              acc[2] = (float)((double)acc[2] + S3);
+              acc[3] = (float)((double)acc[3] + D4);
+            } else {
+              acc[0] = (float)((double)acc[0] + (double)s11 * st[0]);
+            }
+            if (m->lsepar_contrib) {
+              acc[n_Stokes + 1] = (float)((double)acc[n_Stokes + 1] + (double)s11 * st[n_Stokes + 1]);
+              acc[n_Stokes + 3] = (float)((double)acc[n_Stokes + 3] + (double)s11 * st[n_Stokes + 3]);
+            }
+          }
+        float *e = eps + (size_t)ntf * ((size_t)(iscatt - 1) + (size_t)nang_rt * dir);
+        for (int t = 0; t < ntf; ++t) e[t] = (float)(((double)acc[t] * factor) * kappa_sca); /* I_sca2 (:1228) */
+      }
+    /* ---- calc_Isca_rt2_star (:1292-1432): unscattered starlight scattered once towards the observer */
+    float *es = eps_dust2_star + (size_t)n_Stokes * nang_star * 2 * (icell - 1);
+    const double Istar = I_spec_star[icell - 1];
+    if (!(Istar < 1.e-30)) {
+      const double yy = r_grid[icell - 1], zz = z_grid[icell - 1];
+      const double norm = sqrt(yy * yy + zz * zz), u = 0.0, v = yy / norm, w = zz / norm;
+      const double phi_pos = modulo_d(atan2(0.0, yy) + 2 * PI, 2 * PI); /* angles_scatt_rt2 (:327) at x = 0 */
+      for (int iscatt = 1; iscatt <= nang_star; ++iscatt) {
+        double phi = 2 * PI * (double)((float)iscatt / (float)nang_star); /* two_pi * real(iscatt) / real(N) */
+        phi = phi - phi_pos;
+        const double ur = uv0 * sin(phi), vr = -uv0 * cos(phi), wr = w0;
+        const double prod1 = ur * u + vr * v;
+        for (int dir = 0; dir <= 1; ++dir) {
+          const double w2 = dir == 1 ? w : -w;
+          const float cos_scatt = (float)(prod1 + wr * w2); /* cos_thet_ray_tracing_star is a default real */
+          int k = rt2_angle_index(cos_scatt, nang);
+          if (k > nang) k = nang;
+          if (k < 1) k = 1;
+          const float s11 = t11[k];
+          float *e = es + (size_t)n_Stokes * ((size_t)(iscatt - 1) + (size_t)nang_star * dir);
+          if (m->lsepar_pola) {
+            const double omega = (double)(float)rt2_omega(u, v, w2, ur, vr, wr); /* omega_ray_tracing_star: default real */
+            double cosw = cos(omega), sinw = sin(omega);
+            if (fabs(cosw) < 1e-06) cosw = 0.0;
+            if (fabs(sinw) < 1e-06) sinw = 0.0;
+            const float s12 = -s11 * t12[col + k], s22 = s11 * t22[col + k];
+            /* Stokes = (I*, 0, 0, 0): C = Stokes; D = M C; S(2:3) = RPO(2:3,2:3) D(2:3), RPO = [[cosw, sinw], [sinw, -cosw]] */
+            const double D1 = (double)s11 * Istar, D2 = (double)s12 * Istar;
+            (void)s22;
+            e[0] = (float)((D1 * factor) * kappa_sca);
+            e[1] = (float)(((cosw * D2) * factor) * kappa_sca);
+            e[2] = (float)(((sinw * D2) * factor) * kappa_sca);
+            e[3] = 0.f;
+          } else {
+            e[0] = (float)((((double)s11 * Istar) * factor) * kappa_sca);
+          }
+        }
+      }
+    }
+    /* ---- init_dust_source_fct2 (:749-799) */
+    if (kappa_ext > DBL_MIN) {
+      for (int dir = 0; dir <= 1; ++dir) {
+        for (int iscatt = 1; iscatt <= nang_rt; ++iscatt) {
+          float *e = eps + (size_t)ntf * ((size_t)(iscatt - 1) + (size_t)nang_rt * dir);
+          float I2[8];
+          for (int t = 0; t < ntf; ++t) I2[t] = e[t];
+          e[0] = (float)(((double)I2[0] + J_th[icell - 1]) / kappa_ext);
+          if (m->lsepar_pola) {
+            for (int t = 1; t < 4; ++t) e[t] = (float)((double)I2[t] / kappa_ext);
+            const float Q = e[1], U = e[2];
+            e[1] = sqrtf(Q * Q + U * U);
+            e[2] = atan2f(U, Q);
+          }
+          if (m->lsepar_contrib) {
+            e[n_Stokes + 1] = (float)((double)I2[n_Stokes + 1] / kappa_ext);
+            e[n_Stokes + 2] = (float)(J_th[icell - 1] / kappa_ext);
+            e[n_Stokes + 3] = (float)((double)I2[n_Stokes + 3] / kappa_ext);
+            e[n_Stokes] = 0.f; /* (n_Stokes + 1: direct starlight, filled by the ray tracer) */
+          }
+        }
+        for (int iscatt = 1; iscatt <= nang_star; ++iscatt) {
+          float *e = es + (size_t)n_Stokes * ((size_t)(iscatt - 1) + (size_t)nang_star * dir);
+          for (int t = 0; t < n_Stokes; ++t) e[t] = (float)((double)e[t] / kappa_ext);
+          if (m->lsepar_pola) {
+            const float Q = e[1], U = e[2];
+            e[1] = sqrtf(Q * Q + U * U);
+            e[2] = atan2f(U, Q);
+          }
+        }
+      }
+    } else {
+      memset(eps, 0, sizeof(float) * (size_t)ntf * nang_rt * 2);
+      memset(es, 0, sizeof(float) * (size_t)n_Stokes * nang_star * 2);
+    }
+  }
+  free(J_th); free(tab_k); free(tab_sin); free(tab_cosw); free(tab_sinw); free(tab_kc);
+  return 0;
+}
+
 /* interp (utils.f90:130-175, default real): linear interpolation in a table, the end values outside it */
 static float interp_sp(const float *y, const float *x, int n, float xp) {
   float xmin = x[0], xmax = x[0];

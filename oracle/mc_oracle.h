@@ -314,6 +314,17 @@ typedef struct {
   int n_threads;
 } oracle_rt_opts;
 
+/* Ray tracing method 2, the source function of inclination ibin: init_dust_source_fct2 (dust_ray_tracing.f90:717-806)
+ * = calc_Isca_rt2_star (:1245-1440, with angles_scatt_rt2 :304-405) + calc_Isca_rt2 (:907-1240) + calc_Jth + the division
+ * by kappa_ext and the (Q, U) -> (P, angle) form.  2D grids.  In: I_spec(N_type_flux, n_theta_I, n_phi_I, n_cells) and
+ * I_spec_star(n_cells) summed over the threads (double), o->E_src / n_sent_photons / wl_um / lambda, Tdust, r_grid /
+ * z_grid(n_cells).  Out (default real, the reference's arrays): eps_dust2(N_type_flux, nang_rt, 0:1, n_cells),
+ * eps_dust2_star(n_Stokes, nang_star, 0:1, n_cells).  PARITY UNPINNED (dust_ray_tracing.f90 is unbuildable here). */
+int oracle_init_dust_source_fct2(const oracle_model *m, const oracle_rt_opts *o, int p_lambda, int ibin, int n_theta_I,
+                                 int n_phi_I, int nang_rt, int nang_star, const double *I_spec, const double *I_spec_star,
+                                 const float *Tdust, const double *r_grid, const double *z_grid, float *eps_dust2,
+                                 float *eps_dust2_star);
+
 /* compute_stars_map for images (dust_transfer.f90:1604-1854, lresolved = .true.; find_pixel :1858-1893; interp
  * utils.f90:130-175): the stars' discs, limb-darkened (n_mu > 0) and polarised (pola_ld) if asked, in the pixel maps of
  * the observers; see the definition.  PARITY UNPINNED like oracle_stars_map_sed. */
