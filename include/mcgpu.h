@@ -357,8 +357,8 @@ typedef struct {
  *   eps_dust2_star(n_Stokes, nang_ray_tracing_star, 0:1, n_cells) ( once-scattered starlight )
  * (default real; nang_ray_tracing = 15, nang_ray_tracing_star = 1000 in dust_ray_tracing.f90:109-110).  opts: lambda,
  * wl_um, E_src, n_sent_photons; Tdust[n_cells]; r_grid / z_grid[n_cells] (cylindrical_grid.f90:26).  Needs
- * mcgpu_set_rt1 (the observers' inclinations, tab_s11_pos) and mcgpu_set_rt2.  What stays with the host: the ray
- * integration with the interpolating dust_source_fct of method 2 (:1478-1660).
+ * mcgpu_set_rt1 (the observers' inclinations, tab_s11_pos) and mcgpu_set_rt2.  The ray integration with this source
+ * function: mcgpu_rt2_dust_map / mcgpu_rt2_image below.
  */
 int mcgpu_set_rt2(mcgpu_ctx *ctx, int n_theta_I, int n_phi_I, int N_type_flux, int lsepar_contrib);
 int mcgpu_fetch_I_spec(mcgpu_ctx *ctx, float *I_spec, double *I_spec_f64, float *I_spec_star, double *I_spec_star_f64);
@@ -476,10 +476,22 @@ int mcgpu_rt1_stars_map_image(mcgpu_ctx *ctx, const mcgpu_rt_opts *opts, const f
                               const float *mu_limb_darkening, const float *limb_darkening,
                               const float *pola_limb_darkening, double *stars_map, double *star_position);
 
-/* init_dust_source_fct2 of one inclination on the device: described with mcgpu_set_rt2 above */
+/* init_dust_source_fct2 of one inclination on the device: described with mcgpu_set_rt2 above.  eps_dust2 /
+ * eps_dust2_star may be NULL: the source function stays in HBM for the two calls below. */
 int mcgpu_rt2_source(mcgpu_ctx *ctx, const mcgpu_rt_opts *opts, int p_lambda, int ibin, const float *Tdust,
                      const double *r_grid, const double *z_grid, int nang_ray_tracing, int nang_ray_tracing_star,
                      float *eps_dust2, float *eps_dust2_star, double *kernel_ms);
+
+/* Ray tracing with method 2 (lscatt_ray_tracing2): dust_map's SED sampling and image pixels as in mcgpu_rt1_dust_map /
+ * mcgpu_rt1_image, for the inclination of the last mcgpu_rt2_source (same wavelength; iaz = 1: method 2 is 2D and knows
+ * one observer azimuth), with dust_source_fct's method-2 branch (dust_ray_tracing.f90:1478-1700: linear in z between the
+ * cell and its vertical neighbour, linear in azimuth between the tabulated directions, interpolate_Stokes_QU :1705; the
+ * radial interpolation is switched off in the reference) in integ_ray_dust (optical_depth.f90:1327-1421).
+ * stokes[N_type_flux]; image(npix_x, npix_y, N_type_flux) column-major. */
+int mcgpu_rt2_dust_map(mcgpu_ctx *ctx, const mcgpu_rt_opts *opts, const float *tab_RT_az, const float *Tdust,
+                       double *stokes, double *kernel_ms);
+int mcgpu_rt2_image(mcgpu_ctx *ctx, const mcgpu_rt_opts *opts, const float *tab_RT_az, const float *Tdust, int npix_x,
+                    int npix_y, double map_size, double zoom, double *image, uint64_t *n_rays, double *kernel_ms);
 
 /* The same for images: dust_map method 2 (dust_transfer.f90:1537-1577) -- npix_x x npix_y square pixels of
  * (map_size/zoom)/max(npix_x,npix_y) AU, each refined by intensite_pixel_dust (:1899-2004): 1, 2x2, ... 32x32

@@ -31,6 +31,11 @@ struct RtArgs {
   double taille_pix;                                            // AU
   double* image;                                                // [N_type_flux][RT_n_az][RT_n_incl][npix_y][npix_x]
   unsigned long long* n_rays;
+  // method 2 (mcgpu_rt2_dust_map / mcgpu_rt2_image): the source function of ONE inclination, observer q_only
+  int method2, q_only, nang_rt, nang_star;
+  const float* eps2;       // eps_dust2(N_type_flux, nang_rt, 0:1, n_cells)
+  const float* eps2_star;  // eps_dust2_star(n_Stokes, nang_star, 0:1, n_cells)
+  const double* z_grid;    // z_grid(n_cells)
 };
 
 constexpr int RT_N_RAD = 128, RT_N_PHI = 30;  // dust_map (:1434)
@@ -80,6 +85,94 @@ __device__ inline void rt_image_plane(const RtArgs& A, int q, double uvw[3], dou
   ypi[2] = -(xpi[0] * uvw[1] - xpi[1] * uvw[0]);
 }
 
+// ---- ray tracing method 2: dust_source_fct (dust_ray_tracing.f90:1478-1700) on the eps_dust2 / eps_dust2_star that
+// mcgpu_rt2_source left in HBM.  interpolate_Stokes_QU (:1705-1742): between two (P I, 2 theta) pairs, back to (Q, U).
+__device__ inline void interpolate_stokes_qu(const float* a, const float* b, double frac1, float out[2]) {
+  const float PxI1 = a[0], PxI2 = b[0];
+  float two_theta1 = a[1], two_theta2 = b[1];
+  const float PxI = (float)((double)PxI2 * (1.0 - frac1) + (double)PxI1 * frac1);
+  if ((double)fabsf(two_theta2 - two_theta1) >= PI) {
+    if (two_theta2 > two_theta1) two_theta1 = (float)((double)two_theta1 + 2 * PI);
+    else two_theta2 = (float)((double)two_theta2 + 2 * PI);
+  }
+  const float two_theta = (float)((double)two_theta2 * (1.0 - frac1) + (double)two_theta1 * frac1);
+  out[0] = PxI * cosf(two_theta);
+  out[1] = PxI * (-sinf(two_theta));
+}
+
+// one corner of the interpolation: cell ic (0-based), between the tabulated directions around phi_pos
+template <bool POLA>
+__device__ inline void rt2_corner(const RtArgs& A, int ic, int dir, double phi_pos, double SF[8]) {
+  const int n_Stokes = POLA ? 4 : 1, ntf = A.N_type_flux;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) SF[t] = 0.0;
+  {
+    const int N = A.nang_rt;
+    const double xiscatt = fmax(phi_pos / (2 * PI) * (double)N, 0.0);
+    int iscatt1 = (int)floor(xiscatt);
+    const double frac = xiscatt - iscatt1, un_m_frac = 1.0 - frac;
+    int iscatt2 = iscatt1 + 1;
+    iscatt1 = ((iscatt1 % N) + N) % N; if (iscatt1 == 0) iscatt1 = N;
+    iscatt2 = ((iscatt2 % N) + N) % N; if (iscatt2 == 0) iscatt2 = N;
+    const float* e1 = A.eps2 + (size_t)ntf * ((size_t)(iscatt1 - 1) + (size_t)N * (dir + 2 * (size_t)ic));
+    const float* e2 = A.eps2 + (size_t)ntf * ((size_t)(iscatt2 - 1) + (size_t)N * (dir + 2 * (size_t)ic));
+    SF[0] = (double)e2[0] * frac + (double)e1[0] * un_m_frac;
+    if (POLA) {
+      float qu[2];
+      interpolate_stokes_qu(e1 + 1, e2 + 1, un_m_frac, qu);
+      SF[1] = (double)qu[0]; SF[2] = (double)qu[1];
+    }
+    if (A.contrib)
+      for (int t = n_Stokes; t < ntf; ++t) SF[t] = (double)e2[t] * frac + (double)e1[t] * un_m_frac;
+  }
+  {
+    const int N = A.nang_star;
+    const double xiscatt = fmax(phi_pos / (2 * PI) * (double)N, 0.0);
+    int iscatt1 = (int)floor(xiscatt);
+    const double frac = xiscatt - iscatt1, un_m_frac = 1.0 - frac;
+    int iscatt2 = iscatt1 + 1;
+    iscatt1 = ((iscatt1 % N) + N) % N; if (iscatt1 == 0) iscatt1 = N;
+    iscatt2 = ((iscatt2 % N) + N) % N; if (iscatt2 == 0) iscatt2 = N;
+    const float* e1 = A.eps2_star + (size_t)n_Stokes * ((size_t)(iscatt1 - 1) + (size_t)N * (dir + 2 * (size_t)ic));
+    const float* e2 = A.eps2_star + (size_t)n_Stokes * ((size_t)(iscatt2 - 1) + (size_t)N * (dir + 2 * (size_t)ic));
+    SF[0] = (SF[0] + (double)e2[0] * frac) + (double)e1[0] * un_m_frac;
+    if (POLA) {
+      float qu[2];
+      interpolate_stokes_qu(e1 + 1, e2 + 1, un_m_frac, qu);
+      SF[1] = SF[1] + (double)qu[0]; SF[2] = SF[2] + (double)qu[1];
+    }
+    if (A.contrib) SF[n_Stokes + 1] = (SF[n_Stokes + 1] + (double)e2[0] * frac) + (double)e1[0] * un_m_frac;
+  }
+}
+
+// dust_source_fct, method 2: linear in z between the cell and its vertical neighbour on the point's side (the radial
+// interpolation is switched off in the reference: ri1 = ri, frac_r = 1), linear in azimuth between the directions
+template <bool POLA>
+__device__ inline void dust_source_fct2(const DevModel& M, const RtArgs& A, int ri, int zj, double x, double y, double z,
+                                        double SF[8]) {
+#pragma clang fp contract(off)
+  const int n_rad = M.n_rad, nz = M.nz;
+  const int ic = (ri - 1) + n_rad * (zj - 1);
+  int zj1, zj2;
+  double frac_z;
+  if (fabs(z) > A.z_grid[ic]) { zj1 = zj; zj2 = zj + 1; } else { zj1 = zj - 1; zj2 = zj; }
+  if (zj2 > nz) { zj2 = nz; frac_z = 1.0; }
+  else if (zj1 < 1) { zj1 = 1; frac_z = 1.0; }
+  else {
+    const double za = A.z_grid[(ri - 1) + n_rad * (zj2 - 1)], zb = A.z_grid[(ri - 1) + n_rad * (zj1 - 1)];
+    frac_z = (za - fabs(z)) / (za - zb);
+  }
+  frac_z = fmax(fmin(1.0, frac_z), 0.0);
+  const double phi_pos = modulo_d(atan2(x, y) + 2 * PI, 2 * PI);
+  const int dir = z > 0.0 ? 1 : 0;
+  double SF1[8], SF3[8];
+  rt2_corner<POLA>(A, (ri - 1) + n_rad * (zj1 - 1), dir, phi_pos, SF1);
+  rt2_corner<POLA>(A, (ri - 1) + n_rad * (zj2 - 1), dir, phi_pos, SF3);
+  const double frac_r = 1.0;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) SF[t] = frac_r * frac_z * SF1[t] + frac_r * (1.0 - frac_z) * SF3[t];
+}
+
 // move_to_grid + integ_ray_dust (optical_depth.f90:1327-1421) for observer q from the point (x,y,z) of the image
 // plane, propagating along (u0,v0,w0) = -(direction to the observer).  S[0..N_type_flux) is overwritten.
 template <bool L3D, bool POLA>
@@ -115,7 +208,12 @@ __device__ inline void rt1_integ_ray(const Lds& T, const DevModel& M, const RtAr
       const double dtau = l * kappa_ext;
       int phik = 1, psup = 1;
       rt1_subbin_of(A.n_az_rt, L3D, x, y, z, x1, y1, z1, phik, psup);
-      if (kappa_ext > TINY_DP) {
+      if (!L3D && A.method2) {  // the interpolated source function of method 2 at the middle of the path (:1396-1404)
+        double SF[8];
+        dust_source_fct2<POLA>(M, A, ri, zj, 0.5 * (x + x1), 0.5 * (y + y1), 0.5 * (z + z1), SF);
+        const double wgt = exp(-tau) * (1.0 - exp(-dtau));
+        for (int t = 0; t < A.N_type_flux; ++t) S[t] += wgt * SF[t];
+      } else if (kappa_ext > TINY_DP) {
         const double factor = A.photon_energy / M.volume[ic] * A.n_az_rt * A.n_theta_rt;
         const double kappa_sca = kappa_ext * (double)(M.n_classes ? M.v_albedo[vrow] : T.albedo[A.lambda - 1]);
         const size_t bin = ((size_t)ic * A.n_theta_rt + (psup - 1)) * A.n_az_rt + (phik - 1);
@@ -155,12 +253,13 @@ __global__ void __launch_bounds__(256) k_rt1_dust_map(const DevModel M, const Rt
   lds_stage_mono(T, M, 1);
   __syncthreads();
   const int rays_per_dir = RT_N_RAD * RT_N_PHI;  // 3840 = 60 wavefronts: a wavefront never straddles two directions
-  const int n_rays = A.nRT * rays_per_dir;
+  const int n_rays = (A.method2 ? 1 : A.nRT) * rays_per_dir;  // (method 2: the one inclination of its source function)
   const int lane = threadIdx.x & 63;
 
   for (int base = (blockIdx.x * blockDim.x + (threadIdx.x & ~63)); base < n_rays; base += gridDim.x * blockDim.x) {
     const int ray = base + lane;  // (n_rays is a multiple of 64)
-    const int q = ray / rays_per_dir, rem = ray - q * rays_per_dir;
+    const int q0 = ray / rays_per_dir, rem = ray - q0 * rays_per_dir;
+    const int q = A.method2 ? A.q_only : q0;
     const int ri_RT = rem / RT_N_PHI, phi_RT = rem - ri_RT * RT_N_PHI + 1;
     double uvw[3], xpi[3], ypi[3];
     rt_image_plane(A, q, uvw, xpi, ypi);
@@ -195,14 +294,15 @@ __global__ void __launch_bounds__(256) k_rt1_image(const DevModel M, const RtArg
   const int lane = threadIdx.x % lanes;
   const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) / lanes;
   const long n_waves = (long)gridDim.x * blockDim.x / lanes;
-  const long pix_per_dir = (long)A.npix_x_max * A.npix_y, n_pix = pix_per_dir * A.nRT;
+  const long pix_per_dir = (long)A.npix_x_max * A.npix_y, n_pix = pix_per_dir * (A.method2 ? 1 : A.nRT);
   const int n_iter_min = 2, n_iter_max = 6;  // dust_map (:1566-1567)
   const double precision = 1.e-2;            // intensite_pixel_dust (:1921)
   unsigned long long rays = 0;
 
   for (long pix = wave; pix < n_pix; pix += n_waves) {
-    const int q = (int)(pix / pix_per_dir);
-    const long rem = pix - (long)q * pix_per_dir;
+    const int q0 = (int)(pix / pix_per_dir);
+    const long rem = pix - (long)q0 * pix_per_dir;
+    const int q = A.method2 ? A.q_only : q0;
     const int i = (int)(rem / A.npix_y) + 1, j = (int)(rem - (long)(i - 1) * A.npix_y) + 1;
     double uvw[3], xpi[3], ypi[3], corner[3], dx[3], dy[3];
     rt_image_plane(A, q, uvw, xpi, ypi);

@@ -131,6 +131,10 @@ struct mcgpu_ctx {
   bool have_rt2 = false;            // ray tracing method 2 (mcgpu_set_rt2): I_spec, I_spec_star
   int n_theta_I = 0, n_phi_I = 0, rt2_N_type_flux = 0, rt2_contrib = 0;
   double *d_I_spec = nullptr, *d_I_spec_star = nullptr;
+  // the source function of the last mcgpu_rt2_source, resident for mcgpu_rt2_dust_map / mcgpu_rt2_image
+  float *d_eps2 = nullptr, *d_eps2_star = nullptr;
+  double* d_rt2_zgrid = nullptr;
+  int rt2_src_ibin = 0, rt2_src_lambda = 0, rt2_src_nang = 0, rt2_src_nang_star = 0;
   size_t n_xI = 0;
   int xI_bytes = 8;  // accumulator type of xI_scatt on the device: 8 = FP64 (default), 4 = default real (mcgpu_set_xI_precision)
   double* d_prob_E = nullptr;               // prob_E_cell(0:n_cells) of the current wavelength
@@ -1971,7 +1975,7 @@ extern "C" int mcgpu_rt2_source(mcgpu_ctx* ctx, const mcgpu_rt_opts* o, int p_la
                                 int nang_ray_tracing_star, float* eps_dust2, float* eps_dust2_star, double* kernel_ms) {
   int rc = ready(ctx);
   if (rc) return rc;
-  if (!o || !Tdust || !r_grid || !z_grid || !eps_dust2 || !eps_dust2_star || nang_ray_tracing < 1 || nang_ray_tracing_star < 1 ||
+  if (!o || !Tdust || !r_grid || !z_grid || nang_ray_tracing < 1 || nang_ray_tracing_star < 1 ||
       nang_ray_tracing > 4096 || nang_ray_tracing_star > 65536)
     return fail(ctx, MCGPU_ERR_ARG, "mcgpu_rt2_source: bad argument");
   DevModel& M = ctx->M;
@@ -2045,7 +2049,7 @@ extern "C" int mcgpu_rt2_source(mcgpu_ctx* ctx, const mcgpu_rt_opts* o, int p_la
         }
     }
   DevBuf<int> d_k;
-  DevBuf<float> d_sin, d_T, d_eps, d_eps_star;
+  DevBuf<float> d_sin, d_T;
   DevBuf<double> d_cw, d_sw, d_J, d_rg, d_zg;
   HIPCHK(d_k.alloc(tab_k.size())); HIPCHK(d_k.put(tab_k.data(), tab_k.size()));
   HIPCHK(d_sin.alloc(tab_sin.size())); HIPCHK(d_sin.put(tab_sin.data(), tab_sin.size()));
@@ -2056,7 +2060,15 @@ extern "C" int mcgpu_rt2_source(mcgpu_ctx* ctx, const mcgpu_rt_opts* o, int p_la
   HIPCHK(d_rg.alloc(M.n_cells)); HIPCHK(d_rg.put(r_grid, M.n_cells));
   HIPCHK(d_zg.alloc(M.n_cells)); HIPCHK(d_zg.put(z_grid, M.n_cells));
   const size_t n_eps = (size_t)ntf * na * 2 * M.n_cells, n_eps_s = (size_t)n_Stokes * ns * 2 * M.n_cells;
-  HIPCHK(d_eps.alloc(n_eps)); HIPCHK(d_eps_star.alloc(n_eps_s));
+  // (the result stays in HBM for mcgpu_rt2_dust_map / mcgpu_rt2_image)
+  if (ctx->d_eps2) hipFree(ctx->d_eps2);
+  if (ctx->d_eps2_star) hipFree(ctx->d_eps2_star);
+  if (ctx->d_rt2_zgrid) hipFree(ctx->d_rt2_zgrid);
+  ctx->d_eps2 = ctx->d_eps2_star = nullptr; ctx->d_rt2_zgrid = nullptr; ctx->rt2_src_ibin = 0;
+  HIPCHK(hipMalloc((void**)&ctx->d_eps2, n_eps * sizeof(float)));
+  HIPCHK(hipMalloc((void**)&ctx->d_eps2_star, n_eps_s * sizeof(float)));
+  HIPCHK(hipMalloc((void**)&ctx->d_rt2_zgrid, (size_t)M.n_cells * sizeof(double)));
+  HIPCHK(hipMemcpyAsync(ctx->d_rt2_zgrid, z_grid, (size_t)M.n_cells * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   Rt2Args A;
   std::memset(&A, 0, sizeof(A));
   A.lambda = o->lambda; A.p_lambda = p_lambda; A.n_theta_I = nt; A.n_phi_I = np; A.nang_rt = na; A.nang_star = ns;
@@ -2067,7 +2079,7 @@ extern "C" int mcgpu_rt2_source(mcgpu_ctx* ctx, const mcgpu_rt_opts* o, int p_la
   A.I_spec = ctx->d_I_spec; A.I_spec_star = ctx->d_I_spec_star; A.J_th = d_J.p; A.r_grid = d_rg.p; A.z_grid = d_zg.p;
   A.tab_k = d_k.p; A.tab_sin = d_sin.p; A.tab_cosw = d_cw.p; A.tab_sinw = d_sw.p;
   A.s11_single = M.n_classes ? nullptr : ctx->d_tab_s11 + (size_t)(M.nang + 1) * (p_lambda - 1);
-  A.eps_dust2 = d_eps.p; A.eps_dust2_star = d_eps_star.p;
+  A.eps_dust2 = ctx->d_eps2; A.eps_dust2_star = ctx->d_eps2_star;
   HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
   hipLaunchKernelGGL(k_calc_Jth, dim3((M.n_cells + 255) / 256), dim3(256), 0, ctx->stream, M, o->lambda, o->wl_um * 1.e-6, d_T.p, d_J.p);
   const size_t n1 = (size_t)M.n_cells * 2 * na, n2 = (size_t)M.n_cells * 2 * ns;
@@ -2082,8 +2094,9 @@ extern "C" int mcgpu_rt2_source(mcgpu_ctx* ctx, const mcgpu_rt_opts* o, int p_la
   HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   if (kernel_ms) { float ms = 0.f; hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1); *kernel_ms = ms; }
-  HIPCHK(d_eps.get(eps_dust2, n_eps));
-  HIPCHK(d_eps_star.get(eps_dust2_star, n_eps_s));
+  ctx->rt2_src_ibin = ibin; ctx->rt2_src_lambda = o->lambda; ctx->rt2_src_nang = na; ctx->rt2_src_nang_star = ns;
+  if (eps_dust2) HIPCHK(hipMemcpy(eps_dust2, ctx->d_eps2, n_eps * sizeof(float), hipMemcpyDeviceToHost));
+  if (eps_dust2_star) HIPCHK(hipMemcpy(eps_dust2_star, ctx->d_eps2_star, n_eps_s * sizeof(float), hipMemcpyDeviceToHost));
   return MCGPU_OK;
 }
 
@@ -2479,6 +2492,7 @@ struct Rt1Job {
   DevBuf<float> d_T, d_az;
   DevBuf<double> d_J;
   RtArgs A;
+  bool method2 = false;
 };
 
 static int rt1_prepare(mcgpu_ctx* ctx, const mcgpu_rt_opts* o, const float* tab_RT_az, const float* Tdust, Rt1Job& J,
@@ -2487,8 +2501,11 @@ static int rt1_prepare(mcgpu_ctx* ctx, const mcgpu_rt_opts* o, const float* tab_
   if (rc) return rc;
   if (ctx->voro || ctx->M.grid_sph) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "RT1 ray tracing: cylindrical grids only");
   if (!o || !tab_RT_az || !Tdust) return fail(ctx, MCGPU_ERR_ARG, "RT1 ray tracing: null argument");
-  if (!ctx->have_rt1 || !ctx->d_xI)
+  if (!ctx->have_rt1 || (!ctx->d_xI && !J.method2))
     return fail(ctx, MCGPU_ERR_STATE, "RT1 ray tracing needs the xI_scatt of mcgpu_run_mono(rt1=1) or mcgpu_set_xI");
+  if (J.method2 && (!ctx->d_eps2 || !ctx->rt2_src_ibin || ctx->rt2_src_lambda != (o ? o->lambda : 0)))
+    return fail(ctx, MCGPU_ERR_STATE, "method 2 ray tracing needs mcgpu_rt2_source of this wavelength first");
+  if (J.method2 && ctx->RT_n_az != 1) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "method 2 is 2D and knows one observer azimuth (RT_n_az = 1)");
   const DevModel& M = ctx->M;
   if (o->lambda < 1 || o->lambda > M.n_lambda || !(o->wl_um > 0.0) || !(o->n_sent_photons > 0.0) ||
       !(o->distance > 0.0) || !(o->Rmin > 0.0) || !(o->Rmax > o->Rmin))
@@ -2516,6 +2533,11 @@ static int rt1_prepare(mcgpu_ctx* ctx, const mcgpu_rt_opts* o, const float* tab_
   A.rt_u = ctx->d_rt_u; A.rt_v = ctx->d_rt_v; A.rt_w = ctx->d_rt_w; A.rt_az = J.d_az.p;
   A.xI = ctx->d_xI; A.J_th = J.d_J.p;
   A.xI_f32 = ctx->xI_bytes == 4 ? 1 : 0; A.nRT_pad = xi_nrt_pad(ctx);
+  if (J.method2) {
+    A.method2 = 1; A.q_only = ctx->rt2_src_ibin - 1; A.nang_rt = ctx->rt2_src_nang; A.nang_star = ctx->rt2_src_nang_star;
+    A.eps2 = ctx->d_eps2; A.eps2_star = ctx->d_eps2_star; A.z_grid = ctx->d_rt2_zgrid;
+    A.N_type_flux = ctx->rt2_N_type_flux; A.contrib = ctx->rt2_contrib;
+  }
   HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
   hipLaunchKernelGGL(k_calc_Jth, dim3((M.n_cells + 255) / 256), dim3(256), 0, ctx->stream, M, o->lambda, A.wl, J.d_T.p, J.d_J.p);
   HIPCHK(hipGetLastError());
@@ -2525,7 +2547,7 @@ static int rt1_prepare(mcgpu_ctx* ctx, const mcgpu_rt_opts* o, const float* tab_
 template <bool IMAGE>
 static int rt1_launch(mcgpu_ctx* ctx, const RtArgs& A, int blocks) {
   const size_t lds = lds_bytes(ctx->M, true);
-  const bool pola = ctx->N_type_flux == 4 || ctx->N_type_flux == 8, l3d = ctx->M.l3D != 0;
+  const bool pola = A.N_type_flux == 4 || A.N_type_flux == 8, l3d = ctx->M.l3D != 0;
 #define RT1_GO(a, b) do {                                                                                          \
     const void* fn = IMAGE ? (const void*)k_rt1_image<a, b> : (const void*)k_rt1_dust_map<a, b>;                    \
     HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                           \
@@ -2643,6 +2665,66 @@ extern "C" int mcgpu_define_dark_zone(mcgpu_ctx* ctx, int lambda, double tau_max
   }
   *ri_in_dark_zone = ri_in; *ri_out_dark_zone = ri_out;
   for (int i = 0; i < n_rad; ++i) zj_sup_dark_zone[i] = zj[i];
+  return MCGPU_OK;
+}
+
+// dust_map with method 2's source function (the inclination of the last mcgpu_rt2_source): see include/mcgpu.h
+extern "C" int mcgpu_rt2_dust_map(mcgpu_ctx* ctx, const mcgpu_rt_opts* o, const float* tab_RT_az, const float* Tdust,
+                                  double* stokes, double* kernel_ms) {
+  if (ctx && !stokes) return fail(ctx, MCGPU_ERR_ARG, "mcgpu_rt2_dust_map: null argument");
+  Rt1Job J;
+  J.method2 = true;
+  int rc = rt1_prepare(ctx, o, tab_RT_az, Tdust, J, "mcgpu_rt2_dust_map: bad option");
+  if (rc) return rc;
+  const int ntf = ctx->rt2_N_type_flux;
+  const size_t n_out = (size_t)J.A.nRT * ntf;
+  DevBuf<double> d_out;
+  HIPCHK(d_out.alloc(n_out));
+  HIPCHK(hipMemsetAsync(d_out.p, 0, n_out * sizeof(double), ctx->stream));
+  J.A.out = d_out.p;
+  const int n_rays = RT_N_RAD * RT_N_PHI;
+  if ((rc = rt1_launch<false>(ctx, J.A, (n_rays + 255) / 256))) return rc;
+  if (kernel_ms) { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1)); *kernel_ms = ms; }
+  std::vector<double> all(n_out);
+  HIPCHK(d_out.get(all.data(), n_out));
+  for (int t = 0; t < ntf; ++t) stokes[t] = all[(size_t)J.A.q_only * ntf + t];
+  return MCGPU_OK;
+}
+
+extern "C" int mcgpu_rt2_image(mcgpu_ctx* ctx, const mcgpu_rt_opts* o, const float* tab_RT_az, const float* Tdust,
+                               int npix_x, int npix_y, double map_size, double zoom, double* image, uint64_t* n_rays,
+                               double* kernel_ms) {
+  if (ctx && (!image || npix_x < 1 || npix_y < 1 || npix_x > 32768 || npix_y > 32768 || !(map_size > 0.0) || !(zoom > 0.0)))
+    return fail(ctx, MCGPU_ERR_ARG, "mcgpu_rt2_image: bad argument");
+  Rt1Job J;
+  J.method2 = true;
+  int rc = rt1_prepare(ctx, o, tab_RT_az, Tdust, J, "mcgpu_rt2_image: bad option");
+  if (rc) return rc;
+  RtArgs& A = J.A;
+  const int ntf = ctx->rt2_N_type_flux;
+  A.npix_x = npix_x; A.npix_y = npix_y;
+  A.npix_x_max = o->l_sym_ima ? npix_x / 2 + npix_x % 2 : npix_x;
+  A.taille_pix = (map_size / zoom) / (double)(npix_x > npix_y ? npix_x : npix_y);
+  const size_t n_all = (size_t)A.nRT * ntf * npix_x * npix_y;
+  DevBuf<double> d_img;
+  DevBuf<unsigned long long> d_rays;
+  HIPCHK(d_img.alloc(n_all)); HIPCHK(d_rays.alloc(1));
+  HIPCHK(hipMemsetAsync(d_img.p, 0, n_all * sizeof(double), ctx->stream));
+  HIPCHK(hipMemsetAsync(d_rays.p, 0, sizeof(unsigned long long), ctx->stream));
+  A.image = d_img.p; A.n_rays = d_rays.p;
+  const long n_waves = (long)A.npix_x_max * npix_y;   // one wavefront per pixel
+  long blocks = (n_waves + 3) / 4;
+  if (blocks > 65536) blocks = 65536;
+  if ((rc = rt1_launch<true>(ctx, A, (int)blocks))) return rc;
+  if (kernel_ms) { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1)); *kernel_ms = ms; }
+  std::vector<double> all(n_all);
+  HIPCHK(d_img.get(all.data(), n_all));
+  // image(npix_x, npix_y, N_type_flux) of the inclination: the slice (ibin, iaz = 1) of the full layout
+  const int n_az = A.nRT / A.RT_n_incl, ibin0 = A.q_only % A.RT_n_incl, iaz0 = A.q_only / A.RT_n_incl;
+  for (int t = 0; t < ntf; ++t)
+    std::memcpy(image + (size_t)t * npix_x * npix_y,
+                all.data() + ((((size_t)t * n_az + iaz0) * A.RT_n_incl + ibin0) * npix_y) * npix_x, (size_t)npix_x * npix_y * sizeof(double));
+  if (n_rays) { unsigned long long r = 0; HIPCHK(d_rays.get(&r, 1)); *n_rays = r; }
   return MCGPU_OK;
 }
 

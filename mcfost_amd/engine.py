@@ -36,7 +36,7 @@ ABI_SYMBOLS = (
     "mcgpu_device_xI", "mcgpu_set_ism", "mcgpu_rt1_dust_map", "mcgpu_set_xI", "mcgpu_rt1_image", "mcgpu_set_xI_precision",
     "mcgpu_get_xI_precision", "mcgpu_set_option", "mcgpu_get_info", "mcgpu_counters_to_accum", "mcgpu_counters_from_accum",
     "mcgpu_set_grid_sph", "mcgpu_temp_approx_diffusion_vertical", "mcgpu_set_mrw", "mcgpu_fetch_radiation_field", "mcgpu_set_variable_dust", "mcgpu_rt1_stars_map_sed", "mcgpu_define_dark_zone", "mcgpu_init_reemission", "mcgpu_multi_create", "mcgpu_multi_destroy", "mcgpu_multi_size", "mcgpu_multi_ctx", "mcgpu_multi_last_error",
-    "mcgpu_repartition_energie", "mcgpu_opacity", "mcgpu_set_variable_dust_s11", "mcgpu_set_scattering_method1", "mcgpu_set_rt2", "mcgpu_fetch_I_spec", "mcgpu_rt1_stars_map_image", "mcgpu_set_I_spec", "mcgpu_rt2_source", "mcgpu_shard_packets", "mcgpu_multi_run_thermal", "mcgpu_multi_run_mono", "mcgpu_multi_rccl_ranks",
+    "mcgpu_repartition_energie", "mcgpu_opacity", "mcgpu_set_variable_dust_s11", "mcgpu_set_scattering_method1", "mcgpu_set_rt2", "mcgpu_fetch_I_spec", "mcgpu_rt1_stars_map_image", "mcgpu_set_I_spec", "mcgpu_rt2_source", "mcgpu_rt2_dust_map", "mcgpu_rt2_image", "mcgpu_shard_packets", "mcgpu_multi_run_thermal", "mcgpu_multi_run_mono", "mcgpu_multi_rccl_ranks",
 )
 
 
@@ -602,6 +602,36 @@ class Engine:
             C.c_int(nang_rt), C.c_int(nang_star), _p(eps, C.c_float), _p(eps_star, C.c_float), C.byref(ms)), "mcgpu_rt2_source")
         self.last_rt2_ms = ms.value
         return eps, eps_star
+
+    def rt2_dust_map_sed(self, lam, Tdust, n_sent_photons, E_disk, l_sym_ima=True, tau_dark_zone_obs=100.0):
+        """Ray-traced SED of the dust with method 2's source function (the inclination of the last
+        ``init_dust_source_fct2``): (N_type_flux,) and the kernel time."""
+        m = self.model
+        rt = m.rt
+        o = RtOpts(int(lam), float(m.lam[lam - 1]), float(m.E_stars[lam - 1] + E_disk), float(n_sent_photons),
+                   float(m.cfg.distance), 0.0, int(l_sym_ima), float(tau_dark_zone_obs), float(m.cfg.rin), float(m.cfg.rout))
+        out = np.zeros(self._rt2[2], np.float64)
+        ms = C.c_double()
+        self._chk(self.lib.mcgpu_rt2_dust_map(self.ctx, C.byref(o), _p(_a(rt["tab_RT_az"], np.float32), C.c_float),
+                                              _p(_a(Tdust, np.float32), C.c_float), _p(out, C.c_double), C.byref(ms)),
+                  "mcgpu_rt2_dust_map")
+        return out, ms.value
+
+    def rt2_dust_map_image(self, lam, Tdust, n_sent_photons, E_disk, npix_x, npix_y, map_size, zoom=1.0, l_sym_ima=False,
+                           tau_dark_zone_obs=100.0):
+        """The image of that inclination with method 2's source function: (N_type_flux, npix_y, npix_x), rays, kernel ms."""
+        m = self.model
+        rt = m.rt
+        o = RtOpts(int(lam), float(m.lam[lam - 1]), float(m.E_stars[lam - 1] + E_disk), float(n_sent_photons),
+                   float(m.cfg.distance), 0.0, int(l_sym_ima), float(tau_dark_zone_obs), float(m.cfg.rin), float(m.cfg.rout))
+        img = np.zeros((self._rt2[2], npix_y, npix_x), np.float64)
+        n = C.c_uint64(0)
+        ms = C.c_double()
+        self._chk(self.lib.mcgpu_rt2_image(self.ctx, C.byref(o), _p(_a(rt["tab_RT_az"], np.float32), C.c_float),
+                                           _p(_a(Tdust, np.float32), C.c_float), C.c_int(npix_x), C.c_int(npix_y),
+                                           C.c_double(map_size), C.c_double(zoom), _p(img, C.c_double), C.byref(n), C.byref(ms)),
+                  "mcgpu_rt2_image")
+        return img, int(n.value), ms.value
 
     def run_mono(self, lam, n_photons2, n_phot_lim=None, p_lambda=None, seed=1, n_chunks=None, rt1=True,
                  accumulate=False, grid_blocks=0, block_threads=0, fetch_xI=True, first_chunk=0, device_tables=None,

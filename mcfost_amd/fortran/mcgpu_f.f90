@@ -88,7 +88,7 @@ module mcgpu_f
        mcgpu_run_mono, mcgpu_fetch, mcgpu_fetch_xI, mcgpu_rt1_dust_map, mcgpu_set_xI, mcgpu_rt1_image, mcgpu_set_xI_precision, &
        mcgpu_set_E_prior, mcgpu_multi_create, mcgpu_multi_destroy, mcgpu_multi_size, mcgpu_multi_ctx, mcgpu_multi_run_thermal, mcgpu_multi_run_mono, mcgpu_multi_rccl_ranks, &
        mcgpu_counters_to_accum, mcgpu_counters_from_accum, mcgpu_temp_approx_diffusion_vertical, mcgpu_set_mrw, mcgpu_fetch_radiation_field, &
-       mcgpu_set_variable_dust, mcgpu_rt1_stars_map_sed, mcgpu_define_dark_zone, mcgpu_init_reemission, mcgpu_repartition_energie, mcgpu_opacity, mcgpu_set_variable_dust_s11, mcgpu_set_scattering_method1, mcgpu_set_rt2, mcgpu_fetch_I_spec, mcgpu_rt1_stars_map_image, mcgpu_set_I_spec, mcgpu_rt2_source
+       mcgpu_set_variable_dust, mcgpu_rt1_stars_map_sed, mcgpu_define_dark_zone, mcgpu_init_reemission, mcgpu_repartition_energie, mcgpu_opacity, mcgpu_set_variable_dust_s11, mcgpu_set_scattering_method1, mcgpu_set_rt2, mcgpu_fetch_I_spec, mcgpu_rt1_stars_map_image, mcgpu_set_I_spec, mcgpu_rt2_source, mcgpu_rt2_dust_map, mcgpu_rt2_image
 
   interface
      integer(c_int) function mcgpu_create(device, ctx) bind(C, name="mcgpu_create")
@@ -445,6 +445,27 @@ module mcgpu_f
        real(c_float), intent(out) :: eps_dust2(*), eps_dust2_star(*)
        real(c_double), intent(out) :: kernel_ms
      end function mcgpu_rt2_source
+
+     ! dust_map with lscatt_ray_tracing2 for the inclination of the last mcgpu_rt2_source (dust_transfer.f90:1467-1577)
+     integer(c_int) function mcgpu_rt2_dust_map(ctx, opts, tab_RT_az, Tdust, stokes, kernel_ms) bind(C, name="mcgpu_rt2_dust_map")
+       import :: c_int, c_ptr, c_double, c_float, mcgpu_rt_opts
+       type(c_ptr), value :: ctx
+       type(mcgpu_rt_opts), intent(in) :: opts
+       real(c_float), intent(in) :: tab_RT_az(*), Tdust(*)
+       real(c_double), intent(out) :: stokes(*), kernel_ms
+     end function mcgpu_rt2_dust_map
+
+     integer(c_int) function mcgpu_rt2_image(ctx, opts, tab_RT_az, Tdust, npix_x, npix_y, map_size, zoom, image, n_rays, &
+          kernel_ms) bind(C, name="mcgpu_rt2_image")
+       import :: c_int, c_ptr, c_double, c_float, c_int64_t, mcgpu_rt_opts
+       type(c_ptr), value :: ctx
+       type(mcgpu_rt_opts), intent(in) :: opts
+       real(c_float), intent(in) :: tab_RT_az(*), Tdust(*)
+       integer(c_int), value :: npix_x, npix_y
+       real(c_double), value :: map_size, zoom
+       real(c_double), intent(out) :: image(*), kernel_ms
+       integer(c_int64_t), intent(out) :: n_rays
+     end function mcgpu_rt2_image
 
      integer(c_int) function mcgpu_fetch_I_spec(ctx, I_spec, I_spec_f64, I_spec_star, I_spec_star_f64) &
           bind(C, name="mcgpu_fetch_I_spec")

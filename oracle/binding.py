@@ -393,6 +393,36 @@ class Oracle:
             raise RuntimeError(f"oracle_dust_map_sed failed: {rc}")
         return out
 
+    def rt2_dust_map_sed(self, lam, ibin, eps_dust2, eps_dust2_star, Tdust, n_sent_photons, E_disk, l_sym_ima=True,
+                         tau_dark_zone_obs=100.0, n_threads=1):
+        """Ray-traced SED of the dust of inclination ``ibin`` with method 2's source function (``init_dust_source_fct2``'s
+        ``eps_dust2 [n_cells, 2, nang_rt, N_type_flux]`` / ``eps_dust2_star``): (N_type_flux,)."""
+        m = self.model
+        e2, es = _a(eps_dust2, np.float32), _a(eps_dust2_star, np.float32)
+        zg = _a(np.abs(m.grid["z_grid"]), np.float64)
+        self.lib.oracle_set_rt2_source(_p(e2, C.c_float), _p(es, C.c_float), C.c_int(e2.shape[2]), C.c_int(es.shape[2]),
+                                       C.c_int(int(ibin)), _p(zg, C.c_double))
+        try:
+            out = self.dust_map_sed(lam, np.zeros(1), Tdust, n_sent_photons, E_disk, 0.0, l_sym_ima, tau_dark_zone_obs, n_threads)
+        finally:
+            self.lib.oracle_set_rt2_source(None, None, C.c_int(0), C.c_int(0), C.c_int(0), None)
+        return out[int(ibin) - 1]
+
+    def rt2_dust_map_image(self, lam, ibin, eps_dust2, eps_dust2_star, Tdust, n_sent_photons, E_disk, npix_x, npix_y, map_size,
+                           zoom=1.0, l_sym_ima=False, tau_dark_zone_obs=100.0, n_threads=1):
+        """The image of inclination ``ibin`` with method 2's source function: (N_type_flux, npix_y, npix_x), rays traced."""
+        m = self.model
+        e2, es = _a(eps_dust2, np.float32), _a(eps_dust2_star, np.float32)
+        zg = _a(np.abs(m.grid["z_grid"]), np.float64)
+        self.lib.oracle_set_rt2_source(_p(e2, C.c_float), _p(es, C.c_float), C.c_int(e2.shape[2]), C.c_int(es.shape[2]),
+                                       C.c_int(int(ibin)), _p(zg, C.c_double))
+        try:
+            img, n = self.dust_map_image(lam, np.zeros(1), Tdust, n_sent_photons, E_disk, npix_x, npix_y, map_size, zoom, 0.0,
+                                         l_sym_ima, tau_dark_zone_obs, n_threads)
+        finally:
+            self.lib.oracle_set_rt2_source(None, None, C.c_int(0), C.c_int(0), C.c_int(0), None)
+        return img[:, 0, int(ibin) - 1], n
+
     def stars_map_sed(self, lam, star_flux, seed=1, ang_disque=0.0):
         """compute_stars_map for the SED: the stars' flux towards every observer, (nRT,)."""
         m = self.model

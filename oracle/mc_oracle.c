@@ -2504,6 +2504,102 @@ static double *rt_calc_Jth(const oracle_model *m, int lam, double wl, const floa
   return J_th;
 }
 
+/* ---- ray tracing method 2: dust_source_fct (dust_ray_tracing.f90:1478-1700) on the eps_dust2 / eps_dust2_star of one
+ * inclination (oracle_init_dust_source_fct2).  While a source is set, the dust maps below ray-trace that inclination
+ * (observer q = ibin - 1; method 2 is 2D and knows no observer azimuth) with it instead of method 1's eps_dust1. */
+typedef struct { const float *eps2, *eps2_star; int nang_rt, nang_star, q; const double *z_grid; } rt2_source_t;
+static rt2_source_t g_rt2_store;
+static const rt2_source_t *g_rt2 = NULL;
+void oracle_set_rt2_source(const float *eps_dust2, const float *eps_dust2_star, int nang_rt, int nang_star, int ibin,
+                           const double *z_grid) {
+  if (!eps_dust2) { g_rt2 = NULL; return; }
+  g_rt2_store.eps2 = eps_dust2; g_rt2_store.eps2_star = eps_dust2_star; g_rt2_store.nang_rt = nang_rt;
+  g_rt2_store.nang_star = nang_star; g_rt2_store.q = ibin - 1; g_rt2_store.z_grid = z_grid;
+  g_rt2 = &g_rt2_store;
+}
+
+/* interpolate_Stokes_QU (:1705-1742): between two (P I, 2 theta) pairs, back to (Q, U) */
+static void interpolate_stokes_qu(const float a[2], const float b[2], double frac1, float out[2]) {
+  const float PxI1 = a[0], PxI2 = b[0];
+  float two_theta1 = a[1], two_theta2 = b[1];
+  const float PxI = (float)((double)PxI2 * (1.0 - frac1) + (double)PxI1 * frac1);
+  if ((double)fabsf(two_theta2 - two_theta1) >= PI) {
+    if (two_theta2 > two_theta1) two_theta1 = (float)((double)two_theta1 + 2 * PI);
+    else two_theta2 = (float)((double)two_theta2 + 2 * PI);
+  }
+  const float two_theta = (float)((double)two_theta2 * (1.0 - frac1) + (double)two_theta1 * frac1);
+  out[0] = PxI * cosf(two_theta);
+  out[1] = PxI * (-sinf(two_theta));
+}
+
+/* one corner of dust_source_fct's interpolation: the cell icell_tmp, between the directions iscatt1 / iscatt2 */
+static void rt2_corner(const oracle_model *m, const rt2_source_t *R, int icell_tmp, int dir, double phi_pos, double SF[8]) {
+  const int n_Stokes = m->lsepar_pola ? 4 : 1, ntf = m->N_type_flux;
+  for (int t = 0; t < 8; ++t) SF[t] = 0.0;
+  {
+    const int N = R->nang_rt;
+    const double xiscatt = fmax(phi_pos / (2 * PI) * (double)N, 0.0);
+    int iscatt1 = (int)floor(xiscatt);
+    const double frac = xiscatt - iscatt1, un_m_frac = 1.0 - frac;
+    int iscatt2 = iscatt1 + 1;
+    iscatt1 = ((iscatt1 % N) + N) % N; if (iscatt1 == 0) iscatt1 = N;
+    iscatt2 = ((iscatt2 % N) + N) % N; if (iscatt2 == 0) iscatt2 = N;
+    const float *e1 = R->eps2 + (size_t)ntf * ((size_t)(iscatt1 - 1) + (size_t)N * (dir + 2 * (size_t)(icell_tmp - 1)));
+    const float *e2 = R->eps2 + (size_t)ntf * ((size_t)(iscatt2 - 1) + (size_t)N * (dir + 2 * (size_t)(icell_tmp - 1)));
+    SF[0] = (double)e2[0] * frac + (double)e1[0] * un_m_frac;
+    if (m->lsepar_pola) {
+      float qu[2];
+      interpolate_stokes_qu(e1 + 1, e2 + 1, un_m_frac, qu);
+      SF[1] = (double)qu[0]; SF[2] = (double)qu[1];
+    }
+    if (m->lsepar_contrib)
+      for (int t = n_Stokes; t < ntf; ++t) SF[t] = (double)e2[t] * frac + (double)e1[t] * un_m_frac;
+  }
+  {
+    const int N = R->nang_star;
+    const double xiscatt = fmax(phi_pos / (2 * PI) * (double)N, 0.0);
+    int iscatt1 = (int)floor(xiscatt);
+    const double frac = xiscatt - iscatt1, un_m_frac = 1.0 - frac;
+    int iscatt2 = iscatt1 + 1;
+    iscatt1 = ((iscatt1 % N) + N) % N; if (iscatt1 == 0) iscatt1 = N;
+    iscatt2 = ((iscatt2 % N) + N) % N; if (iscatt2 == 0) iscatt2 = N;
+    const float *e1 = R->eps2_star + (size_t)n_Stokes * ((size_t)(iscatt1 - 1) + (size_t)N * (dir + 2 * (size_t)(icell_tmp - 1)));
+    const float *e2 = R->eps2_star + (size_t)n_Stokes * ((size_t)(iscatt2 - 1) + (size_t)N * (dir + 2 * (size_t)(icell_tmp - 1)));
+    SF[0] = (SF[0] + (double)e2[0] * frac) + (double)e1[0] * un_m_frac;
+    if (m->lsepar_pola) {
+      float qu[2];
+      interpolate_stokes_qu(e1 + 1, e2 + 1, un_m_frac, qu);
+      SF[1] = SF[1] + (double)qu[0]; SF[2] = SF[2] + (double)qu[1];
+    }
+    if (m->lsepar_contrib) SF[n_Stokes + 1] = (SF[n_Stokes + 1] + (double)e2[0] * frac) + (double)e1[0] * un_m_frac;
+  }
+}
+
+/* dust_source_fct, method 2 (:1478-1700): linear in z between the cell and its vertical neighbour on the side of the
+ * point (the radial interpolation is switched off in the reference: ri1 = ri, frac_r = 1), linear in the azimuth between
+ * the tabulated directions */
+static void dust_source_fct2(const oracle_model *m, const rt2_source_t *R, int icell, double x, double y, double z, double SF[8]) {
+  const int n_rad = m->n_rad, nz = m->nz, ntf = m->N_type_flux;
+  const int ri = m->cell_map_i[icell - 1], zj = m->cell_map_j[icell - 1];
+  int zj1, zj2;
+  double frac_z;
+  if (fabs(z) > R->z_grid[icell - 1]) { zj1 = zj; zj2 = zj + 1; } else { zj1 = zj - 1; zj2 = zj; }
+  if (zj2 > nz) { zj2 = nz; frac_z = 1.0; }
+  else if (zj1 < 1) { zj1 = 1; frac_z = 1.0; }
+  else {
+    const double za = R->z_grid[(ri - 1) + n_rad * (zj2 - 1)], zb = R->z_grid[(ri - 1) + n_rad * (zj1 - 1)];
+    frac_z = (za - fabs(z)) / (za - zb);
+  }
+  frac_z = fmax(fmin(1.0, frac_z), 0.0);
+  const double phi_pos = modulo_d(atan2(x, y) + 2 * PI, 2 * PI);
+  const int dir = z > 0.0 ? 1 : 0;
+  double SF1[8], SF3[8];
+  rt2_corner(m, R, (ri - 1) + n_rad * (zj1 - 1) + 1, dir, phi_pos, SF1);
+  rt2_corner(m, R, (ri - 1) + n_rad * (zj2 - 1) + 1, dir, phi_pos, SF3);
+  const double frac_r = 1.0;
+  for (int t = 0; t < ntf; ++t) SF[t] = frac_r * frac_z * SF1[t] + frac_r * (1.0 - frac_z) * SF3[t];
+}
+
 /* integ_ray_dust (optical_depth.f90:1327-1421) from (x0,y0,z0) on the grid edge in cell icell, direction
  * (u0,v0,w0), with dust_source_fct of RT method 1 (dust_ray_tracing.f90:1455-1475) = eps_dust1(k,psup,:,icell)
  * / kappa_ext, eps_dust1 built here from xI_scatt like init_dust_source_fct1 (:676-703) for observer q. */
@@ -2535,7 +2631,12 @@ static void rt1_integ_ray_dust(const oracle_model *m, int lam, double tau_dark_z
         k = (int)floor(modulo_d(phi_pos, 2 * PI) / (2 * PI) * (double)m->n_az_rt) + 1;
         if (k > m->n_az_rt) k = m->n_az_rt;
       }
-      if (kappa_ext > DBL_MIN) {
+      if (g_rt2) { /* method 2: the interpolated source function at the middle of the path (optical_depth.f90:1396-1404) */
+        double SF[8];
+        dust_source_fct2(m, g_rt2, ic, xm, ym, zm, SF);
+        const double wgt = exp(-tau) * (1.0 - exp(-dtau));
+        for (int t = 0; t < ntf; ++t) S[t] += wgt * SF[t];
+      } else if (kappa_ext > DBL_MIN) {
         const double factor = photon_energy / m->volume[ic - 1] * m->n_az_rt * m->n_theta_rt;
         const double kappa_sca = kappa_ext * (double)tab_albedo(m, ic, lam);
         const double *px = xI + (size_t)(k - 1) + (size_t)m->n_az_rt * (psup - 1) + st_rt * ((size_t)q + (size_t)nRT * (ic - 1));
@@ -3023,6 +3124,7 @@ int oracle_dust_map_sed(const oracle_model *m, const oracle_rt_opts *o, const do
   for (int ibin = 1; ibin <= m->RT_n_incl; ++ibin)
     for (int iaz = 1; iaz <= m->RT_n_az; ++iaz) {
       const int q = (ibin - 1) + m->RT_n_incl * (iaz - 1);
+      if (g_rt2 && q != g_rt2->q) continue; /* method 2: the inclination its source function was built for */
       double uvw[3], xpi[3], ypi[3], center[3];
       rt_image_plane(m, o, ibin, iaz, uvw, xpi, ypi, center);
       const double u0 = -uvw[0], v0 = -uvw[1], w0 = -uvw[2]; /* reverse propagation */
@@ -3081,6 +3183,7 @@ int oracle_dust_map_image(const oracle_model *m, const oracle_rt_opts *o, int np
   for (int ibin = 1; ibin <= m->RT_n_incl; ++ibin)
     for (int iaz = 1; iaz <= m->RT_n_az; ++iaz) {
       const int q = (ibin - 1) + m->RT_n_incl * (iaz - 1);
+      if (g_rt2 && q != g_rt2->q) continue; /* method 2: the inclination its source function was built for */
       double uvw[3], xpi[3], ypi[3], center[3], dx[3], dy[3], Icorner[3];
       rt_image_plane(m, o, ibin, iaz, uvw, xpi, ypi, center);
       const double u0 = -uvw[0], v0 = -uvw[1], w0 = -uvw[2];

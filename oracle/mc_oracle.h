@@ -325,6 +325,14 @@ int oracle_init_dust_source_fct2(const oracle_model *m, const oracle_rt_opts *o,
                                  const float *Tdust, const double *r_grid, const double *z_grid, float *eps_dust2,
                                  float *eps_dust2_star);
 
+/* Ray tracing method 2, the ray integration: while a source function is set (eps_dust2 / eps_dust2_star of inclination
+ * ibin from oracle_init_dust_source_fct2, z_grid(n_cells)), oracle_dust_map_sed and oracle_dust_map_image integrate that
+ * inclination (iaz = 1) with dust_source_fct's method-2 branch (dust_ray_tracing.f90:1478-1700: linear in z between the
+ * cell and its vertical neighbour, linear in azimuth between the tabulated directions, interpolate_Stokes_QU :1705) instead
+ * of method 1's eps_dust1 -- xI may then be NULL; the other observers' outputs stay 0.  eps_dust2 = NULL: off. */
+void oracle_set_rt2_source(const float *eps_dust2, const float *eps_dust2_star, int nang_rt, int nang_star, int ibin,
+                           const double *z_grid);
+
 /* compute_stars_map for images (dust_transfer.f90:1604-1854, lresolved = .true.; find_pixel :1858-1893; interp
  * utils.f90:130-175): the stars' discs, limb-darkened (n_mu > 0) and polarised (pola_ld) if asked, in the pixel maps of
  * the observers; see the definition.  PARITY UNPINNED like oracle_stars_map_sed. */

@@ -126,3 +126,43 @@ def test_source_function_from_the_packet_loop_without_leaving_the_device():
     print("init_dust_source_fct2 at 7000 cells (15 x 15 bins, 15 + 1000 directions): %.2f ms (first call %.2f ms)" % (e.last_rt2_ms, ms))
     assert e.last_rt2_ms < 200.0
     e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(), dict(lsepar_pola=False, lsepar_contrib=False)])
+def test_method2_ray_tracing_equals_the_restatement(kw):
+    """Ray tracing method 2 end to end on the device: packet loop with I_spec deposits -> source function -> dust_map's SED
+    sampling and an image with the interpolating dust_source_fct, against the oracle's restatement on the same source
+    function; and against method 1 of the same Monte Carlo (two estimators of the same scattered light)."""
+    from mcfost_amd.engine import Engine
+    m = sed_model(M.small(RT_n_incl=3, **kw), n_thermal=50000)
+    o = Oracle(m, 1000)
+    e = Engine(m, 1e5)
+    T = m.extra["Tdust"]
+    for lam in (4, 12):
+        Ed = m.extra["E_disk"][lam - 1]
+        a = e.run_mono(lam, 400, seed=6, n_chunks=32, rt2=(15, 15))
+        ns = a["n_sent"][lam - 1]
+        for ibin in (1, 3):
+            eps, eps_s = e.init_dust_source_fct2(lam, ibin, None, None, T, ns, Ed)
+            got, ms = e.rt2_dust_map_sed(lam, T, ns, Ed)
+            want = o.rt2_dust_map_sed(lam, ibin, eps, eps_s, T, ns, Ed, n_threads=8)
+            # (I and its contributions to 1e-6; Q, U are sums with cancellation of default-real cosf / sinf products)
+            assert (want[0] > 0) and np.allclose(got, want, rtol=1e-6, atol=1e-6 * abs(want[0]))
+            assert np.allclose(got[[0] + list(range(4 if len(got) > 4 else 1, len(got)))], want[[0] + list(range(4 if len(got) > 4 else 1, len(got)))], rtol=1e-6, atol=1e-12 * abs(want[0]))
+            img, n_rays, _ = e.rt2_dust_map_image(lam, T, ns, Ed, 21, 21, 2.2 * m.cfg.rout)
+            wimg, wn = o.rt2_dust_map_image(lam, ibin, eps, eps_s, T, ns, Ed, 21, 21, 2.2 * m.cfg.rout, n_threads=8)
+            assert n_rays == wn
+            # (default-real source function with cosf / sinf in interpolate_Stokes_QU: last-place differences per pixel)
+            assert np.allclose(img, wimg, rtol=2e-5, atol=1e-6 * np.abs(wimg).max()), np.abs(img - wimg).max() / np.abs(wimg).max()
+        # method 1 on the same model: the two ray tracers see the same disc (Monte Carlo noise and the coarse 15 x 15
+        # direction bins of method 2 between them)
+        b = e.run_mono(lam, 400, seed=7, n_chunks=32)
+        rt1, _ = e.dust_map_sed(lam, T, b["n_sent"][lam - 1], Ed)
+        eps, eps_s = None, None
+        e.run_mono(lam, 400, seed=6, n_chunks=32, rt2=(15, 15))
+        for ibin in (1, 3):
+            e.init_dust_source_fct2(lam, ibin, None, None, T, ns, Ed)
+            rt2, _ = e.rt2_dust_map_sed(lam, T, ns, Ed)
+            assert abs(rt2[0] / rt1[ibin - 1, 0] - 1.0) < 0.25, (lam, ibin, rt2[0], rt1[ibin - 1, 0])
+    e.close()
