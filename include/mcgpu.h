@@ -670,7 +670,8 @@ int mcgpu_fetch_radiation_field(mcgpu_ctx *ctx, double *xN_abs, double *xJ_abs);
  * Modified random walk (module MRW, MRW.f90; the call site dust_transfer.f90:1222-1239 is commented out in the
  * reference and make_MRW_step, MRW.f90:74-115, is an unfinished stub: this is the working form of what they
  * describe -- Min et al. 2009, Robitaille 2010 -- see DESIGN.md; PARITY UNPINNED, validated against the brute-force
- * loop).  Cylindrical grids, 2D and 3D, thermal step (3D: the azimuthal walls enter the distance, cylindrical_grid.f90:
+ * loop).  Cylindrical and spherical grids (distance_to_closest_wall_sph, spherical_grid.f90:451-499, with the cones of
+ * the polar walls in their working form), 2D and 3D, thermal step (3D: the azimuthal walls enter the distance, cylindrical_grid.f90:
  * 1198-1218 with sin / cos_phi_lim built as :586-599 -- wall 0 taken as wall n_az where the reference indexes out of
  * bounds, and the true (cos, sin) = (0, 1) where it stores the sentinel (0, 1e300) that would put a wall at phi = pi/2
  * infinitely far; the single-role kernels run it).  After more than n_interactions (reference: 5) interactions in a row

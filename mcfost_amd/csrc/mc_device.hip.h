@@ -1421,6 +1421,24 @@ __device__ __forceinline__ void interact(const Lds& T, const DevModel& M, const 
 // distance_to_closest_wall_cyl (cylindrical_grid.f90:1179-1226), 2D
 __device__ inline double distance_to_closest_wall_cyl(const Lds& T, const DevModel& M, int ri, int zj, double x,
                                                       double y, double z, int kaz = 1) {
+  if (M.grid_sph) {
+    // distance_to_closest_wall_sph (spherical_grid.f90:451-499): the shells and the cones of the polar walls --
+    // |rcyl sin(a) - z0 cos(a)| with tan a = tan_theta_lim; the reference's sketch multiplies z0 with cos_phi_lim, the
+    // azimuthal walls' table, where this cosine is meant -- and the azimuthal walls of a 3D grid
+    const double r2c = x * x + y * y, rcyl = sqrt(r2c), rr = sqrt(r2c + z * z), z0 = fabs(z);
+    const int tj = zj < 0 ? -zj : zj;
+    double s = fmin(M.r_lim[ri] - rr, rr - M.r_lim[ri - 1]);
+    for (int j = tj - 1; j <= tj; ++j) {
+      const double t = M.tan_theta_lim[j];
+      const double c = 1.0 / sqrt(1.0 + t * t), sn = t * c;
+      s = fmin(s, fabs(rcyl * sn - z0 * c));
+    }
+    if (M.l3D && M.n_az > 1) {
+      const int km = kaz > 1 ? kaz - 1 : M.n_az;
+      s = fmin(s, fmin(fabs(x * M.sin_phi[kaz - 1] - y * M.cos_phi[kaz - 1]), fabs(x * M.sin_phi[km - 1] - y * M.cos_phi[km - 1])));
+    }
+    return s;
+  }
   const double r = sqrt(x * x + y * y);
   const double s1 = M.r_lim[ri] - r, s2 = r - M.r_lim[ri - 1];
   const double z0 = fabs(z);
@@ -1941,10 +1959,10 @@ __global__ void __launch_bounds__(LDSE ? MCGPU_LDS_BLOCK : 256) k_thermal_var(co
 }
 
 // the spherical grid (spherical_grid.f90): the same packet loop with that grid's operators; no dark zone
-template <bool L3D, bool POLA, bool LDSE>
+template <bool L3D, bool POLA, bool LDSE, bool MRW = false>
 __global__ void __launch_bounds__(LDSE ? MCGPU_LDS_BLOCK : 256) k_thermal_sph(const DevModel M, const RunArgs A) {
   extern __shared__ double lds_raw[];
-  thermal_body<L3D, POLA, false, LDSE, true>(M, A, lds_raw);
+  thermal_body<L3D, POLA, false, LDSE, true, MRW>(M, A, lds_raw);
 }
 
 // LDS-deposit variant: one MCGPU_LDS_BLOCK-thread workgroup per CU shares one private grid.

@@ -1009,7 +1009,7 @@ extern "C" int mcgpu_set_mrw(mcgpu_ctx* ctx, int n_zeta, const double* zeta, con
   if (n_zeta < 2 || !zeta || !chi || !kappa_dep || !ext || !r_lim || !(gamma > 0.0) || n_interactions < 0 || n_interactions > 6)
     return fail(ctx, MCGPU_ERR_ARG, "mcgpu_set_mrw: bad argument (n_interactions is 0..6)");
   if (!ctx->have_grid || !ctx->have_thermal) return fail(ctx, MCGPU_ERR_STATE, "set the grid and the thermal tables first");
-  if (ctx->voro || M.grid_sph) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "modified random walk: cylindrical grids only");
+  if (ctx->voro) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "modified random walk: cylindrical and spherical grids");
   for (int i = 1; i < n_zeta; ++i)
     if (!(zeta[i] >= zeta[i - 1])) return fail(ctx, MCGPU_ERR_ARG, "mcgpu_set_mrw: zeta must not decrease");
   HIPCHK(hipSetDevice(ctx->device));
@@ -1023,7 +1023,7 @@ extern "C" int mcgpu_set_mrw(mcgpu_ctx* ctx, int n_zeta, const double* zeta, con
   if ((rc = upload(ctx, ext, n_tab, &M.mrw_ext))) return rc;
   if ((rc = upload(ctx, r_lim, (size_t)M.n_rad + 1, &M.r_lim))) return rc;
   if (M.l3D) {
-    // sin_phi_lim, cos_phi_lim of the azimuthal walls (cylindrical_grid.f90:586-599, default-real phi) for
+    // sin_phi_lim, cos_phi_lim of the azimuthal walls (cylindrical_grid.f90:586-599, default-real phi; both grid types) for
     // distance_to_closest_wall_cyl's 3D branch (:1198-1218).  Where the reference stores the sentinel pair
     // (cos, sin) = (0, 1e300) for a wall at phi = pi/2 (mod pi) -- which makes that wall infinitely far for the walk -- the
     // true pair (0, 1) is used: |x sin - y cos| = |x| is the distance to that wall.
@@ -1230,10 +1230,11 @@ static int launch_mega(mcgpu_ctx* ctx, const RunArgs& A, bool use_lds, int grid_
   if (M.grid_sph) {  // the spherical grid runs the single-role kernel with its own grid operators
     const size_t lds_k2 = lds_k;
     const void* fn;
-    if (l3d) fn = pola ? (use_lds ? (const void*)k_thermal_sph<true, true, true> : (const void*)k_thermal_sph<true, true, false>)
-                       : (use_lds ? (const void*)k_thermal_sph<true, false, true> : (const void*)k_thermal_sph<true, false, false>);
-    else fn = pola ? (use_lds ? (const void*)k_thermal_sph<false, true, true> : (const void*)k_thermal_sph<false, true, false>)
-                   : (use_lds ? (const void*)k_thermal_sph<false, false, true> : (const void*)k_thermal_sph<false, false, false>);
+#define PICKS(a, w) fn = pola ? (use_lds ? (const void*)k_thermal_sph<a, true, true, w> : (const void*)k_thermal_sph<a, true, false, w>) \
+                              : (use_lds ? (const void*)k_thermal_sph<a, false, true, w> : (const void*)k_thermal_sph<a, false, false, w>)
+    if (M.mrw) { if (l3d) PICKS(true, true); else PICKS(false, true); }
+    else { if (l3d) PICKS(true, false); else PICKS(false, false); }
+#undef PICKS
     HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k2));
     void* args[] = {(void*)&M, (void*)&A};
     HIPCHK(hipLaunchKernel(fn, dim3(blocks), dim3(threads), args, lds_k2, ctx->stream));

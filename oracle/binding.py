@@ -252,7 +252,7 @@ class Oracle:
                     setattr(s, f, self._hold(_a(vd[k], np.float32), C.c_float))
             if vd.get("tab_s11_pos") is not None:
                 s.v_tab_s11_pos = self._hold(_a(vd["tab_s11_pos"], np.float32), C.c_float)
-        if g.get("l3D") and g.get("grid_type", 1) == 1 and "tan_phi_lim" in g:   # the walk's azimuthal walls
+        if g.get("l3D") and g.get("grid_type", 1) in (1, 2) and "tan_phi_lim" in g:   # the walk's azimuthal walls
             from mcfost_amd.host.model import phi_wall_sin_cos
             sp, cp = g.get("sin_phi_lim"), g.get("cos_phi_lim")
             if sp is None:

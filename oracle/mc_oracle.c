@@ -1792,7 +1792,36 @@ static int emit_packet(worker_t *W, int lambda, int *icell, double *x,
 /* but its step is an unfinished stub behind a commented-out call.  What follows is the algorithm those pieces and    */
 /* their TODO comments describe, made to work: PARITY UNPINNED, checked against the brute-force loop.                 */
 /* ------------------------------------------------------------------------ */
+/* distance_to_closest_wall_sph (spherical_grid.f90:451-499): the shells and -- the working form of what the reference
+ * sketches: it multiplies z0 with cos_phi_lim(thetaj0), the table of the AZIMUTHAL walls, where the cosine of the polar
+ * wall is meant -- the cones |rcyl sin(a) - z0 cos(a)|, a the elevation of the wall (tan_theta_lim = tan a, 1e30 at the
+ * pole); the azimuthal walls of a 3D grid like in the cylindrical routine. */
+static double distance_to_closest_wall_sph(const oracle_model *m, int icell, double x, double y, double z) {
+  const int ri0 = m->cell_map_i[icell - 1];
+  int tj0 = m->cell_map_j[icell - 1];
+  if (tj0 < 0) tj0 = -tj0;
+  const double r2_cyl = x * x + y * y, rcyl = sqrt(r2_cyl), r = sqrt(r2_cyl + z * z), z0 = fabs(z);
+  double s = m->r_lim[ri0] - r;
+  const double s2 = r - m->r_lim[ri0 - 1];
+  if (s2 < s) s = s2;
+  for (int j = tj0 - 1; j <= tj0; ++j) {
+    const double t = m->tan_theta_lim[j];
+    const double c = 1.0 / sqrt(1.0 + t * t), sn = t * c;
+    const double d = fabs(rcyl * sn - z0 * c);
+    if (d < s) s = d;
+  }
+  if (m->l3D && m->n_az > 1 && m->sin_phi_lim) {
+    const int k0 = m->cell_map_k[icell - 1], km = k0 > 1 ? k0 - 1 : m->n_az;
+    const double s5 = fabs(x * m->sin_phi_lim[k0 - 1] - y * m->cos_phi_lim[k0 - 1]);
+    const double s6 = fabs(x * m->sin_phi_lim[km - 1] - y * m->cos_phi_lim[km - 1]);
+    if (s5 < s) s = s5;
+    if (s6 < s) s = s6;
+  }
+  return s;
+}
+
 double oracle_distance_to_closest_wall_cyl(const oracle_model *m, int icell, double x, double y, double z) {
+  if (m->grid_type == 2) return distance_to_closest_wall_sph(m, icell, x, y, z);
   const int ri0 = m->cell_map_i[icell - 1];
   int zj0 = m->cell_map_j[icell - 1];
   const double r = sqrt(x * x + y * y);

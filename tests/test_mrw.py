@@ -454,3 +454,75 @@ def test_device_walk_on_variable_dust():
     for k in keys:
         assert abs(g[k] - w[k]) <= 4.0 * np.sqrt(2.0) * sigma[k], (k, g[k], w[k], sigma[k])
     assert np.array_equal(got["n_sent"], want["n_sent"])
+
+
+def thick_sphere(mrw=True, l3D=False, **kw):
+    cfg = M.small(n_rad=16, nz=10, n_az=6 if l3D else 1, l3D=l3D, grid_type=2, dust_mass=1e-2)
+    m = M.build_model(cfg)
+    if mrw:
+        M.init_mrw(m, **kw)
+    return m
+
+
+def test_walk_on_a_spherical_grid():
+    """distance_to_closest_wall on the spherical grid (shells, the cones of the polar walls, the azimuthal planes in 3D):
+    known answers at points whose closest wall is obvious, and the walk's bookkeeping like on the other grids."""
+    m = thick_sphere(mrw=False)
+    o = Oracle(m, 1000)
+    g = m.grid
+    r_lim, tt = np.asarray(g["r_lim"]), np.asarray(g["tan_theta_lim"])
+    ri, tj = 8, 4
+    icell = int(np.asarray(g["cell_map"]).reshape(-1)[0]) if False else None
+    cm_i, cm_j = np.asarray(g["cell_map_i"]), np.asarray(g["cell_map_j"])
+    icell = int(np.nonzero((cm_i[:m.n_cells] == ri) & (cm_j[:m.n_cells] == tj))[0][0]) + 1
+    a_lo, a_hi = np.arctan(tt[tj - 1]), np.arctan(tt[tj])
+    rm, am = 0.5 * (r_lim[ri - 1] + r_lim[ri]), 0.5 * (a_lo + a_hi)
+    # (a) just inside the outer shell, mid-elevation: the shell is the closest wall
+    r = r_lim[ri] - 1e-3 * (r_lim[ri] - r_lim[ri - 1])
+    d = o.distance_to_closest_wall([icell], [r * np.cos(am)], [0.0], [r * np.sin(am)])[0]
+    assert np.isclose(d, r_lim[ri] - r, rtol=1e-9)
+    # (b) mid-radius, just above the lower cone: the distance to that cone is r sin(delta)
+    a = a_lo + 1e-3 * (a_hi - a_lo)
+    d = o.distance_to_closest_wall([icell], [rm * np.cos(a)], [0.0], [rm * np.sin(a)])[0]
+    assert np.isclose(d, rm * np.sin(a - a_lo), rtol=1e-6)
+    # (c) the mirror image below the equator gives the same
+    d2 = o.distance_to_closest_wall([icell], [rm * np.cos(a)], [0.0], [-rm * np.sin(a)])[0]
+    assert d2 == d
+    n = 20000
+    a = Oracle(thick_sphere(), n).run_thermal(n, seed=3, n_threads=8)
+    b = Oracle(thick_sphere(mrw=False), n).run_thermal(n, seed=3, n_threads=8)
+    ca, cb = a["counters"], b["counters"]
+    assert ca["mrw_walks"] > 300 and ca["escaped"] + ca["killed_star"] == n
+    assert ca["absorptions"] + ca["scatterings"] < 0.6 * (cb["absorptions"] + cb["scatterings"])
+    assert abs(a["E_abs"].sum() / b["E_abs"].sum() - 1.0) < 0.06
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("l3D", [False, True])
+def test_device_walk_on_spherical_grids(l3D):
+    """k_thermal_sph<..., MRW>: without the walk packet for packet, with it the noise-aware gates against the oracle."""
+    from mcfost_amd.engine import Engine
+    n = 20000
+    m0 = thick_sphere(mrw=False, l3D=l3D)
+    prior = Oracle(m0, n).run_thermal(n, seed=1, n_threads=1)["E_abs"]
+    from test_kernel_emulation import _check_spherical
+    e = Engine(m0, n)
+    got0 = e.run_thermal(n, seed=9, frozen=True, E_prior=prior)
+    e.close()
+    _check_spherical(got0, Oracle(m0, n), m0, n, 9, prior)     # (the spherical grid's own parity: see there)
+    m = thick_sphere(l3D=l3D)
+    orc = Oracle(m, n)
+    want = orc.run_thermal(n, seed=9, frozen=True, E_prior=prior, n_threads=8)
+    keys = ("mrw_walks", "mrw_steps", "absorptions", "scatterings", "crossings", "flights")
+    others = [orc.run_thermal(n, seed=s, frozen=True, E_prior=prior, n_threads=8) for s in (21, 22, 23, 24, 25, 26)]
+    sigma = {k: np.std([r["counters"][k] for r in others], ddof=1) for k in keys}
+    e = Engine(m, n)
+    got = e.run_thermal(n, seed=9, frozen=True, E_prior=prior)
+    e.close()
+    g, w = got["counters"], want["counters"]
+    assert g["mrw_walks"] > 200
+    for k in ("packets", "escaped", "killed_star"):
+        assert g[k] == w[k]
+    for k in keys:
+        assert abs(g[k] - w[k]) <= 4.0 * np.sqrt(2.0) * sigma[k], (k, g[k], w[k], sigma[k])
+    assert np.array_equal(got["n_sent"], want["n_sent"])
