@@ -684,7 +684,10 @@ int mcgpu_fetch_radiation_field(mcgpu_ctx *ctx, double *xN_abs, double *xJ_abs);
  *                    what compute_Planck_opacities (diffusion.f90:631) calls rec_Planck_opacity
  *   kappa_dep[n_T]   mean of kappa_abs_LTE with which the walk's path deposits ("Planck_opacity")
  *   ext[n_T]         length added to d in the path (zeros: the formula of MRW.f90:99 as written)
- *   r_lim[n_rad+1]   cylindrical_grid's r_lim(0:n_rad)
+ *   r_lim[n_rad+1]   cylindrical_grid's r_lim(0:n_rad); NULL on a Voronoi grid
+ * Voronoi grids (distance_to_closest_wall_Voronoi, Voronoi.f90:996-1061): the perpendicular distance to the closest face
+ * of the cell -- the reference's routine divides by the neighbour separation once too often --, 0 in cut cells and in
+ * cells that touch the box, where no walk is made; the kernel is k_thermal_voro_mrw.
  * With lvariable_dust (set before this call) chi, kappa_dep and ext hold one row of n_T values per class, class after
  * class; the walk of a cell reads its class's row (single-role kernels).
  * n_zeta = 0 switches the walk off.  Counters 8 and 9 count walks and sphere steps.

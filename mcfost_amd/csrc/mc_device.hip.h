@@ -1472,16 +1472,17 @@ __device__ inline double mrw_sample_y(const DevModel& M, float xi) {
 // One walk of a packet the cell (ri, zj; index ic) has just re-emitted.  cell_energy() as in interact();
 // add_energy(v) deposits v into the cell.  Returns false (nothing drawn, nothing changed) when the sphere is
 // not optically thick enough.
-template <typename EnergyFn, typename DepositFn>
-__device__ inline bool mrw_walk(const Lds& T, const DevModel& M, uint32_t k0, uint32_t k1, uint32_t p_lo, uint32_t p_hi,
-                                uint32_t event, int ri, int zj, int ic, double S0, double& x, double& y, double& z,
-                                double& u, double& v, double& w, int& lambda, EnergyFn cell_energy,
-                                DepositFn add_energy, unsigned int& c_walks, unsigned int& c_steps, int kaz = 1) {
-  double d = distance_to_closest_wall_cyl(T, M, ri, zj, x, y, z, kaz);
+// (mrw_walk_with: the walk with the cell's closest-wall distance and kappa_factor supplied by the caller -- the grids differ
+// only there; mrw_walk: the structured grids)
+template <typename DistFn, typename EnergyFn, typename DepositFn>
+__device__ inline bool mrw_walk_with(const Lds& T, const DevModel& M, uint32_t k0, uint32_t k1, uint32_t p_lo, uint32_t p_hi,
+                                     uint32_t event, int ic, double kf, double S0, double& x, double& y, double& z,
+                                     double& u, double& v, double& w, int& lambda, DistFn closest_wall, EnergyFn cell_energy,
+                                     DepositFn add_energy, unsigned int& c_walks, unsigned int& c_steps) {
+  double d = closest_wall(x, y, z);
   int Ti;
   double frac;
   temp_lte(T.lq, M.n_T, cell_energy(), M.L_packet_th, M.volume[ic], Ti, frac);
-  const double kf = M.kappa_factor[ic];
   // (lvariable_dust: the mean opacities of the cell's class, [n_classes][n_T]; T then holds the class's lq / cdf)
   const size_t co = M.n_classes ? (size_t)M.cell_class[ic] * M.n_T : 0;
   const double *t_chi = M.mrw_chi + co, *t_kdep = M.mrw_kdep + co, *t_ext = M.mrw_ext + co;
@@ -1503,7 +1504,7 @@ __device__ inline bool mrw_walk(const Lds& T, const DevModel& M, uint32_t k0, ui
     const double ct = -log(yv) * cst_ct * chi * (de * de);
     add_energy(kdep * ct * S0);
     c_steps++;
-    d = distance_to_closest_wall_cyl(T, M, ri, zj, x, y, z, kaz);
+    d = closest_wall(x, y, z);
   } while (d * chi > (double)M.mrw_gamma);
   philox4x32_10(blk, event, p_lo, p_hi, k0, k1, o);
   // the cell's temperature now, the walk's deposits included (im_reemission_LTE)
@@ -1512,6 +1513,16 @@ __device__ inline bool mrw_walk(const Lds& T, const DevModel& M, uint32_t k0, ui
   cdapres(sqrt((double)Rng::real(o[1])), PI * (2.0 * (double)Rng::real(o[2]) - 1.0), su, sv, sw, u, v, w);
   c_walks++;
   return true;
+}
+
+template <typename EnergyFn, typename DepositFn>
+__device__ inline bool mrw_walk(const Lds& T, const DevModel& M, uint32_t k0, uint32_t k1, uint32_t p_lo, uint32_t p_hi,
+                                uint32_t event, int ri, int zj, int ic, double S0, double& x, double& y, double& z,
+                                double& u, double& v, double& w, int& lambda, EnergyFn cell_energy,
+                                DepositFn add_energy, unsigned int& c_walks, unsigned int& c_steps, int kaz = 1) {
+  return mrw_walk_with(T, M, k0, k1, p_lo, p_hi, event, ic, M.kappa_factor[ic], S0, x, y, z, u, v, w, lambda,
+                       [&](double px, double py, double pz) { return distance_to_closest_wall_cyl(T, M, ri, zj, px, py, pz, kaz); },
+                       cell_energy, add_energy, c_walks, c_steps);
 }
 
 // ---------------------------------------------------------------------------

@@ -307,13 +307,34 @@ struct VoroEmitOps {
   }
 };
 
+// distance_to_closest_wall_Voronoi (Voronoi.f90:996-1061) in its working form: the perpendicular distance from the
+// point to the closest face, n . (p - r) / |n| with n the vector to the neighbour's site and p the midpoint -- the
+// reference divides by n . n, which is that distance in units of the neighbour separation.  As there: 0 (no walk) in a
+// cut cell and in a cell that touches the box.
+__device__ inline double voro_distance_to_closest_wall(const VoroGrid& G, const VoroCell& C, double x, double y, double z) {
+  if (C.flags & 1) return 0.0;
+  const VoroNb* nb = G.nb + C.first;
+  double s = 1.0e30;
+  for (int i = 0; i < C.count; ++i) {
+    const VoroNb N = nb[i];
+    if (N.id <= 0) return 0.0;
+    const double n0 = (double)N.x - (double)C.x, n1 = (double)N.y - (double)C.y, n2 = (double)N.z - (double)C.z;
+    const double p0 = 0.5 * ((double)N.x + (double)C.x), p1 = 0.5 * ((double)N.y + (double)C.y), p2 = 0.5 * ((double)N.z + (double)C.z);
+    double d = (n0 * (p0 - x) + n1 * (p1 - y) + n2 * (p2 - z)) / sqrt(n0 * n0 + n1 * n1 + n2 * n2);
+    if (d < 0.0) d = 0.0;  // (a point that rounding has put beyond a face: no walk)
+    s = fmin(s, d);
+  }
+  return s;
+}
+
 constexpr int VORO_CACHE_BLOCK = 1024;  // most threads of a cached-deposit workgroup (one per CU)
 
 // ---------------------------------------------------------------------------
 // The thermal packet kernel on a Voronoi grid.  CACHE: deposits go through the workgroup's LDS
 // deposit cache; otherwise straight to HBM (global_atomic_add_f64).
 // ---------------------------------------------------------------------------
-template <bool POLA, bool CACHE>
+// MRW: the modified random walk (mc_device.hip.h) with the Voronoi cell's closest face.
+template <bool POLA, bool CACHE, bool MRW = false>
 __device__ __forceinline__ void thermal_body_voro(const DevModel& M, const RunArgs& A, const VoroGrid& G,
                                                   double* lds_base, int cache_log_ns) {
   const Lds T = lds_carve(lds_base, M);
@@ -339,6 +360,9 @@ __device__ __forceinline__ void thermal_body_voro(const DevModel& M, const RunAr
   unsigned int pk_cross = 0;
   unsigned long long pk_next = 0, pk_end = 0;
   float tau_rand = 0.0f;
+  int n_inter = 0;            // MRW: interactions in a row whose flights never left the cell (0..7)
+  bool first_cross = true;    // MRW: the flight is still in the cell it started in
+  unsigned int c_walks = 0, c_steps = 0;
 
   for (int ep = 0;; ++ep) {
     if (st == S_EXITED) {
@@ -410,6 +434,20 @@ __device__ __forceinline__ void thermal_body_voro(const DevModel& M, const RunAr
       }, M.volume + ic);
       if (!flag_scatt) flag_ism = false;
       u = u1; v = v1; w = w1;
+      if (MRW) {  // dust_transfer.f90:1222-1239: a packet its cell has just re-emitted for the (n_inter + 1)-th time in a row
+        if (__builtin_expect(!flag_scatt && !flag_star && n_inter > M.mrw_n_inter, 0)) {
+          const VoroCell C = G.cell[ic];
+          mrw_walk_with(T, M, rng.k0, rng.k1, rng.p_lo, rng.p_hi, rng.event, ic, C.kf, S[0], x, y, z, u, v, w, lambda,
+                        [&](double px, double py, double pz) { return voro_distance_to_closest_wall(G, C, px, py, pz); },
+                        [&]() {
+                          if (A.frozen) return A.E_prior[ic];
+                          double E = __hip_atomic_load(&A.E_abs[ic], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                          if (CACHE) E += DC.pending(ic + 1) * (double)gridDim.x;
+                          return E * A.qscale;
+                        },
+                        [&](double e) { if (!(CACHE && DC.add(ic + 1, e))) atomic_add_f64(&A.E_abs[ic], e); }, c_walks, c_steps);
+        }
+      }
       st = S_NEWFLIGHT;
     }
 
@@ -420,6 +458,7 @@ __device__ __forceinline__ void thermal_body_voro(const DevModel& M, const RunAr
       star_icell = (i_star > 0) ? M.star_cell[4 * (i_star - 1)] : 0;
       c_flight++;
       prev_cell = 0;
+      first_cross = true;
       st = S_FLIGHT;
     }
 
@@ -458,7 +497,9 @@ __device__ __forceinline__ void thermal_body_voro(const DevModel& M, const RunAr
             y = nd_add(y, nd_mul(ls, v));
             z = nd_add(z, nd_mul(ls, w));
             st = S_INTERACT;
+            if (MRW) n_inter = first_cross ? (n_inter < 7 ? n_inter + 1 : 7) : 0;  // dust_transfer.f90:1244-1249
           } else {
+            first_cross = false;
             extr = extr - tau;
             const double dE = T.kabs[lambda - 1] * l_contrib * S[0];
             if (dE != 0.0 && !MCGPU_DIAG(A.flags, 1)) {
@@ -509,12 +550,25 @@ __device__ __forceinline__ void thermal_body_voro(const DevModel& M, const RunAr
     for (int off = 32; off > 0; off >>= 1) vsum += __shfl_down(vsum, off);
     if (lane == 0 && vsum) atomicAdd(&A.counters[q], vsum);
   }
+  if (MRW) {
+    unsigned long long v8 = c_walks, v9 = c_steps;
+    for (int off = 32; off > 0; off >>= 1) { v8 += __shfl_down(v8, off); v9 += __shfl_down(v9, off); }
+    if (lane == 0 && v8) atomicAdd(&A.counters[8], v8);
+    if (lane == 0 && v9) atomicAdd(&A.counters[9], v9);
+  }
 }
 
 template <bool POLA>
 __global__ void __launch_bounds__(256) k_thermal_voro(const DevModel M, const RunArgs A, const VoroGrid G) {
   extern __shared__ double lds_raw[];
   thermal_body_voro<POLA, false>(M, A, G, lds_raw, 0);
+}
+
+// ... with the modified random walk (HBM deposits)
+template <bool POLA>
+__global__ void __launch_bounds__(256) k_thermal_voro_mrw(const DevModel M, const RunArgs A, const VoroGrid G) {
+  extern __shared__ double lds_raw[];
+  thermal_body_voro<POLA, false, true>(M, A, G, lds_raw, 0);
 }
 
 // BLOCK = 1024: 4 waves/SIMD at <= 128 VGPRs (spills); 768 (default): 3 waves/SIMD at <= 168, no scratch; 512: 2 waves/SIMD

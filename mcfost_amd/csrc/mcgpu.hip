@@ -1006,10 +1006,9 @@ extern "C" int mcgpu_set_mrw(mcgpu_ctx* ctx, int n_zeta, const double* zeta, con
   if (!ctx) return MCGPU_ERR_ARG;
   DevModel& M = ctx->M;
   if (n_zeta == 0) { M.mrw = 0; return MCGPU_OK; }  // off
-  if (n_zeta < 2 || !zeta || !chi || !kappa_dep || !ext || !r_lim || !(gamma > 0.0) || n_interactions < 0 || n_interactions > 6)
+  if (n_zeta < 2 || !zeta || !chi || !kappa_dep || !ext || (!r_lim && !ctx->voro) || !(gamma > 0.0) || n_interactions < 0 || n_interactions > 6)
     return fail(ctx, MCGPU_ERR_ARG, "mcgpu_set_mrw: bad argument (n_interactions is 0..6)");
   if (!ctx->have_grid || !ctx->have_thermal) return fail(ctx, MCGPU_ERR_STATE, "set the grid and the thermal tables first");
-  if (ctx->voro) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "modified random walk: cylindrical and spherical grids");
   for (int i = 1; i < n_zeta; ++i)
     if (!(zeta[i] >= zeta[i - 1])) return fail(ctx, MCGPU_ERR_ARG, "mcgpu_set_mrw: zeta must not decrease");
   HIPCHK(hipSetDevice(ctx->device));
@@ -1021,8 +1020,8 @@ extern "C" int mcgpu_set_mrw(mcgpu_ctx* ctx, int n_zeta, const double* zeta, con
   if ((rc = upload(ctx, chi, n_tab, &M.mrw_chi))) return rc;
   if ((rc = upload(ctx, kappa_dep, n_tab, &M.mrw_kdep))) return rc;
   if ((rc = upload(ctx, ext, n_tab, &M.mrw_ext))) return rc;
-  if ((rc = upload(ctx, r_lim, (size_t)M.n_rad + 1, &M.r_lim))) return rc;
-  if (M.l3D) {
+  if (!ctx->voro && (rc = upload(ctx, r_lim, (size_t)M.n_rad + 1, &M.r_lim))) return rc;
+  if (M.l3D && !ctx->voro) {
     // sin_phi_lim, cos_phi_lim of the azimuthal walls (cylindrical_grid.f90:586-599, default-real phi; both grid types) for
     // distance_to_closest_wall_cyl's 3D branch (:1198-1218).  Where the reference stores the sentinel pair
     // (cos, sin) = (0, 1e300) for a wall at phi = pi/2 (mod pi) -- which makes that wall infinitely far for the walk -- the
@@ -1345,6 +1344,25 @@ static int launch_voro(mcgpu_ctx* ctx, const RunArgs& A, int grid_blocks, int bl
   // measured at 100 000 sites 2.5e7 packets/s against 4.7e7 for the single-role kernel below -- the stand-in disk's
   // packets interact 119 times for 162 crossings, so almost all work is serving work, and the serving lanes are
   // limited by the records that fit into LDS (512 for 1024 lanes).
+  if (M.mrw) {  // the random walk: the single-role kernel with HBM deposits
+    const bool pola = ctx->lsepar_pola != 0;
+    const int threads = (block_threads > 0 && block_threads <= 256) ? block_threads : 256;
+    if (threads % 64) return fail(ctx, MCGPU_ERR_ARG, "block_threads must be a multiple of 64");
+    const void* fn = pola ? (const void*)k_thermal_voro_mrw<true> : (const void*)k_thermal_voro_mrw<false>;
+    HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t));
+    int blocks = grid_blocks;
+    if (blocks <= 0) {
+      int occ = 1;
+      HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, threads, lds_t));
+      if (occ < 1) occ = 1;
+      blocks = ctx->prop.multiProcessorCount * occ;
+      const unsigned long long need = (A.n_packets + threads - 1) / threads;
+      if ((unsigned long long)blocks > need) blocks = (int)(need ? need : 1);
+    }
+    void* args[] = {(void*)&M, (void*)&A, (void*)&ctx->V};
+    HIPCHK(hipLaunchKernel(fn, dim3(blocks), dim3(threads), args, lds_t, ctx->stream));
+    return MCGPU_OK;
+  }
   if (ctx->opt_schedule == 2 && ctx->opt_deposit != 1 && !A.xN_abs && !A.xJ_abs) {
     const bool pola = ctx->lsepar_pola != 0;
     int log_ns = ctx->opt_cache_log_slots, n_rec = 0;

@@ -343,7 +343,8 @@ class Engine:
         self._chk(self.lib.mcgpu_set_mrw(
             self.ctx, C.c_int(mrw["zeta"].size), _p(_a(mrw["zeta"], d), C.c_double), _p(_a(mrw["chi"], d), C.c_double),
             _p(_a(mrw["kappa_dep"], d), C.c_double), _p(_a(mrw["ext"], d), C.c_double), C.c_double(mrw["gamma"]),
-            C.c_int(mrw["n_inter"]), _p(_a(self.model.grid["r_lim"], d), C.c_double)), "mcgpu_set_mrw")
+            C.c_int(mrw["n_inter"]),
+            _p(_a(self.model.grid["r_lim"], d), C.c_double) if "r_lim" in self.model.grid else None), "mcgpu_set_mrw")
 
     # -- the packet loop ---------------------------------------------------
     def _opts(self, n_packets, seed, first_packet, frozen, n_replicas, accumulate, grid_blocks,

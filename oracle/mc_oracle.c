@@ -1820,7 +1820,27 @@ static double distance_to_closest_wall_sph(const oracle_model *m, int icell, dou
   return s;
 }
 
+/* distance_to_closest_wall_Voronoi (Voronoi.f90:996-1061) in its working form: n . (p - r) / |n| to the closest face (the
+ * reference divides by n . n: the distance in units of the neighbour separation); 0 in a cut cell and next to the box */
+static double distance_to_closest_wall_voro(const oracle_model *m, int icell, double x, double y, double z) {
+  if (m->v_was_cut && m->v_was_cut[icell - 1]) return 0.0;
+  const float *c = m->v_xyz + 3 * (size_t)(icell - 1);
+  double s = 1.0e30;
+  for (int i = m->v_first[icell - 1]; i <= m->v_last[icell - 1]; ++i) {
+    const int id = m->v_neigh[i - 1];
+    if (id <= 0) return 0.0;
+    const float *nbx = m->v_xyz + 3 * (size_t)(id - 1);
+    const double n0 = (double)nbx[0] - (double)c[0], n1 = (double)nbx[1] - (double)c[1], n2 = (double)nbx[2] - (double)c[2];
+    const double p0 = 0.5 * ((double)nbx[0] + (double)c[0]), p1 = 0.5 * ((double)nbx[1] + (double)c[1]), p2 = 0.5 * ((double)nbx[2] + (double)c[2]);
+    double d = (n0 * (p0 - x) + n1 * (p1 - y) + n2 * (p2 - z)) / sqrt(n0 * n0 + n1 * n1 + n2 * n2);
+    if (d < 0.0) d = 0.0;
+    if (d < s) s = d;
+  }
+  return s;
+}
+
 double oracle_distance_to_closest_wall_cyl(const oracle_model *m, int icell, double x, double y, double z) {
+  if (m->grid_type == 3) return distance_to_closest_wall_voro(m, icell, x, y, z);
   if (m->grid_type == 2) return distance_to_closest_wall_sph(m, icell, x, y, z);
   const int ri0 = m->cell_map_i[icell - 1];
   int zj0 = m->cell_map_j[icell - 1];

@@ -526,3 +526,75 @@ def test_device_walk_on_spherical_grids(l3D):
     for k in keys:
         assert abs(g[k] - w[k]) <= 4.0 * np.sqrt(2.0) * sigma[k], (k, g[k], w[k], sigma[k])
     assert np.array_equal(got["n_sent"], want["n_sent"])
+
+
+def thick_voronoi(mrw=True, **kw):
+    # (cut = False: in a cut cell the reference's routine -- and this one -- returns 0, and the test disk's dense cells are
+    # the elongated ones the cut is made for: the walk would hardly ever run)
+    m = M.build_voronoi_model(M.small(dust_mass=3e-2), 1500, seed=3, cut=False)
+    if mrw:
+        M.init_mrw(m, **kw)
+    return m
+
+
+def test_walk_on_a_voronoi_grid():
+    """distance_to_closest_wall on a Voronoi cell -- the perpendicular distance to the closest face (the reference's
+    routine returns it in units of the neighbour separation): at a cell's site it is half the distance to the nearest
+    neighbouring site, next to the box and in cut cells it is 0 (no walk); and the walk's bookkeeping."""
+    m = thick_voronoi(mrw=False)
+    o = Oracle(m, 1000)
+    g = m.grid
+    xyz = np.asarray(g["v_xyz_dp"]).reshape(-1, 3)
+    first, last, neigh = np.asarray(g["v_first"]), np.asarray(g["v_last"]), np.asarray(g["v_neigh"])
+    cut = np.asarray(g["v_was_cut"]) if "v_was_cut" in g else np.zeros(len(first), np.uint8)
+    n_in = 0
+    for ic in range(0, m.n_cells, 37):
+        nb = neigh[first[ic] - 1:last[ic]]
+        d = o.distance_to_closest_wall([ic + 1], [xyz[ic, 0]], [xyz[ic, 1]], [xyz[ic, 2]])[0]
+        if (nb <= 0).any() or cut[ic]:
+            assert d == 0.0
+        else:
+            want = 0.5 * np.min(np.linalg.norm(xyz[nb - 1] - xyz[ic], axis=1))
+            assert np.isclose(d, want, rtol=1e-5)          # (the sites are default reals in the crossing tables)
+            n_in += 1
+    assert n_in > 10
+    n = 20000
+    a = Oracle(thick_voronoi(), n).run_thermal(n, seed=3, n_threads=8)
+    b = Oracle(thick_voronoi(mrw=False), n).run_thermal(n, seed=3, n_threads=8)
+    ca, cb = a["counters"], b["counters"]
+    assert ca["mrw_walks"] > 200 and ca["escaped"] + ca["killed_star"] == n
+    # (a 1500-cell tessellation: a cell is a few mean free paths across only near the midplane -- the walk replaces ~14 % of the events)
+    assert ca["absorptions"] + ca["scatterings"] < 0.92 * (cb["absorptions"] + cb["scatterings"])
+    assert abs(a["E_abs"].sum() / b["E_abs"].sum() - 1.0) < 0.08
+
+
+@pytest.mark.gpu
+def test_device_walk_on_a_voronoi_grid():
+    """k_thermal_voro_mrw: without the walk the same packets as the default Voronoi kernel; with it the noise-aware gates
+    against the oracle."""
+    from mcfost_amd.engine import Engine
+    n = 20000
+    m0 = thick_voronoi(mrw=False)
+    prior = Oracle(m0, n).run_thermal(n, seed=1, n_threads=1)["E_abs"]
+    want0 = Oracle(m0, n).run_thermal(n, seed=9, frozen=True, E_prior=prior, n_threads=8)
+    e = Engine(m0, n)
+    got0 = e.run_thermal(n, seed=9, frozen=True, E_prior=prior)
+    e.close()
+    assert got0["counters"] == want0["counters"]
+    m = thick_voronoi()
+    orc = Oracle(m, n)
+    want = orc.run_thermal(n, seed=9, frozen=True, E_prior=prior, n_threads=8)
+    keys = ("mrw_walks", "mrw_steps", "absorptions", "scatterings", "crossings", "flights")
+    others = [orc.run_thermal(n, seed=s, frozen=True, E_prior=prior, n_threads=8) for s in (21, 22, 23, 24, 25, 26)]
+    sigma = {k: np.std([r["counters"][k] for r in others], ddof=1) for k in keys}
+    e = Engine(m, n)
+    got = e.run_thermal(n, seed=9, frozen=True, E_prior=prior)
+    e.close()
+    g, w = got["counters"], want["counters"]
+    assert g["mrw_walks"] > 200
+    for k in ("packets", "escaped", "killed_star"):
+        assert g[k] == w[k]
+    for k in keys:
+        assert abs(g[k] - w[k]) <= 4.0 * np.sqrt(2.0) * sigma[k], (k, g[k], w[k], sigma[k])
+    assert np.array_equal(got["n_sent"], want["n_sent"])
+    assert abs(got["E_abs"].sum() / want["E_abs"].sum() - 1.0) < 0.05
