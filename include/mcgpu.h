@@ -563,6 +563,8 @@ int mcgpu_probe_packet_rand(mcgpu_ctx *ctx, uint64_t seed, uint64_t packet,
  * tab_s11_pos per class, mcgpu_set_variable_dust_s11), mcgpu_repartition_energie and the ray tracer (mcgpu_rt1_dust_map,
  * mcgpu_rt1_image, mcgpu_rt1_stars_map_sed), mcgpu_define_dark_zone, the diffusion fill and the random walk (mcgpu_set_mrw
  * with one row of tables per class) read per class too.
+ * Grids: cylindrical (every path above) and Voronoi (the thermal step, with or without the random walk:
+ * k_thermal_voro_var; mcgpu_run_mono refuses classes there); not spherical.
  * p_n_cells = 0: off.  log_Qcool and kdB_dT_CDF may both be NULL (see mcgpu_init_reemission).
  */
 int mcgpu_set_variable_dust(mcgpu_ctx *ctx, int p_n_cells, const int *p_icell, const double *kappa,

@@ -334,7 +334,8 @@ constexpr int VORO_CACHE_BLOCK = 1024;  // most threads of a cached-deposit work
 // deposit cache; otherwise straight to HBM (global_atomic_add_f64).
 // ---------------------------------------------------------------------------
 // MRW: the modified random walk (mc_device.hip.h) with the Voronoi cell's closest face.
-template <bool POLA, bool CACHE, bool MRW = false>
+// VAR: lvariable_dust -- the tables of the cell's class (DevModel::cell_class), as thermal_body has it on cylindrical grids
+template <bool POLA, bool CACHE, bool MRW = false, bool VAR = false>
 __device__ __forceinline__ void thermal_body_voro(const DevModel& M, const RunArgs& A, const VoroGrid& G,
                                                   double* lds_base, int cache_log_ns) {
   const Lds T = lds_carve(lds_base, M);
@@ -424,20 +425,22 @@ __device__ __forceinline__ void thermal_body_voro(const DevModel& M, const RunAr
       tau_rand = g[5];
       double u1, v1, w1;
       const int ic = icell - 1;
-      interact<POLA>(T, M, g, lambda, u, v, w, u1, v1, w1, S, flag_star, flag_scatt, c_scatt, c_abs, [&]() {
+      const int cls = VAR ? M.cell_class[ic] : -1;
+      const Lds Tc = VAR ? class_tables(T, M, cls) : T;   // (lvariable_dust: this cell's tables)
+      interact<POLA>(Tc, M, g, lambda, u, v, w, u1, v1, w1, S, flag_star, flag_scatt, c_scatt, c_abs, [&]() {
         if (A.frozen) return A.E_prior[ic];
         // what every workgroup has put into HBM so far + this workgroup's pending part standing
         // in for the others' (the reference's partial * nb_proc, thermal_emission.f90:670)
         double E = __hip_atomic_load(&A.E_abs[ic], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (CACHE) E += DC.pending(ic + 1) * (double)gridDim.x;
         return E * A.qscale;
-      }, M.volume + ic);
+      }, M.volume + ic, false, nullptr, -1, (VAR && M.v_scatt) ? cls : -1, (VAR && M.m1) ? cls : -1);
       if (!flag_scatt) flag_ism = false;
       u = u1; v = v1; w = w1;
       if (MRW) {  // dust_transfer.f90:1222-1239: a packet its cell has just re-emitted for the (n_inter + 1)-th time in a row
         if (__builtin_expect(!flag_scatt && !flag_star && n_inter > M.mrw_n_inter, 0)) {
           const VoroCell C = G.cell[ic];
-          mrw_walk_with(T, M, rng.k0, rng.k1, rng.p_lo, rng.p_hi, rng.event, ic, C.kf, S[0], x, y, z, u, v, w, lambda,
+          mrw_walk_with(Tc, M, rng.k0, rng.k1, rng.p_lo, rng.p_hi, rng.event, ic, C.kf, S[0], x, y, z, u, v, w, lambda,
                         [&](double px, double py, double pz) { return voro_distance_to_closest_wall(G, C, px, py, pz); },
                         [&]() {
                           if (A.frozen) return A.E_prior[ic];
@@ -479,7 +482,15 @@ __device__ __forceinline__ void thermal_body_voro(const DevModel& M, const RunAr
           st = S_EMIT;
         } else {
           const VoroCell C = G.cell[icell - 1];
-          const double opacity = T.kappa[lambda - 1] * C.kf;
+          double opacity, kabs_c;
+          if (VAR) {
+            const size_t row = (size_t)M.cell_class[icell - 1] * M.n_lambda + (lambda - 1);
+            opacity = M.v_kappa[row] * C.kf;
+            kabs_c = M.v_kabs[row];
+          } else {
+            opacity = T.kappa[lambda - 1] * C.kf;
+            kabs_c = T.kabs[lambda - 1];
+          }
           double x1, y1, z1, l, l_contrib, l_void;
           int next;
           voro_cross_cell(G, M, C, x, y, z, u, v, w, icell, prev_cell, x1, y1, z1, next, l, l_contrib, l_void);
@@ -488,7 +499,7 @@ __device__ __forceinline__ void thermal_body_voro(const DevModel& M, const RunAr
           if (tau > extr) {
             const double lc = l_contrib * (extr / tau);
             const double ls = l_void + lc;
-            const double dE = T.kabs[lambda - 1] * lc * S[0];
+            const double dE = kabs_c * lc * S[0];
             if (dE != 0.0 && !MCGPU_DIAG(A.flags, 1)) {
               if (!(CACHE && DC.add(icell, dE))) atomic_add_f64(&A.E_abs[icell - 1], dE);
             }
@@ -501,7 +512,7 @@ __device__ __forceinline__ void thermal_body_voro(const DevModel& M, const RunAr
           } else {
             first_cross = false;
             extr = extr - tau;
-            const double dE = T.kabs[lambda - 1] * l_contrib * S[0];
+            const double dE = kabs_c * l_contrib * S[0];
             if (dE != 0.0 && !MCGPU_DIAG(A.flags, 1)) {
               if (!(CACHE && DC.add(icell, dE))) atomic_add_f64(&A.E_abs[icell - 1], dE);
             }
@@ -569,6 +580,13 @@ template <bool POLA>
 __global__ void __launch_bounds__(256) k_thermal_voro_mrw(const DevModel M, const RunArgs A, const VoroGrid G) {
   extern __shared__ double lds_raw[];
   thermal_body_voro<POLA, false, true>(M, A, G, lds_raw, 0);
+}
+
+// lvariable_dust (the deposit cache, 768 threads; MRW: with the random walk)
+template <bool POLA, bool MRW>
+__global__ void __launch_bounds__(768) k_thermal_voro_var(const DevModel M, const RunArgs A, const VoroGrid G, int cache_log_ns) {
+  extern __shared__ double lds_raw[];
+  thermal_body_voro<POLA, true, MRW, true>(M, A, G, lds_raw, cache_log_ns);
 }
 
 // BLOCK = 1024: 4 waves/SIMD at <= 128 VGPRs (spills); 768 (default): 3 waves/SIMD at <= 168, no scratch; 512: 2 waves/SIMD

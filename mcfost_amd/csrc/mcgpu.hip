@@ -713,7 +713,7 @@ extern "C" int mcgpu_set_variable_dust(mcgpu_ctx* ctx, int p_n_cells, const int*
     return fail(ctx, MCGPU_ERR_ARG, "mcgpu_set_variable_dust: bad argument");
   if (!ctx->have_grid || !ctx->have_opacity || !ctx->have_thermal)
     return fail(ctx, MCGPU_ERR_STATE, "set the grid, the opacities and the thermal tables first");
-  if (ctx->voro || M.grid_sph) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "variable dust: cylindrical grids only");
+  if (M.grid_sph) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "variable dust: cylindrical and Voronoi grids");
   for (int i = 0; i < M.n_cells; ++i)
     if (p_icell[i] < 1 || p_icell[i] > p_n_cells) return fail(ctx, MCGPU_ERR_ARG, "mcgpu_set_variable_dust: p_icell out of range");
   const int nc = p_n_cells, nl = M.n_lambda, nT = M.n_T;
@@ -837,7 +837,7 @@ extern "C" int mcgpu_opacity(mcgpu_ctx* ctx, const mcgpu_grain_tables* G, int p_
   if (!ctx->have_grid || !ctx->have_opacity || !ctx->have_thermal || !ctx->have_scatt)
     return fail(ctx, MCGPU_ERR_STATE, "set the grid, the opacities, the scattering and the thermal tables first");
   DevModel& M = ctx->M;
-  if (ctx->voro || M.grid_sph) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "variable dust: cylindrical grids only");
+  if (M.grid_sph) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "variable dust: cylindrical and Voronoi grids");
   const int ng = G->n_grains, nl = M.n_lambda, nc = p_n_cells, nT = M.n_T, na1 = M.nang + 1;
   const bool pola = ctx->lsepar_pola != 0, mueller = M.aniso_method == 1;
   if (ng < 1 || G->grain_RE_LTE_start < 1 || G->grain_RE_LTE_end > ng || !G->C_ext || !G->C_sca || !G->C_abs || !G->S_grain ||
@@ -1344,6 +1344,30 @@ static int launch_voro(mcgpu_ctx* ctx, const RunArgs& A, int grid_blocks, int bl
   // measured at 100 000 sites 2.5e7 packets/s against 4.7e7 for the single-role kernel below -- the stand-in disk's
   // packets interact 119 times for 162 crossings, so almost all work is serving work, and the serving lanes are
   // limited by the records that fit into LDS (512 for 1024 lanes).
+  if (M.n_classes) {  // lvariable_dust (what a multi-grain SPH dump gives: p_n_cells = n_cells): the single-role kernel
+    const bool pola = ctx->lsepar_pola != 0;   // with the deposit cache, the class's tables from HBM
+    int log_ns = ctx->opt_cache_log_slots;
+    while (log_ns > 6 && lds_t + ((size_t)12 << log_ns) > lds_cap) --log_ns;
+    if (lds_t + ((size_t)12 << log_ns) > lds_cap) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "wavelength tables exceed the LDS of one CU");
+    const size_t lds = lds_t + ((size_t)12 << log_ns);
+    const int threads = (block_threads > 0 && block_threads <= 768) ? block_threads : 768;
+    if (threads % 64) return fail(ctx, MCGPU_ERR_ARG, "block_threads must be a multiple of 64");
+    const void* fn = M.mrw ? (pola ? (const void*)k_thermal_voro_var<true, true> : (const void*)k_thermal_voro_var<false, true>)
+                           : (pola ? (const void*)k_thermal_voro_var<true, false> : (const void*)k_thermal_voro_var<false, false>);
+    HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int blocks = grid_blocks;
+    if (blocks <= 0) {
+      int occ = 1;
+      HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, threads, lds));
+      if (occ < 1) occ = 1;
+      blocks = ctx->prop.multiProcessorCount * occ;
+      const unsigned long long need = (A.n_packets + threads - 1) / threads;
+      if ((unsigned long long)blocks > need) blocks = (int)(need ? need : 1);
+    }
+    void* args[] = {(void*)&M, (void*)&A, (void*)&ctx->V, (void*)&log_ns};
+    HIPCHK(hipLaunchKernel(fn, dim3(blocks), dim3(threads), args, lds, ctx->stream));
+    return MCGPU_OK;
+  }
   if (M.mrw) {  // the random walk: the single-role kernel with HBM deposits
     const bool pola = ctx->lsepar_pola != 0;
     const int threads = (block_threads > 0 && block_threads <= 256) ? block_threads : 256;
@@ -2130,7 +2154,8 @@ extern "C" int mcgpu_run_mono(mcgpu_ctx* ctx, const mcgpu_mono_opts* o, double f
       return fail(ctx, MCGPU_ERR_STATE, "SED mode with variable dust needs prob_s11_pos per wavelength: set the scattering tables with p_lambda_fixed = 0");
     if (!M.v_scatt) return fail(ctx, MCGPU_ERR_STATE, "SED mode with variable dust needs the per-class scattering tables");
     if (o->rt1 == 1 && !M.v_s11) return fail(ctx, MCGPU_ERR_STATE, "rt1 deposits with variable dust need tab_s11_pos per class (mcgpu_opacity or mcgpu_set_variable_dust_s11)");
-    if (ctx->voro) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "variable dust: cylindrical grids only");
+    if (ctx->voro) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "SED mode with variable dust: cylindrical grids only");
+    if (M.m1) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "scattering method 1 is for the thermal step (ray tracing forces method 2, init_mcfost.f90:1659)");
   }
   if (o->lambda < 1 || o->lambda > M.n_lambda || o->n_chunks < 1 || o->n_chunks > (1 << 22) || o->capt_sup < 1 ||
       o->first_chunk < 0 || (long long)o->first_chunk + o->n_chunks > (1 << 23))

@@ -716,11 +716,21 @@ def init_variable_dust(m: "Model", n_classes: int = 0, slope: float = 0.15, iden
     rises -- inputs, not algorithm.  ``identical``: every class gets the model's own tables (the known-answer case:
     the run must equal the single-class run)."""
     g = m.grid
-    n_rad, nz, n_cells = g["n_rad"], g["nz"], m.n_cells
-    nc = int(n_classes) if n_classes else nz
+    n_cells = m.n_cells
     nl, nT = m.n_lambda, m.tab_Temp.size
-    j = np.abs(np.asarray(g["cell_map_j"], np.int64)[:n_cells])              # 1..nz
-    p_icell = (np.minimum((j - 1) * nc // nz, nc - 1) + 1).astype(np.int32)
+    if g.get("grid_type", 1) == 3:
+        # Voronoi grid (what a multi-grain SPH dump gives; the reference then has one class per cell, p_n_cells =
+        # n_cells): the classes are bins of |z| / H(r), 0.5 scale heights each -- the same stand-in for settling
+        nc = int(n_classes) if n_classes else 8
+        xyz = np.asarray(g["v_xyz_dp"], f64).reshape(-1, 3)[:n_cells]
+        rc = np.maximum(np.hypot(xyz[:, 0], xyz[:, 1]), 1e-30)
+        H = m.cfg.sclht * (rc / m.cfg.rref) ** m.cfg.exp_beta
+        p_icell = (np.minimum((np.abs(xyz[:, 2]) / (0.5 * H)).astype(np.int64), nc - 1) + 1).astype(np.int32)
+    else:
+        n_rad, nz = g["n_rad"], g["nz"]
+        nc = int(n_classes) if n_classes else nz
+        j = np.abs(np.asarray(g["cell_map_j"], np.int64)[:n_cells])              # 1..nz
+        p_icell = (np.minimum((j - 1) * nc // nz, nc - 1) + 1).astype(np.int32)
     lam = np.asarray(m.lam, f64)
     kappa = np.zeros((nl, nc), f64)          # Fortran (p_n_cells, n_lambda): class fastest
     kabs = np.zeros((nl, nc), f64)

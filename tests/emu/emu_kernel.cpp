@@ -237,6 +237,12 @@ extern "C" int emu_run_thermal(const oracle_model* m, const oracle_opts* o, cons
     for (int q = 0; q < ORACLE_N_COUNTERS; ++q) counters[q] = cnt[q];
     return err;
   }
+  if (voro && M.n_classes) {  // lvariable_dust on a Voronoi grid (deposit cache, few slots)
+    if (M.mrw) { if (pola) k_thermal_voro_var<true, true>(M, A, G, 6); else k_thermal_voro_var<false, true>(M, A, G, 6); }
+    else { if (pola) k_thermal_voro_var<true, false>(M, A, G, 6); else k_thermal_voro_var<false, false>(M, A, G, 6); }
+    for (int q = 0; q < ORACLE_N_COUNTERS; ++q) counters[q] = cnt[q];
+    return err;
+  }
   if (voro) {
     if (getenv("MCGPU_EMU_LDS")) {  // deposit cache, few slots so that hits, misses and folds all occur
       if (pola) k_thermal_voro_cache<true, 512>(M, A, G, 6); else k_thermal_voro_cache<false, 512>(M, A, G, 6);

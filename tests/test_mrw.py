@@ -528,10 +528,12 @@ def test_device_walk_on_spherical_grids(l3D):
     assert np.array_equal(got["n_sent"], want["n_sent"])
 
 
-def thick_voronoi(mrw=True, **kw):
+def thick_voronoi(mrw=True, var=False, **kw):
     # (cut = False: in a cut cell the reference's routine -- and this one -- returns 0, and the test disk's dense cells are
     # the elongated ones the cut is made for: the walk would hardly ever run)
     m = M.build_voronoi_model(M.small(dust_mass=3e-2), 1500, seed=3, cut=False)
+    if var:
+        M.init_variable_dust(m)          # (classes of |z| / H: the walk reads the class's row of mean opacities)
     if mrw:
         M.init_mrw(m, **kw)
     return m
@@ -569,19 +571,20 @@ def test_walk_on_a_voronoi_grid():
 
 
 @pytest.mark.gpu
-def test_device_walk_on_a_voronoi_grid():
-    """k_thermal_voro_mrw: without the walk the same packets as the default Voronoi kernel; with it the noise-aware gates
-    against the oracle."""
+@pytest.mark.parametrize("var", [False, True])
+def test_device_walk_on_a_voronoi_grid(var):
+    """k_thermal_voro_mrw (var: k_thermal_voro_var<., MRW> with dust classes): without the walk the oracle's packets;
+    with it the noise-aware gates against the oracle."""
     from mcfost_amd.engine import Engine
     n = 20000
-    m0 = thick_voronoi(mrw=False)
+    m0 = thick_voronoi(mrw=False, var=var)
     prior = Oracle(m0, n).run_thermal(n, seed=1, n_threads=1)["E_abs"]
     want0 = Oracle(m0, n).run_thermal(n, seed=9, frozen=True, E_prior=prior, n_threads=8)
     e = Engine(m0, n)
     got0 = e.run_thermal(n, seed=9, frozen=True, E_prior=prior)
     e.close()
     assert got0["counters"] == want0["counters"]
-    m = thick_voronoi()
+    m = thick_voronoi(var=var)
     orc = Oracle(m, n)
     want = orc.run_thermal(n, seed=9, frozen=True, E_prior=prior, n_threads=8)
     keys = ("mrw_walks", "mrw_steps", "absorptions", "scatterings", "crossings", "flights")

@@ -106,6 +106,10 @@ def test_device_method1_equals_the_oracle_frozen(kw):
     if m.cfg.lsepar_pola and m.cfg.aniso_method == 1:
         assert np.allclose(a["sed"][1:4], b["sed"][1:4], rtol=1e-5, atol=1e-6 * max(1.0, np.abs(b["sed"][0]).max()))
     assert a["counters"]["scatterings"] > 5000
+    # SED mode is method 2's (ray tracing forces it, init_mcfost.f90:1659): a clear error, not a run with other tables
+    from mcfost_amd.engine import McgpuError
+    with pytest.raises(McgpuError):
+        e.run_mono(3, 5, seed=1, n_chunks=4, rt1=False)
     # method 2 on the same context runs other packets: the switch is live
     e.set_scattering_method1(None)
     a2 = e.run_thermal(n, seed=6, frozen=True, E_prior=prior)

@@ -67,6 +67,67 @@ def test_emulated_kernel_against_the_oracle(emu, kw):   # noqa: F811
         assert np.allclose(got["E_abs"], want["E_abs"], rtol=1e-7, atol=1e-12 * want["E_abs"].max())   # (FMA-level: grazing segments)
 
 
+def voronoi_settled(identical=False, **kw):
+    """A Voronoi grid with dust classes (what a multi-grain SPH dump gives): bins of |z| / H."""
+    m = M.build_voronoi_model(M.small(**kw), 1500, seed=3)
+    M.init_variable_dust(m, identical=identical)
+    return m
+
+
+def test_voronoi_identical_classes_equal_the_single_class_run():
+    base = M.build_voronoi_model(M.small(), 1500, seed=3)
+    a = Oracle(base, 5000).run_thermal(5000, seed=3, n_threads=1)
+    b = Oracle(voronoi_settled(identical=True), 5000).run_thermal(5000, seed=3, n_threads=1)
+    assert a["counters"] == b["counters"] and np.array_equal(a["E_abs"], b["E_abs"]) and np.array_equal(a["sed"], b["sed"])
+    m = voronoi_settled()
+    assert len(np.unique(m.variable_dust["p_icell"])) >= 5
+    c = Oracle(m, 5000).run_thermal(5000, seed=3, n_threads=1)
+    assert c["counters"]["escaped"] + c["counters"]["killed_star"] == 5000
+    assert abs(c["counters"]["scatterings"] / a["counters"]["scatterings"] - 1.0) > 0.02
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(aniso_method=2, lsepar_pola=False)])
+def test_emulated_voronoi_kernel_against_the_oracle(emu, kw):   # noqa: F811
+    """k_thermal_voro_var on one lane: the class's tables in the crossing, the interaction and the re-emission."""
+    m = voronoi_settled(**kw)
+    n = 3000
+    orc = Oracle(m, n)
+    prior = orc.run_thermal(2000, seed=1, n_threads=1)["E_abs"]
+    want = orc.run_thermal(n, seed=7, frozen=True, E_prior=prior, n_threads=4)
+    got = emu_run(emu, orc, n, 7, prior=prior)
+    assert got["counters"] == list(want["counters"].values())
+    assert np.array_equal(got["n_sent"], want["n_sent"]) and np.array_equal(got["sed"][4], want["sed"][4])
+    assert np.allclose(got["E_abs"], want["E_abs"], rtol=1e-7, atol=1e-12 * want["E_abs"].max())
+
+
+@pytest.mark.gpu
+def test_device_voronoi_against_the_oracle_frozen():
+    """lvariable_dust on a Voronoi grid (k_thermal_voro_var): the oracle's packets; the temperatures of the classes."""
+    from mcfost_amd.engine import Engine
+    m = voronoi_settled()
+    n = 20000
+    orc = Oracle(m, n)
+    prior = orc.run_thermal(2000, seed=1)["E_abs"]
+    want = orc.run_thermal(n, seed=7, frozen=True, E_prior=prior, n_threads=8)
+    e = Engine(m, n)
+    got = e.run_thermal(n, seed=7, frozen=True, E_prior=prior)
+    assert got["counters"] == want["counters"]
+    assert np.array_equal(got["n_sent"], want["n_sent"]) and np.array_equal(got["sed"][4], want["sed"][4])
+    assert np.allclose(got["E_abs"], want["E_abs"], rtol=1e-7, atol=1e-12 * want["E_abs"].max())
+    assert np.allclose(e.temp_finale(got["E_abs"]), orc.temp_finale(want["E_abs"]), rtol=2e-6)
+    e.close()
+    # identical classes: the packets of the default Voronoi kernel
+    base = M.build_voronoi_model(M.small(), 1500, seed=3)
+    e0 = Engine(base, n)
+    a = e0.run_thermal(n, seed=7, frozen=True, E_prior=prior)
+    e0.close()
+    e1 = Engine(voronoi_settled(identical=True), n)
+    b = e1.run_thermal(n, seed=7, frozen=True, E_prior=prior)
+    e1.close()
+    assert a["counters"] == b["counters"]
+    assert np.allclose(a["E_abs"], b["E_abs"], rtol=1e-9, atol=1e-12 * a["E_abs"].max())
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("kw", [dict(), dict(n_rad=12, nz=6, n_az=8, l3D=True)])
 def test_device_against_the_oracle_frozen(kw):
