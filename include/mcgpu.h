@@ -396,6 +396,8 @@ int mcgpu_repartition_energie(mcgpu_ctx *ctx, int lambda, double wl_um, double E
  * n_sent_chunk[n_chunks] (may be NULL) returns the packets each stream sent; their sum is
  * what the call added to n_sent(lambda) = n_phot_envoyes(lambda,:).  sed, n_sent and the
  * counters are read back with mcgpu_fetch, xI_scatt with mcgpu_fetch_xI.
+ * Grids: cylindrical, spherical (one dust class; rt1 = 0 or 1) and Voronoi (one dust class).  Scattering method 1 is
+ * refused (the reference forces method 2 with ray tracing, init_mcfost.f90:1659).
  */
 int mcgpu_run_mono(mcgpu_ctx *ctx, const mcgpu_mono_opts *opts,
                    double frac_E_stars, double frac_E_disk,
@@ -437,7 +439,7 @@ int mcgpu_device_xI(mcgpu_ctx *ctx, void **xI_dev, uint64_t *n_values);
  * mcgpu_set_rt1, from the xI_scatt the last mcgpu_run_mono(rt1=1) of this
  * wavelength left on the device (after the all-reduce on several GPUs).
  * The stellar term (compute_stars_map, :1603-1895): mcgpu_rt1_stars_map_sed below.
- * Cylindrical grids.
+ * Cylindrical and spherical grids (the ray integration picks the operators of the grid at run time).
  * ------------------------------------------------------------------------ */
 typedef struct {
   int lambda;               /* 1-based wavelength index                                   */

@@ -489,7 +489,8 @@ __device__ inline double mono_opacity(const Lds& T, const DevModel& M, int lambd
 }
 
 // SCOUT: no deposits, no SED; records hits.  Otherwise the COMMIT pass.
-template <bool L3D, bool POLA, bool DARK, bool SCOUT, bool F32 = false>
+// SPH: the grid operators of spherical_grid.f90 (as thermal_body has them)
+template <bool L3D, bool POLA, bool DARK, bool SCOUT, bool F32 = false, bool SPH = false>
 __device__ __forceinline__ void mono_body(const DevModel& M, const MonoArgs& A, double* lds_base) {
   const Lds T = lds_carve(lds_base, M, true);
   lds_stage_mono(T, M, A.p_lambda);
@@ -569,9 +570,16 @@ __device__ __forceinline__ void mono_body(const DevModel& M, const MonoArgs& A, 
           bool lintersect;
           flag_scatt = false;
           S[0] = 1.0; S[1] = 0.0; S[2] = 0.0; S[3] = 0.0;
-          CylEmitOps<L3D> ops{T, M, ri, zj, k};
-          const int rc = emit_packet(M, f, lambda, A.frac_E_stars, A.frac_E_disk, A.prob_E_cell, ops, x, y, z, u, v, w,
-                                     flag_star, flag_ism, lintersect);
+          int rc;
+          if (SPH) {
+            SphEmitOps<L3D> ops{T, M, ri, zj, k};
+            rc = emit_packet(M, f, lambda, A.frac_E_stars, A.frac_E_disk, A.prob_E_cell, ops, x, y, z, u, v, w,
+                             flag_star, flag_ism, lintersect);
+          } else {
+            CylEmitOps<L3D> ops{T, M, ri, zj, k};
+            rc = emit_packet(M, f, lambda, A.frac_E_stars, A.frac_E_disk, A.prob_E_cell, ops, x, y, z, u, v, w,
+                             flag_star, flag_ism, lintersect);
+          }
           if (rc) {
             *A.err = rc;
             st = S_DONE;
@@ -637,7 +645,7 @@ __device__ __forceinline__ void mono_body(const DevModel& M, const MonoArgs& A, 
       dep.on = false; dep.icell = 1; dep.phik = 1; dep.psup = 1; dep.l = 0.0;
       if (st == S_FLIGHT) {
         const int azj = zj < 0 ? -zj : zj;
-        const bool out = (ri == n_rad + 1) || ((azj == nz + 1) && (fabs(z) > M.zmaxmax));
+        const bool out = (ri == n_rad + 1) || (!SPH && (azj == nz + 1) && (fabs(z) > M.zmaxmax));   // (test_exit_grid_sph: the outer radius only)
         bool killed = false;
         if (star_key >= 0) {
           const int key = ri + (n_rad + 2) * ((zj + nz + 1) + (2 * nz + 3) * (k - 1));
@@ -670,7 +678,8 @@ __device__ __forceinline__ void mono_body(const DevModel& M, const MonoArgs& A, 
           if (!mirrored) {
             double x1, y1, z1, l;
             int ri1, zj1, k1;
-            MCGPU_CROSS<L3D>(T, M, x, y, z, u, v, w, inv_a, inv_w, ri, zj, k, x1, y1, z1, ri1, zj1, k1, l);
+            if (SPH) cross_cell_sph<L3D>(T, M, x, y, z, u, v, w, ri, zj, k, x1, y1, z1, ri1, zj1, k1, l);
+            else MCGPU_CROSS<L3D>(T, M, x, y, z, u, v, w, inv_a, inv_w, ri, zj, k, x1, y1, z1, ri1, zj1, k1, l);
             c_cross++;
             const double tau = l * opacity;
             if (tau > extr) {
@@ -686,7 +695,7 @@ __device__ __forceinline__ void mono_body(const DevModel& M, const MonoArgs& A, 
               x = x + lc * u;
               y = y + lc * v;
               z = z + lc * w;
-              if (L3D) index_cell<L3D>(T, M, x, y, z, ri, zj, k);
+              if (L3D && !SPH) index_cell<L3D>(T, M, x, y, z, ri, zj, k);   // (optical_depth.f90:162-165: lcylindrical only)
               st = S_INTERACT;
             } else {
               extr = extr - tau;
@@ -744,6 +753,13 @@ template <bool L3D, bool POLA, bool DARK, bool SCOUT, bool F32 = false>
 __global__ void __launch_bounds__(512) k_mono(const DevModel M, const MonoArgs A) {
   extern __shared__ double lds_raw[];
   mono_body<L3D, POLA, DARK, SCOUT, F32>(M, A, lds_raw);
+}
+
+// ... on a spherical grid (no dark zone there)
+template <bool L3D, bool POLA, bool SCOUT, bool F32 = false>
+__global__ void __launch_bounds__(512) k_mono_sph(const DevModel M, const MonoArgs A) {
+  extern __shared__ double lds_raw[];
+  mono_body<L3D, POLA, false, SCOUT, F32, true>(M, A, lds_raw);
 }
 
 // Stopping index of every active stream from this batch's hit flags: one wave per stream.

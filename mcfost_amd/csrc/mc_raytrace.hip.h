@@ -183,7 +183,8 @@ __device__ inline void rt1_integ_ray(const Lds& T, const DevModel& M, const RtAr
 #pragma unroll
   for (int t = 0; t < 8; ++t) S[t] = 0.0;
   int ri, zj, k;
-  if (!move_to_grid<L3D>(T, M, x, y, z, u0, v0, w0, ri, zj, k)) return;
+  const bool sph = M.grid_sph != 0;   // (the ray tracer picks the grid's operators at run time: not the hot path)
+  if (!(sph ? move_to_grid_sph<L3D>(T, M, x, y, z, u0, v0, w0, ri, zj, k) : move_to_grid<L3D>(T, M, x, y, z, u0, v0, w0, ri, zj, k))) return;
   const double a = u0 * u0 + v0 * v0;
   const double inv_a = (a > TINY_REAL) ? 1.0 / a : HUGE_REAL;
   const double inv_w = (fabs(w0) > TINY_REAL) ? 1.0 / w0 : copysign(HUGE_DP, w0);
@@ -196,11 +197,12 @@ __device__ inline void rt1_integ_ray(const Lds& T, const DevModel& M, const RtAr
   double tau = 0.0;
   for (long guard = 0; guard < 100000000L; ++guard) {
     const int azj = zj < 0 ? -zj : zj;
-    if ((ri == n_rad + 1) || ((azj == nz + 1) && (fabs(z) > M.zmaxmax))) break;  // test_exit_grid
+    if ((ri == n_rad + 1) || (!sph && (azj == nz + 1) && (fabs(z) > M.zmaxmax))) break;  // test_exit_grid
     if (star_key >= 0 && (ri + (n_rad + 2) * ((zj + nz + 1) + (2 * nz + 3) * (k - 1))) == star_key) break;
     double x1, y1, z1, l;
     int ri1, zj1, k1;
-    MCGPU_CROSS<L3D>(T, M, x, y, z, u0, v0, w0, inv_a, inv_w, ri, zj, k, x1, y1, z1, ri1, zj1, k1, l);
+    if (sph) cross_cell_sph<L3D>(T, M, x, y, z, u0, v0, w0, ri, zj, k, x1, y1, z1, ri1, zj1, k1, l);
+    else MCGPU_CROSS<L3D>(T, M, x, y, z, u0, v0, w0, inv_a, inv_w, ri, zj, k, x1, y1, z1, ri1, zj1, k1, l);
     if (is_real_cell<L3D>(n_rad, nz, ri, zj)) {
       const int ic = cell_index<L3D>(n_rad, nz, ri, zj, k);
       const size_t vrow = M.n_classes ? (size_t)M.cell_class[ic] * M.n_lambda + (A.lambda - 1) : 0;  // (lvariable_dust)
@@ -371,17 +373,20 @@ __device__ inline float optical_length_tot(const Lds& T, const DevModel& M, int 
                                            double u, double v, double w) {
   const int n_rad = M.n_rad, nz = M.nz;
   int ri, zj, k;
-  index_cell<L3D>(T, M, x, y, z, ri, zj, k);
+  const bool sph = M.grid_sph != 0;
+  if (sph) index_cell_sph<L3D>(T, M, x, y, z, ri, zj, k);
+  else index_cell<L3D>(T, M, x, y, z, ri, zj, k);
   const double a = u * u + v * v;
   const double inv_a = (a > TINY_REAL) ? 1.0 / a : HUGE_REAL;
   const double inv_w = (fabs(w) > TINY_REAL) ? 1.0 / w : copysign(HUGE_DP, w);
   double tau = 0.0;
   for (long guard = 0; guard < 100000000L; ++guard) {
     const int azj = zj < 0 ? -zj : zj;
-    if ((ri == n_rad + 1) || ((azj == nz + 1) && (fabs(z) > M.zmaxmax))) break;  // test_exit_grid
+    if ((ri == n_rad + 1) || (!sph && (azj == nz + 1) && (fabs(z) > M.zmaxmax))) break;  // test_exit_grid
     double x1, y1, z1, l;
     int ri1, zj1, k1;
-    MCGPU_CROSS<L3D>(T, M, x, y, z, u, v, w, inv_a, inv_w, ri, zj, k, x1, y1, z1, ri1, zj1, k1, l);
+    if (sph) cross_cell_sph<L3D>(T, M, x, y, z, u, v, w, ri, zj, k, x1, y1, z1, ri1, zj1, k1, l);
+    else MCGPU_CROSS<L3D>(T, M, x, y, z, u, v, w, inv_a, inv_w, ri, zj, k, x1, y1, z1, ri1, zj1, k1, l);
     if (is_real_cell<L3D>(n_rad, nz, ri, zj)) {
       const int ic = cell_index<L3D>(n_rad, nz, ri, zj, k);
       const double kap = M.n_classes ? M.v_kappa[(size_t)M.cell_class[ic] * M.n_lambda + (lambda - 1)] : T.kappa[lambda - 1];

@@ -1900,6 +1900,11 @@ static int launch_mono(mcgpu_ctx* ctx, const MonoArgs& A, int grid_blocks, int b
   if (ctx->voro) {
     if (f32) fn = pola ? (const void*)k_mono_voro<true, SCOUT, kCommit> : (const void*)k_mono_voro<false, SCOUT, kCommit>;
     else fn = pola ? (const void*)k_mono_voro<true, SCOUT, false> : (const void*)k_mono_voro<false, SCOUT, false>;
+  } else if (M.grid_sph) {
+#define PICKS(a, b) fn = f32 ? (const void*)k_mono_sph<a, b, SCOUT, kCommit> : (const void*)k_mono_sph<a, b, SCOUT, false>
+    if (l3d) { if (pola) PICKS(true, true); else PICKS(true, false); }
+    else { if (pola) PICKS(false, true); else PICKS(false, false); }
+#undef PICKS
   } else if (l3d) {
     if (pola) { if (dark) PICK(true, true, true); else PICK(true, true, false); }
     else { if (dark) PICK(true, false, true); else PICK(true, false, false); }
@@ -2164,7 +2169,7 @@ extern "C" int mcgpu_run_mono(mcgpu_ctx* ctx, const mcgpu_mono_opts* o, double f
   if (rt1 && !ctx->have_rt1) return fail(ctx, MCGPU_ERR_STATE, "rt1 deposits need mcgpu_set_rt1");
   if (rt2 && !ctx->have_rt2) return fail(ctx, MCGPU_ERR_STATE, "rt2 deposits need mcgpu_set_rt2");
   if (rt2 && (M.l3D || ctx->voro)) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "ray tracing method 2 is 2D only (radiation_field.f90:91)");
-  if (M.grid_sph) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "SED mode on a spherical grid is not supported yet");
+  if (M.grid_sph && (rt2 || M.n_classes)) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "SED mode on a spherical grid: one dust class, no ray tracing method 2");
   const int n_pos = ctx->have_rt1 ? ctx->n_lambda_pos : M.n_lambda;
   if (o->p_lambda < 1 || o->p_lambda > n_pos || o->p_lambda > M.n_lambda) return fail(ctx, MCGPU_ERR_ARG, "p_lambda out of range");
   // prob_E_cell = NULL: the table mcgpu_repartition_energie left on the device for this wavelength
@@ -2543,7 +2548,8 @@ static int rt1_prepare(mcgpu_ctx* ctx, const mcgpu_rt_opts* o, const float* tab_
                        const char* who) {
   int rc = ready(ctx);
   if (rc) return rc;
-  if (ctx->voro || ctx->M.grid_sph) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "RT1 ray tracing: cylindrical grids only");
+  if (ctx->voro) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "RT1 ray tracing: cylindrical and spherical grids");
+  if (ctx->M.grid_sph && J.method2) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "ray tracing method 2: 2D cylindrical grids");
   if (!o || !tab_RT_az || !Tdust) return fail(ctx, MCGPU_ERR_ARG, "RT1 ray tracing: null argument");
   if (!ctx->have_rt1 || (!ctx->d_xI && !J.method2))
     return fail(ctx, MCGPU_ERR_STATE, "RT1 ray tracing needs the xI_scatt of mcgpu_run_mono(rt1=1) or mcgpu_set_xI");
@@ -2779,7 +2785,7 @@ extern "C" int mcgpu_rt1_stars_map_sed(mcgpu_ctx* ctx, const mcgpu_rt_opts* o, c
   if (rc) return rc;
   if (!o || !tab_RT_az || !star_flux || !stars_flux) return fail(ctx, MCGPU_ERR_ARG, "mcgpu_rt1_stars_map_sed: null argument");
   const DevModel& M = ctx->M;
-  if (ctx->voro || M.grid_sph) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "stars map: cylindrical grids");
+  if (ctx->voro) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "stars map: cylindrical and spherical grids");
   if (!ctx->have_rt1) return fail(ctx, MCGPU_ERR_STATE, "stars map: set the observers first (mcgpu_set_rt1)");
   if (o->lambda < 1 || o->lambda > M.n_lambda) return fail(ctx, MCGPU_ERR_ARG, "mcgpu_rt1_stars_map_sed: bad option");
   HIPCHK(hipSetDevice(ctx->device));
@@ -2819,7 +2825,7 @@ extern "C" int mcgpu_rt1_stars_map_image(mcgpu_ctx* ctx, const mcgpu_rt_opts* o,
       !(map_size > 0.0) || !(zoom > 0.0) || n_mu < 0 || (n_mu > 0 && (n_mu < 2 || !mu_limb_darkening || !limb_darkening)))
     return fail(ctx, MCGPU_ERR_ARG, "mcgpu_rt1_stars_map_image: bad argument");
   const DevModel& M = ctx->M;
-  if (ctx->voro || M.grid_sph) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "stars map: cylindrical grids");
+  if (ctx->voro) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "stars map: cylindrical and spherical grids");
   if (!ctx->have_rt1) return fail(ctx, MCGPU_ERR_STATE, "stars map: set the observers first (mcgpu_set_rt1)");
   if (o->lambda < 1 || o->lambda > M.n_lambda || !(o->distance > 0.0)) return fail(ctx, MCGPU_ERR_ARG, "mcgpu_rt1_stars_map_image: bad option");
   HIPCHK(hipSetDevice(ctx->device));

@@ -1034,6 +1034,22 @@ static inline int grid_test_exit(const oracle_model *m, int icell, double x, dou
   if (m->grid_type == 2) return oracle_test_exit_grid_sph(m, icell);
   return oracle_test_exit_grid_cyl(m, icell, x, y, z);
 }
+/* ... the same table for the ray tracer (cylindrical and spherical grids) */
+static inline void grid_cross_cell(const oracle_model *m, double x0, double y0, double z0, double u, double v, double w, int icell,
+                                   int previous_cell, double *x1, double *y1, double *z1, int *next_cell, double *l,
+                                   double *l_contrib, double *l_void_before) {
+  if (m->grid_type == 2) oracle_cross_spherical_cell(m, x0, y0, z0, u, v, w, icell, previous_cell, x1, y1, z1, next_cell, l, l_contrib, l_void_before);
+  else oracle_cross_cylindrical_cell(m, x0, y0, z0, u, v, w, icell, previous_cell, x1, y1, z1, next_cell, l, l_contrib, l_void_before);
+}
+static inline void grid_move_to_grid(const oracle_model *m, double *x, double *y, double *z, double u, double v, double w, int *icell,
+                                     int *lintersect) {
+  if (m->grid_type == 2) oracle_move_to_grid_sph(m, x, y, z, u, v, w, icell, lintersect);
+  else oracle_move_to_grid_cyl(m, x, y, z, u, v, w, icell, lintersect);
+}
+static inline void grid_index_cell(const oracle_model *m, double x, double y, double z, int *icell) {
+  if (m->grid_type == 2) oracle_index_cell_sph(m, x, y, z, icell);
+  else oracle_index_cell_cyl(m, x, y, z, icell);
+}
 
 /* ------------------------------------------------------------------------ */
 /* Direction helpers                                                         */
@@ -2665,10 +2681,10 @@ static void rt1_integ_ray_dust(const oracle_model *m, int lam, double tau_dark_z
   for (long guard = 0; guard < 100000000L; ++guard) {
     const int ic = next_cell;
     const double xa = x1, ya = y1, za = z1;
-    if (oracle_test_exit_grid_cyl(m, ic, xa, ya, za)) break;
+    if (grid_test_exit(m, ic, xa, ya, za)) break;
     if (lis && ic == icell_star) break;
     double l, lc, lv;
-    oracle_cross_cylindrical_cell(m, xa, ya, za, u0, v0, w0, ic, 0, &x1, &y1, &z1, &next_cell, &l, &lc, &lv);
+    grid_cross_cell(m, xa, ya, za, u0, v0, w0, ic, 0, &x1, &y1, &z1, &next_cell, &l, &lc, &lv);
     if (ic <= nc) {
       const double kappa_ext = tab_kappa(m, ic, lam) * m->kappa_factor[ic - 1];
       const double dtau = lc * kappa_ext;
@@ -2736,7 +2752,7 @@ static double rt_photon_energy(const oracle_rt_opts *o) { /* (:661-663), SED / i
 static float optical_length_tot(const oracle_model *m, int lambda, double x, double y, double z, double u, double v,
                                 double w) {
   int icell, next_cell, previous_cell = 0;
-  oracle_index_cell_cyl(m, x, y, z, &icell);
+  grid_index_cell(m, x, y, z, &icell);
   next_cell = icell;
   double x1 = x, y1 = y, z1 = z, tau_tot = 0.0;
   int icell0 = 0;
@@ -2744,18 +2760,17 @@ static float optical_length_tot(const oracle_model *m, int lambda, double x, dou
     previous_cell = icell0;
     icell0 = next_cell;
     const double x0 = x1, y0 = y1, z0 = z1;
-    if (oracle_test_exit_grid_cyl(m, icell0, x0, y0, z0)) return (float)tau_tot;
+    if (grid_test_exit(m, icell0, x0, y0, z0)) return (float)tau_tot;
     const double opacity = (icell0 <= m->n_cells && icell0 >= 1) ? tab_kappa(m, icell0, lambda) * m->kappa_factor[icell0 - 1] : 0.0;
     double l, l_contrib, l_void;
-    oracle_cross_cylindrical_cell(m, x0, y0, z0, u, v, w, icell0, previous_cell, &x1, &y1, &z1, &next_cell, &l, &l_contrib,
-                                  &l_void);
+    grid_cross_cell(m, x0, y0, z0, u, v, w, icell0, previous_cell, &x1, &y1, &z1, &next_cell, &l, &l_contrib, &l_void);
     tau_tot += l_contrib * opacity;
   }
 }
 
 int oracle_stars_map_sed(const oracle_model *m, const oracle_rt_opts *o, uint64_t seed, const double *star_flux,
                          double *out) {
-  if (m->grid_type != 1) return 31;
+  if (m->grid_type == 3) return 31;
   enum { NXS = 10, NS = 21, N_RAY_SED = 1024 };
   const int nRT = m->RT_n_incl * m->RT_n_az;
   const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
@@ -3053,7 +3068,7 @@ static float interp_sp(const float *y, const float *x, int n, float xp) {
 int oracle_stars_map_image(const oracle_model *m, const oracle_rt_opts *o, uint64_t seed, const double *star_flux,
                            int npix_x, int npix_y, double map_size, double zoom, int n_mu, const float *mu_ld,
                            const float *ld, const float *pola_ld, double *map, double *star_position) {
-  if (m->grid_type != 1) return 31;
+  if (m->grid_type == 3) return 31;
   enum { NXS = 10, NS = 21, N_RAY_SED = 1024 };
   const int nRT = m->RT_n_incl * m->RT_n_az, n_maps = (n_mu > 0 && pola_ld) ? 3 : 1;
   const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
@@ -3191,7 +3206,7 @@ int oracle_dust_map_sed(const oracle_model *m, const oracle_rt_opts *o, const do
           double y0 = center[1] + r * sin(phi) * xpi[1] + r * cos(phi) * ypi[1];
           double z0 = center[2] + r * sin(phi) * xpi[2] + r * cos(phi) * ypi[2];
           int icell, lintersect;
-          oracle_move_to_grid_cyl(m, &x0, &y0, &z0, u0, v0, w0, &icell, &lintersect);
+          grid_move_to_grid(m, &x0, &y0, &z0, u0, v0, w0, &icell, &lintersect);
           if (!lintersect) continue;
           double S[8];
           rt1_integ_ray_dust(m, lam, o->tau_dark_zone_obs, xI, J_th, photon_energy, q, x0, y0, z0, u0, v0, w0, icell, S);
@@ -3258,7 +3273,7 @@ int oracle_dust_map_image(const oracle_model *m, const oracle_rt_opts *o, int np
                 double y0 = corner[1] + (si - 0.5) * sdx[1] + (sj - 0.5) * sdy[1];
                 double z0 = corner[2] + (si - 0.5) * sdx[2] + (sj - 0.5) * sdy[2];
                 int icell, lintersect;
-                oracle_move_to_grid_cyl(m, &x0, &y0, &z0, u0, v0, w0, &icell, &lintersect);
+                grid_move_to_grid(m, &x0, &y0, &z0, u0, v0, w0, &icell, &lintersect);
                 ++rays;
                 if (!lintersect) continue;
                 double R[8];

@@ -459,7 +459,10 @@ extern "C" int emu_run_mono(const oracle_model* m, const oracle_mono_opts* o, do
   A.inner_iters = 8; A.min_active = 0;
 #define MONO(sc_) do {                                                                     \
     if (voro) { if (pola) k_mono_voro<true, sc_>(M, A, G); else k_mono_voro<false, sc_>(M, A, G); }               \
-    else if (l3d) {                                                                            \
+    else if (M.grid_sph) {                                                                     \
+      if (l3d) { if (pola) k_mono_sph<true, true, sc_>(M, A); else k_mono_sph<true, false, sc_>(M, A); }            \
+      else { if (pola) k_mono_sph<false, true, sc_>(M, A); else k_mono_sph<false, false, sc_>(M, A); }              \
+    } else if (l3d) {                                                                            \
       if (pola) { if (dark) k_mono<true, true, true, sc_>(M, A); else k_mono<true, true, false, sc_>(M, A); }      \
       else { if (dark) k_mono<true, false, true, sc_>(M, A); else k_mono<true, false, false, sc_>(M, A); }         \
     } else {                                                                              \

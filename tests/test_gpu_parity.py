@@ -1131,3 +1131,80 @@ def test_rt2_deposits_parity():
     with pytest.raises(McgpuError):
         e.set_rt2()
     e.close()
+
+
+def test_sed_mode_on_spherical_grids():
+    """k_mono_sph (mono_body with spherical_grid.f90's operators), 2D and 3D: every stream stops at the oracle's packet, the
+    same SED bins, xI_scatt per cell; tolerances of the midplane cone's double root as in the thermal test
+    (test_kernel_emulation._check_spherical): a zero-length crossing more or less, sub-bins of the layer next to the cone
+    and (3D) the hemisphere's label compared summed."""
+    from helpers import sed_model, xI_close
+    for kw, lam in ((dict(), 5), (dict(lsepar_pola=False), 9), (dict(n_rad=10, nz=5, n_az=6, l3D=True), 4)):
+        cfg = M.small(grid_type=2, **kw)
+        m = sed_model(cfg, n_thermal=20000)
+        e, o = _engine(m, 1e5), _oracle(m, 1e5)
+        for rt1 in (False, True):
+            a = e.run_mono(lam, 12, seed=41, n_chunks=32, rt1=rt1)
+            b = o.run_mono(lam, 12, seed=41, n_chunks=32, rt1=rt1, n_threads=8)
+            ca, cb = a["counters"], b["counters"]
+            assert np.array_equal(a["n_sent_chunk"], b["n_sent_chunk"])
+            for k in cb:
+                if k == "crossings":
+                    assert abs(ca[k] - cb[k]) <= 3 + (3e-2 if cfg.l3D else 3e-4) * cb[k]
+                else:
+                    assert ca[k] == cb[k], k
+            assert np.array_equal(a["sed"][4], b["sed"][4])
+            assert np.allclose(a["sed"][0], b["sed"][0], rtol=1e-11, atol=1e-11)
+            if rt1:
+                pola = cfg.lsepar_pola and cfg.aniso_method == 1
+                rtol, atol_rel = (3e-5, 1e-6) if pola else (1e-6, 1e-8)
+                xa, xb = a["xI_scatt"], b["xI_scatt"]
+                scale = np.abs(xb).max()
+                assert scale > 0
+                if cfg.l3D:
+                    g = m.grid
+                    i, j, k = g["cell_map_i"][:m.n_cells], g["cell_map_j"][:m.n_cells], g["cell_map_k"][:m.n_cells]
+                    key = (i - 1) + g["n_rad"] * ((np.abs(j) - 1) + g["nz"] * (k - 1))
+                    ta, tb = xa.sum(axis=(3, 4)).reshape(m.n_cells, -1), xb.sum(axis=(3, 4)).reshape(m.n_cells, -1)
+                    fa = np.stack([np.bincount(key, weights=ta[:, q]) for q in range(ta.shape[1])], 1)
+                    fb = np.stack([np.bincount(key, weights=tb[:, q]) for q in range(tb.shape[1])], 1)
+                    assert np.allclose(fa, fb, rtol=rtol, atol=atol_rel * np.abs(fb).max())
+                else:
+                    assert np.allclose(xa.sum(axis=(3, 4)), xb.sum(axis=(3, 4)), rtol=rtol, atol=atol_rel * scale)
+                    xI_close(xa[cfg.n_rad:], xb[cfg.n_rad:], rtol=rtol, atol_rel=atol_rel)
+        e.close()
+
+
+def test_ray_tracer_on_spherical_grids():
+    """rt1_integ_ray / optical_length_tot with spherical_grid.f90's operators: the dust's SED (2D, 3D), an image, the stars'
+    SED and image -- the device against the oracle on the same xI_scatt (the layer next to the midplane cone blurred:
+    test_kernel_emulation._blur_midplane_layer says why)."""
+    from helpers import sed_model
+    from test_kernel_emulation import _blur_midplane_layer
+    for kw in (dict(RT_n_incl=3), dict(lsepar_pola=False), dict(n_rad=10, nz=5, n_az=6, l3D=True)):
+        cfg = M.small(grid_type=2, **kw)
+        m = sed_model(cfg, n_thermal=50000)
+        e, o = _engine(m, 1e5), _oracle(m, 1e5)
+        for lam in (3, 12):
+            a = e.run_mono(lam, 30, seed=20 + lam, n_chunks=32)
+            x, T = _blur_midplane_layer(m, a["xI_scatt"], m.extra["Tdust"])
+            e.set_xI(x)
+            ns, Ed = a["n_sent"][lam - 1], m.extra["E_disk"][lam - 1]
+            got, ms = e.dust_map_sed(lam, T, ns, Ed)
+            ref = o.dust_map_sed(lam, e.fetch_xI(), T, ns, Ed, n_threads=8)
+            assert (ref[:, 0] > 0).all() and ms > 0
+            assert np.allclose(got, ref, rtol=1e-9, atol=1e-13 * np.abs(ref).max()), np.abs(got / ref - 1).max()
+            flux = np.array([1.3])
+            want = o.stars_map_sed(lam, flux, seed=4)
+            have = e.stars_map_sed(lam, flux, seed=4)
+            assert np.allclose(have, want, rtol=2e-6) and (want > 0).all()
+        if not cfg.l3D:
+            got, n_rays, ms = e.dust_map_image(12, T, ns, Ed, 24, 24, 2.2 * cfg.rout, zoom=1.2, l_sym_ima=False, ang_disque=17.3)
+            ref, nr = o.dust_map_image(12, x, T, ns, Ed, 24, 24, 2.2 * cfg.rout, zoom=1.2, l_sym_ima=False, ang_disque=17.3, n_threads=8)
+            assert n_rays == nr and ref[0].max() > 0
+            assert np.allclose(got, ref, rtol=1e-9, atol=1e-13 * np.abs(ref).max())
+            rs = cfg.R_star * 0.00465047
+            want, wpos = o.stars_map_image(12, flux, 33, 33, 33 * rs / 6.0, seed=5)
+            have, hpos = e.stars_map_image(12, flux, 33, 33, 33 * rs / 6.0, seed=5)
+            assert np.array_equal(have != 0, want != 0) and np.allclose(have, want, rtol=2e-5, atol=1e-6 * np.abs(want).max())
+        e.close()

@@ -489,6 +489,40 @@ def test_emulated_rt1_dust_map(emu, kw):
         assert np.allclose(got, ref, rtol=1e-10, atol=1e-14 * np.abs(ref).max())
 
 
+def _blur_midplane_layer(m, xI, Tdust):
+    """Spherical grids: a ray through the midplane cone is one crossing or two (the double root ~1e-10 apart, kept or dropped
+    at the last ulp), so in the layer next to the cone the path's midpoint -- its sub-bin, and in 3D the hemisphere's
+    label -- is rounding noise in any build: make both irrelevant there."""
+    g, cfg = m.grid, m.cfg
+    xI, T = xI.copy(), np.array(Tdust, np.float32).copy()
+    j = np.asarray(g["cell_map_j"])[:m.n_cells]
+    lay = np.abs(j) == 1
+    xI[lay] = xI[lay].mean(axis=(3, 4), keepdims=True)
+    if cfg.l3D:
+        i, k = np.asarray(g["cell_map_i"])[:m.n_cells], np.asarray(g["cell_map_k"])[:m.n_cells]
+        up, dn = np.flatnonzero(j == 1), np.flatnonzero(j == -1)
+        assert np.array_equal(i[up], i[dn]) and np.array_equal(k[up], k[dn])
+        xI[up] = xI[dn] = 0.5 * (xI[up] + xI[dn])
+        T[up] = T[dn] = 0.5 * (T[up] + T[dn])
+    return xI, T
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(lsepar_pola=False), dict(l3D=True, n_az=4)])
+def test_emulated_rt1_dust_map_spherical(emu, kw):
+    """The ray tracer with spherical_grid.f90's operators (picked at run time in rt1_integ_ray / optical_length_tot)."""
+    cfg = M.small(**{**dict(grid_type=2, n_rad=10, nz=6, RT_n_incl=2), **kw})
+    m = sed_model(cfg, n_thermal=20000)
+    orc = Oracle(m, 1e5)
+    for lam, ang, sym in ((3, 0.0, True), (m.n_lambda - 6, 17.0, False)):
+        b = orc.run_mono(lam, 40, seed=5, n_chunks=4, rt1=True, n_threads=1)
+        xI, T = _blur_midplane_layer(m, b["xI_scatt"], m.extra["Tdust"])
+        args = (lam, xI, T, b["n_sent"][lam - 1], m.extra["E_disk"][lam - 1])
+        ref = orc.dust_map_sed(*args, ang_disque=ang, l_sym_ima=sym)
+        got = emu_dust_map(emu, orc, *args, ang_disque=ang, l_sym_ima=sym)
+        assert np.abs(ref[:, 0]).max() > 0
+        assert np.allclose(got, ref, rtol=1e-9, atol=1e-13 * np.abs(ref).max()), np.abs(got / ref - 1).max()
+
+
 def test_emulated_rt1_image(emu):
     """k_rt1_image (one pixel per wavefront, sub-pixel refinement) against the oracle's dust_map method 2: the same
     refinement decisions (same number of rays) and the same pixels."""
@@ -518,3 +552,37 @@ def test_emulated_rt1_image(emu):
         assert np.allclose(got, ref, rtol=1e-10, atol=1e-14 * np.abs(ref).max())
         if sym:
             assert not ref[..., npx // 2 + npx % 2:].any() and not got[..., npx // 2 + npx % 2:].any()
+
+
+def test_emulated_sed_mode_spherical(emu):
+    """SED mode on a spherical grid (k_mono_sph: mono_body with the operators of spherical_grid.f90), 2D and 3D, with and
+    without the rt1 deposits.  Tolerances as in _check_spherical: the midplane cone's double root is a last-ulp matter
+    (a zero-length crossing more or less), in 3D the hemisphere's label too (compared summed)."""
+    for kw, lam in ((dict(), 5), (dict(lsepar_pola=False), 9), (dict(n_rad=10, nz=5, n_az=6, l3D=True), 4)):
+        cfg = M.small(grid_type=2, **kw)
+        m = sed_model(cfg, n_thermal=20000)
+        orc = Oracle(m, 1e5)
+        for rt1 in (False, True):
+            a = emu_mono(emu, orc, lam, 6, 41, rt1=rt1)
+            b = orc.run_mono(lam, 6, seed=41, n_chunks=8, rt1=rt1, n_threads=4)
+            ca, cb = a["counters"], list(b["counters"].values())
+            assert np.array_equal(a["n_sent_chunk"], b["n_sent_chunk"])
+            assert ca[0] == cb[0] and ca[2:] == cb[2:] and abs(ca[1] - cb[1]) <= 3 + (3e-2 if cfg.l3D else 3e-4) * cb[1]
+            assert np.array_equal(a["sed"][4], b["sed"][4])
+            assert np.allclose(a["sed"][0], b["sed"][0], rtol=1e-12, atol=1e-12)
+            if rt1:
+                xa, xb = a["xI_scatt"], b["xI_scatt"]
+                assert np.abs(xb).max() > 0
+                if cfg.l3D:   # hemispheres (and the sub-bins that go with them) summed: cells (j, -j) of one (i, k)
+                    g = m.grid
+                    i, j, k = g["cell_map_i"][:m.n_cells], g["cell_map_j"][:m.n_cells], g["cell_map_k"][:m.n_cells]
+                    key = (i - 1) + g["n_rad"] * ((np.abs(j) - 1) + g["nz"] * (k - 1))
+                    fold = lambda x: np.stack([np.bincount(key, weights=x.reshape(m.n_cells, -1)[:, q]) for q in range(x[0].size)], 1)
+                    sa, sb = fold(xa.sum(axis=(3, 4), keepdims=True)), fold(xb.sum(axis=(3, 4), keepdims=True))
+                    assert np.allclose(sa, sb, rtol=1e-6, atol=1e-8 * np.abs(sb).max())
+                else:
+                    # the layer next to the midplane cone: a path through the cone is one crossing or two (the double
+                    # root), so its midpoint -- hence its sub-bin -- is a last-ulp matter there: the cell's total
+                    scale = np.abs(xb).max()
+                    assert np.allclose(xa.sum(axis=(3, 4)), xb.sum(axis=(3, 4)), rtol=1e-6, atol=1e-8 * scale)
+                    xI_close(xa[cfg.n_rad:], xb[cfg.n_rad:])
