@@ -248,9 +248,9 @@ __device__ inline void rt1_integ_ray(const Lds& T, const DevModel& M, const RtAr
   }
 }
 
-template <bool L3D, bool POLA>
-__global__ void __launch_bounds__(256) k_rt1_dust_map(const DevModel M, const RtArgs A) {
-  extern __shared__ double lds_raw[];
+// (Ray: the ray integration of the grid -- rt1_integ_ray, or rt1_integ_ray_voro of mc_raytrace_voronoi.hip.h)
+template <typename Ray>
+__device__ __forceinline__ void rt1_dust_map_body(const DevModel& M, const RtArgs& A, double* lds_raw, Ray integ_ray) {
   const Lds T = lds_carve(lds_raw, M, true);  // geometry, kappa, albedo: the SED-mode table set
   lds_stage_mono(T, M, 1);
   __syncthreads();
@@ -276,7 +276,7 @@ __global__ void __launch_bounds__(256) k_rt1_dust_map(const DevModel M, const Rt
     const double y = uvw[1] * A.l_far + r * sp * xpi[1] + r * cp * ypi[1];
     const double z = uvw[2] * A.l_far + r * sp * xpi[2] + r * cp * ypi[2];
     double S[8];
-    rt1_integ_ray<L3D, POLA>(T, M, A, q, x, y, z, -uvw[0], -uvw[1], -uvw[2], S);  // reverse propagation
+    integ_ray(T, q, x, y, z, -uvw[0], -uvw[1], -uvw[2], S);  // reverse propagation
     const double pix = taille_pix * A.pix_scale;
     for (int t = 0; t < A.N_type_flux; ++t) {
       double vsum = S[t] * pix * pix;
@@ -287,8 +287,15 @@ __global__ void __launch_bounds__(256) k_rt1_dust_map(const DevModel M, const Rt
 }
 
 template <bool L3D, bool POLA>
-__global__ void __launch_bounds__(256) k_rt1_image(const DevModel M, const RtArgs A) {
+__global__ void __launch_bounds__(256) k_rt1_dust_map(const DevModel M, const RtArgs A) {
   extern __shared__ double lds_raw[];
+  rt1_dust_map_body(M, A, lds_raw, [&](const Lds& T, int q, double x, double y, double z, double u, double v, double w, double* S) {
+    rt1_integ_ray<L3D, POLA>(T, M, A, q, x, y, z, u, v, w, S);
+  });
+}
+
+template <typename Ray>
+__device__ __forceinline__ void rt1_image_body(const DevModel& M, const RtArgs& A, double* lds_raw, Ray integ_ray) {
   const Lds T = lds_carve(lds_raw, M, true);  // geometry, kappa, albedo: the SED-mode table set
   lds_stage_mono(T, M, 1);
   __syncthreads();
@@ -328,7 +335,7 @@ __global__ void __launch_bounds__(256) k_rt1_image(const DevModel M, const RtArg
         const double y = corner[1] + (si - 0.5) * sdx[1] + (sj - 0.5) * sdy[1];
         const double z = corner[2] + (si - 0.5) * sdx[2] + (sj - 0.5) * sdy[2];
         double R[8];
-        rt1_integ_ray<L3D, POLA>(T, M, A, q, x, y, z, -uvw[0], -uvw[1], -uvw[2], R);
+        integ_ray(T, q, x, y, z, -uvw[0], -uvw[1], -uvw[2], R);
         rays++;
         for (int t = 0; t < 8; ++t) acc[t] += R[t];
       }
@@ -357,6 +364,14 @@ __global__ void __launch_bounds__(256) k_rt1_image(const DevModel M, const RtArg
     for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off);
     if (lane == 0) atomicAdd(A.n_rays, rays);
   }
+}
+
+template <bool L3D, bool POLA>
+__global__ void __launch_bounds__(256) k_rt1_image(const DevModel M, const RtArgs A) {
+  extern __shared__ double lds_raw[];
+  rt1_image_body(M, A, lds_raw, [&](const Lds& T, int q, double x, double y, double z, double u, double v, double w, double* S) {
+    rt1_integ_ray<L3D, POLA>(T, M, A, q, x, y, z, u, v, w, S);
+  });
 }
 
 // ---------------------------------------------------------------------------

@@ -21,6 +21,7 @@
 #include "mc_mono.hip.h"
 #include "mc_mono_voronoi.hip.h"
 #include "mc_raytrace.hip.h"
+#include "mc_raytrace_voronoi.hip.h"
 #include "mc_roles.hip.h"
 #include "mc_binned.hip.h"
 #include "mc_tail.hip.h"
@@ -2548,7 +2549,7 @@ static int rt1_prepare(mcgpu_ctx* ctx, const mcgpu_rt_opts* o, const float* tab_
                        const char* who) {
   int rc = ready(ctx);
   if (rc) return rc;
-  if (ctx->voro) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "RT1 ray tracing: cylindrical and spherical grids");
+  if (ctx->voro && (J.method2 || ctx->M.n_classes)) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "ray tracing on a Voronoi grid: method 1, one dust class");
   if (ctx->M.grid_sph && J.method2) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "ray tracing method 2: 2D cylindrical grids");
   if (!o || !tab_RT_az || !Tdust) return fail(ctx, MCGPU_ERR_ARG, "RT1 ray tracing: null argument");
   if (!ctx->have_rt1 || (!ctx->d_xI && !J.method2))
@@ -2604,8 +2605,16 @@ static int rt1_launch(mcgpu_ctx* ctx, const RtArgs& A, int blocks) {
     if (IMAGE) hipLaunchKernelGGL((k_rt1_image<a, b>), dim3(blocks), dim3(256), lds, ctx->stream, ctx->M, A);       \
     else hipLaunchKernelGGL((k_rt1_dust_map<a, b>), dim3(blocks), dim3(256), lds, ctx->stream, ctx->M, A);          \
   } while (0)
-  if (l3d) { if (pola) RT1_GO(true, true); else RT1_GO(true, false); }
+#define RT1_GO_VORO(b) do {                                                                                         \
+    const void* fn = IMAGE ? (const void*)k_rt1_image_voro<b> : (const void*)k_rt1_dust_map_voro<b>;                 \
+    HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                           \
+    if (IMAGE) hipLaunchKernelGGL((k_rt1_image_voro<b>), dim3(blocks), dim3(256), lds, ctx->stream, ctx->M, A, ctx->V);   \
+    else hipLaunchKernelGGL((k_rt1_dust_map_voro<b>), dim3(blocks), dim3(256), lds, ctx->stream, ctx->M, A, ctx->V);      \
+  } while (0)
+  if (ctx->voro) { if (pola) RT1_GO_VORO(true); else RT1_GO_VORO(false); }
+  else if (l3d) { if (pola) RT1_GO(true, true); else RT1_GO(true, false); }
   else { if (pola) RT1_GO(false, true); else RT1_GO(false, false); }
+#undef RT1_GO_VORO
 #undef RT1_GO
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));

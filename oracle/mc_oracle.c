@@ -1038,12 +1038,14 @@ static inline int grid_test_exit(const oracle_model *m, int icell, double x, dou
 static inline void grid_cross_cell(const oracle_model *m, double x0, double y0, double z0, double u, double v, double w, int icell,
                                    int previous_cell, double *x1, double *y1, double *z1, int *next_cell, double *l,
                                    double *l_contrib, double *l_void_before) {
-  if (m->grid_type == 2) oracle_cross_spherical_cell(m, x0, y0, z0, u, v, w, icell, previous_cell, x1, y1, z1, next_cell, l, l_contrib, l_void_before);
+  if (m->grid_type == 3) oracle_cross_voronoi_cell(m, x0, y0, z0, u, v, w, icell, previous_cell, x1, y1, z1, next_cell, l, l_contrib, l_void_before);
+  else if (m->grid_type == 2) oracle_cross_spherical_cell(m, x0, y0, z0, u, v, w, icell, previous_cell, x1, y1, z1, next_cell, l, l_contrib, l_void_before);
   else oracle_cross_cylindrical_cell(m, x0, y0, z0, u, v, w, icell, previous_cell, x1, y1, z1, next_cell, l, l_contrib, l_void_before);
 }
 static inline void grid_move_to_grid(const oracle_model *m, double *x, double *y, double *z, double u, double v, double w, int *icell,
                                      int *lintersect) {
-  if (m->grid_type == 2) oracle_move_to_grid_sph(m, x, y, z, u, v, w, icell, lintersect);
+  if (m->grid_type == 3) oracle_move_to_grid_voronoi(m, x, y, z, u, v, w, icell, lintersect);
+  else if (m->grid_type == 2) oracle_move_to_grid_sph(m, x, y, z, u, v, w, icell, lintersect);
   else oracle_move_to_grid_cyl(m, x, y, z, u, v, w, icell, lintersect);
 }
 static inline void grid_index_cell(const oracle_model *m, double x, double y, double z, int *icell) {
@@ -3167,7 +3169,7 @@ int oracle_stars_map_image(const oracle_model *m, const oracle_rt_opts *o, uint6
 
 int oracle_dust_map_sed(const oracle_model *m, const oracle_rt_opts *o, const double *xI, const float *Tdust,
                         double *out) {
-  if (m->grid_type == 3) return 31;
+  if (m->grid_type == 3 && (g_rt2 || m->p_n_cells)) return 31; /* Voronoi: method 1, one dust class */
   const int ntf = m->N_type_flux, nRT = m->RT_n_incl * m->RT_n_az;
   const int lam = o->lambda;
   memset(out, 0, sizeof(double) * (size_t)ntf * nRT);
@@ -3230,7 +3232,7 @@ int oracle_dust_map_sed(const oracle_model *m, const oracle_rt_opts *o, const do
  * iaz,type); with l_sym_ima only i <= npix_x/2 + mod(npix_x,2) is computed (the writer mirrors, output.f90:1007). */
 int oracle_dust_map_image(const oracle_model *m, const oracle_rt_opts *o, int npix_x, int npix_y, double map_size,
                           double zoom, const double *xI, const float *Tdust, double *image, int *n_rays) {
-  if (m->grid_type == 3) return 31;
+  if (m->grid_type == 3 && (g_rt2 || m->p_n_cells)) return 31;
   if (npix_x < 1 || npix_y < 1 || !(map_size > 0.0) || !(zoom > 0.0)) return 11;
   const int ntf = m->N_type_flux, nRT = m->RT_n_incl * m->RT_n_az;
   const int lam = o->lambda;

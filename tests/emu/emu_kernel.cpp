@@ -82,6 +82,7 @@ namespace mcgpu { double lds_raw[1 << 18]; }
 #include "../../mcfost_amd/csrc/mc_mono.hip.h"
 #include "../../mcfost_amd/csrc/mc_mono_voronoi.hip.h"
 #include "../../mcfost_amd/csrc/mc_raytrace.hip.h"
+#include "../../mcfost_amd/csrc/mc_raytrace_voronoi.hip.h"
 #include "../../mcfost_amd/csrc/mc_roles.hip.h"
 #include "../../mcfost_amd/csrc/mc_tail.hip.h"
 #include "../../oracle/mc_oracle.h"
@@ -556,13 +557,13 @@ struct EmuRt {
 
 extern "C" int emu_rt1_dust_map(const oracle_model* m, const oracle_rt_opts* o, const double* xI, const float* Tdust,
                                 double* out) {
-  if (m->grid_type == 3) return 31;
   EmuRt E(m, o, xI, Tdust);
   const int ntf = m->N_type_flux;
   memset(out, 0, sizeof(double) * (size_t)E.A.nRT * ntf);
   E.A.out = out;
   const bool pola = ntf == 4 || ntf == 8;
-  if (m->l3D) { if (pola) k_rt1_dust_map<true, true>(E.cv.M, E.A); else k_rt1_dust_map<true, false>(E.cv.M, E.A); }
+  if (E.cv.voro) { if (pola) k_rt1_dust_map_voro<true>(E.cv.M, E.A, E.cv.G); else k_rt1_dust_map_voro<false>(E.cv.M, E.A, E.cv.G); }
+  else if (m->l3D) { if (pola) k_rt1_dust_map<true, true>(E.cv.M, E.A); else k_rt1_dust_map<true, false>(E.cv.M, E.A); }
   else { if (pola) k_rt1_dust_map<false, true>(E.cv.M, E.A); else k_rt1_dust_map<false, false>(E.cv.M, E.A); }
   return 0;
 }
@@ -617,7 +618,6 @@ extern "C" int emu_stars_map_sed(const oracle_model* m, const oracle_rt_opts* o,
 
 extern "C" int emu_rt1_image(const oracle_model* m, const oracle_rt_opts* o, int npix_x, int npix_y, double map_size,
                              double zoom, const double* xI, const float* Tdust, double* image, int* n_rays) {
-  if (m->grid_type == 3) return 31;
   EmuRt E(m, o, xI, Tdust);
   const int ntf = m->N_type_flux;
   memset(image, 0, sizeof(double) * (size_t)E.A.nRT * ntf * npix_x * npix_y);
@@ -627,7 +627,8 @@ extern "C" int emu_rt1_image(const oracle_model* m, const oracle_rt_opts* o, int
   E.A.taille_pix = (map_size / zoom) / (double)(npix_x > npix_y ? npix_x : npix_y);
   E.A.image = image; E.A.n_rays = &rays;
   const bool pola = ntf == 4 || ntf == 8;
-  if (m->l3D) { if (pola) k_rt1_image<true, true>(E.cv.M, E.A); else k_rt1_image<true, false>(E.cv.M, E.A); }
+  if (E.cv.voro) { if (pola) k_rt1_image_voro<true>(E.cv.M, E.A, E.cv.G); else k_rt1_image_voro<false>(E.cv.M, E.A, E.cv.G); }
+  else if (m->l3D) { if (pola) k_rt1_image<true, true>(E.cv.M, E.A); else k_rt1_image<true, false>(E.cv.M, E.A); }
   else { if (pola) k_rt1_image<false, true>(E.cv.M, E.A); else k_rt1_image<false, false>(E.cv.M, E.A); }
   if (n_rays) *n_rays = (int)rays;
   return 0;

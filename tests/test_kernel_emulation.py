@@ -30,11 +30,12 @@ DEV5 = os.path.join(os.path.dirname(HERE), "mcfost_amd", "csrc", "mc_roles.hip.h
 DEV6 = os.path.join(os.path.dirname(HERE), "mcfost_amd", "csrc", "mc_raytrace.hip.h")
 DEV7 = os.path.join(os.path.dirname(HERE), "mcfost_amd", "csrc", "mc_binned.hip.h")
 DEV8 = os.path.join(os.path.dirname(HERE), "mcfost_amd", "csrc", "mc_tail.hip.h")
+DEV9 = os.path.join(os.path.dirname(HERE), "mcfost_amd", "csrc", "mc_raytrace_voronoi.hip.h")
 
 
 @pytest.fixture(scope="module")
 def emu():
-    if (not os.path.exists(LIB)) or os.path.getmtime(LIB) < max(os.path.getmtime(SRC), os.path.getmtime(DEV), os.path.getmtime(DEV2), os.path.getmtime(DEV3), os.path.getmtime(DEV4), os.path.getmtime(DEV5), os.path.getmtime(DEV6), os.path.getmtime(DEV7), os.path.getmtime(DEV8)):
+    if (not os.path.exists(LIB)) or os.path.getmtime(LIB) < max(os.path.getmtime(SRC), os.path.getmtime(DEV), os.path.getmtime(DEV2), os.path.getmtime(DEV3), os.path.getmtime(DEV4), os.path.getmtime(DEV5), os.path.getmtime(DEV6), os.path.getmtime(DEV7), os.path.getmtime(DEV8), os.path.getmtime(DEV9)):
         fma = ["-mfma"] if "fma" in open("/proc/cpuinfo").read() else []
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=fast"] + fma +
                               ["-o", LIB, SRC])
@@ -521,6 +522,39 @@ def test_emulated_rt1_dust_map_spherical(emu, kw):
         got = emu_dust_map(emu, orc, *args, ang_disque=ang, l_sym_ima=sym)
         assert np.abs(ref[:, 0]).max() > 0
         assert np.allclose(got, ref, rtol=1e-9, atol=1e-13 * np.abs(ref).max()), np.abs(got / ref - 1).max()
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(lsepar_pola=False)])
+def test_emulated_rt1_on_a_voronoi_grid(emu, kw):
+    """The ray tracer on a Voronoi grid (mc_raytrace_voronoi.hip.h: move_to_grid_Voronoi, cross_Voronoi_cell with
+    previous_cell = 0 as integ_ray_dust has it, cut cells, the star's site) against the oracle: SED sampling and an image."""
+    from oracle.binding import _RtOpts
+    cfg = M.small(RT_n_incl=2, **kw)
+    m = sed_model(cfg, voronoi_sites=1200, n_thermal=30000)
+    orc = Oracle(m, 1e5)
+    for lam, ang, sym in ((3, 0.0, True), (m.n_lambda - 6, 17.0, False)):
+        b = orc.run_mono(lam, 40, seed=5, n_chunks=4, rt1=True, n_threads=1)
+        args = (lam, b["xI_scatt"], m.extra["Tdust"], b["n_sent"][lam - 1], m.extra["E_disk"][lam - 1])
+        ref = orc.dust_map_sed(*args, ang_disque=ang, l_sym_ima=sym)
+        got = emu_dust_map(emu, orc, *args, ang_disque=ang, l_sym_ima=sym)
+        assert np.abs(ref[:, 0]).max() > 0
+        assert np.allclose(got, ref, rtol=1e-9, atol=1e-13 * np.abs(ref).max()), np.abs(got / ref - 1).max()
+    lam = 9
+    b = orc.run_mono(lam, 10 ** 9, seed=5, n_chunks=4, n_phot_lim=300.0, rt1=True, n_threads=1)
+    xI, T = b["xI_scatt"], np.ascontiguousarray(m.extra["Tdust"], np.float32)
+    az = np.ascontiguousarray(m.rt["tab_RT_az"], np.float32)
+    ns, Ed = b["n_sent"][lam - 1], m.extra["E_disk"][lam - 1]
+    npx, npy = 9, 9
+    ref, nr = orc.dust_map_image(lam, xI, T, ns, Ed, npx, npy, 2.2 * cfg.rout, zoom=1.5, ang_disque=17.3, l_sym_ima=False)
+    o = _RtOpts(int(lam), float(m.lam[lam - 1]), float(m.E_stars[lam - 1] + Ed), float(ns), float(cfg.distance),
+                17.3, 0, 100.0, float(cfg.rin), float(cfg.rout), _p(az, C.c_float), 1)
+    got = np.zeros_like(ref)
+    n_rays = C.c_int(0)
+    rc = emu.emu_rt1_image(C.byref(orc.cm), C.byref(o), C.c_int(npx), C.c_int(npy), C.c_double(2.2 * cfg.rout),
+                           C.c_double(1.5), _p(np.ascontiguousarray(xI, np.float64), C.c_double), _p(T, C.c_float),
+                           _p(got, C.c_double), C.byref(n_rays))
+    assert rc == 0 and n_rays.value == nr and ref[0].max() > 0
+    assert np.allclose(got, ref, rtol=1e-9, atol=1e-13 * np.abs(ref).max())
 
 
 def test_emulated_rt1_image(emu):
