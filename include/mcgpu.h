@@ -396,7 +396,7 @@ int mcgpu_repartition_energie(mcgpu_ctx *ctx, int lambda, double wl_um, double E
  * n_sent_chunk[n_chunks] (may be NULL) returns the packets each stream sent; their sum is
  * what the call added to n_sent(lambda) = n_phot_envoyes(lambda,:).  sed, n_sent and the
  * counters are read back with mcgpu_fetch, xI_scatt with mcgpu_fetch_xI.
- * Grids: cylindrical, spherical (one dust class; rt1 = 0 or 1) and Voronoi (one dust class).  Scattering method 1 is
+ * Grids: cylindrical, spherical (one dust class; rt1 = 0 or 1) and Voronoi.  Scattering method 1 is
  * refused (the reference forces method 2 with ray tracing, init_mcfost.f90:1659).
  */
 int mcgpu_run_mono(mcgpu_ctx *ctx, const mcgpu_mono_opts *opts,
@@ -440,8 +440,8 @@ int mcgpu_device_xI(mcgpu_ctx *ctx, void **xI_dev, uint64_t *n_values);
  * wavelength left on the device (after the all-reduce on several GPUs).
  * The stellar term (compute_stars_map, :1603-1895): mcgpu_rt1_stars_map_sed below.
  * Cylindrical and spherical grids (the ray integration picks the operators of the grid at run time) and Voronoi grids
- * (mcgpu_rt1_dust_map and mcgpu_rt1_image: move_to_grid_Voronoi + cross_Voronoi_cell; one dust class; the stars' maps
- * are not built there).
+ * (mcgpu_rt1_dust_map and mcgpu_rt1_image: move_to_grid_Voronoi + cross_Voronoi_cell; the stars' maps are not built
+ * there).
  * ------------------------------------------------------------------------ */
 typedef struct {
   int lambda;               /* 1-based wavelength index                                   */
@@ -568,7 +568,7 @@ int mcgpu_probe_packet_rand(mcgpu_ctx *ctx, uint64_t seed, uint64_t packet,
  * mcgpu_rt1_image, mcgpu_rt1_stars_map_sed), mcgpu_define_dark_zone, the diffusion fill and the random walk (mcgpu_set_mrw
  * with one row of tables per class) read per class too.
  * Grids: cylindrical (every path above) and Voronoi (the thermal step, with or without the random walk:
- * k_thermal_voro_var; mcgpu_run_mono refuses classes there); not spherical.
+ * k_thermal_voro_var; mcgpu_run_mono, mcgpu_repartition_energie, mcgpu_rt1_dust_map / _image); not spherical.
  * p_n_cells = 0: off.  log_Qcool and kdB_dT_CDF may both be NULL (see mcgpu_init_reemission).
  */
 int mcgpu_set_variable_dust(mcgpu_ctx *ctx, int p_n_cells, const int *p_icell, const double *kappa,

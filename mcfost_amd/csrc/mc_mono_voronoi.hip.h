@@ -28,6 +28,8 @@ __device__ __forceinline__ void mono_body_voro(const DevModel& M, const MonoArgs
   unsigned int pk_cross = 0;
   unsigned long long pk_next = 0, pk_end = 0, my_item = 0;
   float tau_rand = 0.0f;
+  const bool var = M.n_classes != 0;   // lvariable_dust: the tables of the cell's class, as in mono_body
+  const int na1 = M.nang + 1;
 
   for (;;) {
     if (st == S_EXITED) {
@@ -92,14 +94,17 @@ __device__ __forceinline__ void mono_body_voro(const DevModel& M, const MonoArgs
       float g[8];
       rng.interaction_event(g);
       tau_rand = g[5];
-      if (mono_attenuate<POLA>(T, lambda, S)) {
+      const int cls = var ? M.cell_class[icell - 1] : -1;
+      const Lds Tc = var ? class_tables(T, M, cls) : T;
+      if (mono_attenuate<POLA>(Tc, lambda, S)) {
         c_abs++;
         st = S_EMIT;
       } else {
         double u1, v1, w1;
         int lam = lambda;
-        interact<POLA>(T, M, g, lam, u, v, w, u1, v1, w1, S, flag_star, flag_scatt, c_scatt, c_abs,
-                       []() { return 0.0; }, M.volume, true, nullptr, 0);  // T.prob = column p_lambda
+        const float* prob_c = (var && M.v_scatt) ? M.v_prob + ((size_t)cls * M.n_lambda + (A.p_lambda - 1)) * na1 : nullptr;
+        interact<POLA>(Tc, M, g, lam, u, v, w, u1, v1, w1, S, flag_star, flag_scatt, c_scatt, c_abs,
+                       []() { return 0.0; }, M.volume, true, prob_c, 0, (var && M.v_scatt) ? cls : -1);  // T.prob = column p_lambda
         u = u1; v = v1; w = w1;
         st = S_NEWFLIGHT;
       }
@@ -134,7 +139,7 @@ __device__ __forceinline__ void mono_body_voro(const DevModel& M, const MonoArgs
           st = S_EMIT;
         } else {
           const VoroCell C = G.cell[icell - 1];
-          const double opacity = T.kappa[lambda - 1] * C.kf;
+          const double opacity = (var ? M.v_kappa[(size_t)M.cell_class[icell - 1] * M.n_lambda + (lambda - 1)] : T.kappa[lambda - 1]) * C.kf;
           double x1, y1, z1, l, l_contrib, l_void;
           int next;
           voro_cross_cell(G, M, C, x, y, z, u, v, w, icell, prev_cell, x1, y1, z1, next, l, l_contrib, l_void);

@@ -28,11 +28,12 @@ __device__ inline void rt1_integ_ray_voro(const Lds& T, const DevModel& M, const
     voro_cross_cell(G, M, C, x, y, z, u0, v0, w0, icell, 0, x1, y1, z1, next, l, l_contrib, l_void);  // (previous_cell = 0, :1393)
     if (icell <= M.n_cells) {
       const int ic = icell - 1;
-      const double kappa_ext = T.kappa[A.lambda - 1] * C.kf;
+      const size_t vrow = M.n_classes ? (size_t)M.cell_class[ic] * M.n_lambda + (A.lambda - 1) : 0;  // (lvariable_dust)
+      const double kappa_ext = (M.n_classes ? M.v_kappa[vrow] : T.kappa[A.lambda - 1]) * C.kf;
       const double dtau = l_contrib * kappa_ext;
       if (kappa_ext > TINY_DP) {
         const double factor = A.photon_energy / M.volume[ic] * A.n_az_rt * A.n_theta_rt;
-        const double kappa_sca = kappa_ext * (double)T.albedo[A.lambda - 1];
+        const double kappa_sca = kappa_ext * (double)(M.n_classes ? M.v_albedo[vrow] : T.albedo[A.lambda - 1]);
         const size_t bin = (size_t)ic * A.n_theta_rt * A.n_az_rt;
         double rec[XI_LINE];
         if (A.xI_f32) {

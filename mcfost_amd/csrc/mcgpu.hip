@@ -2160,7 +2160,6 @@ extern "C" int mcgpu_run_mono(mcgpu_ctx* ctx, const mcgpu_mono_opts* o, double f
       return fail(ctx, MCGPU_ERR_STATE, "SED mode with variable dust needs prob_s11_pos per wavelength: set the scattering tables with p_lambda_fixed = 0");
     if (!M.v_scatt) return fail(ctx, MCGPU_ERR_STATE, "SED mode with variable dust needs the per-class scattering tables");
     if (o->rt1 == 1 && !M.v_s11) return fail(ctx, MCGPU_ERR_STATE, "rt1 deposits with variable dust need tab_s11_pos per class (mcgpu_opacity or mcgpu_set_variable_dust_s11)");
-    if (ctx->voro) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "SED mode with variable dust: cylindrical grids only");
     if (M.m1) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "scattering method 1 is for the thermal step (ray tracing forces method 2, init_mcfost.f90:1659)");
   }
   if (o->lambda < 1 || o->lambda > M.n_lambda || o->n_chunks < 1 || o->n_chunks > (1 << 22) || o->capt_sup < 1 ||
@@ -2549,7 +2548,7 @@ static int rt1_prepare(mcgpu_ctx* ctx, const mcgpu_rt_opts* o, const float* tab_
                        const char* who) {
   int rc = ready(ctx);
   if (rc) return rc;
-  if (ctx->voro && (J.method2 || ctx->M.n_classes)) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "ray tracing on a Voronoi grid: method 1, one dust class");
+  if (ctx->voro && J.method2) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "ray tracing on a Voronoi grid: method 1");
   if (ctx->M.grid_sph && J.method2) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "ray tracing method 2: 2D cylindrical grids");
   if (!o || !tab_RT_az || !Tdust) return fail(ctx, MCGPU_ERR_ARG, "RT1 ray tracing: null argument");
   if (!ctx->have_rt1 || (!ctx->d_xI && !J.method2))

@@ -763,6 +763,8 @@ def init_variable_dust(m: "Model", n_classes: int = 0, slope: float = 0.15, iden
                 ("prob_s11_pos", "s12_o_s11", "s22_o_s11", "s33_o_s11", "s34_o_s11", "s44_o_s11")}
         out = {k: np.zeros((nl, nc, na1), f32) for k in base}
         gtab = np.zeros((nl, nc), f32)
+        s11tab = np.zeros((nl, nc, na1), f32)     # tab_s11_pos per class: the phase function of the rt1 deposits
+        base_s11 = np.asarray(m.tab_s11_pos, f32).reshape(nl, na1) if m.tab_s11_pos is not None else None
         for c in range(nc):
             depth = 0.0 if identical else 1.0 - (c + 0.5) / nc
             g_c = np.clip(np.asarray(m.tab_g_pos, f64) + 0.15 * depth, -0.9, 0.9)
@@ -770,15 +772,20 @@ def init_variable_dust(m: "Model", n_classes: int = 0, slope: float = 0.15, iden
             for l in range(nl):
                 if identical:
                     out["prob_s11_pos"][l, c] = base["prob_s11_pos"][l]
+                    if base_s11 is not None:
+                        s11tab[l, c] = base_s11[l]
                 else:
                     s11 = (1 - g_c[l] ** 2) / (1 + g_c[l] ** 2 - 2 * g_c[l] * mu) ** 1.5
                     k_sca = kappa[l, c] * float(alb[l, c])
                     norm = float(np.sum(s11[1:NANG_SCATT] * np.sin(th[1:NANG_SCATT]) * dtheta))
                     out["prob_s11_pos"][l, c] = scattering_cdf(s11 * (k_sca / norm) * 0.97, k_sca)
+                    s11tab[l, c] = (s11 * (k_sca / norm) * 0.97).astype(f32)
             for k in ("s12_o_s11", "s22_o_s11", "s33_o_s11", "s34_o_s11", "s44_o_s11"):
                 out[k][:, c, :] = base[k] * (f32(1.0 - 0.3 * depth) if k in ("s12_o_s11", "s34_o_s11") else f32(1.0))
         m.variable_dust.update({k: v.reshape(-1) for k, v in out.items()})
         m.variable_dust["tab_g_pos"] = gtab.reshape(-1)
+        if base_s11 is not None:
+            m.variable_dust["tab_s11_pos"] = s11tab.reshape(-1)
     return m.variable_dust
 
 

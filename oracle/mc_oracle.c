@@ -3169,7 +3169,7 @@ int oracle_stars_map_image(const oracle_model *m, const oracle_rt_opts *o, uint6
 
 int oracle_dust_map_sed(const oracle_model *m, const oracle_rt_opts *o, const double *xI, const float *Tdust,
                         double *out) {
-  if (m->grid_type == 3 && (g_rt2 || m->p_n_cells)) return 31; /* Voronoi: method 1, one dust class */
+  if (m->grid_type == 3 && g_rt2) return 31; /* Voronoi: method 1 */
   const int ntf = m->N_type_flux, nRT = m->RT_n_incl * m->RT_n_az;
   const int lam = o->lambda;
   memset(out, 0, sizeof(double) * (size_t)ntf * nRT);
@@ -3232,7 +3232,7 @@ int oracle_dust_map_sed(const oracle_model *m, const oracle_rt_opts *o, const do
  * iaz,type); with l_sym_ima only i <= npix_x/2 + mod(npix_x,2) is computed (the writer mirrors, output.f90:1007). */
 int oracle_dust_map_image(const oracle_model *m, const oracle_rt_opts *o, int npix_x, int npix_y, double map_size,
                           double zoom, const double *xI, const float *Tdust, double *image, int *n_rays) {
-  if (m->grid_type == 3 && (g_rt2 || m->p_n_cells)) return 31;
+  if (m->grid_type == 3 && g_rt2) return 31;
   if (npix_x < 1 || npix_y < 1 || !(map_size > 0.0) || !(zoom > 0.0)) return 11;
   const int ntf = m->N_type_flux, nRT = m->RT_n_incl * m->RT_n_az;
   const int lam = o->lambda;

@@ -95,7 +95,7 @@ struct Conv {
   VoroGrid G;
   bool voro;
   std::vector<double> ch, sx, ct, vk, vka, kfpad;
-  std::vector<float> val, vsc[7];
+  std::vector<float> val, vsc[8];
   std::vector<int> sc, vcls;
   std::vector<VoroCell> vcell;
   std::vector<VoroNb> vnb;
@@ -198,6 +198,7 @@ struct Conv {
           for (int l = 0; l < nl; ++l) vsc[6][(size_t)c * nl + l] = m->v_tab_g_pos[c + (size_t)nc * l];
         M.v_g = vsc[6].data();
         M.v_scatt = 1;
+        if (m->v_tab_s11_pos) M.v_s11 = relay(m->v_tab_s11_pos, nl, vsc[7]);   // (mcgpu_set_variable_dust_s11)
       }
     }
   }

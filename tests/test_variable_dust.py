@@ -177,3 +177,69 @@ def test_device_identical_classes_and_live_statistics():
     with pytest.raises(McgpuError):
         e2.run_mono(3, 5, seed=1, n_chunks=4, rt1=False)
     e2.close()
+
+
+def voronoi_settled_sed(**kw):
+    """voronoi_settled with the SED step's tables (the emission tables of a temperature step of the oracle)."""
+    m = M.build_voronoi_model(M.small(**kw), 1200, seed=3)
+    m.p_lambda_fixed = 0            # SED mode: p_lambda = lambda, every wavelength its own cumulative table
+    M.init_variable_dust(m)
+    orc = Oracle(m, 30000)
+    T = orc.temp_finale(orc.run_thermal(30000, seed=3, n_threads=1)["E_abs"])
+    M.repartition_energie(m, T)
+    m.extra["Tdust"] = T
+    return m
+
+
+@pytest.mark.parametrize("kw", [dict(RT_n_incl=2), dict(lsepar_pola=False)])
+def test_emulated_sed_mode_and_ray_tracer_on_voronoi_classes(emu, kw):   # noqa: F811
+    """k_mono_voro and rt1_integ_ray_voro with dust classes: albedo, opacity, cumulative table, tab_s11_pos and Mueller ratios
+    of the crossed cell's class."""
+    from test_kernel_emulation import emu_mono, emu_dust_map
+    m = voronoi_settled_sed(**kw)
+    orc = Oracle(m, 1e5)
+    for lam in (3, 12):
+        a = emu_mono(emu, orc, lam, 6, 40 + lam)
+        b = orc.run_mono(lam, 6, seed=40 + lam, n_chunks=8, rt1=True, n_threads=4)
+        assert np.array_equal(a["n_sent_chunk"], b["n_sent_chunk"]) and a["counters"] == list(b["counters"].values())
+        assert np.array_equal(a["sed"][4], b["sed"][4]) and np.allclose(a["sed"][0], b["sed"][0], rtol=1e-12, atol=1e-12)
+        pola = m.cfg.lsepar_pola and m.cfg.aniso_method == 1
+        sc = np.abs(b["xI_scatt"]).max()
+        assert sc > 0 and np.allclose(a["xI_scatt"], b["xI_scatt"], rtol=3e-5 if pola else 1e-6, atol=(1e-6 if pola else 1e-8) * sc)
+        args = (lam, b["xI_scatt"], m.extra["Tdust"], b["n_sent"][lam - 1], m.extra["E_disk"][lam - 1])
+        ref = orc.dust_map_sed(*args)
+        got = emu_dust_map(emu, orc, *args)
+        assert np.abs(ref[:, 0]).max() > 0
+        assert np.allclose(got, ref, rtol=1e-9, atol=1e-13 * np.abs(ref).max())
+    # the classes matter: the single-class run of the same grid sends other packets
+    m1 = M.build_voronoi_model(M.small(**kw), 1200, seed=3)
+    m1.frac_E_stars, m1.frac_E_disk, m1.prob_E_cell = m.frac_E_stars, m.frac_E_disk, m.prob_E_cell
+    c = Oracle(m1, 1e5).run_mono(12, 6, seed=52, n_chunks=8, rt1=False, n_threads=4)
+    assert c["counters"] != b["counters"]
+
+
+@pytest.mark.gpu
+def test_device_sed_mode_and_ray_tracer_on_voronoi_classes():
+    """The SED step and the ray-traced SED of a Voronoi grid with dust classes, on the device, against the oracle."""
+    from mcfost_amd.engine import Engine
+    for kw in (dict(RT_n_incl=2), dict(lsepar_pola=False)):
+        m = voronoi_settled_sed(**kw)
+        e, o = Engine(m, 1e5), Oracle(m, 1e5)
+        for lam in (3, 12):
+            a = e.run_mono(lam, 30, seed=40 + lam, n_chunks=32)
+            b = o.run_mono(lam, 30, seed=40 + lam, n_chunks=32, n_threads=8)
+            assert np.array_equal(a["n_sent_chunk"], b["n_sent_chunk"]) and a["counters"] == b["counters"]
+            assert np.array_equal(a["sed"][4], b["sed"][4]) and np.allclose(a["sed"][0], b["sed"][0], rtol=1e-11, atol=1e-11)
+            pola = m.cfg.lsepar_pola and m.cfg.aniso_method == 1
+            sc = np.abs(b["xI_scatt"]).max()
+            assert sc > 0 and np.allclose(a["xI_scatt"], b["xI_scatt"], rtol=3e-5 if pola else 1e-6, atol=(1e-6 if pola else 1e-8) * sc)
+            ns, Ed = a["n_sent"][lam - 1], m.extra["E_disk"][lam - 1]
+            got, ms = e.dust_map_sed(lam, m.extra["Tdust"], ns, Ed)
+            ref = o.dust_map_sed(lam, e.fetch_xI(), m.extra["Tdust"], ns, Ed, n_threads=8)
+            assert (ref[:, 0] > 0).all()
+            assert np.allclose(got, ref, rtol=1e-9, atol=1e-13 * np.abs(ref).max()), np.abs(got / ref - 1).max()
+            d = e.repartition_energie(lam, m.extra["Tdust"])
+            r = o.repartition_energie(lam, m.extra["Tdust"])
+            assert np.isclose(d["frac_E_stars"], r["frac_E_stars"], rtol=1e-12)
+            assert np.allclose(d["prob_E_cell"], r["prob_E_cell"], rtol=1e-12, atol=1e-15)
+        e.close()
