@@ -440,8 +440,7 @@ int mcgpu_device_xI(mcgpu_ctx *ctx, void **xI_dev, uint64_t *n_values);
  * wavelength left on the device (after the all-reduce on several GPUs).
  * The stellar term (compute_stars_map, :1603-1895): mcgpu_rt1_stars_map_sed below.
  * Cylindrical and spherical grids (the ray integration picks the operators of the grid at run time) and Voronoi grids
- * (mcgpu_rt1_dust_map and mcgpu_rt1_image: move_to_grid_Voronoi + cross_Voronoi_cell; the stars' maps are not built
- * there).
+ * (move_to_grid_Voronoi + cross_Voronoi_cell; the stars' maps start from index_cell_voronoi of the point of the disc).
  * ------------------------------------------------------------------------ */
 typedef struct {
   int lambda;               /* 1-based wavelength index                                   */

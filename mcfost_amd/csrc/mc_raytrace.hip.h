@@ -13,6 +13,7 @@
 // The stellar term (compute_stars_map: 1024 random rays per star on the host) is not part of these kernels.
 #pragma once
 #include "mc_mono.hip.h"
+#include "mc_voronoi.hip.h"
 
 namespace mcgpu {
 
@@ -31,6 +32,7 @@ struct RtArgs {
   double taille_pix;                                            // AU
   double* image;                                                // [N_type_flux][RT_n_az][RT_n_incl][npix_y][npix_x]
   unsigned long long* n_rays;
+  const VoroGrid* voro;                                         // stars' maps on a Voronoi grid: the grid's record in HBM (else null)
   // method 2 (mcgpu_rt2_dust_map / mcgpu_rt2_image): the source function of ONE inclination, observer q_only
   int method2, q_only, nang_rt, nang_star;
   const float* eps2;       // eps_dust2(N_type_flux, nang_rt, 0:1, n_cells)
@@ -413,6 +415,29 @@ __device__ inline float optical_length_tot(const Lds& T, const DevModel& M, int 
   return (float)tau;  // tau_tot_out is a default real
 }
 
+// ... on a Voronoi grid: index_cell_voronoi (the nearest site), then cross_Voronoi_cell to the box
+__device__ inline float optical_length_tot_voro(const Lds& T, const DevModel& M, const VoroGrid& G, int lambda, double x, double y,
+                                                double z, double u, double v, double w) {
+  int next = voro_index_cell(G, x, y, z), icell0 = 0, prev = 0;
+  double tau = 0.0;
+  for (long guard = 0; guard < 100000000L; ++guard) {
+    prev = icell0;
+    icell0 = next;
+    if (icell0 < 0) break;  // test_exit_grid
+    const VoroCell C = G.cell[icell0 - 1];
+    double opacity = 0.0;
+    if (icell0 <= M.n_cells) {
+      const double kap = M.n_classes ? M.v_kappa[(size_t)M.cell_class[icell0 - 1] * M.n_lambda + (lambda - 1)] : T.kappa[lambda - 1];
+      opacity = kap * C.kf;
+    }
+    double x1, y1, z1, l, l_contrib, l_void;
+    voro_cross_cell(G, M, C, x, y, z, u, v, w, icell0, prev, x1, y1, z1, next, l, l_contrib, l_void);
+    tau += l_contrib * opacity;
+    x = x1; y = y1; z = z1;
+  }
+  return (float)tau;
+}
+
 constexpr int STARS_NX_SCREEN = 10, STARS_N_RAY_SED = 1024;  // dust_transfer.f90:1615,1627
 
 template <bool L3D>
@@ -437,7 +462,8 @@ __global__ void __launch_bounds__(512) k_stars_map_sed(const DevModel M, const R
   for (int p = tid; p < ns * ns; p += nt) {
     const int i = p % ns - STARS_NX_SCREEN, j = p / ns - STARS_NX_SCREEN;
     const double x = s4[0] + dxs[0] * i + dys[0] * j, y = s4[1] + dxs[1] * i + dys[1] * j, z = s4[2] + dxs[2] * i + dys[2] * j;
-    tau_screen[p] = optical_length_tot<L3D>(T, M, A.lambda, x, y, z, uvw[0], uvw[1], uvw[2]);
+    tau_screen[p] = A.voro ? optical_length_tot_voro(T, M, *A.voro, A.lambda, x, y, z, uvw[0], uvw[1], uvw[2])
+                           : optical_length_tot<L3D>(T, M, A.lambda, x, y, z, uvw[0], uvw[1], uvw[2]);
   }
   __syncthreads();
   const int n_ray = STARS_N_RAY_SED / M.n_stars > 1 ? STARS_N_RAY_SED / M.n_stars : 1;
@@ -529,7 +555,8 @@ __global__ void __launch_bounds__(512) k_stars_map_image(const DevModel M, const
   for (int p = tid; p < ns * ns; p += nt) {
     const int i = p % ns - STARS_NX_SCREEN, j = p / ns - STARS_NX_SCREEN;
     const double x = s4[0] + dxs[0] * i + dys[0] * j, y = s4[1] + dxs[1] * i + dys[1] * j, z = s4[2] + dxs[2] * i + dys[2] * j;
-    tau_screen[p] = optical_length_tot<L3D>(T, M, A.lambda, x, y, z, uvw[0], uvw[1], uvw[2]);
+    tau_screen[p] = A.voro ? optical_length_tot_voro(T, M, *A.voro, A.lambda, x, y, z, uvw[0], uvw[1], uvw[2])
+                           : optical_length_tot<L3D>(T, M, A.lambda, x, y, z, uvw[0], uvw[1], uvw[2]);
   }
   __syncthreads();
   int n_ray = STARS_N_RAY_SED / M.n_stars > 1 ? STARS_N_RAY_SED / M.n_stars : 1;

@@ -2793,7 +2793,6 @@ extern "C" int mcgpu_rt1_stars_map_sed(mcgpu_ctx* ctx, const mcgpu_rt_opts* o, c
   if (rc) return rc;
   if (!o || !tab_RT_az || !star_flux || !stars_flux) return fail(ctx, MCGPU_ERR_ARG, "mcgpu_rt1_stars_map_sed: null argument");
   const DevModel& M = ctx->M;
-  if (ctx->voro) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "stars map: cylindrical and spherical grids");
   if (!ctx->have_rt1) return fail(ctx, MCGPU_ERR_STATE, "stars map: set the observers first (mcgpu_set_rt1)");
   if (o->lambda < 1 || o->lambda > M.n_lambda) return fail(ctx, MCGPU_ERR_ARG, "mcgpu_rt1_stars_map_sed: bad option");
   HIPCHK(hipSetDevice(ctx->device));
@@ -2807,6 +2806,8 @@ extern "C" int mcgpu_rt1_stars_map_sed(mcgpu_ctx* ctx, const mcgpu_rt_opts* o, c
   std::memset(&A, 0, sizeof(A));
   A.lambda = o->lambda; A.RT_n_incl = ctx->RT_n_incl; A.nRT = nRT; A.ang_disque = o->ang_disque;
   A.rt_u = ctx->d_rt_u; A.rt_v = ctx->d_rt_v; A.rt_w = ctx->d_rt_w; A.rt_az = d_az.p;
+  DevBuf<VoroGrid> d_V;   // Voronoi grid: the kernels pick optical_length_tot_voro when they are handed the grid's record
+  if (ctx->voro) { HIPCHK(d_V.alloc(1)); HIPCHK(d_V.put(&ctx->V, 1)); A.voro = d_V.p; }
   const size_t lds = lds_bytes(M, true);
   const unsigned int k0 = (unsigned int)seed, k1 = (unsigned int)(seed >> 32);
   if (M.l3D) {
@@ -2833,7 +2834,6 @@ extern "C" int mcgpu_rt1_stars_map_image(mcgpu_ctx* ctx, const mcgpu_rt_opts* o,
       !(map_size > 0.0) || !(zoom > 0.0) || n_mu < 0 || (n_mu > 0 && (n_mu < 2 || !mu_limb_darkening || !limb_darkening)))
     return fail(ctx, MCGPU_ERR_ARG, "mcgpu_rt1_stars_map_image: bad argument");
   const DevModel& M = ctx->M;
-  if (ctx->voro) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "stars map: cylindrical and spherical grids");
   if (!ctx->have_rt1) return fail(ctx, MCGPU_ERR_STATE, "stars map: set the observers first (mcgpu_set_rt1)");
   if (o->lambda < 1 || o->lambda > M.n_lambda || !(o->distance > 0.0)) return fail(ctx, MCGPU_ERR_ARG, "mcgpu_rt1_stars_map_image: bad option");
   HIPCHK(hipSetDevice(ctx->device));
@@ -2855,6 +2855,8 @@ extern "C" int mcgpu_rt1_stars_map_image(mcgpu_ctx* ctx, const mcgpu_rt_opts* o,
   std::memset(&A, 0, sizeof(A));
   A.lambda = o->lambda; A.RT_n_incl = ctx->RT_n_incl; A.nRT = nRT; A.ang_disque = o->ang_disque;
   A.rt_u = ctx->d_rt_u; A.rt_v = ctx->d_rt_v; A.rt_w = ctx->d_rt_w; A.rt_az = d_az.p;
+  DevBuf<VoroGrid> d_V;   // Voronoi grid: the kernels pick optical_length_tot_voro when they are handed the grid's record
+  if (ctx->voro) { HIPCHK(d_V.alloc(1)); HIPCHK(d_V.put(&ctx->V, 1)); A.voro = d_V.p; }
   StarsImageArgs I;
   I.npix_x = npix_x; I.npix_y = npix_y; I.n_maps = n_maps; I.n_mu = n_mu;
   I.taille_pix = (map_size / zoom) / (double)(npix_x > npix_y ? npix_x : npix_y);

@@ -1049,7 +1049,8 @@ static inline void grid_move_to_grid(const oracle_model *m, double *x, double *y
   else oracle_move_to_grid_cyl(m, x, y, z, u, v, w, icell, lintersect);
 }
 static inline void grid_index_cell(const oracle_model *m, double x, double y, double z, int *icell) {
-  if (m->grid_type == 2) oracle_index_cell_sph(m, x, y, z, icell);
+  if (m->grid_type == 3) oracle_index_cell_voronoi(m, x, y, z, icell);
+  else if (m->grid_type == 2) oracle_index_cell_sph(m, x, y, z, icell);
   else oracle_index_cell_cyl(m, x, y, z, icell);
 }
 
@@ -2772,7 +2773,6 @@ static float optical_length_tot(const oracle_model *m, int lambda, double x, dou
 
 int oracle_stars_map_sed(const oracle_model *m, const oracle_rt_opts *o, uint64_t seed, const double *star_flux,
                          double *out) {
-  if (m->grid_type == 3) return 31;
   enum { NXS = 10, NS = 21, N_RAY_SED = 1024 };
   const int nRT = m->RT_n_incl * m->RT_n_az;
   const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
@@ -3070,7 +3070,6 @@ static float interp_sp(const float *y, const float *x, int n, float xp) {
 int oracle_stars_map_image(const oracle_model *m, const oracle_rt_opts *o, uint64_t seed, const double *star_flux,
                            int npix_x, int npix_y, double map_size, double zoom, int n_mu, const float *mu_ld,
                            const float *ld, const float *pola_ld, double *map, double *star_position) {
-  if (m->grid_type == 3) return 31;
   enum { NXS = 10, NS = 21, N_RAY_SED = 1024 };
   const int nRT = m->RT_n_incl * m->RT_n_az, n_maps = (n_mu > 0 && pola_ld) ? 3 : 1;
   const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};

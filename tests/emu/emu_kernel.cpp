@@ -600,12 +600,12 @@ extern "C" int emu_init_reemission(int n_classes, int n_T, int n_lambda, const f
 
 extern "C" int emu_stars_map_sed(const oracle_model* m, const oracle_rt_opts* o, uint64_t seed, const double* star_flux,
                                  double* out) {
-  if (m->grid_type != 1) return 31;
   Conv cv(m);
   RtArgs A;
   memset(&A, 0, sizeof(A));
   A.lambda = o->lambda; A.RT_n_incl = m->RT_n_incl; A.nRT = m->RT_n_incl * m->RT_n_az; A.ang_disque = o->ang_disque;
   A.rt_u = m->tab_u_rt; A.rt_v = m->tab_v_rt; A.rt_w = m->tab_w_rt; A.rt_az = o->tab_RT_az;
+  if (cv.voro) A.voro = &cv.G;
   for (int q = 0; q < A.nRT; ++q) out[q] = 0.0;
   gridDim.x = (unsigned)(A.nRT * m->n_stars); blockDim.x = 1; threadIdx.x = 0;
   for (unsigned b = 0; b < gridDim.x; ++b) {

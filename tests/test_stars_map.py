@@ -34,11 +34,13 @@ def test_known_answers():
     assert np.allclose(other[sel], thick[sel], rtol=0.05)
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(n_rad=12, nz=6, n_az=8, l3D=True)])
+@pytest.mark.parametrize("kw", [dict(), dict(n_rad=12, nz=6, n_az=8, l3D=True), dict(grid_type=2), dict(voronoi_sites=1200)])
 def test_emulated_kernel_against_the_oracle(emu, kw):   # noqa: F811
     from oracle.binding import _RtOpts
     from oracle.binding import _a, _p
-    m = sed_model(M.small(RT_imax=90.0, RT_n_incl=5, **kw), n_thermal=20000)
+    kw = dict(kw)
+    sites = kw.pop("voronoi_sites", 0)   # (Voronoi: index_cell_voronoi of the point of the star's disc, then cross_Voronoi_cell)
+    m = sed_model(M.small(RT_imax=90.0, RT_n_incl=5, **kw), n_thermal=20000, voronoi_sites=sites)
     o = Oracle(m, 1000)
     flux = np.array([1.0])
     for lam in (3, int(np.argmin(np.abs(m.lam - 1.0))) + 1, m.n_lambda):
@@ -54,10 +56,12 @@ def test_emulated_kernel_against_the_oracle(emu, kw):   # noqa: F811
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kw", [dict(), dict(n_rad=12, nz=6, n_az=8, l3D=True)])
+@pytest.mark.parametrize("kw", [dict(), dict(n_rad=12, nz=6, n_az=8, l3D=True), dict(grid_type=2), dict(voronoi_sites=3000)])
 def test_device_against_the_oracle(kw):
     from mcfost_amd.engine import Engine
-    m = sed_model(M.small(RT_imax=90.0, RT_n_incl=5, **kw), n_thermal=20000)
+    kw = dict(kw)
+    sites = kw.pop("voronoi_sites", 0)
+    m = sed_model(M.small(RT_imax=90.0, RT_n_incl=5, **kw), n_thermal=20000, voronoi_sites=sites)
     o = Oracle(m, 1000)
     e = Engine(m, 1000)
     flux = np.array([2.5])
@@ -114,8 +118,9 @@ def test_stars_image_known_answers():
 def test_device_stars_image_equals_the_oracle():
     from mcfost_amd.engine import Engine
     mu, ld, pld = _ld_table()
-    for cfg in (M.small(RT_n_incl=3), M.small(n_rad=10, nz=5, n_az=6, l3D=True, RT_n_incl=2)):
-        m = M.build_model(cfg)
+    for cfg, sites in ((M.small(RT_n_incl=3), 0), (M.small(n_rad=10, nz=5, n_az=6, l3D=True, RT_n_incl=2), 0),
+                       (M.small(RT_n_incl=2), 2000)):
+        m = M.build_voronoi_model(cfg, sites, seed=3) if sites else M.build_model(cfg)
         o = Oracle(m, 1000)
         e = Engine(m, 1000)
         rs = m.cfg.R_star * 0.00465047
