@@ -273,6 +273,7 @@ module mcgpu_f
 
      ! modified random walk (module MRW): zeta(:) of initialize_cumulative_zeta, the mean opacities per tab_Temp,
      ! gamma_MRW, the interaction count of dust_transfer.f90:1223, r_lim(0:n_rad); n_zeta = 0 switches it off
+     ! (r_lim: cylindrical_grid's r_lim(0:n_rad); not read on a Voronoi grid -- pass any array there)
      integer(c_int) function mcgpu_set_mrw(ctx, n_zeta, zeta, chi, kappa_dep, ext, gamma, n_interactions, r_lim) &
           bind(C, name="mcgpu_set_mrw")
        import :: c_int, c_ptr, c_double
