@@ -748,16 +748,29 @@ int mcgpu_temp_approx_diffusion_vertical(mcgpu_ctx *ctx, const double *tab_lambd
  * parts, and the in-flight temperature's `local * n_replicas` stays the right estimate.
  * An error on one device leaves nothing of the call running on the others.
  *
+ * mcgpu_multi_create_ex(..., MCGPU_MULTI_SHARED_DEVICE, ...) opens the n_dev contexts on ONE device
+ * (devices[i] all equal; NULL: device 0) and sums with the library's own kernel in place of
+ * ncclAllReduce, which refuses a communicator that names a device twice.  Everything else --
+ * shards, n_replicas, the 1 / n_dev rescale of an accumulating call, the counters, the error
+ * path, the chunked 3D launch on several contexts, the host threads of mcgpu_multi_run_mono -- is
+ * the code of distinct devices, so a box with one GPU executes it (tests/test_multi_shared_device.py,
+ * `bench.py --gpus N --shared-device`).  Not for production: the contexts share the device's CUs.
+ * mcgpu_multi_reductions counts the collectives a handle has executed (either kind).
+ *
  * mcgpu_multi_run_mono replaces `call mc_photon_loop(lambda, ...)` of the SED loop
  * (dust_transfer.f90:939) the same way: the opts->n_chunks independent streams are split into
  * contiguous ranges (n_dev <= n_chunks), every device runs mcgpu_run_mono on its range (one host
  * thread per device inside the call), then one all-reduce sums [sed | n_sent | counters] and one
  * xI_scatt.  Afterwards every context holds the sums: read them with mcgpu_fetch / mcgpu_fetch_xI
  * on mcgpu_multi_ctx(m, 0) and run mcgpu_rt1_dust_map on any device.  n_sent_chunk[n_chunks] as
- * in mcgpu_run_mono.
+ * in mcgpu_run_mono.  opts->rt1 = 2 (ray tracing method 2): the second all-reduce sums I_spec and
+ * I_spec_star instead, so that mcgpu_rt2_source on any device sees the global field.
  */
 typedef struct mcgpu_multi mcgpu_multi;
+#define MCGPU_MULTI_SHARED_DEVICE 1u
 int mcgpu_multi_create(int n_dev, const int *devices, mcgpu_multi **out);
+int mcgpu_multi_create_ex(int n_dev, const int *devices, unsigned int flags, mcgpu_multi **out);
+uint64_t mcgpu_multi_reductions(const mcgpu_multi *m);
 int mcgpu_multi_destroy(mcgpu_multi *m);
 int mcgpu_multi_size(const mcgpu_multi *m);
 mcgpu_ctx *mcgpu_multi_ctx(mcgpu_multi *m, int i);

@@ -44,7 +44,10 @@ constexpr int BIN_WAVE = 64;
 // first packets; the host keeps it short and lets the chunks grow geometrically.
 __device__ inline double bin_energy_scale(const RunArgs& A) {
   if (!(A.n_folded > 0.0)) return 1.0;
-  const unsigned long long p = __hip_atomic_load(A.next_packet, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  unsigned long long p = __hip_atomic_load(A.next_packet, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // (the work counter hands out the carried records first: they are packets of earlier chunks, already in n_folded)
+  const unsigned long long n_carry = A.carry_in_n ? (unsigned long long)*A.carry_in_n : 0ull;
+  p = p > n_carry ? p - n_carry : 0ull;
   const double started = (double)(p < A.n_packets ? p : A.n_packets);
   return (A.n_folded + started) / A.n_folded;
 }
@@ -195,7 +198,7 @@ __device__ inline void bin_drain(const BinStage& S, const BinLog& L, double* E) 
 #ifdef MCGPU_LANE_EMULATION
 double bin_fold_slice[1 << 14];
 #endif
-__global__ void __launch_bounds__(1024) k_fold_bins(const BinLog L, double* E, int n_cells, int split) {
+static __global__ void __launch_bounds__(1024) k_fold_bins(const BinLog L, double* E, int n_cells, int split) {
 #ifdef MCGPU_LANE_EMULATION
   double* const slice = bin_fold_slice;
 #else
@@ -238,7 +241,7 @@ __global__ void __launch_bounds__(1024) k_fold_bins(const BinLog L, double* E, i
 }
 
 // The first chunk's regions: the log split evenly.  One workgroup.
-__global__ void k_plan_uniform(unsigned int* off, unsigned int* cap, int n_buckets, unsigned long long total_blocks, int n_parts) {
+static __global__ void k_plan_uniform(unsigned int* off, unsigned int* cap, int n_buckets, unsigned long long total_blocks, int n_parts) {
   const unsigned long long per = total_blocks / (unsigned long long)n_buckets / (unsigned long long)n_parts;
   for (int b = threadIdx.x; b < n_buckets; b += blockDim.x) {
     off[b] = (unsigned int)(per * n_parts * b);
@@ -250,7 +253,7 @@ __global__ void k_plan_uniform(unsigned int* off, unsigned int* cap, int n_bucke
 // count times `growth` (the next chunk's packets over the last one's) plus a half plus a floor -- cut down in
 // proportion when the log is smaller than that --, split evenly among n_parts_next workgroups (they take packets from
 // one global counter, so their shares are even); the counts are cleared.  One workgroup.
-__global__ void __launch_bounds__(128) k_plan_bins(const BinLog L, unsigned int* off, unsigned int* cap, unsigned long long total_blocks,
+static __global__ void __launch_bounds__(128) k_plan_bins(const BinLog L, unsigned int* off, unsigned int* cap, unsigned long long total_blocks,
                                                   double growth, int n_parts_next, double* want /* [n_buckets] scratch */) {
   for (int b = threadIdx.x; b < L.n_buckets; b += blockDim.x) {
     unsigned long long n = 0ull;

@@ -199,7 +199,7 @@ struct RunArgs {
   int min_active;   // leave the crossing loop early once fewer lanes than this are in flight
   int flags;        // diagnostics, -DMCGPU_TUNING builds only (MCGPU_DIAG)
   // optional radiation-field accumulators of save_radiation_field (radiation_field.f90:54-55): null = off
-  unsigned int* xN_abs;  // [n_cells] path segments per cell (xN_abs(icell,1,id), lmcfost_lib)
+  unsigned long long* xN_abs;  // [n_cells] path segments per cell (xN_abs(icell,1,id), lmcfost_lib)
   double* xJ_abs;        // (n_cells, n_lambda) sum of l * Stokes(1) (lxJ_abs_step1)
   // binned deposits (mc_binned.hip.h): the launch is one CHUNK of a run whose deposits reach E_abs when the chunk's
   // log is folded; n_folded = packets whose deposits E_abs holds when this chunk starts (see bin_energy_scale)
@@ -404,7 +404,7 @@ __device__ inline Lds class_tables(const Lds& T, const DevModel& M, int cls) {
 }
 
 // the per-cell opacity pairs of the variable-dust role kernel (DevModel::v_kk): one thread per (cell, wavelength)
-__global__ void k_build_vkk(const DevModel M, double2* out) {
+static __global__ void k_build_vkk(const DevModel M, double2* out) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t n = ((size_t)M.n_cells + 1) * M.n_lambda;
   if (i >= n) return;
@@ -1076,7 +1076,7 @@ __device__ inline void deposit(double* E_glob, double* E_lds, int ic, double v) 
 
 // the optional accumulators of save_radiation_field's thermal branch (radiation_field.f90:54-55)
 __device__ inline void radiation_field_extras(const DevModel& M, const RunArgs& A, int ic, int lambda, double l_S0) {
-  if (A.xN_abs) atomicAdd(&A.xN_abs[ic], 1u);
+  if (A.xN_abs) atomicAdd(&A.xN_abs[ic], 1ull);
   if (A.xJ_abs) atomic_add_f64(&A.xJ_abs[(size_t)ic + (size_t)M.n_cells * (size_t)(lambda - 1)], l_S0);
 }
 
@@ -1986,7 +1986,7 @@ __global__ void __launch_bounds__(MCGPU_LDS_BLOCK) k_thermal_lds(const DevModel 
 // ---------------------------------------------------------------------------
 // Temp_finale (thermal_emission.f90:870-906)
 // ---------------------------------------------------------------------------
-__global__ void k_temp_finale(const DevModel M, const double* E_abs, const float* tab_Temp, float T_min,
+static __global__ void k_temp_finale(const DevModel M, const double* E_abs, const float* tab_Temp, float T_min,
                               float* Tdust) {
   const int ic = blockIdx.x * blockDim.x + threadIdx.x;
   if (ic >= M.n_cells) return;
@@ -2035,7 +2035,7 @@ __device__ inline double reemission_sums(double Temp, int n_lambda, const double
   return integ;
 }
 
-__global__ void k_init_reemission(int n_classes, int n_T, int n_lambda, const float* tab_Temp, const double* tab_lambda,
+static __global__ void k_init_reemission(int n_classes, int n_T, int n_lambda, const float* tab_Temp, const double* tab_lambda,
                                   const double* tab_delta_lambda, const double* kabs, double* lq, double* cdf) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n_classes * n_T) return;
@@ -2065,7 +2065,7 @@ __global__ void k_init_reemission(int n_classes, int n_T, int n_lambda, const fl
 // ---------------------------------------------------------------------------
 constexpr int DELTA_CELL_DARK_ZONE = 3;  // cylindrical_grid.f90:39
 
-__global__ void k_clean_dark_temperature(int n_rad, int ri_in, int ri_out, const int* zj_sup, float T_min, float* Tdust) {
+static __global__ void k_clean_dark_temperature(int n_rad, int ri_in, int ri_out, const int* zj_sup, float T_min, float* Tdust) {
   const int i = ri_in + blockIdx.x;
   if (i > ri_out) return;
   for (int j = 1 + threadIdx.x; j <= zj_sup[i - 1]; j += blockDim.x) Tdust[(i - 1) + n_rad * (j - 1)] = T_min;
@@ -2095,7 +2095,7 @@ __device__ inline double diffusion_coeff(const DevModel& M, const double* tab_la
   return cst_Dcoeff * total_sum / (Temp * Temp * Temp);
 }
 
-__global__ void __launch_bounds__(128) k_diffusion_vertical(const DevModel M, const double* tab_lambda,
+static __global__ void __launch_bounds__(128) k_diffusion_vertical(const DevModel M, const double* tab_lambda,
                                                             const double* tab_delta_lambda, int i_lo, int i_hi,
                                                             const int* zj_sup, float* Tdust, int* n_iter_out,
                                                             int* err) {
@@ -2177,7 +2177,7 @@ __global__ void __launch_bounds__(128) k_diffusion_vertical(const DevModel M, co
 // repartition_energie (thermal_emission.f90:1771-1949), LTE grains: E_cell of one wavelength (one thread per cell),
 // then the cumulative distribution prob_E_cell(0:n_cells) summed in the reference's own order (k_cumsum_in_order).
 // ---------------------------------------------------------------------------
-__global__ void k_repart_E_cell(const DevModel M, int lambda, double wl, const float* Tdust, const float* weight,
+static __global__ void k_repart_E_cell(const DevModel M, int lambda, double wl, const float* Tdust, const float* weight,
                                 double* E_cell, double* E_corr) {
   const int ic = blockIdx.x * blockDim.x + threadIdx.x;
   if (ic >= M.n_cells) return;
@@ -2204,7 +2204,7 @@ constexpr int SCAN_TILE = 1024;
 // distribution monotone and its last entry, divided by itself, exactly 1), tot[0] = its last entry, tot[1] = the
 // running sum of in2 (E_disk = sum(E_cell), :1897).  One workgroup: the tiles are staged in LDS by all threads, the
 // additions are one thread's -- 3 ms per million cells, next to seconds of Monte Carlo per wavelength.
-__global__ void __launch_bounds__(SCAN_TILE) k_cumsum_in_order(const double* in, const double* in2, int n, double* prob, double* tot) {
+static __global__ void __launch_bounds__(SCAN_TILE) k_cumsum_in_order(const double* in, const double* in2, int n, double* prob, double* tot) {
   __shared__ double buf[SCAN_TILE], buf2[SCAN_TILE];
   __shared__ double carry, carry2;
   if (threadIdx.x == 0) { carry = 0.0; carry2 = 0.0; prob[0] = 0.0; }
@@ -2227,7 +2227,7 @@ __global__ void __launch_bounds__(SCAN_TILE) k_cumsum_in_order(const double* in,
   if (threadIdx.x == 0) { tot[0] = carry; tot[1] = carry2; }
 }
 // prob(:) = prob(:) / prob(n_cells), or 0 when that is not positive (:1933-1937)
-__global__ void k_cumsum_normalise(double* prob, const double* tot, int n) {
+static __global__ void k_cumsum_normalise(double* prob, const double* tot, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i > n) return;
   const double last = tot[0];
@@ -2272,14 +2272,14 @@ __global__ void k_probe_index(const DevModel M, int n, const double* x, const do
   }
 }
 
-__global__ void k_probe_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+static __global__ void k_probe_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                uint32_t k1, uint32_t* out) {
   uint32_t o[4];
   philox4x32_10(c0, c1, c2, c3, k0, k1, o);
   out[0] = o[0]; out[1] = o[1]; out[2] = o[2]; out[3] = o[3];
 }
 
-__global__ void k_probe_rand(uint64_t seed, uint64_t packet, int n, float* out) {
+static __global__ void k_probe_rand(uint64_t seed, uint64_t packet, int n, float* out) {
   Rng r;
   r.init(seed, packet);
   for (int i = 0; i < n; i += 4) {

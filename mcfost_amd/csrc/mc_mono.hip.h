@@ -767,7 +767,7 @@ __global__ void __launch_bounds__(512) k_mono_sph(const DevModel M, const MonoAr
 //   sent[c]  packets sent so far = seq0 (updated: += batch, or the exact stop)
 //   lim      n_phot_lim as an integer cap
 // done[c] = 1 when the stream stopped inside this batch (or hit the cap).
-__global__ void k_mono_scan(const int* active, int n_active, unsigned long long batch, const unsigned char* hits,
+static __global__ void k_mono_scan(const int* active, int n_active, unsigned long long batch, const unsigned char* hits,
                             unsigned long long* need, unsigned long long* sent, unsigned long long lim,
                             int* done) {
   const int a = blockIdx.x;
@@ -807,7 +807,7 @@ __global__ void k_mono_scan(const int* active, int n_active, unsigned long long 
 
 // device layout [icell][psup][phik][iRT][8] -> the reference's xI_scatt(phik,psup,type,iRT,icell),
 // in FP64 and/or default real (what the reference's array holds).  One thread per output element.
-__global__ void k_xI_fetch(const double* xI, float* out32, double* out64, int n_az, int n_theta, int n_type, int nRT,
+static __global__ void k_xI_fetch(const double* xI, float* out32, double* out64, int n_az, int n_theta, int n_type, int nRT,
                            size_t n, int f32, int nRT_pad) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -824,7 +824,7 @@ __global__ void k_xI_fetch(const double* xI, float* out32, double* out64, int n_
 }
 
 // the reference's xI_scatt(phik,psup,type,iRT,icell) -> device layout (mcgpu_set_xI).  One thread per element.
-__global__ void k_xI_put(double* xI, const double* in64, int n_az, int n_theta, int n_type, int nRT, size_t n, int f32,
+static __global__ void k_xI_put(double* xI, const double* in64, int n_az, int n_theta, int n_type, int nRT, size_t n, int f32,
                          int nRT_pad) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;

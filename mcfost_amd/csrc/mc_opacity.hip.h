@@ -33,7 +33,7 @@ constexpr double OPA_AU_TO_CM = 149597870700.0 * 100.0;  // constants.f90:61-64
 constexpr double OPA_FACT = OPA_AU_TO_CM * (1.0e-4 * 1.0e-4);  // AU_to_cm * mum_to_cm**2 (dust_prop.f90:958)
 
 // one thread per (class, wavelength): the sums of opacity() (dust_prop.f90:850-876, :960-961)
-__global__ void k_opacity_sum(const OpacityIn I, const OpacityOut O) {
+static __global__ void k_opacity_sum(const OpacityIn I, const OpacityOut O) {
 #pragma clang fp contract(off)
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= I.n_classes * I.n_lambda) return;
@@ -97,7 +97,7 @@ __global__ void k_scatt_sum(const OpacityIn I, const OpacityOut O) {
 
 // one thread per (class, wavelength): the cumulative scattering probability and the normalisations
 // (dust_prop.f90:1122-1236) -- sequential along the angle like the reference (every partial sum is rounded to default real)
-__global__ void k_scatt_norm(const OpacityIn I, const OpacityOut O) {
+static __global__ void k_scatt_norm(const OpacityIn I, const OpacityOut O) {
 #pragma clang fp contract(off)
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= I.n_classes * I.n_lambda) return;

@@ -42,7 +42,7 @@ struct RtArgs {
 
 constexpr int RT_N_RAD = 128, RT_N_PHI = 30;  // dust_map (:1434)
 
-__global__ void k_calc_Jth(const DevModel M, int lambda, double wl, const float* Tdust, double* J_th) {
+static __global__ void k_calc_Jth(const DevModel M, int lambda, double wl, const float* Tdust, double* J_th) {
   const int ic = blockIdx.x * blockDim.x + threadIdx.x;
   if (ic >= M.n_cells) return;
   const double cst_E = 2.0 * 6.626070040e-34 * 299792458.0 * 299792458.0;
@@ -642,7 +642,7 @@ __global__ void __launch_bounds__(512) k_stars_map_image(const DevModel M, const
 // cell.  One ray per thread: physical_length (optical_depth.f90:21-178) without deposits (Stokes = 0).
 // flag[icell] = 1 when some ray of the cell does not leave.
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_dark_zone_rays(const DevModel M, int lambda, float tau_max, int i_lo, int i_hi,
+static __global__ void __launch_bounds__(256) k_dark_zone_rays(const DevModel M, int lambda, float tau_max, int i_lo, int i_hi,
                                                         const int* zj_sup, const double* r_grid, const double* z_grid,
                                                         unsigned char* flag) {
   extern __shared__ double lds_raw[];

@@ -192,7 +192,7 @@ __global__ void k_rt2_source_star(const DevModel M, const Rt2Args A) {
 }
 
 // mcgpu_set_I_spec: the reference's layout (N_type_flux, n_theta_I, n_phi_I, n_cells) -> the device's records
-__global__ void k_I_spec_put(double* dev, const double* in, int ntf, int nt, int np, size_t n) {
+static __global__ void k_I_spec_put(double* dev, const double* in, int ntf, int nt, int np, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   size_t r = i;

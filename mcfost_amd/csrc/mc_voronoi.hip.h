@@ -598,7 +598,7 @@ __global__ void __launch_bounds__(BLOCK) k_thermal_voro_cache(const DevModel M, 
 }
 
 // probe: one cross_Voronoi_cell per thread (tests)
-__global__ void k_probe_cross_voro(const DevModel M, const VoroGrid G, int n, const double* x0, const double* y0,
+static __global__ void k_probe_cross_voro(const DevModel M, const VoroGrid G, int n, const double* x0, const double* y0,
                                    const double* z0, const double* u, const double* v, const double* w,
                                    const int* cell, const int* prev, double* x1, double* y1, double* z1,
                                    int* next, double* l, double* l_contrib, double* l_void) {

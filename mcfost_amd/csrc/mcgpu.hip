@@ -27,6 +27,7 @@
 #include "mc_tail.hip.h"
 #include "mc_opacity.hip.h"
 #include "mc_rt2.hip.h"
+#include "mc_kernels.h"
 
 using namespace mcgpu;
 
@@ -98,6 +99,7 @@ struct mcgpu_ctx {
   unsigned int *d_bin_off = nullptr, *d_bin_cap = nullptr;
   double* d_bin_want = nullptr;  // [n_buckets] scratch of k_plan_bins
   unsigned long long bin_total_blocks = 0;
+  bool bin_log_capped = false;      // the log was cut to a share of the free memory (asking again would not get more)
   int bin_max_parts = 0;
   double bin_dep_per_packet = 0.0;  // deposits per packet of the last run (0: not yet known)
   int bin_chunks = 0;               // chunks of the last launch
@@ -110,7 +112,7 @@ struct mcgpu_ctx {
   int opt_speculation = 1;  // SED mode: commit most of every stream before the scout pass
   int opt_cache_log_slots = 13;  // Voronoi deposit cache: 2^13 slots = 96 KB of LDS
   int opt_radiation_field = 0;   // bit 0: xN_abs, bit 1: xJ_abs (thermal step; radiation_field.f90:54-55)
-  unsigned int* d_xN = nullptr;  // [n_cells]
+  unsigned long long* d_xN = nullptr;  // [n_cells] (64-bit: a hot cell passes 2^32 segments within one 1e9-packet run)
   double* d_xJ = nullptr;        // (n_cells, n_lambda)
   std::vector<void*> allocs;   // every table buffer (freed in destroy)
   // per-setter buffers that may be replaced
@@ -154,6 +156,7 @@ struct mcgpu_ctx {
 };
 
 static void bin_release(mcgpu_ctx* ctx);
+static void grid_release(mcgpu_ctx* ctx);
 static int tail_threshold(const mcgpu_ctx* ctx);
 
 #define HIPCHK(call)                                                              \
@@ -329,6 +332,7 @@ extern "C" int mcgpu_set_grid_cyl(mcgpu_ctx* ctx, int n_rad, int nz, int n_az, i
   if ((rc = upload(ctx, cell_map_k, (size_t)ntot2, &c))) return rc;
   ctx->d_cmi = (int*)a; ctx->d_cmj = (int*)b; ctx->d_cmk = (int*)c;
   bin_release(ctx);
+  grid_release(ctx);   // (d_prob_E, xN_abs, xJ_abs were sized for the old grid)
   ctx->have_grid = true;
   return MCGPU_OK;
 }
@@ -386,6 +390,7 @@ extern "C" int mcgpu_set_grid_sph(mcgpu_ctx* ctx, int n_rad, int nz, int n_az, i
   if ((rc = upload(ctx, cell_map_k, (size_t)ntot2, &c))) return rc;
   ctx->d_cmi = (int*)a; ctx->d_cmj = (int*)b; ctx->d_cmk = (int*)c;
   bin_release(ctx);
+  grid_release(ctx);   // (d_prob_E, xN_abs, xJ_abs were sized for the old grid)
   ctx->have_grid = true;
   return MCGPU_OK;
 }
@@ -461,12 +466,24 @@ extern "C" int mcgpu_set_grid_voronoi(mcgpu_ctx* ctx, int n_cells, const float* 
   V.cell = dc;
   ctx->voro = true;
   bin_release(ctx);
+  grid_release(ctx);   // (d_prob_E, xN_abs, xJ_abs were sized for the old grid)
   ctx->have_grid = true;
   return MCGPU_OK;
 }
 
 // the binned-deposit log is allocated by the first launch that uses it and kept until the context goes (or the grid /
 // the option that sizes it changes)
+// what was sized for the grid that is being replaced
+static void grid_release(mcgpu_ctx* ctx) {
+  if (ctx->d_prob_E) hipFree(ctx->d_prob_E);
+  ctx->d_prob_E = nullptr;
+  ctx->prob_E_lambda = 0;
+  if (ctx->d_xN) hipFree(ctx->d_xN);
+  ctx->d_xN = nullptr;
+  if (ctx->d_xJ) hipFree(ctx->d_xJ);
+  ctx->d_xJ = nullptr;
+}
+
 static void bin_release(mcgpu_ctx* ctx) {
   if (ctx->bin.keys) hipFree(ctx->bin.keys);
   if (ctx->bin.vals) hipFree(ctx->bin.vals);
@@ -510,6 +527,7 @@ extern "C" int mcgpu_get_info(mcgpu_ctx* ctx, const char* name, double* value) {
   HIPCHK(hipSetDevice(ctx->device));
   if (!strcmp(name, "bin_buckets")) *value = ctx->bin.n_buckets;
   else if (!strcmp(name, "bin_log_blocks")) *value = (double)ctx->bin_total_blocks;
+  else if (!strcmp(name, "bin_log_bytes")) *value = (double)ctx->bin_total_blocks * (double)BIN_H * (double)(sizeof(double) + sizeof(unsigned int));
   else if (!strcmp(name, "bin_chunks")) *value = ctx->bin_chunks;
   else if (!strcmp(name, "bin_deposits_per_packet")) *value = ctx->bin_dep_per_packet;
   else if (!strcmp(name, "tail_threshold")) *value = tail_threshold(ctx);
@@ -1090,23 +1108,16 @@ extern "C" int mcgpu_set_E_prior(mcgpu_ctx* ctx, const double* E_prior) {
   return MCGPU_OK;
 }
 
-template <bool L3D, bool POLA, bool DARK, bool LDSE>
-static hipError_t launch_k(const DevModel& M, const RunArgs& A, int blocks, int threads, size_t lds, hipStream_t s) {
-  auto kern = LDSE ? k_thermal_lds<L3D, POLA, DARK> : k_thermal<L3D, POLA, DARK>;
-  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, s, M, A);
-  return hipGetLastError();
-}
+// the kernels themselves live in the kern_*.hip translation units; mc_kernels.h hands out their handles
 
 // The hand-over threshold of this launch.  The kernels that can hand packets over run their bulk ~8 % slower (more
 // spilled registers: 160 against 116 bytes of scratch on the Pascucci instance), and the tail kernel only pays where
 // packets get trapped: Pascucci's launch has no tail at all (T(N) linear through 5 ms), ref4.1's has 73 ms, a thick
-// disk's seconds.  Automatic: what the context's last launch showed (at least one interaction per packet), else --
-// first launch -- the radial optical depth of the midplane at the most opaque wavelength (> 1000).
+// disk's seconds.  Automatic: from the model alone -- the radial optical depth of the midplane at the most opaque
+// wavelength (> 1000) --, so that two launches on the same model follow the same schedule whatever ran before
+// (round 3 also looked at the last launch's interactions per packet: a plan that depended on the call history).
 static int tail_threshold(const mcgpu_ctx* ctx) {
   if (ctx->opt_tail >= 0) return ctx->opt_tail;
-  if (ctx->last_inter_pp >= 0.0) return ctx->last_inter_pp >= 1.0 ? 48 : 0;
   return ctx->tau_midplane > 1000.0 ? 48 : 0;
 }
 
@@ -1134,11 +1145,7 @@ static int launch_tail(mcgpu_ctx* ctx, const RunArgs& A, const void* carry, cons
   if (per_cu < 1) per_cu = 1;
   if (per_cu > 8) per_cu = 8;
   const int blocks = ctx->prop.multiProcessorCount * per_cu;
-  const void* fn;
-#define PICKT(a, m) fn = pola ? (dark ? (const void*)k_tail<a, true, true, m> : (const void*)k_tail<a, true, false, m>) \
-                              : (dark ? (const void*)k_tail<a, false, true, m> : (const void*)k_tail<a, false, false, m>)
-  if (l3d) PICKT(true, false); else if (mrw) PICKT(false, true); else PICKT(false, false);
-#undef PICKT
+  const void* fn = kpick_tail(l3d, pola, dark, !l3d && mrw);
   HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   HIPCHK(hipMemsetAsync(ctx->d_tail_next, 0, sizeof(unsigned int), ctx->stream));
   void* args[] = {(void*)&M, (void*)&A, (void*)&carry, (void*)&carry_n, (void*)&ctx->d_tail_next};
@@ -1201,27 +1208,14 @@ static int launch_mega(mcgpu_ctx* ctx, const RunArgs& A, bool use_lds, int grid_
         const unsigned long long need = (A.n_packets + rthreads - 1) / rthreads;
         if (grid_blocks <= 0 && (unsigned long long)rblocks > need) rblocks = (int)(need ? need : 1);
         int n_srv_pref = (rthreads / 64 + 3) / 4, k_short = 2, fly_iters = 16, fly_idle = 32, emit_qmax = 128;
-#define PICKRV(a, l) fn = pola ? (dark ? (const void*)k_thermal_roles_var<a, true, true, l> : (const void*)k_thermal_roles_var<a, true, false, l>) \
-                               : (dark ? (const void*)k_thermal_roles_var<a, false, true, l> : (const void*)k_thermal_roles_var<a, false, false, l>)
-        if (l3d) { if (use_lds) PICKRV(true, true); else PICKRV(true, false); }
-        else { if (use_lds) PICKRV(false, true); else PICKRV(false, false); }
-#undef PICKRV
+        fn = kpick_roles_var(l3d, pola, dark, use_lds);
         HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));
         void* rargs[] = {(void*)&Mv, (void*)&A, (void*)&n_rec, (void*)&n_srv_pref, (void*)&k_short, (void*)&fly_iters, (void*)&fly_idle, (void*)&emit_qmax};
         HIPCHK(hipLaunchKernel(fn, dim3(rblocks), dim3(rthreads), rargs, lds_r, ctx->stream));
         return MCGPU_OK;
       }
     }
-#define PICKV(a, l, w) fn = pola ? (dark ? (const void*)k_thermal_var<a, true, true, l, w> : (const void*)k_thermal_var<a, true, false, l, w>) \
-                                 : (dark ? (const void*)k_thermal_var<a, false, true, l, w> : (const void*)k_thermal_var<a, false, false, l, w>)
-    if (M.mrw) {
-      if (l3d) { if (use_lds) PICKV(true, true, true); else PICKV(true, false, true); }
-      else { if (use_lds) PICKV(false, true, true); else PICKV(false, false, true); }
-    } else {
-      if (l3d) { if (use_lds) PICKV(true, true, false); else PICKV(true, false, false); }
-      else { if (use_lds) PICKV(false, true, false); else PICKV(false, false, false); }
-    }
-#undef PICKV
+    fn = kpick_thermal_var(l3d, pola, dark, use_lds, M.mrw != 0);
     HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k));
     void* args[] = {(void*)&M, (void*)&A};
     HIPCHK(hipLaunchKernel(fn, dim3(blocks), dim3(threads), args, lds_k, ctx->stream));
@@ -1229,12 +1223,7 @@ static int launch_mega(mcgpu_ctx* ctx, const RunArgs& A, bool use_lds, int grid_
   }
   if (M.grid_sph) {  // the spherical grid runs the single-role kernel with its own grid operators
     const size_t lds_k2 = lds_k;
-    const void* fn;
-#define PICKS(a, w) fn = pola ? (use_lds ? (const void*)k_thermal_sph<a, true, true, w> : (const void*)k_thermal_sph<a, true, false, w>) \
-                              : (use_lds ? (const void*)k_thermal_sph<a, false, true, w> : (const void*)k_thermal_sph<a, false, false, w>)
-    if (M.mrw) { if (l3d) PICKS(true, true); else PICKS(false, true); }
-    else { if (l3d) PICKS(true, false); else PICKS(false, false); }
-#undef PICKS
+    const void* fn = kpick_thermal_sph(l3d, pola, use_lds, M.mrw != 0);
     HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k2));
     void* args[] = {(void*)&M, (void*)&A};
     HIPCHK(hipLaunchKernel(fn, dim3(blocks), dim3(threads), args, lds_k2, ctx->stream));
@@ -1264,21 +1253,7 @@ static int launch_mega(mcgpu_ctx* ctx, const RunArgs& A, bool use_lds, int grid_
       int n_srv_pref = tune("MCGPU_N_SRV", (rthreads / 64 + 3) / 4, 1, 1016);  // serving waves to start with (adaptive; 1000 + n: fixed)
       int k_short = tune("MCGPU_K_SHORT", 2, 0, 64), fly_iters = tune("MCGPU_FLY_ITERS", 16, 1, 256);
       int fly_idle = tune("MCGPU_FLY_IDLE", 32, 1, 65), emit_qmax = tune("MCGPU_EMIT_QMAX", 128, 0, 1 << 20);
-      const void* fn;
-#define PICKR(a, b, c) fn = use_lds ? (const void*)k_thermal_roles<a, b, c, true> : (const void*)k_thermal_roles<a, b, c, false>
-#define PICKM(b, c) fn = use_lds ? (const void*)k_thermal_roles<false, b, c, true, true> : (const void*)k_thermal_roles<false, b, c, false, true>
-      if (M.mrw) {  // (2D; mcgpu_set_mrw refuses the other grids)
-        if (pola) { if (dark) PICKM(true, true); else PICKM(true, false); }
-        else { if (dark) PICKM(false, true); else PICKM(false, false); }
-      } else if (l3d) {
-        if (pola) { if (dark) PICKR(true, true, true); else PICKR(true, true, false); }
-        else { if (dark) PICKR(true, false, true); else PICKR(true, false, false); }
-      } else {
-        if (pola) { if (dark) PICKR(false, true, true); else PICKR(false, true, false); }
-        else { if (dark) PICKR(false, false, true); else PICKR(false, false, false); }
-      }
-#undef PICKR
-#undef PICKM
+      const void* fn = kpick_roles(l3d, pola, dark, use_lds, M.mrw != 0);   // (the walk: 2D; 3D was sent to the single-role kernel above)
       // 2D grids: the launch's last packets go to the tail kernel (one packet per wave, mc_tail.hip.h) once a
       // workgroup has no more than opt_tail of them left
       RunArgs At = A;
@@ -1289,12 +1264,7 @@ static int launch_mega(mcgpu_ctx* ctx, const RunArgs& A, bool use_lds, int grid_
         HIPCHK(hipMemsetAsync(ctx->d_carry_n, 0, 2 * sizeof(unsigned int), ctx->stream));
         At.carry_out = ctx->d_carry[0]; At.carry_out_n = ctx->d_carry_n; At.carry_cap = (unsigned int)ctx->carry_cap;
         At.tail_threshold = tail_thr;
-#define PICKRT(b, c, m) fn = use_lds ? (const void*)k_thermal_roles_tail<b, c, true, m> : (const void*)k_thermal_roles_tail<b, c, false, m>
-        if (M.mrw) { if (pola) { if (dark) PICKRT(true, true, true); else PICKRT(true, false, true); }
-                     else { if (dark) PICKRT(false, true, true); else PICKRT(false, false, true); } }
-        else { if (pola) { if (dark) PICKRT(true, true, false); else PICKRT(true, false, false); }
-               else { if (dark) PICKRT(false, true, false); else PICKRT(false, false, false); } }
-#undef PICKRT
+        fn = kpick_roles_tail(pola, dark, use_lds, M.mrw != 0);
       }
       HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));
       void* args[] = {(void*)&M, (void*)&At, (void*)&n_rec, (void*)&n_srv_pref, (void*)&k_short, (void*)&fly_iters, (void*)&fly_idle, (void*)&emit_qmax};
@@ -1303,29 +1273,12 @@ static int launch_mega(mcgpu_ctx* ctx, const RunArgs& A, bool use_lds, int grid_
       return MCGPU_OK;
     }
   }
-#define LAUNCH(a, b, c)                                                                \
-  e = use_lds ? launch_k<a, b, c, true>(M, A, blocks, threads, lds_k, ctx->stream)     \
-              : launch_k<a, b, c, false>(M, A, blocks, threads, lds_k, ctx->stream)
-#define LAUNCHM(b, c)                                                                                                   \
-  {                                                                                                                     \
-    const void* kern = l3d ? (use_lds ? (const void*)k_thermal_lds<true, b, c, true> : (const void*)k_thermal<true, b, c, true>) \
-                           : (use_lds ? (const void*)k_thermal_lds<false, b, c, true> : (const void*)k_thermal<false, b, c, true>); \
-    e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k);                               \
-    void* args[] = {(void*)&M, (void*)&A};                                                                               \
-    if (e == hipSuccess) e = hipLaunchKernel(kern, dim3(blocks), dim3(threads), args, lds_k, ctx->stream);               \
+  {
+    const void* kern = kpick_thermal(use_lds, l3d, pola, dark, M.mrw != 0);
+    e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k);
+    void* args[] = {(void*)&M, (void*)&A};
+    if (e == hipSuccess) e = hipLaunchKernel(kern, dim3(blocks), dim3(threads), args, lds_k, ctx->stream);
   }
-  if (M.mrw) {
-    if (pola) { if (dark) LAUNCHM(true, true) else LAUNCHM(true, false) }
-    else { if (dark) LAUNCHM(false, true) else LAUNCHM(false, false) }
-  } else if (l3d) {
-    if (pola) { if (dark) LAUNCH(true, true, true); else LAUNCH(true, true, false); }
-    else { if (dark) LAUNCH(true, false, true); else LAUNCH(true, false, false); }
-  } else {
-    if (pola) { if (dark) LAUNCH(false, true, true); else LAUNCH(false, true, false); }
-    else { if (dark) LAUNCH(false, false, true); else LAUNCH(false, false, false); }
-  }
-#undef LAUNCH
-#undef LAUNCHM
   if (e != hipSuccess) {
     ctx->err = std::string("kernel launch: ") + hipGetErrorString(e);
     return MCGPU_ERR_HIP;
@@ -1353,8 +1306,7 @@ static int launch_voro(mcgpu_ctx* ctx, const RunArgs& A, int grid_blocks, int bl
     const size_t lds = lds_t + ((size_t)12 << log_ns);
     const int threads = (block_threads > 0 && block_threads <= 768) ? block_threads : 768;
     if (threads % 64) return fail(ctx, MCGPU_ERR_ARG, "block_threads must be a multiple of 64");
-    const void* fn = M.mrw ? (pola ? (const void*)k_thermal_voro_var<true, true> : (const void*)k_thermal_voro_var<false, true>)
-                           : (pola ? (const void*)k_thermal_voro_var<true, false> : (const void*)k_thermal_voro_var<false, false>);
+    const void* fn = kpick_voro_var(pola, M.mrw != 0);
     HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int blocks = grid_blocks;
     if (blocks <= 0) {
@@ -1373,7 +1325,7 @@ static int launch_voro(mcgpu_ctx* ctx, const RunArgs& A, int grid_blocks, int bl
     const bool pola = ctx->lsepar_pola != 0;
     const int threads = (block_threads > 0 && block_threads <= 256) ? block_threads : 256;
     if (threads % 64) return fail(ctx, MCGPU_ERR_ARG, "block_threads must be a multiple of 64");
-    const void* fn = pola ? (const void*)k_thermal_voro_mrw<true> : (const void*)k_thermal_voro_mrw<false>;
+    const void* fn = kpick_voro_mrw(pola);
     HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t));
     int blocks = grid_blocks;
     if (blocks <= 0) {
@@ -1407,7 +1359,7 @@ static int launch_voro(mcgpu_ctx* ctx, const RunArgs& A, int grid_blocks, int bl
       int n_srv_pref = tune("MCGPU_N_SRV", (rthreads / 64 + 1) / 2, 1, 1016);  // (this grid's packets interact as often as they cross)
       int k_short = tune("MCGPU_K_SHORT", 2, 0, 64), fly_iters = tune("MCGPU_FLY_ITERS", 16, 1, 256);
       int fly_idle = tune("MCGPU_FLY_IDLE", 32, 1, 65), emit_qmax = tune("MCGPU_EMIT_QMAX", 128, 0, 1 << 20);
-      const void* fn = pola ? (const void*)k_thermal_voro_roles<true> : (const void*)k_thermal_voro_roles<false>;
+      const void* fn = kpick_voro_roles(pola);
       HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));
       void* args[] = {(void*)&M, (void*)&A, (void*)&ctx->V, (void*)&log_ns, (void*)&n_rec, (void*)&n_srv_pref, (void*)&k_short,
                       (void*)&fly_iters, (void*)&fly_idle, (void*)&emit_qmax};
@@ -1429,11 +1381,8 @@ static int launch_voro(mcgpu_ctx* ctx, const RunArgs& A, int grid_blocks, int bl
   const int threads = (block_threads > 0 && block_threads <= max_threads) ? block_threads : (cache ? 768 : max_threads);
   if (threads % 64) return fail(ctx, MCGPU_ERR_ARG, "block_threads must be a multiple of 64");
   const bool pola = ctx->lsepar_pola != 0;
-  const bool big = threads > 768, mid = threads > 512 && !big;  // which register budget the workgroup was compiled for
-  const void* fn = cache ? (big ? (pola ? (const void*)k_thermal_voro_cache<true, 1024> : (const void*)k_thermal_voro_cache<false, 1024>)
-                            : mid ? (pola ? (const void*)k_thermal_voro_cache<true, 768> : (const void*)k_thermal_voro_cache<false, 768>)
-                                  : (pola ? (const void*)k_thermal_voro_cache<true, 512> : (const void*)k_thermal_voro_cache<false, 512>))
-                         : (pola ? (const void*)k_thermal_voro<true> : (const void*)k_thermal_voro<false>);
+  // (which register budget the workgroup was compiled for: 512 / 768 / 1024 threads)
+  const void* fn = cache ? kpick_voro_cache(pola, threads) : kpick_voro(pola);
   HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int blocks = grid_blocks;
   if (blocks <= 0) {
@@ -1444,18 +1393,9 @@ static int launch_voro(mcgpu_ctx* ctx, const RunArgs& A, int grid_blocks, int bl
     const unsigned long long need = (A.n_packets + threads - 1) / threads;
     if ((unsigned long long)blocks > need) blocks = (int)(need ? need : 1);
   }
-  if (cache && big) {
-    if (pola) hipLaunchKernelGGL((k_thermal_voro_cache<true, 1024>), dim3(blocks), dim3(threads), lds, ctx->stream, M, A, ctx->V, log_ns);
-    else hipLaunchKernelGGL((k_thermal_voro_cache<false, 1024>), dim3(blocks), dim3(threads), lds, ctx->stream, M, A, ctx->V, log_ns);
-  } else if (cache && mid) {
-    if (pola) hipLaunchKernelGGL((k_thermal_voro_cache<true, 768>), dim3(blocks), dim3(threads), lds, ctx->stream, M, A, ctx->V, log_ns);
-    else hipLaunchKernelGGL((k_thermal_voro_cache<false, 768>), dim3(blocks), dim3(threads), lds, ctx->stream, M, A, ctx->V, log_ns);
-  } else if (cache) {
-    if (pola) hipLaunchKernelGGL((k_thermal_voro_cache<true, 512>), dim3(blocks), dim3(threads), lds, ctx->stream, M, A, ctx->V, log_ns);
-    else hipLaunchKernelGGL((k_thermal_voro_cache<false, 512>), dim3(blocks), dim3(threads), lds, ctx->stream, M, A, ctx->V, log_ns);
-  } else {
-    if (pola) hipLaunchKernelGGL(k_thermal_voro<true>, dim3(blocks), dim3(threads), lds, ctx->stream, M, A, ctx->V);
-    else hipLaunchKernelGGL(k_thermal_voro<false>, dim3(blocks), dim3(threads), lds, ctx->stream, M, A, ctx->V);
+  {
+    void* args[] = {(void*)&M, (void*)&A, (void*)&ctx->V, (void*)&log_ns};   // (k_thermal_voro takes the first three)
+    hipLaunchKernel(fn, dim3(blocks), dim3(threads), args, lds, ctx->stream);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
@@ -1484,21 +1424,44 @@ static int bin_shift_for(int n_cells) {
   return s;
 }
 
-static int bin_prepare(mcgpu_ctx* ctx, int n_parts) {
+// Does the binned path fit this model at all?  (bucket count, and the staging buckets + tables + the least number of
+// packet records in the LDS of one CU.)  The automatic deposit mode falls back to HBM atomics where it does not.
+static bool bin_fits(const mcgpu_ctx* ctx) {
+  const DevModel& M = ctx->M;
+  const int shift = bin_shift_for(M.n_cells);
+  const int nb = (M.n_cells + (1 << shift) - 1) >> shift;
+  if (nb > BIN_MAX_BUCKETS) return false;
+  const size_t lds_cap = 160 * 1024 - 512;
+  const size_t lds_t = (lds_bytes(M) + 7) / 8 * 8, lds_b = (bin_lds_bytes(nb) + 7) / 8 * 8;
+  return lds_t + lds_b < lds_cap && rq_records_that_fit(ctx->lsepar_pola != 0, lds_cap - lds_t - lds_b) > 0;
+}
+
+// The deposit log of this launch.  Automatic size: what the packets asked for are expected to deposit -- n_packets x
+// deposits per packet (measured by the context's first launch; 400 before that) x 1.5 of slack, 12 bytes each --,
+// at most 24 GiB (32 M blocks = 2e9 deposits per chunk) and at most a quarter of the device's free memory (other
+// contexts of the process, xJ_abs, xI_scatt want theirs); an existing log is kept while it is large enough.
+static int bin_prepare(mcgpu_ctx* ctx, int n_parts, uint64_t n_packets) {
   const DevModel& M = ctx->M;
   const int shift = bin_shift_for(M.n_cells);
   const int nb = (M.n_cells + (1 << shift) - 1) >> shift;
   if (nb > BIN_MAX_BUCKETS) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "binned deposits: too many cells");
-  if (ctx->bin.keys && ctx->bin.n_buckets == nb && ctx->bin.shift == shift && ctx->bin_max_parts >= n_parts) return MCGPU_OK;
+  const size_t block_bytes = (size_t)BIN_H * (sizeof(double) + sizeof(unsigned int));
+  const unsigned long long least = (unsigned long long)nb * n_parts * 2;
+  const double dep_pp = ctx->bin_dep_per_packet > 0.0 ? ctx->bin_dep_per_packet : 400.0;
+  double want_b = (double)n_packets * dep_pp * 1.5 * (double)(sizeof(double) + sizeof(unsigned int));
+  if (want_b < 64.0 * 1048576.0) want_b = 64.0 * 1048576.0;
+  if (want_b > 24.0 * 1073741824.0) want_b = 24.0 * 1073741824.0;
+  if (ctx->opt_log_mb > 0) want_b = (double)((size_t)ctx->opt_log_mb << 20);
+  const bool same = ctx->bin.keys && ctx->bin.n_buckets == nb && ctx->bin.shift == shift && ctx->bin_max_parts >= n_parts;
+  if (same && (ctx->opt_log_mb > 0 || (double)ctx->bin_total_blocks * (double)block_bytes >= 0.999 * want_b ||
+               ctx->bin_log_capped)) return MCGPU_OK;
   bin_release(ctx);
   size_t free_b = 0, total_b = 0;
   HIPCHK(hipMemGetInfo(&free_b, &total_b));
-  // automatic size: 24 GiB (32 M blocks = 2e9 deposits per chunk) or a third of what is free
-  size_t bytes = ctx->opt_log_mb > 0 ? (size_t)ctx->opt_log_mb << 20 : (size_t)24 << 30;
-  if (ctx->opt_log_mb <= 0 && bytes > free_b / 3) bytes = free_b / 3;
-  const size_t block_bytes = (size_t)BIN_H * (sizeof(double) + sizeof(unsigned int));
+  size_t bytes = (size_t)want_b;
+  ctx->bin_log_capped = false;
+  if (ctx->opt_log_mb <= 0 && bytes > free_b / 4) { bytes = free_b / 4; ctx->bin_log_capped = true; }
   unsigned long long blocks = bytes / block_bytes;
-  const unsigned long long least = (unsigned long long)nb * n_parts * 2;
   if (blocks < least) blocks = least;
   if (blocks > 0xFFFFFFFFull) blocks = 0xFFFFFFFFull;  // (block indices are 32-bit)
   HIPCHK(hipMalloc((void**)&ctx->bin.keys, blocks * BIN_H * sizeof(unsigned int)));
@@ -1529,15 +1492,14 @@ static int launch_binned(mcgpu_ctx* ctx, RunArgs A, const mcgpu_run_opts* o) {
   if (rthreads % 64) return fail(ctx, MCGPU_ERR_ARG, "block_threads must be a multiple of 64");
   const int n_cu = ctx->prop.multiProcessorCount;
   const int max_parts = o->grid_blocks > n_cu ? o->grid_blocks : n_cu;
-  int rc = bin_prepare(ctx, max_parts);
+  int rc = bin_prepare(ctx, max_parts, A.n_packets);
   if (rc) return rc;
   const size_t lds_b = (bin_lds_bytes(ctx->bin.n_buckets) + 7) / 8 * 8;
   int n_rec = lds_t + lds_b < lds_cap ? rq_records_that_fit(pola, lds_cap - lds_t - lds_b) : 0;
   if (n_rec > 2 * rthreads) n_rec = 2 * rthreads > RQ_MIN_REC ? 2 * rthreads : RQ_MIN_REC;
   if (n_rec <= 0) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "binned deposits: the staging buckets and the packet records do not fit in LDS");
   const size_t lds_r = lds_t + lds_b + rq_lds_bytes(pola, n_rec);
-  const void* fn = pola ? (dark ? (const void*)k_thermal_roles_bin<true, true> : (const void*)k_thermal_roles_bin<true, false>)
-                        : (dark ? (const void*)k_thermal_roles_bin<false, true> : (const void*)k_thermal_roles_bin<false, false>);
+  const void* fn = kpick_roles_bin(pola, dark);
   if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r) != hipSuccess) {
     ctx->err = "binned deposits: LDS request of " + std::to_string(lds_r) + " bytes refused (tables " + std::to_string(lds_t) +
                ", staging " + std::to_string(lds_b) + ", records " + std::to_string(n_rec) + ")";
@@ -1659,8 +1621,8 @@ extern "C" int mcgpu_launch_thermal(mcgpu_ctx* ctx, const mcgpu_run_opts* o) {
   A.min_active = tune("MCGPU_MIN_ACTIVE", ctx->voro ? 48 : 32, 0, 64);
   A.flags = tune("MCGPU_DIAG_FLAGS", 0, 0, 0x7FFFFFFF);  // (diagnostic builds only)
   if (ctx->opt_radiation_field & 1) {
-    if (!ctx->d_xN) { HIPCHK(hipMalloc((void**)&ctx->d_xN, (size_t)M.n_cells * sizeof(unsigned int))); HIPCHK(hipMemset(ctx->d_xN, 0, (size_t)M.n_cells * sizeof(unsigned int))); }
-    if (!o->accumulate) HIPCHK(hipMemsetAsync(ctx->d_xN, 0, (size_t)M.n_cells * sizeof(unsigned int), ctx->stream));
+    if (!ctx->d_xN) { HIPCHK(hipMalloc((void**)&ctx->d_xN, (size_t)M.n_cells * sizeof(unsigned long long))); HIPCHK(hipMemset(ctx->d_xN, 0, (size_t)M.n_cells * sizeof(unsigned long long))); }
+    if (!o->accumulate) HIPCHK(hipMemsetAsync(ctx->d_xN, 0, (size_t)M.n_cells * sizeof(unsigned long long), ctx->stream));
     A.xN_abs = ctx->d_xN;
   }
   if (ctx->opt_radiation_field & 2) {
@@ -1692,7 +1654,13 @@ extern "C" int mcgpu_launch_thermal(mcgpu_ctx* ctx, const mcgpu_run_opts* o) {
   if (ctx->opt_deposit == 3) {
     if (!bin_applicable(ctx, A)) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "deposit = binned: 3D cylindrical grids, one dust class, role schedule");
     use_bin = true; use_lds = false;
-  } else if (ctx->opt_deposit == 0 && !use_lds && bin_applicable(ctx, A)) use_bin = true;
+  } else if (ctx->opt_deposit == 0 && !use_lds && bin_applicable(ctx, A) && bin_fits(ctx)) {
+    // automatic mode: binned deposits where they fit -- and where the log can be had; otherwise the HBM atomics every
+    // such grid ran on before round 3 (only the explicit deposit = 3 reports why the binned path cannot run)
+    const int n_cu = ctx->prop.multiProcessorCount;
+    use_bin = bin_prepare(ctx, o->grid_blocks > n_cu ? o->grid_blocks : n_cu, A.n_packets) == MCGPU_OK;
+    if (!use_bin) { (void)hipGetLastError(); bin_release(ctx); ctx->err.clear(); }
+  }
   HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
   int rc3 = use_bin ? launch_binned(ctx, A, o) : launch_mega(ctx, A, use_lds, o->grid_blocks, o->block_threads);
   if (rc3) return rc3;
@@ -1718,7 +1686,9 @@ extern "C" int mcgpu_sync(mcgpu_ctx* ctx, double* kernel_ms) {
     unsigned long long c[5] = {0ull, 0ull, 0ull, 0ull, 0ull};
     HIPCHK(hipMemcpy(c, ctx->d_counters, sizeof(c), hipMemcpyDeviceToHost));
     if (c[0] > 1000ull) {
-      if (ctx->bin.keys) ctx->bin_dep_per_packet = (double)c[1] / (double)c[0];
+      // (sticky: the first launch's measurement sizes the chunks of every later one, so that launches 2, 3, ... of a
+      // context follow one plan; the first runs on the guess of 400 deposits per packet)
+      if (ctx->bin.keys && !(ctx->bin_dep_per_packet > 0.0)) ctx->bin_dep_per_packet = (double)c[1] / (double)c[0];
       ctx->last_inter_pp = (double)(c[3] + c[4]) / (double)c[0];
     }
   }
@@ -1777,8 +1747,8 @@ extern "C" int mcgpu_fetch_radiation_field(mcgpu_ctx* ctx, double* xN_abs, doubl
   const DevModel& M = ctx->M;
   if (xN_abs) {
     if (!ctx->d_xN) return fail(ctx, MCGPU_ERR_STATE, "xN_abs was not accumulated (option radiation_field bit 0)");
-    std::vector<unsigned int> h(M.n_cells);
-    HIPCHK(hipMemcpy(h.data(), ctx->d_xN, (size_t)M.n_cells * sizeof(unsigned int), hipMemcpyDeviceToHost));
+    std::vector<unsigned long long> h(M.n_cells);
+    HIPCHK(hipMemcpy(h.data(), ctx->d_xN, (size_t)M.n_cells * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     for (int i = 0; i < M.n_cells; ++i) xN_abs[i] = (double)h[i];
   }
   if (xJ_abs) {
@@ -1897,23 +1867,9 @@ static int launch_mono(mcgpu_ctx* ctx, const MonoArgs& A, int grid_blocks, int b
   // (the commit pass of a context with default-real xI_scatt runs the F32 variant of the deposit code)
   constexpr bool kCommit = !SCOUT;
   const bool f32 = kCommit && A.rt1 && ctx->xI_bytes == 4;
-#define PICK(a, b, c) fn = f32 ? (const void*)k_mono<a, b, c, SCOUT, kCommit> : (const void*)k_mono<a, b, c, SCOUT, false>
-  if (ctx->voro) {
-    if (f32) fn = pola ? (const void*)k_mono_voro<true, SCOUT, kCommit> : (const void*)k_mono_voro<false, SCOUT, kCommit>;
-    else fn = pola ? (const void*)k_mono_voro<true, SCOUT, false> : (const void*)k_mono_voro<false, SCOUT, false>;
-  } else if (M.grid_sph) {
-#define PICKS(a, b) fn = f32 ? (const void*)k_mono_sph<a, b, SCOUT, kCommit> : (const void*)k_mono_sph<a, b, SCOUT, false>
-    if (l3d) { if (pola) PICKS(true, true); else PICKS(true, false); }
-    else { if (pola) PICKS(false, true); else PICKS(false, false); }
-#undef PICKS
-  } else if (l3d) {
-    if (pola) { if (dark) PICK(true, true, true); else PICK(true, true, false); }
-    else { if (dark) PICK(true, false, true); else PICK(true, false, false); }
-  } else {
-    if (pola) { if (dark) PICK(false, true, true); else PICK(false, true, false); }
-    else { if (dark) PICK(false, false, true); else PICK(false, false, false); }
-  }
-#undef PICK
+  if (ctx->voro) fn = kpick_mono_voro(pola, SCOUT, f32);
+  else if (M.grid_sph) fn = kpick_mono_sph(l3d, pola, SCOUT, f32);
+  else fn = kpick_mono(l3d, pola, dark, SCOUT, f32);
   // workgroup size: the one that keeps the most wavefronts on a CU, up to 8 (2 per SIMD).  The r02 build needs only
   // 101-169 VGPRs here, so the registers would admit 3-4 waves per SIMD -- measured slower (bench sed 4.03e7 against
   // 4.87e7 packets/s): this mode is bound by the xI_scatt atomics, and more waves in flight only deepen their queues.
@@ -3029,8 +2985,11 @@ struct mcgpu_multi {
   std::vector<int> devs;
   std::vector<mcgpu_ctx*> ctx;
   std::vector<ncclComm_t> comm;   // empty until the first collective (one device never needs them)
+  bool shared = false;            // MCGPU_MULTI_SHARED_DEVICE: every context on ONE device, sums by k_sum_into (RCCL refuses duplicate devices)
+  std::vector<hipEvent_t> ev;     // shared mode: one event per context for the cross-stream ordering of the in-library sum
+  unsigned long long n_reduce = 0; // collectives executed (either kind)
   bool reduced = false;           // the accumulators of every device hold the all-reduced totals of the last call
-  bool reduced_xI = false;
+  int reduced_what = 0;           // ... and which of xI_scatt / I_spec do (MULTI_XI | MULTI_ISPEC)
   std::string err;
 };
 
@@ -3043,32 +3002,62 @@ __global__ void k_scale_f32(float* a, size_t n, float f) {
   if (i < n) a[i] *= f;
 }
 
-extern "C" int mcgpu_multi_create(int n_dev, const int* devices, mcgpu_multi** out) {
-  if (!out || n_dev < 1) return MCGPU_ERR_ARG;
+__global__ void k_sum_into(double* a, const double* b, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a[i] += b[i];
+}
+__global__ void k_sum_into_f32(float* a, const float* b, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a[i] += b[i];
+}
+
+// flags = MCGPU_MULTI_SHARED_DEVICE: the n_dev contexts all live on ONE device (devices[i] all equal; NULL: device 0)
+// and the reduction is the library's own sum kernel -- RCCL refuses a communicator with a device twice.  This is how
+// the sharding, rescaling, counter and error logic of n_dev > 1 is executed on a box with one GPU (tests, dry runs);
+// a production host passes flags = 0 and distinct devices.
+extern "C" int mcgpu_multi_create_ex(int n_dev, const int* devices, unsigned int flags, mcgpu_multi** out) {
+  if (!out || n_dev < 1 || (flags & ~(unsigned int)MCGPU_MULTI_SHARED_DEVICE)) return MCGPU_ERR_ARG;
   *out = nullptr;
+  const bool shared = (flags & MCGPU_MULTI_SHARED_DEVICE) != 0;
   int n_have = 0;
   if (hipGetDeviceCount(&n_have) != hipSuccess || n_have <= 0) return MCGPU_ERR_NO_DEVICE;
   std::vector<int> devs(n_dev);
   for (int i = 0; i < n_dev; ++i) {
-    devs[i] = devices ? devices[i] : i;
+    devs[i] = devices ? devices[i] : (shared ? 0 : i);
     if (devs[i] < 0 || devs[i] >= n_have) return MCGPU_ERR_ARG;
-    for (int j = 0; j < i; ++j) if (devs[j] == devs[i]) return MCGPU_ERR_ARG;
+    for (int j = 0; j < i; ++j) if ((devs[j] == devs[i]) != shared) return MCGPU_ERR_ARG;
   }
   mcgpu_multi* mm = new mcgpu_multi();
   mm->n_dev = n_dev;
   mm->devs = devs;
+  mm->shared = shared;
   mm->ctx.assign(n_dev, nullptr);
   for (int i = 0; i < n_dev; ++i) {
     const int rc = mcgpu_create(devs[i], &mm->ctx[i]);
     if (rc) { for (int j = 0; j < i; ++j) mcgpu_destroy(mm->ctx[j]); delete mm; return rc; }
   }
+  if (shared) {
+    mm->ev.assign(n_dev, nullptr);
+    hipSetDevice(devs[0]);
+    for (int i = 0; i < n_dev; ++i)
+      if (hipEventCreateWithFlags(&mm->ev[i], hipEventDisableTiming) != hipSuccess) {
+        for (int j = 0; j < i; ++j) hipEventDestroy(mm->ev[j]);
+        for (int j = 0; j < n_dev; ++j) mcgpu_destroy(mm->ctx[j]);
+        delete mm;
+        return MCGPU_ERR_HIP;
+      }
+  }
   *out = mm;
   return MCGPU_OK;
 }
 
+extern "C" int mcgpu_multi_create(int n_dev, const int* devices, mcgpu_multi** out) {
+  return mcgpu_multi_create_ex(n_dev, devices, 0u, out);
+}
+
 // the RCCL communicators, created by the first call that has something to reduce (n_dev > 1)
 static int multi_comms(mcgpu_multi* mm) {
-  if (mm->n_dev < 2 || !mm->comm.empty()) return MCGPU_OK;
+  if (mm->n_dev < 2 || mm->shared || !mm->comm.empty()) return MCGPU_OK;
   mm->comm.assign(mm->n_dev, nullptr);
   if (ncclCommInitAll(mm->comm.data(), mm->n_dev, mm->devs.data()) != ncclSuccess) {
     mm->comm.clear();
@@ -3083,6 +3072,7 @@ extern "C" int mcgpu_multi_destroy(mcgpu_multi* mm) {
   for (int i = 0; i < mm->n_dev; ++i) {
     if (mm->ctx[i]) { hipSetDevice(mm->ctx[i]->device); hipDeviceSynchronize(); }
     if (i < (int)mm->comm.size() && mm->comm[i]) ncclCommDestroy(mm->comm[i]);
+    if (i < (int)mm->ev.size() && mm->ev[i]) hipEventDestroy(mm->ev[i]);
   }
   for (int i = 0; i < mm->n_dev; ++i) mcgpu_destroy(mm->ctx[i]);
   delete mm;
@@ -3098,6 +3088,8 @@ extern "C" int mcgpu_multi_rccl_ranks(mcgpu_multi* mm) {
   int n = 0;
   return ncclCommCount(mm->comm[0], &n) == ncclSuccess ? n : -1;
 }
+// collectives this handle has executed so far (RCCL all-reduces, or the shared-device sums that stand in for them)
+extern "C" uint64_t mcgpu_multi_reductions(const mcgpu_multi* mm) { return mm ? mm->n_reduce : 0; }
 
 // the shard of device i: contiguous, disjoint, exhaustive (same rule as mcfost_amd/distributed.py::shard_packets)
 extern "C" void mcgpu_shard_packets(uint64_t n_packets, int rank, int world, uint64_t* first, uint64_t* count) {
@@ -3110,53 +3102,102 @@ static void multi_drain(mcgpu_multi* mm) {  // after an error: nothing of this c
   for (int i = 0; i < mm->n_dev; ++i) { hipSetDevice(mm->ctx[i]->device); hipStreamSynchronize(mm->ctx[i]->stream); }
 }
 
+// What a collective sums besides the fused accumulator: the SED step's ray-tracing deposits
+enum { MULTI_XI = 1, MULTI_ISPEC = 2 };
+struct RedBuf { void* p; size_t n; bool f32; };
+static std::vector<RedBuf> multi_bufs(mcgpu_ctx* c, int what, bool accum) {
+  std::vector<RedBuf> v;
+  if (accum && c->d_accum) v.push_back({c->d_accum, c->n_accum, false});
+  if ((what & MULTI_XI) && c->d_xI) v.push_back({c->d_xI, xi_dev_values(c), c->xI_bytes == 4});
+  if ((what & MULTI_ISPEC) && c->d_I_spec) {   // ray tracing method 2 (radiation_field.f90:91-129)
+    v.push_back({c->d_I_spec, (size_t)c->M.n_cells * c->n_phi_I * c->n_theta_I * XI_LINE, false});
+    v.push_back({c->d_I_spec_star, (size_t)c->M.n_cells, false});
+  }
+  return v;
+}
+static inline int multi_what(const mcgpu_mono_opts* o) { return o->rt1 == 1 ? MULTI_XI : (o->rt1 == 2 ? MULTI_ISPEC : 0); }
+
 // An accumulating call on several devices: after the last call's in-place all-reduce EVERY device holds the global
 // sums G, and adding this call's local parts L_i to n copies of G would reduce to n G + sum L_i.  So each device first
 // scales what it holds by 1/n -- n (G / n + L_i) = G + n L_i is also exactly what the in-flight temperature's
 // `local * n_replicas` should see -- and devices > 0 clear their event counters (integers; device 0 keeps the totals).
-// Exact for 2, 4, 8 devices (a power of two); otherwise G / n carries one rounding.
-static int multi_prepare_accumulate(mcgpu_multi* mm, bool with_xI) {
+// Exact for 2, 4, 8 devices (a power of two); otherwise G / n carries one rounding.  Only buffers that HOLD reduced
+// totals are scaled (reduced_what: which of xI_scatt / I_spec the last collective summed).
+static int multi_prepare_accumulate(mcgpu_multi* mm, int what) {
   const int n = mm->n_dev;
   if (n < 2) return MCGPU_OK;
   for (int i = 0; i < n; ++i) {
     mcgpu_ctx* c = mm->ctx[i];
     if (hipSetDevice(c->device) != hipSuccess) return MCGPU_ERR_HIP;
-    if (mm->reduced && c->d_accum) {
-      hipLaunchKernelGGL(k_scale_f64, dim3((unsigned)((c->n_accum + 255) / 256)), dim3(256), 0, c->stream, c->d_accum, c->n_accum, 1.0 / n);
-      if (i > 0 && hipMemsetAsync(c->d_counters, 0, MCGPU_N_COUNTERS * sizeof(unsigned long long), c->stream) != hipSuccess) return MCGPU_ERR_HIP;
-    }
-    if (with_xI && mm->reduced_xI && c->d_xI) {
-      const size_t nv = xi_dev_values(c);
-      if (c->xI_bytes == 4) hipLaunchKernelGGL(k_scale_f32, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, c->stream, reinterpret_cast<float*>(c->d_xI), nv, 1.0f / n);
-      else hipLaunchKernelGGL(k_scale_f64, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, c->stream, c->d_xI, nv, 1.0 / n);
+    if (mm->reduced && c->d_accum && i > 0 &&
+        hipMemsetAsync(c->d_counters, 0, MCGPU_N_COUNTERS * sizeof(unsigned long long), c->stream) != hipSuccess) return MCGPU_ERR_HIP;
+    for (const RedBuf& b : multi_bufs(c, what & mm->reduced_what, mm->reduced)) {
+      const dim3 g((unsigned)((b.n + 255) / 256));
+      if (b.f32) hipLaunchKernelGGL(k_scale_f32, g, dim3(256), 0, c->stream, reinterpret_cast<float*>(b.p), b.n, 1.0f / n);
+      else hipLaunchKernelGGL(k_scale_f64, g, dim3(256), 0, c->stream, reinterpret_cast<double*>(b.p), b.n, 1.0 / n);
     }
     if (hipGetLastError() != hipSuccess) return MCGPU_ERR_HIP;
   }
   return MCGPU_OK;
 }
 
-// ONE all-reduce of the fused accumulator (counters in its tail), in place, on every device's own stream; with_xI:
-// and one of xI_scatt
-static int multi_allreduce(mcgpu_multi* mm, bool with_xI) {
+// ONE all-reduce of the fused accumulator (counters in its tail), in place, on every device's own stream; `what`:
+// and one of xI_scatt (ray tracing method 1) or of I_spec + I_spec_star (method 2)
+static int multi_allreduce(mcgpu_multi* mm, int what) {
   const int n = mm->n_dev;
   auto failed = [&](int i, int rc) { mm->err = "device " + std::to_string(i) + ": " + mcgpu_last_error(mm->ctx[i]); return rc; };
   if (n < 2) return MCGPU_OK;
   int rc = multi_comms(mm);
   if (rc) return rc;
   for (int i = 0; i < n; ++i) if ((rc = mcgpu_counters_to_accum(mm->ctx[i]))) return failed(i, rc);
-  if (ncclGroupStart() != ncclSuccess) { mm->err = "ncclGroupStart failed"; return MCGPU_ERR_HIP; }
-  bool bad = false;
-  for (int i = 0; i < n && !bad; ++i) {
-    mcgpu_ctx* c = mm->ctx[i];
-    hipSetDevice(c->device);
-    bad = ncclAllReduce(c->d_accum, c->d_accum, c->n_accum, ncclDouble, ncclSum, mm->comm[i], c->stream) != ncclSuccess;
-    if (!bad && with_xI && c->d_xI)
-      bad = ncclAllReduce(c->d_xI, c->d_xI, xi_dev_values(c), c->xI_bytes == 4 ? ncclFloat : ncclDouble, ncclSum, mm->comm[i], c->stream) != ncclSuccess;
+  std::vector<std::vector<RedBuf>> bufs(n);
+  for (int i = 0; i < n; ++i) {
+    bufs[i] = multi_bufs(mm->ctx[i], what, true);
+    bool same = bufs[i].size() == bufs[0].size();
+    for (size_t q = 0; same && q < bufs[i].size(); ++q) same = bufs[i][q].n == bufs[0][q].n && bufs[i][q].f32 == bufs[0][q].f32;
+    if (!same) { mm->err = "the contexts of the handle do not hold the same model"; return MCGPU_ERR_STATE; }
   }
-  if (ncclGroupEnd() != ncclSuccess || bad) { mm->err = "ncclAllReduce failed"; return MCGPU_ERR_HIP; }
+  if (mm->shared) {
+    // every context on one device: context 0's stream waits for the others, sums their buffers into its own, and the
+    // others copy the totals back -- what the in-place all-reduce leaves behind, by plain kernels
+    mcgpu_ctx* c0 = mm->ctx[0];
+    if (hipSetDevice(c0->device) != hipSuccess) return MCGPU_ERR_HIP;
+    bool bad = false;
+    for (int i = 1; i < n && !bad; ++i) {
+      bad = hipEventRecord(mm->ev[i], mm->ctx[i]->stream) != hipSuccess || hipStreamWaitEvent(c0->stream, mm->ev[i], 0) != hipSuccess;
+      for (size_t q = 0; q < bufs[0].size() && !bad; ++q) {
+        const RedBuf &a = bufs[0][q], &b = bufs[i][q];
+        const dim3 g((unsigned)((a.n + 255) / 256));
+        if (a.f32) hipLaunchKernelGGL(k_sum_into_f32, g, dim3(256), 0, c0->stream, reinterpret_cast<float*>(a.p), reinterpret_cast<const float*>(b.p), a.n);
+        else hipLaunchKernelGGL(k_sum_into, g, dim3(256), 0, c0->stream, reinterpret_cast<double*>(a.p), reinterpret_cast<const double*>(b.p), a.n);
+        bad = hipGetLastError() != hipSuccess;
+      }
+    }
+    bad = bad || hipEventRecord(mm->ev[0], c0->stream) != hipSuccess;
+    for (int i = 1; i < n && !bad; ++i) {
+      mcgpu_ctx* c = mm->ctx[i];
+      bad = hipStreamWaitEvent(c->stream, mm->ev[0], 0) != hipSuccess;
+      for (size_t q = 0; q < bufs[0].size() && !bad; ++q)
+        bad = hipMemcpyAsync(bufs[i][q].p, bufs[0][q].p, bufs[0][q].n * (bufs[0][q].f32 ? 4 : 8), hipMemcpyDeviceToDevice, c->stream) != hipSuccess;
+      // (context 0 must not start its next launch before the others have read its totals)
+      bad = bad || hipEventRecord(mm->ev[i], c->stream) != hipSuccess || hipStreamWaitEvent(c0->stream, mm->ev[i], 0) != hipSuccess;
+    }
+    if (bad) { mm->err = "shared-device reduction failed"; return MCGPU_ERR_HIP; }
+  } else {
+    if (ncclGroupStart() != ncclSuccess) { mm->err = "ncclGroupStart failed"; return MCGPU_ERR_HIP; }
+    bool bad = false;
+    for (int i = 0; i < n && !bad; ++i) {
+      mcgpu_ctx* c = mm->ctx[i];
+      hipSetDevice(c->device);
+      for (size_t q = 0; q < bufs[i].size() && !bad; ++q)
+        bad = ncclAllReduce(bufs[i][q].p, bufs[i][q].p, bufs[i][q].n, bufs[i][q].f32 ? ncclFloat : ncclDouble, ncclSum, mm->comm[i], c->stream) != ncclSuccess;
+    }
+    if (ncclGroupEnd() != ncclSuccess || bad) { mm->err = "ncclAllReduce failed"; return MCGPU_ERR_HIP; }
+  }
   for (int i = 0; i < n; ++i) if ((rc = mcgpu_counters_from_accum(mm->ctx[i]))) return failed(i, rc);
   mm->reduced = true;
-  if (with_xI) mm->reduced_xI = true;
+  mm->reduced_what |= what;
+  mm->n_reduce++;
   return MCGPU_OK;
 }
 
@@ -3166,7 +3207,7 @@ extern "C" int mcgpu_multi_run_thermal(mcgpu_multi* mm, const mcgpu_run_opts* op
   const int n = mm->n_dev;
   auto failed = [&](int i, int rc) { mm->err = "device " + std::to_string(i) + ": " + mcgpu_last_error(mm->ctx[i]); multi_drain(mm); return rc; };
   int rc;
-  if (opts->accumulate) { if ((rc = multi_prepare_accumulate(mm, false))) { multi_drain(mm); return rc; } }
+  if (opts->accumulate) { if ((rc = multi_prepare_accumulate(mm, 0))) { multi_drain(mm); return rc; } }
   else mm->reduced = false;
   // 1) every device runs its shard of the packet ids; the in-flight temperature scales the local partial sum by
   //    the number of replicas (thermal_emission.f90:670)
@@ -3180,7 +3221,7 @@ extern "C" int mcgpu_multi_run_thermal(mcgpu_multi* mm, const mcgpu_run_opts* op
     if ((rc = mcgpu_launch_thermal(mm->ctx[i], &o))) return failed(i, rc);
   }
   // 2) the all-reduce (nothing to do on one device: no communicator is ever created there)
-  if ((rc = multi_allreduce(mm, false))) { multi_drain(mm); return rc; }
+  if ((rc = multi_allreduce(mm, 0))) { multi_drain(mm); return rc; }
   // 3) wait; the packet loop's time is the slowest device's
   double ms_max = 0.0;
   for (int i = 0; i < n; ++i) {
@@ -3205,8 +3246,9 @@ extern "C" int mcgpu_multi_run_mono(mcgpu_multi* mm, const mcgpu_mono_opts* opts
   const int n = mm->n_dev;
   if (opts->n_chunks < n) { mm->err = "mcgpu_multi_run_mono: more devices than streams"; return MCGPU_ERR_ARG; }
   int rc;
-  if (opts->accumulate) { if ((rc = multi_prepare_accumulate(mm, opts->rt1 != 0))) { multi_drain(mm); return rc; } }
-  else { mm->reduced = false; mm->reduced_xI = false; }
+  const int what = multi_what(opts);
+  if (opts->accumulate) { if ((rc = multi_prepare_accumulate(mm, what))) { multi_drain(mm); return rc; } }
+  else { mm->reduced = false; mm->reduced_what &= ~what; }   // (this call clears what it deposits into; the other kind keeps its state)
   std::vector<int> rcs(n, 0);
   std::vector<double> ms(n, 0.0);
   std::vector<std::thread> th;
@@ -3223,7 +3265,7 @@ extern "C" int mcgpu_multi_run_mono(mcgpu_multi* mm, const mcgpu_mono_opts* opts
   for (auto& t : th) t.join();
   for (int i = 0; i < n; ++i)
     if (rcs[i]) { mm->err = "device " + std::to_string(i) + ": " + mcgpu_last_error(mm->ctx[i]); multi_drain(mm); return rcs[i]; }
-  if ((rc = multi_allreduce(mm, opts->rt1 != 0))) { multi_drain(mm); return rc; }
+  if ((rc = multi_allreduce(mm, what))) { multi_drain(mm); return rc; }
   double ms_max = 0.0;
   for (int i = 0; i < n; ++i) {
     hipSetDevice(mm->ctx[i]->device);

@@ -36,7 +36,7 @@ ABI_SYMBOLS = (
     "mcgpu_device_xI", "mcgpu_set_ism", "mcgpu_rt1_dust_map", "mcgpu_set_xI", "mcgpu_rt1_image", "mcgpu_set_xI_precision",
     "mcgpu_get_xI_precision", "mcgpu_set_option", "mcgpu_get_info", "mcgpu_counters_to_accum", "mcgpu_counters_from_accum",
     "mcgpu_set_grid_sph", "mcgpu_temp_approx_diffusion_vertical", "mcgpu_set_mrw", "mcgpu_fetch_radiation_field", "mcgpu_set_variable_dust", "mcgpu_rt1_stars_map_sed", "mcgpu_define_dark_zone", "mcgpu_init_reemission", "mcgpu_multi_create", "mcgpu_multi_destroy", "mcgpu_multi_size", "mcgpu_multi_ctx", "mcgpu_multi_last_error",
-    "mcgpu_repartition_energie", "mcgpu_opacity", "mcgpu_set_variable_dust_s11", "mcgpu_set_scattering_method1", "mcgpu_set_rt2", "mcgpu_fetch_I_spec", "mcgpu_rt1_stars_map_image", "mcgpu_set_I_spec", "mcgpu_rt2_source", "mcgpu_rt2_dust_map", "mcgpu_rt2_image", "mcgpu_shard_packets", "mcgpu_multi_run_thermal", "mcgpu_multi_run_mono", "mcgpu_multi_rccl_ranks",
+    "mcgpu_repartition_energie", "mcgpu_opacity", "mcgpu_set_variable_dust_s11", "mcgpu_set_scattering_method1", "mcgpu_set_rt2", "mcgpu_fetch_I_spec", "mcgpu_rt1_stars_map_image", "mcgpu_set_I_spec", "mcgpu_rt2_source", "mcgpu_rt2_dust_map", "mcgpu_rt2_image", "mcgpu_shard_packets", "mcgpu_multi_run_thermal", "mcgpu_multi_run_mono", "mcgpu_multi_rccl_ranks", "mcgpu_multi_create_ex", "mcgpu_multi_reductions",
 )
 
 
@@ -797,14 +797,17 @@ class MultiEngine:
     replica of the model, packets sharded by id range, ONE RCCL all-reduce of the fused accumulator per
     temperature iteration inside the library."""
 
-    def __init__(self, model, n_packets_total, devices=(0,)):
+    def __init__(self, model, n_packets_total, devices=(0,), shared_device=False):
+        """``shared_device``: every context on ONE device (``devices`` all equal) with the library's own sum kernel in
+        place of the RCCL all-reduce (``MCGPU_MULTI_SHARED_DEVICE``): how a box with one GPU executes the n_dev > 1 code."""
         self.lib = load_library()
         self.model = model
         self.h = C.c_void_p()
         devs = (C.c_int * len(devices))(*[int(d) for d in devices])
         self.lib.mcgpu_multi_ctx.restype = C.c_void_p
         self.lib.mcgpu_multi_last_error.restype = C.c_char_p
-        rc = self.lib.mcgpu_multi_create(C.c_int(len(devices)), devs, C.byref(self.h))
+        self.lib.mcgpu_multi_reductions.restype = C.c_uint64
+        rc = self.lib.mcgpu_multi_create_ex(C.c_int(len(devices)), devs, C.c_uint(1 if shared_device else 0), C.byref(self.h))
         if rc:
             self.h = C.c_void_p()
             raise McgpuError(f"mcgpu_multi_create({list(devices)}) failed with code {rc}")
@@ -837,7 +840,7 @@ class MultiEngine:
                     counters=dict(zip(COUNTER_NAMES, (int(c) for c in cnt))))
 
     def run_mono(self, lam, n_photons2, n_phot_lim=None, p_lambda=None, seed=1, n_chunks=None, rt1=True,
-                 accumulate=False, fetch_xI=True, first_chunk=0, Tdust=None):
+                 accumulate=False, fetch_xI=True, first_chunk=0, Tdust=None, rt2=None):
         """One wavelength of the SED Monte Carlo on every device (``mcgpu_multi_run_mono``): the streams are split
         among the devices, ONE all-reduce of [sed | n_sent | counters] and one of xI_scatt; same outputs as
         ``Engine.run_mono``, read from device 0.  ``Tdust`` given: every device first builds the wavelength's emission
@@ -847,8 +850,13 @@ class MultiEngine:
         tables = None
         if Tdust is not None:
             tables = [e.repartition_energie(lam, Tdust, fetch=False) for e in self.engines][0]
+        if rt2 is not None:   # method 2's deposits (I_spec, I_spec_star) instead of xI_scatt
+            for e in self.engines:
+                if getattr(e, "_rt2", (0, 0, 0))[:2] != (int(rt2[0]), int(rt2[1])):
+                    e.set_rt2(*rt2)
+            rt1 = 2
         for e in self.engines:
-            if rt1 and not getattr(e, "_rt1", False):
+            if rt1 == 1 and not getattr(e, "_rt1", False):
                 e.set_rt1()
         nt, nphi = m.cfg.N_thet, m.cfg.N_phi
         n_chunks = int(n_chunks or m.cfg.n_photons_loop)
@@ -874,12 +882,18 @@ class MultiEngine:
         out = e0.fetch()
         out["n_sent_chunk"] = per_chunk
         out["kernel_ms"] = ms.value
-        if rt1 and fetch_xI:
+        if rt1 == 2:
+            out["I_spec"], out["I_spec_star"] = e0.fetch_I_spec()
+        if rt1 == 1 and fetch_xI:
             x64 = np.zeros(e0.xI_shape(), np.float64)
             x32 = np.zeros(e0.xI_shape(), np.float32)
             e0._chk(self.lib.mcgpu_fetch_xI(e0.ctx, _p(x32, C.c_float), _p(x64, C.c_double)), "mcgpu_fetch_xI")
             out["xI_scatt"], out["xI_scatt_f32"] = x64, x32
         return out
+
+    def reductions(self):
+        """Collectives the handle has executed (RCCL all-reduces or the shared-device sums standing in for them)."""
+        return int(self.lib.mcgpu_multi_reductions(self.h))
 
     def rccl_ranks(self):
         """Ranks of the handle's RCCL communicator as ``ncclCommCount`` reports them (0 before the first collective

@@ -22,6 +22,7 @@ module mcgpu_f
   integer, parameter :: dp = selected_real_kind(p=13,r=200) ! mcfost_env.f90:23
 
   integer(c_int), parameter, public :: MCGPU_N_SED_TYPES = 9, MCGPU_N_COUNTERS = 10
+  integer(c_int), parameter, public :: MCGPU_MULTI_SHARED_DEVICE = 1
 
   type, bind(C), public :: mcgpu_run_opts
      integer(c_int64_t) :: seed
@@ -86,7 +87,7 @@ module mcgpu_f
        mcgpu_set_stars, mcgpu_set_opacity, mcgpu_set_scattering, mcgpu_set_thermal, mcgpu_set_sed_bins, &
        mcgpu_run_thermal, mcgpu_temp_finale, mcgpu_thermal_loop, mcgpu_error_message, mcgpu_set_rt1, &
        mcgpu_run_mono, mcgpu_fetch, mcgpu_fetch_xI, mcgpu_rt1_dust_map, mcgpu_set_xI, mcgpu_rt1_image, mcgpu_set_xI_precision, &
-       mcgpu_set_E_prior, mcgpu_multi_create, mcgpu_multi_destroy, mcgpu_multi_size, mcgpu_multi_ctx, mcgpu_multi_run_thermal, mcgpu_multi_run_mono, mcgpu_multi_rccl_ranks, &
+       mcgpu_set_E_prior, mcgpu_multi_create, mcgpu_multi_destroy, mcgpu_multi_size, mcgpu_multi_ctx, mcgpu_multi_run_thermal, mcgpu_multi_run_mono, mcgpu_multi_rccl_ranks, mcgpu_multi_create_ex, mcgpu_multi_reductions, &
        mcgpu_counters_to_accum, mcgpu_counters_from_accum, mcgpu_temp_approx_diffusion_vertical, mcgpu_set_mrw, mcgpu_fetch_radiation_field, &
        mcgpu_set_variable_dust, mcgpu_rt1_stars_map_sed, mcgpu_define_dark_zone, mcgpu_init_reemission, mcgpu_repartition_energie, mcgpu_opacity, mcgpu_set_variable_dust_s11, mcgpu_set_scattering_method1, mcgpu_set_rt2, mcgpu_fetch_I_spec, mcgpu_rt1_stars_map_image, mcgpu_set_I_spec, mcgpu_rt2_source, mcgpu_rt2_dust_map, mcgpu_rt2_image
 
@@ -317,6 +318,22 @@ module mcgpu_f
        type(c_ptr), value :: devices
        type(c_ptr), intent(out) :: multi
      end function mcgpu_multi_create
+
+     ! flags = MCGPU_MULTI_SHARED_DEVICE: all n_dev contexts on ONE device, the library's own sum in place of the
+     ! RCCL all-reduce (tests and dry runs of the n_dev > 1 code on a box with one GPU)
+     integer(c_int) function mcgpu_multi_create_ex(n_dev, devices, flags, multi) bind(C, name="mcgpu_multi_create_ex")
+       import :: c_int, c_ptr
+       integer(c_int), value :: n_dev
+       type(c_ptr), value :: devices
+       integer(c_int), value :: flags
+       type(c_ptr), intent(out) :: multi
+     end function mcgpu_multi_create_ex
+
+     ! collectives the handle has executed so far
+     integer(c_int64_t) function mcgpu_multi_reductions(multi) bind(C, name="mcgpu_multi_reductions")
+       import :: c_int64_t, c_ptr
+       type(c_ptr), value :: multi
+     end function mcgpu_multi_reductions
 
      integer(c_int) function mcgpu_multi_destroy(multi) bind(C, name="mcgpu_multi_destroy")
        import :: c_int, c_ptr

@@ -126,7 +126,7 @@ def pascucci() -> DiskConfig:
         lambda_min=0.110662,
         lambda_max=2168.76,
         dust_mass=1.1e-6,
-        sclht=99.7356,
+        sclht=99.73557010035817,   # Pascucci_3.0.para:47, every digit
         rref=500.0,
         rin=1.0,
         rout=1000.0,
