@@ -1270,8 +1270,13 @@ def test_temperature_and_sed_end_to_end_on_other_grids(grid):
     assert np.percentile(np.abs(g["Tdust"][sel] / c["Tdust"][sel] - 1), 75) < 0.05
     fg = P.sed_flux(mg, g["sed_mc"], g["n_sent"])[0].sum(axis=0)[:, li]
     fc = P.sed_flux(mc, c["sed_mc"], c["n_sent"])[0].sum(axis=0)[:, li]
-    ok = c["sed_mc"][4].sum(axis=0)[:, li] >= 200
-    assert ok.sum() > 0.3 * ok.size
+    # two independent runs: a bin of N packets on each side scatters by at least sqrt(2 / N) in the ratio (more: the packets
+    # carry weights under forced scattering), and the 75th percentile of |N(0, s)| is 1.15 s -- the reference's 10 % gate
+    # is a statement about bins with at least ~500 packets (6.3 % per bin, expected p75 about 7 %; round 3's floor of 200
+    # packets put the pure counting noise AT the gate: 0.1013 on one box of round 4)
+    ng, nc = g["sed_mc"][4].sum(axis=0)[:, li], c["sed_mc"][4].sum(axis=0)[:, li]
+    ok = (nc >= 500) & (ng >= 500)
+    assert ok.sum() >= 20 and ((nc >= 50) & (ng >= 50)).sum() > 0.3 * nc.size, ok.sum()
     assert np.percentile(np.abs(fg[ok] / fc[ok] - 1), 75) < 0.10
     ig, ic_ = g["sed_rt"][li, :, 0], c["sed_rt"][li, :, 0]
     assert (ic_ > 0).all()
