@@ -75,6 +75,23 @@ __device__ __forceinline__ double nd_add(double a, double b) {
 #pragma clang fp contract(off)
   return a + b;
 }
+// sqrt(x) for x = 0 or x far above the subnormals (x >= 2^-767): the instruction sequence hipcc expands sqrt(double)
+// into -- v_rsq_f64 and two coupled Newton steps -- without the rescaling of tiny arguments and the infinity test
+// that sequence carries for the general case (7 of its 24 vector instructions).  The same bits as sqrt() on that
+// domain; the crossing's discriminants (AU^2) are never anywhere near 1e-231.
+__device__ __forceinline__ double sqrt_nonneg(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y;
+  double h = y * 0.5;
+  const double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  double d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  return (x == 0.0) ? 0.0 : g;
+}
 #endif
 
 struct DevModel {
@@ -274,7 +291,19 @@ struct Rng {
 // ---------------------------------------------------------------------------
 // LDS-resident tables
 // ---------------------------------------------------------------------------
+// What the 2D crossing (fly_step_2d, mc_roles.hip.h) reads of a radial index ri = 0 .. n_rad + 2, in ONE 40-byte row so
+// that a crossing forms one LDS address per cell instead of clamping row indices into four tables: the wall radii
+// already multiplied by the reference's correction factors (r_lim_2(ri-1) * correct_moins, r_lim_2(ri) * correct_plus:
+// cylindrical_grid.f90:978, 982 -- the products are the reference's own, rounded once, whoever forms them), the
+// cell height and surface of the column, and nz / zmax for the zj of an end point.  ri = 0 is the central hole
+// (rl_in = r_lim_2(0) unscaled, :963; rzn = 0: zj = 1 there, :1117), ri > n_rad repeats the last column (read by lanes
+// whose results are discarded).
+struct RowT {
+  double rl_in, rl_out, ch, zmax, rzn;
+};
+
 struct Lds {
+  RowT* row;        // n_rad+3 (thermal kernels only)
   double* r_lim_2;  // n_rad+1
   double* zmax;     // n_rad
   double* ch;       // n_rad
@@ -298,7 +327,7 @@ struct Lds {
 // only column p_lambda of prob_s11, which leaves the LDS to the per-lane ray-tracing scratch and to more waves.
 __host__ __device__ inline size_t lds_doubles(const DevModel& M, bool mono = false) {
   const size_t geo = (size_t)(M.n_rad + 1) + M.n_rad + M.n_rad + M.n_rad + M.n_az + M.n_lambda + M.n_lambda + (M.nang + 1);
-  return mono ? geo : geo + M.n_T + (M.n_lambda + 1) + M.n_lambda + (size_t)M.n_lambda * M.n_T;
+  return mono ? geo : geo + M.n_T + (M.n_lambda + 1) + M.n_lambda + (size_t)M.n_lambda * M.n_T + (M.n_rad > 0 ? 5 * (size_t)(M.n_rad + 3) : 0);
 }
 __host__ __device__ inline size_t lds_floats(const DevModel& M, bool mono = false) {
   return (size_t)M.n_lambda + (size_t)(M.nang + 1) * ((mono || M.p_lambda_fixed) ? 1 : M.n_lambda) + M.n_lambda +
@@ -320,7 +349,9 @@ __device__ inline Lds lds_carve(double* base, const DevModel& M, bool mono = fal
   T.kabs = p; p += M.n_lambda;
   if (mono) {
     T.lq = p; T.cum = p; T.fstar = p; T.cdf = p;  // (not staged, never read by those kernels)
+    T.row = nullptr;
   } else {
+    T.row = reinterpret_cast<RowT*>(p); p += (M.n_rad > 0 ? 5 * (size_t)(M.n_rad + 3) : 0);
     T.lq = p; p += M.n_T;
     T.cum = p; p += M.n_lambda + 1;
     T.fstar = p; p += M.n_lambda;
@@ -345,6 +376,17 @@ __device__ inline void lds_stage(const Lds& T, const DevModel& M) {
   stage(T.zmax, M.zmax, (size_t)M.n_rad);
   stage(T.ch, M.ch, (size_t)M.n_rad);
   for (int i = threadIdx.x; i < M.n_rad; i += blockDim.x) T.rzn[i] = (double)M.nz / M.zmax[i];
+  for (int i = threadIdx.x; i < (M.n_rad > 0 ? M.n_rad + 3 : 0); i += blockDim.x) {   // (Voronoi grids: n_rad = 0, no such tables)
+    const int rin = i == 0 ? 0 : (i - 1 < M.n_rad ? i - 1 : M.n_rad - 1);
+    const int rout = i == 0 ? 0 : (i < M.n_rad ? i : M.n_rad);
+    RowT r;
+    r.rl_in = i == 0 ? M.r_lim_2[0] : nd_mul(M.r_lim_2[rin], 1.0 - GRID_PREC);
+    r.rl_out = nd_mul(M.r_lim_2[rout], 1.0 + GRID_PREC);
+    r.ch = M.ch[rin];
+    r.zmax = M.zmax[rin];
+    r.rzn = i == 0 ? 0.0 : (double)M.nz / M.zmax[rin];
+    T.row[i] = r;
+  }
   stage(T.tan_phi, M.tan_phi_lim, (size_t)M.n_az);
   stage(T.kappa, M.kappa, (size_t)M.n_lambda);
   stage(T.kabs, M.kappa_abs, (size_t)M.n_lambda);

@@ -169,11 +169,12 @@ struct Flight {
   int ri, zj, k, star_key, st;
   unsigned int pk_cross;
   int lam;  // (VAR: the packet's wavelength, for the per-cell opacities)
+  int ic;   // (2D crossing: the 0-based index of the cell (ri, zj), n_cells outside the real cells; flight_constants sets it)
 };
 
 __device__ inline void flight_clear(Flight& F) {
   F.x = F.y = F.z = F.u = F.v = 0.0; F.w = 1.0; F.extr = 0.0; F.S0 = 1.0; F.inv_a = F.inv_w = F.kf = F.kap = F.kab = 0.0;
-  F.ri = 0; F.zj = 1; F.k = 1; F.star_key = -1; F.st = S_EMIT; F.pk_cross = 0u; F.lam = 1;
+  F.ri = 0; F.zj = 1; F.k = 1; F.star_key = -1; F.st = S_EMIT; F.pk_cross = 0u; F.lam = 1; F.ic = 0;
 }
 
 // VAR (lvariable_dust): the opacities change from cell to cell.  DevModel::v_kk holds, per (cell, wavelength), the pair
@@ -190,15 +191,16 @@ __device__ inline void flight_constants(const Lds& T, const DevModel& M, Flight&
   const double a = F.u * F.u + F.v * F.v;  // cylindrical_grid.f90:941-952
   F.inv_a = (a > TINY_REAL) ? 1.0 / a : HUGE_REAL;
   F.inv_w = (fabs(F.w) > TINY_REAL) ? 1.0 / F.w : copysign(HUGE_DP, F.w);
+  F.ic = is_real_cell<L3D>(M.n_rad, M.nz, F.ri, F.zj) ? cell_index<L3D>(M.n_rad, M.nz, F.ri, F.zj, F.k) : M.n_cells;
   if (VAR) {
     F.lam = lambda;
     F.kap = 1.0;
-    var_cell_opacities(M, F, is_real_cell<L3D>(M.n_rad, M.nz, F.ri, F.zj) ? cell_index<L3D>(M.n_rad, M.nz, F.ri, F.zj, F.k) : M.n_cells);
+    var_cell_opacities(M, F, F.ic);
     return;
   }
   F.kap = T.kappa[lambda - 1];
   F.kab = T.kabs[lambda - 1];
-  F.kf = is_real_cell<L3D>(M.n_rad, M.nz, F.ri, F.zj) ? M.kappa_factor[cell_index<L3D>(M.n_rad, M.nz, F.ri, F.zj, F.k)] : 0.0;
+  F.kf = M.kappa_factor[F.ic];   // (the device's array ends in a zero entry for "no cell")
 }
 
 // One cell crossing of a packet in flight (physical_length's loop body, optical_depth.f90:77-178).  Returns the
@@ -280,7 +282,11 @@ __device__ __forceinline__ int fly_step_2d(const Lds& T, const DevModel& M, cons
                                            unsigned int& c_cross, unsigned int& c_kill, unsigned int& c_dark,
                                            int* dep_ic = nullptr, double* dep_v = nullptr) {
   const int n_rad = M.n_rad, nz = M.nz;
-  const double cm = 1.0 - GRID_PREC, cp = 1.0 + GRID_PREC;
+  // correct_plus = 1 + e and correct_moins = 1 - e with e = 45 * 2^-52 EXACTLY (1e-14 rounds to 45 units in the last
+  // place of 1.0 and 90 of the doubles below it): a * correct_plus = a + a e is then one fma(a, e, a) -- the very
+  // product, rounded once -- and the choice between the two factors is the sign bit of e (section 2 below)
+  static_assert((1.0 + GRID_PREC) - 1.0 == 0x1.68p-47 && 1.0 - (1.0 - GRID_PREC) == 0x1.68p-47, "grid_prec is not 45 ulp");
+  const double cp = 1.0 + GRID_PREC;
   const bool active = (p.st == S_FLIGHT);
   const int ri0 = p.ri, zj0 = p.zj;
   const double x0 = p.x, y0 = p.y, z0 = p.z, u = p.u, v = p.v, w = p.w;
@@ -290,27 +296,26 @@ __device__ __forceinline__ int fly_step_2d(const Lds& T, const DevModel& M, cons
   const bool killed = (p.star_key >= 0) && (ri0 + (n_rad + 2) * (zj0 + nz + 1) == p.star_key);
   const bool go = active && !out && !killed;
   const bool hole = (ri0 == 0);
-  const bool real_cell = (ri0 >= 1) && (ri0 <= n_rad) && (zj0 >= 1) && (zj0 <= nz);
-  const int ic = real_cell ? (ri0 - 1) + n_rad * (zj0 - 1) : 0;
-  // rows of the tables (lanes outside the grid read a valid row; their results are discarded)
-  const int row_in = hole ? 0 : (ri0 - 1 < n_rad ? ri0 - 1 : n_rad - 1);
-  const int row_out = hole ? 0 : (ri0 < n_rad ? ri0 : n_rad);
+  // the cell's index travels with the flight (p.ic; n_cells = "no cell"): what the last crossing computed for the
+  // kappa_factor of this cell is the address of this crossing's deposit
+  const int ic = p.ic;
+  const bool real_cell = ic < M.n_cells;
+  // the row of this radial index (lanes outside the grid read a valid row; their results are discarded)
+  const RowT& R0 = T.row[ri0];
 
-  // 1) radial wall (:959-1000)
+  // 1) radial wall (:959-1000); rl_in / rl_out carry the correction factors (RowT)
   const double r_2 = x0 * x0 + y0 * y0;
   const double dot = x0 * u + y0 * v;
   const double b = dot * p.inv_a;
-  const double rl_in = T.r_lim_2[row_in];
-  const double rl_out = T.r_lim_2[row_out];
-  const double c_in = (r_2 - (hole ? rl_in : rl_in * cm)) * p.inv_a;
-  const double c_out = (r_2 - rl_out * cp) * p.inv_a;
+  const double c_in = (r_2 - R0.rl_in) * p.inv_a;
+  const double c_out = (r_2 - R0.rl_out) * p.inv_a;
   const double bb = b * b;
   const double d_in = bb - c_in;
   const double d_out = fmax(bb - c_out, 0.0);
   const bool use_in = hole || ((dot < 0.0) && !(d_in < 0.0));
   const double delta = use_in ? d_in : d_out;
   const int delta_rad = (use_in && !hole) ? -1 : 1;
-  const double rac = sqrt(delta);
+  const double rac = sqrt_nonneg(delta);   // (in the hole delta > 0: the packet is inside that circle)
   const double s1 = (-b - rac) * cp, s2 = (-b + rac) * cp;
   const double s_pos = (s1 == 0.0) ? GRID_PREC : s1;
   const double s = (hole || (s1 < 0.0)) ? s2 : s_pos;
@@ -320,10 +325,10 @@ __device__ __forceinline__ int fly_step_2d(const Lds& T, const DevModel& M, cons
   const bool away = dz > 0.0;
   const bool flip = !away && (zj0 == 1);  // through the midplane to the mirror side
   const int jsel = away ? zj0 + 1 : (zj0 == 1 ? 2 : zj0);
-  const double chr = T.ch[row_in], zmr = T.zmax[row_in];
   // (jsel = nz + 2, where z_lim is 1e30, only occurs for away && top, which the 1e10 below replaces)
-  double zmag = (jsel <= nz) ? ((double)jsel - 1.0) * chr : zmr;
-  zmag = zmag * (away ? cp : cm);
+  double zmag = (jsel <= nz) ? ((double)jsel - 1.0) * R0.ch : R0.zmax;
+  // zmag * (away ? correct_plus : correct_moins), see the top of the function
+  zmag = __builtin_fma(zmag, __longlong_as_double(away ? 0x3D06800000000000ll : (long long)0xBD06800000000000ull), zmag);
   zmag = (away && top) ? 1.0e10 : zmag;
   const bool neg = (z0 < 0.0) != flip;
   // zl = neg ? -zmag : zmag (zmag >= 0): the sign bit is set directly
@@ -342,20 +347,19 @@ __device__ __forceinline__ int fly_step_2d(const Lds& T, const DevModel& M, cons
   // products rounded before the sum, like the reference build (see cross_cell_lean)
   double z1 = nd_add(z0, nd_mul(l, w));
   const int ri1 = rad ? ri0 + delta_rad : ri0;
-  // zj of the end point for a radial move (:1116): the fast form of zj_capped, its rare default-real fallback below
-  const int row1 = ri1 < 1 ? 0 : (ri1 > n_rad ? n_rad - 1 : ri1 - 1);
-  const double qd = fabs(z1) * T.rzn[row1];
+  // zj of the end point for a radial move (:1116): the fast form of zj_capped -- floor(|z1| nz / zmax) + 1, at most
+  // nz + 1 (the minimum is taken on the double: |z1| is unbounded above the disk); in the hole rzn = 0 gives the
+  // reference's zj = 1 (:1117) -- and its rare default-real fallback, taken within 1e-4 of an integer
+  const double qd = fabs(z1) * T.row[ri1].rzn;
   const double fl = floor(qd);
-  const double fr = qd - fl;
-  const bool far_above = !(qd < (double)nz + 0.5);
-  int zjr = far_above ? nz + 1 : (int)fl + 1;
-  zjr = zjr > nz ? nz + 1 : zjr;
+  int zjr = (int)fmin(fl, (double)nz) + 1;
   const bool rad_in = rad && (ri1 >= 1) && (ri1 <= n_rad);
-  if (__builtin_expect(go && rad_in && !far_above && (fr < 1.0e-4 || fr > 1.0 - 1.0e-4), 0)) {  // (rare) within 1e-4 of an integer
-    int zq = zj_from_z_real(T, nz, fabs(z1), ri1);
+  const double fr = qd - fl;
+  if (__builtin_expect(go && rad_in && (fr < 1.0e-4 || fr > 1.0 - 1.0e-4), 0)) {  // (rare)
+    const int zq = zj_from_z_real(T, nz, fabs(z1), ri1);
     zjr = zq > nz ? nz + 1 : zq;
   }
-  zjr = (ri1 == 0) ? 1 : ((ri1 > n_rad) ? zj0 : zjr);
+  zjr = (ri1 > n_rad) ? zj0 : zjr;
   const int zj1 = rad ? zjr : zj0 + delta_zj;
   z1 = (z1 == 0.0) ? GRID_PREC : z1;
 
@@ -395,6 +399,7 @@ __device__ __forceinline__ int fly_step_2d(const Lds& T, const DevModel& M, cons
   p.extr = p.extr - tau;
   p.ri = move ? ri1 : ri0;
   p.zj = move ? zj1 : zj0;
+  p.ic = move ? ic1 : ic;
   p.kf = move ? kf1 : p.kf;
   if (VAR) p.kab = move ? kk1.y : p.kab;
   if (DARK) {

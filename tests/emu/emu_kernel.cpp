@@ -67,6 +67,7 @@ static inline float atomicAdd(float* p, float v) { float o = *p; *p += v; return
 namespace mcgpu {  // the device source's unfused helpers (mc_device.hip.h), for the host compiler
 static inline double nd_mul(double a, double b) { volatile double r = a * b; return r; }
 static inline double nd_add(double a, double b) { volatile double r = a + b; return r; }
+static inline double sqrt_nonneg(double x) { return std::sqrt(x); }   // (the device's Newton sequence is correctly rounded on its domain)
 static inline float nf_mul(float a, float b) { volatile float r = a * b; return r; }
 static inline float nf_add(float a, float b) { volatile float r = a + b; return r; }
 static inline float nf_sub(float a, float b) { volatile float r = a - b; return r; }
