@@ -702,6 +702,21 @@ int mcgpu_set_mrw(mcgpu_ctx *ctx, int n_zeta, const double *zeta, const double *
                   const double *r_lim);
 
 /*
+ * The wavelength a walk's last step leaves its sphere with ("Only at end of MRW, to switch to MC: select new
+ * wavelength", MRW.f90:108-110 -- the reference's stub does not say from which spectrum).  exit_cdf[n_T][n_lambda]
+ * (one block per class with lvariable_dust), cumulative over the wavelengths like kdB_dT_CDF, rows at tab_Temp,
+ * interpolated in temperature like im_reemission_LTE does; NULL (the state after mcgpu_set_mrw): the cell's emission
+ * spectrum kdB_dT_CDF, i.e. kappa_abs dB/dT.  The host harness passes the spectrum of the packets IN FLIGHT in a
+ * thick cell, weights dB/dT: a packet crosses the sphere in the middle of a flight, and the packets in flight are the
+ * emitted ones weighted with the path 1 / kappa_abs they fly before they are absorbed.  With the emission spectrum the
+ * packet prefers the opaque wavelengths, is re-absorbed next to the sphere and the walk carries too little heat
+ * outwards: +2 ... +4 % in the temperature of the illuminated inner rim of a thick disk against brute force (8 + 8
+ * seeds of 4e6 packets: +2.5 % over radial cells 16-23 of BASELINE config 4, -1 % behind them); with the spectrum in
+ * flight 0.1 % where the statistics resolve it and at most 1.7 % ("Modified random walk").
+ */
+int mcgpu_set_mrw_exit_spectrum(mcgpu_ctx *ctx, const double *exit_cdf);
+
+/*
  * define_dark_zone (optical_depth.f90:1425-1651) for a 2D cylindrical grid: steps 1-3 (the radii and heights where the
  * optical depth at `lambda` exceeds tau_max from outside) and step 4 (11 test rays from the centre of every candidate
  * cell; one ray per device thread).  r_lim[n_rad+1], r_grid / z_grid[n_cells], z_lim(n_rad, nz+1...) are module

@@ -153,6 +153,8 @@ struct DevModel {
   const double* mrw_kdep;  // [n_T] mean absorption opacity of the walk's deposits
   const double *sin_phi, *cos_phi;  // [n_az] sin / cos of the azimuthal walls (3D; cylindrical_grid.f90:586-599), for the walk
   const double* mrw_ext;   // [n_T] extrapolation length of the sphere radius, reference cell
+  const double* mrw_exit_cdf;  // [n_T][n_lambda] (per class) cumulative spectrum a walk's last step leaves its sphere with;
+                               // nullptr: the emission spectrum kdB_dT_CDF (mcgpu_set_mrw_exit_spectrum)
   const double* r_lim;     // [n_rad+1] (distance_to_closest_wall_cyl)
   // lvariable_dust (mcgpu_set_variable_dust; mem.f90:213-244, p_n_cells > 1): per-class tables in HBM, class-major
   int n_classes;             // 0: one class, the tables above (and their LDS copies)
@@ -980,6 +982,23 @@ __device__ inline void cdapres(double cospsi, double phi, double u0, double v0, 
   sincos(phi, &sphi, &cphi);
   cdapres_sc(cospsi, sphi, cphi, u0, v0, w0, u1, v1, w1);
 }
+// sin and cos of pi * x: what every azimuth of the packet loop is -- phi = pi (2 rand - 1) (utils.f90 / dust_transfer.f90:
+// 1297, random_numbers.f90:44) -- without forming pi * x first: sincospi reduces its argument exactly (71 vector
+// instructions against the 158 of sincos); the same numbers to the rounding of the product pi * x
+__device__ inline void sincos_pi(double x, double* s, double* c) {
+#ifdef MCGPU_LANE_EMULATION
+  sincos(PI * x, s, c);
+#else
+  sincospi(x, s, c);
+#endif
+}
+// cdapres with the azimuth given in units of pi
+__device__ inline void cdapres_pi(double cospsi, double phi_over_pi, double u0, double v0, double w0, double& u1,
+                                  double& v1, double& w1) {
+  double sphi, cphi;
+  sincos_pi(phi_over_pi, &sphi, &cphi);
+  cdapres_sc(cospsi, sphi, cphi, u0, v0, w0, u1, v1, w1);
+}
 __device__ inline void cdapres_sc(double cospsi, double sphi, double cphi, double u0, double v0, double w0, double& u1,
                                   double& v1, double& w1) {
   double cpsi = cospsi;
@@ -1035,12 +1054,16 @@ __device__ inline void update_stokes(double S[4], double u0, double v0, double w
   float costhet;
   if (xnyp < 1e-10f) costhet = 1.0f;
   else costhet = (float)(-1.0 * v1pj / (double)xnyp);
-  float theta = acosf(costhet);
-  if ((double)theta >= PI) theta = 0.0f;
-  theta = (float)((double)theta + 0.5 * PI);
-  float omega = 2.0f * theta;
-  if (v1pk < 0.0) omega = -1.0f * omega;
-  float cosw = cosf(omega), sinw = sinf(omega);
+  // theta = acos(costhet) (reset to 0 at pi), theta += pi / 2, omega = 2 theta, omega = -omega for v1pk < 0
+  // (scattering.f90:1206-1217): cos(omega) = cos(2 acos(c) + pi) = 1 - 2 c^2 and sin(omega) = -2 c sqrt(1 - c^2), its
+  // sign with v1pk's -- the same two default-real numbers to their last place (1e-7) without acosf, cosf and sinf (150 of
+  // this routine's 446 vector instructions); the reset at pi (c = -1) gives cos = -1, sin = 0 either way
+  // (formed in double from the default-real costhet -- c^2 and 1 - c^2 are then exact, no cancellation next to c = +-1
+  // -- and rounded to default real like the reference's cosw, sinw)
+  const double cd = (double)costhet, c2 = cd * cd;
+  float sinw = (float)(-2.0 * cd * sqrt(fmax(1.0 - c2, 0.0)));
+  if (v1pk < 0.0) sinw = -sinw;
+  float cosw = (float)(1.0 - 2.0 * c2);
   if (fabsf(cosw) < 1e-06f) cosw = 0.0f;
   if (fabsf(sinw) < 1e-06f) sinw = 0.0f;
   const double cw = (double)cosw, sw = (double)sinw;
@@ -1241,14 +1264,12 @@ __device__ inline void emit_uniform_sphere(const DevModel& M, int i_star, float 
                                            double& w) {
   z = 2.0 * (double)r1 - 1.0;
   const double srw02 = sqrt(1.0 - z * z);
-  const double argmt = PI * (2.0 * (double)r2 - 1.0);
   double sa, ca;
-  sincos(argmt, &sa, &ca);
+  sincos_pi(2.0 * (double)r2 - 1.0, &sa, &ca);   // (argmt = pi (2 r2 - 1))
   x = srw02 * ca;
   y = srw02 * sa;
   const double cospsi = sqrt((double)r3);
-  const double phi = 2.0 * PI * (double)r4;
-  cdapres(cospsi, phi, x, y, z, u, v, w);
+  cdapres_pi(cospsi, 2.0 * (double)r4, x, y, z, u, v, w);   // (phi = 2 pi r4)
   const double* st4 = &M.star_xyzr[4 * (i_star - 1)];
   const double r_star = st4[3] * (1.0 + 1e-6);
   x = x * r_star + st4[0];
@@ -1260,9 +1281,8 @@ __device__ inline void emit_uniform_sphere(const DevModel& M, int i_star, float 
 __device__ inline void random_isotropic_direction(float r1, float r2, double& u, double& v, double& w) {
   w = 2.0 * (double)r1 - 1.0;
   const double uv = sqrt(1.0 - w * w);
-  const double ph = PI * (2.0 * (double)r2 - 1.0);
   double sp, cp;
-  sincos(ph, &sp, &cp);
+  sincos_pi(2.0 * (double)r2 - 1.0, &sp, &cp);   // (phi = pi (2 r2 - 1))
   u = uv * cp;
   v = uv * sp;
 }
@@ -1332,7 +1352,7 @@ __device__ __forceinline__ bool interact_direction(const Lds& T, const DevModel&
   const float rand = m1 ? g[2] : g[1], rand2 = m1 ? g[3] : g[2], rand_phi = m1 ? g[4] : g[3];
   itheta = 1;
   rand2_out = rand2;
-  double cospsi, phi;
+  double cospsi, phi;   // (phi in units of pi)
   if (scat) {
     flag_scatt = true;
     c_scatt++;
@@ -1380,7 +1400,7 @@ __device__ __forceinline__ bool interact_direction(const Lds& T, const DevModel&
       if (itheta > M.nang) itheta = M.nang;
     }
     if (M.lisotropic && !(m1 && M.aniso_method == 1)) { itheta = 1; cospsi = 2.0 * (double)rand - 1.0; }
-    phi = PI * (2.0 * (double)rand_phi - 1.0);
+    phi = 2.0 * (double)rand_phi - 1.0;
   } else {
     c_abs++;
     flag_star = false;
@@ -1394,10 +1414,10 @@ __device__ __forceinline__ bool interact_direction(const Lds& T, const DevModel&
     // random_isotropic_direction (random_numbers.f90:32-51): w = 2r-1, (u,v) = sqrt(1-w^2)
     // (cos,sin)(phi) is cdapres' own |w0| > 0.999999 branch applied to the z axis
     cospsi = 2.0 * (double)g[3] - 1.0;
-    phi = PI * (2.0 * (double)g[4] - 1.0);
+    phi = 2.0 * (double)g[4] - 1.0;
   }
   // new direction: one instruction stream for both kinds of event
-  cdapres(cospsi, phi, scat ? u : 0.0, scat ? v : 0.0, scat ? w : 1.0, u1, v1, w1);
+  cdapres_pi(cospsi, phi, scat ? u : 0.0, scat ? v : 0.0, scat ? w : 1.0, u1, v1, w1);
   return scat;
 }
 
@@ -1551,8 +1571,22 @@ __device__ inline bool mrw_walk_with(const Lds& T, const DevModel& M, uint32_t k
   philox4x32_10(blk, event, p_lo, p_hi, k0, k1, o);
   // the cell's temperature now, the walk's deposits included (im_reemission_LTE)
   temp_lte(T.lq, M.n_T, cell_energy(), M.L_packet_th, M.volume[ic], Ti, frac);
-  lambda = reemission_wavelength(T, M, Ti, frac, Rng::real(o[0]));
-  cdapres(sqrt((double)Rng::real(o[1])), PI * (2.0 * (double)Rng::real(o[2]) - 1.0), su, sv, sw, u, v, w);
+  if (M.mrw_exit_cdf) {
+    // the packet crosses the sphere in the middle of a flight: it carries the spectrum of the packets IN FLIGHT in the
+    // thick cell (weights dB/dT), not that of a packet which has just been emitted (kappa_abs dB/dT) -- see
+    // mcgpu_set_mrw_exit_spectrum (include/mcgpu.h); the same search as im_reemission_LTE's, in the table in HBM
+    const double* c1 = M.mrw_exit_cdf + (co + (size_t)(Ti - 2)) * M.n_lambda;
+    const double* c2 = c1 + M.n_lambda;
+    const double f1 = 1.0 - frac, r = (double)Rng::real(o[0]);
+    int l1 = 0, l2 = M.n_lambda, l = (l1 + l2) / 2;
+    while ((l2 - l1) > 1) {
+      const double proba = f1 * c1[l - 1] + frac * c2[l - 1];
+      if (r > proba) l1 = l; else l2 = l;
+      l = (l1 + l2) / 2;
+    }
+    lambda = l + 1;
+  } else lambda = reemission_wavelength(T, M, Ti, frac, Rng::real(o[0]));
+  cdapres_pi(sqrt((double)Rng::real(o[1])), 2.0 * (double)Rng::real(o[2]) - 1.0, su, sv, sw, u, v, w);
   c_walks++;
   return true;
 }
@@ -1602,14 +1636,12 @@ __device__ inline int emit_packet(const DevModel& M, const float f[12], int lamb
   flag_ism = true;  // emit_packet_ISM: a point of the sphere, cosine law towards the interior
   z = 2.0 * (double)f[2] - 1.0;
   const double srw02 = sqrt(1.0 - z * z);
-  const double argmt = PI * (2.0 * (double)f[3] - 1.0);
   double sa, ca;
-  sincos(argmt, &sa, &ca);
+  sincos_pi(2.0 * (double)f[3] - 1.0, &sa, &ca);
   x = srw02 * ca;
   y = srw02 * sa;
   const double cospsi = -sqrt((double)f[4]);
-  const double phi = 2.0 * PI * (double)f[5];
-  cdapres(cospsi, phi, x, y, z, u, v, w);
+  cdapres_pi(cospsi, 2.0 * (double)f[5], x, y, z, u, v, w);
   x = M.centre_ISM[0] + x * M.R_ISM;
   y = M.centre_ISM[1] + y * M.R_ISM;
   z = M.centre_ISM[2] + z * M.R_ISM;

@@ -433,7 +433,7 @@ __device__ __forceinline__ int fly_step_3d(const Lds& T, const DevModel& M, cons
                                            unsigned int& c_cross, unsigned int& c_kill, unsigned int& c_dark, int& dep_ic,
                                            double& dep_v) {
   const int n_rad = M.n_rad, nz = M.nz, n_az = M.n_az;
-  const double cm = 1.0 - GRID_PREC, cp = 1.0 + GRID_PREC;
+  const double cp = 1.0 + GRID_PREC;  // (correct_moins: in the rows' rl_in and in the fused product below, see fly_step_2d)
   const double r1e30 = 1.00000001504746621988e+30;
   const bool active = (p.st == S_FLIGHT);
   const int ri0 = p.ri, zj0 = p.zj, k0 = p.k;
@@ -444,27 +444,24 @@ __device__ __forceinline__ int fly_step_3d(const Lds& T, const DevModel& M, cons
   const bool killed = (p.star_key >= 0) && (ri0 + (n_rad + 2) * ((zj0 + nz + 1) + (2 * nz + 3) * (k0 - 1)) == p.star_key);
   const bool go = active && !out && !killed;
   const bool hole = (ri0 == 0);
-  const bool real_cell = (ri0 >= 1) && (ri0 <= n_rad) && (azj >= 1) && (azj <= nz);
-  const int jj0 = zj0 < 0 ? zj0 + nz : zj0 + nz - 1;
-  const int ic = real_cell ? (ri0 - 1) + n_rad * (jj0 + 2 * nz * (k0 - 1)) : 0;
-  const int row_in = hole ? 0 : (ri0 - 1 < n_rad ? ri0 - 1 : n_rad - 1);
-  const int row_out = hole ? 0 : (ri0 < n_rad ? ri0 : n_rad);
+  // the cell's index travels with the flight and the radial index names ONE row of tables (see fly_step_2d)
+  const int ic = p.ic;
+  const bool real_cell = ic < M.n_cells;
+  const RowT& R0 = T.row[ri0];
 
   // 1) radial wall (:959-1000)
   const double r_2 = x0 * x0 + y0 * y0;
   const double dot = x0 * u + y0 * v;
   const double b = dot * p.inv_a;
-  const double rl_in = T.r_lim_2[row_in];
-  const double rl_out = T.r_lim_2[row_out];
-  const double c_in = (r_2 - (hole ? rl_in : rl_in * cm)) * p.inv_a;
-  const double c_out = (r_2 - rl_out * cp) * p.inv_a;
+  const double c_in = (r_2 - R0.rl_in) * p.inv_a;
+  const double c_out = (r_2 - R0.rl_out) * p.inv_a;
   const double bb = b * b;
   const double d_in = bb - c_in;
   const double d_out = fmax(bb - c_out, 0.0);
   const bool use_in = hole || ((dot < 0.0) && !(d_in < 0.0));
   const double delta = use_in ? d_in : d_out;
   const int delta_rad = (use_in && !hole) ? -1 : 1;
-  const double rac = sqrt(delta);
+  const double rac = sqrt_nonneg(delta);
   const double s1 = (-b - rac) * cp, s2 = (-b + rac) * cp;
   const double s_pos = (s1 == 0.0) ? GRID_PREC : s1;
   const double s = (hole || (s1 < 0.0)) ? s2 : s_pos;
@@ -474,10 +471,10 @@ __device__ __forceinline__ int fly_step_3d(const Lds& T, const DevModel& M, cons
   const bool away = dz > 0.0;
   const bool neg = z0 < 0.0;
   const int jsel = away ? azj + 1 : azj;
-  const double chr = T.ch[row_in], zmr = T.zmax[row_in];
   // (jsel = nz + 2, where z_lim is 1e30, only occurs for away && top, which the 1e10 below replaces)
-  double zmag = (jsel <= nz) ? ((double)jsel - 1.0) * chr : zmr;
-  zmag = zmag * (away ? cp : cm);
+  double zmag = (jsel <= nz) ? ((double)jsel - 1.0) * R0.ch : R0.zmax;
+  // zmag * (away ? correct_plus : correct_moins) as one fma with e = +-45 * 2^-52 (fly_step_2d)
+  zmag = __builtin_fma(zmag, __longlong_as_double(away ? 0x3D06800000000000ll : (long long)0xBD06800000000000ull), zmag);
   zmag = (away && top) ? 1.0e10 : zmag;
   const double zl = __longlong_as_double(__double_as_longlong(zmag) | (neg ? (long long)0x8000000000000000ull : 0ll));
   const int dzj_away = top ? 0 : (neg ? -1 : 1);
@@ -514,16 +511,15 @@ __device__ __forceinline__ int fly_step_3d(const Lds& T, const DevModel& M, cons
   const int ri1 = rad ? ri0 + delta_rad : ri0;
   // zj of the end point of a radial (:1116, through default real) or azimuthal (:1139, FP64) move: one multiply by
   // nz / zmax decides it unless the quotient is within 1e-4 of an integer, where the reference's own expression runs
-  const int row1 = ri1 < 1 ? 0 : (ri1 > n_rad ? n_rad - 1 : ri1 - 1);
-  const double qd = fabs(z1) * T.rzn[row1];
+  const double qd = fabs(z1) * T.row[ri1].rzn;
   const double fl = floor(qd);
   const double fr = qd - fl;
-  const bool far_above = !(qd < (double)nz + 0.5);
-  int zjr = far_above ? nz + 1 : (int)fl + 1;
-  zjr = zjr > nz ? nz + 1 : zjr;
+  int zjr = (int)fmin(fl, (double)nz) + 1;   // (at most nz + 1; the minimum on the double: |z1| is unbounded above the disk)
   const bool ri1_in = (ri1 >= 1) && (ri1 <= n_rad);
-  if (__builtin_expect(go && !vert && ri1_in && !far_above && (fr < 1.0e-4 || fr > 1.0 - 1.0e-4), 0)) {  // (rare)
-    int zq = rad ? zj_from_z_real(T, nz, fabs(z1), ri1) : (int)floor(fabs(z1) / T.zmax[ri1 - 1] * (double)nz) + 1;
+  if (__builtin_expect(go && !vert && ri1_in && (fr < 1.0e-4 || fr > 1.0 - 1.0e-4), 0)) {  // (rare)
+    // (far above the disk both expressions exceed nz and the cap below applies, as it does to zjr above)
+    const double qe = rad ? 0.0 : floor(fabs(z1) / T.zmax[ri1 - 1] * (double)nz);
+    int zq = rad ? zj_from_z_real(T, nz, fabs(z1), ri1) : (int)fmin(qe, (double)nz) + 1;
     zjr = zq > nz ? nz + 1 : zq;
   }
   zjr = (z1 < 0.0) ? -zjr : zjr;
@@ -576,9 +572,13 @@ __device__ __forceinline__ int fly_step_3d(const Lds& T, const DevModel& M, cons
   p.ri = move ? ri1 : ri0;
   p.zj = move ? zj1 : zj0;
   p.k = move ? k1 : k0;
+  p.ic = move ? ic1 : ic;
   p.kf = move ? kf1 : p.kf;
   if (VAR) p.kab = move ? kk1.y : p.kab;
-  if (__builtin_expect(stop, 0)) index_cell<true>(T, M, p.x, p.y, p.z, p.ri, p.zj, p.k);  // (:140: 3D re-indexes the stopping point)
+  if (__builtin_expect(stop, 0)) {  // (:140: 3D re-indexes the stopping point)
+    index_cell<true>(T, M, p.x, p.y, p.z, p.ri, p.zj, p.k);
+    p.ic = is_real_cell<true>(n_rad, nz, p.ri, p.zj) ? cell_index<true>(n_rad, nz, p.ri, p.zj, p.k) : M.n_cells;
+  }
   if (DARK) {
     p.u = mirror ? -u : u; p.v = mirror ? -v : v; p.w = mirror ? -w : w;
     c_dark += mirror ? 1u : 0u;

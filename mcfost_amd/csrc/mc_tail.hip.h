@@ -50,8 +50,8 @@ __device__ inline void tail_draw(TailBatch& B, uint32_t k0, uint32_t k1, uint32_
   B.g0 = g[0]; B.g1 = g[1]; B.g2 = g[2]; B.g3 = g[3]; B.g4 = g[4]; B.g5 = g[5];
   const float rand = g[5];
   B.tau = (rand > 1.0e-6f) ? -log(1.0 - (double)rand) : (double)rand;
-  sincos(PI * (2.0 * (double)g[3] - 1.0), &B.ss, &B.cs);
-  sincos(PI * (2.0 * (double)g[4] - 1.0), &B.sa, &B.ca);
+  sincos_pi(2.0 * (double)g[3] - 1.0, &B.ss, &B.cs);
+  sincos_pi(2.0 * (double)g[4] - 1.0, &B.sa, &B.ca);
   B.base = event;
 }
 

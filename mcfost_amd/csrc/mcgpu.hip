@@ -1058,7 +1058,26 @@ extern "C" int mcgpu_set_mrw(mcgpu_ctx* ctx, int n_zeta, const double* zeta, con
     if ((rc = upload(ctx, sp.data(), sp.size(), &M.sin_phi)) || (rc = upload(ctx, cp.data(), cp.size(), &M.cos_phi))) return rc;
   }
   M.mrw_n_zeta = n_zeta; M.mrw_gamma = (float)gamma; M.mrw_n_inter = n_interactions; M.mrw = 1;
+  M.mrw_exit_cdf = nullptr;   // (mcgpu_set_mrw_exit_spectrum, after this call)
   return MCGPU_OK;
+}
+
+// The spectrum a walk's last step leaves its sphere with: exit_cdf[class][n_T][n_lambda], cumulative over the wavelengths
+// (non-decreasing rows ending in 1), or NULL for the cell's emission spectrum kdB_dT_CDF.
+extern "C" int mcgpu_set_mrw_exit_spectrum(mcgpu_ctx* ctx, const double* exit_cdf) {
+  if (!ctx) return MCGPU_ERR_ARG;
+  DevModel& M = ctx->M;
+  if (!M.mrw) return fail(ctx, MCGPU_ERR_STATE, "mcgpu_set_mrw_exit_spectrum: call mcgpu_set_mrw first");
+  if (!exit_cdf) { M.mrw_exit_cdf = nullptr; return MCGPU_OK; }
+  const size_t rows = (size_t)M.n_T * (M.n_classes ? M.n_classes : 1);
+  for (size_t r = 0; r < rows; ++r) {
+    const double* c = exit_cdf + r * M.n_lambda;
+    for (int l = 1; l < M.n_lambda; ++l)
+      if (!(c[l] >= c[l - 1])) return fail(ctx, MCGPU_ERR_ARG, "mcgpu_set_mrw_exit_spectrum: a row decreases");
+    if (!(c[0] >= 0.0) || !(c[M.n_lambda - 1] <= 1.0 + 1e-12)) return fail(ctx, MCGPU_ERR_ARG, "mcgpu_set_mrw_exit_spectrum: a row leaves [0, 1]");
+  }
+  HIPCHK(hipSetDevice(ctx->device));
+  return upload(ctx, exit_cdf, rows * (size_t)M.n_lambda, &M.mrw_exit_cdf);
 }
 
 extern "C" int mcgpu_set_ism(mcgpu_ctx* ctx, double R_ISM, const double* centre_ISM) {
@@ -1251,7 +1270,10 @@ static int launch_mega(mcgpu_ctx* ctx, const RunArgs& A, bool use_lds, int grid_
         if (grid_blocks <= 0 && (unsigned long long)rblocks > need) rblocks = (int)(need ? need : 1);
       }
       int n_srv_pref = tune("MCGPU_N_SRV", (rthreads / 64 + 3) / 4, 1, 1016);  // serving waves to start with (adaptive; 1000 + n: fixed)
-      int k_short = tune("MCGPU_K_SHORT", 2, 0, 64), fly_iters = tune("MCGPU_FLY_ITERS", 16, 1, 256);
+      // crossings between two visits of the rings: 16 where packets interact (ref4.1: 247 / 252 / 257 ms per 1e8 packets
+      // at 16 / 24 / 32), 32 on thin models whose flights are a packet's whole life (Pascucci: 131.7 / 128.7 / 128.6 / 131.4
+      // ms at 16 / 24 / 32 / 48) -- told apart like the tail hand-over, by the model's midplane optical depth
+      int k_short = tune("MCGPU_K_SHORT", 2, 0, 64), fly_iters = tune("MCGPU_FLY_ITERS", ctx->tau_midplane > 1000.0 ? 16 : 32, 1, 256);
       int fly_idle = tune("MCGPU_FLY_IDLE", 32, 1, 65), emit_qmax = tune("MCGPU_EMIT_QMAX", 128, 0, 1 << 20);
       const void* fn = kpick_roles(l3d, pola, dark, use_lds, M.mrw != 0);   // (the walk: 2D; 3D was sent to the single-role kernel above)
       // 2D grids: the launch's last packets go to the tail kernel (one packet per wave, mc_tail.hip.h) once a

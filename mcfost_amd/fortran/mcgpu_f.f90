@@ -88,7 +88,7 @@ module mcgpu_f
        mcgpu_run_thermal, mcgpu_temp_finale, mcgpu_thermal_loop, mcgpu_error_message, mcgpu_set_rt1, &
        mcgpu_run_mono, mcgpu_fetch, mcgpu_fetch_xI, mcgpu_rt1_dust_map, mcgpu_set_xI, mcgpu_rt1_image, mcgpu_set_xI_precision, &
        mcgpu_set_E_prior, mcgpu_multi_create, mcgpu_multi_destroy, mcgpu_multi_size, mcgpu_multi_ctx, mcgpu_multi_run_thermal, mcgpu_multi_run_mono, mcgpu_multi_rccl_ranks, mcgpu_multi_create_ex, mcgpu_multi_reductions, &
-       mcgpu_counters_to_accum, mcgpu_counters_from_accum, mcgpu_temp_approx_diffusion_vertical, mcgpu_set_mrw, mcgpu_fetch_radiation_field, &
+       mcgpu_counters_to_accum, mcgpu_counters_from_accum, mcgpu_temp_approx_diffusion_vertical, mcgpu_set_mrw, mcgpu_set_mrw_exit_spectrum, mcgpu_fetch_radiation_field, &
        mcgpu_set_variable_dust, mcgpu_rt1_stars_map_sed, mcgpu_define_dark_zone, mcgpu_init_reemission, mcgpu_repartition_energie, mcgpu_opacity, mcgpu_set_variable_dust_s11, mcgpu_set_scattering_method1, mcgpu_set_rt2, mcgpu_fetch_I_spec, mcgpu_rt1_stars_map_image, mcgpu_set_I_spec, mcgpu_rt2_source, mcgpu_rt2_dust_map, mcgpu_rt2_image
 
   interface
@@ -283,6 +283,14 @@ module mcgpu_f
        real(c_double), intent(in) :: zeta(*), chi(*), kappa_dep(*), ext(*), r_lim(*)
        real(c_double), value :: gamma
      end function mcgpu_set_mrw
+
+     ! the spectrum a walk's last step leaves its sphere with: exit_cdf(n_lambda, n_T [, p_n_cells]) cumulative over the
+     ! wavelengths, or c_null_ptr for the cell's emission spectrum (include/mcgpu.h)
+     integer(c_int) function mcgpu_set_mrw_exit_spectrum(ctx, exit_cdf) bind(C, name="mcgpu_set_mrw_exit_spectrum")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       type(c_ptr), value :: exit_cdf
+     end function mcgpu_set_mrw_exit_spectrum
 
      ! define_dark_zone (optical_depth.f90:1425), 2D: module cylindrical_grid's r_lim, r_grid, z_grid, z_lim in;
      ! l_dark_zone (as integer(c_int8_t)), ri_in/out_dark_zone(1), zj_sup_dark_zone(:,1) out

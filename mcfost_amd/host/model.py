@@ -924,7 +924,7 @@ def cumulative_zeta(n: int = 10000):
 
 
 def init_mrw(m: "Model", gamma: float = 2.0, n_inter: int = 5, n_zeta: int = 10000, weights: str = "dB_dT",
-             ext_factor: float = 0.4):
+             ext_factor: float = 0.4, exit_spectrum: str = "in_flight"):
     """Tables of the modified random walk (``mcgpu_set_mrw``), one value per temperature of ``tab_Temp``, for the
     reference cell (the engine scales by ``kappa_factor``) -- the working form of ``compute_Planck_opacities``
     (diffusion.f90:631-696), which the reference evaluates at a fixed T = 20 K only:
@@ -966,6 +966,7 @@ def init_mrw(m: "Model", gamma: float = 2.0, n_inter: int = 5, n_zeta: int = 100
         nc = 1
         kap_c, alb_c, kab_c, g_c = (np.asarray(v, f64)[None, :] for v in (m.kappa, m.albedo, m.kappa_abs_LTE, g))
     chi, kdep, ext = np.zeros((nc, n_T), f64), np.zeros((nc, n_T), f64), np.zeros((nc, n_T), f64)
+    exit_cdf = np.zeros((nc, n_T, nl), f64) if exit_spectrum == "in_flight" else None
     for c in range(nc):
         k_tr = kap_c[c] * (1.0 - alb_c[c] * g_c[c])
         k_abs = kab_c[c]
@@ -983,6 +984,9 @@ def init_mrw(m: "Model", gamma: float = 2.0, n_inter: int = 5, n_zeta: int = 100
                 chi[c, t] = norm / (wgt / k_tr).sum()
                 kdep[c, t] = (wgt * k_abs).sum() / norm
                 ext[c, t] = ext_factor * 0.7104 * (wgt / k_tr ** 2).sum() / (wgt / k_tr).sum()
+                if exit_cdf is not None:
+                    exit_cdf[c, t] = np.cumsum(wgt) / norm
+                    exit_cdf[c, t, -1] = 1.0
     if vd is None:
         chi, kdep, ext = chi[0], kdep[0], ext[0]
     else:
@@ -990,7 +994,8 @@ def init_mrw(m: "Model", gamma: float = 2.0, n_inter: int = 5, n_zeta: int = 100
     # (the series saturates at 1 to within rounding for y > 0.9: the sampler wants a non-decreasing table)
     zeta = np.minimum(np.maximum.accumulate(cumulative_zeta(n_zeta)), 1.0)
     m.mrw = dict(zeta=zeta, chi=chi, kappa_dep=kdep, ext=ext, gamma=float(gamma),
-                 n_inter=int(n_inter), weights=weights)
+                 n_inter=int(n_inter), weights=weights,
+                 exit_cdf=None if exit_cdf is None else exit_cdf.reshape(-1))
     return m.mrw
 
 

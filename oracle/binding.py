@@ -95,7 +95,7 @@ class _Model(C.Structure):
         ("tab_w_rt", _dp), ("n_az_rt", C.c_int), ("n_theta_rt", C.c_int), ("N_type_flux", C.c_int),
         ("lsepar_contrib", C.c_int), ("tab_s11_pos", _fp),
         ("mrw", C.c_int), ("mrw_n_zeta", C.c_int), ("mrw_zeta", _dp), ("mrw_chi", _dp), ("mrw_kappa_dep", _dp),
-        ("mrw_ext", _dp), ("mrw_gamma", C.c_float), ("mrw_n_inter", C.c_int),
+        ("mrw_ext", _dp), ("mrw_exit_cdf", _dp), ("mrw_gamma", C.c_float), ("mrw_n_inter", C.c_int),
         ("p_n_cells", C.c_int), ("p_icell", _ip), ("v_kappa", _dp), ("v_kappa_abs_LTE", _dp), ("v_albedo", _fp),
         ("v_log_Qcool", _dp), ("v_kdB_dT_CDF", _dp), ("v_prob_s11_pos", _fp), ("v_s12_o_s11", _fp), ("v_s22_o_s11", _fp),
         ("v_s33_o_s11", _fp), ("v_s34_o_s11", _fp), ("v_s44_o_s11", _fp), ("v_tab_g_pos", _fp), ("r_lim", _dp),
@@ -273,6 +273,8 @@ class Oracle:
             s.mrw, s.mrw_n_zeta = 1, int(mrw["zeta"].size)
             for k in ("zeta", "chi", "kappa_dep", "ext"):
                 setattr(s, "mrw_" + k, self._hold(_a(mrw[k], np.float64), C.c_double))
+            if mrw.get("exit_cdf") is not None:
+                s.mrw_exit_cdf = self._hold(_a(mrw["exit_cdf"], np.float64), C.c_double)
             s.mrw_gamma, s.mrw_n_inter = float(mrw["gamma"]), int(mrw["n_inter"])
         return s
 

@@ -1958,7 +1958,22 @@ static int mrw_walk(worker_t *W, int *lambda, int icell, double *x, double *y, d
    * the packet was absorbed and re-emitted inside, so it leaves as a thermal packet of this cell -- through the
    * sphere's surface, i.e. outwards: cosine law about the last step's direction */
   rng_mrw_block(&W->rng, blk, r4);
-  im_reemission_LTE(W, icell, r4[3], r4[0], lambda);
+  if (m->mrw_exit_cdf) {
+    /* the packet crosses the sphere in the middle of a flight: its wavelength is that of the packets in flight (the
+     * thick cell's radiation field), not of a packet that has just been emitted -- the latter prefers the wavelengths of
+     * high opacity and would be re-absorbed next to the sphere, where the former flies on */
+    const size_t eo = (m->p_n_cells ? (size_t)(m->p_icell[icell - 1] - 1) * m->n_T : 0) * (size_t)m->n_lambda;
+    int Te; float Tf; double fe;
+    cell_temperature(W, icell, &Te, &Tf, &fe);   /* (the walk's deposits included, as im_reemission_LTE has it) */
+    const double *c1 = m->mrw_exit_cdf + eo + (size_t)m->n_lambda * (Te - 2), *c2 = m->mrw_exit_cdf + eo + (size_t)m->n_lambda * (Te - 1);
+    int l1 = 0, l2 = m->n_lambda, l = (l1 + l2) / 2;
+    while ((l2 - l1) > 1) {
+      const double proba = (1.0 - fe) * c1[l - 1] + fe * c2[l - 1];
+      if ((double)r4[0] > proba) l1 = l; else l2 = l;
+      l = (l1 + l2) / 2;
+    }
+    *lambda = l + 1;
+  } else im_reemission_LTE(W, icell, r4[3], r4[0], lambda);
   oracle_cdapres(sqrt((double)r4[1]), PI * (2.0 * (double)r4[2] - 1.0), su, sv, sw, u, v, w);
   Stokes[1] = 0.0; Stokes[2] = 0.0; Stokes[3] = 0.0;
   W->cnt[ORC_CNT_MRW_WALKS]++;

@@ -172,6 +172,10 @@ typedef struct {
                                   of make_MRW_step, D = 1/(3 chi kappa_factor) */
   const double *mrw_kappa_dep; /* [n_T] mean absorption opacity the walk deposits with (units of kappa_abs_LTE) */
   const double *mrw_ext;       /* [n_T] extrapolation length of the sphere radius, reference cell (AU); zeros: none */
+  const double *mrw_exit_cdf;  /* [n_T][n_lambda] cumulative spectrum of a packet IN FLIGHT in a thick cell at tab_Temp (weights
+                                  dB/dT: the emission spectrum kappa_abs dB/dT times the path 1 / kappa_abs a packet flies at
+                                  that wavelength before it is absorbed), which the walk's last step leaves the sphere with;
+                                  NULL: the emission spectrum kdB_dT_CDF (round 3) */
   float mrw_gamma;             /* gamma_MRW = 2 (MRW.f90:11) */
   int mrw_n_inter;             /* a walk may start after more than this many interactions in one cell: 5 (:1223) */
   /* ---- lvariable_dust (mem.f90:213-244): tables with the cell axis p_n_cells, in the reference's layouts.  p_n_cells = 0:

@@ -167,7 +167,7 @@ struct Conv {
     M.R_ISM = m->R_ISM;
     for (int q = 0; q < 3; ++q) M.centre_ISM[q] = m->centre_ISM[q];
     M.mrw = m->mrw; M.mrw_n_zeta = m->mrw_n_zeta; M.mrw_n_inter = m->mrw_n_inter; M.mrw_gamma = m->mrw_gamma;
-    M.mrw_zeta = m->mrw_zeta; M.mrw_chi = m->mrw_chi; M.mrw_kdep = m->mrw_kappa_dep; M.mrw_ext = m->mrw_ext;
+    M.mrw_zeta = m->mrw_zeta; M.mrw_chi = m->mrw_chi; M.mrw_kdep = m->mrw_kappa_dep; M.mrw_ext = m->mrw_ext; M.mrw_exit_cdf = m->mrw_exit_cdf;
     M.r_lim = m->r_lim;
     M.n_classes = m->p_n_cells;
     if (m->p_n_cells) {  // class-major copies, as mcgpu_set_variable_dust lays them out

@@ -289,7 +289,12 @@ def check_mono(emu, m, lam, n2, seed, **kw):
     # Q, U, V go through update_Stokes' default-real trigonometry (scattering.f90:1218): FMA-level noise
     assert np.allclose(a["sed"][1:4], b["sed"][1:4], rtol=1e-5, atol=1e-6 * max(1.0, np.abs(b["sed"][0]).max()))
     if kw.get("rt1", True):
-        xI_close(a["xI_scatt"], b["xI_scatt"], n_midplane_cells=0 if m.cfg.l3D else m.cfg.n_rad)
+        # with Stokes tracking every deposit inherits the default-real trigonometry of update_Stokes (scattering.f90:1206-
+        # 1218: acos, cos, sin in default real; the device forms the same cos / sin of the rotation angle algebraically):
+        # the tolerances of tests/test_gpu_parity.py::_mono_parity
+        pola = m.cfg.lsepar_pola and m.cfg.aniso_method == 1
+        xI_close(a["xI_scatt"], b["xI_scatt"], n_midplane_cells=0 if m.cfg.l3D else m.cfg.n_rad,
+                 rtol=3e-5 if pola else 1e-6, atol_rel=1e-6 if pola else 1e-8)
     return a, b
 
 

@@ -321,8 +321,14 @@ def test_config4_thick_ref41_live_against_brute_force_with_the_reference_gate():
     # the difference of the means; with two degrees of freedom per cell that estimate has heavy tails, so it is pooled:
     # the cells are ranked by absorbed energy and the relative error of a cell is the median over its 140 neighbours in
     # that ranking.  A cell may be off by the reference's own gate value (5 % in T, which its suite only asks of the
-    # 75th percentile; 8 % in the located inner-rim columns, where the walk's bias is 3.5-6.2 %) plus 5 sigma of that noise; the cells above a signal-to-noise floor by 4 % outright (the walk's
-    # bias bound at gamma = 2, as in test_device_walk_against_brute_force).
+    # 75th percentile) plus 5 sigma of that noise; the cells above a signal-to-noise floor by 4 % outright (the walk's
+    # bias bound at gamma = 2, as in test_device_walk_against_brute_force) -- EVERYWHERE since round 4: round 3 had to
+    # allow 8 % in the columns of the illuminated inner rim (radial cells 17-23, up to 12 cells above the midplane),
+    # which the walk heated by 3.5-6.2 %.  The cause was the wavelength the walk's last step left its sphere with -- the
+    # cell's EMISSION spectrum, which prefers the opaque wavelengths, so that the packet was re-absorbed next to the
+    # sphere and the walk carried too little heat outwards; with the spectrum of the packets IN FLIGHT
+    # (mcgpu_set_mrw_exit_spectrum, include/mcgpu.h; host/model.py::init_mrw) the rim agrees with brute force to 0.1 %
+    # where the statistics resolve it (CPU oracle, 8 + 8 seeds of 4e6 packets) and to 1.7 % at worst.
     a, b = T0.mean(0), T1.mean(0)
     se = np.sqrt(T0.var(0, ddof=1) / 3 + T1.var(0, ddof=1) / 3)
     E0 = np.mean([r["E_abs"] for r in r0], axis=0)
@@ -333,31 +339,16 @@ def test_config4_thick_ref41_live_against_brute_force_with_the_reference_gate():
         rel[idx] = np.median(se[idx] / np.maximum(a[idx], 1e-30))
     se_s = rel * a
     sel = (a > 1.2 * cfg.T_min) & (b > 1.2 * cfg.T_min)
-    ri_all = np.asarray(m0.grid["cell_map_i"])[:m0.n_cells]
-    zj_all = np.abs(np.asarray(m0.grid["cell_map_j"])[:m0.n_cells])
-    rim_all = (ri_all >= 17) & (ri_all <= 23) & (zj_all <= 12)   # (the inner-rim columns, see below: 8 % there)
-    bound = np.where(rim_all, 0.08, 0.05)
-    excess = np.abs(b[sel] - a[sel]) - (bound[sel] * a[sel] + 5.0 * se_s[sel])
+    excess = np.abs(b[sel] - a[sel]) - (0.05 * a[sel] + 5.0 * se_s[sel])
     assert (excess <= 0.0).all(), (float(excess.max()), int(np.argmax(excess)))
-    # the cells above a signal-to-noise floor, where a deviation IS the walk's bias: 4 % at most (the bound at gamma = 2)
-    # but for the columns of the illuminated inner rim (radial cells 18-22, the first behind the n_rad_in subdivision,
-    # up to 12 cells above the midplane), which the walk heats by 3.5-6.2 % -- measured on three independent seeds each
-    # way (ri 20: brute force 366 K, walk 384 K; ri 21: 307 / 321 K), the largest cell between 5.1 % and 6.2 % over eight
-    # executions of this test (both sides run live, the in-flight temperature depends on the order in which the
-    # workgroups' deposits arrive): one-sided illumination is where the diffusion solution inside the walk's sphere is
-    # at its worst, packets that still carry scattered starlight do not walk, and the cells behind
-    # the rim see their neighbours' walks end at their wall.  Stated, located (tests/devtools/mrw_cfg4_debug.py lists
-    # them), bounded at 8 %; everywhere else the 4 % of the bias bound holds outright.
     clear = se_s[sel] < 0.002 * a[sel]
     dev_clear = np.abs(b[sel][clear] / a[sel][clear] - 1.0)
     ri = np.asarray(m0.grid["cell_map_i"])[:m0.n_cells][sel][clear]
-    zj = np.abs(np.asarray(m0.grid["cell_map_j"])[:m0.n_cells][sel][clear])
-    rim = (ri >= 17) & (ri <= 23) & (zj <= 12)          # the located cells: the columns of the illuminated inner rim
+    zj = np.abs(np.asarray(m0.grid["cell_map_j"])[:m0.n_cells])[sel][clear]
+    rim = (ri >= 17) & (ri <= 23) & (zj <= 12)          # (round 3's located cells: now held to the same bound)
     assert clear.sum() > 1000 and rim.sum() >= 40
-    assert dev_clear[~rim].max() < 0.04, (float(dev_clear[~rim].max()), int(np.argmax(np.where(rim, 0.0, dev_clear))))
-    assert dev_clear[rim].max() < 0.08
-    worst = np.flatnonzero(sel)[clear][dev_clear > 0.04]    # (0-based cell = (ri - 1) + n_rad (zj - 1): all of them in the rim)
-    assert np.all((worst % cfg.n_rad >= 16) & (worst % cfg.n_rad <= 22) & (worst // cfg.n_rad <= 11)), worst
+    assert dev_clear.max() < 0.04, (float(dev_clear.max()), int(np.argmax(dev_clear)))
+    assert dev_clear[rim].max() < 0.03, float(dev_clear[rim].max())
     print("config 4 (thick ref4.1): p75 |dT/T| = %.4f, largest |dT/T| over the %d clear cells %.4f, kernel %.0f -> %.0f ms" %
           (p75, int(clear.sum()), np.abs(b[sel][clear] / a[sel][clear] - 1.0).max(), r0[0]["kernel_ms"], r1[0]["kernel_ms"]))
 
