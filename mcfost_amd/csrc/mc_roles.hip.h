@@ -724,6 +724,7 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
 
   unsigned int c_cross = 0, c_flight = 0, c_scatt = 0, c_abs = 0, c_esc = 0, c_kill = 0, c_pack = 0, c_dark = 0;
   unsigned int c_walks = 0, c_steps = 0;  // MRW
+  unsigned int ev_max = 0;  // the longest packet this lane binned: crossings + interactions (slot 10 of the counters, a maximum)
   unsigned long long pk_next = 0, pk_end = 0;
   bool no_more_ids = false;  // wave-uniform: the global id counter is exhausted
   // consecutive rounds in which neither this wave nor any other wave of the workgroup had work (Q->beat stands
@@ -1159,6 +1160,7 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
             capteur<POLA>(M, A.sed, R.lambda, R.u, R.v, R.w, S, (fl & ST_STAR) != 0, (fl & ST_SCATT) != 0);
             c_esc++;
           }
+          { const unsigned int ev = (R.pk_cross & 0x7FFFFFFFu) + R.event; ev_max = ev > ev_max ? ev : ev_max; }
           st = S_EMIT;
           finished++;
         }
@@ -1291,6 +1293,11 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
     unsigned long long vsum = cs[q];
     for (int off = 32; off > 0; off >>= 1) vsum += __shfl_down(vsum, off);
     if (lane == 0 && vsum) atomicAdd(&A.counters[q], vsum);
+  }
+  {
+    unsigned int vm = ev_max;
+    for (int off = 32; off > 0; off >>= 1) { const unsigned int o = __shfl_down(vm, off); vm = o > vm ? o : vm; }
+    if (lane == 0 && vm) atomicMax(&A.counters[10], (unsigned long long)vm);
   }
   if (MRW) {
     unsigned long long v8 = c_walks, v9 = c_steps;

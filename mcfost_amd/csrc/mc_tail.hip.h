@@ -268,6 +268,7 @@ __device__ __forceinline__ void tail_packet(const Lds& T, const DevModel& M, con
     if (st == S_EMIT) break;  // (killed at the star)
   }
   flush();
+  { const unsigned int ev = (F.pk_cross & 0x7FFFFFFFu) + event; cs[TAIL_N_COUNTERS] = ev > cs[TAIL_N_COUNTERS] ? ev : cs[TAIL_N_COUNTERS]; }
   cs[1] += c_cross; cs[2] += c_flight; cs[3] += c_scatt; cs[4] += c_abs; cs[5] += c_esc; cs[6] += c_kill; cs[7] += c_dark;
   cs[8] += c_walks; cs[9] += c_steps;
 }
@@ -288,8 +289,8 @@ __global__ void __launch_bounds__(MCGPU_TAIL_BLOCK) k_tail(const DevModel M, con
   const int lane = threadIdx.x & (BIN_WAVE - 1);
   const unsigned int n = *carry_n;
   const Rec<POLA>* recs = reinterpret_cast<const Rec<POLA>*>(carry);
-  unsigned int cs[TAIL_N_COUNTERS];
-  for (int q = 0; q < TAIL_N_COUNTERS; ++q) cs[q] = 0u;
+  unsigned int cs[TAIL_N_COUNTERS + 1];   // (the last entry: the longest packet's events, a maximum -> slot 10)
+  for (int q = 0; q <= TAIL_N_COUNTERS; ++q) cs[q] = 0u;
   for (;;) {
     unsigned int i = 0u;
     if (lane == 0) i = atomicAdd(next, 1u);
@@ -301,6 +302,7 @@ __global__ void __launch_bounds__(MCGPU_TAIL_BLOCK) k_tail(const DevModel M, con
   if (lane == 0)
     for (int q = 0; q < TAIL_N_COUNTERS; ++q)
       if (cs[q]) atomicAdd(&A.counters[q], (unsigned long long)cs[q]);
+  if (lane == 0 && cs[TAIL_N_COUNTERS]) atomicMax(&A.counters[10], (unsigned long long)cs[TAIL_N_COUNTERS]);
 }
 
 }  // namespace mcgpu

@@ -72,6 +72,8 @@ struct mcgpu_ctx {
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev_tail = nullptr;     // recorded in front of k_tail: the launch's tail is [ev_tail, ev1]
+  bool tail_launched = false;
   hipDeviceProp_t prop;
   std::string err;
   DevModel M;
@@ -217,7 +219,7 @@ extern "C" int mcgpu_create(int device, mcgpu_ctx** out) {
   std::memset(&ctx->M, 0, sizeof(DevModel));
   if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&ctx->prop, device) != hipSuccess ||
       hipStreamCreate(&ctx->own_stream) != hipSuccess || hipEventCreate(&ctx->ev0) != hipSuccess ||
-      hipEventCreate(&ctx->ev1) != hipSuccess) {
+      hipEventCreate(&ctx->ev1) != hipSuccess || hipEventCreate(&ctx->ev_tail) != hipSuccess) {
     delete ctx;
     return MCGPU_ERR_HIP;
   }
@@ -256,6 +258,7 @@ extern "C" int mcgpu_destroy(mcgpu_ctx* ctx) {
   bin_release(ctx);
   if (ctx->ev0) hipEventDestroy(ctx->ev0);
   if (ctx->ev1) hipEventDestroy(ctx->ev1);
+  if (ctx->ev_tail) hipEventDestroy(ctx->ev_tail);
   if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
   delete ctx;
   return MCGPU_OK;
@@ -531,6 +534,22 @@ extern "C" int mcgpu_get_info(mcgpu_ctx* ctx, const char* name, double* value) {
   else if (!strcmp(name, "bin_chunks")) *value = ctx->bin_chunks;
   else if (!strcmp(name, "bin_deposits_per_packet")) *value = ctx->bin_dep_per_packet;
   else if (!strcmp(name, "tail_threshold")) *value = tail_threshold(ctx);
+  else if (!strcmp(name, "tail_ms")) {   // k_tail's share of the last thermal launch (0: that launch had no tail kernel)
+    *value = 0.0;
+    if (ctx->launched && ctx->tail_launched) {
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      float ms = 0.f;
+      HIPCHK(hipEventElapsedTime(&ms, ctx->ev_tail, ctx->ev1));
+      *value = ms;
+    }
+  } else if (!strcmp(name, "longest_packet_events")) {   // crossings + interactions of the longest packet binned by the
+    unsigned long long v = 0ull;                            // context's launches since the last non-accumulating one
+    if (ctx->d_counters) {
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      HIPCHK(hipMemcpy(&v, ctx->d_counters + 10, sizeof(v), hipMemcpyDeviceToHost));
+    }
+    *value = (double)v;
+  }
   else if (!strcmp(name, "tau_midplane")) *value = ctx->tau_midplane;
   else if (!strcmp(name, "bin_overflow_blocks") || !strcmp(name, "bin_drained_records")) {
     unsigned long long st[2] = {0ull, 0ull};
@@ -1167,6 +1186,8 @@ static int launch_tail(mcgpu_ctx* ctx, const RunArgs& A, const void* carry, cons
   const void* fn = kpick_tail(l3d, pola, dark, !l3d && mrw);
   HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   HIPCHK(hipMemsetAsync(ctx->d_tail_next, 0, sizeof(unsigned int), ctx->stream));
+  HIPCHK(hipEventRecord(ctx->ev_tail, ctx->stream));   // (what follows is the launch's tail: mcgpu_get_info "tail_ms")
+  ctx->tail_launched = true;
   void* args[] = {(void*)&M, (void*)&A, (void*)&carry, (void*)&carry_n, (void*)&ctx->d_tail_next};
   HIPCHK(hipLaunchKernel(fn, dim3(blocks), dim3(MCGPU_TAIL_BLOCK), args, lds, ctx->stream));
   return MCGPU_OK;
@@ -1624,6 +1645,7 @@ extern "C" int mcgpu_launch_thermal(mcgpu_ctx* ctx, const mcgpu_run_opts* o) {
     HIPCHK(hipMemsetAsync(ctx->d_counters + WORK_SLOT, 0, sizeof(unsigned long long), ctx->stream));
   }
   HIPCHK(hipMemsetAsync(ctx->d_err, 0, sizeof(int), ctx->stream));
+  ctx->tail_launched = false;
   RunArgs A;
   std::memset(&A, 0, sizeof(A));
   A.seed = o->seed; A.first_packet = o->first_packet; A.n_packets = o->n_packets;

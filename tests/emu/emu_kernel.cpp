@@ -40,7 +40,6 @@ template <class T> static inline T __shfl_down(T, int) { return T(0); }
 template <class T> static inline T __shfl_up(T, int) { return T(0); }
 template <class T> static inline T __shfl_xor(T, int) { return T(0); }
 static inline unsigned long long wall_clock64() { return 0ull; }
-static inline unsigned long long atomicMax(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; if (v > o) *p = v; return o; }
 static inline unsigned int atomicAdd(unsigned int* p, unsigned int v) { unsigned int o = *p; *p += v; return o; }
 static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) {
   unsigned long long o = *p; *p += v; return o;
@@ -57,6 +56,7 @@ static inline void __syncthreads() {}
 static inline int __syncthreads_or(int p) { return p; }
 static inline unsigned long long atomicExch(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p = v; return o; }
 static inline int atomicAdd(int* p, int v) { int o = *p; *p += v; return o; }
+static inline unsigned long long atomicMax(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; if (v > o) *p = v; return o; }
 static inline int atomicExch(int* p, int v) { int o = *p; *p = v; return o; }
 static inline int atomicCAS(int* p, int cmp, int v) { int o = *p; if (o == cmp) *p = v; return o; }
 static inline unsigned int atomicCAS(unsigned int* p, unsigned int cmp, unsigned int v) { unsigned int o = *p; if (o == cmp) *p = v; return o; }
