@@ -35,6 +35,11 @@ ATOMIC_LINE_PEAK = 2.37e10   # memory-side atomic operations/s, any type or foot
 PROFILE_ROUND = "r03"
 
 
+def np_sum(a):
+    import numpy as np
+    return np.asarray(a).sum()
+
+
 def _quota_cores():
     cores = os.cpu_count() or 1
     try:
@@ -184,7 +189,15 @@ def build_workload(M, args, config):
         cfg.name += " with M_dust = %g Msun" % dust_mass
     if config == "voronoi":
         cfg.name = "ref4.1 disk as %d Voronoi sites" % args.sites
-        model = M.build_voronoi_model(cfg, args.sites, seed=1, cache_dir=os.path.join(ROOT, "tools", "cache"))
+        # the tessellation is built here, on the box, by the product's kernel (mcgpu_voronoi_tesselation: one thread per
+        # cell; the candidates of a cell are its Delaunay neighbours from one qhull run on the host), with the
+        # reference's cuts of elongated cells and at the stellar surface (voro++_wrapper.cpp:209-262)
+        from mcfost_amd.host import voronoi as V
+        t_tess = time.perf_counter()
+        kern = V.device_tessellator(int(os.environ.get("LOCAL_RANK", "0")))
+        model = M.build_voronoi_model(cfg, args.sites, seed=1, tessellator=kern, platonic=True)
+        model.extra["tessellation_s"] = time.perf_counter() - t_tess
+        model.extra["tessellation_kernel_ms"] = kern.kernel_ms
     else:
         model = M.build_model(cfg)
     model.midplane_snap = 0   # 3D grids: the library's default, the reference's literal arithmetic (include/mcgpu.h)
@@ -255,7 +268,7 @@ def thermal_block(par, args, config, steps, warmup, with_cpu, n_local):
         k_ms = sum(kernel_ms) / len(kernel_ms)
         achieved = bytes_launch / (k_ms * 1e-3) / 1e9
         pmc = pmc_summary(config, n_local, world)
-        if config == "voronoi" and args.sites != 100000:   # (the committed counter passes are those of the default tessellation)
+        if config == "voronoi" and args.sites != 1000000:   # (the committed counter passes are those of the default tessellation)
             pmc = {}
         rate_gpu = n_local / (k_ms * 1e-3)
         valu_pp = (pmc.get("insts_per_packet") or {}).get("valu")
@@ -296,6 +309,12 @@ def thermal_block(par, args, config, steps, warmup, with_cpu, n_local):
         block["tail"] = {"tail_ms": tail_ms, "longest_packet_events": ev_max,
                          "us_per_event_if_one_packet": (tail_ms * 1e3 / ev_max) if (tail_ms > 0 and ev_max > 0) else None,
                          "tail_threshold": eng.get_info("tail_threshold")}
+        if config == "voronoi":
+            block["tessellation"] = {"sites": args.sites, "host_s": model.extra.get("tessellation_s"),
+                                     "kernel_ms": model.extra.get("tessellation_kernel_ms"),
+                                     "faces_per_cell": float(model.grid["v_neigh"].size / model.grid["n_cells"]),
+                                     "cut_cells": int(np_sum(model.grid["v_was_cut"])),
+                                     "builder": "mcgpu_voronoi_tesselation (Delaunay candidates from qhull, clipping on the device)"}
         if binned:   # binned deposits (mc_binned.hip.h): how the step was chunked, what overflowed
             block["binned_deposits"] = {k: eng.get_info("bin_" + k) for k in
                                         ("buckets", "log_blocks", "chunks", "deposits_per_packet", "overflow_blocks", "drained_records")}
@@ -452,7 +471,7 @@ def main():
                          "blocks of the same line")
     ap.add_argument("--sed-lambdas", default="5,15,25,35",
                     help="--config sed: wavelengths (1-based) whose SED Monte Carlo one step runs")
-    ap.add_argument("--sites", type=int, default=100000,
+    ap.add_argument("--sites", type=int, default=1000000,
                     help="--config voronoi: number of SPH-like sites of the tessellation (BASELINE config 5 stand-in)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sed-observers", type=int, default=0, help="--config sed: RT_n_incl (default: the configuration's)")

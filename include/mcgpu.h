@@ -744,6 +744,34 @@ int mcgpu_temp_approx_diffusion_vertical(mcgpu_ctx *ctx, const double *tab_lambd
                                          float *Tdust, int *n_iterations);
 
 /*
+ * The Voronoi tessellation on the device: what the reference gets from voro_C (voro++_wrapper.cpp:43-277; interface
+ * Voronoi.f90:70-96, call :487-520) -- every cell built on its own from the box and the bisector planes of the sites
+ * around it, ONE THREAD PER CELL (mcfost_amd/csrc/mc_tessellate.hip.h).  The candidates of a cell come from the host: knn[n_run][k],
+ * 0-based site ids by increasing distance (a kd-tree search; -1 pads a short list).  A cell is complete once the next
+ * candidate is farther than twice its farthest vertex; otherwise n_neigh = -1 and the host calls again for those cells
+ * (cells[n_run]: the cells to build, NULL = 0 .. n_run - 1) with a larger k.  n_neigh = -2: more faces / vertices than
+ * the kernel holds (96 / 160) or than max_neighbours.
+ * knn_first[n_run + 1] (else NULL): the candidates are ragged rows knn[knn_first[r] .. knn_first[r + 1]) that hold EVERY
+ * site that can cut cell r -- its Delaunay neighbours, e.g. qhull's -- and the security radius is not needed: the mode for
+ * point sets with voids (the cells at a disk's surface reach far into the void and would want every site as candidate).
+ *   xyz[n][3], h[n]            the sites (stars last, h = huge) and their smoothing lengths
+ *   limits[6]                  the box (Voronoi.f90:1275-1280); every site strictly inside
+ *   threshold, n_vectors, cutting_vectors[n_vectors][3], cutting_distance_o_h
+ *                              the cut of elongated cells by the Platonic solid (init_Platonic_Solid, Voronoi.f90:108-192;
+ *                              voro++_wrapper.cpp:209-227): when the farthest vertex is beyond threshold * h
+ *   extra_plane[n_run][4]      NULL, or per cell one more cut, unit normal + distance (<= 0: none): the stellar surface
+ *                              for a star's neighbours (voro++_wrapper.cpp:229-262)
+ * Outputs, per cell of the call: n_neigh, neigh[max_neighbours] (0-based site ids; -1 .. -6 = walls -x +x -y +y -z +z) --
+ * the faces BEFORE the cuts, like the reference's list (:195-207) --, volume AFTER the cuts, delta_edge (the farthest
+ * vertex before the cuts), was_cut.  kernel_ms: the kernel alone.
+ */
+int mcgpu_voronoi_tesselation(int device, int n, const double *xyz, const double *h, const double limits[6],
+                              double threshold, int n_vectors, const double *cutting_vectors,
+                              double cutting_distance_o_h, int n_run, const int *cells, int k, const int *knn,
+                              const int *knn_first, const double *extra_plane, int max_neighbours, int *n_neigh, int *neigh,
+                              double *volume, double *delta_edge, unsigned char *was_cut, double *kernel_ms);
+
+/*
  * Several GPUs of one node behind ONE host thread -- the reference's host is a single OpenMP
  * process (mcfost.f90; the Phantom caller mcfost2phantom.f90:159), so this is the entry it binds.
  * mcgpu_multi_create opens one context per device and one RCCL communicator over them

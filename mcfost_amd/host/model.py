@@ -1156,7 +1156,7 @@ VORONOI_CACHE_VERSION = 1
 
 
 def build_voronoi_model(cfg: DiskConfig, n_sites: int, seed: int = 1, box_z_over_h: float = 6.0,
-                        cut: bool = True, cache_dir: Optional[str] = None) -> Model:
+                        cut: bool = True, cache_dir: Optional[str] = None, tessellator=None, platonic: bool = False) -> Model:
     """BASELINE config 5 stand-in: ``n_sites`` SPH-like sites drawn from the cfg's disk,
     tessellated in a box (``Voronoi.f90:183-640`` hands the same arrays to the loop), the
     star added as its own site, densities from the analytic disk evaluated at the sites."""
@@ -1185,13 +1185,16 @@ def build_voronoi_model(cfg: DiskConfig, n_sites: int, seed: int = 1, box_z_over
         # the key names everything the tessellation depends on: the disk that the sites sample, the box, the star's
         # site, and the version of the builder (bump VORONOI_CACHE_VERSION when host/voronoi.py changes its output)
         geo = repr((VORONOI_CACHE_VERSION, n_sites, seed, box_z_over_h, int(cut), cfg.rin, cfg.rout, cfg.sclht, cfg.rref,
-                    cfg.exp_beta, cfg.surf, tuple(cfg.star_xyz), float(r_au), limits))
+                    cfg.exp_beta, cfg.surf, tuple(cfg.star_xyz), float(r_au), limits) + ((int(platonic),) if platonic else ()))
         cache = os.path.join(cache_dir, "voronoi_%d_%s.npz" % (n_sites, hashlib.sha1(geo.encode()).hexdigest()[:12]))
         if os.path.exists(cache):
             z = np.load(cache)
             grid = {k: (z[k] if z[k].ndim else z[k].item()) for k in z.files}
     if grid is None:
-        grid = V.build_voronoi_grid(sites, limits, stars_xyz_r=[(sx, sy, sz, r_au)], h=h, cut=cut)
+        # (tessellator: None = scipy on the host; V.device_tessellator() = the product's kernel, mcgpu_voronoi_tesselation --
+        # the same grid bit for bit (tests/test_tessellation.py); platonic: the reference's cuts in full, host/voronoi.py)
+        grid = V.build_voronoi_grid(sites, limits, stars_xyz_r=[(sx, sy, sz, r_au)], h=h, cut=cut, tessellator=tessellator,
+                                    platonic=platonic)
         if cache:
             # written under a private name and moved into place: concurrent builders (one per rank) never leave a torn file
             os.makedirs(cache_dir, exist_ok=True)
