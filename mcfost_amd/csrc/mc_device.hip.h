@@ -153,6 +153,8 @@ struct DevModel {
   const double* mrw_kdep;  // [n_T] mean absorption opacity of the walk's deposits
   const double *sin_phi, *cos_phi;  // [n_az] sin / cos of the azimuthal walls (3D; cylindrical_grid.f90:586-599), for the walk
   const double* mrw_ext;   // [n_T] extrapolation length of the sphere radius, reference cell
+  const int* mrw_guide;    // [MRW_GUIDE + 1] mrw_guide[b] = the last index i with zeta[i] <= b / MRW_GUIDE: where the search of
+                           // mrw_sample_y starts for a draw in bucket b (14 dependent loads -> ~4)
   const double* mrw_exit_cdf;  // [n_T][n_lambda] (per class) cumulative spectrum a walk's last step leaves its sphere with;
                                // nullptr: the emission spectrum kdB_dT_CDF (mcgpu_set_mrw_exit_spectrum)
   const double* r_lim;     // [n_rad+1] (distance_to_closest_wall_cyl)
@@ -1519,10 +1521,19 @@ __device__ inline double distance_to_closest_wall_cyl(const Lds& T, const DevMod
 }
 
 // y with zeta(y) = xi (MRW.f90:58-70 read as the inverse it means)
+constexpr int MRW_GUIDE = 1024;
 __device__ inline double mrw_sample_y(const DevModel& M, float xi) {
   const double* zt = M.mrw_zeta;
   const double x = xi > 0.0f ? (double)xi : 2.9802322387695312e-08;
+  // zeta[lo] <= x < zeta[hi], hi - lo = 1: unique in a non-decreasing table, so the guide (the answers at the bucket
+  // edges) only narrows the bracket the bisection starts from
   int lo = 0, hi = M.mrw_n_zeta - 1;
+  if (M.mrw_guide) {
+    const int b = (int)(x * (double)MRW_GUIDE);   // x < 1
+    lo = M.mrw_guide[b];
+    const int h2 = M.mrw_guide[b + 1] + 1;
+    hi = h2 < hi ? h2 : hi;
+  }
   while (hi - lo > 1) {
     const int mid = (lo + hi) / 2;
     if (zt[mid] <= x) lo = mid; else hi = mid;

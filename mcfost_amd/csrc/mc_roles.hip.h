@@ -186,12 +186,20 @@ __device__ inline void var_cell_opacities(const DevModel& M, Flight& F, int ic) 
   F.kab = kk.y;
 }
 
-template <bool L3D, bool VAR = false>
+// REUSE (the tail kernel, whose trapped packets start flight after flight in one cell): F.ic / F.kf still hold the last
+// flight's cell and its kappa_factor (F.ic = -1: nothing yet), and the load from HBM is skipped while the cell is the same
+template <bool L3D, bool VAR = false, bool REUSE = false>
 __device__ inline void flight_constants(const Lds& T, const DevModel& M, Flight& F, int lambda) {
   const double a = F.u * F.u + F.v * F.v;  // cylindrical_grid.f90:941-952
   F.inv_a = (a > TINY_REAL) ? 1.0 / a : HUGE_REAL;
   F.inv_w = (fabs(F.w) > TINY_REAL) ? 1.0 / F.w : copysign(HUGE_DP, F.w);
-  F.ic = is_real_cell<L3D>(M.n_rad, M.nz, F.ri, F.zj) ? cell_index<L3D>(M.n_rad, M.nz, F.ri, F.zj, F.k) : M.n_cells;
+  const int ic_new = is_real_cell<L3D>(M.n_rad, M.nz, F.ri, F.zj) ? cell_index<L3D>(M.n_rad, M.nz, F.ri, F.zj, F.k) : M.n_cells;
+  if (REUSE && !VAR && ic_new == F.ic) {
+    F.kap = T.kappa[lambda - 1];
+    F.kab = T.kabs[lambda - 1];
+    return;
+  }
+  F.ic = ic_new;
   if (VAR) {
     F.lam = lambda;
     F.kap = 1.0;

@@ -104,7 +104,8 @@ __device__ __forceinline__ void tail_packet(const Lds& T, const DevModel& M, con
     tau_next = (rand > 1.0e-6f) ? -log(1.0 - (double)rand) : (double)rand;
     st = lintersect ? S_NEWFLIGHT : S_EXITED;
   }
-  if (st == S_FLIGHT) flight_constants<L3D>(T, M, F, lambda);
+  F.ic = -1;   // (no cell's kappa_factor at hand yet: flight_constants<..., REUSE>)
+  if (st == S_FLIGHT) flight_constants<L3D, false, true>(T, M, F, lambda);
   TailBatch B;
   B.base = 0u;
 
@@ -127,8 +128,12 @@ __device__ __forceinline__ void tail_packet(const Lds& T, const DevModel& M, con
   // the tail packets' own deposits -- 1e-4 of the total -- and a value some microseconds old is as good an estimate as
   // the reference's per-thread partial sum.  (The agent-scope load of the throughput kernels goes to the memory side
   // -- the line was last written by an atomic --: ~2 us, more than the rest of the event.)
-  int e_cell = -1;
-  double e_val = 0.0;
+  int e_cell = -1, v_cell = -1;
+  double e_val = 0.0, v_val = 1.0;
+  auto cell_volume = [&](int ic) {   // (a trapped packet is absorbed in one cell again and again: one load per cell)
+    if (ic != v_cell) { v_val = M.volume[ic]; v_cell = ic; }
+    return v_val;
+  };
   auto cell_energy = [&](int ic) {
     if (A.frozen) return A.E_prior[ic];
     if (ic != e_cell) { e_val = A.E_abs[ic]; e_cell = ic; }
@@ -178,7 +183,7 @@ __device__ __forceinline__ void tail_packet(const Lds& T, const DevModel& M, con
         flag_scatt = false;
         // im_reemission_LTE (thermal_emission.f90:710-771): Temp_LTE, then the wavelength
         const int ic = cell_index<L3D>(n_rad, nz, F.ri, F.zj, F.k);
-        const double Qheat = cell_energy(ic) * M.L_packet_th / M.volume[ic];
+        const double Qheat = cell_energy(ic) * M.L_packet_th / cell_volume(ic);
         int Ti = 2;
         double frac_T2 = 0.0;
         if (!(Qheat < TINY_DP)) {
@@ -239,7 +244,7 @@ __device__ __forceinline__ void tail_packet(const Lds& T, const DevModel& M, con
       }
       F.star_key = key;
       c_flight++;
-      flight_constants<L3D>(T, M, F, lambda);
+      flight_constants<L3D, false, true>(T, M, F, lambda);
       st = S_FLIGHT;
     }
     if (st == S_FLIGHT) {

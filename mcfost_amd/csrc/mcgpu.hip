@@ -1052,6 +1052,16 @@ extern "C" int mcgpu_set_mrw(mcgpu_ctx* ctx, int n_zeta, const double* zeta, con
   HIPCHK(hipSetDevice(ctx->device));
   int rc;
   if ((rc = upload(ctx, zeta, (size_t)n_zeta, &M.mrw_zeta))) return rc;
+  {  // the guide of mrw_sample_y (mc_device.hip.h): per bucket edge b / MRW_GUIDE the last entry not above it
+    std::vector<int> guide((size_t)MRW_GUIDE + 1);
+    int i = 0;
+    for (int b = 0; b <= MRW_GUIDE; ++b) {
+      const double edge = (double)b / (double)MRW_GUIDE;
+      while (i + 1 < n_zeta && zeta[i + 1] <= edge) ++i;
+      guide[b] = i;   // (zeta[0] = 0 <= every edge)
+    }
+    if ((rc = upload(ctx, guide.data(), guide.size(), &M.mrw_guide))) return rc;
+  }
   // (lvariable_dust, set before this call: one row of n_T values per class)
   const size_t n_tab = (size_t)M.n_T * (M.n_classes ? M.n_classes : 1);
   ctx->mrw_classes = M.n_classes;
