@@ -539,7 +539,7 @@ def main():
                 "launcher": launcher}
         if par.rccl_ranks is not None:
             line["rccl_ranks"] = par.rccl_ranks
-        for k in ("cpu_baseline", "tdust_vs_cpu", "binned_deposits"):
+        for k in ("cpu_baseline", "tdust_vs_cpu", "binned_deposits", "tail", "tessellation", "mrw_vs_brute_force_gpu"):
             if k in block:
                 line[k] = block[k]
         line.update(extras)

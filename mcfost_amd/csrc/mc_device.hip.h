@@ -94,6 +94,44 @@ __device__ __forceinline__ double sqrt_nonneg(double x) {
 }
 #endif
 
+// log(x) for positive, finite, normal x: frexp, s = (m - 1) / (m + 1) with m in [sqrt(1/2), sqrt(2)), the series
+// 2 s (1 + s^2 / 3 + ... + s^18 / 19) and e ln 2 -- 4e-16 of libm's log (2 ulp; checked over 5e6 arguments on the host),
+// 35 vector instructions against the 98 of the library routine, which carries a double-double tail for its last bit.
+// The packet loop takes two logarithms per interaction: the optical depth of the next flight, -log(1 - rand)
+// (dust_transfer.f90:1208-1215 -- in default real there) and Temp_LTE's log(Qheat) (thermal_emission.f90:684).
+__device__ __forceinline__ double log_pos(double x) {
+#ifdef MCGPU_LANE_EMULATION
+  return log(x);
+#else
+  double m = __builtin_amdgcn_frexp_mant(x);   // [0.5, 1)
+  int e = __builtin_amdgcn_frexp_exp(x);
+  const bool lo = m < 0.70710678118654752;
+  m = lo ? m + m : m;
+  e = lo ? e - 1 : e;
+  // 1 / (m + 1), m + 1 in [1.7, 2.42): the hardware's estimate and two Newton steps
+  const double d = m + 1.0;
+  double r = __builtin_amdgcn_rcp(d);
+  r = __builtin_fma(r, __builtin_fma(-d, r, 1.0), r);
+  r = __builtin_fma(r, __builtin_fma(-d, r, 1.0), r);
+  const double s = (m - 1.0) * r, z = s * s;
+  double p = 1.0 / 19.0;
+  p = __builtin_fma(p, z, 1.0 / 17.0);
+  p = __builtin_fma(p, z, 1.0 / 15.0);
+  p = __builtin_fma(p, z, 1.0 / 13.0);
+  p = __builtin_fma(p, z, 1.0 / 11.0);
+  p = __builtin_fma(p, z, 1.0 / 9.0);
+  p = __builtin_fma(p, z, 1.0 / 7.0);
+  p = __builtin_fma(p, z, 1.0 / 5.0);
+  p = __builtin_fma(p, z, 1.0 / 3.0);
+  p = __builtin_fma(p, z, 1.0);
+  return __builtin_fma((double)e, 0.6931471805599453, (s + s) * p);
+#endif
+}
+// the optical depth a flight is given (dust_transfer.f90:1208-1215)
+__device__ __forceinline__ double tau_of_draw(float rand) {
+  return (rand > 1.0e-6f) ? -log_pos(1.0 - (double)rand) : (double)rand;
+}
+
 struct DevModel {
   // grid
   int n_rad, nz, n_az, l3D, n_cells;
@@ -262,9 +300,11 @@ __host__ __device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 //   event 0 (emission + first flight): blocks 0,1,2 -> f[0..11]
 //       f0 wavelength, f1 star/disk choice, star: f2 select_star, f3..f6 uniform sphere,
 //       disk: f2 select_cellule, f3..f5 pos_em_cell, f6,f7 isotropic direction, f8 first tau
-//   event e >= 1 (e-th interaction + next flight): blocks 3+2(e-1), 4+2(e-1) -> g[0..7]
-//       g0 scatter/absorb, g1 rand, g2 rand2, scatter: g3 azimuth, absorb: g3,g4 isotropic
-//       direction, g5 tau of the next flight
+//   event e >= 1 (e-th interaction + next flight): ONE block, 3+(e-1) -> five 24-bit uniforms (the upper 24 bits of the
+//       four words, and the three lower bytes of words 0, 1, 2): g0 scatter/absorb, g1 rand, g2 rand2, scatter: g3 azimuth,
+//       absorb: g3, g4 (= g1, which a re-emission does not use otherwise) isotropic direction, g5 tau of the next flight.
+//       Round 4: two blocks per event before -- 61 vector instructions each; scattering method 1 (six draws per
+//       scattering) keeps the two blocks 3+2(e-1), 4+2(e-1) -> g[0..7].
 struct Rng {
   uint32_t k0, k1;      // seed (wave-uniform)
   uint32_t p_lo, p_hi;  // packet id
@@ -285,9 +325,18 @@ struct Rng {
     block(0u, f); block(1u, f + 4); block(2u, f + 8);
     event = 1;
   }
-  __device__ inline void interaction_event(float g[8]) {
-    const uint32_t first = 3u + 2u * (event - 1u);
-    block(first, g); block(first + 1u, g + 4);
+  __device__ inline void interaction_event(float g[8], bool two_blocks = false) {
+    if (two_blocks) {   // (wave-uniform: scattering method 1)
+      const uint32_t first = 3u + 2u * (event - 1u);
+      block(first, g); block(first + 1u, g + 4);
+    } else {
+      uint32_t o[4];
+      philox4x32_10(3u + (event - 1u), 0u, p_lo, p_hi, k0, k1, o);
+      g[0] = real(o[0]); g[1] = real(o[1]); g[2] = real(o[2]); g[3] = real(o[3]);
+      g[4] = g[1];
+      g[5] = (float)(((o[0] & 0xFFu) << 16) | ((o[1] & 0xFFu) << 8) | (o[2] & 0xFFu)) * (1.0f / 16777216.0f);
+      g[6] = g[7] = 0.0f;
+    }
     event += 1;
   }
 };
@@ -1120,7 +1169,7 @@ __device__ inline void temp_lte(const double* lq, int n_T, double E_scaled, doub
   frac = 0.0;
   Ti = 2;
   if (Qheat < TINY_DP) return;
-  double log_Qheat = log(Qheat);
+  double log_Qheat = log_pos(Qheat);   // (Qheat >= tiny_dp: positive and normal)
   if (log_Qheat < lq[0]) return;
   int lo = 2, hi = n_T;  // 1-based
   while (lo < hi) {
@@ -1840,7 +1889,7 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
     // ---- INTERACT: scatter or absorb + re-emit (dust_transfer.f90:1260-1402)
     if (st == S_INTERACT) {
       float g[8];
-      rng.interaction_event(g);
+      rng.interaction_event(g, M.m1 != 0);
       tau_rand = g[5];
       double u1, v1, w1;
       const int ic = cell_index<L3D>(n_rad, nz, ri, zj, k);
@@ -1888,7 +1937,7 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
     // ---- NEWFLIGHT: optical depth to the next event + per-flight constants
     if (st == S_NEWFLIGHT) {
       const float rand = tau_rand;  // dust_transfer.f90:1208-1215 (tau in FP64)
-      extr = (rand > 1.0e-6f) ? -log(1.0 - (double)rand) : (double)rand;
+      extr = tau_of_draw(rand);
       const double a = u * u + v * v;  // cylindrical_grid.f90:941-952
       inv_a = (a > TINY_REAL) ? 1.0 / a : HUGE_REAL;
       inv_w = (fabs(w) > TINY_REAL) ? 1.0 / w : copysign(HUGE_DP, w);

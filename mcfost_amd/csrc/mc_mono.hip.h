@@ -591,7 +591,7 @@ __device__ __forceinline__ void mono_body(const DevModel& M, const MonoArgs& A, 
 
     if (st == S_INTERACT) {  // forced scattering (dust_transfer.f90:1263-1278)
       float g[8];
-      rng.interaction_event(g);
+      rng.interaction_event(g, M.m1 != 0);
       tau_rand = g[5];
       bool dead = false;
       if (DARK) dead = M.dark[cell_index<L3D>(n_rad, nz, ri, zj, k)] != 0;
@@ -615,7 +615,7 @@ __device__ __forceinline__ void mono_body(const DevModel& M, const MonoArgs& A, 
 
     if (st == S_NEWFLIGHT) {
       const float rand = tau_rand;
-      extr = (rand > 1.0e-6f) ? -log(1.0 - (double)rand) : (double)rand;
+      extr = tau_of_draw(rand);
       const double a = u * u + v * v;
       inv_a = (a > TINY_REAL) ? 1.0 / a : HUGE_REAL;
       inv_w = (fabs(w) > TINY_REAL) ? 1.0 / w : copysign(HUGE_DP, w);

@@ -92,7 +92,7 @@ __device__ __forceinline__ void mono_body_voro(const DevModel& M, const MonoArgs
 
     if (st == S_INTERACT) {  // forced scattering (dust_transfer.f90:1263-1278); no dark zone on this grid
       float g[8];
-      rng.interaction_event(g);
+      rng.interaction_event(g, M.m1 != 0);
       tau_rand = g[5];
       const int cls = var ? M.cell_class[icell - 1] : -1;
       const Lds Tc = var ? class_tables(T, M, cls) : T;
@@ -112,7 +112,7 @@ __device__ __forceinline__ void mono_body_voro(const DevModel& M, const MonoArgs
 
     if (st == S_NEWFLIGHT) {
       const float rand = tau_rand;
-      extr = (rand > 1.0e-6f) ? -log(1.0 - (double)rand) : (double)rand;
+      extr = tau_of_draw(rand);
       if (!SCOUT && A.rt1) angles_scatt_rt1<POLA>(M, A, ML.R, u, v, w);  // optical_depth.f90:65
       const int i_star = intersect_stars(M, x, y, z, u, v, w);
       star_icell = (i_star > 0) ? M.star_cell[4 * (i_star - 1)] : 0;

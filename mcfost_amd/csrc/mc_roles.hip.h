@@ -1020,7 +1020,7 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
           Rng rng;
           rng.k0 = key0; rng.k1 = key1; rng.p_lo = R.p_lo; rng.p_hi = R.p_hi; rng.event = R.event;
           float g[8];
-          rng.interaction_event(g);
+          rng.interaction_event(g, M.m1 != 0);
           int lambda = R.lambda;
           lambda_sc = lambda;
           const int fl = R.flags;
@@ -1104,7 +1104,7 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
         if (rid >= 0 && st == S_NEWFLIGHT) {
           Rec<POLA>& R = recs[rid];
           const float rand = R.tau_rand;
-          R.extr = (rand > 1.0e-6f) ? -log(1.0 - (double)rand) : (double)rand;
+          R.extr = tau_of_draw(rand);
           const int i_star = intersect_stars(M, R.x, R.y, R.z, R.u, R.v, R.w);
           int key = -1;
           if (i_star > 0) {

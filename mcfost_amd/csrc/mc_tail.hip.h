@@ -46,10 +46,10 @@ __device__ inline void tail_draw(TailBatch& B, uint32_t k0, uint32_t k1, uint32_
   Rng rng;
   rng.k0 = k0; rng.k1 = k1; rng.p_lo = p_lo; rng.p_hi = p_hi; rng.event = event + (uint32_t)lane;
   float g[8];
-  rng.interaction_event(g);
+  rng.interaction_event(g);   // (one block per event; scattering method 1 never comes here)
   B.g0 = g[0]; B.g1 = g[1]; B.g2 = g[2]; B.g3 = g[3]; B.g4 = g[4]; B.g5 = g[5];
   const float rand = g[5];
-  B.tau = (rand > 1.0e-6f) ? -log(1.0 - (double)rand) : (double)rand;
+  B.tau = tau_of_draw(rand);
   sincos_pi(2.0 * (double)g[3] - 1.0, &B.ss, &B.cs);
   sincos_pi(2.0 * (double)g[4] - 1.0, &B.sa, &B.ca);
   B.base = event;
@@ -75,7 +75,7 @@ __device__ __forceinline__ void tail_packet(const Lds& T, const DevModel& M, con
   double tau_next = 0.0;   // the optical depth of the next flight
   {                        // (a record in state NEWFLIGHT carries the draw, not the depth)
     const float rand = R0.tau_rand;
-    tau_next = (rand > 1.0e-6f) ? -log(1.0 - (double)rand) : (double)rand;
+    tau_next = tau_of_draw(rand);
   }
   unsigned int c_cross = 0, c_flight = 0, c_scatt = 0, c_abs = 0, c_esc = 0, c_kill = 0, c_dark = 0, c_walks = 0, c_steps = 0;
   if (st == S_EMIT) {
@@ -101,7 +101,7 @@ __device__ __forceinline__ void tail_packet(const Lds& T, const DevModel& M, con
     n_int = 0;
     event = rng.event;
     const float rand = f[8];
-    tau_next = (rand > 1.0e-6f) ? -log(1.0 - (double)rand) : (double)rand;
+    tau_next = tau_of_draw(rand);
     st = lintersect ? S_NEWFLIGHT : S_EXITED;
   }
   F.ic = -1;   // (no cell's kappa_factor at hand yet: flight_constants<..., REUSE>)
@@ -187,7 +187,7 @@ __device__ __forceinline__ void tail_packet(const Lds& T, const DevModel& M, con
         int Ti = 2;
         double frac_T2 = 0.0;
         if (!(Qheat < TINY_DP)) {
-          const double log_Qheat = log(Qheat);
+          const double log_Qheat = log_pos(Qheat);
           if (!(log_Qheat < T.lq[0])) {
             Ti = wave_first_ge(T.lq, 1, M.n_T - 1, log_Qheat, lane) + 1;  // first Ti in [2, n_T] with lq(Ti) >= log Qheat
             frac_T2 = (log_Qheat - T.lq[Ti - 2]) / (T.lq[Ti - 1] - T.lq[Ti - 2]);

@@ -421,7 +421,7 @@ __device__ __forceinline__ void thermal_body_voro(const DevModel& M, const RunAr
 
     if (st == S_INTERACT) {  // dust_transfer.f90:1260-1402
       float g[8];
-      rng.interaction_event(g);
+      rng.interaction_event(g, M.m1 != 0);
       tau_rand = g[5];
       double u1, v1, w1;
       const int ic = icell - 1;
@@ -456,7 +456,7 @@ __device__ __forceinline__ void thermal_body_voro(const DevModel& M, const RunAr
 
     if (st == S_NEWFLIGHT) {
       const float rand = tau_rand;  // dust_transfer.f90:1208-1215
-      extr = (rand > 1.0e-6f) ? -log(1.0 - (double)rand) : (double)rand;
+      extr = tau_of_draw(rand);
       const int i_star = intersect_stars(M, x, y, z, u, v, w);  // optical_depth.f90:68
       star_icell = (i_star > 0) ? M.star_cell[4 * (i_star - 1)] : 0;
       c_flight++;

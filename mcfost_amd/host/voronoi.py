@@ -187,7 +187,7 @@ def delaunay_candidates(pts):
     return np.ascontiguousarray(indptr.astype(np.int32)), np.ascontiguousarray(indices[order].astype(np.int32))
 
 
-def tessellate_knn(pts, limits, h, kernel, threshold=3.0, vectors=None, cd_o_h=3.0, extra=None, k0=40, max_neighbours=64,
+def tessellate_knn(pts, limits, h, kernel, threshold=3.0, vectors=None, cd_o_h=3.0, extra=None, k0=40, max_neighbours=96,
                    workers=-1, candidates="delaunay"):
     """Every cell clipped out of the box on the device (``kernel``: ``device_tessellator()``, or the emulated lane of
     tests/emu).  ``candidates``: "delaunay" -- the host hands every cell its Delaunay neighbours (one qhull run: 33 s per

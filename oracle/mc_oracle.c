@@ -74,10 +74,14 @@ void oracle_philox4x32_10(const uint32_t ctr_in[4], const uint32_t key_in[2],
  *       star:  f2 select_star, f3..f6 emit_packet_uniform_sphere
  *       disk:  f2 select_cellule, f3..f5 pos_em_cell, f6,f7 isotropic direction
  *       f8 optical depth of the first flight
- *   event e >= 1 (e-th interaction + next flight): blocks 3+2(e-1), 4+2(e-1) -> g[0..7]
- *       g0 scatter / absorb choice, g1 rand, g2 rand2
- *       scatter: g3 azimuth          absorb: g3,g4 isotropic direction
- *       g5 optical depth of the next flight
+ *   event e >= 1 (e-th interaction + next flight): ONE block, 3 + (e-1) -> five 24-bit uniforms: the upper 24 bits of
+ *       the four words (h0..h3) and the three lower bytes of words 0, 1, 2 (h4)
+ *       g0 = h0 scatter / absorb choice, g1 = h1 rand, g2 = h2 rand2
+ *       scatter: g3 = h3 azimuth     absorb: g3 = h3, g4 = h1 isotropic direction (a re-emission does not use g1)
+ *       g5 = h4 optical depth of the next flight
+ *     (round 4: an event took two blocks; five draws fit in the 128 bits of one)
+ *     scattering method 1 draws six numbers per scattering (grain, angle, angle, azimuth): two blocks as before,
+ *       3+2(e-1), 4+2(e-1) -> g[0..7], g5 the optical depth
  */
 typedef struct {
   uint32_t key[2];
@@ -86,6 +90,7 @@ typedef struct {
   float ev[12];     /* the current event's uniforms */
   int pos;          /* next unread entry of ev */
   int tau_idx;      /* where the current event keeps the flight's optical-depth draw */
+  int two_blocks;   /* scattering method 1: two blocks per interaction (see above) */
 } rng_t;
 
 static inline float u32_to_real(uint32_t u) {
@@ -102,8 +107,20 @@ static void rng_init(rng_t *r, uint64_t seed, uint64_t packet) {
   r->event = 0;
   r->pos = 0;
   r->tau_idx = 8;
+  r->two_blocks = 0;
 }
 static void rng_begin_event(rng_t *r) {
+  if (r->event >= 1 && !r->two_blocks) {
+    uint32_t ctr[4] = {3u + (r->event - 1u), 0u, r->p_lo, r->p_hi}, out[4];
+    oracle_philox4x32_10(ctr, r->key, out);
+    for (int q = 0; q < 4; ++q) r->ev[q] = u32_to_real(out[q]);
+    r->ev[4] = r->ev[1];
+    r->ev[5] = (float)(((out[0] & 0xFFu) << 16) | ((out[1] & 0xFFu) << 8) | (out[2] & 0xFFu)) * (1.0f / 16777216.0f);
+    r->tau_idx = 5;
+    r->pos = 0;
+    r->event += 1;
+    return;
+  }
   const uint32_t first = r->event == 0 ? 0u : 3u + 2u * (r->event - 1u);
   const int nb = r->event == 0 ? 3 : 2;
   for (int b = 0; b < nb; ++b) {
@@ -2157,6 +2174,7 @@ static int capteur(worker_t *W, int lambda, double uin, double vin,
 static int one_packet(worker_t *W, uint64_t packet) {
   const oracle_model *m = W->m;
   rng_init(&W->rng, W->o->seed, packet);
+  W->rng.two_blocks = W->m->scattering_method1 != 0;
   rng_begin_event(&W->rng);
   W->cnt[ORC_CNT_PACKETS]++;
   int lambda, icell = 0, lintersect, flag_star, flag_ISM, flag_scatt = 0;
@@ -2250,6 +2268,7 @@ int oracle_run_thermal(const oracle_model *m, const oracle_opts *o,
  * returns 1 when the packet was binned in capt_sup (:551) */
 static int one_packet_mono(worker_t *W, uint64_t packet, int *err) {
   rng_init(&W->rng, W->o->seed, packet);
+  W->rng.two_blocks = W->m->scattering_method1 != 0;
   rng_begin_event(&W->rng);
   W->cnt[ORC_CNT_PACKETS]++;
   int lambda = W->mono->lambda, icell = 0, lintersect, flag_star, flag_ISM, flag_scatt = 0;
