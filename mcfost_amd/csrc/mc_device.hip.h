@@ -1096,9 +1096,10 @@ __device__ inline void rotation(double xinit, double yinit, double zinit, double
 
 // update_Stokes (scattering.f90:1187-1298) with get_Mueller_matrix_per_cell
 // (:1328-1350) folded in: M11 = 1, M12 = M21, M34 = -M43.
-__device__ inline void update_stokes(double S[4], double u0, double v0, double w0, double u1, double v1,
-                                     double w1, double M12, double M22, double M33, double M34,
-                                     double M44, double M11 = 1.0) {
+// (two halves, so that the tail kernel can compute the first -- the expensive one: a rotation, two square roots, three
+// divisions -- for many scatterings at once and apply the second in sequence, mc_tail.hip.h)
+// the rotation of the Stokes vector into the scattering plane: cos and sin of omega (scattering.f90:1187-1226)
+__device__ inline void stokes_rotation(double u0, double v0, double w0, double u1, double v1, double w1, double& cw, double& sw) {
   double v1pi, v1pj, v1pk;
   rotation(u0, v0, w0, u1, v1, w1, v1pi, v1pj, v1pk);
   float xnyp = (float)sqrt(v1pk * v1pk + v1pj * v1pj);
@@ -1117,7 +1118,11 @@ __device__ inline void update_stokes(double S[4], double u0, double v0, double w
   float cosw = (float)(1.0 - 2.0 * c2);
   if (fabsf(cosw) < 1e-06f) cosw = 0.0f;
   if (fabsf(sinw) < 1e-06f) sinw = 0.0f;
-  const double cw = (double)cosw, sw = (double)sinw;
+  cw = (double)cosw; sw = (double)sinw;
+}
+// ... and the Mueller matrix applied between the two rotations, I renormalised (scattering.f90:1228-1298)
+__device__ inline void stokes_apply(double S[4], double cw, double sw, double M12, double M22, double M33, double M34,
+                                    double M44, double M11 = 1.0) {
   double C0 = S[0], C1 = cw * S[1] - sw * S[2], C2 = sw * S[1] + cw * S[2], C3 = S[3];
   // D = M*C with M = [[M11,M12,0,0],[M12,M22,0,0],[0,0,M33,M34],[0,0,-M34,M44]] (M11 = 1 but for scattering method 1)
   double D0 = M11 * C0 + M12 * C1;
@@ -1133,6 +1138,13 @@ __device__ inline void update_stokes(double S[4], double u0, double v0, double w
     double f = M11 * S1_0 / S[0];
     S[0] *= f; S[1] *= f; S[2] *= f; S[3] *= f;
   }
+}
+__device__ inline void update_stokes(double S[4], double u0, double v0, double w0, double u1, double v1,
+                                     double w1, double M12, double M22, double M33, double M34,
+                                     double M44, double M11 = 1.0) {
+  double cw, sw;
+  stokes_rotation(u0, v0, w0, u1, v1, w1, cw, sw);
+  stokes_apply(S, cw, sw, M12, M22, M33, M34, M44, M11);
 }
 
 // intersect_stars (stars.f90:812-884): returns star index (1-based) or 0
@@ -1472,6 +1484,24 @@ __device__ __forceinline__ bool interact_direction(const Lds& T, const DevModel&
   return scat;
 }
 
+// get_Mueller_matrix_per_cell (scattering.f90:1328-1350): the ratios S12/S11 ... interpolated between the angle bins
+__device__ __forceinline__ void mueller_pos(const DevModel& M, int lambda, int itheta, float rand2, int cls, double& M12,
+                                            double& M22, double& M33, double& M34, double& M44) {
+  const size_t o = (size_t)(M.nang + 1) * (lambda - 1) + itheta;
+  const float fr = rand2, fm = 1.0f - rand2;
+  const size_t co = cls >= 0 ? (size_t)cls * M.n_lambda * (M.nang + 1) : 0;
+  const float* s22 = (cls >= 0 ? M.v_s22 : M.s22) + co;
+  const float* s12 = (cls >= 0 ? M.v_s12 : M.s12) + co;
+  const float* s33 = (cls >= 0 ? M.v_s33 : M.s33) + co;
+  const float* s44 = (cls >= 0 ? M.v_s44 : M.s44) + co;
+  const float* s34 = (cls >= 0 ? M.v_s34 : M.s34) + co;
+  M22 = (double)(s22[o] * fr + s22[o - 1] * fm);
+  M12 = (double)(s12[o] * fr + s12[o - 1] * fm);
+  M33 = (double)(s33[o] * fr + s33[o - 1] * fm);
+  M44 = (double)(s44[o] * fr + s44[o - 1] * fm);
+  M34 = (double)(-s34[o] * fr - s34[o - 1] * fm);
+}
+
 // lambda: the packet's wavelength at the time of the scattering (a scattering does not change it)
 // cls >= 0: the Mueller ratios of that cell class (lvariable_dust with per-class scattering tables)
 __device__ __forceinline__ void interact_stokes(const DevModel& M, bool scat, int lambda, int itheta, float rand2,
@@ -1489,19 +1519,8 @@ __device__ __forceinline__ void interact_stokes(const DevModel& M, bool scat, in
     const double M34 = (double)(-M.m1_s34[o] * fr - M.m1_s34[o - 1] * fm);
     update_stokes(S, u, v, w, u1, v1, w1, M12, M22, M33, M34, M44, M11);
   } else if (scat && M.aniso_method == 1) {
-    const size_t o = (size_t)(M.nang + 1) * (lambda - 1) + itheta;
-    const float fr = rand2, fm = 1.0f - rand2;
-    const size_t co = cls >= 0 ? (size_t)cls * M.n_lambda * (M.nang + 1) : 0;
-    const float* s22 = (cls >= 0 ? M.v_s22 : M.s22) + co;
-    const float* s12 = (cls >= 0 ? M.v_s12 : M.s12) + co;
-    const float* s33 = (cls >= 0 ? M.v_s33 : M.s33) + co;
-    const float* s44 = (cls >= 0 ? M.v_s44 : M.s44) + co;
-    const float* s34 = (cls >= 0 ? M.v_s34 : M.s34) + co;
-    const double M22 = (double)(s22[o] * fr + s22[o - 1] * fm);
-    const double M12 = (double)(s12[o] * fr + s12[o - 1] * fm);
-    const double M33 = (double)(s33[o] * fr + s33[o - 1] * fm);
-    const double M44 = (double)(s44[o] * fr + s44[o - 1] * fm);
-    const double M34 = (double)(-s34[o] * fr - s34[o - 1] * fm);
+    double M12, M22, M33, M34, M44;
+    mueller_pos(M, lambda, itheta, rand2, cls, M12, M22, M33, M34, M44);
     update_stokes(S, u, v, w, u1, v1, w1, M12, M22, M33, M34, M44);
   }
   if (!scat) { S[1] = 0.0; S[2] = 0.0; S[3] = 0.0; }
@@ -1623,7 +1642,7 @@ __device__ inline bool mrw_walk_with(const Lds& T, const DevModel& M, uint32_t k
     z += sw * d;
     const double yv = mrw_sample_y(M, Rng::real(o[2]));
     const double de = d + ext;
-    const double ct = -log(yv) * cst_ct * chi * (de * de);
+    const double ct = -log_pos(yv) * cst_ct * chi * (de * de);
     add_energy(kdep * ct * S0);
     c_steps++;
     d = closest_wall(x, y, z);

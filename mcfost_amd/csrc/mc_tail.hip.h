@@ -140,6 +140,32 @@ __device__ __forceinline__ void tail_packet(const Lds& T, const DevModel& M, con
     return (e_val + (ic == dep_cell ? dep_sum : 0.0)) * A.qscale;
   };
 
+  // Stokes Q, U, V lazily (POLA): a scattering leaves I unchanged (update_Stokes renormalises it, scattering.f90:1294) and
+  // an absorption sets Q = U = V = 0 (dust_transfer.f90:1369), so the scatterings BEFORE a packet's last absorption never
+  // reach the SED -- and a trapped packet has thousands of them, each a rotation, two square roots and three divisions
+  // (290 of an event's ~700 dependent vector instructions).  Lane q keeps the q-th scattering since the last absorption
+  // (directions before and after, angle bin, draw, wavelength); an absorption forgets them; the packet's end -- or the
+  // 65th pending scattering -- has every lane compute ITS scattering's rotation and Mueller ratios at once
+  // (stokes_rotation, mueller_pos) and the wave apply them in order (stokes_apply: the very expressions of
+  // update_stokes).  Q, U, V at the end are the throughput kernels' bit for bit; I differs from theirs by the rounding of
+  // the forgotten renormalisations (1e-16 per scattering).
+  int n_pend = 0, pe_it = 1, pe_lam = 1;
+  float pe_r2 = 0.0f;
+  double pe_u0 = 0.0, pe_v0 = 0.0, pe_w0 = 1.0, pe_u1 = 0.0, pe_v1 = 0.0, pe_w1 = 1.0;
+  auto stokes_flush = [&]() {
+    if (!POLA || n_pend == 0) return;
+    double cw = 1.0, sw = 0.0, M12 = 0.0, M22 = 1.0, M33 = 1.0, M34 = 0.0, M44 = 1.0;
+    if (lane < n_pend) {
+      stokes_rotation(pe_u0, pe_v0, pe_w0, pe_u1, pe_v1, pe_w1, cw, sw);
+      mueller_pos(M, pe_lam, pe_it, pe_r2, -1, M12, M22, M33, M34, M44);
+    }
+    double S[4] = {F.S0, S1, S2, S3};
+    for (int q = 0; q < n_pend; ++q)
+      stokes_apply(S, __shfl(cw, q), __shfl(sw, q), __shfl(M12, q), __shfl(M22, q), __shfl(M33, q), __shfl(M34, q), __shfl(M44, q));
+    F.S0 = S[0]; S1 = S[1]; S2 = S[2]; S3 = S[3];
+    n_pend = 0;
+  };
+
   for (;;) {
     if (st == S_INTERACT) {
       // ---- the interaction's draws, from the batch the wave drew ahead ------------------------------------------
@@ -213,10 +239,16 @@ __device__ __forceinline__ void tail_packet(const Lds& T, const DevModel& M, con
       double u1, v1, w1;
       cdapres_sc(cospsi, sphi, cphi, scat ? F.u : 0.0, scat ? F.v : 0.0, scat ? F.w : 1.0, u1, v1, w1);
       if (!flag_scatt) flag_ism = false;  // absorbed and re-emitted by the dust (:1367)
-      if (POLA) {
-        double S[4] = {F.S0, S1, S2, S3};
-        interact_stokes(M, scat, lambda_in, itheta, g2, F.u, F.v, F.w, u1, v1, w1, S);
-        F.S0 = S[0]; S1 = S[1]; S2 = S[2]; S3 = S[3];
+      if (POLA) {   // (interact_stokes, lazily: see stokes_flush)
+        if (!scat) { n_pend = 0; S1 = 0.0; S2 = 0.0; S3 = 0.0; }
+        else if (M.aniso_method == 1) {
+          if (n_pend == BIN_WAVE) stokes_flush();
+          if (lane == n_pend) {
+            pe_u0 = F.u; pe_v0 = F.v; pe_w0 = F.w; pe_u1 = u1; pe_v1 = v1; pe_w1 = w1;
+            pe_it = itheta; pe_lam = lambda_in; pe_r2 = g2;
+          }
+          n_pend++;
+        }
       }
       F.u = u1; F.v = v1; F.w = w1;
       if (MRW) {  // (dust_transfer.f90:1244-1249, 1222-1239; see roles_body)
@@ -261,6 +293,7 @@ __device__ __forceinline__ void tail_packet(const Lds& T, const DevModel& M, con
       if (killed) break;  // (the star's cell, or a runaway packet: finished)
     }
     if (st == S_EXITED) {  // capteur (output.f90:294-597)
+      stokes_flush();
       if (!flag_ism) {
         if (lane == 0) {
           const double S[4] = {F.S0, S1, S2, S3};

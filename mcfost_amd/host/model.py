@@ -1156,7 +1156,8 @@ VORONOI_CACHE_VERSION = 1
 
 
 def build_voronoi_model(cfg: DiskConfig, n_sites: int, seed: int = 1, box_z_over_h: float = 6.0,
-                        cut: bool = True, cache_dir: Optional[str] = None, tessellator=None, platonic: bool = False) -> Model:
+                        cut: bool = True, cache_dir: Optional[str] = None, tessellator=None, platonic: bool = False,
+                        density: str = "smoothed") -> Model:
     """BASELINE config 5 stand-in: ``n_sites`` SPH-like sites drawn from the cfg's disk,
     tessellated in a box (``Voronoi.f90:183-640`` hands the same arrays to the loop), the
     star added as its own site, densities from the analytic disk evaluated at the sites."""
@@ -1217,7 +1218,19 @@ def build_voronoi_model(cfg: DiskConfig, n_sites: int, seed: int = 1, box_z_over
     l_sum = lv + np.bincount(owner[gas], weights=lv[neigh[gas] - 1], minlength=nb)[:nb]
     n_sum = 1.0 + np.bincount(owner[gas], minlength=nb)[:nb]
     rho = np.zeros(grid["n_cells"], f64)
-    rho[:nb] = np.exp(-l_sum / n_sum)
+    if density == "sph":
+        # ... or the density the dump itself carries: an SPH code knows rho_i = m (hfact / h_i)^3 from its own kernel sum
+        # (hfact = 1.2), the reference reads it with the particles and gives every cell ITS particle's density -- the
+        # tessellation only supplies the volumes (cut for elongated cells, so that the mass rho V of a particle at the
+        # disk's ragged surface is not that of its huge Voronoi cell; voro++_wrapper.cpp:209-227).  With h from the
+        # analytic number density of the sites this is the cfg's disk sampled at the sites, without the Poisson noise
+        # of m / V: the Voronoi run then is the ref4.1 disk of the cylindrical runs (same optical depths: ~11
+        # interactions per packet instead of the 130-210 of the smoothed m / V at 1e6 sites).
+        rho[:nb] = (1.2 / np.asarray(grid["v_h"], f64)[:nb]) ** 3
+    elif density == "smoothed":
+        rho[:nb] = np.exp(-l_sum / n_sum)
+    else:
+        raise ValueError("build_voronoi_model: density is 'smoothed' or 'sph'")
     rho[:nb] *= cfg.dust_mass * MSUN_TO_G / (float(np.sum(rho[:nb] * vol[:nb])) * AU_TO_CM ** 3)
     m = build_model(cfg, grid=grid, rho=rho)
     return m

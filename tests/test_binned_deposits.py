@@ -31,7 +31,7 @@ def _same_packets(a, b, rtol=1e-9):
     assert a["counters"] == b["counters"]
     assert np.array_equal(a["n_sent"], b["n_sent"])
     assert np.array_equal(a["sed"][4], b["sed"][4])
-    assert np.allclose(a["E_abs"], b["E_abs"], rtol=rtol, atol=1e-12 * b["E_abs"].max())
+    assert np.allclose(a["E_abs"], b["E_abs"], rtol=rtol, atol=1e-11 * b["E_abs"].max())
 
 
 @pytest.mark.parametrize("log_mb", [0, 1])
@@ -52,7 +52,7 @@ def test_binned_frozen_parity_against_the_oracle(log_mb):
     # a second launch on the same context (the log, its plan and the carry buffers are reused), accumulating
     a2 = e.run_thermal(n, seed=9, first_packet=n, frozen=True, E_prior=prior, accumulate=True)
     b2 = o.run_thermal(n, seed=9, first_packet=n, frozen=True, E_prior=prior, n_threads=8)
-    assert np.allclose(a2["E_abs"], a["E_abs"] + b2["E_abs"], rtol=1e-9, atol=1e-12 * a2["E_abs"].max())
+    assert np.allclose(a2["E_abs"], a["E_abs"] + b2["E_abs"], rtol=1e-9, atol=1e-11 * a2["E_abs"].max())
     assert a2["counters"]["packets"] == 2 * n
     e.close()
 

@@ -10,7 +10,14 @@ Tolerances (stated here, used below):
     (|x|+|y|+|z|+l)  (the device contracts a*b+c into FMA, the reference
     build does not);
   * absorbed energy per cell, frozen-temperature mode (same packets, same
-    random numbers, different summation order and FMA): rtol 1e-9;
+    random numbers, different summation order and FMA): rtol 1e-9 plus 1e-11 of
+    the largest cell -- a packet that ends a radial crossing within default-real
+    rounding of a layer's wall (cylindrical_grid.f90:1116 computes zj through
+    default real) is booked in one layer or the other by the last place of z1,
+    and the sliver it then crosses (1e-4 of a deposit) moves between the two
+    vertically adjacent cells: 1e-12 ... 4e-12 of the largest cell, about once
+    per 1e7 crossings, every counter equal (round 4 measured it with the lane
+    emulation; the old bound of 1e-12 held or not with the random sample);
   * live Bjorkman & Wood mode is not bit-reproducible by construction (the
     reference's own threads race the same way): statistical gate = relative
     RMS of Tdust over cells with T > 1.01 T_min  <= 3 * sigma_MC(N) and the
@@ -125,7 +132,7 @@ def _frozen_parity(m, n, seed, n_prior=2000, rtol=1e-9, **kw):
         else:
             assert np.array_equal(a["sed"][t], b["sed"][t]), t
     assert np.allclose(a["sed"][1:4], b["sed"][1:4], rtol=1e-5, atol=1e-5 * max(1.0, np.abs(b["sed"][0]).max()))
-    assert np.allclose(a["E_abs"], b["E_abs"], rtol=rtol, atol=1e-12 * b["E_abs"].max())
+    assert np.allclose(a["E_abs"], b["E_abs"], rtol=rtol, atol=1e-11 * b["E_abs"].max())
     Ta, Tb = e.temp_finale(a["E_abs"]), o.temp_finale(b["E_abs"])
     assert np.allclose(Ta, Tb, rtol=2e-6)
     e.close()
@@ -313,7 +320,7 @@ def test_fortran_host_through_iso_c_binding(small_model, tmp_path):
     f = dump.read_result(small_model, fout)
     b = o.run_thermal(n, seed=seed, frozen=True, E_prior=prior, n_threads=8)
     assert np.array_equal(f["n_sent"], b["n_sent"]) and np.array_equal(f["sed"][4], b["sed"][4])
-    assert np.allclose(f["E_abs"], b["E_abs"], rtol=1e-9, atol=1e-12 * b["E_abs"].max())
+    assert np.allclose(f["E_abs"], b["E_abs"], rtol=1e-9, atol=1e-11 * b["E_abs"].max())
     # live mode (the reference algorithm) still runs through the same binding
     out = subprocess.run([exe, fin, fout, str(n), str(seed)], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
@@ -385,7 +392,7 @@ def test_single_role_schedule_option(small_model):
         a = e.run_thermal(20000, seed=21, frozen=True, E_prior=prior)
         assert a["counters"] == ref["counters"], opts
         assert np.array_equal(a["n_sent"], ref["n_sent"])
-        assert np.allclose(a["E_abs"], ref["E_abs"], rtol=1e-9, atol=1e-12 * ref["E_abs"].max())
+        assert np.allclose(a["E_abs"], ref["E_abs"], rtol=1e-9, atol=1e-11 * ref["E_abs"].max())
         e.close()
 
 
@@ -513,13 +520,13 @@ def test_voronoi_launch_geometry_independence(voro_model):
         r = e.run_thermal(10000, seed=9, frozen=True, E_prior=prior, grid_blocks=gb, block_threads=bt)
         assert r["counters"] == ref["counters"]
         assert np.array_equal(r["sed"][4], ref["sed"][4])
-        assert np.allclose(r["E_abs"], ref["E_abs"], rtol=1e-10, atol=1e-12 * ref["E_abs"].max())
+        assert np.allclose(r["E_abs"], ref["E_abs"], rtol=1e-10, atol=1e-11 * ref["E_abs"].max())
     e.set_option("schedule", 2)   # the role schedule on this grid (opt-in: slower here, same packets)
     for gb, bt in ((0, 0), (3, 256)):
         r = e.run_thermal(10000, seed=9, frozen=True, E_prior=prior, grid_blocks=gb, block_threads=bt)
         assert r["counters"] == ref["counters"]
         assert np.array_equal(r["sed"][4], ref["sed"][4])
-        assert np.allclose(r["E_abs"], ref["E_abs"], rtol=1e-10, atol=1e-12 * ref["E_abs"].max())
+        assert np.allclose(r["E_abs"], ref["E_abs"], rtol=1e-10, atol=1e-11 * ref["E_abs"].max())
     e.close()
 
 
@@ -576,7 +583,7 @@ def test_voronoi_deposit_paths_agree(voro_model):
     runs.append(e.run_thermal(30000, seed=13, frozen=True, E_prior=prior))
     for r in runs:
         assert r["counters"] == ref["counters"]
-        assert np.allclose(r["E_abs"], ref["E_abs"], rtol=1e-7, atol=1e-12 * ref["E_abs"].max())
+        assert np.allclose(r["E_abs"], ref["E_abs"], rtol=1e-7, atol=1e-11 * ref["E_abs"].max())
     e.close()
 
 
@@ -1066,7 +1073,7 @@ def test_voronoi_at_scale_properties():
     r2 = e.run_thermal(nf, seed=82, frozen=True, E_prior=a["E_abs"])
     e.close()
     assert r1["counters"] == r2["counters"] and np.array_equal(r1["sed"][4], r2["sed"][4])
-    assert np.allclose(r1["E_abs"], r2["E_abs"], rtol=1e-9, atol=1e-12 * r2["E_abs"].max())
+    assert np.allclose(r1["E_abs"], r2["E_abs"], rtol=1e-9, atol=1e-11 * r2["E_abs"].max())
     # (c) the CPU oracle on the same tessellation
     no = 2_000_000
     o = _oracle(mv, no)

@@ -157,5 +157,5 @@ def test_temperature_step_on_device_built_tables():
     e.close()
     assert a["counters"] == b["counters"]
     assert np.array_equal(a["n_sent"], b["n_sent"])
-    assert np.allclose(a["E_abs"], b["E_abs"], rtol=1e-9, atol=1e-12 * b["E_abs"].max())
+    assert np.allclose(a["E_abs"], b["E_abs"], rtol=1e-9, atol=1e-11 * b["E_abs"].max())
     assert a["counters"]["scatterings"] > 1000 and a["counters"]["absorptions"] > 1000

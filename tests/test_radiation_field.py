@@ -44,7 +44,7 @@ def test_device_accumulators_against_the_oracle(grid):
     # FMA-level rounding relative to the cell size, not to itself)
     assert np.allclose(xJ, want["xJ_abs"], rtol=1e-7, atol=1e-9 * want["xJ_abs"].max())
     assert np.allclose(xJ.sum(axis=0), want["xJ_abs"].sum(axis=0), rtol=1e-9, atol=1e-12 * want["xJ_abs"].sum(axis=0).max())
-    assert np.allclose(got["E_abs"], want["E_abs"], rtol=1e-9, atol=1e-12 * want["E_abs"].max())
+    assert np.allclose(got["E_abs"], want["E_abs"], rtol=1e-9, atol=1e-11 * want["E_abs"].max())
     # accumulate: a second launch adds to them
     e.run_thermal(n, seed=5, frozen=True, E_prior=prior, accumulate=True)
     xN2, _ = e.fetch_radiation_field(xJ=False)

@@ -101,7 +101,7 @@ def test_device_method1_equals_the_oracle_frozen(kw):
     a = e.run_thermal(n, seed=6, frozen=True, E_prior=prior)
     assert a["counters"] == b["counters"]
     assert np.array_equal(a["n_sent"], b["n_sent"]) and np.array_equal(a["sed"][4], b["sed"][4])
-    assert np.allclose(a["E_abs"], b["E_abs"], rtol=1e-9, atol=1e-12 * b["E_abs"].max())
+    assert np.allclose(a["E_abs"], b["E_abs"], rtol=1e-9, atol=1e-11 * b["E_abs"].max())
     assert np.allclose(a["sed"][0], b["sed"][0], rtol=1e-9, atol=1e-12)
     if m.cfg.lsepar_pola and m.cfg.aniso_method == 1:
         assert np.allclose(a["sed"][1:4], b["sed"][1:4], rtol=1e-5, atol=1e-6 * max(1.0, np.abs(b["sed"][0]).max()))

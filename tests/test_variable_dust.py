@@ -64,7 +64,7 @@ def test_emulated_kernel_against_the_oracle(emu, kw):   # noqa: F811
             os.environ.pop("MCGPU_EMU_LDS", None)
         assert got["counters"] == list(want["counters"].values())
         assert np.array_equal(got["n_sent"], want["n_sent"]) and np.array_equal(got["sed"][4], want["sed"][4])
-        assert np.allclose(got["E_abs"], want["E_abs"], rtol=1e-7, atol=1e-12 * want["E_abs"].max())   # (FMA-level: grazing segments)
+        assert np.allclose(got["E_abs"], want["E_abs"], rtol=1e-7, atol=1e-11 * want["E_abs"].max())   # (FMA-level: grazing segments)
 
 
 def voronoi_settled(identical=False, **kw):
@@ -97,7 +97,7 @@ def test_emulated_voronoi_kernel_against_the_oracle(emu, kw):   # noqa: F811
     got = emu_run(emu, orc, n, 7, prior=prior)
     assert got["counters"] == list(want["counters"].values())
     assert np.array_equal(got["n_sent"], want["n_sent"]) and np.array_equal(got["sed"][4], want["sed"][4])
-    assert np.allclose(got["E_abs"], want["E_abs"], rtol=1e-7, atol=1e-12 * want["E_abs"].max())
+    assert np.allclose(got["E_abs"], want["E_abs"], rtol=1e-7, atol=1e-11 * want["E_abs"].max())
 
 
 @pytest.mark.gpu
@@ -113,7 +113,7 @@ def test_device_voronoi_against_the_oracle_frozen():
     got = e.run_thermal(n, seed=7, frozen=True, E_prior=prior)
     assert got["counters"] == want["counters"]
     assert np.array_equal(got["n_sent"], want["n_sent"]) and np.array_equal(got["sed"][4], want["sed"][4])
-    assert np.allclose(got["E_abs"], want["E_abs"], rtol=1e-7, atol=1e-12 * want["E_abs"].max())
+    assert np.allclose(got["E_abs"], want["E_abs"], rtol=1e-7, atol=1e-11 * want["E_abs"].max())
     assert np.allclose(e.temp_finale(got["E_abs"]), orc.temp_finale(want["E_abs"]), rtol=2e-6)
     e.close()
     # identical classes: the packets of the default Voronoi kernel
@@ -125,7 +125,7 @@ def test_device_voronoi_against_the_oracle_frozen():
     b = e1.run_thermal(n, seed=7, frozen=True, E_prior=prior)
     e1.close()
     assert a["counters"] == b["counters"]
-    assert np.allclose(a["E_abs"], b["E_abs"], rtol=1e-9, atol=1e-12 * a["E_abs"].max())
+    assert np.allclose(a["E_abs"], b["E_abs"], rtol=1e-9, atol=1e-11 * a["E_abs"].max())
 
 
 @pytest.mark.gpu
@@ -143,7 +143,7 @@ def test_device_against_the_oracle_frozen(kw):
         got = e.run_thermal(n, seed=7, frozen=True, E_prior=prior)
         assert got["counters"] == want["counters"], schedule
         assert np.array_equal(got["n_sent"], want["n_sent"]) and np.array_equal(got["sed"][4], want["sed"][4])
-        assert np.allclose(got["E_abs"], want["E_abs"], rtol=1e-7, atol=1e-12 * want["E_abs"].max())   # (FMA-level: grazing segments)
+        assert np.allclose(got["E_abs"], want["E_abs"], rtol=1e-7, atol=1e-11 * want["E_abs"].max())   # (FMA-level: grazing segments)
         assert np.allclose(e.temp_finale(got["E_abs"]), orc.temp_finale(want["E_abs"]), rtol=2e-6)
         e.close()
 
@@ -162,7 +162,7 @@ def test_device_identical_classes_and_live_statistics():
     b = e1.run_thermal(n, seed=5, frozen=True, E_prior=prior)
     e1.close()
     assert a["counters"] == b["counters"]                       # the gather variant runs the same packets
-    assert np.allclose(a["E_abs"], b["E_abs"], rtol=1e-9, atol=1e-12 * a["E_abs"].max())
+    assert np.allclose(a["E_abs"], b["E_abs"], rtol=1e-9, atol=1e-11 * a["E_abs"].max())
     # live mode with real classes: temperature against the oracle's own live run
     m = settled()
     e2 = Engine(m, n)
