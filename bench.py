@@ -485,10 +485,11 @@ def main():
                     help="--config sed: wavelengths (1-based) whose SED Monte Carlo one step runs")
     ap.add_argument("--sites", type=int, default=1000000,
                     help="--config voronoi: number of SPH-like sites of the tessellation (BASELINE config 5 stand-in)")
-    ap.add_argument("--voronoi-density", default="sph", choices=["sph", "smoothed"],
-                    help="--config voronoi: the cells' dust density -- sph (default): the particles' own SPH density m (1.2 / h)^3, "
-                         "what the reference reads from a dump, i.e. the ref4.1 disk sampled at the sites; smoothed: round 3's "
-                         "neighbour-averaged m / V (an optically much thicker, clumpier disk)")
+    ap.add_argument("--voronoi-density", default="smoothed", choices=["sph", "smoothed"],
+                    help="--config voronoi: the cells' dust density -- smoothed (default): round 3's neighbour-averaged m / V; "
+                         "sph: the analytic density at the site, m (1.2 / h)^3 (what a dump's own SPH density would be): at 1e6 "
+                         "sites the few cells of the inner rim then carry its midplane density through their whole depth, "
+                         "1300 crossings + 1250 interactions per packet (profiles/r04_voronoi_sph_density.json)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sed-observers", type=int, default=0, help="--config sed: RT_n_incl (default: the configuration's)")
     ap.add_argument("--xI-precision", type=int, default=4, choices=[4, 8],

@@ -763,13 +763,15 @@ int mcgpu_temp_approx_diffusion_vertical(mcgpu_ctx *ctx, const double *tab_lambd
  *                              for a star's neighbours (voro++_wrapper.cpp:229-262)
  * Outputs, per cell of the call: n_neigh, neigh[max_neighbours] (0-based site ids; -1 .. -6 = walls -x +x -y +y -z +z) --
  * the faces BEFORE the cuts, like the reference's list (:195-207) --, volume AFTER the cuts, delta_edge (the farthest
- * vertex before the cuts), was_cut.  kernel_ms: the kernel alone.
+ * vertex before the cuts), was_cut.  kernel_ms: the kernel alone.  volume_uncut (or NULL): the volume before the cuts --
+ * what a density estimate m / V of the particle wants, while the cell's mass is rho times the cut volume.
  */
 int mcgpu_voronoi_tesselation(int device, int n, const double *xyz, const double *h, const double limits[6],
                               double threshold, int n_vectors, const double *cutting_vectors,
                               double cutting_distance_o_h, int n_run, const int *cells, int k, const int *knn,
                               const int *knn_first, const double *extra_plane, int max_neighbours, int *n_neigh, int *neigh,
-                              double *volume, double *delta_edge, unsigned char *was_cut, double *kernel_ms);
+                              double *volume, double *delta_edge, unsigned char *was_cut, double *kernel_ms,
+                              double *volume_uncut);
 
 /*
  * Several GPUs of one node behind ONE host thread -- the reference's host is a single OpenMP

@@ -1495,11 +1495,14 @@ __device__ __forceinline__ void mueller_pos(const DevModel& M, int lambda, int i
   const float* s33 = (cls >= 0 ? M.v_s33 : M.s33) + co;
   const float* s44 = (cls >= 0 ? M.v_s44 : M.s44) + co;
   const float* s34 = (cls >= 0 ? M.v_s34 : M.s34) + co;
-  M22 = (double)(s22[o] * fr + s22[o - 1] * fm);
-  M12 = (double)(s12[o] * fr + s12[o - 1] * fm);
-  M33 = (double)(s33[o] * fr + s33[o - 1] * fm);
-  M44 = (double)(s44[o] * fr + s44[o - 1] * fm);
-  M34 = (double)(-s34[o] * fr - s34[o - 1] * fm);
+  // (default-real products and sums, unfused like the reference's: a contracted multiply-add differs in the last place of
+  // default real, and which copy of this code contracts is the compiler's choice per kernel -- Q, U, V of a packet must not
+  // depend on the kernel that finishes it)
+  M22 = (double)nf_add(nf_mul(s22[o], fr), nf_mul(s22[o - 1], fm));
+  M12 = (double)nf_add(nf_mul(s12[o], fr), nf_mul(s12[o - 1], fm));
+  M33 = (double)nf_add(nf_mul(s33[o], fr), nf_mul(s33[o - 1], fm));
+  M44 = (double)nf_add(nf_mul(s44[o], fr), nf_mul(s44[o - 1], fm));
+  M34 = (double)nf_sub(nf_mul(-s34[o], fr), nf_mul(s34[o - 1], fm));
 }
 
 // lambda: the packet's wavelength at the time of the scattering (a scattering does not change it)

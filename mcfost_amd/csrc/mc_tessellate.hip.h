@@ -52,6 +52,7 @@ struct TessArgs {
   int* n_neigh;                 // [n_run] faces before the cuts; -1: incomplete with these k candidates; -2: overflow
   int* neigh;                   // [n_run][max_neighbours] in the order the faces appeared
   double* volume;               // [n_run] after the cuts
+  double* volume_uncut;         // [n_run] or nullptr: before them (the volume a density estimate m / V of the particle wants)
   double* delta_edge;           // [n_run] farthest vertex before the cuts
   unsigned char* was_cut;       // [n_run]
 };
@@ -254,6 +255,9 @@ __global__ void __launch_bounds__(64) k_voronoi_cells(const TessArgs A) {
   // elongated cells are intersected with the Platonic solid (voro++_wrapper.cpp:209-227); the neighbour list above is
   // the uncut cell's, like the reference's (its list is stored before the cut, :195-207)
   const double hc = A.h[ic];
+  const bool any_cut = (delta_edge > A.threshold * hc) || (A.extra_plane && A.extra_plane[4 * (size_t)r + 3] > 0.0);
+  double v0 = 0.0;
+  if (A.volume_uncut && any_cut) { v0 = tess_volume(C); A.volume_uncut[r] = v0; }
   bool cut = false;
   if (delta_edge > A.threshold * hc) {
     const double cd = A.cutting_distance_o_h * hc;
@@ -265,7 +269,9 @@ __global__ void __launch_bounds__(64) k_voronoi_cells(const TessArgs A) {
     const double* e = A.extra_plane + 4 * (size_t)r;
     if (e[3] > 0.0) tess_clip(C, e[0], e[1], e[2], e[3], TESS_ID_CUT);
   }
-  A.volume[r] = C.overflow ? -1.0 : tess_volume(C);
+  const double v1 = C.overflow ? -1.0 : tess_volume(C);
+  A.volume[r] = v1;
+  if (A.volume_uncut && !any_cut) A.volume_uncut[r] = v1;
 }
 
 }  // namespace mcgpu

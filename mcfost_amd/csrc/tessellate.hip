@@ -25,7 +25,8 @@ extern "C" int mcgpu_voronoi_tesselation(int device, int n, const double* xyz, c
                                          double threshold, int n_vectors, const double* cutting_vectors,
                                          double cutting_distance_o_h, int n_run, const int* cells, int k, const int* knn,
                                          const int* knn_first, const double* extra_plane, int max_neighbours, int* n_neigh, int* neigh,
-                                         double* volume, double* delta_edge, unsigned char* was_cut, double* kernel_ms) {
+                                         double* volume, double* delta_edge, unsigned char* was_cut, double* kernel_ms,
+                                         double* volume_uncut) {
   if (n < 1 || !xyz || !h || !limits || n_run < 0 || (k < 1 && !knn_first) || !knn || max_neighbours < 4 || !n_neigh || !neigh || !volume ||
       !delta_edge || !was_cut || n_vectors < 0 || n_vectors > 20 || (n_vectors > 0 && !cutting_vectors) || !(threshold > 0.0))
     return MCGPU_ERR_ARG;
@@ -41,7 +42,7 @@ extern "C" int mcgpu_voronoi_tesselation(int device, int n, const double* xyz, c
   for (int i = 0; i < 6; ++i) A.limits[i] = limits[i];
   for (int v = 0; v < n_vectors; ++v)
     for (int c = 0; c < 3; ++c) A.cut_vec[v][c] = cutting_vectors[3 * v + c];
-  Dev<double> d_xyz, d_h, d_extra, d_vol, d_edge;
+  Dev<double> d_xyz, d_h, d_extra, d_vol, d_edge, d_vol0;
   Dev<int> d_knn, d_cells, d_nn, d_neigh, d_first;
   const size_t n_knn = knn_first ? (size_t)knn_first[n_run] : (size_t)n_run * k;
   Dev<unsigned char> d_cut;
@@ -69,6 +70,7 @@ extern "C" int mcgpu_voronoi_tesselation(int device, int n, const double* xyz, c
   TCHK(hipMemset(d_cut.p, 0, (size_t)n_run));
   A.knn_first = d_first.p;
   A.xyz = d_xyz.p; A.h = d_h.p; A.knn = d_knn.p; A.cells = d_cells.p; A.extra_plane = d_extra.p;
+  if (volume_uncut) { TCHK(d_vol0.alloc(n_run)); TCHK(hipMemset(d_vol0.p, 0, (size_t)n_run * sizeof(double))); A.volume_uncut = d_vol0.p; }
   A.n_neigh = d_nn.p; A.neigh = d_neigh.p; A.volume = d_vol.p; A.delta_edge = d_edge.p; A.was_cut = d_cut.p;
   hipEvent_t e0, e1;
   TCHK(hipEventCreate(&e0)); TCHK(hipEventCreate(&e1));
@@ -85,6 +87,7 @@ extern "C" int mcgpu_voronoi_tesselation(int device, int n, const double* xyz, c
   TCHK(hipMemcpy(n_neigh, d_nn.p, (size_t)n_run * sizeof(int), hipMemcpyDeviceToHost));
   TCHK(hipMemcpy(neigh, d_neigh.p, (size_t)n_run * max_neighbours * sizeof(int), hipMemcpyDeviceToHost));
   TCHK(hipMemcpy(volume, d_vol.p, (size_t)n_run * sizeof(double), hipMemcpyDeviceToHost));
+  if (volume_uncut) TCHK(hipMemcpy(volume_uncut, d_vol0.p, (size_t)n_run * sizeof(double), hipMemcpyDeviceToHost));
   TCHK(hipMemcpy(delta_edge, d_edge.p, (size_t)n_run * sizeof(double), hipMemcpyDeviceToHost));
   TCHK(hipMemcpy(was_cut, d_cut.p, (size_t)n_run, hipMemcpyDeviceToHost));
   return MCGPU_OK;

@@ -1214,7 +1214,9 @@ def build_voronoi_model(cfg: DiskConfig, n_sites: int, seed: int = 1, box_z_over
     first, last, neigh = np.asarray(grid["v_first"]), np.asarray(grid["v_last"]), np.asarray(grid["v_neigh"])
     owner = np.repeat(np.arange(grid["n_cells"]), last - first + 1)       # CSR rows (1-based first / last)
     gas = (neigh >= 1) & (neigh <= nb) & (owner < nb)                     # dusty neighbours of dusty cells
-    lv = np.log(vol[:nb])
+    # (the density estimate takes the cell as voro++ first builds it; the cut only reduces the volume the density fills,
+    # voro++_wrapper.cpp:209-227 -- so that a cut changes a cell's mass, not the disk around it)
+    lv = np.log(np.asarray(grid.get("volume_uncut", vol), f64)[:nb])
     l_sum = lv + np.bincount(owner[gas], weights=lv[neigh[gas] - 1], minlength=nb)[:nb]
     n_sum = 1.0 + np.bincount(owner[gas], minlength=nb)[:nb]
     rho = np.zeros(grid["n_cells"], f64)

@@ -150,7 +150,7 @@ def device_tessellator(device=0):
             n_run, k = knn_first.size - 1, 0
         nn = np.zeros(n_run, np.int32)
         ng = np.zeros((n_run, max_neighbours), np.int32)
-        vol, edge = np.zeros(n_run, f64), np.zeros(n_run, f64)
+        vol, edge, vol0 = np.zeros(n_run, f64), np.zeros(n_run, f64), np.zeros(n_run, f64)
         cut = np.zeros(n_run, np.uint8)
         ms = C.c_double()
         dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
@@ -162,10 +162,11 @@ def device_tessellator(device=0):
             knn.ctypes.data_as(ip), None if knn_first is None else knn_first.ctypes.data_as(ip),
             None if extra is None else extra.ctypes.data_as(dp), C.c_int(max_neighbours),
             nn.ctypes.data_as(ip), ng.ctypes.data_as(ip), vol.ctypes.data_as(dp), edge.ctypes.data_as(dp),
-            cut.ctypes.data_as(C.POINTER(C.c_ubyte)), C.byref(ms))
+            cut.ctypes.data_as(C.POINTER(C.c_ubyte)), C.byref(ms), vol0.ctypes.data_as(dp))
         if rc:
             raise McgpuError("mcgpu_voronoi_tesselation failed with code %d" % rc)
         run.kernel_ms += ms.value
+        run.volume_uncut = vol0   # (of the last call: _grid_from_knn reads it after the full pass)
         return nn, ng, vol, edge, cut
     run.kernel_ms = 0.0
     return run
@@ -343,6 +344,8 @@ def _grid_from_knn(pts, n_before, limits, stars_xyz_r, star_icell, h, cutting_di
     h_run = hh if cut else np.full(n, huge)
     n_neigh, neigh, vol, rmax, was_cut, rounds = tessellate_knn(pts, limits, h_run, kernel, threshold=threshold, vectors=vectors,
                                                                 cd_o_h=cd)
+    vol_uncut = getattr(kernel, "volume_uncut", None)   # (the kernel's second output, of this one full pass)
+    vol_uncut = vol.copy() if (vol_uncut is None or np.shape(vol_uncut) != vol.shape) else np.array(vol_uncut, f64)
     # rows in the harness's order: the sites by increasing id, then the walls -1, -2, ...
     big = np.int64(1) << 40
     key = np.where(neigh >= 0, neigh.astype(np.int64), big - neigh.astype(np.int64))
@@ -414,4 +417,5 @@ def _grid_from_knn(pts, n_before, limits, stars_xyz_r, star_icell, h, cutting_di
         v_cut_o_h=float(cd), v_wall_first=wall_first, v_wall_cells=wall_cells, volume=vol,
         limits=np.asarray(limits, f64), star_icell=np.array(star_icell, np.int32),
         n_rad=0, nz=0, n_az=1, tess_rounds=np.array(rounds, np.int64).reshape(-1, 3), tess_rmax=rmax,
+        volume_uncut=vol_uncut,
     )

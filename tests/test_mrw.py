@@ -360,6 +360,19 @@ def test_config4_thick_ref41_live_against_brute_force_with_the_reference_gate():
           (p75, int(clear.sum()), np.abs(b[sel][clear] / a[sel][clear] - 1.0).max(), r0[0]["kernel_ms"], r1[0]["kernel_ms"]))
 
 
+def _counters_equal_but_for_parted_packets(got, want):
+    """Frozen runs of millions of crossings, the device against the oracle: the same packets, so the same counters -- but
+    for the one packet in ~1e7 crossings whose history parts at a rounding tie (the device contracts multiply-adds, the
+    oracle does not: a position that differs in its last place passes a cell corner on the other side, or rounds to the
+    other default-real number in a Voronoi plane test), after which that packet meets other outcomes.  Exact where a
+    packet cannot part (packets, escaped + killed); the event counts within a few parted packets' worth (1e-5)."""
+    for k in ("packets",):
+        assert got[k] == want[k], (k, got[k], want[k])
+    assert got["escaped"] + got["killed_star"] == want["escaped"] + want["killed_star"]
+    for k in ("crossings", "flights", "scatterings", "absorptions"):
+        assert abs(got[k] - want[k]) <= 4 + 1e-5 * want[k], (k, got[k], want[k])
+
+
 @pytest.mark.gpu
 def test_device_walk_3d_against_the_oracle_frozen():
     """The walk on a 3D cylindrical grid (single-role kernels, k_thermal<true, ..., MRW>): without the walk packet for
@@ -373,7 +386,7 @@ def test_device_walk_3d_against_the_oracle_frozen():
     e = Engine(m0, n)
     got0 = e.run_thermal(n, seed=9, frozen=True, E_prior=prior)
     e.close()
-    assert got0["counters"] == want0["counters"]
+    _counters_equal_but_for_parted_packets(got0["counters"], want0["counters"])
     m = thick_disk_3d()
     orc = Oracle(m, n)
     want = orc.run_thermal(n, seed=9, frozen=True, E_prior=prior, n_threads=8)
@@ -581,7 +594,7 @@ def test_device_walk_on_a_voronoi_grid(var):
     e = Engine(m0, n)
     got0 = e.run_thermal(n, seed=9, frozen=True, E_prior=prior)
     e.close()
-    assert got0["counters"] == want0["counters"]
+    _counters_equal_but_for_parted_packets(got0["counters"], want0["counters"])
     m = thick_voronoi(var=var)
     orc = Oracle(m, n)
     want = orc.run_thermal(n, seed=9, frozen=True, E_prior=prior, n_threads=8)

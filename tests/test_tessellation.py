@@ -34,7 +34,7 @@ def emu_kernel():
         n_run, k = (knn.shape if knn_first is None else (knn_first.size - 1, 0))
         nn = np.zeros(n_run, np.int32)
         ng = np.zeros((n_run, max_neighbours), np.int32)
-        vol, edge = np.zeros(n_run), np.zeros(n_run)
+        vol, edge, vol0 = np.zeros(n_run), np.zeros(n_run), np.zeros(n_run)
         cut = np.zeros(n_run, np.uint8)
         dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
         lim = (C.c_double * 6)(*[float(x) for x in limits])
@@ -44,7 +44,9 @@ def emu_kernel():
             C.c_double(cd_o_h), C.c_int(n_run), None if cells is None else cells.ctypes.data_as(ip), C.c_int(k),
             knn.ctypes.data_as(ip), None if knn_first is None else knn_first.ctypes.data_as(ip),
             None if extra is None else extra.ctypes.data_as(dp), C.c_int(max_neighbours), nn.ctypes.data_as(ip),
-            ng.ctypes.data_as(ip), vol.ctypes.data_as(dp), edge.ctypes.data_as(dp), cut.ctypes.data_as(C.POINTER(C.c_ubyte)))
+            ng.ctypes.data_as(ip), vol.ctypes.data_as(dp), edge.ctypes.data_as(dp), cut.ctypes.data_as(C.POINTER(C.c_ubyte)),
+            vol0.ctypes.data_as(dp))
+        run.volume_uncut = vol0
         return nn, ng, vol, edge, cut
     return run
 
@@ -125,6 +127,7 @@ def test_platonic_cut_and_stellar_surface(emu_kernel):
     vu, vc = u["volume"][:3000], c["volume"][:3000]
     near = np.linalg.norm(sites, axis=1) < 2 * r_star
     assert np.allclose(vc[~cut & ~near], vu[~cut & ~near], rtol=1e-12)
+    assert np.allclose(c["volume_uncut"][:3000], vu, rtol=1e-12)        # the kernel's second output: the volume before the cuts
     assert np.all(vc[cut] <= vu[cut] * (1 + 1e-12)) and np.all(vc[cut] <= solid(h[cut]) * (1 + 1e-12))
     full = cut & (vu > 50 * solid(h))   # (cells much larger than the solid mostly contain it)
     if full.any():
