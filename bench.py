@@ -103,7 +103,7 @@ def cpu_baseline(model, n_total, target_s=15.0):
     return base, orc.temp_finale(res["E_abs"]), n
 
 
-def tdust_parity(T_gpu, n_gpu, T_cpu, n_cpu, T_min, noise_pair=None):
+def tdust_parity(T_gpu, n_gpu, T_cpu, n_cpu, T_min, noise_pair=None, bins=None):
     """Temperature of the GPU step against the CPU port's (independent noise): relative RMS over the cells with
     T > 1.01 T_min, the reference's own gate p75(|dT|/T) (test_suite/test_mcfost.py:46-57,88: < 5 %), and the
     tolerance 3 sigma_MC.  2D grids: sigma_MC(N) = 1.7 % sqrt(1.28e5 / N) per run (measured on
@@ -135,6 +135,20 @@ def tdust_parity(T_gpu, n_gpu, T_cpu, n_cpu, T_min, noise_pair=None):
             out["resolved_cells"] = int(quiet.sum())
             out["p75_resolved_cells"] = float(np.percentile(np.abs(relq), 75))
             out["reference_gate_p75_below_5pct_resolved_cells"] = bool(out["p75_resolved_cells"] < 0.05)
+    if bins is not None:
+        # ... and the gate on the temperature MAP: the cells averaged over what the axisymmetric disk cannot tell apart
+        # (3D: the azimuths of a ring; Voronoi: cells of one (log r, |z| / r) bin), where the CPU sample's per-cell noise
+        # averages out and a difference of the two codes would not
+        nb = int(bins.max()) + 1
+        cnt = np.bincount(bins[sel], minlength=nb)
+        mg = np.bincount(bins[sel], weights=T_gpu[sel], minlength=nb)
+        mc = np.bincount(bins[sel], weights=T_cpu[sel], minlength=nb)
+        okb = cnt >= 8
+        relb = np.abs(mg[okb] / mc[okb] - 1.0)
+        if relb.size:
+            out["map_bins"] = int(okb.sum())
+            out["p75_map"] = float(np.percentile(relb, 75))
+            out["reference_gate_p75_below_5pct_map"] = bool(out["p75_map"] < 0.05)
     return out
 
 
@@ -237,6 +251,9 @@ def thermal_block(par, args, config, steps, warmup, with_cpu, n_local):
         me = None
         eng = Engine(model, n_total, device=par.local_rank)
     first = par.rank * n_local
+    if args.tail >= 0:
+        for x in (me.engines if me is not None else [eng]):
+            x.set_option("tail", args.tail)
     if args.frozen:
         eng.set_E_prior(eng.run_thermal(min(n_local, 2_000_000), seed=5)["E_abs"] * (n_local / min(n_local, 2_000_000)))
     last = {}
@@ -342,7 +359,20 @@ def thermal_block(par, args, config, steps, warmup, with_cpu, n_local):
                 if (cfg.l3D or config in ("voronoi", "ref41_mrw")) and me is None:
                     pair = [eng.temp_finale(eng.run_thermal(n_cpu, seed=s)["E_abs"]) for s in (7001, 7002)]
                 T_gpu = eng.temp_finale(out["E_abs"])
-                block["tdust_vs_cpu"] = tdust_parity(T_gpu, n_total, T_cpu, n_cpu, cfg.T_min, pair)
+                bins = None
+                if config == "voronoi":
+                    import numpy as np
+                    xyz = np.asarray(model.grid["v_xyz_dp"], float).reshape(-1, 3)
+                    rc = np.maximum(np.hypot(xyz[:, 0], xyz[:, 1]), 1e-6)
+                    ir = np.clip((np.log(rc / cfg.rin) / np.log(cfg.rout / cfg.rin) * 60).astype(int), 0, 59)
+                    iz = np.clip((np.abs(xyz[:, 2]) / rc / 0.5 * 30).astype(int), 0, 29)
+                    bins = ir * 30 + iz
+                elif cfg.l3D:
+                    import numpy as np
+                    per_az = model.n_cells // cfg.n_az       # (cells are ordered azimuth outermost: mcfost_amd/host/model.py)
+                    bins = np.arange(model.n_cells) % per_az
+                    bins = (bins % cfg.n_rad) + cfg.n_rad * (np.abs((bins // cfg.n_rad) - cfg.nz + 0.5).astype(int))   # (both hemispheres)
+                block["tdust_vs_cpu"] = tdust_parity(T_gpu, n_total, T_cpu, n_cpu, cfg.T_min, pair, bins)
                 if config == "ref41_mrw" and me is None:
                     # the walk against the brute-force loop on the GPU at the same packet count (the walk is "parity
                     # unpinned": the reference's MRW is a stub): the reference's p75 gate, the
@@ -505,6 +535,8 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="--config pascucci: the headline block alone")
     ap.add_argument("--no-pascucci", action="store_true", help="(kept for older command lines: same as --no-extra)")
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
+    ap.add_argument("--tail", type=int, default=-1, help="tuning aid: option \"tail\" (packets left per workgroup at the hand-over to "
+                    "k_tail; -1 = the library's choice)")
     ap.add_argument("--grid-blocks", type=int, default=0)
     ap.add_argument("--block-threads", type=int, default=0)
     ap.add_argument("--no-pola", action="store_true", help="tuning aid: do not track Stokes Q,U,V")

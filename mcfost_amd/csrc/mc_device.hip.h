@@ -1172,11 +1172,30 @@ __device__ inline int intersect_stars(const DevModel& M, double x, double y, dou
   return i_star;
 }
 
+// The walk's table searches when a whole wave runs ONE packet (the tail kernel, mc_tail.hip.h: every lane holds the same
+// state): wl = the lane, and a search is one probe per lane and a ballot instead of a chain of dependent loads -- the
+// same "first entry that ..." the bisections return for the monotone tables.  wl < 0: one packet per lane, bisections.
+#ifdef MCGPU_LANE_EMULATION
+constexpr int WAVE_LANES = 1;    // (tests/emu: a wave of one lane)
+#else
+constexpr int WAVE_LANES = 64;
+#endif
+template <typename Pred>
+__device__ inline int wave_first(int lo, int hi, int wl, Pred pred) {   // smallest k in [lo, hi) with pred(k), else hi
+  for (int base = lo; base < hi; base += WAVE_LANES) {
+    const int k = base + wl;
+    const bool hit = (k < hi) && pred(k < hi ? k : lo);
+    const unsigned long long m = __ballot(hit);
+    if (m) return base + (__ffsll((long long)m) - 1);
+  }
+  return hi;
+}
+
 // Temp_LTE (thermal_emission.f90:649-706) -> (Ti, frac); E_scaled already
 // includes the replica factor.  First Ti >= 2 with lq(Ti) >= log Qheat,
 // equal to the reference's cached linear scan because Qheat only grows.
 __device__ inline void temp_lte(const double* lq, int n_T, double E_scaled, double L_packet_th,
-                                double volume, int& Ti, double& frac) {
+                                double volume, int& Ti, double& frac, int wl = -1) {
   double Qheat = E_scaled * L_packet_th / volume;
   frac = 0.0;
   Ti = 2;
@@ -1184,6 +1203,7 @@ __device__ inline void temp_lte(const double* lq, int n_T, double E_scaled, doub
   double log_Qheat = log_pos(Qheat);   // (Qheat >= tiny_dp: positive and normal)
   if (log_Qheat < lq[0]) return;
   int lo = 2, hi = n_T;  // 1-based
+  if (wl >= 0) lo = hi = wave_first(1, n_T - 1, wl, [&](int k) { return !(lq[k] < log_Qheat); }) + 1;   // (see wave_first)
   while (lo < hi) {
     int mid = (lo + hi) >> 1;
     if (lq[mid - 1] < log_Qheat) lo = mid + 1; else hi = mid;
@@ -1593,7 +1613,7 @@ __device__ inline double distance_to_closest_wall_cyl(const Lds& T, const DevMod
 
 // y with zeta(y) = xi (MRW.f90:58-70 read as the inverse it means)
 constexpr int MRW_GUIDE = 1024;
-__device__ inline double mrw_sample_y(const DevModel& M, float xi) {
+__device__ inline double mrw_sample_y(const DevModel& M, float xi, int wl = -1) {
   const double* zt = M.mrw_zeta;
   const double x = xi > 0.0f ? (double)xi : 2.9802322387695312e-08;
   // zeta[lo] <= x < zeta[hi], hi - lo = 1: unique in a non-decreasing table, so the guide (the answers at the bucket
@@ -1604,6 +1624,10 @@ __device__ inline double mrw_sample_y(const DevModel& M, float xi) {
     lo = M.mrw_guide[b];
     const int h2 = M.mrw_guide[b + 1] + 1;
     hi = h2 < hi ? h2 : hi;
+  }
+  if (wl >= 0) {   // the first entry above x in (lo, hi] (zt[hi] > x): hi; lo is the one before
+    hi = wave_first(lo + 1, hi, wl, [&](int k) { return !(zt[k] <= x); });
+    lo = hi - 1;
   }
   while (hi - lo > 1) {
     const int mid = (lo + hi) / 2;
@@ -1622,11 +1646,11 @@ template <typename DistFn, typename EnergyFn, typename DepositFn>
 __device__ inline bool mrw_walk_with(const Lds& T, const DevModel& M, uint32_t k0, uint32_t k1, uint32_t p_lo, uint32_t p_hi,
                                      uint32_t event, int ic, double kf, double S0, double& x, double& y, double& z,
                                      double& u, double& v, double& w, int& lambda, DistFn closest_wall, EnergyFn cell_energy,
-                                     DepositFn add_energy, unsigned int& c_walks, unsigned int& c_steps) {
+                                     DepositFn add_energy, unsigned int& c_walks, unsigned int& c_steps, int wl = -1) {
   double d = closest_wall(x, y, z);
   int Ti;
   double frac;
-  temp_lte(T.lq, M.n_T, cell_energy(), M.L_packet_th, M.volume[ic], Ti, frac);
+  temp_lte(T.lq, M.n_T, cell_energy(), M.L_packet_th, M.volume[ic], Ti, frac, wl);
   // (lvariable_dust: the mean opacities of the cell's class, [n_classes][n_T]; T then holds the class's lq / cdf)
   const size_t co = M.n_classes ? (size_t)M.cell_class[ic] * M.n_T : 0;
   const double *t_chi = M.mrw_chi + co, *t_kdep = M.mrw_kdep + co, *t_ext = M.mrw_ext + co;
@@ -1643,7 +1667,7 @@ __device__ inline bool mrw_walk_with(const Lds& T, const DevModel& M, uint32_t k
     x += su * d;
     y += sv * d;
     z += sw * d;
-    const double yv = mrw_sample_y(M, Rng::real(o[2]));
+    const double yv = mrw_sample_y(M, Rng::real(o[2]), wl);
     const double de = d + ext;
     const double ct = -log_pos(yv) * cst_ct * chi * (de * de);
     add_energy(kdep * ct * S0);
@@ -1652,7 +1676,7 @@ __device__ inline bool mrw_walk_with(const Lds& T, const DevModel& M, uint32_t k
   } while (d * chi > (double)M.mrw_gamma);
   philox4x32_10(blk, event, p_lo, p_hi, k0, k1, o);
   // the cell's temperature now, the walk's deposits included (im_reemission_LTE)
-  temp_lte(T.lq, M.n_T, cell_energy(), M.L_packet_th, M.volume[ic], Ti, frac);
+  temp_lte(T.lq, M.n_T, cell_energy(), M.L_packet_th, M.volume[ic], Ti, frac, wl);
   if (M.mrw_exit_cdf) {
     // the packet crosses the sphere in the middle of a flight: it carries the spectrum of the packets IN FLIGHT in the
     // thick cell (weights dB/dT), not that of a packet which has just been emitted (kappa_abs dB/dT) -- see
@@ -1661,6 +1685,10 @@ __device__ inline bool mrw_walk_with(const Lds& T, const DevModel& M, uint32_t k
     const double* c2 = c1 + M.n_lambda;
     const double f1 = 1.0 - frac, r = (double)Rng::real(o[0]);
     int l1 = 0, l2 = M.n_lambda, l = (l1 + l2) / 2;
+    if (wl >= 0) {   // the first l in [1, n_lambda) whose interpolated cumulative spectrum reaches the draw, else n_lambda
+      l2 = wave_first(1, M.n_lambda, wl, [&](int k) { return !(r > f1 * c1[k - 1] + frac * c2[k - 1]); });
+      l1 = l2 - 1; l = l1;
+    }
     while ((l2 - l1) > 1) {
       const double proba = f1 * c1[l - 1] + frac * c2[l - 1];
       if (r > proba) l1 = l; else l2 = l;
@@ -1677,10 +1705,10 @@ template <typename EnergyFn, typename DepositFn>
 __device__ inline bool mrw_walk(const Lds& T, const DevModel& M, uint32_t k0, uint32_t k1, uint32_t p_lo, uint32_t p_hi,
                                 uint32_t event, int ri, int zj, int ic, double S0, double& x, double& y, double& z,
                                 double& u, double& v, double& w, int& lambda, EnergyFn cell_energy,
-                                DepositFn add_energy, unsigned int& c_walks, unsigned int& c_steps, int kaz = 1) {
+                                DepositFn add_energy, unsigned int& c_walks, unsigned int& c_steps, int kaz = 1, int wl = -1) {
   return mrw_walk_with(T, M, k0, k1, p_lo, p_hi, event, ic, M.kappa_factor[ic], S0, x, y, z, u, v, w, lambda,
                        [&](double px, double py, double pz) { return distance_to_closest_wall_cyl(T, M, ri, zj, px, py, pz, kaz); },
-                       cell_energy, add_energy, c_walks, c_steps);
+                       cell_energy, add_energy, c_walks, c_steps, wl);
 }
 
 // ---------------------------------------------------------------------------

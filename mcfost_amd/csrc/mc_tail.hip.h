@@ -260,7 +260,7 @@ __device__ __forceinline__ void tail_packet(const Lds& T, const DevModel& M, con
           int lam2 = lambda;
           const bool done = mrw_walk(T, M, key0, key1, p_lo, p_hi, event, F.ri, F.zj, ic, F.S0, x, y, z, u, v, w, lam2,
                                      [&]() { return cell_energy(ic); },
-                                     [&](double e) { add_energy(ic, e); }, c_walks, c_steps);
+                                     [&](double e) { add_energy(ic, e); }, c_walks, c_steps, 1, lane);   // (lane: wave-wide searches)
           if (done) { F.x = x; F.y = y; F.z = z; F.u = u; F.v = v; F.w = w; lambda = lam2; }
         }
       }
