@@ -156,8 +156,9 @@ class Par:
     """How the N GPUs are driven: "single" (N = 1), "torchrun" (one process per GPU, torch.distributed nccl = RCCL) or
     "library" (ONE process, mcgpu_multi_*: RCCL inside the library)."""
 
-    def __init__(self, gpus):
-        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+    def __init__(self, gpus, shared_device=False):
+        self.shared_device = bool(shared_device)   # library mode on ONE GPU: every context on device 0 (a dry run of the
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))   # n_dev > 1 code; mcgpu_multi_create_ex, include/mcgpu.h)
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.dist = self.torch = None
@@ -245,7 +246,8 @@ def thermal_block(par, args, config, steps, warmup, with_cpu, n_local):
     n_local = int(n_local)
     n_total = n_local * world
     if par.mode == "library":
-        me = MultiEngine(model, n_total, devices=tuple(range(world)))
+        me = MultiEngine(model, n_total, devices=((0,) * world if par.shared_device else tuple(range(world))),
+                         shared_device=par.shared_device)
         eng = me.engines[0]
     else:
         me = None
@@ -417,7 +419,8 @@ def sed_block(par, args, steps, warmup, with_cpu, packets, observers):
     T = e.temp_finale(e.run_thermal(5_000_000, seed=3)["E_abs"])   # the dust temperature the SED step emits with
     e.close()
     if par.mode == "library":
-        me = MultiEngine(m, 5e6, devices=tuple(range(world)))
+        me = MultiEngine(m, 5e6, devices=((0,) * world if par.shared_device else tuple(range(world))),
+                         shared_device=par.shared_device)
         engs = me.engines
     else:
         me = None
@@ -535,6 +538,10 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="--config pascucci: the headline block alone")
     ap.add_argument("--no-pascucci", action="store_true", help="(kept for older command lines: same as --no-extra)")
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
+    ap.add_argument("--shared-device", action="store_true",
+                    help="--gpus N started plainly (library mode) on a box with ONE GPU: the N contexts share device 0 and the "
+                         "library's own sum stands in for the RCCL all-reduce -- a dry run of the multi-device code, not a "
+                         "scaling measurement (the line says so in \"launcher\")")
     ap.add_argument("--tail", type=int, default=-1, help="tuning aid: option \"tail\" (packets left per workgroup at the hand-over to "
                     "k_tail; -1 = the library's choice)")
     ap.add_argument("--grid-blocks", type=int, default=0)
@@ -545,13 +552,15 @@ def main():
                          "(keeps the physics identical across diagnostic builds); not the benchmark")
     args = ap.parse_args()
 
-    par = Par(args.gpus)
+    par = Par(args.gpus, args.shared_device)
     if par.mode == "torchrun" and par.world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE = %d" % (args.gpus, par.world))
     world = par.n_gpus
     with_cpu = world == 1 and not args.no_cpu_baseline
     launcher = {"single": "one process, one GPU", "torchrun": "one process per GPU, torch.distributed nccl (RCCL)",
                 "library": "one process, mcgpu_multi_* (RCCL inside the library)"}[par.mode]
+    if par.mode == "library" and par.shared_device:
+        launcher = "one process, mcgpu_multi_* with every context on device 0 (shared-device dry run: NOT a scaling measurement)"
 
     if args.config == "sed":
         line = sed_block(par, args, args.steps, args.warmup, with_cpu, args.packets, args.sed_observers)

@@ -209,3 +209,21 @@ def test_an_error_on_one_context_drains_the_others(small_model):
     good = me.run_thermal(n, seed=11, frozen=True, E_prior=prior)
     me.close()
     _same_packets(good, o.run_thermal(n, seed=11, frozen=True, E_prior=prior, n_threads=8), oracle=True)
+
+
+def test_bench_dry_run_in_library_mode_with_two_contexts():
+    """`python bench.py --gpus 2 --shared-device`: the bench's library mode (ONE process, mcgpu_multi_*) on two contexts of
+    this box's one GPU -- the line an 8-GPU node's single-process run would print, dry."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--shared-device", "--packets", "2e6",
+                          "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extra"],
+                         capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and "shared-device" in line["launcher"]
+    assert line["config"]["packets_per_gpu"] == 2000000 and abs(line["config"]["crossings_per_packet"] - 252) < 5
