@@ -659,6 +659,15 @@ int mcgpu_set_scattering_method1(mcgpu_ctx *ctx, const mcgpu_grain_tables *grain
                                  int p_n_cells, const double *dust_density_o_n_grains);
 
 /*
+ * ksca_CDF(0:n_grains, p_n_cells, n_lambda) (dust_prop.f90:24) on the device, after mcgpu_set_scattering_method1: per class
+ * and wavelength the normalised cumulative C_sca n over the grain sizes (dust_prop.f90:976-994; all ones where the sum is
+ * not positive).  With it the scattering grain is selected by the dichotomy of select_grainsize_high_mem (dust_prop.f90:
+ * 1245-1288) -- the branch the reference takes when the table fits max_mem (mem.f90:245-258) -- instead of the walk of the
+ * low-memory mode.  ksca_CDF_out: NULL, or the table in the reference's layout.  build = 0: back to the walk.
+ */
+int mcgpu_build_ksca_CDF(mcgpu_ctx *ctx, int build, double *ksca_CDF_out);
+
+/*
  * The optional accumulators of save_radiation_field's thermal branch (radiation_field.f90:54-55):
  *   xN_abs[n_cells]             path segments per cell (xN_abs(icell,1,id) with lmcfost_lib: what run_mcfost_phantom
  *                               returns, mcfost2phantom.f90:361), summed over "threads"

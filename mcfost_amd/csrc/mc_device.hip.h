@@ -221,6 +221,8 @@ struct DevModel {
   const float* m1_Csca;      // C_sca(n_grains, n_lambda)
   const double* m1_nk;       // n_grains(k)
   const double* m1_dens;     // dust_density_o_n_grains(n_grains, class)
+  const double* m1_ksca;     // nullptr (low_mem_scattering: the walk below), or ksca_CDF [class][lambda][0:n_grains]
+                             // (dust_prop.f90:24, built by k_ksca_cdf / mcgpu_build_ksca_CDF): select_grainsize_high_mem
   const float* m1_prob;      // [n_lambda][n_grains][nang+1] cumulative phase function of the grain
   const float* m1_g;         // tab_g(n_grains, n_lambda)
   const float *m1_s11, *m1_s12, *m1_s22, *m1_s33, *m1_s34, *m1_s44;  // tab_s1x(0:nang, n_grains, n_lambda)
@@ -1399,6 +1401,19 @@ __device__ inline int reemission_wavelength(const Lds& T, const DevModel& M, int
 // the cell's class from the small grains (rand < 0.5) or from the big ones; k_sca = kappa albedo / (AU_to_cm mum_to_cm^2)
 __device__ inline int select_scattering_grain(const DevModel& M, int cls, int lambda, float rand, double norm) {
   const int ng = M.m1_ng;
+  if (M.m1_ksca) {
+    // select_grainsize_high_mem (dust_prop.f90:1245-1288): the dichotomy in the stored, normalised CDF, statement for
+    // statement (prob is the default-real draw; an entry EQUAL to it ends the search with the current kmax)
+    const double* cdf = M.m1_ksca + ((size_t)cls * M.n_lambda + (size_t)(lambda - 1)) * (size_t)(ng + 1);
+    const double prob = (double)rand;
+    int kmin = 0, kmax = ng, k = (kmin + kmax) / 2;
+    while (cdf[k] != prob) {
+      if (cdf[k] < prob) kmin = k; else kmax = k;
+      k = (kmin + kmax) / 2;
+      if ((kmax - kmin) <= 1) break;
+    }
+    return kmax;
+  }
   const double* d = M.m1_dens + (size_t)ng * cls;
   const float* Cs = M.m1_Csca + (size_t)ng * (lambda - 1);
   double CDF = 0.0;

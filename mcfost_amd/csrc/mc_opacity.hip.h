@@ -153,3 +153,28 @@ static __global__ void k_scatt_norm(const OpacityIn I, const OpacityOut O) {
     }
   }
 }
+
+// ksca_CDF(0:n_grains, p_n_cells, n_lambda) (dust_prop.f90:24, built at :976-994 when scattering method 1 has the memory
+// for it, mem.f90:245-258): per (class, wavelength) the running sum of C_sca(k, lambda) dust_density_o_n_grains(k, class)
+// n_grains(k) over the grain sizes, normalised by its last entry -- or all ones where that is not positive ("at the
+// surface ... only the smallest grains").  One thread per (class, wavelength), the sum in the reference's order and
+// association, unfused.  Device layout [class][lambda][0:n_grains]: the dichotomy of select_grainsize_high_mem walks one row.
+static __global__ void k_ksca_cdf(int n_classes, int n_lambda, int ng, const float* C_sca, const double* dens, const double* nk,
+                                  double* out) {
+#pragma clang fp contract(off)
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_classes * n_lambda) return;
+  const int cls = i / n_lambda, l = i % n_lambda;
+  double* row = out + (size_t)i * (ng + 1);
+  double c = 0.0;
+  row[0] = 0.0;
+  for (int k = 1; k <= ng; ++k) {
+    c = c + (double)C_sca[(size_t)(k - 1) + (size_t)ng * l] * dens[(size_t)(k - 1) + (size_t)ng * cls] * nk[k - 1];
+    row[k] = c;
+  }
+  if (c > (double)1.17549435082228750797e-38f) {
+    for (int k = 0; k <= ng; ++k) row[k] = row[k] / c;
+  } else {
+    for (int k = 0; k <= ng; ++k) row[k] = 1.0;
+  }
+}

@@ -865,6 +865,39 @@ extern "C" int mcgpu_set_scattering_method1(mcgpu_ctx* ctx, const mcgpu_grain_ta
   } else if ((rc = upload(ctx, G->tab_g, n_gl, &M.m1_g))) return rc;
   M.m1_ng = ng;
   M.m1 = 1;
+  M.m1_ksca = nullptr;   // (low_mem_scattering until mcgpu_build_ksca_CDF)
+  return MCGPU_OK;
+}
+
+// ksca_CDF on the device (dust_prop.f90:976-994): the grain selection of scattering method 1 then is the dichotomy of
+// select_grainsize_high_mem instead of the walk of the low-memory mode -- the reference takes this branch when
+// n_grains x p_n_cells x n_lambda x 4 bytes fit max_mem (mem.f90:245-258); 288 GB of HBM make that the rule.
+// ksca_CDF_out (or NULL): the table in the reference's layout (0:n_grains, p_n_cells, n_lambda).  build = 0: back to
+// the low-memory walk.
+extern "C" int mcgpu_build_ksca_CDF(mcgpu_ctx* ctx, int build, double* ksca_CDF_out) {
+  if (!ctx) return MCGPU_ERR_ARG;
+  DevModel& M = ctx->M;
+  if (!build) { M.m1_ksca = nullptr; return MCGPU_OK; }
+  if (!M.m1 || !M.n_classes) return fail(ctx, MCGPU_ERR_STATE, "mcgpu_build_ksca_CDF: mcgpu_set_scattering_method1 first");
+  HIPCHK(hipSetDevice(ctx->device));
+  const int ng = M.m1_ng, nc = M.n_classes, nl = M.n_lambda;
+  const size_t n = (size_t)nc * nl * (ng + 1);
+  double* d = nullptr;
+  HIPCHK(hipMalloc((void**)&d, n * sizeof(double)));
+  ctx->allocs.push_back(d);
+  hipLaunchKernelGGL(k_ksca_cdf, dim3((unsigned)((nc * nl + 127) / 128)), dim3(128), 0, ctx->stream, nc, nl, ng, M.m1_Csca, M.m1_dens,
+                     M.m1_nk, d);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (ksca_CDF_out) {   // [class][lambda][k] -> (k, class, lambda) with k fastest
+    std::vector<double> h(n);
+    HIPCHK(hipMemcpy(h.data(), d, n * sizeof(double), hipMemcpyDeviceToHost));
+    for (int c = 0; c < nc; ++c)
+      for (int l = 0; l < nl; ++l)
+        for (int k = 0; k <= ng; ++k)
+          ksca_CDF_out[(size_t)k + (size_t)(ng + 1) * ((size_t)c + (size_t)nc * l)] = h[((size_t)c * nl + l) * (ng + 1) + k];
+  }
+  M.m1_ksca = d;
   return MCGPU_OK;
 }
 

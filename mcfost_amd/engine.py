@@ -36,7 +36,7 @@ ABI_SYMBOLS = (
     "mcgpu_device_xI", "mcgpu_set_ism", "mcgpu_rt1_dust_map", "mcgpu_set_xI", "mcgpu_rt1_image", "mcgpu_set_xI_precision",
     "mcgpu_get_xI_precision", "mcgpu_set_option", "mcgpu_get_info", "mcgpu_counters_to_accum", "mcgpu_counters_from_accum",
     "mcgpu_set_grid_sph", "mcgpu_temp_approx_diffusion_vertical", "mcgpu_set_mrw", "mcgpu_fetch_radiation_field", "mcgpu_set_variable_dust", "mcgpu_rt1_stars_map_sed", "mcgpu_define_dark_zone", "mcgpu_init_reemission", "mcgpu_multi_create", "mcgpu_multi_destroy", "mcgpu_multi_size", "mcgpu_multi_ctx", "mcgpu_multi_last_error",
-    "mcgpu_repartition_energie", "mcgpu_opacity", "mcgpu_set_variable_dust_s11", "mcgpu_set_scattering_method1", "mcgpu_set_rt2", "mcgpu_fetch_I_spec", "mcgpu_rt1_stars_map_image", "mcgpu_set_I_spec", "mcgpu_rt2_source", "mcgpu_rt2_dust_map", "mcgpu_rt2_image", "mcgpu_shard_packets", "mcgpu_multi_run_thermal", "mcgpu_multi_run_mono", "mcgpu_multi_rccl_ranks", "mcgpu_multi_create_ex", "mcgpu_multi_reductions", "mcgpu_set_mrw_exit_spectrum", "mcgpu_voronoi_tesselation",
+    "mcgpu_repartition_energie", "mcgpu_opacity", "mcgpu_set_variable_dust_s11", "mcgpu_set_scattering_method1", "mcgpu_set_rt2", "mcgpu_fetch_I_spec", "mcgpu_rt1_stars_map_image", "mcgpu_set_I_spec", "mcgpu_rt2_source", "mcgpu_rt2_dust_map", "mcgpu_rt2_image", "mcgpu_shard_packets", "mcgpu_multi_run_thermal", "mcgpu_multi_run_mono", "mcgpu_multi_rccl_ranks", "mcgpu_multi_create_ex", "mcgpu_multi_reductions", "mcgpu_set_mrw_exit_spectrum", "mcgpu_voronoi_tesselation", "mcgpu_build_ksca_CDF",
 )
 
 
@@ -271,6 +271,18 @@ class Engine:
         if vd.get("tab_s11_pos") is not None:   # the phase function of the rt1 deposits, per class
             self._chk(self.lib.mcgpu_set_variable_dust_s11(self.ctx, _p(_a(vd["tab_s11_pos"], np.float32), C.c_float)),
                       "mcgpu_set_variable_dust_s11")
+
+    def build_ksca_CDF(self, build=True, fetch=True):
+        """``ksca_CDF(0:n_grains, p_n_cells, n_lambda)`` on the device (``mcgpu_build_ksca_CDF``): scattering method 1 then selects
+        the grain by ``select_grainsize_high_mem``'s dichotomy.  Returns the table ``[n_lambda, p_n_cells, n_grains + 1]``
+        (C order of the reference's layout) when ``fetch``."""
+        if not build:
+            self._chk(self.lib.mcgpu_build_ksca_CDF(self.ctx, C.c_int(0), None), "mcgpu_build_ksca_CDF")
+            return None
+        m1 = self.model.method1
+        out = np.zeros((self.model.n_lambda, int(self.model.variable_dust["p_n_cells"]), int(m1["n_grains"]) + 1), np.float64) if fetch else None
+        self._chk(self.lib.mcgpu_build_ksca_CDF(self.ctx, C.c_int(1), _p(out, C.c_double) if fetch else None), "mcgpu_build_ksca_CDF")
+        return out
 
     def opacity(self, grains, p_icell, dens, fetch=True):
         """``opacity`` + ``calc_local_scattering_matrices`` (dust_prop.f90:791-1243) on the device: builds the per-class

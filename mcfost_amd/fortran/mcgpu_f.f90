@@ -89,6 +89,7 @@ module mcgpu_f
        mcgpu_run_mono, mcgpu_fetch, mcgpu_fetch_xI, mcgpu_rt1_dust_map, mcgpu_set_xI, mcgpu_rt1_image, mcgpu_set_xI_precision, &
        mcgpu_set_E_prior, mcgpu_multi_create, mcgpu_multi_destroy, mcgpu_multi_size, mcgpu_multi_ctx, mcgpu_multi_run_thermal, mcgpu_multi_run_mono, mcgpu_multi_rccl_ranks, mcgpu_multi_create_ex, mcgpu_multi_reductions, &
        mcgpu_counters_to_accum, mcgpu_counters_from_accum, mcgpu_temp_approx_diffusion_vertical, mcgpu_set_mrw, mcgpu_set_mrw_exit_spectrum, mcgpu_fetch_radiation_field, &
+       mcgpu_build_ksca_CDF, mcgpu_voronoi_tesselation, &
        mcgpu_set_variable_dust, mcgpu_rt1_stars_map_sed, mcgpu_define_dark_zone, mcgpu_init_reemission, mcgpu_repartition_energie, mcgpu_opacity, mcgpu_set_variable_dust_s11, mcgpu_set_scattering_method1, mcgpu_set_rt2, mcgpu_fetch_I_spec, mcgpu_rt1_stars_map_image, mcgpu_set_I_spec, mcgpu_rt2_source, mcgpu_rt2_dust_map, mcgpu_rt2_image
 
   interface
@@ -291,6 +292,30 @@ module mcgpu_f
        type(c_ptr), value :: ctx
        type(c_ptr), value :: exit_cdf
      end function mcgpu_set_mrw_exit_spectrum
+
+     ! ksca_CDF(0:n_grains, p_n_cells, n_lambda) on the device after mcgpu_set_scattering_method1 (dust_prop.f90:976-994): the
+     ! grain of a scattering is then selected like select_grainsize_high_mem does; ksca_CDF_out: c_null_ptr or the table
+     integer(c_int) function mcgpu_build_ksca_CDF(ctx, build, ksca_CDF_out) bind(C, name="mcgpu_build_ksca_CDF")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: build
+       type(c_ptr), value :: ksca_CDF_out
+     end function mcgpu_build_ksca_CDF
+
+     ! the tessellation voro_C returns (Voronoi.f90:70-96), built on the device: see include/mcgpu.h and INTEGRATION.md
+     integer(c_int) function mcgpu_voronoi_tesselation(device, n, xyz, h, limits, threshold, n_vectors, cutting_vectors, &
+          cutting_distance_o_h, n_run, cells, k, knn, knn_first, extra_plane, max_neighbours, n_neigh, neigh, volume, &
+          delta_edge, was_cut, kernel_ms, volume_uncut) bind(C, name="mcgpu_voronoi_tesselation")
+       import :: c_int, c_double, c_ptr, c_int8_t
+       integer(c_int), value :: device, n, n_vectors, n_run, k, max_neighbours
+       real(c_double), intent(in) :: xyz(3,*), h(*), limits(6), cutting_vectors(3,*)
+       real(c_double), value :: threshold, cutting_distance_o_h
+       type(c_ptr), value :: cells, knn_first, extra_plane, volume_uncut
+       integer(c_int), intent(in) :: knn(*)
+       integer(c_int), intent(out) :: n_neigh(*), neigh(max_neighbours,*)
+       real(c_double), intent(out) :: volume(*), delta_edge(*), kernel_ms
+       integer(c_int8_t), intent(out) :: was_cut(*)
+     end function mcgpu_voronoi_tesselation
 
      ! define_dark_zone (optical_depth.f90:1425), 2D: module cylindrical_grid's r_lim, r_grid, z_grid, z_lim in;
      ! l_dark_zone (as integer(c_int8_t)), ri_in/out_dark_zone(1), zj_sup_dark_zone(:,1) out

@@ -100,7 +100,7 @@ class _Model(C.Structure):
         ("v_log_Qcool", _dp), ("v_kdB_dT_CDF", _dp), ("v_prob_s11_pos", _fp), ("v_s12_o_s11", _fp), ("v_s22_o_s11", _fp),
         ("v_s33_o_s11", _fp), ("v_s34_o_s11", _fp), ("v_s44_o_s11", _fp), ("v_tab_g_pos", _fp), ("r_lim", _dp),
         ("v_tab_s11_pos", _fp),
-        ("scattering_method1", C.c_int), ("m1_n_grains", C.c_int), ("m1_C_sca", _fp), ("m1_nk", _dp), ("m1_dens", _dp),
+        ("scattering_method1", C.c_int), ("m1_n_grains", C.c_int), ("m1_C_sca", _fp), ("m1_nk", _dp), ("m1_dens", _dp), ("m1_ksca_CDF", _dp),
         ("m1_prob_s11", _fp), ("m1_tab_g", _fp), ("m1_s11", _fp), ("m1_s12", _fp), ("m1_s22", _fp), ("m1_s33", _fp),
         ("m1_s34", _fp), ("m1_s44", _fp), ("sin_phi_lim", _dp), ("cos_phi_lim", _dp),
     ]
@@ -268,6 +268,8 @@ class Oracle:
                          ("tab_s12", "m1_s12"), ("tab_s22", "m1_s22"), ("tab_s33", "m1_s33"), ("tab_s34", "m1_s34"),
                          ("tab_s44", "m1_s44")):
                 setattr(s, f, self._hold(_a(m1[k], np.float32), C.c_float))
+            if m1.get("ksca_CDF") is not None:   # the high-memory grain selection (oracle_build_ksca_CDF / Oracle.build_ksca_CDF)
+                s.m1_ksca_CDF = self._hold(_a(m1["ksca_CDF"], np.float64), C.c_double)
         mrw = getattr(m, "mrw", None)
         if mrw is not None:
             s.mrw, s.mrw_n_zeta = 1, int(mrw["zeta"].size)

@@ -1193,7 +1193,40 @@ static void get_mueller_matrix_per_cell(const oracle_model *m, int lambda,
 /* select_scattering_grain (dust_prop.f90:1292-1336), low_mem_scattering: the CDF of C_sca n over the grain sizes of the
  * cell is walked on the fly, from the small grains when rand < 0.5, else from the big ones.  (A walk that rounding lets
  * run off the end would index out of bounds in the reference: the last grain visited is returned here.) */
+/* ksca_CDF (dust_prop.f90:976-994): what `opacity` stores per (cell class, wavelength) when scattering method 1 has the
+ * memory for it -- the running sum of C_sca n over the grain sizes, normalised, or all ones where it is not positive */
+void oracle_build_ksca_CDF(const oracle_model *m, double *ksca_CDF) {
+  const int ng = m->m1_n_grains, nc = m->p_n_cells ? m->p_n_cells : 1, nl = m->n_lambda;
+  for (int l = 0; l < nl; ++l)
+    for (int c = 0; c < nc; ++c) {
+      double *row = ksca_CDF + (size_t)(ng + 1) * ((size_t)c + (size_t)nc * l);
+      row[0] = 0.0;
+      for (int k = 1; k <= ng; ++k)
+        row[k] = row[k - 1] + (double)m->m1_C_sca[(size_t)(k - 1) + (size_t)ng * l] * m->m1_dens[(size_t)(k - 1) + (size_t)ng * c] *
+                 m->m1_nk[k - 1];
+      const double last = row[ng];
+      if (last > (double)1.17549435082228750797e-38f) { for (int k = 0; k <= ng; ++k) row[k] = row[k] / last; }
+      else { for (int k = 0; k <= ng; ++k) row[k] = 1.0; }
+    }
+}
+
+/* select_grainsize_high_mem (dust_prop.f90:1245-1288) */
+static int select_grainsize_high_mem(const oracle_model *m, int lambda, int icell, float rand) {
+  const int ng = m->m1_n_grains, nc = m->p_n_cells ? m->p_n_cells : 1;
+  const int cls = m->p_n_cells ? m->p_icell[icell - 1] - 1 : 0;
+  const double *cdf = m->m1_ksca_CDF + (size_t)(ng + 1) * ((size_t)cls + (size_t)nc * (lambda - 1));
+  const float prob = rand;
+  int kmin = 0, kmax = ng, k = (kmin + kmax) / 2;
+  while (cdf[k] != (double)prob) {
+    if (cdf[k] < (double)prob) kmin = k; else kmax = k;
+    k = (kmin + kmax) / 2;
+    if ((kmax - kmin) <= 1) break;
+  }
+  return kmax;
+}
+
 int oracle_select_scattering_grain(const oracle_model *m, int lambda, int icell, float rand) {
+  if (m->m1_ksca_CDF) return select_grainsize_high_mem(m, lambda, icell, rand);   /* .not. low_mem_scattering (:1330) */
   const int ng = m->m1_n_grains;
   const double AU_to_cm = 149597870700.0 * 100.0, mum_to_cm = 1.0e-4;
   const double norm = tab_kappa(m, icell, lambda) * (double)tab_albedo(m, icell, lambda) / (AU_to_cm * (mum_to_cm * mum_to_cm));

@@ -199,6 +199,8 @@ typedef struct {
   const float *m1_C_sca;          /* C_sca(n_grains, n_lambda) */
   const double *m1_nk;            /* n_grains(k) */
   const double *m1_dens;          /* dust_density_o_n_grains(n_grains, p_n_cells) (one column without lvariable_dust) */
+  const double *m1_ksca_CDF;      /* NULL (low_mem_scattering), or ksca_CDF(0:n_grains, p_n_cells, n_lambda) (dust_prop.f90:24): the
+                                     grain is then selected by select_grainsize_high_mem (oracle_build_ksca_CDF fills it) */
   const float *m1_prob_s11;       /* prob_s11(n_lambda, n_grains, 0:nang) (grains.f90:53) */
   const float *m1_tab_g;          /* tab_g(n_grains, n_lambda) */
   const float *m1_s11, *m1_s12, *m1_s22, *m1_s33, *m1_s34, *m1_s44; /* tab_s1x(0:nang, n_grains, n_lambda), per-grain normalisation (s11 = 1) */
@@ -398,6 +400,7 @@ int oracle_init_reemission(int p_n_cells, int n_T, int n_lambda, const float *ta
                            double *kdB_dT_CDF);
 
 /* select_scattering_grain (dust_prop.f90:1292-1336) of the model's method-1 tables: 1-based grain for the draw `rand` */
+void oracle_build_ksca_CDF(const oracle_model *m, double *ksca_CDF);
 int oracle_select_scattering_grain(const oracle_model *m, int lambda, int icell, float rand);
 
 /* opacity(lambda, p_lambda = lambda) (dust_prop.f90:791-1033; LTE grains, no scattering suppression) followed by

@@ -61,6 +61,55 @@ def test_select_scattering_grain_against_a_numpy_search():
                     assert np.min(np.abs(c - x)) < 1e-5 * c[-1]
 
 
+def _oracle_ksca_CDF(o, m):
+    """ksca_CDF(0:n_grains, p_n_cells, n_lambda) by the oracle's restatement of dust_prop.f90:976-994 -> [n_lambda, p_n_cells, n_grains + 1]."""
+    out = np.zeros((m.n_lambda, int(m.variable_dust["p_n_cells"]), int(m.method1["n_grains"]) + 1), np.float64)
+    o.lib.oracle_build_ksca_CDF.restype = None
+    o.lib.oracle_build_ksca_CDF(C.byref(o.cm), out.ctypes.data_as(C.POINTER(C.c_double)))
+    return out
+
+
+def test_ksca_CDF_and_the_high_memory_grain_selection():
+    """`.not. low_mem_scattering` (mem.f90:245-258): ksca_CDF stored (dust_prop.f90:976-994) and the grain selected by
+    select_grainsize_high_mem's dichotomy (:1245-1288).  The restated table against numpy (rows start at 0, end at 1, never
+    decrease; an empty class is all ones); the dichotomy against searchsorted on the same table; and the two modes of
+    select_scattering_grain pick the same grain but where the draw sits on a step of the CDF (the walk of the low-memory
+    mode normalises with kappa * albedo, the table with its own last entry)."""
+    from oracle import Oracle
+    m, g, p_icell, dens = _model()
+    dens = np.array(dens)
+    dens[3] = 0.0                                             # a class without dust
+    M.init_scattering_method1(m, g, dens)
+    o = Oracle(m, 1000)
+    cdf = _oracle_ksca_CDF(o, m)
+    nk = np.asarray(g["n_grains_k"])
+    w = np.asarray(g["C_sca"], np.float64)[:, None, :] * dens[None, :, :] * nk[None, None, :]     # [lambda, class, grain]
+    want = np.concatenate([np.zeros(w.shape[:2] + (1,)), np.cumsum(w, axis=2)], axis=2)
+    tot = want[..., -1:]
+    want = np.where(tot > 0, want / np.where(tot > 0, tot, 1.0), 1.0)
+    assert np.allclose(cdf, want, rtol=1e-13, atol=0) and np.all(cdf[:, 3, :] == 1.0)
+    assert np.all(cdf[:, [0, 1, 2, 4], 0] == 0.0) and np.all(cdf[..., -1] == 1.0) and np.all(np.diff(cdf, axis=2) >= 0)
+    f = o.lib.oracle_select_scattering_grain
+    f.restype = C.c_int
+    lo = [(lam, ic, r, f(C.byref(o.cm), C.c_int(lam), C.c_int(ic), C.c_float(r)))
+          for lam in (1, 9, 16) for ic in (1, 17, m.n_cells) for r in np.random.default_rng(7).random(300, dtype=np.float32)]
+    m.method1["ksca_CDF"] = cdf
+    o2 = Oracle(m, 1000)
+    f2 = o2.lib.oracle_select_scattering_grain
+    f2.restype = C.c_int
+    n_diff = 0
+    for lam, ic, r, k_low in lo:
+        k = f2(C.byref(o2.cm), C.c_int(lam), C.c_int(ic), C.c_float(r))
+        row = cdf[lam - 1, p_icell[ic - 1] - 1]
+        if p_icell[ic - 1] - 1 == 3:
+            continue                                           # (the empty class never scatters)
+        want_k = int(np.searchsorted(row, np.float64(r), side="left"))   # first k with CDF(k) >= r ...
+        assert k == max(want_k, 1) or (row[k - 1] == np.float64(r)), (lam, ic, r, k, want_k)   # (... an exact hit ends the search early)
+        assert abs(k - k_low) <= 1
+        n_diff += k != k_low
+    assert n_diff <= 0.02 * len(lo)
+
+
 def test_identical_grains_give_the_temperature_of_method_2():
     """Every size bin with the same optical properties: drawing the grain changes nothing physical.  Frozen temperature,
     one thread (reproducible): the two methods are two samples of the same transport."""
@@ -110,6 +159,20 @@ def test_device_method1_equals_the_oracle_frozen(kw):
     from mcfost_amd.engine import McgpuError
     with pytest.raises(McgpuError):
         e.run_mono(3, 5, seed=1, n_chunks=4, rt1=False)
+    # ksca_CDF on the device: the table equals the restatement bit for bit, and the loop with the dichotomy of
+    # select_grainsize_high_mem equals the oracle's with the same table, packet for packet
+    cdf = e.build_ksca_CDF()
+    want_cdf = _oracle_ksca_CDF(o, m)
+    assert np.array_equal(cdf, want_cdf)
+    m.method1["ksca_CDF"] = want_cdf
+    bh = Oracle(m, n).run_thermal(n, seed=6, frozen=True, E_prior=prior, n_threads=8)
+    ah = e.run_thermal(n, seed=6, frozen=True, E_prior=prior)
+    assert ah["counters"] == bh["counters"] and np.array_equal(ah["sed"][4], bh["sed"][4])
+    assert np.allclose(ah["E_abs"], bh["E_abs"], rtol=1e-9, atol=1e-11 * bh["E_abs"].max())
+    assert abs(ah["counters"]["scatterings"] / a["counters"]["scatterings"] - 1) < 0.05   # (the same physics as the walk)
+    e.build_ksca_CDF(build=False)
+    assert e.run_thermal(n, seed=6, frozen=True, E_prior=prior)["counters"] == b["counters"]
+    del m.method1["ksca_CDF"]
     # method 2 on the same context runs other packets: the switch is live
     e.set_scattering_method1(None)
     a2 = e.run_thermal(n, seed=6, frozen=True, E_prior=prior)
