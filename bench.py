@@ -222,7 +222,8 @@ def build_workload(M, args, config):
         from mcfost_amd.host import voronoi as V
         t_tess = time.perf_counter()
         kern = V.device_tessellator(int(os.environ.get("LOCAL_RANK", "0")))
-        model = M.build_voronoi_model(cfg, args.sites, seed=1, tessellator=kern, platonic=True, density=args.voronoi_density)
+        model = M.build_voronoi_model(cfg, args.sites, seed=1, tessellator=kern, platonic=True, density=args.voronoi_density,
+                                      order=args.site_order)
         model.extra["tessellation_s"] = time.perf_counter() - t_tess
         model.extra["tessellation_kernel_ms"] = kern.kernel_ms
     else:
@@ -518,6 +519,9 @@ def main():
                     help="--config sed: wavelengths (1-based) whose SED Monte Carlo one step runs")
     ap.add_argument("--sites", type=int, default=1000000,
                     help="--config voronoi: number of SPH-like sites of the tessellation (BASELINE config 5 stand-in)")
+    ap.add_argument("--site-order", default="file", choices=["file", "morton"],
+                    help="--config voronoi: the order of the cells -- file: as the sample lists its particles; morton: along a "
+                         "space-filling curve (host/voronoi.py::spatial_order), neighbours in space at neighbouring addresses")
     ap.add_argument("--voronoi-density", default="smoothed", choices=["sph", "smoothed"],
                     help="--config voronoi: the cells' dust density -- smoothed (default): round 3's neighbour-averaged m / V; "
                          "sph: the analytic density at the site, m (1.2 / h)^3 (what a dump's own SPH density would be): at 1e6 "

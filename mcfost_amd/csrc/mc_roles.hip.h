@@ -436,7 +436,11 @@ __device__ __forceinline__ int fly_step_2d(const Lds& T, const DevModel& M, cons
 // central hole (atan2), and the rare fallbacks of the zj recomputation.  The wall at tan(phi) = +-1e300 and the
 // ordinary azimuthal wall share ONE division (numerator and denominator are selected first).
 // BIN: the deposit is handed back (dep_ic >= 0, dep_v) for the caller's bin_deposit.
-template <bool DARK, bool LDSE, bool BIN, bool VAR = false>
+// DEFER (the role kernels): the re-indexing of a stopping point (optical_depth.f90:140 -> index_cell: a bisection, the
+// default-real zj and an atan2, ~250 vector instructions) is NOT done here, where it would run in almost every iteration
+// of the flying loop for the two or three lanes of 64 that stop in it, but by the interaction that follows, which runs
+// for the stopped packets together; the packet carries the request as a negative azimuthal index k.
+template <bool DARK, bool LDSE, bool BIN, bool VAR = false, bool DEFER = false>
 __device__ __forceinline__ int fly_step_3d(const Lds& T, const DevModel& M, const RunArgs& A, double* E_lds, Flight& p,
                                            unsigned int& c_cross, unsigned int& c_kill, unsigned int& c_dark, int& dep_ic,
                                            double& dep_v) {
@@ -583,7 +587,9 @@ __device__ __forceinline__ int fly_step_3d(const Lds& T, const DevModel& M, cons
   p.ic = move ? ic1 : ic;
   p.kf = move ? kf1 : p.kf;
   if (VAR) p.kab = move ? kk1.y : p.kab;
-  if (__builtin_expect(stop, 0)) {  // (:140: 3D re-indexes the stopping point)
+  if (DEFER) {
+    p.k = stop ? -p.k : p.k;   // (:140: the interaction re-indexes the stopping point, see reindex_stop)
+  } else if (__builtin_expect(stop, 0)) {  // (:140: 3D re-indexes the stopping point)
     index_cell<true>(T, M, p.x, p.y, p.z, p.ri, p.zj, p.k);
     p.ic = is_real_cell<true>(n_rad, nz, p.ri, p.zj) ? cell_index<true>(n_rad, nz, p.ri, p.zj, p.k) : M.n_cells;
   }
@@ -883,7 +889,7 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
             int dep_ic = -1;
             double dep_v = 0.0;
             if (MCGPU_3D_BRANCHY) { if (F.st == S_FLIGHT) finished += roles_cross<L3D, DARK, LDSE, BIN>(T, M, A, E_lds, F, c_cross, c_kill, c_dark, dep_ic, dep_v); }
-            else finished += fly_step_3d<DARK, LDSE, BIN, VAR>(T, M, A, E_lds, F, c_cross, c_kill, c_dark, dep_ic, dep_v);
+            else finished += fly_step_3d<DARK, LDSE, BIN, VAR, true>(T, M, A, E_lds, F, c_cross, c_kill, c_dark, dep_ic, dep_v);
             if (BIN) bin_deposit(BS, A.bin, A.E_abs, lane, BP, dep_ic >= 0, dep_ic, dep_v);
           } else {
             finished += fly_step_2d<DARK, LDSE, MRW, false, VAR>(T, M, A, E_lds, F, c_cross, c_kill, c_dark);
@@ -1025,6 +1031,11 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
           lambda_sc = lambda;
           const int fl = R.flags;
           bool flag_star = (fl & ST_STAR) != 0, flag_scatt = (fl & ST_SCATT) != 0, flag_ism = (fl & ST_ISM) != 0;
+          if (L3D && !VORO && R.k < 0) {   // a flight stopped here: the cell of the stopping point (fly_step_3d, DEFER)
+            int ri_s, zj_s, k_s;
+            index_cell<true>(T, M, R.x, R.y, R.z, ri_s, zj_s, k_s);
+            R.ri = ri_s; R.zj = zj_s; R.k = k_s;
+          }
           const int ic = VORO ? R.ri - 1 : cell_index<L3D>(n_rad, nz, R.ri, R.zj, R.k);
           const int cls = VAR ? M.cell_class[ic] : -1;
           const Lds Tc = VAR ? class_tables(T, M, cls) : T;   // (lvariable_dust: this cell's tables)
@@ -1141,7 +1152,7 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
               int dep_ic = -1;
               double dep_v = 0.0;
               if (MCGPU_3D_BRANCHY) { if (F.st == S_FLIGHT) finished += roles_cross<L3D, DARK, LDSE, BIN>(T, M, A, E_lds, F, c_cross, c_kill, c_dark, dep_ic, dep_v); }
-              else finished += fly_step_3d<DARK, LDSE, BIN, VAR>(T, M, A, E_lds, F, c_cross, c_kill, c_dark, dep_ic, dep_v);
+              else finished += fly_step_3d<DARK, LDSE, BIN, VAR, true>(T, M, A, E_lds, F, c_cross, c_kill, c_dark, dep_ic, dep_v);
               if (BIN) bin_deposit(BS, A.bin, A.E_abs, lane, BP, dep_ic >= 0, dep_ic, dep_v);
             } else {
               finished += fly_step_2d<DARK, LDSE, MRW, false, VAR>(T, M, A, E_lds, F, c_cross, c_kill, c_dark);

@@ -1157,13 +1157,17 @@ VORONOI_CACHE_VERSION = 1
 
 def build_voronoi_model(cfg: DiskConfig, n_sites: int, seed: int = 1, box_z_over_h: float = 6.0,
                         cut: bool = True, cache_dir: Optional[str] = None, tessellator=None, platonic: bool = False,
-                        density: str = "smoothed") -> Model:
+                        density: str = "smoothed", order: str = "file") -> Model:
     """BASELINE config 5 stand-in: ``n_sites`` SPH-like sites drawn from the cfg's disk,
     tessellated in a box (``Voronoi.f90:183-640`` hands the same arrays to the loop), the
     star added as its own site, densities from the analytic disk evaluated at the sites."""
     from . import voronoi as V
 
     sites = V.sample_disk_sites(cfg, n_sites, seed)
+    site_id = np.arange(n_sites)
+    if order == "morton":     # (cells along a space-filling curve; site_id maps a cell back to its particle)
+        site_id = V.spatial_order(sites)
+        sites = np.ascontiguousarray(sites[site_id])
     zlim = box_z_over_h * cfg.sclht * (cfg.rout / cfg.rref) ** cfg.exp_beta
     zlim = max(zlim, 1.001 * float(np.abs(sites[:, 2]).max()))
     L = 1.001 * cfg.rout
@@ -1186,7 +1190,7 @@ def build_voronoi_model(cfg: DiskConfig, n_sites: int, seed: int = 1, box_z_over
         # the key names everything the tessellation depends on: the disk that the sites sample, the box, the star's
         # site, and the version of the builder (bump VORONOI_CACHE_VERSION when host/voronoi.py changes its output)
         geo = repr((VORONOI_CACHE_VERSION, n_sites, seed, box_z_over_h, int(cut), cfg.rin, cfg.rout, cfg.sclht, cfg.rref,
-                    cfg.exp_beta, cfg.surf, tuple(cfg.star_xyz), float(r_au), limits) + ((int(platonic),) if platonic else ()))
+                    cfg.exp_beta, cfg.surf, tuple(cfg.star_xyz), float(r_au), limits) + ((int(platonic),) if platonic else ()) + ((order,) if order != "file" else ()))
         cache = os.path.join(cache_dir, "voronoi_%d_%s.npz" % (n_sites, hashlib.sha1(geo.encode()).hexdigest()[:12]))
         if os.path.exists(cache):
             z = np.load(cache)
@@ -1235,4 +1239,5 @@ def build_voronoi_model(cfg: DiskConfig, n_sites: int, seed: int = 1, box_z_over
         raise ValueError("build_voronoi_model: density is 'smoothed' or 'sph'")
     rho[:nb] *= cfg.dust_mass * MSUN_TO_G / (float(np.sum(rho[:nb] * vol[:nb])) * AU_TO_CM ** 3)
     m = build_model(cfg, grid=grid, rho=rho)
+    m.extra["site_id"] = site_id       # cell i (0-based, before the stars' cells) is particle site_id[i] of the sample
     return m

@@ -43,6 +43,23 @@ def sample_disk_sites(cfg, n_sites, seed):
     return np.stack([r * np.cos(phi), r * np.sin(phi), z], axis=1)
 
 
+def spatial_order(sites, bits=10):
+    """A permutation that lists the sites along a Morton (Z-order) curve over their per-axis RANKS (equal-count bins, so
+    that a thin disk uses all bits of its z axis): cells that are neighbours in space get neighbouring indices -- and
+    neighbouring addresses in the device's records.  The reference's cells keep the particles' ids the same way
+    (``Voronoi(icell)%id``, Voronoi.f90:20-30: the cells are the particles it kept, not the file's order)."""
+    sites = np.asarray(sites, np.float64)
+    n = sites.shape[0]
+    key = np.zeros(n, np.uint64)
+    for ax in range(3):
+        rank = np.empty(n, np.int64)
+        rank[np.argsort(sites[:, ax], kind="stable")] = np.arange(n)
+        q = (rank * (1 << bits) // max(n, 1)).astype(np.uint64)
+        for b in range(bits):
+            key |= ((q >> np.uint64(b)) & np.uint64(1)) << np.uint64(3 * b + ax)
+    return np.argsort(key, kind="stable")
+
+
 def _tessellate(pts, limits):
     """Bounded Voronoi diagram of ``pts`` inside the box ``limits``.
 

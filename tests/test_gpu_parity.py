@@ -240,9 +240,12 @@ def test_live_mode_statistical_parity_ref41(ref41_model):
         # live feedback: the oracle estimates the in-flight temperature from a per-thread partial
         # sum * nb_proc (thermal_emission.f90:670), the device from the folded global sum plus its
         # workgroup's partial * n_workgroups: same limit, different noise early in a run this
-        # small (8 packets per lane) -> a several-percent shift of the event counts.  The gate on
-        # the physics is the temperature and SED comparison below.
-        assert abs(ca[k] / cb[k] - 1) < 0.10, k
+        # small (8 packets per lane) -> a several-percent shift of the event counts.  Measured
+        # (tests/devtools/live_counts.py, round 4): device / oracle = 1.067 at 1e6 packets and 1.028 at 8e6 (it shrinks
+        # with N as an early-estimate effect must), device seed to seed 0.3 %, the 8-thread oracle seed to seed 3 %
+        # (its per-thread sums are the noisier estimate).  The gate on the physics is the temperature and SED
+        # comparison below.
+        assert abs(ca[k] / cb[k] - 1) < 0.15, k
     Ta, Tb = e.temp_finale(a["E_abs"]), o.temp_finale(b["E_abs"])
     T_floor = 1.01 * m.cfg.T_min
     # sigma_MC(N) ~ 1.7 % sqrt(1.28e5/N) for one run; two independent runs -> sqrt(2)
