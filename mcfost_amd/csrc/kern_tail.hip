@@ -19,17 +19,16 @@ const void* kpick_roles_tail(bool pola, bool dark, bool lds, bool mrw) {
     }); }); }); });
 }
 
-const void* kpick_roles_bin(bool pola, bool dark) {
-  return bsel(pola, [&](auto POLA) { return bsel(dark, [&](auto DARK) -> const void* {
-    return (const void*)k_thermal_roles_bin<MCGPU_BV(POLA), MCGPU_BV(DARK)>;
-  }); });
+const void* kpick_roles_bin(bool pola, bool dark, bool mrw) {
+  return bsel(pola, [&](auto POLA) { return bsel(dark, [&](auto DARK) { return bsel(mrw, [&](auto MRW) -> const void* {
+    return (const void*)k_thermal_roles_bin<MCGPU_BV(POLA), MCGPU_BV(DARK), MCGPU_BV(MRW)>;
+  }); }); });
 }
 
 const void* kpick_tail(bool l3d, bool pola, bool dark, bool mrw) {
   return bsel(l3d, [&](auto L3D) { return bsel(pola, [&](auto POLA) { return bsel(dark, [&](auto DARK) {
     return bsel(mrw, [&](auto MRW) -> const void* {
-      if constexpr (MCGPU_BV(L3D) && MCGPU_BV(MRW)) return nullptr;
-      else return (const void*)k_tail<MCGPU_BV(L3D), MCGPU_BV(POLA), MCGPU_BV(DARK), MCGPU_BV(MRW)>;
+      return (const void*)k_tail<MCGPU_BV(L3D), MCGPU_BV(POLA), MCGPU_BV(DARK), MCGPU_BV(MRW)>;
     }); }); }); });
 }
 

@@ -23,6 +23,10 @@ const void* kpick_voro_var(bool pola, bool mrw) {
     return (const void*)k_thermal_voro_var<MCGPU_BV(POLA), MCGPU_BV(MRW)>;
   }); });
 }
-const void* kpick_voro_roles(bool pola) { return pola ? (const void*)k_thermal_voro_roles<true> : (const void*)k_thermal_voro_roles<false>; }
+const void* kpick_voro_roles(bool pola, bool mrw) {
+  return bsel(pola, [&](auto POLA) { return bsel(mrw, [&](auto MRW) -> const void* {
+    return (const void*)k_thermal_voro_roles<MCGPU_BV(POLA), MCGPU_BV(MRW)>;
+  }); });
+}
 
 }  // namespace mcgpu

@@ -577,6 +577,65 @@ __device__ inline int zj_from_z_real(const Lds& T, int nz, double absz, int ri) 
 
 __device__ inline double modulo_d(double a, double p) { return a - floor(a / p) * p; }
 
+
+// The azimuthal sector of a point, k = floor(phi / 2 pi * n_az) + 1 with phi = modulo(atan2(y, x), 2 pi)
+// (cylindrical_grid.f90:1121-1126, 399-411), decided in default real where that is certain: an arctangent good to 1e-6
+// rad (odd polynomial of the smaller over the larger coordinate: 7e-7 against atan over 2e6 arguments on the host, the
+// reciprocal and the constants' roundings on top) gives the quotient q; unless q lies within delta = 2e-6 n_az + 1e-5 of
+// an integer -- four times the error bound -- floor(q) is the floor of the reference's FP64 expression.  Returns
+// false in that sliver (and for points the conversion loses: NaN compares false), where the caller runs the reference's
+// expression with its atan2 (~170 vector instructions; 1.2 exits from the central hole per packet of ref4.1_3D kept that
+// branch in a fifth of the flying loop's iterations, and every stopping point's index_cell pays one).
+__device__ __forceinline__ bool az_sector_certain(double x, double y, int n_az, int& k) {
+#ifdef MCGPU_NO_FAST_SECTOR   // (A/B builds)
+  k = 0;
+  return false;
+#endif
+  const float xf = (float)x, yf = (float)y;
+  const float ax = fabsf(xf), ay = fabsf(yf);
+  const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+#ifdef MCGPU_LANE_EMULATION
+  const float t = mn / mx;
+#else
+  const float t = mn * __builtin_amdgcn_rcpf(mx);
+#endif
+  const float t2 = t * t;
+  float a = 0.00809729f;
+  a = fmaf(a, t2, -0.03775171f);
+  a = fmaf(a, t2, 0.0847597f);
+  a = fmaf(a, t2, -0.13537675f);
+  a = fmaf(a, t2, 0.19895026f);
+  a = fmaf(a, t2, -0.33327976f);
+  a = fmaf(a, t2, 0.99999972f);
+  a = a * t;
+  a = (ay > ax) ? 1.57079632679f - a : a;
+  a = (xf < 0.0f) ? 3.14159265359f - a : a;
+  a = (yf < 0.0f) ? 6.28318530718f - a : a;
+  const float q = a * ((float)n_az * 0.159154943092f);
+  const float fl = floorf(q);
+  const float fr = q - fl;
+  const float delta = 2.0e-6f * (float)n_az + 1.0e-5f;
+  k = (int)fl + 1;
+  return (fr > delta) && (fr < 1.0f - delta) && (k >= 1) && (k <= n_az);
+}
+
+// The sector of a point, out of line: the callers sit in the flying loop's rare branches (an exit from the central hole,
+// 0.6 % of the crossings) and in the re-indexing of a stopping point, and inlined there the arctangent's temporaries
+// cost the binned 3D role kernel 60 more spilled registers (68 -> 130 at its 168) and 4 % of its speed -- more than the
+// atan2 they replace.  recip_form: phi * (1 / 2 pi) * n_az (the crossing, cylindrical_grid.f90:1125), else phi / (2 pi) * n_az
+// (indice_cellule_3D, :405) -- the reference's two spellings, kept apart for the sliver where they could differ.
+__device__ __attribute__((noinline)) int az_sector(double x, double y, int n_az, bool recip_form) {
+  int k;
+  if (__builtin_expect(!az_sector_certain(x, y, n_az, k), 0)) {
+    const double a = atan2(y, x);
+    const double phi = a - floor(a / (2 * PI)) * (2 * PI);   // (modulo_d)
+    const double q = recip_form ? phi * (1.0 / (2.0 * PI)) * (double)(float)n_az : phi / (2 * PI) * (double)(float)n_az;
+    k = (int)floor(q) + 1;
+    if (k == n_az + 1) k = n_az;
+  }
+  return k;
+}
+
 // index_cell_cyl (cylindrical_grid.f90:833-890) -> (ri,zj,k)
 template <bool L3D>
 __device__ inline void index_cell(const Lds& T, const DevModel& M, double x, double y, double z,
@@ -599,12 +658,7 @@ __device__ inline void index_cell(const Lds& T, const DevModel& M, double x, dou
     k_out = 1;
     if (L3D) {
       if (z < 0.0) zj = -zj;
-      if (z != 0.0) {
-        double phi = modulo_d(atan2(y, x), 2 * PI);
-        int pk = (int)floor(phi / (2 * PI) * (double)(float)M.n_az) + 1;
-        if (pk == M.n_az + 1) pk = M.n_az;
-        k_out = pk;
-      }
+      if (z != 0.0) k_out = az_sector(x, y, M.n_az, false);
     }
     zj_out = zj;
   }
@@ -725,12 +779,7 @@ __device__ inline void cross_cell_lean(const Lds& T, const DevModel& M, double x
       if (L3D && (z1 < 0.0)) zj = -zj;
       zj1 = zj;
     }
-    if (L3D && hole) {
-      const double phi = modulo_d(atan2(y1, x1), 2 * PI);
-      int kk = (int)floor(phi * (1.0 / (2.0 * PI)) * (double)(float)n_az) + 1;
-      if (kk == n_az + 1) kk = n_az;
-      k1 = kk;
-    }
+    if (L3D && hole) k1 = az_sector(x1, y1, n_az, true);
   } else if (vert) {
     zj1 = zj0 + delta_zj;
     if (L3D && M.midplane_snap && (delta_zj == 2 || delta_zj == -2)) z1 = copysign(GRID_PREC, w);
@@ -839,12 +888,7 @@ __device__ inline void sph_theta_phi(const DevModel& M, double x, double y, doub
   k_out = 1;
   if (L3D) {
     if (z < 0.0) tj_out = -tj_out;
-    if (z != 0.0) {
-      const double phi = modulo_d(atan2(y, x), 2 * PI);
-      int pk = (int)floor(phi / (2 * PI) * (double)(float)M.n_az) + 1;
-      if (pk == M.n_az + 1) pk = M.n_az;
-      k_out = pk;
-    }
+    if (z != 0.0) k_out = az_sector(x, y, M.n_az, false);
   }
 }
 
@@ -1661,11 +1705,14 @@ template <typename DistFn, typename EnergyFn, typename DepositFn>
 __device__ inline bool mrw_walk_with(const Lds& T, const DevModel& M, uint32_t k0, uint32_t k1, uint32_t p_lo, uint32_t p_hi,
                                      uint32_t event, int ic, double kf, double S0, double& x, double& y, double& z,
                                      double& u, double& v, double& w, int& lambda, DistFn closest_wall, EnergyFn cell_energy,
-                                     DepositFn add_energy, unsigned int& c_walks, unsigned int& c_steps, int wl = -1) {
+                                     DepositFn add_energy, unsigned int& c_walks, unsigned int& c_steps, int wl = -1,
+                                     int Ti0 = 0, double frac0 = 0.0) {
   double d = closest_wall(x, y, z);
-  int Ti;
-  double frac;
-  temp_lte(T.lq, M.n_T, cell_energy(), M.L_packet_th, M.volume[ic], Ti, frac, wl);
+  int Ti = Ti0;
+  double frac = frac0;
+  // (Ti0 > 0: the caller has the cell's temperature bracket from the absorption that precedes the walk -- same cell, same
+  // energy, same expression: k_tail hands it over instead of paying a logarithm and a search twice per event)
+  if (Ti0 <= 0) temp_lte(T.lq, M.n_T, cell_energy(), M.L_packet_th, M.volume[ic], Ti, frac, wl);
   // (lvariable_dust: the mean opacities of the cell's class, [n_classes][n_T]; T then holds the class's lq / cdf)
   const size_t co = M.n_classes ? (size_t)M.cell_class[ic] * M.n_T : 0;
   const double *t_chi = M.mrw_chi + co, *t_kdep = M.mrw_kdep + co, *t_ext = M.mrw_ext + co;
@@ -1720,10 +1767,11 @@ template <typename EnergyFn, typename DepositFn>
 __device__ inline bool mrw_walk(const Lds& T, const DevModel& M, uint32_t k0, uint32_t k1, uint32_t p_lo, uint32_t p_hi,
                                 uint32_t event, int ri, int zj, int ic, double S0, double& x, double& y, double& z,
                                 double& u, double& v, double& w, int& lambda, EnergyFn cell_energy,
-                                DepositFn add_energy, unsigned int& c_walks, unsigned int& c_steps, int kaz = 1, int wl = -1) {
+                                DepositFn add_energy, unsigned int& c_walks, unsigned int& c_steps, int kaz = 1, int wl = -1,
+                                int Ti0 = 0, double frac0 = 0.0) {
   return mrw_walk_with(T, M, k0, k1, p_lo, p_hi, event, ic, M.kappa_factor[ic], S0, x, y, z, u, v, w, lambda,
                        [&](double px, double py, double pz) { return distance_to_closest_wall_cyl(T, M, ri, zj, px, py, pz, kaz); },
-                       cell_energy, add_energy, c_walks, c_steps, wl);
+                       cell_energy, add_energy, c_walks, c_steps, wl, Ti0, frac0);
 }
 
 // ---------------------------------------------------------------------------

@@ -18,7 +18,7 @@ const void* kpick_roles(bool l3d, bool pola, bool dark, bool lds, bool mrw);
 // kern_tail.hip: the kernels of a launch's end -- k_thermal_roles_tail (2D, hands packets over), k_thermal_roles_bin
 // (3D, binned deposits, chunks), k_tail (one packet per wave)
 const void* kpick_roles_tail(bool pola, bool dark, bool lds, bool mrw);
-const void* kpick_roles_bin(bool pola, bool dark);
+const void* kpick_roles_bin(bool pola, bool dark, bool mrw);
 const void* kpick_tail(bool l3d, bool pola, bool dark, bool mrw);
 // kern_var.hip / kern_var_single.hip: lvariable_dust -- k_thermal_roles_var, k_thermal_var
 const void* kpick_roles_var(bool l3d, bool pola, bool dark, bool lds);
@@ -28,7 +28,7 @@ const void* kpick_voro_cache(bool pola, int block);
 const void* kpick_voro(bool pola);
 const void* kpick_voro_mrw(bool pola);
 const void* kpick_voro_var(bool pola, bool mrw);
-const void* kpick_voro_roles(bool pola);
+const void* kpick_voro_roles(bool pola, bool mrw);
 // kern_mono.hip / kern_mono_other.hip: the SED / image Monte Carlo -- k_mono, k_mono_sph, k_mono_voro
 const void* kpick_mono(bool l3d, bool pola, bool dark, bool scout, bool f32);
 const void* kpick_mono_sph(bool l3d, bool pola, bool scout, bool f32);

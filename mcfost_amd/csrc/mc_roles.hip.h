@@ -440,7 +440,8 @@ __device__ __forceinline__ int fly_step_2d(const Lds& T, const DevModel& M, cons
 // default-real zj and an atan2, ~250 vector instructions) is NOT done here, where it would run in almost every iteration
 // of the flying loop for the two or three lanes of 64 that stop in it, but by the interaction that follows, which runs
 // for the stopped packets together; the packet carries the request as a negative azimuthal index k.
-template <bool DARK, bool LDSE, bool BIN, bool VAR = false, bool DEFER = false>
+// MRW: bit 31 of the crossing counter remembers that the flight has left the cell it started in (fly_step_2d).
+template <bool DARK, bool LDSE, bool BIN, bool VAR = false, bool DEFER = false, bool MRW = false>
 __device__ __forceinline__ int fly_step_3d(const Lds& T, const DevModel& M, const RunArgs& A, double* E_lds, Flight& p,
                                            unsigned int& c_cross, unsigned int& c_kill, unsigned int& c_dark, int& dep_ic,
                                            double& dep_v) {
@@ -544,9 +545,7 @@ __device__ __forceinline__ int fly_step_3d(const Lds& T, const DevModel& M, cons
   k1 = (rad && ri1 == 0) ? 1 : k1;
   if (__builtin_expect(go && rad && hole, 0)) {  // out of the central hole: the azimuth of the landing point (:1121-1126)
     const double x1h = x0 + dv * u, y1h = y0 + dv * v;
-    const double phi = modulo_d(atan2(y1h, x1h), 2 * PI);
-    int kh = (int)floor(phi * (1.0 / (2.0 * PI)) * (double)(float)n_az) + 1;
-    k1 = (kh == n_az + 1) ? n_az : kh;
+    k1 = az_sector(x1h, y1h, n_az, true);
   }
   const bool snap = vert && (M.midplane_snap != 0) && (delta_zj == 2 || delta_zj == -2);
   z1 = (snap || z1 == 0.0) ? copysign(GRID_PREC, w) : z1;
@@ -604,7 +603,8 @@ __device__ __forceinline__ int fly_step_3d(const Lds& T, const DevModel& M, cons
   c_cross += go ? 1u : 0u;
   c_kill += (active && !out && killed) ? 1u : 0u;
   p.pk_cross += go ? 1u : 0u;
-  const bool runaway = go && (p.pk_cross > 200000000u);  // a packet that never leaves: flag it, drop it
+  if (MRW) p.pk_cross |= (move || mirror) ? 0x80000000u : 0u;
+  const bool runaway = go && ((MRW ? (p.pk_cross & 0x7FFFFFFFu) : p.pk_cross) > 200000000u);  // a packet that never leaves: flag it, drop it
   if (runaway) { *A.err = 13; st = S_EMIT; }
   p.st = st;
   return ((active && !out && killed) || runaway) ? 1 : 0;
@@ -612,7 +612,7 @@ __device__ __forceinline__ int fly_step_3d(const Lds& T, const DevModel& M, cons
 
 // One cell crossing of a packet in flight on a Voronoi grid (the crossing of thermal_body_voro, mc_voronoi.hip.h, on a
 // Flight): p.ri = the cell, p.zj = the cell it came from, p.star_key = the cell of the star on the way (0: none).
-template <bool CACHE>
+template <bool CACHE, bool MRW = false>
 __device__ inline int voro_roles_cross(const Lds& T, const DevModel& M, const RunArgs& A, const VoroGrid& G,
                                        const DepCache& DC, Flight& p, unsigned int& c_cross, unsigned int& c_kill) {
   const int icell = p.ri;
@@ -642,8 +642,10 @@ __device__ inline int voro_roles_cross(const Lds& T, const DevModel& M, const Ru
     p.x = x1; p.y = y1; p.z = z1;
     p.zj = icell;
     p.ri = next;
+    if (MRW) p.pk_cross |= 0x80000000u;   // (the flight has left the cell it started in, see fly_step_2d)
   }
-  if (++p.pk_cross > 200000000u) { *A.err = 13; p.st = S_EMIT; return 1; }  // a packet that never leaves: flag it, drop it
+  ++p.pk_cross;
+  if ((MRW ? (p.pk_cross & 0x7FFFFFFFu) : p.pk_cross) > 200000000u) { *A.err = 13; p.st = S_EMIT; return 1; }  // a packet that never leaves: flag it, drop it
   return 0;
 }
 
@@ -667,8 +669,9 @@ template <bool L3D, bool POLA, bool DARK, bool LDSE, bool MRW = false, bool VORO
 __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, double* lds_base, int n_rec, int n_srv_pref,
                                            int k_short, int fly_iters, int fly_idle, int emit_qmax,
                                            const VoroGrid* Gp = nullptr, int cache_log_ns = 0) {
-  static_assert(!VORO || (L3D && !DARK && !LDSE && !MRW), "Voronoi variant");
-  static_assert(!BIN || (!LDSE && !MRW && !VORO), "binned deposits: grids that do not fit in LDS");
+  static_assert(!VORO || (L3D && !DARK && !LDSE), "Voronoi variant");
+  static_assert(!BIN || (!LDSE && !VORO), "binned deposits: grids that do not fit in LDS");
+  static_assert(!(L3D && MRW) || BIN || VORO, "the walk on 3D grids: the binned role kernel");
   static_assert(!BIN || CARRY, "the chunks of a binned run hand their packets on");
   static_assert(!CARRY || !VORO, "no carry-over on Voronoi grids");
   static_assert(!VAR || (!MRW && !VORO && !BIN && !CARRY), "variable dust: the plain role kernel on cylindrical grids");
@@ -884,12 +887,12 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
           if (it > 0 && __popcll(__ballot(F.st != S_FLIGHT)) >= fly_idle) break;
           RQ_DIAG(if (lane == 0) d_fly_iters++; if (F.st == S_FLIGHT) d_fly_cross++;)
           if (VORO) {
-            if (F.st == S_FLIGHT) finished += voro_roles_cross<true>(T, M, A, *Gp, DC, F, c_cross, c_kill);
+            if (F.st == S_FLIGHT) finished += voro_roles_cross<true, MRW>(T, M, A, *Gp, DC, F, c_cross, c_kill);
           } else if (L3D) {
             int dep_ic = -1;
             double dep_v = 0.0;
             if (MCGPU_3D_BRANCHY) { if (F.st == S_FLIGHT) finished += roles_cross<L3D, DARK, LDSE, BIN>(T, M, A, E_lds, F, c_cross, c_kill, c_dark, dep_ic, dep_v); }
-            else finished += fly_step_3d<DARK, LDSE, BIN, VAR, true>(T, M, A, E_lds, F, c_cross, c_kill, c_dark, dep_ic, dep_v);
+            else finished += fly_step_3d<DARK, LDSE, BIN, VAR, true, MRW>(T, M, A, E_lds, F, c_cross, c_kill, c_dark, dep_ic, dep_v);
             if (BIN) bin_deposit(BS, A.bin, A.E_abs, lane, BP, dep_ic >= 0, dep_ic, dep_v);
           } else {
             finished += fly_step_2d<DARK, LDSE, MRW, false, VAR>(T, M, A, E_lds, F, c_cross, c_kill, c_dark);
@@ -1089,24 +1092,47 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
             const int fl = recs[rid].flags;
             walk = !(fl & (ST_SCATT | ST_STAR)) && ((fl >> ST_NINT_SHIFT) & 7) > M.mrw_n_inter;
           }
+          // BIN: a walk stays in its cell, so its deposits (two or three steps) are summed here and logged as ONE deposit
+          // by the whole wave below (bin_deposit wants converged control flow); the walk's own temperature sees them
+          int walk_ic = -1;
+          double walk_dep = 0.0;
           if (__builtin_expect(walk, 0)) {  // (rare: the hint keeps its registers out of the common path, +5 % with no walks)
             Rec<POLA>& R = recs[rid];
-            const int ic = cell_index<L3D>(n_rad, nz, R.ri, R.zj, R.k);
+            const int ic = VORO ? R.ri - 1 : cell_index<L3D>(n_rad, nz, R.ri, R.zj, R.k);
             double x = R.x, y = R.y, z = R.z, u = R.u, v = R.v, w = R.w;
             int lambda = R.lambda;
-            const bool done = mrw_walk(T, M, key0, key1, R.p_lo, R.p_hi, R.event, R.ri, R.zj, ic, R.S[0], x, y, z, u, v, w, lambda,
+            bool done;
+            if (VORO) {   // (distance_to_closest_wall_Voronoi, the deposit cache: as k_thermal_voro_mrw, mc_voronoi.hip.h)
+              const VoroCell C = Gp->cell[ic];
+              done = mrw_walk_with(T, M, key0, key1, R.p_lo, R.p_hi, R.event, ic, C.kf, R.S[0], x, y, z, u, v, w, lambda,
+                [&](double px, double py, double pz) { return voro_distance_to_closest_wall(*Gp, C, px, py, pz); },
+                [&]() {
+                  if (A.frozen) return A.E_prior[ic];
+                  double E = __hip_atomic_load(&A.E_abs[ic], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  E += DC.pending(ic + 1) * (double)gridDim.x;
+                  return E * A.qscale;
+                },
+                [&](double e) { if (!DC.add(ic + 1, e)) atomic_add_f64(&A.E_abs[ic], e); }, c_walks, c_steps);
+            } else
+            done = mrw_walk(T, M, key0, key1, R.p_lo, R.p_hi, R.event, R.ri, R.zj, ic, R.S[0], x, y, z, u, v, w, lambda,
               [&]() {
                 double E;
                 if (A.frozen) E = A.E_prior[ic];
                 else {
                   E = __hip_atomic_load(&A.E_abs[ic], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                   if (LDSE) E += E_lds[ic] * (double)gridDim.x;
+                  if (BIN) E = E * bin_energy_scale(A) + walk_dep;
                   E *= A.qscale;
                 }
                 return E;
               },
-              [&](double e) { deposit<LDSE>(A.E_abs, E_lds, ic, e); }, c_walks, c_steps);
+              [&](double e) { if (BIN) walk_dep += e; else deposit<LDSE>(A.E_abs, E_lds, ic, e); }, c_walks, c_steps, L3D ? R.k : 1);
             if (done) { R.x = x; R.y = y; R.z = z; R.u = u; R.v = v; R.w = w; R.lambda = lambda; }
+            walk_ic = ic;
+          }
+          if (BIN) {
+            bin_deposit(BS, A.bin, A.E_abs, lane, BP, walk_ic >= 0 && walk_dep != 0.0, walk_ic, walk_dep);
+            bin_settle(BS, A.bin, A.E_abs, lane, BP);
           }
           RQ_PHASE_END();
         }
@@ -1147,12 +1173,12 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
             if (__ballot(F.st == S_FLIGHT) == 0ull) break;
             RQ_DIAG(if (lane == 0) d_srv_iters++;)
             if (VORO) {
-              if (F.st == S_FLIGHT) finished += voro_roles_cross<true>(T, M, A, *Gp, DC, F, c_cross, c_kill);
+              if (F.st == S_FLIGHT) finished += voro_roles_cross<true, MRW>(T, M, A, *Gp, DC, F, c_cross, c_kill);
             } else if (L3D) {
               int dep_ic = -1;
               double dep_v = 0.0;
               if (MCGPU_3D_BRANCHY) { if (F.st == S_FLIGHT) finished += roles_cross<L3D, DARK, LDSE, BIN>(T, M, A, E_lds, F, c_cross, c_kill, c_dark, dep_ic, dep_v); }
-              else finished += fly_step_3d<DARK, LDSE, BIN, VAR, true>(T, M, A, E_lds, F, c_cross, c_kill, c_dark, dep_ic, dep_v);
+              else finished += fly_step_3d<DARK, LDSE, BIN, VAR, true, MRW>(T, M, A, E_lds, F, c_cross, c_kill, c_dark, dep_ic, dep_v);
               if (BIN) bin_deposit(BS, A.bin, A.E_abs, lane, BP, dep_ic >= 0, dep_ic, dep_v);
             } else {
               finished += fly_step_2d<DARK, LDSE, MRW, false, VAR>(T, M, A, E_lds, F, c_cross, c_kill, c_dark);
@@ -1358,21 +1384,21 @@ __global__ void __launch_bounds__(MCGPU_ROLES_BLOCK) k_thermal_roles_tail(const 
 #ifndef MCGPU_ROLES_BIN_BLOCK
 #define MCGPU_ROLES_BIN_BLOCK 768  // 168 VGPRs, 3 waves per SIMD: the 3D crossing + the staging do not fit into 128 registers
 #endif
-template <bool POLA, bool DARK>
+template <bool POLA, bool DARK, bool MRW = false>
 __global__ void __launch_bounds__(MCGPU_ROLES_BIN_BLOCK) k_thermal_roles_bin(const DevModel M, const RunArgs A, int n_rec, int n_srv_pref,
                                                                          int k_short, int fly_iters, int fly_idle, int emit_qmax) {
   extern __shared__ double lds_raw[];
-  roles_body<true, POLA, DARK, false, false, false, true>(M, A, lds_raw, n_rec, n_srv_pref, k_short, fly_iters, fly_idle, emit_qmax);
+  roles_body<true, POLA, DARK, false, MRW, false, true>(M, A, lds_raw, n_rec, n_srv_pref, k_short, fly_iters, fly_idle, emit_qmax);
 }
 
 // the role schedule on a Voronoi grid
-template <bool POLA>
+template <bool POLA, bool MRW = false>
 __global__ void __launch_bounds__(MCGPU_ROLES_BLOCK) k_thermal_voro_roles(const DevModel M, const RunArgs A, const VoroGrid G,
                                                                           int cache_log_ns, int n_rec, int n_srv_pref, int k_short,
                                                                           int fly_iters, int fly_idle, int emit_qmax) {
   extern __shared__ double lds_raw[];
-  roles_body<true, POLA, false, false, false, true>(M, A, lds_raw, n_rec, n_srv_pref, k_short, fly_iters, fly_idle, emit_qmax,
-                                                    &G, cache_log_ns);
+  roles_body<true, POLA, false, false, MRW, true>(M, A, lds_raw, n_rec, n_srv_pref, k_short, fly_iters, fly_idle, emit_qmax,
+                                                  &G, cache_log_ns);
 }
 
 }  // namespace mcgpu

@@ -180,6 +180,8 @@ __device__ __forceinline__ void tail_packet(const Lds& T, const DevModel& M, con
       const int lambda_in = lambda;
       int itheta = 1;
       double cospsi, sphi, cphi;
+      int abs_Ti = 0;            // (an absorption's temperature bracket, for the walk that may follow it)
+      double abs_frac = 0.0;
       if (scat) {
         flag_scatt = true;
         c_scatt++;
@@ -220,6 +222,7 @@ __device__ __forceinline__ void tail_packet(const Lds& T, const DevModel& M, con
             frac_T2 = (log_Qheat - T.lq[Ti - 2]) / (T.lq[Ti - 1] - T.lq[Ti - 2]);
           }
         }
+        abs_Ti = Ti; abs_frac = frac_T2;
         {  // reemission_wavelength: the first l in [1, n_lambda) whose interpolated CDF reaches the draw, else n_lambda
           const double frac_T1 = 1.0 - frac_T2;
           const double* cdf1 = T.cdf + (size_t)M.n_lambda * (Ti - 2);
@@ -261,7 +264,8 @@ __device__ __forceinline__ void tail_packet(const Lds& T, const DevModel& M, con
           int lam2 = lambda;
           const bool done = mrw_walk(T, M, key0, key1, p_lo, p_hi, event, F.ri, F.zj, ic, F.S0, x, y, z, u, v, w, lam2,
                                      [&]() { return cell_energy(ic); },
-                                     [&](double e) { add_energy(ic, e); }, c_walks, c_steps, 1, lane);   // (lane: wave-wide searches)
+                                     [&](double e) { add_energy(ic, e); }, c_walks, c_steps, L3D ? F.k : 1, lane,   // (lane: wave-wide searches)
+                                     abs_Ti, abs_frac);
           if (done) { F.x = x; F.y = y; F.z = z; F.u = u; F.v = v; F.w = w; lambda = lam2; }
         }
       }
@@ -286,7 +290,7 @@ __device__ __forceinline__ void tail_packet(const Lds& T, const DevModel& M, con
       while (F.st == S_FLIGHT) {
         int dep_ic = -1;
         double dep_v = 0.0;
-        if (L3D) killed += fly_step_3d<DARK, false, true>(T, M, A, nullptr, F, c_cross, c_kill, c_dark, dep_ic, dep_v);
+        if (L3D) killed += fly_step_3d<DARK, false, true, false, false, MRW>(T, M, A, nullptr, F, c_cross, c_kill, c_dark, dep_ic, dep_v);
         else killed += fly_step_2d<DARK, false, MRW, true>(T, M, A, nullptr, F, c_cross, c_kill, c_dark, &dep_ic, &dep_v);
         if (dep_ic >= 0) add_energy(dep_ic, dep_v);
       }

@@ -1226,7 +1226,7 @@ static int launch_tail(mcgpu_ctx* ctx, const RunArgs& A, const void* carry, cons
   if (per_cu < 1) per_cu = 1;
   if (per_cu > 8) per_cu = 8;
   const int blocks = ctx->prop.multiProcessorCount * per_cu;
-  const void* fn = kpick_tail(l3d, pola, dark, !l3d && mrw);
+  const void* fn = kpick_tail(l3d, pola, dark, mrw);
   HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   HIPCHK(hipMemsetAsync(ctx->d_tail_next, 0, sizeof(unsigned int), ctx->stream));
   HIPCHK(hipEventRecord(ctx->ev_tail, ctx->stream));   // (what follows is the launch's tail: mcgpu_get_info "tail_ms")
@@ -1407,26 +1407,8 @@ static int launch_voro(mcgpu_ctx* ctx, const RunArgs& A, int grid_blocks, int bl
     HIPCHK(hipLaunchKernel(fn, dim3(blocks), dim3(threads), args, lds, ctx->stream));
     return MCGPU_OK;
   }
-  if (M.mrw) {  // the random walk: the single-role kernel with HBM deposits
-    const bool pola = ctx->lsepar_pola != 0;
-    const int threads = (block_threads > 0 && block_threads <= 256) ? block_threads : 256;
-    if (threads % 64) return fail(ctx, MCGPU_ERR_ARG, "block_threads must be a multiple of 64");
-    const void* fn = kpick_voro_mrw(pola);
-    HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t));
-    int blocks = grid_blocks;
-    if (blocks <= 0) {
-      int occ = 1;
-      HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, threads, lds_t));
-      if (occ < 1) occ = 1;
-      blocks = ctx->prop.multiProcessorCount * occ;
-      const unsigned long long need = (A.n_packets + threads - 1) / threads;
-      if ((unsigned long long)blocks > need) blocks = (int)(need ? need : 1);
-    }
-    void* args[] = {(void*)&M, (void*)&A, (void*)&ctx->V};
-    HIPCHK(hipLaunchKernel(fn, dim3(blocks), dim3(threads), args, lds_t, ctx->stream));
-    return MCGPU_OK;
-  }
-  if (ctx->opt_schedule == 2 && ctx->opt_deposit != 1 && !A.xN_abs && !A.xJ_abs) {
+  const bool voro_roles = ctx->opt_schedule == 2 && ctx->opt_deposit != 1 && !A.xN_abs && !A.xJ_abs;
+  if (voro_roles) {
     const bool pola = ctx->lsepar_pola != 0;
     int log_ns = ctx->opt_cache_log_slots, n_rec = 0;
     for (; log_ns >= 6; --log_ns) {
@@ -1445,13 +1427,32 @@ static int launch_voro(mcgpu_ctx* ctx, const RunArgs& A, int grid_blocks, int bl
       int n_srv_pref = tune("MCGPU_N_SRV", (rthreads / 64 + 1) / 2, 1, 1016);  // (this grid's packets interact as often as they cross)
       int k_short = tune("MCGPU_K_SHORT", 2, 0, 64), fly_iters = tune("MCGPU_FLY_ITERS", 16, 1, 256);
       int fly_idle = tune("MCGPU_FLY_IDLE", 32, 1, 65), emit_qmax = tune("MCGPU_EMIT_QMAX", 128, 0, 1 << 20);
-      const void* fn = kpick_voro_roles(pola);
+      const void* fn = kpick_voro_roles(pola, M.mrw != 0);
       HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));
       void* args[] = {(void*)&M, (void*)&A, (void*)&ctx->V, (void*)&log_ns, (void*)&n_rec, (void*)&n_srv_pref, (void*)&k_short,
                       (void*)&fly_iters, (void*)&fly_idle, (void*)&emit_qmax};
       HIPCHK(hipLaunchKernel(fn, dim3(rblocks), dim3(rthreads), args, lds_r, ctx->stream));
       return MCGPU_OK;
     }
+  }
+  if (M.mrw) {  // the random walk: the single-role kernel with HBM deposits (schedule 2: the role kernel above, where it fits)
+    const bool pola = ctx->lsepar_pola != 0;
+    const int threads = (block_threads > 0 && block_threads <= 256) ? block_threads : 256;
+    if (threads % 64) return fail(ctx, MCGPU_ERR_ARG, "block_threads must be a multiple of 64");
+    const void* fn = kpick_voro_mrw(pola);
+    HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t));
+    int blocks = grid_blocks;
+    if (blocks <= 0) {
+      int occ = 1;
+      HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, threads, lds_t));
+      if (occ < 1) occ = 1;
+      blocks = ctx->prop.multiProcessorCount * occ;
+      const unsigned long long need = (A.n_packets + threads - 1) / threads;
+      if ((unsigned long long)blocks > need) blocks = (int)(need ? need : 1);
+    }
+    void* args[] = {(void*)&M, (void*)&A, (void*)&ctx->V};
+    HIPCHK(hipLaunchKernel(fn, dim3(blocks), dim3(threads), args, lds_t, ctx->stream));
+    return MCGPU_OK;
   }
   bool cache = ctx->opt_deposit != 1;
   int log_ns = 0;
@@ -1494,11 +1495,11 @@ static int launch_voro(mcgpu_ctx* ctx, const RunArgs& A, int grid_blocks, int bl
 // ---------------------------------------------------------------------------------------------
 // Binned deposits (mc_binned.hip.h): 3D cylindrical grids -- the absorbed-energy array does not fit in LDS
 // ---------------------------------------------------------------------------------------------
-// can this context's thermal step run with binned deposits?  (cylindrical 3D grids, one dust class, no MRW; the
-// optional radiation-field arrays are kept by the single-role kernel)
+// can this context's thermal step run with binned deposits?  (cylindrical 3D grids, one dust class -- with the random
+// walk since round 4: k_thermal_roles_bin<..., MRW> --; the optional radiation-field arrays are kept by the single-role kernel)
 static bool bin_applicable(const mcgpu_ctx* ctx, const RunArgs& A) {
   const DevModel& M = ctx->M;
-  if (ctx->voro || M.grid_sph || M.n_classes || M.mrw || !M.l3D || A.xN_abs || A.xJ_abs) return false;
+  if (ctx->voro || M.grid_sph || M.n_classes || !M.l3D || A.xN_abs || A.xJ_abs) return false;
   if (ctx->opt_schedule == 1) return false;
   return true;
 }
@@ -1585,7 +1586,7 @@ static int launch_binned(mcgpu_ctx* ctx, RunArgs A, const mcgpu_run_opts* o) {
   if (n_rec > 2 * rthreads) n_rec = 2 * rthreads > RQ_MIN_REC ? 2 * rthreads : RQ_MIN_REC;
   if (n_rec <= 0) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "binned deposits: the staging buckets and the packet records do not fit in LDS");
   const size_t lds_r = lds_t + lds_b + rq_lds_bytes(pola, n_rec);
-  const void* fn = kpick_roles_bin(pola, dark);
+  const void* fn = kpick_roles_bin(pola, dark, M.mrw != 0);
   if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r) != hipSuccess) {
     ctx->err = "binned deposits: LDS request of " + std::to_string(lds_r) + " bytes refused (tables " + std::to_string(lds_t) +
                ", staging " + std::to_string(lds_b) + ", records " + std::to_string(n_rec) + ")";
@@ -1655,7 +1656,7 @@ static int launch_binned(mcgpu_ctx* ctx, RunArgs A, const mcgpu_run_opts* o) {
     if (done + c >= n_total && tail_thr > 0) {  // behind the fold: E_abs is complete but for these packets' own deposits
       RunArgs At = A;
       At.n_folded = 0.0;
-      if ((rc = launch_tail(ctx, At, A.carry_out, A.carry_out_n, true, false))) return rc;
+      if ((rc = launch_tail(ctx, At, A.carry_out, A.carry_out_n, true, M.mrw != 0))) return rc;
     }
     done += c;
     last_chunk = c;

@@ -169,6 +169,7 @@ struct Conv {
     M.mrw = m->mrw; M.mrw_n_zeta = m->mrw_n_zeta; M.mrw_n_inter = m->mrw_n_inter; M.mrw_gamma = m->mrw_gamma;
     M.mrw_zeta = m->mrw_zeta; M.mrw_chi = m->mrw_chi; M.mrw_kdep = m->mrw_kappa_dep; M.mrw_ext = m->mrw_ext; M.mrw_exit_cdf = m->mrw_exit_cdf;
     M.r_lim = m->r_lim;
+    M.sin_phi = m->sin_phi_lim; M.cos_phi = m->cos_phi_lim;   // (the walk's azimuthal walls, 3D)
     M.n_classes = m->p_n_cells;
     if (m->p_n_cells) {  // class-major copies, as mcgpu_set_variable_dust lays them out
       const int nc = m->p_n_cells, nl = m->n_lambda;
@@ -235,7 +236,9 @@ extern "C" int emu_run_thermal(const oracle_model* m, const oracle_opts* o, cons
     const int n_rec = RQ_MIN_REC, log_ns = 6;
     if (lds_bytes(M) + ((size_t)12 << log_ns) + rq_lds_bytes(true, n_rec) + 64 > sizeof(lds_raw)) return 31;
     A.flush_every = 4;
-    if (pola) k_thermal_voro_roles<true>(M, A, G, log_ns, n_rec, nsp, ks, fi, 65, eq);
+    if (M.mrw) { if (pola) k_thermal_voro_roles<true, true>(M, A, G, log_ns, n_rec, nsp, ks, fi, 65, eq);
+                 else k_thermal_voro_roles<false, true>(M, A, G, log_ns, n_rec, nsp, ks, fi, 65, eq); }
+    else if (pola) k_thermal_voro_roles<true>(M, A, G, log_ns, n_rec, nsp, ks, fi, 65, eq);
     else k_thermal_voro_roles<false>(M, A, G, log_ns, n_rec, nsp, ks, fi, 65, eq);
     for (int q = 0; q < ORACLE_N_COUNTERS; ++q) counters[q] = cnt[q];
     return err;
@@ -247,7 +250,9 @@ extern "C" int emu_run_thermal(const oracle_model* m, const oracle_opts* o, cons
     return err;
   }
   if (voro) {
-    if (getenv("MCGPU_EMU_LDS")) {  // deposit cache, few slots so that hits, misses and folds all occur
+    if (M.mrw) {   // the walk: the single-role kernel with HBM deposits
+      if (pola) k_thermal_voro_mrw<true>(M, A, G); else k_thermal_voro_mrw<false>(M, A, G);
+    } else if (getenv("MCGPU_EMU_LDS")) {  // deposit cache, few slots so that hits, misses and folds all occur
       if (pola) k_thermal_voro_cache<true, 512>(M, A, G, 6); else k_thermal_voro_cache<false, 512>(M, A, G, 6);
     } else {
       if (pola) k_thermal_voro<true>(M, A, G); else k_thermal_voro<false>(M, A, G);
@@ -278,7 +283,7 @@ extern "C" int emu_run_thermal(const oracle_model* m, const oracle_opts* o, cons
   if (getenv("MCGPU_EMU_BIN")) {
     // Binned deposits with chunks (mcgpu.hip::launch_binned on one lane): MCGPU_EMU_BIN = "<packets per chunk>,<log blocks>,
     // <n_srv_pref>,<k_short>,<fly_iters>".  Every chunk but the last hands its unfinished packets on (carry_*).
-    if (!l3d || M.mrw || M.n_classes) return 31;
+    if (!l3d || M.n_classes) return 31;
     long chunk = 1000, log_blocks = 64;
     int nsp = 1, ks = 2, fi = 3, tail_thr = 0;   // tail_thr > 0: the last chunk hands its last packets to k_tail
     sscanf(getenv("MCGPU_EMU_BIN"), "%ld,%ld,%d,%d,%d,%d", &chunk, &log_blocks, &nsp, &ks, &fi, &tail_thr);
@@ -316,8 +321,10 @@ extern "C" int emu_run_thermal(const oracle_model* m, const oracle_opts* o, cons
       A.carry_cap = (unsigned int)carry_cap;
       A.tail_threshold = to_tail ? tail_thr : 0;
       carry_n[out] = 0u;
-      if (pola) { if (dark) k_thermal_roles_bin<true, true>(M, A, n_rec, nsp, ks, fi, 65, 128); else k_thermal_roles_bin<true, false>(M, A, n_rec, nsp, ks, fi, 65, 128); }
-      else { if (dark) k_thermal_roles_bin<false, true>(M, A, n_rec, nsp, ks, fi, 65, 128); else k_thermal_roles_bin<false, false>(M, A, n_rec, nsp, ks, fi, 65, 128); }
+#define RUNB(b, c) do { if (M.mrw) k_thermal_roles_bin<b, c, true>(M, A, n_rec, nsp, ks, fi, 65, 128); else k_thermal_roles_bin<b, c, false>(M, A, n_rec, nsp, ks, fi, 65, 128); } while (0)
+      if (pola) { if (dark) RUNB(true, true); else RUNB(true, false); }
+      else { if (dark) RUNB(false, true); else RUNB(false, false); }
+#undef RUNB
       if (err) return err;
       for (int b = 0; b < nb; ++b) { blockIdx.x = (unsigned)b; k_fold_bins(L, E_abs, m->n_cells, 1); }
       blockIdx.x = 0;
@@ -325,8 +332,10 @@ extern "C" int emu_run_thermal(const oracle_model* m, const oracle_opts* o, cons
         unsigned int next = 0u;
         RunArgs At = A;
         At.n_folded = 0.0;
-        if (pola) { if (dark) k_tail<true, true, true, false>(M, At, carry[out].data(), &carry_n[out], &next); else k_tail<true, true, false, false>(M, At, carry[out].data(), &carry_n[out], &next); }
-        else { if (dark) k_tail<true, false, true, false>(M, At, carry[out].data(), &carry_n[out], &next); else k_tail<true, false, false, false>(M, At, carry[out].data(), &carry_n[out], &next); }
+#define RUNK(b, c) do { if (M.mrw) k_tail<true, b, c, true>(M, At, carry[out].data(), &carry_n[out], &next); else k_tail<true, b, c, false>(M, At, carry[out].data(), &carry_n[out], &next); } while (0)
+        if (pola) { if (dark) RUNK(true, true); else RUNK(true, false); }
+        else { if (dark) RUNK(false, true); else RUNK(false, false); }
+#undef RUNK
         if (err) return err;
         if (getenv("MCGPU_EMU_BIN_STATS")) fprintf(stderr, "tail: %u packets\n", carry_n[out]);
       }
@@ -633,5 +642,20 @@ extern "C" int emu_rt1_image(const oracle_model* m, const oracle_rt_opts* o, int
   else if (m->l3D) { if (pola) k_rt1_image<true, true>(E.cv.M, E.A); else k_rt1_image<true, false>(E.cv.M, E.A); }
   else { if (pola) k_rt1_image<false, true>(E.cv.M, E.A); else k_rt1_image<false, false>(E.cv.M, E.A); }
   if (n_rays) *n_rays = (int)rays;
+  return 0;
+}
+
+// az_sector_certain (mc_device.hip.h) beside the reference's expression for the azimuthal sector of a point
+// (cylindrical_grid.f90:1121-1126): certain[i] = the default-real decision claimed certainty, k_fast / k_ref the two sectors.
+extern "C" int emu_az_sector(int n, int n_az, const double* x, const double* y, int* k_fast, int* k_ref, int* certain) {
+  for (int i = 0; i < n; ++i) {
+    int kf = 0;
+    certain[i] = az_sector_certain(x[i], y[i], n_az, kf) ? 1 : 0;
+    k_fast[i] = kf;
+    const double phi = modulo_d(atan2(y[i], x[i]), 2 * PI);
+    int kk = (int)floor(phi * (1.0 / (2.0 * PI)) * (double)(float)n_az) + 1;
+    if (kk == n_az + 1) kk = n_az;
+    k_ref[i] = kk;
+  }
   return 0;
 }

@@ -98,6 +98,35 @@ def test_emulated_cross_cell_against_reference_golden(emu, name):
             assert np.all(np.abs(a - b) <= 1e-13 * scale)
 
 
+def test_azimuthal_sector_in_default_real_is_the_reference_sector_where_it_is_certain(emu):
+    """`az_sector_certain` (mc_device.hip.h) replaces the atan2 of a stopping point / an exit from the central hole by a
+    default-real arctangent wherever the sector does not depend on its last digits: where it claims certainty the sector
+    is the reference's (cylindrical_grid.f90:1121-1126), and it claims it for all but a sliver of the points -- also for
+    points generated ON the walls (never certain there) and with coordinates of very different magnitudes."""
+    rng = np.random.default_rng(11)
+    for n_az in (1, 2, 8, 72, 360, 5000):
+        n = 400000
+        phi = rng.random(n) * 2 * np.pi
+        r = 10.0 ** rng.uniform(-3, 3, n)
+        x, y = r * np.cos(phi), r * np.sin(phi)
+        # a tenth of the points next to a wall, within 1e-9 .. 1e-3 of a sector width
+        w = rng.integers(0, n_az, n // 10) * (2 * np.pi / n_az) + (2 * np.pi / n_az) * rng.choice([-1, 1], n // 10) * 10.0 ** rng.uniform(-9, -3, n // 10)
+        x[: n // 10], y[: n // 10] = r[: n // 10] * np.cos(w), r[: n // 10] * np.sin(w)
+        x[-4:] = [1.0, 0.0, -1.0, 0.0]; y[-4:] = [0.0, 1.0, 0.0, -1.0]   # on the axes
+        kf, kr, ok = (np.zeros(n, np.int32) for _ in range(3))
+        assert emu.emu_az_sector(n, n_az, _p(x, C.c_double), _p(y, C.c_double), _p(kf, C.c_int), _p(kr, C.c_int), _p(ok, C.c_int)) == 0
+        sure = ok == 1
+        assert np.array_equal(kf[sure], kr[sure]), n_az
+        assert kr.min() >= 1 and kr.max() <= n_az
+        free = np.ones(n, bool); free[: n // 10] = False; free[-4:] = False
+        assert (~sure[free]).mean() < 4 * (2e-6 * n_az + 1e-5) + 1e-4, n_az      # (the sliver: 2 delta of every sector)
+    # nothing certain without a direction
+    z = np.zeros(1)
+    kf, kr, ok = (np.zeros(1, np.int32) for _ in range(3))
+    emu.emu_az_sector(1, 72, _p(z, C.c_double), _p(z, C.c_double), _p(kf, C.c_int), _p(kr, C.c_int), _p(ok, C.c_int))
+    assert ok[0] == 0
+
+
 def test_emulated_kernel_2d(emu, small_model):
     check(emu, small_model, 5000, 7)
 

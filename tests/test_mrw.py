@@ -194,6 +194,31 @@ def test_emulated_kernels_walk_like_the_oracle(emu):
         assert err.max() < 1.0, (env, err.max(), int(err.argmax()))
 
 
+def test_emulated_binned_role_kernel_walks_like_the_oracle_in_3d(emu):
+    """Round 4: the walk in the role schedule of 3D grids -- k_thermal_roles_bin<..., MRW> (fly_step_3d keeps the
+    "left its cell" bit, the serving waves walk with the azimuthal walls in the sphere's radius and log a walk's deposits
+    as one) and k_tail<true, ..., MRW> for the packets the last chunk hands over -- on one lane on the CPU against the
+    oracle in the frozen mode: the same packets, whatever the chunking."""
+    import test_kernel_emulation as K
+    m = thick_disk_3d()
+    n = 3000
+    orc = Oracle(m, n)
+    prior = Oracle(thick_disk_3d(mrw=False), n).run_thermal(20000, seed=1, n_threads=1)["E_abs"] * (n / 20000)
+    seed = 10
+    want = orc.run_thermal(n, seed=seed, frozen=True, E_prior=prior, n_threads=4)
+    assert want["counters"]["mrw_walks"] > 100
+    for cfg in ("100000,4096,1,2,3", "300,4096,1,2,3", "97,64,0,2,3,30", "300,4096,1,2,3,100000"):
+        os.environ["MCGPU_EMU_BIN"] = cfg
+        try:
+            got = K.emu_run(emu, orc, n, seed, prior=prior)
+        finally:
+            os.environ.pop("MCGPU_EMU_BIN", None)
+        gc, wc = dict(zip(want["counters"].keys(), got["counters"])), want["counters"]
+        _counters_equal_but_for_parted_packets(gc, wc)
+        assert abs(gc["mrw_walks"] - wc["mrw_walks"]) <= 2 and abs(gc["mrw_steps"] - wc["mrw_steps"]) <= 8, (cfg, gc, wc)
+        assert abs(got["E_abs"].sum() / want["E_abs"].sum() - 1.0) < 1e-3
+
+
 # ---------------------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
 def test_device_walk_equals_the_oracle_frozen():
@@ -375,9 +400,11 @@ def _counters_equal_but_for_parted_packets(got, want):
 
 @pytest.mark.gpu
 def test_device_walk_3d_against_the_oracle_frozen():
-    """The walk on a 3D cylindrical grid (single-role kernels, k_thermal<true, ..., MRW>): without the walk packet for
-    packet; with it the noise-aware gates of the 2D test (two independent samples of a chaotic walk) -- and against brute
-    force: the absorbed energy of the thick region within the bias bound."""
+    """The walk on a 3D cylindrical grid, in the default schedule -- round 4: the role kernel with binned deposits,
+    k_thermal_roles_bin<..., MRW>, and k_tail<true, ..., MRW> behind its last chunk -- and in the single-role kernel
+    (k_thermal<true, ..., MRW>, option "schedule" = 1): without the walk packet for packet; with it the noise-aware gates
+    of the 2D test (two independent samples of a chaotic walk) -- and against brute force: the absorbed energy of the thick
+    region within the bias bound."""
     from mcfost_amd.engine import Engine
     n = 20000
     prior = Oracle(thick_disk_3d(mrw=False), n).run_thermal(n, seed=1, n_threads=1)["E_abs"]
@@ -395,15 +422,23 @@ def test_device_walk_3d_against_the_oracle_frozen():
     sigma = {k: np.std([r["counters"][k] for r in others], ddof=1) for k in keys}
     sigma_E = np.std([r["E_abs"].sum() for r in others], ddof=1)
     e = Engine(m, n)
-    got = e.run_thermal(n, seed=9, frozen=True, E_prior=prior)
-    g, w = got["counters"], want["counters"]
-    assert g["mrw_walks"] > 300
-    for k in ("packets", "escaped", "killed_star"):
-        assert g[k] == w[k]
-    for k in keys:
-        assert abs(g[k] - w[k]) <= 4.0 * np.sqrt(2.0) * sigma[k], (k, g[k], w[k], sigma[k])
-    assert np.array_equal(got["n_sent"], want["n_sent"])
-    assert abs(got["E_abs"].sum() - want["E_abs"].sum()) <= 4.0 * np.sqrt(2.0) * sigma_E
+    for schedule in (0, 1):
+        e.set_option("schedule", schedule)
+        # (this small grid would fit in LDS, where the automatic mode keeps the single-role kernel: ask for the log)
+        e.set_option("deposit", 3 if schedule == 0 else 0)
+        got = e.run_thermal(n, seed=9, frozen=True, E_prior=prior)
+        g, w = got["counters"], want["counters"]
+        assert g["mrw_walks"] > 300
+        for k in ("packets", "escaped", "killed_star"):
+            assert g[k] == w[k]
+        for k in keys:
+            assert abs(g[k] - w[k]) <= 4.0 * np.sqrt(2.0) * sigma[k], (schedule, k, g[k], w[k], sigma[k])
+        assert np.array_equal(got["n_sent"], want["n_sent"])
+        assert abs(got["E_abs"].sum() - want["E_abs"].sum()) <= 4.0 * np.sqrt(2.0) * sigma_E
+        if schedule == 0:
+            assert e.get_info("bin_chunks") >= 1               # (the binned role kernel ran)
+    e.set_option("schedule", 0)
+    e.set_option("deposit", 3)
     # against brute force on the device, more packets: the temperature of the thick inner region within the bias bound
     n2 = 1_000_000
     prior2 = e.run_thermal(n2, seed=1)["E_abs"]
@@ -581,6 +616,41 @@ def test_walk_on_a_voronoi_grid():
     assert abs(a["E_abs"].sum() / b["E_abs"].sum() - 1.0) < 0.08
 
 
+def test_emulated_voronoi_role_kernel_walks_like_the_oracle(emu):
+    """Round 4: the walk in the role schedule of a Voronoi grid (k_thermal_voro_roles<., MRW>: voro_roles_cross keeps
+    the "left its cell" bit, the serving waves walk with distance_to_closest_wall_Voronoi and deposit through the
+    workgroup's cache) and in the single-role kernel (k_thermal_voro_mrw), one lane on the CPU against the oracle, frozen.
+    The packets of this disk take ~5000 crossings and ~50 walks each and the plane tests of a Voronoi cell run in default
+    real: of 3000 packets a few part from the oracle's at a rounding tie (the emulation contracts multiply-adds, the
+    oracle does not) and a walk amplifies that -- seed 11: every counter within 1e-4, seed 10: one long packet parts,
+    0.2 %; without the walk the same kernels ARE the oracle's packets to the last count (asserted first)."""
+    import test_kernel_emulation as K
+    n = 3000
+    prior = Oracle(thick_voronoi(mrw=False), n).run_thermal(20000, seed=1, n_threads=1)["E_abs"] * (n / 20000)
+    seed = 11
+    envs = ({}, {"MCGPU_EMU_ROLES": "1,2,3,128"}, {"MCGPU_EMU_ROLES": "0,1,64,4"})
+    for mrw in (False, True):
+        orc = Oracle(thick_voronoi(mrw=mrw), n)
+        want = orc.run_thermal(n, seed=seed, frozen=True, E_prior=prior, n_threads=4)
+        assert (want["counters"]["mrw_walks"] > 50000) == mrw
+        for env in envs:
+            os.environ.update(env)
+            try:
+                got = K.emu_run(emu, orc, n, seed, prior=prior)
+            finally:
+                for k in env:
+                    os.environ.pop(k, None)
+            gc, wc = dict(zip(want["counters"].keys(), got["counters"])), want["counters"]
+            if not mrw:
+                assert gc == wc, (env, gc, wc)
+                continue
+            for k in ("packets", "escaped", "killed_star"):
+                assert gc[k] == wc[k]
+            for k in ("crossings", "flights", "scatterings", "absorptions", "mrw_walks", "mrw_steps"):
+                assert abs(gc[k] / wc[k] - 1.0) < 1e-3, (env, k, gc[k], wc[k])
+            assert abs(got["E_abs"].sum() / want["E_abs"].sum() - 1.0) < 1e-3
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("var", [False, True])
 def test_device_walk_on_a_voronoi_grid(var):
@@ -602,13 +672,15 @@ def test_device_walk_on_a_voronoi_grid(var):
     others = [orc.run_thermal(n, seed=s, frozen=True, E_prior=prior, n_threads=8) for s in (21, 22, 23, 24, 25, 26)]
     sigma = {k: np.std([r["counters"][k] for r in others], ddof=1) for k in keys}
     e = Engine(m, n)
-    got = e.run_thermal(n, seed=9, frozen=True, E_prior=prior)
+    for schedule in ((0,) if var else (0, 2)):       # (2: round 4's k_thermal_voro_roles<., MRW>, one dust class)
+        e.set_option("schedule", schedule)
+        got = e.run_thermal(n, seed=9, frozen=True, E_prior=prior)
+        g, w = got["counters"], want["counters"]
+        assert g["mrw_walks"] > 200
+        for k in ("packets", "escaped", "killed_star"):
+            assert g[k] == w[k]
+        for k in keys:
+            assert abs(g[k] - w[k]) <= 4.0 * np.sqrt(2.0) * sigma[k], (schedule, k, g[k], w[k], sigma[k])
+        assert np.array_equal(got["n_sent"], want["n_sent"])
+        assert abs(got["E_abs"].sum() / want["E_abs"].sum() - 1.0) < 0.05
     e.close()
-    g, w = got["counters"], want["counters"]
-    assert g["mrw_walks"] > 200
-    for k in ("packets", "escaped", "killed_star"):
-        assert g[k] == w[k]
-    for k in keys:
-        assert abs(g[k] - w[k]) <= 4.0 * np.sqrt(2.0) * sigma[k], (k, g[k], w[k], sigma[k])
-    assert np.array_equal(got["n_sent"], want["n_sent"])
-    assert abs(got["E_abs"].sum() / want["E_abs"].sum() - 1.0) < 0.05
