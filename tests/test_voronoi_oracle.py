@@ -165,3 +165,32 @@ def test_voronoi_thermal_run_conserves_packets(vmodel):
     assert c["crossings"] > c["flights"] > c["absorptions"] > 0
     T = orc.temp_finale(r["E_abs"])
     assert T[:-1].max() < 1500 and T[:-1].min() >= 1.0
+
+
+def test_cells_along_a_space_filling_curve_are_the_same_cells():
+    """`build_voronoi_model(..., order="morton")` (host/voronoi.py::spatial_order) lists the cells along a Morton curve and
+    keeps each cell's particle in `extra["site_id"]`, like the reference's `Voronoi(icell)%id`: the same tessellation and
+    the same densities, permuted -- and the oracle's temperature step sees the same disk (total absorbed energy)."""
+    cfg = M.small(dust_mass=1e-3)
+    a = M.build_voronoi_model(cfg, 400, seed=4)
+    b = M.build_voronoi_model(cfg, 400, seed=4, order="morton")
+    sid = np.asarray(b.extra["site_id"])
+    assert sorted(sid) == list(range(400)) and not np.array_equal(sid, np.arange(400))
+    nb = a.grid["n_cells_before_stars"]
+    assert np.allclose(np.asarray(b.grid["volume"])[:nb], np.asarray(a.grid["volume"])[:nb][sid], rtol=1e-12)
+    assert np.allclose(np.asarray(b.rho_dust)[:nb], np.asarray(a.rho_dust)[:nb][sid], rtol=1e-9)
+    # neighbours: the same particles (cell i of b is particle sid[i])
+    def neighbour_particles(m, i, ids):
+        f, l, nbh = np.asarray(m.grid["v_first"]), np.asarray(m.grid["v_last"]), np.asarray(m.grid["v_neigh"])
+        row = nbh[f[i] - 1:l[i]]
+        return sorted(int(ids[j - 1]) if 1 <= j <= nb else int(-abs(j)) if j < 0 else 10**6 + int(j) for j in row)
+    for i in (0, 17, 399):
+        assert neighbour_particles(b, i, sid) == neighbour_particles(a, int(sid[i]), np.arange(nb))
+    n = 20000
+    ra = Oracle(a, n).run_thermal(n, seed=2, n_threads=4)
+    rb = Oracle(b, n).run_thermal(n, seed=2, n_threads=4)
+    for k in ("crossings", "flights", "scatterings", "absorptions"):      # (the same packets in the same disk)
+        assert abs(rb["counters"][k] / ra["counters"][k] - 1.0) < 0.01, k
+    ea, eb = ra["E_abs"][:nb][sid], rb["E_abs"][:nb]
+    # (E_abs is in units of the reference cell's opacity, and the reference cell is another particle: one common factor)
+    assert np.corrcoef(ea, eb)[0, 1] > 0.9999
