@@ -190,12 +190,36 @@ __device__ inline void deposit_rt2_wave(const MonoArgs& A, bool on, int icell, i
 // group g = lane/8 add the 8 slots of lane 8r+g's record -- one instruction, 8 records, 8 line
 // operations instead of 40.
 #ifndef MCGPU_LANE_EMULATION
+// The wave's tile, explicitly in LDS, and the records' addresses, explicitly global.  Round 4 found what the SED mode's
+// commit pass waited for (`wait_frac` 0.56 at 42 % of the atomic-line rate): the tile was read and written through
+// `volatile` generic pointers -- LLVM's address-space inference leaves volatile accesses alone -- so every tile access
+// was a FLAT load / store with `sc0 sc1` and an `s_waitcnt vmcnt(0)` behind it, and the atomics (addresses that came out
+// of the tile as integers: generic again) were flat atomics: each tile access waited for the previous atomic to COMPLETE
+// (~2-3 us under load).  Now: ds_read / ds_write, global atomics, the order between the lanes' writes and reads kept by
+// the wave barrier (one wave executes its LDS instructions in order) and a compiler fence; the reads of a round are
+// issued together, ahead of its atomics.
+typedef __attribute__((address_space(3))) double lds_f64;
+typedef __attribute__((address_space(3))) float lds_f32;
+typedef __attribute__((address_space(3))) unsigned int lds_u32;
+typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+typedef __attribute__((address_space(1))) double glb_f64;
+typedef __attribute__((address_space(1))) float glb_f32;
+__device__ __forceinline__ void tile_sync() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("" ::: "memory");
+}
+constexpr int TILE_UNROLL = 4;   // rounds whose tile reads are in flight together
+
 // The records of one instruction's lanes (<= 4 Stokes values + the copy of I in the slot of its origin, all in one
 // 64-byte line per lane) go out through the wave's LDS tile: the lanes that deposit stage their record in consecutive
 // places, then K lanes serve each record -- floor(64 / K) records per atomic instruction instead of one value of 64.
 __device__ inline void wave_deposit_records(int lane, int K, unsigned int mask, int cslot, double* rec, double v0, double v1,
-                                            double v2, double v3, double* tile, unsigned long long* tile_addr,
-                                            unsigned int* tile_mask, bool contrib) {
+                                            double v2, double v3, double* tile_g, unsigned long long* tile_addr_g,
+                                            unsigned int* tile_mask_g, bool contrib) {
+  lds_f64* const tile = (lds_f64*)tile_g;
+  lds_u64* const tile_addr = (lds_u64*)tile_addr_g;
+  lds_u32* const tile_mask = (lds_u32*)tile_mask_g;
   const int NR = 64 / K;
   const int rl = lane / K, j = lane - rl * K;
   const bool lane_used = rl < NR;
@@ -204,24 +228,33 @@ __device__ inline void wave_deposit_records(int lane, int K, unsigned int mask, 
   const int n_act = __popcll(any);
   if (mask) {
     const int place = __popcll(any & ((1ull << lane) - 1ull));
-    volatile double* my = tile + place * XI_LINE;
+    lds_f64* my = tile + place * XI_LINE;
     my[0] = v0; my[1] = v1; my[2] = v2; my[3] = v3;
     tile_addr[place] = (unsigned long long)rec;
     tile_mask[place] = mask | ((unsigned int)cslot << 8);
   }
-  __builtin_amdgcn_wave_barrier();
-  for (int r0 = 0; r0 < n_act; r0 += NR) {
-    const int src = r0 + rl;
-    if (lane_used && src < n_act) {
-      const unsigned int mw = ((volatile unsigned int*)tile_mask)[src];
-      const int slot = is_contrib ? (int)(mw >> 8) : j;
-      if ((mw >> slot) & 1u) {
-        double* dst = reinterpret_cast<double*>(((volatile unsigned long long*)tile_addr)[src]) + slot;
-        atomic_add_f64(dst, ((volatile double*)tile)[src * XI_LINE + (is_contrib ? 0 : j)]);
-      }
+  tile_sync();
+  for (int r0 = 0; r0 < n_act; r0 += TILE_UNROLL * NR) {
+    unsigned int mw[TILE_UNROLL];
+    unsigned long long ad[TILE_UNROLL];
+    double val[TILE_UNROLL];
+#pragma unroll
+    for (int t = 0; t < TILE_UNROLL; ++t) {
+      const int src = r0 + t * NR + rl;
+      const bool ok = lane_used && src < n_act;
+      const int sc = ok ? src : 0;
+      const unsigned int m_t = tile_mask[sc];
+      mw[t] = ok ? m_t : 0u;
+      ad[t] = tile_addr[sc];
+      val[t] = tile[sc * XI_LINE + (is_contrib ? 0 : j)];
+    }
+#pragma unroll
+    for (int t = 0; t < TILE_UNROLL; ++t) {
+      const int slot = is_contrib ? (int)(mw[t] >> 8) : j;
+      if ((mw[t] >> slot) & 1u) atomic_add_f64((double*)((glb_f64*)ad[t] + slot), val[t]);
     }
   }
-  __builtin_amdgcn_wave_barrier();
+  tile_sync();
 }
 #endif
 
@@ -253,7 +286,13 @@ __device__ inline void deposit_rt2_wave(const MonoArgs& A, bool on, int icell, i
 __device__ inline size_t mono_class_col(const DevModel& M, const MonoArgs& A, int icell) {
   return M.n_classes ? ((size_t)M.cell_class[icell - 1] * M.n_lambda + (A.p_lambda - 1)) * (size_t)(M.nang + 1) : 0;
 }
+#ifdef MCGPU_LANE_EMULATION
 #define MONO_MU(tbl, vtab) (var ? (vtab)[vcol + it] : mu[(tbl) * na1 + it])
+#else
+// (the class tables are global, the columns of p_lambda sit in LDS: two loads in two address spaces, selected by VALUE --
+// a select of the pointers made every read a flat load, whose `vmcnt` wait also waits for the atomics in flight)
+#define MONO_MU(tbl, vtab) (var ? (vtab)[vcol + it] : ((const lds_f32*)mu)[(tbl) * na1 + it])
+#endif
 
 template <bool POLA>
 __device__ inline void deposit_rt1_wave(const DevModel& M, const MonoArgs& A, const RtScratch& R, const float* mu,
@@ -350,7 +389,9 @@ __device__ inline void deposit_rt1_wave_f32(const DevModel& M, const MonoArgs& A
   const int n_act = __popcll(any);
   if (n_act == 0) return;
   const int place = __popcll(any & ((1ull << lane) - 1ull));
-  volatile float* const tile32 = reinterpret_cast<volatile float*>(tile);
+  lds_f32* const tile32 = (lds_f32*)tile;            // (explicit address spaces, tile_sync: see wave_deposit_records)
+  lds_u64* const taddr = (lds_u64*)tile_addr;
+  lds_u32* const tmask = (lds_u32*)tile_mask;
   for (int q0 = 0; q0 < A.nRT; q0 += 2) {
     unsigned int pair_mask = 0;
     for (int h = 0; h < 2; ++h) {
@@ -386,7 +427,7 @@ __device__ inline void deposit_rt1_wave_f32(const DevModel& M, const MonoArgs& A
         if (MCGPU_DIAG(A.flags, 1)) mask = 0;
         else if (MCGPU_DIAG(A.flags, 2)) mask &= 1u;
         if (mask) {
-          volatile float* my = tile32 + place * 2 * XI_LINE + h * XI_LINE;
+          lds_f32* my = tile32 + place * 2 * XI_LINE + h * XI_LINE;
           my[0] = (float)v0; my[1] = (float)v1; my[2] = (float)v2; my[3] = (float)v3;
         }
       }
@@ -394,21 +435,31 @@ __device__ inline void deposit_rt1_wave_f32(const DevModel& M, const MonoArgs& A
     }
     if (pair_mask & 0x00FF00FFu) {
       const size_t bin = ((size_t)(D.icell - 1) * A.n_theta_rt + (D.psup - 1)) * A.n_az_rt + (D.phik - 1);
-      tile_addr[place] = (unsigned long long)(reinterpret_cast<float*>(A.xI) + (bin * A.nRT_pad + q0) * XI_LINE);
-      tile_mask[place] = pair_mask;
+      taddr[place] = (unsigned long long)(reinterpret_cast<float*>(A.xI) + (bin * A.nRT_pad + q0) * XI_LINE);
+      tmask[place] = pair_mask;
     }
-    __builtin_amdgcn_wave_barrier();
-    for (int r0 = 0; r0 < n_act; r0 += NR) {
-      const int src = r0 + rl;
-      if (lane_used && src < n_act) {
-        const unsigned int mw = (((volatile unsigned int*)tile_mask)[src] >> (16 * hh)) & 0xFFFFu;
-        const int slot = is_contrib ? (int)(mw >> 8) : j;
-        if ((mw >> slot) & 1u)
-          atomicAdd(reinterpret_cast<float*>(((volatile unsigned long long*)tile_addr)[src]) + hh * XI_LINE + slot,
-                    tile32[src * 2 * XI_LINE + hh * XI_LINE + (is_contrib ? 0 : j)]);
+    tile_sync();
+    for (int r0 = 0; r0 < n_act; r0 += TILE_UNROLL * NR) {
+      unsigned int mw[TILE_UNROLL];
+      unsigned long long ad[TILE_UNROLL];
+      float val[TILE_UNROLL];
+#pragma unroll
+      for (int t = 0; t < TILE_UNROLL; ++t) {
+        const int src = r0 + t * NR + rl;
+        const bool ok = lane_used && src < n_act;
+        const int sc = ok ? src : 0;
+        const unsigned int m_t = tmask[sc];
+        mw[t] = ok ? ((m_t >> (16 * hh)) & 0xFFFFu) : 0u;
+        ad[t] = taddr[sc];
+        val[t] = tile32[sc * 2 * XI_LINE + hh * XI_LINE + (is_contrib ? 0 : j)];
+      }
+#pragma unroll
+      for (int t = 0; t < TILE_UNROLL; ++t) {
+        const int slot = is_contrib ? (int)(mw[t] >> 8) : j;
+        if ((mw[t] >> slot) & 1u) atomicAdd((float*)((glb_f32*)ad[t] + hh * XI_LINE + slot), val[t]);
       }
     }
-    __builtin_amdgcn_wave_barrier();
+    tile_sync();
   }
 }
 #endif
