@@ -85,9 +85,14 @@ __host__ __device__ inline size_t mono_lds_bytes(const DevModel& M, int nRT, int
 }
 
 // angles_scatt_rt1 (dust_ray_tracing.f90:409-476) for this lane's direction
+// w_mu != nullptr (the commit pass with default-real records and one dust class): the flight's DEPOSIT WEIGHTS are stored
+// instead of the angles -- between two interactions the packet's Stokes vector, its direction and hence the product
+// RPO . Mueller . ROP . Stokes for every observer are constant, a crossing only multiplies them by its path length
+// (calc_xI_scatt_pola, dust_ray_tracing.f90:533-632, evaluated once per flight instead of once per crossing).  Four
+// default-real weights take the 16 bytes of (cosw, sinw); without Stokes tracking the one weight takes itheta's 4.
 template <bool POLA>
 __device__ inline void angles_scatt_rt1(const DevModel& M, const MonoArgs& A, const RtScratch& R, double u,
-                                        double v, double w) {
+                                        double v, double w, const float* w_mu = nullptr, const double* S = nullptr) {
   for (int q = 0; q < A.nRT; ++q) {
     const double ur = A.rt_u[q], vr = A.rt_v[q], wr = A.rt_w[q % A.RT_n_incl];
     const float cos_scatt = (float)nd_add(nd_add(nd_mul(ur, u), nd_mul(vr, v)), nd_mul(wr, w));
@@ -98,6 +103,7 @@ __device__ inline void angles_scatt_rt1(const DevModel& M, const MonoArgs& A, co
     if (k > M.nang) k = M.nang;
     if (k < 1) k = 1;
     R.itheta[q * blockDim.x + threadIdx.x] = k;
+    if (!POLA && w_mu) R.itheta[q * blockDim.x + threadIdx.x] = __float_as_int((float)(S[0] * (double)w_mu[k]));
     if (POLA) {
       double v1pi, v1pj, v1pk;
       rotation(u, v, w, -ur, -vr, -wr, v1pi, v1pj, v1pk);
@@ -115,6 +121,23 @@ __device__ inline void angles_scatt_rt1(const DevModel& M, const MonoArgs& A, co
       if (fabs(sinw) < 1e-06) sinw = 0.0;
       R.cosw[q * blockDim.x + threadIdx.x] = cosw;
       R.sinw[q * blockDim.x + threadIdx.x] = sinw;
+      if (w_mu) {   // (the expressions of deposit_rt1_wave, without the path length)
+        const int na1 = M.nang + 1;
+        const float s11 = w_mu[k];
+        const float s12 = -s11 * w_mu[na1 + k], s22 = s11 * w_mu[2 * na1 + k], s33 = -s11 * w_mu[3 * na1 + k];
+        const float s34 = -s11 * w_mu[4 * na1 + k], s44 = -s11 * w_mu[5 * na1 + k];
+        const double C1 = S[0], C4 = S[3];
+        const double C2 = cosw * S[1] + (-sinw) * S[2];
+        const double C3 = sinw * S[1] + cosw * S[2];
+        const double D1 = (double)s11 * C1 + (double)s12 * C2;
+        const double D2 = (double)s12 * C1 + (double)s22 * C2;
+        const double D3 = (double)s33 * C3 + (double)(-s34) * C4;
+        const double D4 = (double)s34 * C3 + (double)s44 * C4;
+        float2* wc = reinterpret_cast<float2*>(R.cosw) + (q * blockDim.x + threadIdx.x);
+        float2* ws = reinterpret_cast<float2*>(R.sinw) + (q * blockDim.x + threadIdx.x);
+        *wc = make_float2((float)D1, (float)((-cosw) * D2 + (-sinw) * D3));
+        *ws = make_float2((float)((-sinw) * D2 + cosw * D3), (float)D4);
+      }
     }
   }
 }
@@ -399,7 +422,25 @@ __device__ inline void deposit_rt1_wave_f32(const DevModel& M, const MonoArgs& A
       double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
       unsigned int mask = 0;
       int cslot = 0;
-      if (D.on && q < A.nRT) {
+      if (D.on && q < A.nRT && !var) {   // the flight's weights (angles_scatt_rt1) times this crossing's path length
+        if (!POLA) {
+          v0 = D.l * (double)__int_as_float(R.itheta[q * blockDim.x + threadIdx.x]);
+          mask = 1u;
+          if (A.contrib) { cslot = flag_star ? 2 : 4; mask |= 1u << cslot; }
+        } else {
+          const float2 wc = reinterpret_cast<const float2*>(R.cosw)[q * blockDim.x + threadIdx.x];
+          const float2 ws = reinterpret_cast<const float2*>(R.sinw)[q * blockDim.x + threadIdx.x];
+          v0 = D.l * (double)wc.x; v1 = D.l * (double)wc.y; v2 = D.l * (double)ws.x; v3 = D.l * (double)ws.y;
+          mask = 0xFu;
+          if (A.contrib) { cslot = flag_star ? 5 : 7; mask |= 1u << cslot; }
+        }
+        if (MCGPU_DIAG(A.flags, 1)) mask = 0;
+        else if (MCGPU_DIAG(A.flags, 2)) mask &= 1u;
+        if (mask) {
+          lds_f32* my = tile32 + place * 2 * XI_LINE + h * XI_LINE;
+          my[0] = (float)v0; my[1] = (float)v1; my[2] = (float)v2; my[3] = (float)v3;
+        }
+      } else if (D.on && q < A.nRT) {
         const int it = R.itheta[q * blockDim.x + threadIdx.x];
         const float s11 = MONO_MU(0, M.v_s11);
         if (!POLA) {
@@ -670,7 +711,7 @@ __device__ __forceinline__ void mono_body(const DevModel& M, const MonoArgs& A, 
       const double a = u * u + v * v;
       inv_a = (a > TINY_REAL) ? 1.0 / a : HUGE_REAL;
       inv_w = (fabs(w) > TINY_REAL) ? 1.0 / w : copysign(HUGE_DP, w);
-      if (!SCOUT && A.rt1) angles_scatt_rt1<POLA>(M, A, R, u, v, w);  // optical_depth.f90:65
+      if (!SCOUT && A.rt1) angles_scatt_rt1<POLA>(M, A, R, u, v, w, (F32 && !var) ? mu : nullptr, S);  // optical_depth.f90:65
       const int i_star = intersect_stars(M, x, y, z, u, v, w);
       star_key = -1;
       if (i_star > 0) {

@@ -113,7 +113,7 @@ __device__ __forceinline__ void mono_body_voro(const DevModel& M, const MonoArgs
     if (st == S_NEWFLIGHT) {
       const float rand = tau_rand;
       extr = tau_of_draw(rand);
-      if (!SCOUT && A.rt1) angles_scatt_rt1<POLA>(M, A, ML.R, u, v, w);  // optical_depth.f90:65
+      if (!SCOUT && A.rt1) angles_scatt_rt1<POLA>(M, A, ML.R, u, v, w, (F32 && M.n_classes == 0) ? ML.mu : nullptr, S);  // optical_depth.f90:65
       const int i_star = intersect_stars(M, x, y, z, u, v, w);
       star_icell = (i_star > 0) ? M.star_cell[4 * (i_star - 1)] : 0;
       c_flight++;
