@@ -103,7 +103,9 @@ __device__ inline void angles_scatt_rt1(const DevModel& M, const MonoArgs& A, co
     if (k > M.nang) k = M.nang;
     if (k < 1) k = 1;
     R.itheta[q * blockDim.x + threadIdx.x] = k;
+#ifndef MCGPU_LANE_EMULATION   // (the lane emulation has no default-real commit pass)
     if (!POLA && w_mu) R.itheta[q * blockDim.x + threadIdx.x] = __float_as_int((float)(S[0] * (double)w_mu[k]));
+#endif
     if (POLA) {
       double v1pi, v1pj, v1pk;
       rotation(u, v, w, -ur, -vr, -wr, v1pi, v1pj, v1pk);
@@ -121,6 +123,7 @@ __device__ inline void angles_scatt_rt1(const DevModel& M, const MonoArgs& A, co
       if (fabs(sinw) < 1e-06) sinw = 0.0;
       R.cosw[q * blockDim.x + threadIdx.x] = cosw;
       R.sinw[q * blockDim.x + threadIdx.x] = sinw;
+#ifndef MCGPU_LANE_EMULATION
       if (w_mu) {   // (the expressions of deposit_rt1_wave, without the path length)
         const int na1 = M.nang + 1;
         const float s11 = w_mu[k];
@@ -138,6 +141,7 @@ __device__ inline void angles_scatt_rt1(const DevModel& M, const MonoArgs& A, co
         *wc = make_float2((float)D1, (float)((-cosw) * D2 + (-sinw) * D3));
         *ws = make_float2((float)((-sinw) * D2 + cosw * D3), (float)D4);
       }
+#endif
     }
   }
 }

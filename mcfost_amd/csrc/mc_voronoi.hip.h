@@ -28,13 +28,6 @@
 #pragma once
 #include "mc_device.hip.h"
 
-// (a timing experiment of round 4, -DMCGPU_VORO_DROP_MISSES: what the deposits that miss the workgroup's cache cost)
-#ifdef MCGPU_VORO_DROP_MISSES
-#define VORO_MISS_DEPOSIT(p, v) ((void)0)
-#else
-#define VORO_MISS_DEPOSIT(p, v) atomic_add_f64((p), (v))
-#endif
-
 namespace mcgpu {
 
 struct VoroCell {
@@ -508,7 +501,7 @@ __device__ __forceinline__ void thermal_body_voro(const DevModel& M, const RunAr
             const double ls = l_void + lc;
             const double dE = kabs_c * lc * S[0];
             if (dE != 0.0 && !MCGPU_DIAG(A.flags, 1)) {
-              if (!(CACHE && DC.add(icell, dE))) VORO_MISS_DEPOSIT(&A.E_abs[icell - 1], dE);
+              if (!(CACHE && DC.add(icell, dE))) atomic_add_f64(&A.E_abs[icell - 1], dE);
             }
             radiation_field_extras(M, A, icell - 1, lambda, lc * S[0]);
             x = nd_add(x, nd_mul(ls, u));
@@ -521,7 +514,7 @@ __device__ __forceinline__ void thermal_body_voro(const DevModel& M, const RunAr
             extr = extr - tau;
             const double dE = kabs_c * l_contrib * S[0];
             if (dE != 0.0 && !MCGPU_DIAG(A.flags, 1)) {
-              if (!(CACHE && DC.add(icell, dE))) VORO_MISS_DEPOSIT(&A.E_abs[icell - 1], dE);
+              if (!(CACHE && DC.add(icell, dE))) atomic_add_f64(&A.E_abs[icell - 1], dE);
             }
             radiation_field_extras(M, A, icell - 1, lambda, l_contrib * S[0]);
             x = x1; y = y1; z = z1;
