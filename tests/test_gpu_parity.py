@@ -770,6 +770,24 @@ def test_sed_mode_voronoi():
         a, b = _mono_parity(m, lam, 10, 80 + lam)
         assert a["sed"][4][0, m.capt_sup - 1, lam - 1] == 64 * 10
     _mono_parity(sed_model(M.small(lsepar_pola=False), voronoi_sites=1500, n_thermal=50000), 9, 10, 4)
+    # default-real records (the commit pass with the flight's deposit weights, mc_mono.hip.h) on this grid and on a
+    # spherical one: the same packets, xI_scatt to default-real rounding
+    from helpers import xI_close
+    for mm, lam in ((m, 9), (sed_model(M.small(grid_type=2), n_thermal=20000), 5)):
+        e, o = _engine(mm, 1e5), _oracle(mm, 1e5)
+        e.set_rt1()
+        e.set_xI_precision(4)
+        a = e.run_mono(lam, 10, seed=77, n_chunks=16)
+        b = o.run_mono(lam, 10, seed=77, n_chunks=16, n_threads=8)
+        assert np.array_equal(a["n_sent_chunk"], b["n_sent_chunk"])
+        assert np.array_equal(a["sed"][4], b["sed"][4])
+        if mm is m:
+            assert a["counters"] == b["counters"]
+            xI_close(a["xI_scatt"], b["xI_scatt"], rtol=1e-4, atol_rel=1e-5)
+        else:   # (the spherical grid's midplane cone: sub-bins compared summed, test_sed_mode_on_spherical_grids)
+            xa, xb = a["xI_scatt"], b["xI_scatt"]
+            assert np.allclose(xa.sum(axis=(2, 3, 4)), xb.sum(axis=(2, 3, 4)), rtol=2e-3, atol=1e-5 * np.abs(xb).max())
+        e.close()
 
 
 # ---------------------------------------------------------------------------

@@ -47,6 +47,23 @@ def _check_mono(m, lam, n2, seed, n_chunks=32):
     return e, o, a, b
 
 
+def test_default_real_records_on_variable_dust():
+    """mcgpu_set_xI_precision(4) with dust classes: the Mueller columns change from cell to cell, so the commit pass keeps
+    the per-crossing products (the per-flight weights of round 4 are for one class) -- same packets, xI_scatt to default-
+    real rounding."""
+    from oracle import Oracle
+    from mcfost_amd.engine import Engine
+    m, g, p_icell, dens = _vd_model()
+    e, o = Engine(m, 1e5), Oracle(m, 1e5)
+    e.set_rt1()
+    e.set_xI_precision(4)
+    a = e.run_mono(9, 40, seed=79, n_chunks=32)
+    b = o.run_mono(9, 40, seed=79, n_chunks=32, n_threads=8)
+    assert np.array_equal(a["n_sent_chunk"], b["n_sent_chunk"]) and a["counters"] == b["counters"]
+    xI_close(a["xI_scatt"], b["xI_scatt"], rtol=1e-4, n_midplane_cells=m.cfg.n_rad, atol_rel=1e-5)
+    e.close()
+
+
 @pytest.mark.parametrize("kw", [dict(), dict(lsepar_pola=False), dict(aniso_method=2, lsepar_pola=False),
                                 dict(n_az=4, l3D=True)])
 def test_sed_mode_on_variable_dust(kw):
