@@ -69,6 +69,7 @@ struct RtScratch {
   int* itheta;
   double* cosw;
   double* sinw;
+  const double* rot;   // per observer (cost, sint, sing) of rotation(., -u_obs, -v_obs, -w_obs): they depend on the observer only
 };
 
 // slim = the workgroup stages only the tables the SED mode reads (lds_carve(..., mono = true)).  (The phase-function
@@ -81,6 +82,8 @@ __host__ __device__ inline size_t mono_lds_bytes(const DevModel& M, int nRT, int
   b += (size_t)threads * (8 * sizeof(double) + sizeof(unsigned long long));  // deposit tiles: record + address
   b += (size_t)nRT * threads * sizeof(int);                          // itheta
   b += (size_t)threads * sizeof(unsigned int);                       // deposit tiles: slot mask
+  b = (b + 7) / 8 * 8;
+  b += (size_t)3 * nRT * sizeof(double);                             // the observers' rotation constants
   return b;
 }
 
@@ -96,10 +99,21 @@ __device__ inline void angles_scatt_rt1(const DevModel& M, const MonoArgs& A, co
   for (int q = 0; q < A.nRT; ++q) {
     const double ur = A.rt_u[q], vr = A.rt_v[q], wr = A.rt_w[q % A.RT_n_incl];
     const float cos_scatt = (float)nd_add(nd_add(nd_mul(ur, u), nd_mul(vr, v)), nd_mul(wr, w));
-    const float ac = (float)acos((double)cos_scatt);  // the correctly rounded default-real acos
+    // k = nint(acos(cos_scatt) * nang / pi) in default real (:430-434).  The default-real arccosine of the runtime decides
+    // the bin unless the quotient lies within delta = 1.2e-6 nang of a bin edge (2.2e-4 at 180 bins) -- the roundings of
+    // both evaluations together (acosf to 2 ulp of pi, two default-real operations at ~nang, the reference's correctly
+    // rounded acos and default-real product) stay below 0.5e-6 nang -- where the reference's expression itself runs
+    // (4e-4 of the calls, and NaN): the FP64 acos was 75 of this observer's instructions.
     int k;
-    if (ac != ac) k = 1;
-    else k = (int)llrint(floor(nf_mul(ac, (float)M.nang) / PI + 0.5));  // nint()
+    const float qf = acosf(cos_scatt) * ((float)M.nang * 0.318309886183790672f) + 0.5f;
+    const float qfl = floorf(qf);
+    const float dq = 1.2e-6f * (float)M.nang;
+    if (qf - qfl > dq && qf - qfl < 1.0f - dq) k = (int)qfl;
+    else {
+      const float ac = (float)acos((double)cos_scatt);  // the correctly rounded default-real acos
+      if (ac != ac) k = 1;
+      else k = (int)llrint(floor(nf_mul(ac, (float)M.nang) / PI + 0.5));  // nint()
+    }
     if (k > M.nang) k = M.nang;
     if (k < 1) k = 1;
     R.itheta[q * blockDim.x + threadIdx.x] = k;
@@ -107,18 +121,21 @@ __device__ inline void angles_scatt_rt1(const DevModel& M, const MonoArgs& A, co
     if (!POLA && w_mu) R.itheta[q * blockDim.x + threadIdx.x] = __float_as_int((float)(S[0] * (double)w_mu[k]));
 #endif
     if (POLA) {
-      double v1pi, v1pj, v1pk;
-      rotation(u, v, w, -ur, -vr, -wr, v1pi, v1pj, v1pk);
+      // rotation(u, v, w, -ur, -vr, -wr, ...) with the observer's constants from LDS (only y' and z' are needed)
+      const double cost = R.rot[3 * q], sint = R.rot[3 * q + 1], sing = R.rot[3 * q + 2];
+      const double prod = cost * u + sint * v;
+      const double v1pj = cost * v - sint * u;
+      const double v1pk = sing * w - (-wr) * prod;
       double xnyp = sqrt(v1pk * v1pk + v1pj * v1pj), costhet;
       if (xnyp < 1e-10) { xnyp = 0.0; costhet = 1.0; }
       else costhet = -1.0 * v1pj / xnyp;
-      double theta = acos(costhet);
-      if (theta >= PI) theta = 0.0;
-      theta = theta + PI / 2;
-      double omega = 2.0 * theta;
-      if (v1pk < 0.0) omega = -1.0 * omega;
-      double sinw, cosw;
-      sincos(omega, &sinw, &cosw);
+      // theta = acos(costhet) (pi -> 0), omega = 2 (theta + pi / 2), negated below the plane; cos and sin of omega
+      // (dust_ray_tracing.f90:452-470) without the acos and the sincos -- 180 of this observer's ~450 instructions:
+      // cos(2 theta + pi) = 1 - 2 c^2, sin(2 theta + pi) = -2 c sqrt(1 - c^2); the composition's own rounding apart
+      // (1e-16, like update_stokes' rotation since round 4)
+      double cosw = 1.0 - 2.0 * costhet * costhet;
+      double sinw = -2.0 * costhet * sqrt(fmax(1.0 - costhet * costhet, 0.0));
+      if (v1pk < 0.0) sinw = -sinw;
       if (fabs(cosw) < 1e-06) cosw = 0.0;
       if (fabs(sinw) < 1e-06) sinw = 0.0;
       R.cosw[q * blockDim.x + threadIdx.x] = cosw;
@@ -534,6 +551,20 @@ __device__ inline MonoLds mono_lds_setup(const DevModel& M, const MonoArgs& A, d
   p += blockDim.x;
   L.R.itheta = reinterpret_cast<int*>(p);
   L.tile_mask = reinterpret_cast<unsigned int*>(L.R.itheta + (size_t)A.nRT * blockDim.x) + (size_t)(threadIdx.x >> 6) * 64;
+  {  // rotation()'s cost, sint, sing for the axis (-u_obs, -v_obs, -w_obs): the same expressions, once per observer
+    const size_t used = (size_t)((L.R.itheta + (size_t)A.nRT * blockDim.x) - reinterpret_cast<int*>(lds_base)) * sizeof(int) +
+                        (size_t)blockDim.x * sizeof(unsigned int);
+    double* rot = lds_base + (used + 7) / 8;
+    for (int q = threadIdx.x; q < A.nRT; q += blockDim.x) {
+      const double u1 = -A.rt_u[q], v1 = -A.rt_v[q], w1 = -A.rt_w[q % A.RT_n_incl];
+      double cost, sint, sing;
+      if (w1 > 0.999999999) { cost = 1.0; sint = 0.0; sing = 0.0; }
+      else if (fabs(u1) < TINY_REAL) { cost = 0.0; sint = 1.0; sing = sqrt(1.0 - w1 * w1); }
+      else { const double h = sqrt(u1 * u1 + v1 * v1); cost = u1 / h; sint = v1 / h; sing = sqrt(1.0 - w1 * w1); }
+      rot[3 * q] = cost; rot[3 * q + 1] = sint; rot[3 * q + 2] = sing;
+    }
+    L.R.rot = rot;
+  }
   // the Mueller columns of p_lambda
   const size_t col = (size_t)na1 * (A.p_lambda - 1);
   for (int i = threadIdx.x; i < na1; i += blockDim.x) {
