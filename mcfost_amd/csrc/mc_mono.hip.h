@@ -435,7 +435,7 @@ __device__ inline void deposit_rt1_wave_f32(const DevModel& M, const MonoArgs& A
   const int place = __popcll(any & ((1ull << lane) - 1ull));
   lds_f32* const tile32 = (lds_f32*)tile;            // (explicit address spaces, tile_sync: see wave_deposit_records)
   lds_u64* const taddr = (lds_u64*)tile_addr;
-  lds_u32* const tmask = (lds_u32*)tile_mask;
+  (void)tile_mask;   // (the slot mask travels in the line address's low bits, see below)
   for (int q0 = 0; q0 < A.nRT; q0 += 2) {
     unsigned int pair_mask = 0;
     for (int h = 0; h < 2; ++h) {
@@ -457,9 +457,11 @@ __device__ inline void deposit_rt1_wave_f32(const DevModel& M, const MonoArgs& A
         }
         if (MCGPU_DIAG(A.flags, 1)) mask = 0;
         else if (MCGPU_DIAG(A.flags, 2)) mask &= 1u;
-        if (mask) {
-          lds_f32* my = tile32 + place * 2 * XI_LINE + h * XI_LINE;
-          my[0] = (float)v0; my[1] = (float)v1; my[2] = (float)v2; my[3] = (float)v3;
+        if (mask) {   // (one 16-byte store: the record's four Stokes slots)
+          typedef float f32x4_t __attribute__((ext_vector_type(4)));
+          typedef __attribute__((address_space(3))) f32x4_t lds_f32x4;
+          const f32x4_t rec4 = {(float)v0, (float)v1, (float)v2, (float)v3};
+          *(lds_f32x4*)(tile32 + place * 2 * XI_LINE + h * XI_LINE) = rec4;
         }
       } else if (D.on && q < A.nRT) {
         const int it = R.itheta[q * blockDim.x + threadIdx.x];
@@ -488,21 +490,27 @@ __device__ inline void deposit_rt1_wave_f32(const DevModel& M, const MonoArgs& A
         }
         if (MCGPU_DIAG(A.flags, 1)) mask = 0;
         else if (MCGPU_DIAG(A.flags, 2)) mask &= 1u;
-        if (mask) {
-          lds_f32* my = tile32 + place * 2 * XI_LINE + h * XI_LINE;
-          my[0] = (float)v0; my[1] = (float)v1; my[2] = (float)v2; my[3] = (float)v3;
+        if (mask) {   // (one 16-byte store: the record's four Stokes slots)
+          typedef float f32x4_t __attribute__((ext_vector_type(4)));
+          typedef __attribute__((address_space(3))) f32x4_t lds_f32x4;
+          const f32x4_t rec4 = {(float)v0, (float)v1, (float)v2, (float)v3};
+          *(lds_f32x4*)(tile32 + place * 2 * XI_LINE + h * XI_LINE) = rec4;
         }
       }
       pair_mask |= (mask | ((unsigned int)cslot << 8)) << (16 * h);
     }
-    if (pair_mask & 0x00FF00FFu) {
-      const size_t bin = ((size_t)(D.icell - 1) * A.n_theta_rt + (D.psup - 1)) * A.n_az_rt + (D.phik - 1);
-      taddr[place] = (unsigned long long)(reinterpret_cast<float*>(A.xI) + (bin * A.nRT_pad + q0) * XI_LINE);
-      tmask[place] = pair_mask;
+    // The pair's line (64-byte aligned: nRT_pad and q0 are even) with what the serving lanes need in its six low bits:
+    // the slot of the contribution (0: none) and which of the two records is there -- one LDS read per round instead of
+    // an address and a mask, no per-value bit tests (a staged record always deposits its Stokes slots).
+    {
+      const unsigned int m0 = pair_mask & 0xFFFFu, m1 = pair_mask >> 16;
+      const unsigned int fl = (m0 ? ((m0 >> 8) & 7u) | 8u : 0u) | (m1 ? ((m1 >> 8) & 7u) | 16u : 0u);
+      const bool staged = ((any >> lane) & 1ull) != 0ull;
+      const size_t bin = ((size_t)(staged ? D.icell - 1 : 0) * A.n_theta_rt + (D.psup - 1)) * A.n_az_rt + (D.phik - 1);
+      if (staged) taddr[place] = (unsigned long long)(reinterpret_cast<float*>(A.xI) + (bin * A.nRT_pad + q0) * XI_LINE) | fl;
     }
     tile_sync();
     for (int r0 = 0; r0 < n_act; r0 += TILE_UNROLL * NR) {
-      unsigned int mw[TILE_UNROLL];
       unsigned long long ad[TILE_UNROLL];
       float val[TILE_UNROLL];
 #pragma unroll
@@ -510,15 +518,16 @@ __device__ inline void deposit_rt1_wave_f32(const DevModel& M, const MonoArgs& A
         const int src = r0 + t * NR + rl;
         const bool ok = lane_used && src < n_act;
         const int sc = ok ? src : 0;
-        const unsigned int m_t = tmask[sc];
-        mw[t] = ok ? ((m_t >> (16 * hh)) & 0xFFFFu) : 0u;
-        ad[t] = taddr[sc];
+        const unsigned long long a_t = taddr[sc];
+        ad[t] = ok ? a_t : 0ull;
         val[t] = tile32[sc * 2 * XI_LINE + hh * XI_LINE + (is_contrib ? 0 : j)];
       }
 #pragma unroll
       for (int t = 0; t < TILE_UNROLL; ++t) {
-        const int slot = is_contrib ? (int)(mw[t] >> 8) : j;
-        if ((mw[t] >> slot) & 1u) atomicAdd((float*)((glb_f32*)ad[t] + hh * XI_LINE + slot), val[t]);
+        const unsigned int fl = (unsigned int)ad[t] & 63u;
+        const int slot = is_contrib ? (int)(fl & 7u) : j;
+        const bool go = ((fl >> (3 + hh)) & 1u) && (!is_contrib || (fl & 7u));
+        if (go) atomicAdd((float*)((glb_f32*)(ad[t] & ~63ull) + hh * XI_LINE + slot), val[t]);
       }
     }
     tile_sync();

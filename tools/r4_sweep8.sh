@@ -1,6 +1,6 @@
 #!/bin/bash
 # round-4 A/B no. 8: the SED mode's commit pass -- LDS tile and global atomics by address space (default build) against the
-# volatile / flat version before it (variants/sedfix2.so)
+# volatile / flat version before it (variants/sedfix3.so)
 out=$1; mkdir -p $(dirname $out); : > $out
 run() {  # label, extra args...
   label=$1; shift
@@ -13,7 +13,7 @@ for l in sys.stdin:
 " >> $out
 }
 run new
-MCGPU_LIB=$PWD/mcfost_amd/csrc/variants/sedfix2.so run fix2
+MCGPU_LIB=$PWD/mcfost_amd/csrc/variants/sedfix3.so run fix3
 run new
-MCGPU_LIB=$PWD/mcfost_amd/csrc/variants/sedfix2.so run fix2
+MCGPU_LIB=$PWD/mcfost_amd/csrc/variants/sedfix3.so run fix3
 cat $out
