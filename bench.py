@@ -403,7 +403,7 @@ def thermal_block(par, args, config, steps, warmup, with_cpu, n_local):
     return block, cfg
 
 
-def sed_block(par, args, steps, warmup, with_cpu, packets, observers):
+def sed_block(par, args, steps, warmup, with_cpu, packets, observers, all_lambdas=False):
     """SED mode on the ref4.1 grid (the second half of BASELINE config 2): one step = the SED Monte Carlo
     (mcgpu_run_mono: scout + commit passes, ray-tracing deposits) of the listed wavelengths, every stream asked for
     packets/128/len(wavelengths) packets in the stop bin; streams sharded over the GPUs."""
@@ -430,7 +430,9 @@ def sed_block(par, args, steps, warmup, with_cpu, packets, observers):
     if args.xI_precision == 4:
         for x in engs:
             x.set_xI_precision(4)
-    lams = [int(x) for x in args.sed_lambdas.split(",")]
+    # (the default line runs EVERY wavelength of config 2's SED at reduced packets; --config sed the listed ones)
+    lams = list(range(1, m.n_lambda + 1)) if all_lambdas else [int(x) for x in args.sed_lambdas.split(",")]
+    lam_text = ("all %d wavelengths" % m.n_lambda) if all_lambdas else ("wavelengths %s" % args.sed_lambdas)
     n_streams = m.cfg.n_photons_loop * world                 # weak scaling: 128 streams per GPU
     first, count = D.shard_streams(n_streams, par.rank, par.world)
     # packets in the stop bin per stream so that a step sends about `packets` packets per GPU (1 in ~11 lands there)
@@ -479,9 +481,9 @@ def sed_block(par, args, steps, warmup, with_cpu, packets, observers):
             "value": sent_all / dt, "unit": "packets/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "ref4.1 2D disk 100x70, SED Monte Carlo of wavelengths %s, 128 streams/GPU x %d packets "
+            "config": {"workload": "ref4.1 2D disk 100x70, SED Monte Carlo of %s, 128 streams/GPU x %d packets "
                                    "in the stop bin each, RT1 deposits for %d observers (both passes timed)"
-                                   % (args.sed_lambdas, n2, nRT),
+                                   % (lam_text, n2, nRT),
                        "packets_per_gpu_per_step": sent_all / world / steps, "crossings_per_packet": cross_pp,
                        "observers": nRT, "xI_record": "f32 pairs" if args.xI_precision == 4 else "f64",
                        "records_per_s": sent_all / dt * cross_pp * nRT},
@@ -592,7 +594,10 @@ def main():
             # (DESIGN.md section 7), so a step is 1e7 packets
             extras["ref41_mrw"], _ = thermal_block(par, args, "ref41_mrw", 1, 1, with_cpu, min(args.packets, 1e7))
             # the SED half of BASELINE config 2: 10 observers
-            extras["sed"] = sed_block(par, args, 1, 0, with_cpu, min(args.packets, 2e7), args.sed_observers or 10)
+            # (every wavelength, 1 / 14 of config 2's packets per stream: the launches of a wavelength are small then and
+            # the rate sits below the full run's 2.9e7 packets/s of tools/run_config2.py)
+            extras["sed"] = sed_block(par, args, 1, 1, with_cpu, min(args.packets, 5e7), args.sed_observers or 10,
+                                      all_lambdas=True)
     if par.rank == 0:
         line = {"metric": "photon packets/sec (whole node), thermal MC packet loop, %s" % cfg.name,
                 "value": block["value"], "unit": "packets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
