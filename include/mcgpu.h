@@ -269,6 +269,10 @@ int mcgpu_set_E_prior(mcgpu_ctx *ctx, const double *E_prior);
  *   sed[9][N_phi][N_thet][n_lambda]         -> sed, sed_q, ... (:,:,:,1)
  *   n_sent[n_lambda]                        -> n_phot_envoyes(:,1)
  *   counters[MCGPU_N_COUNTERS], kernel_ms   (any may be NULL)
+ * One deliberate difference in arithmetic: a flight's optical depth tau = -log(1 - rand) is formed from the same
+ * default-real `rand` as the reference's but with an FP64 logarithm, where the reference's `tau` is default real
+ * (dust_transfer.f90:1182,1208-1215): the same distribution to 6e-8 (the CPU oracle has both forms;
+ * tests/test_oracle_kats.py::test_fp32_and_fp64_tau_are_statistically_equivalent).
  */
 int mcgpu_run_thermal(mcgpu_ctx *ctx, const mcgpu_run_opts *opts,
                       double *E_abs, double *sed, double *n_sent,
@@ -767,7 +771,9 @@ int mcgpu_temp_approx_diffusion_vertical(mcgpu_ctx *ctx, const double *tab_lambd
  *   limits[6]                  the box (Voronoi.f90:1275-1280); every site strictly inside
  *   threshold, n_vectors, cutting_vectors[n_vectors][3], cutting_distance_o_h
  *                              the cut of elongated cells by the Platonic solid (init_Platonic_Solid, Voronoi.f90:108-192;
- *                              voro++_wrapper.cpp:209-227): when the farthest vertex is beyond threshold * h
+ *                              voro++_wrapper.cpp:209-227): when the farthest vertex is beyond threshold * h;
+ *                              n_vectors <= 12 (the reference's dodecahedron, Voronoi.f90:243; a solid whose planes meet
+ *                              more than three to a vertex -- 20 faces -- is MCGPU_ERR_UNSUPPORTED)
  *   extra_plane[n_run][4]      NULL, or per cell one more cut, unit normal + distance (<= 0: none): the stellar surface
  *                              for a star's neighbours (voro++_wrapper.cpp:229-262)
  * Outputs, per cell of the call: n_neigh, neigh[max_neighbours] (0-based site ids; -1 .. -6 = walls -x +x -y +y -z +z) --
@@ -810,6 +816,11 @@ int mcgpu_voronoi_tesselation(int device, int n, const double *xyz, const double
  * the code of distinct devices, so a box with one GPU executes it (tests/test_multi_shared_device.py,
  * `bench.py --gpus N --shared-device`).  Not for production: the contexts share the device's CUs.
  * mcgpu_multi_reductions counts the collectives a handle has executed (either kind).
+ * mcgpu_multi_create_ex(..., MCGPU_MULTI_FORCE_RCCL, ...) keeps distinct devices and RCCL but does
+ * not skip the collective when n_dev = 1: ncclCommInitAll over one rank and the grouped
+ * ncclAllReduce of every buffer a call deposits into (the fused accumulator, xI_scatt in either
+ * precision, I_spec / I_spec_star) run as they would on eight devices; the sum over one rank leaves
+ * the buffers bit for bit, mcgpu_multi_rccl_ranks returns 1 (tests/test_rccl_single_rank.py).
  *
  * mcgpu_multi_run_mono replaces `call mc_photon_loop(lambda, ...)` of the SED loop
  * (dust_transfer.f90:939) the same way: the opts->n_chunks independent streams are split into
@@ -822,6 +833,7 @@ int mcgpu_voronoi_tesselation(int device, int n, const double *xyz, const double
  */
 typedef struct mcgpu_multi mcgpu_multi;
 #define MCGPU_MULTI_SHARED_DEVICE 1u
+#define MCGPU_MULTI_FORCE_RCCL 2u
 int mcgpu_multi_create(int n_dev, const int *devices, mcgpu_multi **out);
 int mcgpu_multi_create_ex(int n_dev, const int *devices, unsigned int flags, mcgpu_multi **out);
 uint64_t mcgpu_multi_reductions(const mcgpu_multi *m);

@@ -591,6 +591,10 @@ __device__ __forceinline__ int fly_step_3d(const Lds& T, const DevModel& M, cons
   } else if (__builtin_expect(stop, 0)) {  // (:140: 3D re-indexes the stopping point)
     index_cell<true>(T, M, p.x, p.y, p.z, p.ri, p.zj, p.k);
     p.ic = is_real_cell<true>(n_rad, nz, p.ri, p.zj) ? cell_index<true>(n_rad, nz, p.ri, p.zj, p.k) : M.n_cells;
+    // (the re-indexed point may lie in a neighbouring cell -- zj goes through default real --: the next flight, which
+    // skips the load when the cell is the one it holds, must not inherit the old cell's factor)
+    if (VAR) { const double2 kk = M.v_kk[(size_t)p.ic * M.n_lambda + (p.lam - 1)]; p.kf = kk.x; p.kab = kk.y; }
+    else p.kf = M.kappa_factor[p.ic];
   }
   if (DARK) {
     p.u = mirror ? -u : u; p.v = mirror ? -v : v; p.w = mirror ? -w : w;

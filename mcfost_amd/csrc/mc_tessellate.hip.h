@@ -37,7 +37,7 @@ struct TessArgs {
   const double* h;              // [n] smoothing lengths (huge for stars: never cut)
   double limits[6];             // xmin, xmax, ymin, ymax, zmin, zmax
   double threshold;             // a cell whose farthest vertex is beyond threshold * h is cut (Voronoi.f90:233: 3)
-  int n_vectors;                // faces of the Platonic solid (12 or 20)
+  int n_vectors;                // faces of the Platonic solid (<= 12: planes that meet three to a vertex, the dodecahedron)
   double cut_vec[20][3];        // their unit normals (init_Platonic_Solid, Voronoi.f90:108-181)
   double cutting_distance_o_h;  // distance of those faces in units of h
   int k;                        // candidates per cell (rows of knn), or 0 with knn_first

@@ -123,13 +123,25 @@ __device__ inline int voro_index_cell(const VoroGrid& G, double x, double y, dou
   return ic;
 }
 
+#ifdef MCGPU_VORO_DIAG  // diagnostic builds (tests/devtools/voro_diag.py): where a wave's instructions go
+// VD(w, l): this statement is reached by some lanes of the wave: count the wave once (w) and the lanes (l)
+struct VoroDiag { unsigned int c[10]; };
+#define VD(D, w, l) do { const unsigned long long m__ = __ballot(1); \
+    if ((int)(threadIdx.x & 63) == __ffsll((long long)m__) - 1) (D).c[w]++; (D).c[l]++; } while (0)
+#define VDARG , VoroDiag* VDp = nullptr
+#define VDPASS , &VDg
+#else
+#define VDARG
+#define VDPASS
+#endif
+
 // cross_Voronoi_cell (Voronoi.f90:839-992).  C = the cell's record (loaded by the caller, who also
 // needs its opacity factor).
 __device__ inline void voro_cross_cell(const VoroGrid& G, const DevModel& M, const VoroCell& C, double x,
                                        double y, double z, double u, double v, double w, int icell,
                                        int previous_cell, double& x1, double& y1, double& z1,
                                        int& next_cell, double& s_out, double& s_contrib,
-                                       double& s_void_before) {
+                                       double& s_void_before VDARG) {
   const float r0 = (float)x, r1 = (float)y, r2 = (float)z;
   const float k0 = (float)u, k1 = (float)v, k2 = (float)w;
   // The reference keeps the smallest quotient s_tmp = num / den over the neighbours (:859-905), one FP64 division per
@@ -166,6 +178,9 @@ __device__ inline void voro_cross_cell(const VoroGrid& G, const DevModel& M, con
     for (int j = 0; j < VG; ++j) Nn[j] = nb[j < cnt ? j : last];
   }
   for (int i0 = 0; i0 < cnt; i0 += VG) {
+#if MCGPU_VORO_DIAG == 2
+    if (VDp) VD(*VDp, 1, 2);
+#endif
     VoroNb Nc[VG];
     if (MCGPU_VORO_AHEAD) {
 #pragma unroll
@@ -199,6 +214,9 @@ __device__ inline void voro_cross_cell(const VoroGrid& G, const DevModel& M, con
   }
   double s = s_num / s_den;
   while (__builtin_expect(walls != 0ull, 0)) {
+#if MCGPU_VORO_DIAG == 2
+    if (VDp) VD(*VDp, 3, 4);
+#endif
     const int wid = (int)(walls & 7ull), pos = (int)((walls >> 3) & 127ull);
     walls >>= 10;
     double s_tmp = voro_distance_to_wall(G, x, y, z, u, v, w, wid);
@@ -210,6 +228,9 @@ __device__ inline void voro_cross_cell(const VoroGrid& G, const DevModel& M, con
   y1 = nd_add(y, nd_mul(v, s));
   z1 = nd_add(z, nd_mul(w, s));
   if (next_cell == 0) {  // rounding error somewhere (:926-937)
+#if MCGPU_VORO_DIAG == 2
+    if (VDp) VDp->c[9]++;
+#endif
     x1 = x; y1 = y; z1 = z; s = 0.0;
     if (voro_is_in_volume(G, x, y, z)) {
       next_cell = voro_index_cell(G, x, y, z);
@@ -219,6 +240,9 @@ __device__ inline void voro_cross_cell(const VoroGrid& G, const DevModel& M, con
     }
   }
   if (C.flags & 1) {  // cut cell: only the sphere of radius h*cutting_distance_o_h holds matter (:939-975)
+#if MCGPU_VORO_DIAG == 2
+    if (VDp) VD(*VDp, 5, 6);
+#endif
     const double d0 = (double)nf_sub(r0, C.x), d1 = (double)nf_sub(r1, C.y), d2 = (double)nf_sub(r2, C.z);
     const double b = nd_add(nd_add(nd_mul(d0, (double)k0), nd_mul(d1, (double)k1)), nd_mul(d2, (double)k2));
     const double hc = nd_mul(G.h[icell - 1], G.cut_o_h);
@@ -242,6 +266,9 @@ __device__ inline void voro_cross_cell(const VoroGrid& G, const DevModel& M, con
     s_void_before = 0.0; s_contrib = s;
   }
   if (C.flags & 2) {  // star neighbour (:977-988)
+#if MCGPU_VORO_DIAG == 2
+    if (VDp) VD(*VDp, 7, 8);
+#endif
     int i_star;
     const double d_to_star = voro_distance_to_star(M, x, y, z, u, v, w, i_star);
     if (i_star > 0 && d_to_star < s) {
@@ -364,9 +391,19 @@ __device__ __forceinline__ void thermal_body_voro(const DevModel& M, const RunAr
   int n_inter = 0;            // MRW: interactions in a row whose flights never left the cell (0..7)
   bool first_cross = true;    // MRW: the flight is still in the cell it started in
   unsigned int c_walks = 0, c_steps = 0;
+#ifdef MCGPU_VORO_DIAG
+  VoroDiag VDg;
+  for (int q = 0; q < 10; ++q) VDg.c[q] = 0u;
+#endif
 
   for (int ep = 0;; ++ep) {
+#if MCGPU_VORO_DIAG == 1
+    if (st != S_DONE) VD(VDg, 1, 2);   // outer rounds, lanes that own a packet
+#endif
     if (st == S_EXITED) {
+#if MCGPU_VORO_DIAG == 1
+      VD(VDg, 9, 9);
+#endif
       if (!flag_ism) {
         capteur<POLA>(M, A.sed, lambda, u, v, w, S, flag_star, flag_scatt);
         c_esc++;
@@ -394,6 +431,9 @@ __device__ __forceinline__ void thermal_body_voro(const DevModel& M, const RunAr
         if (need && !served && pk_next >= A.n_packets) st = S_DONE;
         pk_next += (cnt < avail) ? cnt : avail;
         if (served) {
+#if MCGPU_VORO_DIAG == 1
+          VD(VDg, 7, 8);
+#endif
           // mc_photon_loop body (dust_transfer.f90:529-541)
           rng.init(A.seed, A.first_packet + my);
           c_pack++;
@@ -420,6 +460,9 @@ __device__ __forceinline__ void thermal_body_voro(const DevModel& M, const RunAr
     }
 
     if (st == S_INTERACT) {  // dust_transfer.f90:1260-1402
+#if MCGPU_VORO_DIAG == 1
+      VD(VDg, 3, 4);
+#endif
       float g[8];
       rng.interaction_event(g, M.m1 != 0);
       tau_rand = g[5];
@@ -455,6 +498,9 @@ __device__ __forceinline__ void thermal_body_voro(const DevModel& M, const RunAr
     }
 
     if (st == S_NEWFLIGHT) {
+#if MCGPU_VORO_DIAG == 3
+      VD(VDg, 7, 8);
+#endif
       const float rand = tau_rand;  // dust_transfer.f90:1208-1215
       extr = tau_of_draw(rand);
       const int i_star = intersect_stars(M, x, y, z, u, v, w);  // optical_depth.f90:68
@@ -475,6 +521,9 @@ __device__ __forceinline__ void thermal_body_voro(const DevModel& M, const RunAr
         if (flying * 64 < A.min_active * alive) break;
       }
       if (st == S_FLIGHT) {
+#if MCGPU_VORO_DIAG == 1
+        VD(VDg, 5, 6);
+#endif
         if (icell < 0) {  // test_exit_grid_Voronoi (:1446)
           st = S_EXITED;
         } else if (star_icell > 0 && icell == star_icell) {  // optical_depth.f90:91-97
@@ -493,10 +542,13 @@ __device__ __forceinline__ void thermal_body_voro(const DevModel& M, const RunAr
           }
           double x1, y1, z1, l, l_contrib, l_void;
           int next;
-          voro_cross_cell(G, M, C, x, y, z, u, v, w, icell, prev_cell, x1, y1, z1, next, l, l_contrib, l_void);
+          voro_cross_cell(G, M, C, x, y, z, u, v, w, icell, prev_cell, x1, y1, z1, next, l, l_contrib, l_void VDPASS);
           c_cross++;
           const double tau = l_contrib * opacity;
           if (tau > extr) {
+#if MCGPU_VORO_DIAG == 3
+            VD(VDg, 1, 2);
+#endif
             const double lc = l_contrib * (extr / tau);
             const double ls = l_void + lc;
             const double dE = kabs_c * lc * S[0];
@@ -510,6 +562,9 @@ __device__ __forceinline__ void thermal_body_voro(const DevModel& M, const RunAr
             st = S_INTERACT;
             if (MRW) n_inter = first_cross ? (n_inter < 7 ? n_inter + 1 : 7) : 0;  // dust_transfer.f90:1244-1249
           } else {
+#if MCGPU_VORO_DIAG == 3
+            VD(VDg, 3, 4);
+#endif
             first_cross = false;
             extr = extr - tau;
             const double dE = kabs_c * l_contrib * S[0];
@@ -555,13 +610,21 @@ __device__ __forceinline__ void thermal_body_voro(const DevModel& M, const RunAr
   }
 
   unsigned int cs[8] = {c_pack, c_cross, c_flight, c_scatt, c_abs, c_esc, c_kill, 0u};
+#ifdef MCGPU_VORO_DIAG  // counters 1..9 carry the statistics of this diagnostic build instead
+  for (int q = 1; q < 8; ++q) cs[q] = VDg.c[q];
+  c_walks = VDg.c[8]; c_steps = VDg.c[9];
+#endif
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
     unsigned long long vsum = cs[q];
     for (int off = 32; off > 0; off >>= 1) vsum += __shfl_down(vsum, off);
     if (lane == 0 && vsum) atomicAdd(&A.counters[q], vsum);
   }
+#ifdef MCGPU_VORO_DIAG
+  if (true) {
+#else
   if (MRW) {
+#endif
     unsigned long long v8 = c_walks, v9 = c_steps;
     for (int off = 32; off > 0; off >>= 1) { v8 += __shfl_down(v8, off); v9 += __shfl_down(v9, off); }
     if (lane == 0 && v8) atomicAdd(&A.counters[8], v8);

@@ -1137,6 +1137,8 @@ extern "C" int mcgpu_set_mrw_exit_spectrum(mcgpu_ctx* ctx, const double* exit_cd
     for (int l = 1; l < M.n_lambda; ++l)
       if (!(c[l] >= c[l - 1])) return fail(ctx, MCGPU_ERR_ARG, "mcgpu_set_mrw_exit_spectrum: a row decreases");
     if (!(c[0] >= 0.0) || !(c[M.n_lambda - 1] <= 1.0 + 1e-12)) return fail(ctx, MCGPU_ERR_ARG, "mcgpu_set_mrw_exit_spectrum: a row leaves [0, 1]");
+    // (a row that never reaches 1 -- all zero, or not normalised -- would send every draw above its end to the last wavelength)
+    if (!(c[M.n_lambda - 1] >= 1.0 - 1e-12)) return fail(ctx, MCGPU_ERR_ARG, "mcgpu_set_mrw_exit_spectrum: a row does not end in 1");
   }
   HIPCHK(hipSetDevice(ctx->device));
   return upload(ctx, exit_cdf, rows * (size_t)M.n_lambda, &M.mrw_exit_cdf);
@@ -3074,6 +3076,7 @@ struct mcgpu_multi {
   std::vector<mcgpu_ctx*> ctx;
   std::vector<ncclComm_t> comm;   // empty until the first collective (one device never needs them)
   bool shared = false;            // MCGPU_MULTI_SHARED_DEVICE: every context on ONE device, sums by k_sum_into (RCCL refuses duplicate devices)
+  bool force_rccl = false;        // MCGPU_MULTI_FORCE_RCCL: the communicator and the all-reduce also with ONE device (a sum over one rank)
   std::vector<hipEvent_t> ev;     // shared mode: one event per context for the cross-stream ordering of the in-library sum
   unsigned long long n_reduce = 0; // collectives executed (either kind)
   bool reduced = false;           // the accumulators of every device hold the all-reduced totals of the last call
@@ -3103,10 +3106,15 @@ __global__ void k_sum_into_f32(float* a, const float* b, size_t n) {
 // and the reduction is the library's own sum kernel -- RCCL refuses a communicator with a device twice.  This is how
 // the sharding, rescaling, counter and error logic of n_dev > 1 is executed on a box with one GPU (tests, dry runs);
 // a production host passes flags = 0 and distinct devices.
+// flags = MCGPU_MULTI_FORCE_RCCL: open the RCCL communicator and run the grouped ncclAllReduce of every buffer also when
+// n_dev = 1 (ncclCommInitAll over one rank; the sum over one rank leaves the buffers as they are), so that the
+// collective path -- counters into the accumulator's tail, the group call, counters back -- executes on a box with one
+// GPU.  Not with MCGPU_MULTI_SHARED_DEVICE (no communicator exists there).
 extern "C" int mcgpu_multi_create_ex(int n_dev, const int* devices, unsigned int flags, mcgpu_multi** out) {
-  if (!out || n_dev < 1 || (flags & ~(unsigned int)MCGPU_MULTI_SHARED_DEVICE)) return MCGPU_ERR_ARG;
+  if (!out || n_dev < 1 || (flags & ~(unsigned int)(MCGPU_MULTI_SHARED_DEVICE | MCGPU_MULTI_FORCE_RCCL))) return MCGPU_ERR_ARG;
   *out = nullptr;
   const bool shared = (flags & MCGPU_MULTI_SHARED_DEVICE) != 0;
+  if (shared && (flags & MCGPU_MULTI_FORCE_RCCL)) return MCGPU_ERR_ARG;
   int n_have = 0;
   if (hipGetDeviceCount(&n_have) != hipSuccess || n_have <= 0) return MCGPU_ERR_NO_DEVICE;
   std::vector<int> devs(n_dev);
@@ -3119,6 +3127,7 @@ extern "C" int mcgpu_multi_create_ex(int n_dev, const int* devices, unsigned int
   mm->n_dev = n_dev;
   mm->devs = devs;
   mm->shared = shared;
+  mm->force_rccl = (flags & MCGPU_MULTI_FORCE_RCCL) != 0;
   mm->ctx.assign(n_dev, nullptr);
   for (int i = 0; i < n_dev; ++i) {
     const int rc = mcgpu_create(devs[i], &mm->ctx[i]);
@@ -3143,9 +3152,9 @@ extern "C" int mcgpu_multi_create(int n_dev, const int* devices, mcgpu_multi** o
   return mcgpu_multi_create_ex(n_dev, devices, 0u, out);
 }
 
-// the RCCL communicators, created by the first call that has something to reduce (n_dev > 1)
+// the RCCL communicators, created by the first call that has something to reduce (n_dev > 1, or forced)
 static int multi_comms(mcgpu_multi* mm) {
-  if (mm->n_dev < 2 || mm->shared || !mm->comm.empty()) return MCGPU_OK;
+  if ((mm->n_dev < 2 && !mm->force_rccl) || mm->shared || !mm->comm.empty()) return MCGPU_OK;
   mm->comm.assign(mm->n_dev, nullptr);
   if (ncclCommInitAll(mm->comm.data(), mm->n_dev, mm->devs.data()) != ncclSuccess) {
     mm->comm.clear();
@@ -3234,7 +3243,7 @@ static int multi_prepare_accumulate(mcgpu_multi* mm, int what) {
 static int multi_allreduce(mcgpu_multi* mm, int what) {
   const int n = mm->n_dev;
   auto failed = [&](int i, int rc) { mm->err = "device " + std::to_string(i) + ": " + mcgpu_last_error(mm->ctx[i]); return rc; };
-  if (n < 2) return MCGPU_OK;
+  if (n < 2 && !mm->force_rccl) return MCGPU_OK;
   int rc = multi_comms(mm);
   if (rc) return rc;
   for (int i = 0; i < n; ++i) if ((rc = mcgpu_counters_to_accum(mm->ctx[i]))) return failed(i, rc);

@@ -30,6 +30,10 @@ extern "C" int mcgpu_voronoi_tesselation(int device, int n, const double* xyz, c
   if (n < 1 || !xyz || !h || !limits || n_run < 0 || (k < 1 && !knn_first) || !knn || max_neighbours < 4 || !n_neigh || !neigh || !volume ||
       !delta_edge || !was_cut || n_vectors < 0 || n_vectors > 20 || (n_vectors > 0 && !cutting_vectors) || !(threshold > 0.0))
     return MCGPU_ERR_ARG;
+  // The kernel keeps a vertex as the THREE planes that meet in it (general position).  The 12 cutting planes of the
+  // dodecahedron -- the reference's solid, Voronoi.f90:243 -- meet three to a vertex; the 20 of the icosahedron's dual
+  // meet five to a vertex, which the clipping does not represent: refused rather than cut wrongly.
+  if (n_vectors > 12) return MCGPU_ERR_UNSUPPORTED;
   int n_have = 0;
   if (hipGetDeviceCount(&n_have) != hipSuccess || n_have <= 0) return MCGPU_ERR_NO_DEVICE;
   if (device < 0 || device >= n_have) return MCGPU_ERR_ARG;
@@ -72,17 +76,18 @@ extern "C" int mcgpu_voronoi_tesselation(int device, int n, const double* xyz, c
   A.xyz = d_xyz.p; A.h = d_h.p; A.knn = d_knn.p; A.cells = d_cells.p; A.extra_plane = d_extra.p;
   if (volume_uncut) { TCHK(d_vol0.alloc(n_run)); TCHK(hipMemset(d_vol0.p, 0, (size_t)n_run * sizeof(double))); A.volume_uncut = d_vol0.p; }
   A.n_neigh = d_nn.p; A.neigh = d_neigh.p; A.volume = d_vol.p; A.delta_edge = d_edge.p; A.was_cut = d_cut.p;
-  hipEvent_t e0, e1;
-  TCHK(hipEventCreate(&e0)); TCHK(hipEventCreate(&e1));
-  TCHK(hipEventRecord(e0, 0));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (hipEventCreate(&e0) != hipSuccess) return MCGPU_ERR_HIP;
+  if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return MCGPU_ERR_HIP; }
+  hipError_t re = hipEventRecord(e0, 0);
   hipLaunchKernelGGL(k_voronoi_cells, dim3((unsigned)((n_run + 63) / 64)), dim3(64), 0, 0, A);
   hipError_t le = hipGetLastError();
-  TCHK(hipEventRecord(e1, 0));
+  if (re == hipSuccess) re = hipEventRecord(e1, 0);
   hipError_t se = hipDeviceSynchronize();
   float ms = 0.f;
-  (void)hipEventElapsedTime(&ms, e0, e1);
+  if (re == hipSuccess) (void)hipEventElapsedTime(&ms, e0, e1);
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-  if (le != hipSuccess || se != hipSuccess) return MCGPU_ERR_HIP;
+  if (re != hipSuccess || le != hipSuccess || se != hipSuccess) return MCGPU_ERR_HIP;
   if (kernel_ms) *kernel_ms = ms;
   TCHK(hipMemcpy(n_neigh, d_nn.p, (size_t)n_run * sizeof(int), hipMemcpyDeviceToHost));
   TCHK(hipMemcpy(neigh, d_neigh.p, (size_t)n_run * max_neighbours * sizeof(int), hipMemcpyDeviceToHost));

@@ -812,9 +812,11 @@ class MultiEngine:
     replica of the model, packets sharded by id range, ONE RCCL all-reduce of the fused accumulator per
     temperature iteration inside the library."""
 
-    def __init__(self, model, n_packets_total, devices=(0,), shared_device=False):
+    def __init__(self, model, n_packets_total, devices=(0,), shared_device=False, force_rccl=False):
         """``shared_device``: every context on ONE device (``devices`` all equal) with the library's own sum kernel in
-        place of the RCCL all-reduce (``MCGPU_MULTI_SHARED_DEVICE``): how a box with one GPU executes the n_dev > 1 code."""
+        place of the RCCL all-reduce (``MCGPU_MULTI_SHARED_DEVICE``): how a box with one GPU executes the n_dev > 1 code.
+        ``force_rccl`` (``MCGPU_MULTI_FORCE_RCCL``): the communicator and the grouped ``ncclAllReduce`` also with one
+        device -- how a box with one GPU executes the RCCL calls."""
         self.lib = load_library()
         self.model = model
         self.h = C.c_void_p()
@@ -822,7 +824,7 @@ class MultiEngine:
         self.lib.mcgpu_multi_ctx.restype = C.c_void_p
         self.lib.mcgpu_multi_last_error.restype = C.c_char_p
         self.lib.mcgpu_multi_reductions.restype = C.c_uint64
-        rc = self.lib.mcgpu_multi_create_ex(C.c_int(len(devices)), devs, C.c_uint(1 if shared_device else 0), C.byref(self.h))
+        rc = self.lib.mcgpu_multi_create_ex(C.c_int(len(devices)), devs, C.c_uint((1 if shared_device else 0) | (2 if force_rccl else 0)), C.byref(self.h))
         if rc:
             self.h = C.c_void_p()
             raise McgpuError(f"mcgpu_multi_create({list(devices)}) failed with code {rc}")

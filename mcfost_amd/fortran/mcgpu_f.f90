@@ -23,6 +23,7 @@ module mcgpu_f
 
   integer(c_int), parameter, public :: MCGPU_N_SED_TYPES = 9, MCGPU_N_COUNTERS = 10
   integer(c_int), parameter, public :: MCGPU_MULTI_SHARED_DEVICE = 1
+  integer(c_int), parameter, public :: MCGPU_MULTI_FORCE_RCCL = 2   ! the RCCL all-reduce also with n_dev = 1 (a sum over one rank)
 
   type, bind(C), public :: mcgpu_run_opts
      integer(c_int64_t) :: seed

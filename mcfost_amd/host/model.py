@@ -986,7 +986,8 @@ def init_mrw(m: "Model", gamma: float = 2.0, n_inter: int = 5, n_zeta: int = 100
                 ext[c, t] = ext_factor * 0.7104 * (wgt / k_tr ** 2).sum() / (wgt / k_tr).sum()
                 if exit_cdf is not None:
                     exit_cdf[c, t] = np.cumsum(wgt) / norm
-                    exit_cdf[c, t, -1] = 1.0
+            if exit_cdf is not None:
+                exit_cdf[c, t, -1] = 1.0   # (every row ends in exactly 1, also one without weight: chi = 0 there, no walk)
     if vd is None:
         chi, kdep, ext = chi[0], kdep[0], ext[0]
     else:

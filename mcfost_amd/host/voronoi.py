@@ -400,16 +400,23 @@ def _grid_from_knn(pts, n_before, limits, stars_xyz_r, star_icell, h, cutting_di
             extra[cells, 3] = dist - sx[:, 3]
             sub = np.zeros(n, bool)
             sub[cells] = True
-            # (only those cells: the kernel takes the list of cells to build)
-            from scipy.spatial import cKDTree
-            kk = min(256, n - 1)
-            _, idx = cKDTree(pts).query(pts[cells], k=kk + 1)
-            cand = np.ascontiguousarray(idx[:, 1:].astype(np.int32))
+            # (only those cells: the kernel takes the list of cells to build).  Candidates: the cell's own faces of the full
+            # pass -- every site that bounds the uncut cell, so none is missing for the cell cut once more and no security
+            # radius is involved (a kd-tree list of 256 left the surface cells next to a star, which reach far into the
+            # void, incomplete, and they silently kept the volume without the stellar cut)
+            rows = [neigh[c, :n_neigh[c]] for c in cells]
+            rows = [r[r >= 0] for r in rows]
+            rows = [r[np.argsort(((pts[r] - pts[c]) ** 2).sum(axis=1), kind="stable")] for r, c in zip(rows, cells)]
+            cfirst = np.zeros(cells.size + 1, np.int32)
+            cfirst[1:] = np.cumsum([r.size for r in rows])
+            cand = np.ascontiguousarray(np.concatenate(rows).astype(np.int32))
             nn2, _, v2, _, _ = kernel(n, np.ascontiguousarray(pts), np.ascontiguousarray(h_run), limits, threshold, vectors, cd,
                                       np.ascontiguousarray(cells.astype(np.int32)), cand, np.ascontiguousarray(extra[cells]),
-                                      neigh.shape[1])
-            done = nn2 >= 0
-            vol[cells[done]] = v2[done]
+                                      neigh.shape[1], knn_first=cfirst)
+            if (nn2 < 0).any():
+                raise RuntimeError("tessellation: %d star neighbours could not be cut at the stellar surface (code %d)"
+                                   % (int((nn2 < 0).sum()), int(nn2[nn2 < 0][0])))
+            vol[cells] = v2
 
     wl_sets = []
     wall_first = np.zeros(7, np.int32)

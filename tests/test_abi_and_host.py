@@ -89,3 +89,16 @@ def test_model_tables_are_consistent(ref41_model):
 def test_3d_model_has_the_baseline_cell_count():
     g = M.define_cylindrical_grid(M.ref41_3d())
     assert g["n_cells"] == 720000 and g["ntot2"] == 102 * 102 * 72
+
+
+def test_more_gpus_than_the_node_has_is_an_error_not_a_number():
+    """`bench.py --gpus N` started plainly on a node with fewer GPUs must fail with a message, not print a line."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64", "--packets", "1e5", "--steps", "1",
+                          "--warmup", "0", "--no-cpu-baseline", "--no-extra"], capture_output=True, text=True, timeout=600,
+                         env=env, cwd=root)
+    assert out.returncode != 0 and "--gpus 64" in out.stderr and "GPU(s)" in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]

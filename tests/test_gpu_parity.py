@@ -227,25 +227,23 @@ def test_accumulate_is_linear(small_model):
     e.close()
 
 
-def test_live_mode_statistical_parity_ref41(ref41_model):
-    """The reference algorithm proper (live immediate re-emission)."""
+@pytest.mark.parametrize("n", [1_000_000, 8_000_000])
+def test_live_mode_statistical_parity_ref41(ref41_model, n):
+    """The reference algorithm proper (live immediate re-emission), at two packet counts: the event counts of device and
+    oracle differ by an early-estimate effect of the in-flight temperature (the oracle scales a per-thread partial sum by
+    nb_proc, thermal_emission.f90:670; the device folds a global sum) that must SHRINK with N: the gate does."""
     m = ref41_model
-    n = 1_000_000
     e, o = _engine(m, n), _oracle(m, n)
     a = e.run_thermal(n, seed=21)
     b = o.run_thermal(n, seed=22, n_threads=8)         # independent noise realisation
     ca, cb = a["counters"], b["counters"]
     assert ca["packets"] == n and ca["escaped"] + ca["killed_star"] == n
+    # measured (tests/devtools/live_counts.py): device / oracle = 1.067 at 1e6 packets, 1.028 at 8e6; device seed to seed
+    # 0.3 %, the 8-thread oracle seed to seed 3 % (its per-thread sums are the noisier estimate): the bound is the
+    # effect's size at N, max(3 %, 7 % sqrt(1e6 / N)), plus that scatter of the oracle
+    tol = max(0.03, 0.07 * np.sqrt(1.0e6 / n)) + 0.03
     for k in ("crossings", "flights", "scatterings", "absorptions"):
-        # live feedback: the oracle estimates the in-flight temperature from a per-thread partial
-        # sum * nb_proc (thermal_emission.f90:670), the device from the folded global sum plus its
-        # workgroup's partial * n_workgroups: same limit, different noise early in a run this
-        # small (8 packets per lane) -> a several-percent shift of the event counts.  Measured
-        # (tests/devtools/live_counts.py, round 4): device / oracle = 1.067 at 1e6 packets and 1.028 at 8e6 (it shrinks
-        # with N as an early-estimate effect must), device seed to seed 0.3 %, the 8-thread oracle seed to seed 3 %
-        # (its per-thread sums are the noisier estimate).  The gate on the physics is the temperature and SED
-        # comparison below.
-        assert abs(ca[k] / cb[k] - 1) < 0.15, k
+        assert abs(ca[k] / cb[k] - 1) < tol, (k, ca[k] / cb[k], tol)
     Ta, Tb = e.temp_finale(a["E_abs"]), o.temp_finale(b["E_abs"])
     T_floor = 1.01 * m.cfg.T_min
     # sigma_MC(N) ~ 1.7 % sqrt(1.28e5/N) for one run (BASELINE.md); two independent runs -> sqrt(2)
