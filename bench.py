@@ -272,6 +272,11 @@ def thermal_block(par, args, config, steps, warmup, with_cpu, n_local):
     if args.tail >= 0:
         for x in (me.engines if me is not None else [eng]):
             x.set_option("tail", args.tail)
+    for name, value in (("schedule", args.schedule), ("voronoi_pool_log_records", args.pool_log_records),
+                        ("voronoi_cache_log_slots", args.cache_log_slots)):
+        if value >= 0:
+            for x in (me.engines if me is not None else [eng]):
+                x.set_option(name, value)
     if args.frozen:
         eng.set_E_prior(eng.run_thermal(min(n_local, 2_000_000), seed=5)["E_abs"] * (n_local / min(n_local, 2_000_000)))
     last = {}
@@ -575,6 +580,9 @@ def main():
                          "fused device buffer over that world of one -- how a box with one GPU executes the one-process-per-GPU path")
     ap.add_argument("--tail", type=int, default=-1, help="tuning aid: option \"tail\" (packets left per workgroup at the hand-over to "
                     "k_tail; -1 = the library's choice)")
+    ap.add_argument("--schedule", type=int, default=-1, help="tuning aid: option \"schedule\" (include/mcgpu.h)")
+    ap.add_argument("--pool-log-records", type=int, default=-1, help="tuning aid: option \"voronoi_pool_log_records\"")
+    ap.add_argument("--cache-log-slots", type=int, default=-1, help="tuning aid: option \"voronoi_cache_log_slots\"")
     ap.add_argument("--grid-blocks", type=int, default=0)
     ap.add_argument("--block-threads", type=int, default=0)
     ap.add_argument("--no-pola", action="store_true", help="tuning aid: do not track Stokes Q,U,V")

@@ -178,10 +178,13 @@ int mcgpu_set_midplane_snap(mcgpu_ctx *ctx, int on);
  *   "schedule"     0 = automatic (default): waves with roles and LDS packet queues where
  *                      the queues fit (cylindrical grids; Voronoi grids run the single-role
  *                      kernel, which is faster on them); 1 = the single-role kernel;
- *                      2 = the role schedule wherever it is built (also Voronoi grids)
+ *                      2 = the role schedule wherever it is built (also Voronoi grids);
+ *                      3 = Voronoi grids: the pool schedule (packet records in HBM, queues by phase and
+ *                      by neighbour-list length in LDS, one phase per wave pass; mc_voronoi_pool.hip.h)
  *   "speculation"  SED mode: 1 (default) = most of every stream is committed before the
  *                      scout pass (exact; see mcgpu_run_mono), 0 = scout every packet first
  *   "voronoi_cache_log_slots"  6..13 (default 13): log2 of the slots of the Voronoi deposit cache
+ *   "voronoi_pool_log_records" 6..12 (default 12): log2 of the packet records per workgroup of schedule 3
  *   "radiation_field"  bit 0: keep xN_abs, bit 1: keep xJ_abs in the thermal step (mcgpu_fetch_radiation_field);
  *                      cylindrical grids then run the single-role kernel
  * Results do not depend on any of them (same packets, same random numbers).

@@ -53,6 +53,7 @@ struct VoroGrid {
   const double* xyz_dp;   // Voronoi(:)%xyz (3 per cell)
   const int* wall_first;  // [7]
   const int* wall_cells;  // wall(iwall)%neighbour_list, concatenated
+  const unsigned char* nb_cls;  // per entry of nb: the neighbour cell's list-length class (vp_class_of, mc_voronoi_pool.hip.h); 0 for walls
   float walls[24];        // 6 x (x1,x2,x3,x4) (Voronoi.f90:1275-1280)
   double cut_o_h;         // PS%cutting_distance_o_h
 };
@@ -129,7 +130,7 @@ struct VoroDiag { unsigned int c[10]; };
 #define VD(D, w, l) do { const unsigned long long m__ = __ballot(1); \
     if ((int)(threadIdx.x & 63) == __ffsll((long long)m__) - 1) (D).c[w]++; (D).c[l]++; } while (0)
 #define VDARG , VoroDiag* VDp = nullptr
-#define VDPASS , &VDg
+#define VDPASS , nullptr, &VDg
 #else
 #define VDARG
 #define VDPASS
@@ -137,11 +138,15 @@ struct VoroDiag { unsigned int c[10]; };
 
 // cross_Voronoi_cell (Voronoi.f90:839-992).  C = the cell's record (loaded by the caller, who also
 // needs its opacity factor).
+// BATCH > 0 (the pool schedule): the records are requested BATCH at a time, all of a batch back to back before the first
+// is looked at -- a list of up to BATCH neighbours costs ONE memory latency instead of one per group of four (measured:
+// the scan was 46 % of the pool's wave time, waiting; tests/devtools/voro_pool_diag.py) -- at the price of 4 BATCH registers.
+template <int BATCH = 0>
 __device__ inline void voro_cross_cell(const VoroGrid& G, const DevModel& M, const VoroCell& C, double x,
                                        double y, double z, double u, double v, double w, int icell,
                                        int previous_cell, double& x1, double& y1, double& z1,
                                        int& next_cell, double& s_out, double& s_contrib,
-                                       double& s_void_before VDARG) {
+                                       double& s_void_before, int* cls_out = nullptr VDARG) {
   const float r0 = (float)x, r1 = (float)y, r2 = (float)z;
   const float k0 = (float)u, k1 = (float)v, k2 = (float)w;
   // The reference keeps the smallest quotient s_tmp = num / den over the neighbours (:859-905), one FP64 division per
@@ -172,6 +177,35 @@ __device__ inline void voro_cross_cell(const VoroGrid& G, const DevModel& M, con
 #ifndef MCGPU_VORO_AHEAD
 #define MCGPU_VORO_AHEAD 1
 #endif
+  // one neighbour of the list (position i): Voronoi.f90:879-917
+  auto look_at = [&](const VoroNb& N, int i) {
+    if (i >= cnt || N.id == previous_cell) return;
+    if (N.id > 0) {
+      const float n0 = nf_sub(N.x, C.x), n1 = nf_sub(N.y, C.y), n2 = nf_sub(N.z, C.z);
+      const double den = (double)dot3f(n0, n1, n2, k0, k1, k2);
+      if (den <= 0.0) return;
+      const float p0 = nf_mul(0.5f, nf_add(N.x, C.x)), p1 = nf_mul(0.5f, nf_add(N.y, C.y)),
+                  p2 = nf_mul(0.5f, nf_add(N.z, C.z));
+      const double num = (double)dot3f(n0, n1, n2, nf_sub(p0, r0), nf_sub(p1, r1), nf_sub(p2, r2));
+      // num < 0: the reference sets s_tmp = huge(1.0) > 1e30, never the minimum
+      if (!(num < 0.0) && nd_mul(num, s_den) < nd_mul(s_num, den)) { s_num = num; s_den = den; next_cell = N.id; best_pos = i; }
+    } else {
+      walls = (walls << 10) | (unsigned long long)(((i < 127 ? i : 127) << 3) | (-N.id));
+    }
+  };
+  if (BATCH > 0) {
+    constexpr int VB = BATCH > 0 ? BATCH : 4;
+    for (int i0 = 0; i0 < cnt; i0 += VB) {
+      VoroNb Nb[VB];
+#pragma unroll
+      for (int j = 0; j < VB; ++j) Nb[j] = nb[(i0 + j < cnt) ? i0 + j : last];
+#pragma unroll
+      for (int j = 0; j < VB; ++j) {
+        if ((j & 3) == 0 && j > 0 && __ballot(i0 + j < cnt) == 0ull) break;   // (no lane of the wave has a neighbour left in this batch)
+        look_at(Nb[j], i0 + j);
+      }
+    }
+  } else {
   VoroNb Nn[VG];
   if (MCGPU_VORO_AHEAD) {
 #pragma unroll
@@ -194,23 +228,8 @@ __device__ inline void voro_cross_cell(const VoroGrid& G, const DevModel& M, con
       for (int j = 0; j < VG; ++j) Nc[j] = nb[(i0 + j < cnt) ? i0 + j : last];
     }
 #pragma unroll
-    for (int j = 0; j < VG; ++j) {
-      const int i = i0 + j;
-      const VoroNb N = Nc[j];
-      if (i >= cnt || N.id == previous_cell) continue;
-      if (N.id > 0) {
-        const float n0 = nf_sub(N.x, C.x), n1 = nf_sub(N.y, C.y), n2 = nf_sub(N.z, C.z);
-        const double den = (double)dot3f(n0, n1, n2, k0, k1, k2);
-        if (den <= 0.0) continue;
-        const float p0 = nf_mul(0.5f, nf_add(N.x, C.x)), p1 = nf_mul(0.5f, nf_add(N.y, C.y)),
-                    p2 = nf_mul(0.5f, nf_add(N.z, C.z));
-        const double num = (double)dot3f(n0, n1, n2, nf_sub(p0, r0), nf_sub(p1, r1), nf_sub(p2, r2));
-        // num < 0: the reference sets s_tmp = huge(1.0) > 1e30, never the minimum
-        if (!(num < 0.0) && nd_mul(num, s_den) < nd_mul(s_num, den)) { s_num = num; s_den = den; next_cell = N.id; best_pos = i; }
-      } else {
-        walls = (walls << 10) | (unsigned long long)(((i < 127 ? i : 127) << 3) | (-N.id));
-      }
-    }
+    for (int j = 0; j < VG; ++j) look_at(Nc[j], i0 + j);
+  }
   }
   double s = s_num / s_den;
   while (__builtin_expect(walls != 0ull, 0)) {
@@ -231,6 +250,7 @@ __device__ inline void voro_cross_cell(const VoroGrid& G, const DevModel& M, con
 #if MCGPU_VORO_DIAG == 2
     if (VDp) VDp->c[9]++;
 #endif
+    best_pos = -1;
     x1 = x; y1 = y; z1 = z; s = 0.0;
     if (voro_is_in_volume(G, x, y, z)) {
       next_cell = voro_index_cell(G, x, y, z);
@@ -239,6 +259,10 @@ __device__ inline void voro_cross_cell(const VoroGrid& G, const DevModel& M, con
       next_cell = -1;
     }
   }
+  // (the pool schedule, mc_voronoi_pool.hip.h: the list-length class of the cell entered, a byte per neighbour; read here,
+  // ahead of the cut-cell and star code, so that its latency is theirs; -1: the next cell did not come out of the scan)
+  int cls_next = -1;
+  if (cls_out && next_cell > 0 && best_pos >= 0 && best_pos < cnt) cls_next = (int)G.nb_cls[C.first + best_pos];
   if (C.flags & 1) {  // cut cell: only the sphere of radius h*cutting_distance_o_h holds matter (:939-975)
 #if MCGPU_VORO_DIAG == 2
     if (VDp) VD(*VDp, 5, 6);
@@ -274,9 +298,11 @@ __device__ inline void voro_cross_cell(const VoroGrid& G, const DevModel& M, con
     if (i_star > 0 && d_to_star < s) {
       s_contrib = d_to_star;
       next_cell = M.star_cell[4 * (i_star - 1)];
+      cls_next = -1;
     }
   }
   s_out = s;
+  if (cls_out) *cls_out = cls_next;
 }
 
 // move_to_grid_Voronoi (Voronoi.f90:1379-1442) + find_Voronoi_cell (:1625; the kd-tree's answer by direct search)

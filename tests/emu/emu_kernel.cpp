@@ -80,6 +80,7 @@ namespace mcgpu { double lds_raw[1 << 18]; }
 #include "../../mcfost_amd/csrc/mc_device.hip.h"
 #include "cross_cell_literal.h"
 #include "../../mcfost_amd/csrc/mc_voronoi.hip.h"
+#include "../../mcfost_amd/csrc/mc_voronoi_pool.hip.h"
 #include "../../mcfost_amd/csrc/mc_mono.hip.h"
 #include "../../mcfost_amd/csrc/mc_mono_voronoi.hip.h"
 #include "../../mcfost_amd/csrc/mc_raytrace.hip.h"
@@ -100,6 +101,7 @@ struct Conv {
   std::vector<int> sc, vcls;
   std::vector<VoroCell> vcell;
   std::vector<VoroNb> vnb;
+  std::vector<unsigned char> vnbcls;   // VoroGrid::nb_cls as mcgpu_set_grid_voronoi builds it
   double dummy = 0.0;
   explicit Conv(const oracle_model* m) {
     memset(&M, 0, sizeof(M));
@@ -129,6 +131,10 @@ struct Conv {
           else { vnb[q].x = vnb[q].y = vnb[q].z = 0.0f; }
         }
       }
+      vnbcls.assign(vnb.size(), (unsigned char)0);
+      for (size_t q = 0; q < vnb.size(); ++q)
+        if (vnb[q].id > 0) vnbcls[q] = (unsigned char)vp_class_of(vcell[vnb[q].id - 1].count);
+      G.nb_cls = vnbcls.data();
       G.n_cells = m->n_cells; G.cell = vcell.data(); G.nb = vnb.data(); G.h = m->v_h; G.xyz_dp = m->v_xyz_dp;
       G.wall_first = m->v_wall_first; G.wall_cells = m->v_wall_cells; G.cut_o_h = m->v_cut_o_h;
       memcpy(G.walls, m->v_walls, 24 * sizeof(float));
@@ -230,6 +236,20 @@ extern "C" int emu_run_thermal(const oracle_model* m, const oracle_opts* o, cons
   A.counters = cnt; A.next_packet = cnt + 12; A.err = &err;
   A.inner_iters = 8; A.flags = 0; A.flush_every = 4; A.min_active = 0;
   const bool pola = m->lsepar_pola && m->aniso_method == 1, dark = M.dark != nullptr, l3d = m->l3D != 0;
+  if (voro && getenv("MCGPU_EMU_POOL")) {   // the pool schedule (mc_voronoi_pool.hip.h) with one lane: MCGPU_EMU_POOL = log2(records)
+    PoolArgs PA;
+    PA.log_rec = atoi(getenv("MCGPU_EMU_POOL")); PA.cache_log_ns = 6;
+    if (PA.log_rec < 1 || PA.log_rec > VP_MAX_LOG_REC) return 31;
+    if (lds_bytes(M) + ((size_t)12 << PA.cache_log_ns) + vp_lds_bytes(PA.log_rec) + 64 > sizeof(lds_raw)) return 31;
+    std::vector<PRec> recs((size_t)1 << PA.log_rec);
+    PA.recs = recs.data();
+    A.flush_every = 4;
+    VpBlob blob;
+    blob.M = M; blob.A = A; blob.G = G;
+    if (pola) k_thermal_voro_pool<true, 512>(M, A, G, PA, &blob); else k_thermal_voro_pool<false, 512>(M, A, G, PA, &blob);
+    for (int q = 0; q < ORACLE_N_COUNTERS; ++q) counters[q] = cnt[q];
+    return err;
+  }
   if (voro && getenv("MCGPU_EMU_ROLES")) {  // the role schedule on a Voronoi grid, one lane
     int nsp = 1, ks = 2, fi = 3, eq = 128;
     sscanf(getenv("MCGPU_EMU_ROLES"), "%d,%d,%d,%d", &nsp, &ks, &fi, &eq);

@@ -530,6 +530,56 @@ def test_voronoi_launch_geometry_independence(voro_model):
         assert r["counters"] == ref["counters"]
         assert np.array_equal(r["sed"][4], ref["sed"][4])
         assert np.allclose(r["E_abs"], ref["E_abs"], rtol=1e-10, atol=1e-11 * ref["E_abs"].max())
+    e.set_option("schedule", 3)   # the pool schedule (mc_voronoi_pool.hip.h; opt-in: test_voronoi_pool_schedule)
+    for gb, bt in ((0, 0), (7, 128)):
+        r = e.run_thermal(10000, seed=9, frozen=True, E_prior=prior, grid_blocks=gb, block_threads=bt)
+        assert r["counters"] == ref["counters"]
+        assert np.array_equal(r["sed"][4], ref["sed"][4])
+        assert np.allclose(r["E_abs"], ref["E_abs"], rtol=1e-10, atol=1e-11 * ref["E_abs"].max())
+    e.close()
+
+
+def test_voronoi_pool_schedule(voro_model):
+    """The pool schedule (mc_voronoi_pool.hip.h; option "schedule" = 3, round 5): packet records in HBM, queues by phase
+    and by neighbour-list class in LDS, one phase per wave pass.  Packet for packet the
+    oracle whatever the pool holds -- 64 records per workgroup (fewer than a workgroup's lanes: most passes are thin),
+    256, 4096 (the default) -- and whatever the launch geometry; a deposit cache of 64 slots must miss; a launch of fewer
+    packets than one wave; live mode conserves packets and agrees with the one-packet-per-lane kernel."""
+    m = voro_model
+    e, o = _engine(m, 1e5), _oracle(m, 1e5)
+    prior = o.run_thermal(2000, seed=1)["E_abs"]
+    n = 30000
+    ref = o.run_thermal(n, seed=17, frozen=True, E_prior=prior, n_threads=8)
+    e.set_option("schedule", 3)
+
+    def same(r, b=ref):
+        assert r["counters"] == b["counters"], (r["counters"], b["counters"])
+        assert np.array_equal(r["n_sent"], b["n_sent"]) and np.array_equal(r["sed"][4], b["sed"][4])
+        assert np.allclose(r["E_abs"], b["E_abs"], rtol=1e-7, atol=1e-11 * b["E_abs"].max())
+        for t in (0, 5, 6, 7, 8):
+            assert np.allclose(r["sed"][t], b["sed"][t], rtol=1e-12, atol=1e-9), t
+
+    for log_rec in (6, 8, 12):
+        e.set_option("voronoi_pool_log_records", log_rec)
+        for gb, bt in ((0, 0), (5, 256), (2, 768), (300, 64)):
+            same(e.run_thermal(n, seed=17, frozen=True, E_prior=prior, grid_blocks=gb, block_threads=bt))
+    e.set_option("voronoi_cache_log_slots", 6)
+    same(e.run_thermal(n, seed=17, frozen=True, E_prior=prior))
+    e.set_option("voronoi_cache_log_slots", 13)
+    small = o.run_thermal(37, seed=18, frozen=True, E_prior=prior)
+    same(e.run_thermal(37, seed=18, frozen=True, E_prior=prior), small)
+    # live mode: conservation, and the temperature of the single-role kernel within the reference's gate
+    nl = 1_000_000
+    a = e.run_thermal(nl, seed=41)
+    assert a["counters"]["packets"] == nl and a["counters"]["escaped"] + a["counters"]["killed_star"] == nl and a["n_sent"].sum() == nl
+    e.set_option("schedule", 1)
+    b = e.run_thermal(nl, seed=42)
+    for k in ("crossings", "flights", "scatterings", "absorptions"):   # (the early in-flight estimates differ with the schedule)
+        assert abs(a["counters"][k] / b["counters"][k] - 1) < 0.05, k
+    Ta, Tb = e.temp_finale(a["E_abs"]), e.temp_finale(b["E_abs"])
+    well = (Tb > 1.01 * m.cfg.T_min) & (b["E_abs"] > np.median(b["E_abs"]))
+    ok, p75 = mc_similar(Tb[well], Ta[well], 0.05)
+    assert ok, p75
     e.close()
 
 

@@ -31,11 +31,12 @@ DEV6 = os.path.join(os.path.dirname(HERE), "mcfost_amd", "csrc", "mc_raytrace.hi
 DEV7 = os.path.join(os.path.dirname(HERE), "mcfost_amd", "csrc", "mc_binned.hip.h")
 DEV8 = os.path.join(os.path.dirname(HERE), "mcfost_amd", "csrc", "mc_tail.hip.h")
 DEV9 = os.path.join(os.path.dirname(HERE), "mcfost_amd", "csrc", "mc_raytrace_voronoi.hip.h")
+DEV10 = os.path.join(os.path.dirname(HERE), "mcfost_amd", "csrc", "mc_voronoi_pool.hip.h")
 
 
 @pytest.fixture(scope="module")
 def emu():
-    if (not os.path.exists(LIB)) or os.path.getmtime(LIB) < max(os.path.getmtime(SRC), os.path.getmtime(DEV), os.path.getmtime(DEV2), os.path.getmtime(DEV3), os.path.getmtime(DEV4), os.path.getmtime(DEV5), os.path.getmtime(DEV6), os.path.getmtime(DEV7), os.path.getmtime(DEV8), os.path.getmtime(DEV9)):
+    if (not os.path.exists(LIB)) or os.path.getmtime(LIB) < max(os.path.getmtime(SRC), os.path.getmtime(DEV), os.path.getmtime(DEV2), os.path.getmtime(DEV3), os.path.getmtime(DEV4), os.path.getmtime(DEV5), os.path.getmtime(DEV6), os.path.getmtime(DEV7), os.path.getmtime(DEV8), os.path.getmtime(DEV9), os.path.getmtime(DEV10)):
         fma = ["-mfma"] if "fma" in open("/proc/cpuinfo").read() else []
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=fast"] + fma +
                               ["-o", LIB, SRC])
@@ -265,6 +266,39 @@ def test_emulated_kernel_voronoi(emu):
             check(emu, m, 4000, 21, rtol=1e-7)
         finally:
             del os.environ["MCGPU_EMU_ROLES"]
+
+
+def test_emulated_voronoi_pool_schedule(emu):
+    """The pool schedule (mc_voronoi_pool.hip.h): packet records in memory, queues by phase and by neighbour-list class,
+    one phase per pass -- driven by ONE lane, so every pass pops one record and the scheduler's choices (emission while
+    records are free, the fullest queue, partial passes, the end of the launch) all occur.  Packet for packet the oracle,
+    whatever the pool's size: 2 records (every queue nearly always empty), 8, 64 (more records than packets in flight)."""
+    m = M.build_voronoi_model(M.small(), 1500, seed=3)
+    for log_rec in ("1", "3", "6"):
+        os.environ["MCGPU_EMU_POOL"] = log_rec
+        try:
+            check(emu, m, 4000, 21, rtol=1e-7)
+        finally:
+            del os.environ["MCGPU_EMU_POOL"]
+    # star outside the box (move_to_grid_Voronoi at emission), unpolarised; cell-centre disk emission; ISM packets
+    cfg = M.small(lsepar_pola=False)
+    cfg.star_xyz = (0.0, 0.0, 400.0)
+    m2 = M.build_voronoi_model(cfg, 800, seed=5)
+    m3 = M.build_voronoi_model(M.small(lsepar_pola=False), 800, seed=6)
+    rng = np.random.default_rng(0)
+    E_cell = rng.random((m3.n_lambda, m3.n_cells)) * m3.kappa_factor[None, :]
+    pe = np.zeros((m3.n_lambda, m3.n_cells + 1))
+    pe[:, 1:] = np.cumsum(E_cell, axis=1)
+    pe /= pe[:, -1:]
+    m3.prob_E_cell = pe.reshape(-1)
+    m3.frac_E_stars = np.full(m3.n_lambda, 0.4)
+    os.environ["MCGPU_EMU_POOL"] = "4"
+    try:
+        check(emu, m2, 3000, 22, rtol=1e-7)
+        check(emu, m3, 3000, 23, rtol=1e-6)
+        check(emu, _with_ism(M.build_voronoi_model(M.small(lsepar_pola=False), 600, seed=4)), 2000, 33, rtol=1e-6)
+    finally:
+        del os.environ["MCGPU_EMU_POOL"]
 
 
 def test_emulated_kernel_voronoi_star_outside_and_disk_emission(emu):
