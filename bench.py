@@ -249,11 +249,11 @@ def build_workload(M, args, config):
         M.init_variable_dust(model, identical=args.var_identical)
     if config == "ref41_mrw":   # BASELINE config 4: ref4.1 with the modified random walk (gamma_MRW = 2, MRW.f90:11)
         cfg.name += " + MRW (gamma %g)" % args.mrw_gamma
-        M.init_mrw(model, gamma=args.mrw_gamma)
+        M.init_mrw(model, gamma=args.mrw_gamma, n_inter=args.mrw_n_inter)
     return cfg, model
 
 
-def thermal_block(par, args, config, steps, warmup, with_cpu, n_local):
+def thermal_block(par, args, config, steps, warmup, with_cpu, n_local, crossing=None):
     """Times `steps` passes of the thermal packet loop on one configuration; returns (block or None on ranks > 0, cfg)."""
     from mcfost_amd.engine import Engine, MultiEngine
     from mcfost_amd.host import model as M
@@ -272,7 +272,7 @@ def thermal_block(par, args, config, steps, warmup, with_cpu, n_local):
     if args.tail >= 0:
         for x in (me.engines if me is not None else [eng]):
             x.set_option("tail", args.tail)
-    for name, value in (("schedule", args.schedule), ("voronoi_pool_log_records", args.pool_log_records),
+    for name, value in (("schedule", args.schedule), ("crossing", args.crossing if crossing is None else crossing), ("voronoi_pool_log_records", args.pool_log_records),
                         ("voronoi_cache_log_slots", args.cache_log_slots)):
         if value >= 0:
             for x in (me.engines if me is not None else [eng]):
@@ -359,7 +359,10 @@ def thermal_block(par, args, config, steps, warmup, with_cpu, n_local):
         # share of the last step and the longest packet's events (crossings + interactions), so that
         # tail_ms ~ events x us_per_event can be read off the record
         tail_ms, ev_max = eng.get_info("tail_ms"), eng.get_info("longest_packet_events")
+        longest = {k: eng.get_info("longest_packet_" + k) for k in ("crossings", "scatterings", "absorptions", "walks", "steps")} if ev_max > 10000 else None
         block["tail"] = {"tail_ms": tail_ms, "longest_packet_events": ev_max,
+                         # the longest packet's own counts: crossings over its whole life, the rest as far as k_tail ran it
+                         "longest_packet": longest,
                          "us_per_event_if_one_packet": (tail_ms * 1e3 / ev_max) if (tail_ms > 0 and ev_max > 0) else None,
                          "tail_threshold": eng.get_info("tail_threshold")}
         if config == "voronoi":
@@ -565,6 +568,9 @@ def main():
     ap.add_argument("--var-identical", action="store_true", help="--config ref41_var: every class gets the model's own tables "
                     "(the physics of --config ref41 through the HBM-gather kernel)")
     ap.add_argument("--mrw-gamma", type=float, default=2.0, help="--config ref41_mrw: gamma_MRW")
+    ap.add_argument("--mrw-n-inter", type=int, default=5, help="--config ref41_mrw: a walk may start after more than this many "
+                    "interactions in a row in one cell (dust_transfer.f90:1223: 5); + 256: also from a packet whose last event "
+                    "was a scattering")
     ap.add_argument("--dust-mass", type=float, default=0.0, help="override the disk's dust mass [Msun] (thermal configs; "
                     "ref41_mrw defaults to 10x the stock mass)")
     ap.add_argument("--no-ref41", action="store_true", help="--config pascucci: the headline block alone (same as --no-extra)")
@@ -581,6 +587,8 @@ def main():
     ap.add_argument("--tail", type=int, default=-1, help="tuning aid: option \"tail\" (packets left per workgroup at the hand-over to "
                     "k_tail; -1 = the library's choice)")
     ap.add_argument("--schedule", type=int, default=-1, help="tuning aid: option \"schedule\" (include/mcgpu.h)")
+    ap.add_argument("--crossing", type=int, default=-1, help="option \"crossing\": 1 = the flight-parametric 2D crossing in the flying "
+                    "waves (statistical parity only; include/mcgpu.h)")
     ap.add_argument("--pool-log-records", type=int, default=-1, help="tuning aid: option \"voronoi_pool_log_records\"")
     ap.add_argument("--cache-log-slots", type=int, default=-1, help="tuning aid: option \"voronoi_cache_log_slots\"")
     ap.add_argument("--grid-blocks", type=int, default=0)
@@ -631,6 +639,13 @@ def main():
             # the rate sits below the full run's 2.9e7 packets/s of tools/run_config2.py)
             extras["sed"] = sed_block(par, args, 1, 1, with_cpu, min(args.packets, 5e7), args.sed_observers or 10,
                                       all_lambdas=True)
+            # the headline workload with option "crossing" = 1: the flight-parametric crossing in the flying waves -- NOT the
+            # reference's arithmetic, so not the headline; statistical parity only (its tdust_vs_cpu against the same CPU port)
+            pb, _ = thermal_block(par, args, "pascucci", args.steps, args.warmup, with_cpu, args.packets, crossing=1)
+            pb["note"] = ("option \"crossing\" = 1 (off by default): wall distances as functions of the path parameter along a flight; "
+                          "same cells but for ties at the rounding level, gated statistically (tests/test_param_crossing.py)")
+            pb["roofline"]["kernel"] = "k_thermal_roles_param"
+            extras["pascucci_parametric_crossing"] = pb
     if par.rank == 0:
         line = {"metric": "photon packets/sec (whole node), thermal MC packet loop, %s" % cfg.name,
                 "value": block["value"], "unit": "packets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -181,6 +181,13 @@ int mcgpu_set_midplane_snap(mcgpu_ctx *ctx, int on);
  *                      2 = the role schedule wherever it is built (also Voronoi grids);
  *                      3 = Voronoi grids: the pool schedule (packet records in HBM, queues by phase and
  *                      by neighbour-list length in LDS, one phase per wave pass; mc_voronoi_pool.hip.h)
+ *   "crossing"     0 (default) = the reference's crossing arithmetic everywhere (cross_cylindrical_cell,
+ *                      cylindrical_grid.f90:918-1175: golden walks bit for bit, packets equal to the CPU
+ *                      restatement's one for one); 1 = 2D grids without dark zone / random walk / dust
+ *                      classes: the flying waves take the wall distances as functions of the path parameter
+ *                      along the flight (no position update per crossing; Pascucci +22 %).  NOT the
+ *                      reference's arithmetic: the same cells but for ties at the rounding level, parity with
+ *                      the reference statistical only (tests/test_param_crossing.py).  Never chosen by itself.
  *   "speculation"  SED mode: 1 (default) = most of every stream is committed before the
  *                      scout pass (exact; see mcgpu_run_mono), 0 = scout every packet first
  *   "voronoi_cache_log_slots"  6..13 (default 13): log2 of the slots of the Voronoi deposit cache

@@ -16,4 +16,10 @@ const void* kpick_roles(bool l3d, bool pola, bool dark, bool lds, bool mrw) {
     }); }); }); }); });
 }
 
+const void* kpick_roles_param(bool pola, bool tail) {
+  return bsel(pola, [&](auto POLA) { return bsel(tail, [&](auto TAIL) -> const void* {
+    return (const void*)k_thermal_roles_param<MCGPU_BV(POLA), MCGPU_BV(TAIL)>;
+  }); });
+}
+
 }  // namespace mcgpu

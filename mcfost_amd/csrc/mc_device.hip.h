@@ -93,6 +93,23 @@ __device__ __forceinline__ double sqrt_nonneg(double x) {
   return (x == 0.0) ? 0.0 : g;
 }
 #endif
+// ... without the last correction step: within a few units in the last place (the flight-parametric crossing, which
+// makes no claim on the reference's last bits)
+__device__ __forceinline__ double sqrt_fast_nonneg(double x) {
+#ifdef MCGPU_LANE_EMULATION
+  return sqrt(x);
+#else
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y;
+  double h = y * 0.5;
+  const double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  const double d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  return (x == 0.0) ? 0.0 : g;
+#endif
+}
 
 // log(x) for positive, finite, normal x: frexp, s = (m - 1) / (m + 1) with m in [sqrt(1/2), sqrt(2)), the series
 // 2 s (1 + s^2 / 3 + ... + s^18 / 19) and e ln 2 -- 4e-16 of libm's log (2 ulp; checked over 5e6 arguments on the host),

@@ -15,6 +15,8 @@ const void* kpick_thermal(bool lds, bool l3d, bool pola, bool dark, bool mrw);
 const void* kpick_thermal_sph(bool l3d, bool pola, bool lds, bool mrw);
 // kern_roles.hip: waves with roles -- k_thermal_roles (mrw: 2D only)
 const void* kpick_roles(bool l3d, bool pola, bool dark, bool lds, bool mrw);
+// ... k_thermal_roles_param: 2D, LDS deposits, the flight-parametric crossing in the flying waves (option "crossing" = 1)
+const void* kpick_roles_param(bool pola, bool tail);
 // kern_tail.hip: the kernels of a launch's end -- k_thermal_roles_tail (2D, hands packets over), k_thermal_roles_bin
 // (3D, binned deposits, chunks), k_tail (one packet per wave)
 const void* kpick_roles_tail(bool pola, bool dark, bool lds, bool mrw);

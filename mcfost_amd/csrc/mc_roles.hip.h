@@ -429,6 +429,131 @@ __device__ __forceinline__ int fly_step_2d(const Lds& T, const DevModel& M, cons
   return ((active && !out && killed) || runaway) ? 1 : 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The 2D crossing parametrised along the flight (round 5; option "crossing" = 1, OFF by default).
+// Along one straight flight the point is r(s) = r0 + s d, and everything the crossing recomputes from the current point
+// -- r^2, r.d, the discriminants of both circles -- is a function of constants of the flight: with b0 = (x0 u + y0 v) / a
+// and D0 = b0^2 - (x0^2 + y0^2) / a the wall of radius R is met at s = -b0 -+ sqrt(D0 + R^2 / a), a plane z = zl at
+// s = (zl - z0) / w, and the packet moves inward while s + b0 < 0.  One multiply-add per circle, one for the current height,
+// no position update per crossing (the point is formed when the packet stops or leaves the flying loop): the loop's
+// common path is about two thirds of fly_step_2d's.
+// What it is NOT: the reference's arithmetic.  cross_cylindrical_cell (cylindrical_grid.f90:918-1175) re-derives every
+// crossing from the current point, nudges it by grid_prec and takes zj through default real; this form cannot reproduce
+// its golden walks bit for bit (the cells it visits are the same but for ties at the rounding level), so the frozen
+// packet-for-packet tests do not apply to it and it is gated by the statistical ones only (tests/test_param_crossing.py).
+// Only the flying waves of the role kernel use it; serving waves and the tail kernel keep fly_step_2d.
+// ---------------------------------------------------------------------------------------------
+struct FlightParam {
+  double s;    // the packet is at r0 + s d; F.x, F.y, F.z hold r0 while a lane is inside the flying loop
+  double b0, D0;
+  double zc;   // its height there, z0 + s w
+  double kabS; // kappa_abs_LTE(lambda) Stokes(1): what a crossing's length is multiplied with for its deposit
+};
+
+__device__ __forceinline__ void param_begin(const Flight& F, FlightParam& P) {
+  P.s = 0.0;
+  P.b0 = (F.x * F.u + F.y * F.v) * F.inv_a;
+  P.D0 = P.b0 * P.b0 - (F.x * F.x + F.y * F.y) * F.inv_a;
+  P.zc = F.z;
+  P.kabS = F.kab * F.S0;
+}
+// the point the packet has reached; a packet still in flight is put just beyond the wall it stands on (the exact crossing,
+// which may pick it up, decides by the point's side: the role of the reference's correct_plus / correct_moins)
+__device__ __forceinline__ void param_end(Flight& F, const FlightParam& P) {
+  const double sm = (F.st == S_FLIGHT) ? P.s * (1.0 + 1.0e-13) : P.s;
+  F.x = F.x + sm * F.u;
+  F.y = F.y + sm * F.v;
+  double z = F.z + sm * F.w;
+  F.z = (z == 0.0) ? GRID_PREC : z;
+}
+
+// c_cross_wave: the wave's crossings, counted with a ballot and a scalar add (the caller adds them to one lane's counter);
+// any_star: some lane of the wave flies towards a star's cell (else the test of that cell is skipped); the runaway
+// test of the packet's crossing counter is the caller's, once per visit of the rings
+template <bool LDSE>
+__device__ __forceinline__ int fly_step_2d_param(const Lds& T, const DevModel& M, const RunArgs& A, double* E_lds, Flight& p,
+                                                 FlightParam& P, unsigned int& c_cross_wave, unsigned int& c_kill, bool any_star) {
+  const int n_rad = M.n_rad, nz = M.nz;
+  const bool active = (p.st == S_FLIGHT);
+  const int ri0 = p.ri, zj0 = p.zj;
+  const double z0 = p.z, w = p.w;
+  const double s0 = P.s;
+  const double zc = P.zc;   // the current height
+  const bool top = (zj0 == nz + 1);
+  const bool out = (ri0 == n_rad + 1) || (top && (fabs(zc) > M.zmaxmax));
+  bool killed = false;
+  if (any_star) killed = (p.star_key >= 0) && (ri0 + (n_rad + 2) * (zj0 + nz + 1) == p.star_key);
+  const bool go = active && !out && !killed;
+  const bool hole = (ri0 == 0);
+  const int ic = p.ic;
+  const bool real_cell = ic < M.n_cells;
+  const RowT& R0 = T.row[ri0];
+
+  // 1) the radial wall ahead
+  const double d_in = __builtin_fma(R0.rl_in, p.inv_a, P.D0);
+  const double d_out = fmax(__builtin_fma(R0.rl_out, p.inv_a, P.D0), 0.0);
+  const bool inward = (s0 + P.b0) < 0.0;
+  const bool use_in = hole || (inward && !(d_in < 0.0));
+  const bool minus = use_in && !hole;
+  const double rac = sqrt_fast_nonneg(use_in ? d_in : d_out);
+  const double s_rad = (minus ? -rac : rac) - P.b0;
+  const int delta_rad = minus ? -1 : 1;
+
+  // 2) the vertical wall ahead (2D: zj >= 1, the midplane mirrors).  The upper wall of layer nz is nz ch = zmax to rounding.
+  const double dz = w * zc;
+  const bool away = dz > 0.0;
+  const bool flip = !away && (zj0 == 1);
+  const int jsel = away ? zj0 + 1 : (zj0 == 1 ? 2 : zj0);
+  const double zmag = ((double)jsel - 1.0) * R0.ch;
+  const bool neg = (zc < 0.0) != flip;
+  const double zl = __longlong_as_double(__double_as_longlong(zmag) | (neg ? (long long)0x8000000000000000ull : 0ll));
+  const int delta_zj = away ? (top ? 0 : 1) : ((zj0 == 1) ? 1 : -1);
+  double t = (zl - z0) * p.inv_w;
+  t = ((dz == 0.0) | hole | (away & top)) ? 1.0e10 : t;
+
+  // 3) the nearest wall, the cell behind it
+  const bool rad = (s_rad < t);
+  const double s1 = fmin(s_rad, t);
+  const double l = fmax(s1 - s0, 0.0);   // (a wall the rounding puts behind the packet is crossed on the spot)
+  const int ri1 = rad ? ri0 + delta_rad : ri0;
+  const double z1 = __builtin_fma(s1, w, z0);
+  int zjr = (int)fmin(floor(fabs(z1) * T.row[ri1].rzn), (double)nz) + 1;
+  zjr = (ri1 > n_rad) ? zj0 : zjr;
+  const int zj1 = rad ? zjr : zj0 + delta_zj;
+
+  // 4) optical depth of the crossing, stop or go on (optical_depth.f90:102, 134-146)
+  const double tau = l * (p.kap * p.kf);
+  const bool stop = go && (tau > p.extr);
+  double lc = l;
+  if (__builtin_expect(stop, 0)) lc = l * (p.extr / tau);  // (once per flight)
+  if (go && real_cell && !MCGPU_DIAG(A.flags, 1)) deposit<LDSE>(A.E_abs, E_lds, ic, P.kabS * lc);
+
+  // (unsigned compares: 1 <= ri1 <= n_rad and 1 <= zj1 <= nz in one test each)
+  const bool next_real = ((unsigned)(ri1 - 1) < (unsigned)n_rad) & ((unsigned)(zj1 - 1) < (unsigned)nz);
+  const int ic1 = next_real ? (ri1 - 1) + n_rad * (zj1 - 1) : M.n_cells;
+  const bool move = go && !stop;
+  const double kf1 = M.kappa_factor[ic1];
+
+  // 5) commit
+  P.s = go ? s0 + lc : s0;   // (lc = l = s1 - s0 unless the packet stops)
+  P.zc = move ? z1 : zc;     // (a packet that stops does not look at its height again in this loop)
+  p.extr = p.extr - tau;
+  p.ri = move ? ri1 : ri0;
+  p.zj = move ? zj1 : zj0;
+  p.ic = move ? ic1 : ic;
+  p.kf = move ? kf1 : p.kf;
+  int st = p.st;
+  st = (active && out) ? S_EXITED : st;
+  st = (active && !out && killed) ? S_EMIT : st;
+  st = stop ? S_INTERACT : st;
+  c_cross_wave += (unsigned int)__popcll(__ballot(go));
+  p.pk_cross += go ? 1u : 0u;
+  p.st = st;
+  if (!any_star) return 0;
+  c_kill += (active && !out && killed) ? 1u : 0u;
+  return (active && !out && killed) ? 1 : 0;
+}
+
 // The crossing of a 3D cylindrical grid in the same straight-line, select-committed form (cross_cell_lean<true> +
 // roles_cross above, statement for statement: cylindrical_grid.f90:918-1175 with the azimuthal walls :1058-1094,
 // optical_depth.f90:77-178).  What stays a branch: the stop (a division, and the 3D re-indexing of the stopping point,
@@ -669,7 +794,8 @@ __device__ inline int voro_roles_cross(const Lds& T, const DevModel& M, const Ru
 // above, and the tail kernel, mc_tail.hip.h); BIN implies it.
 // VAR: lvariable_dust -- the flights read the per-cell opacities (var_cell_opacities), the interactions the tables of the
 // cell's class (class_tables); cylindrical grids, no MRW.
-template <bool L3D, bool POLA, bool DARK, bool LDSE, bool MRW = false, bool VORO = false, bool BIN = false, bool CARRY = BIN, bool VAR = false>
+template <bool L3D, bool POLA, bool DARK, bool LDSE, bool MRW = false, bool VORO = false, bool BIN = false, bool CARRY = BIN, bool VAR = false,
+          bool PARAM = false>   // PARAM: the flying waves cross with fly_step_2d_param (2D, no dark zone, no walk, one dust class)
 __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, double* lds_base, int n_rec, int n_srv_pref,
                                            int k_short, int fly_iters, int fly_idle, int emit_qmax,
                                            const VoroGrid* Gp = nullptr, int cache_log_ns = 0) {
@@ -885,12 +1011,18 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
         if (lane == 0) atomicAdd(&Q->beat, 1);
         RQ_DIAG(if (lane == 0) d_fly_rounds++;)
         F.st = st;
+        FlightParam FP;
+        unsigned int c_cross_wave = 0u;
+        bool any_star = true;
+        if (PARAM) { param_begin(F, FP); any_star = __ballot(st == S_FLIGHT && F.star_key >= 0) != 0ull; }
 #pragma unroll 1
         for (int it = 0; it < fly_iters; ++it) {
           // back to the rings as soon as enough lanes have nothing to fly (or after fly_iters crossings)
           if (it > 0 && __popcll(__ballot(F.st != S_FLIGHT)) >= fly_idle) break;
           RQ_DIAG(if (lane == 0) d_fly_iters++; if (F.st == S_FLIGHT) d_fly_cross++;)
-          if (VORO) {
+          if (PARAM) {
+            finished += fly_step_2d_param<LDSE>(T, M, A, E_lds, F, FP, c_cross_wave, c_kill, any_star);
+          } else if (VORO) {
             if (F.st == S_FLIGHT) finished += voro_roles_cross<true, MRW>(T, M, A, *Gp, DC, F, c_cross, c_kill);
           } else if (L3D) {
             int dep_ic = -1;
@@ -903,6 +1035,11 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
           }
         }
         if (BIN) bin_settle(BS, A.bin, A.E_abs, lane, BP);
+        if (PARAM) {
+          param_end(F, FP);
+          if (lane == 0) c_cross += c_cross_wave;
+          if (F.pk_cross > 200000000u && F.st == S_FLIGHT) { *A.err = 13; F.st = S_EMIT; finished += 1; }  // a packet that never leaves: flag it, drop it
+        }
         st = F.st;
       }
     } else {
@@ -1393,6 +1530,14 @@ __global__ void __launch_bounds__(MCGPU_ROLES_BIN_BLOCK) k_thermal_roles_bin(con
                                                                          int k_short, int fly_iters, int fly_idle, int emit_qmax) {
   extern __shared__ double lds_raw[];
   roles_body<true, POLA, DARK, false, MRW, false, true>(M, A, lds_raw, n_rec, n_srv_pref, k_short, fly_iters, fly_idle, emit_qmax);
+}
+
+// ... with the flight-parametric crossing in the flying waves (option "crossing" = 1; TAIL: hands its last packets to k_tail)
+template <bool POLA, bool TAIL>
+__global__ void __launch_bounds__(MCGPU_ROLES_BLOCK) k_thermal_roles_param(const DevModel M, const RunArgs A, int n_rec, int n_srv_pref,
+                                                                           int k_short, int fly_iters, int fly_idle, int emit_qmax) {
+  extern __shared__ double lds_raw[];
+  roles_body<false, POLA, false, true, false, false, false, TAIL, false, true>(M, A, lds_raw, n_rec, n_srv_pref, k_short, fly_iters, fly_idle, emit_qmax);
 }
 
 // the role schedule on a Voronoi grid

@@ -21,6 +21,8 @@
 namespace mcgpu {
 
 constexpr int TAIL_N_COUNTERS = 10;  // packets .. mrw_steps (= TAIL_N_COUNTERS of include/mcgpu.h)
+constexpr int TAIL_LONGEST = 16;     // counters[16 .. 20]: (events << 32 | count) of the longest packet, by atomicMax: its
+                                     // crossings (whole life), and the scatterings, absorptions, walks and walk steps this kernel ran
 
 // smallest k in [lo, hi) with tab[k] >= x, else hi (tab non-decreasing): one probe per lane and pass
 template <typename Tp>
@@ -311,7 +313,20 @@ __device__ __forceinline__ void tail_packet(const Lds& T, const DevModel& M, con
     if (st == S_EMIT) break;  // (killed at the star)
   }
   flush();
-  { const unsigned int ev = (F.pk_cross & 0x7FFFFFFFu) + event; cs[TAIL_N_COUNTERS] = ev > cs[TAIL_N_COUNTERS] ? ev : cs[TAIL_N_COUNTERS]; }
+  {
+    const unsigned int ev = (F.pk_cross & 0x7FFFFFFFu) + event;
+    if (ev > cs[TAIL_N_COUNTERS]) {   // the longest packet of this wave so far: its own counts travel with its events
+      cs[TAIL_N_COUNTERS] = ev;
+      if (lane == 0 && ev > 10000u) {
+        const unsigned long long hi = (unsigned long long)ev << 32;
+        atomicMax(&A.counters[TAIL_LONGEST + 0], hi | (unsigned long long)(F.pk_cross & 0x7FFFFFFFu));
+        atomicMax(&A.counters[TAIL_LONGEST + 1], hi | (unsigned long long)c_scatt);
+        atomicMax(&A.counters[TAIL_LONGEST + 2], hi | (unsigned long long)c_abs);
+        atomicMax(&A.counters[TAIL_LONGEST + 3], hi | (unsigned long long)c_walks);
+        atomicMax(&A.counters[TAIL_LONGEST + 4], hi | (unsigned long long)c_steps);
+      }
+    }
+  }
   cs[1] += c_cross; cs[2] += c_flight; cs[3] += c_scatt; cs[4] += c_abs; cs[5] += c_esc; cs[6] += c_kill; cs[7] += c_dark;
   cs[8] += c_walks; cs[9] += c_steps;
 }

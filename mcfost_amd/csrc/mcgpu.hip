@@ -65,6 +65,7 @@ static void host_rotation(double xinit, double yinit, double zinit, double u1, d
 }
 
 constexpr int WORK_SLOT = 12;  // where the kernels' work counter lives in d_counters
+constexpr int CNT_SLOTS = 24;  // d_counters: the counters, the longest packet's events (10), the work counter, the longest packet's own counts (16..20, TAIL_LONGEST)
 static_assert(MCGPU_N_COUNTERS <= WORK_SLOT, "counter buffer layout");
 static_assert(MCGPU_N_COUNTERS == TAIL_N_COUNTERS, "mc_tail.hip.h counts the same events");
 
@@ -114,6 +115,7 @@ struct mcgpu_ctx {
   int opt_schedule = 0;     // 0 = automatic (waves with roles where the queues fit), 1 = single-role kernel
   int opt_speculation = 1;  // SED mode: commit most of every stream before the scout pass
   int opt_cache_log_slots = 13;  // Voronoi deposit cache: 2^13 slots = 96 KB of LDS
+  int opt_crossing = 0;          // 1: the flight-parametric 2D crossing in the role kernel's flying waves (statistical parity only)
   int opt_pool_log_rec = 12;     // Voronoi pool schedule: 2^12 packet records per workgroup (mc_voronoi_pool.hip.h)
   int opt_radiation_field = 0;   // bit 0: xN_abs, bit 1: xJ_abs (thermal step; radiation_field.f90:54-55)
   unsigned long long* d_xN = nullptr;  // [n_cells] (64-bit: a hot cell passes 2^32 segments within one 1e9-packet run)
@@ -125,7 +127,7 @@ struct mcgpu_ctx {
   // accumulators: [E_abs | sed | n_sent | counters as doubles (mcgpu_counters_to_accum)]
   double* d_accum = nullptr;
   size_t n_accum = 0;
-  unsigned long long* d_counters = nullptr;  // [16]: MCGPU_N_COUNTERS counters, pad, the work counter at WORK_SLOT
+  unsigned long long* d_counters = nullptr;  // [CNT_SLOTS]: MCGPU_N_COUNTERS counters, pad, the work counter at WORK_SLOT
   int* d_err = nullptr;
   double* d_E_prior = nullptr;
   bool launched = false;
@@ -231,12 +233,12 @@ extern "C" int mcgpu_create(int device, mcgpu_ctx** out) {
   }
   ctx->stream = ctx->own_stream;
   ctx->M.midplane_snap = 0;  // the reference's literal arithmetic; mcgpu_set_midplane_snap(ctx, 1) is the option
-  if (hipMalloc((void**)&ctx->d_counters, 16 * sizeof(unsigned long long)) != hipSuccess ||
+  if (hipMalloc((void**)&ctx->d_counters, CNT_SLOTS * sizeof(unsigned long long)) != hipSuccess ||
       hipMalloc((void**)&ctx->d_err, sizeof(int)) != hipSuccess) {
     delete ctx;
     return MCGPU_ERR_HIP;
   }
-  hipMemset(ctx->d_counters, 0, 16 * sizeof(unsigned long long));
+  hipMemset(ctx->d_counters, 0, CNT_SLOTS * sizeof(unsigned long long));
   hipMemset(ctx->d_err, 0, sizeof(int));
   *out = ctx;
   return MCGPU_OK;
@@ -533,6 +535,7 @@ extern "C" int mcgpu_set_option(mcgpu_ctx* ctx, const char* name, int value) {
   }
   else if (!strcmp(name, "schedule")) { if (value < 0 || value > 3) return fail(ctx, MCGPU_ERR_ARG, "schedule: 0, 1, 2 or 3"); ctx->opt_schedule = value; }
   else if (!strcmp(name, "speculation")) ctx->opt_speculation = value ? 1 : 0;
+  else if (!strcmp(name, "crossing")) { if (value < 0 || value > 1) return fail(ctx, MCGPU_ERR_ARG, "crossing: 0 or 1"); ctx->opt_crossing = value; }
   else if (!strcmp(name, "voronoi_pool_log_records")) { if (value < 6 || value > VP_MAX_LOG_REC) return fail(ctx, MCGPU_ERR_ARG, "voronoi_pool_log_records: 6..12"); ctx->opt_pool_log_rec = value; }
   else if (!strcmp(name, "voronoi_cache_log_slots")) { if (value < 6 || value > 13) return fail(ctx, MCGPU_ERR_ARG, "voronoi_cache_log_slots: 6..13"); ctx->opt_cache_log_slots = value; }
   else if (!strcmp(name, "radiation_field")) { if (value < 0 || value > 3) return fail(ctx, MCGPU_ERR_ARG, "radiation_field: bit 0 xN_abs, bit 1 xJ_abs"); ctx->opt_radiation_field = value; }
@@ -564,6 +567,20 @@ extern "C" int mcgpu_get_info(mcgpu_ctx* ctx, const char* name, double* value) {
       HIPCHK(hipMemcpy(&v, ctx->d_counters + 10, sizeof(v), hipMemcpyDeviceToHost));
     }
     *value = (double)v;
+  }
+  else if (!strncmp(name, "longest_packet_", 15) && strcmp(name, "longest_packet_events")) {
+    // the longest packet's own counts, as far as the tail kernel ran it (mc_tail.hip.h: the packet with the most events
+    // wins every slot, its events in the upper half of the word): crossings, scatterings, absorptions, walks, steps
+    static const char* what[5] = {"crossings", "scatterings", "absorptions", "walks", "steps"};
+    int k = -1;
+    for (int q = 0; q < 5; ++q) if (!strcmp(name + 15, what[q])) k = q;
+    if (k < 0) return fail(ctx, MCGPU_ERR_ARG, "mcgpu_get_info: unknown name");
+    unsigned long long v = 0ull;
+    if (ctx->d_counters) {
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      HIPCHK(hipMemcpy(&v, ctx->d_counters + TAIL_LONGEST + k, sizeof(v), hipMemcpyDeviceToHost));
+    }
+    *value = (double)(v & 0xFFFFFFFFull);
   }
   else if (!strcmp(name, "tau_midplane")) *value = ctx->tau_midplane;
   else if (!strcmp(name, "bin_overflow_blocks") || !strcmp(name, "bin_drained_records")) {
@@ -1369,6 +1386,9 @@ static int launch_mega(mcgpu_ctx* ctx, const RunArgs& A, bool use_lds, int grid_
         At.tail_threshold = tail_thr;
         fn = kpick_roles_tail(pola, dark, use_lds, M.mrw != 0);
       }
+      // option "crossing" = 1: the flying waves cross with the flight-parametric form (fly_step_2d_param, mc_roles.hip.h) --
+      // not the reference's arithmetic (statistical parity only), so never by default; 2D, LDS deposits, no dark zone, no walk
+      if (ctx->opt_crossing == 1 && !l3d && !dark && use_lds && !M.mrw) fn = kpick_roles_param(pola, tail);
       HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));
       void* args[] = {(void*)&M, (void*)&At, (void*)&n_rec, (void*)&n_srv_pref, (void*)&k_short, (void*)&fly_iters, (void*)&fly_idle, (void*)&emit_qmax};
       HIPCHK(hipLaunchKernel(fn, dim3(rblocks), dim3(rthreads), args, lds_r, ctx->stream));
@@ -1742,7 +1762,7 @@ extern "C" int mcgpu_launch_thermal(mcgpu_ctx* ctx, const mcgpu_run_opts* o) {
     return fail(ctx, MCGPU_ERR_UNSUPPORTED, "wavelength tables exceed the LDS of one CU");
   if (!o->accumulate) {
     HIPCHK(hipMemsetAsync(ctx->d_accum, 0, ctx->n_accum * sizeof(double), ctx->stream));
-    HIPCHK(hipMemsetAsync(ctx->d_counters, 0, 16 * sizeof(unsigned long long), ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_counters, 0, CNT_SLOTS * sizeof(unsigned long long), ctx->stream));
   } else {
     HIPCHK(hipMemsetAsync(ctx->d_counters + WORK_SLOT, 0, sizeof(unsigned long long), ctx->stream));
   }
@@ -2319,7 +2339,7 @@ extern "C" int mcgpu_run_mono(mcgpu_ctx* ctx, const mcgpu_mono_opts* o, double f
   // then call mcgpu_temp_finale(ctx, NULL, ...) on the device's own absorbed-energy grid)
   if (!o->accumulate) {
     HIPCHK(hipMemsetAsync(ctx->d_accum + M.n_cells, 0, (ctx->n_accum - M.n_cells) * sizeof(double), ctx->stream));
-    HIPCHK(hipMemsetAsync(ctx->d_counters, 0, 16 * sizeof(unsigned long long), ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_counters, 0, CNT_SLOTS * sizeof(unsigned long long), ctx->stream));
   }
   HIPCHK(hipMemsetAsync(ctx->d_err, 0, sizeof(int), ctx->stream));
 
@@ -2453,7 +2473,7 @@ restart:
         if (overshoot) {  // (a 7-sigma event) clear what this call accumulated and run it the plain way
           speculate = false;
           HIPCHK(hipMemsetAsync(ctx->d_accum + M.n_cells, 0, (ctx->n_accum - M.n_cells) * sizeof(double), ctx->stream));
-          HIPCHK(hipMemsetAsync(ctx->d_counters, 0, 16 * sizeof(unsigned long long), ctx->stream));
+          HIPCHK(hipMemsetAsync(ctx->d_counters, 0, CNT_SLOTS * sizeof(unsigned long long), ctx->stream));
           if (rt1) HIPCHK(hipMemsetAsync(ctx->d_xI, 0, xi_bytes, ctx->stream));
           if (rt2) {
             HIPCHK(hipMemsetAsync(ctx->d_I_spec, 0, (size_t)M.n_cells * ctx->n_phi_I * ctx->n_theta_I * XI_LINE * sizeof(double), ctx->stream));

@@ -224,7 +224,7 @@ extern "C" int emu_run_thermal(const oracle_model* m, const oracle_opts* o, cons
   memset(E_abs, 0, sizeof(double) * m->n_cells);
   memset(sed, 0, sizeof(double) * nsed);
   memset(n_sent, 0, sizeof(double) * m->n_lambda);
-  unsigned long long cnt[16];
+  unsigned long long cnt[24];
   memset(cnt, 0, sizeof(cnt));
   int err = 0;
   if (getenv("MCGPU_EMU_TRACE")) { g_trace_base = E_abs; g_trace_n = m->n_cells; }
@@ -390,6 +390,12 @@ extern "C" int emu_run_thermal(const oracle_model* m, const oracle_opts* o, cons
       for (int q = 0; q < ORACLE_N_COUNTERS; ++q) counters[q] = cnt[q];
       return err;
     }
+    if (getenv("MCGPU_EMU_PARAM")) {   // the flight-parametric crossing in the flying role (option "crossing" = 1): 2D, LDS deposits
+      if (l3d || dark || M.mrw) return 31;
+      if (pola) k_thermal_roles_param<true, false>(M, A, n_rec, nsp, ks, fi, 65, eq); else k_thermal_roles_param<false, false>(M, A, n_rec, nsp, ks, fi, 65, eq);
+      for (int q = 0; q < ORACLE_N_COUNTERS; ++q) counters[q] = cnt[q];
+      return err;
+    }
 #define RUNR(a, b, c) do { if (ld) k_thermal_roles<a, b, c, true>(M, A, n_rec, nsp, ks, fi, 65, eq); else k_thermal_roles<a, b, c, false>(M, A, n_rec, nsp, ks, fi, 65, eq); } while (0)
 #define RUNRM(b, c) do { if (ld) k_thermal_roles<false, b, c, true, true>(M, A, n_rec, nsp, ks, fi, 65, eq); else k_thermal_roles<false, b, c, false, true>(M, A, n_rec, nsp, ks, fi, 65, eq); } while (0)
     if (M.mrw) {
@@ -472,7 +478,7 @@ extern "C" int emu_run_mono(const oracle_model* m, const oracle_mono_opts* o, do
   const bool xi32 = getenv("MCGPU_EMU_XI_F32") != nullptr;  // default-real records (mcgpu_set_xI_precision(4))
   const int nRT_pad = xi32 ? nRT + (nRT & 1) : nRT;
   std::vector<double> xI_dev(nxI ? nxI / m->N_type_flux / (nRT ? nRT : 1) * nRT_pad * XI_LINE : 1, 0.0);  // the kernel's own layout (FP32: half of it used)
-  unsigned long long cnt[16];
+  unsigned long long cnt[24];
   memset(cnt, 0, sizeof(cnt));
   int err = 0;
   const bool pola = m->lsepar_pola && m->aniso_method == 1, dark = M.dark != nullptr, l3d = m->l3D != 0;
