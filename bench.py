@@ -476,7 +476,8 @@ def sed_block(par, args, steps, warmup, with_cpu, packets, observers, all_lambda
                 r = me.run_mono(lam, n2, seed=100 + i, n_chunks=n_streams, fetch_xI=False, Tdust=T)
             else:
                 td = eng.repartition_energie(lam, T, fetch=False)
-                r = eng.run_mono(lam, n2, seed=100 + i, n_chunks=count, first_chunk=first, fetch_xI=False, device_tables=td)
+                r = eng.run_mono(lam, n2, seed=100 + i, n_chunks=count, first_chunk=first, fetch_xI=False, device_tables=td,
+                                 block_threads=args.block_threads)
             sent += int(r["n_sent_chunk"].sum())
             if par.mode == "torchrun":   # one all-reduce of [sed | n_sent] + xI_scatt per wavelength
                 acc, cnt = eng.device_accumulators()
@@ -635,9 +636,9 @@ def main():
             # (DESIGN.md section 7), so a step is 1e7 packets
             extras["ref41_mrw"], _ = thermal_block(par, args, "ref41_mrw", 1, 1, with_cpu, min(args.packets, 1e7))
             # the SED half of BASELINE config 2: 10 observers
-            # (every wavelength, 1 / 14 of config 2's packets per stream: the launches of a wavelength are small then and
-            # the rate sits below the full run's 2.9e7 packets/s of tools/run_config2.py)
-            extras["sed"] = sed_block(par, args, 1, 1, with_cpu, min(args.packets, 5e7), args.sed_observers or 10,
+            # (every wavelength, 3 551 packets in the stop bin per stream -- a third of config 2's 10 000; round 4 ran 710, where a
+            # wavelength's launches are small and the rate sat a third below the full run's)
+            extras["sed"] = sed_block(par, args, 1, 0, with_cpu, min(2.5 * args.packets, 2.5e8), args.sed_observers or 10,
                                       all_lambdas=True)
             # the headline workload with option "crossing" = 1: the flight-parametric crossing in the flying waves -- NOT the
             # reference's arithmetic, so not the headline; statistical parity only (its tdust_vs_cpu against the same CPU port)
