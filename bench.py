@@ -273,7 +273,7 @@ def thermal_block(par, args, config, steps, warmup, with_cpu, n_local, crossing=
         for x in (me.engines if me is not None else [eng]):
             x.set_option("tail", args.tail)
     for name, value in (("schedule", args.schedule), ("crossing", args.crossing if crossing is None else crossing), ("voronoi_pool_log_records", args.pool_log_records),
-                        ("voronoi_cache_log_slots", args.cache_log_slots)):
+                        ("voronoi_cache_log_slots", args.cache_log_slots), ("deposit_log_mb", args.deposit_log_mb)):
         if value >= 0:
             for x in (me.engines if me is not None else [eng]):
                 x.set_option(name, value)
@@ -592,6 +592,7 @@ def main():
                     "waves (statistical parity only; include/mcgpu.h)")
     ap.add_argument("--pool-log-records", type=int, default=-1, help="tuning aid: option \"voronoi_pool_log_records\"")
     ap.add_argument("--cache-log-slots", type=int, default=-1, help="tuning aid: option \"voronoi_cache_log_slots\"")
+    ap.add_argument("--deposit-log-mb", type=int, default=-1, help="tuning aid: option \"deposit_log_mb\" (3D grids: the deposit log's size)")
     ap.add_argument("--grid-blocks", type=int, default=0)
     ap.add_argument("--block-threads", type=int, default=0)
     ap.add_argument("--no-pola", action="store_true", help="tuning aid: do not track Stokes Q,U,V")

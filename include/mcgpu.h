@@ -137,8 +137,10 @@ int mcgpu_set_grid_voronoi(mcgpu_ctx *ctx, int n_cells, const float *voronoi_xyz
  * :496-580): r_lim_2(0:n_rad), r_lim_3(0:n_rad), tan_theta_lim(0:nz), theta_lim(0:nz), tan_phi_lim(n_az); the cell
  * mapping arrays are the ones build_cylindrical_cell_mapping fills for both structured grids (verified like
  * mcgpu_set_grid_cyl's).  Replaces cross_spherical_cell (:182), index_cell_sph (:48), move_to_grid_sph (:562),
- * pos_em_cell_sph (:619), test_exit_grid_sph (:24).  Thermal step only for now: a dark zone, the SED mode and the
- * ray tracer on this grid return MCGPU_ERR_UNSUPPORTED.
+ * pos_em_cell_sph (:619), test_exit_grid_sph (:24).  On this grid: the temperature step (with the random walk; or, round 5,
+ * with a dark zone -- l_dark_zone flags of mcgpu_set_opacity -- or with dust classes, mcgpu_set_variable_dust /
+ * mcgpu_opacity; not both at once, not with the walk), the SED / image Monte Carlo and the ray tracer of method 1 (one dust
+ * class, no dark zone).  MCGPU_ERR_UNSUPPORTED: mcgpu_define_dark_zone, the diffusion fill, ray tracing method 2.
  */
 int mcgpu_set_grid_sph(mcgpu_ctx *ctx, int n_rad, int nz, int n_az, int l3D,
                        const double *r_lim_2, const double *r_lim_3,
@@ -172,7 +174,7 @@ int mcgpu_set_midplane_snap(mcgpu_ctx *ctx, int on);
  *                      lanes working ahead for it, mc_tail.hip.h) once a workgroup has this many left; 0 = never;
  *                      -1 (default) = automatic: 48 where packets get trapped (the context's last launch had at
  *                      least one interaction per packet, or -- first launch -- the midplane is optically thick)
- *   "deposit_log_mb"  size of the binned-deposit log in MiB; 0 (default) = 24 GiB or a third of
+ *   "deposit_log_mb"  size of the binned-deposit log in MiB; 0 (default) = up to 64 GiB (what the packets asked for need), at most a quarter of
  *                      the free device memory.  A smaller log means more, shorter chunks; a
  *                      block that finds its part of the log full is added with atomics.
  *   "schedule"     0 = automatic (default): waves with roles and LDS packet queues where
@@ -581,7 +583,8 @@ int mcgpu_probe_packet_rand(mcgpu_ctx *ctx, uint64_t seed, uint64_t packet,
  * mcgpu_rt1_image, mcgpu_rt1_stars_map_sed), mcgpu_define_dark_zone, the diffusion fill and the random walk (mcgpu_set_mrw
  * with one row of tables per class) read per class too.
  * Grids: cylindrical (every path above) and Voronoi (the thermal step, with or without the random walk:
- * k_thermal_voro_var; mcgpu_run_mono, mcgpu_repartition_energie, mcgpu_rt1_dust_map / _image); not spherical.
+ * k_thermal_voro_var; mcgpu_run_mono, mcgpu_repartition_energie, mcgpu_rt1_dust_map / _image); spherical: the
+ * temperature step (round 5).
  * p_n_cells = 0: off.  log_Qcool and kdB_dT_CDF may both be NULL (see mcgpu_init_reemission).
  */
 int mcgpu_set_variable_dust(mcgpu_ctx *ctx, int p_n_cells, const int *p_icell, const double *kappa,

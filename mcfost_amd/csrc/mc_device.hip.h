@@ -654,20 +654,29 @@ __device__ __attribute__((noinline)) int az_sector(double x, double y, int n_az,
 }
 
 // index_cell_cyl (cylindrical_grid.f90:833-890) -> (ri,zj,k)
+// ri_hint (1 .. n_rad, else none): the radial index the point is expected in -- a stopping point lies in the cell its flight
+// was crossing but for rounding --; where r_lim_2(hint - 1) < r^2 <= r_lim_2(hint) holds it IS what the bisection returns
+// (the same comparisons), and its seven dependent table reads are skipped
 template <bool L3D>
 __device__ inline void index_cell(const Lds& T, const DevModel& M, double x, double y, double z,
-                                  int& ri_out, int& zj_out, int& k_out) {
+                                  int& ri_out, int& zj_out, int& k_out, int ri_hint = -1) {
   double r2 = x * x + y * y;
   if (r2 < T.r_lim_2[0]) {
     ri_out = 0; zj_out = 1; k_out = 1;
   } else if (r2 > M.Rmax2) {
     ri_out = M.n_rad + 1; zj_out = 1; k_out = 1;
   } else {
-    int ri_min = 0, ri_max = M.n_rad;
-    int ri = (ri_min + ri_max) / 2;
-    while ((ri_max - ri_min) > 1) {
-      if (r2 > T.r_lim_2[ri]) ri_min = ri; else ri_max = ri;
+    int ri;
+    const bool hinted = ri_hint >= 1 && ri_hint <= M.n_rad;
+    const int hs = hinted ? ri_hint : 1;
+    if (hinted && (hs == 1 || r2 > T.r_lim_2[hs - 1]) && (hs == M.n_rad || !(r2 > T.r_lim_2[hs]))) ri = hs - 1;
+    else {
+      int ri_min = 0, ri_max = M.n_rad;
       ri = (ri_min + ri_max) / 2;
+      while ((ri_max - ri_min) > 1) {
+        if (r2 > T.r_lim_2[ri]) ri_min = ri; else ri_max = ri;
+        ri = (ri_min + ri_max) / 2;
+      }
     }
     ri_out = ri + 1;
     int zj = zj_from_z_real(T, M.nz, fabs(z), ri_out);
@@ -2148,7 +2157,7 @@ __device__ __forceinline__ void thermal_body(const DevModel& M, const RunArgs& A
               x = x + lc * u;
               y = y + lc * v;
               z = z + lc * w;
-              if (L3D && !SPH) index_cell<L3D>(T, M, x, y, z, ri, zj, k);  // optical_depth.f90:162-165 (lcylindrical only)
+              if (L3D && !SPH) index_cell<L3D>(T, M, x, y, z, ri, zj, k, ri);  // optical_depth.f90:162-165 (lcylindrical only)
               st = S_INTERACT;
               if (MRW) n_inter = first_cross ? (n_inter < 7 ? n_inter + 1 : 7) : 0;  // dust_transfer.f90:1244-1249
             } else {
@@ -2238,6 +2247,14 @@ template <bool L3D, bool POLA, bool LDSE, bool MRW = false>
 __global__ void __launch_bounds__(LDSE ? MCGPU_LDS_BLOCK : 256) k_thermal_sph(const DevModel M, const RunArgs A) {
   extern __shared__ double lds_raw[];
   thermal_body<L3D, POLA, false, LDSE, true, MRW>(M, A, lds_raw);
+}
+
+// ... with a dark zone (DARK: the mirror of optical_depth.f90:104-112 at the wall of a flagged cell) and / or dust classes
+// (VAR: lvariable_dust) -- round 5; without the random walk
+template <bool L3D, bool POLA, bool DARK, bool LDSE, bool VAR>
+__global__ void __launch_bounds__(LDSE ? MCGPU_LDS_BLOCK : 256) k_thermal_sph_ext(const DevModel M, const RunArgs A) {
+  extern __shared__ double lds_raw[];
+  thermal_body<L3D, POLA, DARK, LDSE, true, false, VAR>(M, A, lds_raw);
 }
 
 // LDS-deposit variant: one MCGPU_LDS_BLOCK-thread workgroup per CU shares one private grid.

@@ -13,6 +13,8 @@ namespace mcgpu {
 // kern_single.hip: one role per wave -- k_thermal_lds (lds) / k_thermal, k_thermal_sph
 const void* kpick_thermal(bool lds, bool l3d, bool pola, bool dark, bool mrw);
 const void* kpick_thermal_sph(bool l3d, bool pola, bool lds, bool mrw);
+// kern_sph_ext.hip: the spherical grid with a dark zone and / or dust classes -- k_thermal_sph_ext (no random walk)
+const void* kpick_thermal_sph_ext(bool l3d, bool pola, bool dark, bool lds, bool var);
 // kern_roles.hip: waves with roles -- k_thermal_roles (mrw: 2D only)
 const void* kpick_roles(bool l3d, bool pola, bool dark, bool lds, bool mrw);
 // ... k_thermal_roles_param: 2D, LDS deposits, the flight-parametric crossing in the flying waves (option "crossing" = 1)

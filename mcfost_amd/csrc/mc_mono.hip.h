@@ -831,7 +831,7 @@ __device__ __forceinline__ void mono_body(const DevModel& M, const MonoArgs& A, 
               x = x + lc * u;
               y = y + lc * v;
               z = z + lc * w;
-              if (L3D && !SPH) index_cell<L3D>(T, M, x, y, z, ri, zj, k);   // (optical_depth.f90:162-165: lcylindrical only)
+              if (L3D && !SPH) index_cell<L3D>(T, M, x, y, z, ri, zj, k, ri);   // (optical_depth.f90:162-165: lcylindrical only)
               st = S_INTERACT;
             } else {
               extr = extr - tau;

@@ -252,7 +252,7 @@ __device__ inline int roles_cross(const Lds& T, const DevModel& M, const RunArgs
     p.x = p.x + lc * p.u;
     p.y = p.y + lc * p.v;
     p.z = p.z + lc * p.w;
-    if (L3D) index_cell<L3D>(T, M, p.x, p.y, p.z, p.ri, p.zj, p.k);
+    if (L3D) index_cell<L3D>(T, M, p.x, p.y, p.z, p.ri, p.zj, p.k, p.ri);
     p.st = S_INTERACT;
   } else {
     p.extr = p.extr - tau;
@@ -714,7 +714,7 @@ __device__ __forceinline__ int fly_step_3d(const Lds& T, const DevModel& M, cons
   if (DEFER) {
     p.k = stop ? -p.k : p.k;   // (:140: the interaction re-indexes the stopping point, see reindex_stop)
   } else if (__builtin_expect(stop, 0)) {  // (:140: 3D re-indexes the stopping point)
-    index_cell<true>(T, M, p.x, p.y, p.z, p.ri, p.zj, p.k);
+    index_cell<true>(T, M, p.x, p.y, p.z, p.ri, p.zj, p.k, p.ri);
     p.ic = is_real_cell<true>(n_rad, nz, p.ri, p.zj) ? cell_index<true>(n_rad, nz, p.ri, p.zj, p.k) : M.n_cells;
     // (the re-indexed point may lie in a neighbouring cell -- zj goes through default real --: the next flight, which
     // skips the load when the cell is the one it holds, must not inherit the old cell's factor)
@@ -1177,7 +1177,7 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
           bool flag_star = (fl & ST_STAR) != 0, flag_scatt = (fl & ST_SCATT) != 0, flag_ism = (fl & ST_ISM) != 0;
           if (L3D && !VORO && R.k < 0) {   // a flight stopped here: the cell of the stopping point (fly_step_3d, DEFER)
             int ri_s, zj_s, k_s;
-            index_cell<true>(T, M, R.x, R.y, R.z, ri_s, zj_s, k_s);
+            index_cell<true>(T, M, R.x, R.y, R.z, ri_s, zj_s, k_s, R.ri);
             R.ri = ri_s; R.zj = zj_s; R.k = k_s;
           }
           const int ic = VORO ? R.ri - 1 : cell_index<L3D>(n_rad, nz, R.ri, R.zj, R.k);

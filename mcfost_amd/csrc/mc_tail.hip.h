@@ -69,7 +69,7 @@ __device__ __forceinline__ void tail_packet(const Lds& T, const DevModel& M, con
   F.x = R0.x; F.y = R0.y; F.z = R0.z; F.u = R0.u; F.v = R0.v; F.w = R0.w; F.extr = R0.extr; F.S0 = R0.S[0];
   double S1 = POLA ? R0.S[POLA ? 1 : 0] : 0.0, S2 = POLA ? R0.S[POLA ? 2 : 0] : 0.0, S3 = POLA ? R0.S[POLA ? 3 : 0] : 0.0;
   F.ri = R0.ri; F.zj = R0.zj; F.k = R0.k; F.star_key = R0.star_key; F.pk_cross = R0.pk_cross;
-  if (L3D && F.k < 0) index_cell<true>(T, M, F.x, F.y, F.z, F.ri, F.zj, F.k);   // (a stop the role kernel left to re-index)
+  if (L3D && F.k < 0) index_cell<true>(T, M, F.x, F.y, F.z, F.ri, F.zj, F.k, F.ri);   // (a stop the role kernel left to re-index)
   int lambda = R0.lambda, st = R0.flags & ST_MASK;
   bool flag_star = (R0.flags & ST_STAR) != 0, flag_scatt = (R0.flags & ST_SCATT) != 0, flag_ism = (R0.flags & ST_ISM) != 0;
   int n_int = MRW ? ((R0.flags >> ST_NINT_SHIFT) & 7) : 0;

@@ -679,7 +679,6 @@ extern "C" int mcgpu_set_opacity(mcgpu_ctx* ctx, int n_lambda, const double* kap
     for (int i = 0; i < M.n_cells; ++i) any |= (l_dark_zone[i] != 0);
     if (any && ctx->voro)  // the reference never builds a dark zone there (dust_transfer.f90:290-293)
       return fail(ctx, MCGPU_ERR_UNSUPPORTED, "no dark zone on a Voronoi grid");
-    if (any && M.grid_sph) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "dark zones on a spherical grid are not supported yet");
     if (any && (rc = upload(ctx, l_dark_zone, (size_t)M.n_cells, &M.dark))) return rc;
   }
   if (ctx->voro) {  // the cell records carry the opacity factor
@@ -783,7 +782,6 @@ extern "C" int mcgpu_set_variable_dust(mcgpu_ctx* ctx, int p_n_cells, const int*
     return fail(ctx, MCGPU_ERR_ARG, "mcgpu_set_variable_dust: bad argument");
   if (!ctx->have_grid || !ctx->have_opacity || !ctx->have_thermal)
     return fail(ctx, MCGPU_ERR_STATE, "set the grid, the opacities and the thermal tables first");
-  if (M.grid_sph) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "variable dust: cylindrical and Voronoi grids");
   for (int i = 0; i < M.n_cells; ++i)
     if (p_icell[i] < 1 || p_icell[i] > p_n_cells) return fail(ctx, MCGPU_ERR_ARG, "mcgpu_set_variable_dust: p_icell out of range");
   const int nc = p_n_cells, nl = M.n_lambda, nT = M.n_T;
@@ -940,7 +938,6 @@ extern "C" int mcgpu_opacity(mcgpu_ctx* ctx, const mcgpu_grain_tables* G, int p_
   if (!ctx->have_grid || !ctx->have_opacity || !ctx->have_thermal || !ctx->have_scatt)
     return fail(ctx, MCGPU_ERR_STATE, "set the grid, the opacities, the scattering and the thermal tables first");
   DevModel& M = ctx->M;
-  if (M.grid_sph) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "variable dust: cylindrical and Voronoi grids");
   const int ng = G->n_grains, nl = M.n_lambda, nc = p_n_cells, nT = M.n_T, na1 = M.nang + 1;
   const bool pola = ctx->lsepar_pola != 0, mueller = M.aniso_method == 1;
   if (ng < 1 || G->grain_RE_LTE_start < 1 || G->grain_RE_LTE_end > ng || !G->C_ext || !G->C_sca || !G->C_abs || !G->S_grain ||
@@ -1298,6 +1295,15 @@ static int launch_mega(mcgpu_ctx* ctx, const RunArgs& A, bool use_lds, int grid_
   // round, the role in which more of its lanes have work (default).
   if (M.mrw && ctx->mrw_classes != M.n_classes)
     return fail(ctx, MCGPU_ERR_STATE, "the random walk's tables belong to another set of dust classes: mcgpu_set_mrw after mcgpu_set_variable_dust");
+  if (M.grid_sph && (M.n_classes || dark)) {  // the spherical grid with a dark zone and / or dust classes (round 5)
+    if (M.mrw) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "spherical grid: the random walk runs without dark zone and dust classes");
+    if (M.n_classes && dark) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "spherical grid: a dark zone or dust classes, not both (unverified: the CPU restatement has no such case)");
+    const void* fn = kpick_thermal_sph_ext(l3d, pola, dark, use_lds, M.n_classes != 0);
+    HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k));
+    void* args[] = {(void*)&M, (void*)&A};
+    HIPCHK(hipLaunchKernel(fn, dim3(blocks), dim3(threads), args, lds_k, ctx->stream));
+    return MCGPU_OK;
+  }
   if (M.n_classes) {  // lvariable_dust
     const void* fn;
     // the role schedule (k_thermal_roles_var) wherever its records fit; option "schedule" = 1 or the radiation-field
@@ -1603,8 +1609,9 @@ static bool bin_fits(const mcgpu_ctx* ctx) {
 
 // The deposit log of this launch.  Automatic size: what the packets asked for are expected to deposit -- n_packets x
 // deposits per packet (measured by the context's first launch; 400 before that) x 1.5 of slack, 12 bytes each --,
-// at most 24 GiB (32 M blocks = 2e9 deposits per chunk) and at most a quarter of the device's free memory (other
-// contexts of the process, xJ_abs, xI_scatt want theirs); an existing log is kept while it is large enough.
+// at most 64 GiB (89 M blocks = 5.7e9 deposits per chunk; round 5: 24 GiB before -- config 3's step in 10 chunks instead of
+// 19, 473 -> 457 ms; 128 GiB buys nothing more: profiles/r05_bin_log_size.log) and at most a quarter of the device's free
+// memory (other contexts of the process, xJ_abs, xI_scatt want theirs); an existing log is kept while it is large enough.
 static int bin_prepare(mcgpu_ctx* ctx, int n_parts, uint64_t n_packets) {
   const DevModel& M = ctx->M;
   const int shift = bin_shift_for(M.n_cells);
@@ -1615,7 +1622,7 @@ static int bin_prepare(mcgpu_ctx* ctx, int n_parts, uint64_t n_packets) {
   const double dep_pp = ctx->bin_dep_per_packet > 0.0 ? ctx->bin_dep_per_packet : 400.0;
   double want_b = (double)n_packets * dep_pp * 1.5 * (double)(sizeof(double) + sizeof(unsigned int));
   if (want_b < 64.0 * 1048576.0) want_b = 64.0 * 1048576.0;
-  if (want_b > 24.0 * 1073741824.0) want_b = 24.0 * 1073741824.0;
+  if (want_b > 64.0 * 1073741824.0) want_b = 64.0 * 1073741824.0;
   if (ctx->opt_log_mb > 0) want_b = (double)((size_t)ctx->opt_log_mb << 20);
   const bool same = ctx->bin.keys && ctx->bin.n_buckets == nb && ctx->bin.shift == shift && ctx->bin_max_parts >= n_parts;
   if (same && (ctx->opt_log_mb > 0 || (double)ctx->bin_total_blocks * (double)block_bytes >= 0.999 * want_b ||
@@ -2291,7 +2298,8 @@ extern "C" int mcgpu_run_mono(mcgpu_ctx* ctx, const mcgpu_mono_opts* o, double f
   if (rt1 && !ctx->have_rt1) return fail(ctx, MCGPU_ERR_STATE, "rt1 deposits need mcgpu_set_rt1");
   if (rt2 && !ctx->have_rt2) return fail(ctx, MCGPU_ERR_STATE, "rt2 deposits need mcgpu_set_rt2");
   if (rt2 && (M.l3D || ctx->voro)) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "ray tracing method 2 is 2D only (radiation_field.f90:91)");
-  if (M.grid_sph && (rt2 || M.n_classes)) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "SED mode on a spherical grid: one dust class, no ray tracing method 2");
+  if (M.grid_sph && (rt2 || M.n_classes || M.dark))
+    return fail(ctx, MCGPU_ERR_UNSUPPORTED, "SED mode on a spherical grid: one dust class, no dark zone, no ray tracing method 2 (the temperature step takes both)");
   const int n_pos = ctx->have_rt1 ? ctx->n_lambda_pos : M.n_lambda;
   if (o->p_lambda < 1 || o->p_lambda > n_pos || o->p_lambda > M.n_lambda) return fail(ctx, MCGPU_ERR_ARG, "p_lambda out of range");
   // prob_E_cell = NULL: the table mcgpu_repartition_energie left on the device for this wavelength
@@ -2672,6 +2680,8 @@ static int rt1_prepare(mcgpu_ctx* ctx, const mcgpu_rt_opts* o, const float* tab_
   if (rc) return rc;
   if (ctx->voro && J.method2) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "ray tracing on a Voronoi grid: method 1");
   if (ctx->M.grid_sph && J.method2) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "ray tracing method 2: 2D cylindrical grids");
+  if (ctx->M.grid_sph && (ctx->M.n_classes || ctx->M.dark))
+    return fail(ctx, MCGPU_ERR_UNSUPPORTED, "ray tracing on a spherical grid: one dust class, no dark zone");
   if (!o || !tab_RT_az || !Tdust) return fail(ctx, MCGPU_ERR_ARG, "RT1 ray tracing: null argument");
   if (!ctx->have_rt1 || (!ctx->d_xI && !J.method2))
     return fail(ctx, MCGPU_ERR_STATE, "RT1 ray tracing needs the xI_scatt of mcgpu_run_mono(rt1=1) or mcgpu_set_xI");

@@ -282,7 +282,18 @@ extern "C" int emu_run_thermal(const oracle_model* m, const oracle_opts* o, cons
   }
   if (M.grid_sph) {  // spherical grid: the single-role kernel with that grid's operators
     const bool ld = getenv("MCGPU_EMU_LDS") != nullptr;
-    if (dark) return 31;
+    if (dark || M.n_classes) {   // a dark zone and / or dust classes on the spherical grid (k_thermal_sph_ext)
+      if (M.mrw) return 31;
+      const bool var = M.n_classes != 0;
+      if (dark && var) return 31;
+#define RUNSX(a, b) do { if (dark) { if (ld) k_thermal_sph_ext<a, b, true, true, false>(M, A); else k_thermal_sph_ext<a, b, true, false, false>(M, A); } \
+                         else { if (ld) k_thermal_sph_ext<a, b, false, true, true>(M, A); else k_thermal_sph_ext<a, b, false, false, true>(M, A); } } while (0)
+      if (l3d) { if (pola) RUNSX(true, true); else RUNSX(true, false); }
+      else { if (pola) RUNSX(false, true); else RUNSX(false, false); }
+#undef RUNSX
+      for (int q = 0; q < ORACLE_N_COUNTERS; ++q) counters[q] = cnt[q];
+      return err;
+    }
     if (l3d) { if (pola) { if (ld) k_thermal_sph<true, true, true>(M, A); else k_thermal_sph<true, true, false>(M, A); }
                else { if (ld) k_thermal_sph<true, false, true>(M, A); else k_thermal_sph<true, false, false>(M, A); } }
     else { if (pola) { if (ld) k_thermal_sph<false, true, true>(M, A); else k_thermal_sph<false, true, false>(M, A); }

@@ -116,6 +116,47 @@ def test_spherical_grid_on_the_gpu():
         e.close()
 
 
+def test_spherical_grid_dark_zone_and_dust_classes_on_the_gpu():
+    """Round 5: the spherical grid's temperature step takes a dark zone (l_dark_zone flags: the mirror of
+    optical_depth.f90:104-112) or dust classes (lvariable_dust) -- k_thermal_sph_ext --, HBM and LDS deposits; bars as in
+    tests/test_kernel_emulation.py::test_emulated_spherical_grid_with_dark_zone_and_dust_classes.  Both at once, the
+    random walk with either, and the SED mode / ray tracer on such a context are refused with a message."""
+    from test_kernel_emulation import _check_spherical, _check_spherical_loose
+    from mcfost_amd.engine import McgpuError
+    for kw in (dict(), dict(n_rad=12, nz=6, n_az=8, l3D=True)):
+        m = M.build_model(M.small(grid_type=2, **kw))
+        M.init_variable_dust(m)
+        n = 20000
+        e, o = _engine(m, n), _oracle(m, n)
+        prior = o.run_thermal(2000, seed=1)["E_abs"]
+        _check_spherical(e.run_thermal(n, seed=19, frozen=True, E_prior=prior), o, m, n, 19, prior)
+        e.set_option("deposit", 1)
+        _check_spherical(e.run_thermal(n, seed=20, frozen=True, E_prior=prior), o, m, n, 20, prior)
+        live = e.run_thermal(50000, seed=5)
+        assert live["counters"]["escaped"] + live["counters"]["killed_star"] == 50000
+        e.close()
+        md = M.build_model(M.small(grid_type=2, **kw))
+        md.l_dark_zone = (md.kappa_factor > np.percentile(md.kappa_factor, 90)).astype(np.uint8)
+        e, o = _engine(md, n), _oracle(md, n)
+        prior = o.run_thermal(2000, seed=1)["E_abs"]
+        b = o.run_thermal(n, seed=17, frozen=True, E_prior=prior, n_threads=8)
+        assert b["counters"]["dark_mirrors"] > 1000
+        tol = 0.04 if kw.get("l3D") else 0.01
+        a = e.run_thermal(n, seed=17, frozen=True, E_prior=prior)
+        _check_spherical_loose(dict(a, counters=list(a["counters"].values())), b, n, tol)
+        e.set_option("deposit", 1)
+        a = e.run_thermal(n, seed=17, frozen=True, E_prior=prior)
+        _check_spherical_loose(dict(a, counters=list(a["counters"].values())), b, n, tol)
+        e.close()
+    m = M.build_model(M.small(grid_type=2))
+    m.l_dark_zone = (m.kappa_factor > np.percentile(m.kappa_factor, 90)).astype(np.uint8)
+    M.init_variable_dust(m)
+    e = _engine(m, 1000)
+    with pytest.raises(McgpuError, match="not both"):
+        e.run_thermal(1000, seed=1)
+    e.close()
+
+
 def _frozen_parity(m, n, seed, n_prior=2000, rtol=1e-9, **kw):
     e, o = _engine(m, n), _oracle(m, n)
     prior = o.run_thermal(n_prior, seed=1)["E_abs"]
