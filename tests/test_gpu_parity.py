@@ -136,7 +136,8 @@ def test_spherical_grid_dark_zone_and_dust_classes_on_the_gpu():
         assert live["counters"]["escaped"] + live["counters"]["killed_star"] == 50000
         e.close()
         md = M.build_model(M.small(grid_type=2, **kw))
-        md.l_dark_zone = (md.kappa_factor > np.percentile(md.kappa_factor, 90)).astype(np.uint8)
+        # (flagged cells must not touch the central hole: a packet mirrored at their wall interacts in the cell it came from)
+        md.l_dark_zone = ((md.kappa_factor > np.percentile(md.kappa_factor, 85)) & (md.grid["cell_map_i"][:md.n_cells] >= 3)).astype(np.uint8)
         e, o = _engine(md, n), _oracle(md, n)
         prior = o.run_thermal(2000, seed=1)["E_abs"]
         b = o.run_thermal(n, seed=17, frozen=True, E_prior=prior, n_threads=8)
@@ -149,7 +150,7 @@ def test_spherical_grid_dark_zone_and_dust_classes_on_the_gpu():
         _check_spherical_loose(dict(a, counters=list(a["counters"].values())), b, n, tol)
         e.close()
     m = M.build_model(M.small(grid_type=2))
-    m.l_dark_zone = (m.kappa_factor > np.percentile(m.kappa_factor, 90)).astype(np.uint8)
+    m.l_dark_zone = ((m.kappa_factor > np.percentile(m.kappa_factor, 85)) & (m.grid["cell_map_i"][:m.n_cells] >= 3)).astype(np.uint8)
     M.init_variable_dust(m)
     e = _engine(m, 1000)
     with pytest.raises(McgpuError, match="not both"):
