@@ -611,11 +611,20 @@ int mcgpu_set_variable_dust_s11(mcgpu_ctx *ctx, const float *tab_s11_pos);
  * so the host need not build or upload them (with lvariable_dust: n_lambda * n_T * p_n_cells doubles, 280 MB at 7000
  * cells, mem.f90:213-244).  tab_lambda / tab_delta_lambda [n_lambda] in micron (module wavelengths).  Outputs, either
  * may be NULL: the tables in the reference's layouts (of the classes when variable dust is set, else of the single
- * class).  Not built: lextra_heating / dudt (the Phantom coupling's non-radiative heating term, :486-494) and the
- * per-grain tables of the non-LTE / non-equilibrium grains (:517-532, 552-619).
+ * class).  lextra_heating / dudt (the Phantom coupling's non-radiative heating term, :486-494): mcgpu_init_reemission_ex
+ * below.  Not built: the per-grain tables of the non-LTE / non-equilibrium grains (:517-532, 552-619).
  */
 int mcgpu_init_reemission(mcgpu_ctx *ctx, const double *tab_lambda, const double *tab_delta_lambda,
                           double *log_Qcool, double *kdB_dT_CDF);
+/* ... with the non-radiative heating of the Phantom coupling (lextra_heating, thermal_emission.f90:486-494): per class
+ * (p_n_cells of them, or one) dudt and heating_norm = AU_to_m**2 * volume * kappa_factor; the floor of the cooling rate
+ * becomes max(Qcool(tab_Temp(1)), dudt / heating_norm), or, ufac_implicit > 0 (ldudt_implicit),
+ * max(Qcool(tab_Temp(1)), (ufac_implicit * tab_Temp(T) - dudt) / heating_norm).  MCGPU_ERR_UNSUPPORTED when the result
+ * does not increase with T (the reference's "Qrad_minus_dudt is not an increasing function of T", :622-631).
+ * dudt = heating_norm = NULL: mcgpu_init_reemission. */
+int mcgpu_init_reemission_ex(mcgpu_ctx *ctx, const double *tab_lambda, const double *tab_delta_lambda,
+                             const double *dudt, const double *heating_norm, double ufac_implicit,
+                             double *log_Qcool, double *kdB_dT_CDF);
 
 /*
  * opacity + calc_local_scattering_matrices on the device (dust_prop.f90:791-1033 and 1037-1243):

@@ -2288,8 +2288,8 @@ static __global__ void k_temp_finale(const DevModel M, const double* E_abs, cons
 // ---------------------------------------------------------------------------
 // init_reemission (thermal_emission.f90:404-550), the LTE tables: log_Qcool_minus_extra_heating(T, p_icell) and
 // kdB_dT_CDF(lambda, T, p_icell), built where they are used (with lvariable_dust they are 280 MB at 7000 cells,
-// mem.f90:213-244).  One thread per (class, T): the wavelength sums run in the reference's order.  No extra heating
-// (lextra_heating off): the floor is the cooling rate at tab_Temp(1) (:483-485).
+// mem.f90:213-244).  One thread per (class, T): the wavelength sums run in the reference's order.  Without extra heating
+// the floor is the cooling rate at tab_Temp(1) (:483-485); with it (round 5) see k_init_reemission's last arguments.
 // ---------------------------------------------------------------------------
 // sum over lambda of kappa_abs_LTE * B(lambda, T) (:431-452, :468-473); row (may be null) receives the running sum of
 // kappa_abs_LTE * dB_dT (:536-541)
@@ -2316,8 +2316,12 @@ __device__ inline double reemission_sums(double Temp, int n_lambda, const double
   return integ;
 }
 
+// dudt / hnorm (per class, or null): lextra_heating (:486-494) -- the non-radiative heating of the Phantom coupling: the
+// floor becomes max(Qcool0, dudt / hnorm) with hnorm = AU_to_m^2 volume kappa_factor, or, ldudt_implicit (ufac > 0),
+// max(Qcool0, (ufac tab_Temp(T) - dudt) / hnorm)
 static __global__ void k_init_reemission(int n_classes, int n_T, int n_lambda, const float* tab_Temp, const double* tab_lambda,
-                                  const double* tab_delta_lambda, const double* kabs, double* lq, double* cdf) {
+                                  const double* tab_delta_lambda, const double* kabs, double* lq, double* cdf,
+                                  const double* dudt, const double* hnorm, double ufac) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n_classes * n_T) return;
   const int c = idx / n_T, t = idx - c * n_T;
@@ -2328,7 +2332,13 @@ static __global__ void k_init_reemission(int n_classes, int n_T, int n_lambda, c
   // (T = 1 is its own floor, exactly: the two inlined sums need not contract alike)
   const double Qcool0 =
       (t == 0) ? Qcool : reemission_sums((double)tab_Temp[0], n_lambda, tab_lambda, tab_delta_lambda, ka, nullptr) * cst_E;
-  const double q = Qcool - Qcool0;
+  double extra = Qcool0;   // (.not.lextra_heating: the equilibrium with the cloud at T_min, :483-485)
+  if (dudt) {
+    const double Temp = (double)tab_Temp[t];   // (default real in the reference: u_o_dt = ufac_implicit * Temp)
+    const double h = (ufac > 0.0) ? (ufac * Temp - dudt[c]) / hnorm[c] : dudt[c] / hnorm[c];
+    extra = fmax(Qcool0, h);
+  }
+  const double q = Qcool - extra;
   lq[(size_t)c * n_T + t] = (q > TINY_DP) ? log(q) : -1000.0;  // :496-504
   const double tot = row[n_lambda - 1];
   const bool ok = tot > TINY_DP;                               // :544-548 (the table stays 0 otherwise)

@@ -1046,7 +1046,16 @@ extern "C" int mcgpu_opacity(mcgpu_ctx* ctx, const mcgpu_grain_tables* G, int p_
 // init_reemission on the device (thermal_emission.f90:404-550): see include/mcgpu.h
 extern "C" int mcgpu_init_reemission(mcgpu_ctx* ctx, const double* tab_lambda, const double* tab_delta_lambda,
                                      double* log_Qcool, double* kdB_dT_CDF) {
-  if (!ctx || !tab_lambda || !tab_delta_lambda) return fail(ctx, MCGPU_ERR_ARG, "mcgpu_init_reemission: bad argument");
+  return mcgpu_init_reemission_ex(ctx, tab_lambda, tab_delta_lambda, nullptr, nullptr, 0.0, log_Qcool, kdB_dT_CDF);
+}
+
+// lextra_heating (thermal_emission.f90:486-494, 622-631): dudt[nc], heating_norm[nc] = AU_to_m^2 volume kappa_factor per
+// class (nc = p_n_cells, or 1); ufac_implicit > 0: ldudt_implicit.  Both NULL: mcgpu_init_reemission.
+extern "C" int mcgpu_init_reemission_ex(mcgpu_ctx* ctx, const double* tab_lambda, const double* tab_delta_lambda,
+                                        const double* dudt, const double* heating_norm, double ufac_implicit,
+                                        double* log_Qcool, double* kdB_dT_CDF) {
+  if (!ctx || !tab_lambda || !tab_delta_lambda || ((dudt == nullptr) != (heating_norm == nullptr)))
+    return fail(ctx, MCGPU_ERR_ARG, "mcgpu_init_reemission: bad argument");
   if (!ctx->have_opacity || !ctx->have_thermal) return fail(ctx, MCGPU_ERR_STATE, "set the opacities and the thermal tables first");
   HIPCHK(hipSetDevice(ctx->device));
   DevModel& M = ctx->M;
@@ -1059,18 +1068,29 @@ extern "C" int mcgpu_init_reemission(mcgpu_ctx* ctx, const double* tab_lambda, c
   d_dlam = d_lam + nl;
   hipError_t e = hipMemcpy(d_lam, tab_lambda, (size_t)nl * sizeof(double), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(d_dlam, tab_delta_lambda, (size_t)nl * sizeof(double), hipMemcpyHostToDevice);
-  auto build = [&](int nc, const double* kabs, const double* lq, const double* cdf) {
+  // the extra heating's per-class terms (they belong to the tables the loop reads: the classes' when there are classes)
+  const int n_heat = M.n_classes ? M.n_classes : 1;
+  double *d_dudt = nullptr, *d_hnorm = nullptr;
+  if (dudt && e == hipSuccess) {
+    for (int c = 0; c < n_heat; ++c)
+      if (!(heating_norm[c] > 0.0)) { hipFree(d_lam); return fail(ctx, MCGPU_ERR_ARG, "mcgpu_init_reemission: heating_norm must be positive"); }
+    e = hipMalloc((void**)&d_dudt, 2 * (size_t)n_heat * sizeof(double));
+    if (e == hipSuccess) { d_hnorm = d_dudt + n_heat; e = hipMemcpy(d_dudt, dudt, (size_t)n_heat * sizeof(double), hipMemcpyHostToDevice); }
+    if (e == hipSuccess) e = hipMemcpy(d_hnorm, heating_norm, (size_t)n_heat * sizeof(double), hipMemcpyHostToDevice);
+  }
+  auto build = [&](int nc, const double* kabs, const double* lq, const double* cdf, bool heat) {
     const int n = nc * nT, threads = 64;  // one (class, T) row per thread: short rows, many of them
     hipLaunchKernelGGL(k_init_reemission, dim3((n + threads - 1) / threads), dim3(threads), 0, ctx->stream, nc, nT, nl,
-                       ctx->d_tab_Temp, d_lam, d_dlam, kabs, const_cast<double*>(lq), const_cast<double*>(cdf));
+                       ctx->d_tab_Temp, d_lam, d_dlam, kabs, const_cast<double*>(lq), const_cast<double*>(cdf),
+                       heat ? d_dudt : nullptr, heat ? d_hnorm : nullptr, ufac_implicit);
   };
   // the tables the setters left to this call; called with none pending, it rebuilds all of them (an explicit request),
   // otherwise tables the host supplied are left alone
   const bool all = !ctx->pending_single && !ctx->pending_classes;
   const bool do_single = all || ctx->pending_single, do_classes = M.n_classes && (all || ctx->pending_classes);
   if (e == hipSuccess) {
-    if (do_single) build(1, M.kappa_abs, M.log_Qcool, M.cdf);
-    if (do_classes) build(M.n_classes, M.v_kabs, M.v_lq, M.v_cdf);
+    if (do_single) build(1, M.kappa_abs, M.log_Qcool, M.cdf, !M.n_classes);
+    if (do_classes) build(M.n_classes, M.v_kabs, M.v_lq, M.v_cdf, true);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -1083,6 +1103,7 @@ extern "C" int mcgpu_init_reemission(mcgpu_ctx* ctx, const double* tab_lambda, c
   if (e == hipSuccess && kdB_dT_CDF)
     e = hipMemcpy(kdB_dT_CDF, d_cdf, (size_t)nc * nT * nl * sizeof(double), hipMemcpyDeviceToHost);
   hipFree(d_lam);
+  if (d_dudt) hipFree(d_dudt);
   if (e != hipSuccess) return fail(ctx, MCGPU_ERR_HIP, hipGetErrorString(e));
   if (log_Qcool) std::memcpy(log_Qcool, lq.data(), lq.size() * sizeof(double));
   for (int c = 0; c < nc; ++c)

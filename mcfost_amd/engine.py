@@ -36,7 +36,7 @@ ABI_SYMBOLS = (
     "mcgpu_device_xI", "mcgpu_set_ism", "mcgpu_rt1_dust_map", "mcgpu_set_xI", "mcgpu_rt1_image", "mcgpu_set_xI_precision",
     "mcgpu_get_xI_precision", "mcgpu_set_option", "mcgpu_get_info", "mcgpu_counters_to_accum", "mcgpu_counters_from_accum",
     "mcgpu_set_grid_sph", "mcgpu_temp_approx_diffusion_vertical", "mcgpu_set_mrw", "mcgpu_fetch_radiation_field", "mcgpu_set_variable_dust", "mcgpu_rt1_stars_map_sed", "mcgpu_define_dark_zone", "mcgpu_init_reemission", "mcgpu_multi_create", "mcgpu_multi_destroy", "mcgpu_multi_size", "mcgpu_multi_ctx", "mcgpu_multi_last_error",
-    "mcgpu_repartition_energie", "mcgpu_opacity", "mcgpu_set_variable_dust_s11", "mcgpu_set_scattering_method1", "mcgpu_set_rt2", "mcgpu_fetch_I_spec", "mcgpu_rt1_stars_map_image", "mcgpu_set_I_spec", "mcgpu_rt2_source", "mcgpu_rt2_dust_map", "mcgpu_rt2_image", "mcgpu_shard_packets", "mcgpu_multi_run_thermal", "mcgpu_multi_run_mono", "mcgpu_multi_rccl_ranks", "mcgpu_multi_create_ex", "mcgpu_multi_reductions", "mcgpu_set_mrw_exit_spectrum", "mcgpu_voronoi_tesselation", "mcgpu_build_ksca_CDF",
+    "mcgpu_repartition_energie", "mcgpu_opacity", "mcgpu_set_variable_dust_s11", "mcgpu_set_scattering_method1", "mcgpu_set_rt2", "mcgpu_fetch_I_spec", "mcgpu_rt1_stars_map_image", "mcgpu_set_I_spec", "mcgpu_rt2_source", "mcgpu_rt2_dust_map", "mcgpu_rt2_image", "mcgpu_shard_packets", "mcgpu_multi_run_thermal", "mcgpu_multi_run_mono", "mcgpu_multi_rccl_ranks", "mcgpu_multi_create_ex", "mcgpu_multi_reductions", "mcgpu_set_mrw_exit_spectrum", "mcgpu_voronoi_tesselation", "mcgpu_build_ksca_CDF", "mcgpu_init_reemission_ex",
 )
 
 
@@ -330,18 +330,23 @@ class Engine:
         self._chk(self.lib.mcgpu_set_scattering_method1(self.ctx, C.byref(G), _p(prob, C.c_float), C.c_int(dens.shape[0]),
                                                         _p(dens, C.c_double)), "mcgpu_set_scattering_method1")
 
-    def init_reemission(self, fetch=True):
+    def init_reemission(self, fetch=True, dudt=None, heating_norm=None, ufac_implicit=0.0):
         """``init_reemission`` (thermal_emission.f90:404-550) on the device: rebuilds ``log_Qcool_minus_extra_heating``
         and ``kdB_dT_CDF`` of the context (of every class with variable dust) from its ``kappa_abs_LTE``.  Returns
-        ``(log_Qcool [classes, n_T], kdB_dT_CDF [classes, n_T, n_lambda])`` when ``fetch``."""
+        ``(log_Qcool [classes, n_T], kdB_dT_CDF [classes, n_T, n_lambda])`` when ``fetch``.  ``dudt``, ``heating_norm``
+        [classes] (and ``ufac_implicit`` > 0 for ldudt_implicit): lextra_heating (:486-494, ``mcgpu_init_reemission_ex``)."""
         m = self.model
         vd = getattr(m, "variable_dust", None)
         nc = int(vd["p_n_cells"]) if vd is not None else 1
         nT, nl = m.tab_Temp.size, m.n_lambda
         lq = np.zeros((nc, nT), np.float64) if fetch else None
         cdf = np.zeros((nc, nT, nl), np.float64) if fetch else None
-        self._chk(self.lib.mcgpu_init_reemission(
+        du = None if dudt is None else _a(np.broadcast_to(np.asarray(dudt, np.float64), (nc,)), np.float64)
+        hn = None if dudt is None else _a(np.broadcast_to(np.asarray(heating_norm, np.float64), (nc,)), np.float64)
+        self._chk(self.lib.mcgpu_init_reemission_ex(
             self.ctx, _p(_a(m.lam, np.float64), C.c_double), _p(_a(m.delta_lam, np.float64), C.c_double),
+            _p(du, C.c_double) if du is not None else None, _p(hn, C.c_double) if hn is not None else None,
+            C.c_double(float(ufac_implicit)),
             _p(lq, C.c_double) if fetch else None, _p(cdf, C.c_double) if fetch else None), "mcgpu_init_reemission")
         return lq, cdf
 

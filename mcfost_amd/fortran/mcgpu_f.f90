@@ -91,7 +91,7 @@ module mcgpu_f
        mcgpu_set_E_prior, mcgpu_multi_create, mcgpu_multi_destroy, mcgpu_multi_size, mcgpu_multi_ctx, mcgpu_multi_run_thermal, mcgpu_multi_run_mono, mcgpu_multi_rccl_ranks, mcgpu_multi_create_ex, mcgpu_multi_reductions, &
        mcgpu_counters_to_accum, mcgpu_counters_from_accum, mcgpu_temp_approx_diffusion_vertical, mcgpu_set_mrw, mcgpu_set_mrw_exit_spectrum, mcgpu_fetch_radiation_field, &
        mcgpu_build_ksca_CDF, mcgpu_voronoi_tesselation, &
-       mcgpu_set_variable_dust, mcgpu_rt1_stars_map_sed, mcgpu_define_dark_zone, mcgpu_init_reemission, mcgpu_repartition_energie, mcgpu_opacity, mcgpu_set_variable_dust_s11, mcgpu_set_scattering_method1, mcgpu_set_rt2, mcgpu_fetch_I_spec, mcgpu_rt1_stars_map_image, mcgpu_set_I_spec, mcgpu_rt2_source, mcgpu_rt2_dust_map, mcgpu_rt2_image
+       mcgpu_set_variable_dust, mcgpu_rt1_stars_map_sed, mcgpu_define_dark_zone, mcgpu_init_reemission, mcgpu_init_reemission_ex, mcgpu_repartition_energie, mcgpu_opacity, mcgpu_set_variable_dust_s11, mcgpu_set_scattering_method1, mcgpu_set_rt2, mcgpu_fetch_I_spec, mcgpu_rt1_stars_map_image, mcgpu_set_I_spec, mcgpu_rt2_source, mcgpu_rt2_dust_map, mcgpu_rt2_image
 
   interface
      integer(c_int) function mcgpu_create(device, ctx) bind(C, name="mcgpu_create")
@@ -267,6 +267,17 @@ module mcgpu_f
        real(c_double), intent(in) :: tab_lambda(*), tab_delta_lambda(*)
        type(c_ptr), value :: log_Qcool, kdB_dT_CDF
      end function mcgpu_init_reemission
+
+     ! ... with lextra_heating (thermal_emission.f90:486-494): dudt(p_n_cells) and heating_norm = AU_to_m**2 * volume * kappa_factor;
+     ! ufac_implicit > 0: ldudt_implicit
+     integer(c_int) function mcgpu_init_reemission_ex(ctx, tab_lambda, tab_delta_lambda, dudt, heating_norm, ufac_implicit, &
+          log_Qcool, kdB_dT_CDF) bind(C, name="mcgpu_init_reemission_ex")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(in) :: tab_lambda(*), tab_delta_lambda(*), dudt(*), heating_norm(*)
+       real(c_double), value :: ufac_implicit
+       type(c_ptr), value :: log_Qcool, kdB_dT_CDF
+     end function mcgpu_init_reemission_ex
 
      ! xN_abs(:,1) and xJ_abs(:,:) summed over threads (radiation_field.f90:54-55); pass c_null_ptr for either
      integer(c_int) function mcgpu_fetch_radiation_field(ctx, xN_abs, xJ_abs) bind(C, name="mcgpu_fetch_radiation_field")

@@ -558,10 +558,11 @@ class Oracle:
             raise RuntimeError(f"oracle_temp_approx_diffusion_vertical failed: {rc}")
         return T, n_it.value
 
-    def init_reemission(self, kappa_abs_LTE=None, lam=None, delta_lam=None):
+    def init_reemission(self, kappa_abs_LTE=None, lam=None, delta_lam=None, dudt=None, heating_norm=None, ufac_implicit=0.0):
         """init_reemission (thermal_emission.f90:404-550): ``kappa_abs_LTE [classes, n_lambda]`` (default: the
         model's single class) -> ``(log_Qcool [classes, n_T], kdB_dT_CDF [classes, n_T, n_lambda])``; ``lam`` /
-        ``delta_lam`` [micron] default to the model's wavelength grid."""
+        ``delta_lam`` [micron] default to the model's wavelength grid.  ``dudt``, ``heating_norm`` [classes]:
+        lextra_heating (:486-494), ``ufac_implicit`` > 0: ldudt_implicit."""
         m = self.model
         lam = m.lam if lam is None else lam
         delta_lam = m.delta_lam if delta_lam is None else delta_lam
@@ -571,11 +572,15 @@ class Oracle:
         ka_ref = _a(ka.T, np.float64)  # (p_n_cells, n_lambda) column-major = [lambda][class] in memory
         lq = np.zeros((nc, nT), np.float64)
         cdf = np.zeros((nc, nT, nl), np.float64)
-        self.lib.oracle_init_reemission.restype = C.c_int
-        rc = self.lib.oracle_init_reemission(
+        du = None if dudt is None else _a(np.broadcast_to(np.asarray(dudt, np.float64), (nc,)), np.float64)
+        hn = None if dudt is None else _a(np.broadcast_to(np.asarray(heating_norm, np.float64), (nc,)), np.float64)
+        self.lib.oracle_init_reemission_ex.restype = C.c_int
+        rc = self.lib.oracle_init_reemission_ex(
             C.c_int(nc), C.c_int(nT), C.c_int(nl), _p(_a(m.tab_Temp, np.float32), C.c_float),
             _p(_a(lam, np.float64), C.c_double), _p(_a(delta_lam, np.float64), C.c_double),
-            _p(ka_ref, C.c_double), _p(lq, C.c_double), _p(cdf, C.c_double))
+            _p(ka_ref, C.c_double), _p(du, C.c_double) if du is not None else None,
+            _p(hn, C.c_double) if hn is not None else None, C.c_double(float(ufac_implicit)),
+            _p(lq, C.c_double), _p(cdf, C.c_double))
         if rc:
             raise RuntimeError(f"oracle_init_reemission failed: {rc}")
         return lq, cdf

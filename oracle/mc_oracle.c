@@ -3418,6 +3418,15 @@ int oracle_repartition_energie(const oracle_model *m, int lambda, double wl_um, 
 int oracle_init_reemission(int p_n_cells, int n_T, int n_lambda, const float *tab_Temp, const double *tab_lambda,
                            const double *tab_delta_lambda, const double *kappa_abs_LTE, double *log_Qcool,
                            double *kdB_dT_CDF) {
+  return oracle_init_reemission_ex(p_n_cells, n_T, n_lambda, tab_Temp, tab_lambda, tab_delta_lambda, kappa_abs_LTE, NULL,
+                                   NULL, 0.0, log_Qcool, kdB_dT_CDF);
+}
+
+/* ... with lextra_heating (:486-494): dudt(icell), heating_norm(icell) = AU_to_m**2 * volume(icell) * kappa_factor(icell),
+ * ufac_implicit > 0: ldudt_implicit */
+int oracle_init_reemission_ex(int p_n_cells, int n_T, int n_lambda, const float *tab_Temp, const double *tab_lambda,
+                              const double *tab_delta_lambda, const double *kappa_abs_LTE, const double *dudt,
+                              const double *heating_norm, double ufac_implicit, double *log_Qcool, double *kdB_dT_CDF) {
   const double hp = 6.626070040e-34, c_light = 299792458.0, kb = 1.38064852e-23; /* constants.f90:21-23 */
   const float thermal_const = (float)(c_light * hp / kb);                         /* real, constants.f90:24 */
   const double cst_E = 2.0 * hp * (c_light * c_light) * (4.0 * M_PI);             /* :427 */
@@ -3456,7 +3465,13 @@ int oracle_init_reemission(int p_n_cells, int n_T, int n_lambda, const float *ta
                             B[(size_t)(lambda - 1) + (size_t)n_lambda * (t - 1)];
       const double Qcool = integ * cst_E;
       if (t == 1) Qcool0 = Qcool;
-      const double extra_heating = Qcool0; /* .not.lextra_heating (:483-485) */
+      double extra_heating = Qcool0; /* .not.lextra_heating (:483-485) */
+      if (dudt) {                     /* :486-494 */
+        const double Temp = (double)tab_Temp[t - 1];
+        const double h = (ufac_implicit > 0.0) ? (ufac_implicit * Temp - dudt[icell - 1]) / heating_norm[icell - 1]
+                                               : dudt[icell - 1] / heating_norm[icell - 1];
+        extra_heating = h > Qcool0 ? h : Qcool0;
+      }
       const double q = Qcool - extra_heating;
       log_Qcool[(size_t)(t - 1) + (size_t)n_T * (icell - 1)] = (q > tiny_dp) ? log(q) : -1000.0;
     }

@@ -398,6 +398,9 @@ int oracle_temp_approx_diffusion_vertical(const oracle_model *m, const double *t
 int oracle_init_reemission(int p_n_cells, int n_T, int n_lambda, const float *tab_Temp, const double *tab_lambda,
                            const double *tab_delta_lambda, const double *kappa_abs_LTE, double *log_Qcool,
                            double *kdB_dT_CDF);
+int oracle_init_reemission_ex(int p_n_cells, int n_T, int n_lambda, const float *tab_Temp, const double *tab_lambda,
+                              const double *tab_delta_lambda, const double *kappa_abs_LTE, const double *dudt,
+                              const double *heating_norm, double ufac_implicit, double *log_Qcool, double *kdB_dT_CDF);
 
 /* select_scattering_grain (dust_prop.f90:1292-1336) of the model's method-1 tables: 1-based grain for the draw `rand` */
 void oracle_build_ksca_CDF(const oracle_model *m, double *ksca_CDF);

@@ -634,15 +634,20 @@ extern "C" int emu_dark_zone_rays(const oracle_model* m, int lambda, double tau_
 }
 
 // k_init_reemission, one (class, T) row per call; kabs[class][lambda], outputs [class][T] and [class][T][lambda]
-extern "C" int emu_init_reemission(int n_classes, int n_T, int n_lambda, const float* tab_Temp, const double* tab_lambda,
-                                   const double* tab_delta_lambda, const double* kabs, double* lq, double* cdf) {
+extern "C" int emu_init_reemission_ex(int n_classes, int n_T, int n_lambda, const float* tab_Temp, const double* tab_lambda,
+                                      const double* tab_delta_lambda, const double* kabs, const double* dudt, const double* hnorm,
+                                      double ufac, double* lq, double* cdf) {
   gridDim.x = (unsigned)(n_classes * n_T); blockDim.x = 1; threadIdx.x = 0;
   for (unsigned b = 0; b < gridDim.x; ++b) {
     blockIdx.x = b;
-    k_init_reemission(n_classes, n_T, n_lambda, tab_Temp, tab_lambda, tab_delta_lambda, kabs, lq, cdf);
+    k_init_reemission(n_classes, n_T, n_lambda, tab_Temp, tab_lambda, tab_delta_lambda, kabs, lq, cdf, dudt, hnorm, ufac);
   }
   blockIdx.x = 0;
   return 0;
+}
+extern "C" int emu_init_reemission(int n_classes, int n_T, int n_lambda, const float* tab_Temp, const double* tab_lambda,
+                                   const double* tab_delta_lambda, const double* kabs, double* lq, double* cdf) {
+  return emu_init_reemission_ex(n_classes, n_T, n_lambda, tab_Temp, tab_lambda, tab_delta_lambda, kabs, nullptr, nullptr, 0.0, lq, cdf);
 }
 
 extern "C" int emu_stars_map_sed(const oracle_model* m, const oracle_rt_opts* o, uint64_t seed, const double* star_flux,

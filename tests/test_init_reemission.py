@@ -80,6 +80,87 @@ def test_emulated_kernel_against_the_oracle(emu):   # noqa: F811
     assert np.allclose(cdf, want_cdf, rtol=0, atol=1e-13)
 
 
+def _heating(m, ka, frac):
+    """dudt and heating_norm of a made-up heating rate: `frac` of each class's cooling rate somewhere in the table"""
+    lq0, _ = Oracle(m, 10).init_reemission(ka)
+    nT = m.tab_Temp.size
+    q_mid = np.exp(np.where(lq0[:, nT // 3] > -999.0, lq0[:, nT // 3], 0.0))
+    hn = np.linspace(2.0, 5.0, ka.shape[0])
+    return frac * q_mid * hn, hn
+
+
+def test_extra_heating_known_answers_and_the_emulated_kernel(emu):   # noqa: F811
+    """lextra_heating (thermal_emission.f90:486-494): the floor of the cooling rate becomes max(Qcool(T1), dudt / norm)
+    -- or, ldudt_implicit, max(Qcool(T1), (ufac T - dudt) / norm).  Known answers for the restatement: no heating = the
+    plain tables; exp(log_Qcool) + the floor is the same cooling rate whatever the floor; a heating rate below the
+    floor at T1 changes nothing; the re-emission CDF does not depend on it.  Then the device kernel (one lane) = the
+    restatement, explicit and implicit."""
+    m = M.build_model(M.small())
+    o = Oracle(m, 10)
+    ka = _classes(m)[:2]
+    nc, nl, nT = ka.shape[0], m.n_lambda, m.tab_Temp.size
+    lq0, cdf0 = o.init_reemission(ka)
+    dudt, hn = _heating(m, ka, 1.0)
+    lq1, cdf1 = o.init_reemission(ka, dudt=dudt, heating_norm=hn)
+    assert np.array_equal(cdf0, cdf1)
+    lqz, _ = o.init_reemission(ka, dudt=np.zeros(nc), heating_norm=hn)
+    assert np.array_equal(lqz, lq0)                                  # (a heating rate below the floor: max() keeps the floor)
+    # Qcool(T) = exp(lq0) + Qcool(T1) = exp(lq1) + dudt / hn wherever both are defined: the difference of the floors
+    both = (lq0 > -999.0) & (lq1 > -999.0)
+    d = np.exp(lq0) - np.exp(lq1)
+    assert both.sum() > nT
+    for c in range(nc):   # the same constant for every T of a class, to the cancellation of the two exponentials
+        col = np.flatnonzero(both[c])
+        dd = d[c, col]
+        assert np.all(np.abs(dd - dd[0]) <= 1e-6 * dd[0] + 1e-11 * np.exp(lq0[c, col]))
+        assert abs(dd[0] / (dudt[c] / hn[c]) - 1.0) < 1e-3           # (Qcool(T1) is tiny against the heating)
+    assert (lq1 == -1000.0).sum() > (lq0 == -1000.0).sum()          # (temperatures that cool less than they are heated)
+    for ufac in (0.0, 1.0e-3 * float(dudt.max() / m.tab_Temp[-1])):
+        du = dudt if ufac == 0.0 else -dudt        # (implicit: (ufac T - dudt) / norm with dudt = u^n / dt)
+        want_lq, want_cdf = o.init_reemission(ka, dudt=du, heating_norm=hn, ufac_implicit=ufac)
+        lq = np.zeros((nc, nT))
+        cdf = np.zeros((nc, nT, nl))
+        rc = emu.emu_init_reemission_ex(C.c_int(nc), C.c_int(nT), C.c_int(nl), _p(_a(m.tab_Temp, np.float32), C.c_float),
+                                        _p(_a(m.lam, np.float64), C.c_double), _p(_a(m.delta_lam, np.float64), C.c_double),
+                                        _p(_a(ka, np.float64), C.c_double), _p(_a(du, np.float64), C.c_double),
+                                        _p(_a(hn, np.float64), C.c_double), C.c_double(ufac), _p(lq, C.c_double), _p(cdf, C.c_double))
+        assert rc == 0
+        _same_with_heating(lq, want_lq, (ufac * m.tab_Temp[None, :].astype(np.float64) - du[:, None]) / hn[:, None] if ufac else (du / hn)[:, None])
+        assert np.allclose(cdf, want_cdf, rtol=0, atol=1e-13)
+
+
+def _same_with_heating(lq, want_lq, floor):
+    """log(Qcool - floor): where the heating nearly cancels the cooling the difference carries the rounding of Qcool itself
+    (exp and the sums differ in the last place between the builds): 1e-12 of Qcool, not of the difference"""
+    both = (lq != -1000.0) & (want_lq != -1000.0)
+    assert (lq != -1000.0).sum() > 0 and np.abs((lq != -1000.0).astype(int) - (want_lq != -1000.0).astype(int)).sum() <= 1
+    qa, qb = np.exp(np.where(both, lq, 0.0)), np.exp(np.where(both, want_lq, 0.0))
+    tol = 1e-12 * (qb + np.abs(np.broadcast_to(floor, qb.shape)))
+    assert np.all(np.abs(qa - qb)[both] <= tol[both])
+
+
+@pytest.mark.gpu
+def test_extra_heating_on_the_device():
+    """mcgpu_init_reemission_ex on a variable-dust context = the restatement; a heating that makes the table decrease with
+    T is refused (the reference's "Qrad_minus_dudt is not an increasing function of T")."""
+    from mcfost_amd.engine import Engine, McgpuError
+    m = M.build_model(M.small())
+    vd = M.init_variable_dust(m)
+    nc, nl, nT = vd["p_n_cells"], m.n_lambda, m.tab_Temp.size
+    ka = vd["kappa_abs_LTE"].reshape(nl, nc).T
+    dudt, hn = _heating(M.build_model(M.small()), ka, 0.5)
+    want_lq, want_cdf = Oracle(M.build_model(M.small()), 10).init_reemission(ka, dudt=dudt, heating_norm=hn)
+    vd["log_Qcool"] = vd["kdB_dT_CDF"] = None
+    e = Engine(m, 1000)
+    lq, cdf = e.init_reemission(dudt=dudt, heating_norm=hn)
+    assert (want_lq == -1000.0).sum() > nc
+    _same_with_heating(lq, want_lq, (dudt / hn)[:, None])
+    assert np.allclose(cdf, want_cdf, rtol=0, atol=1e-13)
+    with pytest.raises(McgpuError, match="increase with T"):   # implicit, with a u(T) that outgrows the cooling rate
+        e.init_reemission(dudt=-dudt, heating_norm=hn, ufac_implicit=1.0e6 * float(dudt.max()))
+    e.close()
+
+
 @pytest.mark.gpu
 def test_device_tables_against_the_oracle_and_a_run_on_them():
     """single class: the device-built tables equal the oracle's; a frozen step on the device with ITS tables equals the
