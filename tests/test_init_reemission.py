@@ -156,8 +156,13 @@ def test_extra_heating_on_the_device():
     assert (want_lq == -1000.0).sum() > nc
     _same_with_heating(lq, want_lq, (dudt / hn)[:, None])
     assert np.allclose(cdf, want_cdf, rtol=0, atol=1e-13)
-    with pytest.raises(McgpuError, match="increase with T"):   # implicit, with a u(T) that outgrows the cooling rate
-        e.init_reemission(dudt=-dudt, heating_norm=hn, ufac_implicit=1.0e6 * float(dudt.max()))
+    # implicit, with a u(T) / dt that grows faster than class 0's cooling rate over one step of the temperature grid:
+    # Q(T) - (ufac T - dudt) then DEcreases there
+    lq0, _ = Oracle(M.build_model(M.small()), 10).init_reemission(ka)
+    Q, T, k = np.exp(lq0[0]), m.tab_Temp.astype(np.float64), nT // 3
+    a = 2.0 * (Q[k + 1] - Q[k]) / (T[k + 1] - T[k])
+    with pytest.raises(McgpuError, match="increase with T"):
+        e.init_reemission(dudt=np.full(nc, a * T[k] - 0.5 * Q[k]), heating_norm=np.ones(nc), ufac_implicit=a)
     e.close()
 
 
