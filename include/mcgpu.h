@@ -537,6 +537,23 @@ int mcgpu_rt1_image(mcgpu_ctx *ctx, const mcgpu_rt_opts *opts,
 int mcgpu_rt1_stars_map_sed(mcgpu_ctx *ctx, const mcgpu_rt_opts *opts, const float *tab_RT_az,
                             uint64_t seed, const double *star_flux, double *stars_flux);
 
+/* The ray tracer's optical-depth maps (options -tau_map and -tau_surface, init_mcfost.f90:679-681, 1283-1291): replaces
+ * `call compute_tau_map(lambda, ibin, iaz)` and `call compute_tau_surface_map(lambda, tau_surface, ibin, iaz)` at
+ * dust_transfer.f90:785-786 / 799-800 for every observer direction of mcgpu_set_rt1 at once.  One ray per pixel centre,
+ * sent backwards from 10 Rmax through move_to_grid:
+ *   tau_map(npix_x, npix_y, RT_n_incl, RT_n_az)            optical_length_tot (optical_depth.f90:248-324) across the grid
+ *   tau_surface_map(npix_x, npix_y, RT_n_incl, RT_n_az, 3) the point (AU) where physical_length (:21-182) has used up the
+ *                                                          optical depth tau_surface; zeros when the ray leaves the grid or
+ *                                                          ends on a star first (dust_transfer.f90:2092-2100); a cell of
+ *                                                          the dark zone hands back the entry point of the cell before it
+ * Default reals, column-major, the reference's arrays summed over its threads (dust_ray_tracing.f90:59-60); either may be
+ * NULL.  Pixels are (map_size/zoom)/max(npix_x,npix_y) AU.  Of opts: lambda, ang_disque, Rmax.  Every grid (cylindrical,
+ * spherical, Voronoi; dust classes).  The reference's call of physical_length also deposits into the radiation field (a
+ * side effect of reusing the packets' routine after the Monte Carlo); the device deposits nothing. */
+int mcgpu_tau_maps(mcgpu_ctx *ctx, const mcgpu_rt_opts *opts, const float *tab_RT_az, int npix_x, int npix_y,
+                   double map_size, double zoom, double tau_surface, float *tau_map, float *tau_surface_map,
+                   double *kernel_ms);
+
 /* Temp_finale (thermal_emission.f90:870-906): Tdust(icell) from the summed
  * absorbed-energy grid.  E_abs == NULL uses the device accumulator. */
 int mcgpu_temp_finale(mcgpu_ctx *ctx, const double *E_abs, float *Tdust);

@@ -637,6 +637,114 @@ __global__ void __launch_bounds__(512) k_stars_map_image(const DevModel M, const
 }
 
 // ---------------------------------------------------------------------------
+// Optical-depth maps (options -tau_map / -tau_surface): compute_tau_map (dust_transfer.f90:2114-2210) and
+// compute_tau_surface_map (:2006-2110).  One thread per pixel CENTRE of an observer's image: move_to_grid backwards from
+// 10 Rmax, then
+//   tau_map          optical_length_tot (optical_depth.f90:248-324) from the entry point to the far edge of the grid
+//   tau_surface_map  physical_length (:21-182) until the optical depth tau_surface is used up: the point reached, or zeros
+//                    when the ray leaves the grid or ends on a star first; a cell of the dark zone hands back the entry
+//                    point of the cell before it (the mirror of :104-112).  Nothing is deposited (the reference's call
+//                    also runs save_radiation_field: a side effect of reusing the packets' routine, not reproduced).
+// Outputs are default reals in the reference's layouts (npix_x, npix_y, RT_n_incl, RT_n_az[, 3]); either may be null.
+// ---------------------------------------------------------------------------
+__device__ inline void tau_maps_pixel(const RtArgs& A, long pix, int& q, double pc[3], double uvw[3]) {
+  const long per_dir = (long)A.npix_x * A.npix_y;
+  q = (int)(pix / per_dir);
+  const long rem = pix - (long)q * per_dir;
+  const int j = (int)(rem / A.npix_x) + 1, i = (int)(rem - (long)(j - 1) * A.npix_x) + 1;
+  double xpi[3], ypi[3];
+  rt_image_plane(A, q, uvw, xpi, ypi);
+  for (int c = 0; c < 3; ++c) {
+    const double dx = xpi[c] * A.taille_pix, dy = ypi[c] * A.taille_pix;
+    const double Icorner = uvw[c] * A.l_far - (0.5 * A.npix_x * dx + 0.5 * A.npix_y * dy);
+    pc[c] = Icorner + (i - 0.5) * dx + (j - 0.5) * dy;
+  }
+}
+
+template <bool L3D>
+__global__ void __launch_bounds__(256) k_tau_maps(const DevModel M, const RtArgs A, float tau_surface, float* tau_map,
+                                                  float* surf_map) {
+  extern __shared__ double lds_raw[];
+  const Lds T = lds_carve(lds_raw, M, true);
+  lds_stage_mono(T, M, 1);
+  __syncthreads();
+  const int n_rad = M.n_rad, nz = M.nz;
+  const bool sph = M.grid_sph != 0;
+  const long n_pix = (long)A.npix_x * A.npix_y * A.nRT;
+  for (long pix = (long)blockIdx.x * blockDim.x + threadIdx.x; pix < n_pix; pix += (long)gridDim.x * blockDim.x) {
+    int q;
+    double pc[3], uvw[3];
+    tau_maps_pixel(A, pix, q, pc, uvw);
+    const double u = -uvw[0], v = -uvw[1], w = -uvw[2];  // reverse propagation
+    double x = pc[0], y = pc[1], z = pc[2];
+    int ri, zj, k;
+    const bool hit = sph ? move_to_grid_sph<L3D>(T, M, x, y, z, u, v, w, ri, zj, k) : move_to_grid<L3D>(T, M, x, y, z, u, v, w, ri, zj, k);
+    const double a = u * u + v * v;
+    const double inv_a = (a > TINY_REAL) ? 1.0 / a : HUGE_REAL;
+    const double inv_w = (fabs(w) > TINY_REAL) ? 1.0 / w : copysign(HUGE_DP, w);
+    if (tau_map) {
+      double tau = 0.0, xa = x, ya = y, za = z;
+      int r = ri, j = zj, kk = k;
+      for (long guard = 0; hit && guard < 100000000L; ++guard) {
+        const int azj = j < 0 ? -j : j;
+        if ((r == n_rad + 1) || (!sph && (azj == nz + 1) && (fabs(za) > M.zmaxmax))) break;  // test_exit_grid
+        double x1, y1, z1, l;
+        int r1, j1, k1;
+        if (sph) cross_cell_sph<L3D>(T, M, xa, ya, za, u, v, w, r, j, kk, x1, y1, z1, r1, j1, k1, l);
+        else MCGPU_CROSS<L3D>(T, M, xa, ya, za, u, v, w, inv_a, inv_w, r, j, kk, x1, y1, z1, r1, j1, k1, l);
+        if (is_real_cell<L3D>(n_rad, nz, r, j)) {
+          const int ic = cell_index<L3D>(n_rad, nz, r, j, kk);
+          const double kap = M.n_classes ? M.v_kappa[(size_t)M.cell_class[ic] * M.n_lambda + (A.lambda - 1)] : T.kappa[A.lambda - 1];
+          tau += l * (kap * M.kappa_factor[ic]);
+        }
+        xa = x1; ya = y1; za = z1;
+        r = r1; j = j1; kk = k1;
+      }
+      tau_map[pix] = (float)tau;
+    }
+    if (surf_map) {
+      float out[3] = {0.0f, 0.0f, 0.0f};
+      if (hit) {
+        const int i_star = intersect_stars(M, x, y, z, u, v, w);
+        int star_key = -1;
+        if (i_star > 0) {
+          const int* sc = &M.star_cell[4 * (i_star - 1)];
+          star_key = sc[0] + (n_rad + 2) * ((sc[1] + nz + 1) + (2 * nz + 3) * (sc[2] - 1));
+        }
+        double extr = (double)tau_surface, xo = x, yo = y, zo = z;  // (xo: entry point of the cell before the current one)
+        for (long guard = 0; guard < 100000000L; ++guard) {
+          const int azj = zj < 0 ? -zj : zj;
+          if ((ri == n_rad + 1) || (!sph && (azj == nz + 1) && (fabs(z) > M.zmaxmax))) break;  // flag_sortie
+          if (star_key >= 0 && (ri + (n_rad + 2) * ((zj + nz + 1) + (2 * nz + 3) * (k - 1))) == star_key) break;
+          double opacity = 0.0;
+          if (is_real_cell<L3D>(n_rad, nz, ri, zj)) {
+            const int ic = cell_index<L3D>(n_rad, nz, ri, zj, k);
+            if (M.dark && M.dark[ic]) { out[0] = (float)xo; out[1] = (float)yo; out[2] = (float)zo; break; }
+            const double kap = M.n_classes ? M.v_kappa[(size_t)M.cell_class[ic] * M.n_lambda + (A.lambda - 1)] : T.kappa[A.lambda - 1];
+            opacity = kap * M.kappa_factor[ic];
+          }
+          double x1, y1, z1, l;
+          int ri1, zj1, k1;
+          if (sph) cross_cell_sph<L3D>(T, M, x, y, z, u, v, w, ri, zj, k, x1, y1, z1, ri1, zj1, k1, l);
+          else MCGPU_CROSS<L3D>(T, M, x, y, z, u, v, w, inv_a, inv_w, ri, zj, k, x1, y1, z1, ri1, zj1, k1, l);
+          const double tau = l * opacity;
+          if (tau > extr) {
+            const double ls = l * (extr / tau);
+            out[0] = (float)(x + ls * u); out[1] = (float)(y + ls * v); out[2] = (float)(z + ls * w);
+            break;
+          }
+          extr = extr - tau;
+          xo = x; yo = y; zo = z;
+          x = x1; y = y1; z = z1;
+          ri = ri1; zj = zj1; k = k1;
+        }
+      }
+      surf_map[pix] = out[0]; surf_map[pix + n_pix] = out[1]; surf_map[pix + 2 * n_pix] = out[2];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // define_dark_zone, step 4 (optical_depth.f90:1522-1551; 2D): from the centre of every candidate cell, 11 rays in the
 // (x, z) plane at angles pi n / 12; a ray that uses up the optical depth tau_max before it leaves the grid marks its
 // cell.  One ray per thread: physical_length (optical_depth.f90:21-178) without deposits (Stokes = 0).

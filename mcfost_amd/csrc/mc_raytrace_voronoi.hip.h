@@ -80,4 +80,73 @@ __global__ void __launch_bounds__(256) k_rt1_image_voro(const DevModel M, const 
   });
 }
 
+// k_tau_maps (mc_raytrace.hip.h) on a Voronoi grid: move_to_grid_Voronoi, then cross_Voronoi_cell with the cut cells'
+// l_contrib / l_void_before and the star's cell as the end of a ray.
+__global__ void __launch_bounds__(256) k_tau_maps_voro(const DevModel M, const RtArgs A, const VoroGrid G, float tau_surface,
+                                                       float* tau_map, float* surf_map) {
+  extern __shared__ double lds_raw[];
+  const Lds T = lds_carve(lds_raw, M, true);
+  lds_stage_mono(T, M, 1);
+  __syncthreads();
+  const long n_pix = (long)A.npix_x * A.npix_y * A.nRT;
+  for (long pix = (long)blockIdx.x * blockDim.x + threadIdx.x; pix < n_pix; pix += (long)gridDim.x * blockDim.x) {
+    int q;
+    double pc[3], uvw[3];
+    tau_maps_pixel(A, pix, q, pc, uvw);
+    const double u = -uvw[0], v = -uvw[1], w = -uvw[2];
+    double x = pc[0], y = pc[1], z = pc[2];
+    int icell = 0;
+    const bool hit = voro_move_to_grid(G, x, y, z, u, v, w, icell);
+    auto opacity_of = [&](int ic, const VoroCell& C) {
+      if (ic > M.n_cells) return 0.0;
+      const double kap = M.n_classes ? M.v_kappa[(size_t)M.cell_class[ic - 1] * M.n_lambda + (A.lambda - 1)] : T.kappa[A.lambda - 1];
+      return kap * C.kf;
+    };
+    if (tau_map) {
+      double tau = 0.0, xa = x, ya = y, za = z;
+      int next = icell, cur = 0, prev = 0;
+      for (long guard = 0; hit && guard < 100000000L; ++guard) {
+        prev = cur;
+        cur = next;
+        if (cur < 0) break;  // test_exit_grid
+        const VoroCell C = G.cell[cur - 1];
+        double x1, y1, z1, l, l_contrib, l_void;
+        voro_cross_cell(G, M, C, xa, ya, za, u, v, w, cur, prev, x1, y1, z1, next, l, l_contrib, l_void);
+        tau += l_contrib * opacity_of(cur, C);
+        xa = x1; ya = y1; za = z1;
+      }
+      tau_map[pix] = (float)tau;
+    }
+    if (surf_map) {
+      float out[3] = {0.0f, 0.0f, 0.0f};
+      if (hit) {
+        const int i_star = intersect_stars(M, x, y, z, u, v, w);
+        const int star_icell = (i_star > 0) ? M.star_cell[4 * (i_star - 1)] : 0;
+        double extr = (double)tau_surface, xo = x, yo = y, zo = z;
+        int next = icell, cur = 0, prev = 0;
+        for (long guard = 0; guard < 100000000L; ++guard) {
+          prev = cur;
+          cur = next;
+          if (cur < 0) break;
+          if (star_icell > 0 && cur == star_icell) break;
+          const VoroCell C = G.cell[cur - 1];
+          if (cur <= M.n_cells && M.dark && M.dark[cur - 1]) { out[0] = (float)xo; out[1] = (float)yo; out[2] = (float)zo; break; }
+          double x1, y1, z1, l, l_contrib, l_void;
+          voro_cross_cell(G, M, C, x, y, z, u, v, w, cur, prev, x1, y1, z1, next, l, l_contrib, l_void);
+          const double tau = l_contrib * opacity_of(cur, C);
+          if (tau > extr) {
+            const double ls = l_void + l_contrib * (extr / tau);
+            out[0] = (float)(x + ls * u); out[1] = (float)(y + ls * v); out[2] = (float)(z + ls * w);
+            break;
+          }
+          extr = extr - tau;
+          xo = x; yo = y; zo = z;
+          x = x1; y = y1; z = z1;
+        }
+      }
+      surf_map[pix] = out[0]; surf_map[pix + n_pix] = out[1]; surf_map[pix + 2 * n_pix] = out[2];
+    }
+  }
+}
+
 }  // namespace mcgpu

@@ -3062,6 +3062,55 @@ extern "C" int mcgpu_rt1_image(mcgpu_ctx* ctx, const mcgpu_rt_opts* o, const flo
   return MCGPU_OK;
 }
 
+// compute_tau_map / compute_tau_surface_map: see include/mcgpu.h
+extern "C" int mcgpu_tau_maps(mcgpu_ctx* ctx, const mcgpu_rt_opts* o, const float* tab_RT_az, int npix_x, int npix_y,
+                              double map_size, double zoom, double tau_surface, float* tau_map, float* tau_surface_map,
+                              double* kernel_ms) {
+  int rc = ready(ctx);
+  if (rc) return rc;
+  if (!o || !tab_RT_az || (!tau_map && !tau_surface_map) || npix_x < 1 || npix_y < 1 || npix_x > 32768 || npix_y > 32768 ||
+      !(map_size > 0.0) || !(zoom > 0.0) || (tau_surface_map && !(tau_surface > 0.0)))
+    return fail(ctx, MCGPU_ERR_ARG, "mcgpu_tau_maps: bad argument");
+  const DevModel& M = ctx->M;
+  if (!ctx->have_rt1) return fail(ctx, MCGPU_ERR_STATE, "optical-depth maps: set the observers first (mcgpu_set_rt1)");
+  if (o->lambda < 1 || o->lambda > M.n_lambda || !(o->Rmax > 0.0)) return fail(ctx, MCGPU_ERR_ARG, "mcgpu_tau_maps: bad option");
+  HIPCHK(hipSetDevice(ctx->device));
+  const int nRT = ctx->RT_n_incl * ctx->RT_n_az;
+  const size_t n_pix = (size_t)npix_x * npix_y * nRT;
+  DevBuf<float> d_az, d_tau, d_surf;
+  HIPCHK(d_az.alloc(ctx->RT_n_az)); HIPCHK(d_az.put(tab_RT_az, ctx->RT_n_az));
+  if (tau_map) HIPCHK(d_tau.alloc(n_pix));
+  if (tau_surface_map) HIPCHK(d_surf.alloc(3 * n_pix));
+  RtArgs A;
+  std::memset(&A, 0, sizeof(A));
+  A.lambda = o->lambda; A.RT_n_incl = ctx->RT_n_incl; A.nRT = nRT; A.ang_disque = o->ang_disque;
+  A.rt_u = ctx->d_rt_u; A.rt_v = ctx->d_rt_v; A.rt_w = ctx->d_rt_w; A.rt_az = d_az.p;
+  A.npix_x = npix_x; A.npix_y = npix_y;
+  A.taille_pix = (map_size / zoom) / (double)(npix_x > npix_y ? npix_x : npix_y);  // (:2053, :2161)
+  A.l_far = 10.0 * o->Rmax;                                                         // (:2046, :2154)
+  const size_t lds = lds_bytes(M, true);
+  long blocks = (long)((n_pix + 255) / 256);
+  if (blocks > 65536) blocks = 65536;
+  HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+  if (ctx->voro) {
+    HIPCHK(hipFuncSetAttribute((const void*)k_tau_maps_voro, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_tau_maps_voro, dim3(blocks), dim3(256), lds, ctx->stream, M, A, ctx->V, (float)tau_surface, d_tau.p, d_surf.p);
+  } else if (M.l3D) {
+    HIPCHK(hipFuncSetAttribute((const void*)k_tau_maps<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_tau_maps<true>, dim3(blocks), dim3(256), lds, ctx->stream, M, A, (float)tau_surface, d_tau.p, d_surf.p);
+  } else {
+    HIPCHK(hipFuncSetAttribute((const void*)k_tau_maps<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_tau_maps<false>, dim3(blocks), dim3(256), lds, ctx->stream, M, A, (float)tau_surface, d_tau.p, d_surf.p);
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (kernel_ms) { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1)); *kernel_ms = ms; }
+  if (tau_map) HIPCHK(d_tau.get(tau_map, n_pix));
+  if (tau_surface_map) HIPCHK(d_surf.get(tau_surface_map, 3 * n_pix));
+  return MCGPU_OK;
+}
+
 extern "C" int mcgpu_probe_cross_cell(mcgpu_ctx* ctx, int n, const double* x0, const double* y0, const double* z0,
                                       const double* u, const double* v, const double* w, const int* cell,
                                       double* x1, double* y1, double* z1, int* next_cell, double* l) {

@@ -36,7 +36,7 @@ ABI_SYMBOLS = (
     "mcgpu_device_xI", "mcgpu_set_ism", "mcgpu_rt1_dust_map", "mcgpu_set_xI", "mcgpu_rt1_image", "mcgpu_set_xI_precision",
     "mcgpu_get_xI_precision", "mcgpu_set_option", "mcgpu_get_info", "mcgpu_counters_to_accum", "mcgpu_counters_from_accum",
     "mcgpu_set_grid_sph", "mcgpu_temp_approx_diffusion_vertical", "mcgpu_set_mrw", "mcgpu_fetch_radiation_field", "mcgpu_set_variable_dust", "mcgpu_rt1_stars_map_sed", "mcgpu_define_dark_zone", "mcgpu_init_reemission", "mcgpu_multi_create", "mcgpu_multi_destroy", "mcgpu_multi_size", "mcgpu_multi_ctx", "mcgpu_multi_last_error",
-    "mcgpu_repartition_energie", "mcgpu_opacity", "mcgpu_set_variable_dust_s11", "mcgpu_set_scattering_method1", "mcgpu_set_rt2", "mcgpu_fetch_I_spec", "mcgpu_rt1_stars_map_image", "mcgpu_set_I_spec", "mcgpu_rt2_source", "mcgpu_rt2_dust_map", "mcgpu_rt2_image", "mcgpu_shard_packets", "mcgpu_multi_run_thermal", "mcgpu_multi_run_mono", "mcgpu_multi_rccl_ranks", "mcgpu_multi_create_ex", "mcgpu_multi_reductions", "mcgpu_set_mrw_exit_spectrum", "mcgpu_voronoi_tesselation", "mcgpu_build_ksca_CDF", "mcgpu_init_reemission_ex",
+    "mcgpu_repartition_energie", "mcgpu_opacity", "mcgpu_set_variable_dust_s11", "mcgpu_set_scattering_method1", "mcgpu_set_rt2", "mcgpu_fetch_I_spec", "mcgpu_rt1_stars_map_image", "mcgpu_set_I_spec", "mcgpu_rt2_source", "mcgpu_rt2_dust_map", "mcgpu_rt2_image", "mcgpu_shard_packets", "mcgpu_multi_run_thermal", "mcgpu_multi_run_mono", "mcgpu_multi_rccl_ranks", "mcgpu_multi_create_ex", "mcgpu_multi_reductions", "mcgpu_set_mrw_exit_spectrum", "mcgpu_voronoi_tesselation", "mcgpu_build_ksca_CDF", "mcgpu_init_reemission_ex", "mcgpu_tau_maps",
 )
 
 
@@ -729,6 +729,25 @@ class Engine:
             self.ctx, C.byref(o), _p(_a(rt["tab_RT_az"], np.float32), C.c_float), C.c_uint64(int(seed)),
             _p(_a(star_flux, np.float64), C.c_double), _p(out, C.c_double)), "mcgpu_rt1_stars_map_sed")
         return out
+
+    def tau_maps(self, lam, npix_x, npix_y, map_size, zoom=1.0, tau=1.0, ang_disque=0.0, surface=True):
+        """The ray tracer's optical-depth maps (``mcgpu_tau_maps`` = ``compute_tau_map`` + ``compute_tau_surface_map``):
+        ``(tau_map [nRT, npix_y, npix_x], tau_surface_map [3, nRT, npix_y, npix_x] or None, kernel ms)``."""
+        m = self.model
+        rt = m.rt
+        if not getattr(self, "_rt1", False):
+            self.set_rt1()
+        o = RtOpts(int(lam), float(m.lam[lam - 1]), 1.0, 1.0, float(m.cfg.distance), float(ang_disque), 0, 100.0,
+                   float(m.cfg.rin), float(m.cfg.rout))
+        nRT = rt["RT_n_incl"] * rt["RT_n_az"]
+        tm = np.zeros((nRT, npix_y, npix_x), np.float32)
+        sm = np.zeros((3, nRT, npix_y, npix_x), np.float32) if surface else None
+        ms = C.c_double()
+        self._chk(self.lib.mcgpu_tau_maps(
+            self.ctx, C.byref(o), _p(_a(rt["tab_RT_az"], np.float32), C.c_float), C.c_int(int(npix_x)), C.c_int(int(npix_y)),
+            C.c_double(float(map_size)), C.c_double(float(zoom)), C.c_double(float(tau)), _p(tm, C.c_float),
+            _p(sm, C.c_float) if surface else None, C.byref(ms)), "mcgpu_tau_maps")
+        return tm, sm, ms.value
 
     def stars_map_image(self, lam, star_flux, npix_x, npix_y, map_size, zoom=1.0, seed=1, ang_disque=0.0,
                         limb_darkening=None):

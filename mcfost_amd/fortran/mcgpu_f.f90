@@ -91,7 +91,7 @@ module mcgpu_f
        mcgpu_set_E_prior, mcgpu_multi_create, mcgpu_multi_destroy, mcgpu_multi_size, mcgpu_multi_ctx, mcgpu_multi_run_thermal, mcgpu_multi_run_mono, mcgpu_multi_rccl_ranks, mcgpu_multi_create_ex, mcgpu_multi_reductions, &
        mcgpu_counters_to_accum, mcgpu_counters_from_accum, mcgpu_temp_approx_diffusion_vertical, mcgpu_set_mrw, mcgpu_set_mrw_exit_spectrum, mcgpu_fetch_radiation_field, &
        mcgpu_build_ksca_CDF, mcgpu_voronoi_tesselation, &
-       mcgpu_set_variable_dust, mcgpu_rt1_stars_map_sed, mcgpu_define_dark_zone, mcgpu_init_reemission, mcgpu_init_reemission_ex, mcgpu_repartition_energie, mcgpu_opacity, mcgpu_set_variable_dust_s11, mcgpu_set_scattering_method1, mcgpu_set_rt2, mcgpu_fetch_I_spec, mcgpu_rt1_stars_map_image, mcgpu_set_I_spec, mcgpu_rt2_source, mcgpu_rt2_dust_map, mcgpu_rt2_image
+       mcgpu_set_variable_dust, mcgpu_rt1_stars_map_sed, mcgpu_define_dark_zone, mcgpu_init_reemission, mcgpu_init_reemission_ex, mcgpu_repartition_energie, mcgpu_opacity, mcgpu_set_variable_dust_s11, mcgpu_set_scattering_method1, mcgpu_set_rt2, mcgpu_fetch_I_spec, mcgpu_rt1_stars_map_image, mcgpu_set_I_spec, mcgpu_rt2_source, mcgpu_rt2_dust_map, mcgpu_rt2_image, mcgpu_tau_maps
 
   interface
      integer(c_int) function mcgpu_create(device, ctx) bind(C, name="mcgpu_create")
@@ -241,6 +241,19 @@ module mcgpu_f
        real(c_double), intent(in) :: star_flux(*)
        real(c_double), intent(out) :: stars_flux(*)
      end function mcgpu_rt1_stars_map_sed
+
+     ! compute_tau_map / compute_tau_surface_map (dust_transfer.f90:2006, 2114) for every observer: c_loc(tau_map(:,:,:,:)),
+     ! c_loc(tau_surface_map(:,:,:,:,:)) of dust_ray_tracing.f90:59-60 (one thread's slice) or c_null_ptr
+     integer(c_int) function mcgpu_tau_maps(ctx, opts, tab_RT_az, npix_x, npix_y, map_size, zoom, tau_surface, tau_map, &
+          tau_surface_map, kernel_ms) bind(C, name="mcgpu_tau_maps")
+       import :: c_int, c_ptr, c_float, c_double, mcgpu_rt_opts
+       type(c_ptr), value :: ctx
+       type(mcgpu_rt_opts), intent(in) :: opts
+       real(c_float), intent(in) :: tab_RT_az(*)
+       integer(c_int), value :: npix_x, npix_y
+       real(c_double), value :: map_size, zoom, tau_surface
+       type(c_ptr), value :: tau_map, tau_surface_map, kernel_ms
+     end function mcgpu_tau_maps
 
      ! lvariable_dust: p_icell(:) and the tables with the p_n_cells axis, as the modules hold them (mem.f90:213-244)
      ! (the seven scattering tables: c_loc of the arrays, or c_null_ptr for all of them)

@@ -441,6 +441,24 @@ class Oracle:
             raise RuntimeError(f"oracle_stars_map_sed failed: {rc}")
         return out
 
+    def tau_maps(self, lam, npix_x, npix_y, map_size, zoom=1.0, tau=1.0, ang_disque=0.0, surface=True):
+        """compute_tau_map / compute_tau_surface_map for every observer: ``(tau_map [nRT, npix_y, npix_x],
+        tau_surface_map [3, nRT, npix_y, npix_x] or None)``, default reals."""
+        m = self.model
+        rt = m.rt
+        az = _a(rt["tab_RT_az"], np.float32)
+        o = _RtOpts(int(lam), float(m.lam[lam - 1]), 1.0, 1.0, float(m.cfg.distance), float(ang_disque), 0, 100.0,
+                    float(m.cfg.rin), float(m.cfg.rout), _p(az, C.c_float), 1)
+        nRT = rt["RT_n_incl"] * rt["RT_n_az"]
+        tm = np.zeros((nRT, npix_y, npix_x), np.float32)
+        sm = np.zeros((3, nRT, npix_y, npix_x), np.float32) if surface else None
+        rc = self.lib.oracle_tau_maps(C.byref(self.cm), C.byref(o), C.c_int(int(npix_x)), C.c_int(int(npix_y)),
+                                      C.c_double(float(map_size)), C.c_double(float(zoom)), C.c_float(float(tau)),
+                                      _p(tm, C.c_float), _p(sm, C.c_float) if surface else None)
+        if rc:
+            raise RuntimeError(f"oracle_tau_maps failed: {rc}")
+        return tm, sm
+
     def init_dust_source_fct2(self, lam, ibin, I_spec, I_spec_star, Tdust, n_sent_photons, E_disk, nang_rt=15, nang_star=1000,
                               p_lambda=None):
         """Ray tracing method 2's source function of inclination ``ibin`` (1-based) from ``I_spec [n_cells, n_phi_I,

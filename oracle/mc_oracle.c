@@ -2819,10 +2819,18 @@ static double rt_photon_energy(const oracle_rt_opts *o) { /* (:661-663), SED / i
 /* compute_stars_map for the SED (dust_transfer.f90:1604-1854, lresolved = .false., no limb darkening)               */
 /* ------------------------------------------------------------------------ */
 /* optical_length_tot (optical_depth.f90:248-324), cylindrical grids */
+static float optical_length_tot_from(const oracle_model *m, int lambda, int icell, double x, double y, double z, double u, double v,
+                                     double w);
 static float optical_length_tot(const oracle_model *m, int lambda, double x, double y, double z, double u, double v,
                                 double w) {
-  int icell, next_cell, previous_cell = 0;
+  int icell;
   grid_index_cell(m, x, y, z, &icell);
+  return optical_length_tot_from(m, lambda, icell, x, y, z, u, v, w);
+}
+/* ... from a known cell (the callers at dust_transfer.f90:2196 and :1680 hand it in) */
+static float optical_length_tot_from(const oracle_model *m, int lambda, int icell, double x, double y, double z, double u, double v,
+                                     double w) {
+  int next_cell, previous_cell = 0;
   next_cell = icell;
   double x1 = x, y1 = y, z1 = z, tau_tot = 0.0;
   int icell0 = 0;
@@ -3363,6 +3371,66 @@ int oracle_dust_map_image(const oracle_model *m, const oracle_rt_opts *o, int np
     }
   if (n_rays) *n_rays = (int)(rays > 2147483647L ? 2147483647L : rays);
   free(J_th);
+  return 0;
+}
+
+/* ---------------------------------------------------------------------------
+ * Optical-depth maps of the ray tracer: compute_tau_map (dust_transfer.f90:2114-2210, option -tau_map) and
+ * compute_tau_surface_map (:2006-2110, option -tau_surface).  One ray per pixel CENTRE of the observer's image, sent
+ * backwards from 10 Rmax: move_to_grid, then
+ *   tau_map(i,j,ibin,iaz)           = optical_length_tot from the entry point to the far edge of the grid (default real)
+ *   tau_surface_map(i,j,ibin,iaz,:) = the point where physical_length has used up the optical depth `tau` (default reals);
+ *                                     zeros when the ray leaves the grid or ends on a star first (flag_sortie).  A ray that
+ *                                     meets a cell of the dark zone stops at the entry point of the cell BEFORE it, which is
+ *                                     what physical_length's mirror (:104-112) hands back.
+ * physical_length also deposits into the radiation field in the reference (a side effect of reusing the packets' routine
+ * after the Monte Carlo); nothing is deposited here.  Either output may be NULL.
+ * ------------------------------------------------------------------------- */
+int oracle_tau_maps(const oracle_model *m, const oracle_rt_opts *o, int npix_x, int npix_y, double map_size, double zoom,
+                    float tau, float *tau_map, float *tau_surface_map) {
+  if (npix_x < 1 || npix_y < 1 || !(map_size > 0.0) || !(zoom > 0.0)) return 11;
+  const int nRT = m->RT_n_incl * m->RT_n_az, lam = o->lambda;
+  const size_t npix = (size_t)npix_x * npix_y;
+  const double taille_pix = (map_size / zoom) / (double)(npix_x > npix_y ? npix_x : npix_y);
+  worker_t W;
+  memset(&W, 0, sizeof(W));
+  oracle_opts oo;
+  memset(&oo, 0, sizeof(oo));
+  double *E_dummy = (double *)calloc((size_t)m->n_cells, sizeof(double));
+  if (!E_dummy) return 22;
+  W.m = m; W.o = &oo; W.E_abs = E_dummy;
+  const double Stokes[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int ibin = 1; ibin <= m->RT_n_incl; ++ibin)
+    for (int iaz = 1; iaz <= m->RT_n_az; ++iaz) {
+      const int q = (ibin - 1) + m->RT_n_incl * (iaz - 1);
+      double uvw[3], xpi[3], ypi[3], center[3], dx[3], dy[3], Icorner[3];
+      rt_image_plane(m, o, ibin, iaz, uvw, xpi, ypi, center);
+      for (int c = 0; c < 3; ++c) { dx[c] = xpi[c] * taille_pix; dy[c] = ypi[c] * taille_pix; }
+      for (int c = 0; c < 3; ++c) Icorner[c] = center[c] - (0.5 * npix_x * dx[c] + 0.5 * npix_y * dy[c]);
+      for (int i = 1; i <= npix_x; ++i)
+        for (int j = 1; j <= npix_y; ++j) {
+          const size_t at = (size_t)(i - 1) + (size_t)npix_x * ((size_t)(j - 1) + (size_t)npix_y * q);
+          double pc[3];
+          for (int c = 0; c < 3; ++c) pc[c] = Icorner[c] + (i - 0.5) * dx[c] + (j - 0.5) * dy[c];
+          if (tau_map) {
+            double x0 = pc[0], y0 = pc[1], z0 = pc[2];
+            int icell, lintersect;
+            grid_move_to_grid(m, &x0, &y0, &z0, -uvw[0], -uvw[1], -uvw[2], &icell, &lintersect);
+            tau_map[at] = lintersect ? optical_length_tot_from(m, lam, icell, x0, y0, z0, -uvw[0], -uvw[1], -uvw[2]) : 0.0f;
+          }
+          if (tau_surface_map) {
+            double x0 = pc[0], y0 = pc[1], z0 = pc[2], u0 = -uvw[0], v0 = -uvw[1], w0 = -uvw[2];
+            int icell, lintersect, flag_sortie = 1, alive = 1;
+            grid_move_to_grid(m, &x0, &y0, &z0, u0, v0, w0, &icell, &lintersect);
+            if (lintersect) physical_length(&W, lam, Stokes, &icell, &x0, &y0, &z0, &u0, &v0, &w0, 0, (double)tau, &flag_sortie, &alive);
+            const int hit = lintersect && !flag_sortie;
+            tau_surface_map[at] = hit ? (float)x0 : 0.0f;
+            tau_surface_map[at + npix * nRT] = hit ? (float)y0 : 0.0f;
+            tau_surface_map[at + 2 * npix * nRT] = hit ? (float)z0 : 0.0f;
+          }
+        }
+    }
+  free(E_dummy);
   return 0;
 }
 

@@ -346,6 +346,13 @@ int oracle_stars_map_image(const oracle_model *m, const oracle_rt_opts *o, uint6
                            int npix_x, int npix_y, double map_size, double zoom, int n_mu, const float *mu_ld,
                            const float *ld, const float *pola_ld, double *map, double *star_position);
 
+/* compute_tau_map (dust_transfer.f90:2114-2210) and compute_tau_surface_map (:2006-2110) for every observer direction:
+ * tau_map(npix_x, npix_y, RT_n_incl, RT_n_az) and tau_surface_map(npix_x, npix_y, RT_n_incl, RT_n_az, 3), default reals,
+ * column-major; either may be NULL.  Of o: lambda, ang_disque, Rmax, tab_RT_az.  See the definition.  PARITY UNPINNED
+ * (dust_transfer.f90 is unbuildable here); known answers in tests/test_tau_maps.py. */
+int oracle_tau_maps(const oracle_model *m, const oracle_rt_opts *o, int npix_x, int npix_y, double map_size, double zoom,
+                    float tau, float *tau_map, float *tau_surface_map);
+
 /* compute_stars_map for the SED (dust_transfer.f90:1604-1854; lresolved = .false., no limb darkening): out[nRT] =
  * sum over stars of star_flux[istar] * sum(exp(-tau) cos_thet) / sum(cos_thet); 2D / 3D cylindrical grids.  PARITY
  * UNPINNED (dust_transfer.f90 is unbuildable here; the reference's points come from SPRNG). */

@@ -669,6 +669,23 @@ extern "C" int emu_stars_map_sed(const oracle_model* m, const oracle_rt_opts* o,
   return 0;
 }
 
+extern "C" int emu_tau_maps(const oracle_model* m, const oracle_rt_opts* o, int npix_x, int npix_y, double map_size, double zoom,
+                            float tau, float* tau_map, float* surf_map) {
+  Conv cv(m);
+  RtArgs A;
+  memset(&A, 0, sizeof(A));
+  A.lambda = o->lambda; A.RT_n_incl = m->RT_n_incl; A.nRT = m->RT_n_incl * m->RT_n_az; A.ang_disque = o->ang_disque;
+  A.rt_u = m->tab_u_rt; A.rt_v = m->tab_v_rt; A.rt_w = m->tab_w_rt; A.rt_az = o->tab_RT_az;
+  A.npix_x = npix_x; A.npix_y = npix_y;
+  A.taille_pix = (map_size / zoom) / (double)(npix_x > npix_y ? npix_x : npix_y);
+  A.l_far = 10.0 * o->Rmax;
+  gridDim.x = 1; blockDim.x = 1; threadIdx.x = 0; blockIdx.x = 0;
+  if (cv.voro) k_tau_maps_voro(cv.M, A, cv.G, tau, tau_map, surf_map);
+  else if (m->l3D) k_tau_maps<true>(cv.M, A, tau, tau_map, surf_map);
+  else k_tau_maps<false>(cv.M, A, tau, tau_map, surf_map);
+  return 0;
+}
+
 extern "C" int emu_rt1_image(const oracle_model* m, const oracle_rt_opts* o, int npix_x, int npix_y, double map_size,
                              double zoom, const double* xI, const float* Tdust, double* image, int* n_rays) {
   EmuRt E(m, o, xI, Tdust);
