@@ -774,7 +774,12 @@ int mcgpu_set_mrw_exit_spectrum(mcgpu_ctx *ctx, const double *exit_cdf);
  * cell; one ray per device thread).  r_lim[n_rad+1], r_grid / z_grid[n_cells], z_lim(n_rad, nz+1...) are module
  * cylindrical_grid's arrays.  Outputs: l_dark_zone[n_cells] (to be passed to mcgpu_set_opacity), ri_in_dark_zone,
  * ri_out_dark_zone, zj_sup_dark_zone[n_rad] (to mcgpu_temp_approx_diffusion_vertical).  The context's own dark-zone
- * flags, if any, are ignored by the rays.  3D grids (:1553-1618) are not built.
+ * flags, if any, are ignored by the rays; the flags being built are not: the reference decides the columns one after the
+ * other and physical_length mirrors a ray in a cell flagged earlier (:104-112), so such a ray "does not leave" -- the
+ * device repeats its pass of rays with the flags of the columns before the ray's own until nothing changes, which is the
+ * sequential loop's answer.  3D and spherical grids: refused -- the reference's callers never define a dark zone there
+ * (`if (lspherical.or.l3D) call no_dark_zone()`, dust_transfer.f90:290-293, 734-735, 916-917), so neither this routine
+ * nor the diffusion fill below has a caller on those grids.
  */
 int mcgpu_define_dark_zone(mcgpu_ctx *ctx, int lambda, double tau_max, const double *r_lim,
                            const double *r_grid, const double *z_grid, const double *z_lim,

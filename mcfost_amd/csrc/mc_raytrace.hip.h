@@ -749,10 +749,16 @@ __global__ void __launch_bounds__(256) k_tau_maps(const DevModel M, const RtArgs
 // (x, z) plane at angles pi n / 12; a ray that uses up the optical depth tau_max before it leaves the grid marks its
 // cell.  One ray per thread: physical_length (optical_depth.f90:21-178) without deposits (Stokes = 0).
 // flag[icell] = 1 when some ray of the cell does not leave.
+// The reference decides the columns one after the other (i ascending) and sets l_dark_zone as it goes; physical_length
+// reads those flags, so a ray that enters a cell of a column decided EARLIER is mirrored there and counts as "does not
+// leave" (:104-112 -> flag_sortie = .false.).  dark_now[n_cells] (or null) = the flags of a previous pass; only the cells
+// of columns before the ray's own are looked at, which is what the sequential loop has set when it tests this column.  The
+// caller repeats the pass until the flags stop changing: column i is final after i - i_lo + 1 passes at the latest, in
+// practice after one or two (mcgpu_define_dark_zone).
 // ---------------------------------------------------------------------------
 static __global__ void __launch_bounds__(256) k_dark_zone_rays(const DevModel M, int lambda, float tau_max, int i_lo, int i_hi,
                                                         const int* zj_sup, const double* r_grid, const double* z_grid,
-                                                        unsigned char* flag) {
+                                                        const unsigned char* dark_now, unsigned char* flag) {
   extern __shared__ double lds_raw[];
   const Lds T = lds_carve(lds_raw, M, true);
   lds_stage_mono(T, M, 1);
@@ -788,6 +794,7 @@ static __global__ void __launch_bounds__(256) k_dark_zone_rays(const DevModel M,
     double opacity = 0.0;
     if (is_real_cell<false>(n_rad, nz, ri, zj)) {
       const int ic = cell_index<false>(n_rad, nz, ri, zj, k);
+      if (dark_now && ri < i && dark_now[ic]) { flag[icell] = 1; return; }  // mirrored in a column decided earlier
       const double kap = M.n_classes ? M.v_kappa[(size_t)M.cell_class[ic] * M.n_lambda + (lambda - 1)] : T.kappa[lambda - 1];
       opacity = kap * M.kappa_factor[ic];
     }

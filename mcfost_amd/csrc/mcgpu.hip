@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <string>
 #include <thread>
 #include <vector>
@@ -2847,27 +2848,37 @@ extern "C" int mcgpu_define_dark_zone(mcgpu_ctx* ctx, int lambda, double tau_max
   if (i_hi >= i_lo) {
     DevBuf<int> d_zj;
     DevBuf<double> d_rg, d_zg;
-    DevBuf<unsigned char> d_flag;
+    DevBuf<unsigned char> d_flag, d_now;
     HIPCHK(d_zj.alloc(n_rad)); HIPCHK(d_zj.put(zj.data(), n_rad));
     HIPCHK(d_rg.alloc(M.n_cells)); HIPCHK(d_rg.put(r_grid, M.n_cells));
     HIPCHK(d_zg.alloc(M.n_cells)); HIPCHK(d_zg.put(z_grid, M.n_cells));
-    HIPCHK(d_flag.alloc(M.n_cells)); HIPCHK(hipMemsetAsync(d_flag.p, 0, M.n_cells, ctx->stream));
+    HIPCHK(d_flag.alloc(M.n_cells)); HIPCHK(d_now.alloc(M.n_cells));
     const long long n_rays = 11LL * (i_hi - i_lo + 1) * nz;
     const size_t lds = lds_bytes(M, true);
     HIPCHK(hipFuncSetAttribute((const void*)k_dark_zone_rays, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_dark_zone_rays, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), lds, ctx->stream, M, lambda, tau_max, i_lo,
-                       i_hi, d_zj.p, d_rg.p, d_zg.p, d_flag.p);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    std::vector<unsigned char> flag(M.n_cells);
-    HIPCHK(d_flag.get(flag.data(), M.n_cells));
-    // the first flagged cell from the top of the candidate range, and everything below it (:1541-1547)
-    for (int i = i_lo; i <= i_hi; ++i)
-      for (int j = zj[i - 1]; j >= 1; --j)
-        if (flag[(i - 1) + (size_t)n_rad * (j - 1)]) {
-          for (int jj = 1; jj <= j; ++jj) l_dark_zone[(i - 1) + (size_t)n_rad * (jj - 1)] = 1;
-          break;
-        }
+    std::vector<unsigned char> flag(M.n_cells), next(M.n_cells);
+    // The reference's loop is sequential in the column and reads the flags it has set so far (see k_dark_zone_rays): passes
+    // with the previous pass's flags until nothing changes -- the flags only grow, column i depends on the columns before it.
+    for (int pass = 0; pass <= i_hi - i_lo + 1; ++pass) {
+      HIPCHK(d_now.put(l_dark_zone, M.n_cells));
+      HIPCHK(hipMemsetAsync(d_flag.p, 0, M.n_cells, ctx->stream));
+      hipLaunchKernelGGL(k_dark_zone_rays, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), lds, ctx->stream, M, lambda, tau_max, i_lo,
+                         i_hi, d_zj.p, d_rg.p, d_zg.p, d_now.p, d_flag.p);
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      HIPCHK(d_flag.get(flag.data(), M.n_cells));
+      // the first flagged cell from the top of the candidate range, and everything below it (:1541-1547)
+      std::fill(next.begin(), next.end(), (unsigned char)0);
+      for (int i = i_lo; i <= i_hi; ++i)
+        for (int j = zj[i - 1]; j >= 1; --j)
+          if (flag[(i - 1) + (size_t)n_rad * (j - 1)]) {
+            for (int jj = 1; jj <= j; ++jj) next[(i - 1) + (size_t)n_rad * (jj - 1)] = 1;
+            break;
+          }
+      const bool same = std::memcmp(next.data(), l_dark_zone, (size_t)M.n_cells) == 0;
+      std::memcpy(l_dark_zone, next.data(), (size_t)M.n_cells);
+      if (same) break;
+    }
   }
   // (:1621-1628) the extent handed to the diffusion fill
   if (ri_in <= ri_out) {

@@ -2432,7 +2432,10 @@ int oracle_define_dark_zone(const oracle_model *m, int lambda, double tau_max_in
   double *E_dummy = (double *)calloc((size_t)m->n_cells, sizeof(double));
   if (!E_dummy) { free(zj_sup); return 22; }
   oracle_model mm = *m;
-  mm.l_dark_zone = NULL; /* the flags are being built: no mirror while probing */
+  /* l_dark_zone(:) = .false. (:1517), then set column by column while step 4 runs: physical_length reads the flags of the
+   * columns already decided (its mirror, :104-112, returns flag_sortie = .false.), so a ray that enters a cell flagged
+   * earlier "does not leave".  MCGPU_ORACLE_DARK_NO_MIRROR=1: the flags ignored while probing (a test's comparison). */
+  mm.l_dark_zone = getenv("MCGPU_ORACLE_DARK_NO_MIRROR") ? NULL : dz;
   W.m = &mm; W.o = &o; W.E_abs = E_dummy;
   const double Stokes[4] = {0.0, 0.0, 0.0, 0.0};
   for (int i = (ri_in > 2 ? ri_in : 2); i <= ri_out; ++i) {

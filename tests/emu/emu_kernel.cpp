@@ -619,7 +619,7 @@ extern "C" int emu_rt1_dust_map(const oracle_model* m, const oracle_rt_opts* o, 
 // step 4 of define_dark_zone: the device's ray kernel, one thread at a time; flag[n_cells] receives the cells with a ray
 // that does not leave
 extern "C" int emu_dark_zone_rays(const oracle_model* m, int lambda, double tau_max, int i_lo, int i_hi, const int* zj_sup,
-                                  const double* r_grid, const double* z_grid, unsigned char* flag) {
+                                  const double* r_grid, const double* z_grid, const unsigned char* dark_now, unsigned char* flag) {
   if (m->l3D || m->grid_type != 1) return 31;
   Conv cv(m);
   memset(flag, 0, m->n_cells);
@@ -627,7 +627,7 @@ extern "C" int emu_dark_zone_rays(const oracle_model* m, int lambda, double tau_
   gridDim.x = (unsigned)n_rays; blockDim.x = 1; threadIdx.x = 0;
   for (long long t = 0; t < n_rays; ++t) {
     blockIdx.x = (unsigned)t;
-    k_dark_zone_rays(cv.M, lambda, (float)tau_max, i_lo, i_hi, zj_sup, r_grid, z_grid, flag);
+    k_dark_zone_rays(cv.M, lambda, (float)tau_max, i_lo, i_hi, zj_sup, r_grid, z_grid, dark_now, flag);
   }
   blockIdx.x = 0;
   return 0;
