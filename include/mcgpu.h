@@ -139,8 +139,10 @@ int mcgpu_set_grid_voronoi(mcgpu_ctx *ctx, int n_cells, const float *voronoi_xyz
  * mcgpu_set_grid_cyl's).  Replaces cross_spherical_cell (:182), index_cell_sph (:48), move_to_grid_sph (:562),
  * pos_em_cell_sph (:619), test_exit_grid_sph (:24).  On this grid: the temperature step (with the random walk; or, round 5,
  * with a dark zone -- l_dark_zone flags of mcgpu_set_opacity -- or with dust classes, mcgpu_set_variable_dust /
- * mcgpu_opacity; not both at once, not with the walk), the SED / image Monte Carlo and the ray tracer of method 1 (one dust
- * class, no dark zone).  MCGPU_ERR_UNSUPPORTED: mcgpu_define_dark_zone, the diffusion fill, ray tracing method 2.
+ * mcgpu_opacity; not both at once, not with the walk), the SED / image Monte Carlo with the deposits of ray tracing method
+ * 1 or (2D) method 2, both ray tracers, the optical-depth maps -- with dust classes too.  MCGPU_ERR_UNSUPPORTED, because the
+ * reference has no such thing on this grid (`if (lspherical.or.l3D) call no_dark_zone()`, dust_transfer.f90:290-293,
+ * 734-735, 916-917): mcgpu_define_dark_zone, the diffusion fill, a dark zone in SED mode or in the ray tracer.
  */
 int mcgpu_set_grid_sph(mcgpu_ctx *ctx, int n_rad, int nz, int n_az, int l3D,
                        const double *r_lim_2, const double *r_lim_3,
@@ -412,7 +414,7 @@ int mcgpu_repartition_energie(mcgpu_ctx *ctx, int lambda, double wl_um, double E
  * n_sent_chunk[n_chunks] (may be NULL) returns the packets each stream sent; their sum is
  * what the call added to n_sent(lambda) = n_phot_envoyes(lambda,:).  sed, n_sent and the
  * counters are read back with mcgpu_fetch, xI_scatt with mcgpu_fetch_xI.
- * Grids: cylindrical, spherical (one dust class; rt1 = 0 or 1) and Voronoi.  Scattering method 1 is
+ * Grids: cylindrical, spherical (no dark zone: the reference defines none there) and Voronoi (rt1 = 0 or 1).  Scattering method 1 is
  * refused (the reference forces method 2 with ray tracing, init_mcfost.f90:1659).
  */
 int mcgpu_run_mono(mcgpu_ctx *ctx, const mcgpu_mono_opts *opts,
@@ -601,7 +603,7 @@ int mcgpu_probe_packet_rand(mcgpu_ctx *ctx, uint64_t seed, uint64_t packet,
  * with one row of tables per class) read per class too.
  * Grids: cylindrical (every path above) and Voronoi (the thermal step, with or without the random walk:
  * k_thermal_voro_var; mcgpu_run_mono, mcgpu_repartition_energie, mcgpu_rt1_dust_map / _image); spherical: the
- * temperature step (round 5).
+ * temperature step, the SED step and the ray tracers (round 5).
  * p_n_cells = 0: off.  log_Qcool and kdB_dT_CDF may both be NULL (see mcgpu_init_reemission).
  */
 int mcgpu_set_variable_dust(mcgpu_ctx *ctx, int p_n_cells, const int *p_icell, const double *kappa,

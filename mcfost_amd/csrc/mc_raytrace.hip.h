@@ -154,6 +154,7 @@ __device__ inline void dust_source_fct2(const DevModel& M, const RtArgs& A, int 
                                         double SF[8]) {
 #pragma clang fp contract(off)
   const int n_rad = M.n_rad, nz = M.nz;
+  zj = zj < 0 ? -zj : zj;   // cell_map_j of the 2D cell
   const int ic = (ri - 1) + n_rad * (zj - 1);
   int zj1, zj2;
   double frac_z;

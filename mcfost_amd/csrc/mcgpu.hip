@@ -2111,7 +2111,7 @@ extern "C" int mcgpu_set_rt2(mcgpu_ctx* ctx, int n_theta_I, int n_phi_I, int N_t
   const int n_Stokes = ctx->lsepar_pola ? 4 : 1;
   if (n_theta_I < 1 || n_phi_I < 1 || n_theta_I > 1024 || n_phi_I > 1024 || N_type_flux != n_Stokes + (lsepar_contrib ? 4 : 0))
     return fail(ctx, MCGPU_ERR_ARG, "mcgpu_set_rt2: N_type_flux = n_Stokes (+ 4 with lsepar_contrib)");
-  if (ctx->M.l3D || ctx->voro || ctx->M.grid_sph) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "ray tracing method 2 is for 2D cylindrical grids");
+  if (ctx->M.l3D || ctx->voro) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "ray tracing method 2 is for 2D grids (cylindrical or spherical)");
   HIPCHK(hipSetDevice(ctx->device));
   if (ctx->d_I_spec) hipFree(ctx->d_I_spec);
   if (ctx->d_I_spec_star) hipFree(ctx->d_I_spec_star);
@@ -2180,7 +2180,7 @@ extern "C" int mcgpu_rt2_source(mcgpu_ctx* ctx, const mcgpu_rt_opts* o, int p_la
     return fail(ctx, MCGPU_ERR_ARG, "mcgpu_rt2_source: bad argument");
   DevModel& M = ctx->M;
   if (!ctx->have_rt2 || !ctx->have_rt1) return fail(ctx, MCGPU_ERR_STATE, "mcgpu_rt2_source needs mcgpu_set_rt1 (the observers, tab_s11_pos) and mcgpu_set_rt2");
-  if (M.l3D || ctx->voro || M.grid_sph) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "ray tracing method 2 is 2D only");
+  if (M.l3D || ctx->voro) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "ray tracing method 2 is 2D only");
   if (M.n_classes && !M.v_s11) return fail(ctx, MCGPU_ERR_STATE, "variable dust: tab_s11_pos per class is missing (mcgpu_opacity or mcgpu_set_variable_dust_s11)");
   if (o->lambda < 1 || o->lambda > M.n_lambda || p_lambda < 1 || p_lambda > M.n_lambda || ibin < 1 || ibin > ctx->RT_n_incl ||
       !(o->wl_um > 0.0) || !(o->n_sent_photons > 0.0))
@@ -2320,8 +2320,8 @@ extern "C" int mcgpu_run_mono(mcgpu_ctx* ctx, const mcgpu_mono_opts* o, double f
   if (rt1 && !ctx->have_rt1) return fail(ctx, MCGPU_ERR_STATE, "rt1 deposits need mcgpu_set_rt1");
   if (rt2 && !ctx->have_rt2) return fail(ctx, MCGPU_ERR_STATE, "rt2 deposits need mcgpu_set_rt2");
   if (rt2 && (M.l3D || ctx->voro)) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "ray tracing method 2 is 2D only (radiation_field.f90:91)");
-  if (M.grid_sph && (rt2 || M.n_classes || M.dark))
-    return fail(ctx, MCGPU_ERR_UNSUPPORTED, "SED mode on a spherical grid: one dust class, no dark zone, no ray tracing method 2 (the temperature step takes both)");
+  if (M.grid_sph && M.dark)   // (the reference never has one there: `if (lspherical.or.l3D) call no_dark_zone()`, dust_transfer.f90:734, 916)
+    return fail(ctx, MCGPU_ERR_UNSUPPORTED, "SED mode on a spherical grid: no dark zone (the reference defines none there)");
   const int n_pos = ctx->have_rt1 ? ctx->n_lambda_pos : M.n_lambda;
   if (o->p_lambda < 1 || o->p_lambda > n_pos || o->p_lambda > M.n_lambda) return fail(ctx, MCGPU_ERR_ARG, "p_lambda out of range");
   // prob_E_cell = NULL: the table mcgpu_repartition_energie left on the device for this wavelength
@@ -2701,9 +2701,8 @@ static int rt1_prepare(mcgpu_ctx* ctx, const mcgpu_rt_opts* o, const float* tab_
   int rc = ready(ctx);
   if (rc) return rc;
   if (ctx->voro && J.method2) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "ray tracing on a Voronoi grid: method 1");
-  if (ctx->M.grid_sph && J.method2) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "ray tracing method 2: 2D cylindrical grids");
-  if (ctx->M.grid_sph && (ctx->M.n_classes || ctx->M.dark))
-    return fail(ctx, MCGPU_ERR_UNSUPPORTED, "ray tracing on a spherical grid: one dust class, no dark zone");
+  if (ctx->M.grid_sph && ctx->M.dark)
+    return fail(ctx, MCGPU_ERR_UNSUPPORTED, "ray tracing on a spherical grid: no dark zone (the reference defines none there)");
   if (!o || !tab_RT_az || !Tdust) return fail(ctx, MCGPU_ERR_ARG, "RT1 ray tracing: null argument");
   if (!ctx->have_rt1 || (!ctx->d_xI && !J.method2))
     return fail(ctx, MCGPU_ERR_STATE, "RT1 ray tracing needs the xI_scatt of mcgpu_run_mono(rt1=1) or mcgpu_set_xI");

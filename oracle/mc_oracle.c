@@ -2329,7 +2329,7 @@ int oracle_run_mono(const oracle_model *m, const oracle_mono_opts *o, double *xI
   if (o->lambda < 1 || o->lambda > m->n_lambda || o->p_lambda < 1 || o->n_chunks < 1) return 23;
   if (o->rt1 == 1 && (m->RT_n_incl * m->RT_n_az > ORACLE_MAX_RT || m->RT_n_incl < 1 || (!m->p_n_cells && !m->tab_s11_pos))) return 24;
   const size_t nsed = (size_t)ORACLE_N_SED_TYPES * m->n_lambda * m->N_thet * m->N_phi;
-  if (o->rt1 == 2 && (m->l3D || m->grid_type != 1 || !o->I_spec || !o->I_spec_star || o->n_theta_I < 1 || o->n_phi_I < 1)) return 25; /* rt2: 2D only */
+  if (o->rt1 == 2 && (m->l3D || m->grid_type == 3 || !o->I_spec || !o->I_spec_star || o->n_theta_I < 1 || o->n_phi_I < 1)) return 25; /* rt2: 2D only */
   const size_t nxI = o->rt1 == 1 ? (size_t)m->n_az_rt * m->n_theta_rt * m->N_type_flux * m->RT_n_incl * m->RT_n_az * (size_t)m->n_cells : 0;
   double *sed_t = (double *)calloc(nsed * nth, sizeof(double));
   double *ns_t = (double *)calloc((size_t)m->n_lambda * nth, sizeof(double));
@@ -2933,7 +2933,7 @@ int oracle_init_dust_source_fct2(const oracle_model *m, const oracle_rt_opts *o,
                                  int n_phi_I, int nang_rt, int nang_star, const double *I_spec, const double *I_spec_star,
                                  const float *Tdust, const double *r_grid, const double *z_grid, float *eps_dust2,
                                  float *eps_dust2_star) {
-  if (m->l3D || m->grid_type != 1) return 31;
+  if (m->l3D || m->grid_type == 3) return 31;
   const int lam = o->lambda, nang = m->nang_scatt, na1 = nang + 1, nc = m->n_cells;
   const int n_Stokes = m->lsepar_pola ? 4 : 1, ntf = n_Stokes + (m->lsepar_contrib ? 4 : 0);
   const int vd = m->p_n_cells != 0;

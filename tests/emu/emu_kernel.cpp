@@ -574,7 +574,7 @@ struct EmuRt {
     const size_t st_type = (size_t)m->n_az_rt * m->n_theta_rt, st_rt = st_type * ntf;
     // reference layout (n_az_rt, n_theta_rt, N_type_flux, nRT, n_cells) -> engine layout [cell][psup][phik][iRT][XI_LINE]
     xI_dev.assign((size_t)m->n_cells * st_type * nRT * XI_LINE, 0.0);
-    for (int ic = 0; ic < m->n_cells; ++ic)
+    for (int ic = 0; xI && ic < m->n_cells; ++ic)   // (xI = null: method 2, which reads its own source function)
       for (int q = 0; q < nRT; ++q)
         for (int t = 0; t < ntf; ++t)
           for (int ps = 0; ps < m->n_theta_rt; ++ps)
@@ -700,6 +700,39 @@ extern "C" int emu_rt1_image(const oracle_model* m, const oracle_rt_opts* o, int
   if (E.cv.voro) { if (pola) k_rt1_image_voro<true>(E.cv.M, E.A, E.cv.G); else k_rt1_image_voro<false>(E.cv.M, E.A, E.cv.G); }
   else if (m->l3D) { if (pola) k_rt1_image<true, true>(E.cv.M, E.A); else k_rt1_image<true, false>(E.cv.M, E.A); }
   else { if (pola) k_rt1_image<false, true>(E.cv.M, E.A); else k_rt1_image<false, false>(E.cv.M, E.A); }
+  if (n_rays) *n_rays = (int)rays;
+  return 0;
+}
+
+// ray tracing method 2 (the source function of inclination ibin as mcgpu_rt2_source leaves it): the SED sampling (image =
+// null, out[N_type_flux]) or an image(npix_x, npix_y, N_type_flux)
+extern "C" int emu_rt2_map(const oracle_model* m, const oracle_rt_opts* o, const float* eps2, const float* eps2_star, int nang_rt,
+                           int nang_star, int ibin, const double* z_grid, const float* Tdust, int npix_x, int npix_y,
+                           double map_size, double zoom, double* out, double* image, int* n_rays) {
+  if (m->l3D || m->grid_type == 3) return 31;
+  EmuRt E(m, o, nullptr, Tdust);
+  const int ntf = m->N_type_flux;
+  E.A.method2 = 1; E.A.q_only = ibin - 1; E.A.nang_rt = nang_rt; E.A.nang_star = nang_star;
+  E.A.eps2 = eps2; E.A.eps2_star = eps2_star; E.A.z_grid = z_grid;
+  const bool pola = ntf == 4 || ntf == 8;
+  std::vector<double> all((size_t)E.A.nRT * ntf, 0.0);
+  if (!image) {
+    E.A.out = all.data();
+    if (pola) k_rt1_dust_map<false, true>(E.cv.M, E.A); else k_rt1_dust_map<false, false>(E.cv.M, E.A);
+    for (int t = 0; t < ntf; ++t) out[t] = all[(size_t)(ibin - 1) * ntf + t];
+    return 0;
+  }
+  std::vector<double> img((size_t)E.A.nRT * ntf * npix_x * npix_y, 0.0);
+  unsigned long long rays = 0;
+  E.A.npix_x = npix_x; E.A.npix_y = npix_y;
+  E.A.npix_x_max = o->l_sym_ima ? npix_x / 2 + npix_x % 2 : npix_x;
+  E.A.taille_pix = (map_size / zoom) / (double)(npix_x > npix_y ? npix_x : npix_y);
+  E.A.image = img.data(); E.A.n_rays = &rays;
+  if (pola) k_rt1_image<false, true>(E.cv.M, E.A); else k_rt1_image<false, false>(E.cv.M, E.A);
+  const int n_az = E.A.nRT / E.A.RT_n_incl;
+  for (int t = 0; t < ntf; ++t)
+    for (size_t p = 0; p < (size_t)npix_x * npix_y; ++p)
+      image[(size_t)t * npix_x * npix_y + p] = img[(((size_t)t * n_az + 0) * E.A.RT_n_incl + (ibin - 1)) * npix_x * npix_y + p];
   if (n_rays) *n_rays = (int)rays;
   return 0;
 }

@@ -1,0 +1,192 @@
+"""Round 5: what the spherical grid still refused beside the cylindrical one -- dust classes (lvariable_dust) in SED mode and
+in the ray tracer, and ray tracing method 2 (2D).  The packet loop, the source functions and the ray integration are the
+grid-independent routines of the cylindrical tests with spherical_grid.f90's operators underneath (k_mono_sph,
+rt1_integ_ray's run-time switch); dust_source_fct's method-2 branch interpolates between cell_map neighbours with z_grid,
+which the reference fills for the spherical grid too (spherical_grid.f90: z_grid = r sin(latitude) of the cell's centre).
+Not built, because the reference has no such thing: a dark zone on a spherical grid (`if (lspherical.or.l3D) call
+no_dark_zone()`, dust_transfer.f90:290-293, 734-735, 916-917) -- define_dark_zone, the diffusion fill and the mirror in SED
+mode have no caller there.
+Tolerances of the midplane cone's double root as in test_kernel_emulation._check_spherical (a zero-length crossing more
+or less: the crossing counter, the sub-bins of the layer next to the cone)."""
+import numpy as np
+import pytest
+
+from helpers import sed_model, xI_close
+from mcfost_amd.host import model as M
+from oracle import Oracle
+from test_kernel_emulation import emu  # noqa: F401
+
+
+def _sph_classes(n_thermal=20000, **kw):
+    m = M.build_model(M.small(grid_type=2, **kw))
+    m.p_lambda_fixed = 0            # SED mode: p_lambda = lambda, every wavelength its own cumulative table
+    M.init_variable_dust(m)
+    orc = Oracle(m, n_thermal)
+    T = orc.temp_finale(orc.run_thermal(n_thermal, seed=3, n_threads=1)["E_abs"])
+    M.repartition_energie(m, T)
+    m.extra["Tdust"] = T
+    return m
+
+
+def _same_sed_step(m, a, b, ca, cb):
+    cfg = m.cfg
+    assert np.array_equal(a["n_sent_chunk"], b["n_sent_chunk"])
+    assert ca[0] == cb[0] and ca[2:] == cb[2:] and abs(ca[1] - cb[1]) <= 3 + (3e-2 if cfg.l3D else 3e-4) * cb[1]
+    assert np.array_equal(a["sed"][4], b["sed"][4])
+    assert np.allclose(a["sed"][0], b["sed"][0], rtol=1e-11, atol=1e-11)
+    pola = cfg.lsepar_pola and cfg.aniso_method == 1
+    rtol, atol_rel = (3e-5, 1e-6) if pola else (1e-6, 1e-8)
+    xa, xb = a["xI_scatt"], b["xI_scatt"]
+    scale = np.abs(xb).max()
+    assert scale > 0
+    if cfg.l3D:   # hemispheres (and the sub-bins that go with them) summed: cells (j, -j) of one (i, k)
+        g = m.grid
+        i, j, k = g["cell_map_i"][:m.n_cells], g["cell_map_j"][:m.n_cells], g["cell_map_k"][:m.n_cells]
+        key = (i - 1) + g["n_rad"] * ((np.abs(j) - 1) + g["nz"] * (k - 1))
+        ta, tb = xa.sum(axis=(3, 4)).reshape(m.n_cells, -1), xb.sum(axis=(3, 4)).reshape(m.n_cells, -1)
+        fa = np.stack([np.bincount(key, weights=ta[:, q]) for q in range(ta.shape[1])], 1)
+        fb = np.stack([np.bincount(key, weights=tb[:, q]) for q in range(tb.shape[1])], 1)
+        assert np.allclose(fa, fb, rtol=rtol, atol=atol_rel * np.abs(fb).max())
+    else:
+        assert np.allclose(xa.sum(axis=(3, 4)), xb.sum(axis=(3, 4)), rtol=rtol, atol=atol_rel * scale)
+        xI_close(xa[cfg.n_rad:], xb[cfg.n_rad:], rtol=rtol, atol_rel=atol_rel)
+
+
+@pytest.mark.parametrize("kw", [dict(RT_n_incl=2), dict(lsepar_pola=False), dict(n_rad=10, nz=5, n_az=6, l3D=True)])
+def test_emulated_sed_mode_and_ray_tracer_on_spherical_classes(emu, kw):   # noqa: F811
+    from test_kernel_emulation import emu_mono, emu_dust_map, _blur_midplane_layer
+    m = _sph_classes(**kw)
+    vd = m.variable_dust
+    assert len(np.unique(vd["p_icell"])) >= 3
+    orc = Oracle(m, 1e5)
+    for lam in (3, 12):
+        a = emu_mono(emu, orc, lam, 6, 40 + lam)
+        b = orc.run_mono(lam, 6, seed=40 + lam, n_chunks=8, rt1=True, n_threads=4)
+        _same_sed_step(m, a, b, a["counters"], list(b["counters"].values()))
+        xI, T = _blur_midplane_layer(m, b["xI_scatt"], m.extra["Tdust"])
+        args = (lam, xI, T, b["n_sent"][lam - 1], m.extra["E_disk"][lam - 1])
+        ref = orc.dust_map_sed(*args)
+        got = emu_dust_map(emu, orc, *args)
+        assert np.abs(ref[:, 0]).max() > 0
+        assert np.allclose(got, ref, rtol=1e-9, atol=1e-13 * np.abs(ref).max()), np.abs(got / ref - 1).max()
+    # the classes matter: the single-class run of the same grid sends other packets
+    m1 = M.build_model(M.small(grid_type=2, **kw))
+    m1.frac_E_stars, m1.frac_E_disk, m1.prob_E_cell = m.frac_E_stars, m.frac_E_disk, m.prob_E_cell
+    c = Oracle(m1, 1e5).run_mono(12, 6, seed=52, n_chunks=8, rt1=False, n_threads=4)
+    assert c["counters"] != b["counters"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(RT_n_incl=2), dict(lsepar_pola=False), dict(n_rad=10, nz=5, n_az=6, l3D=True)])
+def test_device_sed_mode_and_ray_tracer_on_spherical_classes(kw):
+    from mcfost_amd.engine import Engine
+    from test_kernel_emulation import _blur_midplane_layer
+    m = _sph_classes(**kw)
+    e, o = Engine(m, 1e5), Oracle(m, 1e5)
+    for lam in (3, 12):
+        a = e.run_mono(lam, 30, seed=40 + lam, n_chunks=32)
+        b = o.run_mono(lam, 30, seed=40 + lam, n_chunks=32, n_threads=8)
+        _same_sed_step(m, a, b, list(a["counters"].values()), list(b["counters"].values()))
+        xI, T = _blur_midplane_layer(m, b["xI_scatt"], m.extra["Tdust"])
+        e.set_xI(xI)
+        ns, Ed = a["n_sent"][lam - 1], m.extra["E_disk"][lam - 1]
+        got, ms = e.dust_map_sed(lam, T, ns, Ed)
+        ref = o.dust_map_sed(lam, xI, T, ns, Ed, n_threads=8)
+        assert (ref[:, 0] > 0).all()
+        assert np.allclose(got, ref, rtol=1e-9, atol=1e-13 * np.abs(ref).max()), np.abs(got / ref - 1).max()
+        d = e.repartition_energie(lam, m.extra["Tdust"])
+        r = o.repartition_energie(lam, m.extra["Tdust"])
+        assert np.isclose(d["frac_E_stars"], r["frac_E_stars"], rtol=1e-12)
+        assert np.allclose(d["prob_E_cell"], r["prob_E_cell"], rtol=1e-12, atol=1e-15)
+        flux = np.array([3.0])
+        assert np.allclose(e.stars_map_sed(lam, flux, seed=4), o.stars_map_sed(lam, flux, seed=4), rtol=1e-6)
+    e.close()
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(grid_type=2), dict(grid_type=2, lsepar_pola=False, lsepar_contrib=False)])
+def test_emulated_method2_ray_tracing(emu, kw):   # noqa: F811
+    """The ray integration of method 2 (rt1_integ_ray with dust_source_fct2: linear in z between cell_map neighbours, linear
+    in azimuth between the tabulated directions) through the lane emulation against the oracle, on the oracle's own source
+    function: the SED sampling and an image, cylindrical and spherical 2D grids."""
+    import ctypes as C
+    from oracle.binding import _RtOpts, _a, _p
+    m = sed_model(M.small(RT_n_incl=3, **kw), n_thermal=20000)
+    o = Oracle(m, 1000)
+    T, lam = m.extra["Tdust"], 4
+    Ed = m.extra["E_disk"][lam - 1]
+    b = o.run_mono(lam, 100, seed=6, n_chunks=8, rt2=(15, 15), n_threads=4)
+    ns = b["n_sent"][lam - 1]
+    az = _a(m.rt["tab_RT_az"], np.float32)
+    ntf = m.rt["N_type_flux"]
+    zg = _a(m.grid["z_grid"], np.float64)
+    for ibin in (1, 3):
+        eps, eps_s = o.init_dust_source_fct2(lam, ibin, b["I_spec"], b["I_spec_star"], T, ns, Ed)
+        def run(npx, out, img, nr):
+            opts = _RtOpts(int(lam), float(m.lam[lam - 1]), float(m.E_stars[lam - 1] + Ed), float(ns), float(m.cfg.distance), 0.0,
+                           0 if npx else 1, 100.0, float(m.cfg.rin), float(m.cfg.rout), _p(az, C.c_float), 1)   # (l_sym_ima)
+            return emu.emu_rt2_map(C.byref(o.cm), C.byref(opts), _p(_a(eps, np.float32), C.c_float), _p(_a(eps_s, np.float32), C.c_float),
+                                   C.c_int(eps.shape[2]), C.c_int(eps_s.shape[2]), C.c_int(ibin), _p(zg, C.c_double),
+                                   _p(_a(T, np.float32), C.c_float), C.c_int(npx), C.c_int(npx), C.c_double(2.2 * m.cfg.rout),
+                                   C.c_double(1.0), out, img, nr)
+        got = np.zeros(ntf)
+        assert run(0, _p(got, C.c_double), None, None) == 0
+        want = o.rt2_dust_map_sed(lam, ibin, eps, eps_s, T, ns, Ed, n_threads=4)
+        assert want[0] > 0 and np.allclose(got, want, rtol=1e-6, atol=1e-6 * abs(want[0]))
+        npx = 14
+        img = np.zeros((ntf, npx, npx))
+        nr = C.c_int(0)
+        assert run(npx, None, _p(img, C.c_double), C.byref(nr)) == 0
+        wimg, wn = o.rt2_dust_map_image(lam, ibin, eps, eps_s, T, ns, Ed, npx, npx, 2.2 * m.cfg.rout, n_threads=4)
+        wimg = np.asarray(wimg).reshape(img.shape)
+        assert abs(nr.value - wn) <= 0.03 * wn and wimg[0].max() > 0
+        assert np.allclose(img, wimg, rtol=2e-5, atol=1e-6 * np.abs(wimg).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(), dict(lsepar_pola=False, lsepar_contrib=False)])
+def test_method2_ray_tracing_on_a_spherical_grid(kw):
+    """Ray tracing method 2 on a 2D spherical grid, end to end on the device: packet loop with I_spec deposits (the same
+    packets as the oracle's; I_spec cell by cell) -> source function -> dust_map's SED sampling and an image with the
+    interpolating dust_source_fct, against the oracle's restatement on the same source function; and against method 1 of
+    the same Monte Carlo (two estimators of the same scattered light)."""
+    from mcfost_amd.engine import Engine
+    m = sed_model(M.small(grid_type=2, RT_n_incl=3, **kw), n_thermal=50000)
+    o = Oracle(m, 1000)
+    e = Engine(m, 1e5)
+    T = m.extra["Tdust"]
+    for lam in (4, 12):
+        Ed = m.extra["E_disk"][lam - 1]
+        a = e.run_mono(lam, 400, seed=6, n_chunks=32, rt2=(15, 15))
+        b = o.run_mono(lam, 400, seed=6, n_chunks=32, rt2=(15, 15), n_threads=8)
+        assert np.array_equal(a["n_sent_chunk"], b["n_sent_chunk"]) and np.array_equal(a["sed"][4], b["sed"][4])
+        # I_spec: the deposits of the same paths; a path through the midplane cone is one crossing or two, so the layer next
+        # to it is compared summed over the direction bins its midpoints decide
+        Ia, Ib = a["I_spec"], b["I_spec"]
+        sc = np.abs(Ib).max()
+        assert sc > 0 and np.allclose(Ia[m.cfg.n_rad:], Ib[m.cfg.n_rad:], rtol=3e-5, atol=1e-6 * sc)
+        assert np.allclose(Ia.sum(axis=(1, 2)), Ib.sum(axis=(1, 2)), rtol=3e-5, atol=1e-6 * np.abs(Ib.sum(axis=(1, 2))).max())
+        assert np.allclose(a["I_spec_star"], b["I_spec_star"], rtol=1e-9, atol=1e-12 * np.abs(b["I_spec_star"]).max())
+        ns = a["n_sent"][lam - 1]
+        for ibin in (1, 3):
+            eps, eps_s = e.init_dust_source_fct2(lam, ibin, None, None, T, ns, Ed)
+            weps, weps_s = o.init_dust_source_fct2(lam, ibin, a["I_spec"], a["I_spec_star"], T, ns, Ed)
+            assert np.allclose(eps, weps, rtol=3e-6, atol=3e-6 * np.abs(weps).max(axis=(0, 1, 2)))
+            assert np.allclose(eps_s, weps_s, rtol=3e-6, atol=3e-6 * np.abs(weps_s).max(axis=(0, 1, 2)))
+            got, ms = e.rt2_dust_map_sed(lam, T, ns, Ed)
+            want = o.rt2_dust_map_sed(lam, ibin, eps, eps_s, T, ns, Ed, n_threads=8)
+            assert (want[0] > 0) and np.allclose(got, want, rtol=1e-6, atol=1e-6 * abs(want[0]))
+            # (the faint pixels above the disc cross cells of dtau ~ 1e-12, where 1 - exp(-dtau) carries the last-ulp
+            # difference of the two exp() at 1e-4 relative: a pixel whose refinement test |dI| > 1 % I sits on the threshold
+            # takes one more or one fewer round of sub-pixels -- 1024 rays of ~150 000 in the emulated twin below)
+            img, n_rays, _ = e.rt2_dust_map_image(lam, T, ns, Ed, 20, 20, 2.2 * m.cfg.rout)
+            wimg, wn = o.rt2_dust_map_image(lam, ibin, eps, eps_s, T, ns, Ed, 20, 20, 2.2 * m.cfg.rout, n_threads=8)
+            assert abs(n_rays - wn) <= 0.03 * wn
+            assert np.allclose(img, wimg, rtol=2e-5, atol=1e-6 * np.abs(wimg).max()), np.abs(img - wimg).max() / np.abs(wimg).max()
+        bb = e.run_mono(lam, 400, seed=7, n_chunks=32)
+        rt1, _ = e.dust_map_sed(lam, T, bb["n_sent"][lam - 1], Ed)
+        e.run_mono(lam, 400, seed=6, n_chunks=32, rt2=(15, 15))
+        for ibin in (1, 3):
+            e.init_dust_source_fct2(lam, ibin, None, None, T, ns, Ed)
+            rt2, _ = e.rt2_dust_map_sed(lam, T, ns, Ed)
+            assert abs(rt2[0] / rt1[ibin - 1, 0] - 1.0) < 0.25, (lam, ibin, rt2[0], rt1[ibin - 1, 0])
+    e.close()
