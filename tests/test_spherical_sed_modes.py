@@ -103,6 +103,17 @@ def test_device_sed_mode_and_ray_tracer_on_spherical_classes(kw):
     e.close()
 
 
+def _images_close(img, wimg):
+    """Pixel for pixel to the default-real source function's rounding -- except the (few) pixels whose refinement test sits on
+    its 1 % threshold and takes one round of sub-pixels more or less in one of the two builds: those agree to that 1 %."""
+    img, wimg = np.asarray(img).reshape(np.asarray(wimg).shape), np.asarray(wimg)
+    top = np.abs(wimg).max()
+    off = ~np.isclose(img, wimg, rtol=2e-5, atol=1e-6 * top)
+    pixels = off.reshape(-1, *off.shape[-2:]).any(axis=0)
+    assert pixels.sum() <= 4, pixels.sum()
+    assert np.allclose(img[off], wimg[off], rtol=0.03, atol=1e-4 * top)
+
+
 @pytest.mark.parametrize("kw", [dict(), dict(grid_type=2), dict(grid_type=2, lsepar_pola=False, lsepar_contrib=False)])
 def test_emulated_method2_ray_tracing(emu, kw):   # noqa: F811
     """The ray integration of method 2 (rt1_integ_ray with dust_source_fct2: linear in z between cell_map neighbours, linear
@@ -139,7 +150,7 @@ def test_emulated_method2_ray_tracing(emu, kw):   # noqa: F811
         wimg, wn = o.rt2_dust_map_image(lam, ibin, eps, eps_s, T, ns, Ed, npx, npx, 2.2 * m.cfg.rout, n_threads=4)
         wimg = np.asarray(wimg).reshape(img.shape)
         assert abs(nr.value - wn) <= 0.03 * wn and wimg[0].max() > 0
-        assert np.allclose(img, wimg, rtol=2e-5, atol=1e-6 * np.abs(wimg).max())
+        _images_close(img, wimg)
 
 
 @pytest.mark.gpu
@@ -181,12 +192,30 @@ def test_method2_ray_tracing_on_a_spherical_grid(kw):
             img, n_rays, _ = e.rt2_dust_map_image(lam, T, ns, Ed, 20, 20, 2.2 * m.cfg.rout)
             wimg, wn = o.rt2_dust_map_image(lam, ibin, eps, eps_s, T, ns, Ed, 20, 20, 2.2 * m.cfg.rout, n_threads=8)
             assert abs(n_rays - wn) <= 0.03 * wn
-            assert np.allclose(img, wimg, rtol=2e-5, atol=1e-6 * np.abs(wimg).max()), np.abs(img - wimg).max() / np.abs(wimg).max()
-        bb = e.run_mono(lam, 400, seed=7, n_chunks=32)
-        rt1, _ = e.dust_map_sed(lam, T, bb["n_sent"][lam - 1], Ed)
-        e.run_mono(lam, 400, seed=6, n_chunks=32, rt2=(15, 15))
-        for ibin in (1, 3):
-            e.init_dust_source_fct2(lam, ibin, None, None, T, ns, Ed)
-            rt2, _ = e.rt2_dust_map_sed(lam, T, ns, Ed)
-            assert abs(rt2[0] / rt1[ibin - 1, 0] - 1.0) < 0.25, (lam, ibin, rt2[0], rt1[ibin - 1, 0])
+            _images_close(img, wimg)
     e.close()
+
+
+@pytest.mark.gpu
+def test_method2_converges_to_method1_with_the_latitude_resolution():
+    """The two ray tracers are two estimators of the same light.  On the cylindrical grid they agree to the Monte Carlo noise
+    (test_rt2_source.py); on this grid's uniform-in-cosine latitudes a disc of h/r = 0.1 sits in ONE layer of cells at nz = 10,
+    and dust_source_fct's method-2 interpolation "in z" (dust_ray_tracing.f90:1505-1533: towards the cell_map neighbour of
+    the same shell, weights from z_grid) mixes that layer's source function with the hot, nearly empty layer above it: the
+    reference's algorithm, restated and matched above -- and a factor 2-3 too bright until the latitudes resolve the disc.
+    Measured with the oracle: rt2 / rt1 = 2.8, 2.7, 1.4 at nz = 10, 20, 60 (1 micron, pole-on); 1.9, 1.4, 1.1 at 30 micron."""
+    from mcfost_amd.engine import Engine
+    off = []
+    for nz in (10, 60):
+        m = sed_model(M.small(grid_type=2, RT_n_incl=3, nz=nz), n_thermal=50000)
+        e = Engine(m, 1e5)
+        T, lam, ibin = m.extra["Tdust"], 12, 3
+        Ed = m.extra["E_disk"][lam - 1]
+        b = e.run_mono(lam, 400, seed=7, n_chunks=32)
+        rt1, _ = e.dust_map_sed(lam, T, b["n_sent"][lam - 1], Ed)
+        a = e.run_mono(lam, 400, seed=6, n_chunks=32, rt2=(15, 15))
+        e.init_dust_source_fct2(lam, ibin, None, None, T, a["n_sent"][lam - 1], Ed)
+        rt2, _ = e.rt2_dust_map_sed(lam, T, a["n_sent"][lam - 1], Ed)
+        off.append(abs(rt2[0] / rt1[ibin - 1, 0] - 1.0))
+        e.close()
+    assert off[1] < 0.25 and off[1] < 0.5 * off[0], off
