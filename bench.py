@@ -32,7 +32,7 @@ BYTES_PER_INTERACTION = 8.0  # E_abs read for Temp_LTE
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
 VALU_ISSUE_PEAK = 1024 * 2.4e9 / 4.0   # wave-instructions/s: 256 CUs x 4 SIMDs, one VALU instruction per 4 cycles at 2.4 GHz
 ATOMIC_LINE_PEAK = 2.37e10   # memory-side atomic operations/s, any type or footprint (profiles/r02_atomic_scope_bench.log)
-PROFILE_ROUND = "r04"
+PROFILE_ROUND = "r05"
 
 
 def np_sum(a):
