@@ -689,7 +689,8 @@ __device__ __forceinline__ int fly_step_3d(const Lds& T, const DevModel& M, cons
 
   // the next cell; DARK: mirrored back at the wall of a dark cell (see roles_cross)
   const int azj1 = zj1 < 0 ? -zj1 : zj1;
-  const bool next_real = (ri1 >= 1) && (ri1 <= n_rad) && (azj1 >= 1) && (azj1 <= nz);
+  // (k1 >= 1: a lane that is not flying may carry the DEFER request, a negative k -- its index must not leave the array)
+  const bool next_real = (ri1 >= 1) && (ri1 <= n_rad) && (azj1 >= 1) && (azj1 <= nz) && (k1 >= 1);
   const int jj1 = zj1 < 0 ? zj1 + nz : zj1 + nz - 1;
   const int ic1 = next_real ? (ri1 - 1) + n_rad * (jj1 + 2 * nz * (k1 - 1)) : M.n_cells;  // (n_cells: the entry of "no cell", 0)
   bool mirror = false;
