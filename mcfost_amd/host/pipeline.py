@@ -5,6 +5,9 @@
     repartition_energie (thermal_emission.f90:1771)   emission tables of the SED step from Tdust
     run_sed_mc          (:828-1042)  per wavelength: the monochromatic packet loop (SED bins + xI_scatt),
                                      then the ray-traced SED of the dust (dust_map, RT method 1)
+    run_image_mc        (:692-824)   one wavelength: the image-mode packet loop (a fixed number of packets per stream),
+                                     then per observer the source function, dust_map's pixels, the stars' discs and,
+                                     if asked, the optical-depth maps (``image`` below)
 
 The Fortran host keeps doing this itself; this mirror drives the same C-ABI calls from Python
 for the tests, ``tools/run_config2.py`` and as an executable description of the call order.  ``backend`` is
@@ -49,6 +52,31 @@ class EngineBackend:
 
     def stars_map(self, lam, star_flux, seed):
         return self.e.stars_map_sed(lam, star_flux, seed=seed)
+
+
+    # --- run_image_mc ---
+    def run_image_mc(self, lam, n_photons_image, seed, n_chunks, method):
+        """mc_photon_loop with lmono0 (dust_transfer.f90:711-713): every stream sends exactly n_photons_image packets; the
+        deposits of ray tracing method 1 (xI_scatt) or 2 (I_spec) stay on the device."""
+        t = getattr(self, "_tables", None)
+        return self.e.run_mono(lam, 10 ** 12, n_phot_lim=float(n_photons_image), seed=seed, n_chunks=n_chunks, fetch_xI=False,
+                               device_tables=t[1] if t is not None and t[0] == lam else None,
+                               rt2=(15, 15) if method == 2 else None)
+
+    def dust_image(self, lam, Tdust, res, E_disk, npix_x, npix_y, map_size, zoom, ang_disque):
+        return self.e.dust_map_image(lam, Tdust, res["n_sent"][lam - 1], E_disk, npix_x, npix_y, map_size, zoom=zoom,
+                                     ang_disque=ang_disque)[0]
+
+    def dust_image_method2(self, lam, ibin, Tdust, res, E_disk, npix_x, npix_y, map_size, zoom):
+        ns = res["n_sent"][lam - 1]
+        self.e.init_dust_source_fct2(lam, ibin, None, None, Tdust, ns, E_disk)
+        return self.e.rt2_dust_map_image(lam, Tdust, ns, E_disk, npix_x, npix_y, map_size, zoom=zoom)[0]
+
+    def stars_image(self, lam, star_flux, npix_x, npix_y, map_size, zoom, seed, ang_disque):
+        return self.e.stars_map_image(lam, star_flux, npix_x, npix_y, map_size, zoom=zoom, seed=seed, ang_disque=ang_disque)[0]
+
+    def tau_maps(self, lam, npix_x, npix_y, map_size, zoom, tau, ang_disque):
+        return self.e.tau_maps(lam, npix_x, npix_y, map_size, zoom=zoom, tau=tau, ang_disque=ang_disque)[:2]
 
 
 def temperature_and_sed(backend, m, n_thermal, n_photons_lambda, lambdas=None, seed=1, n_chunks=None,
@@ -120,3 +148,39 @@ def sed_flux(m, sed_mc, n_sent):
     with np.errstate(divide="ignore", invalid="ignore"):
         f = np.where(n_sent > 0, E_tot / n_sent, 0.0)
     return sed_mc * f
+
+
+def image(backend, m, Tdust, lam, n_photons_image, npix_x, npix_y, map_size, zoom=1.0, seed=1, n_chunks=None, method=1,
+          ang_disque=0.0, tau_surface=None):
+    """One wavelength of ``run_image_mc`` (dust_transfer.f90:692-824): ``repartition_energie(lambda)`` (:737), the image-mode
+    packet loop (:748; ``n_photons_image`` packets per stream), then per observer (:775-801) the source function and
+    ``dust_map``'s pixels -- ``init_dust_source_fct1`` + RT method 1 for every (ibin, iaz), or ``init_dust_source_fct2`` +
+    method 2 per inclination (iaz = 1, 2D) -- with ``compute_stars_map``'s discs added to Stokes I (``dust_map`` :1582-1590)
+    and, with ``tau_surface``, the maps of ``compute_tau_map`` / ``compute_tau_surface_map``.
+    Returns ``image`` (N_type_flux, nRT, npix_y, npix_x; q = ibin - 1 + RT_n_incl (iaz - 1)), ``stars`` (nRT, npix_y,
+    npix_x), ``n_sent`` and, if asked, ``tau_map`` / ``tau_surface_map``."""
+    rt = m.rt
+    nRT, n_incl, ntf = rt["RT_n_incl"] * rt["RT_n_az"], rt["RT_n_incl"], rt["N_type_flux"]
+    if hasattr(backend, "repartition_energie"):
+        E_disk = backend.repartition_energie(lam, Tdust)
+    else:
+        M.repartition_energie(m, Tdust)
+        E_disk = float(m.extra["E_disk"][lam - 1])
+    r = backend.run_image_mc(lam, int(n_photons_image), seed, n_chunks, method)
+    img = np.zeros((ntf, nRT, npix_y, npix_x))
+    if method == 1:
+        d = np.asarray(backend.dust_image(lam, Tdust, r, E_disk, npix_x, npix_y, map_size, zoom, ang_disque))
+        img[:] = d.reshape(ntf, nRT, npix_y, npix_x)           # (N_type_flux, RT_n_az, RT_n_incl, ...): q = ibin-1 + n_incl (iaz-1)
+    else:
+        if rt["RT_n_az"] != 1 or m.cfg.l3D:
+            raise ValueError("ray tracing method 2: 2D grids, one observer azimuth (dust_transfer.f90:789-791)")
+        for ibin in range(1, n_incl + 1):
+            img[:, ibin - 1] = np.asarray(backend.dust_image_method2(lam, ibin, Tdust, r, E_disk, npix_x, npix_y, map_size, zoom)).reshape(ntf, npix_y, npix_x)
+    stars = np.asarray(backend.stars_image(lam, stars_flux_factor(m, lam), npix_x, npix_y, map_size, zoom, seed + 7919 * lam,
+                                           ang_disque))[:, 0]
+    img[0] += stars
+    out = dict(image=img, stars=stars, n_sent=r["n_sent"][lam - 1], E_disk=E_disk)
+    if tau_surface is not None:
+        out["tau_map"], out["tau_surface_map"] = backend.tau_maps(lam, npix_x, npix_y, map_size, zoom, float(tau_surface), ang_disque)
+    return out
+

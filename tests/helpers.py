@@ -93,3 +93,28 @@ class OracleBackend:
 
     def stars_map(self, lam, star_flux, seed):
         return self.o.stars_map_sed(lam, star_flux, seed=seed)
+
+    # --- run_image_mc (mcfost_amd.host.pipeline.image) ---
+    def run_image_mc(self, lam, n_photons_image, seed, n_chunks, method):
+        if not self.sed_tables:
+            from oracle import Oracle
+            self.o = Oracle(self.o.model, 1e5)
+            self.sed_tables = True
+        return self.o.run_mono(lam, 10 ** 12, seed=seed, n_chunks=n_chunks, n_phot_lim=float(n_photons_image), rt1=True,
+                               rt2=(15, 15) if method == 2 else None, n_threads=self.nt)
+
+    def dust_image(self, lam, Tdust, res, E_disk, npix_x, npix_y, map_size, zoom, ang_disque):
+        return self.o.dust_map_image(lam, res["xI_scatt"], Tdust, res["n_sent"][lam - 1], E_disk, npix_x, npix_y, map_size,
+                                     zoom=zoom, ang_disque=ang_disque, l_sym_ima=False, n_threads=self.nt)[0]
+
+    def dust_image_method2(self, lam, ibin, Tdust, res, E_disk, npix_x, npix_y, map_size, zoom):
+        ns = res["n_sent"][lam - 1]
+        eps, eps_s = self.o.init_dust_source_fct2(lam, ibin, res["I_spec"], res["I_spec_star"], Tdust, ns, E_disk)
+        return self.o.rt2_dust_map_image(lam, ibin, eps, eps_s, Tdust, ns, E_disk, npix_x, npix_y, map_size, zoom=zoom,
+                                         n_threads=self.nt)[0]
+
+    def stars_image(self, lam, star_flux, npix_x, npix_y, map_size, zoom, seed, ang_disque):
+        return self.o.stars_map_image(lam, star_flux, npix_x, npix_y, map_size, zoom=zoom, seed=seed, ang_disque=ang_disque)[0]
+
+    def tau_maps(self, lam, npix_x, npix_y, map_size, zoom, tau, ang_disque):
+        return self.o.tau_maps(lam, npix_x, npix_y, map_size, zoom=zoom, tau=tau, ang_disque=ang_disque)
