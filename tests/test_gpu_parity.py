@@ -326,6 +326,36 @@ def test_full_size_properties_ref41(ref41_model):
     e.close()
 
 
+@pytest.mark.parametrize("name", ["pascucci", "ref41", "ref41_3d"])
+def test_properties_at_the_benchmark_size(name):
+    """The size bench.py runs (1e8 packets per step: BASELINE's headline, configs[1] and the 3D grid): the properties that do
+    not need the oracle -- every packet accounted for, the emitted wavelengths on the stellar distribution to 3 sigma of 1e8
+    draws, Stokes I the sum of its origins, two seeds inside the Monte Carlo noise, a frozen-temperature rerun of the
+    same seed bit-equal in every integer and (2D: the LDS-private grid folds in launch order; 3D: the log folds in block
+    order) to rounding in the energies."""
+    cfg = {"pascucci": M.pascucci, "ref41": M.ref41, "ref41_3d": M.ref41_3d}[name]()
+    m = M.build_model(cfg)
+    n = 100_000_000
+    e = _engine(m, n)
+    a = e.run_thermal(n, seed=41)
+    c = a["counters"]
+    assert c["packets"] == n and c["escaped"] + c["killed_star"] == n
+    assert a["n_sent"].sum() == n and a["sed"][4].sum() == c["escaped"]
+    assert c["flights"] == c["scatterings"] + c["absorptions"] + c["escaped"] + c["killed_star"]
+    assert np.allclose(a["sed"][0], a["sed"][5:9].sum(axis=0))
+    cdf = np.cumsum(a["n_sent"]) / n
+    assert np.max(np.abs(cdf - m.spectre_emission_cumul[1:])) < 3.0 * 0.5 / np.sqrt(n) + 1e-12
+    b = e.run_thermal(n, seed=42)
+    Ta, Tb = e.temp_finale(a["E_abs"]), e.temp_finale(b["E_abs"])
+    sigma = 0.017 * np.sqrt(1.28e5 / n) * np.sqrt(2.0) * np.sqrt(max(m.n_cells, 7000) / 7000.0)
+    assert rel_rms(Ta, Tb, 1.01 * m.cfg.T_min) <= 3 * sigma
+    f1 = e.run_thermal(n, seed=43, frozen=True, E_prior=a["E_abs"])
+    f2 = e.run_thermal(n, seed=43, frozen=True, E_prior=a["E_abs"])
+    assert f1["counters"] == f2["counters"] and np.array_equal(f1["n_sent"], f2["n_sent"]) and np.array_equal(f1["sed"][4], f2["sed"][4])
+    assert np.allclose(f1["E_abs"], f2["E_abs"], rtol=1e-9, atol=1e-12 * f1["E_abs"].max())
+    e.close()
+
+
 def test_device_accumulator_is_visible_to_torch(small_model):
     import torch
     e = _engine(small_model, 1e4)
