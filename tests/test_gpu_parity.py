@@ -845,8 +845,9 @@ def test_sed_mode_packet_cap_and_launch_geometry(sed_small):
     e.close()
 
 
-def test_sed_mode_full_size_properties(ref41_model):
-    """BASELINE config 2's SED half at a GPU-sized packet count: 128 streams x 2000 packets in capt_sup."""
+@pytest.mark.parametrize("n2", [2000, 10000])
+def test_sed_mode_full_size_properties(ref41_model, n2):
+    """BASELINE config 2's SED half: 128 streams x 2000 packets in capt_sup, and the configuration's own 10 000."""
     from mcfost_amd.host import model as MM
     import copy
     m = copy.copy(ref41_model)
@@ -856,8 +857,8 @@ def test_sed_mode_full_size_properties(ref41_model):
     e.close()
     e = _engine(m, 2e6)
     lam = 20
-    a = e.run_mono(lam, 2000, seed=11)
-    assert a["sed"][4][0, m.capt_sup - 1, lam - 1] == 128 * 2000
+    a = e.run_mono(lam, n2, seed=11)
+    assert a["sed"][4][0, m.capt_sup - 1, lam - 1] == 128 * n2
     assert a["n_sent"][lam - 1] == a["n_sent_chunk"].sum() == a["counters"]["packets"]
     c = a["counters"]
     assert c["escaped"] + c["killed_star"] + c["absorptions"] == c["packets"]
@@ -865,7 +866,7 @@ def test_sed_mode_full_size_properties(ref41_model):
     assert 0 < a["sed"][0][..., lam - 1].sum() <= c["escaped"]
     # the streams are statistically identical: packets sent per stream scatter like a negative binomial
     k = a["n_sent_chunk"].astype(float)
-    assert abs(k.std() / k.mean() - np.sqrt((1 - 2000 / k.mean()) / 2000)) < 0.02
+    assert abs(k.std() / k.mean() - np.sqrt((1 - n2 / k.mean()) / n2)) < 0.02
     x = a["xI_scatt"]
     assert np.all(x[:, :, 0] >= 0) and np.all(x[:, :, 4] == 0) and np.all(x[:, :, 6] == 0)
     assert np.allclose(x[:, :, 0], x[:, :, 5] + x[:, :, 7], rtol=1e-9, atol=1e-12 * x.max())   # star + disk = total
