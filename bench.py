@@ -273,6 +273,7 @@ def thermal_block(par, args, config, steps, warmup, with_cpu, n_local, crossing=
         for x in (me.engines if me is not None else [eng]):
             x.set_option("tail", args.tail)
     for name, value in (("schedule", args.schedule), ("crossing", args.crossing if crossing is None else crossing), ("voronoi_pool_log_records", args.pool_log_records),
+                        ("tail_where", args.tail_where), ("host_threads", args.host_threads), ("tail_host_packets", args.tail_host_packets),
                         ("voronoi_cache_log_slots", args.cache_log_slots), ("deposit_log_mb", args.deposit_log_mb)):
         if value >= 0:
             for x in (me.engines if me is not None else [eng]):
@@ -364,7 +365,15 @@ def thermal_block(par, args, config, steps, warmup, with_cpu, n_local, crossing=
                          # the longest packet's own counts: crossings over its whole life, the rest as far as k_tail ran it
                          "longest_packet": longest,
                          "us_per_event_if_one_packet": (tail_ms * 1e3 / ev_max) if (tail_ms > 0 and ev_max > 0) else None,
-                         "tail_threshold": eng.get_info("tail_threshold")}
+                         "tail_threshold": eng.get_info("tail_threshold"),
+                         # where the launch's last packets ended (mc_tail.hip.h "The last packets on the host"): k_tail thins
+                         # the tail out, the library's host threads finish the last ones
+                         "where": {0: None, 1: "device (k_tail)", 2: "device (k_tail), the last packets on host threads"}[int(eng.get_info("tail_where"))],
+                         "host_ms": eng.get_info("tail_host_ms"), "host_packets": eng.get_info("tail_host_packets"),
+                         "host_threads": eng.get_info("tail_host_threads"), "host_events": eng.get_info("tail_host_events")}
+        if block["tail"]["host_events"]:
+            block["tail"]["host_ns_per_event_per_thread"] = (block["tail"]["host_ms"] * 1e6 * block["tail"]["host_threads"] /
+                                                            block["tail"]["host_events"])
         if config == "voronoi":
             block["tessellation"] = {"sites": args.sites, "host_s": model.extra.get("tessellation_s"),
                                      "kernel_ms": model.extra.get("tessellation_kernel_ms"),
@@ -587,6 +596,10 @@ def main():
                          "fused device buffer over that world of one -- how a box with one GPU executes the one-process-per-GPU path")
     ap.add_argument("--tail", type=int, default=-1, help="tuning aid: option \"tail\" (packets left per workgroup at the hand-over to "
                     "k_tail; -1 = the library's choice)")
+    ap.add_argument("--tail-where", type=int, default=-1, help="option \"tail_where\": 1 = k_tail finishes every packet, 2 = the library's "
+                    "host threads finish the last ones (default)")
+    ap.add_argument("--host-threads", type=int, default=-1, help="option \"host_threads\": host threads of a launch's tail (0 = automatic)")
+    ap.add_argument("--tail-host-packets", type=int, default=-1, help="option \"tail_host_packets\": packets k_tail leaves to the host (0 = 16 per thread)")
     ap.add_argument("--schedule", type=int, default=-1, help="tuning aid: option \"schedule\" (include/mcgpu.h)")
     ap.add_argument("--crossing", type=int, default=-1, help="option \"crossing\": 1 = the flight-parametric 2D crossing in the flying "
                     "waves (statistical parity only; include/mcgpu.h)")

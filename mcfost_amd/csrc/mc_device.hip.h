@@ -292,6 +292,13 @@ struct RunArgs {
   unsigned int carry_cap;
   int tail_threshold;               // <= 0: hand over as soon as the work counter has run out (a chunk of a binned run);
                                     // > 0: once the workgroup has no more than that many packets left (-> k_tail)
+  // k_tail's own hand-over (mc_tail.hip.h "The last packets on the host", host_tail.cpp; option "tail_where" = 2): once no
+  // more than tail_host_max of its packets are unfinished, every wave writes the packet it runs (and the ones not yet
+  // started) to tail_out as records and leaves; 0: k_tail finishes every packet
+  unsigned int tail_host_max;
+  unsigned int* tail_done;          // packets k_tail has finished
+  void* tail_out;                   // [tail_host_max] records (Rec<POLA>)
+  unsigned int* tail_out_n;
 };
 
 // ---------------------------------------------------------------------------

@@ -15,10 +15,26 @@
 //   * the crossing (fly_step_2d / fly_step_3d), the Stokes update and the bookkeeping run wave-uniform, lane 0 deposits.
 // Every value is computed by the very expressions of the throughput kernels (only by another lane, or earlier), so a
 // packet's history is the same whichever kernel finishes it: the frozen parity tests run through this path.
+//
+// The last packets on the host (round 6; RunArgs::tail_host_max, host_tail.cpp).  A wave runs a lone packet's event in
+// 1.0-1.6 us -- the arithmetic depth of one event on a machine built for throughput --, a host core runs it in 50-100 ns,
+// and the longest packet of a launch is one chain of 3e4 (ref4.1) to 5e5 (a thick disk) events: 30 to 800 ms at the end of
+// every launch.  So k_tail only THINS the tail out: its packets' remaining lives are exponentially distributed, the
+// machine runs thousands of them at once, and once no more than tail_host_max are unfinished every wave writes its
+// packet back as a record (at the top of its next interaction: the state a record in S_INTERACT holds) and leaves.
+// The library's host side (host_tail.cpp: THIS header compiled for the CPU, one packet per thread) finishes those from
+// copies of the tables, the absorbed energy and the counters and hands the sums back.  Same functions, same records,
+// same random numbers: a packet's history does not depend on where it ends.
 #pragma once
 #include "mc_roles.hip.h"
 
 namespace mcgpu {
+
+#ifdef MCGPU_HOST_TAIL
+#define TAIL_WL(lane) (-1)     // (the host runs one lane: the walk's searches are the throughput kernels' bisections)
+#else
+#define TAIL_WL(lane) (lane)
+#endif
 
 constexpr int TAIL_N_COUNTERS = 10;  // packets .. mrw_steps (= TAIL_N_COUNTERS of include/mcgpu.h)
 constexpr int TAIL_LONGEST = 16;     // counters[16 .. 20]: (events << 32 | count) of the longest packet, by atomicMax: its
@@ -27,6 +43,14 @@ constexpr int TAIL_LONGEST = 16;     // counters[16 .. 20]: (events << 32 | coun
 // smallest k in [lo, hi) with tab[k] >= x, else hi (tab non-decreasing): one probe per lane and pass
 template <typename Tp>
 __device__ inline int wave_first_ge(const Tp* tab, int lo, int hi, Tp x, int lane) {
+#ifdef MCGPU_HOST_TAIL   // (host_tail.cpp: one lane -- the bisection of the throughput kernels; the tables are monotone)
+  (void)lane;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (tab[mid] < x) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+#endif
   for (int base = lo; base < hi; base += BIN_WAVE) {
     const int k = base + lane;
     const bool hit = (k < hi) && !(tab[k < hi ? k : lo] < x);
@@ -59,9 +83,22 @@ __device__ inline void tail_draw(TailBatch& B, uint32_t k0, uint32_t k1, uint32_
 
 // One packet, from the state its record holds to its end.  Wave-uniform control flow: every lane holds the same
 // packet state; lane 0 makes the deposits and counts.
+#ifndef MCGPU_TAIL_TEST_HOOK   // (tests/emu: hand a packet over after a given number of its events, whatever the others do --
+#define MCGPU_TAIL_TEST_HOOK(events_here) false   // one emulated lane runs the packets one after the other)
+#endif
+
+// have the tail's unfinished packets become few enough for the host?  (wave-uniform: lane 0's load)
+__device__ inline bool tail_hand_over_now(const RunArgs& A, unsigned int n_total) {
+  if (A.tail_host_max == 0u) return false;
+  unsigned int done = __hip_atomic_load(A.tail_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  done = __shfl(done, 0);
+  return n_total - done <= A.tail_host_max;
+}
+
+// Returns true when the packet has ended here, false when it was written to A.tail_out for the host.
 template <bool L3D, bool POLA, bool DARK, bool MRW>
-__device__ __forceinline__ void tail_packet(const Lds& T, const DevModel& M, const RunArgs& A, const Rec<POLA>& R0, int lane,
-                                            unsigned int* cs) {
+__device__ __forceinline__ bool tail_packet(const Lds& T, const DevModel& M, const RunArgs& A, const Rec<POLA>& R0, int lane,
+                                            unsigned int* cs, unsigned int n_total = 0u) {
   const int n_rad = M.n_rad, nz = M.nz;
   const uint32_t key0 = (uint32_t)A.seed, key1 = (uint32_t)(A.seed >> 32);
   Flight F;
@@ -97,7 +134,7 @@ __device__ __forceinline__ void tail_packet(const Lds& T, const DevModel& M, con
     const int rc = emit_packet(M, f, lambda, T.fstar[lambda - 1], M.frac_E_disk[lambda - 1],
                                M.prob_E_cell ? M.prob_E_cell + (size_t)(M.n_cells + 1) * (lambda - 1) : nullptr,
                                ops, F.x, F.y, F.z, F.u, F.v, F.w, flag_star, flag_ism, lintersect);
-    if (rc) { *A.err = rc; return; }
+    if (rc) { *A.err = rc; return true; }
     flag_scatt = false;
     F.S0 = 1.0; S1 = S2 = S3 = 0.0;
     F.ri = ri; F.zj = zj; F.k = k; F.star_key = -1; F.pk_cross = 0u; F.extr = 0.0;
@@ -172,7 +209,30 @@ __device__ __forceinline__ void tail_packet(const Lds& T, const DevModel& M, con
   for (;;) {
     if (st == S_INTERACT) {
       // ---- the interaction's draws, from the batch the wave drew ahead ------------------------------------------
-      if (B.base == 0u || event - B.base >= (uint32_t)BIN_WAVE) tail_draw(B, key0, key1, p_lo, p_hi, event, lane);
+      if (B.base == 0u || event - B.base >= (uint32_t)BIN_WAVE) {
+        if (tail_hand_over_now(A, n_total) || MCGPU_TAIL_TEST_HOOK(event - R0.event)) {   // (once per batch of 64 events) -> the host finishes this packet
+          stokes_flush();
+          flush();
+          if (lane == 0) {
+            const unsigned int at = atomicAdd(A.tail_out_n, 1u);
+            if (at >= A.tail_host_max) *A.err = 17;   // (never: no more than tail_host_max packets are unfinished)
+            else {
+              Rec<POLA>& R = reinterpret_cast<Rec<POLA>*>(A.tail_out)[at];
+              rec_copy(&R, static_cast<const Rec<POLA>*>(nullptr));
+              R.x = F.x; R.y = F.y; R.z = F.z; R.u = F.u; R.v = F.v; R.w = F.w; R.extr = 0.0; R.S[0] = F.S0;
+              if (POLA) { R.S[POLA ? 1 : 0] = S1; R.S[POLA ? 2 : 0] = S2; R.S[POLA ? 3 : 0] = S3; }
+              R.ri = F.ri; R.zj = F.zj; R.k = F.k; R.lambda = lambda; R.star_key = -1;
+              R.p_lo = p_lo; R.p_hi = p_hi; R.event = event; R.pk_cross = F.pk_cross; R.tau_rand = 0.0f;
+              R.flags = S_INTERACT | (flag_star ? ST_STAR : 0) | (flag_scatt ? ST_SCATT : 0) | (flag_ism ? ST_ISM : 0) |
+                        (MRW ? (n_int << ST_NINT_SHIFT) : 0);
+            }
+          }
+          cs[1] += c_cross; cs[2] += c_flight; cs[3] += c_scatt; cs[4] += c_abs; cs[5] += c_esc; cs[6] += c_kill; cs[7] += c_dark;
+          cs[8] += c_walks; cs[9] += c_steps;
+          return false;
+        }
+        tail_draw(B, key0, key1, p_lo, p_hi, event, lane);
+      }
       const int q = (int)(event - B.base);
       const float g0 = __shfl(B.g0, q), g1 = __shfl(B.g1, q), g2 = __shfl(B.g2, q), g3 = __shfl(B.g3, q);
       tau_next = __shfl(B.tau, q);
@@ -225,6 +285,9 @@ __device__ __forceinline__ void tail_packet(const Lds& T, const DevModel& M, con
           }
         }
         abs_Ti = Ti; abs_frac = frac_T2;
+#ifdef MCGPU_HOST_TAIL
+        lambda = reemission_wavelength(T, M, Ti, frac_T2, g2);   // (one lane: the throughput kernels' bisection)
+#else
         {  // reemission_wavelength: the first l in [1, n_lambda) whose interpolated CDF reaches the draw, else n_lambda
           const double frac_T1 = 1.0 - frac_T2;
           const double* cdf1 = T.cdf + (size_t)M.n_lambda * (Ti - 2);
@@ -239,6 +302,7 @@ __device__ __forceinline__ void tail_packet(const Lds& T, const DevModel& M, con
           }
           lambda = found;
         }
+#endif
         cospsi = 2.0 * (double)g3 - 1.0;
         sphi = __shfl(B.sa, q); cphi = __shfl(B.ca, q);
       }
@@ -266,7 +330,7 @@ __device__ __forceinline__ void tail_packet(const Lds& T, const DevModel& M, con
           int lam2 = lambda;
           const bool done = mrw_walk(T, M, key0, key1, p_lo, p_hi, event, F.ri, F.zj, ic, F.S0, x, y, z, u, v, w, lam2,
                                      [&]() { return cell_energy(ic); },
-                                     [&](double e) { add_energy(ic, e); }, c_walks, c_steps, L3D ? F.k : 1, lane,   // (lane: wave-wide searches)
+                                     [&](double e) { add_energy(ic, e); }, c_walks, c_steps, L3D ? F.k : 1, TAIL_WL(lane),   // (lane: wave-wide searches)
                                      abs_Ti, abs_frac);
           if (done) { F.x = x; F.y = y; F.z = z; F.u = u; F.v = v; F.w = w; lambda = lam2; }
         }
@@ -329,6 +393,7 @@ __device__ __forceinline__ void tail_packet(const Lds& T, const DevModel& M, con
   }
   cs[1] += c_cross; cs[2] += c_flight; cs[3] += c_scatt; cs[4] += c_abs; cs[5] += c_esc; cs[6] += c_kill; cs[7] += c_dark;
   cs[8] += c_walks; cs[9] += c_steps;
+  return true;
 }
 
 #ifndef MCGPU_TAIL_BLOCK
@@ -354,8 +419,17 @@ __global__ void __launch_bounds__(MCGPU_TAIL_BLOCK) k_tail(const DevModel M, con
     if (lane == 0) i = atomicAdd(next, 1u);
     i = __shfl(i, 0);
     if (i >= n) break;
+    if (tail_hand_over_now(A, n)) {   // few enough are left: this one goes to the host as it is
+      if (lane == 0) {
+        const unsigned int at = atomicAdd(A.tail_out_n, 1u);
+        if (at >= A.tail_host_max) *A.err = 17;
+        else rec_copy(&reinterpret_cast<Rec<POLA>*>(A.tail_out)[at], &recs[i]);
+      }
+      continue;
+    }
     const Rec<POLA> R = recs[i];
-    tail_packet<L3D, POLA, DARK, MRW>(T, M, A, R, lane, cs);
+    const bool ended = tail_packet<L3D, POLA, DARK, MRW>(T, M, A, R, lane, cs, n);
+    if (ended && A.tail_host_max && lane == 0) atomicAdd(A.tail_done, 1u);
   }
   if (lane == 0)
     for (int q = 0; q < TAIL_N_COUNTERS; ++q)

@@ -30,6 +30,7 @@
 #include "mc_opacity.hip.h"
 #include "mc_rt2.hip.h"
 #include "mc_kernels.h"
+#include "host_tail.h"
 
 using namespace mcgpu;
 
@@ -99,6 +100,23 @@ struct mcgpu_ctx {
   double tau_midplane = -1.0;      // radial optical depth of the midplane at the most opaque wavelength (-1: unknown)
   double last_inter_pp = -1.0;     // interactions per packet of the context's last completed thermal launch (-1: none yet)
   unsigned int* d_tail_next = nullptr;  // the tail kernel's work counter
+  // the tail's last packets on the host (mc_tail.hip.h "The last packets on the host", host_tail.cpp)
+  int opt_tail_where = 0;        // 0 = automatic (the host), 1 = k_tail finishes every packet, 2 = the host finishes the last ones
+  int opt_host_threads = 0;      // host threads of a tail (0: the machine's, shared among its GPUs; at most 32)
+  int opt_tail_host_max = 0;     // packets k_tail leaves to the host (0: 16 per host thread)
+  unsigned int* d_tail_ctl = nullptr;   // [0] packets k_tail has finished, [1] records it has written to d_tail_out
+  void* d_tail_out = nullptr;           // [tail_out_cap] records for the host
+  unsigned int tail_out_cap = 0;
+  char* h_arena = nullptr;              // pinned: the launch's table copies, accumulators, counters and records
+  size_t h_arena_bytes = 0;
+  hipStream_t side_stream = nullptr;    // copies the tables while k_tail runs
+  hipEvent_t ev_side_in = nullptr, ev_side_out = nullptr;
+  bool tail_on_host = false;            // the last thermal launch handed its last packets to the host
+  // what the last host tail did (written by its callback; read after a synchronisation)
+  double host_tail_ms = 0.0;
+  unsigned int host_tail_packets = 0;
+  int host_tail_threads = 0;
+  unsigned long long host_tail_events = 0;
   // binned deposits (mc_binned.hip.h): the log and its plan
   BinLog bin{};
   unsigned int *d_bin_off = nullptr, *d_bin_cap = nullptr;
@@ -266,6 +284,12 @@ extern "C" int mcgpu_destroy(mcgpu_ctx* ctx) {
   if (ctx->d_hits) hipFree(ctx->d_hits);
   if (ctx->d_pool) hipFree(ctx->d_pool);
   if (ctx->d_pool_blob) hipFree(ctx->d_pool_blob);
+  if (ctx->d_tail_ctl) hipFree(ctx->d_tail_ctl);
+  if (ctx->d_tail_out) hipFree(ctx->d_tail_out);
+  if (ctx->h_arena) hipHostFree(ctx->h_arena);
+  if (ctx->side_stream) hipStreamDestroy(ctx->side_stream);
+  if (ctx->ev_side_in) hipEventDestroy(ctx->ev_side_in);
+  if (ctx->ev_side_out) hipEventDestroy(ctx->ev_side_out);
   bin_release(ctx);
   if (ctx->ev0) hipEventDestroy(ctx->ev0);
   if (ctx->ev1) hipEventDestroy(ctx->ev1);
@@ -529,6 +553,9 @@ extern "C" int mcgpu_set_option(mcgpu_ctx* ctx, const char* name, int value) {
   if (!ctx || !name) return MCGPU_ERR_ARG;
   if (!strcmp(name, "deposit")) { if (value < 0 || value > 3) return fail(ctx, MCGPU_ERR_ARG, "deposit: 0, 1, 2 or 3"); ctx->opt_deposit = value; }
   else if (!strcmp(name, "tail")) { if (value < -1 || value > (1 << 20)) return fail(ctx, MCGPU_ERR_ARG, "tail: -1 (automatic), 0 (off), or the packets left per workgroup at the hand-over"); ctx->opt_tail = value; }
+  else if (!strcmp(name, "tail_where")) { if (value < 0 || value > 2) return fail(ctx, MCGPU_ERR_ARG, "tail_where: 0 (automatic), 1 (device), 2 (host)"); ctx->opt_tail_where = value; }
+  else if (!strcmp(name, "host_threads")) { if (value < 0 || value > 256) return fail(ctx, MCGPU_ERR_ARG, "host_threads: 0 (automatic) .. 256"); ctx->opt_host_threads = value; }
+  else if (!strcmp(name, "tail_host_packets")) { if (value < 0 || value > 65536) return fail(ctx, MCGPU_ERR_ARG, "tail_host_packets: 0 (automatic) .. 65536"); ctx->opt_tail_host_max = value; }
   else if (!strcmp(name, "deposit_log_mb")) {
     if (value < 0) return fail(ctx, MCGPU_ERR_ARG, "deposit_log_mb: >= 0");
     if (value != ctx->opt_log_mb) bin_release(ctx);
@@ -582,6 +609,21 @@ extern "C" int mcgpu_get_info(mcgpu_ctx* ctx, const char* name, double* value) {
       HIPCHK(hipMemcpy(&v, ctx->d_counters + TAIL_LONGEST + k, sizeof(v), hipMemcpyDeviceToHost));
     }
     *value = (double)(v & 0xFFFFFFFFull);
+  }
+  else if (!strcmp(name, "tail_where") || !strncmp(name, "tail_host_", 10)) {
+    // where the last thermal launch finished its last packets (0: it had no tail, 1: k_tail, 2: host threads) and what the
+    // host did: its wall time, packets, threads, events (crossings + interactions)
+    *value = 0.0;
+    if (ctx->launched && ctx->tail_launched) {
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      if (!strcmp(name, "tail_where")) *value = ctx->tail_on_host ? 2.0 : 1.0;
+      else if (!ctx->tail_on_host) *value = 0.0;
+      else if (!strcmp(name, "tail_host_ms")) *value = ctx->host_tail_ms;
+      else if (!strcmp(name, "tail_host_packets")) *value = (double)ctx->host_tail_packets;
+      else if (!strcmp(name, "tail_host_threads")) *value = (double)ctx->host_tail_threads;
+      else if (!strcmp(name, "tail_host_events")) *value = (double)ctx->host_tail_events;
+      else return fail(ctx, MCGPU_ERR_ARG, "mcgpu_get_info: unknown name");
+    }
   }
   else if (!strcmp(name, "tau_midplane")) *value = ctx->tau_midplane;
   else if (!strcmp(name, "bin_overflow_blocks") || !strcmp(name, "bin_drained_records")) {
@@ -1269,10 +1311,49 @@ static int carry_prepare(mcgpu_ctx* ctx, int n_wg, int n_rec, int threads) {
   return MCGPU_OK;
 }
 
-// k_tail (mc_tail.hip.h) on the packets in `carry`: one packet per wave, as many 256-thread workgroups as the tables'
-// LDS footprint lets reside
-static int launch_tail(mcgpu_ctx* ctx, const RunArgs& A, const void* carry, const unsigned int* carry_n, bool l3d, bool mrw) {
+// ---- the tail's last packets on the host (mc_tail.hip.h "The last packets on the host"; host_tail.cpp) ----------------
+// One launch's hand-over: the host copies of the model and of the launch's arguments the host threads run on.  Heap
+// object, made by launch_tail, consumed and freed by the stream's callback.
+struct HostTailCall {
+  mcgpu_ctx* ctx;
+  DevModel Mh;
+  RunArgs Ah;
+  mcgpu_host::TailJob job;
+  const unsigned int* h_ctl;   // [1]: records k_tail wrote
+  int* h_err;
+};
+
+static void host_tail_callback(void* p) {   // (runs on a thread of the HIP runtime, in stream order: no HIP calls here)
+  HostTailCall* c = static_cast<HostTailCall*>(p);
+  mcgpu_ctx* ctx = c->ctx;
+  unsigned int n = c->h_ctl[1];
+  if (n > ctx->tail_out_cap) n = ctx->tail_out_cap;   // (k_tail reported error 17)
+  c->job.n = (*c->h_err == 0) ? n : 0u;
+  mcgpu_host::run_tail(&c->job);
+  ctx->host_tail_ms = c->job.ms; ctx->host_tail_packets = c->job.n; ctx->host_tail_threads = c->job.threads_used;
+  ctx->host_tail_events = c->job.events;
+  delete c;
+}
+
+static inline size_t arena_align(size_t x) { return (x + 63) & ~(size_t)63; }
+
+// Can the host finish this launch's last packets?  (One dust class, no radiation-field extras -- what k_tail itself runs --
+// and an emission table small enough to copy per launch.)
+static bool host_tail_applicable(const mcgpu_ctx* ctx, const RunArgs& A) {
   const DevModel& M = ctx->M;
+  if (ctx->opt_tail_where == 1) return false;
+  if (M.n_classes || M.m1 || M.grid_sph || ctx->voro || A.xN_abs || A.xJ_abs) return false;
+  if (M.prob_E_cell && (size_t)(M.n_cells + 1) * M.n_lambda * sizeof(double) > ((size_t)64 << 20)) return false;
+  return true;
+}
+
+// k_tail (mc_tail.hip.h) on the packets in `carry`: one packet per wave, as many 256-thread workgroups as the tables'
+// LDS footprint lets reside.  With the host behind it (option "tail_where"): k_tail leaves the last packets, and the
+// stream continues with [copies to the host | the host threads, as a stream callback | copies back] -- asynchronous like
+// every launch.
+static int launch_tail(mcgpu_ctx* ctx, const RunArgs& A_in, const void* carry, const unsigned int* carry_n, bool l3d, bool mrw) {
+  const DevModel& M = ctx->M;
+  RunArgs A = A_in;
   const bool pola = ctx->lsepar_pola != 0, dark = M.dark != nullptr;
   const size_t lds = (lds_bytes(M) + 7) / 8 * 8;
   int per_cu = (int)((160 * 1024 - 512) / (lds ? lds : 1));
@@ -1282,10 +1363,132 @@ static int launch_tail(mcgpu_ctx* ctx, const RunArgs& A, const void* carry, cons
   const void* fn = kpick_tail(l3d, pola, dark, mrw);
   HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   HIPCHK(hipMemsetAsync(ctx->d_tail_next, 0, sizeof(unsigned int), ctx->stream));
+  const bool host = host_tail_applicable(ctx, A);
+  ctx->tail_on_host = host;
+  int n_threads = 0;
+  unsigned int host_max = 0u;
+  if (host) {
+    int n_dev = 1;
+    (void)hipGetDeviceCount(&n_dev);
+    n_threads = ctx->opt_host_threads > 0 ? ctx->opt_host_threads : mcgpu_host::default_threads(n_dev);
+    host_max = ctx->opt_tail_host_max > 0 ? (unsigned int)ctx->opt_tail_host_max : 16u * (unsigned int)n_threads;
+    if (!ctx->d_tail_ctl) HIPCHK(hipMalloc((void**)&ctx->d_tail_ctl, 2 * sizeof(unsigned int)));
+    if (ctx->tail_out_cap < host_max) {
+      HIPCHK(hipStreamSynchronize(ctx->stream));   // (an earlier launch may still write the old buffer)
+      if (ctx->d_tail_out) hipFree(ctx->d_tail_out);
+      ctx->d_tail_out = nullptr; ctx->tail_out_cap = 0;
+      HIPCHK(hipMalloc(&ctx->d_tail_out, (size_t)host_max * sizeof(Rec<true>)));
+      ctx->tail_out_cap = host_max;
+    }
+    if (!ctx->side_stream) {
+      HIPCHK(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+      HIPCHK(hipEventCreateWithFlags(&ctx->ev_side_in, hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&ctx->ev_side_out, hipEventDisableTiming));
+    }
+    HIPCHK(hipMemsetAsync(ctx->d_tail_ctl, 0, 2 * sizeof(unsigned int), ctx->stream));
+    A.tail_host_max = host_max; A.tail_done = ctx->d_tail_ctl; A.tail_out = ctx->d_tail_out; A.tail_out_n = ctx->d_tail_ctl + 1;
+  }
   HIPCHK(hipEventRecord(ctx->ev_tail, ctx->stream));   // (what follows is the launch's tail: mcgpu_get_info "tail_ms")
   ctx->tail_launched = true;
   void* args[] = {(void*)&M, (void*)&A, (void*)&carry, (void*)&carry_n, (void*)&ctx->d_tail_next};
   HIPCHK(hipLaunchKernel(fn, dim3(blocks), dim3(MCGPU_TAIL_BLOCK), args, lds, ctx->stream));
+  if (!host) return MCGPU_OK;
+
+  // ---- the host's copies: one pinned arena, laid out per launch ---------------------------------------------------------
+  HostTailCall* call = new HostTailCall();
+  call->ctx = ctx;
+  call->Mh = M;
+  call->Ah = A;
+  struct Seg { const void* dev; size_t off, bytes; };
+  std::vector<Seg> segs;
+  size_t total = 0;
+  std::vector<std::pair<const void**, size_t>> fix;   // pointer slots of Mh / Ah and their arena offsets
+  auto table = [&](const void** slot, size_t bytes) {
+    if (!*slot) return;
+    segs.push_back(Seg{*slot, total, bytes});
+    fix.push_back({slot, total});
+    total += arena_align(bytes);
+  };
+#define HT_TAB(field, count) table((const void**)&call->Mh.field, (size_t)(count) * sizeof(*call->Mh.field))
+  DevModel& H = call->Mh;
+  HT_TAB(r_lim_2, H.n_rad + 1); HT_TAB(zmax, H.n_rad); HT_TAB(ch, H.n_rad); HT_TAB(tan_phi_lim, H.n_az);
+  HT_TAB(volume, H.n_cells); HT_TAB(star_xyzr, 4 * H.n_stars); HT_TAB(star_cell, 4 * H.n_stars);
+  HT_TAB(kappa, H.n_lambda); HT_TAB(kappa_abs, H.n_lambda); HT_TAB(albedo, H.n_lambda);
+  HT_TAB(kappa_factor, (size_t)H.n_cells + 1); HT_TAB(dark, H.n_cells);
+  const size_t nt = (size_t)(H.nang + 1) * H.n_lambda;
+  HT_TAB(prob_s11, nt); HT_TAB(s12, nt); HT_TAB(s22, nt); HT_TAB(s33, nt); HT_TAB(s34, nt); HT_TAB(s44, nt);
+  HT_TAB(tab_g, H.n_lambda); HT_TAB(cos_tab, H.nang + 1);
+  HT_TAB(log_Qcool, H.n_T); HT_TAB(cdf, (size_t)H.n_T * H.n_lambda); HT_TAB(spec_cum, H.n_lambda + 1);
+  HT_TAB(frac_E_stars, H.n_lambda); HT_TAB(frac_E_disk, H.n_lambda); HT_TAB(CDF_E_star, (size_t)H.n_lambda * (H.n_stars + 1));
+  HT_TAB(prob_E_cell, (size_t)(H.n_cells + 1) * H.n_lambda);
+  if (H.mrw) {
+    HT_TAB(mrw_zeta, H.mrw_n_zeta); HT_TAB(mrw_chi, H.n_T); HT_TAB(mrw_kdep, H.n_T); HT_TAB(mrw_ext, H.n_T);
+    HT_TAB(mrw_guide, MRW_GUIDE + 1); HT_TAB(mrw_exit_cdf, (size_t)H.n_T * H.n_lambda); HT_TAB(r_lim, H.n_rad + 1);
+    HT_TAB(sin_phi, H.n_az); HT_TAB(cos_phi, H.n_az);
+  } else {
+    H.mrw_zeta = H.mrw_chi = H.mrw_kdep = H.mrw_ext = H.mrw_exit_cdf = H.r_lim = H.sin_phi = H.cos_phi = nullptr; H.mrw_guide = nullptr;
+  }
+#undef HT_TAB
+  // (tables of paths k_tail never runs: a stray access must fault, not read device memory)
+  H.tan_theta_lim = H.theta_lim = H.r_lim_3 = nullptr; H.cell_class = nullptr;
+  H.v_kappa = H.v_kabs = H.v_lq = H.v_cdf = nullptr; H.v_albedo = nullptr; H.v_kk = nullptr;
+  H.v_prob = H.v_g = H.v_s11 = H.v_s12 = H.v_s22 = H.v_s33 = H.v_s34 = H.v_s44 = nullptr;
+  const size_t n_tables = segs.size();
+  RunArgs& Ha = call->Ah;
+  if (Ha.frozen) table((const void**)&Ha.E_prior, (size_t)H.n_cells * sizeof(double)); else Ha.E_prior = nullptr;
+  const size_t n_side = segs.size();   // (tables and the prior: constant during the launch -> the side stream)
+  const size_t off_accum = total; total += arena_align(ctx->n_accum * sizeof(double));
+  const size_t off_cnt = total; total += arena_align(CNT_SLOTS * sizeof(unsigned long long));
+  const size_t off_err = total; total += arena_align(sizeof(int));
+  const size_t off_ctl = total; total += arena_align(2 * sizeof(unsigned int));
+  const size_t rec_bytes = pola ? sizeof(Rec<true>) : sizeof(Rec<false>);
+  const size_t off_rec = total; total += arena_align((size_t)host_max * rec_bytes);
+  (void)n_tables;
+  if (ctx->h_arena_bytes < total) {
+    hipError_t e = hipStreamSynchronize(ctx->stream);   // (an earlier launch's callback may still read the old arena)
+    if (e == hipSuccess && ctx->h_arena) e = hipHostFree(ctx->h_arena);
+    ctx->h_arena = nullptr; ctx->h_arena_bytes = 0;
+    if (e == hipSuccess) e = hipHostMalloc((void**)&ctx->h_arena, total + (total >> 2), hipHostMallocDefault);
+    if (e != hipSuccess) { delete call; ctx->err = std::string("host tail: pinned arena: ") + hipGetErrorString(e); return MCGPU_ERR_HIP; }
+    ctx->h_arena_bytes = total + (total >> 2);
+  }
+  char* const base = ctx->h_arena;
+  for (auto& f : fix) *f.first = base + f.second;
+  Ha.E_abs = reinterpret_cast<double*>(base + off_accum);
+  Ha.sed = Ha.E_abs + M.n_cells;
+  Ha.n_sent = Ha.sed + n_sed(M);
+  Ha.counters = reinterpret_cast<unsigned long long*>(base + off_cnt);
+  Ha.next_packet = nullptr;
+  Ha.err = reinterpret_cast<int*>(base + off_err);
+  Ha.xN_abs = nullptr; Ha.xJ_abs = nullptr;
+  Ha.carry_in = nullptr; Ha.carry_in_n = nullptr; Ha.carry_out = nullptr; Ha.carry_out_n = nullptr;
+  Ha.tail_host_max = 0u; Ha.tail_done = nullptr; Ha.tail_out = nullptr; Ha.tail_out_n = nullptr;
+  std::memset(&Ha.bin, 0, sizeof(Ha.bin));
+  call->h_ctl = reinterpret_cast<const unsigned int*>(base + off_ctl);
+  call->h_err = Ha.err;
+  call->job.model = &call->Mh; call->job.args = &call->Ah; call->job.recs = base + off_rec; call->job.n = 0;
+  call->job.l3d = l3d ? 1 : 0; call->job.pola = pola ? 1 : 0; call->job.dark = dark ? 1 : 0; call->job.mrw = mrw ? 1 : 0;
+  call->job.n_threads = n_threads;
+#define HT_CHK(callexpr) do { hipError_t e_ = (callexpr); if (e_ != hipSuccess) { delete call; ctx->err = std::string(#callexpr) + ": " + hipGetErrorString(e_); return MCGPU_ERR_HIP; } } while (0)
+  // the side stream copies the tables while k_tail runs (it starts where the stream stood in front of k_tail: the previous
+  // launch's callback has finished with the arena by then)
+  HT_CHK(hipStreamWaitEvent(ctx->side_stream, ctx->ev_tail, 0));
+  for (size_t i = 0; i < n_side; ++i)
+    HT_CHK(hipMemcpyAsync(base + segs[i].off, segs[i].dev, segs[i].bytes, hipMemcpyDeviceToHost, ctx->side_stream));
+  HT_CHK(hipEventRecord(ctx->ev_side_out, ctx->side_stream));
+  // behind k_tail: what it left, and the sums the host adds to
+  HT_CHK(hipMemcpyAsync(base + off_ctl, ctx->d_tail_ctl, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
+  HT_CHK(hipMemcpyAsync(base + off_rec, ctx->d_tail_out, (size_t)host_max * rec_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HT_CHK(hipMemcpyAsync(base + off_accum, ctx->d_accum, ctx->n_accum * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HT_CHK(hipMemcpyAsync(base + off_cnt, ctx->d_counters, CNT_SLOTS * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+  HT_CHK(hipMemcpyAsync(base + off_err, ctx->d_err, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HT_CHK(hipStreamWaitEvent(ctx->stream, ctx->ev_side_out, 0));
+  HT_CHK(hipLaunchHostFunc(ctx->stream, host_tail_callback, call));
+  // (from here on the callback owns `call`)
+  HIPCHK(hipMemcpyAsync(ctx->d_accum, base + off_accum, ctx->n_accum * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->d_counters, base + off_cnt, CNT_SLOTS * sizeof(unsigned long long), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->d_err, base + off_err, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+#undef HT_CHK
   return MCGPU_OK;
 }
 
@@ -1797,6 +2000,7 @@ extern "C" int mcgpu_launch_thermal(mcgpu_ctx* ctx, const mcgpu_run_opts* o) {
   }
   HIPCHK(hipMemsetAsync(ctx->d_err, 0, sizeof(int), ctx->stream));
   ctx->tail_launched = false;
+  ctx->tail_on_host = false;
   RunArgs A;
   std::memset(&A, 0, sizeof(A));
   A.seed = o->seed; A.first_packet = o->first_packet; A.n_packets = o->n_packets;

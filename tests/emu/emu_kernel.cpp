@@ -86,131 +86,42 @@ namespace mcgpu { double lds_raw[1 << 18]; }
 #include "../../mcfost_amd/csrc/mc_raytrace.hip.h"
 #include "../../mcfost_amd/csrc/mc_raytrace_voronoi.hip.h"
 #include "../../mcfost_amd/csrc/mc_roles.hip.h"
+// k_tail's hand-over to the host (mc_tail.hip.h "The last packets on the host"): one emulated lane runs the packets one
+// after the other, so "few packets are left" never interrupts a packet here -- this hook does, after a given number of events
+static unsigned int g_tail_hook_events = 0u;
+#define MCGPU_TAIL_TEST_HOOK(events_here) (g_tail_hook_events != 0u && (events_here) >= g_tail_hook_events)
 #include "../../mcfost_amd/csrc/mc_tail.hip.h"
 #include "../../oracle/mc_oracle.h"
 
-using namespace mcgpu;
+#define EMU_CONV_POOL 1
+#include "emu_conv.h"
 
-// oracle_model -> DevModel (+ VoroGrid), as the setters of mcgpu.hip do
-struct Conv {
-  DevModel M;
-  VoroGrid G;
-  bool voro;
-  std::vector<double> ch, sx, ct, vk, vka, kfpad;
-  std::vector<float> val, vsc[8];
-  std::vector<int> sc, vcls;
-  std::vector<VoroCell> vcell;
-  std::vector<VoroNb> vnb;
-  std::vector<unsigned char> vnbcls;   // VoroGrid::nb_cls as mcgpu_set_grid_voronoi builds it
-  double dummy = 0.0;
-  explicit Conv(const oracle_model* m) {
-    memset(&M, 0, sizeof(M));
-    memset(&G, 0, sizeof(G));
-    voro = m->grid_type == 3;
-    M.n_rad = m->n_rad; M.nz = m->nz; M.n_az = m->n_az; M.l3D = m->l3D; M.n_cells = m->n_cells;
-    M.r_lim_2 = m->r_lim_2; M.zmax = m->zmax; M.tan_phi_lim = m->tan_phi_lim;
-    ch.assign(m->n_rad > 0 ? m->n_rad : 1, 0.0);
-    if (voro) { M.n_rad = 0; M.nz = 0; M.n_az = 0; M.l3D = 1; M.r_lim_2 = &dummy; }
-    else if (m->grid_type == 2) for (int i = 0; i < m->n_rad; ++i) ch[i] = 1.0;
-    else for (int i = 0; i < m->n_rad; ++i) ch[i] = m->nz >= 2 ? m->z_lim[i + m->n_rad] : m->zmax[i];
-    M.ch = ch.data();
-    M.zmaxmax = m->zmaxmax; M.Rmax2 = m->Rmax2; M.volume = m->volume;
-    if (voro) {  // the records mcgpu_set_grid_voronoi + mcgpu_set_opacity build
-      vcell.resize(m->n_cells);
-      vnb.resize(m->v_last[m->n_cells - 1]);
-      for (int i = 0; i < m->n_cells; ++i) {
-        VoroCell& Cc = vcell[i];
-        Cc.x = m->v_xyz[3 * i]; Cc.y = m->v_xyz[3 * i + 1]; Cc.z = m->v_xyz[3 * i + 2];
-        Cc.first = m->v_first[i] - 1; Cc.count = m->v_last[i] - m->v_first[i] + 1;
-        Cc.flags = (m->v_was_cut && m->v_was_cut[i] ? 1 : 0) | (m->v_is_star_neighbour && m->v_is_star_neighbour[i] ? 2 : 0);
-        Cc.kf = m->kappa_factor[i];
-        for (int q = m->v_first[i] - 1; q < m->v_last[i]; ++q) {
-          const int id = m->v_neigh[q];
-          vnb[q].id = id;
-          if (id > 0) { vnb[q].x = m->v_xyz[3 * (id - 1)]; vnb[q].y = m->v_xyz[3 * (id - 1) + 1]; vnb[q].z = m->v_xyz[3 * (id - 1) + 2]; }
-          else { vnb[q].x = vnb[q].y = vnb[q].z = 0.0f; }
-        }
-      }
-      vnbcls.assign(vnb.size(), (unsigned char)0);
-      for (size_t q = 0; q < vnb.size(); ++q)
-        if (vnb[q].id > 0) vnbcls[q] = (unsigned char)vp_class_of(vcell[vnb[q].id - 1].count);
-      G.nb_cls = vnbcls.data();
-      G.n_cells = m->n_cells; G.cell = vcell.data(); G.nb = vnb.data(); G.h = m->v_h; G.xyz_dp = m->v_xyz_dp;
-      G.wall_first = m->v_wall_first; G.wall_cells = m->v_wall_cells; G.cut_o_h = m->v_cut_o_h;
-      memcpy(G.walls, m->v_walls, 24 * sizeof(float));
-    }
-    M.n_stars = m->n_stars;
-    sx.resize(4 * m->n_stars);
-    sc.resize(4 * m->n_stars);
-    for (int s = 0; s < m->n_stars; ++s) {
-      sx[4 * s] = m->stars[s].x; sx[4 * s + 1] = m->stars[s].y; sx[4 * s + 2] = m->stars[s].z; sx[4 * s + 3] = m->stars[s].r;
-      int ic = m->stars[s].icell;
-      if (voro) { sc[4 * s] = ic; sc[4 * s + 1] = 0; sc[4 * s + 2] = 0; }
-      else { sc[4 * s] = m->cell_map_i[ic - 1]; sc[4 * s + 1] = m->cell_map_j[ic - 1]; sc[4 * s + 2] = m->cell_map_k[ic - 1]; }
-      sc[4 * s + 3] = m->stars[s].out_model;
-    }
-    M.star_xyzr = sx.data(); M.star_cell = sc.data();
-    M.n_lambda = m->n_lambda; M.kappa = m->kappa; M.kappa_abs = m->kappa_abs_LTE; M.albedo = m->albedo;
-    kfpad.assign(m->kappa_factor, m->kappa_factor + m->n_cells); kfpad.push_back(0.0);  // (+ the entry of "no cell")
-    M.kappa_factor = kfpad.data();
-    bool any_dark = false;
-    if (m->l_dark_zone) for (int i = 0; i < m->n_cells; ++i) any_dark |= m->l_dark_zone[i] != 0;
-    M.dark = any_dark ? m->l_dark_zone : nullptr;
-    M.nang = m->nang_scatt; M.aniso_method = m->aniso_method; M.lisotropic = m->lisotropic;
-    M.p_lambda_fixed = m->p_lambda_fixed;
-    M.prob_s11 = m->prob_s11_pos; M.s12 = m->s12_o_s11; M.s22 = m->s22_o_s11; M.s33 = m->s33_o_s11;
-    M.s34 = m->s34_o_s11; M.s44 = m->s44_o_s11; M.tab_g = m->tab_g_pos;
-    ct.resize(m->nang_scatt + 1);
-    for (int k = 0; k <= m->nang_scatt; ++k) ct[k] = std::cos(((double)k) * PI / (double)m->nang_scatt);
-    M.cos_tab = ct.data();
-    M.n_T = m->n_T; M.log_Qcool = m->log_Qcool; M.cdf = m->kdB_dT_CDF; M.spec_cum = m->spectre_emission_cumul;
-    M.frac_E_stars = m->frac_E_stars; M.frac_E_disk = m->frac_E_disk; M.CDF_E_star = m->CDF_E_star;
-    M.prob_E_cell = m->prob_E_cell; M.L_packet_th = m->L_packet_th;
-    M.N_thet = m->N_thet; M.N_phi = m->N_phi; M.sym_c = m->l_sym_centrale; M.sym_a = m->l_sym_axiale;
-    M.midplane_snap = m->midplane_snap;
-    M.grid_sph = m->grid_type == 2;
-    M.tan_theta_lim = m->tan_theta_lim; M.theta_lim = m->theta_lim; M.r_lim_3 = m->r_lim_3;
-    M.R_ISM = m->R_ISM;
-    for (int q = 0; q < 3; ++q) M.centre_ISM[q] = m->centre_ISM[q];
-    M.mrw = m->mrw; M.mrw_n_zeta = m->mrw_n_zeta; M.mrw_n_inter = m->mrw_n_inter; M.mrw_gamma = m->mrw_gamma;
-    M.mrw_zeta = m->mrw_zeta; M.mrw_chi = m->mrw_chi; M.mrw_kdep = m->mrw_kappa_dep; M.mrw_ext = m->mrw_ext; M.mrw_exit_cdf = m->mrw_exit_cdf;
-    M.r_lim = m->r_lim;
-    M.sin_phi = m->sin_phi_lim; M.cos_phi = m->cos_phi_lim;   // (the walk's azimuthal walls, 3D)
-    M.n_classes = m->p_n_cells;
-    if (m->p_n_cells) {  // class-major copies, as mcgpu_set_variable_dust lays them out
-      const int nc = m->p_n_cells, nl = m->n_lambda;
-      vcls.resize(m->n_cells); vk.resize((size_t)nc * nl); vka.resize((size_t)nc * nl); val.resize((size_t)nc * nl);
-      for (int i = 0; i < m->n_cells; ++i) vcls[i] = m->p_icell[i] - 1;
-      for (int c = 0; c < nc; ++c)
-        for (int l = 0; l < nl; ++l) {
-          vk[(size_t)c * nl + l] = m->v_kappa[c + (size_t)nc * l];
-          vka[(size_t)c * nl + l] = m->v_kappa_abs_LTE[c + (size_t)nc * l];
-          val[(size_t)c * nl + l] = m->v_albedo[c + (size_t)nc * l];
-        }
-      M.cell_class = vcls.data(); M.v_kappa = vk.data(); M.v_kabs = vka.data(); M.v_albedo = val.data();
-      M.v_lq = m->v_log_Qcool; M.v_cdf = m->v_kdB_dT_CDF;
-      if (m->v_prob_s11_pos) {
-        const int na1 = m->nang_scatt + 1, ncol = m->p_lambda_fixed ? 1 : nl;
-        auto relay = [&](const float* src, int cols, std::vector<float>& t) {
-          t.resize((size_t)nc * cols * na1);
-          for (int c = 0; c < nc; ++c)
-            for (int l = 0; l < cols; ++l)
-              memcpy(&t[((size_t)c * cols + l) * na1], &src[((size_t)l * nc + c) * na1], na1 * sizeof(float));
-          return t.data();
-        };
-        M.v_prob = relay(m->v_prob_s11_pos, ncol, vsc[0]); M.v_s12 = relay(m->v_s12_o_s11, nl, vsc[1]);
-        M.v_s22 = relay(m->v_s22_o_s11, nl, vsc[2]); M.v_s33 = relay(m->v_s33_o_s11, nl, vsc[3]);
-        M.v_s34 = relay(m->v_s34_o_s11, nl, vsc[4]); M.v_s44 = relay(m->v_s44_o_s11, nl, vsc[5]);
-        vsc[6].resize((size_t)nc * nl);
-        for (int c = 0; c < nc; ++c)
-          for (int l = 0; l < nl; ++l) vsc[6][(size_t)c * nl + l] = m->v_tab_g_pos[c + (size_t)nc * l];
-        M.v_g = vsc[6].data();
-        M.v_scatt = 1;
-        if (m->v_tab_s11_pos) M.v_s11 = relay(m->v_tab_s11_pos, nl, vsc[7]);   // (mcgpu_set_variable_dust_s11)
-      }
-    }
+// k_tail in rounds (MCGPU_EMU_TAIL_HOST = events per round): every packet is written back as a record after that many of
+// its events (tail_packet's hand-over to the host) and taken up again from the record in the next round, until none is
+// left -- the records must carry a packet's whole state, at any point of its life.  `launch(A, recs, n, next)` runs k_tail.
+template <typename Launch>
+static int emu_tail_rounds(RunArgs A, const std::vector<Rec<true>>& first, unsigned int n_first, Launch launch, int* err) {
+  const char* e = getenv("MCGPU_EMU_TAIL_HOST");
+  unsigned int next = 0u;
+  if (!e) { unsigned int n = n_first; launch(A, (const void*)first.data(), &n, &next); return 0; }
+  g_tail_hook_events = (unsigned int)atoi(e);
+  std::vector<Rec<true>> cur(first.begin(), first.begin() + n_first), out(n_first ? n_first : 1);
+  unsigned int n = n_first, rounds = 0u;
+  while (n && !*err) {
+    unsigned int ctl[2] = {0x80000000u, 0u};   // (done: so large that "few are left" never holds; only the hook hands over)
+    A.tail_host_max = n; A.tail_done = &ctl[0]; A.tail_out = out.data(); A.tail_out_n = &ctl[1];
+    next = 0u;
+    launch(A, (const void*)cur.data(), &n, &next);
+    // (records of packets without Stokes tracking are the shorter Rec<false>: the buffers are raw bytes of the larger type)
+    n = ctl[1];
+    cur.swap(out);
+    if (out.size() < cur.size()) out.resize(cur.size());
+    if (++rounds > 1000000u) return 31;
   }
-};
+  g_tail_hook_events = 0u;
+  if (getenv("MCGPU_EMU_BIN_STATS")) fprintf(stderr, "tail: %u rounds of hand-over\n", rounds);
+  return 0;
+}
 
 extern "C" int emu_run_thermal(const oracle_model* m, const oracle_opts* o, const double* E_prior, double* E_abs,
                                double* sed, double* n_sent, uint64_t* counters) {
@@ -363,10 +274,13 @@ extern "C" int emu_run_thermal(const oracle_model* m, const oracle_opts* o, cons
         unsigned int next = 0u;
         RunArgs At = A;
         At.n_folded = 0.0;
-#define RUNK(b, c) do { if (M.mrw) k_tail<true, b, c, true>(M, At, carry[out].data(), &carry_n[out], &next); else k_tail<true, b, c, false>(M, At, carry[out].data(), &carry_n[out], &next); } while (0)
-        if (pola) { if (dark) RUNK(true, true); else RUNK(true, false); }
-        else { if (dark) RUNK(false, true); else RUNK(false, false); }
+#define RUNK(b, c) do { if (M.mrw) k_tail<true, b, c, true>(M, Ax, recs, np, nx); else k_tail<true, b, c, false>(M, Ax, recs, np, nx); } while (0)
+        const int rct = emu_tail_rounds(At, carry[out], carry_n[out], [&](const RunArgs& Ax, const void* recs, unsigned int* np, unsigned int* nx) {
+          if (pola) { if (dark) RUNK(true, true); else RUNK(true, false); }
+          else { if (dark) RUNK(false, true); else RUNK(false, false); } }, &err);
 #undef RUNK
+        (void)next;
+        if (rct) return rct;
         if (err) return err;
         if (getenv("MCGPU_EMU_BIN_STATS")) fprintf(stderr, "tail: %u packets\n", carry_n[out]);
       }
@@ -393,7 +307,8 @@ extern "C" int emu_run_thermal(const oracle_model* m, const oracle_opts* o, cons
       Ar.carry_out = carry.data(); Ar.carry_out_n = &carry_n; Ar.carry_cap = (unsigned int)carry_cap;
       Ar.tail_threshold = atoi(getenv("MCGPU_EMU_TAIL"));
 #define RUNT(b, c, mm) do { if (ld) k_thermal_roles_tail<b, c, true, mm>(M, Ar, n_rec, nsp, ks, fi, 65, eq); else k_thermal_roles_tail<b, c, false, mm>(M, Ar, n_rec, nsp, ks, fi, 65, eq); \
-                            if (!err) k_tail<false, b, c, mm>(M, A, carry.data(), &carry_n, &next); } while (0)
+                            if (!err) { const int rct = emu_tail_rounds(A, carry, carry_n, [&](const RunArgs& Ax, const void* recs, unsigned int* np, unsigned int* nx) { \
+                              k_tail<false, b, c, mm>(M, Ax, recs, np, nx); }, &err); if (rct) return rct; } } while (0)
       if (M.mrw) { if (pola) { if (dark) RUNT(true, true, true); else RUNT(true, false, true); } else { if (dark) RUNT(false, true, true); else RUNT(false, false, true); } }
       else { if (pola) { if (dark) RUNT(true, true, false); else RUNT(true, false, false); } else { if (dark) RUNT(false, true, false); else RUNT(false, false, false); } }
 #undef RUNT

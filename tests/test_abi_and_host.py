@@ -43,9 +43,25 @@ def test_no_cpu_fallback_without_device(small_model):
 def test_product_does_not_import_the_oracle():
     for dirpath, _, files in os.walk(os.path.join(ROOT, "mcfost_amd")):
         for f in files:
-            if f.endswith((".py", ".hip", ".h", ".f90")):
+            if f.endswith((".py", ".hip", ".h", ".f90", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "mc_oracle" not in src and "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_the_library_holds_no_oracle_symbol_and_needs_no_oracle_library():
+    """The library's host side (host_tail.cpp: the last packets of a launch's tail on CPU threads) is the product's own
+    device source compiled for the CPU -- not the CPU oracle: no symbol of the library, defined or undefined, names the
+    oracle, and it links nothing under oracle/."""
+    import subprocess
+    import __graft_entry__ as g
+    lib = g.build_hip()
+    syms = subprocess.run(["nm", "-C", lib], capture_output=True, text=True).stdout + \
+        subprocess.run(["nm", "-D", "-C", lib], capture_output=True, text=True).stdout
+    assert len(syms) > 1000
+    assert "oracle" not in syms.lower()
+    assert "tail_packet" in syms   # (the host instantiations of the device source's tail_packet are in it)
+    needed = subprocess.run(["readelf", "-d", lib], capture_output=True, text=True).stdout
+    assert "oracle" not in needed.lower()
 
 
 def test_shard_packets_partitions_the_range():

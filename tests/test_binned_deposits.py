@@ -120,10 +120,23 @@ def test_tail_kernel_frozen_parity_and_the_automatic_threshold():
         o = _oracle(m, n)
         prior = o.run_thermal(2000, seed=1)["E_abs"]
         b = o.run_thermal(n, seed=17, frozen=True, E_prior=prior, n_threads=8)
-        for thr in (0, 40, 100000):
+        # (tail_where: 1 = k_tail finishes every packet; 2 = k_tail thins the tail out and the library's host threads --
+        # host_tail.cpp, the device source compiled for the CPU -- finish the last packets; with 4 packets left to the host
+        # most are handed over in the middle of their lives, with 100000 every packet of the tail runs on the host)
+        for thr, where, host_pk in ((0, 0, 0), (40, 1, 0), (100000, 1, 0), (40, 2, 0), (40, 2, 4), (100000, 2, 60000 if m is small else 64), (100000, 0, 0)):
             e = _engine(m, n)
             e.set_option("tail", thr)
+            e.set_option("tail_where", where)
+            e.set_option("tail_host_packets", host_pk)
+            e.set_option("host_threads", 3 if host_pk == 4 else 0)
             a = e.run_thermal(n, seed=17, frozen=True, E_prior=prior)
+            if thr == 0 and not m.cfg.l3D:
+                assert e.get_info("tail_where") == 0
+            elif thr:
+                assert e.get_info("tail_where") == (1 if where == 1 else 2)
+                if where != 1:
+                    assert e.get_info("tail_host_packets") > 0 and e.get_info("tail_host_events") > 0
+                    assert e.get_info("tail_host_packets") <= (host_pk if host_pk else 16 * e.get_info("tail_host_threads"))
             e.close()
             _same_packets(a, b)
     # the automatic choice

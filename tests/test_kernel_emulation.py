@@ -562,6 +562,40 @@ def test_emulated_tail_kernel(emu, small_model):
             os.environ.pop(k, None)
 
 
+def test_emulated_tail_hand_over_records_carry_the_whole_packet(emu, small_model):
+    """k_tail's hand-over to the host (mc_tail.hip.h "The last packets on the host"): every packet of the tail is written
+    back as a record after 1, 3 or 40 of its events and taken up again from that record, round after round, until none is
+    left (MCGPU_EMU_TAIL_HOST) -- at any point of its life the record holds everything: lazy Stokes state flushed, pending
+    deposits made, the walk's interaction count, the flags.  Same packets, same sums as the oracle."""
+    md = copy.copy(small_model)   # dark zone
+    dz = np.zeros(md.n_cells, np.uint8)
+    kf = md.kappa_factor.copy()
+    kf[::md.cfg.n_rad] = 0.0
+    dz[np.argsort(kf)[-40:]] = 1
+    md.l_dark_zone = dz
+    try:
+        for ev in ("1", "3", "40"):
+            os.environ["MCGPU_EMU_TAIL_HOST"] = ev
+            os.environ["MCGPU_EMU_TAIL"], os.environ["MCGPU_EMU_ROLES"] = "100000", "1,2,3,128"
+            check(emu, small_model, 2000, 7)
+            os.environ["MCGPU_EMU_LDS"] = "1"
+            os.environ["MCGPU_EMU_TAIL"] = "40"
+            check(emu, small_model, 2000, 7)
+            del os.environ["MCGPU_EMU_LDS"]
+            check(emu, M.build_model(M.small(aniso_method=2, lsepar_pola=False)), 1500, 10)
+            a, b = check(emu, md, 2000, 12)
+            assert a["counters"][7] > 0
+            check(emu, _with_ism(small_model), 1500, 31, rtol=1e-6)
+            os.environ.pop("MCGPU_EMU_TAIL"); os.environ.pop("MCGPU_EMU_ROLES")
+            m3 = M.build_model(M.small(n_rad=12, nz=6, n_az=8, l3D=True))
+            os.environ["MCGPU_EMU_BIN"] = "300,4096,1,2,3,100000"
+            check(emu, m3, 2000, 8)
+            os.environ.pop("MCGPU_EMU_BIN")
+    finally:
+        for k in ("MCGPU_EMU_TAIL", "MCGPU_EMU_ROLES", "MCGPU_EMU_LDS", "MCGPU_EMU_BIN", "MCGPU_EMU_TAIL_HOST"):
+            os.environ.pop(k, None)
+
+
 def emu_dust_map(emu, orc, lam, xI, Tdust, n_sent, E_disk, ang_disque=0.0, l_sym_ima=True, tau_obs=100.0):
     from oracle.binding import _RtOpts
     m = orc.model

@@ -180,8 +180,12 @@ def test_emulated_kernels_walk_like_the_oracle(emu):
     assert want["counters"]["mrw_walks"] > 100
     # (MCGPU_EMU_TAIL: the role kernel hands its last packets -- or all of them -- to the tail kernel, mc_tail.hip.h)
     for env in ({}, {"MCGPU_EMU_LDS": "1"}, {"MCGPU_EMU_ROLES": "1,2,3,128"}, {"MCGPU_EMU_ROLES": "0,2,3,128", "MCGPU_EMU_LDS": "1"},
-                {"MCGPU_EMU_ROLES": "1,2,3,128", "MCGPU_EMU_TAIL": "30"}, {"MCGPU_EMU_ROLES": "1,2,3,128", "MCGPU_EMU_LDS": "1", "MCGPU_EMU_TAIL": "100000"}):
-        for k in ("MCGPU_EMU_LDS", "MCGPU_EMU_ROLES", "MCGPU_EMU_TAIL"):
+                {"MCGPU_EMU_ROLES": "1,2,3,128", "MCGPU_EMU_TAIL": "30"}, {"MCGPU_EMU_ROLES": "1,2,3,128", "MCGPU_EMU_LDS": "1", "MCGPU_EMU_TAIL": "100000"},
+                # (MCGPU_EMU_TAIL_HOST: k_tail writes every packet back as a record after that many events -- its hand-over to
+                # the host -- and takes it up again: the walk's interaction count and "left its cell" bit travel in the record)
+                {"MCGPU_EMU_ROLES": "1,2,3,128", "MCGPU_EMU_TAIL": "100000", "MCGPU_EMU_TAIL_HOST": "2"},
+                {"MCGPU_EMU_ROLES": "1,2,3,128", "MCGPU_EMU_LDS": "1", "MCGPU_EMU_TAIL": "30", "MCGPU_EMU_TAIL_HOST": "7"}):
+        for k in ("MCGPU_EMU_LDS", "MCGPU_EMU_ROLES", "MCGPU_EMU_TAIL", "MCGPU_EMU_TAIL_HOST"):
             os.environ.pop(k, None)
         os.environ.update(env)
         try:
@@ -207,12 +211,18 @@ def test_emulated_binned_role_kernel_walks_like_the_oracle_in_3d(emu):
     seed = 10
     want = orc.run_thermal(n, seed=seed, frozen=True, E_prior=prior, n_threads=4)
     assert want["counters"]["mrw_walks"] > 100
-    for cfg in ("100000,4096,1,2,3", "300,4096,1,2,3", "97,64,0,2,3,30", "300,4096,1,2,3,100000"):
+    # ("host:": k_tail also writes every packet back as a record every 3 events -- its hand-over to the host -- and takes it up again)
+    for cfg in ("100000,4096,1,2,3", "300,4096,1,2,3", "97,64,0,2,3,30", "300,4096,1,2,3,100000", "host:300,4096,1,2,3,100000"):
+        if cfg.startswith("host:"):
+            cfg = cfg[5:]
+            os.environ["MCGPU_EMU_TAIL_HOST"] = "3"
         os.environ["MCGPU_EMU_BIN"] = cfg
         try:
             got = K.emu_run(emu, orc, n, seed, prior=prior)
         finally:
             os.environ.pop("MCGPU_EMU_BIN", None)
+            os.environ.pop("MCGPU_EMU_TAIL_HOST", None)
+            os.environ.pop("MCGPU_EMU_TAIL_HOST", None)
         gc, wc = dict(zip(want["counters"].keys(), got["counters"])), want["counters"]
         _counters_equal_but_for_parted_packets(gc, wc)
         assert abs(gc["mrw_walks"] - wc["mrw_walks"]) <= 2 and abs(gc["mrw_steps"] - wc["mrw_steps"]) <= 8, (cfg, gc, wc)
