@@ -599,7 +599,7 @@ def main():
     ap.add_argument("--tail-where", type=int, default=-1, help="option \"tail_where\": 1 = k_tail finishes every packet, 2 = the library's "
                     "host threads finish the last ones (default)")
     ap.add_argument("--host-threads", type=int, default=-1, help="option \"host_threads\": host threads of a launch's tail (0 = automatic)")
-    ap.add_argument("--tail-host-packets", type=int, default=-1, help="option \"tail_host_packets\": packets k_tail leaves to the host (0 = 16 per thread)")
+    ap.add_argument("--tail-host-packets", type=int, default=-1, help="option \"tail_host_packets\": packets k_tail leaves to the host (0 = 8 per thread)")
     ap.add_argument("--schedule", type=int, default=-1, help="tuning aid: option \"schedule\" (include/mcgpu.h)")
     ap.add_argument("--crossing", type=int, default=-1, help="option \"crossing\": 1 = the flight-parametric 2D crossing in the flying "
                     "waves (statistical parity only; include/mcgpu.h)")

@@ -176,6 +176,16 @@ int mcgpu_set_midplane_snap(mcgpu_ctx *ctx, int on);
  *                      lanes working ahead for it, mc_tail.hip.h) once a workgroup has this many left; 0 = never;
  *                      -1 (default) = automatic: 48 where packets get trapped (the context's last launch had at
  *                      least one interaction per packet, or -- first launch -- the midplane is optically thick)
+ *   "tail_where"   where a launch's LAST packets end: 0 (default) = automatic, 2 = k_tail thins the tail out (thousands of
+ *                      packets at once) and, once no more than "tail_host_packets" are unfinished, hands them to the
+ *                      library's host threads (host_tail.cpp: the device source compiled for the CPU, one packet per
+ *                      thread -- a packet is one dependent chain of events, which a wave runs at 1.0-1.6 us per event
+ *                      and a host core at 30-100 ns; never the CPU oracle of the tests); 1 = k_tail finishes every
+ *                      packet.  The hand-over is stream-ordered (copies + a host callback on the context's stream):
+ *                      a launch stays asynchronous.  Automatic = 2 wherever k_tail runs.
+ *   "host_threads" host threads of such a tail: 0 (default) = the machine's hardware threads divided by its GPUs,
+ *                      at most 32; 1..256
+ *   "tail_host_packets"  packets k_tail leaves to the host: 0 (default) = 8 per host thread; 1..65536
  *   "deposit_log_mb"  size of the binned-deposit log in MiB; 0 (default) = up to 64 GiB (what the packets asked for need), at most a quarter of
  *                      the free device memory.  A smaller log means more, shorter chunks; a
  *                      block that finds its part of the log full is added with atomics.
@@ -198,11 +208,17 @@ int mcgpu_set_midplane_snap(mcgpu_ctx *ctx, int on);
  *   "voronoi_pool_log_records" 6..12 (default 12): log2 of the packet records per workgroup of schedule 3
  *   "radiation_field"  bit 0: keep xN_abs, bit 1: keep xJ_abs in the thermal step (mcgpu_fetch_radiation_field);
  *                      cylindrical grids then run the single-role kernel
- * Results do not depend on any of them (same packets, same random numbers).
+ * Results do not depend on any of them (same packets, same random numbers) -- except "crossing" = 1, which changes
+ * the crossing's arithmetic (statistical parity only), and to the rounding of a sum's order ("tail_where": a host
+ * thread evaluates log / sin / cos with the host's libm, the device with its own: a packet's history is the same
+ * function of the same random numbers, and differs where a last digit decides a branch).
  */
 int mcgpu_set_option(mcgpu_ctx *ctx, const char *name, int value);
 /* Diagnostics of the last launches: "bin_buckets", "bin_log_blocks", "bin_chunks",
- * "bin_deposits_per_packet", "bin_overflow_blocks", "bin_drained_records", "tail_threshold", "tau_midplane". */
+ * "bin_deposits_per_packet", "bin_overflow_blocks", "bin_drained_records", "tail_threshold", "tau_midplane",
+ * "tail_ms", "longest_packet_events" / _crossings / _scatterings / _absorptions / _walks / _steps, and of the last
+ * launch's tail: "tail_where" (0: it had none, 1: k_tail finished it, 2: the host threads did), "tail_host_ms",
+ * "tail_host_packets", "tail_host_threads", "tail_host_events". */
 int mcgpu_get_info(mcgpu_ctx *ctx, const char *name, double *value);
 
 /* Stars: type star_type (parameters.f90:230-242); icell/out_model from
@@ -391,7 +407,12 @@ int mcgpu_set_I_spec(mcgpu_ctx *ctx, const double *I_spec, const double *I_spec_
  * cumulative distribution is summed in the reference's own cell order, so it is monotone and ends in exactly 1).
  *   lambda, wl_um           the wavelength index (1-based) and tab_lambda(lambda) in micron
  *   E_star, E_ISM           E_stars(lambda), E_ISM(lambda)
- *   Tdust[n_cells]          default real (host); weight_proba_emission[n_cells] or NULL (lweight_emission)
+ *   Tdust[n_cells]          default real (host); weight_proba_emission[n_cells] or NULL (lweight_emission).  The weights
+ *                           must all be 1 (as the reference's own are: its generator of weight_proba_emission and
+ *                           correct_E_emission is commented out, thermal_emission.f90:2078-2135, 2147-2148); any other
+ *                           value is refused with MCGPU_ERR_UNSUPPORTED -- the engine does not apply the compensating
+ *                           packet weight Stokes(1) *= correct_E_emission(icell) (dust_transfer.f90:1140-1142), and a
+ *                           biased table without it would bias the SED silently.
  * Out (any may be NULL): frac_E_stars(lambda), frac_E_disk(lambda), E_disk(lambda), prob_E_cell(0:n_cells, lambda).
  * The cumulative distribution also STAYS on the device: a following mcgpu_run_mono of the same wavelength may pass
  * prob_E_cell = NULL.  Fails (MCGPU_ERR_ARG) where the reference stops: no energy at all at this wavelength (:1899).

@@ -115,6 +115,39 @@ using std::fmin; using std::atan2; using std::acos; using std::cos; using std::c
 #include "mc_voronoi.hip.h"
 #include "mc_binned.hip.h"
 #include "mc_roles.hip.h"
+
+// A thread's deposits.  The packets of a tail are trapped in a few opaque cells, every thread deposits into those cells'
+// lines event after event, and compare-and-swap loops of several threads on one line serialise them (measured: 8 threads
+// as fast as one).  So a thread sums its deposits in a small direct-mapped table of its own -- the idea of the Voronoi
+// kernels' deposit cache in LDS (mc_voronoi.hip.h) -- and adds an entry to the shared array when another cell takes its
+// slot, and everything at the end of the job.  What a thread has not folded yet is part of ITS view of the cell's energy
+// (MCGPU_TAIL_UNFOLDED), as a wave's running sum is on the device.
+namespace mcgpu_host {
+struct DepositCache {
+  static constexpr int SLOTS = 1024;   // (x 12 bytes: L1-resident)
+  int cell[SLOTS];
+  double val[SLOTS];
+  double* shared = nullptr;
+  void reset(double* E) { shared = E; for (int i = 0; i < SLOTS; ++i) { cell[i] = -1; val[i] = 0.0; } }
+  inline void add(int ic, double v) {
+    const int s = ic & (SLOTS - 1);
+    if (cell[s] != ic) {
+      if (cell[s] >= 0 && val[s] != 0.0) (void)atomicAdd(&shared[cell[s]], val[s]);
+      cell[s] = ic; val[s] = 0.0;
+    }
+    val[s] += v;
+  }
+  inline double unfolded(int ic) const { const int s = ic & (SLOTS - 1); return cell[s] == ic ? val[s] : 0.0; }
+  void fold() {
+    for (int i = 0; i < SLOTS; ++i)
+      if (cell[i] >= 0 && val[i] != 0.0) { (void)atomicAdd(&shared[cell[i]], val[i]); val[i] = 0.0; }
+  }
+};
+static thread_local DepositCache* tl_deposits = nullptr;
+}  // namespace mcgpu_host
+#define MCGPU_TAIL_DEPOSIT(A, ic, v) mcgpu_host::tl_deposits->add((ic), (v))
+#define MCGPU_TAIL_UNFOLDED(ic) mcgpu_host::tl_deposits->unfolded(ic)
+
 #include "mc_tail.hip.h"
 
 namespace mcgpu_host {
@@ -156,16 +189,23 @@ struct Pool {
     }
   }
 
+  // at least n_threads - 1 workers (started by the CALLER's thread: a thread inherits its creator's CPU affinity, and
+  // the HIP runtime's callback thread is not a thread to inherit from)
+  void ensure(int n_threads) {
+    std::lock_guard<std::mutex> lk(mu);
+    while ((int)workers.size() < n_threads - 1) {
+      const int id = (int)workers.size();
+      workers.emplace_back([this, id] { worker(id); });
+    }
+  }
+
   // runs fn(arg, 0 .. n_threads - 1): index 0 on the calling thread
   void run(int n_threads, void (*f)(void*, int), void* a) {
     std::lock_guard<std::mutex> job(job_mu);
     const int extra = n_threads - 1;
+    ensure(n_threads);
     {
       std::lock_guard<std::mutex> lk(mu);
-      while ((int)workers.size() < extra) {
-        const int id = (int)workers.size();
-        workers.emplace_back([this, id] { worker(id); });
-      }
       fn = f; arg = a; want = extra; running = extra;
       ++gen;
     }
@@ -193,6 +233,8 @@ Pool& pool() {
   return *p;
 }
 
+constexpr int CS_STRIDE = 32;   // a thread's event counts: TAIL_N_COUNTERS + 1 words on two cache lines of their own
+
 struct Work {
   const DevModel* M;
   const RunArgs* A;
@@ -201,7 +243,7 @@ struct Work {
   Lds T;
   std::atomic<unsigned int> next{0};
   int n_threads;
-  std::vector<unsigned int> cs;   // [n_threads][TAIL_N_COUNTERS + 1]
+  std::vector<unsigned int> cs;   // [n_threads][CS_STRIDE]
   void (*one)(Work&, unsigned int, unsigned int*);
 };
 
@@ -213,12 +255,17 @@ void one_packet(Work& W, unsigned int i, unsigned int* cs) {
 
 void body(void* arg, int tid) {
   Work& W = *static_cast<Work*>(arg);
-  unsigned int* cs = &W.cs[(size_t)tid * (TAIL_N_COUNTERS + 1)];
+  unsigned int* cs = &W.cs[(size_t)tid * CS_STRIDE];
+  DepositCache cache;
+  cache.reset(W.A->E_abs);
+  tl_deposits = &cache;
   for (;;) {
     const unsigned int i = W.next.fetch_add(1u, std::memory_order_relaxed);
     if (i >= W.n) break;
     W.one(W, i, cs);
   }
+  cache.fold();
+  tl_deposits = nullptr;
 }
 
 template <bool L3D, bool POLA>
@@ -239,6 +286,8 @@ int default_threads(int n_devices) {
   return t;
 }
 
+void prepare_threads(int n_threads) { pool().ensure(n_threads > 0 ? n_threads : default_threads(1)); }
+
 void run_tail(TailJob* job) {
   job->ms = 0.0; job->threads_used = 0; job->events = 0ull;
   if (!job->n) return;
@@ -256,14 +305,14 @@ void run_tail(TailJob* job) {
   if ((unsigned int)nt > job->n) nt = (int)job->n;
   if (nt < 1) nt = 1;
   W.n_threads = nt;
-  W.cs.assign((size_t)nt * (TAIL_N_COUNTERS + 1), 0u);
+  W.cs.assign((size_t)nt * CS_STRIDE, 0u);
   if (job->l3d) { if (job->pola) pick2<true, true>(W, job->dark != 0, job->mrw != 0); else pick2<true, false>(W, job->dark != 0, job->mrw != 0); }
   else { if (job->pola) pick2<false, true>(W, job->dark != 0, job->mrw != 0); else pick2<false, false>(W, job->dark != 0, job->mrw != 0); }
   pool().run(nt, body, &W);
   // the threads' event counts -> the counters (as k_tail's waves add theirs)
   unsigned long long longest = 0ull;
   for (int t = 0; t < nt; ++t) {
-    const unsigned int* cs = &W.cs[(size_t)t * (TAIL_N_COUNTERS + 1)];
+    const unsigned int* cs = &W.cs[(size_t)t * CS_STRIDE];
     for (int q = 0; q < TAIL_N_COUNTERS; ++q) A.counters[q] += (unsigned long long)cs[q];
     if (cs[TAIL_N_COUNTERS] > longest) longest = cs[TAIL_N_COUNTERS];
     job->events += (unsigned long long)cs[1] + cs[3] + cs[4];

@@ -24,6 +24,10 @@ struct TailJob {
 // (atomically: the packets are spread over threads).  Thread-safe (jobs of several contexts queue up).
 __attribute__((visibility("hidden"))) void run_tail(TailJob* job);
 
+// Starts the pool's threads for jobs of n_threads, from the calling thread (call it from the thread that enqueues the
+// launch: run_tail is called by a thread of the HIP runtime, whose CPU affinity the workers should not inherit).
+__attribute__((visibility("hidden"))) void prepare_threads(int n_threads);
+
 // threads a job uses when it does not say: the machine's hardware threads shared among `n_devices` processes or
 // contexts, at least 2, at most 32
 __attribute__((visibility("hidden"))) int default_threads(int n_devices);

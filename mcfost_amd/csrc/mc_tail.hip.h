@@ -83,6 +83,13 @@ __device__ inline void tail_draw(TailBatch& B, uint32_t k0, uint32_t k1, uint32_
 
 // One packet, from the state its record holds to its end.  Wave-uniform control flow: every lane holds the same
 // packet state; lane 0 makes the deposits and counts.
+// Where a packet's summed deposits go, and what of the wave's own deposits E_abs does not hold yet (host_tail.cpp keeps a
+// cache of deposits per thread: threads that add to one shared array line by line serialise each other)
+#ifndef MCGPU_TAIL_DEPOSIT
+#define MCGPU_TAIL_DEPOSIT(A, ic, v) atomic_add_f64(&(A).E_abs[ic], (v))
+#define MCGPU_TAIL_UNFOLDED(ic) 0.0
+#endif
+
 #ifndef MCGPU_TAIL_TEST_HOOK   // (tests/emu: hand a packet over after a given number of its events, whatever the others do --
 #define MCGPU_TAIL_TEST_HOOK(events_here) false   // one emulated lane runs the packets one after the other)
 #endif
@@ -155,7 +162,7 @@ __device__ __forceinline__ bool tail_packet(const Lds& T, const DevModel& M, con
   int dep_cell = -1;
   double dep_sum = 0.0;
   auto flush = [&]() {
-    if (dep_cell >= 0 && dep_sum != 0.0 && lane == 0) atomic_add_f64(&A.E_abs[dep_cell], dep_sum);
+    if (dep_cell >= 0 && dep_sum != 0.0 && lane == 0) MCGPU_TAIL_DEPOSIT(A, dep_cell, dep_sum);
     dep_cell = -1; dep_sum = 0.0;
   };
   auto add_energy = [&](int ic, double v) {
@@ -176,7 +183,7 @@ __device__ __forceinline__ bool tail_packet(const Lds& T, const DevModel& M, con
   };
   auto cell_energy = [&](int ic) {
     if (A.frozen) return A.E_prior[ic];
-    if (ic != e_cell) { e_val = A.E_abs[ic]; e_cell = ic; }
+    if (ic != e_cell) { e_val = A.E_abs[ic] + MCGPU_TAIL_UNFOLDED(ic); e_cell = ic; }
     return (e_val + (ic == dep_cell ? dep_sum : 0.0)) * A.qscale;
   };
 
@@ -399,11 +406,14 @@ __device__ __forceinline__ bool tail_packet(const Lds& T, const DevModel& M, con
 #ifndef MCGPU_TAIL_BLOCK
 #define MCGPU_TAIL_BLOCK 256
 #endif
+#ifndef MCGPU_TAIL_MIN_WAVES   // waves per SIMD the register budget is cut for (k_tail is throughput-bound while it holds more
+#define MCGPU_TAIL_MIN_WAVES 1 // packets than waves reside; 1: whatever the packet's state needs, 190-260 VGPRs -> 2 waves)
+#endif
 
 // The packets the role kernel handed over: carry[0 .. *carry_n) (records), one per wave at a time, taken from a global
 // counter.  Launched behind the role kernel (and the fold of its log) on the same stream.
 template <bool L3D, bool POLA, bool DARK, bool MRW>
-__global__ void __launch_bounds__(MCGPU_TAIL_BLOCK) k_tail(const DevModel M, const RunArgs A, const void* carry, const unsigned int* carry_n,
+__global__ void __launch_bounds__(MCGPU_TAIL_BLOCK, MCGPU_TAIL_MIN_WAVES) k_tail(const DevModel M, const RunArgs A, const void* carry, const unsigned int* carry_n,
                                                            unsigned int* next) {
   extern __shared__ double lds_raw[];
   const Lds T = lds_carve(lds_raw, M);

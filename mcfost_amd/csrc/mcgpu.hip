@@ -103,7 +103,7 @@ struct mcgpu_ctx {
   // the tail's last packets on the host (mc_tail.hip.h "The last packets on the host", host_tail.cpp)
   int opt_tail_where = 0;        // 0 = automatic (the host), 1 = k_tail finishes every packet, 2 = the host finishes the last ones
   int opt_host_threads = 0;      // host threads of a tail (0: the machine's, shared among its GPUs; at most 32)
-  int opt_tail_host_max = 0;     // packets k_tail leaves to the host (0: 16 per host thread)
+  int opt_tail_host_max = 0;     // packets k_tail leaves to the host (0: 8 per host thread)
   unsigned int* d_tail_ctl = nullptr;   // [0] packets k_tail has finished, [1] records it has written to d_tail_out
   void* d_tail_out = nullptr;           // [tail_out_cap] records for the host
   unsigned int tail_out_cap = 0;
@@ -1371,7 +1371,8 @@ static int launch_tail(mcgpu_ctx* ctx, const RunArgs& A_in, const void* carry, c
     int n_dev = 1;
     (void)hipGetDeviceCount(&n_dev);
     n_threads = ctx->opt_host_threads > 0 ? ctx->opt_host_threads : mcgpu_host::default_threads(n_dev);
-    host_max = ctx->opt_tail_host_max > 0 ? (unsigned int)ctx->opt_tail_host_max : 16u * (unsigned int)n_threads;
+    mcgpu_host::prepare_threads(n_threads);
+    host_max = ctx->opt_tail_host_max > 0 ? (unsigned int)ctx->opt_tail_host_max : 8u * (unsigned int)n_threads;
     if (!ctx->d_tail_ctl) HIPCHK(hipMalloc((void**)&ctx->d_tail_ctl, 2 * sizeof(unsigned int)));
     if (ctx->tail_out_cap < host_max) {
       HIPCHK(hipStreamSynchronize(ctx->stream));   // (an earlier launch may still write the old buffer)
@@ -2197,8 +2198,18 @@ extern "C" int mcgpu_repartition_energie(mcgpu_ctx* ctx, int lambda, double wl_u
   if (!ctx || !ctx->have_grid || !ctx->have_opacity || !Tdust) return fail(ctx, MCGPU_ERR_ARG, "mcgpu_repartition_energie: grid, opacity and Tdust are needed");
   const DevModel& M = ctx->M;
   if (lambda < 1 || lambda > M.n_lambda || !(wl_um > 0.0)) return fail(ctx, MCGPU_ERR_ARG, "mcgpu_repartition_energie: bad wavelength");
-  HIPCHK(hipSetDevice(ctx->device));
   const int n = M.n_cells;
+  // lweight_emission biases the cells' emission probabilities with weight_proba_emission (thermal_emission.f90:1895-1899) and
+  // compensates with the packet's weight, Stokes(1) *= correct_E_emission(icell) (dust_transfer.f90:1140-1142).  The
+  // reference's generator of both arrays is commented out (thermal_emission.f90:2078-2135: they stay 1.0, :2147-2148), so
+  // there is no compensating weight to restate; a biased table with unit packet weights would be a silently biased SED.
+  if (weight_proba_emission)
+    for (int i = 0; i < n; ++i)
+      if (weight_proba_emission[i] != 1.0f)
+        return fail(ctx, MCGPU_ERR_UNSUPPORTED, "mcgpu_repartition_energie: weight_proba_emission other than 1 (lweight_emission: the "
+                                               "reference never builds such weights, thermal_emission.f90:2078-2135; the packet-weight half, "
+                                               "dust_transfer.f90:1140-1142, is not built)");
+  HIPCHK(hipSetDevice(ctx->device));
   DevBuf<float> d_T, d_w;
   DevBuf<double> d_E, d_Ec, d_tot;
   HIPCHK(hipMalloc((void**)&d_T.p, (size_t)n * sizeof(float)));

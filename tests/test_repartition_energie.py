@@ -75,7 +75,12 @@ def test_device_builder_equals_the_oracle_and_feeds_the_sed_step():
             m.l_dark_zone = dz
             o = _oracle(m, 1e5)
         e = Engine(m, 1e5)
-        wgt = np.linspace(0.5, 2.0, m.n_cells).astype(np.float32)
+        # (lweight_emission: the reference's weights are all 1 -- its generator is commented out, thermal_emission.f90:2078-2135 --
+        # and so must the engine's be: it does not apply the compensating packet weight of dust_transfer.f90:1140-1142)
+        wgt = np.ones(m.n_cells, np.float32)
+        from mcfost_amd.engine import McgpuError
+        with pytest.raises(McgpuError, match="weight_proba_emission"):
+            e.repartition_energie(2, T, weight=np.linspace(0.5, 2.0, m.n_cells).astype(np.float32))
         for lam, w, ism in ((2, None, 0.0), (m.n_lambda // 2, None, 0.0), (m.n_lambda - 1, wgt, 1e3)):
             a, b = e.repartition_energie(lam, T, E_ISM=ism, weight=w), o.repartition_energie(lam, T, E_ISM=ism, weight=w)
             assert abs(a["E_disk"] - b["E_disk"]) <= 1e-12 * b["E_disk"]
