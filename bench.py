@@ -469,6 +469,9 @@ def sed_block(par, args, steps, warmup, with_cpu, packets, observers, all_lambda
     if args.xI_precision == 4:
         for x in engs:
             x.set_xI_precision(4)
+    if args.xi_log >= 0:
+        for x in engs:
+            x.set_option("xi_log", args.xi_log)
     # (the default line runs EVERY wavelength of config 2's SED at reduced packets; --config sed the listed ones)
     lams = list(range(1, m.n_lambda + 1)) if all_lambdas else [int(x) for x in args.sed_lambdas.split(",")]
     lam_text = ("all %d wavelengths" % m.n_lambda) if all_lambdas else ("wavelengths %s" % args.sed_lambdas)
@@ -477,8 +480,12 @@ def sed_block(par, args, steps, warmup, with_cpu, packets, observers, all_lambda
     # packets in the stop bin per stream so that a step sends about `packets` packets per GPU (1 in ~11 lands there)
     n2 = max(10, int(packets / 11.0 / m.cfg.n_photons_loop / len(lams)))
 
+    xlog_tot = {"launches": 0.0, "records": 0.0, "flights": 0.0}
+
     def step(i):
         sent = 0
+        for k in xlog_tot:
+            xlog_tot[k] = 0.0
         for lam in lams:
             # repartition_energie(lambda) on the device (dust_transfer.f90:924), then the wavelength's packet loop (:939)
             if me is not None:   # ONE call per wavelength: streams split, both all-reduces inside the library
@@ -488,6 +495,8 @@ def sed_block(par, args, steps, warmup, with_cpu, packets, observers, all_lambda
                 r = eng.run_mono(lam, n2, seed=100 + i, n_chunks=count, first_chunk=first, fetch_xI=False, device_tables=td,
                                  block_threads=args.block_threads)
             sent += int(r["n_sent_chunk"].sum())
+            for k, name in (("launches", "xi_log_chunks"), ("records", "xi_log_records"), ("flights", "xi_log_flights")):
+                xlog_tot[k] += eng.get_info(name)
             if par.mode == "torchrun":   # one all-reduce of [sed | n_sent] + xI_scatt per wavelength
                 acc, cnt = eng.device_accumulators()
                 par.dist.all_reduce(acc)
@@ -534,6 +543,8 @@ def sed_block(par, args, steps, warmup, with_cpu, packets, observers, all_lambda
                          "atomic_rate_frac": line_ops_s / ATOMIC_LINE_PEAK, "atomic_line_ops_per_s": line_ops_s,
                          "kernel": "k_mono (scout + commit)", "algorithmic_bytes_per_launch": bytes_step},
         }
+        # the deposits of the last wavelength's commit passes: logged and folded (mc_xilog.hip.h), or global atomics
+        block["xi_log"] = dict(xlog_tot, of="the last step's commit passes, rank 0 (0: atomics)")
         if with_cpu:
             from oracle import Oracle
             cores = _quota_cores()
@@ -596,6 +607,8 @@ def main():
                          "fused device buffer over that world of one -- how a box with one GPU executes the one-process-per-GPU path")
     ap.add_argument("--tail", type=int, default=-1, help="tuning aid: option \"tail\" (packets left per workgroup at the hand-over to "
                     "k_tail; -1 = the library's choice)")
+    ap.add_argument("--xi-log", type=int, default=-1, help="--config sed: option \"xi_log\": 1 (default) = the commit pass logs its xI_scatt deposits "
+                    "and a fold sums them (default-real records), 0 = global atomics")
     ap.add_argument("--tail-where", type=int, default=-1, help="option \"tail_where\": 1 = k_tail finishes every packet, 2 = the library's "
                     "host threads finish the last ones (default)")
     ap.add_argument("--host-threads", type=int, default=-1, help="option \"host_threads\": host threads of a launch's tail (0 = automatic)")

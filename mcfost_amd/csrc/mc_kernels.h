@@ -36,7 +36,7 @@ const void* kpick_voro_roles(bool pola, bool mrw);
 // kern_voro_pool.hip: Voronoi grids, the pool schedule -- k_thermal_voro_pool (block = 512 / 768 / 1024)
 const void* kpick_voro_pool(bool pola, int block);
 // kern_mono.hip / kern_mono_other.hip: the SED / image Monte Carlo -- k_mono, k_mono_sph, k_mono_voro
-const void* kpick_mono(bool l3d, bool pola, bool dark, bool scout, bool f32);
+const void* kpick_mono(bool l3d, bool pola, bool dark, bool scout, bool f32, bool log = false);
 const void* kpick_mono_sph(bool l3d, bool pola, bool scout, bool f32);
 const void* kpick_mono_voro(bool pola, bool scout, bool f32);
 

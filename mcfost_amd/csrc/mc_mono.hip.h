@@ -62,6 +62,14 @@ struct MonoArgs {
   int* err;
   int inner_iters, min_active;
   int flags;  // diagnostics: bit 0 = compute the deposits but skip the atomics, bit 1 = only the I deposit
+  // the commit pass's deposits as a LOG (k_mono<..., LOG>; "The deposits as a log" below, mc_xilog.hip.h folds it)
+  unsigned int* log_keys;               // [log_cap] sub-bin index ((icell-1) n_theta_rt + psup-1) n_az_rt + phik-1, bit 31: flag_star
+  unsigned long long* log_vals;         // [log_cap] flight id | path length (default real) << 32
+  float* log_rows;                      // [rows_cap][nRT x (4 with Stokes tracking, else 1)] the flights' deposit weights
+  unsigned long long* log_ctl;          // [0] records reserved, [1] flights reserved (in blocks, by the waves)
+  unsigned long long log_cap, rows_cap;
+  unsigned int log_sentinel;            // key of an unused entry: sorts behind every sub-bin
+  unsigned long long item_lo;           // COMMIT: the launch runs the work items [item_lo, item_lo + n_items)
 };
 
 // per-lane results of angles_scatt_rt1, kept in LDS as [q][thread]
@@ -74,14 +82,17 @@ struct RtScratch {
 
 // slim = the workgroup stages only the tables the SED mode reads (lds_carve(..., mono = true)).  (The phase-function
 // column is selected by index, interact(..., lds_col): choosing between two LDS pointers there crashed hipcc 7.2.)
-__host__ __device__ inline size_t mono_lds_bytes(const DevModel& M, int nRT, int threads, bool pola, bool slim) {
+// log: the kernel that writes its deposits to the log keeps no per-lane results and no tiles (the flight's weights go
+// straight to its row in HBM)
+__host__ __device__ inline size_t mono_lds_bytes(const DevModel& M, int nRT, int threads, bool pola, bool slim, bool log = false) {
   size_t b = (lds_bytes(M, slim) + 7) / 8 * 8;
   b += (size_t)6 * (M.nang + 1) * sizeof(float);                     // the Mueller columns of p_lambda
   b = (b + 7) / 8 * 8;
-  b += (size_t)nRT * threads * (pola ? 2 * sizeof(double) : 0);      // cosw, sinw
-  b += (size_t)threads * (8 * sizeof(double) + sizeof(unsigned long long));  // deposit tiles: record + address
-  b += (size_t)nRT * threads * sizeof(int);                          // itheta
-  b += (size_t)threads * sizeof(unsigned int);                       // deposit tiles: slot mask
+  const int nsc = log ? 0 : nRT, tsc = log ? 0 : threads;
+  b += (size_t)nsc * threads * (pola ? 2 * sizeof(double) : 0);      // cosw, sinw
+  b += (size_t)tsc * (8 * sizeof(double) + sizeof(unsigned long long));  // deposit tiles: record + address
+  b += (size_t)nsc * threads * sizeof(int);                          // itheta
+  b += (size_t)tsc * sizeof(unsigned int);                           // deposit tiles: slot mask
   b = (b + 7) / 8 * 8;
   b += (size_t)3 * nRT * sizeof(double);                             // the observers' rotation constants
   return b;
@@ -93,9 +104,11 @@ __host__ __device__ inline size_t mono_lds_bytes(const DevModel& M, int nRT, int
 // RPO . Mueller . ROP . Stokes for every observer are constant, a crossing only multiplies them by its path length
 // (calc_xI_scatt_pola, dust_ray_tracing.f90:533-632, evaluated once per flight instead of once per crossing).  Four
 // default-real weights take the 16 bytes of (cosw, sinw); without Stokes tracking the one weight takes itheta's 4.
+// row != nullptr (the commit pass that LOGS its deposits): the weights go to the flight's row in HBM, [nRT][4] (Stokes
+// tracking) or [nRT] default reals, and nothing is kept in LDS.
 template <bool POLA>
 __device__ inline void angles_scatt_rt1(const DevModel& M, const MonoArgs& A, const RtScratch& R, double u,
-                                        double v, double w, const float* w_mu = nullptr, const double* S = nullptr) {
+                                        double v, double w, const float* w_mu = nullptr, const double* S = nullptr, float* row = nullptr) {
   for (int q = 0; q < A.nRT; ++q) {
     const double ur = A.rt_u[q], vr = A.rt_v[q], wr = A.rt_w[q % A.RT_n_incl];
     const float cos_scatt = (float)nd_add(nd_add(nd_mul(ur, u), nd_mul(vr, v)), nd_mul(wr, w));
@@ -116,9 +129,12 @@ __device__ inline void angles_scatt_rt1(const DevModel& M, const MonoArgs& A, co
     }
     if (k > M.nang) k = M.nang;
     if (k < 1) k = 1;
-    R.itheta[q * blockDim.x + threadIdx.x] = k;
+    if (!row) R.itheta[q * blockDim.x + threadIdx.x] = k;
 #ifndef MCGPU_LANE_EMULATION   // (the lane emulation has no default-real commit pass)
-    if (!POLA && w_mu) R.itheta[q * blockDim.x + threadIdx.x] = __float_as_int((float)(S[0] * (double)w_mu[k]));
+    if (!POLA && w_mu) {
+      const float wI = (float)(S[0] * (double)w_mu[k]);
+      if (row) row[q] = wI; else R.itheta[q * blockDim.x + threadIdx.x] = __float_as_int(wI);
+    }
 #endif
     if (POLA) {
       // rotation(u, v, w, -ur, -vr, -wr, ...) with the observer's constants from LDS (only y' and z' are needed)
@@ -138,8 +154,10 @@ __device__ inline void angles_scatt_rt1(const DevModel& M, const MonoArgs& A, co
       if (v1pk < 0.0) sinw = -sinw;
       if (fabs(cosw) < 1e-06) cosw = 0.0;
       if (fabs(sinw) < 1e-06) sinw = 0.0;
-      R.cosw[q * blockDim.x + threadIdx.x] = cosw;
-      R.sinw[q * blockDim.x + threadIdx.x] = sinw;
+      if (!row) {
+        R.cosw[q * blockDim.x + threadIdx.x] = cosw;
+        R.sinw[q * blockDim.x + threadIdx.x] = sinw;
+      }
 #ifndef MCGPU_LANE_EMULATION
       if (w_mu) {   // (the expressions of deposit_rt1_wave, without the path length)
         const int na1 = M.nang + 1;
@@ -153,10 +171,14 @@ __device__ inline void angles_scatt_rt1(const DevModel& M, const MonoArgs& A, co
         const double D2 = (double)s12 * C1 + (double)s22 * C2;
         const double D3 = (double)s33 * C3 + (double)(-s34) * C4;
         const double D4 = (double)s34 * C3 + (double)s44 * C4;
-        float2* wc = reinterpret_cast<float2*>(R.cosw) + (q * blockDim.x + threadIdx.x);
-        float2* ws = reinterpret_cast<float2*>(R.sinw) + (q * blockDim.x + threadIdx.x);
-        *wc = make_float2((float)D1, (float)((-cosw) * D2 + (-sinw) * D3));
-        *ws = make_float2((float)((-sinw) * D2 + cosw * D3), (float)D4);
+        if (row) {
+          reinterpret_cast<float4*>(row)[q] = make_float4((float)D1, (float)((-cosw) * D2 + (-sinw) * D3), (float)((-sinw) * D2 + cosw * D3), (float)D4);
+        } else {
+          float2* wc = reinterpret_cast<float2*>(R.cosw) + (q * blockDim.x + threadIdx.x);
+          float2* ws = reinterpret_cast<float2*>(R.sinw) + (q * blockDim.x + threadIdx.x);
+          *wc = make_float2((float)D1, (float)((-cosw) * D2 + (-sinw) * D3));
+          *ws = make_float2((float)((-sinw) * D2 + cosw * D3), (float)D4);
+        }
       }
 #endif
     }
@@ -546,23 +568,24 @@ struct MonoLds {
 };
 
 template <bool POLA>
-__device__ inline MonoLds mono_lds_setup(const DevModel& M, const MonoArgs& A, double* lds_base, bool slim) {
+__device__ inline MonoLds mono_lds_setup(const DevModel& M, const MonoArgs& A, double* lds_base, bool slim, bool log = false) {
   MonoLds L;
   const int na1 = M.nang + 1;
+  const size_t nsc = log ? 0 : (size_t)A.nRT, tsc = log ? 0 : (size_t)blockDim.x;   // (mono_lds_bytes)
   L.mu = reinterpret_cast<float*>(lds_base + (lds_bytes(M, slim) + 7) / 8);
   double* p = lds_base + (lds_bytes(M, slim) + 7) / 8 + ((size_t)6 * na1 * sizeof(float) + 7) / 8;
   L.R.cosw = p;
-  L.R.sinw = p + (POLA ? (size_t)A.nRT * blockDim.x : 0);
-  p += (POLA ? (size_t)2 * A.nRT * blockDim.x : 0);
-  L.tile = p + (size_t)(threadIdx.x >> 6) * 64 * XI_LINE;  // this wave's 64 x 8 doubles
-  p += (size_t)blockDim.x * XI_LINE;
-  L.tile_addr = reinterpret_cast<unsigned long long*>(p) + (size_t)(threadIdx.x >> 6) * 64;
-  p += blockDim.x;
+  L.R.sinw = p + (POLA ? nsc * blockDim.x : 0);
+  p += (POLA ? (size_t)2 * nsc * blockDim.x : 0);
+  L.tile = p + (log ? 0 : (size_t)(threadIdx.x >> 6) * 64 * XI_LINE);  // this wave's 64 x 8 doubles
+  p += tsc * XI_LINE;
+  L.tile_addr = reinterpret_cast<unsigned long long*>(p) + (log ? 0 : (size_t)(threadIdx.x >> 6) * 64);
+  p += tsc;
   L.R.itheta = reinterpret_cast<int*>(p);
-  L.tile_mask = reinterpret_cast<unsigned int*>(L.R.itheta + (size_t)A.nRT * blockDim.x) + (size_t)(threadIdx.x >> 6) * 64;
+  L.tile_mask = reinterpret_cast<unsigned int*>(L.R.itheta + nsc * blockDim.x) + (log ? 0 : (size_t)(threadIdx.x >> 6) * 64);
   {  // rotation()'s cost, sint, sing for the axis (-u_obs, -v_obs, -w_obs): the same expressions, once per observer
-    const size_t used = (size_t)((L.R.itheta + (size_t)A.nRT * blockDim.x) - reinterpret_cast<int*>(lds_base)) * sizeof(int) +
-                        (size_t)blockDim.x * sizeof(unsigned int);
+    const size_t used = (size_t)((L.R.itheta + nsc * blockDim.x) - reinterpret_cast<int*>(lds_base)) * sizeof(int) +
+                        tsc * sizeof(unsigned int);
     double* rot = lds_base + (used + 7) / 8;
     for (int q = threadIdx.x; q < A.nRT; q += blockDim.x) {
       const double u1 = -A.rt_u[q], v1 = -A.rt_v[q], w1 = -A.rt_w[q % A.RT_n_incl];
@@ -624,14 +647,74 @@ __device__ inline double mono_opacity(const Lds& T, const DevModel& M, int lambd
   return kap * M.kappa_factor[ic];
 }
 
+#ifndef MCGPU_LANE_EMULATION
+// ---- The deposits as a log (round 6) ---------------------------------------------------------------------------------
+// The commit pass's xI_scatt atomics -- nRT / 2 line operations per crossing against a chip-wide ceiling of 2.4e10 a
+// second -- were 99 % of BASELINE config 2's wall time.  k_mono<..., LOG> makes none: a crossing appends ONE 12-byte record
+// (sub-bin | flag_star, flight id, path length) and a flight, once, the row of its nRT x 4 default-real deposit weights
+// (what angles_scatt_rt1 computes per flight anyway); mc_xilog.hip.h sorts the records by sub-bin and sums each sub-bin's
+// consecutive records in registers -- 2.4x the atomics' rate standalone (tools/xi_fold_bench.hip), and the transport
+// kernel loses its per-lane LDS scratch, its staging tiles and its waits.  A wave reserves log space in blocks (one
+// global atomic per 2048 records / 256 flights, not per crossing) and fills what it leaves unused with a key that sorts last.
+constexpr unsigned int XLOG_REC_BLOCK = 2048;
+constexpr unsigned int XLOG_FL_BLOCK = 256;
+struct XiLogCursor { unsigned long long rec_next, rec_end, fl_next, fl_end; };   // (wave-uniform)
+
+__device__ inline void xlog_pad(const MonoArgs& A, unsigned long long from, unsigned long long to, int lane) {
+  for (unsigned long long i = from + (unsigned long long)lane; i < to; i += 64ull)
+    if (i < A.log_cap) A.log_keys[i] = A.log_sentinel;
+}
+
+// a flight id for every lane with `want` (call with the whole wave)
+__device__ inline unsigned long long xlog_flights(const MonoArgs& A, XiLogCursor& C, bool want, int lane) {
+  const unsigned long long m = __ballot(want);
+  if (!m) return 0ull;
+  const unsigned long long n = (unsigned long long)__popcll(m);
+  if (C.fl_next + n > C.fl_end) {
+    unsigned long long base = 0ull;
+    if (lane == 0) base = atomicAdd(&A.log_ctl[1], (unsigned long long)XLOG_FL_BLOCK);
+    base = __shfl(base, 0);
+    C.fl_next = base; C.fl_end = base + XLOG_FL_BLOCK;
+    if (C.fl_end > A.rows_cap && lane == 0) *A.err = 18;   // (the host sizes a launch for its flights: see xi_log_commit)
+  }
+  const unsigned long long id = C.fl_next + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
+  C.fl_next += n;
+  return id;
+}
+
+// one record per lane with `on` (call with the whole wave)
+__device__ inline void xlog_append(const MonoArgs& A, XiLogCursor& C, bool on, unsigned int key, unsigned int fid, float l, int lane) {
+  const unsigned long long m = __ballot(on);
+  if (!m) return;
+  const unsigned long long n = (unsigned long long)__popcll(m);
+  if (C.rec_next + n > C.rec_end) {
+    xlog_pad(A, C.rec_next, C.rec_end, lane);
+    unsigned long long base = 0ull;
+    if (lane == 0) base = atomicAdd(&A.log_ctl[0], (unsigned long long)XLOG_REC_BLOCK);
+    base = __shfl(base, 0);
+    C.rec_next = base; C.rec_end = base + XLOG_REC_BLOCK;
+    if (C.rec_end > A.log_cap && lane == 0) *A.err = 18;
+  }
+  if (on) {
+    const unsigned long long at = C.rec_next + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
+    if (at < A.log_cap) {
+      A.log_keys[at] = key;
+      A.log_vals[at] = (unsigned long long)fid | ((unsigned long long)__float_as_uint(l) << 32);
+    }
+  }
+  C.rec_next += n;
+}
+#endif
+
 // SCOUT: no deposits, no SED; records hits.  Otherwise the COMMIT pass.
 // SPH: the grid operators of spherical_grid.f90 (as thermal_body has them)
-template <bool L3D, bool POLA, bool DARK, bool SCOUT, bool F32 = false, bool SPH = false>
+// LOG (with F32, one dust class): the deposits go to the log instead of xI_scatt (see "The deposits as a log")
+template <bool L3D, bool POLA, bool DARK, bool SCOUT, bool F32 = false, bool SPH = false, bool LOG = false>
 __device__ __forceinline__ void mono_body(const DevModel& M, const MonoArgs& A, double* lds_base) {
   const Lds T = lds_carve(lds_base, M, true);
   lds_stage_mono(T, M, A.p_lambda);
   const int na1 = M.nang + 1;
-  const MonoLds ML = mono_lds_setup<POLA>(M, A, lds_base, true);
+  const MonoLds ML = mono_lds_setup<POLA>(M, A, lds_base, true, LOG);
   const float* mu = ML.mu;
   const RtScratch& R = ML.R;
   double* const tile = ML.tile;
@@ -657,6 +740,11 @@ __device__ __forceinline__ void mono_body(const DevModel& M, const MonoArgs& A, 
   float tau_rand = 0.0f;
   double kf = 0.0;  // opacity of the packet's cell (mono_opacity)
   const bool var = M.n_classes != 0;
+#ifndef MCGPU_LANE_EMULATION
+  XiLogCursor LC = {0ull, 0ull, 0ull, 0ull};
+  unsigned int my_fid = 0u;
+  const size_t row_floats = (size_t)A.nRT * (POLA ? 4 : 1);
+#endif
 
   for (;;) {
     if (st == S_EXITED) {  // capteur (dust_transfer.f90:549-552); forced scattering never clears flag_ISM
@@ -694,9 +782,9 @@ __device__ __forceinline__ void mono_body(const DevModel& M, const MonoArgs& A, 
         pk_next += (cnt < avail) ? cnt : avail;
         if (served) {
           // work item -> (stream, sequence number)
-          my_item = my;
+          my_item = my + (SCOUT ? 0ull : A.item_lo);
           unsigned long long chunk, seq;
-          mono_item<SCOUT>(A, my, chunk, seq);
+          mono_item<SCOUT>(A, my_item, chunk, seq);
           rng.init(A.seed, ((chunk + (unsigned long long)A.first_chunk) << 40) | seq);
           c_pack++;
           pk_cross = 0;
@@ -749,12 +837,22 @@ __device__ __forceinline__ void mono_body(const DevModel& M, const MonoArgs& A, 
       }
     }
 
+#ifndef MCGPU_LANE_EMULATION
+    unsigned long long fid_new = 0ull;
+    if (LOG && !SCOUT) fid_new = xlog_flights(A, LC, st == S_NEWFLIGHT && A.rt1, lane);
+#endif
     if (st == S_NEWFLIGHT) {
       const float rand = tau_rand;
       extr = tau_of_draw(rand);
       const double a = u * u + v * v;
       inv_a = (a > TINY_REAL) ? 1.0 / a : HUGE_REAL;
       inv_w = (fabs(w) > TINY_REAL) ? 1.0 / w : copysign(HUGE_DP, w);
+#ifndef MCGPU_LANE_EMULATION
+      if (LOG && !SCOUT && A.rt1) {   // the flight's deposit weights -> its row of the log
+        my_fid = (unsigned int)fid_new;
+        angles_scatt_rt1<POLA>(M, A, R, u, v, w, mu, S, A.log_rows + (fid_new < A.rows_cap ? fid_new : 0ull) * row_floats);
+      } else
+#endif
       if (!SCOUT && A.rt1) angles_scatt_rt1<POLA>(M, A, R, u, v, w, (F32 && !var) ? mu : nullptr, S);  // optical_depth.f90:65
       const int i_star = intersect_stars(M, x, y, z, u, v, w);
       star_key = -1;
@@ -863,13 +961,19 @@ __device__ __forceinline__ void mono_body(const DevModel& M, const MonoArgs& A, 
       if (!SCOUT && A.rt1 && __ballot(dep.on) != 0ull)
       {
 #ifndef MCGPU_LANE_EMULATION
-        if constexpr (F32) deposit_rt1_wave_f32<POLA>(M, A, R, mu, dep, S, flag_star, tile, tile_addr, tile_mask);
+        if constexpr (LOG) {
+          const unsigned int bin = (unsigned int)((((size_t)(dep.icell - 1) * A.n_theta_rt + (dep.psup - 1)) * A.n_az_rt) + (dep.phik - 1));
+          xlog_append(A, LC, dep.on, bin | (flag_star ? 0x80000000u : 0u), my_fid, (float)dep.l, lane);
+        } else if constexpr (F32) deposit_rt1_wave_f32<POLA>(M, A, R, mu, dep, S, flag_star, tile, tile_addr, tile_mask);
         else
 #endif
         deposit_rt1_wave<POLA>(M, A, R, mu, dep, S, flag_star, tile, tile_addr, tile_mask);
       }
     }
   }
+#ifndef MCGPU_LANE_EMULATION
+  if (LOG && !SCOUT) xlog_pad(A, LC.rec_next, LC.rec_end, lane);   // (what the wave reserved and did not use sorts behind the records)
+#endif
 
   if (!SCOUT) {
     unsigned int cs[8] = {c_pack, c_cross, c_flight, c_scatt, c_abs, c_esc, c_kill, c_dark};
@@ -885,10 +989,10 @@ __device__ __forceinline__ void mono_body(const DevModel& M, const MonoArgs& A, 
   }
 }
 
-template <bool L3D, bool POLA, bool DARK, bool SCOUT, bool F32 = false>
+template <bool L3D, bool POLA, bool DARK, bool SCOUT, bool F32 = false, bool LOG = false>
 __global__ void __launch_bounds__(512) k_mono(const DevModel M, const MonoArgs A) {
   extern __shared__ double lds_raw[];
-  mono_body<L3D, POLA, DARK, SCOUT, F32>(M, A, lds_raw);
+  mono_body<L3D, POLA, DARK, SCOUT, F32, false, LOG>(M, A, lds_raw);
 }
 
 // ... on a spherical grid (no dark zone there)

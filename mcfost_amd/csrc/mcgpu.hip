@@ -31,6 +31,7 @@
 #include "mc_rt2.hip.h"
 #include "mc_kernels.h"
 #include "host_tail.h"
+#include "mc_xilog.hip.h"
 
 using namespace mcgpu;
 
@@ -173,6 +174,18 @@ struct mcgpu_ctx {
   int mono_chunks = 0;
   unsigned char* d_hits = nullptr;
   size_t hits_cap = 0;
+  // the SED commit pass's deposit log (mc_mono.hip.h "The deposits as a log", mc_xilog.hip.h)
+  int opt_xi_log = 1;               // 1 (default): default-real xI_scatt of one dust class on a cylindrical grid is summed from a log
+                                    // where a wavelength's flights are long enough for that to pay; 0: atomics; 2: the log always
+  unsigned int* d_xlog_keys[2] = {nullptr, nullptr};       // [0]: the launch's log; [1]: the sorted copy
+  unsigned long long* d_xlog_vals[2] = {nullptr, nullptr};
+  float* d_xlog_rows = nullptr;
+  unsigned long long* d_xlog_ctl = nullptr;     // [0] records, [1] flights the launch's waves reserved
+  size_t xlog_cap = 0, xlog_rows_cap = 0, xlog_row_floats = 0;
+  void* d_xlog_temp = nullptr;
+  size_t xlog_temp_bytes = 0;
+  int xlog_chunks = 0;              // launches of the last wavelength's commit passes
+  unsigned long long xlog_records = 0, xlog_flights = 0;   // ... and what they logged
   // Voronoi grid (mc_voronoi.hip.h)
   bool voro = false;
   VoroGrid V;
@@ -284,6 +297,10 @@ extern "C" int mcgpu_destroy(mcgpu_ctx* ctx) {
   if (ctx->d_hits) hipFree(ctx->d_hits);
   if (ctx->d_pool) hipFree(ctx->d_pool);
   if (ctx->d_pool_blob) hipFree(ctx->d_pool_blob);
+  for (int i = 0; i < 2; ++i) { if (ctx->d_xlog_keys[i]) hipFree(ctx->d_xlog_keys[i]); if (ctx->d_xlog_vals[i]) hipFree(ctx->d_xlog_vals[i]); }
+  if (ctx->d_xlog_rows) hipFree(ctx->d_xlog_rows);
+  if (ctx->d_xlog_ctl) hipFree(ctx->d_xlog_ctl);
+  if (ctx->d_xlog_temp) hipFree(ctx->d_xlog_temp);
   if (ctx->d_tail_ctl) hipFree(ctx->d_tail_ctl);
   if (ctx->d_tail_out) hipFree(ctx->d_tail_out);
   if (ctx->h_arena) hipHostFree(ctx->h_arena);
@@ -553,6 +570,7 @@ extern "C" int mcgpu_set_option(mcgpu_ctx* ctx, const char* name, int value) {
   if (!ctx || !name) return MCGPU_ERR_ARG;
   if (!strcmp(name, "deposit")) { if (value < 0 || value > 3) return fail(ctx, MCGPU_ERR_ARG, "deposit: 0, 1, 2 or 3"); ctx->opt_deposit = value; }
   else if (!strcmp(name, "tail")) { if (value < -1 || value > (1 << 20)) return fail(ctx, MCGPU_ERR_ARG, "tail: -1 (automatic), 0 (off), or the packets left per workgroup at the hand-over"); ctx->opt_tail = value; }
+  else if (!strcmp(name, "xi_log")) { if (value < 0 || value > 2) return fail(ctx, MCGPU_ERR_ARG, "xi_log: 0, 1 or 2"); ctx->opt_xi_log = value; }
   else if (!strcmp(name, "tail_where")) { if (value < 0 || value > 2) return fail(ctx, MCGPU_ERR_ARG, "tail_where: 0 (automatic), 1 (device), 2 (host)"); ctx->opt_tail_where = value; }
   else if (!strcmp(name, "host_threads")) { if (value < 0 || value > 256) return fail(ctx, MCGPU_ERR_ARG, "host_threads: 0 (automatic) .. 256"); ctx->opt_host_threads = value; }
   else if (!strcmp(name, "tail_host_packets")) { if (value < 0 || value > 65536) return fail(ctx, MCGPU_ERR_ARG, "tail_host_packets: 0 (automatic) .. 65536"); ctx->opt_tail_host_max = value; }
@@ -625,6 +643,9 @@ extern "C" int mcgpu_get_info(mcgpu_ctx* ctx, const char* name, double* value) {
       else return fail(ctx, MCGPU_ERR_ARG, "mcgpu_get_info: unknown name");
     }
   }
+  else if (!strcmp(name, "xi_log_chunks")) *value = ctx->xlog_chunks;     // the last mcgpu_run_mono: launches of its commit passes,
+  else if (!strcmp(name, "xi_log_records")) *value = (double)ctx->xlog_records;   // records (crossings with a deposit) and
+  else if (!strcmp(name, "xi_log_flights")) *value = (double)ctx->xlog_flights;   // flights they logged (0: atomics)
   else if (!strcmp(name, "tau_midplane")) *value = ctx->tau_midplane;
   else if (!strcmp(name, "bin_overflow_blocks") || !strcmp(name, "bin_drained_records")) {
     unsigned long long st[2] = {0ull, 0ull};
@@ -2270,7 +2291,7 @@ extern "C" int mcgpu_set_rt1(mcgpu_ctx* ctx, int RT_n_incl, int RT_n_az, const d
 }
 
 template <bool SCOUT>
-static int launch_mono(mcgpu_ctx* ctx, const MonoArgs& A, int grid_blocks, int block_threads) {
+static int launch_mono(mcgpu_ctx* ctx, const MonoArgs& A, int grid_blocks, int block_threads, bool log = false) {
   const DevModel& M = ctx->M;
   const bool pola = ctx->lsepar_pola != 0, dark = M.dark != nullptr, l3d = M.l3D != 0;
   const void* fn;
@@ -2279,12 +2300,13 @@ static int launch_mono(mcgpu_ctx* ctx, const MonoArgs& A, int grid_blocks, int b
   const bool f32 = kCommit && A.rt1 && ctx->xI_bytes == 4;
   if (ctx->voro) fn = kpick_mono_voro(pola, SCOUT, f32);
   else if (M.grid_sph) fn = kpick_mono_sph(l3d, pola, SCOUT, f32);
-  else fn = kpick_mono(l3d, pola, dark, SCOUT, f32);
+  else fn = kpick_mono(l3d, pola, dark, SCOUT, f32, log);
   // workgroup size: the one that keeps the most wavefronts on a CU, up to 8 (2 per SIMD).  The r02 build needs only
   // 101-169 VGPRs here, so the registers would admit 3-4 waves per SIMD -- measured slower (bench sed 4.03e7 against
   // 4.87e7 packets/s): this mode is bound by the xI_scatt atomics, and more waves in flight only deepen their queues.
   // The LDS of a workgroup is the shared tables plus the per-lane ray-tracing scratch, which grows with the observers.
-  const int cu_threads = 512;
+  // (the kernel that logs its deposits makes no atomics, needs 146 VGPRs and almost no LDS: three waves per SIMD)
+  const int cu_threads = log ? 768 : 512;
   int threads = 0;
   const bool slim = true;                   // (mono_lds_bytes)
   const int max_threads = 512;              // (__launch_bounds__ of the kernels)
@@ -2292,8 +2314,8 @@ static int launch_mono(mcgpu_ctx* ctx, const MonoArgs& A, int grid_blocks, int b
     threads = block_threads;
   } else {
     int best_waves = 0;
-    for (int th = max_threads; th >= 64; th -= 64) {
-      const size_t l = mono_lds_bytes(M, A.nRT, th, pola, slim);
+    for (int th = log ? 256 : max_threads; th >= 64; th -= 64) {
+      const size_t l = mono_lds_bytes(M, A.nRT, th, pola, slim, log);
       if (l > 160 * 1024) continue;
       int per_cu = (int)((160 * 1024) / l);
       if (per_cu > cu_threads / th) per_cu = cu_threads / th;
@@ -2302,7 +2324,7 @@ static int launch_mono(mcgpu_ctx* ctx, const MonoArgs& A, int grid_blocks, int b
     }
     if (!threads) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "too many ray-tracing directions for the LDS of one CU");
   }
-  const size_t lds = mono_lds_bytes(M, A.nRT, threads, pola, slim);
+  const size_t lds = mono_lds_bytes(M, A.nRT, threads, pola, slim, log);
   if (lds > 160 * 1024) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "too many ray-tracing directions for the LDS of one CU");
   HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int blocks = grid_blocks;
@@ -2515,6 +2537,120 @@ extern "C" int mcgpu_rt2_source(mcgpu_ctx* ctx, const mcgpu_rt_opts* o, int p_la
   return MCGPU_OK;
 }
 
+// ---- the commit pass with its deposits as a log (mc_mono.hip.h "The deposits as a log"; mc_xilog.hip.h) ---------------
+// Does this context's commit pass log its xI_scatt deposits?  (Default-real records, one dust class, cylindrical grid.)
+static bool xi_log_applicable(const mcgpu_ctx* ctx, bool rt1) {
+  const DevModel& M = ctx->M;
+  return rt1 && ctx->opt_xi_log != 0 && ctx->xI_bytes == 4 && !M.n_classes && !ctx->voro && !M.grid_sph;
+}
+
+// The log's buffers: the launch's records and its flights' rows, the sorted copy of the records, the sort's scratch.
+// Sized for launches of up to 2^28 records / 2^26 flights (2 x 3.2 + 10.7 GB with ten observers and Stokes tracking), less
+// for a run that cannot fill them; a wavelength's commit pass runs in as many launches as that takes.
+// (Measured and dropped, profiles/r06_xi_log_ab.log: two buffer sets with the sort and the fold of launch i on a second
+// stream under launch i + 1's transport -- the persistent transport kernel leaves them a wave per SIMD, the sort ran 4x
+// slower, and the sum stayed what it was.)
+static int xi_log_prepare(mcgpu_ctx* ctx, unsigned long long n_items, int nRT, bool pola) {
+  const size_t row_floats = (size_t)nRT * (pola ? 4 : 1);
+  size_t cap = (size_t)1 << 28, rows = (size_t)1 << 26;
+  // (a run of few packets -- the tests' -- does not need gigabytes: ~4096 crossings and 1024 flights per packet are provided for)
+  while (cap > ((size_t)1 << 22) && (double)cap > 4096.0 * (double)n_items + 8.0e6) cap >>= 1;
+  while (rows > ((size_t)1 << 20) && (double)rows > 1024.0 * (double)n_items + 2.0e6) rows >>= 1;
+  if (ctx->xlog_cap >= cap && ctx->xlog_rows_cap >= rows && ctx->xlog_row_floats == row_floats) return MCGPU_OK;
+  if (ctx->xlog_cap > cap) cap = ctx->xlog_cap;
+  if (ctx->xlog_rows_cap > rows && ctx->xlog_row_floats == row_floats) rows = ctx->xlog_rows_cap;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < 2; ++i) {
+    if (ctx->d_xlog_keys[i]) hipFree(ctx->d_xlog_keys[i]);
+    if (ctx->d_xlog_vals[i]) hipFree(ctx->d_xlog_vals[i]);
+    ctx->d_xlog_keys[i] = nullptr; ctx->d_xlog_vals[i] = nullptr;
+  }
+  if (ctx->d_xlog_rows) hipFree(ctx->d_xlog_rows);
+  if (ctx->d_xlog_temp) hipFree(ctx->d_xlog_temp);
+  ctx->d_xlog_rows = nullptr; ctx->d_xlog_temp = nullptr; ctx->xlog_cap = 0; ctx->xlog_rows_cap = 0;
+  for (int i = 0; i < 2; ++i) {   // [0]: the launch's log; [1]: the sorted copy
+    HIPCHK(hipMalloc((void**)&ctx->d_xlog_keys[i], cap * sizeof(unsigned int)));
+    HIPCHK(hipMalloc((void**)&ctx->d_xlog_vals[i], cap * sizeof(unsigned long long)));
+  }
+  HIPCHK(hipMalloc((void**)&ctx->d_xlog_rows, rows * row_floats * sizeof(float)));
+  if (!ctx->d_xlog_ctl) HIPCHK(hipMalloc((void**)&ctx->d_xlog_ctl, 2 * sizeof(unsigned long long)));
+  ctx->xlog_temp_bytes = xi_sort_temp_bytes(cap, 31);
+  HIPCHK(hipMalloc(&ctx->d_xlog_temp, ctx->xlog_temp_bytes ? ctx->xlog_temp_bytes : 16));
+  ctx->xlog_cap = cap; ctx->xlog_rows_cap = rows; ctx->xlog_row_floats = row_floats;
+  return MCGPU_OK;
+}
+
+// Below this many logged crossings per flight the commit pass deposits with atomics: a flight costs its row -- 160 bytes
+// written once and gathered once per crossing -- whatever its length, and a wavelength at which packets scatter every second
+// cell (ref4.1 at 1 um: 2.2 crossings per flight) pays more for the rows than the atomics cost (1.70 against 1.42 s), while
+// one of long flights (36 per flight at 60 um: 0.36 against 0.47 s) does not.
+constexpr double XI_LOG_MIN_CROSSINGS_PER_FLIGHT = 4.5;
+
+// One commit pass (the work items [0, A.n_items) of `A`): plainly, or -- `*mode` = 1: with its deposits logged, in launches
+// sized for the log, each followed by the sort and the fold of what it logged.  The first launch is short and measures
+// records and flights per packet; the others take what 70 % of the buffers hold at that rate -- or, where the flights
+// turn out too short for the log to pay, the rest of the pass (and of the call: *mode = 2) runs with atomics.
+static int commit_mono(mcgpu_ctx* ctx, MonoArgs A, int grid_blocks, int block_threads, int* mode) {
+  if (*mode != 1) return launch_mono<false>(ctx, A, grid_blocks, block_threads);
+  const DevModel& M = ctx->M;
+  const bool pola = ctx->lsepar_pola != 0;
+  const unsigned long long n_total = A.n_items;
+  int rc = xi_log_prepare(ctx, n_total, A.nRT, pola);
+  if (rc) return rc;
+  const unsigned int n_bins = (unsigned int)((size_t)M.n_cells * A.n_theta_rt * A.n_az_rt);
+  int end_bit = 1;
+  while (end_bit < 31 && (1u << end_bit) <= n_bins) ++end_bit;   // the unused entries' key, 2^end_bit - 1 >= n_bins, sorts last
+  if ((1u << end_bit) - 1u < n_bins) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "xI log: too many sub-bins for a 31-bit key");
+  A.log_keys = ctx->d_xlog_keys[0]; A.log_vals = ctx->d_xlog_vals[0]; A.log_rows = ctx->d_xlog_rows; A.log_ctl = ctx->d_xlog_ctl;
+  A.log_cap = ctx->xlog_cap; A.rows_cap = ctx->xlog_rows_cap; A.log_sentinel = (1u << end_bit) - 1u;
+  const int nv = pola ? 4 : 1;
+  const int slot_star = pola ? 5 : 2, slot_thermal = pola ? 7 : 4;   // (deposit_rt1_wave's cslot)
+  // (the first launch: room for 1024 records and 256 flights per packet -- ref4.1 has 60-160 and 2-60, by wavelength)
+  unsigned long long done = 0, chunk = 1000000ull;
+  if (chunk > ctx->xlog_cap / 1024) chunk = ctx->xlog_cap / 1024;
+  if (chunk > ctx->xlog_rows_cap / 256) chunk = ctx->xlog_rows_cap / 256;
+  double rpp = 0.0, fpp = 0.0;   // records / flights reserved per packet, as measured
+  while (done < n_total) {
+    if (rpp > 0.0) {
+      double c = 0.7 * (double)ctx->xlog_cap / rpp;
+      if (fpp > 0.0 && 0.7 * (double)ctx->xlog_rows_cap / fpp < c) c = 0.7 * (double)ctx->xlog_rows_cap / fpp;
+      chunk = c < 1024.0 ? 1024ull : (unsigned long long)c;
+    }
+    const unsigned long long c = chunk < n_total - done ? chunk : n_total - done;
+    HIPCHK(hipMemsetAsync(ctx->d_xlog_ctl, 0, 2 * sizeof(unsigned long long), ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_counters + WORK_SLOT, 0, sizeof(unsigned long long), ctx->stream));
+    A.item_lo = done; A.n_items = c;
+    if ((rc = launch_mono<false>(ctx, A, grid_blocks, block_threads, true))) return rc;
+    unsigned long long ctl[2] = {0ull, 0ull};
+    int dev_err = 0;
+    HIPCHK(hipMemcpyAsync(ctl, ctx->d_xlog_ctl, sizeof(ctl), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(&dev_err, ctx->d_err, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));   // (the host needs the record count for the sort)
+    if (dev_err == 18 || ctl[0] > ctx->xlog_cap || ctl[1] > ctx->xlog_rows_cap) {
+      ctx->err = "xI log: a launch of " + std::to_string(c) + " packets logged " + std::to_string(ctl[0]) + " records and " + std::to_string(ctl[1]) +
+                 " flights, more than the buffers hold (" + std::to_string(ctx->xlog_cap) + ", " + std::to_string(ctx->xlog_rows_cap) +
+                 "): mcgpu_set_option(ctx, \"xi_log\", 0) runs this model with atomics";
+      return MCGPU_ERR_KERNEL;
+    }
+    if (dev_err) { ctx->err = "device error " + std::to_string(dev_err) + " in the commit pass"; return MCGPU_ERR_KERNEL; }
+    const int e = xi_sort_fold(ctx->stream, ctx->d_xlog_keys[0], ctx->d_xlog_vals[0], ctx->d_xlog_keys[1], ctx->d_xlog_vals[1], (size_t)ctl[0],
+                               end_bit, ctx->d_xlog_temp, ctx->xlog_temp_bytes, ctx->d_xlog_rows, A.nRT, nv, A.contrib, slot_star, slot_thermal,
+                               n_bins, reinterpret_cast<float*>(ctx->d_xI), A.nRT_pad);
+    if (e != (int)hipSuccess) { ctx->err = std::string("xI log: sort / fold: ") + hipGetErrorString((hipError_t)e); return MCGPU_ERR_HIP; }
+    rpp = (double)ctl[0] / (double)c; fpp = (double)ctl[1] / (double)c;
+    ctx->xlog_chunks++; ctx->xlog_records += ctl[0]; ctx->xlog_flights += ctl[1];
+    done += c;
+    if (ctx->opt_xi_log == 1 && done < n_total && ctl[1] > 0 && (double)ctl[0] / (double)ctl[1] < XI_LOG_MIN_CROSSINGS_PER_FLIGHT) {
+      *mode = 2;   // short flights: the rest with atomics (the sums do not care who adds them)
+      A.item_lo = done; A.n_items = n_total - done;
+      A.log_keys = nullptr; A.log_vals = nullptr; A.log_rows = nullptr; A.log_ctl = nullptr;
+      HIPCHK(hipMemsetAsync(ctx->d_counters + WORK_SLOT, 0, sizeof(unsigned long long), ctx->stream));
+      return launch_mono<false>(ctx, A, grid_blocks, block_threads);
+    }
+  }
+  return MCGPU_OK;
+}
+
 extern "C" int mcgpu_run_mono(mcgpu_ctx* ctx, const mcgpu_mono_opts* o, double frac_E_stars, double frac_E_disk,
                               const double* prob_E_cell, uint64_t* n_sent_chunk, double* kernel_ms) {
   int rc = ready(ctx);
@@ -2609,6 +2745,8 @@ extern "C" int mcgpu_run_mono(mcgpu_ctx* ctx, const mcgpu_mono_opts* o, double f
   A.inner_iters = tune("MCGPU_INNER_ITERS", 64, 1, 4096);
   A.min_active = tune("MCGPU_MIN_ACTIVE", 32, 0, 64);
   A.flags = tune("MCGPU_DIAG_FLAGS", 0, 0, 255);  // (diagnostic builds only)
+  int xlog_mode = xi_log_applicable(ctx, rt1) ? 1 : 0;   // 1: the commit passes log their xI_scatt deposits (mc_xilog.hip.h folds them)
+  ctx->xlog_chunks = 0; ctx->xlog_records = 0; ctx->xlog_flights = 0;
 
   // ---- SCOUT: find every stream's stopping index (dust_transfer.f90:526-553) ----------------
   double lim_d = std::ceil((double)o->n_phot_lim);
@@ -2706,7 +2844,7 @@ restart:
         HIPCHK(hipMemsetAsync(ctx->d_counters + WORK_SLOT, 0, sizeof(unsigned long long), ctx->stream));
         A.item_base = d_base; A.n_items = base[nc]; A.active = nullptr; A.seq0 = nullptr; A.hits = nullptr; A.batch = 0;
         A.hit_count = d_hitcnt;
-        if ((rc = launch_mono<false>(ctx, A, o->grid_blocks, o->block_threads))) return rc;
+        if ((rc = commit_mono(ctx, A, o->grid_blocks, o->block_threads, &xlog_mode))) return rc;
         A.hit_count = nullptr;
         std::vector<unsigned long long> hc(nc);
         HIPCHK(hipMemcpyAsync(hc.data(), d_hitcnt, nc * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
@@ -2743,7 +2881,7 @@ restart:
   HIPCHK(hipMemcpyAsync(d_start, start.data(), nc * sizeof(unsigned long long), hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->d_counters + WORK_SLOT, 0, sizeof(unsigned long long), ctx->stream));
   A.item_base = d_base; A.n_items = base[nc]; A.active = nullptr; A.seq0 = d_start; A.hits = nullptr; A.batch = 0;
-  if (A.n_items > 0 && (rc = launch_mono<false>(ctx, A, o->grid_blocks, o->block_threads))) return rc;
+  if (A.n_items > 0 && (rc = commit_mono(ctx, A, o->grid_blocks, o->block_threads, &xlog_mode))) return rc;
   HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
   ctx->launched = true;
   if ((rc = mcgpu_sync(ctx, kernel_ms))) return rc;

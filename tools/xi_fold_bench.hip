@@ -26,6 +26,9 @@ constexpr int Q_STRIDE = 9;                         // floats per (bin, observer
 constexpr int BIN_STRIDE = NRT * Q_STRIDE + 1;      // 91 floats per bin in LDS (odd: bins spread over the banks)
 constexpr int SLICE_BINS = 352;                     // bins a fold workgroup owns: 352 x 91 x 4 = 128 KB of LDS
 constexpr int FOLD_THREADS = 640;                   // 64 records x 10 observers per pass
+#ifndef FOLD_UNROLL
+#define FOLD_UNROLL 4
+#endif
 
 #define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
@@ -111,25 +114,41 @@ __global__ void k_atomics(const uint32_t* keys, const uint2* vals, unsigned long
 }
 
 // ---- B: fold.  offs[b] .. offs[b + 1]: the sorted records of slice b (bins b * SLICE_BINS ...) -----------------------------
-__global__ void __launch_bounds__(FOLD_THREADS) k_fold(const uint32_t* keys, const uint2* vals, const unsigned long long* offs,
+struct FoldItem { unsigned long long r_lo, r_hi; int slice, shared; };   // shared: the slice is folded by several workgroups
+
+__global__ void __launch_bounds__(FOLD_THREADS) k_fold(const uint32_t* keys, const uint2* vals, const FoldItem* items,
                                                       const float4* rows, float* xI) {
   extern __shared__ float acc[];   // [SLICE_BINS][BIN_STRIDE]
-  const int b = blockIdx.x;
+  const FoldItem it = items[blockIdx.x];
+  const int b = it.slice;
   for (int i = threadIdx.x; i < SLICE_BINS * BIN_STRIDE; i += blockDim.x) acc[i] = 0.0f;
   __syncthreads();
-  const unsigned long long r_lo = offs[b], r_hi = offs[b + 1];
+  const unsigned long long r_lo = it.r_lo, r_hi = it.r_hi;
   const int q = threadIdx.x % NRT, rr = threadIdx.x / NRT;   // 64 records per pass, 10 threads each
   const uint32_t bin0 = (uint32_t)b * SLICE_BINS;
-  for (unsigned long long r0 = r_lo; r0 < r_hi; r0 += FOLD_THREADS / NRT) {
-    const unsigned long long r = r0 + rr;
-    if (r < r_hi) {
-      const uint32_t key = keys[r];
-      const uint2 v = vals[r];
-      const float l = __uint_as_float(v.y);
-      const float4 w = rows[(size_t)v.x * NRT + q];
-      float* a = acc + (size_t)((key & 0x7FFFFFFFu) - bin0) * BIN_STRIDE + q * Q_STRIDE;
-      atomicAdd(a + 0, l * w.x); atomicAdd(a + 1, l * w.y); atomicAdd(a + 2, l * w.z); atomicAdd(a + 3, l * w.w);
-      atomicAdd(a + ((key >> 31) ? 5 : 7), l * w.x);
+  // (FOLD_UNROLL records per thread in flight: the row gather is a dependent load behind the record's -- one at a time it
+  // runs at the latency of HBM, not at its bandwidth)
+  constexpr int PER_PASS = FOLD_THREADS / NRT;
+  for (unsigned long long r0 = r_lo; r0 < r_hi; r0 += (unsigned long long)PER_PASS * FOLD_UNROLL) {
+    uint32_t key[FOLD_UNROLL];
+    uint2 v[FOLD_UNROLL];
+    float4 w[FOLD_UNROLL];
+#pragma unroll
+    for (int t = 0; t < FOLD_UNROLL; ++t) {
+      const unsigned long long r = r0 + (unsigned long long)t * PER_PASS + rr;
+      const bool ok = r < r_hi;
+      key[t] = ok ? keys[r] : 0xFFFFFFFFu;
+      v[t] = ok ? vals[r] : make_uint2(0u, 0u);
+    }
+#pragma unroll
+    for (int t = 0; t < FOLD_UNROLL; ++t) w[t] = rows[(size_t)v[t].x * NRT + q];
+#pragma unroll
+    for (int t = 0; t < FOLD_UNROLL; ++t) {
+      if (key[t] == 0xFFFFFFFFu) continue;
+      const float l = __uint_as_float(v[t].y);
+      float* a = acc + (size_t)((key[t] & 0x7FFFFFFFu) - bin0) * BIN_STRIDE + q * Q_STRIDE;
+      atomicAdd(a + 0, l * w[t].x); atomicAdd(a + 1, l * w[t].y); atomicAdd(a + 2, l * w[t].z); atomicAdd(a + 3, l * w[t].w);
+      atomicAdd(a + ((key[t] >> 31) ? 5 : 7), l * w[t].x);
     }
   }
   __syncthreads();
@@ -138,8 +157,63 @@ __global__ void __launch_bounds__(FOLD_THREADS) k_fold(const uint32_t* keys, con
   for (int i = threadIdx.x; i < n_bins * NRT * XI_LINE; i += blockDim.x) {
     const int bl = i / (NRT * XI_LINE), rem = i - bl * NRT * XI_LINE, qq = rem / XI_LINE, s = rem - qq * XI_LINE;
     const float v = acc[(size_t)bl * BIN_STRIDE + qq * Q_STRIDE + s];
-    if (v != 0.0f) xI[((size_t)(bin0 + bl) * NRT + qq) * XI_LINE + s] += v;
+    if (v != 0.0f) {
+      float* dst = xI + ((size_t)(bin0 + bl) * NRT + qq) * XI_LINE + s;
+      if (it.shared) atomicAdd(dst, v); else *dst += v;   // (8 neighbouring lanes = one 32-byte record: one line operation)
+    }
   }
+}
+
+
+// ---- C: segmented sums.  The records are sorted by bin, so the records of one bin are consecutive: a wave walks a chunk of
+// records with the 4 Stokes weights of the 10 observers in 40 lanes (and the copy of I per observer in 10 more), one
+// coalesced 160-byte row load and ONE multiply-add per lane and record, sums in registers while the bin stays the same and
+// adds to xI_scatt when it changes -- no atomics but at the segments' ends (a bin may continue in the next wave's chunk).
+#ifndef SEG_CHUNK
+#define SEG_CHUNK 512
+#endif
+#ifndef SEG_UNROLL
+#define SEG_UNROLL 8
+#endif
+__global__ void __launch_bounds__(256) k_segfold(const uint32_t* keys, const uint2* vals, unsigned long long n_rec, const float* rowsf,
+                                                 float* xI) {
+  const int lane = threadIdx.x & 63;
+  const unsigned long long wave = (unsigned long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const unsigned long long r_lo = wave * SEG_CHUNK;
+  if (r_lo >= n_rec) return;
+  const unsigned long long r_hi = (r_lo + SEG_CHUNK < n_rec) ? r_lo + SEG_CHUNK : n_rec;
+  const bool stokes = lane < 4 * NRT, copy = lane >= 4 * NRT && lane < 5 * NRT;
+  const int q = stokes ? lane >> 2 : (copy ? lane - 4 * NRT : 0);
+  const int col = stokes ? lane : (copy ? 4 * (lane - 4 * NRT) : 0);   // which float of the row this lane multiplies
+  float acc = 0.0f, acc_star = 0.0f;   // (copy lanes: acc = thermal origin (slot 7), acc_star = stellar origin (slot 5))
+  uint32_t cur = 0xFFFFFFFFu;
+  auto flush = [&](uint32_t bin) {
+    float* rec = xI + ((size_t)bin * NRT + q) * XI_LINE;
+    if (stokes && acc != 0.0f) atomicAdd(rec + (lane & 3), acc);
+    if (copy) { if (acc != 0.0f) atomicAdd(rec + 7, acc); if (acc_star != 0.0f) atomicAdd(rec + 5, acc_star); }
+    acc = 0.0f; acc_star = 0.0f;
+  };
+  for (unsigned long long r0 = r_lo; r0 < r_hi; r0 += SEG_UNROLL) {
+    uint32_t key[SEG_UNROLL];
+    float l[SEG_UNROLL], w[SEG_UNROLL];
+#pragma unroll
+    for (int t = 0; t < SEG_UNROLL; ++t) {
+      const unsigned long long r = (r0 + t < r_hi) ? r0 + t : r_hi - 1;   // (wave-uniform: scalar loads)
+      key[t] = (r0 + t < r_hi) ? keys[r] : 0xFFFFFFFFu;
+      const uint2 v = vals[r];
+      l[t] = __uint_as_float(v.y);
+      w[t] = (stokes || copy) ? rowsf[(size_t)v.x * (4 * NRT) + col] : 0.0f;
+    }
+#pragma unroll
+    for (int t = 0; t < SEG_UNROLL; ++t) {
+      if (key[t] == 0xFFFFFFFFu) break;
+      const uint32_t bin = key[t] & 0x7FFFFFFFu;
+      if (bin != cur) { if (cur != 0xFFFFFFFFu) flush(cur); cur = bin; }
+      const float d = l[t] * w[t];
+      if (copy && (key[t] >> 31)) acc_star += d; else acc += d;
+    }
+  }
+  if (cur != 0xFFFFFFFFu) flush(cur);
 }
 
 __global__ void k_offsets(const uint32_t* keys_sorted, unsigned long long n_rec, unsigned long long* offs, int n_slices) {
@@ -202,15 +276,63 @@ int main(int argc, char** argv) {
     hipLaunchKernelGGL(k_offsets, dim3((n_slices + 256) / 256), dim3(256), 0, 0, keys2, n_rec, offs, n_slices);
     hipEventRecord(e1); CHK(hipEventSynchronize(e1)); hipEventElapsedTime(&ms, e0, e1);
     t_sort = ms;
-    hipEventRecord(e0);
-    hipLaunchKernelGGL(k_fold, dim3(n_slices), dim3(FOLD_THREADS), SLICE_BINS * BIN_STRIDE * 4, 0, keys2, vals2, offs, rows, xI_b);
-    hipEventRecord(e1); CHK(hipEventSynchronize(e1)); hipEventElapsedTime(&ms, e0, e1);
-    t_fold = ms;
   }
   CHK(hipGetLastError());
+  // work items: a slice with many records is folded by several workgroups (each at most `chunk` records)
+  std::vector<unsigned long long> h_offs(n_slices + 1);
+  CHK(hipMemcpy(h_offs.data(), offs, (size_t)(n_slices + 1) * 8, hipMemcpyDeviceToHost));
+  for (unsigned long long chunk : {1ull << 62, 1ull << 17, 1ull << 15, 1ull << 13}) {
+    std::vector<FoldItem> items;
+    for (int b = 0; b < n_slices; ++b) {
+      const unsigned long long lo = h_offs[b], hi = h_offs[b + 1];
+      if (hi == lo) continue;
+      const unsigned long long parts = (hi - lo + chunk - 1) / chunk;
+      for (unsigned long long p = 0; p < parts; ++p)
+        items.push_back(FoldItem{lo + p * chunk, (lo + (p + 1) * chunk < hi) ? lo + (p + 1) * chunk : hi, b, parts > 1 ? 1 : 0});
+    }
+    FoldItem* d_items;
+    CHK(hipMalloc(&d_items, items.size() * sizeof(FoldItem)));
+    CHK(hipMemcpy(d_items, items.data(), items.size() * sizeof(FoldItem), hipMemcpyHostToDevice));
+    for (int rep = 0; rep < 2; ++rep) {
+      CHK(hipMemset(xI_b, 0, n_xi * 4));
+      hipEventRecord(e0);
+      hipLaunchKernelGGL(k_fold, dim3((unsigned)items.size()), dim3(FOLD_THREADS), SLICE_BINS * BIN_STRIDE * 4, 0, keys2, vals2, d_items, rows, xI_b);
+      hipEventRecord(e1); CHK(hipEventSynchronize(e1)); hipEventElapsedTime(&ms, e0, e1);
+    }
+    t_fold = ms;
+    unsigned long long biggest = 0;
+    for (int b = 0; b < n_slices; ++b) if (h_offs[b + 1] - h_offs[b] > biggest) biggest = h_offs[b + 1] - h_offs[b];
+    printf("B  fold, at most %8llu records per workgroup: %5zu workgroups (largest slice %llu records) %8.2f ms  %.3e crossings/s  row gather %.0f GB/s\n",
+           chunk > (1ull << 40) ? 0ull : chunk, items.size(), biggest, ms, n_rec / (ms * 1e-3), n_rec * 160.0 / (ms * 1e6));
+    CHK(hipFree(d_items));
+  }
+  {  // C: segmented sums over the sorted records
+    float* xI_c;
+    CHK(hipMalloc(&xI_c, n_xi * 4));
+    const unsigned long long n_waves = (n_rec + SEG_CHUNK - 1) / SEG_CHUNK;
+    for (int rep = 0; rep < 2; ++rep) {
+      CHK(hipMemset(xI_c, 0, n_xi * 4));
+      hipEventRecord(e0);
+      hipLaunchKernelGGL(k_segfold, dim3((unsigned)((n_waves + 3) / 4)), dim3(256), 0, 0, keys2, vals2, n_rec, reinterpret_cast<const float*>(rows), xI_c);
+      hipEventRecord(e1); CHK(hipEventSynchronize(e1)); hipEventElapsedTime(&ms, e0, e1);
+    }
+    CHK(hipGetLastError());
+    std::vector<float> ha2(n_xi), hc(n_xi);
+    CHK(hipMemcpy(ha2.data(), xI_a, n_xi * 4, hipMemcpyDeviceToHost));
+    CHK(hipMemcpy(hc.data(), xI_c, n_xi * 4, hipMemcpyDeviceToHost));
+    double worst_c = 0, sc = 0;
+    for (size_t i = 0; i < n_xi; ++i) {
+      sc += hc[i];
+      const double d = fabs((double)ha2[i] - hc[i]) / (fabs((double)ha2[i]) + 1e-3);
+      if (d > worst_c) worst_c = d;
+    }
+    printf("C  segmented sums over the sorted records (chunks of %d, %d records in flight): %8.2f ms  %.3e crossings/s  row gather %.0f GB/s; "
+           "with the sort %.2f ms = %.2fx the atomics; sum %.6e, largest relative difference %.2e\n", SEG_CHUNK, SEG_UNROLL, ms,
+           n_rec / (ms * 1e-3), n_rec * 160.0 / (ms * 1e6), ms + t_sort, t_atomic / (ms + t_sort), sc, worst_c);
+    CHK(hipFree(xI_c));
+  }
   printf("B  sort by bin (radix, 20 bits: stand-in for 2 partition passes): %8.2f ms  %.3e crossings/s\n", t_sort, n_rec / (t_sort * 1e-3));
-  printf("B  fold (%d slices of %d bins, %d KB of LDS, %d threads):          %8.2f ms  %.3e crossings/s  row gather %.0f GB/s\n", n_slices,
-         SLICE_BINS, SLICE_BINS * BIN_STRIDE * 4 / 1024, FOLD_THREADS, t_fold, n_rec / (t_fold * 1e-3), n_rec * 160.0 / (t_fold * 1e6));
+  printf("B  (%d slices of %d bins, %d KB of LDS, %d threads per workgroup)\n", n_slices, SLICE_BINS, SLICE_BINS * BIN_STRIDE * 4 / 1024, FOLD_THREADS);
   printf("B  sort + fold: %.2f ms = %.2fx the atomics; fold alone %.2fx\n", t_sort + t_fold, t_atomic / (t_sort + t_fold), t_atomic / t_fold);
   // same sums?
   std::vector<float> ha(n_xi), hb(n_xi);
