@@ -32,7 +32,7 @@ BYTES_PER_INTERACTION = 8.0  # E_abs read for Temp_LTE
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
 VALU_ISSUE_PEAK = 1024 * 2.4e9 / 4.0   # wave-instructions/s: 256 CUs x 4 SIMDs, one VALU instruction per 4 cycles at 2.4 GHz
 ATOMIC_LINE_PEAK = 2.37e10   # memory-side atomic operations/s, any type or footprint (profiles/r02_atomic_scope_bench.log)
-PROFILE_ROUND = "r05"
+PROFILE_ROUND = "r06"
 
 
 def np_sum(a):
@@ -78,7 +78,11 @@ def pmc_summary(config, n_local, world):
         d = json.load(open(os.path.join(ROOT, "profiles", "%s_pmc_%s.json" % (PROFILE_ROUND, config))))
         if d.get("source_hash") != source_hash() or int(d.get("packets", 0)) != int(n_local):
             return {}
-        return d.get("per_launch", {})
+        out = dict(d.get("per_launch", {}))
+        # (these fields are NOT measured by this run: they are copied from the committed counter passes of the same command on
+        # the same kernel sources, and the line says so)
+        out["counters_from"] = "profiles/%s_pmc_%s.json @ %s" % (PROFILE_ROUND, config, d.get("source_hash"))
+        return out
     except Exception:
         return {}
 
@@ -340,7 +344,10 @@ def thermal_block(par, args, config, steps, warmup, with_cpu, n_local, crossing=
                 "hbm_frac_measured": (pmc["hbm_bytes"] / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if pmc.get("hbm_bytes") else None,
                 "valu_busy": min(1.0, pmc["valu_busy"]) if pmc.get("valu_busy") else None, "wait_frac": pmc.get("wait_frac"),
                 "waves_per_simd": pmc.get("waves_per_simd"), "fp64_tflops": pmc.get("fp64_tflops"),
-                "lane_utilisation": pmc.get("lane_utilisation")}
+                "lane_utilisation": pmc.get("lane_utilisation"),
+                # where traffic, valu_*, wait_frac, waves_per_simd, fp64_tflops, lane_utilisation come from (null: no committed
+                # counter passes for these kernel sources -- the fields above are then null too)
+                "counters_from": pmc.get("counters_from")}
         block = {"value": n_total * steps / dt, "unit": "packets/s", "steps": steps, "warmup": warmup,
                  "ms_per_step": dt / steps * 1e3,
                  "config": {"workload": ("%s 2D cylindrical disk %dx%dx%d, %d wavelengths, %.3g packets/GPU/step, temperature "
@@ -415,7 +422,7 @@ def thermal_block(par, args, config, steps, warmup, with_cpu, n_local, crossing=
                     bins = np.arange(model.n_cells) % per_az
                     bins = (bins % cfg.n_rad) + cfg.n_rad * (np.abs((bins // cfg.n_rad) - cfg.nz + 0.5).astype(int))   # (both hemispheres)
                 block["tdust_vs_cpu"] = tdust_parity(T_gpu, n_total, T_cpu, n_cpu, cfg.T_min, pair, bins, xN)
-                if config == "ref41_mrw" and me is None:
+                if config == "ref41_mrw" and me is None and n_local <= 2e7:   # (two more brute-force runs: the 1e7-packet block's)
                     # the walk against the brute-force loop on the GPU at the same packet count (the walk is "parity
                     # unpinned": the reference's MRW is a stub): the reference's p75 gate, the
                     # worst cells, and the columns of the illuminated inner rim that round 3 had to bound at 8 %
@@ -521,8 +528,10 @@ def sed_block(par, args, steps, warmup, with_cpu, packets, observers, all_lambda
         cnt = eng.fetch()["counters"]
         cross_pp = cnt["crossings"] / max(cnt["packets"], 1)
         nRT = m.rt["RT_n_incl"] * m.rt["RT_n_az"]
-        # per crossing: kappa_factor 8 B + one 64-byte xI_scatt record RMW per observer
-        bytes_step = sent_all / world / steps * cross_pp * (8.0 + 2 * 64.0 * nRT)
+        # per crossing: kappa_factor 8 B + the read and the write of one xI_scatt record per observer -- 32 bytes in default real
+        # (two observers share a 64-byte line), 64 in FP64
+        rec_bytes = 32.0 if args.xI_precision == 4 else 64.0
+        bytes_step = sent_all / world / steps * cross_pp * (8.0 + 2 * rec_bytes * nRT)
         lines_per_rec = 0.5 if args.xI_precision == 4 else 1.0   # default-real records: two observers share a 64-byte line
         line_ops_s = sent_all / world / dt * cross_pp * nRT * lines_per_rec
         block = {
@@ -590,8 +599,7 @@ def main():
                     "(the physics of --config ref41 through the HBM-gather kernel)")
     ap.add_argument("--mrw-gamma", type=float, default=2.0, help="--config ref41_mrw: gamma_MRW")
     ap.add_argument("--mrw-n-inter", type=int, default=5, help="--config ref41_mrw: a walk may start after more than this many "
-                    "interactions in a row in one cell (dust_transfer.f90:1223: 5); + 256: also from a packet whose last event "
-                    "was a scattering")
+                    "interactions in a row in one cell (dust_transfer.f90:1223: 5; 0..6)")
     ap.add_argument("--dust-mass", type=float, default=0.0, help="override the disk's dust mass [Msun] (thermal configs; "
                     "ref41_mrw defaults to 10x the stock mass)")
     ap.add_argument("--no-ref41", action="store_true", help="--config pascucci: the headline block alone (same as --no-extra)")
@@ -647,26 +655,42 @@ def main():
         par.finish()
         return
 
+    def say(name, blk):
+        # One line per block as it completes, in front of the final combined line: the driver's record keeps the END of
+        # stdout, and the combined line is long.  (Prefixed: the one line that starts with `{` is the contract's.)
+        if par.rank == 0 and blk is not None:
+            print("block %s: %s" % (name, json.dumps(blk)), flush=True)
+
     block, cfg = thermal_block(par, args, args.config, args.steps, args.warmup, with_cpu, args.packets)
+    say("headline_" + args.config, block)
     extras = {}
     if args.config == "pascucci" and not (args.no_ref41 or args.no_pascucci or args.no_extra) and not args.frozen:
         # BASELINE.json lists ref4.1 as the single-GPU configuration (configs[1]): the same loop, same packet count,
         # same steps, barriers and all-reduce, with its own roofline, CPU baseline and temperature parity
         extras["ref41_2d"], _ = thermal_block(par, args, "ref41", args.steps, args.warmup, with_cpu, args.packets)
+        say("ref41_2d", extras["ref41_2d"])
         if world == 1:   # ... and, on one GPU, every other BASELINE configuration under the same clock
             extras["ref41_3d"], _ = thermal_block(par, args, "ref41_3d", args.steps, args.warmup, with_cpu, args.packets)
+            say("ref41_3d", extras["ref41_3d"])
             try:
                 extras["voronoi"], _ = thermal_block(par, args, "voronoi", max(1, args.steps - 1), 1, with_cpu, args.packets)
             except Exception as ex:   # (the tessellation of the stand-in needs scipy's Qhull and a minute of host time)
                 extras["voronoi"] = {"skipped": repr(ex)}
-            # BASELINE config 4: an optically thick midplane (10x the dust) with the modified random walk; tail-bound
-            # (DESIGN.md section 7), so a step is 1e7 packets
+            say("voronoi", extras["voronoi"])
+            # BASELINE config 4: an optically thick midplane (10x the dust) with the modified random walk, at the production
+            # size (1e8 packets, one step) and at 1e7, where the launch's tail -- the serial latency of its longest packets,
+            # whatever the packet count (DESIGN.md "k_tail") -- weighs ten times more
             extras["ref41_mrw"], _ = thermal_block(par, args, "ref41_mrw", 1, 1, with_cpu, min(args.packets, 1e7))
+            if args.packets > 1e7:
+                big, _ = thermal_block(par, args, "ref41_mrw", 1, 1, False, args.packets)
+                extras["ref41_mrw"]["at_%.0e_packets" % args.packets] = {k: big[k] for k in ("value", "unit", "ms_per_step", "tail")}
+            say("ref41_mrw", extras["ref41_mrw"])
             # the SED half of BASELINE config 2: 10 observers
             # (every wavelength, 3 551 packets in the stop bin per stream -- a third of config 2's 10 000; round 4 ran 710, where a
             # wavelength's launches are small and the rate sat a third below the full run's)
             extras["sed"] = sed_block(par, args, 1, 0, with_cpu, min(2.5 * args.packets, 2.5e8), args.sed_observers or 10,
                                       all_lambdas=True)
+            say("sed", extras["sed"])
             # the headline workload with option "crossing" = 1: the flight-parametric crossing in the flying waves -- NOT the
             # reference's arithmetic, so not the headline; statistical parity only (its tdust_vs_cpu against the same CPU port)
             pb, _ = thermal_block(par, args, "pascucci", args.steps, args.warmup, with_cpu, args.packets, crossing=1)
@@ -674,6 +698,7 @@ def main():
                           "same cells but for ties at the rounding level, gated statistically (tests/test_param_crossing.py)")
             pb["roofline"]["kernel"] = "k_thermal_roles_param"
             extras["pascucci_parametric_crossing"] = pb
+            say("pascucci_parametric_crossing", pb)
     if par.rank == 0:
         line = {"metric": "photon packets/sec (whole node), thermal MC packet loop, %s" % cfg.name,
                 "value": block["value"], "unit": "packets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

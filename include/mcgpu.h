@@ -47,6 +47,11 @@ enum {
   MCGPU_ERR_STATE = 5,       /* a required mcgpu_set_* call is missing       */
   MCGPU_ERR_KERNEL = 6       /* the kernel flagged an internal error         */
 };
+/* MCGPU_ERR_KERNEL: mcgpu_last_error names the kernel's code -- 12: an emission source outside the engine's scope;
+ * 13: a packet of more than 2e8 crossings was dropped (a packet that never leaves the grid); 15: a scheduling watchdog
+ * ended the launch instead of letting it hang (every wait of the role / pool schedules is bounded: a logic error, not an
+ * input error); 16, 17: a hand-over buffer (role kernel -> k_tail, k_tail -> host) overflowed; 18: a launch of the SED
+ * commit pass logged more deposits than its log holds (option "xi_log" = 0 runs the model with atomics). */
 
 #define MCGPU_N_SED_TYPES 9 /* sed, sed_q, sed_u, sed_v, n_phot_sed, sed_star,
                                sed_star_scat, sed_disk, sed_disk_scat
@@ -186,6 +191,11 @@ int mcgpu_set_midplane_snap(mcgpu_ctx *ctx, int on);
  *   "host_threads" host threads of such a tail: 0 (default) = the machine's hardware threads divided by its GPUs,
  *                      at most 32; 1..256
  *   "tail_host_packets"  packets k_tail leaves to the host: 0 (default) = 8 per host thread; 1..65536
+ *   "xi_log"       SED mode, default-real xI_scatt (mcgpu_set_xI_precision(4)), one dust class, cylindrical grid: 1 (default) =
+ *                      the commit pass LOGS its deposits (12 bytes per crossing + the flight's weights once) and a sort
+ *                      by sub-bin + segmented sums replace the atomics, at the wavelengths where flights are long
+ *                      enough for that to pay (>= 4.5 crossings per flight, measured by the pass's first launch);
+ *                      0 = atomics always; 2 = the log always.  Same sums to the order of default-real additions.
  *   "deposit_log_mb"  size of the binned-deposit log in MiB; 0 (default) = up to 64 GiB (what the packets asked for need), at most a quarter of
  *                      the free device memory.  A smaller log means more, shorter chunks; a
  *                      block that finds its part of the log full is added with atomics.
@@ -218,7 +228,8 @@ int mcgpu_set_option(mcgpu_ctx *ctx, const char *name, int value);
  * "bin_deposits_per_packet", "bin_overflow_blocks", "bin_drained_records", "tail_threshold", "tau_midplane",
  * "tail_ms", "longest_packet_events" / _crossings / _scatterings / _absorptions / _walks / _steps, and of the last
  * launch's tail: "tail_where" (0: it had none, 1: k_tail finished it, 2: the host threads did), "tail_host_ms",
- * "tail_host_packets", "tail_host_threads", "tail_host_events". */
+ * "tail_host_packets", "tail_host_threads", "tail_host_events"; of the last mcgpu_run_mono's commit passes:
+ * "xi_log_chunks" (launches that logged their deposits; 0: atomics), "xi_log_records", "xi_log_flights". */
 int mcgpu_get_info(mcgpu_ctx *ctx, const char *name, double *value);
 
 /* Stars: type star_type (parameters.f90:230-242); icell/out_model from
@@ -914,6 +925,34 @@ int mcgpu_multi_run_thermal(mcgpu_multi *m, const mcgpu_run_opts *opts, double *
 int mcgpu_multi_run_mono(mcgpu_multi *m, const mcgpu_mono_opts *opts, double frac_E_stars,
                          double frac_E_disk, const double *prob_E_cell, uint64_t *n_sent_chunk,
                          double *kernel_ms);
+
+/*
+ * The SED step on several devices, sharded BY WAVELENGTH: run_sed_mc's own loop (dust_transfer.f90:899-1027: per wavelength
+ * repartition_energie :924, the packet loop :939, then dust_map of every observer) is the partition -- a wavelength's
+ * xI_scatt is produced and consumed within that wavelength.  Device d takes whole wavelengths (longest first by `cost`,
+ * each to the device with the least work so far), builds the wavelength's emission tables from Tdust
+ * (mcgpu_repartition_energie), runs the scout / commit passes (mcgpu_run_mono with opts' stream count, stop bin and
+ * limits) and, with `rt` and opts->rt1 = 1, the ray-traced SED of the dust (mcgpu_rt1_dust_map); only the results travel:
+ *   sed[n_wl][MCGPU_N_SED_TYPES][N_phi][N_thet]   the wavelength's own bins of the nine Monte Carlo SED arrays
+ *   n_sent[n_wl], E_disk[n_wl], counters[n_wl][MCGPU_N_COUNTERS]
+ *   stokes_rt[n_wl][RT_n_incl * RT_n_az][N_type_flux]   (rt / stokes_rt NULL: no ray tracing)
+ *   device_of[n_wl] (which context ran it), seconds[n_wl] (its wall time: next call's `cost`)        -- any may be NULL.
+ * Nothing is summed across devices and no xI_scatt is reduced (mcgpu_multi_run_mono, which splits ONE wavelength's streams,
+ * all-reduces the whole array: 200 MB per wavelength on ref4.1 with ten observers): a wavelength's results are those of
+ * the single-device calls whichever device ran it, to the order of its own atomic sums.  Every context must hold the model
+ * and mcgpu_set_rt1.  opts->lambda, p_lambda and seed are taken from wl[i]; rt's lambda, wl_um, E_src and n_sent_photons
+ * are filled in per wavelength (E_src = E_star + E_disk + E_ISM, :666).
+ */
+typedef struct {
+  int lambda, p_lambda;     /* 1-based; p_lambda = 0: lambda                                   */
+  double wl_um;             /* tab_lambda(lambda)                                              */
+  double E_star, E_ISM;     /* E_stars(lambda), E_ISM(lambda)                                  */
+  uint64_t seed;            /* of this wavelength's packet streams                             */
+  double cost;              /* relative cost (e.g. last time's seconds[i]); 0: unknown (equal) */
+} mcgpu_sed_wavelength;
+int mcgpu_multi_run_sed(mcgpu_multi *mm, const mcgpu_mono_opts *opts, int n_wl, const mcgpu_sed_wavelength *wl,
+                        const float *Tdust, const mcgpu_rt_opts *rt, const float *tab_RT_az, double *sed, double *n_sent,
+                        double *E_disk, double *stokes_rt, uint64_t *counters, int *device_of, double *seconds);
 int mcgpu_multi_rccl_ranks(mcgpu_multi *m);
 
 #ifdef __cplusplus

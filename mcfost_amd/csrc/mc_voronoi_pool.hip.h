@@ -256,7 +256,10 @@ __device__ __forceinline__ void thermal_body_voro_pool(const DevModel& M, const 
       if (__ballot(d_want)) { vp_push(Q, rings, log_cap, lane, d_want, d_q, d_rid); d_want = false; continue; }  // (what this wave still holds back)
       if (!ids_left && vp_ld(&Q->n_live) == 0) break;   // every packet of the launch is finished
       { const int b = vp_ld(&Q->beat); if (b != last_beat) { last_beat = b; idle_spins = 0; } }
-      if (++idle_spins > (1 << 21)) { *A.err = 15; vp_st(&Q->abort_flag, 1); }  // (seconds without a pass anywhere in the workgroup: a lost packet)
+      // (a minute or more without a pass ANYWHERE in the workgroup -- the beat is bumped by every wave in every pass it
+      // works, so a wave stalled behind a long memory or atomic queue, or serialised by a profiler's counter pass, does not
+      // trip this --: a packet has been lost by a logic error; error 15 ends the launch instead of hanging the GPU)
+      if (++idle_spins > (1 << 27)) { *A.err = 15; vp_st(&Q->abort_flag, 1); }
 #if MCGPU_VORO_DIAG == 4
       if (lane == 0) VDg.c[7]++;
 #endif

@@ -30,6 +30,8 @@
 #include "mc_opacity.hip.h"
 #include "mc_rt2.hip.h"
 #include "mc_kernels.h"
+#include <algorithm>
+#include <chrono>
 #include "host_tail.h"
 #include "mc_xilog.hip.h"
 
@@ -1170,15 +1172,22 @@ extern "C" int mcgpu_init_reemission_ex(mcgpu_ctx* ctx, const double* tab_lambda
   if (d_dudt) hipFree(d_dudt);
   if (e != hipSuccess) return fail(ctx, MCGPU_ERR_HIP, hipGetErrorString(e));
   if (log_Qcool) std::memcpy(log_Qcool, lq.data(), lq.size() * sizeof(double));
+  // (a table that fails the gate stays in the context -- it was built in place --, so the context is marked as waiting for
+  // its re-emission tables again: ready() refuses every launch until a build, or tables from the host, pass)
+  auto refuse = [&]() {
+    ctx->pending_single = ctx->pending_single || do_single;
+    ctx->pending_classes = ctx->pending_classes || do_classes;
+    ctx->reemission_pending = true;
+    return fail(ctx, MCGPU_ERR_UNSUPPORTED, "log_Qcool must increase with T (the tables just built do not: no launch until they are replaced)");
+  };
   for (int c = 0; c < nc; ++c)
     for (int t = 2; t < nT; ++t)
-      if (lq[(size_t)c * nT + t] < lq[(size_t)c * nT + t - 1])
-        return fail(ctx, MCGPU_ERR_UNSUPPORTED, "log_Qcool must increase with T");
+      if (lq[(size_t)c * nT + t] < lq[(size_t)c * nT + t - 1]) return refuse();
   if (M.n_classes && do_single) {  // (the single-class table too: spherical / MRW / SED paths read it)
     std::vector<double> lq1((size_t)nT);
     HIPCHK(hipMemcpy(lq1.data(), M.log_Qcool, lq1.size() * sizeof(double), hipMemcpyDeviceToHost));
     for (int t = 2; t < nT; ++t)
-      if (lq1[t] < lq1[t - 1]) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "log_Qcool must increase with T");
+      if (lq1[t] < lq1[t - 1]) return refuse();
   }
   ctx->pending_single = ctx->pending_classes = false;
   ctx->reemission_pending = false;
@@ -1729,7 +1738,10 @@ static int launch_voro(mcgpu_ctx* ctx, const RunArgs& A, int grid_blocks, int bl
       PA.recs = reinterpret_cast<PRec*>(ctx->d_pool); PA.log_rec = log_rec; PA.cache_log_ns = log_ns;
       if (!ctx->d_pool_blob) HIPCHK(hipMalloc((void**)&ctx->d_pool_blob, sizeof(VpBlob)));
       ctx->h_pool_blob.M = M; ctx->h_pool_blob.A = A; ctx->h_pool_blob.G = ctx->V;
-      HIPCHK(hipMemcpyAsync(ctx->d_pool_blob, &ctx->h_pool_blob, sizeof(VpBlob), hipMemcpyHostToDevice, ctx->stream));
+      // (pageable host memory: a synchronous copy -- behind the stream's earlier work -- so that a second launch enqueued
+      // right after this one cannot overwrite the blob before it has been read)
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      HIPCHK(hipMemcpy(ctx->d_pool_blob, &ctx->h_pool_blob, sizeof(VpBlob), hipMemcpyHostToDevice));
       const VpBlob* blob = ctx->d_pool_blob;
       const void* fn = kpick_voro_pool(pola, pthreads);
       HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
@@ -2116,7 +2128,9 @@ extern "C" int mcgpu_sync(mcgpu_ctx* ctx, double* kernel_ms) {
   int herr = 0;
   HIPCHK(hipMemcpy(&herr, ctx->d_err, sizeof(int), hipMemcpyDeviceToHost));
   if (herr) {
-    ctx->err = "kernel error code " + std::to_string(herr) + " (12 = emission source outside the engine's scope)";
+    ctx->err = "kernel error code " + std::to_string(herr) + " (12 = emission source outside the engine's scope, 13 = a packet of more than 2e8 "
+               "crossings was dropped, 15 = a scheduling watchdog ended the launch (a logic error: please report), 16 / 17 = a hand-over "
+               "buffer overflowed, 18 = the xI log overflowed; include/mcgpu.h)";
     return MCGPU_ERR_KERNEL;
   }
   return MCGPU_OK;
@@ -3889,5 +3903,79 @@ extern "C" int mcgpu_multi_run_mono(mcgpu_multi* mm, const mcgpu_mono_opts* opts
     if (ms[i] > ms_max) ms_max = ms[i];
   }
   if (kernel_ms) *kernel_ms = ms_max;
+  return MCGPU_OK;
+}
+
+// The SED step sharded BY WAVELENGTH (round 6).  run_sed_mc's loop over the wavelengths
+// (dust_transfer.f90:899-1027) is itself the natural partition: a wavelength's xI_scatt is produced by that wavelength's
+// packets and consumed by that wavelength's ray tracing, then dead.  So device d takes WHOLE wavelengths -- longest first
+// by the caller's cost hint, each to the device that is free first -- and runs repartition_energie -> scout / commit ->
+// dust_map locally; only the wavelength's SED bins, packet count and ray-traced Stokes values travel (a few KB), and no
+// xI_scatt is ever reduced (mcgpu_multi_run_mono all-reduces 200 MB of it per wavelength).  Nothing is summed across
+// devices: a wavelength's numbers are those of the single-device call, whichever device ran it.
+extern "C" int mcgpu_multi_run_sed(mcgpu_multi* mm, const mcgpu_mono_opts* opts, int n_wl, const mcgpu_sed_wavelength* wl,
+                                   const float* Tdust, const mcgpu_rt_opts* rt, const float* tab_RT_az, double* sed,
+                                   double* n_sent, double* E_disk, double* stokes_rt, uint64_t* counters, int* device_of,
+                                   double* seconds) {
+  if (!mm || !opts || n_wl < 1 || !wl || !Tdust) return MCGPU_ERR_ARG;
+  const int n = mm->n_dev;
+  if (rt && !tab_RT_az) { mm->err = "mcgpu_multi_run_sed: the ray tracing needs tab_RT_az"; return MCGPU_ERR_ARG; }
+  if (opts->accumulate) { mm->err = "mcgpu_multi_run_sed: a wavelength is run once, by one device (accumulate = 0)"; return MCGPU_ERR_ARG; }
+  // longest first, each to the device with the least work so far (a wavelength of ref4.1 takes 13 to 370 ms)
+  std::vector<int> order(n_wl);
+  for (int i = 0; i < n_wl; ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return wl[a].cost > wl[b].cost; });
+  std::vector<std::vector<int>> mine(n);
+  std::vector<double> load(n, 0.0);
+  for (int i : order) {
+    int d = 0;
+    for (int k = 1; k < n; ++k) if (load[k] < load[d]) d = k;
+    mine[d].push_back(i);
+    load[d] += wl[i].cost > 0.0 ? wl[i].cost : 1.0;
+    if (device_of) device_of[i] = d;
+  }
+  mm->reduced = false; mm->reduced_what = 0;   // (every context's accumulators now hold its own last wavelength)
+  std::vector<int> rcs(n, 0);
+  std::vector<std::thread> th;
+  for (int d = 0; d < n; ++d) {
+    th.emplace_back([&, d]() {
+      mcgpu_ctx* ctx = mm->ctx[d];
+      const DevModel& M = ctx->M;
+      const size_t n_bins = (size_t)M.N_thet * M.N_phi, nsed = n_sed(M);
+      const int nRT = ctx->have_rt1 ? ctx->RT_n_incl * ctx->RT_n_az : 0;
+      std::vector<double> sed_all(nsed), ns_all(M.n_lambda);
+      for (int i : mine[d]) {
+        const auto t0 = std::chrono::steady_clock::now();
+        const mcgpu_sed_wavelength& W = wl[i];
+        double fs = 0.0, fd = 0.0, Ed = 0.0;
+        int rc = mcgpu_repartition_energie(ctx, W.lambda, W.wl_um, W.E_star, W.E_ISM, Tdust, nullptr, &fs, &fd, &Ed, nullptr);
+        mcgpu_mono_opts o = *opts;
+        o.lambda = W.lambda; o.p_lambda = W.p_lambda > 0 ? W.p_lambda : W.lambda; o.seed = W.seed;
+        if (!rc) rc = mcgpu_run_mono(ctx, &o, fs, fd, nullptr, nullptr, nullptr);
+        uint64_t cnt[MCGPU_N_COUNTERS];
+        if (!rc) rc = mcgpu_fetch(ctx, nullptr, sed_all.data(), ns_all.data(), cnt);
+        if (!rc) {
+          // the wavelength's own bins of the nine SED arrays: sed(lambda, N_thet, N_phi, type), lambda fastest
+          if (sed)
+            for (int t = 0; t < MCGPU_N_SED_TYPES; ++t)
+              for (size_t b = 0; b < n_bins; ++b)
+                sed[((size_t)i * MCGPU_N_SED_TYPES + t) * n_bins + b] = sed_all[(size_t)(W.lambda - 1) + (size_t)M.n_lambda * (b + n_bins * t)];
+          if (n_sent) n_sent[i] = ns_all[W.lambda - 1];
+          if (E_disk) E_disk[i] = Ed;
+          if (counters) for (int q = 0; q < MCGPU_N_COUNTERS; ++q) counters[(size_t)i * MCGPU_N_COUNTERS + q] = cnt[q];
+        }
+        if (!rc && rt && stokes_rt && o.rt1 == 1) {
+          mcgpu_rt_opts r = *rt;
+          r.lambda = W.lambda; r.wl_um = W.wl_um; r.E_src = W.E_star + Ed + W.E_ISM; r.n_sent_photons = ns_all[W.lambda - 1];
+          rc = mcgpu_rt1_dust_map(ctx, &r, tab_RT_az, Tdust, stokes_rt + (size_t)i * nRT * ctx->N_type_flux, nullptr);
+        }
+        if (seconds) seconds[i] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (rc) { rcs[d] = rc; return; }
+      }
+    });
+  }
+  for (auto& t : th) t.join();
+  for (int d = 0; d < n; ++d)
+    if (rcs[d]) { mm->err = "device " + std::to_string(d) + ": " + mcgpu_last_error(mm->ctx[d]); multi_drain(mm); return rcs[d]; }
   return MCGPU_OK;
 }

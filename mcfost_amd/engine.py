@@ -36,7 +36,7 @@ ABI_SYMBOLS = (
     "mcgpu_device_xI", "mcgpu_set_ism", "mcgpu_rt1_dust_map", "mcgpu_set_xI", "mcgpu_rt1_image", "mcgpu_set_xI_precision",
     "mcgpu_get_xI_precision", "mcgpu_set_option", "mcgpu_get_info", "mcgpu_counters_to_accum", "mcgpu_counters_from_accum",
     "mcgpu_set_grid_sph", "mcgpu_temp_approx_diffusion_vertical", "mcgpu_set_mrw", "mcgpu_fetch_radiation_field", "mcgpu_set_variable_dust", "mcgpu_rt1_stars_map_sed", "mcgpu_define_dark_zone", "mcgpu_init_reemission", "mcgpu_multi_create", "mcgpu_multi_destroy", "mcgpu_multi_size", "mcgpu_multi_ctx", "mcgpu_multi_last_error",
-    "mcgpu_repartition_energie", "mcgpu_opacity", "mcgpu_set_variable_dust_s11", "mcgpu_set_scattering_method1", "mcgpu_set_rt2", "mcgpu_fetch_I_spec", "mcgpu_rt1_stars_map_image", "mcgpu_set_I_spec", "mcgpu_rt2_source", "mcgpu_rt2_dust_map", "mcgpu_rt2_image", "mcgpu_shard_packets", "mcgpu_multi_run_thermal", "mcgpu_multi_run_mono", "mcgpu_multi_rccl_ranks", "mcgpu_multi_create_ex", "mcgpu_multi_reductions", "mcgpu_set_mrw_exit_spectrum", "mcgpu_voronoi_tesselation", "mcgpu_build_ksca_CDF", "mcgpu_init_reemission_ex", "mcgpu_tau_maps",
+    "mcgpu_repartition_energie", "mcgpu_opacity", "mcgpu_set_variable_dust_s11", "mcgpu_set_scattering_method1", "mcgpu_set_rt2", "mcgpu_fetch_I_spec", "mcgpu_rt1_stars_map_image", "mcgpu_set_I_spec", "mcgpu_rt2_source", "mcgpu_rt2_dust_map", "mcgpu_rt2_image", "mcgpu_shard_packets", "mcgpu_multi_run_thermal", "mcgpu_multi_run_mono", "mcgpu_multi_run_sed", "mcgpu_multi_rccl_ranks", "mcgpu_multi_create_ex", "mcgpu_multi_reductions", "mcgpu_set_mrw_exit_spectrum", "mcgpu_voronoi_tesselation", "mcgpu_build_ksca_CDF", "mcgpu_init_reemission_ex", "mcgpu_tau_maps",
 )
 
 
@@ -74,6 +74,11 @@ class RtOpts(C.Structure):
     _fields_ = [("lambda_", C.c_int), ("wl_um", C.c_double), ("E_src", C.c_double), ("n_sent_photons", C.c_double),
                 ("distance", C.c_double), ("ang_disque", C.c_double), ("l_sym_ima", C.c_int),
                 ("tau_dark_zone_obs", C.c_double), ("Rmin", C.c_double), ("Rmax", C.c_double)]
+
+
+class SedWavelength(C.Structure):
+    _fields_ = [("lambda_", C.c_int), ("p_lambda", C.c_int), ("wl_um", C.c_double), ("E_star", C.c_double),
+                ("E_ISM", C.c_double), ("seed", C.c_uint64), ("cost", C.c_double)]
 
 
 _lib = None
@@ -931,6 +936,47 @@ class MultiEngine:
             e0._chk(self.lib.mcgpu_fetch_xI(e0.ctx, _p(x32, C.c_float), _p(x64, C.c_double)), "mcgpu_fetch_xI")
             out["xI_scatt"], out["xI_scatt_f32"] = x64, x32
         return out
+
+    def run_sed(self, lambdas, n_photons2, Tdust, seeds=None, costs=None, n_chunks=None, n_phot_lim=None, ray_tracing=True,
+                ang_disque=0.0, l_sym_ima=True, tau_dark_zone_obs=100.0, E_ISM=0.0):
+        """The SED step sharded BY WAVELENGTH (``mcgpu_multi_run_sed``): every device takes whole wavelengths of ``lambdas``
+        (1-based; longest first by ``costs``) -- emission tables from ``Tdust``, scout / commit passes, ray-traced SED of the
+        dust -- and only the results travel: ``sed`` (n, 9, N_phi, N_thet), ``n_sent``, ``E_disk``, ``sed_rt`` (n, nRT,
+        N_type_flux), ``counters``, ``device_of``, ``seconds`` per wavelength.  No xI_scatt is reduced."""
+        m = self.model
+        rt = m.rt
+        lambdas = [int(l) for l in lambdas]
+        n = len(lambdas)
+        for e in self.engines:
+            if not getattr(e, "_rt1", False):
+                e.set_rt1()
+        nt, nphi = m.cfg.N_thet, m.cfg.N_phi
+        n_chunks = int(n_chunks or m.cfg.n_photons_loop)
+        if n_phot_lim is None:  # read_param.f90:551
+            n_phot_lim = float(np.float32(1.0e4) * np.float32(nt) * np.float32(nphi) * np.float32(n_photons2))
+        o = MonoOpts(0, 0, 0, n_chunks, 0, int(n_photons2), float(n_phot_lim), int(m.capt_sup), 1, 0, 0, 0)
+        wl = (SedWavelength * n)()
+        for i, lam in enumerate(lambdas):
+            wl[i] = SedWavelength(lam, lam, float(m.lam[lam - 1]), float(m.E_stars[lam - 1]), float(E_ISM),
+                                  int(seeds[i]) if seeds is not None else 1 + lam, float(costs[i]) if costs is not None else 0.0)
+        ro = RtOpts(0, 0.0, 0.0, 0.0, float(m.cfg.distance), float(ang_disque), int(l_sym_ima), float(tau_dark_zone_obs),
+                    float(m.cfg.rin), float(m.cfg.rout))
+        nRT = rt["RT_n_incl"] * rt["RT_n_az"]
+        sed = np.zeros((n, N_SED_TYPES, nphi, nt), np.float64)
+        n_sent, E_disk, seconds = np.zeros(n), np.zeros(n), np.zeros(n)
+        sed_rt = np.zeros((n, nRT, rt["N_type_flux"]), np.float64)
+        cnt = np.zeros((n, N_COUNTERS), np.uint64)
+        dev = np.zeros(n, np.int32)
+        rc = self.lib.mcgpu_multi_run_sed(
+            self.h, C.byref(o), C.c_int(n), wl, _p(_a(Tdust, np.float32), C.c_float), C.byref(ro) if ray_tracing else None,
+            _p(_a(rt["tab_RT_az"], np.float32), C.c_float) if ray_tracing else None, _p(sed, C.c_double), _p(n_sent, C.c_double),
+            _p(E_disk, C.c_double), _p(sed_rt, C.c_double) if ray_tracing else None, _p(cnt, C.c_uint64), _p(dev, C.c_int),
+            _p(seconds, C.c_double))
+        if rc:
+            msg = self.lib.mcgpu_multi_last_error(self.h)
+            raise McgpuError(f"mcgpu_multi_run_sed failed ({rc}): {msg.decode() if msg else ''}")
+        return dict(sed=sed, n_sent=n_sent, E_disk=E_disk, sed_rt=sed_rt, seconds=seconds, device_of=dev,
+                    counters=[dict(zip(COUNTER_NAMES, (int(c) for c in row))) for row in cnt])
 
     def reductions(self):
         """Collectives the handle has executed (RCCL all-reduces or the shared-device sums standing in for them)."""

@@ -65,6 +65,14 @@ module mcgpu_f
      real(c_double) :: Rmin, Rmax
   end type mcgpu_rt_opts
 
+  ! one wavelength of mcgpu_multi_run_sed (include/mcgpu.h: mcgpu_sed_wavelength)
+  type, bind(C), public :: mcgpu_sed_wavelength
+     integer(c_int) :: lambda, p_lambda
+     real(c_double) :: wl_um, E_star, E_ISM
+     integer(c_int64_t) :: seed
+     real(c_double) :: cost
+  end type mcgpu_sed_wavelength
+
   ! the grains' tables for mcgpu_opacity (include/mcgpu.h: mcgpu_grain_tables): c_loc of module grains' arrays
   type, bind(C), public :: mcgpu_grain_tables
      integer(c_int) :: n_grains                                  ! n_grains_tot
@@ -88,7 +96,7 @@ module mcgpu_f
        mcgpu_set_stars, mcgpu_set_opacity, mcgpu_set_scattering, mcgpu_set_thermal, mcgpu_set_sed_bins, &
        mcgpu_run_thermal, mcgpu_temp_finale, mcgpu_thermal_loop, mcgpu_error_message, mcgpu_set_rt1, &
        mcgpu_run_mono, mcgpu_fetch, mcgpu_fetch_xI, mcgpu_rt1_dust_map, mcgpu_set_xI, mcgpu_rt1_image, mcgpu_set_xI_precision, &
-       mcgpu_set_E_prior, mcgpu_multi_create, mcgpu_multi_destroy, mcgpu_multi_size, mcgpu_multi_ctx, mcgpu_multi_run_thermal, mcgpu_multi_run_mono, mcgpu_multi_rccl_ranks, mcgpu_multi_create_ex, mcgpu_multi_reductions, &
+       mcgpu_set_E_prior, mcgpu_multi_create, mcgpu_multi_destroy, mcgpu_multi_size, mcgpu_multi_ctx, mcgpu_multi_run_thermal, mcgpu_multi_run_mono, mcgpu_multi_run_sed, mcgpu_multi_rccl_ranks, mcgpu_multi_create_ex, mcgpu_multi_reductions, &
        mcgpu_counters_to_accum, mcgpu_counters_from_accum, mcgpu_temp_approx_diffusion_vertical, mcgpu_set_mrw, mcgpu_set_mrw_exit_spectrum, mcgpu_fetch_radiation_field, &
        mcgpu_build_ksca_CDF, mcgpu_voronoi_tesselation, &
        mcgpu_set_variable_dust, mcgpu_rt1_stars_map_sed, mcgpu_define_dark_zone, mcgpu_init_reemission, mcgpu_init_reemission_ex, mcgpu_repartition_energie, mcgpu_opacity, mcgpu_set_variable_dust_s11, mcgpu_set_scattering_method1, mcgpu_set_rt2, mcgpu_fetch_I_spec, mcgpu_rt1_stars_map_image, mcgpu_set_I_spec, mcgpu_rt2_source, mcgpu_rt2_dust_map, mcgpu_rt2_image, mcgpu_tau_maps
@@ -434,6 +442,20 @@ module mcgpu_f
        integer(c_int64_t), intent(out) :: n_sent_chunk(*)
        real(c_double), intent(out) :: kernel_ms
      end function mcgpu_multi_run_mono
+
+     ! run_sed_mc's loop over the wavelengths (dust_transfer.f90:899-1027) sharded BY WAVELENGTH: every device takes whole
+     ! wavelengths (repartition_energie, the packet loop, dust_map) and only their results travel -- no xI_scatt all-reduce
+     integer(c_int) function mcgpu_multi_run_sed(multi, opts, n_wl, wl, Tdust, rt, tab_RT_az, sed, n_sent, E_disk, stokes_rt, &
+          counters, device_of, seconds) bind(C, name="mcgpu_multi_run_sed")
+       import :: c_int, c_ptr, c_float, mcgpu_mono_opts, mcgpu_sed_wavelength
+       type(c_ptr), value :: multi
+       type(mcgpu_mono_opts), intent(in) :: opts
+       integer(c_int), value :: n_wl
+       type(mcgpu_sed_wavelength), intent(in) :: wl(*)
+       real(c_float), intent(in) :: Tdust(*)
+       type(c_ptr), value :: rt, tab_RT_az      ! c_loc of a mcgpu_rt_opts and of tab_RT_az(RT_n_az), or c_null_ptr: no ray tracing
+       type(c_ptr), value :: sed, n_sent, E_disk, stokes_rt, counters, device_of, seconds   ! c_loc of the output arrays or c_null_ptr
+     end function mcgpu_multi_run_sed
 
      ! ranks of the handle's RCCL communicator (ncclCommCount); 0 while none has been opened
      integer(c_int) function mcgpu_multi_rccl_ranks(multi) bind(C, name="mcgpu_multi_rccl_ranks")

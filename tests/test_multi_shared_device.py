@@ -227,3 +227,44 @@ def test_bench_dry_run_in_library_mode_with_two_contexts():
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["value"] > 0 and "shared-device" in line["launcher"]
     assert line["config"]["packets_per_gpu"] == 2000000 and abs(line["config"]["crossings_per_packet"] - 252) < 5
+
+
+def test_sed_step_sharded_by_wavelength_equals_the_single_context():
+    """`mcgpu_multi_run_sed`: run_sed_mc's loop over the wavelengths (dust_transfer.f90:899-1027) is the partition -- every
+    context takes whole wavelengths (emission tables from Tdust, scout / commit passes, the ray-traced SED of the dust) and
+    only their results travel; no xI_scatt is reduced, nothing is summed across contexts.  With 2 and 3 contexts a
+    wavelength's results are the single context's: stopping packets, counters and SED packet counts exactly, the sums to
+    the order of one context's own atomic additions; the longest wavelengths (by the cost hint) are dealt out first."""
+    m = sed_model(M.small(RT_n_incl=2))
+    T = m.extra["Tdust"]
+    lams = [3, 8, 12, 17, 20, 22]
+    ref = None
+    for n_dev in (1, 2, 3):
+        me = _multi(m, 1e5, n_dev)
+        costs = [1.0, 5.0, 2.0, 4.0, 3.0, 6.0]
+        r = me.run_sed(lams, 30, T, seeds=[100 + l for l in lams], costs=costs, n_chunks=8, l_sym_ima=True)
+        me.close()
+        assert sorted(set(r["device_of"].tolist())) == list(range(n_dev))
+        if n_dev == 3:   # longest first, each to the least loaded: 6 -> 0, 5 -> 1, 4 -> 2, then 3 -> 2, 2 -> 1, 1 -> 0
+            assert r["device_of"].tolist() == [0, 1, 1, 2, 2, 0]
+        assert all(c["packets"] > 0 for c in r["counters"]) and np.all(r["n_sent"] > 0) and np.all(r["seconds"] > 0)
+        if ref is None:
+            ref = r
+            # ... and the single context's results are those of the per-wavelength calls a host makes today
+            e = _engine(m, 1e5)
+            e.set_rt1()
+            for i, lam in enumerate(lams):
+                td = e.repartition_energie(lam, T, fetch=False)
+                a = e.run_mono(lam, 30, seed=100 + lam, n_chunks=8, fetch_xI=False, device_tables=td)
+                assert a["counters"] == r["counters"][i] and a["n_sent"][lam - 1] == r["n_sent"][i]
+                assert np.array_equal(a["sed"][4][..., lam - 1], r["sed"][i, 4])
+                assert abs(td["E_disk"] - r["E_disk"][i]) <= 1e-12 * abs(td["E_disk"])
+                s, _ = e.dust_map_sed(lam, T, a["n_sent"][lam - 1], td["E_disk"], l_sym_ima=True)
+                assert np.allclose(s, r["sed_rt"][i], rtol=1e-9, atol=1e-12 * np.abs(s).max())
+            e.close()
+            continue
+        assert r["counters"] == ref["counters"]
+        assert np.array_equal(r["n_sent"], ref["n_sent"]) and np.array_equal(r["sed"][:, 4], ref["sed"][:, 4])
+        assert np.allclose(r["sed"], ref["sed"], rtol=1e-9, atol=1e-12 * np.abs(ref["sed"]).max())
+        assert np.allclose(r["E_disk"], ref["E_disk"], rtol=1e-12)
+        assert np.allclose(r["sed_rt"], ref["sed_rt"], rtol=1e-9, atol=1e-12 * np.abs(ref["sed_rt"]).max())
