@@ -381,6 +381,29 @@ def thermal_block(par, args, config, steps, warmup, with_cpu, n_local, crossing=
         if block["tail"]["host_events"]:
             block["tail"]["host_ns_per_event_per_thread"] = (block["tail"]["host_ms"] * 1e6 * block["tail"]["host_threads"] /
                                                             block["tail"]["host_events"])
+        if config == "voronoi" and me is None:
+            # The crossing engine alone: the same grid, the same kernel, the same packets, but a transparent disk
+            # (kappa_factor = 0: no interaction ever) -- crossings per second without the 119 interactions per packet of the
+            # stand-in disk that share the step with them; and the step's split that rate implies.
+            import copy
+            import numpy as np
+            mt = copy.copy(model)
+            mt.kappa_factor = np.zeros_like(np.asarray(model.kappa_factor))
+            et = Engine(mt, n_total, device=par.local_rank)
+            n_t = int(min(n_local, 2e7))
+            et.run_thermal(n_t, seed=77)
+            rt_ = et.run_thermal(n_t, seed=78)
+            et.close()
+            c_t = rt_["counters"]["crossings"]
+            rate_t = c_t / (rt_["kernel_ms"] * 1e-3)
+            t_cross = cross_pp * n_local / rate_t * 1e3       # ms of the step the crossings would take at that rate
+            block["crossing_engine"] = {
+                "transparent_disk": {"packets": n_t, "crossings_per_packet": c_t / n_t, "kernel_ms": rt_["kernel_ms"],
+                                     "crossings_per_s": rate_t, "packets_per_s": n_t / (rt_["kernel_ms"] * 1e-3)},
+                "step": {"crossings_per_s": cross_pp * n_local / (k_ms * 1e-3), "interactions_per_s": inter_pp * n_local / (k_ms * 1e-3),
+                         "crossings_ms_at_the_transparent_rate": t_cross, "share_of_step": t_cross / k_ms,
+                         "note": "the rest of the step is the interactions (119 per packet on this stand-in disk, 10.8 on the "
+                                 "cylindrical grid of the same disk) and what their divergence costs the crossing rounds"}}
         if config == "voronoi":
             block["tessellation"] = {"sites": args.sites, "host_s": model.extra.get("tessellation_s"),
                                      "kernel_ms": model.extra.get("tessellation_kernel_ms"),
@@ -710,7 +733,7 @@ def main():
         if par.mode == "torchrun":
             line["dist"] = {"backend": par.dist.get_backend(), "world_size": par.dist.get_world_size(),
                             "device_allreduces": par.n_allreduce}
-        for k in ("cpu_baseline", "tdust_vs_cpu", "binned_deposits", "tail", "tessellation", "mrw_vs_brute_force_gpu"):
+        for k in ("cpu_baseline", "tdust_vs_cpu", "binned_deposits", "tail", "tessellation", "crossing_engine", "mrw_vs_brute_force_gpu"):
             if k in block:
                 line[k] = block[k]
         line.update(extras)

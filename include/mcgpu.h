@@ -194,7 +194,7 @@ int mcgpu_set_midplane_snap(mcgpu_ctx *ctx, int on);
  *   "xi_log"       SED mode, default-real xI_scatt (mcgpu_set_xI_precision(4)), one dust class, cylindrical grid: 1 (default) =
  *                      the commit pass LOGS its deposits (12 bytes per crossing + the flight's weights once) and a sort
  *                      by sub-bin + segmented sums replace the atomics, at the wavelengths where flights are long
- *                      enough for that to pay (>= 4.5 crossings per flight, measured by the pass's first launch);
+ *                      enough for that to pay (>= 20 crossings per flight, measured by the pass's first launch);
  *                      0 = atomics always; 2 = the log always.  Same sums to the order of default-real additions.
  *   "deposit_log_mb"  size of the binned-deposit log in MiB; 0 (default) = up to 64 GiB (what the packets asked for need), at most a quarter of
  *                      the free device memory.  A smaller log means more, shorter chunks; a
@@ -460,10 +460,12 @@ int mcgpu_run_mono(mcgpu_ctx *ctx, const mcgpu_mono_opts *opts,
 int mcgpu_fetch_xI(mcgpu_ctx *ctx, float *xI_scatt_f32, double *xI_scatt_f64);
 
 /* Accumulator type of xI_scatt on the device: 8 = FP64 sums (default: device = oracle to 1e-6), 4 = default real,
- * the type of the reference's own array (dust_ray_tracing.f90:33).  With 4 the records of two observers share a
- * 64-byte line, which halves the L2 read-modify-writes a run with many observers is bound by (-24 % at 10
- * observers, slower below ~5); a sum of N deposits then carries a rounding error ~ sqrt(N) * 6e-8, far below its
- * Monte Carlo noise 1/sqrt(N).  Call before the first mcgpu_run_mono / mcgpu_set_xI; changing it drops what was
+ * the type of the reference's own array (dust_ray_tracing.f90:33).  With 4 a sub-bin's observers lie side by side, each
+ * with the values a deposit can reach (n_Stokes, + the two origins of scattered light with lsepar_contrib): 4 lines of 64
+ * bytes per crossing at 10 observers instead of 10 -- the memory-side line operations a run with many observers is bound by
+ * (DESIGN.md); a sum of N deposits then carries a rounding error ~ sqrt(N) * 6e-8, far below its Monte Carlo noise
+ * 1/sqrt(N).  (mcgpu_set_xI on such a context keeps the flux types a deposit can reach; n_Stokes + 1 and + 3, direct
+ * light, which no Monte Carlo deposit ever touches, have no place there and read back as 0.)  Call before the first mcgpu_run_mono / mcgpu_set_xI; changing it drops what was
  * accumulated.  mcgpu_fetch_xI, mcgpu_set_xI and the ray tracer work with either; mcgpu_device_xI exposes
  * accumulators of this type. */
 int mcgpu_set_xI_precision(mcgpu_ctx *ctx, int bytes_per_value);

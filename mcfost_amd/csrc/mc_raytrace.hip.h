@@ -24,7 +24,7 @@ struct RtArgs {
   const double* rt_u; const double* rt_v; const double* rt_w;  // observer directions (see MonoArgs)
   const float* rt_az;                                           // tab_RT_az [RT_n_az], degrees
   const double* xI;                                             // device layout [cell][psup][phik][iRT][XI_LINE]
-  int xI_f32, nRT_pad;                                          // ... or [iRT_pad][XI_LINE] floats (MonoArgs::xI_f32)
+  int xI_f32, xi_binf, xi_rec;                                  // ... or the packed default-real layout (MonoArgs::xI_f32, xi32_*)
   const double* J_th;                                           // [n_cells]
   double* out;                                                  // [nRT * N_type_flux]
   // images (k_rt1_image)
@@ -224,9 +224,15 @@ __device__ inline void rt1_integ_ray(const Lds& T, const DevModel& M, const RtAr
         const size_t bin = ((size_t)ic * A.n_theta_rt + (psup - 1)) * A.n_az_rt + (phik - 1);
         double rec[XI_LINE];
         if (A.xI_f32) {
-          const float* r32 = reinterpret_cast<const float*>(A.xI) + (bin * A.nRT_pad + q) * XI_LINE;
+          // (the packed default-real layout, mc_mono.hip.h xi32_*: the observer's values side by side; a flux type no
+          // deposit reaches reads as 0)
+          const float* r32 = reinterpret_cast<const float*>(A.xI) + bin * A.xi_binf + (size_t)q * A.xi_rec;
+          const int nS32 = A.xi_rec - (A.contrib ? 2 : 0);
 #pragma unroll
-          for (int t = 0; t < XI_LINE; ++t) rec[t] = (double)r32[t];
+          for (int t = 0; t < XI_LINE; ++t) {
+            const int sl = xi32_slot_of_type(t, nS32);
+            rec[t] = (sl >= 0 && sl < A.xi_rec) ? (double)r32[sl] : 0.0;
+          }
         } else {
           const double* r64 = A.xI + (bin * A.nRT + q) * XI_LINE;
 #pragma unroll

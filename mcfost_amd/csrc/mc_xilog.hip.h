@@ -26,9 +26,10 @@ constexpr int XI_SEG_UNROLL = 8;     // records whose row loads are in flight to
 size_t xi_sort_temp_bytes(size_t n, int end_bit);
 
 // keys / vals [n] (unsorted; entries a wave reserved and did not use hold a key >= n_bins) -> sorted copies keys2 / vals2 ->
-// xI (default-real device layout [bin][nRT_pad][8]) += the sums.  Asynchronous on `stream`; returns a hipError_t.
+// xI (the packed default-real device layout, mc_mono.hip.h xi32_*: [bin][xi_binf floats], observer q at q * xi_rec) += the sums;
+// slot_star / slot_thermal: the record's values for the two origins (n_Stokes, n_Stokes + 1).  Asynchronous on `stream`; returns a hipError_t.
 int xi_sort_fold(hipStream_t stream, const unsigned int* keys, const unsigned long long* vals, unsigned int* keys2,
                  unsigned long long* vals2, size_t n, int end_bit, void* temp, size_t temp_bytes, const float* rows, int nRT,
-                 int nv, int contrib, int slot_star, int slot_thermal, unsigned int n_bins, float* xI, int nRT_pad);
+                 int nv, int contrib, int slot_star, int slot_thermal, unsigned int n_bins, float* xI, int xi_binf, int xi_rec);
 
 }  // namespace mcgpu

@@ -225,13 +225,13 @@ static int upload(mcgpu_ctx* ctx, const Tp* host, size_t n, const Tp** dev_out, 
   return MCGPU_OK;
 }
 
-// xI_scatt on the device: values (of xI_bytes each) and bytes; default-real records are padded to an even observer count
-static inline int xi_nrt_pad(const mcgpu_ctx* ctx) {
-  const int nRT = ctx->RT_n_incl * ctx->RT_n_az;
-  return ctx->xI_bytes == 4 ? nRT + (nRT & 1) : nRT;
-}
+// xI_scatt on the device: values (of xI_bytes each) and bytes.  FP64: one line of XI_LINE values per (sub-bin, observer);
+// default real: the packed layout of mc_mono.hip.h (xi32_*): xi_rec values per observer, xi_binf per sub-bin
+static inline int xi_rec_of(const mcgpu_ctx* ctx) { return xi32_rec(ctx->lsepar_pola != 0, ctx->lsepar_contrib != 0); }
+static inline int xi_bin_floats_of(const mcgpu_ctx* ctx) { return xi32_bin_floats(ctx->RT_n_incl * ctx->RT_n_az, xi_rec_of(ctx)); }
 static inline size_t xi_dev_values(const mcgpu_ctx* ctx) {
-  return (size_t)ctx->n_az_rt * ctx->n_theta_rt * XI_LINE * xi_nrt_pad(ctx) * (size_t)ctx->M.n_cells;
+  const size_t bins = (size_t)ctx->n_az_rt * ctx->n_theta_rt * (size_t)ctx->M.n_cells;
+  return ctx->xI_bytes == 4 ? bins * (size_t)xi_bin_floats_of(ctx) : bins * XI_LINE * (size_t)(ctx->RT_n_incl * ctx->RT_n_az);
 }
 static inline size_t xi_dev_bytes(const mcgpu_ctx* ctx) { return xi_dev_values(ctx) * (size_t)ctx->xI_bytes; }
 
@@ -2595,10 +2595,10 @@ static int xi_log_prepare(mcgpu_ctx* ctx, unsigned long long n_items, int nRT, b
 }
 
 // Below this many logged crossings per flight the commit pass deposits with atomics: a flight costs its row -- 160 bytes
-// written once and gathered once per crossing -- whatever its length, and a wavelength at which packets scatter every second
-// cell (ref4.1 at 1 um: 2.2 crossings per flight) pays more for the rows than the atomics cost (1.70 against 1.42 s), while
-// one of long flights (36 per flight at 60 um: 0.36 against 0.47 s) does not.
-constexpr double XI_LOG_MIN_CROSSINGS_PER_FLIGHT = 4.5;
+// written once and gathered once per crossing -- whatever its length.  Measured at ten observers against the atomics in the
+// packed layout (4 lines per crossing; profiles/r06_xi_log_ab.log): 36 crossings per flight (ref4.1 at 60 um) 367 against
+// 384 ms; 6 per flight (0.3 um) 633 against 534 ms; 2.2 per flight (1 um) 1.70 against 1.30 s.
+constexpr double XI_LOG_MIN_CROSSINGS_PER_FLIGHT = 20.0;
 
 // One commit pass (the work items [0, A.n_items) of `A`): plainly, or -- `*mode` = 1: with its deposits logged, in launches
 // sized for the log, each followed by the sort and the fold of what it logged.  The first launch is short and measures
@@ -2618,7 +2618,7 @@ static int commit_mono(mcgpu_ctx* ctx, MonoArgs A, int grid_blocks, int block_th
   A.log_keys = ctx->d_xlog_keys[0]; A.log_vals = ctx->d_xlog_vals[0]; A.log_rows = ctx->d_xlog_rows; A.log_ctl = ctx->d_xlog_ctl;
   A.log_cap = ctx->xlog_cap; A.rows_cap = ctx->xlog_rows_cap; A.log_sentinel = (1u << end_bit) - 1u;
   const int nv = pola ? 4 : 1;
-  const int slot_star = pola ? 5 : 2, slot_thermal = pola ? 7 : 4;   // (deposit_rt1_wave's cslot)
+  const int slot_star = nv, slot_thermal = nv + 1;   // (the packed record's two origins: xi32_slot_of_type)
   // (the first launch: room for 1024 records and 256 flights per packet -- ref4.1 has 60-160 and 2-60, by wavelength)
   unsigned long long done = 0, chunk = 1000000ull;
   if (chunk > ctx->xlog_cap / 1024) chunk = ctx->xlog_cap / 1024;
@@ -2649,7 +2649,7 @@ static int commit_mono(mcgpu_ctx* ctx, MonoArgs A, int grid_blocks, int block_th
     if (dev_err) { ctx->err = "device error " + std::to_string(dev_err) + " in the commit pass"; return MCGPU_ERR_KERNEL; }
     const int e = xi_sort_fold(ctx->stream, ctx->d_xlog_keys[0], ctx->d_xlog_vals[0], ctx->d_xlog_keys[1], ctx->d_xlog_vals[1], (size_t)ctl[0],
                                end_bit, ctx->d_xlog_temp, ctx->xlog_temp_bytes, ctx->d_xlog_rows, A.nRT, nv, A.contrib, slot_star, slot_thermal,
-                               n_bins, reinterpret_cast<float*>(ctx->d_xI), A.nRT_pad);
+                               n_bins, reinterpret_cast<float*>(ctx->d_xI), A.xi_binf, A.xi_rec);
     if (e != (int)hipSuccess) { ctx->err = std::string("xI log: sort / fold: ") + hipGetErrorString((hipError_t)e); return MCGPU_ERR_HIP; }
     rpp = (double)ctl[0] / (double)c; fpp = (double)ctl[1] / (double)c;
     ctx->xlog_chunks++; ctx->xlog_records += ctl[0]; ctx->xlog_flights += ctl[1];
@@ -2748,7 +2748,7 @@ extern "C" int mcgpu_run_mono(mcgpu_ctx* ctx, const mcgpu_mono_opts* o, double f
   A.rt_u = ctx->d_rt_u; A.rt_v = ctx->d_rt_v; A.rt_w = ctx->d_rt_w;
   A.n_az_rt = ctx->n_az_rt; A.n_theta_rt = ctx->n_theta_rt; A.N_type_flux = ctx->N_type_flux; A.contrib = ctx->lsepar_contrib;
   A.s11 = ctx->have_rt1 ? ctx->d_tab_s11 + (size_t)(M.nang + 1) * (o->p_lambda - 1) : nullptr;
-  A.xI = ctx->d_xI; A.xI_f32 = ctx->xI_bytes == 4 ? 1 : 0; A.nRT_pad = xi_nrt_pad(ctx);
+  A.xI = ctx->d_xI; A.xI_f32 = ctx->xI_bytes == 4 ? 1 : 0; A.xi_binf = xi_bin_floats_of(ctx); A.xi_rec = xi_rec_of(ctx);
   if (rt2) {
     A.rt2 = 1; A.n_theta_I = ctx->n_theta_I; A.n_phi_I = ctx->n_phi_I; A.I_spec = ctx->d_I_spec; A.I_spec_star = ctx->d_I_spec_star;
     A.N_type_flux = ctx->rt2_N_type_flux; A.contrib = ctx->rt2_contrib;
@@ -2943,7 +2943,7 @@ extern "C" int mcgpu_set_xI(mcgpu_ctx* ctx, const double* xI_scatt) {
   hipError_t e = hipMemcpyAsync(d_in, xI_scatt, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) {
     hipLaunchKernelGGL(k_xI_put, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_xI, d_in,
-                       ctx->n_az_rt, ctx->n_theta_rt, ctx->N_type_flux, nRT, n, ctx->xI_bytes == 4 ? 1 : 0, xi_nrt_pad(ctx));
+                       ctx->n_az_rt, ctx->n_theta_rt, ctx->N_type_flux, nRT, n, ctx->xI_bytes == 4 ? 1 : 0, xi_bin_floats_of(ctx), xi_rec_of(ctx), ctx->lsepar_pola ? 4 : 1);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -2964,7 +2964,7 @@ extern "C" int mcgpu_fetch_xI(mcgpu_ctx* ctx, float* xI_scatt_f32, double* xI_sc
   if (e == hipSuccess) {
     hipLaunchKernelGGL(k_xI_fetch, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_xI, d32, d64,
                        ctx->n_az_rt, ctx->n_theta_rt, ctx->N_type_flux, ctx->RT_n_incl * ctx->RT_n_az, n,
-                       ctx->xI_bytes == 4 ? 1 : 0, xi_nrt_pad(ctx));
+                       ctx->xI_bytes == 4 ? 1 : 0, xi_bin_floats_of(ctx), xi_rec_of(ctx), ctx->lsepar_pola ? 4 : 1);
     e = hipGetLastError();
   }
   if (e == hipSuccess && d32) e = hipMemcpyAsync(xI_scatt_f32, d32, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
@@ -3102,7 +3102,7 @@ static int rt1_prepare(mcgpu_ctx* ctx, const mcgpu_rt_opts* o, const float* tab_
   A.l_far = 10. * o->Rmax;
   A.rt_u = ctx->d_rt_u; A.rt_v = ctx->d_rt_v; A.rt_w = ctx->d_rt_w; A.rt_az = J.d_az.p;
   A.xI = ctx->d_xI; A.J_th = J.d_J.p;
-  A.xI_f32 = ctx->xI_bytes == 4 ? 1 : 0; A.nRT_pad = xi_nrt_pad(ctx);
+  A.xI_f32 = ctx->xI_bytes == 4 ? 1 : 0; A.xi_binf = xi_bin_floats_of(ctx); A.xi_rec = xi_rec_of(ctx);
   if (J.method2) {
     A.method2 = 1; A.q_only = ctx->rt2_src_ibin - 1; A.nang_rt = ctx->rt2_src_nang; A.nang_star = ctx->rt2_src_nang_star;
     A.eps2 = ctx->d_eps2; A.eps2_star = ctx->d_eps2_star; A.z_grid = ctx->d_rt2_zgrid;

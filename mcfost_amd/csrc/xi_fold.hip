@@ -9,7 +9,7 @@ namespace mcgpu {
 // nv * nRT Stokes values (column of the row = the value's index) followed, with contributions, by the nRT copies of I.
 __global__ void __launch_bounds__(256) k_xi_segfold(const unsigned int* __restrict__ keys, const unsigned long long* __restrict__ vals,
                                                     unsigned long long n, const float* __restrict__ rows, int nRT, int nv, int contrib,
-                                                    int slot_star, int slot_thermal, unsigned int n_bins, float* xI, int nRT_pad) {
+                                                    int slot_star, int slot_thermal, unsigned int n_bins, float* xI, int xi_binf, int xi_rec) {
   const int lane = threadIdx.x & 63;
   const unsigned long long wave = (unsigned long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const unsigned long long r_lo = wave * XI_SEG_CHUNK;
@@ -25,7 +25,7 @@ __global__ void __launch_bounds__(256) k_xi_segfold(const unsigned int* __restri
   float acc = 0.0f, acc_star = 0.0f;   // (copy lanes: acc = thermal origin, acc_star = stellar origin)
   unsigned int cur = 0xFFFFFFFFu;
   auto flush = [&](unsigned int bin) {
-    float* rec = xI + ((size_t)bin * nRT_pad + q) * 8;
+    float* rec = xI + (size_t)bin * xi_binf + (size_t)q * xi_rec;   // (the packed default-real layout, mc_mono.hip.h xi32_*)
     if (stokes && acc != 0.0f) atomicAdd(rec + slot, acc);
     if (copy) { if (acc != 0.0f) atomicAdd(rec + slot_thermal, acc); if (acc_star != 0.0f) atomicAdd(rec + slot_star, acc_star); }
     acc = 0.0f; acc_star = 0.0f;
@@ -63,7 +63,7 @@ size_t xi_sort_temp_bytes(size_t n, int end_bit) {
 
 int xi_sort_fold(hipStream_t stream, const unsigned int* keys, const unsigned long long* vals, unsigned int* keys2,
                  unsigned long long* vals2, size_t n, int end_bit, void* temp, size_t temp_bytes, const float* rows, int nRT,
-                 int nv, int contrib, int slot_star, int slot_thermal, unsigned int n_bins, float* xI, int nRT_pad) {
+                 int nv, int contrib, int slot_star, int slot_thermal, unsigned int n_bins, float* xI, int xi_binf, int xi_rec) {
   if (n == 0) return (int)hipSuccess;
   hipError_t e = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys, keys2, vals, vals2, (int)n, 0, end_bit, stream);
   if (e != hipSuccess) return (int)e;
@@ -71,7 +71,7 @@ int xi_sort_fold(hipStream_t stream, const unsigned int* keys, const unsigned lo
   const int n_vals = nv * nRT + (contrib ? nRT : 0);
   dim3 grid((unsigned int)((n_waves + 3) / 4), (unsigned int)((n_vals + 63) / 64));
   hipLaunchKernelGGL(k_xi_segfold, grid, dim3(256), 0, stream, keys2, vals2, (unsigned long long)n, rows, nRT, nv, contrib, slot_star,
-                     slot_thermal, n_bins, xI, nRT_pad);
+                     slot_thermal, n_bins, xI, xi_binf, xi_rec);
   return (int)hipGetLastError();
 }
 

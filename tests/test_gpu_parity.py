@@ -786,8 +786,8 @@ def test_sed_mode_speculative_commit(sed_small):
 
 
 def test_sed_mode_default_real_records():
-    """mcgpu_set_xI_precision(4): xI_scatt accumulated in default real (the reference's own type), two observers per
-    64-byte line.  Same packets and SED bins; xI_scatt to FP32 rounding; fetch / set / ray tracing / the zero-copy
+    """mcgpu_set_xI_precision(4): xI_scatt accumulated in default real (the reference's own type), the observers' records
+    packed side by side.  Same packets and SED bins; xI_scatt to FP32 rounding; fetch / set / ray tracing / the zero-copy
     tensor all follow the type; back to FP64 the 1e-6 parity returns."""
     import torch
     from helpers import sed_model, xI_close
@@ -804,7 +804,11 @@ def test_sed_mode_default_real_records():
         xI_close(a["xI_scatt"], b["xI_scatt"], rtol=1e-4, n_midplane_cells=0 if cfg.l3D else cfg.n_rad, atol_rel=1e-5)
         t = e.device_xI()
         nRT = m.rt["RT_n_incl"] * m.rt["RT_n_az"]
-        assert t.dtype == torch.float32 and t.numel() == m.n_cells * m.rt["n_theta_rt"] * m.rt["n_az_rt"] * (nRT + nRT % 2) * 8
+        # (the packed default-real layout, mc_mono.hip.h xi32_*: per sub-bin the observers side by side, each its n_Stokes
+        # values + the two origins a deposit can have, padded to whole 64-byte lines per sub-bin)
+        ntf = m.rt["N_type_flux"]
+        rec = {1: 1, 4: 4, 5: 3, 8: 6}[ntf]
+        assert t.dtype == torch.float32 and t.numel() == m.n_cells * m.rt["n_theta_rt"] * m.rt["n_az_rt"] * ((nRT * rec + 15) // 16 * 16)
         assert abs(float(t.double().sum()) / a["xI_scatt"].sum() - 1) < 1e-6
         # ray tracing from the default-real records == the oracle's on the same values (psup-symmetrised, see above)
         x = a["xI_scatt"].copy()
