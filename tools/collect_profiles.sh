@@ -3,7 +3,7 @@
 #   tools/collect_profiles.sh [config ...]        (default: pascucci ref41)
 # Per configuration: one rocprofv3 kernel trace with --stats of `python3 bench.py --config C` and four PMC passes
 # (separate runs, counters only with --kernel-trace, as the MI355X guide prescribes) of the same command with
-# --steps 1 --warmup 0.  tools/summarize_prof.py turns them into gpurun_out/r05_kt_C.json / r05_pmc_C.json, which
+# --steps 1 --warmup 0.  tools/summarize_prof.py turns them into gpurun_out/r06_kt_C.json / r06_pmc_C.json, which
 # are then copied to profiles/ and committed.
 R=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $R/gpurun_out/prof
@@ -21,4 +21,4 @@ for C in $CFGS; do
   timeout 600 rocprofv3 --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $P/b -o b -- $B --steps 1 --warmup 0 > $P/b.log 2>&1 </dev/null
   (cd $R && python3 tools/summarize_prof.py gpurun_out/prof/$C $C gpurun_out $NP)
 done
-ls -la $R/gpurun_out/r05_*.json
+ls -la $R/gpurun_out/r06_*.json

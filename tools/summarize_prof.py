@@ -1,5 +1,5 @@
 """Summarise the rocprofv3 CSV output of tools/collect_profiles.sh for one configuration into
-<dst>/r05_kt_<config>.json (kernel trace statistics) and <dst>/r05_pmc_<config>.json (counters of the dominant
+<dst>/r06_kt_<config>.json (kernel trace statistics) and <dst>/r06_pmc_<config>.json (counters of the dominant
 kernel per launch, derived figures, and the hash of the kernel sources they were measured on: bench.py only
 reports them while that hash matches).
 
@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 src, config, dst = sys.argv[1], sys.argv[2], sys.argv[3]
 KERNELS = ("k_thermal", "k_mono", "k_fold_bins", "k_tail")
-ROUND = "r05"
+ROUND = "r06"
 
 
 def dominant(name):
