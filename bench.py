@@ -329,6 +329,8 @@ def thermal_block(par, args, config, steps, warmup, with_cpu, n_local, crossing=
         pmc = pmc_summary(config, n_local, world)
         if config == "voronoi" and args.sites != 1000000:   # (the committed counter passes are those of the default tessellation)
             pmc = {}
+        if (args.crossing if crossing is None else crossing) == 1:   # (... and those of the default crossing, not of option "crossing" = 1)
+            pmc = {}
         rate_gpu = n_local / (k_ms * 1e-3)
         valu_pp = (pmc.get("insts_per_packet") or {}).get("valu")
         binned = cfg.l3D and config != "voronoi" and eng.get_info("bin_buckets") > 0
@@ -556,8 +558,12 @@ def sed_block(par, args, steps, warmup, with_cpu, packets, observers, all_lambda
         # (two observers share a 64-byte line), 64 in FP64
         rec_bytes = 32.0 if args.xI_precision == 4 else 64.0
         bytes_step = sent_all / world / steps * cross_pp * (8.0 + 2 * rec_bytes * nRT)
-        lines_per_rec = 0.5 if args.xI_precision == 4 else 1.0   # default-real records: two observers share a 64-byte line
-        line_ops_s = sent_all / world / dt * cross_pp * nRT * lines_per_rec
+        # memory-side line operations per crossing: FP64 records one 64-byte line per observer; default real the packed layout
+        # (mc_mono.hip.h xi32_*): the sub-bin's observers side by side, n_Stokes (+ 2 origins) values each, in whole lines
+        n_st = 4 if (cfg.lsepar_pola and cfg.aniso_method == 1) else 1
+        rec_vals = n_st + (2 if cfg.lsepar_contrib else 0)
+        lines_per_crossing = float((nRT * rec_vals + 15) // 16) if args.xI_precision == 4 else float(nRT)
+        line_ops_s = sent_all / world / dt * cross_pp * lines_per_crossing
         block = {
             "metric": "photon packets/sec (whole node), SED-mode MC packet loop with ray-tracing deposits",
             "value": sent_all / dt, "unit": "packets/s", "n_gpus": world, "steps": steps, "warmup": warmup,
@@ -567,7 +573,7 @@ def sed_block(par, args, steps, warmup, with_cpu, packets, observers, all_lambda
                                    "in the stop bin each, RT1 deposits for %d observers (both passes timed)"
                                    % (lam_text, n2, nRT),
                        "packets_per_gpu_per_step": sent_all / world / steps, "crossings_per_packet": cross_pp,
-                       "observers": nRT, "xI_record": "f32 pairs" if args.xI_precision == 4 else "f64",
+                       "observers": nRT, "xI_record": ("f32 packed, %d lines per crossing" % int(lines_per_crossing)) if args.xI_precision == 4 else "f64",
                        "records_per_s": sent_all / dt * cross_pp * nRT},
             # one 64-byte record per crossing and observer is one memory-side atomic line operation: that rate, not
             # bytes, binds this mode
