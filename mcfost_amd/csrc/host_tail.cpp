@@ -147,6 +147,15 @@ static thread_local DepositCache* tl_deposits = nullptr;
 }  // namespace mcgpu_host
 #define MCGPU_TAIL_DEPOSIT(A, ic, v) mcgpu_host::tl_deposits->add((ic), (v))
 #define MCGPU_TAIL_UNFOLDED(ic) mcgpu_host::tl_deposits->unfolded(ic)
+// the cell's absorbed energy while other threads fold their deposits into it: a relaxed atomic load (any value the cell
+// has held is as good an estimate as the reference's per-thread partial sum; a plain load would be a data race)
+static inline double host_load_f64(const double* p) {
+  const unsigned long long b = __atomic_load_n(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED);
+  double d;
+  memcpy(&d, &b, 8);
+  return d;
+}
+#define MCGPU_TAIL_LOAD_E(p) host_load_f64(p)
 
 #include "mc_tail.hip.h"
 

@@ -50,7 +50,7 @@ __device__ inline int wave_first_ge(const Tp* tab, int lo, int hi, Tp x, int lan
     if (tab[mid] < x) lo = mid + 1; else hi = mid;
   }
   return lo;
-#endif
+#else
   for (int base = lo; base < hi; base += BIN_WAVE) {
     const int k = base + lane;
     const bool hit = (k < hi) && !(tab[k < hi ? k : lo] < x);
@@ -58,6 +58,7 @@ __device__ inline int wave_first_ge(const Tp* tab, int lo, int hi, Tp x, int lan
     if (m) return base + (__ffsll((long long)m) - 1);
   }
   return hi;
+#endif
 }
 
 // what the 64 lanes hold for the interactions [base, base + 64) of the wave's packet
@@ -88,7 +89,8 @@ __device__ inline void tail_draw(TailBatch& B, uint32_t k0, uint32_t k1, uint32_
 #ifndef MCGPU_TAIL_DEPOSIT
 #define MCGPU_TAIL_DEPOSIT(A, ic, v) atomic_add_f64(&(A).E_abs[ic], (v))
 #define MCGPU_TAIL_UNFOLDED(ic) 0.0
-#endif
+#define MCGPU_TAIL_LOAD_E(p) (*(p))   // (the cell's absorbed energy: a PLAIN load on the device, see cell_energy below; the
+#endif                               // host build reads it as a relaxed atomic -- other threads add to it meanwhile)
 
 #ifndef MCGPU_TAIL_TEST_HOOK   // (tests/emu: hand a packet over after a given number of its events, whatever the others do --
 #define MCGPU_TAIL_TEST_HOOK(events_here) false   // one emulated lane runs the packets one after the other)
@@ -183,7 +185,7 @@ __device__ __forceinline__ bool tail_packet(const Lds& T, const DevModel& M, con
   };
   auto cell_energy = [&](int ic) {
     if (A.frozen) return A.E_prior[ic];
-    if (ic != e_cell) { e_val = A.E_abs[ic] + MCGPU_TAIL_UNFOLDED(ic); e_cell = ic; }
+    if (ic != e_cell) { e_val = MCGPU_TAIL_LOAD_E(&A.E_abs[ic]) + MCGPU_TAIL_UNFOLDED(ic); e_cell = ic; }
     return (e_val + (ic == dep_cell ? dep_sum : 0.0)) * A.qscale;
   };
 
