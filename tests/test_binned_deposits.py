@@ -116,6 +116,7 @@ def test_tail_kernel_frozen_parity_and_the_automatic_threshold():
     models = [small, md, M.build_model(M.small(aniso_method=2, lsepar_pola=False)),
               M.build_model(M.small(n_rad=12, nz=6, n_az=8, l3D=True))]
     n = 30000
+    host_ran = 0
     for m in models:
         o = _oracle(m, n)
         prior = o.run_thermal(2000, seed=1)["E_abs"]
@@ -136,10 +137,15 @@ def test_tail_kernel_frozen_parity_and_the_automatic_threshold():
             assert w == (0 if thr == 0 else (1 if where == 1 else 2))
             if w:
                 if where != 1:
-                    assert e.get_info("tail_host_packets") > 0 and e.get_info("tail_host_events") > 0
-                    assert e.get_info("tail_host_packets") <= (host_pk if host_pk else 8 * max(e.get_info("tail_host_threads"), 32))
+                    # (how many packets reach k_tail, and so the host, is the schedule's business: a workgroup hands over what it
+                    # has LEFT when its work runs out -- on a small launch that can be nothing at all)
+                    hp = e.get_info("tail_host_packets")
+                    assert hp <= (host_pk if host_pk else 8 * max(e.get_info("tail_host_threads"), 32))
+                    assert (e.get_info("tail_host_events") > 0) == (hp > 0)
+                    host_ran += hp
             e.close()
             _same_packets(a, b)
+    assert host_ran > 100   # ... but over the four models and their settings the host threads did run packets
     # the automatic choice
     e = _engine(M.build_model(M.pascucci()), 1e6)
     assert e.get_info("tail_threshold") == 0            # thin: no hand-over (its launch has no tail)
