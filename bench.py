@@ -554,14 +554,14 @@ def sed_block(par, args, steps, warmup, with_cpu, packets, observers, all_lambda
         cnt = eng.fetch()["counters"]
         cross_pp = cnt["crossings"] / max(cnt["packets"], 1)
         nRT = m.rt["RT_n_incl"] * m.rt["RT_n_az"]
-        # per crossing: kappa_factor 8 B + the read and the write of one xI_scatt record per observer -- 32 bytes in default real
-        # (two observers share a 64-byte line), 64 in FP64
-        rec_bytes = 32.0 if args.xI_precision == 4 else 64.0
+        # per crossing: kappa_factor 8 B + the read and the write of one xI_scatt record per observer -- in default real the
+        # packed record's n_Stokes (+ 2 origins) values of 4 bytes (24 B with Stokes tracking and contributions), 64 B in FP64
+        n_st = 4 if (cfg.lsepar_pola and cfg.aniso_method == 1) else 1
+        rec_vals = n_st + (2 if cfg.lsepar_contrib else 0)
+        rec_bytes = 4.0 * rec_vals if args.xI_precision == 4 else 64.0
         bytes_step = sent_all / world / steps * cross_pp * (8.0 + 2 * rec_bytes * nRT)
         # memory-side line operations per crossing: FP64 records one 64-byte line per observer; default real the packed layout
         # (mc_mono.hip.h xi32_*): the sub-bin's observers side by side, n_Stokes (+ 2 origins) values each, in whole lines
-        n_st = 4 if (cfg.lsepar_pola and cfg.aniso_method == 1) else 1
-        rec_vals = n_st + (2 if cfg.lsepar_contrib else 0)
         lines_per_crossing = float((nRT * rec_vals + 15) // 16) if args.xI_precision == 4 else float(nRT)
         line_ops_s = sent_all / world / dt * cross_pp * lines_per_crossing
         block = {
