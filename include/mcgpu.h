@@ -187,7 +187,11 @@ int mcgpu_set_midplane_snap(mcgpu_ctx *ctx, int on);
  *                      thread -- a packet is one dependent chain of events, which a wave runs at 1.0-1.6 us per event
  *                      and a host core at 30-100 ns; never the CPU oracle of the tests); 1 = k_tail finishes every
  *                      packet.  The hand-over is stream-ordered (copies + a host callback on the context's stream):
- *                      a launch stays asynchronous.  Automatic = 2 wherever k_tail runs.
+ *                      a launch stays asynchronous.  Automatic = 2 wherever k_tail runs.  Which packets the host
+ *                      finishes depends on the schedule, and its libm rounds log / sin / cos in other last digits
+ *                      than the device's: with 2, two runs of the same seed are two realisations of those few hundred
+ *                      packets (equal to Monte Carlo noise, like two runs of the reference on different thread
+ *                      counts); 1 gives the same sums every time (to the order of the atomic additions).
  *   "host_threads" host threads of such a tail: 0 (default) = the machine's hardware threads divided by its GPUs,
  *                      at most 32; 1..256
  *   "tail_host_packets"  packets k_tail leaves to the host: 0 (default) = 8 per host thread; 1..65536

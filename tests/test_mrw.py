@@ -341,12 +341,20 @@ def test_config4_thick_ref41_live_against_brute_force_with_the_reference_gate():
     cfg.dust_mass = 1e-2
     m0 = M.build_model(cfg)
     e0 = Engine(m0, n)
+    # (tail_where 1: the bars below were set on runs that are the same every time.  With the host threads finishing the last
+    # few hundred packets -- the default -- which packets those are depends on the schedule, their logarithms and sines come
+    # from the host's libm, and a trapped packet's history is chaotic in the last digit: every run is then another, equally
+    # valid realisation of exactly the packets that carry this thick disk's deep cells, and a bar with 3.1 % of 4 % to spare is
+    # crossed by one run in four.  The host tail's own parity is held packet for packet where that is possible, in frozen
+    # mode: test_device_walk_equals_the_oracle_frozen, tests/test_binned_deposits.py.)
+    e0.set_option("tail_where", 1)
     r0 = [e0.run_thermal(n, seed=s) for s in (3, 13, 23)]
     T0 = np.array([e0.temp_finale(r["E_abs"]) for r in r0])
     e0.close()
     m1 = M.build_model(cfg)
     M.init_mrw(m1)
     e1 = Engine(m1, n)
+    e1.set_option("tail_where", 1)
     r1 = [e1.run_thermal(n, seed=s) for s in (4, 14, 24)]
     T1 = np.array([e1.temp_finale(r["E_abs"]) for r in r1])
     e1.close()
