@@ -341,12 +341,12 @@ def test_config4_thick_ref41_live_against_brute_force_with_the_reference_gate():
     cfg.dust_mass = 1e-2
     m0 = M.build_model(cfg)
     e0 = Engine(m0, n)
-    # (tail_where 1: the bars below were set on runs that are the same every time.  With the host threads finishing the last
-    # few hundred packets -- the default -- which packets those are depends on the schedule, their logarithms and sines come
-    # from the host's libm, and a trapped packet's history is chaotic in the last digit: every run is then another, equally
-    # valid realisation of exactly the packets that carry this thick disk's deep cells, and a bar with 3.1 % of 4 % to spare is
-    # crossed by one run in four.  The host tail's own parity is held packet for packet where that is possible, in frozen
-    # mode: test_device_walk_equals_the_oracle_frozen, tests/test_binned_deposits.py.)
+    # (tail_where 1: with the host threads finishing the last few hundred packets -- the default -- which packets those are
+    # depends on the schedule and their logarithms and sines come from the host's libm, so every run is another, equally
+    # valid realisation of exactly the trapped packets that carry this thick disk's deep cells.  The bars below compare the
+    # WALK with brute force; they keep to the device tail, whose runs differ only by the order of the atomic sums.  The
+    # host tail's own parity is held packet for packet in frozen mode: test_device_walk_equals_the_oracle_frozen,
+    # tests/test_binned_deposits.py.)
     e0.set_option("tail_where", 1)
     r0 = [e0.run_thermal(n, seed=s) for s in (3, 13, 23)]
     T0 = np.array([e0.temp_finale(r["E_abs"]) for r in r0])
