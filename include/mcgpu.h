@@ -198,7 +198,8 @@ int mcgpu_set_midplane_snap(mcgpu_ctx *ctx, int on);
  *   "xi_log"       SED mode, default-real xI_scatt (mcgpu_set_xI_precision(4)), one dust class, cylindrical grid: 1 (default) =
  *                      the commit pass LOGS its deposits (12 bytes per crossing + the flight's weights once) and a sort
  *                      by sub-bin + segmented sums replace the atomics, at the wavelengths where flights are long
- *                      enough for that to pay (>= 20 crossings per flight, measured by the pass's first launch);
+ *                      enough for that to pay (>= 20 crossings per flight, measured by the pass's first launch) and a crossing's
+ *                      atomics would touch at least four 64-byte lines (many observers);
  *                      0 = atomics always; 2 = the log always.  Same sums to the order of default-real additions.
  *   "deposit_log_mb"  size of the binned-deposit log in MiB; 0 (default) = up to 64 GiB (what the packets asked for need), at most a quarter of
  *                      the free device memory.  A smaller log means more, shorter chunks; a
