@@ -24,6 +24,7 @@
 // and rounds to default real.
 #pragma once
 #include "mc_device.hip.h"
+#include "mc_xi32.hip.h"
 
 namespace mcgpu {
 
@@ -49,8 +50,8 @@ struct MonoArgs {
   int n_az_rt, n_theta_rt, N_type_flux, contrib;
   const float* s11;                     // tab_s11_pos(0:nang, p_lambda)
   double* xI;                           // device layout [n_cells][n_theta_rt][n_az_rt][nRT][XI_LINE] of doubles, or with
-  int xI_f32, xi_binf, xi_rec;          // xI_f32 (mcgpu_set_xI_precision(4)): the PACKED default-real layout (xi32_*, below):
-                                        // [sub-bin][xi_binf floats], observer q's xi_rec values at q * xi_rec
+  int xI_f32;                           // xI_f32 (mcgpu_set_xI_precision(4)): the PACKED default-real layout (Xi32Lay, above):
+  Xi32Lay xi;                           // [sub-bin][xi.binf default reals]
   // ray tracing method 2 (2D): the specific intensity per cell and direction bin
   int rt2, n_theta_I, n_phi_I;
   double* I_spec;                       // device layout [n_cells][n_phi_I][n_theta_I][XI_LINE]
@@ -221,24 +222,6 @@ __device__ inline void rt1_subbin_of(int n_az_rt, bool l3D, double x0, double y0
 }
 
 constexpr int XI_LINE = 8;  // doubles per (cell, sub-bin, observer) record of the device layout: one 64-byte line
-
-// The default-real device layout (mcgpu_set_xI_precision(4); round 6: PACKED).  What binds the commit pass is the number
-// of 64-byte lines a crossing's deposits touch (memory-side atomics: 2.0e10 line operations a second for the whole chip,
-// whatever the lanes of an instruction put on a line), and a padded record of 8 values per observer holds only the values
-// a deposit can reach: the n_Stokes Stokes values and, with lsepar_contrib, the TWO origins scattered light has (n_Stokes
-// + 2: star, + 4: thermal, dust_ray_tracing.f90:519-521, 620-623; + 1 and + 3 are direct light, never deposited here).
-// So a sub-bin holds its nRT observers side by side, xi_rec = n_Stokes (+ 2) values each, padded to whole lines as a
-// whole: 10 observers with Stokes tracking and contributions = 60 values = 4 lines instead of 5; without contributions 3;
-// without Stokes tracking 2 or 1.  mcgpu_fetch_xI / mcgpu_set_xI and the ray tracers translate.
-__host__ __device__ inline int xi32_rec(bool pola, bool contrib) { return (pola ? 4 : 1) + (contrib ? 2 : 0); }
-__host__ __device__ inline int xi32_bin_floats(int nRT, int rec) { return (nRT * rec + 15) / 16 * 16; }
-// flux type (0-based index into N_type_flux) -> value of the record, -1: a type no deposit reaches (reads as 0)
-__host__ __device__ inline int xi32_slot_of_type(int type, int nS) {
-  if (type < nS) return type;
-  if (type == nS + 1) return nS;
-  if (type == nS + 3) return nS + 1;
-  return -1;
-}
 
 // save_radiation_field, lscatt_ray_tracing2 branch (radiation_field.f90:91-129; 2D only): the direction bin of a path --
 // the azimuth of the packet's direction relative to the azimuth of the path's midpoint, and cos(theta) mirrored below
@@ -432,13 +415,15 @@ __device__ inline void deposit_rt1_wave(const DevModel& M, const MonoArgs& A, co
     }
 #ifdef MCGPU_LANE_EMULATION
     if (A.xI_f32 && D.on) {  // (the CPU emulation has one lane and no tile: the default-real layout, value by value)
-      float* rec32 = reinterpret_cast<float*>(A.xI) +
-          (((size_t)(D.icell - 1) * A.n_theta_rt + (D.psup - 1)) * A.n_az_rt + (D.phik - 1)) * A.xi_binf + (size_t)q * A.xi_rec;
-      if (mask & 1u) atomicAdd(rec32, (float)v0);
-      if (POLA && (mask & 2u)) atomicAdd(rec32 + 1, (float)v1);
-      if (POLA && (mask & 4u)) atomicAdd(rec32 + 2, (float)v2);
-      if (POLA && (mask & 8u)) atomicAdd(rec32 + 3, (float)v3);
-      if (cslot && ((mask >> cslot) & 1u)) atomicAdd(rec32 + xi32_slot_of_type(cslot, POLA ? 4 : 1), (float)v0);
+      float* bin32 = reinterpret_cast<float*>(A.xI) +
+          (((size_t)(D.icell - 1) * A.n_theta_rt + (D.psup - 1)) * A.n_az_rt + (D.phik - 1)) * A.xi.binf;
+      const int nS = POLA ? 4 : 1;
+      const float v[4] = {(float)v0, (float)v1, (float)v2, (float)v3};
+      for (int t = 0; t < nS; ++t) {
+        const int o = xi32_offset(A.xi, q, t, nS);       // (-2: I where it is the sum of the origins -- not stored)
+        if (o >= 0 && ((mask >> t) & 1u)) atomicAdd(bin32 + o, v[t]);
+      }
+      if (cslot && ((mask >> cslot) & 1u)) atomicAdd(bin32 + xi32_offset(A.xi, q, cslot, nS), (float)v0);
     } else {
       if (mask & 1u) atomic_add_f64(rec, v0);
       if (POLA && (mask & 2u)) atomic_add_f64(rec + 1, v1);
@@ -454,13 +439,13 @@ __device__ inline void deposit_rt1_wave(const DevModel& M, const MonoArgs& A, co
 
 #ifndef MCGPU_LANE_EMULATION
 // The same with default-real records (mcgpu_set_xI_precision(4), the type of the reference's own array) in the PACKED
-// layout (xi32_*): the sub-bin's observers side by side, so the wave goes through the sub-bin LINE BY LINE -- per line the
-// depositing lanes stage the 16 values of their crossing that fall on it (the tile: 64 places x 16 default reals), then
-// 16 lanes serve each staged place: four places, four line operations per atomic instruction, every value of a line
-// added by ONE instruction.  (Round 4's arrangement -- a pair of padded records per line, 2K lanes per pair -- touched
-// nRT / 2 lines per crossing; this one ceil(nRT x xi_rec / 16): 4 instead of 5 at ten observers with Stokes tracking and
-// contributions, 3 / 2 / 1 with fewer values per observer.)  var: the weights depend on the cell's dust class and are
-// computed per crossing; otherwise they are the flight's (angles_scatt_rt1 left them in LDS) times the path length.
+// layout (Xi32Lay): the sub-bin's observers side by side, so the wave goes through the sub-bin LINE BY LINE -- per line the
+// lanes whose deposits reach it stage the 16 values of their crossing that fall on it (the tile: 64 places x 16 default
+// reals), then 16 lanes serve each staged place: four places, four line operations per atomic instruction, every value of
+// a line added by ONE instruction.  In the split arrangement a line that holds only one origin's values is staged by the
+// packets of that origin alone.  Lines per crossing at ten observers with Stokes tracking and contributions: 3 (round 4's
+// pairs of padded records: 5; the interleaved records with I: 4).  var: the weights depend on the cell's dust class and
+// are computed per crossing; otherwise they are the flight's (angles_scatt_rt1 left them in LDS) times the path length.
 template <bool POLA>
 __device__ inline void deposit_rt1_wave_f32(const DevModel& M, const MonoArgs& A, const RtScratch& R, const float* mu,
                                             const RtDeposit& D, const double S[4], bool flag_star, double* tile,
@@ -469,73 +454,102 @@ __device__ inline void deposit_rt1_wave_f32(const DevModel& M, const MonoArgs& A
   const int lane = threadIdx.x & 63;
   const bool var = M.n_classes != 0;
   const size_t vcol = D.on ? mono_class_col(M, A, D.icell) : 0;
-  const int nS = POLA ? 4 : 1, REC = A.xi_rec, n_lines = A.xi_binf >> 4;
-  const unsigned long long any = __ballot(D.on && !MCGPU_DIAG(A.flags, 1));
-  const int n_act = __popcll(any);
-  if (n_act == 0) return;
-  const bool staged = ((any >> lane) & 1ull) != 0ull;
-  const int place = __popcll(any & ((1ull << lane) - 1ull));
+  const Xi32Lay X = A.xi;
+  const int n_lines = X.binf >> 4, n_stokes = A.nRT * X.nA;
+  const bool on = D.on && !MCGPU_DIAG(A.flags, 1);
+  if (__ballot(on) == 0ull) return;
+  const unsigned long long lt = (1ull << lane) - 1ull;
   lds_f32* const tile32 = (lds_f32*)tile;            // (explicit address spaces, tile_sync: see wave_deposit_records)
   lds_u64* const taddr = (lds_u64*)tile_addr;
   (void)tile_mask;
-  if (staged) {
-    const size_t bin = ((size_t)(D.icell - 1) * A.n_theta_rt + (D.psup - 1)) * A.n_az_rt + (D.phik - 1);
-    taddr[place] = (unsigned long long)(reinterpret_cast<float*>(A.xI) + bin * (size_t)A.xi_binf);
-  }
+  const size_t bin = on ? ((size_t)(D.icell - 1) * A.n_theta_rt + (D.psup - 1)) * A.n_az_rt + (D.phik - 1) : 0;
+  float* const bin32 = reinterpret_cast<float*>(A.xI) + bin * (size_t)X.binf;
   const int sr = lane >> 4, sf = lane & 15;   // serving: place 4 g + sr of a group, value sf of the line
   const float lf = (float)D.l;
+  const bool quv = POLA && !MCGPU_DIAG(A.flags, 2), origins = X.oS >= 0 && !MCGPU_DIAG(A.flags, 2);
+  // observer q's deposits I, Q, U, V of this crossing
+  auto values = [&](int q, float& v0, float& v1, float& v2, float& v3) {
+    v1 = 0.0f; v2 = 0.0f; v3 = 0.0f;
+    if (!var) {   // the flight's weights (angles_scatt_rt1) times this crossing's path length
+      if (!POLA) v0 = lf * __int_as_float(R.itheta[q * blockDim.x + threadIdx.x]);
+      else {
+        const float2 wc = reinterpret_cast<const float2*>(R.cosw)[q * blockDim.x + threadIdx.x];
+        const float2 ws = reinterpret_cast<const float2*>(R.sinw)[q * blockDim.x + threadIdx.x];
+        v0 = lf * wc.x; v1 = lf * wc.y; v2 = lf * ws.x; v3 = lf * ws.y;
+      }
+    } else {
+      const int it = R.itheta[q * blockDim.x + threadIdx.x];
+      const float s11 = MONO_MU(0, M.v_s11);
+      if (!POLA) v0 = (float)(D.l * S[0] * (double)s11);
+      else {
+        const float s12 = -s11 * MONO_MU(1, M.v_s12), s22 = s11 * MONO_MU(2, M.v_s22), s33 = -s11 * MONO_MU(3, M.v_s33);
+        const float s34 = -s11 * MONO_MU(4, M.v_s34), s44 = -s11 * MONO_MU(5, M.v_s44);
+        const double cosw = R.cosw[q * blockDim.x + threadIdx.x], sinw = R.sinw[q * blockDim.x + threadIdx.x];
+        const double C1 = S[0], C4 = S[3];
+        const double C2 = cosw * S[1] + (-sinw) * S[2];
+        const double C3 = sinw * S[1] + cosw * S[2];
+        const double D1 = (double)s11 * C1 + (double)s12 * C2;
+        const double D2 = (double)s12 * C1 + (double)s22 * C2;
+        const double D3 = (double)s33 * C3 + (double)(-s34) * C4;
+        const double D4 = (double)s34 * C3 + (double)s44 * C4;
+        v0 = (float)(D.l * D1);
+        v1 = (float)(D.l * ((-cosw) * D2 + (-sinw) * D3));
+        v2 = (float)(D.l * ((-sinw) * D2 + cosw * D3));
+        v3 = (float)(D.l * D4);
+      }
+    }
+  };
   for (int line = 0; line < n_lines; ++line) {
     const int g0 = line << 4;
-    if (staged) {
+    // who reaches this line: in the split arrangement the lines behind the Stokes values hold one origin each
+    bool mine = on;
+    if (X.split) {
+      if (g0 >= X.oT) mine = on && !flag_star;
+      else if (g0 >= n_stokes) mine = on && flag_star;
+    }
+    const unsigned long long any = __ballot(mine);
+    const int n_act = __popcll(any);
+    if (n_act == 0) continue;
+    if (mine) {
       typedef float f32x4_t __attribute__((ext_vector_type(4)));
       typedef __attribute__((address_space(3))) f32x4_t lds_f32x4;
       const f32x4_t z4 = {0.0f, 0.0f, 0.0f, 0.0f};
+      const int place = __popcll(any & lt);
+      taddr[place] = (unsigned long long)(bin32 + g0);
       lds_f32* const my = tile32 + place * 16;
       *(lds_f32x4*)(my) = z4; *(lds_f32x4*)(my + 4) = z4; *(lds_f32x4*)(my + 8) = z4; *(lds_f32x4*)(my + 12) = z4;
-      const int q_lo = g0 / REC;
-      int q_hi = (g0 + 15) / REC;
-      if (q_hi > A.nRT - 1) q_hi = A.nRT - 1;
-      for (int q = q_lo; q <= q_hi; ++q) {
-        float v0, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f;
-        if (!var) {   // the flight's weights (angles_scatt_rt1) times this crossing's path length
-          if (!POLA) v0 = lf * __int_as_float(R.itheta[q * blockDim.x + threadIdx.x]);
-          else {
-            const float2 wc = reinterpret_cast<const float2*>(R.cosw)[q * blockDim.x + threadIdx.x];
-            const float2 ws = reinterpret_cast<const float2*>(R.sinw)[q * blockDim.x + threadIdx.x];
-            v0 = lf * wc.x; v1 = lf * wc.y; v2 = lf * ws.x; v3 = lf * ws.y;
+      if (!X.split || g0 < n_stokes) {   // the observers whose (Stokes) values fall on this line (g: position in the line)
+        const int q_lo = g0 / X.sA;
+        int q_hi = (g0 + 15) / X.sA;
+        if (q_hi > A.nRT - 1) q_hi = A.nRT - 1;
+        for (int q = q_lo; q <= q_hi; ++q) {
+          float v0, v1, v2, v3;
+          values(q, v0, v1, v2, v3);
+          int g = q * X.sA - g0;
+          if (!X.sum_I) { if (g >= 0 && g < 16) my[g] = v0; ++g; }
+          if (POLA) {
+            if (quv) {
+              if (g >= 0 && g < 16) my[g] = v1;
+              if (g + 1 >= 0 && g + 1 < 16) my[g + 1] = v2;
+              if (g + 2 >= 0 && g + 2 < 16) my[g + 2] = v3;
+            }
+            g += 3;
           }
-        } else {
-          const int it = R.itheta[q * blockDim.x + threadIdx.x];
-          const float s11 = MONO_MU(0, M.v_s11);
-          if (!POLA) v0 = (float)(D.l * S[0] * (double)s11);
-          else {
-            const float s12 = -s11 * MONO_MU(1, M.v_s12), s22 = s11 * MONO_MU(2, M.v_s22), s33 = -s11 * MONO_MU(3, M.v_s33);
-            const float s34 = -s11 * MONO_MU(4, M.v_s34), s44 = -s11 * MONO_MU(5, M.v_s44);
-            const double cosw = R.cosw[q * blockDim.x + threadIdx.x], sinw = R.sinw[q * blockDim.x + threadIdx.x];
-            const double C1 = S[0], C4 = S[3];
-            const double C2 = cosw * S[1] + (-sinw) * S[2];
-            const double C3 = sinw * S[1] + cosw * S[2];
-            const double D1 = (double)s11 * C1 + (double)s12 * C2;
-            const double D2 = (double)s12 * C1 + (double)s22 * C2;
-            const double D3 = (double)s33 * C3 + (double)(-s34) * C4;
-            const double D4 = (double)s34 * C3 + (double)s44 * C4;
-            v0 = (float)(D.l * D1);
-            v1 = (float)(D.l * ((-cosw) * D2 + (-sinw) * D3));
-            v2 = (float)(D.l * ((-sinw) * D2 + cosw * D3));
-            v3 = (float)(D.l * D4);
+          if (origins && !X.split) {   // interleaved: the flux in the place of its origin, star then thermal
+            const int gc = g + (flag_star ? 0 : 1);
+            if (gc >= 0 && gc < 16) my[gc] = v0;
           }
         }
-        // the record's values that fall on this line (g: position in the line)
-        const int g = q * REC - g0;
-        if (g >= 0 && g < 16) my[g] = v0;
-        if (POLA && !MCGPU_DIAG(A.flags, 2)) {
-          if (g + 1 >= 0 && g + 1 < 16) my[g + 1] = v1;
-          if (g + 2 >= 0 && g + 2 < 16) my[g + 2] = v2;
-          if (g + 3 >= 0 && g + 3 < 16) my[g + 3] = v3;
-        }
-        if (A.contrib && !MCGPU_DIAG(A.flags, 2)) {   // the copy of I in the slot of its origin: star (nS) or thermal (nS + 1)
-          const int gc = g + nS + (flag_star ? 0 : 1);
-          if (gc >= 0 && gc < 16) my[gc] = v0;
+      }
+      if (origins && X.split) {        // split: the origin's values that fall on this line
+        const int o = (flag_star ? X.oS : X.oT) - g0;   // place of observer 0's value relative to the line
+        int q_lo = -o, q_hi = 15 - o;
+        if (q_lo < 0) q_lo = 0;
+        if (q_hi > A.nRT - 1) q_hi = A.nRT - 1;
+        for (int q = q_lo; q <= q_hi; ++q) {
+          float v0, v1, v2, v3;
+          values(q, v0, v1, v2, v3);
+          my[o + q] = v0;
         }
       }
     }
@@ -554,7 +568,7 @@ __device__ inline void deposit_rt1_wave_f32(const DevModel& M, const MonoArgs& A
       }
 #pragma unroll
       for (int t = 0; t < TILE_UNROLL; ++t)
-        if (val[t] != 0.0f) atomicAdd((float*)((glb_f32*)ad[t] + g0 + sf), val[t]);
+        if (val[t] != 0.0f) atomicAdd((float*)((glb_f32*)ad[t] + sf), val[t]);
     }
     tile_sync();
   }
@@ -1052,7 +1066,7 @@ static __global__ void k_mono_scan(const int* active, int n_active, unsigned lon
 // device layout [icell][psup][phik][iRT][8] -> the reference's xI_scatt(phik,psup,type,iRT,icell),
 // in FP64 and/or default real (what the reference's array holds).  One thread per output element.
 static __global__ void k_xI_fetch(const double* xI, float* out32, double* out64, int n_az, int n_theta, int n_type, int nRT,
-                           size_t n, int f32, int xi_binf, int xi_rec, int nS) {
+                           size_t n, int f32, Xi32Lay xi, int nS) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   size_t r = i;
@@ -1063,8 +1077,7 @@ static __global__ void k_xI_fetch(const double* xI, float* out32, double* out64,
   const size_t bin = (r * n_theta + psup) * n_az + phik;
   double v;
   if (f32) {   // (the packed default-real layout, xi32_*: a type no deposit reaches reads as 0)
-    const int slot = xi32_slot_of_type(type, nS);
-    v = slot >= 0 ? (double)reinterpret_cast<const float*>(xI)[bin * xi_binf + (size_t)q * xi_rec + slot] : 0.0;
+    v = xi32_value(reinterpret_cast<const float*>(xI) + bin * xi.binf, xi, q, type, nS);
   } else {
     v = xI[(bin * nRT + q) * XI_LINE + type];
   }
@@ -1073,9 +1086,10 @@ static __global__ void k_xI_fetch(const double* xI, float* out32, double* out64,
 }
 
 // the reference's xI_scatt(phik,psup,type,iRT,icell) -> device layout (mcgpu_set_xI).  One thread per element.  (Default
-// real: the types the Monte Carlo never deposits -- direct light, n_Stokes + 1 and + 3 -- have no place and are dropped.)
+// real: the types the Monte Carlo never deposits -- direct light, n_Stokes + 1 and + 3 -- have no place and are dropped, and
+// with lsepar_contrib neither has I: it is read back as the sum of the two origins, which is what the Monte Carlo makes it.)
 static __global__ void k_xI_put(double* xI, const double* in64, int n_az, int n_theta, int n_type, int nRT, size_t n, int f32,
-                         int xi_binf, int xi_rec, int nS) {
+                         Xi32Lay xi, int nS) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   size_t r = i;
@@ -1085,8 +1099,8 @@ static __global__ void k_xI_put(double* xI, const double* in64, int n_az, int n_
   const int q = (int)(r % nRT); r /= nRT;
   const size_t bin = (r * n_theta + psup) * n_az + phik;
   if (f32) {
-    const int slot = xi32_slot_of_type(type, nS);
-    if (slot >= 0) reinterpret_cast<float*>(xI)[bin * xi_binf + (size_t)q * xi_rec + slot] = (float)in64[i];
+    const int o = xi32_offset(xi, q, type, nS);
+    if (o >= 0) reinterpret_cast<float*>(xI)[bin * xi.binf + o] = (float)in64[i];
   } else {
     xI[(bin * nRT + q) * XI_LINE + type] = in64[i];
   }

@@ -39,13 +39,9 @@ __device__ inline void rt1_integ_ray_voro(const Lds& T, const DevModel& M, const
         if (A.xI_f32) {
           // (the packed default-real layout, mc_mono.hip.h xi32_*: the observer's values side by side; a flux type no
           // deposit reaches reads as 0)
-          const float* r32 = reinterpret_cast<const float*>(A.xI) + bin * A.xi_binf + (size_t)q * A.xi_rec;
-          const int nS32 = A.xi_rec - (A.contrib ? 2 : 0);
+          const float* b32 = reinterpret_cast<const float*>(A.xI) + bin * A.xi.binf;
 #pragma unroll
-          for (int t = 0; t < XI_LINE; ++t) {
-            const int sl = xi32_slot_of_type(t, nS32);
-            rec[t] = (sl >= 0 && sl < A.xi_rec) ? (double)r32[sl] : 0.0;
-          }
+          for (int t = 0; t < XI_LINE; ++t) rec[t] = t < A.N_type_flux ? xi32_value(b32, A.xi, q, t, n_Stokes) : 0.0;
         } else {
           const double* r64 = A.xI + (bin * A.nRT + q) * XI_LINE;
 #pragma unroll

@@ -16,6 +16,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "mc_xi32.hip.h"
 
 namespace mcgpu {
 
@@ -26,10 +27,11 @@ constexpr int XI_SEG_UNROLL = 8;     // records whose row loads are in flight to
 size_t xi_sort_temp_bytes(size_t n, int end_bit);
 
 // keys / vals [n] (unsorted; entries a wave reserved and did not use hold a key >= n_bins) -> sorted copies keys2 / vals2 ->
-// xI (the packed default-real device layout, mc_mono.hip.h xi32_*: [bin][xi_binf floats], observer q at q * xi_rec) += the sums;
-// slot_star / slot_thermal: the record's values for the two origins (n_Stokes, n_Stokes + 1).  Asynchronous on `stream`; returns a hipError_t.
+// xI (the packed default-real device layout `xi`, mc_xi32.hip.h: [bin][xi.binf default reals]) += the sums; where the layout
+// does not store I (lsepar_contrib) the lanes of I add nothing and the copies go to the two origins' places.  Asynchronous
+// on `stream`; returns a hipError_t.
 int xi_sort_fold(hipStream_t stream, const unsigned int* keys, const unsigned long long* vals, unsigned int* keys2,
                  unsigned long long* vals2, size_t n, int end_bit, void* temp, size_t temp_bytes, const float* rows, int nRT,
-                 int nv, int contrib, int slot_star, int slot_thermal, unsigned int n_bins, float* xI, int xi_binf, int xi_rec);
+                 int nv, int contrib, unsigned int n_bins, float* xI, Xi32Lay xi);
 
 }  // namespace mcgpu

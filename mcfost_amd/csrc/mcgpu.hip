@@ -226,9 +226,9 @@ static int upload(mcgpu_ctx* ctx, const Tp* host, size_t n, const Tp** dev_out, 
 }
 
 // xI_scatt on the device: values (of xI_bytes each) and bytes.  FP64: one line of XI_LINE values per (sub-bin, observer);
-// default real: the packed layout of mc_mono.hip.h (xi32_*): xi_rec values per observer, xi_binf per sub-bin
-static inline int xi_rec_of(const mcgpu_ctx* ctx) { return xi32_rec(ctx->lsepar_pola != 0, ctx->lsepar_contrib != 0); }
-static inline int xi_bin_floats_of(const mcgpu_ctx* ctx) { return xi32_bin_floats(ctx->RT_n_incl * ctx->RT_n_az, xi_rec_of(ctx)); }
+// default real: the packed layout of mc_xi32.hip.h
+static inline Xi32Lay xi_layout_of(const mcgpu_ctx* ctx) { return xi32_layout(ctx->RT_n_incl * ctx->RT_n_az, ctx->lsepar_pola != 0, ctx->lsepar_contrib != 0); }
+static inline int xi_bin_floats_of(const mcgpu_ctx* ctx) { return xi_layout_of(ctx).binf; }
 static inline size_t xi_dev_values(const mcgpu_ctx* ctx) {
   const size_t bins = (size_t)ctx->n_az_rt * ctx->n_theta_rt * (size_t)ctx->M.n_cells;
   return ctx->xI_bytes == 4 ? bins * (size_t)xi_bin_floats_of(ctx) : bins * XI_LINE * (size_t)(ctx->RT_n_incl * ctx->RT_n_az);
@@ -2559,7 +2559,7 @@ extern "C" int mcgpu_rt2_source(mcgpu_ctx* ctx, const mcgpu_rt_opts* o, int p_la
 static bool xi_log_applicable(const mcgpu_ctx* ctx, bool rt1) {
   const DevModel& M = ctx->M;
   if (!(rt1 && ctx->opt_xi_log != 0 && ctx->xI_bytes == 4 && !M.n_classes && !ctx->voro && !M.grid_sph)) return false;
-  return ctx->opt_xi_log == 2 || xi_bin_floats_of(ctx) >= 64;
+  return ctx->opt_xi_log == 2 || xi32_lines_touched(xi_layout_of(ctx), ctx->RT_n_incl * ctx->RT_n_az) >= 4;
 }
 
 // The log's buffers: the launch's records and its flights' rows, the sorted copy of the records, the sort's scratch.
@@ -2622,7 +2622,6 @@ static int commit_mono(mcgpu_ctx* ctx, MonoArgs A, int grid_blocks, int block_th
   A.log_keys = ctx->d_xlog_keys[0]; A.log_vals = ctx->d_xlog_vals[0]; A.log_rows = ctx->d_xlog_rows; A.log_ctl = ctx->d_xlog_ctl;
   A.log_cap = ctx->xlog_cap; A.rows_cap = ctx->xlog_rows_cap; A.log_sentinel = (1u << end_bit) - 1u;
   const int nv = pola ? 4 : 1;
-  const int slot_star = nv, slot_thermal = nv + 1;   // (the packed record's two origins: xi32_slot_of_type)
   // (the first launch: room for 1024 records and 256 flights per packet -- ref4.1 has 60-160 and 2-60, by wavelength)
   unsigned long long done = 0, chunk = 1000000ull;
   if (chunk > ctx->xlog_cap / 1024) chunk = ctx->xlog_cap / 1024;
@@ -2652,8 +2651,8 @@ static int commit_mono(mcgpu_ctx* ctx, MonoArgs A, int grid_blocks, int block_th
     }
     if (dev_err) { ctx->err = "device error " + std::to_string(dev_err) + " in the commit pass"; return MCGPU_ERR_KERNEL; }
     const int e = xi_sort_fold(ctx->stream, ctx->d_xlog_keys[0], ctx->d_xlog_vals[0], ctx->d_xlog_keys[1], ctx->d_xlog_vals[1], (size_t)ctl[0],
-                               end_bit, ctx->d_xlog_temp, ctx->xlog_temp_bytes, ctx->d_xlog_rows, A.nRT, nv, A.contrib, slot_star, slot_thermal,
-                               n_bins, reinterpret_cast<float*>(ctx->d_xI), A.xi_binf, A.xi_rec);
+                               end_bit, ctx->d_xlog_temp, ctx->xlog_temp_bytes, ctx->d_xlog_rows, A.nRT, nv, A.contrib, n_bins,
+                               reinterpret_cast<float*>(ctx->d_xI), A.xi);
     if (e != (int)hipSuccess) { ctx->err = std::string("xI log: sort / fold: ") + hipGetErrorString((hipError_t)e); return MCGPU_ERR_HIP; }
     rpp = (double)ctl[0] / (double)c; fpp = (double)ctl[1] / (double)c;
     ctx->xlog_chunks++; ctx->xlog_records += ctl[0]; ctx->xlog_flights += ctl[1];
@@ -2752,7 +2751,7 @@ extern "C" int mcgpu_run_mono(mcgpu_ctx* ctx, const mcgpu_mono_opts* o, double f
   A.rt_u = ctx->d_rt_u; A.rt_v = ctx->d_rt_v; A.rt_w = ctx->d_rt_w;
   A.n_az_rt = ctx->n_az_rt; A.n_theta_rt = ctx->n_theta_rt; A.N_type_flux = ctx->N_type_flux; A.contrib = ctx->lsepar_contrib;
   A.s11 = ctx->have_rt1 ? ctx->d_tab_s11 + (size_t)(M.nang + 1) * (o->p_lambda - 1) : nullptr;
-  A.xI = ctx->d_xI; A.xI_f32 = ctx->xI_bytes == 4 ? 1 : 0; A.xi_binf = xi_bin_floats_of(ctx); A.xi_rec = xi_rec_of(ctx);
+  A.xI = ctx->d_xI; A.xI_f32 = ctx->xI_bytes == 4 ? 1 : 0; A.xi = xi_layout_of(ctx);
   if (rt2) {
     A.rt2 = 1; A.n_theta_I = ctx->n_theta_I; A.n_phi_I = ctx->n_phi_I; A.I_spec = ctx->d_I_spec; A.I_spec_star = ctx->d_I_spec_star;
     A.N_type_flux = ctx->rt2_N_type_flux; A.contrib = ctx->rt2_contrib;
@@ -2947,7 +2946,7 @@ extern "C" int mcgpu_set_xI(mcgpu_ctx* ctx, const double* xI_scatt) {
   hipError_t e = hipMemcpyAsync(d_in, xI_scatt, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) {
     hipLaunchKernelGGL(k_xI_put, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_xI, d_in,
-                       ctx->n_az_rt, ctx->n_theta_rt, ctx->N_type_flux, nRT, n, ctx->xI_bytes == 4 ? 1 : 0, xi_bin_floats_of(ctx), xi_rec_of(ctx), ctx->lsepar_pola ? 4 : 1);
+                       ctx->n_az_rt, ctx->n_theta_rt, ctx->N_type_flux, nRT, n, ctx->xI_bytes == 4 ? 1 : 0, xi_layout_of(ctx), ctx->lsepar_pola ? 4 : 1);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -2968,7 +2967,7 @@ extern "C" int mcgpu_fetch_xI(mcgpu_ctx* ctx, float* xI_scatt_f32, double* xI_sc
   if (e == hipSuccess) {
     hipLaunchKernelGGL(k_xI_fetch, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_xI, d32, d64,
                        ctx->n_az_rt, ctx->n_theta_rt, ctx->N_type_flux, ctx->RT_n_incl * ctx->RT_n_az, n,
-                       ctx->xI_bytes == 4 ? 1 : 0, xi_bin_floats_of(ctx), xi_rec_of(ctx), ctx->lsepar_pola ? 4 : 1);
+                       ctx->xI_bytes == 4 ? 1 : 0, xi_layout_of(ctx), ctx->lsepar_pola ? 4 : 1);
     e = hipGetLastError();
   }
   if (e == hipSuccess && d32) e = hipMemcpyAsync(xI_scatt_f32, d32, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
@@ -3106,7 +3105,7 @@ static int rt1_prepare(mcgpu_ctx* ctx, const mcgpu_rt_opts* o, const float* tab_
   A.l_far = 10. * o->Rmax;
   A.rt_u = ctx->d_rt_u; A.rt_v = ctx->d_rt_v; A.rt_w = ctx->d_rt_w; A.rt_az = J.d_az.p;
   A.xI = ctx->d_xI; A.J_th = J.d_J.p;
-  A.xI_f32 = ctx->xI_bytes == 4 ? 1 : 0; A.xi_binf = xi_bin_floats_of(ctx); A.xi_rec = xi_rec_of(ctx);
+  A.xI_f32 = ctx->xI_bytes == 4 ? 1 : 0; A.xi = xi_layout_of(ctx);
   if (J.method2) {
     A.method2 = 1; A.q_only = ctx->rt2_src_ibin - 1; A.nang_rt = ctx->rt2_src_nang; A.nang_star = ctx->rt2_src_nang_star;
     A.eps2 = ctx->d_eps2; A.eps2_star = ctx->d_eps2_star; A.z_grid = ctx->d_rt2_zgrid;

@@ -9,7 +9,7 @@ namespace mcgpu {
 // nv * nRT Stokes values (column of the row = the value's index) followed, with contributions, by the nRT copies of I.
 __global__ void __launch_bounds__(256) k_xi_segfold(const unsigned int* __restrict__ keys, const unsigned long long* __restrict__ vals,
                                                     unsigned long long n, const float* __restrict__ rows, int nRT, int nv, int contrib,
-                                                    int slot_star, int slot_thermal, unsigned int n_bins, float* xI, int xi_binf, int xi_rec) {
+                                                    unsigned int n_bins, float* xI, Xi32Lay xi) {
   const int lane = threadIdx.x & 63;
   const unsigned long long wave = (unsigned long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const unsigned long long r_lo = wave * XI_SEG_CHUNK;
@@ -20,14 +20,18 @@ __global__ void __launch_bounds__(256) k_xi_segfold(const unsigned int* __restri
   const bool stokes = val < n_stokes, copy = !stokes && val < n_vals;
   const int q = stokes ? val / nv : (copy ? val - n_stokes : 0);
   const int slot = stokes ? val - q * nv : 0;
+  // where this lane's sums go (mc_xi32.hip.h): a Stokes value's place (none for I where it is the sum of the origins),
+  // a copy's two places
+  const int o_stokes = stokes ? xi32_offset(xi, q, slot, nv) : -1;
+  const int o_star = copy ? xi32_offset(xi, q, nv + 1, nv) : -1, o_thermal = copy ? xi32_offset(xi, q, nv + 3, nv) : -1;
   const int col = stokes ? val : q * nv;            // which default real of the row this lane multiplies
   const size_t row_floats = (size_t)n_stokes;
   float acc = 0.0f, acc_star = 0.0f;   // (copy lanes: acc = thermal origin, acc_star = stellar origin)
   unsigned int cur = 0xFFFFFFFFu;
   auto flush = [&](unsigned int bin) {
-    float* rec = xI + (size_t)bin * xi_binf + (size_t)q * xi_rec;   // (the packed default-real layout, mc_mono.hip.h xi32_*)
-    if (stokes && acc != 0.0f) atomicAdd(rec + slot, acc);
-    if (copy) { if (acc != 0.0f) atomicAdd(rec + slot_thermal, acc); if (acc_star != 0.0f) atomicAdd(rec + slot_star, acc_star); }
+    float* rec = xI + (size_t)bin * xi.binf;
+    if (o_stokes >= 0 && acc != 0.0f) atomicAdd(rec + o_stokes, acc);
+    if (copy) { if (acc != 0.0f) atomicAdd(rec + o_thermal, acc); if (acc_star != 0.0f) atomicAdd(rec + o_star, acc_star); }
     acc = 0.0f; acc_star = 0.0f;
   };
   for (unsigned long long r0 = r_lo; r0 < r_hi; r0 += XI_SEG_UNROLL) {
@@ -63,15 +67,15 @@ size_t xi_sort_temp_bytes(size_t n, int end_bit) {
 
 int xi_sort_fold(hipStream_t stream, const unsigned int* keys, const unsigned long long* vals, unsigned int* keys2,
                  unsigned long long* vals2, size_t n, int end_bit, void* temp, size_t temp_bytes, const float* rows, int nRT,
-                 int nv, int contrib, int slot_star, int slot_thermal, unsigned int n_bins, float* xI, int xi_binf, int xi_rec) {
+                 int nv, int contrib, unsigned int n_bins, float* xI, Xi32Lay xi) {
   if (n == 0) return (int)hipSuccess;
   hipError_t e = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys, keys2, vals, vals2, (int)n, 0, end_bit, stream);
   if (e != hipSuccess) return (int)e;
   const unsigned long long n_waves = (n + XI_SEG_CHUNK - 1) / XI_SEG_CHUNK;
   const int n_vals = nv * nRT + (contrib ? nRT : 0);
   dim3 grid((unsigned int)((n_waves + 3) / 4), (unsigned int)((n_vals + 63) / 64));
-  hipLaunchKernelGGL(k_xi_segfold, grid, dim3(256), 0, stream, keys2, vals2, (unsigned long long)n, rows, nRT, nv, contrib, slot_star,
-                     slot_thermal, n_bins, xI, xi_binf, xi_rec);
+  hipLaunchKernelGGL(k_xi_segfold, grid, dim3(256), 0, stream, keys2, vals2, (unsigned long long)n, rows, nRT, nv, contrib, n_bins,
+                     xI, xi);
   return (int)hipGetLastError();
 }
 

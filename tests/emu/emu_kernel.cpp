@@ -403,7 +403,8 @@ extern "C" int emu_run_mono(const oracle_model* m, const oracle_mono_opts* o, do
   memset(n_sent, 0, sizeof(double) * m->n_lambda);
   const bool xi32 = getenv("MCGPU_EMU_XI_F32") != nullptr;  // default-real records (mcgpu_set_xI_precision(4))
   const bool pola_x = m->N_type_flux == 4 || m->N_type_flux == 8;
-  const int xi_rec = xi32_rec(pola_x, m->lsepar_contrib != 0), xi_binf = xi32_bin_floats(nRT, xi_rec);   // (the packed default-real layout)
+  const Xi32Lay xi_lay = xi32_layout(nRT ? nRT : 1, pola_x, m->lsepar_contrib != 0);   // (the packed default-real layout)
+  const int xi_binf = xi_lay.binf;
   std::vector<double> xI_dev(nxI ? nxI / m->N_type_flux / (nRT ? nRT : 1) * (xi32 ? (size_t)(xi_binf + 1) / 2 : (size_t)nRT * XI_LINE) : 1, 0.0);  // the kernel's own layout (FP32: half of it used)
   unsigned long long cnt[24];
   memset(cnt, 0, sizeof(cnt));
@@ -419,7 +420,7 @@ extern "C" int emu_run_mono(const oracle_model* m, const oracle_mono_opts* o, do
   A.rt_u = m->tab_u_rt; A.rt_v = m->tab_v_rt; A.rt_w = m->tab_w_rt;
   A.n_az_rt = m->n_az_rt; A.n_theta_rt = m->n_theta_rt; A.N_type_flux = m->N_type_flux; A.contrib = m->lsepar_contrib;
   A.s11 = m->tab_s11_pos ? m->tab_s11_pos + (size_t)(m->nang_scatt + 1) * (o->p_lambda - 1) : nullptr;
-  A.xI = xI_dev.data(); A.xI_f32 = xi32 ? 1 : 0; A.xi_binf = xi_binf; A.xi_rec = xi_rec;
+  A.xI = xI_dev.data(); A.xI_f32 = xi32 ? 1 : 0; A.xi = xi_lay;
   A.sed = sed; A.n_sent = n_sent; A.counters = cnt; A.next_item = cnt + 8; A.err = &err;
   A.inner_iters = 8; A.min_active = 0;
 #define MONO(sc_) do {                                                                     \
@@ -470,7 +471,7 @@ extern "C" int emu_run_mono(const oracle_model* m, const oracle_mono_opts* o, do
     gridDim.x = 1; blockDim.x = 1; threadIdx.x = 0;
     for (size_t i = 0; i < nxI; ++i) {
       blockIdx.x = (unsigned)i;
-      k_xI_fetch(xI_dev.data(), nullptr, xI, m->n_az_rt, m->n_theta_rt, m->N_type_flux, nRT, nxI, xi32 ? 1 : 0, xi_binf, xi_rec, pola_x ? 4 : 1);
+      k_xI_fetch(xI_dev.data(), nullptr, xI, m->n_az_rt, m->n_theta_rt, m->N_type_flux, nRT, nxI, xi32 ? 1 : 0, xi_lay, pola_x ? 4 : 1);
     }
     blockIdx.x = 0;
   }

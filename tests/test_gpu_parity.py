@@ -791,8 +791,12 @@ def test_sed_mode_default_real_records():
     tensor all follow the type; back to FP64 the 1e-6 parity returns."""
     import torch
     from helpers import sed_model, xI_close
+    # (observer counts on both sides of the layout's choice: 3 and 4 -> interleaved, 10 and 8 -> split, with and without
+    # Stokes tracking, with and without contributions)
     for cfg, lam, n2 in ((M.small(RT_n_incl=3), 9, 40), (M.small(RT_n_incl=2, RT_n_az=2, RT_az_max=60.0, lsepar_pola=False), 5, 40),
-                         (M.small(n_rad=10, nz=5, n_az=6, l3D=True, RT_n_incl=4), 4, 700)):
+                         (M.small(n_rad=10, nz=5, n_az=6, l3D=True, RT_n_incl=4), 4, 700),
+                         (M.small(RT_n_incl=10), 9, 40), (M.small(RT_n_incl=5, RT_n_az=2, RT_az_max=60.0, lsepar_pola=False), 5, 40),
+                         (M.small(RT_n_incl=4, RT_n_az=2, RT_az_max=60.0), 3, 40), (M.small(RT_n_incl=10, lsepar_contrib=False), 9, 40)):
         m = sed_model(cfg, n_thermal=50000)
         e, o = _engine(m, 1e5), _oracle(m, 1e5)
         e.set_rt1()
@@ -804,19 +808,36 @@ def test_sed_mode_default_real_records():
         xI_close(a["xI_scatt"], b["xI_scatt"], rtol=1e-4, n_midplane_cells=0 if cfg.l3D else cfg.n_rad, atol_rel=1e-5)
         t = e.device_xI()
         nRT = m.rt["RT_n_incl"] * m.rt["RT_n_az"]
-        # (the packed default-real layout, mc_mono.hip.h xi32_*: per sub-bin the observers side by side, each its n_Stokes
-        # values + the two origins a deposit can have, padded to whole 64-byte lines per sub-bin)
+        # (the packed default-real layout, mc_xi32.hip.h: per sub-bin the observers side by side -- the Stokes values and
+        # the two origins a deposit can have; with contributions I is not stored, it is the sum of the origins -- padded
+        # to whole 64-byte lines per sub-bin, interleaved or split, whichever a crossing touches in fewer lines)
         ntf = m.rt["N_type_flux"]
-        rec = {1: 1, 4: 4, 5: 3, 8: 6}[ntf]
-        assert t.dtype == torch.float32 and t.numel() == m.n_cells * m.rt["n_theta_rt"] * m.rt["n_az_rt"] * ((nRT * rec + 15) // 16 * 16)
-        assert abs(float(t.double().sum()) / a["xI_scatt"].sum() - 1) < 1e-6
-        # ray tracing from the default-real records == the oracle's on the same values (psup-symmetrised, see above)
+        nS, contrib = (4 if ntf in (4, 8) else 1), ntf in (5, 8)
+        lines = lambda n: (n + 15) // 16
+        if not contrib:
+            binf = 16 * lines(nRT * nS)
+        else:
+            nA = nS - 1
+            l_inter, l_star, l_th = lines(nRT * (nA + 2)), lines(nRT * (nA + 1)), lines(nRT * nA) + lines(nRT)
+            binf = 16 * (l_star + lines(nRT)) if l_star + l_th < 2 * l_inter else 16 * l_inter
+        assert t.dtype == torch.float32 and t.numel() == m.n_cells * m.rt["n_theta_rt"] * m.rt["n_az_rt"] * binf
+        x_f = a["xI_scatt"]
+        stored = x_f.sum() - (x_f[..., 0, :, :].sum() if contrib else 0.0)    # (axes: icell, iRT, type, psup, phik)
+        assert abs(float(t.double().sum()) / stored - 1) < 1e-6
+        if contrib:   # I is the sum of its two origins
+            assert np.allclose(x_f[..., 0, :, :], x_f[..., nS + 1, :, :] + x_f[..., nS + 3, :, :], rtol=3e-7, atol=0)
+        # ray tracing from the default-real records == the oracle's on the same values (psup-symmetrised, see above;
+        # handed to the device and read back: what the device holds)
         x = a["xI_scatt"].copy()
         if not cfg.l3D:
             x[:cfg.n_rad] = x[:cfg.n_rad].mean(axis=3, keepdims=True)
         x = x.astype(np.float32).astype(np.float64)
         e.set_xI(x)
-        assert np.array_equal(e.fetch_xI(), x)
+        x_dev = e.fetch_xI()
+        keep = [k for k in range(ntf) if not (contrib and k == 0)]
+        assert np.array_equal(x_dev[:, :, keep], x[:, :, keep])
+        assert np.allclose(x_dev[:, :, 0], x[:, :, 0], rtol=3e-7, atol=0)
+        x = x_dev.astype(np.float64)
         ns, Ed = a["n_sent"][lam - 1], m.extra["E_disk"][lam - 1]
         got, _ = e.dust_map_sed(lam, m.extra["Tdust"], ns, Ed)
         ref = o.dust_map_sed(lam, x, m.extra["Tdust"], ns, Ed, n_threads=8)

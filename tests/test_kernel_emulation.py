@@ -401,13 +401,18 @@ def check_mono(emu, m, lam, n2, seed, **kw):
 
 
 def test_emulated_sed_mode_default_real_records(emu):
-    """xI_scatt accumulated in default real, two observers per 64-byte line (mcgpu_set_xI_precision(4)): same packets,
+    """xI_scatt accumulated in default real, the packed layout of mc_xi32.hip.h (mcgpu_set_xI_precision(4)): same packets,
     same SED bins, xI_scatt to FP32 rounding -- odd and even observer counts, polarised or not, 2D and 3D.  (The
     emulation covers the layout, the fetch and the values; the pair staging of the wavefront is a GPU test.)"""
     os.environ["MCGPU_EMU_XI_F32"] = "1"
     try:
         for cfg, lam in ((M.small(RT_n_incl=3), 9), (M.small(RT_n_incl=2, RT_n_az=2, RT_az_max=60.0, lsepar_pola=False), 5),
-                         (M.small(n_rad=10, nz=5, n_az=6, l3D=True, RT_n_incl=1), 4)):
+                         (M.small(n_rad=10, nz=5, n_az=6, l3D=True, RT_n_incl=1), 4),
+                         # (the split arrangement of mc_xi32.hip.h: ten observers; eight; ten without Stokes tracking;
+                         # and records that keep I: no contributions)
+                         (M.small(RT_n_incl=10), 9), (M.small(RT_n_incl=4, RT_n_az=2, RT_az_max=60.0), 3),
+                         (M.small(RT_n_incl=5, RT_n_az=2, RT_az_max=60.0, lsepar_pola=False), 5),
+                         (M.small(RT_n_incl=10, lsepar_contrib=False), 9)):
             m = sed_model(cfg, n_thermal=20000)
             orc = Oracle(m, 1e5)
             a = emu_mono(emu, orc, lam, 10, 7)
