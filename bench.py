@@ -514,11 +514,14 @@ def sed_block(par, args, steps, warmup, with_cpu, packets, observers, all_lambda
     n2 = max(10, int(packets / 11.0 / m.cfg.n_photons_loop / len(lams)))
 
     xlog_tot = {"launches": 0.0, "records": 0.0, "flights": 0.0}
+    ev_tot = {"packets": 0.0, "crossings": 0.0}     # the step's commit passes, every wavelength (rank 0's streams)
 
     def step(i):
         sent = 0
         for k in xlog_tot:
             xlog_tot[k] = 0.0
+        for k in ev_tot:
+            ev_tot[k] = 0.0
         for lam in lams:
             # repartition_energie(lambda) on the device (dust_transfer.f90:924), then the wavelength's packet loop (:939)
             if me is not None:   # ONE call per wavelength: streams split, both all-reduces inside the library
@@ -528,6 +531,8 @@ def sed_block(par, args, steps, warmup, with_cpu, packets, observers, all_lambda
                 r = eng.run_mono(lam, n2, seed=100 + i, n_chunks=count, first_chunk=first, fetch_xI=False, device_tables=td,
                                  block_threads=args.block_threads)
             sent += int(r["n_sent_chunk"].sum())
+            for k in ev_tot:        # (a wavelength's run starts its counters at zero)
+                ev_tot[k] += float(r["counters"][k])
             for k, name in (("launches", "xi_log_chunks"), ("records", "xi_log_records"), ("flights", "xi_log_flights")):
                 xlog_tot[k] += eng.get_info(name)
             if par.mode == "torchrun":   # one all-reduce of [sed | n_sent] + xI_scatt per wavelength
@@ -551,18 +556,21 @@ def sed_block(par, args, steps, warmup, with_cpu, packets, observers, all_lambda
     if par.rank == 0:
         if me is not None:
             par.rccl_ranks = me.rccl_ranks()
-        cnt = eng.fetch()["counters"]
-        cross_pp = cnt["crossings"] / max(cnt["packets"], 1)
+        # crossings per packet over ALL the step's wavelengths (until round 6 this read the context's counters after the
+        # loop, i.e. the LAST wavelength's -- 77 crossings per packet at 3 mm where the packet-weighted mean over the 50
+        # wavelengths is twice that: the block's bytes and line operations were under-reported by that factor)
+        cross_pp = ev_tot["crossings"] / max(ev_tot["packets"], 1.0)
         nRT = m.rt["RT_n_incl"] * m.rt["RT_n_az"]
-        # per crossing: kappa_factor 8 B + the read and the write of one xI_scatt record per observer -- in default real the
-        # packed record's n_Stokes (+ 2 origins) values of 4 bytes (24 B with Stokes tracking and contributions), 64 B in FP64
-        n_st = 4 if (cfg.lsepar_pola and cfg.aniso_method == 1) else 1
-        rec_vals = n_st + (2 if cfg.lsepar_contrib else 0)
-        rec_bytes = 4.0 * rec_vals if args.xI_precision == 4 else 64.0
+        # per crossing: kappa_factor 8 B + the read and the write of the values one deposit reaches per observer -- in default
+        # real the packed layout's (mc_xi32.hip.h: the Stokes values, or with contributions Q, U, V + the packet's origin:
+        # I is not stored there), 4 bytes each (16 B with Stokes tracking); one 64-byte record in FP64
+        from mcfost_amd.engine import xi32_layout
+        lay = xi32_layout(nRT, bool(cfg.lsepar_pola and cfg.aniso_method == 1), bool(cfg.lsepar_contrib))
+        rec_bytes = 4.0 * lay["values_per_deposit"] if args.xI_precision == 4 else 64.0
         bytes_step = sent_all / world / steps * cross_pp * (8.0 + 2 * rec_bytes * nRT)
-        # memory-side line operations per crossing: FP64 records one 64-byte line per observer; default real the packed layout
-        # (mc_mono.hip.h xi32_*): the sub-bin's observers side by side, n_Stokes (+ 2 origins) values each, in whole lines
-        lines_per_crossing = float((nRT * rec_vals + 15) // 16) if args.xI_precision == 4 else float(nRT)
+        # memory-side line operations per crossing: FP64 records one 64-byte line per observer; default real the lines of
+        # the packed sub-bin a packet's deposits touch
+        lines_per_crossing = float(lay["lines_touched"]) if args.xI_precision == 4 else float(nRT)
         line_ops_s = sent_all / world / dt * cross_pp * lines_per_crossing
         block = {
             "metric": "photon packets/sec (whole node), SED-mode MC packet loop with ray-tracing deposits",
@@ -573,7 +581,7 @@ def sed_block(par, args, steps, warmup, with_cpu, packets, observers, all_lambda
                                    "in the stop bin each, RT1 deposits for %d observers (both passes timed)"
                                    % (lam_text, n2, nRT),
                        "packets_per_gpu_per_step": sent_all / world / steps, "crossings_per_packet": cross_pp,
-                       "observers": nRT, "xI_record": ("f32 packed, %d lines per crossing" % int(lines_per_crossing)) if args.xI_precision == 4 else "f64",
+                       "observers": nRT, "xI_record": ("f32 packed%s, %d lines per crossing" % (" (split)" if lay["split"] else "", int(lines_per_crossing))) if args.xI_precision == 4 else "f64",
                        "records_per_s": sent_all / dt * cross_pp * nRT},
             # one 64-byte record per crossing and observer is one memory-side atomic line operation: that rate, not
             # bytes, binds this mode

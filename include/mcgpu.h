@@ -234,7 +234,9 @@ int mcgpu_set_option(mcgpu_ctx *ctx, const char *name, int value);
  * "tail_ms", "longest_packet_events" / _crossings / _scatterings / _absorptions / _walks / _steps, and of the last
  * launch's tail: "tail_where" (0: it had none, 1: k_tail finished it, 2: the host threads did), "tail_host_ms",
  * "tail_host_packets", "tail_host_threads", "tail_host_events"; of the last mcgpu_run_mono's commit passes:
- * "xi_log_chunks" (launches that logged their deposits; 0: atomics), "xi_log_records", "xi_log_flights". */
+ * "xi_log_chunks" (launches that logged their deposits; 0: atomics), "xi_log_records", "xi_log_flights"; of the packed
+ * default-real xI_scatt layout this context's observers get (mcgpu_set_xI_precision): "xi_bin_floats" (default reals per
+ * sub-bin), "xi_lines_per_crossing" (64-byte lines one crossing's deposits touch), "xi_split" (1: the split arrangement). */
 int mcgpu_get_info(mcgpu_ctx *ctx, const char *name, double *value);
 
 /* Stars: type star_type (parameters.f90:230-242); icell/out_model from
@@ -465,11 +467,14 @@ int mcgpu_run_mono(mcgpu_ctx *ctx, const mcgpu_mono_opts *opts,
 int mcgpu_fetch_xI(mcgpu_ctx *ctx, float *xI_scatt_f32, double *xI_scatt_f64);
 
 /* Accumulator type of xI_scatt on the device: 8 = FP64 sums (default: device = oracle to 1e-6), 4 = default real,
- * the type of the reference's own array (dust_ray_tracing.f90:33).  With 4 a sub-bin's observers lie side by side, each
- * with the values a deposit can reach (n_Stokes, + the two origins of scattered light with lsepar_contrib): 4 lines of 64
- * bytes per crossing at 10 observers instead of 10 -- the memory-side line operations a run with many observers is bound by
- * (DESIGN.md); a sum of N deposits then carries a rounding error ~ sqrt(N) * 6e-8, far below its Monte Carlo noise
- * 1/sqrt(N).  (mcgpu_set_xI on such a context keeps the flux types a deposit can reach; n_Stokes + 1 and + 3, direct
+ * the type of the reference's own array (dust_ray_tracing.f90:33).  With 4 a sub-bin's observers lie side by side with
+ * only the values a deposit can reach (the Stokes values; with lsepar_contrib Q, U, V and the two origins of scattered
+ * light -- I is not stored there: calc_xI_scatt[_pola] adds the same flux to I and to exactly one origin,
+ * dust_ray_tracing.f90:515-524, 616-627, so I is read back as their sum): 3 lines of 64 bytes per crossing at 10
+ * observers instead of 10 -- the memory-side line operations a run with many observers is bound by; a sum of N
+ * deposits then carries a rounding error ~ sqrt(N) * 6e-8, far below its Monte Carlo noise 1/sqrt(N).  (mcgpu_set_xI on
+ * such a context keeps the flux types a deposit can reach: with lsepar_contrib the I it is handed is ignored -- it must
+ * be the sum of the origins n_Stokes + 2 and + 4, as the Monte Carlo makes it -- and n_Stokes + 1 and + 3, direct
  * light, which no Monte Carlo deposit ever touches, have no place there and read back as 0.)  Call before the first mcgpu_run_mono / mcgpu_set_xI; changing it drops what was
  * accumulated.  mcgpu_fetch_xI, mcgpu_set_xI and the ray tracer work with either; mcgpu_device_xI exposes
  * accumulators of this type. */

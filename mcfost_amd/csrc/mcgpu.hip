@@ -649,6 +649,11 @@ extern "C" int mcgpu_get_info(mcgpu_ctx* ctx, const char* name, double* value) {
   else if (!strcmp(name, "xi_log_records")) *value = (double)ctx->xlog_records;   // records (crossings with a deposit) and
   else if (!strcmp(name, "xi_log_flights")) *value = (double)ctx->xlog_flights;   // flights they logged (0: atomics)
   else if (!strcmp(name, "tau_midplane")) *value = ctx->tau_midplane;
+  // the packed default-real layout of xI_scatt this context would use (mc_xi32.hip.h; needs mcgpu_set_rt1): default reals
+  // per sub-bin, 64-byte lines one crossing's deposits touch, 1 = the split arrangement
+  else if (!strcmp(name, "xi_bin_floats")) *value = xi_layout_of(ctx).binf;
+  else if (!strcmp(name, "xi_lines_per_crossing")) *value = xi32_lines_touched(xi_layout_of(ctx), ctx->RT_n_incl * ctx->RT_n_az);
+  else if (!strcmp(name, "xi_split")) *value = xi_layout_of(ctx).split;
   else if (!strcmp(name, "bin_overflow_blocks") || !strcmp(name, "bin_drained_records")) {
     unsigned long long st[2] = {0ull, 0ull};
     if (ctx->bin.stats) {

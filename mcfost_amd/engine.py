@@ -84,6 +84,21 @@ class SedWavelength(C.Structure):
 _lib = None
 
 
+def xi32_layout(nRT, pola, contrib):
+    """The packed default-real device layout of xI_scatt the library chooses for ``nRT`` observers
+    (``mcfost_amd/csrc/mc_xi32.hip.h::xi32_layout``, mirrored for the tests and the bench's accounting): default reals per
+    sub-bin, the arrangement, and the 64-byte lines one crossing's deposits touch."""
+    lines = lambda n: (n + 15) // 16
+    nS = 4 if pola else 1
+    if not contrib:
+        return dict(binf=16 * lines(nRT * nS), split=False, lines_touched=lines(nRT * nS), values_per_deposit=nS)
+    nA = nS - 1      # I is not stored: it is the sum of the two origins
+    l_inter, l_star, l_th = lines(nRT * (nA + 2)), lines(nRT * (nA + 1)), lines(nRT * nA) + lines(nRT)
+    if l_star + l_th < 2 * l_inter:
+        return dict(binf=16 * (l_star + lines(nRT)), split=True, lines_touched=max(l_star, l_th), values_per_deposit=nA + 1)
+    return dict(binf=16 * l_inter, split=False, lines_touched=l_inter, values_per_deposit=nA + 1)
+
+
 def load_library(path: str = LIB_PATH):
     """Load the C-ABI library; fail loudly if it was not built."""
     global _lib

@@ -107,6 +107,7 @@ def temperature_and_sed(backend, m, n_thermal, n_photons_lambda, lambdas=None, s
     sed_rt = np.zeros((nl, rt["RT_n_incl"] * rt["RT_n_az"], rt["N_type_flux"]))
     sed_rt_stars = np.zeros((nl, rt["RT_n_incl"] * rt["RT_n_az"]))
     t["sed_mc"] = t["ray_tracing"] = 0.0
+    sed_crossings = 0.0   # cell crossings of the SED step's committed packets, all wavelengths (each one a set of deposits)
     for lam in lambdas:
         if on_device:
             t0 = time.perf_counter()
@@ -117,6 +118,7 @@ def temperature_and_sed(backend, m, n_thermal, n_photons_lambda, lambdas=None, s
         t["sed_mc"] += time.perf_counter() - t0
         sed[..., lam - 1] = r["sed"][..., lam - 1]
         n_sent[lam - 1] = r["n_sent"][lam - 1]
+        sed_crossings += float(r["counters"]["crossings"]) if "counters" in r else 0.0
         if ray_tracing:
             t0 = time.perf_counter()
             sed_rt[lam - 1] = backend.dust_map(lam, Tdust, r, E_disk[lam])
@@ -129,7 +131,7 @@ def temperature_and_sed(backend, m, n_thermal, n_photons_lambda, lambdas=None, s
             Ed[lam - 1] = v
         m.extra["E_disk"] = Ed
     return dict(Tdust=Tdust, sed_mc=sed, n_sent=n_sent, sed_rt=sed_rt, sed_rt_stars=sed_rt_stars, seconds=t,
-                thermal_counters=th["counters"], E_disk=E_disk)
+                thermal_counters=th["counters"], E_disk=E_disk, sed_crossings=sed_crossings)
 
 
 def stars_flux_factor(m, lam):

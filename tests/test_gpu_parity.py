@@ -813,13 +813,13 @@ def test_sed_mode_default_real_records():
         # to whole 64-byte lines per sub-bin, interleaved or split, whichever a crossing touches in fewer lines)
         ntf = m.rt["N_type_flux"]
         nS, contrib = (4 if ntf in (4, 8) else 1), ntf in (5, 8)
-        lines = lambda n: (n + 15) // 16
-        if not contrib:
-            binf = 16 * lines(nRT * nS)
-        else:
-            nA = nS - 1
-            l_inter, l_star, l_th = lines(nRT * (nA + 2)), lines(nRT * (nA + 1)), lines(nRT * nA) + lines(nRT)
-            binf = 16 * (l_star + lines(nRT)) if l_star + l_th < 2 * l_inter else 16 * l_inter
+        from mcfost_amd.engine import xi32_layout
+        lay = xi32_layout(nRT, nS == 4, contrib)
+        binf = lay["binf"]
+        assert lay["lines_touched"] == {3: 1, 4: 2 if (nS == 4 and contrib) else 1, 8: 3, 10: 3 if nS == 4 else 1}[nRT]
+        # (the library's own choice -- the mirror in engine.py serves the bench's accounting)
+        assert (e.get_info("xi_bin_floats"), e.get_info("xi_lines_per_crossing"), e.get_info("xi_split")) == \
+            (lay["binf"], lay["lines_touched"], float(lay["split"]))
         assert t.dtype == torch.float32 and t.numel() == m.n_cells * m.rt["n_theta_rt"] * m.rt["n_az_rt"] * binf
         x_f = a["xI_scatt"]
         stored = x_f.sum() - (x_f[..., 0, :, :].sum() if contrib else 0.0)    # (axes: icell, iRT, type, psup, phik)

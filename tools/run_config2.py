@@ -14,7 +14,7 @@ m = M.build_model(cfg)
 e = Engine(m, n_th)
 xi_bytes = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 e.set_rt1()
-e.set_xI_precision(xi_bytes)   # 4: xI_scatt in default real, two observers per line (mcgpu_set_xI_precision)
+e.set_xI_precision(xi_bytes)   # 4: xI_scatt in default real, the packed layout of mc_xi32.hip.h (mcgpu_set_xI_precision)
 e.run_thermal(1000, seed=1)   # (first launch: module load)
 t0 = time.perf_counter()
 r = P.temperature_and_sed(P.EngineBackend(e), m, n_th, n2, seed=5)
@@ -25,6 +25,13 @@ print(f"thermal step: {n_th:.3g} packets in {s['thermal']:.3f} s ({n_th / s['the
 print(f"repartition_energie (device, per wavelength): {s['repartition_energie']:.3f} s")
 print(f"SED Monte Carlo (xI_scatt in {xi_bytes}-byte sums): {m.n_lambda} wavelengths, {n_sed:.3g} packets in {s['sed_mc']:.3f} s ({n_sed / s['sed_mc']:.3g} packets/s, "
       f"scout + commit passes and the fetch of the SED arrays included)")
+if xi_bytes == 4 and r.get("sed_crossings"):
+    from mcfost_amd.engine import xi32_layout
+    lay = xi32_layout(cfg.RT_n_incl * cfg.RT_n_az, bool(cfg.lsepar_pola and cfg.aniso_method == 1), bool(cfg.lsepar_contrib))
+    ops = r["sed_crossings"] * lay["lines_touched"]
+    print(f"  {r['sed_crossings']:.4g} crossings ({r['sed_crossings'] / n_sed:.1f} per packet) x {lay['lines_touched']} lines of 64 bytes = {ops:.4g} memory-side "
+          f"atomic line operations: {ops / s['sed_mc']:.3g} /s over the whole SED step = {ops / s['sed_mc'] / 2.07e10:.2f} of the 2.07e10 /s the chip does "
+          f"(tools/atomic_block_bench.hip)")
 print(f"ray-traced dust SED: {m.n_lambda} x {cfg.RT_n_incl} inclinations in {s['ray_tracing']:.3f} s")
 print(f"total {wall:.2f} s;  Tdust {r['Tdust'].min():.1f} .. {r['Tdust'].max():.1f} K")
 f = P.sed_flux(m, r["sed_mc"], r["n_sent"])[0].sum(axis=0)   # (N_thet, n_lambda)
