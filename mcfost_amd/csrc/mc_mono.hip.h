@@ -732,7 +732,7 @@ __device__ __forceinline__ void mono_body(const DevModel& M, const MonoArgs& A, 
   const Lds T = lds_carve(lds_base, M, true);
   lds_stage_mono(T, M, A.p_lambda);
   const int na1 = M.nang + 1;
-  const MonoLds ML = mono_lds_setup<POLA>(M, A, lds_base, true, LOG);
+  const MonoLds ML = mono_lds_setup<POLA>(M, A, lds_base, true, LOG || SCOUT);   // (a scout pass makes no deposits: no per-lane results, no tiles)
   const float* mu = ML.mu;
   const RtScratch& R = ML.R;
   double* const tile = ML.tile;

@@ -2325,7 +2325,10 @@ static int launch_mono(mcgpu_ctx* ctx, const MonoArgs& A, int grid_blocks, int b
   // 4.87e7 packets/s): this mode is bound by the xI_scatt atomics, and more waves in flight only deepen their queues.
   // The LDS of a workgroup is the shared tables plus the per-lane ray-tracing scratch, which grows with the observers.
   // (the kernel that logs its deposits makes no atomics, needs 146 VGPRs and almost no LDS: three waves per SIMD)
-  const int cu_threads = log ? 768 : 512;
+  // (so does a scout pass of the cylindrical / spherical kernels: no deposits, no per-lane results, no tiles -- round 6;
+  // until then it was launched with the commit pass's LDS and two waves per SIMD)
+  const bool lean = log || (SCOUT && !ctx->voro);
+  const int cu_threads = lean ? 768 : 512;
   int threads = 0;
   const bool slim = true;                   // (mono_lds_bytes)
   const int max_threads = 512;              // (__launch_bounds__ of the kernels)
@@ -2333,8 +2336,8 @@ static int launch_mono(mcgpu_ctx* ctx, const MonoArgs& A, int grid_blocks, int b
     threads = block_threads;
   } else {
     int best_waves = 0;
-    for (int th = log ? 256 : max_threads; th >= 64; th -= 64) {
-      const size_t l = mono_lds_bytes(M, A.nRT, th, pola, slim, log);
+    for (int th = lean ? 256 : max_threads; th >= 64; th -= 64) {
+      const size_t l = mono_lds_bytes(M, A.nRT, th, pola, slim, lean);
       if (l > 160 * 1024) continue;
       int per_cu = (int)((160 * 1024) / l);
       if (per_cu > cu_threads / th) per_cu = cu_threads / th;
@@ -2343,7 +2346,7 @@ static int launch_mono(mcgpu_ctx* ctx, const MonoArgs& A, int grid_blocks, int b
     }
     if (!threads) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "too many ray-tracing directions for the LDS of one CU");
   }
-  const size_t lds = mono_lds_bytes(M, A.nRT, threads, pola, slim, log);
+  const size_t lds = mono_lds_bytes(M, A.nRT, threads, pola, slim, lean);
   if (lds > 160 * 1024) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "too many ray-tracing directions for the LDS of one CU");
   HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int blocks = grid_blocks;
