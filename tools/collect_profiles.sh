@@ -11,7 +11,9 @@ cd /tmp; export TMPDIR=/tmp
 CFGS="$@"; [ -z "$CFGS" ] && CFGS="pascucci ref41"
 for C in $CFGS; do
   NP=100000000; [ "$C" = "ref41_mrw" ] && NP=10000000     # (the default line runs the thick disk with 1e7 packets)
-  B="python3 $R/bench.py --config $C --no-cpu-baseline --no-extra --packets $NP"
+  EXTRA=""; [ "$C" = "sed" ] && EXTRA="--sed-observers 10"   # (the default line's SED block runs ten observers, BASELINE config 2's)
+  B="python3 $R/bench.py --config $C --no-cpu-baseline --no-extra --packets $NP $EXTRA"
+  export PROF_CMD="python3 bench.py --config $C --no-cpu-baseline --no-extra --packets $NP $EXTRA"
   P=$R/gpurun_out/prof/$C
   rm -rf $P; mkdir -p $P
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $P/kt -o kt -- $B > $P/kt.log 2>&1 </dev/null

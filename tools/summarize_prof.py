@@ -24,7 +24,7 @@ def dominant(name):
 
 
 # ---- kernel trace -----------------------------------------------------------------------------------------
-kt = {"config": config, "command": "python3 bench.py --config %s --no-cpu-baseline --no-extra" % config}
+kt = {"config": config, "command": os.environ.get("PROF_CMD", "python3 bench.py --config %s --no-cpu-baseline --no-extra" % config).strip()}
 for f in glob.glob(os.path.join(src, "kt", "**", "*kernel_stats.csv"), recursive=True):
     kt["kernel_stats"] = list(csv.DictReader(open(f)))
 dur = collections.defaultdict(list)
@@ -57,6 +57,13 @@ for sub in ("f", "w", "a", "b"):
 per = dict(cnt)
 dur_pmc = dur_pass
 n_packets = int(float(sys.argv[4])) if len(sys.argv) > 4 else 100000000
+# (the SED step's packets are what its streams needed, not --packets: read them from the bench line of the trace run)
+try:
+    for line in open(os.path.join(src, "kt.log")):
+        if line.startswith("{") and '"packets_per_gpu_per_step"' in line:
+            n_packets = int(json.loads(line)["config"]["packets_per_gpu_per_step"])
+except (OSError, ValueError, KeyError):
+    pass
 out = {"config": config, "command": kt["command"] + " --steps 1 --warmup 0", "packets": n_packets,
        "counters_per_step": per, "launches_per_step": dict(launches)}
 try:
