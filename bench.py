@@ -631,7 +631,7 @@ def main():
     ap.add_argument("--sed-observers", type=int, default=0, help="--config sed: RT_n_incl (default: the configuration's)")
     ap.add_argument("--xI-precision", type=int, default=4, choices=[4, 8],
                     help="--config sed: mcgpu_set_xI_precision -- 4 (default here): xI_scatt accumulated in default real, the type of "
-                         "the reference's own array (dust_ray_tracing.f90:33), two observers per 64-byte line; 8: FP64 sums "
+                         "the reference's own array (dust_ray_tracing.f90:33), in the packed layout of mc_xi32.hip.h; 8: FP64 sums "
                          "(the library's default)")
     ap.add_argument("--var-identical", action="store_true", help="--config ref41_var: every class gets the model's own tables "
                     "(the physics of --config ref41 through the HBM-gather kernel)")
