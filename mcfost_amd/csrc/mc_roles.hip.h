@@ -942,6 +942,9 @@ __device__ __forceinline__ void roles_body(const DevModel& M, const RunArgs& A, 
       serve = (fly_n == 0) && ((srv_n > 0) || can_emit);
     }
 
+#if defined(__HIP_DEVICE_COMPILE__) && defined(MCGPU_PRIO_SERVE)   // (A/B builds: the issue priority of a wave by its role)
+    if (serve) __builtin_amdgcn_s_setprio(MCGPU_PRIO_SERVE); else __builtin_amdgcn_s_setprio(MCGPU_PRIO_FLY);
+#endif
     if (!serve) {
       // ======================= FLYING ==================================================================
       // lanes whose packet stopped swap it for a long flight, empty lanes load one
