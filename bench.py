@@ -475,7 +475,7 @@ def thermal_block(par, args, config, steps, warmup, with_cpu, n_local, crossing=
     return block, cfg
 
 
-def sed_block(par, args, steps, warmup, with_cpu, packets, observers, all_lambdas=False):
+def sed_block(par, args, steps, warmup, with_cpu, packets, observers, all_lambdas=False, n2=None):
     """SED mode on the ref4.1 grid (the second half of BASELINE config 2): one step = the SED Monte Carlo
     (mcgpu_run_mono: scout + commit passes, ray-tracing deposits) of the listed wavelengths, every stream asked for
     packets/128/len(wavelengths) packets in the stop bin; streams sharded over the GPUs."""
@@ -511,7 +511,8 @@ def sed_block(par, args, steps, warmup, with_cpu, packets, observers, all_lambda
     n_streams = m.cfg.n_photons_loop * world                 # weak scaling: 128 streams per GPU
     first, count = D.shard_streams(n_streams, par.rank, par.world)
     # packets in the stop bin per stream so that a step sends about `packets` packets per GPU (1 in ~11 lands there)
-    n2 = max(10, int(packets / 11.0 / m.cfg.n_photons_loop / len(lams)))
+    if n2 is None:
+        n2 = max(10, int(packets / 11.0 / m.cfg.n_photons_loop / len(lams)))
 
     xlog_tot = {"launches": 0.0, "records": 0.0, "flights": 0.0}
     ev_tot = {"packets": 0.0, "crossings": 0.0}     # the step's commit passes, every wavelength (rank 0's streams)
@@ -723,11 +724,11 @@ def main():
                 big, _ = thermal_block(par, args, "ref41_mrw", 1, 1, False, args.packets)
                 extras["ref41_mrw"]["at_%.0e_packets" % args.packets] = {k: big[k] for k in ("value", "unit", "ms_per_step", "tail")}
             say("ref41_mrw", extras["ref41_mrw"])
-            # the SED half of BASELINE config 2: 10 observers
-            # (every wavelength, 3 551 packets in the stop bin per stream -- a third of config 2's 10 000; round 4 ran 710, where a
-            # wavelength's launches are small and the rate sat a third below the full run's)
-            extras["sed"] = sed_block(par, args, 1, 0, with_cpu, min(2.5 * args.packets, 2.5e8), args.sed_observers or 10,
-                                      all_lambdas=True)
+            # the SED half of BASELINE config 2 at its own size: 10 observers, every wavelength, 10 000 packets in the stop bin
+            # per stream (n_photons_lambda of the configuration; rounds 4 / 5 ran 710 / 3 551, where a wavelength's launches are
+            # small and the rate sits below the full run's).  --packets below the default scales it down.
+            extras["sed"] = sed_block(par, args, 1, 0, with_cpu, 0, args.sed_observers or 10, all_lambdas=True,
+                                      n2=max(10, int(round(10000 * min(1.0, args.packets / 1e8)))))
             say("sed", extras["sed"])
             # the headline workload with option "crossing" = 1: the flight-parametric crossing in the flying waves -- NOT the
             # reference's arithmetic, so not the headline; statistical parity only (its tdust_vs_cpu against the same CPU port)
