@@ -2328,7 +2328,10 @@ static int launch_mono(mcgpu_ctx* ctx, const MonoArgs& A, int grid_blocks, int b
   // (so does a scout pass of the cylindrical / spherical kernels: no deposits, no per-lane results, no tiles -- round 6;
   // until then it was launched with the commit pass's LDS and two waves per SIMD)
   const bool lean = log || (SCOUT && !ctx->voro);
-  const int cu_threads = lean ? 768 : 512;
+#ifndef MCGPU_MONO_CU_THREADS
+#define MCGPU_MONO_CU_THREADS 512   // (A/B builds)
+#endif
+  const int cu_threads = lean ? 768 : MCGPU_MONO_CU_THREADS;
   int threads = 0;
   const bool slim = true;                   // (mono_lds_bytes)
   const int max_threads = 512;              // (__launch_bounds__ of the kernels)
