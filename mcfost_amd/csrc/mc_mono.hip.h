@@ -72,6 +72,7 @@ struct MonoArgs {
   unsigned long long log_cap, rows_cap;
   unsigned int log_sentinel;            // key of an unused entry: sorts behind every sub-bin
   unsigned long long item_lo;           // COMMIT: the launch runs the work items [item_lo, item_lo + n_items)
+  int kf_lds;                           // COMMIT: kappa_factor(1:n_cells) is staged in the workgroup's LDS (mono_lds_bytes)
 };
 
 // per-lane results of angles_scatt_rt1, kept in LDS as [q][thread]
@@ -86,7 +87,13 @@ struct RtScratch {
 // column is selected by index, interact(..., lds_col): choosing between two LDS pointers there crashed hipcc 7.2.)
 // log: the kernel that writes its deposits to the log keeps no per-lane results and no tiles (the flight's weights go
 // straight to its row in HBM)
-__host__ __device__ inline size_t mono_lds_bytes(const DevModel& M, int nRT, int threads, bool pola, bool slim, bool log = false) {
+// kf_cells > 0: kappa_factor of that many cells rides along (MonoArgs::kf_lds): a global load in the crossing loop waits
+// for EVERY vector-memory operation of the wave issued before it -- loads and the fire-and-forget atomics share one
+// in-order counter on this target and return out of order with respect to each other, so the compiler's wait is
+// vmcnt(0) -- i.e. for the previous crossing's deposits to come back from the memory side (microseconds under load):
+// with the one per-crossing load served from LDS the commit pass's waves never wait for their own atomics.
+__host__ __device__ inline size_t mono_lds_bytes(const DevModel& M, int nRT, int threads, bool pola, bool slim, bool log = false,
+                                                 int kf_cells = 0) {
   size_t b = (lds_bytes(M, slim) + 7) / 8 * 8;
   b += (size_t)6 * (M.nang + 1) * sizeof(float);                     // the Mueller columns of p_lambda
   b = (b + 7) / 8 * 8;
@@ -97,6 +104,7 @@ __host__ __device__ inline size_t mono_lds_bytes(const DevModel& M, int nRT, int
   b += (size_t)tsc * sizeof(unsigned int);                           // deposit tiles: slot mask
   b = (b + 7) / 8 * 8;
   b += (size_t)3 * nRT * sizeof(double);                             // the observers' rotation constants
+  b += (size_t)kf_cells * sizeof(double);                            // kappa_factor
   return b;
 }
 
@@ -108,83 +116,89 @@ __host__ __device__ inline size_t mono_lds_bytes(const DevModel& M, int nRT, int
 // default-real weights take the 16 bytes of (cosw, sinw); without Stokes tracking the one weight takes itheta's 4.
 // row != nullptr (the commit pass that LOGS its deposits): the weights go to the flight's row in HBM, [nRT][4] (Stokes
 // tracking) or [nRT] default reals, and nothing is kept in LDS.
+// (one observer q of the loop; slot = the thread of the workgroup whose per-lane results in LDS receive it: the lane's
+// own, or -- angles_scatt_rt1_wave below -- the lane another lane computes for)
+template <bool POLA>
+__device__ inline void angles_scatt_rt1_one(const DevModel& M, const MonoArgs& A, const RtScratch& R, int q, int slot, double u,
+                                             double v, double w, const float* w_mu, const double* S, float* row) {
+  const double ur = A.rt_u[q], vr = A.rt_v[q], wr = A.rt_w[q % A.RT_n_incl];
+  const float cos_scatt = (float)nd_add(nd_add(nd_mul(ur, u), nd_mul(vr, v)), nd_mul(wr, w));
+  // k = nint(acos(cos_scatt) * nang / pi) in default real (:430-434).  The default-real arccosine of the runtime decides
+  // the bin unless the quotient lies within delta = 1.2e-6 nang of a bin edge (2.2e-4 at 180 bins) -- the roundings of
+  // both evaluations together (acosf to 2 ulp of pi, two default-real operations at ~nang, the reference's correctly
+  // rounded acos and default-real product) stay below 0.5e-6 nang -- where the reference's expression itself runs
+  // (4e-4 of the calls, and NaN): the FP64 acos was 75 of this observer's instructions.
+  int k;
+  const float qf = acosf(cos_scatt) * ((float)M.nang * 0.318309886183790672f) + 0.5f;
+  const float qfl = floorf(qf);
+  const float dq = 1.2e-6f * (float)M.nang;
+  if (qf - qfl > dq && qf - qfl < 1.0f - dq) k = (int)qfl;
+  else {
+    const float ac = (float)acos((double)cos_scatt);  // the correctly rounded default-real acos
+    if (ac != ac) k = 1;
+    else k = (int)llrint(floor(nf_mul(ac, (float)M.nang) / PI + 0.5));  // nint()
+  }
+  if (k > M.nang) k = M.nang;
+  if (k < 1) k = 1;
+  if (!row) R.itheta[q * blockDim.x + slot] = k;
+#ifndef MCGPU_LANE_EMULATION   // (the lane emulation has no default-real commit pass)
+  if (!POLA && w_mu) {
+    const float wI = (float)(S[0] * (double)w_mu[k]);
+    if (row) row[q] = wI; else R.itheta[q * blockDim.x + slot] = __float_as_int(wI);
+  }
+#endif
+  if (POLA) {
+    // rotation(u, v, w, -ur, -vr, -wr, ...) with the observer's constants from LDS (only y' and z' are needed)
+    const double cost = R.rot[3 * q], sint = R.rot[3 * q + 1], sing = R.rot[3 * q + 2];
+    const double prod = cost * u + sint * v;
+    const double v1pj = cost * v - sint * u;
+    const double v1pk = sing * w - (-wr) * prod;
+    double xnyp = sqrt(v1pk * v1pk + v1pj * v1pj), costhet;
+    if (xnyp < 1e-10) { xnyp = 0.0; costhet = 1.0; }
+    else costhet = -1.0 * v1pj / xnyp;
+    // theta = acos(costhet) (pi -> 0), omega = 2 (theta + pi / 2), negated below the plane; cos and sin of omega
+    // (dust_ray_tracing.f90:452-470) without the acos and the sincos -- 180 of this observer's ~450 instructions:
+    // cos(2 theta + pi) = 1 - 2 c^2, sin(2 theta + pi) = -2 c sqrt(1 - c^2); the composition's own rounding apart
+    // (1e-16, like update_stokes' rotation since round 4)
+    double cosw = 1.0 - 2.0 * costhet * costhet;
+    double sinw = -2.0 * costhet * sqrt(fmax(1.0 - costhet * costhet, 0.0));
+    if (v1pk < 0.0) sinw = -sinw;
+    if (fabs(cosw) < 1e-06) cosw = 0.0;
+    if (fabs(sinw) < 1e-06) sinw = 0.0;
+    if (!row) {
+      R.cosw[q * blockDim.x + slot] = cosw;
+      R.sinw[q * blockDim.x + slot] = sinw;
+    }
+#ifndef MCGPU_LANE_EMULATION
+    if (w_mu) {   // (the expressions of deposit_rt1_wave, without the path length)
+      const int na1 = M.nang + 1;
+      const float s11 = w_mu[k];
+      const float s12 = -s11 * w_mu[na1 + k], s22 = s11 * w_mu[2 * na1 + k], s33 = -s11 * w_mu[3 * na1 + k];
+      const float s34 = -s11 * w_mu[4 * na1 + k], s44 = -s11 * w_mu[5 * na1 + k];
+      const double C1 = S[0], C4 = S[3];
+      const double C2 = cosw * S[1] + (-sinw) * S[2];
+      const double C3 = sinw * S[1] + cosw * S[2];
+      const double D1 = (double)s11 * C1 + (double)s12 * C2;
+      const double D2 = (double)s12 * C1 + (double)s22 * C2;
+      const double D3 = (double)s33 * C3 + (double)(-s34) * C4;
+      const double D4 = (double)s34 * C3 + (double)s44 * C4;
+      if (row) {
+        reinterpret_cast<float4*>(row)[q] = make_float4((float)D1, (float)((-cosw) * D2 + (-sinw) * D3), (float)((-sinw) * D2 + cosw * D3), (float)D4);
+      } else {
+        float2* wc = reinterpret_cast<float2*>(R.cosw) + (q * blockDim.x + slot);
+        float2* ws = reinterpret_cast<float2*>(R.sinw) + (q * blockDim.x + slot);
+        *wc = make_float2((float)D1, (float)((-cosw) * D2 + (-sinw) * D3));
+        *ws = make_float2((float)((-sinw) * D2 + cosw * D3), (float)D4);
+      }
+    }
+#endif
+  }
+}
+
 template <bool POLA>
 __device__ inline void angles_scatt_rt1(const DevModel& M, const MonoArgs& A, const RtScratch& R, double u,
                                         double v, double w, const float* w_mu = nullptr, const double* S = nullptr, float* row = nullptr) {
-  for (int q = 0; q < A.nRT; ++q) {
-    const double ur = A.rt_u[q], vr = A.rt_v[q], wr = A.rt_w[q % A.RT_n_incl];
-    const float cos_scatt = (float)nd_add(nd_add(nd_mul(ur, u), nd_mul(vr, v)), nd_mul(wr, w));
-    // k = nint(acos(cos_scatt) * nang / pi) in default real (:430-434).  The default-real arccosine of the runtime decides
-    // the bin unless the quotient lies within delta = 1.2e-6 nang of a bin edge (2.2e-4 at 180 bins) -- the roundings of
-    // both evaluations together (acosf to 2 ulp of pi, two default-real operations at ~nang, the reference's correctly
-    // rounded acos and default-real product) stay below 0.5e-6 nang -- where the reference's expression itself runs
-    // (4e-4 of the calls, and NaN): the FP64 acos was 75 of this observer's instructions.
-    int k;
-    const float qf = acosf(cos_scatt) * ((float)M.nang * 0.318309886183790672f) + 0.5f;
-    const float qfl = floorf(qf);
-    const float dq = 1.2e-6f * (float)M.nang;
-    if (qf - qfl > dq && qf - qfl < 1.0f - dq) k = (int)qfl;
-    else {
-      const float ac = (float)acos((double)cos_scatt);  // the correctly rounded default-real acos
-      if (ac != ac) k = 1;
-      else k = (int)llrint(floor(nf_mul(ac, (float)M.nang) / PI + 0.5));  // nint()
-    }
-    if (k > M.nang) k = M.nang;
-    if (k < 1) k = 1;
-    if (!row) R.itheta[q * blockDim.x + threadIdx.x] = k;
-#ifndef MCGPU_LANE_EMULATION   // (the lane emulation has no default-real commit pass)
-    if (!POLA && w_mu) {
-      const float wI = (float)(S[0] * (double)w_mu[k]);
-      if (row) row[q] = wI; else R.itheta[q * blockDim.x + threadIdx.x] = __float_as_int(wI);
-    }
-#endif
-    if (POLA) {
-      // rotation(u, v, w, -ur, -vr, -wr, ...) with the observer's constants from LDS (only y' and z' are needed)
-      const double cost = R.rot[3 * q], sint = R.rot[3 * q + 1], sing = R.rot[3 * q + 2];
-      const double prod = cost * u + sint * v;
-      const double v1pj = cost * v - sint * u;
-      const double v1pk = sing * w - (-wr) * prod;
-      double xnyp = sqrt(v1pk * v1pk + v1pj * v1pj), costhet;
-      if (xnyp < 1e-10) { xnyp = 0.0; costhet = 1.0; }
-      else costhet = -1.0 * v1pj / xnyp;
-      // theta = acos(costhet) (pi -> 0), omega = 2 (theta + pi / 2), negated below the plane; cos and sin of omega
-      // (dust_ray_tracing.f90:452-470) without the acos and the sincos -- 180 of this observer's ~450 instructions:
-      // cos(2 theta + pi) = 1 - 2 c^2, sin(2 theta + pi) = -2 c sqrt(1 - c^2); the composition's own rounding apart
-      // (1e-16, like update_stokes' rotation since round 4)
-      double cosw = 1.0 - 2.0 * costhet * costhet;
-      double sinw = -2.0 * costhet * sqrt(fmax(1.0 - costhet * costhet, 0.0));
-      if (v1pk < 0.0) sinw = -sinw;
-      if (fabs(cosw) < 1e-06) cosw = 0.0;
-      if (fabs(sinw) < 1e-06) sinw = 0.0;
-      if (!row) {
-        R.cosw[q * blockDim.x + threadIdx.x] = cosw;
-        R.sinw[q * blockDim.x + threadIdx.x] = sinw;
-      }
-#ifndef MCGPU_LANE_EMULATION
-      if (w_mu) {   // (the expressions of deposit_rt1_wave, without the path length)
-        const int na1 = M.nang + 1;
-        const float s11 = w_mu[k];
-        const float s12 = -s11 * w_mu[na1 + k], s22 = s11 * w_mu[2 * na1 + k], s33 = -s11 * w_mu[3 * na1 + k];
-        const float s34 = -s11 * w_mu[4 * na1 + k], s44 = -s11 * w_mu[5 * na1 + k];
-        const double C1 = S[0], C4 = S[3];
-        const double C2 = cosw * S[1] + (-sinw) * S[2];
-        const double C3 = sinw * S[1] + cosw * S[2];
-        const double D1 = (double)s11 * C1 + (double)s12 * C2;
-        const double D2 = (double)s12 * C1 + (double)s22 * C2;
-        const double D3 = (double)s33 * C3 + (double)(-s34) * C4;
-        const double D4 = (double)s34 * C3 + (double)s44 * C4;
-        if (row) {
-          reinterpret_cast<float4*>(row)[q] = make_float4((float)D1, (float)((-cosw) * D2 + (-sinw) * D3), (float)((-sinw) * D2 + cosw * D3), (float)D4);
-        } else {
-          float2* wc = reinterpret_cast<float2*>(R.cosw) + (q * blockDim.x + threadIdx.x);
-          float2* ws = reinterpret_cast<float2*>(R.sinw) + (q * blockDim.x + threadIdx.x);
-          *wc = make_float2((float)D1, (float)((-cosw) * D2 + (-sinw) * D3));
-          *ws = make_float2((float)((-sinw) * D2 + cosw * D3), (float)D4);
-        }
-      }
-#endif
-    }
-  }
+  for (int q = 0; q < A.nRT; ++q) angles_scatt_rt1_one<POLA>(M, A, R, q, (int)threadIdx.x, u, v, w, w_mu, S, row);
 }
 
 // One pending deposit of a lane: where (cell, azimuth / elevation sub-bin) and how long the path was.
@@ -321,6 +335,38 @@ __device__ inline void wave_deposit_records(int lane, int K, unsigned int mask, 
       const int slot = is_contrib ? (int)(mw[t] >> 8) : j;
       if ((mw[t] >> slot) & 1u) atomic_add_f64((double*)((glb_f64*)ad[t] + slot), val[t]);
     }
+  }
+  tile_sync();
+}
+#endif
+
+#ifndef MCGPU_LANE_EMULATION
+// angles_scatt_rt1 for the lanes of a wave that start a flight (`need`), computed by ALL its lanes (round 6).  The loop
+// over the observers costs ~450 instructions each and runs, in the single-role loop of mono_body, for the third of the
+// lanes that have just interacted while the others wait: here the (lane, observer) pairs are spread over the 64 lanes --
+// the starting lanes put their direction and Stokes vector into the wave's deposit tile (free between deposits), every
+// lane takes pairs i = lane, lane + 64, ... and writes the result into the per-lane LDS results of the lane it computed
+// for.  Same expressions on the same values (angles_scatt_rt1_one): the results do not depend on who computes them.
+// w_mu as in angles_scatt_rt1 (the commit pass with default-real records and one dust class).
+template <bool POLA>
+__device__ inline void angles_scatt_rt1_wave(const DevModel& M, const MonoArgs& A, const RtScratch& R, bool need, double u, double v,
+                                             double w, const float* w_mu, const double S[4], double* tile_g) {
+  const int lane = threadIdx.x & 63;
+  const unsigned long long m = __ballot(need);
+  if (m == 0ull) return;
+  lds_f64* const t = (lds_f64*)tile_g;       // 64 places x XI_LINE doubles
+  if (need) {
+    lds_f64* my = t + __popcll(m & ((1ull << lane) - 1ull)) * XI_LINE;
+    my[0] = u; my[1] = v; my[2] = w; my[3] = S[0]; my[4] = POLA ? S[1] : 0.0; my[5] = POLA ? S[2] : 0.0; my[6] = POLA ? S[3] : 0.0;
+    my[7] = (double)(int)threadIdx.x;        // (whose results these are)
+  }
+  tile_sync();
+  const int n_items = __popcll(m) * A.nRT;
+  for (int i = lane; i < n_items; i += 64) {
+    const int j = i / A.nRT, q = i - j * A.nRT;
+    const lds_f64* p = t + j * XI_LINE;
+    const double Sj[4] = {p[3], p[4], p[5], p[6]};
+    angles_scatt_rt1_one<POLA>(M, A, R, q, (int)p[7], p[0], p[1], p[2], w_mu, Sj, nullptr);
   }
   tile_sync();
 }
@@ -583,6 +629,7 @@ struct MonoLds {
   double* tile;
   unsigned long long* tile_addr;
   unsigned int* tile_mask;
+  const double* kf;     // kappa_factor in LDS (MonoArgs::kf_lds), else null
 };
 
 template <bool POLA>
@@ -614,6 +661,12 @@ __device__ inline MonoLds mono_lds_setup(const DevModel& M, const MonoArgs& A, d
       rot[3 * q] = cost; rot[3 * q + 1] = sint; rot[3 * q + 2] = sing;
     }
     L.R.rot = rot;
+    L.kf = nullptr;
+    if (A.kf_lds) {   // kappa_factor behind the rotation constants
+      double* kf = rot + (size_t)3 * A.nRT;
+      for (int i = threadIdx.x; i < M.n_cells; i += blockDim.x) kf[i] = M.kappa_factor[i];
+      L.kf = kf;
+    }
   }
   // the Mueller columns of p_lambda
   const size_t col = (size_t)na1 * (A.p_lambda - 1);
@@ -657,11 +710,17 @@ __device__ inline bool mono_attenuate(const Lds& T, int lambda, double S[4]) {  
 }
 
 // kappa(p_icell, lambda) * kappa_factor(icell) (optical_depth.f90:100-102) of a real cell
+// (kf_lds: kappa_factor staged in LDS, or null -- see mono_lds_bytes; the two loads in their own address spaces)
 template <bool L3D>
-__device__ inline double mono_opacity(const Lds& T, const DevModel& M, int lambda, int ri, int zj, int k) {
+__device__ inline double mono_opacity(const Lds& T, const DevModel& M, int lambda, int ri, int zj, int k, const double* kf_lds = nullptr) {
   if (!is_real_cell<L3D>(M.n_rad, M.nz, ri, zj)) return 0.0;
   const int ic = cell_index<L3D>(M.n_rad, M.nz, ri, zj, k);
   const double kap = M.n_classes ? M.v_kappa[(size_t)M.cell_class[ic] * M.n_lambda + (lambda - 1)] : T.kappa[lambda - 1];
+#ifndef MCGPU_LANE_EMULATION
+  if (kf_lds) return kap * ((const __attribute__((address_space(3))) double*)kf_lds)[ic];
+#else
+  if (kf_lds) return kap * kf_lds[ic];
+#endif
   return kap * M.kappa_factor[ic];
 }
 
@@ -859,6 +918,13 @@ __device__ __forceinline__ void mono_body(const DevModel& M, const MonoArgs& A, 
     unsigned long long fid_new = 0ull;
     if (LOG && !SCOUT) fid_new = xlog_flights(A, LC, st == S_NEWFLIGHT && A.rt1, lane);
 #endif
+#ifndef MCGPU_LANE_EMULATION
+    // (the commit pass with default-real records and one dust class: the new flights' observer weights by the whole wave)
+    constexpr bool kAnglesByWave = F32 && !SCOUT && !LOG;
+    if (kAnglesByWave && A.rt1 && !var) angles_scatt_rt1_wave<POLA>(M, A, R, st == S_NEWFLIGHT, u, v, w, mu, S, tile);
+#else
+    constexpr bool kAnglesByWave = false;
+#endif
     if (st == S_NEWFLIGHT) {
       const float rand = tau_rand;
       extr = tau_of_draw(rand);
@@ -871,7 +937,8 @@ __device__ __forceinline__ void mono_body(const DevModel& M, const MonoArgs& A, 
         angles_scatt_rt1<POLA>(M, A, R, u, v, w, mu, S, A.log_rows + (fid_new < A.rows_cap ? fid_new : 0ull) * row_floats);
       } else
 #endif
-      if (!SCOUT && A.rt1) angles_scatt_rt1<POLA>(M, A, R, u, v, w, (F32 && !var) ? mu : nullptr, S);  // optical_depth.f90:65
+      if (!SCOUT && A.rt1 && !(kAnglesByWave && !var))
+        angles_scatt_rt1<POLA>(M, A, R, u, v, w, (F32 && !var) ? mu : nullptr, S);  // optical_depth.f90:65
       const int i_star = intersect_stars(M, x, y, z, u, v, w);
       star_key = -1;
       if (i_star > 0) {
@@ -881,7 +948,7 @@ __device__ __forceinline__ void mono_body(const DevModel& M, const MonoArgs& A, 
       c_flight++;
       ri_o = 0; zj_o = 0; k_o = 0;
       xo = x; yo = y; zo = z;
-      kf = mono_opacity<L3D>(T, M, lambda, ri, zj, k);
+      kf = mono_opacity<L3D>(T, M, lambda, ri, zj, k, ML.kf);
       st = S_FLIGHT;
     }
 
@@ -962,7 +1029,7 @@ __device__ __forceinline__ void mono_body(const DevModel& M, const MonoArgs& A, 
               if (DARK) { xo = x; yo = y; zo = z; ri_o = ri; zj_o = zj; k_o = k; }
               x = x1; y = y1; z = z1;
               ri = ri1; zj = zj1; k = k1;
-              kf = mono_opacity<L3D>(T, M, lambda, ri, zj, k);
+              kf = mono_opacity<L3D>(T, M, lambda, ri, zj, k, ML.kf);
             }
             if (++pk_cross > 200000000u) {  // a packet that never leaves: flag it, drop it
               *A.err = 13;

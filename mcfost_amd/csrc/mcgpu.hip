@@ -2349,8 +2349,20 @@ static int launch_mono(mcgpu_ctx* ctx, const MonoArgs& A, int grid_blocks, int b
     }
     if (!threads) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "too many ray-tracing directions for the LDS of one CU");
   }
-  const size_t lds = mono_lds_bytes(M, A.nRT, threads, pola, slim, lean);
+  size_t lds = mono_lds_bytes(M, A.nRT, threads, pola, slim, lean);
   if (lds > 160 * 1024) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "too many ray-tracing directions for the LDS of one CU");
+  // The commit pass's one global load per crossing, kappa_factor, from LDS where the grid is small enough to ride along
+  // without costing a workgroup its place on the CU (2D grids with few observers): see mono_lds_bytes.
+  MonoArgs A2 = A;
+  A2.kf_lds = 0;
+  if (kCommit && !lean && (A.rt1 || A.rt2) && !ctx->voro && !M.n_classes) {
+    const size_t with_kf = mono_lds_bytes(M, A.nRT, threads, pola, slim, lean, M.n_cells);
+    const int per_cu_max = cu_threads / threads > 0 ? cu_threads / threads : 1;
+    int per_cu = (int)((160 * 1024) / lds), per_cu_kf = with_kf <= 160 * 1024 ? (int)((160 * 1024) / with_kf) : 0;
+    if (per_cu > per_cu_max) per_cu = per_cu_max;
+    if (per_cu_kf > per_cu_max) per_cu_kf = per_cu_max;
+    if (per_cu_kf >= per_cu && per_cu_kf > 0) { A2.kf_lds = 1; lds = with_kf; }
+  }
   HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int blocks = grid_blocks;
   if (blocks <= 0) {
@@ -2361,7 +2373,7 @@ static int launch_mono(mcgpu_ctx* ctx, const MonoArgs& A, int grid_blocks, int b
     const unsigned long long need = (A.n_items + threads - 1) / threads;
     if ((unsigned long long)blocks > need) blocks = (int)(need ? need : 1);
   }
-  void* args[] = {(void*)&M, (void*)&A, (void*)&ctx->V};  // the Voronoi kernels take the grid as 3rd argument
+  void* args[] = {(void*)&M, (void*)&A2, (void*)&ctx->V};  // the Voronoi kernels take the grid as 3rd argument
   HIPCHK(hipLaunchKernel(fn, dim3(blocks), dim3(threads), args, lds, ctx->stream));
   return MCGPU_OK;
 }
