@@ -73,6 +73,7 @@ struct MonoArgs {
   unsigned int log_sentinel;            // key of an unused entry: sorts behind every sub-bin
   unsigned long long item_lo;           // COMMIT: the launch runs the work items [item_lo, item_lo + n_items)
   int kf_lds;                           // COMMIT: kappa_factor(1:n_cells) is staged in the workgroup's LDS (mono_lds_bytes)
+  int rowf;                             // COMMIT: > 0: the per-lane results are weight rows of this many default reals
 };
 
 // per-lane results of angles_scatt_rt1, kept in LDS as [q][thread]
@@ -92,16 +93,25 @@ struct RtScratch {
 // in-order counter on this target and return out of order with respect to each other, so the compiler's wait is
 // vmcnt(0) -- i.e. for the previous crossing's deposits to come back from the memory side (microseconds under load):
 // with the one per-crossing load served from LDS the commit pass's waves never wait for their own atomics.
+// rowf > 0 (the commit pass with default-real records and one dust class on cylindrical / spherical grids): the per-lane
+// results are the flight's deposit weights as a row of rowf default reals in the sub-bin's order (xi32_row_floats) instead
+// of (cosw, sinw, itheta), and the tiles carry no slot masks.
 __host__ __device__ inline size_t mono_lds_bytes(const DevModel& M, int nRT, int threads, bool pola, bool slim, bool log = false,
-                                                 int kf_cells = 0) {
+                                                 int kf_cells = 0, int rowf = 0) {
   size_t b = (lds_bytes(M, slim) + 7) / 8 * 8;
   b += (size_t)6 * (M.nang + 1) * sizeof(float);                     // the Mueller columns of p_lambda
   b = (b + 7) / 8 * 8;
   const int nsc = log ? 0 : nRT, tsc = log ? 0 : threads;
-  b += (size_t)nsc * threads * (pola ? 2 * sizeof(double) : 0);      // cosw, sinw
-  b += (size_t)tsc * (8 * sizeof(double) + sizeof(unsigned long long));  // deposit tiles: record + address
-  b += (size_t)nsc * threads * sizeof(int);                          // itheta
-  b += (size_t)tsc * sizeof(unsigned int);                           // deposit tiles: slot mask
+  if (rowf > 0 && !log) {
+    b = (b + 15) / 16 * 16;
+    b += (size_t)rowf * threads * sizeof(float);                     // the flights' weight rows, [chunk of 4][thread]
+    b += (size_t)tsc * (8 * sizeof(double) + sizeof(unsigned long long));  // deposit tiles: 16 default reals + address
+  } else {
+    b += (size_t)nsc * threads * (pola ? 2 * sizeof(double) : 0);      // cosw, sinw
+    b += (size_t)tsc * (8 * sizeof(double) + sizeof(unsigned long long));  // deposit tiles: record + address
+    b += (size_t)nsc * threads * sizeof(int);                          // itheta
+    b += (size_t)tsc * sizeof(unsigned int);                           // deposit tiles: slot mask
+  }
   b = (b + 7) / 8 * 8;
   b += (size_t)3 * nRT * sizeof(double);                             // the observers' rotation constants
   b += (size_t)kf_cells * sizeof(double);                            // kappa_factor
@@ -118,9 +128,19 @@ __host__ __device__ inline size_t mono_lds_bytes(const DevModel& M, int nRT, int
 // tracking) or [nRT] default reals, and nothing is kept in LDS.
 // (one observer q of the loop; slot = the thread of the workgroup whose per-lane results in LDS receive it: the lane's
 // own, or -- angles_scatt_rt1_wave below -- the lane another lane computes for)
+// rowimg != nullptr (MonoArgs::rowf > 0): the weights go to the lane's ROW in LDS, in the order of the sub-bin
+// (xi32_row_floats; `star`: the packet's origin decides which of the two origins' places holds the flux where they are
+// interleaved), so that a crossing stages a line of its deposits as four 16-byte chunks times the path length.
+#ifndef MCGPU_LANE_EMULATION
+__device__ __forceinline__ void row_put(float* rowimg, int p, int slot, float v) {
+  typedef __attribute__((address_space(3))) float lds_f32_t;
+  ((lds_f32_t*)rowimg)[(((size_t)(p >> 2) * blockDim.x + slot) << 2) + (p & 3)] = v;
+}
+#endif
 template <bool POLA>
 __device__ inline void angles_scatt_rt1_one(const DevModel& M, const MonoArgs& A, const RtScratch& R, int q, int slot, double u,
-                                             double v, double w, const float* w_mu, const double* S, float* row) {
+                                             double v, double w, const float* w_mu, const double* S, float* row,
+                                             float* rowimg = nullptr, bool star = false) {
   const double ur = A.rt_u[q], vr = A.rt_v[q], wr = A.rt_w[q % A.RT_n_incl];
   const float cos_scatt = (float)nd_add(nd_add(nd_mul(ur, u), nd_mul(vr, v)), nd_mul(wr, w));
   // k = nint(acos(cos_scatt) * nang / pi) in default real (:430-434).  The default-real arccosine of the runtime decides
@@ -140,11 +160,17 @@ __device__ inline void angles_scatt_rt1_one(const DevModel& M, const MonoArgs& A
   }
   if (k > M.nang) k = M.nang;
   if (k < 1) k = 1;
-  if (!row) R.itheta[q * blockDim.x + slot] = k;
+  if (!row && !rowimg) R.itheta[q * blockDim.x + slot] = k;
 #ifndef MCGPU_LANE_EMULATION   // (the lane emulation has no default-real commit pass)
   if (!POLA && w_mu) {
     const float wI = (float)(S[0] * (double)w_mu[k]);
-    if (row) row[q] = wI; else R.itheta[q * blockDim.x + slot] = __float_as_int(wI);
+    if (row) row[q] = wI;
+    else if (rowimg) {
+      const Xi32Lay& X = A.xi;
+      if (!X.sum_I) row_put(rowimg, q * X.sA, slot, wI);
+      else if (!X.split) { row_put(rowimg, q * X.sA, slot, star ? wI : 0.0f); row_put(rowimg, q * X.sA + 1, slot, star ? 0.0f : wI); }
+      else row_put(rowimg, q, slot, wI);
+    } else R.itheta[q * blockDim.x + slot] = __float_as_int(wI);
   }
 #endif
   if (POLA) {
@@ -165,7 +191,7 @@ __device__ inline void angles_scatt_rt1_one(const DevModel& M, const MonoArgs& A
     if (v1pk < 0.0) sinw = -sinw;
     if (fabs(cosw) < 1e-06) cosw = 0.0;
     if (fabs(sinw) < 1e-06) sinw = 0.0;
-    if (!row) {
+    if (!row && !rowimg) {
       R.cosw[q * blockDim.x + slot] = cosw;
       R.sinw[q * blockDim.x + slot] = sinw;
     }
@@ -184,6 +210,18 @@ __device__ inline void angles_scatt_rt1_one(const DevModel& M, const MonoArgs& A
       const double D4 = (double)s34 * C3 + (double)s44 * C4;
       if (row) {
         reinterpret_cast<float4*>(row)[q] = make_float4((float)D1, (float)((-cosw) * D2 + (-sinw) * D3), (float)((-sinw) * D2 + cosw * D3), (float)D4);
+      } else if (rowimg) {
+        const Xi32Lay& X = A.xi;
+        const float f0 = (float)D1, f1 = (float)((-cosw) * D2 + (-sinw) * D3), f2 = (float)((-sinw) * D2 + cosw * D3), f3 = (float)D4;
+        if (!X.sum_I) {
+          const int b = q * X.sA;
+          row_put(rowimg, b, slot, f0); row_put(rowimg, b + 1, slot, f1); row_put(rowimg, b + 2, slot, f2); row_put(rowimg, b + 3, slot, f3);
+        } else {
+          const int b = q * X.sA;       // (interleaved: sA = 5; split: sA = 3)
+          row_put(rowimg, b, slot, f1); row_put(rowimg, b + 1, slot, f2); row_put(rowimg, b + 2, slot, f3);
+          if (X.split) row_put(rowimg, A.nRT * 3 + q, slot, f0);
+          else { row_put(rowimg, b + 3, slot, star ? f0 : 0.0f); row_put(rowimg, b + 4, slot, star ? 0.0f : f0); }
+        }
       } else {
         float2* wc = reinterpret_cast<float2*>(R.cosw) + (q * blockDim.x + slot);
         float2* ws = reinterpret_cast<float2*>(R.sinw) + (q * blockDim.x + slot);
@@ -197,8 +235,9 @@ __device__ inline void angles_scatt_rt1_one(const DevModel& M, const MonoArgs& A
 
 template <bool POLA>
 __device__ inline void angles_scatt_rt1(const DevModel& M, const MonoArgs& A, const RtScratch& R, double u,
-                                        double v, double w, const float* w_mu = nullptr, const double* S = nullptr, float* row = nullptr) {
-  for (int q = 0; q < A.nRT; ++q) angles_scatt_rt1_one<POLA>(M, A, R, q, (int)threadIdx.x, u, v, w, w_mu, S, row);
+                                        double v, double w, const float* w_mu = nullptr, const double* S = nullptr, float* row = nullptr,
+                                        float* rowimg = nullptr, bool star = false) {
+  for (int q = 0; q < A.nRT; ++q) angles_scatt_rt1_one<POLA>(M, A, R, q, (int)threadIdx.x, u, v, w, w_mu, S, row, rowimg, star);
 }
 
 // One pending deposit of a lane: where (cell, azimuth / elevation sub-bin) and how long the path was.
@@ -350,7 +389,8 @@ __device__ inline void wave_deposit_records(int lane, int K, unsigned int mask, 
 // w_mu as in angles_scatt_rt1 (the commit pass with default-real records and one dust class).
 template <bool POLA>
 __device__ inline void angles_scatt_rt1_wave(const DevModel& M, const MonoArgs& A, const RtScratch& R, bool need, double u, double v,
-                                             double w, const float* w_mu, const double S[4], double* tile_g) {
+                                             double w, const float* w_mu, const double S[4], double* tile_g, float* rowimg = nullptr,
+                                             bool star = false) {
   const int lane = threadIdx.x & 63;
   const unsigned long long m = __ballot(need);
   if (m == 0ull) return;
@@ -358,7 +398,7 @@ __device__ inline void angles_scatt_rt1_wave(const DevModel& M, const MonoArgs& 
   if (need) {
     lds_f64* my = t + __popcll(m & ((1ull << lane) - 1ull)) * XI_LINE;
     my[0] = u; my[1] = v; my[2] = w; my[3] = S[0]; my[4] = POLA ? S[1] : 0.0; my[5] = POLA ? S[2] : 0.0; my[6] = POLA ? S[3] : 0.0;
-    my[7] = (double)(int)threadIdx.x;        // (whose results these are)
+    my[7] = (double)((int)threadIdx.x | (star ? 0x10000 : 0));   // (whose results these are, and the packet's origin)
   }
   tile_sync();
   const int n_items = __popcll(m) * A.nRT;
@@ -366,7 +406,8 @@ __device__ inline void angles_scatt_rt1_wave(const DevModel& M, const MonoArgs& 
     const int j = i / A.nRT, q = i - j * A.nRT;
     const lds_f64* p = t + j * XI_LINE;
     const double Sj[4] = {p[3], p[4], p[5], p[6]};
-    angles_scatt_rt1_one<POLA>(M, A, R, q, (int)p[7], p[0], p[1], p[2], w_mu, Sj, nullptr);
+    const int who = (int)p[7];
+    angles_scatt_rt1_one<POLA>(M, A, R, q, who & 0xFFFF, p[0], p[1], p[2], w_mu, Sj, nullptr, rowimg, (who & 0x10000) != 0);
   }
   tile_sync();
 }
@@ -621,6 +662,109 @@ __device__ inline void deposit_rt1_wave_f32(const DevModel& M, const MonoArgs& A
 }
 #endif
 
+#ifndef MCGPU_LANE_EMULATION
+// The same deposits from the flight's weight ROW (MonoArgs::rowf > 0: default-real records, one dust class; round 6).
+// Measured with the atomic instructions compiled out (profiles/r06_sed_deposit_cost.log): staging and serving the lines
+// cost three times the transport itself and the atomics only 5-10 % on top -- the pass was bound by the instructions of
+// deposit_rt1_wave_f32's staging (per observer two LDS reads, four products and five placed stores).  Here the weights
+// already lie in the sub-bin's order (angles_scatt_rt1_one, row_put), so a line of a crossing's deposits is FOUR 16-byte
+// chunks of the row times the path length, stored as four 16-byte chunks of the tile; the values of the stellar origin a
+// thermal packet shares a line with are cleared, and its own origin's values -- the same numbers -- are placed on the
+// thermal lines one by one.  The serving half is deposit_rt1_wave_f32's (a value of zero is added like any other: it
+// shares its line with values that are not).
+__device__ inline void deposit_rt1_wave_row(const MonoArgs& A, const float* row_g, const RtDeposit& D, bool flag_star, double* tile,
+                                            unsigned long long* tile_addr) {
+  typedef float f32x4_t __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) f32x4_t lds_f32x4;
+  const int lane = threadIdx.x & 63;
+  const Xi32Lay X = A.xi;
+  const int n_lines = X.binf >> 4, n_stokes = A.nRT * X.nA, n_chunks = A.rowf >> 2;
+  const bool on = D.on && !MCGPU_DIAG(A.flags, 1);
+  if (__ballot(on) == 0ull) return;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  lds_f32* const tile32 = (lds_f32*)tile;            // (explicit address spaces, tile_sync: see wave_deposit_records)
+  lds_u64* const taddr = (lds_u64*)tile_addr;
+  const lds_f32x4* const row4 = (const lds_f32x4*)row_g + threadIdx.x;   // chunk c of this lane: row4[c * blockDim.x]
+  const lds_f32* const row1 = (const lds_f32*)row_g;
+  const size_t bin = on ? ((size_t)(D.icell - 1) * A.n_theta_rt + (D.psup - 1)) * A.n_az_rt + (D.phik - 1) : 0;
+  float* const bin32 = reinterpret_cast<float*>(A.xI) + bin * (size_t)X.binf;
+  const int sr = lane >> 4, sf = lane & 15;   // serving: place 4 g + sr of a group, value sf of the line
+  const float lf = (float)D.l;
+  for (int line = 0; line < n_lines; ++line) {
+    const int g0 = line << 4;
+    // who reaches this line: in the split arrangement the lines behind the Stokes values hold one origin each
+    bool mine = on;
+    const bool t_line = X.split && g0 >= X.oT;
+    if (X.split) {
+      if (t_line) mine = on && !flag_star;
+      else if (g0 >= n_stokes) mine = on && flag_star;
+    }
+    const unsigned long long any = __ballot(mine);
+    const int n_act = __popcll(any);
+    if (n_act == 0) continue;
+    if (mine) {
+      const int place = __popcll(any & lt);
+      taddr[place] = (unsigned long long)(bin32 + g0);
+      lds_f32x4* const my4 = (lds_f32x4*)(tile32 + place * 16);
+      if (!t_line) {
+        const int c0 = g0 >> 2;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          f32x4_t v = {0.0f, 0.0f, 0.0f, 0.0f};
+          if (c0 + c < n_chunks) {
+            v = row4[(size_t)(c0 + c) * blockDim.x];
+            v *= lf;
+            if (X.split) {   // (the stellar origin's values on a line a thermal packet reaches for its Stokes values)
+              const int p0 = g0 + 4 * c;
+              if (p0 + 3 >= n_stokes && !flag_star) {
+                if (p0 >= n_stokes) v.x = 0.0f;
+                if (p0 + 1 >= n_stokes) v.y = 0.0f;
+                if (p0 + 2 >= n_stokes) v.z = 0.0f;
+                if (p0 + 3 >= n_stokes) v.w = 0.0f;
+              }
+            }
+          }
+          my4[c] = v;
+        }
+      } else {   // a thermal line: observer q's flux at oT + q, the row holds it at n_stokes + q
+        const int q0 = g0 - X.oT;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          f32x4_t v = {0.0f, 0.0f, 0.0f, 0.0f};
+          const int q = q0 + 4 * c;
+          if (q < A.nRT) {
+            auto w = [&](int qq) {
+              const int p = n_stokes + qq;
+              return qq < A.nRT ? lf * row1[(((size_t)(p >> 2) * blockDim.x + threadIdx.x) << 2) + (p & 3)] : 0.0f;
+            };
+            v.x = w(q); v.y = w(q + 1); v.z = w(q + 2); v.w = w(q + 3);
+          }
+          my4[c] = v;
+        }
+      }
+    }
+    tile_sync();
+    for (int p0 = 0; p0 < n_act; p0 += 4 * TILE_UNROLL) {
+      unsigned long long ad[TILE_UNROLL];
+      float val[TILE_UNROLL];
+      bool ok[TILE_UNROLL];
+#pragma unroll
+      for (int t = 0; t < TILE_UNROLL; ++t) {
+        const int src = p0 + 4 * t + sr;
+        ok[t] = src < n_act;
+        const int sc = ok[t] ? src : 0;
+        ad[t] = taddr[sc];
+        val[t] = tile32[sc * 16 + sf];
+      }
+#pragma unroll
+      for (int t = 0; t < TILE_UNROLL; ++t)
+        if (ok[t] && !MCGPU_DIAG(A.flags, 4)) atomicAdd((float*)((glb_f32*)ad[t] + sf), val[t]);
+    }
+    tile_sync();
+  }
+}
+#endif
+
 // LDS of a SED-mode workgroup after the shared tables: the Mueller columns of p_lambda, the per-lane
 // results of angles_scatt_rt1 and the per-wave deposit tiles (mono_lds_bytes is the matching size).
 struct MonoLds {
@@ -630,6 +774,7 @@ struct MonoLds {
   unsigned long long* tile_addr;
   unsigned int* tile_mask;
   const double* kf;     // kappa_factor in LDS (MonoArgs::kf_lds), else null
+  float* row;           // the weight rows (MonoArgs::rowf > 0), [chunk][thread][4], else null
 };
 
 template <bool POLA>
@@ -639,6 +784,23 @@ __device__ inline MonoLds mono_lds_setup(const DevModel& M, const MonoArgs& A, d
   const size_t nsc = log ? 0 : (size_t)A.nRT, tsc = log ? 0 : (size_t)blockDim.x;   // (mono_lds_bytes)
   L.mu = reinterpret_cast<float*>(lds_base + (lds_bytes(M, slim) + 7) / 8);
   double* p = lds_base + (lds_bytes(M, slim) + 7) / 8 + ((size_t)6 * na1 * sizeof(float) + 7) / 8;
+  L.row = nullptr;
+  size_t used;   // bytes from lds_base to the end of the per-lane arrays
+  if (A.rowf > 0 && !log) {
+    p = lds_base + ((size_t)(p - lds_base) * 8 + 15) / 16 * 2;   // (16-byte chunks)
+    L.row = reinterpret_cast<float*>(p);
+    L.R.cosw = nullptr; L.R.sinw = nullptr; L.R.itheta = nullptr; L.tile_mask = nullptr;
+    {  // (the row's padding stays zero for the whole launch: only the weights' places are ever written)
+      float* r = L.row;
+      for (size_t i = threadIdx.x; i < (size_t)A.rowf * blockDim.x; i += blockDim.x) r[i] = 0.0f;
+    }
+    p += (size_t)A.rowf * blockDim.x / 2;
+    L.tile = p + (size_t)(threadIdx.x >> 6) * 64 * XI_LINE;
+    p += tsc * XI_LINE;
+    L.tile_addr = reinterpret_cast<unsigned long long*>(p) + (size_t)(threadIdx.x >> 6) * 64;
+    p += tsc;
+    used = (size_t)(p - lds_base) * 8;
+  } else {
   L.R.cosw = p;
   L.R.sinw = p + (POLA ? nsc * blockDim.x : 0);
   p += (POLA ? (size_t)2 * nsc * blockDim.x : 0);
@@ -648,9 +810,9 @@ __device__ inline MonoLds mono_lds_setup(const DevModel& M, const MonoArgs& A, d
   p += tsc;
   L.R.itheta = reinterpret_cast<int*>(p);
   L.tile_mask = reinterpret_cast<unsigned int*>(L.R.itheta + nsc * blockDim.x) + (log ? 0 : (size_t)(threadIdx.x >> 6) * 64);
+  used = (size_t)((L.R.itheta + nsc * blockDim.x) - reinterpret_cast<int*>(lds_base)) * sizeof(int) + tsc * sizeof(unsigned int);
+  }
   {  // rotation()'s cost, sint, sing for the axis (-u_obs, -v_obs, -w_obs): the same expressions, once per observer
-    const size_t used = (size_t)((L.R.itheta + nsc * blockDim.x) - reinterpret_cast<int*>(lds_base)) * sizeof(int) +
-                        tsc * sizeof(unsigned int);
     double* rot = lds_base + (used + 7) / 8;
     for (int q = threadIdx.x; q < A.nRT; q += blockDim.x) {
       const double u1 = -A.rt_u[q], v1 = -A.rt_v[q], w1 = -A.rt_w[q % A.RT_n_incl];
@@ -921,7 +1083,7 @@ __device__ __forceinline__ void mono_body(const DevModel& M, const MonoArgs& A, 
 #ifndef MCGPU_LANE_EMULATION
     // (the commit pass with default-real records and one dust class: the new flights' observer weights by the whole wave)
     constexpr bool kAnglesByWave = F32 && !SCOUT && !LOG;
-    if (kAnglesByWave && A.rt1 && !var) angles_scatt_rt1_wave<POLA>(M, A, R, st == S_NEWFLIGHT, u, v, w, mu, S, tile);
+    if (kAnglesByWave && A.rt1 && !var) angles_scatt_rt1_wave<POLA>(M, A, R, st == S_NEWFLIGHT, u, v, w, mu, S, tile, ML.row, flag_star);
 #else
     constexpr bool kAnglesByWave = false;
 #endif
@@ -938,7 +1100,7 @@ __device__ __forceinline__ void mono_body(const DevModel& M, const MonoArgs& A, 
       } else
 #endif
       if (!SCOUT && A.rt1 && !(kAnglesByWave && !var))
-        angles_scatt_rt1<POLA>(M, A, R, u, v, w, (F32 && !var) ? mu : nullptr, S);  // optical_depth.f90:65
+        angles_scatt_rt1<POLA>(M, A, R, u, v, w, (F32 && !var) ? mu : nullptr, S, nullptr, ML.row, flag_star);  // optical_depth.f90:65
       const int i_star = intersect_stars(M, x, y, z, u, v, w);
       star_key = -1;
       if (i_star > 0) {
@@ -1049,8 +1211,10 @@ __device__ __forceinline__ void mono_body(const DevModel& M, const MonoArgs& A, 
         if constexpr (LOG) {
           const unsigned int bin = (unsigned int)((((size_t)(dep.icell - 1) * A.n_theta_rt + (dep.psup - 1)) * A.n_az_rt) + (dep.phik - 1));
           xlog_append(A, LC, dep.on, bin | (flag_star ? 0x80000000u : 0u), my_fid, (float)dep.l, lane);
-        } else if constexpr (F32) deposit_rt1_wave_f32<POLA>(M, A, R, mu, dep, S, flag_star, tile, tile_addr, tile_mask);
-        else
+        } else if constexpr (F32) {
+          if (ML.row) deposit_rt1_wave_row(A, ML.row, dep, flag_star, tile, tile_addr);
+          else deposit_rt1_wave_f32<POLA>(M, A, R, mu, dep, S, flag_star, tile, tile_addr, tile_mask);
+        } else
 #endif
         deposit_rt1_wave<POLA>(M, A, R, mu, dep, S, flag_star, tile, tile_addr, tile_mask);
       }

@@ -55,6 +55,13 @@ __host__ __device__ inline int xi32_lines_touched(const Xi32Lay& L, int nRT) {
   const int l_star = L.oT >> 4, l_thermal = xi32_lines_of(nRT * L.nA) + xi32_lines_of(nRT);
   return l_star > l_thermal ? l_star : l_thermal;
 }
+// The flight's deposit weights as a ROW in the order of the sub-bin (mc_mono.hip.h, deposit_rt1_wave_row): the whole
+// sub-bin's image where the values are interleaved, the stellar part [Stokes x nRT | origin x nRT] in the split
+// arrangement (a thermal packet's origin values are the same numbers, placed on the thermal lines when staged).
+// In default reals, a multiple of 4 (the row is kept as 16-byte chunks).
+__host__ __device__ inline int xi32_row_floats(const Xi32Lay& L, int nRT) {
+  return L.split ? ((nRT * (L.nA + 1) + 3) & ~3) : L.binf;
+}
 // flux type (0-based index into N_type_flux) of observer q -> its place in the sub-bin; -1: a type no deposit reaches
 // (reads as 0), -2: I where it is the sum of the two origins
 __host__ __device__ inline int xi32_offset(const Xi32Lay& L, int q, int type, int nS) {

@@ -2328,6 +2328,9 @@ static int launch_mono(mcgpu_ctx* ctx, const MonoArgs& A, int grid_blocks, int b
   // (so does a scout pass of the cylindrical / spherical kernels: no deposits, no per-lane results, no tiles -- round 6;
   // until then it was launched with the commit pass's LDS and two waves per SIMD)
   const bool lean = log || (SCOUT && !ctx->voro);
+  // (the commit pass with default-real records and one dust class on cylindrical / spherical grids keeps the flights'
+  // deposit weights as rows in the sub-bin's order: deposit_rt1_wave_row)
+  const int rowf = (f32 && !lean && !ctx->voro && !M.n_classes) ? xi32_row_floats(A.xi, A.nRT) : 0;
 #ifndef MCGPU_MONO_CU_THREADS
 #define MCGPU_MONO_CU_THREADS 512   // (A/B builds)
 #endif
@@ -2340,7 +2343,7 @@ static int launch_mono(mcgpu_ctx* ctx, const MonoArgs& A, int grid_blocks, int b
   } else {
     int best_waves = 0;
     for (int th = lean ? 256 : max_threads; th >= 64; th -= 64) {
-      const size_t l = mono_lds_bytes(M, A.nRT, th, pola, slim, lean);
+      const size_t l = mono_lds_bytes(M, A.nRT, th, pola, slim, lean, 0, rowf);
       if (l > 160 * 1024) continue;
       int per_cu = (int)((160 * 1024) / l);
       if (per_cu > cu_threads / th) per_cu = cu_threads / th;
@@ -2349,14 +2352,15 @@ static int launch_mono(mcgpu_ctx* ctx, const MonoArgs& A, int grid_blocks, int b
     }
     if (!threads) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "too many ray-tracing directions for the LDS of one CU");
   }
-  size_t lds = mono_lds_bytes(M, A.nRT, threads, pola, slim, lean);
+  size_t lds = mono_lds_bytes(M, A.nRT, threads, pola, slim, lean, 0, rowf);
   if (lds > 160 * 1024) return fail(ctx, MCGPU_ERR_UNSUPPORTED, "too many ray-tracing directions for the LDS of one CU");
   // The commit pass's one global load per crossing, kappa_factor, from LDS where the grid is small enough to ride along
   // without costing a workgroup its place on the CU (2D grids with few observers): see mono_lds_bytes.
   MonoArgs A2 = A;
   A2.kf_lds = 0;
+  A2.rowf = rowf;
   if (kCommit && !lean && (A.rt1 || A.rt2) && !ctx->voro && !M.n_classes) {
-    const size_t with_kf = mono_lds_bytes(M, A.nRT, threads, pola, slim, lean, M.n_cells);
+    const size_t with_kf = mono_lds_bytes(M, A.nRT, threads, pola, slim, lean, M.n_cells, rowf);
     const int per_cu_max = cu_threads / threads > 0 ? cu_threads / threads : 1;
     int per_cu = (int)((160 * 1024) / lds), per_cu_kf = with_kf <= 160 * 1024 ? (int)((160 * 1024) / with_kf) : 0;
     if (per_cu > per_cu_max) per_cu = per_cu_max;
