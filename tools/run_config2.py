@@ -32,8 +32,8 @@ if xi_bytes == 4 and r.get("sed_crossings"):
     lay = xi32_layout(cfg.RT_n_incl * cfg.RT_n_az, bool(cfg.lsepar_pola and cfg.aniso_method == 1), bool(cfg.lsepar_contrib))
     ops = r["sed_crossings"] * lay["lines_touched"]
     print(f"  {r['sed_crossings']:.4g} crossings ({r['sed_crossings'] / n_sed:.1f} per packet) x {lay['lines_touched']} lines of 64 bytes = {ops:.4g} memory-side "
-          f"atomic line operations: {ops / s['sed_mc']:.3g} /s over the whole SED step = {ops / s['sed_mc'] / 2.07e10:.2f} of the 2.07e10 /s the chip does "
-          f"(tools/atomic_block_bench.hip)")
+          f"atomic line operations: {ops / s['sed_mc']:.3g} /s over the whole SED step = {ops / s['sed_mc'] / 2.37e10:.2f} of the 2.37e10 /s the chip does "
+          f"(tools/atomic_scope_bench.hip; bench.py's ATOMIC_LINE_PEAK)")
 print(f"ray-traced dust SED: {m.n_lambda} x {cfg.RT_n_incl} inclinations in {s['ray_tracing']:.3f} s")
 print(f"total {wall:.2f} s;  Tdust {r['Tdust'].min():.1f} .. {r['Tdust'].max():.1f} K")
 f = P.sed_flux(m, r["sed_mc"], r["n_sent"])[0].sum(axis=0)   # (N_thet, n_lambda)
