@@ -1,5 +1,7 @@
 #!/bin/bash
-# round 6: how many rounds of tile reads the deposit's serve loop keeps in flight (TILE_UNROLL builds), config 2 at 3 and 10 inclinations
+# round 6: how many rounds of tile reads the deposit's serve loop keeps in flight, config 2 at 3 and 10 inclinations.
+# (The variant libraries were built with TILE_UNROLL = 2 / 8 / 16 in mc_mono.hip.h, a constexpr there: 8 gained 1 %, the
+# default stayed 4 -- profiles/r06_sed_tile_unroll_ab.log.)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $R/gpurun_out/r6_tile; cd $R
 for o in 3 10; do
