@@ -330,7 +330,7 @@ __device__ __forceinline__ void tile_sync() {
   __builtin_amdgcn_wave_barrier();
   asm volatile("" ::: "memory");
 }
-constexpr int TILE_UNROLL = 4;   // rounds whose tile reads are in flight together
+constexpr int TILE_UNROLL = 8;   // rounds whose tile reads are in flight together (2 / 4 / 8 / 16 measured: profiles/r06_sed_tile_unroll_ab.log)
 
 // The records of one instruction's lanes (<= 4 Stokes values + the copy of I in the slot of its origin, all in one
 // 64-byte line per lane) go out through the wave's LDS tile: the lanes that deposit stage their record in consecutive
